@@ -1,0 +1,183 @@
+"""ctypes binding of oracle/libnc_oracle.so -- the CPU restatement of the reference path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (nanocaller_amd/) must never import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libnc_oracle.so")
+    src = os.path.join(_HERE, "nc_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libnc_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _reads(world, supplementary=False):
+    from nanocaller_amd.synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
+    filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT
+    keep = ((world.read_flag & filt) == 0).astype(np.uint8)
+    strand = (((world.read_flag & 0x910) // 16) != 0).astype(np.uint8)
+    return (np.ascontiguousarray(world.read_start, np.int32), np.ascontiguousarray(world.read_end, np.int32),
+            np.ascontiguousarray(world.read_off, np.int64), np.ascontiguousarray(world.codes, np.uint8),
+            strand, keep)
+
+
+def ref_codes_with_exclusions(world, exclude=None):
+    from nanocaller_amd.synth import world_ref_codes
+    rc = world_ref_codes(world).copy()
+    if exclude:
+        for (c, a, b) in exclude:                 # IntervalTree.overlaps(pos): a <= pos < b
+            if c == world.chrom:
+                rc[max(0, a - 1):max(0, b - 1)] = 4
+    return rc
+
+
+def get_cnd_pos(v_pos, cnd_pos, seq="ont"):
+    nbr = np.ascontiguousarray(cnd_pos, np.int32)
+    left = np.zeros(64, np.int32)
+    right = np.zeros(64, np.int32)
+    nl, nr = C.c_int32(), C.c_int32()
+    rc = lib().oracle_get_cnd_pos(C.c_int32(int(v_pos)), _p(nbr, C.c_int32), C.c_int32(nbr.size), MODES[seq],
+                                  _p(left, C.c_int32), C.byref(nl), _p(right, C.c_int32), C.byref(nr))
+    assert rc == 0
+    return left[:nl.value].tolist(), right[:nr.value].tolist()
+
+
+def snp_scan(world, rc, start, end, ploidy, mincov, min_allele_freq, threshold, supplementary=False):
+    rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
+    cap = world.length + 1
+    nbr = np.zeros(cap, np.int32)
+    cpos = np.zeros(cap, np.int32)
+    cn = np.zeros(cap, np.int32)
+    calt = np.zeros(cap, np.int32)
+    n_nbr, n_cand = C.c_int32(), C.c_int32()
+    r = lib().oracle_snp_scan(C.c_int32(rs.size), _p(rs, C.c_int32), _p(re_, C.c_int32), _p(ro, C.c_int64),
+                              _p(codes, C.c_uint8), _p(keep, C.c_uint8), _p(rc, C.c_uint8),
+                              C.c_int32(world.length), C.c_int32(start), C.c_int32(end),
+                              C.c_int(1 if ploidy == "haploid" else 0), C.c_int32(mincov),
+                              C.c_double(min_allele_freq), C.c_double(threshold[0]), C.c_double(threshold[1]),
+                              C.c_int32(cap), _p(nbr, C.c_int32), C.byref(n_nbr), _p(cpos, C.c_int32),
+                              _p(cn, C.c_int32), _p(calt, C.c_int32), C.byref(n_cand))
+    assert r == 0, r
+    k, m = n_nbr.value, n_cand.value
+    return nbr[:k].copy(), cpos[:m].copy(), cn[:m].copy(), calt[:m].copy()
+
+
+def snp_featurize(world, rc, nbr, cpos, seq, maxcov, min_nbr_sites, supplementary=False):
+    rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
+    n = int(cpos.size)
+    out_pos = np.zeros(max(n, 1), np.int32)
+    out_ref = np.zeros(max(n, 1), np.int32)
+    mat = np.zeros((max(n, 1), 5, 41, 5), np.float32)
+    fwd = np.zeros((max(n, 1), 4), np.int32)
+    rev = np.zeros((max(n, 1), 4), np.int32)
+    dep = np.zeros(max(n, 1), np.int32)
+    nbr = np.ascontiguousarray(nbr, np.int32)
+    cpos = np.ascontiguousarray(cpos, np.int32)
+    k = lib().oracle_snp_featurize(C.c_int32(rs.size), _p(rs, C.c_int32), _p(re_, C.c_int32), _p(ro, C.c_int64),
+                                   _p(codes, C.c_uint8), _p(strand, C.c_uint8), _p(keep, C.c_uint8),
+                                   _p(rc, C.c_uint8), _p(nbr, C.c_int32), C.c_int32(nbr.size),
+                                   _p(cpos, C.c_int32), C.c_int32(n), C.c_int(MODES[seq]), C.c_int32(maxcov),
+                                   C.c_int32(min_nbr_sites), _p(out_pos, C.c_int32), _p(out_ref, C.c_int32),
+                                   _p(mat, C.c_float), _p(fwd, C.c_int32), _p(rev, C.c_int32), _p(dep, C.c_int32))
+    assert k >= 0, k
+    return out_pos[:k], out_ref[:k], mat[:k], fwd[:k], rev[:k], dep[:k]
+
+
+def get_snp_testing_candidates(world, dct, region, exclude=None):
+    """Same 8-tuple as the reference function (generate_SNP_pileups.py:279), computed by the oracle.
+    (pos, ref_onehot int32 (N,4), mat f32 (N,5,41,5), dp, freq f64, depth f64, fwd_dp f64 (N,4), rev_dp)"""
+    rc = ref_codes_with_exclusions(world, exclude)
+    nbr, cpos, cn, calt = snp_scan(world, rc, region["start"], region["end"], region["ploidy"],
+                                   dct["mincov"], dct["min_allele_freq"], dct["threshold"],
+                                   dct.get("supplementary", False))
+    if cpos.size == 0:
+        return ([], [], [], [], [], 0, [], [])
+    pos, ref, mat, fwd, rev, dep = snp_featurize(world, rc, nbr, cpos, dct["seq"], dct["maxcov"],
+                                                 dct["min_nbr_sites"], dct.get("supplementary", False))
+    if pos.size == 0:
+        return ([], [], [], [], [], 0, [], [])
+    sel = np.searchsorted(cpos, pos)
+    onehot = np.eye(4, dtype=np.int32)[ref]
+    return (pos.astype(np.int64), onehot, mat, cn[sel].astype(np.int64),
+            calt[sel].astype(np.float64) / cn[sel].astype(np.float64), float(np.mean(dep.astype(np.float64))),
+            fwd.astype(np.float64), rev.astype(np.float64))
+
+
+def _fwd(fn, w, x, ref_code, scale, scale_mode, n_out, with_gt):
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.shape[0]
+    w = np.ascontiguousarray(w, np.float32)
+    ref_code = np.ascontiguousarray(ref_code, np.int32)
+    scale = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, np.float64), (n,)))
+    probs = np.zeros((n, n_out), np.float32)
+    if with_gt:
+        gt = np.zeros((n, 2), np.float32)
+        r = fn(_p(w, C.c_float), C.c_int64(n), _p(x, C.c_float), _p(ref_code, C.c_int32), _p(scale, C.c_double),
+               C.c_int(scale_mode), _p(probs, C.c_float), _p(gt, C.c_float))
+        assert r == 0
+        return probs, gt
+    r = fn(_p(w, C.c_float), C.c_int64(n), _p(x, C.c_float), _p(ref_code, C.c_int32), _p(scale, C.c_double),
+           C.c_int(scale_mode), _p(probs, C.c_float))
+    assert r == 0
+    return probs
+
+
+def snp_forward(w_flat, x, ref_code, scale, scale_mode=0, precision="f32"):
+    """-> (probs (N,4) class-1 prob of the A,G,T,C heads, gt (N,2)).  model_architect.py:36-64."""
+    fn = lib().oracle_snp_forward_f if precision == "f32" else lib().oracle_snp_forward_d
+    return _fwd(fn, w_flat, x, ref_code, scale, scale_mode, 4, True)
+
+
+def snp_hap_forward(w_flat, x, ref_code, scale, scale_mode=0, precision="f32"):
+    fn = lib().oracle_snp_hap_forward_f if precision == "f32" else lib().oracle_snp_hap_forward_d
+    return _fwd(fn, w_flat, x, ref_code, scale, scale_mode, 4, False)
+
+
+def indel_forward(w_flat, x, precision="f32"):
+    x = np.ascontiguousarray(x, np.float32)
+    n, rows = x.shape[0], x.shape[1]
+    w = np.ascontiguousarray(w_flat, np.float32)
+    nout = 4 if rows == 15 else 1
+    probs = np.zeros((n, nout), np.float32)
+    fn = lib().oracle_indel_forward_f if precision == "f32" else lib().oracle_indel_forward_d
+    r = fn(_p(w, C.c_float), C.c_int64(n), C.c_int(rows), _p(x, C.c_float), _p(probs, C.c_float))
+    assert r == 0
+    return probs
+
+
+def indel_tensor(rows, ref_row):
+    rows = np.ascontiguousarray(rows, np.uint8)
+    ref_row = np.ascontiguousarray(ref_row, np.uint8)
+    out = np.zeros((5, 128, 2), np.float32)
+    cns = np.zeros(rows.shape[1] + 1, np.uint8)
+    nc = C.c_int32()
+    r = lib().oracle_indel_tensor(_p(rows, C.c_uint8), C.c_int32(rows.shape[0]), C.c_int32(rows.shape[1]),
+                                  _p(ref_row, C.c_uint8), _p(out, C.c_float), _p(cns, C.c_uint8), C.byref(nc))
+    assert r == 0
+    return out, cns[:nc.value].copy()

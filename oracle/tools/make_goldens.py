@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code in the build container.
+
+Container-only (needs /root/reference; never runs on the GPU box).  The reference featurisers are
+imported with the stub modules of oracle/tools/refstub and driven on seeded
+synthetic worlds; what is committed is DATA: the world arrays (inputs) and the reference's outputs.
+
+  world_<w>.npz            inputs (reference string, read-major codes, flags)
+  snp_<case>.npz           8-tuple of get_snp_testing_candidates (generate_SNP_pileups.py:279)
+  cnd_pos.npz              get_cnd_pos on random sorted arrays, all five modes
+  caller_vcf.npz           VCF lines written by snpCaller.caller (snpCaller.py:113-198) on canned
+                           probabilities (TensorFlow stubbed; the models are replaced by canned outputs)
+  indel_msa.npz            msa() tensors (generate_indel_pileups.py:12-73) on canned MUSCLE output
+"""
+import io
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path[:0] = [os.path.join(HERE, "refstub"), "/root/reference", REPO]
+
+import numpy as np  # noqa: E402
+import pysam  # noqa: E402  (stub)
+
+from nanocaller_amd.synth import make_world  # noqa: E402
+from nanocaller_src import generate_SNP_pileups as ref_snp  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def save_world(name, w):
+    np.savez_compressed(os.path.join(OUT, "world_%s.npz" % name), chrom=np.array(w.chrom),
+                        ref=np.frombuffer(w.ref.encode(), dtype=np.uint8), read_start=w.read_start,
+                        read_end=w.read_end, read_flag=w.read_flag, read_off=w.read_off, codes=w.codes)
+
+
+def run_snp(case, world_name, w, seq, ploidy, start, end, threshold=(0.4, 0.6), mincov=4, maxcov=160,
+            min_allele_freq=0.15, min_nbr_sites=1, supplementary=False, exclude=None):
+    pysam.register("bam", w)
+    pysam.register("fa", w)
+    if exclude:
+        pysam.register("bed", exclude)
+    dct = dict(exclude_bed="bed" if exclude else None, sam_path="bam", fasta_path="fa",
+               threshold=list(threshold), supplementary=supplementary, mincov=mincov, maxcov=maxcov,
+               min_allele_freq=min_allele_freq, min_nbr_sites=min_nbr_sites, seq=seq)
+    reg = dict(chrom=w.chrom, start=start, end=end, ploidy=ploidy)
+    pos, ref, mat, dp, freq, depth, fwd, rev = ref_snp.get_snp_testing_candidates(dct, reg)
+    n = len(pos)
+    print("%-22s world=%s seq=%s %s [%d,%d] -> %d sites depth=%s" % (case, world_name, seq, ploidy, start, end, n, depth))
+    mat = np.asarray(mat, np.float32).reshape(n, 5, 41, 5)
+    assert np.array_equal(mat, mat.astype(np.int16).astype(np.float32))
+    np.savez_compressed(
+        os.path.join(OUT, "snp_%s.npz" % case), world=np.array(world_name), seq=np.array(seq),
+        ploidy=np.array(ploidy), start=start, end=end, threshold=np.array(threshold, np.float64), mincov=mincov,
+        maxcov=maxcov, min_allele_freq=np.float64(min_allele_freq), min_nbr_sites=min_nbr_sites,
+        supplementary=supplementary,
+        exclude=np.array([(a, b) for (_, a, b) in (exclude or [])], np.int64).reshape(-1, 2),
+        pos=np.asarray(pos, np.int64), ref=np.asarray(ref, np.int32).reshape(n, 4), mat=mat.astype(np.int16),
+        dp=np.asarray(dp, np.int64), freq=np.asarray(freq, np.float64), depth=np.float64(depth),
+        fwd_dp=np.asarray(fwd, np.float64).reshape(n, 4), rev_dp=np.asarray(rev, np.float64).reshape(n, 4))
+
+
+def make_snp_goldens():
+    w_ont = make_world(seed=812, length=135_000, depth=18, tech="ont", read_len_scale=0.8)
+    # decorate some pileup strings with indel suffixes and explicit 'N' letters (only x[0] is read, :162)
+    rng = np.random.Generator(np.random.PCG64(5))
+    deco = {}
+    for _ in range(4000):
+        i = int(rng.integers(0, w_ont.n_reads))
+        p0 = int(rng.integers(w_ont.read_start[i] - 1, w_ont.read_end[i] - 1))
+        deco[(i, p0)] = ["+2GG", "-1N", "+1a", "-3NNN"][int(rng.integers(0, 4))]
+    w_ont.meta["deco"] = deco
+    save_world("ont", w_ont)
+    w_hifi = make_world(seed=813, length=90_000, depth=24, tech="hifi", read_len_scale=0.6, het_rate=1 / 400.0,
+                        sys_err_rate=0.02)
+    save_world("hifi", w_hifi)
+    w_deep = make_world(seed=814, length=24_000, depth=120, tech="ont", read_len_scale=0.25)
+    save_world("deep", w_deep)
+
+    run_snp("ont_dip", "ont", w_ont, "ont", "diploid", 52_000, 80_000)
+    run_snp("ont_dip_start", "ont", w_ont, "ont", "diploid", 1, 20_000)
+    run_snp("ont_dip_end", "ont", w_ont, "ont", "diploid", 110_000, 135_000)
+    run_snp("ont_hap", "ont", w_ont, "ont", "haploid", 60_000, 75_000)
+    run_snp("short_ont", "ont", w_ont, "short_ont", "diploid", 55_000, 75_000)
+    run_snp("ul_ont", "ont", w_ont, "ul_ont", "diploid", 55_000, 75_000)
+    run_snp("ul_ont_extreme", "ont", w_ont, "ul_ont_extreme", "diploid", 60_000, 70_000)
+    run_snp("ont_exclude", "ont", w_ont, "ont", "diploid", 52_000, 70_000,
+            exclude=[("chr20", 55_000, 58_000), ("chr20", 30_000, 41_000), ("chrX", 1, 100)])
+    run_snp("ont_suppl_params", "ont", w_ont, "ont", "diploid", 60_000, 72_000, threshold=(0.3, 0.7), mincov=8,
+            min_allele_freq=0.2, supplementary=True, min_nbr_sites=3)
+    run_snp("ont_empty", "ont", w_ont, "ont", "diploid", 60_000, 60_400, min_allele_freq=0.999, mincov=500)
+    run_snp("hifi_pacbio_dip", "hifi", w_hifi, "pacbio", "diploid", 30_000, 60_000, threshold=(0.3, 0.7))
+    run_snp("hifi_pacbio_hap", "hifi", w_hifi, "pacbio", "haploid", 30_000, 60_000)
+    run_snp("deep_ont", "deep", w_deep, "ont", "diploid", 6_000, 18_000)
+
+
+def make_cnd_pos_goldens():
+    rng = np.random.Generator(np.random.PCG64(99))
+    rec = {}
+    k = 0
+    for seq in ("ont", "short_ont", "ul_ont", "ul_ont_extreme", "pacbio"):
+        for dens in (0.0002, 0.001, 0.01):
+            span = 700_000
+            sites = np.nonzero(rng.random(span) < dens)[0] + 1_000_000
+            for v in (1_000_010, 1_350_000, 1_350_001, 1_699_990, int(sites[len(sites) // 2])):
+                l, r = ref_snp.get_cnd_pos(v, sites, seq)
+                rec["c%d_seq" % k] = np.array(seq)
+                rec["c%d_v" % k] = v
+                rec["c%d_sites" % k] = sites.astype(np.int32)
+                rec["c%d_l" % k] = np.array(l, np.int64)
+                rec["c%d_r" % k] = np.array(r, np.int64)
+                k += 1
+    rec["n"] = k
+    np.savez_compressed(os.path.join(OUT, "cnd_pos.npz"), **rec)
+    print("cnd_pos cases:", k)
+
+
+def make_caller_goldens():
+    """Run the reference's caller() (snpCaller.py:57-203) with TensorFlow stubbed and the model classes
+    replaced by canned-probability tables; capture the VCF lines it writes."""
+    import queue
+
+    from nanocaller_src import snpCaller as ref_caller
+
+    rng = np.random.Generator(np.random.PCG64(7))
+    n = 400
+    # canned per-site head probabilities, f32, away from the 1-p < 1e-4 region where numpy-1 vs numpy-2
+    # casting changes the QUAL text; saturated cases are hand-enumerated in tests instead.
+    probs = rng.random((n, 4)).astype(np.float32) * np.float32(0.9998) + np.float32(1e-4)
+    probs[::7] = np.round(probs[::7])                       # many 0/1-ish values -> ties kept apart below
+    probs = np.clip(probs, 1e-4, 1 - 1e-4).astype(np.float32)
+    # make ties impossible (E15): perturb so all four values differ per site
+    for j in range(n):
+        while len(set(probs[j].tolist())) < 4:
+            probs[j] = np.clip(probs[j] + (rng.random(4).astype(np.float32) - np.float32(0.5)) * np.float32(2e-3),
+                               2e-4, 1 - 2e-4).astype(np.float32)
+    ref = rng.integers(0, 4, size=n)
+    pos = np.sort(rng.choice(np.arange(1000, 90000), size=n, replace=False))
+    dp = rng.integers(8, 80, size=n)
+    freq = rng.random(n)
+    fwd = rng.integers(0, 30, size=(n, 4)).astype(np.float64)
+    rev = rng.integers(0, 30, size=(n, 4)).astype(np.float64)
+    hap_probs = rng.dirichlet(np.ones(4) * 0.3, size=n).astype(np.float32)
+    hap_probs = np.clip(hap_probs, 1e-4, 1 - 1e-4).astype(np.float32)
+
+    state = {"i": 0}
+
+    class FakeT:
+        def __init__(self, a):
+            self.a = a
+
+        def numpy(self):
+            return self.a
+
+        def __getitem__(self, k):
+            return self.a[k]
+
+    class FakeSNP:
+        def load_weights(self, p):
+            return self
+
+        def expect_partial(self):
+            return self
+
+        def __call__(self, inputs):
+            b = len(inputs[0])
+            i = state["i"]
+            pr = probs[i:i + b]
+            state["i"] += b
+            outs = [np.stack([1 - pr[:, k], pr[:, k]], axis=1).astype(np.float32) for k in range(4)]
+            return outs + [np.tile(np.array([[0.5, 0.5]], np.float32), (b, 1))]
+
+    class FakeHap:
+        def load_weights(self, p):
+            return self
+
+        def __call__(self, inputs):
+            if len(inputs[0]) == 1 and not np.any(inputs[0]):
+                return None
+            b = len(inputs[0])
+            i = state["i"]
+            state["i"] += b
+            return FakeT(hap_probs[i:i + b])
+
+    out = {}
+    for ploidy in ("diploid", "haploid"):
+        state["i"] = 0
+        ref_caller.SNP_model = FakeSNP
+        ref_caller.haploid_SNP_model = FakeHap
+        ref_caller.get_SNP_model = lambda name: ("x", 48.0)
+        onehot = np.eye(4, dtype=np.int32)[ref]
+        mat = np.zeros((n, 5, 41, 5), np.float32)
+        ref_caller.get_snp_testing_candidates = lambda params, chunk: (pos, onehot, mat, dp, freq, 30.0, fwd, rev)
+
+        class P:
+            _identity = (1,)
+
+        ref_caller.current_process = lambda: P
+        tmpdir = "/tmp/nc_gold_vcf"
+        os.makedirs(tmpdir, exist_ok=True)
+        params = dict(intermediate_snp_files_dir=tmpdir, prefix="g", snp_model="ONT-HG002",
+                      disable_coverage_normalization=False)
+        q = queue.Queue()
+        q.put(dict(chrom="chr20", start=1, end=100000, ploidy=ploidy))
+        cq = queue.Queue()
+        files = []
+        ref_caller.caller(params, q, cq, files)
+        lines = open(files[0]).read()
+        out["vcf_" + ploidy] = np.array(lines)
+        print("caller", ploidy, lines.count("\n"), "lines")
+    np.savez_compressed(os.path.join(OUT, "caller_vcf.npz"), probs=probs, hap_probs=hap_probs, ref=ref, pos=pos,
+                        dp=dp, freq=freq, fwd=fwd, rev=rev, **out)
+
+
+def make_msa_goldens():
+    from nanocaller_src import generate_indel_pileups as ref_indel
+
+    rng = np.random.Generator(np.random.PCG64(11))
+    rec = {}
+    k = 0
+    for ncols, nrows in ((90, 7), (128, 20), (161, 33), (200, 12), (170, 2)):
+        ref_row = rng.integers(0, 4, size=ncols)
+        gap = rng.random(ncols) < 0.1
+        ref_row[gap] = 4
+        rows = np.tile(ref_row, (nrows, 1))
+        e = rng.random(rows.shape)
+        rows[e < 0.1] = rng.integers(0, 5, size=int((e < 0.1).sum()))
+        # every column needs at least one non-gap symbol overall in real MUSCLE output; not required here
+        sym = "AGTC-"
+        names = ["rd%03d" % i for i in range(nrows)]
+        fasta = "".join(">%s_SEQ\n%s\n" % (nm, "".join(sym[c] for c in row)) for nm, row in zip(names, rows))
+        fasta += ">ref_SEQ\n%s\n" % "".join(sym[c] for c in ref_row)
+
+        class FakePopen:
+            def __init__(self, *a, **kw):
+                pass
+
+            def communicate(self, input=None):
+                return (fasta.encode(), b"")
+
+        ref_indel.Popen = FakePopen
+        seq_list = {nm: "ACGT" for nm in names}
+        flag, _, mat, cns, ref_seq = ref_indel.msa(seq_list, "ACGT", 100, 2, 160)
+        assert flag == 1
+        rec["m%d_rows" % k] = rows.astype(np.uint8)
+        rec["m%d_ref" % k] = ref_row.astype(np.uint8)
+        rec["m%d_mat" % k] = np.asarray(mat, np.float64)
+        rec["m%d_cns" % k] = np.array(cns)
+        rec["m%d_refseq" % k] = np.array(ref_seq)
+        k += 1
+    rec["n"] = k
+    np.savez_compressed(os.path.join(OUT, "indel_msa.npz"), **rec)
+    print("msa cases:", k)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa"]
+    if "snp" in what:
+        make_snp_goldens()
+    if "cnd" in what:
+        make_cnd_pos_goldens()
+    if "caller" in what:
+        make_caller_goldens()
+    if "msa" in what:
+        make_msa_goldens()

@@ -1,0 +1,141 @@
+"""Stub `pysam` used ONLY in the build container to import and run the reference featurisers
+(/root/reference/nanocaller_src/generate_SNP_pileups.py etc.) on synthetic worlds and capture
+golden vectors.  It is test tooling: nothing here is shipped or imported
+by the product path, and it never travels with reference code.
+
+Semantics mirrored from pysam/htslib documentation [pysam-doc]: pileup() yields only columns
+with depth > 0, applies `flag_filter`, a deletion is '*', the first character of each
+get_query_sequences(add_indels=True) string is the base (upper = forward, lower = reverse
+strand) and an indel that follows is appended as +<n><bases> / -<n><N...>.
+"""
+import numpy as np
+
+WORLDS = {}          # path -> nanocaller_amd.synth.World
+
+
+def register(path, world):
+    WORLDS[path] = world
+
+
+_LET = "AGTC*"
+
+
+class _Aln:
+    def __init__(self, world, i):
+        self.qname = world.names[i]
+        self.query_name = self.qname
+        self.flag = int(world.read_flag[i])
+        self._tags = world.meta.get("tags", {}).get(i, {})
+
+    def has_tag(self, t):
+        return t in self._tags
+
+    def get_tag(self, t):
+        return self._tags[t]
+
+
+class _Col:
+    def __init__(self, pos0, names, seqs):
+        self.pos = pos0
+        self.reference_pos = pos0
+        self._names = names
+        self._seqs = seqs
+
+    def get_query_sequences(self, mark_matches=False, mark_ends=False, add_indels=False):
+        return list(self._seqs)
+
+    def get_query_names(self):
+        return list(self._names)
+
+    def get_num_aligned(self):
+        return len(self._names)
+
+
+class Samfile:
+    def __init__(self, path, *a, reference_filename=None, **k):
+        self.world = WORLDS[path]
+
+    AlignmentFile = None
+
+    def is_valid_reference_name(self, c):
+        return c == self.world.chrom
+
+    def get_reference_length(self, c):
+        return self.world.length
+
+    @property
+    def references(self):
+        return [self.world.chrom]
+
+    def fetch(self, chrom, a, b, multiple_iterators=False):
+        w = self.world
+        # 0-based half-open [a,b); read covers 0-based [start-1, end-1)
+        idx = np.nonzero((w.read_start - 1 < b) & (w.read_end - 1 > a))[0]
+        for i in idx:
+            yield _Aln(w, int(i))
+
+    def pileup(self, chrom, a, b, min_base_quality=0, flag_filter=0, truncate=True,
+               multiple_iterators=False, **k):
+        w = self.world
+        a = max(0, a)
+        b = min(b, w.length)
+        ok = (w.read_flag & flag_filter) == 0
+        idx = np.nonzero(ok & (w.read_start - 1 < b) & (w.read_end - 1 > a))[0]
+        starts = w.read_start[idx].astype(np.int64) - 1
+        ends = w.read_end[idx].astype(np.int64) - 1
+        rev = (w.read_flag[idx] & 16) != 0
+        deco = w.meta.get("deco", {})
+        for p0 in range(a, b):
+            m = (starts <= p0) & (ends > p0)
+            if not m.any():
+                continue
+            sel = idx[m]
+            names, seqs = [], []
+            for i, s0, rv in zip(sel, starts[m], rev[m]):
+                c = int(w.codes[w.read_off[i] + (p0 - s0)])
+                if "letters" in w.meta and (int(i), p0) in w.meta["letters"]:
+                    ch = w.meta["letters"][(int(i), p0)]
+                else:
+                    ch = _LET[c]
+                if rv and ch != "*":
+                    ch = ch.lower()
+                d = deco.get((int(i), p0))
+                if d:
+                    ch = ch + (d.lower() if rv else d)
+                names.append(w.names[i])
+                seqs.append(ch)
+            yield _Col(p0, names, seqs)
+
+
+AlignmentFile = Samfile
+
+
+class FastaFile:
+    def __init__(self, path, *a, **k):
+        self.world = WORLDS[path]
+
+    def fetch(self, chrom, a=None, b=None):
+        return self.world.ref[a:b]
+
+    def get_reference_length(self, chrom):
+        return self.world.length
+
+
+class TabixFile:
+    def __init__(self, path, *a, **k):
+        self.rows = WORLDS[path]     # list of (chrom, start, end)
+
+    def fetch(self, chrom, parser=None):
+        rows = [r for r in self.rows if r[0] == chrom]
+        if not rows:
+            raise ValueError("could not create iterator for region")
+        return iter(rows)
+
+
+def asBed():
+    return None
+
+
+class VariantFile:
+    def __init__(self, *a, **k):
+        pass

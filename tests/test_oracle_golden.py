@@ -1,0 +1,42 @@
+"""Pin the CPU oracle (oracle/nc_oracle.c) against golden vectors produced by the REFERENCE's own code
+(oracle/tools/make_goldens.py, run in the build container).  CPU-only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.util import GOLD, SNP_CASES, assert_tuple_matches_gold, load_snp_case
+
+
+@pytest.mark.parametrize("case", SNP_CASES)
+def test_snp_featuriser_matches_reference(case):
+    world, dct, region, exclude, gold = load_snp_case(case)
+    out = oracle.get_snp_testing_candidates(world, dct, region, exclude=exclude)
+    assert_tuple_matches_gold(out, gold)
+
+
+def test_golden_cases_cover_all_modes():
+    seqs = {str(np.load(os.path.join(GOLD, "snp_%s.npz" % c))["seq"]) for c in SNP_CASES}
+    assert seqs == {"ont", "short_ont", "ul_ont", "ul_ont_extreme", "pacbio"}
+
+
+def test_get_cnd_pos_matches_reference():
+    z = np.load(os.path.join(GOLD, "cnd_pos.npz"))
+    n = int(z["n"])
+    assert n >= 50
+    for k in range(n):
+        left, right = oracle.get_cnd_pos(int(z["c%d_v" % k]), z["c%d_sites" % k], str(z["c%d_seq" % k]))
+        assert left == z["c%d_l" % k].tolist(), k
+        assert right == z["c%d_r" % k].tolist(), k
+
+
+def test_indel_tensor_matches_reference_msa():
+    z = np.load(os.path.join(GOLD, "indel_msa.npz"))
+    sym = "AGTC-"
+    for k in range(int(z["n"])):
+        out, cns = oracle.indel_tensor(z["m%d_rows" % k], z["m%d_ref" % k])
+        gold = z["m%d_mat" % k]
+        assert gold.shape == (5, 128, 2)
+        assert np.array_equal(out.astype(np.float64), gold), k
+        assert "".join(sym[c] for c in cns) == str(z["m%d_cns" % k])
