@@ -1,0 +1,189 @@
+/*
+ * nanocaller_hip.h -- C ABI of libnanocaller_hip.so: NanoCaller's candidate-site pileup featurisation
+ * and CNN inference path on MI355X (gfx950).
+ *
+ * The reference (WGLab/NanoCaller, pure Python) has no FFI; the boundary it exposes for this path is a
+ * set of Python call signatures.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference repository); INTEGRATION.md shows the ctypes stub a
+ * maintainer would add to nanocaller_src/.
+ *
+ * Conventions: every function returns 0 (NC_OK) or a negative nc_status; nothing throws across the
+ * boundary; nc_last_error() gives a message for the last failure on that context.  One context per
+ * (device, stream); a context is not thread-safe; no global state.  All arrays are row-major, little
+ * endian.  "dev" pointers are device (HBM) addresses, "host" pointers are ordinary host memory.
+ * Base codes everywhere: A=0 G=1 T=2 C=3, deletion/N=4 (generate_SNP_pileups.py:104).
+ */
+#ifndef NANOCALLER_HIP_H
+#define NANOCALLER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NC_ABI_VERSION 1
+
+typedef struct nc_ctx nc_ctx;
+
+enum nc_status {
+    NC_OK = 0,
+    NC_ERR_ARG = -1,       /* bad argument */
+    NC_ERR_CAPACITY = -2,  /* caller-provided capacity too small */
+    NC_ERR_NOMEM = -3,     /* host or device allocation failed */
+    NC_ERR_HIP = -4,       /* HIP runtime error (message in nc_last_error) */
+    NC_ERR_STATE = -5,     /* call order violated (e.g. featurize before scan, weights not loaded) */
+    NC_ERR_SELFTEST = -6   /* device self-test failed at context creation */
+};
+
+enum nc_model_kind { NC_MODEL_SNP = 0, NC_MODEL_SNP_HAP = 1, NC_MODEL_INDEL = 2, NC_MODEL_INDEL_HAP = 3 };
+
+/* neighbour-selection mode = the `seq` argument of get_cnd_pos (generate_SNP_pileups.py:6-101) */
+enum nc_seq_mode { NC_SEQ_ONT = 0, NC_SEQ_SHORT_ONT = 1, NC_SEQ_UL_ONT = 2, NC_SEQ_UL_ONT_EXTREME = 3, NC_SEQ_PACBIO = 4 };
+
+#define NC_CODE_ABSENT 7      /* padding byte in packed code slots */
+#define NC_FLANK 50000        /* scan flank around a chunk (generate_SNP_pileups.py:137,156) */
+#define NC_SNP_TENSOR 1025    /* 5*41*5 values per site */
+
+/* ------------------------------------------------------------------ context / device memory */
+int nc_abi_version(void);
+int nc_device_count(int *n);
+/* Creates a context on `device_id`, with its own HIP stream, and runs a device self-test. */
+int nc_ctx_create(int device_id, nc_ctx **out);
+int nc_ctx_destroy(nc_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
+int nc_ctx_set_stream(nc_ctx *ctx, void *hip_stream);
+int nc_ctx_sync(nc_ctx *ctx);
+const char *nc_last_error(const nc_ctx *ctx);
+/* Plain device-memory helpers so a host without any GPU framework can drive the library. */
+int nc_malloc(nc_ctx *ctx, size_t bytes, void **dev);
+int nc_free(nc_ctx *ctx, void *dev);
+int nc_memcpy_h2d(nc_ctx *ctx, void *dev, const void *host, size_t bytes);
+int nc_memcpy_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes);
+/* Wall-clock of the last timed call on this context's stream, measured with HIP events (ms);
+ * `which`: 0 scan, 1 featurize, 2 cnn forward, 3 indel tensor. */
+int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms);
+int nc_enable_timing(nc_ctx *ctx, int on);
+
+/* ------------------------------------------------------------------ packed alignments ("read pack")
+ * Replaces the pysam pileup objects of generate_SNP_pileups.py:134-164: alignments decoded once on the
+ * host are laid out read-major for HBM.  A read covering reference positions [start,end) (1-based) owns
+ * the 16-byte aligned slot of position-addressed bytes [floor16(start), ceil16(end)); its code at position
+ * p is codes[base + p]; bytes of the slot outside [start,end) hold NC_CODE_ABSENT.  `base` is a multiple
+ * of 16, so 16-position groups load as one aligned dwordx4.  Reads are in coordinate (start) order.
+ * The tile index lists, for every tile of `tile_size` consecutive positions, the reads overlapping it.
+ */
+typedef struct {
+    int32_t start;      /* first covered position (1-based) */
+    int32_t end;        /* one past the last covered position */
+    int64_t base_flag;  /* (base & ~15) | flags; bit0 = reverse strand ((flag & 0x910)/16, :143) */
+} nc_tile_entry;
+
+typedef struct {
+    int64_t codes_len;            /* bytes in `codes` (multiple of 16) */
+    const uint8_t *codes;         /* dev */
+    int32_t tile_size;            /* 1024, 2048 or 4096 positions */
+    int32_t tile_pos0;            /* first position of tile 0 (multiple of 16; may be <= 0) */
+    int32_t n_tiles;
+    const int32_t *tile_off;      /* dev [n_tiles+1] */
+    const nc_tile_entry *tile_ent;/* dev [tile_off[n_tiles]], coordinate order within a tile */
+    int64_t n_entries;
+} nc_readpack;
+
+/* Host-side packer.  Inputs (host): n reads in coordinate order, read r covers [start[r], end[r]) and
+ * codes_in[off[r] + p - start[r]] is its code (0..4) at p; keep[r]==0 drops the read (pileup flag filter
+ * 0x4|0x100|0x200|0x400|0x800, generate_SNP_pileups.py:151-157); strand[r] != 0 = reverse.
+ * Step 1 sizes the outputs; step 2 fills caller-allocated host buffers. */
+int nc_pack_plan(int32_t n_reads, const int32_t *start, const int32_t *end, const uint8_t *keep,
+                 int32_t tile_size, int32_t pos_lo, int32_t pos_hi,
+                 int64_t *codes_len, int32_t *tile_pos0, int32_t *n_tiles, int64_t *n_entries);
+int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off,
+                 const uint8_t *codes_in, const uint8_t *strand, const uint8_t *keep,
+                 int32_t tile_size, int32_t tile_pos0, int32_t n_tiles,
+                 uint8_t *codes_out, int64_t codes_len, int32_t *tile_off, nc_tile_entry *tile_ent,
+                 int64_t n_entries);
+
+/* ------------------------------------------------------------------ SNP candidate scan (K1)
+ * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch
+ * of chunks of ONE contig: every position of [scan_lo, scan_hi] is scanned once, per-position base counts
+ * give alt_freq = max_{b != ref} count(b) / n in float64, neighbour sites (t0 <= alt_freq [< t1]) and
+ * candidates (min_allele_freq <= alt_freq) are emitted in ascending position order; each chunk
+ * [chunk_start[c], chunk_end[c]] (both inclusive, utils.py:79-80) then owns the candidates inside it --
+ * a position shared by two adjacent chunks is emitted once per chunk (quirk E3).
+ * ref_code[p - ref_pos0] is the reference code at p: 0..3, or 4 to skip the column (non-AGTC or
+ * soft-masked base, generate_SNP_pileups.py:137,161, or an exclude_bed hit).
+ * Results stay in the context (device); counts are returned.  Synchronises once.
+ */
+typedef struct {
+    int32_t mincov;             /* dct['mincov'] */
+    double min_allele_freq;     /* dct['min_allele_freq'] */
+    double nbr_t0, nbr_t1;      /* dct['threshold'] */
+    int32_t haploid;            /* region['ploidy']=='haploid': neighbour test is t0 <= alt_freq only (:177) */
+} nc_scan_params;
+
+int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack,
+                const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params,
+                int32_t n_chunks, const int32_t *chunk_start_host, const int32_t *chunk_end_host,
+                int32_t *n_nbr, int32_t *n_cand, int32_t *n_sites);
+
+/* Copies the scan results of the context to host arrays (any may be NULL):
+ * nbr_pos[n_nbr]; per site (n_sites, chunk-major then ascending position): pos, chunk id,
+ * n (= dp, pileup entries incl. deletions, :164,186) and alt count (freq = alt/n in float64, :166). */
+int nc_snp_scan_fetch(nc_ctx *ctx, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk,
+                      int32_t *site_n, int32_t *site_alt);
+
+/* ------------------------------------------------------------------ SNP tensor build (K2-K4)
+ * Replaces get_cnd_pos + the per-candidate loop (generate_SNP_pileups.py:6-101, 200-263) for the sites of
+ * the last nc_snp_scan on this context: one wavefront per site picks <= 20+20 neighbour sites, gathers the
+ * codes of the site's reads at those columns and writes the (5,41,5) tensor.
+ * Neighbour sites are limited to the owning chunk's scan window [max(1,start-50000), end+50000] (quirk E9).
+ * Above maxcov the reference draws an unseeded random.sample (:215-216); this library keeps the first
+ * maxcov reads in coordinate order (documented policy; parity is defined for depth <= maxcov).
+ * Outputs (dev, caller-allocated): x f32 [n_sites][5][41][5]; ref_code i32 [n_sites]; fwd_dp, rev_dp
+ * i32 [n_sites][4] (AGTC counts over all reads by strand, :210-213); site_depth i32 [n_sites] (|S| after the
+ * maxcov cut, :263).  Sites failing `len(cols) < min_nbr_sites` (:244) get valid[s]=0 and a zero tensor.
+ */
+int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack,
+                     const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                     int32_t seq_mode, int32_t maxcov, int32_t min_nbr_sites,
+                     float *x_dev, int32_t *ref_code_out_dev, int32_t *fwd_dp_dev, int32_t *rev_dp_dev,
+                     int32_t *site_depth_dev, uint8_t *valid_dev);
+
+/* Per-site coverage scale (snpCaller.py:93-96, 170-173) for the sites of the last scan:
+ * mode 0: scale[s] = train_coverage / mean(site_depth over the site's chunk) (chunk constant, quirk E2)
+ * mode 1: scale[s] = train_coverage / dp[s] (--disable_coverage_normalization).
+ * chunk_depth_host (may be NULL) receives the per-chunk mean depth (float64, :274). */
+int nc_snp_scale(nc_ctx *ctx, const int32_t *site_depth_dev, const uint8_t *valid_dev, double train_coverage,
+                 int32_t mode, double *scale_dev, double *chunk_depth_host);
+
+/* ------------------------------------------------------------------ CNN forward (K5 / K9)
+ * nc_load_weights: canonical flat f32 blob (nanocaller_amd/weights.py LAYER_SPECS order, Keras layouts),
+ * replaces Model.load_weights (snpCaller.py:70-78, indelCaller.py:51-57).
+ * nc_snp_forward replaces SNP_model.call / haploid_SNP_model.call (model_architect.py:36-64,
+ * model_architect_SNP_haploid.py:33-53) including the coverage scaling of rows 1..4 / channels 0..3:
+ * scale_mode 0 multiplies in f32 by (float)scale[s] (numpy<2 scalar semantics), 1 multiplies in f64.
+ * probs f32 [n][4]: diploid = class-1 probability of the A,G,T,C heads; haploid = 4-way softmax.
+ * gt f32 [n][2] (diploid only, may be NULL).
+ */
+int nc_load_weights(nc_ctx *ctx, int32_t model_kind, const float *blob_host, size_t n_floats);
+int nc_snp_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev,
+                   const double *scale_dev, int32_t scale_mode, float *probs_dev, float *gt_dev);
+/* Indel CNN (model_architect_indel.py:28-48 rows=15 -> [n][4]; haploid rows=5 -> [n][1] sigmoid). */
+int nc_indel_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, float *probs_dev);
+
+/* ------------------------------------------------------------------ indel MSA rows -> tensor (K8)
+ * Replaces the histogram part of msa() (generate_indel_pileups.py:57-71): for each of n_sets aligned read
+ * sets (rows[s] is [n_rows[s]][n_cols[s]] symbols 0..4 = A,G,T,C,'-', stored at rows_dev + row_off[s]) and its
+ * aligned reference row, writes x [n_sets][5][128][2] (column frequency minus ref one-hot; ref one-hot), and
+ * the gap-handicapped consensus symbols cns [n_sets][max_cols] (NC_CODE_ABSENT-padded, gaps kept as 4).
+ */
+int nc_indel_tensor(nc_ctx *ctx, int32_t n_sets, const uint8_t *rows_dev, const int64_t *row_off_dev,
+                    const int32_t *n_rows_dev, const int32_t *n_cols_dev, const uint8_t *ref_rows_dev,
+                    const int64_t *ref_off_dev, int32_t max_cols, float *x_dev, uint8_t *cns_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOCALLER_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libnanocaller_hip.so (the C ABI declared in include/nanocaller_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible when a context is
+created, this raises -- the product path never routes through oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnanocaller_hip.so")
+
+NC_OK = 0
+MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
+SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
+CODE_ABSENT = 7
+FLANK = 50000
+SNP_TENSOR = 1025
+
+# every symbol include/nanocaller_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "nc_abi_version", "nc_device_count", "nc_ctx_create", "nc_ctx_destroy", "nc_ctx_set_stream", "nc_ctx_sync",
+    "nc_last_error", "nc_malloc", "nc_free", "nc_memcpy_h2d", "nc_memcpy_d2h", "nc_last_kernel_ms",
+    "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
+    "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor",
+]
+
+
+class TileEntry(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("base_flag", C.c_int64)]
+
+
+TILE_ENTRY_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("base_flag", "<i8")])
+assert TILE_ENTRY_DTYPE.itemsize == C.sizeof(TileEntry) == 16
+
+
+class ReadPackC(C.Structure):
+    _fields_ = [("codes_len", C.c_int64), ("codes", C.c_void_p), ("tile_size", C.c_int32), ("tile_pos0", C.c_int32),
+                ("n_tiles", C.c_int32), ("tile_off", C.c_void_p), ("tile_ent", C.c_void_p), ("n_entries", C.c_int64)]
+
+
+class ScanParamsC(C.Structure):
+    _fields_ = [("mincov", C.c_int32), ("min_allele_freq", C.c_double), ("nbr_t0", C.c_double), ("nbr_t1", C.c_double),
+                ("haploid", C.c_int32)]
+
+
+_lib = None
+
+
+class NanoCallerHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NanoCallerHipError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        L.nc_abi_version.restype = C.c_int
+        L.nc_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.nc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.nc_ctx_destroy.argtypes = [vp]
+        L.nc_ctx_set_stream.argtypes = [vp, vp]
+        L.nc_ctx_sync.argtypes = [vp]
+        L.nc_last_error.argtypes = [vp]
+        L.nc_last_error.restype = C.c_char_p
+        L.nc_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.nc_free.argtypes = [vp, vp]
+        L.nc_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.nc_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.nc_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+        L.nc_enable_timing.argtypes = [vp, C.c_int]
+        L.nc_pack_plan.argtypes = [i32, vp, vp, vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
+                                   C.POINTER(i64)]
+        L.nc_pack_fill.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, vp, vp, i64]
+        L.nc_snp_scan.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, C.POINTER(ScanParamsC), i32, vp, vp,
+                                  C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.nc_snp_scan_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.nc_snp_featurize.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.nc_snp_scale.argtypes = [vp, vp, vp, dbl, i32, vp, vp]
+        L.nc_load_weights.argtypes = [vp, i32, vp, C.c_size_t]
+        L.nc_snp_forward.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp]
+        L.nc_indel_forward.argtypes = [vp, i32, i64, vp, vp]
+        L.nc_indel_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name not in ("nc_last_error",):
+                fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def npp(a):
+    """host pointer of a contiguous numpy array (or None)"""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,107 @@
+// Internal header of libnanocaller_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/nanocaller_hip.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct nc_weights {
+    float *dev = nullptr;      // canonical flat blob
+    size_t n = 0;
+    float *packed = nullptr;   // kernel-specific repack (see nc_cnn.hip)
+    size_t n_packed = 0;
+};
+
+struct nc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms[4] = {0, 0, 0, 0};
+
+    // scan results (device)
+    DevBuf stage_nbr, stage_cpos, stage_cn, stage_calt;   // per-tile staging
+    DevBuf tile_cnt, tile_pre;                            // int2 per tile
+    DevBuf nbr_pos, cand_pos, cand_n, cand_alt;
+    DevBuf chunk_start, chunk_end, chunk_lo, chunk_cnt, chunk_off;
+    DevBuf site_pos, site_chunk, site_n, site_alt;
+    DevBuf totals;                                        // int32[4]: n_nbr, n_cand, n_sites
+    DevBuf cnn_a, cnn_b, cnn_c;                           // CNN intermediates
+    DevBuf chunk_depth;                                   // double per chunk
+    int32_t n_nbr = 0, n_cand = 0, n_sites = 0, n_chunks = 0;
+    bool have_scan = false;
+
+    nc_weights w[4];
+};
+
+inline int nc_fail(nc_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define NC_HIP(ctx, call)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return nc_fail(ctx, NC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                           __FILE__, __LINE__);                                                     \
+    } while (0)
+
+inline int nc_ensure(nc_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return NC_OK;
+    if (b.p) {
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NC_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return NC_OK;
+}
+
+#define NC_TRY(x)                \
+    do {                         \
+        int rc_ = (x);           \
+        if (rc_ != NC_OK) return rc_; \
+    } while (0)
+
+struct NcTimer {
+    nc_ctx *ctx;
+    int which;
+    NcTimer(nc_ctx *c, int w) : ctx(c), which(w)
+    {
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    void stop()
+    {
+        if (ctx->timing) {
+            (void)hipEventRecord(ctx->ev1, ctx->stream);
+            (void)hipEventSynchronize(ctx->ev1);
+            (void)hipEventElapsedTime(&ctx->last_ms[which], ctx->ev0, ctx->ev1);
+        }
+    }
+};
+
+// implemented in the kernel translation units
+int nc_selftest_device(nc_ctx *ctx);

@@ -1,0 +1,215 @@
+// Context, device-memory helpers and the host-side read packer of libnanocaller_hip.so.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "nc_common.h"
+
+extern "C" {
+
+int nc_abi_version(void) { return NC_ABI_VERSION; }
+
+int nc_device_count(int *n)
+{
+    if (!n) return NC_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return NC_ERR_HIP; }
+    *n = c;
+    return NC_OK;
+}
+
+int nc_ctx_create(int device_id, nc_ctx **out)
+{
+    if (!out) return NC_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NC_ERR_HIP;   // fail loudly: no CPU fallback exists
+    if (device_id < 0 || device_id >= n) return NC_ERR_ARG;
+    nc_ctx *ctx = new (std::nothrow) nc_ctx();
+    if (!ctx) return NC_ERR_NOMEM;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return NC_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    int rc = nc_selftest_device(ctx);
+    if (rc != NC_OK) {
+        fprintf(stderr, "nanocaller_hip: device self-test failed: %s\n", ctx->err);
+        nc_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return NC_OK;
+}
+
+static void freebuf(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int nc_ctx_destroy(nc_ctx *ctx)
+{
+    if (!ctx) return NC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->stage_nbr, &ctx->stage_cpos, &ctx->stage_cn, &ctx->stage_calt, &ctx->tile_cnt,
+                      &ctx->tile_pre, &ctx->nbr_pos, &ctx->cand_pos, &ctx->cand_n, &ctx->cand_alt,
+                      &ctx->chunk_start, &ctx->chunk_end, &ctx->chunk_lo, &ctx->chunk_cnt, &ctx->chunk_off,
+                      &ctx->site_pos, &ctx->site_chunk, &ctx->site_n, &ctx->site_alt, &ctx->totals,
+                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth};
+    for (DevBuf *b : bufs) freebuf(*b);
+    for (auto &w : ctx->w) {
+        if (w.dev) (void)hipFree(w.dev);
+        if (w.packed) (void)hipFree(w.packed);
+    }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return NC_OK;
+}
+
+int nc_ctx_set_stream(nc_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return NC_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return NC_OK;
+}
+
+int nc_ctx_sync(nc_ctx *ctx)
+{
+    if (!ctx) return NC_ERR_ARG;
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+const char *nc_last_error(const nc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int nc_malloc(nc_ctx *ctx, size_t bytes, void **dev)
+{
+    if (!ctx || !dev) return NC_ERR_ARG;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dev, bytes ? bytes : 16);
+    if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return NC_OK;
+}
+
+int nc_free(nc_ctx *ctx, void *dev)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (dev) NC_HIP(ctx, hipFree(dev));
+    return NC_OK;
+}
+
+int nc_memcpy_h2d(nc_ctx *ctx, void *dev, const void *host, size_t bytes)
+{
+    if (!ctx || (bytes && (!dev || !host))) return NC_ERR_ARG;
+    if (bytes) NC_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+int nc_memcpy_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    if (!ctx || (bytes && (!dev || !host))) return NC_ERR_ARG;
+    if (bytes) NC_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+int nc_enable_timing(nc_ctx *ctx, int on)
+{
+    if (!ctx) return NC_ERR_ARG;
+    ctx->timing = on != 0;
+    return NC_OK;
+}
+
+int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms)
+{
+    if (!ctx || !ms || which < 0 || which > 3) return NC_ERR_ARG;
+    *ms = ctx->last_ms[which];
+    return NC_OK;
+}
+
+// ---------------------------------------------------------------------------------- host packer
+static inline int64_t floor16(int64_t x) { return x & ~int64_t(15); }   // two's complement: works for x <= 0
+static inline int64_t ceil16(int64_t x) { return (x + 15) & ~int64_t(15); }
+
+static bool tile_size_ok(int32_t t) { return t == 1024 || t == 2048 || t == 4096; }
+
+int nc_pack_plan(int32_t n_reads, const int32_t *start, const int32_t *end, const uint8_t *keep,
+                 int32_t tile_size, int32_t pos_lo, int32_t pos_hi,
+                 int64_t *codes_len, int32_t *tile_pos0, int32_t *n_tiles, int64_t *n_entries)
+{
+    if (n_reads < 0 || (n_reads && (!start || !end)) || !tile_size_ok(tile_size) || pos_hi < pos_lo ||
+        !codes_len || !tile_pos0 || !n_tiles || !n_entries)
+        return NC_ERR_ARG;
+    int64_t t0 = (int64_t)pos_lo - (((int64_t)pos_lo % tile_size) + tile_size) % tile_size;   // floor to tile multiple
+    int64_t nt = ((int64_t)pos_hi - t0) / tile_size + 1;
+    if (nt > INT32_MAX) return NC_ERR_ARG;
+    int64_t bytes = 0, ents = 0;
+    int32_t prev = INT32_MIN;
+    for (int32_t r = 0; r < n_reads; r++) {
+        if (keep && !keep[r]) continue;
+        if (end[r] <= start[r]) return NC_ERR_ARG;
+        if (start[r] < prev) return NC_ERR_ARG;       // coordinate order required (as in a sorted BAM)
+        prev = start[r];
+        bytes += ceil16(end[r]) - floor16(start[r]);
+        int64_t a = std::max<int64_t>(start[r], t0), b = std::min<int64_t>((int64_t)end[r] - 1, t0 + nt * tile_size - 1);
+        if (a <= b) ents += (b - t0) / tile_size - (a - t0) / tile_size + 1;
+    }
+    *codes_len = bytes + 16;   // never empty
+    *tile_pos0 = (int32_t)t0;
+    *n_tiles = (int32_t)nt;
+    *n_entries = ents;
+    return NC_OK;
+}
+
+int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off,
+                 const uint8_t *codes_in, const uint8_t *strand, const uint8_t *keep,
+                 int32_t tile_size, int32_t tile_pos0, int32_t n_tiles,
+                 uint8_t *codes_out, int64_t codes_len, int32_t *tile_off, nc_tile_entry *tile_ent,
+                 int64_t n_entries)
+{
+    if (n_reads < 0 || !tile_size_ok(tile_size) || n_tiles <= 0 || !codes_out || !tile_off ||
+        (n_entries && !tile_ent) || (n_reads && (!start || !end || !off || !codes_in)))
+        return NC_ERR_ARG;
+    const int64_t t0 = tile_pos0;
+    std::vector<int64_t> cnt((size_t)n_tiles + 1, 0);
+    // pass 1: counts per tile
+    for (int32_t r = 0; r < n_reads; r++) {
+        if (keep && !keep[r]) continue;
+        int64_t a = std::max<int64_t>(start[r], t0), b = std::min<int64_t>((int64_t)end[r] - 1, t0 + (int64_t)n_tiles * tile_size - 1);
+        if (a > b) continue;
+        for (int64_t t = (a - t0) / tile_size; t <= (b - t0) / tile_size; t++) cnt[(size_t)t + 1]++;
+    }
+    for (int32_t t = 0; t < n_tiles; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+    if (cnt[(size_t)n_tiles] != n_entries || n_entries > INT32_MAX) return NC_ERR_CAPACITY;
+    for (int32_t t = 0; t <= n_tiles; t++) tile_off[t] = (int32_t)cnt[(size_t)t];
+    std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+    memset(codes_out, NC_CODE_ABSENT, (size_t)codes_len);
+    int64_t w = 0;   // write cursor (multiple of 16)
+    for (int32_t r = 0; r < n_reads; r++) {
+        if (keep && !keep[r]) continue;
+        int64_t lo = floor16(start[r]), hi = ceil16(end[r]);
+        if (w + (hi - lo) > codes_len) return NC_ERR_CAPACITY;
+        int64_t base = w - lo;                                  // codes_out[base + p], multiple of 16
+        memcpy(codes_out + base + start[r], codes_in + off[r], (size_t)(end[r] - start[r]));
+        w += hi - lo;
+        nc_tile_entry e;
+        e.start = start[r];
+        e.end = end[r];
+        e.base_flag = base | ((strand && strand[r]) ? 1 : 0);
+        int64_t a = std::max<int64_t>(start[r], t0), b = std::min<int64_t>((int64_t)end[r] - 1, t0 + (int64_t)n_tiles * tile_size - 1);
+        if (a > b) continue;
+        for (int64_t t = (a - t0) / tile_size; t <= (b - t0) / tile_size; t++) tile_ent[cur[(size_t)t]++] = e;
+    }
+    return NC_OK;
+}
+
+}   // extern "C"

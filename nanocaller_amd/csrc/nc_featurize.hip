@@ -1,0 +1,315 @@
+// K2-K4: per-candidate neighbour selection, read gather and (5,41,5) tensor build (gfx950).
+//
+// Restates get_cnd_pos + the per-candidate loop of get_snp_testing_candidates (reference
+// generate_SNP_pileups.py:6-101, 200-263).  One 64-lane wavefront per candidate
+// site: lanes first act as buckets (binary searches into the sorted neighbour-site list), then as reads
+// (which tile entries cover the site; strand/base depth ballots), then as tensor columns (lane j gathers
+// the code of each sampled read at column j and keeps a 4x4 histogram in packed 16-bit counters).  The
+// site tensor is assembled in LDS and four sites leave the workgroup as one aligned, coalesced dwordx4 stream.
+#include "nc_common.h"
+
+namespace {
+
+constexpr int MAXCOV_CAP = 1024;   // LDS list of sampled reads per wave
+constexpr int NBR = 20;
+
+struct Bucket { int32_t dlo, dhi, k, far; };     // distance range (dlo, dhi], pick k, far=1: farthest k
+struct ModeTab { int32_t nb, W; Bucket b[7]; };
+
+// One row per list comprehension of get_cnd_pos (generate_SNP_pileups.py:6-101), expressed by distance |p-v|.
+// Left and right sides are mirror images; only the innermost bucket may pick the FARTHEST sites (quirk E5).
+__constant__ ModeTab MODES[5] = {
+    {5, 50000, {{0, 2000, 2, 1}, {2000, 5000, 3, 0}, {5000, 10000, 4, 0}, {10000, 20000, 5, 0}, {20000, 1 << 30, 6, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}},
+    {3, 50000, {{0, 2000, 5, 0}, {2000, 5000, 10, 0}, {5000, 1 << 30, 5, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}},
+    {7, 100000, {{0, 2000, 2, 1}, {2000, 5000, 2, 0}, {5000, 10000, 3, 0}, {10000, 20000, 3, 0}, {20000, 40000, 4, 0}, {40000, 50000, 3, 0}, {50000, 1 << 30, 3, 0}}},
+    {7, 300000, {{0, 10000, 2, 1}, {10000, 20000, 2, 0}, {20000, 50000, 3, 0}, {50000, 75000, 3, 0}, {75000, 100000, 4, 0}, {100000, 200000, 4, 0}, {200000, 1 << 30, 2, 0}}},
+    {4, 20000, {{0, 2000, 4, 1}, {2000, 5000, 5, 0}, {5000, 10000, 5, 0}, {10000, 20000, 6, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}},
+};
+
+__device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int64_t key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct FeatArgs {
+    const uint8_t *codes;
+    const int32_t *tile_off;
+    const nc_tile_entry *tile_ent;
+    int32_t tile_pos0, tile_shift;
+    const uint8_t *ref_code;
+    int32_t ref_pos0;
+    const int32_t *nbr_pos;
+    int32_t n_nbr;
+    const int32_t *site_pos, *site_chunk;
+    const int32_t *chunk_start, *chunk_end;
+    int32_t n_sites, mode, maxcov, min_nbr_sites;
+    float *x;
+    int32_t *ref_out, *fwd, *rev, *depth;
+    uint8_t *valid;
+};
+
+__global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sm[4][NC_SNP_TENSOR + 3];
+    __shared__ int32_t slist[4][MAXCOV_CAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wv;
+    float *X = sm[wv];
+    for (int i = lane; i < NC_SNP_TENSOR; i += 64) X[i] = 0.0f;
+
+    if (s < a.n_sites) {
+        const int32_t v = a.site_pos[s];
+        const int32_t ch = a.site_chunk[s];
+        // neighbour sites are those of the owning chunk's own scan window (quirk E9)
+        const int64_t win_lo = max((int64_t)1, (int64_t)a.chunk_start[ch] - NC_FLANK);
+        const int64_t win_hi = (int64_t)a.chunk_end[ch] + NC_FLANK;
+        const ModeTab &M = MODES[a.mode];
+        const int nb = M.nb;
+
+        // ---- K2: lanes [0,nb) = left buckets far->near, lanes [nb,2nb) = right buckets near->far
+        int take = 0, idx0 = 0;
+        if (lane < 2 * nb) {
+            const bool left = lane < nb;
+            const Bucket B = M.b[left ? nb - 1 - lane : lane - nb];
+            const int64_t dhi = min((int64_t)B.dhi, (int64_t)M.W - 1);       // abs(p - v) < W
+            int64_t pmin = left ? (int64_t)v - dhi : (int64_t)v + B.dlo + 1;
+            int64_t pmax = left ? (int64_t)v - B.dlo - 1 : (int64_t)v + dhi;
+            pmin = max(pmin, win_lo);
+            pmax = min(pmax, win_hi);
+            if (pmin <= pmax) {
+                const int lo = lower_bound_i32(a.nbr_pos, a.n_nbr, pmin);
+                const int hi = lower_bound_i32(a.nbr_pos, a.n_nbr, pmax + 1);
+                const int m = hi - lo;
+                take = min(m, B.k);
+                // ascending order: on the left the farthest are first, on the right the farthest are last
+                const bool first = left ? (B.far != 0) : (B.far == 0);
+                idx0 = first ? lo : hi - take;
+            }
+        }
+        int incl = take;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        const int excl = incl - take;
+        const int nl = __shfl(incl, nb - 1, 64);
+        const int ntot = __shfl(incl, 2 * nb - 1, 64);
+        const int nr = ntot - nl;
+        const int ncols = ntot + 1;
+
+        // column position of lane j
+        int32_t col = 0;
+        {
+            const int jj = lane < nl ? lane : lane - 1;          // index into the concatenated neighbour list
+            int32_t q = v;
+            for (int l = 0; l < 2 * nb; l++) {
+                const int o_l = __shfl(excl, l, 64), t_l = __shfl(take, l, 64), i_l = __shfl(idx0, l, 64);
+                if (lane != nl && lane < ncols && jj >= o_l && jj < o_l + t_l) q = a.nbr_pos[i_l + (jj - o_l)];
+            }
+            col = q;
+        }
+        const bool active = lane < ncols;
+        const int rc_col = active ? a.ref_code[(int64_t)col - a.ref_pos0] : 4;
+        const int rc_centre = a.ref_code[(int64_t)v - a.ref_pos0];
+
+        // ---- K4 + read set: which tile entries cover v (the pileup at v, generate_SNP_pileups.py:208)
+        const int t = (v - a.tile_pos0) >> a.tile_shift;
+        const int e0 = a.tile_off[t], e1 = a.tile_off[t + 1];
+        int n_all = 0;
+        int fw[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int e = eb + lane;
+            bool cov = false;
+            int code = 4, strand = 0;
+            if (e < e1) {
+                const nc_tile_entry ent = a.tile_ent[e];
+                cov = ent.start <= v && v < ent.end;
+                if (cov) {
+                    code = a.codes[(ent.base_flag & ~int64_t(15)) + v];
+                    strand = (int)(ent.base_flag & 1);
+                }
+            }
+            const unsigned long long bal = __ballot(cov);
+            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            if (cov && n_all + rank < a.maxcov) slist[wv][n_all + rank] = e;     // first maxcov in coordinate order
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                fw[b] += __popcll(__ballot(cov && code == b && strand == 0));
+                rv[b] += __popcll(__ballot(cov && code == b && strand != 0));
+            }
+            n_all += __popcll(bal);
+        }
+        const int ns = min(n_all, a.maxcov);
+        __builtin_amdgcn_wave_barrier();
+
+        const bool ok = ncols >= a.min_nbr_sites;               // :244, the list includes the candidate itself
+        // ---- K3: lane j gathers column j of every sampled read
+        unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
+        if (ok) {
+#pragma unroll 4
+            for (int i = 0; i < ns; i++) {
+                const int e = slist[wv][i];
+                const nc_tile_entry ent = a.tile_ent[e];
+                int b = 4;
+                if (active && ent.start <= col && col < ent.end) b = a.codes[(ent.base_flag & ~int64_t(15)) + col];
+                const int c = __shfl(b, nl, 64);                 // centre base of this read
+                const unsigned long long inc = b < 4 ? (1ull << (16 * b)) : 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; k++) cnt[k] += (c == k) ? inc : 0ull;
+            }
+            // ---- assemble (Appendix A step 5)
+            if (active) {
+                const int o = NBR - nl;
+                float *Xc = X + (o + lane) * 5;
+                if (rc_col < 4) Xc[rc_col] = 1.0f;                                   // row 0: reference one-hot
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int val = (int)((cnt[i] >> (16 * b)) & 0xFFFF);
+                        Xc[(1 + i) * 41 * 5 + b] = (float)(b == rc_col ? -val : val);
+                    }
+                    Xc[(1 + i) * 41 * 5 + 4] = (i == rc_centre) ? 1.0f : 0.0f;
+                }
+            }
+        }
+        if (lane == 0) {
+            a.ref_out[s] = rc_centre;
+            a.depth[s] = ns;
+            a.valid[s] = ok ? 1 : 0;
+        }
+        if (lane < 4) {
+            a.fwd[s * 4 + lane] = fw[lane];
+            a.rev[s * 4 + lane] = rv[lane];
+        }
+        (void)nr;
+    }
+    __syncthreads();
+    // coalesced store of up to four site tensors
+    const int s0 = blockIdx.x * 4;
+    const int nsite = min(4, a.n_sites - s0);
+    float *dst = a.x + (int64_t)s0 * NC_SNP_TENSOR;
+    if (nsite == 4) {
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int i = threadIdx.x; i < NC_SNP_TENSOR; i += 256) {          // 4*1025 floats = 1025 float4
+            const int f = i * 4;
+            float4 o;
+            o.x = sm[(f + 0) / NC_SNP_TENSOR][(f + 0) % NC_SNP_TENSOR];
+            o.y = sm[(f + 1) / NC_SNP_TENSOR][(f + 1) % NC_SNP_TENSOR];
+            o.z = sm[(f + 2) / NC_SNP_TENSOR][(f + 2) % NC_SNP_TENSOR];
+            o.w = sm[(f + 3) / NC_SNP_TENSOR][(f + 3) % NC_SNP_TENSOR];
+            d4[i] = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nsite * NC_SNP_TENSOR; i += 256) dst[i] = sm[i / NC_SNP_TENSOR][i % NC_SNP_TENSOR];
+    }
+}
+
+// per-chunk mean sampled depth (generate_SNP_pileups.py:274) and per-site scale (snpCaller.py:93-96)
+__global__ __launch_bounds__(256) void k_chunk_scale(const int32_t *__restrict__ chunk_off, const int32_t *__restrict__ depth,
+                                                     const uint8_t *__restrict__ valid, const int32_t *__restrict__ site_n,
+                                                     double train_cov, int mode, double *__restrict__ scale,
+                                                     double *__restrict__ chunk_depth)
+{
+    const int c = blockIdx.x;
+    const int s0 = chunk_off[c], s1 = chunk_off[c + 1];
+    long long sum = 0, cntv = 0;
+    for (int s = s0 + threadIdx.x; s < s1; s += 256)
+        if (valid[s]) { sum += depth[s]; cntv++; }
+    __shared__ long long ssum[256], scnt[256];
+    ssum[threadIdx.x] = sum;
+    scnt[threadIdx.x] = cntv;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    const double mean = scnt[0] ? (double)ssum[0] / (double)scnt[0] : 0.0;       // np.mean of ints: exact sum / count
+    if (threadIdx.x == 0) chunk_depth[c] = mean;
+    for (int s = s0 + threadIdx.x; s < s1; s += 256)
+        scale[s] = mode == 0 ? train_cov / mean : train_cov / (double)site_n[s];
+}
+
+}   // namespace
+
+extern "C" {
+
+int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                     int32_t seq_mode, int32_t maxcov, int32_t min_nbr_sites, float *x_dev, int32_t *ref_code_out_dev,
+                     int32_t *fwd_dp_dev, int32_t *rev_dp_dev, int32_t *site_depth_dev, uint8_t *valid_dev)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!ctx->have_scan) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_featurize: call nc_snp_scan first");
+    if (!pack || !ref_code_dev || seq_mode < 0 || seq_mode > 4)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_featurize: bad argument");
+    if (maxcov < 1 || maxcov > MAXCOV_CAP)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_featurize: maxcov %d outside [1,%d]", maxcov, MAXCOV_CAP);
+    if (ctx->n_sites == 0) return NC_OK;
+    if (!x_dev || !ref_code_out_dev || !fwd_dp_dev || !rev_dp_dev || !site_depth_dev || !valid_dev)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_featurize: null output");
+    if (((uintptr_t)x_dev) & 15) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_featurize: x_dev must be 16-byte aligned");
+    if (ref_pos0 != pack->tile_pos0 || (int64_t)ref_len < (int64_t)pack->n_tiles * pack->tile_size)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_featurize: ref_code must cover the pack's tile grid");
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    FeatArgs a;
+    a.codes = pack->codes;
+    a.tile_off = pack->tile_off;
+    a.tile_ent = pack->tile_ent;
+    a.tile_pos0 = pack->tile_pos0;
+    a.tile_shift = pack->tile_size == 1024 ? 10 : pack->tile_size == 2048 ? 11 : 12;
+    a.ref_code = ref_code_dev;
+    a.ref_pos0 = ref_pos0;
+    a.nbr_pos = (const int32_t *)ctx->nbr_pos.p;
+    a.n_nbr = ctx->n_nbr;
+    a.site_pos = (const int32_t *)ctx->site_pos.p;
+    a.site_chunk = (const int32_t *)ctx->site_chunk.p;
+    a.chunk_start = (const int32_t *)ctx->chunk_start.p;
+    a.chunk_end = (const int32_t *)ctx->chunk_end.p;
+    a.n_sites = ctx->n_sites;
+    a.mode = seq_mode;
+    a.maxcov = maxcov;
+    a.min_nbr_sites = min_nbr_sites;
+    a.x = x_dev;
+    a.ref_out = ref_code_out_dev;
+    a.fwd = fwd_dp_dev;
+    a.rev = rev_dp_dev;
+    a.depth = site_depth_dev;
+    a.valid = valid_dev;
+    NcTimer tm(ctx, 1);
+    hipLaunchKernelGGL(k_featurize, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
+    NC_HIP(ctx, hipGetLastError());
+    tm.stop();
+    return NC_OK;
+}
+
+int nc_snp_scale(nc_ctx *ctx, const int32_t *site_depth_dev, const uint8_t *valid_dev, double train_coverage, int32_t mode,
+                 double *scale_dev, double *chunk_depth_host)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!ctx->have_scan) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scale: call nc_snp_scan first");
+    if (mode != 0 && mode != 1) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scale: mode must be 0 or 1");
+    NC_TRY(nc_ensure(ctx, ctx->chunk_depth, (size_t)ctx->n_chunks * 8));
+    if (ctx->n_sites > 0) {
+        if (!site_depth_dev || !valid_dev || !scale_dev) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scale: null argument");
+        hipLaunchKernelGGL(k_chunk_scale, dim3(ctx->n_chunks), dim3(256), 0, ctx->stream, (const int32_t *)ctx->chunk_off.p,
+                           site_depth_dev, valid_dev, (const int32_t *)ctx->site_n.p, train_coverage, mode, scale_dev,
+                           (double *)ctx->chunk_depth.p);
+        NC_HIP(ctx, hipGetLastError());
+    } else {
+        NC_HIP(ctx, hipMemsetAsync(ctx->chunk_depth.p, 0, (size_t)ctx->n_chunks * 8, ctx->stream));
+    }
+    if (chunk_depth_host) {
+        NC_HIP(ctx, hipMemcpyAsync(chunk_depth_host, ctx->chunk_depth.p, (size_t)ctx->n_chunks * 8, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return NC_OK;
+}
+
+}   // extern "C"

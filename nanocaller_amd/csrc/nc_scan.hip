@@ -1,0 +1,435 @@
+// K1: candidate / neighbour-site scan over packed alignments (gfx950).
+//
+// Restates the column loop of get_snp_testing_candidates (reference generate_SNP_pileups.py:156-186).
+// HBM-bound design: one workgroup per tile of TILE = 16*BLOCK reference positions; every lane owns 16
+// consecutive positions and, for each read overlapping the tile, loads the read's 16 codes as ONE aligned
+// dwordx4 (position-aligned slots, see nanocaller_hip.h).  Codes are counted four positions at a time with
+// v_perm_b32 used as an 8-entry byte LUT (code -> 0/1 per byte lane) into byte-lane accumulators that are
+// widened every 255 reads.  Algorithmic traffic: one byte per pileup entry + one reference byte per column.
+#include "nc_common.h"
+
+namespace {
+
+// byte LUT: result byte i = table[x.byte i], table = {hi:lo} little endian, valid for byte values 0..7
+__device__ __forceinline__ uint32_t lut8(uint32_t x, uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, x); }
+
+constexpr uint32_t LUT_LO[5] = {0x00000001u, 0x00000100u, 0x00010000u, 0x01000000u, 0x01010101u};
+constexpr uint32_t LUT_HI[5] = {0u, 0u, 0u, 0u, 0x00000001u};   // plane 4 = "present" (codes 0..4)
+
+struct ScanP {
+    int32_t mincov;
+    int32_t haploid;
+    double min_af, t0, t1;
+    int32_t scan_lo, scan_hi;
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_scan(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
+                                                const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
+                                                const uint8_t *__restrict__ ref_code, ScanP sp,
+                                                int32_t *__restrict__ stage_nbr, int32_t *__restrict__ stage_cpos,
+                                                int32_t *__restrict__ stage_cn, int32_t *__restrict__ stage_calt,
+                                                int2 *__restrict__ tile_cnt)
+{
+    constexpr int TILE = BLOCK * 16;
+    const int t = blockIdx.x;
+    const int64_t tile_base = (int64_t)tile_pos0 + (int64_t)t * TILE;
+    const int32_t P0 = (int32_t)(tile_base + threadIdx.x * 16);
+
+    uint32_t acc[5][4];
+    uint32_t wide[5][8];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) acc[c][d] = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) wide[c][d] = 0;
+    }
+    const int e0 = tile_off[t], e1 = tile_off[t + 1];
+    int e = e0;
+    while (e < e1) {
+        const int lim = min(e1, e + 255);
+#pragma unroll 4
+        for (; e < lim; e++) {
+            const nc_tile_entry ent = tile_ent[e];            // wave-uniform -> scalar loads
+            const int32_t lo = ent.start & ~15, hi = (ent.end + 15) & ~15;
+            uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+            if (P0 >= lo && P0 < hi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) acc[c][d] += lut8(w[d], LUT_LO[c], LUT_HI[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                wide[c][2 * d] += acc[c][d] & 0x00FF00FFu;            // positions 4d+0 (lo16), 4d+2 (hi16)
+                wide[c][2 * d + 1] += (acc[c][d] >> 8) & 0x00FF00FFu; // positions 4d+1, 4d+3
+                acc[c][d] = 0;
+            }
+        }
+    }
+
+    // per-position decision (generate_SNP_pileups.py:161-186)
+    const uint4 rv = *reinterpret_cast<const uint4 *>(ref_code + (int64_t)t * TILE + threadIdx.x * 16);
+    const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    uint32_t nbr_mask = 0, cand_mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int d = i >> 2, k = i & 3;
+        const int wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
+        const int r = (rw[d] >> (8 * k)) & 0xFF;
+        const int32_t p = P0 + i;
+        const uint32_t n = (wide[4][wi] >> sh) & 0xFFFF;
+        if (r < 4 && n > 0 && p >= sp.scan_lo && p <= sp.scan_hi && (int32_t)n >= sp.mincov) {
+            uint32_t alt = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t cb = (wide[b][wi] >> sh) & 0xFFFF;
+                if (b != r && cb > alt) alt = cb;
+            }
+            const double f = (double)alt / (double)n;                 // alt_freq, float64 (:166)
+            const bool nb = sp.haploid ? (sp.t0 <= f) : (sp.t0 <= f && f < sp.t1);   // :173 / :177
+            if (nb) nbr_mask |= 1u << i;
+            if (sp.min_af <= f) cand_mask |= 1u << i;                 // :183 (chunk membership applied later)
+        }
+    }
+
+    // ordered tile-local compaction: block exclusive scan of (nbr | cand << 16)
+    const uint32_t mine = __popc(nbr_mask) | (__popc(cand_mask) << 16);
+    uint32_t incl = mine;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    __shared__ uint32_t wsum[BLOCK / 64 + 1];
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wpre = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; i++) {
+        const uint32_t s = wsum[i];
+        if (i < wv) wpre += s;
+        total += s;
+    }
+    const uint32_t excl = wpre + incl - mine;
+    int on = excl & 0xFFFF, oc = excl >> 16;
+    const int64_t sbase = (int64_t)t * TILE;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (nbr_mask & (1u << i)) stage_nbr[sbase + on++] = P0 + i;
+        if (cand_mask & (1u << i)) {
+            const int d = i >> 2, k = i & 3;
+            const int wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
+            const int r = (rw[d] >> (8 * k)) & 0xFF;
+            uint32_t alt = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t cb = (wide[b][wi] >> sh) & 0xFFFF;
+                if (b != r && cb > alt) alt = cb;
+            }
+            stage_cpos[sbase + oc] = P0 + i;
+            stage_cn[sbase + oc] = (int32_t)((wide[4][wi] >> sh) & 0xFFFF);
+            stage_calt[sbase + oc] = (int32_t)alt;
+            oc++;
+        }
+    }
+    if (threadIdx.x == 0) tile_cnt[t] = make_int2((int)(total & 0xFFFF), (int)(total >> 16));
+}
+
+// single-workgroup exclusive scan of int2 counts (n_tiles is at most a few million)
+__global__ __launch_bounds__(1024) void k_tile_prefix(const int2 *__restrict__ cnt, int2 *__restrict__ pre, int n,
+                                                      int32_t *__restrict__ totals)
+{
+    __shared__ int2 wsum[16];
+    __shared__ int2 carry;
+    if (threadIdx.x == 0) carry = make_int2(0, 0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        int2 v = i < n ? cnt[i] : make_int2(0, 0);
+        int2 inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yx = __shfl_up(inc.x, o, 64), yy = __shfl_up(inc.y, o, 64);
+            if (lane >= o) { inc.x += yx; inc.y += yy; }
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int2 wp = make_int2(0, 0), tot = make_int2(0, 0);
+        for (int w = 0; w < 16; w++) {
+            const int2 s = wsum[w];
+            if (w < wv) { wp.x += s.x; wp.y += s.y; }
+            tot.x += s.x; tot.y += s.y;
+        }
+        const int2 c = carry;
+        if (i < n) pre[i] = make_int2(c.x + wp.x + inc.x - v.x, c.y + wp.y + inc.y - v.y);
+        __syncthreads();
+        if (threadIdx.x == 0) carry = make_int2(c.x + tot.x, c.y + tot.y);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = carry.x; totals[1] = carry.y; }
+}
+
+__global__ __launch_bounds__(256) void k_compact(int tile, const int2 *__restrict__ cnt, const int2 *__restrict__ pre,
+                                                 const int32_t *__restrict__ stage_nbr, const int32_t *__restrict__ stage_cpos,
+                                                 const int32_t *__restrict__ stage_cn, const int32_t *__restrict__ stage_calt,
+                                                 int32_t *__restrict__ nbr_pos, int32_t *__restrict__ cand_pos,
+                                                 int32_t *__restrict__ cand_n, int32_t *__restrict__ cand_alt)
+{
+    const int t = blockIdx.x;
+    const int2 c = cnt[t], p = pre[t];
+    const int64_t sb = (int64_t)t * tile;
+    for (int i = threadIdx.x; i < c.x; i += 256) nbr_pos[p.x + i] = stage_nbr[sb + i];
+    for (int i = threadIdx.x; i < c.y; i += 256) {
+        cand_pos[p.y + i] = stage_cpos[sb + i];
+        cand_n[p.y + i] = stage_cn[sb + i];
+        cand_alt[p.y + i] = stage_calt[sb + i];
+    }
+}
+
+__device__ __forceinline__ int lower_bound_dev(const int32_t *a, int n, int32_t key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// candidates of chunk c = cand positions in [start, end] (both inclusive, generate_SNP_pileups.py:183)
+__global__ void k_chunk_ranges(const int32_t *__restrict__ cand_pos, const int32_t *__restrict__ totals, int n_chunks,
+                               const int32_t *__restrict__ cs, const int32_t *__restrict__ ce,
+                               int32_t *__restrict__ chunk_lo, int32_t *__restrict__ chunk_cnt)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int n = totals[1];
+    const int lo = lower_bound_dev(cand_pos, n, cs[c]);
+    const int hi = ce[c] == INT32_MAX ? n : lower_bound_dev(cand_pos, n, ce[c] + 1);
+    chunk_lo[c] = lo;
+    chunk_cnt[c] = hi > lo ? hi - lo : 0;
+}
+
+__global__ __launch_bounds__(1024) void k_chunk_prefix(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int n,
+                                                       int32_t *__restrict__ totals)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? cnt[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int wp = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            const int s = wsum[w];
+            if (w < wv) wp += s;
+            tot += s;
+        }
+        const int c = carry;
+        if (i < n) off[i] = c + wp + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { off[n] = carry; totals[2] = carry; }
+}
+
+__global__ void k_sites(int n_sites, int n_chunks, const int32_t *__restrict__ chunk_off, const int32_t *__restrict__ chunk_lo,
+                        const int32_t *__restrict__ cand_pos, const int32_t *__restrict__ cand_n,
+                        const int32_t *__restrict__ cand_alt, int32_t *__restrict__ site_pos,
+                        int32_t *__restrict__ site_chunk, int32_t *__restrict__ site_n, int32_t *__restrict__ site_alt)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sites) return;
+    // chunk = last c with chunk_off[c] <= s
+    int lo = 0, hi = n_chunks;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_off[mid + 1] <= s) lo = mid + 1; else hi = mid;
+    }
+    const int c = lo;
+    const int ci = chunk_lo[c] + (s - chunk_off[c]);
+    site_pos[s] = cand_pos[ci];
+    site_chunk[s] = c;
+    site_n[s] = cand_n[ci];
+    site_alt[s] = cand_alt[ci];
+}
+
+// ---- device self-test: the byte-LUT semantics of v_perm_b32 that k_scan relies on
+__global__ void k_selftest(uint32_t *out)
+{
+    const uint32_t x = 0x07040300u | (threadIdx.x & 3);   // bytes: lane&3, 3, 4, 7
+    uint32_t r = 0;
+    for (int c = 0; c < 5; c++) r |= lut8(x, LUT_LO[c], LUT_HI[c]) << c;
+    out[threadIdx.x] = r;
+}
+
+}   // namespace
+
+int nc_selftest_device(nc_ctx *ctx)
+{
+    uint32_t *d = nullptr, h[64];
+    NC_HIP(ctx, hipMalloc(&d, sizeof h));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, ctx->stream, d);
+    NC_HIP(ctx, hipGetLastError());
+    NC_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    NC_HIP(ctx, hipFree(d));
+    for (int l = 0; l < 64; l++) {
+        // expected: byte0 = code l&3 -> plane (l&3) and present; byte1 = code 3 -> plane 3 + present;
+        // byte2 = code 4 -> present only; byte3 = code 7 -> nothing
+        uint32_t exp = 0;
+        const int c0 = l & 3;
+        exp |= (1u << c0) | (1u << 4);
+        exp |= ((1u << 3) | (1u << 4)) << 8;
+        exp |= (1u << 4) << 16;
+        if (h[l] != exp)
+            return nc_fail(ctx, NC_ERR_SELFTEST, "v_perm_b32 byte-LUT self-test: lane %d got %08x expected %08x", l, h[l], exp);
+    }
+    return NC_OK;
+}
+
+extern "C" {
+
+int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params, int32_t n_chunks,
+                const int32_t *chunk_start_host, const int32_t *chunk_end_host, int32_t *n_nbr, int32_t *n_cand,
+                int32_t *n_sites)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!pack || !ref_code_dev || !params || n_chunks <= 0 || !chunk_start_host || !chunk_end_host)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scan: null argument");
+    const int tile = pack->tile_size;
+    if (!(tile == 1024 || tile == 2048 || tile == 4096) || pack->n_tiles <= 0 || !pack->codes || !pack->tile_off ||
+        (pack->n_entries && !pack->tile_ent) || (pack->tile_pos0 & 15))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scan: malformed read pack");
+    // the reference codes must cover the pack's tile grid exactly (host pads with 4 = skip column)
+    if (ref_pos0 != pack->tile_pos0 || (int64_t)ref_len < (int64_t)pack->n_tiles * tile)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scan: ref_code must start at tile_pos0 (%d) and cover %lld positions",
+                       pack->tile_pos0, (long long)pack->n_tiles * tile);
+    if (scan_hi < scan_lo) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scan: empty scan range");
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->have_scan = false;
+    const int64_t npos = (int64_t)pack->n_tiles * tile;
+    NC_TRY(nc_ensure(ctx, ctx->stage_nbr, npos * 4));
+    NC_TRY(nc_ensure(ctx, ctx->stage_cpos, npos * 4));
+    NC_TRY(nc_ensure(ctx, ctx->stage_cn, npos * 4));
+    NC_TRY(nc_ensure(ctx, ctx->stage_calt, npos * 4));
+    NC_TRY(nc_ensure(ctx, ctx->tile_cnt, (size_t)pack->n_tiles * 8));
+    NC_TRY(nc_ensure(ctx, ctx->tile_pre, (size_t)pack->n_tiles * 8));
+    NC_TRY(nc_ensure(ctx, ctx->totals, 16));
+    NC_TRY(nc_ensure(ctx, ctx->chunk_start, (size_t)n_chunks * 4));
+    NC_TRY(nc_ensure(ctx, ctx->chunk_end, (size_t)n_chunks * 4));
+    NC_TRY(nc_ensure(ctx, ctx->chunk_lo, (size_t)n_chunks * 4));
+    NC_TRY(nc_ensure(ctx, ctx->chunk_cnt, (size_t)n_chunks * 4));
+    NC_TRY(nc_ensure(ctx, ctx->chunk_off, ((size_t)n_chunks + 1) * 4));
+    NC_HIP(ctx, hipMemcpyAsync(ctx->chunk_start.p, chunk_start_host, (size_t)n_chunks * 4, hipMemcpyHostToDevice, ctx->stream));
+    NC_HIP(ctx, hipMemcpyAsync(ctx->chunk_end.p, chunk_end_host, (size_t)n_chunks * 4, hipMemcpyHostToDevice, ctx->stream));
+
+    ScanP sp;
+    sp.mincov = params->mincov;
+    sp.haploid = params->haploid;
+    sp.min_af = params->min_allele_freq;
+    sp.t0 = params->nbr_t0;
+    sp.t1 = params->nbr_t1;
+    sp.scan_lo = scan_lo;
+    sp.scan_hi = scan_hi;
+
+    NcTimer tm(ctx, 0);
+    auto *sn = (int32_t *)ctx->stage_nbr.p;
+    auto *sc = (int32_t *)ctx->stage_cpos.p;
+    auto *scn = (int32_t *)ctx->stage_cn.p;
+    auto *sca = (int32_t *)ctx->stage_calt.p;
+    auto *tc = (int2 *)ctx->tile_cnt.p;
+    if (tile == 1024)
+        hipLaunchKernelGGL(k_scan<64>, dim3(pack->n_tiles), dim3(64), 0, ctx->stream, pack->codes, pack->tile_off,
+                           pack->tile_ent, pack->tile_pos0, ref_code_dev, sp, sn, sc, scn, sca, tc);
+    else if (tile == 2048)
+        hipLaunchKernelGGL(k_scan<128>, dim3(pack->n_tiles), dim3(128), 0, ctx->stream, pack->codes, pack->tile_off,
+                           pack->tile_ent, pack->tile_pos0, ref_code_dev, sp, sn, sc, scn, sca, tc);
+    else
+        hipLaunchKernelGGL(k_scan<256>, dim3(pack->n_tiles), dim3(256), 0, ctx->stream, pack->codes, pack->tile_off,
+                           pack->tile_ent, pack->tile_pos0, ref_code_dev, sp, sn, sc, scn, sca, tc);
+    NC_HIP(ctx, hipGetLastError());
+    tm.stop();
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, ctx->stream, tc, (int2 *)ctx->tile_pre.p, pack->n_tiles,
+                       (int32_t *)ctx->totals.p);
+    NC_HIP(ctx, hipGetLastError());
+    int32_t tot[4] = {0, 0, 0, 0};
+    NC_HIP(ctx, hipMemcpyAsync(tot, ctx->totals.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_nbr = tot[0];
+    ctx->n_cand = tot[1];
+    NC_TRY(nc_ensure(ctx, ctx->nbr_pos, (size_t)(tot[0] + 1) * 4));
+    NC_TRY(nc_ensure(ctx, ctx->cand_pos, (size_t)(tot[1] + 1) * 4));
+    NC_TRY(nc_ensure(ctx, ctx->cand_n, (size_t)(tot[1] + 1) * 4));
+    NC_TRY(nc_ensure(ctx, ctx->cand_alt, (size_t)(tot[1] + 1) * 4));
+    hipLaunchKernelGGL(k_compact, dim3(pack->n_tiles), dim3(256), 0, ctx->stream, tile, tc, (const int2 *)ctx->tile_pre.p, sn,
+                       sc, scn, sca, (int32_t *)ctx->nbr_pos.p, (int32_t *)ctx->cand_pos.p, (int32_t *)ctx->cand_n.p,
+                       (int32_t *)ctx->cand_alt.p);
+    NC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_chunk_ranges, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, (const int32_t *)ctx->cand_pos.p,
+                       (const int32_t *)ctx->totals.p, n_chunks, (const int32_t *)ctx->chunk_start.p,
+                       (const int32_t *)ctx->chunk_end.p, (int32_t *)ctx->chunk_lo.p, (int32_t *)ctx->chunk_cnt.p);
+    NC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->chunk_cnt.p,
+                       (int32_t *)ctx->chunk_off.p, n_chunks, (int32_t *)ctx->totals.p);
+    NC_HIP(ctx, hipGetLastError());
+    NC_HIP(ctx, hipMemcpyAsync(tot, ctx->totals.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_sites = tot[2];
+    ctx->n_chunks = n_chunks;
+    const size_t ns = (size_t)tot[2] + 1;
+    NC_TRY(nc_ensure(ctx, ctx->site_pos, ns * 4));
+    NC_TRY(nc_ensure(ctx, ctx->site_chunk, ns * 4));
+    NC_TRY(nc_ensure(ctx, ctx->site_n, ns * 4));
+    NC_TRY(nc_ensure(ctx, ctx->site_alt, ns * 4));
+    if (tot[2] > 0) {
+        hipLaunchKernelGGL(k_sites, dim3((tot[2] + 255) / 256), dim3(256), 0, ctx->stream, tot[2], n_chunks,
+                           (const int32_t *)ctx->chunk_off.p, (const int32_t *)ctx->chunk_lo.p,
+                           (const int32_t *)ctx->cand_pos.p, (const int32_t *)ctx->cand_n.p, (const int32_t *)ctx->cand_alt.p,
+                           (int32_t *)ctx->site_pos.p, (int32_t *)ctx->site_chunk.p, (int32_t *)ctx->site_n.p,
+                           (int32_t *)ctx->site_alt.p);
+        NC_HIP(ctx, hipGetLastError());
+    }
+    ctx->have_scan = true;
+    if (n_nbr) *n_nbr = tot[0];
+    if (n_cand) *n_cand = tot[1];
+    if (n_sites) *n_sites = tot[2];
+    return NC_OK;
+}
+
+int nc_snp_scan_fetch(nc_ctx *ctx, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk, int32_t *site_n,
+                      int32_t *site_alt)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!ctx->have_scan) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan_fetch: no scan on this context");
+    const size_t nb = (size_t)ctx->n_nbr * 4, ns = (size_t)ctx->n_sites * 4;
+    if (nbr_pos && nb) NC_HIP(ctx, hipMemcpyAsync(nbr_pos, ctx->nbr_pos.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (site_pos && ns) NC_HIP(ctx, hipMemcpyAsync(site_pos, ctx->site_pos.p, ns, hipMemcpyDeviceToHost, ctx->stream));
+    if (site_chunk && ns) NC_HIP(ctx, hipMemcpyAsync(site_chunk, ctx->site_chunk.p, ns, hipMemcpyDeviceToHost, ctx->stream));
+    if (site_n && ns) NC_HIP(ctx, hipMemcpyAsync(site_n, ctx->site_n.p, ns, hipMemcpyDeviceToHost, ctx->stream));
+    if (site_alt && ns) NC_HIP(ctx, hipMemcpyAsync(site_alt, ctx->site_alt.p, ns, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+}   // extern "C"

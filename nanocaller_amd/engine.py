@@ -1,0 +1,235 @@
+"""Device engine: drives libnanocaller_hip.so from Python.
+
+PyTorch is used only as plumbing -- device memory (tensors), the current HIP stream and, for multi-GPU
+runs, torch.distributed rendezvous.  All arithmetic of the hot path runs in the library's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .pack import HostPack
+from .weights import Weights
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@dataclass
+class DevicePack:
+    codes: torch.Tensor
+    tile_off: torch.Tensor
+    tile_ent: torch.Tensor      # uint8 view of the 16-byte entries
+    ref_code: torch.Tensor
+    tile_size: int
+    tile_pos0: int
+    n_tiles: int
+    n_entries: int
+    pos_lo: int
+    pos_hi: int
+
+    def c_struct(self) -> _lib.ReadPackC:
+        return _lib.ReadPackC(codes_len=self.codes.numel(), codes=self.codes.data_ptr(), tile_size=self.tile_size,
+                              tile_pos0=self.tile_pos0, n_tiles=self.n_tiles, tile_off=self.tile_off.data_ptr(),
+                              tile_ent=self.tile_ent.data_ptr(), n_entries=self.n_entries)
+
+    @property
+    def nbytes(self):
+        return self.codes.numel() + self.tile_off.numel() * 4 + self.tile_ent.numel() + self.ref_code.numel()
+
+
+@dataclass
+class SnpSites:
+    """Results of scan + featurize for a batch of chunks (device tensors unless noted)."""
+    n_sites: int
+    n_nbr: int
+    pos: np.ndarray            # host int32 [N]
+    chunk: np.ndarray          # host int32 [N]
+    dp: np.ndarray             # host int32 [N]   pileup entries incl. deletions
+    alt: np.ndarray            # host int32 [N]   max non-reference base count
+    x: torch.Tensor | None = None          # f32 [N,5,41,5]
+    ref_code: torch.Tensor | None = None   # i32 [N]
+    fwd_dp: torch.Tensor | None = None     # i32 [N,4]
+    rev_dp: torch.Tensor | None = None
+    depth: torch.Tensor | None = None      # i32 [N]
+    valid: torch.Tensor | None = None      # u8 [N]
+
+
+class Engine:
+    """One engine per GPU (one process per GPU in multi-GPU runs).  Not thread-safe."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.NanoCallerHipError("no ROCm device visible: the NanoCaller HIP path has no CPU fallback")
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        ctx = C.c_void_p()
+        rc = self.L.nc_ctx_create(device, C.byref(ctx))
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_ctx_create(device=%d) failed with status %d" % (device, rc))
+        self.ctx = ctx
+        self._loaded = {}
+        self.use_torch_stream()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.nc_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != _lib.NC_OK:
+            msg = self.L.nc_last_error(self.ctx)
+            raise _lib.NanoCallerHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def use_torch_stream(self):
+        s = torch.cuda.current_stream(self.device)
+        self._check(self.L.nc_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)), "nc_ctx_set_stream")
+
+    def enable_timing(self, on=True):
+        self._check(self.L.nc_enable_timing(self.ctx, 1 if on else 0), "nc_enable_timing")
+
+    def last_ms(self, which):
+        ms = C.c_float()
+        self._check(self.L.nc_last_kernel_ms(self.ctx, which, C.byref(ms)), "nc_last_kernel_ms")
+        return float(ms.value)
+
+    # ------------------------------------------------------------------ data movement
+    def upload(self, hp: HostPack) -> DevicePack:
+        dev = self.device
+        ent_bytes = np.frombuffer(hp.tile_ent.tobytes(), np.uint8) if hp.tile_ent.size else np.zeros(16, np.uint8)
+        return DevicePack(codes=torch.from_numpy(hp.codes).to(dev), tile_off=torch.from_numpy(hp.tile_off).to(dev),
+                          tile_ent=torch.from_numpy(ent_bytes.copy()).to(dev), ref_code=torch.from_numpy(hp.ref_code).to(dev),
+                          tile_size=hp.tile_size, tile_pos0=hp.tile_pos0, n_tiles=hp.n_tiles,
+                          n_entries=int(hp.tile_ent.shape[0]), pos_lo=hp.pos_lo, pos_hi=hp.pos_hi)
+
+    def load_weights(self, kind: int, w: Weights):
+        if self._loaded.get(kind) == w.path:
+            return
+        if w.kind != kind:
+            raise ValueError("weights %s are of kind %d, expected %d" % (w.path, w.kind, kind))
+        flat = np.ascontiguousarray(w.flat, np.float32)
+        self._check(self.L.nc_load_weights(self.ctx, kind, _lib.npp(flat), flat.size), "nc_load_weights")
+        self._loaded[kind] = w.path
+
+    # ------------------------------------------------------------------ K1
+    def snp_scan(self, dp: DevicePack, chunks, *, mincov, min_allele_freq, threshold, haploid=False) -> SnpSites:
+        """chunks: list of (start, end) inclusive, same contig, ascending."""
+        cs = np.ascontiguousarray([c[0] for c in chunks], np.int32)
+        ce = np.ascontiguousarray([c[1] for c in chunks], np.int32)
+        scan_lo = max(1, int(cs.min()) - _lib.FLANK)
+        scan_hi = int(ce.max()) + _lib.FLANK
+        if scan_lo < dp.pos_lo or min(scan_hi, dp.pos_hi) < scan_lo:
+            pass  # the pack simply has no data there
+        params = _lib.ScanParamsC(mincov=int(mincov), min_allele_freq=float(min_allele_freq), nbr_t0=float(threshold[0]),
+                                  nbr_t1=float(threshold[1]), haploid=1 if haploid else 0)
+        pc = dp.c_struct()
+        n_nbr, n_cand, n_sites = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.L.nc_snp_scan(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(), scan_lo,
+                                       scan_hi, C.byref(params), len(chunks), _lib.npp(cs), _lib.npp(ce), C.byref(n_nbr),
+                                       C.byref(n_cand), C.byref(n_sites)), "nc_snp_scan")
+        N = n_sites.value
+        pos = np.empty(N, np.int32)
+        chunk = np.empty(N, np.int32)
+        n = np.empty(N, np.int32)
+        alt = np.empty(N, np.int32)
+        self._check(self.L.nc_snp_scan_fetch(self.ctx, None, _lib.npp(pos), _lib.npp(chunk), _lib.npp(n), _lib.npp(alt)),
+                    "nc_snp_scan_fetch")
+        return SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=pos, chunk=chunk, dp=n, alt=alt)
+
+    def fetch_nbr_sites(self, n_nbr) -> np.ndarray:
+        out = np.empty(n_nbr, np.int32)
+        self._check(self.L.nc_snp_scan_fetch(self.ctx, _lib.npp(out), None, None, None, None), "nc_snp_scan_fetch")
+        return out
+
+    # ------------------------------------------------------------------ K2-K4
+    def snp_featurize(self, dp: DevicePack, sites: SnpSites, *, seq, maxcov, min_nbr_sites=1) -> SnpSites:
+        N = sites.n_sites
+        dev = self.device
+        sites.x = torch.empty((N, 5, 41, 5), dtype=torch.float32, device=dev)
+        sites.ref_code = torch.empty(N, dtype=torch.int32, device=dev)
+        sites.fwd_dp = torch.empty((N, 4), dtype=torch.int32, device=dev)
+        sites.rev_dp = torch.empty((N, 4), dtype=torch.int32, device=dev)
+        sites.depth = torch.empty(N, dtype=torch.int32, device=dev)
+        sites.valid = torch.empty(N, dtype=torch.uint8, device=dev)
+        pc = dp.c_struct()
+        self._check(self.L.nc_snp_featurize(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(),
+                                            _lib.SEQ_MODES[seq], int(maxcov), int(min_nbr_sites), _ptr(sites.x),
+                                            _ptr(sites.ref_code), _ptr(sites.fwd_dp), _ptr(sites.rev_dp), _ptr(sites.depth),
+                                            _ptr(sites.valid)), "nc_snp_featurize")
+        return sites
+
+    def snp_scale(self, sites: SnpSites, n_chunks, train_coverage, per_site=False):
+        """-> (scale f64 [N] device tensor, chunk_depth float64 host [n_chunks])"""
+        scale = torch.empty(sites.n_sites, dtype=torch.float64, device=self.device)
+        cd = np.zeros(n_chunks, np.float64)
+        self._check(self.L.nc_snp_scale(self.ctx, _ptr(sites.depth), _ptr(sites.valid), float(train_coverage),
+                                        1 if per_site else 0, _ptr(scale), _lib.npp(cd)), "nc_snp_scale")
+        return scale, cd
+
+    # ------------------------------------------------------------------ K5 / K9
+    def snp_forward(self, kind, x, ref_code, scale, scale_mode=0, want_gt=True):
+        n = int(x.shape[0])
+        probs = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        gt = torch.empty((n, 2), dtype=torch.float32, device=self.device) if (want_gt and kind == _lib.MODEL_SNP) else None
+        self._check(self.L.nc_snp_forward(self.ctx, kind, n, _ptr(x), _ptr(ref_code), _ptr(scale), int(scale_mode),
+                                          _ptr(probs), _ptr(gt)), "nc_snp_forward")
+        return probs, gt
+
+    def indel_forward(self, kind, x):
+        n = int(x.shape[0])
+        nout = 4 if kind == _lib.MODEL_INDEL else 1
+        probs = torch.empty((n, nout), dtype=torch.float32, device=self.device)
+        self._check(self.L.nc_indel_forward(self.ctx, kind, n, _ptr(x), _ptr(probs)), "nc_indel_forward")
+        return probs
+
+    def indel_tensor(self, rows_list, ref_rows_list):
+        """rows_list[s]: uint8 [n_rows, n_cols] aligned symbols 0..4; ref_rows_list[s]: uint8 [n_cols].
+        -> (x f32 [S,5,128,2] device, cns list of uint8 arrays with gaps removed)"""
+        S = len(rows_list)
+        dev = self.device
+        n_rows = np.array([r.shape[0] for r in rows_list], np.int32)
+        n_cols = np.array([r.shape[1] for r in rows_list], np.int32)
+        row_off = np.zeros(S, np.int64)
+        ref_off = np.zeros(S, np.int64)
+        if S:
+            np.cumsum((n_rows.astype(np.int64) * n_cols)[:-1], out=row_off[1:])
+            np.cumsum(n_cols.astype(np.int64)[:-1], out=ref_off[1:])
+        max_cols = max(128, int(n_cols.max()) if S else 128)
+        rows = np.concatenate([np.ascontiguousarray(r, np.uint8).ravel() for r in rows_list]) if S else np.zeros(1, np.uint8)
+        refs = np.concatenate([np.ascontiguousarray(r, np.uint8).ravel() for r in ref_rows_list]) if S else np.zeros(1, np.uint8)
+        t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+        d_rows, d_refs, d_ro, d_fo, d_nr, d_nc = t(rows), t(refs), t(row_off), t(ref_off), t(n_rows), t(n_cols)
+        x = torch.empty((S, 5, 128, 2), dtype=torch.float32, device=dev)
+        cns = torch.empty((S, max_cols), dtype=torch.uint8, device=dev)
+        self._check(self.L.nc_indel_tensor(self.ctx, S, _ptr(d_rows), _ptr(d_ro), _ptr(d_nr), _ptr(d_nc), _ptr(d_refs),
+                                           _ptr(d_fo), max_cols, _ptr(x), _ptr(cns)), "nc_indel_tensor")
+        cns_h = cns.cpu().numpy()
+        out = []
+        for s in range(S):
+            row = cns_h[s, :n_cols[s]]
+            out.append(row[row != 4])
+        return x, out
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+_engines = {}
+
+
+def get_engine(device: int = 0) -> Engine:
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]

@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference's SNP featuriser interface.
+
+`get_snp_testing_candidates(dct, region)` keeps the call signature, dict keys and the 8-tuple of
+/root/reference nanocaller_src/generate_SNP_pileups.py:103-279; the column scan, neighbour selection and
+tensor build run in the HIP kernels of libnanocaller_hip.so (nc_snp_scan / nc_snp_featurize).
+
+Boundary note: BAM decoding is a "next" row, so `dct['sam_path']` names DECODED
+alignments -- a `synth.World`, or a key registered with `register_alignments` -- instead of a BAM file, and
+`dct['exclude_bed']` may be a list of (chrom, start, end) rows instead of a tabix path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .engine import get_engine
+from .pack import pack_world
+from .synth import World
+
+_SOURCES = {}
+_PACKS = {}
+
+
+def register_alignments(key, world: World):
+    """Make `dct['sam_path'] == key` resolve to decoded alignments."""
+    _SOURCES[key] = world
+    for k in [k for k in _PACKS if k[0] == key]:
+        del _PACKS[k]
+
+
+def _resolve(sam_path) -> World:
+    if isinstance(sam_path, World):
+        return sam_path
+    if sam_path in _SOURCES:
+        return _SOURCES[sam_path]
+    raise NotImplementedError(
+        "BAM decoding is not part of this build yet (SURVEY.md 8f n1): pass decoded alignments "
+        "(nanocaller_amd.synth.World) or register them with register_alignments(%r, world)" % (sam_path,))
+
+
+def _exclude_rows(dct, chrom):
+    ex = dct.get("exclude_bed")
+    if not ex:
+        return None
+    if isinstance(ex, (list, tuple)):
+        return tuple((int(a), int(b)) for (c, a, b) in ex if c == chrom)
+    raise NotImplementedError("exclude_bed as a tabix file needs the BGZF reader (next row); pass a list of rows")
+
+
+def device_pack_for(dct, chrom, device=0):
+    """Packed + uploaded alignments of a contig (cached per source / filter / exclusion list)."""
+    world = _resolve(dct["sam_path"])
+    excl = _exclude_rows(dct, chrom)
+    key = (dct["sam_path"] if not isinstance(dct["sam_path"], World) else id(world), bool(dct.get("supplementary")),
+           excl, device)
+    if key not in _PACKS:
+        eng = get_engine(device)
+        hp = pack_world(world, supplementary=bool(dct.get("supplementary")), exclude=excl)
+        _PACKS[key] = (eng.upload(hp), world)
+    return _PACKS[key][0]
+
+
+def get_snp_testing_candidates(dct, region, device=0):
+    """-> (pos, ref_onehot, mat, dp, freq, depth, fwd_dp, rev_dp); empty lists / depth 0 when there is no
+    candidate (generate_SNP_pileups.py:193-197, 279)."""
+    chrom, start, end, ploidy = region["chrom"], region["start"], region["end"], region["ploidy"]
+    eng = get_engine(device)
+    eng.use_torch_stream()
+    dp_ = device_pack_for(dct, chrom, device)
+    sites = eng.snp_scan(dp_, [(start, end)], mincov=dct["mincov"], min_allele_freq=dct["min_allele_freq"],
+                         threshold=dct["threshold"], haploid=(ploidy == "haploid"))
+    empty = ([], [], [], [], [], 0, [], [])
+    if sites.n_sites == 0:
+        return empty
+    eng.snp_featurize(dp_, sites, seq=dct["seq"], maxcov=dct["maxcov"], min_nbr_sites=dct["min_nbr_sites"])
+    valid = sites.valid.cpu().numpy().astype(bool)
+    if not valid.any():
+        return empty
+    mat = sites.x.cpu().numpy()[valid]
+    ref = sites.ref_code.cpu().numpy()[valid]
+    depth_each = sites.depth.cpu().numpy()[valid]
+    n = sites.dp[valid].astype(np.int64)
+    alt = sites.alt[valid].astype(np.int64)
+    output_ref = np.eye(4, dtype=np.int32)[ref]                                   # :269-270
+    return (sites.pos[valid].astype(np.int64), output_ref, mat, n, alt.astype(np.float64) / n.astype(np.float64),
+            np.mean(depth_each.astype(np.float64)), sites.fwd_dp.cpu().numpy()[valid].astype(np.float64),
+            sites.rev_dp.cpu().numpy()[valid].astype(np.float64))
+
+
+__all__ = ["get_snp_testing_candidates", "register_alignments", "device_pack_for", "_lib"]

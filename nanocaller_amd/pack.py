@@ -1,0 +1,90 @@
+"""Host side of the packed-alignment layout (see include/nanocaller_hip.h, "read pack").
+
+`pack_reads` turns decoded alignments (read-major codes, the boundary that replaces the pysam objects of
+generate_SNP_pileups.py:134-164) into the position-aligned slots + tile index the kernels read.  The heavy
+lifting is the library's native packer (nc_pack_plan / nc_pack_fill); this module only applies the pileup
+flag filter and builds the padded reference-code array.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL, World, world_ref_codes
+
+
+@dataclass
+class HostPack:
+    codes: np.ndarray        # uint8 [codes_len]
+    tile_size: int
+    tile_pos0: int
+    n_tiles: int
+    tile_off: np.ndarray     # int32 [n_tiles+1]
+    tile_ent: np.ndarray     # TILE_ENTRY_DTYPE [n_entries]
+    ref_code: np.ndarray     # uint8 [n_tiles*tile_size]; index 0 <-> tile_pos0; 4 = skip column
+    pos_lo: int
+    pos_hi: int
+
+    @property
+    def nbytes(self):
+        return self.codes.nbytes + self.tile_off.nbytes + self.tile_ent.nbytes + self.ref_code.nbytes
+
+
+def _check(rc, what):
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("%s failed with status %d" % (what, rc))
+
+
+def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, supplementary=False,
+               tile_size=2048, pos_lo=None, pos_hi=None, exclude=None) -> HostPack:
+    """read_* as in synth.World (coordinate order); ref_codes uint8 [L] (index p-1, 4 = skip).
+    `exclude`: iterable of (start, end) half-open intervals whose columns are skipped, the IntervalTree
+    test `tree.overlaps(pos)` of generate_SNP_pileups.py:116-119,161."""
+    L = _lib.lib()
+    rs = np.ascontiguousarray(read_start, np.int32)
+    re_ = np.ascontiguousarray(read_end, np.int32)
+    ro = np.ascontiguousarray(read_off, np.int64)
+    cd = np.ascontiguousarray(codes, np.uint8)
+    flag = np.asarray(read_flag)
+    filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT      # :151-154
+    keep = np.ascontiguousarray((flag & filt) == 0, np.uint8)
+    strand = np.ascontiguousarray(((flag & 0x910) // 16) != 0, np.uint8)     # :143
+    n = int(rs.shape[0])
+    Lref = int(ref_codes.shape[0])
+    pos_lo = 1 if pos_lo is None else max(1, int(pos_lo))
+    pos_hi = Lref if pos_hi is None else min(Lref, int(pos_hi))
+    if pos_hi < pos_lo:
+        pos_hi = pos_lo
+    codes_len, n_ent = C.c_int64(), C.c_int64()
+    tile_pos0, n_tiles = C.c_int32(), C.c_int32()
+    _check(L.nc_pack_plan(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(keep), tile_size, pos_lo, pos_hi,
+                          C.byref(codes_len), C.byref(tile_pos0), C.byref(n_tiles), C.byref(n_ent)), "nc_pack_plan")
+    out_codes = np.empty(codes_len.value, np.uint8)
+    tile_off = np.empty(n_tiles.value + 1, np.int32)
+    tile_ent = np.empty(max(1, n_ent.value), _lib.TILE_ENTRY_DTYPE)
+    _check(L.nc_pack_fill(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(strand), _lib.npp(keep),
+                          tile_size, tile_pos0.value, n_tiles.value, _lib.npp(out_codes), codes_len.value,
+                          _lib.npp(tile_off), _lib.npp(tile_ent), n_ent.value), "nc_pack_fill")
+    # reference codes on the tile grid
+    npos = n_tiles.value * tile_size
+    rc = np.full(npos, 4, np.uint8)
+    a = max(1, tile_pos0.value)
+    b = min(Lref, tile_pos0.value + npos - 1)
+    if b >= a:
+        rc[a - tile_pos0.value:b - tile_pos0.value + 1] = ref_codes[a - 1:b]
+    if exclude:
+        for (x0, x1) in exclude:
+            lo = max(int(x0), tile_pos0.value) - tile_pos0.value
+            hi = min(int(x1), tile_pos0.value + npos) - tile_pos0.value
+            if hi > lo:
+                rc[lo:hi] = 4
+    return HostPack(codes=out_codes, tile_size=tile_size, tile_pos0=tile_pos0.value, n_tiles=n_tiles.value,
+                    tile_off=tile_off, tile_ent=tile_ent[:n_ent.value], ref_code=rc, pos_lo=pos_lo, pos_hi=pos_hi)
+
+
+def pack_world(world: World, **kw) -> HostPack:
+    return pack_reads(world.read_start, world.read_end, world.read_off, world.codes, world.read_flag,
+                      world_ref_codes(world), **kw)

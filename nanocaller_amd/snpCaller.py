@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference's SNP caller (nanocaller_src/snpCaller.py).
+
+Same entry points, `params` keys, model names, VCF text and output file names; the featurisation and
+the CNN run on the MI355X through libnanocaller_hip.so.  Differences by design:
+
+* one process per GPU instead of `cpu` worker processes; a worker takes ALL chunks of a contig as one
+  device batch (the contig's alignments stay resident in HBM, scanned once);
+* genotype rules (snpCaller.py:113-198) stay on the host: `snp_vcf_lines` / `snp_vcf_lines_haploid`;
+* bcftools/bgzip are optional: records are written position-sorted and BGZF-compressed natively.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import queue
+import shutil
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+from . import _lib
+from .engine import get_engine
+from .generate_SNP_pileups import device_pack_for
+from .weights import Weights, get_SNP_model  # noqa: F401  (re-exported, same name as the reference)
+
+num_to_base_map = {0: 'A', 1: 'G', 2: 'T', 3: 'C'}                 # snpCaller.py:14
+_B = "AGTC"
+
+
+def _qual(p, cap=99.0, mult=-10.0):
+    """min(cap, mult*log10(1e-10 + 1 - p)) evaluated in float64 (numpy<2 scalar semantics)."""
+    return min(cap, mult * np.log10(1e-10 + 1 - float(p)))
+
+
+def snp_vcf_lines(chrom, pos, ref_idx, probs, dp, freq, fwd_dp, rev_dp):
+    """Diploid genotype rules + VCF text (snpCaller.py:113-163).
+    probs float32 [N,4] = class-1 probability of the A,G,T,C heads."""
+    probs = np.asarray(probs, np.float32)
+    order = np.argsort(probs, axis=1)                               # :118 (same call => same tie behaviour)
+    k = np.sum(probs >= 0.5, axis=1)                                # :122
+    out = []
+    for j in range(len(pos)):
+        pr = probs[j]
+        info = 'PR=' + ','.join("{:.4f}".format(x) for x in pr[[0, 3, 1, 2]]) + ";FQ={:.4f}".format(freq[j])   # :127
+        r = int(ref_idx[j])
+        d = int(dp[j])
+        ref_dp = (fwd_dp[j][r], rev_dp[j][r])
+        p1, p2 = int(order[j, -1]), int(order[j, -2])
+        head = '%s\t%d\t.\t%s\t' % (chrom, pos[j], _B[r])
+        fmt = 'GT:DP:VF:AD:ADF:ADR'
+        if k[j] >= 2:
+            if p1 == r:                                             # :132
+                a = (fwd_dp[j][p2], rev_dp[j][p2])
+                out.append(head + '%s\t%.3f\t%s\t%s\t%s\t%s:%d:%.4f:%d,%d:%d,%d:%d,%d\n' % (
+                    _B[p2], _qual(pr[p2]), 'PASS', info, fmt, '0/1', d, sum(a) / d, sum(ref_dp), sum(a), ref_dp[0], a[0],
+                    ref_dp[1], a[1]))
+            elif p2 == r and pr[p2] >= 0.5:                         # :138
+                a = (fwd_dp[j][p1], rev_dp[j][p1])
+                out.append(head + '%s\t%.3f\t%s\t%s\t%s\t%s:%d:%.4f:%d,%d:%d,%d:%d,%d\n' % (
+                    _B[p1], _qual(pr[p2]), 'PASS', info, fmt, '0/1', d, sum(a) / d, sum(ref_dp), sum(a), ref_dp[0], a[0],
+                    ref_dp[1], a[1]))
+            elif p2 != r and p1 != r and pr[p2] >= 0.5:             # :143
+                a1 = (fwd_dp[j][p1], rev_dp[j][p1])
+                a2 = (fwd_dp[j][p2], rev_dp[j][p2])
+                out.append(head + '%s,%s\t%.3f\t%s\t%s\t%s\t%s:%d:%.4f,%.4f:%d,%d,%d:%d,%d,%d:%d,%d,%d\n' % (
+                    _B[p1], _B[p2], _qual(pr[p2]), 'PASS', info, fmt, '1/2', d, sum(a1) / d, sum(a2) / d, sum(ref_dp),
+                    sum(a1), sum(a2), ref_dp[0], a1[0], a2[0], ref_dp[1], a1[1], a2[1]))
+            # else: the reference writes nothing (k>=2 but the second allele is below 0.5 cannot happen)
+        elif k[j] == 1 and r != p1 and pr[p1] >= 0.5:               # :150
+            a = (fwd_dp[j][p1], rev_dp[j][p1])
+            out.append(head + '%s\t%.3f\t%s\t%s\t%s\t%s:%d:%.4f:%d,%d:%d,%d:%d,%d\n' % (
+                _B[p1], _qual(pr[p1]), 'PASS', info, fmt, '1/1', d, sum(a) / d, sum(ref_dp), sum(a), ref_dp[0], a[0],
+                ref_dp[1], a[1]))
+        elif k[j] == 1 and r == p1:                                 # :157
+            out.append(head + '%s\t%.3f\t%s\t%s\t%s\t%s:%d:.:.:.:.\n' % ('.', _qual(pr[p1]), 'REF', info, fmt, './.', d))
+        else:                                                       # :161
+            out.append(head + '%s\t%.3f\t%s\t%s\t%s\t%s:%d:.:.:.:.\n' % ('.', 0, 'LOW', info, fmt, './.', d))
+    return out
+
+
+def snp_vcf_lines_haploid(chrom, pos, ref_idx, probs, dp, freq):
+    """Haploid rules (snpCaller.py:184-198): arg-max of the 4-way softmax, PASS if it differs from ref."""
+    probs = np.asarray(probs, np.float32)
+    pred = np.argmax(probs, 1)
+    out = []
+    for j in range(len(pos)):
+        pr = probs[j]
+        p = int(pred[j])
+        r = int(ref_idx[j])
+        info = 'PR=' + ','.join("{:.4f}".format(x) for x in pr[[0, 3, 1, 2]]) + ";FQ={:.4f}".format(freq[j])
+        out.append('%s\t%d\t.\t%s\t%s\t%.3f\t%s\t%s\tGT:DP:VF:AD:ADF:ADR\t%s:%d:%.4f:.:.:.\n' % (
+            chrom, pos[j], _B[r], _B[p], _qual(pr[p], 999.0, -100.0), 'PASS' if p != r else 'REF', info, '1/1', int(dp[j]),
+            freq[j]))
+    return out
+
+
+VCF_HEADER = (                                                      # snpCaller.py:259-276
+    '##fileformat=VCFv4.2\n'
+    '##FILTER=<ID=PASS,Description="All filters passed">\n'
+    '##FILTER=<ID=LOW,Description="All alleles have probability less than 50%.">\n'
+    '##FILTER=<ID=REF,Description="Homozygous Reference. Only reference allele has greater than 50% probability. '
+    'All alternative alleles having probability less than 50%.">\n'
+    '{contigs}'
+    '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+    '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Depth">\n'
+    '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allelic depths for the ref and alt alleles in the order listed">\n'
+    '##FORMAT=<ID=ADF,Number=R,Type=Integer,Description="Allelic depths on forward strand for the ref and alt alleles in the order listed">\n'
+    '##FORMAT=<ID=ADR,Number=R,Type=Integer,Description="Allelic depths on reverse strand for the ref and alt alleles in the order listed">\n'
+    '##FORMAT=<ID=VF,Number=A,Type=Float,Description="Alternative allele frequency in the order listed">\n'
+    '##INFO=<ID=PR,Number=4,Type=Float,Description="Probability of presence of alleles A, C, G and T, in the given order. '
+    'Probability of each base is out of 1, independent of each other.">\n'
+    '##INFO=<ID=FQ,Number=1,Type=Float,Description="Maximum frequency of non-reference base.">\n'
+    '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample}\n')
+
+
+def call_chunks(params, chunks, device=0):
+    """Run pileup featurisation + CNN for a list of chunks of ONE contig and ploidy on the GPU.
+    -> dict of host arrays (pos, chunk, ref, probs, gt, dp, freq, fwd_dp, rev_dp, chunk_depth)."""
+    chrom = chunks[0]['chrom']
+    ploidy = chunks[0]['ploidy']
+    assert all(c['chrom'] == chrom and c['ploidy'] == ploidy for c in chunks)
+    eng = get_engine(device)
+    eng.use_torch_stream()
+    if ploidy == 'diploid':
+        path, train_cov = get_SNP_model(params['snp_model'])
+        if path is None:
+            print('Invalid SNP model name or path', flush=True)     # snpCaller.py:66-68
+            sys.exit(1)
+        kind = _lib.MODEL_SNP
+    else:
+        path, _ = get_SNP_model('haploid')
+        train_cov = 30                                              # hap_train_coverage, snpCaller.py:73
+        kind = _lib.MODEL_SNP_HAP
+    eng.load_weights(kind, Weights(path))
+    dpk = device_pack_for(params, chrom, device)
+    sites = eng.snp_scan(dpk, [(c['start'], c['end']) for c in chunks], mincov=params['mincov'],
+                         min_allele_freq=params['min_allele_freq'], threshold=params['threshold'],
+                         haploid=(ploidy == 'haploid'))
+    res = dict(chrom=chrom, ploidy=ploidy, n=0)
+    if sites.n_sites == 0:
+        return res
+    eng.snp_featurize(dpk, sites, seq=params['seq'], maxcov=params['maxcov'], min_nbr_sites=params['min_nbr_sites'])
+    per_site = bool(params.get('disable_coverage_normalization'))
+    scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site)
+    probs, gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0)
+    valid = sites.valid.cpu().numpy().astype(bool)
+    n = sites.dp.astype(np.int64)
+    res.update(n=int(valid.sum()), pos=sites.pos[valid].astype(np.int64), chunk=sites.chunk[valid],
+               ref=sites.ref_code.cpu().numpy()[valid], probs=probs.cpu().numpy()[valid],
+               gt=gt.cpu().numpy()[valid] if gt is not None else None, dp=n[valid],
+               freq=(sites.alt.astype(np.float64) / n.astype(np.float64))[valid],
+               fwd_dp=sites.fwd_dp.cpu().numpy()[valid].astype(np.float64),
+               rev_dp=sites.rev_dp.cpu().numpy()[valid].astype(np.float64), chunk_depth=chunk_depth)
+    return res
+
+
+def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
+    """Worker with the reference's signature (snpCaller.py:57): drains `chunks_Q`, writes
+    <intermediate_snp_files_dir>/<prefix>.<worker>.snps.vcf.  Chunks are grouped per (contig, ploidy)
+    and each group is one device batch."""
+    curr_vcf_path = os.path.join(params['intermediate_snp_files_dir'], '%s.%d.snps.vcf' % (params['prefix'], worker_id))
+    snp_files.append(curr_vcf_path)
+    chunks = []
+    while True:
+        try:
+            chunks.append(chunks_Q.get(block=False))
+        except queue.Empty:
+            break
+        except Exception:
+            if chunks_Q.empty():
+                break
+            raise
+    groups = {}
+    for c in chunks:
+        groups.setdefault((c['chrom'], c['ploidy']), []).append(c)
+    with open(curr_vcf_path, 'w') as f:
+        for (chrom, ploidy), grp in groups.items():
+            grp.sort(key=lambda c: c['start'])
+            r = call_chunks(params, grp, device)
+            if r['n']:
+                if ploidy == 'diploid':
+                    f.writelines(snp_vcf_lines(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq'], r['fwd_dp'], r['rev_dp']))
+                else:
+                    f.writelines(snp_vcf_lines_haploid(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq']))
+            f.flush()
+            os.fsync(f.fileno())
+            for _ in grp:
+                counter_Q.put(1)
+
+
+# ------------------------------------------------------------------ BGZF (so no bgzip binary is needed)
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def bgzf_write(path, data: bytes):
+    with open(path, 'wb') as f:
+        for i in range(0, len(data), 0xff00):
+            blk = data[i:i + 0xff00]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = co.compress(blk) + co.flush()
+            f.write(struct.pack('<BBBBIBBHBBHH', 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(comp) + 25))
+            f.write(comp)
+            f.write(struct.pack('<II', zlib.crc32(blk) & 0xffffffff, len(blk)))
+        f.write(_BGZF_EOF)
+
+
+def _sort_key(line, order):
+    f = line.split('\t', 2)
+    return (order.get(f[0], 1 << 30), int(f[1]))
+
+
+def call_manager(params, devices=(0,)):
+    """Same contract as snpCaller.call_manager (snpCaller.py:213-287): returns the PASS VCF path
+    <vcf_path>/<prefix>.snps.vcf.gz (also writes <prefix>.unfiltered.snps.vcf.gz)."""
+    chunks_Q = queue.Queue()
+    counter_Q = queue.Queue()
+    snp_files = []
+    for chunk in params['chunks_list']:
+        chunks_Q.put(chunk)
+    params['intermediate_snp_files_dir'] = os.path.join(params['vcf_path'], 'intermediate_snp_files')
+    if os.path.exists(params['intermediate_snp_files_dir']):
+        shutil.rmtree(params['intermediate_snp_files_dir'])
+    os.makedirs(params['intermediate_snp_files_dir'])
+    caller(params, chunks_Q, counter_Q, snp_files, device=devices[0])
+    all_path = os.path.join(params['vcf_path'], '%s.unfiltered.snps.vcf.gz' % params['prefix'])
+    pass_path = os.path.join(params['vcf_path'], '%s.snps.vcf.gz' % params['prefix'])
+    if not params.get('suppress_progress'):
+        print('\n%s: Combining SNP calls.' % str(datetime.datetime.now()))
+    contigs = []
+    for x in params['regions_list']:
+        if x[0] not in contigs:
+            contigs.append(x[0])
+    header = VCF_HEADER.format(contigs=''.join('##contig=<ID=%s>\n' % c for c in contigs), sample=params['sample'])
+    lines = []
+    for fn in snp_files:
+        with open(fn) as fd:
+            lines.extend(fd.readlines())
+    order = {c: i for i, c in enumerate(contigs)}
+    lines.sort(key=lambda ln: _sort_key(ln, order))                 # bcftools sort (:284); stable, keeps E3 duplicates
+    bgzf_write(all_path, (header + ''.join(lines)).encode())
+    passed = [ln for ln in lines if ln.split('\t', 7)[6] == 'PASS']  # bcftools view -f PASS (:285)
+    bgzf_write(pass_path, (header + ''.join(passed)).encode())
+    return pass_path

@@ -1,0 +1,216 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the reference goldens and the CPU oracle.
+Run on a real MI355X: python -m pytest tests -m gpu"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, SNP_CASES, assert_tuple_matches_gold, load_snp_case, load_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from nanocaller_amd.engine import get_engine
+    return get_engine(0)
+
+
+def _dct(world, dct, exclude):
+    d = dict(dct)
+    d["sam_path"] = world
+    d["fasta_path"] = None
+    d["exclude_bed"] = exclude if exclude else None
+    return d
+
+
+@pytest.mark.parametrize("case", SNP_CASES)
+def test_featuriser_matches_reference_golden(eng, case):
+    """bit-exact: positions, reference one-hot, integer tensors, dp, float64 freq, depth, strand depths"""
+    from nanocaller_amd.generate_SNP_pileups import get_snp_testing_candidates
+    world, dct, region, exclude, gold = load_snp_case(case)
+    out = get_snp_testing_candidates(_dct(world, dct, exclude), region)
+    assert_tuple_matches_gold(out, gold)
+
+
+@pytest.mark.parametrize("tile_size", [1024, 2048, 4096])
+def test_scan_matches_oracle_all_tile_sizes(eng, tile_size):
+    from nanocaller_amd.pack import pack_world
+    from oracle import oracle
+    world = load_world("ont")
+    hp = pack_world(world, tile_size=tile_size)
+    dpk = eng.upload(hp)
+    rc = oracle.ref_codes_with_exclusions(world)
+    start, end = 40_000, 95_000
+    sites = eng.snp_scan(dpk, [(start, end)], mincov=4, min_allele_freq=0.15, threshold=[0.4, 0.6])
+    nbr, cpos, cn, calt = oracle.snp_scan(world, rc, start, end, "diploid", 4, 0.15, [0.4, 0.6])
+    assert np.array_equal(eng.fetch_nbr_sites(sites.n_nbr), nbr)
+    assert np.array_equal(sites.pos, cpos) and np.array_equal(sites.dp, cn) and np.array_equal(sites.alt, calt)
+
+
+def test_multi_chunk_batch_matches_per_chunk_oracle(eng):
+    """A batch of adjacent chunks in one launch == the oracle run chunk by chunk, including the duplicated
+    boundary position (quirk E3) and the per-chunk coverage constant (quirk E2)."""
+    from nanocaller_amd.pack import pack_world
+    from nanocaller_amd.utils import get_chunks
+    from oracle import oracle
+    world = load_world("ont")
+    dpk = eng.upload(pack_world(world))
+    chunks = get_chunks([(world.chrom, 5_000, 125_000, "diploid")], cpu=7, max_chunk_size=20_000)
+    assert len(chunks) >= 6
+    # put two chunk boundaries exactly on known candidate positions (adjacent chunks share one coordinate, E3)
+    gold_pos = load_snp_case("ont_dip")[4]["pos"]
+    b1, b2 = int(gold_pos[len(gold_pos) // 3]), int(gold_pos[2 * len(gold_pos) // 3])
+    chunks = [dict(chrom=world.chrom, start=a, end=b, ploidy="diploid")
+              for a, b in ((5_000, 30_000), (30_000, b1), (b1, b2), (b2, 100_000), (100_000, 125_000))]
+    sites = eng.snp_scan(dpk, [(c["start"], c["end"]) for c in chunks], mincov=4, min_allele_freq=0.15,
+                         threshold=[0.4, 0.6])
+    eng.snp_featurize(dpk, sites, seq="ont", maxcov=160)
+    scale, chunk_depth = eng.snp_scale(sites, len(chunks), 48.0)
+    x = sites.x.cpu().numpy()
+    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, seq="ont")
+    off = 0
+    ndup = 0
+    for ci, c in enumerate(chunks):
+        pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(world, dct, c)
+        n = len(pos)
+        sl = slice(off, off + n)
+        assert np.array_equal(sites.pos[sl], pos) and np.all(sites.chunk[sl] == ci)
+        assert np.array_equal(x[sl], mat)
+        assert np.array_equal(sites.dp[sl], dp)
+        assert chunk_depth[ci] == depth
+        assert np.array_equal(scale.cpu().numpy()[sl], np.full(n, 48.0 / depth))
+        if n and ci + 1 < len(chunks) and pos[-1] == chunks[ci + 1]["start"]:
+            ndup += 1
+        off += n
+    assert off == sites.n_sites
+    assert ndup >= 2, "test world should contain a candidate on a shared chunk boundary"
+
+
+def test_maxcov_policy_matches_oracle(eng):
+    """depth > maxcov: documented deterministic policy (first maxcov reads in coordinate order)"""
+    from nanocaller_amd.generate_SNP_pileups import get_snp_testing_candidates
+    from oracle import oracle
+    world = load_world("deep")
+    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=50, min_allele_freq=0.15, min_nbr_sites=1, seq="ont",
+               supplementary=False, exclude_bed=None)
+    region = dict(chrom=world.chrom, start=6_000, end=18_000, ploidy="diploid")
+    a = get_snp_testing_candidates(_dct(world, dct, None), region)
+    b = oracle.get_snp_testing_candidates(world, dct, region)
+    assert len(a[0]) > 50 and max(a[3]) > 50
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def _golden_inputs(case):
+    _, _, _, _, gold = load_snp_case(case)
+    ref_code = np.argmax(gold["ref"], 1).astype(np.int32)
+    return gold["mat"], ref_code, gold["depth"]
+
+
+@pytest.mark.parametrize("model,case", [("ONT-HG002", "ont_dip"), ("CCS-HG002", "hifi_pacbio_dip"), ("NanoCaller1", "deep_ont")])
+def test_snp_cnn_matches_oracle(eng, model, case):
+    """per-site softmax probabilities within 1e-4 of the CPU restatement (float64 accumulate); measured ~1e-6"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    path, cov = get_SNP_model(model)
+    w = Weights(path)
+    eng.load_weights(_lib.MODEL_SNP, w)
+    x, ref_code, depth = _golden_inputs(case)
+    scale = np.full(len(x), cov / depth)
+    for mode in (0, 1):
+        probs, gt = eng.snp_forward(_lib.MODEL_SNP, torch.from_numpy(x).cuda(), torch.from_numpy(ref_code).cuda(),
+                                    torch.from_numpy(scale).cuda(), scale_mode=mode)
+        ep, eg = oracle.snp_forward(w.flat, x, ref_code, scale, scale_mode=mode, precision="f64")
+        assert np.abs(probs.cpu().numpy() - ep).max() < 1e-4
+        assert np.abs(gt.cpu().numpy() - eg).max() < 1e-4
+        assert np.abs(probs.cpu().numpy() - ep).max() < 2e-5, "fp32 path should be far inside the 1e-4 contract"
+    # genotype-relevant decisions identical
+    assert np.array_equal(probs.cpu().numpy() >= 0.5, ep >= 0.5)
+
+
+def test_snp_hap_cnn_matches_oracle(eng):
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    path, _ = get_SNP_model("haploid")
+    w = Weights(path)
+    eng.load_weights(_lib.MODEL_SNP_HAP, w)
+    x, ref_code, depth = _golden_inputs("ont_hap")
+    scale = np.full(len(x), 30.0 / depth)
+    probs, _ = eng.snp_forward(_lib.MODEL_SNP_HAP, torch.from_numpy(x).cuda(), torch.from_numpy(ref_code).cuda(),
+                               torch.from_numpy(scale).cuda())
+    ep = oracle.snp_hap_forward(w.flat, x, ref_code, scale, precision="f64")
+    assert np.abs(probs.cpu().numpy() - ep).max() < 2e-5
+    assert np.array_equal(np.argmax(probs.cpu().numpy(), 1), np.argmax(ep, 1))
+
+
+def test_indel_tensor_and_cnn_match_oracle(eng):
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_indel_model
+    from oracle import oracle
+    z = np.load(os.path.join(GOLD, "indel_msa.npz"))
+    n = int(z["n"])
+    rows = [z["m%d_rows" % k] for k in range(n)]
+    refs = [z["m%d_ref" % k] for k in range(n)]
+    x, cns = eng.indel_tensor(rows, refs)
+    xh = x.cpu().numpy()
+    sym = "AGTC-"
+    for k in range(n):
+        assert np.array_equal(xh[k].astype(np.float64), z["m%d_mat" % k])          # reference msa() golden, exact
+        assert "".join(sym[c] for c in cns[k]) == str(z["m%d_cns" % k])
+    # diploid CNN on 15x128x2 (three stacked read sets), haploid on 5x128x2
+    rng = np.random.Generator(np.random.PCG64(3))
+    x15 = np.concatenate([xh[rng.integers(0, n, size=6)] for _ in range(3)], axis=1).astype(np.float32)
+    for name, kind, xin in (("ONT-HG002", _lib.MODEL_INDEL, x15), ("haploid", _lib.MODEL_INDEL_HAP, xh)):
+        w = Weights(get_indel_model(name))
+        eng.load_weights(kind, w)
+        p = eng.indel_forward(kind, torch.from_numpy(np.ascontiguousarray(xin)).cuda()).cpu().numpy()
+        e = oracle.indel_forward(w.flat, xin, precision="f64")
+        assert np.abs(p - e).max() < 1e-4
+
+
+def test_end_to_end_vcf_matches_oracle_pipeline(eng, tmp_path):
+    """call_manager on the GPU == oracle featuriser + oracle CNN + the same host rules: identical positions
+    and genotypes, probabilities within 1e-4."""
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.utils import get_chunks
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    world = load_world("ont")
+    regions = [(world.chrom, 30_000, 110_000, "diploid")]
+    chunks = get_chunks(regions, cpu=3)
+    params = dict(chunks_list=chunks, regions_list=regions, sam_path=world, fasta_path=None, mincov=4, maxcov=160,
+                  min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6], snp_model="ONT-HG002", cpu=1,
+                  vcf_path=str(tmp_path), prefix="t", sample="SAMPLE", seq="ont", supplementary=False, exclude_bed=None,
+                  suppress_progress=True, disable_coverage_normalization=False)
+    out = snpCaller.call_manager(params)
+    assert out.endswith("t.snps.vcf.gz") and os.path.exists(out)
+    import gzip
+    got = [ln for ln in gzip.open(os.path.join(str(tmp_path), "t.unfiltered.snps.vcf.gz"), "rt") if not ln.startswith("#")]
+    path, cov = get_SNP_model("ONT-HG002")
+    w = Weights(path)
+    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, seq="ont")
+    exp = []
+    for c in chunks:
+        pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(world, dct, c)
+        rc = np.argmax(ref, 1).astype(np.int32)
+        probs, _ = oracle.snp_forward(w.flat, mat, rc, np.full(len(pos), cov / depth), precision="f32")
+        exp += snpCaller.snp_vcf_lines(world.chrom, pos, rc, probs, dp, freq, fwd, rev)
+    exp.sort(key=lambda ln: int(ln.split("\t")[1]))
+    assert len(got) == len(exp) and len(got) > 100
+    ngt = 0
+    for g, e in zip(got, exp):
+        gf, ef = g.rstrip("\n").split("\t"), e.rstrip("\n").split("\t")
+        assert gf[:5] == ef[:5] and gf[6] == ef[6]                      # CHROM POS ID REF ALT FILTER
+        assert gf[9].split(":")[0] == ef[9].split(":")[0]                # GT
+        assert gf[9] == ef[9]                                            # depths / VF
+        gp = [float(v) for v in gf[7].split(";")[0][3:].split(",")]
+        ep = [float(v) for v in ef[7].split(";")[0][3:].split(",")]
+        assert max(abs(a - b) for a, b in zip(gp, ep)) <= 1.01e-4
+        ngt += gf[6] == "PASS"
+    assert ngt > 10
