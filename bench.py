@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate sites/sec through pileup featurisation + CNN (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: ALL chunks of a chr20-sized contig (64,444,167 bp,
+ONT 30x, 129 chunks of 500 kb -- BASELINE.json configs[1]) whose decoded alignments are already resident in
+HBM: column scan -> neighbour selection -> (N,5,41,5) tensors -> coverage scale -> SNP CNN -> per-site
+results (pos, probs[4], gt[2], dp, alt, fwd_dp[4], rev_dp[4], ref) back in host memory.
+Multi-GPU: one process per GPU, each rank owns an independent region of that size (weak scaling, no
+collective on the data path -- regions shard embarrassingly).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 3 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CHR20_LEN = 64_444_167                 # GRCh38 chr20
+SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--length", type=int, default=CHR20_LEN, help="contig length per GPU (default chr20)")
+    ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--tech", default="ont", choices=["ont", "hifi"])
+    ap.add_argument("--model", default="ONT-HG002")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-chunks", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
+    """Time the oracle (CPU port of the reference path, scalar C) on a bounded sample of the same workload,
+    and check the GPU results of those chunks against it."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from nanocaller_amd.synth_device import host_sample_for_oracle
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+
+    sample = chunks[:n_sample]
+    lo = max(1, sample[0]["start"] - 50_000)
+    hi = sample[-1]["end"] + 50_000
+    h = host_sample_for_oracle(pack, info, lo, hi)
+    rr = oracle.RawReads("chr20", h["L"], h["start"], h["end"], h["off"], h["codes"], h["strand"], h["keep"])
+    path, cov = get_SNP_model(model)
+    w = Weights(path)
+    oracle.lib()
+    cores = min(len(sample), os.cpu_count() or 1)
+
+    def one(c):
+        pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
+        rc = np.argmax(ref, 1).astype(np.int32)
+        probs, gt = oracle.snp_forward(w.flat, mat, rc, np.full(len(pos), cov / depth), precision="f32")
+        return pos, probs, dp
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(one, sample))
+    dt = time.perf_counter() - t0
+    n = sum(len(r[0]) for r in res)
+    # parity of the GPU run on the same chunks
+    pos_ok, max_dp, off = True, 0.0, 0
+    for ci, (pos, probs, dp) in enumerate(res):
+        sel = gpu_result["chunk"] == ci
+        pos_ok &= bool(np.array_equal(gpu_result["pos"][sel], pos) and np.array_equal(gpu_result["dp"][sel], dp))
+        if pos_ok and len(pos):
+            max_dp = max(max_dp, float(np.abs(gpu_result["probs"][sel] - probs).max()))
+    return dict(value=n / dt, unit="sites/s", cores=cores, kind="port",
+                sample="%d chunks of 500 kb (%d sites, %.1f s): oracle/nc_oracle.c scan+tensors+CNN(f32), one thread per chunk"
+                % (len(sample), n, dt)), dict(positions_exact=pos_ok, max_abs_dprob=max_dp, sites_checked=n)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_device_workload
+    from nanocaller_amd.utils import get_chunks
+
+    eng = get_engine(local)
+    L = args.length
+    t_gen = time.perf_counter()
+    pack, info = make_device_workload(eng, L, depth=args.depth, tech=args.tech, seed=812 + rank)
+    t_gen = time.perf_counter() - t_gen
+    chunks = get_chunks([("chr20", 1, L, "diploid")], cpu=16)      # 16 = the reference's documented example (--cpu 16)
+    params = dict(mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
+                  snp_model=args.model, seq="ont" if args.tech == "ont" else "pacbio", supplementary=False,
+                  exclude_bed=None, disable_coverage_normalization=False, sam_path=None)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def step():
+        return snpCaller.call_chunks(params, chunks, device=local, dpk=pack)
+
+    for _ in range(args.warmup):
+        step()
+    eng.enable_timing(True)
+    stage_ms = np.zeros(3)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+        stage_ms += [eng.last_ms(0), eng.last_ms(1), eng.last_ms(2)]
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.enable_timing(False)
+    n_sites = int(r["n"])
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ns = torch.tensor([n_sites], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+        total_sites = int(ns.item())
+    else:
+        total_sites = n_sites
+    stage_ms /= max(1, args.steps)
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_sites * args.steps / dt
+        cnn_tflops = SNP_FLOP_PER_SITE * n_sites / (stage_ms[2] * 1e-3) / 1e12 if stage_ms[2] > 0 else 0.0
+        scan_bytes = info["pileup_entries"] + L               # (d+1) B/column, SURVEY.md 8d
+        feat_bytes = 5403 * n_sites
+        out = {
+            "metric": "candidate sites/sec (pileup+CNN)", "value": value, "unit": "sites/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx, chr20-sized contig (%d bp, %d chunks of 500 kb) per GPU"
+                       % (args.tech.upper(), args.depth, L, len(chunks)), "sites_per_gpu": n_sites,
+                       "pileup_entries_per_gpu": info["pileup_entries"], "model": args.model, "generator": "synth_v1 seed 812+rank",
+                       "data_gen_s": round(t_gen, 2)},
+            "roofline": {"bound": "mfma", "kernel": "SNP CNN forward (fp32)", "achieved": cnn_tflops,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": cnn_tflops / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "avg_ms": float(stage_ms[2])},
+            "stages": {"scan_ms": float(stage_ms[0]), "scan_GBs": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 if stage_ms[0] else 0,
+                       "scan_frac_hbm": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[0] else 0,
+                       "featurize_ms": float(stage_ms[1]),
+                       "featurize_GBs": feat_bytes / (stage_ms[1] * 1e-3) / 1e9 if stage_ms[1] else 0,
+                       "cnn_ms": float(stage_ms[2])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, parity = cpu_baseline(pack, info, chunks, params, args.model, r, args.cpu_sample_chunks)
+            out["cpu_baseline"] = cb
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

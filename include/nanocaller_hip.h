@@ -94,7 +94,8 @@ typedef struct {
 /* Host-side packer.  Inputs (host): n reads in coordinate order, read r covers [start[r], end[r]) and
  * codes_in[off[r] + p - start[r]] is its code (0..4) at p; keep[r]==0 drops the read (pileup flag filter
  * 0x4|0x100|0x200|0x400|0x800, generate_SNP_pileups.py:151-157); strand[r] != 0 = reverse.
- * Step 1 sizes the outputs; step 2 fills caller-allocated host buffers. */
+ * Step 1 sizes the outputs; step 2 fills caller-allocated host buffers.  With codes_in == codes_out == NULL
+ * nc_pack_fill builds the tile index only (slot r starts at byte sum_{q<r} slot_size(q), kept reads only). */
 int nc_pack_plan(int32_t n_reads, const int32_t *start, const int32_t *end, const uint8_t *keep,
                  int32_t tile_size, int32_t pos_lo, int32_t pos_hi,
                  int64_t *codes_len, int32_t *tile_pos0, int32_t *n_tiles, int64_t *n_entries);
@@ -112,7 +113,8 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
  * [chunk_start[c], chunk_end[c]] (both inclusive, utils.py:79-80) then owns the candidates inside it --
  * a position shared by two adjacent chunks is emitted once per chunk (quirk E3).
  * ref_code[p - ref_pos0] is the reference code at p: 0..3, or 4 to skip the column (non-AGTC or
- * soft-masked base, generate_SNP_pileups.py:137,161, or an exclude_bed hit).
+ * soft-masked base, generate_SNP_pileups.py:137,161, or an exclude_bed hit).  It must lie on the pack's tile
+ * grid: ref_pos0 == pack->tile_pos0 and ref_len >= n_tiles*tile_size (pad with 4).
  * Results stay in the context (device); counts are returned.  Synchronises once.
  */
 typedef struct {

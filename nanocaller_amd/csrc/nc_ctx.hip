@@ -176,8 +176,10 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
                  uint8_t *codes_out, int64_t codes_len, int32_t *tile_off, nc_tile_entry *tile_ent,
                  int64_t n_entries)
 {
-    if (n_reads < 0 || !tile_size_ok(tile_size) || n_tiles <= 0 || !codes_out || !tile_off ||
-        (n_entries && !tile_ent) || (n_reads && (!start || !end || !off || !codes_in)))
+    // codes_in == NULL && codes_out == NULL: build the tile index only (the caller fills the slots itself)
+    const bool index_only = !codes_in && !codes_out;
+    if (n_reads < 0 || !tile_size_ok(tile_size) || n_tiles <= 0 || !tile_off || (n_entries && !tile_ent) ||
+        (n_reads && (!start || !end)) || (!index_only && (!codes_out || (n_reads && (!off || !codes_in)))))
         return NC_ERR_ARG;
     const int64_t t0 = tile_pos0;
     std::vector<int64_t> cnt((size_t)n_tiles + 1, 0);
@@ -192,14 +194,14 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
     if (cnt[(size_t)n_tiles] != n_entries || n_entries > INT32_MAX) return NC_ERR_CAPACITY;
     for (int32_t t = 0; t <= n_tiles; t++) tile_off[t] = (int32_t)cnt[(size_t)t];
     std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-    memset(codes_out, NC_CODE_ABSENT, (size_t)codes_len);
+    if (!index_only) memset(codes_out, NC_CODE_ABSENT, (size_t)codes_len);
     int64_t w = 0;   // write cursor (multiple of 16)
     for (int32_t r = 0; r < n_reads; r++) {
         if (keep && !keep[r]) continue;
         int64_t lo = floor16(start[r]), hi = ceil16(end[r]);
         if (w + (hi - lo) > codes_len) return NC_ERR_CAPACITY;
         int64_t base = w - lo;                                  // codes_out[base + p], multiple of 16
-        memcpy(codes_out + base + start[r], codes_in + off[r], (size_t)(end[r] - start[r]));
+        if (!index_only) memcpy(codes_out + base + start[r], codes_in + off[r], (size_t)(end[r] - start[r]));
         w += hi - lo;
         nc_tile_entry e;
         e.start = start[r];

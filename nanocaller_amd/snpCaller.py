@@ -115,8 +115,9 @@ VCF_HEADER = (                                                      # snpCaller.
     '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample}\n')
 
 
-def call_chunks(params, chunks, device=0):
+def call_chunks(params, chunks, device=0, dpk=None):
     """Run pileup featurisation + CNN for a list of chunks of ONE contig and ploidy on the GPU.
+    `dpk`: alignments already resident in HBM (engine.DevicePack); default: packed from params['sam_path'].
     -> dict of host arrays (pos, chunk, ref, probs, gt, dp, freq, fwd_dp, rev_dp, chunk_depth)."""
     chrom = chunks[0]['chrom']
     ploidy = chunks[0]['ploidy']
@@ -134,7 +135,8 @@ def call_chunks(params, chunks, device=0):
         train_cov = 30                                              # hap_train_coverage, snpCaller.py:73
         kind = _lib.MODEL_SNP_HAP
     eng.load_weights(kind, Weights(path))
-    dpk = device_pack_for(params, chrom, device)
+    if dpk is None:
+        dpk = device_pack_for(params, chrom, device)
     sites = eng.snp_scan(dpk, [(c['start'], c['end']) for c in chunks], mincov=params['mincov'],
                          min_allele_freq=params['min_allele_freq'], threshold=params['threshold'],
                          haploid=(ploidy == 'haploid'))

@@ -37,6 +37,16 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+class RawReads:
+    """Minimal stand-in for synth.World built from raw arrays (used by bench.py's cpu_baseline leg)."""
+
+    def __init__(self, chrom, length, read_start, read_end, read_off, codes, strand, keep):
+        self.chrom, self.length = chrom, int(length)
+        self.read_start, self.read_end, self.read_off, self.codes = read_start, read_end, read_off, codes
+        self.read_flag = (np.asarray(strand, np.int32) * 16) | np.where(np.asarray(keep) != 0, 0, 0x100).astype(np.int32)
+        self.ref = None
+
+
 def _reads(world, supplementary=False):
     from nanocaller_amd.synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
     filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT
@@ -70,7 +80,7 @@ def get_cnd_pos(v_pos, cnd_pos, seq="ont"):
 
 def snp_scan(world, rc, start, end, ploidy, mincov, min_allele_freq, threshold, supplementary=False):
     rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
-    cap = world.length + 1
+    cap = min(world.length + 1, end - start + 2 * 50000 + 2)
     nbr = np.zeros(cap, np.int32)
     cpos = np.zeros(cap, np.int32)
     cn = np.zeros(cap, np.int32)
@@ -109,10 +119,11 @@ def snp_featurize(world, rc, nbr, cpos, seq, maxcov, min_nbr_sites, supplementar
     return out_pos[:k], out_ref[:k], mat[:k], fwd[:k], rev[:k], dep[:k]
 
 
-def get_snp_testing_candidates(world, dct, region, exclude=None):
+def get_snp_testing_candidates(world, dct, region, exclude=None, rc=None):
     """Same 8-tuple as the reference function (generate_SNP_pileups.py:279), computed by the oracle.
     (pos, ref_onehot int32 (N,4), mat f32 (N,5,41,5), dp, freq f64, depth f64, fwd_dp f64 (N,4), rev_dp)"""
-    rc = ref_codes_with_exclusions(world, exclude)
+    if rc is None:
+        rc = ref_codes_with_exclusions(world, exclude)
     nbr, cpos, cn, calt = snp_scan(world, rc, region["start"], region["end"], region["ploidy"],
                                    dct["mincov"], dct["min_allele_freq"], dct["threshold"],
                                    dct.get("supplementary", False))
