@@ -1,10 +1,16 @@
-// K5 / K9: CNN forward for the four NanoCaller models (gfx950), fp32.
+// K5 / K9: CNN forward for the four NanoCaller models (gfx950), exact fp32.
 //
 // Restates model_architect.py:36-64, model_architect_SNP_haploid.py:33-53, model_architect_indel.py:28-48,
 // model_architect_indels_haploid.py:29-48: three parallel `same` convs (1x5, 5x1, 5x5)
 // -> concat -> two `valid` 2x3 convs with stride (1,2) -> flatten -> dense layers; SELU everywhere.
-// v1 layout: NHWC activations in HBM per batch of sites, one thread per output element; weights stay in
-// the Keras layouts (HWIO / [in,out]) so consecutive lanes (output channels) read consecutive weights.
+//
+// Kernel shape ("scalar-weight direct convolution"): one lane owns one output POSITION (site, y, x) and keeps
+// ALL output channels of that position in VGPR accumulators; the K loop walks (tap, input channel); the
+// activation is a per-lane value (dwordx4 loads of the NHWC row), the weight row w[tap][ci][0..Co) is
+// wave-uniform and arrives through the scalar cache, so every v_fma_f32 takes one VGPR activation and one SGPR
+// weight: no LDS staging, no im2col, and the arithmetic is an fmaf chain in the reference's (tap, ci) order.
+// fp32 matrix and vector peaks are equal on gfx950 (157.3 TFLOP/s), so this VALU form has the same roof as
+// v_mfma_f32_* while keeping the weights out of the vector register file.
 #include "nc_common.h"
 
 namespace {
@@ -14,62 +20,296 @@ constexpr float SELU_LA = 1.0507009873554805f * 1.6732632423543772f;
 
 __device__ __forceinline__ float selu(float x) { return x > 0.0f ? SELU_L * x : SELU_LA * (expf(x) - 1.0f); }
 
-// coverage scaling of rows 1.., channels 0..3 (snpCaller.py:93-96); see nanocaller_hip.h for the two modes
-__device__ __forceinline__ float scaled_in(float x, const double *scale, int64_t s, int mode, int row, int ch, int Ci)
+// ---- conv1: the three `same` convolutions, fused.  Canonical weights: k11[1][5][CI][C1] b11 k12[5][1][CI][C1] b12
+// k13[5][5][CI][C1] b13.  Output NHWC [site][H][W][3*C1].  Coverage scaling (snpCaller.py:93-96) is applied while
+// loading: rows >= 1, channels < CI-1 (scale == nullptr: none).
+template <int H, int W, int CI, int C1>
+__global__ __launch_bounds__(256) void k2_conv1(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ out,
+                                                int64_t npos, const double *__restrict__ scale, int scale_mode, int64_t site0)
 {
-    if (!scale || row == 0 || ch == Ci - 1) return x;
-    return mode == 0 ? x * (float)scale[s] : (float)((double)x * scale[s]);
-}
-
-struct ConvP {
-    int H, W, Ci, kh, kw, Co, sh, sw, ph, pw, Ho, Wo, co_off, Ctot;
-};
-
-template <bool SCALE>
-__global__ __launch_bounds__(256) void k_conv(const float *__restrict__ in, const float *__restrict__ k, const float *__restrict__ b,
-                                              float *__restrict__ out, int64_t n_out_total, ConvP p,
-                                              const double *__restrict__ scale, int scale_mode, int64_t site0)
-{
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_out_total) return;
-    const int o = (int)(idx % p.Co);
-    int64_t r = idx / p.Co;
-    const int x = (int)(r % p.Wo);
-    r /= p.Wo;
-    const int y = (int)(r % p.Ho);
-    const int64_t s = r / p.Ho;
-    float acc = b[o];
-    const float *ins = in + s * (int64_t)p.H * p.W * p.Ci;
-    for (int dy = 0; dy < p.kh; dy++) {
-        const int iy = y * p.sh + dy - p.ph;
-        if (iy < 0 || iy >= p.H) continue;
-        for (int dx = 0; dx < p.kw; dx++) {
-            const int ix = x * p.sw + dx - p.pw;
-            if (ix < 0 || ix >= p.W) continue;
-            const float *ip = ins + ((int64_t)iy * p.W + ix) * p.Ci;
-            const float *kp = k + ((int64_t)(dy * p.kw + dx) * p.Ci) * p.Co + o;
-            for (int c = 0; c < p.Ci; c++) {
-                float xv = ip[c];
-                if (SCALE) xv = scaled_in(xv, scale, site0 + s, scale_mode, iy, c, p.Ci);
-                acc = fmaf(xv, kp[(int64_t)c * p.Co], acc);
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= npos) return;
+    const int64_t site = g / (H * W);
+    const int r = (int)(g - site * (H * W));
+    const int h = r / W, wq = r - h * W;
+    const float *xs = x + site * (H * W * CI);
+    const float *k11 = w, *b11 = k11 + 5 * CI * C1;
+    const float *k12 = b11 + C1, *b12 = k12 + 5 * CI * C1;
+    const float *k13 = b12 + C1, *b13 = k13 + 25 * CI * C1;
+    float a1[C1], a2[C1], a3[C1];
+#pragma unroll
+    for (int o = 0; o < C1; o++) { a1[o] = b11[o]; a2[o] = b12[o]; a3[o] = b13[o]; }
+    float sf = 1.0f;
+    double sd = 1.0;
+    if (scale) { sd = scale[site0 + site]; sf = (float)sd; }
+#pragma unroll 1
+    for (int dy = -2; dy <= 2; dy++) {
+#pragma unroll 1
+        for (int dx = -2; dx <= 2; dx++) {
+            const int iy = h + dy, ix = wq + dx;
+            const bool inb = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float *ip = xs + (iy * W + ix) * CI;
+#pragma unroll
+            for (int c = 0; c < CI; c++) {
+                float xv = inb ? ip[c] : 0.0f;
+                if (scale && c < CI - 1 && iy > 0) xv = scale_mode == 0 ? xv * sf : (float)((double)xv * sd);
+                const float *w3 = k13 + (((dy + 2) * 5 + (dx + 2)) * CI + c) * C1;
+#pragma unroll
+                for (int o = 0; o < C1; o++) a3[o] = fmaf(xv, w3[o], a3[o]);
+                if (dy == 0) {
+                    const float *w1 = k11 + ((dx + 2) * CI + c) * C1;
+#pragma unroll
+                    for (int o = 0; o < C1; o++) a1[o] = fmaf(xv, w1[o], a1[o]);
+                }
+                if (dx == 0) {
+                    const float *w2 = k12 + ((dy + 2) * CI + c) * C1;
+#pragma unroll
+                    for (int o = 0; o < C1; o++) a2[o] = fmaf(xv, w2[o], a2[o]);
+                }
             }
         }
     }
-    out[((s * p.Ho + y) * p.Wo + x) * p.Ctot + p.co_off + o] = selu(acc);
+    float4 *op = reinterpret_cast<float4 *>(out + g * (3 * C1));
+#pragma unroll
+    for (int o = 0; o < C1; o += 4) {
+        op[o / 4] = make_float4(selu(a1[o]), selu(a1[o + 1]), selu(a1[o + 2]), selu(a1[o + 3]));
+        op[(C1 + o) / 4] = make_float4(selu(a2[o]), selu(a2[o + 1]), selu(a2[o + 2]), selu(a2[o + 3]));
+        op[(2 * C1 + o) / 4] = make_float4(selu(a3[o]), selu(a3[o + 1]), selu(a3[o + 2]), selu(a3[o + 3]));
+    }
 }
 
-__global__ __launch_bounds__(256) void k_dense(const float *__restrict__ in, int n_in, const float *__restrict__ k,
-                                               const float *__restrict__ b, int n_out, float *__restrict__ out, int64_t total,
-                                               int act)
+// ---- conv2 / conv3: 2x3 kernel, stride (1,2), valid.  in NHWC [site][HI][WI][CI], weights [2][3][CI][CO], out NHWC.
+// P positions per lane (register blocking over positions halves the scalar weight traffic per FMA).
+template <int HI, int WI, int CI, int CO, int P>
+__global__ __launch_bounds__(256) void k2_conv23(const float *__restrict__ in, const float *__restrict__ wk, const float *__restrict__ wb,
+                                                 float *__restrict__ out, int64_t npos)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int o = (int)(idx % n_out);
-    const int64_t s = idx / n_out;
-    const float *ip = in + s * n_in;
-    float acc = b[o];
-    for (int i = 0; i < n_in; i++) acc = fmaf(ip[i], k[(int64_t)i * n_out + o], acc);
-    out[idx] = act ? selu(acc) : acc;
+    constexpr int HO = HI - 1, WO = (WI - 3) / 2 + 1;
+    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float acc[P][CO];
+    const float *ip[P];
+    bool live[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int64_t g = g0 + p * nthreads;
+        live[p] = g < npos;
+        const int64_t gg = live[p] ? g : 0;
+        const int64_t site = gg / (HO * WO);
+        const int r = (int)(gg - site * (HO * WO));
+        const int y = r / WO, xq = r - y * WO;
+        ip[p] = in + ((site * HI + y) * WI + 2 * xq) * CI;
+#pragma unroll
+        for (int o = 0; o < CO; o++) acc[p][o] = wb[o];
+    }
+    for (int dy = 0; dy < 2; dy++) {
+        for (int dx = 0; dx < 3; dx++) {
+            const float *wt = wk + (dy * 3 + dx) * CI * CO;
+            const int ioff = (dy * WI + dx) * CI;
+#pragma unroll 2
+            for (int c4 = 0; c4 < CI; c4 += 4) {
+                float4 xv[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) xv[p] = *reinterpret_cast<const float4 *>(ip[p] + ioff + c4);
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    const float *wr = wt + (c4 + cc) * CO;
+#pragma unroll
+                    for (int o = 0; o < CO; o++) {
+                        const float wv = wr[o];
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            const float xs = cc == 0 ? xv[p].x : cc == 1 ? xv[p].y : cc == 2 ? xv[p].z : xv[p].w;
+                            acc[p][o] = fmaf(xs, wv, acc[p][o]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        if (!live[p]) continue;
+        float4 *op = reinterpret_cast<float4 *>(out + (g0 + p * nthreads) * CO);
+#pragma unroll
+        for (int o = 0; o < CO; o += 4)
+            op[o / 4] = make_float4(selu(acc[p][o]), selu(acc[p][o + 1]), selu(acc[p][o + 2]), selu(acc[p][o + 3]));
+    }
+}
+
+// ---- fc1: lane = site, F outputs in registers, K-long dot products with uniform weight rows [K][F]; SELU.
+template <int F>
+__global__ __launch_bounds__(256) void k2_fc1(const float *__restrict__ in, int K, const float *__restrict__ wk, const float *__restrict__ wb,
+                                              float *__restrict__ out, int64_t n)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < n;
+    const float *ip = in + (live ? s : 0) * K;
+    float acc[F];
+#pragma unroll
+    for (int o = 0; o < F; o++) acc[o] = wb[o];
+    for (int k4 = 0; k4 < K; k4 += 4) {
+        const float4 xv = *reinterpret_cast<const float4 *>(ip + k4);
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const float xs = cc == 0 ? xv.x : cc == 1 ? xv.y : cc == 2 ? xv.z : xv.w;
+            const float *wr = wk + (int64_t)(k4 + cc) * F;
+#pragma unroll
+            for (int o = 0; o < F; o++) acc[o] = fmaf(xs, wr[o], acc[o]);
+        }
+    }
+    if (!live) return;
+    float4 *op = reinterpret_cast<float4 *>(out + s * F);
+#pragma unroll
+    for (int o = 0; o < F; o += 4) op[o / 4] = make_float4(selu(acc[o]), selu(acc[o + 1]), selu(acc[o + 2]), selu(acc[o + 3]));
+}
+
+
+// ---- MFMA forms (SNP trunk).  fp32-in/fp32-accumulate MFMA is bit-for-bit an fmaf chain (exact fp32).
+// GEMM view: M = output positions (A fragment: one activation per lane), N = output channels (B fragment: one
+// weight per lane, a coalesced 128-B row segment per half-wave), K = (tap, ci).  K is walked in a permuted order so
+// that the 4 (or 2x4) consecutive input channels a lane loads as ONE dwordx4 feed 4 consecutive MFMAs:
+// v_mfma_f32_32x32x2: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31]; half-wave h takes ci in [8j+4h, 8j+4h+4).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int HI, int WI, int CI, int CO, int TM>
+__global__ __launch_bounds__(256) void k3_conv23(const float *__restrict__ in, const float *__restrict__ wk, const float *__restrict__ wb,
+                                                 float *__restrict__ out, int64_t npos)
+{
+    constexpr int HO = HI - 1, WO = (WI - 3) / 2 + 1, TN = CO / 32;
+    static_assert(CI % 8 == 0 && CO % 32 == 0, "k3_conv23 shape");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * (TM * 32);
+    if (tile0 >= npos) return;
+    const float *ip[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        int64_t g = tile0 + tm * 32 + col;
+        if (g >= npos) g = npos - 1;
+        const int64_t site = g / (HO * WO);
+        const int r = (int)(g - site * (HO * WO));
+        const int y = r / WO, xq = r - y * WO;
+        ip[tm] = in + ((site * HI + y) * WI + 2 * xq) * CI + 4 * half;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const float b = wb[tn * 32 + col];
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][tn][r] = b;
+    }
+    const float *wl = wk + (4 * half) * CO + col;
+#pragma unroll 1
+    for (int tap = 0; tap < 6; tap++) {
+        const int ioff = ((tap / 3) * WI + (tap % 3)) * CI;
+        const float *wt = wl + tap * CI * CO;
+#pragma unroll
+        for (int j = 0; j < CI / 8; j++) {
+            float4 a[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) a[tm] = *reinterpret_cast<const float4 *>(ip[tm] + ioff + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float b[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) b[tn] = wt[(8 * j + i) * CO + tn * 32];
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++) {
+                    const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[tn], acc[tm][tn], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t g = tile0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // C/D row of register r
+            if (g < npos) {
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) out[g * CO + tn * 32 + col] = selu(acc[tm][tn][r]);
+            }
+        }
+    }
+}
+
+// fc1 as v_mfma_f32_16x16x4: M = 16 sites per tile, N = F/16 tiles, K walked in groups of 16 (quarter-wave q takes
+// k in [16j+4q, 16j+4q+4) as one dwordx4).  lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]; C: col l&15, row 4*(l>>4)+r.
+// Split-K: the four waves of a workgroup share the same 16*TM sites and each takes a quarter of K; partial sums are
+// combined through LDS (K = 1728 would otherwise be one 40k-cycle dependent chain per wave).
+template <int F, int TM>
+__global__ __launch_bounds__(256) void k3_fc1(const float *__restrict__ in, int K, const float *__restrict__ wk, const float *__restrict__ wb,
+                                              float *__restrict__ out, int64_t n)
+{
+    constexpr int TN = F / 16;
+    __shared__ float red[3][TM][TN][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int64_t tile0 = (int64_t)blockIdx.x * (TM * 16);
+    const float *ip[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        int64_t s = tile0 + tm * 16 + c16;
+        if (s >= n) s = n - 1;
+        ip[tm] = in + s * K + 4 * q;
+    }
+    f32x4v acc[TM][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const float b = wv == 0 ? wb[tn * 16 + c16] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) acc[tm][tn] = (f32x4v){b, b, b, b};
+    }
+    const float *wl = wk + (4 * q) * F + c16;
+    const int ng = K / 16;
+    const int j0 = (ng * wv) / 4, j1 = (ng * (wv + 1)) / 4;
+#pragma unroll 3
+    for (int j = j0; j < j1; j++) {
+        float4 a[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) a[tm] = *reinterpret_cast<const float4 *>(ip[tm] + 16 * j);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float b[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) b[tn] = wl[(int64_t)(16 * j + i) * F + tn * 16];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) {
+                const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[wv - 1][tm][tn][r][lane] = acc[tm][tn][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t s = tile0 + tm * 16 + 4 * q + r;
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) {
+                    const float v = acc[tm][tn][r] + red[0][tm][tn][r][lane] + red[1][tm][tn][r][lane] + red[2][tm][tn][r][lane];
+                    if (s < n) out[s * F + tn * 16 + c16] = selu(v);
+                }
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void dense_small(const float *in, int n_in, const float *k, const float *b, int n_out, float *out, bool act)
@@ -160,49 +400,40 @@ __global__ __launch_bounds__(256) void k_indel_heads(const float *__restrict__ f
     }
 }
 
-struct Arch { int H, W, Ci, C1, C2, C3, F; };
-const Arch ARCH[4] = {{5, 41, 5, 16, 32, 64, 48}, {5, 41, 5, 16, 32, 64, 48}, {15, 128, 2, 8, 32, 48, 32}, {5, 128, 2, 8, 32, 48, 32}};
 const size_t NPARAM[4] = {109370, 108308, 634420, 158185};
 
-inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
-// conv trunk for sites [site0, site0+nb) -> fc1 activations [nb][F] in ctx->cnn_c ; returns pointer to the tail weights
-int run_trunk(nc_ctx *ctx, int kind, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
-              const float **tail)
+// conv trunk for `nb` sites -> fc1 activations [nb][F]; *f1_out / *tail receive the fc1 buffer and the tail weights
+template <int H, int W, int CI, int C1, int C2, int C3, int F, int P2, int P3, bool MFMA>
+int run_trunk(nc_ctx *ctx, const float *w, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
+              const float **f1_out, const float **tail)
 {
-    const Arch A = ARCH[kind];
-    const float *w = ctx->w[kind].dev;
-    const int H2 = A.H - 1, W2 = (A.W - 3) / 2 + 1, H3 = H2 - 1, W3 = (W2 - 3) / 2 + 1;
-    const int64_t n1 = (int64_t)A.H * A.W * 3 * A.C1, n2 = (int64_t)H2 * W2 * A.C2, n3 = (int64_t)H3 * W3 * A.C3;
+    constexpr int H2 = H - 1, W2 = (W - 3) / 2 + 1, H3 = H2 - 1, W3 = (W2 - 3) / 2 + 1;
+    constexpr int64_t n1 = (int64_t)H * W * 3 * C1, n2 = (int64_t)H2 * W2 * C2, n3 = (int64_t)H3 * W3 * C3;
     NC_TRY(nc_ensure(ctx, ctx->cnn_a, (size_t)(nb * n1) * 4));
     NC_TRY(nc_ensure(ctx, ctx->cnn_b, (size_t)(nb * n2) * 4));
-    NC_TRY(nc_ensure(ctx, ctx->cnn_c, (size_t)(nb * (n3 + A.F)) * 4));
-    float *a1 = (float *)ctx->cnn_a.p, *a2 = (float *)ctx->cnn_b.p, *a3 = (float *)ctx->cnn_c.p, *f1 = a3 + nb * n3;
-    const float *k11 = w, *b11 = k11 + 1 * 5 * A.Ci * A.C1;
-    const float *k12 = b11 + A.C1, *b12 = k12 + 5 * 1 * A.Ci * A.C1;
-    const float *k13 = b12 + A.C1, *b13 = k13 + 5 * 5 * A.Ci * A.C1;
-    const float *k2 = b13 + A.C1, *b2 = k2 + 2 * 3 * 3 * A.C1 * A.C2;
-    const float *k3 = b2 + A.C2, *b3 = k3 + 2 * 3 * A.C2 * A.C3;
-    const float *kf = b3 + A.C3, *bf = kf + n3 * A.F;
-    *tail = bf + A.F;
-    ConvP p;
-    p.H = A.H; p.W = A.W; p.Ci = A.Ci; p.Co = A.C1; p.sh = 1; p.sw = 1; p.Ho = A.H; p.Wo = A.W; p.Ctot = 3 * A.C1;
-    const int64_t tot1 = nb * A.H * A.W * A.C1;
-    p.kh = 1; p.kw = 5; p.ph = 0; p.pw = 2; p.co_off = 0;
-    hipLaunchKernelGGL(k_conv<true>, dim3(blocks_for(tot1)), dim3(256), 0, ctx->stream, x_batch, k11, b11, a1, tot1, p, scale, scale_mode, site0);
-    p.kh = 5; p.kw = 1; p.ph = 2; p.pw = 0; p.co_off = A.C1;
-    hipLaunchKernelGGL(k_conv<true>, dim3(blocks_for(tot1)), dim3(256), 0, ctx->stream, x_batch, k12, b12, a1, tot1, p, scale, scale_mode, site0);
-    p.kh = 5; p.kw = 5; p.ph = 2; p.pw = 2; p.co_off = 2 * A.C1;
-    hipLaunchKernelGGL(k_conv<true>, dim3(blocks_for(tot1)), dim3(256), 0, ctx->stream, x_batch, k13, b13, a1, tot1, p, scale, scale_mode, site0);
-    ConvP q;
-    q.H = A.H; q.W = A.W; q.Ci = 3 * A.C1; q.kh = 2; q.kw = 3; q.Co = A.C2; q.sh = 1; q.sw = 2; q.ph = 0; q.pw = 0;
-    q.Ho = H2; q.Wo = W2; q.co_off = 0; q.Ctot = A.C2;
-    hipLaunchKernelGGL(k_conv<false>, dim3(blocks_for(nb * n2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, nb * n2, q, nullptr, 0, (int64_t)0);
-    ConvP r;
-    r.H = H2; r.W = W2; r.Ci = A.C2; r.kh = 2; r.kw = 3; r.Co = A.C3; r.sh = 1; r.sw = 2; r.ph = 0; r.pw = 0;
-    r.Ho = H3; r.Wo = W3; r.co_off = 0; r.Ctot = A.C3;
-    hipLaunchKernelGGL(k_conv<false>, dim3(blocks_for(nb * n3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, nb * n3, r, nullptr, 0, (int64_t)0);
-    hipLaunchKernelGGL(k_dense, dim3(blocks_for(nb * A.F)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, A.F, f1, nb * A.F, 1);
+    NC_TRY(nc_ensure(ctx, ctx->cnn_c, (size_t)(nb * (n3 + F)) * 4 + 64));
+    float *a1 = (float *)ctx->cnn_a.p, *a2 = (float *)ctx->cnn_b.p, *a3 = (float *)ctx->cnn_c.p;
+    float *f1 = a3 + ((nb * n3 + 3) & ~int64_t(3));
+    const float *k2 = w + (5 + 5 + 25) * CI * C1 + 3 * C1, *b2 = k2 + 2 * 3 * 3 * C1 * C2;
+    const float *k3 = b2 + C2, *b3 = k3 + 2 * 3 * C2 * C3;
+    const float *kf = b3 + C3, *bf = kf + n3 * F;
+    *tail = bf + F;
+    *f1_out = f1;
+    const int64_t np1 = nb * H * W, np2 = nb * H2 * W2, np3 = nb * H3 * W3;
+    hipLaunchKernelGGL((k2_conv1<H, W, CI, C1>), dim3(blocks_for(np1)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1, scale,
+                       scale_mode, site0);
+    if constexpr (MFMA) {
+        constexpr int TM2 = 4, TM3 = 2, TMF = 1;
+        hipLaunchKernelGGL((k3_conv23<H, W, 3 * C1, C2, TM2>), dim3(blocks_for(np2, 4 * 32 * TM2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
+        hipLaunchKernelGGL((k3_conv23<H2, W2, C2, C3, TM3>), dim3(blocks_for(np3, 4 * 32 * TM3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
+        hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+    } else {
+        hipLaunchKernelGGL((k2_conv23<H, W, 3 * C1, C2, P2>), dim3(blocks_for(np2, 256 * P2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
+        hipLaunchKernelGGL((k2_conv23<H2, W2, C2, C3, P3>), dim3(blocks_for(np3, 256 * P3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
+        hipLaunchKernelGGL((k2_fc1<F>), dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+    }
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
 }
@@ -239,12 +470,12 @@ int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, con
     if (scale_mode != 0 && scale_mode != 1) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: scale_mode");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     NcTimer tm(ctx, 2);
-    const int64_t BATCH = 16384;
+    const int64_t BATCH = 32768;
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
-        const float *tail = nullptr;
-        NC_TRY(run_trunk(ctx, kind, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode, &tail));
-        const float *f1 = (const float *)ctx->cnn_c.p + nb * (3 * 9 * 64);
+        const float *tail = nullptr, *f1 = nullptr;
+        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
+                                                          &f1, &tail)));
         if (kind == NC_MODEL_SNP)
             hipLaunchKernelGGL(k_snp_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, ref_code_dev + s0, nb,
                                probs_dev + s0 * 4, gt_dev ? gt_dev + s0 * 2 : nullptr);
@@ -264,17 +495,17 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
     if (!ctx->w[kind].dev) return nc_fail(ctx, NC_ERR_STATE, "nc_indel_forward: weights of kind %d not loaded", kind);
     if (n < 0 || (n && (!x_dev || !probs_dev))) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_forward: null argument");
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    const Arch A = ARCH[kind];
     const int nout = kind == NC_MODEL_INDEL ? 4 : 1;
-    const int64_t xs = (int64_t)A.H * A.W * A.Ci;
-    const int H3 = A.H - 2, W3 = 31;
+    const int64_t xs = kind == NC_MODEL_INDEL ? 15 * 128 * 2 : 5 * 128 * 2;
     NcTimer tm(ctx, 2);
-    const int64_t BATCH = kind == NC_MODEL_INDEL ? 2048 : 8192;
+    const int64_t BATCH = kind == NC_MODEL_INDEL ? 1024 : 4096;
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
-        const float *tail = nullptr;
-        NC_TRY(run_trunk(ctx, kind, s0, nb, x_dev + s0 * xs, nullptr, 0, &tail));
-        const float *f1 = (const float *)ctx->cnn_c.p + nb * ((int64_t)H3 * W3 * A.C3);
+        const float *tail = nullptr, *f1 = nullptr;
+        if (kind == NC_MODEL_INDEL)
+            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+        else
+            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         hipLaunchKernelGGL(k_indel_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, nout, nb, probs_dev + s0 * nout);
         NC_HIP(ctx, hipGetLastError());
     }
@@ -282,4 +513,4 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
     return NC_OK;
 }
 
-}   // extern "C"
+}   // namespace

@@ -222,6 +222,20 @@ class Engine:
             out.append(row[row != 4])
         return x, out
 
+    def to_host(self, tensors):
+        """Copy device tensors to (cached) pinned host memory with ONE synchronisation; -> list of numpy views
+        that own their pinned storage through the returned arrays' base tensors."""
+        outs = []
+        for t in tensors:
+            if t is None:
+                outs.append(None)
+                continue
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            outs.append(h)
+        torch.cuda.current_stream(self.device).synchronize()
+        return [None if h is None else h.numpy() for h in outs]
+
     def sync(self):
         torch.cuda.synchronize(self.device)
 

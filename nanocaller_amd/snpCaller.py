@@ -147,14 +147,17 @@ def call_chunks(params, chunks, device=0, dpk=None):
     per_site = bool(params.get('disable_coverage_normalization'))
     scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site)
     probs, gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0)
-    valid = sites.valid.cpu().numpy().astype(bool)
-    n = sites.dp.astype(np.int64)
-    res.update(n=int(valid.sum()), pos=sites.pos[valid].astype(np.int64), chunk=sites.chunk[valid],
-               ref=sites.ref_code.cpu().numpy()[valid], probs=probs.cpu().numpy()[valid],
-               gt=gt.cpu().numpy()[valid] if gt is not None else None, dp=n[valid],
-               freq=(sites.alt.astype(np.float64) / n.astype(np.float64))[valid],
-               fwd_dp=sites.fwd_dp.cpu().numpy()[valid].astype(np.float64),
-               rev_dp=sites.rev_dp.cpu().numpy()[valid].astype(np.float64), chunk_depth=chunk_depth)
+    all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
+    h_ref, h_probs, h_gt, h_fwd, h_rev, h_valid = eng.to_host([sites.ref_code, probs, gt, sites.fwd_dp, sites.rev_dp,
+                                                              None if all_valid else sites.valid])
+    out = dict(pos=sites.pos, chunk=sites.chunk, ref=h_ref, probs=h_probs, gt=h_gt, dp=sites.dp, alt=sites.alt,
+               fwd_dp=h_fwd, rev_dp=h_rev)
+    if not all_valid:
+        m = h_valid.astype(bool)
+        out = {k: (v[m] if v is not None else None) for k, v in out.items()}
+    # host arrays keep the device dtypes (int32 / float32); freq = alt / n in float64 (:166)
+    out['freq'] = out['alt'].astype(np.float64) / out['dp'].astype(np.float64)
+    res.update(out, n=int(out['pos'].shape[0]), chunk_depth=chunk_depth)
     return res
 
 

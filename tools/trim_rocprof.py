@@ -7,7 +7,7 @@ import sys
 
 rows = list(csv.reader(open(sys.argv[1])))
 hdr, body = rows[0], rows[1:]
-pat = re.compile(r"\(anonymous namespace\)::(k2?_[a-z0-9_]+(<[^>]*>)?)")
+pat = re.compile(r"\(anonymous namespace\)::(k[0-9]?_[a-z0-9_]+(<[^>]*>)?)")
 ours, other = [], []
 for r in body:
     m = pat.search(r[0])
