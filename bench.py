@@ -134,16 +134,9 @@ def main():
     dt = time.perf_counter() - t0
     eng.enable_timing(False)
     n_sites = int(r["n"])
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ns = torch.tensor([n_sites], dtype=torch.int64, device="cuda")
-        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
-        total_sites = int(ns.item())
-    else:
-        total_sites = n_sites
+    from nanocaller_amd.shard import dist_max, dist_sum
+    dt = dist_max(dt)                       # MAX over ranks
+    total_sites = dist_sum(n_sites)         # whole-job aggregate
     stage_ms /= max(1, args.steps)
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -218,17 +218,31 @@ def _sort_key(line, order):
 
 def call_manager(params, devices=(0,)):
     """Same contract as snpCaller.call_manager (snpCaller.py:213-287): returns the PASS VCF path
-    <vcf_path>/<prefix>.snps.vcf.gz (also writes <prefix>.unfiltered.snps.vcf.gz)."""
+    <vcf_path>/<prefix>.snps.vcf.gz (also writes <prefix>.unfiltered.snps.vcf.gz).
+    Under torch.distributed (one process per GPU, e.g. torchrun) every rank calls this function: the chunk list
+    is sharded over the ranks, each rank writes its own worker file, rank 0 merges (other ranks return the path)."""
+    from . import shard
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
     chunks_Q = queue.Queue()
     counter_Q = queue.Queue()
     snp_files = []
-    for chunk in params['chunks_list']:
+    for chunk in shard.shard_chunks(params['chunks_list'], rank, world):
         chunks_Q.put(chunk)
     params['intermediate_snp_files_dir'] = os.path.join(params['vcf_path'], 'intermediate_snp_files')
-    if os.path.exists(params['intermediate_snp_files_dir']):
-        shutil.rmtree(params['intermediate_snp_files_dir'])
-    os.makedirs(params['intermediate_snp_files_dir'])
-    caller(params, chunks_Q, counter_Q, snp_files, device=devices[0])
+    if rank == 0:
+        if os.path.exists(params['intermediate_snp_files_dir']):
+            shutil.rmtree(params['intermediate_snp_files_dir'])
+        os.makedirs(params['intermediate_snp_files_dir'])
+    shard.barrier()
+    caller(params, chunks_Q, counter_Q, snp_files, device=devices[0], worker_id=rank + 1)
+    shard.barrier()
+    all_path_ = os.path.join(params['vcf_path'], '%s.snps.vcf.gz' % params['prefix'])
+    if rank != 0:
+        shard.barrier()
+        return all_path_
+    snp_files = [os.path.join(params['intermediate_snp_files_dir'], '%s.%d.snps.vcf' % (params['prefix'], r + 1))
+                 for r in range(world)]
     all_path = os.path.join(params['vcf_path'], '%s.unfiltered.snps.vcf.gz' % params['prefix'])
     pass_path = os.path.join(params['vcf_path'], '%s.snps.vcf.gz' % params['prefix'])
     if not params.get('suppress_progress'):
@@ -247,4 +261,5 @@ def call_manager(params, devices=(0,)):
     bgzf_write(all_path, (header + ''.join(lines)).encode())
     passed = [ln for ln in lines if ln.split('\t', 7)[6] == 'PASS']  # bcftools view -f PASS (:285)
     bgzf_write(pass_path, (header + ''.join(passed)).encode())
+    shard.barrier()
     return pass_path

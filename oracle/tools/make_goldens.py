@@ -255,9 +255,30 @@ def make_msa_goldens():
     print("msa cases:", k)
 
 
+def make_chunk_goldens():
+    """get_chunks (utils.py:67-83) on a few region lists; utils.py imports pysam at module top (stub)."""
+    import json
+
+    from nanocaller_src import utils as ref_utils
+    cases = []
+    for regions, cpu, kw in [
+        ([("chr22", 20000000, 21000000, "diploid")], 2, {}),
+        ([("chr22", 20000000, 21000000, "diploid")], 16, {}),
+        ([("chr20", 1, 64444167, "diploid")], 16, {}),
+        ([("chr1", 1, 248956422, "diploid"), ("chrX", 1, 156040895, "haploid"), ("chrM", 1, 16569, "haploid")], 8, {}),
+        ([("chr1", 1, 1234567, "diploid")], 3, dict(max_chunk_size=100000)),
+        ([("c", 5, 5, "diploid"), ("d", 10, 10010, "haploid")], 4, {}),
+    ]:
+        out = ref_utils.get_chunks(regions, cpu, **kw)
+        cases.append(dict(regions=[list(r) for r in regions], cpu=cpu, kw=kw, chunks=out))
+    with open(os.path.join(OUT, "chunks.json"), "w") as f:
+        json.dump(cases, f)
+    print("chunk cases:", len(cases), "total chunks", sum(len(c["chunks"]) for c in cases))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa"]
+    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks"]
     if "snp" in what:
         make_snp_goldens()
     if "cnd" in what:
@@ -266,3 +287,5 @@ if __name__ == "__main__":
         make_caller_goldens()
     if "msa" in what:
         make_msa_goldens()
+    if "chunks" in what:
+        make_chunk_goldens()

@@ -1,0 +1,84 @@
+"""CPU-only, world_size 2 over gloo: chunk sharding, scalar reductions and the file-based VCF gather used by
+the multi-GPU path.  The per-rank compute is stood in by the oracle (there is no GPU here); what is under test
+is the host logic that N>1 runs add."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from nanocaller_amd.shard import shard_chunks
+from nanocaller_amd.utils import get_chunks
+
+
+def test_shards_partition_the_chunk_list():
+    chunks = get_chunks([("chr1", 1, 248_956_422, "diploid"), ("chr2", 1, 242_193_529, "diploid"),
+                         ("chrM", 1, 16_569, "haploid")], cpu=16)
+    for world in (1, 2, 3, 8):
+        parts = [shard_chunks(chunks, r, world) for r in range(world)]
+        flat = [c for p in parts for c in p]
+        assert flat == chunks                                       # disjoint, complete, order-preserving, contiguous
+        if world > 1:
+            sizes = [sum(c['end'] - c['start'] for c in p) for p in parts]
+            assert max(sizes) < 1.25 * (sum(sizes) / world)         # balanced
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.shard import barrier, dist_max, dist_sum
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    from tests.util import load_world
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    world_ = load_world("ont")
+    chunks = get_chunks([(world_.chrom, 20_000, 120_000, "diploid")], cpu=5)
+    mine = shard_chunks(chunks, rank, world)
+    path, cov = get_SNP_model("ONT-HG002")
+    w = Weights(path)
+    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, seq="ont")
+    lines = []
+    for c in mine:
+        pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(world_, dct, c)
+        rc = np.argmax(ref, 1).astype(np.int32)
+        probs, _ = oracle.snp_forward(w.flat, mat[:40], rc[:40], cov / depth)      # a slice keeps the CPU test fast
+        lines += snpCaller.snp_vcf_lines(world_.chrom, pos[:40], rc[:40], probs, dp[:40], freq[:40], fwd[:40], rev[:40])
+    with open(os.path.join(tmpdir, "t.%d.snps.vcf" % (rank + 1)), "w") as f:
+        f.writelines(lines)
+    tmax = dist_max(1.0 + rank)
+    total = dist_sum(len(lines))
+    barrier()
+    if rank == 0:
+        with open(os.path.join(tmpdir, "result.txt"), "w") as f:
+            f.write("%g %d %d" % (tmax, total, len(chunks)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_run_matches_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    tmax, total, nchunks = open(os.path.join(str(tmp_path), "result.txt")).read().split()
+    assert float(tmax) == 2.0 and int(nchunks) >= 4
+    merged = []
+    for r in range(world):
+        merged += open(os.path.join(str(tmp_path), "t.%d.snps.vcf" % (r + 1))).readlines()
+    assert int(total) == len(merged) > 50
+    # single-process run of the same thing
+    port2 = _free_port()
+    single = tmp_path / "single"
+    single.mkdir()
+    mp.spawn(_worker, args=(1, port2, str(single)), nprocs=1, join=True)
+    ref = open(os.path.join(str(single), "t.1.snps.vcf")).readlines()
+    assert merged == ref                                             # contiguous shards => same order, same records

@@ -1,0 +1,82 @@
+"""CPU-only: the native host packer (nc_pack_plan / nc_pack_fill) -- slot alignment, padding, tile index."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nanocaller_amd import _lib
+from nanocaller_amd.pack import pack_world
+from nanocaller_amd.synth import FLAG_FILTER_DEFAULT, make_world
+from tests.util import load_world
+
+
+@pytest.mark.parametrize("tile_size", [1024, 2048, 4096])
+def test_pack_roundtrip(tile_size):
+    w = make_world(seed=3, length=30_000, depth=15, read_len_scale=0.2)
+    hp = pack_world(w, tile_size=tile_size)
+    assert hp.tile_pos0 % 16 == 0 and hp.tile_pos0 <= 1 and hp.codes.size % 16 == 0
+    keep = (w.read_flag & FLAG_FILTER_DEFAULT) == 0
+    ents = hp.tile_ent
+    # every kept read appears in exactly the tiles it overlaps, in coordinate order, with its codes recoverable
+    seen = {}
+    for t in range(hp.n_tiles):
+        lo = hp.tile_pos0 + t * tile_size
+        e = ents[hp.tile_off[t]:hp.tile_off[t + 1]]
+        assert np.all(e["start"] < lo + tile_size) and np.all(e["end"] > lo)
+        assert np.all(np.diff(e["start"]) >= 0)
+        for x in e:
+            seen.setdefault((int(x["start"]), int(x["end"]), int(x["base_flag"])), 0)
+            seen[(int(x["start"]), int(x["end"]), int(x["base_flag"]))] += 1
+    kept = np.nonzero(keep)[0]
+    assert len(seen) == len(kept)
+    by_key = {}
+    for k in seen:
+        by_key.setdefault((k[0], k[1]), []).append(k)
+    used = 0
+    for i in kept:
+        s, e = int(w.read_start[i]), int(w.read_end[i])
+        cands = by_key[(s, e)]
+        ok = False
+        for k in cands:
+            base = k[2] & ~15
+            assert base % 16 == 0
+            got = hp.codes[base + s:base + e]
+            if np.array_equal(got, w.read_codes(i)) and (k[2] & 1) == int((w.read_flag[i] & 16) != 0):
+                ok = True
+                # slot padding outside [start, end) is NC_CODE_ABSENT
+                lo16, hi16 = s & ~15, (e + 15) & ~15
+                assert np.all(hp.codes[base + lo16:base + s] == 7) and np.all(hp.codes[base + e:base + hi16] == 7)
+                ntiles = (e - 1 - hp.tile_pos0) // tile_size - (s - hp.tile_pos0) // tile_size + 1
+                assert seen[k] == ntiles
+        assert ok
+        used += e - s
+    assert int((hp.codes != 7).sum()) == used
+    # reference codes on the tile grid, soft-masked / N -> 4
+    assert hp.ref_code.size == hp.n_tiles * tile_size
+    from nanocaller_amd.synth import world_ref_codes
+    rc = world_ref_codes(w)
+    assert np.array_equal(hp.ref_code[1 - hp.tile_pos0:1 - hp.tile_pos0 + w.length], rc)
+    assert (rc == 4).sum() > 100
+
+
+def test_pack_rejects_unsorted_and_bad_args():
+    L = _lib.lib()
+    s = np.array([100, 50], np.int32)
+    e = np.array([200, 150], np.int32)
+    cl, ne = C.c_int64(), C.c_int64()
+    tp, nt = C.c_int32(), C.c_int32()
+    assert L.nc_pack_plan(2, _lib.npp(s), _lib.npp(e), None, 2048, 1, 1000, C.byref(cl), C.byref(tp), C.byref(nt), C.byref(ne)) == -1
+    s2 = np.array([50, 100], np.int32)
+    assert L.nc_pack_plan(2, _lib.npp(s2), _lib.npp(e[::-1].copy()), None, 1000, 1, 1000, C.byref(cl), C.byref(tp), C.byref(nt), C.byref(ne)) == -1
+    assert L.nc_pack_plan(2, _lib.npp(s2), _lib.npp(e[::-1].copy()), None, 2048, 1, 1000, C.byref(cl), C.byref(tp), C.byref(nt), C.byref(ne)) == 0
+    assert nt.value == 1 and ne.value == 2 and cl.value % 16 == 0
+
+
+def test_pack_exclusion_and_empty_region():
+    w = load_world("ont")
+    hp = pack_world(w, exclude=[(55_000, 58_000)])
+    assert np.all(hp.ref_code[55_000 - hp.tile_pos0:58_000 - hp.tile_pos0] == 4)
+    assert hp.ref_code[58_000 - hp.tile_pos0] != 4 or w.ref[58_000 - 1] not in "AGTC"
+    empty = make_world(seed=1, length=5000, depth=0.001, read_len_scale=0.05)
+    hp2 = pack_world(empty)
+    assert hp2.n_tiles >= 1 and hp2.tile_off[-1] == hp2.tile_ent.shape[0]
