@@ -11,6 +11,8 @@
 // weight: no LDS staging, no im2col, and the arithmetic is an fmaf chain in the reference's (tap, ci) order.
 // fp32 matrix and vector peaks are equal on gfx950 (157.3 TFLOP/s), so this VALU form has the same roof as
 // v_mfma_f32_* while keeping the weights out of the vector register file.
+#include <vector>
+
 #include "nc_common.h"
 
 namespace {
@@ -312,6 +314,172 @@ __global__ __launch_bounds__(256) void k3_fc1(const float *__restrict__ in, int 
     }
 }
 
+
+// ---- fused conv1 + conv2 for the SNP trunk (5x41x5 input): the 205x48 conv1 activation lives only in LDS.
+// Per site: (1) the input is staged, coverage-scaled, into a zero-padded [9][45][5] LDS image; (2) conv1 runs as
+// v_mfma_f32_16x16x4 over 13 tiles of 16 positions: K is laid out as 5 input rows x 28 (25 real (dx,ci) values, which
+// are CONTIGUOUS in the NHWC image, + 3 zero-weight slots) = 35 steps for the 5x5 kernel; the 1x5 kernel reuses the
+// A fragments of row dy=2 (7 more MFMAs), the 5x1 kernel those of steps ls=2,3 of every row (10 more MFMAs, zero
+// weights outside dx=2): 52 MFMAs per tile, 35 ds_read_b32; (3) conv2 (2x3, stride (1,2)) reads its A fragments from
+// the LDS activation with one ds_read_b128 per 4 MFMAs.  Weight (B) fragments are pre-packed in fragment order
+// (one coalesced 256-B read per MFMA).  lane l: A[row l&15][k l>>4], B[k l>>4][col l&15], C/D col l&15, row 4*(l>>4)+r.
+constexpr int F12_XP = 2032;             // padded input image (9*45*5 = 2025, +7 so zero-weight slots stay in range)
+constexpr int F12_CP = 52;               // channel pitch of the LDS activation (48 + 4: keeps ds_read_b128 aligned, spreads banks)
+constexpr int F12_W1P = 52 * 64;         // conv1 B fragments
+constexpr int F12_W2P = 6 * 3 * 4 * 2 * 64;
+constexpr int F12_PACKED = F12_W1P + 48 + F12_W2P + 32;
+
+template <int NT>
+__device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const float *__restrict__ w1p, const float *__restrict__ b1,
+                                               int tile_first, int lane)
+{
+    const int kq = lane >> 4, c16 = lane & 15;
+    int rowbase[NT];
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        int p = (tile_first + 4 * tm) * 16 + c16;
+        p = p < 205 ? p : 204;
+        const int h = p / 41, w = p - h * 41;
+        rowbase[tm] = (h * 45 + w) * 5 + kq;
+    }
+    f32x4v acc1[NT], acc2[NT], acc3[NT];
+    {
+        const float x1 = b1[c16], x2 = b1[16 + c16], x3 = b1[32 + c16];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) {
+            acc1[tm] = (f32x4v){x1, x1, x1, x1};
+            acc2[tm] = (f32x4v){x2, x2, x2, x2};
+            acc3[tm] = (f32x4v){x3, x3, x3, x3};
+        }
+    }
+#pragma unroll 1
+    for (int dy = 0; dy < 5; dy++) {
+#pragma unroll
+      for (int ls = 0; ls < 7; ls++) {
+        const int s = dy * 7 + ls;
+        float a[NT];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) a[tm] = Xp[rowbase[tm] + dy * 225 + 4 * ls];
+        const float w3 = w1p[s * 64 + lane];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) acc3[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w3, acc3[tm], 0, 0, 0);
+        if (dy == 2) {
+            const float w1 = w1p[(35 + ls) * 64 + lane];
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) acc1[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w1, acc1[tm], 0, 0, 0);
+        }
+        if (ls == 2 || ls == 3) {
+            const float w2 = w1p[(42 + dy * 2 + (ls - 2)) * 64 + lane];
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) acc2[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w2, acc2[tm], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pos = (tile_first + 4 * tm) * 16 + 4 * kq + r;
+            if (pos < 205) {
+                float *o = A1 + pos * F12_CP + c16;
+                o[0] = selu(acc1[tm][r]);
+                o[16] = selu(acc2[tm][r]);
+                o[32] = selu(acc3[tm][r]);
+            }
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void f12_conv2(const float *A1, const float *__restrict__ w2p, const float *__restrict__ b2,
+                                          float *__restrict__ out_site, int wv, int lane)
+{
+    const int kq = lane >> 4, c16 = lane & 15, tn = wv & 1, t0 = wv >> 1;
+    int abase[NT];
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        const int p = (t0 + 2 * tm) * 16 + c16;          // < 80
+        const int y = p / 20, x = p - y * 20;
+        abase[tm] = (y * 41 + 2 * x) * F12_CP + 4 * kq;
+    }
+    f32x4v acc[NT];
+    {
+        const float b = b2[tn * 16 + c16];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) acc[tm] = (f32x4v){b, b, b, b};
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < 6; tap++) {
+        const int toff = ((tap / 3) * 41 + (tap % 3)) * F12_CP;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float4 a[NT];
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) a[tm] = *reinterpret_cast<const float4 *>(A1 + abase[tm] + toff + 16 * j);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float b = w2p[((((tap * 3 + j) * 4 + i) * 2) + tn) * 64 + lane];
+#pragma unroll
+                for (int tm = 0; tm < NT; tm++) {
+                    const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[tm], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int po = (t0 + 2 * tm) * 16 + 4 * kq + r;
+            out_site[po * 32 + tn * 16 + c16] = selu(acc[tm][r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void k4_conv12(const float *__restrict__ x, const float *__restrict__ wp, float *__restrict__ a2,
+                                                 int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
+{
+    __shared__ __attribute__((aligned(16))) float Xp[F12_XP];
+    __shared__ __attribute__((aligned(16))) float A1[205 * F12_CP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float *w1p = wp, *b1 = wp + F12_W1P, *w2p = b1 + 48, *b2 = w2p + F12_W2P;
+    for (int i = threadIdx.x; i < F12_XP; i += 256) Xp[i] = 0.0f;
+    __syncthreads();
+    auto stage = [&](int64_t site) {
+        const float *xs = x + site * NC_SNP_TENSOR;
+        float sf = 1.0f;
+        double sd = 1.0;
+        if (scale) { sd = scale[site0 + site]; sf = (float)sd; }
+        for (int i = threadIdx.x; i < NC_SNP_TENSOR; i += 256) {
+            const int h = i / 205, rem = i - h * 205, w = rem / 5, c = rem - w * 5;
+            float v = xs[i];
+            if (scale && h > 0 && c < 4) v = scale_mode == 0 ? v * sf : (float)((double)v * sd);    // snpCaller.py:93-96
+            Xp[((h + 2) * 45 + (w + 2)) * 5 + c] = v;
+        }
+    };
+    int64_t site = blockIdx.x;
+    if (site < n_sites) stage(site);
+    __syncthreads();
+    for (; site < n_sites; site += gridDim.x) {
+        // compiler barrier: keeps the (loop-invariant) weight-fragment loads inside the iteration; hoisted, they
+        // would pin ~420 registers per lane and drop the kernel to one wave per SIMD
+        asm volatile("" ::: "memory");
+        // conv1: 13 tiles of 16 positions; wave w owns tiles w, w+4, w+8 (and 12 for wave 0)
+        f12_conv1_pass<2>(Xp, A1, w1p, b1, wv, lane);
+        if (wv == 0) f12_conv1_pass<2>(Xp, A1, w1p, b1, 8, lane);
+        else f12_conv1_pass<1>(Xp, A1, w1p, b1, 8 + wv, lane);
+        __syncthreads();
+        // the padded input is free again: stage the next site while conv2 runs out of A1
+        const int64_t nxt = site + gridDim.x;
+        if (nxt < n_sites) stage(nxt);
+        float *out_site = a2 + site * (80 * 32);
+        if (wv < 2) f12_conv2<3>(A1, w2p, b2, out_site, wv, lane);
+        else f12_conv2<2>(A1, w2p, b2, out_site, wv, lane);
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void dense_small(const float *in, int n_in, const float *k, const float *b, int n_out, float *out, bool act)
 {
     for (int o = 0; o < n_out; o++) {
@@ -406,12 +574,12 @@ inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + pe
 
 // conv trunk for `nb` sites -> fc1 activations [nb][F]; *f1_out / *tail receive the fc1 buffer and the tail weights
 template <int H, int W, int CI, int C1, int C2, int C3, int F, int P2, int P3, bool MFMA>
-int run_trunk(nc_ctx *ctx, const float *w, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
+int run_trunk(nc_ctx *ctx, const float *w, const float *packed, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
               const float **f1_out, const float **tail)
 {
     constexpr int H2 = H - 1, W2 = (W - 3) / 2 + 1, H3 = H2 - 1, W3 = (W2 - 3) / 2 + 1;
     constexpr int64_t n1 = (int64_t)H * W * 3 * C1, n2 = (int64_t)H2 * W2 * C2, n3 = (int64_t)H3 * W3 * C3;
-    NC_TRY(nc_ensure(ctx, ctx->cnn_a, (size_t)(nb * n1) * 4));
+    if constexpr (!MFMA) NC_TRY(nc_ensure(ctx, ctx->cnn_a, (size_t)(nb * n1) * 4));
     NC_TRY(nc_ensure(ctx, ctx->cnn_b, (size_t)(nb * n2) * 4));
     NC_TRY(nc_ensure(ctx, ctx->cnn_c, (size_t)(nb * (n3 + F)) * 4 + 64));
     float *a1 = (float *)ctx->cnn_a.p, *a2 = (float *)ctx->cnn_b.p, *a3 = (float *)ctx->cnn_c.p;
@@ -422,11 +590,14 @@ int run_trunk(nc_ctx *ctx, const float *w, int64_t site0, int64_t nb, const floa
     *tail = bf + F;
     *f1_out = f1;
     const int64_t np1 = nb * H * W, np2 = nb * H2 * W2, np3 = nb * H3 * W3;
-    hipLaunchKernelGGL((k2_conv1<H, W, CI, C1>), dim3(blocks_for(np1)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1, scale,
-                       scale_mode, site0);
+    if constexpr (!MFMA)
+        hipLaunchKernelGGL((k2_conv1<H, W, CI, C1>), dim3(blocks_for(np1)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1, scale,
+                           scale_mode, site0);
     if constexpr (MFMA) {
-        constexpr int TM2 = 4, TM3 = 2, TMF = 1;
-        hipLaunchKernelGGL((k3_conv23<H, W, 3 * C1, C2, TM2>), dim3(blocks_for(np2, 4 * 32 * TM2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
+        constexpr int TM3 = 2, TMF = 1;
+        (void)np2;
+        const unsigned nblk = (unsigned)(nb < 768 ? nb : 768);          // 3 resident workgroups per CU, persistent over sites
+        hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a2, nb, scale, scale_mode, site0);
         hipLaunchKernelGGL((k3_conv23<H2, W2, C2, C3, TM3>), dim3(blocks_for(np3, 4 * 32 * TM3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
         hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
     } else {
@@ -457,6 +628,43 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
     NC_HIP(ctx, hipMemcpyAsync(w.dev, blob_host, n_floats * 4, hipMemcpyHostToDevice, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     w.n = n_floats;
+    if (kind == NC_MODEL_SNP || kind == NC_MODEL_SNP_HAP) {
+        // B fragments of the fused conv1+conv2 kernel, in (step, lane) order
+        std::vector<float> pk((size_t)F12_PACKED, 0.0f);
+        const float *k11 = blob_host, *b11 = k11 + 400, *k12 = b11 + 16, *b12 = k12 + 400, *k13 = b12 + 16, *b13 = k13 + 2000;
+        const float *k2 = b13 + 16, *b2 = k2 + 2 * 3 * 48 * 32;
+        float *w1p = pk.data(), *b1 = w1p + F12_W1P, *w2p = b1 + 48, *b2p = w2p + F12_W2P;
+        for (int lane = 0; lane < 64; lane++) {
+            const int kq = lane >> 4, c = lane & 15;
+            for (int s = 0; s < 35; s++) {
+                const int dy = s / 7, kl = 4 * (s % 7) + kq;
+                if (kl < 25) w1p[s * 64 + lane] = k13[((dy * 5 + kl / 5) * 5 + kl % 5) * 16 + c];
+            }
+            for (int ls = 0; ls < 7; ls++) {
+                const int kl = 4 * ls + kq;
+                if (kl < 25) w1p[(35 + ls) * 64 + lane] = k11[kl * 16 + c];
+            }
+            for (int dy = 0; dy < 5; dy++)
+                for (int t = 0; t < 2; t++) {
+                    const int kl = 4 * (2 + t) + kq;
+                    if (kl >= 10 && kl < 15) w1p[(42 + dy * 2 + t) * 64 + lane] = k12[(dy * 5 + (kl - 10)) * 16 + c];
+                }
+            for (int tap = 0; tap < 6; tap++)
+                for (int j = 0; j < 3; j++)
+                    for (int i = 0; i < 4; i++)
+                        for (int tn = 0; tn < 2; tn++)
+                            w2p[((((tap * 3 + j) * 4 + i) * 2) + tn) * 64 + lane] = k2[(tap * 48 + 16 * j + 4 * kq + i) * 32 + tn * 16 + c];
+        }
+        for (int c = 0; c < 16; c++) { b1[c] = b11[c]; b1[16 + c] = b12[c]; b1[32 + c] = b13[c]; }
+        for (int c = 0; c < 32; c++) b2p[c] = b2[c];
+        if (!w.packed) {
+            hipError_t e = hipMalloc(&w.packed, pk.size() * 4);
+            if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed weights: %s", hipGetErrorString(e));
+        }
+        NC_HIP(ctx, hipMemcpyAsync(w.packed, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        w.n_packed = pk.size();
+    }
     return NC_OK;
 }
 
@@ -474,7 +682,7 @@ int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, con
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
-        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
+        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, ctx->w[kind].packed, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
                                                           &f1, &tail)));
         if (kind == NC_MODEL_SNP)
             hipLaunchKernelGGL(k_snp_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, ref_code_dev + s0, nb,
@@ -503,9 +711,9 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
         if (kind == NC_MODEL_INDEL)
-            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         else
-            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         hipLaunchKernelGGL(k_indel_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, nout, nb, probs_dev + s0 * nout);
         NC_HIP(ctx, hipGetLastError());
     }

@@ -140,13 +140,12 @@ class Engine:
                                        scan_hi, C.byref(params), len(chunks), _lib.npp(cs), _lib.npp(ce), C.byref(n_nbr),
                                        C.byref(n_cand), C.byref(n_sites)), "nc_snp_scan")
         N = n_sites.value
-        pos = np.empty(N, np.int32)
-        chunk = np.empty(N, np.int32)
-        n = np.empty(N, np.int32)
-        alt = np.empty(N, np.int32)
-        self._check(self.L.nc_snp_scan_fetch(self.ctx, None, _lib.npp(pos), _lib.npp(chunk), _lib.npp(n), _lib.npp(alt)),
-                    "nc_snp_scan_fetch")
-        return SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=pos, chunk=chunk, dp=n, alt=alt)
+        # pinned host buffers (cached by torch's host allocator): the four copies run at PCIe speed, one sync
+        hb = torch.empty((4, max(N, 1)), dtype=torch.int32, pin_memory=True)
+        ptr = [C.c_void_p(hb[i].data_ptr()) for i in range(4)]
+        self._check(self.L.nc_snp_scan_fetch(self.ctx, None, ptr[0], ptr[1], ptr[2], ptr[3]), "nc_snp_scan_fetch")
+        h = hb.numpy()
+        return SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=h[0, :N], chunk=h[1, :N], dp=h[2, :N], alt=h[3, :N])
 
     def fetch_nbr_sites(self, n_nbr) -> np.ndarray:
         out = np.empty(n_nbr, np.int32)
