@@ -330,7 +330,7 @@ constexpr int F12_W2P = 6 * 3 * 4 * 2 * 64;
 constexpr int F12_PACKED = F12_W1P + 48 + F12_W2P + 32;
 
 template <int NT>
-__device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const float *__restrict__ w1p, const float *__restrict__ b1,
+__device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const float (&w1r)[52], const float *__restrict__ b1,
                                                int tile_first, int lane)
 {
     const int kq = lane >> 4, c16 = lane & 15;
@@ -352,28 +352,23 @@ __device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const
             acc3[tm] = (f32x4v){x3, x3, x3, x3};
         }
     }
-#pragma unroll 1
-    for (int dy = 0; dy < 5; dy++) {
 #pragma unroll
-      for (int ls = 0; ls < 7; ls++) {
-        const int s = dy * 7 + ls;
+    for (int s = 0; s < 35; s++) {
+        const int dy = s / 7, ls = s % 7;
         float a[NT];
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) a[tm] = Xp[rowbase[tm] + dy * 225 + 4 * ls];
-        const float w3 = w1p[s * 64 + lane];
 #pragma unroll
-        for (int tm = 0; tm < NT; tm++) acc3[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w3, acc3[tm], 0, 0, 0);
+        for (int tm = 0; tm < NT; tm++) acc3[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w1r[s], acc3[tm], 0, 0, 0);
         if (dy == 2) {
-            const float w1 = w1p[(35 + ls) * 64 + lane];
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) acc1[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w1, acc1[tm], 0, 0, 0);
+            for (int tm = 0; tm < NT; tm++) acc1[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w1r[35 + ls], acc1[tm], 0, 0, 0);
         }
         if (ls == 2 || ls == 3) {
-            const float w2 = w1p[(42 + dy * 2 + (ls - 2)) * 64 + lane];
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) acc2[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w2, acc2[tm], 0, 0, 0);
+            for (int tm = 0; tm < NT; tm++)
+                acc2[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], w1r[42 + dy * 2 + (ls - 2)], acc2[tm], 0, 0, 0);
         }
-      }
     }
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
@@ -391,7 +386,7 @@ __device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const
 }
 
 template <int NT>
-__device__ __forceinline__ void f12_conv2(const float *A1, const float *__restrict__ w2p, const float *__restrict__ b2,
+__device__ __forceinline__ void f12_conv2(const float *A1, const float (&w2r)[72], const float *__restrict__ b2,
                                           float *__restrict__ out_site, int wv, int lane)
 {
     const int kq = lane >> 4, c16 = lane & 15, tn = wv & 1, t0 = wv >> 1;
@@ -408,7 +403,7 @@ __device__ __forceinline__ void f12_conv2(const float *A1, const float *__restri
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) acc[tm] = (f32x4v){b, b, b, b};
     }
-#pragma unroll 1
+#pragma unroll
     for (int tap = 0; tap < 6; tap++) {
         const int toff = ((tap / 3) * 41 + (tap % 3)) * F12_CP;
 #pragma unroll
@@ -418,11 +413,10 @@ __device__ __forceinline__ void f12_conv2(const float *A1, const float *__restri
             for (int tm = 0; tm < NT; tm++) a[tm] = *reinterpret_cast<const float4 *>(A1 + abase[tm] + toff + 16 * j);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float b = w2p[((((tap * 3 + j) * 4 + i) * 2) + tn) * 64 + lane];
 #pragma unroll
                 for (int tm = 0; tm < NT; tm++) {
                     const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[tm], 0, 0, 0);
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2r[(tap * 3 + j) * 4 + i], acc[tm], 0, 0, 0);
                 }
             }
         }
@@ -437,13 +431,21 @@ __device__ __forceinline__ void f12_conv2(const float *A1, const float *__restri
     }
 }
 
-__global__ __launch_bounds__(256, 3) void k4_conv12(const float *__restrict__ x, const float *__restrict__ wp, float *__restrict__ a2,
-                                                 int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
+// Weight-stationary and persistent: every wave loads its 52 conv1 and 72 conv2 weight fragments into registers ONCE
+// (124 VGPRs) and then walks sites; in steady state the only memory traffic is the 4.1 KB input tensor in, the 10 KB
+// conv2 activation out, and LDS.  Two workgroups (8 waves) per CU.
+__global__ __launch_bounds__(256, 2) void k4_conv12(const float *__restrict__ x, const float *__restrict__ wp, float *__restrict__ a2,
+                                                    int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
 {
     __shared__ __attribute__((aligned(16))) float Xp[F12_XP];
     __shared__ __attribute__((aligned(16))) float A1[205 * F12_CP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float *w1p = wp, *b1 = wp + F12_W1P, *w2p = b1 + 48, *b2 = w2p + F12_W2P;
+    float w1r[52], w2r[72];
+#pragma unroll
+    for (int s = 0; s < 52; s++) w1r[s] = w1p[s * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 72; s++) w2r[s] = w2p[(s * 2 + (wv & 1)) * 64 + lane];
     for (int i = threadIdx.x; i < F12_XP; i += 256) Xp[i] = 0.0f;
     __syncthreads();
     auto stage = [&](int64_t site) {
@@ -462,20 +464,17 @@ __global__ __launch_bounds__(256, 3) void k4_conv12(const float *__restrict__ x,
     if (site < n_sites) stage(site);
     __syncthreads();
     for (; site < n_sites; site += gridDim.x) {
-        // compiler barrier: keeps the (loop-invariant) weight-fragment loads inside the iteration; hoisted, they
-        // would pin ~420 registers per lane and drop the kernel to one wave per SIMD
-        asm volatile("" ::: "memory");
         // conv1: 13 tiles of 16 positions; wave w owns tiles w, w+4, w+8 (and 12 for wave 0)
-        f12_conv1_pass<2>(Xp, A1, w1p, b1, wv, lane);
-        if (wv == 0) f12_conv1_pass<2>(Xp, A1, w1p, b1, 8, lane);
-        else f12_conv1_pass<1>(Xp, A1, w1p, b1, 8 + wv, lane);
+        f12_conv1_pass<2>(Xp, A1, w1r, b1, wv, lane);
+        if (wv == 0) f12_conv1_pass<2>(Xp, A1, w1r, b1, 8, lane);
+        else f12_conv1_pass<1>(Xp, A1, w1r, b1, 8 + wv, lane);
         __syncthreads();
         // the padded input is free again: stage the next site while conv2 runs out of A1
         const int64_t nxt = site + gridDim.x;
         if (nxt < n_sites) stage(nxt);
         float *out_site = a2 + site * (80 * 32);
-        if (wv < 2) f12_conv2<3>(A1, w2p, b2, out_site, wv, lane);
-        else f12_conv2<2>(A1, w2p, b2, out_site, wv, lane);
+        if (wv < 2) f12_conv2<3>(A1, w2r, b2, out_site, wv, lane);
+        else f12_conv2<2>(A1, w2r, b2, out_site, wv, lane);
         __syncthreads();
     }
 }
@@ -596,7 +595,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, int64_t site0, i
     if constexpr (MFMA) {
         constexpr int TM3 = 2, TMF = 1;
         (void)np2;
-        const unsigned nblk = (unsigned)(nb < 768 ? nb : 768);          // 3 resident workgroups per CU, persistent over sites
+        const unsigned nblk = (unsigned)(nb < 512 ? nb : 512);          // 2 resident workgroups per CU, persistent over sites
         hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a2, nb, scale, scale_mode, site0);
         hipLaunchKernelGGL((k3_conv23<H2, W2, C2, C3, TM3>), dim3(blocks_for(np3, 4 * 32 * TM3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
         hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
