@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CHR20_LEN = 64_444_167                 # GRCh38 chr20
-SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3
+SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3 (haploid model: 3,453,696)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--tech", default="ont", choices=["ont", "hifi"])
     ap.add_argument("--model", default="ONT-HG002")
+    ap.add_argument("--ploidy", default="diploid", choices=["diploid", "haploid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=4)
     return ap.parse_args()
@@ -59,7 +60,10 @@ def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
     hi = sample[-1]["end"] + 50_000
     h = host_sample_for_oracle(pack, info, lo, hi)
     rr = oracle.RawReads("chr20", h["L"], h["start"], h["end"], h["off"], h["codes"], h["strand"], h["keep"])
-    path, cov = get_SNP_model(model)
+    hap = sample[0]["ploidy"] == "haploid"
+    path, cov = get_SNP_model("haploid" if hap else model)
+    if hap:
+        cov = 30.0                                              # hap_train_coverage, snpCaller.py:73
     w = Weights(path)
     oracle.lib()
     cores = min(len(sample), os.cpu_count() or 1)
@@ -67,7 +71,10 @@ def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
     def one(c):
         pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
         rc = np.argmax(ref, 1).astype(np.int32)
-        probs, gt = oracle.snp_forward(w.flat, mat, rc, np.full(len(pos), cov / depth), precision="f32")
+        if hap:
+            probs = oracle.snp_hap_forward(w.flat, mat, rc, np.full(len(pos), cov / depth), precision="f32")
+        else:
+            probs, _ = oracle.snp_forward(w.flat, mat, rc, np.full(len(pos), cov / depth), precision="f32")
         return pos, probs, dp
 
     t0 = time.perf_counter()
@@ -106,7 +113,7 @@ def main():
     t_gen = time.perf_counter()
     pack, info = make_device_workload(eng, L, depth=args.depth, tech=args.tech, seed=812 + rank)
     t_gen = time.perf_counter() - t_gen
-    chunks = get_chunks([("chr20", 1, L, "diploid")], cpu=16)      # 16 = the reference's documented example (--cpu 16)
+    chunks = get_chunks([("chr20", 1, L, args.ploidy)], cpu=16)      # 16 = the reference's documented example (--cpu 16)
     params = dict(mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
                   snp_model=args.model, seq="ont" if args.tech == "ont" else "pacbio", supplementary=False,
                   exclude_bed=None, disable_coverage_normalization=False, sam_path=None)
@@ -148,8 +155,8 @@ def main():
             "metric": "candidate sites/sec (pileup+CNN)", "value": value, "unit": "sites/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx, chr20-sized contig (%d bp, %d chunks of 500 kb) per GPU"
-                       % (args.tech.upper(), args.depth, L, len(chunks)), "sites_per_gpu": n_sites,
+            "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx %s, chr20-sized contig (%d bp, %d chunks of 500 kb) per GPU"
+                       % (args.tech.upper(), args.depth, args.ploidy, L, len(chunks)), "sites_per_gpu": n_sites,
                        "pileup_entries_per_gpu": info["pileup_entries"], "model": args.model, "generator": "synth_v1 seed 812+rank",
                        "data_gen_s": round(t_gen, 2)},
             "roofline": {"bound": "mfma", "kernel": "SNP CNN forward (fp32)", "achieved": cnn_tflops,

@@ -39,6 +39,7 @@ struct nc_ctx {
     DevBuf totals;                                        // int32[4]: n_nbr, n_cand, n_sites
     DevBuf cnn_a, cnn_b, cnn_c;                           // CNN intermediates
     DevBuf chunk_depth;                                   // double per chunk
+    DevBuf nbr_idx;                                       // coarse index over nbr_pos
     int32_t n_nbr = 0, n_cand = 0, n_sites = 0, n_chunks = 0;
     bool have_scan = false;
 

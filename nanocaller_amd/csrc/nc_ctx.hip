@@ -61,7 +61,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
                       &ctx->tile_pre, &ctx->nbr_pos, &ctx->cand_pos, &ctx->cand_n, &ctx->cand_alt,
                       &ctx->chunk_start, &ctx->chunk_end, &ctx->chunk_lo, &ctx->chunk_cnt, &ctx->chunk_off,
                       &ctx->site_pos, &ctx->site_chunk, &ctx->site_n, &ctx->site_alt, &ctx->totals,
-                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth};
+                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth, &ctx->nbr_idx};
     for (DevBuf *b : bufs) freebuf(*b);
     for (auto &w : ctx->w) {
         if (w.dev) (void)hipFree(w.dev);

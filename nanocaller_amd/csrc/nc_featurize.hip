@@ -26,9 +26,19 @@ __constant__ ModeTab MODES[5] = {
     {4, 20000, {{0, 2000, 4, 1}, {2000, 5000, 5, 0}, {5000, 10000, 5, 0}, {10000, 20000, 6, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}},
 };
 
-__device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int64_t key)
+constexpr int NBR_IDX_SHIFT = 10;   // coarse index granularity: first neighbour site >= every 1024th position
+
+__device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int64_t key, const int32_t *cidx, int32_t cidx_pos0, int n_cidx)
 {
     int lo = 0, hi = n;
+    // narrow [lo, hi) with the coarse index: cidx[b] = lower_bound(a, cidx_pos0 + (b << 10))
+    const int64_t rel = key - cidx_pos0;
+    if (rel <= 0) hi = cidx[0];
+    else {
+        const int64_t b = rel >> NBR_IDX_SHIFT;
+        if (b >= n_cidx - 1) lo = cidx[n_cidx - 1];
+        else { lo = cidx[b]; hi = cidx[b + 1]; }
+    }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if ((int64_t)a[mid] < key) lo = mid + 1; else hi = mid;
@@ -45,6 +55,8 @@ struct FeatArgs {
     int32_t ref_pos0;
     const int32_t *nbr_pos;
     int32_t n_nbr;
+    const int32_t *cidx;
+    int32_t cidx_pos0, n_cidx;
     const int32_t *site_pos, *site_chunk;
     const int32_t *chunk_start, *chunk_end;
     int32_t n_sites, mode, maxcov, min_nbr_sites;
@@ -58,7 +70,11 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     __shared__ __attribute__((aligned(16))) float sm[4][NC_SNP_TENSOR + 3];
     __shared__ int32_t slist[4][MAXCOV_CAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int s = blockIdx.x * 4 + wv;
+    // XCD-aware mapping (workgroup b runs on XCD b % 8): each XCD walks ONE contiguous range of position-sorted
+    // sites, so its private L2 holds one genomic neighbourhood instead of all eight sharing every line.
+    const int nblk = (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int s = blk * 4 + wv;
     float *X = sm[wv];
     for (int i = lane; i < NC_SNP_TENSOR; i += 64) X[i] = 0.0f;
 
@@ -82,8 +98,8 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
             pmin = max(pmin, win_lo);
             pmax = min(pmax, win_hi);
             if (pmin <= pmax) {
-                const int lo = lower_bound_i32(a.nbr_pos, a.n_nbr, pmin);
-                const int hi = lower_bound_i32(a.nbr_pos, a.n_nbr, pmax + 1);
+                const int lo = lower_bound_i32(a.nbr_pos, a.n_nbr, pmin, a.cidx, a.cidx_pos0, a.n_cidx);
+                const int hi = lower_bound_i32(a.nbr_pos, a.n_nbr, pmax + 1, a.cidx, a.cidx_pos0, a.n_cidx);
                 const int m = hi - lo;
                 take = min(m, B.k);
                 // ascending order: on the left the farthest are first, on the right the farthest are last
@@ -152,16 +168,29 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
         // ---- K3: lane j gathers column j of every sampled read
         unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
         if (ok) {
-#pragma unroll 4
-            for (int i = 0; i < ns; i++) {
-                const int e = slist[wv][i];
-                const nc_tile_entry ent = a.tile_ent[e];
-                int b = 4;
-                if (active && ent.start <= col && col < ent.end) b = a.codes[(ent.base_flag & ~int64_t(15)) + col];
-                const int c = __shfl(b, nl, 64);                 // centre base of this read
-                const unsigned long long inc = b < 4 ? (1ull << (16 * b)) : 0ull;
+            for (int i0 = 0; i0 < ns; i0 += 8) {
+                // 8 reads per round: all entry loads, then all code gathers, are issued before the first use
+                nc_tile_entry ent[8];
+                int bcode[8];
 #pragma unroll
-                for (int k = 0; k < 4; k++) cnt[k] += (c == k) ? inc : 0ull;
+                for (int u = 0; u < 8; u++) {
+                    const int e = slist[wv][min(i0 + u, ns - 1)];
+                    ent[u] = a.tile_ent[e];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    bcode[u] = 4;
+                    if (active && i0 + u < ns && ent[u].start <= col && col < ent[u].end)
+                        bcode[u] = a.codes[(ent[u].base_flag & ~int64_t(15)) + col];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int b = bcode[u];
+                    const int c = __shfl(b, nl, 64);                 // centre base of this read (4 if past the end)
+                    const unsigned long long inc = b < 4 ? (1ull << (16 * b)) : 0ull;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) cnt[k] += (c == k) ? inc : 0ull;
+                }
             }
             // ---- assemble (Appendix A step 5)
             if (active) {
@@ -192,7 +221,7 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     }
     __syncthreads();
     // coalesced store of up to four site tensors
-    const int s0 = blockIdx.x * 4;
+    const int s0 = blk * 4;
     const int nsite = min(4, a.n_sites - s0);
     float *dst = a.x + (int64_t)s0 * NC_SNP_TENSOR;
     if (nsite == 4) {
@@ -209,6 +238,20 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     } else {
         for (int i = threadIdx.x; i < nsite * NC_SNP_TENSOR; i += 256) dst[i] = sm[i / NC_SNP_TENSOR][i % NC_SNP_TENSOR];
     }
+}
+
+// coarse index over the sorted neighbour sites: cidx[b] = lower_bound(nbr_pos, pos0 + b*1024)
+__global__ void k_nbr_index(const int32_t *__restrict__ nbr_pos, int n_nbr, int32_t pos0, int n_cidx, int32_t *__restrict__ cidx)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_cidx) return;
+    const int64_t key = (int64_t)pos0 + ((int64_t)b << NBR_IDX_SHIFT);
+    int lo = 0, hi = n_nbr;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)nbr_pos[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    cidx[b] = lo;
 }
 
 // per-chunk mean sampled depth (generate_SNP_pileups.py:274) and per-site scale (snpCaller.py:93-96)
@@ -267,6 +310,11 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     a.ref_pos0 = ref_pos0;
     a.nbr_pos = (const int32_t *)ctx->nbr_pos.p;
     a.n_nbr = ctx->n_nbr;
+    const int n_cidx = (int)(((int64_t)pack->n_tiles * pack->tile_size) >> NBR_IDX_SHIFT) + 2;
+    NC_TRY(nc_ensure(ctx, ctx->nbr_idx, (size_t)n_cidx * 4));
+    a.cidx = (const int32_t *)ctx->nbr_idx.p;
+    a.cidx_pos0 = pack->tile_pos0;
+    a.n_cidx = n_cidx;
     a.site_pos = (const int32_t *)ctx->site_pos.p;
     a.site_chunk = (const int32_t *)ctx->site_chunk.p;
     a.chunk_start = (const int32_t *)ctx->chunk_start.p;
@@ -282,6 +330,8 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     a.depth = site_depth_dev;
     a.valid = valid_dev;
     NcTimer tm(ctx, 1);
+    hipLaunchKernelGGL(k_nbr_index, dim3((n_cidx + 255) / 256), dim3(256), 0, ctx->stream, a.nbr_pos, a.n_nbr, a.cidx_pos0, n_cidx,
+                       (int32_t *)ctx->nbr_idx.p);
     hipLaunchKernelGGL(k_featurize, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
     NC_HIP(ctx, hipGetLastError());
     tm.stop();
