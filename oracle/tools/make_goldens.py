@@ -255,6 +255,94 @@ def make_msa_goldens():
     print("msa cases:", k)
 
 
+def make_indel_caller_goldens():
+    """Run the reference's indel_run() (indelCaller.py:41-189) with TensorFlow stubbed, canned probabilities and
+    canned candidate tuples; capture the VCF lines."""
+    import queue
+
+    from nanocaller_src import indelCaller as ref_ic
+
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 330                                   # > 3 batches of 100: `prev` carries across batches
+    bases = "ACGT"
+
+    def rs(k):
+        return "".join(bases[i] for i in rng.integers(0, 4, size=k))
+
+    def allele():
+        u = rng.random()
+        if u < 0.35:
+            return (None, None)
+        ref = rs(int(rng.integers(1, 8)))
+        alt = ref[0] + rs(int(rng.integers(0, 6))) if rng.random() < 0.5 else ref[:max(1, len(ref) - int(rng.integers(0, 4)))]
+        return (ref, alt)
+
+    pos = np.sort(rng.choice(np.arange(100, 4000), size=n, replace=False)).tolist()
+    probs = rng.dirichlet(np.ones(4) * 0.4, size=n).astype(np.float32)
+    probs[::9] = np.float32([0.97, 0.01, 0.01, 0.01])                 # hom-ref > 0.95: skipped
+    alleles = []
+    for j in range(n):
+        a0, a1, at = allele(), allele(), allele()
+        if j % 11 == 0 and a0[0]:
+            a1 = a0                                                   # identical haplotype alleles -> 1/1
+        alleles.append([a0, a1, at])
+    phase = [None if rng.random() < 0.4 else int(rng.integers(1000, 99999)) for _ in range(n)]
+    x = np.zeros((n, 5, 128, 2))
+    hap_probs = rng.random((n, 1)).astype(np.float32)
+    hap_alleles = [a[2] for a in alleles]
+    state = {"i": 0}
+
+    class FakeModel:
+        def load_weights(self, p):
+            return self
+
+        def expect_partial(self):
+            return self
+
+        def build(self, input_shape=None):
+            return None
+
+    class FakeDip(FakeModel):
+        def __call__(self, xb):
+            b = len(xb)
+            i = state["i"]
+            state["i"] += b
+            return probs[i:i + b]
+
+    class FakeHap(FakeModel):
+        def __call__(self, xb):
+            b = len(xb)
+            i = state["i"]
+            state["i"] += b
+            return hap_probs[i:i + b]
+
+    class P:
+        _identity = (1,)
+
+    ref_ic.Indel_model = FakeDip
+    ref_ic.haploid_Indel_model = FakeHap
+    ref_ic.get_indel_model = lambda name: "x"
+    ref_ic.current_process = lambda: P
+    ref_ic.get_indel_testing_candidates = lambda params, chunk: (pos, x, x, x, alleles, phase)
+    ref_ic.get_indel_testing_candidates_haploid = lambda params, chunk: (pos, x, hap_alleles)
+    out = {}
+    tmpdir = "/tmp/nc_gold_indel"
+    os.makedirs(tmpdir, exist_ok=True)
+    for ploidy in ("diploid", "haploid"):
+        state["i"] = 0
+        q = queue.Queue()
+        q.put(("indel", dict(chrom="chr20", start=1, end=5000, ploidy=ploidy)))
+        files = []
+        ref_ic.indel_run(dict(intermediate_indel_files_dir=tmpdir, prefix="g" + ploidy, indel_model="ONT-HG002"), {}, q,
+                         queue.Queue(), files)
+        txt = open(files[0]).read()
+        out["vcf_" + ploidy] = np.array(txt)
+        print("indel_run", ploidy, txt.count("\n"), "lines")
+    import json
+    np.savez_compressed(os.path.join(OUT, "indel_caller_vcf.npz"), pos=np.array(pos), probs=probs, hap_probs=hap_probs,
+                        alleles=np.array(json.dumps(alleles)), phase=np.array(json.dumps(phase)), **out)
+
+
 def make_chunk_goldens():
     """get_chunks (utils.py:67-83) on a few region lists; utils.py imports pysam at module top (stub)."""
     import json
@@ -278,7 +366,7 @@ def make_chunk_goldens():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks"]
+    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller"]
     if "snp" in what:
         make_snp_goldens()
     if "cnd" in what:
@@ -289,3 +377,5 @@ if __name__ == "__main__":
         make_msa_goldens()
     if "chunks" in what:
         make_chunk_goldens()
+    if "indel_caller" in what:
+        make_indel_caller_goldens()
