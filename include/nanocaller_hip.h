@@ -77,7 +77,8 @@ int nc_enable_timing(nc_ctx *ctx, int on);
 typedef struct {
     int32_t start;      /* first covered position (1-based) */
     int32_t end;        /* one past the last covered position */
-    int64_t base_flag;  /* (base & ~15) | flags; bit0 = reverse strand ((flag & 0x910)/16, :143) */
+    int64_t base_flag;  /* (base & ~15) | flags; bit0 = reverse strand ((flag & 0x910)/16, :143);
+                           bits 1-2 = haplotype tag HP (0 untagged, 1, 2; generate_indel_pileups.py:180-185) */
 } nc_tile_entry;
 
 typedef struct {
@@ -93,7 +94,7 @@ typedef struct {
 
 /* Host-side packer.  Inputs (host): n reads in coordinate order, read r covers [start[r], end[r]) and
  * codes_in[off[r] + p - start[r]] is its code (0..4) at p; keep[r]==0 drops the read (pileup flag filter
- * 0x4|0x100|0x200|0x400|0x800, generate_SNP_pileups.py:151-157); strand[r] != 0 = reverse.
+ * 0x4|0x100|0x200|0x400|0x800, generate_SNP_pileups.py:151-157); strand[r] bit0 = reverse strand, bits 1-2 = HP tag.
  * Step 1 sizes the outputs; step 2 fills caller-allocated host buffers.  With codes_in == codes_out == NULL
  * nc_pack_fill builds the tile index only (slot r starts at byte sum_{q<r} slot_size(q), kept reads only). */
 int nc_pack_plan(int32_t n_reads, const int32_t *start, const int32_t *end, const uint8_t *keep,
@@ -184,6 +185,34 @@ int nc_indel_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_
 int nc_indel_tensor(nc_ctx *ctx, int32_t n_sets, const uint8_t *rows_dev, const int64_t *row_off_dev,
                     const int32_t *n_rows_dev, const int32_t *n_cols_dev, const uint8_t *ref_rows_dev,
                     const int64_t *ref_off_dev, int32_t max_cols, float *x_dev, uint8_t *cns_dev);
+
+/* ------------------------------------------------------------------ indel candidate window scan (K7)
+ * Replaces pass 1 of get_indel_testing_candidates (generate_indel_pileups.py:197-276; the impute_indel_phase
+ * branch :278-304 is not covered): for every column of [start, end] the number of haplotype-1 / haplotype-2 reads
+ * and, per haplotype, the number of DISTINCT reads carrying a long (2 < L <= 50) / small (L <= 10) insertion /
+ * deletion marker within the last win_size / small_win_size yielded columns; col_type[v - start] receives the
+ * decision of :266-275 for that column taken in isolation: 0 (long-window rule), 1 (small-window rule), -1 (none,
+ * or the column is not evaluated: zero depth, excluded, or a haplotype below mincov).  The order-dependent
+ * suppression `v <= prev` (:249) is a scalar recurrence over the few flagged columns and stays with the caller.
+ * Events are read-major for the KEPT reads in pack order: read r owns ev_pos/ev_len[ev_off[r] .. ev_off[r+1]),
+ * ascending positions; ev_pos = the column whose pileup string carries the '+n' / '-n' marker, ev_len > 0 insertion,
+ * < 0 deletion.  excl (optional, on the pack's tile grid like ref_code) != 0 skips the column (ex_bed, :217).
+ */
+typedef struct {
+    int32_t n_reads;
+    const int32_t *ev_off;   /* dev [n_reads+1] */
+    const int32_t *ev_pos;   /* dev */
+    const int32_t *ev_len;   /* dev */
+    const uint8_t *read_hap; /* dev [n_reads] 0/1/2 */
+} nc_indel_events;
+
+typedef struct {
+    int32_t mincov, win_size, small_win_size;   /* dct['mincov'], dct['win_size'], dct['small_win_size'] */
+    double ins_t, del_t;                        /* dct['ins_t'], dct['del_t'] */
+} nc_indel_scan_params;
+
+int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
+                  int32_t start, int32_t end, const nc_indel_scan_params *params, int8_t *col_type_host);
 
 #ifdef __cplusplus
 }

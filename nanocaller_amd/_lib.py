@@ -25,7 +25,7 @@ EXPORTS = [
     "nc_abi_version", "nc_device_count", "nc_ctx_create", "nc_ctx_destroy", "nc_ctx_set_stream", "nc_ctx_sync",
     "nc_last_error", "nc_malloc", "nc_free", "nc_memcpy_h2d", "nc_memcpy_d2h", "nc_last_kernel_ms",
     "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
-    "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor",
+    "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
 ]
 
 
@@ -45,6 +45,16 @@ class ReadPackC(C.Structure):
 class ScanParamsC(C.Structure):
     _fields_ = [("mincov", C.c_int32), ("min_allele_freq", C.c_double), ("nbr_t0", C.c_double), ("nbr_t1", C.c_double),
                 ("haploid", C.c_int32)]
+
+
+class IndelEventsC(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("ev_off", C.c_void_p), ("ev_pos", C.c_void_p), ("ev_len", C.c_void_p),
+                ("read_hap", C.c_void_p)]
+
+
+class IndelScanParamsC(C.Structure):
+    _fields_ = [("mincov", C.c_int32), ("win_size", C.c_int32), ("small_win_size", C.c_int32), ("ins_t", C.c_double),
+                ("del_t", C.c_double)]
 
 
 _lib = None
@@ -89,6 +99,7 @@ def lib():
         L.nc_snp_forward.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp]
         L.nc_indel_forward.argtypes = [vp, i32, i64, vp, vp]
         L.nc_indel_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.nc_indel_scan.argtypes = [vp, C.POINTER(ReadPackC), C.POINTER(IndelEventsC), vp, i32, i32, C.POINTER(IndelScanParamsC), vp]
         for name in EXPORTS:
             fn = getattr(L, name)
             if name not in ("nc_last_error",):

@@ -40,6 +40,7 @@ struct nc_ctx {
     DevBuf cnn_a, cnn_b, cnn_c;                           // CNN intermediates
     DevBuf chunk_depth;                                   // double per chunk
     DevBuf nbr_idx;                                       // coarse index over nbr_pos
+    DevBuf indel_ws;                                      // indel window-scan workspace
     int32_t n_nbr = 0, n_cand = 0, n_sites = 0, n_chunks = 0;
     bool have_scan = false;
 

@@ -61,7 +61,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
                       &ctx->tile_pre, &ctx->nbr_pos, &ctx->cand_pos, &ctx->cand_n, &ctx->cand_alt,
                       &ctx->chunk_start, &ctx->chunk_end, &ctx->chunk_lo, &ctx->chunk_cnt, &ctx->chunk_off,
                       &ctx->site_pos, &ctx->site_chunk, &ctx->site_n, &ctx->site_alt, &ctx->totals,
-                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth, &ctx->nbr_idx};
+                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth, &ctx->nbr_idx, &ctx->indel_ws};
     for (DevBuf *b : bufs) freebuf(*b);
     for (auto &w : ctx->w) {
         if (w.dev) (void)hipFree(w.dev);
@@ -206,7 +206,7 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
         nc_tile_entry e;
         e.start = start[r];
         e.end = end[r];
-        e.base_flag = base | ((strand && strand[r]) ? 1 : 0);
+        e.base_flag = base | (strand ? (strand[r] & 7) : 0);          // bit0 reverse strand, bits 1-2 HP tag
         int64_t a = std::max<int64_t>(start[r], t0), b = std::min<int64_t>((int64_t)end[r] - 1, t0 + (int64_t)n_tiles * tile_size - 1);
         if (a > b) continue;
         for (int64_t t = (a - t0) / tile_size; t <= (b - t0) / tile_size; t++) tile_ent[cur[(size_t)t]++] = e;

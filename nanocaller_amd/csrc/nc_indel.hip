@@ -77,3 +77,255 @@ extern "C" int nc_indel_tensor(nc_ctx *ctx, int32_t n_sets, const uint8_t *rows_
     tm.stop();
     return NC_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7: indel candidate window scan (pass 1 of get_indel_testing_candidates, reference generate_indel_pileups.py:197-276)
+namespace {
+
+__device__ __forceinline__ uint32_t lut8i(uint32_t x, uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, x); }
+
+// per-column depth by haplotype tag; same access scheme as k_scan (one aligned dwordx4 of codes per read and lane)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_hap_depth(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
+                                                     const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0, int32_t tile_first,
+                                                     int32_t lo, int32_t hi, int32_t *__restrict__ depth /* [3][ncol] */, int32_t ncol)
+{
+    constexpr int TILE = BLOCK * 16;
+    const int t = tile_first + blockIdx.x;
+    const int32_t P0 = tile_pos0 + t * TILE + threadIdx.x * 16;
+    uint32_t acc[3][4], wide[3][8];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) acc[c][d] = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) wide[c][d] = 0;
+    }
+    const int e0 = tile_off[t], e1 = tile_off[t + 1];
+    int e = e0;
+    while (e < e1) {
+        const int lim = min(e1, e + 255);
+        for (; e < lim; e++) {
+            const nc_tile_entry ent = tile_ent[e];
+            const int32_t slo = ent.start & ~15, shi = (ent.end + 15) & ~15;
+            uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+            if (P0 >= slo && P0 < shi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
+            const int hp = (int)((ent.base_flag >> 1) & 3);           // wave-uniform
+            const int plane = hp == 1 ? 0 : hp == 2 ? 1 : 2;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t pres = lut8i(w[d], 0x01010101u, 0x00000001u);      // codes 0..4 -> 1
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[c][d] += plane == c ? pres : 0u;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                wide[c][2 * d] += acc[c][d] & 0x00FF00FFu;
+                wide[c][2 * d + 1] += (acc[c][d] >> 8) & 0x00FF00FFu;
+                acc[c][d] = 0;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int32_t p = P0 + i;
+        if (p < lo || p > hi) continue;
+        const int d = i >> 2, k = i & 3, wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
+#pragma unroll
+        for (int c = 0; c < 3; c++) depth[(int64_t)c * ncol + (p - lo)] = (int32_t)((wide[c][wi] >> sh) & 0xFFFF);
+    }
+}
+
+// single-workgroup exclusive scan of the "column is yielded" flag -> rank among yielded columns; ny at rank[ncol]
+__global__ __launch_bounds__(1024) void k_yield_rank(const int32_t *__restrict__ depth, const uint8_t *__restrict__ excl, int32_t excl_off,
+                                                     int32_t ncol, int32_t *__restrict__ rank)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < ncol; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = 0;
+        if (i < ncol) {
+            const int tot = depth[i] + depth[ncol + i] + depth[2 * (int64_t)ncol + i];
+            v = tot > 0 && !(excl && excl[excl_off + i]);
+        }
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int wp = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            const int s = wsum[w];
+            if (w < wv) wp += s;
+            tot += s;
+        }
+        const int c = carry;
+        if (i < ncol) rank[i] = v ? c + wp + inc - v : -1;           // -1: not yielded
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rank[ncol] = carry;
+}
+
+// one thread per kept read: merge the window-end intervals [e, e+w-1] of its qualifying events (a read counts once per
+// window, set-union semantics of :254-264) and add them to the per-(class, haplotype) difference arrays
+__global__ void k_event_intervals(int32_t n_reads, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
+                                  const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
+                                  const int32_t *__restrict__ rank, int32_t lo, int32_t hi, int32_t win, int32_t small_win,
+                                  int32_t *__restrict__ diff /* [8][nd] */, int32_t nd)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int hp = read_hap[r];
+    if (hp != 1 && hp != 2) return;
+    const int h = hp - 1;
+    int cur_lo[4] = {-1, -1, -1, -1}, cur_hi[4] = {-1, -1, -1, -1};
+    for (int e = ev_off[r]; e < ev_off[r + 1]; e++) {
+        const int32_t p = ev_pos[e];
+        if (p < lo || p > hi) continue;
+        const int k = rank[p - lo];
+        if (k < 0) continue;                                          // excluded column
+        const int32_t sl = ev_len[e], ln = sl < 0 ? -sl : sl;
+        const bool ins = sl > 0;
+#pragma unroll
+        for (int cls = 0; cls < 4; cls++) {
+            const bool q = cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
+            if (!q) continue;
+            const int w = cls < 2 ? win : small_win;
+            if (cur_lo[cls] >= 0 && k <= cur_hi[cls]) cur_hi[cls] = k + w - 1;
+            else {
+                if (cur_lo[cls] >= 0) {
+                    atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_lo[cls]], 1);
+                    atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_hi[cls] + 1], -1);
+                }
+                cur_lo[cls] = k;
+                cur_hi[cls] = k + w - 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int cls = 0; cls < 4; cls++)
+        if (cur_lo[cls] >= 0) {
+            atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_lo[cls]], 1);
+            atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_hi[cls] + 1], -1);
+        }
+}
+
+// in-place inclusive prefix sum of each of the 8 difference arrays (one workgroup per array)
+__global__ __launch_bounds__(1024) void k_prefix_rows(int32_t *__restrict__ a, int32_t nd)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    int32_t *row = a + (int64_t)blockIdx.x * nd;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < nd; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nd ? row[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int wp = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            const int s = wsum[w];
+            if (w < wv) wp += s;
+            tot += s;
+        }
+        const int c = carry;
+        if (i < nd) row[i] = c + wp + inc;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+}
+
+// per-column decision of :252-275 (float64 divide-and-compare, as in the reference)
+__global__ void k_indel_decide(const int32_t *__restrict__ depth, const int32_t *__restrict__ rank, const int32_t *__restrict__ U,
+                               int32_t nd, int32_t ncol, int32_t mincov, double ins_t, double del_t, int8_t *__restrict__ col_type)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    int8_t type = -1;
+    const int k = rank[c];
+    const int n0 = depth[c], n1 = depth[ncol + c];
+    if (k >= 0 && n0 >= mincov && n1 >= mincov) {
+        double f[4][2];
+#pragma unroll
+        for (int cls = 0; cls < 4; cls++) {
+            f[cls][0] = n0 > 0 ? (double)U[(int64_t)(cls * 2 + 0) * nd + k] / (double)n0 : 0.0;
+            f[cls][1] = n1 > 0 ? (double)U[(int64_t)(cls * 2 + 1) * nd + k] / (double)n1 : 0.0;
+        }
+        if (fmax(f[0][0], f[0][1]) >= del_t || fmax(f[1][0], f[1][1]) >= ins_t) type = 0;                       // :266
+        else if (fmax(f[2][0], f[2][1]) >= del_t || fmax(f[3][0], f[3][1]) >= ins_t || (f[2][0] + f[3][0]) >= 0.9 ||
+                 (f[2][1] + f[3][1]) >= 0.9)
+            type = 1;                                                                                           // :271
+    }
+    col_type[c] = type;
+}
+
+}   // namespace
+
+extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start,
+                             int32_t end, const nc_indel_scan_params *prm, int8_t *col_type_host)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!pack || !ev || !prm || !col_type_host || end < start) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: bad argument");
+    const int tile = pack->tile_size;
+    if (!(tile == 1024 || tile == 2048 || tile == 4096)) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: malformed read pack");
+    if (prm->win_size < 1 || prm->small_win_size < 1 || prm->win_size > 4096) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: window sizes");
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
+    const int32_t lo = start < 1 ? 1 : start, hi = end;
+    const int32_t ncol = hi - lo + 1;
+    // workspace: depth[3][ncol] | rank[ncol+1] | diff[8][nd] | col_type[ncol]
+    const int32_t nd = ncol + prm->win_size + 2;
+    const size_t o_depth = 0, o_rank = o_depth + (size_t)3 * ncol * 4, o_diff = o_rank + ((size_t)ncol + 1) * 4,
+                 o_type = o_diff + (size_t)8 * nd * 4, total = o_type + (size_t)ncol + 16;
+    NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
+    char *ws = (char *)ctx->indel_ws.p;
+    int32_t *depth = (int32_t *)(ws + o_depth), *rank = (int32_t *)(ws + o_rank), *diff = (int32_t *)(ws + o_diff);
+    int8_t *ctype = (int8_t *)(ws + o_type);
+    NC_HIP(ctx, hipMemsetAsync(ws, 0, total, ctx->stream));
+    NcTimer tm(ctx, 3);
+    const int32_t clo = lo > grid_lo ? lo : grid_lo, chi = hi < grid_hi ? hi : grid_hi;
+    if (chi >= clo) {
+        const int t0 = (clo - grid_lo) / tile, t1 = (chi - grid_lo) / tile;
+        const dim3 g((unsigned)(t1 - t0 + 1));
+        if (tile == 1024)
+            hipLaunchKernelGGL(k_hap_depth<64>, g, dim3(64), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol);
+        else if (tile == 2048)
+            hipLaunchKernelGGL(k_hap_depth<128>, g, dim3(128), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol);
+        else
+            hipLaunchKernelGGL(k_hap_depth<256>, g, dim3(256), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol);
+    }
+    hipLaunchKernelGGL(k_yield_rank, dim3(1), dim3(1024), 0, ctx->stream, depth, excl_dev, lo - grid_lo, ncol, rank);
+    if (ev->n_reads > 0)
+        hipLaunchKernelGGL(k_event_intervals, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
+                           ev->ev_len, ev->read_hap, rank, lo, hi, prm->win_size, prm->small_win_size, diff, nd);
+    hipLaunchKernelGGL(k_prefix_rows, dim3(8), dim3(1024), 0, ctx->stream, diff, nd);
+    hipLaunchKernelGGL(k_indel_decide, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, depth, rank, diff, nd, ncol, prm->mincov,
+                       prm->ins_t, prm->del_t, ctype);
+    NC_HIP(ctx, hipGetLastError());
+    tm.stop();
+    NC_HIP(ctx, hipMemcpyAsync(col_type_host, ctype, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}

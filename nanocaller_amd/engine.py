@@ -32,6 +32,7 @@ class DevicePack:
     n_entries: int
     pos_lo: int
     pos_hi: int
+    events: dict | None = None    # device tensors ev_off / ev_pos / ev_len / read_hap (indel scan inputs)
 
     def c_struct(self) -> _lib.ReadPackC:
         return _lib.ReadPackC(codes_len=self.codes.numel(), codes=self.codes.data_ptr(), tile_size=self.tile_size,
@@ -109,10 +110,15 @@ class Engine:
     def upload(self, hp: HostPack) -> DevicePack:
         dev = self.device
         ent_bytes = np.frombuffer(hp.tile_ent.tobytes(), np.uint8) if hp.tile_ent.size else np.zeros(16, np.uint8)
-        return DevicePack(codes=torch.from_numpy(hp.codes).to(dev), tile_off=torch.from_numpy(hp.tile_off).to(dev),
-                          tile_ent=torch.from_numpy(ent_bytes.copy()).to(dev), ref_code=torch.from_numpy(hp.ref_code).to(dev),
-                          tile_size=hp.tile_size, tile_pos0=hp.tile_pos0, n_tiles=hp.n_tiles,
-                          n_entries=int(hp.tile_ent.shape[0]), pos_lo=hp.pos_lo, pos_hi=hp.pos_hi)
+        dp = DevicePack(codes=torch.from_numpy(hp.codes).to(dev), tile_off=torch.from_numpy(hp.tile_off).to(dev),
+                        tile_ent=torch.from_numpy(ent_bytes.copy()).to(dev), ref_code=torch.from_numpy(hp.ref_code).to(dev),
+                        tile_size=hp.tile_size, tile_pos0=hp.tile_pos0, n_tiles=hp.n_tiles,
+                        n_entries=int(hp.tile_ent.shape[0]), pos_lo=hp.pos_lo, pos_hi=hp.pos_hi)
+        if hp.ev_off is not None:
+            z = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt) if a.size else np.zeros(1, dt)).to(dev)   # noqa: E731
+            dp.events = dict(n_reads=int(hp.read_hap.shape[0]), ev_off=z(hp.ev_off, np.int32), ev_pos=z(hp.ev_pos, np.int32),
+                             ev_len=z(hp.ev_len, np.int32), read_hap=z(hp.read_hap, np.uint8))
+        return dp
 
     def load_weights(self, kind: int, w: Weights):
         if self._loaded.get(kind) == w.path:
@@ -192,6 +198,22 @@ class Engine:
         probs = torch.empty((n, nout), dtype=torch.float32, device=self.device)
         self._check(self.L.nc_indel_forward(self.ctx, kind, n, _ptr(x), _ptr(probs)), "nc_indel_forward")
         return probs
+
+    def indel_scan(self, dp: DevicePack, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None):
+        """K7 -> int8 [end-start+1] per-column decision (-1 none, 0 long-window rule, 1 small-window rule)."""
+        if dp.events is None:
+            raise ValueError("this read pack carries no indel events / haplotype tags")
+        ev = dp.events
+        evc = _lib.IndelEventsC(n_reads=ev["n_reads"], ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(),
+                                ev_len=ev["ev_len"].data_ptr(), read_hap=ev["read_hap"].data_ptr())
+        prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size),
+                                    ins_t=float(ins_t), del_t=float(del_t))
+        lo = max(1, int(start))
+        out = np.empty(int(end) - lo + 1, np.int8)
+        pc = dp.c_struct()
+        self._check(self.L.nc_indel_scan(self.ctx, C.byref(pc), C.byref(evc), _ptr(excl), lo, int(end), C.byref(prm),
+                                         _lib.npp(out)), "nc_indel_scan")
+        return out
 
     def indel_tensor(self, rows_list, ref_rows_list):
         """rows_list[s]: uint8 [n_rows, n_cols] aligned symbols 0..4; ref_rows_list[s]: uint8 [n_cols].

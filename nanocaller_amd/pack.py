@@ -27,6 +27,11 @@ class HostPack:
     ref_code: np.ndarray     # uint8 [n_tiles*tile_size]; index 0 <-> tile_pos0; 4 = skip column
     pos_lo: int
     pos_hi: int
+    # optional indel inputs for the kept reads, in pack order (generate_indel_pileups.py:178-235)
+    read_hap: np.ndarray | None = None     # uint8 [n_kept]  0 untagged / 1 / 2
+    ev_off: np.ndarray | None = None       # int32 [n_kept+1]
+    ev_pos: np.ndarray | None = None       # int32
+    ev_len: np.ndarray | None = None       # int32, + insertion / - deletion
 
     @property
     def nbytes(self):
@@ -39,7 +44,7 @@ def _check(rc, what):
 
 
 def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, supplementary=False,
-               tile_size=2048, pos_lo=None, pos_hi=None, exclude=None) -> HostPack:
+               tile_size=2048, pos_lo=None, pos_hi=None, exclude=None, hap=None, events=None) -> HostPack:
     """read_* as in synth.World (coordinate order); ref_codes uint8 [L] (index p-1, 4 = skip).
     `exclude`: iterable of (start, end) half-open intervals whose columns are skipped, the IntervalTree
     test `tree.overlaps(pos)` of generate_SNP_pileups.py:116-119,161."""
@@ -52,6 +57,8 @@ def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, s
     filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT      # :151-154
     keep = np.ascontiguousarray((flag & filt) == 0, np.uint8)
     strand = np.ascontiguousarray(((flag & 0x910) // 16) != 0, np.uint8)     # :143
+    if hap is not None:
+        strand = np.ascontiguousarray(strand | (np.asarray(hap, np.uint8) & 3) << 1)   # bits 1-2: HP tag
     n = int(rs.shape[0])
     Lref = int(ref_codes.shape[0])
     pos_lo = 1 if pos_lo is None else max(1, int(pos_lo))
@@ -81,10 +88,23 @@ def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, s
             hi = min(int(x1), tile_pos0.value + npos) - tile_pos0.value
             if hi > lo:
                 rc[lo:hi] = 4
-    return HostPack(codes=out_codes, tile_size=tile_size, tile_pos0=tile_pos0.value, n_tiles=n_tiles.value,
-                    tile_off=tile_off, tile_ent=tile_ent[:n_ent.value], ref_code=rc, pos_lo=pos_lo, pos_hi=pos_hi)
+    hp = HostPack(codes=out_codes, tile_size=tile_size, tile_pos0=tile_pos0.value, n_tiles=n_tiles.value,
+                  tile_off=tile_off, tile_ent=tile_ent[:n_ent.value], ref_code=rc, pos_lo=pos_lo, pos_hi=pos_hi)
+    if events is not None:
+        ev_off, ev_pos, ev_len = (np.asarray(a) for a in events)
+        kept = np.nonzero(keep)[0]
+        cnt = (ev_off[1:] - ev_off[:-1])[kept]
+        off = np.zeros(kept.size + 1, np.int32)
+        np.cumsum(cnt, out=off[1:])
+        idx = np.concatenate([np.arange(ev_off[r], ev_off[r + 1]) for r in kept]) if kept.size else np.zeros(0, np.int64)
+        hp.ev_off, hp.ev_pos, hp.ev_len = off, np.ascontiguousarray(ev_pos[idx], np.int32), np.ascontiguousarray(ev_len[idx], np.int32)
+        hp.read_hap = np.ascontiguousarray((np.asarray(hap, np.uint8) if hap is not None else np.zeros(n, np.uint8))[kept])
+    return hp
 
 
 def pack_world(world: World, **kw) -> HostPack:
+    if "events" in world.meta:
+        kw.setdefault("hap", world.meta["hap"])
+        kw.setdefault("events", world.meta["events"])
     return pack_reads(world.read_start, world.read_end, world.read_off, world.codes, world.read_flag,
                       world_ref_codes(world), **kw)

@@ -186,3 +186,47 @@ def world_checksum(world: World) -> str:
     for a in (world.read_start, world.read_end, world.read_flag, world.read_off, world.codes):
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
+
+
+def add_indels(world: World, seed: int = SEED, het_rate: float = 1 / 1500.0, noise_rate: float = 0.004,
+               tag_frac: float = 0.85, carry: float = 0.85) -> World:
+    """Decorate a world with per-read indel events and HP/PS phasing tags (inputs of the indel candidate scan,
+    generate_indel_pileups.py:178-304).  Events are stored read-major in world.meta['events'] =
+    (ev_off int32 [R+1], ev_pos int32, ev_len int32 signed: +insertion / -deletion, the marker sits on the column
+    BEFORE the inserted / deleted bases as in pysam pileup strings) and world.meta['hap'] (uint8 [R]: 0 untagged,
+    1/2 = HP), world.meta['ps'] (int32 [R]); world.meta['deco'] / ['tags'] carry the same for the stub pysam."""
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    R, L = world.n_reads, world.length
+    true_hap = world.hap if world.hap is not None else rng.integers(0, 2, size=R)
+    tagged = rng.random(R) < tag_frac
+    hp = np.where(tagged, true_hap + 1, 0).astype(np.uint8)
+    ps = (1000 * (world.read_start // 20000) + 1).astype(np.int32)
+    sites = np.nonzero(rng.random(L) < het_rate)[0] + 1
+    site_hap = rng.integers(0, 2, size=sites.size)
+    site_len = rng.integers(1, 31, size=sites.size) * rng.choice(np.array([-1, 1]), size=sites.size)
+    per_read = []
+    for r in range(R):
+        a, b = int(world.read_start[r]), int(world.read_end[r])
+        ev = {}
+        lo, hi = np.searchsorted(sites, a), np.searchsorted(sites, b - 1)
+        for k in range(lo, hi):
+            if site_hap[k] == true_hap[r] and rng.random() < carry:
+                ev[int(sites[k])] = int(site_len[k])
+        n_noise = rng.poisson(noise_rate * (b - a))
+        for p in rng.integers(a, b - 1, size=n_noise) if b - 1 > a else []:
+            ev.setdefault(int(p), int(rng.integers(1, 4)) * (1 if rng.random() < 0.5 else -1))
+        per_read.append(sorted(ev.items()))
+    ev_off = np.zeros(R + 1, np.int32)
+    ev_off[1:] = np.cumsum([len(e) for e in per_read])
+    ev_pos = np.array([p for e in per_read for p, _ in e], np.int32)
+    ev_len = np.array([ln for e in per_read for _, ln in e], np.int32)
+    deco = {}
+    for r, e in enumerate(per_read):
+        for p, ln in e:
+            deco[(r, p - 1)] = ("+%d%s" % (ln, "ACGT"[p % 4] * ln)) if ln > 0 else ("-%d%s" % (-ln, "N" * (-ln)))
+    world.meta["events"] = (ev_off, ev_pos, ev_len)
+    world.meta["hap"] = hp
+    world.meta["ps"] = ps
+    world.meta["deco"] = deco
+    world.meta["tags"] = {r: {"HP": int(hp[r]), "PS": int(ps[r])} for r in range(R) if hp[r]}
+    return world

@@ -473,3 +473,121 @@ int oracle_indel_tensor(const uint8_t *rows, int32_t nrows, int32_t ncols, const
     *cns_len = nc;
     return 0;
 }
+
+/* ---------------------------------------------------------------- indel candidate window scan (pass 1) */
+/*
+ * generate_indel_pileups.py:197-304 (impute_indel_phase branch excluded).  Reads as above plus hap[r] (0 untagged,
+ * 1/2 = HP tag, :178-188) and read-major indel events (ev_off[r]..ev_off[r+1]: ev_pos = column carrying the
+ * '+n'/'-n' marker, ev_len signed: + insertion, - deletion).  excl[p-1] != 0 skips the column entirely (ex_bed, :217).
+ * Sliding windows are over the last `win` / `small_win` YIELDED columns (deque maxlen, :197-204), a column is yielded
+ * when at least one kept read covers it.  Output: variants (anchor position, type 0/1) in ascending anchor order;
+ * a later detection overwrites an equal anchor (dict semantics, :268,274).
+ */
+int oracle_indel_scan(int32_t n_reads, const int32_t *rstart, const int32_t *rend, const uint8_t *keep, const uint8_t *hap,
+                      const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len, const uint8_t *excl, int32_t L,
+                      int32_t start, int32_t end, int32_t mincov, int32_t win, int32_t small_win, double ins_t, double del_t,
+                      int32_t cap, int32_t *var_pos, int32_t *var_type, int32_t *n_var)
+{
+    int32_t lo = start < 1 ? 1 : start, hi = end > L ? L : end;
+    *n_var = 0;
+    if (hi < lo) return 0;
+    int64_t ncol = (int64_t)hi - lo + 1;
+    /* per-column depths by haplotype */
+    int32_t *d = (int32_t *)calloc((size_t)(ncol + 1) * 3, sizeof(int32_t));
+    /* per-column event lists: counting sort of the qualifying events */
+    int32_t *ecnt = (int32_t *)calloc((size_t)ncol + 1, sizeof(int32_t));
+    if (!d || !ecnt) return -3;
+    int64_t n_ev = 0;
+    for (int r = 0; r < n_reads; r++) {
+        if (keep && !keep[r]) continue;
+        int64_t a = rstart[r] > lo ? rstart[r] : lo, b = (int64_t)rend[r] - 1 < hi ? (int64_t)rend[r] - 1 : hi;
+        if (a > b) continue;
+        int h = hap[r] == 1 ? 0 : hap[r] == 2 ? 1 : 2;
+        d[(a - lo) * 3 + h]++;
+        d[(b - lo + 1) * 3 + h]--;
+        if (h < 2)
+            for (int e = ev_off[r]; e < ev_off[r + 1]; e++)
+                if (ev_pos[e] >= lo && ev_pos[e] <= hi) { ecnt[ev_pos[e] - lo + 1]++; n_ev++; }
+    }
+    for (int64_t c = 1; c <= ncol; c++) {
+        for (int h = 0; h < 3; h++) d[c * 3 + h] += d[(c - 1) * 3 + h];
+        ecnt[c] += ecnt[c - 1];
+    }
+    int32_t *eread = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_ev + 1)), *elen = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_ev + 1));
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ncol + 1));
+    memcpy(fill, ecnt, sizeof(int32_t) * (size_t)(ncol + 1));
+    for (int r = 0; r < n_reads; r++) {
+        if ((keep && !keep[r]) || (hap[r] != 1 && hap[r] != 2)) continue;
+        for (int e = ev_off[r]; e < ev_off[r + 1]; e++)
+            if (ev_pos[e] >= lo && ev_pos[e] <= hi && ev_pos[e] >= rstart[r] && ev_pos[e] < rend[r]) {
+                int32_t k = fill[ev_pos[e] - lo]++;
+                eread[k] = r; elen[k] = ev_len[e];
+            } else if (ev_pos[e] >= lo && ev_pos[e] <= hi) {
+                int32_t k = fill[ev_pos[e] - lo]++;      /* keep the counting sort consistent; mark unusable */
+                eread[k] = -1; elen[k] = 0;
+            }
+    }
+    /* window state: classes 0 del long, 1 ins long, 2 del small, 3 ins small; per class per hap: per-read multiplicity */
+    int32_t *mult = (int32_t *)calloc((size_t)(n_reads > 0 ? n_reads : 1) * 4, sizeof(int32_t));
+    int32_t distinct[4][2];
+    memset(distinct, 0, sizeof distinct);
+    int32_t *ycol = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncol);      /* yielded columns, in order */
+    int64_t ny = 0;
+    int64_t prev = 0;
+    int rc = 0;
+    for (int64_t v = lo; v <= hi; v++) {
+        const int64_t c = v - lo;
+        const int32_t n0 = d[c * 3 + 0], n1 = d[c * 3 + 1], ntot = n0 + n1 + d[c * 3 + 2];
+        if (ntot == 0) continue;                                  /* not yielded */
+        if (excl && excl[v - 1]) continue;                        /* :217 */
+        /* append this column's sets; drop the column that leaves each deque */
+        ycol[ny] = (int32_t)v;
+        for (int pass = 0; pass < 2; pass++) {                    /* pass 0: leaving columns, pass 1: entering column */
+            for (int cls = 0; cls < 4; cls++) {
+                const int w = cls < 2 ? win : small_win;
+                int64_t col;
+                if (pass == 0) { if (ny - w < 0) continue; col = ycol[ny - w]; } else col = v;
+                for (int32_t k = ecnt[col - lo]; k < ecnt[col - lo + 1]; k++) {
+                    const int r = eread[k];
+                    if (r < 0) continue;
+                    const int32_t ln = elen[k] < 0 ? -elen[k] : elen[k];
+                    const int is_ins = elen[k] > 0;
+                    int q;
+                    if (cls < 2) q = (ln > 2 && ln <= 50) && (is_ins == (cls == 1));      /* :225,228 */
+                    else q = (ln <= 10) && (is_ins == (cls == 3));                         /* :226,229 */
+                    if (!q) continue;
+                    const int h = hap[r] - 1;
+                    int32_t *m = &mult[(size_t)r * 4 + cls];
+                    if (pass == 1) { if ((*m)++ == 0) distinct[cls][h]++; }
+                    else { if (--(*m) == 0) distinct[cls][h]--; }
+                }
+            }
+        }
+        ny++;
+        if (v <= prev) continue;                                  /* :249 */
+        if (n0 >= mincov && n1 >= mincov) {                       /* :252 */
+            const double del0 = n0 > 0 ? (double)distinct[0][0] / n0 : 0, del1 = n1 > 0 ? (double)distinct[0][1] / n1 : 0;
+            const double ins0 = n0 > 0 ? (double)distinct[1][0] / n0 : 0, ins1 = n1 > 0 ? (double)distinct[1][1] / n1 : 0;
+            const double dels0 = n0 > 0 ? (double)distinct[2][0] / n0 : 0, dels1 = n1 > 0 ? (double)distinct[2][1] / n1 : 0;
+            const double inss0 = n0 > 0 ? (double)distinct[3][0] / n0 : 0, inss1 = n1 > 0 ? (double)distinct[3][1] / n1 : 0;
+            int type = -1;
+            int64_t anchor = 0;
+            if ((del0 > del1 ? del0 : del1) >= del_t || (ins0 > ins1 ? ins0 : ins1) >= ins_t) {          /* :266 */
+                prev = v + win; anchor = v - win; type = 0;
+            } else if ((dels0 > dels1 ? dels0 : dels1) >= del_t || (inss0 > inss1 ? inss0 : inss1) >= ins_t ||
+                       (dels0 + inss0) >= 0.9 || (dels1 + inss1) >= 0.9) {                               /* :271 */
+                prev = v + 10; anchor = v - 10; type = 1;
+            }
+            if (type >= 0) {
+                if (anchor < 1) anchor = 1;
+                if (*n_var > 0 && var_pos[*n_var - 1] == anchor) var_type[*n_var - 1] = type;            /* dict overwrite */
+                else {
+                    if (*n_var >= cap) { rc = -2; break; }
+                    var_pos[*n_var] = (int32_t)anchor; var_type[*n_var] = type; (*n_var)++;
+                }
+            }
+        }
+    }
+    free(d); free(ecnt); free(eread); free(elen); free(fill); free(mult); free(ycol);
+    return rc;
+}

@@ -192,3 +192,27 @@ def indel_tensor(rows, ref_row):
                                   _p(ref_row, C.c_uint8), _p(out, C.c_float), _p(cns, C.c_uint8), C.byref(nc))
     assert r == 0
     return out, cns[:nc.value].copy()
+
+
+def indel_scan(world, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, exclude=None, supplementary=False):
+    """Pass 1 of get_indel_testing_candidates (generate_indel_pileups.py:197-304) -> (anchor positions, types)."""
+    rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
+    ev_off, ev_pos, ev_len = (np.ascontiguousarray(a, np.int32) for a in world.meta["events"])
+    hap = np.ascontiguousarray(world.meta["hap"], np.uint8)
+    excl = None
+    if exclude:
+        excl = np.zeros(world.length, np.uint8)
+        for (a, b) in exclude:
+            excl[max(0, a - 1):max(0, b - 1)] = 1
+    cap = end - start + 2
+    vp = np.zeros(cap, np.int32)
+    vt = np.zeros(cap, np.int32)
+    nv = C.c_int32()
+    r = lib().oracle_indel_scan(C.c_int32(rs.size), _p(rs, C.c_int32), _p(re_, C.c_int32), _p(keep, C.c_uint8),
+                                _p(hap, C.c_uint8), _p(ev_off, C.c_int32), _p(ev_pos, C.c_int32), _p(ev_len, C.c_int32),
+                                _p(excl, C.c_uint8) if excl is not None else None, C.c_int32(world.length),
+                                C.c_int32(start), C.c_int32(end), C.c_int32(mincov), C.c_int32(win_size),
+                                C.c_int32(small_win_size), C.c_double(ins_t), C.c_double(del_t), C.c_int32(cap),
+                                _p(vp, C.c_int32), _p(vt, C.c_int32), C.byref(nv))
+    assert r == 0, r
+    return vp[:nv.value].copy(), vt[:nv.value].copy()

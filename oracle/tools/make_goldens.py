@@ -343,6 +343,49 @@ def make_indel_caller_goldens():
                         alleles=np.array(json.dumps(alleles)), phase=np.array(json.dumps(phase)), **out)
 
 
+def make_indel_scan_goldens():
+    """Pass 1 of get_indel_testing_candidates (generate_indel_pileups.py:197-304): the `variants` dict, captured from
+    the reference's own frame when it opens its second pileup (stub pysam, CAPTURE_INDEL)."""
+    from nanocaller_amd.synth import add_indels
+    from nanocaller_src import generate_indel_pileups as ref_indel
+
+    w = add_indels(make_world(seed=815, length=60_000, depth=28, tech="ont", read_len_scale=0.5, odd_flag_frac=0.03))
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    np.savez_compressed(os.path.join(OUT, "world_indel.npz"), chrom=np.array(w.chrom),
+                        ref=np.frombuffer(w.ref.encode(), dtype=np.uint8), read_start=w.read_start, read_end=w.read_end,
+                        read_flag=w.read_flag, read_off=w.read_off, codes=w.codes, ev_off=ev_off, ev_pos=ev_pos,
+                        ev_len=ev_len, hap=w.meta["hap"], ps=w.meta["ps"])
+    pysam.register("bam", w)
+    pysam.register("fa", w)
+    pysam.register("bed", [("chr20", 30_000, 30_400)])
+    rec = {}
+    k = 0
+    for (start, end, kw) in [(5_000, 55_000, {}), (1, 20_000, {}), (20_000, 59_990, dict(mincov=8)),
+                             (10_000, 40_000, dict(ins_t=0.3, del_t=0.3, win_size=20, small_win_size=2)),
+                             (25_000, 35_000, dict(exclude_bed="bed")), (40_000, 41_000, dict(mincov=200))]:
+        dct = dict(seq="ont", fasta_path="fa", win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6,
+                   exclude_bed=None, supplementary=False, impute_indel_phase=False)
+        dct.update(kw)
+        pysam.CAPTURE_INDEL = True
+        pysam.CAPTURED.clear()
+        out = ref_indel.get_indel_testing_candidates(dct, dict(chrom=w.chrom, start=start, end=end, sam_path="bam"))
+        pysam.CAPTURE_INDEL = False
+        assert len(out[0]) == 0
+        v = pysam.CAPTURED["variants"]
+        keys = sorted(v)
+        rec["s%d_start" % k], rec["s%d_end" % k] = start, end
+        for name in ("mincov", "win_size", "small_win_size"):
+            rec["s%d_%s" % (k, name)] = dct[name]
+        rec["s%d_ins_t" % k], rec["s%d_del_t" % k] = np.float64(dct["ins_t"]), np.float64(dct["del_t"])
+        rec["s%d_excl" % k] = np.array([[30_000, 30_400]] if dct["exclude_bed"] else [], np.int64).reshape(-1, 2)
+        rec["s%d_pos" % k] = np.array(keys, np.int64)
+        rec["s%d_type" % k] = np.array([v[p] for p in keys], np.int64)
+        print("indel scan [%d,%d] %s -> %d variants (%d type 0)" % (start, end, kw, len(keys), sum(1 for p in keys if v[p] == 0)))
+        k += 1
+    rec["n"] = k
+    np.savez_compressed(os.path.join(OUT, "indel_scan.npz"), **rec)
+
+
 def make_chunk_goldens():
     """get_chunks (utils.py:67-83) on a few region lists; utils.py imports pysam at module top (stub)."""
     import json
@@ -366,7 +409,7 @@ def make_chunk_goldens():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller"]
+    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller", "indel_scan"]
     if "snp" in what:
         make_snp_goldens()
     if "cnd" in what:
@@ -379,3 +422,5 @@ if __name__ == "__main__":
         make_chunk_goldens()
     if "indel_caller" in what:
         make_indel_caller_goldens()
+    if "indel_scan" in what:
+        make_indel_scan_goldens()

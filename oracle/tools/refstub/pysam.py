@@ -11,6 +11,8 @@ strand) and an indel that follows is appended as +<n><bases> / -<n><N...>.
 import numpy as np
 
 WORLDS = {}          # path -> nanocaller_amd.synth.World
+CAPTURE_INDEL = False    # True: the SECOND pileup() of a Samfile captures the caller's `variants` dict and yields nothing
+CAPTURED = {}
 
 
 def register(path, world):
@@ -76,6 +78,16 @@ class Samfile:
 
     def pileup(self, chrom, a, b, min_base_quality=0, flag_filter=0, truncate=True,
                multiple_iterators=False, **k):
+        self._n_pileup = getattr(self, "_n_pileup", 0) + 1
+        if CAPTURE_INDEL and self._n_pileup == 2:
+            import sys as _sys
+            fl = _sys._getframe(1).f_locals
+            CAPTURED["variants"] = dict(fl["variants"])
+            CAPTURED["extra_variants"] = dict(fl["extra_variants"])
+            return iter(())
+        return self._pileup(chrom, a, b, flag_filter)
+
+    def _pileup(self, chrom, a, b, flag_filter):
         w = self.world
         a = max(0, a)
         b = min(b, w.length)

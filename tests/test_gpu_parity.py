@@ -214,3 +214,23 @@ def test_end_to_end_vcf_matches_oracle_pipeline(eng, tmp_path):
         assert max(abs(a - b) for a, b in zip(gp, ep)) <= 1.01e-4
         ngt += gf[6] == "PASS"
     assert ngt > 10
+
+
+def test_indel_window_scan_matches_reference_pass1(eng):
+    """K7: the `variants` dict of the reference's pass 1 (captured from its own frame) and the CPU oracle"""
+    from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
+    from oracle import oracle
+    from tests.util import indel_scan_cases
+    world = load_world("indel")
+    n = 0
+    for c in indel_scan_cases():
+        dct = dict(mincov=c["mincov"], win_size=c["win_size"], small_win_size=c["small_win_size"], ins_t=c["ins_t"],
+                   del_t=c["del_t"], supplementary=False, impute_indel_phase=False,
+                   exclude_bed=[(world.chrom, a, b) for a, b in c["exclude"]] or None)
+        got = scan_indel_candidates(dct, dict(chrom=world.chrom, start=c["start"], end=c["end"], sam_path=world))
+        assert sorted(got) == c["pos"].tolist() and [got[p] for p in sorted(got)] == c["type"].tolist(), (c["start"], c["end"])
+        op, ot = oracle.indel_scan(world, c["start"], c["end"], mincov=c["mincov"], win_size=c["win_size"],
+                                   small_win_size=c["small_win_size"], ins_t=c["ins_t"], del_t=c["del_t"], exclude=c["exclude"])
+        assert sorted(got) == op.tolist()
+        n += len(got)
+    assert n > 100

@@ -40,3 +40,15 @@ def test_indel_tensor_matches_reference_msa():
         assert gold.shape == (5, 128, 2)
         assert np.array_equal(out.astype(np.float64), gold), k
         assert "".join(sym[c] for c in cns) == str(z["m%d_cns" % k])
+
+
+def test_indel_window_scan_matches_reference_pass1():
+    from tests.util import indel_scan_cases, load_world
+    world = load_world("indel")
+    cases = indel_scan_cases()
+    assert len(cases) >= 6 and sum(len(c["pos"]) for c in cases) > 100
+    for c in cases:
+        pos, typ = oracle.indel_scan(world, c["start"], c["end"], mincov=c["mincov"], win_size=c["win_size"],
+                                     small_win_size=c["small_win_size"], ins_t=c["ins_t"], del_t=c["del_t"],
+                                     exclude=c["exclude"])
+        assert np.array_equal(pos, c["pos"]) and np.array_equal(typ, c["type"]), (c["start"], c["end"])

@@ -17,6 +17,8 @@ def load_world(name):
         _worlds[name] = World(chrom=str(z["chrom"]), ref=z["ref"].tobytes().decode(), read_start=z["read_start"],
                               read_end=z["read_end"], read_flag=z["read_flag"], read_off=z["read_off"],
                               codes=z["codes"], names=["r%07d" % i for i in range(R)])
+        if "ev_off" in z:
+            _worlds[name].meta.update(events=(z["ev_off"], z["ev_pos"], z["ev_len"]), hap=z["hap"], ps=z["ps"])
     return _worlds[name]
 
 
@@ -54,3 +56,14 @@ def assert_tuple_matches_gold(out, gold):
     assert float(depth) == gold["depth"]
     assert np.array_equal(np.asarray(fwd), gold["fwd_dp"])
     assert np.array_equal(np.asarray(rev), gold["rev_dp"])
+
+
+def indel_scan_cases():
+    z = np.load(os.path.join(GOLD, "indel_scan.npz"))
+    out = []
+    for k in range(int(z["n"])):
+        out.append(dict(start=int(z["s%d_start" % k]), end=int(z["s%d_end" % k]), mincov=int(z["s%d_mincov" % k]),
+                        win_size=int(z["s%d_win_size" % k]), small_win_size=int(z["s%d_small_win_size" % k]),
+                        ins_t=float(z["s%d_ins_t" % k]), del_t=float(z["s%d_del_t" % k]),
+                        exclude=[(int(a), int(b)) for a, b in z["s%d_excl" % k]], pos=z["s%d_pos" % k], type=z["s%d_type" % k]))
+    return out
