@@ -331,7 +331,9 @@ constexpr int F12_XP = 2032;             // padded input image (9*45*5 = 2025, +
 constexpr int F12_CP = 52;               // channel pitch of the LDS activation (48 + 4: keeps ds_read_b128 aligned, spreads banks)
 constexpr int F12_W1P = 52 * 64;         // conv1 B fragments
 constexpr int F12_W2P = 6 * 3 * 4 * 2 * 64;
-constexpr int F12_PACKED = F12_W1P + 48 + F12_W2P + 32;
+constexpr int F12_W3P = 48 * 4 * 64;      // conv3 B fragments: [step 48][tn 4][lane 64]
+constexpr int F12_CP2 = 36;               // channel pitch of the LDS conv2 activation (32 + 4)
+constexpr int F12_PACKED = F12_W1P + 48 + F12_W2P + 32 + F12_W3P + 64;
 
 template <int NT>
 __device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const float (&w1r)[52], const float *__restrict__ b1,
@@ -391,7 +393,7 @@ __device__ __forceinline__ void f12_conv1_pass(const float *Xp, float *A1, const
 
 template <int NT>
 __device__ __forceinline__ void f12_conv2(const float *A1, const float (&w2r)[72], const float *__restrict__ b2,
-                                          float *__restrict__ out_site, int wv, int lane)
+                                          float *A2, int wv, int lane)
 {
     const int kq = lane >> 4, c16 = lane & 15, tn = wv & 1, t0 = wv >> 1;
     int abase[NT];
@@ -430,7 +432,57 @@ __device__ __forceinline__ void f12_conv2(const float *A1, const float (&w2r)[72
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int po = (t0 + 2 * tm) * 16 + 4 * kq + r;
-            out_site[po * 32 + tn * 16 + c16] = selu(acc[tm][r]);
+            A2[po * F12_CP2 + tn * 16 + c16] = selu(acc[tm][r]);
+        }
+    }
+}
+
+// conv3 (2x3, stride (1,2): 4x20x32 -> 3x9x64) out of the LDS conv2 activation: 27 positions = 2 tiles of 16, wave w
+// owns output channels [16w, 16w+16); its 48 weight fragments are streamed from L2 (the register file is full).
+__device__ __forceinline__ void f12_conv3(const float *A2, const float *__restrict__ w3p, const float *__restrict__ b3,
+                                          float *__restrict__ out_site, int wv, int lane)
+{
+    const int kq = lane >> 4, c16 = lane & 15;
+    int abase[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        int p = tm * 16 + c16;
+        p = p < 27 ? p : 26;
+        const int y = p / 9, x = p - y * 9;
+        abase[tm] = (y * 20 + 2 * x) * F12_CP2 + 4 * kq;
+    }
+    f32x4v acc[2];
+    {
+        const float b = b3[wv * 16 + c16];
+        acc[0] = (f32x4v){b, b, b, b};
+        acc[1] = acc[0];
+    }
+    const float *wl = w3p + wv * 64 + lane;
+#pragma unroll 1
+    for (int tap = 0; tap < 6; tap++) {
+        const int toff = ((tap / 3) * 20 + (tap % 3)) * F12_CP2;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float4 a[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++) a[tm] = *reinterpret_cast<const float4 *>(A2 + abase[tm] + toff + 16 * j);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float b = wl[((tap * 2 + j) * 4 + i) * 256];
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++) {
+                    const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[tm], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int po = tm * 16 + 4 * kq + r;
+            if (po < 27) out_site[po * 64 + wv * 16 + c16] = selu(acc[tm][r]);
         }
     }
 }
@@ -438,13 +490,14 @@ __device__ __forceinline__ void f12_conv2(const float *A1, const float (&w2r)[72
 // Weight-stationary and persistent: every wave loads its 52 conv1 and 72 conv2 weight fragments into registers ONCE
 // (124 VGPRs) and then walks sites; in steady state the only memory traffic is the 4.1 KB input tensor in, the 10 KB
 // conv2 activation out, and LDS.  Two workgroups (8 waves) per CU.
-__global__ __launch_bounds__(256, 2) void k4_conv12(const float *__restrict__ x, const float *__restrict__ wp, float *__restrict__ a2,
+__global__ __launch_bounds__(256, 2) void k4_conv12(const float *__restrict__ x, const float *__restrict__ wp, float *__restrict__ a3,
                                                     int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
 {
     __shared__ __attribute__((aligned(16))) float Xp[F12_XP];
     __shared__ __attribute__((aligned(16))) float A1[205 * F12_CP];
+    __shared__ __attribute__((aligned(16))) float A2[80 * F12_CP2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const float *w1p = wp, *b1 = wp + F12_W1P, *w2p = b1 + 48, *b2 = w2p + F12_W2P;
+    const float *w1p = wp, *b1 = wp + F12_W1P, *w2p = b1 + 48, *b2 = w2p + F12_W2P, *w3p = b2 + 32, *b3 = w3p + F12_W3P;
     float w1r[52], w2r[72];
 #pragma unroll
     for (int s = 0; s < 52; s++) w1r[s] = w1p[s * 64 + lane];
@@ -491,10 +544,12 @@ __global__ __launch_bounds__(256, 2) void k4_conv12(const float *__restrict__ x,
         __syncthreads();
         // the padded input is free again: write the next site's image while conv2 runs out of A1
         if (nxt < n_sites) commit();
-        float *out_site = a2 + site * (80 * 32);
-        if (wv < 2) f12_conv2<3>(A1, w2r, b2, out_site, wv, lane);
-        else f12_conv2<2>(A1, w2r, b2, out_site, wv, lane);
+        if (wv < 2) f12_conv2<3>(A1, w2r, b2, A2, wv, lane);
+        else f12_conv2<2>(A1, w2r, b2, A2, wv, lane);
         __syncthreads();
+        // conv3 reads A2; the next iteration's conv1 only touches Xp / A1, and A2 is not rewritten before the barrier
+        // that follows that conv1, so no third barrier is needed
+        f12_conv3(A2, w3p, b3, a3 + site * (27 * 64), wv, lane);
     }
 }
 
@@ -615,8 +670,8 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, int64_t site0, i
         constexpr int TM3 = 2, TMF = 1;
         (void)np2;
         const unsigned nblk = (unsigned)(nb < 512 ? nb : 512);          // 2 resident workgroups per CU, persistent over sites
-        hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a2, nb, scale, scale_mode, site0);
-        hipLaunchKernelGGL((k3_conv23<H2, W2, C2, C3, TM3>), dim3(blocks_for(np3, 4 * 32 * TM3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
+        (void)np3; (void)TM3; (void)a2; (void)k3;
+        hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a3, nb, scale, scale_mode, site0);
         hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
     } else {
         hipLaunchKernelGGL((k2_conv23<H, W, 3 * C1, C2, P2>), dim3(blocks_for(np2, 256 * P2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
@@ -651,7 +706,8 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         std::vector<float> pk((size_t)F12_PACKED, 0.0f);
         const float *k11 = blob_host, *b11 = k11 + 400, *k12 = b11 + 16, *b12 = k12 + 400, *k13 = b12 + 16, *b13 = k13 + 2000;
         const float *k2 = b13 + 16, *b2 = k2 + 2 * 3 * 48 * 32;
-        float *w1p = pk.data(), *b1 = w1p + F12_W1P, *w2p = b1 + 48, *b2p = w2p + F12_W2P;
+        float *w1p = pk.data(), *b1 = w1p + F12_W1P, *w2p = b1 + 48, *b2p = w2p + F12_W2P, *w3p = b2p + 32, *b3p = w3p + F12_W3P;
+        const float *k3 = b2 + 32, *b3 = k3 + 2 * 3 * 32 * 64;
         for (int lane = 0; lane < 64; lane++) {
             const int kq = lane >> 4, c = lane & 15;
             for (int s = 0; s < 35; s++) {
@@ -675,6 +731,15 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         }
         for (int c = 0; c < 16; c++) { b1[c] = b11[c]; b1[16 + c] = b12[c]; b1[32 + c] = b13[c]; }
         for (int c = 0; c < 32; c++) b2p[c] = b2[c];
+        for (int lane = 0; lane < 64; lane++) {
+            const int kq = lane >> 4, c = lane & 15;
+            for (int tap = 0; tap < 6; tap++)
+                for (int j = 0; j < 2; j++)
+                    for (int i = 0; i < 4; i++)
+                        for (int tn = 0; tn < 4; tn++)
+                            w3p[(((tap * 2 + j) * 4 + i) * 4 + tn) * 64 + lane] = k3[(tap * 32 + 16 * j + 4 * kq + i) * 64 + tn * 16 + c];
+        }
+        for (int c = 0; c < 64; c++) b3p[c] = b3[c];
         if (!w.packed) {
             hipError_t e = hipMalloc(&w.packed, pk.size() * 4);
             if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed weights: %s", hipGetErrorString(e));
