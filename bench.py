@@ -27,6 +27,10 @@ import torch  # noqa: E402
 
 CHR20_LEN = 64_444_167                 # GRCh38 chr20
 SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3 (haploid model: 3,453,696)
+TRUNK_FLOP_PER_SITE = 2 * (574_000 + 737_280 + 331_776)   # conv1 (3 kernels) + conv2 + conv3, SURVEY.md Appendix C.1
+# HBM bytes per launch of the fused trunk kernel (32768 sites), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: profiles/r01_final_pmc.md
+TRUNK_TRAFFIC_PER_SITE = (2 * 69.3e6 + 216e6 * 32768 / 31231) / 32768
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -42,7 +46,7 @@ def parse():
     ap.add_argument("--model", default="ONT-HG002")
     ap.add_argument("--ploidy", default="diploid", choices=["diploid", "haploid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=4)
+    ap.add_argument("--cpu-sample-chunks", type=int, default=16)
     return ap.parse_args()
 
 
@@ -129,13 +133,13 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.enable_timing(True)
-    stage_ms = np.zeros(3)
+    stage_ms = np.zeros(5)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = step()
-        stage_ms += [eng.last_ms(0), eng.last_ms(1), eng.last_ms(2)]
+        stage_ms += [eng.last_ms(0), eng.last_ms(1), eng.last_ms(2), eng.last_ms(4), eng.last_ms(5)]
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -149,6 +153,10 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_sites * args.steps / dt
         cnn_tflops = SNP_FLOP_PER_SITE * n_sites / (stage_ms[2] * 1e-3) / 1e12 if stage_ms[2] > 0 else 0.0
+        # dominant kernel = fused conv1+conv2+conv3 trunk (k4_conv12): algorithmic FLOP of its launches / their summed
+        # HIP-event durations == FLOP per launch / average launch duration
+        n_launch = max(1.0, stage_ms[4])
+        trunk_tflops = TRUNK_FLOP_PER_SITE * n_sites / (stage_ms[3] * 1e-3) / 1e12 if stage_ms[3] > 0 else 0.0
         scan_bytes = info["pileup_entries"] + L               # (d+1) B/column, SURVEY.md 8d
         feat_bytes = 5403 * n_sites
         out = {
@@ -159,9 +167,14 @@ def main():
                        % (args.tech.upper(), args.depth, args.ploidy, L, len(chunks)), "sites_per_gpu": n_sites,
                        "pileup_entries_per_gpu": info["pileup_entries"], "model": args.model, "generator": "synth_v1 seed 812+rank",
                        "data_gen_s": round(t_gen, 2)},
-            "roofline": {"bound": "mfma", "kernel": "SNP CNN forward (fp32)", "achieved": cnn_tflops,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": cnn_tflops / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "avg_ms": float(stage_ms[2])},
+            "roofline": {"bound": "mfma", "kernel": "k4_conv12: fused conv1+conv2+conv3 of the SNP CNN, fp32 MFMA 16x16x4",
+                         "achieved": trunk_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": trunk_tflops / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": TRUNK_TRAFFIC_PER_SITE * n_sites / n_launch,
+                         "traffic_note": "HBM bytes per launch from committed PMC passes (profiles/r01_final_pmc.md), not re-measured in this run",
+                         "launches_per_step": n_launch, "avg_launch_ms": float(stage_ms[3] / n_launch),
+                         "flop_per_launch": TRUNK_FLOP_PER_SITE * n_sites / n_launch,
+                         "cnn_stage_tflops": cnn_tflops, "cnn_stage_ms": float(stage_ms[2])},
             "stages": {"scan_ms": float(stage_ms[0]), "scan_GBs": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 if stage_ms[0] else 0,
                        "scan_frac_hbm": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[0] else 0,
                        "featurize_ms": float(stage_ms[1]),

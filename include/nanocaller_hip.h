@@ -62,7 +62,8 @@ int nc_free(nc_ctx *ctx, void *dev);
 int nc_memcpy_h2d(nc_ctx *ctx, void *dev, const void *host, size_t bytes);
 int nc_memcpy_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes);
 /* Wall-clock of the last timed call on this context's stream, measured with HIP events (ms);
- * `which`: 0 scan, 1 featurize, 2 cnn forward, 3 indel tensor. */
+ * `which`: 0 scan kernel, 1 featurize kernel, 2 CNN forward (all kernels), 3 indel tensor / scan,
+ * 4 sum over the launches of the fused SNP trunk kernel in the last forward, 5 number of those launches. */
 int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms);
 int nc_enable_timing(nc_ctx *ctx, int on);
 

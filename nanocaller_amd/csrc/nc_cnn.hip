@@ -172,78 +172,10 @@ __global__ __launch_bounds__(256) void k2_fc1(const float *__restrict__ in, int 
 
 
 // ---- MFMA forms (SNP trunk).  fp32-in/fp32-accumulate MFMA is bit-for-bit an fmaf chain (exact fp32).
-// GEMM view: M = output positions (A fragment: one activation per lane), N = output channels (B fragment: one
-// weight per lane, a coalesced 128-B row segment per half-wave), K = (tap, ci).  K is walked in a permuted order so
-// that the 4 (or 2x4) consecutive input channels a lane loads as ONE dwordx4 feed 4 consecutive MFMAs:
-// v_mfma_f32_32x32x2: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31]; half-wave h takes ci in [8j+4h, 8j+4h+4).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// GEMM view: M = output positions or sites (A fragment: one activation per lane), N = output channels (B fragment:
+// one weight per lane), K = (tap, ci) walked in a permuted order so that the 4 consecutive input channels a lane
+// loads as ONE dwordx4 feed 4 consecutive MFMAs.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-template <int HI, int WI, int CI, int CO, int TM>
-__global__ __launch_bounds__(256) void k3_conv23(const float *__restrict__ in, const float *__restrict__ wk, const float *__restrict__ wb,
-                                                 float *__restrict__ out, int64_t npos)
-{
-    constexpr int HO = HI - 1, WO = (WI - 3) / 2 + 1, TN = CO / 32;
-    static_assert(CI % 8 == 0 && CO % 32 == 0, "k3_conv23 shape");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int half = lane >> 5, col = lane & 31;
-    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * (TM * 32);
-    if (tile0 >= npos) return;
-    const float *ip[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-        int64_t g = tile0 + tm * 32 + col;
-        if (g >= npos) g = npos - 1;
-        const int64_t site = g / (HO * WO);
-        const int r = (int)(g - site * (HO * WO));
-        const int y = r / WO, xq = r - y * WO;
-        ip[tm] = in + ((site * HI + y) * WI + 2 * xq) * CI + 4 * half;
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-        const float b = wb[tn * 32 + col];
-#pragma unroll
-        for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[tm][tn][r] = b;
-    }
-    const float *wl = wk + (4 * half) * CO + col;
-#pragma unroll 1
-    for (int tap = 0; tap < 6; tap++) {
-        const int ioff = ((tap / 3) * WI + (tap % 3)) * CI;
-        const float *wt = wl + tap * CI * CO;
-#pragma unroll
-        for (int j = 0; j < CI / 8; j++) {
-            float4 a[TM];
-#pragma unroll
-            for (int tm = 0; tm < TM; tm++) a[tm] = *reinterpret_cast<const float4 *>(ip[tm] + ioff + 8 * j);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float b[TN];
-#pragma unroll
-                for (int tn = 0; tn < TN; tn++) b[tn] = wt[(8 * j + i) * CO + tn * 32];
-#pragma unroll
-                for (int tm = 0; tm < TM; tm++) {
-                    const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
-#pragma unroll
-                    for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[tn], acc[tm][tn], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int64_t g = tile0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // C/D row of register r
-            if (g < npos) {
-#pragma unroll
-                for (int tn = 0; tn < TN; tn++) out[g * CO + tn * 32 + col] = selu(acc[tm][tn][r]);
-            }
-        }
-    }
-}
 
 // fc1 as v_mfma_f32_16x16x4: M = 16 sites per tile, N = F/16 tiles, K walked in groups of 16 (quarter-wave q takes
 // k in [16j+4q, 16j+4q+4) as one dwordx4).  lane l: A[row l&15][k l>>4], B[k l>>4][col l&15]; C: col l&15, row 4*(l>>4)+r.
@@ -667,11 +599,21 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, int64_t site0, i
         hipLaunchKernelGGL((k2_conv1<H, W, CI, C1>), dim3(blocks_for(np1)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1, scale,
                            scale_mode, site0);
     if constexpr (MFMA) {
-        constexpr int TM3 = 2, TMF = 1;
+        constexpr int TMF = 1;
         (void)np2;
         const unsigned nblk = (unsigned)(nb < 512 ? nb : 512);          // 2 resident workgroups per CU, persistent over sites
-        (void)np3; (void)TM3; (void)a2; (void)k3;
+        (void)np3; (void)a2; (void)k3; (void)b3;
+        const bool tk = ctx->timing && ctx->n_kev + 2 <= 128;
+        if (tk) {
+            for (int e = 0; e < 2; e++)
+                if (!ctx->kev[ctx->n_kev + e]) NC_HIP(ctx, hipEventCreate(&ctx->kev[ctx->n_kev + e]));
+            (void)hipEventRecord(ctx->kev[ctx->n_kev], ctx->stream);
+        }
         hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a3, nb, scale, scale_mode, site0);
+        if (tk) {
+            (void)hipEventRecord(ctx->kev[ctx->n_kev + 1], ctx->stream);
+            ctx->n_kev += 2;
+        }
         hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
     } else {
         hipLaunchKernelGGL((k2_conv23<H, W, 3 * C1, C2, P2>), dim3(blocks_for(np2, 256 * P2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
@@ -761,6 +703,7 @@ int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, con
     if (scale_mode != 0 && scale_mode != 1) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: scale_mode");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     NcTimer tm(ctx, 2);
+    ctx->n_kev = 0;
     const int64_t BATCH = 32768;
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
@@ -776,6 +719,16 @@ int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, con
         NC_HIP(ctx, hipGetLastError());
     }
     tm.stop();
+    if (ctx->timing) {                       // per-launch durations of the trunk kernel, on the launch stream
+        float tot = 0.0f;
+        for (int e = 0; e + 1 < ctx->n_kev; e += 2) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, ctx->kev[e], ctx->kev[e + 1]);
+            tot += ms;
+        }
+        ctx->last_ms[4] = tot;
+        ctx->last_ms[5] = (float)(ctx->n_kev / 2);
+    }
     return NC_OK;
 }
 

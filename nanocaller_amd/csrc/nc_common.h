@@ -28,7 +28,9 @@ struct nc_ctx {
     char err[512] = {0};
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms[4] = {0, 0, 0, 0};
+    float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
+    hipEvent_t kev[128] = {nullptr};          // per-launch event pairs of the trunk kernel (timing mode)
+    int n_kev = 0;
 
     // scan results (device)
     DevBuf stage_nbr, stage_cpos, stage_cn, stage_calt;   // per-tile staging

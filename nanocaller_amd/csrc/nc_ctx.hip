@@ -67,6 +67,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
         if (w.dev) (void)hipFree(w.dev);
         if (w.packed) (void)hipFree(w.packed);
     }
+    for (auto &e : ctx->kev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -131,7 +132,7 @@ int nc_enable_timing(nc_ctx *ctx, int on)
 
 int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms)
 {
-    if (!ctx || !ms || which < 0 || which > 3) return NC_ERR_ARG;
+    if (!ctx || !ms || which < 0 || which > 5) return NC_ERR_ARG;
     *ms = ctx->last_ms[which];
     return NC_OK;
 }
