@@ -103,10 +103,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ        # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
     from nanocaller_amd import snpCaller
     from nanocaller_amd.engine import get_engine
     from nanocaller_amd.synth_device import make_device_workload
@@ -123,7 +124,7 @@ def main():
                   exclude_bed=None, disable_coverage_normalization=False, sam_path=None)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
 
@@ -186,7 +187,7 @@ def main():
             out["cpu_baseline"] = cb
             out["parity"] = parity
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
