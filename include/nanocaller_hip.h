@@ -215,6 +215,45 @@ typedef struct {
 int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
                   int32_t start, int32_t end, const nc_indel_scan_params *params, int8_t *col_type_host);
 
+/* ------------------------------------------------------------------ BGZF / BAM (+ .bai linear index) ingest, host side
+ * Replaces the pysam/htslib objects of the reference (pysam.Samfile(...).fetch / .pileup, generate_SNP_pileups.py:
+ * 134-164; generate_indel_pileups.py:147,178-188,213-235): a coordinate-sorted BAM is decoded straight into the
+ * read-major arrays nc_pack_plan / nc_pack_fill and nc_indel_scan take.  Per alignment: reference span
+ * [start, end) (1-based), BAM flag, one code per spanned reference position (deletions and reference skips = 4),
+ * the '+n' / '-n' pileup markers as events on the column BEFORE the insertion / deletion, HP and PS tags (0 if
+ * absent), the read name and (keep_seq != 0) the query bases as codes.  Unmapped reads are skipped; every other flag
+ * is returned so that the caller applies the pileup flag filter.  All pointers stay valid until nc_decoded_free.
+ */
+typedef struct nc_bam nc_bam;
+typedef struct nc_decoded nc_decoded;
+typedef struct {
+    int32_t n_reads;
+    const int32_t *start, *end, *flag;   /* [n_reads] */
+    const int64_t *off;                  /* [n_reads+1] into codes */
+    const uint8_t *codes;
+    int64_t n_codes;
+    const int32_t *ev_off;               /* [n_reads+1] */
+    const int32_t *ev_pos, *ev_len;      /* ev_len > 0 insertion, < 0 deletion */
+    int64_t n_events;
+    const uint8_t *hap;                  /* HP tag: 0 / 1 / 2 */
+    const int32_t *ps;                   /* PS tag or 0 */
+    const int64_t *seq_off;              /* [n_reads+1] into seq (all zero when keep_seq == 0) */
+    const uint8_t *seq;
+    int64_t n_seq;
+    const int32_t *name_off;             /* [n_reads+1] into names (NUL-terminated strings) */
+    const char *names;
+} nc_decoded_arrays;
+
+int nc_bam_open(const char *path, nc_bam **out);
+int nc_bam_close(nc_bam *bam);
+int nc_bam_n_refs(nc_bam *bam, int32_t *n_refs, int32_t *has_index);
+int nc_bam_ref(nc_bam *bam, int32_t i, const char **name, int32_t *length);
+const char *nc_bam_error(const nc_bam *bam);
+/* alignments of reference `tid` overlapping [beg1, end1] (1-based, inclusive), in coordinate order */
+int nc_bam_decode(nc_bam *bam, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, nc_decoded **out);
+int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *view);
+int nc_decoded_free(nc_decoded *d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ EXPORTS = [
     "nc_last_error", "nc_malloc", "nc_free", "nc_memcpy_h2d", "nc_memcpy_d2h", "nc_last_kernel_ms",
     "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
+    "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
+    "nc_decoded_free",
 ]
 
 
@@ -55,6 +57,14 @@ class IndelEventsC(C.Structure):
 class IndelScanParamsC(C.Structure):
     _fields_ = [("mincov", C.c_int32), ("win_size", C.c_int32), ("small_win_size", C.c_int32), ("ins_t", C.c_double),
                 ("del_t", C.c_double)]
+
+
+class DecodedArraysC(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("start", C.c_void_p), ("end", C.c_void_p), ("flag", C.c_void_p), ("off", C.c_void_p),
+                ("codes", C.c_void_p), ("n_codes", C.c_int64), ("ev_off", C.c_void_p), ("ev_pos", C.c_void_p),
+                ("ev_len", C.c_void_p), ("n_events", C.c_int64), ("hap", C.c_void_p), ("ps", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq", C.c_void_p), ("n_seq", C.c_int64), ("name_off", C.c_void_p),
+                ("names", C.c_void_p)]
 
 
 _lib = None
@@ -100,9 +110,18 @@ def lib():
         L.nc_indel_forward.argtypes = [vp, i32, i64, vp, vp]
         L.nc_indel_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.nc_indel_scan.argtypes = [vp, C.POINTER(ReadPackC), C.POINTER(IndelEventsC), vp, i32, i32, C.POINTER(IndelScanParamsC), vp]
+        L.nc_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.nc_bam_close.argtypes = [vp]
+        L.nc_bam_n_refs.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        L.nc_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i32)]
+        L.nc_bam_error.argtypes = [vp]
+        L.nc_bam_error.restype = C.c_char_p
+        L.nc_bam_decode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
+        L.nc_decoded_view.argtypes = [vp, C.POINTER(DecodedArraysC)]
+        L.nc_decoded_free.argtypes = [vp]
         for name in EXPORTS:
             fn = getattr(L, name)
-            if name not in ("nc_last_error",):
+            if name not in ("nc_last_error", "nc_bam_error"):
                 fn.restype = C.c_int
         _lib = L
     return _lib

@@ -1,0 +1,119 @@
+"""BAM / FASTA ingest for the hot path: decoded alignments without pysam.
+
+`read_bam(path, chrom, start, end)` uses the library's native BGZF/BAM reader (nc_bam_*) and returns a
+`synth.World` -- the same decoded-alignment object the packer, the kernels and the tests use -- so
+`dct['sam_path']` may be a BAM path wherever a World is accepted.  `read_fasta` is a plain (.fai-aware) reader.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .synth import World
+
+
+def _arr(ptr, n, dtype):
+    if not n or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class BamFile:
+    def __init__(self, path):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        if self.L.nc_bam_open(os.fsencode(path), C.byref(self.h)) != _lib.NC_OK:
+            raise IOError("cannot open %s as a BAM file" % path)
+        n, idx = C.c_int32(), C.c_int32()
+        self.L.nc_bam_n_refs(self.h, C.byref(n), C.byref(idx))
+        self.has_index = bool(idx.value)
+        self.references, self.lengths = [], []
+        for i in range(n.value):
+            nm, ln = C.c_char_p(), C.c_int32()
+            self.L.nc_bam_ref(self.h, i, C.byref(nm), C.byref(ln))
+            self.references.append(nm.value.decode())
+            self.lengths.append(ln.value)
+
+    def close(self):
+        if self.h:
+            self.L.nc_bam_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # pysam.Samfile look-alikes used by utils.get_regions_list (utils.py:9-48)
+    def is_valid_reference_name(self, c):
+        return c in self.references
+
+    def get_reference_length(self, c):
+        return self.lengths[self.references.index(c)]
+
+    def decode(self, chrom, start=1, end=None, keep_seq=False):
+        """-> dict of numpy arrays for the mapped alignments overlapping [start, end] (1-based inclusive)."""
+        tid = self.references.index(chrom)
+        end = self.lengths[tid] if end is None else min(int(end), self.lengths[tid])
+        d = C.c_void_p()
+        rc = self.L.nc_bam_decode(self.h, tid, max(1, int(start)), max(int(start), end), 1 if keep_seq else 0, C.byref(d))
+        if rc != _lib.NC_OK:
+            raise IOError("BAM decode failed: %s" % self.L.nc_bam_error(self.h).decode())
+        v = _lib.DecodedArraysC()
+        self.L.nc_decoded_view(d, C.byref(v))
+        n = v.n_reads
+        out = dict(read_start=_arr(v.start, n, np.int32), read_end=_arr(v.end, n, np.int32), read_flag=_arr(v.flag, n, np.int32),
+                   read_off=_arr(v.off, n + 1, np.int64), codes=_arr(v.codes, v.n_codes, np.uint8),
+                   ev_off=_arr(v.ev_off, n + 1, np.int32), ev_pos=_arr(v.ev_pos, v.n_events, np.int32),
+                   ev_len=_arr(v.ev_len, v.n_events, np.int32), hap=_arr(v.hap, n, np.uint8), ps=_arr(v.ps, n, np.int32),
+                   seq_off=_arr(v.seq_off, n + 1, np.int64), seq=_arr(v.seq, v.n_seq, np.uint8))
+        name_off = _arr(v.name_off, n + 1, np.int32)
+        names_raw = _arr(v.names, int(name_off[-1]) if n else 0, np.uint8).tobytes()
+        out["names"] = [names_raw[name_off[i]:name_off[i + 1] - 1].decode() for i in range(n)]
+        self.L.nc_decoded_free(d)
+        return out
+
+
+def read_fasta(path, chrom):
+    """Whole contig as a string (case preserved: soft-masked bases matter, quirk E4).  Uses <path>.fai if present."""
+    fai = path + ".fai"
+    if os.path.exists(fai):
+        for line in open(fai):
+            f = line.rstrip("\n").split("\t")
+            if f[0] == chrom:
+                length, offset, lb, lw = int(f[1]), int(f[2]), int(f[3]), int(f[4])
+                with open(path, "rb") as fh:
+                    fh.seek(offset)
+                    raw = fh.read(length + (length // lb + 1) * (lw - lb))
+                return raw.replace(b"\n", b"").replace(b"\r", b"")[:length].decode("ascii")
+        raise KeyError(chrom)
+    seq, on = [], False
+    for line in open(path):
+        if line.startswith(">"):
+            if on:
+                break
+            on = line[1:].split()[0] == chrom
+        elif on:
+            seq.append(line.strip())
+    if not seq:
+        raise KeyError(chrom)
+    return "".join(seq)
+
+
+def read_bam(bam_path, fasta_path, chrom, start=1, end=None, keep_seq=False) -> World:
+    """Decoded alignments of `chrom` overlapping [start, end] + the contig's reference sequence."""
+    bf = BamFile(bam_path)
+    d = bf.decode(chrom, start, end, keep_seq)
+    bf.close()
+    ref = read_fasta(fasta_path, chrom)
+    w = World(chrom=chrom, ref=ref, read_start=d["read_start"], read_end=d["read_end"], read_flag=d["read_flag"],
+              read_off=d["read_off"], codes=d["codes"], names=d["names"])
+    w.meta.update(events=(d["ev_off"], d["ev_pos"], d["ev_len"]), hap=d["hap"], ps=d["ps"])
+    if keep_seq:
+        w.meta.update(seq_off=d["seq_off"], seq=d["seq"])
+    return w

@@ -1,0 +1,377 @@
+// Native BGZF / BAM / BAI ingest: decodes alignments straight into the read-major form the read pack is built from.
+//
+// Replaces the pysam/htslib objects of the reference (generate_SNP_pileups.py:134-164, generate_indel_pileups.py:147,
+// 178-188, 213-235): per alignment the reference span [start, end), one base code per spanned reference position
+// (A=0 G=1 T=2 C=3; deletion, reference skip and any other base = 4, i.e. the '*' / 'N' rows of base_to_num_map,
+// generate_SNP_pileups.py:104), the insertion / deletion markers that pysam appends to the pileup string of the column
+// BEFORE the event ('+n' / '-n'), the HP / PS tags, and the query sequence (for the indel pass-2 read slices).
+// Host code only; file formats follow the SAM/BAM specification (SAMv1 section 4 and 5).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nanocaller_hip.h"
+
+namespace {
+
+struct Bgzf {
+    FILE *f = nullptr;
+    std::vector<uint8_t> comp, block;
+    int64_t block_coff = 0;     // compressed offset of the current block
+    size_t upos = 0;            // read position inside `block`
+    bool eof = false;
+
+    bool load_block(int64_t coff)
+    {
+        if (fseeko(f, coff, SEEK_SET) != 0) return false;
+        uint8_t h[18];
+        size_t n = fread(h, 1, 18, f);
+        if (n == 0) { eof = true; block.clear(); upos = 0; block_coff = coff; return true; }
+        if (n != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+        const int xlen = h[10] | (h[11] << 8);
+        // find the BC subfield (it is first in every writer in practice, but walk the extra field to be safe)
+        std::vector<uint8_t> extra((size_t)xlen);
+        memcpy(extra.data(), h + 12, std::min(6, xlen));
+        if (xlen > 6 && fread(extra.data() + 6, 1, (size_t)xlen - 6, f) != (size_t)xlen - 6) return false;
+        int bsize = -1;
+        for (int p = 0; p + 4 <= xlen;) {
+            const int slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = (extra[p + 4] | (extra[p + 5] << 8)) + 1;
+            p += 4 + slen;
+        }
+        if (bsize < 0) return false;
+        const int clen = bsize - xlen - 12 - 8;
+        if (clen < 0) return false;
+        comp.resize((size_t)clen + 8);
+        if (fread(comp.data(), 1, comp.size(), f) != comp.size()) return false;
+        const uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
+        block.resize(isize);
+        if (isize) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            zs.next_in = comp.data();
+            zs.avail_in = (uInt)clen;
+            zs.next_out = block.data();
+            zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) return false;
+            const uint32_t crc = comp[clen] | (comp[clen + 1] << 8) | (comp[clen + 2] << 16) | ((uint32_t)comp[clen + 3] << 24);
+            if ((uint32_t)crc32(0L, block.data(), isize) != crc) return false;
+        }
+        block_coff = coff;
+        next_coff = coff + bsize;
+        upos = 0;
+        return true;
+    }
+    int64_t next_coff = 0;
+
+    bool seek(uint64_t voff)
+    {
+        eof = false;
+        if (!load_block((int64_t)(voff >> 16))) return false;
+        upos = (size_t)(voff & 0xffff);
+        return upos <= block.size();
+    }
+    // returns false on EOF / error; *ok distinguishes
+    bool read(void *dst, size_t n, bool *err)
+    {
+        uint8_t *d = (uint8_t *)dst;
+        while (n) {
+            if (upos >= block.size()) {
+                if (eof) return false;
+                if (!load_block(next_coff)) { *err = true; return false; }
+                if (eof) return false;
+                continue;
+            }
+            const size_t k = std::min(n, block.size() - upos);
+            memcpy(d, block.data() + upos, k);
+            d += k; upos += k; n -= k;
+        }
+        return true;
+    }
+};
+
+inline int32_t rd32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+inline uint32_t rdu32(const uint8_t *p) { return (uint32_t)rd32(p); }
+
+// 4-bit BAM base "=ACMGRSVTWYHKDBN" -> reference code map A=0 G=1 T=2 C=3, everything else 4
+const uint8_t NT16_CODE[16] = {4, 0, 3, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4};
+
+}   // namespace
+
+struct nc_bam {
+    Bgzf z;
+    std::string path;
+    std::vector<std::string> ref_name;
+    std::vector<int32_t> ref_len;
+    uint64_t first_rec_voff = 0;
+    // BAI linear index: per reference, smallest virtual offset of an alignment overlapping each 16 kb window
+    std::vector<std::vector<uint64_t>> lin;
+    bool have_bai = false;
+    char err[256] = {0};
+};
+
+struct nc_decoded {
+    std::vector<int32_t> start, end, flag, ev_off, ev_pos, ev_len, ps, name_off;
+    std::vector<int64_t> off, seq_off;
+    std::vector<uint8_t> codes, hap, seq;
+    std::vector<char> names;
+};
+
+namespace {
+
+int bam_fail(nc_bam *b, int code, const char *msg)
+{
+    if (b) snprintf(b->err, sizeof b->err, "%s", msg);
+    return code;
+}
+
+bool load_bai(nc_bam *b)
+{
+    FILE *f = fopen((b->path + ".bai").c_str(), "rb");
+    if (!f) {
+        std::string alt = b->path;
+        if (alt.size() > 4 && alt.substr(alt.size() - 4) == ".bam") alt = alt.substr(0, alt.size() - 4) + ".bai";
+        f = fopen(alt.c_str(), "rb");
+    }
+    if (!f) return false;
+    auto r32 = [&](int32_t &v) { uint8_t t[4]; if (fread(t, 1, 4, f) != 4) return false; v = rd32(t); return true; };
+    auto r64 = [&](uint64_t &v) { uint8_t t[8]; if (fread(t, 1, 8, f) != 8) return false; v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | t[i]; return true; };
+    char magic[4];
+    int32_t n_ref = 0;
+    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BAI\1", 4) == 0 && r32(n_ref) && n_ref == (int32_t)b->ref_name.size();
+    b->lin.assign(ok ? (size_t)n_ref : 0, {});
+    for (int32_t r = 0; ok && r < n_ref; r++) {
+        int32_t n_bin = 0;
+        ok = r32(n_bin);
+        for (int32_t k = 0; ok && k < n_bin; k++) {
+            int32_t bin = 0, n_chunk = 0;
+            ok = r32(bin) && r32(n_chunk) && fseeko(f, (off_t)n_chunk * 16, SEEK_CUR) == 0;
+        }
+        int32_t n_intv = 0;
+        ok = ok && r32(n_intv);
+        if (ok) b->lin[(size_t)r].resize((size_t)n_intv);
+        for (int32_t k = 0; ok && k < n_intv; k++) ok = r64(b->lin[(size_t)r][(size_t)k]);
+    }
+    fclose(f);
+    if (!ok) b->lin.clear();
+    return ok;
+}
+
+}   // namespace
+
+extern "C" {
+
+int nc_bam_open(const char *path, nc_bam **out)
+{
+    if (!path || !out) return NC_ERR_ARG;
+    *out = nullptr;
+    nc_bam *b = new nc_bam();
+    b->path = path;
+    b->z.f = fopen(path, "rb");
+    if (!b->z.f) { delete b; return NC_ERR_ARG; }
+    bool err = false;
+    uint8_t h[12];
+    auto fail = [&]() { fclose(b->z.f); delete b; return NC_ERR_ARG; };
+    if (!b->z.load_block(0) || !b->z.read(h, 8, &err) || memcmp(h, "BAM\1", 4) != 0) return fail();
+    const int32_t l_text = rd32(h + 4);
+    std::vector<uint8_t> text((size_t)std::max(0, l_text));
+    if (l_text > 0 && !b->z.read(text.data(), (size_t)l_text, &err)) return fail();
+    if (!b->z.read(h, 4, &err)) return fail();
+    const int32_t n_ref = rd32(h);
+    for (int32_t r = 0; r < n_ref; r++) {
+        if (!b->z.read(h, 4, &err)) return fail();
+        const int32_t l_name = rd32(h);
+        std::vector<char> nm((size_t)l_name);
+        if (!b->z.read(nm.data(), (size_t)l_name, &err) || !b->z.read(h, 4, &err)) return fail();
+        b->ref_name.emplace_back(nm.data());
+        b->ref_len.push_back(rd32(h));
+    }
+    b->first_rec_voff = ((uint64_t)b->z.block_coff << 16) | (uint64_t)b->z.upos;
+    if (b->z.upos >= b->z.block.size() && !b->z.eof) b->first_rec_voff = (uint64_t)b->z.next_coff << 16;
+    b->have_bai = load_bai(b);
+    *out = b;
+    return NC_OK;
+}
+
+int nc_bam_close(nc_bam *b)
+{
+    if (!b) return NC_OK;
+    if (b->z.f) fclose(b->z.f);
+    delete b;
+    return NC_OK;
+}
+
+int nc_bam_n_refs(nc_bam *b, int32_t *n, int32_t *has_index)
+{
+    if (!b || !n) return NC_ERR_ARG;
+    *n = (int32_t)b->ref_name.size();
+    if (has_index) *has_index = b->have_bai ? 1 : 0;
+    return NC_OK;
+}
+
+int nc_bam_ref(nc_bam *b, int32_t i, const char **name, int32_t *len)
+{
+    if (!b || i < 0 || i >= (int32_t)b->ref_name.size()) return NC_ERR_ARG;
+    if (name) *name = b->ref_name[(size_t)i].c_str();
+    if (len) *len = b->ref_len[(size_t)i];
+    return NC_OK;
+}
+
+const char *nc_bam_error(const nc_bam *b) { return b ? b->err : "null handle"; }
+
+// Decodes every mapped alignment of reference `tid` that overlaps [beg1, end1] (1-based, inclusive), in file
+// (coordinate) order.  The BAM must be coordinate-sorted; with a .bai next to it the scan starts at the linear-index
+// offset of beg1, otherwise at the first record.
+int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, nc_decoded **out)
+{
+    if (!b || !out || tid < 0 || tid >= (int32_t)b->ref_name.size() || end1 < beg1) return NC_ERR_ARG;
+    *out = nullptr;
+    uint64_t voff = b->first_rec_voff;
+    if (b->have_bai && (size_t)tid < b->lin.size()) {
+        const auto &L = b->lin[(size_t)tid];
+        const size_t w = (size_t)std::max(0, beg1 - 1) >> 14;
+        if (w < L.size() && L[w]) voff = L[w];
+        else if (!L.empty() && w >= L.size()) { if (L.back()) voff = L.back(); }
+    }
+    if (!b->z.seek(voff)) return bam_fail(b, NC_ERR_ARG, "BGZF seek failed");
+    nc_decoded *d = new nc_decoded();
+    d->off.push_back(0);
+    d->ev_off.push_back(0);
+    d->seq_off.push_back(0);
+    d->name_off.push_back(0);
+    std::vector<uint8_t> rec;
+    bool err = false;
+    const int32_t beg0 = beg1 - 1, end0 = end1;      // 0-based half-open
+    for (;;) {
+        uint8_t lb[4];
+        if (!b->z.read(lb, 4, &err)) break;
+        const int32_t bs = rd32(lb);
+        if (bs < 32) { err = true; break; }
+        rec.resize((size_t)bs);
+        if (!b->z.read(rec.data(), (size_t)bs, &err)) { err = true; break; }
+        const uint8_t *p = rec.data();
+        const int32_t refid = rd32(p), pos = rd32(p + 4);
+        const int l_name = p[8];
+        const int n_cig = p[12] | (p[13] << 8), flag = p[14] | (p[15] << 8);
+        const int32_t l_seq = rd32(p + 16);
+        if (refid < 0 || refid > tid) { if (refid > tid) break; else continue; }
+        if (refid < tid) continue;
+        if (pos >= end0) break;                       // sorted: nothing further can overlap
+        if (flag & 0x4) continue;
+        const uint8_t *name = p + 32, *cig = name + l_name, *seq = cig + 4 * n_cig, *qual = seq + (l_seq + 1) / 2;
+        const uint8_t *aux = qual + l_seq, *aux_end = p + bs;
+        if (aux > aux_end) { err = true; break; }
+        // reference span
+        int32_t rlen = 0;
+        for (int k = 0; k < n_cig; k++) {
+            const uint32_t c = rdu32(cig + 4 * k);
+            const int op = c & 15, len = (int)(c >> 4);
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += len;
+        }
+        if (rlen <= 0 || pos + rlen <= beg0) continue;
+        // codes + indel markers
+        const size_t c0 = d->codes.size();
+        d->codes.resize(c0 + (size_t)rlen);
+        uint8_t *co = d->codes.data() + c0;
+        int32_t rp = 0, qp = 0;
+        for (int k = 0; k < n_cig; k++) {
+            const uint32_t c = rdu32(cig + 4 * k);
+            const int op = c & 15, len = (int)(c >> 4);
+            switch (op) {
+            case 0: case 7: case 8:                                   // M, =, X
+                for (int i = 0; i < len; i++, rp++, qp++) co[rp] = NT16_CODE[(seq[qp >> 1] >> ((~qp & 1) << 2)) & 15];
+                break;
+            case 1:                                                   // I: '+n' on the previous reference column
+                if (rp > 0) { d->ev_pos.push_back(pos + rp); d->ev_len.push_back(len); }
+                qp += len;
+                break;
+            case 2:                                                   // D: '-n' on the previous column, then '*' columns
+                if (rp > 0) { d->ev_pos.push_back(pos + rp); d->ev_len.push_back(-len); }
+                for (int i = 0; i < len; i++, rp++) co[rp] = 4;
+                break;
+            case 3:                                                   // N (reference skip): the reference raises KeyError (E10); coded 4 here
+                for (int i = 0; i < len; i++, rp++) co[rp] = 4;
+                break;
+            case 4: qp += len; break;                                 // S
+            default: break;                                           // H, P
+            }
+        }
+        d->start.push_back(pos + 1);
+        d->end.push_back(pos + 1 + rlen);
+        d->flag.push_back(flag);
+        d->off.push_back((int64_t)d->codes.size());
+        d->ev_off.push_back((int32_t)d->ev_pos.size());
+        // tags HP / PS
+        int hp = 0, ps = 0;
+        for (const uint8_t *a = aux; a + 3 <= aux_end;) {
+            const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+            a += 3;
+            int64_t iv = 0;
+            bool is_int = true;
+            switch (ty) {
+            case 'c': iv = (int8_t)a[0]; a += 1; break;
+            case 'C': iv = a[0]; a += 1; break;
+            case 's': iv = (int16_t)(a[0] | (a[1] << 8)); a += 2; break;
+            case 'S': iv = a[0] | (a[1] << 8); a += 2; break;
+            case 'i': iv = rd32(a); a += 4; break;
+            case 'I': iv = rdu32(a); a += 4; break;
+            case 'A': a += 1; is_int = false; break;
+            case 'f': a += 4; is_int = false; break;
+            case 'Z': case 'H': while (a < aux_end && *a) a++; a++; is_int = false; break;
+            case 'B': {
+                const char st = (char)a[0];
+                const uint32_t cnt = rdu32(a + 1);
+                const int es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                a += 5 + (size_t)cnt * es;
+                is_int = false;
+                break; }
+            default: a = aux_end; is_int = false; break;
+            }
+            if (is_int && t0 == 'H' && t1 == 'P') hp = (int)iv;
+            if (is_int && t0 == 'P' && t1 == 'S') ps = (int)iv;
+        }
+        d->hap.push_back((uint8_t)((hp == 1 || hp == 2) ? hp : 0));
+        d->ps.push_back(ps);
+        d->names.insert(d->names.end(), (const char *)name, (const char *)name + l_name);   // includes the NUL
+        d->name_off.push_back((int32_t)d->names.size());
+        if (keep_seq) {
+            const size_t s0 = d->seq.size();
+            d->seq.resize(s0 + (size_t)l_seq);
+            for (int32_t q = 0; q < l_seq; q++) d->seq[s0 + (size_t)q] = NT16_CODE[(seq[q >> 1] >> ((~q & 1) << 2)) & 15];
+        }
+        d->seq_off.push_back((int64_t)d->seq.size());
+    }
+    if (err) { delete d; return bam_fail(b, NC_ERR_ARG, "truncated or corrupt BAM record / BGZF block"); }
+    *out = d;
+    return NC_OK;
+}
+
+int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *v)
+{
+    if (!d || !v) return NC_ERR_ARG;
+    v->n_reads = (int32_t)d->start.size();
+    v->start = d->start.data(); v->end = d->end.data(); v->flag = d->flag.data();
+    v->off = d->off.data(); v->codes = d->codes.data(); v->n_codes = (int64_t)d->codes.size();
+    v->ev_off = d->ev_off.data(); v->ev_pos = d->ev_pos.data(); v->ev_len = d->ev_len.data();
+    v->n_events = (int64_t)d->ev_pos.size();
+    v->hap = d->hap.data(); v->ps = d->ps.data();
+    v->seq_off = d->seq_off.data(); v->seq = d->seq.data(); v->n_seq = (int64_t)d->seq.size();
+    v->name_off = d->name_off.data(); v->names = d->names.data();
+    return NC_OK;
+}
+
+int nc_decoded_free(nc_decoded *d)
+{
+    delete d;
+    return NC_OK;
+}
+
+}   // extern "C"

@@ -4,11 +4,16 @@
 /root/reference nanocaller_src/generate_SNP_pileups.py:103-279; the column scan, neighbour selection and
 tensor build run in the HIP kernels of libnanocaller_hip.so (nc_snp_scan / nc_snp_featurize).
 
-Boundary note: BAM decoding is a "next" row, so `dct['sam_path']` names DECODED
-alignments -- a `synth.World`, or a key registered with `register_alignments` -- instead of a BAM file, and
-`dct['exclude_bed']` may be a list of (chrom, start, end) rows instead of a tabix path.
+Alignments: `dct['sam_path']` is a coordinate-sorted BAM (+ optional .bai) decoded by the library's native
+reader (nanocaller_amd/bam.py) together with `dct['fasta_path']`; already-decoded alignments are
+accepted too (a `synth.World`, or a key registered with `register_alignments`).  `dct['exclude_bed']` is a BED /
+bgzipped BED path (rows of the requested contig are used, like tbx.fetch(chrom), :114-116) or a list of
+(chrom, start, end) rows.
 """
 from __future__ import annotations
+
+import gzip
+import os
 
 import numpy as np
 
@@ -28,14 +33,23 @@ def register_alignments(key, world: World):
         del _PACKS[k]
 
 
-def _resolve(sam_path) -> World:
+_BAM_WORLDS = {}
+
+
+def _resolve(sam_path, chrom=None, fasta_path=None) -> World:
     if isinstance(sam_path, World):
         return sam_path
     if sam_path in _SOURCES:
         return _SOURCES[sam_path]
-    raise NotImplementedError(
-        "BAM decoding is not part of this build yet (SURVEY.md 8f n1): pass decoded alignments "
-        "(nanocaller_amd.synth.World) or register them with register_alignments(%r, world)" % (sam_path,))
+    if isinstance(sam_path, str) and os.path.exists(sam_path):
+        if chrom is None or not fasta_path:
+            raise ValueError("decoding %r needs the contig name and dct['fasta_path']" % sam_path)
+        key = (sam_path, fasta_path, chrom)
+        if key not in _BAM_WORLDS:
+            from .bam import read_bam
+            _BAM_WORLDS[key] = read_bam(sam_path, fasta_path, chrom)
+        return _BAM_WORLDS[key]
+    raise FileNotFoundError("alignments %r: not a BAM file, a World, or a registered key" % (sam_path,))
 
 
 def _exclude_rows(dct, chrom):
@@ -44,12 +58,19 @@ def _exclude_rows(dct, chrom):
         return None
     if isinstance(ex, (list, tuple)):
         return tuple((int(a), int(b)) for (c, a, b) in ex if c == chrom)
-    raise NotImplementedError("exclude_bed as a tabix file needs the BGZF reader (next row); pass a list of rows")
+    opener = gzip.open if str(ex).endswith(".gz") else open          # BGZF is a valid multi-member gzip stream
+    rows = []
+    with opener(ex, "rt") as f:
+        for line in f:
+            t = line.split()
+            if len(t) >= 3 and t[0] == chrom:
+                rows.append((int(t[1]), int(t[2])))
+    return tuple(rows)
 
 
 def device_pack_for(dct, chrom, device=0):
     """Packed + uploaded alignments of a contig (cached per source / filter / exclusion list)."""
-    world = _resolve(dct["sam_path"])
+    world = _resolve(dct["sam_path"], chrom, dct.get("fasta_path"))
     excl = _exclude_rows(dct, chrom)
     key = (dct["sam_path"] if not isinstance(dct["sam_path"], World) else id(world), bool(dct.get("supplementary")),
            excl, device)

@@ -42,7 +42,7 @@ def pick_variants(col_type, start, win_size):
 def scan_indel_candidates(dct, chunk, device=0):
     if dct.get("impute_indel_phase"):
         raise NotImplementedError("impute_indel_phase (generate_indel_pileups.py:278-304) is not part of this build")
-    world = _resolve(chunk["sam_path"])
+    world = _resolve(chunk["sam_path"], chunk["chrom"], dct.get("fasta_path"))
     excl_rows = _exclude_rows(dct, chunk["chrom"])
     key = (id(world), bool(dct.get("supplementary")), device)
     eng = get_engine(device)

@@ -1,0 +1,195 @@
+"""Test tooling: a minimal BAM / BAI / FASTA WRITER following the SAM/BAM specification (SAMv1 sections 4.2, 5.1.3,
+5.2), used to turn synthetic worlds into real files for the native reader (nanocaller_amd/csrc/nc_bam.cpp)."""
+import struct
+import zlib
+
+import numpy as np
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+_NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def reg2bin(beg, end):          # SAMv1 5.3, 0-based half-open
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+class BgzfWriter:
+    def __init__(self, path, block=0xff00):
+        self.f = open(path, "wb")
+        self.buf = bytearray()
+        self.coff = 0
+        self.block = block
+
+    def tell(self):
+        return (self.coff << 16) | len(self.buf)
+
+    def write(self, data):
+        i = 0
+        while i < len(data):
+            k = min(len(data) - i, self.block - len(self.buf))
+            self.buf += data[i:i + k]
+            i += k
+            if len(self.buf) >= self.block:
+                self.flush()
+
+    def flush(self):
+        if not self.buf:
+            return
+        raw = bytes(self.buf)
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(raw) + co.flush()
+        blk = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(comp) + 25) + comp + \
+            struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw))
+        self.f.write(blk)
+        self.coff += len(blk)
+        self.buf = bytearray()
+
+    def close(self):
+        self.flush()
+        self.f.write(_BGZF_EOF)
+        self.f.close()
+
+
+def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
+    """records: list of dict(name, flag, pos0, cigar=[(op,len)...] with op in 'MIDNSHP=X', seq (str), tags={'HP':1,...})
+    in coordinate order."""
+    refs = [(chrom, length)] + list(other_refs)
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    w = BgzfWriter(path)
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for n, ln in refs:
+        hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
+    w.write(hdr)
+    w.flush()
+    lin = {}
+    ops = "MIDNSHP=X"
+    for r in records:
+        cig = r["cigar"]
+        rlen = sum(ln for op, ln in cig if op in "MDN=X")
+        name = r["name"].encode() + b"\0"
+        seq = r["seq"]
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, c in enumerate(seq):
+            packed[i >> 1] |= _NT16.get(c, 15) << (4 if i % 2 == 0 else 0)
+        tags = b""
+        for k, v in r.get("tags", {}).items():
+            if isinstance(v, str):
+                tags += k.encode() + b"Z" + v.encode() + b"\0"
+            elif 0 <= v < 256:
+                tags += k.encode() + b"C" + struct.pack("<B", v)
+            else:
+                tags += k.encode() + b"i" + struct.pack("<i", v)
+        body = struct.pack("<iiBBHHHiiii", 0, r["pos0"], len(name), 60, reg2bin(r["pos0"], r["pos0"] + max(1, rlen)), len(cig),
+                           r["flag"], len(seq), -1, -1, 0) + name + b"".join(struct.pack("<I", (ln << 4) | ops.index(op)) for op, ln in cig) + \
+            bytes(packed) + b"\xff" * len(seq) + tags
+        voff = w.tell()
+        if not (r["flag"] & 4):
+            for win in range(r["pos0"] >> 14, ((r["pos0"] + max(1, rlen) - 1) >> 14) + 1):
+                lin.setdefault(win, voff)
+        w.write(struct.pack("<i", len(body)) + body)
+    w.close()
+    if write_bai:
+        n_intv = (max(lin) + 1) if lin else 0
+        arr = [0] * n_intv
+        last = 0
+        for k in range(n_intv):           # samtools fills empty windows with the previous offset
+            if k in lin:
+                last = lin[k]
+            arr[k] = last
+        with open(path + ".bai", "wb") as f:
+            f.write(b"BAI\1" + struct.pack("<i", len(refs)))
+            f.write(struct.pack("<i", 0) + struct.pack("<i", n_intv) + b"".join(struct.pack("<Q", v) for v in arr))
+            for _ in refs[1:]:
+                f.write(struct.pack("<ii", 0, 0))
+
+
+def write_fasta(path, chrom, seq, width=60, with_fai=True, extra=()):
+    off = {}
+    with open(path, "w") as f:
+        for name, s in [(chrom, seq)] + list(extra):
+            f.write(">%s some description\n" % name)
+            off[name] = (f.tell(), len(s))
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + "\n")
+    if with_fai:
+        with open(path + ".fai", "w") as f:
+            for name, (o, ln) in off.items():
+                f.write("%s\t%d\t%d\t%d\t%d\n" % (name, ln, o, width, width + 1))
+
+
+def world_to_records(world, rng):
+    """Alignment records equivalent to a world: explicit insertion / deletion events become I / D operations (deleted
+    positions must already be code 4 in the world), other code-4 positions are written as base N, reverse-strand /
+    filtered reads keep their flags, a soft clip is added at both ends."""
+    letters = "AGTCN"
+    ev_off, ev_pos, ev_len = world.meta["events"]
+    recs = []
+    for r in range(world.n_reads):
+        s, e = int(world.read_start[r]), int(world.read_end[r])
+        codes = world.read_codes(r)
+        evs = {int(ev_pos[k]): int(ev_len[k]) for k in range(ev_off[r], ev_off[r + 1])}
+        cig, seq = [("S", 3)], ["ACG"]
+        p = s
+        run = 0
+        while p < e:
+            seq.append(letters[codes[p - s]])
+            run += 1
+            ev = evs.get(p)
+            if ev:
+                cig.append(("M", run))
+                run = 0
+                if ev > 0:
+                    cig.append(("I", ev))
+                    seq.append("".join(letters[i] for i in rng.integers(0, 4, size=ev)))
+                else:
+                    cig.append(("D", -ev))
+                    p += -ev
+            p += 1
+        if run:
+            cig.append(("M", run))
+        cig.append(("S", 2))
+        seq.append("TT")
+        tags = {}
+        if world.meta["hap"][r]:
+            tags = {"HP": int(world.meta["hap"][r]), "PS": int(world.meta["ps"][r])}
+        recs.append(dict(name=world.names[r], flag=int(world.read_flag[r]), pos0=s - 1, cigar=cig, seq="".join(seq), tags=tags))
+    return recs
+
+
+def make_bam_world(seed=5, length=30_000, depth=12):
+    """A world whose codes are consistent with its indel events (deleted positions are code 4; events never sit on the
+    last positions of a read, never overlap, never start inside a deletion)."""
+    from nanocaller_amd.synth import add_indels, make_world
+    w = add_indels(make_world(seed=seed, length=length, depth=depth, read_len_scale=0.15, odd_flag_frac=0.05), seed=seed,
+                   het_rate=1 / 400.0, noise_rate=0.003)
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    new_off, new_pos, new_len = [0], [], []
+    codes = w.codes.copy()
+    for r in range(w.n_reads):
+        s, e = int(w.read_start[r]), int(w.read_end[r])
+        busy_until = s
+        for k in range(ev_off[r], ev_off[r + 1]):
+            p, ln = int(ev_pos[k]), int(ev_len[k])
+            need = -ln if ln < 0 else 0
+            if p < busy_until or p + need + 2 >= e or p <= s:
+                continue
+            if ln < 0:
+                codes[w.read_off[r] + (p + 1 - s):w.read_off[r] + (p + 1 - s) + need] = 4
+            new_pos.append(p)
+            new_len.append(ln)
+            busy_until = p + need + 1
+        new_off.append(len(new_pos))
+    w.codes = codes
+    w.meta["events"] = (np.array(new_off, np.int32), np.array(new_pos, np.int32), np.array(new_len, np.int32))
+    return w

@@ -1,0 +1,97 @@
+"""CPU-only: the native BGZF/BAM(+BAI)/FASTA ingest round-trips synthetic worlds written to real files."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from nanocaller_amd.bam import BamFile, read_bam, read_fasta
+from tests import bamio
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("bam")
+    w = bamio.make_bam_world()
+    rng = np.random.Generator(np.random.PCG64(1))
+    recs = bamio.world_to_records(w, rng)
+    # an unmapped read and a read on another contig must be skipped
+    recs_all = recs + [dict(name="other", flag=0, pos0=5, cigar=[("M", 20)], seq="A" * 20, tags={})]
+    bam = str(d / "w.bam")
+    bamio.write_bam(bam, w.chrom, w.length, recs, other_refs=[("chrOther", 1000)])
+    fa = str(d / "ref.fa")
+    bamio.write_fasta(fa, w.chrom, w.ref, extra=[("chrOther", "ACGT" * 250)])
+    return w, bam, fa, recs_all
+
+
+def test_written_bam_is_valid_bgzf(files):
+    _, bam, _, _ = files
+    raw = gzip.open(bam, "rb").read()
+    assert raw[:4] == b"BAM\x01"
+
+
+def _check(world, got, sel):
+    assert np.array_equal(got.read_start, world.read_start[sel]) and np.array_equal(got.read_end, world.read_end[sel])
+    assert np.array_equal(got.read_flag, world.read_flag[sel])
+    assert got.names == [world.names[i] for i in sel]
+    ev_off, ev_pos, ev_len = world.meta["events"]
+    g_off, g_pos, g_len = got.meta["events"]
+    for k, i in enumerate(sel):
+        assert np.array_equal(got.read_codes(k), world.read_codes(i)), i
+        assert np.array_equal(g_pos[g_off[k]:g_off[k + 1]], ev_pos[ev_off[i]:ev_off[i + 1]]), i
+        assert np.array_equal(g_len[g_off[k]:g_off[k + 1]], ev_len[ev_off[i]:ev_off[i + 1]]), i
+    assert np.array_equal(got.meta["hap"], world.meta["hap"][sel])
+    assert np.array_equal(got.meta["ps"], np.where(world.meta["hap"][sel] > 0, world.meta["ps"][sel], 0))
+
+
+def test_whole_contig_roundtrip(files):
+    world, bam, fa, _ = files
+    bf = BamFile(bam)
+    assert bf.references == [world.chrom, "chrOther"] and bf.get_reference_length(world.chrom) == world.length and bf.has_index
+    got = read_bam(bam, fa, world.chrom, keep_seq=True)
+    mapped = np.nonzero((world.read_flag & 4) == 0)[0]
+    assert len(mapped) < world.n_reads                      # the world contains unmapped-flag reads
+    _check(world, got, mapped)
+    assert got.ref == world.ref and read_fasta(fa, "chrOther") == "ACGT" * 250
+    assert got.meta["seq_off"][-1] == got.meta["seq"].size > got.codes.size * 0.9
+    assert sum(int((got.meta["events"][2] > 0).sum()) for _ in [0]) > 20 and int((got.meta["events"][2] < 0).sum()) > 20
+
+
+@pytest.mark.parametrize("use_index", [True, False])
+def test_region_queries(files, tmp_path, use_index):
+    world, bam, fa, _ = files
+    path = bam
+    if not use_index:
+        path = str(tmp_path / "noidx.bam")
+        open(path, "wb").write(open(bam, "rb").read())
+    bf = BamFile(path)
+    assert bf.has_index == use_index
+    for (a, b) in [(1, 500), (9_000, 9_001), (16_300, 16_500), (20_000, 30_000), (29_990, 40_000)]:
+        d = bf.decode(world.chrom, a, b)
+        exp = np.nonzero(((world.read_flag & 4) == 0) & (world.read_start <= min(b, world.length)) & (world.read_end > a))[0]
+        assert np.array_equal(d["read_start"], world.read_start[exp]), (a, b)
+        assert d["names"] == [world.names[i] for i in exp]
+    # no .fai: the plain scanner gives the same sequence
+    fa2 = str(tmp_path / "r2.fa")
+    bamio.write_fasta(fa2, world.chrom, world.ref, width=71, with_fai=False)
+    assert read_fasta(fa2, world.chrom) == world.ref
+
+
+def test_cigar_edge_cases(tmp_path):
+    recs = [
+        dict(name="a", flag=16, pos0=99, cigar=[("H", 5), ("S", 2), ("M", 4), ("I", 3), ("M", 2), ("D", 2), ("M", 3), ("N", 4), ("=", 2), ("X", 1), ("S", 1)],
+             seq="TTACGTAAAGGCATACGA", tags={"HP": 2, "PS": 70000, "XX": "str"}),
+        dict(name="b", flag=0x800, pos0=100, cigar=[("I", 2), ("M", 5)], seq="GGACGTN", tags={}),
+    ]
+    bam = str(tmp_path / "e.bam")
+    bamio.write_bam(bam, "c", 1000, recs)
+    bf = BamFile(bam)
+    d = bf.decode("c", 1, 1000, keep_seq=True)
+    assert d["read_start"].tolist() == [100, 101] and d["read_end"].tolist() == [100 + 4 + 2 + 2 + 3 + 4 + 3, 106]
+    c0 = d["codes"][d["read_off"][0]:d["read_off"][1]].tolist()
+    #      A C G T | G G | D D | C A T | N N N N | A C | G      (codes A0 G1 T2 C3, del/skip 4)
+    assert c0 == [0, 3, 1, 2, 1, 1, 4, 4, 3, 0, 2, 4, 4, 4, 4, 0, 3, 1]
+    assert d["ev_pos"][d["ev_off"][0]:d["ev_off"][1]].tolist() == [103, 105] and d["ev_len"][:2].tolist() == [3, -2]
+    assert d["hap"].tolist() == [2, 0] and d["ps"].tolist() == [70000, 0] and d["read_flag"].tolist() == [16, 0x800]
+    assert d["ev_off"].tolist() == [0, 2, 2]                # a leading insertion has no previous column: no marker
+    assert d["codes"][d["read_off"][1]:].tolist() == [0, 3, 1, 2, 4] and d["names"] == ["a", "b"]

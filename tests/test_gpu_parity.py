@@ -234,3 +234,30 @@ def test_indel_window_scan_matches_reference_pass1(eng):
         assert sorted(got) == op.tolist()
         n += len(got)
     assert n > 100
+
+
+def test_bam_and_fasta_files_end_to_end(eng, tmp_path):
+    """real files in (BAM + BAI + FASTA + bgzipped BED), VCF out: identical to the run on the in-memory world"""
+    import gzip
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.utils import get_chunks
+    from tests import bamio
+    world = bamio.make_bam_world(seed=9, length=40_000, depth=22)
+    rng = np.random.Generator(np.random.PCG64(2))
+    bam, fa, bed = str(tmp_path / "s.bam"), str(tmp_path / "r.fa"), str(tmp_path / "x.bed.gz")
+    bamio.write_bam(bam, world.chrom, world.length, bamio.world_to_records(world, rng))
+    bamio.write_fasta(fa, world.chrom, world.ref)
+    snpCaller.bgzf_write(bed, b"chrZ\t1\t50\n%s\t12000\t12800\n" % world.chrom.encode())
+    regions = [(world.chrom, 2_000, 38_000, "diploid")]
+    outs = []
+    for tag, sam, ex in (("files", bam, bed), ("world", world, [(world.chrom, 12_000, 12_800)])):
+        vdir = tmp_path / tag
+        vdir.mkdir()
+        params = dict(chunks_list=get_chunks(regions, cpu=3), regions_list=regions, sam_path=sam, fasta_path=fa, mincov=4,
+                      maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6], snp_model="ONT-HG002", cpu=1,
+                      vcf_path=str(vdir), prefix="t", sample="S", seq="ont", supplementary=False, exclude_bed=ex,
+                      suppress_progress=True, disable_coverage_normalization=False)
+        snpCaller.call_manager(params)
+        outs.append(gzip.open(str(vdir / "t.unfiltered.snps.vcf.gz"), "rt").read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 100
+    assert not any(12_000 <= int(ln.split("\t")[1]) < 12_800 for ln in outs[0].splitlines() if not ln.startswith("#"))
