@@ -150,6 +150,12 @@ def main():
     dt = dist_max(dt)                       # MAX over ranks
     total_sites = dist_sum(n_sites)         # whole-job aggregate
     stage_ms /= max(1, args.steps)
+    # host genotype rules + VCF record text for one step's results (native formatter), untimed above: it is the third
+    # number SURVEY.md 8(d) asks for (kernels only / + D2H / end to end incl. host K6 + VCF text)
+    tv = time.perf_counter()
+    vcf = snpCaller.snp_vcf_text("chr20", r["pos"], r["ref"], r["probs"], r["dp"], r["freq"], r["fwd_dp"], r["rev_dp"],
+                                 haploid=(args.ploidy == "haploid"))
+    vcf_ms = (time.perf_counter() - tv) * 1e3
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_sites * args.steps / dt
@@ -176,6 +182,10 @@ def main():
                          "launches_per_step": n_launch, "avg_launch_ms": float(stage_ms[3] / n_launch),
                          "flop_per_launch": TRUNK_FLOP_PER_SITE * n_sites / n_launch,
                          "cnn_stage_tflops": cnn_tflops, "cnn_stage_ms": float(stage_ms[2])},
+            "three_numbers": {"kernels_only_sites_s": n_sites / ((stage_ms[0] + stage_ms[1] + stage_ms[2]) * 1e-3),
+                              "with_d2h_sites_s": n_sites / (ms_per_step * 1e-3),
+                              "end_to_end_incl_vcf_text_sites_s": n_sites / ((ms_per_step + vcf_ms) * 1e-3),
+                              "vcf_text_ms": vcf_ms, "vcf_bytes": len(vcf), "note": "rank 0, per GPU"},
             "stages": {"scan_ms": float(stage_ms[0]), "scan_GBs": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 if stage_ms[0] else 0,
                        "scan_frac_hbm": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[0] else 0,
                        "featurize_ms": float(stage_ms[1]),

@@ -254,6 +254,16 @@ int nc_bam_decode(nc_bam *bam, int32_t tid, int32_t beg1, int32_t end1, int32_t 
 int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *view);
 int nc_decoded_free(nc_decoded *d);
 
+/* ------------------------------------------------------------------ SNP genotype rules + VCF record text (host)
+ * Replaces the per-site Python loop of snpCaller.caller (snpCaller.py:113-198).  probs f32 [n][4]
+ * (diploid: class-1 probability of the A,G,T,C heads; haploid: 4-way softmax); order i32 [n][4] = np.argsort(probs,
+ * axis=1) computed by the caller (tie behaviour of the reference, quirk E15; unused when haploid); ref = reference
+ * base code; dp, freq, fwd / rev i32 [n][4] as produced by the scan / featurize calls.  Writes the records
+ * back-to-back into `out`; NC_ERR_CAPACITY if `cap` (>= 400 bytes per record recommended) is too small. */
+int nc_snp_vcf_format(const char *chrom, int64_t n, const int32_t *pos, const int32_t *ref, const float *probs,
+                      const int32_t *order, const int32_t *dp, const double *freq, const int32_t *fwd, const int32_t *rev,
+                      int32_t haploid, char *out, int64_t cap, int64_t *n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

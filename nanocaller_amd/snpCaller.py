@@ -96,6 +96,30 @@ def snp_vcf_lines_haploid(chrom, pos, ref_idx, probs, dp, freq):
     return out
 
 
+def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None, haploid=False) -> bytes:
+    """Same records as snp_vcf_lines / snp_vcf_lines_haploid, formatted by the library's native formatter
+    (nc_snp_vcf_format); np.argsort is evaluated here so ties resolve exactly as in the Python path (E15)."""
+    import ctypes as C
+    L = _lib.lib()
+    n = len(pos)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)          # noqa: E731
+    probs = np.ascontiguousarray(probs, np.float32)
+    order = None if haploid else i32(np.argsort(probs, axis=1))
+    pos_, ref_, dp_ = i32(pos), i32(ref_idx), i32(dp)
+    freq_ = np.ascontiguousarray(freq, np.float64)
+    fwd_ = None if haploid else i32(fwd_dp)
+    rev_ = None if haploid else i32(rev_dp)
+    cap = (400 + len(chrom)) * max(n, 1) + 1024
+    out = np.empty(cap, np.uint8)
+    nb = C.c_int64()
+    rc = L.nc_snp_vcf_format(chrom.encode(), n, _lib.npp(pos_), _lib.npp(ref_), _lib.npp(probs), _lib.npp(order),
+                             _lib.npp(dp_), _lib.npp(freq_), _lib.npp(fwd_), _lib.npp(rev_), 1 if haploid else 0,
+                             _lib.npp(out), cap, C.byref(nb))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_snp_vcf_format failed (%d)" % rc)
+    return out[:nb.value].tobytes()
+
+
 VCF_HEADER = (                                                      # snpCaller.py:259-276
     '##fileformat=VCFv4.2\n'
     '##FILTER=<ID=PASS,Description="All filters passed">\n'
@@ -185,10 +209,8 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             grp.sort(key=lambda c: c['start'])
             r = call_chunks(params, grp, device)
             if r['n']:
-                if ploidy == 'diploid':
-                    f.writelines(snp_vcf_lines(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq'], r['fwd_dp'], r['rev_dp']))
-                else:
-                    f.writelines(snp_vcf_lines_haploid(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq']))
+                f.write(snp_vcf_text(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq'], r['fwd_dp'], r['rev_dp'],
+                                     haploid=(ploidy != 'diploid')).decode())
             f.flush()
             os.fsync(f.fileno())
             for _ in grp:

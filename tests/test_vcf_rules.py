@@ -76,3 +76,29 @@ def test_bgzf_writer_is_valid_gzip(tmp_path):
     assert gzip.open(p, "rb").read() == data
     raw = open(p, "rb").read()
     assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw.endswith(snpCaller._BGZF_EOF)
+
+
+def test_native_formatter_matches_python_rules_and_reference():
+    """nc_snp_vcf_format == snp_vcf_lines (== the reference's caller() output) on the goldens and on 20k random sites
+    including saturated probabilities and ties."""
+    z = np.load(os.path.join(GOLD, "caller_vcf.npz"))
+    txt = snpCaller.snp_vcf_text("chr20", z["pos"], z["ref"], z["probs"], z["dp"], z["freq"], z["fwd"], z["rev"]).decode()
+    assert txt == str(z["vcf_diploid"])
+    rng = np.random.Generator(np.random.PCG64(17))
+    n = 20_000
+    probs = rng.random((n, 4)).astype(np.float32)
+    probs[rng.random((n, 4)) < 0.15] = 1.0
+    probs[rng.random((n, 4)) < 0.15] = 0.0
+    probs[::13] = np.float32(1.0) - np.float32(2.0 ** -24)
+    ref = rng.integers(0, 4, size=n)
+    pos = np.arange(1000, 1000 + n)
+    dp = rng.integers(4, 200, size=n)
+    freq = rng.random(n)
+    fwd = rng.integers(0, 90, size=(n, 4))
+    rev = rng.integers(0, 90, size=(n, 4))
+    assert snpCaller.snp_vcf_text("c", pos, ref, probs, dp, freq, fwd, rev).decode() == \
+        "".join(snpCaller.snp_vcf_lines("c", pos, ref, probs, dp, freq, fwd.astype(np.float64), rev.astype(np.float64)))
+    hp = rng.dirichlet(np.ones(4) * 0.2, size=n).astype(np.float32)
+    hp[::7] = np.float32([0, 1, 0, 0])
+    assert snpCaller.snp_vcf_text("c", pos, ref, hp, dp, freq, haploid=True).decode() == \
+        "".join(snpCaller.snp_vcf_lines_haploid("c", pos, ref, hp, dp, freq))
