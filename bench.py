@@ -32,6 +32,10 @@ TRUNK_FLOP_PER_SITE = 2 * (574_000 + 737_280 + 331_776)   # conv1 (3 kernels) + 
 # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: profiles/r01_final_pmc.md
 TRUNK_TRAFFIC_PER_SITE = (2 * 69.3e6 + 216e6 * 32768 / 31231) / 32768
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md, dense
+# k5_trunk_h3 issues 3 f16 MFMA products per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so the peak its ALGORITHMIC
+# FLOP can reach is the dense f16 MFMA peak / 3; it executes 687 v_mfma_f32_16x16x32_f16 per site (K zero-padding incl.)
+H3_MFMA_PER_SITE = 13 * 21 + 10 * 27 + 8 * 18
 HBM_PEAK_GBS = 8000.0
 
 
@@ -47,6 +51,8 @@ def parse():
     ap.add_argument("--ploidy", default="diploid", choices=["diploid", "haploid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=16)
+    ap.add_argument("--cnn-precision", default="default", choices=["default", "fp32", "fp16x3"],
+                    help="trunk kernel: exact fp32 MFMA (k4_conv12) or fp16x3 split precision (k5_trunk_h3)")
     return ap.parse_args()
 
 
@@ -114,6 +120,8 @@ def main():
     from nanocaller_amd.utils import get_chunks
 
     eng = get_engine(local)
+    exact_fp32 = args.cnn_precision == "fp32"               # library default = fp16x3 split precision
+    eng.set_cnn_precision(exact_fp32=exact_fp32)
     L = args.length
     t_gen = time.perf_counter()
     pack, info = make_device_workload(eng, L, depth=args.depth, tech=args.tech, seed=812 + rank)
@@ -166,22 +174,32 @@ def main():
         trunk_tflops = TRUNK_FLOP_PER_SITE * n_sites / (stage_ms[3] * 1e-3) / 1e12 if stage_ms[3] > 0 else 0.0
         scan_bytes = info["pileup_entries"] + L               # (d+1) B/column, SURVEY.md 8d
         feat_bytes = 5403 * n_sites
+        common = {"achieved": trunk_tflops, "unit": "TFLOP/s", "traffic": TRUNK_TRAFFIC_PER_SITE * n_sites / n_launch,
+                  "traffic_note": "HBM bytes per launch from committed PMC passes (profiles/), not re-measured in this run",
+                  "launches_per_step": n_launch, "avg_launch_ms": float(stage_ms[3] / n_launch),
+                  "flop_per_launch": TRUNK_FLOP_PER_SITE * n_sites / n_launch,
+                  "cnn_stage_tflops": cnn_tflops, "cnn_stage_ms": float(stage_ms[2])}
+        if exact_fp32:
+            roofline = {"bound": "mfma", "kernel": "k4_conv12: fused conv1+conv2+conv3 of the SNP CNN, fp32 MFMA 16x16x4",
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "frac": trunk_tflops / FP32_MFMA_PEAK_TFLOPS, **common}
+        else:
+            peak = F16_MFMA_PEAK_TFLOPS / 3.0
+            exec_tflops = H3_MFMA_PER_SITE * 16384.0 * n_sites / (stage_ms[3] * 1e-3) / 1e12 if stage_ms[3] > 0 else 0.0
+            roofline = {"bound": "mfma", "kernel": "k5_trunk_h3: fused conv1+conv2+conv3 of the SNP CNN, fp32-equivalent via 3 "
+                        "f16 MFMA 16x16x32 products (hi*hi + hi*lo + lo*hi), fp32 accumulate",
+                        "peak": peak, "peak_note": "dense f16 MFMA peak 2500 TF / 3 products per fp32-equivalent product",
+                        "frac": trunk_tflops / peak, "executed_f16_mfma_tflops": exec_tflops,
+                        "executed_frac_of_f16_peak": exec_tflops / F16_MFMA_PEAK_TFLOPS,
+                        "vs_fp32_mfma_peak": trunk_tflops / FP32_MFMA_PEAK_TFLOPS, **common}
         out = {
             "metric": "candidate sites/sec (pileup+CNN)", "value": value, "unit": "sites/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if exact_fp32 else "f32 (f16x3 split MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx %s, chr20-sized contig (%d bp, %d chunks of 500 kb) per GPU"
                        % (args.tech.upper(), args.depth, args.ploidy, L, len(chunks)), "sites_per_gpu": n_sites,
                        "pileup_entries_per_gpu": info["pileup_entries"], "model": args.model, "generator": "synth_v1 seed 812+rank",
                        "data_gen_s": round(t_gen, 2)},
-            "roofline": {"bound": "mfma", "kernel": "k4_conv12: fused conv1+conv2+conv3 of the SNP CNN, fp32 MFMA 16x16x4",
-                         "achieved": trunk_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": trunk_tflops / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": TRUNK_TRAFFIC_PER_SITE * n_sites / n_launch,
-                         "traffic_note": "HBM bytes per launch from committed PMC passes (profiles/r01_final_pmc.md), not re-measured in this run",
-                         "launches_per_step": n_launch, "avg_launch_ms": float(stage_ms[3] / n_launch),
-                         "flop_per_launch": TRUNK_FLOP_PER_SITE * n_sites / n_launch,
-                         "cnn_stage_tflops": cnn_tflops, "cnn_stage_ms": float(stage_ms[2])},
+            "roofline": roofline,
             "three_numbers": {"kernels_only_sites_s": n_sites / ((stage_ms[0] + stage_ms[1] + stage_ms[2]) * 1e-3),
                               "with_d2h_sites_s": n_sites / (ms_per_step * 1e-3),
                               "end_to_end_incl_vcf_text_sites_s": n_sites / ((ms_per_step + vcf_ms) * 1e-3),

@@ -172,6 +172,10 @@ int nc_snp_scale(nc_ctx *ctx, const int32_t *site_depth_dev, const uint8_t *vali
  * gt f32 [n][2] (diploid only, may be NULL).
  */
 int nc_load_weights(nc_ctx *ctx, int32_t model_kind, const float *blob_host, size_t n_floats);
+/* Arithmetic of the SNP convolution trunk: 0 (default) = fp16x3 split precision on the 16x-rate matrix pipe (every fp32
+ * operand as hi + lo halves, hi*hi + hi*lo + lo*hi with fp32 accumulation: fp32-rounding-level error, measured
+ * max |dp| ~1e-6); 1 = exact fp32 MFMA (bit-for-bit an fmaf chain). */
+int nc_set_cnn_precision(nc_ctx *ctx, int exact_fp32);
 int nc_snp_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev,
                    const double *scale_dev, int32_t scale_mode, float *probs_dev, float *gt_dev);
 /* Indel CNN (model_architect_indel.py:28-48 rows=15 -> [n][4]; haploid rows=5 -> [n][1] sigmoid). */

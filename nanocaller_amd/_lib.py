@@ -27,7 +27,7 @@ EXPORTS = [
     "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
-    "nc_decoded_free", "nc_snp_vcf_format",
+    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
         L.nc_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.nc_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
         L.nc_enable_timing.argtypes = [vp, C.c_int]
+        L.nc_set_cnn_precision.argtypes = [vp, C.c_int]
         L.nc_pack_plan.argtypes = [i32, vp, vp, vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
                                    C.POINTER(i64)]
         L.nc_pack_fill.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, vp, vp, i64]

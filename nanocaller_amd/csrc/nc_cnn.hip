@@ -11,6 +11,7 @@
 // weight: no LDS staging, no im2col, and the arithmetic is an fmaf chain in the reference's (tap, ci) order.
 // fp32 matrix and vector peaks are equal on gfx950 (157.3 TFLOP/s), so this VALU form has the same roof as
 // v_mfma_f32_* while keeping the weights out of the vector register file.
+#include <cmath>
 #include <vector>
 
 #include "nc_common.h"
@@ -24,6 +25,12 @@ constexpr float SELU_LA = 1.0507009873554805f * 1.6732632423543772f;
 // relative error ~1e-6 at most for x in [-20, 0]: absolute error of the negative branch < 2e-6); the tiny heads
 // use the accurate expf.  Parity tests hold the end-to-end probabilities far inside 1e-4.
 __device__ __forceinline__ float selu(float x) { return x > 0.0f ? SELU_L * x : SELU_LA * (__expf(x) - 1.0f); }
+// branchless form for the split-precision trunk (one v_exp + select; no exec-mask branch in the epilogues)
+__device__ __forceinline__ float selu_bl(float x)
+{
+    const float e = SELU_LA * (__expf(fminf(x, 0.0f)) - 1.0f);
+    return x > 0.0f ? SELU_L * x : e;
+}
 __device__ __forceinline__ float selu_acc(float x) { return x > 0.0f ? SELU_L * x : SELU_LA * (expf(x) - 1.0f); }
 
 // ---- conv1: the three `same` convolutions, fused.  Canonical weights: k11[1][5][CI][C1] b11 k12[5][1][CI][C1] b12
@@ -485,6 +492,303 @@ __global__ __launch_bounds__(256, 2) void k4_conv12(const float *__restrict__ x,
     }
 }
 
+
+// =====================================================================================================================
+// fp16x3 trunk: the same persistent, weight-stationary fused conv1+conv2+conv3 kernel on the 16x-rate matrix pipe.
+// Every fp32 operand v is split as v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (22 significand bits) and a product
+// is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation in v_mfma_f32_16x16x32_f16 (the dropped lo*lo term is
+// 2^-22 relative).  Weights are multiplied by a power of two S on the host before splitting, so their low parts stay
+// normal fp16 numbers; accumulators carry S*value and are rescaled (exactly) in the epilogue.  Emulated on the CPU
+// with the real weights this is indistinguishable from fp32 rounding (max |dp| 9e-7 vs 9e-7 for plain fp32);
+// activations peak near 1.5e3 for every model of the zoo (fp16 max 65504), and are clamped for safety.
+// K slots only have to agree between the A and B fragments: lane (row/col = l&15, group g = l>>4) holds slots (g, 0..7).
+// conv1: padded input image with channel pitch 6 -> the 5 taps x 5 channels of an image row are 30 contiguous halves
+// (+2 zero-weight slots) = ONE K=32 group per kernel row: 5 groups (5x5) + 1 (1x5, reuses the fragment of row 2) + 1
+// (5x1: its 25 (dy,ci) values are gathered from the centre column with ds_read_u16) = 7 groups x 3 MFMAs per tile of
+// 16 positions.  conv2: K = 288 = 9 groups, conv3: K = 192 = 6 groups.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int H_XP = 2448;               // halves per input plane: 9*45*6 = 2430 (+ slack for the 2 zero-weight slots)
+constexpr int H_P1 = 56;                 // channel pitch of the conv1 activation planes (48 + 8): 112 B, conflict-free b128 reads
+constexpr int H_P2 = 40;                 // channel pitch of the conv2 activation planes (32 + 8)
+constexpr int H_W1 = 7 * 64 * 8, H_W2 = 9 * 2 * 64 * 8, H_W3 = 6 * 4 * 64 * 8;       // halves per plane (hi or lo)
+constexpr int H_PACKED_BYTES = 2 * 2 * (H_W1 + H_W2 + H_W3) + 4 * (48 + 32 + 64 + 4);
+
+__device__ __forceinline__ h8 as_h8(uint4 v) { union { uint4 u; h8 h; } c; c.u = v; return c.h; }
+__device__ __forceinline__ void split_store(float v, _Float16 *hi_p, _Float16 *lo_p)
+{
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    const _Float16 hi = (_Float16)v;
+    *hi_p = hi;
+    *lo_p = (_Float16)(v - (float)hi);
+}
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+// Epilogue constants of the split-precision trunk: accumulators hold S * (conv + bias);
+//   selu(a / S) = L * max(a, 0) / S + L*A * (exp(min(a, 0) / S) - 1)
+// c1 = log2(e) / S, c2 = L / S, c3 = clamp of max(a, 0) that keeps the result inside fp16 range.
+struct h_epi { float c1, c2, c3; };
+__device__ __forceinline__ f32x4v selu4_scaled(const f32x4v &acc, const h_epi &k)
+{
+    f32x4v s;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float a = acc[r];
+        const float e = __builtin_amdgcn_exp2f(fminf(a, 0.0f) * k.c1);
+        const float neg = fmaf(e, SELU_LA, -SELU_LA);                 // exactly 0 for a >= 0
+        const float pos = __builtin_amdgcn_fmed3f(a, 0.0f, k.c3);
+        s[r] = fmaf(pos, k.c2, neg);
+    }
+    return s;
+}
+// The MFMAs are issued with the weights as the A operand, so a lane's four accumulator registers are four CONSECUTIVE
+// channels (4g .. 4g+3) of ONE position (c16): hi and lo halves go out as one ds_write_b64 each, no cross-lane traffic.
+__device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Float16 *lp)
+{
+    const h4 hi = __builtin_convertvector(v, h4);                     // v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x4v d = v - __builtin_convertvector(hi, f32x4v);         // exact in fp32
+    const h4 lo = __builtin_convertvector(d, h4);
+    *reinterpret_cast<h4 *>(hp) = hi;
+    *reinterpret_cast<h4 *>(lp) = lo;
+}
+// X = activation fragments (hi, lo), W = weight fragments (hi, lo); D[channel 4g + r][position c16]
+#define NC_MFMA3(ACC, XH, XL, WH, WL)                                          \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH, XH, ACC, 0, 0, 0);       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH, XL, ACC, 0, 0, 0);       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(WL, XH, ACC, 0, 0, 0);
+
+template <int NT>
+__device__ __forceinline__ void h_conv1_pass(const _Float16 *XH, const _Float16 *XL, _Float16 *A1H, _Float16 *A1L, const h8 (&wh)[7],
+                                             const h8 (&wl)[7], const int (&crel)[8], const float *__restrict__ b1s, const h_epi &epi,
+                                             int tile_first, int lane)
+{
+    const int g = lane >> 4, c16 = lane & 15;
+    int rowbase[NT], colbase[NT];
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        int p = (tile_first + 4 * tm) * 16 + c16;
+        p = p < 205 ? p : 204;
+        const int h = p / 41, w = p - h * 41;
+        rowbase[tm] = ((h * 45 + w) * 6 + 8 * g) >> 1;              // in dwords; 4-byte aligned by construction
+        colbase[tm] = (h * 45 + w + 2) * 6;                          // centre column (dx = 2), in halves
+        // opaque per call: keeps the (site-loop invariant) address arithmetic from being hoisted out of the site loop,
+        // where ~150 precomputed LDS addresses would stay live and spill
+        asm volatile("" : "+v"(rowbase[tm]), "+v"(colbase[tm]));
+    }
+    f32x4v acc1[NT], acc2[NT], acc3[NT];
+    {
+        const f32x4v x1 = *reinterpret_cast<const f32x4v *>(b1s + 4 * g), x2 = *reinterpret_cast<const f32x4v *>(b1s + 16 + 4 * g),
+                     x3 = *reinterpret_cast<const f32x4v *>(b1s + 32 + 4 * g);
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { acc1[tm] = x1; acc2[tm] = x2; acc3[tm] = x3; }
+    }
+    const uint32_t *xh32 = reinterpret_cast<const uint32_t *>(XH), *xl32 = reinterpret_cast<const uint32_t *>(XL);
+    // 5x1 kernel: slot (g, j) = k = 8g + j -> (dy = k / 5, ci = k % 5); crel[j] = dy * 270 + ci (a zero slot for k >= 25)
+    {
+        h8 ah[NT], al[NT];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                ah[tm][j] = XH[colbase[tm] + crel[j]];
+                al[tm][j] = XL[colbase[tm] + crel[j]];
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc2[tm], ah[tm], al[tm], wh[6], wl[6]) }
+    }
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) {
+        h8 ah[NT], al[NT];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) {
+            const int o = rowbase[tm] + dy * 135;                    // 270 halves per image row
+            ah[tm] = as_h8(make_uint4(xh32[o], xh32[o + 1], xh32[o + 2], xh32[o + 3]));
+            al[tm] = as_h8(make_uint4(xl32[o], xl32[o + 1], xl32[o + 2], xl32[o + 3]));
+        }
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc3[tm], ah[tm], al[tm], wh[dy], wl[dy]) }
+        if (dy == 2) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc1[tm], ah[tm], al[tm], wh[5], wl[5]) }
+        }
+        if (dy & 1) asm volatile("" ::: "memory");
+    }
+    int ob = (tile_first * 16 + c16) * H_P1 + 4 * g;                  // rows 205..207 are scratch rows (tile 12)
+    asm volatile("" : "+v"(ob));
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        const int o = ob + 64 * tm * H_P1;
+        split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1L + o);
+        split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 16, A1L + o + 16);
+        split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 32, A1L + o + 32);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void h_conv2(const _Float16 *A1H, const _Float16 *A1L, _Float16 *A2H, _Float16 *A2L, const h8 (&wh)[9],
+                                        const h8 (&wl)[9], const float *__restrict__ b2s, const h_epi &epi, int wv, int lane)
+{
+    const int g = lane >> 4, c16 = lane & 15, tn = wv & 1, t0 = wv >> 1;
+    int abase[NT];
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        const int p = (t0 + 2 * tm) * 16 + c16;          // < 80
+        const int y = p / 20, x = p - y * 20;
+        abase[tm] = (y * 41 + 2 * x) * H_P1;
+        asm volatile("" : "+v"(abase[tm]));
+    }
+    f32x4v acc[NT];
+    {
+        const f32x4v b = *reinterpret_cast<const f32x4v *>(b2s + tn * 16 + 4 * g);
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) acc[tm] = b;
+    }
+#pragma unroll
+    for (int G = 0; G < 9; G++) {
+        const int k0 = 32 * G + 8 * g;                   // first K slot of this lane group: k = tap*48 + ci
+        const int tap = k0 / 48, ci = k0 - tap * 48;
+        const int off = ((tap / 3) * 41 + (tap % 3)) * H_P1 + ci;
+        h8 ah[NT], al[NT];
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) {
+            ah[tm] = as_h8(*reinterpret_cast<const uint4 *>(A1H + abase[tm] + off));
+            al[tm] = as_h8(*reinterpret_cast<const uint4 *>(A1L + abase[tm] + off));
+        }
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc[tm], ah[tm], al[tm], wh[G], wl[G]) }
+        if (G & 1) asm volatile("" ::: "memory");        // keep at most two groups of A fragments in flight
+    }
+    int ob = (t0 * 16 + c16) * H_P2 + tn * 16 + 4 * g;
+    asm volatile("" : "+v"(ob));
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) split4_store(selu4_scaled(acc[tm], epi), A2H + ob + 32 * tm * H_P2, A2L + ob + 32 * tm * H_P2);
+}
+
+__device__ __forceinline__ void h_conv3(const _Float16 *A2H, const _Float16 *A2L, const h8 (&w3h)[6], const h8 (&w3l)[6],
+                                        const float *__restrict__ b3s, const h_epi &epi, float *__restrict__ out_site, int wv, int lane)
+{
+    const int g = lane >> 4, c16 = lane & 15;
+    int abase[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        int p = tm * 16 + c16;
+        p = p < 27 ? p : 26;
+        const int y = p / 9, x = p - y * 9;
+        abase[tm] = (y * 20 + 2 * x) * H_P2 + 8 * g;
+        asm volatile("" : "+v"(abase[tm]));
+    }
+    f32x4v acc[2];
+    acc[0] = *reinterpret_cast<const f32x4v *>(b3s + wv * 16 + 4 * g);
+    acc[1] = acc[0];
+#pragma unroll
+    for (int G = 0; G < 6; G++) {                        // K group G = tap G (32 channels)
+        const int off = ((G / 3) * 20 + (G % 3)) * H_P2;
+        const h8 bh = w3h[G], bl = w3l[G];
+        h8 ah[2], al[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            ah[tm] = as_h8(*reinterpret_cast<const uint4 *>(A2H + abase[tm] + off));
+            al[tm] = as_h8(*reinterpret_cast<const uint4 *>(A2L + abase[tm] + off));
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA3(acc[tm], ah[tm], al[tm], bh, bl) }
+    }
+    int ob = c16 * 64 + wv * 16 + 4 * g;
+    asm volatile("" : "+v"(ob));
+    h_epi e3 = epi;
+    e3.c3 = 3.0e38f;                                                  // fp32 output: no fp16 range clamp
+    *reinterpret_cast<f32x4v *>(out_site + ob) = selu4_scaled(acc[0], e3);
+    if (c16 < 11) *reinterpret_cast<f32x4v *>(out_site + ob + 16 * 64) = selu4_scaled(acc[1], e3);
+}
+
+__global__ __launch_bounds__(256, 2) void k5_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
+                                                      int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 XH[H_XP], XL[H_XP];
+    __shared__ __attribute__((aligned(16))) _Float16 A1H[208 * H_P1], A1L[208 * H_P1];
+    __shared__ __attribute__((aligned(16))) _Float16 A2H[80 * H_P2], A2L[80 * H_P2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // packed weights: [w1 hi | w1 lo | w2 hi | w2 lo | w3 hi | w3 lo] (halves) then b1*S, b2*S, b3*S, 1/S (f32)
+    const uint4 *w1h = reinterpret_cast<const uint4 *>(wp), *w1l = w1h + H_W1 / 8, *w2h = w1l + H_W1 / 8, *w2l = w2h + H_W2 / 8,
+                *w3h = w2l + H_W2 / 8, *w3l = w3h + H_W3 / 8;
+    const float *b1s = reinterpret_cast<const float *>(w3l + H_W3 / 8), *b2s = b1s + 48, *b3s = b2s + 32;
+    const float inv_s = b3s[64];
+    const h_epi epi = {inv_s * 1.44269504088896341f, inv_s * SELU_L, 60000.0f / (inv_s * SELU_L)};
+    // register-resident for the kernel's lifetime: conv1 (7 groups, 56 VGPRs, reused by 3-4 tiles per site); this wave's
+    // conv2 (9 groups) and conv3 (6 groups) fragments are re-read from L2 once per site, just before the barrier that
+    // precedes their use
+    h8 c1h[7], c1l[7];
+#pragma unroll
+    for (int q = 0; q < 7; q++) { c1h[q] = as_h8(w1h[q * 64 + lane]); c1l[q] = as_h8(w1l[q * 64 + lane]); }
+    int crel[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = 8 * (lane >> 4) + j;
+        crel[j] = k < 25 ? (k / 5) * 270 + (k % 5) : 5;             // slot 5 of a pixel is always zero
+    }
+    for (int i = threadIdx.x; i < H_XP; i += 256) { XH[i] = (_Float16)0.0f; XL[i] = (_Float16)0.0f; }
+    __syncthreads();
+    float pre[5];
+    float pre_sf = 1.0f;
+    double pre_sd = 1.0;
+    auto prefetch = [&](int64_t site) {
+        const float *xs = x + site * NC_SNP_TENSOR;
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int i = threadIdx.x + u * 256;
+            pre[u] = i < NC_SNP_TENSOR ? xs[i] : 0.0f;
+        }
+        if (scale) { pre_sd = scale[site0 + site]; pre_sf = (float)pre_sd; }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int i = threadIdx.x + u * 256;
+            if (i < NC_SNP_TENSOR) {
+                const int h = i / 205, rem = i - h * 205, w = rem / 5, c = rem - w * 5;
+                float v = pre[u];
+                if (scale && h > 0 && c < 4) v = scale_mode == 0 ? v * pre_sf : (float)((double)v * pre_sd);    // snpCaller.py:93-96
+                const int o = ((h + 2) * 45 + (w + 2)) * 6 + c;
+                split_store(v, XH + o, XL + o);
+            }
+        }
+    };
+    int64_t site = blockIdx.x;
+    if (site < n_sites) { prefetch(site); commit(); }
+    __syncthreads();
+    for (; site < n_sites; site += gridDim.x) {
+        const int64_t nxt = site + gridDim.x;
+        if (nxt < n_sites) prefetch(nxt);
+        h_conv1_pass<2>(XH, XL, A1H, A1L, c1h, c1l, crel, b1s, epi, wv, lane);
+        if (wv == 0) h_conv1_pass<2>(XH, XL, A1H, A1L, c1h, c1l, crel, b1s, epi, 8, lane);
+        else h_conv1_pass<1>(XH, XL, A1H, A1L, c1h, c1l, crel, b1s, epi, 8 + wv, lane);
+        h8 c2h[9], c2l[9];
+        {
+            // opaque per-iteration copies of the pointers: otherwise the (loop-invariant) fragment loads are hoisted out of
+            // the site loop and 120 VGPRs of conv2/conv3 weights stay live across conv1 -> scratch spills
+            const uint4 *p2h = w2h + (wv & 1) * 64 + lane, *p2l = w2l + (wv & 1) * 64 + lane;
+            asm volatile("" : "+v"(p2h), "+v"(p2l));
+#pragma unroll
+            for (int q = 0; q < 9; q++) { c2h[q] = as_h8(p2h[q * 128]); c2l[q] = as_h8(p2l[q * 128]); }
+        }
+        __syncthreads();
+        if (nxt < n_sites) commit();
+        if (wv < 2) h_conv2<3>(A1H, A1L, A2H, A2L, c2h, c2l, b2s, epi, wv, lane);
+        else h_conv2<2>(A1H, A1L, A2H, A2L, c2h, c2l, b2s, epi, wv, lane);
+        asm volatile("" ::: "memory");                   // conv2's fragments must not be kept live across the site loop
+        h8 c3h[6], c3l[6];
+        {
+            const uint4 *p3h = w3h + wv * 64 + lane, *p3l = w3l + wv * 64 + lane;
+            asm volatile("" : "+v"(p3h), "+v"(p3l));
+#pragma unroll
+            for (int q = 0; q < 6; q++) { c3h[q] = as_h8(p3h[q * 256]); c3l[q] = as_h8(p3l[q * 256]); }
+        }
+        __syncthreads();
+        h_conv3(A2H, A2L, c3h, c3l, b3s, epi, a3 + site * (27 * 64), wv, lane);
+        asm volatile("" ::: "memory");
+    }
+}
+#undef NC_MFMA3
+
 __device__ __forceinline__ void dense_small(const float *in, int n_in, const float *k, const float *b, int n_out, float *out, bool act)
 {
     for (int o = 0; o < n_out; o++) {
@@ -579,7 +883,7 @@ inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + pe
 
 // conv trunk for `nb` sites -> fc1 activations [nb][F]; *f1_out / *tail receive the fc1 buffer and the tail weights
 template <int H, int W, int CI, int C1, int C2, int C3, int F, int P2, int P3, bool MFMA>
-int run_trunk(nc_ctx *ctx, const float *w, const float *packed, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
+int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *packed_h, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
               const float **f1_out, const float **tail)
 {
     constexpr int H2 = H - 1, W2 = (W - 3) / 2 + 1, H3 = H2 - 1, W3 = (W2 - 3) / 2 + 1;
@@ -609,7 +913,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, int64_t site0, i
                 if (!ctx->kev[ctx->n_kev + e]) NC_HIP(ctx, hipEventCreate(&ctx->kev[ctx->n_kev + e]));
             (void)hipEventRecord(ctx->kev[ctx->n_kev], ctx->stream);
         }
-        hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a3, nb, scale, scale_mode, site0);
+        if (ctx->cnn_exact_fp32)
+            hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a3, nb, scale, scale_mode, site0);
+        else
+            hipLaunchKernelGGL(k5_trunk_h3, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
         if (tk) {
             (void)hipEventRecord(ctx->kev[ctx->n_kev + 1], ctx->stream);
             ctx->n_kev += 2;
@@ -689,6 +996,49 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         NC_HIP(ctx, hipMemcpyAsync(w.packed, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         w.n_packed = pk.size();
+        // ---- fp16x3 fragments: weights scaled by a power of two S (so that |w| * S <= 16384), split hi/lo on the host
+        float wmax = 0.0f;
+        for (const float *q = blob_host; q < b3 + 64; q++) wmax = std::fmax(wmax, std::fabs(*q));
+        float S = 1024.0f;
+        while (S > 1.0f && wmax * S > 16384.0f) S *= 0.5f;
+        std::vector<uint8_t> hp((size_t)H_PACKED_BYTES, 0);
+        _Float16 *w1h = reinterpret_cast<_Float16 *>(hp.data()), *w1l = w1h + H_W1, *w2h = w1l + H_W1, *w2l = w2h + H_W2,
+                 *w3h = w2l + H_W2, *w3l = w3h + H_W3;
+        float *b1s = reinterpret_cast<float *>(w3l + H_W3), *b2s = b1s + 48, *b3s = b2s + 32;
+        auto put = [&](_Float16 *hi, _Float16 *lo, size_t idx, float v) {
+            const float sv = v * S;
+            const _Float16 h = (_Float16)sv;
+            hi[idx] = h;
+            lo[idx] = (_Float16)(sv - (float)h);
+        };
+        for (int lane = 0; lane < 64; lane++) {
+            const int g = lane >> 4, c = lane & 15;
+            for (int j = 0; j < 8; j++) {
+                const int kl = 8 * g + j, dx = kl / 6, ci = kl % 6;                  // slot of an image-row group
+                const bool real = kl < 30 && ci < 5;
+                for (int dy = 0; dy < 5; dy++)
+                    put(w1h, w1l, ((size_t)dy * 64 + lane) * 8 + j, real ? k13[((dy * 5 + dx) * 5 + ci) * 16 + c] : 0.0f);
+                put(w1h, w1l, ((size_t)5 * 64 + lane) * 8 + j, real ? k11[(dx * 5 + ci) * 16 + c] : 0.0f);
+                const int kc = 8 * g + j;                                            // 5x1 kernel: slot k = dy*5 + ci
+                put(w1h, w1l, ((size_t)6 * 64 + lane) * 8 + j, kc < 25 ? k12[kc * 16 + c] : 0.0f);
+                for (int G = 0; G < 9; G++)
+                    for (int tn = 0; tn < 2; tn++)
+                        put(w2h, w2l, ((size_t)(G * 2 + tn) * 64 + lane) * 8 + j, k2[(32 * G + 8 * g + j) * 32 + tn * 16 + c]);
+                for (int G = 0; G < 6; G++)
+                    for (int tn = 0; tn < 4; tn++)
+                        put(w3h, w3l, ((size_t)(G * 4 + tn) * 64 + lane) * 8 + j, k3[(32 * G + 8 * g + j) * 64 + tn * 16 + c]);
+            }
+        }
+        for (int c = 0; c < 16; c++) { b1s[c] = b11[c] * S; b1s[16 + c] = b12[c] * S; b1s[32 + c] = b13[c] * S; }
+        for (int c = 0; c < 32; c++) b2s[c] = b2[c] * S;
+        for (int c = 0; c < 64; c++) b3s[c] = b3[c] * S;
+        b3s[64] = 1.0f / S;
+        if (!w.packed_h) {
+            hipError_t e = hipMalloc(&w.packed_h, hp.size());
+            if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed fp16 weights: %s", hipGetErrorString(e));
+        }
+        NC_HIP(ctx, hipMemcpyAsync(w.packed_h, hp.data(), hp.size(), hipMemcpyHostToDevice, ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return NC_OK;
 }
@@ -708,7 +1058,7 @@ int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, con
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
-        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, ctx->w[kind].packed, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
+        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, ctx->w[kind].packed, (const uint8_t *)ctx->w[kind].packed_h, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
                                                           &f1, &tail)));
         if (kind == NC_MODEL_SNP)
             hipLaunchKernelGGL(k_snp_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, ref_code_dev + s0, nb,
@@ -747,9 +1097,9 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
         if (kind == NC_MODEL_INDEL)
-            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, nullptr, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         else
-            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, nullptr, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         hipLaunchKernelGGL(k_indel_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, nout, nb, probs_dev + s0 * nout);
         NC_HIP(ctx, hipGetLastError());
     }

@@ -19,6 +19,7 @@ struct nc_weights {
     size_t n = 0;
     float *packed = nullptr;   // kernel-specific repack (see nc_cnn.hip)
     size_t n_packed = 0;
+    void *packed_h = nullptr;  // fp16x3 fragments of the trunk kernel
 };
 
 struct nc_ctx {
@@ -27,6 +28,7 @@ struct nc_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     bool timing = false;
+    bool cnn_exact_fp32 = false;   // false: fp16x3 split-precision trunk (default); true: exact fp32 MFMA trunk
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
     hipEvent_t kev[128] = {nullptr};          // per-launch event pairs of the trunk kernel (timing mode)

@@ -66,6 +66,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
     for (auto &w : ctx->w) {
         if (w.dev) (void)hipFree(w.dev);
         if (w.packed) (void)hipFree(w.packed);
+        if (w.packed_h) (void)hipFree(w.packed_h);
     }
     for (auto &e : ctx->kev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -120,6 +121,13 @@ int nc_memcpy_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes)
     if (!ctx || (bytes && (!dev || !host))) return NC_ERR_ARG;
     if (bytes) NC_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+int nc_set_cnn_precision(nc_ctx *ctx, int exact_fp32)
+{
+    if (!ctx) return NC_ERR_ARG;
+    ctx->cnn_exact_fp32 = exact_fp32 != 0;
     return NC_OK;
 }
 

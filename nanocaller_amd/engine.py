@@ -98,6 +98,10 @@ class Engine:
         s = torch.cuda.current_stream(self.device)
         self._check(self.L.nc_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)), "nc_ctx_set_stream")
 
+    def set_cnn_precision(self, exact_fp32: bool):
+        """False (default): fp16x3 split-precision trunk; True: exact fp32 MFMA trunk."""
+        self._check(self.L.nc_set_cnn_precision(self.ctx, 1 if exact_fp32 else 0), "nc_set_cnn_precision")
+
     def enable_timing(self, on=True):
         self._check(self.L.nc_enable_timing(self.ctx, 1 if on else 0), "nc_enable_timing")
 

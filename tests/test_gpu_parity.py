@@ -108,8 +108,16 @@ def _golden_inputs(case):
     return gold["mat"], ref_code, gold["depth"]
 
 
+@pytest.fixture(params=["fp16x3", "fp32"])
+def precision(eng, request):
+    """both trunk kernels: k5_trunk_h3 (fp16x3 split precision, the default) and k4_conv12 (exact fp32 MFMA)"""
+    eng.set_cnn_precision(exact_fp32=(request.param == "fp32"))
+    yield request.param
+    eng.set_cnn_precision(exact_fp32=False)
+
+
 @pytest.mark.parametrize("model,case", [("ONT-HG002", "ont_dip"), ("CCS-HG002", "hifi_pacbio_dip"), ("NanoCaller1", "deep_ont")])
-def test_snp_cnn_matches_oracle(eng, model, case):
+def test_snp_cnn_matches_oracle(eng, model, case, precision):
     """per-site softmax probabilities within 1e-4 of the CPU restatement (float64 accumulate); measured ~1e-6"""
     import torch
     from nanocaller_amd import _lib
@@ -126,12 +134,39 @@ def test_snp_cnn_matches_oracle(eng, model, case):
         ep, eg = oracle.snp_forward(w.flat, x, ref_code, scale, scale_mode=mode, precision="f64")
         assert np.abs(probs.cpu().numpy() - ep).max() < 1e-4
         assert np.abs(gt.cpu().numpy() - eg).max() < 1e-4
-        assert np.abs(probs.cpu().numpy() - ep).max() < 2e-5, "fp32 path should be far inside the 1e-4 contract"
+        assert np.abs(probs.cpu().numpy() - ep).max() < 2e-5, "both trunk kernels should be far inside the 1e-4 contract"
     # genotype-relevant decisions identical
     assert np.array_equal(probs.cpu().numpy() >= 0.5, ep >= 0.5)
 
 
-def test_snp_hap_cnn_matches_oracle(eng):
+def test_every_snp_model_both_trunk_kernels(eng):
+    """every shipped SNP model through both trunk kernels (the fp16x3 weight scale S is chosen per model at load time):
+    each within 2e-5 of the float64 oracle, and within 1e-5 of each other"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import SNP_MODEL_FILES, Weights, get_SNP_model
+    from oracle import oracle
+    x, ref_code, depth = _golden_inputs("ont_dip")
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(ref_code).cuda()
+    try:
+        for model in sorted(m for m in SNP_MODEL_FILES if m != 'haploid'):
+            path, cov = get_SNP_model(model)
+            w = Weights(path)
+            eng.load_weights(_lib.MODEL_SNP, w)
+            scale = np.full(len(x), cov / depth)
+            sd = torch.from_numpy(scale).cuda()
+            ep, _ = oracle.snp_forward(w.flat, x, ref_code, scale, precision="f64")
+            got = {}
+            for exact in (False, True):
+                eng.set_cnn_precision(exact_fp32=exact)
+                got[exact] = eng.snp_forward(_lib.MODEL_SNP, xd, rd, sd)[0].cpu().numpy()
+                assert np.abs(got[exact] - ep).max() < 2e-5, (model, exact)
+            assert np.abs(got[False] - got[True]).max() < 1e-5, model
+    finally:
+        eng.set_cnn_precision(exact_fp32=False)
+
+
+def test_snp_hap_cnn_matches_oracle(eng, precision):
     import torch
     from nanocaller_amd import _lib
     from nanocaller_amd.weights import Weights, get_SNP_model
