@@ -501,38 +501,76 @@ __global__ __launch_bounds__(256, 2) void k4_conv12(const float *__restrict__ x,
 // normal fp16 numbers; accumulators carry S*value and are rescaled (exactly) in the epilogue.  Emulated on the CPU
 // with the real weights this is indistinguishable from fp32 rounding (max |dp| 9e-7 vs 9e-7 for plain fp32);
 // activations peak near 1.5e3 for every model of the zoo (fp16 max 65504), and are clamped for safety.
-// K slots only have to agree between the A and B fragments: lane (row/col = l&15, group g = l>>4) holds slots (g, 0..7).
-// conv1: padded input image with channel pitch 6 -> the 5 taps x 5 channels of an image row are 30 contiguous halves
-// (+2 zero-weight slots) = ONE K=32 group per kernel row: 5 groups (5x5) + 1 (1x5, reuses the fragment of row 2) + 1
-// (5x1: its 25 (dy,ci) values are gathered from the centre column with ds_read_u16) = 7 groups x 3 MFMAs per tile of
-// 16 positions.  conv2: K = 288 = 9 groups, conv3: K = 192 = 6 groups.
+//
+// LDS layout ("chunk planar", tools/trunk_layout.py checks every access pattern against the gfx950 bank model): all
+// operands live in 16-byte SLOTS of 8 halves and every MFMA operand fragment is ONE ds_read_b128 per lane.
+//   X   [9 rows x 57] slots, slot = one pixel of the zero-padded 9x45 input.  Two planes with the hi/lo parts of the 5
+//       channels interleaved so that the three split products of a tap take TWO MFMAs:
+//         XA = [h0 h1 h2 h3 h4 l0 l1 l2]  x  WA = [H0 H1 H2 H3 H4 H0 H1 H2]
+//         XB = [l3 l4 h0 h1 h2 h3 h4  0]  x  WB = [H3 H4 L0 L1 L2 L3 L4  0]     (h/l: input, H/L: weight)
+//       A K group = 4 taps (lane group g reads the pixel of tap g).  The 25 taps of the 5x5 kernel form 7 groups whose
+//       lane-group pairs (g0,g1)/(g2,g3) are horizontally adjacent taps or taps 112 slots apart (row pitch 57 = 41+16),
+//       the two cases ds_read_b128's 16-lane groups serve without bank conflicts; the 1x5 and 5x1 kernels reuse the
+//       fragments of the groups that contain their taps (2 + 3 groups, zero weights elsewhere): 24 MFMAs per 16 positions.
+//   A1  [6 chunks][221 slots]: chunk = 8 of the 48 conv1 channels, slot = h*44 + w.  conv2 (stride 2 in w) reads it
+//       conflict-free with tiles (row y, x = 0..15) x 4 + one tile of the 16 left-over columns; chunk pitch is odd.
+//   A2  [4 chunks][119 slots], slot = y*26 + x; conv3's lane -> position map is a table (C3_SLOT/C3_OUT).
+// =====================================================================================================================
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-constexpr int H_XP = 2448;               // halves per input plane: 9*45*6 = 2430 (+ slack for the 2 zero-weight slots)
-constexpr int H_P1 = 56;                 // channel pitch of the conv1 activation planes (48 + 8): 112 B, conflict-free b128 reads
-constexpr int H_P2 = 40;                 // channel pitch of the conv2 activation planes (32 + 8)
-constexpr int H_W1 = 7 * 64 * 8, H_W2 = 9 * 2 * 64 * 8, H_W3 = 6 * 4 * 64 * 8;       // halves per plane (hi or lo)
-constexpr int H_PACKED_BYTES = 2 * 2 * (H_W1 + H_W2 + H_W3) + 4 * (48 + 32 + 64 + 4);
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int T_RX = 57, T_XS = 9 * T_RX;                // X slots per padded row / per plane
+constexpr int T_R1 = 44, T_PL1 = 221;                     // A1 slots per row / per chunk plane (6 chunks)
+constexpr int T_R2 = 26, T_PL2 = 119;                     // A2 slots per row / per chunk plane (4 chunks)
+constexpr int T_NW1 = 24, T_NW2 = 18, T_NW3 = 24;         // fragments: conv1 (7+7 5x5, 2+2 1x5, 3+3 5x1), conv2 (9 x 2), conv3 (6 x 4)
+constexpr int T_FRAG = 64 * 8;                            // halves per fragment
+constexpr int T_XPLANE = T_XS * 8, T_A1PLANE = 6 * T_PL1 * 8, T_A2PLANE = 4 * T_PL2 * 8;   // halves between the two planes of a buffer
+// packed blob: [conv1 24 frags][conv2 hi 18][conv2 lo 18][conv3 hi 24][conv3 lo 24] halves, then f32 b1*S[48] b2*S[32]
+// b3*S[64] 1/S pad[3], then int32 C3_SLOT[32], C3_OUT[32]
+constexpr int H_PACKED_BYTES = 2 * T_FRAG * (T_NW1 + 2 * T_NW2 + 2 * T_NW3) + 4 * (48 + 32 + 64 + 4) + 4 * 64;
+// conv1 K groups: tap (dy, dx) of lane group g, as the slot offset dy * T_RX + dx (tools/trunk_layout.py)
+constexpr int C1_TAPS[7][4][2] = {{{2, 0}, {2, 1}, {2, 3}, {2, 4}}, {{0, 4}, {2, 2}, {1, 4}, {3, 2}}, {{0, 2}, {0, 3}, {1, 2}, {1, 3}},
+                                  {{4, 2}, {4, 3}, {4, 4}, {4, 4}}, {{0, 0}, {0, 1}, {1, 0}, {1, 1}}, {{3, 0}, {3, 1}, {3, 3}, {3, 4}},
+                                  {{4, 0}, {4, 1}, {4, 0}, {4, 1}}};
+constexpr int C3_SLOT[32] = {60, 34, 32, 8, 28, 26, 68, 16, 2, 54, 14, 56, 6, 62, 52, 58, 30, 36, 34, 6, 4, 66, 38, 0, 66, 42, 8, 12, 10, 40, 64, 34};
+constexpr int C3_OUT[32] = {22, 13, 12, 4, 10, 9, 26, 8, 1, 19, 7, 20, 3, 23, 18, 21, 11, 14, -1, -1, 2, 25, 15, 0, -1, 17, -1, 6, 5, 16, 24, -1};
 
 __device__ __forceinline__ h8 as_h8(uint4 v) { union { uint4 u; h8 h; } c; c.u = v; return c.h; }
-__device__ __forceinline__ void split_store(float v, _Float16 *hi_p, _Float16 *lo_p)
+// four 16-bit fields (one per lane group g): offset in halves of the operand slot of K group G
+__host__ __device__ constexpr uint64_t c1_tap_pack(int G)
 {
-    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
-    const _Float16 hi = (_Float16)v;
-    *hi_p = hi;
-    *lo_p = (_Float16)(v - (float)hi);
+    uint64_t v = 0;
+    for (int q = 0; q < 4; q++) v |= (uint64_t)((C1_TAPS[G][q][0] * T_RX + C1_TAPS[G][q][1]) * 8) << (16 * q);
+    return v;
 }
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-// Epilogue constants of the split-precision trunk: accumulators hold S * (conv + bias);
+__host__ __device__ constexpr uint64_t c2_off_pack(int G)
+{
+    uint64_t v = 0;
+    for (int q = 0; q < 4; q++) {
+        const int idx = 4 * G + q, tap = idx / 6, ch = idx - tap * 6;            // K chunk = (tap, chunk of 8 channels)
+        v |= (uint64_t)((ch * T_PL1 + (tap / 3) * T_R1 + (tap % 3)) * 8) << (16 * q);
+    }
+    return v;
+}
+__device__ __forceinline__ h8 lds_h8(const _Float16 *p) { return *reinterpret_cast<const h8 *>(p); }
+// Epilogue constants: accumulators hold S * (conv + bias);
 //   selu(a / S) = L * max(a, 0) / S + L*A * (exp(min(a, 0) / S) - 1)
 // c1 = log2(e) / S, c2 = L / S, c3 = clamp of max(a, 0) that keeps the result inside fp16 range.
 struct h_epi { float c1, c2, c3; };
+// exp2 with the VOP3 clamp modifier (result clamped to [0,1]): clamp01(exp2(x)) == exp2(min(x, 0)), one instruction
+__device__ __forceinline__ float exp2_clamp01(float x) { float r; asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(r) : "v"(x)); return r; }
+// v - float(lo / hi half of a packed f16 pair): v_fma_mix_f32 reads the f16 operand directly (no separate v_cvt_f32_f16)
+__device__ __forceinline__ float sub_h_lo(float v, uint32_t hpk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v)); return r; }
+__device__ __forceinline__ float sub_h_hi(float v, uint32_t hpk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v)); return r; }
 __device__ __forceinline__ f32x4v selu4_scaled(const f32x4v &acc, const h_epi &k)
 {
     f32x4v s;
+#ifdef NC_ABL_NOEPI
+    return acc;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const float a = acc[r];
-        const float e = __builtin_amdgcn_exp2f(fminf(a, 0.0f) * k.c1);
+        const float e = exp2_clamp01(a * k.c1);                       // exp(min(a, 0) / S)
         const float neg = fmaf(e, SELU_LA, -SELU_LA);                 // exactly 0 for a >= 0
         const float pos = __builtin_amdgcn_fmed3f(a, 0.0f, k.c3);
         s[r] = fmaf(pos, k.c2, neg);
@@ -541,38 +579,45 @@ __device__ __forceinline__ f32x4v selu4_scaled(const f32x4v &acc, const h_epi &k
 }
 // The MFMAs are issued with the weights as the A operand, so a lane's four accumulator registers are four CONSECUTIVE
 // channels (4g .. 4g+3) of ONE position (c16): hi and lo halves go out as one ds_write_b64 each, no cross-lane traffic.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Float16 *lp)
 {
-    const h4 hi = __builtin_convertvector(v, h4);                     // v_cvt_pk_f16_f32 (round to nearest even)
-    const f32x4v d = v - __builtin_convertvector(hi, f32x4v);         // exact in fp32
-    const h4 lo = __builtin_convertvector(d, h4);
-    *reinterpret_cast<h4 *>(hp) = hi;
-    *reinterpret_cast<h4 *>(lp) = lo;
+    const h2 h01 = __builtin_convertvector((f32x2v){v[0], v[1]}, h2), h23 = __builtin_convertvector((f32x2v){v[2], v[3]}, h2);   // v_cvt_pk_f16_f32, RNE
+    const uint32_t u01 = __builtin_bit_cast(uint32_t, h01), u23 = __builtin_bit_cast(uint32_t, h23);
+    const f32x2v d01 = {sub_h_lo(v[0], u01), sub_h_hi(v[1], u01)}, d23 = {sub_h_lo(v[2], u23), sub_h_hi(v[3], u23)};              // exact in fp32
+    const h2 l01 = __builtin_convertvector(d01, h2), l23 = __builtin_convertvector(d23, h2);
+    *reinterpret_cast<uint2 *>(hp) = make_uint2(u01, u23);
+    *reinterpret_cast<uint2 *>(lp) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
 }
-// X = activation fragments (hi, lo), W = weight fragments (hi, lo); D[channel 4g + r][position c16]
-#define NC_MFMA3(ACC, XH, XL, WH, WL)                                          \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH, XH, ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH, XL, ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(WL, XH, ACC, 0, 0, 0);
+#ifdef NC_ABL_NOMFMA
+#define NC_MFMA(ACC, W, X) asm volatile("" ::"v"(W), "v"(X));
+#else
+// D[channel 4g + r][position c16] += W[channel][k] * X[k][position]
+#define NC_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(W, X, ACC, 0, 0, 0);
+#endif
+#define NC_MFMA3(ACC, XH, XL, WH, WL) NC_MFMA(ACC, WH, XH) NC_MFMA(ACC, WH, XL) NC_MFMA(ACC, WL, XH)
 
+// conv1 of NT tiles (tile_first, tile_first + 4, ...) of 16 positions.  w1 = the 24 resident fragments:
+// [0..6] 5x5 WA, [7..13] 5x5 WB, [14,15] 1x5 WA (groups 0,1), [16,17] 1x5 WB, [18..20] 5x1 WA (groups 1,2,3), [21..23] 5x1 WB
 template <int NT>
-__device__ __forceinline__ void h_conv1_pass(const _Float16 *XH, const _Float16 *XL, _Float16 *A1H, _Float16 *A1L, const h8 (&wh)[7],
-                                             const h8 (&wl)[7], const int (&crel)[8], const float *__restrict__ b1s, const h_epi &epi,
-                                             int tile_first, int lane)
+__device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const h8 (&w1)[T_NW1],
+                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane)
 {
     const int g = lane >> 4, c16 = lane & 15;
-    int rowbase[NT], colbase[NT];
+    int xbase[NT], obase[NT];
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        int p = (tile_first + 4 * tm) * 16 + c16;
-        p = p < 205 ? p : 204;
-        const int h = p / 41, w = p - h * 41;
-        rowbase[tm] = ((h * 45 + w) * 6 + 8 * g) >> 1;              // in dwords; 4-byte aligned by construction
-        colbase[tm] = (h * 45 + w + 2) * 6;                          // centre column (dx = 2), in halves
-        // opaque per call: keeps the (site-loop invariant) address arithmetic from being hoisted out of the site loop,
-        // where ~150 precomputed LDS addresses would stay live and spill
-        asm volatile("" : "+v"(rowbase[tm]), "+v"(colbase[tm]));
+        const int p = (tile_first + 4 * tm) * 16 + c16;
+        const int pr = p < 205 ? p : 204;
+        const int h = pr / 41, w = pr - h * 41;
+        xbase[tm] = (h * T_RX + w) * 8;                              // halves; tap (dy,dx) of pixel (h,w) is padded pixel (h+dy, w+dx)
+        // positions 205..207 (tile 12) go to the three unused slots at the end of row 4
+        obase[tm] = ((g >> 1) * T_PL1 + (p < 205 ? h * T_R1 + w : 4 * T_R1 + 41 + (p - 205))) * 8 + (g & 1) * 4;
+        // opaque per call: keeps site-loop invariant address arithmetic from being hoisted out of the site loop (spills)
+        asm volatile("" : "+v"(xbase[tm]), "+v"(obase[tm]));
     }
+    const int sh = 16 * g;                                             // field of this lane group in the packed offset constants
     f32x4v acc1[NT], acc2[NT], acc3[NT];
     {
         const f32x4v x1 = *reinterpret_cast<const f32x4v *>(b1s + 4 * g), x2 = *reinterpret_cast<const f32x4v *>(b1s + 16 + 4 * g),
@@ -580,214 +625,299 @@ __device__ __forceinline__ void h_conv1_pass(const _Float16 *XH, const _Float16 
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { acc1[tm] = x1; acc2[tm] = x2; acc3[tm] = x3; }
     }
-    const uint32_t *xh32 = reinterpret_cast<const uint32_t *>(XH), *xl32 = reinterpret_cast<const uint32_t *>(XL);
-    // 5x1 kernel: slot (g, j) = k = 8g + j -> (dy = k / 5, ci = k % 5); crel[j] = dy * 270 + ci (a zero slot for k >= 25)
-    {
-        h8 ah[NT], al[NT];
+    // software pipeline: the ds_reads of group G + 1 are issued before the MFMAs of group G (register double buffer)
+    h8 xa[2][NT], xb[2][NT];
+    auto load1 = [&](int G, int slot) {
+        const int toff = (int)((c1_tap_pack(G) >> sh) & 0xffffu);       // halves
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) {
+#ifdef NC_ABL_NOLDS
+            xa[slot][tm] = w1[(G + tm) % 7]; xb[slot][tm] = w1[7 + (G + 2 * tm) % 7];
+#else
+            xa[slot][tm] = lds_h8(XA + xbase[tm] + toff);
+            xb[slot][tm] = lds_h8(XA + xbase[tm] + toff + T_XPLANE);
+#endif
+        }
+    };
+    load1(0, 0);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                ah[tm][j] = XH[colbase[tm] + crel[j]];
-                al[tm][j] = XL[colbase[tm] + crel[j]];
-            }
+    for (int G = 0; G < 7; G++) {
+        const int cur = G & 1;
+        if (G + 1 < 7) load1(G + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // independent accumulators interleaved: no MFMA depends on the one issued just before it
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[G], xa[cur][tm]) }
+        if (G < 2) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc1[tm], w1[14 + G], xa[cur][tm]) }
+        }
+        if (G >= 1 && G <= 3) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], w1[18 + G - 1], xa[cur][tm]) }
         }
 #pragma unroll
-        for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc2[tm], ah[tm], al[tm], wh[6], wl[6]) }
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[7 + G], xb[cur][tm]) }
+        if (G < 2) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc1[tm], w1[16 + G], xb[cur][tm]) }
+        }
+        if (G >= 1 && G <= 3) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], w1[21 + G - 1], xb[cur][tm]) }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int dy = 0; dy < 5; dy++) {
-        h8 ah[NT], al[NT];
-#pragma unroll
-        for (int tm = 0; tm < NT; tm++) {
-            const int o = rowbase[tm] + dy * 135;                    // 270 halves per image row
-            ah[tm] = as_h8(make_uint4(xh32[o], xh32[o + 1], xh32[o + 2], xh32[o + 3]));
-            al[tm] = as_h8(make_uint4(xl32[o], xl32[o + 1], xl32[o + 2], xl32[o + 3]));
-        }
-#pragma unroll
-        for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc3[tm], ah[tm], al[tm], wh[dy], wl[dy]) }
-        if (dy == 2) {
-#pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc1[tm], ah[tm], al[tm], wh[5], wl[5]) }
-        }
-        if (dy & 1) asm volatile("" ::: "memory");
-    }
-    int ob = (tile_first * 16 + c16) * H_P1 + 4 * g;                  // rows 205..207 are scratch rows (tile 12)
-    asm volatile("" : "+v"(ob));
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        const int o = ob + 64 * tm * H_P1;
-        split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1L + o);
-        split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 16, A1L + o + 16);
-        split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 32, A1L + o + 32);
+        const int o = obase[tm];
+        split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
+        split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
+        split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
     }
 }
 
+// conv2: wave (tn = wv & 1, t0 = wv >> 1) computes output channels 16 tn .. 16 tn + 15 of tiles t0, t0 + 2, (t0 + 4).
+// Tiles 0..3 = output row y, x = 0..15; tile 4 = columns 16..19 of the four rows (lane c16 -> y = c16 & 3, x = 16 + c16/4).
 template <int NT>
-__device__ __forceinline__ void h_conv2(const _Float16 *A1H, const _Float16 *A1L, _Float16 *A2H, _Float16 *A2L, const h8 (&wh)[9],
-                                        const h8 (&wl)[9], const float *__restrict__ b2s, const h_epi &epi, int wv, int lane)
+__device__ __forceinline__ void t_conv2(const _Float16 *A1H, _Float16 *A2H, const h8 (&wh)[9],
+                                        const h8 (&wl)[9], const float *__restrict__ b2s, const h_epi &epi, int tn, int t0, int lane)
 {
-    const int g = lane >> 4, c16 = lane & 15, tn = wv & 1, t0 = wv >> 1;
-    int abase[NT];
+    const int g = lane >> 4, c16 = lane & 15;
+    int abase[NT], obase[NT];
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        const int p = (t0 + 2 * tm) * 16 + c16;          // < 80
-        const int y = p / 20, x = p - y * 20;
-        abase[tm] = (y * 41 + 2 * x) * H_P1;
-        asm volatile("" : "+v"(abase[tm]));
+        const int t = t0 + 2 * tm;
+        const int y = t < 4 ? t : (c16 & 3), x = t < 4 ? c16 : 16 + (c16 >> 2);
+        abase[tm] = (y * T_R1 + 2 * x) * 8;
+        obase[tm] = ((2 * tn + (g >> 1)) * T_PL2 + y * T_R2 + x) * 8 + (g & 1) * 4;
+        asm volatile("" : "+v"(abase[tm]), "+v"(obase[tm]));
     }
+    const int sh = 16 * g;
     f32x4v acc[NT];
     {
         const f32x4v b = *reinterpret_cast<const f32x4v *>(b2s + tn * 16 + 4 * g);
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) acc[tm] = b;
     }
-#pragma unroll
-    for (int G = 0; G < 9; G++) {
-        const int k0 = 32 * G + 8 * g;                   // first K slot of this lane group: k = tap*48 + ci
-        const int tap = k0 / 48, ci = k0 - tap * 48;
-        const int off = ((tap / 3) * 41 + (tap % 3)) * H_P1 + ci;
-        h8 ah[NT], al[NT];
+    h8 ah[2][NT], al[2][NT];
+    auto load2 = [&](int G, int slot) {
+        const int off = (int)((c2_off_pack(G) >> sh) & 0xffffu);
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) {
-            ah[tm] = as_h8(*reinterpret_cast<const uint4 *>(A1H + abase[tm] + off));
-            al[tm] = as_h8(*reinterpret_cast<const uint4 *>(A1L + abase[tm] + off));
+#ifdef NC_ABL_NOLDS
+            ah[slot][tm] = wh[(G + tm) % 9]; al[slot][tm] = wl[(G + 2 * tm) % 9];
+#else
+            ah[slot][tm] = lds_h8(A1H + abase[tm] + off);
+            al[slot][tm] = lds_h8(A1H + abase[tm] + off + T_A1PLANE);
+#endif
         }
+    };
+    load2(0, 0);
 #pragma unroll
-        for (int tm = 0; tm < NT; tm++) { NC_MFMA3(acc[tm], ah[tm], al[tm], wh[G], wl[G]) }
-        if (G & 1) asm volatile("" ::: "memory");        // keep at most two groups of A fragments in flight
+    for (int G = 0; G < 9; G++) {
+        const int cur = G & 1;
+        if (G + 1 < 9) load2(G + 1, cur ^ 1);
+#ifndef NC_V3
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef NC_V1
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], ah[cur][tm]) NC_MFMA(acc[tm], wh[G], al[cur][tm]) NC_MFMA(acc[tm], wl[G], ah[cur][tm]) }
+#else
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], ah[cur][tm]) }
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], al[cur][tm]) }
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wl[G], ah[cur][tm]) }
+#endif
+#ifndef NC_V3
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
-    int ob = (t0 * 16 + c16) * H_P2 + tn * 16 + 4 * g;
-    asm volatile("" : "+v"(ob));
 #pragma unroll
-    for (int tm = 0; tm < NT; tm++) split4_store(selu4_scaled(acc[tm], epi), A2H + ob + 32 * tm * H_P2, A2L + ob + 32 * tm * H_P2);
+    for (int tm = 0; tm < NT; tm++) split4_store(selu4_scaled(acc[tm], epi), A2H + obase[tm], A2H + obase[tm] + T_A2PLANE);
 }
 
-__device__ __forceinline__ void h_conv3(const _Float16 *A2H, const _Float16 *A2L, const h8 (&w3h)[6], const h8 (&w3l)[6],
-                                        const float *__restrict__ b3s, const h_epi &epi, float *__restrict__ out_site, int wv, int lane)
+// conv3: wave wv computes output channels 16 wv .. 16 wv + 15 of both position tiles (lane -> position: C3_SLOT / C3_OUT)
+__device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6], const h8 (&w3l)[6],
+                                        const float *__restrict__ b3s, const h_epi &epi, float *__restrict__ out_site,
+                                        const int (&c3slot)[2], const int (&c3out)[2], int wv, int lane)
 {
-    const int g = lane >> 4, c16 = lane & 15;
+    const int g = lane >> 4;
     int abase[2];
 #pragma unroll
     for (int tm = 0; tm < 2; tm++) {
-        int p = tm * 16 + c16;
-        p = p < 27 ? p : 26;
-        const int y = p / 9, x = p - y * 9;
-        abase[tm] = (y * 20 + 2 * x) * H_P2 + 8 * g;
+        abase[tm] = (g * T_PL2 + c3slot[tm]) * 8;
         asm volatile("" : "+v"(abase[tm]));
     }
     f32x4v acc[2];
     acc[0] = *reinterpret_cast<const f32x4v *>(b3s + wv * 16 + 4 * g);
     acc[1] = acc[0];
-#pragma unroll
-    for (int G = 0; G < 6; G++) {                        // K group G = tap G (32 channels)
-        const int off = ((G / 3) * 20 + (G % 3)) * H_P2;
-        const h8 bh = w3h[G], bl = w3l[G];
-        h8 ah[2], al[2];
+    h8 ah[2][2], al[2][2];
+    auto load3 = [&](int G, int slot) {                   // K group G = tap G, lane group g = channel chunk g
+        const int off = ((G / 3) * T_R2 + (G % 3)) * 8;
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
-            ah[tm] = as_h8(*reinterpret_cast<const uint4 *>(A2H + abase[tm] + off));
-            al[tm] = as_h8(*reinterpret_cast<const uint4 *>(A2L + abase[tm] + off));
+#ifdef NC_ABL_NOLDS
+            ah[slot][tm] = w3h[(G + tm) % 6]; al[slot][tm] = w3l[(G + 2 * tm) % 6];
+#else
+            ah[slot][tm] = lds_h8(A2H + abase[tm] + off);
+            al[slot][tm] = lds_h8(A2H + abase[tm] + off + T_A2PLANE);
+#endif
         }
+    };
+    load3(0, 0);
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) { NC_MFMA3(acc[tm], ah[tm], al[tm], bh, bl) }
+    for (int G = 0; G < 6; G++) {
+        const int cur = G & 1;
+        if (G + 1 < 6) load3(G + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3h[G], ah[cur][tm]) }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3h[G], al[cur][tm]) }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3l[G], ah[cur][tm]) }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    int ob = c16 * 64 + wv * 16 + 4 * g;
-    asm volatile("" : "+v"(ob));
     h_epi e3 = epi;
     e3.c3 = 3.0e38f;                                                  // fp32 output: no fp16 range clamp
-    *reinterpret_cast<f32x4v *>(out_site + ob) = selu4_scaled(acc[0], e3);
-    if (c16 < 11) *reinterpret_cast<f32x4v *>(out_site + ob + 16 * 64) = selu4_scaled(acc[1], e3);
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+        if (c3out[tm] >= 0) *reinterpret_cast<f32x4v *>(out_site + c3out[tm] * 64 + wv * 16 + 4 * g) = selu4_scaled(acc[tm], e3);
 }
 
-__global__ __launch_bounds__(256, 2) void k5_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
-                                                      int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
+// Wave-specialised persistent kernel: one 512-thread workgroup per CU, two waves per SIMD with 256 VGPRs each.
+//   waves 0-3 ("C"): conv1.  The 24 conv1 weight fragments (96 VGPRs) stay in registers for the kernel's lifetime; the waves
+//                    also stage the next site's input tensor (thread = pixel) into the other X buffer.
+//   waves 4-7 ("D"): conv2 + conv3.  This wave's 9+9 conv2 and 6+6 conv3 fragments (120 VGPRs) stay in registers.
+// C works on site k+1 while D works on site k: X and A1 are double-buffered, A2 is single.  Two workgroup barriers per
+// site (alpha_k: A1[k&1] and X[(k+1)&1] complete; beta_k: A2 complete), executed by both roles in the same order:
+//   C:  P0 | conv1(0) alpha_0 | conv1(1) pass 1, beta_0, pass 2, alpha_1 | ... | beta_last
+//   D:  P0 | alpha_0 conv2(0) beta_0 conv3(0) | alpha_1 conv2(1) beta_1 conv3(1) | ...
+// No weight is re-read per site, and the MFMA phases of one role overlap the epilogues of the other on every SIMD.
+#ifdef NC_TRACE
+__device__ unsigned long long nc_trace_buf[8][8][8];     // [wave][site k in 8..15][event]
+#define NC_T(ev) if (blockIdx.x == 3 && lane == 0 && k >= 8 && k < 16) nc_trace_buf[wv][k - 8][ev] = __builtin_readcyclecounter();
+#else
+#define NC_T(ev)
+#endif
+__global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
+                                                   int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 XH[H_XP], XL[H_XP];
-    __shared__ __attribute__((aligned(16))) _Float16 A1H[208 * H_P1], A1L[208 * H_P1];
-    __shared__ __attribute__((aligned(16))) _Float16 A2H[80 * H_P2], A2L[80 * H_P2];
+    // [buffer][plane]: the second plane of a buffer sits at a constant distance (< 64 KB) from the first, so one address
+    // VGPR + the DS instruction's immediate offset serves both
+    __shared__ __attribute__((aligned(16))) _Float16 X[2][2 * T_XPLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 A1[2][2 * T_A1PLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 A2[2 * T_A2PLANE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // packed weights: [w1 hi | w1 lo | w2 hi | w2 lo | w3 hi | w3 lo] (halves) then b1*S, b2*S, b3*S, 1/S (f32)
-    const uint4 *w1h = reinterpret_cast<const uint4 *>(wp), *w1l = w1h + H_W1 / 8, *w2h = w1l + H_W1 / 8, *w2l = w2h + H_W2 / 8,
-                *w3h = w2l + H_W2 / 8, *w3l = w3h + H_W3 / 8;
-    const float *b1s = reinterpret_cast<const float *>(w3l + H_W3 / 8), *b2s = b1s + 48, *b3s = b2s + 32;
+    const uint4 *w1f = reinterpret_cast<const uint4 *>(wp), *w2h = w1f + T_NW1 * 64, *w2l = w2h + T_NW2 * 64, *w3h = w2l + T_NW2 * 64,
+                *w3l = w3h + T_NW3 * 64;
+    const float *b1s = reinterpret_cast<const float *>(w3l + T_NW3 * 64), *b2s = b1s + 48, *b3s = b2s + 32;
+    const int *c3tab = reinterpret_cast<const int *>(b3s + 68);
     const float inv_s = b3s[64];
     const h_epi epi = {inv_s * 1.44269504088896341f, inv_s * SELU_L, 60000.0f / (inv_s * SELU_L)};
-    // register-resident for the kernel's lifetime: conv1 (7 groups, 56 VGPRs, reused by 3-4 tiles per site); this wave's
-    // conv2 (9 groups) and conv3 (6 groups) fragments are re-read from L2 once per site, just before the barrier that
-    // precedes their use
-    h8 c1h[7], c1l[7];
-#pragma unroll
-    for (int q = 0; q < 7; q++) { c1h[q] = as_h8(w1h[q * 64 + lane]); c1l[q] = as_h8(w1l[q * 64 + lane]); }
-    int crel[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int k = 8 * (lane >> 4) + j;
-        crel[j] = k < 25 ? (k / 5) * 270 + (k % 5) : 5;             // slot 5 of a pixel is always zero
-    }
-    for (int i = threadIdx.x; i < H_XP; i += 256) { XH[i] = (_Float16)0.0f; XL[i] = (_Float16)0.0f; }
+    const int64_t n_k = (n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x;        // sites of this workgroup (>= 1)
+    for (int i = threadIdx.x; i < 4 * T_XS; i += 512) *reinterpret_cast<uint4 *>(&X[0][0] + i * 8) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    float pre[5];
-    float pre_sf = 1.0f;
-    double pre_sd = 1.0;
-    auto prefetch = [&](int64_t site) {
-        const float *xs = x + site * NC_SNP_TENSOR;
+    if (wv < 4) {
+        // ------------------------------------------------------------------ role C: staging + conv1
+        h8 w1[T_NW1];
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
-            const int i = threadIdx.x + u * 256;
-            pre[u] = i < NC_SNP_TENSOR ? xs[i] : 0.0f;
-        }
-        if (scale) { pre_sd = scale[site0 + site]; pre_sf = (float)pre_sd; }
-    };
-    auto commit = [&]() {
+        for (int q = 0; q < T_NW1; q++) w1[q] = as_h8(w1f[q * 64 + lane]);
+        // staging: thread t < 205 owns pixel t = h*41 + w (5 channels = 20 contiguous bytes of the site's tensor)
+        const int px = threadIdx.x < 205 ? threadIdx.x : 204, ph = px / 41, pw = px - ph * 41;
+        const int xslot = ((ph + 2) * T_RX + pw + 2) * 8;
+        float pre[5];
+        float pre_sf = 1.0f;
+        double pre_sd = 1.0;
+        auto prefetch = [&](int64_t site) {
+            const float *xs = x + site * NC_SNP_TENSOR + px * 5;
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
-            const int i = threadIdx.x + u * 256;
-            if (i < NC_SNP_TENSOR) {
-                const int h = i / 205, rem = i - h * 205, w = rem / 5, c = rem - w * 5;
-                float v = pre[u];
-                if (scale && h > 0 && c < 4) v = scale_mode == 0 ? v * pre_sf : (float)((double)v * pre_sd);    // snpCaller.py:93-96
-                const int o = ((h + 2) * 45 + (w + 2)) * 6 + c;
-                split_store(v, XH + o, XL + o);
+            for (int u = 0; u < 5; u++) pre[u] = xs[u];
+            if (scale) { pre_sd = scale[site0 + site]; pre_sf = (float)pre_sd; }
+        };
+        auto commit = [&](int buf) {
+            if (threadIdx.x < 205) {
+                _Float16 hi[5], lo[5];
+#pragma unroll
+                for (int u = 0; u < 5; u++) {
+                    float v = pre[u];
+                    if (scale && ph > 0 && u < 4) v = scale_mode == 0 ? v * pre_sf : (float)((double)v * pre_sd);    // snpCaller.py:93-96
+                    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                    hi[u] = (_Float16)v;
+                    lo[u] = (_Float16)(v - (float)hi[u]);
+                }
+                const h8 sa = {hi[0], hi[1], hi[2], hi[3], hi[4], lo[0], lo[1], lo[2]};
+                const h8 sb = {lo[3], lo[4], hi[0], hi[1], hi[2], hi[3], hi[4], (_Float16)0.0f};
+                *reinterpret_cast<h8 *>(&X[buf][xslot]) = sa;
+                *reinterpret_cast<h8 *>(&X[buf][xslot + T_XPLANE]) = sb;
             }
+        };
+        int64_t site = blockIdx.x;
+        prefetch(site);
+        commit(0);
+        __syncthreads();                                                           // P0
+        for (int64_t k = 0; k < n_k; k++, site += gridDim.x) {
+            const int buf = (int)(k & 1);
+            const bool more = k + 1 < n_k;
+#ifndef NC_ABL_NOSTAGE
+            if (more) prefetch(site + gridDim.x);
+#endif
+            NC_T(0)
+#ifndef NC_ABL_NOC
+            t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, wv, lane);
+#endif
+            NC_T(1)
+            if (k > 0) __syncthreads();                                            // beta_{k-1}
+            NC_T(2)
+#ifndef NC_ABL_NOC
+            if (wv == 0) t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, 8, lane);
+            else t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, 8 + wv, lane);
+#endif
+            NC_T(3)
+#ifndef NC_ABL_NOSTAGE
+            if (more) commit(buf ^ 1);
+#endif
+            NC_T(4)
+            __syncthreads();                                                       // alpha_k
+            NC_T(5)
         }
-    };
-    int64_t site = blockIdx.x;
-    if (site < n_sites) { prefetch(site); commit(); }
-    __syncthreads();
-    for (; site < n_sites; site += gridDim.x) {
-        const int64_t nxt = site + gridDim.x;
-        if (nxt < n_sites) prefetch(nxt);
-        h_conv1_pass<2>(XH, XL, A1H, A1L, c1h, c1l, crel, b1s, epi, wv, lane);
-        if (wv == 0) h_conv1_pass<2>(XH, XL, A1H, A1L, c1h, c1l, crel, b1s, epi, 8, lane);
-        else h_conv1_pass<1>(XH, XL, A1H, A1L, c1h, c1l, crel, b1s, epi, 8 + wv, lane);
-        h8 c2h[9], c2l[9];
-        {
-            // opaque per-iteration copies of the pointers: otherwise the (loop-invariant) fragment loads are hoisted out of
-            // the site loop and 120 VGPRs of conv2/conv3 weights stay live across conv1 -> scratch spills
-            const uint4 *p2h = w2h + (wv & 1) * 64 + lane, *p2l = w2l + (wv & 1) * 64 + lane;
-            asm volatile("" : "+v"(p2h), "+v"(p2l));
+        __syncthreads();                                                           // beta_{n_k - 1}
+    } else {
+        // ------------------------------------------------------------------ role D: conv2 + conv3
+        const int d = wv - 4, tn = d & 1, heavy = d >> 1;                          // heavy: conv2 tiles 0,2,4; light: tiles 1,3
+        h8 c2h[9], c2l[9], c3h[6], c3l[6];
 #pragma unroll
-            for (int q = 0; q < 9; q++) { c2h[q] = as_h8(p2h[q * 128]); c2l[q] = as_h8(p2l[q * 128]); }
-        }
-        __syncthreads();
-        if (nxt < n_sites) commit();
-        if (wv < 2) h_conv2<3>(A1H, A1L, A2H, A2L, c2h, c2l, b2s, epi, wv, lane);
-        else h_conv2<2>(A1H, A1L, A2H, A2L, c2h, c2l, b2s, epi, wv, lane);
-        asm volatile("" ::: "memory");                   // conv2's fragments must not be kept live across the site loop
-        h8 c3h[6], c3l[6];
-        {
-            const uint4 *p3h = w3h + wv * 64 + lane, *p3l = w3l + wv * 64 + lane;
-            asm volatile("" : "+v"(p3h), "+v"(p3l));
+        for (int q = 0; q < 9; q++) { c2h[q] = as_h8(w2h[(q * 2 + tn) * 64 + lane]); c2l[q] = as_h8(w2l[(q * 2 + tn) * 64 + lane]); }
 #pragma unroll
-            for (int q = 0; q < 6; q++) { c3h[q] = as_h8(p3h[q * 256]); c3l[q] = as_h8(p3l[q * 256]); }
+        for (int q = 0; q < 6; q++) { c3h[q] = as_h8(w3h[(q * 4 + d) * 64 + lane]); c3l[q] = as_h8(w3l[(q * 4 + d) * 64 + lane]); }
+        const int c3slot[2] = {c3tab[lane & 15], c3tab[16 + (lane & 15)]}, c3out[2] = {c3tab[32 + (lane & 15)], c3tab[48 + (lane & 15)]};
+        __syncthreads();                                                           // P0
+        int64_t site = blockIdx.x;
+        for (int64_t k = 0; k < n_k; k++, site += gridDim.x) {
+            const int buf = (int)(k & 1);
+            NC_T(0)
+            __syncthreads();                                                       // alpha_k
+            NC_T(1)
+#ifndef NC_ABL_NOD
+            if (heavy) t_conv2<3>(A1[buf], A2, c2h, c2l, b2s, epi, tn, 0, lane);
+            else t_conv2<2>(A1[buf], A2, c2h, c2l, b2s, epi, tn, 1, lane);
+#endif
+            NC_T(2)
+            __syncthreads();                                                       // beta_k
+            NC_T(3)
+#ifndef NC_ABL_NOD
+            t_conv3(A2, c3h, c3l, b3s, epi, a3 + site * (27 * 64), c3slot, c3out, d, lane);
+#endif
+            NC_T(4)
         }
-        __syncthreads();
-        h_conv3(A2H, A2L, c3h, c3l, b3s, epi, a3 + site * (27 * 64), wv, lane);
-        asm volatile("" ::: "memory");
     }
 }
 #undef NC_MFMA3
+#undef NC_MFMA
 
 __device__ __forceinline__ void dense_small(const float *in, int n_in, const float *k, const float *b, int n_out, float *out, bool act)
 {
@@ -905,7 +1035,8 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
     if constexpr (MFMA) {
         constexpr int TMF = 1;
         (void)np2;
-        const unsigned nblk = (unsigned)(nb < 512 ? nb : 512);          // 2 resident workgroups per CU, persistent over sites
+        const unsigned nblk = (unsigned)(nb < 512 ? nb : 512);          // k4: 2 resident workgroups per CU, persistent over sites
+        const unsigned nblk5 = (unsigned)(nb < 256 ? nb : 256);        // k5: one 512-thread workgroup per CU
         (void)np3; (void)a2; (void)k3; (void)b3;
         const bool tk = ctx->timing && ctx->n_kev + 2 <= 128;
         if (tk) {
@@ -916,7 +1047,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         if (ctx->cnn_exact_fp32)
             hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a3, nb, scale, scale_mode, site0);
         else
-            hipLaunchKernelGGL(k5_trunk_h3, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
+            hipLaunchKernelGGL(k5_trunk_h3, dim3(nblk5), dim3(512), 0, ctx->stream, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
         if (tk) {
             (void)hipEventRecord(ctx->kev[ctx->n_kev + 1], ctx->stream);
             ctx->n_kev += 2;
@@ -934,6 +1065,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
 }   // namespace
 
 extern "C" {
+
+#ifdef NC_TRACE
+int nc_debug_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nc_trace_buf), sizeof(nc_trace_buf)); }
+#endif
 
 int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_floats)
 {
@@ -1002,37 +1137,63 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         float S = 1024.0f;
         while (S > 1.0f && wmax * S > 16384.0f) S *= 0.5f;
         std::vector<uint8_t> hp((size_t)H_PACKED_BYTES, 0);
-        _Float16 *w1h = reinterpret_cast<_Float16 *>(hp.data()), *w1l = w1h + H_W1, *w2h = w1l + H_W1, *w2l = w2h + H_W2,
-                 *w3h = w2l + H_W2, *w3l = w3h + H_W3;
-        float *b1s = reinterpret_cast<float *>(w3l + H_W3), *b2s = b1s + 48, *b3s = b2s + 32;
-        auto put = [&](_Float16 *hi, _Float16 *lo, size_t idx, float v) {
+        _Float16 *w1f = reinterpret_cast<_Float16 *>(hp.data()), *w2h = w1f + T_NW1 * T_FRAG, *w2l = w2h + T_NW2 * T_FRAG,
+                 *w3h = w2l + T_NW2 * T_FRAG, *w3l = w3h + T_NW3 * T_FRAG;
+        float *b1s = reinterpret_cast<float *>(w3l + T_NW3 * T_FRAG), *b2s = b1s + 48, *b3s = b2s + 32;
+        int32_t *c3tab = reinterpret_cast<int32_t *>(b3s + 68);
+        auto split = [&](float v, _Float16 &h, _Float16 &l) {
             const float sv = v * S;
-            const _Float16 h = (_Float16)sv;
-            hi[idx] = h;
-            lo[idx] = (_Float16)(sv - (float)h);
+            h = (_Float16)sv;
+            l = (_Float16)(sv - (float)h);
+        };
+        // conv1 fragment pair (WA at fragment fa, WB at fragment fb) of one lane: kw[ci] = the 5 channel weights of its tap
+        auto put_tap = [&](int fa, int fb, int lane, const float *kw /* 5 or nullptr */) {
+            _Float16 H[5], L[5];
+            for (int ci = 0; ci < 5; ci++) split(kw ? kw[ci] : 0.0f, H[ci], L[ci]);
+            _Float16 *A = w1f + ((size_t)fa * 64 + lane) * 8, *B = w1f + ((size_t)fb * 64 + lane) * 8;
+            const _Float16 wa[8] = {H[0], H[1], H[2], H[3], H[4], H[0], H[1], H[2]};
+            const _Float16 wb[8] = {H[3], H[4], L[0], L[1], L[2], L[3], L[4], (_Float16)0.0f};
+            for (int j = 0; j < 8; j++) { A[j] = wa[j]; B[j] = wb[j]; }
         };
         for (int lane = 0; lane < 64; lane++) {
             const int g = lane >> 4, c = lane & 15;
+            for (int G = 0; G < 7; G++) {
+                const int dy = C1_TAPS[G][g][0], dx = C1_TAPS[G][g][1];
+                // a tap listed twice in a group (dummy lanes) carries its weights only at its first occurrence
+                bool first = true;
+                for (int q = 0; q < g; q++) first = first && !(C1_TAPS[G][q][0] == dy && C1_TAPS[G][q][1] == dx);
+                float kw[5];
+                for (int ci = 0; ci < 5; ci++) kw[ci] = k13[((dy * 5 + dx) * 5 + ci) * 16 + c];
+                put_tap(G, 7 + G, lane, first ? kw : nullptr);
+                if (G < 2) {                                                         // 1x5 kernel: taps of image row dy == 2
+                    for (int ci = 0; ci < 5; ci++) kw[ci] = k11[(dx * 5 + ci) * 16 + c];
+                    put_tap(14 + G, 16 + G, lane, (first && dy == 2) ? kw : nullptr);
+                }
+                if (G >= 1 && G <= 3) {                                              // 5x1 kernel: taps of image column dx == 2
+                    for (int ci = 0; ci < 5; ci++) kw[ci] = k12[(dy * 5 + ci) * 16 + c];
+                    put_tap(18 + G - 1, 21 + G - 1, lane, (first && dx == 2) ? kw : nullptr);
+                }
+            }
             for (int j = 0; j < 8; j++) {
-                const int kl = 8 * g + j, dx = kl / 6, ci = kl % 6;                  // slot of an image-row group
-                const bool real = kl < 30 && ci < 5;
-                for (int dy = 0; dy < 5; dy++)
-                    put(w1h, w1l, ((size_t)dy * 64 + lane) * 8 + j, real ? k13[((dy * 5 + dx) * 5 + ci) * 16 + c] : 0.0f);
-                put(w1h, w1l, ((size_t)5 * 64 + lane) * 8 + j, real ? k11[(dx * 5 + ci) * 16 + c] : 0.0f);
-                const int kc = 8 * g + j;                                            // 5x1 kernel: slot k = dy*5 + ci
-                put(w1h, w1l, ((size_t)6 * 64 + lane) * 8 + j, kc < 25 ? k12[kc * 16 + c] : 0.0f);
-                for (int G = 0; G < 9; G++)
-                    for (int tn = 0; tn < 2; tn++)
-                        put(w2h, w2l, ((size_t)(G * 2 + tn) * 64 + lane) * 8 + j, k2[(32 * G + 8 * g + j) * 32 + tn * 16 + c]);
+                for (int G = 0; G < 9; G++) {
+                    const int idx = 4 * G + g, tap = idx / 6, ch = (idx % 6) * 8 + j;
+                    for (int tn = 0; tn < 2; tn++) {
+                        const size_t o = ((size_t)(G * 2 + tn) * 64 + lane) * 8 + j;
+                        split(k2[(tap * 48 + ch) * 32 + tn * 16 + c], w2h[o], w2l[o]);
+                    }
+                }
                 for (int G = 0; G < 6; G++)
-                    for (int tn = 0; tn < 4; tn++)
-                        put(w3h, w3l, ((size_t)(G * 4 + tn) * 64 + lane) * 8 + j, k3[(32 * G + 8 * g + j) * 64 + tn * 16 + c]);
+                    for (int tn = 0; tn < 4; tn++) {
+                        const size_t o = ((size_t)(G * 4 + tn) * 64 + lane) * 8 + j;
+                        split(k3[(G * 32 + 8 * g + j) * 64 + tn * 16 + c], w3h[o], w3l[o]);
+                    }
             }
         }
         for (int c = 0; c < 16; c++) { b1s[c] = b11[c] * S; b1s[16 + c] = b12[c] * S; b1s[32 + c] = b13[c] * S; }
         for (int c = 0; c < 32; c++) b2s[c] = b2[c] * S;
         for (int c = 0; c < 64; c++) b3s[c] = b3[c] * S;
         b3s[64] = 1.0f / S;
+        for (int i = 0; i < 32; i++) { c3tab[i] = C3_SLOT[i]; c3tab[32 + i] = C3_OUT[i]; }
         if (!w.packed_h) {
             hipError_t e = hipMalloc(&w.packed_h, hp.size());
             if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed fp16 weights: %s", hipGetErrorString(e));

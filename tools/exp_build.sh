@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build ablation / experiment variants of the library: tools/exp_build.sh NAME "-DFLAG ..." [NAME "-DFLAG" ...]
+# -> build_exp/libnc_NAME.so (timed by tools/exp_trunk.py on the GPU box). Experiment infrastructure only.
+set -e
+cd "$(dirname "$0")/../nanocaller_amd/csrc"
+make -s >/dev/null 2>&1 || make
+while [ $# -gt 0 ]; do
+  name=$1; flags=$2; shift 2
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c nc_cnn.hip -o ../../build_exp/nc_cnn_$name.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_exp/libnc_$name.so nc_ctx.o nc_scan.o nc_featurize.o ../../build_exp/nc_cnn_$name.o nc_indel.o nc_bam.o nc_vcf.o -lz -lpthread
+  rm -f ../../build_exp/nc_cnn_$name.o
+  echo built $name
+done
