@@ -138,6 +138,12 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack,
 int nc_snp_scan_fetch(nc_ctx *ctx, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk,
                       int32_t *site_n, int32_t *site_alt);
 
+/* Same copies, asynchronous: enqueued on `copy_stream` (a hipStream_t; NULL = the context's stream) and NOT waited for.
+ * The host buffers should be pinned; the caller synchronises `copy_stream` before reading them and before the next
+ * nc_snp_scan on this context (the scan results live in the context).  Lets the fetch overlap featurisation / CNN. */
+int nc_snp_scan_fetch_async(nc_ctx *ctx, void *copy_stream, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk,
+                            int32_t *site_n, int32_t *site_alt);
+
 /* ------------------------------------------------------------------ SNP tensor build (K2-K4)
  * Replaces get_cnd_pos + the per-candidate loop (generate_SNP_pileups.py:6-101, 200-263) for the sites of
  * the last nc_snp_scan on this context: one wavefront per site picks <= 20+20 neighbour sites, gathers the
@@ -178,6 +184,14 @@ int nc_load_weights(nc_ctx *ctx, int32_t model_kind, const float *blob_host, siz
 int nc_set_cnn_precision(nc_ctx *ctx, int exact_fp32);
 int nc_snp_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev,
                    const double *scale_dev, int32_t scale_mode, float *probs_dev, float *gt_dev);
+
+/* nc_snp_forward with an asynchronous result drain: as soon as a batch of sites is finished its rows of probs (and gt)
+ * are copied to the pinned host arrays probs_host[n][4] / gt_host[n][2] on `copy_stream`, overlapping the next batch's
+ * compute (the reference moves every batch's predictions to numpy, snpCaller.py:111-113,183-185).  The caller
+ * synchronises `copy_stream` before reading the host arrays.  gt_host / gt_dev may be NULL. */
+int nc_snp_forward_drain(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev,
+                         const double *scale_dev, int32_t scale_mode, float *probs_dev, float *gt_dev,
+                         void *copy_stream, float *probs_host, float *gt_host);
 /* Indel CNN (model_architect_indel.py:28-48 rows=15 -> [n][4]; haploid rows=5 -> [n][1] sigmoid). */
 int nc_indel_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, float *probs_dev);
 

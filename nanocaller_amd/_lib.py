@@ -27,7 +27,7 @@ EXPORTS = [
     "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
-    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision",
+    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain",
 ]
 
 
@@ -104,10 +104,12 @@ def lib():
         L.nc_snp_scan.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, C.POINTER(ScanParamsC), i32, vp, vp,
                                   C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.nc_snp_scan_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.nc_snp_scan_fetch_async.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.nc_snp_featurize.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         L.nc_snp_scale.argtypes = [vp, vp, vp, dbl, i32, vp, vp]
         L.nc_load_weights.argtypes = [vp, i32, vp, C.c_size_t]
         L.nc_snp_forward.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp]
+        L.nc_snp_forward_drain.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.nc_indel_forward.argtypes = [vp, i32, i64, vp, vp]
         L.nc_indel_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.nc_indel_scan.argtypes = [vp, C.POINTER(ReadPackC), C.POINTER(IndelEventsC), vp, i32, i32, C.POINTER(IndelScanParamsC), vp]

@@ -1207,7 +1207,14 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
 int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev, const double *scale_dev,
                    int32_t scale_mode, float *probs_dev, float *gt_dev)
 {
+    return nc_snp_forward_drain(ctx, kind, n, x_dev, ref_code_dev, scale_dev, scale_mode, probs_dev, gt_dev, nullptr, nullptr, nullptr);
+}
+
+int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev, const double *scale_dev,
+                         int32_t scale_mode, float *probs_dev, float *gt_dev, void *copy_stream, float *probs_host, float *gt_host)
+{
     if (!ctx) return NC_ERR_ARG;
+    if (probs_host && !copy_stream) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward_drain: host drain needs a copy stream");
     if (kind != NC_MODEL_SNP && kind != NC_MODEL_SNP_HAP) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: not an SNP model kind");
     if (!ctx->w[kind].dev) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_forward: weights of kind %d not loaded", kind);
     if (n < 0 || (n && (!x_dev || !ref_code_dev || !probs_dev))) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: null argument");
@@ -1228,6 +1235,15 @@ int nc_snp_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, con
             hipLaunchKernelGGL(k_snp_hap_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, ref_code_dev + s0, nb,
                                probs_dev + s0 * 4);
         NC_HIP(ctx, hipGetLastError());
+        if (probs_host) {                    // drain this batch on the copy stream while the next batch computes
+            const int slot = (int)((s0 / BATCH) & 3);
+            if (!ctx->drain_ev[slot]) NC_HIP(ctx, hipEventCreateWithFlags(&ctx->drain_ev[slot], hipEventDisableTiming));
+            NC_HIP(ctx, hipEventRecord(ctx->drain_ev[slot], ctx->stream));
+            NC_HIP(ctx, hipStreamWaitEvent((hipStream_t)copy_stream, ctx->drain_ev[slot], 0));
+            NC_HIP(ctx, hipMemcpyAsync(probs_host + s0 * 4, probs_dev + s0 * 4, (size_t)nb * 16, hipMemcpyDeviceToHost, (hipStream_t)copy_stream));
+            if (gt_host && gt_dev)
+                NC_HIP(ctx, hipMemcpyAsync(gt_host + s0 * 2, gt_dev + s0 * 2, (size_t)nb * 8, hipMemcpyDeviceToHost, (hipStream_t)copy_stream));
+        }
     }
     tm.stop();
     if (ctx->timing) {                       // per-launch durations of the trunk kernel, on the launch stream

@@ -33,6 +33,7 @@ struct nc_ctx {
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
     hipEvent_t kev[128] = {nullptr};          // per-launch event pairs of the trunk kernel (timing mode)
     int n_kev = 0;
+    hipEvent_t drain_ev[4] = {nullptr};       // batch-complete events of nc_snp_forward_drain
 
     // scan results (device)
     DevBuf stage_nbr, stage_cpos, stage_cn, stage_calt;   // per-tile staging

@@ -69,6 +69,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
         if (w.packed_h) (void)hipFree(w.packed_h);
     }
     for (auto &e : ctx->kev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->drain_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -417,19 +417,35 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     return NC_OK;
 }
 
-int nc_snp_scan_fetch(nc_ctx *ctx, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk, int32_t *site_n,
+static int scan_fetch(nc_ctx *ctx, hipStream_t st, bool wait, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk, int32_t *site_n,
                       int32_t *site_alt)
 {
     if (!ctx) return NC_ERR_ARG;
     if (!ctx->have_scan) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan_fetch: no scan on this context");
     const size_t nb = (size_t)ctx->n_nbr * 4, ns = (size_t)ctx->n_sites * 4;
-    if (nbr_pos && nb) NC_HIP(ctx, hipMemcpyAsync(nbr_pos, ctx->nbr_pos.p, nb, hipMemcpyDeviceToHost, ctx->stream));
-    if (site_pos && ns) NC_HIP(ctx, hipMemcpyAsync(site_pos, ctx->site_pos.p, ns, hipMemcpyDeviceToHost, ctx->stream));
-    if (site_chunk && ns) NC_HIP(ctx, hipMemcpyAsync(site_chunk, ctx->site_chunk.p, ns, hipMemcpyDeviceToHost, ctx->stream));
-    if (site_n && ns) NC_HIP(ctx, hipMemcpyAsync(site_n, ctx->site_n.p, ns, hipMemcpyDeviceToHost, ctx->stream));
-    if (site_alt && ns) NC_HIP(ctx, hipMemcpyAsync(site_alt, ctx->site_alt.p, ns, hipMemcpyDeviceToHost, ctx->stream));
-    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nbr_pos && nb) NC_HIP(ctx, hipMemcpyAsync(nbr_pos, ctx->nbr_pos.p, nb, hipMemcpyDeviceToHost, st));
+    if (site_pos && ns) NC_HIP(ctx, hipMemcpyAsync(site_pos, ctx->site_pos.p, ns, hipMemcpyDeviceToHost, st));
+    if (site_chunk && ns) NC_HIP(ctx, hipMemcpyAsync(site_chunk, ctx->site_chunk.p, ns, hipMemcpyDeviceToHost, st));
+    if (site_n && ns) NC_HIP(ctx, hipMemcpyAsync(site_n, ctx->site_n.p, ns, hipMemcpyDeviceToHost, st));
+    if (site_alt && ns) NC_HIP(ctx, hipMemcpyAsync(site_alt, ctx->site_alt.p, ns, hipMemcpyDeviceToHost, st));
+    if (wait) NC_HIP(ctx, hipStreamSynchronize(st));
     return NC_OK;
+}
+
+int nc_snp_scan_fetch(nc_ctx *ctx, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk, int32_t *site_n,
+                      int32_t *site_alt)
+{
+    if (!ctx) return NC_ERR_ARG;
+    return scan_fetch(ctx, ctx->stream, true, nbr_pos, site_pos, site_chunk, site_n, site_alt);
+}
+
+// nc_snp_scan has already synchronised the context's stream (it returns the counts), so the results are complete and
+// may be copied from any stream
+int nc_snp_scan_fetch_async(nc_ctx *ctx, void *copy_stream, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk,
+                            int32_t *site_n, int32_t *site_alt)
+{
+    if (!ctx) return NC_ERR_ARG;
+    return scan_fetch(ctx, copy_stream ? (hipStream_t)copy_stream : ctx->stream, false, nbr_pos, site_pos, site_chunk, site_n, site_alt);
 }
 
 }   // extern "C"

@@ -6,6 +6,7 @@ runs, torch.distributed rendezvous.  All arithmetic of the hot path runs in the 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -61,6 +62,32 @@ class SnpSites:
     valid: torch.Tensor | None = None      # u8 [N]
 
 
+class _PinnedPool:
+    """Page-locked host blocks for result arrays.  hipHostMalloc costs milliseconds, so blocks are reused -- but only
+    when no numpy view handed out from a block is alive any more (tracked with a weak reference), so results of
+    earlier calls stay valid for as long as the caller keeps them."""
+
+    def __init__(self):
+        self.blocks = []                                  # [uint8 pinned tensor, weakref to the numpy array handed out]
+
+    def get(self, shape, dtype):
+        """-> (torch tensor view, numpy array) over the same pinned memory"""
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty(0, dtype=dtype).element_size()
+        best = None
+        for b in self.blocks:
+            if (b[1] is None or b[1]() is None) and b[0].numel() >= nbytes and (best is None or b[0].numel() < best[0].numel()):
+                best = b
+        if best is None:
+            cap = max(4096, nbytes + nbytes // 4)
+            best = [torch.empty(cap, dtype=torch.uint8, pin_memory=True), None]
+            self.blocks.append(best)
+        t = best[0][:nbytes].view(dtype).view(shape)
+        arr = t.numpy()
+        best[1] = weakref.ref(arr)
+        return t, arr
+
+
 class Engine:
     """One engine per GPU (one process per GPU in multi-GPU runs).  Not thread-safe."""
 
@@ -76,6 +103,7 @@ class Engine:
             raise _lib.NanoCallerHipError("nc_ctx_create(device=%d) failed with status %d" % (device, rc))
         self.ctx = ctx
         self._loaded = {}
+        self._pinned = _PinnedPool()
         self.use_torch_stream()
 
     def close(self):
@@ -134,7 +162,7 @@ class Engine:
         self._loaded[kind] = w.path
 
     # ------------------------------------------------------------------ K1
-    def snp_scan(self, dp: DevicePack, chunks, *, mincov, min_allele_freq, threshold, haploid=False) -> SnpSites:
+    def snp_scan(self, dp: DevicePack, chunks, *, mincov, min_allele_freq, threshold, haploid=False, async_fetch=False) -> SnpSites:
         """chunks: list of (start, end) inclusive, same contig, ascending."""
         cs = np.ascontiguousarray([c[0] for c in chunks], np.int32)
         ce = np.ascontiguousarray([c[1] for c in chunks], np.int32)
@@ -151,10 +179,14 @@ class Engine:
                                        C.byref(n_cand), C.byref(n_sites)), "nc_snp_scan")
         N = n_sites.value
         # pinned host buffers (cached by torch's host allocator): the four copies run at PCIe speed, one sync
-        hb = torch.empty((4, max(N, 1)), dtype=torch.int32, pin_memory=True)
+        hb, h = self._pinned.get((4, max(N, 1)), torch.int32)
         ptr = [C.c_void_p(hb[i].data_ptr()) for i in range(4)]
-        self._check(self.L.nc_snp_scan_fetch(self.ctx, None, ptr[0], ptr[1], ptr[2], ptr[3]), "nc_snp_scan_fetch")
-        h = hb.numpy()
+        if async_fetch:
+            # copies go to the copy stream and overlap whatever is launched next; wait_copies() before reading them
+            self._check(self.L.nc_snp_scan_fetch_async(self.ctx, self._copy_stream_ptr(), None, ptr[0], ptr[1], ptr[2], ptr[3]),
+                        "nc_snp_scan_fetch_async")
+        else:
+            self._check(self.L.nc_snp_scan_fetch(self.ctx, None, ptr[0], ptr[1], ptr[2], ptr[3]), "nc_snp_scan_fetch")
         return SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=h[0, :N], chunk=h[1, :N], dp=h[2, :N], alt=h[3, :N])
 
     def fetch_nbr_sites(self, n_nbr) -> np.ndarray:
@@ -188,13 +220,22 @@ class Engine:
         return scale, cd
 
     # ------------------------------------------------------------------ K5 / K9
-    def snp_forward(self, kind, x, ref_code, scale, scale_mode=0, want_gt=True):
+    def snp_forward(self, kind, x, ref_code, scale, scale_mode=0, want_gt=True, drain=False):
+        """-> (probs, gt) device tensors; with drain=True also (probs_host, gt_host) numpy arrays in pinned memory that
+        the copy stream fills batch by batch while the next batch computes (wait_copies() before reading them)."""
         n = int(x.shape[0])
         probs = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         gt = torch.empty((n, 2), dtype=torch.float32, device=self.device) if (want_gt and kind == _lib.MODEL_SNP) else None
-        self._check(self.L.nc_snp_forward(self.ctx, kind, n, _ptr(x), _ptr(ref_code), _ptr(scale), int(scale_mode),
-                                          _ptr(probs), _ptr(gt)), "nc_snp_forward")
-        return probs, gt
+        if not drain:
+            self._check(self.L.nc_snp_forward(self.ctx, kind, n, _ptr(x), _ptr(ref_code), _ptr(scale), int(scale_mode),
+                                              _ptr(probs), _ptr(gt)), "nc_snp_forward")
+            return probs, gt
+        hp, hp_np = self._pinned.get((n, 4), torch.float32)
+        hg, hg_np = self._pinned.get((n, 2), torch.float32) if gt is not None else (None, None)
+        self._check(self.L.nc_snp_forward_drain(self.ctx, kind, n, _ptr(x), _ptr(ref_code), _ptr(scale), int(scale_mode),
+                                                _ptr(probs), _ptr(gt), self._copy_stream_ptr(), C.c_void_p(hp.data_ptr()),
+                                                C.c_void_p(hg.data_ptr()) if hg is not None else None), "nc_snp_forward_drain")
+        return probs, gt, hp_np, hg_np
 
     def indel_forward(self, kind, x):
         n = int(x.shape[0])
@@ -255,11 +296,48 @@ class Engine:
             if t is None:
                 outs.append(None)
                 continue
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h, h_np = self._pinned.get(t.shape, t.dtype)
             h.copy_(t, non_blocking=True)
-            outs.append(h)
+            outs.append(h_np)
         torch.cuda.current_stream(self.device).synchronize()
-        return [None if h is None else h.numpy() for h in outs]
+        return outs
+
+    # ------------------------------------------------------------------ copy stream (results drain overlapping compute)
+    def _copy_stream(self):
+        if getattr(self, "_cstream", None) is None:
+            self._cstream = torch.cuda.Stream(device=self.device)
+        return self._cstream
+
+    def _copy_stream_ptr(self):
+        return C.c_void_p(self._copy_stream().cuda_stream)
+
+    def to_host_async(self, tensors):
+        """Enqueue D2H copies of device tensors on the copy stream, ordered after everything already enqueued on the
+        compute stream; -> list of numpy views of pinned memory, valid after wait_copies()."""
+        cs = self._copy_stream()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        cs.wait_event(ev)
+        outs = []
+        with torch.cuda.stream(cs):
+            for t in tensors:
+                if t is None:
+                    outs.append(None)
+                    continue
+                h, h_np = self._pinned.get(t.shape, t.dtype)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(cs)
+                outs.append(h_np)
+        return outs
+
+    def copy_event(self):
+        """event that completes when the copies enqueued so far on the copy stream are done"""
+        ev = torch.cuda.Event()
+        ev.record(self._copy_stream())
+        return ev
+
+    def wait_copies(self):
+        self._copy_stream().synchronize()
 
     def sync(self):
         torch.cuda.synchronize(self.device)

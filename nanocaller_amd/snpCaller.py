@@ -139,6 +139,16 @@ VCF_HEADER = (                                                      # snpCaller.
     '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample}\n')
 
 
+_WEIGHTS = {}
+
+
+def _weights(path):
+    """parsed .ncw files, cached per path"""
+    if path not in _WEIGHTS:
+        _WEIGHTS[path] = Weights(path)
+    return _WEIGHTS[path]
+
+
 def call_chunks(params, chunks, device=0, dpk=None):
     """Run pileup featurisation + CNN for a list of chunks of ONE contig and ploidy on the GPU.
     `dpk`: alignments already resident in HBM (engine.DevicePack); default: packed from params['sam_path'].
@@ -158,29 +168,35 @@ def call_chunks(params, chunks, device=0, dpk=None):
         path, _ = get_SNP_model('haploid')
         train_cov = 30                                              # hap_train_coverage, snpCaller.py:73
         kind = _lib.MODEL_SNP_HAP
-    eng.load_weights(kind, Weights(path))
+    eng.load_weights(kind, _weights(path))
     if dpk is None:
         dpk = device_pack_for(params, chrom, device)
+    # Results drain on a second stream while the GPU keeps computing: the candidate arrays right after the scan, the
+    # featuriser's per-site arrays during the CNN, and every CNN batch's probabilities while the next batch runs.
     sites = eng.snp_scan(dpk, [(c['start'], c['end']) for c in chunks], mincov=params['mincov'],
                          min_allele_freq=params['min_allele_freq'], threshold=params['threshold'],
-                         haploid=(ploidy == 'haploid'))
+                         haploid=(ploidy == 'haploid'), async_fetch=True)
     res = dict(chrom=chrom, ploidy=ploidy, n=0)
     if sites.n_sites == 0:
+        eng.wait_copies()
         return res
+    scan_copied = eng.copy_event()
     eng.snp_featurize(dpk, sites, seq=params['seq'], maxcov=params['maxcov'], min_nbr_sites=params['min_nbr_sites'])
+    all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
+    h_ref, h_fwd, h_rev, h_valid = eng.to_host_async([sites.ref_code, sites.fwd_dp, sites.rev_dp, None if all_valid else sites.valid])
     per_site = bool(params.get('disable_coverage_normalization'))
     scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site)
-    probs, gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0)
-    all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
-    h_ref, h_probs, h_gt, h_fwd, h_rev, h_valid = eng.to_host([sites.ref_code, probs, gt, sites.fwd_dp, sites.rev_dp,
-                                                              None if all_valid else sites.valid])
+    _, _, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True)
+    # host work that only needs the scan results runs under the CNN: freq = alt / n in float64 (:166)
+    scan_copied.synchronize()
+    freq = sites.alt.astype(np.float64) / sites.dp.astype(np.float64)
+    eng.wait_copies()
     out = dict(pos=sites.pos, chunk=sites.chunk, ref=h_ref, probs=h_probs, gt=h_gt, dp=sites.dp, alt=sites.alt,
-               fwd_dp=h_fwd, rev_dp=h_rev)
+               fwd_dp=h_fwd, rev_dp=h_rev, freq=freq)
     if not all_valid:
         m = h_valid.astype(bool)
         out = {k: (v[m] if v is not None else None) for k, v in out.items()}
-    # host arrays keep the device dtypes (int32 / float32); freq = alt / n in float64 (:166)
-    out['freq'] = out['alt'].astype(np.float64) / out['dp'].astype(np.float64)
+    # host arrays keep the device dtypes (int32 / float32)
     res.update(out, n=int(out['pos'].shape[0]), chunk_depth=chunk_depth)
     return res
 
