@@ -28,9 +28,9 @@ import torch  # noqa: E402
 CHR20_LEN = 64_444_167                 # GRCh38 chr20
 SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3 (haploid model: 3,453,696)
 TRUNK_FLOP_PER_SITE = 2 * (574_000 + 737_280 + 331_776)   # conv1 (3 kernels) + conv2 + conv3, SURVEY.md Appendix C.1
-# HBM bytes per launch of the fused trunk kernel (32768 sites), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: profiles/r01_final_pmc.md
-TRUNK_TRAFFIC_PER_SITE = (2 * 69.3e6 + 216e6 * 32768 / 31231) / 32768
+# HBM bytes per launch of the fused trunk kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: profiles/r01b_pmc.md (k4_conv12: r01_final_pmc.md, same bytes)
+TRUNK_TRAFFIC_PER_SITE = (2 * 68.53e6 + 215.87e6) / 31231      # k5_trunk_h3, profiles/r01b_pmc.md (31,231 sites per launch on average)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md, dense
 # k5_trunk_h3 issues 3 f16 MFMA products per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so the peak its ALGORITHMIC
@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--length", type=int, default=CHR20_LEN, help="contig length per GPU (default chr20)")
     ap.add_argument("--depth", type=float, default=30.0)
@@ -139,6 +139,7 @@ def main():
     def step():
         return snpCaller.call_chunks(params, chunks, device=local, dpk=pack)
 
+    step()                                  # setup: one priming call sizes the device / pinned-host buffer pools (untimed, not a warmup step)
     for _ in range(args.warmup):
         step()
     eng.enable_timing(True)
