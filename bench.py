@@ -163,7 +163,7 @@ def main():
     # number SURVEY.md 8(d) asks for (kernels only / + D2H / end to end incl. host K6 + VCF text)
     tv = time.perf_counter()
     vcf = snpCaller.snp_vcf_text("chr20", r["pos"], r["ref"], r["probs"], r["dp"], r["freq"], r["fwd_dp"], r["rev_dp"],
-                                 haploid=(args.ploidy == "haploid"))
+                                 haploid=(args.ploidy == "haploid"), as_array=True)
     vcf_ms = (time.perf_counter() - tv) * 1e3
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

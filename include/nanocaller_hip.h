@@ -282,6 +282,12 @@ int nc_snp_vcf_format(const char *chrom, int64_t n, const int32_t *pos, const in
                       const int32_t *order, const int32_t *dp, const double *freq, const int32_t *fwd, const int32_t *rev,
                       int32_t haploid, char *out, int64_t cap, int64_t *n_bytes);
 
+/* Ascending argsort of n rows of 4 probabilities (np.argsort(..., axis=1), snpCaller.py:120), multi-threaded.  Rows that
+ * contain equal values are listed in tie_idx[0..*n_ties) (NC_ERR_CAPACITY, with *n_ties set, if tie_cap is too small):
+ * numpy's order of tied elements is implementation dependent, so a caller that needs the
+ * reference's exact records re-sorts those rows with numpy before passing `order` to nc_snp_vcf_format. */
+int nc_argsort4(const float *probs, int64_t n, int32_t *order, int64_t *n_ties, int64_t *tie_idx, int64_t tie_cap);
+
 #ifdef __cplusplus
 }
 #endif

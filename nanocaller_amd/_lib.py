@@ -27,7 +27,7 @@ EXPORTS = [
     "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
-    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain",
+    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4",
 ]
 
 
@@ -122,6 +122,7 @@ def lib():
         L.nc_bam_decode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
         L.nc_decoded_view.argtypes = [vp, C.POINTER(DecodedArraysC)]
         L.nc_decoded_free.argtypes = [vp]
+        L.nc_argsort4.argtypes = [vp, i64, vp, C.POINTER(i64), vp, i64]
         L.nc_snp_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, C.POINTER(i64)]
         for name in EXPORTS:
             fn = getattr(L, name)

@@ -831,16 +831,16 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         const int px = threadIdx.x < 205 ? threadIdx.x : 204, ph = px / 41, pw = px - ph * 41;
         const int xslot = ((ph + 2) * T_RX + pw + 2) * 8;
         float pre[5];
-        float pre_sf = 1.0f;
         double pre_sd = 1.0;
         auto prefetch = [&](int64_t site) {
             const float *xs = x + site * NC_SNP_TENSOR + px * 5;
 #pragma unroll
             for (int u = 0; u < 5; u++) pre[u] = xs[u];
-            if (scale) { pre_sd = scale[site0 + site]; pre_sf = (float)pre_sd; }
+            if (scale) pre_sd = scale[site0 + site];                                  // consumed in commit(): no wait here
         };
         auto commit = [&](int buf) {
             if (threadIdx.x < 205) {
+                const float pre_sf = (float)pre_sd;
                 _Float16 hi[5], lo[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) {

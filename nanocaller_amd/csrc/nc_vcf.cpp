@@ -19,6 +19,55 @@ inline double qual(float p, double cap, double mult)
     const double q = mult * std::log10(1e-10 + 1 - (double)p);            // float64, numpy<2 semantics (E7)
     return q < cap ? q : cap;
 }
+
+// ---- number formatting without printf.  '%.Nf' of a double is the correctly rounded (ties to even, on the EXACT binary
+// value) decimal with N digits; glibc and CPython both do exactly that.  For |x| < 2^40 and N <= 4 the scaled value
+// m * 10^N * 2^e fits a 128-bit integer, so the rounding is done exactly in integer arithmetic.
+inline char *put_uint(char *o, uint64_t v)
+{
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *o++ = tmp[--n];
+    return o;
+}
+inline char *put_int(char *o, int64_t v)
+{
+    if (v < 0) { *o++ = '-'; return put_uint(o, (uint64_t)(-(v + 1)) + 1); }
+    return put_uint(o, (uint64_t)v);
+}
+inline char *put_fixed(char *o, double x, int prec)                        // prec in 1..4, |x| < 2^40, finite
+{
+    static const uint32_t P10[5] = {1, 10, 100, 1000, 10000};
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    if (bits >> 63) *o++ = '-';                                            // also "-0.000" for a negative zero / tiny negative
+    const int be = (int)((bits >> 52) & 0x7ff);
+    uint64_t m = bits & ((1ull << 52) - 1);
+    int e;
+    if (be == 0) e = -1074;                                                // subnormal
+    else { m |= 1ull << 52; e = be - 1075; }
+    unsigned __int128 N = (unsigned __int128)m * P10[prec];                // < 2^53 * 2^14
+    unsigned __int128 q;
+    if (e >= 0) q = N << e;                                                // |x| < 2^40 -> e <= -13 for nonzero m; kept for completeness
+    else {
+        const int sft = -e;
+        if (sft >= 128) q = 0;                                             // N < 2^67 <= half
+        else {
+            q = N >> sft;
+            const unsigned __int128 rem = N & ((((unsigned __int128)1) << sft) - 1), half = ((unsigned __int128)1) << (sft - 1);
+            if (rem > half || (rem == half && (q & 1))) q++;
+        }
+    }
+    const uint64_t qi = (uint64_t)q, ip = qi / P10[prec];
+    uint32_t fp = (uint32_t)(qi % P10[prec]);
+    o = put_uint(o, ip);
+    *o++ = '.';
+    for (int k = prec - 1; k >= 0; k--) { o[k] = (char)('0' + fp % 10); fp /= 10; }
+    return o + prec;
+}
+inline char *put_str(char *o, const char *s, size_t n) { memcpy(o, s, n); return o + n; }
+#define PUT_LIT(o, lit) put_str(o, lit, sizeof(lit) - 1)
 }   // namespace
 
 static int format_range(const char *chrom, int64_t n, const int32_t *pos, const int32_t *ref, const float *probs,
@@ -76,42 +125,119 @@ static int format_range(const char *chrom, int64_t n, const int32_t *pos, const 
         const float *pr = probs + 4 * j;
         const int r = ref[j];
         const int d = dp[j];
-        char info[96];
-        snprintf(info, sizeof info, "PR=%.4f,%.4f,%.4f,%.4f;FQ=%.4f", (double)pr[0], (double)pr[3], (double)pr[1], (double)pr[2], freq[j]);  // :127
-        int len = 0;
+        // genotype decision first (the record's ALT / QUAL / FILTER / sample column depend on it)
+        int kind;                    // 0 haploid, 1 het 0/1, 2 het 1/2, 3 hom 1/1, 4 REF, 5 LOW
+        int a1 = 0, a2 = 0;
+        double q = 0.0;
+        const int32_t *f = nullptr, *v = nullptr;
         if (haploid) {                                                                                     // :184-198
             int p = 0;
             for (int k = 1; k < 4; k++) if (pr[k] > pr[p]) p = k;                                          // np.argmax: first maximum
-            len = sprintf(o, "%s\t%d\t.\t%c\t%c\t%.3f\t%s\t%s\tGT:DP:VF:AD:ADF:ADR\t1/1:%d:%.4f:.:.:.\n", chrom, pos[j], B[r], B[p],
-                          qual(pr[p], 999.0, -100.0), p != r ? "PASS" : "REF", info, d, freq[j]);
+            kind = 0; a1 = p; q = qual(pr[p], 999.0, -100.0);
         } else {
-            const int32_t *f = fwd + 4 * j, *v = rev + 4 * j;
+            f = fwd + 4 * j; v = rev + 4 * j;
             const int p1 = order[4 * j + 3], p2 = order[4 * j + 2];
             int k = 0;
             for (int b = 0; b < 4; b++) k += pr[b] >= 0.5f;                                                // :122
-            const int rf = f[r], rr = v[r];
+            kind = -1;
             if (k >= 2) {
-                if (p1 == r || (p2 == r && pr[p2] >= 0.5f)) {                                              // :132, :138
-                    const int a = p1 == r ? p2 : p1;
-                    len = sprintf(o, "%s\t%d\t.\t%c\t%c\t%.3f\tPASS\t%s\tGT:DP:VF:AD:ADF:ADR\t0/1:%d:%.4f:%d,%d:%d,%d:%d,%d\n", chrom, pos[j], B[r],
-                                  B[a], qual(pr[p2], 99.0, -10.0), info, d, (double)(f[a] + v[a]) / d, rf + rr, f[a] + v[a], rf, f[a], rr, v[a]);
-                } else if (p2 != r && p1 != r && pr[p2] >= 0.5f) {                                         // :143
-                    len = sprintf(o, "%s\t%d\t.\t%c\t%c,%c\t%.3f\tPASS\t%s\tGT:DP:VF:AD:ADF:ADR\t1/2:%d:%.4f,%.4f:%d,%d,%d:%d,%d,%d:%d,%d,%d\n", chrom,
-                                  pos[j], B[r], B[p1], B[p2], qual(pr[p2], 99.0, -10.0), info, d, (double)(f[p1] + v[p1]) / d,
-                                  (double)(f[p2] + v[p2]) / d, rf + rr, f[p1] + v[p1], f[p2] + v[p2], rf, f[p1], f[p2], rr, v[p1], v[p2]);
-                }
-            } else if (k == 1 && r != p1 && pr[p1] >= 0.5f) {                                              // :150
-                len = sprintf(o, "%s\t%d\t.\t%c\t%c\t%.3f\tPASS\t%s\tGT:DP:VF:AD:ADF:ADR\t1/1:%d:%.4f:%d,%d:%d,%d:%d,%d\n", chrom, pos[j], B[r], B[p1],
-                              qual(pr[p1], 99.0, -10.0), info, d, (double)(f[p1] + v[p1]) / d, rf + rr, f[p1] + v[p1], rf, f[p1], rr, v[p1]);
-            } else if (k == 1 && r == p1) {                                                                // :157
-                len = sprintf(o, "%s\t%d\t.\t%c\t.\t%.3f\tREF\t%s\tGT:DP:VF:AD:ADF:ADR\t./.:%d:.:.:.:.\n", chrom, pos[j], B[r],
-                              qual(pr[p1], 99.0, -10.0), info, d);
-            } else {                                                                                       // :161
-                len = sprintf(o, "%s\t%d\t.\t%c\t.\t0.000\tLOW\t%s\tGT:DP:VF:AD:ADF:ADR\t./.:%d:.:.:.:.\n", chrom, pos[j], B[r], info, d);
-            }
+                if (p1 == r || (p2 == r && pr[p2] >= 0.5f)) { kind = 1; a1 = p1 == r ? p2 : p1; q = qual(pr[p2], 99.0, -10.0); }      // :132, :138
+                else if (p2 != r && p1 != r && pr[p2] >= 0.5f) { kind = 2; a1 = p1; a2 = p2; q = qual(pr[p2], 99.0, -10.0); }        // :143
+            } else if (k == 1 && r != p1 && pr[p1] >= 0.5f) { kind = 3; a1 = p1; q = qual(pr[p1], 99.0, -10.0); }                   // :150
+            else if (k == 1 && r == p1) { kind = 4; q = qual(pr[p1], 99.0, -10.0); }                                                 // :157
+            else kind = 5;                                                                                                           // :161
+            if (kind < 0) continue;                          // k >= 2 with neither rule matching: the reference writes no record
         }
-        w += len;
+        o = put_str(o, chrom, lc); *o++ = '\t';
+        o = put_int(o, pos[j]);
+        o = PUT_LIT(o, "\t.\t"); *o++ = B[r]; *o++ = '\t';
+        if (kind == 4 || kind == 5) *o++ = '.';
+        else { *o++ = B[a1]; if (kind == 2) { *o++ = ','; *o++ = B[a2]; } }
+        *o++ = '\t';
+        if (kind == 5) o = PUT_LIT(o, "0.000"); else o = put_fixed(o, q, 3);
+        if (kind == 0) o = (a1 != r) ? PUT_LIT(o, "\tPASS\t") : PUT_LIT(o, "\tREF\t");
+        else if (kind == 4) o = PUT_LIT(o, "\tREF\t");
+        else if (kind == 5) o = PUT_LIT(o, "\tLOW\t");
+        else o = PUT_LIT(o, "\tPASS\t");
+        o = PUT_LIT(o, "PR=");                                                                             // :127
+        o = put_fixed(o, (double)pr[0], 4); *o++ = ',';
+        o = put_fixed(o, (double)pr[3], 4); *o++ = ',';
+        o = put_fixed(o, (double)pr[1], 4); *o++ = ',';
+        o = put_fixed(o, (double)pr[2], 4);
+        o = PUT_LIT(o, ";FQ=");
+        o = put_fixed(o, freq[j], 4);
+        o = PUT_LIT(o, "\tGT:DP:VF:AD:ADF:ADR\t");
+        switch (kind) {
+        case 0:
+            o = PUT_LIT(o, "1/1:"); o = put_int(o, d); *o++ = ':'; o = put_fixed(o, freq[j], 4); o = PUT_LIT(o, ":.:.:.\n");
+            break;
+        case 1: case 3: {
+            const int rf = f[r], rr = v[r];
+            o = kind == 1 ? PUT_LIT(o, "0/1:") : PUT_LIT(o, "1/1:");
+            o = put_int(o, d); *o++ = ':';
+            o = put_fixed(o, (double)(f[a1] + v[a1]) / d, 4); *o++ = ':';
+            o = put_int(o, rf + rr); *o++ = ','; o = put_int(o, f[a1] + v[a1]); *o++ = ':';
+            o = put_int(o, rf); *o++ = ','; o = put_int(o, f[a1]); *o++ = ':';
+            o = put_int(o, rr); *o++ = ','; o = put_int(o, v[a1]); *o++ = '\n';
+            break;
+        }
+        case 2: {
+            const int rf = f[r], rr = v[r];
+            o = PUT_LIT(o, "1/2:"); o = put_int(o, d); *o++ = ':';
+            o = put_fixed(o, (double)(f[a1] + v[a1]) / d, 4); *o++ = ','; o = put_fixed(o, (double)(f[a2] + v[a2]) / d, 4); *o++ = ':';
+            o = put_int(o, rf + rr); *o++ = ','; o = put_int(o, f[a1] + v[a1]); *o++ = ','; o = put_int(o, f[a2] + v[a2]); *o++ = ':';
+            o = put_int(o, rf); *o++ = ','; o = put_int(o, f[a1]); *o++ = ','; o = put_int(o, f[a2]); *o++ = ':';
+            o = put_int(o, rr); *o++ = ','; o = put_int(o, v[a1]); *o++ = ','; o = put_int(o, v[a2]); *o++ = '\n';
+            break;
+        }
+        default:
+            o = PUT_LIT(o, "./.:"); o = put_int(o, d); o = PUT_LIT(o, ":.:.:.:.\n");
+        }
+        w = o - out;
     }
     *n_bytes = w;
     return NC_OK;
+}
+
+// Ascending argsort of n rows of 4 floats (insertion sort: stable, ties keep index order), multi-threaded.  Rows that
+// contain two equal values are listed in tie_idx (ascending) so that the caller can re-sort exactly those rows with the
+// reference's own sorter: numpy's tie order is implementation dependent (quirk E15) and must not be guessed here.
+extern "C" int nc_argsort4(const float *probs, int64_t n, int32_t *order, int64_t *n_ties, int64_t *tie_idx, int64_t tie_cap)
+{
+    if (n < 0 || (n && (!probs || !order)) || !n_ties || (tie_cap && !tie_idx)) return NC_ERR_ARG;
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+    if (n < 50000) T = 1;
+    const int64_t chunk = (n + T - 1) / T;
+    std::vector<std::vector<int64_t>> ties((size_t)T);
+    auto work = [&](int t) {
+        const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
+        for (int64_t j = a; j < b; j++) {
+            const float *p = probs + 4 * j;
+            int o[4] = {0, 1, 2, 3};
+            for (int i = 1; i < 4; i++) {
+                const int k = o[i];
+                int q = i - 1;
+                while (q >= 0 && p[o[q]] > p[k]) { o[q + 1] = o[q]; q--; }
+                o[q + 1] = k;
+            }
+            int32_t *dst = order + 4 * j;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+            if (p[o[0]] == p[o[1]] || p[o[1]] == p[o[2]] || p[o[2]] == p[o[3]]) ties[(size_t)t].push_back(j);
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    int64_t w = 0;
+    for (auto &v : ties)
+        for (int64_t j : v) {
+            if (w < tie_cap) tie_idx[w] = j;
+            w++;
+        }
+    *n_ties = w;
+    return w > tie_cap ? NC_ERR_CAPACITY : NC_OK;
 }

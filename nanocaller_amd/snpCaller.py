@@ -96,15 +96,35 @@ def snp_vcf_lines_haploid(chrom, pos, ref_idx, probs, dp, freq):
     return out
 
 
-def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None, haploid=False) -> bytes:
+def argsort4(probs):
+    """np.argsort(probs, axis=1) for [n, 4] float32 rows: the library sorts (threaded), numpy re-sorts only the rows that
+    contain ties, so the result equals numpy's on this machine element for element (quirk E15)."""
+    import ctypes as C
+    L = _lib.lib()
+    probs = np.ascontiguousarray(probs, np.float32)
+    n = probs.shape[0]
+    order = np.empty((n, 4), np.int32)
+    ties = np.empty(max(n, 1), np.int64)
+    nt = C.c_int64()
+    rc = L.nc_argsort4(_lib.npp(probs), n, _lib.npp(order), C.byref(nt), _lib.npp(ties), ties.size)
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_argsort4 failed (%d)" % rc)
+    if nt.value:
+        t = ties[:nt.value]
+        order[t] = np.argsort(probs[t], axis=1)
+    return order
+
+
+def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None, haploid=False, as_array=False):
     """Same records as snp_vcf_lines / snp_vcf_lines_haploid, formatted by the library's native formatter
-    (nc_snp_vcf_format); np.argsort is evaluated here so ties resolve exactly as in the Python path (E15)."""
+    (nc_snp_vcf_format); ties in the allele order resolve exactly as in the Python path (argsort4, E15).
+    -> bytes, or with as_array=True a uint8 array (buffer protocol: file.write() takes it without another copy)."""
     import ctypes as C
     L = _lib.lib()
     n = len(pos)
     i32 = lambda a: np.ascontiguousarray(a, np.int32)          # noqa: E731
     probs = np.ascontiguousarray(probs, np.float32)
-    order = None if haploid else i32(np.argsort(probs, axis=1))
+    order = None if haploid else argsort4(probs)
     pos_, ref_, dp_ = i32(pos), i32(ref_idx), i32(dp)
     freq_ = np.ascontiguousarray(freq, np.float64)
     fwd_ = None if haploid else i32(fwd_dp)
@@ -117,7 +137,7 @@ def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None,
                              _lib.npp(out), cap, C.byref(nb))
     if rc != _lib.NC_OK:
         raise _lib.NanoCallerHipError("nc_snp_vcf_format failed (%d)" % rc)
-    return out[:nb.value].tobytes()
+    return out[:nb.value] if as_array else out[:nb.value].tobytes()
 
 
 VCF_HEADER = (                                                      # snpCaller.py:259-276
@@ -220,13 +240,13 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
     groups = {}
     for c in chunks:
         groups.setdefault((c['chrom'], c['ploidy']), []).append(c)
-    with open(curr_vcf_path, 'w') as f:
+    with open(curr_vcf_path, 'wb') as f:
         for (chrom, ploidy), grp in groups.items():
             grp.sort(key=lambda c: c['start'])
             r = call_chunks(params, grp, device)
             if r['n']:
                 f.write(snp_vcf_text(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq'], r['fwd_dp'], r['rev_dp'],
-                                     haploid=(ploidy != 'diploid')).decode())
+                                     haploid=(ploidy != 'diploid'), as_array=True))
             f.flush()
             os.fsync(f.fileno())
             for _ in grp:

@@ -102,3 +102,36 @@ def test_native_formatter_matches_python_rules_and_reference():
     hp[::7] = np.float32([0, 1, 0, 0])
     assert snpCaller.snp_vcf_text("c", pos, ref, hp, dp, freq, haploid=True).decode() == \
         "".join(snpCaller.snp_vcf_lines_haploid("c", pos, ref, hp, dp, freq))
+
+
+def test_native_number_formatting_is_printf_exact():
+    """The formatter's '%.4f' / '%.3f' / '%d' replacements equal Python's on exact decimal ties (k / 2^n), values a ulp
+    either side of a tie, tiny and saturated probabilities, tiny negative QUALs ('-0.000') and large depths."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    ties = np.array([k / 2.0 ** b for b in range(5, 20) for k in rng.integers(1, 2 ** b, size=40)], np.float64)
+    ties = ties[ties < 1.0]
+    near = np.concatenate([np.nextafter(ties, 0.0), np.nextafter(ties, 1.0)])
+    dec = np.round(rng.random(4000), 4) + 0.00005                      # decimal half-way points, not exact in binary
+    special = np.array([0.0, 1.0, 0.5, 0.25, 0.03125, 0.00005, 0.99995, 0.999949999, 1e-12, 1e-7, 4.9e-5, 5.1e-5, 0.00015, 0.00025])
+    vals = np.concatenate([ties, near, dec[dec < 1], special])
+    n = len(vals) - len(vals) % 4
+    vals = vals[:n]
+    # haploid records: probabilities (float32) in PR=, freq (float64) in FQ= and the sample column, QUAL = -100*log10(1e-10 + 1 - p)
+    hp = vals.astype(np.float32).reshape(-1, 4)
+    hp[0] = np.float32([1e-12, 0, 0, 0])                               # QUAL = -100*log10(1 + 1e-10 - 1e-12) < 0 -> '-0.000'
+    hp[1] = np.float32([0, 0, 0, 0])
+    m = len(hp)
+    pos = np.arange(1, m + 1) * 3999
+    ref = rng.integers(0, 4, size=m)
+    dp = rng.integers(4, 70000, size=m)
+    freq = vals[:m]
+    assert snpCaller.snp_vcf_text("chrT", pos, ref, hp, dp, freq, haploid=True).decode() == \
+        "".join(snpCaller.snp_vcf_lines_haploid("chrT", pos, ref, hp, dp, freq))
+    # diploid records: allele fractions (a + b) / d with small integers give many exact ties
+    probs = rng.random((m, 4)).astype(np.float32)
+    probs[rng.random((m, 4)) < 0.3] = 1.0
+    fwd = rng.integers(0, 40, size=(m, 4))
+    rev = rng.integers(0, 40, size=(m, 4))
+    dp2 = rng.choice([16, 32, 64, 128, 160, 100, 37], size=m)
+    assert snpCaller.snp_vcf_text("chrT", pos, ref, probs, dp2, freq, fwd, rev).decode() == \
+        "".join(snpCaller.snp_vcf_lines("chrT", pos, ref, probs, dp2, freq, fwd.astype(np.float64), rev.astype(np.float64)))
