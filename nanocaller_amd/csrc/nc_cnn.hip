@@ -795,7 +795,7 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
 //   waves 4-7 ("D"): conv2 + conv3.  This wave's 9+9 conv2 and 6+6 conv3 fragments (120 VGPRs) stay in registers.
 // C works on site k+1 while D works on site k: X and A1 are double-buffered, A2 is single.  Two workgroup barriers per
 // site (alpha_k: A1[k&1] and X[(k+1)&1] complete; beta_k: A2 complete), executed by both roles in the same order:
-//   C:  P0 | conv1(0) alpha_0 | conv1(1) pass 1, beta_0, pass 2, alpha_1 | ... | beta_last
+//   C:  P0 | conv1(0) alpha_0 | conv1(1) first tiles, beta_0, last tile + staging commit, alpha_1 | ... | beta_last
 //   D:  P0 | alpha_0 conv2(0) beta_0 conv3(0) | alpha_1 conv2(1) beta_1 conv3(1) | ...
 // No weight is re-read per site, and the MFMA phases of one role overlap the epilogues of the other on every SIMD.
 #ifdef NC_TRACE
@@ -871,11 +871,13 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
             t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, wv, lane);
 #endif
             NC_T(1)
+#ifndef NC_ABL_NOC
+            if (wv == 0) t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, 8, lane);       // wave 0 owns 4 of the 13 tiles: 3 before beta
+#endif
             if (k > 0) __syncthreads();                                            // beta_{k-1}
             NC_T(2)
 #ifndef NC_ABL_NOC
-            if (wv == 0) t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, 8, lane);
-            else t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, 8 + wv, lane);
+            t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, wv == 0 ? 12 : 8 + wv, lane);
 #endif
             NC_T(3)
 #ifndef NC_ABL_NOSTAGE

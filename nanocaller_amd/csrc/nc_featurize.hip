@@ -10,7 +10,8 @@
 
 namespace {
 
-constexpr int MAXCOV_CAP = 1024;   // LDS list of sampled reads per wave
+constexpr int MAXCOV_CAP = 1024;   // LDS list of sampled reads per wave: largest supported maxcov
+constexpr int MAXCOV_SMALL = 256;  // instantiation for maxcov <= 256 (default 160): 20.5 KB of LDS per block -> 7 waves per SIMD instead of 4
 constexpr int NBR = 20;
 
 struct Bucket { int32_t dlo, dhi, k, far; };     // distance range (dlo, dhi], pick k, far=1: farthest k
@@ -65,10 +66,11 @@ struct FeatArgs {
     uint8_t *valid;
 };
 
+template <int CAP>
 __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sm[4][NC_SNP_TENSOR + 3];
-    __shared__ int32_t slist[4][MAXCOV_CAP];
+    __shared__ int32_t slist[4][CAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware mapping (workgroup b runs on XCD b % 8): each XCD walks ONE contiguous range of position-sorted
     // sites, so its private L2 holds one genomic neighbourhood instead of all eight sharing every line.
@@ -332,7 +334,10 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     NcTimer tm(ctx, 1);
     hipLaunchKernelGGL(k_nbr_index, dim3((n_cidx + 255) / 256), dim3(256), 0, ctx->stream, a.nbr_pos, a.n_nbr, a.cidx_pos0, n_cidx,
                        (int32_t *)ctx->nbr_idx.p);
-    hipLaunchKernelGGL(k_featurize, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
+    if (maxcov <= MAXCOV_SMALL)
+        hipLaunchKernelGGL(k_featurize<MAXCOV_SMALL>, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_featurize<MAXCOV_CAP>, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
     NC_HIP(ctx, hipGetLastError());
     tm.stop();
     return NC_OK;

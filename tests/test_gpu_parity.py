@@ -87,12 +87,14 @@ def test_multi_chunk_batch_matches_per_chunk_oracle(eng):
     assert ndup >= 2, "test world should contain a candidate on a shared chunk boundary"
 
 
-def test_maxcov_policy_matches_oracle(eng):
-    """depth > maxcov: documented deterministic policy (first maxcov reads in coordinate order)"""
+@pytest.mark.parametrize("maxcov", [50, 300])
+def test_maxcov_policy_matches_oracle(eng, maxcov):
+    """depth > maxcov: documented deterministic policy (first maxcov reads in coordinate order).  maxcov = 300 runs the
+    featuriser instantiation with the 1024-entry read list (maxcov <= 256 uses the 256-entry one)."""
     from nanocaller_amd.generate_SNP_pileups import get_snp_testing_candidates
     from oracle import oracle
     world = load_world("deep")
-    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=50, min_allele_freq=0.15, min_nbr_sites=1, seq="ont",
+    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=maxcov, min_allele_freq=0.15, min_nbr_sites=1, seq="ont",
                supplementary=False, exclude_bed=None)
     region = dict(chrom=world.chrom, start=6_000, end=18_000, ploidy="diploid")
     a = get_snp_testing_candidates(_dct(world, dct, None), region)
