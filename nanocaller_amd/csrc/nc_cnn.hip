@@ -921,6 +921,98 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
 #undef NC_MFMA3
 #undef NC_MFMA
 
+// ---- fc1 on the same split-precision scheme: out[site][48] = selu(W^T a3 + b), K = 1728 = 54 groups of 32.
+// A workgroup owns 64 sites (4 position... site tiles of 16) so that every weight fragment read from L2 feeds 4 MFMAs per
+// product; the four waves split K and combine through LDS.  The fp32 activations are split into fp16 hi/lo on load (each
+// lane reads the 8 K values of its site as two dwordx4: the four lane groups of a site cover one 128-byte line).
+constexpr int FC_K = 1728, FC_G = FC_K / 32, FC_TM = 4, FC_TN = 3;
+constexpr int FC_PACKED_BYTES = 2 * FC_G * FC_TN * T_FRAG * 2 + 4 * 64;        // hi + lo fragments, then b*S[48], 1/S
+__device__ __forceinline__ void split8(const float4 &a, const float4 &b, h8 &hi, h8 &lo)
+{
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t uh[4], ul[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const float x0 = fminf(fmaxf(v[2 * p], -65504.0f), 65504.0f), x1 = fminf(fmaxf(v[2 * p + 1], -65504.0f), 65504.0f);
+        const h2 h = __builtin_convertvector((f32x2v){x0, x1}, h2);
+        uh[p] = __builtin_bit_cast(uint32_t, h);
+        const f32x2v d = {sub_h_lo(x0, uh[p]), sub_h_hi(x1, uh[p])};
+        ul[p] = __builtin_bit_cast(uint32_t, (h2)__builtin_convertvector(d, h2));
+    }
+    hi = as_h8(make_uint4(uh[0], uh[1], uh[2], uh[3]));
+    lo = as_h8(make_uint4(ul[0], ul[1], ul[2], ul[3]));
+}
+
+__global__ __launch_bounds__(256) void k6_fc1_h3(const float *__restrict__ in, const uint8_t *__restrict__ wp, float *__restrict__ out, int64_t n)
+{
+    __shared__ f32x4v red[3][FC_TM][FC_TN][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const uint4 *wh = reinterpret_cast<const uint4 *>(wp), *wl = wh + FC_G * FC_TN * 64;
+    const float *bs = reinterpret_cast<const float *>(wl + FC_G * FC_TN * 64);
+    const float inv_s = bs[48];
+    const int64_t tile0 = (int64_t)blockIdx.x * (FC_TM * 16);
+    const float *ip[FC_TM];
+#pragma unroll
+    for (int tm = 0; tm < FC_TM; tm++) {
+        int64_t s = tile0 + tm * 16 + c16;
+        if (s >= n) s = n - 1;
+        ip[tm] = in + s * FC_K + 8 * g;
+    }
+    f32x4v acc[FC_TM][FC_TN];
+#pragma unroll
+    for (int tn = 0; tn < FC_TN; tn++) {
+        f32x4v b = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (wv == 0) b = *reinterpret_cast<const f32x4v *>(bs + tn * 16 + 4 * g);
+#pragma unroll
+        for (int tm = 0; tm < FC_TM; tm++) acc[tm][tn] = b;
+    }
+    const int j0 = (FC_G * wv) / 4, j1 = (FC_G * (wv + 1)) / 4;
+#pragma unroll 2
+    for (int G = j0; G < j1; G++) {
+        float4 a0[FC_TM], a1[FC_TM];
+#pragma unroll
+        for (int tm = 0; tm < FC_TM; tm++) {
+            a0[tm] = *reinterpret_cast<const float4 *>(ip[tm] + 32 * G);
+            a1[tm] = *reinterpret_cast<const float4 *>(ip[tm] + 32 * G + 4);
+        }
+        h8 bh[FC_TN], bl[FC_TN];
+#pragma unroll
+        for (int tn = 0; tn < FC_TN; tn++) {
+            bh[tn] = as_h8(wh[(G * FC_TN + tn) * 64 + lane]);
+            bl[tn] = as_h8(wl[(G * FC_TN + tn) * 64 + lane]);
+        }
+#pragma unroll
+        for (int tm = 0; tm < FC_TM; tm++) {
+            h8 xh, xl;
+            split8(a0[tm], a1[tm], xh, xl);
+#pragma unroll
+            for (int tn = 0; tn < FC_TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], xh, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < FC_TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], xl, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < FC_TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[tn], xh, acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int tm = 0; tm < FC_TM; tm++)
+#pragma unroll
+            for (int tn = 0; tn < FC_TN; tn++) red[wv - 1][tm][tn][lane] = acc[tm][tn];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int tm = 0; tm < FC_TM; tm++) {
+            const int64_t s = tile0 + tm * 16 + c16;                   // D[channel 4g + r][site c16]
+#pragma unroll
+            for (int tn = 0; tn < FC_TN; tn++) {
+                const f32x4v v = (acc[tm][tn] + red[0][tm][tn][lane] + red[1][tm][tn][lane] + red[2][tm][tn][lane]) * inv_s;
+                if (s < n) *reinterpret_cast<f32x4v *>(out + s * 48 + tn * 16 + 4 * g) = (f32x4v){selu(v[0]), selu(v[1]), selu(v[2]), selu(v[3])};
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void dense_small(const float *in, int n_in, const float *k, const float *b, int n_out, float *out, bool act)
 {
     for (int o = 0; o < n_out; o++) {
@@ -1054,7 +1146,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
             (void)hipEventRecord(ctx->kev[ctx->n_kev + 1], ctx->stream);
             ctx->n_kev += 2;
         }
-        hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+        if (ctx->cnn_exact_fp32)
+            hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+        else
+            hipLaunchKernelGGL(k6_fc1_h3, dim3(blocks_for(nb, 16 * FC_TM)), dim3(256), 0, ctx->stream, a3, packed_h + H_PACKED_BYTES, f1, nb);
     } else {
         hipLaunchKernelGGL((k2_conv23<H, W, 3 * C1, C2, P2>), dim3(blocks_for(np2, 256 * P2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
         hipLaunchKernelGGL((k2_conv23<H2, W2, C2, C3, P3>), dim3(blocks_for(np3, 256 * P3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
@@ -1138,7 +1233,7 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         for (const float *q = blob_host; q < b3 + 64; q++) wmax = std::fmax(wmax, std::fabs(*q));
         float S = 1024.0f;
         while (S > 1.0f && wmax * S > 16384.0f) S *= 0.5f;
-        std::vector<uint8_t> hp((size_t)H_PACKED_BYTES, 0);
+        std::vector<uint8_t> hp((size_t)H_PACKED_BYTES + FC_PACKED_BYTES, 0);
         _Float16 *w1f = reinterpret_cast<_Float16 *>(hp.data()), *w2h = w1f + T_NW1 * T_FRAG, *w2l = w2h + T_NW2 * T_FRAG,
                  *w3h = w2l + T_NW2 * T_FRAG, *w3l = w3h + T_NW3 * T_FRAG;
         float *b1s = reinterpret_cast<float *>(w3l + T_NW3 * T_FRAG), *b2s = b1s + 48, *b3s = b2s + 32;
@@ -1196,6 +1291,29 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         for (int c = 0; c < 64; c++) b3s[c] = b3[c] * S;
         b3s[64] = 1.0f / S;
         for (int i = 0; i < 32; i++) { c3tab[i] = C3_SLOT[i]; c3tab[32 + i] = C3_OUT[i]; }
+        {
+            // fc1 fragments for k6_fc1_h3: own power-of-two scale, A operand = W^T (row = output unit, K = 32 G + 8 g + j)
+            const float *kf = b3 + 64, *bf = kf + 1728 * 48;
+            float fmax_ = 0.0f;
+            for (const float *q = kf; q < bf + 48; q++) fmax_ = std::fmax(fmax_, std::fabs(*q));
+            float SF = 1024.0f;
+            while (SF > 1.0f && fmax_ * SF > 16384.0f) SF *= 0.5f;
+            _Float16 *fh = reinterpret_cast<_Float16 *>(hp.data() + H_PACKED_BYTES), *fl = fh + (size_t)FC_G * FC_TN * T_FRAG;
+            float *fbs = reinterpret_cast<float *>(fl + (size_t)FC_G * FC_TN * T_FRAG);
+            for (int G = 0; G < FC_G; G++)
+                for (int tn = 0; tn < FC_TN; tn++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const int g = lane >> 4, c = lane & 15;
+                            const float sv = kf[(size_t)(32 * G + 8 * g + j) * 48 + tn * 16 + c] * SF;
+                            const _Float16 h = (_Float16)sv;
+                            const size_t o = ((size_t)(G * FC_TN + tn) * 64 + lane) * 8 + j;
+                            fh[o] = h;
+                            fl[o] = (_Float16)(sv - (float)h);
+                        }
+            for (int c = 0; c < 48; c++) fbs[c] = bf[c] * SF;
+            fbs[48] = 1.0f / SF;
+        }
         if (!w.packed_h) {
             hipError_t e = hipMalloc(&w.packed_h, hp.size());
             if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed fp16 weights: %s", hipGetErrorString(e));
