@@ -1366,16 +1366,7 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
         }
     }
     tm.stop();
-    if (ctx->timing) {                       // per-launch durations of the trunk kernel, on the launch stream
-        float tot = 0.0f;
-        for (int e = 0; e + 1 < ctx->n_kev; e += 2) {
-            float ms = 0.0f;
-            (void)hipEventElapsedTime(&ms, ctx->kev[e], ctx->kev[e + 1]);
-            tot += ms;
-        }
-        ctx->last_ms[4] = tot;
-        ctx->last_ms[5] = (float)(ctx->n_kev / 2);
-    }
+    if (ctx->timing) ctx->kev_pending = true;     // resolved by nc_last_kernel_ms(4 / 5)
     return NC_OK;
 }
 

@@ -33,6 +33,9 @@ struct nc_ctx {
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
     hipEvent_t kev[128] = {nullptr};          // per-launch event pairs of the trunk kernel (timing mode)
     int n_kev = 0;
+    hipEvent_t tev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // stage timers (scan, featurize, CNN, indel)
+    bool tev_pending[4] = {false, false, false, false};
+    bool kev_pending = false;
     hipEvent_t drain_ev[4] = {nullptr};       // batch-complete events of nc_snp_forward_drain
 
     // scan results (device)
@@ -93,19 +96,24 @@ inline int nc_ensure(nc_ctx *ctx, DevBuf &b, size_t bytes)
         if (rc_ != NC_OK) return rc_; \
     } while (0)
 
+// Stage timer (timing mode only): records an event pair on the launch stream and does NOT wait; the elapsed time is
+// resolved lazily by nc_last_kernel_ms, so a timed step is not perturbed by host synchronisations.
 struct NcTimer {
     nc_ctx *ctx;
     int which;
     NcTimer(nc_ctx *c, int w) : ctx(c), which(w)
     {
-        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (ctx->timing) {
+            for (int e = 0; e < 2; e++)
+                if (!ctx->tev[which][e]) (void)hipEventCreate(&ctx->tev[which][e]);
+            (void)hipEventRecord(ctx->tev[which][0], ctx->stream);
+        }
     }
     void stop()
     {
         if (ctx->timing) {
-            (void)hipEventRecord(ctx->ev1, ctx->stream);
-            (void)hipEventSynchronize(ctx->ev1);
-            (void)hipEventElapsedTime(&ctx->last_ms[which], ctx->ev0, ctx->ev1);
+            (void)hipEventRecord(ctx->tev[which][1], ctx->stream);
+            ctx->tev_pending[which] = true;
         }
     }
 };

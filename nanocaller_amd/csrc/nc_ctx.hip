@@ -70,6 +70,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
     }
     for (auto &e : ctx->kev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->drain_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &p : ctx->tev) for (auto &e : p) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -142,6 +143,23 @@ int nc_enable_timing(nc_ctx *ctx, int on)
 int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms)
 {
     if (!ctx || !ms || which < 0 || which > 5) return NC_ERR_ARG;
+    if (which < 4 && ctx->tev_pending[which]) {              // resolve the stage's event pair now
+        NC_HIP(ctx, hipEventSynchronize(ctx->tev[which][1]));
+        NC_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[which], ctx->tev[which][0], ctx->tev[which][1]));
+        ctx->tev_pending[which] = false;
+    }
+    if (which >= 4 && ctx->kev_pending) {                    // per-launch durations of the trunk kernel, on the launch stream
+        float tot = 0.0f;
+        for (int e = 0; e + 1 < ctx->n_kev; e += 2) {
+            float one = 0.0f;
+            NC_HIP(ctx, hipEventSynchronize(ctx->kev[e + 1]));
+            NC_HIP(ctx, hipEventElapsedTime(&one, ctx->kev[e], ctx->kev[e + 1]));
+            tot += one;
+        }
+        ctx->last_ms[4] = tot;
+        ctx->last_ms[5] = (float)(ctx->n_kev / 2);
+        ctx->kev_pending = false;
+    }
     *ms = ctx->last_ms[which];
     return NC_OK;
 }
