@@ -260,6 +260,7 @@ typedef struct {
     int64_t n_seq;
     const int32_t *name_off;             /* [n_reads+1] into names (NUL-terminated strings) */
     const char *names;
+    const int32_t *qstart;               /* [n_reads] query index of the first aligned base (leading soft clip / insertion) */
 } nc_decoded_arrays;
 
 int nc_bam_open(const char *path, nc_bam **out);
@@ -271,6 +272,41 @@ const char *nc_bam_error(const nc_bam *bam);
 int nc_bam_decode(nc_bam *bam, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, nc_decoded **out);
 int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *view);
 int nc_decoded_free(nc_decoded *d);
+
+/* ------------------------------------------------------------------ indel pass 2, host side
+ * nc_indel_slices replaces the per-read loop of generate_indel_pileups.py:329-338 at the anchor columns chosen by pass 1:
+ * for every alignment of `d` (decoded with keep_seq) covering anchor_pos[a] (1-based; reads in coordinate order, like
+ * pcol.pileups) the window query_sequence[max(0, q - window_before) : q + window_after], q = pysam's
+ * query_position_or_next at that column (inside a deletion: the next aligned query base).  `keep` (per read, may be NULL)
+ * applies the pileup flag filter.  Bases are codes A=0 G=1 T=2 C=3 other=4.  Parity with pysam/htslib is unpinned (absent
+ * from this image): pinned against an independent CIGAR walk in tests/. */
+typedef struct nc_slices nc_slices;
+typedef struct {
+    int32_t n_anchor;
+    const int32_t *anchor_off;           /* [n_anchor+1] into read_idx / seq_off */
+    const int32_t *read_idx;             /* [n_slices] index of the alignment in the decoded set */
+    const int64_t *seq_off;              /* [n_slices+1] into seq */
+    const uint8_t *seq;
+    int64_t n_slices;
+} nc_slices_arrays;
+int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor_pos, int32_t window_before, int32_t window_after,
+                    const uint8_t *keep, nc_slices **out);
+int nc_slices_view(const nc_slices *s, nc_slices_arrays *view);
+int nc_slices_free(nc_slices *s);
+
+/* Global alignment with affine gaps, the call parasail.nw_trace(alt, ref, 9, 1, matrix_create('AGTC', 20, -10)) of
+ * generate_indel_pileups.py:10,79: a gap of length k costs open + (k-1)*extend.  Writes the CIGAR as (op, count) pairs
+ * with parasail's op codes ('=' 7, 'X' 8, 'I' 1 = base of s1 only, 'D' 2 = base of s2 only).  Tie-breaking (parity with
+ * parasail unpinned: the library is absent from this image): a cell prefers the diagonal, then D, then I; a gap prefers
+ * extension over opening on equal scores.  NC_ERR_CAPACITY if `cap` pairs do not suffice (n1 + n2 always does). */
+int nc_nw_cigar(const char *s1, int32_t n1, const char *s2, int32_t n2, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
+                int32_t *ops, int32_t *counts, int32_t cap, int32_t *n_ops);
+
+/* allele_prediction(alt, ref_seq, max_range) of generate_indel_pileups.py:77-127: aligns with nc_nw_cigar (9, 1, 20, -10) and
+ * walks the CIGAR exactly as the reference does.  Returns the lengths of the (REF, ALT) prefixes; *ref_len = -1 means the
+ * reference returns (None, None). */
+int nc_allele_prediction(const char *alt, int32_t n_alt, const char *ref_seq, int32_t n_ref, int32_t max_range, int32_t *ref_len,
+                         int32_t *alt_len);
 
 /* ------------------------------------------------------------------ SNP genotype rules + VCF record text (host)
  * Replaces the per-site Python loop of snpCaller.caller (snpCaller.py:113-198).  probs f32 [n][4]

@@ -27,7 +27,8 @@ EXPORTS = [
     "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
-    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4",
+    "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
+    "nc_nw_cigar", "nc_allele_prediction",
 ]
 
 
@@ -64,7 +65,12 @@ class DecodedArraysC(C.Structure):
                 ("codes", C.c_void_p), ("n_codes", C.c_int64), ("ev_off", C.c_void_p), ("ev_pos", C.c_void_p),
                 ("ev_len", C.c_void_p), ("n_events", C.c_int64), ("hap", C.c_void_p), ("ps", C.c_void_p),
                 ("seq_off", C.c_void_p), ("seq", C.c_void_p), ("n_seq", C.c_int64), ("name_off", C.c_void_p),
-                ("names", C.c_void_p)]
+                ("names", C.c_void_p), ("qstart", C.c_void_p)]
+
+
+class SlicesArraysC(C.Structure):
+    _fields_ = [("n_anchor", C.c_int32), ("anchor_off", C.c_void_p), ("read_idx", C.c_void_p), ("seq_off", C.c_void_p),
+                ("seq", C.c_void_p), ("n_slices", C.c_int64)]
 
 
 _lib = None
@@ -122,6 +128,11 @@ def lib():
         L.nc_bam_decode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
         L.nc_decoded_view.argtypes = [vp, C.POINTER(DecodedArraysC)]
         L.nc_decoded_free.argtypes = [vp]
+        L.nc_indel_slices.argtypes = [vp, i32, vp, i32, i32, vp, C.POINTER(vp)]
+        L.nc_slices_view.argtypes = [vp, C.POINTER(SlicesArraysC)]
+        L.nc_slices_free.argtypes = [vp]
+        L.nc_nw_cigar.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+        L.nc_allele_prediction.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.nc_argsort4.argtypes = [vp, i64, vp, C.POINTER(i64), vp, i64]
         L.nc_snp_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, C.POINTER(i64)]
         for name in EXPORTS:

@@ -56,8 +56,12 @@ class BamFile:
     def get_reference_length(self, c):
         return self.lengths[self.references.index(c)]
 
-    def decode(self, chrom, start=1, end=None, keep_seq=False):
-        """-> dict of numpy arrays for the mapped alignments overlapping [start, end] (1-based inclusive)."""
+    def decode(self, chrom, start=1, end=None, keep_seq=False, anchors=None, window_before=0, window_after=160, keep_mask=None):
+        """-> dict of numpy arrays for the mapped alignments overlapping [start, end] (1-based inclusive).  With `anchors`
+        (ascending 1-based positions; implies keep_seq) also 'windows': the pass-2 read windows at those columns, reads whose
+        flag has a bit of `keep_mask` set being left out (the pileup flag filter)."""
+        if anchors is not None:
+            keep_seq = True
         tid = self.references.index(chrom)
         end = self.lengths[tid] if end is None else min(int(end), self.lengths[tid])
         d = C.c_void_p()
@@ -71,11 +75,38 @@ class BamFile:
                    read_off=_arr(v.off, n + 1, np.int64), codes=_arr(v.codes, v.n_codes, np.uint8),
                    ev_off=_arr(v.ev_off, n + 1, np.int32), ev_pos=_arr(v.ev_pos, v.n_events, np.int32),
                    ev_len=_arr(v.ev_len, v.n_events, np.int32), hap=_arr(v.hap, n, np.uint8), ps=_arr(v.ps, n, np.int32),
-                   seq_off=_arr(v.seq_off, n + 1, np.int64), seq=_arr(v.seq, v.n_seq, np.uint8))
+                   seq_off=_arr(v.seq_off, n + 1, np.int64), seq=_arr(v.seq, v.n_seq, np.uint8),
+                   qstart=_arr(v.qstart, n, np.int32))
         name_off = _arr(v.name_off, n + 1, np.int32)
         names_raw = _arr(v.names, int(name_off[-1]) if n else 0, np.uint8).tobytes()
         out["names"] = [names_raw[name_off[i]:name_off[i + 1] - 1].decode() for i in range(n)]
+        if anchors is not None:
+            out["windows"] = self._windows(d, out, anchors, window_before, window_after, keep_mask)
         self.L.nc_decoded_free(d)
+        return out
+
+    def _windows(self, d, dec, anchors, window_before, window_after, keep_mask):
+        """a11 (generate_indel_pileups.py:329-338): per anchor column the list [(read index, window string)] of the reads in
+        the pileup there, in coordinate order, through nc_indel_slices."""
+        anchors = np.ascontiguousarray(anchors, np.int32)
+        keep = None
+        if keep_mask is not None:
+            keep = np.ascontiguousarray((dec["read_flag"] & int(keep_mask)) == 0, np.uint8)
+        sl = C.c_void_p()
+        rc = self.L.nc_indel_slices(d, len(anchors), _lib.npp(anchors), int(window_before), int(window_after), _lib.npp(keep), C.byref(sl))
+        if rc != _lib.NC_OK:
+            raise IOError("nc_indel_slices failed (%d)" % rc)
+        v = _lib.SlicesArraysC()
+        self.L.nc_slices_view(sl, C.byref(v))
+        a_off = _arr(v.anchor_off, v.n_anchor + 1, np.int32)
+        ridx = _arr(v.read_idx, v.n_slices, np.int32)
+        s_off = _arr(v.seq_off, v.n_slices + 1, np.int64)
+        text = _arr(v.seq, int(s_off[-1]) if v.n_slices else 0, np.uint8)
+        self.L.nc_slices_free(sl)
+        letters = np.frombuffer(b"AGTCN", np.uint8)[text].tobytes().decode("ascii")
+        out = []
+        for a in range(len(anchors)):
+            out.append([(int(ridx[k]), letters[s_off[k]:s_off[k + 1]]) for k in range(a_off[a], a_off[a + 1])])
         return out
 
 

@@ -119,7 +119,7 @@ struct nc_bam {
 };
 
 struct nc_decoded {
-    std::vector<int32_t> start, end, flag, ev_off, ev_pos, ev_len, ps, name_off;
+    std::vector<int32_t> start, end, flag, ev_off, ev_pos, ev_len, ps, name_off, qstart;
     std::vector<int64_t> off, seq_off;
     std::vector<uint8_t> codes, hap, seq;
     std::vector<char> names;
@@ -281,12 +281,13 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         const size_t c0 = d->codes.size();
         d->codes.resize(c0 + (size_t)rlen);
         uint8_t *co = d->codes.data() + c0;
-        int32_t rp = 0, qp = 0;
+        int32_t rp = 0, qp = 0, q_first = -1;
         for (int k = 0; k < n_cig; k++) {
             const uint32_t c = rdu32(cig + 4 * k);
             const int op = c & 15, len = (int)(c >> 4);
             switch (op) {
             case 0: case 7: case 8:                                   // M, =, X
+                if (q_first < 0) q_first = qp;                        // query index of the first aligned base (leading S / I skipped)
                 for (int i = 0; i < len; i++, rp++, qp++) co[rp] = NT16_CODE[(seq[qp >> 1] >> ((~qp & 1) << 2)) & 15];
                 break;
             case 1:                                                   // I: '+n' on the previous reference column
@@ -307,6 +308,7 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         d->start.push_back(pos + 1);
         d->end.push_back(pos + 1 + rlen);
         d->flag.push_back(flag);
+        d->qstart.push_back(q_first < 0 ? qp : q_first);
         d->off.push_back((int64_t)d->codes.size());
         d->ev_off.push_back((int32_t)d->ev_pos.size());
         // tags HP / PS
@@ -365,12 +367,96 @@ int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *v)
     v->hap = d->hap.data(); v->ps = d->ps.data();
     v->seq_off = d->seq_off.data(); v->seq = d->seq.data(); v->n_seq = (int64_t)d->seq.size();
     v->name_off = d->name_off.data(); v->names = d->names.data();
+    v->qstart = d->qstart.data();
     return NC_OK;
 }
 
 int nc_decoded_free(nc_decoded *d)
 {
     delete d;
+    return NC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------- a11: pass-2 read windows
+struct nc_slices {
+    std::vector<int32_t> anchor_off, read_idx;
+    std::vector<int64_t> seq_off;
+    std::vector<uint8_t> seq;
+};
+
+// pysam's PileupRead.query_position_or_next at 1-based reference position p (start <= p < end): the query index aligned
+// to p, or -- when p lies in a deletion -- the index of the next aligned query base.  Events are the '+n' / '-n' markers
+// on the column BEFORE the insertion / deletion, in reference order; qstart = query index of the first aligned base.
+static int32_t qpos_or_next(int32_t start, int32_t qstart, const int32_t *ev_pos, const int32_t *ev_len, int32_t n_ev, int32_t p)
+{
+    int32_t q = qstart, r = start;
+    for (int32_t e = 0; e < n_ev; e++) {
+        const int32_t ep = ev_pos[e], el = ev_len[e];
+        if (p <= ep) return q + (p - r);
+        q += ep - r + 1;
+        r = ep + 1;
+        if (el > 0) q += el;                          // insertion: query bases with no reference column
+        else {
+            if (p <= ep - el) return q;               // inside the deletion: next aligned base
+            r += -el;
+        }
+    }
+    return q + (p - r);
+}
+
+int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor_pos, int32_t window_before, int32_t window_after,
+                    const uint8_t *keep, nc_slices **out)
+{
+    if (!d || !out || n_anchor < 0 || (n_anchor && !anchor_pos) || window_before < 0 || window_after < 0) return NC_ERR_ARG;
+    const int32_t n = (int32_t)d->start.size();
+    if (n && d->seq.empty()) return NC_ERR_STATE;                          // decoded without keep_seq
+    nc_slices *s = new (std::nothrow) nc_slices();
+    if (!s) return NC_ERR_NOMEM;
+    s->anchor_off.push_back(0);
+    s->seq_off.push_back(0);
+    // anchors ascending and reads coordinate-sorted: `first` = first read that can still cover an anchor >= p
+    int32_t first = 0;
+    for (int32_t a = 0; a < n_anchor; a++) {
+        const int32_t p = anchor_pos[a];
+        if (a && p < anchor_pos[a - 1]) first = 0;                         // not ascending: restart
+        while (first < n && d->end[first] <= p) first++;
+        for (int32_t r = first; r < n; r++) {
+            if (d->start[r] > p) break;                                    // coordinate order
+            if (d->end[r] <= p) continue;
+            if (keep && !keep[r]) continue;
+            const int32_t e0 = d->ev_off[r], e1 = d->ev_off[r + 1];
+            const int32_t q = qpos_or_next(d->start[r], d->qstart[r], d->ev_pos.data() + e0, d->ev_len.data() + e0, e1 - e0, p);
+            const int64_t s0 = d->seq_off[r], s1 = d->seq_off[r + 1], L = s1 - s0;
+            int64_t a0 = (int64_t)q - window_before, a1 = (int64_t)q + window_after;
+            if (a0 < 0) a0 = 0;
+            if (a1 > L) a1 = L;
+            if (a1 < a0) a1 = a0;
+            s->read_idx.push_back(r);
+            s->seq.insert(s->seq.end(), d->seq.begin() + (s0 + a0), d->seq.begin() + (s0 + a1));
+            s->seq_off.push_back((int64_t)s->seq.size());
+        }
+        s->anchor_off.push_back((int32_t)s->read_idx.size());
+    }
+    *out = s;
+    return NC_OK;
+}
+
+int nc_slices_view(const nc_slices *s, nc_slices_arrays *v)
+{
+    if (!s || !v) return NC_ERR_ARG;
+    v->n_anchor = (int32_t)s->anchor_off.size() - 1;
+    v->anchor_off = s->anchor_off.data();
+    v->read_idx = s->read_idx.data();
+    v->seq_off = s->seq_off.data();
+    v->seq = s->seq.data();
+    v->n_slices = (int64_t)s->read_idx.size();
+    return NC_OK;
+}
+
+int nc_slices_free(nc_slices *s)
+{
+    delete s;
     return NC_OK;
 }
 

@@ -216,3 +216,151 @@ def indel_scan(world, start, end, *, mincov, win_size, small_win_size, ins_t, de
                                 _p(vp, C.c_int32), _p(vt, C.c_int32), C.byref(nv))
     assert r == 0, r
     return vp[:nv.value].copy(), vt[:nv.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------- indel pass 2 (a11, a13)
+# Pure-Python restatements used only by tests.  parasail / pysam are absent from this image: parity with them is UNPINNED;
+# these pin the library's native code (nc_nw_cigar, nc_allele_prediction, nc_indel_slices) against an independent
+# implementation of the same documented rules.
+def nw_cigar_ref(s1, s2, open_=9, extend=1, match=20, mismatch=-10):
+    """Gotoh global alignment, gap of length k costs open + (k-1)*extend; ties: diagonal, then D (s2 only), then I (s1 only);
+    inside a gap extension is preferred over opening on equal scores.  -> [(op, count)], ops '=' 7, 'X' 8, 'I' 1, 'D' 2
+    (generate_indel_pileups.py:79: parasail.nw_trace(alt, ref_seq, 9, 1, sub_mat).cigar)."""
+    n1, n2 = len(s1), len(s2)
+    NEG = -10 ** 9
+    H = [[0] * (n2 + 1) for _ in range(n1 + 1)]
+    E = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    F = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    who = [[0] * (n2 + 1) for _ in range(n1 + 1)]             # 0 diag, 1 D, 2 I
+    e_ext = [[False] * (n2 + 1) for _ in range(n1 + 1)]
+    f_ext = [[False] * (n2 + 1) for _ in range(n1 + 1)]
+    for j in range(1, n2 + 1):
+        H[0][j] = E[0][j] = -open_ - (j - 1) * extend
+        who[0][j] = 1
+        e_ext[0][j] = j > 1
+    for i in range(1, n1 + 1):
+        H[i][0] = F[i][0] = -open_ - (i - 1) * extend
+        who[i][0] = 2
+        f_ext[i][0] = i > 1
+        for j in range(1, n2 + 1):
+            eo, ee = H[i][j - 1] - open_, E[i][j - 1] - extend
+            e_ext[i][j] = ee >= eo
+            E[i][j] = max(eo, ee)
+            fo, fe = H[i - 1][j] - open_, F[i - 1][j] - extend
+            f_ext[i][j] = fe >= fo
+            F[i][j] = max(fo, fe)
+            d = H[i - 1][j - 1] + (match if s1[i - 1] == s2[j - 1] else mismatch)
+            h, w = d, 0
+            if E[i][j] > h:
+                h, w = E[i][j], 1
+            if F[i][j] > h:
+                h, w = F[i][j], 2
+            H[i][j], who[i][j] = h, w
+    ops = []
+    i, j, state = n1, n2, None
+    while i > 0 or j > 0:
+        if state is None:
+            if who[i][j] == 0:
+                ops.append(7 if s1[i - 1] == s2[j - 1] else 8)
+                i, j = i - 1, j - 1
+                continue
+            state = who[i][j]
+        if state == 1:
+            ops.append(2)
+            ext = e_ext[i][j]
+            j -= 1
+        else:
+            ops.append(1)
+            ext = f_ext[i][j]
+            i -= 1
+        if not ext:
+            state = None
+    ops.reverse()
+    out = []
+    for o in ops:
+        if out and out[-1][0] == o:
+            out[-1][1] += 1
+        else:
+            out.append([o, 1])
+    return [(o, c) for o, c in out]
+
+
+def allele_prediction_ref(alt, ref_seq, max_range, cigar=None):
+    """generate_indel_pileups.py:77-127 transliterated (same variable names); `cigar` defaults to nw_cigar_ref."""
+    cigar_op = cigar if cigar is not None else nw_cigar_ref(alt, ref_seq)
+    indel = False
+    ref_cnt = [0] * 10
+    alt_cnt = [0] * 10
+    mis_match_cnt_before_indel = False
+    mis_match_cnt_after_indel = (0, 0)
+    for op, cnt in cigar_op:
+        if op == 8 or op == 7:
+            ref_cnt[op] += cnt
+            alt_cnt[op] += cnt
+            if indel:
+                mis_match_cnt_after_indel[op - 7] += cnt
+            else:
+                mis_match_cnt_before_indel = True
+        if op == 1:
+            alt_cnt[op] += cnt
+            mis_match_cnt_after_indel = [0, 0]
+            indel = True
+        if op == 2:
+            ref_cnt[op] += cnt
+            mis_match_cnt_after_indel = [0, 0]
+            indel = True
+        if indel is False and sum(ref_cnt) >= max_range + 10:
+            if ref_cnt[8]:
+                out_len = sum(ref_cnt) if op == 8 else sum(ref_cnt) - cnt
+                return ref_seq[:out_len], alt[:out_len]
+            else:
+                return (None, None)
+        if indel is True:
+            if sum(mis_match_cnt_after_indel) > 20:
+                break
+    ref_out_len = sum(ref_cnt) if op == 8 else sum(ref_cnt) - cnt
+    alt_out_len = sum(alt_cnt) if op == 8 else sum(alt_cnt) - cnt
+    if not mis_match_cnt_before_indel:
+        ref_out_len += 1
+        alt_out_len += 1
+    return ref_seq[:ref_out_len], alt[:alt_out_len]
+
+
+def read_windows_ref(records, anchors, window_before, window_after, flag_filter):
+    """generate_indel_pileups.py:306-338 on SAM-like records (dict name, flag, pos0, cigar [(op, len)], seq): for each
+    anchor (1-based) the [(record index, query_sequence[max(0, q - wb) : q + wa])] of the reads in the pileup there, with
+    q = pysam's query_position_or_next, by expanding every CIGAR base by base."""
+    out = []
+    maps = []
+    for r in records:
+        ref_to_q = {}                     # 1-based ref pos -> query index or ('next', index)
+        rp, qp = r["pos0"] + 1, 0
+        pending = []                      # deleted / skipped reference positions waiting for the next aligned query base
+        for op, ln in r["cigar"]:
+            if op in "M=X":
+                for _ in range(ln):
+                    for d in pending:
+                        ref_to_q[d] = qp
+                    pending = []
+                    ref_to_q[rp] = qp
+                    rp += 1
+                    qp += 1
+            elif op in "IS":
+                qp += ln
+            elif op in "DN":
+                for _ in range(ln):
+                    pending.append(rp)
+                    rp += 1
+        for d in pending:
+            ref_to_q[d] = qp
+        maps.append((ref_to_q, r["pos0"] + 1, rp))
+    for a in anchors:
+        here = []
+        for k, r in enumerate(records):
+            m, s, e = maps[k]
+            if (r["flag"] & flag_filter) or (r["flag"] & 4) or not (s <= a < e):
+                continue
+            q = m[a]
+            here.append((k, r["seq"][max(0, q - window_before):q + window_after]))
+        out.append(here)
+    return out

@@ -1,0 +1,220 @@
+"""SURVEY.md 8a rows a11 (pass-2 read windows) and a13 (allele_prediction): the library's native host code against the
+independent pure-Python restatements in oracle/ and against hand-derived cases.  parasail / pysam / MUSCLE are absent from
+this image, so parity with them is unpinned; these tests pin the documented rules."""
+import numpy as np
+import pytest
+
+from nanocaller_amd import generate_indel_pileups as gip
+from nanocaller_amd.bam import BamFile
+from oracle import oracle
+
+import bamio
+
+
+def _rand_seq(rng, n):
+    return "".join("AGTC"[i] for i in rng.integers(0, 4, size=n))
+
+
+def _mutate(rng, s, n_sub, indels):
+    s = list(s)
+    for _ in range(n_sub):
+        i = int(rng.integers(0, len(s)))
+        s[i] = "AGTC"[(("AGTC".index(s[i])) + int(rng.integers(1, 4))) % 4]
+    for pos, ln in sorted(indels, reverse=True):
+        if ln > 0:
+            s[pos:pos] = list(_rand_seq(rng, ln))
+        else:
+            del s[pos:pos - ln]
+    return "".join(s)
+
+
+def test_nw_cigar_hand_cases():
+    assert gip.nw_cigar("AGTCAGTC", "AGTCAGTC") == [(7, 8)]
+    assert gip.nw_cigar("AGTCTGTC", "AGTCAGTC") == [(7, 4), (8, 1), (7, 3)]
+    assert gip.nw_cigar("AGTCGTC", "AGTCAGTC") == [(7, 4), (2, 1), (7, 3)]                 # one base missing from s1: D
+    assert gip.nw_cigar("AGTCACCGTC", "AGTCAGTC") == [(7, 5), (1, 2), (7, 3)]               # two extra bases in s1: I
+    assert gip.nw_cigar("AGTCAGGGTC", "AGTCAGTC") == [(7, 5), (1, 2), (7, 3)]               # inside a run the gap is left-aligned
+    assert gip.nw_cigar("", "AGT") == [(2, 3)] and gip.nw_cigar("AG", "") == [(1, 2)]
+    # one gap of 3 (9 + 2) beats three gaps of 1 (27)
+    c = gip.nw_cigar("AAAACCCCGGGG", "AAAACCCCTTTGGGG")
+    assert [o for o, _ in c].count(2) == 1 and sum(n for o, n in c if o == 2) == 3
+
+
+def test_nw_cigar_matches_independent_restatement():
+    rng = np.random.Generator(np.random.PCG64(41))
+    for trial in range(120):
+        ref = _rand_seq(rng, int(rng.integers(1, 200)))
+        k = int(rng.integers(0, 4))
+        indels = [(int(rng.integers(0, len(ref))), int(rng.choice([-7, -3, -1, 1, 2, 5, 20]))) for _ in range(k)]
+        alt = _mutate(rng, ref, int(rng.integers(0, 6)), indels)
+        got = gip.nw_cigar(alt, ref)
+        assert got == oracle.nw_cigar_ref(alt, ref), (alt, ref)
+        assert sum(n for o, n in got if o in (7, 8, 1)) == len(alt) and sum(n for o, n in got if o in (7, 8, 2)) == len(ref)
+    # low-complexity sequences exercise the tie rules
+    for a, b in [("AAAAAAA", "AAAA"), ("AAAA", "AAAAAAA"), ("AGAGAGAG", "AGAG"), ("TTTTATTTT", "TTTTTTTT"), ("ACACAC", "CACACA")]:
+        assert gip.nw_cigar(a, b) == oracle.nw_cigar_ref(a, b)
+
+
+def test_allele_prediction_matches_reference_walk():
+    rng = np.random.Generator(np.random.PCG64(43))
+    n_none = 0
+    for trial in range(160):
+        ref = _rand_seq(rng, int(rng.integers(40, 262)))
+        kind = trial % 4
+        if kind == 0:                                            # no indel at all: the walk returns early or (None, None)
+            alt = _mutate(rng, ref, int(rng.integers(0, 3)), [])
+        elif kind == 1:                                          # indel at the very start (anchor column)
+            alt = _mutate(rng, ref, 0, [(0, int(rng.choice([-5, -1, 2, 9])))])
+        else:
+            alt = _mutate(rng, ref, int(rng.integers(0, 8)), [(int(rng.integers(0, 60)), int(rng.choice([-30, -4, -1, 1, 3, 12])))])
+        for max_range in (10, 40):
+            got = gip.allele_prediction(alt, ref, max_range)
+            exp = oracle.allele_prediction_ref(alt, ref, max_range)
+            assert got == exp, (alt, ref, max_range)
+            n_none += got == (None, None)
+    assert n_none > 0
+    # a hand-derived case: 2-base deletion after 5 matching bases -> REF keeps the deleted bases, ALT does not
+    ref = "AGTCAGGTTACGATCGATCGATTAGCATCGGATC"
+    alt = ref[:5] + ref[7:]
+    assert gip.allele_prediction(alt, ref, 10) == (ref[:7], alt[:5])
+
+
+@pytest.fixture(scope="module")
+def pass2_bam(tmp_path_factory):
+    rng = np.random.Generator(np.random.PCG64(47))
+    L = 6000
+    ref = _rand_seq(rng, L)
+    recs = []
+    for k in range(220):
+        pos0 = int(rng.integers(0, L - 900))
+        n_ops = int(rng.integers(1, 9))
+        cigar, seq, rp = [], "", pos0
+        if rng.random() < 0.3:
+            cigar.append(("H", int(rng.integers(1, 9))))
+        if rng.random() < 0.4:
+            s = int(rng.integers(1, 30)); cigar.append(("S", s)); seq += _rand_seq(rng, s)
+        if rng.random() < 0.1:
+            s = int(rng.integers(1, 5)); cigar.append(("I", s)); seq += _rand_seq(rng, s)
+        for t in range(n_ops):
+            m = int(rng.integers(5, 120)); cigar.append(("M" if rng.random() < 0.8 else "=", m)); seq += ref[rp:rp + m]; rp += m
+            if t + 1 < n_ops:
+                if rng.random() < 0.5:
+                    s = int(rng.integers(1, 25)); cigar.append(("I", s)); seq += _rand_seq(rng, s)
+                else:
+                    s = int(rng.integers(1, 40)); cigar.append(("D", s)); rp += s
+        if rng.random() < 0.4:
+            s = int(rng.integers(1, 30)); cigar.append(("S", s)); seq += _rand_seq(rng, s)
+        flag = int(rng.choice([0, 16, 0x100, 0x800, 0x400, 1024 + 16], p=[0.4, 0.4, 0.05, 0.05, 0.05, 0.05]))
+        tags = {}
+        if rng.random() < 0.7:
+            tags = {"HP": int(rng.integers(1, 3)), "PS": 1000 + 100 * int(rng.integers(0, 3))}
+        recs.append(dict(name="r%03d" % k, flag=flag, pos0=pos0, cigar=cigar, seq=seq, tags=tags))
+    recs.sort(key=lambda r: r["pos0"])
+    d = tmp_path_factory.mktemp("pass2")
+    bam = str(d / "p.bam")
+    bamio.write_bam(bam, "c", L, recs)
+    return bam, recs
+
+
+@pytest.mark.parametrize("window_before,window_after", [(0, 160), (0, 260), (7, 33)])
+def test_pass2_read_windows_match_independent_cigar_walk(pass2_bam, window_before, window_after):
+    bam, recs = pass2_bam
+    rng = np.random.Generator(np.random.PCG64(53))
+    anchors = sorted(set(int(a) for a in rng.integers(1, 5600, size=400)))
+    flag_filter = 0x4 | 0x100 | 0x200 | 0x400 | 0x800
+    d = BamFile(bam).decode("c", 1, 6000, anchors=anchors, window_before=window_before, window_after=window_after,
+                            keep_mask=flag_filter)
+    exp = oracle.read_windows_ref(recs, anchors, window_before, window_after, flag_filter)
+    assert len(d["windows"]) == len(anchors)
+    n_del = 0
+    for a, got, want in zip(anchors, d["windows"], exp):
+        assert [(d["names"][r], s) for r, s in got] == [(recs[k]["name"], s) for k, s in want], a
+        n_del += len(got)
+    assert n_del > 1000
+    # qstart = leading soft clip (+ leading insertion); hard clips are not part of the query
+    for k, r in enumerate(recs):
+        lead = 0
+        for op, ln in r["cigar"]:
+            if op in "SI":
+                lead += ln
+            elif op != "H":
+                break
+        assert d["qstart"][k] == lead
+
+
+def _pad_aligner(names, seqs, ref):
+    """deterministic stand-in for MUSCLE (absent here): left-justified rows padded with gaps"""
+    w = max([len(ref)] + [len(x) for x in seqs])
+    return [x.ljust(w, "-") for x in seqs], ref.ljust(w, "-")
+
+
+@pytest.mark.gpu
+def test_get_indel_testing_candidates_end_to_end(tmp_path):
+    """BAM + FASTA files in -> (pos, x0, x1, x2, alleles, phase): pass 1 on the GPU, pass-2 windows from the native reader,
+    msa tensors on the GPU, alleles by nc_allele_prediction -- against the same pipeline assembled from the oracle pieces."""
+    from nanocaller_amd.bam import read_bam
+    w = bamio.make_bam_world(seed=11, length=24_000, depth=16)
+    # the synthetic worlds code per-base deletion noise as 4 without an event; written as 'N' bases they would make msa()
+    # raise KeyError exactly as the reference does (:56) -- give those positions the reference base instead
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    refc = np.array(["AGTC".find(c) for c in w.ref], np.int64)
+    for r in range(w.n_reads):
+        s0, o0 = int(w.read_start[r]), int(w.read_off[r])
+        span = w.codes[o0:int(w.read_off[r + 1])]
+        deleted = np.zeros(len(span), bool)
+        for k in range(ev_off[r], ev_off[r + 1]):
+            if ev_len[k] < 0:
+                deleted[ev_pos[k] + 1 - s0:ev_pos[k] + 1 - s0 - ev_len[k]] = True
+        fix = (span == 4) & ~deleted
+        span[fix] = np.where(refc[s0 - 1:s0 - 1 + len(span)][fix] >= 0, refc[s0 - 1:s0 - 1 + len(span)][fix], 0)
+    rng = np.random.Generator(np.random.PCG64(61))
+    recs = bamio.world_to_records(w, rng)
+    bam, fa = str(tmp_path / "i.bam"), str(tmp_path / "i.fa")
+    bamio.write_bam(bam, w.chrom, w.length, recs)
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    dct = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6,
+               supplementary=False, exclude_bed=None, impute_indel_phase=False)
+    chunk = dict(chrom=w.chrom, start=2_000, end=22_000, sam_path=bam)
+    pos, x0, x1, x2, alleles, phase = gip.get_indel_testing_candidates(dct, chunk, aligner=_pad_aligner)
+    assert len(pos) > 5
+    # ---- expected, from the oracle pieces
+    world = read_bam(bam, fa, w.chrom)
+    vp, vt = oracle.indel_scan(world, chunk["start"], chunk["end"], mincov=2, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6)
+    variants = dict(zip(vp.tolist(), vt.tolist()))
+    anchors = sorted(variants)
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | 0x800
+    wins = oracle.read_windows_ref(recs, anchors, 0, 160, flag)
+    sym = {"A": 0, "G": 1, "T": 2, "C": 3, "-": 4}
+    e_pos, e_alleles, e_phase, e_x = [], [], [], []
+    for a, win in zip(anchors, wins):
+        ref = "".join(c if c in "AGTC" else "N" for c in w.ref[a - 1:min(w.length, a + 160)])
+        if "N" in ref:
+            continue
+        sets = [{}, {}, {}]
+        for k, text in win:
+            hp = recs[k].get("tags", {}).get("HP", 0)
+            sets[2][recs[k]["name"]] = text
+            if hp in (1, 2):
+                sets[hp - 1][recs[k]["name"]] = text
+        res = []
+        for d, mc in zip(sets, (2, 2, 2)):
+            names = sorted(d)
+            rows, ref_row = _pad_aligner(names, [d[n] for n in names], ref)
+            if len(rows) < mc:
+                res.append(None)
+                continue
+            mat = np.array([[sym[c] for c in r] for r in rows], np.uint8)
+            x, cns = oracle.indel_tensor(mat, np.array([sym[c] for c in ref_row], np.uint8))
+            res.append((x, "".join("AGTC"[c] for c in cns if c != 4), ref))
+        if any(r is None for r in res):
+            continue
+        e_pos.append(a)
+        e_x.append([r[0] for r in res])
+        mr = {0: 40, 1: 10}[variants[a]]
+        e_alleles.append([oracle.allele_prediction_ref(r[1], r[2], mr) for r in res])
+        first = next(iter(sets[0]))
+        e_phase.append(next(r["tags"]["PS"] for r in recs if r["name"] == first))
+    assert pos == e_pos and alleles == e_alleles and phase == e_phase
+    for got, want in zip((x0, x1, x2), zip(*e_x)):
+        assert got.shape == (len(pos), 5, 128, 2)
+        assert np.array_equal(got.astype(np.float32), np.stack(want))
