@@ -91,93 +91,6 @@ __global__ __launch_bounds__(256) void k2_conv1(const float *__restrict__ x, con
     }
 }
 
-// ---- conv2 / conv3: 2x3 kernel, stride (1,2), valid.  in NHWC [site][HI][WI][CI], weights [2][3][CI][CO], out NHWC.
-// P positions per lane (register blocking over positions halves the scalar weight traffic per FMA).
-template <int HI, int WI, int CI, int CO, int P>
-__global__ __launch_bounds__(256) void k2_conv23(const float *__restrict__ in, const float *__restrict__ wk, const float *__restrict__ wb,
-                                                 float *__restrict__ out, int64_t npos)
-{
-    constexpr int HO = HI - 1, WO = (WI - 3) / 2 + 1;
-    const int64_t nthreads = (int64_t)gridDim.x * 256;
-    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float acc[P][CO];
-    const float *ip[P];
-    bool live[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        const int64_t g = g0 + p * nthreads;
-        live[p] = g < npos;
-        const int64_t gg = live[p] ? g : 0;
-        const int64_t site = gg / (HO * WO);
-        const int r = (int)(gg - site * (HO * WO));
-        const int y = r / WO, xq = r - y * WO;
-        ip[p] = in + ((site * HI + y) * WI + 2 * xq) * CI;
-#pragma unroll
-        for (int o = 0; o < CO; o++) acc[p][o] = wb[o];
-    }
-    for (int dy = 0; dy < 2; dy++) {
-        for (int dx = 0; dx < 3; dx++) {
-            const float *wt = wk + (dy * 3 + dx) * CI * CO;
-            const int ioff = (dy * WI + dx) * CI;
-#pragma unroll 2
-            for (int c4 = 0; c4 < CI; c4 += 4) {
-                float4 xv[P];
-#pragma unroll
-                for (int p = 0; p < P; p++) xv[p] = *reinterpret_cast<const float4 *>(ip[p] + ioff + c4);
-#pragma unroll
-                for (int cc = 0; cc < 4; cc++) {
-                    const float *wr = wt + (c4 + cc) * CO;
-#pragma unroll
-                    for (int o = 0; o < CO; o++) {
-                        const float wv = wr[o];
-#pragma unroll
-                        for (int p = 0; p < P; p++) {
-                            const float xs = cc == 0 ? xv[p].x : cc == 1 ? xv[p].y : cc == 2 ? xv[p].z : xv[p].w;
-                            acc[p][o] = fmaf(xs, wv, acc[p][o]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        if (!live[p]) continue;
-        float4 *op = reinterpret_cast<float4 *>(out + (g0 + p * nthreads) * CO);
-#pragma unroll
-        for (int o = 0; o < CO; o += 4)
-            op[o / 4] = make_float4(selu(acc[p][o]), selu(acc[p][o + 1]), selu(acc[p][o + 2]), selu(acc[p][o + 3]));
-    }
-}
-
-// ---- fc1: lane = site, F outputs in registers, K-long dot products with uniform weight rows [K][F]; SELU.
-template <int F>
-__global__ __launch_bounds__(256) void k2_fc1(const float *__restrict__ in, int K, const float *__restrict__ wk, const float *__restrict__ wb,
-                                              float *__restrict__ out, int64_t n)
-{
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = s < n;
-    const float *ip = in + (live ? s : 0) * K;
-    float acc[F];
-#pragma unroll
-    for (int o = 0; o < F; o++) acc[o] = wb[o];
-    for (int k4 = 0; k4 < K; k4 += 4) {
-        const float4 xv = *reinterpret_cast<const float4 *>(ip + k4);
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
-            const float xs = cc == 0 ? xv.x : cc == 1 ? xv.y : cc == 2 ? xv.z : xv.w;
-            const float *wr = wk + (int64_t)(k4 + cc) * F;
-#pragma unroll
-            for (int o = 0; o < F; o++) acc[o] = fmaf(xs, wr[o], acc[o]);
-        }
-    }
-    if (!live) return;
-    float4 *op = reinterpret_cast<float4 *>(out + s * F);
-#pragma unroll
-    for (int o = 0; o < F; o += 4) op[o / 4] = make_float4(selu(acc[o]), selu(acc[o + 1]), selu(acc[o + 2]), selu(acc[o + 3]));
-}
-
-
 // ---- MFMA forms (SNP trunk).  fp32-in/fp32-accumulate MFMA is bit-for-bit an fmaf chain (exact fp32).
 // GEMM view: M = output positions or sites (A fragment: one activation per lane), N = output channels (B fragment:
 // one weight per lane), K = (tap, ci) walked in a permuted order so that the 4 consecutive input channels a lane
@@ -257,6 +170,63 @@ __global__ __launch_bounds__(256) void k3_fc1(const float *__restrict__ in, int 
     }
 }
 
+
+// ---- conv2 / conv3 of the indel models as an implicit GEMM on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, bit-for-bit an
+// fmaf chain): M = output positions (one tile of 16 per wave iteration), N = CO, K = 6*CI (tap-major) walked in groups of
+// 16.  A lane's float4 = 4 consecutive input channels of one tap and feeds 4 MFMA steps: K slot kq of step j is
+// k = 16 G + 4 kq + j, for the activation and the weight operand alike.  The weights of the layer live in LDS in fragment
+// order (one ds_read_b128 per 4 MFMAs).  in NHWC [site][HI][WI][CI], weights [2][3][CI][CO], out NHWC [site][HO][WO][CO].
+template <int HI, int WI, int CI, int CO>
+__global__ __launch_bounds__(256) void k7_conv23_mfma(const float *__restrict__ in, const float *__restrict__ wk, const float *__restrict__ wb,
+                                                      float *__restrict__ out, int64_t npos)
+{
+    constexpr int HO = HI - 1, WO = (WI - 3) / 2 + 1, K = 6 * CI, NG = K / 16, TN = CO / 16;
+    static_assert(CI % 4 == 0 && K % 16 == 0 && CO % 16 == 0, "k7_conv23_mfma: shape");
+    __shared__ float4 wf[NG][TN][64];
+    for (int idx = threadIdx.x; idx < NG * TN * 64; idx += 256) {
+        const int l = idx & 63, tn = (idx >> 6) % TN, G = (idx >> 6) / TN;
+        const int k0 = 16 * G + 4 * (l >> 4), col = tn * 16 + (l & 15);
+        wf[G][tn][l] = make_float4(wk[(k0 + 0) * CO + col], wk[(k0 + 1) * CO + col], wk[(k0 + 2) * CO + col], wk[(k0 + 3) * CO + col]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, kq = lane >> 4, c16 = lane & 15;
+    const int64_t ntiles = (npos + 15) / 16;
+    float bias[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) bias[tn] = wb[tn * 16 + c16];
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t m = tile * 16 + c16;
+        if (m >= npos) m = npos - 1;
+        const int64_t site = m / (HO * WO);
+        const int r = (int)(m - site * (HO * WO));
+        const int y = r / WO, xq = r - y * WO;
+        const float *ip = in + ((site * HI + y) * WI + 2 * xq) * CI;
+        f32x4v acc[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) acc[tn] = (f32x4v){bias[tn], bias[tn], bias[tn], bias[tn]};
+#pragma unroll
+        for (int G = 0; G < NG; G++) {
+            const int k0 = 16 * G + 4 * kq, tap = k0 / CI, ci = k0 - tap * CI;
+            const float4 a = *reinterpret_cast<const float4 *>(ip + ((tap / 3) * WI + (tap % 3)) * CI + ci);
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                const float4 b = wf[G][tn][lane];
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[tn], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int64_t pos = tile * 16 + 4 * kq + rr;             // D[row 4 kq + rr = position][col c16 = channel]
+            if (pos < npos) {
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) out[pos * CO + tn * 16 + c16] = selu(acc[tn][rr]);
+            }
+        }
+    }
+}
 
 // ---- fused conv1 + conv2 for the SNP trunk (5x41x5 input): the 205x48 conv1 activation lives only in LDS.
 // Per site: (1) the input is staged, coverage-scaled, into a zero-padded [9][45][5] LDS image; (2) conv1 runs as
@@ -1151,9 +1121,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         else
             hipLaunchKernelGGL(k6_fc1_h3, dim3(blocks_for(nb, 16 * FC_TM)), dim3(256), 0, ctx->stream, a3, packed_h + H_PACKED_BYTES, f1, nb);
     } else {
-        hipLaunchKernelGGL((k2_conv23<H, W, 3 * C1, C2, P2>), dim3(blocks_for(np2, 256 * P2)), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
-        hipLaunchKernelGGL((k2_conv23<H2, W2, C2, C3, P3>), dim3(blocks_for(np3, 256 * P3)), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
-        hipLaunchKernelGGL((k2_fc1<F>), dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+        auto grid = [](int64_t npos) { const int64_t t = (npos + 63) / 64; return dim3((unsigned)(t < 2048 ? t : 2048)); };
+        hipLaunchKernelGGL((k7_conv23_mfma<H, W, 3 * C1, C2>), grid(np2), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
+        hipLaunchKernelGGL((k7_conv23_mfma<H2, W2, C2, C3>), grid(np3), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
+        hipLaunchKernelGGL((k3_fc1<F, 2>), dim3(blocks_for(nb, 32)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
     }
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
@@ -1380,7 +1351,7 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
     const int nout = kind == NC_MODEL_INDEL ? 4 : 1;
     const int64_t xs = kind == NC_MODEL_INDEL ? 15 * 128 * 2 : 5 * 128 * 2;
     NcTimer tm(ctx, 2);
-    const int64_t BATCH = kind == NC_MODEL_INDEL ? 1024 : 4096;
+    const int64_t BATCH = kind == NC_MODEL_INDEL ? 8192 : 16384;     // ~3 GB / ~1.3 GB of layer activations in HBM per batch
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
