@@ -168,6 +168,31 @@ def test_every_snp_model_both_trunk_kernels(eng):
         eng.set_cnn_precision(exact_fp32=False)
 
 
+@pytest.mark.parametrize("n", [1, 2, 15, 63, 64, 65, 255, 256, 257, 511, 600])
+def test_snp_cnn_odd_site_counts(eng, n, precision):
+    """site counts around the persistent kernels' grid / tile boundaries (one 512-thread workgroup per CU, 64-site fc1
+    tiles), and the asynchronous drain returning the same numbers as the plain call"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    path, cov = get_SNP_model("ONT-HG002")
+    w = Weights(path)
+    eng.load_weights(_lib.MODEL_SNP, w)
+    x, ref_code, depth = _golden_inputs("ont_dip")
+    reps = -(-n // len(x))
+    x = np.concatenate([x] * reps)[:n]
+    ref_code = np.concatenate([ref_code] * reps)[:n]
+    scale = np.linspace(0.5, 2.0, n)
+    xd, rd, sd = torch.from_numpy(x).cuda(), torch.from_numpy(ref_code).cuda(), torch.from_numpy(scale).cuda()
+    probs, gt = eng.snp_forward(_lib.MODEL_SNP, xd, rd, sd)
+    ep, eg = oracle.snp_forward(w.flat, x, ref_code, scale, precision="f64")
+    assert np.abs(probs.cpu().numpy() - ep).max() < 2e-5 and np.abs(gt.cpu().numpy() - eg).max() < 2e-5
+    _, _, hp, hg = eng.snp_forward(_lib.MODEL_SNP, xd, rd, sd, drain=True)
+    eng.wait_copies()
+    assert np.array_equal(hp, probs.cpu().numpy()) and np.array_equal(hg, gt.cpu().numpy())
+
+
 def test_snp_hap_cnn_matches_oracle(eng, precision):
     import torch
     from nanocaller_amd import _lib
