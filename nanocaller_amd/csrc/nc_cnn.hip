@@ -1313,7 +1313,7 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
     NC_HIP(ctx, hipSetDevice(ctx->device));
     NcTimer tm(ctx, 2);
     ctx->n_kev = 0;
-    const int64_t BATCH = 32768;
+    const int64_t BATCH = 65536;
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
