@@ -323,3 +323,44 @@ def test_bam_and_fasta_files_end_to_end(eng, tmp_path):
         outs.append(gzip.open(str(vdir / "t.unfiltered.snps.vcf.gz"), "rt").read())
     assert outs[0] == outs[1] and outs[0].count("\n") > 100
     assert not any(12_000 <= int(ln.split("\t")[1]) < 12_800 for ln in outs[0].splitlines() if not ln.startswith("#"))
+
+
+def test_degenerate_inputs(eng):
+    """empty / ragged inputs: no reads at all, reads but no candidate, thresholds nothing passes, a chunk past the last read,
+    zero-site CNN calls -- the reference's empty-lists contract (generate_SNP_pileups.py:193-197) and no device faults"""
+    import torch
+    from nanocaller_amd import _lib, snpCaller
+    from nanocaller_amd.generate_SNP_pileups import get_snp_testing_candidates
+    from nanocaller_amd.synth import make_world
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    base = dict(threshold=[0.4, 0.6], mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, seq="ont", supplementary=False,
+                exclude_bed=None)
+    empty = ([], [], [], [], [], 0, [], [])
+    # (1) a contig with (almost) no reads
+    w0 = make_world(seed=1, length=5000, depth=0.001, read_len_scale=0.05)
+    assert get_snp_testing_candidates(_dct(w0, base, None), dict(chrom=w0.chrom, start=1, end=5000, ploidy="diploid")) == empty
+    # (2) normal depth, but nothing can pass: allele frequency above 1, then mincov above the depth
+    w = load_world("ont")
+    for over in (dict(min_allele_freq=1.5), dict(mincov=10_000)):
+        d = dict(base, **over)
+        reg = dict(chrom=w.chrom, start=2_000, end=9_000, ploidy="diploid")
+        got = get_snp_testing_candidates(_dct(w, d, None), reg)
+        exp = oracle.get_snp_testing_candidates(w, d, reg)
+        assert got == empty and len(exp[0]) == 0
+    # (3) a chunk that starts after the last read / one-column chunks at the contig ends
+    for reg in (dict(chrom=w.chrom, start=w.length - 3, end=w.length, ploidy="diploid"), dict(chrom=w.chrom, start=1, end=1, ploidy="diploid"),
+                dict(chrom=w.chrom, start=w.length, end=w.length, ploidy="haploid")):
+        got = get_snp_testing_candidates(_dct(w, base, None), reg)
+        exp = oracle.get_snp_testing_candidates(w, base, reg)
+        assert len(got[0]) == len(exp[0])
+        for x, y in zip(got, exp):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    # (4) the batched entry point on chunks without candidates, and zero-site CNN calls
+    params = dict(base, snp_model="ONT-HG002", disable_coverage_normalization=False, sam_path=w0)
+    r = snpCaller.call_chunks(params, [dict(chrom=w0.chrom, start=1, end=2500, ploidy="diploid"), dict(chrom=w0.chrom, start=2500, end=5000, ploidy="diploid")])
+    assert r["n"] == 0
+    eng.load_weights(_lib.MODEL_SNP, Weights(get_SNP_model("ONT-HG002")[0]))
+    z = torch.zeros((0, 5, 41, 5), device="cuda")
+    p, g = eng.snp_forward(_lib.MODEL_SNP, z, torch.zeros(0, dtype=torch.int32, device="cuda"), torch.zeros(0, dtype=torch.float64, device="cuda"))
+    assert p.shape == (0, 4) and g.shape == (0, 2)
