@@ -11,32 +11,48 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nanocaller_hip.h"
 
 namespace {
 
+// BGZF reader with parallel read-ahead: BGZF blocks (<= 64 KB of payload each) are independent deflate streams, so a window
+// of upcoming blocks is read from the file in one go and inflated (+ CRC-checked) by a pool of host threads; the consumer
+// walks the window in order.  The window starts small (region queries stop early) and doubles up to 1024 blocks (~64 MB).
 struct Bgzf {
     FILE *f = nullptr;
-    std::vector<uint8_t> comp, block;
+    struct Blk {
+        int64_t coff = 0, next = 0;
+        std::vector<uint8_t> comp, data;
+        uint32_t isize = 0, crc = 0;
+        int clen = 0;
+        bool ok = true;
+    };
+    std::vector<Blk> win;       // inflated window, consecutive blocks
+    size_t wi = 0;              // next block of the window to hand out
+    size_t grow = 16;           // blocks to read ahead next time
+    std::vector<uint8_t> block;
     int64_t block_coff = 0;     // compressed offset of the current block
+    int64_t next_coff = 0;
     size_t upos = 0;            // read position inside `block`
     bool eof = false;
 
-    bool load_block(int64_t coff)
+    // raw block at the current file position -> false on error; *at_eof when the file ended cleanly
+    bool read_raw(Blk &k, int64_t coff, bool *at_eof)
     {
-        if (fseeko(f, coff, SEEK_SET) != 0) return false;
         uint8_t h[18];
-        size_t n = fread(h, 1, 18, f);
-        if (n == 0) { eof = true; block.clear(); upos = 0; block_coff = coff; return true; }
+        const size_t n = fread(h, 1, 18, f);
+        if (n == 0) { *at_eof = true; return true; }
         if (n != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
         const int xlen = h[10] | (h[11] << 8);
         // find the BC subfield (it is first in every writer in practice, but walk the extra field to be safe)
         std::vector<uint8_t> extra((size_t)xlen);
-        memcpy(extra.data(), h + 12, std::min(6, xlen));
+        memcpy(extra.data(), h + 12, (size_t)std::min(6, xlen));
         if (xlen > 6 && fread(extra.data() + 6, 1, (size_t)xlen - 6, f) != (size_t)xlen - 6) return false;
         int bsize = -1;
         for (int p = 0; p + 4 <= xlen;) {
@@ -47,34 +63,81 @@ struct Bgzf {
         if (bsize < 0) return false;
         const int clen = bsize - xlen - 12 - 8;
         if (clen < 0) return false;
-        comp.resize((size_t)clen + 8);
-        if (fread(comp.data(), 1, comp.size(), f) != comp.size()) return false;
-        const uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
-        block.resize(isize);
-        if (isize) {
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) return false;
-            zs.next_in = comp.data();
-            zs.avail_in = (uInt)clen;
-            zs.next_out = block.data();
-            zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) return false;
-            const uint32_t crc = comp[clen] | (comp[clen + 1] << 8) | (comp[clen + 2] << 16) | ((uint32_t)comp[clen + 3] << 24);
-            if ((uint32_t)crc32(0L, block.data(), isize) != crc) return false;
+        k.comp.resize((size_t)clen + 8);
+        if (fread(k.comp.data(), 1, k.comp.size(), f) != k.comp.size()) return false;
+        const uint8_t *t = k.comp.data() + clen;
+        k.crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        k.isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+        k.clen = clen;
+        k.coff = coff;
+        k.next = coff + bsize;
+        return true;
+    }
+    static void inflate_blk(Blk &k)
+    {
+        k.data.resize(k.isize);
+        if (!k.isize) return;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { k.ok = false; return; }
+        zs.next_in = k.comp.data();
+        zs.avail_in = (uInt)k.clen;
+        zs.next_out = k.data.data();
+        zs.avail_out = k.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || (uint32_t)crc32(0L, k.data.data(), k.isize) != k.crc) k.ok = false;
+        std::vector<uint8_t>().swap(k.comp);
+    }
+    bool fill(int64_t coff)
+    {
+        win.clear();
+        wi = 0;
+        if (fseeko(f, coff, SEEK_SET) != 0) return false;
+        bool at_eof = false;
+        int64_t c = coff;
+        for (size_t i = 0; i < grow; i++) {
+            Blk k;
+            if (!read_raw(k, c, &at_eof)) return false;
+            if (at_eof) break;
+            c = k.next;
+            win.push_back(std::move(k));
         }
-        block_coff = coff;
-        next_coff = coff + bsize;
+        const size_t n = win.size();
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t T = hw ? (hw > 32 ? 32 : hw) : 1;
+        if (const char *e = getenv("NC_BAM_THREADS")) T = (size_t)std::max(1, atoi(e));       // 1 = sequential inflate
+        if (T > n / 4) T = n / 4;                             // a thread per >= 4 blocks
+        if (T <= 1) {
+            for (auto &k : win) inflate_blk(k);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < T; t++)
+                th.emplace_back([this, t, T, n]() { for (size_t i = t; i < n; i += T) inflate_blk(win[i]); });
+            for (auto &x : th) x.join();
+        }
+        for (auto &k : win) if (!k.ok) return false;
+        if (grow < 1024) grow *= 2;
+        return true;
+    }
+    bool load_block(int64_t coff)
+    {
+        if (wi >= win.size() || win[wi].coff != coff) {
+            if (!fill(coff)) return false;
+            if (win.empty()) { eof = true; block.clear(); upos = 0; block_coff = coff; return true; }
+        }
+        Blk &k = win[wi++];
+        block.swap(k.data);
+        block_coff = k.coff;
+        next_coff = k.next;
         upos = 0;
         return true;
     }
-    int64_t next_coff = 0;
 
     bool seek(uint64_t voff)
     {
         eof = false;
+        grow = 16;
         if (!load_block((int64_t)(voff >> 16))) return false;
         upos = (size_t)(voff & 0xffff);
         return upos <= block.size();
