@@ -228,6 +228,8 @@ typedef struct {
 typedef struct {
     int32_t mincov, win_size, small_win_size;   /* dct['mincov'], dct['win_size'], dct['small_win_size'] */
     double ins_t, del_t;                        /* dct['ins_t'], dct['del_t'] */
+    int32_t haploid;                            /* 1: get_indel_testing_candidates_haploid (generate_indel_pileups_haploid.py:185-241):
+                                                   one read set, HP tags ignored, frequencies over all reads of the column */
 } nc_indel_scan_params;
 
 int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,

@@ -57,7 +57,7 @@ class IndelEventsC(C.Structure):
 
 class IndelScanParamsC(C.Structure):
     _fields_ = [("mincov", C.c_int32), ("win_size", C.c_int32), ("small_win_size", C.c_int32), ("ins_t", C.c_double),
-                ("del_t", C.c_double)]
+                ("del_t", C.c_double), ("haploid", C.c_int32)]
 
 
 class DecodedArraysC(C.Structure):

@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t lut8i(uint32_t x, uint32_t lo, uint32_t hi) 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_hap_depth(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
                                                      const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0, int32_t tile_first,
-                                                     int32_t lo, int32_t hi, int32_t *__restrict__ depth /* [3][ncol] */, int32_t ncol)
+                                                     int32_t lo, int32_t hi, int32_t *__restrict__ depth /* [3][ncol] */, int32_t ncol, int32_t haploid)
 {
     constexpr int TILE = BLOCK * 16;
     const int t = tile_first + blockIdx.x;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth(const uint8_t *__restrict__
             uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
             if (P0 >= slo && P0 < shi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
             const int hp = (int)((ent.base_flag >> 1) & 3);           // wave-uniform
-            const int plane = hp == 1 ? 0 : hp == 2 ? 1 : 2;
+            const int plane = haploid ? 0 : hp == 1 ? 0 : hp == 2 ? 1 : 2;       // haploid: one read set, tags ignored
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int d = 0; d < 4; d++) {
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(1024) void k_yield_rank(const int32_t *__restrict__
 __global__ void k_event_intervals(int32_t n_reads, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
                                   const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
                                   const int32_t *__restrict__ rank, int32_t lo, int32_t hi, int32_t win, int32_t small_win,
-                                  int32_t *__restrict__ diff /* [8][nd] */, int32_t nd)
+                                  int32_t *__restrict__ diff /* [8][nd] */, int32_t nd, int32_t haploid)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int hp = read_hap[r];
-    if (hp != 1 && hp != 2) return;
-    const int h = hp - 1;
+    if (!haploid && hp != 1 && hp != 2) return;
+    const int h = haploid ? 0 : hp - 1;
     int cur_lo[4] = {-1, -1, -1, -1}, cur_hi[4] = {-1, -1, -1, -1};
     for (int e = ev_off[r]; e < ev_off[r + 1]; e++) {
         const int32_t p = ev_pos[e];
@@ -259,13 +259,25 @@ __global__ __launch_bounds__(1024) void k_prefix_rows(int32_t *__restrict__ a, i
 
 // per-column decision of :252-275 (float64 divide-and-compare, as in the reference)
 __global__ void k_indel_decide(const int32_t *__restrict__ depth, const int32_t *__restrict__ rank, const int32_t *__restrict__ U,
-                               int32_t nd, int32_t ncol, int32_t mincov, double ins_t, double del_t, int8_t *__restrict__ col_type)
+                               int32_t nd, int32_t ncol, int32_t mincov, double ins_t, double del_t, int32_t haploid,
+                               int8_t *__restrict__ col_type)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     int8_t type = -1;
     const int k = rank[c];
     const int n0 = depth[c], n1 = depth[ncol + c];
+    if (haploid) {                                                     // generate_indel_pileups_haploid.py:224-241 (all reads in plane 0)
+        if (k >= 0 && n0 >= mincov && n0 > 0) {
+            double f[4];
+#pragma unroll
+            for (int cls = 0; cls < 4; cls++) f[cls] = (double)U[(int64_t)(cls * 2) * nd + k] / (double)n0;
+            if (f[0] >= del_t || f[1] >= ins_t) type = 0;
+            else if (f[2] >= del_t || f[3] >= ins_t || (f[2] + f[3]) >= 0.9) type = 1;
+        }
+        col_type[c] = type;
+        return;
+    }
     if (k >= 0 && n0 >= mincov && n1 >= mincov) {
         double f[4][2];
 #pragma unroll
@@ -310,19 +322,19 @@ extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_inde
         const int t0 = (clo - grid_lo) / tile, t1 = (chi - grid_lo) / tile;
         const dim3 g((unsigned)(t1 - t0 + 1));
         if (tile == 1024)
-            hipLaunchKernelGGL(k_hap_depth<64>, g, dim3(64), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol);
+            hipLaunchKernelGGL(k_hap_depth<64>, g, dim3(64), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol, prm->haploid);
         else if (tile == 2048)
-            hipLaunchKernelGGL(k_hap_depth<128>, g, dim3(128), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol);
+            hipLaunchKernelGGL(k_hap_depth<128>, g, dim3(128), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol, prm->haploid);
         else
-            hipLaunchKernelGGL(k_hap_depth<256>, g, dim3(256), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol);
+            hipLaunchKernelGGL(k_hap_depth<256>, g, dim3(256), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol, prm->haploid);
     }
     hipLaunchKernelGGL(k_yield_rank, dim3(1), dim3(1024), 0, ctx->stream, depth, excl_dev, lo - grid_lo, ncol, rank);
     if (ev->n_reads > 0)
         hipLaunchKernelGGL(k_event_intervals, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
-                           ev->ev_len, ev->read_hap, rank, lo, hi, prm->win_size, prm->small_win_size, diff, nd);
+                           ev->ev_len, ev->read_hap, rank, lo, hi, prm->win_size, prm->small_win_size, diff, nd, prm->haploid);
     hipLaunchKernelGGL(k_prefix_rows, dim3(8), dim3(1024), 0, ctx->stream, diff, nd);
     hipLaunchKernelGGL(k_indel_decide, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, depth, rank, diff, nd, ncol, prm->mincov,
-                       prm->ins_t, prm->del_t, ctype);
+                       prm->ins_t, prm->del_t, prm->haploid, ctype);
     NC_HIP(ctx, hipGetLastError());
     tm.stop();
     NC_HIP(ctx, hipMemcpyAsync(col_type_host, ctype, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));

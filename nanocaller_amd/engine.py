@@ -244,7 +244,7 @@ class Engine:
         self._check(self.L.nc_indel_forward(self.ctx, kind, n, _ptr(x), _ptr(probs)), "nc_indel_forward")
         return probs
 
-    def indel_scan(self, dp: DevicePack, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None):
+    def indel_scan(self, dp: DevicePack, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None, haploid=False):
         """K7 -> int8 [end-start+1] per-column decision (-1 none, 0 long-window rule, 1 small-window rule)."""
         if dp.events is None:
             raise ValueError("this read pack carries no indel events / haplotype tags")
@@ -252,7 +252,7 @@ class Engine:
         evc = _lib.IndelEventsC(n_reads=ev["n_reads"], ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(),
                                 ev_len=ev["ev_len"].data_ptr(), read_hap=ev["read_hap"].data_ptr())
         prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size),
-                                    ins_t=float(ins_t), del_t=float(del_t))
+                                    ins_t=float(ins_t), del_t=float(del_t), haploid=1 if haploid else 0)
         lo = max(1, int(start))
         out = np.empty(int(end) - lo + 1, np.int8)
         pc = dp.c_struct()

@@ -48,7 +48,7 @@ def pick_variants(col_type, start, win_size):
     return variants
 
 
-def scan_indel_candidates(dct, chunk, device=0):
+def scan_indel_candidates(dct, chunk, device=0, haploid=False):
     if dct.get("impute_indel_phase"):
         raise NotImplementedError("impute_indel_phase (generate_indel_pileups.py:278-304) is not part of this build")
     world = _resolve(chunk["sam_path"], chunk["chrom"], dct.get("fasta_path"))
@@ -66,7 +66,7 @@ def scan_indel_candidates(dct, chunk, device=0):
             m[max(0, a - dp.tile_pos0):max(0, b - dp.tile_pos0)] = 1
         excl = torch.from_numpy(m).to(eng.device)
     col_type = eng.indel_scan(dp, chunk["start"], chunk["end"], mincov=dct["mincov"], win_size=dct["win_size"],
-                              small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl)
+                              small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=haploid)
     return pick_variants(col_type, chunk["start"], dct["win_size"])
 
 
@@ -200,3 +200,42 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
     if not out_pos:
         return empty
     return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
+
+
+def get_indel_testing_candidates_haploid(dct, chunk, aligner=None, device=0):
+    """generate_indel_pileups_haploid.py:128-277 -> (pos, x, alleles): one read set per anchor, no HP split."""
+    from .bam import BamFile, read_fasta
+    chrom, start, end = chunk["chrom"], chunk["start"], chunk["end"]
+    window_before, window_after = 0, 160
+    if dct["seq"] == "pacbio":
+        window_after = 260
+    variants = scan_indel_candidates(dct, chunk, device, haploid=True)
+    empty = ([], [], [])
+    if not variants:
+        return empty
+    fasta = read_fasta(dct["fasta_path"], chrom)
+    chrom_length = len(fasta)
+    lo, hi = max(1, start - 200), end + 400
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if dct.get("supplementary") else 0x800)
+    anchors = sorted(v for v in variants if max(0, start - 10 - dct["win_size"]) < v <= end)
+    bf = BamFile(chunk["sam_path"])
+    d = bf.decode(chrom, max(1, start - 10 - dct["win_size"] - window_after), end + 1000, anchors=anchors, window_before=window_before,
+                  window_after=window_after, keep_mask=flag)
+    bf.close()
+    names = d["names"]
+    max_range = {0: max(10, dct["win_size"]), 1: 10}
+    out_pos, xs, alleles = [], [], []
+    for v_pos, win in zip(anchors, d["windows"]):
+        ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
+                      for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))
+        if "N" in ref:
+            continue
+        d_tot = {names[r]: text for r, text in win}
+        ft, _, mt, altt, reft = msa(d_tot, ref, v_pos, dct["mincov"], dct["maxcov"], aligner, device)
+        if ft:
+            out_pos.append(v_pos)
+            xs.append(mt)
+            alleles.append(allele_prediction(altt, reft, max_range[variants[v_pos]]))
+    if not out_pos:
+        return empty
+    return (out_pos, np.array(xs), alleles)

@@ -486,7 +486,7 @@ int oracle_indel_tensor(const uint8_t *rows, int32_t nrows, int32_t ncols, const
 int oracle_indel_scan(int32_t n_reads, const int32_t *rstart, const int32_t *rend, const uint8_t *keep, const uint8_t *hap,
                       const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len, const uint8_t *excl, int32_t L,
                       int32_t start, int32_t end, int32_t mincov, int32_t win, int32_t small_win, double ins_t, double del_t,
-                      int32_t cap, int32_t *var_pos, int32_t *var_type, int32_t *n_var)
+                      int32_t haploid, int32_t cap, int32_t *var_pos, int32_t *var_type, int32_t *n_var)
 {
     int32_t lo = start < 1 ? 1 : start, hi = end > L ? L : end;
     *n_var = 0;
@@ -502,7 +502,8 @@ int oracle_indel_scan(int32_t n_reads, const int32_t *rstart, const int32_t *ren
         if (keep && !keep[r]) continue;
         int64_t a = rstart[r] > lo ? rstart[r] : lo, b = (int64_t)rend[r] - 1 < hi ? (int64_t)rend[r] - 1 : hi;
         if (a > b) continue;
-        int h = hap[r] == 1 ? 0 : hap[r] == 2 ? 1 : 2;
+        /* haploid (generate_indel_pileups_haploid.py:185-241): one read set, HP tags are not looked at */
+        int h = haploid ? 0 : hap[r] == 1 ? 0 : hap[r] == 2 ? 1 : 2;
         d[(a - lo) * 3 + h]++;
         d[(b - lo + 1) * 3 + h]--;
         if (h < 2)
@@ -517,7 +518,7 @@ int oracle_indel_scan(int32_t n_reads, const int32_t *rstart, const int32_t *ren
     int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ncol + 1));
     memcpy(fill, ecnt, sizeof(int32_t) * (size_t)(ncol + 1));
     for (int r = 0; r < n_reads; r++) {
-        if ((keep && !keep[r]) || (hap[r] != 1 && hap[r] != 2)) continue;
+        if ((keep && !keep[r]) || (!haploid && hap[r] != 1 && hap[r] != 2)) continue;
         for (int e = ev_off[r]; e < ev_off[r + 1]; e++)
             if (ev_pos[e] >= lo && ev_pos[e] <= hi && ev_pos[e] >= rstart[r] && ev_pos[e] < rend[r]) {
                 int32_t k = fill[ev_pos[e] - lo]++;
@@ -556,7 +557,7 @@ int oracle_indel_scan(int32_t n_reads, const int32_t *rstart, const int32_t *ren
                     if (cls < 2) q = (ln > 2 && ln <= 50) && (is_ins == (cls == 1));      /* :225,228 */
                     else q = (ln <= 10) && (is_ins == (cls == 3));                         /* :226,229 */
                     if (!q) continue;
-                    const int h = hap[r] - 1;
+                    const int h = haploid ? 0 : hap[r] - 1;
                     int32_t *m = &mult[(size_t)r * 4 + cls];
                     if (pass == 1) { if ((*m)++ == 0) distinct[cls][h]++; }
                     else { if (--(*m) == 0) distinct[cls][h]--; }
@@ -565,6 +566,27 @@ int oracle_indel_scan(int32_t n_reads, const int32_t *rstart, const int32_t *ren
         }
         ny++;
         if (v <= prev) continue;                                  /* :249 */
+        if (haploid) {
+            if (ntot >= mincov) {                                  /* haploid :224 */
+                const double del = (double)distinct[0][0] / ntot, ins = (double)distinct[1][0] / ntot;
+                const double dels = (double)distinct[2][0] / ntot, inss = (double)distinct[3][0] / ntot;
+                int type = -1;
+                int64_t anchor = 0;
+                if (del >= del_t || ins >= ins_t) { prev = v + win; anchor = v - win; type = 0; }                  /* :232 */
+                else if (dels >= del_t || inss >= ins_t || (dels + inss) >= 0.9) { prev = v + 10; anchor = v - 10; type = 1; }   /* :237 */
+                if (type >= 0) {
+                    if (anchor < 1) anchor = 1;
+                    int found = 0;
+                    for (int32_t q = 0; q < *n_var; q++)
+                        if (var_pos[q] == (int32_t)anchor) { var_type[q] = type; found = 1; break; }
+                    if (!found) {
+                        if (*n_var >= cap) { rc = -2; break; }
+                        var_pos[*n_var] = (int32_t)anchor; var_type[*n_var] = type; (*n_var)++;
+                    }
+                }
+            }
+            continue;
+        }
         if (n0 >= mincov && n1 >= mincov) {                       /* :252 */
             const double del0 = n0 > 0 ? (double)distinct[0][0] / n0 : 0, del1 = n1 > 0 ? (double)distinct[0][1] / n1 : 0;
             const double ins0 = n0 > 0 ? (double)distinct[1][0] / n0 : 0, ins1 = n1 > 0 ? (double)distinct[1][1] / n1 : 0;

@@ -194,8 +194,9 @@ def indel_tensor(rows, ref_row):
     return out, cns[:nc.value].copy()
 
 
-def indel_scan(world, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, exclude=None, supplementary=False):
-    """Pass 1 of get_indel_testing_candidates (generate_indel_pileups.py:197-304) -> (anchor positions, types)."""
+def indel_scan(world, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, exclude=None, supplementary=False, haploid=False):
+    """Pass 1 of get_indel_testing_candidates (generate_indel_pileups.py:197-304) -> (anchor positions, types);
+    haploid=True: get_indel_testing_candidates_haploid (generate_indel_pileups_haploid.py:185-241)."""
     rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
     ev_off, ev_pos, ev_len = (np.ascontiguousarray(a, np.int32) for a in world.meta["events"])
     hap = np.ascontiguousarray(world.meta["hap"], np.uint8)
@@ -212,7 +213,7 @@ def indel_scan(world, start, end, *, mincov, win_size, small_win_size, ins_t, de
                                 _p(hap, C.c_uint8), _p(ev_off, C.c_int32), _p(ev_pos, C.c_int32), _p(ev_len, C.c_int32),
                                 _p(excl, C.c_uint8) if excl is not None else None, C.c_int32(world.length),
                                 C.c_int32(start), C.c_int32(end), C.c_int32(mincov), C.c_int32(win_size),
-                                C.c_int32(small_win_size), C.c_double(ins_t), C.c_double(del_t), C.c_int32(cap),
+                                C.c_int32(small_win_size), C.c_double(ins_t), C.c_double(del_t), C.c_int32(1 if haploid else 0), C.c_int32(cap),
                                 _p(vp, C.c_int32), _p(vt, C.c_int32), C.byref(nv))
     assert r == 0, r
     return vp[:nv.value].copy(), vt[:nv.value].copy()

@@ -384,6 +384,33 @@ def make_indel_scan_goldens():
         k += 1
     rec["n"] = k
     np.savez_compressed(os.path.join(OUT, "indel_scan.npz"), **rec)
+    # haploid pass 1 (generate_indel_pileups_haploid.py:185-241): one read set, no HP split
+    from nanocaller_src import generate_indel_pileups_haploid as ref_hap
+    rec, k = {}, 0
+    for (start, end, kw) in [(5_000, 55_000, {}), (1, 20_000, dict(mincov=12)),
+                             (10_000, 40_000, dict(ins_t=0.3, del_t=0.3, win_size=20, small_win_size=2)),
+                             (25_000, 35_000, dict(exclude_bed="bed")), (40_000, 41_000, dict(mincov=200))]:
+        dct = dict(seq="ont", fasta_path="fa", win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6,
+                   exclude_bed=None, supplementary=False, impute_indel_phase=False)
+        dct.update(kw)
+        pysam.CAPTURE_INDEL = True
+        pysam.CAPTURED.clear()
+        out = ref_hap.get_indel_testing_candidates_haploid(dct, dict(chrom=w.chrom, start=start, end=end, sam_path="bam"))
+        pysam.CAPTURE_INDEL = False
+        assert len(out[0]) == 0
+        v = pysam.CAPTURED["variants"]
+        keys = sorted(v)
+        rec["s%d_start" % k], rec["s%d_end" % k] = start, end
+        for name in ("mincov", "win_size", "small_win_size"):
+            rec["s%d_%s" % (k, name)] = dct[name]
+        rec["s%d_ins_t" % k], rec["s%d_del_t" % k] = np.float64(dct["ins_t"]), np.float64(dct["del_t"])
+        rec["s%d_excl" % k] = np.array([[30_000, 30_400]] if dct["exclude_bed"] else [], np.int64).reshape(-1, 2)
+        rec["s%d_pos" % k] = np.array(keys, np.int64)
+        rec["s%d_type" % k] = np.array([v[p] for p in keys], np.int64)
+        print("haploid indel scan [%d,%d] %s -> %d variants (%d type 0)" % (start, end, kw, len(keys), sum(1 for p in keys if v[p] == 0)))
+        k += 1
+    rec["n"] = k
+    np.savez_compressed(os.path.join(OUT, "indel_scan_hap.npz"), **rec)
 
 
 def make_chunk_goldens():

@@ -298,6 +298,22 @@ def test_indel_window_scan_matches_reference_pass1(eng):
     assert n > 100
 
 
+def test_haploid_indel_window_scan_matches_reference_pass1(eng):
+    """K7 in haploid mode (generate_indel_pileups_haploid.py:185-241) against the reference's captured `variants`"""
+    from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
+    from tests.util import indel_scan_cases
+    world = load_world("indel")
+    n = 0
+    for c in indel_scan_cases(haploid=True):
+        dct = dict(mincov=c["mincov"], win_size=c["win_size"], small_win_size=c["small_win_size"], ins_t=c["ins_t"],
+                   del_t=c["del_t"], supplementary=False, impute_indel_phase=False,
+                   exclude_bed=[(world.chrom, a, b) for a, b in c["exclude"]] or None)
+        got = scan_indel_candidates(dct, dict(chrom=world.chrom, start=c["start"], end=c["end"], sam_path=world), haploid=True)
+        assert sorted(got) == c["pos"].tolist() and [got[p] for p in sorted(got)] == c["type"].tolist(), (c["start"], c["end"])
+        n += len(got)
+    assert n > 40
+
+
 def test_bam_and_fasta_files_end_to_end(eng, tmp_path):
     """real files in (BAM + BAI + FASTA + bgzipped BED), VCF out: identical to the run on the in-memory world"""
     import gzip

@@ -218,3 +218,28 @@ def test_get_indel_testing_candidates_end_to_end(tmp_path):
     for got, want in zip((x0, x1, x2), zip(*e_x)):
         assert got.shape == (len(pos), 5, 128, 2)
         assert np.array_equal(got.astype(np.float32), np.stack(want))
+
+    # ---- haploid function on the same files: one read set per anchor (generate_indel_pileups_haploid.py:185-277)
+    hpos, hx, halleles = gip.get_indel_testing_candidates_haploid(dct, chunk, aligner=_pad_aligner)
+    vp, vt = oracle.indel_scan(world, chunk["start"], chunk["end"], mincov=2, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6,
+                               haploid=True)
+    variants = dict(zip(vp.tolist(), vt.tolist()))
+    anchors = sorted(variants)
+    wins = oracle.read_windows_ref(recs, anchors, 0, 160, flag)
+    e_pos, e_alleles, e_x = [], [], []
+    for a, win in zip(anchors, wins):
+        ref = "".join(c if c in "AGTC" else "N" for c in w.ref[a - 1:min(w.length, a + 160)])
+        if "N" in ref:
+            continue
+        d = {recs[k]["name"]: text for k, text in win}
+        names = sorted(d)
+        rows, ref_row = _pad_aligner(names, [d[n] for n in names], ref)
+        if len(rows) < 2:
+            continue
+        mat = np.array([[sym[c] for c in r] for r in rows], np.uint8)
+        x, cns = oracle.indel_tensor(mat, np.array([sym[c] for c in ref_row], np.uint8))
+        e_pos.append(a)
+        e_x.append(x)
+        e_alleles.append(oracle.allele_prediction_ref("".join("AGTC"[c] for c in cns if c != 4), ref, {0: 40, 1: 10}[variants[a]]))
+    assert len(hpos) > 3 and hpos == e_pos and halleles == e_alleles
+    assert np.array_equal(hx.astype(np.float32), np.stack(e_x))

@@ -52,3 +52,16 @@ def test_indel_window_scan_matches_reference_pass1():
                                      small_win_size=c["small_win_size"], ins_t=c["ins_t"], del_t=c["del_t"],
                                      exclude=c["exclude"])
         assert np.array_equal(pos, c["pos"]) and np.array_equal(typ, c["type"]), (c["start"], c["end"])
+
+
+def test_haploid_indel_window_scan_matches_reference_pass1():
+    """generate_indel_pileups_haploid.py:185-241: the `variants` dict captured from the reference's own frame"""
+    from tests.util import indel_scan_cases, load_world
+    world = load_world("indel")
+    cases = indel_scan_cases(haploid=True)
+    assert len(cases) >= 5 and sum(len(c["pos"]) for c in cases) > 40
+    for c in cases:
+        pos, typ = oracle.indel_scan(world, c["start"], c["end"], mincov=c["mincov"], win_size=c["win_size"],
+                                     small_win_size=c["small_win_size"], ins_t=c["ins_t"], del_t=c["del_t"],
+                                     exclude=c["exclude"], haploid=True)
+        assert np.array_equal(pos, c["pos"]) and np.array_equal(typ, c["type"]), (c["start"], c["end"])

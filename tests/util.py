@@ -58,8 +58,8 @@ def assert_tuple_matches_gold(out, gold):
     assert np.array_equal(np.asarray(rev), gold["rev_dp"])
 
 
-def indel_scan_cases():
-    z = np.load(os.path.join(GOLD, "indel_scan.npz"))
+def indel_scan_cases(haploid=False):
+    z = np.load(os.path.join(GOLD, "indel_scan_hap.npz" if haploid else "indel_scan.npz"))
     out = []
     for k in range(int(z["n"])):
         out.append(dict(start=int(z["s%d_start" % k]), end=int(z["s%d_end" % k]), mincov=int(z["s%d_mincov" % k]),
