@@ -30,7 +30,7 @@ SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3 (h
 TRUNK_FLOP_PER_SITE = 2 * (574_000 + 737_280 + 331_776)   # conv1 (3 kernels) + conv2 + conv3, SURVEY.md Appendix C.1
 # HBM bytes per launch of the fused trunk kernel, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: profiles/r01b_pmc.md (k4_conv12: r01_final_pmc.md, same bytes)
-TRUNK_TRAFFIC_PER_SITE = (2 * 68.53e6 + 215.87e6) / 31231      # k5_trunk_h3, profiles/r01b_pmc.md (31,231 sites per launch on average)
+TRUNK_TRAFFIC_PER_SITE = (2 * 68.53e6 + 215.87e6) / 31231      # k5_trunk_h3, profiles/r01b_pmc.md (measured at 31,231 sites per launch; same per site at 62,462: r01d)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md, dense
 # k5_trunk_h3 issues 3 f16 MFMA products per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so the peak its ALGORITHMIC
