@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--length", type=int, default=CHR20_LEN, help="contig length per GPU (default chr20)")
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--tech", default="ont", choices=["ont", "hifi"])
