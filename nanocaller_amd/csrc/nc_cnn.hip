@@ -688,23 +688,14 @@ __device__ __forceinline__ void t_conv2(const _Float16 *A1H, _Float16 *A2H, cons
     for (int G = 0; G < 9; G++) {
         const int cur = G & 1;
         if (G + 1 < 9) load2(G + 1, cur ^ 1);
-#ifndef NC_V3
         __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef NC_V1
-#pragma unroll
-        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], ah[cur][tm]) NC_MFMA(acc[tm], wh[G], al[cur][tm]) NC_MFMA(acc[tm], wl[G], ah[cur][tm]) }
-#else
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], ah[cur][tm]) }
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], al[cur][tm]) }
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wl[G], ah[cur][tm]) }
-#endif
-#ifndef NC_V3
         __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) split4_store(selu4_scaled(acc[tm], epi), A2H + obase[tm], A2H + obase[tm] + T_A2PLANE);
