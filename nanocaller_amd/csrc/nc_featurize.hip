@@ -6,12 +6,15 @@
 // (which tile entries cover the site; strand/base depth ballots), then as tensor columns (lane j gathers
 // the code of each sampled read at column j and keeps a 4x4 histogram in packed 16-bit counters).  The
 // site tensor is assembled in LDS and four sites leave the workgroup as one aligned, coalesced dwordx4 stream.
+#include <type_traits>
+
 #include "nc_common.h"
 
 namespace {
 
 constexpr int MAXCOV_CAP = 1024;   // LDS list of sampled reads per wave: largest supported maxcov
-constexpr int MAXCOV_SMALL = 256;  // instantiation for maxcov <= 256 (default 160): 20.5 KB of LDS per block -> 7 waves per SIMD instead of 4
+constexpr int MAXCOV_SMALL = 256;  // instantiation for maxcov <= 255 (default 160): 20.5 KB of LDS per block -> 7 waves per SIMD instead of 4,
+                                   // and 8-bit histogram fields (32-bit instead of 64-bit counter updates)
 constexpr int NBR = 20;
 
 struct Bucket { int32_t dlo, dhi, k, far; };     // distance range (dlo, dhi], pick k, far=1: farthest k
@@ -168,7 +171,12 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 
         const bool ok = ncols >= a.min_nbr_sites;               // :244, the list includes the candidate itself
         // ---- K3: lane j gathers column j of every sampled read
-        unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
+        // cnt[i] = per-lane counts of bases 0..3 at this column among the reads whose centre base is i.  maxcov <= 255 (the
+        // small instantiation): four 8-bit fields in one dword; otherwise four 16-bit fields in a qword.
+        constexpr bool BYTE_CNT = CAP == MAXCOV_SMALL;
+        using cnt_t = typename std::conditional<BYTE_CNT, uint32_t, unsigned long long>::type;
+        constexpr int FIELD = BYTE_CNT ? 8 : 16;
+        cnt_t cnt[4] = {0, 0, 0, 0};
         if (ok) {
             for (int i0 = 0; i0 < ns; i0 += 8) {
                 // 8 reads per round: all entry loads, then all code gathers, are issued before the first use
@@ -188,10 +196,10 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int b = bcode[u];
-                    const int c = __shfl(b, nl, 64);                 // centre base of this read (4 if past the end)
-                    const unsigned long long inc = b < 4 ? (1ull << (16 * b)) : 0ull;
+                    const int c = __builtin_amdgcn_readlane(b, nl);  // centre base of this read (4 if past the end): wave-uniform
+                    const cnt_t inc = b < 4 ? ((cnt_t)1 << (FIELD * b)) : (cnt_t)0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) cnt[k] += (c == k) ? inc : 0ull;
+                    for (int k = 0; k < 4; k++) cnt[k] += (c == k) ? inc : (cnt_t)0;
                 }
             }
             // ---- assemble (Appendix A step 5)
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
                 for (int i = 0; i < 4; i++) {
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
-                        const int val = (int)((cnt[i] >> (16 * b)) & 0xFFFF);
+                        const int val = (int)((cnt[i] >> (FIELD * b)) & ((1 << FIELD) - 1));
                         Xc[(1 + i) * 41 * 5 + b] = (float)(b == rc_col ? -val : val);
                     }
                     Xc[(1 + i) * 41 * 5 + 4] = (i == rc_centre) ? 1.0f : 0.0f;
@@ -334,7 +342,7 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     NcTimer tm(ctx, 1);
     hipLaunchKernelGGL(k_nbr_index, dim3((n_cidx + 255) / 256), dim3(256), 0, ctx->stream, a.nbr_pos, a.n_nbr, a.cidx_pos0, n_cidx,
                        (int32_t *)ctx->nbr_idx.p);
-    if (maxcov <= MAXCOV_SMALL)
+    if (maxcov < MAXCOV_SMALL)                              // 8-bit counter fields: at most 255 sampled reads
         hipLaunchKernelGGL(k_featurize<MAXCOV_SMALL>, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(k_featurize<MAXCOV_CAP>, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);

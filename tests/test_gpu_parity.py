@@ -104,6 +104,24 @@ def test_maxcov_policy_matches_oracle(eng, maxcov):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+@pytest.mark.parametrize("maxcov", [255, 256])
+def test_very_deep_pileup_counter_limits(eng, maxcov):
+    """depth ~330 with maxcov 255 / 256: the two featuriser instantiations at their boundary (8-bit histogram fields hold
+    exactly 255; 256 switches to 16-bit fields), and the scan's byte-lane counters widening every 255 reads"""
+    from nanocaller_amd.generate_SNP_pileups import get_snp_testing_candidates
+    from nanocaller_amd.synth import make_world
+    from oracle import oracle
+    world = make_world(seed=77, length=9_000, depth=330, tech="hifi", read_len_scale=0.2)
+    dct = dict(threshold=[0.4, 0.6], mincov=4, maxcov=maxcov, min_allele_freq=0.15, min_nbr_sites=1, seq="pacbio",
+               supplementary=False, exclude_bed=None)
+    region = dict(chrom=world.chrom, start=2_000, end=7_000, ploidy="diploid")
+    a = get_snp_testing_candidates(_dct(world, dct, None), region)
+    b = oracle.get_snp_testing_candidates(world, dct, region)
+    assert len(a[0]) > 3 and max(a[3]) > 256 and np.abs(a[2]).max() >= 200
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def _golden_inputs(case):
     _, _, _, _, gold = load_snp_case(case)
     ref_code = np.argmax(gold["ref"], 1).astype(np.int32)
