@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 1
+#define NC_ABI_VERSION 2   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points */
 
 typedef struct nc_ctx nc_ctx;
 

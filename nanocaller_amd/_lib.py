@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnanocaller_hip.so")
 
 NC_OK = 0
+ABI_VERSION = 2          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -90,6 +91,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.nc_abi_version.restype = C.c_int
+        if L.nc_abi_version() != ABI_VERSION:
+            raise NanoCallerHipError("%s has ABI version %d, this binding needs %d: rebuild it" % (LIB_PATH, L.nc_abi_version(), ABI_VERSION))
         L.nc_device_count.argtypes = [C.POINTER(C.c_int)]
         L.nc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.nc_ctx_destroy.argtypes = [vp]
