@@ -326,6 +326,12 @@ int nc_snp_vcf_format(const char *chrom, int64_t n, const int32_t *pos, const in
  * reference's exact records re-sorts those rows with numpy before passing `order` to nc_snp_vcf_format. */
 int nc_argsort4(const float *probs, int64_t n, int32_t *order, int64_t *n_ties, int64_t *tie_idx, int64_t tie_cap);
 
+/* BGZF compression of a byte stream on all host cores (the `| bgzip >` of snpCaller.py:284-285): blocks of 0xff00 payload
+ * bytes + the EOF block.  block_coff[b] (b = 0..*n_blocks, may be NULL) = compressed offset of block b, from which virtual
+ * file offsets (coffset << 16 | offset in block) for an index are formed.  cap >= n + n/100 + 64*(*n_blocks) + 64 suffices. */
+int nc_bgzf_compress(const uint8_t *data, int64_t n, int32_t level, uint8_t *out, int64_t cap, int64_t *n_out,
+                     int64_t *block_coff, int64_t blk_cap, int64_t *n_blocks);
+
 #ifdef __cplusplus
 }
 #endif

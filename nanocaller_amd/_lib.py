@@ -29,7 +29,7 @@ EXPORTS = [
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
-    "nc_nw_cigar", "nc_allele_prediction",
+    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress",
 ]
 
 
@@ -136,6 +136,7 @@ def lib():
         L.nc_slices_free.argtypes = [vp]
         L.nc_nw_cigar.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
         L.nc_allele_prediction.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+        L.nc_bgzf_compress.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64)]
         L.nc_argsort4.argtypes = [vp, i64, vp, C.POINTER(i64), vp, i64]
         L.nc_snp_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, C.POINTER(i64)]
         for name in EXPORTS:

@@ -3,10 +3,13 @@
 // `order` is numpy's argsort of the four probabilities (ascending) computed by the caller, so ties resolve as in
 // the reference on the same machine (quirk E15).  Number formatting: printf("%.Nf") and Python's '%.Nf' are both
 // correctly rounded conversions of the same double.
+#include <zlib.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -240,4 +243,68 @@ extern "C" int nc_argsort4(const float *probs, int64_t n, int32_t *order, int64_
         }
     *n_ties = w;
     return w > tie_cap ? NC_ERR_CAPACITY : NC_OK;
+}
+
+// BGZF (SAMv1 4.1) compression of a byte stream on all host cores: independent blocks of 0xff00 payload bytes, each a
+// raw-deflate gzip member with the 'BC' extra field; the 28-byte empty EOF block is appended.  block_coff[b] = compressed
+// offset of block b (block_coff[n_blocks] = offset of the EOF block), the numbers virtual file offsets are made of.
+// Replaces the `| bgzip >` of snpCaller.py:284-285.
+extern "C" int nc_bgzf_compress(const uint8_t *data, int64_t n, int32_t level, uint8_t *out, int64_t cap, int64_t *n_out,
+                                int64_t *block_coff, int64_t blk_cap, int64_t *n_blocks)
+{
+    if (n < 0 || (n && !data) || !out || !n_out || !n_blocks || level < 0 || level > 9) return NC_ERR_ARG;
+    constexpr int64_t BLK = 0xff00;
+    const int64_t nb = (n + BLK - 1) / BLK;
+    *n_blocks = nb;
+    if (block_coff && blk_cap < nb + 1) return NC_ERR_CAPACITY;
+    std::vector<std::vector<uint8_t>> comp((size_t)nb);
+    std::vector<int> rc((size_t)nb, 0);
+    auto work = [&](int64_t b) {
+        const uint8_t *src = data + b * BLK;
+        const uInt len = (uInt)std::min<int64_t>(BLK, n - b * BLK);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { rc[(size_t)b] = 1; return; }
+        std::vector<uint8_t> &o = comp[(size_t)b];
+        o.resize(18 + deflateBound(&zs, len) + 8);
+        zs.next_in = const_cast<Bytef *>(src);
+        zs.avail_in = len;
+        zs.next_out = o.data() + 18;
+        zs.avail_out = (uInt)(o.size() - 26);
+        const int r = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (r != Z_STREAM_END || clen + 26 > 65536) { rc[(size_t)b] = 1; return; }
+        const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(o.data(), hdr, 16);
+        const uint32_t bsize = (uint32_t)(clen + 25);
+        o[16] = (uint8_t)(bsize & 0xff); o[17] = (uint8_t)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, len);
+        uint8_t *t = o.data() + 18 + clen;
+        for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)len >> (8 * k)); }
+        o.resize(18 + clen + 8);
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+    if (nb < 8) T = 1;
+    if (T == 1) for (int64_t b = 0; b < nb; b++) work(b);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t]() { for (int64_t b = t; b < nb; b += T) work(b); });
+        for (auto &x : th) x.join();
+    }
+    int64_t w = 0;
+    static const uint8_t EOF_BLK[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t b = 0; b < nb; b++) {
+        if (rc[(size_t)b]) return NC_ERR_ARG;
+        if (block_coff) block_coff[b] = w;
+        if (w + (int64_t)comp[(size_t)b].size() + 28 > cap) return NC_ERR_CAPACITY;
+        memcpy(out + w, comp[(size_t)b].data(), comp[(size_t)b].size());
+        w += (int64_t)comp[(size_t)b].size();
+    }
+    if (block_coff) block_coff[nb] = w;
+    if (w + 28 > cap) return NC_ERR_CAPACITY;
+    memcpy(out + w, EOF_BLK, 28);
+    *n_out = w + 28;
+    return NC_OK;
 }

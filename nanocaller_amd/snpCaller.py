@@ -259,15 +259,9 @@ _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000
 
 
 def bgzf_write(path, data: bytes):
-    with open(path, 'wb') as f:
-        for i in range(0, len(data), 0xff00):
-            blk = data[i:i + 0xff00]
-            co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            comp = co.compress(blk) + co.flush()
-            f.write(struct.pack('<BBBBIBBHBBHH', 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(comp) + 25))
-            f.write(comp)
-            f.write(struct.pack('<II', zlib.crc32(blk) & 0xffffffff, len(blk)))
-        f.write(_BGZF_EOF)
+    """BGZF file through the library's multi-threaded compressor (see vcfio.py)"""
+    from . import vcfio
+    vcfio.bgzf_write(path, data)
 
 
 def _sort_key(line, order):
@@ -316,9 +310,16 @@ def call_manager(params, devices=(0,)):
         with open(fn) as fd:
             lines.extend(fd.readlines())
     order = {c: i for i, c in enumerate(contigs)}
-    lines.sort(key=lambda ln: _sort_key(ln, order))                 # bcftools sort (:284); stable, keeps E3 duplicates
-    bgzf_write(all_path, (header + ''.join(lines)).encode())
-    passed = [ln for ln in lines if ln.split('\t', 7)[6] == 'PASS']  # bcftools view -f PASS (:285)
-    bgzf_write(pass_path, (header + ''.join(passed)).encode())
+    keyed = []
+    for ln in lines:                                                # CHROM, POS, REF, FILTER of every record
+        f = ln.split('\t', 7)
+        keyed.append((order.get(f[0], 1 << 30), int(f[1]), len(f[3]), f[6] == 'PASS', ln))
+    keyed.sort(key=lambda k: (k[0], k[1]))                          # bcftools sort (:284); stable, keeps E3 duplicates
+    from . import vcfio
+    for path, recs in ((all_path, keyed), (pass_path, [k for k in keyed if k[3]])):     # bcftools view -f PASS (:285)
+        body = ''.join(k[4] for k in recs).encode()
+        vcfio.write_vcf_gz_with_csi(path, header, body, contigs, np.array([k[0] for k in recs], np.int64),
+                                    np.array([k[1] for k in recs], np.int64), np.array([k[2] for k in recs], np.int64),
+                                    np.array([len(k[4].encode()) for k in recs], np.int64))   # + <path>.csi (tabix -p vcf --csi)
     shard.barrier()
     return pass_path

@@ -1,0 +1,138 @@
+"""BGZF + CSI writer: the files are read back with an independent reader that follows the CSIv1 / tabix /
+BGZF specifications; region queries through the index must return exactly the overlapping records.  htslib / tabix /
+bcftools are absent from this image, so interoperability with them is unpinned."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from nanocaller_amd import vcfio
+
+
+def _read_block(raw, coff):
+    """-> (payload bytes, next compressed offset) of the BGZF block at `coff`"""
+    assert raw[coff:coff + 4] == b"\x1f\x8b\x08\x04"
+    xlen = struct.unpack_from("<H", raw, coff + 10)[0]
+    extra = raw[coff + 12:coff + 12 + xlen]
+    bsize, p = None, 0
+    while p < xlen:
+        si1, si2, slen = extra[p], extra[p + 1], struct.unpack_from("<H", extra, p + 2)[0]
+        if (si1, si2, slen) == (66, 67, 2):
+            bsize = struct.unpack_from("<H", extra, p + 4)[0] + 1
+        p += 4 + slen
+    cdata = raw[coff + 12 + xlen:coff + bsize - 8]
+    crc, isize = struct.unpack_from("<II", raw, coff + bsize - 8)
+    data = zlib.decompress(cdata, -15)
+    assert len(data) == isize and (zlib.crc32(data) & 0xffffffff) == crc
+    return data, coff + bsize
+
+
+def _read_range(raw, vbeg, vend):
+    """bytes between two virtual offsets"""
+    out, coff, off = [], vbeg >> 16, vbeg & 0xffff
+    while True:
+        data, nxt = _read_block(raw, coff)
+        if coff == vend >> 16:
+            out.append(data[off:vend & 0xffff])
+            break
+        out.append(data[off:])
+        coff, off = nxt, 0
+    return b"".join(out)
+
+
+def _parse_csi(blob):
+    assert blob[:4] == b"CSI\1"
+    min_shift, depth, l_aux = struct.unpack_from("<3i", blob, 4)
+    aux = blob[16:16 + l_aux]
+    fmt, col_seq, col_beg, col_end, meta, skip, l_nm = struct.unpack_from("<7i", aux, 0)
+    names = aux[28:28 + l_nm].split(b"\0")[:-1]
+    p = 16 + l_aux
+    n_ref = struct.unpack_from("<i", blob, p)[0]
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", blob, p)[0]
+        p += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, loff, n_chunk = struct.unpack_from("<IQi", blob, p)
+            p += 16
+            chunks = [struct.unpack_from("<QQ", blob, p + 16 * k) for k in range(n_chunk)]
+            p += 16 * n_chunk
+            bins[b] = (loff, chunks)
+        refs.append(bins)
+    n_no_coor = struct.unpack_from("<Q", blob, p)[0]
+    assert p + 8 == len(blob)
+    return dict(min_shift=min_shift, depth=depth, conf=(fmt, col_seq, col_beg, col_end, meta, skip), names=[n.decode() for n in names],
+                refs=refs, n_no_coor=n_no_coor)
+
+
+def _reg2bins(beg, end, min_shift, depth):
+    """bins that may hold records overlapping [beg, end) (hts_reg2bins)"""
+    out, s, t = [], min_shift + depth * 3, 0
+    end -= 1
+    for lv in range(depth + 1):
+        out += list(range(t + (beg >> s), t + (end >> s) + 1))
+        t += 1 << (lv * 3)
+        s -= 3
+    return out
+
+
+@pytest.mark.parametrize("seed,n", [(1, 40_000), (2, 7)])
+def test_bgzf_csi_roundtrip_and_region_queries(tmp_path, seed, n):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    contigs = ["chr20", "chrX", "scaffold_7"]
+    tid = np.sort(rng.integers(0, 3, size=n))
+    pos = np.zeros(n, np.int64)
+    for r in range(3):
+        m = tid == r
+        pos[m] = np.sort(rng.integers(1, 90_000_000 if r == 0 else 400_000, size=int(m.sum())))
+    ref_len = np.where(rng.random(n) < 0.8, 1, rng.integers(2, 40, size=n))
+    lines = [("%s\t%d\t.\t%s\tA\t%.3f\tPASS\tX=%d\tGT\t0/1\n" % (contigs[t], p, "C" * rl, rng.random() * 99, i)).encode()
+             for i, (t, p, rl) in enumerate(zip(tid, pos, ref_len))]
+    header = "##fileformat=VCFv4.2\n" + "".join("##contig=<ID=%s>\n" % c for c in contigs) + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+    path = str(tmp_path / "t.vcf.gz")
+    vcfio.write_vcf_gz_with_csi(path, header, b"".join(lines), contigs, tid, pos, ref_len, np.array([len(x) for x in lines]))
+    raw = open(path, "rb").read()
+    assert gzip.decompress(raw) == header.encode() + b"".join(lines)          # a valid multi-member gzip stream
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    idx = _parse_csi(gzip.decompress(open(path + ".csi", "rb").read()))
+    assert (idx["min_shift"], idx["depth"], idx["conf"], idx["names"], idx["n_no_coor"]) == (14, 5, (2, 1, 2, 0, 35, 0), contigs, 0)
+    meta_bin = ((1 << 18) - 1) // 7 + 1
+    for r in range(3):
+        assert idx["refs"][r][meta_bin][1][1] == (int((tid == r).sum()), 0)     # mapped / unmapped counts of the pseudo-bin
+    queries = [(0, 0, 1 << 29), (1, 0, 1 << 29), (2, 100, 101)]
+    for _ in range(60):
+        r = int(rng.integers(0, 3))
+        a = int(rng.integers(0, 90_000_000 if r == 0 else 400_000))
+        queries.append((r, a, a + int(rng.choice([1, 50, 20_000, 3_000_000]))))
+    for (r, a, b) in queries:
+        want = [lines[i] for i in np.flatnonzero((tid == r) & (pos - 1 < b) & (pos - 1 + ref_len > a))]
+        bins = idx["refs"][r]
+        got = []
+        seen = set()
+        lin_min = min([bins[x][0] for x in _reg2bins(a, b, 14, 5) if x in bins] or [0])
+        for x in _reg2bins(a, b, 14, 5):
+            if x not in bins:
+                continue
+            for (cb, ce) in bins[x][1]:
+                if ce <= lin_min:
+                    continue
+                for rec in _read_range(raw, cb, ce).splitlines(keepends=True):
+                    f = rec.split(b"\t", 4)
+                    p0 = int(f[1]) - 1
+                    if f[0].decode() == contigs[r] and p0 < b and p0 + len(f[3]) > a and rec not in seen:
+                        seen.add(rec)
+                        got.append((p0, rec))
+        got = [rec for _, rec in sorted(got, key=lambda t: t[0])]
+        assert sorted(got) == sorted(want), (r, a, b, len(got), len(want))
+
+
+def test_bgzf_empty_and_block_boundaries():
+    for n in (0, 1, vcfio.BGZF_BLOCK - 1, vcfio.BGZF_BLOCK, vcfio.BGZF_BLOCK + 1, 3 * vcfio.BGZF_BLOCK):
+        data = bytes(np.random.Generator(np.random.PCG64(n)).integers(0, 256, size=n, dtype=np.uint8))
+        comp, coff = vcfio.bgzf_compress(data)
+        assert gzip.decompress(comp.tobytes()) == data
+        assert len(coff) == (n + vcfio.BGZF_BLOCK - 1) // vcfio.BGZF_BLOCK + 1 and coff[-1] == len(comp) - 28
