@@ -198,7 +198,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if exact_fp32 else "f32 (f16x3 split MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx %s, chr20-sized contig (%d bp, %d chunks of 500 kb) per GPU"
                        % (args.tech.upper(), args.depth, args.ploidy, L, len(chunks)), "sites_per_gpu": n_sites,
-                       "pileup_entries_per_gpu": info["pileup_entries"], "model": args.model, "generator": "synth_v1 seed 812+rank",
+                       "pileup_entries_per_gpu": info["pileup_entries"], "snp_weights": args.model, "generator": "synth_v1 seed 812+rank",
                        "data_gen_s": round(t_gen, 2)},
             "roofline": roofline,
             "three_numbers": {"kernels_only_sites_s": n_sites / ((stage_ms[0] + stage_ms[1] + stage_ms[2]) * 1e-3),
