@@ -398,3 +398,26 @@ def test_degenerate_inputs(eng):
     z = torch.zeros((0, 5, 41, 5), device="cuda")
     p, g = eng.snp_forward(_lib.MODEL_SNP, z, torch.zeros(0, dtype=torch.int32, device="cuda"), torch.zeros(0, dtype=torch.float64, device="cuda"))
     assert p.shape == (0, 4) and g.shape == (0, 2)
+
+
+def test_call_chunks_with_min_nbr_sites_filter(eng):
+    """min_nbr_sites > 1 drops sites on the host after the batched device pass (generate_SNP_pileups.py:244): the kept
+    sites and every per-site array must equal the per-chunk oracle"""
+    from nanocaller_amd import snpCaller
+    from oracle import oracle
+    w = load_world("ont")
+    base = dict(threshold=[0.4, 0.6], mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, seq="ont", supplementary=False,
+                exclude_bed=None)
+    chunks = [dict(chrom=w.chrom, start=1_000, end=30_000, ploidy="diploid"), dict(chrom=w.chrom, start=30_000, end=70_000, ploidy="diploid")]
+    # number of real tensor columns of every site (row 0 is the reference one-hot): put the threshold at the median
+    ncols = np.concatenate([np.asarray(oracle.get_snp_testing_candidates(w, base, c)[2])[:, 0, :, :4].sum(axis=(1, 2)) for c in chunks])
+    base["min_nbr_sites"] = int(np.median(ncols)) + 1
+    r = snpCaller.call_chunks(dict(base, snp_model="ONT-HG002", disable_coverage_normalization=False, sam_path=w), chunks)
+    exp = [oracle.get_snp_testing_candidates(w, base, c) for c in chunks]
+    pos = np.concatenate([np.asarray(e[0], np.int64) for e in exp])
+    all_sites = sum(len(oracle.get_snp_testing_candidates(w, dict(base, min_nbr_sites=1), c)[0]) for c in chunks)
+    assert 0 < len(pos) < all_sites                                    # the filter really dropped something
+    assert np.array_equal(r["pos"], pos) and r["n"] == len(pos)
+    assert np.array_equal(r["dp"], np.concatenate([np.asarray(e[3]) for e in exp]))
+    assert np.array_equal(r["fwd_dp"], np.concatenate([np.asarray(e[6]) for e in exp]).astype(np.int32))
+    assert r["probs"].shape == (len(pos), 4) and r["freq"].shape == (len(pos),)
