@@ -115,10 +115,12 @@ def argsort4(probs):
     return order
 
 
-def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None, haploid=False, as_array=False):
+def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None, haploid=False, as_array=False, out=None):
     """Same records as snp_vcf_lines / snp_vcf_lines_haploid, formatted by the library's native formatter
     (nc_snp_vcf_format); ties in the allele order resolve exactly as in the Python path (argsort4, E15).
-    -> bytes, or with as_array=True a uint8 array (buffer protocol: file.write() takes it without another copy)."""
+    -> bytes, or with as_array=True a uint8 array (buffer protocol: file.write() takes it without another copy).
+    `out`: optional uint8 scratch array to format into (reused by callers that write the text out immediately: saves the
+    page faults of a fresh 400 B/record buffer per call)."""
     import ctypes as C
     L = _lib.lib()
     n = len(pos)
@@ -130,7 +132,9 @@ def snp_vcf_text(chrom, pos, ref_idx, probs, dp, freq, fwd_dp=None, rev_dp=None,
     fwd_ = None if haploid else i32(fwd_dp)
     rev_ = None if haploid else i32(rev_dp)
     cap = (400 + len(chrom)) * max(n, 1) + 1024
-    out = np.empty(cap, np.uint8)
+    if out is None or out.size < cap:
+        out = np.empty(cap, np.uint8)
+    cap = out.size
     nb = C.c_int64()
     rc = L.nc_snp_vcf_format(chrom.encode(), n, _lib.npp(pos_), _lib.npp(ref_), _lib.npp(probs), _lib.npp(order),
                              _lib.npp(dp_), _lib.npp(freq_), _lib.npp(fwd_), _lib.npp(rev_), 1 if haploid else 0,
@@ -241,17 +245,34 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
     groups = {}
     for c in chunks:
         groups.setdefault((c['chrom'], c['ploidy']), []).append(c)
-    with open(curr_vcf_path, 'wb') as f:
+    # Host pipeline: the genotype rules + record text of one (contig, ploidy) group are produced and written by a worker
+    # thread (the formatter is native code: the GIL is released) while the GPU already works on the next group.
+    from concurrent.futures import ThreadPoolExecutor
+
+    scratch = [None]
+
+    def emit(f, chrom, ploidy, r, grp):
+        if r['n']:
+            need = (400 + len(chrom)) * r['n'] + 1024
+            if scratch[0] is None or scratch[0].size < need:
+                scratch[0] = np.empty(need + need // 4, np.uint8)
+            f.write(snp_vcf_text(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq'], r['fwd_dp'], r['rev_dp'],
+                                 haploid=(ploidy != 'diploid'), as_array=True, out=scratch[0]))
+        f.flush()
+        os.fsync(f.fileno())
+        for _ in grp:
+            counter_Q.put(1)
+
+    with open(curr_vcf_path, 'wb') as f, ThreadPoolExecutor(max_workers=1) as pool:
+        pending = None
         for (chrom, ploidy), grp in groups.items():
             grp.sort(key=lambda c: c['start'])
             r = call_chunks(params, grp, device)
-            if r['n']:
-                f.write(snp_vcf_text(chrom, r['pos'], r['ref'], r['probs'], r['dp'], r['freq'], r['fwd_dp'], r['rev_dp'],
-                                     haploid=(ploidy != 'diploid'), as_array=True))
-            f.flush()
-            os.fsync(f.fileno())
-            for _ in grp:
-                counter_Q.put(1)
+            if pending is not None:
+                pending.result()                                    # keeps the records in group order; re-raises errors
+            pending = pool.submit(emit, f, chrom, ploidy, r, grp)
+        if pending is not None:
+            pending.result()
 
 
 # ------------------------------------------------------------------ BGZF (so no bgzip binary is needed)
