@@ -270,6 +270,8 @@ int nc_bam_close(nc_bam *bam);
 int nc_bam_n_refs(nc_bam *bam, int32_t *n_refs, int32_t *has_index);
 int nc_bam_ref(nc_bam *bam, int32_t i, const char **name, int32_t *length);
 const char *nc_bam_error(const nc_bam *bam);
+/* host threads that inflate BGZF blocks for this handle (0 = all cores up to 32; 1 when many handles decode regions in parallel) */
+int nc_bam_set_threads(nc_bam *bam, int32_t n);
 /* alignments of reference `tid` overlapping [beg1, end1] (1-based, inclusive), in coordinate order */
 int nc_bam_decode(nc_bam *bam, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, nc_decoded **out);
 int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *view);

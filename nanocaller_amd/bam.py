@@ -38,6 +38,10 @@ class BamFile:
             self.references.append(nm.value.decode())
             self.lengths.append(ln.value)
 
+    def set_threads(self, n):
+        """host threads inflating BGZF blocks for this handle (0 = all cores up to 32)"""
+        self.L.nc_bam_set_threads(self.h, int(n))
+
     def close(self):
         if self.h:
             self.L.nc_bam_close(self.h)
@@ -136,11 +140,67 @@ def read_fasta(path, chrom):
     return "".join(seq)
 
 
-def read_bam(bam_path, fasta_path, chrom, start=1, end=None, keep_seq=False) -> World:
-    """Decoded alignments of `chrom` overlapping [start, end] + the contig's reference sequence."""
+def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=None, min_region=2_000_000):
+    """BamFile.decode of a long interval as parallel regions: each host thread opens its own handle, seeks through the
+    .bai linear index and decodes the alignments that START in its region (the first region also takes those that merely
+    overlap its left edge); inflate, CIGAR walk and tag parsing all scale with the threads (the native calls release the
+    GIL).  Same result as one sequential decode."""
+    from concurrent.futures import ThreadPoolExecutor
     bf = BamFile(bam_path)
-    d = bf.decode(chrom, start, end, keep_seq)
+    tid_len = bf.get_reference_length(chrom)
+    has_index = bf.has_index
     bf.close()
+    end = tid_len if end is None else min(int(end), tid_len)
+    start = max(1, int(start))
+    threads = threads or min(32, os.cpu_count() or 1)
+    n_reg = min(threads, max(1, (end - start + 1) // min_region))
+    if n_reg <= 1 or not has_index:
+        bf = BamFile(bam_path)
+        d = bf.decode(chrom, start, end, keep_seq)
+        bf.close()
+        return d
+    edges = [start + (end - start + 1) * k // n_reg for k in range(n_reg)] + [end + 1]
+
+    def one(k):
+        b = BamFile(bam_path)
+        b.set_threads(max(1, threads // n_reg))              # the regions are the parallelism: do not oversubscribe
+        d = b.decode(chrom, edges[k], edges[k + 1] - 1, keep_seq)
+        b.close()
+        if k == 0:
+            return d
+        cut = int(np.searchsorted(d["read_start"], edges[k], side="left"))       # reads starting before the region belong to an earlier one
+        out = {}
+        for key in ("read_start", "read_end", "read_flag", "hap", "ps", "qstart"):
+            out[key] = d[key][cut:]
+        for off_key, data_key in (("read_off", "codes"), ("ev_off", None), ("seq_off", "seq")):
+            o = d[off_key]
+            out[off_key] = o[cut:] - o[cut]
+            if data_key:
+                out[data_key] = d[data_key][o[cut]:]
+        e0 = d["ev_off"][cut]
+        out["ev_pos"], out["ev_len"] = d["ev_pos"][e0:], d["ev_len"][e0:]
+        out["names"] = d["names"][cut:]
+        return out
+
+    with ThreadPoolExecutor(n_reg) as ex:
+        parts = list(ex.map(one, range(n_reg)))
+    out = {}
+    for key in ("read_start", "read_end", "read_flag", "hap", "ps", "qstart", "codes", "ev_pos", "ev_len", "seq"):
+        out[key] = np.concatenate([p[key] for p in parts])
+    for off_key, data_key in (("read_off", "codes"), ("ev_off", "ev_pos"), ("seq_off", "seq")):
+        offs, base = [np.zeros(1, parts[0][off_key].dtype)], 0
+        for p in parts:
+            offs.append(p[off_key][1:] + base)
+            base += int(p[off_key][-1])
+        out[off_key] = np.concatenate(offs).astype(parts[0][off_key].dtype)
+    out["names"] = [n for p in parts for n in p["names"]]
+    return out
+
+
+def read_bam(bam_path, fasta_path, chrom, start=1, end=None, keep_seq=False, threads=None) -> World:
+    """Decoded alignments of `chrom` overlapping [start, end] + the contig's reference sequence (long intervals are
+    decoded as parallel regions, see decode_parallel)."""
+    d = decode_parallel(bam_path, chrom, start, end, keep_seq, threads)
     ref = read_fasta(fasta_path, chrom)
     w = World(chrom=chrom, ref=ref, read_start=d["read_start"], read_end=d["read_end"], read_flag=d["read_flag"],
               read_off=d["read_off"], codes=d["codes"], names=d["names"])

@@ -36,6 +36,7 @@ struct Bgzf {
     std::vector<Blk> win;       // inflated window, consecutive blocks
     size_t wi = 0;              // next block of the window to hand out
     size_t grow = 16;           // blocks to read ahead next time
+    int max_threads = 0;        // inflate threads (0 = all cores, capped at 32)
     std::vector<uint8_t> block;
     int64_t block_coff = 0;     // compressed offset of the current block
     int64_t next_coff = 0;
@@ -107,6 +108,7 @@ struct Bgzf {
         unsigned hw = std::thread::hardware_concurrency();
         size_t T = hw ? (hw > 32 ? 32 : hw) : 1;
         if (const char *e = getenv("NC_BAM_THREADS")) T = (size_t)std::max(1, atoi(e));       // 1 = sequential inflate
+        if (max_threads > 0) T = (size_t)max_threads;
         if (T > n / 4) T = n / 4;                             // a thread per >= 4 blocks
         if (T <= 1) {
             for (auto &k : win) inflate_blk(k);
@@ -416,6 +418,13 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
     }
     if (err) { delete d; return bam_fail(b, NC_ERR_ARG, "truncated or corrupt BAM record / BGZF block"); }
     *out = d;
+    return NC_OK;
+}
+
+int nc_bam_set_threads(nc_bam *b, int32_t n)
+{
+    if (!b || n < 0) return NC_ERR_ARG;
+    b->z.max_threads = n;
     return NC_OK;
 }
 

@@ -1,6 +1,7 @@
 // Context, device-memory helpers and the host-side read packer of libnanocaller_hip.so.
 #include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "nc_common.h"
@@ -222,22 +223,53 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
     if (cnt[(size_t)n_tiles] != n_entries || n_entries > INT32_MAX) return NC_ERR_CAPACITY;
     for (int32_t t = 0; t <= n_tiles; t++) tile_off[t] = (int32_t)cnt[(size_t)t];
     std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-    if (!index_only) memset(codes_out, NC_CODE_ABSENT, (size_t)codes_len);
+    // slot bases (sequential, cheap), then the tile entries
+    std::vector<int64_t> base((size_t)(n_reads > 0 ? n_reads : 1), 0);
     int64_t w = 0;   // write cursor (multiple of 16)
     for (int32_t r = 0; r < n_reads; r++) {
-        if (keep && !keep[r]) continue;
-        int64_t lo = floor16(start[r]), hi = ceil16(end[r]);
+        if (keep && !keep[r]) { base[(size_t)r] = -1; continue; }
+        const int64_t lo = floor16(start[r]), hi = ceil16(end[r]);
         if (w + (hi - lo) > codes_len) return NC_ERR_CAPACITY;
-        int64_t base = w - lo;                                  // codes_out[base + p], multiple of 16
-        if (!index_only) memcpy(codes_out + base + start[r], codes_in + off[r], (size_t)(end[r] - start[r]));
+        base[(size_t)r] = w - lo;                               // codes_out[base + p], multiple of 16
         w += hi - lo;
         nc_tile_entry e;
         e.start = start[r];
         e.end = end[r];
-        e.base_flag = base | (strand ? (strand[r] & 7) : 0);          // bit0 reverse strand, bits 1-2 HP tag
+        e.base_flag = base[(size_t)r] | (strand ? (strand[r] & 7) : 0);  // bit0 reverse strand, bits 1-2 HP tag
         int64_t a = std::max<int64_t>(start[r], t0), b = std::min<int64_t>((int64_t)end[r] - 1, t0 + (int64_t)n_tiles * tile_size - 1);
         if (a > b) continue;
         for (int64_t t = (a - t0) / tile_size; t <= (b - t0) / tile_size; t++) tile_ent[cur[(size_t)t]++] = e;
+    }
+    if (!index_only) {
+        // the slots of consecutive reads are consecutive in codes_out: host threads fill disjoint, contiguous ranges
+        unsigned hw = std::thread::hardware_concurrency();
+        int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+        if (n_reads < 4096) T = 1;
+        auto fill = [&](int32_t r0, int32_t r1, int64_t out0, int64_t out1) {
+            memset(codes_out + out0, NC_CODE_ABSENT, (size_t)(out1 - out0));
+            for (int32_t r = r0; r < r1; r++)
+                if (!(keep && !keep[r]))
+                    memcpy(codes_out + base[(size_t)r] + start[r], codes_in + off[r], (size_t)(end[r] - start[r]));
+        };
+        // first output byte of read r's slot = base + floor16(start); kept reads only
+        auto slot0 = [&](int32_t r) { return base[(size_t)r] + floor16(start[r]); };
+        std::vector<int32_t> cut((size_t)T + 1, n_reads);
+        cut[0] = 0;
+        for (int t = 1; t < T; t++) {
+            int32_t r = (int32_t)((int64_t)n_reads * t / T);
+            while (r < n_reads && keep && !keep[r]) r++;        // a range starts at a kept read
+            cut[(size_t)t] = r;
+        }
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) {
+            const int32_t r0 = cut[(size_t)t], r1 = cut[(size_t)t + 1];
+            const int64_t out0 = t == 0 ? 0 : (r0 < n_reads ? slot0(r0) : w);
+            const int64_t out1 = t + 1 == T ? codes_len : (r1 < n_reads ? slot0(r1) : w);
+            if (out1 <= out0 && r1 <= r0) continue;
+            if (T == 1) fill(r0, r1, out0, out1);
+            else th.emplace_back(fill, r0, r1, out0, out1);
+        }
+        for (auto &x : th) x.join();
     }
     return NC_OK;
 }

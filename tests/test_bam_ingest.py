@@ -95,3 +95,21 @@ def test_cigar_edge_cases(tmp_path):
     assert d["hap"].tolist() == [2, 0] and d["ps"].tolist() == [70000, 0] and d["read_flag"].tolist() == [16, 0x800]
     assert d["ev_off"].tolist() == [0, 2, 2]                # a leading insertion has no previous column: no marker
     assert d["codes"][d["read_off"][1]:].tolist() == [0, 3, 1, 2, 4] and d["names"] == ["a", "b"]
+
+
+def test_parallel_region_decode_equals_sequential(files):
+    """decode_parallel (one handle + BAI seek per host thread, reads assigned to the region they start in) returns exactly
+    the sequential decode, including offsets, events, tags, names and query sequences"""
+    from nanocaller_amd.bam import decode_parallel
+    _, bam, _, _ = files
+    bf = BamFile(bam)
+    chrom = bf.references[0]
+    L = bf.lengths[0]
+    seq = bf.decode(chrom, 1, L, keep_seq=True)
+    bf.close()
+    for threads, min_region in ((4, 3_000), (7, 1_000), (3, 10_000_000)):
+        par = decode_parallel(bam, chrom, 1, L, keep_seq=True, threads=threads, min_region=min_region)
+        assert par["names"] == seq["names"]
+        for k in ("read_start", "read_end", "read_flag", "read_off", "codes", "ev_off", "ev_pos", "ev_len", "hap", "ps", "seq_off", "seq",
+                  "qstart"):
+            assert np.array_equal(par[k], seq[k]), k

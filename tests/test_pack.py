@@ -80,3 +80,22 @@ def test_pack_exclusion_and_empty_region():
     empty = make_world(seed=1, length=5000, depth=0.001, read_len_scale=0.05)
     hp2 = pack_world(empty)
     assert hp2.n_tiles >= 1 and hp2.tile_off[-1] == hp2.tile_ent.shape[0]
+
+
+def test_pack_many_reads_threaded_fill():
+    """>= 4096 reads: the packer's copy loop runs on several host threads over disjoint slot ranges -- every kept read's codes
+    and the padding between slots must be exactly as in the single-threaded layout (vectorised check)"""
+    w = make_world(seed=9, length=120_000, depth=40, read_len_scale=0.04, odd_flag_frac=0.1)
+    assert w.n_reads >= 8192
+    hp = pack_world(w, tile_size=2048)
+    keep = (w.read_flag & FLAG_FILTER_DEFAULT) == 0
+    # expected layout: slots of kept reads back to back, base = cursor - floor16(start)
+    cur = 0
+    exp = np.full(hp.codes.size, 7, np.uint8)
+    for i in np.nonzero(keep)[0]:
+        s, e = int(w.read_start[i]), int(w.read_end[i])
+        lo, hi = s & ~15, (e + 15) & ~15
+        exp[cur + (s - lo):cur + (s - lo) + (e - s)] = w.read_codes(i)
+        cur += hi - lo
+    assert cur + 16 == hp.codes.size and np.array_equal(hp.codes, exp)
+    assert hp.tile_off[-1] == len(hp.tile_ent)
