@@ -34,8 +34,8 @@ TRUNK_TRAFFIC_PER_SITE = (2 * 68.53e6 + 215.87e6) / 31231      # k5_trunk_h3, pr
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md, dense
 # k5_trunk_h3 issues 3 f16 MFMA products per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so the peak its ALGORITHMIC
-# FLOP can reach is the dense f16 MFMA peak / 3; it executes 687 v_mfma_f32_16x16x32_f16 per site (K zero-padding incl.)
-H3_MFMA_PER_SITE = 13 * 21 + 10 * 27 + 8 * 18
+# FLOP can reach is the dense f16 MFMA peak / 3; it executes 726 v_mfma_f32_16x16x32_f16 per site (zero-weight tap slots incl.)
+H3_MFMA_PER_SITE = 13 * 24 + 10 * 27 + 8 * 18      # conv1 24 per 16-position tile, conv2 27 per (tile, half of the channels), conv3 18
 HBM_PEAK_GBS = 8000.0
 
 
