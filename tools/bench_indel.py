@@ -1,0 +1,47 @@
+"""Throughput of the indel-path kernels on synthetic data (reporting helper; the headline bench is the SNP path):
+K7 window scan (columns/s), K8 MSA-rows -> tensor (read sets/s), K9 indel CNN (sites/s)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from nanocaller_amd import _lib
+from nanocaller_amd.engine import get_engine
+from nanocaller_amd.pack import pack_world
+from nanocaller_amd.synth import add_indels, make_world
+from nanocaller_amd.weights import Weights, get_indel_model
+
+eng = get_engine(0)
+# ---- K7
+L = 3_000_000
+w = add_indels(make_world(seed=5, length=L, depth=30, tech="ont", read_len_scale=1.0), seed=5)
+dp = eng.upload(pack_world(w))
+chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    nflag = 0
+    for (a, b) in chunks:
+        col = eng.indel_scan(dp, a, b, mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6)
+        nflag += int((col >= 0).sum())
+    dt = time.perf_counter() - t
+print("K7 indel window scan: %d chunks of 100 kb, %.1f ms -> %.1f M columns/s (%d flagged columns)" % (len(chunks), dt * 1e3, L / dt / 1e6, nflag))
+# ---- K8
+rng = np.random.Generator(np.random.PCG64(1))
+S = 4096
+rows = [rng.integers(0, 5, size=(30, 170)).astype(np.uint8) for _ in range(S)]
+refs = [rng.integers(0, 5, size=170).astype(np.uint8) for _ in range(S)]
+eng.indel_tensor(rows[:16], refs[:16])
+torch.cuda.synchronize(); t = time.perf_counter()
+x, cns = eng.indel_tensor(rows, refs)
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+print("K8 MSA rows -> tensor (incl. host marshalling of %d read sets of 30x170): %.1f ms -> %.0f sets/s" % (S, dt * 1e3, S / dt))
+# ---- K9
+for name, kind, shape, flop in (("ONT-HG002", _lib.MODEL_INDEL, (15, 128, 2), 18_946_752), ("haploid", _lib.MODEL_INDEL_HAP, (5, 128, 2), 5_040_688)):
+    eng.load_weights(kind, Weights(get_indel_model(name)))
+    n = 65536
+    xx = torch.rand((n,) + shape, device="cuda") - 0.3
+    eng.indel_forward(kind, xx); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        eng.indel_forward(kind, xx)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 3
+    print("K9 indel CNN %-10s %d sites: %.2f ms -> %.2f M sites/s, %.1f TFLOP/s" % (name, n, dt * 1e3, n / dt / 1e6, n * flop / dt / 1e12))
