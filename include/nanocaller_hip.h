@@ -235,6 +235,14 @@ typedef struct {
 int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
                   int32_t start, int32_t end, const nc_indel_scan_params *params, int8_t *col_type_host);
 
+/* The same for many chunks of one contig in one call (chunks keep their per-chunk semantics: the window deques start
+ * empty at each chunk's first column, as in the reference, which calls the function once per chunk): col_type of chunk c
+ * is written at col_type_host + col_off[c] (max(1,start_c) .. end_c).  Kernels of up to 64 chunks are enqueued back to
+ * back and synchronised once. */
+int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
+                        int32_t n_chunks, const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *params,
+                        int8_t *col_type_host, const int64_t *col_off);
+
 /* ------------------------------------------------------------------ BGZF / BAM (+ .bai linear index) ingest, host side
  * Replaces the pysam/htslib objects of the reference (pysam.Samfile(...).fetch / .pileup, generate_SNP_pileups.py:
  * 134-164; generate_indel_pileups.py:147,178-188,213-235): a coordinate-sorted BAM is decoded straight into the

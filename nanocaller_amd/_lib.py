@@ -29,7 +29,7 @@ EXPORTS = [
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
-    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads",
+    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch",
 ]
 
 
@@ -122,6 +122,7 @@ def lib():
         L.nc_indel_forward.argtypes = [vp, i32, i64, vp, vp]
         L.nc_indel_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.nc_indel_scan.argtypes = [vp, C.POINTER(ReadPackC), C.POINTER(IndelEventsC), vp, i32, i32, C.POINTER(IndelScanParamsC), vp]
+        L.nc_indel_scan_batch.argtypes = [vp, C.POINTER(ReadPackC), C.POINTER(IndelEventsC), vp, i32, vp, vp, C.POINTER(IndelScanParamsC), vp, vp]
         L.nc_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.nc_bam_close.argtypes = [vp]
         L.nc_bam_set_threads.argtypes = [vp, i32]

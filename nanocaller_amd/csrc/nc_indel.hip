@@ -295,28 +295,25 @@ __global__ void k_indel_decide(const int32_t *__restrict__ depth, const int32_t 
 
 }   // namespace
 
-extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start,
-                             int32_t end, const nc_indel_scan_params *prm, int8_t *col_type_host)
+// workspace of one chunk: depth[3][ncol] | rank[ncol+1] | diff[8][nd] | col_type[ncol]   (16-byte aligned total)
+static size_t indel_ws_bytes(int32_t ncol, int32_t win) 
 {
-    if (!ctx) return NC_ERR_ARG;
-    if (!pack || !ev || !prm || !col_type_host || end < start) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: bad argument");
+    const int32_t nd = ncol + win + 2;
+    return (((size_t)3 * ncol * 4 + ((size_t)ncol + 1) * 4 + (size_t)8 * nd * 4 + (size_t)ncol + 16) + 15) & ~(size_t)15;
+}
+
+// enqueue the kernels of one chunk on the context's stream (workspace `ws` must be zeroed); -> device pointer of col_type
+static int8_t *indel_enqueue(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start, int32_t end,
+                             const nc_indel_scan_params *prm, char *ws)
+{
     const int tile = pack->tile_size;
-    if (!(tile == 1024 || tile == 2048 || tile == 4096)) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: malformed read pack");
-    if (prm->win_size < 1 || prm->small_win_size < 1 || prm->win_size > 4096) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: window sizes");
-    NC_HIP(ctx, hipSetDevice(ctx->device));
     const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
     const int32_t lo = start < 1 ? 1 : start, hi = end;
     const int32_t ncol = hi - lo + 1;
-    // workspace: depth[3][ncol] | rank[ncol+1] | diff[8][nd] | col_type[ncol]
     const int32_t nd = ncol + prm->win_size + 2;
-    const size_t o_depth = 0, o_rank = o_depth + (size_t)3 * ncol * 4, o_diff = o_rank + ((size_t)ncol + 1) * 4,
-                 o_type = o_diff + (size_t)8 * nd * 4, total = o_type + (size_t)ncol + 16;
-    NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
-    char *ws = (char *)ctx->indel_ws.p;
+    const size_t o_depth = 0, o_rank = o_depth + (size_t)3 * ncol * 4, o_diff = o_rank + ((size_t)ncol + 1) * 4, o_type = o_diff + (size_t)8 * nd * 4;
     int32_t *depth = (int32_t *)(ws + o_depth), *rank = (int32_t *)(ws + o_rank), *diff = (int32_t *)(ws + o_diff);
     int8_t *ctype = (int8_t *)(ws + o_type);
-    NC_HIP(ctx, hipMemsetAsync(ws, 0, total, ctx->stream));
-    NcTimer tm(ctx, 3);
     const int32_t clo = lo > grid_lo ? lo : grid_lo, chi = hi < grid_hi ? hi : grid_hi;
     if (chi >= clo) {
         const int t0 = (clo - grid_lo) / tile, t1 = (chi - grid_lo) / tile;
@@ -335,9 +332,71 @@ extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_inde
     hipLaunchKernelGGL(k_prefix_rows, dim3(8), dim3(1024), 0, ctx->stream, diff, nd);
     hipLaunchKernelGGL(k_indel_decide, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, depth, rank, diff, nd, ncol, prm->mincov,
                        prm->ins_t, prm->del_t, prm->haploid, ctype);
+    return ctype;
+}
+
+static int indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const nc_indel_scan_params *prm, const char *who)
+{
+    if (!pack || !ev || !prm) return nc_fail(ctx, NC_ERR_ARG, "%s: bad argument", who);
+    const int tile = pack->tile_size;
+    if (!(tile == 1024 || tile == 2048 || tile == 4096)) return nc_fail(ctx, NC_ERR_ARG, "%s: malformed read pack", who);
+    if (prm->win_size < 1 || prm->small_win_size < 1 || prm->win_size > 4096) return nc_fail(ctx, NC_ERR_ARG, "%s: window sizes", who);
+    return NC_OK;
+}
+
+extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start,
+                             int32_t end, const nc_indel_scan_params *prm, int8_t *col_type_host)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!col_type_host || end < start) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: bad argument");
+    NC_TRY(indel_check(ctx, pack, ev, prm, "nc_indel_scan"));
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t lo = start < 1 ? 1 : start, ncol = end - lo + 1;
+    const size_t total = indel_ws_bytes(ncol, prm->win_size);
+    NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
+    char *ws = (char *)ctx->indel_ws.p;
+    NC_HIP(ctx, hipMemsetAsync(ws, 0, total, ctx->stream));
+    NcTimer tm(ctx, 3);
+    int8_t *ctype = indel_enqueue(ctx, pack, ev, excl_dev, start, end, prm, ws);
     NC_HIP(ctx, hipGetLastError());
     tm.stop();
     NC_HIP(ctx, hipMemcpyAsync(col_type_host, ctype, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+// Many chunks of one contig per call: every chunk keeps the reference's per-chunk semantics (fresh window deques at the
+// chunk start), the kernels of up to 64 chunks are enqueued back to back into disjoint workspaces and synchronised once.
+extern "C" int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev,
+                                   int32_t n_chunks, const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm,
+                                   int8_t *col_type_host, const int64_t *col_off)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_chunks < 0 || (n_chunks && (!starts || !ends || !col_type_host || !col_off))) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: bad argument");
+    NC_TRY(indel_check(ctx, pack, ev, prm, "nc_indel_scan_batch"));
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    NcTimer tm(ctx, 3);
+    for (int32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+        const int32_t c1 = c0 + 64 < n_chunks ? c0 + 64 : n_chunks;
+        size_t total = 0;
+        for (int32_t c = c0; c < c1; c++) {
+            if (ends[c] < starts[c]) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: chunk %d has end < start", c);
+            const int32_t lo = starts[c] < 1 ? 1 : starts[c];
+            total += indel_ws_bytes(ends[c] - lo + 1, prm->win_size);
+        }
+        NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
+        char *ws = (char *)ctx->indel_ws.p;
+        NC_HIP(ctx, hipMemsetAsync(ws, 0, total, ctx->stream));
+        size_t o = 0;
+        for (int32_t c = c0; c < c1; c++) {
+            const int32_t lo = starts[c] < 1 ? 1 : starts[c], ncol = ends[c] - lo + 1;
+            int8_t *ctype = indel_enqueue(ctx, pack, ev, excl_dev, starts[c], ends[c], prm, ws + o);
+            NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[c], ctype, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
+            o += indel_ws_bytes(ncol, prm->win_size);
+        }
+        NC_HIP(ctx, hipGetLastError());
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    tm.stop();
     return NC_OK;
 }

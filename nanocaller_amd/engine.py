@@ -260,6 +260,27 @@ class Engine:
                                          _lib.npp(out)), "nc_indel_scan")
         return out
 
+    def indel_scan_batch(self, dp: DevicePack, chunks, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None, haploid=False):
+        """K7 for a list of (start, end) chunks of one contig -> list of int8 arrays (one per chunk), one device sync per
+        64 chunks instead of one per chunk."""
+        if dp.events is None:
+            raise ValueError("this read pack carries no indel events / haplotype tags")
+        ev = dp.events
+        evc = _lib.IndelEventsC(n_reads=ev["n_reads"], ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(),
+                                ev_len=ev["ev_len"].data_ptr(), read_hap=ev["read_hap"].data_ptr())
+        prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size),
+                                    ins_t=float(ins_t), del_t=float(del_t), haploid=1 if haploid else 0)
+        starts = np.ascontiguousarray([c[0] for c in chunks], np.int32)
+        ends = np.ascontiguousarray([c[1] for c in chunks], np.int32)
+        ncol = ends.astype(np.int64) - np.maximum(starts, 1) + 1
+        off = np.zeros(len(chunks) + 1, np.int64)
+        np.cumsum(ncol, out=off[1:])
+        out = np.empty(int(off[-1]), np.int8)
+        pc = dp.c_struct()
+        self._check(self.L.nc_indel_scan_batch(self.ctx, C.byref(pc), C.byref(evc), _ptr(excl), len(chunks), _lib.npp(starts),
+                                               _lib.npp(ends), C.byref(prm), _lib.npp(out), _lib.npp(off)), "nc_indel_scan_batch")
+        return [out[off[k]:off[k + 1]] for k in range(len(chunks))]
+
     def indel_tensor(self, rows_list, ref_rows_list):
         """rows_list[s]: uint8 [n_rows, n_cols] aligned symbols 0..4; ref_rows_list[s]: uint8 [n_cols].
         -> (x f32 [S,5,128,2] device, cns list of uint8 arrays with gaps removed)"""

@@ -332,6 +332,26 @@ def test_haploid_indel_window_scan_matches_reference_pass1(eng):
     assert n > 40
 
 
+@pytest.mark.parametrize("haploid", [False, True])
+def test_indel_scan_batch_equals_per_chunk_calls(eng, haploid):
+    """nc_indel_scan_batch keeps the per-chunk semantics (fresh window state at every chunk start): identical per-column
+    decisions to one nc_indel_scan call per chunk, for ragged chunk lengths incl. one-column chunks"""
+    from nanocaller_amd.pack import pack_world
+    world = load_world("indel")
+    dp = eng.upload(pack_world(world))
+    chunks = [(1, 9_000), (9_000, 9_000), (9_001, 23_456), (23_400, 41_000), (41_001, world.length), (58_000, 58_001)] + \
+             [(a, a + 777) for a in range(2_000, 57_000, 911)]
+    kw = dict(mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, haploid=haploid)
+    got = eng.indel_scan_batch(dp, chunks, **kw)
+    assert len(got) == len(chunks) > 64
+    n = 0
+    for (a, b), g in zip(chunks, got):
+        one = eng.indel_scan(dp, a, b, **kw)
+        assert np.array_equal(g, one), (a, b)
+        n += int((one >= 0).sum())
+    assert n > 100
+
+
 def test_bam_and_fasta_files_end_to_end(eng, tmp_path):
     """real files in (BAM + BAI + FASTA + bgzipped BED), VCF out: identical to the run on the in-memory world"""
     import gzip
