@@ -237,8 +237,9 @@ int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *e
 
 /* The same for many chunks of one contig in one call (chunks keep their per-chunk semantics: the window deques start
  * empty at each chunk's first column, as in the reference, which calls the function once per chunk): col_type of chunk c
- * is written at col_type_host + col_off[c] (max(1,start_c) .. end_c).  Kernels of up to 64 chunks are enqueued back to
- * back and synchronised once. */
+ * is written at col_type_host + col_off[c] (max(1,start_c) .. end_c).  Chunk lists ascending in start and end (chunks may
+ * overlap or abut) run in the same kernel launches, the chunk being a grid dimension, in groups bounded by a 6 GiB
+ * workspace; any other order is processed chunk by chunk. */
 int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
                         int32_t n_chunks, const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *params,
                         int8_t *col_type_host, const int64_t *col_off);

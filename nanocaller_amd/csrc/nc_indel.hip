@@ -4,6 +4,8 @@
 // symbol histogram over the read rows, normalised by the row count in f32, minus the aligned reference's
 // one-hot; the consensus symbol is the arg-max with the gap handicapped by 0.01.  One workgroup per read set,
 // one lane per alignment column, rows streamed with coalesced byte loads (row-major rows: lane = column).
+#include <vector>
+
 #include "nc_common.h"
 
 namespace {
@@ -293,6 +295,248 @@ __global__ void k_indel_decide(const int32_t *__restrict__ depth, const int32_t 
     col_type[c] = type;
 }
 
+
+// ---- batched forms: all chunks of a contig in the same launches (chunk = a grid dimension), each chunk with its own
+// workspace slice and the reference's per-chunk semantics (window deques start empty at the chunk's first column)
+struct IndelChunk {
+    int32_t lo, hi, ncol, nd;
+    int64_t ws;          // byte offset of depth[3][ncol] | rank[ncol+1] | diff[8][nd] in the workspace
+    int64_t coloff;      // offset of this chunk's col_type in the concatenated output
+    int32_t tile0, blk0; // first tile of the chunk on the pack's grid, first k_hap_depth_b block of the chunk
+};
+__device__ __forceinline__ int32_t *ck_depth(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws); }
+__device__ __forceinline__ int32_t *ck_rank(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws) + (int64_t)3 * c.ncol; }
+__device__ __forceinline__ int32_t *ck_diff(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws) + (int64_t)3 * c.ncol + c.ncol + 1; }
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
+                                                       const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
+                                                       const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t haploid)
+{
+    constexpr int TILE = BLOCK * 16;
+    int a = 0, b = n_chunks - 1;                                   // last chunk with blk0 <= blockIdx.x
+    while (a < b) {
+        const int m = (a + b + 1) >> 1;
+        if (ck[m].blk0 <= (int)blockIdx.x) a = m; else b = m - 1;
+    }
+    const IndelChunk c = ck[a];
+    const int t = c.tile0 + ((int)blockIdx.x - c.blk0);
+    const int32_t lo = c.lo, hi = c.hi, ncol = c.ncol;
+    int32_t *depth = ck_depth(ws, c);
+    const int32_t P0 = tile_pos0 + t * TILE + threadIdx.x * 16;
+    uint32_t acc[3][4], wide[3][8];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) acc[q][d] = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) wide[q][d] = 0;
+    }
+    const int e0 = tile_off[t], e1 = tile_off[t + 1];
+    int e = e0;
+    while (e < e1) {
+        const int lim = min(e1, e + 255);
+        for (; e < lim; e++) {
+            const nc_tile_entry ent = tile_ent[e];
+            const int32_t slo = ent.start & ~15, shi = (ent.end + 15) & ~15;
+            uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+            if (P0 >= slo && P0 < shi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
+            const int hp = (int)((ent.base_flag >> 1) & 3);           // wave-uniform
+            const int plane = haploid ? 0 : hp == 1 ? 0 : hp == 2 ? 1 : 2;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t pres = lut8i(w[d], 0x01010101u, 0x00000001u);      // codes 0..4 -> 1
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc[q][d] += plane == q ? pres : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                wide[q][2 * d] += acc[q][d] & 0x00FF00FFu;
+                wide[q][2 * d + 1] += (acc[q][d] >> 8) & 0x00FF00FFu;
+                acc[q][d] = 0;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int32_t p = P0 + i;
+        if (p < lo || p > hi) continue;
+        const int d = i >> 2, k = i & 3, wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
+#pragma unroll
+        for (int q = 0; q < 3; q++) depth[(int64_t)q * ncol + (p - lo)] = (int32_t)((wide[q][wi] >> sh) & 0xFFFF);
+    }
+}
+
+// block-wide scan helper shared by the two per-chunk scans below: returns this thread's inclusive prefix inside the block
+// and the block total (16 waves)
+__device__ __forceinline__ int block_scan_1024(int v, int *wsum, int &tot)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += y;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wp = 0;
+    tot = 0;
+    for (int w = 0; w < 16; w++) {
+        const int s = wsum[w];
+        if (w < wv) wp += s;
+        tot += s;
+    }
+    return wp + inc;
+}
+
+__global__ __launch_bounds__(1024) void k_yield_rank_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws, const uint8_t *__restrict__ excl,
+                                                       int32_t grid_lo)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const IndelChunk c = ck[blockIdx.x];
+    const int32_t ncol = c.ncol;
+    const int32_t *depth = ck_depth(ws, c);
+    int32_t *rank = ck_rank(ws, c);
+    const int32_t excl_off = c.lo - grid_lo;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ncol; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = 0;
+        if (i < ncol) {
+            const int tot = depth[i] + depth[ncol + i] + depth[2 * (int64_t)ncol + i];
+            v = tot > 0 && !(excl && excl[excl_off + i]);
+        }
+        int tot;
+        const int inc = block_scan_1024(v, wsum, tot);
+        const int cc = carry;
+        if (i < ncol) rank[i] = v ? cc + inc - v : -1;               // -1: not yielded
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cc + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rank[ncol] = carry;
+}
+
+// one thread per read; a read's events may fall into several chunks (chunks are ascending; neighbours share one column)
+__global__ void k_event_intervals_b(int32_t n_reads, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
+                                    const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
+                                    const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win, int32_t small_win,
+                                    int32_t haploid)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int hp = read_hap[r];
+    if (!haploid && hp != 1 && hp != 2) return;
+    const int h = haploid ? 0 : hp - 1;
+    const int ea = ev_off[r], eb = ev_off[r + 1];
+    if (ea >= eb) return;
+    const int32_t p_first = ev_pos[ea], p_last = ev_pos[eb - 1];
+    int a = 0, b = n_chunks;                                       // first chunk with hi >= p_first
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (ck[m].hi < p_first) a = m + 1; else b = m;
+    }
+    for (int ci = a; ci < n_chunks && ck[ci].lo <= p_last; ci++) {
+        const IndelChunk c = ck[ci];
+        const int32_t *rank = ck_rank(ws, c);
+        int32_t *diff = ck_diff(ws, c);
+        const int32_t nd = c.nd;
+        int cur_lo[4] = {-1, -1, -1, -1}, cur_hi[4] = {-1, -1, -1, -1};
+        for (int e = ea; e < eb; e++) {
+            const int32_t p = ev_pos[e];
+            if (p < c.lo || p > c.hi) continue;
+            const int k = rank[p - c.lo];
+            if (k < 0) continue;                                      // excluded column
+            const int32_t sl = ev_len[e], ln = sl < 0 ? -sl : sl;
+            const bool ins = sl > 0;
+#pragma unroll
+            for (int cls = 0; cls < 4; cls++) {
+                const bool q = cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
+                if (!q) continue;
+                const int w = cls < 2 ? win : small_win;
+                if (cur_lo[cls] >= 0 && k <= cur_hi[cls]) cur_hi[cls] = k + w - 1;
+                else {
+                    if (cur_lo[cls] >= 0) {
+                        atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_lo[cls]], 1);
+                        atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_hi[cls] + 1], -1);
+                    }
+                    cur_lo[cls] = k;
+                    cur_hi[cls] = k + w - 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int cls = 0; cls < 4; cls++)
+            if (cur_lo[cls] >= 0) {
+                atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_lo[cls]], 1);
+                atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_hi[cls] + 1], -1);
+            }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_prefix_rows_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const IndelChunk c = ck[blockIdx.y];
+    const int32_t nd = c.nd;
+    int32_t *row = ck_diff(ws, c) + (int64_t)blockIdx.x * nd;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nd; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nd ? row[i] : 0;
+        int tot;
+        const int inc = block_scan_1024(v, wsum, tot);
+        const int cc = carry;
+        if (i < nd) row[i] = cc + inc;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cc + tot;
+        __syncthreads();
+    }
+}
+
+__global__ void k_indel_decide_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws, int32_t mincov, double ins_t, double del_t,
+                                 int32_t haploid, int8_t *__restrict__ col_type_all)
+{
+    const IndelChunk c = ck[blockIdx.y];
+    const int32_t ncol = c.ncol, nd = c.nd;
+    const int32_t *depth = ck_depth(ws, c), *rank = ck_rank(ws, c), *U = ck_diff(ws, c);
+    int8_t *col_type = col_type_all + c.coloff;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncol; i += gridDim.x * blockDim.x) {
+        int8_t type = -1;
+        const int k = rank[i];
+        const int n0 = depth[i], n1 = depth[ncol + i];
+        if (haploid) {
+            if (k >= 0 && n0 >= mincov && n0 > 0) {
+                double f[4];
+#pragma unroll
+                for (int cls = 0; cls < 4; cls++) f[cls] = (double)U[(int64_t)(cls * 2) * nd + k] / (double)n0;
+                if (f[0] >= del_t || f[1] >= ins_t) type = 0;
+                else if (f[2] >= del_t || f[3] >= ins_t || (f[2] + f[3]) >= 0.9) type = 1;
+            }
+        } else if (k >= 0 && n0 >= mincov && n1 >= mincov) {
+            double f[4][2];
+#pragma unroll
+            for (int cls = 0; cls < 4; cls++) {
+                f[cls][0] = n0 > 0 ? (double)U[(int64_t)(cls * 2 + 0) * nd + k] / (double)n0 : 0.0;
+                f[cls][1] = n1 > 0 ? (double)U[(int64_t)(cls * 2 + 1) * nd + k] / (double)n1 : 0.0;
+            }
+            if (fmax(f[0][0], f[0][1]) >= del_t || fmax(f[1][0], f[1][1]) >= ins_t) type = 0;
+            else if (fmax(f[2][0], f[2][1]) >= del_t || fmax(f[3][0], f[3][1]) >= ins_t || (f[2][0] + f[3][0]) >= 0.9 ||
+                     (f[2][1] + f[3][1]) >= 0.9)
+                type = 1;
+        }
+        col_type[i] = type;
+    }
+}
+
 }   // namespace
 
 // workspace of one chunk: depth[3][ncol] | rank[ncol+1] | diff[8][nd] | col_type[ncol]   (16-byte aligned total)
@@ -366,7 +610,8 @@ extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_inde
 }
 
 // Many chunks of one contig per call: every chunk keeps the reference's per-chunk semantics (fresh window deques at the
-// chunk start), the kernels of up to 64 chunks are enqueued back to back into disjoint workspaces and synchronised once.
+// chunk start).  Ascending chunk lists (the normal case) run as ONE set of launches per group of chunks, the chunk being a
+// grid dimension, with one device-to-host copy of the concatenated decisions; other lists fall back to chunk-by-chunk.
 extern "C" int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev,
                                    int32_t n_chunks, const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm,
                                    int8_t *col_type_host, const int64_t *col_off)
@@ -374,28 +619,77 @@ extern "C" int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const n
     if (!ctx) return NC_ERR_ARG;
     if (n_chunks < 0 || (n_chunks && (!starts || !ends || !col_type_host || !col_off))) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: bad argument");
     NC_TRY(indel_check(ctx, pack, ev, prm, "nc_indel_scan_batch"));
+    if (n_chunks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
+    bool ascending = true;
+    for (int32_t c = 0; c < n_chunks; c++) {
+        if (ends[c] < starts[c]) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: chunk %d has end < start", c);
+        if (c && (starts[c] < starts[c - 1] || ends[c] < ends[c - 1])) ascending = false;
+    }
+    if (!ascending) {
+        for (int32_t c = 0; c < n_chunks; c++) NC_TRY(nc_indel_scan(ctx, pack, ev, excl_dev, starts[c], ends[c], prm, col_type_host + col_off[c]));
+        return NC_OK;
+    }
+    const int tile = pack->tile_size;
+    const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
     NcTimer tm(ctx, 3);
-    for (int32_t c0 = 0; c0 < n_chunks; c0 += 64) {
-        const int32_t c1 = c0 + 64 < n_chunks ? c0 + 64 : n_chunks;
-        size_t total = 0;
-        for (int32_t c = c0; c < c1; c++) {
-            if (ends[c] < starts[c]) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: chunk %d has end < start", c);
-            const int32_t lo = starts[c] < 1 ? 1 : starts[c];
-            total += indel_ws_bytes(ends[c] - lo + 1, prm->win_size);
+    const size_t BUDGET = (size_t)6 << 30;                           // workspace per group of chunks
+    int32_t c0 = 0;
+    while (c0 < n_chunks) {
+        std::vector<IndelChunk> ck;
+        size_t wsb = 0;
+        int64_t ncols = 0;
+        int32_t nblk = 0, c1 = c0;
+        for (; c1 < n_chunks; c1++) {
+            IndelChunk k;
+            k.lo = starts[c1] < 1 ? 1 : starts[c1];
+            k.hi = ends[c1];
+            k.ncol = k.hi - k.lo + 1;
+            k.nd = k.ncol + prm->win_size + 2;
+            const size_t need = ((size_t)3 * k.ncol * 4 + ((size_t)k.ncol + 1) * 4 + (size_t)8 * k.nd * 4 + 15) & ~(size_t)15;
+            if (!ck.empty() && (wsb + need + (size_t)ncols + k.ncol > BUDGET || ck.size() >= 32768)) break;   // gridDim.y < 65536
+            k.ws = (int64_t)wsb;
+            k.coloff = ncols;
+            const int32_t clo = k.lo > grid_lo ? k.lo : grid_lo, chi = k.hi < grid_hi ? k.hi : grid_hi;
+            k.tile0 = chi >= clo ? (clo - grid_lo) / tile : 0;
+            k.blk0 = nblk;
+            nblk += chi >= clo ? (chi - grid_lo) / tile - k.tile0 + 1 : 0;
+            wsb += need;
+            ncols += k.ncol;
+            ck.push_back(k);
         }
+        const int32_t ng = (int32_t)ck.size();
+        const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, total = o_ck + (size_t)ng * sizeof(IndelChunk);
         NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
         char *ws = (char *)ctx->indel_ws.p;
-        NC_HIP(ctx, hipMemsetAsync(ws, 0, total, ctx->stream));
-        size_t o = 0;
-        for (int32_t c = c0; c < c1; c++) {
-            const int32_t lo = starts[c] < 1 ? 1 : starts[c], ncol = ends[c] - lo + 1;
-            int8_t *ctype = indel_enqueue(ctx, pack, ev, excl_dev, starts[c], ends[c], prm, ws + o);
-            NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[c], ctype, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
-            o += indel_ws_bytes(ncol, prm->win_size);
+        NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
+        IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
+        NC_HIP(ctx, hipMemcpyAsync(ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), hipMemcpyHostToDevice, ctx->stream));
+        int8_t *ctype = (int8_t *)(ws + o_type);
+        if (nblk > 0) {
+            if (tile == 1024)
+                hipLaunchKernelGGL(k_hap_depth_b<64>, dim3(nblk), dim3(64), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, ck_dev, ng, ws, prm->haploid);
+            else if (tile == 2048)
+                hipLaunchKernelGGL(k_hap_depth_b<128>, dim3(nblk), dim3(128), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, ck_dev, ng, ws, prm->haploid);
+            else
+                hipLaunchKernelGGL(k_hap_depth_b<256>, dim3(nblk), dim3(256), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, ck_dev, ng, ws, prm->haploid);
         }
+        hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
+        if (ev->n_reads > 0)
+            hipLaunchKernelGGL(k_event_intervals_b, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
+                               ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid);
+        hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
+        hipLaunchKernelGGL(k_indel_decide_b, dim3(64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t, prm->haploid, ctype);
         NC_HIP(ctx, hipGetLastError());
+        // the chunks of a group are consecutive in col_off as well when the caller laid them out back to back
+        bool packed = true;
+        for (int32_t k = 0; k < ng; k++) packed = packed && col_off[c0 + k] == col_off[c0] + ck[(size_t)k].coloff;
+        if (packed) NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[c0], ctype, (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            for (int32_t k = 0; k < ng; k++)
+                NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[c0 + k], ctype + ck[(size_t)k].coloff, (size_t)ck[(size_t)k].ncol, hipMemcpyDeviceToHost, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        c0 = c1;
     }
     tm.stop();
     return NC_OK;

@@ -49,10 +49,21 @@ def pick_variants(col_type, start, win_size):
 
 
 def scan_indel_candidates(dct, chunk, device=0, haploid=False):
+    """Pass 1 for one chunk (dict, like the reference's per-chunk call) -> {anchor: type}; or for a list of chunks of ONE
+    contig and BAM -> list of such dicts, every chunk with the reference's per-chunk semantics, all of them in the same
+    kernel launches (nc_indel_scan_batch)."""
     if dct.get("impute_indel_phase"):
         raise NotImplementedError("impute_indel_phase (generate_indel_pileups.py:278-304) is not part of this build")
-    world = _resolve(chunk["sam_path"], chunk["chrom"], dct.get("fasta_path"))
-    excl_rows = _exclude_rows(dct, chunk["chrom"])
+    chunks = None
+    if not isinstance(chunk, dict):
+        chunks = list(chunk)
+        if not chunks:
+            return []
+        if any((c["sam_path"], c["chrom"]) != (chunks[0]["sam_path"], chunks[0]["chrom"]) for c in chunks):
+            raise ValueError("scan_indel_candidates: a chunk list must be of one BAM and one contig")
+    first = chunk if isinstance(chunk, dict) else chunks[0]
+    world = _resolve(first["sam_path"], first["chrom"], dct.get("fasta_path"))
+    excl_rows = _exclude_rows(dct, first["chrom"])
     key = (id(world), bool(dct.get("supplementary")), device)
     eng = get_engine(device)
     eng.use_torch_stream()
@@ -65,9 +76,13 @@ def scan_indel_candidates(dct, chunk, device=0, haploid=False):
         for (a, b) in excl_rows:                                    # IntervalTree.overlaps(pos): a <= pos < b
             m[max(0, a - dp.tile_pos0):max(0, b - dp.tile_pos0)] = 1
         excl = torch.from_numpy(m).to(eng.device)
-    col_type = eng.indel_scan(dp, chunk["start"], chunk["end"], mincov=dct["mincov"], win_size=dct["win_size"],
-                              small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=haploid)
-    return pick_variants(col_type, chunk["start"], dct["win_size"])
+    if isinstance(chunk, dict):
+        col_type = eng.indel_scan(dp, chunk["start"], chunk["end"], mincov=dct["mincov"], win_size=dct["win_size"],
+                                  small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=haploid)
+        return pick_variants(col_type, chunk["start"], dct["win_size"])
+    cols = eng.indel_scan_batch(dp, [(c["start"], c["end"]) for c in chunks], mincov=dct["mincov"], win_size=dct["win_size"],
+                                small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=haploid)
+    return [pick_variants(ct, c["start"], dct["win_size"]) for ct, c in zip(cols, chunks)]
 
 
 def msa_tensor(rows_list, ref_rows_list, device=0):

@@ -336,20 +336,53 @@ def test_haploid_indel_window_scan_matches_reference_pass1(eng):
 def test_indel_scan_batch_equals_per_chunk_calls(eng, haploid):
     """nc_indel_scan_batch keeps the per-chunk semantics (fresh window state at every chunk start): identical per-column
     decisions to one nc_indel_scan call per chunk, for ragged chunk lengths incl. one-column chunks"""
+    import torch
     from nanocaller_amd.pack import pack_world
     world = load_world("indel")
     dp = eng.upload(pack_world(world))
     chunks = [(1, 9_000), (9_000, 9_000), (9_001, 23_456), (23_400, 41_000), (41_001, world.length), (58_000, 58_001)] + \
              [(a, a + 777) for a in range(2_000, 57_000, 911)]
     kw = dict(mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, haploid=haploid)
-    got = eng.indel_scan_batch(dp, chunks, **kw)
-    assert len(got) == len(chunks) > 64
+    excl = torch.zeros(dp.n_tiles * dp.tile_size, dtype=torch.uint8, device="cuda")
+    excl[30_000 - dp.tile_pos0:31_500 - dp.tile_pos0] = 1
+    # ascending lists run with the chunk as a grid dimension (overlapping, abutting and one-column chunks, chunks past the
+    # last read); any other order takes the chunk-by-chunk route
+    ascending = sorted([(a, a + 777) for a in range(2_000, 57_000, 911)] + [(a + 400, a + 1_200) for a in range(2_000, 57_000, 1_822)])
+    ascending = [(1, 1_500), (1_500, 1_500), (1_501, 2_776)] + ascending + [(58_500, 58_500), (58_501, world.length),
+                                                                         (world.length + 5_000, world.length + 6_000)]
+    assert all(b[0] >= a[0] and b[1] >= a[1] for a, b in zip(ascending, ascending[1:])) and len(ascending) > 90
     n = 0
-    for (a, b), g in zip(chunks, got):
-        one = eng.indel_scan(dp, a, b, **kw)
-        assert np.array_equal(g, one), (a, b)
-        n += int((one >= 0).sum())
-    assert n > 100
+    for lst, ex in ((ascending, None), (ascending, excl), (chunks, None)):
+        got = eng.indel_scan_batch(dp, lst, excl=ex, **kw)
+        assert len(got) == len(lst)
+        for (a, b), g in zip(lst, got):
+            one = eng.indel_scan(dp, a, b, excl=ex, **kw)
+            assert np.array_equal(g, one), (a, b)
+            n += int((one >= 0).sum())
+    assert n > 300
+
+
+def test_indel_scan_chunk_list_matches_reference_pass1(eng):
+    """the chunk-list form of scan_indel_candidates (one set of launches for all chunks) against the reference's captured
+    `variants` of every chunk"""
+    from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
+    from tests.util import indel_scan_cases
+    world = load_world("indel")
+    for haploid in (False, True):
+        groups = {}
+        for c in indel_scan_cases(haploid=haploid):
+            key = (c["mincov"], c["win_size"], c["small_win_size"], c["ins_t"], c["del_t"], tuple(map(tuple, c["exclude"])))
+            groups.setdefault(key, []).append(c)
+        n = 0
+        for key, cases in groups.items():
+            cases.sort(key=lambda c: (c["start"], c["end"]))
+            dct = dict(mincov=key[0], win_size=key[1], small_win_size=key[2], ins_t=key[3], del_t=key[4], supplementary=False,
+                       impute_indel_phase=False, exclude_bed=[(world.chrom, a, b) for a, b in key[5]] or None)
+            got = scan_indel_candidates(dct, [dict(chrom=world.chrom, start=c["start"], end=c["end"], sam_path=world) for c in cases], haploid=haploid)
+            for g, c in zip(got, cases):
+                assert sorted(g) == c["pos"].tolist() and [g[p] for p in sorted(g)] == c["type"].tolist(), (c["start"], c["end"])
+                n += len(g)
+        assert n > 40
 
 
 def test_bam_and_fasta_files_end_to_end(eng, tmp_path):

@@ -27,7 +27,7 @@ for rep in range(2):
     torch.cuda.synchronize(); t = time.perf_counter()
     cols = eng.indel_scan_batch(dp, chunks, mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6)
     dt = time.perf_counter() - t
-print("K7 batched (nc_indel_scan_batch, one sync per 64 chunks): %.1f ms -> %.1f M columns/s (%d flagged)" % (dt * 1e3, L / dt / 1e6, sum(int((c >= 0).sum()) for c in cols)))
+print("K7 batched (nc_indel_scan_batch, chunk = grid dimension): %.1f ms -> %.1f M columns/s (%d flagged)" % (dt * 1e3, L / dt / 1e6, sum(int((c >= 0).sum()) for c in cols)))
 # ---- K8
 rng = np.random.Generator(np.random.PCG64(1))
 S = 4096
