@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 2   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points */
+#define NC_ABI_VERSION 3   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+                              3: nc_indel_scan_params.impute */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -230,6 +231,10 @@ typedef struct {
     double ins_t, del_t;                        /* dct['ins_t'], dct['del_t'] */
     int32_t haploid;                            /* 1: get_indel_testing_candidates_haploid (generate_indel_pileups_haploid.py:185-241):
                                                    one read set, HP tags ignored, frequencies over all reads of the column */
+    int32_t impute;                             /* 1: dct['impute_indel_phase'] (generate_indel_pileups.py:278-284, diploid only): columns
+                                                   without mincov reads on both haplotypes but >= 2*mincov reads in total whose share
+                                                   of '-'/'*' or '+' pileup strings reaches del_t / ins_t get col_type 2; the caller
+                                                   groups the reads of these columns (:285-304) */
 } nc_indel_scan_params;
 
 int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
@@ -239,7 +244,8 @@ int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *e
  * empty at each chunk's first column, as in the reference, which calls the function once per chunk): col_type of chunk c
  * is written at col_type_host + col_off[c] (max(1,start_c) .. end_c).  Chunk lists ascending in start and end (chunks may
  * overlap or abut) run in the same kernel launches, the chunk being a grid dimension, in groups bounded by a 6 GiB
- * workspace; any other order is processed chunk by chunk. */
+ * workspace; a list in any other order is cut into its ascending runs.  nc_indel_scan is the one-chunk form.  col_type:
+ * -1 none, 0 long-window rule (:266), 1 small-window rule (:271), 2 (params.impute) impute_indel_phase candidate. */
 int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *events, const uint8_t *excl_dev,
                         int32_t n_chunks, const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *params,
                         int8_t *col_type_host, const int64_t *col_off);

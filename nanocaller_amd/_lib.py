@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnanocaller_hip.so")
 
 NC_OK = 0
-ABI_VERSION = 2          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
+ABI_VERSION = 3          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -58,7 +58,7 @@ class IndelEventsC(C.Structure):
 
 class IndelScanParamsC(C.Structure):
     _fields_ = [("mincov", C.c_int32), ("win_size", C.c_int32), ("small_win_size", C.c_int32), ("ins_t", C.c_double),
-                ("del_t", C.c_double), ("haploid", C.c_int32)]
+                ("del_t", C.c_double), ("haploid", C.c_int32), ("impute", C.c_int32)]
 
 
 class DecodedArraysC(C.Structure):

@@ -87,228 +87,23 @@ namespace {
 
 __device__ __forceinline__ uint32_t lut8i(uint32_t x, uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, x); }
 
-// per-column depth by haplotype tag; same access scheme as k_scan (one aligned dwordx4 of codes per read and lane)
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_hap_depth(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
-                                                     const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0, int32_t tile_first,
-                                                     int32_t lo, int32_t hi, int32_t *__restrict__ depth /* [3][ncol] */, int32_t ncol, int32_t haploid)
-{
-    constexpr int TILE = BLOCK * 16;
-    const int t = tile_first + blockIdx.x;
-    const int32_t P0 = tile_pos0 + t * TILE + threadIdx.x * 16;
-    uint32_t acc[3][4], wide[3][8];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int d = 0; d < 4; d++) acc[c][d] = 0;
-#pragma unroll
-        for (int d = 0; d < 8; d++) wide[c][d] = 0;
-    }
-    const int e0 = tile_off[t], e1 = tile_off[t + 1];
-    int e = e0;
-    while (e < e1) {
-        const int lim = min(e1, e + 255);
-        for (; e < lim; e++) {
-            const nc_tile_entry ent = tile_ent[e];
-            const int32_t slo = ent.start & ~15, shi = (ent.end + 15) & ~15;
-            uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
-            if (P0 >= slo && P0 < shi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
-            const int hp = (int)((ent.base_flag >> 1) & 3);           // wave-uniform
-            const int plane = haploid ? 0 : hp == 1 ? 0 : hp == 2 ? 1 : 2;       // haploid: one read set, tags ignored
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t pres = lut8i(w[d], 0x01010101u, 0x00000001u);      // codes 0..4 -> 1
-#pragma unroll
-                for (int c = 0; c < 3; c++) acc[c][d] += plane == c ? pres : 0u;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                wide[c][2 * d] += acc[c][d] & 0x00FF00FFu;
-                wide[c][2 * d + 1] += (acc[c][d] >> 8) & 0x00FF00FFu;
-                acc[c][d] = 0;
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int32_t p = P0 + i;
-        if (p < lo || p > hi) continue;
-        const int d = i >> 2, k = i & 3, wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
-#pragma unroll
-        for (int c = 0; c < 3; c++) depth[(int64_t)c * ncol + (p - lo)] = (int32_t)((wide[c][wi] >> sh) & 0xFFFF);
-    }
-}
-
-// single-workgroup exclusive scan of the "column is yielded" flag -> rank among yielded columns; ny at rank[ncol]
-__global__ __launch_bounds__(1024) void k_yield_rank(const int32_t *__restrict__ depth, const uint8_t *__restrict__ excl, int32_t excl_off,
-                                                     int32_t ncol, int32_t *__restrict__ rank)
-{
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < ncol; base += 1024) {
-        const int i = base + threadIdx.x;
-        int v = 0;
-        if (i < ncol) {
-            const int tot = depth[i] + depth[ncol + i] + depth[2 * (int64_t)ncol + i];
-            v = tot > 0 && !(excl && excl[excl_off + i]);
-        }
-        int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += y;
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int wp = 0, tot = 0;
-        for (int w = 0; w < 16; w++) {
-            const int s = wsum[w];
-            if (w < wv) wp += s;
-            tot += s;
-        }
-        const int c = carry;
-        if (i < ncol) rank[i] = v ? c + wp + inc - v : -1;           // -1: not yielded
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) rank[ncol] = carry;
-}
-
-// one thread per kept read: merge the window-end intervals [e, e+w-1] of its qualifying events (a read counts once per
-// window, set-union semantics of :254-264) and add them to the per-(class, haplotype) difference arrays
-__global__ void k_event_intervals(int32_t n_reads, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
-                                  const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
-                                  const int32_t *__restrict__ rank, int32_t lo, int32_t hi, int32_t win, int32_t small_win,
-                                  int32_t *__restrict__ diff /* [8][nd] */, int32_t nd, int32_t haploid)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const int hp = read_hap[r];
-    if (!haploid && hp != 1 && hp != 2) return;
-    const int h = haploid ? 0 : hp - 1;
-    int cur_lo[4] = {-1, -1, -1, -1}, cur_hi[4] = {-1, -1, -1, -1};
-    for (int e = ev_off[r]; e < ev_off[r + 1]; e++) {
-        const int32_t p = ev_pos[e];
-        if (p < lo || p > hi) continue;
-        const int k = rank[p - lo];
-        if (k < 0) continue;                                          // excluded column
-        const int32_t sl = ev_len[e], ln = sl < 0 ? -sl : sl;
-        const bool ins = sl > 0;
-#pragma unroll
-        for (int cls = 0; cls < 4; cls++) {
-            const bool q = cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
-            if (!q) continue;
-            const int w = cls < 2 ? win : small_win;
-            if (cur_lo[cls] >= 0 && k <= cur_hi[cls]) cur_hi[cls] = k + w - 1;
-            else {
-                if (cur_lo[cls] >= 0) {
-                    atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_lo[cls]], 1);
-                    atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_hi[cls] + 1], -1);
-                }
-                cur_lo[cls] = k;
-                cur_hi[cls] = k + w - 1;
-            }
-        }
-    }
-#pragma unroll
-    for (int cls = 0; cls < 4; cls++)
-        if (cur_lo[cls] >= 0) {
-            atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_lo[cls]], 1);
-            atomicAdd(&diff[(int64_t)(cls * 2 + h) * nd + cur_hi[cls] + 1], -1);
-        }
-}
-
-// in-place inclusive prefix sum of each of the 8 difference arrays (one workgroup per array)
-__global__ __launch_bounds__(1024) void k_prefix_rows(int32_t *__restrict__ a, int32_t nd)
-{
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    int32_t *row = a + (int64_t)blockIdx.x * nd;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < nd; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < nd ? row[i] : 0;
-        int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += y;
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int wp = 0, tot = 0;
-        for (int w = 0; w < 16; w++) {
-            const int s = wsum[w];
-            if (w < wv) wp += s;
-            tot += s;
-        }
-        const int c = carry;
-        if (i < nd) row[i] = c + wp + inc;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + tot;
-        __syncthreads();
-    }
-}
-
-// per-column decision of :252-275 (float64 divide-and-compare, as in the reference)
-__global__ void k_indel_decide(const int32_t *__restrict__ depth, const int32_t *__restrict__ rank, const int32_t *__restrict__ U,
-                               int32_t nd, int32_t ncol, int32_t mincov, double ins_t, double del_t, int32_t haploid,
-                               int8_t *__restrict__ col_type)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
-    int8_t type = -1;
-    const int k = rank[c];
-    const int n0 = depth[c], n1 = depth[ncol + c];
-    if (haploid) {                                                     // generate_indel_pileups_haploid.py:224-241 (all reads in plane 0)
-        if (k >= 0 && n0 >= mincov && n0 > 0) {
-            double f[4];
-#pragma unroll
-            for (int cls = 0; cls < 4; cls++) f[cls] = (double)U[(int64_t)(cls * 2) * nd + k] / (double)n0;
-            if (f[0] >= del_t || f[1] >= ins_t) type = 0;
-            else if (f[2] >= del_t || f[3] >= ins_t || (f[2] + f[3]) >= 0.9) type = 1;
-        }
-        col_type[c] = type;
-        return;
-    }
-    if (k >= 0 && n0 >= mincov && n1 >= mincov) {
-        double f[4][2];
-#pragma unroll
-        for (int cls = 0; cls < 4; cls++) {
-            f[cls][0] = n0 > 0 ? (double)U[(int64_t)(cls * 2 + 0) * nd + k] / (double)n0 : 0.0;
-            f[cls][1] = n1 > 0 ? (double)U[(int64_t)(cls * 2 + 1) * nd + k] / (double)n1 : 0.0;
-        }
-        if (fmax(f[0][0], f[0][1]) >= del_t || fmax(f[1][0], f[1][1]) >= ins_t) type = 0;                       // :266
-        else if (fmax(f[2][0], f[2][1]) >= del_t || fmax(f[3][0], f[3][1]) >= ins_t || (f[2][0] + f[3][0]) >= 0.9 ||
-                 (f[2][1] + f[3][1]) >= 0.9)
-            type = 1;                                                                                           // :271
-    }
-    col_type[c] = type;
-}
-
-
-// ---- batched forms: all chunks of a contig in the same launches (chunk = a grid dimension), each chunk with its own
-// workspace slice and the reference's per-chunk semantics (window deques start empty at the chunk's first column)
+// All chunks of a call run in the same launches (chunk = a grid dimension), each chunk with its own workspace slice and
+// the reference's per-chunk semantics (window deques start empty at the chunk's first column)
 struct IndelChunk {
     int32_t lo, hi, ncol, nd;
-    int64_t ws;          // byte offset of depth[3][ncol] | rank[ncol+1] | diff[8][nd] in the workspace
+    int64_t ws;          // byte offset of depth[3][ncol] | rank[ncol+1] | diff[8][nd] | (impute) cnt[3][ncol] in the workspace
     int64_t coloff;      // offset of this chunk's col_type in the concatenated output
     int32_t tile0, blk0; // first tile of the chunk on the pack's grid, first k_hap_depth_b block of the chunk
 };
 __device__ __forceinline__ int32_t *ck_depth(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws); }
 __device__ __forceinline__ int32_t *ck_rank(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws) + (int64_t)3 * c.ncol; }
 __device__ __forceinline__ int32_t *ck_diff(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws) + (int64_t)3 * c.ncol + c.ncol + 1; }
+// impute_indel_phase only: per column, over ALL kept reads: [0] reads deleted here ('*'), [1] insertions / [2] deletions that follow this column
+__device__ __forceinline__ int32_t *ck_cnt(char *ws, const IndelChunk &c) { return ck_diff(ws, c) + (int64_t)8 * c.nd; }
 
-template <int BLOCK>
+// per-column depth by haplotype tag; same access scheme as k_scan (one aligned dwordx4 of codes per read and lane).
+// STAR: count the reads whose code is 4 (deleted at this column) of all haplotypes instead, into cnt[0]
+template <int BLOCK, bool STAR>
 __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
                                                        const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
                                                        const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t haploid)
@@ -322,7 +117,7 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
     const IndelChunk c = ck[a];
     const int t = c.tile0 + ((int)blockIdx.x - c.blk0);
     const int32_t lo = c.lo, hi = c.hi, ncol = c.ncol;
-    int32_t *depth = ck_depth(ws, c);
+    int32_t *depth = STAR ? ck_cnt(ws, c) : ck_depth(ws, c);
     const int32_t P0 = tile_pos0 + t * TILE + threadIdx.x * 16;
     uint32_t acc[3][4], wide[3][8];
 #pragma unroll
@@ -342,13 +137,13 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
             uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
             if (P0 >= slo && P0 < shi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
             const int hp = (int)((ent.base_flag >> 1) & 3);           // wave-uniform
-            const int plane = haploid ? 0 : hp == 1 ? 0 : hp == 2 ? 1 : 2;
+            const int plane = (STAR || haploid) ? 0 : hp == 1 ? 0 : hp == 2 ? 1 : 2;       // haploid: one read set, tags ignored
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                const uint32_t pres = lut8i(w[d], 0x01010101u, 0x00000001u);      // codes 0..4 -> 1
+                const uint32_t pres = STAR ? lut8i(w[d], 0u, 0x00000001u) : lut8i(w[d], 0x01010101u, 0x00000001u);   // code 4 | codes 0..4 -> 1
 #pragma unroll
-                for (int q = 0; q < 3; q++) acc[q][d] += plane == q ? pres : 0u;
+                for (int q = 0; q < (STAR ? 1 : 3); q++) acc[q][d] += plane == q ? pres : 0u;
             }
         }
 #pragma unroll
@@ -366,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
         if (p < lo || p > hi) continue;
         const int d = i >> 2, k = i & 3, wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
 #pragma unroll
-        for (int q = 0; q < 3; q++) depth[(int64_t)q * ncol + (p - lo)] = (int32_t)((wide[q][wi] >> sh) & 0xFFFF);
+        for (int q = 0; q < (STAR ? 1 : 3); q++) depth[(int64_t)q * ncol + (p - lo)] = (int32_t)((wide[q][wi] >> sh) & 0xFFFF);
     }
 }
 
@@ -393,6 +188,7 @@ __device__ __forceinline__ int block_scan_1024(int v, int *wsum, int &tot)
     return wp + inc;
 }
 
+// one workgroup per chunk: exclusive scan of the "column is yielded" flag -> rank among yielded columns; ny at rank[ncol]
 __global__ __launch_bounds__(1024) void k_yield_rank_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws, const uint8_t *__restrict__ excl,
                                                        int32_t grid_lo)
 {
@@ -423,16 +219,19 @@ __global__ __launch_bounds__(1024) void k_yield_rank_b(const IndelChunk *__restr
     if (threadIdx.x == 0) rank[ncol] = carry;
 }
 
-// one thread per read; a read's events may fall into several chunks (chunks are ascending; neighbours share one column)
+// one thread per kept read: merge the window-end intervals [e, e+w-1] of its qualifying events (a read counts once per
+// window, set-union semantics of :254-264) and add them to the per-(class, haplotype) difference arrays of every chunk
+// its events fall into (chunks are ascending and may overlap)
 __global__ void k_event_intervals_b(int32_t n_reads, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
                                     const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
                                     const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win, int32_t small_win,
-                                    int32_t haploid)
+                                    int32_t haploid, int32_t impute)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int hp = read_hap[r];
-    if (!haploid && hp != 1 && hp != 2) return;
+    const bool tagged = haploid || hp == 1 || hp == 2;
+    if (!tagged && !impute) return;
     const int h = haploid ? 0 : hp - 1;
     const int ea = ev_off[r], eb = ev_off[r + 1];
     if (ea >= eb) return;
@@ -444,6 +243,14 @@ __global__ void k_event_intervals_b(int32_t n_reads, const int32_t *__restrict__
     }
     for (int ci = a; ci < n_chunks && ck[ci].lo <= p_last; ci++) {
         const IndelChunk c = ck[ci];
+        if (impute) {                                                 // :279-284: '+' / '-' in the column's pileup strings, every read
+            int32_t *cnt = ck_cnt(ws, c);
+            for (int e = ea; e < eb; e++) {
+                const int32_t p = ev_pos[e];
+                if (p >= c.lo && p <= c.hi) atomicAdd(&cnt[(int64_t)(ev_len[e] > 0 ? 1 : 2) * c.ncol + (p - c.lo)], 1);
+            }
+        }
+        if (!tagged) continue;
         const int32_t *rank = ck_rank(ws, c);
         int32_t *diff = ck_diff(ws, c);
         const int32_t nd = c.nd;
@@ -480,6 +287,7 @@ __global__ void k_event_intervals_b(int32_t n_reads, const int32_t *__restrict__
     }
 }
 
+// in-place inclusive prefix sum of each of the 8 difference arrays of each chunk (one workgroup per array)
 __global__ __launch_bounds__(1024) void k_prefix_rows_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws)
 {
     __shared__ int wsum[16];
@@ -502,8 +310,10 @@ __global__ __launch_bounds__(1024) void k_prefix_rows_b(const IndelChunk *__rest
     }
 }
 
+// per-column decision of :252-275 (float64 divide-and-compare, as in the reference); with impute_indel_phase also the
+// column-level part of :278-284 (type 2: the read grouping of :285-304 is left to the host for these few columns)
 __global__ void k_indel_decide_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws, int32_t mincov, double ins_t, double del_t,
-                                 int32_t haploid, int8_t *__restrict__ col_type_all)
+                                 int32_t haploid, int32_t impute, int8_t *__restrict__ col_type_all)
 {
     const IndelChunk c = ck[blockIdx.y];
     const int32_t ncol = c.ncol, nd = c.nd;
@@ -532,52 +342,20 @@ __global__ void k_indel_decide_b(const IndelChunk *__restrict__ ck, char *__rest
             else if (fmax(f[2][0], f[2][1]) >= del_t || fmax(f[3][0], f[3][1]) >= ins_t || (f[2][0] + f[3][0]) >= 0.9 ||
                      (f[2][1] + f[3][1]) >= 0.9)
                 type = 1;
+        } else if (impute && k >= 0) {
+            const int tot = n0 + n1 + depth[2 * (int64_t)ncol + i];
+            if (tot >= 2 * mincov && tot > 0) {                                                          // :278
+                const int32_t *cnt = ck_cnt(ws, c);
+                const double del_f = (double)(cnt[i] + cnt[2 * (int64_t)ncol + i]) / (double)tot;        // '-' and '*' (:282)
+                const double ins_f = (double)cnt[(int64_t)ncol + i] / (double)tot;                       // '+' (:283)
+                if (del_t <= del_f || ins_t <= ins_f) type = 2;                                          // :284
+            }
         }
         col_type[i] = type;
     }
 }
 
 }   // namespace
-
-// workspace of one chunk: depth[3][ncol] | rank[ncol+1] | diff[8][nd] | col_type[ncol]   (16-byte aligned total)
-static size_t indel_ws_bytes(int32_t ncol, int32_t win) 
-{
-    const int32_t nd = ncol + win + 2;
-    return (((size_t)3 * ncol * 4 + ((size_t)ncol + 1) * 4 + (size_t)8 * nd * 4 + (size_t)ncol + 16) + 15) & ~(size_t)15;
-}
-
-// enqueue the kernels of one chunk on the context's stream (workspace `ws` must be zeroed); -> device pointer of col_type
-static int8_t *indel_enqueue(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start, int32_t end,
-                             const nc_indel_scan_params *prm, char *ws)
-{
-    const int tile = pack->tile_size;
-    const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
-    const int32_t lo = start < 1 ? 1 : start, hi = end;
-    const int32_t ncol = hi - lo + 1;
-    const int32_t nd = ncol + prm->win_size + 2;
-    const size_t o_depth = 0, o_rank = o_depth + (size_t)3 * ncol * 4, o_diff = o_rank + ((size_t)ncol + 1) * 4, o_type = o_diff + (size_t)8 * nd * 4;
-    int32_t *depth = (int32_t *)(ws + o_depth), *rank = (int32_t *)(ws + o_rank), *diff = (int32_t *)(ws + o_diff);
-    int8_t *ctype = (int8_t *)(ws + o_type);
-    const int32_t clo = lo > grid_lo ? lo : grid_lo, chi = hi < grid_hi ? hi : grid_hi;
-    if (chi >= clo) {
-        const int t0 = (clo - grid_lo) / tile, t1 = (chi - grid_lo) / tile;
-        const dim3 g((unsigned)(t1 - t0 + 1));
-        if (tile == 1024)
-            hipLaunchKernelGGL(k_hap_depth<64>, g, dim3(64), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol, prm->haploid);
-        else if (tile == 2048)
-            hipLaunchKernelGGL(k_hap_depth<128>, g, dim3(128), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol, prm->haploid);
-        else
-            hipLaunchKernelGGL(k_hap_depth<256>, g, dim3(256), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, t0, lo, hi, depth, ncol, prm->haploid);
-    }
-    hipLaunchKernelGGL(k_yield_rank, dim3(1), dim3(1024), 0, ctx->stream, depth, excl_dev, lo - grid_lo, ncol, rank);
-    if (ev->n_reads > 0)
-        hipLaunchKernelGGL(k_event_intervals, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
-                           ev->ev_len, ev->read_hap, rank, lo, hi, prm->win_size, prm->small_win_size, diff, nd, prm->haploid);
-    hipLaunchKernelGGL(k_prefix_rows, dim3(8), dim3(1024), 0, ctx->stream, diff, nd);
-    hipLaunchKernelGGL(k_indel_decide, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, depth, rank, diff, nd, ncol, prm->mincov,
-                       prm->ins_t, prm->del_t, prm->haploid, ctype);
-    return ctype;
-}
 
 static int indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const nc_indel_scan_params *prm, const char *who)
 {
@@ -588,30 +366,81 @@ static int indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_even
     return NC_OK;
 }
 
-extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start,
-                             int32_t end, const nc_indel_scan_params *prm, int8_t *col_type_host)
+// one group of ascending chunks: a single set of launches, one device-to-host copy per run of back-to-back outputs
+static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
+                            const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int8_t *col_type_host,
+                            const int64_t *col_off, int32_t *consumed)
 {
-    if (!ctx) return NC_ERR_ARG;
-    if (!col_type_host || end < start) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: bad argument");
-    NC_TRY(indel_check(ctx, pack, ev, prm, "nc_indel_scan"));
-    NC_HIP(ctx, hipSetDevice(ctx->device));
-    const int32_t lo = start < 1 ? 1 : start, ncol = end - lo + 1;
-    const size_t total = indel_ws_bytes(ncol, prm->win_size);
+    const int tile = pack->tile_size;
+    const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
+    const int impute = prm->impute && !prm->haploid;
+    const size_t BUDGET = (size_t)6 << 30;                           // workspace per group of chunks
+    std::vector<IndelChunk> ck;
+    size_t wsb = 0;
+    int64_t ncols = 0;
+    int32_t nblk = 0, c1 = 0;
+    for (; c1 < n_chunks; c1++) {
+        IndelChunk k;
+        k.lo = starts[c1] < 1 ? 1 : starts[c1];
+        k.hi = ends[c1];
+        k.ncol = k.hi - k.lo + 1;
+        k.nd = k.ncol + prm->win_size + 2;
+        const size_t need = ((size_t)3 * k.ncol * 4 + ((size_t)k.ncol + 1) * 4 + (size_t)8 * k.nd * 4 + (impute ? (size_t)3 * k.ncol * 4 : 0) + 15) & ~(size_t)15;
+        if (!ck.empty() && (wsb + need + (size_t)ncols + k.ncol > BUDGET || ck.size() >= 32768)) break;   // gridDim.y < 65536
+        k.ws = (int64_t)wsb;
+        k.coloff = ncols;
+        const int32_t clo = k.lo > grid_lo ? k.lo : grid_lo, chi = k.hi < grid_hi ? k.hi : grid_hi;
+        k.tile0 = chi >= clo ? (clo - grid_lo) / tile : 0;
+        k.blk0 = nblk;
+        nblk += chi >= clo ? (chi - grid_lo) / tile - k.tile0 + 1 : 0;
+        wsb += need;
+        ncols += k.ncol;
+        ck.push_back(k);
+    }
+    *consumed = c1;
+    const int32_t ng = (int32_t)ck.size();
+    const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, total = o_ck + (size_t)ng * sizeof(IndelChunk);
     NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
     char *ws = (char *)ctx->indel_ws.p;
-    NC_HIP(ctx, hipMemsetAsync(ws, 0, total, ctx->stream));
-    NcTimer tm(ctx, 3);
-    int8_t *ctype = indel_enqueue(ctx, pack, ev, excl_dev, start, end, prm, ws);
+    NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
+    IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
+    NC_HIP(ctx, hipMemcpyAsync(ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), hipMemcpyHostToDevice, ctx->stream));
+    int8_t *ctype = (int8_t *)(ws + o_type);
+#define NC_HAP_DEPTH(B, STAR)                                                                                                        \
+    hipLaunchKernelGGL((k_hap_depth_b<B, STAR>), dim3(nblk), dim3(B), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, \
+                       pack->tile_pos0, ck_dev, ng, ws, prm->haploid)
+    if (nblk > 0) {
+        if (tile == 1024) NC_HAP_DEPTH(64, false);
+        else if (tile == 2048) NC_HAP_DEPTH(128, false);
+        else NC_HAP_DEPTH(256, false);
+        if (impute) {
+            if (tile == 1024) NC_HAP_DEPTH(64, true);
+            else if (tile == 2048) NC_HAP_DEPTH(128, true);
+            else NC_HAP_DEPTH(256, true);
+        }
+    }
+#undef NC_HAP_DEPTH
+    hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
+    if (ev->n_reads > 0)
+        hipLaunchKernelGGL(k_event_intervals_b, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
+                           ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid, impute);
+    hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
+    hipLaunchKernelGGL(k_indel_decide_b, dim3(ng == 1 ? 512 : 64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t,
+                       prm->haploid, impute, ctype);
     NC_HIP(ctx, hipGetLastError());
-    tm.stop();
-    NC_HIP(ctx, hipMemcpyAsync(col_type_host, ctype, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
+    for (int32_t k = 0; k < ng;) {                                   // runs of chunks laid out back to back on the host as well
+        int32_t j = k + 1;
+        while (j < ng && col_off[j] - col_off[k] == ck[(size_t)j].coloff - ck[(size_t)k].coloff) j++;
+        const int64_t nbytes = ck[(size_t)j - 1].coloff + ck[(size_t)j - 1].ncol - ck[(size_t)k].coloff;
+        NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[k], ctype + ck[(size_t)k].coloff, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+        k = j;
+    }
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NC_OK;
 }
 
 // Many chunks of one contig per call: every chunk keeps the reference's per-chunk semantics (fresh window deques at the
-// chunk start).  Ascending chunk lists (the normal case) run as ONE set of launches per group of chunks, the chunk being a
-// grid dimension, with one device-to-host copy of the concatenated decisions; other lists fall back to chunk-by-chunk.
+// chunk start).  Runs of chunks ascending in start and end go into the same launches, the chunk being a grid dimension.
 extern "C" int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev,
                                    int32_t n_chunks, const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm,
                                    int8_t *col_type_host, const int64_t *col_off)
@@ -621,76 +450,28 @@ extern "C" int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const n
     NC_TRY(indel_check(ctx, pack, ev, prm, "nc_indel_scan_batch"));
     if (n_chunks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    bool ascending = true;
-    for (int32_t c = 0; c < n_chunks; c++) {
+    for (int32_t c = 0; c < n_chunks; c++)
         if (ends[c] < starts[c]) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: chunk %d has end < start", c);
-        if (c && (starts[c] < starts[c - 1] || ends[c] < ends[c - 1])) ascending = false;
-    }
-    if (!ascending) {
-        for (int32_t c = 0; c < n_chunks; c++) NC_TRY(nc_indel_scan(ctx, pack, ev, excl_dev, starts[c], ends[c], prm, col_type_host + col_off[c]));
-        return NC_OK;
-    }
-    const int tile = pack->tile_size;
-    const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
     NcTimer tm(ctx, 3);
-    const size_t BUDGET = (size_t)6 << 30;                           // workspace per group of chunks
     int32_t c0 = 0;
     while (c0 < n_chunks) {
-        std::vector<IndelChunk> ck;
-        size_t wsb = 0;
-        int64_t ncols = 0;
-        int32_t nblk = 0, c1 = c0;
-        for (; c1 < n_chunks; c1++) {
-            IndelChunk k;
-            k.lo = starts[c1] < 1 ? 1 : starts[c1];
-            k.hi = ends[c1];
-            k.ncol = k.hi - k.lo + 1;
-            k.nd = k.ncol + prm->win_size + 2;
-            const size_t need = ((size_t)3 * k.ncol * 4 + ((size_t)k.ncol + 1) * 4 + (size_t)8 * k.nd * 4 + 15) & ~(size_t)15;
-            if (!ck.empty() && (wsb + need + (size_t)ncols + k.ncol > BUDGET || ck.size() >= 32768)) break;   // gridDim.y < 65536
-            k.ws = (int64_t)wsb;
-            k.coloff = ncols;
-            const int32_t clo = k.lo > grid_lo ? k.lo : grid_lo, chi = k.hi < grid_hi ? k.hi : grid_hi;
-            k.tile0 = chi >= clo ? (clo - grid_lo) / tile : 0;
-            k.blk0 = nblk;
-            nblk += chi >= clo ? (chi - grid_lo) / tile - k.tile0 + 1 : 0;
-            wsb += need;
-            ncols += k.ncol;
-            ck.push_back(k);
+        int32_t c1 = c0 + 1;                                         // maximal ascending run
+        while (c1 < n_chunks && starts[c1] >= starts[c1 - 1] && ends[c1] >= ends[c1 - 1]) c1++;
+        while (c0 < c1) {
+            int32_t used = 0;
+            NC_TRY(indel_scan_group(ctx, pack, ev, excl_dev, c1 - c0, starts + c0, ends + c0, prm, col_type_host, col_off + c0, &used));
+            c0 += used;
         }
-        const int32_t ng = (int32_t)ck.size();
-        const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, total = o_ck + (size_t)ng * sizeof(IndelChunk);
-        NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
-        char *ws = (char *)ctx->indel_ws.p;
-        NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
-        IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
-        NC_HIP(ctx, hipMemcpyAsync(ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), hipMemcpyHostToDevice, ctx->stream));
-        int8_t *ctype = (int8_t *)(ws + o_type);
-        if (nblk > 0) {
-            if (tile == 1024)
-                hipLaunchKernelGGL(k_hap_depth_b<64>, dim3(nblk), dim3(64), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, ck_dev, ng, ws, prm->haploid);
-            else if (tile == 2048)
-                hipLaunchKernelGGL(k_hap_depth_b<128>, dim3(nblk), dim3(128), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, ck_dev, ng, ws, prm->haploid);
-            else
-                hipLaunchKernelGGL(k_hap_depth_b<256>, dim3(nblk), dim3(256), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, pack->tile_pos0, ck_dev, ng, ws, prm->haploid);
-        }
-        hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
-        if (ev->n_reads > 0)
-            hipLaunchKernelGGL(k_event_intervals_b, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
-                               ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid);
-        hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
-        hipLaunchKernelGGL(k_indel_decide_b, dim3(64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t, prm->haploid, ctype);
-        NC_HIP(ctx, hipGetLastError());
-        // the chunks of a group are consecutive in col_off as well when the caller laid them out back to back
-        bool packed = true;
-        for (int32_t k = 0; k < ng; k++) packed = packed && col_off[c0 + k] == col_off[c0] + ck[(size_t)k].coloff;
-        if (packed) NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[c0], ctype, (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
-        else
-            for (int32_t k = 0; k < ng; k++)
-                NC_HIP(ctx, hipMemcpyAsync(col_type_host + col_off[c0 + k], ctype + ck[(size_t)k].coloff, (size_t)ck[(size_t)k].ncol, hipMemcpyDeviceToHost, ctx->stream));
-        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        c0 = c1;
     }
     tm.stop();
     return NC_OK;
+}
+
+extern "C" int nc_indel_scan(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t start,
+                             int32_t end, const nc_indel_scan_params *prm, int8_t *col_type_host)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!col_type_host || end < start) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan: bad argument");
+    const int64_t off = 0;
+    return nc_indel_scan_batch(ctx, pack, ev, excl_dev, 1, &start, &end, prm, col_type_host, &off);
 }

@@ -244,15 +244,16 @@ class Engine:
         self._check(self.L.nc_indel_forward(self.ctx, kind, n, _ptr(x), _ptr(probs)), "nc_indel_forward")
         return probs
 
-    def indel_scan(self, dp: DevicePack, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None, haploid=False):
-        """K7 -> int8 [end-start+1] per-column decision (-1 none, 0 long-window rule, 1 small-window rule)."""
+    def indel_scan(self, dp: DevicePack, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None, haploid=False, impute=False):
+        """K7 -> int8 [end-start+1] per-column decision (-1 none, 0 long-window rule, 1 small-window rule, 2 impute_indel_phase
+        candidate when impute=True)."""
         if dp.events is None:
             raise ValueError("this read pack carries no indel events / haplotype tags")
         ev = dp.events
         evc = _lib.IndelEventsC(n_reads=ev["n_reads"], ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(),
                                 ev_len=ev["ev_len"].data_ptr(), read_hap=ev["read_hap"].data_ptr())
         prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size),
-                                    ins_t=float(ins_t), del_t=float(del_t), haploid=1 if haploid else 0)
+                                    ins_t=float(ins_t), del_t=float(del_t), haploid=1 if haploid else 0, impute=1 if impute else 0)
         lo = max(1, int(start))
         out = np.empty(int(end) - lo + 1, np.int8)
         pc = dp.c_struct()
@@ -260,16 +261,16 @@ class Engine:
                                          _lib.npp(out)), "nc_indel_scan")
         return out
 
-    def indel_scan_batch(self, dp: DevicePack, chunks, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None, haploid=False):
-        """K7 for a list of (start, end) chunks of one contig -> list of int8 arrays (one per chunk), one device sync per
-        64 chunks instead of one per chunk."""
+    def indel_scan_batch(self, dp: DevicePack, chunks, *, mincov, win_size, small_win_size, ins_t, del_t, excl=None, haploid=False, impute=False):
+        """K7 for a list of (start, end) chunks of one contig -> list of int8 arrays (one per chunk); ascending chunk lists run in
+        the same kernel launches (chunk = a grid dimension)."""
         if dp.events is None:
             raise ValueError("this read pack carries no indel events / haplotype tags")
         ev = dp.events
         evc = _lib.IndelEventsC(n_reads=ev["n_reads"], ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(),
                                 ev_len=ev["ev_len"].data_ptr(), read_hap=ev["read_hap"].data_ptr())
         prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size),
-                                    ins_t=float(ins_t), del_t=float(del_t), haploid=1 if haploid else 0)
+                                    ins_t=float(ins_t), del_t=float(del_t), haploid=1 if haploid else 0, impute=1 if impute else 0)
         starts = np.ascontiguousarray([c[0] for c in chunks], np.int32)
         ends = np.ascontiguousarray([c[1] for c in chunks], np.int32)
         ncol = ends.astype(np.int64) - np.maximum(starts, 1) + 1

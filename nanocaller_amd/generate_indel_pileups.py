@@ -9,7 +9,9 @@
   `msa()` with a pluggable aligner (MUSCLE itself is an external binary, absent here; its aligned rows are the input of
   msa_tensor), `allele_prediction` (row a13) through nc_allele_prediction.  pysam / MUSCLE / parasail parity is unpinned
   (SURVEY.md 8c): the restatements are pinned against independent implementations in tests/.
-The impute_indel_phase branch (:278-304) is not covered.
+* dct['impute_indel_phase'] (:278-304): the column-level predicate (:278-284) is part of the GPU scan (col_type 2); the
+  read grouping of the few flagged columns (:285-304) runs here on their pileup strings (`impute_groups`), and pass 2
+  takes its two read sets from `extra_variants` (:310-312).
 """
 from __future__ import annotations
 
@@ -29,9 +31,10 @@ from .pack import pack_world
 _PACKS = {}
 
 
-def pick_variants(col_type, start, win_size):
+def pick_variants(col_type, start, win_size, groups=None, extra=None):
     """Apply `if v_pos <= prev: continue` (:249) to the per-column decisions; -> {anchor: type} (dict semantics:
-    a later detection overwrites an equal anchor)."""
+    a later detection overwrites an equal anchor).  col_type 2 (impute_indel_phase candidates): `groups(v)` returns the
+    two read-name collections of :285-300 or None; accepted ones go to `extra` {anchor: (names0, names1)} (:301-304)."""
     variants = {}
     prev = 0
     lo = max(1, int(start))
@@ -42,18 +45,98 @@ def pick_variants(col_type, start, win_size):
         if col_type[c] == 0:
             prev = v + win_size
             variants[max(1, v - win_size)] = 0                      # :267-268
-        else:
+        elif col_type[c] == 1:
             prev = v + 10
             variants[max(1, v - 10)] = 1                            # :273-274
+        else:
+            sets = groups(v) if groups else None
+            if sets is not None:
+                prev = v + 10                                       # :301-303
+                variants[max(1, v - 10)] = 1
+                if extra is not None:
+                    extra[max(1, v - 10)] = sets
     return variants
 
 
-def scan_indel_candidates(dct, chunk, device=0, haploid=False):
+def impute_groups(names, strings, mincov):
+    """:285-300 for one column: `names` / `strings` = get_query_names() and the upper-cased get_query_sequences(
+    add_indels=True) in pileup order.  Reads are grouped by identical string; the largest group against the runner-up
+    (or everything else), or, when one group holds more than 80 % of the reads, its two halves.  -> (names0, names1) or
+    None when either side has fewer than mincov reads."""
+    tot = len(names)
+    groups = {}
+    for s, n in zip(strings, names):
+        groups.setdefault(s, []).append(n)
+    order = sorted(groups, key=lambda g: len(groups[g]), reverse=True)          # stable: ties keep first-seen order
+    top = groups[order[0]]
+    if len(top) <= 0.8 * tot:
+        r0 = set(top)
+        r1 = set(groups[order[1]]) if len(groups[order[1]]) >= mincov else set(names) - r0
+    else:
+        r0, r1 = top[:len(top) // 2], top[len(top) // 2:]
+    if len(r0) >= mincov and len(r1) >= mincov:
+        return (r0, r1)
+    return None
+
+
+def column_strings(world, sam_path, chrom, cols, supplementary=False):
+    """{column: (names, upper-cased pileup strings with indels)} of the kept reads, in file order, for the few columns the
+    impute_indel_phase rule looks at.  In-memory worlds carry the inserted bases in meta['ev_ins']; for a BAM file the
+    columns are read through the native reader (base + inserted bases = the head of the pass-2 window at that column)."""
+    cols = sorted(set(int(c) for c in cols))
+    out = {}
+    if not cols:
+        return out
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if supplementary else 0x800)
+    ev_off, ev_pos, ev_len = world.meta["events"]
+    if "ev_ins" in world.meta:
+        ins_off, ins_bases = world.meta["ev_ins"]
+        keep = (world.read_flag & flag) == 0
+        rs, re_ = world.read_start, world.read_end
+        letters = world.meta.get("letters", {})
+        for v in cols:
+            names, strs = [], []
+            for r in np.nonzero(keep & (rs <= v) & (re_ > v))[0]:
+                code = int(world.codes[world.read_off[r] + (v - rs[r])])
+                s = letters.get((int(r), v - 1), "AGTC*"[code]).upper()
+                e0, e1 = ev_off[r], ev_off[r + 1]
+                k = e0 + int(np.searchsorted(ev_pos[e0:e1], v))
+                if k < e1 and ev_pos[k] == v:
+                    ln = int(ev_len[k])
+                    s += ("+%d%s" % (ln, bytes(ins_bases[ins_off[k]:ins_off[k + 1]]).decode().upper())) if ln > 0 else ("-%d%s" % (-ln, "N" * -ln))
+                names.append(world.names[r])
+                strs.append(s)
+            out[v] = (names, strs)
+        return out
+    if not isinstance(sam_path, str):
+        raise ValueError("impute_indel_phase needs the inserted bases: a BAM path, or a world with meta['ev_ins']")
+    from .bam import BamFile
+    sel = np.isin(ev_pos, np.asarray(cols, ev_pos.dtype)) & (ev_len > 0)
+    w_after = 1 + (int(ev_len[sel].max()) if sel.any() else 0)
+    bf = BamFile(sam_path)
+    d = bf.decode(chrom, cols[0], cols[-1], anchors=cols, window_before=0, window_after=w_after, keep_mask=flag)
+    bf.close()
+    for v, win in zip(cols, d["windows"]):
+        names, strs = [], []
+        for r, text in win:
+            e0, e1 = d["ev_off"][r], d["ev_off"][r + 1]
+            k = e0 + int(np.searchsorted(d["ev_pos"][e0:e1], v))
+            deleted = k > e0 and d["ev_len"][k - 1] < 0 and d["ev_pos"][k - 1] - d["ev_len"][k - 1] >= v
+            s = "*" if deleted else (text[:1] or "N")
+            if k < e1 and d["ev_pos"][k] == v:
+                ln = int(d["ev_len"][k])
+                s += ("+%d%s" % (ln, text[1:1 + ln])) if ln > 0 else ("-%d%s" % (-ln, "N" * -ln))
+            names.append(d["names"][r])
+            strs.append(s)
+        out[v] = (names, strs)
+    return out
+
+
+def scan_indel_candidates(dct, chunk, device=0, haploid=False, extra_variants=None):
     """Pass 1 for one chunk (dict, like the reference's per-chunk call) -> {anchor: type}; or for a list of chunks of ONE
     contig and BAM -> list of such dicts, every chunk with the reference's per-chunk semantics, all of them in the same
-    kernel launches (nc_indel_scan_batch)."""
-    if dct.get("impute_indel_phase"):
-        raise NotImplementedError("impute_indel_phase (generate_indel_pileups.py:278-304) is not part of this build")
+    kernel launches (nc_indel_scan_batch).  With dct['impute_indel_phase'] (diploid only) `extra_variants` (a dict, or a
+    list of dicts for a chunk list) receives {anchor: (names0, names1)} of the imputed columns (:304)."""
     chunks = None
     if not isinstance(chunk, dict):
         chunks = list(chunk)
@@ -64,11 +147,12 @@ def scan_indel_candidates(dct, chunk, device=0, haploid=False):
     first = chunk if isinstance(chunk, dict) else chunks[0]
     world = _resolve(first["sam_path"], first["chrom"], dct.get("fasta_path"))
     excl_rows = _exclude_rows(dct, first["chrom"])
-    key = (id(world), bool(dct.get("supplementary")), device)
+    supp = bool(dct.get("supplementary"))
+    key = (id(world), supp, device)
     eng = get_engine(device)
     eng.use_torch_stream()
     if key not in _PACKS:
-        _PACKS[key] = (eng.upload(pack_world(world, supplementary=bool(dct.get("supplementary")))), world)
+        _PACKS[key] = (eng.upload(pack_world(world, supplementary=supp)), world)
     dp = _PACKS[key][0]
     excl = None
     if excl_rows:
@@ -76,13 +160,22 @@ def scan_indel_candidates(dct, chunk, device=0, haploid=False):
         for (a, b) in excl_rows:                                    # IntervalTree.overlaps(pos): a <= pos < b
             m[max(0, a - dp.tile_pos0):max(0, b - dp.tile_pos0)] = 1
         excl = torch.from_numpy(m).to(eng.device)
-    if isinstance(chunk, dict):
-        col_type = eng.indel_scan(dp, chunk["start"], chunk["end"], mincov=dct["mincov"], win_size=dct["win_size"],
-                                  small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=haploid)
-        return pick_variants(col_type, chunk["start"], dct["win_size"])
-    cols = eng.indel_scan_batch(dp, [(c["start"], c["end"]) for c in chunks], mincov=dct["mincov"], win_size=dct["win_size"],
-                                small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=haploid)
-    return [pick_variants(ct, c["start"], dct["win_size"]) for ct, c in zip(cols, chunks)]
+    impute = bool(dct.get("impute_indel_phase")) and not haploid
+    kw = dict(mincov=dct["mincov"], win_size=dct["win_size"], small_win_size=dct["small_win_size"], ins_t=dct["ins_t"],
+              del_t=dct["del_t"], excl=excl, haploid=haploid, impute=impute)
+    one = chunks is None
+    todo = [chunk] if one else chunks
+    cols = [eng.indel_scan(dp, chunk["start"], chunk["end"], **kw)] if one else eng.indel_scan_batch(dp, [(c["start"], c["end"]) for c in chunks], **kw)
+    groups = None
+    if impute:
+        want = np.concatenate([max(1, int(c["start"])) + np.nonzero(ct == 2)[0] for ct, c in zip(cols, todo)])
+        strings = column_strings(world, first["sam_path"], first["chrom"], want, supp)
+        groups = lambda v: impute_groups(*strings[v], dct["mincov"])
+    extras = [extra_variants] if one else (extra_variants if extra_variants is not None else [None] * len(todo))
+    if not one and extra_variants is not None and len(extras) != len(todo):
+        raise ValueError("scan_indel_candidates: extra_variants must be a list of one dict per chunk")
+    out = [pick_variants(ct, c["start"], dct["win_size"], groups, ex) for ct, c, ex in zip(cols, todo, extras)]
+    return out[0] if one else out
 
 
 def msa_tensor(rows_list, ref_rows_list, device=0):
@@ -171,7 +264,8 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
     window_before, window_after = 0, 160
     if dct["seq"] == "pacbio":
         window_after = 260
-    variants = scan_indel_candidates(dct, chunk, device)
+    extra_variants = {}
+    variants = scan_indel_candidates(dct, chunk, device, extra_variants=extra_variants)
     empty = ([], [], [], [], [], [])
     if not variants:
         return empty
@@ -195,11 +289,12 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
         if "N" in ref:
             continue
         d_tot, d0, d1 = {}, {}, {}
+        imputed = extra_variants.get(v_pos)                                      # :310-312
         for r, text in win:
             d_tot[names[r]] = text
-            if hap[r] == 1:
+            if (names[r] in imputed[0]) if imputed else hap[r] == 1:
                 d0[names[r]] = text
-            elif hap[r] == 2:
+            elif (names[r] in imputed[1]) if imputed else hap[r] == 2:
                 d1[names[r]] = text
         f0, _, m0, alt0, ref0 = msa(d0, ref, v_pos, 2, dct["maxcov"], aligner, device)
         f1, _, m1, alt1, ref1 = msa(d1, ref, v_pos, 2, dct["maxcov"], aligner, device)

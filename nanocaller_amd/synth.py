@@ -230,3 +230,41 @@ def add_indels(world: World, seed: int = SEED, het_rate: float = 1 / 1500.0, noi
     world.meta["deco"] = deco
     world.meta["tags"] = {r: {"HP": int(hp[r]), "PS": int(ps[r])} for r in range(R) if hp[r]}
     return world
+
+
+def unphase_blocks(world: World, blocks, seed: int = SEED, drop: float = 0.85, alt_base_frac: float = 0.3) -> World:
+    """Inputs of the impute_indel_phase rule (generate_indel_pileups.py:278-304) on a world decorated by add_indels: the
+    HP tag of most reads overlapping `blocks` [(start, end)] is removed (unphased stretches), and every insertion event
+    gets its inserted bases in world.meta['ev_ins'] = (ins_off int64 [n_events+1], ins_bases uint8 ASCII) - a fraction of
+    the reads carries a different base, so that the reads of a column fall into several groups."""
+    rng = np.random.Generator(np.random.PCG64(seed + 4242))
+    R = world.n_reads
+    ev_off, ev_pos, ev_len = world.meta["events"]
+    hp = np.array(world.meta["hap"], np.uint8)
+    for (a, b) in blocks:
+        m = (world.read_start < b) & (world.read_end > a)
+        hp[m & (rng.random(R) < drop)] = 0
+    n_ev = int(ev_pos.shape[0])
+    ins_len = np.where(ev_len > 0, ev_len, 0).astype(np.int64)
+    ins_off = np.zeros(n_ev + 1, np.int64)
+    np.cumsum(ins_len, out=ins_off[1:])
+    letter = np.frombuffer(b"ACGT", np.uint8)[(ev_pos % 4 + np.where(rng.random(n_ev) < alt_base_frac, rng.integers(1, 4, size=n_ev), 0)) % 4]
+    ins_bases = np.repeat(letter, ins_len)
+    return apply_impute_inputs(world, hp, ins_off, ins_bases)
+
+
+def apply_impute_inputs(world: World, hp, ins_off, ins_bases) -> World:
+    """Install HP tags and inserted bases (and the matching stub-pysam decorations)."""
+    ev_off, ev_pos, ev_len = world.meta["events"]
+    world.meta["hap"] = np.asarray(hp, np.uint8)
+    world.meta["ev_ins"] = (np.asarray(ins_off, np.int64), np.asarray(ins_bases, np.uint8))
+    ps = world.meta["ps"]
+    world.meta["tags"] = {r: {"HP": int(hp[r]), "PS": int(ps[r])} for r in range(world.n_reads) if hp[r]}
+    deco = {}
+    raw = np.asarray(ins_bases, np.uint8).tobytes().decode("ascii")
+    for r in range(world.n_reads):
+        for k in range(int(ev_off[r]), int(ev_off[r + 1])):
+            ln, p = int(ev_len[k]), int(ev_pos[k])
+            deco[(r, p - 1)] = ("+%d%s" % (ln, raw[ins_off[k]:ins_off[k + 1]])) if ln > 0 else ("-%d%s" % (-ln, "N" * (-ln)))
+    world.meta["deco"] = deco
+    return world

@@ -219,6 +219,93 @@ def indel_scan(world, start, end, *, mincov, win_size, small_win_size, ins_t, de
     return vp[:nv.value].copy(), vt[:nv.value].copy()
 
 
+def indel_scan_impute(world, start, end, *, mincov, win_size, small_win_size, ins_t, del_t, exclude=None, supplementary=False):
+    """Pass 1 of get_indel_testing_candidates WITH dct['impute_indel_phase'] (generate_indel_pileups.py:197-304), restated
+    column by column with read-index sets and deques (pure Python: small chunks only) -> (variants {anchor: type},
+    extra_variants {anchor: (read indices 0, read indices 1)}).  Pileup strings: base letter of the read's code (code 4 =
+    '*'), then '+<n><inserted bases>' / '-<n>N..' of an event on this column (world.meta['ev_ins'] holds the bases)."""
+    import collections
+    rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
+    ev_off, ev_pos, ev_len = world.meta["events"]
+    ins_off, ins_bases = world.meta["ev_ins"]
+    hap = world.meta["hap"]
+    raw = np.asarray(ins_bases, np.uint8).tobytes().decode("ascii")
+    excl = np.zeros(world.length + 2, bool)
+    for (a, b) in exclude or []:
+        excl[max(0, a):max(0, b)] = True                              # IntervalTree.overlaps(pos): a <= pos < b
+    lo, hi = max(1, start), min(end, world.length)
+    order = np.nonzero(keep)[0]
+    ev_at = {}
+    for r in order:
+        for k in range(int(ev_off[r]), int(ev_off[r + 1])):
+            ev_at[(int(r), int(ev_pos[k]))] = k
+    classes = [("del", False), ("ins", False), ("del", True), ("ins", True)]
+    dq = {(c, h): collections.deque([set()] * (small_win_size if c >= 2 else win_size), small_win_size if c >= 2 else win_size)
+          for c in range(4) for h in (0, 1)}
+    variants, extra = {}, {}
+    prev = 0
+    for v in range(lo, hi + 1):
+        reads = [int(r) for r in order[(rs[order] <= v) & (re_[order] > v)]]
+        if not reads or excl[v]:
+            continue
+        strs = []
+        for r in reads:
+            s = "AGTC*"[int(codes[ro[r] + (v - rs[r])])]
+            k = ev_at.get((r, v))
+            if k is not None:
+                ln = int(ev_len[k])
+                s += ("+%d%s" % (ln, raw[ins_off[k]:ins_off[k + 1]].upper())) if ln > 0 else ("-%d%s" % (-ln, "N" * -ln))
+            strs.append(s)
+        r0 = [r for r in reads if hap[r] == 1]
+        r1 = [r for r in reads if hap[r] == 2]
+        for c, (kind, small) in enumerate(classes):
+            for h, rh in ((0, r0), (1, r1)):
+                members = set()
+                for r in rh:
+                    k = ev_at.get((r, v))
+                    if k is None:
+                        continue
+                    ln = int(ev_len[k])
+                    if (ln > 0) != (kind == "ins"):
+                        continue
+                    n = abs(ln)
+                    if (n <= 10) if small else (2 < n <= 50):
+                        members.add(r)
+                dq[(c, h)].append(members)
+        if v <= prev:
+            continue
+        n0, n1, tot = len(r0), len(r1), len(reads)
+        if n0 >= mincov and n1 >= mincov:
+            f = {(c, h): (len(set.union(*dq[(c, h)])) / n if n > 0 else 0) for c in range(4) for h, n in ((0, n0), (1, n1))}
+            if max(f[(0, 0)], f[(0, 1)]) >= del_t or max(f[(1, 0)], f[(1, 1)]) >= ins_t:
+                prev = v + win_size
+                variants[max(1, v - win_size)] = 0
+            elif (max(f[(2, 0)], f[(2, 1)]) >= del_t or max(f[(3, 0)], f[(3, 1)]) >= ins_t or f[(2, 0)] + f[(3, 0)] >= 0.9 or
+                  f[(2, 1)] + f[(3, 1)] >= 0.9):
+                prev = v + 10
+                variants[max(1, v - 10)] = 1
+        elif tot >= 2 * mincov:
+            two = "".join(s[:2] for s in strs)
+            del_f = (two.count("-") + two.count("*")) / tot
+            ins_f = two.count("+") / tot
+            if del_t <= del_f or ins_t <= ins_f:
+                groups = {}
+                for s, r in zip(strs, reads):
+                    groups.setdefault(s, []).append(r)
+                counts = sorted(((g, len(m)) for g, m in groups.items()), key=lambda x: x[1], reverse=True)
+                if counts[0][1] <= 0.8 * tot:
+                    a = set(groups[counts[0][0]])
+                    b = set(groups[counts[1][0]]) if counts[1][1] >= mincov else set(reads) - a
+                else:
+                    m = groups[counts[0][0]]
+                    a, b = m[:counts[0][1] // 2], m[counts[0][1] // 2:]
+                if len(a) >= mincov and len(b) >= mincov:
+                    prev = v + 10
+                    variants[max(1, v - 10)] = 1
+                    extra[max(1, v - 10)] = (sorted(a), sorted(b))
+    return variants, extra
+
+
 # ------------------------------------------------------------------------------------------------- indel pass 2 (a11, a13)
 # Pure-Python restatements used only by tests.  parasail / pysam are absent from this image: parity with them is UNPINNED;
 # these pin the library's native code (nc_nw_cigar, nc_allele_prediction, nc_indel_slices) against an independent

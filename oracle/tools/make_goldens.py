@@ -11,6 +11,8 @@ synthetic worlds; what is committed is DATA: the world arrays (inputs) and the r
   caller_vcf.npz           VCF lines written by snpCaller.caller (snpCaller.py:113-198) on canned
                            probabilities (TensorFlow stubbed; the models are replaced by canned outputs)
   indel_msa.npz            msa() tensors (generate_indel_pileups.py:12-73) on canned MUSCLE output
+  indel_scan*.npz          `variants` of pass 1 (:197-276, haploid :185-241) captured from the reference's frame
+  indel_impute.npz         `variants` + `extra_variants` of pass 1 with impute_indel_phase (:278-304)
 """
 import io
 import os
@@ -413,6 +415,52 @@ def make_indel_scan_goldens():
     np.savez_compressed(os.path.join(OUT, "indel_scan_hap.npz"), **rec)
 
 
+def make_indel_impute_goldens():
+    """Pass 1 with dct['impute_indel_phase'] (generate_indel_pileups.py:278-304): `variants` and `extra_variants` captured
+    from the reference's frame, on the indel world with unphased stretches and per-read inserted bases."""
+    from nanocaller_amd.synth import add_indels, unphase_blocks
+    from nanocaller_src import generate_indel_pileups as ref_indel
+
+    w = add_indels(make_world(seed=815, length=60_000, depth=28, tech="ont", read_len_scale=0.5, odd_flag_frac=0.03))
+    w = unphase_blocks(w, [(8_000, 16_000), (33_000, 39_000), (50_000, 52_000)], seed=815)
+    idx = {n: i for i, n in enumerate(w.names)}
+    pysam.register("bam_imp", w)
+    pysam.register("fa_imp", w)
+    pysam.register("bed_imp", [("chr20", 35_000, 36_000)])
+    rec = dict(hap=w.meta["hap"], ins_off=w.meta["ev_ins"][0], ins_bases=w.meta["ev_ins"][1])
+    k = 0
+    for (start, end, kw) in [(1, 30_000, dict(del_t=0.4)), (5_000, 59_000, dict(del_t=0.4)), (30_000, 45_000, {}),
+                             (7_000, 40_000, dict(ins_t=0.3, del_t=0.3, mincov=6, win_size=10, small_win_size=2)),
+                             (30_000, 45_000, dict(del_t=0.4, exclude_bed="bed_imp")), (8_000, 16_000, dict(del_t=0.4, mincov=2)),
+                             (8_000, 16_000, dict(del_t=0.2, ins_t=0.2, mincov=10)), (49_000, 53_000, dict(del_t=0.05, ins_t=0.05))]:
+        dct = dict(seq="ont", fasta_path="fa_imp", win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6,
+                   exclude_bed=None, supplementary=False, impute_indel_phase=True)
+        dct.update(kw)
+        pysam.CAPTURE_INDEL = True
+        pysam.CAPTURED.clear()
+        out = ref_indel.get_indel_testing_candidates(dct, dict(chrom=w.chrom, start=start, end=end, sam_path="bam_imp"))
+        pysam.CAPTURE_INDEL = False
+        assert len(out[0]) == 0
+        v, ex = pysam.CAPTURED["variants"], pysam.CAPTURED["extra_variants"]
+        keys, xkeys = sorted(v), sorted(ex)
+        rec["s%d_start" % k], rec["s%d_end" % k] = start, end
+        for name in ("mincov", "win_size", "small_win_size"):
+            rec["s%d_%s" % (k, name)] = dct[name]
+        rec["s%d_ins_t" % k], rec["s%d_del_t" % k] = np.float64(dct["ins_t"]), np.float64(dct["del_t"])
+        rec["s%d_excl" % k] = np.array([[35_000, 36_000]] if dct["exclude_bed"] else [], np.int64).reshape(-1, 2)
+        rec["s%d_pos" % k] = np.array(keys, np.int64)
+        rec["s%d_type" % k] = np.array([v[p] for p in keys], np.int64)
+        rec["s%d_xpos" % k] = np.array(xkeys, np.int64)
+        for j, p in enumerate(xkeys):                             # the two read collections as sorted read indices
+            for side in (0, 1):
+                rec["s%d_x%d_%d" % (k, j, side)] = np.array(sorted(idx[n] for n in ex[p][side]), np.int32)
+        n_split = sum(1 for p in xkeys if isinstance(ex[p][0], list))
+        print("impute scan [%d,%d] %s -> %d variants, %d imputed (%d by halving the top group)" % (start, end, kw, len(keys), len(xkeys), n_split))
+        k += 1
+    rec["n"] = k
+    np.savez_compressed(os.path.join(OUT, "indel_impute.npz"), **rec)
+
+
 def make_chunk_goldens():
     """get_chunks (utils.py:67-83) on a few region lists; utils.py imports pysam at module top (stub)."""
     import json
@@ -436,7 +484,7 @@ def make_chunk_goldens():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller", "indel_scan"]
+    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller", "indel_scan", "indel_impute"]
     if "snp" in what:
         make_snp_goldens()
     if "cnd" in what:
@@ -451,3 +499,5 @@ if __name__ == "__main__":
         make_indel_caller_goldens()
     if "indel_scan" in what:
         make_indel_scan_goldens()
+    if "indel_impute" in what:
+        make_indel_impute_goldens()

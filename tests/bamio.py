@@ -139,6 +139,10 @@ def world_to_records(world, rng):
         s, e = int(world.read_start[r]), int(world.read_end[r])
         codes = world.read_codes(r)
         evs = {int(ev_pos[k]): int(ev_len[k]) for k in range(ev_off[r], ev_off[r + 1])}
+        ins = {}
+        if "ev_ins" in world.meta:                                               # inserted bases given by the world
+            ins_off, ins_bases = world.meta["ev_ins"]
+            ins = {int(ev_pos[k]): bytes(ins_bases[ins_off[k]:ins_off[k + 1]]).decode() for k in range(ev_off[r], ev_off[r + 1])}
         cig, seq = [("S", 3)], ["ACG"]
         p = s
         run = 0
@@ -151,7 +155,7 @@ def world_to_records(world, rng):
                 run = 0
                 if ev > 0:
                     cig.append(("I", ev))
-                    seq.append("".join(letters[i] for i in rng.integers(0, 4, size=ev)))
+                    seq.append(ins[p] if ins else "".join(letters[i] for i in rng.integers(0, 4, size=ev)))
                 else:
                     cig.append(("D", -ev))
                     p += -ev

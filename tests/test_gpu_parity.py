@@ -385,6 +385,67 @@ def test_indel_scan_chunk_list_matches_reference_pass1(eng):
         assert n > 40
 
 
+def _names_to_idx(sets):
+    return {p: (sorted(int(n[1:]) for n in a), sorted(int(n[1:]) for n in b)) for p, (a, b) in sets.items()}
+
+
+def test_impute_indel_phase_scan_matches_reference_pass1(eng):
+    """K7 with dct['impute_indel_phase'] (generate_indel_pileups.py:278-304): `variants` and `extra_variants` captured from
+    the reference's own frame -- one call per chunk, and all chunks of equal parameters as one chunk list"""
+    from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
+    from tests.util import indel_impute_cases, load_impute_world
+    world = load_impute_world()
+    cases = indel_impute_cases()
+    groups = {}
+    n = 0
+    for c in cases:
+        dct = dict(mincov=c["mincov"], win_size=c["win_size"], small_win_size=c["small_win_size"], ins_t=c["ins_t"],
+                   del_t=c["del_t"], supplementary=False, impute_indel_phase=True,
+                   exclude_bed=[(world.chrom, a, b) for a, b in c["exclude"]] or None)
+        extra = {}
+        got = scan_indel_candidates(dct, dict(chrom=world.chrom, start=c["start"], end=c["end"], sam_path=world), extra_variants=extra)
+        assert sorted(got) == c["pos"].tolist() and [got[p] for p in sorted(got)] == c["type"].tolist(), (c["start"], c["end"])
+        assert _names_to_idx(extra) == c["extra"], (c["start"], c["end"])
+        n += len(extra)
+        key = (c["mincov"], c["win_size"], c["small_win_size"], c["ins_t"], c["del_t"], tuple(map(tuple, c["exclude"])))
+        groups.setdefault(key, (dct, []))[1].append(c)
+    assert n > 300
+    for dct, cs in groups.values():
+        cs.sort(key=lambda c: (c["start"], c["end"]))
+        extras = [{} for _ in cs]
+        got = scan_indel_candidates(dct, [dict(chrom=world.chrom, start=c["start"], end=c["end"], sam_path=world) for c in cs], extra_variants=extras)
+        for g, x, c in zip(got, extras, cs):
+            assert sorted(g) == c["pos"].tolist() and [g[p] for p in sorted(g)] == c["type"].tolist() and _names_to_idx(x) == c["extra"]
+    # the flag off: the plain rule, nothing imputed, on the same unphased world
+    from oracle import oracle
+    dct = dict(mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.4, supplementary=False, impute_indel_phase=False, exclude_bed=None)
+    got = scan_indel_candidates(dct, dict(chrom=world.chrom, start=5_000, end=59_000, sam_path=world))
+    op, ot = oracle.indel_scan(world, 5_000, 59_000, mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.4)
+    assert sorted(got) == op.tolist() and [got[p] for p in sorted(got)] == ot.tolist()
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_impute_indel_phase_scan_matches_oracle_on_other_worlds(eng, seed):
+    """seeded worlds the goldens do not hold (other depth / read lengths / thresholds) against the Python restatement"""
+    from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
+    from nanocaller_amd.synth import add_indels, make_world, unphase_blocks
+    from oracle import oracle
+    w = add_indels(make_world(seed=seed, length=30_000, depth=18 + 10 * (seed % 2), tech="ont", read_len_scale=0.3, odd_flag_frac=0.04), seed=seed)
+    w = unphase_blocks(w, [(2_000, 11_000), (17_000, 26_000)], seed=seed, drop=0.7 + 0.05 * (seed % 2))
+    n = 0
+    for (a, b, kw) in [(1, 30_000, dict(mincov=4, ins_t=0.4, del_t=0.4)), (1_500, 27_000, dict(mincov=3, ins_t=0.25, del_t=0.3)),
+                       (9_000, 20_000, dict(mincov=5, ins_t=0.1, del_t=0.1))]:
+        dct = dict(win_size=40, small_win_size=4, supplementary=False, impute_indel_phase=True, exclude_bed=[(w.chrom, 5_000, 5_600)], **kw)
+        extra = {}
+        got = scan_indel_candidates(dct, dict(chrom=w.chrom, start=a, end=b, sam_path=w), extra_variants=extra)
+        idx = {nm: i for i, nm in enumerate(w.names)}
+        ev, ex = oracle.indel_scan_impute(w, a, b, win_size=40, small_win_size=4, exclude=[(5_000, 5_600)], **kw)
+        assert got == ev, (a, b)
+        assert {p: (sorted(idx[q] for q in s0), sorted(idx[q] for q in s1)) for p, (s0, s1) in extra.items()} == ex
+        n += len(ex)
+    assert n > 30
+
+
 def test_bam_and_fasta_files_end_to_end(eng, tmp_path):
     """real files in (BAM + BAI + FASTA + bgzipped BED), VCF out: identical to the run on the in-memory world"""
     import gzip

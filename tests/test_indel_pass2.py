@@ -243,3 +243,125 @@ def test_get_indel_testing_candidates_end_to_end(tmp_path):
         e_alleles.append(oracle.allele_prediction_ref("".join("AGTC"[c] for c in cns if c != 4), ref, {0: 40, 1: 10}[variants[a]]))
     assert len(hpos) > 3 and hpos == e_pos and halleles == e_alleles
     assert np.array_equal(hx.astype(np.float32), np.stack(e_x))
+
+
+# ----------------------------------------------------------------------------------------- impute_indel_phase (:278-304)
+def test_impute_groups_rules():
+    g = gip.impute_groups
+    names = ["r%d" % i for i in range(10)]
+    # largest group <= 80 %: it against the runner-up when that has mincov reads ...
+    s = ["A"] * 5 + ["A+2GT"] * 4 + ["C"]
+    a, b = g(names, s, 4)
+    assert a == set(names[:5]) and b == set(names[5:9])
+    # ... or against everything else when it has not
+    a, b = g(names, ["A"] * 5 + ["A+2GT"] * 3 + ["C", "*"], 4)
+    assert a == set(names[:5]) and b == set(names[5:])
+    assert g(names, ["A"] * 7 + ["A+2GT"] * 2 + ["C"], 4) is None                 # 7 vs 3 others: one side below mincov
+    # a group above 80 %: its two halves, in pileup order (lists, as in the reference)
+    a, b = g(names, ["A-1N"] * 9 + ["A"], 4)
+    assert a == names[:4] and b == names[4:9]
+    assert g(names, ["A-1N"] * 9 + ["A"], 5) is None
+    # ties keep first-seen order; equal strings only (the inserted bases matter)
+    a, b = g(names[:8], ["A+1G"] * 4 + ["A+1T"] * 4, 4)
+    assert a == set(names[:4]) and b == set(names[4:8])
+
+
+def test_pick_variants_with_imputed_columns():
+    col = np.full(200, -1, np.int8)
+    col[[20, 25, 60, 100, 105, 150]] = [2, 1, 2, 0, 2, 2]
+    calls = []
+
+    def groups(v):
+        calls.append(v)
+        return None if v == 1060 else ({"a"}, {"b"})
+    extra = {}
+    got = gip.pick_variants(col, 1000, 40, groups, extra)
+    # 1020 imputed -> prev 1030 swallows 1025; 1060 refused by the grouping; 1100 long rule -> prev 1140 swallows 1105
+    assert got == {1010: 1, 1060: 0, 1140: 1} and sorted(extra) == [1010, 1140] and calls == [1020, 1060, 1150]
+
+
+def test_column_strings_bam_equals_in_memory_world(tmp_path):
+    """the pileup strings of the imputed columns read back from a BAM file (native reader: base, '*' inside deletions,
+    inserted bases from the query) equal those of the in-memory world the file was written from"""
+    from nanocaller_amd.synth import unphase_blocks
+    w = bamio.make_bam_world(seed=21, length=12_000, depth=14)
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    refc = np.array(["AGTC".find(c) for c in w.ref], np.int64)
+    for r in range(w.n_reads):                                                    # code-4 noise outside deletions -> a base
+        s0, o0 = int(w.read_start[r]), int(w.read_off[r])
+        span = w.codes[o0:int(w.read_off[r + 1])]
+        deleted = np.zeros(len(span), bool)
+        for k in range(ev_off[r], ev_off[r + 1]):
+            if ev_len[k] < 0:
+                deleted[ev_pos[k] + 1 - s0:ev_pos[k] + 1 - s0 - ev_len[k]] = True
+        fix = (span == 4) & ~deleted
+        span[fix] = np.maximum(refc[s0 - 1:s0 - 1 + len(span)][fix], 0)
+    w = unphase_blocks(w, [(3_000, 9_000)], seed=3)
+    bam, fa = str(tmp_path / "c.bam"), str(tmp_path / "c.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, np.random.Generator(np.random.PCG64(1))))
+    cols = sorted(set(ev_pos[::7].tolist() + (ev_pos[ev_len < 0][::5] + 1).tolist() + list(range(5_000, 5_040))))
+    a = gip.column_strings(w, None, w.chrom, cols)
+    w2 = type(w)(chrom=w.chrom, ref=w.ref, read_start=w.read_start, read_end=w.read_end, read_flag=w.read_flag, read_off=w.read_off,
+                 codes=w.codes, names=w.names)
+    w2.meta.update(events=w.meta["events"], hap=w.meta["hap"], ps=w.meta["ps"])   # no 'ev_ins': forces the BAM route
+    b = gip.column_strings(w2, bam, w.chrom, cols)
+    assert sorted(a) == sorted(b) == cols
+    n_ins = n_del = n_star = 0
+    for v in cols:
+        assert a[v] == b[v], v
+        n_ins += sum("+" in s for s in a[v][1]); n_del += sum("-" in s for s in a[v][1]); n_star += sum(s[0] == "*" for s in a[v][1])
+    assert n_ins > 50 and n_del > 50 and n_star > 50
+    with pytest.raises(ValueError):
+        gip.column_strings(w2, None, w.chrom, cols)
+
+
+@pytest.mark.gpu
+def test_get_indel_testing_candidates_uses_imputed_read_sets(tmp_path):
+    """BAM + FASTA in, impute_indel_phase on: at the imputed anchors the three msa() calls get the read sets of
+    `extra_variants` (generate_indel_pileups.py:310-312,335-339), at the others the HP sets -- checked through the aligner hook
+    against the Python restatement of pass 1"""
+    from nanocaller_amd.bam import read_bam
+    from nanocaller_amd.synth import unphase_blocks
+    w = bamio.make_bam_world(seed=31, length=20_000, depth=18)
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    refc = np.array(["AGTC".find(c) for c in w.ref], np.int64)
+    for r in range(w.n_reads):
+        s0, o0 = int(w.read_start[r]), int(w.read_off[r])
+        span = w.codes[o0:int(w.read_off[r + 1])]
+        deleted = np.zeros(len(span), bool)
+        for k in range(ev_off[r], ev_off[r + 1]):
+            if ev_len[k] < 0:
+                deleted[ev_pos[k] + 1 - s0:ev_pos[k] + 1 - s0 - ev_len[k]] = True
+        fix = (span == 4) & ~deleted
+        span[fix] = np.maximum(refc[s0 - 1:s0 - 1 + len(span)][fix], 0)
+    w = unphase_blocks(w, [(4_000, 15_000)], seed=31)
+    bam, fa = str(tmp_path / "m.bam"), str(tmp_path / "m.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, np.random.Generator(np.random.PCG64(2))))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    dct = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=3, maxcov=160, ins_t=0.3, del_t=0.3,
+               supplementary=False, exclude_bed=None, impute_indel_phase=True)
+    chunk = dict(chrom=w.chrom, start=1_000, end=19_000, sam_path=bam)
+    seen = []
+
+    def spy(names, seqs, ref):
+        seen.append(list(names))
+        return _pad_aligner(names, seqs, ref)
+    pos, x0, x1, x2, alleles, phase = gip.get_indel_testing_candidates(dct, chunk, aligner=spy)
+    ev, ex = oracle.indel_scan_impute(w, 1_000, 19_000, mincov=3, win_size=40, small_win_size=4, ins_t=0.3, del_t=0.3)
+    assert len(ex) > 5 and len(ev) > len(ex)
+    anchors = [a for a in sorted(ev) if all(c in "AGTC" for c in w.ref[a - 1:min(w.length, a + 161)])]      # :326 ('N' in ref)
+    assert len(seen) == 3 * len(anchors)
+    hap = w.meta["hap"]
+    n_imp = 0
+    for k, a in enumerate(anchors):
+        at = [r for r in range(w.n_reads) if (w.read_flag[r] & 0xF04) == 0 and w.read_start[r] <= a < w.read_end[r]]
+        if a in ex:
+            e0, e1 = ex[a]
+            n_imp += 1
+        else:
+            e0, e1 = [r for r in at if hap[r] == 1], [r for r in at if hap[r] == 2]
+        here = set(at)
+        assert seen[3 * k] == sorted(w.names[r] for r in e0 if r in here), a
+        assert seen[3 * k + 1] == sorted(w.names[r] for r in e1 if r in here and r not in set(e0)), a
+        assert seen[3 * k + 2] == sorted(w.names[r] for r in at), a
+    assert n_imp > 5 and set(pos) <= set(anchors)

@@ -65,3 +65,24 @@ def test_haploid_indel_window_scan_matches_reference_pass1():
                                      small_win_size=c["small_win_size"], ins_t=c["ins_t"], del_t=c["del_t"],
                                      exclude=c["exclude"], haploid=True)
         assert np.array_equal(pos, c["pos"]) and np.array_equal(typ, c["type"]), (c["start"], c["end"])
+
+
+def test_impute_indel_phase_scan_matches_reference_pass1():
+    """generate_indel_pileups.py:197-304 with dct['impute_indel_phase']: `variants` AND `extra_variants` (the two read
+    collections per imputed anchor) captured from the reference's own frame; also the plain branch of the Python
+    restatement against the C oracle on the same world"""
+    from tests.util import indel_impute_cases, load_impute_world
+    world = load_impute_world()
+    cases = indel_impute_cases()
+    assert len(cases) >= 8 and sum(len(c["extra"]) for c in cases) > 300
+    for c in cases:
+        kw = dict(mincov=c["mincov"], win_size=c["win_size"], small_win_size=c["small_win_size"], ins_t=c["ins_t"], del_t=c["del_t"],
+                  exclude=c["exclude"])
+        v, x = oracle.indel_scan_impute(world, c["start"], c["end"], **kw)
+        assert sorted(v) == c["pos"].tolist() and [v[p] for p in sorted(v)] == c["type"].tolist(), (c["start"], c["end"])
+        assert x == c["extra"], (c["start"], c["end"])
+    # thresholds nothing imputed can reach: the restatement must agree with the C oracle of the plain rule
+    kw = dict(mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6)
+    v, x = oracle.indel_scan_impute(world, 20_000, 30_000, **dict(kw, mincov=4))
+    pos, typ = oracle.indel_scan(world, 20_000, 30_000, **kw)
+    assert not x and sorted(v) == pos.tolist() and [v[p] for p in sorted(v)] == typ.tolist() and len(v) > 3

@@ -58,6 +58,32 @@ def assert_tuple_matches_gold(out, gold):
     assert np.array_equal(np.asarray(rev), gold["rev_dp"])
 
 
+def load_impute_world():
+    """the indel world with unphased stretches + per-read inserted bases (inputs stored in indel_impute.npz)"""
+    if "impute" not in _worlds:
+        import copy
+        from nanocaller_amd.synth import apply_impute_inputs
+        z = np.load(os.path.join(GOLD, "indel_impute.npz"))
+        base = load_world("indel")
+        w = copy.copy(base)
+        w.meta = dict(base.meta)
+        _worlds["impute"] = apply_impute_inputs(w, z["hap"], z["ins_off"], z["ins_bases"])
+    return _worlds["impute"]
+
+
+def indel_impute_cases():
+    z = np.load(os.path.join(GOLD, "indel_impute.npz"))
+    out = []
+    for k in range(int(z["n"])):
+        xpos = z["s%d_xpos" % k]
+        out.append(dict(start=int(z["s%d_start" % k]), end=int(z["s%d_end" % k]), mincov=int(z["s%d_mincov" % k]),
+                        win_size=int(z["s%d_win_size" % k]), small_win_size=int(z["s%d_small_win_size" % k]),
+                        ins_t=float(z["s%d_ins_t" % k]), del_t=float(z["s%d_del_t" % k]),
+                        exclude=[(int(a), int(b)) for a, b in z["s%d_excl" % k]], pos=z["s%d_pos" % k], type=z["s%d_type" % k],
+                        extra={int(p): (z["s%d_x%d_0" % (k, j)].tolist(), z["s%d_x%d_1" % (k, j)].tolist()) for j, p in enumerate(xpos)}))
+    return out
+
+
 def indel_scan_cases(haploid=False):
     z = np.load(os.path.join(GOLD, "indel_scan_hap.npz" if haploid else "indel_scan.npz"))
     out = []
