@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--model", default="ONT-HG002")
     ap.add_argument("--ploidy", default="diploid", choices=["diploid", "haploid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="collect every step's results before the next step is enqueued")
     ap.add_argument("--cpu-sample-chunks", type=int, default=16)
     ap.add_argument("--cnn-precision", default="default", choices=["default", "fp32", "fp16x3"],
                     help="trunk kernel: exact fp32 MFMA (k4_conv12) or fp16x3 split precision (k5_trunk_h3)")
@@ -139,32 +140,60 @@ def main():
     def step():
         return snpCaller.call_chunks(params, chunks, device=local, dpk=pack)
 
-    step()                                  # setup: one priming call sizes the device / pinned-host buffer pools (untimed, not a warmup step)
-    for _ in range(args.warmup):
-        step()
-    eng.enable_timing(True)
-    stage_ms = np.zeros(5)
+    def run_steps(n):
+        """n steps, step i+1 enqueued behind step i's CNN unless --no-overlap; every result is collected before returning"""
+        prev, r = None, None
+        for _ in range(n):
+            cur = snpCaller.call_chunks(params, chunks, device=local, dpk=pack, defer=not args.no_overlap)
+            if prev is not None:
+                r = prev.result() if not args.no_overlap else prev
+            prev = cur
+        if prev is not None:
+            r = prev.result() if not args.no_overlap else prev
+        return r
+
+    run_steps(2)                            # setup: priming calls size the device / pinned-host buffer pools (untimed, not warmup steps)
+    run_steps(args.warmup)
+    # The timed region: K steps, each enqueued as soon as the previous one's CNN is (snpCaller.caller does the same with
+    # consecutive contig groups): step i's results drain and the host turns around while the GPU already runs step i+1's
+    # scan.  All K results are collected (copies complete) before the closing synchronize.
+    eng.enable_timing(True, trunk_only=True)                      # live HIP events on the dominant kernel's launches only
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-        stage_ms += [eng.last_ms(0), eng.last_ms(1), eng.last_ms(2), eng.last_ms(4), eng.last_ms(5)]
+    r = run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    sums, _ = eng.timing_sums()                                   # HIP-event totals over the K steps of the timed region
+    trunk_ms, trunk_launches = sums[4], sums[5]
     eng.enable_timing(False)
     n_sites = int(r["n"])
     from nanocaller_amd.shard import dist_max, dist_sum
     dt = dist_max(dt)                       # MAX over ranks
     total_sites = dist_sum(n_sites)         # whole-job aggregate
-    stage_ms /= max(1, args.steps)
+    # stage breakdown (scan / featurize / CNN stage): event pairs around each stage put barrier packets on the stream, so
+    # they are taken in their own short loop after the timed region
+    eng.enable_timing(True)
+    for _ in range(min(3, args.steps)):
+        step()
+    sums, cnt = eng.timing_sums()
+    eng.enable_timing(False)
+    stage_ms = np.array([sums[0] / max(1, cnt[0]), sums[1] / max(1, cnt[1]), sums[2] / max(1, cnt[2]),
+                         trunk_ms / max(1, args.steps), trunk_launches / max(1, args.steps)])
     # host genotype rules + VCF record text for one step's results (native formatter), untimed above: it is the third
     # number SURVEY.md 8(d) asks for (kernels only / + D2H / end to end incl. host K6 + VCF text)
     tv = time.perf_counter()
     vcf = snpCaller.snp_vcf_text("chr20", r["pos"], r["ref"], r["probs"], r["dp"], r["freq"], r["fwd_dp"], r["rev_dp"],
                                  haploid=(args.ploidy == "haploid"), as_array=True)
     vcf_ms = (time.perf_counter() - tv) * 1e3
+    # the same K steps strictly one after the other (results collected before the next step is enqueued), for comparison
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sequential_ms = (time.perf_counter() - ts) * 1e3 / args.steps
     # the production loop (snpCaller.caller) formats contig i on a worker thread while the GPU runs contig i+1: measure that
     # pipeline on the same step repeated args.steps times
     from concurrent.futures import ThreadPoolExecutor
@@ -178,11 +207,15 @@ def main():
         torch.cuda.synchronize()
         tp = time.perf_counter()
         pend = None
-        for _ in range(args.steps):
-            res = step()
-            if pend is not None:
-                pend.result()
-            pend = pool.submit(fmt, res)
+        prev = None
+        for _ in range(args.steps + 1):
+            cur = snpCaller.call_chunks(params, chunks, device=local, dpk=pack, defer=True) if _ < args.steps else None
+            if prev is not None:
+                res = prev.result()
+                if pend is not None:
+                    pend.result()
+                pend = pool.submit(fmt, res)
+            prev = cur
         pend.result()
         pipelined_ms = (time.perf_counter() - tp) * 1e3 / args.steps
     if rank == 0:
@@ -223,10 +256,13 @@ def main():
             "roofline": roofline,
             "three_numbers": {"kernels_only_sites_s": n_sites / ((stage_ms[0] + stage_ms[1] + stage_ms[2]) * 1e-3),
                               "with_d2h_sites_s": n_sites / (ms_per_step * 1e-3),
+                              "with_d2h_sequential_calls_sites_s": n_sites / (sequential_ms * 1e-3),
                               "end_to_end_incl_vcf_text_sites_s": n_sites / ((ms_per_step + vcf_ms) * 1e-3),
                               "end_to_end_incl_vcf_text_pipelined_sites_s": n_sites / (pipelined_ms * 1e-3),
                               "vcf_text_ms": vcf_ms, "vcf_bytes": len(vcf),
-                              "note": "rank 0, per GPU; pipelined = VCF text of step i formatted on a host thread while the GPU runs step i+1 (snpCaller.caller)"},
+                              "note": "rank 0, per GPU; with_d2h = the timed region (step i+1 enqueued behind step i's CNN, all results collected "
+                                      "inside the region); sequential_calls = results collected before the next step is enqueued; "
+                                      "pipelined = + VCF text of step i formatted on a host thread while the GPU runs step i+1 (snpCaller.caller)"},
             "stages": {"scan_ms": float(stage_ms[0]), "scan_GBs": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 if stage_ms[0] else 0,
                        "scan_frac_hbm": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[0] else 0,
                        "featurize_ms": float(stage_ms[1]),

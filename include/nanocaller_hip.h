@@ -66,7 +66,13 @@ int nc_memcpy_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes);
  * `which`: 0 scan kernel, 1 featurize kernel, 2 CNN forward (all kernels), 3 indel tensor / scan,
  * 4 sum over the launches of the fused SNP trunk kernel in the last forward, 5 number of those launches. */
 int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms);
+/* on = 1: all six; on = 2: only the trunk kernel's launches (4, 5) -- their start / stop events ride on the kernel's own
+ * dispatch packets and do not perturb the stream, whereas each stage timer puts two barrier packets on it; 0: off. */
 int nc_enable_timing(nc_ctx *ctx, int on);
+/* Totals of the same six quantities over all calls since nc_enable_timing(ctx, 1) (sum_ms[6]; count[6] = calls folded in,
+ * may be NULL).  A call's timers are folded in when its events are re-used by the next call of the same stage or here, so
+ * calls may be left in flight while the next one is enqueued (snpCaller.call_chunks(defer=True)). */
+int nc_timing_sums(nc_ctx *ctx, double *sum_ms, int64_t *count);
 
 /* ------------------------------------------------------------------ packed alignments ("read pack")
  * Replaces the pysam pileup objects of generate_SNP_pileups.py:134-164: alignments decoded once on the

@@ -29,7 +29,7 @@ EXPORTS = [
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
-    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch",
+    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
         L.nc_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.nc_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.nc_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+        L.nc_timing_sums.argtypes = [vp, vp, vp]
         L.nc_enable_timing.argtypes = [vp, C.c_int]
         L.nc_set_cnn_precision.argtypes = [vp, C.c_int]
         L.nc_pack_plan.argtypes = [i32, vp, vp, vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),

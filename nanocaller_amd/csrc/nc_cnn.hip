@@ -14,6 +14,8 @@
 #include <cmath>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "nc_common.h"
 
 namespace {
@@ -1094,19 +1096,20 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         const unsigned nblk5 = (unsigned)(nb < 256 ? nb : 256);        // k5: one 512-thread workgroup per CU
         (void)np3; (void)a2; (void)k3; (void)b3;
         const bool tk = ctx->timing && ctx->n_kev + 2 <= 128;
+        // timing mode: the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL), so they
+        // read the kernel's execution time and put no barrier packets between the launches of a batch
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (tk) {
             for (int e = 0; e < 2; e++)
                 if (!ctx->kev[ctx->n_kev + e]) NC_HIP(ctx, hipEventCreate(&ctx->kev[ctx->n_kev + e]));
-            (void)hipEventRecord(ctx->kev[ctx->n_kev], ctx->stream);
-        }
-        if (ctx->cnn_exact_fp32)
-            hipLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, x_batch, packed, a3, nb, scale, scale_mode, site0);
-        else
-            hipLaunchKernelGGL(k5_trunk_h3, dim3(nblk5), dim3(512), 0, ctx->stream, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
-        if (tk) {
-            (void)hipEventRecord(ctx->kev[ctx->n_kev + 1], ctx->stream);
+            ev0 = ctx->kev[ctx->n_kev];
+            ev1 = ctx->kev[ctx->n_kev + 1];
             ctx->n_kev += 2;
         }
+        if (ctx->cnn_exact_fp32)
+            hipExtLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, ev0, ev1, 0, x_batch, packed, a3, nb, scale, scale_mode, site0);
+        else
+            hipExtLaunchKernelGGL(k5_trunk_h3, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
         if (ctx->cnn_exact_fp32)
             hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
         else
@@ -1303,6 +1306,7 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
     if (scale_mode != 0 && scale_mode != 1) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: scale_mode");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     NcTimer tm(ctx, 2);
+    if (ctx->timing) nc_timing_resolve(ctx, 4);   // fold an earlier call's per-launch events in before they are re-used
     ctx->n_kev = 0;
     const int64_t BATCH = 65536;
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {

@@ -27,7 +27,7 @@ struct nc_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     char err[512] = {0};
-    bool timing = false;
+    int timing = 0;                           // 0 off; 1 stage timers + trunk launches; 2 trunk launches only (events on the dispatch packets, no barrier packets)
     bool cnn_exact_fp32 = false;   // false: fp16x3 split-precision trunk (default); true: exact fp32 MFMA trunk
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
@@ -36,6 +36,8 @@ struct nc_ctx {
     hipEvent_t tev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // stage timers (scan, featurize, CNN, indel)
     bool tev_pending[4] = {false, false, false, false};
     bool kev_pending = false;
+    double sum_ms[6] = {0, 0, 0, 0, 0, 0};   // running totals of last_ms[] since nc_enable_timing(1): calls may be left in flight
+    int64_t sum_n[6] = {0, 0, 0, 0, 0, 0};   // while the next one is enqueued, their timers are folded in before the events are re-used
     hipEvent_t drain_ev[4] = {nullptr};       // batch-complete events of nc_snp_forward_drain
 
     // scan results (device)
@@ -96,6 +98,9 @@ inline int nc_ensure(nc_ctx *ctx, DevBuf &b, size_t bytes)
         if (rc_ != NC_OK) return rc_; \
     } while (0)
 
+// resolves pending event pairs of stage `which` (0..3) or of the trunk launches (4) into last_ms / sum_ms (nc_ctx.hip)
+extern "C" __attribute__((visibility("hidden"))) void nc_timing_resolve(nc_ctx *ctx, int which);
+
 // Stage timer (timing mode only): records an event pair on the launch stream and does NOT wait; the elapsed time is
 // resolved lazily by nc_last_kernel_ms, so a timed step is not perturbed by host synchronisations.
 struct NcTimer {
@@ -103,7 +108,8 @@ struct NcTimer {
     int which;
     NcTimer(nc_ctx *c, int w) : ctx(c), which(w)
     {
-        if (ctx->timing) {
+        if (ctx->timing == 1) {
+            nc_timing_resolve(ctx, which);                   // an earlier call's pair (complete by now or soon): fold it in first
             for (int e = 0; e < 2; e++)
                 if (!ctx->tev[which][e]) (void)hipEventCreate(&ctx->tev[which][e]);
             (void)hipEventRecord(ctx->tev[which][0], ctx->stream);
@@ -111,7 +117,7 @@ struct NcTimer {
     }
     void stop()
     {
-        if (ctx->timing) {
+        if (ctx->timing == 1) {
             (void)hipEventRecord(ctx->tev[which][1], ctx->stream);
             ctx->tev_pending[which] = true;
         }

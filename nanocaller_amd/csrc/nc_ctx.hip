@@ -137,31 +137,55 @@ int nc_set_cnn_precision(nc_ctx *ctx, int exact_fp32)
 int nc_enable_timing(nc_ctx *ctx, int on)
 {
     if (!ctx) return NC_ERR_ARG;
-    ctx->timing = on != 0;
+    if (on && !ctx->timing)
+        for (int w = 0; w < 6; w++) { ctx->sum_ms[w] = 0.0; ctx->sum_n[w] = 0; }
+    ctx->timing = on == 2 ? 2 : on != 0;
     return NC_OK;
+}
+
+void nc_timing_resolve(nc_ctx *ctx, int which)
+{
+    if (which < 4) {
+        if (!ctx->tev_pending[which]) return;
+        if (hipEventSynchronize(ctx->tev[which][1]) == hipSuccess &&
+            hipEventElapsedTime(&ctx->last_ms[which], ctx->tev[which][0], ctx->tev[which][1]) == hipSuccess) {
+            ctx->sum_ms[which] += ctx->last_ms[which];
+            ctx->sum_n[which]++;
+        }
+        ctx->tev_pending[which] = false;
+        return;
+    }
+    if (!ctx->kev_pending) return;                            // per-launch durations of the trunk kernel, on the launch stream
+    float tot = 0.0f;
+    for (int e = 0; e + 1 < ctx->n_kev; e += 2) {
+        float one = 0.0f;
+        if (hipEventSynchronize(ctx->kev[e + 1]) == hipSuccess && hipEventElapsedTime(&one, ctx->kev[e], ctx->kev[e + 1]) == hipSuccess) tot += one;
+    }
+    ctx->last_ms[4] = tot;
+    ctx->last_ms[5] = (float)(ctx->n_kev / 2);
+    ctx->sum_ms[4] += tot;
+    ctx->sum_ms[5] += ctx->n_kev / 2;
+    ctx->sum_n[4]++;
+    ctx->sum_n[5]++;
+    ctx->kev_pending = false;
 }
 
 int nc_last_kernel_ms(nc_ctx *ctx, int which, float *ms)
 {
     if (!ctx || !ms || which < 0 || which > 5) return NC_ERR_ARG;
-    if (which < 4 && ctx->tev_pending[which]) {              // resolve the stage's event pair now
-        NC_HIP(ctx, hipEventSynchronize(ctx->tev[which][1]));
-        NC_HIP(ctx, hipEventElapsedTime(&ctx->last_ms[which], ctx->tev[which][0], ctx->tev[which][1]));
-        ctx->tev_pending[which] = false;
-    }
-    if (which >= 4 && ctx->kev_pending) {                    // per-launch durations of the trunk kernel, on the launch stream
-        float tot = 0.0f;
-        for (int e = 0; e + 1 < ctx->n_kev; e += 2) {
-            float one = 0.0f;
-            NC_HIP(ctx, hipEventSynchronize(ctx->kev[e + 1]));
-            NC_HIP(ctx, hipEventElapsedTime(&one, ctx->kev[e], ctx->kev[e + 1]));
-            tot += one;
-        }
-        ctx->last_ms[4] = tot;
-        ctx->last_ms[5] = (float)(ctx->n_kev / 2);
-        ctx->kev_pending = false;
-    }
+    nc_timing_resolve(ctx, which < 4 ? which : 4);
     *ms = ctx->last_ms[which];
+    return NC_OK;
+}
+
+int nc_timing_sums(nc_ctx *ctx, double *sum_ms, int64_t *count)
+{
+    if (!ctx || !sum_ms) return NC_ERR_ARG;
+    for (int w = 0; w < 5; w++) nc_timing_resolve(ctx, w);
+    for (int w = 0; w < 6; w++) {
+        sum_ms[w] = ctx->sum_ms[w];
+        if (count) count[w] = ctx->sum_n[w];
+    }
     return NC_OK;
 }
 

@@ -130,13 +130,22 @@ class Engine:
         """False (default): fp16x3 split-precision trunk; True: exact fp32 MFMA trunk."""
         self._check(self.L.nc_set_cnn_precision(self.ctx, 1 if exact_fp32 else 0), "nc_set_cnn_precision")
 
-    def enable_timing(self, on=True):
-        self._check(self.L.nc_enable_timing(self.ctx, 1 if on else 0), "nc_enable_timing")
+    def enable_timing(self, on=True, trunk_only=False):
+        """HIP-event timers: all stages, or (trunk_only) just the trunk kernel's launches, whose events ride on the
+        kernel's dispatch packets and leave the stream undisturbed"""
+        self._check(self.L.nc_enable_timing(self.ctx, (2 if trunk_only else 1) if on else 0), "nc_enable_timing")
 
     def last_ms(self, which):
         ms = C.c_float()
         self._check(self.L.nc_last_kernel_ms(self.ctx, which, C.byref(ms)), "nc_last_kernel_ms")
         return float(ms.value)
+
+    def timing_sums(self):
+        """-> (sum_ms float64 [6], count int64 [6]) over the calls since enable_timing(True): 0 scan, 1 featurize, 2 CNN
+        stage, 3 indel, 4 trunk kernel launches (summed), 5 number of trunk launches."""
+        sums, cnt = np.zeros(6, np.float64), np.zeros(6, np.int64)
+        self._check(self.L.nc_timing_sums(self.ctx, _lib.npp(sums), _lib.npp(cnt)), "nc_timing_sums")
+        return sums, cnt
 
     # ------------------------------------------------------------------ data movement
     def upload(self, hp: HostPack) -> DevicePack:

@@ -173,10 +173,25 @@ def _weights(path):
     return _WEIGHTS[path]
 
 
-def call_chunks(params, chunks, device=0, dpk=None):
+class PendingCall:
+    """call_chunks(defer=True): everything is enqueued, the result copies may still be in flight; result() waits for them."""
+
+    def __init__(self, finish):
+        self._finish, self._res = finish, None
+
+    def result(self):
+        if self._finish is not None:
+            self._res, self._finish = self._finish(), None
+        return self._res
+
+
+def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     """Run pileup featurisation + CNN for a list of chunks of ONE contig and ploidy on the GPU.
     `dpk`: alignments already resident in HBM (engine.DevicePack); default: packed from params['sam_path'].
-    -> dict of host arrays (pos, chunk, ref, probs, gt, dp, freq, fwd_dp, rev_dp, chunk_depth)."""
+    -> dict of host arrays (pos, chunk, ref, probs, gt, dp, freq, fwd_dp, rev_dp, chunk_depth).
+    defer=True -> PendingCall: returns once the CNN is enqueued; the caller starts the next group (its scan queues right
+    behind this group's CNN, so the GPU does not idle while results drain and the host turns around) and collects
+    result() afterwards."""
     chrom = chunks[0]['chrom']
     ploidy = chunks[0]['ploidy']
     assert all(c['chrom'] == chrom and c['ploidy'] == ploidy for c in chunks)
@@ -203,7 +218,7 @@ def call_chunks(params, chunks, device=0, dpk=None):
     res = dict(chrom=chrom, ploidy=ploidy, n=0)
     if sites.n_sites == 0:
         eng.wait_copies()
-        return res
+        return PendingCall(lambda: res) if defer else res
     scan_copied = eng.copy_event()
     eng.snp_featurize(dpk, sites, seq=params['seq'], maxcov=params['maxcov'], min_nbr_sites=params['min_nbr_sites'])
     all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
@@ -211,19 +226,26 @@ def call_chunks(params, chunks, device=0, dpk=None):
     scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site)
     # enqueued after the (short, latency-sensitive) scale kernel so that these copies run under the CNN, not beside it
     h_ref, h_fwd, h_rev, h_valid = eng.to_host_async([sites.ref_code, sites.fwd_dp, sites.rev_dp, None if all_valid else sites.valid])
-    _, _, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True)
+    d_probs, d_gt, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True)
+    drained = eng.copy_event()                                     # completes with this call's last result copy
     # host work that only needs the scan results runs under the CNN: freq = alt / n in float64 (:166)
     scan_copied.synchronize()
     freq = sites.alt.astype(np.float64) / sites.dp.astype(np.float64)
-    eng.wait_copies()
-    out = dict(pos=sites.pos, chunk=sites.chunk, ref=h_ref, probs=h_probs, gt=h_gt, dp=sites.dp, alt=sites.alt,
-               fwd_dp=h_fwd, rev_dp=h_rev, freq=freq)
-    if not all_valid:
-        m = h_valid.astype(bool)
-        out = {k: (v[m] if v is not None else None) for k, v in out.items()}
-    # host arrays keep the device dtypes (int32 / float32)
-    res.update(out, n=int(out['pos'].shape[0]), chunk_depth=chunk_depth)
-    return res
+    keep_alive = (sites, scale, d_probs, d_gt)                     # device buffers the pending copies read from
+
+    def finish():
+        nonlocal keep_alive
+        drained.synchronize()
+        keep_alive = None
+        out = dict(pos=sites.pos, chunk=sites.chunk, ref=h_ref, probs=h_probs, gt=h_gt, dp=sites.dp, alt=sites.alt,
+                   fwd_dp=h_fwd, rev_dp=h_rev, freq=freq)
+        if not all_valid:
+            m = h_valid.astype(bool)
+            out = {k: (v[m] if v is not None else None) for k, v in out.items()}
+        # host arrays keep the device dtypes (int32 / float32)
+        res.update(out, n=int(out['pos'].shape[0]), chunk_depth=chunk_depth)
+        return res
+    return PendingCall(finish) if defer else finish()
 
 
 def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
@@ -264,13 +286,23 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             counter_Q.put(1)
 
     with open(curr_vcf_path, 'wb') as f, ThreadPoolExecutor(max_workers=1) as pool:
-        pending = None
-        for (chrom, ploidy), grp in groups.items():
-            grp.sort(key=lambda c: c['start'])
-            r = call_chunks(params, grp, device)
+        pending, in_flight = None, None
+
+        def collect():
+            nonlocal pending
+            chrom, ploidy, call, grp = in_flight
+            r = call.result()
             if pending is not None:
                 pending.result()                                    # keeps the records in group order; re-raises errors
             pending = pool.submit(emit, f, chrom, ploidy, r, grp)
+        for (chrom, ploidy), grp in groups.items():
+            grp.sort(key=lambda c: c['start'])
+            call = call_chunks(params, grp, device, defer=True)     # enqueued behind the previous group's CNN
+            if in_flight is not None:
+                collect()
+            in_flight = (chrom, ploidy, call, grp)
+        if in_flight is not None:
+            collect()
         if pending is not None:
             pending.result()
 
