@@ -410,6 +410,9 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
                            (int32_t *)ctx->site_alt.p);
         NC_HIP(ctx, hipGetLastError());
     }
+    // k_sites runs behind the last synchronisation: copies of the site arrays from another stream wait for this event
+    if (!ctx->scan_ev) NC_HIP(ctx, hipEventCreateWithFlags(&ctx->scan_ev, hipEventDisableTiming));
+    NC_HIP(ctx, hipEventRecord(ctx->scan_ev, ctx->stream));
     ctx->have_scan = true;
     if (n_nbr) *n_nbr = tot[0];
     if (n_cand) *n_cand = tot[1];
@@ -439,12 +442,13 @@ int nc_snp_scan_fetch(nc_ctx *ctx, int32_t *nbr_pos, int32_t *site_pos, int32_t 
     return scan_fetch(ctx, ctx->stream, true, nbr_pos, site_pos, site_chunk, site_n, site_alt);
 }
 
-// nc_snp_scan has already synchronised the context's stream (it returns the counts), so the results are complete and
-// may be copied from any stream
+// The copies are ordered behind the scan's last kernel (scan_ev) on whichever stream they are put
 int nc_snp_scan_fetch_async(nc_ctx *ctx, void *copy_stream, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk,
                             int32_t *site_n, int32_t *site_alt)
 {
     if (!ctx) return NC_ERR_ARG;
+    if (copy_stream && (hipStream_t)copy_stream != ctx->stream && ctx->have_scan && ctx->scan_ev)
+        NC_HIP(ctx, hipStreamWaitEvent((hipStream_t)copy_stream, ctx->scan_ev, 0));
     return scan_fetch(ctx, copy_stream ? (hipStream_t)copy_stream : ctx->stream, false, nbr_pos, site_pos, site_chunk, site_n, site_alt);
 }
 
