@@ -4,7 +4,11 @@
 // generate_SNP_pileups.py:6-101, 200-263).  One 64-lane wavefront per candidate
 // site: lanes first act as buckets (binary searches into the sorted neighbour-site list), then as reads
 // (which tile entries cover the site; strand/base depth ballots), then as tensor columns (lane j gathers
-// the code of each sampled read at column j and keeps a 4x4 histogram in packed 16-bit counters).  The
+// the code of each sampled read at column j and keeps a 4x4 histogram in packed 8/16-bit counters).  The
+// walk over the sampled reads is driven by SCALAR code: the covering entries are a wave-uniform bit mask, split
+// by the read's base at the candidate so that the histogram row is a compile-time register; the entry record
+// comes through the scalar cache (s_load_dwordx4) and the gather is one global_load_ubyte with a scalar base and
+// a 32-bit lane offset (~6 vector instructions per read and 35 VGPRs: 8 waves per SIMD).  The
 // site tensor is assembled in LDS and four sites leave the workgroup as one aligned, coalesced dwordx4 stream.
 #include <type_traits>
 
@@ -73,8 +77,9 @@ template <int CAP>
 __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sm[4][NC_SNP_TENSOR + 3];
-    __shared__ int32_t slist[4][CAP];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave index is wave-uniform: telling the compiler so puts the site's scalars (position, tile, entry range) and
+    // the entry records of the read loop into SGPRs / the scalar cache
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware mapping (workgroup b runs on XCD b % 8): each XCD walks ONE contiguous range of position-sorted
     // sites, so its private L2 holds one genomic neighbourhood instead of all eight sharing every line.
     const int nblk = (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     for (int i = lane; i < NC_SNP_TENSOR; i += 64) X[i] = 0.0f;
 
     if (s < a.n_sites) {
-        const int32_t v = a.site_pos[s];
-        const int32_t ch = a.site_chunk[s];
+        const int32_t v = __builtin_amdgcn_readfirstlane(a.site_pos[s]);
+        const int32_t ch = __builtin_amdgcn_readfirstlane(a.site_chunk[s]);
         // neighbour sites are those of the owning chunk's own scan window (quirk E9)
         const int64_t win_lo = max((int64_t)1, (int64_t)a.chunk_start[ch] - NC_FLANK);
         const int64_t win_hi = (int64_t)a.chunk_end[ch] + NC_FLANK;
@@ -119,8 +124,8 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
             if (lane >= o) incl += y;
         }
         const int excl = incl - take;
-        const int nl = __shfl(incl, nb - 1, 64);
-        const int ntot = __shfl(incl, 2 * nb - 1, 64);
+        const int nl = __builtin_amdgcn_readlane(incl, nb - 1);      // wave-uniform (SGPRs)
+        const int ntot = __builtin_amdgcn_readlane(incl, 2 * nb - 1);
         const int nr = ntot - nl;
         const int ncols = ntot + 1;
 
@@ -139,10 +144,26 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
         const int rc_col = active ? a.ref_code[(int64_t)col - a.ref_pos0] : 4;
         const int rc_centre = a.ref_code[(int64_t)v - a.ref_pos0];
 
-        // ---- K4 + read set: which tile entries cover v (the pileup at v, generate_SNP_pileups.py:208)
+        // ---- K4 + K3 in one pass over the tile's entries, 64 at a time.
+        // Lanes as reads: which entries cover v (the pileup at v, generate_SNP_pileups.py:208), their base at v and strand
+        // -> depth ballots.  Then the covering entries (a wave-uniform bit mask; the first maxcov in coordinate order)
+        // are walked with SCALAR code: the entry record comes through the scalar cache, and lanes as columns gather the
+        // code of that read at column j into a 4x4 histogram.  cnt[i] = per-lane counts of bases 0..3 at this column
+        // among the reads whose centre base is i.  maxcov <= 255 (the small instantiation): four 8-bit fields in one
+        // dword; otherwise four 16-bit fields in a qword.
         const int t = (v - a.tile_pos0) >> a.tile_shift;
-        const int e0 = a.tile_off[t], e1 = a.tile_off[t + 1];
+        const int e0 = __builtin_amdgcn_readfirstlane(a.tile_off[t]), e1 = __builtin_amdgcn_readfirstlane(a.tile_off[t + 1]);
+        const bool ok = ncols >= a.min_nbr_sites;               // :244, the list includes the candidate itself
+        constexpr bool BYTE_CNT = CAP == MAXCOV_SMALL;
+        using cnt_t = typename std::conditional<BYTE_CNT, uint32_t, unsigned long long>::type;
+        constexpr int FIELD = BYTE_CNT ? 8 : 16;
+        cnt_t cnt[4] = {0, 0, 0, 0};
         int n_all = 0;
+        // the read pack is not written while this kernel runs: reading the entry records through the constant address
+        // space lets wave-uniform loads go through the scalar cache
+        typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+        typedef const v4i32 __attribute__((address_space(4))) *ent_const_ptr;      // one 16-byte entry record
+        const ent_const_ptr ent_k = (ent_const_ptr)(uintptr_t)a.tile_ent;
         int fw[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
         for (int eb = e0; eb < e1; eb += 64) {
             const int e = eb + lane;
@@ -156,52 +177,67 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
                     strand = (int)(ent.base_flag & 1);
                 }
             }
-            const unsigned long long bal = __ballot(cov);
-            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-            if (cov && n_all + rank < a.maxcov) slist[wv][n_all + rank] = e;     // first maxcov in coordinate order
+            unsigned long long m = __ballot(cov);
+            unsigned long long mb[4];                           // covering reads by their base at v (= the centre column)
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                fw[b] += __popcll(__ballot(cov && code == b && strand == 0));
-                rv[b] += __popcll(__ballot(cov && code == b && strand != 0));
+                mb[b] = __ballot(cov && code == b);
+                const unsigned long long f = __ballot(cov && code == b && strand == 0);
+                fw[b] += __popcll(f);
+                rv[b] += __popcll(mb[b] & ~f);
             }
-            n_all += __popcll(bal);
+            const int room = a.maxcov - n_all;                  // sampled reads still to take (wave-uniform)
+            n_all += __popcll(m);
+            if (!ok || room <= 0) continue;
+            while (__popcll(m) > room) m &= ~(1ull << (63 - __builtin_clzll(m)));   // deeper than maxcov: the first maxcov in coordinate order
+            // Reads are walked grouped by centre base k, so the histogram row is a compile-time register; reads deleted
+            // at the centre (code 4) count nowhere and are skipped.
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned long long mk = mb[k] & m;
+                while (mk != 0ull) {
+                    // up to 8 reads per round: all entry loads, then all code gathers, are issued before the first use
+                    int idx[8];
+                    int nu = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        idx[u] = 0;
+                        if (mk != 0ull) {
+                            idx[u] = __builtin_ctzll(mk);
+                            mk &= mk - 1ull;
+                            nu = u + 1;
+                        }
+                    }
+                    // per read, all wave-uniform: first covered position, span, and the address of the code AT that position
+                    int32_t rstart[8];
+                    uint32_t rlen[8];
+                    const uint8_t *rrow[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const v4i32 r = ent_k[eb + idx[u]];                               // uniform address, constant address space: s_load_dwordx4
+                        rstart[u] = r.x;
+                        rlen[u] = (uint32_t)(r.y - r.x);
+                        rrow[u] = a.codes + ((int64_t)((((uint64_t)(uint32_t)r.w << 32) | (uint32_t)r.z) & ~uint64_t(15)) + r.x);
+                    }
+                    int bcode[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        bcode[u] = 4;
+                        const uint32_t off = (uint32_t)(col - rstart[u]);                 // covered <=> off < span (one unsigned compare)
+                        if (u < nu && active && off < rlen[u]) bcode[u] = rrow[u][off];     // scalar base + 32-bit lane offset
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        // 64-bit shift: a code of 4 (not covered / deleted) shifts the one out of an 8-bit-field dword
+                        const cnt_t inc = BYTE_CNT ? (cnt_t)(uint32_t)(1ull << (8 * bcode[u]))
+                                                   : (bcode[u] < 4 ? ((cnt_t)1 << (16 * bcode[u])) : (cnt_t)0);
+                        if (u < nu) cnt[k] += inc;
+                    }
+                }
+            }
         }
         const int ns = min(n_all, a.maxcov);
-        __builtin_amdgcn_wave_barrier();
-
-        const bool ok = ncols >= a.min_nbr_sites;               // :244, the list includes the candidate itself
-        // ---- K3: lane j gathers column j of every sampled read
-        // cnt[i] = per-lane counts of bases 0..3 at this column among the reads whose centre base is i.  maxcov <= 255 (the
-        // small instantiation): four 8-bit fields in one dword; otherwise four 16-bit fields in a qword.
-        constexpr bool BYTE_CNT = CAP == MAXCOV_SMALL;
-        using cnt_t = typename std::conditional<BYTE_CNT, uint32_t, unsigned long long>::type;
-        constexpr int FIELD = BYTE_CNT ? 8 : 16;
-        cnt_t cnt[4] = {0, 0, 0, 0};
         if (ok) {
-            for (int i0 = 0; i0 < ns; i0 += 8) {
-                // 8 reads per round: all entry loads, then all code gathers, are issued before the first use
-                nc_tile_entry ent[8];
-                int bcode[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int e = slist[wv][min(i0 + u, ns - 1)];
-                    ent[u] = a.tile_ent[e];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    bcode[u] = 4;
-                    if (active && i0 + u < ns && ent[u].start <= col && col < ent[u].end)
-                        bcode[u] = a.codes[(ent[u].base_flag & ~int64_t(15)) + col];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int b = bcode[u];
-                    const int c = __builtin_amdgcn_readlane(b, nl);  // centre base of this read (4 if past the end): wave-uniform
-                    const cnt_t inc = b < 4 ? ((cnt_t)1 << (FIELD * b)) : (cnt_t)0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) cnt[k] += (c == k) ? inc : (cnt_t)0;
-                }
-            }
             // ---- assemble (Appendix A step 5)
             if (active) {
                 const int o = NBR - nl;
