@@ -1308,7 +1308,10 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
     NcTimer tm(ctx, 2);
     if (ctx->timing) nc_timing_resolve(ctx, 4);   // fold an earlier call's per-launch events in before they are re-used
     ctx->n_kev = 0;
-    const int64_t BATCH = 65536;
+    // 262,144 sites per batch (1.8 GB of conv3 activations): the kernel boundaries between trunk, fc1 and heads cost ~40 us per
+    // batch, and a batch still drains to the host while the next one computes; one launch for a whole 625k-site contig is
+    // slower again (the trunk itself loses 3 % on a 4.3 GB activation buffer)
+    const int64_t BATCH = 262144;
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
