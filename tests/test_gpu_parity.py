@@ -296,6 +296,34 @@ def test_end_to_end_vcf_matches_oracle_pipeline(eng, tmp_path):
     assert ngt > 10
 
 
+def test_deferred_calls_equal_drained_calls(eng):
+    """call_chunks(defer=True): several groups enqueued back to back (the next group's scan queued behind the previous
+    group's CNN, results collected afterwards, in any order) give bit-identical arrays to one drained call per group;
+    the HIP-event totals cover every call."""
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.utils import get_chunks
+    world = load_world("ont")
+    params = dict(sam_path=world, fasta_path=None, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
+                  snp_model="ONT-HG002", seq="ont", supplementary=False, exclude_bed=None, disable_coverage_normalization=False)
+    groups = [get_chunks([(world.chrom, a, b, "diploid")], cpu=2) for (a, b) in ((20_000, 70_000), (60_000, 118_000), (1, 9_000), (119_000, 119_400))]
+    groups.append([dict(chrom=world.chrom, start=world.length + 10, end=world.length + 500, ploidy="diploid")])      # no sites at all
+    drained = [snpCaller.call_chunks(params, g) for g in groups]
+    eng.enable_timing(True, trunk_only=True)
+    pend = [snpCaller.call_chunks(params, g, defer=True) for g in groups]
+    got = [p.result() for p in reversed(pend)][::-1]
+    sums, cnt = eng.timing_sums()
+    eng.enable_timing(False)
+    assert sum(r["n"] for r in drained) > 500 and drained[-1]["n"] == 0
+    for a, b in zip(drained, got):
+        assert a["n"] == b["n"]
+        for key in ("pos", "chunk", "ref", "probs", "gt", "dp", "alt", "fwd_dp", "rev_dp", "freq", "chunk_depth"):
+            if a["n"]:
+                assert np.array_equal(a[key], b[key]), key
+    n_calls = sum(1 for r in drained if r["n"])
+    assert cnt[4] == n_calls and sums[5] == n_calls and sums[4] > 0.0      # one trunk launch per (small) call, all folded in
+    assert pend[0].result() is got[0]                                        # result() is idempotent
+
+
 def test_indel_window_scan_matches_reference_pass1(eng):
     """K7: the `variants` dict of the reference's pass 1 (captured from its own frame) and the CPU oracle"""
     from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
