@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -77,6 +78,19 @@ static int format_range(const char *chrom, int64_t n, const int32_t *pos, const 
                         const int32_t *order, const int32_t *dp, const double *freq, const int32_t *fwd,
                         const int32_t *rev, int32_t haploid, char *out, int64_t cap, int64_t *n_bytes);
 
+// Host threads of the formatter / sorter: NC_VCF_THREADS, else the hardware threads minus two (the thread that feeds the
+// GPU and the HIP runtime's own keep their cores while a worker formats the previous group), at most 32.
+static int host_threads()
+{
+    if (const char *e = getenv("NC_VCF_THREADS")) {
+        const int t = atoi(e);
+        if (t >= 1) return t > 256 ? 256 : t;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int t = hw > 2 ? (int)hw - 2 : 1;
+    return t > 32 ? 32 : t;
+}
+
 // Records are independent: ranges of sites are formatted by host threads into disjoint slices of `out` (400-byte
 // budget per record) and compacted in order afterwards.
 extern "C" int nc_snp_vcf_format(const char *chrom, int64_t n, const int32_t *pos, const int32_t *ref, const float *probs,
@@ -85,8 +99,7 @@ extern "C" int nc_snp_vcf_format(const char *chrom, int64_t n, const int32_t *po
 {
     if (!chrom || n < 0 || !n_bytes) return NC_ERR_ARG;
     const int64_t per = 400 + (int64_t)strlen(chrom);
-    unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+    int T = host_threads();
     if (n < 20000 || cap < n * per) T = 1;
     if (T == 1) return format_range(chrom, n, pos, ref, probs, order, dp, freq, fwd, rev, haploid, out, cap, n_bytes);
     std::vector<int64_t> nb((size_t)T, 0);
@@ -208,8 +221,7 @@ static int format_range(const char *chrom, int64_t n, const int32_t *pos, const 
 extern "C" int nc_argsort4(const float *probs, int64_t n, int32_t *order, int64_t *n_ties, int64_t *tie_idx, int64_t tie_cap)
 {
     if (n < 0 || (n && (!probs || !order)) || !n_ties || (tie_cap && !tie_idx)) return NC_ERR_ARG;
-    unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+    int T = host_threads();
     if (n < 50000) T = 1;
     const int64_t chunk = (n + T - 1) / T;
     std::vector<std::vector<int64_t>> ties((size_t)T);
@@ -284,8 +296,7 @@ extern "C" int nc_bgzf_compress(const uint8_t *data, int64_t n, int32_t level, u
         for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)len >> (8 * k)); }
         o.resize(18 + clen + 8);
     };
-    unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+    int T = host_threads();
     if (nb < 8) T = 1;
     if (T == 1) for (int64_t b = 0; b < nb; b++) work(b);
     else {
