@@ -7,8 +7,9 @@
 // the code of each sampled read at column j and keeps a 4x4 histogram in packed 8/16-bit counters).  The
 // walk over the sampled reads is driven by SCALAR code: the covering entries are a wave-uniform bit mask, split
 // by the read's base at the candidate so that the histogram row is a compile-time register; the entry record
-// comes through the scalar cache (s_load_dwordx4) and the gather is one global_load_ubyte with a scalar base and
-// a 32-bit lane offset (~6 vector instructions per read and 35 VGPRs: 8 waves per SIMD).  The
+// of a read is fetched from the lane that loaded it in the coverage pass (v_readlane: no second trip to memory)
+// and the gather is one global_load_ubyte with a scalar base and a 32-bit lane offset, 16 reads in flight per
+// round (~6 vector instructions per read and 34 VGPRs: 8 waves per SIMD).  The
 // site tensor is assembled in LDS and four sites leave the workgroup as one aligned, coalesced dwordx4 stream.
 #include <type_traits>
 
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
         // ---- K4 + K3 in one pass over the tile's entries, 64 at a time.
         // Lanes as reads: which entries cover v (the pileup at v, generate_SNP_pileups.py:208), their base at v and strand
         // -> depth ballots.  Then the covering entries (a wave-uniform bit mask; the first maxcov in coordinate order)
-        // are walked with SCALAR code: the entry record comes through the scalar cache, and lanes as columns gather the
-        // code of that read at column j into a 4x4 histogram.  cnt[i] = per-lane counts of bases 0..3 at this column
+        // are walked with SCALAR code: the entry record comes back from its lane with v_readlane, and lanes as columns
+        // gather the code of that read at column j into a 4x4 histogram.  cnt[i] = per-lane counts of bases 0..3 at this column
         // among the reads whose centre base is i.  maxcov <= 255 (the small instantiation): four 8-bit fields in one
         // dword; otherwise four 16-bit fields in a qword.
         const int t = (v - a.tile_pos0) >> a.tile_shift;
@@ -159,19 +160,23 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
         constexpr int FIELD = BYTE_CNT ? 8 : 16;
         cnt_t cnt[4] = {0, 0, 0, 0};
         int n_all = 0;
-        // the read pack is not written while this kernel runs: reading the entry records through the constant address
-        // space lets wave-uniform loads go through the scalar cache
-        typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
-        typedef const v4i32 __attribute__((address_space(4))) *ent_const_ptr;      // one 16-byte entry record
-        const ent_const_ptr ent_k = (ent_const_ptr)(uintptr_t)a.tile_ent;
         int fw[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
         for (int eb = e0; eb < e1; eb += 64) {
             const int e = eb + lane;
             bool cov = false;
             int code = 4, strand = 0;
+            // this lane's read: first covered position, span, address of the code AT that position (read back by the
+            // column phase below with v_readlane: no second trip to memory for the entry records)
+            int32_t estart = 0;
+            uint32_t elen = 0, erow_lo = 0, erow_hi = 0;
             if (e < e1) {
                 const nc_tile_entry ent = a.tile_ent[e];
                 cov = ent.start <= v && v < ent.end;
+                const uint64_t row = (uint64_t)(uintptr_t)a.codes + (uint64_t)((ent.base_flag & ~int64_t(15)) + ent.start);
+                estart = ent.start;
+                elen = (uint32_t)(ent.end - ent.start);
+                erow_lo = (uint32_t)row;
+                erow_hi = (uint32_t)(row >> 32);
                 if (cov) {
                     code = a.codes[(ent.base_flag & ~int64_t(15)) + v];
                     strand = (int)(ent.base_flag & 1);
@@ -196,38 +201,30 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
             for (int k = 0; k < 4; k++) {
                 unsigned long long mk = mb[k] & m;
                 while (mk != 0ull) {
-                    // up to 8 reads per round: all entry loads, then all code gathers, are issued before the first use
-                    int idx[8];
+                    // up to RND reads per round: every read's record is fetched from its lane (v_readlane) and its gather
+                    // issued before the first loaded code is used
+                    constexpr int RND = 16;
+                    typedef const uint8_t __attribute__((address_space(1))) *gbyte_ptr;     // global (not flat) loads
+                    int bcode[RND];
                     int nu = 0;
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        idx[u] = 0;
+                    for (int u = 0; u < RND; u++) {
+                        bcode[u] = 4;
                         if (mk != 0ull) {
-                            idx[u] = __builtin_ctzll(mk);
+                            const int idx = __builtin_ctzll(mk);
                             mk &= mk - 1ull;
                             nu = u + 1;
+                            // wave-uniform: first covered position, span, and the address of the code AT that position
+                            const int32_t rstart = __builtin_amdgcn_readlane(estart, idx);
+                            const uint32_t rlen = (uint32_t)__builtin_amdgcn_readlane((int)elen, idx);
+                            const gbyte_ptr rrow = (gbyte_ptr)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)erow_hi, idx) << 32) |
+                                                                         (uint32_t)__builtin_amdgcn_readlane((int)erow_lo, idx));
+                            const uint32_t off = (uint32_t)(col - rstart);                // covered <=> off < span (one unsigned compare)
+                            if (active && off < rlen) bcode[u] = rrow[off];                 // scalar base + 32-bit lane offset
                         }
                     }
-                    // per read, all wave-uniform: first covered position, span, and the address of the code AT that position
-                    int32_t rstart[8];
-                    uint32_t rlen[8];
-                    const uint8_t *rrow[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const v4i32 r = ent_k[eb + idx[u]];                               // uniform address, constant address space: s_load_dwordx4
-                        rstart[u] = r.x;
-                        rlen[u] = (uint32_t)(r.y - r.x);
-                        rrow[u] = a.codes + ((int64_t)((((uint64_t)(uint32_t)r.w << 32) | (uint32_t)r.z) & ~uint64_t(15)) + r.x);
-                    }
-                    int bcode[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        bcode[u] = 4;
-                        const uint32_t off = (uint32_t)(col - rstart[u]);                 // covered <=> off < span (one unsigned compare)
-                        if (u < nu && active && off < rlen[u]) bcode[u] = rrow[u][off];     // scalar base + 32-bit lane offset
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < RND; u++) {
                         // 64-bit shift: a code of 4 (not covered / deleted) shifts the one out of an 8-bit-field dword
                         const cnt_t inc = BYTE_CNT ? (cnt_t)(uint32_t)(1ull << (8 * bcode[u]))
                                                    : (bcode[u] < 4 ? ((cnt_t)1 << (16 * bcode[u])) : (cnt_t)0);
