@@ -23,8 +23,8 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 3   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
-                              3: nc_indel_scan_params.impute */
+#define NC_ABI_VERSION 4   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+                              3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -174,6 +174,10 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack,
  * chunk_depth_host (may be NULL) receives the per-chunk mean depth (float64, :274). */
 int nc_snp_scale(nc_ctx *ctx, const int32_t *site_depth_dev, const uint8_t *valid_dev, double train_coverage,
                  int32_t mode, double *scale_dev, double *chunk_depth_host);
+/* The per-chunk mean depths of the last nc_snp_scale, copied on `copy_stream` (ordered behind the scale kernel) without
+ * synchronising: with chunk_depth_host = NULL above, the caller's stream is never drained between the featuriser and the
+ * CNN.  `chunk_depth_host_pinned` [n_chunks] must be page-locked and is valid once the copy stream has passed. */
+int nc_snp_chunk_depth_async(nc_ctx *ctx, void *copy_stream, double *chunk_depth_host_pinned);
 
 /* ------------------------------------------------------------------ CNN forward (K5 / K9)
  * nc_load_weights: canonical flat f32 blob (nanocaller_amd/weights.py LAYER_SPECS order, Keras layouts),

@@ -39,6 +39,7 @@ struct nc_ctx {
     double sum_ms[6] = {0, 0, 0, 0, 0, 0};   // running totals of last_ms[] since nc_enable_timing(1): calls may be left in flight
     int64_t sum_n[6] = {0, 0, 0, 0, 0, 0};   // while the next one is enqueued, their timers are folded in before the events are re-used
     hipEvent_t drain_ev[4] = {nullptr};       // batch-complete events of nc_snp_forward_drain
+    hipEvent_t scale_ev = nullptr;            // recorded behind nc_snp_scale's kernel for nc_snp_chunk_depth_async
     hipEvent_t scan_ev = nullptr;             // recorded behind the last kernel of nc_snp_scan (its site arrays are complete)
 
     // scan results (device)

@@ -72,6 +72,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
     for (auto &e : ctx->kev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->drain_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->scan_ev) (void)hipEventDestroy(ctx->scan_ev);
+    if (ctx->scale_ev) (void)hipEventDestroy(ctx->scale_ev);
     for (auto &p : ctx->tev) for (auto &e : p) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

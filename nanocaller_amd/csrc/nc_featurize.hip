@@ -408,4 +408,16 @@ int nc_snp_scale(nc_ctx *ctx, const int32_t *site_depth_dev, const uint8_t *vali
     return NC_OK;
 }
 
+int nc_snp_chunk_depth_async(nc_ctx *ctx, void *copy_stream, double *chunk_depth_host_pinned)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!copy_stream || !chunk_depth_host_pinned) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_chunk_depth_async: null argument");
+    if (!ctx->have_scan || !ctx->chunk_depth.p) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_chunk_depth_async: call nc_snp_scale first");
+    if (!ctx->scale_ev) NC_HIP(ctx, hipEventCreateWithFlags(&ctx->scale_ev, hipEventDisableTiming));
+    NC_HIP(ctx, hipEventRecord(ctx->scale_ev, ctx->stream));
+    NC_HIP(ctx, hipStreamWaitEvent((hipStream_t)copy_stream, ctx->scale_ev, 0));
+    NC_HIP(ctx, hipMemcpyAsync(chunk_depth_host_pinned, ctx->chunk_depth.p, (size_t)ctx->n_chunks * 8, hipMemcpyDeviceToHost, (hipStream_t)copy_stream));
+    return NC_OK;
+}
+
 }   // extern "C"

@@ -220,13 +220,21 @@ class Engine:
                                             _ptr(sites.valid)), "nc_snp_featurize")
         return sites
 
-    def snp_scale(self, sites: SnpSites, n_chunks, train_coverage, per_site=False):
-        """-> (scale f64 [N] device tensor, chunk_depth float64 host [n_chunks])"""
+    def snp_scale(self, sites: SnpSites, n_chunks, train_coverage, per_site=False, async_fetch=False):
+        """-> (scale f64 [N] device tensor, chunk_depth float64 host [n_chunks]).  async_fetch: the chunk depths arrive in
+        pinned memory through the copy stream (valid after wait_copies() / a later copy_event()), and the compute stream
+        is not synchronised between the featuriser and the CNN."""
         scale = torch.empty(sites.n_sites, dtype=torch.float64, device=self.device)
-        cd = np.zeros(n_chunks, np.float64)
+        if not async_fetch:
+            cd = np.zeros(n_chunks, np.float64)
+            self._check(self.L.nc_snp_scale(self.ctx, _ptr(sites.depth), _ptr(sites.valid), float(train_coverage),
+                                            1 if per_site else 0, _ptr(scale), _lib.npp(cd)), "nc_snp_scale")
+            return scale, cd
+        hb, cd = self._pinned.get((max(int(n_chunks), 1),), torch.float64)
         self._check(self.L.nc_snp_scale(self.ctx, _ptr(sites.depth), _ptr(sites.valid), float(train_coverage),
-                                        1 if per_site else 0, _ptr(scale), _lib.npp(cd)), "nc_snp_scale")
-        return scale, cd
+                                        1 if per_site else 0, _ptr(scale), None), "nc_snp_scale")
+        self._check(self.L.nc_snp_chunk_depth_async(self.ctx, self._copy_stream_ptr(), C.c_void_p(hb.data_ptr())), "nc_snp_chunk_depth_async")
+        return scale, cd[:int(n_chunks)]
 
     # ------------------------------------------------------------------ K5 / K9
     def snp_forward(self, kind, x, ref_code, scale, scale_mode=0, want_gt=True, drain=False):

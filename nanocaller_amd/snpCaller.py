@@ -219,11 +219,11 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     if sites.n_sites == 0:
         eng.wait_copies()
         return PendingCall(lambda: res) if defer else res
-    scan_copied = eng.copy_event()
     eng.snp_featurize(dpk, sites, seq=params['seq'], maxcov=params['maxcov'], min_nbr_sites=params['min_nbr_sites'])
     all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
     per_site = bool(params.get('disable_coverage_normalization'))
-    scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site)
+    scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site, async_fetch=True)
+    scan_copied = eng.copy_event()                                 # candidate arrays + chunk depths are on the host behind this
     # enqueued after the (short, latency-sensitive) scale kernel so that these copies run under the CNN, not beside it
     h_ref, h_fwd, h_rev, h_valid = eng.to_host_async([sites.ref_code, sites.fwd_dp, sites.rev_dp, None if all_valid else sites.valid])
     d_probs, d_gt, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True)
