@@ -299,6 +299,11 @@ const char *nc_bam_error(const nc_bam *bam);
 int nc_bam_set_threads(nc_bam *bam, int32_t n);
 /* alignments of reference `tid` overlapping [beg1, end1] (1-based, inclusive), in coordinate order */
 int nc_bam_decode(nc_bam *bam, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, nc_decoded **out);
+/* The same interval decoded as `n_regions` equal sub-intervals by as many host threads (own file handle each, seek through
+ * the .bai linear index, a read belongs to the sub-interval it starts in) and merged in parallel: identical result to one
+ * nc_bam_decode call, several times the throughput on long intervals.  Needs the .bai for the seeks to pay. */
+int nc_bam_decode_regions(const char *path, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, int32_t n_regions,
+                          nc_decoded **out);
 int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *view);
 int nc_decoded_free(nc_decoded *d);
 

@@ -15,11 +15,52 @@ from . import _lib
 from .synth import World
 
 
-def _arr(ptr, n, dtype):
+def usable_cpus():
+    """CPUs this process may really use: os.cpu_count() capped by the affinity mask and the cgroup CPU quota (a container
+    that sees 256 CPUs under a quota of 16 runs 32 busy threads slower than 16)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+class _Owner:
+    """keeps a native result alive for as long as a numpy view of its arrays exists (views are zero-copy: a fresh copy of
+    a gigabyte array costs more in page faults than the decode itself)"""
+
+    def __init__(self, lib, handle, free):
+        self.lib, self.handle, self.free = lib, handle, free
+
+    def __del__(self):
+        try:
+            getattr(self.lib, self.free)(self.handle)
+        except Exception:
+            pass
+
+
+def _arr(ptr, n, dtype, owner=None):
+    """numpy array over native memory: a view that keeps `owner` alive, or (owner None) a copy"""
     if not n or not ptr:
         return np.zeros(0, dtype)
     buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
-    return np.frombuffer(buf, dtype=dtype).copy()
+    if owner is None:
+        return np.frombuffer(buf, dtype=dtype).copy()
+    buf._nc_owner = owner                                # the ctypes array is the numpy array's base
+    return np.frombuffer(buf, dtype=dtype)
 
 
 class BamFile:
@@ -72,21 +113,9 @@ class BamFile:
         rc = self.L.nc_bam_decode(self.h, tid, max(1, int(start)), max(int(start), end), 1 if keep_seq else 0, C.byref(d))
         if rc != _lib.NC_OK:
             raise IOError("BAM decode failed: %s" % self.L.nc_bam_error(self.h).decode())
-        v = _lib.DecodedArraysC()
-        self.L.nc_decoded_view(d, C.byref(v))
-        n = v.n_reads
-        out = dict(read_start=_arr(v.start, n, np.int32), read_end=_arr(v.end, n, np.int32), read_flag=_arr(v.flag, n, np.int32),
-                   read_off=_arr(v.off, n + 1, np.int64), codes=_arr(v.codes, v.n_codes, np.uint8),
-                   ev_off=_arr(v.ev_off, n + 1, np.int32), ev_pos=_arr(v.ev_pos, v.n_events, np.int32),
-                   ev_len=_arr(v.ev_len, v.n_events, np.int32), hap=_arr(v.hap, n, np.uint8), ps=_arr(v.ps, n, np.int32),
-                   seq_off=_arr(v.seq_off, n + 1, np.int64), seq=_arr(v.seq, v.n_seq, np.uint8),
-                   qstart=_arr(v.qstart, n, np.int32))
-        name_off = _arr(v.name_off, n + 1, np.int32)
-        names_raw = _arr(v.names, int(name_off[-1]) if n else 0, np.uint8).tobytes()
-        out["names"] = [names_raw[name_off[i]:name_off[i + 1] - 1].decode() for i in range(n)]
+        out = _decoded_dict(self.L, d)
         if anchors is not None:
             out["windows"] = self._windows(d, out, anchors, window_before, window_after, keep_mask)
-        self.L.nc_decoded_free(d)
         return out
 
     def _windows(self, d, dec, anchors, window_before, window_after, keep_mask):
@@ -112,6 +141,30 @@ class BamFile:
         for a in range(len(anchors)):
             out.append([(int(ridx[k]), letters[s_off[k]:s_off[k + 1]]) for k in range(a_off[a], a_off[a + 1])])
         return out
+
+
+def _decoded_dict(L, d):
+    """dict of zero-copy numpy views over a native nc_decoded (freed when the last view goes)"""
+    own = _Owner(L, d, "nc_decoded_free")
+    v = _lib.DecodedArraysC()
+    L.nc_decoded_view(d, C.byref(v))
+    n = v.n_reads
+    a = lambda ptr, cnt, dt: _arr(ptr, cnt, dt, own)     # noqa: E731
+    out = dict(read_start=a(v.start, n, np.int32), read_end=a(v.end, n, np.int32), read_flag=a(v.flag, n, np.int32),
+               read_off=a(v.off, n + 1, np.int64), codes=a(v.codes, v.n_codes, np.uint8),
+               ev_off=a(v.ev_off, n + 1, np.int32), ev_pos=a(v.ev_pos, v.n_events, np.int32),
+               ev_len=a(v.ev_len, v.n_events, np.int32), hap=a(v.hap, n, np.uint8), ps=a(v.ps, n, np.int32),
+               seq_off=a(v.seq_off, n + 1, np.int64), seq=a(v.seq, v.n_seq, np.uint8),
+               qstart=a(v.qstart, n, np.int32))
+    if n == 0:                                           # empty arrays are copies: keep the (n + 1)-offset convention
+        for k in ("read_off", "seq_off"):
+            out[k] = np.zeros(1, np.int64)
+        out["ev_off"] = np.zeros(1, np.int32)
+    name_off = _arr(v.name_off, n + 1, np.int32)
+    names_raw = _arr(v.names, int(name_off[-1]) if n else 0, np.uint8).tobytes()
+    out["names"] = [names_raw[name_off[i]:name_off[i + 1] - 1].decode() for i in range(n)]
+    out["_owner"] = own
+    return out
 
 
 def read_fasta(path, chrom):
@@ -140,25 +193,38 @@ def read_fasta(path, chrom):
     return "".join(seq)
 
 
-def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=None, min_region=2_000_000):
-    """BamFile.decode of a long interval as parallel regions: each host thread opens its own handle, seeks through the
-    .bai linear index and decodes the alignments that START in its region (the first region also takes those that merely
-    overlap its left edge); inflate, CIGAR walk and tag parsing all scale with the threads (the native calls release the
-    GIL).  Same result as one sequential decode."""
-    from concurrent.futures import ThreadPoolExecutor
+def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=None, min_region=500_000):
+    """BamFile.decode of a long interval as parallel regions (nc_bam_decode_regions): each host thread opens its own handle,
+    seeks through the .bai linear index and decodes the alignments that START in its region (the first region also takes
+    those that merely overlap its left edge); inflate, CIGAR walk, tag parsing and the merge into one set of arrays all run
+    on native threads.  Same result as one sequential decode; the arrays are zero-copy views of the native result."""
     bf = BamFile(bam_path)
     tid_len = bf.get_reference_length(chrom)
     has_index = bf.has_index
     bf.close()
     end = tid_len if end is None else min(int(end), tid_len)
     start = max(1, int(start))
-    threads = threads or min(32, os.cpu_count() or 1)
+    threads = threads or min(64, usable_cpus())
     n_reg = min(threads, max(1, (end - start + 1) // min_region))
     if n_reg <= 1 or not has_index:
         bf = BamFile(bam_path)
         d = bf.decode(chrom, start, end, keep_seq)
         bf.close()
         return d
+    L = _lib.lib()
+    bf = BamFile(bam_path)
+    tid = bf.references.index(chrom)
+    bf.close()
+    d = C.c_void_p()
+    rc = L.nc_bam_decode_regions(os.fsencode(bam_path), tid, start, end, 1 if keep_seq else 0, n_reg, C.byref(d))
+    if rc != _lib.NC_OK:
+        raise IOError("BAM decode failed (%d): %s" % (rc, bam_path))
+    return _decoded_dict(L, d)
+
+
+def _decode_parallel_py(bam_path, chrom, start, end, keep_seq, threads, n_reg):
+    """the same with Python threads around nc_bam_decode (kept as the independent statement the native merge is tested against)"""
+    from concurrent.futures import ThreadPoolExecutor
     edges = [start + (end - start + 1) * k // n_reg for k in range(n_reg)] + [end + 1]
 
     def one(k):

@@ -6,18 +6,23 @@
 // generate_SNP_pileups.py:104), the insertion / deletion markers that pysam appends to the pileup string of the column
 // BEFORE the event ('+n' / '-n'), the HP / PS tags, and the query sequence (for the indel pass-2 read slices).
 // Host code only; file formats follow the SAM/BAM specification (SAMv1 section 4 and 5).
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/nanocaller_hip.h"
+#include "nc_host.h"
 
 namespace {
 
@@ -105,8 +110,8 @@ struct Bgzf {
             win.push_back(std::move(k));
         }
         const size_t n = win.size();
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t T = hw ? (hw > 32 ? 32 : hw) : 1;
+        const int hw = nc_host_cpus();
+        size_t T = (size_t)(hw > 32 ? 32 : hw);
         if (const char *e = getenv("NC_BAM_THREADS")) T = (size_t)std::max(1, atoi(e));       // 1 = sequential inflate
         if (max_threads > 0) T = (size_t)max_threads;
         if (T > n / 4) T = n / 4;                             // a thread per >= 4 blocks
@@ -183,11 +188,43 @@ struct nc_bam {
     char err[256] = {0};
 };
 
+// allocator whose resize() leaves new elements uninitialised: the gigabyte arrays are filled right after they are sized,
+// and their pages are first touched by whichever thread fills them (parallel page faults in the merged decode)
+// Blocks of 4 MB and more are 2 MB-aligned and advised as transparent huge pages: first-touch page faults (one per 4 KB
+// page, serialised across threads by the kernel's memory accounting) are what bounds a multi-threaded decode otherwise.
+template <class T>
+struct NoInit {
+    typedef T value_type;
+    NoInit() noexcept {}
+    template <class U> NoInit(const NoInit<U> &) noexcept {}
+    template <class U> struct rebind { typedef NoInit<U> other; };
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        void *p = nullptr;
+        if (bytes >= ((size_t)4 << 20)) {
+            const size_t huge = (size_t)2 << 20, rounded = (bytes + huge - 1) & ~(huge - 1);
+            if (posix_memalign(&p, huge, rounded) != 0) throw std::bad_alloc();
+            (void)madvise(p, rounded, MADV_HUGEPAGE);
+        } else {
+            p = malloc(bytes ? bytes : 1);
+            if (!p) throw std::bad_alloc();
+        }
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) noexcept { free(p); }
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const NoInit<U> &) const noexcept { return true; }
+    template <class U> bool operator!=(const NoInit<U> &) const noexcept { return false; }
+};
+template <class T> using bigvec = std::vector<T, NoInit<T>>;
+
 struct nc_decoded {
-    std::vector<int32_t> start, end, flag, ev_off, ev_pos, ev_len, ps, name_off, qstart;
-    std::vector<int64_t> off, seq_off;
-    std::vector<uint8_t> codes, hap, seq;
-    std::vector<char> names;
+    bigvec<int32_t> start, end, flag, ev_off, ev_pos, ev_len, ps, name_off, qstart;
+    bigvec<int64_t> off, seq_off;
+    bigvec<uint8_t> codes, hap, seq;
+    bigvec<char> names;
 };
 
 namespace {
@@ -308,6 +345,20 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
     }
     if (!b->z.seek(voff)) return bam_fail(b, NC_ERR_ARG, "BGZF seek failed");
     nc_decoded *d = new nc_decoded();
+    // Address space for ~48x coverage of the interval up front (untouched pages cost nothing): a growing gigabyte vector
+    // is re-mapped and copied again and again, and with many decoding threads those mmap / munmap calls serialise on the
+    // process's address-space lock.  Deeper data simply grows the vectors as usual.
+    try {
+        const size_t span = (size_t)(end1 - beg1) + 1;
+        d->codes.reserve(span * 48 + (1u << 20));
+        if (keep_seq) d->seq.reserve(span * 48 + (1u << 20));
+        const size_t nr = span / 64 + 1024;
+        d->start.reserve(nr); d->end.reserve(nr); d->flag.reserve(nr); d->qstart.reserve(nr); d->ps.reserve(nr); d->hap.reserve(nr);
+        d->off.reserve(nr + 1); d->ev_off.reserve(nr + 1); d->seq_off.reserve(nr + 1); d->name_off.reserve(nr + 1);
+        d->ev_pos.reserve(span / 2 + 4096); d->ev_len.reserve(span / 2 + 4096);
+        d->names.reserve(nr * 40);
+    } catch (const std::bad_alloc &) {
+    }
     d->off.push_back(0);
     d->ev_off.push_back(0);
     d->seq_off.push_back(0);
@@ -418,6 +469,109 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
     }
     if (err) { delete d; return bam_fail(b, NC_ERR_ARG, "truncated or corrupt BAM record / BGZF block"); }
     *out = d;
+    return NC_OK;
+}
+
+// The same over `n_regions` equal sub-intervals at once: every host thread opens its own handle, seeks through the .bai
+// linear index and decodes the alignments that START in its sub-interval (the first one also takes those that merely
+// overlap its left edge); the parts are then copied -- again one thread per part, so that the pages of the merged arrays
+// are faulted in in parallel -- into one nc_decoded identical to what a single nc_bam_decode call returns.
+int nc_bam_decode_regions(const char *path, int32_t tid, int32_t beg1, int32_t end1, int32_t keep_seq, int32_t n_regions,
+                          nc_decoded **out)
+{
+    if (!path || !out || end1 < beg1 || n_regions < 1) return NC_ERR_ARG;
+    *out = nullptr;
+    const int R = n_regions;
+    const bool dbg = getenv("NC_BAM_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
+    std::vector<int32_t> edge((size_t)R + 1);
+    for (int k = 0; k <= R; k++) edge[(size_t)k] = (int32_t)(beg1 + ((int64_t)end1 - beg1 + 1) * k / R);
+    std::vector<nc_decoded *> part((size_t)R, nullptr);
+    std::vector<int> rc((size_t)R, NC_OK);
+    std::vector<int32_t> cut((size_t)R, 0);                       // first read of part k that starts inside its sub-interval
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < R; k++)
+            th.emplace_back([&, k]() {
+                if (edge[(size_t)k + 1] <= edge[(size_t)k]) return;            // empty sub-interval
+                nc_bam *b = nullptr;
+                const double t0 = now();
+                rc[(size_t)k] = nc_bam_open(path, &b);
+                if (rc[(size_t)k] != NC_OK) return;
+                const double t1 = now();
+                b->z.max_threads = 1;                                           // the regions are the parallelism
+                rc[(size_t)k] = nc_bam_decode(b, tid, edge[(size_t)k], edge[(size_t)k + 1] - 1, keep_seq, &part[(size_t)k]);
+                const double t2 = now();
+                nc_bam_close(b);
+                if (dbg && (k < 8 || k == R - 1)) fprintf(stderr, "  region %d: start +%.3f open %.3f decode %.3f close %.3f\n", k, t0 - t_a, t1 - t0, t2 - t1, now() - t2);
+                if (rc[(size_t)k] == NC_OK && k > 0) {
+                    const auto &st = part[(size_t)k]->start;
+                    cut[(size_t)k] = (int32_t)(std::lower_bound(st.begin(), st.end(), edge[(size_t)k]) - st.begin());
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    const double t_b = now();
+    int err = NC_OK;
+    for (int k = 0; k < R; k++) if (rc[(size_t)k] != NC_OK) err = rc[(size_t)k];
+    if (err != NC_OK) { for (auto *d : part) delete d; return err; }
+    // offsets of every part in the merged arrays
+    std::vector<int64_t> r0((size_t)R + 1, 0), c0((size_t)R + 1, 0), e0((size_t)R + 1, 0), s0((size_t)R + 1, 0), n0((size_t)R + 1, 0);
+    for (int k = 0; k < R; k++) {
+        const nc_decoded *d = part[(size_t)k];
+        int64_t nr = 0, nc = 0, ne = 0, ns = 0, nn = 0;
+        if (d) {
+            const size_t c = (size_t)cut[(size_t)k], n = d->start.size();
+            nr = (int64_t)(n - c);
+            nc = d->off[n] - d->off[c];
+            ne = d->ev_off[n] - d->ev_off[c];
+            ns = d->seq_off[n] - d->seq_off[c];
+            nn = d->name_off[n] - d->name_off[c];
+        }
+        r0[(size_t)k + 1] = r0[(size_t)k] + nr; c0[(size_t)k + 1] = c0[(size_t)k] + nc; e0[(size_t)k + 1] = e0[(size_t)k] + ne;
+        s0[(size_t)k + 1] = s0[(size_t)k] + ns; n0[(size_t)k + 1] = n0[(size_t)k] + nn;
+    }
+    if (e0[(size_t)R] > INT32_MAX || n0[(size_t)R] > INT32_MAX) { for (auto *d : part) delete d; return NC_ERR_CAPACITY; }
+    nc_decoded *m = new nc_decoded();
+    const size_t NR = (size_t)r0[(size_t)R];
+    m->start.resize(NR); m->end.resize(NR); m->flag.resize(NR); m->ps.resize(NR); m->qstart.resize(NR); m->hap.resize(NR);
+    m->off.resize(NR + 1); m->ev_off.resize(NR + 1); m->seq_off.resize(NR + 1); m->name_off.resize(NR + 1);
+    m->codes.resize((size_t)c0[(size_t)R]); m->ev_pos.resize((size_t)e0[(size_t)R]); m->ev_len.resize((size_t)e0[(size_t)R]);
+    m->seq.resize((size_t)s0[(size_t)R]); m->names.resize((size_t)n0[(size_t)R]);
+    m->off[0] = 0; m->ev_off[0] = 0; m->seq_off[0] = 0; m->name_off[0] = 0;
+    const double t_c = now();
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < R; k++)
+            th.emplace_back([&, k]() {
+                nc_decoded *d = part[(size_t)k];
+                if (!d) return;
+                const size_t c = (size_t)cut[(size_t)k], n = d->start.size(), nr = n - c, r = (size_t)r0[(size_t)k];
+                auto cp = [](void *dst, const void *src, size_t bytes) { if (bytes) memcpy(dst, src, bytes); };
+                cp(m->start.data() + r, d->start.data() + c, nr * 4); cp(m->end.data() + r, d->end.data() + c, nr * 4);
+                cp(m->flag.data() + r, d->flag.data() + c, nr * 4); cp(m->ps.data() + r, d->ps.data() + c, nr * 4);
+                cp(m->qstart.data() + r, d->qstart.data() + c, nr * 4); cp(m->hap.data() + r, d->hap.data() + c, nr);
+                const int64_t dc = c0[(size_t)k] - d->off[c], ds = s0[(size_t)k] - d->seq_off[c];
+                const int32_t de = (int32_t)(e0[(size_t)k] - d->ev_off[c]), dn = (int32_t)(n0[(size_t)k] - d->name_off[c]);
+                for (size_t i = 1; i <= nr; i++) {
+                    m->off[r + i] = d->off[c + i] + dc;
+                    m->seq_off[r + i] = d->seq_off[c + i] + ds;
+                    m->ev_off[r + i] = d->ev_off[c + i] + de;
+                    m->name_off[r + i] = d->name_off[c + i] + dn;
+                }
+                cp(m->codes.data() + c0[(size_t)k], d->codes.data() + d->off[c], (size_t)(d->off[n] - d->off[c]));
+                cp(m->ev_pos.data() + e0[(size_t)k], d->ev_pos.data() + d->ev_off[c], (size_t)(d->ev_off[n] - d->ev_off[c]) * 4);
+                cp(m->ev_len.data() + e0[(size_t)k], d->ev_len.data() + d->ev_off[c], (size_t)(d->ev_off[n] - d->ev_off[c]) * 4);
+                cp(m->seq.data() + s0[(size_t)k], d->seq.data() + d->seq_off[c], (size_t)(d->seq_off[n] - d->seq_off[c]));
+                cp(m->names.data() + n0[(size_t)k], d->names.data() + d->name_off[c], (size_t)(d->name_off[n] - d->name_off[c]));
+                delete d;                                                       // frees this part's pages in parallel as well
+                part[(size_t)k] = nullptr;
+            });
+        for (auto &t : th) t.join();
+    }
+    if (dbg) fprintf(stderr, "nc_bam_decode_regions: %d regions: decode %.3f s, alloc %.3f s, merge %.3f s\n", R, t_b - t_a, t_c - t_b, now() - t_c);
+    *out = m;
     return NC_OK;
 }
 

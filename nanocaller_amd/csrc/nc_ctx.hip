@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "nc_common.h"
+#include "nc_host.h"
 
 extern "C" {
 
@@ -268,8 +269,8 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
     }
     if (!index_only) {
         // the slots of consecutive reads are consecutive in codes_out: host threads fill disjoint, contiguous ranges
-        unsigned hw = std::thread::hardware_concurrency();
-        int T = (int)(hw ? (hw > 32 ? 32 : hw) : 1);
+        const int hw = nc_host_cpus();
+        int T = hw > 32 ? 32 : hw;
         if (n_reads < 4096) T = 1;
         auto fill = [&](int32_t r0, int32_t r1, int64_t out0, int64_t out1) {
             memset(codes_out + out0, NC_CODE_ABSENT, (size_t)(out1 - out0));

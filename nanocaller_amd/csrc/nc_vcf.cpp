@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <thread>
+
+#include "nc_host.h"
 #include <vector>
 
 #include "../../include/nanocaller_hip.h"
@@ -78,7 +80,7 @@ static int format_range(const char *chrom, int64_t n, const int32_t *pos, const 
                         const int32_t *order, const int32_t *dp, const double *freq, const int32_t *fwd,
                         const int32_t *rev, int32_t haploid, char *out, int64_t cap, int64_t *n_bytes);
 
-// Host threads of the formatter / sorter: NC_VCF_THREADS, else the hardware threads minus two (the thread that feeds the
+// Host threads of the formatter / sorter: NC_VCF_THREADS, else the usable CPUs (nc_host.h: affinity and cgroup quota) minus two (the thread that feeds the
 // GPU and the HIP runtime's own keep their cores while a worker formats the previous group), at most 32.
 static int host_threads()
 {
@@ -86,8 +88,8 @@ static int host_threads()
         const int t = atoi(e);
         if (t >= 1) return t > 256 ? 256 : t;
     }
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int t = hw > 2 ? (int)hw - 2 : 1;
+    const int hw = nc_host_cpus();
+    const int t = hw > 4 ? hw - 2 : hw;
     return t > 32 ? 32 : t;
 }
 

@@ -110,6 +110,25 @@ def test_parallel_region_decode_equals_sequential(files):
     for threads, min_region in ((4, 3_000), (7, 1_000), (3, 10_000_000)):
         par = decode_parallel(bam, chrom, 1, L, keep_seq=True, threads=threads, min_region=min_region)
         assert par["names"] == seq["names"]
-        for k in ("read_start", "read_end", "read_flag", "read_off", "codes", "ev_off", "ev_pos", "ev_len", "hap", "ps", "seq_off", "seq",
-                  "qstart"):
-            assert np.array_equal(par[k], seq[k]), k
+        keys = ("read_start", "read_end", "read_flag", "read_off", "codes", "ev_off", "ev_pos", "ev_len", "hap", "ps", "seq_off", "seq",
+                "qstart")
+        for k in keys:
+            assert np.array_equal(par[k], seq[k]) and par[k].dtype == seq[k].dtype, k
+        # sub-intervals, more regions than reads start in, and the Python-threads statement of the same merge
+        from nanocaller_amd.bam import _decode_parallel_py
+        for (a, b) in ((1, L), (L // 3, 2 * L // 3), (L - 50, L)):
+            sub = BamFile(bam)
+            want = sub.decode(chrom, a, b, keep_seq=True)
+            sub.close()
+            got = decode_parallel(bam, chrom, a, b, keep_seq=True, threads=threads, min_region=min(min_region, 500))
+            py = _decode_parallel_py(bam, chrom, a, b, True, threads, min(threads, 5))
+            assert got["names"] == want["names"] == py["names"]
+            for k in keys:
+                assert np.array_equal(got[k], want[k]) and np.array_equal(py[k], want[k]), (k, a, b)
+    # the views stay valid after every other reference to the native result is gone
+    import gc
+    codes = decode_parallel(bam, chrom, 1, L, threads=4, min_region=2_000)["codes"]
+    ref_sum = int(seq["codes"].astype(np.int64).sum())
+    del par, got
+    gc.collect()
+    assert int(codes.astype(np.int64).sum()) == ref_sum and codes.flags.writeable

@@ -43,9 +43,9 @@ for rep in range(3):
     dt = time.perf_counter() - t
     print("decode: %.3f s  -> %.1f M pileup entries/s, %.1f MB/s of BAM" % (dt, len(dd["codes"]) / dt / 1e6, os.path.getsize(bam) / dt / 1e6))
 from nanocaller_amd.bam import decode_parallel
-for threads in (1, 8, 32):
+for threads in (1, 4, 8, 16, 32):
     t = time.perf_counter()
-    dd = decode_parallel(bam, "c", 1, L + 20_000, threads=threads, min_region=100_000)
+    dd = decode_parallel(bam, "c", 1, L + 20_000, threads=threads, min_region=50_000)
     dt = time.perf_counter() - t
     print("decode_parallel(%2d threads): %.3f s -> %.1f M pileup entries/s" % (threads, dt, len(dd["codes"]) / dt / 1e6))
 t = time.perf_counter()
