@@ -63,3 +63,9 @@ def test_product_never_imports_oracle():
     code = "import sys; sys.path.insert(0, %r); import nanocaller_amd.snpCaller, nanocaller_amd.model_architect; " \
            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_graft_entry_build_checks_pass():
+    """__graft_entry__.build() (the driver's does-it-build check): compiles, loads and resolves every export"""
+    import __graft_entry__ as g
+    g.build()
