@@ -78,6 +78,7 @@ template <int CAP>
 __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sm[4][NC_SNP_TENSOR + 3];
+    __shared__ int32_t nlist[4][64];                              // per wave: indices (into nbr_pos) of the picked neighbour sites
     // the wave index is wave-uniform: telling the compiler so puts the site's scalars (position, tile, entry range) and
     // the entry records of the read loop into SGPRs / the scalar cache
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,16 +131,15 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
         const int nr = ntot - nl;
         const int ncols = ntot + 1;
 
-        // column position of lane j
-        int32_t col = 0;
+        // column position of lane j: every bucket lane writes the indices of its picks into the wave's scratch list
+        // (at most k <= 10 per bucket), lane j reads entry j of the concatenated list
+        int32_t col = v;
         {
+            for (int i = 0; i < take; i++) nlist[wv][excl + i] = idx0 + i;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // other lanes' LDS writes are read back below (one wave: LDS is in order)
+            __builtin_amdgcn_wave_barrier();
             const int jj = lane < nl ? lane : lane - 1;          // index into the concatenated neighbour list
-            int32_t q = v;
-            for (int l = 0; l < 2 * nb; l++) {
-                const int o_l = __shfl(excl, l, 64), t_l = __shfl(take, l, 64), i_l = __shfl(idx0, l, 64);
-                if (lane != nl && lane < ncols && jj >= o_l && jj < o_l + t_l) q = a.nbr_pos[i_l + (jj - o_l)];
-            }
-            col = q;
+            if (lane != nl && lane < ncols) col = a.nbr_pos[nlist[wv][jj]];
         }
         const bool active = lane < ncols;
         const int rc_col = active ? a.ref_code[(int64_t)col - a.ref_pos0] : 4;
