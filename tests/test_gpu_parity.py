@@ -249,9 +249,37 @@ def test_indel_tensor_and_cnn_match_oracle(eng):
     for name, kind, xin in (("ONT-HG002", _lib.MODEL_INDEL, x15), ("haploid", _lib.MODEL_INDEL_HAP, xh)):
         w = Weights(get_indel_model(name))
         eng.load_weights(kind, w)
-        p = eng.indel_forward(kind, torch.from_numpy(np.ascontiguousarray(xin)).cuda()).cpu().numpy()
         e = oracle.indel_forward(w.flat, xin, precision="f64")
-        assert np.abs(p - e).max() < 1e-4
+        for exact in (False, True):                                   # split-precision (default) and exact fp32 conv2 / conv3
+            eng.set_cnn_precision(exact_fp32=exact)
+            p = eng.indel_forward(kind, torch.from_numpy(np.ascontiguousarray(xin)).cuda()).cpu().numpy()
+            assert np.abs(p - e).max() < 1e-4, (name, exact)
+        eng.set_cnn_precision(exact_fp32=False)
+
+
+@pytest.mark.parametrize("n", [1, 17, 333])
+def test_indel_cnn_split_precision_on_dense_inputs(eng, n):
+    """k8_conv23_h3 (fp16 hi/lo planes, three MFMA products per fp32 product) against the float64 oracle and the exact
+    fp32 kernels on dense random tensors (every tap and channel exercised, site counts that leave partial tiles)"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_indel_model
+    from oracle import oracle
+    rng = np.random.Generator(np.random.PCG64(100 + n))
+    for name, kind, rows in (("ONT-HG002", _lib.MODEL_INDEL, 15), ("haploid", _lib.MODEL_INDEL_HAP, 5)):
+        w = Weights(get_indel_model(name))
+        eng.load_weights(kind, w)
+        x = (rng.random((n, rows, 128, 2)) * 1.6 - 0.5).astype(np.float32)
+        x[rng.random(x.shape) < 0.3] = 0.0
+        e = oracle.indel_forward(w.flat, x, precision="f64")
+        xd = torch.from_numpy(x).cuda()
+        eng.set_cnn_precision(exact_fp32=False)
+        p = eng.indel_forward(kind, xd).cpu().numpy()
+        eng.set_cnn_precision(exact_fp32=True)
+        q = eng.indel_forward(kind, xd).cpu().numpy()
+        eng.set_cnn_precision(exact_fp32=False)
+        assert np.abs(q - e).max() < 1e-4 and np.abs(p - e).max() < 1e-4, (name, float(np.abs(p - e).max()))
+        assert np.abs(p - q).max() < 2e-5                              # the two kernel families agree far inside the tolerance
 
 
 def test_end_to_end_vcf_matches_oracle_pipeline(eng, tmp_path):
