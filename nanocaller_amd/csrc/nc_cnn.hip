@@ -38,9 +38,7 @@ __device__ __forceinline__ float selu_acc(float x) { return x > 0.0f ? SELU_L * 
 // ---- conv1: the three `same` convolutions, fused.  Canonical weights: k11[1][5][CI][C1] b11 k12[5][1][CI][C1] b12
 // k13[5][5][CI][C1] b13.  Output NHWC [site][H][W][3*C1].  Coverage scaling (snpCaller.py:93-96) is applied while
 // loading: rows >= 1, channels < CI-1 (scale == nullptr: none).
-// SPLIT: the activations leave as two fp16 planes (hi = fp16(v), lo = fp16(v - hi); same bytes as fp32), the operand form of
-// the split-precision conv2 (k8_conv23_h3): `out` = hi plane [npos][3*C1], the lo plane follows it.
-template <int H, int W, int CI, int C1, bool SPLIT = false>
+template <int H, int W, int CI, int C1>
 __global__ __launch_bounds__(256) void k2_conv1(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ out,
                                                 int64_t npos, const double *__restrict__ scale, int scale_mode, int64_t site0)
 {
@@ -86,24 +84,6 @@ __global__ __launch_bounds__(256) void k2_conv1(const float *__restrict__ x, con
             }
         }
     }
-    if constexpr (SPLIT) {
-        static_assert(C1 == 8, "k2_conv1<SPLIT>: one 16-byte store per branch");
-        _Float16 *hp = reinterpret_cast<_Float16 *>(out) + g * (3 * C1), *lp = hp + npos * (3 * C1);
-        const float *acc[3] = {a1, a2, a3};
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            _Float16 hi[8], lo[8];
-#pragma unroll
-            for (int o = 0; o < 8; o++) {
-                const float v = fminf(fmaxf(selu(acc[b][o]), -65504.0f), 65504.0f);
-                hi[o] = (_Float16)v;
-                lo[o] = (_Float16)(v - (float)hi[o]);
-            }
-            *reinterpret_cast<uint4 *>(hp + 8 * b) = *reinterpret_cast<const uint4 *>(hi);
-            *reinterpret_cast<uint4 *>(lp + 8 * b) = *reinterpret_cast<const uint4 *>(lo);
-        }
-        return;
-    }
     float4 *op = reinterpret_cast<float4 *>(out + g * (3 * C1));
 #pragma unroll
     for (int o = 0; o < C1; o += 4) {
@@ -116,6 +96,8 @@ __global__ __launch_bounds__(256) void k2_conv1(const float *__restrict__ x, con
 // conv1 of the indel models (CI = 2, W a multiple of 4), four x-adjacent output positions per thread: the 5 x 8 input
 // window of the four positions is loaded once (20 dwordx4 instead of 100 8-byte loads) and every weight, a wave-uniform
 // scalar operand, feeds four FMAs.  Same fmaf order per output as k2_conv1 (tap-major, channel-minor): bit-identical.
+// SPLIT: the activations leave as two fp16 planes (hi = fp16(v), lo = fp16(v - hi); same bytes as fp32), the operand form
+// of the split-precision conv2 (k8_conv23_h3): `out` = hi plane [npos][3*C1], the lo plane follows it.
 template <int H, int W, int C1, bool SPLIT>
 __global__ __launch_bounds__(256) void k2_conv1_x4(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ out, int64_t npos)
 {
