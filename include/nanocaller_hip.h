@@ -342,6 +342,16 @@ int nc_nw_cigar(const char *s1, int32_t n1, const char *s2, int32_t n2, int32_t 
 int nc_allele_prediction(const char *alt, int32_t n_alt, const char *ref_seq, int32_t n_ref, int32_t max_range, int32_t *ref_len,
                          int32_t *alt_len);
 
+/* Star alignment of a read set to its reference window: replaces the MUSCLE subprocess of
+ * generate_indel_pileups.py:24-44 with pairwise Gotoh alignments (anchored at the window start, free tail; scoring as above)
+ * merged in reference coordinates -- longest insertion per reference slot, shorter ones left-justified.  NOT MUSCLE's
+ * algorithm: rows are not comparable with its output, only the resulting calls are.
+ * reads: concatenated characters, read r = reads[read_off[r] .. read_off[r+1]); rows: [n_reads][col_cap] symbols
+ * A=0 G=1 T=2 C=3 gap=4 other=5, the first *n_cols columns of each row valid; ref_row [col_cap] likewise.
+ * NC_ERR_CAPACITY (with *n_cols set) when col_cap is too small. */
+int nc_star_msa(int32_t n_reads, const char *reads, const int32_t *read_off, const char *ref, int32_t n_ref, int32_t open,
+                int32_t extend, int32_t match, int32_t mismatch, int32_t col_cap, uint8_t *rows, uint8_t *ref_row, int32_t *n_cols);
+
 /* ------------------------------------------------------------------ SNP genotype rules + VCF record text (host)
  * Replaces the per-site Python loop of snpCaller.caller (snpCaller.py:113-198).  probs f32 [n][4]
  * (diploid: class-1 probability of the A,G,T,C heads; haploid: 4-way softmax); order i32 [n][4] = np.argsort(probs,

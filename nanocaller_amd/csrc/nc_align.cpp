@@ -12,8 +12,10 @@ constexpr int32_t NEG = -(1 << 29);
 enum : uint8_t { H_DIAG = 0, H_DEL = 1, H_INS = 2, E_EXT = 4, F_EXT = 8 };   // E: gap consuming s2 (D), F: gap consuming s1 (I)
 
 // -> CIGAR in alignment order
+// free_tail: the alignment is anchored at the start only; it ends at the best cell of the last row or last column (ties:
+// the cell closest to the corner along the last row first), and the unaligned tail follows as one trailing gap.
 void nw_cigar(const char *s1, int n1, const char *s2, int n2, int open, int extend, int match, int mismatch,
-              std::vector<int32_t> &ops, std::vector<int32_t> &cnts)
+              std::vector<int32_t> &ops, std::vector<int32_t> &cnts, bool free_tail = false)
 {
     const int W = n2 + 1;
     std::vector<int32_t> H((size_t)(n1 + 1) * W), E((size_t)(n1 + 1) * W, NEG), F((size_t)(n1 + 1) * W, NEG);
@@ -45,6 +47,15 @@ void nw_cigar(const char *s1, int n1, const char *s2, int n2, int open, int exte
     // traceback
     std::vector<int32_t> rops;
     int i = n1, j = n2;
+    if (free_tail && n1 > 0 && n2 > 0) {
+        int32_t best = H[(size_t)n1 * W + n2];
+        for (int jj = n2 - 1; jj >= 0; jj--)                       // last row: the rest of s2 is unaligned
+            if (H[(size_t)n1 * W + jj] > best) { best = H[(size_t)n1 * W + jj]; i = n1; j = jj; }
+        for (int ii = n1 - 1; ii >= 0; ii--)                       // last column: the rest of s1 is unaligned
+            if (H[(size_t)ii * W + n2] > best) { best = H[(size_t)ii * W + n2]; i = ii; j = n2; }
+        for (int t = n2; t > j; t--) rops.push_back(2);
+        for (int t = n1; t > i; t--) rops.push_back(1);
+    }
     int state = -1;                                   // -1: follow H, 1: inside a D gap (E), 2: inside an I gap (F)
     while (i > 0 || j > 0) {
         const size_t c = (size_t)i * W + j;
@@ -129,5 +140,76 @@ extern "C" int nc_allele_prediction(const char *alt, int32_t n_alt, const char *
     if (!mm_before) { ro += 1; ao += 1; }
     *ref_len = clamp(ro, n_ref);
     *alt_len = clamp(ao, n_alt);
+    return NC_OK;
+}
+
+
+// ---- Star alignment of a read set to its reference window (replaces the MUSCLE subprocess of
+// generate_indel_pileups.py:24-44 -- not MUSCLE's algorithm, so not comparable row by row with it; judged by call concordance).
+// Every read is aligned to the reference window on its own (Gotoh, anchored at the window start, free tail), then the
+// pairwise alignments are merged in reference coordinates: a reference slot gets as many insertion columns as the longest
+// insertion any read has there, shorter insertions are left-justified.  Symbols as in msa(): A=0 G=1 T=2 C=3 gap=4; any other
+// read character is kept (5) so that the caller can reject it as the reference's `KeyError` does.
+#include <thread>
+
+#include "nc_host.h"
+
+static inline uint8_t sym_code(char c)
+{
+    switch (c) { case 'A': return 0; case 'G': return 1; case 'T': return 2; case 'C': return 3; case '-': return 4; default: return 5; }
+}
+
+extern "C" int nc_star_msa(int32_t n_reads, const char *reads, const int32_t *read_off, const char *ref, int32_t n_ref, int32_t open,
+                           int32_t extend, int32_t match, int32_t mismatch, int32_t col_cap, uint8_t *rows, uint8_t *ref_row,
+                           int32_t *n_cols)
+{
+    if (n_reads < 0 || n_ref < 1 || !ref || !n_cols || (n_reads && (!reads || !read_off)) || col_cap < n_ref || !ref_row || (n_reads && !rows))
+        return NC_ERR_ARG;
+    for (int r = 0; r < n_reads; r++)
+        if (read_off[r + 1] < read_off[r] || (int64_t)(read_off[r + 1] - read_off[r] + 1) * (n_ref + 1) > (int64_t)1 << 26) return NC_ERR_ARG;
+    std::vector<std::vector<int32_t>> ops((size_t)n_reads), cnts((size_t)n_reads);
+    int T = nc_host_cpus();
+    if (T > 32) T = 32;
+    if (T > n_reads) T = n_reads;
+    auto work = [&](int t) {
+        for (int r = t; r < n_reads; r += (T > 0 ? T : 1))
+            nw_cigar(reads + read_off[r], read_off[r + 1] - read_off[r], ref, n_ref, open, extend, match, mismatch, ops[(size_t)r], cnts[(size_t)r], true);
+    };
+    if (T <= 1) { if (n_reads) work(0); }
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    // insertion columns per reference slot (slot j = before reference position j; slot n_ref = after the last)
+    std::vector<int32_t> ins((size_t)n_ref + 1, 0);
+    for (int r = 0; r < n_reads; r++) {
+        int j = 0;
+        for (size_t k = 0; k < ops[(size_t)r].size(); k++) {
+            const int op = ops[(size_t)r][k], c = cnts[(size_t)r][k];
+            if (op == 1) { if (c > ins[(size_t)j]) ins[(size_t)j] = c; }
+            else j += c;
+        }
+    }
+    std::vector<int32_t> col((size_t)n_ref + 1);                    // column of reference position j (col[n_ref] = end)
+    int32_t acc = 0;
+    for (int j = 0; j <= n_ref; j++) { acc += ins[(size_t)j]; col[(size_t)j] = acc + j; }
+    const int32_t nc = col[(size_t)n_ref];
+    *n_cols = nc;
+    if (nc > col_cap) return NC_ERR_CAPACITY;
+    memset(ref_row, 4, (size_t)nc);
+    for (int j = 0; j < n_ref; j++) ref_row[col[(size_t)j]] = sym_code(ref[j]);
+    for (int r = 0; r < n_reads; r++) {
+        uint8_t *row = rows + (size_t)r * col_cap;
+        memset(row, 4, (size_t)nc);
+        const char *q = reads + read_off[r];
+        int i = 0, j = 0;
+        for (size_t k = 0; k < ops[(size_t)r].size(); k++) {
+            const int op = ops[(size_t)r][k], c = cnts[(size_t)r][k];
+            if (op == 7 || op == 8) { for (int t = 0; t < c; t++, i++, j++) row[col[(size_t)j]] = sym_code(q[i]); }
+            else if (op == 2) j += c;
+            else { const int32_t s0 = col[(size_t)j] - ins[(size_t)j]; for (int t = 0; t < c; t++, i++) row[s0 + t] = sym_code(q[i]); }
+        }
+    }
     return NC_OK;
 }

@@ -8,6 +8,7 @@
 #include <sched.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 static inline int nc_host_cpus()

@@ -236,6 +236,43 @@ def muscle_aligner(names, seqs, ref):
     return rows, ref_row
 
 
+def star_aligner(names, seqs, ref, open_=9, extend=1, match=20, mismatch=-10):
+    """Same interface as muscle_aligner, without the external binary: every read is aligned to the
+    reference window (Gotoh, anchored at the window start, free tail; the scoring of the reference's own parasail call) and
+    the pairwise alignments are merged in reference coordinates by nc_star_msa -- the longest insertion per reference slot
+    makes the columns, shorter ones are left-justified.  Not MUSCLE's algorithm: its rows are not comparable with MUSCLE's
+    output, only the calls made from them are.  -> (aligned read rows in input order, aligned reference row)."""
+    L = _lib.lib()
+    n = len(seqs)
+    raw = "".join(seqs).encode()
+    off = np.zeros(n + 1, np.int32)
+    np.cumsum([len(q) for q in seqs], out=off[1:])
+    rb = ref.encode()
+    cap = len(rb) + sum(len(q) for q in seqs) + 1                     # every read base could be an insertion
+    cap = min(cap, 4 * len(rb) + 64)
+    ncol = C.c_int32()
+    while True:
+        rows = np.empty((max(n, 1), cap), np.uint8)
+        ref_row = np.empty(cap, np.uint8)
+        rc = L.nc_star_msa(n, raw, _lib.npp(off), rb, len(rb), int(open_), int(extend), int(match), int(mismatch), cap,
+                           _lib.npp(rows), _lib.npp(ref_row), C.byref(ncol))
+        if rc == _lib.NC_ERR_CAPACITY:
+            cap = ncol.value
+            continue
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_star_msa failed (%d)" % rc)
+        break
+    sym = np.frombuffer(b"AGTC-N", np.uint8)
+    nc = ncol.value
+    return [sym[rows[r, :nc]].tobytes().decode() for r in range(n)], sym[ref_row[:nc]].tobytes().decode()
+
+
+def default_aligner():
+    """MUSCLE when it is on PATH (the reference's aligner), else the built-in star aligner"""
+    import shutil
+    return muscle_aligner if shutil.which("muscle") else star_aligner
+
+
 _SYM = {"A": 0, "G": 1, "T": 2, "C": 3, "-": 4}
 
 
@@ -247,7 +284,7 @@ def msa(seq_list, ref, v_pos, mincov, maxcov, aligner=None, device=0):
     if len(sample) > maxcov:
         sample = random.sample(sample, min(len(sample), maxcov))
     sample = sorted(sample)
-    rows, ref_row = (aligner or muscle_aligner)(sample, [seq_list[n] for n in sample], ref)
+    rows, ref_row = (aligner or default_aligner())(sample, [seq_list[n] for n in sample], ref)
     if len(rows) < mincov or ref_row is None:
         return (0, 0, None, None, None)
     mat = np.array([[_SYM[c] for c in r] for r in rows], np.uint8)                # KeyError on 'N', as in the reference (:56)

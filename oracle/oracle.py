@@ -373,6 +373,86 @@ def nw_cigar_ref(s1, s2, open_=9, extend=1, match=20, mismatch=-10):
     return [(o, c) for o, c in out]
 
 
+def nw_cigar_free_tail_ref(s1, s2, open_=9, extend=1, match=20, mismatch=-10):
+    """nw_cigar_ref anchored at the start only: the alignment ends at the best cell of the last row or last column (ties: the
+    corner, then the last row from the corner outwards, then the last column), the unaligned tail is one trailing gap."""
+    n1, n2 = len(s1), len(s2)
+    if n1 == 0 or n2 == 0:
+        return nw_cigar_ref(s1, s2, open_, extend, match, mismatch)
+    NEG = -10 ** 9
+    H = [[0] * (n2 + 1) for _ in range(n1 + 1)]
+    E = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    F = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    for j in range(1, n2 + 1):
+        H[0][j] = E[0][j] = -open_ - (j - 1) * extend
+    for i in range(1, n1 + 1):
+        H[i][0] = F[i][0] = -open_ - (i - 1) * extend
+        for j in range(1, n2 + 1):
+            E[i][j] = max(H[i][j - 1] - open_, E[i][j - 1] - extend)
+            F[i][j] = max(H[i - 1][j] - open_, F[i - 1][j] - extend)
+            H[i][j] = max(H[i - 1][j - 1] + (match if s1[i - 1] == s2[j - 1] else mismatch), E[i][j], F[i][j])
+    best, bi, bj = H[n1][n2], n1, n2
+    for j in range(n2 - 1, -1, -1):
+        if H[n1][j] > best:
+            best, bi, bj = H[n1][j], n1, j
+    for i in range(n1 - 1, -1, -1):
+        if H[i][n2] > best:
+            best, bi, bj = H[i][n2], i, n2
+    head = nw_cigar_ref(s1[:bi], s2[:bj], open_, extend, match, mismatch)
+    tail = ([(2, n2 - bj)] if bj < n2 else []) + ([(1, n1 - bi)] if bi < n1 else [])
+    out = [list(t) for t in head]
+    for o, c in tail:                                           # the library emits the tail gap before merging runs
+        if out and out[-1][0] == o:
+            out[-1][1] += c
+        else:
+            out.append([o, c])
+    return [(o, c) for o, c in out]
+
+
+def star_msa_ref(seqs, ref, open_=9, extend=1, match=20, mismatch=-10):
+    """Star alignment restated in pure Python (checks nc_star_msa): pairwise free-tail alignments to `ref`, merged in reference
+    coordinates -- per reference slot as many insertion columns as the longest insertion, shorter ones left-justified.
+    -> (rows, ref_row) as strings over AGTC-"""
+    n_ref = len(ref)
+    cig = [nw_cigar_free_tail_ref(q, ref, open_, extend, match, mismatch) for q in seqs]
+    ins = [0] * (n_ref + 1)
+    for c in cig:
+        j = 0
+        for op, cnt in c:
+            if op == 1:
+                ins[j] = max(ins[j], cnt)
+            else:
+                j += cnt
+    col, acc = [], 0
+    for j in range(n_ref + 1):
+        acc += ins[j]
+        col.append(acc + j)
+    ncol = col[n_ref]
+    ref_row = ["-"] * ncol
+    for j in range(n_ref):
+        ref_row[col[j]] = ref[j]
+    rows = []
+    for q, c in zip(seqs, cig):
+        row = ["-"] * ncol
+        i = j = 0
+        for op, cnt in c:
+            if op in (7, 8):
+                for _ in range(cnt):
+                    row[col[j]] = q[i]
+                    i += 1
+                    j += 1
+            elif op == 2:
+                j += cnt
+            else:
+                s0 = col[j] - ins[j]
+                for t in range(cnt):
+                    row[s0 + t] = q[i]
+                    i += 1
+        assert i == len(q)
+        rows.append("".join(row))
+    return rows, "".join(ref_row)
+
+
 def allele_prediction_ref(alt, ref_seq, max_range, cigar=None):
     """generate_indel_pileups.py:77-127 transliterated (same variable names); `cigar` defaults to nw_cigar_ref."""
     cigar_op = cigar if cigar is not None else nw_cigar_ref(alt, ref_seq)

@@ -365,3 +365,116 @@ def test_get_indel_testing_candidates_uses_imputed_read_sets(tmp_path):
         assert seen[3 * k + 1] == sorted(w.names[r] for r in e1 if r in here and r not in set(e0)), a
         assert seen[3 * k + 2] == sorted(w.names[r] for r in at), a
     assert n_imp > 5 and set(pos) <= set(anchors)
+
+
+# ----------------------------------------------------------------------------------------- star aligner (8f n4)
+def _mutate(rng, ref, n_sub, indels):
+    q = list(ref)
+    for p in rng.choice(len(q), size=n_sub, replace=False):
+        q[p] = "AGTC"[("AGTC".index(q[p]) + int(rng.integers(1, 4))) % 4]
+    for pos, ln in sorted(indels, reverse=True):
+        if ln > 0:
+            q[pos:pos] = list("".join("AGTC"[i] for i in rng.integers(0, 4, size=ln)))
+        else:
+            del q[pos:pos - ln]
+    return "".join(q)
+
+
+def test_star_aligner_hand_cases():
+    ref = "ACGTACGTACGTAAAACCCCGGGGTTTT"
+    rows, rr = gip.star_aligner(["a", "b", "c"], [ref, ref[:10] + "GG" + ref[10:], ref[:14] + ref[17:]], ref)
+    assert rr == ref[:10] + "--" + ref[10:]                          # two insertion columns, in the reference row too
+    assert rows[0] == rr                                             # the unchanged read follows the reference, gaps included
+    assert rows[1] == ref[:10] + "GG" + ref[10:]
+    assert rows[2].replace("-", "") == ref[:14] + ref[17:] and rows[2].count("-") == 5 and len({len(r) for r in rows} | {len(rr)}) == 1
+    # a read that ends early: trailing gap, nothing forced onto the window's end (free tail)
+    rows, rr = gip.star_aligner(["a"], [ref[:12]], ref)
+    assert rows[0] == ref[:12] + "-" * (len(ref) - 12) and rr == ref
+    # a read longer than the window: its tail becomes insertion columns after the last reference position
+    rows, rr = gip.star_aligner(["a", "b"], [ref + "ACG", ref], ref)
+    assert rr == ref + "---" and rows[0] == ref + "ACG" and rows[1] == ref + "---"
+    # no reads at all
+    rows, rr = gip.star_aligner([], [], ref)
+    assert rows == [] and rr == ref
+
+
+def test_star_aligner_matches_pure_python_restatement_and_is_lossless():
+    rng = np.random.Generator(np.random.PCG64(77))
+    for trial in range(12):
+        n_ref = int(rng.integers(40, 120))
+        ref = "".join("AGTC"[i] for i in rng.integers(0, 4, size=n_ref))
+        seqs = []
+        for r in range(int(rng.integers(1, 9))):
+            indels = [(int(rng.integers(2, n_ref - 8)), int(rng.choice([-4, -2, -1, 1, 2, 3, 6]))) for _ in range(int(rng.integers(0, 3)))]
+            indels = [(p, l) for k, (p, l) in enumerate(indels) if all(abs(p - p2) > 8 for p2, _ in indels[:k])]
+            q = _mutate(rng, ref, int(rng.integers(0, 5)), indels)
+            seqs.append(q[:int(rng.integers(max(10, len(q) - 15), len(q) + 1))])
+        rows, rr = gip.star_aligner(["r%d" % k for k in range(len(seqs))], seqs, ref)
+        erows, err = oracle.star_msa_ref(seqs, ref)
+        assert rr == err and rows == erows, trial
+        assert rr.replace("-", "") == ref and all(r.replace("-", "") == q for r, q in zip(rows, seqs))
+        assert len({len(r) for r in rows} | {len(rr)}) == 1
+        # every insertion column holds at least one base, no column is all gaps
+        for c in range(len(rr)):
+            assert rr[c] != "-" or any(r[c] != "-" for r in rows)
+
+
+def test_free_tail_alignment_restatement_agrees_with_library_on_pairs():
+    """the pairwise alignments inside nc_star_msa (read vs reference, free tail) == the Python restatement, seen through a
+    one-read star alignment: the read row / reference row pair spells the CIGAR"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    for trial in range(40):
+        n_ref = int(rng.integers(8, 60))
+        ref = "".join("AGTC"[i] for i in rng.integers(0, 4, size=n_ref))
+        q = _mutate(rng, ref, int(rng.integers(0, 4)), [(int(rng.integers(1, n_ref - 2)), int(rng.choice([-2, -1, 1, 2])))])
+        q = q[:int(rng.integers(3, len(q) + 1))]
+        (row,), rr = gip.star_aligner(["q"], [q], ref)
+        ops = []
+        for a, b in zip(row, rr):
+            o = 1 if b == "-" else 2 if a == "-" else 7 if a == b else 8
+            if ops and ops[-1][0] == o:
+                ops[-1][1] += 1
+            else:
+                ops.append([o, 1])
+        assert [tuple(o) for o in ops] == oracle.nw_cigar_free_tail_ref(q, ref), (q, ref)
+
+
+@pytest.mark.gpu
+def test_indel_calls_with_the_star_aligner_recover_the_planted_indels(tmp_path):
+    """SURVEY.md 8f n4 is judged by call concordance, not by MUSCLE's rows: BAM + FASTA in, pass 1 on the GPU, pass-2 windows,
+    the built-in star aligner (no external binary), msa tensors on the GPU, allele_prediction -- the alleles called at the
+    anchors recover the indels planted in the reads (every event carried by >= 5 reads)"""
+    import collections
+    from nanocaller_amd.synth import unphase_blocks
+    w = bamio.make_bam_world(seed=41, length=40_000, depth=24)
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    refc = np.array(["AGTC".find(c) for c in w.ref], np.int64)
+    for r in range(w.n_reads):                                                    # code-4 noise outside deletions -> a base
+        s0, o0 = int(w.read_start[r]), int(w.read_off[r])
+        span = w.codes[o0:int(w.read_off[r + 1])]
+        deleted = np.zeros(len(span), bool)
+        for k in range(ev_off[r], ev_off[r + 1]):
+            if ev_len[k] < 0:
+                deleted[ev_pos[k] + 1 - s0:ev_pos[k] + 1 - s0 - ev_len[k]] = True
+        fix = (span == 4) & ~deleted
+        span[fix] = np.maximum(refc[s0 - 1:s0 - 1 + len(span)][fix], 0)
+    w = unphase_blocks(w, [], seed=41, drop=0.0, alt_base_frac=0.0)               # the same inserted bases in every carrier
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, np.random.Generator(np.random.PCG64(61))))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    truth = collections.Counter()
+    for r in range(w.n_reads):
+        for k in range(ev_off[r], ev_off[r + 1]):
+            truth[(int(ev_pos[k]), int(ev_len[k]))] += 1
+    truth = [k for k, v in sorted(truth.items()) if v >= 5 and 3_000 < k[0] < 37_000]
+    dct = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6,
+               supplementary=False, exclude_bed=None, impute_indel_phase=False)
+    pos, x0, x1, x2, alleles, phase = gip.get_indel_testing_candidates(dct, dict(chrom=w.chrom, start=2_000, end=38_000, sam_path=bam),
+                                                                       aligner=gip.star_aligner)
+    assert len(truth) > 50 and len(pos) > 50 and x0.shape[1:] == (5, 128, 2)
+    exact = close = 0
+    for (p, ln) in truth:
+        diffs = [len(A) - len(R) for a, al in zip(pos, alleles) if a <= p <= a + 60 for (R, A) in al if R is not None]
+        exact += ln in diffs
+        close += any(abs(d - ln) <= 3 and d * ln > 0 for d in diffs)
+    assert exact >= 0.65 * len(truth) and close >= 0.8 * len(truth), (exact, close, len(truth))
