@@ -352,6 +352,17 @@ int nc_allele_prediction(const char *alt, int32_t n_alt, const char *ref_seq, in
 int nc_star_msa(int32_t n_reads, const char *reads, const int32_t *read_off, const char *ref, int32_t n_ref, int32_t open,
                 int32_t extend, int32_t match, int32_t mismatch, int32_t col_cap, uint8_t *rows, uint8_t *ref_row, int32_t *n_cols);
 
+/* The same star alignment on the device, for many read sets at once, followed by the rows -> tensor kernel (K8): one lane per
+ * read fills the Gotoh DP in HBM and walks it back, one workgroup per set merges the alignments into rows.  Bit-identical rows
+ * to nc_star_msa.  Host arrays in: reads (concatenated characters, read a = [read_off[a], read_off[a+1])), the reads of set s
+ * are set_read0[s] .. set_read0[s+1]; refs / ref_off: the reference window of every set.  Out: x_dev [n_sets][5][128][2] (device),
+ * cns_host [n_sets][max_cols] (consensus symbols, gaps kept as 4, NC_CODE_ABSENT padding), n_cols_host [n_sets].  rows_host /
+ * ref_rows_host (optional, with per-set byte offsets; set s needs n_reads[s] * n_cols[s] resp. n_cols[s] bytes): the rows. */
+int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads, const int32_t *read_off, const int32_t *set_read0,
+                       const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
+                       int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
+                       const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off);
+
 /* ------------------------------------------------------------------ SNP genotype rules + VCF record text (host)
  * Replaces the per-site Python loop of snpCaller.caller (snpCaller.py:113-198).  probs f32 [n][4]
  * (diploid: class-1 probability of the A,G,T,C heads; haploid: 4-way softmax); order i32 [n][4] = np.argsort(probs,

@@ -1,0 +1,320 @@
+// Star alignment of read sets to their reference windows on the device (replaces the MUSCLE subprocess
+// of generate_indel_pileups.py:24-44; the host statement of the same algorithm is nc_star_msa in nc_align.cpp, and the two
+// agree bit for bit -- same recurrences, same tie rules, same end-point choice).
+//
+//   A  k_nw_fill       one lane per read: Gotoh DP of the read against its set's reference window, row by row; the H / F rows
+//                      and the traceback bytes live in HBM in [cell][alignment] order, so the 64 lanes of a wave (64 reads)
+//                      touch consecutive addresses on every access
+//   B  k_nw_trace      one lane per read: end point (free tail), traceback -> the alignment in reference coordinates
+//                      (read index aligned to every reference position, length / start of the insertion in every slot)
+//   C1 k_set_columns   one workgroup per set: longest insertion per slot over the set's reads -> column of every reference
+//                      position, number of columns
+//   C2 k_set_rows      one workgroup per set: the aligned rows (symbols 0..4, other = 5) and the aligned reference row in the
+//                      layout nc_indel_tensor reads
+// then nc_indel_tensor's kernel (K8) on the rows.  Host round trips: the per-set column counts (row offsets are a prefix sum).
+#include <vector>
+
+#include "nc_common.h"
+
+namespace {
+
+constexpr int32_t NW_NEG = -(1 << 29);
+enum : uint8_t { T_DIAG = 0, T_DEL = 1, T_INS = 2, T_EEXT = 4, T_FEXT = 8 };
+
+struct NwArgs {
+    const uint8_t *reads;          // concatenated read characters
+    const int32_t *read_off;       // [A + 1]
+    const int32_t *read_set;       // [A] set of every read
+    const uint8_t *refs;           // concatenated reference windows
+    const int32_t *ref_off;        // [n_sets + 1]
+    int32_t A, Apad;               // alignments in this launch, padded to a multiple of 64 (the stride of the [cell][a] arrays)
+    int32_t W;                     // max reference length + 1 (row pitch of the DP)
+    int32_t a0;                    // first alignment of this launch (index into read_off / read_set)
+    int32_t open, extend, match, mismatch;
+    int32_t *Hrow, *Frow;          // [W][Apad]
+    int32_t *hcol;                 // [N1 + 1][Apad]: H[i][n2]
+    uint8_t *T;                    // [N1 + 1][W][Apad]
+};
+
+__global__ __launch_bounds__(64) void k_nw_fill(NwArgs p)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    if (al >= p.A) return;
+    const int a = p.a0 + al;
+    const uint8_t *s1 = p.reads + p.read_off[a];
+    const int n1 = p.read_off[a + 1] - p.read_off[a];
+    const int set = p.read_set[a];
+    const uint8_t *s2 = p.refs + p.ref_off[set];
+    const int n2 = p.ref_off[set + 1] - p.ref_off[set];
+    const int64_t S = p.Apad;
+    int32_t *H = p.Hrow + al, *F = p.Frow + al;
+    uint8_t *T = p.T + al;
+    H[0] = 0;
+    F[0] = NW_NEG;
+    for (int j = 1; j <= n2; j++) {
+        H[j * S] = -p.open - (j - 1) * p.extend;
+        F[j * S] = NW_NEG;
+        T[j * S] = (uint8_t)(T_DEL | (j > 1 ? T_EEXT : 0));
+    }
+    p.hcol[al] = n2 > 0 ? -p.open - (n2 - 1) * p.extend : 0;
+    for (int i = 1; i <= n1; i++) {
+        const uint8_t c1 = s1[i - 1];
+        int32_t hdiag = H[0];
+        int32_t hleft = -p.open - (i - 1) * p.extend;
+        H[0] = hleft;
+        F[0] = hleft;
+        uint8_t *Ti = T + (int64_t)i * p.W * S;
+        Ti[0] = (uint8_t)(T_INS | (i > 1 ? T_FEXT : 0));
+        int32_t e = NW_NEG;
+        for (int j = 1; j <= n2; j++) {
+            const int32_t hup = H[j * S], fup = F[j * S];
+            uint8_t t = 0;
+            const int32_t e_open = hleft - p.open, e_ext = e - p.extend;
+            e = e_open;
+            if (e_ext >= e_open) { e = e_ext; t |= T_EEXT; }
+            const int32_t f_open = hup - p.open, f_ext = fup - p.extend;
+            int32_t f = f_open;
+            if (f_ext >= f_open) { f = f_ext; t |= T_FEXT; }
+            const int32_t d = hdiag + (c1 == s2[j - 1] ? p.match : p.mismatch);
+            int32_t h = d;
+            uint8_t w = T_DIAG;
+            if (e > h) { h = e; w = T_DEL; }
+            if (f > h) { h = f; w = T_INS; }
+            H[j * S] = h;
+            F[j * S] = f;
+            Ti[j * S] = (uint8_t)(t | w);
+            hdiag = hup;
+            hleft = h;
+        }
+        p.hcol[(int64_t)i * S + al] = hleft;                      // H[i][n2] (n2 = 0: H[i][0])
+    }
+}
+
+struct TraceOut {
+    int16_t *qidx;                 // [A][W]: read index aligned to reference position j, -1 = gap
+    int16_t *ins_len, *ins_q;      // [A][W]: insertion in slot j (before reference position j; slot n2 = after the last)
+};
+
+__global__ __launch_bounds__(64) void k_nw_trace(NwArgs p, TraceOut o)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    if (al >= p.A) return;
+    const int a = p.a0 + al;
+    const int n1 = p.read_off[a + 1] - p.read_off[a];
+    const int set = p.read_set[a];
+    const int n2 = p.ref_off[set + 1] - p.ref_off[set];
+    const int64_t S = p.Apad;
+    int16_t *qidx = o.qidx + (int64_t)al * p.W, *il = o.ins_len + (int64_t)al * p.W, *iq = o.ins_q + (int64_t)al * p.W;
+    for (int j = 0; j <= n2; j++) { qidx[j] = -1; il[j] = 0; iq[j] = 0; }
+    int i = n1, j = n2;
+    if (n1 > 0 && n2 > 0) {                                           // free tail: best cell of the last row / last column
+        int32_t best = p.Hrow[(int64_t)n2 * S + al];
+        for (int jj = n2 - 1; jj >= 0; jj--) {
+            const int32_t v = p.Hrow[(int64_t)jj * S + al];
+            if (v > best) { best = v; i = n1; j = jj; }
+        }
+        for (int ii = n1 - 1; ii >= 0; ii--) {
+            const int32_t v = p.hcol[(int64_t)ii * S + al];
+            if (v > best) { best = v; i = ii; j = n2; }
+        }
+        if (i < n1) { il[n2] = (int16_t)(n1 - i); iq[n2] = (int16_t)i; }   // the rest of the read: insertion after the window
+    }
+    const uint8_t *T = p.T + al;
+    int state = -1;
+    while (i > 0 || j > 0) {
+        const uint8_t t = T[((int64_t)i * p.W + j) * S];
+        if (state < 0) {
+            const int w = t & 3;
+            if (w == T_DIAG) { qidx[j - 1] = (int16_t)(i - 1); i--; j--; continue; }
+            state = w == T_DEL ? 1 : 2;
+        }
+        if (state == 1) {
+            const bool ext = (t & T_EEXT) != 0;
+            j--;                                                       // reference position j stays a gap
+            if (!ext) state = -1;
+        } else {
+            const bool ext = (t & T_FEXT) != 0;
+            il[j]++;
+            iq[j] = (int16_t)(i - 1);
+            i--;
+            if (!ext) state = -1;
+        }
+    }
+}
+
+// per set: columns.  set_read0[s] .. set_read0[s+1]: the set's alignments (indices local to the launch)
+__global__ __launch_bounds__(256) void k_set_columns(int32_t W, const int32_t *__restrict__ set_read0, const int32_t *__restrict__ ref_off,
+                                                     int32_t set0, const int16_t *__restrict__ ins_len, int32_t *__restrict__ col /* [sets][W] */,
+                                                     int32_t *__restrict__ n_cols)
+{
+    __shared__ int32_t mx[1024];
+    const int sl = blockIdx.x, s = set0 + sl;
+    const int n2 = ref_off[s + 1] - ref_off[s];
+    const int r0 = set_read0[sl], r1 = set_read0[sl + 1];
+    for (int j = threadIdx.x; j <= n2; j += 256) {
+        int m = 0;
+        for (int r = r0; r < r1; r++) m = max(m, (int)ins_len[(int64_t)r * W + j]);
+        mx[j] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int j = 0; j <= n2; j++) { acc += mx[j]; col[(int64_t)sl * W + j] = acc + j; }
+        n_cols[sl] = acc + n2;
+    }
+}
+
+__device__ __forceinline__ uint8_t sym_code(uint8_t c)
+{
+    return c == 'A' ? 0 : c == 'G' ? 1 : c == 'T' ? 2 : c == 'C' ? 3 : c == '-' ? 4 : 5;
+}
+
+__global__ __launch_bounds__(256) void k_set_rows(NwArgs p, TraceOut o, const int32_t *__restrict__ set_read0, int32_t set0,
+                                                  const int32_t *__restrict__ col, const int32_t *__restrict__ n_cols,
+                                                  const int64_t *__restrict__ row_off, const int64_t *__restrict__ refrow_off,
+                                                  uint8_t *__restrict__ rows, uint8_t *__restrict__ ref_rows)
+{
+    const int sl = blockIdx.x, s = set0 + sl;
+    const uint8_t *s2 = p.refs + p.ref_off[s];
+    const int n2 = p.ref_off[s + 1] - p.ref_off[s];
+    const int nc = n_cols[sl];
+    const int r0 = set_read0[sl], r1 = set_read0[sl + 1];
+    const int32_t *C = col + (int64_t)sl * p.W;
+    uint8_t *R = rows + row_off[sl], *RR = ref_rows + refrow_off[sl];
+    for (int c = threadIdx.x; c < nc; c += 256) RR[c] = 4;
+    for (int64_t k = threadIdx.x; k < (int64_t)(r1 - r0) * nc; k += 256) R[k] = 4;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n2; j += 256) RR[C[j]] = sym_code(s2[j]);
+    for (int r = r0; r < r1; r++) {
+        const uint8_t *s1 = p.reads + p.read_off[p.a0 + r];
+        const int16_t *qidx = o.qidx + (int64_t)r * p.W, *il = o.ins_len + (int64_t)r * p.W, *iq = o.ins_q + (int64_t)r * p.W;
+        uint8_t *row = R + (int64_t)(r - r0) * nc;
+        for (int j = threadIdx.x; j <= n2; j += 256) {
+            if (j < n2 && qidx[j] >= 0) row[C[j]] = sym_code(s1[qidx[j]]);
+            const int L = il[j];
+            if (L > 0) {
+                const int slot_cols = j == 0 ? C[0] : C[j] - C[j - 1] - 1;         // longest insertion of the set in this slot
+                const int c0 = C[j] - slot_cols;
+                for (int t = 0; t < L; t++) row[c0 + t] = sym_code(s1[iq[j] + t]);
+            }
+        }
+    }
+}
+
+}   // namespace
+
+// from nc_indel.hip
+extern "C" int nc_indel_tensor(nc_ctx *ctx, int32_t n_sets, const uint8_t *rows_dev, const int64_t *row_off_dev, const int32_t *n_rows_dev,
+                               const int32_t *n_cols_dev, const uint8_t *ref_rows_dev, const int64_t *ref_off_dev, int32_t max_cols,
+                               float *x_dev, uint8_t *cns_dev);
+
+// Host arrays in, tensors out: reads of set s = reads read_set0[s] .. read_set0[s+1]; x_dev [n_sets][5][128][2] (device),
+// cns_host [n_sets][max_cols] (NC_CODE_ABSENT-padded consensus symbols, gaps kept as 4), n_cols_host [n_sets].
+// Optional rows_host / ref_rows_host (+ their offsets): the aligned rows themselves, for checks against nc_star_msa.
+extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads, const int32_t *read_off, const int32_t *set_read0,
+                                  const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
+                                  int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
+                                  const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_sets < 0 || (n_sets && (!read_off || !set_read0 || !refs || !ref_off || !x_dev || !cns_host || !n_cols_host)) || max_cols < 1)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_star_msa_tensor: bad argument");
+    if (n_sets == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t A = set_read0[n_sets];
+    int32_t N1 = 0, N2 = 0;
+    for (int32_t a = 0; a < A; a++) N1 = std::max(N1, read_off[a + 1] - read_off[a]);
+    for (int32_t s = 0; s < n_sets; s++) {
+        if (set_read0[s + 1] < set_read0[s] || ref_off[s + 1] <= ref_off[s]) return nc_fail(ctx, NC_ERR_ARG, "nc_star_msa_tensor: set %d malformed", s);
+        N2 = std::max(N2, ref_off[s + 1] - ref_off[s]);
+    }
+    if (N1 > 1000 || N2 > 1000) return nc_fail(ctx, NC_ERR_ARG, "nc_star_msa_tensor: windows longer than 1000 bases");
+    const int32_t W = N2 + 1;
+    std::vector<int32_t> read_set((size_t)std::max(A, 1));
+    for (int32_t s = 0; s < n_sets; s++)
+        for (int32_t a = set_read0[s]; a < set_read0[s + 1]; a++) read_set[(size_t)a] = s;
+    // ---- device copies of the inputs
+    const size_t n_read_bytes = (size_t)read_off[A], n_ref_bytes = (size_t)ref_off[n_sets];
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        NC_TRY(nc_ensure(ctx, b, bytes + 16));
+        if (bytes) NC_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return NC_OK;
+    };
+    NC_TRY(up(ctx->msa_reads, reads, n_read_bytes));
+    NC_TRY(up(ctx->msa_read_off, read_off, ((size_t)A + 1) * 4));
+    NC_TRY(up(ctx->msa_read_set, read_set.data(), (size_t)std::max(A, 1) * 4));
+    NC_TRY(up(ctx->msa_refs, refs, n_ref_bytes));
+    NC_TRY(up(ctx->msa_ref_off, ref_off, ((size_t)n_sets + 1) * 4));
+    // ---- groups of whole sets, at most GROUP alignments each (bounds the traceback matrix: (N1+1) * W bytes per alignment)
+    const int64_t per_al = (int64_t)(N1 + 1) * W;
+    int32_t GROUP = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(64, ((int64_t)3 << 30) / std::max<int64_t>(per_al, 1)));
+    GROUP &= ~63;
+    std::vector<int32_t> n_cols((size_t)n_sets);
+    std::vector<int64_t> row_off((size_t)n_sets + 1, 0), refrow_off((size_t)n_sets + 1, 0);
+    int32_t s0 = 0;
+    while (s0 < n_sets) {
+        int32_t s1 = s0;
+        while (s1 < n_sets && (s1 == s0 || set_read0[s1 + 1] - set_read0[s0] <= GROUP)) s1++;
+        const int32_t ng = s1 - s0, a0 = set_read0[s0], Ag = set_read0[s1] - a0, Apad = std::max(64, (Ag + 63) & ~63);
+        NC_TRY(nc_ensure(ctx, ctx->msa_rows_hf, (size_t)2 * W * Apad * 4));
+        NC_TRY(nc_ensure(ctx, ctx->msa_hcol, (size_t)(N1 + 1) * Apad * 4));
+        NC_TRY(nc_ensure(ctx, ctx->msa_tb, (size_t)per_al * Apad));
+        NC_TRY(nc_ensure(ctx, ctx->msa_trace, (size_t)3 * std::max(Ag, 1) * W * 2));
+        NC_TRY(nc_ensure(ctx, ctx->msa_cols, ((size_t)ng * W + (size_t)ng + (size_t)ng + 1) * 4 + 64));
+        std::vector<int32_t> sr0((size_t)ng + 1);
+        for (int32_t k = 0; k <= ng; k++) sr0[(size_t)k] = set_read0[s0 + k] - a0;
+        int32_t *col = (int32_t *)ctx->msa_cols.p, *ncol_dev = col + (size_t)ng * W, *sr0_dev = ncol_dev + ng;
+        NC_HIP(ctx, hipMemcpyAsync(sr0_dev, sr0.data(), ((size_t)ng + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        NwArgs p;
+        p.reads = (const uint8_t *)ctx->msa_reads.p; p.read_off = (const int32_t *)ctx->msa_read_off.p;
+        p.read_set = (const int32_t *)ctx->msa_read_set.p; p.refs = (const uint8_t *)ctx->msa_refs.p; p.ref_off = (const int32_t *)ctx->msa_ref_off.p;
+        p.A = Ag; p.Apad = Apad; p.W = W; p.a0 = a0; p.open = open; p.extend = extend; p.match = match; p.mismatch = mismatch;
+        p.Hrow = (int32_t *)ctx->msa_rows_hf.p; p.Frow = p.Hrow + (size_t)W * Apad; p.hcol = (int32_t *)ctx->msa_hcol.p; p.T = (uint8_t *)ctx->msa_tb.p;
+        TraceOut o;
+        o.qidx = (int16_t *)ctx->msa_trace.p; o.ins_len = o.qidx + (size_t)std::max(Ag, 1) * W; o.ins_q = o.ins_len + (size_t)std::max(Ag, 1) * W;
+        if (Ag > 0) {
+            hipLaunchKernelGGL(k_nw_fill, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p);
+            hipLaunchKernelGGL(k_nw_trace, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p, o);
+        }
+        hipLaunchKernelGGL(k_set_columns, dim3(ng), dim3(256), 0, ctx->stream, W, sr0_dev, p.ref_off, s0, o.ins_len, col, ncol_dev);
+        NC_HIP(ctx, hipGetLastError());
+        NC_HIP(ctx, hipMemcpyAsync(n_cols.data() + s0, ncol_dev, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // rows of the group in the K8 layout
+        std::vector<int64_t> ro((size_t)ng + 1, 0), rro((size_t)ng + 1, 0);
+        std::vector<int32_t> nrows((size_t)ng);
+        int32_t mc = 1;
+        for (int32_t k = 0; k < ng; k++) {
+            nrows[(size_t)k] = sr0[(size_t)k + 1] - sr0[(size_t)k];
+            ro[(size_t)k + 1] = ro[(size_t)k] + (int64_t)nrows[(size_t)k] * n_cols[(size_t)(s0 + k)];
+            rro[(size_t)k + 1] = rro[(size_t)k] + n_cols[(size_t)(s0 + k)];
+            mc = std::max(mc, n_cols[(size_t)(s0 + k)]);
+        }
+        const size_t o_rows = 0, o_ref = (size_t)((ro[(size_t)ng] + 15) & ~int64_t(15)), o_ro = (o_ref + (size_t)rro[(size_t)ng] + 15) & ~(size_t)15,
+                     o_rro = o_ro + ((size_t)ng + 1) * 8, o_nr = o_rro + ((size_t)ng + 1) * 8, o_cns = o_nr + (size_t)ng * 4;
+        const int32_t mcols = std::max(max_cols, 1);
+        NC_TRY(nc_ensure(ctx, ctx->msa_out, o_cns + (size_t)ng * mcols + 64));
+        uint8_t *ob = (uint8_t *)ctx->msa_out.p;
+        NC_HIP(ctx, hipMemcpyAsync(ob + o_ro, ro.data(), ((size_t)ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        NC_HIP(ctx, hipMemcpyAsync(ob + o_rro, rro.data(), ((size_t)ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        NC_HIP(ctx, hipMemcpyAsync(ob + o_nr, nrows.data(), (size_t)ng * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_set_rows, dim3(ng), dim3(256), 0, ctx->stream, p, o, sr0_dev, s0, col, ncol_dev, (const int64_t *)(ob + o_ro),
+                           (const int64_t *)(ob + o_rro), ob + o_rows, ob + o_ref);
+        NC_HIP(ctx, hipGetLastError());
+        NC_TRY(nc_indel_tensor(ctx, ng, ob + o_rows, (const int64_t *)(ob + o_ro), (const int32_t *)(ob + o_nr), ncol_dev, ob + o_ref,
+                               (const int64_t *)(ob + o_rro), mcols, x_dev + (size_t)s0 * 5 * 128 * 2, ob + o_cns));
+        NC_HIP(ctx, hipMemcpyAsync(cns_host + (size_t)s0 * mcols, ob + o_cns, (size_t)ng * mcols, hipMemcpyDeviceToHost, ctx->stream));
+        if (rows_host && rows_host_off && ref_rows_host && ref_rows_host_off) {
+            for (int32_t k = 0; k < ng; k++) {
+                const size_t nb = (size_t)(ro[(size_t)k + 1] - ro[(size_t)k]);
+                if (nb) NC_HIP(ctx, hipMemcpyAsync(rows_host + rows_host_off[s0 + k], ob + o_rows + ro[(size_t)k], nb, hipMemcpyDeviceToHost, ctx->stream));
+                NC_HIP(ctx, hipMemcpyAsync(ref_rows_host + ref_rows_host_off[s0 + k], ob + o_ref + rro[(size_t)k], (size_t)n_cols[(size_t)(s0 + k)],
+                                           hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        s0 = s1;
+    }
+    for (int32_t s = 0; s < n_sets; s++) n_cols_host[s] = n_cols[(size_t)s];
+    return NC_OK;
+}

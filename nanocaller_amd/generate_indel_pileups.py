@@ -320,6 +320,11 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
     names, hap, ps = d["names"], d["hap"], d["ps"]
     max_range = {0: max(10, dct["win_size"]), 1: 10}
     out_pos, x0, x1, x2, alleles, phase = [], [], [], [], [], []
+    if aligner is None and default_aligner() is star_aligner:
+        aligner = "device"                                                         # no MUSCLE here: star alignment on the GPU
+    if aligner == "device":
+        return _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo, hi, chrom_length, window_before,
+                                      window_after, max_range, device)
     for v_pos, win in zip(anchors, d["windows"]):
         ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
                       for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))
@@ -346,6 +351,67 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
             alleles.append([allele_prediction(alt0, ref0, mr), allele_prediction(alt1, ref1, mr), allele_prediction(altt, reft, mr)])
     if not out_pos:
         return empty
+    return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
+
+
+def _sample_set(seq_list, mincov, maxcov):
+    """the part of msa() before the aligner (:13-23): down-sample to maxcov (unseeded, as in the reference), sort the names;
+    -> (names, seqs) or None when fewer than mincov reads remain"""
+    sample = list(seq_list.keys())
+    if len(sample) > maxcov:
+        sample = random.sample(sample, min(len(sample), maxcov))
+    sample = sorted(sample)
+    if len(sample) < mincov:
+        return None
+    return sample, [seq_list[n] for n in sample]
+
+
+def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo, hi, chrom_length, window_before, window_after,
+                           max_range, device):
+    """pass 2 of get_indel_testing_candidates with every read set of the chunk aligned in ONE device call
+    (engine.star_msa_tensor: star alignment + rows -> tensor), instead of three aligner calls per anchor"""
+    names, hap, ps = d["names"], d["hap"], d["ps"]
+    todo, sets, refs = [], [], []
+    for v_pos, win in zip(anchors, d["windows"]):
+        ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
+                      for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))
+        if "N" in ref:
+            continue
+        d_tot, d0, d1 = {}, {}, {}
+        imputed = extra_variants.get(v_pos)                                      # :310-312
+        for r, text in win:
+            d_tot[names[r]] = text
+            if (names[r] in imputed[0]) if imputed else hap[r] == 1:
+                d0[names[r]] = text
+            elif (names[r] in imputed[1]) if imputed else hap[r] == 2:
+                d1[names[r]] = text
+        picked = [_sample_set(d0, 2, dct["maxcov"]), _sample_set(d1, 2, dct["maxcov"]), _sample_set(d_tot, dct["mincov"], dct["maxcov"])]
+        if any(p is None for p in picked):
+            continue                                                             # flag0 and flag1 and flag_total (:345)
+        for _, seqs in picked:
+            for q in seqs:
+                for c in q:
+                    if c not in "AGTC":
+                        raise KeyError(c)                                        # as the reference's symbol table does (:56)
+            sets.append(seqs)
+            refs.append(ref)
+        todo.append((v_pos, next(iter(d0.keys()))))
+    empty = ([], [], [], [], [], [])
+    if not todo:
+        return empty
+    eng = get_engine(device)
+    eng.use_torch_stream()
+    x, cns, _ = eng.star_msa_tensor(sets, refs)
+    xh = x.cpu().numpy().astype(np.float64)
+    sym = "AGTC"
+    out_pos, x0, x1, x2, alleles, phase = [], [], [], [], [], []
+    for k, (v_pos, first) in enumerate(todo):
+        out_pos.append(v_pos)
+        x0.append(xh[3 * k]); x1.append(xh[3 * k + 1]); x2.append(xh[3 * k + 2])
+        r = names.index(first)
+        phase.append(int(ps[r]) if hap[r] else None)
+        mr = max_range[variants[v_pos]]
+        alleles.append([allele_prediction("".join(sym[c] for c in cns[3 * k + i]), refs[3 * k + i], mr) for i in range(3)])
     return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
 
 

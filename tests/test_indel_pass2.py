@@ -478,3 +478,56 @@ def test_indel_calls_with_the_star_aligner_recover_the_planted_indels(tmp_path):
         exact += ln in diffs
         close += any(abs(d - ln) <= 3 and d * ln > 0 for d in diffs)
     assert exact >= 0.65 * len(truth) and close >= 0.8 * len(truth), (exact, close, len(truth))
+    # the batched device path (every read set of the chunk in one nc_star_msa_tensor call) returns the same tuple; it is also
+    # what runs when no aligner is given and MUSCLE is not installed
+    for al in ("device", None):
+        import shutil
+        if al is None and shutil.which("muscle"):
+            continue
+        pos2, y0, y1, y2, alleles2, phase2 = gip.get_indel_testing_candidates(dct, dict(chrom=w.chrom, start=2_000, end=38_000, sam_path=bam), aligner=al)
+        assert pos2 == pos and alleles2 == alleles and phase2 == phase
+        assert np.array_equal(y0, x0) and np.array_equal(y1, x1) and np.array_equal(y2, x2)
+
+
+@pytest.mark.gpu
+def test_device_star_alignment_equals_host_star_alignment():
+    """nc_star_msa_tensor (one lane per read: Gotoh fill + traceback in HBM, one workgroup per set: merge) gives bit-identical
+    rows to nc_star_msa, and its tensors / consensus equal the rows -> tensor kernel on those rows; ragged sets, empty sets,
+    reads longer and shorter than the window, sets that differ in window length"""
+    from nanocaller_amd.engine import get_engine
+    eng = get_engine(0)
+    rng = np.random.Generator(np.random.PCG64(909))
+    sets, refs = [], []
+    for s in range(40):
+        n_ref = int(rng.integers(30, 170))
+        ref = "".join("AGTC"[i] for i in rng.integers(0, 4, size=n_ref))
+        reads = []
+        for r in range(int(rng.integers(0, 24)) if s % 7 else 0):
+            indels = [(int(rng.integers(2, n_ref - 8)), int(rng.choice([-9, -3, -1, 1, 2, 5, 12]))) for _ in range(int(rng.integers(0, 3)))]
+            indels = [(p, l) for k, (p, l) in enumerate(indels) if all(abs(p - p2) > 14 for p2, _ in indels[:k])]
+            q = _mutate(rng, ref, int(rng.integers(0, 6)), indels)
+            cut = int(rng.integers(max(5, len(q) - 20), len(q) + 1))
+            reads.append(q[:cut] + ("ACGTTGCA"[:int(rng.integers(0, 8))] if r % 5 == 0 else ""))
+        sets.append(reads)
+        refs.append(ref)
+    x, cns, ncols, rows, rrs = eng.star_msa_tensor(sets, refs, want_rows=True)
+    sym = "AGTC-N"
+    n_checked = 0
+    for s in range(len(sets)):
+        hrows, hrr = gip.star_aligner(["r%d" % k for k in range(len(sets[s]))], sets[s], refs[s])
+        assert "".join(sym[c] for c in rrs[s]) == hrr, s
+        assert ["".join(sym[c] for c in row) for row in rows[s]] == hrows, s
+        assert int(ncols[s]) == len(hrr)
+        n_checked += len(hrows)
+    assert n_checked > 300
+    # tensors and consensus: the K8 kernel on the host-built rows of the non-empty sets
+    keep = [s for s in range(len(sets)) if sets[s]]
+    x2, cns2 = eng.indel_tensor([rows[s] for s in keep], [rrs[s] for s in keep])
+    assert torch_equal(x[keep], x2)
+    for k, s in enumerate(keep):
+        assert np.array_equal(cns[s], cns2[k])
+
+
+def torch_equal(a, b):
+    import torch
+    return bool(torch.equal(a, b))

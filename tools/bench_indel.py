@@ -28,6 +28,35 @@ for rep in range(2):
     cols = eng.indel_scan_batch(dp, chunks, mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6)
     dt = time.perf_counter() - t
 print("K7 batched (nc_indel_scan_batch, chunk = grid dimension): %.1f ms -> %.1f M columns/s (%d flagged)" % (dt * 1e3, L / dt / 1e6, sum(int((c >= 0).sum()) for c in cols)))
+# ---- n4: star alignment of read sets to their reference windows (device, one call) vs the host statement (per set)
+from nanocaller_amd import generate_indel_pileups as gip
+rng = np.random.Generator(np.random.PCG64(4))
+def _reads(ref, n):
+    out = []
+    for _ in range(n):
+        q = list(ref)
+        for p in rng.choice(len(q), size=6, replace=False):
+            q[p] = "AGTC"[int(rng.integers(0, 4))]
+        p = int(rng.integers(10, 140)); ln = int(rng.choice([-5, -2, -1, 1, 2, 4]))
+        if ln > 0: q[p:p] = list("AGTC"[int(rng.integers(0, 4))] * ln)
+        else: del q[p:p - ln]
+        out.append("".join(q)[:160])
+    return out
+NS = 3072                                                       # 1,024 anchors x (hap0, hap1, all reads)
+refs = ["".join("AGTC"[i] for i in rng.integers(0, 4, size=161)) for _ in range(NS)]
+sets = [_reads(refs[s], 30 if s % 3 == 2 else 15) for s in range(NS)]
+eng.star_msa_tensor(sets[:30], refs[:30])
+torch.cuda.synchronize(); t = time.perf_counter()
+x, cns, ncols = eng.star_msa_tensor(sets, refs)
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+n_al = sum(len(r) for r in sets)
+print("n4 device star alignment + tensors: %d read sets (%d alignments of 160 x 161): %.1f ms -> %.0f sets/s, %.2f M alignments/s, %.1f G DP cells/s (incl. host marshalling)"
+      % (NS, n_al, dt * 1e3, NS / dt, n_al / dt / 1e6, n_al * 160 * 161 / dt / 1e9))
+t = time.perf_counter()
+for s in range(0, 96):
+    gip.star_aligner(None, sets[s], refs[s])
+dt = (time.perf_counter() - t) / 96
+print("   host star aligner (nc_star_msa, all usable cores): %.2f ms per set -> %.0f sets/s" % (dt * 1e3, 1 / dt))
 # ---- K8
 rng = np.random.Generator(np.random.PCG64(1))
 S = 4096
