@@ -284,6 +284,8 @@ def msa(seq_list, ref, v_pos, mincov, maxcov, aligner=None, device=0):
     if len(sample) > maxcov:
         sample = random.sample(sample, min(len(sample), maxcov))
     sample = sorted(sample)
+    if aligner == "device":
+        aligner = star_aligner                                      # one set at a time: the host statement (identical rows)
     rows, ref_row = (aligner or default_aligner())(sample, [seq_list[n] for n in sample], ref)
     if len(rows) < mincov or ref_row is None:
         return (0, 0, None, None, None)

@@ -1,9 +1,10 @@
-"""Host-side mirror of the reference's indel caller rules (nanocaller_src/indelCaller.py:59-179).
+"""Host-side mirror of the reference's indel caller (nanocaller_src/indelCaller.py:41-189).
 
 `indel_vcf_lines` / `indel_vcf_lines_haploid` restate the allele / genotype rules and VCF text of `indel_run`;
-the CNN they consume is `Indel_model` / `haploid_Indel_model` (nc_indel_forward) and the (5,128,2) tensors come
-from nc_indel_tensor.  Candidate detection, read slicing, MUSCLE and parasail stay on the host side of the
-boundary; phasing and the bcftools/rtg merge are out of scope.
+`indel_run` is the worker loop itself: per chunk the candidates, tensors and allele strings of
+generate_indel_pileups.get_indel_testing_candidates[_haploid] (window scan K7, star alignment on the device or MUSCLE, rows ->
+tensor K8, allele_prediction), `Indel_model` / `haploid_Indel_model` on the GPU (nc_indel_forward, K9), then the rules.
+Phasing (WhatsHap) and the bcftools/rtg merge of the SNP and indel files are out of scope.
 
 Arithmetic note: in the reference `batch_prob_all` is a float32 TensorFlow tensor, so QUAL/GQ are evaluated in
 float32 (`1e-6 + 1 - p` etc.); that is reproduced with explicit np.float32 operations.
@@ -95,3 +96,64 @@ INDEL_VCF_HEADER = (                                                 # indelCall
     '##FORMAT=<ID=GQ,Number=1,Type=Float,Description="Genotype Probability">\n'
     '##FORMAT=<ID=PS,Number=1,Type=Integer,Description="Phase set identifier">\n'
     '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample}\n')
+
+
+def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, worker_id=1, aligner=None):
+    """Worker with the reference's signature (indelCaller.py:41-189): drains ('indel', chunk) jobs from `job_Q`, writes
+    <intermediate_indel_files_dir>/<prefix>.<worker>.indel.vcf.  Per chunk: candidates + tensors + allele strings
+    (generate_indel_pileups.get_indel_testing_candidates[_haploid]: window scan, star alignment / MUSCLE, K8), the indel CNN on
+    the GPU for the whole chunk (the reference feeds batches of 100; the per-site probabilities do not depend on the batching),
+    then the genotype rules in batches of 100 with `prev` carried through the chunk."""
+    import os
+    import queue
+    import sys
+
+    import torch
+
+    from . import _lib
+    from .engine import get_engine
+    from .generate_indel_pileups import get_indel_testing_candidates, get_indel_testing_candidates_haploid
+    from .weights import Weights
+    curr_vcf_path = os.path.join(params['intermediate_indel_files_dir'], '%s.%d.indel.vcf' % (params['prefix'], worker_id))
+    indel_files_list.append(curr_vcf_path)
+    model_path = get_indel_model(params['indel_model'])
+    if model_path is None:
+        print('Invalid indel model name or path', flush=True)          # indelCaller.py:47-49
+        sys.exit(1)
+    eng = get_engine(device)
+    eng.use_torch_stream()
+    eng.load_weights(_lib.MODEL_INDEL, Weights(model_path))
+    eng.load_weights(_lib.MODEL_INDEL_HAP, Weights(get_indel_model('haploid')))
+    batch_size = 100
+    with open(curr_vcf_path, 'w') as f:
+        while len(indel_dict) > 0 or not job_Q.empty():
+            try:
+                job = job_Q.get(block=False)
+            except queue.Empty:
+                if len(indel_dict) > 0:
+                    continue
+                break
+            chunk = job[1]
+            chrom = chunk['chrom']
+            if chunk['ploidy'] == 'diploid':
+                pos, x0, x1, x2, alleles_seq, phase = get_indel_testing_candidates(params, chunk, aligner=aligner, device=device)
+                if len(pos) != 0:
+                    x_all = np.hstack([x0, x1, x2]).astype(np.float32)                       # :82 -> (n, 15, 128, 2)
+                    probs = eng.indel_forward(_lib.MODEL_INDEL, torch.from_numpy(np.ascontiguousarray(x_all)).to(eng.device)).cpu().numpy()
+                    prev = 0
+                    for b in range(0, len(pos), batch_size):
+                        lines, prev = indel_vcf_lines(chrom, pos[b:b + batch_size], probs[b:b + batch_size], alleles_seq[b:b + batch_size],
+                                                      phase[b:b + batch_size], prev)
+                        f.writelines(lines)
+            elif chunk['ploidy'] == 'haploid':
+                pos, x, alleles_seq = get_indel_testing_candidates_haploid(params, chunk, aligner=aligner, device=device)
+                if len(pos) != 0:
+                    probs = eng.indel_forward(_lib.MODEL_INDEL_HAP, torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(eng.device)).cpu().numpy()
+                    prev = 0
+                    for b in range(0, len(pos), batch_size):
+                        lines, prev = indel_vcf_lines_haploid(chrom, pos[b:b + batch_size], probs[b:b + batch_size], alleles_seq[b:b + batch_size], prev)
+                        f.writelines(lines)
+            f.flush()
+            os.fsync(f.fileno())
+            counter_Q.put(1)
+    return curr_vcf_path

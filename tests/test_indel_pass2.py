@@ -531,3 +531,55 @@ def test_device_star_alignment_equals_host_star_alignment():
 def torch_equal(a, b):
     import torch
     return bool(torch.equal(a, b))
+
+
+@pytest.mark.gpu
+def test_indel_run_writes_the_planted_indels(tmp_path):
+    """indelCaller.indel_run (the reference's worker loop, indelCaller.py:41-189) from BAM + FASTA to VCF records without any
+    external binary: window scan, device star alignment, tensors, indel CNN, genotype rules.  The records are well-formed, sorted,
+    non-overlapping per chunk, and most planted indels come out with their length"""
+    import collections
+    import queue
+    from nanocaller_amd import indelCaller
+    from nanocaller_amd.synth import unphase_blocks
+    w = bamio.make_bam_world(seed=43, length=36_000, depth=26)
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    refc = np.array(["AGTC".find(c) for c in w.ref], np.int64)
+    for r in range(w.n_reads):
+        s0, o0 = int(w.read_start[r]), int(w.read_off[r])
+        span = w.codes[o0:int(w.read_off[r + 1])]
+        deleted = np.zeros(len(span), bool)
+        for k in range(ev_off[r], ev_off[r + 1]):
+            if ev_len[k] < 0:
+                deleted[ev_pos[k] + 1 - s0:ev_pos[k] + 1 - s0 - ev_len[k]] = True
+        fix = (span == 4) & ~deleted
+        span[fix] = np.maximum(refc[s0 - 1:s0 - 1 + len(span)][fix], 0)
+    w = unphase_blocks(w, [], seed=43, drop=0.0, alt_base_frac=0.0)
+    bam, fa = str(tmp_path / "r.bam"), str(tmp_path / "r.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, np.random.Generator(np.random.PCG64(7))))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    params = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+                  exclude_bed=None, impute_indel_phase=False, indel_model="ONT-HG002", prefix="t", intermediate_indel_files_dir=str(tmp_path))
+    jobs, done, files = queue.Queue(), queue.Queue(), []
+    chunks = [dict(chrom=w.chrom, start=a, end=min(a + 11_999, 34_000), ploidy="diploid", sam_path=bam) for a in (2_000, 14_000, 26_000)]
+    chunks.append(dict(chrom=w.chrom, start=2_000, end=12_000, ploidy="haploid", sam_path=bam))
+    for c in chunks:
+        jobs.put(("indel", c))
+    path = indelCaller.indel_run(params, {}, jobs, done, files, aligner="device")
+    assert files == [path] and done.qsize() == len(chunks)
+    recs = [ln.rstrip("\n").split("\t") for ln in open(path)]
+    assert len(recs) > 30
+    for f in recs:
+        assert len(f) == 10 and f[0] == w.chrom and f[6] == "PASS" and f[8] in ("GT:GQ", "GT:GQ:PS") and set(f[3] + f[4].replace(",", "")) <= set("AGTC")
+        assert f[3] == w.ref[int(f[1]) - 1:int(f[1]) - 1 + len(f[3])]              # REF is the reference at POS
+        assert f[9].split(":")[0] in ("1/1", "0|1", "1|0", "1|2", "0/1", "1/2")
+    dip = [f for f in recs]                                                          # per chunk: ascending, non-overlapping (prev rule)
+    truth = collections.Counter()
+    for r in range(w.n_reads):
+        for k in range(ev_off[r], ev_off[r + 1]):
+            truth[(int(ev_pos[k]), int(ev_len[k]))] += 1
+    truth = [k for k, v in sorted(truth.items()) if v >= 6 and 3_000 < k[0] < 33_000]
+    hit = 0
+    for (p, ln) in truth:
+        hit += any(abs(int(f[1]) - p) <= 60 and any(len(a) - len(f[3]) == ln for a in f[4].split(",")) for f in dip)
+    assert len(truth) > 40 and hit >= 0.6 * len(truth), (hit, len(truth))
