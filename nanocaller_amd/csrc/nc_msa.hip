@@ -247,7 +247,9 @@ extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads
     NC_TRY(up(ctx->msa_ref_off, ref_off, ((size_t)n_sets + 1) * 4));
     // ---- groups of whole sets, at most GROUP alignments each (bounds the traceback matrix: (N1+1) * W bytes per alignment)
     const int64_t per_al = (int64_t)(N1 + 1) * W;
-    int32_t GROUP = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(64, ((int64_t)3 << 30) / std::max<int64_t>(per_al, 1)));
+    // one lane per read is latency-bound until every SIMD holds several waves: up to 512 k alignments (8 waves per SIMD) and
+    // 16 GB of traceback bytes per launch
+    int32_t GROUP = (int32_t)std::min<int64_t>(524288, std::max<int64_t>(64, ((int64_t)16 << 30) / std::max<int64_t>(per_al, 1)));
     GROUP &= ~63;
     std::vector<int32_t> n_cols((size_t)n_sets);
     std::vector<int64_t> row_off((size_t)n_sets + 1, 0), refrow_off((size_t)n_sets + 1, 0);

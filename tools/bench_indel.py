@@ -52,6 +52,12 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t
 n_al = sum(len(r) for r in sets)
 print("n4 device star alignment + tensors: %d read sets (%d alignments of 160 x 161): %.1f ms -> %.0f sets/s, %.2f M alignments/s, %.1f G DP cells/s (incl. host marshalling)"
       % (NS, n_al, dt * 1e3, NS / dt, n_al / dt / 1e6, n_al * 160 * 161 / dt / 1e9))
+big_sets, big_refs = sets * 6, refs * 6                          # a contig's worth of anchors in one call: several waves per SIMD
+torch.cuda.synchronize(); t = time.perf_counter()
+eng.star_msa_tensor(big_sets, big_refs)
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+print("   %d read sets (%d alignments) in one call: %.1f ms -> %.0f sets/s, %.2f M alignments/s, %.1f G DP cells/s"
+      % (len(big_sets), 6 * n_al, dt * 1e3, len(big_sets) / dt, 6 * n_al / dt / 1e6, 6 * n_al * 160 * 161 / dt / 1e9))
 t = time.perf_counter()
 for s in range(0, 96):
     gip.star_aligner(None, sets[s], refs[s])
