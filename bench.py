@@ -227,7 +227,7 @@ def main():
         n_launch = max(1.0, stage_ms[4])
         trunk_tflops = TRUNK_FLOP_PER_SITE * n_sites / (stage_ms[3] * 1e-3) / 1e12 if stage_ms[3] > 0 else 0.0
         scan_bytes = info["pileup_entries"] + L               # (d+1) B/column, SURVEY.md 8d
-        feat_bytes = 5403 * n_sites
+        feat_bytes = (5403 - 2050) * n_sites                  # SURVEY.md 8d's 5,403 B/site with the tensor written as int16 (2,050 B) instead of fp32
         common = {"achieved": trunk_tflops, "unit": "TFLOP/s", "traffic": TRUNK_TRAFFIC_PER_SITE * n_sites / n_launch,
                   "traffic_note": "HBM bytes per launch from committed PMC passes (profiles/), not re-measured in this run",
                   "launches_per_step": n_launch, "avg_launch_ms": float(stage_ms[3] / n_launch),
@@ -251,7 +251,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if exact_fp32 else "f32 (f16x3 split MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx %s, chr20-sized contig (%d bp, %d chunks of 500 kb) per GPU"
                        % (args.tech.upper(), args.depth, args.ploidy, L, len(chunks)), "sites_per_gpu": n_sites,
-                       "pileup_entries_per_gpu": info["pileup_entries"], "snp_weights": args.model, "generator": "synth_v1 seed 812+rank",
+                       "pileup_entries_per_gpu": info["pileup_entries"], "snp_weights": args.model, "tensor_format": "int16 between featuriser and CNN (exact; fp32 with --cnn-precision fp32)", "generator": "synth_v1 seed 812+rank",
                        "data_gen_s": round(t_gen, 2)},
             "roofline": roofline,
             "three_numbers": {"kernels_only_sites_s": n_sites / ((stage_ms[0] + stage_ms[1] + stage_ms[2]) * 1e-3),

@@ -193,6 +193,11 @@ int nc_load_weights(nc_ctx *ctx, int32_t model_kind, const float *blob_host, siz
  * operand as hi + lo halves, hi*hi + hi*lo + lo*hi with fp32 accumulation: fp32-rounding-level error, measured
  * max |dp| ~1e-6); 1 = exact fp32 MFMA (bit-for-bit an fmaf chain). */
 int nc_set_cnn_precision(nc_ctx *ctx, int exact_fp32);
+/* Format of the SNP tensors between nc_snp_featurize and nc_snp_forward: 0 (default) = float32 [n][5][41][5], the reference's
+ * array; 1 = int16 with the same shape -- every entry is a small integer (a count of at most maxcov <= 1024 reads, +-, or a
+ * 0/1 flag), so the conversion is exact, and the 4,100 B per site that the featuriser writes and the CNN reads become 2,050.
+ * x_dev of both calls is then an int16 buffer.  Only the split-precision trunk reads it (not nc_set_cnn_precision(ctx, 1)). */
+int nc_set_tensor_format(nc_ctx *ctx, int fmt);
 int nc_snp_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev,
                    const double *scale_dev, int32_t scale_mode, float *probs_dev, float *gt_dev);
 

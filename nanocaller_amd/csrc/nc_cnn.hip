@@ -866,6 +866,7 @@ __device__ unsigned long long nc_trace_buf[8][8][8];     // [wave][site k in 8..
 #else
 #define NC_T(ev)
 #endif
+template <bool X16>                                             // X16: the site tensors are int16 (nc_set_tensor_format(ctx, 1))
 __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
                                                    int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
 {
@@ -895,9 +896,15 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         float pre[5];
         double pre_sd = 1.0;
         auto prefetch = [&](int64_t site) {
-            const float *xs = x + site * NC_SNP_TENSOR + px * 5;
+            if constexpr (X16) {
+                const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;
 #pragma unroll
-            for (int u = 0; u < 5; u++) pre[u] = xs[u];
+                for (int u = 0; u < 5; u++) pre[u] = (float)xs[u];
+            } else {
+                const float *xs = x + site * NC_SNP_TENSOR + px * 5;
+#pragma unroll
+                for (int u = 0; u < 5; u++) pre[u] = xs[u];
+            }
             if (scale) pre_sd = scale[site0 + site];                                  // consumed in commit(): no wait here
         };
         auto commit = [&](int buf) {
@@ -1345,7 +1352,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         if (ctx->cnn_exact_fp32)
             hipExtLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, ev0, ev1, 0, x_batch, packed, a3, nb, scale, scale_mode, site0);
         else
-            hipExtLaunchKernelGGL(k5_trunk_h3, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
+            if (ctx->x_i16)
+                hipExtLaunchKernelGGL(k5_trunk_h3<true>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
+            else
+                hipExtLaunchKernelGGL(k5_trunk_h3<false>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
         if (ctx->cnn_exact_fp32)
             hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
         else
@@ -1563,6 +1573,7 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
     if (!ctx->w[kind].dev) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_forward: weights of kind %d not loaded", kind);
     if (n < 0 || (n && (!x_dev || !ref_code_dev || !probs_dev))) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: null argument");
     if (scale_mode != 0 && scale_mode != 1) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_forward: scale_mode");
+    if (ctx->x_i16 && ctx->cnn_exact_fp32) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_forward: int16 tensors are read by the split-precision trunk only");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     NcTimer tm(ctx, 2);
     if (ctx->timing) nc_timing_resolve(ctx, 4);   // fold an earlier call's per-launch events in before they are re-used
@@ -1574,7 +1585,7 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
-        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, ctx->w[kind].packed, (const uint8_t *)ctx->w[kind].packed_h, s0, nb, x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
+        NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, ctx->w[kind].packed, (const uint8_t *)ctx->w[kind].packed_h, s0, nb, ctx->x_i16 ? (const float *)((const int16_t *)x_dev + s0 * NC_SNP_TENSOR) : x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
                                                           &f1, &tail)));
         if (kind == NC_MODEL_SNP)
             hipLaunchKernelGGL(k_snp_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, ref_code_dev + s0, nb,

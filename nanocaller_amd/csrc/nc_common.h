@@ -28,6 +28,7 @@ struct nc_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     int timing = 0;                           // 0 off; 1 stage timers + trunk launches; 2 trunk launches only (events on the dispatch packets, no barrier packets)
+    bool x_i16 = false;            // SNP tensors between featuriser and CNN as int16 instead of fp32 (nc_set_tensor_format)
     bool cnn_exact_fp32 = false;   // false: fp16x3 split-precision trunk (default); true: exact fp32 MFMA trunk
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches

@@ -139,6 +139,13 @@ int nc_set_cnn_precision(nc_ctx *ctx, int exact_fp32)
     return NC_OK;
 }
 
+int nc_set_tensor_format(nc_ctx *ctx, int fmt)
+{
+    if (!ctx || (fmt != 0 && fmt != 1)) return NC_ERR_ARG;
+    ctx->x_i16 = fmt == 1;
+    return NC_OK;
+}
+
 int nc_enable_timing(nc_ctx *ctx, int on)
 {
     if (!ctx) return NC_ERR_ARG;

@@ -72,6 +72,7 @@ struct FeatArgs {
     float *x;
     int32_t *ref_out, *fwd, *rev, *depth;
     uint8_t *valid;
+    int32_t x_i16;                 // 1: the tensors leave as int16 (every entry is a small integer: exact), half the bytes
 };
 
 template <int CAP>
@@ -266,6 +267,22 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     // coalesced store of up to four site tensors
     const int s0 = blk * 4;
     const int nsite = min(4, a.n_sites - s0);
+    if (a.x_i16) {
+        // 4,100 int16 of up to four sites; 16-byte stores of 8 values (4 * 1025 = 512.5 groups of 8: the tail is scalar)
+        int16_t *d16 = reinterpret_cast<int16_t *>(a.x) + (int64_t)s0 * NC_SNP_TENSOR;
+        const int total = nsite * NC_SNP_TENSOR;
+        for (int i = threadIdx.x * 8; i < total; i += 256 * 8) {
+            if (i + 8 <= total) {
+                union { int16_t h[8]; uint4 u; } o;
+#pragma unroll
+                for (int q = 0; q < 8; q++) o.h[q] = (int16_t)sm[(i + q) / NC_SNP_TENSOR][(i + q) % NC_SNP_TENSOR];
+                *reinterpret_cast<uint4 *>(d16 + i) = o.u;
+            } else {
+                for (int q = i; q < total; q++) d16[q] = (int16_t)sm[q / NC_SNP_TENSOR][q % NC_SNP_TENSOR];
+            }
+        }
+        return;
+    }
     float *dst = a.x + (int64_t)s0 * NC_SNP_TENSOR;
     if (nsite == 4) {
         float4 *d4 = reinterpret_cast<float4 *>(dst);
@@ -372,6 +389,7 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     a.rev = rev_dp_dev;
     a.depth = site_depth_dev;
     a.valid = valid_dev;
+    a.x_i16 = ctx->x_i16 ? 1 : 0;
     NcTimer tm(ctx, 1);
     hipLaunchKernelGGL(k_nbr_index, dim3((n_cidx + 255) / 256), dim3(256), 0, ctx->stream, a.nbr_pos, a.n_nbr, a.cidx_pos0, n_cidx,
                        (int32_t *)ctx->nbr_idx.p);

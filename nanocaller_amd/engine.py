@@ -129,6 +129,13 @@ class Engine:
     def set_cnn_precision(self, exact_fp32: bool):
         """False (default): fp16x3 split-precision trunk; True: exact fp32 MFMA trunk."""
         self._check(self.L.nc_set_cnn_precision(self.ctx, 1 if exact_fp32 else 0), "nc_set_cnn_precision")
+        self.exact_fp32 = bool(exact_fp32)
+
+    def set_tensor_format(self, int16: bool):
+        """SNP tensors between snp_featurize and snp_forward as int16 (exact: every entry is a small integer; half the
+        bytes) instead of the reference's float32.  Read by the split-precision trunk only."""
+        self._check(self.L.nc_set_tensor_format(self.ctx, 1 if int16 else 0), "nc_set_tensor_format")
+        self.x_int16 = bool(int16)
 
     def enable_timing(self, on=True, trunk_only=False):
         """HIP-event timers: all stages, or (trunk_only) just the trunk kernel's launches, whose events ride on the
@@ -207,7 +214,7 @@ class Engine:
     def snp_featurize(self, dp: DevicePack, sites: SnpSites, *, seq, maxcov, min_nbr_sites=1) -> SnpSites:
         N = sites.n_sites
         dev = self.device
-        sites.x = torch.empty((N, 5, 41, 5), dtype=torch.float32, device=dev)
+        sites.x = torch.empty((N, 5, 41, 5), dtype=torch.int16 if getattr(self, "x_int16", False) else torch.float32, device=dev)
         sites.ref_code = torch.empty(N, dtype=torch.int32, device=dev)
         sites.fwd_dp = torch.empty((N, 4), dtype=torch.int32, device=dev)
         sites.rev_dp = torch.empty((N, 4), dtype=torch.int32, device=dev)

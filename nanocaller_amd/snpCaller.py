@@ -219,6 +219,9 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     if sites.n_sites == 0:
         eng.wait_copies()
         return PendingCall(lambda: res) if defer else res
+    # the tensors stay on the device: int16 between featuriser and CNN (exact, half the HBM traffic) unless the exact-fp32
+    # trunk, which reads the reference's float32 layout, has been selected
+    eng.set_tensor_format(int16=not getattr(eng, "exact_fp32", False))
     eng.snp_featurize(dpk, sites, seq=params['seq'], maxcov=params['maxcov'], min_nbr_sites=params['min_nbr_sites'])
     all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
     per_site = bool(params.get('disable_coverage_normalization'))
@@ -227,6 +230,7 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     # enqueued after the (short, latency-sensitive) scale kernel so that these copies run under the CNN, not beside it
     h_ref, h_fwd, h_rev, h_valid = eng.to_host_async([sites.ref_code, sites.fwd_dp, sites.rev_dp, None if all_valid else sites.valid])
     d_probs, d_gt, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True)
+    eng.set_tensor_format(int16=False)                             # the direct API keeps the reference's float32 default
     drained = eng.copy_event()                                     # completes with this call's last result copy
     # host work that only needs the scan results runs under the CNN: freq = alt / n in float64 (:166)
     scan_copied.synchronize()

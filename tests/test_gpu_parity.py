@@ -324,6 +324,35 @@ def test_end_to_end_vcf_matches_oracle_pipeline(eng, tmp_path):
     assert ngt > 10
 
 
+def test_int16_tensors_equal_float32_tensors(eng):
+    """nc_set_tensor_format(ctx, 1): the featuriser's int16 tensors are the float32 tensors value for value, and the
+    split-precision trunk returns bit-identical probabilities from either; the exact-fp32 trunk refuses int16"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.pack import pack_world
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    world = load_world("ont")
+    dp = eng.upload(pack_world(world))
+    path, cov = get_SNP_model("ONT-HG002")
+    eng.load_weights(_lib.MODEL_SNP, Weights(path))
+    out = {}
+    for i16 in (False, True):
+        eng.set_tensor_format(int16=i16)
+        sites = eng.snp_scan(dp, [(20_000, 60_000), (60_001, 100_003)], mincov=4, min_allele_freq=0.15, threshold=[0.4, 0.6])
+        eng.snp_featurize(dp, sites, seq="ont", maxcov=160)
+        scale, _ = eng.snp_scale(sites, 2, cov)
+        probs, gt = eng.snp_forward(_lib.MODEL_SNP, sites.x, sites.ref_code, scale)
+        out[i16] = (sites.x.clone(), probs.clone(), gt.clone(), sites.n_sites)
+    assert out[True][0].dtype == torch.int16 and out[False][0].dtype == torch.float32 and out[True][3] == out[False][3] > 300
+    assert torch.equal(out[True][0].to(torch.float32), out[False][0])
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+    eng.set_cnn_precision(exact_fp32=True)
+    with pytest.raises(Exception):
+        eng.snp_forward(_lib.MODEL_SNP, out[True][0], sites.ref_code, scale)
+    eng.set_cnn_precision(exact_fp32=False)
+    eng.set_tensor_format(int16=False)
+
+
 def test_deferred_calls_equal_drained_calls(eng):
     """call_chunks(defer=True): several groups enqueued back to back (the next group's scan queued behind the previous
     group's CNN, results collected afterwards, in any order) give bit-identical arrays to one drained call per group;
