@@ -11,6 +11,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <thread>
 
 #include "nc_host.h"
@@ -104,28 +105,52 @@ extern "C" int nc_snp_vcf_format(const char *chrom, int64_t n, const int32_t *po
     int T = host_threads();
     if (n < 20000 || cap < n * per) T = 1;
     if (T == 1) return format_range(chrom, n, pos, ref, probs, order, dp, freq, fwd, rev, haploid, out, cap, n_bytes);
-    std::vector<int64_t> nb((size_t)T, 0);
+    // Two parallel phases: every thread formats its range of sites into its slice of `out` (400-byte budget per record),
+    // then -- once all lengths are known -- the slices are closed up.  Slice t moves left to its final place only after the
+    // slices whose bytes it would overwrite have moved (a slice depends on earlier slices only), so the compaction runs in
+    // parallel as well instead of as one 70 MB memmove.
+    std::vector<int64_t> nb((size_t)T, 0), src((size_t)T, 0), dst((size_t)T + 1, 0);
     std::vector<int> rc((size_t)T, NC_OK);
-    std::vector<std::thread> th;
     const int64_t chunk = (n + T - 1) / T;
-    for (int t = 0; t < T; t++) {
-        const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
-        if (a >= b) break;
-        th.emplace_back([=, &nb, &rc]() {
-            rc[(size_t)t] = format_range(chrom, b - a, pos + a, ref + a, probs + 4 * a, order ? order + 4 * a : nullptr, dp + a, freq + a,
-                                         fwd ? fwd + 4 * a : nullptr, rev ? rev + 4 * a : nullptr, haploid, out + a * per, (b - a) * per,
-                                         &nb[(size_t)t]);
-        });
+    int used = 0;
+    for (int t = 0; t < T; t++) if ((int64_t)t * chunk < n) used = t + 1;
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < used; t++) {
+            const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
+            src[(size_t)t] = a * per;
+            th.emplace_back([=, &nb, &rc]() {
+                rc[(size_t)t] = format_range(chrom, b - a, pos + a, ref + a, probs + 4 * a, order ? order + 4 * a : nullptr, dp + a, freq + a,
+                                             fwd ? fwd + 4 * a : nullptr, rev ? rev + 4 * a : nullptr, haploid, out + a * per, (b - a) * per,
+                                             &nb[(size_t)t]);
+            });
+        }
+        for (auto &x : th) x.join();
     }
-    for (auto &x : th) x.join();
-    int64_t w = 0;
-    for (size_t t = 0; t < th.size(); t++) {
-        if (rc[t] != NC_OK) return rc[t];
-        const int64_t a = (int64_t)t * chunk;
-        if (w != a * per) memmove(out + w, out + a * per, (size_t)nb[t]);
-        w += nb[t];
+    for (int t = 0; t < used; t++) {
+        if (rc[(size_t)t] != NC_OK) return rc[(size_t)t];
+        dst[(size_t)t + 1] = dst[(size_t)t] + nb[(size_t)t];
     }
-    *n_bytes = w;
+    {
+        // moved[t] = 1 once slice t sits at dst[t].  Slice t's destination [dst[t], dst[t] + nb[t]) may overlap the SOURCE of
+        // earlier slices s < t only (dst[t] <= src[t]); it waits for exactly those.
+        std::vector<std::atomic<int>> moved((size_t)used);
+        for (auto &m : moved) m.store(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < used; t++)
+            th.emplace_back([&, t]() {
+                const int64_t d0 = dst[(size_t)t], d1 = d0 + nb[(size_t)t];
+                for (int s2 = t - 1; s2 >= 0; s2--) {
+                    const int64_t s0 = src[(size_t)s2], s1 = s0 + nb[(size_t)s2];
+                    if (s1 <= d0) break;                                // earlier slices lie further left still
+                    if (s0 < d1) while (moved[(size_t)s2].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+                }
+                if (d0 != src[(size_t)t] && nb[(size_t)t]) memmove(out + d0, out + src[(size_t)t], (size_t)nb[(size_t)t]);
+                moved[(size_t)t].store(1, std::memory_order_release);
+            });
+        for (auto &x : th) x.join();
+    }
+    *n_bytes = dst[(size_t)used];
     return NC_OK;
 }
 
