@@ -346,6 +346,9 @@ int nc_nw_cigar(const char *s1, int32_t n1, const char *s2, int32_t n2, int32_t 
  * reference returns (None, None). */
 int nc_allele_prediction(const char *alt, int32_t n_alt, const char *ref_seq, int32_t n_ref, int32_t max_range, int32_t *ref_len,
                          int32_t *alt_len);
+/* the same for n independent (alt, ref) pairs, on the usable host cores: alt i = alts[alt_off[i] .. alt_off[i+1]), ref i likewise */
+int nc_allele_prediction_batch(int32_t n, const char *alts, const int32_t *alt_off, const char *refs, const int32_t *ref_off,
+                               const int32_t *max_range, int32_t *ref_len, int32_t *alt_len);
 
 /* Star alignment of a read set to its reference window: replaces the MUSCLE subprocess of
  * generate_indel_pileups.py:24-44 with pairwise Gotoh alignments (anchored at the window start, free tail; scoring as above)

@@ -213,3 +213,31 @@ extern "C" int nc_star_msa(int32_t n_reads, const char *reads, const int32_t *re
     }
     return NC_OK;
 }
+
+
+// nc_allele_prediction for many (consensus, reference window) pairs at once, on the usable host cores (the three calls per
+// indel anchor are independent).  alt i = alts[alt_off[i] .. alt_off[i+1]), ref i likewise.
+extern "C" int nc_allele_prediction_batch(int32_t n, const char *alts, const int32_t *alt_off, const char *refs, const int32_t *ref_off,
+                                          const int32_t *max_range, int32_t *ref_len, int32_t *alt_len)
+{
+    if (n < 0 || (n && (!alt_off || !ref_off || !max_range || !ref_len || !alt_len))) return NC_ERR_ARG;
+    int T = nc_host_cpus();
+    if (T > 32) T = 32;
+    if (T > n / 8) T = n / 8;
+    std::vector<int> rc((size_t)(T > 0 ? T : 1), NC_OK);
+    auto work = [&](int t, int stride) {
+        for (int i = t; i < n; i += stride) {
+            const int r = nc_allele_prediction(alts + alt_off[i], alt_off[i + 1] - alt_off[i], refs + ref_off[i], ref_off[i + 1] - ref_off[i],
+                                               max_range[i], &ref_len[i], &alt_len[i]);
+            if (r != NC_OK) rc[(size_t)t] = r;
+        }
+    };
+    if (T <= 1) work(0, 1);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t, T);
+        for (auto &x : th) x.join();
+    }
+    for (int r : rc) if (r != NC_OK) return r;
+    return NC_OK;
+}

@@ -216,6 +216,24 @@ def allele_prediction(alt, ref_seq, max_range):
     return ref_seq[:rl.value], alt[:al.value]
 
 
+def allele_prediction_batch(alts, ref_seqs, max_ranges):
+    """[allele_prediction(alt, ref_seq, max_range) for ...] in one native call on the usable host cores"""
+    n = len(alts)
+    if n == 0:
+        return []
+    L = _lib.lib()
+    aoff, roff = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.int32)
+    np.cumsum([len(a) for a in alts], out=aoff[1:])
+    np.cumsum([len(r) for r in ref_seqs], out=roff[1:])
+    mr = np.ascontiguousarray(max_ranges, np.int32)
+    rl, al = np.empty(n, np.int32), np.empty(n, np.int32)
+    rc = L.nc_allele_prediction_batch(n, "".join(alts).encode(), _lib.npp(aoff), "".join(ref_seqs).encode(), _lib.npp(roff), _lib.npp(mr),
+                                      _lib.npp(rl), _lib.npp(al))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_allele_prediction_batch failed (%d)" % rc)
+    return [(None, None) if rl[i] < 0 else (ref_seqs[i][:rl[i]], alts[i][:al[i]]) for i in range(n)]
+
+
 def muscle_aligner(names, seqs, ref):
     """The reference's aligner call (:24-44): MUSCLE 3.8 as a subprocess on a FASTA of the reads (+ '_SEQ' suffix) and
     the reference row.  -> (aligned read rows in MUSCLE's output order, aligned reference row)."""
@@ -356,6 +374,9 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
     return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
 
 
+_DROP_AGTC = str.maketrans("", "", "AGTC")
+
+
 def _sample_set(seq_list, mincov, maxcov):
     """the part of msa() before the aligner (:13-23): down-sample to maxcov (unseeded, as in the reference), sort the names;
     -> (names, seqs) or None when fewer than mincov reads remain"""
@@ -375,10 +396,15 @@ def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo,
     names, hap, ps = d["names"], d["hap"], d["ps"]
     todo, sets, refs = [], [], []
     for v_pos, win in zip(anchors, d["windows"]):
-        ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
-                      for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))
-        if "N" in ref:
-            continue
+        a, b = v_pos - window_before, min(chrom_length, v_pos + window_after + 1)
+        if lo <= a and b - 1 <= hi:
+            ref = fasta[a - 1:b - 1]
+            if ref.translate(_DROP_AGTC):
+                continue                                                         # 'N' (anything but upper-case AGTC) in ref (:326)
+        else:
+            ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N") for p in range(a, b))
+            if "N" in ref:
+                continue
         d_tot, d0, d1 = {}, {}, {}
         imputed = extra_variants.get(v_pos)                                      # :310-312
         for r, text in win:
@@ -392,9 +418,9 @@ def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo,
             continue                                                             # flag0 and flag1 and flag_total (:345)
         for _, seqs in picked:
             for q in seqs:
-                for c in q:
-                    if c not in "AGTC":
-                        raise KeyError(c)                                        # as the reference's symbol table does (:56)
+                bad = q.translate(_DROP_AGTC)
+                if bad:
+                    raise KeyError(bad[0])                                       # as the reference's symbol table does (:56)
             sets.append(seqs)
             refs.append(ref)
         todo.append((v_pos, next(iter(d0.keys()))))
@@ -407,13 +433,18 @@ def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo,
     xh = x.cpu().numpy().astype(np.float64)
     sym = "AGTC"
     out_pos, x0, x1, x2, alleles, phase = [], [], [], [], [], []
+    name_row = {}
+    for i, nm in enumerate(names):
+        name_row.setdefault(nm, i)                                               # names.index(): the first occurrence
+    lut = np.frombuffer(b"AGTC", np.uint8)
+    cns_str = [lut[c].tobytes().decode() for c in cns]
+    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[v_pos]] for (v_pos, _) in todo for _i in range(3)])
     for k, (v_pos, first) in enumerate(todo):
         out_pos.append(v_pos)
         x0.append(xh[3 * k]); x1.append(xh[3 * k + 1]); x2.append(xh[3 * k + 2])
-        r = names.index(first)
+        r = name_row[first]
         phase.append(int(ps[r]) if hap[r] else None)
-        mr = max_range[variants[v_pos]]
-        alleles.append([allele_prediction("".join(sym[c] for c in cns[3 * k + i]), refs[3 * k + i], mr) for i in range(3)])
+        alleles.append([preds[3 * k], preds[3 * k + 1], preds[3 * k + 2]])
     return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
 
 

@@ -116,6 +116,21 @@ def pass2_bam(tmp_path_factory):
     return bam, recs
 
 
+def test_allele_prediction_batch_equals_single_calls():
+    rng = np.random.Generator(np.random.PCG64(12))
+    alts, refs, mrs = [], [], []
+    for k in range(300):
+        n_ref = int(rng.integers(60, 170))
+        ref = "".join("AGTC"[i] for i in rng.integers(0, 4, size=n_ref))
+        alts.append(_mutate(rng, ref, int(rng.integers(0, 4)), [(int(rng.integers(5, n_ref - 30)), int(rng.choice([-12, -3, -1, 1, 4, 15])))] if k % 4 else []))
+        refs.append(ref)
+        mrs.append(int(rng.choice([10, 40])))
+    alts.append(""); refs.append("ACGT"); mrs.append(10)
+    got = gip.allele_prediction_batch(alts, refs, mrs)
+    assert got == [gip.allele_prediction(a, r, m) for a, r, m in zip(alts, refs, mrs)]
+    assert sum(g[0] is not None for g in got) > 150 and gip.allele_prediction_batch([], [], []) == []
+
+
 @pytest.mark.parametrize("window_before,window_after", [(0, 160), (0, 260), (7, 33)])
 def test_pass2_read_windows_match_independent_cigar_walk(pass2_bam, window_before, window_after):
     bam, recs = pass2_bam
