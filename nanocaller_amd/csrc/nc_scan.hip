@@ -49,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const uint8_t *__restrict__ code
     int e = e0;
     while (e < e1) {
         const int lim = min(e1, e + 255);
-#pragma unroll 4
+#pragma unroll 8
         for (; e < lim; e++) {
             const nc_tile_entry ent = tile_ent[e];            // wave-uniform -> scalar loads
             const int32_t lo = ent.start & ~15, hi = (ent.end + 15) & ~15;
