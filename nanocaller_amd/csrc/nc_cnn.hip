@@ -1265,7 +1265,118 @@ __global__ __launch_bounds__(256) void k8_conv23_h3(const _Float16 *__restrict__
     (void)npos_in;
 }
 
-constexpr size_t INDEL_H3_BYTES = H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES;
+// ---- conv1 of the indel models (CI = 2, three `same` kernels 1x5 / 5x1 / 5x5 with 8 filters each) on the matrix pipe, same
+// split-precision scheme.  A tap needs 6 K slots: [w_hi w_hi | w_hi w_hi | w_lo w_lo] x [x_hi(c0) x_hi(c1) | x_lo(c0) x_lo(c1) |
+// x_hi(c0) x_hi(c1)], so one kernel row of five taps is ONE v_mfma_f32_16x16x32_f16 (30 of its 32 K slots).  With a pixel kept
+// in LDS as three dwords [H, L, H] (H = its two channels' hi halves, L = the lo halves), the 32 K values of an output position are
+// 16 CONSECUTIVE dwords starting at its leftmost tap: lane (position, quarter g) reads dwords 3 x + 4 g .. + 3.  The A operand of
+// kernel row dy carries the 5x5 filters in rows 0-7 and, in rows 8-15, the 5x1 filters on its centre tap; a sixth MFMA on the
+// centre row carries the 1x5 filters: 6 MFMAs per 16 positions for all 24 channels.  One workgroup per site, rows top to
+// bottom through a five-row ring in LDS (every input row is staged once).
+constexpr int C1H_ROWPX = 134;                                  // pixels -2 .. 131 of a row (zero padded)
+constexpr size_t C1H_BYTES = 6 * 64 * 16 + 4 * 40;            // 6 A fragments, then S*bias[32] (acc35 rows 0-15, acc1 rows 0-15), 1/S
+
+template <int H>
+__global__ __launch_bounds__(256) void k2_conv1_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, void *__restrict__ out,
+                                                   int64_t n_sites, int64_t npos)
+{
+    constexpr int W = 128;
+    __shared__ uint32_t X3[5 * C1H_ROWPX * 3 + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const uint4 *wf = reinterpret_cast<const uint4 *>(wp);
+    const float *bs = reinterpret_cast<const float *>(wf + 6 * 64);
+    h8 A[6];
+#pragma unroll
+    for (int f = 0; f < 6; f++) A[f] = as_h8(wf[f * 64 + lane]);
+    const f32x4v b35 = *reinterpret_cast<const f32x4v *>(bs + 4 * g), b1 = *reinterpret_cast<const f32x4v *>(bs + 16 + 4 * g);
+    const float inv_s = bs[32];
+    _Float16 *hp0 = reinterpret_cast<_Float16 *>(out), *lp0 = hp0 + npos * 24;
+    // image row iy lives in LDS slot (iy + 5) % 5; a site is walked top to bottom, every row is staged once
+    auto stage_row = [&](int64_t site, int iy) {
+        const int slot = (iy + 5) % 5;
+        for (int p = threadIdx.x; p < C1H_ROWPX; p += 256) {
+            const int px = p - 2;
+            uint32_t Hh = 0, Ll = 0;
+            if (iy >= 0 && iy < H && px >= 0 && px < W) {
+                const float2 v = *reinterpret_cast<const float2 *>(x + ((site * H + iy) * W + px) * 2);
+                const float v0 = fminf(fmaxf(v.x, -65504.0f), 65504.0f), v1 = fminf(fmaxf(v.y, -65504.0f), 65504.0f);
+                const h2 hh = __builtin_convertvector((f32x2v){v0, v1}, h2);
+                Hh = __builtin_bit_cast(uint32_t, hh);
+                const f32x2v d = {v0 - (float)hh[0], v1 - (float)hh[1]};
+                Ll = __builtin_bit_cast(uint32_t, (h2)__builtin_convertvector(d, h2));
+            }
+            uint32_t *q = X3 + (slot * C1H_ROWPX + p) * 3;
+            q[0] = Hh; q[1] = Ll; q[2] = Hh;
+        }
+    };
+    for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
+        __syncthreads();                                              // the previous site's last row has been read
+        for (int iy = -2; iy <= 2; iy++) stage_row(site, iy);
+        for (int y = 0; y < H; y++) {
+            __syncthreads();                                          // rows y-2 .. y+2 are in LDS
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                const int x0 = 16 * (2 * wv + tt), xx = x0 + c16;
+                f32x4v acc35 = b35, acc1 = b1;
+#pragma unroll
+                for (int dy = 0; dy < 5; dy++) {
+                    const uint32_t *q = X3 + (((y + dy - 2 + 5) % 5) * C1H_ROWPX) * 3 + 3 * xx + 4 * g;
+                    const uint4 bw = make_uint4(q[0], q[1], q[2], q[3]);
+                    const h8 B = as_h8(bw);
+                    acc35 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[dy], B, acc35, 0, 0, 0);
+                    if (dy == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[5], B, acc1, 0, 0, 0);
+                }
+                const int64_t pos = (site * H + y) * W + xx;
+                auto put = [&](const f32x4v &acc, int ch0) {
+                    _Float16 hi[4], lo[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float v = fminf(fmaxf(selu(acc[r] * inv_s), -65504.0f), 65504.0f);
+                        hi[r] = (_Float16)v;
+                        lo[r] = (_Float16)(v - (float)hi[r]);
+                    }
+                    *reinterpret_cast<uint2 *>(hp0 + pos * 24 + ch0) = *reinterpret_cast<const uint2 *>(hi);
+                    *reinterpret_cast<uint2 *>(lp0 + pos * 24 + ch0) = *reinterpret_cast<const uint2 *>(lo);
+                };
+                put(acc35, g < 2 ? 16 + 4 * g : 8 + 4 * (g - 2));  // rows 0-7: 5x5 filters (channels 16-23), rows 8-15: 5x1 (8-15)
+                if (g < 2) put(acc1, 4 * g);                        // rows 0-7: 1x5 filters (channels 0-7)
+            }
+            __syncthreads();                                          // row y-2 is no longer needed: its slot takes row y+3
+            if (y + 1 < H) stage_row(site, y + 3);
+        }
+    }
+}
+
+// host: A fragments of k2_conv1_h3 from the canonical conv1 weights (k11 [5][2][8], k12 [5][2][8], k13 [25][2][8] + biases)
+inline void pack_conv1_h3(const float *w, uint8_t *dst)
+{
+    const float *k11 = w, *b11 = k11 + 5 * 2 * 8, *k12 = b11 + 8, *b12 = k12 + 5 * 2 * 8, *k13 = b12 + 8, *b13 = k13 + 25 * 2 * 8;
+    float wmax = 0.0f;
+    for (const float *q = w; q < b13 + 8; q++) wmax = std::fmax(wmax, std::fabs(*q));
+    float S = 4096.0f;
+    while (S > 1.0f && wmax * S > 16384.0f) S *= 0.5f;
+    _Float16 *fr = reinterpret_cast<_Float16 *>(dst);
+    float *bs = reinterpret_cast<float *>(dst + 6 * 64 * 16);
+    for (int f = 0; f < 6; f++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 8; j++) {
+                const int g = lane >> 4, c = lane & 15, s = 8 * g + j, t = s / 6, r = s % 6, ci = r & 1;
+                float wv = 0.0f;
+                if (s < 30) {
+                    if (f < 5) {
+                        if (c < 8) wv = k13[((f * 5 + t) * 2 + ci) * 8 + c];
+                        else if (t == 2) wv = k12[(f * 2 + ci) * 8 + (c - 8)];
+                    } else if (c < 8) wv = k11[(t * 2 + ci) * 8 + c];
+                }
+                const float sv = wv * S;
+                const _Float16 hh = (_Float16)sv, ll = (_Float16)(sv - (float)hh);
+                fr[((size_t)f * 64 + lane) * 8 + j] = r < 4 ? hh : ll;
+            }
+    for (int c = 0; c < 8; c++) { bs[c] = b13[c] * S; bs[8 + c] = b12[c] * S; bs[16 + c] = b11[c] * S; bs[24 + c] = 0.0f; }
+    bs[32] = 1.0f / S;
+}
+
+constexpr size_t INDEL_H3_BYTES = H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES + C1H_BYTES;
 
 // host: fragments of one layer (canonical weights k[6][CI][CO], bias[CO]) into `dst`
 template <int CI, int CO>
@@ -1323,8 +1434,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
     const bool indel_h3 = !MFMA && !ctx->cnn_exact_fp32 && packed_h != nullptr;
     if constexpr (!MFMA) {
         if constexpr (CI == 2 && W % 4 == 0 && C1 == 8) {
-            if (indel_h3)
-                hipLaunchKernelGGL((k2_conv1_x4<H, W, C1, true>), dim3(blocks_for(np1 / 4)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1);
+            if (indel_h3) {
+                hipLaunchKernelGGL((k2_conv1_h3<H>), dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, ctx->stream, x_batch,
+                                   packed_h + H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES, (void *)a1, nb, np1);
+            }
             else
                 hipLaunchKernelGGL((k2_conv1_x4<H, W, C1, false>), dim3(blocks_for(np1 / 4)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1);
         } else {
@@ -1548,6 +1661,7 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         std::vector<uint8_t> hp(INDEL_H3_BYTES, 0);
         pack_h3_layer<24, 32>(k2, b2, hp.data());
         pack_h3_layer<32, 48>(k3, b3, hp.data() + H3Layer<24, 32>::BYTES);
+        pack_conv1_h3(blob_host, hp.data() + H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES);
         if (!w.packed_h) {
             hipError_t e = hipMalloc(&w.packed_h, hp.size());
             if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed fp16 weights: %s", hipGetErrorString(e));
