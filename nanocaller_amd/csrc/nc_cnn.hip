@@ -1272,26 +1272,52 @@ __global__ __launch_bounds__(256) void k8_conv23_h3(const _Float16 *__restrict__
 // 16 CONSECUTIVE dwords starting at its leftmost tap: lane (position, quarter g) reads dwords 3 x + 4 g .. + 3.  The A operand of
 // kernel row dy carries the 5x5 filters in rows 0-7 and, in rows 8-15, the 5x1 filters on its centre tap; a sixth MFMA on the
 // centre row carries the 1x5 filters: 6 MFMAs per 16 positions for all 24 channels.  One workgroup per site, rows top to
-// bottom through a five-row ring in LDS (every input row is staged once).
+// bottom through a five-row ring in LDS (every input row is staged once).  The kernel that does this, k9_conv12_h3, runs conv2
+// on the rows as they appear.
 constexpr int C1H_ROWPX = 134;                                  // pixels -2 .. 131 of a row (zero padded)
 constexpr size_t C1H_BYTES = 6 * 64 * 16 + 4 * 40;            // 6 A fragments, then S*bias[32] (acc35 rows 0-15, acc1 rows 0-15), 1/S
 
+// conv1 + conv2 of one site per workgroup iteration: conv1's output rows never leave the chip -- they go, as hi / lo fp16
+// planes, into a two-row LDS ring from which conv2 (2x3 taps, stride 2 in x: output row r needs conv1 rows r and r+1) reads
+// its B operands (one ds_read_b128 of 8 channels per plane and MFMA step).  conv2's weight fragments sit in LDS as in
+// k8_conv23_h3.  Per image row y: conv1 row y -> ring; conv2 row y-1 (63 positions: one 16-position tile per wave).
+// out: conv2's activations as fp16 planes [site][H-1][63][32] (lo plane = hi plane + npos2 * 32).
 template <int H>
-__global__ __launch_bounds__(256) void k2_conv1_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, void *__restrict__ out,
-                                                   int64_t n_sites, int64_t npos)
+__global__ __launch_bounds__(256) void k9_conv12_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp1, const uint8_t *__restrict__ wp2,
+                                                    void *__restrict__ out, int64_t n_sites, int64_t npos2)
 {
-    constexpr int W = 128;
+    constexpr int W = 128, HO = H - 1, WO = 63, C1C = 24, CO = 32;
+    typedef H3Layer<24, 32> LY;
+    constexpr int NG = LY::NG, TN = LY::TN;
     __shared__ uint32_t X3[5 * C1H_ROWPX * 3 + 4];
+    __shared__ __attribute__((aligned(16))) _Float16 A1H[2 * W * C1C], A1L[2 * W * C1C];      // conv1 rows (slot = row & 1): hi / lo planes
+    __shared__ uint4 wfh[NG * TN * 64], wfl[NG * TN * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
-    const uint4 *wf = reinterpret_cast<const uint4 *>(wp);
+    const uint4 *wf = reinterpret_cast<const uint4 *>(wp1);
     const float *bs = reinterpret_cast<const float *>(wf + 6 * 64);
     h8 A[6];
 #pragma unroll
     for (int f = 0; f < 6; f++) A[f] = as_h8(wf[f * 64 + lane]);
     const f32x4v b35 = *reinterpret_cast<const f32x4v *>(bs + 4 * g), b1 = *reinterpret_cast<const f32x4v *>(bs + 16 + 4 * g);
-    const float inv_s = bs[32];
-    _Float16 *hp0 = reinterpret_cast<_Float16 *>(out), *lp0 = hp0 + npos * 24;
-    // image row iy lives in LDS slot (iy + 5) % 5; a site is walked top to bottom, every row is staged once
+    const float inv_s1 = bs[32];
+    const uint4 *gh = reinterpret_cast<const uint4 *>(wp2), *gl = gh + NG * TN * 64;
+    const float *bs2 = reinterpret_cast<const float *>(gl + NG * TN * 64);
+    for (int i = threadIdx.x; i < NG * TN * 64; i += 256) { wfh[i] = gh[i]; wfl[i] = gl[i]; }
+    const float inv_s2 = bs2[CO];
+    f32x4v bias2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) bias2[tn] = *reinterpret_cast<const f32x4v *>(bs2 + 16 * tn + 4 * g);
+    // conv2: LDS offset (halves) of this lane's chunk of every MFMA step relative to (ring row 0, input pixel 2 xq)
+    int toff[NG], trow[NG];
+    bool tval[NG];
+#pragma unroll
+    for (int G = 0; G < NG; G++) {
+        const int chunk = 4 * G + g, tap = chunk / 3, c8 = chunk - tap * 3;
+        tval[G] = chunk < LY::NCH;
+        trow[G] = tval[G] ? tap / 3 : 0;
+        toff[G] = tval[G] ? (tap % 3) * C1C + 8 * c8 : 0;
+    }
+    _Float16 *hp0 = reinterpret_cast<_Float16 *>(out), *lp0 = hp0 + npos2 * CO;
     auto stage_row = [&](int64_t site, int iy) {
         const int slot = (iy + 5) % 5;
         for (int p = threadIdx.x; p < C1H_ROWPX; p += 256) {
@@ -1310,44 +1336,84 @@ __global__ __launch_bounds__(256) void k2_conv1_h3(const float *__restrict__ x, 
         }
     };
     for (int64_t site = blockIdx.x; site < n_sites; site += gridDim.x) {
-        __syncthreads();                                              // the previous site's last row has been read
+        __syncthreads();
         for (int iy = -2; iy <= 2; iy++) stage_row(site, iy);
         for (int y = 0; y < H; y++) {
-            __syncthreads();                                          // rows y-2 .. y+2 are in LDS
+            __syncthreads();                                          // input rows y-2 .. y+2 staged; conv2 of row y-2 done with ring slot y & 1
+            // ---- conv1, row y -> ring slot y & 1
 #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
-                const int x0 = 16 * (2 * wv + tt), xx = x0 + c16;
+                const int xx = 16 * (2 * wv + tt) + c16;
                 f32x4v acc35 = b35, acc1 = b1;
 #pragma unroll
                 for (int dy = 0; dy < 5; dy++) {
                     const uint32_t *q = X3 + (((y + dy - 2 + 5) % 5) * C1H_ROWPX) * 3 + 3 * xx + 4 * g;
-                    const uint4 bw = make_uint4(q[0], q[1], q[2], q[3]);
-                    const h8 B = as_h8(bw);
+                    const h8 B = as_h8(make_uint4(q[0], q[1], q[2], q[3]));
                     acc35 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[dy], B, acc35, 0, 0, 0);
                     if (dy == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[5], B, acc1, 0, 0, 0);
                 }
-                const int64_t pos = (site * H + y) * W + xx;
+                const int o = ((y & 1) * W + xx) * C1C;
                 auto put = [&](const f32x4v &acc, int ch0) {
                     _Float16 hi[4], lo[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float v = fminf(fmaxf(selu(acc[r] * inv_s), -65504.0f), 65504.0f);
+                        const float v = fminf(fmaxf(selu(acc[r] * inv_s1), -65504.0f), 65504.0f);
                         hi[r] = (_Float16)v;
                         lo[r] = (_Float16)(v - (float)hi[r]);
                     }
-                    *reinterpret_cast<uint2 *>(hp0 + pos * 24 + ch0) = *reinterpret_cast<const uint2 *>(hi);
-                    *reinterpret_cast<uint2 *>(lp0 + pos * 24 + ch0) = *reinterpret_cast<const uint2 *>(lo);
+                    *reinterpret_cast<uint2 *>(A1H + o + ch0) = *reinterpret_cast<const uint2 *>(hi);
+                    *reinterpret_cast<uint2 *>(A1L + o + ch0) = *reinterpret_cast<const uint2 *>(lo);
                 };
-                put(acc35, g < 2 ? 16 + 4 * g : 8 + 4 * (g - 2));  // rows 0-7: 5x5 filters (channels 16-23), rows 8-15: 5x1 (8-15)
-                if (g < 2) put(acc1, 4 * g);                        // rows 0-7: 1x5 filters (channels 0-7)
+                put(acc35, g < 2 ? 16 + 4 * g : 8 + 4 * (g - 2));
+                if (g < 2) put(acc1, 4 * g);
             }
-            __syncthreads();                                          // row y-2 is no longer needed: its slot takes row y+3
+            __syncthreads();                                          // conv1 row y is in the ring; input row y-2 is free
             if (y + 1 < H) stage_row(site, y + 3);
+            // ---- conv2, output row y-1 (conv1 rows y-1 and y), positions 16 wv .. 16 wv + 15
+            if (y >= 1) {
+                const int r2 = y - 1, xq = 16 * wv + c16, xc = xq < WO ? xq : WO - 1;
+                f32x4v acc[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) acc[tn] = bias2[tn];
+                h8 xh[NG], xl[NG];
+#pragma unroll
+                for (int G = 0; G < NG; G++) {
+                    const int o = ((((r2 + trow[G]) & 1) * W) + 2 * xc) * C1C + toff[G];
+                    const uint4 z = make_uint4(0, 0, 0, 0);
+                    xh[G] = as_h8(tval[G] ? *reinterpret_cast<const uint4 *>(A1H + o) : z);
+                    xl[G] = as_h8(tval[G] ? *reinterpret_cast<const uint4 *>(A1L + o) : z);
+                }
+#pragma unroll
+                for (int G = 0; G < NG; G++) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) {
+                        const h8 wh = as_h8(wfh[(G * TN + tn) * 64 + lane]), wl = as_h8(wfl[(G * TN + tn) * 64 + lane]);
+                        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[G], acc[tn], 0, 0, 0);
+                        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[G], acc[tn], 0, 0, 0);
+                        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[G], acc[tn], 0, 0, 0);
+                    }
+                }
+                if (xq < WO) {
+                    const int64_t pos = (site * HO + r2) * WO + xq;
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) {
+                        _Float16 hi[4], lo[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float c = fminf(fmaxf(selu(acc[tn][q] * inv_s2), -65504.0f), 65504.0f);
+                            hi[q] = (_Float16)c;
+                            lo[q] = (_Float16)(c - (float)hi[q]);
+                        }
+                        *reinterpret_cast<uint2 *>(hp0 + pos * CO + 16 * tn + 4 * g) = *reinterpret_cast<const uint2 *>(hi);
+                        *reinterpret_cast<uint2 *>(lp0 + pos * CO + 16 * tn + 4 * g) = *reinterpret_cast<const uint2 *>(lo);
+                    }
+                }
+            }
         }
     }
 }
 
-// host: A fragments of k2_conv1_h3 from the canonical conv1 weights (k11 [5][2][8], k12 [5][2][8], k13 [25][2][8] + biases)
+// host: A fragments of conv1 (k9_conv12_h3) from the canonical conv1 weights (k11 [5][2][8], k12 [5][2][8], k13 [25][2][8] + biases)
 inline void pack_conv1_h3(const float *w, uint8_t *dst)
 {
     const float *k11 = w, *b11 = k11 + 5 * 2 * 8, *k12 = b11 + 8, *b12 = k12 + 5 * 2 * 8, *k13 = b12 + 8, *b13 = k13 + 25 * 2 * 8;
@@ -1434,10 +1500,9 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
     const bool indel_h3 = !MFMA && !ctx->cnn_exact_fp32 && packed_h != nullptr;
     if constexpr (!MFMA) {
         if constexpr (CI == 2 && W % 4 == 0 && C1 == 8) {
-            if (indel_h3) {
-                hipLaunchKernelGGL((k2_conv1_h3<H>), dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, ctx->stream, x_batch,
-                                   packed_h + H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES, (void *)a1, nb, np1);
-            }
+            if (indel_h3)                                         // conv1 + conv2 fused: conv1's activations stay in LDS
+                hipLaunchKernelGGL((k9_conv12_h3<H>), dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, ctx->stream, x_batch,
+                                   packed_h + H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES, packed_h, (void *)a2, nb, np2);
             else
                 hipLaunchKernelGGL((k2_conv1_x4<H, W, C1, false>), dim3(blocks_for(np1 / 4)), dim3(256), 0, ctx->stream, x_batch, w, a1, np1);
         } else {
@@ -1477,9 +1542,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         auto grid = [](int64_t npos) { const int64_t t = (npos + 63) / 64; return dim3((unsigned)(t < 2048 ? t : 2048)); };
         if constexpr (3 * C1 == 24 && C2 == 32 && C3 == 48) {
             if (indel_h3) {
-                const _Float16 *a1h = reinterpret_cast<const _Float16 *>(a1), *a1l = a1h + np1 * 24;
                 const _Float16 *a2h = reinterpret_cast<const _Float16 *>(a2), *a2l = a2h + np2 * 32;
-                hipLaunchKernelGGL((k8_conv23_h3<H, W, 24, 32, false>), grid(np2), dim3(256), 0, ctx->stream, a1h, a1l, packed_h, (void *)a2, np1, np2);
                 hipLaunchKernelGGL((k8_conv23_h3<H2, W2, 32, 48, true>), grid(np3), dim3(256), 0, ctx->stream, a2h, a2l,
                                    packed_h + H3Layer<24, 32>::BYTES, (void *)a3, np2, np3);
             }
