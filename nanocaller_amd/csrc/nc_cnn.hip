@@ -1283,7 +1283,7 @@ constexpr size_t C1H_BYTES = 6 * 64 * 16 + 4 * 40;            // 6 A fragments, 
 // k8_conv23_h3.  Per image row y: conv1 row y -> ring; conv2 row y-1 (63 positions: one 16-position tile per wave).
 // out: conv2's activations as fp16 planes [site][H-1][63][32] (lo plane = hi plane + npos2 * 32).
 template <int H>
-__global__ __launch_bounds__(256) void k9_conv12_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp1, const uint8_t *__restrict__ wp2,
+__global__ __launch_bounds__(256, 3) void k9_conv12_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp1, const uint8_t *__restrict__ wp2,
                                                     void *__restrict__ out, int64_t n_sites, int64_t npos2)
 {
     constexpr int W = 128, HO = H - 1, WO = 63, C1C = 24, CO = 32;
