@@ -471,6 +471,33 @@ def get_indel_testing_candidates_haploid(dct, chunk, aligner=None, device=0):
     names = d["names"]
     max_range = {0: max(10, dct["win_size"]), 1: 10}
     out_pos, xs, alleles = [], [], []
+    if aligner is None and default_aligner() is star_aligner:
+        aligner = "device"
+    if aligner == "device":                                                         # every anchor's read set in one device call
+        todo, sets, refs = [], [], []
+        for v_pos, win in zip(anchors, d["windows"]):
+            a, b = v_pos - window_before, min(chrom_length, v_pos + window_after + 1)
+            ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N") for p in range(a, b))
+            if "N" in ref:
+                continue
+            picked = _sample_set({names[r]: text for r, text in win}, dct["mincov"], dct["maxcov"])
+            if picked is None:
+                continue
+            for q in picked[1]:
+                bad = q.translate(_DROP_AGTC)
+                if bad:
+                    raise KeyError(bad[0])
+            todo.append(v_pos)
+            sets.append(picked[1])
+            refs.append(ref)
+        if not todo:
+            return empty
+        eng = get_engine(device)
+        eng.use_torch_stream()
+        x, cns, _ = eng.star_msa_tensor(sets, refs)
+        lut = np.frombuffer(b"AGTC", np.uint8)
+        preds = allele_prediction_batch([lut[c].tobytes().decode() for c in cns], refs, [max_range[variants[v]] for v in todo])
+        return (todo, x.cpu().numpy().astype(np.float64), preds)
     for v_pos, win in zip(anchors, d["windows"]):
         ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
                       for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))

@@ -502,6 +502,10 @@ def test_indel_calls_with_the_star_aligner_recover_the_planted_indels(tmp_path):
         pos2, y0, y1, y2, alleles2, phase2 = gip.get_indel_testing_candidates(dct, dict(chrom=w.chrom, start=2_000, end=38_000, sam_path=bam), aligner=al)
         assert pos2 == pos and alleles2 == alleles and phase2 == phase
         assert np.array_equal(y0, x0) and np.array_equal(y1, x1) and np.array_equal(y2, x2)
+    # the haploid caller: one read set per anchor, device batch == host star aligner per set
+    hp = gip.get_indel_testing_candidates_haploid(dct, dict(chrom=w.chrom, start=2_000, end=20_000, sam_path=bam), aligner=gip.star_aligner)
+    hd = gip.get_indel_testing_candidates_haploid(dct, dict(chrom=w.chrom, start=2_000, end=20_000, sam_path=bam), aligner="device")
+    assert list(hp[0]) == list(hd[0]) and len(hp[0]) > 10 and np.array_equal(hp[1], hd[1]) and list(hp[2]) == list(hd[2])
 
 
 @pytest.mark.gpu
