@@ -529,6 +529,10 @@ def test_device_star_alignment_equals_host_star_alignment():
             reads.append(q[:cut] + ("ACGTTGCA"[:int(rng.integers(0, 8))] if r % 5 == 0 else ""))
         sets.append(reads)
         refs.append(ref)
+    for s in range(4):                                                             # PacBio windows: 261 reference bases, reads of 260
+        ref = "".join("AGTC"[i] for i in rng.integers(0, 4, size=261))
+        sets.append([_mutate(rng, ref, 3, [(int(rng.integers(20, 200)), int(rng.choice([-7, 9])))])[:260] for _ in range(11)])
+        refs.append(ref)
     x, cns, ncols, rows, rrs = eng.star_msa_tensor(sets, refs, want_rows=True)
     sym = "AGTC-N"
     n_checked = 0
