@@ -453,47 +453,6 @@ def star_msa_ref(seqs, ref, open_=9, extend=1, match=20, mismatch=-10):
     return rows, "".join(ref_row)
 
 
-def allele_prediction_ref(alt, ref_seq, max_range, cigar=None):
-    """generate_indel_pileups.py:77-127 transliterated (same variable names); `cigar` defaults to nw_cigar_ref."""
-    cigar_op = cigar if cigar is not None else nw_cigar_ref(alt, ref_seq)
-    indel = False
-    ref_cnt = [0] * 10
-    alt_cnt = [0] * 10
-    mis_match_cnt_before_indel = False
-    mis_match_cnt_after_indel = (0, 0)
-    for op, cnt in cigar_op:
-        if op == 8 or op == 7:
-            ref_cnt[op] += cnt
-            alt_cnt[op] += cnt
-            if indel:
-                mis_match_cnt_after_indel[op - 7] += cnt
-            else:
-                mis_match_cnt_before_indel = True
-        if op == 1:
-            alt_cnt[op] += cnt
-            mis_match_cnt_after_indel = [0, 0]
-            indel = True
-        if op == 2:
-            ref_cnt[op] += cnt
-            mis_match_cnt_after_indel = [0, 0]
-            indel = True
-        if indel is False and sum(ref_cnt) >= max_range + 10:
-            if ref_cnt[8]:
-                out_len = sum(ref_cnt) if op == 8 else sum(ref_cnt) - cnt
-                return ref_seq[:out_len], alt[:out_len]
-            else:
-                return (None, None)
-        if indel is True:
-            if sum(mis_match_cnt_after_indel) > 20:
-                break
-    ref_out_len = sum(ref_cnt) if op == 8 else sum(ref_cnt) - cnt
-    alt_out_len = sum(alt_cnt) if op == 8 else sum(alt_cnt) - cnt
-    if not mis_match_cnt_before_indel:
-        ref_out_len += 1
-        alt_out_len += 1
-    return ref_seq[:ref_out_len], alt[:alt_out_len]
-
-
 def read_windows_ref(records, anchors, window_before, window_after, flag_filter):
     """generate_indel_pileups.py:306-338 on SAM-like records (dict name, flag, pos0, cigar [(op, len)], seq): for each
     anchor (1-based) the [(record index, query_sequence[max(0, q - wb) : q + wa])] of the reads in the pileup there, with

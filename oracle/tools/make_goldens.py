@@ -482,9 +482,164 @@ def make_chunk_goldens():
     print("chunk cases:", len(cases), "total chunks", sum(len(c["chunks"]) for c in cases))
 
 
+# ----------------------------------------------------------------------------- pass 2 of the indel featuriser (a11-a13)
+def _install_aligner_stubs(ref_mod, check_every=25):
+    """MUSCLE and parasail are absent.  The reference's msa() and allele_prediction() are run UNCHANGED with
+    * `Popen` replaced by an object that answers the FASTA the reference writes with the star alignment of the same reads
+      (nc_star_msa, the aligner the product uses when `muscle` is not on PATH), in the FASTA format the reference parses;
+    * `parasail.nw_trace` answered by the Gotoh aligner behind nc_nw_cigar.
+    Every `check_every`-th call is repeated with the pure-Python restatements in oracle/ (star_msa_ref, nw_cigar_ref) and
+    must agree, so the goldens do not depend on which of the two produced them."""
+    import parasail
+
+    from nanocaller_amd import generate_indel_pileups as gip
+    from oracle import oracle
+
+    cnt = {"msa": 0, "nw": 0}
+
+    class FakePopen:
+        def __init__(self, argv, **kw):
+            assert argv[0] == "muscle", argv
+
+        def communicate(self, input=None):
+            recs = input.decode("utf-8")[1:].split(">")
+            names, seqs, ref = [], [], None
+            for rec in recs:
+                nm, sq = rec.split("\n", 1)
+                sq = sq.replace("\n", "")
+                assert nm.endswith("_SEQ")
+                if nm == "ref_SEQ":
+                    ref = sq
+                else:
+                    names.append(nm[:-4])
+                    seqs.append(sq)
+            if not seqs:
+                return (b">ref_SEQ\n" + ref.encode() + b"\n", b"")
+            rows, ref_row = gip.star_aligner(names, seqs, ref)
+            cnt["msa"] += 1
+            if cnt["msa"] % check_every == 1:
+                assert (rows, ref_row) == oracle.star_msa_ref(seqs, ref)
+            out = "".join(">%s_SEQ\n%s\n" % (n, r) for n, r in zip(names, rows)) + ">ref_SEQ\n%s\n" % ref_row
+            return (out.encode(), b"")
+
+    def backend(s1, s2, open_, extend, match, mismatch):
+        ops = gip.nw_cigar(s1, s2, open_, extend, match, mismatch)
+        cnt["nw"] += 1
+        if cnt["nw"] % check_every == 1:
+            assert ops == oracle.nw_cigar_ref(s1, s2, open_, extend, match, mismatch)
+        return ops
+
+    ref_mod.Popen = FakePopen
+    parasail.BACKEND = backend
+    return cnt
+
+
+def make_pass2_goldens():
+    """The reference's FULL get_indel_testing_candidates 6-tuple / haploid 3-tuple (generate_indel_pileups.py:129-371,
+    generate_indel_pileups_haploid.py:128-277) on record-based worlds served by the stub pysam (pileups[*].alignment.
+    query_sequence, query_position_or_next), plus every (alt, ref_seq, max_range) -> (REF, ALT) the reference's own
+    allele_prediction (:77-127) returned on the way and on a set of seeded mutated pairs."""
+    import json
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import bamio
+    from nanocaller_src import generate_indel_pileups as ref_indel
+    from nanocaller_src import generate_indel_pileups_haploid as ref_hap
+
+    calls = []
+
+    def wrap(mod):
+        orig = mod.allele_prediction
+
+        def spy(alt, ref_seq, max_range):
+            out = orig(alt, ref_seq, max_range)
+            calls.append([alt, ref_seq, int(max_range), out[0], out[1]])
+            return out
+        mod.allele_prediction = spy
+        return orig
+    ref_ap = wrap(ref_indel)
+    wrap(ref_hap)
+    _install_aligner_stubs(ref_indel)
+    ref_hap.Popen = ref_indel.Popen
+
+    worlds = {"a": bamio.make_pass2_world(seed=11, length=24_000, depth=16),
+              "b": bamio.make_pass2_world(seed=31, length=20_000, depth=18, blocks=[(4_000, 15_000)])}
+    rec = {}
+    for wn, w in worlds.items():
+        rec.update(bamio.world_arrays(w, "w%s_" % wn))
+        pysam.register_records("bam_" + wn, w.chrom, w.length, w.ref, bamio.world_to_records(w, None))
+        pysam.register_records("fa_" + wn, w.chrom, w.length, w.ref, [])
+    base = dict(seq="ont", win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+                exclude_bed=None, impute_indel_phase=False)
+    cases = [("a", "diploid", 2_000, 22_000, {}), ("a", "haploid", 2_000, 22_000, {}),
+             ("a", "diploid", 1, 9_000, dict(seq="pacbio", mincov=3)), ("a", "haploid", 15_000, 24_000, dict(seq="pacbio", mincov=4)),
+             ("a", "diploid", 5_000, 16_000, dict(supplementary=True, win_size=20, small_win_size=2, ins_t=0.3, del_t=0.4)),
+             ("b", "diploid", 1_000, 19_000, dict(impute_indel_phase=True, del_t=0.4)),
+             ("b", "diploid", 1_000, 19_000, dict(impute_indel_phase=False, del_t=0.4)),
+             ("a", "diploid", 12_000, 12_300, dict(mincov=40))]
+    for k, (wn, ploidy, start, end, kw) in enumerate(cases):
+        w = worlds[wn]
+        dct = dict(base, fasta_path="fa_" + wn)
+        dct.update(kw)
+        chunk = dict(chrom=w.chrom, start=start, end=end, sam_path="bam_" + wn)
+        if ploidy == "diploid":
+            pos, x0, x1, x2, alleles, phase = ref_indel.get_indel_testing_candidates(dct, chunk)
+            xs = [np.asarray(x0), np.asarray(x1), np.asarray(x2)]
+        else:
+            pos, x, alleles = ref_hap.get_indel_testing_candidates_haploid(dct, chunk)
+            xs, phase = [np.asarray(x)], None
+        rec["c%d_world" % k], rec["c%d_ploidy" % k] = np.array(wn), np.array(ploidy)
+        rec["c%d_start" % k], rec["c%d_end" % k] = start, end
+        rec["c%d_dct" % k] = np.array(json.dumps({kk: vv for kk, vv in dct.items() if kk != "fasta_path"}))
+        rec["c%d_pos" % k] = np.asarray(pos, np.int64)
+        for i, x in enumerate(xs):
+            if len(pos):
+                assert x.dtype == np.float64 and x.shape == (len(pos), 5, 128, 2)
+                assert np.array_equal(x.astype(np.float32).astype(np.float64), x)        # f32-rounded values (:59)
+                rec["c%d_x%d" % (k, i)] = x.astype(np.float32)
+        rec["c%d_alleles" % k] = np.array(json.dumps(alleles))
+        rec["c%d_phase" % k] = np.array(json.dumps(phase))
+        print("pass2 case %d world=%s %s [%d,%d] %s -> %d sites" % (k, wn, ploidy, start, end, kw, len(pos)))
+    rec["n"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "indel_pass2.npz"), **rec)
+    # ---- the reference's allele_prediction on seeded pairs (in addition to the calls it made above)
+    n_pipeline = len(calls)
+    rng = np.random.Generator(np.random.PCG64(43))
+    letters = "AGTC"
+
+    def rand_seq(n):
+        return "".join(letters[i] for i in rng.integers(0, 4, size=n))
+    for trial in range(260):
+        ref = rand_seq(int(rng.integers(30, 262)))
+        s = list(ref)
+        for _ in range(int(rng.integers(0, 5))):
+            i = int(rng.integers(0, len(s)))
+            s[i] = letters[(letters.index(s[i]) + int(rng.integers(1, 4))) % 4]
+        for _ in range(int(rng.integers(0, 3))):
+            i = int(rng.integers(0, len(s)))
+            ln = int(rng.choice([-30, -7, -3, -1, 1, 2, 5, 20]))
+            if ln > 0:
+                s[i:i] = list(rand_seq(ln))
+            else:
+                del s[i:i - ln]
+        alt = "".join(s) or "A"
+        if trial % 9 == 0:
+            alt = alt[:int(rng.integers(1, len(alt) + 1))]                 # consensus shorter than the window
+        mr = int(rng.choice([10, 40, 20]))
+        try:
+            out = ref_ap(alt, ref, mr)
+            calls.append([alt, ref, mr, out[0], out[1]])
+        except Exception as e:                                              # the latent tuple-mutation bug (E12) raises
+            calls.append([alt, ref, mr, "!" + type(e).__name__, None])
+    with open(os.path.join(OUT, "allele_prediction.json"), "w") as f:
+        json.dump(dict(n_pipeline=n_pipeline, calls=calls), f)
+    print("allele_prediction cases: %d from the pipeline + %d seeded (%d (None, None), %d raised)" % (
+        n_pipeline, len(calls) - n_pipeline, sum(1 for c in calls if c[3] is None), sum(1 for c in calls if isinstance(c[3], str) and c[3].startswith("!"))))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller", "indel_scan", "indel_impute"]
+    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller", "indel_scan", "indel_impute", "pass2"]
     if "snp" in what:
         make_snp_goldens()
     if "cnd" in what:
@@ -501,3 +656,5 @@ if __name__ == "__main__":
         make_indel_scan_goldens()
     if "indel_impute" in what:
         make_indel_impute_goldens()
+    if "pass2" in what:
+        make_pass2_goldens()

@@ -53,7 +53,102 @@ class _Col:
         return len(self._names)
 
 
+class RecordWorld:
+    """SAM-like records (dict name, flag, pos0, cigar [(op, len)], seq, tags) in coordinate order: the second kind of
+    world the stub serves.  Here the stub restates htslib's pileup engine from the SAM spec + pysam documentation
+    [pysam-doc]: a column lists the reads whose alignment spans it in file order; inside M/=/X the entry is the read
+    base (lower case on the reverse strand), inside D it is '*' with is_del set; the LAST aligned base before an I / D
+    operation carries the indel (`+<n><bases>` / `-<n><N...>` with add_indels=True); soft clips stay in query_sequence and
+    count in query positions; query_position_or_next of a deleted position is the index of the next aligned query base."""
+
+    def __init__(self, chrom, length, ref, records):
+        self.chrom, self.length, self.ref, self.records = chrom, length, ref, records
+        self.names = [r["name"] for r in records]
+        self.span = []
+        for r in records:
+            rlen = sum(ln for op, ln in r["cigar"] if op in "MDN=X")
+            self.span.append((r["pos0"], r["pos0"] + rlen))
+        self._exp = {}
+
+    def expand(self, k):
+        """per reference position of record k: (is_del, query index or next, pileup string)"""
+        if k in self._exp:
+            return self._exp[k]
+        r = self.records[k]
+        rev = bool(r["flag"] & 16)
+        seq = r["seq"]
+        out = []
+        qp = 0
+        cig = r["cigar"]
+        for ci, (op, ln) in enumerate(cig):
+            if op in "M=X":
+                for t in range(ln):
+                    ch = seq[qp].lower() if rev else seq[qp].upper()
+                    suffix = ""
+                    if t == ln - 1 and ci + 1 < len(cig):
+                        nop, nln = cig[ci + 1]
+                        if nop == "I":
+                            ins = seq[qp + 1:qp + 1 + nln]
+                            suffix = "+%d%s" % (nln, ins.lower() if rev else ins.upper())
+                        elif nop == "D":
+                            suffix = "-%d%s" % (nln, ("n" if rev else "N") * nln)
+                    out.append((False, qp, ch + suffix))
+                    qp += 1
+            elif op in "IS":
+                qp += ln
+            elif op == "D":
+                for _ in range(ln):
+                    out.append((True, qp, "*"))
+            elif op == "N":
+                for _ in range(ln):
+                    out.append((True, qp, "<" if rev else ">"))
+            elif op in "HP":
+                pass
+            else:
+                raise ValueError(op)
+        self._exp[k] = out
+        return out
+
+
+def register_records(path, chrom, length, ref, records):
+    WORLDS[path] = RecordWorld(chrom, length, ref, records)
+
+
+class _RecAlignment:
+    def __init__(self, rec):
+        self.qname = self.query_name = rec["name"]
+        self.flag = rec["flag"]
+        self.query_sequence = rec["seq"]
+        self._tags = rec.get("tags", {})
+
+    def has_tag(self, t):
+        return t in self._tags
+
+    def get_tag(self, t):
+        return self._tags[t]
+
+
+class _PileupRead:
+    def __init__(self, aln, is_del, qpos):
+        self.alignment = aln
+        self.is_del = int(is_del)
+        self.is_refskip = 0
+        self.query_position = None if is_del else qpos
+        self.query_position_or_next = qpos
+
+
+class _RecCol(_Col):
+    def __init__(self, pos0, names, seqs, pileups):
+        super().__init__(pos0, names, seqs)
+        self.pileups = pileups
+
+
 class Samfile:
+    def __new__(cls, path, *a, **k):
+        if isinstance(WORLDS.get(path), RecordWorld) and cls is Samfile:
+            return object.__new__(_RecSamfile)
+        return object.__new__(cls)
+
     def __init__(self, path, *a, reference_filename=None, **k):
         self.world = WORLDS[path]
 
@@ -119,12 +214,38 @@ class Samfile:
             yield _Col(p0, names, seqs)
 
 
+class _RecSamfile(Samfile):
+    def fetch(self, chrom, a, b, multiple_iterators=False):
+        w = self.world
+        for k, (s0, e0) in enumerate(w.span):
+            if s0 < b and e0 > a:
+                yield _RecAlignment(w.records[k])
+
+    def _pileup(self, chrom, a, b, flag_filter):
+        w = self.world
+        a = max(0, a)
+        b = min(b, w.length)
+        live = [k for k, (s0, e0) in enumerate(w.span) if s0 < b and e0 > a and not (w.records[k]["flag"] & flag_filter)]
+        alns = {k: _RecAlignment(w.records[k]) for k in live}
+        for p0 in range(a, b):
+            names, seqs, pil = [], [], []
+            for k in live:
+                s0, e0 = w.span[k]
+                if s0 <= p0 < e0:
+                    is_del, qp, text = w.expand(k)[p0 - s0]
+                    names.append(w.names[k])
+                    seqs.append(text)
+                    pil.append(_PileupRead(alns[k], is_del, qp))
+            if names:
+                yield _RecCol(p0, names, seqs, pil)
+
+
 AlignmentFile = Samfile
 
 
 class FastaFile:
     def __init__(self, path, *a, **k):
-        self.world = WORLDS[path]
+        self.world = WORLDS[path]          # World or RecordWorld: both have .ref / .length
 
     def fetch(self, chrom, a=None, b=None):
         return self.world.ref[a:b]

@@ -197,3 +197,50 @@ def make_bam_world(seed=5, length=30_000, depth=12):
     w.codes = codes
     w.meta["events"] = (np.array(new_off, np.int32), np.array(new_pos, np.int32), np.array(new_len, np.int32))
     return w
+
+
+def clean_noise_deletions(w):
+    """The synthetic worlds code per-base deletion noise (and read 'N') as 4 without an event; written as 'N' bases they make
+    msa() raise KeyError exactly as the reference does (generate_indel_pileups.py:56).  Give those positions the reference
+    base instead (in place), so that every code 4 left belongs to a deletion event."""
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    refc = np.array(["AGTC".find(c) for c in w.ref], np.int64)
+    for r in range(w.n_reads):
+        s0, o0 = int(w.read_start[r]), int(w.read_off[r])
+        span = w.codes[o0:int(w.read_off[r + 1])]
+        deleted = np.zeros(len(span), bool)
+        for k in range(ev_off[r], ev_off[r + 1]):
+            if ev_len[k] < 0:
+                deleted[ev_pos[k] + 1 - s0:ev_pos[k] + 1 - s0 - ev_len[k]] = True
+        fix = (span == 4) & ~deleted
+        rc = refc[s0 - 1:s0 - 1 + len(span)][fix]
+        span[fix] = np.where(rc >= 0, rc, 0)
+    return w
+
+
+def make_pass2_world(seed, length, depth, blocks=(), drop=0.85, alt_base_frac=0.3):
+    """make_bam_world + clean_noise_deletions + per-event inserted bases (and, with `blocks`, unphased stretches):
+    the input of the reference-executed pass-2 goldens (oracle/tools/make_goldens.py pass2) and of their tests"""
+    from nanocaller_amd.synth import unphase_blocks
+    w = clean_noise_deletions(make_bam_world(seed=seed, length=length, depth=depth))
+    return unphase_blocks(w, list(blocks), seed=seed, drop=drop if blocks else 0.0, alt_base_frac=alt_base_frac)
+
+
+def world_arrays(w, prefix):
+    """the arrays that define a pass-2 world, for np.savez"""
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    ins_off, ins_bases = w.meta["ev_ins"]
+    return {prefix + k: v for k, v in dict(
+        chrom=np.array(w.chrom), ref=np.frombuffer(w.ref.encode(), dtype=np.uint8), read_start=w.read_start, read_end=w.read_end,
+        read_flag=w.read_flag, read_off=w.read_off, codes=w.codes, ev_off=ev_off, ev_pos=ev_pos, ev_len=ev_len,
+        hap=np.asarray(w.meta["hap"], np.uint8), ps=np.asarray(w.meta["ps"], np.int32), ins_off=ins_off, ins_bases=ins_bases).items()}
+
+
+def world_from_arrays(z, prefix):
+    from nanocaller_amd.synth import World, apply_impute_inputs
+    g = lambda k: z[prefix + k]
+    R = g("read_start").shape[0]
+    w = World(chrom=str(g("chrom")), ref=g("ref").tobytes().decode(), read_start=g("read_start"), read_end=g("read_end"),
+              read_flag=g("read_flag"), read_off=g("read_off"), codes=g("codes"), names=["r%07d" % i for i in range(R)])
+    w.meta.update(events=(g("ev_off"), g("ev_pos"), g("ev_len")), hap=g("hap"), ps=g("ps"))
+    return apply_impute_inputs(w, g("hap"), g("ins_off"), g("ins_bases"))

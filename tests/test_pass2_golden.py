@@ -1,0 +1,171 @@
+"""SURVEY.md 8a rows a11 / a13 (and a10 + a12 on the way) against the REFERENCE's own outputs: tests/golden/indel_pass2.npz
+holds the full 6-tuple of get_indel_testing_candidates (generate_indel_pileups.py:129-371) and the 3-tuple of
+get_indel_testing_candidates_haploid (generate_indel_pileups_haploid.py:128-277) as returned by the reference's code run in
+the build container (oracle/tools/make_goldens.py pass2: stub pysam serving SAM-like records, MUSCLE answered by the star
+aligner, parasail by the Gotoh aligner); tests/golden/allele_prediction.json holds what the reference's allele_prediction
+(:77-127) returned for 801 (alt, ref_seq, max_range) triples.  The library's native code must reproduce them exactly."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nanocaller_amd import generate_indel_pileups as gip
+from nanocaller_amd.bam import BamFile, read_bam
+from oracle import oracle
+
+import bamio
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    z = np.load(os.path.join(GOLD, "indel_pass2.npz"))
+    out = []
+    for k in range(int(z["n"])):
+        dct = json.loads(str(z["c%d_dct" % k]))
+        n = len(z["c%d_pos" % k])
+        xs = [z["c%d_x%d" % (k, i)] for i in range(3) if ("c%d_x%d" % (k, i)) in z]
+        alleles = json.loads(str(z["c%d_alleles" % k]))
+        out.append(dict(k=k, world=str(z["c%d_world" % k]), ploidy=str(z["c%d_ploidy" % k]), start=int(z["c%d_start" % k]),
+                        end=int(z["c%d_end" % k]), dct=dct, pos=z["c%d_pos" % k].tolist(), xs=xs, n=n,
+                        alleles=alleles, phase=json.loads(str(z["c%d_phase" % k]))))
+    return z, out
+
+
+Z, CASES = _cases()
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pass2gold")
+    out = {}
+    for wn in ("a", "b"):
+        w = bamio.world_from_arrays(Z, "w%s_" % wn)
+        bam, fa = str(d / ("%s.bam" % wn)), str(d / ("%s.fa" % wn))
+        bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, None))
+        bamio.write_fasta(fa, w.chrom, w.ref)
+        out[wn] = (w, bam, fa)
+    return out
+
+
+def _norm_alleles(a):
+    """JSON turned the (REF, ALT) tuples into lists"""
+    if a and isinstance(a[0], (list, tuple)) and len(a[0]) == 3 and isinstance(a[0][0], (list, tuple)):
+        return [[tuple(x) for x in site] for site in a]
+    return [tuple(x) for x in a]
+
+
+def test_allele_prediction_equals_the_reference_outputs():
+    """nc_allele_prediction (+ batch) against what the reference's own allele_prediction returned"""
+    rec = json.load(open(os.path.join(GOLD, "allele_prediction.json")))
+    calls = rec["calls"]
+    assert len(calls) > 700 and rec["n_pipeline"] > 400
+    n_alt = 0
+    for alt, ref, mr, r, a in calls:
+        assert not (isinstance(r, str) and r.startswith("!"))
+        assert gip.allele_prediction(alt, ref, mr) == (r, a), (alt, ref, mr)
+        n_alt += r is not None
+    assert n_alt > 200
+    got = gip.allele_prediction_batch([c[0] for c in calls], [c[1] for c in calls], [c[2] for c in calls])
+    assert got == [(c[3], c[4]) for c in calls]
+
+
+def _assemble(case, w, bam, fa):
+    """pass 2 assembled from the CPU oracle (pass 1, K8) and the library's host code (BAM windows, star alignment, allele
+    strings): what the reference's tuple must equal without any GPU"""
+    dct = case["dct"]
+    world = read_bam(bam, fa, w.chrom)
+    kw = dict(mincov=dct["mincov"], win_size=dct["win_size"], small_win_size=dct["small_win_size"], ins_t=dct["ins_t"],
+              del_t=dct["del_t"], supplementary=dct["supplementary"])
+    hapl = case["ploidy"] == "haploid"
+    extra = {}
+    if dct["impute_indel_phase"] and not hapl:
+        variants, extra_idx = oracle.indel_scan_impute(w, case["start"], case["end"], **kw)
+        extra = {p: tuple([w.names[i] for i in side] for side in sets) for p, sets in extra_idx.items()}
+    else:
+        vp, vt = oracle.indel_scan(world, case["start"], case["end"], haploid=hapl, **kw)
+        variants = dict(zip(vp.tolist(), vt.tolist()))
+    wa = 260 if dct["seq"] == "pacbio" else 160
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if dct["supplementary"] else 0x800)
+    anchors = sorted(v for v in variants if max(0, case["start"] - 10 - dct["win_size"]) < v <= case["end"])
+    bf = BamFile(bam)
+    d = bf.decode(w.chrom, max(1, case["start"] - 100000), case["end"] + 1000, anchors=anchors, window_before=0, window_after=wa,
+                  keep_mask=flag)
+    bf.close()
+    names, hap, ps = d["names"], d["hap"], d["ps"]
+    sym = {"A": 0, "G": 1, "T": 2, "C": 3, "-": 4}
+    lo, hi = max(1, case["start"] - 200), case["end"] + 400
+    pos, xs, alleles, phase = [], [], [], []
+    for a, win in zip(anchors, d["windows"]):
+        ref = "".join((w.ref[p - 1] if (lo <= p <= hi and w.ref[p - 1] in "AGTC") else "N") for p in range(a, min(w.length, a + wa + 1)))
+        if "N" in ref:
+            continue
+        sets = [{}, {}, {}]
+        imp = extra.get(a)
+        for r, text in win:
+            sets[2][names[r]] = text
+            if (names[r] in imp[0]) if imp else hap[r] == 1:
+                sets[0][names[r]] = text
+            elif (names[r] in imp[1]) if imp else hap[r] == 2:
+                sets[1][names[r]] = text
+        todo = [(sets[2], dct["mincov"])] if hapl else [(sets[0], 2), (sets[1], 2), (sets[2], dct["mincov"])]
+        res = []
+        for s, mc in todo:
+            nm = sorted(s)
+            if len(nm) < mc:
+                res = None
+                break
+            rows, ref_row = gip.star_aligner(nm, [s[n] for n in nm], ref)
+            x, cns = oracle.indel_tensor(np.array([[sym[c] for c in r] for r in rows], np.uint8), np.array([sym[c] for c in ref_row], np.uint8))
+            res.append((x, "".join("AGTC"[c] for c in cns if c != 4)))
+        if res is None:
+            continue
+        pos.append(a)
+        xs.append([r[0] for r in res])
+        mr = {0: max(10, dct["win_size"]), 1: 10}[variants[a]]
+        al = [gip.allele_prediction(r[1], ref, mr) for r in res]
+        alleles.append(al[0] if hapl else al)
+        if not hapl:
+            first = next(iter(sets[0]))
+            k = names.index(first)
+            phase.append(int(ps[k]) if hap[k] else None)
+    return pos, xs, alleles, (None if hapl else phase)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%d_%s_%s" % (c["k"], c["world"], c["ploidy"]))
+def test_oracle_and_host_pieces_reproduce_the_reference_tuple(files, case):
+    w, bam, fa = files[case["world"]]
+    pos, xs, alleles, phase = _assemble(case, w, bam, fa)
+    assert pos == case["pos"]
+    assert alleles == _norm_alleles(case["alleles"])
+    assert phase == case["phase"]
+    for i, gx in enumerate(case["xs"]):
+        got = np.stack([x[i] for x in xs])
+        assert np.array_equal(got.astype(np.float32), gx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aligner", ["host_star", "device"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%d_%s_%s" % (c["k"], c["world"], c["ploidy"]))
+def test_get_indel_testing_candidates_equals_the_reference_tuple(files, case, aligner):
+    """the product functions (pass 1 K7 on the GPU, native BAM windows, star alignment on the host cores or on the device,
+    K8, nc_allele_prediction) return exactly what the reference's functions returned"""
+    w, bam, fa = files[case["world"]]
+    dct = dict(case["dct"], fasta_path=fa)
+    chunk = dict(chrom=w.chrom, start=case["start"], end=case["end"], sam_path=bam)
+    al = gip.star_aligner if aligner == "host_star" else "device"
+    if case["ploidy"] == "haploid":
+        pos, x, alleles = gip.get_indel_testing_candidates_haploid(dct, chunk, aligner=al)
+        xs, phase = [x], None
+    else:
+        pos, x0, x1, x2, alleles, phase = gip.get_indel_testing_candidates(dct, chunk, aligner=al)
+        xs = [x0, x1, x2]
+    assert list(pos) == case["pos"]
+    assert [tuple(a) if case["ploidy"] == "haploid" else [tuple(t) for t in a] for a in alleles] == _norm_alleles(case["alleles"])
+    assert (None if phase is None else list(phase)) == case["phase"]
+    if case["n"] == 0:
+        return
+    for got, gx in zip(xs, case["xs"]):
+        assert np.asarray(got).dtype == np.float64 and np.asarray(got).shape == (case["n"], 5, 128, 2)
+        assert np.array_equal(np.asarray(got).astype(np.float32), gx)
