@@ -637,24 +637,219 @@ def make_pass2_goldens():
         n_pipeline, len(calls) - n_pipeline, sum(1 for c in calls if c[3] is None), sum(1 for c in calls if isinstance(c[3], str) and c[3].startswith("!"))))
 
 
+# ----------------------------------------------------------------------------- CNNs through the reference's own call()
+REFSRC = "/root/reference/nanocaller_src"
+
+
+def make_cnn_goldens():
+    """Probabilities returned by the reference's own model classes (model_architect.py:36-64, model_architect_SNP_haploid.py:
+    33-53, model_architect_indel.py:28-48, model_architect_indels_haploid.py:29-48) with the reference's REAL checkpoints,
+    executed on the numpy Keras layers of oracle/tools/refstub/tensorflow (float64 arithmetic on float32 inputs / weights).
+    Inputs are the committed reference-made tensors (snp_*.npz, indel_pass2.npz), fed as snpCaller.py:90-111,167-183 and
+    indelCaller.py:83-85,171 feed them."""
+    import tensorflow as tf
+
+    sys.path.insert(0, HERE)
+    from convert_weights import INDEL_MODELS, SNP_MODELS
+    from nanocaller_src.model_architect import SNP_model
+    from nanocaller_src.model_architect_indel import Indel_model
+    from nanocaller_src.model_architect_indels_haploid import haploid_Indel_model
+    from nanocaller_src.model_architect_SNP_haploid import haploid_SNP_model
+
+    assert tf.COMPUTE_DTYPE is np.float64 and not tf.RETURN_F32
+
+    def coverage_of(prefix):
+        return float(open(os.path.join(REFSRC, prefix + ".coverage")).readline().strip())
+
+    def snp_inputs(case, n, train_cov, mode):
+        z = np.load(os.path.join(OUT, "snp_%s.npz" % case))
+        n = min(n, len(z["pos"]))
+        x = z["mat"][:n].astype(np.float32)
+        ref = z["ref"][:n]
+        if mode == 0:      # snpCaller.py:96 under numpy < 2 (environment.yml:10): f32 array * f64 scalar multiplies in f32 (E7)
+            x[:, 1:, :, :4] = x[:, 1:, :, :4] * np.float32(train_cov / float(z["depth"]))
+        else:              # snpCaller.py:94: f32 array * f64 array -> f64 product, rounded into the f32 array
+            x[:, 1:, :, :4] = (x[:, 1:, :, :4].astype(np.float64) * (train_cov / z["dp"][:n, None, None, None])).astype(np.float32)
+        return n, x, ref.astype(np.float16)
+
+    rec, k = {}, 0
+    models = {}
+    todo = [("ONT-HG002", "ont_dip", 400, 0), ("ONT-HG002", "deep_ont", 160, 0), ("ONT-HG002", "ont_dip_start", 120, 1),
+            ("ONT-HG002", "ul_ont", 120, 0), ("CCS-HG002", "hifi_pacbio_dip", 400, 0), ("CLR-HG002", "short_ont", 120, 0)]
+    todo += [(m, "ont_dip", 48, 0) for m in SNP_MODELS if m not in ("ONT-HG002",)]
+    for name, case, n, mode in todo:
+        prefix = SNP_MODELS[name]
+        if name not in models:
+            models[name] = SNP_model()
+            models[name].load_weights(os.path.join(REFSRC, prefix)).expect_partial()
+        cov = coverage_of(prefix)
+        n, x, r16 = snp_inputs(case, n, cov, mode)
+        out = models[name]([x, r16[:, 0][:, np.newaxis], r16[:, 1][:, np.newaxis], r16[:, 2][:, np.newaxis], r16[:, 3][:, np.newaxis]])
+        out = np.stack([np.asarray(o) for o in out], axis=1)                      # (n, 5 heads A G T C GT, 2)
+        assert out.shape == (n, 5, 2) and out.dtype == np.float64
+        rec.update({"c%d_model" % k: np.array(name), "c%d_case" % k: np.array(case), "c%d_n" % k: n, "c%d_mode" % k: mode,
+                    "c%d_cov" % k: np.float64(cov), "c%d_out" % k: out})
+        k += 1
+    rec["n"] = k
+    hap = haploid_SNP_model()
+    hap([np.zeros(5 * 41 * 5).reshape(1, 5, 41, 5), np.zeros(4).reshape(1, 4)])          # snpCaller.py:76-77
+    hap.load_weights(os.path.join(REFSRC, "release_data/haploid_models/SNPs/CHM13/model.24-0.9985.h5"))
+    h = 0
+    for case, n, mode in (("ont_hap", 400, 0), ("hifi_pacbio_hap", 400, 0), ("ont_hap", 100, 1)):
+        n, x, r16 = snp_inputs(case, n, 30, mode)                                 # hap_train_coverage (snpCaller.py:73)
+        out = np.asarray(hap([x, r16]).numpy())
+        assert out.shape == (n, 4)
+        rec.update({"h%d_case" % h: np.array(case), "h%d_n" % h: n, "h%d_mode" % h: mode, "h%d_out" % h: out})
+        h += 1
+    rec["nh"] = h
+    np.savez_compressed(os.path.join(OUT, "cnn_snp.npz"), **rec)
+    print("cnn_snp: %d diploid cases (%d models), %d haploid cases" % (k, len(models), h))
+
+    # ---- indel models on the reference-made pass-2 tensors
+    zp = np.load(os.path.join(OUT, "indel_pass2.npz"))
+    rec, k = {}, 0
+    rng = np.random.Generator(np.random.PCG64(77))
+    dense = np.round(rng.random((24, 15, 128, 2)) * 2 - 1, 3)                     # dense inputs: every tap of every filter is hit
+    dense[..., 1] = (rng.random((24, 15, 128)) < 0.25)
+    rec["dense"] = dense.astype(np.float32)
+    todo = [(m, 0) for m in INDEL_MODELS] + [("ONT-HG002", 4), ("CCS-HG002", 2), ("ONT-HG002", 5), ("ONT-HG002", -1)]
+    models = {}
+    for name, c in todo:
+        if name not in models:
+            models[name] = Indel_model()
+            models[name].load_weights(os.path.join(REFSRC, INDEL_MODELS[name])).expect_partial()
+        if c >= 0:
+            x = np.hstack([zp["c%d_x%d" % (c, i)].astype(np.float64) for i in range(3)])   # indelCaller.py:83
+        else:
+            x = dense.astype(np.float32).astype(np.float64)
+        out = np.asarray(models[name](x))
+        assert out.shape == (len(x), 4)
+        rec.update({"c%d_model" % k: np.array(name), "c%d_src" % k: c, "c%d_out" % k: out})
+        k += 1
+    rec["n"] = k
+    hm = haploid_Indel_model()
+    hm.build(input_shape=(1, 5, 128, 2))                                          # indelCaller.py:56-57
+    hm.load_weights(os.path.join(REFSRC, "release_data/haploid_models/indels/CHM13/model.19-0.9811.h5"))
+    h = 0
+    for c in (1, 3, -1):
+        x = zp["c%d_x0" % c].astype(np.float64) if c >= 0 else dense[:, :5].astype(np.float32).astype(np.float64)
+        out = np.asarray(hm(x))
+        assert out.shape == (len(x), 1)
+        rec.update({"h%d_src" % h: c, "h%d_out" % h: out})
+        h += 1
+    rec["nh"] = h
+    np.savez_compressed(os.path.join(OUT, "cnn_indel.npz"), **rec)
+    print("cnn_indel: %d diploid cases (%d models), %d haploid cases" % (k, len(models), h))
+
+
+def make_e2e_goldens():
+    """The reference's worker loops END TO END in the build container: snpCaller.caller (snpCaller.py:57-203) and
+    indelCaller.indel_run (indelCaller.py:41-189) unchanged, featurisers on the stub pysam, models = the reference's classes
+    on the numpy Keras layers with the real checkpoints (outputs rounded to float32 as TensorFlow returns them).  The VCF
+    text they write is the golden.  Caveat: this container has numpy 2, the reference pins numpy < 2 -- the
+    coverage scale is multiplied in float64 here and in float32 there (a last-place difference of the inputs)."""
+    import queue
+
+    import tensorflow as tf
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import bamio
+    from nanocaller_src import indelCaller as ref_ic
+    from nanocaller_src import snpCaller as ref_caller
+    from nanocaller_src import generate_indel_pileups as ref_indel
+    from nanocaller_src import generate_indel_pileups_haploid as ref_hap
+
+    class P:
+        _identity = (1,)
+
+    tf.RETURN_F32 = True
+    out = {}
+    try:
+        # ---- SNPs: the committed worlds (world_ont.npz / world_hifi.npz are exactly these)
+        w_ont = make_world(seed=812, length=135_000, depth=18, tech="ont", read_len_scale=0.8)
+        w_hifi = make_world(seed=813, length=90_000, depth=24, tech="hifi", read_len_scale=0.6, het_rate=1 / 400.0, sys_err_rate=0.02)
+        ref_caller.current_process = lambda: P
+        tmpdir = "/tmp/nc_gold_e2e"
+        os.makedirs(tmpdir, exist_ok=True)
+        runs = [("snp_ont", w_ont, "ONT-HG002", "ont", [0.4, 0.6], False,
+                 [("diploid", 52_000, 66_000), ("diploid", 66_000, 80_000), ("haploid", 60_000, 75_000)]),
+                ("snp_ont_nonorm", w_ont, "ONT-HG002", "ont", [0.4, 0.6], True, [("diploid", 100_000, 112_000)]),
+                ("snp_hifi", w_hifi, "CCS-HG002", "pacbio", [0.3, 0.7], False, [("diploid", 30_000, 60_000), ("haploid", 30_000, 45_000)])]
+        for tag, w, model, seq, thr, nonorm, chunks in runs:
+            pysam.register("bam", w)
+            pysam.register("fa", w)
+            params = dict(intermediate_snp_files_dir=tmpdir, prefix=tag, snp_model=model, disable_coverage_normalization=nonorm,
+                          exclude_bed=None, sam_path="bam", fasta_path="fa", threshold=thr, supplementary=False, mincov=4,
+                          maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, seq=seq)
+            q = queue.Queue()
+            for ploidy, a, b in chunks:
+                q.put(dict(chrom=w.chrom, start=a, end=b, ploidy=ploidy))
+            files = []
+            ref_caller.caller(params, q, queue.Queue(), files)
+            txt = open(files[0]).read()
+            out[tag + "_vcf"] = np.array(txt)
+            out[tag + "_chunks"] = np.array(json_dumps(chunks))
+            out[tag + "_params"] = np.array(json_dumps({kk: vv for kk, vv in params.items() if kk not in ("intermediate_snp_files_dir", "sam_path", "fasta_path")}))
+            print("e2e %s: %d VCF lines (%d PASS)" % (tag, txt.count("\n"), txt.count("\tPASS\t")))
+        # ---- indels: the pass-2 worlds
+        _install_aligner_stubs(ref_indel)
+        ref_hap.Popen = ref_indel.Popen
+        ref_ic.current_process = lambda: P
+        z = np.load(os.path.join(OUT, "indel_pass2.npz"))
+        for tag, wn, model, kw, chunks in [
+                ("indel_a", "a", "ONT-HG002", {}, [("diploid", 2_000, 12_000), ("diploid", 12_000, 22_000), ("haploid", 2_000, 22_000)]),
+                ("indel_b", "b", "CCS-HG002", dict(impute_indel_phase=True, del_t=0.4), [("diploid", 1_000, 19_000)])]:
+            w = bamio.world_from_arrays(z, "w%s_" % wn)
+            pysam.register_records("bam_e2e", w.chrom, w.length, w.ref, bamio.world_to_records(w, None))
+            pysam.register_records("fa_e2e", w.chrom, w.length, w.ref, [])
+            params = dict(intermediate_indel_files_dir=tmpdir, prefix=tag, indel_model=model, seq="ont", win_size=40, small_win_size=4,
+                          mincov=2, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False, exclude_bed=None, impute_indel_phase=False,
+                          fasta_path="fa_e2e")
+            params.update(kw)
+            q = queue.Queue()
+            for ploidy, a, b in chunks:
+                q.put(("indel", dict(chrom=w.chrom, start=a, end=b, ploidy=ploidy, sam_path="bam_e2e")))
+            files = []
+            ref_ic.indel_run(params, {}, q, queue.Queue(), files)
+            txt = open(files[0]).read()
+            out[tag + "_vcf"] = np.array(txt)
+            out[tag + "_world"] = np.array(wn)
+            out[tag + "_chunks"] = np.array(json_dumps(chunks))
+            out[tag + "_params"] = np.array(json_dumps({kk: vv for kk, vv in params.items() if kk not in ("intermediate_indel_files_dir", "fasta_path")}))
+            print("e2e %s: %d VCF lines" % (tag, txt.count("\n")))
+    finally:
+        tf.RETURN_F32 = False
+    np.savez_compressed(os.path.join(OUT, "e2e_vcf.npz"), **out)
+
+
+def json_dumps(o):
+    import json
+    return json.dumps(o)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    what = sys.argv[1:] or ["snp", "cnd", "caller", "msa", "chunks", "indel_caller", "indel_scan", "indel_impute", "pass2"]
+    # order matters: "e2e" runs the reference's real loops and must come before "caller" / "indel_caller" replace the model classes
+    what = sys.argv[1:] or ["snp", "cnd", "msa", "chunks", "indel_scan", "indel_impute", "pass2", "cnn", "e2e", "caller", "indel_caller"]
     if "snp" in what:
         make_snp_goldens()
     if "cnd" in what:
         make_cnd_pos_goldens()
-    if "caller" in what:
-        make_caller_goldens()
     if "msa" in what:
         make_msa_goldens()
     if "chunks" in what:
         make_chunk_goldens()
-    if "indel_caller" in what:
-        make_indel_caller_goldens()
     if "indel_scan" in what:
         make_indel_scan_goldens()
     if "indel_impute" in what:
         make_indel_impute_goldens()
     if "pass2" in what:
         make_pass2_goldens()
+    if "cnn" in what:
+        make_cnn_goldens()
+    if "e2e" in what:
+        make_e2e_goldens()
+    if "caller" in what:                      # these two replace the reference's model classes by canned tables: last
+        make_caller_goldens()
+    if "indel_caller" in what:
+        make_indel_caller_goldens()

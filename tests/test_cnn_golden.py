@@ -1,0 +1,249 @@
+"""SURVEY.md 8a rows a7 / a8 / a14 against the REFERENCE's own model code: tests/golden/cnn_snp.npz and cnn_indel.npz hold the
+probabilities returned by the reference's SNP_model / haploid_SNP_model / Indel_model / haploid_Indel_model `call()`
+(model_architect.py:36-64, model_architect_SNP_haploid.py:33-53, model_architect_indel.py:28-48,
+model_architect_indels_haploid.py:29-48) loaded from the reference's real checkpoints and executed in the build container on
+numpy Keras layers (oracle/tools/make_goldens.py cnn; float64 arithmetic on float32 inputs and weights).  tests/golden/
+e2e_vcf.npz holds the VCF text the reference's worker loops (snpCaller.caller, indelCaller.indel_run) wrote end to end.
+
+  * not gpu: the C oracle (and so everything checked against it) equals those goldens to <= 1e-6;
+  * gpu:     the HIP kernels (both precisions) are within the north star's 1e-4 of them, with identical calls."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nanocaller_amd import _lib
+from nanocaller_amd.weights import INDEL_MODEL_FILES, SNP_MODEL_FILES, Weights, get_indel_model, get_SNP_model
+from oracle import oracle
+
+from util import GOLD, load_snp_case, load_world
+
+ZS = np.load(os.path.join(GOLD, "cnn_snp.npz"))
+ZI = np.load(os.path.join(GOLD, "cnn_indel.npz"))
+ZP = np.load(os.path.join(GOLD, "indel_pass2.npz"))
+TOL_ORACLE = 1e-6      # float64 oracle vs float64 numpy Keras: differences are the float32 rounding of the stored outputs
+TOL_GPU = 1e-4         # north star: per-site softmax probabilities within 1e-4
+
+
+def _snp_case(prefix, k):
+    case = str(ZS["%s%d_case" % (prefix, k)])
+    n, mode = int(ZS["%s%d_n" % (prefix, k)]), int(ZS["%s%d_mode" % (prefix, k)])
+    _, _, _, _, gold = load_snp_case(case)
+    x = gold["mat"][:n]
+    ref_code = np.argmax(gold["ref"][:n], 1).astype(np.int32)
+    return case, n, mode, x, ref_code, gold["depth"], gold["dp"][:n], ZS["%s%d_out" % (prefix, k)]
+
+
+def _scale(cov, depth, dp, mode, n):
+    return (cov / dp.astype(np.float64)) if mode == 1 else np.full(n, cov / depth)
+
+
+def _indel_input(src, hap):
+    if src < 0:
+        d = ZI["dense"].astype(np.float32)
+        return d[:, :5] if hap else d
+    if hap:
+        return ZP["c%d_x0" % src].astype(np.float32)
+    return np.hstack([ZP["c%d_x%d" % (src, i)] for i in range(3)]).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------- CPU: the oracle is pinned
+def test_goldens_cover_every_shipped_model():
+    snp = {str(ZS["c%d_model" % k]) for k in range(int(ZS["n"]))}
+    assert snp == {m for m in SNP_MODEL_FILES if m != "haploid"}
+    ind = {str(ZI["c%d_model" % k]) for k in range(int(ZI["n"]))}
+    assert ind == {m for m in INDEL_MODEL_FILES if m != "haploid"}
+    assert int(ZS["nh"]) >= 2 and int(ZI["nh"]) >= 2
+
+
+@pytest.mark.parametrize("k", range(int(ZS["n"])))
+def test_oracle_snp_forward_equals_reference_call(k):
+    model = str(ZS["c%d_model" % k])
+    case, n, mode, x, ref_code, depth, dp, out = _snp_case("c", k)
+    path, cov = get_SNP_model(model)
+    assert cov == float(ZS["c%d_cov" % k])                              # the .coverage scalar next to the checkpoint
+    w = Weights(path)
+    probs, gt = oracle.snp_forward(w.flat, x, ref_code, _scale(cov, depth, dp, mode, n), scale_mode=mode, precision="f64")
+    assert np.abs(probs - out[:, :4, 1]).max() < TOL_ORACLE, (model, case)
+    assert np.abs(gt - out[:, 4, :]).max() < TOL_ORACLE
+    assert np.abs(out.sum(-1) - 1).max() < 1e-12                        # both classes of every head are stored
+    # the float32 oracle (what bench.py's cpu_baseline runs) is inside float32 rounding of it
+    p32, _ = oracle.snp_forward(w.flat, x, ref_code, _scale(cov, depth, dp, mode, n), scale_mode=mode, precision="f32")
+    assert np.abs(p32 - out[:, :4, 1]).max() < 2e-5
+
+
+@pytest.mark.parametrize("k", range(int(ZS["nh"])))
+def test_oracle_snp_hap_forward_equals_reference_call(k):
+    case, n, mode, x, ref_code, depth, dp, out = _snp_case("h", k)
+    w = Weights(get_SNP_model("haploid")[0])
+    probs = oracle.snp_hap_forward(w.flat, x, ref_code, _scale(30.0, depth, dp, mode, n), scale_mode=mode, precision="f64")
+    assert np.abs(probs - out).max() < TOL_ORACLE
+
+
+@pytest.mark.parametrize("k", range(int(ZI["n"])))
+def test_oracle_indel_forward_equals_reference_call(k):
+    model, src = str(ZI["c%d_model" % k]), int(ZI["c%d_src" % k])
+    w = Weights(get_indel_model(model))
+    p = oracle.indel_forward(w.flat, _indel_input(src, False), precision="f64")
+    assert np.abs(p - ZI["c%d_out" % k]).max() < TOL_ORACLE, (model, src)
+
+
+@pytest.mark.parametrize("k", range(int(ZI["nh"])))
+def test_oracle_indel_hap_forward_equals_reference_call(k):
+    w = Weights(get_indel_model("haploid"))
+    p = oracle.indel_forward(w.flat, _indel_input(int(ZI["h%d_src" % k]), True), precision="f64")
+    assert np.abs(p - ZI["h%d_out" % k]).max() < TOL_ORACLE
+
+
+# --------------------------------------------------------------------------------------------------- e2e VCF text of the reference
+ZE = np.load(os.path.join(GOLD, "e2e_vcf.npz"))
+
+
+def _fields(line):
+    f = line.rstrip("\n").split("\t")
+    pr = [float(v) for v in f[7].split(";")[0][3:].split(",")] if f[7].startswith("PR=") else []
+    return f, pr
+
+
+def _compare_snp_vcf(got, exp):
+    """discrete content identical (CHROM POS REF ALT FILTER, GT and every depth-derived sample field), probabilities within
+    1e-4 (printed with 4 decimals: + half a unit of the last place), QUAL = -10 log10(1e-10 + 1 - p) within the error a 1e-4
+    change of p allows"""
+    assert len(got) == len(exp)
+    npass = 0
+    for g, e in zip(got, exp):
+        (gf, gp), (ef, ep) = _fields(g), _fields(e)
+        assert gf[:5] == ef[:5] and gf[6] == ef[6], (g, e)
+        assert gf[8] == ef[8] and gf[9] == ef[9], (g, e)
+        assert gf[7].split(";")[1] == ef[7].split(";")[1]                # FQ
+        assert max(abs(a - b) for a, b in zip(gp, ep)) <= 1.01e-4 + 1e-4
+        qg, qe = float(gf[5]), float(ef[5])
+        pg, pe = 1 - 10 ** (-qg / 10), 1 - 10 ** (-qe / 10)
+        assert abs(pg - pe) <= 2e-4 or abs(qg - qe) <= 0.05 * max(1.0, qe), (g, e)
+        npass += ef[6] == "PASS"
+    return npass
+
+
+def _oracle_snp_lines(tag):
+    from nanocaller_amd import snpCaller
+    params = json.loads(str(ZE[tag + "_params"]))
+    chunks = json.loads(str(ZE[tag + "_chunks"]))
+    world = load_world("hifi" if tag == "snp_hifi" else "ont")
+    path, cov = get_SNP_model(params["snp_model"])
+    w = Weights(path)
+    wh = Weights(get_SNP_model("haploid")[0])
+    dct = {k: params[k] for k in ("threshold", "mincov", "maxcov", "min_allele_freq", "min_nbr_sites", "seq")}
+    lines = []
+    for ploidy, a, b in chunks:
+        c = dict(chrom=world.chrom, start=a, end=b, ploidy=ploidy)
+        pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(world, dct, c)
+        rc = np.argmax(ref, 1).astype(np.int32)
+        mode = 1 if params["disable_coverage_normalization"] else 0
+        if ploidy == "diploid":
+            probs, _ = oracle.snp_forward(w.flat, mat, rc, _scale(cov, depth, np.asarray(dp), mode, len(pos)), scale_mode=mode, precision="f32")
+            lines += snpCaller.snp_vcf_lines(world.chrom, pos, rc, probs, dp, freq, fwd, rev)
+        else:
+            probs = oracle.snp_hap_forward(wh.flat, mat, rc, _scale(30.0, depth, np.asarray(dp), mode, len(pos)), scale_mode=mode, precision="f32")
+            lines += snpCaller.snp_vcf_lines_haploid(world.chrom, pos, rc, probs, dp, freq)
+    return lines
+
+
+@pytest.mark.parametrize("tag", ["snp_ont", "snp_ont_nonorm", "snp_hifi"])
+def test_oracle_pipeline_writes_the_reference_callers_vcf(tag):
+    """oracle featuriser + oracle CNN + the host rules == the lines the reference's caller() wrote with its own models"""
+    exp = str(ZE[tag + "_vcf"]).splitlines()
+    got = [ln.rstrip("\n") for ln in _oracle_snp_lines(tag)]
+    assert len(exp) > 200
+    assert _compare_snp_vcf(got, exp) > 20
+
+
+# --------------------------------------------------------------------------------------------------- GPU: the kernels
+@pytest.fixture(scope="module")
+def eng():
+    from nanocaller_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [False, True], ids=["fp16x3", "fp32"])
+def test_hip_snp_cnn_equals_reference_call(eng, exact):
+    import torch
+    worst = 0.0
+    try:
+        eng.set_cnn_precision(exact_fp32=exact)
+        for k in range(int(ZS["n"])):
+            model = str(ZS["c%d_model" % k])
+            case, n, mode, x, ref_code, depth, dp, out = _snp_case("c", k)
+            path, cov = get_SNP_model(model)
+            eng.load_weights(_lib.MODEL_SNP, Weights(path))
+            sc = torch.from_numpy(_scale(cov, depth, dp, mode, n)).cuda()
+            probs, gt = eng.snp_forward(_lib.MODEL_SNP, torch.from_numpy(np.ascontiguousarray(x)).cuda(), torch.from_numpy(ref_code).cuda(),
+                                        sc, scale_mode=mode)
+            p, g = probs.cpu().numpy(), gt.cpu().numpy()
+            err = max(np.abs(p - out[:, :4, 1]).max(), np.abs(g - out[:, 4, :]).max())
+            worst = max(worst, err)
+            assert err < TOL_GPU, (model, case, err)
+            far = np.abs(out[:, :4, 1] - 0.5) > 1e-4
+            assert np.array_equal((p >= 0.5)[far], (out[:, :4, 1] >= 0.5)[far])          # the genotype-relevant decisions
+        for k in range(int(ZS["nh"])):
+            case, n, mode, x, ref_code, depth, dp, out = _snp_case("h", k)
+            eng.load_weights(_lib.MODEL_SNP_HAP, Weights(get_SNP_model("haploid")[0]))
+            sc = torch.from_numpy(_scale(30.0, depth, dp, mode, n)).cuda()
+            probs, _ = eng.snp_forward(_lib.MODEL_SNP_HAP, torch.from_numpy(np.ascontiguousarray(x)).cuda(), torch.from_numpy(ref_code).cuda(),
+                                       sc, scale_mode=mode)
+            err = np.abs(probs.cpu().numpy() - out).max()
+            worst = max(worst, err)
+            assert err < TOL_GPU, (case, err)
+    finally:
+        eng.set_cnn_precision(exact_fp32=False)
+    assert worst < 2e-5, "measured ~3e-6: far inside the 1e-4 contract"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [False, True], ids=["fp16x3", "fp32"])
+def test_hip_indel_cnn_equals_reference_call(eng, exact):
+    import torch
+    try:
+        eng.set_cnn_precision(exact_fp32=exact)
+        for k in range(int(ZI["n"])):
+            model, src = str(ZI["c%d_model" % k]), int(ZI["c%d_src" % k])
+            eng.load_weights(_lib.MODEL_INDEL, Weights(get_indel_model(model)))
+            x = np.ascontiguousarray(_indel_input(src, False))
+            p = eng.indel_forward(_lib.MODEL_INDEL, torch.from_numpy(x).cuda()).cpu().numpy()
+            assert np.abs(p - ZI["c%d_out" % k]).max() < TOL_GPU, (model, src)
+        eng.load_weights(_lib.MODEL_INDEL_HAP, Weights(get_indel_model("haploid")))
+        for k in range(int(ZI["nh"])):
+            x = np.ascontiguousarray(_indel_input(int(ZI["h%d_src" % k]), True))
+            p = eng.indel_forward(_lib.MODEL_INDEL_HAP, torch.from_numpy(x).cuda()).cpu().numpy()
+            assert np.abs(p - ZI["h%d_out" % k]).max() < TOL_GPU
+    finally:
+        eng.set_cnn_precision(exact_fp32=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["snp_ont", "snp_ont_nonorm", "snp_hifi"])
+def test_hip_caller_writes_the_reference_callers_vcf(eng, tag, tmp_path):
+    """snpCaller.caller (the product worker loop: scan, tensors, CNN on the GPU, host rules) on the same world and chunks
+    writes the lines the reference's caller() wrote"""
+    import queue
+
+    from nanocaller_amd import snpCaller
+    params = json.loads(str(ZE[tag + "_params"]))
+    chunks = json.loads(str(ZE[tag + "_chunks"]))
+    world = load_world("hifi" if tag == "snp_hifi" else "ont")
+    params.update(sam_path=world, fasta_path=None, intermediate_snp_files_dir=str(tmp_path), prefix="t")
+    q = queue.Queue()
+    for ploidy, a, b in chunks:
+        q.put(dict(chrom=world.chrom, start=a, end=b, ploidy=ploidy))
+    files = []
+    snpCaller.caller(params, q, queue.Queue(), files)
+    got = open(files[0]).read().splitlines()
+    exp = str(ZE[tag + "_vcf"]).splitlines()
+    # the reference writes chunk after chunk in queue order, the product one (contig, ploidy) group after the other: compare
+    # per ploidy in position order (stable: a position shared by two chunks keeps its chunk order, quirk E3)
+    def is_hap(ln):
+        smp = ln.split("\t")[9]
+        return smp.startswith("1/1:") and smp.endswith(":.:.:.")
+    order = lambda lines: sorted(lines, key=lambda ln: (is_hap(ln), int(ln.split("\t")[1])))   # noqa: E731
+    assert _compare_snp_vcf(order(got), order(exp)) > 20

@@ -169,3 +169,63 @@ def test_get_indel_testing_candidates_equals_the_reference_tuple(files, case, al
     for got, gx in zip(xs, case["xs"]):
         assert np.asarray(got).dtype == np.float64 and np.asarray(got).shape == (case["n"], 5, 128, 2)
         assert np.array_equal(np.asarray(got).astype(np.float32), gx)
+
+
+# ------------------------------------------------------------------------- the reference's indel_run() end to end (e2e_vcf.npz)
+ZE = np.load(os.path.join(GOLD, "e2e_vcf.npz"))
+
+
+def _compare_indel_vcf(got, exp):
+    """records identical in CHROM POS REF ALT FILTER FORMAT, GT and PS; QUAL / GQ (%.2f of -10 log10 of float32 probabilities)
+    within what a 1e-4 change of the probability allows"""
+    assert len(got) == len(exp), (len(got), len(exp))
+    for g, e in zip(got, exp):
+        gf, ef = g.rstrip("\n").split("\t"), e.rstrip("\n").split("\t")
+        assert gf[:5] == ef[:5] and gf[6:9] == ef[6:9], (g, e)
+        gs, es = gf[9].split(":"), ef[9].split(":")
+        assert gs[0] == es[0] and gs[2:] == es[2:], (g, e)
+        for a, b in ((float(gf[5]), float(ef[5])), (float(gs[1]), float(es[1]))):
+            pa, pb = 10 ** (-abs(a) / 10), 10 ** (-abs(b) / 10)
+            assert abs(pa - pb) <= 2e-4 or abs(a - b) <= 0.02 * max(1.0, abs(b)), (g, e)
+
+
+@pytest.mark.parametrize("tag", ["indel_a", "indel_b"])
+def test_oracle_pipeline_writes_the_reference_indel_runs_vcf(files, tag):
+    """pass 2 from the oracle / host pieces + oracle indel CNN + the host rules == the lines of the reference's indel_run()"""
+    from nanocaller_amd import indelCaller
+    from nanocaller_amd.weights import Weights, get_indel_model
+    params = json.loads(str(ZE[tag + "_params"]))
+    w, bam, fa = files[str(ZE[tag + "_world"])]
+    wd = Weights(get_indel_model(params["indel_model"]))
+    wh = Weights(get_indel_model("haploid"))
+    lines = []
+    for ploidy, a, b in json.loads(str(ZE[tag + "_chunks"])):
+        pos, xs, alleles, phase = _assemble(dict(dct=params, ploidy=ploidy, start=a, end=b), w, bam, fa)
+        if not pos:
+            continue
+        if ploidy == "diploid":
+            x = np.hstack([np.stack([x[i] for x in xs]) for i in range(3)]).astype(np.float32)
+            lines += indelCaller.indel_vcf_lines(w.chrom, pos, oracle.indel_forward(wd.flat, x, precision="f32"), alleles, phase)[0]
+        else:
+            x = np.stack([x[0] for x in xs]).astype(np.float32)
+            lines += indelCaller.indel_vcf_lines_haploid(w.chrom, pos, oracle.indel_forward(wh.flat, x, precision="f32"), alleles)[0]
+    exp = str(ZE[tag + "_vcf"]).splitlines()
+    assert len(exp) > 20
+    _compare_indel_vcf(lines, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["indel_a", "indel_b"])
+def test_hip_indel_run_writes_the_reference_indel_runs_vcf(files, tag, tmp_path):
+    """indelCaller.indel_run (the product worker loop, everything on the GPU / native host code) on the same BAM and chunks"""
+    import queue
+
+    from nanocaller_amd import indelCaller
+    params = json.loads(str(ZE[tag + "_params"]))
+    w, bam, fa = files[str(ZE[tag + "_world"])]
+    params.update(fasta_path=fa, intermediate_indel_files_dir=str(tmp_path), prefix="t")
+    jobs, files_out = queue.Queue(), []
+    for ploidy, a, b in json.loads(str(ZE[tag + "_chunks"])):
+        jobs.put(("indel", dict(chrom=w.chrom, start=a, end=b, ploidy=ploidy, sam_path=bam)))
+    path = indelCaller.indel_run(params, {}, jobs, queue.Queue(), files_out, aligner="device")
+    _compare_indel_vcf(open(path).read().splitlines(), str(ZE[tag + "_vcf"]).splitlines())
