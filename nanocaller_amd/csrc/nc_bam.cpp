@@ -382,29 +382,63 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         if (refid < tid) continue;
         if (pos >= end0) break;                       // sorted: nothing further can overlap
         if (flag & 0x4) continue;
-        const uint8_t *name = p + 32, *cig = name + l_name, *seq = cig + 4 * n_cig, *qual = seq + (l_seq + 1) / 2;
+        if (l_seq < 0) { err = true; break; }
+        const uint8_t *name = p + 32, *cig = name + l_name, *seq = cig + 4 * (size_t)n_cig, *qual = seq + ((size_t)l_seq + 1) / 2;
         const uint8_t *aux = qual + l_seq, *aux_end = p + bs;
         if (aux > aux_end) { err = true; break; }
-        // reference span
-        int32_t rlen = 0;
-        for (int k = 0; k < n_cig; k++) {
+        int64_t n_cig_real = n_cig;
+        // SAMv1 4.2.2: a CIGAR of more than 65535 operations (ultra-long reads) is stored in the CG:B,I tag and the record
+        // carries the placeholder <l_seq>S<ref_len>N -- htslib swaps the real one in transparently, and so does this reader.
+        if (n_cig == 2 && (rdu32(cig) & 15) == 4 && (int64_t)(rdu32(cig) >> 4) == l_seq && (rdu32(cig + 4) & 15) == 3) {
+            for (const uint8_t *a = aux; a + 3 <= aux_end;) {
+                const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+                a += 3;
+                size_t adv = 0;
+                switch (ty) {
+                case 'c': case 'C': case 'A': adv = 1; break;
+                case 's': case 'S': adv = 2; break;
+                case 'i': case 'I': case 'f': adv = 4; break;
+                case 'Z': case 'H': { const uint8_t *z = a; while (z < aux_end && *z) z++; adv = (size_t)(z - a) + 1; break; }
+                case 'B': {
+                    if (a + 5 > aux_end) { adv = (size_t)(aux_end - a); break; }
+                    const char st = (char)a[0];
+                    const uint32_t cnt = rdu32(a + 1);
+                    const int es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                    if (t0 == 'C' && t1 == 'G' && st == 'I' && a + 5 + (size_t)cnt * 4 <= aux_end) { cig = a + 5; n_cig_real = cnt; }
+                    adv = 5 + (size_t)cnt * es;
+                    break; }
+                default: adv = (size_t)(aux_end - a); break;
+                }
+                if (adv > (size_t)(aux_end - a)) break;
+                a += adv;
+            }
+        }
+        // reference span and query length of the CIGAR
+        int64_t rlen64 = 0, qlen = 0;
+        for (int64_t k = 0; k < n_cig_real; k++) {
             const uint32_t c = rdu32(cig + 4 * k);
             const int op = c & 15, len = (int)(c >> 4);
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += len;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen64 += len;
+            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += len;
         }
-        if (rlen <= 0 || pos + rlen <= beg0) continue;
+        if (rlen64 <= 0 || rlen64 > INT32_MAX - pos - 2 || pos + rlen64 <= beg0) continue;
+        const int32_t rlen = (int32_t)rlen64;
+        // A record without its bases (SEQ '*': l_seq 0, what minimap2 writes for secondary alignments) or with fewer bases
+        // than its CIGAR consumes must not be read past its end: its aligned positions decode as 'N' (code 4).
+        const bool has_seq = qlen <= (int64_t)l_seq;
         // codes + indel markers
         const size_t c0 = d->codes.size();
         d->codes.resize(c0 + (size_t)rlen);
         uint8_t *co = d->codes.data() + c0;
         int32_t rp = 0, qp = 0, q_first = -1;
-        for (int k = 0; k < n_cig; k++) {
+        for (int64_t k = 0; k < n_cig_real; k++) {
             const uint32_t c = rdu32(cig + 4 * k);
             const int op = c & 15, len = (int)(c >> 4);
             switch (op) {
             case 0: case 7: case 8:                                   // M, =, X
                 if (q_first < 0) q_first = qp;                        // query index of the first aligned base (leading S / I skipped)
-                for (int i = 0; i < len; i++, rp++, qp++) co[rp] = NT16_CODE[(seq[qp >> 1] >> ((~qp & 1) << 2)) & 15];
+                if (has_seq) for (int i = 0; i < len; i++, rp++, qp++) co[rp] = NT16_CODE[(seq[qp >> 1] >> ((~qp & 1) << 2)) & 15];
+                else for (int i = 0; i < len; i++, rp++, qp++) co[rp] = 4;
                 break;
             case 1:                                                   // I: '+n' on the previous reference column
                 if (rp > 0) { d->ev_pos.push_back(pos + rp); d->ev_len.push_back(len); }
@@ -656,6 +690,7 @@ int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor
             const int64_t s0 = d->seq_off[r], s1 = d->seq_off[r + 1], L = s1 - s0;
             int64_t a0 = (int64_t)q - window_before, a1 = (int64_t)q + window_after;
             if (a0 < 0) a0 = 0;
+            if (a0 > L) a0 = L;                                            // a record without bases (SEQ '*')
             if (a1 > L) a1 = L;
             if (a1 < a0) a1 = a0;
             s->read_idx.push_back(r);

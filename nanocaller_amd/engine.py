@@ -439,3 +439,14 @@ def get_engine(device: int = 0) -> Engine:
     if device not in _engines:
         _engines[device] = Engine(device)
     return _engines[device]
+
+
+def local_device(devices=None, rank=0) -> int:
+    """GPU of this process: one process per GPU.  `devices` (a sequence) is indexed by the local rank; by default the local
+    rank itself (LOCAL_RANK from torchrun, else the global rank) modulo the number of visible devices."""
+    import os
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if devices:
+        return int(devices[local % len(devices)])
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return local % n if n > 0 else 0

@@ -23,17 +23,53 @@ from .pack import pack_world
 from .synth import World
 
 _SOURCES = {}
-_PACKS = {}
+
+
+class _LRU:
+    """Small bounded cache: a whole-genome run walks contig after contig, and a decoded contig (~1 B per aligned base on
+    the host) or its pack (the same in HBM) must not outlive the next ones.  The bound counts entries (contigs x variants);
+    NANOCALLER_CONTIG_CACHE overrides it."""
+
+    def __init__(self, cap):
+        self.cap = max(1, int(os.environ.get("NANOCALLER_CONTIG_CACHE", cap)))
+        self.d = {}
+
+    def get(self, key, make):
+        if key in self.d:
+            self.d[key] = self.d.pop(key)                            # most recently used last
+            return self.d[key]
+        val = make()
+        self.d[key] = val
+        while len(self.d) > self.cap:
+            self.d.pop(next(iter(self.d)))
+        return val
+
+    def drop(self, pred):
+        for k in [k for k in self.d if pred(k)]:
+            del self.d[k]
+
+    def __len__(self):
+        return len(self.d)
+
+    def __contains__(self, key):
+        return key in self.d
+
+
+_BAM_WORLDS = _LRU(2)        # (bam, fasta, contig) -> decoded World
+_PACKS = _LRU(3)             # (source, fasta, contig, supplementary, exclusions, device) -> (DevicePack, World)
 
 
 def register_alignments(key, world: World):
     """Make `dct['sam_path'] == key` resolve to decoded alignments."""
     _SOURCES[key] = world
-    for k in [k for k in _PACKS if k[0] == key]:
-        del _PACKS[k]
+    _PACKS.drop(lambda k: k[0] == key)
 
 
-_BAM_WORLDS = {}
+def release_contig(chrom=None):
+    """Forget the decoded alignments and HBM packs of `chrom` (all contigs when None): callers that walk a genome contig by
+    contig call this when they move on (the LRU bound does the same, later)."""
+    _BAM_WORLDS.drop(lambda k: chrom is None or k[2] == chrom)
+    _PACKS.drop(lambda k: chrom is None or k[2] == chrom)
 
 
 def _resolve(sam_path, chrom=None, fasta_path=None) -> World:
@@ -44,11 +80,8 @@ def _resolve(sam_path, chrom=None, fasta_path=None) -> World:
     if isinstance(sam_path, str) and os.path.exists(sam_path):
         if chrom is None or not fasta_path:
             raise ValueError("decoding %r needs the contig name and dct['fasta_path']" % sam_path)
-        key = (sam_path, fasta_path, chrom)
-        if key not in _BAM_WORLDS:
-            from .bam import read_bam
-            _BAM_WORLDS[key] = read_bam(sam_path, fasta_path, chrom)
-        return _BAM_WORLDS[key]
+        from .bam import read_bam
+        return _BAM_WORLDS.get((sam_path, fasta_path, chrom), lambda: read_bam(sam_path, fasta_path, chrom))
     raise FileNotFoundError("alignments %r: not a BAM file, a World, or a registered key" % (sam_path,))
 
 
@@ -68,17 +101,24 @@ def _exclude_rows(dct, chrom):
     return tuple(rows)
 
 
-def device_pack_for(dct, chrom, device=0):
-    """Packed + uploaded alignments of a contig (cached per source / filter / exclusion list)."""
-    world = _resolve(dct["sam_path"], chrom, dct.get("fasta_path"))
-    excl = _exclude_rows(dct, chrom)
-    key = (dct["sam_path"] if not isinstance(dct["sam_path"], World) else id(world), bool(dct.get("supplementary")),
-           excl, device)
-    if key not in _PACKS:
+def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, device=0):
+    """Packed + uploaded alignments of ONE contig -> (DevicePack, World).  The key carries the contig (one BAM holds many),
+    the FASTA, the flag filter, the exclusion list and the device; the SNP and the indel path share the entry."""
+    world = _resolve(sam_path, chrom, fasta_path)
+    if world.chrom != chrom:
+        raise ValueError("alignments of contig %r requested, the source holds %r" % (chrom, world.chrom))
+    src = id(world) if isinstance(sam_path, World) else sam_path
+    key = (src, fasta_path, chrom, bool(supplementary), excl, device)
+
+    def make():
         eng = get_engine(device)
-        hp = pack_world(world, supplementary=bool(dct.get("supplementary")), exclude=excl)
-        _PACKS[key] = (eng.upload(hp), world)
-    return _PACKS[key][0]
+        return (eng.upload(pack_world(world, supplementary=bool(supplementary), exclude=excl)), world)
+    return _PACKS.get(key, make)
+
+
+def device_pack_for(dct, chrom, device=0):
+    """Packed + uploaded alignments of contig `chrom` of dct['sam_path'] (cached per source / contig / filter / exclusions)."""
+    return device_pack(dct["sam_path"], dct.get("fasta_path"), chrom, dct.get("supplementary"), _exclude_rows(dct, chrom), device)[0]
 
 
 def get_snp_testing_candidates(dct, region, device=0):
@@ -108,4 +148,4 @@ def get_snp_testing_candidates(dct, region, device=0):
             sites.rev_dp.cpu().numpy()[valid].astype(np.float64))
 
 
-__all__ = ["get_snp_testing_candidates", "register_alignments", "device_pack_for", "_lib"]
+__all__ = ["get_snp_testing_candidates", "register_alignments", "device_pack_for", "device_pack", "release_contig", "_lib"]

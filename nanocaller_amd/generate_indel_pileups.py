@@ -25,10 +25,7 @@ import torch
 from . import _lib
 
 from .engine import get_engine
-from .generate_SNP_pileups import _exclude_rows, _resolve
-from .pack import pack_world
-
-_PACKS = {}
+from .generate_SNP_pileups import _exclude_rows, _resolve, device_pack
 
 
 def pick_variants(col_type, start, win_size, groups=None, extra=None):
@@ -148,12 +145,10 @@ def scan_indel_candidates(dct, chunk, device=0, haploid=False, extra_variants=No
     world = _resolve(first["sam_path"], first["chrom"], dct.get("fasta_path"))
     excl_rows = _exclude_rows(dct, first["chrom"])
     supp = bool(dct.get("supplementary"))
-    key = (id(world), supp, device)
     eng = get_engine(device)
     eng.use_torch_stream()
-    if key not in _PACKS:
-        _PACKS[key] = (eng.upload(pack_world(world, supplementary=supp)), world)
-    dp = _PACKS[key][0]
+    # the SNP path's pack of this contig (same key when no exclusion list is folded into its reference codes)
+    dp = device_pack(first["sam_path"], dct.get("fasta_path"), first["chrom"], supp, None, device)[0]
     excl = None
     if excl_rows:
         m = np.zeros(dp.n_tiles * dp.tile_size, np.uint8)
@@ -448,67 +443,9 @@ def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo,
     return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
 
 
-def get_indel_testing_candidates_haploid(dct, chunk, aligner=None, device=0):
-    """generate_indel_pileups_haploid.py:128-277 -> (pos, x, alleles): one read set per anchor, no HP split."""
-    from .bam import BamFile, read_fasta
-    chrom, start, end = chunk["chrom"], chunk["start"], chunk["end"]
-    window_before, window_after = 0, 160
-    if dct["seq"] == "pacbio":
-        window_after = 260
-    variants = scan_indel_candidates(dct, chunk, device, haploid=True)
-    empty = ([], [], [])
-    if not variants:
-        return empty
-    fasta = read_fasta(dct["fasta_path"], chrom)
-    chrom_length = len(fasta)
-    lo, hi = max(1, start - 200), end + 400
-    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if dct.get("supplementary") else 0x800)
-    anchors = sorted(v for v in variants if max(0, start - 10 - dct["win_size"]) < v <= end)
-    bf = BamFile(chunk["sam_path"])
-    d = bf.decode(chrom, max(1, start - 10 - dct["win_size"] - window_after), end + 1000, anchors=anchors, window_before=window_before,
-                  window_after=window_after, keep_mask=flag)
-    bf.close()
-    names = d["names"]
-    max_range = {0: max(10, dct["win_size"]), 1: 10}
-    out_pos, xs, alleles = [], [], []
-    if aligner is None and default_aligner() is star_aligner:
-        aligner = "device"
-    if aligner == "device":                                                         # every anchor's read set in one device call
-        todo, sets, refs = [], [], []
-        for v_pos, win in zip(anchors, d["windows"]):
-            a, b = v_pos - window_before, min(chrom_length, v_pos + window_after + 1)
-            ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N") for p in range(a, b))
-            if "N" in ref:
-                continue
-            picked = _sample_set({names[r]: text for r, text in win}, dct["mincov"], dct["maxcov"])
-            if picked is None:
-                continue
-            for q in picked[1]:
-                bad = q.translate(_DROP_AGTC)
-                if bad:
-                    raise KeyError(bad[0])
-            todo.append(v_pos)
-            sets.append(picked[1])
-            refs.append(ref)
-        if not todo:
-            return empty
-        eng = get_engine(device)
-        eng.use_torch_stream()
-        x, cns, _ = eng.star_msa_tensor(sets, refs)
-        lut = np.frombuffer(b"AGTC", np.uint8)
-        preds = allele_prediction_batch([lut[c].tobytes().decode() for c in cns], refs, [max_range[variants[v]] for v in todo])
-        return (todo, x.cpu().numpy().astype(np.float64), preds)
-    for v_pos, win in zip(anchors, d["windows"]):
-        ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
-                      for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))
-        if "N" in ref:
-            continue
-        d_tot = {names[r]: text for r, text in win}
-        ft, _, mt, altt, reft = msa(d_tot, ref, v_pos, dct["mincov"], dct["maxcov"], aligner, device)
-        if ft:
-            out_pos.append(v_pos)
-            xs.append(mt)
-            alleles.append(allele_prediction(altt, reft, max_range[variants[v_pos]]))
-    if not out_pos:
-        return empty
-    return (out_pos, np.array(xs), alleles)
+def __getattr__(name):
+    # round-1 location of the haploid function; the reference imports it from generate_indel_pileups_haploid (indelCaller.py:9)
+    if name == "get_indel_testing_candidates_haploid":
+        from .generate_indel_pileups_haploid import get_indel_testing_candidates_haploid
+        return get_indel_testing_candidates_haploid
+    raise AttributeError(name)

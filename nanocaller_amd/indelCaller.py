@@ -4,7 +4,11 @@
 `indel_run` is the worker loop itself: per chunk the candidates, tensors and allele strings of
 generate_indel_pileups.get_indel_testing_candidates[_haploid] (window scan K7, star alignment on the device or MUSCLE, rows ->
 tensor K8, allele_prediction), `Indel_model` / `haploid_Indel_model` on the GPU (nc_indel_forward, K9), then the rules.
-Phasing (WhatsHap) and the bcftools/rtg merge of the SNP and indel files are out of scope.
+`call_manager` / `caller` / `phase_run` keep the reference's job structure (indelCaller.py:192-400): per-contig 'phase' jobs
+that release that contig's indel chunks, then 'indel' jobs; the merges that the reference delegates to bcftools / bgzip /
+tabix / rtg are done by vcfio (sorted BGZF + CSI).  WhatsHap itself stays an optional external step (out of scope,
+SURVEY.md section 2): when `whatshap` is on PATH the reference's two commands are run, otherwise the contig's SNP records pass
+through unphased and the indel chunks read `params['sam_path']` as it is (a BAM that already carries HP / PS tags works).
 
 Arithmetic note: in the reference `batch_prob_all` is a float32 TensorFlow tensor, so QUAL/GQ are evaluated in
 float32 (`1e-6 + 1 - p` etc.); that is reproduced with explicit np.float32 operations.
@@ -14,6 +18,11 @@ from __future__ import annotations
 import numpy as np
 
 from .weights import get_indel_model  # noqa: F401  (same name as indelCaller.py:26)
+
+# keys of the `params` dict this module and the indel featurisers read (all of them are in the dict NanoCaller:45-53 builds)
+PARAM_KEYS = frozenset(['chunks_list', 'mode', 'snp_vcf', 'regions_list', 'sam_path', 'fasta_path', 'mincov', 'maxcov', 'indel_model',
+                        'vcf_path', 'prefix', 'sample', 'seq', 'del_t', 'ins_t', 'impute_indel_phase', 'supplementary', 'exclude_bed',
+                        'win_size', 'small_win_size', 'enable_whatshap', 'suppress_progress', 'phase_qual_score', 'verbose'])
 
 rev_gt_map = {0: 'hom-ref', 1: 'hom-alt', 2: 'het-ref', 3: 'het-alt'}       # indelCaller.py:14
 _F = np.float32
@@ -112,7 +121,8 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
 
     from . import _lib
     from .engine import get_engine
-    from .generate_indel_pileups import get_indel_testing_candidates, get_indel_testing_candidates_haploid
+    from .generate_indel_pileups import get_indel_testing_candidates
+    from .generate_indel_pileups_haploid import get_indel_testing_candidates_haploid
     from .weights import Weights
     curr_vcf_path = os.path.join(params['intermediate_indel_files_dir'], '%s.%d.indel.vcf' % (params['prefix'], worker_id))
     indel_files_list.append(curr_vcf_path)
@@ -157,3 +167,195 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
             os.fsync(f.fileno())
             counter_Q.put(1)
     return curr_vcf_path
+
+
+# ------------------------------------------------------------------------------------------- job structure (:192-400)
+def _whatshap_available():
+    import shutil
+    return all(shutil.which(b) for b in ("whatshap", "samtools"))
+
+
+def phase_run(contig_dict, params, indel_dict, job_Q, counter_Q, phased_snp_files_list):
+    """indelCaller.py:192-262 for one contig: split the SNP calls of the contig at `phase_qual_score`, phase the confident
+    ones and haplotag the reads (WhatsHap: external, optional), write <contig>.snps.phased.vcf.gz (+ the low-quality rest),
+    then release the contig's indel chunks with chunk['sam_path'] = the haplotagged BAM (or params['sam_path'])."""
+    import os
+
+    from . import vcfio
+    from .utils import run_cmd
+    contig = contig_dict['name']
+    phase_dir = params['intermediate_phase_files_dir']
+    out_vcf = os.path.join(phase_dir, '%s.snps.phased.vcf.gz' % contig)
+    hdr, recs = vcfio.read_vcf_gz(params['snp_vcf'])
+    recs = [ln for ln in recs if ln.split('\t', 1)[0] == contig]             # bcftools view -r <contig>
+    header = ''.join(hdr)
+    sam_path = params['sam_path']
+    if contig_dict['ploidy'] == 'haploid':                                     # :193-200
+        vcfio.write_sorted_vcf(out_vcf, header, recs, [contig])
+        phased_snp_files_list.append(out_vcf)
+    else:
+        q = float(params['phase_qual_score'])
+        hi = [ln for ln in recs if float(ln.split('\t', 6)[5]) >= q]           # -i "QUAL>=q" (:233)
+        lo = [ln for ln in recs if not float(ln.split('\t', 6)[5]) >= q]
+        lowq_vcf = os.path.join(phase_dir, '%s.snps.lowq.unphased.vcf.gz' % contig)
+        vcfio.write_sorted_vcf(lowq_vcf, header, lo, [contig])
+        phased = False
+        if _whatshap_available() and isinstance(sam_path, str):
+            unph = os.path.join(phase_dir, '%s.snps.unphased.vcf' % contig)
+            raw = os.path.join(phase_dir, '%s.snps.phased.raw.vcf' % contig)
+            with open(unph, 'w') as f:
+                f.write(header + ''.join(hi))
+            extra = '--distrust-genotypes --include-homozygous' if params.get('enable_whatshap') else ''
+            run_cmd("whatshap phase %s %s -o %s -r %s --ignore-read-groups --chromosome %s %s" % (
+                unph, sam_path, raw, params['fasta_path'], contig, extra), verbose=params.get('verbose'))
+            if os.path.exists(raw):
+                _, ph = vcfio.read_vcf_gz(raw)
+                hi = [ln for ln in ph if ln.rstrip('\n').split('\t')[9].split(':')[0] not in ('0/0', '0|0')]   # -e 'GT="0\\0"' (:239)
+                vcfio.write_sorted_vcf(out_vcf, header, hi, [contig])
+                tagged = os.path.join(phase_dir, '%s.phased.bam' % contig)
+                run_cmd("whatshap haplotag --ignore-read-groups --ignore-linked-read --reference %s %s %s --regions %s:%d-%d "
+                        "--tag-supplementary -o - | samtools view -b -1 --write-index -o %s" % (
+                            params['fasta_path'], out_vcf, sam_path, contig, contig_dict['start'], contig_dict['end'], tagged),
+                        verbose=params.get('verbose'))
+                if os.path.exists(tagged):
+                    sam_path, phased = tagged, True
+        if not phased:
+            vcfio.write_sorted_vcf(out_vcf, header, hi, [contig])
+        phased_snp_files_list.append(out_vcf)
+        phased_snp_files_list.append(lowq_vcf)
+    if params['mode'] == 'snps':
+        counter_Q.put(1)
+    else:
+        for chunk in indel_dict.get(contig, []):
+            chunk['sam_path'] = sam_path                                       # :258
+            job_Q.put(('indel', chunk))
+        indel_dict.pop(contig, None)
+
+
+def caller(params, job_Q, counter_Q, indel_dict, phased_snp_files_list, indel_files_list, device=0, worker_id=1, aligner=None):
+    """indelCaller.py:264-276: 'phase' jobs first (each releases its contig's indel jobs), then the indel worker loop"""
+    import queue
+    while len(indel_dict) > 0 or not job_Q.empty():
+        try:
+            job = job_Q.get(block=False)
+        except queue.Empty:
+            continue
+        if job[0] == 'phase':
+            phase_run(job[1], params, indel_dict, job_Q, counter_Q, phased_snp_files_list)
+        elif job[0] == 'indel':
+            job_Q.put(job)
+            indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=device, worker_id=worker_id, aligner=aligner)
+
+
+def _non_snp(line):
+    """rtg vcffilter --non-snps-only (:391): keep a record unless every ALT allele has the length of REF"""
+    f = line.split('\t', 5)
+    return any(len(a) != len(f[3]) for a in f[4].split(','))
+
+
+def call_manager(params, devices=None, aligner=None):
+    """Same contract as indelCaller.call_manager (indelCaller.py:290-400): -> {'snps': <prefix>.snps.phased.vcf.gz or None,
+    'indels': <prefix>.indels.vcf.gz or None, 'final': <prefix>.vcf.gz or None}; every file BGZF + .csi.
+    params['mode']: 'snps' (phase jobs only), 'indels' (indel jobs on params['sam_path']), 'all' (both).
+    Under torch.distributed every rank calls this: rank 0 runs the (cheap) phase jobs, the indel chunks are sharded over
+    the ranks (contiguous blocks), rank 0 merges the per-rank files.  Deviation, stated: `rtg vcfdecompose` (splitting of
+    complex records into atoms) is not reproduced; the records the indel rules write are already single indel alleles."""
+    import os
+    import queue
+
+    import torch.distributed as dist
+
+    from . import shard, vcfio
+    from .engine import local_device
+    from .utils import make_and_remove_path
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    device = local_device(devices, rank)
+    mode = params['mode']
+    contigs_list = {}
+    for x in params['regions_list']:                                           # :299-305
+        c = contigs_list.setdefault(x[0], {'name': x[0], 'start': x[1], 'end': x[2], 'ploidy': x[3]})
+        c['start'], c['end'] = min(x[1], c['start']), max(x[2], c['end'])
+    if mode in ('indels', 'all'):
+        params['intermediate_indel_files_dir'] = os.path.join(params['vcf_path'], 'intermediate_indel_files')
+    if mode in ('snps', 'all'):
+        params['intermediate_phase_files_dir'] = os.path.join(params['vcf_path'], 'intermediate_phase_files')
+    if rank == 0:
+        for k in ('intermediate_indel_files_dir', 'intermediate_phase_files_dir'):
+            if k in params:
+                make_and_remove_path(params[k])
+    shard.barrier()
+    job_Q, counter_Q = queue.Queue(), queue.Queue()
+    indel_dict, phased_snp_files_list, indel_files_list = {}, [], []
+    mine = shard.shard_chunks(params['chunks_list'], rank, world) if mode != 'snps' else []
+    if mode == 'indels':
+        for chunk in mine:
+            chunk['sam_path'] = params['sam_path']                             # :322
+            job_Q.put(('indel', chunk))
+    else:
+        if mode == 'all':
+            for chunk in mine:
+                indel_dict.setdefault(chunk['chrom'], []).append(chunk)
+        if rank == 0:
+            for cd in contigs_list.values():
+                job_Q.put(('phase', cd))
+    if mode == 'all' and world > 1:
+        # phase on rank 0 first, then every rank releases its own chunks against the (possibly haplotagged) BAMs
+        if rank == 0:
+            while not job_Q.empty():
+                job = job_Q.get()
+                phase_run(job[1], dict(params, mode='snps'), {}, queue.Queue(), queue.Queue(), phased_snp_files_list)
+        shard.barrier()
+        for name in list(indel_dict):
+            tagged = os.path.join(params['intermediate_phase_files_dir'], '%s.phased.bam' % name)
+            for chunk in indel_dict.pop(name):
+                chunk['sam_path'] = tagged if os.path.exists(tagged) else params['sam_path']
+                job_Q.put(('indel', chunk))
+    caller(params, job_Q, counter_Q, indel_dict, phased_snp_files_list, indel_files_list, device=device, worker_id=rank + 1,
+           aligner=aligner)
+    shard.barrier()
+    output_files = {'snps': None, 'indels': None, 'final': None}
+    if mode in ('snps', 'all'):
+        output_files['snps'] = os.path.join(params['vcf_path'], '%s.snps.phased.vcf.gz' % params['prefix'])
+    if mode in ('indels', 'all'):
+        output_files['indels'] = os.path.join(params['vcf_path'], '%s.indels.vcf.gz' % params['prefix'])
+    if mode == 'all':
+        output_files['final'] = os.path.join(params['vcf_path'], '%s.vcf.gz' % params['prefix'])
+    if rank != 0:
+        shard.barrier()
+        return output_files
+    contigs = list(contigs_list)
+    snp_hdr, snp_recs = None, []
+    if output_files['snps']:                                                   # bcftools concat -a of the per-contig files (:360-366)
+        for fn in phased_snp_files_list:
+            h, r = vcfio.read_vcf_gz(fn)
+            snp_hdr = snp_hdr or ''.join(h)
+            snp_recs += r
+        if snp_hdr is None:
+            snp_hdr = ''.join(vcfio.read_vcf_gz(params['snp_vcf'])[0])
+        vcfio.write_sorted_vcf(output_files['snps'], snp_hdr, snp_recs, contigs)
+    indel_recs = []
+    if output_files['indels']:
+        header = INDEL_VCF_HEADER.format(contigs=''.join('##contig=<ID=%s>\n' % c for c in contigs), sample=params['sample'])
+        raw_indel_vcf = os.path.join(params['intermediate_indel_files_dir'], '%s.raw.indel.vcf' % params['prefix'])
+        files = [os.path.join(params['intermediate_indel_files_dir'], '%s.%d.indel.vcf' % (params['prefix'], r + 1)) for r in range(world)]
+        with open(raw_indel_vcf, 'w') as outfile:                              # :370-388
+            outfile.write(header)
+            for fn in files:
+                if os.path.exists(fn):
+                    with open(fn) as fd:
+                        lines = fd.readlines()
+                    outfile.writelines(lines)
+                    indel_recs += lines
+        if not params.get('suppress_progress'):
+            import datetime
+            print('\n%s: Compressing and indexing indel calls.' % str(datetime.datetime.now()))
+        indel_recs = [ln for ln in indel_recs if _non_snp(ln)]
+        vcfio.write_sorted_vcf(output_files['indels'], header, indel_recs, contigs)
+    if output_files['final']:                                                  # bcftools concat -a snps indels (:397)
+        # one header for both record kinds: the SNP header plus the indel FORMAT lines it lacks
+        extra = [ln for ln in INDEL_VCF_HEADER.split('\n') if ln.startswith('##FORMAT') and ln not in snp_hdr]
+        lines = snp_hdr.rstrip('\n').split('\n')
+        final_hdr = '\n'.join(lines[:-1] + extra + lines[-1:]) + '\n'
+        vcfio.write_sorted_vcf(output_files['final'], final_hdr, snp_recs + indel_recs, contigs)
+    shard.barrier()
+    return output_files

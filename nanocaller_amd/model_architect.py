@@ -1,8 +1,9 @@
-"""Host-side mirror of the reference's model classes (nanocaller_src/model_architect*.py).
+"""Host-side mirror of the reference's nanocaller_src/model_architect.py: `SNP_model`.
 
-The four classes keep their names and call conventions (callable on numpy batches, `load_weights`), but
-the forward pass is the HIP CNN of libnanocaller_hip.so (nc_snp_forward / nc_indel_forward); weights come
-from the converted `.ncw` files (nanocaller_amd/weights.py).
+The class keeps its name and call convention (callable on numpy batches, `load_weights(...).expect_partial()`), but the
+forward pass is the HIP CNN of libnanocaller_hip.so (nc_snp_forward); weights come from the converted `.ncw` files
+(nanocaller_amd/weights.py).  The three other model classes live in the modules the reference imports them from
+(snpCaller.py:6-8, indelCaller.py:6-9): model_architect_SNP_haploid, model_architect_indel, model_architect_indels_haploid.
 """
 from __future__ import annotations
 
@@ -11,7 +12,7 @@ import torch
 
 from . import _lib
 from .engine import get_engine
-from .weights import Weights
+from .weights import Weights, resolve_weight_file
 
 
 class _Model:
@@ -22,13 +23,17 @@ class _Model:
         self._w = None
 
     def load_weights(self, path):
-        """path: an .ncw file (the reference passes a TF checkpoint prefix / .h5, snpCaller.py:71,78)."""
-        self._w = Weights(path)
+        """path: an .ncw file, or the path the reference passes (TF checkpoint prefix / .h5, snpCaller.py:71,78) which is
+        mapped to the converted file of that model"""
+        self._w = Weights(resolve_weight_file(path, self.KIND))
         get_engine(self._device).load_weights(self.KIND, self._w)
         return self
 
     def expect_partial(self):                     # keras idiom used at snpCaller.py:71
         return self
+
+    def build(self, input_shape=None):            # indelCaller.py:56
+        return None
 
     def _engine(self):
         if self._w is None:
@@ -63,29 +68,15 @@ class SNP_model(_Model):
         return outs + [gt.cpu().numpy()]
 
 
-class haploid_SNP_model(_Model):
-    """model_architect_SNP_haploid.py:7-53.  inputs = [x (B,5,41,5), ref (B,4)] -> (B,4) softmax."""
-    KIND = _lib.MODEL_SNP_HAP
-
-    def __call__(self, inputs):
-        x, ref = inputs
-        eng = self._engine()
-        dev = eng.device
-        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
-        probs, _ = eng.snp_forward(self.KIND, xd, torch.from_numpy(_ref_code(ref)).to(dev), None)
-        return probs.cpu().numpy()
-
-
-class Indel_model(_Model):
-    """model_architect_indel.py:6-48.  x (B,15,128,2) -> (B,4) softmax."""
-    KIND = _lib.MODEL_INDEL
-
-    def __call__(self, x):
-        eng = self._engine()
-        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(eng.device)
-        return eng.indel_forward(self.KIND, xd).cpu().numpy()
-
-
-class haploid_Indel_model(Indel_model):
-    """model_architect_indels_haploid.py:7-48.  x (B,5,128,2) -> (B,1) sigmoid."""
-    KIND = _lib.MODEL_INDEL_HAP
+def __getattr__(name):
+    # the three other classes were importable from here in round 1
+    if name == "haploid_SNP_model":
+        from .model_architect_SNP_haploid import haploid_SNP_model
+        return haploid_SNP_model
+    if name == "Indel_model":
+        from .model_architect_indel import Indel_model
+        return Indel_model
+    if name == "haploid_Indel_model":
+        from .model_architect_indels_haploid import haploid_Indel_model
+        return haploid_Indel_model
+    raise AttributeError(name)

@@ -56,7 +56,10 @@ def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, s
     flag = np.asarray(read_flag)
     filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT      # :151-154
     keep = np.ascontiguousarray((flag & filt) == 0, np.uint8)
-    strand = np.ascontiguousarray(((flag & 0x910) // 16) != 0, np.uint8)     # :143
+    # strand: the reference looks the read NAME up in a table of the primary alignments' `(flag & 0x910) // 16` (:141-143),
+    # i.e. bit 0x10 of a primary record.  With dct['supplementary'] a supplementary record is counted on its own 0x10 bit
+    # (the reference takes its primary's, and raises KeyError when that is outside the fetch window).
+    strand = np.ascontiguousarray((flag & 0x10) != 0, np.uint8)
     if hap is not None:
         strand = np.ascontiguousarray(strand | (np.asarray(hap, np.uint8) & 3) << 1)   # bits 1-2: HP tag
     n = int(rs.shape[0])

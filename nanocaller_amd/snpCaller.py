@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _lib
 from .engine import get_engine
-from .generate_SNP_pileups import device_pack_for
+from .generate_SNP_pileups import device_pack_for, release_contig
 from .weights import Weights, get_SNP_model  # noqa: F401  (re-exported, same name as the reference)
 
 num_to_base_map = {0: 'A', 1: 'G', 2: 'T', 3: 'C'}                 # snpCaller.py:14
@@ -163,6 +163,11 @@ VCF_HEADER = (                                                      # snpCaller.
     '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample}\n')
 
 
+# keys of the `params` dict this module reads (all of them are in the dict NanoCaller:28-35 builds)
+PARAM_KEYS = frozenset(['chunks_list', 'regions_list', 'sam_path', 'fasta_path', 'mincov', 'maxcov', 'min_allele_freq', 'min_nbr_sites',
+                        'threshold', 'snp_model', 'vcf_path', 'prefix', 'sample', 'seq', 'supplementary', 'exclude_bed',
+                        'suppress_progress', 'disable_coverage_normalization'])
+
 _WEIGHTS = {}
 
 
@@ -299,12 +304,18 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             if pending is not None:
                 pending.result()                                    # keeps the records in group order; re-raises errors
             pending = pool.submit(emit, f, chrom, ploidy, r, grp)
-        for (chrom, ploidy), grp in groups.items():
+        keys = list(groups)
+        last_use = {chrom: i for i, (chrom, _) in enumerate(keys)}         # last group of every contig
+        for i, (chrom, ploidy) in enumerate(keys):
+            grp = groups[(chrom, ploidy)]
             grp.sort(key=lambda c: c['start'])
             call = call_chunks(params, grp, device, defer=True)     # enqueued behind the previous group's CNN
             if in_flight is not None:
                 collect()
-            in_flight = (chrom, ploidy, call, grp)
+                done = keys[i - 1][0]
+                if last_use[done] == i - 1:
+                    release_contig(done)     # a genome is walked contig by contig: drop the decoded alignments and the HBM
+            in_flight = (chrom, ploidy, call, grp)                  # pack of the one just finished
         if in_flight is not None:
             collect()
         if pending is not None:
@@ -326,12 +337,14 @@ def _sort_key(line, order):
     return (order.get(f[0], 1 << 30), int(f[1]))
 
 
-def call_manager(params, devices=(0,)):
+def call_manager(params, devices=None):
     """Same contract as snpCaller.call_manager (snpCaller.py:213-287): returns the PASS VCF path
     <vcf_path>/<prefix>.snps.vcf.gz (also writes <prefix>.unfiltered.snps.vcf.gz).
     Under torch.distributed (one process per GPU, e.g. torchrun) every rank calls this function: the chunk list
-    is sharded over the ranks, each rank writes its own worker file, rank 0 merges (other ranks return the path)."""
+    is sharded over the ranks, each rank works on ITS GPU (engine.local_device: LOCAL_RANK, or devices[local rank]) and
+    writes its own worker file, rank 0 merges (other ranks return the path)."""
     from . import shard
+    from .engine import local_device
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
     chunks_Q = queue.Queue()
@@ -345,7 +358,7 @@ def call_manager(params, devices=(0,)):
             shutil.rmtree(params['intermediate_snp_files_dir'])
         os.makedirs(params['intermediate_snp_files_dir'])
     shard.barrier()
-    caller(params, chunks_Q, counter_Q, snp_files, device=devices[0], worker_id=rank + 1)
+    caller(params, chunks_Q, counter_Q, snp_files, device=local_device(devices, rank), worker_id=rank + 1)
     shard.barrier()
     all_path_ = os.path.join(params['vcf_path'], '%s.snps.vcf.gz' % params['prefix'])
     if rank != 0:

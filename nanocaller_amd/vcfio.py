@@ -136,3 +136,33 @@ def write_vcf_gz_with_csi(path, header, lines_bytes, contigs, tid, pos1, ref_len
     idx = csi_bytes(contigs, tid, pos1 - 1, pos1 - 1 + np.asarray(ref_len, np.int64), vb, ve)
     bgzf_write(path + ".csi", idx)
     return coff
+
+
+def read_vcf_gz(path):
+    """-> (header lines, record lines) of a (BGZF-)gzipped or plain VCF; lines keep their newline"""
+    import gzip
+    op = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    hdr, recs = [], []
+    with op(path, "rt") as f:
+        for ln in f:
+            (hdr if ln.startswith("#") else recs).append(ln)
+    return hdr, recs
+
+
+def write_sorted_vcf(path, header, lines, contigs):
+    """`bcftools sort | bgzip && tabix -p vcf --csi` of text records: stable sort by (contig order, POS), BGZF + .csi.
+    -> number of records.  Contigs not in `contigs` are appended in order of first appearance."""
+    contigs = list(contigs)
+    order = {c: i for i, c in enumerate(contigs)}
+    keyed = []
+    for ln in lines:
+        f = ln.split("\t", 4)
+        if f[0] not in order:
+            order[f[0]] = len(contigs)
+            contigs.append(f[0])
+        keyed.append((order[f[0]], int(f[1]), len(f[3]), ln))
+    keyed.sort(key=lambda k: (k[0], k[1]))
+    body = "".join(k[3] for k in keyed).encode()
+    write_vcf_gz_with_csi(path, header, body, contigs, np.array([k[0] for k in keyed], np.int64), np.array([k[1] for k in keyed], np.int64),
+                          np.array([k[2] for k in keyed], np.int64), np.array([len(k[3].encode()) for k in keyed], np.int64))
+    return len(keyed)

@@ -140,3 +140,20 @@ def get_indel_model(indel_model):
     if isinstance(indel_model, str) and indel_model.endswith(".ncw") and os.path.exists(indel_model):
         return indel_model
     return None
+
+
+def resolve_weight_file(path, kind):
+    """What the model classes' load_weights() accepts: an .ncw file, or a path in the reference's layout -- a TF checkpoint
+    prefix `.../release_data/<family>_models/<SNPs|indels>/<dir>/<model-N>` (snpCaller.py:16-34, indelCaller.py:17-24) or a
+    haploid Keras `.h5` -- which is mapped to the converted file of the same model (the checkpoint itself is not read)."""
+    if path.endswith(".ncw"):
+        return path
+    if path.endswith(".h5"):
+        return os.path.join(WEIGHT_DIR, "snp_hap__CHM13.ncw" if kind in (KIND_SNP, KIND_SNP_HAP) else "indel_hap__CHM13.ncw")
+    parts = os.path.normpath(path).split(os.sep)
+    if len(parts) >= 4:
+        stem = "snp" if kind in (KIND_SNP, KIND_SNP_HAP) else "indel"
+        cand = os.path.join(WEIGHT_DIR, "%s__%s__%s__%s.ncw" % (stem, parts[-2], parts[-1], parts[-4]))
+        if os.path.exists(cand):
+            return cand
+    raise FileNotFoundError("no converted weights for %r (expected an .ncw file or a release_data path)" % path)

@@ -20,7 +20,7 @@
  * Input boundary = decoded alignments, read-major: read r covers reference positions
  * [start[r], end[r]) (1-based) and codes[off[r] + p - start[r]] is its base code at p
  * (A=0 G=1 T=2 C=3, deletion/N=4: generate_SNP_pileups.py:104).  keep[r]=0 drops a read
- * (pileup flag filter, generate_SNP_pileups.py:151-157).  strand[r] = (flag & 0x910)/16 != 0.
+ * (pileup flag filter, generate_SNP_pileups.py:151-157).  strand[r] = bit 0x10 of the record's flag (:143 on a primary record).
  */
 #include <math.h>
 #include <stdint.h>

@@ -51,7 +51,7 @@ def _reads(world, supplementary=False):
     from nanocaller_amd.synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
     filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT
     keep = ((world.read_flag & filt) == 0).astype(np.uint8)
-    strand = (((world.read_flag & 0x910) // 16) != 0).astype(np.uint8)
+    strand = ((world.read_flag & 0x10) != 0).astype(np.uint8)       # :143 for a primary record; see pack.pack_reads
     return (np.ascontiguousarray(world.read_start, np.int32), np.ascontiguousarray(world.read_end, np.int32),
             np.ascontiguousarray(world.read_off, np.int64), np.ascontiguousarray(world.codes, np.uint8),
             strand, keep)

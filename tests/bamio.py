@@ -62,8 +62,8 @@ class BgzfWriter:
 
 
 def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
-    """records: list of dict(name, flag, pos0, cigar=[(op,len)...] with op in 'MIDNSHP=X', seq (str), tags={'HP':1,...})
-    in coordinate order."""
+    """records: list of dict(name, flag, pos0, cigar=[(op,len)...] with op in 'MIDNSHP=X', seq (str), tags={'HP':1,...},
+    optional tid = index into [(chrom, length)] + other_refs, default 0) in coordinate order."""
     refs = [(chrom, length)] + list(other_refs)
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     w = BgzfWriter(path)
@@ -72,9 +72,10 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
         hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
     w.write(hdr)
     w.flush()
-    lin = {}
+    lins = [dict() for _ in refs]
     ops = "MIDNSHP=X"
     for r in records:
+        lin = lins[r.get("tid", 0)]
         cig = r["cigar"]
         rlen = sum(ln for op, ln in cig if op in "MDN=X")
         name = r["name"].encode() + b"\0"
@@ -84,13 +85,15 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
             packed[i >> 1] |= _NT16.get(c, 15) << (4 if i % 2 == 0 else 0)
         tags = b""
         for k, v in r.get("tags", {}).items():
-            if isinstance(v, str):
+            if isinstance(v, (list, tuple)):                 # B,I array (e.g. the CG tag)
+                tags += k.encode() + b"BI" + struct.pack("<I", len(v)) + b"".join(struct.pack("<I", x) for x in v)
+            elif isinstance(v, str):
                 tags += k.encode() + b"Z" + v.encode() + b"\0"
             elif 0 <= v < 256:
                 tags += k.encode() + b"C" + struct.pack("<B", v)
             else:
                 tags += k.encode() + b"i" + struct.pack("<i", v)
-        body = struct.pack("<iiBBHHHiiii", 0, r["pos0"], len(name), 60, reg2bin(r["pos0"], r["pos0"] + max(1, rlen)), len(cig),
+        body = struct.pack("<iiBBHHHiiii", r.get("tid", 0), r["pos0"], len(name), 60, reg2bin(r["pos0"], r["pos0"] + max(1, rlen)), len(cig),
                            r["flag"], len(seq), -1, -1, 0) + name + b"".join(struct.pack("<I", (ln << 4) | ops.index(op)) for op, ln in cig) + \
             bytes(packed) + b"\xff" * len(seq) + tags
         voff = w.tell()
@@ -100,18 +103,17 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
         w.write(struct.pack("<i", len(body)) + body)
     w.close()
     if write_bai:
-        n_intv = (max(lin) + 1) if lin else 0
-        arr = [0] * n_intv
-        last = 0
-        for k in range(n_intv):           # samtools fills empty windows with the previous offset
-            if k in lin:
-                last = lin[k]
-            arr[k] = last
         with open(path + ".bai", "wb") as f:
             f.write(b"BAI\1" + struct.pack("<i", len(refs)))
-            f.write(struct.pack("<i", 0) + struct.pack("<i", n_intv) + b"".join(struct.pack("<Q", v) for v in arr))
-            for _ in refs[1:]:
-                f.write(struct.pack("<ii", 0, 0))
+            for lin in lins:
+                n_intv = (max(lin) + 1) if lin else 0
+                arr = [0] * n_intv
+                last = 0
+                for k in range(n_intv):           # samtools fills empty windows with the previous offset
+                    if k in lin:
+                        last = lin[k]
+                    arr[k] = last
+                f.write(struct.pack("<i", 0) + struct.pack("<i", n_intv) + b"".join(struct.pack("<Q", v) for v in arr))
 
 
 def write_fasta(path, chrom, seq, width=60, with_fai=True, extra=()):

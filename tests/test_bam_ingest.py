@@ -132,3 +132,38 @@ def test_parallel_region_decode_equals_sequential(files):
     del par, got
     gc.collect()
     assert int(codes.astype(np.int64).sum()) == ref_sum and codes.flags.writeable
+
+
+def test_records_without_bases_and_long_cigars_in_the_cg_tag(tmp_path):
+    """(a) SEQ '*' (l_seq 0, minimap2's secondary alignments) with a long CIGAR must not be read past the record: aligned
+    positions decode as 'N' (code 4) and the pileup flag filter drops the read later; (b) SAMv1 4.2.2: a CIGAR of > 65535
+    operations lives in the CG:B,I tag behind the placeholder <l_seq>S<ref_len>N -- the real one must be decoded"""
+    ops = "MIDNSHP=X"
+    ref = "ACGT" * 500
+    seq = "ACGTACGTAC" + "GG" + "TACGTACG"                    # 10M 2I 3D 8M over ref positions 101..121
+    real = [("M", 10), ("I", 2), ("D", 3), ("M", 8)]
+    cg = [(ln << 4) | ops.index(op) for op, ln in real]
+    recs = [dict(name="noseq", flag=0x100, pos0=40, cigar=[("M", 300), ("D", 4), ("M", 200)], seq="", tags={}),
+            dict(name="short", flag=0, pos0=60, cigar=[("M", 30)], seq="ACGTA", tags={}),
+            dict(name="longcig", flag=0, pos0=100, cigar=[("S", len(seq)), ("N", 21)], seq=seq, tags={"HP": 2, "CG": cg, "PS": 77}),
+            dict(name="plain", flag=16, pos0=100, cigar=real, seq=seq, tags={})]
+    bam, fa = str(tmp_path / "c.bam"), str(tmp_path / "c.fa")
+    bamio.write_bam(bam, "chrT", len(ref), recs)
+    bamio.write_fasta(fa, "chrT", ref)
+    w = read_bam(bam, fa, "chrT", keep_seq=True)
+    assert w.names == ["noseq", "short", "longcig", "plain"]
+    assert (w.read_start[0], w.read_end[0]) == (41, 41 + 504) and set(w.read_codes(0).tolist()) == {4}
+    assert set(w.read_codes(1).tolist()) == {4}
+    # the CG record decodes exactly like the same alignment with an inline CIGAR
+    assert (w.read_start[2], w.read_end[2]) == (w.read_start[3], w.read_end[3]) == (101, 122)
+    assert np.array_equal(w.read_codes(2), w.read_codes(3))
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    assert ev_pos[ev_off[2]:ev_off[3]].tolist() == ev_pos[ev_off[3]:ev_off[4]].tolist() == [110, 110]
+    assert ev_len[ev_off[2]:ev_off[3]].tolist() == [2, -3]
+    assert w.meta["hap"].tolist() == [0, 0, 2, 0] and w.meta["ps"][2] == 77
+    # pass-2 windows over the record without bases are empty strings, never out-of-range reads
+    bf = BamFile(bam)
+    d = bf.decode("chrT", 1, 600, anchors=[105, 300], window_before=0, window_after=160, keep_mask=0x4)
+    bf.close()
+    win = {d["names"][r]: t for r, t in d["windows"][0]}
+    assert win["noseq"] == "" and win["longcig"] == win["plain"] and len(win["plain"]) > 5
