@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 4   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
-                              3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async */
+#define NC_ABI_VERSION 5   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+                              3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
+                              5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -62,6 +63,11 @@ int nc_malloc(nc_ctx *ctx, size_t bytes, void **dev);
 int nc_free(nc_ctx *ctx, void *dev);
 int nc_memcpy_h2d(nc_ctx *ctx, void *dev, const void *host, size_t bytes);
 int nc_memcpy_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes);
+/* Asynchronous device -> host transfer on `stream` (NULL: the context's stream).  Small transfers (<= 64 KB) into page-locked,
+ * device-accessible memory are written by a copy kernel instead of hipMemcpyAsync: every hipMemcpyAsync, of either direction,
+ * queues in order behind a large host -> device copy in flight (a contig's wire pack: ~7 ms), a kernel does not -- the scan
+ * totals the host waits for mid-step go this way.  Bulk results use the copy engine. */
+int nc_d2h_async(nc_ctx *ctx, void *stream, void *host, const void *dev, size_t bytes);
 /* Wall-clock of the last timed call on this context's stream, measured with HIP events (ms);
  * `which`: 0 scan kernel, 1 featurize kernel, 2 CNN forward (all kernels), 3 indel tensor / scan,
  * 4 sum over the launches of the fused SNP trunk kernel in the last forward, 5 number of those launches. */
@@ -113,6 +119,47 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
                  int32_t tile_size, int32_t tile_pos0, int32_t n_tiles,
                  uint8_t *codes_out, int64_t codes_len, int32_t *tile_off, nc_tile_entry *tile_ent,
                  int64_t n_entries);
+
+/* ------------------------------------------------------------------ wire pack: host -> device transfer form of the read pack
+ * The reference feeds every chunk from host memory (snpCaller.py:86, generate_SNP_pileups.py:156); here a contig's decoded
+ * alignments cross PCIe once.  At 1 B per pileup entry that is 1.9 GB for a chr20-sized 30x contig (~35 ms of PCIe Gen5
+ * against ~11.5 ms of GPU work), but 92 % of an ONT read's positions (99.8 % of a HiFi read's) carry the reference base.
+ * The transfer form therefore holds only the differences against the reference:
+ *   rd_start / rd_end / slot_off   the kept reads in slot order (slot_off[r] = byte offset of read r's slot in `codes`);
+ *   ref_wire                       one byte per reference position of the tile grid: bits 0-2 base code (A0 G1 T2 C3, 4 =
+ *                                  unknown), bit 3 = column skipped by the scan (soft-masked / non-AGTC, quirk E4, or
+ *                                  excluded, :161) -- so ref_code[i] = (ref_wire[i] & 8) ? 4 : (ref_wire[i] & 7);
+ *   blk_read / blk_off / events    per 1024-byte block of `codes`: the first read whose slot reaches into it, and its
+ *                                  difference events, 2 B each: (byte offset in the block) | code << 12, for every read
+ *                                  position whose code differs from the reference base (deleted positions: code 4).
+ * nc_wire_build makes it on the host cores from the same inputs as nc_pack_fill; nc_wire_expand rebuilds the
+ * position-addressed `codes` in HBM byte for byte as nc_pack_fill writes them (and the scan's ref_code array).
+ * The tile index still comes from nc_pack_plan / nc_pack_fill (index-only mode). */
+typedef struct nc_wire nc_wire;
+typedef struct {
+    int32_t n_reads;            /* kept reads */
+    const int32_t *rd_start;    /* host [n_reads] */
+    const int32_t *rd_end;      /* host [n_reads] */
+    const int64_t *slot_off;    /* host [n_reads + 1] */
+    int64_t codes_len;          /* bytes of the expanded codes array (= nc_pack_plan's codes_len) */
+    int64_t n_blocks;           /* ceil(codes_len / 1024) */
+    const uint32_t *blk_off;    /* host [n_blocks + 1]; NC_ERR_CAPACITY from nc_wire_build at >= 2^32 events */
+    const int32_t *blk_read;    /* host [n_blocks] */
+    const uint16_t *events;     /* host [n_events] */
+    int64_t n_events;
+} nc_wire_arrays;
+/* ref_wire[i] describes position ref_pos0 + i (ref_pos0 a multiple of 16: the tile grid's tile_pos0), i < ref_len;
+ * positions outside predict code 4.  Other arguments as nc_pack_fill.  The result is owned by the library. */
+int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                  const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, nc_wire **out);
+int nc_wire_view(const nc_wire *w, nc_wire_arrays *view);
+int nc_wire_free(nc_wire *w);
+/* All pointers dev, 16-byte aligned; d_codes [codes_len] and d_ref_code [ref_len] (may be NULL) are written on the
+ * context's stream.  HBM-write-bound: 1 B per pileup entry. */
+int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                   const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                   const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                   uint8_t *d_ref_code);
 
 /* ------------------------------------------------------------------ SNP candidate scan (K1)
  * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libnanocaller_hip.so")
 
 NC_OK = 0
 NC_ERR_CAPACITY = -2
-ABI_VERSION = 4          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
+ABI_VERSION = 5          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -31,6 +31,7 @@ EXPORTS = [
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
     "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_set_tensor_format", "nc_allele_prediction_batch",
+    "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
 ]
 
 
@@ -73,6 +74,12 @@ class DecodedArraysC(C.Structure):
 class SlicesArraysC(C.Structure):
     _fields_ = [("n_anchor", C.c_int32), ("anchor_off", C.c_void_p), ("read_idx", C.c_void_p), ("seq_off", C.c_void_p),
                 ("seq", C.c_void_p), ("n_slices", C.c_int64)]
+
+
+class WireArraysC(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("rd_start", C.c_void_p), ("rd_end", C.c_void_p), ("slot_off", C.c_void_p),
+                ("codes_len", C.c_int64), ("n_blocks", C.c_int64), ("blk_off", C.c_void_p), ("blk_read", C.c_void_p), ("events", C.c_void_p),
+                ("n_events", C.c_int64)]
 
 
 _lib = None
@@ -147,6 +154,11 @@ def lib():
         L.nc_nw_cigar.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
         L.nc_allele_prediction.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.nc_bgzf_compress.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64)]
+        L.nc_d2h_async.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        L.nc_wire_build.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i64, C.POINTER(vp)]
+        L.nc_wire_view.argtypes = [vp, C.POINTER(WireArraysC)]
+        L.nc_wire_free.argtypes = [vp]
+        L.nc_wire_expand.argtypes = [vp, i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, i64, vp, i64, vp]
         L.nc_argsort4.argtypes = [vp, i64, vp, C.POINTER(i64), vp, i64]
         L.nc_snp_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, C.POINTER(i64)]
         for name in EXPORTS:

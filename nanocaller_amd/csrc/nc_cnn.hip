@@ -1776,9 +1776,9 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
             if (!ctx->drain_ev[slot]) NC_HIP(ctx, hipEventCreateWithFlags(&ctx->drain_ev[slot], hipEventDisableTiming));
             NC_HIP(ctx, hipEventRecord(ctx->drain_ev[slot], ctx->stream));
             NC_HIP(ctx, hipStreamWaitEvent((hipStream_t)copy_stream, ctx->drain_ev[slot], 0));
-            NC_HIP(ctx, hipMemcpyAsync(probs_host + s0 * 4, probs_dev + s0 * 4, (size_t)nb * 16, hipMemcpyDeviceToHost, (hipStream_t)copy_stream));
+            NC_TRY(nc_d2h(ctx, probs_host + s0 * 4, probs_dev + s0 * 4, (size_t)nb * 16, (hipStream_t)copy_stream));
             if (gt_host && gt_dev)
-                NC_HIP(ctx, hipMemcpyAsync(gt_host + s0 * 2, gt_dev + s0 * 2, (size_t)nb * 8, hipMemcpyDeviceToHost, (hipStream_t)copy_stream));
+                NC_TRY(nc_d2h(ctx, gt_host + s0 * 2, gt_dev + s0 * 2, (size_t)nb * 8, (hipStream_t)copy_stream));
         }
     }
     tm.stop();

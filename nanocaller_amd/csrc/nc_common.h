@@ -60,7 +60,22 @@ struct nc_ctx {
     bool have_scan = false;
 
     nc_weights w[4];
+
+    // The small transfers the host waits for in the middle of a step go through kernels that read / write page-locked host
+    // memory directly, NOT through hipMemcpyAsync: on this platform every hipMemcpyAsync of either direction queues in order
+    // behind a large H2D copy in flight (7 ms for a contig's wire pack), measured with tools/exp_sdma.py.
+    int32_t *mbox = nullptr;       // pinned host, 64 int32: scan totals
+    uint8_t *stage_h = nullptr;    // pinned host ring for small host -> device arrays (chunk bounds)
+    int stage_turn = 0;
 };
+
+// device -> host: a copy kernel on `st` when `host` is device-accessible page-locked memory, hipMemcpyAsync otherwise
+int nc_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes, hipStream_t st);
+// host -> device for small arrays (<= NC_STAGE_SLOT bytes): through the pinned ring and a copy kernel
+int nc_h2d_small(nc_ctx *ctx, void *dev, const void *host, size_t bytes, hipStream_t st);
+#define NC_D2H_KERNEL_MAX 65536
+#define NC_STAGE_SLOT 16384
+#define NC_STAGE_SLOTS 8
 
 inline int nc_fail(nc_ctx *ctx, int code, const char *fmt, ...)
 {

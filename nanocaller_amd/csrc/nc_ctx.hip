@@ -21,6 +21,85 @@ int nc_device_count(int *n)
     return NC_OK;
 }
 
+}   // extern "C" (the copy helpers below have C++ linkage)
+
+// ------------------------------------------------------------------ small transfers without the SDMA queue
+namespace {
+__global__ void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+__global__ void k_copy4(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+__global__ void k_copy1(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+
+void launch_copy(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    const uintptr_t a = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+    // few, small workgroups: they must fit beside the persistent CNN workgroups (<= 16 VGPRs, no LDS) and a PCIe link is
+    // saturated by a few hundred 16-byte stores in flight
+    if ((a & 15) == 0) {
+        const size_t n = bytes / 16;
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, n);
+    } else if ((a & 3) == 0) {
+        const size_t n = bytes / 4;
+        hipLaunchKernelGGL(k_copy4, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(256), 0, st, (uint32_t *)dst, (const uint32_t *)src, n);
+    } else {
+        hipLaunchKernelGGL(k_copy1, dim3((unsigned)std::min<size_t>((bytes + 255) / 256, 128)), dim3(256), 0, st, (uint8_t *)dst, (const uint8_t *)src, bytes);
+    }
+}
+}   // namespace
+
+int nc_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return NC_OK;
+    hipPointerAttribute_t at;
+    void *alias = nullptr;
+    if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) alias = at.devicePointer;
+    else (void)hipGetLastError();                                  // an ordinary host pointer is not an error
+    // Bulk results stay on the copy engine (no CU time, full PCIe rate): the caller enqueues a contig's upload BEFORE the
+    // result copies of the step running under it, so they queue behind it and still land before the step ends.  Only the
+    // small transfers the HOST WAITS FOR mid-step (scan totals) must not queue behind 7 ms of upload: those go by kernel.
+    if (!alias || bytes > NC_D2H_KERNEL_MAX) {
+        NC_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        return NC_OK;
+    }
+    launch_copy(alias, dev, bytes, st);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}
+
+int nc_h2d_small(nc_ctx *ctx, void *dev, const void *host, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return NC_OK;
+    if (bytes > NC_STAGE_SLOT || !ctx->stage_h) {
+        NC_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+        return NC_OK;
+    }
+    uint8_t *slot = ctx->stage_h + (size_t)(ctx->stage_turn++ % NC_STAGE_SLOTS) * NC_STAGE_SLOT;
+    memcpy(slot, host, bytes);
+    const size_t padded = (bytes + 15) & ~(size_t)15;              // slots and device buffers are 16-byte granular
+    launch_copy(dev, slot, ((uintptr_t)dev & 15) ? bytes : padded, st);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}
+
+extern "C" {
+
+int nc_d2h_async(nc_ctx *ctx, void *stream, void *host, const void *dev, size_t bytes)
+{
+    if (!ctx || (bytes && (!host || !dev))) return NC_ERR_ARG;
+    return nc_d2h(ctx, host, dev, bytes, stream ? (hipStream_t)stream : ctx->stream);
+}
+
 int nc_ctx_create(int device_id, nc_ctx **out)
 {
     if (!out) return NC_ERR_ARG;
@@ -37,6 +116,11 @@ int nc_ctx_create(int device_id, nc_ctx **out)
         return NC_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipHostMalloc((void **)&ctx->mbox, 256, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->stage_h, (size_t)NC_STAGE_SLOT * NC_STAGE_SLOTS, hipHostMallocDefault) != hipSuccess) {
+        nc_ctx_destroy(ctx);
+        return NC_ERR_NOMEM;
+    }
     int rc = nc_selftest_device(ctx);
     if (rc != NC_OK) {
         fprintf(stderr, "nanocaller_hip: device self-test failed: %s\n", ctx->err);
@@ -80,6 +164,8 @@ int nc_ctx_destroy(nc_ctx *ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->mbox) (void)hipHostFree(ctx->mbox);
+    if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
     delete ctx;
     return NC_OK;
 }

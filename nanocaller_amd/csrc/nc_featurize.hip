@@ -434,7 +434,7 @@ int nc_snp_chunk_depth_async(nc_ctx *ctx, void *copy_stream, double *chunk_depth
     if (!ctx->scale_ev) NC_HIP(ctx, hipEventCreateWithFlags(&ctx->scale_ev, hipEventDisableTiming));
     NC_HIP(ctx, hipEventRecord(ctx->scale_ev, ctx->stream));
     NC_HIP(ctx, hipStreamWaitEvent((hipStream_t)copy_stream, ctx->scale_ev, 0));
-    NC_HIP(ctx, hipMemcpyAsync(chunk_depth_host_pinned, ctx->chunk_depth.p, (size_t)ctx->n_chunks * 8, hipMemcpyDeviceToHost, (hipStream_t)copy_stream));
+    NC_TRY(nc_d2h(ctx, chunk_depth_host_pinned, ctx->chunk_depth.p, (size_t)ctx->n_chunks * 8, (hipStream_t)copy_stream));
     return NC_OK;
 }
 

@@ -341,8 +341,8 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     NC_TRY(nc_ensure(ctx, ctx->chunk_lo, (size_t)n_chunks * 4));
     NC_TRY(nc_ensure(ctx, ctx->chunk_cnt, (size_t)n_chunks * 4));
     NC_TRY(nc_ensure(ctx, ctx->chunk_off, ((size_t)n_chunks + 1) * 4));
-    NC_HIP(ctx, hipMemcpyAsync(ctx->chunk_start.p, chunk_start_host, (size_t)n_chunks * 4, hipMemcpyHostToDevice, ctx->stream));
-    NC_HIP(ctx, hipMemcpyAsync(ctx->chunk_end.p, chunk_end_host, (size_t)n_chunks * 4, hipMemcpyHostToDevice, ctx->stream));
+    NC_TRY(nc_h2d_small(ctx, ctx->chunk_start.p, chunk_start_host, (size_t)n_chunks * 4, ctx->stream));
+    NC_TRY(nc_h2d_small(ctx, ctx->chunk_end.p, chunk_end_host, (size_t)n_chunks * 4, ctx->stream));
 
     ScanP sp;
     sp.mincov = params->mincov;
@@ -373,8 +373,8 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, ctx->stream, tc, (int2 *)ctx->tile_pre.p, pack->n_tiles,
                        (int32_t *)ctx->totals.p);
     NC_HIP(ctx, hipGetLastError());
-    int32_t tot[4] = {0, 0, 0, 0};
-    NC_HIP(ctx, hipMemcpyAsync(tot, ctx->totals.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    volatile int32_t *tot = ctx->mbox;                           // pinned mailbox: the totals arrive through a copy kernel
+    NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_nbr = tot[0];
     ctx->n_cand = tot[1];
@@ -393,7 +393,7 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->chunk_cnt.p,
                        (int32_t *)ctx->chunk_off.p, n_chunks, (int32_t *)ctx->totals.p);
     NC_HIP(ctx, hipGetLastError());
-    NC_HIP(ctx, hipMemcpyAsync(tot, ctx->totals.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+    NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_sites = tot[2];
     ctx->n_chunks = n_chunks;
@@ -426,11 +426,11 @@ static int scan_fetch(nc_ctx *ctx, hipStream_t st, bool wait, int32_t *nbr_pos, 
     if (!ctx) return NC_ERR_ARG;
     if (!ctx->have_scan) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan_fetch: no scan on this context");
     const size_t nb = (size_t)ctx->n_nbr * 4, ns = (size_t)ctx->n_sites * 4;
-    if (nbr_pos && nb) NC_HIP(ctx, hipMemcpyAsync(nbr_pos, ctx->nbr_pos.p, nb, hipMemcpyDeviceToHost, st));
-    if (site_pos && ns) NC_HIP(ctx, hipMemcpyAsync(site_pos, ctx->site_pos.p, ns, hipMemcpyDeviceToHost, st));
-    if (site_chunk && ns) NC_HIP(ctx, hipMemcpyAsync(site_chunk, ctx->site_chunk.p, ns, hipMemcpyDeviceToHost, st));
-    if (site_n && ns) NC_HIP(ctx, hipMemcpyAsync(site_n, ctx->site_n.p, ns, hipMemcpyDeviceToHost, st));
-    if (site_alt && ns) NC_HIP(ctx, hipMemcpyAsync(site_alt, ctx->site_alt.p, ns, hipMemcpyDeviceToHost, st));
+    if (nbr_pos && nb) NC_TRY(nc_d2h(ctx, nbr_pos, ctx->nbr_pos.p, nb, st));
+    if (site_pos && ns) NC_TRY(nc_d2h(ctx, site_pos, ctx->site_pos.p, ns, st));
+    if (site_chunk && ns) NC_TRY(nc_d2h(ctx, site_chunk, ctx->site_chunk.p, ns, st));
+    if (site_n && ns) NC_TRY(nc_d2h(ctx, site_n, ctx->site_n.p, ns, st));
+    if (site_alt && ns) NC_TRY(nc_d2h(ctx, site_alt, ctx->site_alt.p, ns, st));
     if (wait) NC_HIP(ctx, hipStreamSynchronize(st));
     return NC_OK;
 }

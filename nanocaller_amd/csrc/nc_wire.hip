@@ -1,0 +1,249 @@
+// Wire pack: the host -> device transfer form of the read pack (the timed region starts at decoded alignments
+// in pinned host memory; the reference feeds every chunk from the host, snpCaller.py:86, generate_SNP_pileups.py:156).
+//
+// The read pack costs 1 B per pileup entry -- 1.93 GB for a chr20-sized 30x contig, i.e. ~35 ms of PCIe Gen5 against
+// ~11.5 ms of GPU work per contig.  But a decoded alignment is almost the reference: 92 % of an ONT read's positions (99.8 %
+// of a HiFi read's) carry the reference base.  The transfer form therefore stores only the DIFFERENCES against the reference:
+//   * the read table (start, end, slot offset) of the kept reads, 16 B per read;
+//   * one byte per reference position (`ref_wire`: base code in bits 0-2, bit 3 = column skipped);
+//   * per 1024-byte block of the codes array the index of the first read reaching into it and its difference events,
+//     2 B each: (byte offset in block) | code << 12.
+// nc_wire_expand rebuilds the position-addressed codes in HBM (one wave per block: reference bases through LDS, events
+// scattered on top, one coalesced dwordx4 store per lane) -- byte for byte what nc_pack_fill writes.  ONT 30x chr20:
+// 0.39 GB over PCIe instead of 1.93 GB; the expansion is an HBM-write-bound kernel (1 B written per pileup entry).
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "nc_common.h"
+#include "nc_host.h"
+
+#define WIRE_BLOCK 1024
+
+struct nc_wire {
+    std::vector<int32_t> rd_start, rd_end;
+    std::vector<int64_t> slot_off;
+    std::vector<uint32_t> blk_off;
+    std::vector<int32_t> blk_read;
+    std::vector<uint16_t> events;
+    int64_t codes_len = 0;
+};
+
+static inline int64_t floor16w(int64_t p) { return p & ~(int64_t)15; }
+static inline int64_t ceil16w(int64_t p) { return (p + 15) & ~(int64_t)15; }
+
+extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                             const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, nc_wire **out)
+{
+    if (!out || n_reads < 0 || (n_reads && (!start || !end || !off || !codes_in)) || !ref_wire || ref_len < 0 || (ref_pos0 & 15))
+        return NC_ERR_ARG;
+    *out = nullptr;
+    nc_wire *w = new (std::nothrow) nc_wire;
+    if (!w) return NC_ERR_NOMEM;
+    try {
+        std::vector<int64_t> rd_off;
+        w->slot_off.push_back(0);
+        int32_t prev = INT32_MIN;
+        for (int32_t r = 0; r < n_reads; r++) {
+            if (keep && !keep[r]) continue;
+            if (end[r] <= start[r] || start[r] < prev) { delete w; return NC_ERR_ARG; }      // coordinate order, as nc_pack_plan
+            prev = start[r];
+            w->rd_start.push_back(start[r]);
+            w->rd_end.push_back(end[r]);
+            rd_off.push_back(off[r]);
+            w->slot_off.push_back(w->slot_off.back() + (ceil16w(end[r]) - floor16w(start[r])));
+        }
+        const int64_t n = (int64_t)w->rd_start.size();
+        const int64_t total = w->slot_off[(size_t)n];
+        w->codes_len = total + 16;                                                          // nc_pack_plan's convention: never empty
+        const int64_t n_blocks = (w->codes_len + WIRE_BLOCK - 1) / WIRE_BLOCK;
+        w->blk_off.assign((size_t)n_blocks + 1, 0);
+        w->blk_read.assign((size_t)n_blocks, 0);
+        int T = std::min(nc_host_cpus(), 32);
+        if (n_blocks < 64) T = 1;
+        std::vector<std::vector<uint16_t>> part((size_t)T);
+        std::vector<int> status((size_t)T, NC_OK);
+        auto work = [&](int t) {
+            const int64_t b0 = n_blocks * t / T, b1 = n_blocks * (t + 1) / T;
+            std::vector<uint16_t> &ev = part[(size_t)t];
+            ev.reserve((size_t)((b1 - b0) * 400));
+            int64_t r = std::upper_bound(w->slot_off.begin(), w->slot_off.end(), b0 * WIRE_BLOCK) - w->slot_off.begin() - 1;
+            if (r < 0) r = 0;
+            for (int64_t b = b0; b < b1; b++) {
+                const int64_t byte0 = b * WIRE_BLOCK, byte1 = std::min<int64_t>(byte0 + WIRE_BLOCK, total);
+                const size_t before = ev.size();
+                while (r < n && w->slot_off[(size_t)r + 1] <= byte0) r++;
+                w->blk_read[(size_t)b] = (int32_t)r;                                         // first read reaching into the block (n: none)
+                for (int64_t q = r; q < n && w->slot_off[(size_t)q] < byte1; q++) {
+                    const int64_t s = w->rd_start[(size_t)q], e = w->rd_end[(size_t)q];
+                    const int64_t base = w->slot_off[(size_t)q] - floor16w(s);                // codes[base + p]
+                    const int64_t p_lo = std::max<int64_t>(s, byte0 - base), p_hi = std::min<int64_t>(e, byte1 - base);
+                    const uint8_t *src = codes_in + rd_off[(size_t)q] - s;                     // src[p]
+                    for (int64_t p = p_lo; p < p_hi; p++) {
+                        const int64_t ri = p - ref_pos0;
+                        const unsigned rb = (ri >= 0 && ri < ref_len) ? (ref_wire[ri] & 7u) : 4u;
+                        const unsigned c = src[p];
+                        if (c > 7u || c == NC_CODE_ABSENT) { status[(size_t)t] = NC_ERR_ARG; return; }
+                        if (c != rb) ev.push_back((uint16_t)((base + p - byte0) | (c << 12)));
+                    }
+                }
+                w->blk_off[(size_t)b + 1] = (uint32_t)(ev.size() - before);
+            }
+        };
+        if (T == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < T; t++)
+            if (status[(size_t)t] != NC_OK) { delete w; return status[(size_t)t]; }
+        {
+            uint64_t acc = 0;
+            for (int64_t b = 0; b < n_blocks; b++) {
+                acc += w->blk_off[(size_t)b + 1];
+                if (acc > 0xffffffffull) { delete w; return NC_ERR_CAPACITY; }               // 32-bit event offsets: < 4 G events per contig
+                w->blk_off[(size_t)b + 1] = (uint32_t)acc;
+            }
+        }
+        w->events.resize((size_t)w->blk_off[(size_t)n_blocks]);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&, t]() {
+                    const int64_t b0 = n_blocks * t / T;
+                    if (!part[(size_t)t].empty())
+                        memcpy(w->events.data() + w->blk_off[(size_t)b0], part[(size_t)t].data(), part[(size_t)t].size() * sizeof(uint16_t));
+                });
+            for (auto &x : th) x.join();
+        }
+    } catch (const std::bad_alloc &) {
+        delete w;
+        return NC_ERR_NOMEM;
+    }
+    *out = w;
+    return NC_OK;
+}
+
+extern "C" int nc_wire_view(const nc_wire *w, nc_wire_arrays *v)
+{
+    if (!w || !v) return NC_ERR_ARG;
+    v->n_reads = (int32_t)w->rd_start.size();
+    v->rd_start = w->rd_start.data();
+    v->rd_end = w->rd_end.data();
+    v->slot_off = w->slot_off.data();
+    v->codes_len = w->codes_len;
+    v->n_blocks = (int64_t)w->blk_off.size() - 1;
+    v->blk_off = w->blk_off.data();
+    v->blk_read = w->blk_read.data();
+    v->events = w->events.data();
+    v->n_events = (int64_t)w->events.size();
+    return NC_OK;
+}
+
+extern "C" int nc_wire_free(nc_wire *w)
+{
+    delete w;
+    return NC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------ device side
+// One WAVE per 1024-byte block (four per workgroup), no workgroup barrier: lane t owns the aligned 16-byte group t of the
+// block.  A 16-byte group never straddles two reads (slots are 16-byte aligned) and maps to 16 consecutive, 16-aligned
+// reference positions, so the predicted bytes are ONE aligned dwordx4 of ref_wire, masked to the read's span.  blk_read gives
+// the first read reaching into the block (reads are kilobases long: usually THE read); the block's events are scattered over
+// the wave's LDS image (no two events address the same byte), then every lane stores one dwordx4.
+__global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
+                                                     const int64_t *__restrict__ slot_off, const uint8_t *__restrict__ ref_wire,
+                                                     int32_t ref_pos0, int64_t ref_len, const uint32_t *__restrict__ blk_off,
+                                                     const int32_t *__restrict__ blk_read, const uint16_t *__restrict__ events,
+                                                     int64_t n_blocks, uint8_t *__restrict__ codes, int64_t codes_len)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t img_all[4 * WIRE_BLOCK];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t blk = (int64_t)blockIdx.x * 4 + wv;
+    if (blk >= n_blocks) return;
+    uint8_t *img = img_all + wv * WIRE_BLOCK;
+    const int64_t B = blk * WIRE_BLOCK + (int64_t)lane * 16;
+    int64_t r = blk_read[blk];
+    while (r < n_reads && slot_off[r + 1] <= B) r++;             // at most 63 steps, almost always none
+    uint32_t o[4] = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
+    if (r < n_reads) {
+        const int64_t s = rd_start[r], e = rd_end[r];
+        const int64_t p0 = (s & ~(int64_t)15) + (B - slot_off[r]);          // position of this group's first byte
+        if (p0 < e && p0 + 16 > s) {
+            const int64_t ri = p0 - ref_pos0;
+            uint32_t w[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+            if (ri >= 0 && ri + 16 <= ref_len) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ref_wire + ri);
+                w[0] = v.x & 0x07070707u; w[1] = v.y & 0x07070707u; w[2] = v.z & 0x07070707u; w[3] = v.w & 0x07070707u;
+            } else {
+                for (int j = 0; j < 16; j++) {
+                    const int64_t q = ri + j;
+                    const uint32_t b = (q >= 0 && q < ref_len) ? (ref_wire[q] & 7u) : 4u;
+                    w[j >> 2] = (w[j >> 2] & ~(0xffu << ((j & 3) * 8))) | (b << ((j & 3) * 8));
+                }
+            }
+            if (p0 >= s && p0 + 16 <= e) {
+                o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
+            } else {
+                for (int j = 0; j < 16; j++) {
+                    const int64_t p = p0 + j;
+                    if (p >= s && p < e) {
+                        const uint32_t sh = (j & 3) * 8;
+                        o[j >> 2] = (o[j >> 2] & ~(0xffu << sh)) | (((w[j >> 2] >> sh) & 0xffu) << sh);
+                    }
+                }
+            }
+        }
+    }
+    *reinterpret_cast<uint4 *>(img + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    const uint32_t e0 = blk_off[blk], e1 = blk_off[blk + 1];
+    // LDS operations of one wave execute in program order: the byte stores below land on top of the 16-byte stores above
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = e0 + lane; k < e1; k += 64) {
+        const uint32_t ev = events[k];
+        img[ev & 0x3ffu] = (uint8_t)(ev >> 12);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (B + 16 <= codes_len) *reinterpret_cast<uint4 *>(codes + B) = *reinterpret_cast<const uint4 *>(img + lane * 16);
+}
+
+// reference codes of the column scan from the wire form: skipped columns (bit 3: soft-masked, non-AGTC, excluded) become 4
+__global__ void k_ref_from_wire(const uint8_t *__restrict__ ref_wire, uint8_t *__restrict__ ref_code, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ref_wire + i);
+        auto f = [](uint32_t x) {
+            const uint32_t m = ((x >> 3) & 0x01010101u) * 0xffu;           // 0xff in the bytes whose skip bit is set
+            return ((x & 0x07070707u) & ~m) | (0x04040404u & m);
+        };
+        *reinterpret_cast<uint4 *>(ref_code + i) = make_uint4(f(v.x), f(v.y), f(v.z), f(v.w));
+    } else {
+        for (int64_t j = i; j < n; j++) ref_code[j] = (ref_wire[j] & 8) ? 4 : (ref_wire[j] & 7);
+    }
+}
+
+extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                              const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                              const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                              uint8_t *d_ref_code)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_reads < 0 || !d_slot_off || (n_reads && (!d_rd_start || !d_rd_end)) || !d_ref_wire || (ref_pos0 & 15) || ref_len < 0 ||
+        !d_blk_off || !d_blk_read || n_blocks < 1 || !d_codes || codes_len < 16 || (codes_len & 15) || n_blocks != (codes_len + WIRE_BLOCK - 1) / WIRE_BLOCK ||
+        (n_blocks + 3) / 4 > INT32_MAX || ((uintptr_t)d_codes & 15) || ((uintptr_t)d_ref_wire & 15) || (d_ref_code && ((uintptr_t)d_ref_code & 15)))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand: bad argument");
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_wire_expand, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_rd_end, d_slot_off,
+                       d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len);
+    if (d_ref_code && ref_len) {
+        const int64_t groups = (ref_len + 15) / 16;
+        hipLaunchKernelGGL(k_ref_from_wire, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_wire, d_ref_code, ref_len);
+    }
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}

@@ -137,6 +137,11 @@ class Engine:
         self._check(self.L.nc_set_tensor_format(self.ctx, 1 if int16 else 0), "nc_set_tensor_format")
         self.x_int16 = bool(int16)
 
+    def trunk_mfma_per_site(self) -> int:
+        """v_mfma_f32_16x16x32_f16 instructions k5_trunk_h3 executes per site (zero-weight tap slots included): conv1 24 per
+        16-position tile x 13 tiles, conv2 27 per (tile, half of the channels) x 10, conv3 18 x 8"""
+        return 13 * 24 + 10 * 27 + 8 * 18
+
     def enable_timing(self, on=True, trunk_only=False):
         """HIP-event timers: all stages, or (trunk_only) just the trunk kernel's launches, whose events ride on the
         kernel's dispatch packets and leave the stream undisturbed"""
@@ -414,7 +419,10 @@ class Engine:
                     outs.append(None)
                     continue
                 h, h_np = self._pinned.get(t.shape, t.dtype)
-                h.copy_(t, non_blocking=True)
+                t = t.contiguous()
+                # small blocks go by copy kernel, bulk by the copy engine (see nc_d2h_async)
+                self._check(self.L.nc_d2h_async(self.ctx, C.c_void_p(cs.cuda_stream), C.c_void_p(h.data_ptr()), C.c_void_p(t.data_ptr()),
+                                                t.numel() * t.element_size()), "nc_d2h_async")
                 t.record_stream(cs)
                 outs.append(h_np)
         return outs

@@ -19,7 +19,6 @@ import numpy as np
 
 from . import _lib
 from .engine import get_engine
-from .pack import pack_world
 from .synth import World
 
 _SOURCES = {}
@@ -111,8 +110,10 @@ def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, dev
     key = (src, fasta_path, chrom, bool(supplementary), excl, device)
 
     def make():
-        eng = get_engine(device)
-        return (eng.upload(pack_world(world, supplementary=bool(supplementary), exclude=excl)), world)
+        # the contig crosses PCIe in the reference-difference wire form (~0.2 B instead of 1 B per pileup entry) and is
+        # expanded to the position-addressed codes in HBM (wire.py, nc_wire_expand)
+        from .wire import build_wire_from_world, upload_wire
+        return (upload_wire(get_engine(device), build_wire_from_world(world, supplementary=bool(supplementary), exclude=excl)), world)
     return _PACKS.get(key, make)
 
 

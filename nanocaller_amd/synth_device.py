@@ -126,7 +126,10 @@ def make_device_workload(eng, L, depth=30.0, tech="ont", seed=812, tile_size=204
     pack = DevicePack(codes=codes, tile_off=torch.from_numpy(tile_off).to(dev), tile_ent=torch.from_numpy(ent_bytes).to(dev),
                       ref_code=ref_code, tile_size=tile_size, tile_pos0=tile_pos0, n_tiles=n_tiles, n_entries=int(ne.value),
                       pos_lo=1, pos_hi=L)
-    info = dict(L=L, n_reads=R, read_start=starts, read_end=ends, read_base=base, strand=strand,
+    # wire form of the reference (nc_wire_*): true base in bits 0-2, bit 3 = skipped column
+    ref_wire = torch.full((n_tiles * tile_size,), 4 | 8, dtype=torch.uint8, device=dev)
+    ref_wire[1:L + 1] = refc[1:] | ((ref_code[1:L + 1] == 4).to(torch.uint8) << 3)
+    info = dict(L=L, n_reads=R, read_start=starts, read_end=ends, read_base=base, strand=strand, ref_wire=ref_wire, tile_size=tile_size,
                 pileup_entries=int((ends.astype(np.int64) - starts).sum()), tech=tech, depth=depth, seed=seed)
     torch.cuda.synchronize(dev)
     return pack, info
@@ -150,3 +153,17 @@ def host_sample_for_oracle(pack: DevicePack, info, pos_lo, pos_hi):
     keep[sel - r0] = 1
     return dict(start=np.ascontiguousarray(s[r0:r1]), end=np.ascontiguousarray(e[r0:r1]), off=np.ascontiguousarray(off),
                 codes=raw, strand=np.ascontiguousarray(info["strand"][r0:r1]), keep=keep, ref_codes=ref, L=L)
+
+
+def wire_from_device_workload(pack: DevicePack, info, pin=True):
+    """The workload as the host would hold it after decoding a BAM: codes copied back to host memory and put into the
+    reference-difference transfer form by the library's host builder (nc_wire_build) -- bench.py uploads THIS inside its
+    timed region (the timed region starts at decoded alignments in pinned host memory)."""
+    from .wire import build_wire
+    L = info["L"]
+    codes_h = pack.codes.cpu().numpy()
+    ref_h = info["ref_wire"][1:L + 1].cpu().numpy()
+    off = info["read_base"] + info["read_start"].astype(np.int64)               # codes[off + p - start]: the slot layout is read-major
+    n = info["n_reads"]
+    return build_wire(info["read_start"], info["read_end"], off, codes_h, None, ref_h, tile_size=info["tile_size"], pos_lo=1, pos_hi=L,
+                      keep=np.ones(n, np.uint8), strand=info["strand"], pin=pin)

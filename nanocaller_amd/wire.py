@@ -1,0 +1,267 @@
+"""Host -> device transfer of a contig's decoded alignments in the reference-difference "wire" form (nc_wire_*, see
+include/nanocaller_hip.h and csrc/nc_wire.hip).
+
+SURVEY.md 8(d) starts the timed region at decoded alignments in pinned host memory: the reference feeds every chunk from the
+host (snpCaller.py:86, generate_SNP_pileups.py:156).  `build_wire` lays ONE page-locked buffer out per contig -- read table,
+reference bytes, difference events, tile index (+ the indel events) -- so that a contig crosses PCIe as a single copy of
+~0.2 B per pileup entry (ONT) instead of 1 B; `WireUploader` double-buffers those copies on their own stream against the
+compute stream and rebuilds the position-addressed codes in HBM (nc_wire_expand) right before the scan.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import DevicePack
+from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL, World
+
+_ALIGN = 256
+
+
+@dataclass
+class WirePack:
+    buf: torch.Tensor                      # uint8, page-locked when pin=True: every section back to back
+    sections: dict                         # name -> (byte offset, numpy dtype, count)
+    tile_size: int
+    tile_pos0: int
+    n_tiles: int
+    n_entries: int
+    codes_len: int
+    n_reads: int
+    n_blocks: int
+    n_events: int
+    ref_len: int
+    pos_lo: int
+    pos_hi: int
+    n_indel_reads: int = -1                # >= 0: indel event sections present
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def nbytes(self):
+        return int(self.buf.numel())
+
+    def host(self, name):
+        off, dt, cnt = self.sections[name]
+        return self.buf.numpy()[off:off + cnt * np.dtype(dt).itemsize].view(dt)
+
+
+def ref_wire_from_string(ref: str, exclude=None, pos0=1):
+    """uint8 per position (index p - pos0): bits 0-2 base code of the letter in either case (A0 G1 T2 C3, else 4), bit 3 =
+    the column is skipped by the scan: not an UPPER-case AGTC (`s in 'AGTC'` before .upper(), generate_SNP_pileups.py:137,
+    quirk E4) or inside an exclude interval (tree.overlaps(pos): a <= pos < b, :116-119,161)"""
+    raw = np.frombuffer(ref.encode("ascii"), np.uint8)
+    base = np.full(256, 4, np.uint8)
+    skip = np.full(256, 8, np.uint8)
+    for i, b in enumerate("AGTC"):
+        base[ord(b)] = base[ord(b.lower())] = i
+        skip[ord(b)] = 0
+    out = base[raw] | skip[raw]
+    for (a, b) in exclude or ():
+        lo, hi = max(0, int(a) - pos0), max(0, int(b) - pos0)
+        out[lo:hi] |= 8
+    return out
+
+
+def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, *, supplementary=False, tile_size=2048,
+               pos_lo=None, pos_hi=None, hap=None, events=None, strand=None, keep=None, pin=True) -> WirePack:
+    """read_* / codes as synth.World (coordinate order, codes[read_off[r] + p - read_start[r]]); `ref_wire_pos1`: uint8 per
+    position, index p - 1 (ref_wire_from_string).  Flag filter and strand as pack.pack_reads, or given directly (`keep`,
+    `strand`).  -> WirePack: one host buffer ready for a single H2D copy."""
+    L = _lib.lib()
+    rs = np.ascontiguousarray(read_start, np.int32)
+    re_ = np.ascontiguousarray(read_end, np.int32)
+    ro = np.ascontiguousarray(read_off, np.int64)
+    cd = np.ascontiguousarray(codes, np.uint8)
+    n = int(rs.shape[0])
+    if keep is None:
+        flag = np.asarray(read_flag)
+        keep = np.ascontiguousarray((flag & (FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT)) == 0, np.uint8)
+        strand = np.ascontiguousarray((flag & 0x10) != 0, np.uint8)
+    else:
+        keep = np.ascontiguousarray(keep, np.uint8)
+        strand = np.ascontiguousarray(strand, np.uint8)
+    if hap is not None:
+        strand = np.ascontiguousarray(strand | (np.asarray(hap, np.uint8) & 3) << 1)          # bits 1-2: HP tag
+    Lref = int(ref_wire_pos1.shape[0])
+    pos_lo = 1 if pos_lo is None else max(1, int(pos_lo))
+    pos_hi = max(pos_lo, Lref if pos_hi is None else min(Lref, int(pos_hi)))
+    codes_len, n_ent = C.c_int64(), C.c_int64()
+    tile_pos0, n_tiles = C.c_int32(), C.c_int32()
+    rc = L.nc_pack_plan(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(keep), tile_size, pos_lo, pos_hi, C.byref(codes_len), C.byref(tile_pos0),
+                        C.byref(n_tiles), C.byref(n_ent))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_pack_plan failed (%d)" % rc)
+    # reference bytes on the tile grid (what nc_wire_expand and the scan address)
+    ref_len = n_tiles.value * tile_size
+    ref_grid = np.full(ref_len, 4 | 8, np.uint8)
+    a, b = max(1, tile_pos0.value), min(Lref, tile_pos0.value + ref_len - 1)
+    if b >= a:
+        ref_grid[a - tile_pos0.value:b - tile_pos0.value + 1] = ref_wire_pos1[a - 1:b]
+    tile_off = np.empty(n_tiles.value + 1, np.int32)
+    tile_ent = np.empty(max(1, n_ent.value), _lib.TILE_ENTRY_DTYPE)
+    rc = L.nc_pack_fill(n, _lib.npp(rs), _lib.npp(re_), None, None, _lib.npp(strand), _lib.npp(keep), tile_size, tile_pos0.value,
+                        n_tiles.value, None, codes_len.value, _lib.npp(tile_off), _lib.npp(tile_ent), n_ent.value)      # index only
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_pack_fill (index) failed (%d)" % rc)
+    h = C.c_void_p()
+    rc = L.nc_wire_build(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value,
+                         ref_len, C.byref(h))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_wire_build failed (%d)" % rc)
+    try:
+        v = _lib.WireArraysC()
+        L.nc_wire_view(h, C.byref(v))
+        assert v.codes_len == codes_len.value, (v.codes_len, codes_len.value)
+
+        def arr(ptr, cnt, dt):
+            if not cnt:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_char * (int(cnt) * np.dtype(dt).itemsize)).from_address(ptr), dt)
+        parts = [("rd_start", arr(v.rd_start, v.n_reads, np.int32)), ("rd_end", arr(v.rd_end, v.n_reads, np.int32)),
+                 ("slot_off", arr(v.slot_off, v.n_reads + 1, np.int64)), ("blk_off", arr(v.blk_off, v.n_blocks + 1, np.uint32)),
+                 ("blk_read", arr(v.blk_read, v.n_blocks, np.int32)),
+                 ("events", arr(v.events, v.n_events, np.uint16)), ("ref_wire", ref_grid), ("tile_off", tile_off),
+                 ("tile_ent", np.frombuffer(tile_ent[:n_ent.value].tobytes(), np.uint8) if n_ent.value else np.zeros(16, np.uint8))]
+        n_indel = -1
+        if events is not None:
+            ev_off, ev_pos, ev_len = (np.asarray(x) for x in events)
+            kept = np.nonzero(keep)[0]
+            cnt = (ev_off[1:] - ev_off[:-1])[kept]
+            off = np.zeros(kept.size + 1, np.int32)
+            np.cumsum(cnt, out=off[1:])
+            idx = np.concatenate([np.arange(ev_off[r], ev_off[r + 1]) for r in kept]) if kept.size else np.zeros(0, np.int64)
+            hp = (np.asarray(hap, np.uint8) if hap is not None else np.zeros(n, np.uint8))[kept]
+            z = lambda x, dt: np.ascontiguousarray(x, dt) if len(x) else np.zeros(1, dt)      # noqa: E731
+            parts += [("ev_off", z(off, np.int32)), ("ev_pos", z(ev_pos[idx], np.int32)), ("ev_len", z(ev_len[idx], np.int32)),
+                      ("read_hap", z(hp, np.uint8))]
+            n_indel = int(kept.size)
+        sections, total = {}, 0
+        for name, a_ in parts:
+            sections[name] = (total, a_.dtype, int(a_.size))
+            total += (a_.nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        buf = torch.empty(max(total, _ALIGN), dtype=torch.uint8, pin_memory=bool(pin and torch.cuda.is_available()))
+        hb = buf.numpy()
+        for name, a_ in parts:
+            o = sections[name][0]
+            hb[o:o + a_.nbytes] = a_.view(np.uint8).reshape(-1)
+        return WirePack(buf=buf, sections=sections, tile_size=tile_size, tile_pos0=tile_pos0.value, n_tiles=n_tiles.value,
+                        n_entries=int(n_ent.value), codes_len=int(codes_len.value), n_reads=int(v.n_reads), n_blocks=int(v.n_blocks),
+                        n_events=int(v.n_events), ref_len=ref_len, pos_lo=pos_lo, pos_hi=pos_hi, n_indel_reads=n_indel)
+    finally:
+        L.nc_wire_free(h)
+
+
+def build_wire_from_world(world: World, supplementary=False, exclude=None, **kw) -> WirePack:
+    if "events" in world.meta:
+        kw.setdefault("hap", world.meta["hap"])
+        kw.setdefault("events", world.meta["events"])
+    return build_wire(world.read_start, world.read_end, world.read_off, world.codes, world.read_flag,
+                      ref_wire_from_string(world.ref, exclude), supplementary=supplementary, **kw)
+
+
+def _views(dev_buf, wp: WirePack):
+    out = {}
+    for name, (off, dt, cnt) in wp.sections.items():
+        nb = cnt * np.dtype(dt).itemsize
+        t = dev_buf[off:off + nb]
+        out[name] = t if np.dtype(dt) == np.uint8 else t.view({np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.uint32): torch.int32,
+                                                                np.dtype(np.uint16): torch.int16}[np.dtype(dt)])
+    return out
+
+
+def _expand(eng, wp: WirePack, v, codes, ref_code):
+    rc = eng.L.nc_wire_expand(eng.ctx, wp.n_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
+                              C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ref_wire"].data_ptr()), wp.tile_pos0, wp.ref_len,
+                              C.c_void_p(v["blk_off"].data_ptr()), C.c_void_p(v["blk_read"].data_ptr()),
+                              C.c_void_p(v["events"].data_ptr() if wp.n_events else v["blk_off"].data_ptr()),
+                              wp.n_blocks, C.c_void_p(codes.data_ptr()), wp.codes_len, C.c_void_p(ref_code.data_ptr()))
+    eng._check(rc, "nc_wire_expand")
+
+
+def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
+    g = (lambda t: t.clone()) if own_index else (lambda t: t)
+    dp = DevicePack(codes=codes, tile_off=g(v["tile_off"]), tile_ent=g(v["tile_ent"]), ref_code=ref_code, tile_size=wp.tile_size,
+                    tile_pos0=wp.tile_pos0, n_tiles=wp.n_tiles, n_entries=wp.n_entries, pos_lo=wp.pos_lo, pos_hi=wp.pos_hi)
+    if wp.n_indel_reads >= 0:
+        dp.events = dict(n_reads=wp.n_indel_reads, ev_off=g(v["ev_off"]), ev_pos=g(v["ev_pos"]), ev_len=g(v["ev_len"]), read_hap=g(v["read_hap"]))
+    return dp
+
+
+def upload_wire(eng, wp: WirePack) -> DevicePack:
+    """One contig, synchronously: copy the wire buffer, expand it into its own codes / ref_code tensors; the tile index and
+    the indel events are cloned out so that the 0.2 B/entry wire copy can be freed"""
+    eng.use_torch_stream()
+    dev = eng.device
+    d = wp.buf.to(dev, non_blocking=True)
+    v = _views(d, wp)
+    codes = torch.empty(wp.codes_len, dtype=torch.uint8, device=dev)
+    ref_code = torch.empty(wp.ref_len, dtype=torch.uint8, device=dev)
+    _expand(eng, wp, v, codes, ref_code)
+    return _device_pack(wp, v, codes, ref_code, own_index=True)
+
+
+class WireUploader:
+    """Double-buffered uploads: `submit(wp)` enqueues the single H2D copy of a contig on the upload stream (it waits, on the
+    device, until the slot's previous user has been released); `expand(ticket)` makes the compute stream wait for that copy and
+    rebuilds the codes in HBM; `release(ticket)` marks -- in compute-stream order -- that the step which used the pack has been
+    enqueued completely, so the slot may be overwritten.  The expanded codes / ref_code live in ONE buffer pair that every
+    step reuses: all steps run on the same compute stream, so step i+1's expansion is ordered behind step i's last reader."""
+
+    def __init__(self, eng, slots=2):
+        self.eng = eng
+        self.stream = torch.cuda.Stream(device=eng.device)
+        self.slots = [dict(buf=None, free=None) for _ in range(slots)]
+        self.turn = 0
+        self.codes = None
+        self.ref_code = None
+        self.h2d_events = []                       # (start, stop) event pairs of the copies, for the achieved PCIe rate
+        self.timing = False
+
+    def submit(self, wp: WirePack):
+        s = self.slots[self.turn % len(self.slots)]
+        self.turn += 1
+        if s["buf"] is None or s["buf"].numel() < wp.nbytes:
+            if s["free"] is not None:
+                s["free"].synchronize()
+            s["buf"] = torch.empty(wp.nbytes + wp.nbytes // 8, dtype=torch.uint8, device=self.eng.device)
+        with torch.cuda.stream(self.stream):
+            if s["free"] is not None:
+                self.stream.wait_event(s["free"])
+            if self.timing:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+            s["buf"][:wp.nbytes].copy_(wp.buf, non_blocking=True)
+            done = torch.cuda.Event(enable_timing=self.timing)
+            done.record(self.stream)
+            if self.timing:
+                self.h2d_events.append((e0, done, wp.nbytes))
+        return dict(wp=wp, slot=s, done=done)
+
+    def expand(self, ticket) -> DevicePack:
+        eng, wp = self.eng, ticket["wp"]
+        eng.use_torch_stream()
+        cur = torch.cuda.current_stream(eng.device)
+        cur.wait_event(ticket["done"])
+        if self.codes is None or self.codes.numel() < wp.codes_len:
+            self.codes = torch.empty(wp.codes_len + wp.codes_len // 16, dtype=torch.uint8, device=eng.device)
+        if self.ref_code is None or self.ref_code.numel() < wp.ref_len:
+            self.ref_code = torch.empty(wp.ref_len + wp.ref_len // 16, dtype=torch.uint8, device=eng.device)
+        v = _views(ticket["slot"]["buf"], wp)
+        codes, ref_code = self.codes[:wp.codes_len], self.ref_code[:wp.ref_len]
+        _expand(eng, wp, v, codes, ref_code)
+        return _device_pack(wp, v, codes, ref_code, own_index=False)
+
+    def release(self, ticket):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.eng.device))
+        ticket["slot"]["free"] = ev
+
+    def h2d_rate(self):
+        """-> (GB/s over the timed copies, total ms, bytes); call after a synchronize"""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.h2d_events)
+        nb = sum(n for _, _, n in self.h2d_events)
+        return (nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0), ms, nb

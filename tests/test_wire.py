@@ -1,0 +1,119 @@
+"""The reference-difference transfer form of the read pack (nc_wire_*, nanocaller_amd/wire.py): the host builder against a
+numpy restatement of the expansion (CPU), and nc_wire_expand on the GPU byte for byte against nc_pack_fill's codes."""
+import numpy as np
+import pytest
+
+from nanocaller_amd.pack import pack_world
+from nanocaller_amd.wire import build_wire_from_world, ref_wire_from_string
+
+from util import load_world
+
+
+def _expand_numpy(wp):
+    """what nc_wire_expand writes, restated with numpy on the host arrays of a WirePack"""
+    rs, re_, so = wp.host("rd_start").astype(np.int64), wp.host("rd_end").astype(np.int64), wp.host("slot_off")
+    refw, bo, ev = wp.host("ref_wire"), wp.host("blk_off"), wp.host("events")
+    codes = np.full(wp.codes_len, 7, np.uint8)
+    for r in range(wp.n_reads):
+        base = so[r] - (rs[r] & ~15)
+        ri = np.arange(rs[r], re_[r]) - wp.tile_pos0
+        ok = (ri >= 0) & (ri < wp.ref_len)
+        codes[base + rs[r]:base + re_[r]] = np.where(ok, refw[np.clip(ri, 0, wp.ref_len - 1)] & 7, 4)
+    blk = np.repeat(np.arange(wp.n_blocks), np.diff(bo.astype(np.int64)))
+    codes[blk * 1024 + (ev & 0x3ff)] = ev >> 12
+    ref_code = np.where(refw & 8, 4, refw & 7).astype(np.uint8)
+    return codes, ref_code
+
+
+CASES = [("ont", False, None, 2048), ("ont", True, [(55_000, 58_000), (30_000, 41_000)], 1024), ("hifi", False, None, 4096),
+         ("deep", False, None, 2048), ("indel", False, None, 2048)]
+
+
+@pytest.mark.parametrize("name,supp,excl,tile", CASES)
+def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
+    w = load_world(name)
+    hp = pack_world(w, supplementary=supp, exclude=excl, tile_size=tile)
+    wp = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile, pin=False)
+    codes, ref_code = _expand_numpy(wp)
+    assert wp.codes_len == hp.codes.size and np.array_equal(codes, hp.codes)
+    assert np.array_equal(ref_code, hp.ref_code)
+    assert np.array_equal(wp.host("tile_off"), hp.tile_off)
+    assert wp.host("tile_ent").tobytes() == hp.tile_ent.tobytes()
+    assert (wp.tile_size, wp.tile_pos0, wp.n_tiles, wp.n_entries) == (hp.tile_size, hp.tile_pos0, hp.n_tiles, hp.tile_ent.shape[0])
+    if hp.ev_off is not None:
+        for k, a in (("ev_off", hp.ev_off), ("ev_pos", hp.ev_pos), ("ev_len", hp.ev_len), ("read_hap", hp.read_hap)):
+            assert np.array_equal(wp.host(k)[:a.size], a)
+    # the point of it: far fewer bytes than 1 B per pileup entry (ONT worlds: 4 % substitutions + 4 % deletions)
+    entries = int((w.read_end - w.read_start).sum())
+    assert 2 * wp.n_events < 0.25 * entries
+    ev, bo = wp.host("events"), wp.host("blk_off")
+    assert bo[0] == 0 and bo[-1] == wp.n_events and np.all(np.diff(bo.astype(np.int64)) >= 0) and np.all((ev >> 12) <= 4)
+    br, so = wp.host("blk_read"), wp.host("slot_off")
+    b0 = np.arange(wp.n_blocks, dtype=np.int64) * 1024
+    assert np.array_equal(br, np.minimum(np.searchsorted(so[1:], b0, side="right"), wp.n_reads))   # first read with slot end > block start
+
+
+def test_ref_wire_bytes():
+    rw = ref_wire_from_string("AGTCagtcNnR", exclude=[(2, 4)])
+    assert rw.tolist() == [0, 1 | 8, 2 | 8, 3, 0 | 8, 1 | 8, 2 | 8, 3 | 8, 4 | 8, 4 | 8, 4 | 8]
+
+
+def test_degenerate_worlds():
+    from nanocaller_amd.synth import World
+    ref = "ACGT" * 40
+    z = np.zeros(0, np.int32)
+    empty = World(chrom="c", ref=ref, read_start=z, read_end=z, read_flag=z, read_off=np.zeros(1, np.int64), codes=np.zeros(0, np.uint8))
+    wp = build_wire_from_world(empty, pin=False)
+    assert wp.n_reads == 0 and wp.n_events == 0 and wp.codes_len == 16 and wp.n_blocks == 1
+    codes, _ = _expand_numpy(wp)
+    assert np.all(codes == 7)
+    # many tiny reads in one block, one of them all-different from the reference, one filtered
+    n = 120
+    rs = (np.arange(n, dtype=np.int32) // 2) + 3
+    re_ = rs + 11
+    codes_in = np.tile(np.array([4, 0, 1, 2, 3, 4, 4, 0, 1, 2, 3], np.uint8), n)
+    flags = np.zeros(n, np.int32)
+    flags[7] = 0x400
+    w = World(chrom="c", ref=ref, read_start=rs, read_end=re_, read_flag=flags, read_off=np.arange(n + 1, dtype=np.int64) * 11, codes=codes_in)
+    hp = pack_world(w)
+    wp = build_wire_from_world(w, pin=False)
+    c2, rc = _expand_numpy(wp)
+    assert np.array_equal(c2, hp.codes) and np.array_equal(rc, hp.ref_code) and wp.n_reads == n - 1
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from nanocaller_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,supp,excl,tile", CASES)
+def test_wire_expand_on_device_equals_direct_pack(eng, name, supp, excl, tile):
+    import torch
+    from nanocaller_amd.wire import WireUploader, upload_wire
+    w = load_world(name)
+    a = eng.upload(pack_world(w, supplementary=supp, exclude=excl, tile_size=tile))
+    wp = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile)
+    b = upload_wire(eng, wp)
+    up = WireUploader(eng)
+    t = up.submit(wp)
+    c = up.expand(t)
+    up.release(t)
+    torch.cuda.synchronize()
+    for d in (b, c):
+        assert torch.equal(d.codes, a.codes) and torch.equal(d.ref_code, a.ref_code)
+        assert torch.equal(d.tile_off, a.tile_off) and torch.equal(d.tile_ent[:a.tile_ent.numel()], a.tile_ent)
+        assert (d.tile_size, d.tile_pos0, d.n_tiles, d.n_entries, d.pos_lo, d.pos_hi) == (a.tile_size, a.tile_pos0, a.n_tiles, a.n_entries, a.pos_lo, a.pos_hi)
+        if a.events is not None:
+            for k in ("ev_off", "ev_pos", "ev_len", "read_hap"):
+                assert torch.equal(d.events[k][:a.events[k].numel()], a.events[k])
+            assert d.events["n_reads"] == a.events["n_reads"]
+    # slot reuse: a second and third contig through the same two slots, each expanded result checked before the next
+    for nm in ("hifi", "ont", "deep"):
+        w2 = load_world(nm)
+        t2 = up.submit(build_wire_from_world(w2))
+        d2 = up.expand(t2)
+        up.release(t2)
+        torch.cuda.synchronize()
+        assert torch.equal(d2.codes, eng.upload(pack_world(w2)).codes)
