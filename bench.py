@@ -260,9 +260,16 @@ def extra_indel_config(eng, local):
     eng.star_msa_tensor(sets[:30], refs[:30])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    x, cns, ncols, rows, rrows = eng.star_msa_tensor(sets, refs, want_rows=True)
+    x, cns, ncols = eng.star_msa_tensor(sets, refs)
     torch.cuda.synchronize()
     t_msa = time.perf_counter() - t0
+    eng.enable_timing(True)
+    eng.star_msa_tensor(sets, refs)
+    torch.cuda.synchronize()
+    msa_dev_ms = eng.last_ms(3)
+    eng.enable_timing(False)
+    n_par = min(len(sets), 63)
+    xs, _, _, rows, rrows = eng.star_msa_tensor(sets[:n_par], refs[:n_par], want_rows=True)     # the aligned rows of a sample, for the K8 check
     wgt = Weights(get_indel_model("ONT-HG002"))
     eng.load_weights(_lib.MODEL_INDEL, wgt)
     x15 = x.reshape(n_sites, 3, 5, 128, 2).reshape(n_sites, 15, 128, 2).contiguous()
@@ -284,8 +291,8 @@ def extra_indel_config(eng, local):
     t_k9 = (time.perf_counter() - t0) / 3
     # parity: K8 tensors of a few sets against the oracle's msa() half on the device's own rows; K9 against the f64 oracle
     xh = x.cpu().numpy()
-    k8_ok = True
-    for s in range(0, min(len(sets), 60), 7):
+    k8_ok = bool(np.array_equal(xs.cpu().numpy(), xh[:n_par]))
+    for s in range(0, n_par, 7):
         ex, _ = oracle.indel_tensor(rows[s], rrows[s])
         k8_ok &= bool(np.array_equal(ex, xh[s]))
     m = min(n_sites, 256)
@@ -297,7 +304,8 @@ def extra_indel_config(eng, local):
                         "%d anchors; 3 read sets per anchor (15/15/30 reads of 160 b) through the device star alignment + K8, "
                         "Indel_model (K9); host marshalling of the read sets included" % n_sites,
             "value": n_sites / total, "unit": "candidate sites/s", "sites": n_sites,
-            "stages_ms": {"k7_scan_and_pick": t_scan * 1e3, "star_alignment_k8": t_msa * 1e3, "k9_cnn": t_cnn * 1e3},
+            "stages_ms": {"k7_scan_and_pick": t_scan * 1e3, "star_alignment_k8": t_msa * 1e3, "star_alignment_k8_device_only": msa_dev_ms,
+                          "k9_cnn": t_cnn * 1e3},
             "k7_columns_per_s": Lw / t_scan, "alignments_per_s": sum(len(s) for s in sets) / t_msa,
             "roofline": {"bound": "mfma", "kernel": "K9 indel CNN (k9_conv12_h3 + k8_conv23_h3 + k3_fc1), %d sites per call" % nb,
                          "achieved": k9_tf, "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s", "frac": k9_tf / (F16_MFMA_PEAK_TFLOPS / 3.0),
@@ -321,10 +329,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ        # launched by torch.distributed.run
+    # test hooks: several ranks on ONE GPU (a 1-GPU box can exercise the N > 1 code path: NC_BENCH_ONE_GPU=1 puts every rank
+    # on device 0 and rendezvous goes over gloo, since RCCL refuses two ranks on one device)
+    one_gpu = os.environ.get("NC_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
     from nanocaller_amd import snpCaller
     from nanocaller_amd.engine import get_engine
     from nanocaller_amd.utils import get_chunks
@@ -342,7 +358,8 @@ def main():
         mine, scaling, job_contigs = [rank], "weak", world
     else:
         T = max(args.total_contigs, world)
-        mine, scaling, job_contigs = list(range(rank * T // world, (rank + 1) * T // world)), "strong", T
+        from nanocaller_amd.shard import shard_range
+        mine, scaling, job_contigs = list(shard_range(T, rank, world)), "strong", T
     t_setup = time.perf_counter()
     contigs = [Contig(eng, L, args.depth, args.tech, 812 + k, keep_pack=(i == 0 or args.resident)) for i, k in enumerate(mine)]
     t_setup = time.perf_counter() - t_setup

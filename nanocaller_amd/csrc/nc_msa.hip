@@ -12,6 +12,7 @@
 //   C2 k_set_rows      one workgroup per set: the aligned rows (symbols 0..4, other = 5) and the aligned reference row in the
 //                      layout nc_indel_tensor reads
 // then nc_indel_tensor's kernel (K8) on the rows.  Host round trips: the per-set column counts (row offsets are a prefix sum).
+#include <cstdlib>
 #include <vector>
 
 #include "nc_common.h"
@@ -90,6 +91,115 @@ __global__ __launch_bounds__(64) void k_nw_fill(NwArgs p)
     }
 }
 
+
+// ---- A', B': the same DP with 16 lanes per alignment and the DP rows in REGISTERS ---------------------------------------------
+// k_nw_fill keeps H / F and one traceback BYTE per cell in HBM (17 B of traffic per cell: 46 ms per 368 k alignments of 160 x 161,
+// HBM-bound).  Here a group of 16 lanes owns one alignment, lane q the CPL consecutive reference columns q*CPL+1 .. q*CPL+CPL; the
+// group sweeps the matrix in anti-diagonal order (at step t lane q works on read row t - q), H[i-1][.] / F[i-1][.] of a lane's own
+// columns never leave its registers, and what crosses a column-block boundary -- H[i][j-1], E[i][j-1] -- moves one lane to the
+// right with a DPP row shift (row_shr:1: a 16-lane DPP row IS the group).  Per cell only the 4-bit traceback code reaches HBM
+// (8 cells per dword, 16 lanes = one 64-byte line per row and word): 0.5 B per cell instead of 17.  Same recurrences, same tie
+// rules, same results as k_nw_fill / nc_star_msa.
+__device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_nw_fill16(NwArgs p, int32_t N1, uint32_t *__restrict__ Tw, int32_t *__restrict__ Hlast,
+                                                  int32_t *__restrict__ hcolA)
+{
+    constexpr int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;      // words per lane and row, padded to a vector store
+    const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
+    const int al = blockIdx.x * 4 + g;
+    const bool live = al < p.A;
+    int n1 = 0, n2 = 0;
+    const uint8_t *s1 = p.reads, *s2 = p.refs;
+    if (live) {
+        const int a = p.a0 + al;
+        s1 = p.reads + p.read_off[a];
+        n1 = p.read_off[a + 1] - p.read_off[a];
+        const int set = p.read_set[a];
+        s2 = p.refs + p.ref_off[set];
+        n2 = p.ref_off[set + 1] - p.ref_off[set];
+    }
+    int32_t H[CPL], F[CPL];
+    int32_t rb[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int j = q * CPL + c + 1;
+        H[c] = -p.open - (j - 1) * p.extend;                 // row 0
+        F[c] = NW_NEG;
+        rb[c] = j <= n2 ? (int32_t)s2[j - 1] : -1;
+    }
+    // the longest read of the wave's four alignments bounds the sweep
+    int nmax = n1;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    const int64_t arow = (int64_t)al * (N1 + 1);
+    int32_t h_out = 0, e_out = NW_NEG;
+    int32_t h_in_prev = q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend;      // H[0][q*CPL]: the diagonal of the lane's first row
+    const int jn_lane = (n2 - 1) / CPL, jn_c = (n2 - 1) % CPL;                    // owner of column n2
+    for (int t = 1; t <= nmax + 15; t++) {
+        const int i = t - q;
+        int32_t nh = dpp_shr1(0, h_out), ne = dpp_shr1(NW_NEG, e_out);
+        if (q == 0) {
+            nh = -p.open - (i - 1) * p.extend;                // H[i][0]
+            ne = NW_NEG;
+        }
+        const bool active = live && i >= 1 && i <= n1 && q * CPL < n2;
+        if (active) {
+            const int32_t c1 = (int32_t)s1[i - 1];
+            int32_t hdiag = h_in_prev, hleft = nh, e = ne;
+            uint32_t words[NWD];
+#pragma unroll
+            for (int k = 0; k < NWD; k++) words[k] = 0;
+            // straight-line: columns beyond n2 (rb = -1: they never match) are computed like real ones -- nothing reads them:
+            // they lie to the right of everything valid, in this lane and in the lanes after it
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int32_t hup = H[c], fup = F[c];
+                const int32_t e_open = hleft - p.open, e_ext = e - p.extend;
+                const uint32_t te = e_ext >= e_open ? (uint32_t)T_EEXT : 0u;
+                e = max(e_open, e_ext);
+                const int32_t f_open = hup - p.open, f_ext = fup - p.extend;
+                const uint32_t tf = f_ext >= f_open ? (uint32_t)T_FEXT : 0u;
+                const int32_t f = max(f_open, f_ext);
+                const int32_t d = hdiag + (c1 == rb[c] ? p.match : p.mismatch);
+                const int32_t h1 = max(d, e);
+                const uint32_t w1 = e > d ? (uint32_t)T_DEL : (uint32_t)T_DIAG;
+                const int32_t h = max(h1, f);
+                const uint32_t w = f > h1 ? (uint32_t)T_INS : w1;
+                H[c] = h;
+                F[c] = f;
+                words[c >> 3] |= (te | tf | w) << ((c & 7) * 4);
+                hdiag = hup;
+                hleft = h;
+            }
+            h_out = hleft;
+            e_out = e;
+            // one vector store per lane: the 16 lanes of the group write one contiguous 64 / 128 / 256-byte run per row
+            uint32_t *tp = Tw + ((arow + i) * 16 + q) * NWP;
+            if (NWP == 1) tp[0] = words[0];
+            else if (NWP == 2) *reinterpret_cast<uint2 *>(tp) = make_uint2(words[0], words[1]);
+            else *reinterpret_cast<uint4 *>(tp) = make_uint4(words[0], words[1], NWD > 2 ? words[NWD > 2 ? 2 : 0] : 0u, 0u);
+            if (q == jn_lane) {
+                int32_t hv = H[0];
+#pragma unroll
+                for (int c = 1; c < CPL; c++) hv = c == jn_c ? H[c] : hv;
+                hcolA[arow + i] = hv;                         // H[i][n2]
+            }
+            if (i == n1) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    if (rb[c] >= 0) Hlast[(int64_t)al * p.W + q * CPL + c + 1] = H[c];
+            }
+        }
+        if (i >= 1) h_in_prev = nh;                           // H[i][q*CPL]: the diagonal of the next row (before row 1: row 0's value)
+    }
+}
+
+
 struct TraceOut {
     int16_t *qidx;                 // [A][W]: read index aligned to reference position j, -1 = gap
     int16_t *ins_len, *ins_q;      // [A][W]: insertion in slot j (before reference position j; slot n2 = after the last)
@@ -142,6 +252,63 @@ __global__ __launch_bounds__(64) void k_nw_trace(NwArgs p, TraceOut o)
     }
 }
 
+
+// B': traceback over the packed codes of k_nw_fill16 (boundary row / column codes are implied: row 0 is a deletion run, column
+// 0 an insertion run)
+__global__ __launch_bounds__(64) void k_nw_trace16(NwArgs p, TraceOut o, int32_t N1, int32_t CPL, const uint32_t *__restrict__ Tw,
+                                                   const int32_t *__restrict__ Hlast, const int32_t *__restrict__ hcolA)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    if (al >= p.A) return;
+    const int a = p.a0 + al;
+    const int n1 = p.read_off[a + 1] - p.read_off[a];
+    const int set = p.read_set[a];
+    const int n2 = p.ref_off[set + 1] - p.ref_off[set];
+    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    const int64_t arow = (int64_t)al * (N1 + 1);
+    int16_t *qidx = o.qidx + (int64_t)al * p.W, *il = o.ins_len + (int64_t)al * p.W, *iq = o.ins_q + (int64_t)al * p.W;
+    for (int j = 0; j <= n2; j++) { qidx[j] = -1; il[j] = 0; iq[j] = 0; }
+    int i = n1, j = n2;
+    if (n1 > 0 && n2 > 0) {                                           // free tail: best cell of the last row / last column
+        int32_t best = Hlast[(int64_t)al * p.W + n2];
+        for (int jj = n2 - 1; jj >= 0; jj--) {
+            const int32_t v = jj > 0 ? Hlast[(int64_t)al * p.W + jj] : -p.open - (n1 - 1) * p.extend;
+            if (v > best) { best = v; i = n1; j = jj; }
+        }
+        for (int ii = n1 - 1; ii >= 0; ii--) {
+            const int32_t v = ii > 0 ? hcolA[arow + ii] : -p.open - (n2 - 1) * p.extend;
+            if (v > best) { best = v; i = ii; j = n2; }
+        }
+        if (i < n1) { il[n2] = (int16_t)(n1 - i); iq[n2] = (int16_t)i; }   // the rest of the read: insertion after the window
+    }
+    int state = -1;
+    while (i > 0 || j > 0) {
+        uint32_t t;
+        if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
+        else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
+        else {
+            const int q = (j - 1) / CPL, c = (j - 1) % CPL;
+            t = (Tw[((arow + i) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
+        }
+        if (state < 0) {
+            const int w = t & 3;
+            if (w == T_DIAG) { qidx[j - 1] = (int16_t)(i - 1); i--; j--; continue; }
+            state = w == T_DEL ? 1 : 2;
+        }
+        if (state == 1) {
+            const bool ext = (t & T_EEXT) != 0;
+            j--;                                                       // reference position j stays a gap
+            if (!ext) state = -1;
+        } else {
+            const bool ext = (t & T_FEXT) != 0;
+            il[j]++;
+            iq[j] = (int16_t)(i - 1);
+            i--;
+            if (!ext) state = -1;
+        }
+    }
+}
+
 // per set: columns.  set_read0[s] .. set_read0[s+1]: the set's alignments (indices local to the launch)
 __global__ __launch_bounds__(256) void k_set_columns(int32_t W, const int32_t *__restrict__ set_read0, const int32_t *__restrict__ ref_off,
                                                      int32_t set0, const int16_t *__restrict__ ins_len, int32_t *__restrict__ col /* [sets][W] */,
@@ -166,7 +333,9 @@ __global__ __launch_bounds__(256) void k_set_columns(int32_t W, const int32_t *_
 
 __device__ __forceinline__ uint8_t sym_code(uint8_t c)
 {
-    return c == 'A' ? 0 : c == 'G' ? 1 : c == 'T' ? 2 : c == 'C' ? 3 : c == '-' ? 4 : 5;
+    // anything but AGTC (a read base N) counts as a gap at its column: the reference's symbol table raises KeyError there
+    // (generate_indel_pileups.py:56), the host statement (generate_indel_pileups.msa) maps it the same way
+    return c == 'A' ? 0 : c == 'G' ? 1 : c == 'T' ? 2 : c == 'C' ? 3 : 4;
 }
 
 __global__ __launch_bounds__(256) void k_set_rows(NwArgs p, TraceOut o, const int32_t *__restrict__ set_read0, int32_t set0,
@@ -258,9 +427,19 @@ extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads
         int32_t s1 = s0;
         while (s1 < n_sets && (s1 == s0 || set_read0[s1 + 1] - set_read0[s0] <= GROUP)) s1++;
         const int32_t ng = s1 - s0, a0 = set_read0[s0], Ag = set_read0[s1] - a0, Apad = std::max(64, (Ag + 63) & ~63);
-        NC_TRY(nc_ensure(ctx, ctx->msa_rows_hf, (size_t)2 * W * Apad * 4));
-        NC_TRY(nc_ensure(ctx, ctx->msa_hcol, (size_t)(N1 + 1) * Apad * 4));
-        NC_TRY(nc_ensure(ctx, ctx->msa_tb, (size_t)per_al * Apad));
+        // register / DPP kernel when 16 lanes x <= 17 columns cover the window (160 b ONT and 260 b PacBio windows do)
+        const int CPL = N2 <= 64 ? 4 : N2 <= 128 ? 8 : N2 <= 176 ? 11 : N2 <= 272 ? 17 : 0;
+        const bool fast = CPL > 0 && !getenv("NC_MSA_LANE_PER_READ");
+        const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+        if (fast) {
+            NC_TRY(nc_ensure(ctx, ctx->msa_rows_hf, (size_t)std::max(Ag, 1) * W * 4));                       // Hlast [A][W]
+            NC_TRY(nc_ensure(ctx, ctx->msa_hcol, (size_t)std::max(Ag, 1) * (N1 + 1) * 4));                    // hcol  [A][N1 + 1]
+            NC_TRY(nc_ensure(ctx, ctx->msa_tb, (size_t)std::max(Ag, 1) * (N1 + 1) * NWP * 64 + 64));          // 4-bit codes
+        } else {
+            NC_TRY(nc_ensure(ctx, ctx->msa_rows_hf, (size_t)2 * W * Apad * 4));
+            NC_TRY(nc_ensure(ctx, ctx->msa_hcol, (size_t)(N1 + 1) * Apad * 4));
+            NC_TRY(nc_ensure(ctx, ctx->msa_tb, (size_t)per_al * Apad));
+        }
         NC_TRY(nc_ensure(ctx, ctx->msa_trace, (size_t)3 * std::max(Ag, 1) * W * 2));
         NC_TRY(nc_ensure(ctx, ctx->msa_cols, ((size_t)ng * W + (size_t)ng + (size_t)ng + 1) * 4 + 64));
         std::vector<int32_t> sr0((size_t)ng + 1);
@@ -274,7 +453,17 @@ extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads
         p.Hrow = (int32_t *)ctx->msa_rows_hf.p; p.Frow = p.Hrow + (size_t)W * Apad; p.hcol = (int32_t *)ctx->msa_hcol.p; p.T = (uint8_t *)ctx->msa_tb.p;
         TraceOut o;
         o.qidx = (int16_t *)ctx->msa_trace.p; o.ins_len = o.qidx + (size_t)std::max(Ag, 1) * W; o.ins_q = o.ins_len + (size_t)std::max(Ag, 1) * W;
-        if (Ag > 0) {
+        if (Ag > 0 && fast) {
+            uint32_t *Tw = (uint32_t *)ctx->msa_tb.p;
+            int32_t *Hl = (int32_t *)ctx->msa_rows_hf.p, *hc = (int32_t *)ctx->msa_hcol.p;
+            const dim3 gr((unsigned)((Ag + 3) / 4));
+            if (CPL == 4) hipLaunchKernelGGL(k_nw_fill16<4>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+            else if (CPL == 8) hipLaunchKernelGGL(k_nw_fill16<8>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+            else if (CPL == 11) hipLaunchKernelGGL(k_nw_fill16<11>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+            else hipLaunchKernelGGL(k_nw_fill16<17>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+            hipLaunchKernelGGL(k_nw_trace16, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p, o, N1, CPL, (const uint32_t *)Tw, (const int32_t *)Hl,
+                               (const int32_t *)hc);
+        } else if (Ag > 0) {
             hipLaunchKernelGGL(k_nw_fill, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p);
             hipLaunchKernelGGL(k_nw_trace, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p, o);
         }

@@ -311,26 +311,32 @@ class Engine:
                                                _lib.npp(ends), C.byref(prm), _lib.npp(out), _lib.npp(off)), "nc_indel_scan_batch")
         return [out[off[k]:off[k + 1]] for k in range(len(chunks))]
 
-    def star_msa_tensor(self, read_sets, refs, *, open_=9, extend=1, match=20, mismatch=-10, max_cols=None, want_rows=False):
+    def star_msa_tensor(self, read_sets, refs, *, open_=9, extend=1, match=20, mismatch=-10, max_cols=None, want_rows=False, cns_as_str=False):
         """Device star alignment (nc_star_msa_tensor) of many read sets at once + the rows -> tensor kernel.
         read_sets[s]: list of read strings, refs[s]: reference window string.
-        -> (x f32 [S,5,128,2] device, cns list of uint8 arrays with gaps removed, n_cols int32 [S]
+        -> (x f32 [S,5,128,2] device, cns list of uint8 arrays (or, cns_as_str, AGTC strings) with gaps removed, n_cols int32 [S]
             [, rows list of uint8 [n_reads, n_cols], ref_rows list of uint8 [n_cols]])"""
         S = len(read_sets)
         x = torch.empty((S, 5, 128, 2), dtype=torch.float32, device=self.device)
         if S == 0:
             return (x, [], np.zeros(0, np.int32)) + (([], []) if want_rows else ())
-        n_reads = np.array([len(rs) for rs in read_sets], np.int64)
+        n_reads = np.fromiter(map(len, read_sets), np.int64, S)
         set0 = np.zeros(S + 1, np.int32)
         np.cumsum(n_reads, out=set0[1:])
         flat = [q for rs in read_sets for q in rs]
+        rlen = np.fromiter(map(len, flat), np.int64, len(flat))
         read_off = np.zeros(len(flat) + 1, np.int32)
-        np.cumsum([len(q) for q in flat], out=read_off[1:])
+        np.cumsum(rlen, out=read_off[1:])
+        reflen = np.fromiter(map(len, refs), np.int64, S)
         ref_off = np.zeros(S + 1, np.int32)
-        np.cumsum([len(r) for r in refs], out=ref_off[1:])
+        np.cumsum(reflen, out=ref_off[1:])
         raw_reads, raw_refs = "".join(flat).encode(), "".join(refs).encode()
         # every read base can at most add one column to its set
-        cap = np.array([len(refs[s]) + sum(len(q) for q in read_sets[s]) for s in range(S)], np.int64)
+        per_set = np.zeros(S, np.int64)
+        nz = n_reads > 0
+        if len(flat):
+            per_set[nz] = np.add.reduceat(rlen, set0[:-1][nz])
+        cap = reflen + per_set
         mc = int(max_cols) if max_cols else int(cap.max())
         cns = np.empty((S, mc), np.uint8)
         ncols = np.empty(S, np.int32)
@@ -344,10 +350,17 @@ class Engine:
         self._check(self.L.nc_star_msa_tensor(self.ctx, S, raw_reads, _lib.npp(read_off), _lib.npp(set0), raw_refs, _lib.npp(ref_off),
                                               int(open_), int(extend), int(match), int(mismatch), mc, _ptr(x), _lib.npp(cns), _lib.npp(ncols),
                                               _lib.npp(rows), _lib.npp(roff), _lib.npp(rr), _lib.npp(rroff)), "nc_star_msa_tensor")
-        out_cns = []
-        for s in range(S):
-            c = cns[s, :min(int(ncols[s]), mc)]
-            out_cns.append(c[c != 4])
+        # consensus with the gap symbols removed: one pass over the [S, mc] block instead of S small array operations
+        keep = (np.arange(mc, dtype=np.int32)[None, :] < np.minimum(ncols, mc)[:, None]) & (cns != 4)
+        cnt = keep.sum(1)
+        cut = np.zeros(S + 1, np.int64)
+        np.cumsum(cnt, out=cut[1:])
+        flat_cns = cns[keep]
+        if cns_as_str:
+            big = np.frombuffer(b"AGTC-NNN", np.uint8)[flat_cns].tobytes().decode("ascii")
+            out_cns = [big[cut[k]:cut[k + 1]] for k in range(S)]
+        else:
+            out_cns = [flat_cns[cut[k]:cut[k + 1]] for k in range(S)]
         if not want_rows:
             return x, out_cns, ncols
         out_rows = [rows[roff[s]:roff[s] + int(n_reads[s]) * int(ncols[s])].reshape(int(n_reads[s]), int(ncols[s])) for s in range(S)]

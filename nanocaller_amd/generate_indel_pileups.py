@@ -16,7 +16,6 @@
 from __future__ import annotations
 
 import ctypes as C
-import random
 import subprocess
 
 import numpy as np
@@ -291,18 +290,18 @@ _SYM = {"A": 0, "G": 1, "T": 2, "C": 3, "-": 4}
 
 def msa(seq_list, ref, v_pos, mincov, maxcov, aligner=None, device=0):
     """generate_indel_pileups.py:12-73 -> (flag, indel_flag, final_mat float64 (5,128,2), cns, ref_seq).  Down-sampling
-    (unseeded random.sample, as in the reference), name sort, alignment by `aligner(names, seqs, ref)` (default: MUSCLE),
+    (deterministic: the first `maxcov` reads in pileup order -- the reference draws an unseeded random.sample, :19-20, so its
+    result above maxcov is not reproducible; same policy as the SNP path), name sort, alignment by `aligner(names, seqs, ref)`,
     the histogram / consensus / tensor half on the GPU (nc_indel_tensor)."""
-    sample = list(seq_list.keys())
-    if len(sample) > maxcov:
-        sample = random.sample(sample, min(len(sample), maxcov))
-    sample = sorted(sample)
+    sample = sorted(list(seq_list.keys())[:maxcov])
     if aligner == "device":
         aligner = star_aligner                                      # one set at a time: the host statement (identical rows)
     rows, ref_row = (aligner or default_aligner())(sample, [seq_list[n] for n in sample], ref)
     if len(rows) < mincov or ref_row is None:
         return (0, 0, None, None, None)
-    mat = np.array([[_SYM[c] for c in r] for r in rows], np.uint8)                # KeyError on 'N', as in the reference (:56)
+    # a read base other than AGTC (N): the reference's symbol table raises KeyError and the chunk is lost (:56); here it
+    # counts as a gap at its column (the device rows do the same, nc_msa.hip sym_code)
+    mat = np.array([[_SYM.get(c, 4) for c in r] for r in rows], np.uint8)
     ref_codes = np.array([_SYM[c] for c in ref_row], np.uint8)
     x, cns = msa_tensor([mat], [ref_codes], device)
     return (1, 1, x[0], cns[0], ref_row.replace("-", ""))
@@ -373,12 +372,10 @@ _DROP_AGTC = str.maketrans("", "", "AGTC")
 
 
 def _sample_set(seq_list, mincov, maxcov):
-    """the part of msa() before the aligner (:13-23): down-sample to maxcov (unseeded, as in the reference), sort the names;
+    """the part of msa() before the aligner (:13-23): down-sample to maxcov (the first maxcov reads in pileup order: a
+    deterministic stand-in for the reference's unseeded random.sample), sort the names;
     -> (names, seqs) or None when fewer than mincov reads remain"""
-    sample = list(seq_list.keys())
-    if len(sample) > maxcov:
-        sample = random.sample(sample, min(len(sample), maxcov))
-    sample = sorted(sample)
+    sample = sorted(list(seq_list.keys())[:maxcov])
     if len(sample) < mincov:
         return None
     return sample, [seq_list[n] for n in sample]
@@ -412,11 +409,7 @@ def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo,
         if any(p is None for p in picked):
             continue                                                             # flag0 and flag1 and flag_total (:345)
         for _, seqs in picked:
-            for q in seqs:
-                bad = q.translate(_DROP_AGTC)
-                if bad:
-                    raise KeyError(bad[0])                                       # as the reference's symbol table does (:56)
-            sets.append(seqs)
+            sets.append(seqs)                                                    # read bases other than AGTC count as gaps (see msa())
             refs.append(ref)
         todo.append((v_pos, next(iter(d0.keys()))))
     empty = ([], [], [], [], [], [])
@@ -424,15 +417,13 @@ def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo,
         return empty
     eng = get_engine(device)
     eng.use_torch_stream()
-    x, cns, _ = eng.star_msa_tensor(sets, refs)
+    x, cns_str, _ = eng.star_msa_tensor(sets, refs, cns_as_str=True)
     xh = x.cpu().numpy().astype(np.float64)
     sym = "AGTC"
     out_pos, x0, x1, x2, alleles, phase = [], [], [], [], [], []
     name_row = {}
     for i, nm in enumerate(names):
         name_row.setdefault(nm, i)                                               # names.index(): the first occurrence
-    lut = np.frombuffer(b"AGTC", np.uint8)
-    cns_str = [lut[c].tobytes().decode() for c in cns]
     preds = allele_prediction_batch(cns_str, refs, [max_range[variants[v_pos]] for (v_pos, _) in todo for _i in range(3)])
     for k, (v_pos, first) in enumerate(todo):
         out_pos.append(v_pos)

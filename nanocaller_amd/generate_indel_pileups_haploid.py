@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from .engine import get_engine
-from .generate_indel_pileups import (_DROP_AGTC, _sample_set, allele_prediction, allele_prediction_batch, default_aligner, msa,
+from .generate_indel_pileups import (_sample_set, allele_prediction, allele_prediction_batch, default_aligner, msa,
                                      scan_indel_candidates, star_aligner)
 
 
@@ -49,10 +49,6 @@ def get_indel_testing_candidates_haploid(dct, chunk, aligner=None, device=0):
             picked = _sample_set({names[r]: text for r, text in win}, dct["mincov"], dct["maxcov"])
             if picked is None:
                 continue
-            for q in picked[1]:
-                bad = q.translate(_DROP_AGTC)
-                if bad:
-                    raise KeyError(bad[0])
             todo.append(v_pos)
             sets.append(picked[1])
             refs.append(ref)
@@ -60,9 +56,8 @@ def get_indel_testing_candidates_haploid(dct, chunk, aligner=None, device=0):
             return empty
         eng = get_engine(device)
         eng.use_torch_stream()
-        x, cns, _ = eng.star_msa_tensor(sets, refs)
-        lut = np.frombuffer(b"AGTC", np.uint8)
-        preds = allele_prediction_batch([lut[c].tobytes().decode() for c in cns], refs, [max_range[variants[v]] for v in todo])
+        x, cns_str, _ = eng.star_msa_tensor(sets, refs, cns_as_str=True)
+        preds = allele_prediction_batch(cns_str, refs, [max_range[variants[v]] for v in todo])
         return (todo, x.cpu().numpy().astype(np.float64), preds)
     for v_pos, win in zip(anchors, d["windows"]):
         ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")

@@ -34,6 +34,11 @@ def shard_chunks(chunks, rank, world):
     return out[rank]
 
 
+def shard_range(n_items, rank, world):
+    """contiguous, near-equal block of range(n_items) owned by `rank` (bench.py: the job's contig list over the GPUs)"""
+    return range(rank * n_items // world, (rank + 1) * n_items // world)
+
+
 def _dev(device):
     return device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
 

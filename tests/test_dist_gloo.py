@@ -23,6 +23,17 @@ def test_shards_partition_the_chunk_list():
             assert max(sizes) < 1.25 * (sum(sizes) / world)         # balanced
 
 
+def test_shard_range_partitions_a_contig_list():
+    from nanocaller_amd.shard import shard_range
+    for n in (8, 9, 24, 5):
+        for world in (1, 2, 4, 8):
+            if world > n:
+                continue
+            parts = [list(shard_range(n, r, world)) for r in range(world)]
+            assert [i for p in parts for i in p] == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -590,3 +590,37 @@ def test_indel_run_writes_the_planted_indels(tmp_path):
     for (p, ln) in truth:
         hit += any(abs(int(f[1]) - p) <= 60 and any(len(a) - len(f[3]) == ln for a in f[4].split(",")) for f in dip)
     assert len(truth) > 40 and hit >= 0.6 * len(truth), (hit, len(truth))
+
+
+def test_maxcov_policy_is_deterministic():
+    """above maxcov the reference draws an unseeded random.sample (generate_indel_pileups.py:19-20): not reproducible.  Policy
+    here, as on the SNP path: the first maxcov reads in pileup order."""
+    d = {"r%03d" % (97 * i % 50): "ACGT" * 3 for i in range(50)}                  # insertion order = pileup order
+    names, seqs = gip._sample_set(d, 2, 7)
+    assert names == sorted(list(d)[:7]) and len(seqs) == 7
+    assert gip._sample_set(d, 2, 7) == (names, seqs)                                # same again
+    assert gip._sample_set({"a": "A"}, 2, 7) is None                               # fewer than mincov reads
+    assert gip._sample_set(d, 2, 500)[0] == sorted(d)
+
+
+@pytest.mark.gpu
+def test_read_base_n_counts_as_a_gap_on_both_paths():
+    """a read base N makes the reference raise KeyError (:56) and lose the chunk; here it is a gap at its column, identically
+    through the host star aligner + K8 and through the device star alignment"""
+    from nanocaller_amd.engine import get_engine
+    rng = np.random.Generator(np.random.PCG64(8))
+    ref = _rand_seq(rng, 161)
+    reads = {"r%02d" % k: ref[:150] for k in range(6)}
+    reads["r02"] = ref[:40] + "N" + ref[41:150]
+    reads["r04"] = ref[:40] + "N" + ref[41:100] + "NN" + ref[102:150]
+    f, _, m_host, cns_host, _ = gip.msa(reads, ref, 100, 2, 160, aligner=gip.star_aligner)
+    assert f == 1
+    eng = get_engine(0)
+    names = sorted(reads)
+    x, cns, _ = eng.star_msa_tensor([[reads[n] for n in names]], [ref])
+    xd = x.cpu().numpy()[0].astype(np.float64)
+    assert np.array_equal(xd, m_host) and "".join("AGTC"[c] for c in cns[0]) == cns_host
+    col = 40                                                                        # 2 of 6 reads carry N at reference column 40
+    b = "AGTC".index(ref[col])
+    assert abs(m_host[4, col, 0] - 2 / 6) < 1e-6 and abs(m_host[b, col, 0] - (4 / 6 - 1)) < 1e-6
+    assert not np.isnan(m_host).any()
