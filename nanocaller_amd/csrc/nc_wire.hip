@@ -148,6 +148,7 @@ extern "C" int nc_wire_free(nc_wire *w)
 }
 
 // ------------------------------------------------------------------------------------------------------------ device side
+namespace {
 // One WAVE per 1024-byte block (four per workgroup), no workgroup barrier: lane t owns the aligned 16-byte group t of the
 // block.  A 16-byte group never straddles two reads (slots are 16-byte aligned) and maps to 16 consecutive, 16-aligned
 // reference positions, so the predicted bytes are ONE aligned dwordx4 of ref_wire, masked to the read's span.  blk_read gives
@@ -226,6 +227,8 @@ __global__ void k_ref_from_wire(const uint8_t *__restrict__ ref_wire, uint8_t *_
         for (int64_t j = i; j < n; j++) ref_code[j] = (ref_wire[j] & 8) ? 4 : (ref_wire[j] & 7);
     }
 }
+
+}   // namespace
 
 extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
                               const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
