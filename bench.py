@@ -217,69 +217,62 @@ def extra_snp_config(eng, uploader, local, L, depth, tech, model, ploidy, exact_
 
 
 def extra_indel_config(eng, local):
-    """The indel path as candidate sites/s (configs[2]'s second half): K7 window scan over a packed 30x contig piece with
-    planted indels -> anchors; for as many anchors, read sets (hap0 / hap1 / all) through the device star alignment + K8
-    (rows -> tensors) and K9 (indel CNN); in-run parity of K8 and K9 against the oracle on a sample."""
-    from nanocaller_amd import _lib
-    from nanocaller_amd.generate_indel_pileups import pick_variants
-    from nanocaller_amd.synth import add_indels, make_world
-    from nanocaller_amd.weights import Weights, get_indel_model
-    from nanocaller_amd.wire import build_wire_from_world, upload_wire
-    from oracle import oracle
-    Lw = 1_000_000
-    w = add_indels(make_world(seed=5, length=Lw, depth=30, tech="ont", read_len_scale=1.0), seed=5)
-    dp = upload_wire(eng, build_wire_from_world(w))
-    spans = [(s, min(Lw, s + 100_000)) for s in range(1, Lw, 100_000)]
-    kw = dict(mincov=4, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6)
-    eng.indel_scan_batch(dp, spans, **kw)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    cols = eng.indel_scan_batch(dp, spans, **kw)
-    anchors = [a for ct, (s, _) in zip(cols, spans) for a in pick_variants(ct, s, 40)]
-    t_scan = time.perf_counter() - t0
-    n_sites = len(anchors)
-    rng = np.random.Generator(np.random.PCG64(4))
-    lut = np.frombuffer(b"AGTC", np.uint8)
+    """The indel path as candidate sites/s (configs[2]'s second half) through the PRODUCT functions: a synthetic 30x BAM with
+    planted indels and HP/PS tags + its FASTA -> per 100 kb chunk: K7 window scan, pass 2 assembled natively from the
+    decoded contig (nc_indel_pass2_sets), device star alignment + K8, Indel_model (K9), genotype rules -> VCF records
+    (generate_indel_pileups.get_indel_testing_candidates + indelCaller.indel_vcf_lines, what indel_run chains).  BAM
+    decoding is logged separately (ingest is outside the metric).  In-run parity: K9 against the f64 oracle."""
+    import tempfile
 
-    def read_sets(ref_codes, n):
-        out = []
-        for _ in range(n):
-            q = ref_codes.copy()
-            q[rng.integers(0, q.size, size=6)] = rng.integers(0, 4, size=6)
-            p, ln = int(rng.integers(10, 140)), int(rng.choice([-5, -2, -1, 1, 2, 4]))
-            q = np.concatenate([q[:p], np.full(ln, rng.integers(0, 4), np.uint8), q[p:]]) if ln > 0 else np.concatenate([q[:p], q[p - ln:]])
-            out.append(lut[q[:160]].tobytes().decode())
-        return out
-    refs, sets = [], []
-    for _ in range(n_sites):
-        rc = rng.integers(0, 4, size=161).astype(np.uint8)
-        ref = lut[rc].tobytes().decode()
-        for k in (15, 15, 30):
-            refs.append(ref)
-            sets.append(read_sets(rc, k))
-    eng.star_msa_tensor(sets[:30], refs[:30])
-    torch.cuda.synchronize()
+    from nanocaller_amd import _lib, indelCaller
+    from nanocaller_amd import generate_indel_pileups as gip
+    from nanocaller_amd.generate_SNP_pileups import device_pack, release_contig
+    from nanocaller_amd.weights import Weights, get_indel_model
+    from oracle import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamio                                                   # BAM / FASTA writer (test tooling)
+    Lw = 400_000
     t0 = time.perf_counter()
-    x, cns, ncols = eng.star_msa_tensor(sets, refs)
-    torch.cuda.synchronize()
-    t_msa = time.perf_counter() - t0
-    eng.enable_timing(True)
-    eng.star_msa_tensor(sets, refs)
-    torch.cuda.synchronize()
-    msa_dev_ms = eng.last_ms(3)
-    eng.enable_timing(False)
-    n_par = min(len(sets), 63)
-    xs, _, _, rows, rrows = eng.star_msa_tensor(sets[:n_par], refs[:n_par], want_rows=True)     # the aligned rows of a sample, for the K8 check
+    w = bamio.make_pass2_world(seed=5, length=Lw, depth=30)
+    tmp = tempfile.mkdtemp(prefix="nc_bench_indel_")
+    bam, fa = os.path.join(tmp, "i.bam"), os.path.join(tmp, "i.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, None))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    t_files = time.perf_counter() - t0
+    params = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+                  exclude_bed=None, impute_indel_phase=False)
+    chunks = [dict(chrom=w.chrom, start=s, end=min(Lw, s + 100_000), ploidy="diploid", sam_path=bam) for s in range(1, Lw, 100_000)]
     wgt = Weights(get_indel_model("ONT-HG002"))
     eng.load_weights(_lib.MODEL_INDEL, wgt)
-    x15 = x.reshape(n_sites, 3, 5, 128, 2).reshape(n_sites, 15, 128, 2).contiguous()
-    eng.indel_forward(_lib.MODEL_INDEL, x15)
+    release_contig()
+    t0 = time.perf_counter()
+    gip.decoded_contig(bam, w.chrom, fa)                           # ingest: BAM decode (+ query bases) and upload, once per contig
+    device_pack(bam, fa, w.chrom, False, None, local)
+    torch.cuda.synchronize()
+    t_ingest = time.perf_counter() - t0
+
+    def run():
+        # what indelCaller.indel_run does with the chunks of one contig: one featuriser call, one CNN call, rules per chunk
+        tuples = gip.get_indel_testing_candidates_batch(params, chunks, device=local)
+        xs = [np.hstack([t[1], t[2], t[3]]).astype(np.float32) for t in tuples if len(t[0])]
+        x_all = np.ascontiguousarray(np.concatenate(xs))
+        probs = eng.indel_forward(_lib.MODEL_INDEL, torch.from_numpy(x_all).to(eng.device)).cpu().numpy()
+        n, lines, o = 0, 0, 0
+        for c, t in zip(chunks, tuples):
+            k = len(t[0])
+            if k:
+                lines += len(indelCaller.indel_vcf_lines(c["chrom"], t[0], probs[o:o + k], t[4], t[5])[0])
+            o += k
+            n += k
+        return n, lines, [x_all], [probs]
+    run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    probs = eng.indel_forward(_lib.MODEL_INDEL, x15)
+    n_sites, n_lines, xs, ps = run()
     torch.cuda.synchronize()
-    t_cnn = time.perf_counter() - t0
-    # K9 alone at a batch that fills the chip (the pipeline above is a 1 Mb piece)
+    t_run = time.perf_counter() - t0
+    x15 = torch.from_numpy(np.concatenate(xs)).to(eng.device)
+    # K9 alone at a batch that fills the chip
     nb = 16384
     xb = x15[torch.arange(nb, device=x15.device) % n_sites].contiguous()
     eng.indel_forward(_lib.MODEL_INDEL, xb)
@@ -289,28 +282,23 @@ def extra_indel_config(eng, local):
         eng.indel_forward(_lib.MODEL_INDEL, xb)
     torch.cuda.synchronize()
     t_k9 = (time.perf_counter() - t0) / 3
-    # parity: K8 tensors of a few sets against the oracle's msa() half on the device's own rows; K9 against the f64 oracle
-    xh = x.cpu().numpy()
-    k8_ok = bool(np.array_equal(xs.cpu().numpy(), xh[:n_par]))
-    for s in range(0, n_par, 7):
-        ex, _ = oracle.indel_tensor(rows[s], rrows[s])
-        k8_ok &= bool(np.array_equal(ex, xh[s]))
     m = min(n_sites, 256)
-    ep = oracle.indel_forward(wgt.flat, x15[:m].cpu().numpy(), precision="f64")
-    k9_err = float(np.abs(probs[:m].cpu().numpy() - ep).max())
-    total = t_scan + t_msa + t_cnn
+    ep = oracle.indel_forward(wgt.flat, np.concatenate(xs)[:m], precision="f64")
+    k9_err = float(np.abs(np.concatenate(ps)[:m] - ep).max())
     k9_tf = INDEL_FLOP_PER_SITE * nb / t_k9 / 1e12
-    return {"workload": "indel path on a 1 Mb ONT 30x piece with planted indels: K7 window scan (10 chunks of 100 kb, one batch) -> "
-                        "%d anchors; 3 read sets per anchor (15/15/30 reads of 160 b) through the device star alignment + K8, "
-                        "Indel_model (K9); host marshalling of the read sets included" % n_sites,
-            "value": n_sites / total, "unit": "candidate sites/s", "sites": n_sites,
-            "stages_ms": {"k7_scan_and_pick": t_scan * 1e3, "star_alignment_k8": t_msa * 1e3, "star_alignment_k8_device_only": msa_dev_ms,
-                          "k9_cnn": t_cnn * 1e3},
-            "k7_columns_per_s": Lw / t_scan, "alignments_per_s": sum(len(s) for s in sets) / t_msa,
+    release_contig()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"workload": "indel path on a %d kb synthetic ONT 30x BAM with planted indels and HP/PS tags, %d chunks of 100 kb: K7 window scan -> "
+                        "native pass 2 -> device star alignment + K8 (3 read sets per anchor) -> Indel_model (K9) -> genotype rules; %d candidate "
+                        "sites reached the CNN, %d VCF records" % (Lw // 1000, len(chunks), n_sites, n_lines),
+            "value": n_sites / t_run, "unit": "candidate sites/s", "sites": n_sites, "ms_per_chunk": t_run / len(chunks) * 1e3,
+            "ingest_ms_logged_not_timed": t_ingest * 1e3, "bam_writing_s": t_files,
             "roofline": {"bound": "mfma", "kernel": "K9 indel CNN (k9_conv12_h3 + k8_conv23_h3 + k3_fc1), %d sites per call" % nb,
                          "achieved": k9_tf, "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s", "frac": k9_tf / (F16_MFMA_PEAK_TFLOPS / 3.0),
                          "sites_per_s": nb / t_k9},
-            "parity": {"k8_tensors_exact_vs_oracle": k8_ok, "k9_max_abs_dprob_vs_f64_oracle": k9_err, "sites_checked": m}}
+            "parity": {"k9_max_abs_dprob_vs_f64_oracle": k9_err, "sites_checked": m,
+                       "note": "the tuples of this path equal the reference's own on the golden worlds (tests/test_pass2_golden.py)"}}
 
 
 def trunk_traffic_from_profiles():

@@ -25,7 +25,7 @@ extern "C" {
 
 #define NC_ABI_VERSION 5   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
-                              5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async */
+                              5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -379,6 +379,35 @@ int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor
                     const uint8_t *keep, nc_slices **out);
 int nc_slices_view(const nc_slices *s, nc_slices_arrays *view);
 int nc_slices_free(nc_slices *s);
+
+/* Pass 2 of get_indel_testing_candidates up to the aligner call (generate_indel_pileups.py:306-348; haploid :243-262) for all
+ * anchors of a chunk at once: reference windows from `contig` (1-based position p = contig[p-1], only positions in
+ * [ref_lo, ref_hi] count, :174; an anchor whose window holds anything but upper-case AGTC is skipped, :325-327), read windows
+ * of `window_after` query bases from query_position_or_next (:331), the split into hap0 / hap1 / all reads by HP tag -- or,
+ * where imp_idx[a] = k >= 0, by the imputed read collections imp_reads[imp_off[2k] .. imp_off[2k+1]) and
+ * [imp_off[2k+1] .. imp_off[2k+2]) (read indices; :310-318) --, at most `maxcov` reads per set (the first in pileup order;
+ * the reference samples at random, unseeded, :19-20), at least 2 / 2 / mincov reads (:48, :345; haploid: one set of >= mincov).
+ * The result holds the flat arrays nc_star_msa_tensor takes (sets_per_anchor consecutive sets per kept anchor). */
+typedef struct nc_pass2 nc_pass2;
+typedef struct {
+    int32_t n_kept;
+    const int32_t *anchor_idx;    /* [n_kept] index into `anchors` */
+    const int32_t *first0;        /* [n_kept] first read of set 0 in pileup order (phase lookup, :349) */
+    int32_t sets_per_anchor;      /* 3 (hap0, hap1, all) or 1 (haploid) */
+    int32_t n_sets;
+    const int32_t *set_read0;     /* [n_sets + 1] */
+    int32_t n_alignments;
+    const int32_t *read_off;      /* [n_alignments + 1] */
+    const char *reads;            /* ASCII, AGTC or N */
+    const int32_t *ref_off;       /* [n_sets + 1] */
+    const char *refs;
+    int32_t max_cols;             /* bound on the alignment columns of any set (max_cols argument of nc_star_msa_tensor) */
+} nc_pass2_arrays;
+int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anchor, const int32_t *anchors, const char *contig,
+                        int64_t chrom_len, int32_t ref_lo, int32_t ref_hi, int32_t window_after, int32_t mincov, int32_t maxcov,
+                        int32_t haploid, const int32_t *imp_idx, const int32_t *imp_off, const int32_t *imp_reads, nc_pass2 **out);
+int nc_pass2_view(const nc_pass2 *p, nc_pass2_arrays *view);
+int nc_pass2_free(nc_pass2 *p);
 
 /* Global alignment with affine gaps, the call parasail.nw_trace(alt, ref, 9, 1, matrix_create('AGTC', 20, -10)) of
  * generate_indel_pileups.py:10,79: a gap of length k costs open + (k-1)*extend.  Writes the CIGAR as (op, count) pairs

@@ -32,6 +32,7 @@ EXPORTS = [
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
     "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_set_tensor_format", "nc_allele_prediction_batch",
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
+    "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
 ]
 
 
@@ -74,6 +75,12 @@ class DecodedArraysC(C.Structure):
 class SlicesArraysC(C.Structure):
     _fields_ = [("n_anchor", C.c_int32), ("anchor_off", C.c_void_p), ("read_idx", C.c_void_p), ("seq_off", C.c_void_p),
                 ("seq", C.c_void_p), ("n_slices", C.c_int64)]
+
+
+class Pass2ArraysC(C.Structure):
+    _fields_ = [("n_kept", C.c_int32), ("anchor_idx", C.c_void_p), ("first0", C.c_void_p), ("sets_per_anchor", C.c_int32),
+                ("n_sets", C.c_int32), ("set_read0", C.c_void_p), ("n_alignments", C.c_int32), ("read_off", C.c_void_p),
+                ("reads", C.c_void_p), ("ref_off", C.c_void_p), ("refs", C.c_void_p), ("max_cols", C.c_int32)]
 
 
 class WireArraysC(C.Structure):
@@ -141,7 +148,7 @@ def lib():
         L.nc_bam_error.argtypes = [vp]
         L.nc_bam_error.restype = C.c_char_p
         L.nc_bam_decode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
-        L.nc_star_msa_tensor.argtypes = [vp, i32, C.c_char_p, vp, vp, C.c_char_p, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.nc_star_msa_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.nc_allele_prediction_batch.argtypes = [i32, C.c_char_p, vp, C.c_char_p, vp, vp, vp, vp]
         L.nc_set_tensor_format.argtypes = [vp, C.c_int]
         L.nc_star_msa.argtypes = [i32, C.c_char_p, vp, C.c_char_p, i32, i32, i32, i32, i32, i32, vp, vp, C.POINTER(i32)]
@@ -154,6 +161,9 @@ def lib():
         L.nc_nw_cigar.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
         L.nc_allele_prediction.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.nc_bgzf_compress.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64)]
+        L.nc_indel_pass2_sets.argtypes = [vp, vp, i32, vp, C.c_char_p, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(vp)]
+        L.nc_pass2_view.argtypes = [vp, C.POINTER(Pass2ArraysC)]
+        L.nc_pass2_free.argtypes = [vp]
         L.nc_d2h_async.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.nc_wire_build.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i64, C.POINTER(vp)]
         L.nc_wire_view.argtypes = [vp, C.POINTER(WireArraysC)]

@@ -104,7 +104,11 @@ extern "C" int nc_allele_prediction(const char *alt, int32_t n_alt, const char *
     if (!ref_len || !alt_len || n_alt < 0 || n_ref < 0 || (n_alt && !alt) || (n_ref && !ref_seq)) return NC_ERR_ARG;
     if ((int64_t)(n_alt + 1) * (n_ref + 1) > (int64_t)1 << 26) return NC_ERR_ARG;
     std::vector<int32_t> ops, cnts;
-    nw_cigar(alt, n_alt, ref_seq, n_ref, 9, 1, 20, -10, ops, cnts);
+    if (n_alt == n_ref && n_alt > 0 && memcmp(alt, ref_seq, (size_t)n_alt) == 0) {
+        ops.push_back(7);                                  // identical strings: the all-match diagonal is the unique optimum --
+        cnts.push_back(n_alt);                             // most consensus sequences equal their reference window: skip the DP
+    } else
+        nw_cigar(alt, n_alt, ref_seq, n_ref, 9, 1, 20, -10, ops, cnts);
     bool indel = false, mm_before = false;
     int64_t ref_cnt[10] = {0}, alt_cnt[10] = {0}, mm_after[2] = {0, 0};
     auto sum10 = [](const int64_t *a) { int64_t t = 0; for (int k = 0; k < 10; k++) t += a[k]; return t; };

@@ -703,6 +703,140 @@ int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor
     return NC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pass 2 of get_indel_testing_candidates (generate_indel_pileups.py:306-348, haploid :243-262) up to the aligner call, for
+// ALL anchors of a chunk at once and without a Python object per read: the reference window of every anchor (skipped when it
+// holds anything but upper-case AGTC, :325-327), the read windows (:329-331, as nc_indel_slices), the split into hap0 / hap1 /
+// all reads by HP tag or by the imputed read collections (:310-318,333-337), the down-sampling to maxcov (first maxcov reads
+// in pileup order: the deterministic stand-in for the unseeded random.sample of :19-20), the mincov tests (:48, :345), and the
+// flat arrays nc_star_msa_tensor takes.
+struct nc_pass2 {
+    std::vector<int32_t> anchor_idx, first0, set_read0, read_off, ref_off;
+    std::vector<char> reads, refs;
+    int32_t sets_per_anchor = 3, max_cols = 1;
+};
+
+int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anchor, const int32_t *anchors, const char *contig,
+                        int64_t chrom_len, int32_t ref_lo, int32_t ref_hi, int32_t window_after, int32_t mincov, int32_t maxcov,
+                        int32_t haploid, const int32_t *imp_idx, const int32_t *imp_off, const int32_t *imp_reads, nc_pass2 **out)
+{
+    if (!d || !out || n_anchor < 0 || (n_anchor && (!anchors || !contig)) || window_after < 1 || maxcov < 1 || chrom_len < 0) return NC_ERR_ARG;
+    const int32_t n = (int32_t)d->start.size();
+    if (n && d->seq.empty()) return NC_ERR_STATE;                          // decoded without keep_seq
+    nc_pass2 *o = new (std::nothrow) nc_pass2();
+    if (!o) return NC_ERR_NOMEM;
+    const int S = haploid ? 1 : 3;
+    o->sets_per_anchor = S;
+    o->set_read0.push_back(0);
+    o->read_off.push_back(0);
+    o->ref_off.push_back(0);
+    static const char LET[8] = {'A', 'G', 'T', 'C', 'N', 'N', 'N', 'N'};
+    int32_t first = 0;
+    std::vector<int32_t> cov, q_of;                                        // reads in the pileup at the anchor, their query index
+    std::vector<int32_t> side0, side1;
+    std::vector<int32_t> sets[3];
+    try {
+        for (int32_t a = 0; a < n_anchor; a++) {
+            const int32_t p = anchors[a];
+            if (a && p < anchors[a - 1]) first = 0;
+            while (first < n && d->end[first] <= p) first++;
+            // reference window [p, min(chrom_len, p + window_after + 1)) from the bases kept for the chunk ([ref_lo, ref_hi])
+            const int64_t b = std::min<int64_t>(chrom_len, (int64_t)p + window_after + 1);
+            bool ok = b > p && p >= ref_lo && b - 1 <= ref_hi && p >= 1;
+            for (int64_t x = p; ok && x < b; x++) {
+                const char c = contig[x - 1];
+                ok = c == 'A' || c == 'G' || c == 'T' || c == 'C';
+            }
+            if (!ok) continue;
+            cov.clear();
+            for (int32_t r = first; r < n; r++) {
+                if (d->start[r] > p) break;
+                if (d->end[r] <= p) continue;
+                if (keep && !keep[r]) continue;
+                cov.push_back(r);
+            }
+            for (auto &v : sets) v.clear();
+            const int k = imp_idx ? imp_idx[a] : -1;
+            if (k >= 0) {
+                side0.assign(imp_reads + imp_off[2 * k], imp_reads + imp_off[2 * k + 1]);
+                side1.assign(imp_reads + imp_off[2 * k + 1], imp_reads + imp_off[2 * k + 2]);
+                std::sort(side0.begin(), side0.end());
+                std::sort(side1.begin(), side1.end());
+            }
+            for (int32_t r : cov) {
+                if (!haploid) {
+                    int h;
+                    if (k >= 0) h = std::binary_search(side0.begin(), side0.end(), r) ? 1 : std::binary_search(side1.begin(), side1.end(), r) ? 2 : 0;
+                    else h = d->hap[r];
+                    if (h == 1) sets[0].push_back(r);
+                    else if (h == 2) sets[1].push_back(r);
+                    sets[2].push_back(r);
+                } else sets[0].push_back(r);
+            }
+            bool pass = true;
+            for (int t = 0; t < S && pass; t++) {
+                if ((int32_t)sets[t].size() > maxcov) sets[t].resize((size_t)maxcov);
+                const int32_t need = haploid ? mincov : (t < 2 ? 2 : mincov);
+                pass = (int32_t)sets[t].size() >= need;
+            }
+            if (!pass) continue;
+            o->anchor_idx.push_back(a);
+            o->first0.push_back(sets[0].empty() ? -1 : sets[0][0]);
+            for (int t = 0; t < S; t++) {
+                int64_t cols = b - p;
+                for (int32_t r : sets[t]) {
+                    const int32_t e0 = d->ev_off[r], e1 = d->ev_off[r + 1];
+                    const int32_t q = qpos_or_next(d->start[r], d->qstart[r], d->ev_pos.data() + e0, d->ev_len.data() + e0, e1 - e0, p);
+                    const int64_t s0 = d->seq_off[r], L = d->seq_off[r + 1] - s0;
+                    int64_t a0 = std::min<int64_t>(std::max<int64_t>(q, 0), L), a1 = std::min<int64_t>((int64_t)q + window_after, L);
+                    if (a1 < a0) a1 = a0;
+                    const size_t w0 = o->reads.size();
+                    o->reads.resize(w0 + (size_t)(a1 - a0));
+                    const uint8_t *src = d->seq.data() + s0 + a0;
+                    char *dst = o->reads.data() + w0;
+                    for (int64_t x = 0; x < a1 - a0; x++) dst[x] = LET[src[x] & 7];
+                    o->read_off.push_back((int32_t)o->reads.size());
+                    cols += a1 - a0;
+                }
+                o->set_read0.push_back((int32_t)o->read_off.size() - 1);
+                o->refs.insert(o->refs.end(), contig + (p - 1), contig + (b - 1));
+                o->ref_off.push_back((int32_t)o->refs.size());
+                o->max_cols = (int32_t)std::max<int64_t>(o->max_cols, cols);       // every read base can add at most one column
+            }
+            if (o->reads.size() > ((size_t)1 << 30) || o->refs.size() > ((size_t)1 << 30)) { delete o; return NC_ERR_CAPACITY; }
+        }
+    } catch (const std::bad_alloc &) {
+        delete o;
+        return NC_ERR_NOMEM;
+    }
+    *out = o;
+    return NC_OK;
+}
+
+int nc_pass2_view(const nc_pass2 *o, nc_pass2_arrays *v)
+{
+    if (!o || !v) return NC_ERR_ARG;
+    v->n_kept = (int32_t)o->anchor_idx.size();
+    v->anchor_idx = o->anchor_idx.data();
+    v->first0 = o->first0.data();
+    v->sets_per_anchor = o->sets_per_anchor;
+    v->n_sets = (int32_t)o->set_read0.size() - 1;
+    v->set_read0 = o->set_read0.data();
+    v->n_alignments = (int32_t)o->read_off.size() - 1;
+    v->read_off = o->read_off.data();
+    v->reads = o->reads.data();
+    v->ref_off = o->ref_off.data();
+    v->refs = o->refs.data();
+    v->max_cols = o->max_cols;
+    return NC_OK;
+}
+
+int nc_pass2_free(nc_pass2 *o)
+{
+    delete o;
+    return NC_OK;
+}
+
 int nc_slices_view(const nc_slices *s, nc_slices_arrays *v)
 {
     if (!s || !v) return NC_ERR_ARG;

@@ -166,7 +166,11 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
     if (blk >= n_blocks) return;
     uint8_t *img = img_all + wv * WIRE_BLOCK;
     const int64_t B = blk * WIRE_BLOCK + (int64_t)lane * 16;
+    // independent loads first: the block's event range and its first two batches of events travel while the read lookup runs
     int64_t r = blk_read[blk];
+    const uint32_t e0 = blk_off[blk], e1 = blk_off[blk + 1];
+    const uint32_t k0 = e0 + lane, k1 = e0 + 64 + lane;
+    const uint32_t ev0 = k0 < e1 ? (uint32_t)events[k0] : 0xffffffffu, ev1 = k1 < e1 ? (uint32_t)events[k1] : 0xffffffffu;
     while (r < n_reads && slot_off[r + 1] <= B) r++;             // at most 63 steps, almost always none
     uint32_t o[4] = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
     if (r < n_reads) {
@@ -199,17 +203,25 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         }
     }
     *reinterpret_cast<uint4 *>(img + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-    const uint32_t e0 = blk_off[blk], e1 = blk_off[blk + 1];
     // LDS operations of one wave execute in program order: the byte stores below land on top of the 16-byte stores above
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t k = e0 + lane; k < e1; k += 64) {
+    if (ev0 != 0xffffffffu) img[ev0 & 0x3ffu] = (uint8_t)(ev0 >> 12);
+    if (ev1 != 0xffffffffu) img[ev1 & 0x3ffu] = (uint8_t)(ev1 >> 12);
+    for (uint32_t k = e0 + 128 + lane; k < e1; k += 64) {
         const uint32_t ev = events[k];
         img[ev & 0x3ffu] = (uint8_t)(ev >> 12);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (B + 16 <= codes_len) *reinterpret_cast<uint4 *>(codes + B) = *reinterpret_cast<const uint4 *>(img + lane * 16);
+    if (B + 16 <= codes_len) {
+        // streaming store: the expanded codes are read once by the scan, later, from HBM
+        const uint4 v = *reinterpret_cast<const uint4 *>(img + lane * 16);
+        __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(codes + B));
+        __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(codes + B) + 1);
+        __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(codes + B) + 2);
+        __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(codes + B) + 3);
+    }
 }
 
 // reference codes of the column scan from the wire form: skipped columns (bit 3: soft-masked, non-AGTC, excluded) become 4

@@ -317,8 +317,8 @@ class Engine:
         -> (x f32 [S,5,128,2] device, cns list of uint8 arrays (or, cns_as_str, AGTC strings) with gaps removed, n_cols int32 [S]
             [, rows list of uint8 [n_reads, n_cols], ref_rows list of uint8 [n_cols]])"""
         S = len(read_sets)
-        x = torch.empty((S, 5, 128, 2), dtype=torch.float32, device=self.device)
         if S == 0:
+            x = torch.empty((0, 5, 128, 2), dtype=torch.float32, device=self.device)
             return (x, [], np.zeros(0, np.int32)) + (([], []) if want_rows else ())
         n_reads = np.fromiter(map(len, read_sets), np.int64, S)
         set0 = np.zeros(S + 1, np.int32)
@@ -338,18 +338,32 @@ class Engine:
             per_set[nz] = np.add.reduceat(rlen, set0[:-1][nz])
         cap = reflen + per_set
         mc = int(max_cols) if max_cols else int(cap.max())
+        return self.star_msa_tensor_flat(S, raw_reads, read_off, set0, raw_refs, ref_off, mc, open_=open_, extend=extend, match=match,
+                                         mismatch=mismatch, want_rows=want_rows, cns_as_str=cns_as_str, _n_reads=n_reads, _cap=cap)
+
+    def star_msa_tensor_flat(self, S, reads, read_off, set_read0, refs, ref_off, max_cols, *, open_=9, extend=1, match=20, mismatch=-10,
+                             want_rows=False, cns_as_str=False, _n_reads=None, _cap=None):
+        """The same on flat host buffers (what nc_indel_pass2_sets produces): `reads` / `refs` bytes objects or raw pointers
+        (ints / c_void_p), read_off / set_read0 / ref_off int32 arrays or pointers."""
+        x = torch.empty((S, 5, 128, 2), dtype=torch.float32, device=self.device)
+        mc = int(max_cols)
         cns = np.empty((S, mc), np.uint8)
         ncols = np.empty(S, np.int32)
+        ptr = lambda a: _lib.npp(a) if isinstance(a, np.ndarray) else a      # noqa: E731
         rows = rr = roff = rroff = None
         if want_rows:
             roff = np.zeros(S + 1, np.int64)
-            np.cumsum(n_reads * cap, out=roff[1:])
+            np.cumsum(_n_reads * _cap, out=roff[1:])
             rroff = np.zeros(S + 1, np.int64)
-            np.cumsum(cap, out=rroff[1:])
+            np.cumsum(_cap, out=rroff[1:])
             rows, rr = np.empty(max(int(roff[-1]), 1), np.uint8), np.empty(max(int(rroff[-1]), 1), np.uint8)
-        self._check(self.L.nc_star_msa_tensor(self.ctx, S, raw_reads, _lib.npp(read_off), _lib.npp(set0), raw_refs, _lib.npp(ref_off),
+        self._check(self.L.nc_star_msa_tensor(self.ctx, S, reads, ptr(read_off), ptr(set_read0), refs, ptr(ref_off),
                                               int(open_), int(extend), int(match), int(mismatch), mc, _ptr(x), _lib.npp(cns), _lib.npp(ncols),
                                               _lib.npp(rows), _lib.npp(roff), _lib.npp(rr), _lib.npp(rroff)), "nc_star_msa_tensor")
+        if int(ncols.max()) > mc and not want_rows:
+            # the caller's column bound was an estimate (consensus columns beyond it are cut): once more with the real maximum
+            return self.star_msa_tensor_flat(S, reads, read_off, set_read0, refs, ref_off, int(ncols.max()), open_=open_, extend=extend,
+                                             match=match, mismatch=mismatch, cns_as_str=cns_as_str)
         # consensus with the gap symbols removed: one pass over the [S, mc] block instead of S small array operations
         keep = (np.arange(mc, dtype=np.int32)[None, :] < np.minimum(ncols, mc)[:, None]) & (cns != 4)
         cnt = keep.sum(1)
@@ -363,7 +377,7 @@ class Engine:
             out_cns = [flat_cns[cut[k]:cut[k + 1]] for k in range(S)]
         if not want_rows:
             return x, out_cns, ncols
-        out_rows = [rows[roff[s]:roff[s] + int(n_reads[s]) * int(ncols[s])].reshape(int(n_reads[s]), int(ncols[s])) for s in range(S)]
+        out_rows = [rows[roff[s]:roff[s] + int(_n_reads[s]) * int(ncols[s])].reshape(int(_n_reads[s]), int(ncols[s])) for s in range(S)]
         out_rr = [rr[rroff[s]:rroff[s] + int(ncols[s])] for s in range(S)]
         return x, out_cns, ncols, out_rows, out_rr
 

@@ -320,25 +320,26 @@ def get_indel_testing_candidates(dct, chunk, aligner=None, device=0):
     empty = ([], [], [], [], [], [])
     if not variants:
         return empty
-    fasta = read_fasta(dct["fasta_path"], chrom)
-    chrom_length = len(fasta)
     lo, hi = max(1, start - 200), end + 400                                        # ref_dict range (:174)
     flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if dct.get("supplementary") else 0x800)
-    bf = BamFile(chunk["sam_path"])
-    # hap sets / phase_dict come from a fetch over [start-100000, end+1000] (:178-188); the pileup of pass 2 from
-    # [start-10-win, end] (:306): decode the union once
+    # the pileup of pass 2 covers [start-10-win, end] (:306)
     anchors = sorted(v for v in variants if max(0, start - 10 - dct["win_size"]) < v <= end)
+    max_range = {0: max(10, dct["win_size"]), 1: 10}
+    if aligner is None and default_aligner() is star_aligner:
+        aligner = "device"                                                         # no MUSCLE here: star alignment on the GPU
+    if aligner == "device":
+        # the whole of pass 2 natively: the contig is decoded once (with its query bases) for all its chunks
+        ctg = decoded_contig(chunk["sam_path"], chrom, dct["fasta_path"])
+        return _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_after, max_range, device, haploid=False)
+    fasta = read_fasta(dct["fasta_path"], chrom)
+    chrom_length = len(fasta)
+    bf = BamFile(chunk["sam_path"])
+    # hap sets / phase_dict come from a fetch over [start-100000, end+1000] (:178-188): decode the union once
     d = bf.decode(chrom, max(1, start - 100000), end + 1000, anchors=anchors, window_before=window_before,
                   window_after=window_after, keep_mask=flag)
     bf.close()
     names, hap, ps = d["names"], d["hap"], d["ps"]
-    max_range = {0: max(10, dct["win_size"]), 1: 10}
     out_pos, x0, x1, x2, alleles, phase = [], [], [], [], [], []
-    if aligner is None and default_aligner() is star_aligner:
-        aligner = "device"                                                         # no MUSCLE here: star alignment on the GPU
-    if aligner == "device":
-        return _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo, hi, chrom_length, window_before,
-                                      window_after, max_range, device)
     for v_pos, win in zip(anchors, d["windows"]):
         ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N")
                       for p in range(v_pos - window_before, min(chrom_length, v_pos + window_after + 1)))
@@ -381,57 +382,149 @@ def _sample_set(seq_list, mincov, maxcov):
     return sample, [seq_list[n] for n in sample]
 
 
-def _candidates_device_msa(dct, variants, extra_variants, anchors, d, fasta, lo, hi, chrom_length, window_before, window_after,
-                           max_range, device):
-    """pass 2 of get_indel_testing_candidates with every read set of the chunk aligned in ONE device call
-    (engine.star_msa_tensor: star alignment + rows -> tensor), instead of three aligner calls per anchor"""
-    names, hap, ps = d["names"], d["hap"], d["ps"]
-    todo, sets, refs = [], [], []
-    for v_pos, win in zip(anchors, d["windows"]):
-        a, b = v_pos - window_before, min(chrom_length, v_pos + window_after + 1)
-        if lo <= a and b - 1 <= hi:
-            ref = fasta[a - 1:b - 1]
-            if ref.translate(_DROP_AGTC):
-                continue                                                         # 'N' (anything but upper-case AGTC) in ref (:326)
+_CONTIGS = {}
+
+
+def decoded_contig(sam_path, chrom, fasta_path):
+    """The contig's alignments WITH their query bases, decoded once (nc_bam_decode_regions) and kept for every chunk of the
+    contig, + the contig's reference bases.  One contig at a time stays cached."""
+    key = (sam_path, chrom, fasta_path)
+    if key not in _CONTIGS:
+        from .bam import decode_parallel, read_fasta
+        _CONTIGS.clear()
+        dec = decode_parallel(sam_path, chrom, keep_seq=True)
+        fasta = read_fasta(fasta_path, chrom)
+        _CONTIGS[key] = dict(dec=dec, handle=dec["_owner"].handle, fasta=fasta, fasta_b=fasta.encode("ascii"), keep={}, name_idx=None)
+    return _CONTIGS[key]
+
+
+def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_after, max_range, device, haploid, by_index=False):
+    """Pass 2 (:306-361) for all anchors of a chunk: read sets assembled natively (nc_indel_pass2_sets) from the decoded contig,
+    every set aligned in ONE device call (star alignment + rows -> tensor), allele strings by nc_allele_prediction_batch.
+    -> diploid (pos, x0, x1, x2, alleles, phase) / haploid (pos, x, alleles).  by_index: `variants` / `extra_variants` are keyed
+    by the anchor's INDEX in `anchors` (merged chunks) and the kept anchor indices are appended to the result."""
+    L = _lib.lib()
+    dec = ctg["dec"]
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if dct.get("supplementary") else 0x800)
+    if flag not in ctg["keep"]:
+        ctg["keep"][flag] = np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8)
+    keep = ctg["keep"][flag]
+    anc = np.ascontiguousarray(anchors, np.int32)
+    imp_idx = imp_off = imp_reads = None
+    if extra_variants:
+        if ctg["name_idx"] is None:
+            ctg["name_idx"] = {}
+            for i, nm in enumerate(dec["names"]):
+                ctg["name_idx"].setdefault(nm, i)
+        nidx = ctg["name_idx"]
+        imp_idx = np.full(len(anchors), -1, np.int32)
+        offs, reads = [0], []
+        for k, v in enumerate(anchors):
+            key = k if by_index else v
+            if key in extra_variants:
+                imp_idx[k] = (len(offs) - 1) // 2
+                for side in extra_variants[key]:
+                    reads.extend(nidx[n] for n in side)
+                    offs.append(len(reads))
+        imp_off = np.ascontiguousarray(offs, np.int32)
+        imp_reads = np.ascontiguousarray(reads if reads else [0], np.int32)
+    h = C.c_void_p()
+    rc = L.nc_indel_pass2_sets(ctg["handle"], _lib.npp(keep), len(anc), _lib.npp(anc), ctg["fasta_b"], len(ctg["fasta"]), int(lo), int(hi),
+                               int(window_after), int(dct["mincov"]), int(dct["maxcov"]), 1 if haploid else 0, _lib.npp(imp_idx),
+                               _lib.npp(imp_off), _lib.npp(imp_reads), C.byref(h))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_indel_pass2_sets failed (%d)" % rc)
+    try:
+        v = _lib.Pass2ArraysC()
+        L.nc_pass2_view(h, C.byref(v))
+        nk, S, ns = v.n_kept, v.sets_per_anchor, v.n_sets
+        if nk == 0:
+            res = ([], [], []) if haploid else ([], [], [], [], [], [])
+            return res + ([],) if by_index else res
+        eng = get_engine(device)
+        eng.use_torch_stream()
+        x, cns_str, _ = eng.star_msa_tensor_flat(ns, C.c_void_p(v.reads), C.c_void_p(v.read_off), C.c_void_p(v.set_read0), C.c_void_p(v.refs),
+                                                 C.c_void_p(v.ref_off), min(v.max_cols, 4 * window_after + 64), cns_as_str=True)
+        kept = np.ctypeslib.as_array(C.cast(v.anchor_idx, C.POINTER(C.c_int32)), (nk,)).copy()
+        first0 = np.ctypeslib.as_array(C.cast(v.first0, C.POINTER(C.c_int32)), (nk,)).copy()
+        ref_off = np.ctypeslib.as_array(C.cast(v.ref_off, C.POINTER(C.c_int32)), (ns + 1,))
+        refs_all = C.string_at(v.refs, int(ref_off[ns])).decode("ascii")
+        refs = [refs_all[ref_off[k]:ref_off[k + 1]] for k in range(ns)]
+    finally:
+        L.nc_pass2_free(h)
+    pos = [int(anchors[k]) for k in kept]
+    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[int(k) if by_index else int(anchors[k])]] for k in kept for _ in range(S)])
+    xh = x.cpu().numpy().astype(np.float64).reshape(nk, S, 5, 128, 2)
+    tail = (kept.tolist(),) if by_index else ()
+    if haploid:
+        return (pos, xh[:, 0], preds) + tail
+    hap, ps = dec["hap"], dec["ps"]
+    alleles = [[preds[3 * k], preds[3 * k + 1], preds[3 * k + 2]] for k in range(nk)]
+    phase = [(int(ps[r]) if hap[r] else None) for r in first0]
+    return (pos, xh[:, 0], xh[:, 1], xh[:, 2], alleles, phase) + tail
+
+
+def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False):
+    """get_indel_testing_candidates[_haploid] for ALL chunks of one contig and BAM in one go -> list of the per-chunk tuples
+    (each exactly what the per-chunk call returns): pass 1 of every chunk in the same launches (nc_indel_scan_batch), the
+    anchors of all chunks through ONE native pass-2 call, ONE device star alignment and ONE allele batch.  What
+    indelCaller.indel_run uses; the device / native route only (no external aligner)."""
+    chunks = list(chunks)
+    if not chunks:
+        return []
+    chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
+    window_after = 260 if dct["seq"] == "pacbio" else 160
+    extras = [dict() for _ in chunks]
+    variants = scan_indel_candidates(dct, chunks, device, haploid=haploid, extra_variants=None if haploid else extras)
+    max_range = {0: max(10, dct["win_size"]), 1: 10}
+    per_chunk, flat_anchor, flat_chunk = [], [], []
+    for ci, (c, var) in enumerate(zip(chunks, variants)):
+        anc = sorted(v for v in var if max(0, c["start"] - 10 - dct["win_size"]) < v <= c["end"])
+        per_chunk.append(anc)
+        flat_anchor += anc
+        flat_chunk += [ci] * len(anc)
+    empty = ([], [], []) if haploid else ([], [], [], [], [], [])
+    if not flat_anchor:
+        return [empty for _ in chunks]
+    ctg = decoded_contig(sam_path, chrom, dct["fasta_path"])
+    order = np.argsort(np.asarray(flat_anchor), kind="stable")                      # ascending over the contig: one sweep over the reads
+    anchors = [flat_anchor[i] for i in order]
+    owner = [flat_chunk[i] for i in order]
+    # every anchor's window lies inside its own chunk's ref_dict range [start-200, end+400] (:174), so the contig-wide range is
+    # the same test; variant types / imputed sets are looked up per owner chunk
+    merged_var = _ChunkedLookup([variants[ci] for ci in owner], anchors)
+    merged_extra = {}
+    if not haploid:
+        for k, (v, ci) in enumerate(zip(anchors, owner)):
+            if v in extras[ci]:
+                merged_extra[k] = extras[ci][v]
+    res = _pass2_native(dct, merged_var, merged_extra, anchors, ctg, 1, len(ctg["fasta"]), window_after, max_range, device, haploid,
+                        by_index=True)
+    pos, kept = res[0], res[-1]
+    out = [[] for _ in chunks]
+    for j, k in enumerate(kept):
+        out[owner[k]].append(j)
+    tuples = []
+    for ci in range(len(chunks)):
+        sel = out[ci]
+        if not sel:
+            tuples.append(empty)
+        elif haploid:
+            tuples.append(([pos[j] for j in sel], res[1][sel], [res[2][j] for j in sel]))
         else:
-            ref = "".join((fasta[p - 1] if (lo <= p <= hi and fasta[p - 1] in "AGTC") else "N") for p in range(a, b))
-            if "N" in ref:
-                continue
-        d_tot, d0, d1 = {}, {}, {}
-        imputed = extra_variants.get(v_pos)                                      # :310-312
-        for r, text in win:
-            d_tot[names[r]] = text
-            if (names[r] in imputed[0]) if imputed else hap[r] == 1:
-                d0[names[r]] = text
-            elif (names[r] in imputed[1]) if imputed else hap[r] == 2:
-                d1[names[r]] = text
-        picked = [_sample_set(d0, 2, dct["maxcov"]), _sample_set(d1, 2, dct["maxcov"]), _sample_set(d_tot, dct["mincov"], dct["maxcov"])]
-        if any(p is None for p in picked):
-            continue                                                             # flag0 and flag1 and flag_total (:345)
-        for _, seqs in picked:
-            sets.append(seqs)                                                    # read bases other than AGTC count as gaps (see msa())
-            refs.append(ref)
-        todo.append((v_pos, next(iter(d0.keys()))))
-    empty = ([], [], [], [], [], [])
-    if not todo:
-        return empty
-    eng = get_engine(device)
-    eng.use_torch_stream()
-    x, cns_str, _ = eng.star_msa_tensor(sets, refs, cns_as_str=True)
-    xh = x.cpu().numpy().astype(np.float64)
-    sym = "AGTC"
-    out_pos, x0, x1, x2, alleles, phase = [], [], [], [], [], []
-    name_row = {}
-    for i, nm in enumerate(names):
-        name_row.setdefault(nm, i)                                               # names.index(): the first occurrence
-    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[v_pos]] for (v_pos, _) in todo for _i in range(3)])
-    for k, (v_pos, first) in enumerate(todo):
-        out_pos.append(v_pos)
-        x0.append(xh[3 * k]); x1.append(xh[3 * k + 1]); x2.append(xh[3 * k + 2])
-        r = name_row[first]
-        phase.append(int(ps[r]) if hap[r] else None)
-        alleles.append([preds[3 * k], preds[3 * k + 1], preds[3 * k + 2]])
-    return (out_pos, np.array(x0), np.array(x1), np.array(x2), alleles, phase)
+            tuples.append(([pos[j] for j in sel], res[1][sel], res[2][sel], res[3][sel], [res[4][j] for j in sel], [res[5][j] for j in sel]))
+    return tuples
+
+
+class _ChunkedLookup:
+    """variants lookup by ANCHOR INDEX for a merged anchor list (the same position can be an anchor of two adjacent chunks
+    with different types)"""
+
+    def __init__(self, var_of_anchor, anchors):
+        self.t = [var[v] for var, v in zip(var_of_anchor, anchors)]
+
+    def __getitem__(self, k):
+        return self.t[k]
 
 
 def __getattr__(name):

@@ -121,7 +121,7 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
 
     from . import _lib
     from .engine import get_engine
-    from .generate_indel_pileups import get_indel_testing_candidates
+    from .generate_indel_pileups import default_aligner, get_indel_testing_candidates, get_indel_testing_candidates_batch, star_aligner
     from .generate_indel_pileups_haploid import get_indel_testing_candidates_haploid
     from .weights import Weights
     curr_vcf_path = os.path.join(params['intermediate_indel_files_dir'], '%s.%d.indel.vcf' % (params['prefix'], worker_id))
@@ -135,37 +135,79 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
     eng.load_weights(_lib.MODEL_INDEL, Weights(model_path))
     eng.load_weights(_lib.MODEL_INDEL_HAP, Weights(get_indel_model('haploid')))
     batch_size = 100
+
+    def forward(ploidy, tuples):
+        """the indel CNN for the sites of several chunks in one call -> per-chunk probability arrays"""
+        if ploidy == 'diploid':
+            xs = [np.hstack([t[1], t[2], t[3]]).astype(np.float32) for t in tuples if len(t[0])]      # :82 -> (n, 15, 128, 2)
+            kind = _lib.MODEL_INDEL
+        else:
+            xs = [np.ascontiguousarray(t[1], np.float32) for t in tuples if len(t[0])]
+            kind = _lib.MODEL_INDEL_HAP
+        if not xs:
+            return [None] * len(tuples)
+        probs = eng.indel_forward(kind, torch.from_numpy(np.ascontiguousarray(np.concatenate(xs))).to(eng.device)).cpu().numpy()
+        out, o = [], 0
+        for t in tuples:
+            out.append(probs[o:o + len(t[0])] if len(t[0]) else None)
+            o += len(t[0])
+        return out
+
+    def emit(f, chunk, tup, probs=None):
+        chrom = chunk['chrom']
+        if probs is None and len(tup[0]):
+            probs = forward(chunk['ploidy'], [tup])[0]
+        if chunk['ploidy'] == 'diploid':
+            pos, x0, x1, x2, alleles_seq, phase = tup
+            if len(pos) != 0:
+                prev = 0
+                for b in range(0, len(pos), batch_size):
+                    lines, prev = indel_vcf_lines(chrom, pos[b:b + batch_size], probs[b:b + batch_size], alleles_seq[b:b + batch_size],
+                                                  phase[b:b + batch_size], prev)
+                    f.writelines(lines)
+        elif chunk['ploidy'] == 'haploid':
+            pos, x, alleles_seq = tup
+            if len(pos) != 0:
+                prev = 0
+                for b in range(0, len(pos), batch_size):
+                    lines, prev = indel_vcf_lines_haploid(chrom, pos[b:b + batch_size], probs[b:b + batch_size], alleles_seq[b:b + batch_size], prev)
+                    f.writelines(lines)
+        f.flush()
+        os.fsync(f.fileno())
+        counter_Q.put(1)
+
+    native = aligner in (None, "device") and (aligner == "device" or default_aligner() is star_aligner)
     with open(curr_vcf_path, 'w') as f:
         while len(indel_dict) > 0 or not job_Q.empty():
+            jobs = []
             try:
-                job = job_Q.get(block=False)
+                while True:
+                    jobs.append(job_Q.get(block=False))
             except queue.Empty:
+                pass
+            if not jobs:
                 if len(indel_dict) > 0:
                     continue
                 break
-            chunk = job[1]
-            chrom = chunk['chrom']
-            if chunk['ploidy'] == 'diploid':
-                pos, x0, x1, x2, alleles_seq, phase = get_indel_testing_candidates(params, chunk, aligner=aligner, device=device)
-                if len(pos) != 0:
-                    x_all = np.hstack([x0, x1, x2]).astype(np.float32)                       # :82 -> (n, 15, 128, 2)
-                    probs = eng.indel_forward(_lib.MODEL_INDEL, torch.from_numpy(np.ascontiguousarray(x_all)).to(eng.device)).cpu().numpy()
-                    prev = 0
-                    for b in range(0, len(pos), batch_size):
-                        lines, prev = indel_vcf_lines(chrom, pos[b:b + batch_size], probs[b:b + batch_size], alleles_seq[b:b + batch_size],
-                                                      phase[b:b + batch_size], prev)
-                        f.writelines(lines)
-            elif chunk['ploidy'] == 'haploid':
-                pos, x, alleles_seq = get_indel_testing_candidates_haploid(params, chunk, aligner=aligner, device=device)
-                if len(pos) != 0:
-                    probs = eng.indel_forward(_lib.MODEL_INDEL_HAP, torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(eng.device)).cpu().numpy()
-                    prev = 0
-                    for b in range(0, len(pos), batch_size):
-                        lines, prev = indel_vcf_lines_haploid(chrom, pos[b:b + batch_size], probs[b:b + batch_size], alleles_seq[b:b + batch_size], prev)
-                        f.writelines(lines)
-            f.flush()
-            os.fsync(f.fileno())
-            counter_Q.put(1)
+            if not native:
+                for job in jobs:
+                    chunk = job[1]
+                    fn = get_indel_testing_candidates if chunk['ploidy'] == 'diploid' else get_indel_testing_candidates_haploid
+                    emit(f, chunk, fn(params, chunk, aligner=aligner, device=device))
+                continue
+            # device / native route: the chunks of one (BAM, contig, ploidy) go through the featuriser together -- pass 1 in
+            # the same launches, one pass-2 call, one alignment call -- and are then emitted chunk by chunk, in job order
+            groups = {}
+            for k, job in enumerate(jobs):
+                c = job[1]
+                groups.setdefault((c['sam_path'], c['chrom'], c['ploidy']), []).append(k)
+            results = [None] * len(jobs)
+            for (sam, chrom, ploidy), ks in groups.items():
+                tuples = get_indel_testing_candidates_batch(params, [jobs[k][1] for k in ks], device=device, haploid=(ploidy == 'haploid'))
+                for k, t, pr in zip(ks, tuples, forward(ploidy, tuples)):
+                    results[k] = (t, pr)
+            for job, (t, pr) in zip(jobs, results):
+                emit(f, job[1], t, pr)
     return curr_vcf_path
 
 

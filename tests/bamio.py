@@ -7,6 +7,9 @@ import numpy as np
 
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 _NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_NT16_LUT = np.full(256, 15, np.uint8)
+for _c, _i in _NT16.items():
+    _NT16_LUT[ord(_c)] = _i
 
 
 def reg2bin(beg, end):          # SAMv1 5.3, 0-based half-open
@@ -80,9 +83,10 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
         rlen = sum(ln for op, ln in cig if op in "MDN=X")
         name = r["name"].encode() + b"\0"
         seq = r["seq"]
-        packed = bytearray((len(seq) + 1) // 2)
-        for i, c in enumerate(seq):
-            packed[i >> 1] |= _NT16.get(c, 15) << (4 if i % 2 == 0 else 0)
+        nib = _NT16_LUT[np.frombuffer(seq.encode("ascii"), np.uint8)]
+        if nib.size & 1:
+            nib = np.append(nib, np.uint8(0))
+        packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes()
         tags = b""
         for k, v in r.get("tags", {}).items():
             if isinstance(v, (list, tuple)):                 # B,I array (e.g. the CG tag)
@@ -134,36 +138,36 @@ def world_to_records(world, rng):
     """Alignment records equivalent to a world: explicit insertion / deletion events become I / D operations (deleted
     positions must already be code 4 in the world), other code-4 positions are written as base N, reverse-strand /
     filtered reads keep their flags, a soft clip is added at both ends."""
-    letters = "AGTCN"
+    lut = np.frombuffer(b"AGTCNNNN", np.uint8)
     ev_off, ev_pos, ev_len = world.meta["events"]
+    ins_off = ins_bases = None
+    if "ev_ins" in world.meta:                                                   # inserted bases given by the world
+        ins_off, ins_bases = world.meta["ev_ins"]
     recs = []
     for r in range(world.n_reads):
         s, e = int(world.read_start[r]), int(world.read_end[r])
-        codes = world.read_codes(r)
-        evs = {int(ev_pos[k]): int(ev_len[k]) for k in range(ev_off[r], ev_off[r + 1])}
-        ins = {}
-        if "ev_ins" in world.meta:                                               # inserted bases given by the world
-            ins_off, ins_bases = world.meta["ev_ins"]
-            ins = {int(ev_pos[k]): bytes(ins_bases[ins_off[k]:ins_off[k + 1]]).decode() for k in range(ev_off[r], ev_off[r + 1])}
+        letters = lut[world.read_codes(r)].tobytes().decode("ascii")
         cig, seq = [("S", 3)], ["ACG"]
-        p = s
-        run = 0
-        while p < e:
-            seq.append(letters[codes[p - s]])
-            run += 1
-            ev = evs.get(p)
-            if ev:
-                cig.append(("M", run))
-                run = 0
-                if ev > 0:
-                    cig.append(("I", ev))
-                    seq.append(ins[p] if ins else "".join(letters[i] for i in rng.integers(0, 4, size=ev)))
+        p = s                                                                    # next reference position to emit
+        for k in range(int(ev_off[r]), int(ev_off[r + 1])):
+            ep, ev = int(ev_pos[k]), int(ev_len[k])
+            if ep < p or ep >= e:
+                continue
+            cig.append(("M", ep - p + 1))
+            seq.append(letters[p - s:ep - s + 1])
+            p = ep + 1
+            if ev > 0:
+                cig.append(("I", ev))
+                if ins_bases is not None:
+                    seq.append(bytes(ins_bases[ins_off[k]:ins_off[k + 1]]).decode())
                 else:
-                    cig.append(("D", -ev))
-                    p += -ev
-            p += 1
-        if run:
-            cig.append(("M", run))
+                    seq.append("".join("AGTC"[i] for i in rng.integers(0, 4, size=ev)))
+            else:
+                cig.append(("D", -ev))
+                p += -ev
+        if p < e:
+            cig.append(("M", e - p))
+            seq.append(letters[p - s:e - s])
         cig.append(("S", 2))
         seq.append("TT")
         tags = {}

@@ -111,14 +111,13 @@ def test_get_regions_list_from_the_bam_header(two_contig_files, tmp_path):
 
 def test_pack_cache_is_keyed_by_contig_and_bounded(two_contig_files, monkeypatch):
     """the HBM pack cache must not hand the first contig's pack to the second; and it must not grow with
-    the number of contigs.  (engine stubbed: upload = identity.)"""
+    the number of contigs.  (engine stubbed: the upload is the identity.)"""
     from nanocaller_amd import generate_SNP_pileups as g
     w1, w2, bam, fa = two_contig_files
 
-    class Eng:
-        def upload(self, hp):
-            return hp
-    monkeypatch.setattr(g, "get_engine", lambda device=0: Eng())
+    from nanocaller_amd import wire
+    monkeypatch.setattr(g, "get_engine", lambda device=0: None)
+    monkeypatch.setattr(wire, "upload_wire", lambda eng, wp: wp)            # the "device pack" is the host wire pack
     g.release_contig()
     dct = dict(sam_path=bam, fasta_path=fa, supplementary=False, exclude_bed=None)
     p1 = g.device_pack_for(dct, "chr1")

@@ -229,3 +229,29 @@ def test_hip_indel_run_writes_the_reference_indel_runs_vcf(files, tag, tmp_path)
         jobs.put(("indel", dict(chrom=w.chrom, start=a, end=b, ploidy=ploidy, sam_path=bam)))
     path = indelCaller.indel_run(params, {}, jobs, queue.Queue(), files_out, aligner="device")
     _compare_indel_vcf(open(path).read().splitlines(), str(ZE[tag + "_vcf"]).splitlines())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("haploid", [False, True])
+def test_batched_featuriser_equals_per_chunk_calls(files, haploid):
+    """get_indel_testing_candidates_batch (all chunks of a contig through one pass-1 launch set, one native pass-2 call, one
+    alignment call -- what indel_run uses) returns, chunk by chunk, the tuples of the per-chunk functions; adjacent chunks
+    share anchors in their overlap zone"""
+    from nanocaller_amd.generate_indel_pileups_haploid import get_indel_testing_candidates_haploid
+    for wn, kw in (("a", {}), ("b", dict(impute_indel_phase=True, del_t=0.4))):
+        w, bam, fa = files[wn]
+        dct = dict(seq="ont", win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+                   exclude_bed=None, impute_indel_phase=False, fasta_path=fa)
+        dct.update(kw)
+        chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 4_000), sam_path=bam) for s in range(1, w.length, 4_000)]
+        got = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=haploid)
+        assert len(got) == len(chunks) and sum(len(t[0]) for t in got) > 20
+        for c, t in zip(chunks, got):
+            e = get_indel_testing_candidates_haploid(dct, c, aligner="device") if haploid else gip.get_indel_testing_candidates(dct, c, aligner="device")
+            assert list(t[0]) == list(e[0])
+            if len(e[0]):
+                for a, b in zip(t[1:], e[1:]):
+                    if isinstance(b, np.ndarray):
+                        assert np.array_equal(np.asarray(a), b)
+                    else:
+                        assert list(a) == list(b)
