@@ -21,6 +21,11 @@ SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio
 CODE_ABSENT = 7
 FLANK = 50000
 SNP_TENSOR = 1025
+# Scoring of the product's own star alignment (gap open, gap extend, match, mismatch): a gap must cost more than a mismatch
+# or sequencing noise next to a real indel is absorbed as extra gaps and the consensus length comes out wrong; with (25, 1, 20,
+# -10) 90 % of planted indels come back with their exact length against 77 % with parasail's call-site values (9, 1, 20, -10),
+# which stay in use where the reference uses them: allele_prediction (tools/exp_concordance.py).
+STAR_SCORING = (25, 1, 20, -10)
 
 # every symbol include/nanocaller_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

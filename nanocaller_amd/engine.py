@@ -311,7 +311,7 @@ class Engine:
                                                _lib.npp(ends), C.byref(prm), _lib.npp(out), _lib.npp(off)), "nc_indel_scan_batch")
         return [out[off[k]:off[k + 1]] for k in range(len(chunks))]
 
-    def star_msa_tensor(self, read_sets, refs, *, open_=9, extend=1, match=20, mismatch=-10, max_cols=None, want_rows=False, cns_as_str=False):
+    def star_msa_tensor(self, read_sets, refs, *, open_=None, extend=None, match=None, mismatch=None, max_cols=None, want_rows=False, cns_as_str=False):
         """Device star alignment (nc_star_msa_tensor) of many read sets at once + the rows -> tensor kernel.
         read_sets[s]: list of read strings, refs[s]: reference window string.
         -> (x f32 [S,5,128,2] device, cns list of uint8 arrays (or, cns_as_str, AGTC strings) with gaps removed, n_cols int32 [S]
@@ -341,10 +341,11 @@ class Engine:
         return self.star_msa_tensor_flat(S, raw_reads, read_off, set0, raw_refs, ref_off, mc, open_=open_, extend=extend, match=match,
                                          mismatch=mismatch, want_rows=want_rows, cns_as_str=cns_as_str, _n_reads=n_reads, _cap=cap)
 
-    def star_msa_tensor_flat(self, S, reads, read_off, set_read0, refs, ref_off, max_cols, *, open_=9, extend=1, match=20, mismatch=-10,
+    def star_msa_tensor_flat(self, S, reads, read_off, set_read0, refs, ref_off, max_cols, *, open_=None, extend=None, match=None, mismatch=None,
                              want_rows=False, cns_as_str=False, _n_reads=None, _cap=None):
         """The same on flat host buffers (what nc_indel_pass2_sets produces): `reads` / `refs` bytes objects or raw pointers
         (ints / c_void_p), read_off / set_read0 / ref_off int32 arrays or pointers."""
+        open_, extend, match, mismatch = [d if v is None else v for v, d in zip((open_, extend, match, mismatch), _lib.STAR_SCORING)]
         x = torch.empty((S, 5, 128, 2), dtype=torch.float32, device=self.device)
         mc = int(max_cols)
         cns = np.empty((S, mc), np.uint8)

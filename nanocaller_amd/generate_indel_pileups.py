@@ -248,13 +248,14 @@ def muscle_aligner(names, seqs, ref):
     return rows, ref_row
 
 
-def star_aligner(names, seqs, ref, open_=9, extend=1, match=20, mismatch=-10):
+def star_aligner(names, seqs, ref, open_=None, extend=None, match=None, mismatch=None):
     """Same interface as muscle_aligner, without the external binary: every read is aligned to the
     reference window (Gotoh, anchored at the window start, free tail; the scoring of the reference's own parasail call) and
     the pairwise alignments are merged in reference coordinates by nc_star_msa -- the longest insertion per reference slot
     makes the columns, shorter ones are left-justified.  Not MUSCLE's algorithm: its rows are not comparable with MUSCLE's
     output, only the calls made from them are.  -> (aligned read rows in input order, aligned reference row)."""
     L = _lib.lib()
+    open_, extend, match, mismatch = [d if v is None else v for v, d in zip((open_, extend, match, mismatch), _lib.STAR_SCORING)]
     n = len(seqs)
     raw = "".join(seqs).encode()
     off = np.zeros(n + 1, np.int32)

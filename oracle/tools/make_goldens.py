@@ -23,6 +23,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path[:0] = [os.path.join(HERE, "refstub"), "/root/reference", REPO]
 
+import types  # noqa: E402
+
+# `nanocaller_src` must be the REFERENCE's package here.  This repository has a regular package of the same name (the drop-in
+# alias of nanocaller_amd), which would shadow the reference's namespace package whatever the path order: pin the name to the
+# reference directory before anything imports it.
+_ref_pkg = types.ModuleType("nanocaller_src")
+_ref_pkg.__path__ = ["/root/reference/nanocaller_src"]
+sys.modules["nanocaller_src"] = _ref_pkg
+
 import numpy as np  # noqa: E402
 import pysam  # noqa: E402  (stub)
 
@@ -518,7 +527,8 @@ def _install_aligner_stubs(ref_mod, check_every=25):
             rows, ref_row = gip.star_aligner(names, seqs, ref)
             cnt["msa"] += 1
             if cnt["msa"] % check_every == 1:
-                assert (rows, ref_row) == oracle.star_msa_ref(seqs, ref)
+                from nanocaller_amd import _lib
+                assert (rows, ref_row) == oracle.star_msa_ref(seqs, ref, *_lib.STAR_SCORING)
             out = "".join(">%s_SEQ\n%s\n" % (n, r) for n, r in zip(names, rows)) + ">ref_SEQ\n%s\n" % ref_row
             return (out.encode(), b"")
 

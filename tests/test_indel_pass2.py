@@ -4,6 +4,7 @@ this image, so parity with them is unpinned; these tests pin the 
 import numpy as np
 import pytest
 
+from nanocaller_amd import _lib
 from nanocaller_amd import generate_indel_pileups as gip
 from nanocaller_amd.bam import BamFile
 from oracle import oracle
@@ -409,7 +410,7 @@ def test_star_aligner_matches_pure_python_restatement_and_is_lossless():
             q = _mutate(rng, ref, int(rng.integers(0, 5)), indels)
             seqs.append(q[:int(rng.integers(max(10, len(q) - 15), len(q) + 1))])
         rows, rr = gip.star_aligner(["r%d" % k for k in range(len(seqs))], seqs, ref)
-        erows, err = oracle.star_msa_ref(seqs, ref)
+        erows, err = oracle.star_msa_ref(seqs, ref, *_lib.STAR_SCORING)
         assert rr == err and rows == erows, trial
         assert rr.replace("-", "") == ref and all(r.replace("-", "") == q for r, q in zip(rows, seqs))
         assert len({len(r) for r in rows} | {len(rr)}) == 1
@@ -435,7 +436,7 @@ def test_free_tail_alignment_restatement_agrees_with_library_on_pairs():
                 ops[-1][1] += 1
             else:
                 ops.append([o, 1])
-        assert [tuple(o) for o in ops] == oracle.nw_cigar_free_tail_ref(q, ref), (q, ref)
+        assert [tuple(o) for o in ops] == oracle.nw_cigar_free_tail_ref(q, ref, *_lib.STAR_SCORING), (q, ref)
 
 
 @pytest.mark.gpu
@@ -476,7 +477,7 @@ def test_indel_calls_with_the_star_aligner_recover_the_planted_indels(tmp_path):
         diffs = [len(A) - len(R) for a, al in zip(pos, alleles) if a <= p <= a + 60 for (R, A) in al if R is not None]
         exact += ln in diffs
         close += any(abs(d - ln) <= 3 and d * ln > 0 for d in diffs)
-    assert exact >= 0.65 * len(truth) and close >= 0.8 * len(truth), (exact, close, len(truth))
+    assert exact >= 0.85 * len(truth) and close >= 0.88 * len(truth), (exact, close, len(truth))      # measured 90 % / 92 %
     # the batched device path (every read set of the chunk in one nc_star_msa_tensor call) returns the same tuple; it is also
     # what runs when no aligner is given and MUSCLE is not installed
     for al in ("device", None):
