@@ -6,6 +6,7 @@
 // generate_SNP_pileups.py:104), the insertion / deletion markers that pysam appends to the pileup string of the column
 // BEFORE the event ('+n' / '-n'), the HP / PS tags, and the query sequence (for the indel pass-2 read slices).
 // Host code only; file formats follow the SAM/BAM specification (SAMv1 section 4 and 5).
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <zlib.h>
 
@@ -79,10 +80,45 @@ struct Bgzf {
         k.next = coff + bsize;
         return true;
     }
+    struct Deflate {
+        bool ok = false;
+        void *(*alloc)() = nullptr;
+        int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+        uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+    };
+    static const Deflate &deflate_lib()
+    {
+        static const Deflate D = []() {
+            Deflate d;
+            if (getenv("NC_BAM_ZLIB")) return d;
+            void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return d;
+            d.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+            d.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+            d.crc32 = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+            d.ok = d.alloc && d.decompress && d.crc32;
+            return d;
+        }();
+        return D;
+    }
     static void inflate_blk(Blk &k)
     {
         k.data.resize(k.isize);
         if (!k.isize) return;
+        // libdeflate (2-3x zlib's inflate rate, vectorised CRC-32) when the shared library is present; it ships without headers
+        // in this image, so its four entry points are bound at run time.  zlib otherwise.
+        const Deflate &D = deflate_lib();
+        if (D.ok) {
+            thread_local void *dec = nullptr;
+            if (!dec) dec = D.alloc();
+            size_t got = 0;
+            if (dec && D.decompress(dec, k.comp.data(), (size_t)k.clen, k.data.data(), (size_t)k.isize, &got) == 0 && got == (size_t)k.isize) {
+                if (D.crc32(0, k.data.data(), (size_t)k.isize) != k.crc) k.ok = false;
+                std::vector<uint8_t>().swap(k.comp);
+                return;
+            }
+        }
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) { k.ok = false; return; }

@@ -386,3 +386,59 @@ def test_call_managers_on_a_two_contig_bam(two_contig_files, tmp_path):
     assert len(_records(files["final"])) == len(ind) + len(_records(files["snps"]))
     for fn in files.values():
         assert os.path.exists(fn + ".csi")
+
+
+def _icm_worker(rank, world, port, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    from nanocaller_amd import indelCaller
+    from nanocaller_amd.utils import get_chunks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 8
+    seen = []
+
+    def fake_indel_run(params, indel_dict, job_Q, counter_Q, files, device=0, worker_id=1, aligner=None):
+        path = os.path.join(params["intermediate_indel_files_dir"], "%s.%d.indel.vcf" % (params["prefix"], worker_id))
+        files.append(path)
+        with open(path, "a") as f:
+            while not job_Q.empty():
+                kind, chunk = job_Q.get()
+                seen.append((device, worker_id, chunk["chrom"], chunk["start"], chunk["sam_path"]))
+                f.write("%s\t%d\t.\tAT\tA\t12.00\tPASS\t.\tGT:GQ\t0|1:3.00\n" % (chunk["chrom"], chunk["start"] + 7))
+    indelCaller.indel_run = fake_indel_run
+    indelCaller._whatshap_available = lambda: False
+    regions = [("chr1", 1, 20_000, "diploid"), ("chrX", 1, 20_000, "haploid")]
+    snp_vcf = os.path.join(tmpdir, "t.snps.vcf.gz")
+    if rank == 0:
+        _fake_snp_vcf(snp_vcf, ["chr1", "chrX"])
+    dist.barrier()
+    params = dict(chunks_list=get_chunks(regions, 2, max_chunk_size=2_500), mode="all", snp_vcf=snp_vcf, regions_list=regions, sam_path="in.bam",
+                  fasta_path="x.fa", vcf_path=tmpdir, prefix="t", sample="S", phase_qual_score=10, suppress_progress=True, verbose=False,
+                  enable_whatshap=False, cpu=2)
+    out = indelCaller.call_manager(params)
+    with open(os.path.join(tmpdir, "ilog.%d" % rank), "w") as f:
+        f.write(repr((out, seen)))
+    dist.destroy_process_group()
+
+
+def test_indel_call_manager_under_gloo_shards_chunks_and_merges(tmp_path):
+    """indelCaller.call_manager with two ranks: rank 0 phases, the indel chunks are sharded in contiguous blocks, every rank
+    works on its own GPU and writes its own worker file, rank 0 merges all of them into the three sorted, indexed outputs"""
+    from nanocaller_amd.utils import get_chunks
+    world = 2
+    mp.spawn(_icm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    logs = [eval(open(os.path.join(str(tmp_path), "ilog.%d" % r)).read()) for r in range(world)]
+    chunks = get_chunks([("chr1", 1, 20_000, "diploid"), ("chrX", 1, 20_000, "haploid")], 2, max_chunk_size=2_500)
+    got = [(c, s) for lg in logs for (_, _, c, s, _) in lg[1]]
+    assert sorted(got) == sorted((c["chrom"], c["start"]) for c in chunks) and len(logs[0][1]) > 0 and len(logs[1][1]) > 0
+    assert {d for (d, _, _, _, _) in logs[0][1]} == {0} and {d for (d, _, _, _, _) in logs[1][1]} == {1}        # rank -> GPU
+    assert {w for (_, w, _, _, _) in logs[1][1]} == {2} and all(sp == "in.bam" for lg in logs for (_, _, _, _, sp) in lg[1])
+    assert logs[0][0] == logs[1][0] and logs[0][0]["final"].endswith("t.vcf.gz")
+    ind = _records(logs[0][0]["indels"])
+    assert len(ind) == len(chunks)
+    keys = [(["chr1", "chrX"].index(r.split("\t")[0]), int(r.split("\t")[1])) for r in ind]
+    assert keys == sorted(keys)
+    assert len(_records(logs[0][0]["final"])) == len(ind) + len(_records(logs[0][0]["snps"]))
