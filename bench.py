@@ -47,7 +47,7 @@ PCIE_PEAK_GBS = 63.0                   # MI355X_MICROARCH.md: PCIe Gen5 x16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--length", type=int, default=CHR20_LEN, help="contig length (default chr20)")
     ap.add_argument("--depth", type=float, default=30.0)

@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/nanocaller_hip.h"
@@ -221,6 +222,11 @@ struct nc_bam {
     // BAI linear index: per reference, smallest virtual offset of an alignment overlapping each 16 kb window
     std::vector<std::vector<uint64_t>> lin;
     bool have_bai = false;
+    // CSI index (samtools index -c; needed for contigs longer than 2^29): per reference, bin -> (loffset, chunks)
+    struct CsiBin { uint64_t loff; std::vector<std::pair<uint64_t, uint64_t>> chunks; };
+    std::vector<std::unordered_map<uint32_t, CsiBin>> csi;
+    int32_t csi_min_shift = 14, csi_depth = 5;
+    bool have_csi = false;
     char err[256] = {0};
 };
 
@@ -303,6 +309,85 @@ bool load_bai(nc_bam *b)
     return ok;
 }
 
+// <bam>.csi: a BGZF-compressed CSIv1 file (hts-specs CSIv1.pdf); zlib's gz reader handles the multi-member stream
+bool load_csi(nc_bam *b)
+{
+    gzFile g = gzopen((b->path + ".csi").c_str(), "rb");
+    if (!g) return false;
+    std::vector<uint8_t> raw;
+    uint8_t buf[1 << 16];
+    for (int k; (k = gzread(g, buf, sizeof buf)) > 0;) raw.insert(raw.end(), buf, buf + k);
+    gzclose(g);
+    size_t p = 0;
+    auto need = [&](size_t k) { return p + k <= raw.size(); };
+    auto r32 = [&]() { const int32_t v = rd32(raw.data() + p); p += 4; return v; };
+    auto r64 = [&]() { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | raw[p + (size_t)i]; p += 8; return v; };
+    if (!need(16) || memcmp(raw.data(), "CSI\1", 4) != 0) return false;
+    p = 4;
+    b->csi_min_shift = r32();
+    b->csi_depth = r32();
+    const int32_t l_aux = r32();
+    if (l_aux < 0 || !need((size_t)l_aux + 4) || b->csi_min_shift < 1 || b->csi_min_shift > 30 || b->csi_depth < 1 || b->csi_depth > 9) return false;
+    p += (size_t)l_aux;
+    const int32_t n_ref = r32();
+    if (n_ref != (int32_t)b->ref_name.size()) return false;
+    b->csi.assign((size_t)n_ref, {});
+    for (int32_t r = 0; r < n_ref; r++) {
+        if (!need(4)) return false;
+        const int32_t n_bin = r32();
+        for (int32_t k = 0; k < n_bin; k++) {
+            if (!need(16)) return false;
+            const uint32_t bin = (uint32_t)r32();
+            nc_bam::CsiBin cb;
+            cb.loff = r64();
+            const int32_t n_chunk = r32();
+            if (n_chunk < 0 || !need((size_t)n_chunk * 16)) return false;
+            for (int32_t c = 0; c < n_chunk; c++) { const uint64_t u = r64(), v = r64(); cb.chunks.emplace_back(u, v); }
+            b->csi[(size_t)r].emplace(bin, std::move(cb));
+        }
+    }
+    return true;
+}
+
+// htslib's rule (hts_itr_query): min_off = loffset of the finest existing bin that holds `beg` or lies to its left (walking up
+// the hierarchy); the scan starts at the smallest chunk start among the bins overlapping [beg, end) whose chunk end exceeds it.
+// -> virtual offset to start reading from, or 0 when the index holds nothing for the interval (nothing to read)
+uint64_t csi_start(const nc_bam *b, int32_t tid, int64_t beg0, int64_t end0, bool *empty)
+{
+    const auto &bins = b->csi[(size_t)tid];
+    const int ms = b->csi_min_shift, dp = b->csi_depth;
+    *empty = false;
+    auto first_of = [](int lvl) { return (uint32_t)(((1ull << (3 * lvl)) - 1) / 7); };
+    const int64_t maxpos = (int64_t)1 << (ms + 3 * dp);
+    if (beg0 < 0) beg0 = 0;
+    if (end0 > maxpos) end0 = maxpos;
+    if (beg0 >= end0) { *empty = true; return 0; }
+    uint64_t min_off = 0;
+    {
+        uint32_t bin = first_of(dp) + (uint32_t)(beg0 >> ms);
+        for (;;) {
+            auto it = bins.find(bin);
+            if (it != bins.end()) { min_off = it->second.loff; break; }
+            if (bin == 0) break;
+            const uint32_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
+            if (bin > first) --bin; else bin = parent;
+        }
+    }
+    uint64_t best = UINT64_MAX;
+    int64_t e = end0 - 1;
+    for (int lvl = 0, s = ms + 3 * dp; lvl <= dp; lvl++, s -= 3) {
+        const uint32_t t = first_of(lvl);
+        for (uint32_t k = t + (uint32_t)(beg0 >> s); k <= t + (uint32_t)(e >> s); k++) {
+            auto it = bins.find(k);
+            if (it == bins.end()) continue;
+            for (const auto &c : it->second.chunks)
+                if (c.second > min_off && c.first < best) best = c.first;
+        }
+    }
+    if (best == UINT64_MAX) { *empty = true; return 0; }
+    return best;
+}
+
 }   // namespace
 
 extern "C" {
@@ -335,6 +420,7 @@ int nc_bam_open(const char *path, nc_bam **out)
     b->first_rec_voff = ((uint64_t)b->z.block_coff << 16) | (uint64_t)b->z.upos;
     if (b->z.upos >= b->z.block.size() && !b->z.eof) b->first_rec_voff = (uint64_t)b->z.next_coff << 16;
     b->have_bai = load_bai(b);
+    if (!b->have_bai) b->have_csi = load_csi(b);
     *out = b;
     return NC_OK;
 }
@@ -351,7 +437,7 @@ int nc_bam_n_refs(nc_bam *b, int32_t *n, int32_t *has_index)
 {
     if (!b || !n) return NC_ERR_ARG;
     *n = (int32_t)b->ref_name.size();
-    if (has_index) *has_index = b->have_bai ? 1 : 0;
+    if (has_index) *has_index = (b->have_bai || b->have_csi) ? 1 : 0;
     return NC_OK;
 }
 
@@ -379,7 +465,9 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         if (w < L.size() && L[w]) voff = L[w];
         else if (!L.empty() && w >= L.size()) { if (L.back()) voff = L.back(); }
     }
-    if (!b->z.seek(voff)) return bam_fail(b, NC_ERR_ARG, "BGZF seek failed");
+    bool nothing = false;
+    if (!b->have_bai && b->have_csi && (size_t)tid < b->csi.size()) voff = csi_start(b, tid, (int64_t)beg1 - 1, end1, &nothing);
+    if (!nothing && !b->z.seek(voff)) return bam_fail(b, NC_ERR_ARG, "BGZF seek failed");
     nc_decoded *d = new nc_decoded();
     // Address space for ~48x coverage of the interval up front (untouched pages cost nothing): a growing gigabyte vector
     // is re-mapped and copied again and again, and with many decoding threads those mmap / munmap calls serialise on the
@@ -402,7 +490,7 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
     std::vector<uint8_t> rec;
     bool err = false;
     const int32_t beg0 = beg1 - 1, end0 = end1;      // 0-based half-open
-    for (;;) {
+    for (; !nothing;) {
         uint8_t lb[4];
         if (!b->z.read(lb, 4, &err)) break;
         const int32_t bs = rd32(lb);

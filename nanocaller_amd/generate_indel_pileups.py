@@ -396,6 +396,16 @@ def decoded_contig(sam_path, chrom, fasta_path):
         dec = decode_parallel(sam_path, chrom, keep_seq=True)
         fasta = read_fasta(fasta_path, chrom)
         _CONTIGS[key] = dict(dec=dec, handle=dec["_owner"].handle, fasta=fasta, fasta_b=fasta.encode("ascii"), keep={}, name_idx=None)
+        # the same decode serves pass 1 (and the SNP path): register it as the contig's World so that nothing decodes the BAM twice
+        from . import generate_SNP_pileups as gsp
+        from .synth import World
+
+        def as_world():
+            w = World(chrom=chrom, ref=fasta, read_start=dec["read_start"], read_end=dec["read_end"], read_flag=dec["read_flag"],
+                      read_off=dec["read_off"], codes=dec["codes"], names=dec["names"])
+            w.meta.update(events=(dec["ev_off"], dec["ev_pos"], dec["ev_len"]), hap=dec["hap"], ps=dec["ps"], seq_off=dec["seq_off"], seq=dec["seq"])
+            return w
+        gsp._BAM_WORLDS.get((sam_path, fasta_path, chrom), as_world)
     return _CONTIGS[key]
 
 
@@ -476,6 +486,7 @@ def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False):
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
     window_after = 260 if dct["seq"] == "pacbio" else 160
     extras = [dict() for _ in chunks]
+    ctg = decoded_contig(sam_path, chrom, dct["fasta_path"]) if isinstance(sam_path, str) else None   # before pass 1: one decode for both
     variants = scan_indel_candidates(dct, chunks, device, haploid=haploid, extra_variants=None if haploid else extras)
     max_range = {0: max(10, dct["win_size"]), 1: 10}
     per_chunk, flat_anchor, flat_chunk = [], [], []
@@ -487,7 +498,8 @@ def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False):
     empty = ([], [], []) if haploid else ([], [], [], [], [], [])
     if not flat_anchor:
         return [empty for _ in chunks]
-    ctg = decoded_contig(sam_path, chrom, dct["fasta_path"])
+    if ctg is None:
+        raise ValueError("the batched indel featuriser reads a BAM file (chunk['sam_path'])")
     order = np.argsort(np.asarray(flat_anchor), kind="stable")                      # ascending over the contig: one sweep over the reads
     anchors = [flat_anchor[i] for i in order]
     owner = [flat_chunk[i] for i in order]

@@ -64,7 +64,7 @@ class BgzfWriter:
         self.f.close()
 
 
-def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
+def write_bam(path, chrom, length, records, other_refs=(), write_bai=True, write_csi=False):
     """records: list of dict(name, flag, pos0, cigar=[(op,len)...] with op in 'MIDNSHP=X', seq (str), tags={'HP':1,...},
     optional tid = index into [(chrom, length)] + other_refs, default 0) in coordinate order."""
     refs = [(chrom, length)] + list(other_refs)
@@ -76,6 +76,7 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
     w.write(hdr)
     w.flush()
     lins = [dict() for _ in refs]
+    spans = [[] for _ in refs]                       # (beg0, end0, voff_beg, voff_end) of every mapped record, for the CSI
     ops = "MIDNSHP=X"
     for r in records:
         lin = lins[r.get("tid", 0)]
@@ -105,7 +106,11 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
             for win in range(r["pos0"] >> 14, ((r["pos0"] + max(1, rlen) - 1) >> 14) + 1):
                 lin.setdefault(win, voff)
         w.write(struct.pack("<i", len(body)) + body)
+        if not (r["flag"] & 4):
+            spans[r.get("tid", 0)].append((r["pos0"], r["pos0"] + max(1, rlen), voff, w.tell()))
     w.close()
+    if write_csi:
+        write_bam_csi(path + ".csi", spans)
     if write_bai:
         with open(path + ".bai", "wb") as f:
             f.write(b"BAI\1" + struct.pack("<i", len(refs)))
@@ -118,6 +123,58 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True):
                         last = lin[k]
                     arr[k] = last
                 f.write(struct.pack("<i", 0) + struct.pack("<i", n_intv) + b"".join(struct.pack("<Q", v) for v in arr))
+
+
+def write_bam_csi(path, spans, min_shift=14, depth=5):
+    """CSIv1 index of a BAM (hts-specs CSIv1: no auxiliary data; per reference the bins with their chunks and `loffset` =
+    linear-index value of the bin's first window, empty windows back-filled from the next one as htslib does), BGZF-compressed
+    like the files `samtools index -c` writes"""
+    def reg2bin(beg, end):
+        end -= 1
+        s, t = min_shift, ((1 << (depth * 3)) - 1) // 7
+        for lv in range(depth, 0, -1):
+            if beg >> s == end >> s:
+                return t + (beg >> s)
+            s += 3
+            t -= 1 << ((lv - 1) * 3)
+        return 0
+
+    def bin_start_window(b):
+        lv, t = 0, 0
+        while b >= t + (1 << (3 * lv)):
+            t += 1 << (3 * lv)
+            lv += 1
+        return ((b - t) << (3 * (depth - lv)))           # index of the bin's first 2^min_shift window
+    out = [b"CSI\1", struct.pack("<3i", min_shift, depth, 0), struct.pack("<i", len(spans))]
+    for recs in spans:
+        if not recs:
+            out.append(struct.pack("<i", 0))
+            continue
+        n_win = ((max(e for _, e, _, _ in recs) - 1) >> min_shift) + 1
+        lin = [None] * (n_win + 1)
+        bins = {}
+        for b0, e0, vb, ve in recs:
+            for wdx in range(b0 >> min_shift, ((e0 - 1) >> min_shift) + 1):
+                if lin[wdx] is None or vb < lin[wdx]:
+                    lin[wdx] = vb
+            ch = bins.setdefault(reg2bin(b0, e0), [])
+            if ch and ch[-1][1] == vb:
+                ch[-1][1] = ve                               # adjacent records form one chunk
+            else:
+                ch.append([vb, ve])
+        for k in range(n_win - 1, -1, -1):
+            if lin[k] is None:
+                lin[k] = lin[k + 1]
+        blob = [struct.pack("<i", len(bins))]
+        for b in sorted(bins):
+            wdx = bin_start_window(b)
+            loff = lin[wdx] if wdx < n_win and lin[wdx] is not None else 0
+            blob.append(struct.pack("<IQi", b, loff, len(bins[b])) + b"".join(struct.pack("<QQ", u, v) for u, v in bins[b]))
+        out.append(b"".join(blob))
+    out.append(struct.pack("<Q", 0))
+    w = BgzfWriter(path)
+    w.write(b"".join(out))
+    w.close()
 
 
 def write_fasta(path, chrom, seq, width=60, with_fai=True, extra=()):

@@ -167,3 +167,31 @@ def test_records_without_bases_and_long_cigars_in_the_cg_tag(tmp_path):
     bf.close()
     win = {d["names"][r]: t for r, t in d["windows"][0]}
     assert win["noseq"] == "" and win["longcig"] == win["plain"] and len(win["plain"]) > 5
+
+
+def test_csi_index_gives_the_same_regions_as_bai(tmp_path):
+    """`samtools index -c` writes a CSI index (the only kind for contigs longer than 2^29): region decodes through it equal
+    those through the BAI linear index and those of a sequential scan"""
+    import shutil
+    w = bamio.make_bam_world(seed=9, length=90_000, depth=10)
+    recs = bamio.world_to_records(w, np.random.Generator(np.random.PCG64(3)))
+    bai, csi, plain = str(tmp_path / "a.bam"), str(tmp_path / "c.bam"), str(tmp_path / "p.bam")
+    bamio.write_bam(bai, w.chrom, w.length, recs, write_bai=True)
+    bamio.write_bam(csi, w.chrom, w.length, recs, write_bai=False, write_csi=True)
+    bamio.write_bam(plain, w.chrom, w.length, recs, write_bai=False)
+    fa = BamFile(bai), BamFile(csi), BamFile(plain)
+    assert fa[0].has_index and fa[1].has_index and not fa[2].has_index
+    for (a, b) in [(1, 90_000), (40_000, 41_000), (16_384, 16_385), (70_001, 90_000), (89_990, 90_000), (32_768, 49_152), (5, 5)]:
+        ds = [f.decode(w.chrom, a, b, keep_seq=True) for f in fa]
+        for d in ds[1:]:
+            assert d["names"] == ds[0]["names"], (a, b)
+            for k in ("read_start", "read_end", "read_flag", "codes", "ev_pos", "ev_len", "hap", "ps", "seq"):
+                assert np.array_equal(d[k], ds[0][k]), (k, a, b)
+        assert len(ds[0]["names"]) == sum(1 for r in recs if not r["flag"] & 4 and r["pos0"] < b and r["pos0"] + sum(n for o, n in r["cigar"] if o in "MDN=X") >= a)
+    for f in fa:
+        f.close()
+    # a whole-contig parallel decode through the CSI
+    from nanocaller_amd.bam import decode_parallel
+    d1 = decode_parallel(csi, w.chrom, threads=4, min_region=10_000)
+    d2 = decode_parallel(bai, w.chrom, threads=4, min_region=10_000)
+    assert d1["names"] == d2["names"] and np.array_equal(d1["codes"], d2["codes"])
