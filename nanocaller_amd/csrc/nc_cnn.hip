@@ -671,10 +671,14 @@ __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Flo
 
 // conv1 of NT tiles (tile_first, tile_first + 4, ...) of 16 positions.  w1 = the 24 resident fragments:
 // [0..6] 5x5 WA, [7..13] 5x5 WB, [14,15] 1x5 WA (groups 0,1), [16,17] 1x5 WB, [18..20] 5x1 WA (groups 1,2,3), [21..23] 5x1 WB
-template <int NT>
+// PART: 0 = all 48 output channels; 1 = the 5x5 kernel's 16 only (14 MFMAs per tile); 2 = the 1x5 and 5x1 kernels' 32 only
+// (10 MFMAs per tile, K groups 0..3) -- a tile can be shared by two waves to even out the SIMDs
+template <int NT, int PART = 0>
 __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const h8 (&w1)[T_NW1],
                                         const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane)
 {
+    constexpr bool DO55 = PART != 2, DO15 = PART != 1;
+    constexpr int NG = DO55 ? 7 : 4;
     const int g = lane >> 4, c16 = lane & 15;
     int xbase[NT], obase[NT];
 #pragma unroll
@@ -712,28 +716,32 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
     };
     load1(0, 0);
 #pragma unroll
-    for (int G = 0; G < 7; G++) {
+    for (int G = 0; G < NG; G++) {
         const int cur = G & 1;
-        if (G + 1 < 7) load1(G + 1, cur ^ 1);
+        if (G + 1 < NG) load1(G + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         // independent accumulators interleaved: no MFMA depends on the one issued just before it
+        if (DO55) {
 #pragma unroll
-        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[G], xa[cur][tm]) }
-        if (G < 2) {
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[G], xa[cur][tm]) }
+        }
+        if (DO15 && G < 2) {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc1[tm], w1[14 + G], xa[cur][tm]) }
         }
-        if (G >= 1 && G <= 3) {
+        if (DO15 && G >= 1 && G <= 3) {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], w1[18 + G - 1], xa[cur][tm]) }
         }
+        if (DO55) {
 #pragma unroll
-        for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[7 + G], xb[cur][tm]) }
-        if (G < 2) {
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[7 + G], xb[cur][tm]) }
+        }
+        if (DO15 && G < 2) {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc1[tm], w1[16 + G], xb[cur][tm]) }
         }
-        if (G >= 1 && G <= 3) {
+        if (DO15 && G >= 1 && G <= 3) {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], w1[21 + G - 1], xb[cur][tm]) }
         }
@@ -742,9 +750,11 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
         const int o = obase[tm];
-        split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
-        split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
-        split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
+        if (DO15) {
+            split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
+            split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
+        }
+        if (DO55) split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
     }
 }
 
@@ -941,7 +951,9 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
 #endif
             NC_T(1)
 #ifndef NC_ABL_NOC
-            if (wv == 0) t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, 8, lane);       // wave 0 owns 4 of the 13 tiles: 3 before beta
+            // 13 tiles over 4 waves: tile 8 is shared, wave 0 its 5x5 channels (14 MFMAs), wave 1 the 1x5 + 5x1 ones (10)
+            if (wv == 0) t_conv1<1, 1>(X[buf], A1[buf], w1, b1s, epi, 8, lane);
+            if (wv == 1) t_conv1<1, 2>(X[buf], A1[buf], w1, b1s, epi, 8, lane);
 #endif
             if (k > 0) __syncthreads();                                            // beta_{k-1}
             NC_T(2)

@@ -21,10 +21,14 @@ def one(libpath):
     eng.load_weights(_lib.MODEL_SNP, w)
     n = 32768 * 8
     g = torch.Generator(device="cuda").manual_seed(1)
+    i16 = os.environ.get("NC_EXP_FP32X") is None                  # product format: int16 site tensors
     x = torch.rand((n, 5, 41, 5), device="cuda", generator=g) * 30
+    if i16:
+        x = x.to(torch.int16)
+        eng.set_tensor_format(int16=True)
     rc = torch.randint(0, 4, (n,), device="cuda", dtype=torch.int32)
     sc = torch.full((n,), 0.9, device="cuda", dtype=torch.float64)
-    for exact in ([False, True] if not libpath else [False]):
+    for exact in ([False, True] if (not libpath and not i16) else [False]):
         eng.set_cnn_precision(exact_fp32=exact)
         eng.snp_forward(_lib.MODEL_SNP, x, rc, sc)
         eng.enable_timing(True)
