@@ -669,21 +669,25 @@ __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Flo
 #endif
 #define NC_MFMA3(ACC, XH, XL, WH, WL) NC_MFMA(ACC, WH, XH) NC_MFMA(ACC, WH, XL) NC_MFMA(ACC, WL, XH)
 
-// conv1 of NT tiles (tile_first, tile_first + 4, ...) of 16 positions.  w1 = the 24 resident fragments:
+// conv1 of NT tiles of 16 positions: tile_first, tile_first + 4, ... and, when tile_last >= 0, tile_last as the last one.
+// w1 = the 24 resident fragments:
 // [0..6] 5x5 WA, [7..13] 5x5 WB, [14,15] 1x5 WA (groups 0,1), [16,17] 1x5 WB, [18..20] 5x1 WA (groups 1,2,3), [21..23] 5x1 WB
-// PART: 0 = all 48 output channels; 1 = the 5x5 kernel's 16 only (14 MFMAs per tile); 2 = the 1x5 and 5x1 kernels' 32 only
-// (10 MFMAs per tile, K groups 0..3) -- a tile can be shared by two waves to even out the SIMDs
-template <int NT, int PART = 0>
+// KL: which kernels' output channels the LAST tile computes -- bit 0 the 1x5 kernel's 16 (4 MFMAs per tile, K groups 0,1), bit 1
+// the 5x1 kernel's (6 MFMAs, groups 1..3), bit 2 the 5x5 kernel's (14 MFMAs, all groups).  A tile can so be shared by two
+// waves to even out the SIMDs, and its MFMAs are interleaved with those of the wave's full tiles (a partial tile on its own
+// is one chain of dependent MFMAs: latency-bound).
+template <int NT, int KL = 7>
 __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const h8 (&w1)[T_NW1],
-                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane)
+                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane, int tile_last = -1)
 {
-    constexpr bool DO55 = PART != 2, DO15 = PART != 1;
-    constexpr int NG = DO55 ? 7 : 4;
+    // kernel mask and K-group range of tile tm
+#define C1_KM(tm) ((tm) == NT - 1 ? KL : 7)
+#define C1_GHI(tm) ((C1_KM(tm) & 4) ? 7 : ((C1_KM(tm) & 2) ? 4 : 2))
     const int g = lane >> 4, c16 = lane & 15;
     int xbase[NT], obase[NT];
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        const int p = (tile_first + 4 * tm) * 16 + c16;
+        const int p = ((tm == NT - 1 && tile_last >= 0) ? tile_last : tile_first + 4 * tm) * 16 + c16;
         const int pr = p < 205 ? p : 204;
         const int h = pr / 41, w = pr - h * 41;
         xbase[tm] = (h * T_RX + w) * 8;                              // halves; tap (dy,dx) of pixel (h,w) is padded pixel (h+dy, w+dx)
@@ -706,6 +710,7 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
         const int toff = (int)((c1_tap_pack(G) >> sh) & 0xffffu);       // halves
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) {
+            if (G >= C1_GHI(tm)) continue;
 #ifdef NC_ABL_NOLDS
             xa[slot][tm] = w1[(G + tm) % 7]; xb[slot][tm] = w1[7 + (G + 2 * tm) % 7];
 #else
@@ -714,6 +719,7 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
 #endif
         }
     };
+    constexpr int NG = NT > 1 ? 7 : C1_GHI(0);
     load1(0, 0);
 #pragma unroll
     for (int G = 0; G < NG; G++) {
@@ -721,41 +727,37 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
         if (G + 1 < NG) load1(G + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         // independent accumulators interleaved: no MFMA depends on the one issued just before it
-        if (DO55) {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[G], xa[cur][tm]) }
+        for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 4) { NC_MFMA(acc3[tm], w1[G], xa[cur][tm]) }
+        if (G < 2) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 1) { NC_MFMA(acc1[tm], w1[14 + G], xa[cur][tm]) }
         }
-        if (DO15 && G < 2) {
+        if (G >= 1 && G <= 3) {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc1[tm], w1[14 + G], xa[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 2) { NC_MFMA(acc2[tm], w1[18 + G - 1], xa[cur][tm]) }
         }
-        if (DO15 && G >= 1 && G <= 3) {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], w1[18 + G - 1], xa[cur][tm]) }
+        for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 4) { NC_MFMA(acc3[tm], w1[7 + G], xb[cur][tm]) }
+        if (G < 2) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 1) { NC_MFMA(acc1[tm], w1[16 + G], xb[cur][tm]) }
         }
-        if (DO55) {
+        if (G >= 1 && G <= 3) {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc3[tm], w1[7 + G], xb[cur][tm]) }
-        }
-        if (DO15 && G < 2) {
-#pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc1[tm], w1[16 + G], xb[cur][tm]) }
-        }
-        if (DO15 && G >= 1 && G <= 3) {
-#pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], w1[21 + G - 1], xb[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 2) { NC_MFMA(acc2[tm], w1[21 + G - 1], xb[cur][tm]) }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
         const int o = obase[tm];
-        if (DO15) {
-            split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
-            split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
-        }
-        if (DO55) split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
+        if (C1_KM(tm) & 1) split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
+        if (C1_KM(tm) & 2) split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
+        if (C1_KM(tm) & 4) split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
     }
+#undef C1_KM
+#undef C1_GHI
 }
 
 // conv2: wave (tn = wv & 1, t0 = wv >> 1) computes output channels 16 tn .. 16 tn + 15 of tiles t0, t0 + 2, (t0 + 4).
@@ -867,7 +869,7 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
 //   waves 4-7 ("D"): conv2 + conv3.  This wave's 9+9 conv2 and 6+6 conv3 fragments (120 VGPRs) stay in registers.
 // C works on site k+1 while D works on site k: X and A1 are double-buffered, A2 is single.  Two workgroup barriers per
 // site (alpha_k: A1[k&1] and X[(k+1)&1] complete; beta_k: A2 complete), executed by both roles in the same order:
-//   C:  P0 | conv1(0) alpha_0 | conv1(1) first tiles, beta_0, last tile + staging commit, alpha_1 | ... | beta_last
+//   C:  P0 | conv1(0) alpha_0 | conv1(1) first tiles, staging commit of site 2, beta_0, last tile, alpha_1 | ... | beta_last
 //   D:  P0 | alpha_0 conv2(0) beta_0 conv3(0) | alpha_1 conv2(1) beta_1 conv3(1) | ...
 // No weight is re-read per site, and the MFMA phases of one role overlap the epilogues of the other on every SIMD.
 #ifdef NC_TRACE
@@ -888,9 +890,14 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint4 *w1f = reinterpret_cast<const uint4 *>(wp), *w2h = w1f + T_NW1 * 64, *w2l = w2h + T_NW2 * 64, *w3h = w2l + T_NW2 * 64,
                 *w3l = w3h + T_NW3 * 64;
-    const float *b1s = reinterpret_cast<const float *>(w3l + T_NW3 * 64), *b2s = b1s + 48, *b3s = b2s + 32;
-    const int *c3tab = reinterpret_cast<const int *>(b3s + 68);
-    const float inv_s = b3s[64];
+    // the scaled biases live in LDS: a global load inside the site loop would make its s_waitcnt vmcnt also wait for the
+    // staging loads (role C) / the activation stores (role D) issued before it
+    __shared__ __attribute__((aligned(16))) float BIAS[48 + 32 + 64];
+    const float *bg = reinterpret_cast<const float *>(w3l + T_NW3 * 64);
+    const float *b1s = BIAS, *b2s = BIAS + 48, *b3s = BIAS + 80;
+    const int *c3tab = reinterpret_cast<const int *>(bg + 48 + 32 + 68);
+    const float inv_s = bg[48 + 32 + 64];
+    if (threadIdx.x < 48 + 32 + 64) BIAS[threadIdx.x] = bg[threadIdx.x];
     const h_epi epi = {inv_s * 1.44269504088896341f, inv_s * SELU_L, 60000.0f / (inv_s * SELU_L)};
     const int64_t n_k = (n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x;        // sites of this workgroup (>= 1)
     for (int i = threadIdx.x; i < 4 * T_XS; i += 512) *reinterpret_cast<uint4 *>(&X[0][0] + i * 8) = make_uint4(0, 0, 0, 0);
@@ -903,13 +910,18 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         // staging: thread t < 205 owns pixel t = h*41 + w (5 channels = 20 contiguous bytes of the site's tensor)
         const int px = threadIdx.x < 205 ? threadIdx.x : 204, ph = px / 41, pw = px - ph * 41;
         const int xslot = ((ph + 2) * T_RX + pw + 2) * 8;
+        // prefetch() only ISSUES the loads (raw bits stay in registers); every conversion happens in commit(), a conv1 call
+        // later, so that no wave waits for memory at the top of a site
         float pre[5];
+        uint32_t raw[3];
         double pre_sd = 1.0;
         auto prefetch = [&](int64_t site) {
             if constexpr (X16) {
-                const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;
-#pragma unroll
-                for (int u = 0; u < 5; u++) pre[u] = (float)xs[u];
+                const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;       // 2-byte aligned
+                typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                raw[0] = *reinterpret_cast<const u32_a2 *>(xs);
+                raw[1] = *reinterpret_cast<const u32_a2 *>(xs + 2);
+                raw[2] = (uint32_t)(uint16_t)xs[4];
             } else {
                 const float *xs = x + site * NC_SNP_TENSOR + px * 5;
 #pragma unroll
@@ -919,12 +931,25 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         };
         auto commit = [&](int buf) {
             if (threadIdx.x < 205) {
-                const float pre_sf = (float)pre_sd;
+                if constexpr (X16) {
+                    pre[0] = (float)(int16_t)(raw[0] & 0xffffu); pre[1] = (float)(int16_t)(raw[0] >> 16);
+                    pre[2] = (float)(int16_t)(raw[1] & 0xffffu); pre[3] = (float)(int16_t)(raw[1] >> 16);
+                    pre[4] = (float)(int16_t)raw[2];
+                }
+                // snpCaller.py:93-96: rows 1..4, channels 0..3 are scaled; a multiplier of exactly 1 elsewhere keeps this branch-free
+                const double md = (scale && ph > 0) ? pre_sd : 1.0;
+                const float mf = (float)md;
+                if (scale_mode == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pre[u] *= mf;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pre[u] = (float)((double)pre[u] * md);
+                }
                 _Float16 hi[5], lo[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) {
                     float v = pre[u];
-                    if (scale && ph > 0 && u < 4) v = scale_mode == 0 ? v * pre_sf : (float)((double)v * pre_sd);    // snpCaller.py:93-96
                     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
                     hi[u] = (_Float16)v;
                     lo[u] = (_Float16)(v - (float)hi[u]);
@@ -947,23 +972,25 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
 #endif
             NC_T(0)
 #ifndef NC_ABL_NOC
-            t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, wv, lane);
+            // 13 tiles over 4 waves, 9 of them before beta: wave w its tiles w and w + 4; tile 8 is shared, wave 0 computes its
+            // 5x5 channels (14 MFMAs) and wave 1 the 1x5 + 5x1 ones (10), interleaved with their full tiles
+            if (wv == 0) t_conv1<3, 4>(X[buf], A1[buf], w1, b1s, epi, wv, lane, 8);
+            else if (wv == 1) t_conv1<3, 3>(X[buf], A1[buf], w1, b1s, epi, wv, lane, 8);
+            else t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, wv, lane);
 #endif
             NC_T(1)
-#ifndef NC_ABL_NOC
-            // 13 tiles over 4 waves: tile 8 is shared, wave 0 its 5x5 channels (14 MFMAs), wave 1 the 1x5 + 5x1 ones (10)
-            if (wv == 0) t_conv1<1, 1>(X[buf], A1[buf], w1, b1s, epi, 8, lane);
-            if (wv == 1) t_conv1<1, 2>(X[buf], A1[buf], w1, b1s, epi, 8, lane);
+            // the other X buffer's last reader was conv1 of site k-1 (finished before alpha_{k-1}): the next site's tensor is
+            // committed here, where role C has slack, and long after its loads were issued
+#ifndef NC_ABL_NOSTAGE
+            if (more) commit(buf ^ 1);
 #endif
+            NC_T(6)
             if (k > 0) __syncthreads();                                            // beta_{k-1}
             NC_T(2)
 #ifndef NC_ABL_NOC
             t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, wv == 0 ? 12 : 8 + wv, lane);
 #endif
             NC_T(3)
-#ifndef NC_ABL_NOSTAGE
-            if (more) commit(buf ^ 1);
-#endif
             NC_T(4)
             __syncthreads();                                                       // alpha_k
             NC_T(5)

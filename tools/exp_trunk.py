@@ -47,7 +47,7 @@ def one(libpath):
         for w in range(8):
             print("wave %d:" % w)
             for k in range(8):
-                print("   site %d: %s" % (k, " ".join("%7d" % v for v in rel[w, k, :6])))
+                print("   site %d: %s" % (k, " ".join("%7d" % v for v in rel[w, k, :8])))
 
 
 if __name__ == "__main__":
