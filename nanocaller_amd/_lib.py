@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnanocaller_hip.so")
+LIB_PATH = os.environ.get("NANOCALLER_HIP_LIB") or os.path.join(_HERE, "libnanocaller_hip.so")   # env: another build of the same ABI
 
 NC_OK = 0
 NC_ERR_CAPACITY = -2

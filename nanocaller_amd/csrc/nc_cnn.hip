@@ -856,8 +856,8 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3l[G], ah[cur][tm]) }
         __builtin_amdgcn_sched_barrier(0);
     }
-    h_epi e3 = epi;
-    e3.c3 = 3.0e38f;                                                  // fp32 output: no fp16 range clamp
+    const h_epi &e3 = epi;                                            // same fp16 range clamp as the other layers: k6_fc1_h3 splits
+                                                                      // these values into fp16 hi/lo without a clamp of its own
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
         if (c3out[tm] >= 0) *reinterpret_cast<f32x4v *>(out_site + c3out[tm] * 64 + wv * 16 + 4 * g) = selu4_scaled(acc[tm], e3);
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void split8(const float4 &a, const float4 &b, h8 &hi,
     uint32_t uh[4], ul[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        const float x0 = fminf(fmaxf(v[2 * p], -65504.0f), 65504.0f), x1 = fminf(fmaxf(v[2 * p + 1], -65504.0f), 65504.0f);
+        const float x0 = v[2 * p], x1 = v[2 * p + 1];                  // selu outputs clamped to fp16 range by k5_trunk_h3's conv3 epilogue
         const h2 h = __builtin_convertvector((f32x2v){x0, x1}, h2);
         uh[p] = __builtin_bit_cast(uint32_t, h);
         const f32x2v d = {sub_h_lo(x0, uh[p]), sub_h_hi(x1, uh[p])};

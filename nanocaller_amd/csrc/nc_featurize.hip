@@ -75,10 +75,13 @@ struct FeatArgs {
     int32_t x_i16;                 // 1: the tensors leave as int16 (every entry is a small integer: exact), half the bytes
 };
 
-template <int CAP>
+// I16: the tensors leave as int16 (product path).  Then nothing is assembled in LDS: lane L < 41 takes tensor column L, fetches
+// the counters of the lane that walked that column (ds_bpermute) and writes its five rows' 10 bytes straight to global memory
+// (41 lanes x 10 B = one contiguous 410-byte row per store pair) -- no zero fill, no workgroup barrier, no LDS round trip.
+template <int CAP, bool I16>
 __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sm[4][NC_SNP_TENSOR + 3];
+    __shared__ __attribute__((aligned(16))) float sm[I16 ? 1 : 4][I16 ? 4 : NC_SNP_TENSOR + 3];
     __shared__ int32_t nlist[4][64];                              // per wave: indices (into nbr_pos) of the picked neighbour sites
     // the wave index is wave-uniform: telling the compiler so puts the site's scalars (position, tile, entry range) and
     // the entry records of the read loop into SGPRs / the scalar cache
@@ -88,8 +91,9 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     const int nblk = (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     const int s = blk * 4 + wv;
-    float *X = sm[wv];
-    for (int i = lane; i < NC_SNP_TENSOR; i += 64) X[i] = 0.0f;
+    float *X = sm[I16 ? 0 : wv];
+    if constexpr (!I16)
+        for (int i = lane; i < NC_SNP_TENSOR; i += 64) X[i] = 0.0f;
 
     if (s < a.n_sites) {
         const int32_t v = __builtin_amdgcn_readfirstlane(a.site_pos[s]);
@@ -235,7 +239,42 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
             }
         }
         const int ns = min(n_all, a.maxcov);
-        if (ok) {
+        if constexpr (I16) {
+            // ---- assemble (Appendix A step 5) in registers, one tensor column per lane
+            const int o = NBR - nl;
+            const int src = lane - o;                                        // the lane that walked tensor column `lane`
+            const bool have = ok && lane < 41 && src >= 0 && src < ncols;
+            const int sl = have ? src : lane;
+            const int rc_s = __shfl(rc_col, sl, 64);
+            cnt_t cs[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if constexpr (BYTE_CNT) cs[i] = (cnt_t)__shfl((int)cnt[i], sl, 64);
+                else cs[i] = ((cnt_t)(uint32_t)__shfl((int)(cnt[i] >> 32), sl, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)cnt[i], sl, 64);
+            }
+            if (lane < 41) {
+                int16_t *dst = reinterpret_cast<int16_t *>(a.x) + (int64_t)s * NC_SNP_TENSOR + lane * 5;     // 2-byte aligned
+                typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                auto put_row = [&](int row, int v0, int v1, int v2, int v3, int v4) {
+                    int16_t *d = dst + row * (41 * 5);
+                    *reinterpret_cast<u32_a2 *>(d) = (uint32_t)(v0 & 0xffff) | ((uint32_t)v1 << 16);
+                    *reinterpret_cast<u32_a2 *>(d + 2) = (uint32_t)(v2 & 0xffff) | ((uint32_t)v3 << 16);
+                    d[4] = (int16_t)v4;
+                };
+                const int rcs = have ? rc_s : 4;
+                put_row(0, rcs == 0, rcs == 1, rcs == 2, rcs == 3, 0);                   // row 0: reference one-hot
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int v[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int val = have ? (int)((cs[i] >> (FIELD * b)) & ((1 << FIELD) - 1)) : 0;
+                        v[b] = b == rcs ? -val : val;
+                    }
+                    put_row(1 + i, v[0], v[1], v[2], v[3], (have && i == rc_centre) ? 1 : 0);
+                }
+            }
+        } else if (ok) {
             // ---- assemble (Appendix A step 5)
             if (active) {
                 const int o = NBR - nl;
@@ -263,6 +302,7 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
         }
         (void)nr;
     }
+    if constexpr (I16) return;
     __syncthreads();
     // coalesced store of up to four site tensors
     const int s0 = blk * 4;
@@ -393,10 +433,14 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     NcTimer tm(ctx, 1);
     hipLaunchKernelGGL(k_nbr_index, dim3((n_cidx + 255) / 256), dim3(256), 0, ctx->stream, a.nbr_pos, a.n_nbr, a.cidx_pos0, n_cidx,
                        (int32_t *)ctx->nbr_idx.p);
-    if (maxcov < MAXCOV_SMALL)                              // 8-bit counter fields: at most 255 sampled reads
-        hipLaunchKernelGGL(k_featurize<MAXCOV_SMALL>, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(k_featurize<MAXCOV_CAP>, dim3((ctx->n_sites + 3) / 4), dim3(256), 0, ctx->stream, a);
+    const dim3 grid((ctx->n_sites + 3) / 4);
+    if (maxcov < MAXCOV_SMALL) {                            // 8-bit counter fields: at most 255 sampled reads
+        if (a.x_i16) hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, true>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, false>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        if (a.x_i16) hipLaunchKernelGGL((k_featurize<MAXCOV_CAP, true>), grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_featurize<MAXCOV_CAP, false>), grid, dim3(256), 0, ctx->stream, a);
+    }
     NC_HIP(ctx, hipGetLastError());
     tm.stop();
     return NC_OK;

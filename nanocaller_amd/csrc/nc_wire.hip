@@ -15,10 +15,15 @@
 #include <thread>
 #include <vector>
 
+#include <cstdlib>
+
 #include "nc_common.h"
 #include "nc_host.h"
 
 #define WIRE_BLOCK 1024
+#ifndef NC_WIRE_U
+#define NC_WIRE_U 4
+#endif
 
 struct nc_wire {
     std::vector<int32_t> rd_start, rd_end;
@@ -149,29 +154,22 @@ extern "C" int nc_wire_free(nc_wire *w)
 
 // ------------------------------------------------------------------------------------------------------------ device side
 namespace {
-// One WAVE per 1024-byte block (four per workgroup), no workgroup barrier: lane t owns the aligned 16-byte group t of the
-// block.  A 16-byte group never straddles two reads (slots are 16-byte aligned) and maps to 16 consecutive, 16-aligned
-// reference positions, so the predicted bytes are ONE aligned dwordx4 of ref_wire, masked to the read's span.  blk_read gives
-// the first read reaching into the block (reads are kilobases long: usually THE read); the block's events are scattered over
-// the wave's LDS image (no two events address the same byte), then every lane stores one dwordx4.
-__global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
-                                                     const int64_t *__restrict__ slot_off, const uint8_t *__restrict__ ref_wire,
-                                                     int32_t ref_pos0, int64_t ref_len, const uint32_t *__restrict__ blk_off,
-                                                     const int32_t *__restrict__ blk_read, const uint16_t *__restrict__ events,
-                                                     int64_t n_blocks, uint8_t *__restrict__ codes, int64_t codes_len)
+// One WAVE per U consecutive 1024-byte blocks (four waves per workgroup), no workgroup barrier: lane t owns the aligned
+// 16-byte group t of each block.  A 16-byte group never straddles two reads (slots are 16-byte aligned) and maps to 16
+// consecutive, 16-aligned reference positions, so the predicted bytes are ONE aligned dwordx4 of ref_wire, masked to the read's
+// span.  blk_read gives the first read reaching into the block (reads are kilobases long: usually THE read); the block's
+// events are scattered over the wave's LDS image (no two events address the same byte), then every lane stores one dwordx4.
+// The kernel is a chain of four dependent loads (block table -> read boundaries -> read record -> reference bytes): every
+// level is issued for all U blocks before the first result is used, so a wave has U KiB in flight per memory latency.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// the 16 bytes of group B for a lane whose block is NOT wholly inside one read (read boundaries, reference edges): the general
+// per-lane form.  r = the block's first read.
+__device__ __noinline__ uint4 wire_group_general(int64_t B, int64_t r, int32_t n_reads, const int32_t *__restrict__ rd_start,
+                                                const int32_t *__restrict__ rd_end, const int64_t *__restrict__ slot_off,
+                                                const uint8_t *__restrict__ ref_wire, int32_t ref_pos0, int64_t ref_len)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t img_all[4 * WIRE_BLOCK];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + wv;
-    if (blk >= n_blocks) return;
-    uint8_t *img = img_all + wv * WIRE_BLOCK;
-    const int64_t B = blk * WIRE_BLOCK + (int64_t)lane * 16;
-    // independent loads first: the block's event range and its first two batches of events travel while the read lookup runs
-    int64_t r = blk_read[blk];
-    const uint32_t e0 = blk_off[blk], e1 = blk_off[blk + 1];
-    const uint32_t k0 = e0 + lane, k1 = e0 + 64 + lane;
-    const uint32_t ev0 = k0 < e1 ? (uint32_t)events[k0] : 0xffffffffu, ev1 = k1 < e1 ? (uint32_t)events[k1] : 0xffffffffu;
-    while (r < n_reads && slot_off[r + 1] <= B) r++;             // at most 63 steps, almost always none
+    while (r < n_reads && slot_off[r + 1] <= B) r++;             // at most 63 steps, almost always none or one
     uint32_t o[4] = {0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u};
     if (r < n_reads) {
         const int64_t s = rd_start[r], e = rd_end[r];
@@ -189,38 +187,121 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
                     w[j >> 2] = (w[j >> 2] & ~(0xffu << ((j & 3) * 8))) | (b << ((j & 3) * 8));
                 }
             }
-            if (p0 >= s && p0 + 16 <= e) {
-                o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
-            } else {
-                for (int j = 0; j < 16; j++) {
-                    const int64_t p = p0 + j;
-                    if (p >= s && p < e) {
-                        const uint32_t sh = (j & 3) * 8;
-                        o[j >> 2] = (o[j >> 2] & ~(0xffu << sh)) | (((w[j >> 2] >> sh) & 0xffu) << sh);
-                    }
-                }
+            // bytes [lo, hi) of the group belong to the read (a read's first and last group are partial): a 16-bit byte mask,
+            // each nibble widened to a dword of 0x00 / 0xff bytes (the multiply spreads bit i to bit 8 i, no carries)
+            const int64_t dl = s - p0, dh = e - p0;
+            const int lo = dl < 0 ? 0 : (int)dl, hi = dh > 16 ? 16 : (int)dh;       // 0 <= lo < 16, 0 < hi <= 16 here
+            const uint32_t bits = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t m = (((bits >> (4 * d)) & 0xfu) * 0x00204081u) & 0x01010101u;
+                m = (m << 8) - m;
+                o[d] = (w[d] & m) | (0x07070707u & ~m);
             }
         }
     }
-    *reinterpret_cast<uint4 *>(img + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// The kernel is issue-bound, not bandwidth-bound (1 KiB per wave pass): everything that is the same for the 64 lanes of a block
+// is SCALAR work.  The block's first read and its record are scalar loads; a block that lies wholly inside that read's span and
+// inside the reference (8 of 10 blocks: reads are kilobases long) takes the short path -- one dwordx4 of ref_wire per lane from a
+// scalar base, masked, into LDS.  Only blocks with a read boundary or a reference edge run the per-lane general form.  U blocks
+// per wave: the scalar loads of all of them are issued before the first is used.
+template <int U>
+__global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
+                                                     const int64_t *__restrict__ slot_off, const uint8_t *__restrict__ ref_wire,
+                                                     int32_t ref_pos0, int64_t ref_len, const uint32_t *__restrict__ blk_off,
+                                                     const int32_t *__restrict__ blk_read, const uint16_t *__restrict__ events,
+                                                     int64_t n_blocks, uint8_t *__restrict__ codes, int64_t codes_len)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t img_all[4 * U * WIRE_BLOCK];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t blk0 = ((int64_t)blockIdx.x * 4 + wv) * U;                    // wave-uniform
+    if (blk0 >= n_blocks) return;
+    uint8_t *img = img_all + wv * (U * WIRE_BLOCK);
+    const int nu = (int)(n_blocks - blk0 < U ? n_blocks - blk0 : U);
+    // ---- scalar: the blocks' first read, event range, and that read's record
+    int32_t r[U];
+    uint32_t e0[U], e1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t blk = u < nu ? blk0 + u : blk0;
+        r[u] = blk_read[blk];
+        e0[u] = blk_off[blk];
+        e1[u] = blk_off[blk + 1];
+    }
+    int64_t ri0[U];                                                  // short path: reference index of the block's first byte, else -1
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        ri0[u] = -1;
+        if (u < nu && r[u] < n_reads) {
+            const int64_t s = rd_start[r[u]], e = rd_end[r[u]], so = slot_off[r[u]];
+            const int64_t p0 = (s & ~(int64_t)15) + ((blk0 + u) * WIRE_BLOCK - so);
+            const int64_t ri = p0 - ref_pos0;
+            if (p0 >= s && p0 + WIRE_BLOCK <= e && ri >= 0 && ri + WIRE_BLOCK <= ref_len) ri0[u] = ri;
+        }
+    }
+    // ---- vector: the first 128 events of every block (a PAIR of events per lane: one dword load -- sub-dword global loads run
+    // at a fraction of the dword rate and were a third of this kernel), the predicted bytes
+    // pair k, k + 1 (k even) as lo | hi << 16, halves outside [e0, e1) set to 0xffff (never an event: bits 10, 11 are clear)
+    auto load_pair = [&](uint32_t k, uint32_t ea, uint32_t eb, bool last_block) -> uint32_t {
+        if (k >= eb) return 0xffffffffu;
+        uint32_t pr;
+#ifdef NC_ABL_EVSMALL
+        if (!last_block || k + 1 < eb) pr = *reinterpret_cast<const uint32_t *>(events + (k & 0xffffeu));
+#else
+        if (!last_block || k + 1 < eb) pr = *reinterpret_cast<const uint32_t *>(events + k);
+#endif
+        else pr = (uint32_t)events[k] | 0xffff0000u;                 // the array's last element: no read past its end
+        if (k < ea) pr |= 0x0000ffffu;
+        if (k + 1 >= eb) pr |= 0xffff0000u;
+        return pr;
+    };
+    uint32_t pr0[U];
+    uint4 rv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        pr0[u] = u < nu ? load_pair((e0[u] & ~1u) + 2 * lane, e0[u], e1[u], blk0 + u == n_blocks - 1) : 0xffffffffu;
+        if (ri0[u] >= 0) rv[u] = *reinterpret_cast<const uint4 *>(ref_wire + ri0[u] + lane * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (u >= nu) continue;
+        uint4 o;
+        if (ri0[u] >= 0) o = make_uint4(rv[u].x & 0x07070707u, rv[u].y & 0x07070707u, rv[u].z & 0x07070707u, rv[u].w & 0x07070707u);
+        else o = wire_group_general((blk0 + u) * WIRE_BLOCK + (int64_t)lane * 16, r[u], n_reads, rd_start, rd_end, slot_off, ref_wire, ref_pos0, ref_len);
+        *reinterpret_cast<uint4 *>(img + u * WIRE_BLOCK + lane * 16) = o;
+    }
     // LDS operations of one wave execute in program order: the byte stores below land on top of the 16-byte stores above
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (ev0 != 0xffffffffu) img[ev0 & 0x3ffu] = (uint8_t)(ev0 >> 12);
-    if (ev1 != 0xffffffffu) img[ev1 & 0x3ffu] = (uint8_t)(ev1 >> 12);
-    for (uint32_t k = e0 + 128 + lane; k < e1; k += 64) {
-        const uint32_t ev = events[k];
-        img[ev & 0x3ffu] = (uint8_t)(ev >> 12);
+    auto scatter = [&](uint8_t *im, uint32_t pr) {
+        const uint32_t a = pr & 0xffffu, b = pr >> 16;
+        if (a != 0xffffu) im[a & 0x3ffu] = (uint8_t)(a >> 12);
+        if (b != 0xffffu) im[b & 0x3ffu] = (uint8_t)(b >> 12);
+    };
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        uint8_t *im = img + u * WIRE_BLOCK;
+        scatter(im, pr0[u]);
+        if (u < nu)
+            for (uint32_t k = (e0[u] & ~1u) + 128 + 2 * lane; k < e1[u]; k += 128) scatter(im, load_pair(k, e0[u], e1[u], blk0 + u == n_blocks - 1));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (B + 16 <= codes_len) {
-        // streaming store: the expanded codes are read once by the scan, later, from HBM
-        const uint4 v = *reinterpret_cast<const uint4 *>(img + lane * 16);
-        __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(codes + B));
-        __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(codes + B) + 1);
-        __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(codes + B) + 2);
-        __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(codes + B) + 3);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t B = (blk0 + u) * WIRE_BLOCK + (int64_t)lane * 16;
+        if (u < nu && B + 16 <= codes_len) {
+            // streaming store: the expanded codes are read once by the scan, later, from HBM
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(img + u * WIRE_BLOCK + lane * 16);
+#ifdef NC_ABL_PLAINST
+            *reinterpret_cast<u32x4 *>(codes + B) = v;
+#else
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(codes + B));
+#endif
+        }
     }
 }
 
@@ -250,11 +331,15 @@ extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_
     if (!ctx) return NC_ERR_ARG;
     if (n_reads < 0 || !d_slot_off || (n_reads && (!d_rd_start || !d_rd_end)) || !d_ref_wire || (ref_pos0 & 15) || ref_len < 0 ||
         !d_blk_off || !d_blk_read || n_blocks < 1 || !d_codes || codes_len < 16 || (codes_len & 15) || n_blocks != (codes_len + WIRE_BLOCK - 1) / WIRE_BLOCK ||
-        (n_blocks + 3) / 4 > INT32_MAX || ((uintptr_t)d_codes & 15) || ((uintptr_t)d_ref_wire & 15) || (d_ref_code && ((uintptr_t)d_ref_code & 15)))
+        (n_blocks + 3) / 4 > INT32_MAX || ((uintptr_t)d_codes & 15) || ((uintptr_t)d_events & 3) || ((uintptr_t)d_ref_wire & 15) || (d_ref_code && ((uintptr_t)d_ref_code & 15)))
         return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand: bad argument");
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_wire_expand, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_rd_end, d_slot_off,
-                       d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len);
+    static const int U = [] { const char *e = getenv("NC_WIRE_U"); const int v = e ? atoi(e) : NC_WIRE_U; return (v == 1 || v == 2 || v == 8) ? v : 4; }();
+#define NC_LAUNCH_EXPAND(UU)                                                                                                                  \
+    hipLaunchKernelGGL(k_wire_expand<UU>, dim3((unsigned)((n_blocks + 4 * UU - 1) / (4 * UU))), dim3(256), 0, ctx->stream, n_reads, d_rd_start, \
+                       d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len)
+    if (U == 1) NC_LAUNCH_EXPAND(1); else if (U == 2) NC_LAUNCH_EXPAND(2); else if (U == 8) NC_LAUNCH_EXPAND(8); else NC_LAUNCH_EXPAND(4);
+#undef NC_LAUNCH_EXPAND
     if (d_ref_code && ref_len) {
         const int64_t groups = (ref_len + 15) / 16;
         hipLaunchKernelGGL(k_ref_from_wire, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_wire, d_ref_code, ref_len);

@@ -4,10 +4,13 @@
 set -e
 cd "$(dirname "$0")/../nanocaller_amd/csrc"
 make -s >/dev/null 2>&1 || make
+SRC=${SRC:-nc_cnn}          # which source the flags apply to (SRC=nc_wire tools/exp_build.sh ...)
+OBJS=""
+for o in nc_ctx nc_scan nc_featurize nc_cnn nc_indel nc_msa nc_wire; do [ $o = $SRC ] || OBJS="$OBJS $o.o"; done
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c nc_cnn.hip -o ../../build_exp/nc_cnn_$name.o 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_exp/libnc_$name.so nc_ctx.o nc_scan.o nc_featurize.o ../../build_exp/nc_cnn_$name.o nc_indel.o nc_msa.o nc_wire.o nc_bam.o nc_vcf.o nc_align.o -lz -lpthread -ldl
-  rm -f ../../build_exp/nc_cnn_$name.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c $SRC.hip -o ../../build_exp/${SRC}_$name.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_exp/libnc_$name.so $OBJS ../../build_exp/${SRC}_$name.o nc_bam.o nc_vcf.o nc_align.o -lz -lpthread -ldl
+  rm -f ../../build_exp/${SRC}_$name.o
   echo built $name
 done
