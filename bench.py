@@ -253,10 +253,9 @@ def extra_indel_config(eng, local):
 
     def run():
         # what indelCaller.indel_run does with the chunks of one contig: one featuriser call, one CNN call, rules per chunk
-        tuples = gip.get_indel_testing_candidates_batch(params, chunks, device=local)
-        xs = [np.hstack([t[1], t[2], t[3]]).astype(np.float32) for t in tuples if len(t[0])]
-        x_all = np.ascontiguousarray(np.concatenate(xs))
-        probs = eng.indel_forward(_lib.MODEL_INDEL, torch.from_numpy(x_all).to(eng.device)).cpu().numpy()
+        tuples = gip.get_indel_testing_candidates_batch(params, chunks, device=local, device_x=True)    # tensors stay in HBM
+        x_all = torch.cat([torch.cat([t[1], t[2], t[3]], dim=1) for t in tuples if len(t[0])]).contiguous()
+        probs = eng.indel_forward(_lib.MODEL_INDEL, x_all).cpu().numpy()
         n, lines, o = 0, 0, 0
         for c, t in zip(chunks, tuples):
             k = len(t[0])
@@ -283,7 +282,7 @@ def extra_indel_config(eng, local):
     for (p_, ln) in truth:
         lo_i, hi_i = np.searchsorted(apos, p_ - 60), np.searchsorted(apos, p_, side="right")
         exact += any(R is not None and len(A) - len(R) == ln for k in range(lo_i, hi_i) for (R, A) in aall[k])
-    x15 = torch.from_numpy(np.concatenate(xs)).to(eng.device)
+    x15 = torch.cat(xs)
     # K9 alone at a batch that fills the chip
     nb = 16384
     xb = x15[torch.arange(nb, device=x15.device) % n_sites].contiguous()
@@ -295,7 +294,7 @@ def extra_indel_config(eng, local):
     torch.cuda.synchronize()
     t_k9 = (time.perf_counter() - t0) / 3
     m = min(n_sites, 256)
-    ep = oracle.indel_forward(wgt.flat, np.concatenate(xs)[:m], precision="f64")
+    ep = oracle.indel_forward(wgt.flat, torch.cat(xs)[:m].cpu().numpy(), precision="f64")
     k9_err = float(np.abs(np.concatenate(ps)[:m] - ep).max())
     k9_tf = INDEL_FLOP_PER_SITE * nb / t_k9 / 1e12
     release_contig()

@@ -409,7 +409,7 @@ def decoded_contig(sam_path, chrom, fasta_path):
     return _CONTIGS[key]
 
 
-def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_after, max_range, device, haploid, by_index=False):
+def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_after, max_range, device, haploid, by_index=False, device_x=False):
     """Pass 2 (:306-361) for all anchors of a chunk: read sets assembled natively (nc_indel_pass2_sets) from the decoded contig,
     every set aligned in ONE device call (star alignment + rows -> tensor), allele strings by nc_allele_prediction_batch.
     -> diploid (pos, x0, x1, x2, alleles, phase) / haploid (pos, x, alleles).  by_index: `variants` / `extra_variants` are keyed
@@ -465,7 +465,7 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
         L.nc_pass2_free(h)
     pos = [int(anchors[k]) for k in kept]
     preds = allele_prediction_batch(cns_str, refs, [max_range[variants[int(k) if by_index else int(anchors[k])]] for k in kept for _ in range(S)])
-    xh = x.cpu().numpy().astype(np.float64).reshape(nk, S, 5, 128, 2)
+    xh = x.view(nk, S, 5, 128, 2) if device_x else x.cpu().numpy().astype(np.float64).reshape(nk, S, 5, 128, 2)
     tail = (kept.tolist(),) if by_index else ()
     if haploid:
         return (pos, xh[:, 0], preds) + tail
@@ -475,11 +475,12 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
     return (pos, xh[:, 0], xh[:, 1], xh[:, 2], alleles, phase) + tail
 
 
-def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False):
+def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False, device_x=False):
     """get_indel_testing_candidates[_haploid] for ALL chunks of one contig and BAM in one go -> list of the per-chunk tuples
     (each exactly what the per-chunk call returns): pass 1 of every chunk in the same launches (nc_indel_scan_batch), the
     anchors of all chunks through ONE native pass-2 call, ONE device star alignment and ONE allele batch.  What
-    indelCaller.indel_run uses; the device / native route only (no external aligner)."""
+    indelCaller.indel_run uses; the device / native route only (no external aligner).  device_x: the tensors of the tuples are
+    torch float32 tensors on the device (no download / float64 conversion / upload round trip on the way to the CNN)."""
     chunks = list(chunks)
     if not chunks:
         return []
@@ -512,7 +513,7 @@ def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False):
             if v in extras[ci]:
                 merged_extra[k] = extras[ci][v]
     res = _pass2_native(dct, merged_var, merged_extra, anchors, ctg, 1, len(ctg["fasta"]), window_after, max_range, device, haploid,
-                        by_index=True)
+                        by_index=True, device_x=device_x)
     pos, kept = res[0], res[-1]
     out = [[] for _ in chunks]
     for j, k in enumerate(kept):

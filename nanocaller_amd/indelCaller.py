@@ -138,15 +138,19 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
 
     def forward(ploidy, tuples):
         """the indel CNN for the sites of several chunks in one call -> per-chunk probability arrays"""
-        if ploidy == 'diploid':
-            xs = [np.hstack([t[1], t[2], t[3]]).astype(np.float32) for t in tuples if len(t[0])]      # :82 -> (n, 15, 128, 2)
-            kind = _lib.MODEL_INDEL
-        else:
-            xs = [np.ascontiguousarray(t[1], np.float32) for t in tuples if len(t[0])]
-            kind = _lib.MODEL_INDEL_HAP
-        if not xs:
+        kind = _lib.MODEL_INDEL if ploidy == 'diploid' else _lib.MODEL_INDEL_HAP
+        live = [t for t in tuples if len(t[0])]
+        if not live:
             return [None] * len(tuples)
-        probs = eng.indel_forward(kind, torch.from_numpy(np.ascontiguousarray(np.concatenate(xs))).to(eng.device)).cpu().numpy()
+        if torch.is_tensor(live[0][1]):
+            # the batched featuriser left the tensors on the device
+            xs = [torch.cat([t[1], t[2], t[3]], dim=1) if ploidy == 'diploid' else t[1] for t in live]          # :82 -> (n, 15, 128, 2)
+            x = torch.cat(xs).contiguous()
+        else:
+            xs = [np.hstack([t[1], t[2], t[3]]).astype(np.float32) if ploidy == 'diploid' else np.ascontiguousarray(t[1], np.float32)
+                  for t in live]
+            x = torch.from_numpy(np.ascontiguousarray(np.concatenate(xs))).to(eng.device)
+        probs = eng.indel_forward(kind, x).cpu().numpy()
         out, o = [], 0
         for t in tuples:
             out.append(probs[o:o + len(t[0])] if len(t[0]) else None)
@@ -203,7 +207,8 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
                 groups.setdefault((c['sam_path'], c['chrom'], c['ploidy']), []).append(k)
             results = [None] * len(jobs)
             for (sam, chrom, ploidy), ks in groups.items():
-                tuples = get_indel_testing_candidates_batch(params, [jobs[k][1] for k in ks], device=device, haploid=(ploidy == 'haploid'))
+                tuples = get_indel_testing_candidates_batch(params, [jobs[k][1] for k in ks], device=device, haploid=(ploidy == 'haploid'),
+                                                            device_x=True)
                 for k, t, pr in zip(ks, tuples, forward(ploidy, tuples)):
                     results[k] = (t, pr)
             for job, (t, pr) in zip(jobs, results):

@@ -255,3 +255,12 @@ def test_batched_featuriser_equals_per_chunk_calls(files, haploid):
                         assert np.array_equal(np.asarray(a), b)
                     else:
                         assert list(a) == list(b)
+        # device_x=True (what indel_run feeds the CNN): the same tuples with the tensors left in HBM as float32
+        dev = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=haploid, device_x=True)
+        for t, d in zip(got, dev):
+            assert list(t[0]) == list(d[0])
+            for a, b in zip(t[1:], d[1:]):
+                if isinstance(a, np.ndarray):
+                    assert b.is_cuda and np.array_equal(a.astype(np.float32), b.cpu().numpy())
+                else:
+                    assert list(a) == list(b)
