@@ -17,15 +17,15 @@ bamio.write_fasta(fa, w.chrom, w.ref)
 params = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
               exclude_bed=None, impute_indel_phase=False)
 chunks = [dict(chrom=w.chrom, start=s, end=min(Lw, s + 100_000), ploidy="diploid", sam_path=bam) for s in range(1, Lw, 100_000)]
-gip.get_indel_testing_candidates_batch(params, chunks)
+gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
 t = time.perf_counter()
-r = gip.get_indel_testing_candidates_batch(params, chunks)
+r = gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
 print("batch: %.1f ms for %d sites" % ((time.perf_counter() - t) * 1e3, sum(len(x[0]) for x in r)))
 pr = cProfile.Profile()
 pr.enable()
-gip.get_indel_testing_candidates_batch(params, chunks)
+gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
