@@ -61,10 +61,30 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (HiFi 60x haploid, exact fp32, indel pipeline)")
     ap.add_argument("--no-overlap", action="store_true", help="collect every step's results before the next step is enqueued")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=16)
+    ap.add_argument("--cpu-sample-chunks", type=int, default=0,
+                    help="chunks of contig 0 the CPU baseline runs (one thread each); 0 = one per CPU this process may use (SURVEY 8d: all host cores; the cgroup quota counts)")
     ap.add_argument("--cnn-precision", default="default", choices=["default", "fp32", "fp16x3"],
                     help="trunk kernel: exact fp32 MFMA (k4_conv12) or fp16x3 split precision (k5_trunk_h3)")
     return ap.parse_args()
+
+
+def usable_cpus():
+    """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota (a 256-thread box may grant a
+    container 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
@@ -87,7 +107,7 @@ def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
         cov = 30.0                                              # hap_train_coverage, snpCaller.py:73
     w = Weights(path)
     oracle.lib()
-    cores = min(len(sample), os.cpu_count() or 1)
+    cores = min(len(sample), usable_cpus())
 
     def one(c):
         pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
@@ -111,8 +131,8 @@ def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
         if pos_ok and len(pos):
             max_dp = max(max_dp, float(np.abs(gpu_result["probs"][sel] - probs).max()))
     return dict(value=n / dt, unit="sites/s", cores=cores, kind="port",
-                sample="%d chunks of 500 kb (%d sites, %.1f s): oracle/nc_oracle.c scan+tensors+CNN(f32), one thread per chunk"
-                % (len(sample), n, dt)), dict(positions_exact=pos_ok, max_abs_dprob=max_dp, sites_checked=n)
+                sample="%d chunks of 500 kb (%d sites, %.1f s): oracle/nc_oracle.c scan+tensors+CNN(f32), one thread per chunk; the process may use %d of the box's %d logical CPUs"
+                % (len(sample), n, dt, usable_cpus(), os.cpu_count() or 0)), dict(positions_exact=pos_ok, max_abs_dprob=max_dp, sites_checked=n)
 
 
 class Contig:
@@ -540,7 +560,8 @@ def main():
                        "cnn_ms": float(stage_ms[2]), "trunk_ms_per_contig": float(trunk_ms / max(1, n_units))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, parity = cpu_baseline(pack, c0.info, chunks, params, args.model, r0, args.cpu_sample_chunks)
+            n_cpu = args.cpu_sample_chunks or min(len(chunks), max(1, usable_cpus()))
+            cb, parity = cpu_baseline(pack, c0.info, chunks, params, args.model, r0, n_cpu)
             out["cpu_baseline"] = cb
             out["parity"] = parity
         if world == 1 and not args.no_extra:
