@@ -202,13 +202,19 @@ class Engine:
         # pinned host buffers (cached by torch's host allocator): the four copies run at PCIe speed, one sync
         hb, h = self._pinned.get((4, max(N, 1)), torch.int32)
         ptr = [C.c_void_p(hb[i].data_ptr()) for i in range(4)]
-        if async_fetch:
+        sites = SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=h[0, :N], chunk=h[1, :N], dp=h[2, :N], alt=h[3, :N])
+
+        def fetch():
             # copies go to the copy stream and overlap whatever is launched next; wait_copies() before reading them
             self._check(self.L.nc_snp_scan_fetch_async(self.ctx, self._copy_stream_ptr(), None, ptr[0], ptr[1], ptr[2], ptr[3]),
                         "nc_snp_scan_fetch_async")
+        if async_fetch == "deferred":
+            sites.start_fetch = fetch          # the caller enqueues the featuriser first: the GPU waits for nothing but that launch
+        elif async_fetch:
+            fetch()
         else:
             self._check(self.L.nc_snp_scan_fetch(self.ctx, None, ptr[0], ptr[1], ptr[2], ptr[3]), "nc_snp_scan_fetch")
-        return SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=h[0, :N], chunk=h[1, :N], dp=h[2, :N], alt=h[3, :N])
+        return sites
 
     def fetch_nbr_sites(self, n_nbr) -> np.ndarray:
         out = np.empty(n_nbr, np.int32)
@@ -219,12 +225,18 @@ class Engine:
     def snp_featurize(self, dp: DevicePack, sites: SnpSites, *, seq, maxcov, min_nbr_sites=1) -> SnpSites:
         N = sites.n_sites
         dev = self.device
-        sites.x = torch.empty((N, 5, 41, 5), dtype=torch.int16 if getattr(self, "x_int16", False) else torch.float32, device=dev)
-        sites.ref_code = torch.empty(N, dtype=torch.int32, device=dev)
-        sites.fwd_dp = torch.empty((N, 4), dtype=torch.int32, device=dev)
-        sites.rev_dp = torch.empty((N, 4), dtype=torch.int32, device=dev)
-        sites.depth = torch.empty(N, dtype=torch.int32, device=dev)
-        sites.valid = torch.empty(N, dtype=torch.uint8, device=dev)
+        # one allocation carved into the six outputs (this sits between the scan's totals and the featuriser's launch: the GPU idles)
+        i16 = getattr(self, "x_int16", False)
+        xb = N * 1025 * (2 if i16 else 4)
+        a16 = lambda v: (v + 15) & ~15     # noqa: E731
+        o_ref = a16(xb); o_fwd = a16(o_ref + 4 * N); o_rev = a16(o_fwd + 16 * N); o_dep = a16(o_rev + 16 * N); o_val = a16(o_dep + 4 * N)
+        buf = torch.empty(o_val + N + 16, dtype=torch.uint8, device=dev)
+        sites.x = buf[:xb].view(torch.int16 if i16 else torch.float32).view(N, 5, 41, 5)
+        sites.ref_code = buf[o_ref:o_ref + 4 * N].view(torch.int32)
+        sites.fwd_dp = buf[o_fwd:o_fwd + 16 * N].view(torch.int32).view(N, 4)
+        sites.rev_dp = buf[o_rev:o_rev + 16 * N].view(torch.int32).view(N, 4)
+        sites.depth = buf[o_dep:o_dep + 4 * N].view(torch.int32)
+        sites.valid = buf[o_val:o_val + N]
         pc = dp.c_struct()
         self._check(self.L.nc_snp_featurize(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(),
                                             _lib.SEQ_MODES[seq], int(maxcov), int(min_nbr_sites), _ptr(sites.x),
