@@ -128,3 +128,50 @@ def test_first_chunks_equal_the_oracle(setup):
         assert np.array_equal(r["fwd_dp"][sel], fwd) and np.array_equal(r["rev_dp"][sel], rev)
         probs, _ = oracle.snp_forward(w.flat, mat, np.argmax(ref, 1).astype(np.int32), np.full(len(pos), cov / depth), precision="f64")
         assert np.abs(r["probs"][sel] - probs).max() < 1e-4
+
+
+def test_hifi_60x_haploid_at_full_size():
+    """BASELINE.json configs[4]'s shape: a chr20-sized HiFi 60x contig (3.9 G pileup entries), `pacbio` neighbour buckets,
+    haploid model.  The wire form (0.04 B per entry: a HiFi read is 99.8 % reference) reproduces the pack byte for byte, the
+    uploaded and the resident route agree bit for bit, and the first chunks equal the oracle."""
+    import torch
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import host_sample_for_oracle, make_device_workload, wire_from_device_workload
+    from nanocaller_amd.utils import get_chunks
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from nanocaller_amd.wire import WireUploader
+    from oracle import oracle
+    eng = get_engine(0)
+    pack, info = make_device_workload(eng, L, depth=60.0, tech="hifi", seed=913)
+    try:
+        wire = wire_from_device_workload(pack, info)
+        assert wire.nbytes < 0.06 * info["pileup_entries"]
+        chunks = get_chunks([("chr20", 1, L, "haploid")], cpu=16)
+        params = dict(mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6], snp_model="CCS-HG002", seq="pacbio",
+                      supplementary=False, exclude_bed=None, disable_coverage_normalization=False, sam_path=None)
+        up = WireUploader(eng)
+        t = up.submit(wire)
+        dpk = up.expand(t)
+        torch.cuda.synchronize()
+        assert torch.equal(dpk.codes, pack.codes) and torch.equal(dpk.ref_code, pack.ref_code)
+        a = snpCaller.call_chunks(params, chunks, dpk=dpk)
+        up.release(t)
+        b = snpCaller.call_chunks(params, chunks, dpk=pack)
+        assert a["n"] == b["n"] > 100_000
+        for k in ("pos", "chunk", "ref", "dp", "alt", "fwd_dp", "rev_dp", "probs", "freq"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.all((b["probs"] >= 0) & (b["probs"] <= 1))
+        sub = chunks[:2]
+        h = host_sample_for_oracle(pack, info, 1, sub[-1]["end"] + 50_000)
+        rr = oracle.RawReads("chr20", h["L"], h["start"], h["end"], h["off"], h["codes"], h["strand"], h["keep"])
+        w = Weights(get_SNP_model("haploid")[0])
+        for ci, c in enumerate(sub):
+            pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
+            sel = b["chunk"] == ci
+            assert np.array_equal(b["pos"][sel], pos) and np.array_equal(b["dp"][sel], dp)
+            probs = oracle.snp_hap_forward(w.flat, mat, np.argmax(ref, 1).astype(np.int32), np.full(len(pos), 30.0 / depth), precision="f64")
+            assert np.abs(b["probs"][sel] - probs).max() < 1e-4
+    finally:
+        del pack
+        torch.cuda.empty_cache()
