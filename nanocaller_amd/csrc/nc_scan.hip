@@ -6,6 +6,8 @@
 // dwordx4 (position-aligned slots, see nanocaller_hip.h).  Codes are counted four positions at a time with
 // v_perm_b32 used as an 8-entry byte LUT (code -> 0/1 per byte lane) into byte-lane accumulators that are
 // widened every 255 reads.  Algorithmic traffic: one byte per pileup entry + one reference byte per column.
+#include <algorithm>
+
 #include "nc_common.h"
 
 namespace {
@@ -181,13 +183,17 @@ __global__ __launch_bounds__(256) void k_compact(int tile, const int2 *__restric
                                                  const int32_t *__restrict__ stage_nbr, const int32_t *__restrict__ stage_cpos,
                                                  const int32_t *__restrict__ stage_cn, const int32_t *__restrict__ stage_calt,
                                                  int32_t *__restrict__ nbr_pos, int32_t *__restrict__ cand_pos,
-                                                 int32_t *__restrict__ cand_n, int32_t *__restrict__ cand_alt)
+                                                 int32_t *__restrict__ cand_n, int32_t *__restrict__ cand_alt, int cap_nbr, int cap_cand)
 {
+    // cap_*: capacity of the outputs in elements.  The host launches this kernel BEFORE it knows the totals (the buffers of the
+    // previous scan, a quarter larger than its totals, are reused) and repeats it with larger ones in the rare case they overflow.
     const int t = blockIdx.x;
     const int2 c = cnt[t], p = pre[t];
     const int64_t sb = (int64_t)t * tile;
-    for (int i = threadIdx.x; i < c.x; i += 256) nbr_pos[p.x + i] = stage_nbr[sb + i];
+    for (int i = threadIdx.x; i < c.x; i += 256)
+        if (p.x + i < cap_nbr) nbr_pos[p.x + i] = stage_nbr[sb + i];
     for (int i = threadIdx.x; i < c.y; i += 256) {
+        if (p.y + i >= cap_cand) continue;
         cand_pos[p.y + i] = stage_cpos[sb + i];
         cand_n[p.y + i] = stage_cn[sb + i];
         cand_alt[p.y + i] = stage_calt[sb + i];
@@ -205,20 +211,19 @@ __device__ __forceinline__ int lower_bound_dev(const int32_t *a, int n, int32_t 
 }
 
 // candidates of chunk c = cand positions in [start, end] (both inclusive, generate_SNP_pileups.py:183)
-__global__ void k_chunk_ranges(const int32_t *__restrict__ cand_pos, const int32_t *__restrict__ totals, int n_chunks,
-                               const int32_t *__restrict__ cs, const int32_t *__restrict__ ce,
-                               int32_t *__restrict__ chunk_lo, int32_t *__restrict__ chunk_cnt)
+// candidates of chunk c: [lo, lo + cnt) of the position-sorted candidate list (both chunk ends inclusive)
+__device__ __forceinline__ int chunk_range(const int32_t *__restrict__ cand_pos, int n, int32_t cs, int32_t ce, int32_t *lo_out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    const int n = totals[1];
-    const int lo = lower_bound_dev(cand_pos, n, cs[c]);
-    const int hi = ce[c] == INT32_MAX ? n : lower_bound_dev(cand_pos, n, ce[c] + 1);
-    chunk_lo[c] = lo;
-    chunk_cnt[c] = hi > lo ? hi - lo : 0;
+    const int lo = lower_bound_dev(cand_pos, n, cs);
+    const int hi = ce == INT32_MAX ? n : lower_bound_dev(cand_pos, n, ce + 1);
+    *lo_out = lo;
+    return hi > lo ? hi - lo : 0;
 }
 
-__global__ __launch_bounds__(1024) void k_chunk_prefix(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int n,
+// ranges of every chunk + their exclusive prefix in ONE single-workgroup kernel (the chunk list is a few hundred entries)
+__global__ __launch_bounds__(1024) void k_chunk_prefix(const int32_t *__restrict__ cand_pos, int cap_cand, const int32_t *__restrict__ cs,
+                                                       const int32_t *__restrict__ ce, int32_t *__restrict__ chunk_lo,
+                                                       int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ off, int n,
                                                        int32_t *__restrict__ totals)
 {
     __shared__ int wsum[16];
@@ -226,9 +231,16 @@ __global__ __launch_bounds__(1024) void k_chunk_prefix(const int32_t *__restrict
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n_cand = totals[1] < cap_cand ? totals[1] : cap_cand;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
-        const int v = i < n ? cnt[i] : 0;
+        int v = 0;
+        if (i < n) {
+            int32_t lo;
+            v = chunk_range(cand_pos, n_cand, cs[i], ce[i], &lo);
+            chunk_lo[i] = lo;
+            chunk_cnt[i] = v;
+        }
         int inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -374,27 +386,46 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
                        (int32_t *)ctx->totals.p);
     NC_HIP(ctx, hipGetLastError());
     volatile int32_t *tot = ctx->mbox;                           // pinned mailbox: the totals arrive through a copy kernel
-    NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
-    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto compact_and_ranges = [&](int cap_nbr, int cap_cand) -> int {
+        hipLaunchKernelGGL(k_compact, dim3(pack->n_tiles), dim3(256), 0, ctx->stream, tile, tc, (const int2 *)ctx->tile_pre.p, sn,
+                           sc, scn, sca, (int32_t *)ctx->nbr_pos.p, (int32_t *)ctx->cand_pos.p, (int32_t *)ctx->cand_n.p,
+                           (int32_t *)ctx->cand_alt.p, cap_nbr, cap_cand);
+        NC_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->cand_pos.p, cap_cand,
+                           (const int32_t *)ctx->chunk_start.p, (const int32_t *)ctx->chunk_end.p, (int32_t *)ctx->chunk_lo.p,
+                           (int32_t *)ctx->chunk_cnt.p, (int32_t *)ctx->chunk_off.p, n_chunks, (int32_t *)ctx->totals.p);
+        NC_HIP(ctx, hipGetLastError());
+        NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return NC_OK;
+    };
+    auto cap_of = [](const DevBuf &b) { return (int)std::min<size_t>(b.cap / 4, (size_t)INT32_MAX); };
+    int cap_nbr = cap_of(ctx->nbr_pos), cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
+    bool known = false;
+    if (cap_nbr == 0 || cap_cand == 0) {
+        // first scan of this context: one round trip for the totals that size the outputs
+        NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        known = true;
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (known) {
+            NC_TRY(nc_ensure(ctx, ctx->nbr_pos, (size_t)(tot[0] + 1) * 4));
+            NC_TRY(nc_ensure(ctx, ctx->cand_pos, (size_t)(tot[1] + 1) * 4));
+            NC_TRY(nc_ensure(ctx, ctx->cand_n, (size_t)(tot[1] + 1) * 4));
+            NC_TRY(nc_ensure(ctx, ctx->cand_alt, (size_t)(tot[1] + 1) * 4));
+            cap_nbr = cap_of(ctx->nbr_pos);
+            cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
+        }
+        // otherwise: the outputs of the previous scan (a quarter larger than its totals) are reused without asking first --
+        // ONE host round trip per scan; the kernels never write past the capacities
+        NC_TRY(compact_and_ranges(cap_nbr, cap_cand));
+        if (tot[0] <= cap_nbr && tot[1] <= cap_cand) break;
+        if (attempt == 1) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan: outputs still too small after regrowth");
+        known = true;                                                // they did not fit: grow and repeat (rare)
+    }
     ctx->n_nbr = tot[0];
     ctx->n_cand = tot[1];
-    NC_TRY(nc_ensure(ctx, ctx->nbr_pos, (size_t)(tot[0] + 1) * 4));
-    NC_TRY(nc_ensure(ctx, ctx->cand_pos, (size_t)(tot[1] + 1) * 4));
-    NC_TRY(nc_ensure(ctx, ctx->cand_n, (size_t)(tot[1] + 1) * 4));
-    NC_TRY(nc_ensure(ctx, ctx->cand_alt, (size_t)(tot[1] + 1) * 4));
-    hipLaunchKernelGGL(k_compact, dim3(pack->n_tiles), dim3(256), 0, ctx->stream, tile, tc, (const int2 *)ctx->tile_pre.p, sn,
-                       sc, scn, sca, (int32_t *)ctx->nbr_pos.p, (int32_t *)ctx->cand_pos.p, (int32_t *)ctx->cand_n.p,
-                       (int32_t *)ctx->cand_alt.p);
-    NC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_chunk_ranges, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, (const int32_t *)ctx->cand_pos.p,
-                       (const int32_t *)ctx->totals.p, n_chunks, (const int32_t *)ctx->chunk_start.p,
-                       (const int32_t *)ctx->chunk_end.p, (int32_t *)ctx->chunk_lo.p, (int32_t *)ctx->chunk_cnt.p);
-    NC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->chunk_cnt.p,
-                       (int32_t *)ctx->chunk_off.p, n_chunks, (int32_t *)ctx->totals.p);
-    NC_HIP(ctx, hipGetLastError());
-    NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
-    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_sites = tot[2];
     ctx->n_chunks = n_chunks;
     const size_t ns = (size_t)tot[2] + 1;

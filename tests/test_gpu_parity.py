@@ -48,6 +48,24 @@ def test_scan_matches_oracle_all_tile_sizes(eng, tile_size):
     assert np.array_equal(sites.pos, cpos) and np.array_equal(sites.dp, cn) and np.array_equal(sites.alt, calt)
 
 
+def test_scan_outputs_regrow_when_a_scan_finds_more_than_the_last(eng):
+    """nc_snp_scan sizes its outputs from the PREVIOUS scan of the context (one host round trip per scan instead of two) and
+    repeats the compaction with larger buffers when they overflow: a fresh context scans a tiny range first, then the whole
+    world, then the tiny range again -- each equal to the oracle."""
+    from nanocaller_amd.engine import Engine
+    from nanocaller_amd.pack import pack_world
+    from oracle import oracle
+    world = load_world("ont")
+    e2 = Engine(0)                                            # its own context: no buffers from earlier scans
+    dpk = e2.upload(pack_world(world))
+    rc = oracle.ref_codes_with_exclusions(world)
+    for start, end in ((60_000, 60_400), (5_000, 125_000), (60_000, 60_400), (5_000, 125_000)):
+        sites = e2.snp_scan(dpk, [(start, end)], mincov=4, min_allele_freq=0.15, threshold=[0.4, 0.6])
+        nbr, cpos, cn, calt = oracle.snp_scan(world, rc, start, end, "diploid", 4, 0.15, [0.4, 0.6])
+        assert np.array_equal(e2.fetch_nbr_sites(sites.n_nbr), nbr)
+        assert np.array_equal(sites.pos, cpos) and np.array_equal(sites.dp, cn) and np.array_equal(sites.alt, calt)
+
+
 def test_multi_chunk_batch_matches_per_chunk_oracle(eng):
     """A batch of adjacent chunks in one launch == the oracle run chunk by chunk, including the duplicated
     boundary position (quirk E3) and the per-chunk coverage constant (quirk E2)."""
