@@ -248,11 +248,7 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
     auto load_pair = [&](uint32_t k, uint32_t ea, uint32_t eb, bool last_block) -> uint32_t {
         if (k >= eb) return 0xffffffffu;
         uint32_t pr;
-#ifdef NC_ABL_EVSMALL
-        if (!last_block || k + 1 < eb) pr = *reinterpret_cast<const uint32_t *>(events + (k & 0xffffeu));
-#else
         if (!last_block || k + 1 < eb) pr = *reinterpret_cast<const uint32_t *>(events + k);
-#endif
         else pr = (uint32_t)events[k] | 0xffff0000u;                 // the array's last element: no read past its end
         if (k < ea) pr |= 0x0000ffffu;
         if (k + 1 >= eb) pr |= 0xffff0000u;
@@ -296,11 +292,7 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         if (u < nu && B + 16 <= codes_len) {
             // streaming store: the expanded codes are read once by the scan, later, from HBM
             const u32x4 v = *reinterpret_cast<const u32x4 *>(img + u * WIRE_BLOCK + lane * 16);
-#ifdef NC_ABL_PLAINST
-            *reinterpret_cast<u32x4 *>(codes + B) = v;
-#else
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(codes + B));
-#endif
         }
     }
 }
