@@ -1,6 +1,7 @@
 // Host-side global alignment + the reference's allele extraction.
 // Restates parasail.nw_trace(...).cigar as used by generate_indel_pileups.py:77-127 (parasail itself is a third-party
 // dependency that is absent from this image: tie-breaking documented in include/nanocaller_hip.h, parity unpinned).
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -17,42 +18,58 @@ enum : uint8_t { H_DIAG = 0, H_DEL = 1, H_INS = 2, E_EXT = 4, F_EXT = 8 };   // 
 void nw_cigar(const char *s1, int n1, const char *s2, int n2, int open, int extend, int match, int mismatch,
               std::vector<int32_t> &ops, std::vector<int32_t> &cnts, bool free_tail = false)
 {
+    // Only the traceback codes are kept for every cell (1 byte each); H and F live in two rolling rows and E in a scalar: a
+    // 160 x 161 alignment touches ~30 KB instead of 340 KB.  Buffers are per thread and reused between calls.
     const int W = n2 + 1;
-    std::vector<int32_t> H((size_t)(n1 + 1) * W), E((size_t)(n1 + 1) * W, NEG), F((size_t)(n1 + 1) * W, NEG);
-    std::vector<uint8_t> T((size_t)(n1 + 1) * W, 0);
-    H[0] = 0;
-    for (int j = 1; j <= n2; j++) { H[j] = -open - (j - 1) * extend; E[j] = H[j]; T[j] = (uint8_t)(H_DEL | (j > 1 ? E_EXT : 0)); }
+    thread_local std::vector<int32_t> Hrow[2], Frow[2], lastcol;
+    thread_local std::vector<uint8_t> T;
+    for (int k = 0; k < 2; k++) { if ((int)Hrow[k].size() < W) { Hrow[k].resize(W); Frow[k].resize(W); } }
+    if (T.size() < (size_t)(n1 + 1) * W) T.resize((size_t)(n1 + 1) * W);
+    if ((int)lastcol.size() < n1 + 1) lastcol.resize(n1 + 1);
+    int32_t *Hp = Hrow[0].data(), *Hc = Hrow[1].data(), *Fp = Frow[0].data(), *Fc = Frow[1].data();
+    Hp[0] = 0;
+    Fp[0] = NEG;
+    T[0] = 0;
+    for (int j = 1; j <= n2; j++) { Hp[j] = -open - (j - 1) * extend; Fp[j] = NEG; T[j] = (uint8_t)(H_DEL | (j > 1 ? E_EXT : 0)); }
+    lastcol[0] = Hp[n2];
     for (int i = 1; i <= n1; i++) {
-        H[(size_t)i * W] = -open - (i - 1) * extend;
-        F[(size_t)i * W] = H[(size_t)i * W];
-        T[(size_t)i * W] = (uint8_t)(H_INS | (i > 1 ? F_EXT : 0));
+        uint8_t *Ti = T.data() + (size_t)i * W;
+        Hc[0] = -open - (i - 1) * extend;
+        Fc[0] = Hc[0];
+        Ti[0] = (uint8_t)(H_INS | (i > 1 ? F_EXT : 0));
+        int32_t e_left = NEG;                                       // E[i][0]
+        const char a = s1[i - 1];
         for (int j = 1; j <= n2; j++) {
-            const size_t c = (size_t)i * W + j, up = c - W, left = c - 1, dg = c - W - 1;
             uint8_t t = 0;
-            const int32_t e_open = H[left] - open, e_ext = E[left] - extend;
+            const int32_t e_open = Hc[j - 1] - open, e_ext = e_left - extend;
             int32_t e = e_open;
             if (e_ext >= e_open) { e = e_ext; t |= E_EXT; }
-            const int32_t f_open = H[up] - open, f_ext = F[up] - extend;
+            const int32_t f_open = Hp[j] - open, f_ext = Fp[j] - extend;
             int32_t f = f_open;
             if (f_ext >= f_open) { f = f_ext; t |= F_EXT; }
-            const int32_t d = H[dg] + (s1[i - 1] == s2[j - 1] ? match : mismatch);
+            const int32_t d = Hp[j - 1] + (a == s2[j - 1] ? match : mismatch);
             int32_t h = d;
             uint8_t w = H_DIAG;
             if (e > h) { h = e; w = H_DEL; }
             if (f > h) { h = f; w = H_INS; }
-            H[c] = h; E[c] = e; F[c] = f;
-            T[c] = (uint8_t)(t | w);
+            Hc[j] = h; e_left = e; Fc[j] = f;
+            Ti[j] = (uint8_t)(t | w);
         }
+        lastcol[i] = Hc[n2];
+        std::swap(Hp, Hc);
+        std::swap(Fp, Fc);
     }
+    // Hp now holds the last row (row n1; row 0 when n1 == 0)
     // traceback
     std::vector<int32_t> rops;
+    rops.reserve((size_t)n1 + n2 + 2);
     int i = n1, j = n2;
     if (free_tail && n1 > 0 && n2 > 0) {
-        int32_t best = H[(size_t)n1 * W + n2];
+        int32_t best = Hp[n2];
         for (int jj = n2 - 1; jj >= 0; jj--)                       // last row: the rest of s2 is unaligned
-            if (H[(size_t)n1 * W + jj] > best) { best = H[(size_t)n1 * W + jj]; i = n1; j = jj; }
+            if (Hp[jj] > best) { best = Hp[jj]; i = n1; j = jj; }
         for (int ii = n1 - 1; ii >= 0; ii--)                       // last column: the rest of s1 is unaligned
-            if (H[(size_t)ii * W + n2] > best) { best = H[(size_t)ii * W + n2]; i = ii; j = n2; }
+            if (lastcol[ii] > best) { best = lastcol[ii]; i = ii; j = n2; }
         for (int t = n2; t > j; t--) rops.push_back(2);
         for (int t = n1; t > i; t--) rops.push_back(1);
     }
