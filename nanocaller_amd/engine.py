@@ -6,6 +6,7 @@ runs, torch.distributed rendezvous.  All arithmetic of the hot path runs in the 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 
@@ -202,19 +203,14 @@ class Engine:
         # pinned host buffers (cached by torch's host allocator): the four copies run at PCIe speed, one sync
         hb, h = self._pinned.get((4, max(N, 1)), torch.int32)
         ptr = [C.c_void_p(hb[i].data_ptr()) for i in range(4)]
-        sites = SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=h[0, :N], chunk=h[1, :N], dp=h[2, :N], alt=h[3, :N])
-
-        def fetch():
-            # copies go to the copy stream and overlap whatever is launched next; wait_copies() before reading them
+        if async_fetch:
+            # copies go to the copy stream NOW: they run in the host's turn-around before the featuriser is launched (issued behind
+            # that launch they collide with the featuriser and spill into the kernels after it: measured, worse)
             self._check(self.L.nc_snp_scan_fetch_async(self.ctx, self._copy_stream_ptr(), None, ptr[0], ptr[1], ptr[2], ptr[3]),
                         "nc_snp_scan_fetch_async")
-        if async_fetch == "deferred":
-            sites.start_fetch = fetch          # the caller enqueues the featuriser first: the GPU waits for nothing but that launch
-        elif async_fetch:
-            fetch()
         else:
             self._check(self.L.nc_snp_scan_fetch(self.ctx, None, ptr[0], ptr[1], ptr[2], ptr[3]), "nc_snp_scan_fetch")
-        return sites
+        return SnpSites(n_sites=N, n_nbr=n_nbr.value, pos=h[0, :N], chunk=h[1, :N], dp=h[2, :N], alt=h[3, :N])
 
     def fetch_nbr_sites(self, n_nbr) -> np.ndarray:
         out = np.empty(n_nbr, np.int32)

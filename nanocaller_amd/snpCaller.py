@@ -219,17 +219,15 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     # featuriser's per-site arrays during the CNN, and every CNN batch's probabilities while the next batch runs.
     sites = eng.snp_scan(dpk, [(c['start'], c['end']) for c in chunks], mincov=params['mincov'],
                          min_allele_freq=params['min_allele_freq'], threshold=params['threshold'],
-                         haploid=(ploidy == 'haploid'), async_fetch="deferred")
+                         haploid=(ploidy == 'haploid'), async_fetch=True)
     res = dict(chrom=chrom, ploidy=ploidy, n=0)
     if sites.n_sites == 0:
-        sites.start_fetch()
         eng.wait_copies()
         return PendingCall(lambda: res) if defer else res
     # the tensors stay on the device: int16 between featuriser and CNN (exact, half the HBM traffic) unless the exact-fp32
     # trunk, which reads the reference's float32 layout, has been selected
     eng.set_tensor_format(int16=not getattr(eng, "exact_fp32", False))
     eng.snp_featurize(dpk, sites, seq=params['seq'], maxcov=params['maxcov'], min_nbr_sites=params['min_nbr_sites'])
-    sites.start_fetch()                                            # the candidate arrays' copies: behind the featuriser's launch
     all_valid = bool(sites.valid.all().item()) if params['min_nbr_sites'] > 1 else True   # default 1 never filters (:244)
     per_site = bool(params.get('disable_coverage_normalization'))
     scale, chunk_depth = eng.snp_scale(sites, len(chunks), train_cov, per_site=per_site, async_fetch=True)
