@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 5   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+#define NC_ABI_VERSION 6   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
-                              5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets */
+                              5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
+                              6: nc_allele_prediction_device */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -425,6 +426,11 @@ int nc_allele_prediction(const char *alt, int32_t n_alt, const char *ref_seq, in
 /* the same for n independent (alt, ref) pairs, on the usable host cores: alt i = alts[alt_off[i] .. alt_off[i+1]), ref i likewise */
 int nc_allele_prediction_batch(int32_t n, const char *alts, const int32_t *alt_off, const char *refs, const int32_t *ref_off,
                                const int32_t *max_range, int32_t *ref_len, int32_t *alt_len);
+/* The same on the device (the 16-lane register aligner of nc_star_msa_tensor with parasail's scoring, one lane per alignment for
+ * the traceback and the allele extraction): identical results.  Host arrays in and out.  NC_ERR_CAPACITY when a reference window
+ * is longer than 272 bases, a consensus longer than 1000, or a string empty: use nc_allele_prediction_batch then. */
+int nc_allele_prediction_device(nc_ctx *ctx, int32_t n, const char *alts, const int32_t *alt_off, const char *refs, const int32_t *ref_off,
+                                const int32_t *max_range, int32_t *ref_len, int32_t *alt_len);
 
 /* Star alignment of a read set to its reference window: replaces the MUSCLE subprocess of
  * generate_indel_pileups.py:24-44 with pairwise Gotoh alignments (anchored at the window start, free tail; scoring as above)

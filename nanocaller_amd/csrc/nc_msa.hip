@@ -309,6 +309,100 @@ __global__ __launch_bounds__(64) void k_nw_trace16(NwArgs p, TraceOut o, int32_t
     }
 }
 
+// allele_prediction (generate_indel_pileups.py:77-127) on the device: GLOBAL alignment of a consensus (s1) against its reference
+// window (s2) filled by k_nw_fill16 with parasail's scoring, then one lane per alignment: traceback from (n1, n2) into runs of
+// CIGAR operations (7 '=', 8 'X', 1 'I' consumes the consensus, 2 'D' consumes the reference), and the reference's allele
+// extraction over the runs in alignment order -- nc_allele_prediction (nc_align.cpp) statement by statement.
+__global__ __launch_bounds__(64) void k_allele_trace16(NwArgs p, int32_t N1, int32_t CPL, const uint32_t *__restrict__ Tw,
+                                                       const int32_t *__restrict__ max_range, int16_t *__restrict__ runs, int32_t run_cap,
+                                                       int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    if (al >= p.A) return;
+    const int a = p.a0 + al;
+    const uint8_t *s1 = p.reads + p.read_off[a];
+    const int n1 = p.read_off[a + 1] - p.read_off[a];
+    const int set = p.read_set[a];
+    const uint8_t *s2 = p.refs + p.ref_off[set];
+    const int n2 = p.ref_off[set + 1] - p.ref_off[set];
+    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    const int64_t arow = (int64_t)al * (N1 + 1);
+    int16_t *rop = runs + (int64_t)al * run_cap * 2, *rcn = rop + run_cap;          // runs in REVERSE alignment order
+    int nr = 0, last_op = -1;
+    auto push = [&](int op) {
+        if (op == last_op) rcn[nr - 1]++;
+        else if (nr < run_cap) { rop[nr] = (int16_t)op; rcn[nr] = 1; nr++; last_op = op; }
+    };
+    int i = n1, j = n2, state = -1;
+    while (i > 0 || j > 0) {
+        uint32_t t;
+        if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
+        else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
+        else {
+            const int q = (j - 1) / CPL, c = (j - 1) % CPL;
+            t = (Tw[((arow + i) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
+        }
+        if (state < 0) {
+            const int w = t & 3;
+            if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; continue; }
+            state = w == T_DEL ? 1 : 2;
+        }
+        if (state == 1) {
+            push(2);
+            const bool ext = (t & T_EEXT) != 0;
+            j--;
+            if (!ext) state = -1;
+        } else {
+            push(1);
+            const bool ext = (t & T_FEXT) != 0;
+            i--;
+            if (!ext) state = -1;
+        }
+    }
+    // the reference's loop over the CIGAR (ref_cnt / alt_cnt indexed by op: only 1, 2, 7, 8 occur)
+    bool indel = false, mm_before = false;
+    int32_t rc7 = 0, rc8 = 0, rc2 = 0, ac7 = 0, ac8 = 0, ac1 = 0, mm_after = 0;
+    const int32_t mr = max_range[a];
+    auto clampi = [](int32_t v, int32_t n) { return v < 0 ? (v + n < 0 ? 0 : v + n) : (v > n ? n : v); };       // Python slice s[:v]
+    int op = 0, cnt = 0;
+    bool done = false;
+    int32_t out_r = 0, out_a = 0;
+    for (int k = nr - 1; k >= 0 && !done; k--) {
+        op = rop[k];
+        cnt = rcn[k];
+        if (op == 8 || op == 7) {
+            if (op == 7) { rc7 += cnt; ac7 += cnt; } else { rc8 += cnt; ac8 += cnt; }
+            if (indel) mm_after += cnt;
+            else mm_before = true;
+        }
+        if (op == 1) { ac1 += cnt; mm_after = 0; indel = true; }
+        if (op == 2) { rc2 += cnt; mm_after = 0; indel = true; }
+        const int32_t rsum = rc7 + rc8 + rc2;
+        if (!indel && rsum >= mr + 10) {
+            if (rc8) {
+                const int32_t ol = op == 8 ? rsum : rsum - cnt;
+                out_r = clampi(ol, n2);
+                out_a = clampi(ol, n1);
+            } else {
+                out_r = -1;
+                out_a = -1;
+            }
+            done = true;
+            break;
+        }
+        if (indel && mm_after > 20) break;
+    }
+    if (!done) {
+        const int32_t rsum = rc7 + rc8 + rc2, asum = ac7 + ac8 + ac1;
+        int32_t ro = op == 8 ? rsum : rsum - cnt, ao = op == 8 ? asum : asum - cnt;
+        if (!mm_before) { ro += 1; ao += 1; }
+        out_r = clampi(ro, n2);
+        out_a = clampi(ao, n1);
+    }
+    ref_len[a] = out_r;
+    alt_len[a] = out_a;
+}
+
 // per set: columns.  set_read0[s] .. set_read0[s+1]: the set's alignments (indices local to the launch)
 __global__ __launch_bounds__(256) void k_set_columns(int32_t W, const int32_t *__restrict__ set_read0, const int32_t *__restrict__ ref_off,
                                                      int32_t set0, const int16_t *__restrict__ ins_len, int32_t *__restrict__ col /* [sets][W] */,
@@ -507,5 +601,69 @@ extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads
         s0 = s1;
     }
     for (int32_t s = 0; s < n_sets; s++) n_cols_host[s] = n_cols[(size_t)s];
+    return NC_OK;
+}
+
+// nc_allele_prediction_batch on the device (same results: the fill kernel's recurrences and tie rules are nc_nw_cigar's).
+// Host arrays in and out.  NC_ERR_CAPACITY when a window is longer than the register kernel covers (272 reference bases, 1000
+// consensus bases) or a string is empty: the caller then uses the host version.
+extern "C" int nc_allele_prediction_device(nc_ctx *ctx, int32_t n, const char *alts, const int32_t *alt_off, const char *refs,
+                                           const int32_t *ref_off, const int32_t *max_range, int32_t *ref_len, int32_t *alt_len)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n < 0 || (n && (!alts || !alt_off || !refs || !ref_off || !max_range || !ref_len || !alt_len))) return nc_fail(ctx, NC_ERR_ARG, "nc_allele_prediction_device: bad argument");
+    if (n == 0) return NC_OK;
+    int32_t N1 = 0, N2 = 0;
+    for (int32_t a = 0; a < n; a++) {
+        const int32_t l1 = alt_off[a + 1] - alt_off[a], l2 = ref_off[a + 1] - ref_off[a];
+        if (l1 <= 0 || l2 <= 0) return NC_ERR_CAPACITY;
+        N1 = std::max(N1, l1);
+        N2 = std::max(N2, l2);
+    }
+    const int CPL = N2 <= 64 ? 4 : N2 <= 128 ? 8 : N2 <= 176 ? 11 : N2 <= 272 ? 17 : 0;
+    if (CPL == 0 || N1 > 1000) return NC_ERR_CAPACITY;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t W = N2 + 1;
+    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    std::vector<int32_t> ident((size_t)n);
+    for (int32_t a = 0; a < n; a++) ident[(size_t)a] = a;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        NC_TRY(nc_ensure(ctx, b, bytes + 16));
+        if (bytes) NC_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return NC_OK;
+    };
+    NC_TRY(up(ctx->msa_reads, alts, (size_t)alt_off[n]));
+    NC_TRY(up(ctx->msa_read_off, alt_off, ((size_t)n + 1) * 4));
+    NC_TRY(up(ctx->msa_read_set, ident.data(), (size_t)n * 4));
+    NC_TRY(up(ctx->msa_refs, refs, (size_t)ref_off[n]));
+    NC_TRY(up(ctx->msa_ref_off, ref_off, ((size_t)n + 1) * 4));
+    const int32_t run_cap = N1 + N2 + 2;
+    // outputs + max_range + runs share msa_out / msa_trace
+    NC_TRY(nc_ensure(ctx, ctx->msa_out, (size_t)n * 12 + 64));
+    int32_t *d_mr = (int32_t *)ctx->msa_out.p, *d_rl = d_mr + n, *d_al = d_rl + n;
+    NC_HIP(ctx, hipMemcpyAsync(d_mr, max_range, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    NC_TRY(nc_ensure(ctx, ctx->msa_trace, (size_t)n * run_cap * 4 + 64));
+    NC_TRY(nc_ensure(ctx, ctx->msa_rows_hf, (size_t)n * W * 4));
+    NC_TRY(nc_ensure(ctx, ctx->msa_hcol, (size_t)n * (N1 + 1) * 4));
+    NC_TRY(nc_ensure(ctx, ctx->msa_tb, (size_t)n * (N1 + 1) * NWP * 64 + 64));
+    NwArgs p;
+    p.reads = (const uint8_t *)ctx->msa_reads.p; p.read_off = (const int32_t *)ctx->msa_read_off.p;
+    p.read_set = (const int32_t *)ctx->msa_read_set.p; p.refs = (const uint8_t *)ctx->msa_refs.p; p.ref_off = (const int32_t *)ctx->msa_ref_off.p;
+    p.A = n; p.Apad = std::max(64, (n + 63) & ~63); p.W = W; p.a0 = 0;
+    p.open = 9; p.extend = 1; p.match = 20; p.mismatch = -10;                      // parasail.nw_trace(alt, ref, 9, 1, matrix 20 / -10), :79
+    p.Hrow = nullptr; p.Frow = nullptr; p.hcol = nullptr; p.T = nullptr;
+    uint32_t *Tw = (uint32_t *)ctx->msa_tb.p;
+    int32_t *Hl = (int32_t *)ctx->msa_rows_hf.p, *hc = (int32_t *)ctx->msa_hcol.p;
+    const dim3 gr((unsigned)((n + 3) / 4));
+    if (CPL == 4) hipLaunchKernelGGL(k_nw_fill16<4>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+    else if (CPL == 8) hipLaunchKernelGGL(k_nw_fill16<8>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+    else if (CPL == 11) hipLaunchKernelGGL(k_nw_fill16<11>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+    else hipLaunchKernelGGL(k_nw_fill16<17>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
+    hipLaunchKernelGGL(k_allele_trace16, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, p, N1, CPL, (const uint32_t *)Tw, (const int32_t *)d_mr,
+                       (int16_t *)ctx->msa_trace.p, run_cap, d_rl, d_al);
+    NC_HIP(ctx, hipGetLastError());
+    NC_HIP(ctx, hipMemcpyAsync(ref_len, d_rl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipMemcpyAsync(alt_len, d_al, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NC_OK;
 }

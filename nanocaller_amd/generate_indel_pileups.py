@@ -210,8 +210,10 @@ def allele_prediction(alt, ref_seq, max_range):
     return ref_seq[:rl.value], alt[:al.value]
 
 
-def allele_prediction_batch(alts, ref_seqs, max_ranges):
-    """[allele_prediction(alt, ref_seq, max_range) for ...] in one native call on the usable host cores"""
+def allele_prediction_batch(alts, ref_seqs, max_ranges, eng=None):
+    """[allele_prediction(alt, ref_seq, max_range) for ...] in one native call: on the device when an engine is given (the
+    16-lane register aligner with parasail's scoring + one lane per alignment for the allele extraction: same results), else,
+    and for windows the device kernel does not cover, on the usable host cores"""
     n = len(alts)
     if n == 0:
         return []
@@ -221,8 +223,14 @@ def allele_prediction_batch(alts, ref_seqs, max_ranges):
     np.cumsum([len(r) for r in ref_seqs], out=roff[1:])
     mr = np.ascontiguousarray(max_ranges, np.int32)
     rl, al = np.empty(n, np.int32), np.empty(n, np.int32)
-    rc = L.nc_allele_prediction_batch(n, "".join(alts).encode(), _lib.npp(aoff), "".join(ref_seqs).encode(), _lib.npp(roff), _lib.npp(mr),
-                                      _lib.npp(rl), _lib.npp(al))
+    a_b, r_b = "".join(alts).encode(), "".join(ref_seqs).encode()
+    rc = _lib.NC_ERR_CAPACITY
+    if eng is not None:
+        rc = L.nc_allele_prediction_device(eng.ctx, n, a_b, _lib.npp(aoff), r_b, _lib.npp(roff), _lib.npp(mr), _lib.npp(rl), _lib.npp(al))
+        if rc not in (_lib.NC_OK, _lib.NC_ERR_CAPACITY):
+            raise _lib.NanoCallerHipError("nc_allele_prediction_device failed (%d): %s" % (rc, eng.last_error() if hasattr(eng, "last_error") else ""))
+    if rc == _lib.NC_ERR_CAPACITY:
+        rc = L.nc_allele_prediction_batch(n, a_b, _lib.npp(aoff), r_b, _lib.npp(roff), _lib.npp(mr), _lib.npp(rl), _lib.npp(al))
     if rc != _lib.NC_OK:
         raise _lib.NanoCallerHipError("nc_allele_prediction_batch failed (%d)" % rc)
     return [(None, None) if rl[i] < 0 else (ref_seqs[i][:rl[i]], alts[i][:al[i]]) for i in range(n)]
@@ -464,7 +472,8 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
     finally:
         L.nc_pass2_free(h)
     pos = [int(anchors[k]) for k in kept]
-    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[int(k) if by_index else int(anchors[k])]] for k in kept for _ in range(S)])
+    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[int(k) if by_index else int(anchors[k])]] for k in kept for _ in range(S)],
+                                    eng=eng)
     xh = x.view(nk, S, 5, 128, 2) if device_x else x.cpu().numpy().astype(np.float64).reshape(nk, S, 5, 128, 2)
     tail = (kept.tolist(),) if by_index else ()
     if haploid:

@@ -625,3 +625,41 @@ def test_read_base_n_counts_as_a_gap_on_both_paths():
     b = "AGTC".index(ref[col])
     assert abs(m_host[4, col, 0] - 2 / 6) < 1e-6 and abs(m_host[b, col, 0] - (4 / 6 - 1)) < 1e-6
     assert not np.isnan(m_host).any()
+
+
+@pytest.mark.gpu
+def test_device_allele_prediction_equals_the_host_version():
+    """nc_allele_prediction_device (16-lane register aligner with parasail's scoring, traceback + allele extraction one lane per
+    alignment) == nc_allele_prediction_batch on the reference-executed golden inputs and on random consensus / window pairs
+    with substitutions, insertions, deletions, identical strings and both window lengths (161 ONT, 261 PacBio)"""
+    import json
+    import os
+    from nanocaller_amd import generate_indel_pileups as gip
+    from nanocaller_amd.engine import get_engine
+    from util import GOLD
+    eng = get_engine(0)
+    gold = json.load(open(os.path.join(GOLD, "allele_prediction.json")))
+    alts, refs, mrs, want = [], [], [], []
+    for a, r, m, er, ea in gold["calls"]:                 # (alt, ref_seq, max_range) -> the reference's own (REF, ALT)
+        if a and r:
+            alts.append(a); refs.append(r); mrs.append(int(m)); want.append((er, ea))
+    assert gip.allele_prediction_batch(alts, refs, mrs, eng=eng) == want
+    rng = np.random.default_rng(7)
+    for k in range(3000):
+        n = 261 if k % 7 == 0 else 161
+        r = "".join(rng.choice(list("AGTC"), n))
+        a = list(r)
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, max(1, len(a) - 1)))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                a[p] = "AGTC"[int(rng.integers(0, 4))]
+            elif kind == 1:
+                del a[p:p + int(rng.integers(1, 30))]
+            else:
+                a[p:p] = list(rng.choice(list("AGTC"), int(rng.integers(1, 30))))
+        alts.append("".join(a)[:n + 40] or "A"); refs.append(r); mrs.append(40 if k % 3 else 10)
+    host = gip.allele_prediction_batch(alts, refs, mrs)
+    dev = gip.allele_prediction_batch(alts, refs, mrs, eng=eng)
+    assert len(alts) > 3500 and host == dev
+    assert sum(1 for h in host if h != (None, None) and len(h[0]) != len(h[1])) > 500       # indel alleles are exercised
