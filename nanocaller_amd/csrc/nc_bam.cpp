@@ -851,87 +851,126 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
     if (!o) return NC_ERR_NOMEM;
     const int S = haploid ? 1 : 3;
     o->sets_per_anchor = S;
-    o->set_read0.push_back(0);
-    o->read_off.push_back(0);
-    o->ref_off.push_back(0);
     static const char LET[8] = {'A', 'G', 'T', 'C', 'N', 'N', 'N', 'N'};
-    int32_t first = 0;
-    std::vector<int32_t> cov, q_of;                                        // reads in the pileup at the anchor, their query index
-    std::vector<int32_t> side0, side1;
-    std::vector<int32_t> sets[3];
-    try {
-        for (int32_t a = 0; a < n_anchor; a++) {
-            const int32_t p = anchors[a];
-            if (a && p < anchors[a - 1]) first = 0;
-            while (first < n && d->end[first] <= p) first++;
-            // reference window [p, min(chrom_len, p + window_after + 1)) from the bases kept for the chunk ([ref_lo, ref_hi])
-            const int64_t b = std::min<int64_t>(chrom_len, (int64_t)p + window_after + 1);
-            bool ok = b > p && p >= ref_lo && b - 1 <= ref_hi && p >= 1;
-            for (int64_t x = p; ok && x < b; x++) {
-                const char c = contig[x - 1];
-                ok = c == 'A' || c == 'G' || c == 'T' || c == 'C';
-            }
-            if (!ok) continue;
-            cov.clear();
-            for (int32_t r = first; r < n; r++) {
-                if (d->start[r] > p) break;
-                if (d->end[r] <= p) continue;
-                if (keep && !keep[r]) continue;
-                cov.push_back(r);
-            }
-            for (auto &v : sets) v.clear();
-            const int k = imp_idx ? imp_idx[a] : -1;
-            if (k >= 0) {
-                side0.assign(imp_reads + imp_off[2 * k], imp_reads + imp_off[2 * k + 1]);
-                side1.assign(imp_reads + imp_off[2 * k + 1], imp_reads + imp_off[2 * k + 2]);
-                std::sort(side0.begin(), side0.end());
-                std::sort(side1.begin(), side1.end());
-            }
-            for (int32_t r : cov) {
-                if (!haploid) {
-                    int h;
-                    if (k >= 0) h = std::binary_search(side0.begin(), side0.end(), r) ? 1 : std::binary_search(side1.begin(), side1.end(), r) ? 2 : 0;
-                    else h = d->hap[r];
-                    if (h == 1) sets[0].push_back(r);
-                    else if (h == 2) sets[1].push_back(r);
-                    sets[2].push_back(r);
-                } else sets[0].push_back(r);
-            }
-            bool pass = true;
-            for (int t = 0; t < S && pass; t++) {
-                if ((int32_t)sets[t].size() > maxcov) sets[t].resize((size_t)maxcov);
-                const int32_t need = haploid ? mincov : (t < 2 ? 2 : mincov);
-                pass = (int32_t)sets[t].size() >= need;
-            }
-            if (!pass) continue;
-            o->anchor_idx.push_back(a);
-            o->first0.push_back(sets[0].empty() ? -1 : sets[0][0]);
-            for (int t = 0; t < S; t++) {
-                int64_t cols = b - p;
-                for (int32_t r : sets[t]) {
-                    const int32_t e0 = d->ev_off[r], e1 = d->ev_off[r + 1];
-                    const int32_t q = qpos_or_next(d->start[r], d->qstart[r], d->ev_pos.data() + e0, d->ev_len.data() + e0, e1 - e0, p);
-                    const int64_t s0 = d->seq_off[r], L = d->seq_off[r + 1] - s0;
-                    int64_t a0 = std::min<int64_t>(std::max<int64_t>(q, 0), L), a1 = std::min<int64_t>((int64_t)q + window_after, L);
-                    if (a1 < a0) a1 = a0;
-                    const size_t w0 = o->reads.size();
-                    o->reads.resize(w0 + (size_t)(a1 - a0));
-                    const uint8_t *src = d->seq.data() + s0 + a0;
-                    char *dst = o->reads.data() + w0;
-                    for (int64_t x = 0; x < a1 - a0; x++) dst[x] = LET[src[x] & 7];
-                    o->read_off.push_back((int32_t)o->reads.size());
-                    cols += a1 - a0;
+    // anchors [a_lo, a_hi) into `po` (offsets local to po); anchors are independent: contiguous ranges go to worker threads and
+    // the partial results are concatenated in anchor order
+    auto run = [&](int32_t a_lo, int32_t a_hi, nc_pass2 *po) -> int {
+        po->set_read0.push_back(0);
+        po->read_off.push_back(0);
+        po->ref_off.push_back(0);
+        int32_t first = 0;
+        std::vector<int32_t> cov;                                          // reads in the pileup at the anchor
+        std::vector<int32_t> side0, side1;
+        std::vector<int32_t> sets[3];
+        try {
+            for (int32_t a = a_lo; a < a_hi; a++) {
+                const int32_t p = anchors[a];
+                if (a > a_lo && p < anchors[a - 1]) first = 0;
+                while (first < n && d->end[first] <= p) first++;
+                // reference window [p, min(chrom_len, p + window_after + 1)) from the bases kept for the chunk ([ref_lo, ref_hi])
+                const int64_t b = std::min<int64_t>(chrom_len, (int64_t)p + window_after + 1);
+                bool ok = b > p && p >= ref_lo && b - 1 <= ref_hi && p >= 1;
+                for (int64_t x = p; ok && x < b; x++) {
+                    const char c = contig[x - 1];
+                    ok = c == 'A' || c == 'G' || c == 'T' || c == 'C';
                 }
-                o->set_read0.push_back((int32_t)o->read_off.size() - 1);
-                o->refs.insert(o->refs.end(), contig + (p - 1), contig + (b - 1));
-                o->ref_off.push_back((int32_t)o->refs.size());
-                o->max_cols = (int32_t)std::max<int64_t>(o->max_cols, cols);       // every read base can add at most one column
+                if (!ok) continue;
+                cov.clear();
+                for (int32_t r = first; r < n; r++) {
+                    if (d->start[r] > p) break;
+                    if (d->end[r] <= p) continue;
+                    if (keep && !keep[r]) continue;
+                    cov.push_back(r);
+                }
+                for (auto &v : sets) v.clear();
+                const int k = imp_idx ? imp_idx[a] : -1;
+                if (k >= 0) {
+                    side0.assign(imp_reads + imp_off[2 * k], imp_reads + imp_off[2 * k + 1]);
+                    side1.assign(imp_reads + imp_off[2 * k + 1], imp_reads + imp_off[2 * k + 2]);
+                    std::sort(side0.begin(), side0.end());
+                    std::sort(side1.begin(), side1.end());
+                }
+                for (int32_t r : cov) {
+                    if (!haploid) {
+                        int h;
+                        if (k >= 0) h = std::binary_search(side0.begin(), side0.end(), r) ? 1 : std::binary_search(side1.begin(), side1.end(), r) ? 2 : 0;
+                        else h = d->hap[r];
+                        if (h == 1) sets[0].push_back(r);
+                        else if (h == 2) sets[1].push_back(r);
+                        sets[2].push_back(r);
+                    } else sets[0].push_back(r);
+                }
+                bool pass = true;
+                for (int t = 0; t < S && pass; t++) {
+                    if ((int32_t)sets[t].size() > maxcov) sets[t].resize((size_t)maxcov);
+                    const int32_t need = haploid ? mincov : (t < 2 ? 2 : mincov);
+                    pass = (int32_t)sets[t].size() >= need;
+                }
+                if (!pass) continue;
+                po->anchor_idx.push_back(a);
+                po->first0.push_back(sets[0].empty() ? -1 : sets[0][0]);
+                for (int t = 0; t < S; t++) {
+                    int64_t cols = b - p;
+                    for (int32_t r : sets[t]) {
+                        const int32_t e0 = d->ev_off[r], e1 = d->ev_off[r + 1];
+                        const int32_t q = qpos_or_next(d->start[r], d->qstart[r], d->ev_pos.data() + e0, d->ev_len.data() + e0, e1 - e0, p);
+                        const int64_t s0 = d->seq_off[r], L = d->seq_off[r + 1] - s0;
+                        int64_t a0 = std::min<int64_t>(std::max<int64_t>(q, 0), L), a1 = std::min<int64_t>((int64_t)q + window_after, L);
+                        if (a1 < a0) a1 = a0;
+                        const size_t w0 = po->reads.size();
+                        po->reads.resize(w0 + (size_t)(a1 - a0));
+                        const uint8_t *src = d->seq.data() + s0 + a0;
+                        char *dst = po->reads.data() + w0;
+                        for (int64_t x = 0; x < a1 - a0; x++) dst[x] = LET[src[x] & 7];
+                        po->read_off.push_back((int32_t)po->reads.size());
+                        cols += a1 - a0;
+                    }
+                    po->set_read0.push_back((int32_t)po->read_off.size() - 1);
+                    po->refs.insert(po->refs.end(), contig + (p - 1), contig + (b - 1));
+                    po->ref_off.push_back((int32_t)po->refs.size());
+                    po->max_cols = (int32_t)std::max<int64_t>(po->max_cols, cols);     // every read base can add at most one column
+                }
+                if (po->reads.size() > ((size_t)1 << 30) || po->refs.size() > ((size_t)1 << 30)) return NC_ERR_CAPACITY;
             }
-            if (o->reads.size() > ((size_t)1 << 30) || o->refs.size() > ((size_t)1 << 30)) { delete o; return NC_ERR_CAPACITY; }
+        } catch (const std::bad_alloc &) {
+            return NC_ERR_NOMEM;
         }
-    } catch (const std::bad_alloc &) {
-        delete o;
-        return NC_ERR_NOMEM;
+        return NC_OK;
+    };
+    int T = std::min(nc_host_cpus(), 16);
+    if (T > n_anchor / 64) T = n_anchor / 64;
+    if (T <= 1) {
+        const int rc = run(0, n_anchor, o);
+        if (rc != NC_OK) { delete o; return rc; }
+    } else {
+        std::vector<nc_pass2> part((size_t)T);
+        std::vector<int> rcs((size_t)T, NC_OK);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] { rcs[(size_t)t] = run((int32_t)((int64_t)n_anchor * t / T), (int32_t)((int64_t)n_anchor * (t + 1) / T), &part[(size_t)t]); });
+        for (auto &x : th) x.join();
+        for (int rc : rcs)
+            if (rc != NC_OK) { delete o; return rc; }
+        try {
+            o->set_read0.push_back(0);
+            o->read_off.push_back(0);
+            o->ref_off.push_back(0);
+            for (auto &pp : part) {
+                const int32_t b_al = (int32_t)o->read_off.size() - 1, b_rb = (int32_t)o->reads.size(), b_fb = (int32_t)o->refs.size();
+                if ((size_t)b_rb + pp.reads.size() > ((size_t)1 << 30) || (size_t)b_fb + pp.refs.size() > ((size_t)1 << 30)) { delete o; return NC_ERR_CAPACITY; }
+                o->anchor_idx.insert(o->anchor_idx.end(), pp.anchor_idx.begin(), pp.anchor_idx.end());
+                o->first0.insert(o->first0.end(), pp.first0.begin(), pp.first0.end());
+                for (size_t k = 1; k < pp.set_read0.size(); k++) o->set_read0.push_back(pp.set_read0[k] + b_al);
+                for (size_t k = 1; k < pp.read_off.size(); k++) o->read_off.push_back(pp.read_off[k] + b_rb);
+                for (size_t k = 1; k < pp.ref_off.size(); k++) o->ref_off.push_back(pp.ref_off[k] + b_fb);
+                o->reads.insert(o->reads.end(), pp.reads.begin(), pp.reads.end());
+                o->refs.insert(o->refs.end(), pp.refs.begin(), pp.refs.end());
+                o->max_cols = std::max(o->max_cols, pp.max_cols);
+            }
+        } catch (const std::bad_alloc &) {
+            delete o;
+            return NC_ERR_NOMEM;
+        }
     }
     *out = o;
     return NC_OK;

@@ -28,4 +28,4 @@ pr.enable()
 gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
