@@ -34,14 +34,16 @@ def pick_variants(col_type, start, win_size, groups=None, extra=None):
     variants = {}
     prev = 0
     lo = max(1, int(start))
-    for c in np.nonzero(col_type >= 0)[0]:
-        v = lo + int(c)
+    idx = np.nonzero(col_type >= 0)[0]
+    # plain Python ints: a flagged region is hundreds of consecutive columns, almost all skipped by `v <= prev`
+    for c, t in zip(idx.tolist(), col_type[idx].tolist()):
+        v = lo + c
         if v <= prev:
             continue
-        if col_type[c] == 0:
+        if t == 0:
             prev = v + win_size
             variants[max(1, v - win_size)] = 0                      # :267-268
-        elif col_type[c] == 1:
+        elif t == 1:
             prev = v + 10
             variants[max(1, v - 10)] = 1                            # :273-274
         else:
