@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 6   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+#define NC_ABI_VERSION 7   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
                               6: nc_allele_prediction_device */
@@ -403,6 +403,8 @@ typedef struct {
     const int32_t *ref_off;       /* [n_sets + 1] */
     const char *refs;
     int32_t max_cols;             /* bound on the alignment columns of any set (max_cols argument of nc_star_msa_tensor) */
+    const int32_t *al_dup;        /* [n_alignments] an earlier alignment of the same read window to the same reference window (a read
+                                     of the third set that is in a haplotype set too), or -1: nc_star_msa_tensor_dup's al_dup */
 } nc_pass2_arrays;
 int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anchor, const int32_t *anchors, const char *contig,
                         int64_t chrom_len, int32_t ref_lo, int32_t ref_hi, int32_t window_after, int32_t mincov, int32_t maxcov,
@@ -452,6 +454,13 @@ int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads, const int
                        const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
                        int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
                        const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off);
+/* The same with a duplicate map: al_dup[a] = b < a when alignment a is the same read window against the same reference window
+ * as alignment b (what nc_pass2_arrays.al_dup holds), else -1; NULL = none.  A duplicate is not aligned again -- the set
+ * kernels read b's traceback -- so the results are those of nc_star_msa_tensor on the same arrays. */
+int nc_star_msa_tensor_dup(nc_ctx *ctx, int32_t n_sets, const char *reads, const int32_t *read_off, const int32_t *set_read0,
+                           const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
+                           int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
+                           const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off, const int32_t *al_dup);
 
 /* ------------------------------------------------------------------ SNP genotype rules + VCF record text (host)
  * Replaces the per-site Python loop of snpCaller.caller (snpCaller.py:113-198).  probs f32 [n][4]

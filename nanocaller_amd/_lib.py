@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NANOCALLER_HIP_LIB") or os.path.join(_HERE, "libnanoc
 
 NC_OK = 0
 NC_ERR_CAPACITY = -2
-ABI_VERSION = 6          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
+ABI_VERSION = 7          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -35,7 +35,7 @@ EXPORTS = [
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
-    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_set_tensor_format", "nc_allele_prediction_batch", "nc_allele_prediction_device",
+    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_star_msa_tensor_dup", "nc_set_tensor_format", "nc_allele_prediction_batch", "nc_allele_prediction_device",
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
 ]
@@ -85,7 +85,7 @@ class SlicesArraysC(C.Structure):
 class Pass2ArraysC(C.Structure):
     _fields_ = [("n_kept", C.c_int32), ("anchor_idx", C.c_void_p), ("first0", C.c_void_p), ("sets_per_anchor", C.c_int32),
                 ("n_sets", C.c_int32), ("set_read0", C.c_void_p), ("n_alignments", C.c_int32), ("read_off", C.c_void_p),
-                ("reads", C.c_void_p), ("ref_off", C.c_void_p), ("refs", C.c_void_p), ("max_cols", C.c_int32)]
+                ("reads", C.c_void_p), ("ref_off", C.c_void_p), ("refs", C.c_void_p), ("max_cols", C.c_int32), ("al_dup", C.c_void_p)]
 
 
 class WireArraysC(C.Structure):
@@ -154,6 +154,7 @@ def lib():
         L.nc_bam_error.restype = C.c_char_p
         L.nc_bam_decode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
         L.nc_star_msa_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.nc_star_msa_tensor_dup.argtypes = L.nc_star_msa_tensor.argtypes + [vp]
         L.nc_allele_prediction_batch.argtypes = [i32, C.c_char_p, vp, C.c_char_p, vp, vp, vp, vp]
         L.nc_allele_prediction_device.argtypes = [vp, i32, C.c_char_p, vp, C.c_char_p, vp, vp, vp, vp]
         L.nc_set_tensor_format.argtypes = [vp, C.c_int]

@@ -835,7 +835,7 @@ int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor
 // in pileup order: the deterministic stand-in for the unseeded random.sample of :19-20), the mincov tests (:48, :345), and the
 // flat arrays nc_star_msa_tensor takes.
 struct nc_pass2 {
-    std::vector<int32_t> anchor_idx, first0, set_read0, read_off, ref_off;
+    std::vector<int32_t> anchor_idx, first0, set_read0, read_off, ref_off, al_dup;
     std::vector<char> reads, refs;
     int32_t sets_per_anchor = 3, max_cols = 1;
 };
@@ -909,9 +909,21 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
                 if (!pass) continue;
                 po->anchor_idx.push_back(a);
                 po->first0.push_back(sets[0].empty() ? -1 : sets[0][0]);
+                const int32_t al0 = (int32_t)po->read_off.size() - 1;                 // the anchor's first alignment
                 for (int t = 0; t < S; t++) {
                     int64_t cols = b - p;
                     for (int32_t r : sets[t]) {
+                        // a read of the "all reads" set that is in a haplotype set too: same window, same reference -> same alignment
+                        int32_t same = -1;
+                        if (t == 2) {
+                            auto i0 = std::lower_bound(sets[0].begin(), sets[0].end(), r);
+                            if (i0 != sets[0].end() && *i0 == r) same = al0 + (int32_t)(i0 - sets[0].begin());
+                            else {
+                                auto i1 = std::lower_bound(sets[1].begin(), sets[1].end(), r);
+                                if (i1 != sets[1].end() && *i1 == r) same = al0 + (int32_t)sets[0].size() + (int32_t)(i1 - sets[1].begin());
+                            }
+                        }
+                        po->al_dup.push_back(same);
                         const int32_t e0 = d->ev_off[r], e1 = d->ev_off[r + 1];
                         const int32_t q = qpos_or_next(d->start[r], d->qstart[r], d->ev_pos.data() + e0, d->ev_len.data() + e0, e1 - e0, p);
                         const int64_t s0 = d->seq_off[r], L = d->seq_off[r + 1] - s0;
@@ -962,6 +974,7 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
                 o->first0.insert(o->first0.end(), pp.first0.begin(), pp.first0.end());
                 for (size_t k = 1; k < pp.set_read0.size(); k++) o->set_read0.push_back(pp.set_read0[k] + b_al);
                 for (size_t k = 1; k < pp.read_off.size(); k++) o->read_off.push_back(pp.read_off[k] + b_rb);
+                for (int32_t v : pp.al_dup) o->al_dup.push_back(v < 0 ? -1 : v + b_al);
                 for (size_t k = 1; k < pp.ref_off.size(); k++) o->ref_off.push_back(pp.ref_off[k] + b_fb);
                 o->reads.insert(o->reads.end(), pp.reads.begin(), pp.reads.end());
                 o->refs.insert(o->refs.end(), pp.refs.begin(), pp.refs.end());
@@ -991,6 +1004,7 @@ int nc_pass2_view(const nc_pass2 *o, nc_pass2_arrays *v)
     v->ref_off = o->ref_off.data();
     v->refs = o->refs.data();
     v->max_cols = o->max_cols;
+    v->al_dup = o->al_dup.data();
     return NC_OK;
 }
 

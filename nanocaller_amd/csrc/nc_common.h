@@ -55,6 +55,7 @@ struct nc_ctx {
     DevBuf nbr_idx;                                       // coarse index over nbr_pos
     DevBuf indel_ws;                                      // indel window-scan workspace
     DevBuf msa_reads, msa_read_off, msa_read_set, msa_refs, msa_ref_off;   // device star alignment (nc_msa.hip): inputs,
+    DevBuf msa_dup;                                        // duplicate map + list of alignments to compute (nc_star_msa_tensor_dup)
     DevBuf msa_rows_hf, msa_hcol, msa_tb, msa_trace, msa_cols, msa_out;    // DP rows / last column / traceback bytes / alignments / columns / rows
     int32_t n_nbr = 0, n_cand = 0, n_sites = 0, n_chunks = 0;
     bool have_scan = false;

@@ -149,7 +149,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
                       &ctx->site_pos, &ctx->site_chunk, &ctx->site_n, &ctx->site_alt, &ctx->totals,
                       &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth, &ctx->nbr_idx, &ctx->indel_ws,
                       &ctx->msa_reads, &ctx->msa_read_off, &ctx->msa_read_set, &ctx->msa_refs, &ctx->msa_ref_off, &ctx->msa_rows_hf,
-                      &ctx->msa_hcol, &ctx->msa_tb, &ctx->msa_trace, &ctx->msa_cols, &ctx->msa_out};
+                      &ctx->msa_hcol, &ctx->msa_tb, &ctx->msa_trace, &ctx->msa_cols, &ctx->msa_out, &ctx->msa_dup};
     for (DevBuf *b : bufs) freebuf(*b);
     for (auto &w : ctx->w) {
         if (w.dev) (void)hipFree(w.dev);

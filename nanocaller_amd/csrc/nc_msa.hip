@@ -32,6 +32,8 @@ struct NwArgs {
     int32_t W;                     // max reference length + 1 (row pitch of the DP)
     int32_t a0;                    // first alignment of this launch (index into read_off / read_set)
     int32_t open, extend, match, mismatch;
+    const int32_t *uniq;           // optional: the launch-local indices of the alignments to compute (duplicates skipped), n_uniq of them
+    int32_t n_uniq;
     int32_t *Hrow, *Frow;          // [W][Apad]
     int32_t *hcol;                 // [N1 + 1][Apad]: H[i][n2]
     uint8_t *T;                    // [N1 + 1][W][Apad]
@@ -111,8 +113,9 @@ __global__ __launch_bounds__(64) void k_nw_fill16(NwArgs p, int32_t N1, uint32_t
 {
     constexpr int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;      // words per lane and row, padded to a vector store
     const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
-    const int al = blockIdx.x * 4 + g;
-    const bool live = al < p.A;
+    const int slot = blockIdx.x * 4 + g;
+    const bool live = slot < (p.uniq ? p.n_uniq : p.A);
+    const int al = live ? (p.uniq ? p.uniq[slot] : slot) : 0;
     int n1 = 0, n2 = 0;
     const uint8_t *s1 = p.reads, *s2 = p.refs;
     if (live) {
@@ -258,8 +261,9 @@ __global__ __launch_bounds__(64) void k_nw_trace(NwArgs p, TraceOut o)
 __global__ __launch_bounds__(64) void k_nw_trace16(NwArgs p, TraceOut o, int32_t N1, int32_t CPL, const uint32_t *__restrict__ Tw,
                                                    const int32_t *__restrict__ Hlast, const int32_t *__restrict__ hcolA)
 {
-    const int al = blockIdx.x * 64 + threadIdx.x;
-    if (al >= p.A) return;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= (p.uniq ? p.n_uniq : p.A)) return;
+    const int al = p.uniq ? p.uniq[slot] : slot;
     const int a = p.a0 + al;
     const int n1 = p.read_off[a + 1] - p.read_off[a];
     const int set = p.read_set[a];
@@ -406,15 +410,20 @@ __global__ __launch_bounds__(64) void k_allele_trace16(NwArgs p, int32_t N1, int
 // per set: columns.  set_read0[s] .. set_read0[s+1]: the set's alignments (indices local to the launch)
 __global__ __launch_bounds__(256) void k_set_columns(int32_t W, const int32_t *__restrict__ set_read0, const int32_t *__restrict__ ref_off,
                                                      int32_t set0, const int16_t *__restrict__ ins_len, int32_t *__restrict__ col /* [sets][W] */,
-                                                     int32_t *__restrict__ n_cols)
+                                                     int32_t *__restrict__ n_cols, const int32_t *__restrict__ dup)
 {
+    // dup[r] >= 0: alignment r is the same read window against the same reference as alignment dup[r] (a read of the "all reads"
+    // set that also sits in a haplotype set): it was not aligned again, its traceback is the other one's
     __shared__ int32_t mx[1024];
     const int sl = blockIdx.x, s = set0 + sl;
     const int n2 = ref_off[s + 1] - ref_off[s];
     const int r0 = set_read0[sl], r1 = set_read0[sl + 1];
     for (int j = threadIdx.x; j <= n2; j += 256) {
         int m = 0;
-        for (int r = r0; r < r1; r++) m = max(m, (int)ins_len[(int64_t)r * W + j]);
+        for (int r = r0; r < r1; r++) {
+            const int rs = dup && dup[r] >= 0 ? dup[r] : r;
+            m = max(m, (int)ins_len[(int64_t)rs * W + j]);
+        }
         mx[j] = m;
     }
     __syncthreads();
@@ -435,7 +444,7 @@ __device__ __forceinline__ uint8_t sym_code(uint8_t c)
 __global__ __launch_bounds__(256) void k_set_rows(NwArgs p, TraceOut o, const int32_t *__restrict__ set_read0, int32_t set0,
                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ n_cols,
                                                   const int64_t *__restrict__ row_off, const int64_t *__restrict__ refrow_off,
-                                                  uint8_t *__restrict__ rows, uint8_t *__restrict__ ref_rows)
+                                                  uint8_t *__restrict__ rows, uint8_t *__restrict__ ref_rows, const int32_t *__restrict__ dup)
 {
     const int sl = blockIdx.x, s = set0 + sl;
     const uint8_t *s2 = p.refs + p.ref_off[s];
@@ -450,7 +459,8 @@ __global__ __launch_bounds__(256) void k_set_rows(NwArgs p, TraceOut o, const in
     for (int j = threadIdx.x; j < n2; j += 256) RR[C[j]] = sym_code(s2[j]);
     for (int r = r0; r < r1; r++) {
         const uint8_t *s1 = p.reads + p.read_off[p.a0 + r];
-        const int16_t *qidx = o.qidx + (int64_t)r * p.W, *il = o.ins_len + (int64_t)r * p.W, *iq = o.ins_q + (int64_t)r * p.W;
+        const int rs = dup && dup[r] >= 0 ? dup[r] : r;
+        const int16_t *qidx = o.qidx + (int64_t)rs * p.W, *il = o.ins_len + (int64_t)rs * p.W, *iq = o.ins_q + (int64_t)rs * p.W;
         uint8_t *row = R + (int64_t)(r - r0) * nc;
         for (int j = threadIdx.x; j <= n2; j += 256) {
             if (j < n2 && qidx[j] >= 0) row[C[j]] = sym_code(s1[qidx[j]]);
@@ -474,10 +484,27 @@ extern "C" int nc_indel_tensor(nc_ctx *ctx, int32_t n_sets, const uint8_t *rows_
 // Host arrays in, tensors out: reads of set s = reads read_set0[s] .. read_set0[s+1]; x_dev [n_sets][5][128][2] (device),
 // cns_host [n_sets][max_cols] (NC_CODE_ABSENT-padded consensus symbols, gaps kept as 4), n_cols_host [n_sets].
 // Optional rows_host / ref_rows_host (+ their offsets): the aligned rows themselves, for checks against nc_star_msa.
+extern "C" int nc_star_msa_tensor_dup(nc_ctx *ctx, int32_t n_sets, const char *reads, const int32_t *read_off, const int32_t *set_read0,
+                                      const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
+                                      int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
+                                      const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off, const int32_t *al_dup);
+
 extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads, const int32_t *read_off, const int32_t *set_read0,
                                   const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
                                   int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
                                   const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off)
+{
+    return nc_star_msa_tensor_dup(ctx, n_sets, reads, read_off, set_read0, refs, ref_off, open, extend, match, mismatch, max_cols, x_dev, cns_host,
+                                  n_cols_host, rows_host, rows_host_off, ref_rows_host, ref_rows_host_off, nullptr);
+}
+
+// al_dup (optional, [n alignments]): al_dup[a] = b < a when alignment a is the same read window against the same reference
+// window as alignment b (nc_indel_pass2_sets: the reads of an anchor's "all reads" set that also sit in one of its haplotype
+// sets), else -1.  Such an alignment is not computed again: the set kernels read b's traceback.  Same results.
+extern "C" int nc_star_msa_tensor_dup(nc_ctx *ctx, int32_t n_sets, const char *reads, const int32_t *read_off, const int32_t *set_read0,
+                                      const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
+                                      int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
+                                      const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off, const int32_t *al_dup)
 {
     if (!ctx) return NC_ERR_ARG;
     if (n_sets < 0 || (n_sets && (!read_off || !set_read0 || !refs || !ref_off || !x_dev || !cns_host || !n_cols_host)) || max_cols < 1)
@@ -540,28 +567,50 @@ extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads
         for (int32_t k = 0; k <= ng; k++) sr0[(size_t)k] = set_read0[s0 + k] - a0;
         int32_t *col = (int32_t *)ctx->msa_cols.p, *ncol_dev = col + (size_t)ng * W, *sr0_dev = ncol_dev + ng;
         NC_HIP(ctx, hipMemcpyAsync(sr0_dev, sr0.data(), ((size_t)ng + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        // duplicates (register kernel only): launch-local source index per alignment, and the list of alignments to compute
+        const int32_t *dup_dev = nullptr, *uniq_dev = nullptr;
+        int32_t n_uniq = Ag;
+        if (al_dup && fast && Ag > 0) {
+            std::vector<int32_t> dl((size_t)Ag), ul;                                          // pageable sources: staged before the copy call returns
+            ul.reserve((size_t)Ag);
+            for (int32_t r = 0; r < Ag; r++) {
+                const int32_t b = al_dup[a0 + r];
+                // only a source inside this launch that is itself computed counts
+                dl[(size_t)r] = (b >= a0 && b < a0 + r && al_dup[b] < 0) ? b - a0 : -1;
+                if (dl[(size_t)r] < 0) ul.push_back(r);
+            }
+            n_uniq = (int32_t)ul.size();
+            NC_TRY(nc_ensure(ctx, ctx->msa_dup, ((size_t)Ag + (size_t)n_uniq) * 4 + 64));
+            int32_t *dd = (int32_t *)ctx->msa_dup.p;
+            NC_HIP(ctx, hipMemcpyAsync(dd, dl.data(), (size_t)Ag * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (n_uniq) NC_HIP(ctx, hipMemcpyAsync(dd + Ag, ul.data(), (size_t)n_uniq * 4, hipMemcpyHostToDevice, ctx->stream));
+            dup_dev = dd;
+            uniq_dev = dd + Ag;
+        }
         NwArgs p;
         p.reads = (const uint8_t *)ctx->msa_reads.p; p.read_off = (const int32_t *)ctx->msa_read_off.p;
         p.read_set = (const int32_t *)ctx->msa_read_set.p; p.refs = (const uint8_t *)ctx->msa_refs.p; p.ref_off = (const int32_t *)ctx->msa_ref_off.p;
         p.A = Ag; p.Apad = Apad; p.W = W; p.a0 = a0; p.open = open; p.extend = extend; p.match = match; p.mismatch = mismatch;
+        p.uniq = uniq_dev; p.n_uniq = n_uniq;
         p.Hrow = (int32_t *)ctx->msa_rows_hf.p; p.Frow = p.Hrow + (size_t)W * Apad; p.hcol = (int32_t *)ctx->msa_hcol.p; p.T = (uint8_t *)ctx->msa_tb.p;
         TraceOut o;
         o.qidx = (int16_t *)ctx->msa_trace.p; o.ins_len = o.qidx + (size_t)std::max(Ag, 1) * W; o.ins_q = o.ins_len + (size_t)std::max(Ag, 1) * W;
         if (Ag > 0 && fast) {
             uint32_t *Tw = (uint32_t *)ctx->msa_tb.p;
             int32_t *Hl = (int32_t *)ctx->msa_rows_hf.p, *hc = (int32_t *)ctx->msa_hcol.p;
-            const dim3 gr((unsigned)((Ag + 3) / 4));
+            const int32_t nrun = std::max(n_uniq, 1);
+            const dim3 gr((unsigned)((nrun + 3) / 4));
             if (CPL == 4) hipLaunchKernelGGL(k_nw_fill16<4>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
             else if (CPL == 8) hipLaunchKernelGGL(k_nw_fill16<8>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
             else if (CPL == 11) hipLaunchKernelGGL(k_nw_fill16<11>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
             else hipLaunchKernelGGL(k_nw_fill16<17>, gr, dim3(64), 0, ctx->stream, p, N1, Tw, Hl, hc);
-            hipLaunchKernelGGL(k_nw_trace16, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p, o, N1, CPL, (const uint32_t *)Tw, (const int32_t *)Hl,
+            hipLaunchKernelGGL(k_nw_trace16, dim3((nrun + 63) / 64), dim3(64), 0, ctx->stream, p, o, N1, CPL, (const uint32_t *)Tw, (const int32_t *)Hl,
                                (const int32_t *)hc);
         } else if (Ag > 0) {
             hipLaunchKernelGGL(k_nw_fill, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p);
             hipLaunchKernelGGL(k_nw_trace, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, p, o);
         }
-        hipLaunchKernelGGL(k_set_columns, dim3(ng), dim3(256), 0, ctx->stream, W, sr0_dev, p.ref_off, s0, o.ins_len, col, ncol_dev);
+        hipLaunchKernelGGL(k_set_columns, dim3(ng), dim3(256), 0, ctx->stream, W, sr0_dev, p.ref_off, s0, o.ins_len, col, ncol_dev, dup_dev);
         NC_HIP(ctx, hipGetLastError());
         NC_HIP(ctx, hipMemcpyAsync(n_cols.data() + s0, ncol_dev, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -584,7 +633,7 @@ extern "C" int nc_star_msa_tensor(nc_ctx *ctx, int32_t n_sets, const char *reads
         NC_HIP(ctx, hipMemcpyAsync(ob + o_rro, rro.data(), ((size_t)ng + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         NC_HIP(ctx, hipMemcpyAsync(ob + o_nr, nrows.data(), (size_t)ng * 4, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_set_rows, dim3(ng), dim3(256), 0, ctx->stream, p, o, sr0_dev, s0, col, ncol_dev, (const int64_t *)(ob + o_ro),
-                           (const int64_t *)(ob + o_rro), ob + o_rows, ob + o_ref);
+                           (const int64_t *)(ob + o_rro), ob + o_rows, ob + o_ref, dup_dev);
         NC_HIP(ctx, hipGetLastError());
         NC_TRY(nc_indel_tensor(ctx, ng, ob + o_rows, (const int64_t *)(ob + o_ro), (const int32_t *)(ob + o_nr), ncol_dev, ob + o_ref,
                                (const int64_t *)(ob + o_rro), mcols, x_dev + (size_t)s0 * 5 * 128 * 2, ob + o_cns));
@@ -651,6 +700,7 @@ extern "C" int nc_allele_prediction_device(nc_ctx *ctx, int32_t n, const char *a
     p.read_set = (const int32_t *)ctx->msa_read_set.p; p.refs = (const uint8_t *)ctx->msa_refs.p; p.ref_off = (const int32_t *)ctx->msa_ref_off.p;
     p.A = n; p.Apad = std::max(64, (n + 63) & ~63); p.W = W; p.a0 = 0;
     p.open = 9; p.extend = 1; p.match = 20; p.mismatch = -10;                      // parasail.nw_trace(alt, ref, 9, 1, matrix 20 / -10), :79
+    p.uniq = nullptr; p.n_uniq = n;
     p.Hrow = nullptr; p.Frow = nullptr; p.hcol = nullptr; p.T = nullptr;
     uint32_t *Tw = (uint32_t *)ctx->msa_tb.p;
     int32_t *Hl = (int32_t *)ctx->msa_rows_hf.p, *hc = (int32_t *)ctx->msa_hcol.p;

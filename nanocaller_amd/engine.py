@@ -350,9 +350,10 @@ class Engine:
                                          mismatch=mismatch, want_rows=want_rows, cns_as_str=cns_as_str, _n_reads=n_reads, _cap=cap)
 
     def star_msa_tensor_flat(self, S, reads, read_off, set_read0, refs, ref_off, max_cols, *, open_=None, extend=None, match=None, mismatch=None,
-                             want_rows=False, cns_as_str=False, _n_reads=None, _cap=None):
+                             want_rows=False, cns_as_str=False, _n_reads=None, _cap=None, al_dup=None):
         """The same on flat host buffers (what nc_indel_pass2_sets produces): `reads` / `refs` bytes objects or raw pointers
-        (ints / c_void_p), read_off / set_read0 / ref_off int32 arrays or pointers."""
+        (ints / c_void_p), read_off / set_read0 / ref_off int32 arrays or pointers.  al_dup (int32 array or pointer, optional):
+        nc_pass2_arrays.al_dup -- alignments that repeat an earlier one are not computed again."""
         open_, extend, match, mismatch = [d if v is None else v for v, d in zip((open_, extend, match, mismatch), _lib.STAR_SCORING)]
         x = torch.empty((S, 5, 128, 2), dtype=torch.float32, device=self.device)
         mc = int(max_cols)
@@ -366,13 +367,13 @@ class Engine:
             rroff = np.zeros(S + 1, np.int64)
             np.cumsum(_cap, out=rroff[1:])
             rows, rr = np.empty(max(int(roff[-1]), 1), np.uint8), np.empty(max(int(rroff[-1]), 1), np.uint8)
-        self._check(self.L.nc_star_msa_tensor(self.ctx, S, reads, ptr(read_off), ptr(set_read0), refs, ptr(ref_off),
-                                              int(open_), int(extend), int(match), int(mismatch), mc, _ptr(x), _lib.npp(cns), _lib.npp(ncols),
-                                              _lib.npp(rows), _lib.npp(roff), _lib.npp(rr), _lib.npp(rroff)), "nc_star_msa_tensor")
+        self._check(self.L.nc_star_msa_tensor_dup(self.ctx, S, reads, ptr(read_off), ptr(set_read0), refs, ptr(ref_off),
+                                                  int(open_), int(extend), int(match), int(mismatch), mc, _ptr(x), _lib.npp(cns), _lib.npp(ncols),
+                                                  _lib.npp(rows), _lib.npp(roff), _lib.npp(rr), _lib.npp(rroff), ptr(al_dup)), "nc_star_msa_tensor")
         if int(ncols.max()) > mc and not want_rows:
             # the caller's column bound was an estimate (consensus columns beyond it are cut): once more with the real maximum
             return self.star_msa_tensor_flat(S, reads, read_off, set_read0, refs, ref_off, int(ncols.max()), open_=open_, extend=extend,
-                                             match=match, mismatch=mismatch, cns_as_str=cns_as_str)
+                                             match=match, mismatch=mismatch, cns_as_str=cns_as_str, al_dup=al_dup)
         # consensus with the gap symbols removed: one pass over the [S, mc] block instead of S small array operations
         keep = (np.arange(mc, dtype=np.int32)[None, :] < np.minimum(ncols, mc)[:, None]) & (cns != 4)
         cnt = keep.sum(1)

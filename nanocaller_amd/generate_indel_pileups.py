@@ -16,6 +16,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 
 import numpy as np
@@ -465,7 +466,8 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
         eng = get_engine(device)
         eng.use_torch_stream()
         x, cns_str, _ = eng.star_msa_tensor_flat(ns, C.c_void_p(v.reads), C.c_void_p(v.read_off), C.c_void_p(v.set_read0), C.c_void_p(v.refs),
-                                                 C.c_void_p(v.ref_off), min(v.max_cols, 4 * window_after + 64), cns_as_str=True)
+                                                 C.c_void_p(v.ref_off), min(v.max_cols, 4 * window_after + 64), cns_as_str=True,
+                                                 al_dup=None if haploid or os.environ.get("NC_MSA_NO_DEDUP") else C.c_void_p(v.al_dup))
         kept = np.ctypeslib.as_array(C.cast(v.anchor_idx, C.POINTER(C.c_int32)), (nk,)).copy()
         first0 = np.ctypeslib.as_array(C.cast(v.first0, C.POINTER(C.c_int32)), (nk,)).copy()
         ref_off = np.ctypeslib.as_array(C.cast(v.ref_off, C.POINTER(C.c_int32)), (ns + 1,))

@@ -264,3 +264,64 @@ def test_batched_featuriser_equals_per_chunk_calls(files, haploid):
                     assert b.is_cuda and np.array_equal(a.astype(np.float32), b.cpu().numpy())
                 else:
                     assert list(a) == list(b)
+
+
+def test_pass2_sets_mark_repeated_alignments(files):
+    """nc_pass2_arrays.al_dup (host code, no GPU): every read of an anchor's third ("all reads") set that is in one of its
+    haplotype sets points at that earlier alignment -- same read window, same reference window -- and nothing else does"""
+    import ctypes as C
+    from nanocaller_amd import _lib
+    L = _lib.lib()
+    n_dup = n_all = 0
+    for wn in ("a", "b"):
+        w, bam, fa = files[wn]
+        ctg = gip.decoded_contig(bam, w.chrom, fa)
+        dec = ctg["dec"]
+        keep = np.ascontiguousarray((dec["read_flag"] & 0xF04) == 0, np.uint8)
+        anc = np.arange(50, w.length - 200, 17, dtype=np.int32)       # > 128 anchors: worker threads, partial results merged
+        h = C.c_void_p()
+        assert L.nc_indel_pass2_sets(ctg["handle"], _lib.npp(keep), len(anc), _lib.npp(anc), ctg["fasta_b"], len(ctg["fasta"]), 1,
+                                     len(ctg["fasta"]), 160, 2, 160, 0, None, None, None, C.byref(h)) == _lib.NC_OK
+        v = _lib.Pass2ArraysC()
+        L.nc_pass2_view(h, C.byref(v))
+        as_i32 = lambda p, n: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), (n,)).copy()   # noqa: E731
+        A, ns = v.n_alignments, v.n_sets
+        assert v.sets_per_anchor == 3 and ns == 3 * v.n_kept and v.n_kept > 20
+        dup, roff, s0 = as_i32(v.al_dup, A), as_i32(v.read_off, A + 1), as_i32(v.set_read0, ns + 1)
+        reads = C.string_at(v.reads, int(roff[A]))
+        for k in range(v.n_kept):
+            a0, a1, a2, a3 = s0[3 * k:3 * k + 4]
+            assert (dup[a0:a2] == -1).all()
+            for a in range(a2, a3):
+                if dup[a] >= 0:
+                    assert a0 <= dup[a] < a2 and reads[roff[dup[a]]:roff[dup[a] + 1]] == reads[roff[a]:roff[a + 1]]
+                    n_dup += 1
+            n_all += a3 - a2
+            # every phased read is in the third set (below maxcov): all of them are marked
+            assert (dup[a2:a3] >= 0).sum() == a2 - a0
+        L.nc_pass2_free(h)
+    assert n_dup > 500 and n_dup < n_all
+
+
+@pytest.mark.gpu
+def test_skipping_repeated_alignments_changes_nothing(files, monkeypatch):
+    """nc_star_msa_tensor_dup with the duplicate map of nc_indel_pass2_sets (the product path) returns what the plain call
+    that aligns every read of every set returns, with and without imputed read sets"""
+    for wn, kw in (("a", {}), ("b", dict(impute_indel_phase=True, del_t=0.4))):
+        w, bam, fa = files[wn]
+        dct = dict(seq="ont", win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+                   exclude_bed=None, impute_indel_phase=False, fasta_path=fa)
+        dct.update(kw)
+        chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 4_000), sam_path=bam) for s in range(1, w.length, 4_000)]
+        monkeypatch.delenv("NC_MSA_NO_DEDUP", raising=False)
+        got = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=False)
+        monkeypatch.setenv("NC_MSA_NO_DEDUP", "1")
+        exp = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=False)
+        assert sum(len(t[0]) for t in got) > 20
+        for t, e in zip(got, exp):
+            assert list(t[0]) == list(e[0])
+            for a, b in zip(t[1:], e[1:]):
+                if isinstance(b, np.ndarray):
+                    assert np.array_equal(np.asarray(a), b)
+                else:
+                    assert list(a) == list(b)
