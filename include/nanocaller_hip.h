@@ -26,7 +26,7 @@ extern "C" {
 #define NC_ABI_VERSION 7   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
-                              6: nc_allele_prediction_device */
+                              6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -483,6 +483,12 @@ int nc_argsort4(const float *probs, int64_t n, int32_t *order, int64_t *n_ties, 
  * file offsets (coffset << 16 | offset in block) for an index are formed.  cap >= n + n/100 + 64*(*n_blocks) + 64 suffices. */
 int nc_bgzf_compress(const uint8_t *data, int64_t n, int32_t level, uint8_t *out, int64_t cap, int64_t *n_out,
                      int64_t *block_coff, int64_t blk_cap, int64_t *n_blocks);
+
+/* A whole BGZF file (bgzip output: a BED, a VCF, ...) inflated into `out` by the BGZF layer of the BAM reader: every block's
+ * CRC-32 and ISIZE are checked.  *n_out = the inflated size, also when NC_ERR_CAPACITY says `cap` was too small (cap 0 / out
+ * NULL: size query).  NC_ERR_ARG: not readable or not BGZF.  Reads the `exclude_bed` file the reference opens with
+ * pysam.TabixFile (generate_SNP_pileups.py:113-116). */
+int nc_bgzf_read_file(const char *path, uint8_t *out, int64_t cap, int64_t *n_out);
 
 #ifdef __cplusplus
 }

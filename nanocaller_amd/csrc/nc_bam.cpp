@@ -392,6 +392,29 @@ uint64_t csi_start(const nc_bam *b, int32_t tid, int64_t beg0, int64_t end0, boo
 
 extern "C" {
 
+// Whole BGZF file -> bytes, through the reader the BAM path uses (block walk, inflate, CRC-32 and ISIZE checks).
+int nc_bgzf_read_file(const char *path, uint8_t *out, int64_t cap, int64_t *n_out)
+{
+    if (!path || !n_out || cap < 0 || (cap && !out)) return NC_ERR_ARG;
+    *n_out = 0;
+    Bgzf z;
+    z.f = fopen(path, "rb");
+    if (!z.f) return NC_ERR_ARG;
+    int rc = NC_OK;
+    int64_t total = 0;
+    if (!z.load_block(0)) rc = NC_ERR_ARG;
+    while (rc == NC_OK && !z.eof) {
+        const int64_t k = (int64_t)z.block.size();
+        if (total + k <= cap && k) memcpy(out + total, z.block.data(), (size_t)k);
+        total += k;
+        if (!z.load_block(z.next_coff)) rc = NC_ERR_ARG;
+    }
+    fclose(z.f);
+    *n_out = total;
+    if (rc == NC_OK && total > cap) rc = NC_ERR_CAPACITY;
+    return rc;
+}
+
 int nc_bam_open(const char *path, nc_bam **out)
 {
     if (!path || !out) return NC_ERR_ARG;

@@ -58,6 +58,12 @@ _BAM_WORLDS = _LRU(2)        # (bam, fasta, contig) -> decoded World
 _PACKS = _LRU(3)             # (source, fasta, contig, supplementary, exclusions, device) -> (DevicePack, World)
 
 
+# BED files of centromere / telomere intervals that ship with the reference (data; `--exclude_bed hg38` of its CLI resolves to
+# nanocaller_src/release_data/bed_files/hg38_centro_telo.bed.gz next to the script, NanoCaller:21-22): kept at the same place
+BED_SHORTCUTS = ("hg38", "hg19", "mm10", "mm39")
+RELEASE_BED_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nanocaller_src", "release_data", "bed_files")
+
+
 def register_alignments(key, world: World):
     """Make `dct['sam_path'] == key` resolve to decoded alignments."""
     _SOURCES[key] = world
@@ -90,13 +96,22 @@ def _exclude_rows(dct, chrom):
         return None
     if isinstance(ex, (list, tuple)):
         return tuple((int(a), int(b)) for (c, a, b) in ex if c == chrom)
-    opener = gzip.open if str(ex).endswith(".gz") else open          # BGZF is a valid multi-member gzip stream
+    ex = str(ex)
+    if ex in BED_SHORTCUTS:                                          # the names the reference's CLI accepts (NanoCaller:21-22)
+        ex = os.path.join(RELEASE_BED_DIR, "%s_centro_telo.bed.gz" % ex)
+    with open(ex, "rb") as f:
+        head = f.read(18)
+    if head[:4] == b"\x1f\x8b\x08\x04" and head[12:14] == b"BC":    # bgzip output, what pysam.TabixFile needs (:113-116)
+        from .vcfio import bgzf_read
+        text = bgzf_read(ex).decode("ascii", "replace")
+    else:
+        with (gzip.open if head[:2] == b"\x1f\x8b" else open)(ex, "rt") as f:
+            text = f.read()
     rows = []
-    with opener(ex, "rt") as f:
-        for line in f:
-            t = line.split()
-            if len(t) >= 3 and t[0] == chrom:
-                rows.append((int(t[1]), int(t[2])))
+    for line in text.splitlines():
+        t = line.split()
+        if len(t) >= 3 and t[0] == chrom:
+            rows.append((int(t[1]), int(t[2])))
     return tuple(rows)
 
 

@@ -43,6 +43,21 @@ def bgzf_write(path, data, level=6):
     return coff
 
 
+def bgzf_read(path):
+    """The inflated bytes of a BGZF file (bgzip output), every block CRC-checked by the library's BAM-side BGZF reader."""
+    L = _lib.lib()
+    L.nc_bgzf_read_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    n = C.c_int64()
+    rc = L.nc_bgzf_read_file(str(path).encode(), None, 0, C.byref(n))
+    if rc not in (_lib.NC_OK, _lib.NC_ERR_CAPACITY):
+        raise _lib.NanoCallerHipError("%s: not a readable BGZF file (%d)" % (path, rc))
+    out = np.empty(max(n.value, 1), np.uint8)
+    rc = L.nc_bgzf_read_file(str(path).encode(), _lib.npp(out), n.value, C.byref(n))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("%s: not a readable BGZF file (%d)" % (path, rc))
+    return out[:n.value].tobytes()
+
+
 def virtual_offsets(block_coff, uoff):
     """virtual file offsets of uncompressed offsets `uoff` in a stream written by bgzf_write"""
     uoff = np.asarray(uoff, np.int64)

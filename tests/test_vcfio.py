@@ -1,14 +1,16 @@
 """BGZF + CSI writer: the files are read back with an independent reader that follows the CSIv1 / tabix /
 BGZF specifications; region queries through the index must return exactly the overlapping records.  htslib / tabix /
-bcftools are absent from this image, so interoperability with them is unpinned."""
+bcftools are absent from this image; what htslib itself wrote and the image holds (the reference's bgzipped, tabix-indexed
+BED files) pins the BGZF reader and the binning scheme -- see the last test."""
 import gzip
+import os
 import struct
 import zlib
 
 import numpy as np
 import pytest
 
-from nanocaller_amd import vcfio
+from nanocaller_amd import _lib, vcfio
 
 
 def _read_block(raw, coff):
@@ -136,3 +138,70 @@ def test_bgzf_empty_and_block_boundaries():
         comp, coff = vcfio.bgzf_compress(data)
         assert gzip.decompress(comp.tobytes()) == data
         assert len(coff) == (n + vcfio.BGZF_BLOCK - 1) // vcfio.BGZF_BLOCK + 1 and coff[-1] == len(comp) - 28
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Files written by htslib itself (bgzip + tabix): the four centromere / telomere BED files that ship with the reference
+# (nanocaller_src/release_data/bed_files, data the reference's `--exclude_bed hg38` resolves to, NanoCaller:21-22) are the only
+# htslib output in this image.  They pin the BGZF layer of the BAM reader and the binning scheme of the index writer.
+def _tbi(raw):
+    """tabix index (SAM spec section 5 / tabix.pdf) -> (names, [per reference {bin: [(beg, end)]}], [linear index])"""
+    assert raw[:4] == b"TBI\x01"
+    n_ref, fmt, col_seq, col_beg, col_end, meta, skip, l_nm = struct.unpack_from("<8i", raw, 4)
+    names = raw[36:36 + l_nm].split(b"\0")[:n_ref]
+    p = 36 + l_nm
+    bins, lin = [], []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", raw, p); p += 4
+        d = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", raw, p); p += 8
+            d[b] = [struct.unpack_from("<QQ", raw, p + 16 * c) for c in range(n_chunk)]
+            p += 16 * n_chunk
+        bins.append(d)
+        (n_intv,) = struct.unpack_from("<i", raw, p); p += 4
+        lin.append(struct.unpack_from("<%dQ" % n_intv, raw, p)); p += 8 * n_intv
+    return dict(fmt=fmt, cols=(col_seq, col_beg, col_end)), [n.decode() for n in names], bins, lin
+
+
+@pytest.mark.parametrize("genome", ["hg38", "hg19", "mm10", "mm39"])
+def test_htslib_written_bgzf_files_and_their_tabix_bins(genome):
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    path = os.path.join(gsp.RELEASE_BED_DIR, "%s_centro_telo.bed.gz" % genome)
+    text = vcfio.bgzf_read(path)
+    assert text == gzip.decompress(open(path, "rb").read()) and text.count(b"\n") > 40
+    with pytest.raises(_lib.NanoCallerHipError):
+        vcfio.bgzf_read(__file__)                                                   # not BGZF: refused, not garbage
+    hdr, names, bins, lin = _tbi(vcfio.bgzf_read(path + ".tbi"))
+    assert hdr["cols"] == (1, 2, 0) and hdr["fmt"] == 2          # indexed with tabix's VCF preset: a row is the position in column 2
+    # every row sits in the bin reg2bin gives it, inside one of that bin's chunks (virtual offset = block offset << 16 | offset
+    # in the block; these files are one block), and not before its 16 kb window's linear-index entry
+    off, n_rows = 0, 0
+    r_tid, r_beg, r_off, r_end = [], [], [], []
+    for line in text.split(b"\n")[:-1]:
+        c, a, b = line.split(b"\t")[:3]
+        tid = names.index(c.decode())
+        r_tid.append(tid); r_beg.append(int(a) - 1); r_off.append(off); r_end.append(off + len(line) + 1)
+        beg0 = int(a) - 1                                                           # 1-based POS -> [POS - 1, POS)
+        bn = int(vcfio.reg2bin(np.array([beg0]), np.array([beg0 + 1]))[0])
+        assert bn in bins[tid], (line, bn)
+        assert any(lo <= off < hi for lo, hi in bins[tid][bn]), (line, bins[tid][bn])
+        assert lin[tid][beg0 >> 14] <= off
+        off += len(line) + 1
+        n_rows += 1
+    assert sum(len(ch) for d in bins for k, ch in d.items() if k != 37450) >= len(names) and n_rows > 40
+    # the index writer of the VCF path (vcfio.csi_bytes), fed the same rows and offsets, lists the bins, chunks, pseudo-bin
+    # statistics and aux block that tabix wrote for this file
+    r_end[-1] = (os.path.getsize(path) - 28) << 16       # the data block ends with the last row: "tell" = start of the next (EOF) block
+    ours = _parse_csi(vcfio.csi_bytes(names, r_tid, r_beg, np.array(r_beg) + 1, r_off, r_end))
+    assert ours["names"] == names and ours["conf"] == (2, 1, 2, 0, ord("#"), 0)
+    for tid in range(len(names)):
+        assert {k: [tuple(c) for c in v[1]] for k, v in ours["refs"][tid].items()} == {k: [tuple(c) for c in v] for k, v in bins[tid].items()}
+        for k, (loff, _) in ours["refs"][tid].items():
+            if k != 37450:
+                assert loff == lin[tid][min(k - 4681, len(lin[tid]) - 1)]           # level-5 bins: loffset = the window's entry
+    # and the exclusion rows the featuriser derives from it, by the path and by the reference CLI's short name
+    rows = gsp._exclude_rows({"exclude_bed": genome}, "chr1")
+    assert rows == gsp._exclude_rows({"exclude_bed": path}, "chr1") and len(rows) >= 2
+    exp = tuple((int(t[1]), int(t[2])) for t in (ln.split() for ln in text.decode().splitlines()) if t[0] == "chr1")
+    assert rows == exp
