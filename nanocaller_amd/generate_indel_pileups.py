@@ -429,7 +429,8 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
     dec = ctg["dec"]
     flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if dct.get("supplementary") else 0x800)
     if flag not in ctg["keep"]:
-        ctg["keep"][flag] = np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8)
+        from .pack import pileup_depth_cap
+        ctg["keep"][flag] = pileup_depth_cap(dec["read_start"], dec["read_end"], np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8))
     keep = ctg["keep"][flag]
     anc = np.ascontiguousarray(anchors, np.int32)
     imp_idx = imp_off = imp_reads = None

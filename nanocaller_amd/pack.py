@@ -43,6 +43,43 @@ def _check(rc, what):
         raise _lib.NanoCallerHipError("%s failed with status %d" % (what, rc))
 
 
+# pysam's AlignmentFile.pileup(..., max_depth=8000) default, which the reference does not override (generate_SNP_pileups.py:156,
+# generate_indel_pileups.py:213): htslib's pileup buffer refuses a read that starts at the column it is about to emit while
+# it already holds max_depth reads.
+PILEUP_MAX_DEPTH = 8000
+
+
+def pileup_depth_cap(read_start, read_end, keep, max_depth=PILEUP_MAX_DEPTH):
+    """`keep` (uint8 per read, file = coordinate order) with the reads htslib's pileup engine drops cleared.  bam_plp_push:
+    a record whose start equals the iterator's current column is skipped when the buffer holds `max_depth` reads; the buffer
+    then holds every accepted read that ends after the previous column (reads are released as columns are emitted), and the
+    FIRST record of a start position is pushed while the iterator is still before it, so it always enters.  [pysam-doc:
+    unpinned, the library is absent from the image.]  Data below max_depth everywhere (any ordinary WGS run) is untouched."""
+    keep = np.ascontiguousarray(keep, np.uint8)
+    idx = np.flatnonzero(keep)
+    if idx.size <= max_depth:
+        return keep
+    s = np.asarray(read_start, np.int64)[idx]
+    e = np.asarray(read_end, np.int64)[idx]
+    # reads ahead of read i that are still buffered when it arrives, if nothing had been dropped: an upper bound
+    alive = np.arange(idx.size) - np.searchsorted(np.sort(e), s - 1, side="right")
+    if int(alive.max()) < max_depth:
+        return keep
+    import heapq
+    keep = keep.copy()
+    heap, last = [], None
+    for k in range(idx.size):
+        sk = int(s[k])
+        while heap and heap[0] <= sk - 1:
+            heapq.heappop(heap)
+        if sk == last and len(heap) >= max_depth:
+            keep[idx[k]] = 0
+        else:
+            heapq.heappush(heap, int(e[k]))
+        last = sk
+    return keep
+
+
 def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, supplementary=False,
                tile_size=2048, pos_lo=None, pos_hi=None, exclude=None, hap=None, events=None) -> HostPack:
     """read_* as in synth.World (coordinate order); ref_codes uint8 [L] (index p-1, 4 = skip).
@@ -55,7 +92,7 @@ def pack_reads(read_start, read_end, read_off, codes, read_flag, ref_codes, *, s
     cd = np.ascontiguousarray(codes, np.uint8)
     flag = np.asarray(read_flag)
     filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT      # :151-154
-    keep = np.ascontiguousarray((flag & filt) == 0, np.uint8)
+    keep = pileup_depth_cap(read_start, read_end, np.ascontiguousarray((flag & filt) == 0, np.uint8))
     # strand: the reference looks the read NAME up in a table of the primary alignments' `(flag & 0x910) // 16` (:141-143),
     # i.e. bit 0x10 of a primary record.  With dct['supplementary'] a supplementary record is counted on its own 0x10 bit
     # (the reference takes its primary's, and raises KeyError when that is outside the fetch window).

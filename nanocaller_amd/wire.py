@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from .engine import DevicePack
+from .pack import pileup_depth_cap
 from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL, World
 
 _ALIGN = 256
@@ -79,7 +80,7 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
     n = int(rs.shape[0])
     if keep is None:
         flag = np.asarray(read_flag)
-        keep = np.ascontiguousarray((flag & (FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT)) == 0, np.uint8)
+        keep = pileup_depth_cap(read_start, read_end, np.ascontiguousarray((flag & (FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT)) == 0, np.uint8))
         strand = np.ascontiguousarray((flag & 0x10) != 0, np.uint8)
     else:
         keep = np.ascontiguousarray(keep, np.uint8)

@@ -99,3 +99,79 @@ def test_pack_many_reads_threaded_fill():
         cur += hi - lo
     assert cur + 16 == hp.codes.size and np.array_equal(hp.codes, exp)
     assert hp.tile_off[-1] == len(hp.tile_ent)
+
+
+def _plp_kept(starts0, ends0, maxcnt):
+    """Restatement of htslib's pileup buffer for ONE contig (bam_plp_push / bam_plp_next / bam_plp_auto, sam.c): which records
+    enter the buffer.  starts0 / ends0: 0-based start and exclusive end in file order.  The buffer is the list of nodes with a
+    dummy tail (the memory pool counts it: `cnt` = records held + 1)."""
+    nodes = []                      # held records (beg, end, index), list order = push order
+    pos, max_pos = 0, -1
+    kept = []
+    nxt, n = 0, len(starts0)
+    eof = False
+
+    def push(i):
+        nonlocal max_pos
+        b, e = starts0[i], ends0[i]
+        if pos == b and len(nodes) + 1 > maxcnt:
+            return
+        kept.append(i)
+        max_pos = b
+        if e > pos:
+            nodes.append((b, e, i))
+
+    while True:
+        # bam_plp_next: emit columns while the look-ahead record starts beyond the current column
+        progressed = False
+        while eof or max_pos > pos:
+            nodes[:] = [nd for nd in nodes if nd[1] > pos]              # release records that ended at or before this column
+            if nodes and pos < nodes[0][0]:
+                pos = nodes[0][0]
+            else:
+                pos += 1
+            progressed = True
+            if eof and not nodes:
+                return kept
+        if eof and not nodes:
+            return kept
+        if nxt < n:
+            push(nxt)
+            nxt += 1
+        else:
+            eof = True
+        if not progressed and eof and not nodes:
+            return kept
+
+
+def test_pileup_depth_cap_follows_the_htslib_buffer_rule():
+    """pack.pileup_depth_cap (what pysam's default max_depth = 8000 does to reads in very deep regions) against a restatement of
+    htslib's buffer logic, at small limits so that the rule triggers; below the limit nothing changes"""
+    from nanocaller_amd.pack import PILEUP_MAX_DEPTH, pileup_depth_cap
+    assert PILEUP_MAX_DEPTH == 8000
+    rng = np.random.Generator(np.random.PCG64(77))
+    n_dropped = 0
+    for case in range(30):
+        n = int(rng.integers(50, 400))
+        span = int(rng.integers(20, 300))
+        s0 = np.sort(rng.integers(0, span, size=n))
+        if case % 3 == 0:
+            s0 = np.sort(rng.choice(s0[: max(3, n // 10)], size=n))                 # many records per start position
+        e0 = s0 + rng.integers(1, 120, size=n)
+        flag_keep = (rng.random(n) < 0.9).astype(np.uint8)                          # records the flag filter removed never reach the buffer
+        for maxcnt in (3, 8, 25, 10_000):
+            idx = np.flatnonzero(flag_keep)
+            exp = np.zeros(n, np.uint8)
+            exp[idx[_plp_kept(s0[idx].tolist(), e0[idx].tolist(), maxcnt)]] = 1
+            got = pileup_depth_cap(s0 + 1, e0 + 1, flag_keep, max_depth=maxcnt)     # the package's arrays are 1-based
+            assert np.array_equal(got, exp), (case, maxcnt)
+            n_dropped += int(flag_keep.sum() - got.sum())
+            if maxcnt == 10_000:
+                assert np.array_equal(got, flag_keep)
+    assert n_dropped > 2000
+    # a pile of 9,000 records on one window: the first 8,000 that are held together stay, later ones starting at a column already
+    # at the limit go, a record that is the first of its start position always enters
+    s = np.concatenate([np.full(8500, 100), np.full(300, 101), [102], np.full(200, 5000)]).astype(np.int64)
+    e = s + 50
+    k = pileup_depth_cap(s, e, np.ones(s.size, np.uint8))
+    assert k[:8000].all() and not k[8000:8500].any() and k[8500] == 1 and not k[8501:8800].any() and k[8800] == 1 and k[8801:].all()
