@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path over one batch.  The unit of work is a chr20-sized contig (64,444,167 bp, ONT 30x,
 129 chunks of 500 kb -- BASELINE.json configs[1]) whose decoded alignments sit in PINNED HOST MEMORY (the
 timed region starts there, as the reference feeds every chunk from the host): transfer (reference-difference wire form,
-one PCIe copy per contig on its own stream, double-buffered against compute) -> expansion to the position-addressed codes
+one PCIe copy per contig on its own stream, a ring of three device slots) -> expansion to the position-addressed codes
 in HBM -> column scan -> neighbour selection -> (N,5,41,5) tensors -> coverage scale -> SNP CNN -> per-site results
 (pos, probs[4], gt[2], dp, alt, fwd_dp[4], rev_dp[4], ref) back in host memory.
 
@@ -386,7 +386,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
     chunks = get_chunks([("chr20", 1, L, args.ploidy)], cpu=16)      # 16 = the reference's documented example (--cpu 16)
     params = snp_params(args.model, args.tech)
-    uploader = WireUploader(eng)
+    uploader = WireUploader(eng, slots=int(os.environ.get("NC_UPLOAD_SLOTS", "3")))
     uploader.timing = True
 
     def barrier():
@@ -531,7 +531,7 @@ def main():
                           ("%d contigs per step sharded over %d GPUs in contiguous blocks (%d on rank 0)" % (job_contigs, world, len(mine))) if scaling == "strong"
                           else "1 contig per GPU per step"),
                        "timed_region": "HBM-resident packs (--resident)" if args.resident else
-                       "pinned host memory -> H2D (reference-difference wire form, own stream, double-buffered) -> expand -> scan -> tensors -> CNN -> results in pinned host memory",
+                       "pinned host memory -> H2D (reference-difference wire form, own stream, ring of three slots) -> expand -> scan -> tensors -> CNN -> results in pinned host memory",
                        "contigs_per_step": job_contigs if world > 1 else 1, "sites_per_contig": n_sites,
                        "pileup_entries_per_contig": c0.entries, "snp_weights": args.model,
                        "tensor_format": "int16 between featuriser and CNN (exact; fp32 with --cnn-precision fp32)", "generator": "synth_v1 seed 812+contig",
