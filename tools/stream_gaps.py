@@ -36,3 +36,12 @@ n_trunk = sum(1 for r in rows if r[2].startswith("k5_trunk")) / 3.0
 print("~%.0f contig passes: idle %.3f ms per pass" % (n_trunk, (span - busy) / 1e6 / max(n_trunk, 1)))
 for (a, b), g in gap.most_common(14):
     print("  %-40s -> %-40s %8.3f ms total, %6.1f us x %d" % (a, b, g / 1e6, g / 1e3 / cnt[(a, b)], cnt[(a, b)]))
+
+# per-kernel totals in the same window (blit kernels of the runtime's copies show up here: CU time beside the compute kernels)
+tot = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n_ in rows:
+    tot[n_][0] += 1
+    tot[n_][1] += e_ - s_
+print("kernel totals in the window:")
+for n_, (c_, t_) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:16]:
+    print("  %-44s x %5d  %9.3f ms total  %9.1f us avg" % (n_, c_, t_ / 1e6, t_ / 1e3 / c_))
