@@ -456,7 +456,9 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
                                int(window_after), int(dct["mincov"]), int(dct["maxcov"]), 1 if haploid else 0, _lib.npp(imp_idx),
                                _lib.npp(imp_off), _lib.npp(imp_reads), C.byref(h))
     if rc != _lib.NC_OK:
-        raise _lib.NanoCallerHipError("nc_indel_pass2_sets failed (%d)" % rc)
+        err = _lib.NanoCallerHipError("nc_indel_pass2_sets failed (%d)" % rc)
+        err.status = rc
+        raise err
     try:
         v = _lib.Pass2ArraysC()
         L.nc_pass2_view(h, C.byref(v))
@@ -498,6 +500,28 @@ def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False, dev
     chunks = list(chunks)
     if not chunks:
         return []
+    # A whole chromosome is hundreds of chunks and ~10^5 anchors: the read windows of all of them do not fit the native
+    # assembler's 1 GiB arrays.  Chunks are independent (a chunk's tuple is what the per-chunk call returns), so long lists go
+    # through in groups, and a group that still overflows is halved.
+    if len(chunks) > MAX_BATCH_CHUNKS:
+        out = []
+        for i in range(0, len(chunks), MAX_BATCH_CHUNKS):
+            out += get_indel_testing_candidates_batch(dct, chunks[i:i + MAX_BATCH_CHUNKS], device=device, haploid=haploid, device_x=device_x)
+        return out
+    try:
+        return _indel_batch(dct, chunks, device, haploid, device_x)
+    except _lib.NanoCallerHipError as e:
+        if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY or len(chunks) == 1:
+            raise
+    h = len(chunks) // 2
+    return (get_indel_testing_candidates_batch(dct, chunks[:h], device=device, haploid=haploid, device_x=device_x) +
+            get_indel_testing_candidates_batch(dct, chunks[h:], device=device, haploid=haploid, device_x=device_x))
+
+
+MAX_BATCH_CHUNKS = 64          # chunks per native pass-2 / alignment call (100 kb chunks at 30x: ~15 k anchors, ~150 MB of read windows)
+
+
+def _indel_batch(dct, chunks, device, haploid, device_x):
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
     window_after = 260 if dct["seq"] == "pacbio" else 160
     extras = [dict() for _ in chunks]

@@ -325,3 +325,42 @@ def test_skipping_repeated_alignments_changes_nothing(files, monkeypatch):
                     assert np.array_equal(np.asarray(a), b)
                 else:
                     assert list(a) == list(b)
+
+
+@pytest.mark.gpu
+def test_long_chunk_lists_go_through_in_groups(files, monkeypatch):
+    """a chromosome's worth of chunks exceeds the native pass-2 arrays: the batched featuriser splits the list (and halves a
+    group that still overflows); the per-chunk tuples are the same"""
+    from nanocaller_amd import _lib
+    w, bam, fa = files["a"]
+    dct = dict(seq="ont", win_size=40, small_win_size=4, mincov=2, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+               exclude_bed=None, impute_indel_phase=False, fasta_path=fa)
+    chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 3_000), sam_path=bam) for s in range(1, w.length, 3_000)]
+    assert len(chunks) >= 6
+    exp = gip.get_indel_testing_candidates_batch(dct, chunks)
+
+    def same(got):
+        assert len(got) == len(exp)
+        for t, e in zip(got, exp):
+            assert list(t[0]) == list(e[0])
+            for a, b in zip(t[1:], e[1:]):
+                if isinstance(b, np.ndarray):
+                    assert np.array_equal(np.asarray(a), b)
+                else:
+                    assert list(a) == list(b)
+    monkeypatch.setattr(gip, "MAX_BATCH_CHUNKS", 2)
+    same(gip.get_indel_testing_candidates_batch(dct, chunks))
+    # the native assembler reports NC_ERR_CAPACITY for more than two chunks at once: the list is halved until it fits
+    monkeypatch.setattr(gip, "MAX_BATCH_CHUNKS", 64)
+    inner, calls = gip._indel_batch, []
+
+    def limited(dct_, chunks_, *a):
+        calls.append(len(chunks_))
+        if len(chunks_) > 2:
+            err = _lib.NanoCallerHipError("nc_indel_pass2_sets failed (-2)")
+            err.status = _lib.NC_ERR_CAPACITY
+            raise err
+        return inner(dct_, chunks_, *a)
+    monkeypatch.setattr(gip, "_indel_batch", limited)
+    same(gip.get_indel_testing_candidates_batch(dct, chunks))
+    assert calls[0] == len(chunks) and max(calls[1:]) < len(chunks) and sum(c for c in calls if c <= 2) == len(chunks)
