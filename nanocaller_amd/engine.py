@@ -382,7 +382,8 @@ class Engine:
         flat_cns = cns[keep]
         if cns_as_str:
             big = np.frombuffer(b"AGTC-NNN", np.uint8)[flat_cns].tobytes().decode("ascii")
-            out_cns = [big[cut[k]:cut[k + 1]] for k in range(S)]
+            cl = cut.tolist()
+            out_cns = [big[a:b] for a, b in zip(cl, cl[1:])]
         else:
             out_cns = [flat_cns[cut[k]:cut[k + 1]] for k in range(S)]
         if not want_rows:

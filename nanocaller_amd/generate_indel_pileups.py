@@ -15,7 +15,9 @@
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import gc
 import os
 import subprocess
 
@@ -236,7 +238,8 @@ def allele_prediction_batch(alts, ref_seqs, max_ranges, eng=None):
         rc = L.nc_allele_prediction_batch(n, a_b, _lib.npp(aoff), r_b, _lib.npp(roff), _lib.npp(mr), _lib.npp(rl), _lib.npp(al))
     if rc != _lib.NC_OK:
         raise _lib.NanoCallerHipError("nc_allele_prediction_batch failed (%d)" % rc)
-    return [(None, None) if rl[i] < 0 else (ref_seqs[i][:rl[i]], alts[i][:al[i]]) for i in range(n)]
+    # plain ints: indexing numpy scalars and slicing with them costs ~2 us per pair, a third of the whole batch at 10^4 anchors
+    return [(None, None) if r < 0 else (rs[:r], a_[:a]) for rs, a_, r, a in zip(ref_seqs, alts, rl.tolist(), al.tolist())]
 
 
 def muscle_aligner(names, seqs, ref):
@@ -475,19 +478,21 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
         first0 = np.ctypeslib.as_array(C.cast(v.first0, C.POINTER(C.c_int32)), (nk,)).copy()
         ref_off = np.ctypeslib.as_array(C.cast(v.ref_off, C.POINTER(C.c_int32)), (ns + 1,))
         refs_all = C.string_at(v.refs, int(ref_off[ns])).decode("ascii")
-        refs = [refs_all[ref_off[k]:ref_off[k + 1]] for k in range(ns)]
+        ro = ref_off.tolist()                                       # plain ints: slicing with numpy scalars is ~1 us apiece
+        refs = [refs_all[a:b] for a, b in zip(ro, ro[1:])]
     finally:
         L.nc_pass2_free(h)
-    pos = [int(anchors[k]) for k in kept]
-    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[int(k) if by_index else int(anchors[k])]] for k in kept for _ in range(S)],
+    kept_l = kept.tolist()
+    pos = [int(anchors[k]) for k in kept_l]
+    preds = allele_prediction_batch(cns_str, refs, [max_range[variants[k if by_index else int(anchors[k])]] for k in kept_l for _ in range(S)],
                                     eng=eng)
     xh = x.view(nk, S, 5, 128, 2) if device_x else x.cpu().numpy().astype(np.float64).reshape(nk, S, 5, 128, 2)
-    tail = (kept.tolist(),) if by_index else ()
+    tail = (kept_l,) if by_index else ()
     if haploid:
         return (pos, xh[:, 0], preds) + tail
     hap, ps = dec["hap"], dec["ps"]
     alleles = [[preds[3 * k], preds[3 * k + 1], preds[3 * k + 2]] for k in range(nk)]
-    phase = [(int(ps[r]) if hap[r] else None) for r in first0]
+    phase = [(p if h else None) for h, p in zip(hap[first0].tolist(), ps[first0].tolist())]
     return (pos, xh[:, 0], xh[:, 1], xh[:, 2], alleles, phase) + tail
 
 
@@ -509,13 +514,29 @@ def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False, dev
             out += get_indel_testing_candidates_batch(dct, chunks[i:i + MAX_BATCH_CHUNKS], device=device, haploid=haploid, device_x=device_x)
         return out
     try:
-        return _indel_batch(dct, chunks, device, haploid, device_x)
+        with _gc_paused():
+            return _indel_batch(dct, chunks, device, haploid, device_x)
     except _lib.NanoCallerHipError as e:
         if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY or len(chunks) == 1:
             raise
     h = len(chunks) // 2
     return (get_indel_testing_candidates_batch(dct, chunks[:h], device=device, haploid=haploid, device_x=device_x) +
             get_indel_testing_candidates_batch(dct, chunks[h:], device=device, haploid=haploid, device_x=device_x))
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    """The batch builds ~10^5 result objects (tuples, strings) that all survive: every threshold they cross starts a
+    collection that finds nothing, and a full one walks the whole heap (measured: 53 ms of a 125 ms batch of 40 chunks went into
+    one generation-2 pass started from the allele list).  Collections are postponed to the end of the call."""
+    if os.environ.get("NC_KEEP_GC") or not gc.isenabled():
+        yield
+        return
+    gc.disable()
+    try:
+        yield
+    finally:
+        gc.enable()
 
 
 MAX_BATCH_CHUNKS = 64          # chunks per native pass-2 / alignment call (100 kb chunks at 30x: ~15 k anchors, ~150 MB of read windows)

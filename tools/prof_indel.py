@@ -19,6 +19,9 @@ params = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=4,
 chunks = [dict(chrom=w.chrom, start=s, end=min(Lw, s + 100_000), ploidy="diploid", sam_path=bam) for s in range(1, Lw, 100_000)]
 gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
+if os.environ.get("NO_GC"):
+    import gc
+    gc.disable()
 t = time.perf_counter()
 r = gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
