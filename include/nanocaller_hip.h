@@ -26,7 +26,7 @@ extern "C" {
 #define NC_ABI_VERSION 7   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
-                              6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file */
+                              6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -461,6 +461,11 @@ int nc_star_msa_tensor_dup(nc_ctx *ctx, int32_t n_sets, const char *reads, const
                            const char *refs, const int32_t *ref_off, int32_t open, int32_t extend, int32_t match, int32_t mismatch,
                            int32_t max_cols, float *x_dev, uint8_t *cns_host, int32_t *n_cols_host, uint8_t *rows_host,
                            const int64_t *rows_host_off, uint8_t *ref_rows_host, const int64_t *ref_rows_host_off, const int32_t *al_dup);
+
+/* The consensus rows of nc_star_msa_tensor[_dup] as the strings msa() returns (generate_indel_pileups.py:58-61: gap symbols
+ * removed; 0..3 -> AGTC, 5.. -> N): set s = out[off[s] .. off[s+1]), concatenated; `out` needs at most n_sets * max_cols bytes.
+ * Host code on the usable cores. */
+int nc_consensus_strings(const uint8_t *cns, int32_t n_sets, int32_t max_cols, const int32_t *n_cols, char *out, int64_t *off);
 
 /* ------------------------------------------------------------------ SNP genotype rules + VCF record text (host)
  * Replaces the per-site Python loop of snpCaller.caller (snpCaller.py:113-198).  probs f32 [n][4]

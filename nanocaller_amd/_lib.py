@@ -35,7 +35,7 @@ EXPORTS = [
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
-    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_star_msa_tensor_dup", "nc_set_tensor_format", "nc_allele_prediction_batch", "nc_allele_prediction_device", "nc_bgzf_read_file",
+    "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_star_msa_tensor_dup", "nc_set_tensor_format", "nc_allele_prediction_batch", "nc_allele_prediction_device", "nc_bgzf_read_file", "nc_consensus_strings",
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
 ]
@@ -155,6 +155,7 @@ def lib():
         L.nc_bam_decode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp)]
         L.nc_star_msa_tensor.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.nc_star_msa_tensor_dup.argtypes = L.nc_star_msa_tensor.argtypes + [vp]
+        L.nc_consensus_strings.argtypes = [vp, i32, i32, vp, vp, vp]
         L.nc_allele_prediction_batch.argtypes = [i32, C.c_char_p, vp, C.c_char_p, vp, vp, vp, vp]
         L.nc_allele_prediction_device.argtypes = [vp, i32, C.c_char_p, vp, C.c_char_p, vp, vp, vp, vp]
         L.nc_set_tensor_format.argtypes = [vp, C.c_int]

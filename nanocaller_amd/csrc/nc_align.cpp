@@ -262,3 +262,46 @@ extern "C" int nc_allele_prediction_batch(int32_t n, const char *alts, const int
     for (int r : rc) if (r != NC_OK) return r;
     return NC_OK;
 }
+
+// Consensus rows of nc_star_msa_tensor (cns [n_sets][max_cols]: symbols 0..3 = AGTC, 4 = gap, 5.. = other, the first
+// min(n_cols[s], max_cols) of a row valid) -> the strings msa() hands to allele_prediction (generate_indel_pileups.py:58-61: the
+// consensus with the gap symbols removed), concatenated in `out` (capacity n_sets * max_cols suffices) with off[s] .. off[s + 1]
+// delimiting set s.  On the usable host cores: a contig arm's consensus matrix is tens of megabytes.
+extern "C" int nc_consensus_strings(const uint8_t *cns, int32_t n_sets, int32_t max_cols, const int32_t *n_cols, char *out, int64_t *off)
+{
+    if (n_sets < 0 || max_cols < 1 || (n_sets && (!cns || !n_cols || !out)) || !off) return NC_ERR_ARG;
+    off[0] = 0;
+    if (n_sets == 0) return NC_OK;
+    int T = nc_host_cpus();
+    if (T > 16) T = 16;
+    if (T > n_sets / 256) T = n_sets / 256;
+    if (T < 1) T = 1;
+    auto each = [&](auto &&fn) {
+        if (T == 1) { fn(0, n_sets); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] { fn((int32_t)((int64_t)n_sets * t / T), (int32_t)((int64_t)n_sets * (t + 1) / T)); });
+        for (auto &x : th) x.join();
+    };
+    each([&](int32_t s0, int32_t s1) {
+        for (int32_t s = s0; s < s1; s++) {
+            const uint8_t *row = cns + (size_t)s * max_cols;
+            const int32_t n = std::min(std::max(n_cols[s], 0), max_cols);
+            int64_t k = 0;
+            for (int32_t c = 0; c < n; c++) k += row[c] != 4;
+            off[s + 1] = k;
+        }
+    });
+    for (int32_t s = 0; s < n_sets; s++) off[s + 1] += off[s];
+    static const char LET[8] = {'A', 'G', 'T', 'C', '-', 'N', 'N', 'N'};
+    each([&](int32_t s0, int32_t s1) {
+        for (int32_t s = s0; s < s1; s++) {
+            const uint8_t *row = cns + (size_t)s * max_cols;
+            const int32_t n = std::min(std::max(n_cols[s], 0), max_cols);
+            char *d = out + off[s];
+            for (int32_t c = 0; c < n; c++)
+                if (row[c] != 4) *d++ = LET[row[c] & 7];
+        }
+    });
+    return NC_OK;
+}

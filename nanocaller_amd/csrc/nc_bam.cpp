@@ -858,8 +858,8 @@ int nc_indel_slices(const nc_decoded *d, int32_t n_anchor, const int32_t *anchor
 // in pileup order: the deterministic stand-in for the unseeded random.sample of :19-20), the mincov tests (:48, :345), and the
 // flat arrays nc_star_msa_tensor takes.
 struct nc_pass2 {
-    std::vector<int32_t> anchor_idx, first0, set_read0, read_off, ref_off, al_dup;
-    std::vector<char> reads, refs;
+    bigvec<int32_t> anchor_idx, first0, set_read0, read_off, ref_off, al_dup;
+    bigvec<char> reads, refs;                                              // (no zero fill when the merged arrays are sized)
     int32_t sets_per_anchor = 3, max_cols = 1;
 };
 
@@ -881,6 +881,8 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
         po->set_read0.push_back(0);
         po->read_off.push_back(0);
         po->ref_off.push_back(0);
+        // address space for the usual case (~60 windows per anchor): the vector does not move while it grows, untouched pages cost nothing
+        try { po->reads.reserve(std::min<size_t>((size_t)(a_hi - a_lo) * 64 * (size_t)window_after, (size_t)1 << 30)); } catch (const std::bad_alloc &) {}
         int32_t first = 0;
         std::vector<int32_t> cov;                                          // reads in the pileup at the anchor
         std::vector<int32_t> side0, side1;
@@ -986,23 +988,46 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
         for (auto &x : th) x.join();
         for (int rc : rcs)
             if (rc != NC_OK) { delete o; return rc; }
+        // the merged arrays are sized once and every worker copies its own part to its place (the read windows of a chromosome
+        // arm are ~100 MB: one thread appending them costs more than assembling them did)
         try {
-            o->set_read0.push_back(0);
-            o->read_off.push_back(0);
-            o->ref_off.push_back(0);
-            for (auto &pp : part) {
-                const int32_t b_al = (int32_t)o->read_off.size() - 1, b_rb = (int32_t)o->reads.size(), b_fb = (int32_t)o->refs.size();
-                if ((size_t)b_rb + pp.reads.size() > ((size_t)1 << 30) || (size_t)b_fb + pp.refs.size() > ((size_t)1 << 30)) { delete o; return NC_ERR_CAPACITY; }
-                o->anchor_idx.insert(o->anchor_idx.end(), pp.anchor_idx.begin(), pp.anchor_idx.end());
-                o->first0.insert(o->first0.end(), pp.first0.begin(), pp.first0.end());
-                for (size_t k = 1; k < pp.set_read0.size(); k++) o->set_read0.push_back(pp.set_read0[k] + b_al);
-                for (size_t k = 1; k < pp.read_off.size(); k++) o->read_off.push_back(pp.read_off[k] + b_rb);
-                for (int32_t v : pp.al_dup) o->al_dup.push_back(v < 0 ? -1 : v + b_al);
-                for (size_t k = 1; k < pp.ref_off.size(); k++) o->ref_off.push_back(pp.ref_off[k] + b_fb);
-                o->reads.insert(o->reads.end(), pp.reads.begin(), pp.reads.end());
-                o->refs.insert(o->refs.end(), pp.refs.begin(), pp.refs.end());
+            std::vector<size_t> b_k((size_t)T + 1, 0), b_s((size_t)T + 1, 0), b_al((size_t)T + 1, 0), b_rb((size_t)T + 1, 0), b_fb((size_t)T + 1, 0);
+            for (int t = 0; t < T; t++) {
+                const nc_pass2 &pp = part[(size_t)t];
+                b_k[(size_t)t + 1] = b_k[(size_t)t] + pp.anchor_idx.size();
+                b_s[(size_t)t + 1] = b_s[(size_t)t] + pp.set_read0.size() - 1;
+                b_al[(size_t)t + 1] = b_al[(size_t)t] + pp.read_off.size() - 1;
+                b_rb[(size_t)t + 1] = b_rb[(size_t)t] + pp.reads.size();
+                b_fb[(size_t)t + 1] = b_fb[(size_t)t] + pp.refs.size();
                 o->max_cols = std::max(o->max_cols, pp.max_cols);
             }
+            if (b_rb[(size_t)T] > ((size_t)1 << 30) || b_fb[(size_t)T] > ((size_t)1 << 30)) { delete o; return NC_ERR_CAPACITY; }
+            o->anchor_idx.resize(b_k[(size_t)T]);
+            o->first0.resize(b_k[(size_t)T]);
+            o->set_read0.resize(b_s[(size_t)T] + 1);
+            o->ref_off.resize(b_s[(size_t)T] + 1);
+            o->read_off.resize(b_al[(size_t)T] + 1);
+            o->al_dup.resize(b_al[(size_t)T]);
+            o->reads.resize(b_rb[(size_t)T]);
+            o->refs.resize(b_fb[(size_t)T]);
+            o->set_read0[0] = 0;
+            o->read_off[0] = 0;
+            o->ref_off[0] = 0;
+            std::vector<std::thread> tc;
+            for (int t = 0; t < T; t++)
+                tc.emplace_back([&, t] {
+                    const nc_pass2 &pp = part[(size_t)t];
+                    const size_t k0 = b_k[(size_t)t], s0 = b_s[(size_t)t], a0 = b_al[(size_t)t], r0 = b_rb[(size_t)t], f0 = b_fb[(size_t)t];
+                    std::copy(pp.anchor_idx.begin(), pp.anchor_idx.end(), o->anchor_idx.begin() + (ptrdiff_t)k0);
+                    std::copy(pp.first0.begin(), pp.first0.end(), o->first0.begin() + (ptrdiff_t)k0);
+                    for (size_t k = 1; k < pp.set_read0.size(); k++) o->set_read0[s0 + k] = pp.set_read0[k] + (int32_t)a0;
+                    for (size_t k = 1; k < pp.ref_off.size(); k++) o->ref_off[s0 + k] = pp.ref_off[k] + (int32_t)f0;
+                    for (size_t k = 1; k < pp.read_off.size(); k++) o->read_off[a0 + k] = pp.read_off[k] + (int32_t)r0;
+                    for (size_t k = 0; k < pp.al_dup.size(); k++) o->al_dup[a0 + k] = pp.al_dup[k] < 0 ? -1 : pp.al_dup[k] + (int32_t)a0;
+                    if (!pp.reads.empty()) memcpy(o->reads.data() + r0, pp.reads.data(), pp.reads.size());
+                    if (!pp.refs.empty()) memcpy(o->refs.data() + f0, pp.refs.data(), pp.refs.size());
+                });
+            for (auto &x : tc) x.join();
         } catch (const std::bad_alloc &) {
             delete o;
             return NC_ERR_NOMEM;

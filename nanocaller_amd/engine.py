@@ -374,17 +374,21 @@ class Engine:
             # the caller's column bound was an estimate (consensus columns beyond it are cut): once more with the real maximum
             return self.star_msa_tensor_flat(S, reads, read_off, set_read0, refs, ref_off, int(ncols.max()), open_=open_, extend=extend,
                                              match=match, mismatch=mismatch, cns_as_str=cns_as_str, al_dup=al_dup)
-        # consensus with the gap symbols removed: one pass over the [S, mc] block instead of S small array operations
-        keep = (np.arange(mc, dtype=np.int32)[None, :] < np.minimum(ncols, mc)[:, None]) & (cns != 4)
-        cnt = keep.sum(1)
-        cut = np.zeros(S + 1, np.int64)
-        np.cumsum(cnt, out=cut[1:])
-        flat_cns = cns[keep]
+        # consensus with the gap symbols removed
         if cns_as_str:
-            big = np.frombuffer(b"AGTC-NNN", np.uint8)[flat_cns].tobytes().decode("ascii")
+            # natively (worker threads): the [S, mc] matrix of a contig arm is tens of megabytes, numpy masks over it cost more than the alignments
+            cut = np.empty(S + 1, np.int64)
+            flat = np.empty(max(S * mc, 1), np.uint8)
+            self._check(self.L.nc_consensus_strings(_lib.npp(cns), S, mc, _lib.npp(ncols), _lib.npp(flat), _lib.npp(cut)), "nc_consensus_strings")
             cl = cut.tolist()
+            big = flat[:cl[-1]].tobytes().decode("ascii")
             out_cns = [big[a:b] for a, b in zip(cl, cl[1:])]
         else:
+            keep = (np.arange(mc, dtype=np.int32)[None, :] < np.minimum(ncols, mc)[:, None]) & (cns != 4)
+            cnt = keep.sum(1)
+            cut = np.zeros(S + 1, np.int64)
+            np.cumsum(cnt, out=cut[1:])
+            flat_cns = cns[keep]
             out_cns = [flat_cns[cut[k]:cut[k + 1]] for k in range(S)]
         if not want_rows:
             return x, out_cns, ncols

@@ -663,3 +663,24 @@ def test_device_allele_prediction_equals_the_host_version():
     dev = gip.allele_prediction_batch(alts, refs, mrs, eng=eng)
     assert len(alts) > 3500 and host == dev
     assert sum(1 for h in host if h != (None, None) and len(h[0]) != len(h[1])) > 500       # indel alleles are exercised
+
+
+def test_native_consensus_strings_equal_the_numpy_statement():
+    """nc_consensus_strings (host threads) against the mask-and-gather it replaces: gaps (4) removed, columns beyond n_cols and
+    beyond max_cols ignored, 0..3 -> AGTC, other symbols -> N; single- and multi-threaded sizes, empty rows"""
+    import ctypes as C
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(9))
+    for S, mc in ((0, 7), (1, 1), (5, 40), (3000, 97)):
+        cns = rng.choice(np.array([0, 1, 2, 3, 4, 4, 5, 255], np.uint8), size=(S, mc)).astype(np.uint8)
+        ncols = rng.integers(0, mc + 30, size=S).astype(np.int32)
+        if S > 2:
+            ncols[1] = 0
+        out, off = np.full(max(S * mc, 1), ord("?"), np.uint8), np.full(S + 1, -1, np.int64)
+        assert L.nc_consensus_strings(_lib.npp(cns) if S else None, S, mc, _lib.npp(ncols) if S else None, _lib.npp(out), _lib.npp(off)) == _lib.NC_OK
+        keep = (np.arange(mc)[None, :] < np.minimum(ncols, mc)[:, None]) & (cns != 4)
+        lut = np.frombuffer(b"AGTC-NNN", np.uint8)
+        exp = [lut[cns[s][keep[s]] & 7].tobytes().decode() for s in range(S)]
+        got = [out[off[s]:off[s + 1]].tobytes().decode() for s in range(S)]
+        assert off[0] == 0 and got == exp
+    assert L.nc_consensus_strings(None, 3, 5, None, None, None) == -1                 # NC_ERR_ARG
