@@ -15,6 +15,7 @@
 """
 from __future__ import annotations
 
+import bisect
 import contextlib
 import ctypes as C
 import gc
@@ -38,11 +39,17 @@ def pick_variants(col_type, start, win_size, groups=None, extra=None):
     prev = 0
     lo = max(1, int(start))
     idx = np.nonzero(col_type >= 0)[0]
-    # plain Python ints: a flagged region is hundreds of consecutive columns, almost all skipped by `v <= prev`
-    for c, t in zip(idx.tolist(), col_type[idx].tolist()):
-        v = lo + c
+    # plain Python ints; a flagged region is hundreds of consecutive columns, almost all skipped by `v <= prev`: the skip is a
+    # bisection over the (ascending) column list instead of a walk
+    cols, types = idx.tolist(), col_type[idx].tolist()
+    i, n = 0, len(cols)
+    while i < n:
+        v = lo + cols[i]
         if v <= prev:
+            i = bisect.bisect_right(cols, prev - lo, i + 1)
             continue
+        t = types[i]
+        i += 1
         if t == 0:
             prev = v + win_size
             variants[max(1, v - win_size)] = 0                      # :267-268
