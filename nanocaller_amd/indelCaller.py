@@ -36,26 +36,33 @@ def indel_vcf_lines(chrom, pos, probs, alleles_seq, phase, prev=0):
     """Diploid rules (indelCaller.py:87-152).  probs float32 [N,4] (hom-ref, hom-alt, het-ref, het-alt);
     alleles_seq[j] = [(ref0, alt0), (ref1, alt1), (ref_total, alt_total)], entries may be (None, None);
     phase[j] = phase-set id or None.  -> (lines, prev) where prev carries the overlap suppression across batches."""
-    probs = np.asarray(probs, np.float32)
-    pred = np.argmax(probs, axis=1)
+    probs = np.asarray(probs, np.float32).reshape(len(pos), -1)
+    if len(pos) == 0:
+        return [], prev
+    # the float32 arithmetic of :95-97 and of the GQ terms for the whole batch at once (the same ufunc loops as the scalar
+    # expressions: identical values), then plain Python numbers in the per-site rules
+    pred = np.argmax(probs, axis=1).tolist()
+    passes = (probs[:, 0] <= 0.95).tolist()                          # :95
+    qs = _q10(_F(1e-6) + probs[:, 0]).tolist()                       # :97
+    one = _F(1 + 1e-6)
+    gq1, gq2, gq3 = _q10(one - probs[:, 1]).tolist(), _q10(one - probs[:, 2]).tolist(), _q10(one - probs[:, 3]).tolist()
+    pos = pos.tolist() if isinstance(pos, np.ndarray) else pos
     out = []
     for j in range(len(pos)):
-        if not pos[j] > prev:
+        pj = pos[j]
+        if not pj > prev:
             continue
-        p = probs[j]
-        if not p[0] <= 0.95:                                         # :95
+        if not passes[j]:
             continue
-        q = _q10(_F(1e-6) + p[0])                                    # :97
+        q = qs[j]
         a0, a1, at = alleles_seq[j]
         if pred[j] == 1 and at[0]:                                   # :100
-            gq = _q10(_F(1 + 1e-6) - p[1])
-            out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t1/1:%.2f\n' % (chrom, pos[j], at[0], at[1], q, gq))
-            prev = pos[j] + max(len(at[0]), len(at[1]))
+            out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t1/1:%.2f\n' % (chrom, pj, at[0], at[1], q, gq1[j]))
+            prev = pj + max(len(at[0]), len(at[1]))
         elif a0[0] and a1[0]:
             if a0[0] == a1[0] and a0[1] == a1[1]:                     # :109
-                gq = _q10(_F(1 + 1e-6) - p[1])
-                out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t1/1:%.2f\n' % (chrom, pos[j], a0[0], a0[1], q, gq))
-                prev = pos[j] + max(len(a0[0]), len(a0[1]))
+                out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t1/1:%.2f\n' % (chrom, pj, a0[0], a0[1], q, gq1[j]))
+                prev = pj + max(len(a0[0]), len(a0[1]))
             else:                                                    # :115-133 het-alt, alleles padded to one REF
                 ref1, alt1 = a0
                 ref2, alt2 = a1
@@ -66,20 +73,18 @@ def indel_vcf_lines(chrom, pos, probs, alleles_seq, phase, prev=0):
                 else:
                     ref = ref2
                     alt1 = alt1 + ref2[ln:]
-                gq = _q10(_F(1 + 1e-6) - p[3])
                 if phase[j]:
-                    out.append('%s\t%d\t.\t%s\t%s,%s\t%.2f\tPASS\t.\tGT:GQ:PS\t1|2:%.2f:%d\n' % (chrom, pos[j], ref, alt1, alt2, q, gq, phase[j]))
+                    out.append('%s\t%d\t.\t%s\t%s,%s\t%.2f\tPASS\t.\tGT:GQ:PS\t1|2:%.2f:%d\n' % (chrom, pj, ref, alt1, alt2, q, gq3[j], phase[j]))
                 else:
-                    out.append('%s\t%d\t.\t%s\t%s,%s\t%.2f\tPASS\t.\tGT:GQ\t1|2:%.2f\n' % (chrom, pos[j], ref, alt1, alt2, q, gq))
-                prev = pos[j] + max(len(ref), len(alt1), len(alt2))
+                    out.append('%s\t%d\t.\t%s\t%s,%s\t%.2f\tPASS\t.\tGT:GQ\t1|2:%.2f\n' % (chrom, pj, ref, alt1, alt2, q, gq3[j]))
+                prev = pj + max(len(ref), len(alt1), len(alt2))
         elif a0[0] or a1[0]:                                         # :135-151
             a, gt = (a0, '0|1') if a0[0] else (a1, '1|0')
-            gq = _q10(_F(1 + 1e-6) - p[2])
             if phase[j]:
-                out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ:PS\t%s:%.2f:%d\n' % (chrom, pos[j], a[0], a[1], q, gt, gq, phase[j]))
+                out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ:PS\t%s:%.2f:%d\n' % (chrom, pj, a[0], a[1], q, gt, gq2[j], phase[j]))
             else:
-                out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t%s:%.2f\n' % (chrom, pos[j], a[0], a[1], q, gt, gq))
-            prev = pos[j] + max(len(a[0]), len(a[1]))
+                out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t%s:%.2f\n' % (chrom, pj, a[0], a[1], q, gt, gq2[j]))
+            prev = pj + max(len(a[0]), len(a[1]))
     return out, prev
 
 
