@@ -31,4 +31,4 @@ pr.enable()
 gip.get_indel_testing_candidates_batch(params, chunks, device_x=True)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(40)
+pstats.Stats(pr).sort_stats(os.environ.get("SORT", "tottime")).print_stats(40)
