@@ -91,12 +91,17 @@ def indel_vcf_lines(chrom, pos, probs, alleles_seq, phase, prev=0):
 def indel_vcf_lines_haploid(chrom, pos, probs, alleles_seq, prev=0):
     """Haploid rules (indelCaller.py:173-179).  probs float32 [N,1] sigmoid; alleles_seq[j] = (ref, alt)."""
     probs = np.asarray(probs, np.float32).reshape(len(pos), -1)
+    if len(pos) == 0:
+        return [], prev
+    called = (probs[:, 0] >= 0.5).tolist()
+    with np.errstate(divide="ignore", invalid="ignore"):                # rows below 0.5 are not used
+        qs = (_F(-100) * np.log10(_F(1e-6 + 1) - probs[:, 0])).tolist()
+    pos = pos.tolist() if isinstance(pos, np.ndarray) else pos
     out = []
     for j in range(len(pos)):
         at = alleles_seq[j]
-        pj = probs[j, 0]
-        if pos[j] > prev and pj >= 0.5 and at[0]:
-            q = _F(-100) * np.log10(_F(1e-6 + 1) - pj)
+        if pos[j] > prev and called[j] and at[0]:
+            q = qs[j]
             out.append('%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t1/1:%.2f\n' % (chrom, pos[j], at[0], at[1], q, q))
             prev = pos[j] + max(len(at[0]), len(at[1]))
     return out, prev
