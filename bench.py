@@ -572,9 +572,9 @@ def main():
             torch.cuda.empty_cache()
             extra = {}
             try:
-                extra["hifi60x_haploid"] = extra_snp_config(eng, uploader, local, L, 60.0, "hifi", "CCS-HG002", "haploid", False, 3,
+                extra["hifi60x_haploid"] = extra_snp_config(eng, uploader, local, L, 60.0, "hifi", "CCS-HG002", "haploid", False, 12,
                                                             "SNP-only pileup+CNN, HiFi 60x haploid model (--haploid_genome), pacbio neighbour buckets, chr20-sized contig")
-                extra["exact_fp32_trunk"] = extra_snp_config(eng, uploader, local, L, args.depth, args.tech, args.model, args.ploidy, True, 3,
+                extra["exact_fp32_trunk"] = extra_snp_config(eng, uploader, local, L, args.depth, args.tech, args.model, args.ploidy, True, 8,
                                                              "headline workload with the exact fp32 MFMA trunk (k4_conv12) on float32 tensors")
                 extra["indel_pipeline"] = extra_indel_config(eng, local)
             except Exception as e:                                  # an extra must never take the headline line down
