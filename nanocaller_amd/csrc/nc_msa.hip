@@ -570,8 +570,9 @@ extern "C" int nc_star_msa_tensor_dup(nc_ctx *ctx, int32_t n_sets, const char *r
         // duplicates (register kernel only): launch-local source index per alignment, and the list of alignments to compute
         const int32_t *dup_dev = nullptr, *uniq_dev = nullptr;
         int32_t n_uniq = Ag;
+        std::vector<int32_t> dl, ul;                              // copy sources: alive until this group's closing synchronisation
         if (al_dup && fast && Ag > 0) {
-            std::vector<int32_t> dl((size_t)Ag), ul;                                          // pageable sources: staged before the copy call returns
+            dl.resize((size_t)Ag);
             ul.reserve((size_t)Ag);
             for (int32_t r = 0; r < Ag; r++) {
                 const int32_t b = al_dup[a0 + r];
