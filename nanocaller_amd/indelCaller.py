@@ -266,9 +266,10 @@ def phase_run(contig_dict, params, indel_dict, job_Q, counter_Q, phased_snp_file
             run_cmd("whatshap phase %s %s -o %s -r %s --ignore-read-groups --chromosome %s %s" % (
                 unph, sam_path, raw, params['fasta_path'], contig, extra), verbose=params.get('verbose'))
             if os.path.exists(raw):
-                _, ph = vcfio.read_vcf_gz(raw)
+                # WhatsHap's own header goes with its records (`bcftools view` keeps it, :239): it declares the PS FORMAT key
+                ph_hdr, ph = vcfio.read_vcf_gz(raw)
                 hi = [ln for ln in ph if ln.rstrip('\n').split('\t')[9].split(':')[0] not in ('0/0', '0|0')]   # -e 'GT="0\\0"' (:239)
-                vcfio.write_sorted_vcf(out_vcf, header, hi, [contig])
+                vcfio.write_sorted_vcf(out_vcf, _with_phase_format(''.join(ph_hdr) or header), hi, [contig])
                 tagged = os.path.join(phase_dir, '%s.phased.bam' % contig)
                 run_cmd("whatshap haplotag --ignore-read-groups --ignore-linked-read --reference %s %s %s --regions %s:%d-%d "
                         "--tag-supplementary -o - | samtools view -b -1 --write-index -o %s" % (
@@ -287,6 +288,17 @@ def phase_run(contig_dict, params, indel_dict, job_Q, counter_Q, phased_snp_file
             chunk['sam_path'] = sam_path                                       # :258
             job_Q.put(('indel', chunk))
         indel_dict.pop(contig, None)
+
+
+PS_FORMAT_LINE = '##FORMAT=<ID=PS,Number=1,Type=Integer,Description="Phase set identifier">\n'
+
+
+def _with_phase_format(header):
+    """`header` with the PS FORMAT declaration WhatsHap's phased records use (GT:...:PS), added before #CHROM when missing"""
+    if '##FORMAT=<ID=PS,' in header:
+        return header
+    lines = header.rstrip('\n').split('\n')
+    return '\n'.join(lines[:-1] + [PS_FORMAT_LINE.rstrip('\n')] + lines[-1:]) + '\n'
 
 
 def caller(params, job_Q, counter_Q, indel_dict, phased_snp_files_list, indel_files_list, device=0, worker_id=1, aligner=None):
@@ -385,10 +397,14 @@ def call_manager(params, devices=None, aligner=None):
     if output_files['snps']:                                                   # bcftools concat -a of the per-contig files (:360-366)
         for fn in phased_snp_files_list:
             h, r = vcfio.read_vcf_gz(fn)
-            snp_hdr = snp_hdr or ''.join(h)
+            h = ''.join(h)
+            if snp_hdr is None or ('##FORMAT=<ID=PS,' in h and '##FORMAT=<ID=PS,' not in snp_hdr):
+                snp_hdr = h                                                     # a WhatsHap-phased contig's header declares PS
             snp_recs += r
         if snp_hdr is None:
             snp_hdr = ''.join(vcfio.read_vcf_gz(params['snp_vcf'])[0])
+        if any('PS' in ln.split('\t', 9)[8].split(':') for ln in snp_recs):
+            snp_hdr = _with_phase_format(snp_hdr)
         vcfio.write_sorted_vcf(output_files['snps'], snp_hdr, snp_recs, contigs)
     indel_recs = []
     if output_files['indels']:
