@@ -23,10 +23,12 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 7   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+#define NC_ABI_VERSION 8   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
-                              6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings */
+                              6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
+                              8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
+                                 nc_decoded_check, NC_ERR_RANGE + nc_cnn_range_hits, nc_synth_indel_contig */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -37,7 +39,9 @@ enum nc_status {
     NC_ERR_NOMEM = -3,     /* host or device allocation failed */
     NC_ERR_HIP = -4,       /* HIP runtime error (message in nc_last_error) */
     NC_ERR_STATE = -5,     /* call order violated (e.g. featurize before scan, weights not loaded) */
-    NC_ERR_SELFTEST = -6   /* device self-test failed at context creation */
+    NC_ERR_SELFTEST = -6,  /* device self-test failed at context creation */
+    NC_ERR_UNSUPPORTED = -7, /* input the library does not reproduce (reference skips, same-name reads in one column): nc_decoded_check */
+    NC_ERR_RANGE = -8      /* an activation left the range of the split-precision CNN kernels (nc_cnn_range_hits) */
 };
 
 enum nc_model_kind { NC_MODEL_SNP = 0, NC_MODEL_SNP_HAP = 1, NC_MODEL_INDEL = 2, NC_MODEL_INDEL_HAP = 3 };
@@ -359,6 +363,14 @@ int nc_bam_decode_regions(const char *path, int32_t tid, int32_t beg1, int32_t e
                           nc_decoded **out);
 int nc_decoded_view(const nc_decoded *d, nc_decoded_arrays *view);
 int nc_decoded_free(nc_decoded *d);
+/* Bit set in nc_decoded_arrays.flag (above the 16 BAM flag bits) for an alignment whose CIGAR holds a reference skip (N). */
+#define NC_FLAG_REFSKIP 0x10000
+/* Inputs the library does not reproduce, reported instead of silently accepted: kept (keep[r] != 0,
+ * NULL = all) alignments with a reference skip -- the reference's code table raises KeyError on their '>' / '<' pileup symbols
+ * (generate_SNP_pileups.py:104,175) -- and pairs of kept alignments with the same read name that overlap on the reference -- the
+ * reference's per-column dicts are keyed by name (:175,185,208), the read-major pack keeps them apart.  Returns NC_ERR_UNSUPPORTED
+ * when either count is non-zero, NC_OK otherwise. */
+int nc_decoded_check(const nc_decoded *d, const uint8_t *keep, int64_t *n_refskip, int64_t *n_dup_overlap);
 
 /* ------------------------------------------------------------------ indel pass 2, host side
  * nc_indel_slices replaces the per-read loop of generate_indel_pileups.py:329-338 at the anchor columns chosen by pass 1:
@@ -411,6 +423,93 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
                         int32_t haploid, const int32_t *imp_idx, const int32_t *imp_off, const int32_t *imp_reads, nc_pass2 **out);
 int nc_pass2_view(const nc_pass2 *p, nc_pass2_arrays *view);
 int nc_pass2_free(nc_pass2 *p);
+
+
+/* ------------------------------------------------------------------ indel path, device resident
+ * The whole of get_indel_testing_candidates (generate_indel_pileups.py:129-371; haploid generate_indel_pileups_haploid.py) for
+ * every chunk of a contig without the host in the loop: pass 1 (nc_indel_scan_batch's kernels), the order-dependent anchor
+ * selection (:249,266-275), the read sets of pass 2 (:306-348) taken from the read pack's tile index, the query windows
+ * (:331) rebuilt from the position-addressed codes + the indel events + the bases that have no reference column, the star
+ * alignment (nc_star_msa_tensor_dup's algorithm: same recurrences and tie rules), msa()'s histogram / consensus / tensor
+ * (:57-71) and allele_prediction (:77-127).  Results equal nc_indel_pass2_sets -> nc_star_msa_tensor_dup ->
+ * nc_allele_prediction_device on the same inputs.  dct['impute_indel_phase'] is not covered (its read grouping needs the
+ * pileup strings): callers use the host route for it.
+ *
+ * nc_indel_pack_build (host): the per-read arrays of the KEPT reads in pack order, from a decoded contig (keep_seq != 0):
+ * events / HP / PS, the inserted bases of every insertion event (ins_off [n_events + 1] into ins_bases; deletions own empty
+ * ranges), and up to `tail_cap` query bases following the last aligned one (trailing soft clip; tail_off [n_reads + 1]):
+ * query_sequence[q : q + window] runs into them near a read's end.  Bases are codes A0 G1 T2 C3 other 4.  read_flag bit 0: a
+ * record without bases (SEQ '*'): its windows are empty. */
+typedef struct nc_indel_pack_h nc_indel_pack_h;
+typedef struct {
+    int32_t n_reads;
+    const int32_t *ev_off;     /* [n_reads + 1] */
+    const int32_t *ev_pos, *ev_len;
+    int64_t n_events;
+    const int32_t *ins_off;    /* [n_events + 1] */
+    const uint8_t *ins_bases;
+    int64_t n_ins_bases;
+    const int32_t *tail_off;   /* [n_reads + 1] */
+    const uint8_t *tail_bases;
+    int64_t n_tail_bases;
+    const int32_t *read_ps;    /* [n_reads] PS tag or 0 */
+    const uint8_t *read_hap;   /* [n_reads] HP tag 0 / 1 / 2 */
+    const uint8_t *read_flag;  /* [n_reads] */
+} nc_indel_pack_arrays;
+int nc_indel_pack_build(const nc_decoded *d, const uint8_t *keep, int32_t tail_cap, nc_indel_pack_h **out);
+int nc_indel_pack_view(const nc_indel_pack_h *p, nc_indel_pack_arrays *view);
+int nc_indel_pack_free(nc_indel_pack_h *p);
+
+/* The same arrays in HBM (+ what maps a tile entry to its read: slot_off / rd_start of the wire pack, nc_wire_arrays) */
+typedef struct {
+    int32_t n_reads;
+    const int64_t *slot_off;   /* dev [n_reads + 1] */
+    const int32_t *rd_start;   /* dev [n_reads] */
+    const int32_t *rd_end;     /* dev [n_reads] */
+    const int32_t *ev_off, *ev_pos, *ev_len;
+    const int32_t *ins_off;
+    const uint8_t *ins_bases;
+    const int32_t *tail_off;
+    const uint8_t *tail_bases;
+    const int32_t *read_ps;
+    const uint8_t *read_hap, *read_flag;
+} nc_indel_reads;
+
+/* Step 1: pass 1 + anchor selection + read sets of all chunks (ascending, one contig) -> *n_sites candidate sites that reach
+ * the CNN (chunk-major, ascending position inside a chunk; an anchor shared by two chunks appears once per chunk, like
+ * the reference's per-chunk calls), *n_alignments read windows to align.  ref_code as nc_snp_scan (4 = not an upper-case
+ * AGTC: an anchor whose window [p, p + window_after] touches one is skipped, :325-327; exclusions must NOT be folded in);
+ * chrom_len = length of the contig.  The state stays in the context for step 2.  Synchronises. */
+int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                        int64_t chrom_len, const nc_indel_reads *reads, const uint8_t *excl_dev, int32_t n_chunks,
+                        const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *params, int32_t window_after,
+                        int32_t maxcov, int32_t *n_sites, int64_t *n_alignments);
+/* Step 2: windows -> alignment -> tensors + consensus -> alleles, in groups of sites bounded by the traceback workspace.
+ * x_dev f32 [n_sites][sets * 5][128][2] (sets = 3: hap0 | hap1 | all reads stacked as indelCaller.py:83 does; haploid 1) is
+ * the input of nc_indel_forward.  Does not synchronise. */
+int nc_indel_sites_run(nc_ctx *ctx, float *x_dev);
+/* Step 3: per-site results to host arrays (any may be NULL): pos, chunk (index into the plan's chunk list), var_type (0 long
+ * window / 1 small window rule), phase (PS tag of the first read of the first set, :349; 0 = none), ref_len / alt_len
+ * [n_sites][sets] (allele_prediction's REF = window[:ref_len], ALT = consensus[:alt_len]; ref_len < 0: (None, None)), and
+ * *n_alt_bytes = sum of max(alt_len, 0).  Synchronises.  NC_ERR_CAPACITY: a read set needed more than 1024 alignment
+ * columns or a window exceeded the register aligner (the caller falls back to the host route). */
+int nc_indel_sites_fetch(nc_ctx *ctx, int32_t *pos, int32_t *chunk, int32_t *var_type, int32_t *phase, int32_t *ref_len,
+                         int32_t *alt_len, int64_t *n_alt_bytes);
+/* the ALT prefixes back to back in (site, set) order, codes A0 G1 T2 C3 */
+int nc_indel_sites_fetch_alt(nc_ctx *ctx, uint8_t *alt_bases, int64_t cap);
+/* per-stage HIP-event milliseconds of the last plan + run on this context (timing mode 1): [0] pass 1 + anchors + sets,
+ * [1] query windows, [2] alignment fill, [3] traceback, [4] tensors + consensus, [5] allele alignment + extraction */
+int nc_indel_sites_stage_ms(nc_ctx *ctx, float *ms6, int64_t *cells2 /* [0] DP cells of the star alignments, [1] of the allele alignments */);
+
+/* Indel genotype rules + VCF record text (indelCaller.py:87-152, haploid :173-179), host, printf-free: sites in the order of
+ * nc_indel_sites_fetch; `prev` (overlap suppression, :93) restarts at every chunk, as each chunk is one call of indel_run's
+ * loop body.  probs f32 [n][4] (hom-ref, hom-alt, het-ref, het-alt) or, haploid, [n][1]; contig = the reference bases
+ * (position p = contig[p-1]).  out receives the records back to back; chunk_txt_off [n_chunks + 1] (may be NULL) the byte
+ * offset of every chunk's first record. */
+int nc_indel_vcf_format(const char *chrom, int64_t n, const int32_t *pos, const int32_t *chunk, int32_t n_chunks, const float *probs,
+                        int32_t sets, const int32_t *ref_len, const int32_t *alt_len, const uint8_t *alt_bases, const int32_t *phase,
+                        const char *contig, int64_t chrom_len, int32_t haploid, char *out, int64_t cap, int64_t *n_bytes,
+                        int64_t *chunk_txt_off);
 
 /* Global alignment with affine gaps, the call parasail.nw_trace(alt, ref, 9, 1, matrix_create('AGTC', 20, -10)) of
  * generate_indel_pileups.py:10,79: a gap of length k costs open + (k-1)*extend.  Writes the CIGAR as (op, count) pairs

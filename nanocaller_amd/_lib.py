@@ -15,7 +15,10 @@ LIB_PATH = os.environ.get("NANOCALLER_HIP_LIB") or os.path.join(_HERE, "libnanoc
 
 NC_OK = 0
 NC_ERR_CAPACITY = -2
-ABI_VERSION = 7          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
+NC_ERR_UNSUPPORTED = -7
+NC_ERR_RANGE = -8
+FLAG_REFSKIP = 0x10000   # nc_decoded_arrays.flag bit: the CIGAR holds a reference skip
+ABI_VERSION = 8          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -38,6 +41,8 @@ EXPORTS = [
     "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_star_msa_tensor_dup", "nc_set_tensor_format", "nc_allele_prediction_batch", "nc_allele_prediction_device", "nc_bgzf_read_file", "nc_consensus_strings",
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
+    "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
+    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_vcf_format",
 ]
 
 
@@ -86,6 +91,19 @@ class Pass2ArraysC(C.Structure):
     _fields_ = [("n_kept", C.c_int32), ("anchor_idx", C.c_void_p), ("first0", C.c_void_p), ("sets_per_anchor", C.c_int32),
                 ("n_sets", C.c_int32), ("set_read0", C.c_void_p), ("n_alignments", C.c_int32), ("read_off", C.c_void_p),
                 ("reads", C.c_void_p), ("ref_off", C.c_void_p), ("refs", C.c_void_p), ("max_cols", C.c_int32), ("al_dup", C.c_void_p)]
+
+
+class IndelPackArraysC(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("ev_off", C.c_void_p), ("ev_pos", C.c_void_p), ("ev_len", C.c_void_p), ("n_events", C.c_int64),
+                ("ins_off", C.c_void_p), ("ins_bases", C.c_void_p), ("n_ins_bases", C.c_int64), ("tail_off", C.c_void_p),
+                ("tail_bases", C.c_void_p), ("n_tail_bases", C.c_int64), ("read_ps", C.c_void_p), ("read_hap", C.c_void_p),
+                ("read_flag", C.c_void_p)]
+
+
+class IndelReadsC(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("slot_off", C.c_void_p), ("rd_start", C.c_void_p), ("rd_end", C.c_void_p), ("ev_off", C.c_void_p),
+                ("ev_pos", C.c_void_p), ("ev_len", C.c_void_p), ("ins_off", C.c_void_p), ("ins_bases", C.c_void_p), ("tail_off", C.c_void_p),
+                ("tail_bases", C.c_void_p), ("read_ps", C.c_void_p), ("read_hap", C.c_void_p), ("read_flag", C.c_void_p)]
 
 
 class WireArraysC(C.Structure):
@@ -177,6 +195,17 @@ def lib():
         L.nc_wire_view.argtypes = [vp, C.POINTER(WireArraysC)]
         L.nc_wire_free.argtypes = [vp]
         L.nc_wire_expand.argtypes = [vp, i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, i64, vp, i64, vp]
+        L.nc_decoded_check.argtypes = [vp, vp, C.POINTER(i64), C.POINTER(i64)]
+        L.nc_indel_pack_build.argtypes = [vp, vp, i32, C.POINTER(vp)]
+        L.nc_indel_pack_view.argtypes = [vp, C.POINTER(IndelPackArraysC)]
+        L.nc_indel_pack_free.argtypes = [vp]
+        L.nc_indel_sites_plan.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i64, C.POINTER(IndelReadsC), vp, i32, vp, vp,
+                                          C.POINTER(IndelScanParamsC), i32, i32, C.POINTER(i32), C.POINTER(i64)]
+        L.nc_indel_sites_run.argtypes = [vp, vp]
+        L.nc_indel_sites_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+        L.nc_indel_sites_fetch_alt.argtypes = [vp, vp, i64]
+        L.nc_indel_sites_stage_ms.argtypes = [vp, vp, vp]
+        L.nc_indel_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, i32, vp, i32, vp, vp, vp, vp, C.c_char_p, i64, i32, vp, i64, C.POINTER(i64), vp]
         L.nc_argsort4.argtypes = [vp, i64, vp, C.POINTER(i64), vp, i64]
         L.nc_snp_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, C.POINTER(i64)]
         for name in EXPORTS:

@@ -578,6 +578,7 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         d->codes.resize(c0 + (size_t)rlen);
         uint8_t *co = d->codes.data() + c0;
         int32_t rp = 0, qp = 0, q_first = -1;
+        bool has_refskip = false;
         for (int64_t k = 0; k < n_cig_real; k++) {
             const uint32_t c = rdu32(cig + 4 * k);
             const int op = c & 15, len = (int)(c >> 4);
@@ -596,7 +597,8 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
                 for (int i = 0; i < len; i++, rp++) co[rp] = 4;
                 break;
             case 3:                                                   // N (reference skip): the reference raises KeyError (E10); coded 4 here
-                for (int i = 0; i < len; i++, rp++) co[rp] = 4;
+                for (int i = 0; i < len; i++, rp++) co[rp] = 4;           // and the read is marked (NC_FLAG_REFSKIP): nc_decoded_check
+                has_refskip = true;
                 break;
             case 4: qp += len; break;                                 // S
             default: break;                                           // H, P
@@ -604,7 +606,7 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         }
         d->start.push_back(pos + 1);
         d->end.push_back(pos + 1 + rlen);
-        d->flag.push_back(flag);
+        d->flag.push_back(flag | (has_refskip ? NC_FLAG_REFSKIP : 0));
         d->qstart.push_back(q_first < 0 ? qp : q_first);
         d->off.push_back((int64_t)d->codes.size());
         d->ev_off.push_back((int32_t)d->ev_pos.size());
@@ -1034,6 +1036,161 @@ int nc_indel_pass2_sets(const nc_decoded *d, const uint8_t *keep, int32_t n_anch
         }
     }
     *out = o;
+    return NC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inputs this library does not reproduce, found instead of silently accepted:
+//   * a kept alignment whose CIGAR holds a reference skip (N): the reference's code table raises KeyError on the '>' / '<'
+//     pileup symbols (generate_SNP_pileups.py:104,175);
+//   * two kept alignments with the same read name that overlap on the reference: the reference's per-column dicts are keyed by
+//     name, so the later one replaces the earlier in a column's pileup (generate_SNP_pileups.py:175,185,208) while both count
+//     in `n`; the read-major pack keeps them apart.
+int nc_decoded_check(const nc_decoded *d, const uint8_t *keep, int64_t *n_refskip, int64_t *n_dup_overlap)
+{
+    if (!d) return NC_ERR_ARG;
+    const int32_t n = (int32_t)d->start.size();
+    int64_t nskip = 0, ndup = 0;
+    std::vector<std::pair<uint64_t, int32_t>> h;
+    try { h.reserve((size_t)n); } catch (const std::bad_alloc &) { return NC_ERR_NOMEM; }
+    for (int32_t r = 0; r < n; r++) {
+        if (keep && !keep[r]) continue;
+        if (d->flag[r] & NC_FLAG_REFSKIP) nskip++;
+        uint64_t x = 1469598103934665603ull;                                   // FNV-1a of the name
+        for (const char *c = d->names.data() + d->name_off[r]; *c; c++) x = (x ^ (uint8_t)*c) * 1099511628211ull;
+        h.emplace_back(x, r);
+    }
+    std::sort(h.begin(), h.end());
+    for (size_t i = 0; i < h.size();) {
+        size_t j = i + 1;
+        while (j < h.size() && h[j].first == h[i].first) j++;
+        for (size_t a = i; a < j; a++)
+            for (size_t b = a + 1; b < j; b++) {
+                const int32_t ra = h[a].second, rb = h[b].second;
+                if (strcmp(d->names.data() + d->name_off[ra], d->names.data() + d->name_off[rb]) != 0) continue;
+                if (d->start[ra] < d->end[rb] && d->start[rb] < d->end[ra]) ndup++;
+            }
+        i = j;
+    }
+    if (n_refskip) *n_refskip = nskip;
+    if (n_dup_overlap) *n_dup_overlap = ndup;
+    return (nskip || ndup) ? NC_ERR_UNSUPPORTED : NC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The per-read inputs of the DEVICE pass 2 (nc_indel_sites_*), for the kept reads in pack order.  The position-addressed
+// codes in HBM hold every aligned base of a read; what a query window (query_sequence[q : q + window], generate_indel_pileups.py:
+// 331) needs beyond them are the bases WITHOUT a reference column: the inserted bases of every insertion event and the
+// query bases that follow the last aligned one (trailing soft clip), at most `tail_cap` of them.  Also the events / HP / PS
+// of the kept reads (what pack.pack_reads gathers for nc_indel_scan).
+struct nc_indel_pack_h {
+    bigvec<int32_t> ev_off, ev_pos, ev_len, ins_off, tail_off, ps;
+    bigvec<uint8_t> hap, ins_bases, tail_bases, rflag;
+};
+
+int nc_indel_pack_build(const nc_decoded *d, const uint8_t *keep, int32_t tail_cap, nc_indel_pack_h **out)
+{
+    if (!d || !out || tail_cap < 0) return NC_ERR_ARG;
+    *out = nullptr;
+    const int32_t n = (int32_t)d->start.size();
+    const bool have_seq = !d->seq.empty();
+    nc_indel_pack_h *o = new (std::nothrow) nc_indel_pack_h();
+    if (!o) return NC_ERR_NOMEM;
+    try {
+        std::vector<int32_t> kept;
+        kept.reserve((size_t)n);
+        for (int32_t r = 0; r < n; r++)
+            if (!keep || keep[r]) kept.push_back(r);
+        const size_t K = kept.size();
+        // pass 1: per read, the number of events, inserted bases and tail bases
+        std::vector<int64_t> c_ev(K + 1, 0), c_ins(K + 1, 0), c_tail(K + 1, 0);
+        int T = std::min(nc_host_cpus(), 16);
+        if ((size_t)T > K / 1024 + 1) T = (int)(K / 1024 + 1);
+        auto each = [&](auto fn) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back([&, t] { for (size_t k = K * (size_t)t / (size_t)T; k < K * ((size_t)t + 1) / (size_t)T; k++) fn(k); });
+            for (auto &x : th) x.join();
+        };
+        // the query walk of one read: calls ins(e, q0, len) for every insertion event and returns the query index that follows
+        // the last aligned base
+        auto walk = [&](int32_t r, auto on_ins) -> int64_t {
+            int64_t q = d->qstart[r];
+            int32_t rp = d->start[r];
+            for (int32_t e = d->ev_off[r]; e < d->ev_off[r + 1]; e++) {
+                const int32_t ep = d->ev_pos[e], el = d->ev_len[e];
+                q += ep - rp + 1;
+                rp = ep + 1;
+                if (el > 0) { on_ins(e, q, el); q += el; }
+                else rp += -el;
+            }
+            return q + (d->end[r] - rp);
+        };
+        each([&](size_t k) {
+            const int32_t r = kept[k];
+            c_ev[k + 1] = d->ev_off[r + 1] - d->ev_off[r];
+            const int64_t L = have_seq ? d->seq_off[r + 1] - d->seq_off[r] : 0;
+            int64_t ni = 0;
+            const int64_t qe = walk(r, [&](int32_t, int64_t q0, int32_t len) { ni += std::max<int64_t>(0, std::min<int64_t>(L, q0 + len) - std::min<int64_t>(L, q0)); });
+            c_ins[k + 1] = ni;
+            c_tail[k + 1] = std::max<int64_t>(0, std::min<int64_t>(L, qe + tail_cap) - std::min<int64_t>(L, qe));
+        });
+        for (size_t k = 0; k < K; k++) { c_ev[k + 1] += c_ev[k]; c_ins[k + 1] += c_ins[k]; c_tail[k + 1] += c_tail[k]; }
+        if (c_ev[K] > INT32_MAX - 1 || c_ins[K] > INT32_MAX - 1 || c_tail[K] > INT32_MAX - 1) { delete o; return NC_ERR_CAPACITY; }
+        const size_t NE = (size_t)c_ev[K];
+        o->ev_off.resize(K + 1); o->tail_off.resize(K + 1); o->ps.resize(K); o->hap.resize(K); o->rflag.resize(K);
+        o->ev_pos.resize(NE); o->ev_len.resize(NE); o->ins_off.resize(NE + 1);
+        o->ins_bases.resize((size_t)c_ins[K]); o->tail_bases.resize((size_t)c_tail[K]);
+        o->ev_off[K] = (int32_t)NE;
+        o->tail_off[K] = (int32_t)c_tail[K];
+        o->ins_off[NE] = (int32_t)c_ins[K];
+        each([&](size_t k) {
+            const int32_t r = kept[k];
+            const int32_t e0 = d->ev_off[r], ne = d->ev_off[r + 1] - e0, w0 = (int32_t)c_ev[k];
+            o->ev_off[k] = w0;
+            o->tail_off[k] = (int32_t)c_tail[k];
+            o->ps[k] = d->ps[r];
+            o->hap[k] = d->hap[r];
+            const int64_t s0 = have_seq ? d->seq_off[r] : 0, L = have_seq ? d->seq_off[r + 1] - s0 : 0;
+            o->rflag[k] = (uint8_t)(L == 0 ? 1 : 0);                              // bit 0: a record without bases (SEQ '*'): its windows are empty
+            if (ne) {
+                memcpy(o->ev_pos.data() + w0, d->ev_pos.data() + e0, (size_t)ne * 4);
+                memcpy(o->ev_len.data() + w0, d->ev_len.data() + e0, (size_t)ne * 4);
+            }
+            int64_t io = c_ins[k];
+            int32_t e_next = e0;
+            const int64_t qe = walk(r, [&](int32_t e, int64_t q0, int32_t len) {
+                for (; e_next <= e; e_next++) o->ins_off[(size_t)(w0 + (e_next - e0))] = (int32_t)io;      // deletions before it: empty ranges
+                const int64_t a = std::min<int64_t>(L, q0), b = std::min<int64_t>(L, q0 + len);
+                if (b > a) { memcpy(o->ins_bases.data() + io, d->seq.data() + s0 + a, (size_t)(b - a)); io += b - a; }
+            });
+            for (; e_next < e0 + ne; e_next++) o->ins_off[(size_t)(w0 + (e_next - e0))] = (int32_t)io;
+            const int64_t a = std::min<int64_t>(L, qe), b = std::min<int64_t>(L, qe + tail_cap);
+            if (b > a) memcpy(o->tail_bases.data() + c_tail[k], d->seq.data() + s0 + a, (size_t)(b - a));
+        });
+    } catch (const std::bad_alloc &) {
+        delete o;
+        return NC_ERR_NOMEM;
+    }
+    *out = o;
+    return NC_OK;
+}
+
+int nc_indel_pack_view(const nc_indel_pack_h *o, nc_indel_pack_arrays *v)
+{
+    if (!o || !v) return NC_ERR_ARG;
+    v->n_reads = (int32_t)o->ps.size();
+    v->ev_off = o->ev_off.data(); v->ev_pos = o->ev_pos.data(); v->ev_len = o->ev_len.data();
+    v->n_events = (int64_t)o->ev_pos.size();
+    v->ins_off = o->ins_off.data(); v->ins_bases = o->ins_bases.data(); v->n_ins_bases = (int64_t)o->ins_bases.size();
+    v->tail_off = o->tail_off.data(); v->tail_bases = o->tail_bases.data(); v->n_tail_bases = (int64_t)o->tail_bases.size();
+    v->read_ps = o->ps.data(); v->read_hap = o->hap.data(); v->read_flag = o->rflag.data();
+    return NC_OK;
+}
+
+int nc_indel_pack_free(nc_indel_pack_h *o)
+{
+    delete o;
     return NC_OK;
 }
 

@@ -61,6 +61,8 @@ struct nc_ctx {
     bool have_scan = false;
 
     nc_weights w[4];
+    struct nc_pipe_state *pipe = nullptr;   // device-resident indel pipeline (nc_pipe.hip): plan state, workspaces, results
+    uint32_t *range_flag = nullptr;         // device word: split-precision CNN epilogues OR a bit in when a value met the f16 clamp
 
     // The small transfers the host waits for in the middle of a step go through kernels that read / write page-locked host
     // memory directly, NOT through hipMemcpyAsync: on this platform every hipMemcpyAsync of either direction queues in order
@@ -147,3 +149,12 @@ struct NcTimer {
 
 // implemented in the kernel translation units
 int nc_selftest_device(nc_ctx *ctx);
+void nc_pipe_destroy(nc_ctx *ctx);          // nc_pipe.hip
+
+// K7 (nc_indel.hip): one chunk of a batched window scan
+struct IndelChunk {
+    int32_t lo, hi, ncol, nd;
+    int64_t ws;          // byte offset of depth[3][ncol] | rank[ncol+1] | diff[8][nd] | (impute) cnt[3][ncol] in the workspace
+    int64_t coloff;      // offset of this chunk's col_type in the concatenated output
+    int32_t tile0, blk0; // first tile of the chunk on the pack's grid, first k_hap_depth_b block of the chunk
+};

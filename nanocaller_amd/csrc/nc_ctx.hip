@@ -151,6 +151,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
                       &ctx->msa_reads, &ctx->msa_read_off, &ctx->msa_read_set, &ctx->msa_refs, &ctx->msa_ref_off, &ctx->msa_rows_hf,
                       &ctx->msa_hcol, &ctx->msa_tb, &ctx->msa_trace, &ctx->msa_cols, &ctx->msa_out, &ctx->msa_dup};
     for (DevBuf *b : bufs) freebuf(*b);
+    nc_pipe_destroy(ctx);
     for (auto &w : ctx->w) {
         if (w.dev) (void)hipFree(w.dev);
         if (w.packed) (void)hipFree(w.packed);

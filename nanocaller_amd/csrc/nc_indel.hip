@@ -89,12 +89,7 @@ __device__ __forceinline__ uint32_t lut8i(uint32_t x, uint32_t lo, uint32_t hi) 
 
 // All chunks of a call run in the same launches (chunk = a grid dimension), each chunk with its own workspace slice and
 // the reference's per-chunk semantics (window deques start empty at the chunk's first column)
-struct IndelChunk {
-    int32_t lo, hi, ncol, nd;
-    int64_t ws;          // byte offset of depth[3][ncol] | rank[ncol+1] | diff[8][nd] | (impute) cnt[3][ncol] in the workspace
-    int64_t coloff;      // offset of this chunk's col_type in the concatenated output
-    int32_t tile0, blk0; // first tile of the chunk on the pack's grid, first k_hap_depth_b block of the chunk
-};
+// IndelChunk: nc_common.h (shared with the device-resident pipeline, nc_pipe.hip)
 __device__ __forceinline__ int32_t *ck_depth(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws); }
 __device__ __forceinline__ int32_t *ck_rank(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws) + (int64_t)3 * c.ncol; }
 __device__ __forceinline__ int32_t *ck_diff(char *ws, const IndelChunk &c) { return (int32_t *)(ws + c.ws) + (int64_t)3 * c.ncol + c.ncol + 1; }
@@ -357,7 +352,7 @@ __global__ void k_indel_decide_b(const IndelChunk *__restrict__ ck, char *__rest
 
 }   // namespace
 
-static int indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const nc_indel_scan_params *prm, const char *who)
+int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const nc_indel_scan_params *prm, const char *who)
 {
     if (!pack || !ev || !prm) return nc_fail(ctx, NC_ERR_ARG, "%s: bad argument", who);
     const int tile = pack->tile_size;
@@ -366,16 +361,17 @@ static int indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_even
     return NC_OK;
 }
 
-// one group of ascending chunks: a single set of launches, one device-to-host copy per run of back-to-back outputs
-static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
-                            const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int8_t *col_type_host,
-                            const int64_t *col_off, int32_t *consumed)
+// the launches of one group (up to and including the per-column decisions, which stay on the device at *ctype_out; chunk
+// descriptors in `ck`, on the device at *ck_dev_out); no synchronisation
+int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
+                               const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t *consumed,
+                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out)
 {
     const int tile = pack->tile_size;
     const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
     const int impute = prm->impute && !prm->haploid;
     const size_t BUDGET = (size_t)6 << 30;                           // workspace per group of chunks
-    std::vector<IndelChunk> ck;
+    ck.clear();
     size_t wsb = 0;
     int64_t ncols = 0;
     int32_t nblk = 0, c1 = 0;
@@ -428,6 +424,21 @@ static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel
     hipLaunchKernelGGL(k_indel_decide_b, dim3(ng == 1 ? 512 : 64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t,
                        prm->haploid, impute, ctype);
     NC_HIP(ctx, hipGetLastError());
+    *ck_dev_out = ck_dev;
+    *ctype_out = ctype;
+    return NC_OK;
+}
+
+// one group of ascending chunks: a single set of launches, one device-to-host copy per run of back-to-back outputs
+static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
+                            const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int8_t *col_type_host,
+                            const int64_t *col_off, int32_t *consumed)
+{
+    std::vector<IndelChunk> ck;
+    const IndelChunk *ck_dev = nullptr;
+    const int8_t *ctype = nullptr;
+    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype));
+    const int32_t ng = (int32_t)ck.size();
     for (int32_t k = 0; k < ng;) {                                   // runs of chunks laid out back to back on the host as well
         int32_t j = k + 1;
         while (j < ng && col_off[j] - col_off[k] == ck[(size_t)j].coloff - ck[(size_t)k].coloff) j++;
@@ -447,7 +458,7 @@ extern "C" int nc_indel_scan_batch(nc_ctx *ctx, const nc_readpack *pack, const n
 {
     if (!ctx) return NC_ERR_ARG;
     if (n_chunks < 0 || (n_chunks && (!starts || !ends || !col_type_host || !col_off))) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_scan_batch: bad argument");
-    NC_TRY(indel_check(ctx, pack, ev, prm, "nc_indel_scan_batch"));
+    NC_TRY(nc_indel_check(ctx, pack, ev, prm, "nc_indel_scan_batch"));
     if (n_chunks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
     for (int32_t c = 0; c < n_chunks; c++)

@@ -1,0 +1,1196 @@
+// Device-resident indel featuriser (gfx950): get_indel_testing_candidates (reference generate_indel_pileups.py:129-371; haploid
+// generate_indel_pileups_haploid.py:118-277) for all chunks of a contig with no host code between the column decisions and the CNN input.
+//
+//   plan   K7 (nc_indel.hip's kernels; col_type stays in HBM)
+//          k_pick        one wave per chunk: the order-dependent anchor selection `if v_pos <= prev: continue` (:249,266-275) with the
+//                        dict semantics of `variants[anchor] = type`, then the pass-2 range test (:306)
+//          k_sets        one wave per anchor: reference window test (:325-327), the pileup at the anchor from the read pack's tile
+//                        index, the hap0 / hap1 / all read sets with the first-maxcov policy and the mincov tests (:333-348)
+//   run    per group of sites (bounded by the traceback workspace):
+//          k_windows     one lane per (site, read): query_sequence[q : q + window] (:331) rebuilt from the position-addressed codes, the
+//                        read's indel events and the bases that have no reference column (inserted bases, trailing soft clip)
+//          k_fill16p     Gotoh DP, 16 lanes per alignment, rows in registers (nc_msa.hip's k_nw_fill16: same recurrences and tie
+//                        rules), read bases passed down the lanes by DPP instead of a byte load per step
+//          k_trace16p    traceback -> alignment in reference coordinates
+//          k_site_tensor one workgroup per site: per read set the longest insertion per slot -> columns, the per-column symbol histogram
+//                        straight from the tracebacks (no row matrix in HBM), msa()'s frequencies / consensus / tensor (:57-71)
+//          k_fill16p + k_allele_trace16p   allele_prediction (:77-127) of every consensus against its window
+//          k_alt_gather  the ALT prefixes, back to back
+// Results equal nc_indel_pass2_sets -> nc_star_msa_tensor_dup -> nc_allele_prediction_device (tests/test_indel_pipeline.py).
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "nc_common.h"
+
+int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
+                               const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t *consumed,
+                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out);
+int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const nc_indel_scan_params *prm, const char *who);
+
+namespace {
+
+constexpr int PICK_CAP = 12288;        // anchors of one chunk held in LDS by k_pick (a 100 kb chunk has at most 9,092)
+constexpr int CNS_CAP = 1024;          // alignment columns of one read set (window + the longest insertion of every slot)
+constexpr int32_t NW_NEG = -(1 << 29);
+enum : uint32_t { T_DIAG = 0, T_DEL = 1, T_INS = 2, T_EEXT = 4, T_FEXT = 8 };
+
+struct PipeChunk {
+    int32_t lo, hi, ncol;      // columns lo .. hi (lo = max(1, start))
+    int32_t a_lo;              // anchors with a_lo < v <= hi go to pass 2 (:306)
+    int64_t coloff;            // offset of the chunk's col_type
+    int32_t seg0;              // offset of the chunk's anchor segment
+    int32_t id;                // index in the caller's chunk list
+};
+
+// ---------------------------------------------------------------------------------------------------------------- plan
+__global__ __launch_bounds__(64) void k_pick(const PipeChunk *__restrict__ pc, const int8_t *__restrict__ ctype, int32_t win,
+                                             int32_t *__restrict__ seg_pos, int8_t *__restrict__ seg_type, int32_t *__restrict__ cnt,
+                                             int32_t *__restrict__ err)
+{
+    __shared__ int32_t apos[PICK_CAP];
+    __shared__ int8_t atype[PICK_CAP];
+    const PipeChunk c = pc[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int8_t *ct = ctype + c.coloff;
+    int n = 0;
+    int base = 0;
+    bool over = false;
+    while (base < c.ncol) {
+        const int col = base + lane;
+        const int t = col < c.ncol ? (int)ct[col] : -1;
+        uint64_t mask = __ballot(t == 0 || t == 1);
+        int next_base = base + 64;
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            const int32_t v = c.lo + base + b;
+            const int tb = __shfl(t, b);
+            const int32_t prev = tb == 0 ? v + win : v + 10;                     // :267, :273
+            const int32_t an = tb == 0 ? max(1, v - win) : max(1, v - 10);       // :268, :274
+            // variants[an] = tb: the anchors stay sorted; an equal key is overwritten (dict), a smaller one (a small-window
+            // anchor followed by a long-window one less than 30 columns later) goes a few places back
+            int i = n;
+            while (i > 0 && apos[i - 1] > an) i--;
+            if (i > 0 && apos[i - 1] == an) {
+                if (lane == 0) atype[i - 1] = (int8_t)tb;
+            } else if (n >= PICK_CAP) {
+                over = true;
+            } else {
+                if (lane == 0) {
+                    for (int k = n; k > i; k--) { apos[k] = apos[k - 1]; atype[k] = atype[k - 1]; }
+                    apos[i] = an;
+                    atype[i] = (int8_t)tb;
+                }
+                n++;
+            }
+            __syncthreads();
+            // every column up to `prev` is skipped by `if v_pos <= prev: continue` (:249)
+            const int64_t skip_to = (int64_t)prev - c.lo + 1;
+            if (skip_to >= base + 64) {
+                next_base = (int)min((int64_t)c.ncol, skip_to);
+                mask = 0;
+            } else {
+                const int sb = (int)(skip_to - base);
+                mask &= ~((sb >= 64 ? ~0ull : ((1ull << sb) - 1)));
+            }
+        }
+        base = next_base;
+    }
+    if (over && lane == 0) atomicOr(err, 1);
+    // pass-2 range (:306) and the copy to the chunk's segment, in order
+    int m = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const bool ok = k < n && apos[k] > c.a_lo && apos[k] <= c.hi;
+        const uint64_t bm = __ballot(ok);
+        if (ok) {
+            const int w = m + __popcll(bm & ((1ull << lane) - 1));
+            seg_pos[c.seg0 + w] = apos[k];
+            seg_type[c.seg0 + w] = atype[k];
+        }
+        m += __popcll(bm);
+    }
+    if (lane == 0) cnt[c.id] = m;
+}
+
+__device__ __forceinline__ int block_scan(int v, int *wsum, int &tot)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += y;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wp = 0;
+    tot = 0;
+    for (int w = 0; w < nw; w++) {
+        const int s = wsum[w];
+        if (w < wv) wp += s;
+        tot += s;
+    }
+    return wp + inc;
+}
+
+// exclusive scan of in[0..n) into out[0..n], out[n] = total (one workgroup); `add` (optional) is added to every input first
+__global__ __launch_bounds__(1024) void k_scan_excl(const int32_t *__restrict__ in, int32_t n, int32_t add, int32_t *__restrict__ out)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? in[i] + add : 0;
+        int tot;
+        const int inc = block_scan(v, wsum, tot);
+        const int cc = carry;
+        if (i < n) out[i] = cc + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cc + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_flatten(const PipeChunk *__restrict__ pc, const int32_t *__restrict__ seg_pos, const int8_t *__restrict__ seg_type,
+                                                 const int32_t *__restrict__ cnt, const int32_t *__restrict__ off, int32_t *__restrict__ anc_pos,
+                                                 int8_t *__restrict__ anc_type, int32_t *__restrict__ anc_chunk)
+{
+    const PipeChunk c = pc[blockIdx.x];
+    const int n = cnt[c.id], o = off[c.id];
+    for (int k = threadIdx.x; k < n; k += 256) {
+        anc_pos[o + k] = seg_pos[c.seg0 + k];
+        anc_type[o + k] = seg_type[c.seg0 + k];
+        anc_chunk[o + k] = c.id;
+    }
+}
+
+struct SetArgs {
+    const int32_t *tile_off;
+    const nc_tile_entry *tile_ent;
+    int32_t tile_pos0, tile_size, n_tiles;
+    const uint8_t *ref_code;
+    int32_t ref_pos0, ref_len;
+    int64_t chrom_len;
+    int32_t window_after, maxcov, mincov, haploid;
+    const int64_t *slot_off;
+    const int32_t *read_ps;
+    int32_t n_reads;
+    int32_t n_anchor;
+    const int32_t *anc_pos, *anc_chunk;
+    const int8_t *anc_type;
+    // count pass out
+    int32_t *kept, *nuniq;
+    // fill pass in / out
+    const int32_t *site_of, *al_of;
+    int32_t *site_pos, *site_chunk, *site_type, *site_phase, *site_al0, *site_nr, *site_n2;
+    int32_t *al_read, *al_site;
+    uint8_t *al_member;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_sets(SetArgs p)
+{
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= p.n_anchor) return;
+    if (FILL && !p.kept[a]) return;
+    const int32_t v = p.anc_pos[a];
+    // reference window [v, min(chrom_len, v + window_after + 1)): upper-case AGTC only (:325-327)
+    const int64_t b = min(p.chrom_len, (int64_t)v + p.window_after + 1);
+    bool ok = b > v && v >= 1;
+    if (!FILL) {
+        bool mine = true;
+        for (int64_t x = v + lane; x < b; x += 64) {
+            const int64_t i = x - p.ref_pos0;
+            mine = mine && i >= 0 && i < p.ref_len && p.ref_code[i] < 4;
+        }
+        ok = ok && __all(mine);
+    }
+    int n_all = 0, n_1 = 0, n_2 = 0, n_u = 0, first0 = -1;
+    const int t = (v - p.tile_pos0) / p.tile_size;
+    const int site = FILL ? p.site_of[a] : 0;
+    const int al0 = FILL ? p.al_of[a] : 0;
+    if (ok && v >= p.tile_pos0 && t < p.n_tiles) {
+        const int e0 = p.tile_off[t], e1 = p.tile_off[t + 1];
+        const uint64_t lt = (1ull << lane) - 1;
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int e = eb + lane;
+            nc_tile_entry ent;
+            ent.start = 0; ent.end = 0; ent.base_flag = 0;
+            if (e < e1) ent = p.tile_ent[e];
+            const bool cov = e < e1 && ent.start <= v && v < ent.end;            // the pileup at the anchor, in pack (= file) order
+            const int hp = (int)((ent.base_flag >> 1) & 3);
+            const uint64_t m_all = __ballot(cov), m_1 = __ballot(cov && hp == 1), m_2 = __ballot(cov && hp == 2);
+            const int my_all = n_all + __popcll(m_all & lt), my_1 = n_1 + __popcll(m_1 & lt), my_2 = n_2 + __popcll(m_2 & lt);
+            int member = 0;
+            if (cov) {
+                if (p.haploid) member = my_all < p.maxcov ? 1 : 0;
+                else member = ((hp == 1 && my_1 < p.maxcov) ? 1 : 0) | ((hp == 2 && my_2 < p.maxcov) ? 2 : 0) | (my_all < p.maxcov ? 4 : 0);
+            }
+            const uint64_t m_u = __ballot(member != 0);
+            if (FILL) {
+                // the entry's read: its slot offset is unique
+                int r = -1;
+                if (member != 0 || (cov && hp == 1 && first0 < 0)) {
+                    const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
+                    int lo = 0, hi = p.n_reads;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (p.slot_off[mid] < so) lo = mid + 1; else hi = mid;
+                    }
+                    r = lo;
+                }
+                if (member != 0) {
+                    const int w = al0 + n_u + __popcll(m_u & lt);
+                    p.al_read[w] = r;
+                    p.al_site[w] = site;
+                    p.al_member[w] = (uint8_t)member;
+                }
+                if (first0 < 0) {
+                    const uint64_t mf = p.haploid ? m_all : m_1;
+                    if (mf) first0 = __shfl(r, __ffsll((long long)mf) - 1);
+                }
+            }
+            n_all += __popcll(m_all);
+            n_1 += __popcll(m_1);
+            n_2 += __popcll(m_2);
+            n_u += __popcll(m_u);
+        }
+    }
+    const int s_all = min(n_all, p.maxcov), s_1 = min(n_1, p.maxcov), s_2 = min(n_2, p.maxcov);
+    const bool pass = ok && (p.haploid ? s_all >= p.mincov : (s_1 >= 2 && s_2 >= 2 && s_all >= p.mincov));     // :48, :345
+    if (!FILL) {
+        if (lane == 0) {
+            p.kept[a] = pass ? 1 : 0;
+            p.nuniq[a] = pass ? n_u : 0;
+        }
+    } else if (lane == 0) {
+        p.site_pos[site] = v;
+        p.site_chunk[site] = p.anc_chunk[a];
+        p.site_type[site] = p.anc_type[a];
+        p.site_phase[site] = (!p.haploid && first0 >= 0) ? p.read_ps[first0] : 0;       // :349 (set 0 holds HP-tagged reads only)
+        p.site_al0[site] = al0;
+        p.site_n2[site] = (int32_t)(b - v);
+        if (p.haploid) p.site_nr[site] = s_all;
+        else { p.site_nr[site * 3] = s_1; p.site_nr[site * 3 + 1] = s_2; p.site_nr[site * 3 + 2] = s_all; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- run
+struct WinArgs {
+    const uint8_t *codes;
+    const int64_t *slot_off;
+    const int32_t *rd_start, *rd_end;
+    const int32_t *ev_off, *ev_pos, *ev_len, *ins_off, *tail_off;
+    const uint8_t *ins_bases, *tail_bases, *read_flag;
+    const int32_t *al_read, *al_site, *site_pos, *site_n2;    // al_* offset to the group's first alignment
+    int32_t A, W, WS;
+    uint8_t *win;           // [A][WS]
+    int32_t *n1;            // [A]
+    unsigned long long *cells;
+};
+
+__global__ __launch_bounds__(64) void k_windows(WinArgs p)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    long long mycells = 0;
+    if (al < p.A) {
+        const int r = p.al_read[al], site = p.al_site[al];
+        const int32_t v = p.site_pos[site];
+        uint8_t *out = p.win + (int64_t)al * p.WS;
+        int n = 0;
+        if (!(p.read_flag[r] & 1)) {
+            const int e0 = p.ev_off[r], e1 = p.ev_off[r + 1];
+            int lo = e0, hi = e1;                                  // first event on a column >= v
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (p.ev_pos[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            int k = lo;
+            int32_t del_until = 0;                                 // last position of the deletion that covers v, if any
+            if (k > e0) {
+                const int32_t el = p.ev_len[k - 1];
+                if (el < 0) del_until = p.ev_pos[k - 1] - el;
+            }
+            const int32_t rs = p.rd_start[r], re = p.rd_end[r];
+            const uint8_t *cd = p.codes + (p.slot_off[r] - (rs & ~15));
+            int32_t next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
+            int32_t x = v;
+            while (n < p.W && x < re) {
+                if (x > del_until) out[n++] = cd[x];
+                while (next_ev == x) {
+                    const int32_t el = p.ev_len[k];
+                    if (el > 0) {
+                        for (int i = p.ins_off[k]; i < p.ins_off[k + 1] && n < p.W; i++) out[n++] = p.ins_bases[i];
+                    } else del_until = x - el;
+                    k++;
+                    next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
+                }
+                x++;
+            }
+            if (x >= re)
+                for (int i = p.tail_off[r]; i < p.tail_off[r + 1] && n < p.W; i++) out[n++] = p.tail_bases[i];
+        }
+        p.n1[al] = n;
+        mycells = (long long)n * p.site_n2[site];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
+    if (threadIdx.x == 0 && mycells) atomicAdd(p.cells, (unsigned long long)mycells);
+}
+
+struct FillArgs {
+    const uint8_t *s1;           // read a = s1 + a * s1_stride, n1[a] bases (codes 0..4)
+    int32_t s1_stride;
+    const int32_t *n1;
+    const uint8_t *ref_code;     // reference window of alignment a: ref_code + site_pos[site] - ref_pos0, site_n2[site] bases
+    int32_t ref_pos0;
+    const int32_t *site_pos, *site_n2;
+    const int32_t *al_site;      // site of alignment a, or (NULL) site0 + a / site_div
+    int32_t site0, site_div;
+    int32_t A, W;                // alignments; row pitch of Hlast
+    int32_t open, extend, match, mismatch;
+    const int64_t *arow;         // first traceback row of alignment a, or (NULL) a * (N1 + 1)
+    int32_t N1;
+    uint32_t *Tw;
+    int32_t *Hlast, *hcol;       // free-tail end point inputs (NULL for a global alignment)
+};
+
+__device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int fill_site(const FillArgs &p, int al) { return p.al_site ? p.al_site[al] : p.site0 + al / p.site_div; }
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
+{
+    constexpr int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
+    const int al_raw = blockIdx.x * 4 + g;
+    const bool live = al_raw < p.A;
+    const int al = live ? al_raw : 0;
+    int n1 = 0, n2 = 0;
+    const uint8_t *s1 = p.s1, *s2 = p.ref_code;
+    if (live) {
+        s1 = p.s1 + (int64_t)al * p.s1_stride;
+        n1 = p.n1[al];
+        const int site = fill_site(p, al);
+        s2 = p.ref_code + (p.site_pos[site] - p.ref_pos0);
+        n2 = p.site_n2[site];
+    }
+    int32_t H[CPL], F[CPL];
+    int32_t rb[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int j = q * CPL + c + 1;
+        H[c] = -p.open - (j - 1) * p.extend;                 // row 0
+        F[c] = NW_NEG;
+        rb[c] = j <= n2 ? (int32_t)s2[j - 1] : -1;
+    }
+    int nmax = n1;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    const int64_t arow = p.arow ? p.arow[al] : (int64_t)al * (p.N1 + 1);
+    int32_t h_out = 0, e_out = NW_NEG;
+    int32_t h_in_prev = q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend;      // H[0][q*CPL]
+    const int jn_lane = (n2 - 1) / CPL, jn_c = (n2 - 1) % CPL;                    // owner of column n2
+    // read bases: lane q of a group holds base 16*blk + q; lane 0 takes base t-1 from lane (t-1) & 15, the others get theirs
+    // from the lane to their left one step later (lane q works on read row t - q)
+    int32_t chunk = q < n1 ? (int32_t)s1[q] : 4;
+    int32_t chunk_nxt = 16 + q < n1 ? (int32_t)s1[16 + q] : 4;
+    int32_t c1 = 4;
+    for (int t = 1; t <= nmax + 15; t++) {
+        const int i = t - q;
+        if (t > 1 && ((t - 1) & 15) == 0) {
+            chunk = chunk_nxt;
+            const int idx = t - 1 + 16 + q;
+            chunk_nxt = idx < n1 ? (int32_t)s1[idx] : 4;
+        }
+        const int32_t c_new = __shfl(chunk, (lane & 48) | ((t - 1) & 15));
+        c1 = dpp_shr1(4, c1);
+        if (q == 0) c1 = c_new;
+        int32_t nh = dpp_shr1(0, h_out), ne = dpp_shr1(NW_NEG, e_out);
+        if (q == 0) {
+            nh = -p.open - (i - 1) * p.extend;                // H[i][0]
+            ne = NW_NEG;
+        }
+        const bool active = live && i >= 1 && i <= n1 && q * CPL < n2;
+        if (active) {
+            int32_t hdiag = h_in_prev, hleft = nh, e = ne;
+            uint32_t words[NWD];
+#pragma unroll
+            for (int k = 0; k < NWD; k++) words[k] = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int32_t hup = H[c], fup = F[c];
+                const int32_t e_open = hleft - p.open, e_ext = e - p.extend;
+                const uint32_t te = e_ext >= e_open ? (uint32_t)T_EEXT : 0u;
+                e = max(e_open, e_ext);
+                const int32_t f_open = hup - p.open, f_ext = fup - p.extend;
+                const uint32_t tf = f_ext >= f_open ? (uint32_t)T_FEXT : 0u;
+                const int32_t f = max(f_open, f_ext);
+                const int32_t d = hdiag + (c1 == rb[c] ? p.match : p.mismatch);
+                const int32_t h1 = max(d, e);
+                const uint32_t w1 = e > d ? (uint32_t)T_DEL : (uint32_t)T_DIAG;
+                const int32_t h = max(h1, f);
+                const uint32_t w = f > h1 ? (uint32_t)T_INS : w1;
+                H[c] = h;
+                F[c] = f;
+                words[c >> 3] |= (te | tf | w) << ((c & 7) * 4);
+                hdiag = hup;
+                hleft = h;
+            }
+            h_out = hleft;
+            e_out = e;
+            uint32_t *tp = p.Tw + ((arow + i) * 16 + q) * NWP;
+            if (NWP == 1) tp[0] = words[0];
+            else if (NWP == 2) *reinterpret_cast<uint2 *>(tp) = make_uint2(words[0], words[1]);
+            else *reinterpret_cast<uint4 *>(tp) = make_uint4(words[0], words[1], NWD > 2 ? words[NWD > 2 ? 2 : 0] : 0u, 0u);
+            if (p.hcol && q == jn_lane) {
+                int32_t hv = H[0];
+#pragma unroll
+                for (int c = 1; c < CPL; c++) hv = c == jn_c ? H[c] : hv;
+                p.hcol[arow + i] = hv;                        // H[i][n2]
+            }
+            if (p.Hlast && i == n1) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    if (rb[c] >= 0) p.Hlast[(int64_t)al * p.W + q * CPL + c + 1] = H[c];
+            }
+        }
+        if (i >= 1) h_in_prev = nh;
+    }
+}
+
+// traceback of a free-tail alignment into reference coordinates (nc_msa.hip k_nw_trace16)
+__global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int16_t *__restrict__ qidx_all, int16_t *__restrict__ il_all,
+                                                 int16_t *__restrict__ iq_all)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    if (al >= p.A) return;
+    const int n1 = p.n1[al];
+    const int n2 = p.site_n2[fill_site(p, al)];
+    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    const int64_t arow = (int64_t)al * (p.N1 + 1);
+    int16_t *qidx = qidx_all + (int64_t)al * p.W, *il = il_all + (int64_t)al * p.W, *iq = iq_all + (int64_t)al * p.W;
+    for (int j = 0; j <= n2; j++) { qidx[j] = -1; il[j] = 0; iq[j] = 0; }
+    int i = n1, j = n2;
+    if (n1 > 0 && n2 > 0) {                                           // free tail: best cell of the last row / last column
+        int32_t best = p.Hlast[(int64_t)al * p.W + n2];
+        for (int jj = n2 - 1; jj >= 0; jj--) {
+            const int32_t v = jj > 0 ? p.Hlast[(int64_t)al * p.W + jj] : -p.open - (n1 - 1) * p.extend;
+            if (v > best) { best = v; i = n1; j = jj; }
+        }
+        for (int ii = n1 - 1; ii >= 0; ii--) {
+            const int32_t v = ii > 0 ? p.hcol[arow + ii] : -p.open - (n2 - 1) * p.extend;
+            if (v > best) { best = v; i = ii; j = n2; }
+        }
+        if (i < n1) { il[n2] = (int16_t)(n1 - i); iq[n2] = (int16_t)i; }   // the rest of the read: insertion after the window
+    }
+    int state = -1;
+    while (i > 0 || j > 0) {
+        uint32_t t;
+        if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
+        else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
+        else {
+            const int q = (j - 1) / CPL, c = (j - 1) % CPL;
+            t = (p.Tw[((arow + i) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
+        }
+        if (state < 0) {
+            const int w = t & 3;
+            if (w == T_DIAG) { qidx[j - 1] = (int16_t)(i - 1); i--; j--; continue; }
+            state = w == T_DEL ? 1 : 2;
+        }
+        if (state == 1) {
+            const bool ext = (t & T_EEXT) != 0;
+            j--;
+            if (!ext) state = -1;
+        } else {
+            const bool ext = (t & T_FEXT) != 0;
+            il[j]++;
+            iq[j] = (int16_t)(i - 1);
+            i--;
+            if (!ext) state = -1;
+        }
+    }
+}
+
+struct TensorArgs {
+    int32_t site0, n_sites_g, S, haploid, W, WS;
+    int64_t A0;                                 // first alignment of the group
+    const int32_t *site_al0, *site_nr, *site_pos, *site_n2;
+    const uint8_t *al_member;                   // global
+    const uint8_t *win;                         // group-local [A][WS]
+    const int16_t *qidx, *il, *iq;              // group-local [A][W]
+    const uint8_t *ref_code;
+    int32_t ref_pos0;
+    float *x;                                   // global [n_sites][S*5][128][2]
+    uint8_t *cns;                               // group-local [n_sites_g * S][CNS_CAP], gap-free consensus
+    int32_t *ncns;                              // group-local [n_sites_g * S]
+    int32_t *err;
+};
+
+__global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
+{
+    __shared__ int32_t colv[288];
+    __shared__ int16_t mxv[288];
+    __shared__ uint16_t hist[CNS_CAP * 4];
+    __shared__ uint8_t refrow[CNS_CAP];
+    __shared__ uint8_t cnsv[CNS_CAP];
+    __shared__ int32_t s_ncols, s_run;
+    __shared__ int32_t wcnt[4];
+    const int kl = blockIdx.x, site = p.site0 + kl;
+    const int tid = threadIdx.x;
+    const int n2 = p.site_n2[site];
+    const int64_t a0 = p.site_al0[site] - p.A0, a1 = p.site_al0[site + 1] - p.A0;
+    const uint8_t *mem = p.al_member + p.A0;
+    const uint8_t *s2 = p.ref_code + (p.site_pos[site] - p.ref_pos0);
+    for (int t = 0; t < p.S; t++) {
+        const int bit = p.haploid ? 1 : (1 << t);
+        const int nr = p.site_nr[site * p.S + t];
+        float *X = p.x + ((int64_t)site * p.S + t) * 5 * 128 * 2;
+        // longest insertion of the set in every slot (slot j = before reference position j; slot n2 = after the last)
+        for (int j = tid; j <= n2; j += 256) {
+            int m = 0;
+            for (int64_t a = a0; a < a1; a++)
+                if (mem[a] & bit) m = max(m, (int)p.il[a * p.W + j]);
+            mxv[j] = (int16_t)m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int j = 0; j <= n2; j++) { acc += mxv[j]; colv[j] = acc + j; }
+            s_ncols = acc + n2;
+        }
+        __syncthreads();
+        const int ncols = s_ncols;
+        if (ncols > CNS_CAP) {                                        // never with real windows: reported, the caller falls back
+            if (tid == 0) { atomicOr(p.err, 2); p.ncns[kl * p.S + t] = 0; }
+            for (int c = tid; c < 128 * 5; c += 256) { X[c * 2] = 0.0f; X[c * 2 + 1] = 0.0f; }
+            __syncthreads();
+            continue;
+        }
+        for (int c = tid; c < ncols * 4; c += 256) hist[c] = 0;
+        for (int c = tid; c < ncols; c += 256) refrow[c] = 4;
+        __syncthreads();
+        for (int j = tid; j <= n2; j += 256) {
+            const int cj = colv[j], c0 = cj - mxv[j];                 // thread j owns the columns c0 .. cj of every read
+            if (j < n2) refrow[cj] = s2[j];
+            for (int64_t a = a0; a < a1; a++) {
+                if (!(mem[a] & bit)) continue;
+                const uint8_t *s1 = p.win + a * p.WS;
+                if (j < n2) {
+                    const int qi = p.qidx[a * p.W + j];
+                    if (qi >= 0) {
+                        const int sym = s1[qi];
+                        if (sym < 4) hist[cj * 4 + sym]++;            // anything else (a read base N) counts as a gap at its column
+                    }
+                }
+                const int L = p.il[a * p.W + j];
+                if (L > 0) {
+                    const int q0 = p.iq[a * p.W + j];
+                    for (int u = 0; u < L; u++) {
+                        const int sym = s1[q0 + u];
+                        if (sym < 4) hist[(c0 + u) * 4 + sym]++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // frequencies, consensus symbol, tensor (:57-71)
+        const float tot = (float)nr;
+        for (int c = tid; c < max(ncols, 128); c += 256) {
+            if (c < ncols) {
+                int h[5];
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { h[k] = hist[c * 4 + k]; sum += h[k]; }
+                h[4] = nr - sum;
+                float alt[5], best = -1e30f;
+                int arg = 0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    alt[k] = (float)h[k] / tot;
+                    const float tv = k == 4 ? alt[k] - 0.01f : alt[k];
+                    if (tv > best) { best = tv; arg = k; }
+                }
+                cnsv[c] = (uint8_t)arg;
+                if (c < 128) {
+                    const int rc = refrow[c];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const float rf = rc == k ? 1.0f : 0.0f;
+                        *reinterpret_cast<float2 *>(X + (k * 128 + c) * 2) = make_float2(alt[k] - rf, rf);
+                    }
+                }
+            } else if (c < 128) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) *reinterpret_cast<float2 *>(X + (k * 128 + c) * 2) = make_float2(0.0f, 0.0f);
+            }
+        }
+        if (tid == 0) s_run = 0;
+        __syncthreads();
+        // consensus with the gap symbols removed (:61-64)
+        uint8_t *out = p.cns + ((int64_t)kl * p.S + t) * CNS_CAP;
+        for (int base = 0; base < ncols; base += 256) {
+            const int c = base + tid;
+            const bool f = c < ncols && cnsv[c] != 4;
+            const uint64_t bm = __ballot(f);
+            if ((tid & 63) == 0) wcnt[tid >> 6] = __popcll(bm);
+            __syncthreads();
+            int wp = s_run, totw = 0;
+            for (int w = 0; w < 4; w++) {
+                if (w < (tid >> 6)) wp += wcnt[w];
+                totw += wcnt[w];
+            }
+            if (f) out[wp + __popcll(bm & ((1ull << (tid & 63)) - 1))] = cnsv[c];
+            __syncthreads();
+            if (tid == 0) s_run += totw;
+            __syncthreads();
+        }
+        if (tid == 0) p.ncns[kl * p.S + t] = s_run;
+        __syncthreads();
+    }
+}
+
+// allele_prediction on the packed traceback of a GLOBAL alignment of the consensus (s1) against the window (nc_msa.hip k_allele_trace16)
+__global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL, const int32_t *__restrict__ site_type, int32_t win_size,
+                                                        int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    if (al >= p.A) return;
+    const int site = fill_site(p, al);
+    const uint8_t *s1 = p.s1 + (int64_t)al * p.s1_stride;
+    const int n1 = p.n1[al];
+    const uint8_t *s2 = p.ref_code + (p.site_pos[site] - p.ref_pos0);
+    const int n2 = p.site_n2[site];
+    if (n1 <= 0) {                                                   // (an empty consensus cannot happen: every column of a set has a symbol or a gap)
+        ref_len[al] = -1;
+        alt_len[al] = -1;
+        return;
+    }
+    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    const int64_t arow = p.arow[al];
+    const int run_cap = n1 + n2 + 2;
+    int16_t *rop = runs + 2 * (arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;      // runs in REVERSE alignment order
+    int nr = 0, last_op = -1;
+    auto push = [&](int op) {
+        if (op == last_op) rcn[nr - 1]++;
+        else if (nr < run_cap) { rop[nr] = (int16_t)op; rcn[nr] = 1; nr++; last_op = op; }
+    };
+    int i = n1, j = n2, state = -1;
+    while (i > 0 || j > 0) {
+        uint32_t t;
+        if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
+        else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
+        else {
+            const int q = (j - 1) / CPL, c = (j - 1) % CPL;
+            t = (p.Tw[((arow + i) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
+        }
+        if (state < 0) {
+            const int w = t & 3;
+            if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; continue; }
+            state = w == T_DEL ? 1 : 2;
+        }
+        if (state == 1) {
+            push(2);
+            const bool ext = (t & T_EEXT) != 0;
+            j--;
+            if (!ext) state = -1;
+        } else {
+            push(1);
+            const bool ext = (t & T_FEXT) != 0;
+            i--;
+            if (!ext) state = -1;
+        }
+    }
+    bool indel = false, mm_before = false;
+    int32_t rc7 = 0, rc8 = 0, rc2 = 0, ac7 = 0, ac8 = 0, ac1 = 0, mm_after = 0;
+    const int32_t mr = site_type[site] == 0 ? max(10, win_size) : 10;       // max_range {0: max(10, win_size), 1: 10}
+    auto clampi = [](int32_t v, int32_t n) { return v < 0 ? (v + n < 0 ? 0 : v + n) : (v > n ? n : v); };       // Python slice s[:v]
+    int op = 0, cnt = 0;
+    bool done = false;
+    int32_t out_r = 0, out_a = 0;
+    for (int k = nr - 1; k >= 0 && !done; k--) {
+        op = rop[k];
+        cnt = rcn[k];
+        if (op == 8 || op == 7) {
+            if (op == 7) { rc7 += cnt; ac7 += cnt; } else { rc8 += cnt; ac8 += cnt; }
+            if (indel) mm_after += cnt;
+            else mm_before = true;
+        }
+        if (op == 1) { ac1 += cnt; mm_after = 0; indel = true; }
+        if (op == 2) { rc2 += cnt; mm_after = 0; indel = true; }
+        const int32_t rsum = rc7 + rc8 + rc2;
+        if (!indel && rsum >= mr + 10) {
+            if (rc8) {
+                const int32_t ol = op == 8 ? rsum : rsum - cnt;
+                out_r = clampi(ol, n2);
+                out_a = clampi(ol, n1);
+            } else {
+                out_r = -1;
+                out_a = -1;
+            }
+            done = true;
+            break;
+        }
+        if (indel && mm_after > 20) break;
+    }
+    if (!done) {
+        const int32_t rsum = rc7 + rc8 + rc2, asum = ac7 + ac8 + ac1;
+        int32_t ro = op == 8 ? rsum : rsum - cnt, ao = op == 8 ? asum : asum - cnt;
+        if (!mm_before) { ro += 1; ao += 1; }
+        out_r = clampi(ro, n2);
+        out_a = clampi(ao, n1);
+    }
+    ref_len[al] = out_r;
+    alt_len[al] = out_a;
+}
+
+// rows of the allele alignments: arow[a] = sum_{b<a} (n1[b] + 1); arow[n] = total
+__global__ __launch_bounds__(1024) void k_scan_rows(const int32_t *__restrict__ n1, int32_t n, int64_t *__restrict__ arow, int32_t *__restrict__ total_mbox)
+{
+    __shared__ int wsum[16];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? n1[i] + 1 : 0;
+        int tot;
+        const int inc = block_scan(v, wsum, tot);
+        const long long cc = carry;
+        if (i < n) arow[i] = cc + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cc + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        arow[n] = carry;
+        total_mbox[0] = (int32_t)(carry & 0x7fffffff);
+        total_mbox[1] = (int32_t)(carry >> 31);
+    }
+}
+
+// ALT prefixes of the group's sets appended to the pool: pool_base[0] = bytes used so far (updated)
+__global__ __launch_bounds__(1024) void k_alt_offsets(const int32_t *__restrict__ alt_len, int32_t n, long long *__restrict__ pool_base,
+                                                      int64_t *__restrict__ off /* [n] */)
+{
+    __shared__ int wsum[16];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = pool_base[0];
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? max(alt_len[i], 0) : 0;
+        int tot;
+        const int inc = block_scan(v, wsum, tot);
+        const long long cc = carry;
+        if (i < n) off[i] = cc + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cc + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pool_base[0] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_alt_copy(const uint8_t *__restrict__ cns, const int32_t *__restrict__ alt_len, const int64_t *__restrict__ off,
+                                                  int32_t n, uint8_t *__restrict__ pool, int64_t pool_cap, int32_t *__restrict__ err)
+{
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a >= n) return;
+    const int L = alt_len[a];
+    if (L <= 0) return;
+    const int64_t o = off[a];
+    if (o + L > pool_cap) { if (lane == 0) atomicOr(err, 4); return; }
+    for (int i = lane; i < L; i += 64) pool[o + i] = cns[(int64_t)a * CNS_CAP + i];
+}
+
+}   // namespace
+
+// ------------------------------------------------------------------------------------------------------------ host side
+struct nc_pipe_state {
+    bool planned = false, ran = false;
+    nc_readpack pack;
+    nc_indel_reads rd;
+    const uint8_t *ref_code = nullptr;
+    int32_t ref_pos0 = 0, ref_len = 0;
+    int64_t chrom_len = 0;
+    int32_t window_after = 0, maxcov = 0, mincov = 0, win_size = 0, haploid = 0, S = 3;
+    int32_t n_chunks = 0, n_anchor = 0, n_sites = 0;
+    int64_t n_al = 0;
+    std::vector<int32_t> site_al0_h;
+    DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
+    DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
+    DevBuf win, n1, tw, hlast, hcol, trace, cns, ncns, arow, tw2, runs, rlen, alen, alt_off, alt_pool, misc;
+    int64_t alt_pool_cap = 0;
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float stage_ms[6] = {0, 0, 0, 0, 0, 0};
+    int64_t cells[2] = {0, 0};
+};
+
+void nc_pipe_destroy(nc_ctx *ctx)
+{
+    nc_pipe_state *s = ctx->pipe;
+    if (!s) return;
+    DevBuf *bufs[] = {&s->pc, &s->seg_pos, &s->seg_type, &s->cnt, &s->off, &s->anc_pos, &s->anc_type, &s->anc_chunk, &s->kept, &s->nuniq, &s->site_of,
+                      &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
+                      &s->al_site, &s->al_member, &s->win, &s->n1, &s->tw, &s->hlast, &s->hcol, &s->trace, &s->cns, &s->ncns, &s->arow, &s->tw2,
+                      &s->runs, &s->rlen, &s->alen, &s->alt_off, &s->alt_pool, &s->misc};
+    for (DevBuf *b : bufs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+    ctx->pipe = nullptr;
+}
+
+static int cpl_for(int n2) { return n2 <= 64 ? 4 : n2 <= 128 ? 8 : n2 <= 176 ? 11 : n2 <= 272 ? 17 : 0; }
+
+static void launch_fill(nc_ctx *ctx, int CPL, const FillArgs &fa)
+{
+    const dim3 gr((unsigned)((fa.A + 3) / 4));
+    if (CPL == 4) hipLaunchKernelGGL(k_fill16p<4>, gr, dim3(64), 0, ctx->stream, fa);
+    else if (CPL == 8) hipLaunchKernelGGL(k_fill16p<8>, gr, dim3(64), 0, ctx->stream, fa);
+    else if (CPL == 11) hipLaunchKernelGGL(k_fill16p<11>, gr, dim3(64), 0, ctx->stream, fa);
+    else hipLaunchKernelGGL(k_fill16p<17>, gr, dim3(64), 0, ctx->stream, fa);
+}
+
+extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                                   int64_t chrom_len, const nc_indel_reads *reads, const uint8_t *excl_dev, int32_t n_chunks,
+                                   const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t window_after,
+                                   int32_t maxcov, int32_t *n_sites, int64_t *n_alignments)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!pack || !ref_code_dev || !reads || !prm || !n_sites || !n_alignments || n_chunks < 0 || (n_chunks && (!starts || !ends)) || window_after < 1 ||
+        maxcov < 1 || chrom_len < 1)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: bad argument");
+    if (prm->impute && !prm->haploid) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: impute_indel_phase is not covered by the device pipeline");
+    if (cpl_for(window_after + 1) == 0) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: windows longer than 271 bases");
+    nc_indel_events ev;
+    ev.n_reads = reads->n_reads; ev.ev_off = reads->ev_off; ev.ev_pos = reads->ev_pos; ev.ev_len = reads->ev_len; ev.read_hap = reads->read_hap;
+    NC_TRY(nc_indel_check(ctx, pack, &ev, prm, "nc_indel_sites_plan"));
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->pipe) ctx->pipe = new (std::nothrow) nc_pipe_state();
+    nc_pipe_state *s = ctx->pipe;
+    if (!s) return NC_ERR_NOMEM;
+    s->planned = s->ran = false;
+    s->pack = *pack; s->rd = *reads; s->ref_code = ref_code_dev; s->ref_pos0 = ref_pos0; s->ref_len = ref_len; s->chrom_len = chrom_len;
+    s->window_after = window_after; s->maxcov = maxcov; s->mincov = prm->mincov; s->win_size = prm->win_size; s->haploid = prm->haploid ? 1 : 0;
+    s->S = prm->haploid ? 1 : 3;
+    s->n_chunks = n_chunks; s->n_sites = 0; s->n_al = 0; s->n_anchor = 0;
+    *n_sites = 0;
+    *n_alignments = 0;
+    for (auto &m : s->stage_ms) m = 0;
+    s->cells[0] = s->cells[1] = 0;
+    if (n_chunks == 0) { s->planned = true; return NC_OK; }
+    for (int32_t c = 0; c < n_chunks; c++) {
+        if (ends[c] < starts[c]) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: chunk %d has end < start", c);
+        if (c && (starts[c] < starts[c - 1] || ends[c] < ends[c - 1])) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: chunks must ascend");
+    }
+    const bool timing = ctx->timing == 1;
+    if (timing)
+        for (auto &e : s->ev) if (!e) NC_HIP(ctx, hipEventCreate(&e));
+    if (timing) NC_HIP(ctx, hipEventRecord(s->ev[0], ctx->stream));
+    // ---- anchors of every chunk
+    std::vector<PipeChunk> pcs((size_t)n_chunks);
+    int64_t seg_total = 0;
+    for (int32_t c = 0; c < n_chunks; c++) {
+        PipeChunk &k = pcs[(size_t)c];
+        k.lo = starts[c] < 1 ? 1 : starts[c];
+        k.hi = ends[c];
+        k.ncol = k.hi - k.lo + 1;
+        k.a_lo = std::max(0, starts[c] - 10 - prm->win_size);
+        k.coloff = 0;
+        k.seg0 = (int32_t)seg_total;
+        k.id = c;
+        const int64_t cap = k.ncol / 11 + 2;
+        if (cap > PICK_CAP) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: chunk %d is longer than the anchor buffer covers", c);
+        seg_total += cap;
+        if (seg_total > INT32_MAX / 2) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: too many columns in one call");
+    }
+    NC_TRY(nc_ensure(ctx, s->pc, (size_t)n_chunks * sizeof(PipeChunk)));
+    NC_TRY(nc_ensure(ctx, s->seg_pos, (size_t)seg_total * 4));
+    NC_TRY(nc_ensure(ctx, s->seg_type, (size_t)seg_total));
+    NC_TRY(nc_ensure(ctx, s->cnt, ((size_t)n_chunks + 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->off, ((size_t)n_chunks + 2) * 4));
+    NC_TRY(nc_ensure(ctx, s->misc, 256));
+    int32_t *err = (int32_t *)s->misc.p;                              // [0] error bits, [2..3] row total mailbox, [4..5] cells, [8..9] alt pool bytes
+    NC_HIP(ctx, hipMemsetAsync(s->misc.p, 0, 256, ctx->stream));
+    int32_t c0 = 0;
+    std::vector<IndelChunk> ck;
+    while (c0 < n_chunks) {
+        int32_t used = 0;
+        const IndelChunk *ck_dev = nullptr;
+        const int8_t *ctype = nullptr;
+        NC_TRY(nc_indel_scan_group_launch(ctx, pack, &ev, excl_dev, n_chunks - c0, starts + c0, ends + c0, prm, &used, ck, &ck_dev, &ctype));
+        for (int32_t k = 0; k < used; k++) pcs[(size_t)(c0 + k)].coloff = ck[(size_t)k].coloff;
+        NC_HIP(ctx, hipMemcpyAsync((PipeChunk *)s->pc.p + c0, pcs.data() + c0, (size_t)used * sizeof(PipeChunk), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_pick, dim3(used), dim3(64), 0, ctx->stream, (const PipeChunk *)s->pc.p + c0, ctype, prm->win_size, (int32_t *)s->seg_pos.p,
+                           (int8_t *)s->seg_type.p, (int32_t *)s->cnt.p, err);
+        NC_HIP(ctx, hipGetLastError());
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));               // `pcs` / `ck` are copy sources; the next group reuses the K7 workspace
+        c0 += used;
+    }
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->cnt.p, n_chunks, 0, (int32_t *)s->off.p);
+    int32_t na = 0, errh = 0;
+    NC_HIP(ctx, hipMemcpyAsync(&na, (int32_t *)s->off.p + n_chunks, 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipMemcpyAsync(&errh, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (errh & 1) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: anchor buffer of a chunk overflowed");
+    s->n_anchor = na;
+    s->planned = true;
+    if (na == 0) {
+        if (timing) { NC_HIP(ctx, hipEventRecord(s->ev[1], ctx->stream)); }
+        return NC_OK;
+    }
+    NC_TRY(nc_ensure(ctx, s->anc_pos, (size_t)na * 4));
+    NC_TRY(nc_ensure(ctx, s->anc_type, (size_t)na));
+    NC_TRY(nc_ensure(ctx, s->anc_chunk, (size_t)na * 4));
+    NC_TRY(nc_ensure(ctx, s->kept, ((size_t)na + 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->nuniq, ((size_t)na + 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->site_of, ((size_t)na + 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->al_of, ((size_t)na + 1) * 4));
+    hipLaunchKernelGGL(k_flatten, dim3(n_chunks), dim3(256), 0, ctx->stream, (const PipeChunk *)s->pc.p, (const int32_t *)s->seg_pos.p,
+                       (const int8_t *)s->seg_type.p, (const int32_t *)s->cnt.p, (const int32_t *)s->off.p, (int32_t *)s->anc_pos.p,
+                       (int8_t *)s->anc_type.p, (int32_t *)s->anc_chunk.p);
+    SetArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.tile_off = pack->tile_off; sa.tile_ent = pack->tile_ent; sa.tile_pos0 = pack->tile_pos0; sa.tile_size = pack->tile_size; sa.n_tiles = pack->n_tiles;
+    sa.ref_code = ref_code_dev; sa.ref_pos0 = ref_pos0; sa.ref_len = ref_len; sa.chrom_len = chrom_len;
+    sa.window_after = window_after; sa.maxcov = maxcov; sa.mincov = prm->mincov; sa.haploid = s->haploid;
+    sa.slot_off = reads->slot_off; sa.read_ps = reads->read_ps; sa.n_reads = reads->n_reads;
+    sa.n_anchor = na; sa.anc_pos = (const int32_t *)s->anc_pos.p; sa.anc_chunk = (const int32_t *)s->anc_chunk.p; sa.anc_type = (const int8_t *)s->anc_type.p;
+    sa.kept = (int32_t *)s->kept.p; sa.nuniq = (int32_t *)s->nuniq.p;
+    hipLaunchKernelGGL(k_sets<false>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->kept.p, na, 0, (int32_t *)s->site_of.p);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->nuniq.p, na, 0, (int32_t *)s->al_of.p);
+    NC_HIP(ctx, hipGetLastError());
+    int32_t ns = 0, nal = 0;
+    NC_HIP(ctx, hipMemcpyAsync(&ns, (int32_t *)s->site_of.p + na, 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipMemcpyAsync(&nal, (int32_t *)s->al_of.p + na, 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->n_sites = ns;
+    s->n_al = nal;
+    *n_sites = ns;
+    *n_alignments = nal;
+    if (ns == 0) {
+        if (timing) { NC_HIP(ctx, hipEventRecord(s->ev[1], ctx->stream)); }
+        return NC_OK;
+    }
+    const size_t NS = (size_t)ns;
+    NC_TRY(nc_ensure(ctx, s->site_pos, NS * 4));
+    NC_TRY(nc_ensure(ctx, s->site_chunk, NS * 4));
+    NC_TRY(nc_ensure(ctx, s->site_type, NS * 4));
+    NC_TRY(nc_ensure(ctx, s->site_phase, NS * 4));
+    NC_TRY(nc_ensure(ctx, s->site_al0, (NS + 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->site_nr, NS * 3 * 4));
+    NC_TRY(nc_ensure(ctx, s->site_n2, NS * 4));
+    NC_TRY(nc_ensure(ctx, s->al_read, (size_t)std::max(nal, 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->al_site, (size_t)std::max(nal, 1) * 4));
+    NC_TRY(nc_ensure(ctx, s->al_member, (size_t)std::max(nal, 1) + 16));
+    sa.site_of = (const int32_t *)s->site_of.p; sa.al_of = (const int32_t *)s->al_of.p;
+    sa.site_pos = (int32_t *)s->site_pos.p; sa.site_chunk = (int32_t *)s->site_chunk.p; sa.site_type = (int32_t *)s->site_type.p;
+    sa.site_phase = (int32_t *)s->site_phase.p; sa.site_al0 = (int32_t *)s->site_al0.p; sa.site_nr = (int32_t *)s->site_nr.p;
+    sa.site_n2 = (int32_t *)s->site_n2.p; sa.al_read = (int32_t *)s->al_read.p; sa.al_site = (int32_t *)s->al_site.p; sa.al_member = (uint8_t *)s->al_member.p;
+    hipLaunchKernelGGL(k_sets<true>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
+    NC_HIP(ctx, hipGetLastError());
+    NC_HIP(ctx, hipMemcpyAsync((int32_t *)s->site_al0.p + ns, &s->n_al, 4, hipMemcpyHostToDevice, ctx->stream));   // little endian: low word of n_al
+    s->site_al0_h.resize(NS + 1);
+    NC_HIP(ctx, hipMemcpyAsync(s->site_al0_h.data(), s->site_al0.p, NS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    s->site_al0_h[NS] = nal;
+    if (timing) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]);
+        s->stage_ms[0] = ms;
+    }
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
+{
+    if (!ctx) return NC_ERR_ARG;
+    nc_pipe_state *s = ctx->pipe;
+    if (!s || !s->planned) return nc_fail(ctx, NC_ERR_STATE, "nc_indel_sites_run: nc_indel_sites_plan first");
+    s->ran = true;
+    if (s->n_sites == 0) return NC_OK;
+    if (!x_dev) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_run: x_dev");
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const bool timing = ctx->timing == 1;
+    const int S = s->S, ns = s->n_sites;
+    const int W = s->window_after + 2;                             // n2 <= window_after + 1; row pitch n2 + 1
+    const int WS = (s->window_after + 15) & ~15;
+    const int N1 = WS;
+    const int CPL = cpl_for(s->window_after + 1);
+    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    // groups of whole sites: traceback codes of a group's alignments <= 12 GiB
+    const int64_t tw_per_al = (int64_t)(N1 + 1) * NWP * 64;
+    int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)12 << 30) / tw_per_al);
+    if (const char *g = getenv("NC_PIPE_GROUP_AL")) GROUP_AL = std::max<int64_t>(64, atoll(g));
+    const int64_t GROUP_SITES = 65536;
+    int32_t *err = (int32_t *)s->misc.p;
+    unsigned long long *cells = (unsigned long long *)((int32_t *)s->misc.p + 4);
+    long long *pool_base = (long long *)((int32_t *)s->misc.p + 8);
+    // ALT pool: generous (most ALT alleles are a few dozen bases); an overflow is reported, not silent
+    s->alt_pool_cap = std::max<int64_t>((int64_t)1 << 20, (int64_t)ns * S * 160);
+    NC_TRY(nc_ensure(ctx, s->alt_pool, (size_t)s->alt_pool_cap));
+    NC_TRY(nc_ensure(ctx, s->rlen, (size_t)ns * S * 4));
+    NC_TRY(nc_ensure(ctx, s->alen, (size_t)ns * S * 4));
+    const int32_t *al0h = s->site_al0_h.data();
+    int k0 = 0;
+    while (k0 < ns) {
+        int k1 = k0 + 1;
+        while (k1 < ns && k1 - k0 < GROUP_SITES && (int64_t)al0h[k1 + 1] - al0h[k0] <= GROUP_AL) k1++;
+        const int ng = k1 - k0;
+        const int64_t A0 = al0h[k0];
+        const int32_t Ag = al0h[k1] - al0h[k0];
+        const size_t Agz = (size_t)std::max(Ag, 1);
+        NC_TRY(nc_ensure(ctx, s->win, Agz * WS + 64));
+        NC_TRY(nc_ensure(ctx, s->n1, Agz * 4));
+        NC_TRY(nc_ensure(ctx, s->tw, Agz * (size_t)tw_per_al + 64));
+        NC_TRY(nc_ensure(ctx, s->hlast, Agz * W * 4));
+        NC_TRY(nc_ensure(ctx, s->hcol, Agz * (N1 + 1) * 4));
+        NC_TRY(nc_ensure(ctx, s->trace, (size_t)3 * Agz * W * 2));
+        NC_TRY(nc_ensure(ctx, s->cns, (size_t)ng * S * CNS_CAP));
+        NC_TRY(nc_ensure(ctx, s->ncns, (size_t)ng * S * 4));
+        NC_TRY(nc_ensure(ctx, s->arow, ((size_t)ng * S + 1) * 8));
+        NC_TRY(nc_ensure(ctx, s->alt_off, (size_t)ng * S * 8));
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[0], ctx->stream));
+        // ---- query windows
+        WinArgs wa;
+        wa.codes = s->pack.codes; wa.slot_off = s->rd.slot_off; wa.rd_start = s->rd.rd_start; wa.rd_end = s->rd.rd_end;
+        wa.ev_off = s->rd.ev_off; wa.ev_pos = s->rd.ev_pos; wa.ev_len = s->rd.ev_len; wa.ins_off = s->rd.ins_off; wa.tail_off = s->rd.tail_off;
+        wa.ins_bases = s->rd.ins_bases; wa.tail_bases = s->rd.tail_bases; wa.read_flag = s->rd.read_flag;
+        wa.al_read = (const int32_t *)s->al_read.p + A0; wa.al_site = (const int32_t *)s->al_site.p + A0;
+        wa.site_pos = (const int32_t *)s->site_pos.p; wa.site_n2 = (const int32_t *)s->site_n2.p;
+        wa.A = Ag; wa.W = s->window_after; wa.WS = WS; wa.win = (uint8_t *)s->win.p; wa.n1 = (int32_t *)s->n1.p; wa.cells = cells;
+        if (Ag > 0) hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, wa);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], ctx->stream));
+        // ---- star alignment: every read window against its site's reference window (free tail)
+        FillArgs fa;
+        fa.s1 = (const uint8_t *)s->win.p; fa.s1_stride = WS; fa.n1 = (const int32_t *)s->n1.p;
+        fa.ref_code = s->ref_code; fa.ref_pos0 = s->ref_pos0; fa.site_pos = (const int32_t *)s->site_pos.p; fa.site_n2 = (const int32_t *)s->site_n2.p;
+        fa.al_site = (const int32_t *)s->al_site.p + A0; fa.site0 = 0; fa.site_div = 1;
+        fa.A = Ag; fa.W = W;
+        fa.open = 25; fa.extend = 1; fa.match = 20; fa.mismatch = -10;          // the product's star-alignment scoring (_lib.STAR_SCORING)
+        if (const char *sc = getenv("NC_STAR_SCORING")) (void)sscanf(sc, "%d,%d,%d,%d", &fa.open, &fa.extend, &fa.match, &fa.mismatch);
+        fa.arow = nullptr; fa.N1 = N1;
+        fa.Tw = (uint32_t *)s->tw.p; fa.Hlast = (int32_t *)s->hlast.p; fa.hcol = (int32_t *)s->hcol.p;
+        if (Ag > 0) launch_fill(ctx, CPL, fa);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[2], ctx->stream));
+        int16_t *qidx = (int16_t *)s->trace.p, *il = qidx + Agz * W, *iq = il + Agz * W;
+        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, fa, CPL, qidx, il, iq);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], ctx->stream));
+        // ---- columns, histogram, tensor, consensus
+        TensorArgs ta;
+        ta.site0 = k0; ta.n_sites_g = ng; ta.S = S; ta.haploid = s->haploid; ta.W = W; ta.WS = WS; ta.A0 = A0;
+        ta.site_al0 = (const int32_t *)s->site_al0.p; ta.site_nr = (const int32_t *)s->site_nr.p; ta.site_pos = (const int32_t *)s->site_pos.p;
+        ta.site_n2 = (const int32_t *)s->site_n2.p; ta.al_member = (const uint8_t *)s->al_member.p; ta.win = (const uint8_t *)s->win.p;
+        ta.qidx = qidx; ta.il = il; ta.iq = iq; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
+        ta.cns = (uint8_t *)s->cns.p; ta.ncns = (int32_t *)s->ncns.p; ta.err = err;
+        hipLaunchKernelGGL(k_site_tensor, dim3(ng), dim3(256), 0, ctx->stream, ta);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], ctx->stream));
+        // ---- allele_prediction: global alignment of every consensus against its window (parasail scoring 9 / 1 / 20 / -10, :79)
+        const int nset = ng * S;
+        int32_t *mbox = (int32_t *)s->misc.p + 2;
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->ncns.p, nset, (int64_t *)s->arow.p, mbox);
+        NC_HIP(ctx, hipGetLastError());
+        int32_t mb[2] = {0, 0};
+        NC_HIP(ctx, hipMemcpyAsync(mb, mbox, 8, hipMemcpyDeviceToHost, ctx->stream));
+        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
+        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * NWP * 64 + 64));
+        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
+        FillArgs fb = fa;
+        fb.s1 = (const uint8_t *)s->cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)s->ncns.p;
+        fb.al_site = nullptr; fb.site0 = k0; fb.site_div = S;
+        fb.A = nset;
+        fb.open = 9; fb.extend = 1; fb.match = 20; fb.mismatch = -10;
+        fb.arow = (const int64_t *)s->arow.p; fb.N1 = 0;
+        fb.Tw = (uint32_t *)s->tw2.p; fb.Hlast = nullptr; fb.hcol = nullptr;
+        launch_fill(ctx, CPL, fb);
+        int32_t *rl = (int32_t *)s->rlen.p + (size_t)k0 * S, *al = (int32_t *)s->alen.p + (size_t)k0 * S;
+        hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, ctx->stream, fb, CPL, (const int32_t *)s->site_type.p, s->win_size,
+                           (int16_t *)s->runs.p, rl, al);
+        hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)al, nset, pool_base, (int64_t *)s->alt_off.p);
+        hipLaunchKernelGGL(k_alt_copy, dim3((nset + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t *)s->cns.p, (const int32_t *)al,
+                           (const int64_t *)s->alt_off.p, nset, (uint8_t *)s->alt_pool.p, s->alt_pool_cap, err);
+        NC_HIP(ctx, hipGetLastError());
+        if (timing) {
+            NC_HIP(ctx, hipEventRecord(s->ev[5], ctx->stream));
+            NC_HIP(ctx, hipEventSynchronize(s->ev[5]));
+            for (int st = 0; st < 5; st++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, s->ev[st], s->ev[st + 1]);
+                s->stage_ms[st + 1] += ms;
+            }
+            s->cells[1] += rows * (int64_t)(s->window_after + 1);
+        }
+        k0 = k1;
+    }
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_fetch(nc_ctx *ctx, int32_t *pos, int32_t *chunk, int32_t *var_type, int32_t *phase, int32_t *ref_len,
+                                    int32_t *alt_len, int64_t *n_alt_bytes)
+{
+    if (!ctx) return NC_ERR_ARG;
+    nc_pipe_state *s = ctx->pipe;
+    if (!s || !s->planned) return nc_fail(ctx, NC_ERR_STATE, "nc_indel_sites_fetch: nc_indel_sites_plan first");
+    if (n_alt_bytes) *n_alt_bytes = 0;
+    if (s->n_sites == 0) return NC_OK;
+    const size_t NS = (size_t)s->n_sites;
+    auto cp = [&](void *dst, const DevBuf &b, size_t bytes) -> int {
+        if (dst) NC_HIP(ctx, hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return NC_OK;
+    };
+    NC_TRY(cp(pos, s->site_pos, NS * 4));
+    NC_TRY(cp(chunk, s->site_chunk, NS * 4));
+    NC_TRY(cp(var_type, s->site_type, NS * 4));
+    NC_TRY(cp(phase, s->site_phase, NS * 4));
+    int32_t misc[16] = {0};
+    if (s->ran) {
+        NC_TRY(cp(ref_len, s->rlen, NS * s->S * 4));
+        NC_TRY(cp(alt_len, s->alen, NS * s->S * 4));
+    }
+    NC_HIP(ctx, hipMemcpyAsync(misc, s->misc.p, sizeof misc, hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (misc[0] & 2) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites: a read set needs more than %d alignment columns", CNS_CAP);
+    if (misc[0] & 4) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites: ALT allele pool overflow");
+    long long cells = 0, pool = 0;
+    memcpy(&cells, misc + 4, 8);
+    memcpy(&pool, misc + 8, 8);
+    s->cells[0] = cells;
+    if (n_alt_bytes) *n_alt_bytes = pool;
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_fetch_alt(nc_ctx *ctx, uint8_t *alt_bases, int64_t cap)
+{
+    if (!ctx) return NC_ERR_ARG;
+    nc_pipe_state *s = ctx->pipe;
+    if (!s || !s->ran) return nc_fail(ctx, NC_ERR_STATE, "nc_indel_sites_fetch_alt: nc_indel_sites_run first");
+    if (cap <= 0 || s->n_sites == 0) return NC_OK;
+    if (!alt_bases) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_fetch_alt: null buffer");
+    NC_HIP(ctx, hipMemcpyAsync(alt_bases, s->alt_pool.p, (size_t)std::min<int64_t>(cap, s->alt_pool_cap), hipMemcpyDeviceToHost, ctx->stream));
+    NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_stage_ms(nc_ctx *ctx, float *ms6, int64_t *cells2)
+{
+    if (!ctx || !ctx->pipe) return NC_ERR_ARG;
+    if (ms6) for (int k = 0; k < 6; k++) ms6[k] = ctx->pipe->stage_ms[k];
+    if (cells2) { cells2[0] = ctx->pipe->cells[0]; cells2[1] = ctx->pipe->cells[1]; }
+    return NC_OK;
+}

@@ -346,3 +346,128 @@ extern "C" int nc_bgzf_compress(const uint8_t *data, int64_t n, int32_t level, u
     *n_out = w + 28;
     return NC_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Indel genotype rules + VCF record text (indelCaller.py:87-152; haploid :173-179), as nanocaller_amd/indelCaller.py::
+// indel_vcf_lines[_haploid] state them: float32 arithmetic for QUAL / GQ (`batch_prob_all` is a float32 tensor in the reference),
+// '%.2f' of the float32 value widened to double.  Sites arrive chunk-major (nc_indel_sites_fetch); `prev` restarts per chunk.
+extern "C" int nc_indel_vcf_format(const char *chrom, int64_t n, const int32_t *pos, const int32_t *chunk, int32_t n_chunks, const float *probs,
+                                   int32_t sets, const int32_t *ref_len, const int32_t *alt_len, const uint8_t *alt_bases, const int32_t *phase,
+                                   const char *contig, int64_t chrom_len, int32_t haploid, char *out, int64_t cap, int64_t *n_bytes,
+                                   int64_t *chunk_txt_off)
+{
+    if (!chrom || n < 0 || !n_bytes || (n && (!pos || !chunk || !probs || !ref_len || !alt_len || !contig || !out)) || (sets != 1 && sets != 3) ||
+        (haploid ? sets != 1 : sets != 3) || n_chunks < 0)
+        return NC_ERR_ARG;
+    static const char LET[8] = {'A', 'G', 'T', 'C', 'N', 'N', 'N', 'N'};
+    const size_t lc = strlen(chrom);
+    // offsets of the ALT prefixes: (site, set) order, lengths max(alt_len, 0)
+    std::vector<int64_t> aoff((size_t)n * sets + 1, 0);
+    for (int64_t k = 0; k < n * sets; k++) aoff[(size_t)k + 1] = aoff[(size_t)k] + (alt_len[k] > 0 ? alt_len[k] : 0);
+    if (aoff[(size_t)n * sets] && !alt_bases) return NC_ERR_ARG;
+    char *o = out, *const end = out + cap;
+    int32_t cur_chunk = -1, prev = 0;
+    int next_chunk_mark = 0;
+    auto mark = [&](int upto) { if (chunk_txt_off) for (; next_chunk_mark <= upto && next_chunk_mark <= n_chunks; next_chunk_mark++) chunk_txt_off[next_chunk_mark] = o - out; };
+    auto q10 = [](float x) { return -10.0f * log10f(x); };
+    struct Al { const char *ref; int32_t rl; const uint8_t *alt; int32_t al; bool ok; };
+    for (int64_t j = 0; j < n; j++) {
+        if (chunk[j] != cur_chunk) {
+            if (chunk[j] < cur_chunk || chunk[j] >= (n_chunks ? n_chunks : INT32_MAX)) return NC_ERR_ARG;      // chunk-major order
+            cur_chunk = chunk[j];
+            prev = 0;
+            mark(cur_chunk);
+        }
+        const int32_t pj = pos[j];
+        if (!(pj > prev)) continue;                                                 // :93
+        Al a[3];
+        int64_t need = 64 + (int64_t)lc;
+        for (int t = 0; t < sets; t++) {
+            const int32_t rl = ref_len[j * sets + t], al = alt_len[j * sets + t];
+            a[t].ok = rl > 0;                                                       // `if at[0]`: None and '' are both false
+            a[t].rl = rl;
+            a[t].al = al > 0 ? al : 0;
+            a[t].ref = contig + (pj - 1);
+            a[t].alt = alt_bases ? alt_bases + aoff[(size_t)(j * sets + t)] : nullptr;
+            if (a[t].ok && (pj < 1 || (int64_t)pj - 1 + rl > chrom_len)) return NC_ERR_ARG;
+            if (a[t].ok) need += 2 * ((int64_t)rl + a[t].al);
+        }
+        if (end - o < need + 64) return NC_ERR_CAPACITY;
+        auto head = [&]() { o = put_str(o, chrom, lc); *o++ = '\t'; o = put_int(o, pj); o = PUT_LIT(o, "\t.\t"); };
+        auto put_alt = [&](const uint8_t *s, int32_t len) { for (int32_t i = 0; i < len; i++) *o++ = LET[s[i] & 7]; };
+        if (haploid) {
+            const float p0 = probs[j];
+            if (!(p0 >= 0.5f) || !a[0].ok) continue;                                // :173
+            const float q = -100.0f * log10f((float)(1e-6 + 1) - p0);
+            head();
+            o = put_str(o, a[0].ref, (size_t)a[0].rl); *o++ = '\t';
+            put_alt(a[0].alt, a[0].al); *o++ = '\t';
+            o = put_fixed(o, (double)q, 2);
+            o = PUT_LIT(o, "\tPASS\t.\tGT:GQ\t1/1:");
+            o = put_fixed(o, (double)q, 2);
+            *o++ = '\n';
+            prev = pj + std::max(a[0].rl, a[0].al);
+            continue;
+        }
+        const float *pr = probs + j * 4;
+        if (!(pr[0] <= 0.95f)) continue;                                            // :95
+        int pred = 0;
+        for (int k = 1; k < 4; k++) if (pr[k] > pr[pred]) pred = k;                 // np.argmax: first maximum
+        const float q = q10(1e-6f + pr[0]);                                         // :97
+        const float one = (float)(1 + 1e-6);
+        const Al &a0 = a[0], &a1 = a[1], &at = a[2];
+        auto tail_simple = [&](const char *gt, float gq, bool with_ps) {
+            *o++ = '\t';
+            o = put_fixed(o, (double)q, 2);
+            o = PUT_LIT(o, "\tPASS\t.\tGT:GQ");
+            if (with_ps) o = PUT_LIT(o, ":PS");
+            *o++ = '\t';
+            o = put_str(o, gt, 3);
+            *o++ = ':';
+            o = put_fixed(o, (double)gq, 2);
+            if (with_ps) { *o++ = ':'; o = put_int(o, phase[j]); }
+            *o++ = '\n';
+        };
+        const bool ps = phase && phase[j] != 0;                                     // `if phase[j]:` (None and 0 are false)
+        if (pred == 1 && at.ok) {                                                   // :100
+            head();
+            o = put_str(o, at.ref, (size_t)at.rl); *o++ = '\t';
+            put_alt(at.alt, at.al);
+            tail_simple("1/1", q10(one - pr[1]), false);
+            prev = pj + std::max(at.rl, at.al);
+        } else if (a0.ok && a1.ok) {
+            if (a0.rl == a1.rl && a0.al == a1.al && memcmp(a0.alt, a1.alt, (size_t)a0.al) == 0) {       // :109
+                head();
+                o = put_str(o, a0.ref, (size_t)a0.rl); *o++ = '\t';
+                put_alt(a0.alt, a0.al);
+                tail_simple("1/1", q10(one - pr[1]), false);
+                prev = pj + std::max(a0.rl, a0.al);
+            } else {                                                                // :115-133 het-alt, alleles padded to one REF
+                const int32_t ln = std::min(a0.rl, a1.rl);
+                const bool first_longer = a0.rl > a1.rl;
+                const int32_t rl = first_longer ? a0.rl : a1.rl, pad = rl - ln;
+                const int32_t l1 = a0.al + (first_longer ? 0 : pad), l2 = a1.al + (first_longer ? pad : 0);
+                head();
+                o = put_str(o, contig + (pj - 1), (size_t)rl); *o++ = '\t';
+                put_alt(a0.alt, a0.al);
+                if (!first_longer) o = put_str(o, contig + (pj - 1) + ln, (size_t)pad);
+                *o++ = ',';
+                put_alt(a1.alt, a1.al);
+                if (first_longer) o = put_str(o, contig + (pj - 1) + ln, (size_t)pad);
+                tail_simple("1|2", q10(one - pr[3]), ps);
+                prev = pj + std::max(rl, std::max(l1, l2));
+            }
+        } else if (a0.ok || a1.ok) {                                                // :135-151
+            const Al &x = a0.ok ? a0 : a1;
+            head();
+            o = put_str(o, x.ref, (size_t)x.rl); *o++ = '\t';
+            put_alt(x.alt, x.al);
+            tail_simple(a0.ok ? "0|1" : "1|0", q10(one - pr[2]), ps);
+            prev = pj + std::max(x.rl, x.al);
+        }
+    }
+    mark(n_chunks);
+    *n_bytes = o - out;
+    return NC_OK;
+}

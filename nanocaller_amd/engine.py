@@ -35,6 +35,7 @@ class DevicePack:
     pos_lo: int
     pos_hi: int
     events: dict | None = None    # device tensors ev_off / ev_pos / ev_len / read_hap (indel scan inputs)
+    reads: dict | None = None     # device tensors rd_start / rd_end / slot_off of the kept reads (device pass 2: tile entry -> read)
 
     def c_struct(self) -> _lib.ReadPackC:
         return _lib.ReadPackC(codes_len=self.codes.numel(), codes=self.codes.data_ptr(), tile_size=self.tile_size,

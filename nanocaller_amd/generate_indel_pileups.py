@@ -549,8 +549,221 @@ def _gc_paused():
 MAX_BATCH_CHUNKS = 64          # chunks per native pass-2 / alignment call (100 kb chunks at 30x: ~15 k anchors, ~150 MB of read windows)
 
 
+
+# ------------------------------------------------------------------------------------------------- device-resident pass 1 + 2
+TAIL_CAP = 272                 # query bases kept behind a read's last aligned base (>= the longest window, 260 + rounding)
+
+
+def device_indel_reads(ctg, flag, dp, device):
+    """The per-read inputs of the device pass 2 beyond the read pack: inserted bases of every insertion event, the bases that
+    follow the last aligned one, PS tags (nc_indel_pack_build), uploaded once per (contig, flag filter).  -> (IndelReadsC, tensors)"""
+    key = ("dev_reads", flag, device)
+    if key not in ctg:
+        L = _lib.lib()
+        keep = ctg["keep"][flag]
+        h = C.c_void_p()
+        rc = L.nc_indel_pack_build(ctg["handle"], _lib.npp(keep), TAIL_CAP, C.byref(h))
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_indel_pack_build failed (%d)" % rc)
+        try:
+            v = _lib.IndelPackArraysC()
+            L.nc_indel_pack_view(h, C.byref(v))
+            if dp.events is None or dp.reads is None or v.n_reads != dp.events["n_reads"] or v.n_reads != dp.reads["n_reads"]:
+                raise _lib.NanoCallerHipError("the contig's read pack carries no indel events / read table for %d kept reads" % v.n_reads)
+            dev = get_engine(device).device
+
+            def up(ptr, cnt, dt):
+                a = np.frombuffer((C.c_char * (int(cnt) * np.dtype(dt).itemsize)).from_address(ptr), dt) if cnt and ptr else np.zeros(0, dt)
+                a = a if a.size else np.zeros(4, dt)
+                return torch.from_numpy(a.copy()).to(dev)
+            t = dict(ins_off=up(v.ins_off, v.n_events + 1, np.int32), ins_bases=up(v.ins_bases, v.n_ins_bases, np.uint8),
+                     tail_off=up(v.tail_off, v.n_reads + 1, np.int32), tail_bases=up(v.tail_bases, v.n_tail_bases, np.uint8),
+                     read_ps=up(v.read_ps, v.n_reads, np.int32), read_flag=up(v.read_flag, v.n_reads, np.uint8))
+        finally:
+            L.nc_indel_pack_free(h)
+        ev, rd = dp.events, dp.reads
+        st = _lib.IndelReadsC(n_reads=rd["n_reads"], slot_off=rd["slot_off"].data_ptr(), rd_start=rd["rd_start"].data_ptr(), rd_end=rd["rd_end"].data_ptr(),
+                              ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(), ev_len=ev["ev_len"].data_ptr(),
+                              ins_off=t["ins_off"].data_ptr(), ins_bases=t["ins_bases"].data_ptr(), tail_off=t["tail_off"].data_ptr(),
+                              tail_bases=t["tail_bases"].data_ptr(), read_ps=t["read_ps"].data_ptr(), read_hap=ev["read_hap"].data_ptr(),
+                              read_flag=t["read_flag"].data_ptr())
+        ctg[key] = (st, t, dp)                                       # dp: keeps the pack's tensors alive with the pointers
+    return ctg[key][0]
+
+
+def indel_sites_device(eng, dp, reads_c, chrom_len, chunks, *, mincov, maxcov, win_size, small_win_size, ins_t, del_t, window_after,
+                       haploid=False, excl=None, fetch=True):
+    """nc_indel_sites_plan + _run (+ _fetch) for a list of (start, end) chunks of one contig -> dict: n, x (device float32
+    [n, sets * 5, 128, 2]: the CNN input), and with fetch: pos / chunk / type / phase int32 [n], ref_len / alt_len int32 [n, sets],
+    alt (uint8 codes, the ALT prefixes back to back in (site, set) order).  Raises NanoCallerHipError with .status."""
+    L = eng.L
+    prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size), ins_t=float(ins_t),
+                                del_t=float(del_t), haploid=1 if haploid else 0, impute=0)
+    starts = np.ascontiguousarray([c[0] for c in chunks], np.int32)
+    ends = np.ascontiguousarray([c[1] for c in chunks], np.int32)
+    pc = dp.c_struct()
+    n, na = C.c_int32(), C.c_int64()
+
+    def check(rc, what):
+        if rc != _lib.NC_OK:
+            msg = L.nc_last_error(eng.ctx)
+            err = _lib.NanoCallerHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+            err.status = rc
+            raise err
+    check(L.nc_indel_sites_plan(eng.ctx, C.byref(pc), C.c_void_p(dp.ref_code.data_ptr()), dp.tile_pos0, dp.ref_code.numel(), int(chrom_len),
+                                C.byref(reads_c), C.c_void_p(excl.data_ptr()) if excl is not None else None, len(chunks), _lib.npp(starts),
+                                _lib.npp(ends), C.byref(prm), int(window_after), int(maxcov), C.byref(n), C.byref(na)), "nc_indel_sites_plan")
+    S = 1 if haploid else 3
+    N = n.value
+    x = torch.empty((N, S * 5, 128, 2), dtype=torch.float32, device=eng.device)
+    check(L.nc_indel_sites_run(eng.ctx, C.c_void_p(x.data_ptr())), "nc_indel_sites_run")
+    out = dict(n=N, sets=S, x=x, n_alignments=na.value)
+    if fetch:
+        out.update(indel_sites_fetch(eng, N, S))
+    return out
+
+
+def indel_sites_fetch(eng, N, S):
+    L = eng.L
+    pos, chunk, typ, phase = (np.empty(max(N, 1), np.int32) for _ in range(4))
+    rl, al = np.empty((max(N, 1), S), np.int32), np.empty((max(N, 1), S), np.int32)
+    nb = C.c_int64()
+    rc = L.nc_indel_sites_fetch(eng.ctx, _lib.npp(pos), _lib.npp(chunk), _lib.npp(typ), _lib.npp(phase), _lib.npp(rl), _lib.npp(al), C.byref(nb))
+    if rc != _lib.NC_OK:
+        msg = L.nc_last_error(eng.ctx)
+        err = _lib.NanoCallerHipError("nc_indel_sites_fetch failed (%d): %s" % (rc, msg.decode() if msg else ""))
+        err.status = rc
+        raise err
+    alt = np.empty(max(int(nb.value), 1), np.uint8)
+    if nb.value:
+        rc = L.nc_indel_sites_fetch_alt(eng.ctx, _lib.npp(alt), int(nb.value))
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_indel_sites_fetch_alt failed (%d)" % rc)
+    return dict(pos=pos[:N], chunk=chunk[:N], type=typ[:N], phase=phase[:N], ref_len=rl[:N], alt_len=al[:N], alt=alt[:int(nb.value)])
+
+
+def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
+    """The device pipeline for chunks (ascending) of one BAM and contig -> (result dict of indel_sites_device, contig dict)"""
+    chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
+    window_after = 260 if dct["seq"] == "pacbio" else 160
+    ctg = decoded_contig(sam_path, chrom, dct["fasta_path"])
+    supp = bool(dct.get("supplementary"))
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if supp else 0x800)
+    if flag not in ctg["keep"]:
+        from .pack import pileup_depth_cap
+        dec = ctg["dec"]
+        ctg["keep"][flag] = pileup_depth_cap(dec["read_start"], dec["read_end"], np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8))
+    eng = get_engine(device)
+    eng.use_torch_stream()
+    dp = device_pack(sam_path, dct.get("fasta_path"), chrom, supp, None, device)[0]
+    reads_c = device_indel_reads(ctg, flag, dp, device)
+    excl = None
+    excl_rows = _exclude_rows(dct, chrom)
+    if excl_rows:
+        m = np.zeros(dp.n_tiles * dp.tile_size, np.uint8)
+        for (a, b) in excl_rows:
+            m[max(0, a - dp.tile_pos0):max(0, b - dp.tile_pos0)] = 1
+        excl = torch.from_numpy(m).to(eng.device)
+    r = indel_sites_device(eng, dp, reads_c, len(ctg["fasta"]), [(c["start"], c["end"]) for c in chunks], mincov=dct["mincov"], maxcov=dct["maxcov"],
+                           win_size=dct["win_size"], small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"],
+                           window_after=window_after, haploid=haploid, excl=excl, fetch=fetch)
+    return r, ctg
+
+
+def _indel_batch_device(dct, chunks, device, haploid, device_x):
+    """_indel_batch on the device-resident pipeline (no impute_indel_phase): the per-chunk tuples of the reference's calls"""
+    order = sorted(range(len(chunks)), key=lambda k: (chunks[k]["start"], chunks[k]["end"]))
+    r, ctg = indel_sites_for_chunks(dct, [chunks[k] for k in order], device, haploid)
+    tuples = sites_to_tuples(r, len(chunks), ctg["fasta"], haploid, device_x)
+    out = [None] * len(chunks)
+    for k, t in zip(order, tuples):
+        out[k] = t
+    return out
+
+
+def device_route_ok(dct, chunks, haploid):
+    """the device pipeline covers BAM inputs without impute_indel_phase (whose read grouping needs the pileup strings)"""
+    return (isinstance(chunks[0]["sam_path"], str) and not (dct.get("impute_indel_phase") and not haploid)
+            and not os.environ.get("NC_INDEL_HOST_PASS2"))
+
+
+def indel_chunks_vcf_text(dct, chunks, device, haploid, model_kind):
+    """candidates -> tensors -> Indel_model -> genotype rules -> VCF record text for chunks of one BAM and contig, without a
+    Python object per site: nc_indel_sites_* (device), nc_indel_forward (K9), nc_indel_vcf_format (native host rules).
+    -> list of bytes, the records of every chunk (what indelCaller.indel_run writes chunk by chunk)"""
+    order = sorted(range(len(chunks)), key=lambda k: (chunks[k]["start"], chunks[k]["end"]))
+    r, ctg = indel_sites_for_chunks(dct, [chunks[k] for k in order], device, haploid)
+    out = [b""] * len(chunks)
+    N, S = r["n"], r["sets"]
+    if N == 0:
+        return out
+    eng = get_engine(device)
+    probs = eng.indel_forward(model_kind, r["x"]).cpu().numpy()
+    del r["x"]
+    L = eng.L
+    chrom = chunks[0]["chrom"].encode()
+    cap = int(N) * (96 + len(chrom)) + 2 * int(np.maximum(r["ref_len"], 0).sum() + np.maximum(r["alt_len"], 0).sum()) * 2 + 4096
+    buf = np.empty(cap, np.uint8)
+    nb = C.c_int64()
+    coff = np.empty(len(chunks) + 1, np.int64)
+    pos, chunk, phase = (np.ascontiguousarray(r[k], np.int32) for k in ("pos", "chunk", "phase"))
+    rl, al = np.ascontiguousarray(r["ref_len"], np.int32), np.ascontiguousarray(r["alt_len"], np.int32)
+    rc = L.nc_indel_vcf_format(chrom, N, _lib.npp(pos), _lib.npp(chunk), len(chunks), _lib.npp(np.ascontiguousarray(probs, np.float32)), S,
+                               _lib.npp(rl), _lib.npp(al), _lib.npp(np.ascontiguousarray(r["alt"], np.uint8)), _lib.npp(phase), ctg["fasta_b"],
+                               len(ctg["fasta"]), 1 if haploid else 0, _lib.npp(buf), cap, C.byref(nb), _lib.npp(coff))
+    if rc != _lib.NC_OK:
+        raise _lib.NanoCallerHipError("nc_indel_vcf_format failed (%d)" % rc)
+    raw = buf[:nb.value].tobytes()
+    co = coff.tolist()
+    for j, k in enumerate(order):
+        out[k] = raw[co[j]:co[j + 1]]
+    return out
+
+
+def sites_to_tuples(r, n_chunks, fasta, haploid, device_x):
+    """the per-chunk tuples get_indel_testing_candidates[_haploid] returns, from the arrays of the device pipeline"""
+    N, S = r["n"], r["sets"]
+    empty = ([], [], []) if haploid else ([], [], [], [], [], [])
+    if N == 0:
+        return [empty for _ in range(n_chunks)]
+    x = r["x"] if device_x else r["x"].cpu().numpy().astype(np.float64)
+    pos, chunk = r["pos"].tolist(), r["chunk"]
+    rl, al = r["ref_len"].reshape(-1).tolist(), r["alt_len"].reshape(-1).tolist()
+    alt_all = np.frombuffer(b"AGTCN", np.uint8)[r["alt"]].tobytes().decode("ascii")
+    alleles, o = [], 0
+    for k in range(N):
+        p, row = pos[k], []
+        for t in range(S):
+            a, b = rl[k * S + t], al[k * S + t]
+            if a < 0:
+                row.append((None, None))
+            else:
+                row.append((fasta[p - 1:p - 1 + a], alt_all[o:o + b]))
+            o += max(b, 0)
+        alleles.append(row)
+    phase = r["phase"].tolist()
+    bounds = np.searchsorted(chunk, np.arange(n_chunks + 1))                       # sites are chunk-major
+    out = []
+    for ci in range(n_chunks):
+        a, b = int(bounds[ci]), int(bounds[ci + 1])
+        if a == b:
+            out.append(empty)
+        elif haploid:
+            out.append((pos[a:b], x[a:b], [alleles[k][0] for k in range(a, b)]))
+        else:
+            out.append((pos[a:b], x[a:b, 0:5], x[a:b, 5:10], x[a:b, 10:15], alleles[a:b], phase[a:b]))
+    return out
+
 def _indel_batch(dct, chunks, device, haploid, device_x):
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
+    if device_route_ok(dct, chunks, haploid):
+        # everything between the column decisions and the CNN input on the device (nc_pipe.hip); a capacity limit of that route
+        # (sets of > 1024 alignment columns, chunks of > 130 kb) sends the group through the host-assembled route below
+        try:
+            return _indel_batch_device(dct, chunks, device, haploid, device_x)
+        except _lib.NanoCallerHipError as e:
+            if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY:
+                raise
     window_after = 260 if dct["seq"] == "pacbio" else 160
     extras = [dict() for _ in chunks]
     ctg = decoded_contig(sam_path, chrom, dct["fasta_path"]) if isinstance(sam_path, str) else None   # before pass 1: one decode for both

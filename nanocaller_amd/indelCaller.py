@@ -131,7 +131,8 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
 
     from . import _lib
     from .engine import get_engine
-    from .generate_indel_pileups import default_aligner, get_indel_testing_candidates, get_indel_testing_candidates_batch, star_aligner
+    from .generate_indel_pileups import (default_aligner, device_route_ok, get_indel_testing_candidates, get_indel_testing_candidates_batch,
+                                         indel_chunks_vcf_text, star_aligner)
     from .generate_indel_pileups_haploid import get_indel_testing_candidates_haploid
     from .weights import Weights
     curr_vcf_path = os.path.join(params['intermediate_indel_files_dir'], '%s.%d.indel.vcf' % (params['prefix'], worker_id))
@@ -215,14 +216,32 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
             for k, job in enumerate(jobs):
                 c = job[1]
                 groups.setdefault((c['sam_path'], c['chrom'], c['ploidy']), []).append(k)
-            results = [None] * len(jobs)
+            # Each group is featurised, called and WRITTEN before the next one starts: nothing of a group outlives it in HBM.  The
+            # usual case runs without a Python object per site: device pipeline -> K9 -> native rules -> text (indel_chunks_vcf_text);
+            # impute_indel_phase, or a capacity limit of the device route, goes through the per-chunk tuples.
+            import os as _os
             for (sam, chrom, ploidy), ks in groups.items():
-                tuples = get_indel_testing_candidates_batch(params, [jobs[k][1] for k in ks], device=device, haploid=(ploidy == 'haploid'),
-                                                            device_x=True)
-                for k, t, pr in zip(ks, tuples, forward(ploidy, tuples)):
-                    results[k] = (t, pr)
-            for job, (t, pr) in zip(jobs, results):
-                emit(f, job[1], t, pr)
+                group = [jobs[k][1] for k in ks]
+                hap = ploidy == 'haploid'
+                texts = None
+                if device_route_ok(params, group, hap) and not _os.environ.get("NC_INDEL_PY_RULES"):
+                    try:
+                        texts = indel_chunks_vcf_text(params, group, device, hap, _lib.MODEL_INDEL_HAP if hap else _lib.MODEL_INDEL)
+                    except _lib.NanoCallerHipError as e:
+                        if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY:
+                            raise
+                if texts is not None:
+                    for txt in texts:
+                        f.write(txt.decode("ascii"))
+                        f.flush()
+                        os.fsync(f.fileno())
+                        counter_Q.put(1)
+                    continue
+                tuples = get_indel_testing_candidates_batch(params, group, device=device, haploid=hap, device_x=True)
+                probs = forward(ploidy, tuples)
+                tuples = [tuple(None if torch.is_tensor(v) else v for v in t) for t in tuples]        # the tensors are not needed any more
+                for k, t, pr in zip(ks, tuples, probs):
+                    emit(f, jobs[k][1], t, pr)
     return curr_vcf_path
 
 

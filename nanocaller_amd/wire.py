@@ -189,6 +189,7 @@ def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
                     tile_pos0=wp.tile_pos0, n_tiles=wp.n_tiles, n_entries=wp.n_entries, pos_lo=wp.pos_lo, pos_hi=wp.pos_hi)
     if wp.n_indel_reads >= 0:
         dp.events = dict(n_reads=wp.n_indel_reads, ev_off=g(v["ev_off"]), ev_pos=g(v["ev_pos"]), ev_len=g(v["ev_len"]), read_hap=g(v["read_hap"]))
+        dp.reads = dict(n_reads=wp.n_reads, rd_start=g(v["rd_start"]), rd_end=g(v["rd_end"]), slot_off=g(v["slot_off"]))
     return dp
 
 

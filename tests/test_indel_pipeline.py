@@ -1,0 +1,264 @@
+"""The device-resident indel path (csrc/nc_pipe.hip: nc_indel_sites_plan / _run / _fetch, rows a10-a15 of SURVEY.md 8a) and its host pieces.
+
+CPU: nc_indel_pack_build (bases without a reference column) against a restatement from the decoded query sequences;
+nc_decoded_check (reference skips, same-name overlaps -> NC_ERR_UNSUPPORTED); nc_indel_vcf_format against the Python statement
+of the reference's rules (indelCaller.indel_vcf_lines[_haploid], itself pinned by the reference's indel_run() text).
+GPU: the device pipeline returns, chunk by chunk, exactly the tuples of the host-assembled route (nc_indel_pass2_sets ->
+nc_star_msa_tensor_dup -> nc_allele_prediction_device), which tests/test_pass2_golden.py pins to the reference's own outputs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from nanocaller_amd import _lib, indelCaller
+from nanocaller_amd import generate_indel_pileups as gip
+from nanocaller_amd.bam import decode_parallel
+
+import bamio
+
+
+@pytest.fixture(scope="module")
+def world_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pipe")
+    w = bamio.make_pass2_world(seed=11, length=150_000, depth=26)
+    bam, fa = str(d / "p.bam"), str(d / "p.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, None))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    return w, bam, fa
+
+
+def _pack(dec, keep, tail_cap):
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.nc_indel_pack_build(dec["_owner"].handle, _lib.npp(keep), tail_cap, C.byref(h)) == _lib.NC_OK
+    v = _lib.IndelPackArraysC()
+    L.nc_indel_pack_view(h, C.byref(v))
+
+    def arr(ptr, n, dt):
+        return np.frombuffer((C.c_char * (int(n) * np.dtype(dt).itemsize)).from_address(ptr), dt).copy() if n else np.zeros(0, dt)
+    out = dict(n=v.n_reads, ev_off=arr(v.ev_off, v.n_reads + 1, np.int32), ev_pos=arr(v.ev_pos, v.n_events, np.int32),
+               ev_len=arr(v.ev_len, v.n_events, np.int32), ins_off=arr(v.ins_off, v.n_events + 1, np.int32),
+               ins=arr(v.ins_bases, v.n_ins_bases, np.uint8), tail_off=arr(v.tail_off, v.n_reads + 1, np.int32),
+               tail=arr(v.tail_bases, v.n_tail_bases, np.uint8), ps=arr(v.read_ps, v.n_reads, np.int32), hap=arr(v.read_hap, v.n_reads, np.uint8),
+               flag=arr(v.read_flag, v.n_reads, np.uint8))
+    L.nc_indel_pack_free(h)
+    return out
+
+
+def test_indel_pack_holds_the_bases_without_a_reference_column(world_files):
+    w, bam, fa = world_files
+    dec = decode_parallel(bam, w.chrom, keep_seq=True)
+    n = len(dec["read_start"])
+    keep = np.ascontiguousarray((dec["read_flag"] & 0xF04) == 0, np.uint8)
+    keep[::17] = 0
+    p = _pack(dec, keep, 40)
+    kept = np.nonzero(keep)[0]
+    assert p["n"] == len(kept) and n > 300
+    n_ins = n_tail = 0
+    for k, r in enumerate(kept.tolist()):
+        e0, e1 = int(dec["ev_off"][r]), int(dec["ev_off"][r + 1])
+        assert p["ev_off"][k + 1] - p["ev_off"][k] == e1 - e0
+        w0 = int(p["ev_off"][k])
+        assert np.array_equal(p["ev_pos"][w0:w0 + e1 - e0], dec["ev_pos"][e0:e1]) and np.array_equal(p["ev_len"][w0:w0 + e1 - e0], dec["ev_len"][e0:e1])
+        assert p["ps"][k] == dec["ps"][r] and p["hap"][k] == dec["hap"][r] and p["flag"][k] == 0
+        seq = dec["seq"][dec["seq_off"][r]:dec["seq_off"][r + 1]]
+        q, rp = int(dec["qstart"][r]), int(dec["read_start"][r])
+        for e in range(e0, e1):                                                   # the query walk of the CIGAR, event by event
+            ep, el = int(dec["ev_pos"][e]), int(dec["ev_len"][e])
+            q += ep - rp + 1
+            rp = ep + 1
+            a, b = int(p["ins_off"][w0 + e - e0]), int(p["ins_off"][w0 + e - e0 + 1])
+            if el > 0:
+                assert np.array_equal(p["ins"][a:b], seq[q:q + el])
+                q += el
+                n_ins += 1
+            else:
+                assert a == b
+                rp += -el
+        q += int(dec["read_end"][r]) - rp
+        t0, t1 = int(p["tail_off"][k]), int(p["tail_off"][k + 1])
+        assert np.array_equal(p["tail"][t0:t1], seq[q:q + 40])
+        n_tail += t1 - t0
+    assert n_ins > 100 and n_tail == 2 * len(kept)                                 # world_to_records ends every read with a 2-base soft clip
+
+
+def test_unsupported_inputs_are_reported_not_accepted(tmp_path):
+    """a reference-skip CIGAR and two overlapping alignments with one read name (quirks E10, Appendix A.1): NC_ERR_UNSUPPORTED"""
+    L = _lib.lib()
+    ref = "ACGT" * 500
+
+    def dec_of(recs, name):
+        bam = str(tmp_path / name)
+        bamio.write_bam(bam, "c", len(ref), recs)
+        return decode_parallel(bam, "c", keep_seq=True)
+
+    def check(dec, keep=None):
+        a, b = C.c_int64(), C.c_int64()
+        rc = L.nc_decoded_check(dec["_owner"].handle, _lib.npp(keep) if keep is not None else None, C.byref(a), C.byref(b))
+        return rc, a.value, b.value
+    ok = [dict(name="r1", flag=0, pos0=10, cigar=[("M", 50)], seq="A" * 50), dict(name="r2", flag=16, pos0=30, cigar=[("M", 20), ("D", 3), ("M", 20)], seq="C" * 40)]
+    assert check(dec_of(ok, "ok.bam")) == (_lib.NC_OK, 0, 0)
+    skip = ok + [dict(name="r3", flag=0, pos0=40, cigar=[("M", 10), ("N", 100), ("M", 10)], seq="G" * 20)]
+    d = dec_of(skip, "skip.bam")
+    assert check(d) == (_lib.NC_ERR_UNSUPPORTED, 1, 0)
+    assert (d["read_flag"] & _lib.FLAG_REFSKIP).tolist() == [0, 0, _lib.FLAG_REFSKIP]
+    assert check(d, np.array([1, 1, 0], np.uint8)) == (_lib.NC_OK, 0, 0)           # ... unless the flag filter drops the read
+    dup = ok + [dict(name="r1", flag=0x800, pos0=45, cigar=[("M", 30)], seq="T" * 30), dict(name="r2", flag=0x800, pos0=500, cigar=[("M", 30)], seq="T" * 30)]
+    d = dec_of(dup, "dup.bam")
+    assert check(d) == (_lib.NC_ERR_UNSUPPORTED, 0, 1)                              # r1 twice over [46, 60]; r2's second alignment is elsewhere
+    assert check(d, np.ascontiguousarray((d["read_flag"] & 0x800) == 0, np.uint8)) == (_lib.NC_OK, 0, 0)
+
+
+def _random_sites(rng, n, n_chunks, L, haploid):
+    contig = "".join("AGTC"[i] for i in rng.integers(0, 4, size=L))
+    chunk = np.sort(rng.integers(0, n_chunks, size=n)).astype(np.int32)
+    pos = np.zeros(n, np.int32)
+    for c in range(n_chunks):
+        sel = np.nonzero(chunk == c)[0]
+        pos[sel] = np.sort(rng.integers(1, L - 200, size=len(sel)))                  # close and repeated positions: `prev` matters
+    S = 1 if haploid else 3
+    rl = rng.integers(1, 30, size=(n, S)).astype(np.int32)
+    al = rng.integers(0, 30, size=(n, S)).astype(np.int32)
+    none = rng.random((n, S)) < 0.25
+    rl[none], al[none] = -1, -1
+    same = rng.random(n) < 0.2
+    if not haploid:
+        rl[same, 1], al[same, 1] = rl[same, 0], al[same, 0]
+    tot = int(np.maximum(al, 0).sum())
+    alt = rng.integers(0, 4, size=max(tot, 1)).astype(np.uint8)
+    off = np.zeros(n * S + 1, np.int64)
+    np.cumsum(np.maximum(al.reshape(-1), 0), out=off[1:])
+    if not haploid:
+        for j in np.nonzero(same)[0]:                                               # equal alleles on both haplotypes (:109)
+            if al[j, 0] > 0:
+                alt[off[j * 3 + 1]:off[j * 3 + 2]] = alt[off[j * 3]:off[j * 3 + 1]]
+    if haploid:
+        probs = rng.random((n, 1)).astype(np.float32)
+    else:
+        probs = rng.dirichlet([0.6, 0.6, 0.6, 0.6], size=n).astype(np.float32)
+        probs[rng.random(n) < 0.1, 0] = np.float32(0.97)
+    phase = np.where(rng.random(n) < 0.7, rng.integers(1, 10**6, size=n), 0).astype(np.int32)
+    return contig, pos, chunk, probs, rl, al, alt, off, phase
+
+
+@pytest.mark.parametrize("haploid", [False, True])
+def test_native_indel_rules_write_the_python_statements_text(haploid):
+    L = _lib.lib()
+    rng = np.random.default_rng(5 + haploid)
+    n, n_chunks, Lc = 4000, 23, 60_000
+    contig, pos, chunk, probs, rl, al, alt, off, phase = _random_sites(rng, n, n_chunks, Lc, haploid)
+    S = 1 if haploid else 3
+    letters = np.frombuffer(b"AGTC", np.uint8)[alt].tobytes().decode()
+    exp, exp_off = [], [0]
+    for c in range(n_chunks):
+        sel = np.nonzero(chunk == c)[0]
+        alle = []
+        for j in sel:
+            row = [(None, None) if rl[j, t] < 0 else (contig[pos[j] - 1:pos[j] - 1 + rl[j, t]], letters[off[j * S + t]:off[j * S + t + 1]]) for t in range(S)]
+            alle.append(row[0] if haploid else row)
+        prev = 0
+        for b in range(0, len(sel), 100):                                           # indel_run's batches of 100 (indelCaller.py:59), prev carried
+            s = sel[b:b + 100]
+            if haploid:
+                lines, prev = indelCaller.indel_vcf_lines_haploid("chrT", pos[s].tolist(), probs[s], alle[b:b + 100], prev)
+            else:
+                lines, prev = indelCaller.indel_vcf_lines("chrT", pos[s].tolist(), probs[s], alle[b:b + 100], [int(p) if p else None for p in phase[s]], prev)
+            exp += lines
+        exp_off.append(sum(len(x) for x in exp))
+    out = np.empty(n * 400, np.uint8)
+    nb = C.c_int64()
+    coff = np.empty(n_chunks + 1, np.int64)
+    rc = L.nc_indel_vcf_format(b"chrT", n, _lib.npp(pos), _lib.npp(chunk), n_chunks, _lib.npp(probs), S, _lib.npp(rl), _lib.npp(al), _lib.npp(alt),
+                               _lib.npp(phase), contig.encode(), Lc, 1 if haploid else 0, _lib.npp(out), out.size, C.byref(nb), _lib.npp(coff))
+    assert rc == _lib.NC_OK
+    got = out[:nb.value].tobytes().decode()
+    assert len(exp) > 800 and got == "".join(exp)
+    assert coff.tolist() == exp_off
+    if not haploid:
+        kinds = {ln.split("\t")[9].split(":")[0] for ln in exp}
+        assert kinds == {"1/1", "1|2", "0|1", "1|0"} and any("GT:GQ:PS" in ln for ln in exp) and any(ln.endswith("GT:GQ\t1|2:%s\n" % ln.rstrip("\n").split(":")[-1]) for ln in exp)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+def _params(fa, **kw):
+    d = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+             exclude_bed=None, impute_indel_phase=False)
+    d.update(kw)
+    return d
+
+
+def _same_tuples(got, exp):
+    assert len(got) == len(exp)
+    n = 0
+    for t, e in zip(got, exp):
+        assert list(t[0]) == list(e[0])
+        n += len(e[0])
+        for a, b in zip(t[1:], e[1:]):
+            if isinstance(b, np.ndarray):
+                assert np.asarray(a).dtype == b.dtype and np.array_equal(np.asarray(a), b)
+            else:
+                assert list(a) == list(b)
+    return n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["ont", "ont_mincov2_maxcov9", "pacbio_window", "haploid", "small_chunks", "excluded"])
+def test_device_pipeline_returns_the_host_routes_tuples(world_files, variant, monkeypatch):
+    w, bam, fa = world_files
+    kw, haploid, step = {}, False, 50_000
+    if variant == "ont_mincov2_maxcov9":
+        kw = dict(mincov=2, maxcov=9, del_t=0.4)                                    # the first-maxcov policy bites: sets are cut
+    elif variant == "pacbio_window":
+        kw = dict(seq="pacbio", ins_t=0.4, del_t=0.4)                               # window_after 260: the 17-column aligner
+    elif variant == "haploid":
+        haploid = True
+    elif variant == "small_chunks":
+        step = 3_000                                                                 # anchors shared by adjacent chunks
+    elif variant == "excluded":
+        kw = dict(exclude_bed=[(w.chrom, 20_000, 60_000), (w.chrom, 100_000, 100_500)])
+    dct = _params(fa, **kw)
+    chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + step), sam_path=bam) for s in range(1, w.length, step)]
+    gip._CONTIGS.clear()
+    monkeypatch.setenv("NC_INDEL_HOST_PASS2", "1")
+    exp = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=haploid)
+    monkeypatch.delenv("NC_INDEL_HOST_PASS2")
+
+    def boom(*a, **k):
+        raise AssertionError("the host-assembled route ran where the device pipeline was expected")
+    monkeypatch.setattr(gip, "_pass2_native", boom)
+    got = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=haploid)
+    assert _same_tuples(got, exp) > (100 if variant != "excluded" else 50)
+
+
+@pytest.mark.gpu
+def test_device_pipeline_in_small_groups_is_the_same(world_files, monkeypatch):
+    """the run loop cut into many groups of sites (traceback workspace bound) gives the same arrays"""
+    w, bam, fa = world_files
+    dct = _params(fa)
+    chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 50_000), sam_path=bam) for s in range(1, w.length, 50_000)]
+    a = gip.get_indel_testing_candidates_batch(dct, chunks)
+    monkeypatch.setenv("NC_PIPE_GROUP_AL", "700")
+    b = gip.get_indel_testing_candidates_batch(dct, chunks)
+    assert _same_tuples(b, a) > 100
+
+
+@pytest.mark.gpu
+def test_indel_run_native_text_equals_the_python_rules(world_files, tmp_path, monkeypatch):
+    """indelCaller.indel_run on the device pipeline + nc_indel_vcf_format writes the file the tuple route + Python rules write"""
+    import queue
+    w, bam, fa = world_files
+    outs = []
+    for tag, env in (("py", "1"), ("native", None)):
+        if env:
+            monkeypatch.setenv("NC_INDEL_PY_RULES", env)
+        else:
+            monkeypatch.delenv("NC_INDEL_PY_RULES", raising=False)
+        d = tmp_path / tag
+        d.mkdir()
+        params = _params(fa, indel_model="ONT-HG002", intermediate_indel_files_dir=str(d), prefix="t")
+        jobs = queue.Queue()
+        for s in range(1, w.length, 40_000):
+            jobs.put(("indel", dict(chrom=w.chrom, start=s, end=min(w.length, s + 40_000), ploidy="diploid" if s < 100_000 else "haploid", sam_path=bam)))
+        outs.append(open(indelCaller.indel_run(params, {}, jobs, queue.Queue(), [], aligner="device")).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 60
