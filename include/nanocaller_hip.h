@@ -28,7 +28,7 @@ extern "C" {
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
-                                 nc_decoded_check, NC_ERR_RANGE + nc_cnn_range_hits, nc_synth_indel_contig */
+                                 nc_decoded_check, NC_ERR_RANGE + nc_cnn_range_hits, nc_synth_indel_* */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -593,6 +593,23 @@ int nc_bgzf_compress(const uint8_t *data, int64_t n, int32_t level, uint8_t *out
  * NULL: size query).  NC_ERR_ARG: not readable or not BGZF.  Reads the `exclude_bed` file the reference opens with
  * pysam.TabixFile (generate_SNP_pileups.py:113-116). */
 int nc_bgzf_read_file(const char *path, uint8_t *out, int64_t cap, int64_t *n_out);
+
+/* ------------------------------------------------------------------ synthetic indel workload (bench.py / tests tooling, not product)
+ * SURVEY.md 8d's generator for the indel configs, in HBM: a contig with planted het / hom SNPs and indels (lengths 1..max_len, never
+ * overlapping) and ONT-like reads that carry their haplotype's variants plus sequencing noise (substitutions; noise deletions
+ * and insertions as EVENTS, as a decoded ONT BAM has them).  Pure functions of (seed, read, position).
+ * nc_synth_indel_truth: ref_dev [L + 1] base code of position p at index p; hap_base_dev [2][L + 1]; hap_indel_dev int8 [2][L + 1]: the
+ * indel that FOLLOWS position p on each haplotype (+ insertion / - deletion length, 0 none).
+ * nc_synth_indel_reads: fill = 0 counts events / inserted bases per read; fill = 1 (with the exclusive prefix sums ev_off /
+ * ins_off_read [n_reads]) writes the position-addressed codes in nc_pack_fill's slot layout (slot_off per read), ev_pos / ev_len /
+ * ins_off per event and the inserted bases.  All pointers dev. */
+int nc_synth_indel_truth(nc_ctx *ctx, int64_t L, uint64_t seed, double het_snp, double hom_snp, double het_indel, double hom_indel,
+                         int32_t max_len, uint8_t *ref_dev, uint8_t *hap_base_dev, int8_t *hap_indel_dev);
+int nc_synth_indel_reads(nc_ctx *ctx, int64_t L, uint64_t seed, double p_sub, double p_del, double p_ins, double carry, int32_t n_reads,
+                         const int32_t *start_dev, const int32_t *end_dev, const int64_t *slot_off_dev, const uint8_t *hap_dev,
+                         const uint8_t *hap_base_dev, const int8_t *hap_indel_dev, int32_t fill, int32_t *ev_cnt_dev, int32_t *ins_cnt_dev,
+                         const int32_t *ev_off_dev, const int32_t *ins_off_read_dev, uint8_t *codes_dev, int32_t *ev_pos_dev,
+                         int32_t *ev_len_dev, int32_t *ins_off_dev, uint8_t *ins_bases_dev);
 
 #ifdef __cplusplus
 }

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
     int nmax = n1;
     nmax = max(nmax, __shfl_xor(nmax, 16));
     nmax = max(nmax, __shfl_xor(nmax, 32));
-    const int64_t arow = p.arow ? p.arow[al] : (int64_t)al * (p.N1 + 1);
+    const int64_t arow = p.arow ? p.arow[al] : (int64_t)al * (p.N1 + 16);
     int32_t h_out = 0, e_out = NW_NEG;
     int32_t h_in_prev = q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend;      // H[0][q*CPL]
     const int jn_lane = (n2 - 1) / CPL, jn_c = (n2 - 1) % CPL;                    // owner of column n2
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
             }
             h_out = hleft;
             e_out = e;
-            uint32_t *tp = p.Tw + ((arow + i) * 16 + q) * NWP;
+            uint32_t *tp = p.Tw + ((arow + t) * 16 + q) * NWP;      // skewed rows: a group's 16 lanes (rows t .. t-15) write ONE line per step
             if (NWP == 1) tp[0] = words[0];
             else if (NWP == 2) *reinterpret_cast<uint2 *>(tp) = make_uint2(words[0], words[1]);
             else *reinterpret_cast<uint4 *>(tp) = make_uint4(words[0], words[1], NWD > 2 ? words[NWD > 2 ? 2 : 0] : 0u, 0u);
@@ -468,8 +468,201 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
     }
 }
 
+
+// ---- the same DP with TWO alignments per 16-lane group: every score is an exact small integer (|H| < 5,500 + 1,300 for windows of
+// <= 272 bases, consensus rows <= 1,024), so a lane keeps alignment A in the low and alignment B in the high 16 bits of each
+// register and every recurrence is ONE packed 16-bit instruction for both (v_pk_sub_i16, v_pk_max_i16, ...).  The kernel is bound
+// by vector issue (k_fill16p: 23.5 VALU per cell, ~70 % of the issue rate): packing halves the instructions per cell.
+// Traceback bits (format 1, decoded by tb_code): bit 0 = E beats the diagonal, bit 1 = F beats both, bit 2 = E opened, bit 3 = F opened
+// -- the raw sign bits of four differences, folded by multiply-adds; the decisions are those of k_fill16p (same ties).
+constexpr int NEG16 = -20000;              // "minus infinity": never selected, and NEG16 - extend - (any score) stays inside int16
+
+// packed 16-bit VALU (two alignments per register).  Inline assembly: written as vector C the compiler turns the sign-mask
+// arithmetic back into per-half compares and selects (measured: no fewer instructions than the 32-bit kernel).
+#define NC_PK2(name, op)                                                                                     \
+    __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b)                                         \
+    {                                                                                                        \
+        uint32_t r;                                                                                          \
+        asm(op " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));                                                    \
+        return r;                                                                                            \
+    }
+NC_PK2(pk_sub, "v_pk_sub_i16")
+NC_PK2(pk_add, "v_pk_add_i16")
+NC_PK2(pk_max, "v_pk_max_i16")
+#undef NC_PK2
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a)                    // 0xffff in every half that is negative
+{
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));    // the inline constant lives in the low half: both halves shift by it
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)     // a * b + c per half (low 16 bits)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)      // (a & mask) | (b & ~mask)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t splat16(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
+__device__ __forceinline__ uint32_t dpp_shr1_u(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x111, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int32_t half_of(uint32_t v, int k) { return k == 0 ? (int32_t)(int16_t)(v & 0xffffu) : (int32_t)(int16_t)(v >> 16); }
+
+template <int CPL>
+__global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
+{
+    constexpr int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
+    constexpr int NH = (CPL + 3) / 4;                          // packed registers of 4 cells x 4 bits per alignment
+    const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
+    const int pair = blockIdx.x * 4 + g;
+    int al[2], n1[2], n2[2];
+    bool live[2];
+    const uint8_t *s1[2], *s2[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int a = pair * 2 + k;
+        live[k] = a < p.A;
+        al[k] = live[k] ? a : 0;
+        n1[k] = 0; n2[k] = 0;
+        s1[k] = p.s1; s2[k] = p.ref_code;
+        if (live[k]) {
+            s1[k] = p.s1 + (int64_t)al[k] * p.s1_stride;
+            n1[k] = p.n1[al[k]];
+            const int site = fill_site(p, al[k]);
+            s2[k] = p.ref_code + (p.site_pos[site] - p.ref_pos0);
+            n2[k] = p.site_n2[site];
+        }
+    }
+    uint32_t H[CPL], F[CPL], rb[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int j = q * CPL + c + 1;
+        H[c] = splat16(-p.open - (j - 1) * p.extend);         // row 0
+        F[c] = splat16(NEG16);
+        const uint32_t r0 = j <= n2[0] ? (uint32_t)s2[0][j - 1] : 8u, r1 = j <= n2[1] ? (uint32_t)s2[1][j - 1] : 8u;     // 8: no read base equals it
+        rb[c] = r0 | (r1 << 16);
+    }
+    int nmax = max(n1[0], n1[1]);
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    int64_t arow[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * (p.N1 + 16);
+    const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match), k_mis = splat16(p.mismatch);
+    const uint32_t k_one = splat16(1), k_two = splat16(2), k_four = splat16(4);
+    uint32_t k_sh[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) k_sh[u] = splat16(-(1 << (u * 4)));
+    uint32_t h_out = 0, e_out = splat16(NEG16);
+    uint32_t h_in_prev = splat16(q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend);     // H[0][q*CPL]
+    int jn_lane[2], jn_c[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { jn_lane[k] = (n2[k] - 1) / CPL; jn_c[k] = (n2[k] - 1) % CPL; }
+    // read bases of both alignments: lane q holds base 16*blk + q (packed), see k_fill16p
+    auto load_chunk = [&](int idx) {
+        const uint32_t b0 = idx < n1[0] ? (uint32_t)s1[0][idx] : 4u, b1 = idx < n1[1] ? (uint32_t)s1[1][idx] : 4u;
+        return b0 | (b1 << 16);
+    };
+    uint32_t chunk = load_chunk(q), chunk_nxt = load_chunk(16 + q), c1 = splat16(4);
+    for (int t = 1; t <= nmax + 15; t++) {
+        const int i = t - q;
+        if (t > 1 && ((t - 1) & 15) == 0) {
+            chunk = chunk_nxt;
+            chunk_nxt = load_chunk(t - 1 + 16 + q);
+        }
+#ifdef NC_ABL_FILL_NOBPERM
+        const uint32_t c_new = chunk;
+#else
+        const uint32_t c_new = (uint32_t)__shfl((int)chunk, (lane & 48) | ((t - 1) & 15));
+#endif
+        c1 = dpp_shr1_u(splat16(4), c1);
+        if (q == 0) c1 = c_new;
+        uint32_t nh = dpp_shr1_u(0u, h_out), ne = dpp_shr1_u(splat16(NEG16), e_out);
+        if (q == 0) {
+            nh = splat16(-p.open - (i - 1) * p.extend);       // H[i][0]
+            ne = splat16(NEG16);
+        }
+        if (i >= 1) {                                          // rows beyond a read's end compute values nothing reads
+            uint32_t hdiag = h_in_prev, hleft = nh, e = ne;
+            uint32_t words[NH + 1];
+#pragma unroll
+            for (int k = 0; k <= NH; k++) words[k] = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const uint32_t hup = H[c], fup = F[c];
+                const uint32_t e_open = pk_sub(hleft, k_open), e_ext = pk_sub(e, k_ext);
+                const uint32_t m_e = pk_sign(pk_sub(e_ext, e_open));                 // E opened (e_ext < e_open)
+                e = pk_max(e_open, e_ext);
+                const uint32_t f_open = pk_sub(hup, k_open), f_ext = pk_sub(fup, k_ext);
+                const uint32_t m_f = pk_sign(pk_sub(f_ext, f_open));                 // F opened
+                const uint32_t f = pk_max(f_open, f_ext);
+                const uint32_t eq = pk_sign(pk_sub(c1 ^ rb[c], k_one));              // the bases match
+                const uint32_t d = pk_add(hdiag, bfi(eq, k_match, k_mis));
+                const uint32_t h1 = pk_max(d, e);
+                const uint32_t m_1 = pk_sign(pk_sub(d, e));                          // E beats the diagonal
+                const uint32_t h = pk_max(h1, f);
+                const uint32_t m_2 = pk_sign(pk_sub(h1, f));                         // F beats both
+                H[c] = h;
+                F[c] = f;
+                // masks are -1 / 0: -(code) = m_1 + 2 m_2 + 4 (m_e + 2 m_f); folded into the row's words with a negative power of 16
+                const uint32_t neg_code = pk_mad(pk_mad(m_f, k_two, m_e), k_four, pk_mad(m_2, k_two, m_1));
+                words[c >> 2] = pk_mad(neg_code, k_sh[c & 3], words[c >> 2]);
+                hdiag = hup;
+                hleft = h;
+            }
+            h_out = hleft;
+            e_out = e;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!(live[k] && i <= n1[k] && q * CPL < n2[k])) continue;
+#ifdef NC_ABL_FILL_NOSTORE
+                if (i != 100000) continue;
+#endif
+                uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < NWD; j++) {
+                    const uint32_t lo = words[2 * j], hi = words[2 * j + 1 <= NH ? 2 * j + 1 : NH];
+                    wd[j] = k == 0 ? ((lo & 0xffffu) | (hi << 16)) : ((lo >> 16) | (hi & 0xffff0000u));
+                }
+                uint32_t *tp = p.Tw + ((arow[k] + t) * 16 + q) * NWP;   // skewed rows: a group's 16 lanes (rows t .. t-15) write ONE line per step
+                if (NWP == 1) tp[0] = wd[0];
+                else if (NWP == 2) *reinterpret_cast<uint2 *>(tp) = make_uint2(wd[0], wd[1]);
+                else *reinterpret_cast<uint4 *>(tp) = make_uint4(wd[0], wd[1], wd[2], 0u);
+                if (p.hcol && q == jn_lane[k]) {
+                    uint32_t hv = H[0];
+#pragma unroll
+                    for (int c = 1; c < CPL; c++) hv = c == jn_c[k] ? H[c] : hv;
+                    p.hcol[arow[k] + i] = half_of(hv, k);
+                }
+                if (p.Hlast && i == n1[k]) {
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                        if (q * CPL + c + 1 <= n2[k]) p.Hlast[(int64_t)al[k] * p.W + q * CPL + c + 1] = half_of(H[c], k);
+                }
+            }
+            h_in_prev = nh;
+        }
+    }
+}
+
+// the 4-bit traceback code of cell (i, j), i, j >= 1, in k_fill16p's terms (T_DIAG / T_DEL / T_INS | T_EEXT | T_FEXT)
+__device__ __forceinline__ uint32_t tb_code(const uint32_t *__restrict__ Tw, int64_t arow, int i, int j, int CPL, int NWP, int fmt)
+{
+    const int q = (j - 1) / CPL, c = (j - 1) % CPL;
+    const uint32_t t = (Tw[((arow + i + q) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;      // row i of lane q was written at step i + q
+    if (fmt == 0) return t;
+    return ((t & 2u) ? (uint32_t)T_INS : (t & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((t & 4u) ? 0u : (uint32_t)T_EEXT) | ((t & 8u) ? 0u : (uint32_t)T_FEXT);
+}
+
 // traceback of a free-tail alignment into reference coordinates (nc_msa.hip k_nw_trace16)
-__global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int16_t *__restrict__ qidx_all, int16_t *__restrict__ il_all,
+__global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_t fmt, int16_t *__restrict__ qidx_all, int16_t *__restrict__ il_all,
                                                  int16_t *__restrict__ iq_all)
 {
     const int al = blockIdx.x * 64 + threadIdx.x;
@@ -477,7 +670,7 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int16_
     const int n1 = p.n1[al];
     const int n2 = p.site_n2[fill_site(p, al)];
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
-    const int64_t arow = (int64_t)al * (p.N1 + 1);
+    const int64_t arow = (int64_t)al * (p.N1 + 16);
     int16_t *qidx = qidx_all + (int64_t)al * p.W, *il = il_all + (int64_t)al * p.W, *iq = iq_all + (int64_t)al * p.W;
     for (int j = 0; j <= n2; j++) { qidx[j] = -1; il[j] = 0; iq[j] = 0; }
     int i = n1, j = n2;
@@ -498,10 +691,7 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int16_
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else {
-            const int q = (j - 1) / CPL, c = (j - 1) % CPL;
-            t = (p.Tw[((arow + i) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
-        }
+        else t = tb_code(p.Tw, arow, i, j, CPL, NWP, fmt);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) { qidx[j - 1] = (int16_t)(i - 1); i--; j--; continue; }
@@ -660,7 +850,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
 }
 
 // allele_prediction on the packed traceback of a GLOBAL alignment of the consensus (s1) against the window (nc_msa.hip k_allele_trace16)
-__global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL, const int32_t *__restrict__ site_type, int32_t win_size,
+__global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL, int32_t fmt, const int32_t *__restrict__ site_type, int32_t win_size,
                                                         int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
 {
     const int al = blockIdx.x * 64 + threadIdx.x;
@@ -689,10 +879,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else {
-            const int q = (j - 1) / CPL, c = (j - 1) % CPL;
-            t = (p.Tw[((arow + i) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
-        }
+        else t = tb_code(p.Tw, arow, i, j, CPL, NWP, fmt);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; continue; }
@@ -753,7 +940,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     alt_len[al] = out_a;
 }
 
-// rows of the allele alignments: arow[a] = sum_{b<a} (n1[b] + 1); arow[n] = total
+// rows of the allele alignments: arow[a] = sum_{b<a} (n1[b] + 16) (skewed rows, see k_fill16p); arow[n] = total
 __global__ __launch_bounds__(1024) void k_scan_rows(const int32_t *__restrict__ n1, int32_t n, int64_t *__restrict__ arow, int32_t *__restrict__ total_mbox)
 {
     __shared__ int wsum[16];
@@ -762,7 +949,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(const int32_t *__restrict__ 
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
-        const int v = i < n ? n1[i] + 1 : 0;
+        const int v = i < n ? n1[i] + 16 : 0;
         int tot;
         const int inc = block_scan(v, wsum, tot);
         const long long cc = carry;
@@ -855,8 +1042,18 @@ void nc_pipe_destroy(nc_ctx *ctx)
 
 static int cpl_for(int n2) { return n2 <= 64 ? 4 : n2 <= 128 ? 8 : n2 <= 176 ? 11 : n2 <= 272 ? 17 : 0; }
 
+static bool packed_fill() { static const bool on = !getenv("NC_PIPE_FILL32"); return on; }
+
 static void launch_fill(nc_ctx *ctx, int CPL, const FillArgs &fa)
 {
+    if (packed_fill()) {
+        const dim3 gq((unsigned)((fa.A + 7) / 8));
+        if (CPL == 4) hipLaunchKernelGGL(k_fill16q<4>, gq, dim3(64), 0, ctx->stream, fa);
+        else if (CPL == 8) hipLaunchKernelGGL(k_fill16q<8>, gq, dim3(64), 0, ctx->stream, fa);
+        else if (CPL == 11) hipLaunchKernelGGL(k_fill16q<11>, gq, dim3(64), 0, ctx->stream, fa);
+        else hipLaunchKernelGGL(k_fill16q<17>, gq, dim3(64), 0, ctx->stream, fa);
+        return;
+    }
     const dim3 gr((unsigned)((fa.A + 3) / 4));
     if (CPL == 4) hipLaunchKernelGGL(k_fill16p<4>, gr, dim3(64), 0, ctx->stream, fa);
     else if (CPL == 8) hipLaunchKernelGGL(k_fill16p<8>, gr, dim3(64), 0, ctx->stream, fa);
@@ -1034,7 +1231,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     const int CPL = cpl_for(s->window_after + 1);
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     // groups of whole sites: traceback codes of a group's alignments <= 12 GiB
-    const int64_t tw_per_al = (int64_t)(N1 + 1) * NWP * 64;
+    const int64_t tw_per_al = (int64_t)(N1 + 16) * NWP * 64;     // rows 1 .. n1 of lane q live at the skewed rows 1 + q .. n1 + q
     int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)12 << 30) / tw_per_al);
     if (const char *g = getenv("NC_PIPE_GROUP_AL")) GROUP_AL = std::max<int64_t>(64, atoll(g));
     const int64_t GROUP_SITES = 65536;
@@ -1059,7 +1256,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, s->n1, Agz * 4));
         NC_TRY(nc_ensure(ctx, s->tw, Agz * (size_t)tw_per_al + 64));
         NC_TRY(nc_ensure(ctx, s->hlast, Agz * W * 4));
-        NC_TRY(nc_ensure(ctx, s->hcol, Agz * (N1 + 1) * 4));
+        NC_TRY(nc_ensure(ctx, s->hcol, Agz * (N1 + 16) * 4));
         NC_TRY(nc_ensure(ctx, s->trace, (size_t)3 * Agz * W * 2));
         NC_TRY(nc_ensure(ctx, s->cns, (size_t)ng * S * CNS_CAP));
         NC_TRY(nc_ensure(ctx, s->ncns, (size_t)ng * S * 4));
@@ -1088,8 +1285,18 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fa.Tw = (uint32_t *)s->tw.p; fa.Hlast = (int32_t *)s->hlast.p; fa.hcol = (int32_t *)s->hcol.p;
         if (Ag > 0) launch_fill(ctx, CPL, fa);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[2], ctx->stream));
+        if (getenv("NC_PIPE_STOP_AFTER_FILL")) {                      // experiment: time the alignment fill alone (ablation builds write no traceback)
+            if (timing) {
+                NC_HIP(ctx, hipEventSynchronize(s->ev[2]));
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
+                s->stage_ms[2] += ms;
+            }
+            k0 = k1;
+            continue;
+        }
         int16_t *qidx = (int16_t *)s->trace.p, *il = qidx + Agz * W, *iq = il + Agz * W;
-        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, fa, CPL, qidx, il, iq);
+        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, fa, CPL, packed_fill() ? 1 : 0, qidx, il, iq);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], ctx->stream));
         // ---- columns, histogram, tensor, consensus
         TensorArgs ta;
@@ -1109,7 +1316,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_HIP(ctx, hipMemcpyAsync(mb, mbox, 8, hipMemcpyDeviceToHost, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
-        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * NWP * 64 + 64));
+        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 16) * NWP * 64 + 64));
         NC_TRY(nc_ensure(ctx, s->runs, (size_t)(rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
         FillArgs fb = fa;
         fb.s1 = (const uint8_t *)s->cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)s->ncns.p;
@@ -1120,7 +1327,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fb.Tw = (uint32_t *)s->tw2.p; fb.Hlast = nullptr; fb.hcol = nullptr;
         launch_fill(ctx, CPL, fb);
         int32_t *rl = (int32_t *)s->rlen.p + (size_t)k0 * S, *al = (int32_t *)s->alen.p + (size_t)k0 * S;
-        hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, ctx->stream, fb, CPL, (const int32_t *)s->site_type.p, s->win_size,
+        hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, ctx->stream, fb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p, s->win_size,
                            (int16_t *)s->runs.p, rl, al);
         hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)al, nset, pool_base, (int64_t *)s->alt_off.p);
         hipLaunchKernelGGL(k_alt_copy, dim3((nset + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t *)s->cns.p, (const int32_t *)al,

@@ -167,3 +167,93 @@ def wire_from_device_workload(pack: DevicePack, info, pin=True):
     n = info["n_reads"]
     return build_wire(info["read_start"], info["read_end"], off, codes_h, None, ref_h, tile_size=info["tile_size"], pos_lo=1, pos_hi=L,
                       keep=np.ones(n, np.uint8), strand=info["strand"], pin=pin)
+
+
+# ---------------------------------------------------------------------------------------------------------------- indel workload
+def make_indel_device_workload(eng, L, depth=30.0, seed=812, tile_size=2048, het_snp=1 / 1000.0, hom_snp=1 / 2000.0, het_indel=1 / 5000.0,
+                               hom_indel=1 / 15000.0, max_len=50, p_sub=0.03, p_del=0.025, p_ins=0.012, carry=0.92, untagged=0.08,
+                               mask_frac=0.005):
+    """Synthetic ONT contig with planted indels and HP / PS tags, generated in HBM (nc_synth_indel_*): the inputs of the
+    device-resident indel pipeline.  -> (DevicePack with .events / .reads, IndelReadsC, info dict).  info['tensors'] keeps the
+    device arrays alive; info['truth'] = (hap_indel int8 [2, L + 1] on the device)."""
+    from .generate_indel_pileups import TAIL_CAP  # noqa: F401  (documented bound of the tail section; synthetic reads have no soft clips)
+    dev = eng.device
+    eng.use_torch_stream()
+    L_ = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    starts, ends = _read_layout(rng, L, depth, "ont")
+    R = starts.shape[0]
+    strand = rng.integers(0, 2, size=R).astype(np.uint8)
+    hap = rng.integers(1, 3, size=R).astype(np.uint8)
+    hap[rng.random(R) < untagged] = 0
+    ps = np.where(hap > 0, 1 + (starts // 400_000) * 400_000, 0).astype(np.int32)
+    lo16 = starts.astype(np.int64) & ~np.int64(15)
+    hi16 = (ends.astype(np.int64) + 15) & ~np.int64(15)
+    slot_off = np.zeros(R + 1, np.int64)
+    np.cumsum(hi16 - lo16, out=slot_off[1:])
+    codes_len = int(slot_off[-1]) + 16
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    d_start, d_end, d_slot, d_hap, d_ps = t(starts), t(ends), t(slot_off), t(hap), t(ps)
+    ref = torch.zeros(L + 1, dtype=torch.uint8, device=dev)
+    hapb = torch.zeros(2 * (L + 1), dtype=torch.uint8, device=dev)
+    hapi = torch.zeros(2 * (L + 1), dtype=torch.int8, device=dev)
+    P = lambda x: C.c_void_p(x.data_ptr())                              # noqa: E731
+    rc = L_.nc_synth_indel_truth(eng.ctx, L, seed, het_snp, hom_snp, het_indel, hom_indel, max_len, P(ref), P(hapb), P(hapi))
+    assert rc == 0, rc
+    ev_cnt = torch.zeros(R, dtype=torch.int32, device=dev)
+    ins_cnt = torch.zeros(R, dtype=torch.int32, device=dev)
+    args = (eng.ctx, L, seed, p_sub, p_del, p_ins, carry, R, P(d_start), P(d_end), P(d_slot), P(d_hap), P(hapb), P(hapi))
+    rc = L_.nc_synth_indel_reads(*args, 0, P(ev_cnt), P(ins_cnt), None, None, None, None, None, None, None)
+    assert rc == 0, rc
+    ev_off = torch.zeros(R + 1, dtype=torch.int32, device=dev)
+    ev_off[1:] = torch.cumsum(ev_cnt, 0)
+    ins_off_read = torch.zeros(R + 1, dtype=torch.int32, device=dev)
+    ins_off_read[1:] = torch.cumsum(ins_cnt, 0)
+    n_ev, n_ins = int(ev_off[-1]), int(ins_off_read[-1])
+    codes = torch.empty(codes_len, dtype=torch.uint8, device=dev)
+    codes[codes_len - 16:] = _lib.CODE_ABSENT
+    ev_pos = torch.zeros(max(n_ev, 4), dtype=torch.int32, device=dev)
+    ev_len = torch.zeros(max(n_ev, 4), dtype=torch.int32, device=dev)
+    ins_off = torch.zeros(max(n_ev, 3) + 1, dtype=torch.int32, device=dev)
+    ins_bases = torch.zeros(max(n_ins, 4), dtype=torch.uint8, device=dev)
+    rc = L_.nc_synth_indel_reads(*args, 1, None, None, P(ev_off), P(ins_off_read), P(codes), P(ev_pos), P(ev_len), P(ins_off), P(ins_bases))
+    assert rc == 0, rc
+    ins_off[n_ev] = n_ins
+    # reference codes on the tile grid; a few soft-masked runs (quirk E4)
+    tile_pos0, n_tiles = 0, L // tile_size + 1
+    ref_code = torch.full((n_tiles * tile_size,), 4, dtype=torch.uint8, device=dev)
+    ref_code[1:L + 1] = ref[1:]
+    n_mask = int(mask_frac * L / 500)
+    if n_mask:
+        ms = torch.from_numpy(rng.integers(1, max(2, L - 600), size=n_mask)).to(dev)
+        mi = (ms[:, None] + torch.arange(500, device=dev)[None, :]).reshape(-1)
+        ref_code[mi] = 4
+    rs, re_ = np.ascontiguousarray(starts), np.ascontiguousarray(ends)
+    cl, ne = C.c_int64(), C.c_int64()
+    tp0, nt = C.c_int32(), C.c_int32()
+    rc = L_.nc_pack_plan(R, _lib.npp(rs), _lib.npp(re_), None, tile_size, 1, L, C.byref(cl), C.byref(tp0), C.byref(nt), C.byref(ne))
+    assert rc == 0 and cl.value == codes_len and tp0.value == tile_pos0 and nt.value == n_tiles, (rc, cl.value, codes_len)
+    tile_off = np.empty(n_tiles + 1, np.int32)
+    tile_ent = np.empty(max(1, ne.value), _lib.TILE_ENTRY_DTYPE)
+    sflag = np.ascontiguousarray(strand | (hap << 1))
+    rc = L_.nc_pack_fill(R, _lib.npp(rs), _lib.npp(re_), None, None, _lib.npp(sflag), None, tile_size, tile_pos0, n_tiles, None, codes_len,
+                         _lib.npp(tile_off), _lib.npp(tile_ent), ne.value)
+    assert rc == 0, rc
+    ent_bytes = np.frombuffer(tile_ent[:ne.value].tobytes(), np.uint8).copy()
+    pack = DevicePack(codes=codes, tile_off=t(tile_off), tile_ent=t(ent_bytes), ref_code=ref_code, tile_size=tile_size, tile_pos0=tile_pos0,
+                      n_tiles=n_tiles, n_entries=int(ne.value), pos_lo=1, pos_hi=L)
+    pack.events = dict(n_reads=R, ev_off=ev_off, ev_pos=ev_pos, ev_len=ev_len, read_hap=d_hap)
+    pack.reads = dict(n_reads=R, rd_start=d_start, rd_end=d_end, slot_off=d_slot)
+    tail_off = torch.zeros(R + 1, dtype=torch.int32, device=dev)
+    tail_bases = torch.zeros(16, dtype=torch.uint8, device=dev)
+    rflag = torch.zeros(R, dtype=torch.uint8, device=dev)
+    reads_c = _lib.IndelReadsC(n_reads=R, slot_off=d_slot.data_ptr(), rd_start=d_start.data_ptr(), rd_end=d_end.data_ptr(), ev_off=ev_off.data_ptr(),
+                               ev_pos=ev_pos.data_ptr(), ev_len=ev_len.data_ptr(), ins_off=ins_off.data_ptr(), ins_bases=ins_bases.data_ptr(),
+                               tail_off=tail_off.data_ptr(), tail_bases=tail_bases.data_ptr(), read_ps=d_ps.data_ptr(), read_hap=d_hap.data_ptr(),
+                               read_flag=rflag.data_ptr())
+    torch.cuda.synchronize(dev)
+    info = dict(L=L, n_reads=R, read_start=starts, read_end=ends, hap=hap, ps=ps, strand=strand, n_events=n_ev, n_ins_bases=n_ins,
+                pileup_entries=int((ends.astype(np.int64) - starts).sum()), seed=seed, depth=depth,
+                tensors=dict(ins_off=ins_off, ins_bases=ins_bases, tail_off=tail_off, tail_bases=tail_bases, read_ps=d_ps, read_flag=rflag, ref=ref),
+                truth=hapi.view(2, L + 1))
+    return pack, reads_c, info
