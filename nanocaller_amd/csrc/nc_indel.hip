@@ -282,6 +282,70 @@ __global__ void k_event_intervals_b(int32_t n_reads, const int32_t *__restrict__
     }
 }
 
+// The same, one WAVE per kept read with the read's events across the lanes (k_event_intervals_b walks a read's ~400 events in one
+// thread: 10 ms per chr20-sized contig, latency-bound).  The merged intervals of a (read, class, chunk) are the union of equal-length
+// intervals [k, k + w - 1] over its qualifying events in rank order: an event OPENS an interval iff no qualifying event of the class
+// precedes it within w - 1 ranks, and CLOSES one (at k + w) iff none follows within w - 1 ranks -- two local look-ups per event.
+__global__ __launch_bounds__(256) void k_event_intervals_w(int32_t n_reads, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
+                                                           const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
+                                                           const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win,
+                                                           int32_t small_win, int32_t haploid, int32_t impute)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const int hp = read_hap[r];
+    const bool tagged = haploid || hp == 1 || hp == 2;
+    if (!tagged && !impute) return;
+    const int h = haploid ? 0 : hp - 1;
+    const int ea = ev_off[r], eb = ev_off[r + 1];
+    auto qualifies = [](int32_t sl, int cls) {
+        const int32_t ln = sl < 0 ? -sl : sl;
+        const bool ins = sl > 0;
+        return cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
+    };
+    for (int e = ea + lane; e < eb; e += 64) {
+        const int32_t p = ev_pos[e], sl = ev_len[e];
+        int a = 0, b = n_chunks;                                       // first chunk with hi >= p
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (ck[m].hi < p) a = m + 1; else b = m;
+        }
+        for (int ci = a; ci < n_chunks && ck[ci].lo <= p; ci++) {
+            const IndelChunk c = ck[ci];
+            if (impute) atomicAdd(&ck_cnt(ws, c)[(int64_t)(sl > 0 ? 1 : 2) * c.ncol + (p - c.lo)], 1);      // :279-284, every read
+            if (!tagged) continue;
+            const int32_t *rank = ck_rank(ws, c);
+            const int k = rank[p - c.lo];
+            if (k < 0) continue;                                      // excluded column
+            int32_t *diff = ck_diff(ws, c);
+#pragma unroll
+            for (int cls = 0; cls < 4; cls++) {
+                if (!qualifies(sl, cls)) continue;
+                const int w = cls < 2 ? win : small_win;
+                bool has_prev = false, has_next = false;
+                for (int e2 = e - 1; e2 >= ea; e2--) {
+                    const int32_t p2 = ev_pos[e2];
+                    if (p2 < c.lo) break;
+                    const int k2 = rank[p2 - c.lo];
+                    if (k2 < 0) continue;
+                    if (k - k2 > w - 1) break;
+                    if (qualifies(ev_len[e2], cls)) { has_prev = true; break; }
+                }
+                for (int e2 = e + 1; e2 < eb; e2++) {
+                    const int32_t p2 = ev_pos[e2];
+                    if (p2 > c.hi) break;
+                    const int k2 = rank[p2 - c.lo];
+                    if (k2 < 0) continue;
+                    if (k2 - k > w - 1) break;
+                    if (qualifies(ev_len[e2], cls)) { has_next = true; break; }
+                }
+                if (!has_prev) atomicAdd(&diff[(int64_t)(cls * 2 + h) * c.nd + k], 1);
+                if (!has_next) atomicAdd(&diff[(int64_t)(cls * 2 + h) * c.nd + k + w], -1);
+            }
+        }
+    }
+}
+
 // in-place inclusive prefix sum of each of the 8 difference arrays of each chunk (one workgroup per array)
 __global__ __launch_bounds__(1024) void k_prefix_rows_b(const IndelChunk *__restrict__ ck, char *__restrict__ ws)
 {
@@ -417,9 +481,15 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     }
 #undef NC_HAP_DEPTH
     hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
-    if (ev->n_reads > 0)
-        hipLaunchKernelGGL(k_event_intervals_b, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
-                           ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid, impute);
+    if (ev->n_reads > 0) {
+        static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
+        if (per_thread)
+            hipLaunchKernelGGL(k_event_intervals_b, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
+                               ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid, impute);
+        else
+            hipLaunchKernelGGL(k_event_intervals_w, dim3((ev->n_reads + 3) / 4), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
+                               ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid, impute);
+    }
     hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
     hipLaunchKernelGGL(k_indel_decide_b, dim3(ng == 1 ? 512 : 64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t,
                        prm->haploid, impute, ctype);

@@ -301,8 +301,14 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
     if (al < p.A) {
         const int r = p.al_read[al], site = p.al_site[al];
         const int32_t v = p.site_pos[site];
-        uint8_t *out = p.win + (int64_t)al * p.WS;
+        uint32_t *out = reinterpret_cast<uint32_t *>(p.win + (int64_t)al * p.WS);       // rows are 16-byte aligned
         int n = 0;
+        uint32_t acc = 0;
+        auto emit = [&](uint32_t b) {                                                     // bases leave as whole words
+            acc |= b << ((n & 3) * 8);
+            n++;
+            if ((n & 3) == 0) { out[(n >> 2) - 1] = acc; acc = 0; }
+        };
         if (!(p.read_flag[r] & 1)) {
             const int e0 = p.ev_off[r], e1 = p.ev_off[r + 1];
             int lo = e0, hi = e1;                                  // first event on a column >= v
@@ -317,24 +323,35 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
                 if (el < 0) del_until = p.ev_pos[k - 1] - el;
             }
             const int32_t rs = p.rd_start[r], re = p.rd_end[r];
-            const uint8_t *cd = p.codes + (p.slot_off[r] - (rs & ~15));
+            const uint8_t *cd = p.codes + (p.slot_off[r] - (rs & ~15));       // code of position x at cd[x]; 16-position groups are aligned
             int32_t next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
             int32_t x = v;
             while (n < p.W && x < re) {
-                if (x > del_until) out[n++] = cd[x];
-                while (next_ev == x) {
-                    const int32_t el = p.ev_len[k];
-                    if (el > 0) {
-                        for (int i = p.ins_off[k]; i < p.ins_off[k + 1] && n < p.W; i++) out[n++] = p.ins_bases[i];
-                    } else del_until = x - el;
-                    k++;
-                    next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
+                const int32_t x0 = x & ~15;
+                const uint4 g = *reinterpret_cast<const uint4 *>(cd + x0);
+                const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+                const int32_t xe = min(x0 + 16, re);
+                for (; x < xe && n < p.W; x++) {
+                    const int o = x - x0;
+                    uint32_t code = 0;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) code = (o >> 2) == q4 ? gw[q4] : code;
+                    code = (code >> ((o & 3) * 8)) & 0xffu;
+                    if (x > del_until) emit(code);
+                    while (next_ev == x) {
+                        const int32_t el = p.ev_len[k];
+                        if (el > 0) {
+                            for (int i = p.ins_off[k]; i < p.ins_off[k + 1] && n < p.W; i++) emit(p.ins_bases[i]);
+                        } else del_until = x - el;
+                        k++;
+                        next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
+                    }
                 }
-                x++;
             }
             if (x >= re)
-                for (int i = p.tail_off[r]; i < p.tail_off[r + 1] && n < p.W; i++) out[n++] = p.tail_bases[i];
+                for (int i = p.tail_off[r]; i < p.tail_off[r + 1] && n < p.W; i++) emit(p.tail_bases[i]);
         }
+        if (n & 3) out[n >> 2] = acc;
         p.n1[al] = n;
         mycells = (long long)n * p.site_n2[site];
     }
@@ -354,8 +371,8 @@ struct FillArgs {
     int32_t site0, site_div;
     int32_t A, W;                // alignments; row pitch of Hlast
     int32_t open, extend, match, mismatch;
-    const int64_t *arow;         // first traceback row of alignment a, or (NULL) a * (N1 + 1)
-    int32_t N1;
+    const int64_t *arow;         // first traceback BLOCK (8 steps) of alignment a, or (NULL) a * tw_blocks(N1)
+    int32_t N1;                  // longest read of the launch (row pitch of hcol: N1 + 1)
     uint32_t *Tw;
     int32_t *Hlast, *hcol;       // free-tail end point inputs (NULL for a global alignment)
 };
@@ -366,6 +383,38 @@ __device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t v)
 }
 
 __device__ __forceinline__ int fill_site(const FillArgs &p, int al) { return p.al_site ? p.al_site[al] : p.site0 + al / p.site_div; }
+
+// Traceback storage.  The DP runs as a wavefront: at step t lane q of a 16-lane group works on read row t - q.  A lane's NWP words
+// of step t go to block t >> 3 of its alignment, where the 8 steps of ONE lane are contiguous:
+//     word index = (((first_block + (t >> 3)) * 16 + q) * 8 + (t & 7)) * NWP + w
+// so a traceback that climbs a diagonal (row - 1, column - 1: same lane, step - 1) stays inside one 64-byte run for 8 steps.  [Rows
+// stored one after the other made the fill write 16 partial lines per instruction (33 ms, 2.6x the arithmetic); steps stored one after
+// the other fixed the writes (15 ms) but left the traceback one 64-byte sector per step (11 GB per chr20-sized contig).]  The fill
+// kernels collect 8 steps per lane in LDS (a lane reads back only what it wrote itself) and write whole runs.
+__host__ __device__ __forceinline__ int tw_blocks(int n1) { return ((n1 + 15) >> 3) + 1; }
+__device__ __forceinline__ int64_t tw_word(int64_t first_block, int t, int q, int NWP) { return (((first_block + (t >> 3)) * 16 + q) * 8 + (t & 7)) * (int64_t)NWP; }
+
+template <int NWP>
+__device__ __forceinline__ void tw_stage(uint32_t *lds, int k, int t, int lane, const uint32_t *wd)
+{
+    uint32_t *ls = lds + ((k * 8 + (t & 7)) * 64 + lane) * NWP;
+    if (NWP == 1) ls[0] = wd[0];
+    else if (NWP == 2) *reinterpret_cast<uint2 *>(ls) = make_uint2(wd[0], wd[1]);
+    else *reinterpret_cast<uint4 *>(ls) = make_uint4(wd[0], wd[1], wd[2], 0u);
+}
+// the 8 steps of block t >> 3 of this lane, LDS -> HBM (8 * NWP words = 32 / 64 / 128 contiguous bytes)
+template <int NWP>
+__device__ __forceinline__ void tw_flush(const uint32_t *lds, int k, int t, int lane, int q, uint32_t *Tw, int64_t first_block)
+{
+    uint32_t *dst = Tw + tw_word(first_block, t & ~7, q, NWP);
+    uint32_t v[8 * NWP];
+#pragma unroll
+    for (int ts = 0; ts < 8; ts++)
+#pragma unroll
+        for (int w = 0; w < NWP; w++) v[ts * NWP + w] = lds[((k * 8 + ts) * 64 + lane) * NWP + w];
+#pragma unroll
+    for (int x = 0; x < 2 * NWP; x++) reinterpret_cast<uint4 *>(dst)[x] = make_uint4(v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]);
+}
 
 template <int CPL>
 __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
@@ -396,7 +445,8 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
     int nmax = n1;
     nmax = max(nmax, __shfl_xor(nmax, 16));
     nmax = max(nmax, __shfl_xor(nmax, 32));
-    const int64_t arow = p.arow ? p.arow[al] : (int64_t)al * (p.N1 + 16);
+    __shared__ uint32_t tw_lds[8 * 64 * NWP];
+    const int64_t arow = p.arow ? p.arow[al] : (int64_t)al * tw_blocks(p.N1);
     int32_t h_out = 0, e_out = NW_NEG;
     int32_t h_in_prev = q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend;      // H[0][q*CPL]
     const int jn_lane = (n2 - 1) / CPL, jn_c = (n2 - 1) % CPL;                    // owner of column n2
@@ -448,15 +498,15 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
             }
             h_out = hleft;
             e_out = e;
-            uint32_t *tp = p.Tw + ((arow + t) * 16 + q) * NWP;      // skewed rows: a group's 16 lanes (rows t .. t-15) write ONE line per step
-            if (NWP == 1) tp[0] = words[0];
-            else if (NWP == 2) *reinterpret_cast<uint2 *>(tp) = make_uint2(words[0], words[1]);
-            else *reinterpret_cast<uint4 *>(tp) = make_uint4(words[0], words[1], NWD > 2 ? words[NWD > 2 ? 2 : 0] : 0u, 0u);
+            {
+                uint32_t wd[4] = {words[0], NWD > 1 ? words[NWD > 1 ? 1 : 0] : 0u, NWD > 2 ? words[NWD > 2 ? 2 : 0] : 0u, 0u};
+                tw_stage<NWP>(tw_lds, 0, t, lane, wd);
+            }
             if (p.hcol && q == jn_lane) {
                 int32_t hv = H[0];
 #pragma unroll
                 for (int c = 1; c < CPL; c++) hv = c == jn_c ? H[c] : hv;
-                p.hcol[arow + i] = hv;                        // H[i][n2]
+                p.hcol[(int64_t)al * (p.N1 + 1) + i] = hv;      // H[i][n2]
             }
             if (p.Hlast && i == n1) {
 #pragma unroll
@@ -465,6 +515,7 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
             }
         }
         if (i >= 1) h_in_prev = nh;
+        if (((t & 7) == 7 || t == nmax + 15) && live && (t >> 3) < tw_blocks(n1)) tw_flush<NWP>(tw_lds, 0, t, lane, q, p.Tw, arow);
     }
 }
 
@@ -554,7 +605,8 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     nmax = max(nmax, __shfl_xor(nmax, 32));
     int64_t arow[2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * (p.N1 + 16);
+    for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * tw_blocks(p.N1);
+    __shared__ uint32_t tw_lds[2 * 8 * 64 * NWP];
     const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match), k_mis = splat16(p.mismatch);
     const uint32_t k_one = splat16(1), k_two = splat16(2), k_four = splat16(4);
     uint32_t k_sh[4];
@@ -631,15 +683,12 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
                     const uint32_t lo = words[2 * j], hi = words[2 * j + 1 <= NH ? 2 * j + 1 : NH];
                     wd[j] = k == 0 ? ((lo & 0xffffu) | (hi << 16)) : ((lo >> 16) | (hi & 0xffff0000u));
                 }
-                uint32_t *tp = p.Tw + ((arow[k] + t) * 16 + q) * NWP;   // skewed rows: a group's 16 lanes (rows t .. t-15) write ONE line per step
-                if (NWP == 1) tp[0] = wd[0];
-                else if (NWP == 2) *reinterpret_cast<uint2 *>(tp) = make_uint2(wd[0], wd[1]);
-                else *reinterpret_cast<uint4 *>(tp) = make_uint4(wd[0], wd[1], wd[2], 0u);
+                tw_stage<NWP>(tw_lds, k, t, lane, wd);
                 if (p.hcol && q == jn_lane[k]) {
                     uint32_t hv = H[0];
 #pragma unroll
                     for (int c = 1; c < CPL; c++) hv = c == jn_c[k] ? H[c] : hv;
-                    p.hcol[arow[k] + i] = half_of(hv, k);
+                    p.hcol[(int64_t)al[k] * (p.N1 + 1) + i] = half_of(hv, k);
                 }
                 if (p.Hlast && i == n1[k]) {
 #pragma unroll
@@ -649,6 +698,11 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
             }
             h_in_prev = nh;
         }
+        if ((t & 7) == 7 || t == nmax + 15) {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (live[k] && (t >> 3) < tw_blocks(n1[k])) tw_flush<NWP>(tw_lds, k, t, lane, q, p.Tw, arow[k]);
+        }
     }
 }
 
@@ -656,24 +710,30 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
 __device__ __forceinline__ uint32_t tb_code(const uint32_t *__restrict__ Tw, int64_t arow, int i, int j, int CPL, int NWP, int fmt)
 {
     const int q = (j - 1) / CPL, c = (j - 1) % CPL;
-    const uint32_t t = (Tw[((arow + i + q) * 16 + q) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;      // row i of lane q was written at step i + q
+    const uint32_t t = (Tw[tw_word(arow, i + q, q, NWP) + (c >> 3)] >> ((c & 7) * 4)) & 15u;      // row i of lane q was written at step i + q
     if (fmt == 0) return t;
     return ((t & 2u) ? (uint32_t)T_INS : (t & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((t & 4u) ? 0u : (uint32_t)T_EEXT) | ((t & 8u) ? 0u : (uint32_t)T_FEXT);
 }
 
-// traceback of a free-tail alignment into reference coordinates (nc_msa.hip k_nw_trace16)
-__global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_t fmt, int16_t *__restrict__ qidx_all, int16_t *__restrict__ il_all,
-                                                 int16_t *__restrict__ iq_all)
+// traceback of a free-tail alignment into reference coordinates (nc_msa.hip k_nw_trace16): one lane per alignment.  Entry x of an
+// alignment packs, for reference position x (0-based) and the slot BEFORE it (slot n2 = after the last position):
+//     bits 0-9  read index aligned to position x, plus 1 (0 = gap)     bits 10-19  length of the insertion in slot x
+//     bits 20-29 read index of the insertion's first base
+// The walk visits the slots from n2 down to 0 and an entry is final when the walk leaves its slot, so every entry is written once
+// (no initialisation pass, no read-modify-write); a lane collects 16 entries in LDS and writes 64-byte runs.
+__global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_t fmt, uint32_t *__restrict__ ent_all, int32_t EW)
 {
+    __shared__ uint32_t stage[16 * 64];
     const int al = blockIdx.x * 64 + threadIdx.x;
     if (al >= p.A) return;
+    const int lane = threadIdx.x;
     const int n1 = p.n1[al];
     const int n2 = p.site_n2[fill_site(p, al)];
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
-    const int64_t arow = (int64_t)al * (p.N1 + 16);
-    int16_t *qidx = qidx_all + (int64_t)al * p.W, *il = il_all + (int64_t)al * p.W, *iq = iq_all + (int64_t)al * p.W;
-    for (int j = 0; j <= n2; j++) { qidx[j] = -1; il[j] = 0; iq[j] = 0; }
+    const int64_t arow = (int64_t)al * tw_blocks(p.N1), hrow = (int64_t)al * (p.N1 + 1);
+    uint32_t *ent = ent_all + (int64_t)al * EW;                       // EW: a multiple of 16 entries >= n2 + 1
     int i = n1, j = n2;
+    uint32_t cur = 0;                                                  // the entry of slot j being built (position j's read index comes last)
     if (n1 > 0 && n2 > 0) {                                           // free tail: best cell of the last row / last column
         int32_t best = p.Hlast[(int64_t)al * p.W + n2];
         for (int jj = n2 - 1; jj >= 0; jj--) {
@@ -681,11 +741,25 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
             if (v > best) { best = v; i = n1; j = jj; }
         }
         for (int ii = n1 - 1; ii >= 0; ii--) {
-            const int32_t v = ii > 0 ? p.hcol[arow + ii] : -p.open - (n2 - 1) * p.extend;
+            const int32_t v = ii > 0 ? p.hcol[hrow + ii] : -p.open - (n2 - 1) * p.extend;
             if (v > best) { best = v; i = ii; j = n2; }
         }
-        if (i < n1) { il[n2] = (int16_t)(n1 - i); iq[n2] = (int16_t)i; }   // the rest of the read: insertion after the window
+        if (i < n1) cur = ((uint32_t)(n1 - i) << 10) | ((uint32_t)i << 20);       // the rest of the read: insertion after the window
     }
+    // slots above the end point (free tail in the reference: j < n2) are empty
+    int x = n2;                                                        // slot whose entry is being built
+    auto put = [&](uint32_t e) {                                       // entry x is final
+        stage[(x & 15) * 64 + lane] = e;
+        if ((x & 15) == 0) {
+            // entries x .. min(x | 15, n2) of this lane, 64 bytes
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                reinterpret_cast<uint4 *>(ent + (x & ~15))[u] = make_uint4(stage[(4 * u) * 64 + lane], stage[(4 * u + 1) * 64 + lane],
+                                                                           stage[(4 * u + 2) * 64 + lane], stage[(4 * u + 3) * 64 + lane]);
+        }
+        x--;
+    };
+    while (x > j) put(0u);                                            // (end point in the last ROW: i == n1, so cur is 0 and stays the entry of slot j)
     int state = -1;
     while (i > 0 || j > 0) {
         uint32_t t;
@@ -694,21 +768,28 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
         else t = tb_code(p.Tw, arow, i, j, CPL, NWP, fmt);
         if (state < 0) {
             const int w = t & 3;
-            if (w == T_DIAG) { qidx[j - 1] = (int16_t)(i - 1); i--; j--; continue; }
+            if (w == T_DIAG) {                                        // position j-1 takes read base i-1; slot j is complete
+                put(cur);
+                cur = (uint32_t)i;                                    // (i - 1) + 1: the read index of position j - 1, entry j - 1
+                i--; j--;
+                continue;
+            }
             state = w == T_DEL ? 1 : 2;
         }
         if (state == 1) {
             const bool ext = (t & T_EEXT) != 0;
+            put(cur);                                                  // reference position j-1 stays a gap
+            cur = 0;
             j--;
             if (!ext) state = -1;
         } else {
             const bool ext = (t & T_FEXT) != 0;
-            il[j]++;
-            iq[j] = (int16_t)(i - 1);
+            cur = (cur & 0x3ffu) | ((((cur >> 10) & 0x3ffu) + 1u) << 10) | ((uint32_t)(i - 1) << 20);     // il[j]++, iq[j] = i - 1
             i--;
             if (!ext) state = -1;
         }
     }
+    put(cur);                                                          // slot 0
 }
 
 struct TensorArgs {
@@ -717,7 +798,8 @@ struct TensorArgs {
     const int32_t *site_al0, *site_nr, *site_pos, *site_n2;
     const uint8_t *al_member;                   // global
     const uint8_t *win;                         // group-local [A][WS]
-    const int16_t *qidx, *il, *iq;              // group-local [A][W]
+    const uint32_t *ent;                        // group-local [A][EW] packed alignment entries (k_trace16p)
+    int32_t EW;
     const uint8_t *ref_code;
     int32_t ref_pos0;
     float *x;                                   // global [n_sites][S*5][128][2]
@@ -749,7 +831,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
         for (int j = tid; j <= n2; j += 256) {
             int m = 0;
             for (int64_t a = a0; a < a1; a++)
-                if (mem[a] & bit) m = max(m, (int)p.il[a * p.W + j]);
+                if (mem[a] & bit) m = max(m, (int)((p.ent[a * p.EW + j] >> 10) & 0x3ffu));
             mxv[j] = (int16_t)m;
         }
         __syncthreads();
@@ -775,16 +857,17 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
             for (int64_t a = a0; a < a1; a++) {
                 if (!(mem[a] & bit)) continue;
                 const uint8_t *s1 = p.win + a * p.WS;
+                const uint32_t en = p.ent[a * p.EW + j];
                 if (j < n2) {
-                    const int qi = p.qidx[a * p.W + j];
+                    const int qi = (int)(en & 0x3ffu) - 1;
                     if (qi >= 0) {
                         const int sym = s1[qi];
                         if (sym < 4) hist[cj * 4 + sym]++;            // anything else (a read base N) counts as a gap at its column
                     }
                 }
-                const int L = p.il[a * p.W + j];
+                const int L = (int)((en >> 10) & 0x3ffu);
                 if (L > 0) {
-                    const int q0 = p.iq[a * p.W + j];
+                    const int q0 = (int)(en >> 20);
                     for (int u = 0; u < L; u++) {
                         const int sym = s1[q0 + u];
                         if (sym < 4) hist[(c0 + u) * 4 + sym]++;
@@ -868,7 +951,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     const int64_t arow = p.arow[al];
     const int run_cap = n1 + n2 + 2;
-    int16_t *rop = runs + 2 * (arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;      // runs in REVERSE alignment order
+    int16_t *rop = runs + 2 * (8 * arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;  // runs in REVERSE alignment order (8 * blocks >= n1 + 1)
     int nr = 0, last_op = -1;
     auto push = [&](int op) {
         if (op == last_op) rcn[nr - 1]++;
@@ -940,7 +1023,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     alt_len[al] = out_a;
 }
 
-// rows of the allele alignments: arow[a] = sum_{b<a} (n1[b] + 16) (skewed rows, see k_fill16p); arow[n] = total
+// traceback blocks of the allele alignments: arow[a] = sum_{b<a} tw_blocks(n1[b]); arow[n] = total
 __global__ __launch_bounds__(1024) void k_scan_rows(const int32_t *__restrict__ n1, int32_t n, int64_t *__restrict__ arow, int32_t *__restrict__ total_mbox)
 {
     __shared__ int wsum[16];
@@ -949,7 +1032,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(const int32_t *__restrict__ 
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
-        const int v = i < n ? n1[i] + 16 : 0;
+        const int v = i < n ? tw_blocks(n1[i]) : 0;
         int tot;
         const int inc = block_scan(v, wsum, tot);
         const long long cc = carry;
@@ -1231,7 +1314,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     const int CPL = cpl_for(s->window_after + 1);
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     // groups of whole sites: traceback codes of a group's alignments <= 12 GiB
-    const int64_t tw_per_al = (int64_t)(N1 + 16) * NWP * 64;     // rows 1 .. n1 of lane q live at the skewed rows 1 + q .. n1 + q
+    const int64_t tw_per_al = (int64_t)tw_blocks(N1) * 512 * NWP;   // blocks of 8 steps x 16 lanes x NWP words
     int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)12 << 30) / tw_per_al);
     if (const char *g = getenv("NC_PIPE_GROUP_AL")) GROUP_AL = std::max<int64_t>(64, atoll(g));
     const int64_t GROUP_SITES = 65536;
@@ -1256,8 +1339,9 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, s->n1, Agz * 4));
         NC_TRY(nc_ensure(ctx, s->tw, Agz * (size_t)tw_per_al + 64));
         NC_TRY(nc_ensure(ctx, s->hlast, Agz * W * 4));
-        NC_TRY(nc_ensure(ctx, s->hcol, Agz * (N1 + 16) * 4));
-        NC_TRY(nc_ensure(ctx, s->trace, (size_t)3 * Agz * W * 2));
+        NC_TRY(nc_ensure(ctx, s->hcol, Agz * (N1 + 1) * 4));
+        const int EW = (W + 15) & ~15;
+        NC_TRY(nc_ensure(ctx, s->trace, Agz * EW * 4 + 64));
         NC_TRY(nc_ensure(ctx, s->cns, (size_t)ng * S * CNS_CAP));
         NC_TRY(nc_ensure(ctx, s->ncns, (size_t)ng * S * 4));
         NC_TRY(nc_ensure(ctx, s->arow, ((size_t)ng * S + 1) * 8));
@@ -1295,15 +1379,14 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
             k0 = k1;
             continue;
         }
-        int16_t *qidx = (int16_t *)s->trace.p, *il = qidx + Agz * W, *iq = il + Agz * W;
-        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, fa, CPL, packed_fill() ? 1 : 0, qidx, il, iq);
+        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, fa, CPL, packed_fill() ? 1 : 0, (uint32_t *)s->trace.p, EW);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], ctx->stream));
         // ---- columns, histogram, tensor, consensus
         TensorArgs ta;
         ta.site0 = k0; ta.n_sites_g = ng; ta.S = S; ta.haploid = s->haploid; ta.W = W; ta.WS = WS; ta.A0 = A0;
         ta.site_al0 = (const int32_t *)s->site_al0.p; ta.site_nr = (const int32_t *)s->site_nr.p; ta.site_pos = (const int32_t *)s->site_pos.p;
         ta.site_n2 = (const int32_t *)s->site_n2.p; ta.al_member = (const uint8_t *)s->al_member.p; ta.win = (const uint8_t *)s->win.p;
-        ta.qidx = qidx; ta.il = il; ta.iq = iq; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
+        ta.ent = (const uint32_t *)s->trace.p; ta.EW = EW; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
         ta.cns = (uint8_t *)s->cns.p; ta.ncns = (int32_t *)s->ncns.p; ta.err = err;
         hipLaunchKernelGGL(k_site_tensor, dim3(ng), dim3(256), 0, ctx->stream, ta);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], ctx->stream));
@@ -1316,8 +1399,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_HIP(ctx, hipMemcpyAsync(mb, mbox, 8, hipMemcpyDeviceToHost, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
-        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 16) * NWP * 64 + 64));
-        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
+        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 512 * NWP + 64));                         // `rows` counts blocks of 8 steps
+        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(8 * rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
         FillArgs fb = fa;
         fb.s1 = (const uint8_t *)s->cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)s->ncns.p;
         fb.al_site = nullptr; fb.site0 = k0; fb.site_div = S;
@@ -1341,7 +1424,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
                 (void)hipEventElapsedTime(&ms, s->ev[st], s->ev[st + 1]);
                 s->stage_ms[st + 1] += ms;
             }
-            s->cells[1] += rows * (int64_t)(s->window_after + 1);
+            s->cells[1] += 8 * rows * (int64_t)(s->window_after + 1);                  // (upper estimate: blocks of 8 rows)
         }
         k0 = k1;
     }
