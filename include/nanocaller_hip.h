@@ -484,6 +484,9 @@ int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref
                         int64_t chrom_len, const nc_indel_reads *reads, const uint8_t *excl_dev, int32_t n_chunks,
                         const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *params, int32_t window_after,
                         int32_t maxcov, int32_t *n_sites, int64_t *n_alignments);
+/* Scoring of the star alignment (gap open, gap extend, match, mismatch; default 25, 1, 20, -10 = the product's _lib.STAR_SCORING;
+ * allele_prediction always uses the reference's call-site values 9, 1, 20, -10).  Persists on the context. */
+int nc_indel_sites_scoring(nc_ctx *ctx, int32_t open, int32_t extend, int32_t match, int32_t mismatch);
 /* Step 2: windows -> alignment -> tensors + consensus -> alleles, in groups of sites bounded by the traceback workspace.
  * x_dev f32 [n_sites][sets * 5][128][2] (sets = 3: hap0 | hap1 | all reads stacked as indelCaller.py:83 does; haploid 1) is
  * the input of nc_indel_forward.  Does not synchronise. */

@@ -42,7 +42,7 @@ EXPORTS = [
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
     "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
-    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads",
+    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads",
 ]
 
 
@@ -202,6 +202,7 @@ def lib():
         L.nc_indel_sites_plan.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i64, C.POINTER(IndelReadsC), vp, i32, vp, vp,
                                           C.POINTER(IndelScanParamsC), i32, i32, C.POINTER(i32), C.POINTER(i64)]
         L.nc_indel_sites_run.argtypes = [vp, vp]
+        L.nc_indel_sites_scoring.argtypes = [vp, i32, i32, i32, i32]
         L.nc_indel_sites_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
         L.nc_indel_sites_fetch_alt.argtypes = [vp, vp, i64]
         L.nc_indel_sites_stage_ms.argtypes = [vp, vp, vp]

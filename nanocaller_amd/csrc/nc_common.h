@@ -78,7 +78,34 @@ int nc_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes, hipStream_t s
 int nc_h2d_small(nc_ctx *ctx, void *dev, const void *host, size_t bytes, hipStream_t st);
 #define NC_D2H_KERNEL_MAX 65536
 #define NC_STAGE_SLOT 16384
-#define NC_STAGE_SLOTS 8
+#define NC_STAGE_SLOTS 16
+
+// the same for arrays of any size, in ring-slot pieces (descriptor tables of a few tens of kilobytes: a hipMemcpyAsync would wait for
+// a contig's upload in flight).  The source may be released on return; the stream is drained before the ring would wrap.
+inline int nc_h2d_pieces(nc_ctx *ctx, void *dev, const void *host, size_t bytes, hipStream_t st)
+{
+    int in_flight = 0;
+    for (size_t o = 0; o < bytes; o += NC_STAGE_SLOT) {
+        if (++in_flight >= NC_STAGE_SLOTS - 2) {
+            if (hipStreamSynchronize(st) != hipSuccess) return NC_ERR_HIP;
+            in_flight = 1;
+        }
+        const size_t n = bytes - o < (size_t)NC_STAGE_SLOT ? bytes - o : (size_t)NC_STAGE_SLOT;
+        const int rc = nc_h2d_small(ctx, (char *)dev + o, (const char *)host + o, n, st);
+        if (rc != NC_OK) return rc;
+    }
+    return NC_OK;
+}
+// device -> page-locked host in copy-kernel pieces (see nc_d2h): for arrays the host waits for while an upload is in flight
+inline int nc_d2h_pieces(nc_ctx *ctx, void *host_pinned, const void *dev, size_t bytes, hipStream_t st)
+{
+    for (size_t o = 0; o < bytes; o += NC_D2H_KERNEL_MAX) {
+        const size_t n = bytes - o < (size_t)NC_D2H_KERNEL_MAX ? bytes - o : (size_t)NC_D2H_KERNEL_MAX;
+        const int rc = nc_d2h(ctx, (char *)host_pinned + o, (const char *)dev + o, n, st);
+        if (rc != NC_OK) return rc;
+    }
+    return NC_OK;
+}
 
 inline int nc_fail(nc_ctx *ctx, int code, const char *fmt, ...)
 {

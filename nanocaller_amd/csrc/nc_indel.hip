@@ -464,7 +464,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     char *ws = (char *)ctx->indel_ws.p;
     NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
     IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
-    NC_HIP(ctx, hipMemcpyAsync(ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), hipMemcpyHostToDevice, ctx->stream));
+    NC_TRY(nc_h2d_pieces(ctx, ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), ctx->stream));   // by copy kernel: never behind an upload in flight
     int8_t *ctype = (int8_t *)(ws + o_type);
 #define NC_HAP_DEPTH(B, STAR)                                                                                                        \
     hipLaunchKernelGGL((k_hap_depth_b<B, STAR>), dim3(nblk), dim3(B), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, \

@@ -1095,12 +1095,14 @@ struct nc_pipe_state {
     int32_t window_after = 0, maxcov = 0, mincov = 0, win_size = 0, haploid = 0, S = 3;
     int32_t n_chunks = 0, n_anchor = 0, n_sites = 0;
     int64_t n_al = 0;
-    std::vector<int32_t> site_al0_h;
+    int32_t *al0_pin = nullptr;             // page-locked: first alignment of every site (+ total), read by the host to cut the groups
+    size_t al0_cap = 0;
     DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
     DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
     DevBuf win, n1, tw, hlast, hcol, trace, cns, ncns, arow, tw2, runs, rlen, alen, alt_off, alt_pool, misc;
     int64_t alt_pool_cap = 0;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t scoring[4] = {25, 1, 20, -10};         // star alignment: gap open, gap extend, match, mismatch (nc_indel_sites_scoring)
     float stage_ms[6] = {0, 0, 0, 0, 0, 0};
     int64_t cells[2] = {0, 0};
 };
@@ -1119,6 +1121,7 @@ void nc_pipe_destroy(nc_ctx *ctx)
         b->cap = 0;
     }
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->al0_pin) (void)hipHostFree(s->al0_pin);
     delete s;
     ctx->pipe = nullptr;
 }
@@ -1213,18 +1216,20 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
         const int8_t *ctype = nullptr;
         NC_TRY(nc_indel_scan_group_launch(ctx, pack, &ev, excl_dev, n_chunks - c0, starts + c0, ends + c0, prm, &used, ck, &ck_dev, &ctype));
         for (int32_t k = 0; k < used; k++) pcs[(size_t)(c0 + k)].coloff = ck[(size_t)k].coloff;
-        NC_HIP(ctx, hipMemcpyAsync((PipeChunk *)s->pc.p + c0, pcs.data() + c0, (size_t)used * sizeof(PipeChunk), hipMemcpyHostToDevice, ctx->stream));
+        NC_TRY(nc_h2d_pieces(ctx, (PipeChunk *)s->pc.p + c0, pcs.data() + c0, (size_t)used * sizeof(PipeChunk), ctx->stream));
         hipLaunchKernelGGL(k_pick, dim3(used), dim3(64), 0, ctx->stream, (const PipeChunk *)s->pc.p + c0, ctype, prm->win_size, (int32_t *)s->seg_pos.p,
                            (int8_t *)s->seg_type.p, (int32_t *)s->cnt.p, err);
         NC_HIP(ctx, hipGetLastError());
-        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));               // `pcs` / `ck` are copy sources; the next group reuses the K7 workspace
-        c0 += used;
+        c0 += used;                                                   // (the next group's K7 reuses the workspace in stream order)
     }
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->cnt.p, n_chunks, 0, (int32_t *)s->off.p);
-    int32_t na = 0, errh = 0;
-    NC_HIP(ctx, hipMemcpyAsync(&na, (int32_t *)s->off.p + n_chunks, 4, hipMemcpyDeviceToHost, ctx->stream));
-    NC_HIP(ctx, hipMemcpyAsync(&errh, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    // counts the host waits for travel by copy kernel into the context's page-locked mailbox (a hipMemcpyAsync of either direction
+    // queues behind a contig's upload in flight on this platform: DESIGN.md section 2)
+    volatile int32_t *mb = ctx->mbox + 32;
+    NC_TRY(nc_d2h(ctx, ctx->mbox + 32, (int32_t *)s->off.p + n_chunks, 4, ctx->stream));
+    NC_TRY(nc_d2h(ctx, ctx->mbox + 33, err, 4, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t na = mb[0], errh = mb[1];
     if (errh & 1) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: anchor buffer of a chunk overflowed");
     s->n_anchor = na;
     s->planned = true;
@@ -1254,10 +1259,10 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->kept.p, na, 0, (int32_t *)s->site_of.p);
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->nuniq.p, na, 0, (int32_t *)s->al_of.p);
     NC_HIP(ctx, hipGetLastError());
-    int32_t ns = 0, nal = 0;
-    NC_HIP(ctx, hipMemcpyAsync(&ns, (int32_t *)s->site_of.p + na, 4, hipMemcpyDeviceToHost, ctx->stream));
-    NC_HIP(ctx, hipMemcpyAsync(&nal, (int32_t *)s->al_of.p + na, 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_TRY(nc_d2h(ctx, ctx->mbox + 34, (int32_t *)s->site_of.p + na, 4, ctx->stream));
+    NC_TRY(nc_d2h(ctx, ctx->mbox + 35, (int32_t *)s->al_of.p + na, 4, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t ns = mb[2], nal = mb[3];
     s->n_sites = ns;
     s->n_al = nal;
     *n_sites = ns;
@@ -1283,17 +1288,35 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     sa.site_n2 = (int32_t *)s->site_n2.p; sa.al_read = (int32_t *)s->al_read.p; sa.al_site = (int32_t *)s->al_site.p; sa.al_member = (uint8_t *)s->al_member.p;
     hipLaunchKernelGGL(k_sets<true>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
     NC_HIP(ctx, hipGetLastError());
-    NC_HIP(ctx, hipMemcpyAsync((int32_t *)s->site_al0.p + ns, &s->n_al, 4, hipMemcpyHostToDevice, ctx->stream));   // little endian: low word of n_al
-    s->site_al0_h.resize(NS + 1);
-    NC_HIP(ctx, hipMemcpyAsync(s->site_al0_h.data(), s->site_al0.p, NS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NC_TRY(nc_h2d_small(ctx, (int32_t *)s->site_al0.p + ns, &nal, 4, ctx->stream));
+    if (s->al0_cap < NS + 1) {
+        if (s->al0_pin) (void)hipHostFree(s->al0_pin);
+        s->al0_pin = nullptr;
+        s->al0_cap = 0;
+        NC_HIP(ctx, hipHostMalloc((void **)&s->al0_pin, (NS + 1 + NS / 4) * 4, hipHostMallocDefault));
+        s->al0_cap = NS + 1 + NS / 4;
+    }
+    NC_TRY(nc_d2h_pieces(ctx, s->al0_pin, s->site_al0.p, NS * 4, ctx->stream));
     if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    s->site_al0_h[NS] = nal;
+    s->al0_pin[NS] = nal;
     if (timing) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]);
         s->stage_ms[0] = ms;
     }
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_scoring(nc_ctx *ctx, int32_t open, int32_t extend, int32_t match, int32_t mismatch)
+{
+    if (!ctx) return NC_ERR_ARG;
+    // the packed 16-bit fill keeps |scores| below 2^15: 272 matches and 1,300 gap extensions must fit
+    if (open < 0 || extend < 0 || open > 100 || extend > 10 || match < 0 || match > 100 || mismatch > 0 || mismatch < -100)
+        return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_scoring: scores out of the range the 16-bit aligner covers");
+    if (!ctx->pipe) ctx->pipe = new (std::nothrow) nc_pipe_state();
+    if (!ctx->pipe) return NC_ERR_NOMEM;
+    ctx->pipe->scoring[0] = open; ctx->pipe->scoring[1] = extend; ctx->pipe->scoring[2] = match; ctx->pipe->scoring[3] = mismatch;
     return NC_OK;
 }
 
@@ -1326,7 +1349,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     NC_TRY(nc_ensure(ctx, s->alt_pool, (size_t)s->alt_pool_cap));
     NC_TRY(nc_ensure(ctx, s->rlen, (size_t)ns * S * 4));
     NC_TRY(nc_ensure(ctx, s->alen, (size_t)ns * S * 4));
-    const int32_t *al0h = s->site_al0_h.data();
+    const int32_t *al0h = s->al0_pin;
     int k0 = 0;
     while (k0 < ns) {
         int k1 = k0 + 1;
@@ -1363,8 +1386,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fa.ref_code = s->ref_code; fa.ref_pos0 = s->ref_pos0; fa.site_pos = (const int32_t *)s->site_pos.p; fa.site_n2 = (const int32_t *)s->site_n2.p;
         fa.al_site = (const int32_t *)s->al_site.p + A0; fa.site0 = 0; fa.site_div = 1;
         fa.A = Ag; fa.W = W;
-        fa.open = 25; fa.extend = 1; fa.match = 20; fa.mismatch = -10;          // the product's star-alignment scoring (_lib.STAR_SCORING)
-        if (const char *sc = getenv("NC_STAR_SCORING")) (void)sscanf(sc, "%d,%d,%d,%d", &fa.open, &fa.extend, &fa.match, &fa.mismatch);
+        fa.open = s->scoring[0]; fa.extend = s->scoring[1]; fa.match = s->scoring[2]; fa.mismatch = s->scoring[3];
         fa.arow = nullptr; fa.N1 = N1;
         fa.Tw = (uint32_t *)s->tw.p; fa.Hlast = (int32_t *)s->hlast.p; fa.hcol = (int32_t *)s->hcol.p;
         if (Ag > 0) launch_fill(ctx, CPL, fa);
@@ -1395,8 +1417,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         int32_t *mbox = (int32_t *)s->misc.p + 2;
         hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->ncns.p, nset, (int64_t *)s->arow.p, mbox);
         NC_HIP(ctx, hipGetLastError());
-        int32_t mb[2] = {0, 0};
-        NC_HIP(ctx, hipMemcpyAsync(mb, mbox, 8, hipMemcpyDeviceToHost, ctx->stream));
+        volatile int32_t *mb = ctx->mbox + 36;
+        NC_TRY(nc_d2h(ctx, ctx->mbox + 36, mbox, 8, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
         NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 512 * NWP + 64));                         // `rows` counts blocks of 8 steps

@@ -36,6 +36,7 @@ class DevicePack:
     pos_hi: int
     events: dict | None = None    # device tensors ev_off / ev_pos / ev_len / read_hap (indel scan inputs)
     reads: dict | None = None     # device tensors rd_start / rd_end / slot_off of the kept reads (device pass 2: tile entry -> read)
+    indel: dict | None = None     # device tensors ins_off / ins_bases / tail_off / tail_bases / read_ps / read_flag (device pass 2)
 
     def c_struct(self) -> _lib.ReadPackC:
         return _lib.ReadPackC(codes_len=self.codes.numel(), codes=self.codes.data_ptr(), tile_size=self.tile_size,

@@ -610,6 +610,7 @@ def indel_sites_device(eng, dp, reads_c, chrom_len, chunks, *, mincov, maxcov, w
             err = _lib.NanoCallerHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
             err.status = rc
             raise err
+    check(L.nc_indel_sites_scoring(eng.ctx, *[int(v) for v in _lib.STAR_SCORING]), "nc_indel_sites_scoring")
     check(L.nc_indel_sites_plan(eng.ctx, C.byref(pc), C.c_void_p(dp.ref_code.data_ptr()), dp.tile_pos0, dp.ref_code.numel(), int(chrom_len),
                                 C.byref(reads_c), C.c_void_p(excl.data_ptr()) if excl is not None else None, len(chunks), _lib.npp(starts),
                                 _lib.npp(ends), C.byref(prm), int(window_after), int(maxcov), C.byref(n), C.byref(na)), "nc_indel_sites_plan")

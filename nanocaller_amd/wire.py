@@ -68,10 +68,12 @@ def ref_wire_from_string(ref: str, exclude=None, pos0=1):
 
 
 def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, *, supplementary=False, tile_size=2048,
-               pos_lo=None, pos_hi=None, hap=None, events=None, strand=None, keep=None, pin=True) -> WirePack:
+               pos_lo=None, pos_hi=None, hap=None, events=None, strand=None, keep=None, pin=True, indel_extra=None) -> WirePack:
     """read_* / codes as synth.World (coordinate order, codes[read_off[r] + p - read_start[r]]); `ref_wire_pos1`: uint8 per
     position, index p - 1 (ref_wire_from_string).  Flag filter and strand as pack.pack_reads, or given directly (`keep`,
-    `strand`).  -> WirePack: one host buffer ready for a single H2D copy."""
+    `strand`).  `indel_extra` (with `events`): dict of the per-read arrays of the device pass 2 for the KEPT reads (ins_off,
+    ins_bases, tail_off, tail_bases, read_ps, read_flag: nc_indel_pack_build) -- they ride in the same buffer.
+    -> WirePack: one host buffer ready for a single H2D copy."""
     L = _lib.lib()
     rs = np.ascontiguousarray(read_start, np.int32)
     re_ = np.ascontiguousarray(read_end, np.int32)
@@ -134,12 +136,19 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
             cnt = (ev_off[1:] - ev_off[:-1])[kept]
             off = np.zeros(kept.size + 1, np.int32)
             np.cumsum(cnt, out=off[1:])
-            idx = np.concatenate([np.arange(ev_off[r], ev_off[r + 1]) for r in kept]) if kept.size else np.zeros(0, np.int64)
+            if kept.size == n:                                        # nothing filtered: the events are already in pack order
+                idx = slice(0, int(ev_off[-1]))
+            else:
+                idx = np.concatenate([np.arange(ev_off[r], ev_off[r + 1]) for r in kept]) if kept.size else np.zeros(0, np.int64)
             hp = (np.asarray(hap, np.uint8) if hap is not None else np.zeros(n, np.uint8))[kept]
             z = lambda x, dt: np.ascontiguousarray(x, dt) if len(x) else np.zeros(1, dt)      # noqa: E731
             parts += [("ev_off", z(off, np.int32)), ("ev_pos", z(ev_pos[idx], np.int32)), ("ev_len", z(ev_len[idx], np.int32)),
                       ("read_hap", z(hp, np.uint8))]
             n_indel = int(kept.size)
+            if indel_extra is not None:
+                for name, dt in (("ins_off", np.int32), ("ins_bases", np.uint8), ("tail_off", np.int32), ("tail_bases", np.uint8),
+                                 ("read_ps", np.int32), ("read_flag", np.uint8)):
+                    parts.append((name, z(indel_extra[name], dt)))
         sections, total = {}, 0
         for name, a_ in parts:
             sections[name] = (total, a_.dtype, int(a_.size))
@@ -190,7 +199,19 @@ def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
     if wp.n_indel_reads >= 0:
         dp.events = dict(n_reads=wp.n_indel_reads, ev_off=g(v["ev_off"]), ev_pos=g(v["ev_pos"]), ev_len=g(v["ev_len"]), read_hap=g(v["read_hap"]))
         dp.reads = dict(n_reads=wp.n_reads, rd_start=g(v["rd_start"]), rd_end=g(v["rd_end"]), slot_off=g(v["slot_off"]))
+        if "ins_off" in v:
+            dp.indel = {k: g(v[k]) for k in ("ins_off", "ins_bases", "tail_off", "tail_bases", "read_ps", "read_flag")}
     return dp
+
+
+def indel_reads_struct(dp: DevicePack):
+    """nc_indel_reads over the tensors of a pack that carries the indel sections (build_wire(..., indel_extra=...))"""
+    ev, rd, ix = dp.events, dp.reads, dp.indel
+    return _lib.IndelReadsC(n_reads=rd["n_reads"], slot_off=rd["slot_off"].data_ptr(), rd_start=rd["rd_start"].data_ptr(), rd_end=rd["rd_end"].data_ptr(),
+                            ev_off=ev["ev_off"].data_ptr(), ev_pos=ev["ev_pos"].data_ptr(), ev_len=ev["ev_len"].data_ptr(),
+                            ins_off=ix["ins_off"].data_ptr(), ins_bases=ix["ins_bases"].data_ptr(), tail_off=ix["tail_off"].data_ptr(),
+                            tail_bases=ix["tail_bases"].data_ptr(), read_ps=ix["read_ps"].data_ptr(), read_hap=ev["read_hap"].data_ptr(),
+                            read_flag=ix["read_flag"].data_ptr())
 
 
 def upload_wire(eng, wp: WirePack) -> DevicePack:

@@ -491,3 +491,57 @@ def read_windows_ref(records, anchors, window_before, window_after, flag_filter)
             here.append((k, r["seq"][max(0, q - window_before):q + window_after]))
         out.append(here)
     return out
+
+
+# ------------------------------------------------------------------------------------------------- device indel pipeline sample
+def records_from_indel_pack(read_start, read_end, codes_of, ev_of, ins_of, names=None, flags=None):
+    """SAM-like records (what read_windows_ref takes) rebuilt from the pack form of reads: `codes_of(r)` = uint8 code per spanned
+    reference position (4 = deleted or N), `ev_of(r)` = [(column, +ins / -del length)], `ins_of(r, k)` = codes of the k-th event's
+    inserted bases.  The CIGAR walk of tests/bamio.world_to_records, stated independently of the device's window rebuild."""
+    lut = "AGTCNNNN"
+    recs = []
+    for r in range(len(read_start)):
+        s, e = int(read_start[r]), int(read_end[r])
+        c = codes_of(r)
+        cig, seq, p = [], [], s
+        for k, (ep, el) in enumerate(ev_of(r)):
+            cig.append(("M", ep - p + 1))
+            seq.append("".join(lut[x] for x in c[p - s:ep - s + 1]))
+            p = ep + 1
+            if el > 0:
+                cig.append(("I", el))
+                seq.append("".join(lut[x] for x in ins_of(r, k)))
+            else:
+                cig.append(("D", -el))
+                p += -el
+        if p < e:
+            cig.append(("M", e - p))
+            seq.append("".join(lut[x] for x in c[p - s:e - s]))
+        recs.append(dict(name=names[r] if names else "r%d" % r, flag=int(flags[r]) if flags is not None else 0, pos0=s - 1, cigar=cig, seq="".join(seq)))
+    return recs
+
+
+def indel_site_ref(records, hap, ps, ref, v_pos, window_after, mincov, maxcov, aligner=None, scoring=(25, 1, 20, -10), haploid=False):
+    """One pass-2 site from records: read sets (first-maxcov policy), star alignment (`aligner(names, seqs, ref)` or the pure-Python
+    star_msa_ref), msa()'s tensor by the C oracle.  -> None when the site fails the set-size tests, else (x float32 [S,5,128,2],
+    [consensus strings], reference window, phase)"""
+    win = ref[v_pos - 1:min(len(ref), v_pos + window_after)]
+    if any(ch not in "AGTC" for ch in win):
+        return None
+    here = read_windows_ref(records, [v_pos], 0, window_after, 0)[0]
+    sets = [[(k, s) for k, s in here]] if haploid else [[(k, s) for k, s in here if hap[k] == 1], [(k, s) for k, s in here if hap[k] == 2], list(here)]
+    sets = [x[:maxcov] for x in sets]
+    need = [mincov] if haploid else [2, 2, mincov]
+    if any(len(x) < n for x, n in zip(sets, need)):
+        return None
+    sym = {"A": 0, "G": 1, "T": 2, "C": 3, "-": 4}
+    xs, cns = [], []
+    for st in sets:
+        seqs = [s for _, s in st]
+        rows, ref_row = aligner(["r%d" % k for k, _ in st], seqs, win) if aligner else star_msa_ref(seqs, win, *scoring)
+        mat = np.array([[sym.get(c, 4) for c in row] for row in rows], np.uint8)
+        x, c = indel_tensor(mat, np.array([sym[c] for c in ref_row], np.uint8))
+        xs.append(x)
+        cns.append("".join("AGTC"[k] for k in c if k < 4))
+    phase = 0 if haploid or not sets[0] else int(ps[sets[0][0][0]])
+    return np.stack(xs).astype(np.float32), cns, win, phase

@@ -262,3 +262,79 @@ def test_indel_run_native_text_equals_the_python_rules(world_files, tmp_path, mo
             jobs.put(("indel", dict(chrom=w.chrom, start=s, end=min(w.length, s + 40_000), ploidy="diploid" if s < 100_000 else "haploid", sam_path=bam)))
         outs.append(open(indelCaller.indel_run(params, {}, jobs, queue.Queue(), [], aligner="device")).read())
     assert outs[0] == outs[1] and outs[0].count("\n") > 60
+
+
+def _host_sample(pack, reads_c, info, r1):
+    """host copies of the first r1 reads of a synthetic device workload, as callables for oracle.records_from_indel_pack"""
+    s, e = info["read_start"][:r1], info["read_end"][:r1]
+    slot = pack.reads["slot_off"][:r1 + 1].cpu().numpy()
+    codes = pack.codes[:int(slot[-1])].cpu().numpy()
+    ev_off = pack.events["ev_off"][:r1 + 1].cpu().numpy()
+    ev_pos = pack.events["ev_pos"][:int(ev_off[-1])].cpu().numpy()
+    ev_len = pack.events["ev_len"][:int(ev_off[-1])].cpu().numpy()
+    ins_off = info["tensors"]["ins_off"][:int(ev_off[-1]) + 1].cpu().numpy()
+    ins = info["tensors"]["ins_bases"][:int(ins_off[-1])].cpu().numpy()
+
+    def codes_of(r):
+        o = int(slot[r]) + (int(s[r]) & 15)
+        return codes[o:o + int(e[r] - s[r])]
+
+    def ev_of(r):
+        return list(zip(ev_pos[ev_off[r]:ev_off[r + 1]].tolist(), ev_len[ev_off[r]:ev_off[r + 1]].tolist()))
+
+    def ins_of(r, k):
+        a = int(ev_off[r]) + k
+        return ins[ins_off[a]:ins_off[a + 1]]
+    return s, e, codes_of, ev_of, ins_of
+
+
+@pytest.mark.gpu
+def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement():
+    """the bench workload (generated in HBM, no BAM behind it): sites, tensors, consensus-derived alleles and phase of the device
+    pipeline against pass 2 restated from SAM-like records (CIGAR expansion base by base, oracle.read_windows_ref), the star
+    alignment in pure Python (oracle.star_msa_ref) for a few sites and the host statement (nc_star_msa) for the rest, msa() by the C oracle"""
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    from oracle import oracle
+    eng = get_engine(0)
+    L = 260_000
+    pack, reads_c, info = make_indel_device_workload(eng, L, depth=28.0, seed=99)
+    chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+    r = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+    assert r["n"] > 80
+    x = r["x"].cpu().numpy()
+    hi = 60_000
+    r1 = int(np.searchsorted(info["read_start"], hi + 400))
+    s, e, codes_of, ev_of, ins_of = _host_sample(pack, reads_c, info, r1)
+    recs = oracle.records_from_indel_pack(s, e, codes_of, ev_of, ins_of)
+    ref = np.frombuffer(b"AGTCN", np.uint8)[info["tensors"]["ref"].cpu().numpy()[1:]].tobytes().decode()
+    masked = pack.ref_code[1:L + 1].cpu().numpy() == 4
+    ref = "".join(c.lower() if m else c for c, m in zip(ref[:hi + 400], masked[:hi + 400]))      # soft-masked runs: not upper-case AGTC
+    alt_all = np.frombuffer(b"AGTCN", np.uint8)[r["alt"]].tobytes().decode()
+    aoff = np.zeros(r["n"] * 3 + 1, np.int64)
+    np.cumsum(np.maximum(r["alt_len"].reshape(-1), 0), out=aoff[1:])
+    checked = pure = 0
+    for k in range(r["n"]):
+        p = int(r["pos"][k])
+        if p > hi:
+            break
+        use_pure = pure < 2
+        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref, p, 160, 4, 160, aligner=None if use_pure else gip.star_aligner)
+        assert got is not None, p
+        pure += use_pure
+        xs, cns, win, phase = got
+        assert np.array_equal(x[k].reshape(3, 5, 128, 2), xs), p
+        assert phase == int(r["phase"][k])
+        mr = 40 if r["type"][k] == 0 else 10
+        for t in range(3):
+            exp = gip.allele_prediction(cns[t], win, mr)
+            rl, al = int(r["ref_len"][k, t]), int(r["alt_len"][k, t])
+            have = (None, None) if rl < 0 else (win[:rl], alt_all[aoff[k * 3 + t]:aoff[k * 3 + t] + al])
+            assert have == exp, (p, t)
+        checked += 1
+    assert checked >= 15
+    # and no site of the oracle's is missing: every anchor position the device kept in the sample range passes the oracle's set tests (above);
+    # positions are unique per chunk and ascending
+    pos0 = r["pos"][r["chunk"] == 0]
+    assert np.all(np.diff(pos0) > 0)
