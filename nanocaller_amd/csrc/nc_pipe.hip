@@ -391,13 +391,17 @@ __device__ __forceinline__ int fill_site(const FillArgs &p, int al) { return p.a
 // stored one after the other made the fill write 16 partial lines per instruction (33 ms, 2.6x the arithmetic); steps stored one after
 // the other fixed the writes (15 ms) but left the traceback one 64-byte sector per step (11 GB per chr20-sized contig).]  The fill
 // kernels collect 8 steps per lane in LDS (a lane reads back only what it wrote itself) and write whole runs.
-__host__ __device__ __forceinline__ int tw_blocks(int n1) { return ((n1 + 15) >> 3) + 1; }
-__device__ __forceinline__ int64_t tw_word(int64_t first_block, int t, int q, int NWP) { return (((first_block + (t >> 3)) * 16 + q) * 8 + (t & 7)) * (int64_t)NWP; }
+#ifndef NC_TWB_LOG
+#define NC_TWB_LOG 3
+#endif
+constexpr int TWB_LOG = NC_TWB_LOG, TWB = 1 << TWB_LOG;        // steps per block (8 in the text above)
+__host__ __device__ __forceinline__ int tw_blocks(int n1) { return ((n1 + 15) >> TWB_LOG) + 1; }
+__device__ __forceinline__ int64_t tw_word(int64_t first_block, int t, int q, int NWP) { return (((first_block + (t >> TWB_LOG)) * 16 + q) * TWB + (t & (TWB - 1))) * (int64_t)NWP; }
 
 template <int NWP>
 __device__ __forceinline__ void tw_stage(uint32_t *lds, int k, int t, int lane, const uint32_t *wd)
 {
-    uint32_t *ls = lds + ((k * 8 + (t & 7)) * 64 + lane) * NWP;
+    uint32_t *ls = lds + ((k * TWB + (t & (TWB - 1))) * 64 + lane) * NWP;
     if (NWP == 1) ls[0] = wd[0];
     else if (NWP == 2) *reinterpret_cast<uint2 *>(ls) = make_uint2(wd[0], wd[1]);
     else *reinterpret_cast<uint4 *>(ls) = make_uint4(wd[0], wd[1], wd[2], 0u);
@@ -406,14 +410,14 @@ __device__ __forceinline__ void tw_stage(uint32_t *lds, int k, int t, int lane, 
 template <int NWP>
 __device__ __forceinline__ void tw_flush(const uint32_t *lds, int k, int t, int lane, int q, uint32_t *Tw, int64_t first_block)
 {
-    uint32_t *dst = Tw + tw_word(first_block, t & ~7, q, NWP);
-    uint32_t v[8 * NWP];
+    uint32_t *dst = Tw + tw_word(first_block, t & ~(TWB - 1), q, NWP);
+    uint32_t v[TWB * NWP];
 #pragma unroll
-    for (int ts = 0; ts < 8; ts++)
+    for (int ts = 0; ts < TWB; ts++)
 #pragma unroll
-        for (int w = 0; w < NWP; w++) v[ts * NWP + w] = lds[((k * 8 + ts) * 64 + lane) * NWP + w];
+        for (int w = 0; w < NWP; w++) v[ts * NWP + w] = lds[((k * TWB + ts) * 64 + lane) * NWP + w];
 #pragma unroll
-    for (int x = 0; x < 2 * NWP; x++) reinterpret_cast<uint4 *>(dst)[x] = make_uint4(v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]);
+    for (int x = 0; x < TWB * NWP / 4; x++) reinterpret_cast<uint4 *>(dst)[x] = make_uint4(v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]);
 }
 
 template <int CPL>
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
     int nmax = n1;
     nmax = max(nmax, __shfl_xor(nmax, 16));
     nmax = max(nmax, __shfl_xor(nmax, 32));
-    __shared__ uint32_t tw_lds[8 * 64 * NWP];
+    __shared__ uint32_t tw_lds[TWB * 64 * NWP];
     const int64_t arow = p.arow ? p.arow[al] : (int64_t)al * tw_blocks(p.N1);
     int32_t h_out = 0, e_out = NW_NEG;
     int32_t h_in_prev = q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend;      // H[0][q*CPL]
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
             }
         }
         if (i >= 1) h_in_prev = nh;
-        if (((t & 7) == 7 || t == nmax + 15) && live && (t >> 3) < tw_blocks(n1)) tw_flush<NWP>(tw_lds, 0, t, lane, q, p.Tw, arow);
+        if (((t & (TWB - 1)) == TWB - 1 || t == nmax + 15) && live && (t >> TWB_LOG) < tw_blocks(n1)) tw_flush<NWP>(tw_lds, 0, t, lane, q, p.Tw, arow);
     }
 }
 
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     int64_t arow[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * tw_blocks(p.N1);
-    __shared__ uint32_t tw_lds[2 * 8 * 64 * NWP];
+    __shared__ uint32_t tw_lds[2 * TWB * 64 * NWP];
     const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match), k_mis = splat16(p.mismatch);
     const uint32_t k_one = splat16(1), k_two = splat16(2), k_four = splat16(4);
     uint32_t k_sh[4];
@@ -698,10 +702,10 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
             }
             h_in_prev = nh;
         }
-        if ((t & 7) == 7 || t == nmax + 15) {
+        if ((t & (TWB - 1)) == TWB - 1 || t == nmax + 15) {
 #pragma unroll
             for (int k = 0; k < 2; k++)
-                if (live[k] && (t >> 3) < tw_blocks(n1[k])) tw_flush<NWP>(tw_lds, k, t, lane, q, p.Tw, arow[k]);
+                if (live[k] && (t >> TWB_LOG) < tw_blocks(n1[k])) tw_flush<NWP>(tw_lds, k, t, lane, q, p.Tw, arow[k]);
         }
     }
 }
@@ -951,7 +955,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     const int64_t arow = p.arow[al];
     const int run_cap = n1 + n2 + 2;
-    int16_t *rop = runs + 2 * (8 * arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;  // runs in REVERSE alignment order (8 * blocks >= n1 + 1)
+    int16_t *rop = runs + 2 * (TWB * arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;  // runs in REVERSE alignment order (TWB * blocks >= n1 + 1)
     int nr = 0, last_op = -1;
     auto push = [&](int op) {
         if (op == last_op) rcn[nr - 1]++;
@@ -1099,7 +1103,10 @@ struct nc_pipe_state {
     size_t al0_cap = 0;
     DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
     DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
-    DevBuf win, n1, tw, hlast, hcol, trace, cns, ncns, arow, tw2, runs, rlen, alen, alt_off, alt_pool, misc;
+    struct GroupBufs { DevBuf win, n1, tw, hlast, hcol, trace, cns, ncns, arow, alt_off; } gb[2];   // two sets: group g+1 is aligned while g is reduced
+    DevBuf tw2, runs, rlen, alen, alt_pool, misc;
+    hipStream_t sB = nullptr;                // second stream: traceback / tensors / alleles of group g beside the alignment fill of g + 1
+    hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, ev_join = nullptr;
     int64_t alt_pool_cap = 0;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t scoring[4] = {25, 1, 20, -10};         // star alignment: gap open, gap extend, match, mismatch (nc_indel_sites_scoring)
@@ -1113,14 +1120,20 @@ void nc_pipe_destroy(nc_ctx *ctx)
     if (!s) return;
     DevBuf *bufs[] = {&s->pc, &s->seg_pos, &s->seg_type, &s->cnt, &s->off, &s->anc_pos, &s->anc_type, &s->anc_chunk, &s->kept, &s->nuniq, &s->site_of,
                       &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
-                      &s->al_site, &s->al_member, &s->win, &s->n1, &s->tw, &s->hlast, &s->hcol, &s->trace, &s->cns, &s->ncns, &s->arow, &s->tw2,
-                      &s->runs, &s->rlen, &s->alen, &s->alt_off, &s->alt_pool, &s->misc};
+                      &s->al_site, &s->al_member, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc,
+                      &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
+                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].trace,
+                      &s->gb[1].cns, &s->gb[1].ncns, &s->gb[1].arow, &s->gb[1].alt_off};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
         b->cap = 0;
     }
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : s->evA) if (e) (void)hipEventDestroy(e);
+    for (auto &e : s->evB) if (e) (void)hipEventDestroy(e);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->sB) (void)hipStreamDestroy(s->sB);
     if (s->al0_pin) (void)hipHostFree(s->al0_pin);
     delete s;
     ctx->pipe = nullptr;
@@ -1130,21 +1143,22 @@ static int cpl_for(int n2) { return n2 <= 64 ? 4 : n2 <= 128 ? 8 : n2 <= 176 ? 1
 
 static bool packed_fill() { static const bool on = !getenv("NC_PIPE_FILL32"); return on; }
 
-static void launch_fill(nc_ctx *ctx, int CPL, const FillArgs &fa)
+static void launch_fill(nc_ctx *ctx, hipStream_t st, int CPL, const FillArgs &fa)
 {
+    (void)ctx;
     if (packed_fill()) {
         const dim3 gq((unsigned)((fa.A + 7) / 8));
-        if (CPL == 4) hipLaunchKernelGGL(k_fill16q<4>, gq, dim3(64), 0, ctx->stream, fa);
-        else if (CPL == 8) hipLaunchKernelGGL(k_fill16q<8>, gq, dim3(64), 0, ctx->stream, fa);
-        else if (CPL == 11) hipLaunchKernelGGL(k_fill16q<11>, gq, dim3(64), 0, ctx->stream, fa);
-        else hipLaunchKernelGGL(k_fill16q<17>, gq, dim3(64), 0, ctx->stream, fa);
+        if (CPL == 4) hipLaunchKernelGGL(k_fill16q<4>, gq, dim3(64), 0, st, fa);
+        else if (CPL == 8) hipLaunchKernelGGL(k_fill16q<8>, gq, dim3(64), 0, st, fa);
+        else if (CPL == 11) hipLaunchKernelGGL(k_fill16q<11>, gq, dim3(64), 0, st, fa);
+        else hipLaunchKernelGGL(k_fill16q<17>, gq, dim3(64), 0, st, fa);
         return;
     }
     const dim3 gr((unsigned)((fa.A + 3) / 4));
-    if (CPL == 4) hipLaunchKernelGGL(k_fill16p<4>, gr, dim3(64), 0, ctx->stream, fa);
-    else if (CPL == 8) hipLaunchKernelGGL(k_fill16p<8>, gr, dim3(64), 0, ctx->stream, fa);
-    else if (CPL == 11) hipLaunchKernelGGL(k_fill16p<11>, gr, dim3(64), 0, ctx->stream, fa);
-    else hipLaunchKernelGGL(k_fill16p<17>, gr, dim3(64), 0, ctx->stream, fa);
+    if (CPL == 4) hipLaunchKernelGGL(k_fill16p<4>, gr, dim3(64), 0, st, fa);
+    else if (CPL == 8) hipLaunchKernelGGL(k_fill16p<8>, gr, dim3(64), 0, st, fa);
+    else if (CPL == 11) hipLaunchKernelGGL(k_fill16p<11>, gr, dim3(64), 0, st, fa);
+    else hipLaunchKernelGGL(k_fill16p<17>, gr, dim3(64), 0, st, fa);
 }
 
 extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
@@ -1332,13 +1346,14 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     const bool timing = ctx->timing == 1;
     const int S = s->S, ns = s->n_sites;
     const int W = s->window_after + 2;                             // n2 <= window_after + 1; row pitch n2 + 1
+    const int EW = (W + 15) & ~15;
     const int WS = (s->window_after + 15) & ~15;
     const int N1 = WS;
     const int CPL = cpl_for(s->window_after + 1);
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
-    // groups of whole sites: traceback codes of a group's alignments <= 12 GiB
-    const int64_t tw_per_al = (int64_t)tw_blocks(N1) * 512 * NWP;   // blocks of 8 steps x 16 lanes x NWP words
-    int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)12 << 30) / tw_per_al);
+    // groups of whole sites: traceback codes of a group's alignments <= 6 GiB (two groups are in flight)
+    const int64_t tw_per_al = (int64_t)tw_blocks(N1) * 64 * TWB * NWP;   // blocks of TWB steps x 16 lanes x NWP words
+    int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)6 << 30) / tw_per_al);
     if (const char *g = getenv("NC_PIPE_GROUP_AL")) GROUP_AL = std::max<int64_t>(64, atoll(g));
     const int64_t GROUP_SITES = 65536;
     int32_t *err = (int32_t *)s->misc.p;
@@ -1350,26 +1365,52 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     NC_TRY(nc_ensure(ctx, s->rlen, (size_t)ns * S * 4));
     NC_TRY(nc_ensure(ctx, s->alen, (size_t)ns * S * 4));
     const int32_t *al0h = s->al0_pin;
-    int k0 = 0;
-    while (k0 < ns) {
+    std::vector<std::pair<int, int>> groups;
+    for (int k0 = 0; k0 < ns;) {
         int k1 = k0 + 1;
         while (k1 < ns && k1 - k0 < GROUP_SITES && (int64_t)al0h[k1 + 1] - al0h[k0] <= GROUP_AL) k1++;
+        groups.emplace_back(k0, k1);
+        k0 = k1;
+    }
+    const int G = (int)groups.size();
+    // Stream A (the context's): query windows + alignment fill (bound by vector issue).  Stream B: traceback, tensors, allele_prediction
+    // (bound by memory latency) of the previous group, beside it on the same CUs.  Stage timers (timing mode) need the stages one
+    // after the other: one stream then.
+    const bool two = !timing && G > 1 && !getenv("NC_PIPE_ONE_STREAM");
+    if (two && !s->sB) {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        // high priority: its latency-bound kernels take the wave slots the issue-bound fill leaves free as soon as they open
+        NC_HIP(ctx, hipStreamCreateWithPriority(&s->sB, hipStreamNonBlocking, getenv("NC_PIPE_B_PRIO_LOW") ? prio_lo : prio_hi));
+        for (auto &e : s->evA) NC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : s->evB) NC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        NC_HIP(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t sA = ctx->stream, sB = two ? s->sB : ctx->stream;
+    if (two) {                                                         // B starts behind the plan's kernels
+        NC_HIP(ctx, hipEventRecord(s->ev_join, sA));
+        NC_HIP(ctx, hipStreamWaitEvent(sB, s->ev_join, 0));
+    }
+    FillArgs fa_of[2];
+    auto stage_a = [&](int g) -> int {
+        const int b = g & 1, k0 = groups[(size_t)g].first, k1 = groups[(size_t)g].second;
+        nc_pipe_state::GroupBufs &B = s->gb[b];
         const int ng = k1 - k0;
         const int64_t A0 = al0h[k0];
         const int32_t Ag = al0h[k1] - al0h[k0];
         const size_t Agz = (size_t)std::max(Ag, 1);
-        NC_TRY(nc_ensure(ctx, s->win, Agz * WS + 64));
-        NC_TRY(nc_ensure(ctx, s->n1, Agz * 4));
-        NC_TRY(nc_ensure(ctx, s->tw, Agz * (size_t)tw_per_al + 64));
-        NC_TRY(nc_ensure(ctx, s->hlast, Agz * W * 4));
-        NC_TRY(nc_ensure(ctx, s->hcol, Agz * (N1 + 1) * 4));
-        const int EW = (W + 15) & ~15;
-        NC_TRY(nc_ensure(ctx, s->trace, Agz * EW * 4 + 64));
-        NC_TRY(nc_ensure(ctx, s->cns, (size_t)ng * S * CNS_CAP));
-        NC_TRY(nc_ensure(ctx, s->ncns, (size_t)ng * S * 4));
-        NC_TRY(nc_ensure(ctx, s->arow, ((size_t)ng * S + 1) * 8));
-        NC_TRY(nc_ensure(ctx, s->alt_off, (size_t)ng * S * 8));
-        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[0], ctx->stream));
+        NC_TRY(nc_ensure(ctx, B.win, Agz * WS + 64));
+        NC_TRY(nc_ensure(ctx, B.n1, Agz * 4));
+        NC_TRY(nc_ensure(ctx, B.tw, Agz * (size_t)tw_per_al + 64));
+        NC_TRY(nc_ensure(ctx, B.hlast, Agz * W * 4));
+        NC_TRY(nc_ensure(ctx, B.hcol, Agz * (N1 + 1) * 4));
+        NC_TRY(nc_ensure(ctx, B.trace, Agz * EW * 4 + 64));
+        NC_TRY(nc_ensure(ctx, B.cns, (size_t)ng * S * CNS_CAP));
+        NC_TRY(nc_ensure(ctx, B.ncns, (size_t)ng * S * 4));
+        NC_TRY(nc_ensure(ctx, B.arow, ((size_t)ng * S + 1) * 8));
+        NC_TRY(nc_ensure(ctx, B.alt_off, (size_t)ng * S * 8));
+        if (two && g >= 2) NC_HIP(ctx, hipStreamWaitEvent(sA, s->evB[b], 0));     // stream B is done with this buffer set (group g - 2)
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[0], sA));
         // ---- query windows
         WinArgs wa;
         wa.codes = s->pack.codes; wa.slot_off = s->rd.slot_off; wa.rd_start = s->rd.rd_start; wa.rd_end = s->rd.rd_end;
@@ -1377,78 +1418,98 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         wa.ins_bases = s->rd.ins_bases; wa.tail_bases = s->rd.tail_bases; wa.read_flag = s->rd.read_flag;
         wa.al_read = (const int32_t *)s->al_read.p + A0; wa.al_site = (const int32_t *)s->al_site.p + A0;
         wa.site_pos = (const int32_t *)s->site_pos.p; wa.site_n2 = (const int32_t *)s->site_n2.p;
-        wa.A = Ag; wa.W = s->window_after; wa.WS = WS; wa.win = (uint8_t *)s->win.p; wa.n1 = (int32_t *)s->n1.p; wa.cells = cells;
-        if (Ag > 0) hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, wa);
-        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], ctx->stream));
+        wa.A = Ag; wa.W = s->window_after; wa.WS = WS; wa.win = (uint8_t *)B.win.p; wa.n1 = (int32_t *)B.n1.p; wa.cells = cells;
+        if (Ag > 0) hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, sA, wa);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], sA));
         // ---- star alignment: every read window against its site's reference window (free tail)
-        FillArgs fa;
-        fa.s1 = (const uint8_t *)s->win.p; fa.s1_stride = WS; fa.n1 = (const int32_t *)s->n1.p;
+        FillArgs &fa = fa_of[b];
+        fa.s1 = (const uint8_t *)B.win.p; fa.s1_stride = WS; fa.n1 = (const int32_t *)B.n1.p;
         fa.ref_code = s->ref_code; fa.ref_pos0 = s->ref_pos0; fa.site_pos = (const int32_t *)s->site_pos.p; fa.site_n2 = (const int32_t *)s->site_n2.p;
         fa.al_site = (const int32_t *)s->al_site.p + A0; fa.site0 = 0; fa.site_div = 1;
         fa.A = Ag; fa.W = W;
         fa.open = s->scoring[0]; fa.extend = s->scoring[1]; fa.match = s->scoring[2]; fa.mismatch = s->scoring[3];
         fa.arow = nullptr; fa.N1 = N1;
-        fa.Tw = (uint32_t *)s->tw.p; fa.Hlast = (int32_t *)s->hlast.p; fa.hcol = (int32_t *)s->hcol.p;
-        if (Ag > 0) launch_fill(ctx, CPL, fa);
-        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[2], ctx->stream));
-        if (getenv("NC_PIPE_STOP_AFTER_FILL")) {                      // experiment: time the alignment fill alone (ablation builds write no traceback)
-            if (timing) {
-                NC_HIP(ctx, hipEventSynchronize(s->ev[2]));
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, s->ev[1], s->ev[2]);
-                s->stage_ms[2] += ms;
-            }
-            k0 = k1;
-            continue;
-        }
-        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, ctx->stream, fa, CPL, packed_fill() ? 1 : 0, (uint32_t *)s->trace.p, EW);
-        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], ctx->stream));
+        fa.Tw = (uint32_t *)B.tw.p; fa.Hlast = (int32_t *)B.hlast.p; fa.hcol = (int32_t *)B.hcol.p;
+        if (Ag > 0) launch_fill(ctx, sA, CPL, fa);
+        NC_HIP(ctx, hipGetLastError());
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[2], sA));
+        if (two) NC_HIP(ctx, hipEventRecord(s->evA[b], sA));
+        return NC_OK;
+    };
+    // traceback + tensors + the row count of the allele alignments (left in the mailbox)
+    auto stage_b1 = [&](int g) -> int {
+        const int b = g & 1, k0 = groups[(size_t)g].first, k1 = groups[(size_t)g].second;
+        nc_pipe_state::GroupBufs &B = s->gb[b];
+        const int ng = k1 - k0;
+        const int64_t A0 = al0h[k0];
+        const int32_t Ag = al0h[k1] - al0h[k0];
+        const FillArgs &fa = fa_of[b];
+        if (two) NC_HIP(ctx, hipStreamWaitEvent(sB, s->evA[b], 0));
+        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, sB, fa, CPL, packed_fill() ? 1 : 0, (uint32_t *)B.trace.p, EW);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], sB));
         // ---- columns, histogram, tensor, consensus
         TensorArgs ta;
         ta.site0 = k0; ta.n_sites_g = ng; ta.S = S; ta.haploid = s->haploid; ta.W = W; ta.WS = WS; ta.A0 = A0;
         ta.site_al0 = (const int32_t *)s->site_al0.p; ta.site_nr = (const int32_t *)s->site_nr.p; ta.site_pos = (const int32_t *)s->site_pos.p;
-        ta.site_n2 = (const int32_t *)s->site_n2.p; ta.al_member = (const uint8_t *)s->al_member.p; ta.win = (const uint8_t *)s->win.p;
-        ta.ent = (const uint32_t *)s->trace.p; ta.EW = EW; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
-        ta.cns = (uint8_t *)s->cns.p; ta.ncns = (int32_t *)s->ncns.p; ta.err = err;
-        hipLaunchKernelGGL(k_site_tensor, dim3(ng), dim3(256), 0, ctx->stream, ta);
-        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], ctx->stream));
-        // ---- allele_prediction: global alignment of every consensus against its window (parasail scoring 9 / 1 / 20 / -10, :79)
-        const int nset = ng * S;
+        ta.site_n2 = (const int32_t *)s->site_n2.p; ta.al_member = (const uint8_t *)s->al_member.p; ta.win = (const uint8_t *)B.win.p;
+        ta.ent = (const uint32_t *)B.trace.p; ta.EW = EW; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
+        ta.cns = (uint8_t *)B.cns.p; ta.ncns = (int32_t *)B.ncns.p; ta.err = err;
+        hipLaunchKernelGGL(k_site_tensor, dim3(ng), dim3(256), 0, sB, ta);
+        if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], sB));
         int32_t *mbox = (int32_t *)s->misc.p + 2;
-        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->ncns.p, nset, (int64_t *)s->arow.p, mbox);
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, sB, (const int32_t *)B.ncns.p, ng * S, (int64_t *)B.arow.p, mbox);
         NC_HIP(ctx, hipGetLastError());
-        volatile int32_t *mb = ctx->mbox + 36;
-        NC_TRY(nc_d2h(ctx, ctx->mbox + 36, mbox, 8, ctx->stream));
-        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
-        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 512 * NWP + 64));                         // `rows` counts blocks of 8 steps
-        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(8 * rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
-        FillArgs fb = fa;
-        fb.s1 = (const uint8_t *)s->cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)s->ncns.p;
+        NC_TRY(nc_d2h(ctx, ctx->mbox + 36, mbox, 8, sB));
+        return NC_OK;
+    };
+    // allele_prediction: global alignment of every consensus against its window (parasail scoring 9 / 1 / 20 / -10, :79)
+    auto stage_b2 = [&](int g, int64_t rows) -> int {
+        const int b = g & 1, k0 = groups[(size_t)g].first, k1 = groups[(size_t)g].second;
+        nc_pipe_state::GroupBufs &B = s->gb[b];
+        const int nset = (k1 - k0) * S;
+        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 64 * TWB * NWP + 64));                     // `rows` counts blocks of TWB steps
+        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(TWB * rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
+        FillArgs fb = fa_of[b];
+        fb.s1 = (const uint8_t *)B.cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)B.ncns.p;
         fb.al_site = nullptr; fb.site0 = k0; fb.site_div = S;
         fb.A = nset;
         fb.open = 9; fb.extend = 1; fb.match = 20; fb.mismatch = -10;
-        fb.arow = (const int64_t *)s->arow.p; fb.N1 = 0;
+        fb.arow = (const int64_t *)B.arow.p; fb.N1 = 0;
         fb.Tw = (uint32_t *)s->tw2.p; fb.Hlast = nullptr; fb.hcol = nullptr;
-        launch_fill(ctx, CPL, fb);
+        launch_fill(ctx, sB, CPL, fb);
         int32_t *rl = (int32_t *)s->rlen.p + (size_t)k0 * S, *al = (int32_t *)s->alen.p + (size_t)k0 * S;
-        hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, ctx->stream, fb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p, s->win_size,
-                           (int16_t *)s->runs.p, rl, al);
-        hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)al, nset, pool_base, (int64_t *)s->alt_off.p);
-        hipLaunchKernelGGL(k_alt_copy, dim3((nset + 3) / 4), dim3(256), 0, ctx->stream, (const uint8_t *)s->cns.p, (const int32_t *)al,
-                           (const int64_t *)s->alt_off.p, nset, (uint8_t *)s->alt_pool.p, s->alt_pool_cap, err);
+        hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, sB, fb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p,
+                           s->win_size, (int16_t *)s->runs.p, rl, al);
+        hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(1024), 0, sB, (const int32_t *)al, nset, pool_base, (int64_t *)B.alt_off.p);
+        hipLaunchKernelGGL(k_alt_copy, dim3((nset + 3) / 4), dim3(256), 0, sB, (const uint8_t *)B.cns.p, (const int32_t *)al,
+                           (const int64_t *)B.alt_off.p, nset, (uint8_t *)s->alt_pool.p, s->alt_pool_cap, err);
         NC_HIP(ctx, hipGetLastError());
+        if (two) NC_HIP(ctx, hipEventRecord(s->evB[b], sB));
         if (timing) {
-            NC_HIP(ctx, hipEventRecord(s->ev[5], ctx->stream));
+            NC_HIP(ctx, hipEventRecord(s->ev[5], sB));
             NC_HIP(ctx, hipEventSynchronize(s->ev[5]));
             for (int st = 0; st < 5; st++) {
                 float ms = 0;
                 (void)hipEventElapsedTime(&ms, s->ev[st], s->ev[st + 1]);
                 s->stage_ms[st + 1] += ms;
             }
-            s->cells[1] += 8 * rows * (int64_t)(s->window_after + 1);                  // (upper estimate: blocks of 8 rows)
+            s->cells[1] += TWB * rows * (int64_t)(s->window_after + 1);               // (upper estimate: whole blocks)
         }
-        k0 = k1;
+        return NC_OK;
+    };
+    NC_TRY(stage_a(0));
+    for (int g = 0; g < G; g++) {
+        if (!timing && g + 1 < G) NC_TRY(stage_a(g + 1));            // the next group's alignments are enqueued before the host waits for this one's row count
+        NC_TRY(stage_b1(g));
+        volatile int32_t *mb = ctx->mbox + 36;
+        NC_HIP(ctx, hipStreamSynchronize(sB));
+        const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
+        NC_TRY(stage_b2(g, rows));
+        if (timing && g + 1 < G) NC_TRY(stage_a(g + 1));
+    }
+    if (two) {                                                         // the caller's stream continues behind stream B
+        NC_HIP(ctx, hipEventRecord(s->ev_join, sB));
+        NC_HIP(ctx, hipStreamWaitEvent(sA, s->ev_join, 0));
     }
     return NC_OK;
 }
