@@ -199,6 +199,11 @@ def measure(eng, uploader, contigs, units, warm, params, chunks, local, barrier,
     return total, time.perf_counter() - t0, r
 
 
+def _lib_kind(ploidy):
+    from nanocaller_amd import _lib
+    return _lib.MODEL_SNP if ploidy == "diploid" else _lib.MODEL_SNP_HAP
+
+
 def snp_params(model, tech):
     return dict(mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6], snp_model=model,
                 seq="ont" if tech == "ont" else "pacbio", supplementary=False, exclude_bed=None,
@@ -677,6 +682,9 @@ def main():
                               "note": "rank 0, per GPU; with_h2d_d2h = the timed region (= value at N=1); hbm_resident = the same passes over a pack "
                                       "already in HBM (round 1's headline); pipelined = + VCF text of pass i formatted on a host thread while the "
                                       "GPU runs pass i+1 (snpCaller.caller), uploads included"},
+            "range_guard": {"x_limit": eng.x_limit(_lib_kind(args.ploidy)), "sites_rerun_on_exact_trunk": int(r.get("range_reruns", 0)) if r else None,
+                            "note": "fp16x3 trunk: sites whose scaled tensor exceeds the model's proven-safe input bound are re-run on the exact fp32 trunk "
+                                    "(nc_cnn_range_watch); 0 = every result of the timed region is proven inside the fp16 range"},
             "stages": {"expand_ms": expand_ms, "scan_ms": float(stage_ms[0]), "scan_GBs": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 if stage_ms[0] else 0,
                        "scan_frac_hbm": scan_bytes / (stage_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[0] else 0,
                        "featurize_ms": float(stage_ms[1]),

@@ -28,7 +28,7 @@ extern "C" {
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
-                                 nc_decoded_check, NC_ERR_RANGE + nc_cnn_range_hits, nc_synth_indel_* */
+                                 nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_* */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -40,8 +40,7 @@ enum nc_status {
     NC_ERR_HIP = -4,       /* HIP runtime error (message in nc_last_error) */
     NC_ERR_STATE = -5,     /* call order violated (e.g. featurize before scan, weights not loaded) */
     NC_ERR_SELFTEST = -6,  /* device self-test failed at context creation */
-    NC_ERR_UNSUPPORTED = -7, /* input the library does not reproduce (reference skips, same-name reads in one column): nc_decoded_check */
-    NC_ERR_RANGE = -8      /* an activation left the range of the split-precision CNN kernels (nc_cnn_range_hits) */
+    NC_ERR_UNSUPPORTED = -7 /* input the library does not reproduce (reference skips, same-name reads in one column): nc_decoded_check */
 };
 
 enum nc_model_kind { NC_MODEL_SNP = 0, NC_MODEL_SNP_HAP = 1, NC_MODEL_INDEL = 2, NC_MODEL_INDEL_HAP = 3 };
@@ -260,6 +259,17 @@ int nc_snp_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_de
 int nc_snp_forward_drain(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, const int32_t *ref_code_dev,
                          const double *scale_dev, int32_t scale_mode, float *probs_dev, float *gt_dev,
                          void *copy_stream, float *probs_host, float *gt_host);
+/* Range guard of the split-precision kernels.  Their epilogues clamp activations to the fp16 range (6e4); a clamp that fired
+ * would be a wrong probability.  nc_load_weights derives, from the L1 norms of the three convolutions and |selu(v)| <= lambda |v|,
+ * x_limit = the largest |input value| (after the coverage scaling) for which NO activation of that model can reach the clamp
+ * (ONT-HG002: 171; a 30x site scaled by 48/30 has |x| <= 48).  nc_cnn_range_watch(ctx, flags): the following nc_snp_forward[_drain]
+ * calls on the split-precision trunk set flags[s] = 1 (dev, one byte per site of the call, zeroed by the caller) for every site
+ * whose scaled tensor exceeds x_limit; the caller re-runs exactly those sites with nc_set_cnn_precision(ctx, 1) (what
+ * nanocaller_amd.snpCaller.call_chunks does), so a result is either proven in range or computed by the exact fp32 trunk.  NULL
+ * stops watching.  The indel CNN's inputs are msa() frequencies (|x| <= 1): a model with x_limit < 1 (none of the shipped ones)
+ * runs on the exact fp32 kernels. */
+int nc_cnn_x_limit(nc_ctx *ctx, int32_t model_kind, float *x_limit);
+int nc_cnn_range_watch(nc_ctx *ctx, uint8_t *site_flags_dev);
 /* Indel CNN (model_architect_indel.py:28-48 rows=15 -> [n][4]; haploid rows=5 -> [n][1] sigmoid). */
 int nc_indel_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, float *probs_dev);
 

@@ -880,7 +880,8 @@ __device__ unsigned long long nc_trace_buf[8][8][8];     // [wave][site k in 8..
 #endif
 template <bool X16>                                             // X16: the site tensors are int16 (nc_set_tensor_format(ctx, 1))
 __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
-                                                   int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0)
+                                                   int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0, float x_limit,
+                                                   uint8_t *__restrict__ range_sites)
 {
     // [buffer][plane]: the second plane of a buffer sits at a constant distance (< 64 KB) from the first, so one address
     // VGPR + the DS instruction's immediate offset serves both
@@ -915,7 +916,9 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         float pre[5];
         uint32_t raw[3];
         double pre_sd = 1.0;
+        int64_t pre_site = 0;
         auto prefetch = [&](int64_t site) {
+            pre_site = site;
             if constexpr (X16) {
                 const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;       // 2-byte aligned
                 typedef uint32_t __attribute__((aligned(2))) u32_a2;
@@ -946,6 +949,10 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
 #pragma unroll
                     for (int u = 0; u < 4; u++) pre[u] = (float)((double)pre[u] * md);
                 }
+                // range guard: the epilogues clamp activations to the fp16 range; below x_limit the weights' L1 norms prove that none gets
+                // there (nc_load_weights), above it the site is flagged and the caller re-runs it on the exact fp32 trunk
+                const float amax = fmaxf(fmaxf(fmaxf(fabsf(pre[0]), fabsf(pre[1])), fmaxf(fabsf(pre[2]), fabsf(pre[3]))), fabsf(pre[4]));
+                if (range_sites && !(amax <= x_limit)) range_sites[site0 + pre_site] = 1;
                 _Float16 hi[5], lo[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) {
@@ -1520,7 +1527,7 @@ inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + pe
 // conv trunk for `nb` sites -> fc1 activations [nb][F]; *f1_out / *tail receive the fc1 buffer and the tail weights
 template <int H, int W, int CI, int C1, int C2, int C3, int F, int P2, int P3, bool MFMA>
 int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *packed_h, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
-              const float **f1_out, const float **tail)
+              const float **f1_out, const float **tail, float x_limit = 0.0f)
 {
     constexpr int H2 = H - 1, W2 = (W - 3) / 2 + 1, H3 = H2 - 1, W3 = (W2 - 3) / 2 + 1;
     constexpr int64_t n1 = (int64_t)H * W * 3 * C1, n2 = (int64_t)H2 * W2 * C2, n3 = (int64_t)H3 * W3 * C3;
@@ -1570,9 +1577,9 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
             hipExtLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, ev0, ev1, 0, x_batch, packed, a3, nb, scale, scale_mode, site0);
         else
             if (ctx->x_i16)
-                hipExtLaunchKernelGGL(k5_trunk_h3<true>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
+                hipExtLaunchKernelGGL(k5_trunk_h3<true>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
             else
-                hipExtLaunchKernelGGL(k5_trunk_h3<false>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0);
+                hipExtLaunchKernelGGL(k5_trunk_h3<false>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
         if (ctx->cnn_exact_fp32)
             hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
         else
@@ -1619,6 +1626,41 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
     NC_HIP(ctx, hipMemcpyAsync(w.dev, blob_host, n_floats * 4, hipMemcpyHostToDevice, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     w.n = n_floats;
+    {
+        // Range guard of the split-precision kernels: their epilogues clamp activations at 6e4 (fp16).  With L_l = the largest L1 norm of
+        // an output channel's weights and |selu(v)| <= max(lambda |v|, lambda alpha), an input bounded by X bounds every activation:
+        //   a_l = max(lambda (L_l a_{l-1} + max|b_l|), lambda alpha),  a_0 = X;    x_limit = the largest X with max a_l < 6e4.
+        const bool snp = kind == NC_MODEL_SNP || kind == NC_MODEL_SNP_HAP;
+        const int CI = snp ? 5 : 2, C1 = snp ? 16 : 8, C2 = 32, C3 = snp ? 64 : 48;
+        auto l1 = [](const float *k, int n_in, int cout) {
+            double best = 0;
+            for (int c = 0; c < cout; c++) {
+                double acc = 0;
+                for (int i = 0; i < n_in; i++) acc += std::fabs((double)k[(size_t)i * cout + c]);
+                best = std::max(best, acc);
+            }
+            return best;
+        };
+        auto amax = [](const float *b, int n) { double m = 0; for (int i = 0; i < n; i++) m = std::max(m, std::fabs((double)b[i])); return m; };
+        const float *k11 = blob_host, *b11 = k11 + 5 * CI * C1, *k12 = b11 + C1, *b12 = k12 + 5 * CI * C1, *k13 = b12 + C1, *b13 = k13 + 25 * CI * C1;
+        const float *k2 = b13 + C1, *b2 = k2 + 6 * 3 * C1 * C2, *k3 = b2 + C2, *b3 = k3 + 6 * C2 * C3;
+        const double L1 = std::max(l1(k11, 5 * CI, C1), std::max(l1(k12, 5 * CI, C1), l1(k13, 25 * CI, C1)));
+        const double B1 = std::max(amax(b11, C1), std::max(amax(b12, C1), amax(b13, C1)));
+        const double L2 = l1(k2, 6 * 3 * C1, C2), B2 = amax(b2, C2), L3 = l1(k3, 6 * C2, C3), B3 = amax(b3, C3);
+        const double LAM = 1.0507009873554805, LA = LAM * 1.6732632423543772, CAP = 60000.0 * 0.999;
+        auto worst = [&](double X) {
+            const double a1 = std::max(LAM * (L1 * X + B1), LA), a2 = std::max(LAM * (L2 * a1 + B2), LA), a3 = std::max(LAM * (L3 * a2 + B3), LA);
+            // the indel kernels clamp conv1's and conv2's outputs only (conv3 leaves k8_conv23_h3 as fp32)
+            return snp ? std::max(a1, std::max(a2, a3)) : std::max(a1, a2);
+        };
+        double lo = 0.0, hi = 1e6;
+        if (worst(0.0) >= CAP) hi = 0.0;
+        for (int it = 0; it < 60 && hi > 0.0; it++) {
+            const double mid = 0.5 * (lo + hi);
+            if (worst(mid) < CAP) lo = mid; else hi = mid;
+        }
+        w.x_limit = (float)lo;
+    }
     if (kind == NC_MODEL_SNP || kind == NC_MODEL_SNP_HAP) {
         // B fragments of the fused conv1+conv2 kernel, in (step, lane) order
         std::vector<float> pk((size_t)F12_PACKED, 0.0f);
@@ -1802,7 +1844,7 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
         NC_TRY((run_trunk<5, 41, 5, 16, 32, 64, 48, 2, 1, true>(ctx, ctx->w[kind].dev, ctx->w[kind].packed, (const uint8_t *)ctx->w[kind].packed_h, s0, nb, ctx->x_i16 ? (const float *)((const int16_t *)x_dev + s0 * NC_SNP_TENSOR) : x_dev + s0 * NC_SNP_TENSOR, scale_dev, scale_mode,
-                                                          &f1, &tail)));
+                                                          &f1, &tail, ctx->w[kind].x_limit)));
         if (kind == NC_MODEL_SNP)
             hipLaunchKernelGGL(k_snp_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, ref_code_dev + s0, nb,
                                probs_dev + s0 * 4, gt_dev ? gt_dev + s0 * 2 : nullptr);
@@ -1825,6 +1867,21 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_de
     return NC_OK;
 }
 
+int nc_cnn_x_limit(nc_ctx *ctx, int32_t kind, float *x_limit)
+{
+    if (!ctx || kind < 0 || kind > 3 || !x_limit) return NC_ERR_ARG;
+    if (!ctx->w[kind].dev) return nc_fail(ctx, NC_ERR_STATE, "nc_cnn_x_limit: weights of kind %d not loaded", kind);
+    *x_limit = ctx->w[kind].x_limit;
+    return NC_OK;
+}
+
+int nc_cnn_range_watch(nc_ctx *ctx, uint8_t *site_flags_dev)
+{
+    if (!ctx) return NC_ERR_ARG;
+    ctx->range_sites = site_flags_dev;
+    return NC_OK;
+}
+
 int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, float *probs_dev)
 {
     if (!ctx) return NC_ERR_ARG;
@@ -1839,10 +1896,13 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
+        // msa() tensors are frequencies: |x| <= 1.  A model whose L1 norms do not prove the fp16 range safe for such inputs (x_limit < 1;
+        // none of the shipped ones) runs on the exact fp32 kernels instead
+        const uint8_t *ph = ctx->w[kind].x_limit >= 1.0f ? (const uint8_t *)ctx->w[kind].packed_h : nullptr;
         if (kind == NC_MODEL_INDEL)
-            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, (const uint8_t *)ctx->w[kind].packed_h, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+            NC_TRY((run_trunk<15, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, ph, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         else
-            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, (const uint8_t *)ctx->w[kind].packed_h, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
+            NC_TRY((run_trunk<5, 128, 2, 8, 32, 48, 32, 2, 1, false>(ctx, ctx->w[kind].dev, nullptr, ph, s0, nb, x_dev + s0 * xs, nullptr, 0, &f1, &tail)));
         hipLaunchKernelGGL(k_indel_heads, dim3(blocks_for(nb)), dim3(256), 0, ctx->stream, f1, tail, nout, nb, probs_dev + s0 * nout);
         NC_HIP(ctx, hipGetLastError());
     }

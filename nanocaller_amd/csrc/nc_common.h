@@ -20,6 +20,7 @@ struct nc_weights {
     float *packed = nullptr;   // kernel-specific repack (see nc_cnn.hip)
     size_t n_packed = 0;
     void *packed_h = nullptr;  // fp16x3 fragments of the trunk kernel
+    float x_limit = 0.0f;      // largest |input value| for which the L1 norms of conv1-3 prove that no activation reaches the fp16 clamp
 };
 
 struct nc_ctx {
@@ -62,7 +63,8 @@ struct nc_ctx {
 
     nc_weights w[4];
     struct nc_pipe_state *pipe = nullptr;   // device-resident indel pipeline (nc_pipe.hip): plan state, workspaces, results
-    uint32_t *range_flag = nullptr;         // device word: split-precision CNN epilogues OR a bit in when a value met the f16 clamp
+    uint8_t *range_sites = nullptr;         // nc_cnn_range_watch: device byte per site of the next nc_snp_forward, set when the site's
+                                            // scaled tensor exceeds the model's x_limit (the caller re-runs those sites on the exact trunk)
 
     // The small transfers the host waits for in the middle of a step go through kernels that read / write page-locked host
     // memory directly, NOT through hipMemcpyAsync: on this platform every hipMemcpyAsync of either direction queues in order

@@ -259,10 +259,56 @@ class Engine:
         return scale, cd[:int(n_chunks)]
 
     # ------------------------------------------------------------------ K5 / K9
-    def snp_forward(self, kind, x, ref_code, scale, scale_mode=0, want_gt=True, drain=False):
-        """-> (probs, gt) device tensors; with drain=True also (probs_host, gt_host) numpy arrays in pinned memory that
-        the copy stream fills batch by batch while the next batch computes (wait_copies() before reading them)."""
+    def x_limit(self, kind) -> float:
+        """largest |scaled input value| for which the loaded model's weights prove that the split-precision trunk stays inside the
+        fp16 range (nc_cnn_x_limit)"""
+        v = C.c_float()
+        self._check(self.L.nc_cnn_x_limit(self.ctx, kind, C.byref(v)), "nc_cnn_x_limit")
+        return float(v.value)
+
+    def snp_forward_guarded(self, kind, x, ref_code, scale, scale_mode=0):
+        """snp_forward on the split-precision trunk with its range guard closed: sites whose scaled tensor exceeds x_limit are re-run
+        on the exact fp32 trunk.  -> (probs, gt, number of re-run sites); synchronous (tests, small batches; call_chunks does the same
+        asynchronously)."""
         n = int(x.shape[0])
+        flags = torch.zeros(max(n, 1), dtype=torch.uint8, device=self.device)
+        probs, gt = self.snp_forward(kind, x, ref_code, scale, scale_mode, range_flags=flags)
+        idx = torch.nonzero(flags[:n]).squeeze(1)
+        if idx.numel():
+            self.range_rerun(kind, x, ref_code, scale, scale_mode, idx, probs, gt)
+        return probs, gt, int(idx.numel())
+
+    def range_rerun(self, kind, x, ref_code, scale, scale_mode, idx, probs, gt):
+        """the sites `idx` (device int64) once more on the exact fp32 MFMA trunk; their rows of probs / gt (device tensors) are replaced"""
+        was_exact, was_i16 = getattr(self, "exact_fp32", False), getattr(self, "x_int16", False)
+        xs = x[idx].to(torch.float32).contiguous()                   # the exact trunk reads the reference's float32 layout
+        self.set_tensor_format(int16=False)
+        self.set_cnn_precision(exact_fp32=True)
+        try:
+            p2, g2 = self.snp_forward(kind, xs, ref_code[idx].contiguous(), scale[idx].contiguous() if scale is not None else None, scale_mode,
+                                      want_gt=gt is not None)
+        finally:
+            self.set_cnn_precision(exact_fp32=was_exact)
+            self.set_tensor_format(int16=was_i16)
+        probs[idx] = p2
+        if gt is not None and g2 is not None:
+            gt[idx] = g2
+
+    def snp_forward(self, kind, x, ref_code, scale, scale_mode=0, want_gt=True, drain=False, range_flags=None):
+        """-> (probs, gt) device tensors; with drain=True also (probs_host, gt_host) numpy arrays in pinned memory that
+        the copy stream fills batch by batch while the next batch computes (wait_copies() before reading them).
+        range_flags (uint8 device tensor [n], zeroed): the split-precision trunk marks the sites whose scaled tensor exceeds the
+        model's x_limit (nc_cnn_range_watch)."""
+        n = int(x.shape[0])
+        if range_flags is not None:
+            self._check(self.L.nc_cnn_range_watch(self.ctx, C.c_void_p(range_flags.data_ptr())), "nc_cnn_range_watch")
+        try:
+            return self._snp_forward(kind, x, ref_code, scale, scale_mode, want_gt, drain, n)
+        finally:
+            if range_flags is not None:
+                self.L.nc_cnn_range_watch(self.ctx, None)
+
+    def _snp_forward(self, kind, x, ref_code, scale, scale_mode, want_gt, drain, n):
         probs = torch.empty((n, 4), dtype=torch.float32, device=self.device)
         gt = torch.empty((n, 2), dtype=torch.float32, device=self.device) if (want_gt and kind == _lib.MODEL_SNP) else None
         if not drain:

@@ -19,6 +19,7 @@ import sys
 import zlib
 
 import numpy as np
+import torch
 
 from . import _lib
 from .engine import get_engine
@@ -234,7 +235,13 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     scan_copied = eng.copy_event()                                 # candidate arrays + chunk depths are on the host behind this
     # enqueued after the (short, latency-sensitive) scale kernel so that these copies run under the CNN, not beside it
     h_ref, h_fwd, h_rev, h_valid = eng.to_host_async([sites.ref_code, sites.fwd_dp, sites.rev_dp, None if all_valid else sites.valid])
-    d_probs, d_gt, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True)
+    # range guard of the split-precision trunk (nc_cnn_range_watch): sites whose scaled tensor exceeds what the model's weights prove
+    # safe for the fp16 range are marked and, in finish(), computed once more by the exact fp32 trunk
+    guard = not getattr(eng, "exact_fp32", False)
+    flags = torch.zeros(sites.n_sites, dtype=torch.uint8, device=eng.device) if guard else None
+    d_probs, d_gt, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True,
+                                                   range_flags=flags)
+    h_nflag = eng.to_host_async([flags.sum(dtype=torch.int32).reshape(1)])[0] if guard else None
     eng.set_tensor_format(int16=False)                             # the direct API keeps the reference's float32 default
     drained = eng.copy_event()                                     # completes with this call's last result copy
     # host work that only needs the scan results runs under the CNN: freq = alt / n in float64 (:166)
@@ -245,6 +252,16 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     def finish():
         nonlocal keep_alive
         drained.synchronize()
+        n_rerun = int(h_nflag[0]) if h_nflag is not None else 0
+        if n_rerun:
+            idx = torch.nonzero(flags).squeeze(1)
+            eng.use_torch_stream()
+            eng.range_rerun(kind, sites.x, sites.ref_code, scale, 1 if per_site else 0, idx, d_probs, d_gt)
+            ih = idx.cpu().numpy()
+            h_probs[ih] = d_probs[idx].cpu().numpy()
+            if h_gt is not None and d_gt is not None:
+                h_gt[ih] = d_gt[idx].cpu().numpy()
+        res['range_reruns'] = n_rerun
         keep_alive = None
         out = dict(pos=sites.pos, chunk=sites.chunk, ref=h_ref, probs=h_probs, gt=h_gt, dp=sites.dp, alt=sites.alt,
                    fwd_dp=h_fwd, rev_dp=h_rev, freq=freq)
