@@ -77,7 +77,10 @@ def release_contig(chrom=None):
     _PACKS.drop(lambda k: chrom is None or k[2] == chrom)
 
 
-def _resolve(sam_path, chrom=None, fasta_path=None) -> World:
+DECODES = []                  # (bam, contig, span or None) of every BAM decode of this process (tests: no contig is decoded twice)
+
+
+def _resolve(sam_path, chrom=None, fasta_path=None, span=None) -> World:
     if isinstance(sam_path, World):
         return sam_path
     if sam_path in _SOURCES:
@@ -86,7 +89,13 @@ def _resolve(sam_path, chrom=None, fasta_path=None) -> World:
         if chrom is None or not fasta_path:
             raise ValueError("decoding %r needs the contig name and dct['fasta_path']" % sam_path)
         from .bam import read_bam
-        return _BAM_WORLDS.get((sam_path, fasta_path, chrom), lambda: read_bam(sam_path, fasta_path, chrom))
+
+        def make():
+            DECODES.append((sam_path, chrom, span))
+            w = read_bam(sam_path, fasta_path, chrom) if span is None else read_bam(sam_path, fasta_path, chrom, span[0], span[1])
+            _check_supported(w, sam_path, chrom)
+            return w
+        return _BAM_WORLDS.get((sam_path, fasta_path, chrom) + ((span,) if span else ()), make)
     raise FileNotFoundError("alignments %r: not a BAM file, a World, or a registered key" % (sam_path,))
 
 
@@ -115,26 +124,58 @@ def _exclude_rows(dct, chrom):
     return tuple(rows)
 
 
-def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, device=0):
+def _check_supported(world, sam_path, chrom):
+    """inputs the library does not reproduce are refused, not silently accepted: reference skips in the CIGAR of a read
+    the pileup keeps (the reference raises KeyError on their pileup symbols, quirk E10)"""
+    keep = (world.read_flag & 0x704) == 0                          # unmapped / secondary / qcfail / duplicate are never kept
+    n = int(np.count_nonzero(keep & ((world.read_flag & _lib.FLAG_REFSKIP) != 0)))
+    if n:
+        err = _lib.NanoCallerHipError("%s, contig %s: %d alignments with a reference skip (CIGAR N) would enter the pileup; the reference's "
+                                      "code table has no entry for their '>' / '<' symbols (generate_SNP_pileups.py:104) -- NC_ERR_UNSUPPORTED"
+                                      % (sam_path, chrom, n))
+        err.status = _lib.NC_ERR_UNSUPPORTED
+        raise err
+
+
+def contig_span(sam_path, chrom, chunks):
+    """the part of a contig a rank has to decode for `chunks` (all of one contig): None = the whole contig, else (lo, hi) = the
+    chunks' extent +- the 50 kb scan flank (generate_SNP_pileups.py:137,156) when that is less than 90 % of the contig (a contig
+    split over several ranks, shard.shard_plan)"""
+    if not (isinstance(sam_path, str) and os.path.exists(sam_path)):
+        return None
+    from .bam import BamFile
+    bf = BamFile(sam_path)
+    try:
+        length = bf.get_reference_length(chrom)
+    finally:
+        bf.close()
+    lo = max(1, min(c['start'] for c in chunks) - _lib.FLANK)
+    hi = min(length, max(c['end'] for c in chunks) + _lib.FLANK)
+    return None if (hi - lo + 1) >= 0.9 * length else (lo, hi)
+
+
+def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, device=0, span=None):
     """Packed + uploaded alignments of ONE contig -> (DevicePack, World).  The key carries the contig (one BAM holds many),
-    the FASTA, the flag filter, the exclusion list and the device; the SNP and the indel path share the entry."""
-    world = _resolve(sam_path, chrom, fasta_path)
+    the FASTA, the flag filter, the exclusion list and the device; the SNP and the indel path share the entry.
+    span (lo, hi): only the alignments overlapping it are decoded and packed (a rank that owns part of a contig)."""
+    world = _resolve(sam_path, chrom, fasta_path, span)
     if world.chrom != chrom:
         raise ValueError("alignments of contig %r requested, the source holds %r" % (chrom, world.chrom))
     src = id(world) if isinstance(sam_path, World) else sam_path
-    key = (src, fasta_path, chrom, bool(supplementary), excl, device)
+    key = (src, fasta_path, chrom, bool(supplementary), excl, device) + ((span,) if span else ())
 
     def make():
         # the contig crosses PCIe in the reference-difference wire form (~0.2 B instead of 1 B per pileup entry) and is
         # expanded to the position-addressed codes in HBM (wire.py, nc_wire_expand)
         from .wire import build_wire_from_world, upload_wire
-        return (upload_wire(get_engine(device), build_wire_from_world(world, supplementary=bool(supplementary), exclude=excl)), world)
+        kw = dict(pos_lo=span[0], pos_hi=span[1]) if span else {}
+        return (upload_wire(get_engine(device), build_wire_from_world(world, supplementary=bool(supplementary), exclude=excl, **kw)), world)
     return _PACKS.get(key, make)
 
 
-def device_pack_for(dct, chrom, device=0):
-    """Packed + uploaded alignments of contig `chrom` of dct['sam_path'] (cached per source / contig / filter / exclusions)."""
-    return device_pack(dct["sam_path"], dct.get("fasta_path"), chrom, dct.get("supplementary"), _exclude_rows(dct, chrom), device)[0]
+def device_pack_for(dct, chrom, device=0, span=None):
+    """Packed + uploaded alignments of contig `chrom` of dct['sam_path'] (cached per source / contig / filter / exclusions / span)."""
+    return device_pack(dct["sam_path"], dct.get("fasta_path"), chrom, dct.get("supplementary"), _exclude_rows(dct, chrom), device, span)[0]
 
 
 def get_snp_testing_candidates(dct, region, device=0):

@@ -17,21 +17,44 @@ def chunk_weight(c):
     return c['end'] - c['start'] + 1 + 100_000
 
 
-def shard_chunks(chunks, rank, world):
-    """Contiguous block partition balanced by scanned columns.  Chunk boundaries are never moved (they define the
-    coverage constant E2 and the duplicated boundary record E3)."""
+def shard_plan(chunks, world, snap=0.10):
+    """-> list (per rank) of chunk lists: CONTIGUOUS blocks of the chunk list balanced by scanned columns, with every cut that lies
+    within `snap` x (a rank's share) of a contig boundary moved onto it.  A rank decodes and uploads only what its chunks need
+    (snpCaller.call_chunks: whole contigs, or -- for the at most two contigs a block shares with its neighbours -- the span of its
+    chunks +- the 50 kb scan flank), so no part of a contig is decoded by two ranks beyond that flank.  Chunk boundaries are never
+    moved (they define the coverage constant E2 and the duplicated boundary record E3)."""
+    chunks = list(chunks)
     if world <= 1:
-        return list(chunks)
+        return [chunks]
     w = [chunk_weight(c) for c in chunks]
-    total = float(sum(w))
-    out, acc, r = [[] for _ in range(world)], 0.0, 0
-    for c, wi in zip(chunks, w):
-        # advance to the rank whose [r, r+1) * total/world band contains this chunk's midpoint
-        mid = acc + wi / 2.0
-        r = min(world - 1, int(mid * world / total))
-        out[r].append(c)
-        acc += wi
-    return out[rank]
+    total = float(sum(w)) or 1.0
+    share = total / world
+    pre = [0.0]
+    for wi in w:
+        pre.append(pre[-1] + wi)
+    # first chunk of every block: the chunk whose midpoint crosses k * share
+    cuts = []
+    for k in range(1, world):
+        i = 0
+        while i < len(chunks) and pre[i] + w[i] / 2.0 < k * share:
+            i += 1
+        cuts.append(i)
+    bounds = [i for i in range(1, len(chunks)) if chunks[i]['chrom'] != chunks[i - 1]['chrom']]
+    out_cuts = []
+    for i in cuts:
+        best = i
+        near = [b for b in bounds if abs(pre[b] - pre[i]) <= snap * share]
+        if near:
+            best = min(near, key=lambda b: abs(pre[b] - pre[i]))
+        out_cuts.append(best)
+    out_cuts = sorted(out_cuts)
+    edges = [0] + out_cuts + [len(chunks)]
+    return [chunks[edges[r]:edges[r + 1]] for r in range(world)]
+
+
+def shard_chunks(chunks, rank, world):
+    """this rank's chunks of shard_plan()"""
+    return shard_plan(chunks, world)[rank] if world > 1 else list(chunks)
 
 
 def shard_range(n_items, rank, world):

@@ -215,7 +215,9 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
         kind = _lib.MODEL_SNP_HAP
     eng.load_weights(kind, _weights(path))
     if dpk is None:
-        dpk = device_pack_for(params, chrom, device)
+        # a rank that owns only part of a contig (shard.shard_plan) decodes and uploads only its span +- the scan flank
+        from .generate_SNP_pileups import contig_span
+        dpk = device_pack_for(params, chrom, device, span=contig_span(params['sam_path'], chrom, chunks))
     # Results drain on a second stream while the GPU keeps computing: the candidate arrays right after the scan, the
     # featuriser's per-site arrays during the CNN, and every CNN batch's probabilities while the next batch runs.
     sites = eng.snp_scan(dpk, [(c['start'], c['end']) for c in chunks], mincov=params['mincov'],

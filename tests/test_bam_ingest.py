@@ -92,7 +92,8 @@ def test_cigar_edge_cases(tmp_path):
     #      A C G T | G G | D D | C A T | N N N N | A C | G      (codes A0 G1 T2 C3, del/skip 4)
     assert c0 == [0, 3, 1, 2, 1, 1, 4, 4, 3, 0, 2, 4, 4, 4, 4, 0, 3, 1]
     assert d["ev_pos"][d["ev_off"][0]:d["ev_off"][1]].tolist() == [103, 105] and d["ev_len"][:2].tolist() == [3, -2]
-    assert d["hap"].tolist() == [2, 0] and d["ps"].tolist() == [70000, 0] and d["read_flag"].tolist() == [16, 0x800]
+    assert d["hap"].tolist() == [2, 0] and d["ps"].tolist() == [70000, 0]
+    assert d["read_flag"].tolist() == [16 | 0x10000, 0x800]                    # bit 16 (NC_FLAG_REFSKIP): the CIGAR holds a reference skip
     assert d["ev_off"].tolist() == [0, 2, 2]                # a leading insertion has no previous column: no marker
     assert d["codes"][d["read_off"][1]:].tolist() == [0, 3, 1, 2, 4] and d["names"] == ["a", "b"]
 

@@ -23,6 +23,32 @@ def test_shards_partition_the_chunk_list():
             assert max(sizes) < 1.25 * (sum(sizes) / world)         # balanced
 
 
+def test_shard_cuts_snap_to_contig_boundaries_and_split_contigs_are_decoded_by_span():
+    """a 24-contig genome over 8 ranks: blocks stay contiguous and balanced, cuts near a contig boundary sit ON it, and a contig shared
+    by two ranks is decoded by each only over its own span +- the scan flank (generate_SNP_pileups.contig_span)"""
+    from nanocaller_amd.shard import chunk_weight, shard_plan
+    lens = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57]
+    chunks = get_chunks([("chr%d" % (k + 1), 1, L * 1_000_000, "diploid") for k, L in enumerate(lens)], cpu=16)
+    plan = shard_plan(chunks, 8)
+    assert [c for p in plan for c in p] == chunks
+    wts = [sum(chunk_weight(c) for c in p) for p in plan]
+    assert max(wts) < 1.15 * (sum(wts) / 8)
+    owners = {}
+    for r, p in enumerate(plan):
+        for c in p:
+            owners.setdefault(c["chrom"], set()).add(r)
+    assert sum(len(v) > 1 for v in owners.values()) <= 7 and max(len(v) for v in owners.values()) <= 2
+    whole = sum(len(v) == 1 for v in owners.values())
+    assert whole >= 17                                              # most contigs are one rank's
+    # spans of a shared contig do not overlap beyond the flanks
+    for name, rs in owners.items():
+        if len(rs) == 2:
+            a, b = sorted(rs)
+            hi_a = max(c["end"] for c in plan[a] if c["chrom"] == name)
+            lo_b = min(c["start"] for c in plan[b] if c["chrom"] == name)
+            assert lo_b >= hi_a                                     # (chunks share one boundary position, utils.get_chunks)
+
+
 def test_shard_range_partitions_a_contig_list():
     from nanocaller_amd.shard import shard_range
     for n in (8, 9, 24, 5):

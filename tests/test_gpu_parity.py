@@ -638,3 +638,49 @@ def test_call_chunks_with_min_nbr_sites_filter(eng):
     assert np.array_equal(r["dp"], np.concatenate([np.asarray(e[3]) for e in exp]))
     assert np.array_equal(r["fwd_dp"], np.concatenate([np.asarray(e[6]) for e in exp]).astype(np.int32))
     assert r["probs"].shape == (len(pos), 4) and r["freq"].shape == (len(pos),)
+
+
+def test_a_rank_that_owns_part_of_a_contig_decodes_its_span_only(eng, tmp_path, monkeypatch):
+    """shard.shard_plan may cut a contig between two ranks: call_chunks then decodes / uploads only the span of its chunks +- the 50 kb
+    scan flank (generate_SNP_pileups.contig_span) and returns exactly what the whole-contig decode returns for those chunks"""
+    from nanocaller_amd import generate_SNP_pileups as gsp, snpCaller
+    from tests import bamio
+    world = bamio.make_bam_world(seed=12, length=420_000, depth=14)
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "r.fa")
+    bamio.write_bam(bam, world.chrom, world.length, bamio.world_to_records(world, np.random.Generator(np.random.PCG64(2))))
+    bamio.write_fasta(fa, world.chrom, world.ref)
+    params = dict(sam_path=bam, fasta_path=fa, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
+                  snp_model="ONT-HG002", seq="ont", supplementary=False, exclude_bed=None, disable_coverage_normalization=False)
+    chunks = [dict(chrom=world.chrom, start=150_000, end=200_000, ploidy="diploid"), dict(chrom=world.chrom, start=200_000, end=260_000, ploidy="diploid")]
+    assert gsp.contig_span(bam, world.chrom, chunks) == (100_000, 310_000)
+    gsp.release_contig()
+    del gsp.DECODES[:]
+    part = snpCaller.call_chunks(params, chunks)
+    assert gsp.DECODES == [(bam, world.chrom, (100_000, 310_000))]
+    gsp.release_contig()
+    monkeypatch.setattr(gsp, "contig_span", lambda *a: None)
+    whole = snpCaller.call_chunks(params, chunks)
+    assert part["n"] == whole["n"] > 100
+    for k in ("pos", "chunk", "ref", "dp", "alt", "fwd_dp", "rev_dp", "probs", "gt", "freq"):
+        assert np.array_equal(part[k], whole[k]), k
+    gsp.release_contig()
+
+
+def test_reference_skips_are_refused_not_silently_accepted(eng, tmp_path):
+    """a kept alignment with a reference skip (CIGAR N): the reference raises KeyError on its '>' pileup symbols (quirk E10); the
+    product path answers NC_ERR_UNSUPPORTED instead of coding the skipped positions as deletions"""
+    from nanocaller_amd import _lib, generate_SNP_pileups as gsp, snpCaller
+    from tests import bamio
+    ref = "ACGT" * 2000
+    recs = [dict(name="r%d" % k, flag=0, pos0=100 + 7 * k, cigar=[("M", 300)], seq=ref[100 + 7 * k:400 + 7 * k]) for k in range(30)]
+    recs.append(dict(name="skip", flag=0, pos0=400, cigar=[("M", 50), ("N", 500), ("M", 50)], seq="A" * 100))
+    bam, fa = str(tmp_path / "n.bam"), str(tmp_path / "n.fa")
+    bamio.write_bam(bam, "c", len(ref), recs)
+    bamio.write_fasta(fa, "c", ref)
+    params = dict(sam_path=bam, fasta_path=fa, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
+                  snp_model="ONT-HG002", seq="ont", supplementary=False, exclude_bed=None, disable_coverage_normalization=False)
+    gsp.release_contig()
+    with pytest.raises(_lib.NanoCallerHipError) as e:
+        snpCaller.call_chunks(params, [dict(chrom="c", start=1, end=len(ref), ploidy="diploid")])
+    assert e.value.status == _lib.NC_ERR_UNSUPPORTED
+    gsp.release_contig()
