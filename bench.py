@@ -539,6 +539,83 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
     return out
 
 
+def extra_from_bam(eng, local, n_contigs=3, L=3_000_000):
+    """From a BAM FILE through the product worker loop: snpCaller.caller (BGZF inflate + record decode + wire build on host threads for
+    contig i + 1 while the GPU runs contig i, upload through the three-slot ring) -> candidate sites/s including ingest.  The BAM is
+    written by test tooling from device-generated reads; sizes are kept small because that writer is Python."""
+    import queue
+    import shutil
+    import tempfile
+
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.synth_device import make_device_workload
+    from nanocaller_amd.utils import get_chunks
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamio
+    tmp = tempfile.mkdtemp(prefix="nc_bench_bam_")
+    t0 = time.perf_counter()
+    lut = np.frombuffer(b"AGTCNNNN", np.uint8)
+    recs, refs, fasta = [], [], []
+    for k in range(n_contigs):
+        pack, info = make_device_workload(eng, L, depth=30.0, tech="ont", seed=7000 + k)
+        codes = pack.codes.cpu().numpy()
+        refc = info["ref_wire"][1:L + 1].cpu().numpy()
+        ref = lut[refc & 7].copy()
+        ref[(refc & 8) != 0] |= 0x20                                 # skipped columns: soft-masked (lower case) in the FASTA
+        name = "ctg%d" % (k + 1)
+        refs.append((name, L))
+        fasta.append((name, ref.tobytes().decode()))
+        s_, e_, base = info["read_start"], info["read_end"], info["read_base"]
+        for r in range(info["n_reads"]):
+            o = int(base[r]) + int(s_[r])
+            recs.append(dict(tid=k, name="r%d_%d" % (k, r), flag=16 if info["strand"][r] else 0, pos0=int(s_[r]) - 1,
+                             cigar=[("M", int(e_[r] - s_[r]))], seq=lut[codes[o:o + int(e_[r] - s_[r])]].tobytes().decode(), tags={}))
+        del pack
+    bam, fa = os.path.join(tmp, "b.bam"), os.path.join(tmp, "b.fa")
+    bamio.write_bam(bam, refs[0][0], refs[0][1], recs, other_refs=refs[1:], level=1)
+    bamio.write_fasta(fa, fasta[0][0], fasta[0][1], extra=fasta[1:])
+    t_files = time.perf_counter() - t0
+    regions = [(n, 1, ln, "diploid") for n, ln in refs]
+    base_params = dict(regions_list=regions, sam_path=bam, fasta_path=fa, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1,
+                       threshold=[0.4, 0.6], snp_model="ONT-HG002", cpu=16, prefix="t", sample="S", seq="ont", supplementary=False,
+                       exclude_bed=None, suppress_progress=True, disable_coverage_normalization=False)
+    out = {}
+    for tag, serial in (("pipelined", None), ("serial_ingest", "1")):
+        if serial:
+            os.environ["NC_SERIAL_INGEST"] = serial
+        else:
+            os.environ.pop("NC_SERIAL_INGEST", None)
+        best = None
+        for rep in range(2):
+            gsp.release_contig()
+            d = os.path.join(tmp, "%s%d" % (tag, rep))
+            os.makedirs(d)
+            params = dict(base_params, chunks_list=get_chunks(regions, 16), vcf_path=d, intermediate_snp_files_dir=d)
+            q = queue.Queue()
+            for c in params["chunks_list"]:
+                q.put(c)
+            files = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            snpCaller.caller(params, q, queue.Queue(), files, device=local)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            n_rec = sum(1 for _ in open(files[0], "rb"))
+            if best is None or dt < best[0]:
+                best = (dt, n_rec)
+        out[tag] = {"seconds": best[0], "sites_s": best[1] / best[0], "records": best[1]}
+    os.environ.pop("NC_SERIAL_INGEST", None)
+    gsp.release_contig()
+    size = os.path.getsize(bam)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"workload": "%d contigs of %d bp, ONT 30x, one BAM file (%.0f MB, BGZF level 1) + FASTA -> snpCaller.caller -> worker VCF file; host threads: %d usable CPUs"
+                        % (n_contigs, L, size / 1e6, usable_cpus()),
+            "from_bam_sites_s": out["pipelined"]["sites_s"], "unit": "candidate sites/s incl. BGZF inflate, record decode, wire build, upload, GPU, rules + text, file write",
+            "pipelined": out["pipelined"], "serial_ingest": out["serial_ingest"], "bam_writing_s": round(t_files, 1),
+            "note": "ingest is outside SURVEY 8d's timed region (its row n1); this is the product worker loop end to end, best of 2 runs"}
+
+
 def trunk_traffic_from_profiles():
     """HBM bytes per site of the dominant kernel from the committed PMC passes (profiles/trunk_traffic.json, written from the
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes by tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md says)"""
@@ -800,6 +877,7 @@ def main():
                 extra["exact_fp32_trunk"] = extra_snp_config(eng, uploader, local, L, args.depth, args.tech, args.model, args.ploidy, True, 8,
                                                              "headline workload with the exact fp32 MFMA trunk (k4_conv12) on float32 tensors")
                 extra["indel_pipeline"] = extra_indel_config(eng, uploader, local, L)
+                extra["from_bam"] = extra_from_bam(eng, local)
             except Exception as e:                                  # an extra must never take the headline line down
                 extra["error"] = "%s: %s" % (type(e).__name__, e)
             out["extra_configs"] = extra

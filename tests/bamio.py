@@ -28,7 +28,8 @@ def reg2bin(beg, end):          # SAMv1 5.3, 0-based half-open
 
 
 class BgzfWriter:
-    def __init__(self, path, block=0xff00):
+    def __init__(self, path, block=0xff00, level=6):
+        self.level = level
         self.f = open(path, "wb")
         self.buf = bytearray()
         self.coff = 0
@@ -50,7 +51,7 @@ class BgzfWriter:
         if not self.buf:
             return
         raw = bytes(self.buf)
-        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        co = zlib.compressobj(self.level, zlib.DEFLATED, -15)
         comp = co.compress(raw) + co.flush()
         blk = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(comp) + 25) + comp + \
             struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw))
@@ -64,12 +65,12 @@ class BgzfWriter:
         self.f.close()
 
 
-def write_bam(path, chrom, length, records, other_refs=(), write_bai=True, write_csi=False):
+def write_bam(path, chrom, length, records, other_refs=(), write_bai=True, write_csi=False, level=6):
     """records: list of dict(name, flag, pos0, cigar=[(op,len)...] with op in 'MIDNSHP=X', seq (str), tags={'HP':1,...},
     optional tid = index into [(chrom, length)] + other_refs, default 0) in coordinate order."""
     refs = [(chrom, length)] + list(other_refs)
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
-    w = BgzfWriter(path)
+    w = BgzfWriter(path, level=level)
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
     for n, ln in refs:
         hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)

@@ -442,3 +442,39 @@ def test_indel_call_manager_under_gloo_shards_chunks_and_merges(tmp_path):
     keys = [(["chr1", "chrX"].index(r.split("\t")[0]), int(r.split("\t")[1])) for r in ind]
     assert keys == sorted(keys)
     assert len(_records(logs[0][0]["final"])) == len(ind) + len(_records(logs[0][0]["snps"]))
+
+
+@pytest.mark.gpu
+def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files, tmp_path, monkeypatch):
+    """snpCaller.caller decodes + wire-builds group i + 1 on a host thread and uploads it through the three-slot ring while the GPU runs
+    group i (VERDICT r2 #2); the worker file is byte-identical to the one the serial caller (NC_SERIAL_INGEST=1) writes"""
+    import queue
+
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    from nanocaller_amd.utils import get_chunks, get_regions_list
+    w1, w2, bam, fa = two_contig_files
+    a = _args(bam, fa, str(tmp_path), haploid_X=True, mincov=2)
+    regions = get_regions_list(a)
+    outs = []
+    for tag, serial in (("serial", "1"), ("piped", None)):
+        if serial:
+            monkeypatch.setenv("NC_SERIAL_INGEST", serial)
+        else:
+            monkeypatch.delenv("NC_SERIAL_INGEST", raising=False)
+        gsp.release_contig()
+        del gsp.DECODES[:]
+        d = tmp_path / tag
+        d.mkdir()
+        params = dict(chunks_list=get_chunks(regions, a.cpu), regions_list=regions, sam_path=bam, fasta_path=fa, mincov=2, maxcov=160,
+                      min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6], snp_model="ONT-HG002", cpu=2, vcf_path=str(d), prefix="t",
+                      sample="S", seq="ont", supplementary=False, exclude_bed=None, suppress_progress=True,
+                      disable_coverage_normalization=False, intermediate_snp_files_dir=str(d))
+        q = queue.Queue()
+        for c in params["chunks_list"]:
+            q.put(c)
+        files = []
+        snpCaller.caller(params, q, queue.Queue(), files)
+        outs.append(open(files[0], "rb").read())
+        assert sorted(x[1] for x in gsp.DECODES) == ["chr1", "chrX"]                # every contig decoded once
+    assert outs[0] == outs[1] and outs[0].count(b"\n") > 100
