@@ -714,6 +714,14 @@ def main():
     h2d_gbs, h2d_ms, h2d_bytes = uploader.h2d_rate()
     from nanocaller_amd.shard import dist_max, dist_sum
     total_sites = dist_sum(n_sites_rank)                # whole-job aggregate over the K steps of one region
+    # per-rank upload rates (N > 1: the ranks' copies share the host's DRAM and PCIe root complexes)
+    per_rank_h2d = None
+    if use_dist and world > 1:
+        import torch.distributed as dist
+        mine_t = torch.tensor([h2d_gbs, float(h2d_bytes)], dtype=torch.float64, device="cpu" if one_gpu else torch.device("cuda", local))
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        per_rank_h2d = [[float(t[0]), float(t[1])] for t in allt]
     if rank == 0:
         n_units = args.steps * per_step
         c0 = contigs[0]
@@ -837,7 +845,9 @@ def main():
                     "uncompressed_pack_bytes": c0.entries + L, "achieved_GBs": h2d_gbs, "pcie_peak_GBs": PCIE_PEAK_GBS,
                     "copy_ms_per_contig": h2d_ms / max(1, len(uploader.h2d_events)), "copies_timed": len(uploader.h2d_events),
                     "expand_ms": expand_ms, "expand_GBs_written": c0.wire.codes_len / (expand_ms * 1e-3) / 1e9,
-                    "note": "copies run on their own stream under the previous contig's compute; expansion is on the compute stream"},
+                    "note": "copies run on their own stream under the previous contig's compute; expansion is on the compute stream",
+                    "per_rank_achieved_GBs": [round(v[0], 2) for v in per_rank_h2d] if per_rank_h2d else None,
+                    "host_dram_read_GBs_all_ranks": (sum(v[1] for v in per_rank_h2d) / sum(dts)) / 1e9 if per_rank_h2d else None},
             "three_numbers": {"kernels_only_sites_s": n_sites / ((stage_ms[0] + stage_ms[1] + stage_ms[2] + expand_ms) * 1e-3),
                               "with_h2d_d2h_sites_s": value if not args.resident else None,
                               "hbm_resident_with_d2h_sites_s": rs_sites / rs_dt,

@@ -804,10 +804,14 @@ __device__ __forceinline__ void t_conv2(const _Float16 *A1H, _Float16 *A2H, cons
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], ah[cur][tm]) }
+#ifndef NC_EXP_C2_DROP_AL
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], al[cur][tm]) }
+#endif
+#ifndef NC_EXP_C2_DROP_WL
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wl[G], ah[cur][tm]) }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -850,10 +854,14 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3h[G], ah[cur][tm]) }
+#ifndef NC_EXP_C3_DROP_AL
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3h[G], al[cur][tm]) }
+#endif
+#ifndef NC_EXP_C3_DROP_WL
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3l[G], ah[cur][tm]) }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     const h_epi &e3 = epi;                                            // same fp16 range clamp as the other layers: k6_fc1_h3 splits

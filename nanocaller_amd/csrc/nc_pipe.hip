@@ -134,25 +134,22 @@ __device__ __forceinline__ int block_scan(int v, int *wsum, int &tot)
     return wp + inc;
 }
 
-// exclusive scan of in[0..n) into out[0..n], out[n] = total (one workgroup); `add` (optional) is added to every input first
+// exclusive scan of in[0..n) into out[0..n], out[n] = total (one workgroup, every thread a contiguous chunk); `add` is added to every input first
 __global__ __launch_bounds__(1024) void k_scan_excl(const int32_t *__restrict__ in, int32_t n, int32_t add, int32_t *__restrict__ out)
 {
     __shared__ int wsum[16];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? in[i] + add : 0;
-        int tot;
-        const int inc = block_scan(v, wsum, tot);
-        const int cc = carry;
-        if (i < n) out[i] = cc + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = cc + tot;
-        __syncthreads();
+    const int per = (n + 1023) / 1024, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += in[i] + add;
+    int tot;
+    const int inc = block_scan(local, wsum, tot);
+    int run = inc - local;
+    for (int i = i0; i < i1; i++) {
+        const int v = in[i] + add;
+        out[i] = run;
+        run += v;
     }
-    if (threadIdx.x == 0) out[n] = carry;
+    if (threadIdx.x == 0) out[n] = tot;
 }
 
 __global__ __launch_bounds__(256) void k_flatten(const PipeChunk *__restrict__ pc, const int32_t *__restrict__ seg_pos, const int8_t *__restrict__ seg_type,
@@ -956,10 +953,14 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     const int64_t arow = p.arow[al];
     const int run_cap = n1 + n2 + 2;
     int16_t *rop = runs + 2 * (TWB * arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;  // runs in REVERSE alignment order (TWB * blocks >= n1 + 1)
-    int nr = 0, last_op = -1;
+    int nr = 0, last_op = -1, last_cnt = 0;                            // the open run lives in registers: one store pair per run, no read-modify-write
     auto push = [&](int op) {
-        if (op == last_op) rcn[nr - 1]++;
-        else if (nr < run_cap) { rop[nr] = (int16_t)op; rcn[nr] = 1; nr++; last_op = op; }
+        if (op == last_op) last_cnt++;
+        else {
+            if (last_op >= 0 && nr < run_cap) { rop[nr] = (int16_t)last_op; rcn[nr] = (int16_t)last_cnt; nr++; }
+            last_op = op;
+            last_cnt = 1;
+        }
     };
     int i = n1, j = n2, state = -1;
     while (i > 0 || j > 0) {
@@ -984,6 +985,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
             if (!ext) state = -1;
         }
     }
+    if (last_op >= 0 && nr < run_cap) { rop[nr] = (int16_t)last_op; rcn[nr] = (int16_t)last_cnt; nr++; }
     bool indel = false, mm_before = false;
     int32_t rc7 = 0, rc8 = 0, rc2 = 0, ac7 = 0, ac8 = 0, ac1 = 0, mm_after = 0;
     const int32_t mr = site_type[site] == 0 ? max(10, win_size) : 10;       // max_range {0: max(10, win_size), 1: 10}
@@ -1027,28 +1029,26 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     alt_len[al] = out_a;
 }
 
+// One workgroup, every thread a contiguous chunk of ceil(n / 1024) items: local sum -> block scan of the 1,024 sums -> local scan.  (The
+// strided form -- 1,024 items per round, two barriers per round -- took 0.3 ms for 30 k items on the critical path of every group.)
 // traceback blocks of the allele alignments: arow[a] = sum_{b<a} tw_blocks(n1[b]); arow[n] = total
 __global__ __launch_bounds__(1024) void k_scan_rows(const int32_t *__restrict__ n1, int32_t n, int64_t *__restrict__ arow, int32_t *__restrict__ total_mbox)
 {
     __shared__ int wsum[16];
-    __shared__ long long carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? tw_blocks(n1[i]) : 0;
-        int tot;
-        const int inc = block_scan(v, wsum, tot);
-        const long long cc = carry;
-        if (i < n) arow[i] = cc + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = cc + tot;
-        __syncthreads();
+    const int per = (n + 1023) / 1024, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += tw_blocks(n1[i]);
+    int tot;
+    const int inc = block_scan(local, wsum, tot);
+    long long run = inc - local;
+    for (int i = i0; i < i1; i++) {
+        arow[i] = run;
+        run += tw_blocks(n1[i]);
     }
     if (threadIdx.x == 0) {
-        arow[n] = carry;
-        total_mbox[0] = (int32_t)(carry & 0x7fffffff);
-        total_mbox[1] = (int32_t)(carry >> 31);
+        arow[n] = tot;
+        total_mbox[0] = tot & 0x7fffffff;
+        total_mbox[1] = 0;
     }
 }
 
@@ -1057,21 +1057,18 @@ __global__ __launch_bounds__(1024) void k_alt_offsets(const int32_t *__restrict_
                                                       int64_t *__restrict__ off /* [n] */)
 {
     __shared__ int wsum[16];
-    __shared__ long long carry;
-    if (threadIdx.x == 0) carry = pool_base[0];
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? max(alt_len[i], 0) : 0;
-        int tot;
-        const int inc = block_scan(v, wsum, tot);
-        const long long cc = carry;
-        if (i < n) off[i] = cc + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = cc + tot;
-        __syncthreads();
+    const int per = (n + 1023) / 1024, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += max(alt_len[i], 0);
+    int tot;
+    const int inc = block_scan(local, wsum, tot);
+    long long run = pool_base[0] + inc - local;
+    __syncthreads();                                               // every thread has read pool_base before it is updated
+    for (int i = i0; i < i1; i++) {
+        off[i] = run;
+        run += max(alt_len[i], 0);
     }
-    if (threadIdx.x == 0) pool_base[0] = carry;
+    if (threadIdx.x == 0) pool_base[0] += tot;
 }
 
 __global__ __launch_bounds__(256) void k_alt_copy(const uint8_t *__restrict__ cns, const int32_t *__restrict__ alt_len, const int64_t *__restrict__ off,
