@@ -1329,7 +1329,8 @@ __global__ __launch_bounds__(256) void k8_conv23_h3(const _Float16 *__restrict__
 // bottom through a five-row ring in LDS (every input row is staged once).  The kernel that does this, k9_conv12_h3, runs conv2
 // on the rows as they appear.
 constexpr int C1H_ROWPX = 134;                                  // pixels -2 .. 131 of a row (zero padded)
-constexpr size_t C1H_BYTES = 6 * 64 * 16 + 4 * 40;            // 6 A fragments, then S*bias[32] (acc35 rows 0-15, acc1 rows 0-15), 1/S
+constexpr size_t C1H_FRAG7 = 6 * 64 * 16 + 4 * 40;            // 6 A fragments, then S*bias[32] (acc35 rows 0-15, acc1 rows 0-15), 1/S
+constexpr size_t C1H_BYTES = C1H_FRAG7 + 64 * 16;             // + the 1x5 fragment with its filters in rows 8-15 (k10_indel_trunk_h3)
 
 // conv1 + conv2 of one site per workgroup iteration: conv1's output rows never leave the chip -- they go, as hi / lo fp16
 // planes, into a two-row LDS ring from which conv2 (2x3 taps, stride 2 in x: output row r needs conv1 rows r and r+1) reads
@@ -1467,6 +1468,276 @@ __global__ __launch_bounds__(256, 3) void k9_conv12_h3(const float *__restrict__
     }
 }
 
+// ---- the whole conv trunk of the indel models in one kernel, one workgroup per CU, twelve waves with fixed roles (three per SIMD:
+// one of each).  The rows of a site (and of the sites after it: the workgroup's sites form one stream of P = H + 3 rows each --
+// two zero rows, the H image rows, one zero row) move through three LDS rings, two rows per step; at step T
+//     wave 11    writes input rows 2T+4, 2T+5 into the X3 ring (requested from HBM eight rows earlier),
+//     waves 0-3  conv1 of rows 2T, 2T+1 (two 16-pixel tiles each: 24 MFMAs; the six input rows are read once for both) -> ring R1,
+//     waves 4-7  conv2 of the row pairs starting at conv1 rows 2T-4 and 2T-3 (one 16-position tile, both channel tiles: 60 MFMAs)
+//                -> ring R2,
+//     waves 8-10 conv3 of the row pairs starting at conv2 rows 2T-8 and 2T-7 (one channel tile each, both position tiles: 72 MFMAs)
+//                -> HBM (fp32, fc1's input),
+// every role reading only what earlier steps wrote: ONE barrier per step, and the weight fragments of a wave's role stay in its
+// registers for the whole launch.  Two rows per step give every wave two independent accumulation chains per tile (a step of one
+// row was latency-bound: 1.04 ms per 13 k sites against 0.6 for this form), and P even keeps the pairs aligned with the sites: a
+// pair is either skipped or computed whole (conv1 and conv3 have an odd number of rows per site: one row in 16 / 14 is computed and dropped).
+// k9_conv12_h3 / k8_conv23_h3 re-read the weights from LDS for every tile (60 KB per wave and row) and passed conv2's activations
+// through HBM (226 KB per site).
+constexpr int T_P1 = 24, T_P2 = 40;                            // pixel pitch (halves) of rings R1 / R2: 8 consecutive lanes of a b128 read hit 8 distinct bank groups
+constexpr int K10_NS = 6;                                       // slots of R1 / R2 (rows live at a time: the two a role writes + the four its reader is behind)
+constexpr size_t K10_LDS = 8 * C1H_ROWPX * 12 + 64 + 2 * (K10_NS * 128 * T_P1 * 2) + 2 * (K10_NS * 64 * T_P2 * 2);
+
+#ifdef NC_K10_NOBAR
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+// a loaded weight fragment the compiler may not re-load inside the step loop (it otherwise sinks the loads into the loop to reach an
+// occupancy the kernel's LDS use rules out anyway)
+__device__ __forceinline__ void pin(h8 &v) { asm volatile("" : "+v"(v)); }
+
+// ablation switches (tools/exp_build.sh): a role that only keeps the barrier
+#ifdef NC_K10_SKIP
+constexpr bool K10_C1 = !(NC_K10_SKIP & 1), K10_C2 = !(NC_K10_SKIP & 2), K10_C3 = !(NC_K10_SKIP & 4);
+#else
+constexpr bool K10_C1 = true, K10_C2 = true, K10_C3 = true;
+#endif
+#ifdef NC_K10_NOMFMA
+#define K10_MFMA(ACC, A_, B_) asm volatile("" ::"v"(A_), "v"(B_));
+#else
+#define K10_MFMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0);
+#endif
+template <int H>
+__global__ __launch_bounds__(768) void k10_indel_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp1, const uint8_t *__restrict__ wp2,
+                                                          const uint8_t *__restrict__ wp3, float *__restrict__ a3, int64_t n_sites)
+{
+    constexpr int W = 128, P = H + 3, WO2 = 63, WO3 = 31, HO3 = H - 2, NS = K10_NS;
+    static_assert(P % 2 == 0, "k10_indel_trunk_h3: the stream period must be even");
+    typedef H3Layer<24, 32> L2;
+    typedef H3Layer<32, 48> L3;
+    static_assert(L2::NG == 5 && L2::TN == 2 && L3::NG == 6 && L3::TN == 3, "k10_indel_trunk_h3: shape");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *X3 = reinterpret_cast<uint32_t *>(smem);                                           // 8 slots x 134 pixels x [H L H]
+    constexpr int R1S = W * T_P1, R2S = 64 * T_P2;                                                // halves per ring slot
+    _Float16 *R1H = reinterpret_cast<_Float16 *>(smem + 8 * C1H_ROWPX * 12 + 64), *R1L = R1H + NS * R1S;
+    _Float16 *R2H = R1L + NS * R1S, *R2L = R2H + NS * R2S;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int nloc = (int)((n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x);                   // this workgroup's sites: blockIdx.x + k gridDim.x
+    constexpr int RD = 8;                                             // the input stager's look-ahead (rows); T is a multiple of RD / 2
+    const int T = ((nloc * P + 8) / 2 + RD / 2 - 1) / (RD / 2) * (RD / 2);
+    if (wv < 4) {
+        // ---------------- conv1.  acc: rows 0-7 the 5x5 filters, rows 8-15 the 5x1 filters (centre column of A[dy]); accp: the 1x5
+        // filters of BOTH tiles (A[5] has them in rows 0-7, A[6] in rows 8-15: lanes g < 2 end up with tile 0's pixel, g >= 2 with tile 1's)
+        const uint4 *wf = reinterpret_cast<const uint4 *>(wp1);
+        const float *bs = reinterpret_cast<const float *>(wf + 6 * 64);
+        h8 A[7];
+#pragma unroll
+        for (int f = 0; f < 6; f++) A[f] = as_h8(wf[f * 64 + lane]);
+        A[6] = as_h8(reinterpret_cast<const uint4 *>(wp1 + C1H_FRAG7)[lane]);
+#pragma unroll
+        for (int f = 0; f < 7; f++) pin(A[f]);
+        const f32x4v b35 = *reinterpret_cast<const f32x4v *>(bs + 4 * g), b1 = *reinterpret_cast<const f32x4v *>(bs + 16 + 4 * (g & 1));
+        const float inv_s1 = bs[32];
+        const h_epi e1 = {inv_s1 * 1.44269504088896341f, inv_s1 * SELU_L, 60000.0f / (inv_s1 * SELU_L)};
+        const int xx0 = 32 * wv + c16;
+        const int o35 = xx0 * T_P1 + (g < 2 ? 16 + 4 * g : 8 + 4 * (g - 2)), op = (xx0 + 16 * (g >> 1)) * T_P1 + 4 * (g & 1);
+        const uint32_t *xb = X3 + 3 * xx0 + 4 * g;
+        for (int t = 0; t < T; t++) {
+            const int u0 = 2 * t;
+            if (K10_C1 && u0 % P != 0 && u0 / P < nloc) {                      // conv1 of stream rows u0, u0 + 1 (input rows u0 - 2 .. u0 + 3)
+                f32x4v acc[2][2] = {{b35, b35}, {b35, b35}}, accp[2] = {b1, b1};
+#pragma unroll
+                for (int ir = 0; ir < 6; ir++) {
+                    const uint32_t *q0 = xb + (((u0 + ir - 2) & 7) * C1H_ROWPX) * 3, *q1 = q0 + 48;
+                    const h8 B0 = as_h8(make_uint4(q0[0], q0[1], q0[2], q0[3])), B1 = as_h8(make_uint4(q1[0], q1[1], q1[2], q1[3]));
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int dy = ir - r;
+                        if (dy < 0 || dy > 4) continue;
+                        K10_MFMA(acc[r][0], A[dy], B0)
+                        K10_MFMA(acc[r][1], A[dy], B1)
+                        if (dy == 2) {
+                            K10_MFMA(accp[r], A[5], B0)
+                            K10_MFMA(accp[r], A[6], B1)
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int o = ((u0 + r) % NS) * R1S;
+                    split4_store(selu4_scaled(acc[r][0], e1), R1H + o + o35, R1L + o + o35);
+                    split4_store(selu4_scaled(acc[r][1], e1), R1H + o + o35 + 16 * T_P1, R1L + o + o35 + 16 * T_P1);
+                    split4_store(selu4_scaled(accp[r], e1), R1H + o + op, R1L + o + op);
+                }
+            }
+            lds_barrier();
+        }
+    } else if (wv < 8) {
+        // ---------------- conv2, position tile wv - 4
+        const uint4 *gh = reinterpret_cast<const uint4 *>(wp2), *gl = gh + L2::NG * L2::TN * 64;
+        const float *bs2 = reinterpret_cast<const float *>(gl + L2::NG * L2::TN * 64);
+        h8 wh[L2::NG][L2::TN], wl[L2::NG][L2::TN];
+#pragma unroll
+        for (int G = 0; G < L2::NG; G++)
+#pragma unroll
+            for (int tn = 0; tn < L2::TN; tn++) {
+                wh[G][tn] = as_h8(gh[(G * L2::TN + tn) * 64 + lane]);
+                wl[G][tn] = as_h8(gl[(G * L2::TN + tn) * 64 + lane]);
+                pin(wh[G][tn]);
+                pin(wl[G][tn]);
+            }
+        const float inv_s2 = bs2[32];
+        const h_epi e2 = {inv_s2 * 1.44269504088896341f, inv_s2 * SELU_L, 60000.0f / (inv_s2 * SELU_L)};
+        f32x4v bias2[L2::TN];
+#pragma unroll
+        for (int tn = 0; tn < L2::TN; tn++) bias2[tn] = *reinterpret_cast<const f32x4v *>(bs2 + 16 * tn + 4 * g);
+        const int xq = 16 * (wv - 4) + c16, xc = xq < WO2 ? xq : WO2 - 1;
+        int toff[L2::NG], trow[L2::NG];
+        bool tval[L2::NG];
+#pragma unroll
+        for (int G = 0; G < L2::NG; G++) {
+            const int chunk = 4 * G + g, tap = chunk / 3, c8 = chunk - tap * 3;
+            tval[G] = chunk < L2::NCH;
+            trow[G] = tval[G] ? tap / 3 : 0;
+            toff[G] = tval[G] ? (2 * xc + tap % 3) * T_P1 + 8 * c8 : 0;
+        }
+        const int oq = xq * T_P2 + 4 * g;
+        for (int t = 0; t < T; t++) {
+            const int v0 = 2 * t - 4, s2 = v0 % P;                             // an even lag: the 14 (H - 1) conv2 rows of a site are whole pairs
+            if (K10_C2 && v0 >= 0 && s2 >= 2 && s2 <= P - 4 && v0 / P < nloc) {  // conv2 rows of the conv1 stream rows (v0, v0+1) and (v0+1, v0+2)
+                const _Float16 *rp[3];                                         // this lane's pixel in the three conv1 rows
+#pragma unroll
+                for (int r = 0; r < 3; r++) rp[r] = R1H + ((v0 + r) % NS) * R1S;
+                f32x4v acc[2][L2::TN];
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int tn = 0; tn < L2::TN; tn++) acc[r][tn] = bias2[tn];
+#pragma unroll
+                for (int G = 0; G < L2::NG; G++) {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        // K slots past the last tap (G = 4, g >= 2) read the row's first pixel: their weights are zero
+                        const _Float16 *q = (trow[G] ? rp[r + 1] : rp[r]) + toff[G];
+                        const h8 xh = as_h8(*reinterpret_cast<const uint4 *>(q)), xl = as_h8(*reinterpret_cast<const uint4 *>(q + NS * R1S));
+#pragma unroll
+                        for (int tn = 0; tn < L2::TN; tn++) {
+                            K10_MFMA(acc[r][tn], wh[G][tn], xh)
+                            K10_MFMA(acc[r][tn], wh[G][tn], xl)
+                            K10_MFMA(acc[r][tn], wl[G][tn], xh)
+                        }
+                    }
+                }
+                if (xq < WO2) {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int o = ((v0 + r) % NS) * R2S + oq;
+#pragma unroll
+                        for (int tn = 0; tn < L2::TN; tn++) split4_store(selu4_scaled(acc[r][tn], e2), R2H + o + 16 * tn, R2L + o + 16 * tn);
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    } else if (wv < 11) {
+        // ---------------- conv3, channel tile tn = wv - 8
+        const int tn = wv - 8;
+        const uint4 *gh = reinterpret_cast<const uint4 *>(wp3), *gl = gh + L3::NG * L3::TN * 64;
+        const float *bs3 = reinterpret_cast<const float *>(gl + L3::NG * L3::TN * 64);
+        h8 wh[L3::NG], wl[L3::NG];
+#pragma unroll
+        for (int G = 0; G < L3::NG; G++) {
+            wh[G] = as_h8(gh[(G * L3::TN + tn) * 64 + lane]);
+            wl[G] = as_h8(gl[(G * L3::TN + tn) * 64 + lane]);
+            pin(wh[G]);
+            pin(wl[G]);
+        }
+        const float inv_s3 = bs3[48];
+        const h_epi e3 = {inv_s3 * 1.44269504088896341f, inv_s3 * SELU_L, 3.0e38f};
+        const f32x4v bias3 = *reinterpret_cast<const f32x4v *>(bs3 + 16 * tn + 4 * g);
+        const int xqb = 16 + c16, xcb = xqb < WO3 ? xqb : WO3 - 1;
+        const int oa = 2 * c16 * T_P2 + 8 * g, ob = 2 * xcb * T_P2 + 8 * g;
+        for (int t = 0; t < T; t++) {
+            const int w0 = 2 * t - 8, s3 = w0 % P;
+            if (K10_C3 && w0 >= 0 && s3 != 0 && s3 < P - 2 && w0 / P < nloc) {  // conv3 rows of the conv2 stream rows (w0, w0+1) and (w0+1, w0+2)
+                const int64_t site = blockIdx.x + (int64_t)(w0 / P) * gridDim.x;
+                const _Float16 *pa[3], *pb[3];                                  // this lane's two pixels in the three conv2 rows
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    pa[r] = R2H + ((w0 + r) % NS) * R2S + oa;
+                    pb[r] = R2H + ((w0 + r) % NS) * R2S + ob;
+                }
+                f32x4v acc[2][2] = {{bias3, bias3}, {bias3, bias3}};
+#pragma unroll
+                for (int G = 0; G < L3::NG; G++) {                             // tap G = (row G / 3, column G % 3), channels 8 g .. 8 g + 7
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const _Float16 *qa = pa[r + G / 3] + (G % 3) * T_P2, *qb = pb[r + G / 3] + (G % 3) * T_P2;
+                        const h8 xh0 = as_h8(*reinterpret_cast<const uint4 *>(qa)), xl0 = as_h8(*reinterpret_cast<const uint4 *>(qa + NS * R2S));
+                        const h8 xh1 = as_h8(*reinterpret_cast<const uint4 *>(qb)), xl1 = as_h8(*reinterpret_cast<const uint4 *>(qb + NS * R2S));
+                        K10_MFMA(acc[r][0], wh[G], xh0)
+                        K10_MFMA(acc[r][1], wh[G], xh1)
+                        K10_MFMA(acc[r][0], wh[G], xl0)
+                        K10_MFMA(acc[r][1], wh[G], xl1)
+                        K10_MFMA(acc[r][0], wl[G], xh0)
+                        K10_MFMA(acc[r][1], wl[G], xh1)
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    if (s3 + r > P - 4) continue;                              // the pair's second row is past the site's last conv3 row
+                    float *o = a3 + ((site * HO3 + (s3 + r - 2)) * WO3) * 48 + 16 * tn + 4 * g;
+                    *reinterpret_cast<f32x4v *>(o + c16 * 48) = selu4_scaled(acc[r][0], e3);
+                    if (xqb < WO3) *reinterpret_cast<f32x4v *>(o + xqb * 48) = selu4_scaled(acc[r][1], e3);
+                }
+            }
+            lds_barrier();
+        }
+    } else {
+        // ---------------- input rows: stream row u = [zero, zero, row 0 .. row H-1, zero] of the workgroup's sites, then zeros.
+        // A row is requested RD rows before it is written into X3: HBM latency (~1-2 us) is several steps long.
+        float2 rgs[RD][3];
+        // the loads are unconditional (clamped address, value masked when stored) and the loop below has no branch: a load under a
+        // branch makes the compiler wait for vmcnt(0) at every step, i.e. for the rows it has just requested
+        auto load_row = [&](int u, float2 *rg) {
+            const int k = min(u / P, nloc - 1), iy = min(max(u % P - 2, 0), H - 1);
+            const float *row = x + ((blockIdx.x + (int64_t)k * gridDim.x) * H + iy) * (W * 2);
+#pragma unroll
+            for (int j = 0; j < 3; j++) rg[j] = *reinterpret_cast<const float2 *>(row + 2 * min(max(lane + 64 * j - 2, 0), W - 1));
+        };
+        auto store_row = [&](int u, const float2 *rg) {
+            const bool row_ok = u / P < nloc && u % P >= 2 && u % P < H + 2;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int p = min(lane + 64 * j, C1H_ROWPX - 1);                // lanes past the row rewrite its last pixel (a zero pad: same value)
+                const bool ok = row_ok && p >= 2 && p < W + 2;
+                const float v0 = ok ? fminf(fmaxf(rg[j].x, -65504.0f), 65504.0f) : 0.0f, v1 = ok ? fminf(fmaxf(rg[j].y, -65504.0f), 65504.0f) : 0.0f;
+                const h2 hh = __builtin_convertvector((f32x2v){v0, v1}, h2);
+                const uint32_t Hh = __builtin_bit_cast(uint32_t, hh);
+                const f32x2v d = {sub_h_lo(v0, Hh), sub_h_hi(v1, Hh)};
+                const uint32_t Ll = __builtin_bit_cast(uint32_t, (h2)__builtin_convertvector(d, h2));
+                uint32_t *q = X3 + ((u & 7) * C1H_ROWPX + p) * 3;
+                q[0] = Hh; q[1] = Ll; q[2] = Hh;
+            }
+        };
+        for (int u = 0; u < 4; u++) { load_row(u, rgs[0]); store_row(u, rgs[0]); }
+#pragma unroll
+        for (int d = 0; d < RD; d++) load_row(4 + d, rgs[d]);
+        for (int t0 = 0; t0 < T; t0 += RD / 2) {                             // rows 0-3 are first read at step 1, after the barrier of step 0
+#pragma unroll
+            for (int d = 0; d < RD; d += 2) {
+                const int u = 2 * t0 + 4 + d;                                 // step t0 + d / 2 writes rows u, u + 1
+                store_row(u, rgs[d]);
+                store_row(u + 1, rgs[d + 1]);
+                load_row(u + RD, rgs[d]);
+                load_row(u + 1 + RD, rgs[d + 1]);
+                lds_barrier();
+            }
+        }
+    }
+}
+#undef K10_MFMA
+
 // host: A fragments of conv1 (k9_conv12_h3) from the canonical conv1 weights (k11 [5][2][8], k12 [5][2][8], k13 [25][2][8] + biases)
 inline void pack_conv1_h3(const float *w, uint8_t *dst)
 {
@@ -1494,6 +1765,12 @@ inline void pack_conv1_h3(const float *w, uint8_t *dst)
             }
     for (int c = 0; c < 8; c++) { bs[c] = b13[c] * S; bs[8 + c] = b12[c] * S; bs[16 + c] = b11[c] * S; bs[24 + c] = 0.0f; }
     bs[32] = 1.0f / S;
+    _Float16 *f7 = reinterpret_cast<_Float16 *>(dst + C1H_FRAG7);            // fragment 5 moved down by eight rows
+    for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+            const int c = lane & 15;
+            f7[(size_t)lane * 8 + j] = c >= 8 ? fr[((size_t)5 * 64 + (lane - 8)) * 8 + j] : (_Float16)0.0f;
+        }
 }
 
 constexpr size_t INDEL_H3_BYTES = H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES + C1H_BYTES;
@@ -1539,8 +1816,14 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
 {
     constexpr int H2 = H - 1, W2 = (W - 3) / 2 + 1, H3 = H2 - 1, W3 = (W2 - 3) / 2 + 1;
     constexpr int64_t n1 = (int64_t)H * W * 3 * C1, n2 = (int64_t)H2 * W2 * C2, n3 = (int64_t)H3 * W3 * C3;
-    if constexpr (!MFMA) NC_TRY(nc_ensure(ctx, ctx->cnn_a, (size_t)(nb * n1) * 4));
-    NC_TRY(nc_ensure(ctx, ctx->cnn_b, (size_t)(nb * n2) * 4));
+    // indel models: exact fp32 MFMA (k7) or, by default, the split-precision kernels fed with fp16 hi/lo planes: one fused kernel
+    // (k10_indel_trunk_h3; NC_INDEL_TRUNK_SPLIT=1 keeps round 2's pair k9_conv12_h3 + k8_conv23_h3 for comparison)
+    const bool indel_h3 = !MFMA && !ctx->cnn_exact_fp32 && packed_h != nullptr;
+    static const bool trunk_split = getenv("NC_INDEL_TRUNK_SPLIT") != nullptr;
+    const bool indel_fused = indel_h3 && !trunk_split && CI == 2 && C1 == 8 && W == 128;
+    if constexpr (!MFMA)
+        if (!indel_h3) NC_TRY(nc_ensure(ctx, ctx->cnn_a, (size_t)(nb * n1) * 4));
+    if (!indel_fused) NC_TRY(nc_ensure(ctx, ctx->cnn_b, (size_t)(nb * n2) * 4));
     NC_TRY(nc_ensure(ctx, ctx->cnn_c, (size_t)(nb * (n3 + F)) * 4 + 64));
     float *a1 = (float *)ctx->cnn_a.p, *a2 = (float *)ctx->cnn_b.p, *a3 = (float *)ctx->cnn_c.p;
     float *f1 = a3 + ((nb * n3 + 3) & ~int64_t(3));
@@ -1550,11 +1833,18 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
     *tail = bf + F;
     *f1_out = f1;
     const int64_t np1 = nb * H * W, np2 = nb * H2 * W2, np3 = nb * H3 * W3;
-    // indel models: exact fp32 MFMA (k7) or, by default, the split-precision kernels (k8) fed with fp16 hi/lo planes
-    const bool indel_h3 = !MFMA && !ctx->cnn_exact_fp32 && packed_h != nullptr;
     if constexpr (!MFMA) {
         if constexpr (CI == 2 && W % 4 == 0 && C1 == 8) {
-            if (indel_h3)                                         // conv1 + conv2 fused: conv1's activations stay in LDS
+            if (indel_fused) {
+                constexpr size_t LDS = K10_LDS;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k10_indel_trunk_h3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((k10_indel_trunk_h3<H>), dim3((unsigned)(nb < 256 ? nb : 256)), dim3(768), LDS, ctx->stream, x_batch,
+                                   packed_h + H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES, packed_h, packed_h + H3Layer<24, 32>::BYTES, a3, nb);
+            } else if (indel_h3)                                  // conv1 + conv2 fused: conv1's activations stay in LDS
                 hipLaunchKernelGGL((k9_conv12_h3<H>), dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, ctx->stream, x_batch,
                                    packed_h + H3Layer<24, 32>::BYTES + H3Layer<32, 48>::BYTES, packed_h, (void *)a2, nb, np2);
             else
@@ -1595,7 +1885,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
     } else {
         auto grid = [](int64_t npos) { const int64_t t = (npos + 63) / 64; return dim3((unsigned)(t < 2048 ? t : 2048)); };
         if constexpr (3 * C1 == 24 && C2 == 32 && C3 == 48) {
-            if (indel_h3) {
+            if (indel_h3 && !indel_fused) {
                 const _Float16 *a2h = reinterpret_cast<const _Float16 *>(a2), *a2l = a2h + np2 * 32;
                 hipLaunchKernelGGL((k8_conv23_h3<H2, W2, 32, 48, true>), grid(np3), dim3(256), 0, ctx->stream, a2h, a2l,
                                    packed_h + H3Layer<24, 32>::BYTES, (void *)a3, np2, np3);
@@ -1605,7 +1895,13 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
             hipLaunchKernelGGL((k7_conv23_mfma<H, W, 3 * C1, C2>), grid(np2), dim3(256), 0, ctx->stream, a1, k2, b2, a2, np2);
             hipLaunchKernelGGL((k7_conv23_mfma<H2, W2, C2, C3>), grid(np3), dim3(256), 0, ctx->stream, a2, k3, b3, a3, np3);
         }
+#if defined(NC_FC1_TM) && NC_FC1_TM == 4
+        hipLaunchKernelGGL((k3_fc1<F, 4>), dim3(blocks_for(nb, 64)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+#elif defined(NC_FC1_TM) && NC_FC1_TM == 1
+        hipLaunchKernelGGL((k3_fc1<F, 1>), dim3(blocks_for(nb, 16)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+#else
         hipLaunchKernelGGL((k3_fc1<F, 2>), dim3(blocks_for(nb, 32)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
+#endif
     }
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
@@ -1900,7 +2196,9 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
     const int nout = kind == NC_MODEL_INDEL ? 4 : 1;
     const int64_t xs = kind == NC_MODEL_INDEL ? 15 * 128 * 2 : 5 * 128 * 2;
     NcTimer tm(ctx, 2);
-    const int64_t BATCH = kind == NC_MODEL_INDEL ? 16384 : 32768;     // ~6 GB / ~4 GB of layer activations in HBM per batch (8,192 sites: 6 % slower, 4,096: 17 %)
+    // batch = what the conv3 activations (fc1's input, 77 KB / 18 KB per site) may take in HBM: ~5 GB.  NC_INDEL_TRUNK_SPLIT's kernels keep conv2's too
+    static const bool split_env = getenv("NC_INDEL_TRUNK_SPLIT") != nullptr;
+    const int64_t BATCH = split_env ? (kind == NC_MODEL_INDEL ? 16384 : 32768) : (kind == NC_MODEL_INDEL ? 65536 : 262144);
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;
