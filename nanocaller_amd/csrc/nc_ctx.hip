@@ -147,7 +147,7 @@ int nc_ctx_destroy(nc_ctx *ctx)
                       &ctx->tile_pre, &ctx->nbr_pos, &ctx->cand_pos, &ctx->cand_n, &ctx->cand_alt,
                       &ctx->chunk_start, &ctx->chunk_end, &ctx->chunk_lo, &ctx->chunk_cnt, &ctx->chunk_off,
                       &ctx->site_pos, &ctx->site_chunk, &ctx->site_n, &ctx->site_alt, &ctx->totals,
-                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth, &ctx->nbr_idx, &ctx->indel_ws,
+                      &ctx->cnn_a, &ctx->cnn_b, &ctx->cnn_c, &ctx->chunk_depth, &ctx->nbr_idx, &ctx->indel_ws, &ctx->indel_ent_read,
                       &ctx->msa_reads, &ctx->msa_read_off, &ctx->msa_read_set, &ctx->msa_refs, &ctx->msa_ref_off, &ctx->msa_rows_hf,
                       &ctx->msa_hcol, &ctx->msa_tb, &ctx->msa_trace, &ctx->msa_cols, &ctx->msa_out, &ctx->msa_dup};
     for (DevBuf *b : bufs) freebuf(*b);

@@ -303,13 +303,22 @@ __global__ __launch_bounds__(256) void k_event_intervals_w(int32_t n_reads, cons
         const bool ins = sl > 0;
         return cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
     };
+    if (ea >= eb) return;
+    // first chunk with hi >= the read's first event: one search per read on the scalar unit; an event's own first chunk is at most a
+    // few steps further (a search per event was ten dependent loads, half of this kernel's time)
+    int a0 = 0;
+    {
+        const int32_t p_first = __builtin_amdgcn_readfirstlane(ev_pos[ea]);
+        int b = n_chunks;
+        while (a0 < b) {
+            const int m = (a0 + b) >> 1;
+            if (ck[m].hi < p_first) a0 = m + 1; else b = m;
+        }
+    }
     for (int e = ea + lane; e < eb; e += 64) {
         const int32_t p = ev_pos[e], sl = ev_len[e];
-        int a = 0, b = n_chunks;                                       // first chunk with hi >= p
-        while (a < b) {
-            const int m = (a + b) >> 1;
-            if (ck[m].hi < p) a = m + 1; else b = m;
-        }
+        int a = a0;
+        while (a < n_chunks && ck[a].hi < p) a++;
         for (int ci = a; ci < n_chunks && ck[ci].lo <= p; ci++) {
             const IndelChunk c = ck[ci];
             if (impute) atomicAdd(&ck_cnt(ws, c)[(int64_t)(sl > 0 ? 1 : 2) * c.ncol + (p - c.lo)], 1);      // :279-284, every read
@@ -339,9 +348,275 @@ __global__ __launch_bounds__(256) void k_event_intervals_w(int32_t n_reads, cons
                     if (k2 - k > w - 1) break;
                     if (qualifies(ev_len[e2], cls)) { has_next = true; break; }
                 }
+#ifdef NC_ABL_EV_NOATOMIC
+                if (!has_prev && !has_next && k == -12345) diff[0] = 1;
+#else
                 if (!has_prev) atomicAdd(&diff[(int64_t)(cls * 2 + h) * c.nd + k], 1);
                 if (!has_next) atomicAdd(&diff[(int64_t)(cls * 2 + h) * c.nd + k + w], -1);
+#endif
             }
+        }
+    }
+}
+
+// The same result without global atomics (k_event_intervals_w spends 4.8 of its 5.1 ms per chr20-sized contig in ~150 M scattered
+// atomic adds): one workgroup per 1024 columns of a chunk.  It takes the reads of the tile index that overlap its columns (and the
+// columns before them whose windows reach in: the last wmax - 1 yielded columns), finds each read's events there by bisection, gives
+// every event to a lane, accumulates the interval ends in LDS (clipped to the block's ranks: what a read covers INSIDE the block does
+// not depend on events outside the margin), scans the eight rows and writes the finished window counts U[class, haplotype][rank]
+// -- k_prefix_rows_b has nothing left to do.  Needs the map tile entry -> read (slot_off of the wire pack): the device pipeline has
+// it (nc_indel_sites_plan); the host-route API keeps k_event_intervals_w.
+#ifndef NC_EV_NT
+#define NC_EV_NT 512
+#endif
+constexpr int EV_SUB = 1024, EV_MARGIN = 256, EV_CAP = 2048, EV_NT = NC_EV_NT;
+
+// read index of every tile entry (its slot offset is unique): once per call, so that the blocks below do not repeat the bisection
+__global__ void k_entry_reads(const nc_tile_entry *__restrict__ tile_ent, int64_t n_entries, const int64_t *__restrict__ slot_off, int32_t n_reads,
+                              int32_t *__restrict__ ent_read)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const nc_tile_entry ent = tile_ent[e];
+    const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
+    int lo = 0, hi = n_reads;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (slot_off[mid] < so) lo = mid + 1; else hi = mid;
+    }
+    ent_read[e] = lo;
+}
+
+__global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict__ tile_off, const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
+                                                     int32_t tile_size, const int32_t *__restrict__ ent_read,
+                                                     const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
+                                                     const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
+                                                     const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win,
+                                                     int32_t small_win, int32_t haploid)
+{
+    __shared__ int32_t dif[8][EV_SUB];
+    __shared__ int32_t rkw[EV_SUB + EV_MARGIN];
+    __shared__ int32_t en_e0[256], en_pre[257], en_lim[256];
+    __shared__ uint8_t en_h[256];
+    __shared__ int32_t evk[EV_CAP];                                  // the batch's events: rank of the column (-1 excluded), classes they qualify for
+    __shared__ uint8_t evq[EV_CAP];
+    __shared__ int32_t sh_k0, sh_k1, sh_mlo, wsum[EV_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int SPT = tile_size / EV_SUB;
+    int a = 0, b = n_chunks - 1;                                   // last chunk whose first block is <= blockIdx.x
+    while (a < b) {
+        const int m = (a + b + 1) >> 1;
+        if (ck[m].blk0 * SPT <= (int)blockIdx.x) a = m; else b = m - 1;
+    }
+    const IndelChunk c = ck[a];
+    const int rel = (int)blockIdx.x - c.blk0 * SPT, t = c.tile0 + rel / SPT;
+    const int32_t s_lo = tile_pos0 + t * tile_size + (rel % SPT) * EV_SUB;
+    const int32_t b_lo = max(s_lo, c.lo), b_hi = min(s_lo + EV_SUB - 1, c.hi);
+    if (b_lo > b_hi) return;
+    const int32_t *rank = ck_rank(ws, c);
+    const int32_t w_lo = max(c.lo, b_lo - EV_MARGIN);             // LDS window of the rank array
+    if (tid == 0) { sh_k0 = INT32_MAX; sh_k1 = -1; sh_mlo = c.lo; }
+    for (int i = tid; i < 8 * EV_SUB; i += EV_NT) (&dif[0][0])[i] = 0;
+    __syncthreads();
+    {
+        int32_t kmin = INT32_MAX, kmax = -1;                         // first / last yielded rank of the block's own columns
+        for (int i = tid; i <= b_hi - w_lo; i += EV_NT) {
+            const int32_t r = rank[w_lo + i - c.lo];
+            rkw[i] = r;
+            if (r >= 0 && w_lo + i >= b_lo) { kmin = min(kmin, r); kmax = max(kmax, r); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmin = min(kmin, __shfl_xor(kmin, o, 64));
+            kmax = max(kmax, __shfl_xor(kmax, o, 64));
+        }
+        if (lane == 0) { atomicMin(&sh_k0, kmin); atomicMax(&sh_k1, kmax); }
+    }
+    __syncthreads();
+#ifdef NC_ABL_EVT_A
+    return;
+#endif
+    const int32_t k0 = sh_k0, nk = sh_k1 - k0 + 1;
+    if (sh_k1 < 0) return;                                           // no yielded column here
+    auto rk = [&](int32_t p) {                                       // (written so that the common case is a plain LDS read, not a flat load)
+        int32_t k = rkw[max(p - w_lo, 0)];
+        if (p < w_lo) k = rank[p - c.lo];
+        return k;
+    };
+    const int wmax = max(win, small_win);
+    if (wv == 0) {
+        // margin: the columns before b_lo holding the ranks k0 - (wmax - 1) .. k0 - 1 -> its first column (walk back, 64 columns a step)
+        const int32_t need = k0 - (wmax - 1);
+        int32_t mlo = c.lo;
+        for (int32_t base = b_lo - 1; base >= c.lo; base -= 64) {
+            const int32_t pos = base - lane;
+            const int32_t r = pos >= c.lo ? rk(pos) : -1;
+            const uint64_t m = __ballot(r >= 0 && r < need);       // columns already outside the margin: the nearest one ends it
+            if (m) { mlo = base - (int)__builtin_ctzll(m) + 1; break; }
+        }
+        if (lane == 0) sh_mlo = mlo;
+    }
+    __syncthreads();
+    const int32_t m_lo = sh_mlo;
+    auto qualifies = [](int32_t sl, int cls) {
+        const int32_t ln = sl < 0 ? -sl : sl;
+        const bool ins = sl > 0;
+        return cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
+    };
+    const int t_first = max(0, (m_lo - tile_pos0) / tile_size);
+    for (int tt = t_first; tt <= t; tt++) {
+        const int32_t tt_lo = tile_pos0 + tt * tile_size;
+        const int e0 = tile_off[tt], e1 = tile_off[tt + 1];
+        for (int eb0 = e0; eb0 < e1; eb0 += 256) {
+            // ---- one entry per thread: its read, the read's events in [m_lo, b_hi]
+            int cnt = 0;
+            const int e = eb0 + tid;
+            if (tid < 256 && e < e1) {
+                const nc_tile_entry ent = tile_ent[e];
+                const bool mine = tt == t_first || ent.start >= tt_lo;           // a read is taken at the first of these tiles it is listed in
+                if (mine && ent.start <= b_hi && ent.end > m_lo) {
+                    const int r = ent_read[e];
+                    const int hp = read_hap[r];
+                    if (haploid || hp == 1 || hp == 2) {
+                        const int ea = ev_off[r], eb = ev_off[r + 1];
+                        int x0 = ea, y0 = eb, x1 = ea, y1 = eb;                   // first event at or after m_lo / after b_hi: the two bisections side by side
+                        while (x0 < y0 || x1 < y1) {
+                            const int m0 = (x0 + y0) >> 1, m1 = (x1 + y1) >> 1;
+                            const int32_t p0 = x0 < y0 ? ev_pos[m0] : 0, p1 = x1 < y1 ? ev_pos[m1] : 0;
+                            if (x0 < y0) { if (p0 < m_lo) x0 = m0 + 1; else y0 = m0; }
+                            if (x1 < y1) { if (p1 <= b_hi) x1 = m1 + 1; else y1 = m1; }
+                        }
+                        cnt = x1 - x0;
+                        en_e0[tid] = x0;
+                        en_lim[tid] = x1;
+                        en_h[tid] = (uint8_t)(haploid ? 0 : hp - 1);
+                    }
+                }
+            }
+            // ---- exclusive prefix of the counts over the 256 entries
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int yv = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += yv;
+            }
+            if (lane == 63 && wv < 4) wsum[wv] = inc;
+            __syncthreads();
+            int wp = 0;
+            for (int q = 0; q < wv && q < 4; q++) wp += wsum[q];
+            if (tid < 256) en_pre[tid] = wp + inc - cnt;
+            const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tid == 0) en_pre[256] = total;
+            __syncthreads();
+            // ---- one event per thread
+#ifdef NC_ABL_EVT_B
+            if (total >= 0) { __syncthreads(); continue; }
+#endif
+            if (total <= EV_CAP) {
+                // the batch's events into LDS (independent loads), then every look-up at a neighbour is an LDS read
+                for (int idx = tid; idx < total; idx += EV_NT) {
+                    int lo = 0, hi = 255;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (en_pre[mid] <= idx) lo = mid; else hi = mid - 1;
+                    }
+                    const int ev = en_e0[lo] + (idx - en_pre[lo]);
+                    const int32_t sl = ev_len[ev];
+                    evk[idx] = rk(ev_pos[ev]);
+                    evq[idx] = (uint8_t)((qualifies(sl, 0) ? 1 : 0) | (qualifies(sl, 1) ? 2 : 0) | (qualifies(sl, 2) ? 4 : 0) | (qualifies(sl, 3) ? 8 : 0));
+                }
+                __syncthreads();
+                for (int idx = tid; idx < total; idx += EV_NT) {
+                    const int k = evk[idx], qm = evq[idx];
+                    if (k < 0 || qm == 0) continue;
+                    int lo = 0, hi = 255;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (en_pre[mid] <= idx) lo = mid; else hi = mid - 1;
+                    }
+                    const int i0 = en_pre[lo], i1 = en_pre[lo + 1], h = en_h[lo];
+#pragma unroll
+                    for (int cls = 0; cls < 4; cls++) {
+                        if (!((qm >> cls) & 1)) continue;
+                        const int w = cls < 2 ? win : small_win;
+                        bool has_prev = false, has_next = false;
+                        for (int i2 = idx - 1; i2 >= i0; i2--) {
+                            const int k2 = evk[i2];
+                            if (k2 < 0) continue;
+                            if (k - k2 > w - 1) break;
+                            if ((evq[i2] >> cls) & 1) { has_prev = true; break; }
+                        }
+                        for (int i2 = idx + 1; i2 < i1; i2++) {
+                            const int k2 = evk[i2];
+                            if (k2 < 0) continue;
+                            if (k2 - k > w - 1) break;
+                            if ((evq[i2] >> cls) & 1) { has_next = true; break; }
+                        }
+                        if (!has_prev) atomicAdd(&dif[cls * 2 + h][max(k, k0) - k0], 1);
+                        if (!has_next && max(k + w, k0) - k0 < nk) atomicAdd(&dif[cls * 2 + h][max(k + w, k0) - k0], -1);
+                    }
+                }
+            } else
+            for (int idx = tid; idx < total; idx += EV_NT) {                        // (a batch of more events than the LDS arrays hold: straight from HBM)
+                int lo = 0, hi = 255;                                             // last entry whose prefix is <= idx
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (en_pre[mid] <= idx) lo = mid; else hi = mid - 1;
+                }
+                const int j = lo, ef = en_e0[j], el = en_lim[j], h = en_h[j];
+                const int ev = ef + (idx - en_pre[j]);
+                const int32_t p = ev_pos[ev], sl = ev_len[ev];
+                const int k = rk(p);
+                if (k < 0) continue;                                              // excluded column
+#pragma unroll
+                for (int cls = 0; cls < 4; cls++) {
+                    if (!qualifies(sl, cls)) continue;
+                    const int w = cls < 2 ? win : small_win;
+                    bool has_prev = false, has_next = false;
+                    for (int e2 = ev - 1; e2 >= ef; e2--) {
+                        const int k2 = rk(ev_pos[e2]);
+                        if (k2 < 0) continue;
+                        if (k - k2 > w - 1) break;
+                        if (qualifies(ev_len[e2], cls)) { has_prev = true; break; }
+                    }
+                    for (int e2 = ev + 1; e2 < el; e2++) {
+                        const int k2 = rk(ev_pos[e2]);
+                        if (k2 < 0) continue;
+                        if (k2 - k > w - 1) break;
+                        if (qualifies(ev_len[e2], cls)) { has_next = true; break; }
+                    }
+                    // ends clipped to the block's first rank: a margin event whose own window stops short of the block may still open the
+                    // chain a later margin event continues into it (+1 and -1 on rank k0 cancel when nothing does)
+                    if (!has_prev) atomicAdd(&dif[cls * 2 + h][max(k, k0) - k0], 1);
+                    if (!has_next && max(k + w, k0) - k0 < nk) atomicAdd(&dif[cls * 2 + h][max(k + w, k0) - k0], -1);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- inclusive scan of the eight rows (two per wave) -> U[row][k0 .. k0 + nk)
+    int32_t *U = ck_diff(ws, c);
+    // a wave per row: each lane sums 16 consecutive ranks, one scan over the 64 lane totals, then the lane's 16 outputs
+    for (int row = wv; row < 8; row += EV_NT / 64) {
+        int v[EV_SUB / 64], tot = 0;
+#pragma unroll
+        for (int q = 0; q < EV_SUB / 64; q++) {
+            const int i = lane * (EV_SUB / 64) + q;
+            v[q] = i < nk ? dif[row][i] : 0;
+            tot += v[q];
+        }
+        int inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yv = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += yv;
+        }
+        int run = inc - tot;
+        int32_t *out = U + (int64_t)row * c.nd + k0 + lane * (EV_SUB / 64);
+#pragma unroll
+        for (int q = 0; q < EV_SUB / 64; q++) {
+            run += v[q];
+            if (lane * (EV_SUB / 64) + q < nk) out[q] = run;
         }
     }
 }
@@ -429,7 +704,7 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 // descriptors in `ck`, on the device at *ck_dev_out); no synchronisation
 int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
                                const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t *consumed,
-                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out)
+                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev)
 {
     const int tile = pack->tile_size;
     const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
@@ -481,7 +756,17 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     }
 #undef NC_HAP_DEPTH
     hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
-    if (ev->n_reads > 0) {
+    const bool no_tiles = getenv("NC_K7_EVENT_ATOMICS") != nullptr;                         // k_event_intervals_w + k_prefix_rows_b, for A/B checks (read per call: tests flip it)
+    const bool tiles = slot_off_dev && !impute && !no_tiles && ev->n_reads > 0 && nblk > 0 && tile % EV_SUB == 0;
+    if (tiles) {
+        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4));
+        int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p;
+        hipLaunchKernelGGL(k_entry_reads, dim3((unsigned)((pack->n_entries + 255) / 256)), dim3(256), 0, ctx->stream, pack->tile_ent, pack->n_entries,
+                           slot_off_dev, ev->n_reads, ent_read);
+        hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
+                           ent_read, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size,
+                           prm->small_win_size, prm->haploid);
+    } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
         if (per_thread)
             hipLaunchKernelGGL(k_event_intervals_b, dim3((ev->n_reads + 255) / 256), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
@@ -490,7 +775,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
             hipLaunchKernelGGL(k_event_intervals_w, dim3((ev->n_reads + 3) / 4), dim3(256), 0, ctx->stream, ev->n_reads, ev->ev_off, ev->ev_pos,
                                ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid, impute);
     }
-    hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
+    if (!tiles) hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
     hipLaunchKernelGGL(k_indel_decide_b, dim3(ng == 1 ? 512 : 64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t,
                        prm->haploid, impute, ctype);
     NC_HIP(ctx, hipGetLastError());
@@ -507,7 +792,7 @@ static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel
     std::vector<IndelChunk> ck;
     const IndelChunk *ck_dev = nullptr;
     const int8_t *ctype = nullptr;
-    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype));
+    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype, nullptr));
     const int32_t ng = (int32_t)ck.size();
     for (int32_t k = 0; k < ng;) {                                   // runs of chunks laid out back to back on the host as well
         int32_t j = k + 1;

@@ -338,3 +338,26 @@ def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement
     # positions are unique per chunk and ascending
     pos0 = r["pos"][r["chunk"] == 0]
     assert np.all(np.diff(pos0) > 0)
+
+
+@pytest.mark.gpu
+def test_tiled_event_windows_equal_the_atomic_form(monkeypatch):
+    """pass 1 of the device pipeline counts the reads with an indel event in each window in LDS, one workgroup per 1024 columns
+    (k_event_tiles: margins, clipped interval ends, reads listed in the previous tile); NC_K7_EVENT_ATOMICS=1 keeps the form the host
+    route runs (k_event_intervals_w + k_prefix_rows_b, pinned by the golden tests): same sites, same types, same tensors"""
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    eng = get_engine(0)
+    L = 2_600_000
+    pack, reads_c, info = make_indel_device_workload(eng, L, depth=30.0, seed=4711)
+    # chunks that do not sit on the tile grid, one shorter than a workgroup's 1024 columns
+    cuts = [1, 70_123, 70_900, 171_555, 300_001] + list(range(400_000, L, 100_000)) + [L]
+    chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+    new = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+    monkeypatch.setenv("NC_K7_EVENT_ATOMICS", "1")
+    old = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+    assert new["n"] == old["n"] and new["n"] > 1000
+    for key in ("pos", "chunk", "type", "phase", "ref_len", "alt_len"):
+        assert np.array_equal(np.asarray(new[key]), np.asarray(old[key])), key
+    assert bool((new["x"] == old["x"]).all())
