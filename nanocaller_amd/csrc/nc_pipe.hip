@@ -811,71 +811,123 @@ struct TensorArgs {
 
 __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
 {
-    __shared__ int32_t colv[288];
-    __shared__ int16_t mxv[288];
-    __shared__ uint16_t hist[CNS_CAP * 4];
+    // the three read sets of a site share its alignments (member bits): ONE sweep over the packed entries for the insertion widths and
+    // one for the histograms serve all sets (a sweep per set and pass read the site's entries six times: 4.5 GB per chr20-sized contig)
+    __shared__ int32_t colv[3][288];
+    __shared__ int16_t mxv[3][288];
+    __shared__ uint16_t hist[3][CNS_CAP * 4];
     __shared__ uint8_t refrow[CNS_CAP];
     __shared__ uint8_t cnsv[CNS_CAP];
-    __shared__ int32_t s_ncols, s_run;
+    __shared__ int32_t s_ncols[3], s_run;
     __shared__ int32_t wcnt[4];
     const int kl = blockIdx.x, site = p.site0 + kl;
     const int tid = threadIdx.x;
     const int n2 = p.site_n2[site];
+    const int S = p.S;
     const int64_t a0 = p.site_al0[site] - p.A0, a1 = p.site_al0[site + 1] - p.A0;
     const uint8_t *mem = p.al_member + p.A0;
     const uint8_t *s2 = p.ref_code + (p.site_pos[site] - p.ref_pos0);
-    for (int t = 0; t < p.S; t++) {
-        const int bit = p.haploid ? 1 : (1 << t);
-        const int nr = p.site_nr[site * p.S + t];
-        float *X = p.x + ((int64_t)site * p.S + t) * 5 * 128 * 2;
-        // longest insertion of the set in every slot (slot j = before reference position j; slot n2 = after the last)
-        for (int j = tid; j <= n2; j += 256) {
-            int m = 0;
-            for (int64_t a = a0; a < a1; a++)
-                if (mem[a] & bit) m = max(m, (int)((p.ent[a * p.EW + j] >> 10) & 0x3ffu));
-            mxv[j] = (int16_t)m;
+    // ---- longest insertion of every set in every slot (slot j = before reference position j; slot n2 = after the last).
+    // Eight alignments a step, loads first: a load behind a test of the one before it costs a full memory latency each
+    for (int j = tid; j <= n2; j += 256) {
+        int m[3] = {0, 0, 0};
+        for (int64_t a = a0; a < a1; a += 8) {
+            uint32_t en[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) en[u] = p.ent[min(a + u, a1 - 1) * p.EW + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (a + u >= a1) continue;
+                const int mb = mem[a + u], L = (int)((en[u] >> 10) & 0x3ffu);
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+                    if (mb & (1 << t)) m[t] = max(m[t], L);        // haploid: one set, member bit 0
+            }
         }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int j = 0; j <= n2; j++) { acc += mxv[j]; colv[j] = acc + j; }
-            s_ncols = acc + n2;
+#pragma unroll
+        for (int t = 0; t < 3; t++) mxv[t][j] = (int16_t)m[t];
+    }
+    __syncthreads();
+    // ---- column of every slot's position = running sum of the insertion widths + j: scan over the block (2 slots per thread: n2 + 1 <= 288)
+    for (int t = 0; t < S; t++) {
+        const int j0 = 2 * tid, v0 = j0 <= n2 ? mxv[t][j0] : 0, v1 = j0 + 1 <= n2 ? mxv[t][j0 + 1] : 0;
+        int inc = v0 + v1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if ((tid & 63) >= o) inc += y;
         }
+        if ((tid & 63) == 63) wcnt[tid >> 6] = inc;
         __syncthreads();
-        const int ncols = s_ncols;
-        if (ncols > CNS_CAP) {                                        // never with real windows: reported, the caller falls back
-            if (tid == 0) { atomicOr(p.err, 2); p.ncns[kl * p.S + t] = 0; }
-            for (int c = tid; c < 128 * 5; c += 256) { X[c * 2] = 0.0f; X[c * 2 + 1] = 0.0f; }
-            __syncthreads();
-            continue;
-        }
-        for (int c = tid; c < ncols * 4; c += 256) hist[c] = 0;
-        for (int c = tid; c < ncols; c += 256) refrow[c] = 4;
+        int wp = 0;
+        for (int w = 0; w < (tid >> 6); w++) wp += wcnt[w];
+        const int before = wp + inc - v0 - v1;
+        if (j0 <= n2) colv[t][j0] = before + v0 + j0;
+        if (j0 + 1 <= n2) colv[t][j0 + 1] = before + v0 + v1 + j0 + 1;
+        if (tid == 255) s_ncols[t] = wp + inc + n2;
         __syncthreads();
-        for (int j = tid; j <= n2; j += 256) {
-            const int cj = colv[j], c0 = cj - mxv[j];                 // thread j owns the columns c0 .. cj of every read
-            if (j < n2) refrow[cj] = s2[j];
-            for (int64_t a = a0; a < a1; a++) {
-                if (!(mem[a] & bit)) continue;
-                const uint8_t *s1 = p.win + a * p.WS;
-                const uint32_t en = p.ent[a * p.EW + j];
-                if (j < n2) {
-                    const int qi = (int)(en & 0x3ffu) - 1;
-                    if (qi >= 0) {
-                        const int sym = s1[qi];
-                        if (sym < 4) hist[cj * 4 + sym]++;            // anything else (a read base N) counts as a gap at its column
-                    }
+    }
+    bool ok[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) ok[t] = t < S && s_ncols[t] <= CNS_CAP;      // a longer set: never with real windows; reported, the caller falls back
+    for (int t = 0; t < S; t++)
+        if (ok[t])
+            for (int c = tid; c < s_ncols[t] * 4; c += 256) hist[t][c] = 0;
+    __syncthreads();
+    // ---- symbol histogram of every column of every set
+    for (int j = tid; j <= n2; j += 256) {
+        int cj[3], c0[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) { cj[t] = t < S ? colv[t][j] : 0; c0[t] = cj[t] - (t < S ? mxv[t][j] : 0); }   // thread j owns the columns c0 .. cj of every read
+        for (int64_t ab = a0; ab < a1; ab += 8) {
+            uint32_t en8[8];
+            int sym8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) en8[u] = p.ent[min(ab + u, a1 - 1) * p.EW + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {                             // the base aligned to position j (index clamped: unused when there is none)
+                const int qi = (int)(en8[u] & 0x3ffu) - 1;
+                sym8[u] = p.win[min(ab + u, a1 - 1) * p.WS + max(qi, 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t a = ab + u;
+                if (a >= a1) continue;
+                const int mb = mem[a];
+                const uint32_t en = en8[u];
+                if (j < n2 && (en & 0x3ffu) != 0 && sym8[u] < 4) {    // anything else (a read base N) counts as a gap at its column
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+                        if ((mb & (1 << t)) && ok[t]) hist[t][cj[t] * 4 + sym8[u]]++;
                 }
                 const int L = (int)((en >> 10) & 0x3ffu);
                 if (L > 0) {
-                    const int q0 = (int)(en >> 20);
-                    for (int u = 0; u < L; u++) {
-                        const int sym = s1[q0 + u];
-                        if (sym < 4) hist[(c0 + u) * 4 + sym]++;
+                    const uint8_t *s1 = p.win + a * p.WS + (int)(en >> 20);
+                    for (int v = 0; v < L; v++) {
+                        const int sym = s1[v];
+                        if (sym < 4) {
+#pragma unroll
+                            for (int t = 0; t < 3; t++)
+                                if ((mb & (1 << t)) && ok[t]) hist[t][(c0[t] + v) * 4 + sym]++;
+                        }
                     }
                 }
             }
         }
+    }
+    __syncthreads();
+    for (int t = 0; t < S; t++) {
+        const int nr = p.site_nr[site * S + t];
+        float *X = p.x + ((int64_t)site * S + t) * 5 * 128 * 2;
+        const int ncols = s_ncols[t];
+        if (!ok[t]) {
+            if (tid == 0) { atomicOr(p.err, 2); p.ncns[kl * S + t] = 0; }
+            for (int c = tid; c < 128 * 5; c += 256) { X[c * 2] = 0.0f; X[c * 2 + 1] = 0.0f; }
+            continue;
+        }
+        for (int c = tid; c < ncols; c += 256) refrow[c] = 4;
+        __syncthreads();
+        for (int j = tid; j < n2; j += 256) refrow[colv[t][j]] = s2[j];
         __syncthreads();
         // frequencies, consensus symbol, tensor (:57-71)
         const float tot = (float)nr;
@@ -884,7 +936,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
                 int h[5];
                 int sum = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { h[k] = hist[c * 4 + k]; sum += h[k]; }
+                for (int k = 0; k < 4; k++) { h[k] = hist[t][c * 4 + k]; sum += h[k]; }
                 h[4] = nr - sum;
                 float alt[5], best = -1e30f;
                 int arg = 0;
@@ -911,7 +963,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
         if (tid == 0) s_run = 0;
         __syncthreads();
         // consensus with the gap symbols removed (:61-64)
-        uint8_t *out = p.cns + ((int64_t)kl * p.S + t) * CNS_CAP;
+        uint8_t *out = p.cns + ((int64_t)kl * S + t) * CNS_CAP;
         for (int base = 0; base < ncols; base += 256) {
             const int c = base + tid;
             const bool f = c < ncols && cnsv[c] != 4;
@@ -928,7 +980,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
             if (tid == 0) s_run += totw;
             __syncthreads();
         }
-        if (tid == 0) p.ncns[kl * p.S + t] = s_run;
+        if (tid == 0) p.ncns[kl * S + t] = s_run;
         __syncthreads();
     }
 }
