@@ -371,7 +371,8 @@ struct FillArgs {
     const int64_t *arow;         // first traceback BLOCK (8 steps) of alignment a, or (NULL) a * tw_blocks(N1)
     int32_t N1;                  // longest read of the launch (row pitch of hcol: N1 + 1)
     uint32_t *Tw;
-    int32_t *Hlast, *hcol;       // free-tail end point inputs (NULL for a global alignment)
+    int32_t *Hlast, *hcol;       // free-tail end point inputs (NULL for a global alignment, and when `endcell` is set)
+    int2 *endcell;               // free-tail end point (i, j) of alignment a (k_end_cells), read by k_trace16p instead of Hlast / hcol
 };
 
 __device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t v)
@@ -716,6 +717,68 @@ __device__ __forceinline__ uint32_t tb_code(const uint32_t *__restrict__ Tw, int
     return ((t & 2u) ? (uint32_t)T_INS : (t & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((t & 4u) ? 0u : (uint32_t)T_EEXT) | ((t & 8u) ? 0u : (uint32_t)T_FEXT);
 }
 
+// free-tail end point of every alignment: the best cell of the last row (ties: the larger column) or a cell of the last column that is
+// strictly better (ties: the larger row) -- the order k_nw_trace16 scans them in.  16 lanes per alignment over Hlast / hcol (one lane per
+// alignment inside the traceback kernel read its ~360 values one after the other: 2.4 of that kernel's 4.5 ms)
+__global__ __launch_bounds__(256) void k_end_cells(FillArgs p)
+{
+    const int al = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const bool live = al < p.A;
+    const int a = live ? al : 0;
+    const int n1 = p.n1[a], n2 = p.site_n2[fill_site(p, a)];
+    int32_t rv = INT32_MIN, rj = 0, cv = INT32_MIN, ci = 0;
+    if (live && n1 > 0 && n2 > 0) {
+        const int32_t *hl = p.Hlast + (int64_t)a * p.W, *hc = p.hcol + (int64_t)a * (p.N1 + 1);
+        for (int j = l; j <= n2; j += 16) {
+            const int32_t v = j > 0 ? hl[j] : -p.open - (n1 - 1) * p.extend;
+            if (v >= rv) { rv = v; rj = j; }
+        }
+        for (int i = l; i < n1; i += 16) {
+            const int32_t v = i > 0 ? hc[i] : -p.open - (n2 - 1) * p.extend;
+            if (v >= cv) { cv = v; ci = i; }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int32_t ov = __shfl_xor(rv, o), oj = __shfl_xor(rj, o), pv = __shfl_xor(cv, o), pi = __shfl_xor(ci, o);
+        if (ov > rv || (ov == rv && oj > rj)) { rv = ov; rj = oj; }
+        if (pv > cv || (pv == cv && pi > ci)) { cv = pv; ci = pi; }
+    }
+    if (live && l == 0) p.endcell[al] = (n1 <= 0 || n2 <= 0) ? make_int2(n1, n2) : cv > rv ? make_int2(ci, n2) : make_int2(n1, rj);
+}
+
+// The walk of a lane reads one 4-bit code a step, each the end of a chain of dependent loads; the codes of the eight steps a lane q of
+// the fill spent on one block are 8 * NWP consecutive words, and a path stays in such a line for several steps (i-- and j-- both lower
+// t = i + q).  A lane therefore keeps the line it is in in LDS (odd pitch: no bank conflicts between lanes) and goes to HBM only when it leaves
+// it -- in EPOCHS: the lanes that need a new line load it together, then every lane walks on inside its line until none can (a lane that
+// fetched on its own whenever it left a line made the whole wave wait at nearly every step: some lane always does).
+struct TbLine {
+    uint32_t *slot;                                                    // this lane's 8 * NWP words (+1 pad) in LDS
+    int cblk, cq;                                                      // block and fill lane of the cached line (-1: none)
+    int q, c;                                                          // fill lane and cell-in-lane of column j, kept in step with j (no division per step)
+    __device__ __forceinline__ void set_j(int j, int CPL) { q = j > 0 ? (j - 1) / CPL : 0; c = j > 0 ? (j - 1) % CPL : 0; }
+    __device__ __forceinline__ void dec_j(int CPL) { if (--c < 0) { c = CPL - 1; q--; } }
+    __device__ __forceinline__ bool has(int i) const { return ((i + q) >> TWB_LOG) == cblk && q == cq; }
+    __device__ __forceinline__ void load(const uint32_t *__restrict__ Tw, int64_t arow, int i, int NWP)
+    {
+        cblk = (i + q) >> TWB_LOG;
+        cq = q;
+        const uint4 *src = reinterpret_cast<const uint4 *>(Tw + tw_word(arow, (i + q) & ~(TWB - 1), q, NWP));
+        for (int u = 0; u < TWB * NWP / 4; u++) {
+            const uint4 v = src[u];
+            slot[4 * u] = v.x; slot[4 * u + 1] = v.y; slot[4 * u + 2] = v.z; slot[4 * u + 3] = v.w;
+        }
+    }
+    // cell (i, j) of the cached line (the caller checked has(i))
+    __device__ __forceinline__ uint32_t code(int i, int NWP, int fmt) const
+    {
+        const uint32_t tc = (slot[((i + q) & (TWB - 1)) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
+        if (fmt == 0) return tc;
+        return ((tc & 2u) ? (uint32_t)T_INS : (tc & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((tc & 4u) ? 0u : (uint32_t)T_EEXT) | ((tc & 8u) ? 0u : (uint32_t)T_FEXT);
+    }
+};
+constexpr int TBL_PITCH = TWB * 4 + 1;                                 // words per lane (NWP <= 4)
+
 // traceback of a free-tail alignment into reference coordinates (nc_msa.hip k_nw_trace16): one lane per alignment.  Entry x of an
 // alignment packs, for reference position x (0-based) and the slot BEFORE it (slot n2 = after the last position):
 //     bits 0-9  read index aligned to position x, plus 1 (0 = gap)     bits 10-19  length of the insertion in slot x
@@ -725,9 +788,11 @@ __device__ __forceinline__ uint32_t tb_code(const uint32_t *__restrict__ Tw, int
 __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_t fmt, uint32_t *__restrict__ ent_all, int32_t EW)
 {
     __shared__ uint32_t stage[16 * 64];
+    __shared__ uint32_t tbl[64 * TBL_PITCH];
     const int al = blockIdx.x * 64 + threadIdx.x;
     if (al >= p.A) return;
     const int lane = threadIdx.x;
+    TbLine tb = {tbl + lane * TBL_PITCH, -1, -1, 0, 0};
     const int n1 = p.n1[al];
     const int n2 = p.site_n2[fill_site(p, al)];
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
@@ -735,7 +800,12 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
     uint32_t *ent = ent_all + (int64_t)al * EW;                       // EW: a multiple of 16 entries >= n2 + 1
     int i = n1, j = n2;
     uint32_t cur = 0;                                                  // the entry of slot j being built (position j's read index comes last)
-    if (n1 > 0 && n2 > 0) {                                           // free tail: best cell of the last row / last column
+    if (p.endcell) {
+        const int2 ec = p.endcell[al];
+        i = ec.x;
+        j = ec.y;
+        if (i < n1) cur = ((uint32_t)(n1 - i) << 10) | ((uint32_t)i << 20);
+    } else if (n1 > 0 && n2 > 0) {                                    // free tail: best cell of the last row / last column
         int32_t best = p.Hlast[(int64_t)al * p.W + n2];
         for (int jj = n2 - 1; jj >= 0; jj--) {
             const int32_t v = jj > 0 ? p.Hlast[(int64_t)al * p.W + jj] : -p.open - (n1 - 1) * p.extend;
@@ -762,18 +832,19 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
     };
     while (x > j) put(0u);                                            // (end point in the last ROW: i == n1, so cur is 0 and stays the entry of slot j)
     int state = -1;
-    while (i > 0 || j > 0) {
+    auto step = [&]() {
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else t = tb_code(p.Tw, arow, i, j, CPL, NWP, fmt);
+        else t = tb.code(i, NWP, fmt);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) {                                        // position j-1 takes read base i-1; slot j is complete
                 put(cur);
                 cur = (uint32_t)i;                                    // (i - 1) + 1: the read index of position j - 1, entry j - 1
                 i--; j--;
-                continue;
+                tb.dec_j(CPL);
+                return;
             }
             state = w == T_DEL ? 1 : 2;
         }
@@ -782,12 +853,22 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
             put(cur);                                                  // reference position j-1 stays a gap
             cur = 0;
             j--;
+            tb.dec_j(CPL);
             if (!ext) state = -1;
         } else {
             const bool ext = (t & T_FEXT) != 0;
             cur = (cur & 0x3ffu) | ((((cur >> 10) & 0x3ffu) + 1u) << 10) | ((uint32_t)(i - 1) << 20);     // il[j]++, iq[j] = i - 1
             i--;
             if (!ext) state = -1;
+        }
+    };
+    tb.set_j(j, CPL);
+    while (__any(i > 0 || j > 0)) {                                    // epochs
+        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, NWP);
+        for (;;) {                                                     // every lane walks on inside its line
+            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i));
+            if (!__any(can)) break;
+            if (can) step();
         }
     }
     put(cur);                                                          // slot 0
@@ -989,8 +1070,10 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
 __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL, int32_t fmt, const int32_t *__restrict__ site_type, int32_t win_size,
                                                         int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
 {
+    __shared__ uint32_t tbl[64 * TBL_PITCH];
     const int al = blockIdx.x * 64 + threadIdx.x;
     if (al >= p.A) return;
+    TbLine tb = {tbl + threadIdx.x * TBL_PITCH, -1, -1, 0, 0};
     const int site = fill_site(p, al);
     const uint8_t *s1 = p.s1 + (int64_t)al * p.s1_stride;
     const int n1 = p.n1[al];
@@ -1015,26 +1098,36 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
         }
     };
     int i = n1, j = n2, state = -1;
-    while (i > 0 || j > 0) {
+    auto step = [&]() {
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else t = tb_code(p.Tw, arow, i, j, CPL, NWP, fmt);
+        else t = tb.code(i, NWP, fmt);
         if (state < 0) {
             const int w = t & 3;
-            if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; continue; }
+            if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; tb.dec_j(CPL); return; }
             state = w == T_DEL ? 1 : 2;
         }
         if (state == 1) {
             push(2);
             const bool ext = (t & T_EEXT) != 0;
             j--;
+            tb.dec_j(CPL);
             if (!ext) state = -1;
         } else {
             push(1);
             const bool ext = (t & T_FEXT) != 0;
             i--;
             if (!ext) state = -1;
+        }
+    };
+    tb.set_j(j, CPL);
+    while (__any(i > 0 || j > 0)) {                                    // epochs: see TbLine
+        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, NWP);
+        for (;;) {
+            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i));
+            if (!__any(can)) break;
+            if (can) step();
         }
     }
     if (last_op >= 0 && nr < run_cap) { rop[nr] = (int16_t)last_op; rcn[nr] = (int16_t)last_cnt; nr++; }
@@ -1152,7 +1245,7 @@ struct nc_pipe_state {
     size_t al0_cap = 0;
     DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
     DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
-    struct GroupBufs { DevBuf win, n1, tw, hlast, hcol, trace, cns, ncns, arow, alt_off; } gb[2];   // two sets: group g+1 is aligned while g is reduced
+    struct GroupBufs { DevBuf win, n1, tw, hlast, hcol, endc, trace, cns, ncns, arow, alt_off; } gb[2];   // two sets: group g+1 is aligned while g is reduced
     DevBuf tw2, runs, rlen, alen, alt_pool, misc;
     hipStream_t sB = nullptr;                // second stream: traceback / tensors / alleles of group g beside the alignment fill of g + 1
     hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -1170,8 +1263,8 @@ void nc_pipe_destroy(nc_ctx *ctx)
     DevBuf *bufs[] = {&s->pc, &s->seg_pos, &s->seg_type, &s->cnt, &s->off, &s->anc_pos, &s->anc_type, &s->anc_chunk, &s->kept, &s->nuniq, &s->site_of,
                       &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
                       &s->al_site, &s->al_member, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc,
-                      &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
-                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].trace,
+                      &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].endc, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
+                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].endc, &s->gb[1].trace,
                       &s->gb[1].cns, &s->gb[1].ncns, &s->gb[1].arow, &s->gb[1].alt_off};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
@@ -1454,6 +1547,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, B.tw, Agz * (size_t)tw_per_al + 64));
         NC_TRY(nc_ensure(ctx, B.hlast, Agz * W * 4));
         NC_TRY(nc_ensure(ctx, B.hcol, Agz * (N1 + 1) * 4));
+        NC_TRY(nc_ensure(ctx, B.endc, Agz * sizeof(int2)));
         NC_TRY(nc_ensure(ctx, B.trace, Agz * EW * 4 + 64));
         NC_TRY(nc_ensure(ctx, B.cns, (size_t)ng * S * CNS_CAP));
         NC_TRY(nc_ensure(ctx, B.ncns, (size_t)ng * S * 4));
@@ -1479,7 +1573,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fa.A = Ag; fa.W = W;
         fa.open = s->scoring[0]; fa.extend = s->scoring[1]; fa.match = s->scoring[2]; fa.mismatch = s->scoring[3];
         fa.arow = nullptr; fa.N1 = N1;
-        fa.Tw = (uint32_t *)B.tw.p; fa.Hlast = (int32_t *)B.hlast.p; fa.hcol = (int32_t *)B.hcol.p;
+        fa.Tw = (uint32_t *)B.tw.p;
+        fa.Hlast = (int32_t *)B.hlast.p; fa.hcol = (int32_t *)B.hcol.p; fa.endcell = (int2 *)B.endc.p;
         if (Ag > 0) launch_fill(ctx, sA, CPL, fa);
         NC_HIP(ctx, hipGetLastError());
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[2], sA));
@@ -1495,6 +1590,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int32_t Ag = al0h[k1] - al0h[k0];
         const FillArgs &fa = fa_of[b];
         if (two) NC_HIP(ctx, hipStreamWaitEvent(sB, s->evA[b], 0));
+        if (Ag > 0) hipLaunchKernelGGL(k_end_cells, dim3((Ag + 15) / 16), dim3(256), 0, sB, fa);
         if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, sB, fa, CPL, packed_fill() ? 1 : 0, (uint32_t *)B.trace.p, EW);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], sB));
         // ---- columns, histogram, tensor, consensus
@@ -1525,7 +1621,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fb.A = nset;
         fb.open = 9; fb.extend = 1; fb.match = 20; fb.mismatch = -10;
         fb.arow = (const int64_t *)B.arow.p; fb.N1 = 0;
-        fb.Tw = (uint32_t *)s->tw2.p; fb.Hlast = nullptr; fb.hcol = nullptr;
+        fb.Tw = (uint32_t *)s->tw2.p; fb.Hlast = nullptr; fb.hcol = nullptr; fb.endcell = nullptr;
         launch_fill(ctx, sB, CPL, fb);
         int32_t *rl = (int32_t *)s->rlen.p + (size_t)k0 * S, *al = (int32_t *)s->alen.p + (size_t)k0 * S;
         hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, sB, fb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p,
