@@ -363,12 +363,39 @@ __global__ __launch_bounds__(256) void k_event_intervals_w(int32_t n_reads, cons
 // atomic adds): one workgroup per 1024 columns of a chunk.  It takes the reads of the tile index that overlap its columns (and the
 // columns before them whose windows reach in: the last wmax - 1 yielded columns), finds each read's events there by bisection, gives
 // every event to a lane, accumulates the interval ends in LDS (clipped to the block's ranks: what a read covers INSIDE the block does
-// not depend on events outside the margin), scans the eight rows and writes the finished window counts U[class, haplotype][rank]
-// -- k_prefix_rows_b has nothing left to do.  Needs the map tile entry -> read (slot_off of the wire pack): the device pipeline has
+// not depend on events outside the margin), scans the eight rows into the window counts U[class, haplotype][rank] and takes the
+// columns' decisions from them: k_prefix_rows_b and k_indel_decide_b have nothing left to do, the counts never reach HBM (2 GB
+// written and 2 GB read per chr20-sized contig) and the workspace needs no zeroing.  Needs the map tile entry -> read (slot_off of the wire pack): the device pipeline has
 // it (nc_indel_sites_plan); the host-route API keeps k_event_intervals_w.
 #ifndef NC_EV_NT
 #define NC_EV_NT 512
 #endif
+// per-column decision of :252-275 (float64 divide-and-compare, as in the reference) from the depths n0 / n1 of the two haplotypes (haploid:
+// n0 = all reads) and the window counts U(class, haplotype) at the column's rank
+template <class UF>
+__device__ __forceinline__ int8_t indel_decide(int k, int n0, int n1, UF U, int32_t mincov, double ins_t, double del_t, int32_t haploid)
+{
+    if (haploid) {
+        if (k >= 0 && n0 >= mincov && n0 > 0) {
+            double f[4];
+#pragma unroll
+            for (int cls = 0; cls < 4; cls++) f[cls] = (double)U(cls, 0) / (double)n0;
+            if (f[0] >= del_t || f[1] >= ins_t) return 0;
+            if (f[2] >= del_t || f[3] >= ins_t || (f[2] + f[3]) >= 0.9) return 1;
+        }
+    } else if (k >= 0 && n0 >= mincov && n1 >= mincov) {
+        double f[4][2];
+#pragma unroll
+        for (int cls = 0; cls < 4; cls++) {
+            f[cls][0] = n0 > 0 ? (double)U(cls, 0) / (double)n0 : 0.0;
+            f[cls][1] = n1 > 0 ? (double)U(cls, 1) / (double)n1 : 0.0;
+        }
+        if (fmax(f[0][0], f[0][1]) >= del_t || fmax(f[1][0], f[1][1]) >= ins_t) return 0;
+        if (fmax(f[2][0], f[2][1]) >= del_t || fmax(f[3][0], f[3][1]) >= ins_t || (f[2][0] + f[3][0]) >= 0.9 || (f[2][1] + f[3][1]) >= 0.9) return 1;
+    }
+    return -1;
+}
+
 constexpr int EV_SUB = 1024, EV_MARGIN = 256, EV_CAP = 2048, EV_NT = NC_EV_NT;
 
 // read index of every tile entry (its slot offset is unique): once per call, so that the blocks below do not repeat the bisection
@@ -392,7 +419,8 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                                                      const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
                                                      const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
                                                      const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win,
-                                                     int32_t small_win, int32_t haploid)
+                                                     int32_t small_win, int32_t haploid, int32_t mincov, double ins_t, double del_t,
+                                                     int8_t *__restrict__ col_type_all)
 {
     __shared__ int32_t dif[8][EV_SUB];
     __shared__ int32_t rkw[EV_SUB + EV_MARGIN];
@@ -437,7 +465,11 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     return;
 #endif
     const int32_t k0 = sh_k0, nk = sh_k1 - k0 + 1;
-    if (sh_k1 < 0) return;                                           // no yielded column here
+    int8_t *col_type = col_type_all + c.coloff;
+    if (sh_k1 < 0) {                                                 // no yielded column here
+        for (int i = b_lo + tid; i <= b_hi; i += EV_NT) col_type[i - c.lo] = -1;
+        return;
+    }
     auto rk = [&](int32_t p) {                                       // (written so that the common case is a plain LDS read, not a flat load)
         int32_t k = rkw[max(p - w_lo, 0)];
         if (p < w_lo) k = rank[p - c.lo];
@@ -594,9 +626,8 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             __syncthreads();
         }
     }
-    // ---- inclusive scan of the eight rows (two per wave) -> U[row][k0 .. k0 + nk)
-    int32_t *U = ck_diff(ws, c);
-    // a wave per row: each lane sums 16 consecutive ranks, one scan over the 64 lane totals, then the lane's 16 outputs
+    // ---- inclusive scan of the eight rows: dif becomes U[class, haplotype][rank - k0]
+    // a wave per row: each lane sums 16 consecutive ranks, one scan over the 64 lane totals, then the lane's 16 window counts (in place)
     for (int row = wv; row < 8; row += EV_NT / 64) {
         int v[EV_SUB / 64], tot = 0;
 #pragma unroll
@@ -612,12 +643,19 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             if (lane >= o) inc += yv;
         }
         int run = inc - tot;
-        int32_t *out = U + (int64_t)row * c.nd + k0 + lane * (EV_SUB / 64);
 #pragma unroll
         for (int q = 0; q < EV_SUB / 64; q++) {
             run += v[q];
-            if (lane * (EV_SUB / 64) + q < nk) out[q] = run;
+            if (lane * (EV_SUB / 64) + q < nk) dif[row][lane * (EV_SUB / 64) + q] = run;
         }
+    }
+    __syncthreads();
+    // the columns' decisions (k_indel_decide_b's, without the window counts' trip through HBM)
+    const int32_t *depth = ck_depth(ws, c);
+    for (int i = b_lo + tid; i <= b_hi; i += EV_NT) {
+        const int k = rkw[i - w_lo];
+        const int n0 = depth[i - c.lo], n1 = depth[c.ncol + (i - c.lo)];
+        col_type[i - c.lo] = indel_decide(k, n0, n1, [&](int cls, int h) { return dif[cls * 2 + h][k - k0]; }, mincov, ins_t, del_t, haploid);
     }
 }
 
@@ -654,29 +692,11 @@ __global__ void k_indel_decide_b(const IndelChunk *__restrict__ ck, char *__rest
     const int32_t *depth = ck_depth(ws, c), *rank = ck_rank(ws, c), *U = ck_diff(ws, c);
     int8_t *col_type = col_type_all + c.coloff;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncol; i += gridDim.x * blockDim.x) {
-        int8_t type = -1;
         const int k = rank[i];
         const int n0 = depth[i], n1 = depth[ncol + i];
-        if (haploid) {
-            if (k >= 0 && n0 >= mincov && n0 > 0) {
-                double f[4];
-#pragma unroll
-                for (int cls = 0; cls < 4; cls++) f[cls] = (double)U[(int64_t)(cls * 2) * nd + k] / (double)n0;
-                if (f[0] >= del_t || f[1] >= ins_t) type = 0;
-                else if (f[2] >= del_t || f[3] >= ins_t || (f[2] + f[3]) >= 0.9) type = 1;
-            }
-        } else if (k >= 0 && n0 >= mincov && n1 >= mincov) {
-            double f[4][2];
-#pragma unroll
-            for (int cls = 0; cls < 4; cls++) {
-                f[cls][0] = n0 > 0 ? (double)U[(int64_t)(cls * 2 + 0) * nd + k] / (double)n0 : 0.0;
-                f[cls][1] = n1 > 0 ? (double)U[(int64_t)(cls * 2 + 1) * nd + k] / (double)n1 : 0.0;
-            }
-            if (fmax(f[0][0], f[0][1]) >= del_t || fmax(f[1][0], f[1][1]) >= ins_t) type = 0;
-            else if (fmax(f[2][0], f[2][1]) >= del_t || fmax(f[3][0], f[3][1]) >= ins_t || (f[2][0] + f[3][0]) >= 0.9 ||
-                     (f[2][1] + f[3][1]) >= 0.9)
-                type = 1;
-        } else if (impute && k >= 0) {
+        int8_t type = indel_decide(k, n0, n1, [&](int cls, int h) { return U[(int64_t)(cls * 2 + h) * nd + k]; }, mincov, ins_t, del_t, haploid);
+        const bool ruled = haploid || (k >= 0 && n0 >= mincov && n1 >= mincov);                         // :252-275 applied; otherwise (impute_indel_phase) :278-284
+        if (!ruled && impute && k >= 0) {
             const int tot = n0 + n1 + depth[2 * (int64_t)ncol + i];
             if (tot >= 2 * mincov && tot > 0) {                                                          // :278
                 const int32_t *cnt = ck_cnt(ws, c);
@@ -714,6 +734,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     size_t wsb = 0;
     int64_t ncols = 0;
     int32_t nblk = 0, c1 = 0;
+    bool clipped = false;                                            // a chunk reaches past the pack's tile grid (columns no kernel of the tile index visits)
     for (; c1 < n_chunks; c1++) {
         IndelChunk k;
         k.lo = starts[c1] < 1 ? 1 : starts[c1];
@@ -728,6 +749,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
         k.tile0 = chi >= clo ? (clo - grid_lo) / tile : 0;
         k.blk0 = nblk;
         nblk += chi >= clo ? (chi - grid_lo) / tile - k.tile0 + 1 : 0;
+        if (k.lo < grid_lo || k.hi > grid_hi) clipped = true;
         wsb += need;
         ncols += k.ncol;
         ck.push_back(k);
@@ -737,7 +759,10 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, total = o_ck + (size_t)ng * sizeof(IndelChunk);
     NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
     char *ws = (char *)ctx->indel_ws.p;
-    NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
+    const bool no_tiles = getenv("NC_K7_EVENT_ATOMICS") != nullptr;                         // k_event_intervals_w + k_prefix_rows_b + k_indel_decide_b, for A/B checks (read per call: tests flip it)
+    const bool tiles = slot_off_dev && !impute && !no_tiles && !clipped && ev->n_reads > 0 && nblk > 0 && tile % EV_SUB == 0;
+    // the tiled form writes every word it reads (depths, ranks, window counts in LDS, decisions); the other one accumulates into zeros
+    if (!tiles) NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
     IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
     NC_TRY(nc_h2d_pieces(ctx, ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), ctx->stream));   // by copy kernel: never behind an upload in flight
     int8_t *ctype = (int8_t *)(ws + o_type);
@@ -756,8 +781,6 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     }
 #undef NC_HAP_DEPTH
     hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
-    const bool no_tiles = getenv("NC_K7_EVENT_ATOMICS") != nullptr;                         // k_event_intervals_w + k_prefix_rows_b, for A/B checks (read per call: tests flip it)
-    const bool tiles = slot_off_dev && !impute && !no_tiles && ev->n_reads > 0 && nblk > 0 && tile % EV_SUB == 0;
     if (tiles) {
         NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4));
         int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p;
@@ -765,7 +788,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
                            slot_off_dev, ev->n_reads, ent_read);
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            ent_read, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size,
-                           prm->small_win_size, prm->haploid);
+                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype);
     } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
         if (per_thread)
@@ -776,8 +799,9 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
                                ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size, prm->small_win_size, prm->haploid, impute);
     }
     if (!tiles) hipLaunchKernelGGL(k_prefix_rows_b, dim3(8, ng), dim3(1024), 0, ctx->stream, ck_dev, ws);
-    hipLaunchKernelGGL(k_indel_decide_b, dim3(ng == 1 ? 512 : 64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t,
-                       prm->haploid, impute, ctype);
+    if (!tiles)
+        hipLaunchKernelGGL(k_indel_decide_b, dim3(ng == 1 ? 512 : 64, ng), dim3(256), 0, ctx->stream, ck_dev, ws, prm->mincov, prm->ins_t, prm->del_t,
+                           prm->haploid, impute, ctype);
     NC_HIP(ctx, hipGetLastError());
     *ck_dev_out = ck_dev;
     *ctype_out = ctype;
