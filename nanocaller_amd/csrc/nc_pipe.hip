@@ -561,6 +561,13 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)  
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
     return r;
 }
+// full-rate 32-bit ops on the packed pair (the traceback bits are gathered with these: the packed 16-bit forms issue at half rate)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c)      // (a & b) | c
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t splat16(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
 __device__ __forceinline__ uint32_t dpp_shr1_u(uint32_t old, uint32_t v)
 {
@@ -610,10 +617,7 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * tw_blocks(p.N1);
     __shared__ uint32_t tw_lds[2 * TWB * 64 * NWP];
     const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match), k_mis = splat16(p.mismatch);
-    const uint32_t k_one = splat16(1), k_two = splat16(2), k_four = splat16(4);
-    uint32_t k_sh[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) k_sh[u] = splat16(-(1 << (u * 4)));
+    const uint32_t k_one = splat16(1);
     uint32_t h_out = 0, e_out = splat16(NEG16);
     uint32_t h_in_prev = splat16(q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend);     // H[0][q*CPL]
     int jn_lane[2], jn_c[2];
@@ -652,22 +656,26 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
             for (int c = 0; c < CPL; c++) {
                 const uint32_t hup = H[c], fup = F[c];
                 const uint32_t e_open = pk_sub(hleft, k_open), e_ext = pk_sub(e, k_ext);
-                const uint32_t m_e = pk_sign(pk_sub(e_ext, e_open));                 // E opened (e_ext < e_open)
+                const uint32_t d_e = pk_sub(e_ext, e_open);                          // < 0: E opened
                 e = pk_max(e_open, e_ext);
                 const uint32_t f_open = pk_sub(hup, k_open), f_ext = pk_sub(fup, k_ext);
-                const uint32_t m_f = pk_sign(pk_sub(f_ext, f_open));                 // F opened
+                const uint32_t d_f = pk_sub(f_ext, f_open);                          // < 0: F opened
                 const uint32_t f = pk_max(f_open, f_ext);
                 const uint32_t eq = pk_sign(pk_sub(c1 ^ rb[c], k_one));              // the bases match
                 const uint32_t d = pk_add(hdiag, bfi(eq, k_match, k_mis));
                 const uint32_t h1 = pk_max(d, e);
-                const uint32_t m_1 = pk_sign(pk_sub(d, e));                          // E beats the diagonal
+                const uint32_t d_1 = pk_sub(d, e);                                   // < 0: E beats the diagonal
                 const uint32_t h = pk_max(h1, f);
-                const uint32_t m_2 = pk_sign(pk_sub(h1, f));                         // F beats both
+                const uint32_t d_2 = pk_sub(h1, f);                                  // < 0: F beats both
                 H[c] = h;
                 F[c] = f;
-                // masks are -1 / 0: -(code) = m_1 + 2 m_2 + 4 (m_e + 2 m_f); folded into the row's words with a negative power of 16
-                const uint32_t neg_code = pk_mad(pk_mad(m_f, k_two, m_e), k_four, pk_mad(m_2, k_two, m_1));
-                words[c >> 2] = pk_mad(neg_code, k_sh[c & 3], words[c >> 2]);
+                // the four sign bits of each half -> its 4-bit code (d_1 bit 0, d_2 bit 1, d_e bit 2, d_f bit 3), with 32-bit shifts and
+                // and-ors (full rate; the bits of the two halves never meet), then into the row's words
+                uint32_t acc = d_1 & 0x80008000u;                                    // (the first one in ends lowest)
+                acc = and_or(d_2, 0x80008000u, acc >> 1);
+                acc = and_or(d_e, 0x80008000u, acc >> 1);
+                acc = and_or(d_f, 0x80008000u, acc >> 1);
+                words[c >> 2] |= (acc >> 12) << ((c & 3) * 4);
                 hdiag = hup;
                 hleft = h;
             }
