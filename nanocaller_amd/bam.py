@@ -273,4 +273,15 @@ def read_bam(bam_path, fasta_path, chrom, start=1, end=None, keep_seq=False, thr
     w.meta.update(events=(d["ev_off"], d["ev_pos"], d["ev_len"]), hap=d["hap"], ps=d["ps"])
     if keep_seq:
         w.meta.update(seq_off=d["seq_off"], seq=d["seq"])
+    # inputs the library does not reproduce (nc_decoded_check): counted here, under either flag filter; the pack builders refuse them
+    owner = d.get("_owner")
+    if owner is not None:
+        L = _lib.lib()
+        counts = {}
+        for supp in (False, True):
+            keep = np.ascontiguousarray(((d["read_flag"] & (0x704 if supp else 0xF04)) == 0).astype(np.uint8))
+            a, b = C.c_int64(), C.c_int64()
+            L.nc_decoded_check(owner.handle, _lib.npp(keep), C.byref(a), C.byref(b))
+            counts[supp] = (int(a.value), int(b.value))
+        w.meta["unsupported"] = counts
     return w

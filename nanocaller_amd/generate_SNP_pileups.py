@@ -92,9 +92,7 @@ def _resolve(sam_path, chrom=None, fasta_path=None, span=None) -> World:
 
         def make():
             DECODES.append((sam_path, chrom, span))
-            w = read_bam(sam_path, fasta_path, chrom) if span is None else read_bam(sam_path, fasta_path, chrom, span[0], span[1])
-            _check_supported(w, sam_path, chrom)
-            return w
+            return read_bam(sam_path, fasta_path, chrom) if span is None else read_bam(sam_path, fasta_path, chrom, span[0], span[1])
         return _BAM_WORLDS.get((sam_path, fasta_path, chrom) + ((span,) if span else ()), make)
     raise FileNotFoundError("alignments %r: not a BAM file, a World, or a registered key" % (sam_path,))
 
@@ -124,15 +122,23 @@ def _exclude_rows(dct, chrom):
     return tuple(rows)
 
 
-def _check_supported(world, sam_path, chrom):
-    """inputs the library does not reproduce are refused, not silently accepted: reference skips in the CIGAR of a read
-    the pileup keeps (the reference raises KeyError on their pileup symbols, quirk E10)"""
-    keep = (world.read_flag & 0x704) == 0                          # unmapped / secondary / qcfail / duplicate are never kept
-    n = int(np.count_nonzero(keep & ((world.read_flag & _lib.FLAG_REFSKIP) != 0)))
-    if n:
-        err = _lib.NanoCallerHipError("%s, contig %s: %d alignments with a reference skip (CIGAR N) would enter the pileup; the reference's "
-                                      "code table has no entry for their '>' / '<' symbols (generate_SNP_pileups.py:104) -- NC_ERR_UNSUPPORTED"
-                                      % (sam_path, chrom, n))
+def _check_supported(world, sam_path, chrom, supplementary=False):
+    """inputs the library does not reproduce are refused, not silently accepted (nc_decoded_check): among the alignments
+    the pileup keeps, reference skips in the CIGAR (the reference raises KeyError on their pileup symbols, quirk E10) and same-name
+    alignments that overlap on the reference (the reference's per-column dicts are keyed by name: one entry where the pack has two)"""
+    mask = 0x704 if supplementary else 0xF04                      # unmapped / secondary / qcfail / duplicate (/ supplementary) are never kept
+    keep = (world.read_flag & mask) == 0
+    n_skip = int(np.count_nonzero(keep & ((world.read_flag & _lib.FLAG_REFSKIP) != 0)))
+    n_dup = world.meta.get("unsupported", {}).get(bool(supplementary), (0, 0))[1]
+    if n_skip or n_dup:
+        what = []
+        if n_skip:
+            what.append("%d alignments with a reference skip (CIGAR N) would enter the pileup; the reference's code table has no entry for "
+                        "their '>' / '<' symbols (generate_SNP_pileups.py:104)" % n_skip)
+        if n_dup:
+            what.append("%d pairs of kept alignments carry the same read name and overlap on the reference; the reference's per-column "
+                        "dicts hold one entry per name (generate_SNP_pileups.py:175,185,208)" % n_dup)
+        err = _lib.NanoCallerHipError("%s, contig %s: %s -- NC_ERR_UNSUPPORTED" % (sam_path, chrom, "; ".join(what)))
         err.status = _lib.NC_ERR_UNSUPPORTED
         raise err
 
@@ -159,6 +165,7 @@ def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, dev
     the FASTA, the flag filter, the exclusion list and the device; the SNP and the indel path share the entry.
     span (lo, hi): only the alignments overlapping it are decoded and packed (a rank that owns part of a contig)."""
     world = _resolve(sam_path, chrom, fasta_path, span)
+    _check_supported(world, sam_path, chrom, supplementary)
     if world.chrom != chrom:
         raise ValueError("alignments of contig %r requested, the source holds %r" % (chrom, world.chrom))
     src = id(world) if isinstance(sam_path, World) else sam_path

@@ -279,10 +279,11 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
 def _prepare_wire(params, chrom, grp):
     """host half of a group's ingest, on a worker thread: decode the contig (or this rank's span of it) and build its wire pack
     in page-locked memory (what device_pack() does synchronously)"""
-    from .generate_SNP_pileups import _exclude_rows, _resolve, contig_span
+    from .generate_SNP_pileups import _check_supported, _exclude_rows, _resolve, contig_span
     from .wire import build_wire_from_world
     span = contig_span(params['sam_path'], chrom, grp)
     world = _resolve(params['sam_path'], chrom, params.get('fasta_path'), span)
+    _check_supported(world, params['sam_path'], chrom, bool(params.get('supplementary')))
     kw = dict(pos_lo=span[0], pos_hi=span[1]) if span else {}
     return build_wire_from_world(world, supplementary=bool(params.get('supplementary')), exclude=_exclude_rows(params, chrom), **kw)
 

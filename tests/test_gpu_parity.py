@@ -684,3 +684,36 @@ def test_reference_skips_are_refused_not_silently_accepted(eng, tmp_path):
         snpCaller.call_chunks(params, [dict(chrom="c", start=1, end=len(ref), ploidy="diploid")])
     assert e.value.status == _lib.NC_ERR_UNSUPPORTED
     gsp.release_contig()
+
+
+def test_same_name_overlaps_are_refused_not_silently_accepted(eng, tmp_path):
+    """two kept alignments of one read name that overlap on the reference: the reference's per-column dicts hold ONE entry per name
+    (generate_SNP_pileups.py:175,185,208), the read-major pack would count two -- NC_ERR_UNSUPPORTED (nc_decoded_check).  A supplementary
+    alignment of the same name is only in the way when the flag filter keeps supplementary alignments"""
+    from nanocaller_amd import _lib, generate_SNP_pileups as gsp, snpCaller
+    from tests import bamio
+    ref = "ACGT" * 2000
+    recs = [dict(name="r%d" % k, flag=0, pos0=100 + 7 * k, cigar=[("M", 300)], seq=ref[100 + 7 * k:400 + 7 * k]) for k in range(30)]
+    base = dict(sam_path=None, fasta_path=None, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
+                snp_model="ONT-HG002", seq="ont", supplementary=False, exclude_bed=None, disable_coverage_normalization=False)
+    chunks = [dict(chrom="c", start=1, end=len(ref), ploidy="diploid")]
+    fa = str(tmp_path / "d.fa")
+    bamio.write_fasta(fa, "c", ref)
+    # (1) the same name twice, both primary
+    bam1 = str(tmp_path / "d1.bam")
+    bamio.write_bam(bam1, "c", len(ref), sorted(recs + [dict(name="r3", flag=0, pos0=150, cigar=[("M", 200)], seq=ref[150:350])], key=lambda r: r["pos0"]))
+    gsp.release_contig()
+    with pytest.raises(_lib.NanoCallerHipError) as e:
+        snpCaller.call_chunks(dict(base, sam_path=bam1, fasta_path=fa), chunks)
+    assert e.value.status == _lib.NC_ERR_UNSUPPORTED and "same read name" in str(e.value)
+    # (2) the second one flagged supplementary: dropped by the default filter, refused with dct['supplementary']
+    bam2 = str(tmp_path / "d2.bam")
+    bamio.write_bam(bam2, "c", len(ref), sorted(recs + [dict(name="r3", flag=0x800, pos0=150, cigar=[("M", 200)], seq=ref[150:350])], key=lambda r: r["pos0"]))
+    gsp.release_contig()
+    res = snpCaller.call_chunks(dict(base, sam_path=bam2, fasta_path=fa), chunks)
+    assert res["n"] >= 0
+    gsp.release_contig()
+    with pytest.raises(_lib.NanoCallerHipError) as e:
+        snpCaller.call_chunks(dict(base, sam_path=bam2, fasta_path=fa, supplementary=True), chunks)
+    assert e.value.status == _lib.NC_ERR_UNSUPPORTED
+    gsp.release_contig()
