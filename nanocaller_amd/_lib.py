@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("NANOCALLER_HIP_LIB") or os.path.join(_HERE, "libnanoc
 
 NC_OK = 0
 NC_ERR_CAPACITY = -2
+NC_ERR_NOMEM = -3
 NC_ERR_UNSUPPORTED = -7
 FLAG_REFSKIP = 0x10000   # nc_decoded_arrays.flag bit: the CIGAR holds a reference skip
 ABI_VERSION = 8          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for

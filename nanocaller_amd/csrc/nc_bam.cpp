@@ -86,6 +86,7 @@ struct Bgzf {
         void *(*alloc)() = nullptr;
         int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
         uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+        void (*free_dec)(void *) = nullptr;
     };
     static const Deflate &deflate_lib()
     {
@@ -98,6 +99,7 @@ struct Bgzf {
             d.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
             d.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
             d.crc32 = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+            d.free_dec = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
             d.ok = d.alloc && d.decompress && d.crc32;
             return d;
         }();
@@ -111,8 +113,15 @@ struct Bgzf {
         // in this image, so its four entry points are bound at run time.  zlib otherwise.
         const Deflate &D = deflate_lib();
         if (D.ok) {
-            thread_local void *dec = nullptr;
-            if (!dec) dec = D.alloc();
+            // one decompressor per thread, released when the thread ends (decode threads live for one call)
+            struct Dec {
+                void *p = nullptr;
+                void (*free_fn)(void *) = nullptr;
+                ~Dec() { if (p && free_fn) free_fn(p); }
+            };
+            thread_local Dec tl;
+            if (!tl.p) { tl.p = D.alloc(); tl.free_fn = D.free_dec; }
+            void *dec = tl.p;
             size_t got = 0;
             if (dec && D.decompress(dec, k.comp.data(), (size_t)k.clen, k.data.data(), (size_t)k.isize, &got) == 0 && got == (size_t)k.isize) {
                 if (D.crc32(0, k.data.data(), (size_t)k.isize) != k.crc) k.ok = false;

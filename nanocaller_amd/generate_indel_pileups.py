@@ -239,9 +239,11 @@ def allele_prediction_batch(alts, ref_seqs, max_ranges, eng=None):
     rc = _lib.NC_ERR_CAPACITY
     if eng is not None:
         rc = L.nc_allele_prediction_device(eng.ctx, n, a_b, _lib.npp(aoff), r_b, _lib.npp(roff), _lib.npp(mr), _lib.npp(rl), _lib.npp(al))
-        if rc not in (_lib.NC_OK, _lib.NC_ERR_CAPACITY):
+        if rc not in (_lib.NC_OK, _lib.NC_ERR_CAPACITY, _lib.NC_ERR_NOMEM):
             raise _lib.NanoCallerHipError("nc_allele_prediction_device failed (%d): %s" % (rc, eng.last_error() if hasattr(eng, "last_error") else ""))
-    if rc == _lib.NC_ERR_CAPACITY:
+    # (a batch whose traceback does not fit the device call -- one very long consensus sizes every row of it -- goes to the host aligner
+    # like one beyond the kernel's shapes: same results)
+    if rc in (_lib.NC_ERR_CAPACITY, _lib.NC_ERR_NOMEM):
         rc = L.nc_allele_prediction_batch(n, a_b, _lib.npp(aoff), r_b, _lib.npp(roff), _lib.npp(mr), _lib.npp(rl), _lib.npp(al))
     if rc != _lib.NC_OK:
         raise _lib.NanoCallerHipError("nc_allele_prediction_batch failed (%d)" % rc)
@@ -447,8 +449,8 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
     if extra_variants:
         if ctg["name_idx"] is None:
             ctg["name_idx"] = {}
-            for i, nm in enumerate(dec["names"]):
-                ctg["name_idx"].setdefault(nm, i)
+            for i, nm in enumerate(dec["names"]):                     # every alignment of a name (the reference's collections are by name:
+                ctg["name_idx"].setdefault(nm, []).append(i)            # a supplementary alignment at the anchor belongs to its read's side)
         nidx = ctg["name_idx"]
         imp_idx = np.full(len(anchors), -1, np.int32)
         offs, reads = [0], []
@@ -457,7 +459,8 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
             if key in extra_variants:
                 imp_idx[k] = (len(offs) - 1) // 2
                 for side in extra_variants[key]:
-                    reads.extend(nidx[n] for n in side)
+                    for n in side:
+                        reads.extend(nidx[n])
                     offs.append(len(reads))
         imp_off = np.ascontiguousarray(offs, np.int32)
         imp_reads = np.ascontiguousarray(reads if reads else [0], np.int32)
