@@ -193,7 +193,7 @@ def read_fasta(path, chrom):
     return "".join(seq)
 
 
-def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=None, min_region=500_000):
+def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=None, min_region=125_000):
     """BamFile.decode of a long interval as parallel regions (nc_bam_decode_regions): each host thread opens its own handle,
     seeks through the .bai linear index and decodes the alignments that START in its region (the first region also takes
     those that merely overlap its left edge); inflate, CIGAR walk, tag parsing and the merge into one set of arrays all run
@@ -205,6 +205,7 @@ def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=
     end = tid_len if end is None else min(int(end), tid_len)
     start = max(1, int(start))
     threads = threads or min(64, usable_cpus())
+    min_region = int(os.environ.get("NANOCALLER_DECODE_MIN_REGION", min_region))
     n_reg = min(threads, max(1, (end - start + 1) // min_region))
     if n_reg <= 1 or not has_index:
         bf = BamFile(bam_path)
