@@ -12,7 +12,7 @@ agg = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(set)
 for r in rows:
     name = r.get("Kernel_Name", "")
-    m = re.search(r"\(anonymous namespace\)::(k[0-9]?_[a-z0-9_]+(<[^>]*>)?)", name)
+    m = re.search(r"\(anonymous namespace\)::(k[0-9]*_[a-z0-9_]+(<[^>]*>)?)", name)
     if not m or "at::native" in name:
         continue
     k = m.group(1)

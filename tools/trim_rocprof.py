@@ -7,9 +7,9 @@ import sys
 
 rows = list(csv.reader(open(sys.argv[1])))
 hdr, body = rows[0], rows[1:]
-pat = re.compile(r"\(anonymous namespace\)::(k[0-9]?_[a-z0-9_]+(<[^>]*>)?)")
+pat = re.compile(r"\(anonymous namespace\)::(k[0-9]*_[a-z0-9_]+(<[^>]*>)?)")
 ours, other = [], []
-pat_mangled = re.compile(r"_ZN12_GLOBAL__N_1\d+(k[0-9]?_[a-z0-9_]+?)(I[A-Za-z0-9_]*E)?v?P")     # kernels rocprofv3 left mangled
+pat_mangled = re.compile(r"_ZN12_GLOBAL__N_1\d+(k[0-9]*_[a-z0-9_]+?)(I[A-Za-z0-9_]*E)?v?P")     # kernels rocprofv3 left mangled
 for r in body:
     m = pat.search(r[0]) or pat_mangled.search(r[0])
     if m and "at::native" not in r[0]:
