@@ -463,6 +463,20 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
         "k9_indel_cnn": {"ms": float(k9_ms), "bound": "mfma", "achieved": k9_tf, "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                          "frac": k9_tf / (F16_MFMA_PEAK_TFLOPS / 3.0), "sites_per_s": n_sites / (k9_ms * 1e-3)},
     }
+    # HBM bytes by counter (committed FETCH_SIZE / WRITE_SIZE passes of tools/bench_indel_pipe.py -> profiles/indel_traffic.json, bytes per
+    # candidate site): `traffic` per pass of this run; the fill's counters cover both of its launches (star alignment + allele alignment)
+    try:
+        with open(os.path.join(ROOT, "profiles", "indel_traffic.json")) as f:
+            it = json.load(f)
+        for name, st in stages.items():
+            key = "fill (star alignment + allele alignment)" if name == "star_alignment_fill" else name
+            if key in it["stages"]:
+                st["traffic"] = it["stages"][key]["bytes_per_site"] * n_sites
+                st["traffic_note"] = "HBM bytes per pass = bytes per candidate site by counter (%s) x sites of this run" % it.get("source", "profiles/indel_traffic.json")
+                if st.get("bound") == "hbm" and st["ms"] > 0:
+                    st["traffic_GBs"] = st["traffic"] / (st["ms"] * 1e-3) / 1e9
+    except (OSError, ValueError, KeyError):
+        pass
     # ---- in-run parity on a sample: pass 2 restated from SAM-like records by the oracle (CIGAR expansion, host star alignment, msa() in C)
     hi = 40_000
     r1 = int(np.searchsorted(info["read_start"], hi + 400))
