@@ -126,19 +126,27 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
     int e = e0;
     while (e < e1) {
         const int lim = min(e1, e + 255);
-        for (; e < lim; e++) {
+#pragma unroll 8
+        for (; e < lim; e++) {                                         // (eight reads' loads in flight, as in k_scan)
             const nc_tile_entry ent = tile_ent[e];
             const int32_t slo = ent.start & ~15, shi = (ent.end + 15) & ~15;
             uint4 v = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
             if (P0 >= slo && P0 < shi) v = *reinterpret_cast<const uint4 *>(codes + (ent.base_flag & ~int64_t(15)) + P0);
-            const int hp = (int)((ent.base_flag >> 1) & 3);           // wave-uniform
+            const int hp = __builtin_amdgcn_readfirstlane((int)((ent.base_flag >> 1) & 3));           // wave-uniform: the plane is chosen by scalar branches
             const int plane = (STAR || haploid) ? 0 : hp == 1 ? 0 : hp == 2 ? 1 : 2;       // haploid: one read set, tags ignored
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t pres[4];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t pres = STAR ? lut8i(w[d], 0u, 0x00000001u) : lut8i(w[d], 0x01010101u, 0x00000001u);   // code 4 | codes 0..4 -> 1
+            for (int d = 0; d < 4; d++) pres[d] = STAR ? lut8i(w[d], 0u, 0x00000001u) : lut8i(w[d], 0x01010101u, 0x00000001u);   // code 4 | codes 0..4 -> 1
+            if (STAR || plane == 0) {
 #pragma unroll
-                for (int q = 0; q < (STAR ? 1 : 3); q++) acc[q][d] += plane == q ? pres : 0u;
+                for (int d = 0; d < 4; d++) acc[0][d] += pres[d];
+            } else if (plane == 1) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) acc[1][d] += pres[d];
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; d++) acc[2][d] += pres[d];
             }
         }
 #pragma unroll
@@ -150,13 +158,24 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
                 acc[q][d] = 0;
             }
     }
+    // a lane holds 16 consecutive positions: through LDS (17-word pitch) so that a store instruction writes 64 consecutive positions
+    // (a lane storing its own 16 made every instruction 64 four-byte pieces of 64 different lines: 1.26 GB written for 0.77)
+    __shared__ int32_t tr[STAR ? 1 : 3][BLOCK * 17];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int32_t p = P0 + i;
-        if (p < lo || p > hi) continue;
         const int d = i >> 2, k = i & 3, wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
 #pragma unroll
-        for (int q = 0; q < (STAR ? 1 : 3); q++) depth[(int64_t)q * ncol + (p - lo)] = (int32_t)((wide[q][wi] >> sh) & 0xFFFF);
+        for (int q = 0; q < (STAR ? 1 : 3); q++) tr[q][threadIdx.x * 17 + i] = (int32_t)((wide[q][wi] >> sh) & 0xFFFF);
+    }
+    __syncthreads();
+    const int32_t T0 = tile_pos0 + t * TILE;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int j = r * BLOCK + threadIdx.x;                        // position T0 + j = lane j / 16, element j % 16
+        const int32_t p = T0 + j;
+        if (p < lo || p > hi) continue;
+#pragma unroll
+        for (int q = 0; q < (STAR ? 1 : 3); q++) depth[(int64_t)q * ncol + (p - lo)] = tr[q][(j >> 4) * 17 + (j & 15)];
     }
 }
 
