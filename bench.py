@@ -316,11 +316,13 @@ def extra_snp_config(eng, uploader, local, L, depth, tech, model, ploidy, exact_
         eng.set_cnn_precision(exact_fp32=False)
 
 
-# issue rate of the packed 16-bit VALU instructions the alignment fill is made of (tools/ubench/valu_rate.hip on MI355X: 1.83 ns per
-# wave-instruction per SIMD at 4 waves per SIMD = half the rate of v_sub_u32); 25 of them advance two DP cells in each of 64 lanes
-VALU_PK_NS = 1.83
-FILL_INSTR_PER_CELL_PAIR = 25
-FILL_PEAK_CELLS_S = 256 * 4 / (VALU_PK_NS * 1e-9) * 64 * 2 / FILL_INSTR_PER_CELL_PAIR
+# issue rates of the vector instructions the alignment fill is made of (tools/ubench/valu_rate.hip on MI355X, per wave-instruction and SIMD at
+# 4 waves per SIMD): packed 16-bit 1.83 ns, plain 32-bit 1.1 ns.  k_fill16q's cell body (two DP cells in each of 64 lanes): 14 packed
+# (7 v_pk_sub, 4 v_pk_max, v_pk_min_u16, v_pk_mad, v_pk_add) + 10 plain (xor, and, 4 shifts, 3 and-or, shift-or) instructions
+VALU_PK_NS, VALU_NS = 1.83, 1.1
+FILL_INSTR_PK, FILL_INSTR_PLAIN = 14, 10
+FILL_INSTR_PER_CELL_PAIR = FILL_INSTR_PK + FILL_INSTR_PLAIN
+FILL_PEAK_CELLS_S = 256 * 4 * 64 * 2 / ((FILL_INSTR_PK * VALU_PK_NS + FILL_INSTR_PLAIN * VALU_NS) * 1e-9)
 
 
 def _indel_wire(eng, pack, reads_c, info):
@@ -454,8 +456,8 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
                           "frac": gbs(win_bytes, ms[1]) / HBM_PEAK_GBS},
         "star_alignment_fill": {"ms": float(ms[2]), "bound": "valu issue", "dp_cells": int(cells[0]), "achieved_cells_s": fill_cells_s,
                                 "peak_cells_s": FILL_PEAK_CELLS_S, "frac": fill_cells_s / FILL_PEAK_CELLS_S,
-                                "peak_note": "1024 SIMDs / %.2f ns per packed 16-bit VALU instruction (tools/ubench/valu_rate.hip) x 128 cells per %d instructions"
-                                             % (VALU_PK_NS, FILL_INSTR_PER_CELL_PAIR)},
+                                "peak_note": "1024 SIMDs x 128 cells per (%d packed 16-bit instructions x %.2f ns + %d plain x %.1f ns; tools/ubench/valu_rate.hip): "
+                                             "the issue time of the kernel's own cell body" % (FILL_INSTR_PK, VALU_PK_NS, FILL_INSTR_PLAIN, VALU_NS)},
         "star_alignment_traceback": {"ms": float(ms[3]), "bound": "latency (one dependent 4-bit code per step and alignment)"},
         "k8_tensors_consensus": {"ms": float(ms[4]), "bound": "hbm", "algorithmic_bytes": int(k8_bytes), "achieved_GBs": gbs(k8_bytes, ms[4]),
                                  "frac": gbs(k8_bytes, ms[4]) / HBM_PEAK_GBS},

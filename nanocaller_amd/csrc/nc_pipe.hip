@@ -542,7 +542,9 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
 // register and every recurrence is ONE packed 16-bit instruction for both (v_pk_sub_i16, v_pk_max_i16, ...).  The kernel is bound
 // by vector issue (k_fill16p: 23.5 VALU per cell, ~70 % of the issue rate): packing halves the instructions per cell.
 // Traceback bits (format 1, decoded by tb_code): bit 0 = E beats the diagonal, bit 1 = F beats both, bit 2 = E opened, bit 3 = F opened
-// -- the raw sign bits of four differences, folded by multiply-adds; the decisions are those of k_fill16p (same ties).
+// -- the raw sign bits of four differences, gathered by 32-bit and-ors; the decisions are those of k_fill16p (same ties).  22.6 vector
+// instructions per cell pair: the registers hold H - open (what E's and F's openings need; the diagonal's `open` is folded into the score),
+// the score is match + (mismatch - match) * min(base xor base, 1).
 constexpr int NEG16 = -20000;              // "minus infinity": never selected, and NEG16 - extend - (any score) stays inside int16
 
 // packed 16-bit VALU (two alignments per register).  Inline assembly: written as vector C the compiler turns the sign-mask
@@ -557,23 +559,12 @@ constexpr int NEG16 = -20000;              // "minus infinity": never selected, 
 NC_PK2(pk_sub, "v_pk_sub_i16")
 NC_PK2(pk_add, "v_pk_add_i16")
 NC_PK2(pk_max, "v_pk_max_i16")
+NC_PK2(pk_min_u, "v_pk_min_u16")
 #undef NC_PK2
-__device__ __forceinline__ uint32_t pk_sign(uint32_t a)                    // 0xffff in every half that is negative
-{
-    uint32_t r;
-    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));    // the inline constant lives in the low half: both halves shift by it
-    return r;
-}
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)     // a * b + c per half (low 16 bits)
 {
     uint32_t r;
     asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)      // (a & mask) | (b & ~mask)
-{
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
     return r;
 }
 // full-rate 32-bit ops on the packed pair (the traceback bits are gathered with these: the packed 16-bit forms issue at half rate)
@@ -619,8 +610,8 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int j = q * CPL + c + 1;
-        H[c] = splat16(-p.open - (j - 1) * p.extend);         // row 0
-        F[c] = splat16(NEG16);
+        H[c] = splat16(-2 * p.open - (j - 1) * p.extend);     // row 0.  H[] holds H - open throughout: that is what both the cell to the
+        F[c] = splat16(NEG16);                                 // right (E's opening) and the cell below (F's) need; the diagonal adds `open` back inside the score
         const uint32_t r0 = j <= n2[0] ? (uint32_t)s2[0][j - 1] : 8u, r1 = j <= n2[1] ? (uint32_t)s2[1][j - 1] : 8u;     // 8: no read base equals it
         rb[c] = r0 | (r1 << 16);
     }
@@ -631,10 +622,10 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
 #pragma unroll
     for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * tw_blocks(p.N1);
     __shared__ uint32_t tw_lds[2 * TWB * 64 * NWP];
-    const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match), k_mis = splat16(p.mismatch);
+    const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match + p.open), k_dmis = splat16(p.mismatch - p.match);
     const uint32_t k_one = splat16(1);
     uint32_t h_out = 0, e_out = splat16(NEG16);
-    uint32_t h_in_prev = splat16(q == 0 ? 0 : -p.open - (q * CPL - 1) * p.extend);     // H[0][q*CPL]
+    uint32_t h_in_prev = splat16(q == 0 ? -p.open : -2 * p.open - (q * CPL - 1) * p.extend);     // H[0][q*CPL] - open
     int jn_lane[2], jn_c[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) { jn_lane[k] = (n2[k] - 1) / CPL; jn_c[k] = (n2[k] - 1) % CPL; }
@@ -659,7 +650,7 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
         if (q == 0) c1 = c_new;
         uint32_t nh = dpp_shr1_u(0u, h_out), ne = dpp_shr1_u(splat16(NEG16), e_out);
         if (q == 0) {
-            nh = splat16(-p.open - (i - 1) * p.extend);       // H[i][0]
+            nh = splat16(-2 * p.open - (i - 1) * p.extend);   // H[i][0] - open
             ne = splat16(NEG16);
         }
         if (i >= 1) {                                          // rows beyond a read's end compute values nothing reads
@@ -670,18 +661,19 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 const uint32_t hup = H[c], fup = F[c];
-                const uint32_t e_open = pk_sub(hleft, k_open), e_ext = pk_sub(e, k_ext);
-                const uint32_t d_e = pk_sub(e_ext, e_open);                          // < 0: E opened
-                e = pk_max(e_open, e_ext);
-                const uint32_t f_open = pk_sub(hup, k_open), f_ext = pk_sub(fup, k_ext);
-                const uint32_t d_f = pk_sub(f_ext, f_open);                          // < 0: F opened
-                const uint32_t f = pk_max(f_open, f_ext);
-                const uint32_t eq = pk_sign(pk_sub(c1 ^ rb[c], k_one));              // the bases match
-                const uint32_t d = pk_add(hdiag, bfi(eq, k_match, k_mis));
+                const uint32_t e_ext = pk_sub(e, k_ext);                             // (E's opening = hleft, F's = hup: both already H - open)
+                const uint32_t d_e = pk_sub(e_ext, hleft);                           // < 0: E opened
+                e = pk_max(hleft, e_ext);
+                const uint32_t f_ext = pk_sub(fup, k_ext);
+                const uint32_t d_f = pk_sub(f_ext, hup);                             // < 0: F opened
+                const uint32_t f = pk_max(hup, f_ext);
+                const uint32_t ne_b = pk_min_u(c1 ^ rb[c], k_one);                   // 1: the bases differ
+                const uint32_t d = pk_add(hdiag, pk_mad(ne_b, k_dmis, k_match));     // (H - open of the diagonal) + score + open
                 const uint32_t h1 = pk_max(d, e);
                 const uint32_t d_1 = pk_sub(d, e);                                   // < 0: E beats the diagonal
-                const uint32_t h = pk_max(h1, f);
+                const uint32_t hh = pk_max(h1, f);
                 const uint32_t d_2 = pk_sub(h1, f);                                  // < 0: F beats both
+                const uint32_t h = pk_sub(hh, k_open);
                 H[c] = h;
                 F[c] = f;
                 // the four sign bits of each half -> its 4-bit code (d_1 bit 0, d_2 bit 1, d_e bit 2, d_f bit 3), with 32-bit shifts and
@@ -713,12 +705,12 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
                     uint32_t hv = H[0];
 #pragma unroll
                     for (int c = 1; c < CPL; c++) hv = c == jn_c[k] ? H[c] : hv;
-                    p.hcol[(int64_t)al[k] * (p.N1 + 1) + i] = half_of(hv, k);
+                    p.hcol[(int64_t)al[k] * (p.N1 + 1) + i] = half_of(hv, k) + p.open;
                 }
                 if (p.Hlast && i == n1[k]) {
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
-                        if (q * CPL + c + 1 <= n2[k]) p.Hlast[(int64_t)al[k] * p.W + q * CPL + c + 1] = half_of(H[c], k);
+                        if (q * CPL + c + 1 <= n2[k]) p.Hlast[(int64_t)al[k] * p.W + q * CPL + c + 1] = half_of(H[c], k) + p.open;
                 }
             }
             h_in_prev = nh;
