@@ -439,9 +439,13 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                                                      const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
                                                      const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win,
                                                      int32_t small_win, int32_t haploid, int32_t mincov, double ins_t, double del_t,
-                                                     int8_t *__restrict__ col_type_all)
+                                                     int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits)
 {
-    __shared__ int32_t dif[8][EV_SUB];
+    // interval ends per (class, haplotype) row and rank as 16-bit fields, two ranks per word, each biased by 0x4000: +1 is an atomic add and
+    // -1 an atomic SUBTRACT of the field's unit, so neither carries into the neighbour field (16 KB instead of 32: a fourth workgroup per CU)
+    __shared__ uint32_t difw[8][EV_SUB / 2];
+    auto dif_add = [&](int row, int i) { atomicAdd(&difw[row][i >> 1], 1u << (16 * (i & 1))); };
+    auto dif_sub = [&](int row, int i) { atomicSub(&difw[row][i >> 1], 1u << (16 * (i & 1))); };
     __shared__ int32_t rkw[EV_SUB + EV_MARGIN];
     __shared__ int32_t en_e0[256], en_pre[257], en_lim[256];
     __shared__ uint8_t en_h[256];
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     const int32_t *rank = ck_rank(ws, c);
     const int32_t w_lo = max(c.lo, b_lo - EV_MARGIN);             // LDS window of the rank array
     if (tid == 0) { sh_k0 = INT32_MAX; sh_k1 = -1; sh_mlo = c.lo; }
-    for (int i = tid; i < 8 * EV_SUB; i += EV_NT) (&dif[0][0])[i] = 0;
+    for (int i = tid; i < 8 * EV_SUB / 2; i += EV_NT) (&difw[0][0])[i] = 0x40004000u;
     __syncthreads();
     {
         int32_t kmin = INT32_MAX, kmax = -1;                         // first / last yielded rank of the block's own columns
@@ -518,6 +522,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     for (int tt = t_first; tt <= t; tt++) {
         const int32_t tt_lo = tile_pos0 + tt * tile_size;
         const int e0 = tile_off[tt], e1 = tile_off[tt + 1];
+        if (e1 - e0 > 16000 && tid == 0) atomicOr(err_bits, 8);    // more reads than a 16-bit field counts interval ends for: the caller takes the other route
         for (int eb0 = e0; eb0 < e1; eb0 += 256) {
             // ---- one entry per thread: its read, the read's events in [m_lo, b_hi]
             int cnt = 0;
@@ -603,8 +608,8 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                             if (k2 - k > w - 1) break;
                             if ((evq[i2] >> cls) & 1) { has_next = true; break; }
                         }
-                        if (!has_prev) atomicAdd(&dif[cls * 2 + h][max(k, k0) - k0], 1);
-                        if (!has_next && max(k + w, k0) - k0 < nk) atomicAdd(&dif[cls * 2 + h][max(k + w, k0) - k0], -1);
+                        if (!has_prev) dif_add(cls * 2 + h, max(k, k0) - k0);
+                        if (!has_next && max(k + w, k0) - k0 < nk) dif_sub(cls * 2 + h, max(k + w, k0) - k0);
                     }
                 }
             } else
@@ -638,8 +643,8 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                     }
                     // ends clipped to the block's first rank: a margin event whose own window stops short of the block may still open the
                     // chain a later margin event continues into it (+1 and -1 on rank k0 cancel when nothing does)
-                    if (!has_prev) atomicAdd(&dif[cls * 2 + h][max(k, k0) - k0], 1);
-                    if (!has_next && max(k + w, k0) - k0 < nk) atomicAdd(&dif[cls * 2 + h][max(k + w, k0) - k0], -1);
+                    if (!has_prev) dif_add(cls * 2 + h, max(k, k0) - k0);
+                    if (!has_next && max(k + w, k0) - k0 < nk) dif_sub(cls * 2 + h, max(k + w, k0) - k0);
                 }
             }
             __syncthreads();
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
 #pragma unroll
         for (int q = 0; q < EV_SUB / 64; q++) {
             const int i = lane * (EV_SUB / 64) + q;
-            v[q] = i < nk ? dif[row][i] : 0;
+            v[q] = i < nk ? (int)((difw[row][i >> 1] >> (16 * (i & 1))) & 0xffffu) - 0x4000 : 0;
             tot += v[q];
         }
         int inc = tot;
@@ -662,10 +667,11 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             if (lane >= o) inc += yv;
         }
         int run = inc - tot;
-#pragma unroll
+        uint16_t *U16 = reinterpret_cast<uint16_t *>(&difw[row][0]);        // the window counts (0 .. reads of the block) over the fields they came from:
+#pragma unroll                                                        // a lane rewrites the 16 ranks (8 words) it has just read
         for (int q = 0; q < EV_SUB / 64; q++) {
             run += v[q];
-            if (lane * (EV_SUB / 64) + q < nk) dif[row][lane * (EV_SUB / 64) + q] = run;
+            U16[lane * (EV_SUB / 64) + q] = (uint16_t)run;
         }
     }
     __syncthreads();
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     for (int i = b_lo + tid; i <= b_hi; i += EV_NT) {
         const int k = rkw[i - w_lo];
         const int n0 = depth[i - c.lo], n1 = depth[c.ncol + (i - c.lo)];
-        col_type[i - c.lo] = indel_decide(k, n0, n1, [&](int cls, int h) { return dif[cls * 2 + h][k - k0]; }, mincov, ins_t, del_t, haploid);
+        col_type[i - c.lo] = indel_decide(k, n0, n1, [&](int cls, int h) { return (int)reinterpret_cast<const uint16_t *>(&difw[cls * 2 + h][0])[k - k0]; }, mincov, ins_t, del_t, haploid);
     }
 }
 
@@ -743,7 +749,8 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 // descriptors in `ck`, on the device at *ck_dev_out); no synchronisation
 int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
                                const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t *consumed,
-                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev)
+                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev,
+                               int32_t *err_bits_dev)
 {
     const int tile = pack->tile_size;
     const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
@@ -779,7 +786,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
     char *ws = (char *)ctx->indel_ws.p;
     const bool no_tiles = getenv("NC_K7_EVENT_ATOMICS") != nullptr;                         // k_event_intervals_w + k_prefix_rows_b + k_indel_decide_b, for A/B checks (read per call: tests flip it)
-    const bool tiles = slot_off_dev && !impute && !no_tiles && !clipped && ev->n_reads > 0 && nblk > 0 && tile % EV_SUB == 0;
+    const bool tiles = slot_off_dev && err_bits_dev && !impute && !no_tiles && !clipped && ev->n_reads > 0 && nblk > 0 && tile % EV_SUB == 0;
     // the tiled form writes every word it reads (depths, ranks, window counts in LDS, decisions); the other one accumulates into zeros
     if (!tiles) NC_HIP(ctx, hipMemsetAsync(ws, 0, o_type, ctx->stream));
     IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
@@ -807,7 +814,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
                            slot_off_dev, ev->n_reads, ent_read);
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            ent_read, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size,
-                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype);
+                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev);
     } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
         if (per_thread)
@@ -835,7 +842,7 @@ static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel
     std::vector<IndelChunk> ck;
     const IndelChunk *ck_dev = nullptr;
     const int8_t *ctype = nullptr;
-    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype, nullptr));
+    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype, nullptr, nullptr));
     const int32_t ng = (int32_t)ck.size();
     for (int32_t k = 0; k < ng;) {                                   // runs of chunks laid out back to back on the host as well
         int32_t j = k + 1;
