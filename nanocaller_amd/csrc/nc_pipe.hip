@@ -905,13 +905,16 @@ struct TensorArgs {
     int32_t *err;
 };
 
+// HT: the histogram's counter type -- a read set holds at most maxcov reads, so bytes do for maxcov <= 255 (the reference's default is 160)
+// and the kernel's LDS drops from 31 to 19 KB: eight workgroups per CU instead of five (3.1 -> 2.x ms; the kernel waits on memory)
+template <class HT>
 __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
 {
     // the three read sets of a site share its alignments (member bits): ONE sweep over the packed entries for the insertion widths and
     // one for the histograms serve all sets (a sweep per set and pass read the site's entries six times: 4.5 GB per chr20-sized contig)
     __shared__ int32_t colv[3][288];
     __shared__ int16_t mxv[3][288];
-    __shared__ uint16_t hist[3][CNS_CAP * 4];
+    __shared__ HT hist[3][CNS_CAP * 4];
     __shared__ uint8_t refrow[CNS_CAP];
     __shared__ uint8_t cnsv[CNS_CAP];
     __shared__ int32_t s_ncols[3], s_run;
@@ -1616,7 +1619,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         ta.site_n2 = (const int32_t *)s->site_n2.p; ta.al_member = (const uint8_t *)s->al_member.p; ta.win = (const uint8_t *)B.win.p;
         ta.ent = (const uint32_t *)B.trace.p; ta.EW = EW; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
         ta.cns = (uint8_t *)B.cns.p; ta.ncns = (int32_t *)B.ncns.p; ta.err = err;
-        hipLaunchKernelGGL(k_site_tensor, dim3(ng), dim3(256), 0, sB, ta);
+        if (s->maxcov <= 255) hipLaunchKernelGGL(k_site_tensor<uint8_t>, dim3(ng), dim3(256), 0, sB, ta);
+        else hipLaunchKernelGGL(k_site_tensor<uint16_t>, dim3(ng), dim3(256), 0, sB, ta);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], sB));
         int32_t *mbox = (int32_t *)s->misc.p + 2;
         hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, sB, (const int32_t *)B.ncns.p, ng * S, (int64_t *)B.arow.p, mbox);

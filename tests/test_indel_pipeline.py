@@ -203,12 +203,14 @@ def _same_tuples(got, exp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["ont", "ont_mincov2_maxcov9", "pacbio_window", "haploid", "small_chunks", "excluded"])
+@pytest.mark.parametrize("variant", ["ont", "ont_mincov2_maxcov9", "maxcov300", "pacbio_window", "haploid", "small_chunks", "excluded"])
 def test_device_pipeline_returns_the_host_routes_tuples(world_files, variant, monkeypatch):
     w, bam, fa = world_files
     kw, haploid, step = {}, False, 50_000
     if variant == "ont_mincov2_maxcov9":
         kw = dict(mincov=2, maxcov=9, del_t=0.4)                                    # the first-maxcov policy bites: sets are cut
+    elif variant == "maxcov300":
+        kw = dict(maxcov=300)                                                        # the tensor kernel's 16-bit histogram form (bytes up to 255)
     elif variant == "pacbio_window":
         kw = dict(seq="pacbio", ins_t=0.4, del_t=0.4)                               # window_after 260: the 17-column aligner
     elif variant == "haploid":
