@@ -384,7 +384,7 @@ struct FillArgs {
     int32_t A, W;                // alignments; row pitch of Hlast
     int32_t open, extend, match, mismatch;
     const int64_t *arow;         // first traceback BLOCK (8 steps) of alignment a, or (NULL) a * tw_blocks(N1)
-    int32_t N1;                  // longest read of the launch (row pitch of hcol: N1 + 1)
+    int32_t N1;                  // longest read of the launch (row pitch of hcol: hcol_pitch(N1), a multiple of four words)
     uint32_t *Tw;
     int32_t *Hlast, *hcol;       // free-tail end point inputs (NULL for a global alignment, and when `endcell` is set)
     int2 *endcell;               // free-tail end point (i, j) of alignment a (k_end_cells), read by k_trace16p instead of Hlast / hcol
@@ -394,6 +394,9 @@ __device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t v)
 {
     return __builtin_amdgcn_update_dpp(old, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
+
+__host__ __device__ __forceinline__ int hcol_pitch(int N1) { return (N1 + 1 + 3) & ~3; }
+__host__ __device__ __forceinline__ int hlast_pitch(int W) { return (W + 3) & ~3; }      // row pitch of Hlast (FillArgs::W columns)
 
 __device__ __forceinline__ int fill_site(const FillArgs &p, int al) { return p.al_site ? p.al_site[al] : p.site0 + al / p.site_div; }
 
@@ -523,12 +526,12 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
                 int32_t hv = H[0];
 #pragma unroll
                 for (int c = 1; c < CPL; c++) hv = c == jn_c ? H[c] : hv;
-                p.hcol[(int64_t)al * (p.N1 + 1) + i] = hv;      // H[i][n2]
+                p.hcol[(int64_t)al * hcol_pitch(p.N1) + i] = hv;      // H[i][n2]
             }
             if (p.Hlast && i == n1) {
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
-                    if (rb[c] >= 0) p.Hlast[(int64_t)al * p.W + q * CPL + c + 1] = H[c];
+                    if (rb[c] >= 0) p.Hlast[(int64_t)al * hlast_pitch(p.W) + q * CPL + c + 1] = H[c];
             }
         }
         if (i >= 1) h_in_prev = nh;
@@ -705,12 +708,12 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
                     uint32_t hv = H[0];
 #pragma unroll
                     for (int c = 1; c < CPL; c++) hv = c == jn_c[k] ? H[c] : hv;
-                    p.hcol[(int64_t)al[k] * (p.N1 + 1) + i] = half_of(hv, k) + p.open;
+                    p.hcol[(int64_t)al[k] * hcol_pitch(p.N1) + i] = half_of(hv, k) + p.open;
                 }
                 if (p.Hlast && i == n1[k]) {
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
-                        if (q * CPL + c + 1 <= n2[k]) p.Hlast[(int64_t)al[k] * p.W + q * CPL + c + 1] = half_of(H[c], k) + p.open;
+                        if (q * CPL + c + 1 <= n2[k]) p.Hlast[(int64_t)al[k] * hlast_pitch(p.W) + q * CPL + c + 1] = half_of(H[c], k) + p.open;
                 }
             }
             h_in_prev = nh;
@@ -743,14 +746,28 @@ __global__ __launch_bounds__(256) void k_end_cells(FillArgs p)
     const int n1 = p.n1[a], n2 = p.site_n2[fill_site(p, a)];
     int32_t rv = INT32_MIN, rj = 0, cv = INT32_MIN, ci = 0;
     if (live && n1 > 0 && n2 > 0) {
-        const int32_t *hl = p.Hlast + (int64_t)a * p.W, *hc = p.hcol + (int64_t)a * (p.N1 + 1);
-        for (int j = l; j <= n2; j += 16) {
-            const int32_t v = j > 0 ? hl[j] : -p.open - (n1 - 1) * p.extend;
-            if (v >= rv) { rv = v; rj = j; }
+        // four values a load (both rows are 16-byte aligned: hlast_pitch and hcol_pitch are multiples of four words); any split of the
+        // indices over the lanes will do, the reduction below orders (value, index) pairs
+        const int32_t *hl = p.Hlast + (int64_t)a * hlast_pitch(p.W), *hc = p.hcol + (int64_t)a * hcol_pitch(p.N1);
+        for (int j0 = 4 * l; j0 <= n2; j0 += 64) {
+            const int4 g = *reinterpret_cast<const int4 *>(hl + j0);
+            const int32_t gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                const int32_t v = j > 0 ? gv[u] : -p.open - (n1 - 1) * p.extend;
+                if (j <= n2 && v >= rv) { rv = v; rj = j; }
+            }
         }
-        for (int i = l; i < n1; i += 16) {
-            const int32_t v = i > 0 ? hc[i] : -p.open - (n2 - 1) * p.extend;
-            if (v >= cv) { cv = v; ci = i; }
+        for (int i0 = 4 * l; i0 < n1; i0 += 64) {
+            const int4 g = *reinterpret_cast<const int4 *>(hc + i0);
+            const int32_t gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u;
+                const int32_t v = i > 0 ? gv[u] : -p.open - (n2 - 1) * p.extend;
+                if (i < n1 && v >= cv) { cv = v; ci = i; }
+            }
         }
     }
 #pragma unroll
@@ -811,7 +828,7 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
     const int n1 = p.n1[al];
     const int n2 = p.site_n2[fill_site(p, al)];
     const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
-    const int64_t arow = (int64_t)al * tw_blocks(p.N1), hrow = (int64_t)al * (p.N1 + 1);
+    const int64_t arow = (int64_t)al * tw_blocks(p.N1), hrow = (int64_t)al * hcol_pitch(p.N1);
     uint32_t *ent = ent_all + (int64_t)al * EW;                       // EW: a multiple of 16 entries >= n2 + 1
     int i = n1, j = n2;
     uint32_t cur = 0;                                                  // the entry of slot j being built (position j's read index comes last)
@@ -821,9 +838,9 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
         j = ec.y;
         if (i < n1) cur = ((uint32_t)(n1 - i) << 10) | ((uint32_t)i << 20);
     } else if (n1 > 0 && n2 > 0) {                                    // free tail: best cell of the last row / last column
-        int32_t best = p.Hlast[(int64_t)al * p.W + n2];
+        int32_t best = p.Hlast[(int64_t)al * hlast_pitch(p.W) + n2];
         for (int jj = n2 - 1; jj >= 0; jj--) {
-            const int32_t v = jj > 0 ? p.Hlast[(int64_t)al * p.W + jj] : -p.open - (n1 - 1) * p.extend;
+            const int32_t v = jj > 0 ? p.Hlast[(int64_t)al * hlast_pitch(p.W) + jj] : -p.open - (n1 - 1) * p.extend;
             if (v > best) { best = v; i = n1; j = jj; }
         }
         for (int ii = n1 - 1; ii >= 0; ii--) {
@@ -1564,8 +1581,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, B.win, Agz * WS + 64));
         NC_TRY(nc_ensure(ctx, B.n1, Agz * 4));
         NC_TRY(nc_ensure(ctx, B.tw, Agz * (size_t)tw_per_al + 64));
-        NC_TRY(nc_ensure(ctx, B.hlast, Agz * W * 4));
-        NC_TRY(nc_ensure(ctx, B.hcol, Agz * (N1 + 1) * 4));
+        NC_TRY(nc_ensure(ctx, B.hlast, Agz * hlast_pitch(W) * 4 + 64));
+        NC_TRY(nc_ensure(ctx, B.hcol, Agz * hcol_pitch(N1) * 4 + 64));
         NC_TRY(nc_ensure(ctx, B.endc, Agz * sizeof(int2)));
         NC_TRY(nc_ensure(ctx, B.trace, Agz * EW * 4 + 64));
         NC_TRY(nc_ensure(ctx, B.cns, (size_t)ng * S * CNS_CAP));
