@@ -219,6 +219,18 @@ inline uint32_t rdu32(const uint8_t *p) { return (uint32_t)rd32(p); }
 
 // 4-bit BAM base "=ACMGRSVTWYHKDBN" -> reference code map A=0 G=1 T=2 C=3, everything else 4
 const uint8_t NT16_CODE[16] = {4, 0, 3, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4};
+// codes of the two bases of a byte of BAM's 4-bit sequence (first base = high nibble), as they lie in memory
+struct Nt16Pair {
+    uint16_t v[256];
+    Nt16Pair()
+    {
+        for (int b = 0; b < 256; b++) {
+            const uint8_t two[2] = {NT16_CODE[b >> 4], NT16_CODE[b & 15]};
+            memcpy(&v[b], two, 2);
+        }
+    }
+};
+const Nt16Pair NT16_PAIR;
 
 }   // namespace
 
@@ -594,8 +606,13 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
             switch (op) {
             case 0: case 7: case 8:                                   // M, =, X
                 if (q_first < 0) q_first = qp;                        // query index of the first aligned base (leading S / I skipped)
-                if (has_seq) for (int i = 0; i < len; i++, rp++, qp++) co[rp] = NT16_CODE[(seq[qp >> 1] >> ((~qp & 1) << 2)) & 15];
-                else for (int i = 0; i < len; i++, rp++, qp++) co[rp] = 4;
+                if (has_seq) {
+                    // two bases a byte: after an odd first base, whole bytes of the 4-bit sequence go through a 256-entry table of code pairs
+                    int i = 0;
+                    if ((qp & 1) && i < len) { co[rp++] = NT16_CODE[seq[qp >> 1] & 15]; qp++; i++; }
+                    for (; i + 2 <= len; i += 2, rp += 2, qp += 2) memcpy(co + rp, &NT16_PAIR.v[seq[qp >> 1]], 2);
+                    if (i < len) { co[rp++] = NT16_CODE[seq[qp >> 1] >> 4]; qp++; }
+                } else for (int i = 0; i < len; i++, rp++, qp++) co[rp] = 4;
                 break;
             case 1:                                                   // I: '+n' on the previous reference column
                 if (rp > 0) { d->ev_pos.push_back(pos + rp); d->ev_len.push_back(len); }
