@@ -632,6 +632,8 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     int jn_lane[2], jn_c[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) { jn_lane[k] = (n2[k] - 1) / CPL; jn_c[k] = (n2[k] - 1) % CPL; }
+    const int n2_first = __builtin_amdgcn_readfirstlane(n2[0]);
+    const int jc_uni = __all(n2[0] == n2_first && n2[1] == n2_first && n2_first > 0) ? (n2_first - 1) % CPL : -1;      // wave-uniform (scalar)
     // read bases of both alignments: lane q holds base 16*blk + q (packed), see k_fill16p
     auto load_chunk = [&](int idx) {
         const uint32_t b0 = idx < n1[0] ? (uint32_t)s1[0][idx] : 4u, b1 = idx < n1[1] ? (uint32_t)s1[1][idx] : 4u;
@@ -706,8 +708,18 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
                 tw_stage<NWP>(tw_lds, k, t, lane, wd);
                 if (p.hcol && q == jn_lane[k]) {
                     uint32_t hv = H[0];
+                    if (jc_uni >= 0) {                               // every window of the wave has the same length: the cell is picked by a scalar branch
+                        switch (jc_uni) {
+#define NC_HV(C) case C: hv = H[C < CPL ? C : 0]; break;
+                            NC_HV(1) NC_HV(2) NC_HV(3) NC_HV(4) NC_HV(5) NC_HV(6) NC_HV(7) NC_HV(8) NC_HV(9) NC_HV(10) NC_HV(11) NC_HV(12) NC_HV(13)
+                            NC_HV(14) NC_HV(15) NC_HV(16)
+#undef NC_HV
+                        default: break;
+                        }
+                    } else {
 #pragma unroll
-                    for (int c = 1; c < CPL; c++) hv = c == jn_c[k] ? H[c] : hv;
+                        for (int c = 1; c < CPL; c++) hv = c == jn_c[k] ? H[c] : hv;
+                    }
                     p.hcol[(int64_t)al[k] * hcol_pitch(p.N1) + i] = half_of(hv, k) + p.open;
                 }
                 if (p.Hlast && i == n1[k]) {
