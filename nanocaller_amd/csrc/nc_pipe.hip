@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
 #pragma unroll
                 for (int j = 0; j < NWD; j++) {
                     const uint32_t lo = words[2 * j], hi = words[2 * j + 1 <= NH ? 2 * j + 1 : NH];
-                    wd[j] = k == 0 ? ((lo & 0xffffu) | (hi << 16)) : ((lo >> 16) | (hi & 0xffff0000u));
+                    wd[j] = __builtin_amdgcn_perm(hi, lo, k == 0 ? 0x05040100u : 0x07060302u);      // this alignment's halves of the two registers: one v_perm_b32
                 }
                 tw_stage<NWP>(tw_lds, k, t, lane, wd);
                 if (p.hcol && q == jn_lane[k]) {
