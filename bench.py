@@ -410,17 +410,21 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
         resident_ms.append((time.perf_counter() - t0) * 1e3)
     n_sites = r["n"]
     uploader.h2d_events.clear()
-    from_host_pass(uploader.submit(wire))                           # sizes the upload slots
+    for _ in range(len(uploader.slots)):                            # sizes EVERY upload slot of the ring (they held the SNP contigs' smaller wires: a slot
+        from_host_pass(uploader.submit(wire))                       # that grows inside the timed loop costs an allocation + a device synchronisation, ~30 ms)
+    uploader.h2d_events.clear()
     with ThreadPoolExecutor(max_workers=1) as pool:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nxt, pend = uploader.submit(wire), None
+        nxt, pend, pass_ms = uploader.submit(wire), None, []
         for i in range(reps):
             tk = nxt
             nxt = uploader.submit(wire) if i + 1 < reps else None    # the next pass's copy runs under this pass's kernels
+            tp = time.perf_counter()
             rr = from_host_pass(tk)
             if pend is not None:
                 pend.result()
+            pass_ms.append((time.perf_counter() - tp) * 1e3)          # (the first one waits for its own upload: nothing to hide it under)
             pend = pool.submit(rules, rr)                            # rules + text of pass i under pass i + 1
         pend.result()
         torch.cuda.synchronize()
@@ -535,7 +539,7 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
     out = {"workload": "indel half of configs[2]: synthetic ONT 30x contig of %d bp with planted indels (1-50 bp) and HP/PS tags, %d chunks of 100 kb; "
                        "%d reads, %d indel events, %d candidate sites reach the CNN (%d read windows aligned), %d VCF records per pass"
                        % (L, len(chunks), info["n_reads"], info["n_events"], n_sites, A, n_rec),
-           "value": n_sites * reps / t_host, "unit": "candidate sites/s", "reps": reps, "ms_per_pass": t_host / reps * 1e3,
+           "value": n_sites * reps / t_host, "unit": "candidate sites/s", "reps": reps, "pass_ms": [round(v, 2) for v in pass_ms], "ms_per_pass": t_host / reps * 1e3,
            "timed_region": "pinned host memory (wire form + indel events + bases without a reference column: %.0f MB, one copy per pass on the upload "
                            "stream) -> expansion -> K7 -> anchors / read sets -> windows -> star alignment -> K8 -> allele_prediction -> K9 -> host arrays -> "
                            "native rules + VCF text (host thread, under the next pass)" % (wire.nbytes / 1e6),
