@@ -717,3 +717,32 @@ def test_same_name_overlaps_are_refused_not_silently_accepted(eng, tmp_path):
         snpCaller.call_chunks(dict(base, sam_path=bam2, fasta_path=fa, supplementary=True), chunks)
     assert e.value.status == _lib.NC_ERR_UNSUPPORTED
     gsp.release_contig()
+
+
+def test_indel_cnn_fused_trunk_at_scale(eng):
+    """k10_indel_trunk_h3 with more sites than one workgroup per CU sees in a pass and more than one batch (70,001 diploid sites: 65,536 +
+    the rest; 300,001 haploid: 262,144 + the rest): distinct tensors at chosen indices (first / last site of a workgroup's stream, both
+    sides of the batch border, the last site) against the float64 oracle; every other site is a copy of one of four tensors and must
+    equal that tensor's result bit for bit (a site's result does not depend on its place in the stream)"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_indel_model
+    from oracle import oracle
+    rng = np.random.Generator(np.random.PCG64(77))
+    for name, kind, rows, n, batch in (("ONT-HG002", _lib.MODEL_INDEL, 15, 70_001, 65_536), ("haploid", _lib.MODEL_INDEL_HAP, 5, 300_001, 262_144)):
+        w = Weights(get_indel_model(name))
+        eng.load_weights(kind, w)
+        base = (rng.random((4, rows, 128, 2)) * (rng.random((4, rows, 128, 2)) < 0.4)).astype(np.float32)
+        special = [0, 255, 256, 511, batch - 1, batch, batch + 255, n - 1]
+        xs = (rng.random((len(special), rows, 128, 2)) * (rng.random((len(special), rows, 128, 2)) < 0.4)).astype(np.float32)
+        xd = torch.from_numpy(base).cuda()[torch.arange(n, device="cuda") % 4].contiguous()
+        xd[torch.tensor(special, device="cuda")] = torch.from_numpy(xs).cuda()
+        p = eng.indel_forward(kind, xd).cpu().numpy()
+        e = oracle.indel_forward(w.flat, np.concatenate([base, xs]), precision="f64")
+        assert np.abs(p[special] - e[4:]).max() < 1e-4, name
+        plain = np.ones(n, bool)
+        plain[special] = False
+        for k in range(4):
+            rowsk = p[(np.arange(n) % 4 == k) & plain]
+            assert np.abs(rowsk[0] - e[k]).max() < 1e-4
+            assert np.all(rowsk == rowsk[0]), (name, k)
