@@ -1837,7 +1837,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         if constexpr (CI == 2 && W % 4 == 0 && C1 == 8) {
             if (indel_fused) {
                 constexpr size_t LDS = K10_LDS;
-                static bool attr_set = false;
+                bool &attr_set = ctx->k10_lds_set[H == 15 ? 0 : 1];          // per context (= per device): the attribute belongs to the device's copy of the function
                 if (!attr_set) {
                     NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k10_indel_trunk_h3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
                     attr_set = true;

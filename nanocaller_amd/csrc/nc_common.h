@@ -31,6 +31,7 @@ struct nc_ctx {
     int timing = 0;                           // 0 off; 1 stage timers + trunk launches; 2 trunk launches only (events on the dispatch packets, no barrier packets)
     bool x_i16 = false;            // SNP tensors between featuriser and CNN as int16 instead of fp32 (nc_set_tensor_format)
     bool cnn_exact_fp32 = false;   // false: fp16x3 split-precision trunk (default); true: exact fp32 MFMA trunk
+    bool k10_lds_set[2] = {false, false};   // k10_indel_trunk_h3<15 / 5>: dynamic LDS limit raised on this device
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
     hipEvent_t kev[128] = {nullptr};          // per-launch event pairs of the trunk kernel (timing mode)
