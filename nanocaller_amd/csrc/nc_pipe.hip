@@ -400,19 +400,20 @@ __host__ __device__ __forceinline__ int hlast_pitch(int W) { return (W + 3) & ~3
 
 __device__ __forceinline__ int fill_site(const FillArgs &p, int al) { return p.al_site ? p.al_site[al] : p.site0 + al / p.site_div; }
 
-// Traceback storage.  The DP runs as a wavefront: at step t lane q of a 16-lane group works on read row t - q.  A lane's NWP words
-// of step t go to block t >> 3 of its alignment, where the 8 steps of ONE lane are contiguous:
-//     word index = (((first_block + (t >> 3)) * 16 + q) * 8 + (t & 7)) * NWP + w
-// so a traceback that climbs a diagonal (row - 1, column - 1: same lane, step - 1) stays inside one 64-byte run for 8 steps.  [Rows
-// stored one after the other made the fill write 16 partial lines per instruction (33 ms, 2.6x the arithmetic); steps stored one after
-// the other fixed the writes (15 ms) but left the traceback one 64-byte sector per step (11 GB per chr20-sized contig).]  The fill
-// kernels collect 8 steps per lane in LDS (a lane reads back only what it wrote itself) and write whole runs.
-#ifndef NC_TWB_LOG
-#define NC_TWB_LOG 3
-#endif
-constexpr int TWB_LOG = NC_TWB_LOG, TWB = 1 << TWB_LOG;        // steps per block (8 in the text above)
+// Traceback storage.  The DP runs as a wavefront: at step t lane q of a 16-lane group works on read row t - q and produces CPL 4-bit
+// codes.  The codes of the 8 steps lane q spends on block t >> 3 of its alignment are ONE contiguous run of CPL words:
+//     run = ((first_block + (t >> 3)) * 16 + q) * CPL            [words]
+//     words 0 .. 8 F - 1      the F = CPL / 8 full words (8 codes each) of step s = t & 7 at s * F + w
+//     words 8 F .. CPL - 1    the R = CPL % 8 remaining codes of every step, 4 R bits a step, step s at bit 4 R s (8 steps = R words)
+// so a traceback that climbs a diagonal (row - 1, column - 1: same lane, step - 1) stays inside one 44-byte run (CPL = 11) for 8 steps.
+// [Rows stored one after the other made the fill write 16 partial lines per instruction (33 ms, 2.6x the arithmetic); steps stored one
+// after the other fixed the writes (15 ms) but left the traceback one 64-byte sector per step (11 GB per chr20-sized contig); whole words
+// per step (2 for 11 codes, 4 for 17) wrote 28.5 GB per pass for 15.3 GB of codes.]  The fill kernels collect 8 steps per lane in LDS (a
+// lane reads back only what it wrote itself) and write whole runs.
+constexpr int TWB_LOG = 3, TWB = 1 << TWB_LOG;                  // steps per block
 __host__ __device__ __forceinline__ int tw_blocks(int n1) { return ((n1 + 15) >> TWB_LOG) + 1; }
-__device__ __forceinline__ int64_t tw_word(int64_t first_block, int t, int q, int NWP) { return (((first_block + (t >> TWB_LOG)) * 16 + q) * TWB + (t & (TWB - 1))) * (int64_t)NWP; }
+__device__ __forceinline__ int64_t tw_run(int64_t first_block, int t, int q, int CPL) { return ((first_block + (t >> TWB_LOG)) * 16 + q) * (int64_t)CPL; }
+struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };      // four words at a 4-byte aligned address (one dwordx4 access)
 
 template <int NWP>
 __device__ __forceinline__ void tw_stage(uint32_t *lds, int k, int t, int lane, const uint32_t *wd)
@@ -422,18 +423,31 @@ __device__ __forceinline__ void tw_stage(uint32_t *lds, int k, int t, int lane, 
     else if (NWP == 2) *reinterpret_cast<uint2 *>(ls) = make_uint2(wd[0], wd[1]);
     else *reinterpret_cast<uint4 *>(ls) = make_uint4(wd[0], wd[1], wd[2], 0u);
 }
-// the 8 steps of block t >> 3 of this lane, LDS -> HBM (8 * NWP words = 32 / 64 / 128 contiguous bytes)
-template <int NWP>
+// the 8 steps of block t >> 3 of this lane, LDS (NWP words a step) -> its run in HBM (CPL words)
+template <int CPL, int NWP>
 __device__ __forceinline__ void tw_flush(const uint32_t *lds, int k, int t, int lane, int q, uint32_t *Tw, int64_t first_block)
 {
-    uint32_t *dst = Tw + tw_word(first_block, t & ~(TWB - 1), q, NWP);
-    uint32_t v[TWB * NWP];
+    constexpr int F = CPL / 8, R = CPL % 8;
+    uint32_t *dst = Tw + tw_run(first_block, t, q, CPL);
+    uint32_t out[CPL];
 #pragma unroll
-    for (int ts = 0; ts < TWB; ts++)
+    for (int w = 0; w < CPL; w++) out[w] = 0;
 #pragma unroll
-        for (int w = 0; w < NWP; w++) v[ts * NWP + w] = lds[((k * TWB + ts) * 64 + lane) * NWP + w];
+    for (int ts = 0; ts < TWB; ts++) {
+        const uint32_t *ls = lds + ((k * TWB + ts) * 64 + lane) * NWP;
 #pragma unroll
-    for (int x = 0; x < TWB * NWP / 4; x++) reinterpret_cast<uint4 *>(dst)[x] = make_uint4(v[4 * x], v[4 * x + 1], v[4 * x + 2], v[4 * x + 3]);
+        for (int w = 0; w < F; w++) out[ts * F + w] = ls[w];
+        if (R > 0) {
+            const uint32_t part = ls[F] & ((1u << (4 * R)) - 1u);     // the step's last R codes (a step the lane never staged holds anything)
+            const int pos = 4 * R * ts, dw = 8 * F + (pos >> 5), sh = pos & 31;
+            out[dw] |= part << sh;
+            if (sh + 4 * R > 32) out[dw + 1] |= part >> (32 - sh);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x + 4 <= CPL; x += 4) *reinterpret_cast<U4 *>(dst + x) = U4{out[x], out[x + 1], out[x + 2], out[x + 3]};
+#pragma unroll
+    for (int x = CPL & ~3; x < CPL; x++) dst[x] = out[x];
 }
 
 template <int CPL>
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(64) void k_fill16p(FillArgs p)
             }
         }
         if (i >= 1) h_in_prev = nh;
-        if (((t & (TWB - 1)) == TWB - 1 || t == nmax + 15) && live && (t >> TWB_LOG) < tw_blocks(n1)) tw_flush<NWP>(tw_lds, 0, t, lane, q, p.Tw, arow);
+        if (((t & (TWB - 1)) == TWB - 1 || t == nmax + 15) && live && (t >> TWB_LOG) < tw_blocks(n1)) tw_flush<CPL, NWP>(tw_lds, 0, t, lane, q, p.Tw, arow);
     }
 }
 
@@ -733,18 +747,9 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
         if ((t & (TWB - 1)) == TWB - 1 || t == nmax + 15) {
 #pragma unroll
             for (int k = 0; k < 2; k++)
-                if (live[k] && (t >> TWB_LOG) < tw_blocks(n1[k])) tw_flush<NWP>(tw_lds, k, t, lane, q, p.Tw, arow[k]);
+                if (live[k] && (t >> TWB_LOG) < tw_blocks(n1[k])) tw_flush<CPL, NWP>(tw_lds, k, t, lane, q, p.Tw, arow[k]);
         }
     }
-}
-
-// the 4-bit traceback code of cell (i, j), i, j >= 1, in k_fill16p's terms (T_DIAG / T_DEL / T_INS | T_EEXT | T_FEXT)
-__device__ __forceinline__ uint32_t tb_code(const uint32_t *__restrict__ Tw, int64_t arow, int i, int j, int CPL, int NWP, int fmt)
-{
-    const int q = (j - 1) / CPL, c = (j - 1) % CPL;
-    const uint32_t t = (Tw[tw_word(arow, i + q, q, NWP) + (c >> 3)] >> ((c & 7) * 4)) & 15u;      // row i of lane q was written at step i + q
-    if (fmt == 0) return t;
-    return ((t & 2u) ? (uint32_t)T_INS : (t & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((t & 4u) ? 0u : (uint32_t)T_EEXT) | ((t & 8u) ? 0u : (uint32_t)T_FEXT);
 }
 
 // free-tail end point of every alignment: the best cell of the last row (ties: the larger column) or a cell of the last column that is
@@ -797,31 +802,38 @@ __global__ __launch_bounds__(256) void k_end_cells(FillArgs p)
 // it -- in EPOCHS: the lanes that need a new line load it together, then every lane walks on inside its line until none can (a lane that
 // fetched on its own whenever it left a line made the whole wave wait at nearly every step: some lane always does).
 struct TbLine {
-    uint32_t *slot;                                                    // this lane's 8 * NWP words (+1 pad) in LDS
+    uint32_t *slot;                                                    // this lane's run of CPL words in LDS (odd pitch)
     int cblk, cq;                                                      // block and fill lane of the cached line (-1: none)
     int q, c;                                                          // fill lane and cell-in-lane of column j, kept in step with j (no division per step)
     __device__ __forceinline__ void set_j(int j, int CPL) { q = j > 0 ? (j - 1) / CPL : 0; c = j > 0 ? (j - 1) % CPL : 0; }
     __device__ __forceinline__ void dec_j(int CPL) { if (--c < 0) { c = CPL - 1; q--; } }
     __device__ __forceinline__ bool has(int i) const { return ((i + q) >> TWB_LOG) == cblk && q == cq; }
-    __device__ __forceinline__ void load(const uint32_t *__restrict__ Tw, int64_t arow, int i, int NWP)
+    __device__ __forceinline__ void load(const uint32_t *__restrict__ Tw, int64_t arow, int i, int CPL)
     {
         cblk = (i + q) >> TWB_LOG;
         cq = q;
-        const uint4 *src = reinterpret_cast<const uint4 *>(Tw + tw_word(arow, (i + q) & ~(TWB - 1), q, NWP));
-        for (int u = 0; u < TWB * NWP / 4; u++) {
-            const uint4 v = src[u];
-            slot[4 * u] = v.x; slot[4 * u + 1] = v.y; slot[4 * u + 2] = v.z; slot[4 * u + 3] = v.w;
+        const uint32_t *src = Tw + tw_run(arow, i + q, q, CPL);
+        for (int u = 0; u < CPL; u += 4) {                               // (whole dwordx4s: up to three words of the next run come along; the buffers end in a pad)
+            const U4 v = *reinterpret_cast<const U4 *>(src + u);
+            slot[u] = v.x; slot[u + 1] = v.y; slot[u + 2] = v.z; slot[u + 3] = v.w;
         }
     }
     // cell (i, j) of the cached line (the caller checked has(i))
-    __device__ __forceinline__ uint32_t code(int i, int NWP, int fmt) const
+    __device__ __forceinline__ uint32_t code(int i, int CPL, int fmt) const
     {
-        const uint32_t tc = (slot[((i + q) & (TWB - 1)) * NWP + (c >> 3)] >> ((c & 7) * 4)) & 15u;
+        const int F = CPL >> 3, R = CPL & 7, st = (i + q) & (TWB - 1);
+        int word = st * F + (c >> 3), sh = (c & 7) * 4;
+        if (c >= 8 * F) {                                                // one of the step's last R codes
+            const int bit = 4 * (R * st + c - 8 * F);
+            word = 8 * F + (bit >> 5);
+            sh = bit & 31;
+        }
+        const uint32_t tc = (slot[word] >> sh) & 15u;
         if (fmt == 0) return tc;
         return ((tc & 2u) ? (uint32_t)T_INS : (tc & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((tc & 4u) ? 0u : (uint32_t)T_EEXT) | ((tc & 8u) ? 0u : (uint32_t)T_FEXT);
     }
 };
-constexpr int TBL_PITCH = TWB * 4 + 1;                                 // words per lane (NWP <= 4)
+constexpr int TBL_PITCH = 33;                                          // words per lane (a run is CPL <= 32 words; odd pitch)
 
 // traceback of a free-tail alignment into reference coordinates (nc_msa.hip k_nw_trace16): one lane per alignment.  Entry x of an
 // alignment packs, for reference position x (0-based) and the slot BEFORE it (slot n2 = after the last position):
@@ -839,7 +851,6 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
     TbLine tb = {tbl + lane * TBL_PITCH, -1, -1, 0, 0};
     const int n1 = p.n1[al];
     const int n2 = p.site_n2[fill_site(p, al)];
-    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     const int64_t arow = (int64_t)al * tw_blocks(p.N1), hrow = (int64_t)al * hcol_pitch(p.N1);
     uint32_t *ent = ent_all + (int64_t)al * EW;                       // EW: a multiple of 16 entries >= n2 + 1
     int i = n1, j = n2;
@@ -880,7 +891,7 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else t = tb.code(i, NWP, fmt);
+        else t = tb.code(i, CPL, fmt);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) {                                        // position j-1 takes read base i-1; slot j is complete
@@ -908,7 +919,7 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
     };
     tb.set_j(j, CPL);
     while (__any(i > 0 || j > 0)) {                                    // epochs
-        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, NWP);
+        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, CPL);
         for (;;) {                                                     // every lane walks on inside its line
             const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i));
             if (!__any(can)) break;
@@ -1131,7 +1142,6 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
         alt_len[al] = -1;
         return;
     }
-    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     const int64_t arow = p.arow[al];
     const int run_cap = n1 + n2 + 2;
     int16_t *rop = runs + 2 * (TWB * arow + (int64_t)al * (p.W + 1)), *rcn = rop + run_cap;  // runs in REVERSE alignment order (TWB * blocks >= n1 + 1)
@@ -1149,7 +1159,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else t = tb.code(i, NWP, fmt);
+        else t = tb.code(i, CPL, fmt);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; tb.dec_j(CPL); return; }
@@ -1170,7 +1180,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     };
     tb.set_j(j, CPL);
     while (__any(i > 0 || j > 0)) {                                    // epochs: see TbLine
-        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, NWP);
+        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, CPL);
         for (;;) {
             const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i));
             if (!__any(can)) break;
@@ -1541,9 +1551,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     const int WS = (s->window_after + 15) & ~15;
     const int N1 = WS;
     const int CPL = cpl_for(s->window_after + 1);
-    const int NWD = (CPL + 7) / 8, NWP = NWD <= 1 ? 1 : NWD == 2 ? 2 : 4;
     // groups of whole sites: traceback codes of a group's alignments <= 6 GiB (two groups are in flight)
-    const int64_t tw_per_al = (int64_t)tw_blocks(N1) * 64 * TWB * NWP;   // blocks of TWB steps x 16 lanes x NWP words
+    const int64_t tw_per_al = (int64_t)tw_blocks(N1) * 64 * CPL;          // bytes: blocks of 8 steps x 16 lanes x CPL words
     int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)6 << 30) / tw_per_al);
     if (const char *g = getenv("NC_PIPE_GROUP_AL")) GROUP_AL = std::max<int64_t>(64, atoll(g));
     const int64_t GROUP_SITES = 65536;
@@ -1662,7 +1671,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int b = g & 1, k0 = groups[(size_t)g].first, k1 = groups[(size_t)g].second;
         nc_pipe_state::GroupBufs &B = s->gb[b];
         const int nset = (k1 - k0) * S;
-        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 64 * TWB * NWP + 64));                     // `rows` counts blocks of TWB steps
+        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 64 * CPL + 64));                     // `rows` counts blocks of TWB steps
         NC_TRY(nc_ensure(ctx, s->runs, (size_t)(TWB * rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
         FillArgs fb = fa_of[b];
         fb.s1 = (const uint8_t *)B.cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)B.ncns.p;
