@@ -119,3 +119,64 @@ def test_two_rank_gloo_run_matches_single_process(tmp_path):
     mp.spawn(_worker, args=(1, port2, str(single)), nprocs=1, join=True)
     ref = open(os.path.join(str(single), "t.1.snps.vcf")).readlines()
     assert merged == ref                                             # contiguous shards => same order, same records
+
+
+def _decode_worker(rank, world, port, bam, fa, tmpdir):
+    """what a rank's ingest does for its shard: the contig-aware plan, then one decode per contig (or per span of a shared one)"""
+    import json
+
+    import torch.distributed as dist
+
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    from nanocaller_amd.shard import barrier, shard_plan
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    chunks = get_chunks([("cA", 1, 900_000, "diploid"), ("cB", 1, 600_000, "diploid"), ("cC", 1, 300_000, "diploid")], cpu=4)
+    mine = shard_plan(chunks, world)[rank]
+    by_contig = {}
+    for c in mine:
+        by_contig.setdefault(c["chrom"], []).append(c)
+    del gsp.DECODES[:]
+    for name, grp in by_contig.items():
+        span = gsp.contig_span(bam, name, grp)
+        gsp._resolve(bam, name, fa, span)
+        gsp._resolve(bam, name, fa, span)                            # a second request is served from the cache
+    with open(os.path.join(tmpdir, "decodes.%d.json" % rank), "w") as f:
+        json.dump([[d[1], list(d[2]) if d[2] else None] for d in gsp.DECODES], f)
+    barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_ingest_decodes_no_contig_twice(tmp_path):
+    """under the contig-aware shard plan every contig is decoded ONCE across the job; a contig shared by two ranks is decoded by
+    each over its own span (+- the 50 kb scan flank) only -- the real decode path (native BAM reader) of two gloo ranks on one file"""
+    import json
+
+    from tests import bamio
+    rng = np.random.default_rng(3)
+    lens = dict(cA=900_000, cB=600_000, cC=300_000)
+    recs = []
+    for tid, (name, L) in enumerate(lens.items()):
+        for p in range(1_000, L - 6_000, 25_000):                    # a sparse BAM: the test is about WHO decodes WHAT
+            recs.append(dict(name="%s_%d" % (name, p), flag=0, pos0=p, tid=tid, cigar=[("M", 5_000)], seq="".join("ACGT"[b] for b in rng.integers(0, 4, 5_000))))
+    bam, fa = str(tmp_path / "g.bam"), str(tmp_path / "g.fa")
+    bamio.write_bam(bam, "cA", lens["cA"], recs, other_refs=[("cB", lens["cB"]), ("cC", lens["cC"])], level=1)
+    bamio.write_fasta(fa, "cA", "A" * lens["cA"], extra=[("cB", "C" * lens["cB"]), ("cC", "G" * lens["cC"])])
+    port = _free_port()
+    mp.spawn(_decode_worker, args=(2, port, bam, fa, str(tmp_path)), nprocs=2, join=True)
+    dec = [json.load(open(os.path.join(str(tmp_path), "decodes.%d.json" % r))) for r in range(2)]
+    assert all(len(d) == len({(n, tuple(s) if s else None) for n, s in d}) for d in dec)          # the cache: one decode per (contig, span) and rank
+    seen = {}
+    for r, d in enumerate(dec):
+        for name, span in d:
+            seen.setdefault(name, []).append((r, span))
+    assert set(seen) == set(lens)
+    for name, who in seen.items():
+        if len(who) == 1:
+            continue                                                  # a whole contig (or most of one) is one rank's
+        assert len(who) == 2 and who[0][0] != who[1][0]
+        (ra, sa), (rb, sb) = sorted(who, key=lambda t: t[1][0] if t[1] else 0)
+        assert sa is not None and sb is not None                      # neither rank decoded the whole contig
+        assert sb[0] >= sa[1] - 2 * 50_000 - 1                        # the spans overlap by the two flanks at most
+    assert sum(len(w) for w in seen.values()) <= len(lens) + 1        # at most one contig is shared between the two ranks
