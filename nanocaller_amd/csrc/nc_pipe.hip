@@ -957,7 +957,15 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
     __shared__ HT hist[3][CNS_CAP * 4];
     __shared__ uint8_t refrow[CNS_CAP];
     __shared__ uint8_t cnsv[CNS_CAP];
+    constexpr int TQ_CAP = 1024;
+    __shared__ uint2 qitems[TQ_CAP];                               // insertions of the site's reads: alignment | slot | member bits, length | first base
+    __shared__ int32_t s_nq;
     __shared__ int32_t s_ncols[3], s_run;
+    // one more read with symbol `sym` in column c of set t: an atomic add on the 32-bit word that holds the counter (no carry: a counter stays <= maxcov)
+    auto hist_add = [&](int t, int c, int sym) {
+        if (sizeof(HT) == 1) atomicAdd(reinterpret_cast<uint32_t *>(&hist[t][0]) + c, 1u << (8 * sym));
+        else atomicAdd(reinterpret_cast<uint32_t *>(&hist[t][0]) + 2 * c + (sym >> 1), 1u << (16 * (sym & 1)));
+    };
     __shared__ int32_t wcnt[4];
     const int kl = blockIdx.x, site = p.site0 + kl;
     const int tid = threadIdx.x;
@@ -986,6 +994,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
 #pragma unroll
         for (int t = 0; t < 3; t++) mxv[t][j] = (int16_t)m[t];
     }
+    if (tid == 0) s_nq = 0;
     __syncthreads();
     // ---- column of every slot's position = running sum of the insertion widths + j: scan over the block (2 slots per thread: n2 + 1 <= 288)
     for (int t = 0; t < S; t++) {
@@ -1018,11 +1027,16 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
         int cj[3], c0[3];
 #pragma unroll
         for (int t = 0; t < 3; t++) { cj[t] = t < S ? colv[t][j] : 0; c0[t] = cj[t] - (t < S ? mxv[t][j] : 0); }   // thread j owns the columns c0 .. cj of every read
+        // the position column's four counters of every set live in registers (16-bit fields) for the sweep: a read-modify-write of LDS per
+        // (read, set) was a chain of ~50 dependent LDS round trips, 5/6 of this kernel
+        uint64_t cnt[3] = {0, 0, 0};
         for (int64_t ab = a0; ab < a1; ab += 8) {
             uint32_t en8[8];
-            int sym8[8];
+            int sym8[8], mb8[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) en8[u] = p.ent[min(ab + u, a1 - 1) * p.EW + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) mb8[u] = ab + u < a1 ? (int)mem[ab + u] : 0;        // (with the other loads, not one by one inside the loop below)
 #pragma unroll
             for (int u = 0; u < 8; u++) {                             // the base aligned to position j (index clamped: unused when there is none)
                 const int qi = (int)(en8[u] & 0x3ffu) - 1;
@@ -1032,24 +1046,60 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
             for (int u = 0; u < 8; u++) {
                 const int64_t a = ab + u;
                 if (a >= a1) continue;
-                const int mb = mem[a];
+                const int mb = mb8[u];
                 const uint32_t en = en8[u];
                 if (j < n2 && (en & 0x3ffu) != 0 && sym8[u] < 4) {    // anything else (a read base N) counts as a gap at its column
+                    const uint64_t one = 1ull << (16 * sym8[u]);
 #pragma unroll
                     for (int t = 0; t < 3; t++)
-                        if ((mb & (1 << t)) && ok[t]) hist[t][cj[t] * 4 + sym8[u]]++;
+                        if (mb & (1 << t)) cnt[t] += one;
                 }
+                // an insertion goes on the block's list: walked here, the whole wave waited for one lane's loads at nearly every alignment
+                // (some lane always has one) -- 2/3 of the kernel; from the list every thread takes one insertion
                 const int L = (int)((en >> 10) & 0x3ffu);
                 if (L > 0) {
-                    const uint8_t *s1 = p.win + a * p.WS + (int)(en >> 20);
-                    for (int v = 0; v < L; v++) {
-                        const int sym = s1[v];
-                        if (sym < 4) {
+                    const int slot = atomicAdd(&s_nq, 1);
+                    if (slot < TQ_CAP) qitems[slot] = make_uint2((uint32_t)(a - a0) | ((uint32_t)j << 16) | ((uint32_t)mb << 25), en >> 10);
+                    else {                                            // (a list longer than the LDS holds: the old way)
+                        const uint8_t *s1 = p.win + a * p.WS + (int)(en >> 20);
+                        for (int v = 0; v < L; v++) {
+                            const int sym = s1[v];
+                            if (sym < 4) {
 #pragma unroll
-                            for (int t = 0; t < 3; t++)
-                                if ((mb & (1 << t)) && ok[t]) hist[t][(c0[t] + v) * 4 + sym]++;
+                                for (int t = 0; t < 3; t++)
+                                    if ((mb & (1 << t)) && ok[t]) hist_add(t, c0[t] + v, sym);
+                            }
                         }
                     }
+                }
+            }
+        }
+        if (j < n2) {
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (t < S && ok[t]) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) hist[t][cj[t] * 4 + k] = (HT)((cnt[t] >> (16 * k)) & 0xffffu);
+                }
+        }
+    }
+    __syncthreads();
+    // ---- the inserted bases: one insertion per thread (columns c0 .. c0 + L - 1 of its slot, shared by the reads of a set: atomic adds)
+    {
+        const int nq = min(s_nq, TQ_CAP);
+        for (int i = tid; i < nq; i += 256) {
+            const uint2 it = qitems[i];
+            const int a = (int)(it.x & 0xffffu), j = (int)((it.x >> 16) & 0x1ffu), mb = (int)(it.x >> 25), L = (int)(it.y & 0x3ffu), q0 = (int)(it.y >> 10);
+            const uint8_t *s1 = p.win + (a0 + a) * p.WS + q0;
+            int c0[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) c0[t] = t < S ? colv[t][j] - mxv[t][j] : 0;
+            for (int v = 0; v < L; v++) {
+                const int sym = s1[v];
+                if (sym < 4) {
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+                        if ((mb & (1 << t)) && ok[t]) hist_add(t, c0[t] + v, sym);
                 }
             }
         }
