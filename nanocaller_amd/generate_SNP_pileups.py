@@ -30,22 +30,27 @@ class _LRU:
     NANOCALLER_CONTIG_CACHE overrides it."""
 
     def __init__(self, cap):
+        import threading
         self.cap = max(1, int(os.environ.get("NANOCALLER_CONTIG_CACHE", cap)))
         self.d = {}
+        self.lock = threading.Lock()                                 # the caller's ingest threads prepare two contigs side by side
 
     def get(self, key, make):
-        if key in self.d:
-            self.d[key] = self.d.pop(key)                            # most recently used last
-            return self.d[key]
-        val = make()
-        self.d[key] = val
-        while len(self.d) > self.cap:
-            self.d.pop(next(iter(self.d)))
+        with self.lock:
+            if key in self.d:
+                self.d[key] = self.d.pop(key)                        # most recently used last
+                return self.d[key]
+        val = make()                                                 # (outside the lock: a decode takes tens of milliseconds)
+        with self.lock:
+            self.d[key] = val
+            while len(self.d) > self.cap:
+                self.d.pop(next(iter(self.d)))
         return val
 
     def drop(self, pred):
-        for k in [k for k in self.d if pred(k)]:
-            del self.d[k]
+        with self.lock:
+            for k in [k for k in self.d if pred(k)]:
+                del self.d[k]
 
     def __len__(self):
         return len(self.d)

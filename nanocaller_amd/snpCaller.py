@@ -344,17 +344,26 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
         # that pack then crosses PCIe on the upload stream through a ring of three device slots, under group i's kernels.  BAM inputs
         # only; NC_SERIAL_INGEST=1 keeps the round-2 behaviour (decode + upload inside call_chunks, the GPU idle meanwhile).
         piped = isinstance(params['sam_path'], str) and os.path.exists(params['sam_path']) and not os.environ.get('NC_SERIAL_INGEST')
-        uploader = prep = None
+        uploader = None
+        preps = []                                                   # the next groups' packs, being prepared
         if piped and keys:
             from .wire import WireUploader
             uploader = WireUploader(get_engine(device))
-            prep_pool = ThreadPoolExecutor(max_workers=1)
-            prep = prep_pool.submit(_prepare_wire, params, keys[0][0], groups[keys[0]])
+            # two groups ahead: the Python half of one pack's preparation (header parsing, the wire's index arrays, freeing the decoded
+            # arrays: ~35 of ~58 ms per 3 Mb contig) runs beside the native decode of the next one, which releases the GIL
+            ahead = int(os.environ.get('NC_INGEST_AHEAD', 2))
+            prep_pool = ThreadPoolExecutor(max_workers=max(1, ahead))
+            nxt = 0
+            while nxt < len(keys) and len(preps) < max(1, ahead):
+                preps.append(prep_pool.submit(_prepare_wire, params, keys[nxt][0], groups[keys[nxt]]))
+                nxt += 1
         for i, (chrom, ploidy) in enumerate(keys):
             grp = groups[(chrom, ploidy)]
             if piped:
-                wp = prep.result()
-                prep = prep_pool.submit(_prepare_wire, params, keys[i + 1][0], groups[keys[i + 1]]) if i + 1 < len(keys) else None
+                wp = preps.pop(0).result()
+                if nxt < len(keys):
+                    preps.append(prep_pool.submit(_prepare_wire, params, keys[nxt][0], groups[keys[nxt]]))
+                    nxt += 1
                 tk = uploader.submit(wp)
                 call = call_chunks(params, grp, device, dpk=uploader.expand(tk), defer=True)
                 uploader.release(tk)
