@@ -143,6 +143,41 @@ class BamFile:
         return out
 
 
+class _Names:
+    """the read names of a decoded set as a read-only sequence of str, decoded when asked for (a chromosome has ~10^5-10^6 alignments and
+    most runs never look at a name: building the list cost 2 ms per 3 Mb contig on the ingest thread, with the GIL held)"""
+
+    def __init__(self, raw, off):
+        self.raw, self.off = raw, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self.raw[self.off[i]:self.off[i + 1] - 1].decode()
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def index(self, name):
+        for k in range(len(self)):
+            if self[k] == name:
+                return k
+        raise ValueError(name)
+
+    def __contains__(self, name):
+        return any(self[k] == name for k in range(len(self)))
+
+
 def _decoded_dict(L, d):
     """dict of zero-copy numpy views over a native nc_decoded (freed when the last view goes)"""
     own = _Owner(L, d, "nc_decoded_free")
@@ -161,8 +196,7 @@ def _decoded_dict(L, d):
             out[k] = np.zeros(1, np.int64)
         out["ev_off"] = np.zeros(1, np.int32)
     name_off = _arr(v.name_off, n + 1, np.int32)
-    names_raw = _arr(v.names, int(name_off[-1]) if n else 0, np.uint8).tobytes()
-    out["names"] = [names_raw[name_off[i]:name_off[i + 1] - 1].decode() for i in range(n)]
+    out["names"] = _Names(_arr(v.names, int(name_off[-1]) if n else 0, np.uint8).tobytes(), np.array(name_off, np.int64))
     out["_owner"] = own
     return out
 
