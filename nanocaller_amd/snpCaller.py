@@ -373,7 +373,12 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
                 collect()
                 done = keys[i - 1][0]
                 if last_use[done] == i - 1:
-                    release_contig(done)     # a genome is walked contig by contig: drop the decoded alignments and the HBM
+                    # a genome is walked contig by contig: drop the decoded alignments and the HBM pack of the one just finished (on an
+                    # ingest thread when there is one: unmapping ~100 MB takes 8 ms this thread would not be launching kernels)
+                    if piped:
+                        prep_pool.submit(release_contig, done)
+                    else:
+                        release_contig(done)
             in_flight = (chrom, ploidy, call, grp)                  # pack of the one just finished
         if in_flight is not None:
             collect()

@@ -50,17 +50,23 @@ class WirePack:
         return self.buf.numpy()[off:off + cnt * np.dtype(dt).itemsize].view(dt)
 
 
+def _ref_wire_lut():
+    lut = np.full(256, 4 | 8, np.uint8)
+    for i, b in enumerate("AGTC"):
+        lut[ord(b)] = i                                            # upper case: base code, scanned
+        lut[ord(b.lower())] = i | 8                                # lower case: base code, skipped
+    return lut
+
+
+_REF_WIRE_LUT = _ref_wire_lut()
+
+
 def ref_wire_from_string(ref: str, exclude=None, pos0=1):
     """uint8 per position (index p - pos0): bits 0-2 base code of the letter in either case (A0 G1 T2 C3, else 4), bit 3 =
     the column is skipped by the scan: not an UPPER-case AGTC (`s in 'AGTC'` before .upper(), generate_SNP_pileups.py:137,
     quirk E4) or inside an exclude interval (tree.overlaps(pos): a <= pos < b, :116-119,161)"""
-    raw = np.frombuffer(ref.encode("ascii"), np.uint8)
-    base = np.full(256, 4, np.uint8)
-    skip = np.full(256, 8, np.uint8)
-    for i, b in enumerate("AGTC"):
-        base[ord(b)] = base[ord(b.lower())] = i
-        skip[ord(b)] = 0
-    out = base[raw] | skip[raw]
+    raw = np.frombuffer(ref.encode("ascii") if isinstance(ref, str) else ref, np.uint8)
+    out = _REF_WIRE_LUT[raw]                                       # one table pass (base | skip)
     for (a, b) in exclude or ():
         lo, hi = max(0, int(a) - pos0), max(0, int(b) - pos0)
         out[lo:hi] |= 8
