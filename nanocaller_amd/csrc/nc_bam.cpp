@@ -44,6 +44,7 @@ struct Bgzf {
     size_t wi = 0;              // next block of the window to hand out
     size_t grow = 16;           // blocks to read ahead next time
     int max_threads = 0;        // inflate threads (0 = all cores, capped at 32)
+    size_t grow_cap = 1024;     // largest window of blocks inflated ahead of the parser (a region decode stops inside its last window: what lies past the region's end there was inflated for nothing)
     std::vector<uint8_t> block;
     int64_t block_coff = 0;     // compressed offset of the current block
     int64_t next_coff = 0;
@@ -170,7 +171,7 @@ struct Bgzf {
             for (auto &x : th) x.join();
         }
         for (auto &k : win) if (!k.ok) return false;
-        if (grow < 1024) grow *= 2;
+        if (grow < grow_cap) grow *= 2;
         return true;
     }
     bool load_block(int64_t coff)
@@ -710,6 +711,7 @@ int nc_bam_decode_regions(const char *path, int32_t tid, int32_t beg1, int32_t e
                 if (rc[(size_t)k] != NC_OK) return;
                 const double t1 = now();
                 b->z.max_threads = 1;                                           // the regions are the parallelism
+                b->z.grow_cap = 32;                                             // ... and short: at most 2 MB inflated past a region's end (up to 64 MB of a 1024-block window before)
                 rc[(size_t)k] = nc_bam_decode(b, tid, edge[(size_t)k], edge[(size_t)k + 1] - 1, keep_seq, &part[(size_t)k]);
                 const double t2 = now();
                 nc_bam_close(b);
