@@ -228,24 +228,50 @@ __global__ __launch_bounds__(256) void k3_fc1(const float *__restrict__ in, int 
     const float *wl = wk + (4 * q) * F + c16;
     const int ng = K / 16;
     const int j0 = (ng * wv) / 4, j1 = (ng * (wv + 1)) / 4;
-#pragma unroll 3
-    for (int j = j0; j < j1; j++) {
-        float4 a[TM];
+    // The loads of group j + NS - 1 are issued before the MFMAs of group j: a wave keeps NS - 1 groups (activations from HBM,
+    // weights from L2) in flight instead of waiting for each group's loads with nothing behind them.
+#ifdef NC_K3_NS
+    constexpr int NS = NC_K3_NS;
+#else
+    constexpr int NS = TM <= 2 ? 4 : 2;
+#endif
+    float4 a[NS][TM];
+    float b[NS][4][TN];
+    auto ld = [&](int st, int j) {
+        j = min(j, j1 - 1);                                             // (past the end: the last group again, unused)
 #pragma unroll
-        for (int tm = 0; tm < TM; tm++) a[tm] = *reinterpret_cast<const float4 *>(ip[tm] + 16 * j);
+        for (int tm = 0; tm < TM; tm++) a[st][tm] = *reinterpret_cast<const float4 *>(ip[tm] + 16 * j);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float b[TN];
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int tn = 0; tn < TN; tn++) b[tn] = wl[(int64_t)(16 * j + i) * F + tn * 16];
+            for (int tn = 0; tn < TN; tn++) b[st][i][tn] = wl[(int64_t)(16 * j + i) * F + tn * 16];
+    };
+    if (j0 < j1) {
+#pragma unroll
+        for (int st = 0; st < NS - 1; st++) ld(st, j0 + st);
+    }
+    auto mm = [&](int u) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int tm = 0; tm < TM; tm++) {
-                const float av = i == 0 ? a[tm].x : i == 1 ? a[tm].y : i == 2 ? a[tm].z : a[tm].w;
+                const float av = i == 0 ? a[u][tm].x : i == 1 ? a[u][tm].y : i == 2 ? a[u][tm].z : a[u][tm].w;
 #pragma unroll
-                for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[tn], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][i][tn], acc[tm][tn], 0, 0, 0);
             }
+    };
+    int j = j0;
+    for (; j + NS <= j1; j += NS) {                                     // whole rounds: no branch between a load and its use
+#pragma unroll
+        for (int u = 0; u < NS; u++) {
+            ld((u + NS - 1) % NS, j + u + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise sinks these loads below the products)
+            mm(u);
         }
     }
+#pragma unroll
+    for (int u = 0; u < NS - 1; u++)                                    // the last groups are already on their way (stage u = group j + u)
+        if (j + u < j1) mm(u);
     if (wv > 0) {
 #pragma unroll
         for (int tm = 0; tm < TM; tm++)
