@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <zlib.h>
+#include <tmmintrin.h>
 
 #include <algorithm>
 #include <chrono>
@@ -232,6 +233,27 @@ struct Nt16Pair {
     }
 };
 const Nt16Pair NT16_PAIR;
+
+// out[q] = NT16_CODE[base q of BAM's 4-bit sequence], q < n (the buffer takes up to 31 bytes more): the whole SEQ of a record at once,
+// so that every M run of its CIGAR is a plain copy.  32 bases a step through two 16-entry byte shuffles where the CPU has SSSE3.
+__attribute__((target("ssse3"))) void seq_codes_ssse3(const uint8_t *seq, int32_t n, uint8_t *out)
+{
+    const __m128i lut = _mm_loadu_si128(reinterpret_cast<const __m128i *>(NT16_CODE)), nib = _mm_set1_epi8(15);
+    const int32_t nb = (n + 1) / 2;
+    int32_t b = 0;
+    for (; b + 16 <= nb; b += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(seq + b));
+        const __m128i hi = _mm_shuffle_epi8(lut, _mm_and_si128(_mm_srli_epi16(v, 4), nib)), lo = _mm_shuffle_epi8(lut, _mm_and_si128(v, nib));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(out + 2 * b), _mm_unpacklo_epi8(hi, lo));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(out + 2 * b + 16), _mm_unpackhi_epi8(hi, lo));
+    }
+    for (; b < nb; b++) memcpy(out + 2 * b, &NT16_PAIR.v[seq[b]], 2);
+}
+void seq_codes_plain(const uint8_t *seq, int32_t n, uint8_t *out)
+{
+    for (int32_t b = 0, nb = (n + 1) / 2; b < nb; b++) memcpy(out + 2 * b, &NT16_PAIR.v[seq[b]], 2);
+}
+void (*const SEQ_CODES)(const uint8_t *, int32_t, uint8_t *) = (__builtin_cpu_init(), __builtin_cpu_supports("ssse3")) ? seq_codes_ssse3 : seq_codes_plain;
 
 }   // namespace
 
@@ -532,7 +554,7 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
     d->ev_off.push_back(0);
     d->seq_off.push_back(0);
     d->name_off.push_back(0);
-    std::vector<uint8_t> rec;
+    std::vector<uint8_t> rec, qc;                    // the record; its bases as codes (SEQ_CODES)
     bool err = false;
     const int32_t beg0 = beg1 - 1, end0 = end1;      // 0-based half-open
     for (; !nothing;) {
@@ -595,6 +617,10 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         // A record without its bases (SEQ '*': l_seq 0, what minimap2 writes for secondary alignments) or with fewer bases
         // than its CIGAR consumes must not be read past its end: its aligned positions decode as 'N' (code 4).
         const bool has_seq = qlen <= (int64_t)l_seq;
+        if (has_seq || keep_seq) {
+            if (qc.size() < (size_t)l_seq + 34) qc.resize((size_t)l_seq + 34 + (size_t)l_seq / 4);
+            SEQ_CODES(seq, l_seq, qc.data());
+        }
         // codes + indel markers
         const size_t c0 = d->codes.size();
         d->codes.resize(c0 + (size_t)rlen);
@@ -607,13 +633,10 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
             switch (op) {
             case 0: case 7: case 8:                                   // M, =, X
                 if (q_first < 0) q_first = qp;                        // query index of the first aligned base (leading S / I skipped)
-                if (has_seq) {
-                    // two bases a byte: after an odd first base, whole bytes of the 4-bit sequence go through a 256-entry table of code pairs
-                    int i = 0;
-                    if ((qp & 1) && i < len) { co[rp++] = NT16_CODE[seq[qp >> 1] & 15]; qp++; i++; }
-                    for (; i + 2 <= len; i += 2, rp += 2, qp += 2) memcpy(co + rp, &NT16_PAIR.v[seq[qp >> 1]], 2);
-                    if (i < len) { co[rp++] = NT16_CODE[seq[qp >> 1] >> 4]; qp++; }
-                } else for (int i = 0; i < len; i++, rp++, qp++) co[rp] = 4;
+                if (has_seq) memcpy(co + rp, qc.data() + qp, (size_t)len);
+                else memset(co + rp, 4, (size_t)len);
+                rp += len;
+                qp += len;
                 break;
             case 1:                                                   // I: '+n' on the previous reference column
                 if (rp > 0) { d->ev_pos.push_back(pos + rp); d->ev_len.push_back(len); }
@@ -673,7 +696,7 @@ int nc_bam_decode(nc_bam *b, int32_t tid, int32_t beg1, int32_t end1, int32_t ke
         if (keep_seq) {
             const size_t s0 = d->seq.size();
             d->seq.resize(s0 + (size_t)l_seq);
-            for (int32_t q = 0; q < l_seq; q++) d->seq[s0 + (size_t)q] = NT16_CODE[(seq[q >> 1] >> ((~q & 1) << 2)) & 15];
+            if (l_seq > 0) memcpy(d->seq.data() + s0, qc.data(), (size_t)l_seq);
         }
         d->seq_off.push_back((int64_t)d->seq.size());
     }

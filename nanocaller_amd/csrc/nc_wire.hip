@@ -16,6 +16,7 @@
 #include <vector>
 
 #include <cstdlib>
+#include <emmintrin.h>
 
 #include "nc_common.h"
 #include "nc_host.h"
@@ -84,13 +85,48 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
                     const int64_t base = w->slot_off[(size_t)q] - floor16w(s);                // codes[base + p]
                     const int64_t p_lo = std::max<int64_t>(s, byte0 - base), p_hi = std::min<int64_t>(e, byte1 - base);
                     const uint8_t *src = codes_in + rd_off[(size_t)q] - s;                     // src[p]
-                    for (int64_t p = p_lo; p < p_hi; p++) {
-                        const int64_t ri = p - ref_pos0;
-                        const unsigned rb = (ri >= 0 && ri < ref_len) ? (ref_wire[ri] & 7u) : 4u;
+                    const int64_t off0 = base - byte0;                                         // event offset of position p: off0 + p
+                    // positions off the reference grid (none in a pack built by build_wire: the grid covers every kept read) compare with 'N'
+                    const int64_t g_lo = std::min(std::max<int64_t>(p_lo, ref_pos0), p_hi), g_hi = std::max(std::min<int64_t>(p_hi, ref_pos0 + ref_len), g_lo);
+                    unsigned worst = 0;
+                    for (int64_t p = p_lo; p < g_lo; p++) {
                         const unsigned c = src[p];
-                        if (c > 7u || c == NC_CODE_ABSENT) { status[(size_t)t] = NC_ERR_ARG; return; }
-                        if (c != rb) ev.push_back((uint16_t)((base + p - byte0) | (c << 12)));
+                        worst = std::max(worst, c);
+                        if (c != 4u) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
                     }
+                    // on the grid: 16 positions a step (SSE2 is part of x86-64), the ~8 % that differ leave through the mask's set bits
+                    const uint8_t *rf = ref_wire - ref_pos0;                                    // rf[p]
+                    int64_t p = g_lo;
+                    const __m128i seven = _mm_set1_epi8(7);
+                    __m128i vmax = _mm_setzero_si128();
+                    for (; p + 16 <= g_hi; p += 16) {
+                        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + p));
+                        const __m128i r = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i *>(rf + p)), seven);
+                        vmax = _mm_max_epu8(vmax, c);
+                        unsigned m = ~(unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(c, r)) & 0xffffu;
+                        while (m) {
+                            const int k = __builtin_ctz(m);
+                            m &= m - 1;
+                            ev.push_back((uint16_t)((off0 + p + k) | ((unsigned)src[p + k] << 12)));
+                        }
+                    }
+                    vmax = _mm_max_epu8(vmax, _mm_srli_si128(vmax, 8));
+                    vmax = _mm_max_epu8(vmax, _mm_srli_si128(vmax, 4));
+                    vmax = _mm_max_epu8(vmax, _mm_srli_si128(vmax, 2));
+                    vmax = _mm_max_epu8(vmax, _mm_srli_si128(vmax, 1));
+                    worst = std::max(worst, (unsigned)_mm_cvtsi128_si32(vmax) & 0xffu);         // (a byte >= 7 shows in the maximum)
+                    unsigned wmax = worst;
+                    for (; p < g_hi; p++) {
+                        const unsigned c = src[p];
+                        wmax = std::max(wmax, c);
+                        if (c != (rf[p] & 7u)) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                    }
+                    for (p = g_hi; p < p_hi; p++) {
+                        const unsigned c = src[p];
+                        wmax = std::max(wmax, c);
+                        if (c != 4u) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                    }
+                    if (wmax >= NC_CODE_ABSENT) { status[(size_t)t] = NC_ERR_ARG; return; }   // codes are 0..6
                 }
                 w->blk_off[(size_t)b + 1] = (uint32_t)(ev.size() - before);
             }
