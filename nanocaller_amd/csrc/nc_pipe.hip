@@ -813,10 +813,13 @@ struct TbLine {
         cblk = (i + q) >> TWB_LOG;
         cq = q;
         const uint32_t *src = Tw + tw_run(arow, i + q, q, CPL);
-        for (int u = 0; u < CPL; u += 4) {                               // (whole dwordx4s: up to three words of the next run come along; the buffers end in a pad)
-            const U4 v = *reinterpret_cast<const U4 *>(src + u);
-            slot[u] = v.x; slot[u + 1] = v.y; slot[u + 2] = v.z; slot[u + 3] = v.w;
-        }
+        U4 v[5];                                                         // (whole dwordx4s: up to three words of the next run come along; the buffers end in a pad)
+#pragma unroll
+        for (int u = 0; u < 5; u++)                                      // CPL <= 17: at most five, all on their way before the first is used (left as an open
+            if (4 * u < CPL) v[u] = *reinterpret_cast<const U4 *>(src + 4 * u);     // loop the compiler unrolled it sixteen times: 114 VGPRs instead of 42)
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+            if (4 * u < CPL) { slot[4 * u] = v[u].x; slot[4 * u + 1] = v[u].y; slot[4 * u + 2] = v[u].z; slot[4 * u + 3] = v[u].w; }
     }
     // cell (i, j) of the cached line (the caller checked has(i))
     __device__ __forceinline__ uint32_t code(int i, int CPL, int fmt) const
