@@ -253,7 +253,9 @@ void seq_codes_plain(const uint8_t *seq, int32_t n, uint8_t *out)
 {
     for (int32_t b = 0, nb = (n + 1) / 2; b < nb; b++) memcpy(out + 2 * b, &NT16_PAIR.v[seq[b]], 2);
 }
-void (*const SEQ_CODES)(const uint8_t *, int32_t, uint8_t *) = (__builtin_cpu_init(), __builtin_cpu_supports("ssse3")) ? seq_codes_ssse3 : seq_codes_plain;
+// (NC_BAM_PLAIN_SEQ=1: the table form on any CPU -- what tests/test_bam_ingest.py compares the shuffle form with)
+void (*const SEQ_CODES)(const uint8_t *, int32_t, uint8_t *) =
+    (__builtin_cpu_init(), __builtin_cpu_supports("ssse3")) && !getenv("NC_BAM_PLAIN_SEQ") ? seq_codes_ssse3 : seq_codes_plain;
 
 }   // namespace
 

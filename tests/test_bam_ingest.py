@@ -57,6 +57,23 @@ def test_whole_contig_roundtrip(files):
     assert sum(int((got.meta["events"][2] > 0).sum()) for _ in [0]) > 20 and int((got.meta["events"][2] < 0).sum()) > 20
 
 
+def test_table_form_of_the_sequence_decode_equals_the_shuffle_form(files):
+    """nc_bam_decode turns a record's 4-bit SEQ into codes with two byte shuffles per 32 bases where the CPU has SSSE3 and through a
+    256-entry pair table otherwise; the library picks once at load time, so the other form runs in a second interpreter"""
+    import hashlib
+    import subprocess
+    import sys
+    world, bam, fa, _ = files
+    prog = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from nanocaller_amd.bam import read_bam\n"
+            "g = read_bam(%r, %r, %r, keep_seq=True)\n"
+            "print(hashlib.md5(g.codes.tobytes() + g.meta['seq'].tobytes()).hexdigest())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bam, fa, world.chrom)
+    out = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, NC_BAM_PLAIN_SEQ="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = read_bam(bam, fa, world.chrom, keep_seq=True)
+    assert out.stdout.strip().splitlines()[-1] == hashlib.md5(got.codes.tobytes() + got.meta["seq"].tobytes()).hexdigest()
+
+
 @pytest.mark.parametrize("use_index", [True, False])
 def test_region_queries(files, tmp_path, use_index):
     world, bam, fa, _ = files
