@@ -607,16 +607,17 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     const int pair = blockIdx.x * 4 + g;
     int al[2], n1[2], n2[2];
     bool live[2];
-    const uint8_t *s1[2], *s2[2];
+    const uint8_t *s2[2];
+    uint32_t s1o[2];                                                  // the read's bases at p.s1 + s1o (32-bit offsets and block indices: a register fewer each than 64-bit values)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int a = pair * 2 + k;
         live[k] = a < p.A;
         al[k] = live[k] ? a : 0;
         n1[k] = 0; n2[k] = 0;
-        s1[k] = p.s1; s2[k] = p.ref_code;
+        s1o[k] = 0; s2[k] = p.ref_code;
         if (live[k]) {
-            s1[k] = p.s1 + (int64_t)al[k] * p.s1_stride;
+            s1o[k] = (uint32_t)al[k] * (uint32_t)p.s1_stride;
             n1[k] = p.n1[al[k]];
             const int site = fill_site(p, al[k]);
             s2[k] = p.ref_code + (p.site_pos[site] - p.ref_pos0);
@@ -635,9 +636,9 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     int nmax = max(n1[0], n1[1]);
     nmax = max(nmax, __shfl_xor(nmax, 16));
     nmax = max(nmax, __shfl_xor(nmax, 32));
-    int64_t arow[2];
+    uint32_t arow[2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) arow[k] = p.arow ? p.arow[al[k]] : (int64_t)al[k] * tw_blocks(p.N1);
+    for (int k = 0; k < 2; k++) arow[k] = p.arow ? (uint32_t)p.arow[al[k]] : (uint32_t)al[k] * (uint32_t)tw_blocks(p.N1);
     __shared__ uint32_t tw_lds[2 * TWB * 64 * NWP];
     const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match + p.open), k_dmis = splat16(p.mismatch - p.match);
     const uint32_t k_one = splat16(1);
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     const int jc_uni = __all(n2[0] == n2_first && n2[1] == n2_first && n2_first > 0) ? (n2_first - 1) % CPL : -1;      // wave-uniform (scalar)
     // read bases of both alignments: lane q holds base 16*blk + q (packed), see k_fill16p
     auto load_chunk = [&](int idx) {
-        const uint32_t b0 = idx < n1[0] ? (uint32_t)s1[0][idx] : 4u, b1 = idx < n1[1] ? (uint32_t)s1[1][idx] : 4u;
+        const uint32_t b0 = idx < n1[0] ? (uint32_t)p.s1[s1o[0] + (uint32_t)idx] : 4u, b1 = idx < n1[1] ? (uint32_t)p.s1[s1o[1] + (uint32_t)idx] : 4u;
         return b0 | (b1 << 16);
     };
     uint32_t chunk = load_chunk(q), chunk_nxt = load_chunk(16 + q), c1 = splat16(4);
@@ -1035,11 +1036,12 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
         uint64_t cnt[3] = {0, 0, 0};
         for (int64_t ab = a0; ab < a1; ab += 8) {
             uint32_t en8[8];
-            int sym8[8], mb8[8];
+            int sym8[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) en8[u] = p.ent[min(ab + u, a1 - 1) * p.EW + j];
-#pragma unroll
-            for (int u = 0; u < 8; u++) mb8[u] = ab + u < a1 ? (int)mem[ab + u] : 0;        // (with the other loads, not one by one inside the loop below)
+            // the eight member bytes as two unaligned words, with the other loads, not one by one inside the loop below (the array ends in a pad)
+            typedef uint32_t __attribute__((aligned(1))) u32_u;
+            const uint32_t mlo = *reinterpret_cast<const u32_u *>(mem + ab), mhi = *reinterpret_cast<const u32_u *>(mem + ab + 4);
 #pragma unroll
             for (int u = 0; u < 8; u++) {                             // the base aligned to position j (index clamped: unused when there is none)
                 const int qi = (int)(en8[u] & 0x3ffu) - 1;
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
             for (int u = 0; u < 8; u++) {
                 const int64_t a = ab + u;
                 if (a >= a1) continue;
-                const int mb = mb8[u];
+                const int mb = (int)(((u < 4 ? mlo : mhi) >> (8 * (u & 3))) & 0xffu);
                 const uint32_t en = en8[u];
                 if (j < n2 && (en & 0x3ffu) != 0 && sym8[u] < 4) {    // anything else (a read base N) counts as a gap at its column
                     const uint64_t one = 1ull << (16 * sym8[u]);
