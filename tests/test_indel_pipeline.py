@@ -343,6 +343,39 @@ def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement
 
 
 @pytest.mark.gpu
+def test_device_pipeline_at_scale_is_deterministic_and_group_invariant(monkeypatch):
+    """8 Mb of the bench workload (5 k candidate sites, 130 k read windows): two runs give the same bytes, and so does the run loop cut into
+    ~40 groups of alignments (two streams, two buffer sets handed back and forth by events: a race there shows up only with many groups)"""
+    import torch
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    eng = get_engine(0)
+    L = 8_000_000
+    pack, reads_c, info = make_indel_device_workload(eng, L, depth=30.0, seed=4242)
+    chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+    keys = ("pos", "chunk", "type", "phase", "ref_len", "alt_len", "alt")
+
+    def run():
+        r = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+        return {k: np.array(r[k]) for k in keys}, r["x"].clone(), r["n"], r["n_alignments"]
+    a, xa, n, nal = run()
+    assert n > 3000 and nal > 80_000
+    b, xb, _, _ = run()
+    monkeypatch.setenv("NC_PIPE_GROUP_AL", str(max(1000, nal // 40)))
+    c, xc, _, _ = run()
+    for other, xo in ((b, xb), (c, xc)):
+        for k in keys:
+            assert np.array_equal(other[k], a[k]), k
+        assert torch.equal(xo, xa)
+    # the tensors' frequencies: every used column of every set sums to one over the five symbols (msa(), :57-71), before the reference one-hot is taken off
+    x = xa.view(n, -1, 5, 128, 2)
+    tot = (x[..., 0] + x[..., 1]).sum(dim=2)
+    used = x[..., 1].sum(dim=2) > 0
+    assert used.any() and float((tot[used] - 1.0).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
 def test_tiled_event_windows_equal_the_atomic_form(monkeypatch):
     """pass 1 of the device pipeline counts the reads with an indel event in each window in LDS, one workgroup per 1024 columns
     (k_event_tiles: margins, clipped interval ends, reads listed in the previous tile); NC_K7_EVENT_ATOMICS=1 keeps the form the host
