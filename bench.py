@@ -474,9 +474,15 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
     try:
         with open(os.path.join(ROOT, "profiles", "indel_traffic.json")) as f:
             it = json.load(f)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from build_tag import INDEL_SOURCES
+        tag_ok, tag_note = traffic_build_check(it, INDEL_SOURCES)
         for name, st in stages.items():
             key = "fill (star alignment + allele alignment)" if name == "star_alignment_fill" else name
-            if key in it["stages"]:
+            if key in it["stages"] and not tag_ok:
+                st["traffic"] = None
+                st["traffic_note"] = tag_note
+            elif key in it["stages"]:
                 st["traffic"] = it["stages"][key]["bytes_per_site"] * n_sites
                 st["traffic_note"] = "HBM bytes per pass = bytes per candidate site by counter (%s) x sites of this run" % it.get("source", "profiles/indel_traffic.json")
                 if st.get("bound") == "hbm" and st["ms"] > 0:
@@ -644,6 +650,19 @@ def trunk_traffic_from_profiles():
             return json.load(f)
     except (OSError, ValueError):
         return None
+
+
+def traffic_build_check(record, sources):
+    """(ok, note): counter passes are reported only when they were taken on the kernel sources this run executes -- the json carries the
+    sha-256 tag of those files (tools/build_tag.py), compared with the files beside this script"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_tag import build_tag
+    have = build_tag(sources, ROOT)
+    want = record.get("build_tag")
+    if want == have:
+        return True, None
+    return False, "the committed PMC passes (%s) belong to another build of %s (tag %s, this build %s): not reported" % (
+        record.get("source", "profiles"), ", ".join(os.path.basename(s_) for s_ in sources), want, have)
 
 
 def main():
@@ -819,12 +838,16 @@ def main():
         scan_bytes = c0.entries + L                            # (d+1) B/column, SURVEY.md 8d
         feat_bytes = (5403 - 2050) * n_sites                  # SURVEY.md 8d's 5,403 B/site with the tensor written as int16 (2,050 B) instead of fp32
         tt = trunk_traffic_from_profiles()
-        traffic = None
+        traffic, stale_note = None, None
         if tt and tt.get("kernel") == ("k4_conv12" if exact_fp32 else "k5_trunk_h3"):
-            traffic = tt["bytes_per_site"] * sites_timed / n_launch
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from build_tag import TRUNK_SOURCES
+            tag_ok, stale_note = traffic_build_check(tt, TRUNK_SOURCES)
+            if tag_ok:
+                traffic = tt["bytes_per_site"] * sites_timed / n_launch
         common = {"achieved": trunk_tflops, "unit": "TFLOP/s", "traffic": traffic,
                   "traffic_note": ("HBM bytes per launch = bytes per site from the committed PMC passes (%s) x sites per launch of this run"
-                                   % tt.get("source", "profiles/trunk_traffic.json")) if traffic else "no PMC pass committed for this kernel build",
+                                   % tt.get("source", "profiles/trunk_traffic.json")) if traffic else (stale_note or "no PMC pass committed for this kernel build"),
                   "launches_in_timed_region": n_launch, "avg_launch_ms": float(trunk_ms / n_launch),
                   "flop_per_launch": TRUNK_FLOP_PER_SITE * sites_timed / n_launch,
                   "cnn_stage_tflops": cnn_tflops, "cnn_stage_ms": float(stage_ms[2])}

@@ -6,8 +6,12 @@ usage: pmc_indel_to_json.py fetch_counter_collection.csv write_counter_collectio
 import csv
 import json
 import re
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_tag import INDEL_SOURCES, build_tag
 
 STAGE = {"k_hap_depth_b": "k7_scan_anchors_sets", "k_yield_rank_b": "k7_scan_anchors_sets", "k_entry_reads": "k7_scan_anchors_sets",
          "k_event_tiles": "k7_scan_anchors_sets", "k_pick": "k7_scan_anchors_sets", "k_sets": "k7_scan_anchors_sets", "k_flatten": "k7_scan_anchors_sets",
@@ -39,6 +43,6 @@ for k in sorted(set(f) | set(w)):
     stage[STAGE[k]][1] += wr
 out = {"sites_per_pass": sites, "passes": passes, "kernels": kern,
        "stages": {s: {"read_bytes_per_site_corrected": v[0], "write_bytes_per_site": v[1], "bytes_per_site": v[0] + v[1]} for s, v in stage.items()},
-       "source": sys.argv[6]}
+       "source": sys.argv[6], "build_tag": build_tag(INDEL_SOURCES), "build_tag_of": list(INDEL_SOURCES)}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(json.dumps(out["stages"], indent=1))

@@ -5,8 +5,12 @@ FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 reports half o
 usage: pmc_to_json.py fetch_counter_collection.csv write_counter_collection.csv kernel-substring sites_per_unit out.json source-note"""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_tag import TRUNK_SOURCES, build_tag
 
 
 def total(path, want, counter):
@@ -30,6 +34,6 @@ sites = float(sys.argv[4])
 out = {"kernel": sys.argv[3], "bytes_per_site": (2 * f * 1024 / fu + w * 1024 / wu) / sites,
        "read_bytes_per_site_corrected": 2 * f * 1024 / fu / sites, "write_bytes_per_site": w * 1024 / wu / sites,
        "fetch_size_raw_KiB": f, "write_size_KiB": w, "launches": [fd, wd], "contig_passes": [fu, wu], "sites_per_pass": sites,
-       "source": sys.argv[6]}
+       "source": sys.argv[6], "build_tag": build_tag(TRUNK_SOURCES), "build_tag_of": list(TRUNK_SOURCES)}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(out)
