@@ -1354,6 +1354,7 @@ struct nc_pipe_state {
     int32_t n_chunks = 0, n_anchor = 0, n_sites = 0;
     int64_t n_al = 0;
     int32_t *al0_pin = nullptr;             // page-locked: first alignment of every site (+ total), read by the host to cut the groups
+    int64_t tw_budget = 0;                  // bytes of traceback codes per group (set at the first run from the free device memory)
     size_t al0_cap = 0;
     DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
     DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
@@ -1606,9 +1607,16 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     const int WS = (s->window_after + 15) & ~15;
     const int N1 = WS;
     const int CPL = cpl_for(s->window_after + 1);
-    // groups of whole sites: traceback codes of a group's alignments <= 6 GiB (two groups are in flight)
+    // groups of whole sites, two in flight: the traceback codes of a group's alignments (16 KB each for 160-base windows) take a twelfth of
+    // the device memory that is free when the context first runs, at most 24 GiB (a chr20-sized contig's 1.07 M alignments are then ONE group:
+    // 24.4 -> 23.7 ms per pass against three groups of 6 GiB -- fewer launches and host waits, no allele stage with stream A idle); at least 1 GiB
     const int64_t tw_per_al = (int64_t)tw_blocks(N1) * 64 * CPL;          // bytes: blocks of 8 steps x 16 lanes x CPL words
-    int64_t GROUP_AL = std::max<int64_t>(4096, ((int64_t)6 << 30) / tw_per_al);
+    if (s->tw_budget == 0) {
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) mfree = (size_t)72 << 30;
+        s->tw_budget = std::min<int64_t>((int64_t)24 << 30, std::max<int64_t>((int64_t)1 << 30, (int64_t)(mfree / 12)));
+    }
+    int64_t GROUP_AL = std::max<int64_t>(4096, s->tw_budget / tw_per_al);
     if (const char *g = getenv("NC_PIPE_GROUP_AL")) GROUP_AL = std::max<int64_t>(64, atoll(g));
     const int64_t GROUP_SITES = 65536;
     int32_t *err = (int32_t *)s->misc.p;
@@ -1621,11 +1629,17 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
     NC_TRY(nc_ensure(ctx, s->alen, (size_t)ns * S * 4));
     const int32_t *al0h = s->al0_pin;
     std::vector<std::pair<int, int>> groups;
-    for (int k0 = 0; k0 < ns;) {
-        int k1 = k0 + 1;
-        while (k1 < ns && k1 - k0 < GROUP_SITES && (int64_t)al0h[k1 + 1] - al0h[k0] <= GROUP_AL) k1++;
-        groups.emplace_back(k0, k1);
-        k0 = k1;
+    {
+        // as many groups as the bounds need, of about the same number of alignments each (filled greedily the last one is a remainder)
+        const int64_t total_al = al0h[ns];
+        const int64_t ng = std::max<int64_t>(std::max<int64_t>(1, (total_al + GROUP_AL - 1) / GROUP_AL), (ns + GROUP_SITES - 1) / GROUP_SITES);
+        const int64_t target = std::min<int64_t>(GROUP_AL, (total_al + ng - 1) / ng + 64);
+        for (int k0 = 0; k0 < ns;) {
+            int k1 = k0 + 1;
+            while (k1 < ns && k1 - k0 < GROUP_SITES && (int64_t)al0h[k1 + 1] - al0h[k0] <= target) k1++;
+            groups.emplace_back(k0, k1);
+            k0 = k1;
+        }
     }
     const int G = (int)groups.size();
     // Stream A (the context's): query windows + alignment fill (bound by vector issue).  Stream B: traceback, tensors, allele_prediction
