@@ -23,12 +23,13 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 8   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+#define NC_ABI_VERSION 9   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
-                                 nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_* */
+                                 nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
+                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -513,6 +514,14 @@ int nc_indel_sites_fetch_alt(nc_ctx *ctx, uint8_t *alt_bases, int64_t cap);
 /* per-stage HIP-event milliseconds of the last plan + run on this context (timing mode 1): [0] pass 1 + anchors + sets,
  * [1] query windows, [2] alignment fill, [3] traceback, [4] tensors + consensus, [5] allele alignment + extraction */
 int nc_indel_sites_stage_ms(nc_ctx *ctx, float *ms6, int64_t *cells2 /* [0] DP cells of the star alignments, [1] of the allele alignments */);
+/* The star alignment behind msa() (generate_indel_pileups.py:24-44; MUSCLE in the reference) runs on a BAND of 32 or 64 diagonals around
+ * the diagonals the read's own CIGAR visits inside the window; an alignment whose band would be wider, or whose banded path touches an edge
+ * diagonal, runs on the full matrix.  Counts of the last plan + run + fetch: [0] alignments on 32 diagonals, [1] on 64, [2] on the full
+ * matrix because of their width, [3] re-run on the full matrix after an edge touch.  NC_PIPE_BAND=0 in the environment turns the band off. */
+int nc_indel_sites_band_stats(nc_ctx *ctx, int64_t *stats4);
+/* mode 1 / 0: band on / off for this context (-1: the environment's setting, the default = on); margin = diagonals kept free on either side
+ * of the CIGAR's range, 1 .. 15 (0: the default, 6; NC_PIPE_BAND_MARGIN) */
+int nc_indel_sites_band(nc_ctx *ctx, int32_t mode, int32_t margin);
 
 /* Indel genotype rules + VCF record text (indelCaller.py:87-152, haploid :173-179), host, printf-free: sites in the order of
  * nc_indel_sites_fetch; `prev` (overlap suppression, :93) restarts at every chunk, as each chunk is one call of indel_run's

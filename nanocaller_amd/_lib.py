@@ -18,7 +18,7 @@ NC_ERR_CAPACITY = -2
 NC_ERR_NOMEM = -3
 NC_ERR_UNSUPPORTED = -7
 FLAG_REFSKIP = 0x10000   # nc_decoded_arrays.flag bit: the CIGAR holds a reference skip
-ABI_VERSION = 8          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
+ABI_VERSION = 9          # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -42,7 +42,7 @@ EXPORTS = [
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
     "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
-    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
+    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
 ]
 
 
@@ -206,6 +206,8 @@ def lib():
         L.nc_indel_sites_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
         L.nc_indel_sites_fetch_alt.argtypes = [vp, vp, i64]
         L.nc_indel_sites_stage_ms.argtypes = [vp, vp, vp]
+        L.nc_indel_sites_band_stats.argtypes = [vp, vp]
+        L.nc_indel_sites_band.argtypes = [vp, i32, i32]
         L.nc_indel_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, i32, vp, i32, vp, vp, vp, vp, C.c_char_p, i64, i32, vp, i64, C.POINTER(i64), vp]
         L.nc_synth_indel_truth.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
         L.nc_synth_indel_reads.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -19,6 +19,7 @@
 // Results equal nc_indel_pass2_sets -> nc_star_msa_tensor_dup -> nc_allele_prediction_device (tests/test_indel_pipeline.py).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "nc_common.h"
@@ -31,6 +32,7 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 namespace {
 
 constexpr int PICK_CAP = 12288;        // anchors of one chunk held in LDS by k_pick (a 100 kb chunk has at most 9,092)
+constexpr int BAND_NBLK = 41;        // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= 328
 constexpr int CNS_CAP = 1024;          // alignment columns of one read set (window + the longest insertion of every slot)
 constexpr int32_t NW_NEG = -(1 << 29);
 enum : uint32_t { T_DIAG = 0, T_DEL = 1, T_INS = 2, T_EEXT = 4, T_FEXT = 8 };
@@ -304,17 +306,24 @@ struct WinArgs {
     uint8_t *win;           // [A][WS]
     int32_t *n1;            // [A]
     unsigned long long *cells;
+    // banded alignment (k_fill_band): the diagonals j - i the read's own CIGAR visits inside the window bound the band
+    int8_t *band_lo;        // [A] lowest diagonal of the alignment's band (even, <= 0), or NULL: no banding
+    int32_t *list1, *list2, *listF;   // alignments whose band fits 32 / 64 diagonals; the rest (full matrix)
+    int32_t *counts;        // [0] list1, [1] list2, [2] listF (k_trace_band appends the paths that touch a band edge), [3] class F by width alone
+    int32_t band_margin;    // diagonals kept free on either side of the CIGAR's range
 };
 
 __global__ __launch_bounds__(64) void k_windows(WinArgs p)
 {
     const int al = blockIdx.x * 64 + threadIdx.x;
     long long mycells = 0;
+    int cls = -1;
     if (al < p.A) {
         const int r = p.al_read[al], site = p.al_site[al];
         const int32_t v = p.site_pos[site];
         uint32_t *out = reinterpret_cast<uint32_t *>(p.win + (int64_t)al * p.WS);       // rows are 16-byte aligned
         int n = 0;
+        int dcur = 0, dmin = 0, dmax = 0;                                                 // diagonal (window column - read index) of the CIGAR's path
         uint32_t acc = 0;
         auto emit = [&](uint32_t b) {                                                     // bases leave as whole words
             acc |= b << ((n & 3) * 8);
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
                 const int32_t el = p.ev_len[k - 1];
                 if (el < 0) del_until = p.ev_pos[k - 1] - el;
             }
+            if (del_until >= v) { dcur = del_until + 1 - v; dmax = dcur; }     // the window opens inside a deletion: its first base sits on column del_until + 1
             const int32_t rs = p.rd_start[r], re = p.rd_end[r];
             const uint8_t *cd = p.codes + (p.slot_off[r] - (rs & ~15));       // code of position x at cd[x]; 16-position groups are aligned
             int32_t next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
@@ -353,19 +363,55 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
                     while (next_ev == x) {
                         const int32_t el = p.ev_len[k];
                         if (el > 0) {
+                            const int nb = n;
                             for (int i = p.ins_off[k]; i < p.ins_off[k + 1] && n < p.W; i++) emit(p.ins_bases[i]);
-                        } else del_until = x - el;
+                            dcur -= n - nb;
+                            dmin = min(dmin, dcur);
+                        } else {
+                            del_until = x - el;
+                            dcur -= el;
+                            dmax = max(dmax, dcur);
+                        }
                         k++;
                         next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
                     }
                 }
             }
-            if (x >= re)
+            if (x >= re) {                                           // the soft-clipped tail has no column of its own: an insertion behind the last one
+                const int nb = n;
                 for (int i = p.tail_off[r]; i < p.tail_off[r + 1] && n < p.W; i++) emit(p.tail_bases[i]);
+                dcur -= n - nb;
+                dmin = min(dmin, dcur);
+            }
         }
         if (n & 3) out[n >> 2] = acc;
         p.n1[al] = n;
         mycells = (long long)n * p.site_n2[site];
+        if (p.band_lo) {
+            // band of B = 32 or 64 diagonals around [dmin, dmax] (0 is inside: the path starts at the origin), the slack split evenly, lowest
+            // diagonal even (the anti-diagonal sweep alternates between the even and the odd diagonals of the band)
+            const int w = dmax - dmin;
+            cls = w + 2 * p.band_margin <= 31 ? 0 : w + 2 * p.band_margin <= 63 ? 1 : 2;
+            const int B = cls == 0 ? 32 : 64;
+            int lo = dmin - ((B - 1 - w) >> 1);
+            lo -= lo & 1;
+            p.band_lo[al] = (int8_t)(cls == 2 ? 0 : lo);
+        }
+    }
+    if (p.band_lo) {                                                                      // class lists: one atomic per wave and class
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const unsigned long long m = __ballot(cls == c);
+            if (!m) continue;
+            int base = 0;
+            if (threadIdx.x == __ffsll((long long)m) - 1) {
+                base = atomicAdd(p.counts + c, __popcll(m));
+                if (c == 2) atomicAdd(p.counts + 3, __popcll(m));
+            }
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            int32_t *lst = c == 0 ? p.list1 : c == 1 ? p.list2 : p.listF;
+            if (cls == c) lst[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = al;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
@@ -388,6 +434,8 @@ struct FillArgs {
     uint32_t *Tw;
     int32_t *Hlast, *hcol;       // free-tail end point inputs (NULL for a global alignment, and when `endcell` is set)
     int2 *endcell;               // free-tail end point (i, j) of alignment a (k_end_cells), read by k_trace16p instead of Hlast / hcol
+    // list mode (the banded route's fallback): entry x < min(*count, A) of `list` is the alignment, x its slot in Tw / Hlast / hcol / endcell
+    const int32_t *list, *count;
 };
 
 __device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t v)
@@ -605,21 +653,24 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     constexpr int NH = (CPL + 3) / 4;                          // packed registers of 4 cells x 4 bits per alignment
     const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
     const int pair = blockIdx.x * 4 + g;
-    int al[2], n1[2], n2[2];
+    const int A_live = p.count ? min(*p.count, p.A) : p.A;
+    if ((int)blockIdx.x * 8 >= A_live) return;
+    int al[2], n1[2], n2[2];                                          // al: the slot in Tw / Hlast / hcol (the alignment itself outside list mode)
     bool live[2];
     const uint8_t *s2[2];
     uint32_t s1o[2];                                                  // the read's bases at p.s1 + s1o (32-bit offsets and block indices: a register fewer each than 64-bit values)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int a = pair * 2 + k;
-        live[k] = a < p.A;
+        live[k] = a < A_live;
         al[k] = live[k] ? a : 0;
         n1[k] = 0; n2[k] = 0;
         s1o[k] = 0; s2[k] = p.ref_code;
         if (live[k]) {
-            s1o[k] = (uint32_t)al[k] * (uint32_t)p.s1_stride;
-            n1[k] = p.n1[al[k]];
-            const int site = fill_site(p, al[k]);
+            const int ain = p.list ? p.list[a] : a;
+            s1o[k] = (uint32_t)ain * (uint32_t)p.s1_stride;
+            n1[k] = p.n1[ain];
+            const int site = fill_site(p, ain);
             s2[k] = p.ref_code + (p.site_pos[site] - p.ref_pos0);
             n2[k] = p.site_n2[site];
         }
@@ -753,15 +804,328 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     }
 }
 
+// ---- the banded form.  Every read window was rebuilt from the reference and the read's own CIGAR events (k_windows), so the diagonals
+// d = j - i the optimal path can visit are known up front: the range the CIGAR's path covers inside the window plus a margin.  The band
+// of B = 32 C diagonals [lo, lo + B) (lo even) is swept by ANTI-DIAGONALS a = i + j: on an even a the band's even diagonals hold a cell,
+// on an odd a the odd ones, B / 2 cells either way -- one (C = 1) or two (C = 2) per lane of a 16-lane group, all independent:
+//     lane q, cell c, x = q C + c:   a even: d = lo + 2 x        a odd: d = lo + 2 x + 1          i = (a - d) / 2, j = (a + d) / 2
+//     left (i, j-1) = diagonal d - 1 of a - 1:   a odd: the same lane cell     a even: lane cell x - 1 (row_shr:1 across lanes)
+//     up   (i-1, j) = diagonal d + 1 of a - 1:   a odd: lane cell x + 1 (row_shl:1)     a even: the same lane cell
+//     diag (i-1, j-1) = diagonal d of a - 2:     the same lane cell
+// so a lane cell walks a staircase down its pair of diagonals: j grows on odd steps (the reference bases move one lane cell down, a new one
+// enters at the top lane), i on even steps (the read bases move one lane cell up, a new one enters at lane 0).  321 steps of one or two
+// cells replace 175 steps of 11 (k_fill16q), and 4 bits per cell and step leave as ONE word per lane and 8 steps: 2.6 KB of traceback
+// codes per alignment instead of 19 KB.  Cells outside the rectangle compute bounded garbage nothing reads: H(0,0) = 0 is planted in the
+// registers of step 0, everything around it starts at "minus infinity", and the recurrence itself then produces row 0 and column 0
+// (E / F chains from the origin).  Cells outside the band read as minus infinity (what a DPP shift hands the lanes at a row's end).  Two alignments per
+// group in the halves of every register, arithmetic and tie rules exactly those of k_fill16q; a path that touches an edge diagonal of the
+// band is re-run on the full matrix (k_trace_band -> listF).
+struct BandArgs {
+    FillArgs f;                  // windows, reference, scoring (Tw / Hlast / hcol / endcell unused)
+    const int32_t *list;         // the alignments of this class (indices into the group), *count of them
+    const int32_t *count;
+    const int8_t *band_lo;       // [A] lowest diagonal (even, -B < lo <= 0)
+    uint32_t *Twb;               // [A][NBLK * 32] words: block b of an alignment = 16 C words at b * 16 C (lane q's C words at q * C)
+    int16_t *hrow, *hcolb;       // [A][64] H of the band's cells in the last row / the last column, by diagonal index d - lo
+    int32_t NBLK;                // blocks of 8 anti-diagonals per alignment
+    int32_t *redo_list, *redo_count;      // k_trace_band: alignments whose path touched an edge of the band
+    int32_t edge;                // ... = came within `edge` diagonals of it (0: the edge diagonals themselves)
+};
+
+__device__ __forceinline__ uint32_t dpp_shl1_u(uint32_t old, uint32_t v)          // lane q <- lane q + 1; the row's last lane keeps `old`
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x101, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_shl1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }   // ... gets 0
+__device__ __forceinline__ uint32_t dpp_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_ror_u(uint32_t v, int n)                   // lane q <- lane (q - n) mod 16
+{
+    return n == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false)
+                  : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12f, 0xf, 0xf, false);
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
+{
+    constexpr int B = 32 * C;
+    const int cnt = *p.count;
+    if ((int)blockIdx.x * 8 >= cnt) return;
+    const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
+    const int pair = blockIdx.x * 4 + g;
+    const FillArgs &f = p.f;
+    int al[2], n1[2], n2[2], l0[2];
+    bool live[2];
+    const uint8_t *s1[2], *s2[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int a = pair * 2 + k;
+        live[k] = a < cnt;
+        al[k] = p.list[live[k] ? a : 0];
+        s1[k] = f.s1 + (int64_t)al[k] * f.s1_stride;
+        const int site = fill_site(f, al[k]);
+        s2[k] = f.ref_code + (f.site_pos[site] - f.ref_pos0);
+        n1[k] = live[k] ? f.n1[al[k]] : 0;
+        n2[k] = live[k] ? f.site_n2[site] : 0;
+        l0[k] = -(int)p.band_lo[al[k]] / 2;
+    }
+    // scores carry the bias -NEG16 (H' = H + 20000, likewise E and F): minus infinity is 0, which is what a DPP shift with bound_ctrl hands
+    // the lanes at a row's end -- no `old` operand to load; every recurrence is linear in the bias
+    constexpr int BIAS = -NEG16;
+    const uint32_t k_open = splat16(f.open), k_ext = splat16(f.extend), k_match = splat16(f.match + f.open), k_dmis = splat16(f.mismatch - f.match);
+    const uint32_t k_one = splat16(1);
+    auto rd_base = [&](int k, int idx) -> uint32_t { return idx >= 0 && idx < n1[k] ? (uint32_t)s1[k][idx] : 4u; };      // string index -> code; 4 / 8 never match
+    auto rf_base = [&](int k, int idx) -> uint32_t { return idx >= 0 && idx < n2[k] ? (uint32_t)s2[k][idx] : 8u; };
+    // state of anti-diagonal 0 (H holds H - open, as in k_fill16q)
+    uint32_t Hp1[C], Hp2[C], Ep1[C], Fp1[C], rd[C], rf[C];
+    int di[2][C];                                                       // row of this lane cell at a = 0 (its column is the negative)
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int x = q * C + c;
+        di[0][c] = l0[0] - x;
+        di[1][c] = l0[1] - x;
+        const uint32_t h0 = (uint32_t)(x == l0[0] ? BIAS - f.open : 0) & 0xffffu, h1 = (uint32_t)(x == l0[1] ? BIAS - f.open : 0) & 0xffffu;
+        Hp1[c] = h0 | (h1 << 16);
+        Hp2[c] = 0; Ep1[c] = 0; Fp1[c] = 0;
+        rd[c] = rd_base(0, di[0][c] - 1) | (rd_base(1, di[1][c] - 1) << 16);
+        rf[c] = rf_base(0, -di[0][c] - 1) | (rf_base(1, -di[1][c] - 1) << 16);
+    }
+    // the streams of bases that enter: read element e = string index l0 + e at lane 0 (lane q of a chunk holds element 16 blk + q, the chunk
+    // rotates left after every entry); reference element e = string index 16 C - 1 - l0 + e at lane 15 (lane q holds 16 blk + 15 - q, rotates right)
+    auto rd_chunk = [&](int blk) -> uint32_t { return rd_base(0, l0[0] + 16 * blk + q) | (rd_base(1, l0[1] + 16 * blk + q) << 16); };
+    auto rf_chunk = [&](int blk) -> uint32_t {
+        return rf_base(0, 16 * C - 1 - l0[0] + 16 * blk + 15 - q) | (rf_base(1, 16 * C - 1 - l0[1] + 16 * blk + 15 - q) << 16);
+    };
+    uint32_t ch_rd = rd_chunk(0), ch_rf = rf_chunk(0), ch_rd_n = rd_chunk(1), ch_rf_n = rf_chunk(1);
+    int nb[2], nbw = 0, a_tail = 1 << 20;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        nb[k] = live[k] ? (n1[k] + n2[k] + 7) >> 3 : 0;
+        nbw = max(nbw, nb[k]);
+        if (live[k]) a_tail = min(a_tail, min(2 * n1[k] - 2 * l0[k], 2 * n2[k] + 2 * l0[k] - B + 1));      // first step with a cell in the last row / column
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+        nbw = max(nbw, __shfl_xor(nbw, o));
+        a_tail = min(a_tail, __shfl_xor(a_tail, o));
+    }
+    nbw = __builtin_amdgcn_readfirstlane(nbw);
+    const int b_tail = __builtin_amdgcn_readfirstlane(max(0, (a_tail - 1) >> 3));
+    uint32_t P[4] = {0, 0, 0, 0};
+    // one step.  ODD: the reference base moves (j grows); even: the read base (i grows).  TAIL: the cells of the last row / last column leave
+    auto step = [&](auto odd_tag, auto tail_tag, int a, int s) {
+        constexpr bool ODD = decltype(odd_tag)::value, TAIL = decltype(tail_tag)::value;
+        uint32_t hl[C], el[C], hu[C], fu[C];
+        if (ODD) {
+            const uint32_t top = dpp_shl1_u(ch_rf, rf[0]);
+#pragma unroll
+            for (int c = 0; c + 1 < C; c++) rf[c] = rf[c + 1];
+            rf[C - 1] = top;
+            ch_rf = dpp_ror_u(ch_rf, 1);
+            const uint32_t hn = dpp_shl1_z(Hp1[0]), fn = dpp_shl1_z(Fp1[0]);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                hl[c] = Hp1[c]; el[c] = Ep1[c];
+                hu[c] = c + 1 < C ? Hp1[c + 1 < C ? c + 1 : 0] : hn;
+                fu[c] = c + 1 < C ? Fp1[c + 1 < C ? c + 1 : 0] : fn;
+            }
+        } else {
+            const uint32_t bot = dpp_shr1_u(ch_rd, rd[C - 1]);
+#pragma unroll
+            for (int c = C - 1; c > 0; c--) rd[c] = rd[c - 1];
+            rd[0] = bot;
+            ch_rd = dpp_ror_u(ch_rd, 15);
+            const uint32_t hn = dpp_shr1_z(Hp1[C - 1]), en = dpp_shr1_z(Ep1[C - 1]);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                hu[c] = Hp1[c]; fu[c] = Fp1[c];
+                hl[c] = c > 0 ? Hp1[c > 0 ? c - 1 : 0] : hn;
+                el[c] = c > 0 ? Ep1[c > 0 ? c - 1 : 0] : en;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t e_ext = pk_sub(el[c], k_ext);
+            const uint32_t d_e = pk_sub(e_ext, hl[c]);                           // < 0: E opened
+            const uint32_t e = pk_max(hl[c], e_ext);
+            const uint32_t f_ext = pk_sub(fu[c], k_ext);
+            const uint32_t d_f = pk_sub(f_ext, hu[c]);                           // < 0: F opened
+            const uint32_t ff = pk_max(hu[c], f_ext);
+            const uint32_t ne_b = pk_min_u(rd[c] ^ rf[c], k_one);
+            const uint32_t d = pk_add(Hp2[c], pk_mad(ne_b, k_dmis, k_match));
+            const uint32_t h1 = pk_max(d, e);
+            const uint32_t d_1 = pk_sub(d, e);                                   // < 0: E beats the diagonal
+            const uint32_t hh = pk_max(h1, ff);
+            const uint32_t d_2 = pk_sub(h1, ff);                                 // < 0: F beats both
+            const uint32_t h = pk_sub(hh, k_open);
+            // the cell's four sign bits join the register of its group of four cells (16 bits a half: the first cell in ends lowest)
+            const int cell = s * C + c;                                          // cell of the block: 8 C of them, four to a register
+            uint32_t &Pr = P[cell >> 2];
+            Pr = (cell & 3) == 0 ? (d_1 & 0x80008000u) : and_or(d_1, 0x80008000u, Pr >> 1);
+            Pr = and_or(d_2, 0x80008000u, Pr >> 1);
+            Pr = and_or(d_e, 0x80008000u, Pr >> 1);
+            Pr = and_or(d_f, 0x80008000u, Pr >> 1);
+            Hp2[c] = Hp1[c];
+            Hp1[c] = h; Ep1[c] = e; Fp1[c] = ff;
+        }
+        if (TAIL) {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int i = (a >> 1) + di[k][c], j = ((a + 1) >> 1) - di[k][c];
+                    const int kk = 2 * (q * C + c) + (ODD ? 1 : 0);
+                    const int32_t hv = half_of(Hp1[c], k) - BIAS + f.open;
+                    if (live[k] && i == n1[k] && j >= 0 && j <= n2[k]) p.hrow[(int64_t)al[k] * 64 + kk] = (int16_t)hv;
+                    if (live[k] && j == n2[k] && i >= 0 && i < n1[k]) p.hcolb[(int64_t)al[k] * 64 + kk] = (int16_t)hv;
+                }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    for (int b = 0; b < nbw; b++) {
+        if ((b & 3) == 0 && b > 0) {                                       // 16 bases of either stream are used up every four blocks
+            ch_rd = ch_rd_n; ch_rf = ch_rf_n;
+            ch_rd_n = rd_chunk((b >> 2) + 1); ch_rf_n = rf_chunk((b >> 2) + 1);
+        }
+        const int a0 = 8 * b + 1;
+        if (b < b_tail) {
+#pragma unroll
+            for (int s = 0; s < 8; s += 2) { step(T_{}, F_{}, a0 + s, s); step(F_{}, F_{}, a0 + s + 1, s + 1); }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; s += 2) { step(T_{}, T_{}, a0 + s, s); step(F_{}, T_{}, a0 + s + 1, s + 1); }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!(live[k] && b < nb[k])) continue;
+            const uint32_t sel = k == 0 ? 0x05040100u : 0x07060302u;
+            uint32_t *dst = p.Twb + (int64_t)al[k] * p.NBLK * 32 + (b * 16 + q) * C;
+            if (C == 1) dst[0] = __builtin_amdgcn_perm(P[1], P[0], sel);
+            else *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_amdgcn_perm(P[1], P[0], sel), __builtin_amdgcn_perm(P[3], P[2], sel));
+        }
+    }
+}
+
+// traceback of a banded alignment: k_trace16p's walk and entries; a block of 8 anti-diagonals is one line of 64 C bytes (16 lanes x C words),
+// cached in LDS per walking lane and re-fetched in epochs.  The end point (best cell of the last row, ties to the larger column, or a strictly
+// better cell of the last column, ties to the larger row) comes from the band's 2 x B last-row / last-column values.
+template <int C>
+__global__ __launch_bounds__(64) void k_trace_band(BandArgs p, uint32_t *__restrict__ ent_all, int32_t EW)
+{
+    constexpr int B = 32 * C, PITCH = 33;
+    __shared__ uint32_t stage[16 * 64];
+    __shared__ uint32_t tbl[64 * PITCH];
+    const int cnt = *p.count;
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= cnt) return;
+    const int lane = threadIdx.x;
+    const FillArgs &f = p.f;
+    const int al = p.list[idx];
+    const int n1 = f.n1[al], n2 = f.site_n2[fill_site(f, al)], lo = p.band_lo[al];
+    uint32_t *slot = tbl + lane * PITCH;
+    uint32_t *ent = ent_all + (int64_t)al * EW;
+    int i = n1, j = n2;
+    if (n1 > 0 && n2 > 0) {
+        int32_t rv = INT32_MIN, cv = INT32_MIN;
+        int rj = 0, ci = 0;
+        const int16_t *hr = p.hrow + (int64_t)al * 64, *hc = p.hcolb + (int64_t)al * 64;
+        for (int k0 = 0; k0 < B; k0 += 8) {
+            const uint4 gr = *reinterpret_cast<const uint4 *>(hr + k0), gc = *reinterpret_cast<const uint4 *>(hc + k0);
+            const uint32_t wr[4] = {gr.x, gr.y, gr.z, gr.w}, wc[4] = {gc.x, gc.y, gc.z, gc.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + u;
+                const int32_t vr = (int16_t)(wr[u >> 1] >> ((u & 1) * 16)), vc = (int16_t)(wc[u >> 1] >> ((u & 1) * 16));
+                const int jr = n1 + lo + k, ic = n2 - lo - k;
+                if (jr >= 0 && jr <= n2 && vr >= rv) { rv = vr; rj = jr; }
+                if (ic >= 0 && ic < n1 && vc > cv) { cv = vc; ci = ic; }
+            }
+        }
+        if (cv > rv) { i = ci; j = n2; } else { i = n1; j = rj; }
+    }
+    uint32_t cur = 0;
+    if (i < n1) cur = ((uint32_t)(n1 - i) << 10) | ((uint32_t)i << 20);       // the rest of the read: insertion after the window
+    int x = n2;
+    auto put = [&](uint32_t e) {
+        stage[(x & 15) * 64 + lane] = e;
+        if ((x & 15) == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                reinterpret_cast<uint4 *>(ent + (x & ~15))[u] = make_uint4(stage[(4 * u) * 64 + lane], stage[(4 * u + 1) * 64 + lane],
+                                                                           stage[(4 * u + 2) * 64 + lane], stage[(4 * u + 3) * 64 + lane]);
+        }
+        x--;
+    };
+    while (x > j) put(0u);
+    int state = -1, cblk = -1;
+    bool touched = false;
+    const uint32_t *tw = p.Twb + (int64_t)al * p.NBLK * 32;
+    auto step = [&]() {
+        uint32_t t;
+        if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
+        else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
+        else {
+            const int k = j - i - lo, s = (i + j - 1) & 7, xx = k >> 1;
+            touched |= k <= p.edge || k >= B - 1 - p.edge;
+            uint32_t tc;
+            if (C == 1) tc = (slot[xx] >> (4 * s)) & 15u;
+            else tc = (slot[(xx >> 1) * 2 + (s >> 2)] >> (4 * ((s & 3) * 2 + (xx & 1)))) & 15u;
+            t = ((tc & 2u) ? (uint32_t)T_INS : (tc & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((tc & 4u) ? 0u : (uint32_t)T_EEXT) | ((tc & 8u) ? 0u : (uint32_t)T_FEXT);
+        }
+        if (state < 0) {
+            const int w = t & 3;
+            if (w == T_DIAG) {
+                put(cur);
+                cur = (uint32_t)i;
+                i--; j--;
+                return;
+            }
+            state = w == T_DEL ? 1 : 2;
+        }
+        if (state == 1) {
+            const bool ext = (t & T_EEXT) != 0;
+            put(cur);
+            cur = 0;
+            j--;
+            if (!ext) state = -1;
+        } else {
+            const bool ext = (t & T_FEXT) != 0;
+            cur = (cur & 0x3ffu) | ((((cur >> 10) & 0x3ffu) + 1u) << 10) | ((uint32_t)(i - 1) << 20);
+            i--;
+            if (!ext) state = -1;
+        }
+    };
+    while (__any(i > 0 || j > 0)) {                                    // epochs: the lanes that left their line load the next one together
+        if (i > 0 && j > 0 && ((i + j - 1) >> 3) != cblk) {
+            cblk = (i + j - 1) >> 3;
+            const U4 *src = reinterpret_cast<const U4 *>(tw + cblk * 16 * C);
+            U4 v[4 * C];
+#pragma unroll
+            for (int u = 0; u < 4 * C; u++) v[u] = src[u];
+#pragma unroll
+            for (int u = 0; u < 4 * C; u++) { slot[4 * u] = v[u].x; slot[4 * u + 1] = v[u].y; slot[4 * u + 2] = v[u].z; slot[4 * u + 3] = v[u].w; }
+        }
+        for (;;) {
+            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || ((i + j - 1) >> 3) == cblk);
+            if (!__any(can)) break;
+            if (can) step();
+        }
+    }
+    put(cur);
+    if (touched) p.redo_list[atomicAdd(p.redo_count, 1)] = al;
+}
+
 // free-tail end point of every alignment: the best cell of the last row (ties: the larger column) or a cell of the last column that is
 // strictly better (ties: the larger row) -- the order k_nw_trace16 scans them in.  16 lanes per alignment over Hlast / hcol (one lane per
 // alignment inside the traceback kernel read its ~360 values one after the other: 2.4 of that kernel's 4.5 ms)
 __global__ __launch_bounds__(256) void k_end_cells(FillArgs p)
 {
     const int al = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
-    const bool live = al < p.A;
-    const int a = live ? al : 0;
-    const int n1 = p.n1[a], n2 = p.site_n2[fill_site(p, a)];
+    const int A_live = p.count ? min(*p.count, p.A) : p.A;
+    const bool live = al < A_live;
+    const int a = live ? al : 0;                                       // slot
+    const int ain = p.list ? p.list[a] : a;
+    const int n1 = p.n1[ain], n2 = p.site_n2[fill_site(p, ain)];
     int32_t rv = INT32_MIN, rj = 0, cv = INT32_MIN, ci = 0;
     if (live && n1 > 0 && n2 > 0) {
         // four values a load (both rows are 16-byte aligned: hlast_pitch and hcol_pitch are multiples of four words); any split of the
@@ -849,14 +1213,15 @@ __global__ __launch_bounds__(64) void k_trace16p(FillArgs p, int32_t CPL, int32_
 {
     __shared__ uint32_t stage[16 * 64];
     __shared__ uint32_t tbl[64 * TBL_PITCH];
-    const int al = blockIdx.x * 64 + threadIdx.x;
-    if (al >= p.A) return;
+    const int al = blockIdx.x * 64 + threadIdx.x;                     // slot (the alignment itself outside list mode)
+    if (al >= (p.count ? min(*p.count, p.A) : p.A)) return;
     const int lane = threadIdx.x;
     TbLine tb = {tbl + lane * TBL_PITCH, -1, -1, 0, 0};
-    const int n1 = p.n1[al];
-    const int n2 = p.site_n2[fill_site(p, al)];
+    const int ain = p.list ? p.list[al] : al;
+    const int n1 = p.n1[ain];
+    const int n2 = p.site_n2[fill_site(p, ain)];
     const int64_t arow = (int64_t)al * tw_blocks(p.N1), hrow = (int64_t)al * hcol_pitch(p.N1);
-    uint32_t *ent = ent_all + (int64_t)al * EW;                       // EW: a multiple of 16 entries >= n2 + 1
+    uint32_t *ent = ent_all + (int64_t)ain * EW;                      // EW: a multiple of 16 entries >= n2 + 1
     int i = n1, j = n2;
     uint32_t cur = 0;                                                  // the entry of slot j being built (position j's read index comes last)
     if (p.endcell) {
@@ -1358,7 +1723,12 @@ struct nc_pipe_state {
     size_t al0_cap = 0;
     DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
     DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
-    struct GroupBufs { DevBuf win, n1, tw, hlast, hcol, endc, trace, cns, ncns, arow, alt_off; } gb[2];   // two sets: group g+1 is aligned while g is reduced
+    struct GroupBufs {
+        DevBuf win, n1, tw, hlast, hcol, endc, trace, cns, ncns, arow, alt_off;
+        DevBuf band_lo, lists, counts, twb, hrow, hcolb;                // banded star alignment: per-alignment band, class lists, codes, last row / column
+    } gb[2];                                // two sets: group g+1 is aligned while g is reduced
+    int32_t band_mode = -1, band_margin_v = 0;   // nc_indel_sites_band: -1 = the environment's setting
+    int64_t band_stats[4] = {0, 0, 0, 0};   // of the last run: alignments on 32 / 64 diagonals, on the full matrix by width, re-run after an edge touch
     DevBuf tw2, runs, rlen, alen, alt_pool, misc;
     hipStream_t sB = nullptr;                // second stream: traceback / tensors / alleles of group g beside the alignment fill of g + 1
     hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -1377,7 +1747,8 @@ void nc_pipe_destroy(nc_ctx *ctx)
                       &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
                       &s->al_site, &s->al_member, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc,
                       &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].endc, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
-                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].endc, &s->gb[1].trace,
+                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[0].band_lo, &s->gb[0].lists, &s->gb[0].counts, &s->gb[0].twb, &s->gb[0].hrow, &s->gb[0].hcolb,
+                      &s->gb[1].band_lo, &s->gb[1].lists, &s->gb[1].counts, &s->gb[1].twb, &s->gb[1].hrow, &s->gb[1].hcolb, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].endc, &s->gb[1].trace,
                       &s->gb[1].cns, &s->gb[1].ncns, &s->gb[1].arow, &s->gb[1].alt_off};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
@@ -1397,6 +1768,15 @@ void nc_pipe_destroy(nc_ctx *ctx)
 static int cpl_for(int n2) { return n2 <= 64 ? 4 : n2 <= 128 ? 8 : n2 <= 176 ? 11 : n2 <= 272 ? 17 : 0; }
 
 static bool packed_fill() { static const bool on = !getenv("NC_PIPE_FILL32"); return on; }
+// banded star alignment (k_fill_band): on unless NC_PIPE_BAND=0 or the 32-bit fill is forced; NC_PIPE_BAND_MARGIN = diagonals kept free on
+// either side of the range the read's CIGAR covers (default 6)
+static bool band_on() { static const bool on = packed_fill() && !(getenv("NC_PIPE_BAND") && atoi(getenv("NC_PIPE_BAND")) == 0); return on; }
+static int band_margin() { static const int m = getenv("NC_PIPE_BAND_MARGIN") ? std::max(1, std::min(15, atoi(getenv("NC_PIPE_BAND_MARGIN")))) : 6; return m; }
+
+__global__ void k_band_stats(const int32_t *__restrict__ counts, long long *__restrict__ acc)
+{
+    acc[0] += counts[0]; acc[1] += counts[1]; acc[2] += counts[3]; acc[3] += counts[2] - counts[3];
+}
 
 static void launch_fill(nc_ctx *ctx, hipStream_t st, int CPL, const FillArgs &fa)
 {
@@ -1661,6 +2041,8 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_HIP(ctx, hipStreamWaitEvent(sB, s->ev_join, 0));
     }
     FillArgs fa_of[2];
+    BandArgs ba_of[2];
+    bool band_of[2] = {false, false};
     auto stage_a = [&](int g) -> int {
         const int b = g & 1, k0 = groups[(size_t)g].first, k1 = groups[(size_t)g].second;
         nc_pipe_state::GroupBufs &B = s->gb[b];
@@ -1679,8 +2061,18 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, B.ncns, (size_t)ng * S * 4));
         NC_TRY(nc_ensure(ctx, B.arow, ((size_t)ng * S + 1) * 8));
         NC_TRY(nc_ensure(ctx, B.alt_off, (size_t)ng * S * 8));
+        const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && W <= 162 && N1 <= 160;          // the band's 41 blocks of 8 anti-diagonals cover n1 + n2 <= 328
+        if (band) {
+            NC_TRY(nc_ensure(ctx, B.band_lo, Agz + 64));
+            NC_TRY(nc_ensure(ctx, B.lists, Agz * 3 * 4 + 64));
+            NC_TRY(nc_ensure(ctx, B.counts, 64));
+            NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)BAND_NBLK * 128 + 256));
+            NC_TRY(nc_ensure(ctx, B.hrow, Agz * 128 + 64));
+            NC_TRY(nc_ensure(ctx, B.hcolb, Agz * 128 + 64));
+        }
         if (two && g >= 2) NC_HIP(ctx, hipStreamWaitEvent(sA, s->evB[b], 0));     // stream B is done with this buffer set (group g - 2)
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[0], sA));
+        if (band) NC_HIP(ctx, hipMemsetAsync(B.counts.p, 0, 64, sA));
         // ---- query windows
         WinArgs wa;
         wa.codes = s->pack.codes; wa.slot_off = s->rd.slot_off; wa.rd_start = s->rd.rd_start; wa.rd_end = s->rd.rd_end;
@@ -1689,6 +2081,9 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         wa.al_read = (const int32_t *)s->al_read.p + A0; wa.al_site = (const int32_t *)s->al_site.p + A0;
         wa.site_pos = (const int32_t *)s->site_pos.p; wa.site_n2 = (const int32_t *)s->site_n2.p;
         wa.A = Ag; wa.W = s->window_after; wa.WS = WS; wa.win = (uint8_t *)B.win.p; wa.n1 = (int32_t *)B.n1.p; wa.cells = cells;
+        wa.band_lo = band ? (int8_t *)B.band_lo.p : nullptr;
+        wa.list1 = (int32_t *)B.lists.p; wa.list2 = wa.list1 + Agz; wa.listF = wa.list2 + Agz;
+        wa.counts = (int32_t *)B.counts.p; wa.band_margin = s->band_margin_v > 0 ? s->band_margin_v : band_margin();
         if (Ag > 0) hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, sA, wa);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], sA));
         // ---- star alignment: every read window against its site's reference window (free tail)
@@ -1701,7 +2096,21 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fa.arow = nullptr; fa.N1 = N1;
         fa.Tw = (uint32_t *)B.tw.p;
         fa.Hlast = (int32_t *)B.hlast.p; fa.hcol = (int32_t *)B.hcol.p; fa.endcell = (int2 *)B.endc.p;
-        if (Ag > 0) launch_fill(ctx, sA, CPL, fa);
+        fa.list = nullptr; fa.count = nullptr;
+        band_of[b] = band;
+        if (band && Ag > 0) {
+            // every alignment on its band (the classes' sizes are known on the device only: the grids cover the group, blocks beyond a
+            // class's count leave at once); the full matrix runs behind the banded traceback, over listF (stage_b1)
+            BandArgs &ba = ba_of[b];
+            ba.f = fa;
+            ba.band_lo = (const int8_t *)B.band_lo.p; ba.Twb = (uint32_t *)B.twb.p; ba.hrow = (int16_t *)B.hrow.p; ba.hcolb = (int16_t *)B.hcolb.p;
+            ba.NBLK = BAND_NBLK; ba.redo_list = wa.listF; ba.redo_count = wa.counts + 2;
+            ba.edge = getenv("NC_PIPE_BAND_EDGE") ? atoi(getenv("NC_PIPE_BAND_EDGE")) : 0;
+            ba.list = wa.list1; ba.count = wa.counts;
+            hipLaunchKernelGGL(k_fill_band<1>, dim3((Ag + 7) / 8), dim3(64), 0, sA, ba);
+            ba.list = wa.list2; ba.count = wa.counts + 1;
+            hipLaunchKernelGGL(k_fill_band<2>, dim3((Ag + 7) / 8), dim3(64), 0, sA, ba);
+        } else if (Ag > 0) launch_fill(ctx, sA, CPL, fa);
         NC_HIP(ctx, hipGetLastError());
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[2], sA));
         if (two) NC_HIP(ctx, hipEventRecord(s->evA[b], sA));
@@ -1716,8 +2125,24 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int32_t Ag = al0h[k1] - al0h[k0];
         const FillArgs &fa = fa_of[b];
         if (two) NC_HIP(ctx, hipStreamWaitEvent(sB, s->evA[b], 0));
-        if (Ag > 0) hipLaunchKernelGGL(k_end_cells, dim3((Ag + 15) / 16), dim3(256), 0, sB, fa);
-        if (Ag > 0) hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, sB, fa, CPL, packed_fill() ? 1 : 0, (uint32_t *)B.trace.p, EW);
+        if (band_of[b] && Ag > 0) {
+            BandArgs ba = ba_of[b];
+            const int32_t *cnts = ba.count - 1;                         // (ba.count was left on the second class)
+            ba.list = (const int32_t *)B.lists.p; ba.count = cnts;
+            hipLaunchKernelGGL(k_trace_band<1>, dim3((Ag + 63) / 64), dim3(64), 0, sB, ba, (uint32_t *)B.trace.p, EW);
+            ba.list = (const int32_t *)B.lists.p + std::max(Ag, 1); ba.count = cnts + 1;
+            hipLaunchKernelGGL(k_trace_band<2>, dim3((Ag + 63) / 64), dim3(64), 0, sB, ba, (uint32_t *)B.trace.p, EW);
+            // the rest on the full matrix: too wide for a band, or a path that touched the edge of its band
+            FillArgs fl = fa;
+            fl.list = ba.redo_list; fl.count = ba.redo_count;
+            launch_fill(ctx, sB, CPL, fl);
+            hipLaunchKernelGGL(k_end_cells, dim3((Ag + 15) / 16), dim3(256), 0, sB, fl);
+            hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, sB, fl, CPL, 1, (uint32_t *)B.trace.p, EW);
+            hipLaunchKernelGGL(k_band_stats, dim3(1), dim3(1), 0, sB, cnts, (long long *)((int32_t *)s->misc.p + 16));
+        } else if (Ag > 0) {
+            hipLaunchKernelGGL(k_end_cells, dim3((Ag + 15) / 16), dim3(256), 0, sB, fa);
+            hipLaunchKernelGGL(k_trace16p, dim3((Ag + 63) / 64), dim3(64), 0, sB, fa, CPL, packed_fill() ? 1 : 0, (uint32_t *)B.trace.p, EW);
+        }
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[3], sB));
         // ---- columns, histogram, tensor, consensus
         TensorArgs ta;
@@ -1776,6 +2201,25 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(stage_b1(g));
         volatile int32_t *mb = ctx->mbox + 36;
         NC_HIP(ctx, hipStreamSynchronize(sB));
+        if (const char *dump = getenv("NC_PIPE_DUMP")) {              // debugging aid: the group's alignments as files <dump>.<name>
+            const int b = g & 1;
+            const int32_t Ag = al0h[groups[(size_t)g].second] - al0h[groups[(size_t)g].first];
+            nc_pipe_state::GroupBufs &B = s->gb[b];
+            auto wr = [&](const char *name, const void *dev, size_t bytes) {
+                std::vector<char> h(bytes);
+                if (hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+                char path[512];
+                snprintf(path, sizeof path, "%s.%s", dump, name);
+                if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, bytes, fp); fclose(fp); }
+            };
+            wr("trace", B.trace.p, (size_t)Ag * EW * 4);
+            wr("win", B.win.p, (size_t)Ag * WS);
+            wr("n1", B.n1.p, (size_t)Ag * 4);
+            wr("al_site", (const int32_t *)s->al_site.p + al0h[groups[(size_t)g].first], (size_t)Ag * 4);
+            wr("site_pos", s->site_pos.p, (size_t)ns * 4);
+            wr("site_n2", s->site_n2.p, (size_t)ns * 4);
+            if (B.band_lo.p) wr("band_lo", B.band_lo.p, (size_t)Ag);
+        }
         const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
         NC_TRY(stage_b2(g, rows));
         if (timing && g + 1 < G) NC_TRY(stage_a(g + 1));
@@ -1804,7 +2248,7 @@ extern "C" int nc_indel_sites_fetch(nc_ctx *ctx, int32_t *pos, int32_t *chunk, i
     NC_TRY(cp(chunk, s->site_chunk, NS * 4));
     NC_TRY(cp(var_type, s->site_type, NS * 4));
     NC_TRY(cp(phase, s->site_phase, NS * 4));
-    int32_t misc[16] = {0};
+    int32_t misc[32] = {0};
     if (s->ran) {
         NC_TRY(cp(ref_len, s->rlen, NS * s->S * 4));
         NC_TRY(cp(alt_len, s->alen, NS * s->S * 4));
@@ -1816,6 +2260,7 @@ extern "C" int nc_indel_sites_fetch(nc_ctx *ctx, int32_t *pos, int32_t *chunk, i
     long long cells = 0, pool = 0;
     memcpy(&cells, misc + 4, 8);
     memcpy(&pool, misc + 8, 8);
+    memcpy(s->band_stats, misc + 16, 32);
     s->cells[0] = cells;
     if (n_alt_bytes) *n_alt_bytes = pool;
     return NC_OK;
@@ -1830,6 +2275,23 @@ extern "C" int nc_indel_sites_fetch_alt(nc_ctx *ctx, uint8_t *alt_bases, int64_t
     if (!alt_bases) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_fetch_alt: null buffer");
     NC_HIP(ctx, hipMemcpyAsync(alt_bases, s->alt_pool.p, (size_t)std::min<int64_t>(cap, s->alt_pool_cap), hipMemcpyDeviceToHost, ctx->stream));
     NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_band(nc_ctx *ctx, int32_t mode, int32_t margin)
+{
+    if (!ctx || mode < -1 || mode > 1 || margin < 0 || margin > 15) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_band: mode -1 / 0 / 1, margin 0 (default) .. 15");
+    if (!ctx->pipe) ctx->pipe = new (std::nothrow) nc_pipe_state();
+    if (!ctx->pipe) return NC_ERR_NOMEM;
+    ctx->pipe->band_mode = mode;
+    ctx->pipe->band_margin_v = margin;
+    return NC_OK;
+}
+
+extern "C" int nc_indel_sites_band_stats(nc_ctx *ctx, int64_t *stats4)
+{
+    if (!ctx || !ctx->pipe || !stats4) return NC_ERR_ARG;
+    for (int k = 0; k < 4; k++) stats4[k] = ctx->pipe->band_stats[k];
     return NC_OK;
 }
 

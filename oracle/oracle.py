@@ -409,12 +409,12 @@ def nw_cigar_free_tail_ref(s1, s2, open_=9, extend=1, match=20, mismatch=-10):
     return [(o, c) for o, c in out]
 
 
-def star_msa_ref(seqs, ref, open_=9, extend=1, match=20, mismatch=-10):
+def star_msa_ref(seqs, ref, open_=9, extend=1, match=20, mismatch=-10, cigars=None):
     """Star alignment restated in pure Python (checks nc_star_msa): pairwise free-tail alignments to `ref`, merged in reference
     coordinates -- per reference slot as many insertion columns as the longest insertion, shorter ones left-justified.
     -> (rows, ref_row) as strings over AGTC-"""
     n_ref = len(ref)
-    cig = [nw_cigar_free_tail_ref(q, ref, open_, extend, match, mismatch) for q in seqs]
+    cig = cigars if cigars is not None else [nw_cigar_free_tail_ref(q, ref, open_, extend, match, mismatch) for q in seqs]
     ins = [0] * (n_ref + 1)
     for c in cig:
         j = 0
@@ -493,6 +493,163 @@ def read_windows_ref(records, anchors, window_before, window_after, flag_filter)
     return out
 
 
+# ---- the banded form of the star alignment (the product's default: nc_pipe.hip k_fill_band / k_trace_band), restated independently.
+# The band is derived from the read's own CIGAR inside the window; an alignment whose band would be wider than 64 diagonals, or whose
+# banded path touches an edge diagonal, is the full-matrix alignment (nw_cigar_free_tail_ref).
+BAND_MARGIN = 6
+
+
+def window_band_ref(record, anchor, window_after):
+    """(dmin, dmax) of the diagonals j - i (window column - window base, both 1-based) the CIGAR's own path visits inside
+    query_sequence[q : q + window_after], q = query_position_or_next at `anchor`; 0 is always inside (the path starts at the origin).
+    Inserted and soft-clipped bases have no column: each lowers the diagonal by one; a deletion raises it by its length, also when it
+    directly follows the window's last base."""
+    base_col, gap_before = [], []                    # per query base: reference position or None; deleted length right before it
+    rp, pend = record["pos0"] + 1, 0
+    for op, ln in record["cigar"]:
+        if op in "M=X":
+            for _ in range(ln):
+                base_col.append(rp)
+                gap_before.append(pend)
+                pend = 0
+                rp += 1
+        elif op in "IS":
+            for _ in range(ln):
+                base_col.append(None)
+                gap_before.append(pend)
+                pend = 0
+        elif op in "DN":
+            pend += ln
+            rp += ln
+    gap_before.append(pend)                          # behind the last base
+    q = next((k for k, c in enumerate(base_col) if c is not None and c >= anchor), len(base_col))
+    n = min(window_after, len(base_col) - q)
+    dmin = dmax = d = 0
+    if n > 0:
+        d = base_col[q] - anchor                     # the anchor itself may be deleted: the window opens on the next aligned base
+        dmax = max(dmax, d)
+    for t in range(n):
+        qi = q + t
+        if t > 0:
+            d += gap_before[qi]
+            dmax = max(dmax, d)
+        if base_col[qi] is None:
+            d -= 1
+            dmin = min(dmin, d)
+    if n > 0:
+        # what follows the last base at the same column: the rest of an insertion (not emitted), then a deletion
+        k = q + n
+        while k < len(base_col) and base_col[k] is None and gap_before[k] == 0:
+            k += 1
+        d += gap_before[k]
+        dmax = max(dmax, d)
+    return dmin, dmax
+
+
+def band_of(dmin, dmax, margin=BAND_MARGIN):
+    """-> (lo, B) of the band [lo, lo + B) or None (full matrix): B = 32 or 64, the slack split evenly, lo even"""
+    w = dmax - dmin
+    if w + 2 * margin <= 31:
+        B = 32
+    elif w + 2 * margin <= 63:
+        B = 64
+    else:
+        return None
+    lo = dmin - ((B - 1 - w) >> 1)
+    lo -= lo & 1
+    return lo, B
+
+
+def nw_cigar_band_free_tail_ref(s1, s2, lo, B, open_=9, extend=1, match=20, mismatch=-10):
+    """nw_cigar_free_tail_ref restricted to the diagonals lo <= j - i < lo + B (everything else is minus infinity), same tie rules;
+    -> None when the traceback reads a cell of an edge diagonal (the caller then aligns on the full matrix)"""
+    n1, n2 = len(s1), len(s2)
+    if n1 == 0 or n2 == 0:
+        return nw_cigar_ref(s1, s2, open_, extend, match, mismatch)
+    NEG = -10 ** 9
+    hi = lo + B - 1
+    H = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    E = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    F = [[NEG] * (n2 + 1) for _ in range(n1 + 1)]
+    who = [[0] * (n2 + 1) for _ in range(n1 + 1)]
+    e_ext = [[False] * (n2 + 1) for _ in range(n1 + 1)]
+    f_ext = [[False] * (n2 + 1) for _ in range(n1 + 1)]
+    H[0][0] = 0
+    for j in range(1, min(n2, hi) + 1):
+        H[0][j] = E[0][j] = -open_ - (j - 1) * extend
+        who[0][j] = 1
+        e_ext[0][j] = j > 1
+    for i in range(1, n1 + 1):
+        if -i >= lo:
+            H[i][0] = F[i][0] = -open_ - (i - 1) * extend
+            who[i][0] = 2
+            f_ext[i][0] = i > 1
+        for j in range(max(1, i + lo), min(n2, i + hi) + 1):
+            eo, ee = H[i][j - 1] - open_, E[i][j - 1] - extend
+            e_ext[i][j] = ee >= eo
+            E[i][j] = max(eo, ee)
+            fo, fe = H[i - 1][j] - open_, F[i - 1][j] - extend
+            f_ext[i][j] = fe >= fo
+            F[i][j] = max(fo, fe)
+            d = H[i - 1][j - 1] + (match if s1[i - 1] == s2[j - 1] else mismatch)
+            h, w = d, 0
+            if E[i][j] > h:
+                h, w = E[i][j], 1
+            if F[i][j] > h:
+                h, w = F[i][j], 2
+            H[i][j], who[i][j] = h, w
+    best, bi, bj = NEG * 2, n1, n2
+    for j in range(n2, -1, -1):                                 # last row: ties to the larger column
+        if lo <= j - n1 <= hi and H[n1][j] > best:
+            best, bi, bj = H[n1][j], n1, j
+    for i in range(n1 - 1, -1, -1):                             # last column: strictly better only, ties to the larger row
+        if lo <= n2 - i <= hi and H[i][n2] > best:
+            best, bi, bj = H[i][n2], i, n2
+    ops = []
+    i, j, state = bi, bj, None
+    while i > 0 or j > 0:
+        if i > 0 and j > 0 and (j - i - lo <= 0 or j - i - lo >= B - 1):
+            return None
+        if state is None:
+            if who[i][j] == 0:
+                ops.append(7 if s1[i - 1] == s2[j - 1] else 8)
+                i, j = i - 1, j - 1
+                continue
+            state = who[i][j]
+        if state == 1:
+            ops.append(2)
+            ext = e_ext[i][j]
+            j -= 1
+        else:
+            ops.append(1)
+            ext = f_ext[i][j]
+            i -= 1
+        if not ext:
+            state = None
+    ops.reverse()
+    out = []
+    for o in ops + [2] * (n2 - bj) + [1] * (n1 - bi):
+        if out and out[-1][0] == o:
+            out[-1][1] += 1
+        else:
+            out.append([o, 1])
+    return [(o, c) for o, c in out]
+
+
+def star_cigars_banded_ref(seqs, bands, ref, open_=9, extend=1, match=20, mismatch=-10, margin=BAND_MARGIN):
+    """the pairwise alignments of the product's star alignment: on the band `bands[k] = (dmin, dmax)` allows, else / after an edge
+    touch on the full matrix.  -> (cigars, [how each was aligned: 32, 64, 'width', 'edge'])"""
+    cig, how = [], []
+    for q, (dmin, dmax) in zip(seqs, bands):
+        b = band_of(dmin, dmax, margin)
+        c = None
+        if b is not None:
+            c = nw_cigar_band_free_tail_ref(q, ref, b[0], b[1], open_, extend, match, mismatch)
+        how.append(b[1] if c is not None else ("width" if b is None else "edge"))
+        cig.append(c if c is not None else nw_cigar_free_tail_ref(q, ref, open_, extend, match, mismatch))
+    return cig, how
+
+
 # ------------------------------------------------------------------------------------------------- device indel pipeline sample
 def records_from_indel_pack(read_start, read_end, codes_of, ev_of, ins_of, names=None, flags=None):
     """SAM-like records (what read_windows_ref takes) rebuilt from the pack form of reads: `codes_of(r)` = uint8 code per spanned
@@ -521,10 +678,11 @@ def records_from_indel_pack(read_start, read_end, codes_of, ev_of, ins_of, names
     return recs
 
 
-def indel_site_ref(records, hap, ps, ref, v_pos, window_after, mincov, maxcov, aligner=None, scoring=(25, 1, 20, -10), haploid=False):
+def indel_site_ref(records, hap, ps, ref, v_pos, window_after, mincov, maxcov, aligner=None, scoring=(25, 1, 20, -10), haploid=False, band=False,
+                   how_out=None):
     """One pass-2 site from records: read sets (first-maxcov policy), star alignment (`aligner(names, seqs, ref)` or the pure-Python
-    star_msa_ref), msa()'s tensor by the C oracle.  -> None when the site fails the set-size tests, else (x float32 [S,5,128,2],
-    [consensus strings], reference window, phase)"""
+    star_msa_ref; band=True: every pairwise alignment on the band its CIGAR allows, as the device pipeline runs it), msa()'s tensor by
+    the C oracle.  -> None when the site fails the set-size tests, else (x float32 [S,5,128,2], [consensus strings], reference window, phase)"""
     win = ref[v_pos - 1:min(len(ref), v_pos + window_after)]
     if any(ch not in "AGTC" for ch in win):
         return None
@@ -538,7 +696,15 @@ def indel_site_ref(records, hap, ps, ref, v_pos, window_after, mincov, maxcov, a
     xs, cns = [], []
     for st in sets:
         seqs = [s for _, s in st]
-        rows, ref_row = aligner(["r%d" % k for k, _ in st], seqs, win) if aligner else star_msa_ref(seqs, win, *scoring)
+        if aligner:
+            rows, ref_row = aligner(["r%d" % k for k, _ in st], seqs, win)
+        elif band:
+            cig, how = star_cigars_banded_ref(seqs, [window_band_ref(records[k], v_pos, window_after) for k, _ in st], win, *scoring)
+            if how_out is not None:
+                how_out.extend(how)
+            rows, ref_row = star_msa_ref(seqs, win, *scoring, cigars=cig)
+        else:
+            rows, ref_row = star_msa_ref(seqs, win, *scoring)
         mat = np.array([[sym.get(c, 4) for c in row] for row in rows], np.uint8)
         x, c = indel_tensor(mat, np.array([sym[c] for c in ref_row], np.uint8))
         xs.append(x)
