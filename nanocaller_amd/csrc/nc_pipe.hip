@@ -390,6 +390,9 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
         if (p.band_lo) {
             // band of B = 32 or 64 diagonals around [dmin, dmax] (0 is inside: the path starts at the origin), the slack split evenly, lowest
             // diagonal even (the anti-diagonal sweep alternates between the even and the odd diagonals of the band)
+            // a read that ends inside the window leaves last-row cells to the right of its path: the free tail may jump there (a deletion, then
+            // a few chance matches of the read's last bases), so the band reaches the last row's end: hi >= n2 - n1
+            dmax = max(dmax, p.site_n2[site] - n - p.band_margin + 1);
             const int w = dmax - dmin;
             cls = w + 2 * p.band_margin <= 31 ? 0 : w + 2 * p.band_margin <= 63 ? 1 : 2;
             const int B = cls == 0 ? 32 : 64;
@@ -1770,8 +1773,8 @@ static int cpl_for(int n2) { return n2 <= 64 ? 4 : n2 <= 128 ? 8 : n2 <= 176 ? 1
 static bool packed_fill() { static const bool on = !getenv("NC_PIPE_FILL32"); return on; }
 // banded star alignment (k_fill_band): on unless NC_PIPE_BAND=0 or the 32-bit fill is forced; NC_PIPE_BAND_MARGIN = diagonals kept free on
 // either side of the range the read's CIGAR covers (default 6)
-static bool band_on() { static const bool on = packed_fill() && !(getenv("NC_PIPE_BAND") && atoi(getenv("NC_PIPE_BAND")) == 0); return on; }
-static int band_margin() { static const int m = getenv("NC_PIPE_BAND_MARGIN") ? std::max(1, std::min(15, atoi(getenv("NC_PIPE_BAND_MARGIN")))) : 6; return m; }
+static bool band_on() { const char *e = getenv("NC_PIPE_BAND"); return !(e && atoi(e) == 0); }                 // (read at every run: tests switch it)
+static int band_margin() { const char *e = getenv("NC_PIPE_BAND_MARGIN"); return e ? std::max(1, std::min(15, atoi(e))) : 6; }
 
 __global__ void k_band_stats(const int32_t *__restrict__ counts, long long *__restrict__ acc)
 {
@@ -2216,6 +2219,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
             wr("win", B.win.p, (size_t)Ag * WS);
             wr("n1", B.n1.p, (size_t)Ag * 4);
             wr("al_site", (const int32_t *)s->al_site.p + al0h[groups[(size_t)g].first], (size_t)Ag * 4);
+            wr("al_read", (const int32_t *)s->al_read.p + al0h[groups[(size_t)g].first], (size_t)Ag * 4);
             wr("site_pos", s->site_pos.p, (size_t)ns * 4);
             wr("site_n2", s->site_n2.p, (size_t)ns * 4);
             if (B.band_lo.p) wr("band_lo", B.band_lo.p, (size_t)Ag);

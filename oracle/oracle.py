@@ -546,8 +546,11 @@ def window_band_ref(record, anchor, window_after):
     return dmin, dmax
 
 
-def band_of(dmin, dmax, margin=BAND_MARGIN):
-    """-> (lo, B) of the band [lo, lo + B) or None (full matrix): B = 32 or 64, the slack split evenly, lo even"""
+def band_of(dmin, dmax, n1, n2, margin=BAND_MARGIN):
+    """-> (lo, B) of the band [lo, lo + B) or None (full matrix): B = 32 or 64, the slack split evenly, lo even.  A read that ends inside
+    the window (n1 + dmax well below n2) leaves last-row cells to the right of its path, where the free tail may end after a jump: the
+    band then reaches the end of the last row (hi >= n2 - n1)."""
+    dmax = max(dmax, n2 - n1 - margin + 1)
     w = dmax - dmin
     if w + 2 * margin <= 31:
         B = 32
@@ -641,7 +644,7 @@ def star_cigars_banded_ref(seqs, bands, ref, open_=9, extend=1, match=20, mismat
     touch on the full matrix.  -> (cigars, [how each was aligned: 32, 64, 'width', 'edge'])"""
     cig, how = [], []
     for q, (dmin, dmax) in zip(seqs, bands):
-        b = band_of(dmin, dmax, margin)
+        b = band_of(dmin, dmax, len(q), len(ref), margin)
         c = None
         if b is not None:
             c = nw_cigar_band_free_tail_ref(q, ref, b[0], b[1], open_, extend, match, mismatch)

@@ -229,8 +229,21 @@ def test_device_pipeline_returns_the_host_routes_tuples(world_files, variant, mo
     def boom(*a, **k):
         raise AssertionError("the host-assembled route ran where the device pipeline was expected")
     monkeypatch.setattr(gip, "_pass2_native", boom)
+    # the host-assembled route aligns on the full matrix: the device pipeline with its band switched off returns the same tuples ...
+    monkeypatch.setenv("NC_PIPE_BAND", "0")
     got = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=haploid)
-    assert _same_tuples(got, exp) > (100 if variant != "excluded" else 50)
+    n_sites = _same_tuples(got, exp)
+    assert n_sites > (100 if variant != "excluded" else 50)
+    # ... and on the band (the default) the same sites, with the tensors and alleles of all but a few sites identical (a banded alignment is the
+    # full-matrix one unless the optimal path leaves the band without the banded path touching its edge: non-homologous stretches, read ends)
+    monkeypatch.delenv("NC_PIPE_BAND")
+    band = gip.get_indel_testing_candidates_batch(dct, chunks, haploid=haploid)
+    same = 0
+    for t, e in zip(band, exp):
+        assert list(t[0]) == list(e[0])
+        for k in range(len(e[0])):
+            same += all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) if isinstance(b, np.ndarray) else a[k] == b[k] for a, b in zip(t[1:], e[1:]))
+    assert same >= 0.98 * n_sites, (same, n_sites)
 
 
 @pytest.mark.gpu
@@ -291,10 +304,11 @@ def _host_sample(pack, reads_c, info, r1):
 
 
 @pytest.mark.gpu
-def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement():
+def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement(tmp_path, monkeypatch):
     """the bench workload (generated in HBM, no BAM behind it): sites, tensors, consensus-derived alleles and phase of the device
     pipeline against pass 2 restated from SAM-like records (CIGAR expansion base by base, oracle.read_windows_ref), the star
-    alignment in pure Python (oracle.star_msa_ref) for a few sites and the host statement (nc_star_msa) for the rest, msa() by the C oracle"""
+    alignment in PURE PYTHON for every site checked -- banded exactly as the device runs it (oracle.window_band_ref -> band_of ->
+    nw_cigar_band_free_tail_ref, full matrix after an edge touch or for wide bands) --, msa() by the C oracle; no product aligner involved"""
     from nanocaller_amd.engine import get_engine
     from nanocaller_amd.synth_device import make_indel_device_workload
     from oracle import oracle
@@ -303,10 +317,12 @@ def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement
     pack, reads_c, info = make_indel_device_workload(eng, L, depth=28.0, seed=99)
     chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
     kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+    monkeypatch.setenv("NC_PIPE_DUMP", str(tmp_path / "d"))                      # the run's per-alignment arrays as files (a debugging aid of the library)
     r = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+    monkeypatch.delenv("NC_PIPE_DUMP")
     assert r["n"] > 80
     x = r["x"].cpu().numpy()
-    hi = 60_000
+    hi = 100_000
     r1 = int(np.searchsorted(info["read_start"], hi + 400))
     s, e, codes_of, ev_of, ins_of = _host_sample(pack, reads_c, info, r1)
     recs = oracle.records_from_indel_pack(s, e, codes_of, ev_of, ins_of)
@@ -316,15 +332,14 @@ def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement
     alt_all = np.frombuffer(b"AGTCN", np.uint8)[r["alt"]].tobytes().decode()
     aoff = np.zeros(r["n"] * 3 + 1, np.int64)
     np.cumsum(np.maximum(r["alt_len"].reshape(-1), 0), out=aoff[1:])
-    checked = pure = 0
+    checked = 0
+    how = []
     for k in range(r["n"]):
         p = int(r["pos"][k])
         if p > hi:
             break
-        use_pure = pure < 2
-        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref, p, 160, 4, 160, aligner=None if use_pure else gip.star_aligner)
+        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref, p, 160, 4, 160, band=True, how_out=how)
         assert got is not None, p
-        pure += use_pure
         xs, cns, win, phase = got
         assert np.array_equal(x[k].reshape(3, 5, 128, 2), xs), p
         assert phase == int(r["phase"][k])
@@ -335,7 +350,19 @@ def test_device_pipeline_on_the_synthetic_workload_equals_the_oracle_restatement
             have = (None, None) if rl < 0 else (win[:rl], alt_all[aoff[k * 3 + t]:aoff[k * 3 + t] + al])
             assert have == exp, (p, t)
         checked += 1
-    assert checked >= 15
+    assert checked >= 32
+    assert how.count(32) > 0.7 * len(how) and how.count(64) > 0, (how.count(32), how.count(64), len(how))      # both band widths met
+    # the band of every alignment of those sites, as the device derived it from the events of the read, against the CIGAR walk of the oracle
+    d = {n: np.fromfile(str(tmp_path / ("d." + n)), dt) for n, dt in (("al_site", np.int32), ("al_read", np.int32), ("band_lo", np.int8), ("site_pos", np.int32), ("n1", np.int32))}
+    nb = 0
+    for a in range(len(d["al_site"])):
+        p = int(d["site_pos"][d["al_site"][a]])
+        if p > hi:
+            break
+        b = oracle.band_of(*oracle.window_band_ref(recs[int(d["al_read"][a])], p, 160), int(d["n1"][a]), min(161, L - p + 1))
+        assert int(d["band_lo"][a]) == (b[0] if b else 0), (a, p, b)
+        nb += 1
+    assert nb > 1000
     # and no site of the oracle's is missing: every anchor position the device kept in the sample range passes the oracle's set tests (above);
     # positions are unique per chunk and ascending
     pos0 = r["pos"][r["chunk"] == 0]
@@ -373,6 +400,37 @@ def test_device_pipeline_at_scale_is_deterministic_and_group_invariant(monkeypat
     tot = (x[..., 0] + x[..., 1]).sum(dim=2)
     used = x[..., 1].sum(dim=2) > 0
     assert used.any() and float((tot[used] - 1.0).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_banded_star_alignment_against_the_full_matrix(monkeypatch):
+    """the default (every read window aligned on the 32 / 64 diagonals its own CIGAR allows, full matrix after an edge touch) against the
+    full matrix for every window: same sites, and all but a few per ten thousand tensors / alleles identical; most windows fit 32 diagonals"""
+    import torch
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    eng = get_engine(0)
+    L = 8_000_000
+    pack, reads_c, info = make_indel_device_workload(eng, L, depth=30.0, seed=777)
+    chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+    res = {}
+    for mode in (0, 1):
+        assert eng.L.nc_indel_sites_band(eng.ctx, mode, 0) == 0
+        r = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+        st = np.zeros(4, np.int64)
+        eng.L.nc_indel_sites_band_stats(eng.ctx, _lib.npp(st))
+        res[mode] = (r, st)
+    assert eng.L.nc_indel_sites_band(eng.ctx, -1, 0) == 0
+    (f, sf), (b, sb) = res[0], res[1]
+    assert not sf.any() and int(sb[:3].sum()) == b["n_alignments"] == f["n_alignments"]
+    assert sb[0] > 0.85 * b["n_alignments"] and sb[1] > 0 and sb[2] < 0.02 * b["n_alignments"] and sb[3] < 0.001 * b["n_alignments"]
+    assert f["n"] == b["n"] > 3000
+    for k in ("pos", "chunk", "type", "phase"):
+        assert np.array_equal(np.asarray(f[k]), np.asarray(b[k])), k
+    dx = int((f["x"] != b["x"]).reshape(f["n"], -1).any(1).sum())
+    dal = int(((f["ref_len"] != b["ref_len"]) | (f["alt_len"] != b["alt_len"])).any(1).sum())
+    assert dx <= 0.002 * f["n"] and dal <= 0.002 * f["n"], (dx, dal, f["n"])
 
 
 @pytest.mark.gpu
