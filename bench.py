@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CHR20_LEN = 64_444_167                 # GRCh38 chr20
+CHR1_LEN = 248_956_422                 # GRCh38 chr1 (BASELINE.json configs[2])
 SNP_FLOP_PER_SITE = 3_455_760          # SURVEY.md 8d / BASELINE.md section 3 (haploid model: 3,453,696)
 TRUNK_FLOP_PER_SITE = 2 * (574_000 + 737_280 + 331_776)   # conv1 (3 kernels) + conv2 + conv3, SURVEY.md Appendix C.1
 INDEL_FLOP_PER_SITE = 18_946_752       # SURVEY.md 8d (haploid 5,040,688)
@@ -60,6 +61,9 @@ def parse():
     ap.add_argument("--resident", action="store_true", help="headline from HBM-resident packs (round-1 definition; not SURVEY 8d's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (HiFi 60x haploid, exact fp32, indel pipeline)")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] block (chr1-sized SNP + indel in one timed region)")
+    ap.add_argument("--configs2-steps", type=int, default=3)
+    ap.add_argument("--configs2-length", type=int, default=CHR1_LEN)
     ap.add_argument("--no-overlap", action="store_true", help="collect every step's results before the next step is enqueued")
     ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each; value = the median, min / max reported")
     ap.add_argument("--cpu-sample-chunks", type=int, default=0,
@@ -316,13 +320,15 @@ def extra_snp_config(eng, uploader, local, L, depth, tech, model, ploidy, exact_
         eng.set_cnn_precision(exact_fp32=False)
 
 
-# issue rates of the vector instructions the alignment fill is made of (tools/ubench/valu_rate.hip on MI355X, per wave-instruction and SIMD at
-# 4 waves per SIMD): packed 16-bit 1.83 ns, plain 32-bit 1.1 ns.  k_fill16q's cell body (two DP cells in each of 64 lanes): 14 packed
-# (7 v_pk_sub, 4 v_pk_max, v_pk_min_u16, v_pk_mad, v_pk_add) + 10 plain (xor, and, 4 shifts, 3 and-or, shift-or) instructions
-VALU_PK_NS, VALU_NS = 1.83, 1.1
-FILL_INSTR_PK, FILL_INSTR_PLAIN = 14, 10
-FILL_INSTR_PER_CELL_PAIR = FILL_INSTR_PK + FILL_INSTR_PLAIN
-FILL_PEAK_CELLS_S = 256 * 4 * 64 * 2 / ((FILL_INSTR_PK * VALU_PK_NS + FILL_INSTR_PLAIN * VALU_NS) * 1e-9)
+# Vector-issue roofline of the banded alignment fill (k_fill_band).  MI355X_MICROARCH.md: a SIMD issues a wave's plain 32-bit VALU instruction over
+# 2 cycles (SIMD-32); packed 16-bit arithmetic (v_pk_*_i16) issues at half that rate (tools/ubench/valu_rate.hip: 1.83 ns against 1.1 ns).  The DP
+# recurrence of one cell PAIR (two alignments in the halves of a register, 64 lanes) is 15 packed + 9 plain instructions (7 v_pk_sub, 4 v_pk_max,
+# v_pk_min_u16, v_pk_mad, v_pk_add, v_pk_sub; xor, and, 3 shifts, 3 and-or ... the traceback bits) = 78 issue cycles per 128 cells and SIMD.
+# peak = 1024 SIMDs x 2.4 GHz x 128 / 78 cells/s; the neighbour shifts (DPP), base streams and stores the kernel also issues count against it.
+VALU_PLAIN_CYC, VALU_PK_CYC = 2, 4
+FILL_INSTR_PK, FILL_INSTR_PLAIN = 15, 9
+CLOCK_HZ = 2.4e9
+FILL_PEAK_CELLS_S = 256 * 4 * CLOCK_HZ * 128 / (FILL_INSTR_PK * VALU_PK_CYC + FILL_INSTR_PLAIN * VALU_PLAIN_CYC)
 
 
 def _indel_wire(eng, pack, reads_c, info):
@@ -347,58 +353,85 @@ def _indel_wire(eng, pack, reads_c, info):
                       events=(h(ev["ev_off"]), h(ev["ev_pos"])[:n_ev], h(ev["ev_len"])[:n_ev]), indel_extra=extra)
 
 
-def extra_indel_config(eng, uploader, local, L, reps=10):
-    """The indel half of configs[2] at chromosome scale, as candidate sites/s: a chr20-sized synthetic ONT 30x contig with planted
-    indels and HP / PS tags (SURVEY 8d's generator, nc_synth_indel_*), 100 kb chunks.  Timed region: decoded alignments +
-    the bases without a reference column in PINNED HOST MEMORY -> one H2D copy (own stream, under the previous pass) -> expansion ->
-    K7 window scan -> anchors + read sets -> query windows -> star alignment -> tensors + consensus (K8) -> allele_prediction -> Indel_model
-    (K9) -> per-site arrays in host memory -> genotype rules + VCF text (native, on a host thread under the next pass).  Stage times are
-    HIP events of a separate instrumented pass; in-run parity against the oracle's restatement on a sample."""
-    from concurrent.futures import ThreadPoolExecutor
+class IndelJob:
+    """The indel half of the path over one synthetic contig: an ONT 30x contig with planted indels and HP / PS tags (SURVEY 8d's generator,
+    nc_synth_indel_*), 100 kb chunks, its transfer form (reference-difference wire + indel events + bases without a reference column) in
+    page-locked host memory, and one pass of the product path over it: expansion -> K7 window scan -> anchors + read sets -> query windows ->
+    star alignment (banded) -> tensors + consensus (K8) -> allele_prediction -> Indel_model (K9) -> per-site arrays in host memory; genotype
+    rules + VCF text natively on the host."""
 
-    from nanocaller_amd import _lib
-    from nanocaller_amd import generate_indel_pileups as gip
-    from nanocaller_amd.synth_device import make_indel_device_workload
-    from nanocaller_amd.weights import Weights, get_indel_model
-    from nanocaller_amd.wire import indel_reads_struct
-    from oracle import oracle
-    import ctypes as C
-    t0 = time.perf_counter()
-    pack, reads_c, info = make_indel_device_workload(eng, L, depth=30.0, seed=4813)
-    t_gen = time.perf_counter() - t0
-    wgt = Weights(get_indel_model("ONT-HG002"))
-    eng.load_weights(_lib.MODEL_INDEL, wgt)
-    chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
-    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
-    contig = np.frombuffer(b"AGTCN", np.uint8)[info["tensors"]["ref"].cpu().numpy()[1:]].tobytes()
-    t0 = time.perf_counter()
-    wire = _indel_wire(eng, pack, reads_c, info)
-    t_wire = time.perf_counter() - t0
+    def __init__(self, eng, L, seed=4813, name=b"chr20"):
+        from nanocaller_amd import _lib
+        from nanocaller_amd.synth_device import make_indel_device_workload
+        from nanocaller_amd.weights import Weights, get_indel_model
+        self.eng, self.L, self.name = eng, L, name
+        t0 = time.perf_counter()
+        self.pack, self.reads_c, self.info = make_indel_device_workload(eng, L, depth=30.0, seed=seed)
+        self.t_gen = time.perf_counter() - t0
+        self.wgt = Weights(get_indel_model("ONT-HG002"))
+        eng.load_weights(_lib.MODEL_INDEL, self.wgt)
+        self.chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+        self.kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+        self.contig = np.frombuffer(b"AGTCN", np.uint8)[self.info["tensors"]["ref"].cpu().numpy()[1:]].tobytes()
+        t0 = time.perf_counter()
+        self.wire = _indel_wire(eng, self.pack, self.reads_c, self.info)
+        self.t_wire = time.perf_counter() - t0
 
-    def gpu_pass(dp, rc):
-        r = gip.indel_sites_device(eng, dp, rc, L, chunks, fetch=False, **kw)
+    def drop_pack(self):
+        """keep only the host-side transfer form (the HBM-resident pack is for the resident / instrumented passes)"""
+        self.pack = self.reads_c = None
+        torch.cuda.empty_cache()
+
+    def gpu_pass(self, dp, rc):
+        from nanocaller_amd import _lib
+        from nanocaller_amd import generate_indel_pileups as gip
+        eng = self.eng
+        r = gip.indel_sites_device(eng, dp, rc, self.L, self.chunks, fetch=False, **self.kw)
         probs = eng.indel_forward(_lib.MODEL_INDEL, r["x"])
         r.update(gip.indel_sites_fetch(eng, r["n"], r["sets"]))
         r["probs"] = probs.cpu().numpy()
         del r["x"]
         return r
 
-    def rules(r):
+    def rules(self, r):
+        import ctypes as C
+
+        from nanocaller_amd import _lib
         N = r["n"]
         buf = np.empty(N * 110 + 4 * int(np.maximum(r["ref_len"], 0).sum() + np.maximum(r["alt_len"], 0).sum()) + 4096, np.uint8)
         nb = C.c_int64()
-        rc = eng.L.nc_indel_vcf_format(b"chr20", N, _lib.npp(np.ascontiguousarray(r["pos"])), _lib.npp(np.ascontiguousarray(r["chunk"])), len(chunks),
-                                       _lib.npp(r["probs"]), r["sets"], _lib.npp(np.ascontiguousarray(r["ref_len"])),
-                                       _lib.npp(np.ascontiguousarray(r["alt_len"])), _lib.npp(r["alt"]), _lib.npp(np.ascontiguousarray(r["phase"])),
-                                       contig, L, 0, _lib.npp(buf), buf.size, C.byref(nb), None)
+        rc = self.eng.L.nc_indel_vcf_format(self.name, N, _lib.npp(np.ascontiguousarray(r["pos"])), _lib.npp(np.ascontiguousarray(r["chunk"])), len(self.chunks),
+                                            _lib.npp(r["probs"]), r["sets"], _lib.npp(np.ascontiguousarray(r["ref_len"])),
+                                            _lib.npp(np.ascontiguousarray(r["alt_len"])), _lib.npp(r["alt"]), _lib.npp(np.ascontiguousarray(r["phase"])),
+                                            self.contig, self.L, 0, _lib.npp(buf), buf.size, C.byref(nb), None)
         assert rc == 0, rc
         return int((buf[:nb.value] == 10).sum())
 
-    def from_host_pass(tk):
+    def from_host_pass(self, uploader, tk):
+        from nanocaller_amd.wire import indel_reads_struct
         dp = uploader.expand(tk)
-        r = gpu_pass(dp, indel_reads_struct(dp))
+        r = self.gpu_pass(dp, indel_reads_struct(dp))
         uploader.release(tk)
         return r
+
+
+def extra_indel_config(eng, uploader, local, L, reps=10):
+    """The indel half of configs[2] at chromosome scale, as candidate sites/s: a chr20-sized synthetic ONT 30x contig (IndelJob).  Timed
+    region: decoded alignments + the bases without a reference column in PINNED HOST MEMORY -> one H2D copy (own stream, under the
+    previous pass) -> the pass -> genotype rules + VCF text (native, on a host thread under the next pass).  Stage times are HIP events of a
+    separate instrumented pass; in-run parity against the oracle's restatement on a sample."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from nanocaller_amd import _lib
+    from nanocaller_amd import generate_indel_pileups as gip
+    from oracle import oracle
+    job = IndelJob(eng, L)
+    pack, reads_c, info, wgt, chunks, kw, contig, wire = job.pack, job.reads_c, job.info, job.wgt, job.chunks, job.kw, job.contig, job.wire
+    t_gen, t_wire = job.t_gen, job.t_wire
+    gpu_pass, rules = job.gpu_pass, job.rules
+
+    def from_host_pass(tk):
+        return job.from_host_pass(uploader, tk)
     # ---- warm-up (sizes every workspace), then: (a) HBM-resident passes one by one, (b) from pinned host memory, pipelined
     gpu_pass(pack, reads_c)
     resident_ms, n_rec = [], 0
@@ -445,24 +478,31 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
     cells = np.zeros(2, np.int64)
     eng.L.nc_indel_sites_stage_ms(eng.ctx, _lib.npp(ms), _lib.npp(cells))
     ms, cells = [float(v) for v in ms], [int(v) for v in cells]
+    band = np.zeros(6, np.int64)
+    eng.L.nc_indel_sites_band_stats(eng.ctx, _lib.npp(band))
+    band = [int(v) for v in band]
     A = int(rt["n_alignments"])
     S = rt["sets"]
     gbs = lambda nbytes, t_ms: nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0       # noqa: E731
     k7_bytes = info["pileup_entries"] + L + 8 * info["n_events"]                     # (d+1) B/column + 8 B/event
     win_bytes = A * 2 * 160                                                          # every window read once, written once
     k8_bytes = 2 * A * 128 + n_sites * S * (128 + 5120)                              # R x 128 + 128 + 5,120 B per set (R summed: <= 2 x alignments)
-    fill_cells_s = cells[0] / (ms[2] * 1e-3) if ms[2] > 0 else 0.0
+    fill_cells_s = band[4] / (ms[2] * 1e-3) if ms[2] > 0 else 0.0
     k9_tf = INDEL_FLOP_PER_SITE * n_sites / (k9_ms * 1e-3) / 1e12
     stages = {
         "k7_scan_anchors_sets": {"ms": float(ms[0]), "bound": "hbm", "algorithmic_bytes": int(k7_bytes), "achieved_GBs": gbs(k7_bytes, ms[0]),
                                  "frac": gbs(k7_bytes, ms[0]) / HBM_PEAK_GBS, "note": "(d+1) B/column + 8 B/event; the launch set also selects the anchors and builds the read sets"},
         "query_windows": {"ms": float(ms[1]), "bound": "hbm", "algorithmic_bytes": int(win_bytes), "achieved_GBs": gbs(win_bytes, ms[1]),
                           "frac": gbs(win_bytes, ms[1]) / HBM_PEAK_GBS},
-        "star_alignment_fill": {"ms": float(ms[2]), "bound": "valu issue", "dp_cells": int(cells[0]), "achieved_cells_s": fill_cells_s,
+        "star_alignment_fill": {"ms": float(ms[2]), "bound": "valu issue", "kernel": "k_fill_band<1> + k_fill_band<2> (anti-diagonal sweep over 32 / 64 diagonals)",
+                                "dp_cells": band[4], "dp_cells_full_matrices": int(cells[0]), "achieved_cells_s": fill_cells_s,
                                 "peak_cells_s": FILL_PEAK_CELLS_S, "frac": fill_cells_s / FILL_PEAK_CELLS_S,
-                                "peak_note": "1024 SIMDs x 128 cells per (%d packed 16-bit instructions x %.2f ns + %d plain x %.1f ns; tools/ubench/valu_rate.hip): "
-                                             "the issue time of the kernel's own cell body" % (FILL_INSTR_PK, VALU_PK_NS, FILL_INSTR_PLAIN, VALU_NS)},
-        "star_alignment_traceback": {"ms": float(ms[3]), "bound": "latency (one dependent 4-bit code per step and alignment)"},
+                                "alignments": {"band32": band[0], "band64": band[1], "full_matrix_by_width": band[2], "full_matrix_after_edge_touch": band[3]},
+                                "peak_note": "1024 SIMDs x 2.4 GHz x 128 cells per (%d packed 16-bit instructions x %d cycles + %d plain x %d cycles): the vector-issue "
+                                             "time of the DP recurrence alone (MI355X_MICROARCH.md: SIMD-32, 2 cycles per wave instruction; packed 16-bit at half rate)"
+                                             % (FILL_INSTR_PK, VALU_PK_CYC, FILL_INSTR_PLAIN, VALU_PLAIN_CYC)},
+        "star_alignment_traceback": {"ms": float(ms[3]), "bound": "latency (one dependent 4-bit code per step and alignment)",
+                                     "note": "banded tracebacks + the full-matrix fill / traceback of the alignments that do not fit a band"},
         "k8_tensors_consensus": {"ms": float(ms[4]), "bound": "hbm", "algorithmic_bytes": int(k8_bytes), "achieved_GBs": gbs(k8_bytes, ms[4]),
                                  "frac": gbs(k8_bytes, ms[4]) / HBM_PEAK_GBS},
         "allele_prediction": {"ms": float(ms[5]), "bound": "valu issue", "dp_cells_upper": int(cells[1])},
@@ -478,7 +518,7 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
         from build_tag import INDEL_SOURCES
         tag_ok, tag_note = traffic_build_check(it, INDEL_SOURCES)
         for name, st in stages.items():
-            key = "fill (star alignment + allele alignment)" if name == "star_alignment_fill" else name
+            key = name
             if key in it["stages"] and not tag_ok:
                 st["traffic"] = None
                 st["traffic_note"] = tag_note
@@ -511,11 +551,11 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
     aoff = np.zeros(rt["n"] * S + 1, np.int64)
     np.cumsum(np.maximum(rt["alt_len"].reshape(-1), 0), out=aoff[1:])
     checked, x_exact, alleles_exact = 0, True, True
-    for k in range(min(rt["n"], 64)):
+    for k in range(min(rt["n"], 40)):
         p_ = int(rt["pos"][k])
         if p_ > hi:
             break
-        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref_s, p_, 160, 4, 160, aligner=None if checked == 0 else gip.star_aligner)
+        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref_s, p_, 160, 4, 160, band=True)     # pure Python: no product aligner in the check
         if got is None:
             x_exact = False
             break
@@ -557,10 +597,152 @@ def extra_indel_config(eng, uploader, local, L, reps=10):
                            "star_scoring_open_extend_match_mismatch": list(_lib.STAR_SCORING)},
            "parity": {"sites_checked_against_oracle_restatement": checked, "tensors_and_phase_exact": bool(x_exact), "alleles_exact": bool(alleles_exact),
                       "k9_max_abs_dprob_vs_f64_oracle": k9_err, "k9_sites_checked": int(m),
-                      "note": "pass 2 restated from SAM-like records (oracle.read_windows_ref: CIGAR expansion), star alignment in pure Python for the first "
-                              "site and by the host statement nc_star_msa for the rest, msa() by the C oracle; the same check over more sites and the "
-                              "reference-executed tuples: tests/test_indel_pipeline.py, tests/test_pass2_golden.py"}}
+                      "note": "pass 2 restated from SAM-like records (oracle.read_windows_ref: CIGAR expansion), every star alignment in pure Python on the band "
+                              "the read's CIGAR allows, as the device runs it (oracle.star_cigars_banded_ref), msa() by the C oracle; the reference-executed "
+                              "tuples: tests/test_pass2_golden.py"}}
     del pack, rt, wire
+    torch.cuda.empty_cache()
+    return out
+
+
+def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
+    """BASELINE.json configs[2]: "SNP+indel full pipeline on 1 MI355X, HG002 ONT 30x chr1" as ONE timed region.  A step = the SNP pass over a
+    chr1-sized contig (248,956,422 bp, 498 chunks of 500 kb; upload -> expansion -> scan -> tensors -> SNP CNN -> per-site results) followed by the
+    indel pass over a chr1-sized contig with planted indels and HP / PS tags (2,490 chunks of 100 kb; upload -> expansion -> K7 -> read sets ->
+    windows -> banded star alignment -> tensors -> allele_prediction -> indel CNN -> per-site results), both from PINNED HOST MEMORY -- the reference
+    runs the two halves one after the other in one invocation (NanoCaller:25-55; the indel half reads the phased BAM: its own decode and upload).
+    The copy of each half runs under the kernels of the other; genotype rules + VCF text of both halves run natively on a host thread under the
+    next step.  value = (SNP candidate sites + indel candidate sites) / wall time."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from nanocaller_amd import _lib, snpCaller
+    from nanocaller_amd import generate_indel_pileups as gip
+    from nanocaller_amd.utils import get_chunks
+    t0 = time.perf_counter()
+    snp = Contig(eng, L, 30.0, "ont", seed=912, keep_pack=False)
+    chunks = get_chunks([("chr1", 1, L, "diploid")], cpu=16)
+    params = snp_params(model, "ont")
+    job = IndelJob(eng, L, seed=4913, name=b"chr1")
+    t_setup = time.perf_counter() - t0
+    scratch = {}
+
+    def snp_text(res):
+        n = max(int(res["n"]), 1)
+        if scratch.get("n", 0) < n:
+            scratch["buf"], scratch["n"] = np.empty((400 + 5) * n * 5 // 4 + 65536, np.uint8), n
+        return len(snpCaller.snp_vcf_text("chr1", res["pos"], res["ref"], res["probs"], res["dp"], res["freq"], res["fwd_dp"], res["rev_dp"],
+                                          haploid=False, as_array=True, out=scratch["buf"]))
+
+    def host_half(rs, ri):
+        if rs is not None:
+            snp_text(rs)
+        return job.rules(ri) if ri is not None else 0
+
+    def run(n_steps, snp_half=True, indel_half=True):
+        """n_steps steps; the copies of step i + 1 (SNP wire, then indel wire: 110 ms of PCIe at chr1 size) are both enqueued before the indel
+        pass of step i starts, so they run under ~100 ms of its kernels and the SNP kernels of step i + 1"""
+        ns = ni = nrec = 0
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pend = prev = None
+            tk_s = uploader.submit(snp.wire) if snp_half else None
+            tk_i = uploader.submit(job.wire) if indel_half else None
+            for i in range(n_steps):
+                more = i + 1 < n_steps
+                cur = ri = rs = None
+                nxt_s = nxt_i = None
+                if snp_half:
+                    dpk = uploader.expand(tk_s)
+                    cur = snpCaller.call_chunks(params, chunks, device=local, dpk=dpk, defer=True)
+                    uploader.release(tk_s)
+                    nxt_s = uploader.submit(snp.wire) if more else None
+                if indel_half:
+                    nxt_i = uploader.submit(job.wire) if more else None
+                    ri = job.from_host_pass(uploader, tk_i)
+                    ni += int(ri["n"])
+                    rs = cur.result() if cur is not None else None       # (the indel pass ends on host waits: the SNP half before it is complete)
+                elif prev is not None:
+                    rs = prev.result()                                   # SNP alone: step i - 1 is collected while step i runs
+                prev = cur
+                tk_s, tk_i = nxt_s, nxt_i
+                if rs is not None:
+                    ns += int(rs["n"])
+                if pend is not None:
+                    nrec += pend.result()
+                    pend = None
+                if rs is not None or ri is not None:
+                    pend = pool.submit(host_half, rs, ri)
+            if not indel_half and prev is not None:
+                rs = prev.result()
+                ns += int(rs["n"])
+                if pend is not None:
+                    nrec += pend.result()
+                pend = pool.submit(host_half, rs, None)
+            if pend is not None:
+                nrec += pend.result()
+        return ns, ni, nrec
+
+    def timed(n_steps, **kw):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = run(n_steps, **kw)
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t
+    run(len(uploader.slots))                                            # sizes every upload slot, every workspace and the result pools
+    uploader.h2d_events.clear()
+    eng.enable_timing(True, trunk_only=True)
+    s0, _ = eng.timing_sums()
+    (ns, ni, nrec), dt = timed(steps)
+    s1, _ = eng.timing_sums()
+    eng.enable_timing(False)
+    h2d_gbs, _, h2d_bytes = uploader.h2d_rate()
+    trunk_ms, trunk_n = s1[4] - s0[4], max(1.0, s1[5] - s0[5])
+    trunk_tf = TRUNK_FLOP_PER_SITE * ns / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
+    (ns_a, _, _), dt_s = timed(steps, indel_half=False)
+    (_, ni_a, _), dt_i = timed(steps, snp_half=False)
+    # instrumented indel pass over the HBM-resident pack: stage times by HIP events
+    eng.enable_timing(True)
+    rt = gip.indel_sites_device(eng, job.pack, job.reads_c, L, job.chunks, fetch=False, **job.kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.indel_forward(_lib.MODEL_INDEL, rt["x"])
+    e1.record()
+    torch.cuda.synchronize()
+    k9_ms = e0.elapsed_time(e1)
+    gip.indel_sites_fetch(eng, rt["n"], rt["sets"])
+    eng.enable_timing(False)
+    ms = np.zeros(6, np.float32)
+    cells = np.zeros(2, np.int64)
+    eng.L.nc_indel_sites_stage_ms(eng.ctx, _lib.npp(ms), _lib.npp(cells))
+    band = np.zeros(6, np.int64)
+    eng.L.nc_indel_sites_band_stats(eng.ctx, _lib.npp(band))
+    n_i = int(rt["n"])
+    k9_tf = INDEL_FLOP_PER_SITE * n_i / (k9_ms * 1e-3) / 1e12 if k9_ms > 0 else 0.0
+    fill_cells_s = int(band[4]) / (float(ms[2]) * 1e-3) if ms[2] > 0 else 0.0
+    peak = F16_MFMA_PEAK_TFLOPS / 3.0
+    out = {"workload": "BASELINE.json configs[2]: SNP + indel pipeline over chr1-sized synthetic ONT 30x contigs (%d bp): SNP half %d chunks of 500 kb, %d candidate "
+                       "sites per step; indel half (planted indels 1-50 bp, HP/PS tags) %d chunks of 100 kb, %d candidate sites (%d read windows aligned) per step"
+                       % (L, len(chunks), ns // steps, len(job.chunks), ni // steps, int(rt["n_alignments"])),
+           "value": (ns + ni) / dt, "unit": "candidate sites/s (SNP + indel, one timed region)", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "timed_region": "per step: SNP wire (%.0f MB) and indel wire (%.0f MB) from pinned host memory, each copy under the other half's kernels -> both halves' "
+                           "per-site results in host memory -> native rules + VCF text of both on a host thread under the next step"
+                           % (snp.wire.nbytes / 1e6, job.wire.nbytes / 1e6),
+           "vcf_records_per_step_indel": nrec // steps,
+           "snp_half": {"sites_per_step": ns // steps, "ms_per_step_alone": dt_s / steps * 1e3, "sites_s_alone": ns_a / dt_s,
+                        "roofline": {"bound": "mfma", "kernel": "k5_trunk_h3", "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
+                                     "avg_launch_ms": float(trunk_ms / trunk_n), "launches": trunk_n,
+                                     "note": "HIP events on the trunk's launches inside the combined timed region"}},
+           "indel_half": {"sites_per_step": ni // steps, "ms_per_step_alone": dt_i / steps * 1e3, "sites_s_alone": ni_a / dt_i,
+                          "stages_ms": {"k7_scan_anchors_sets": float(ms[0]), "query_windows": float(ms[1]), "star_alignment_fill": float(ms[2]),
+                                        "star_alignment_traceback": float(ms[3]), "k8_tensors_consensus": float(ms[4]), "allele_prediction": float(ms[5]),
+                                        "k9_indel_cnn": float(k9_ms), "note": "HIP events of one instrumented pass over the HBM-resident pack (stages one after the other)"},
+                          "alignments": {"band32": int(band[0]), "band64": int(band[1]), "full_matrix_by_width": int(band[2]), "full_matrix_after_edge_touch": int(band[3])},
+                          "roofline": {"bound": "mfma", "kernel": "k10_indel_trunk_h3 + k3_fc1 (K9)", "achieved": k9_tf, "peak": peak, "unit": "TFLOP/s", "frac": k9_tf / peak,
+                                       "ms": float(k9_ms)},
+                          "roofline_alignment": {"bound": "valu issue", "kernel": "k_fill_band", "achieved": fill_cells_s, "peak": FILL_PEAK_CELLS_S, "unit": "DP cells/s",
+                                                 "frac": fill_cells_s / FILL_PEAK_CELLS_S, "dp_cells": int(band[4]), "dp_cells_full_matrices": int(cells[0])}},
+           "h2d": {"bytes_per_step": snp.wire.nbytes + job.wire.nbytes, "achieved_GBs": h2d_gbs},
+           "setup_s": round(t_setup, 1)}
+    del snp, job, rt
     torch.cuda.empty_cache()
     return out
 
@@ -908,7 +1090,7 @@ def main():
                        "featurize_ms": float(stage_ms[1]),
                        "featurize_GBs": feat_bytes / (stage_ms[1] * 1e-3) / 1e9 if stage_ms[1] else 0,
                        "featurize_frac_hbm": feat_bytes / (stage_ms[1] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[1] else 0,
-                       "cnn_ms": float(stage_ms[2]), "trunk_ms_per_contig": float(trunk_ms / max(1, n_units))},
+                       "cnn_ms": float(stage_ms[2]), "trunk_ms_per_contig": float(trunk_ms / max(1, n_units * len(dts)))},
         }
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_sample_chunks or len(chunks)
@@ -917,11 +1099,20 @@ def main():
             out["parity"] = parity
             cbt, _ = cpu_baseline(pack, c0.info, chunks, params, args.model, r0, min(len(chunks), max(1, usable_cpus())))
             out["cpu_baseline"]["thread_variant"] = {"value": cbt["value"], "cores": cbt["cores"], "sample": cbt["sample"]}
+        if world == 1 and not args.no_configs2:
+            # BASELINE.json configs[2] as a first-class block of the line: chr1-sized SNP + indel, one timed region
+            contigs.clear()
+            c0 = pack = None
+            torch.cuda.empty_cache()
+            try:
+                out["configs2_snp_indel_chr1"] = configs2_block(eng, uploader, local, args.model, args.configs2_steps, args.configs2_length)
+            except Exception as e:
+                out["configs2_snp_indel_chr1"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_extra:
             # other configurations, outside the headline's timed region (BASELINE.json configs[4], the exact-fp32 trunk,
             # and the indel half of configs[2]); each with its own workload and roofline
             contigs.clear()
-            del c0, pack
+            c0 = pack = None
             torch.cuda.empty_cache()
             extra = {}
             try:

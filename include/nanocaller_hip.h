@@ -517,8 +517,10 @@ int nc_indel_sites_stage_ms(nc_ctx *ctx, float *ms6, int64_t *cells2 /* [0] DP c
 /* The star alignment behind msa() (generate_indel_pileups.py:24-44; MUSCLE in the reference) runs on a BAND of 32 or 64 diagonals around
  * the diagonals the read's own CIGAR visits inside the window; an alignment whose band would be wider, or whose banded path touches an edge
  * diagonal, runs on the full matrix.  Counts of the last plan + run + fetch: [0] alignments on 32 diagonals, [1] on 64, [2] on the full
- * matrix because of their width, [3] re-run on the full matrix after an edge touch.  NC_PIPE_BAND=0 in the environment turns the band off. */
-int nc_indel_sites_band_stats(nc_ctx *ctx, int64_t *stats4);
+ * matrix because of their width, [3] re-run on the full matrix after an edge touch, [4] DP cells of the banded alignments [0] + [1]
+ * ((n1 + n2) x 16 or 32 each; nc_indel_sites_stage_ms' cells2[0] keeps counting n1 x n2 for every alignment), [5] 0.  NC_PIPE_BAND=0 in the
+ * environment turns the band off. */
+int nc_indel_sites_band_stats(nc_ctx *ctx, int64_t *stats6);
 /* mode 1 / 0: band on / off for this context (-1: the environment's setting, the default = on); margin = diagonals kept free on either side
  * of the CIGAR's range, 1 .. 15 (0: the default, 6; NC_PIPE_BAND_MARGIN) */
 int nc_indel_sites_band(nc_ctx *ctx, int32_t mode, int32_t margin);

@@ -305,7 +305,7 @@ struct WinArgs {
     int32_t A, W, WS;
     uint8_t *win;           // [A][WS]
     int32_t *n1;            // [A]
-    unsigned long long *cells;
+    unsigned long long *cells;       // [0] += n1 x n2 of every alignment (the full matrices), [1] += the cells the banded route computes
     // banded alignment (k_fill_band): the diagonals j - i the read's own CIGAR visits inside the window bound the band
     int8_t *band_lo;        // [A] lowest diagonal of the alignment's band (even, <= 0), or NULL: no banding
     int32_t *list1, *list2, *listF;   // alignments whose band fits 32 / 64 diagonals; the rest (full matrix)
@@ -316,7 +316,7 @@ struct WinArgs {
 __global__ __launch_bounds__(64) void k_windows(WinArgs p)
 {
     const int al = blockIdx.x * 64 + threadIdx.x;
-    long long mycells = 0;
+    long long mycells = 0, bandcells = 0;
     int cls = -1;
     if (al < p.A) {
         const int r = p.al_read[al], site = p.al_site[al];
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
             int lo = dmin - ((B - 1 - w) >> 1);
             lo -= lo & 1;
             p.band_lo[al] = (int8_t)(cls == 2 ? 0 : lo);
+            bandcells = cls == 2 ? 0 : (long long)(n + p.site_n2[site]) * (B / 2);
         }
     }
     if (p.band_lo) {                                                                      // class lists: one atomic per wave and class
@@ -417,8 +418,9 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
+    for (int o = 32; o > 0; o >>= 1) { mycells += __shfl_xor(mycells, o); bandcells += __shfl_xor(bandcells, o); }
     if (threadIdx.x == 0 && mycells) atomicAdd(p.cells, (unsigned long long)mycells);
+    if (threadIdx.x == 0 && bandcells) atomicAdd(p.cells + 1, (unsigned long long)bandcells);
 }
 
 struct FillArgs {
@@ -1731,7 +1733,7 @@ struct nc_pipe_state {
         DevBuf band_lo, lists, counts, twb, hrow, hcolb;                // banded star alignment: per-alignment band, class lists, codes, last row / column
     } gb[2];                                // two sets: group g+1 is aligned while g is reduced
     int32_t band_mode = -1, band_margin_v = 0;   // nc_indel_sites_band: -1 = the environment's setting
-    int64_t band_stats[4] = {0, 0, 0, 0};   // of the last run: alignments on 32 / 64 diagonals, on the full matrix by width, re-run after an edge touch
+    int64_t band_stats[6] = {0, 0, 0, 0, 0, 0};   // of the last run: alignments on 32 / 64 diagonals, on the full matrix by width, re-run after an edge touch
     DevBuf tw2, runs, rlen, alen, alt_pool, misc;
     hipStream_t sB = nullptr;                // second stream: traceback / tensors / alleles of group g beside the alignment fill of g + 1
     hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -1858,7 +1860,7 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     NC_TRY(nc_ensure(ctx, s->cnt, ((size_t)n_chunks + 1) * 4));
     NC_TRY(nc_ensure(ctx, s->off, ((size_t)n_chunks + 2) * 4));
     NC_TRY(nc_ensure(ctx, s->misc, 256));
-    int32_t *err = (int32_t *)s->misc.p;                              // [0] error bits, [2..3] row total mailbox, [4..5] cells, [8..9] alt pool bytes
+    int32_t *err = (int32_t *)s->misc.p;                              // [0] error bits, [2..3] row total mailbox, [4..5] cells, [6..7] banded cells, [8..9] alt pool bytes, [16..23] band classes
     NC_HIP(ctx, hipMemsetAsync(s->misc.p, 0, 256, ctx->stream));
     int32_t c0 = 0;
     std::vector<IndelChunk> ck;
@@ -2265,6 +2267,7 @@ extern "C" int nc_indel_sites_fetch(nc_ctx *ctx, int32_t *pos, int32_t *chunk, i
     memcpy(&cells, misc + 4, 8);
     memcpy(&pool, misc + 8, 8);
     memcpy(s->band_stats, misc + 16, 32);
+    memcpy(s->band_stats + 4, misc + 6, 8);
     s->cells[0] = cells;
     if (n_alt_bytes) *n_alt_bytes = pool;
     return NC_OK;
@@ -2292,10 +2295,10 @@ extern "C" int nc_indel_sites_band(nc_ctx *ctx, int32_t mode, int32_t margin)
     return NC_OK;
 }
 
-extern "C" int nc_indel_sites_band_stats(nc_ctx *ctx, int64_t *stats4)
+extern "C" int nc_indel_sites_band_stats(nc_ctx *ctx, int64_t *stats6)
 {
-    if (!ctx || !ctx->pipe || !stats4) return NC_ERR_ARG;
-    for (int k = 0; k < 4; k++) stats4[k] = ctx->pipe->band_stats[k];
+    if (!ctx || !ctx->pipe || !stats6) return NC_ERR_ARG;
+    for (int k = 0; k < 6; k++) stats6[k] = ctx->pipe->band_stats[k];
     return NC_OK;
 }
 

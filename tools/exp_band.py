@@ -37,7 +37,7 @@ def run(mode, margin, timing):
     ms = np.zeros(6, np.float32)
     cells = np.zeros(2, np.int64)
     eng.L.nc_indel_sites_stage_ms(eng.ctx, _lib.npp(ms), _lib.npp(cells))
-    st = np.zeros(4, np.int64)
+    st = np.zeros(6, np.int64)
     eng.L.nc_indel_sites_band_stats(eng.ctx, _lib.npp(st))
     return r, dt, ms, st
 
