@@ -29,7 +29,7 @@ extern "C" {
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
-                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment) */
+                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -165,6 +165,20 @@ int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, cons
                    const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
                    const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
                    uint8_t *d_ref_code);
+
+/* Transfer form of the indel path's per-read events (csrc/nc_wire.hip): 3 bytes per event instead of the 12 the kernels read.
+ *   d16 [n_events]  column - column of the read's previous event (the first one: - rd_start[r]); 0xFFFF: the event is in the side table
+ *   l8  [n_events]  signed length ('+n' / '-n' of the pileup, generate_indel_pileups.py:216-231); the side table's when d16 is 0xFFFF
+ *   big_idx (ascending event indices) / big_pos / big_len: events with a distance >= 0xFFFF or |length| >= 128
+ *   read_ins_off [n_reads + 1] (may be NULL): offset of each read's first inserted base; the per-event ins_off is its running sum
+ * nc_indel_events_pack: host; returns NC_ERR_CAPACITY with *n_big = the needed size when big_cap is too small.
+ * nc_indel_events_expand: all pointers dev; writes ev_pos / ev_len [n_events] and (if given) ins_off [n_events + 1] on the context's stream. */
+int nc_indel_events_pack(int32_t n_reads, const int32_t *rd_start, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len,
+                         uint16_t *d16, int8_t *l8, int32_t *read_ins_off, int64_t big_cap, int32_t *big_idx, int32_t *big_pos,
+                         int32_t *big_len, int64_t *n_big);
+int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint16_t *d_d16,
+                           const int8_t *d_l8, int32_t n_big, const int32_t *d_big_idx, const int32_t *d_big_pos, const int32_t *d_big_len,
+                           const int32_t *d_read_ins_off, int32_t *d_ev_pos, int32_t *d_ev_len, int32_t *d_ins_off);
 
 /* ------------------------------------------------------------------ SNP candidate scan (K1)
  * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch

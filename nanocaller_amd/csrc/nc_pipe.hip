@@ -664,6 +664,7 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     bool live[2];
     const uint8_t *s2[2];
     uint32_t s1o[2];                                                  // the read's bases at p.s1 + s1o (32-bit offsets and block indices: a register fewer each than 64-bit values)
+    uint32_t arow[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int a = pair * 2 + k;
@@ -671,8 +672,10 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
         al[k] = live[k] ? a : 0;
         n1[k] = 0; n2[k] = 0;
         s1o[k] = 0; s2[k] = p.ref_code;
+        arow[k] = 0;
         if (live[k]) {
             const int ain = p.list ? p.list[a] : a;
+            arow[k] = p.arow ? (uint32_t)p.arow[ain] : (uint32_t)a * (uint32_t)tw_blocks(p.N1);      // (a row table is per alignment, a uniform pitch per slot)
             s1o[k] = (uint32_t)ain * (uint32_t)p.s1_stride;
             n1[k] = p.n1[ain];
             const int site = fill_site(p, ain);
@@ -692,9 +695,6 @@ __global__ __launch_bounds__(64) void k_fill16q(FillArgs p)
     int nmax = max(n1[0], n1[1]);
     nmax = max(nmax, __shfl_xor(nmax, 16));
     nmax = max(nmax, __shfl_xor(nmax, 32));
-    uint32_t arow[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) arow[k] = p.arow ? (uint32_t)p.arow[al[k]] : (uint32_t)al[k] * (uint32_t)tw_blocks(p.N1);
     __shared__ uint32_t tw_lds[2 * TWB * 64 * NWP];
     const uint32_t k_open = splat16(p.open), k_ext = splat16(p.extend), k_match = splat16(p.match + p.open), k_dmis = splat16(p.mismatch - p.match);
     const uint32_t k_one = splat16(1);
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
         a_tail = min(a_tail, __shfl_xor(a_tail, o));
     }
     nbw = __builtin_amdgcn_readfirstlane(nbw);
-    const int b_tail = __builtin_amdgcn_readfirstlane(max(0, (a_tail - 1) >> 3));
+    const int b_tail = p.hrow ? __builtin_amdgcn_readfirstlane(max(0, (a_tail - 1) >> 3)) : nbw;      // (a global alignment ends at the corner: no last row / column to keep)
     uint32_t P[4] = {0, 0, 0, 0};
     // one step.  ODD: the reference base moves (j grows); even: the read base (i grows).  TAIL: the cells of the last row / last column leave
     auto step = [&](auto odd_tag, auto tail_tag, int a, int s) {
@@ -1011,15 +1011,45 @@ __global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
     }
 }
 
-// traceback of a banded alignment: k_trace16p's walk and entries; a block of 8 anti-diagonals is one line of 64 C bytes (16 lanes x C words),
-// cached in LDS per walking lane and re-fetched in epochs.  The end point (best cell of the last row, ties to the larger column, or a strictly
+// The line cache of a banded traceback (TbLine's role): a block of 8 anti-diagonals is one line of 64 C bytes (16 lanes x C words), kept in LDS per
+// walking lane and re-fetched in epochs.
+template <int C>
+struct TbBand {
+    static constexpr int B = 32 * C;
+    uint32_t *slot;                                                    // this lane's 16 C words in LDS (odd pitch)
+    const uint32_t *tw;                                                // the alignment's codes
+    int lo, cblk, edge;
+    bool touched;
+    __device__ __forceinline__ bool has(int i, int j) const { return ((i + j - 1) >> 3) == cblk; }
+    __device__ __forceinline__ void load(int i, int j)
+    {
+        cblk = (i + j - 1) >> 3;
+        const U4 *src = reinterpret_cast<const U4 *>(tw + cblk * 16 * C);
+        U4 v[4 * C];
+#pragma unroll
+        for (int u = 0; u < 4 * C; u++) v[u] = src[u];
+#pragma unroll
+        for (int u = 0; u < 4 * C; u++) { slot[4 * u] = v[u].x; slot[4 * u + 1] = v[u].y; slot[4 * u + 2] = v[u].z; slot[4 * u + 3] = v[u].w; }
+    }
+    // cell (i, j), i, j > 0, of the cached line as a T_* code; notes a cell on (or within `edge` of) an edge diagonal of the band
+    __device__ __forceinline__ uint32_t code(int i, int j)
+    {
+        const int k = j - i - lo, s = (i + j - 1) & 7, xx = k >> 1;
+        touched |= k <= edge || k >= B - 1 - edge;
+        uint32_t tc;
+        if (C == 1) tc = (slot[xx] >> (4 * s)) & 15u;
+        else tc = (slot[(xx >> 1) * 2 + (s >> 2)] >> (4 * ((s & 3) * 2 + (xx & 1)))) & 15u;
+        return ((tc & 2u) ? (uint32_t)T_INS : (tc & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((tc & 4u) ? 0u : (uint32_t)T_EEXT) | ((tc & 8u) ? 0u : (uint32_t)T_FEXT);
+    }
+};
+constexpr int TBB_PITCH = 33;
+
+// traceback of a banded alignment: k_trace16p's walk and entries.  The end point (best cell of the last row, ties to the larger column, or a strictly
 // better cell of the last column, ties to the larger row) comes from the band's 2 x B last-row / last-column values.
 template <int C>
-__global__ __launch_bounds__(64) void k_trace_band(BandArgs p, uint32_t *__restrict__ ent_all, int32_t EW)
+__device__ __forceinline__ void trace_band_body(const BandArgs &p, uint32_t *__restrict__ ent_all, int32_t EW, uint32_t *stage, uint32_t *tbl)
 {
-    constexpr int B = 32 * C, PITCH = 33;
-    __shared__ uint32_t stage[16 * 64];
-    __shared__ uint32_t tbl[64 * PITCH];
+    constexpr int B = 32 * C;
     const int cnt = *p.count;
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= cnt) return;
@@ -1027,7 +1057,7 @@ __global__ __launch_bounds__(64) void k_trace_band(BandArgs p, uint32_t *__restr
     const FillArgs &f = p.f;
     const int al = p.list[idx];
     const int n1 = f.n1[al], n2 = f.site_n2[fill_site(f, al)], lo = p.band_lo[al];
-    uint32_t *slot = tbl + lane * PITCH;
+    TbBand<C> tb = {tbl + lane * TBB_PITCH, p.Twb + (int64_t)al * p.NBLK * 32, lo, -1, p.edge, false};
     uint32_t *ent = ent_all + (int64_t)al * EW;
     int i = n1, j = n2;
     if (n1 > 0 && n2 > 0) {
@@ -1062,21 +1092,12 @@ __global__ __launch_bounds__(64) void k_trace_band(BandArgs p, uint32_t *__restr
         x--;
     };
     while (x > j) put(0u);
-    int state = -1, cblk = -1;
-    bool touched = false;
-    const uint32_t *tw = p.Twb + (int64_t)al * p.NBLK * 32;
+    int state = -1;
     auto step = [&]() {
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else {
-            const int k = j - i - lo, s = (i + j - 1) & 7, xx = k >> 1;
-            touched |= k <= p.edge || k >= B - 1 - p.edge;
-            uint32_t tc;
-            if (C == 1) tc = (slot[xx] >> (4 * s)) & 15u;
-            else tc = (slot[(xx >> 1) * 2 + (s >> 2)] >> (4 * ((s & 3) * 2 + (xx & 1)))) & 15u;
-            t = ((tc & 2u) ? (uint32_t)T_INS : (tc & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((tc & 4u) ? 0u : (uint32_t)T_EEXT) | ((tc & 8u) ? 0u : (uint32_t)T_FEXT);
-        }
+        else t = tb.code(i, j);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) {
@@ -1101,23 +1122,24 @@ __global__ __launch_bounds__(64) void k_trace_band(BandArgs p, uint32_t *__restr
         }
     };
     while (__any(i > 0 || j > 0)) {                                    // epochs: the lanes that left their line load the next one together
-        if (i > 0 && j > 0 && ((i + j - 1) >> 3) != cblk) {
-            cblk = (i + j - 1) >> 3;
-            const U4 *src = reinterpret_cast<const U4 *>(tw + cblk * 16 * C);
-            U4 v[4 * C];
-#pragma unroll
-            for (int u = 0; u < 4 * C; u++) v[u] = src[u];
-#pragma unroll
-            for (int u = 0; u < 4 * C; u++) { slot[4 * u] = v[u].x; slot[4 * u + 1] = v[u].y; slot[4 * u + 2] = v[u].z; slot[4 * u + 3] = v[u].w; }
-        }
+        if (i > 0 && j > 0 && !tb.has(i, j)) tb.load(i, j);
         for (;;) {
-            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || ((i + j - 1) >> 3) == cblk);
+            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i, j));
             if (!__any(can)) break;
             if (can) step();
         }
     }
     put(cur);
-    if (touched) p.redo_list[atomicAdd(p.redo_count, 1)] = al;
+    if (tb.touched) p.redo_list[atomicAdd(p.redo_count, 1)] = al;
+}
+// both band widths in one launch (blockIdx.y): the 64-diagonal class is a fifteenth of the alignments, on its own a launch of one wave per SIMD
+// whose time is the latency of a single traceback
+__global__ __launch_bounds__(64) void k_trace_band12(BandArgs p1, BandArgs p2, uint32_t *__restrict__ ent_all, int32_t EW)
+{
+    __shared__ uint32_t stage[16 * 64];
+    __shared__ uint32_t tbl[64 * TBB_PITCH];
+    if (blockIdx.y == 0) trace_band_body<1>(p1, ent_all, EW, stage, tbl);
+    else trace_band_body<2>(p2, ent_all, EW, stage, tbl);
 }
 
 // free-tail end point of every alignment: the best cell of the last row (ties: the larger column) or a cell of the last column that is
@@ -1316,6 +1338,7 @@ struct TensorArgs {
     float *x;                                   // global [n_sites][S*5][128][2]
     uint8_t *cns;                               // group-local [n_sites_g * S][CNS_CAP], gap-free consensus
     int32_t *ncns;                              // group-local [n_sites_g * S]
+    int16_t *cband;                             // group-local [n_sites_g * S][2]: lowest / highest diagonal of the consensus against the window (or NULL)
     int32_t *err;
 };
 
@@ -1340,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
         if (sizeof(HT) == 1) atomicAdd(reinterpret_cast<uint32_t *>(&hist[t][0]) + c, 1u << (8 * sym));
         else atomicAdd(reinterpret_cast<uint32_t *>(&hist[t][0]) + 2 * c + (sym >> 1), 1u << (16 * (sym & 1)));
     };
-    __shared__ int32_t wcnt[4];
+    __shared__ int32_t wcnt[4], wcntr[4], s_runr, s_dmin, s_dmax;
     const int kl = blockIdx.x, site = p.site0 + kl;
     const int tid = threadIdx.x;
     const int n2 = p.site_n2[site];
@@ -1524,39 +1547,60 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
                 for (int k = 0; k < 5; k++) *reinterpret_cast<float2 *>(X + (k * 128 + c) * 2) = make_float2(0.0f, 0.0f);
             }
         }
-        if (tid == 0) s_run = 0;
+        if (tid == 0) { s_run = 0; s_runr = 0; s_dmin = 0; s_dmax = 0; }
         __syncthreads();
-        // consensus with the gap symbols removed (:61-64)
+        // consensus with the gap symbols removed (:61-64).  On the way: the diagonals (window columns passed) - (consensus bases written) of the
+        // consensus against its window, column by column -- the band of its global alignment in allele_prediction (k_allele_classes)
         uint8_t *out = p.cns + ((int64_t)kl * S + t) * CNS_CAP;
+        int dlo = 0, dhi = 0;
         for (int base = 0; base < ncols; base += 256) {
             const int c = base + tid;
-            const bool f = c < ncols && cnsv[c] != 4;
-            const uint64_t bm = __ballot(f);
-            if ((tid & 63) == 0) wcnt[tid >> 6] = __popcll(bm);
+            const bool f = c < ncols && cnsv[c] != 4, isr = c < ncols && refrow[c] != 4;
+            const uint64_t bm = __ballot(f), br = __ballot(isr);
+            if ((tid & 63) == 0) { wcnt[tid >> 6] = __popcll(bm); wcntr[tid >> 6] = __popcll(br); }
             __syncthreads();
-            int wp = s_run, totw = 0;
+            int wp = s_run, totw = 0, wr = s_runr, totr = 0;
             for (int w = 0; w < 4; w++) {
-                if (w < (tid >> 6)) wp += wcnt[w];
+                if (w < (tid >> 6)) { wp += wcnt[w]; wr += wcntr[w]; }
                 totw += wcnt[w];
+                totr += wcntr[w];
             }
-            if (f) out[wp + __popcll(bm & ((1ull << (tid & 63)) - 1))] = cnsv[c];
+            const uint64_t below = (1ull << (tid & 63)) - 1, upto = below | (1ull << (tid & 63));
+            if (f) out[wp + __popcll(bm & below)] = cnsv[c];
+            if (c < ncols) {
+                const int d = (wr + __popcll(br & upto)) - (wp + __popcll(bm & upto));
+                dlo = min(dlo, d);
+                dhi = max(dhi, d);
+            }
             __syncthreads();
-            if (tid == 0) s_run += totw;
+            if (tid == 0) { s_run += totw; s_runr += totr; }
             __syncthreads();
+        }
+        if (p.cband) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { dlo = min(dlo, __shfl_xor(dlo, o)); dhi = max(dhi, __shfl_xor(dhi, o)); }
+            if ((tid & 63) == 0) { atomicMin(&s_dmin, dlo); atomicMax(&s_dmax, dhi); }
+            __syncthreads();
+            if (tid == 0) { p.cband[(kl * S + t) * 2] = (int16_t)s_dmin; p.cband[(kl * S + t) * 2 + 1] = (int16_t)s_dmax; }
         }
         if (tid == 0) p.ncns[kl * S + t] = s_run;
         __syncthreads();
     }
 }
 
-// allele_prediction on the packed traceback of a GLOBAL alignment of the consensus (s1) against the window (nc_msa.hip k_allele_trace16)
-__global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL, int32_t fmt, const int32_t *__restrict__ site_type, int32_t win_size,
-                                                        int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
+// allele_prediction on the packed traceback of a GLOBAL alignment of the consensus (s1) against the window (nc_msa.hip k_allele_trace16).
+// C = 0: the full-matrix codes of k_fill16q (all alignments, or bp.f.list's); C = 1 / 2: the banded codes of k_fill_band<C> over bp.list --
+// an alignment whose path touches an edge diagonal of its band joins bp.redo_list (the caller runs those on the full matrix) and writes nothing
+template <int C>
+__device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CPL, int32_t fmt, const int32_t *__restrict__ site_type, int32_t win_size,
+                                                  int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len, uint32_t *tbl)
 {
-    __shared__ uint32_t tbl[64 * TBL_PITCH];
-    const int al = blockIdx.x * 64 + threadIdx.x;
-    if (al >= p.A) return;
+    const FillArgs &p = bp.f;
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= (C ? *bp.count : p.count ? min(*p.count, p.A) : p.A)) return;
+    const int al = C ? bp.list[idx] : p.list ? p.list[idx] : idx;
     TbLine tb = {tbl + threadIdx.x * TBL_PITCH, -1, -1, 0, 0};
+    TbBand<(C ? C : 1)> tbb = {tbl + threadIdx.x * TBB_PITCH, C ? bp.Twb + (int64_t)al * bp.NBLK * 32 : nullptr, C ? (int)bp.band_lo[al] : 0, -1, bp.edge, false};
     const int site = fill_site(p, al);
     const uint8_t *s1 = p.s1 + (int64_t)al * p.s1_stride;
     const int n1 = p.n1[al];
@@ -1584,7 +1628,7 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
         else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else t = tb.code(i, CPL, fmt);
+        else t = C ? tbb.code(i, j) : tb.code(i, CPL, fmt);
         if (state < 0) {
             const int w = t & 3;
             if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; tb.dec_j(CPL); return; }
@@ -1605,12 +1649,17 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     };
     tb.set_j(j, CPL);
     while (__any(i > 0 || j > 0)) {                                    // epochs: see TbLine
-        if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, CPL);
+        if (C) { if (i > 0 && j > 0 && !tbb.has(i, j)) tbb.load(i, j); }
+        else if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, CPL);
         for (;;) {
-            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i));
+            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || (C ? tbb.has(i, j) : tb.has(i)));
             if (!__any(can)) break;
             if (can) step();
         }
+    }
+    if (C && tbb.touched) {
+        bp.redo_list[atomicAdd(bp.redo_count, 1)] = al;
+        return;
     }
     if (last_op >= 0 && nr < run_cap) { rop[nr] = (int16_t)last_op; rcn[nr] = (int16_t)last_cnt; nr++; }
     bool indel = false, mm_before = false;
@@ -1654,6 +1703,49 @@ __global__ __launch_bounds__(64) void k_allele_trace16p(FillArgs p, int32_t CPL,
     }
     ref_len[al] = out_r;
     alt_len[al] = out_a;
+}
+template <int C>
+__global__ __launch_bounds__(64) void k_allele_trace16p(BandArgs bp, int32_t CPL, int32_t fmt, const int32_t *__restrict__ site_type, int32_t win_size,
+                                                        int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
+{
+    __shared__ uint32_t tbl[64 * TBL_PITCH];
+    allele_trace_body<C>(bp, CPL, fmt, site_type, win_size, runs, ref_len, alt_len, tbl);
+}
+__global__ __launch_bounds__(64) void k_allele_trace_b12(BandArgs b1, BandArgs b2, int32_t CPL, const int32_t *__restrict__ site_type, int32_t win_size,
+                                                         int16_t *__restrict__ runs, int32_t *__restrict__ ref_len, int32_t *__restrict__ alt_len)
+{
+    __shared__ uint32_t tbl[64 * TBL_PITCH];
+    if (blockIdx.y == 0) allele_trace_body<1>(b1, CPL, 1, site_type, win_size, runs, ref_len, alt_len, tbl);
+    else allele_trace_body<2>(b2, CPL, 1, site_type, win_size, runs, ref_len, alt_len, tbl);
+}
+
+// band of a GLOBAL alignment of a consensus (n1 bases) against its window (n2): the consensus is the window with the set's indels applied, and
+// k_site_tensor noted the diagonals its columns run on (cband); classes and lists as k_windows makes them for the star alignment
+__global__ __launch_bounds__(256) void k_allele_classes(FillArgs p, const int16_t *__restrict__ cband, int32_t margin, int32_t max_sum, int8_t *__restrict__ band_lo, int32_t *__restrict__ list1,
+                                                       int32_t *__restrict__ list2, int32_t *__restrict__ listF, int32_t *__restrict__ counts)
+{
+    const int al = blockIdx.x * 256 + threadIdx.x;
+    int cls = -1;
+    if (al < p.A) {
+        const int n1 = p.n1[al], n2 = p.site_n2[fill_site(p, al)];
+        const int dend = n2 - n1, dmin = min(min(0, dend), (int)cband[2 * al]), dmax = max(max(0, dend), (int)cband[2 * al + 1]), w = dmax - dmin;
+        cls = (n1 <= 0 || n1 + n2 > max_sum) ? 2 : w + 2 * margin <= 31 ? 0 : w + 2 * margin <= 63 ? 1 : 2;      // (an empty consensus: the full route reports it)
+        const int B = cls == 0 ? 32 : 64;
+        int lo = dmin - ((B - 1 - w) >> 1);
+        lo -= lo & 1;
+        band_lo[al] = (int8_t)(cls == 2 ? 0 : lo);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const unsigned long long m = __ballot(cls == c);
+        if (!m) continue;
+        const int lead = __ffsll((long long)m) - 1, ln = threadIdx.x & 63;
+        int base = 0;
+        if (ln == lead) base = atomicAdd(counts + c, __popcll(m));
+        base = __shfl(base, lead);
+        int32_t *lst = c == 0 ? list1 : c == 1 ? list2 : listF;
+        if (cls == c) lst[base + __popcll(m & ((1ull << ln) - 1ull))] = al;
+    }
 }
 
 // One workgroup, every thread a contiguous chunk of ceil(n / 1024) items: local sum -> block scan of the 1,024 sums -> local scan.  (The
@@ -1730,11 +1822,12 @@ struct nc_pipe_state {
     DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
     struct GroupBufs {
         DevBuf win, n1, tw, hlast, hcol, endc, trace, cns, ncns, arow, alt_off;
-        DevBuf band_lo, lists, counts, twb, hrow, hcolb;                // banded star alignment: per-alignment band, class lists, codes, last row / column
+        DevBuf band_lo, lists, counts, twb, hrow, hcolb, cband;                // banded star alignment: per-alignment band, class lists, codes, last row / column
     } gb[2];                                // two sets: group g+1 is aligned while g is reduced
     int32_t band_mode = -1, band_margin_v = 0;   // nc_indel_sites_band: -1 = the environment's setting
     int64_t band_stats[6] = {0, 0, 0, 0, 0, 0};   // of the last run: alignments on 32 / 64 diagonals, on the full matrix by width, re-run after an edge touch
     DevBuf tw2, runs, rlen, alen, alt_pool, misc;
+    DevBuf ab_lo, ab_lists, ab_counts, ab_twb;             // banded allele alignments (stage_b2; one group at a time on stream B)
     hipStream_t sB = nullptr;                // second stream: traceback / tensors / alleles of group g beside the alignment fill of g + 1
     hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, ev_join = nullptr;
     int64_t alt_pool_cap = 0;
@@ -1750,9 +1843,9 @@ void nc_pipe_destroy(nc_ctx *ctx)
     if (!s) return;
     DevBuf *bufs[] = {&s->pc, &s->seg_pos, &s->seg_type, &s->cnt, &s->off, &s->anc_pos, &s->anc_type, &s->anc_chunk, &s->kept, &s->nuniq, &s->site_of,
                       &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
-                      &s->al_site, &s->al_member, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc,
+                      &s->al_site, &s->al_member, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc, &s->ab_lo, &s->ab_lists, &s->ab_counts, &s->ab_twb,
                       &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].endc, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
-                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[0].band_lo, &s->gb[0].lists, &s->gb[0].counts, &s->gb[0].twb, &s->gb[0].hrow, &s->gb[0].hcolb,
+                      &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[0].band_lo, &s->gb[0].lists, &s->gb[0].counts, &s->gb[0].twb, &s->gb[0].hrow, &s->gb[0].hcolb, &s->gb[0].cband, &s->gb[1].cband,
                       &s->gb[1].band_lo, &s->gb[1].lists, &s->gb[1].counts, &s->gb[1].twb, &s->gb[1].hrow, &s->gb[1].hcolb, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].endc, &s->gb[1].trace,
                       &s->gb[1].cns, &s->gb[1].ncns, &s->gb[1].arow, &s->gb[1].alt_off};
     for (DevBuf *b : bufs) {
@@ -2064,6 +2157,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, B.trace, Agz * EW * 4 + 64));
         NC_TRY(nc_ensure(ctx, B.cns, (size_t)ng * S * CNS_CAP));
         NC_TRY(nc_ensure(ctx, B.ncns, (size_t)ng * S * 4));
+        NC_TRY(nc_ensure(ctx, B.cband, (size_t)ng * S * 4));
         NC_TRY(nc_ensure(ctx, B.arow, ((size_t)ng * S + 1) * 8));
         NC_TRY(nc_ensure(ctx, B.alt_off, (size_t)ng * S * 8));
         const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && W <= 162 && N1 <= 160;          // the band's 41 blocks of 8 anti-diagonals cover n1 + n2 <= 328
@@ -2134,9 +2228,9 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
             BandArgs ba = ba_of[b];
             const int32_t *cnts = ba.count - 1;                         // (ba.count was left on the second class)
             ba.list = (const int32_t *)B.lists.p; ba.count = cnts;
-            hipLaunchKernelGGL(k_trace_band<1>, dim3((Ag + 63) / 64), dim3(64), 0, sB, ba, (uint32_t *)B.trace.p, EW);
-            ba.list = (const int32_t *)B.lists.p + std::max(Ag, 1); ba.count = cnts + 1;
-            hipLaunchKernelGGL(k_trace_band<2>, dim3((Ag + 63) / 64), dim3(64), 0, sB, ba, (uint32_t *)B.trace.p, EW);
+            BandArgs ba2 = ba;
+            ba2.list = (const int32_t *)B.lists.p + std::max(Ag, 1); ba2.count = cnts + 1;
+            hipLaunchKernelGGL(k_trace_band12, dim3((Ag + 63) / 64, 2), dim3(64), 0, sB, ba, ba2, (uint32_t *)B.trace.p, EW);
             // the rest on the full matrix: too wide for a band, or a path that touched the edge of its band
             FillArgs fl = fa;
             fl.list = ba.redo_list; fl.count = ba.redo_count;
@@ -2155,7 +2249,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         ta.site_al0 = (const int32_t *)s->site_al0.p; ta.site_nr = (const int32_t *)s->site_nr.p; ta.site_pos = (const int32_t *)s->site_pos.p;
         ta.site_n2 = (const int32_t *)s->site_n2.p; ta.al_member = (const uint8_t *)s->al_member.p; ta.win = (const uint8_t *)B.win.p;
         ta.ent = (const uint32_t *)B.trace.p; ta.EW = EW; ta.ref_code = s->ref_code; ta.ref_pos0 = s->ref_pos0; ta.x = x_dev;
-        ta.cns = (uint8_t *)B.cns.p; ta.ncns = (int32_t *)B.ncns.p; ta.err = err;
+        ta.cns = (uint8_t *)B.cns.p; ta.ncns = (int32_t *)B.ncns.p; ta.cband = (int16_t *)B.cband.p; ta.err = err;
         if (s->maxcov <= 255) hipLaunchKernelGGL(k_site_tensor<uint8_t>, dim3(ng), dim3(256), 0, sB, ta);
         else hipLaunchKernelGGL(k_site_tensor<uint16_t>, dim3(ng), dim3(256), 0, sB, ta);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], sB));
@@ -2179,9 +2273,36 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         fb.open = 9; fb.extend = 1; fb.match = 20; fb.mismatch = -10;
         fb.arow = (const int64_t *)B.arow.p; fb.N1 = 0;
         fb.Tw = (uint32_t *)s->tw2.p; fb.Hlast = nullptr; fb.hcol = nullptr; fb.endcell = nullptr;
-        launch_fill(ctx, sB, CPL, fb);
+        fb.list = nullptr; fb.count = nullptr;
         int32_t *rl = (int32_t *)s->rlen.p + (size_t)k0 * S, *al = (int32_t *)s->alen.p + (size_t)k0 * S;
-        hipLaunchKernelGGL(k_allele_trace16p, dim3((nset + 63) / 64), dim3(64), 0, sB, fb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p,
+        BandArgs bb;
+        memset(&bb, 0, sizeof bb);
+        bb.f = fb;
+        if (band_of[b]) {
+            // the consensus against its window on a band around the diagonals 0 .. n2 - n1; too long / too wide / edge-touching ones on the full matrix
+            const size_t nz = (size_t)std::max(nset, 1);
+            NC_TRY(nc_ensure(ctx, s->ab_lo, nz + 64));
+            NC_TRY(nc_ensure(ctx, s->ab_lists, nz * 3 * 4 + 64));
+            NC_TRY(nc_ensure(ctx, s->ab_counts, 64));
+            NC_TRY(nc_ensure(ctx, s->ab_twb, nz * (size_t)BAND_NBLK * 128 + 256));
+            NC_HIP(ctx, hipMemsetAsync(s->ab_counts.p, 0, 64, sB));
+            int32_t *l1 = (int32_t *)s->ab_lists.p, *l2 = l1 + nz, *lF = l2 + nz, *cn = (int32_t *)s->ab_counts.p;
+            hipLaunchKernelGGL(k_allele_classes, dim3((nset + 255) / 256), dim3(256), 0, sB, fb, (const int16_t *)B.cband.p, s->band_margin_v > 0 ? s->band_margin_v : band_margin(),
+                               8 * BAND_NBLK, (int8_t *)s->ab_lo.p, l1, l2, lF, cn);
+            bb.band_lo = (const int8_t *)s->ab_lo.p; bb.Twb = (uint32_t *)s->ab_twb.p; bb.hrow = nullptr; bb.hcolb = nullptr; bb.NBLK = BAND_NBLK;
+            bb.redo_list = lF; bb.redo_count = cn + 2; bb.edge = 0;
+            bb.list = l1; bb.count = cn;
+            BandArgs bb2 = bb;
+            bb2.list = l2; bb2.count = cn + 1;
+            hipLaunchKernelGGL(k_fill_band<1>, dim3((nset + 7) / 8), dim3(64), 0, sB, bb);
+            hipLaunchKernelGGL(k_fill_band<2>, dim3((nset + 7) / 8), dim3(64), 0, sB, bb2);
+            hipLaunchKernelGGL(k_allele_trace_b12, dim3((nset + 63) / 64, 2), dim3(64), 0, sB, bb, bb2, CPL, (const int32_t *)s->site_type.p, s->win_size,
+                               (int16_t *)s->runs.p, rl, al);
+            fb.list = lF; fb.count = cn + 2;
+            bb.f = fb;
+        }
+        launch_fill(ctx, sB, CPL, fb);
+        hipLaunchKernelGGL(k_allele_trace16p<0>, dim3((nset + 63) / 64), dim3(64), 0, sB, bb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p,
                            s->win_size, (int16_t *)s->runs.p, rl, al);
         hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(1024), 0, sB, (const int32_t *)al, nset, pool_base, (int64_t *)B.alt_off.p);
         hipLaunchKernelGGL(k_alt_copy, dim3((nset + 3) / 4), dim3(256), 0, sB, (const uint8_t *)B.cns.p, (const int32_t *)al,
@@ -2200,6 +2321,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         }
         return NC_OK;
     };
+    int dump_g = -1;
     NC_TRY(stage_a(0));
     for (int g = 0; g < G; g++) {
         if (!timing && g + 1 < G) NC_TRY(stage_a(g + 1));            // the next group's alignments are enqueued before the host waits for this one's row count
@@ -2225,9 +2347,29 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
             wr("site_pos", s->site_pos.p, (size_t)ns * 4);
             wr("site_n2", s->site_n2.p, (size_t)ns * 4);
             if (B.band_lo.p) wr("band_lo", B.band_lo.p, (size_t)Ag);
+            dump_g = g;
         }
         const int64_t rows = ((int64_t)mb[1] << 31) | (int64_t)(mb[0] & 0x7fffffff);
         NC_TRY(stage_b2(g, rows));
+        if (dump_g == g) {                                           // (debugging aid, continued: the allele stage's arrays of the group)
+            const char *dump = getenv("NC_PIPE_DUMP");
+            NC_HIP(ctx, hipStreamSynchronize(sB));
+            const int k0 = groups[(size_t)g].first, nset = (groups[(size_t)g].second - k0) * S;
+            nc_pipe_state::GroupBufs &B = s->gb[g & 1];
+            auto wr = [&](const char *name, const void *dev, size_t bytes) {
+                std::vector<char> h(bytes);
+                if (!dev || hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+                char path[512];
+                snprintf(path, sizeof path, "%s.%s", dump, name);
+                if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), 1, bytes, fp); fclose(fp); }
+            };
+            wr("cns", B.cns.p, (size_t)nset * CNS_CAP);
+            wr("ncns", B.ncns.p, (size_t)nset * 4);
+            wr("rlen", (const int32_t *)s->rlen.p + (size_t)k0 * S, (size_t)nset * 4);
+            wr("alen", (const int32_t *)s->alen.p + (size_t)k0 * S, (size_t)nset * 4);
+            wr("ab_lo", s->ab_lo.p, (size_t)nset);
+            wr("ab_counts", s->ab_counts.p, 16);
+        }
         if (timing && g + 1 < G) NC_TRY(stage_a(g + 1));
     }
     if (two) {                                                         // the caller's stream continues behind stream B

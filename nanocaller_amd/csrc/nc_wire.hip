@@ -375,3 +375,113 @@ extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------- indel events, transfer form
+// The indel path's per-read events ('+n' / '-n' of the pileup: column, signed length, offset of the inserted bases) are 12 bytes each as the
+// kernels read them -- 830 MB of a chr20-sized ONT contig's 1.2 GB transfer, more than its 21 ms pass can hide.  They cross PCIe as 3 bytes:
+//     d16  uint16  column - column of the read's previous event (the first one: - the read's start); 0xFFFF = see the side table
+//     l8   int8    signed length; the side table's entry when d16 is 0xFFFF
+//     side table (big_idx ascending, big_pos, big_len): events with a distance >= 0xFFFF or |length| >= 128
+//     read_ins_off [n_reads + 1]: offset of the read's first inserted base (the per-event offsets are its running sum of the positive lengths)
+// nc_indel_events_pack makes them on the host; nc_indel_events_expand rebuilds ev_pos / ev_len / ins_off in HBM, one wave per read.
+extern "C" int nc_indel_events_pack(int32_t n_reads, const int32_t *rd_start, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len,
+                                    uint16_t *d16, int8_t *l8, int32_t *read_ins_off, int64_t big_cap, int32_t *big_idx, int32_t *big_pos,
+                                    int32_t *big_len, int64_t *n_big)
+{
+    if (n_reads < 0 || (n_reads && (!rd_start || !ev_off)) || !n_big) return NC_ERR_ARG;
+    int64_t nb = 0, ins = 0;
+    for (int32_t r = 0; r < n_reads; r++) {
+        int32_t prev = rd_start[r];
+        if (read_ins_off) read_ins_off[r] = (int32_t)ins;
+        for (int32_t e = ev_off[r]; e < ev_off[r + 1]; e++) {
+            const int32_t d = ev_pos[e] - prev, l = ev_len[e];
+            if (d < 0) return NC_ERR_ARG;                            // events of a read ascend
+            if (d >= 0xFFFF || l >= 128 || l <= -128) {
+                if (nb < big_cap) { big_idx[nb] = e; big_pos[nb] = ev_pos[e]; big_len[nb] = l; }
+                nb++;
+                d16[e] = 0xFFFF;
+                l8[e] = 0;
+            } else {
+                d16[e] = (uint16_t)d;
+                l8[e] = (int8_t)l;
+            }
+            prev = ev_pos[e];
+            if (l > 0) ins += l;
+        }
+    }
+    if (read_ins_off) read_ins_off[n_reads] = (int32_t)ins;
+    *n_big = nb;
+    return nb > big_cap ? NC_ERR_CAPACITY : NC_OK;
+}
+
+namespace {
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_events_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ ev_off,
+                                                       const uint16_t *__restrict__ d16, const int8_t *__restrict__ l8, int32_t n_big,
+                                                       const int32_t *__restrict__ big_idx, const int32_t *__restrict__ big_pos,
+                                                       const int32_t *__restrict__ big_len, const int32_t *__restrict__ read_ins_off,
+                                                       int32_t *__restrict__ ev_pos, int32_t *__restrict__ ev_len, int32_t *__restrict__ ins_off)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const int e0 = ev_off[r], e1 = ev_off[r + 1];
+    int32_t run_pos = rd_start[r], run_ins = read_ins_off ? read_ins_off[r] : 0;
+    for (int c = e0; c < e1; c += 64) {
+        const int e = c + lane;
+        const bool valid = e < e1;
+        int32_t d = valid ? (int32_t)d16[e] : 0, l = valid ? (int32_t)l8[e] : 0, ab = 0;
+        const bool big = valid && d == 0xFFFF;
+        if (big) {
+            int lo = 0, hi = n_big;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (big_idx[mid] < e) lo = mid + 1; else hi = mid;
+            }
+            ab = big_pos[lo];
+            l = big_len[lo];
+            d = 0;
+        }
+        const int32_t ip = l > 0 ? l : 0;
+        const int32_t P = wave_incl_scan(d, lane), Q = wave_incl_scan(ip, lane);
+        const unsigned long long bm = __ballot(big), mine = bm & ((lane == 63 ? 0ull : (1ull << (lane + 1))) - 1ull);
+        int32_t pos = run_pos + P;
+        const int lb = mine ? 63 - __builtin_clzll(mine) : 0;          // the last side-table event at or before this lane restarts the sum
+        const int32_t ab_l = __shfl(ab, lb), P_l = __shfl(P, lb);
+        if (mine) pos = ab_l + (P - P_l);
+        if (valid) {
+            ev_pos[e] = pos;
+            ev_len[e] = l;
+            if (ins_off) ins_off[e] = run_ins + Q - ip;
+        }
+        run_pos = __shfl(pos, 63);
+        run_ins += __shfl(Q, 63);
+    }
+    if (ins_off && r == n_reads - 1 && lane == 0) ins_off[e1] = run_ins;
+}
+}   // namespace
+
+extern "C" int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint16_t *d_d16,
+                                      const int8_t *d_l8, int32_t n_big, const int32_t *d_big_idx, const int32_t *d_big_pos,
+                                      const int32_t *d_big_len, const int32_t *d_read_ins_off, int32_t *d_ev_pos, int32_t *d_ev_len,
+                                      int32_t *d_ins_off)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_reads < 0 || n_big < 0 || (n_reads && (!d_rd_start || !d_ev_off || !d_d16 || !d_l8 || !d_ev_pos || !d_ev_len)) ||
+        (n_big && (!d_big_idx || !d_big_pos || !d_big_len)) || (d_ins_off && !d_read_ins_off))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_indel_events_expand: bad argument");
+    if (n_reads == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_events_expand, dim3((n_reads + 3) / 4), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_ev_off, d_d16, d_l8, n_big, d_big_idx,
+                       d_big_pos, d_big_len, d_read_ins_off, d_ev_pos, d_ev_len, d_ins_off);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}

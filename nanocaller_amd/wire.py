@@ -130,6 +130,7 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
             if not cnt:
                 return np.zeros(0, dt)
             return np.frombuffer((C.c_char * (int(cnt) * np.dtype(dt).itemsize)).from_address(ptr), dt)
+        meta_ev = None
         parts = [("rd_start", arr(v.rd_start, v.n_reads, np.int32)), ("rd_end", arr(v.rd_end, v.n_reads, np.int32)),
                  ("slot_off", arr(v.slot_off, v.n_reads + 1, np.int64)), ("blk_off", arr(v.blk_off, v.n_blocks + 1, np.uint32)),
                  ("blk_read", arr(v.blk_read, v.n_blocks, np.int32)),
@@ -148,13 +149,36 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
                 idx = np.concatenate([np.arange(ev_off[r], ev_off[r + 1]) for r in kept]) if kept.size else np.zeros(0, np.int64)
             hp = (np.asarray(hap, np.uint8) if hap is not None else np.zeros(n, np.uint8))[kept]
             z = lambda x, dt: np.ascontiguousarray(x, dt) if len(x) else np.zeros(1, dt)      # noqa: E731
-            parts += [("ev_off", z(off, np.int32)), ("ev_pos", z(ev_pos[idx], np.int32)), ("ev_len", z(ev_len[idx], np.int32)),
-                      ("read_hap", z(hp, np.uint8))]
+            # the events cross PCIe as 3 bytes each (distance to the read's previous event, signed length; a side table for the few that do
+            # not fit) + one inserted-base offset per READ: nc_indel_events_expand rebuilds ev_pos / ev_len / ins_off in HBM
+            evp, evl = np.ascontiguousarray(ev_pos[idx], np.int32), np.ascontiguousarray(ev_len[idx], np.int32)
+            n_ev = int(evp.size)
+            kept_start = np.ascontiguousarray(rs[kept], np.int32)
+            d16, l8 = np.empty(max(n_ev, 1), np.uint16), np.empty(max(n_ev, 1), np.int8)
+            rio = np.zeros(kept.size + 1, np.int32)
+            cap = max(1024, n_ev // 64)
+            while True:
+                bi, bp, bl = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int32)
+                nbig = C.c_int64()
+                rc = L.nc_indel_events_pack(int(kept.size), _lib.npp(kept_start), _lib.npp(off), _lib.npp(evp), _lib.npp(evl), _lib.npp(d16), _lib.npp(l8),
+                                            _lib.npp(rio), cap, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nbig))
+                if rc == _lib.NC_ERR_CAPACITY:
+                    cap = int(nbig.value)
+                    continue
+                if rc != _lib.NC_OK:
+                    raise _lib.NanoCallerHipError("nc_indel_events_pack failed (%d)" % rc)
+                break
+            nb_ = int(nbig.value)
+            parts += [("ev_off", z(off, np.int32)), ("ev_d16", d16), ("ev_l8", l8), ("ev_big_idx", z(bi[:nb_], np.int32)),
+                      ("ev_big_pos", z(bp[:nb_], np.int32)), ("ev_big_len", z(bl[:nb_], np.int32)), ("read_ins_off", rio), ("read_hap", z(hp, np.uint8))]
+            meta_ev = dict(n_ev=n_ev, n_big=nb_)
             n_indel = int(kept.size)
             if indel_extra is not None:
-                for name, dt in (("ins_off", np.int32), ("ins_bases", np.uint8), ("tail_off", np.int32), ("tail_bases", np.uint8),
-                                 ("read_ps", np.int32), ("read_flag", np.uint8)):
+                if n_ev and int(np.asarray(indel_extra["ins_off"])[n_ev]) != int(rio[-1]):
+                    raise _lib.NanoCallerHipError("indel_extra['ins_off'] is not the running sum of the insertion lengths")
+                for name, dt in (("ins_bases", np.uint8), ("tail_off", np.int32), ("tail_bases", np.uint8), ("read_ps", np.int32), ("read_flag", np.uint8)):
                     parts.append((name, z(indel_extra[name], dt)))
+                meta_ev["extra"] = True
         sections, total = {}, 0
         for name, a_ in parts:
             sections[name] = (total, a_.dtype, int(a_.size))
@@ -166,7 +190,8 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
             hb[o:o + a_.nbytes] = a_.view(np.uint8).reshape(-1)
         return WirePack(buf=buf, sections=sections, tile_size=tile_size, tile_pos0=tile_pos0.value, n_tiles=n_tiles.value,
                         n_entries=int(n_ent.value), codes_len=int(codes_len.value), n_reads=int(v.n_reads), n_blocks=int(v.n_blocks),
-                        n_events=int(v.n_events), ref_len=ref_len, pos_lo=pos_lo, pos_hi=pos_hi, n_indel_reads=n_indel)
+                        n_events=int(v.n_events), ref_len=ref_len, pos_lo=pos_lo, pos_hi=pos_hi, n_indel_reads=n_indel,
+                        meta=dict(indel_events=meta_ev) if n_indel >= 0 else {})
     finally:
         L.nc_wire_free(h)
 
@@ -185,7 +210,7 @@ def _views(dev_buf, wp: WirePack):
         nb = cnt * np.dtype(dt).itemsize
         t = dev_buf[off:off + nb]
         out[name] = t if np.dtype(dt) == np.uint8 else t.view({np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.uint32): torch.int32,
-                                                                np.dtype(np.uint16): torch.int16}[np.dtype(dt)])
+                                                                np.dtype(np.uint16): torch.int16, np.dtype(np.int8): torch.int8}[np.dtype(dt)])
     return out
 
 
@@ -196,6 +221,28 @@ def _expand(eng, wp: WirePack, v, codes, ref_code):
                               C.c_void_p(v["events"].data_ptr() if wp.n_events else v["blk_off"].data_ptr()),
                               wp.n_blocks, C.c_void_p(codes.data_ptr()), wp.codes_len, C.c_void_p(ref_code.data_ptr()))
     eng._check(rc, "nc_wire_expand")
+
+
+def _expand_events(eng, wp: WirePack, v, out):
+    """the 3-byte transfer form of the indel events -> ev_pos / ev_len / ins_off int32 in `out` (dict of device tensors, grown on demand),
+    put into the views dict `v` under the names the kernels' structs take"""
+    me = wp.meta.get("indel_events") if wp.meta else None
+    if not me:
+        return
+    n_ev, dev = me["n_ev"], eng.device
+    for name, n in (("ev_pos", n_ev), ("ev_len", n_ev), ("ins_off", n_ev + 1)):
+        if out.get(name) is None or out[name].numel() < max(n, 4):
+            out[name] = torch.zeros(max(n, 4) + max(n, 4) // 16, dtype=torch.int32, device=dev)
+    if n_ev:
+        rc = eng.L.nc_indel_events_expand(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
+                                          C.c_void_p(v["ev_d16"].data_ptr()), C.c_void_p(v["ev_l8"].data_ptr()), me["n_big"],
+                                          C.c_void_p(v["ev_big_idx"].data_ptr()), C.c_void_p(v["ev_big_pos"].data_ptr()), C.c_void_p(v["ev_big_len"].data_ptr()),
+                                          C.c_void_p(v["read_ins_off"].data_ptr()), C.c_void_p(out["ev_pos"].data_ptr()), C.c_void_p(out["ev_len"].data_ptr()),
+                                          C.c_void_p(out["ins_off"].data_ptr()))
+        eng._check(rc, "nc_indel_events_expand")
+    v["ev_pos"], v["ev_len"] = out["ev_pos"][:max(n_ev, 1)], out["ev_len"][:max(n_ev, 1)]
+    if me.get("extra"):
+        v["ins_off"] = out["ins_off"][:n_ev + 1]
 
 
 def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
@@ -230,6 +277,7 @@ def upload_wire(eng, wp: WirePack) -> DevicePack:
     codes = torch.empty(wp.codes_len, dtype=torch.uint8, device=dev)
     ref_code = torch.empty(wp.ref_len, dtype=torch.uint8, device=dev)
     _expand(eng, wp, v, codes, ref_code)
+    _expand_events(eng, wp, v, {})
     return _device_pack(wp, v, codes, ref_code, own_index=True)
 
 
@@ -248,6 +296,7 @@ class WireUploader:
         self.turn = 0
         self.codes = None
         self.ref_code = None
+        self.ev = {}                               # expanded indel events (ev_pos / ev_len / ins_off), like codes: one set, reused by every step
         self.h2d_events = []                       # (start, stop) event pairs of the copies, for the achieved PCIe rate
         self.timing = False
 
@@ -283,6 +332,7 @@ class WireUploader:
         v = _views(ticket["slot"]["buf"], wp)
         codes, ref_code = self.codes[:wp.codes_len], self.ref_code[:wp.ref_len]
         _expand(eng, wp, v, codes, ref_code)
+        _expand_events(eng, wp, v, self.ev)
         return _device_pack(wp, v, codes, ref_code, own_index=False)
 
     def release(self, ticket):

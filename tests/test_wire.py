@@ -25,6 +25,53 @@ def _expand_numpy(wp):
     return codes, ref_code
 
 
+def _expand_events_numpy(wp):
+    """the 3-byte transfer form of the indel events (nc_indel_events_pack) restated: ev_pos / ev_len / ins_off as nc_indel_events_expand writes them"""
+    me = wp.meta["indel_events"]
+    n_ev, off, start = me["n_ev"], wp.host("ev_off"), wp.host("rd_start")
+    d16, l8 = wp.host("ev_d16")[:n_ev].astype(np.int64), wp.host("ev_l8")[:n_ev].astype(np.int64)
+    big = {int(i): (int(p), int(ln)) for i, p, ln in zip(wp.host("ev_big_idx")[:me["n_big"]], wp.host("ev_big_pos")[:me["n_big"]], wp.host("ev_big_len")[:me["n_big"]])}
+    pos, ln = np.zeros(n_ev, np.int32), np.zeros(n_ev, np.int32)
+    for r in range(wp.n_indel_reads):
+        prev = int(start[r])
+        for e in range(int(off[r]), int(off[r + 1])):
+            if d16[e] == 0xFFFF:
+                prev, ln[e] = big[e]
+            else:
+                prev, ln[e] = prev + int(d16[e]), l8[e]
+            pos[e] = prev
+    ins = np.zeros(n_ev + 1, np.int64)
+    np.cumsum(np.maximum(ln, 0), out=ins[1:])
+    assert np.array_equal(wp.host("read_ins_off"), ins[off[:wp.n_indel_reads + 1]])
+    return pos, ln, ins
+
+
+def test_indel_events_side_table():
+    """distances >= 0xFFFF and lengths beyond a signed byte go through the side table; a too small table is reported with the size it needs"""
+    import ctypes as C
+
+    from nanocaller_amd import _lib
+    L = _lib.lib()
+    start = np.array([100, 500_000], np.int32)
+    off = np.array([0, 4, 7], np.int32)
+    pos = np.array([100, 70_000, 70_001, 200_000, 500_010, 500_020, 565_555], np.int32)
+    ln = np.array([1, -127, 128, -3, -200, 127, 5], np.int32)
+    d16, l8, rio = np.zeros(7, np.uint16), np.zeros(7, np.int8), np.zeros(3, np.int32)
+    bi, bp, bl = (np.zeros(8, np.int32) for _ in range(3))
+    nb = C.c_int64()
+    assert L.nc_indel_events_pack(2, _lib.npp(start), _lib.npp(off), _lib.npp(pos), _lib.npp(ln), _lib.npp(d16), _lib.npp(l8), _lib.npp(rio), 2,
+                                  _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nb)) == _lib.NC_ERR_CAPACITY and nb.value == 5
+    assert L.nc_indel_events_pack(2, _lib.npp(start), _lib.npp(off), _lib.npp(pos), _lib.npp(ln), _lib.npp(d16), _lib.npp(l8), _lib.npp(rio), 8,
+                                  _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nb)) == _lib.NC_OK
+    assert bi[:5].tolist() == [1, 2, 3, 4, 6] and bp[:5].tolist() == [70_000, 70_001, 200_000, 500_010, 565_555] and bl[:5].tolist() == [-127, 128, -3, -200, 5]
+    assert d16.tolist() == [0, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 10, 0xFFFF] and l8[[0, 5]].tolist() == [1, 127]
+    assert rio.tolist() == [0, 129, 261]
+    bad = pos.copy()
+    bad[2] = 60_000
+    assert L.nc_indel_events_pack(2, _lib.npp(start), _lib.npp(off), _lib.npp(bad), _lib.npp(ln), _lib.npp(d16), _lib.npp(l8), _lib.npp(rio), 8,
+                                  _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nb)) == -1                    # NC_ERR_ARG: the events of a read ascend
+
+
 CASES = [("ont", False, None, 2048), ("ont", True, [(55_000, 58_000), (30_000, 41_000)], 1024), ("hifi", False, None, 4096),
          ("deep", False, None, 2048), ("indel", False, None, 2048)]
 
@@ -41,8 +88,12 @@ def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
     assert wp.host("tile_ent").tobytes() == hp.tile_ent.tobytes()
     assert (wp.tile_size, wp.tile_pos0, wp.n_tiles, wp.n_entries) == (hp.tile_size, hp.tile_pos0, hp.n_tiles, hp.tile_ent.shape[0])
     if hp.ev_off is not None:
-        for k, a in (("ev_off", hp.ev_off), ("ev_pos", hp.ev_pos), ("ev_len", hp.ev_len), ("read_hap", hp.read_hap)):
+        for k, a in (("ev_off", hp.ev_off), ("read_hap", hp.read_hap)):
             assert np.array_equal(wp.host(k)[:a.size], a)
+        ev_pos, ev_len, ins_off = _expand_events_numpy(wp)
+        assert np.array_equal(ev_pos, hp.ev_pos) and np.array_equal(ev_len, hp.ev_len)
+        assert np.array_equal(ins_off[1:], np.cumsum(np.maximum(hp.ev_len, 0)))
+        assert 3 * ev_pos.size + 12 * wp.meta["indel_events"]["n_big"] < 0.3 * 12 * max(ev_pos.size, 1) or ev_pos.size < 100
     # the point of it: far fewer bytes than 1 B per pileup entry (ONT worlds: 4 % substitutions + 4 % deletions)
     entries = int((w.read_end - w.read_start).sum())
     assert 2 * wp.n_events < 0.25 * entries
