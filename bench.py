@@ -646,7 +646,11 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
             pend = prev = None
             tk_s = uploader.submit(snp.wire) if snp_half else None
             tk_i = uploader.submit(job.wire) if indel_half else None
+            dbg = os.environ.get("NC_BENCH_DEBUG") == "1"
+            tdbg = time.perf_counter()
             for i in range(n_steps):
+                if dbg:
+                    print("configs2 step %d (snp %s indel %s): +%.1f ms" % (i, snp_half, indel_half, (time.perf_counter() - tdbg) * 1e3), file=sys.stderr, flush=True)
                 more = i + 1 < n_steps
                 cur = ri = rs = None
                 nxt_s = nxt_i = None
@@ -682,11 +686,17 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
         return ns, ni, nrec
 
     def timed(n_steps, **kw):
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        r = run(n_steps, **kw)
-        torch.cuda.synchronize()
-        return r, time.perf_counter() - t
+        import gc
+        gc.collect()
+        gc.disable()                                                    # (a collector pause is tens of ms)
+        try:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = run(n_steps, **kw)
+            torch.cuda.synchronize()
+            return r, time.perf_counter() - t
+        finally:
+            gc.enable()
     run(len(uploader.slots))                                            # sizes every upload slot, every workspace and the result pools
     uploader.h2d_events.clear()
     eng.enable_timing(True, trunk_only=True)
