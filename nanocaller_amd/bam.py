@@ -309,14 +309,36 @@ def read_bam(bam_path, fasta_path, chrom, start=1, end=None, keep_seq=False, thr
     if keep_seq:
         w.meta.update(seq_off=d["seq_off"], seq=d["seq"])
     # inputs the library does not reproduce (nc_decoded_check): counted here, under either flag filter; the pack builders refuse them
-    owner = d.get("_owner")
-    if owner is not None:
-        L = _lib.lib()
-        counts = {}
-        for supp in (False, True):
-            keep = np.ascontiguousarray(((d["read_flag"] & (0x704 if supp else 0xF04)) == 0).astype(np.uint8))
-            a, b = C.c_int64(), C.c_int64()
-            L.nc_decoded_check(owner.handle, _lib.npp(keep), C.byref(a), C.byref(b))
-            counts[supp] = (int(a.value), int(b.value))
-        w.meta["unsupported"] = counts
+    w.meta["unsupported"] = unsupported_counts(d)
     return w
+
+
+def unsupported_counts(d):
+    """{supplementary flag: (kept alignments with a reference skip, pairs of kept alignments with one read name that overlap on the reference)}
+    of a decode, under either flag filter: nc_decoded_check on the decode's native handle, or -- a decode assembled from several regions has
+    none -- the same two counts from the arrays"""
+    counts = {}
+    owner = d.get("_owner")
+    for supp in (False, True):
+        keep = np.ascontiguousarray(((d["read_flag"] & (0x704 if supp else 0xF04)) == 0).astype(np.uint8))
+        if owner is not None:
+            a, b = C.c_int64(), C.c_int64()
+            _lib.lib().nc_decoded_check(owner.handle, _lib.npp(keep), C.byref(a), C.byref(b))
+            counts[supp] = (int(a.value), int(b.value))
+        else:
+            n_skip = int(np.count_nonzero(keep.astype(bool) & ((d["read_flag"] & _lib.FLAG_REFSKIP) != 0)))
+            counts[supp] = (n_skip, same_name_overlaps(d["names"], d["read_start"], d["read_end"], keep))
+    return counts
+
+
+def same_name_overlaps(names, start, end, keep):
+    """pairs of kept alignments that carry one read name and overlap on the reference (the reference's per-column dicts are keyed by name and
+    hold one of them, generate_SNP_pileups.py:175,185,208): only supplementary alignments kept by --supplementary can produce them"""
+    last, n = {}, 0
+    for r in np.nonzero(np.asarray(keep))[0].tolist():             # coordinate order: starts ascend
+        nm = names[r]
+        e = last.get(nm)
+        if e is not None and int(start[r]) < e:
+            n += 1
+        last[nm] = max(int(end[r]), e or 0)
+    return n

@@ -43,13 +43,25 @@ inline char *put_int(char *o, int64_t v)
     if (v < 0) { *o++ = '-'; return put_uint(o, (uint64_t)(-(v + 1)) + 1); }
     return put_uint(o, (uint64_t)v);
 }
-inline char *put_fixed(char *o, double x, int prec)                        // prec in 1..4, |x| < 2^40, finite
+inline char *put_fixed(char *o, double x, int prec)                        // prec in 1..4; exact for |x| < 2^40
 {
     static const uint32_t P10[5] = {1, 10, 100, 1000, 10000};
     uint64_t bits;
     memcpy(&bits, &x, 8);
-    if (bits >> 63) *o++ = '-';                                            // also "-0.000" for a negative zero / tiny negative
     const int be = (int)((bits >> 52) & 0x7ff);
+    // what Python's format() prints for values outside the exact range: a non-finite probability (a model that overflowed) gives 'nan' /
+    // 'inf' in the reference's VCF too; the shifts below are defined for finite |x| < 2^40 only
+    if (be == 0x7ff) {
+        const bool nan = (bits & ((1ull << 52) - 1)) != 0;
+        if (!nan && (bits >> 63)) *o++ = '-';
+        memcpy(o, nan ? "nan" : "inf", 3);
+        return o + 3;
+    }
+    if (be >= 1023 + 40) {                                                 // huge but finite: digits by the C library (never on a quality value)
+        const int w = snprintf(o, 48, "%.*e", prec, x);                     // (bounded: a record keeps 64 spare bytes)
+        return o + (w < 47 ? w : 47);
+    }
+    if (bits >> 63) *o++ = '-';                                            // also "-0.000" for a negative zero / tiny negative
     uint64_t m = bits & ((1ull << 52) - 1);
     int e;
     if (be == 0) e = -1074;                                                // subnormal
@@ -413,7 +425,8 @@ extern "C" int nc_indel_vcf_format(const char *chrom, int64_t n, const int32_t *
         const float *pr = probs + j * 4;
         if (!(pr[0] <= 0.95f)) continue;                                            // :95
         int pred = 0;
-        for (int k = 1; k < 4; k++) if (pr[k] > pr[pred]) pred = k;                 // np.argmax: first maximum
+        for (int k = 1; k < 4; k++) if (pr[k] > pr[pred]) pred = k;                 // np.argmax: first maximum ...
+        for (int k = 3; k >= 0; k--) if (pr[k] != pr[k]) pred = k;                  // ... and a NaN is its maximum (the first one)
         const float q = q10(1e-6f + pr[0]);                                         // :97
         const float one = (float)(1 + 1e-6);
         const Al &a0 = a[0], &a1 = a[1], &at = a[2];

@@ -134,7 +134,13 @@ def _check_supported(world, sam_path, chrom, supplementary=False):
     mask = 0x704 if supplementary else 0xF04                      # unmapped / secondary / qcfail / duplicate (/ supplementary) are never kept
     keep = (world.read_flag & mask) == 0
     n_skip = int(np.count_nonzero(keep & ((world.read_flag & _lib.FLAG_REFSKIP) != 0)))
-    n_dup = world.meta.get("unsupported", {}).get(bool(supplementary), (0, 0))[1]
+    if "unsupported" in world.meta:
+        n_dup = world.meta["unsupported"].get(bool(supplementary), (0, 0))[1]
+    elif getattr(world, "names", None) is not None and len(world.names) == len(world.read_start):
+        from .bam import same_name_overlaps                       # a World nobody counted for: count now rather than assume none
+        n_dup = same_name_overlaps(world.names, world.read_start, world.read_end, keep)
+    else:
+        n_dup = 0
     if n_skip or n_dup:
         what = []
         if n_skip:

@@ -414,7 +414,7 @@ def decoded_contig(sam_path, chrom, fasta_path):
     contig, + the contig's reference bases.  One contig at a time stays cached."""
     key = (sam_path, chrom, fasta_path)
     if key not in _CONTIGS:
-        from .bam import decode_parallel, read_fasta
+        from .bam import decode_parallel, read_fasta, unsupported_counts
         _CONTIGS.clear()
         dec = decode_parallel(sam_path, chrom, keep_seq=True)
         fasta = read_fasta(fasta_path, chrom)
@@ -427,6 +427,7 @@ def decoded_contig(sam_path, chrom, fasta_path):
             w = World(chrom=chrom, ref=fasta, read_start=dec["read_start"], read_end=dec["read_end"], read_flag=dec["read_flag"],
                       read_off=dec["read_off"], codes=dec["codes"], names=dec["names"])
             w.meta.update(events=(dec["ev_off"], dec["ev_pos"], dec["ev_len"]), hap=dec["hap"], ps=dec["ps"], seq_off=dec["seq_off"], seq=dec["seq"])
+            w.meta["unsupported"] = unsupported_counts(dec)          # (bam.read_bam's check: this World serves the SNP path and pass 1 too)
             return w
         gsp._BAM_WORLDS.get((sam_path, fasta_path, chrom), as_world)
     return _CONTIGS[key]
@@ -506,7 +507,7 @@ def _pass2_native(dct, variants, extra_variants, anchors, ctg, lo, hi, window_af
     return (pos, xh[:, 0], xh[:, 1], xh[:, 2], alleles, phase) + tail
 
 
-def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False, device_x=False):
+def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False, device_x=False, device_route=True):
     """get_indel_testing_candidates[_haploid] for ALL chunks of one contig and BAM in one go -> list of the per-chunk tuples
     (each exactly what the per-chunk call returns): pass 1 of every chunk in the same launches (nc_indel_scan_batch), the
     anchors of all chunks through ONE native pass-2 call, ONE device star alignment and ONE allele batch.  What
@@ -521,17 +522,18 @@ def get_indel_testing_candidates_batch(dct, chunks, device=0, haploid=False, dev
     if len(chunks) > MAX_BATCH_CHUNKS:
         out = []
         for i in range(0, len(chunks), MAX_BATCH_CHUNKS):
-            out += get_indel_testing_candidates_batch(dct, chunks[i:i + MAX_BATCH_CHUNKS], device=device, haploid=haploid, device_x=device_x)
+            out += get_indel_testing_candidates_batch(dct, chunks[i:i + MAX_BATCH_CHUNKS], device=device, haploid=haploid, device_x=device_x,
+                                                      device_route=device_route)
         return out
     try:
         with _gc_paused():
-            return _indel_batch(dct, chunks, device, haploid, device_x)
+            return _indel_batch(dct, chunks, device, haploid, device_x, device_route)
     except _lib.NanoCallerHipError as e:
         if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY or len(chunks) == 1:
             raise
     h = len(chunks) // 2
-    return (get_indel_testing_candidates_batch(dct, chunks[:h], device=device, haploid=haploid, device_x=device_x) +
-            get_indel_testing_candidates_batch(dct, chunks[h:], device=device, haploid=haploid, device_x=device_x))
+    return (get_indel_testing_candidates_batch(dct, chunks[:h], device=device, haploid=haploid, device_x=device_x, device_route=device_route) +
+            get_indel_testing_candidates_batch(dct, chunks[h:], device=device, haploid=haploid, device_x=device_x, device_route=device_route))
 
 
 @contextlib.contextmanager
@@ -561,6 +563,8 @@ def device_indel_reads(ctg, flag, dp, device):
     """The per-read inputs of the device pass 2 beyond the read pack: inserted bases of every insertion event, the bases that
     follow the last aligned one, PS tags (nc_indel_pack_build), uploaded once per (contig, flag filter).  -> (IndelReadsC, tensors)"""
     key = ("dev_reads", flag, device)
+    if key in ctg and ctg[key][2] is not dp:                         # the pack was rebuilt (LRU eviction, release_contig): these pointers belong to the old one
+        del ctg[key]
     if key not in ctg:
         L = _lib.lib()
         keep = ctg["keep"][flag]
@@ -572,7 +576,9 @@ def device_indel_reads(ctg, flag, dp, device):
             v = _lib.IndelPackArraysC()
             L.nc_indel_pack_view(h, C.byref(v))
             if dp.events is None or dp.reads is None or v.n_reads != dp.events["n_reads"] or v.n_reads != dp.reads["n_reads"]:
-                raise _lib.NanoCallerHipError("the contig's read pack carries no indel events / read table for %d kept reads" % v.n_reads)
+                err = _lib.NanoCallerHipError("the contig's read pack carries no indel events / read table for %d kept reads" % v.n_reads)
+                err.status = _lib.NC_ERR_CAPACITY                   # the callers fall back to the host-assembled route
+                raise err
             dev = get_engine(device).device
 
             def up(ptr, cnt, dt):
@@ -686,9 +692,14 @@ def _indel_batch_device(dct, chunks, device, haploid, device_x):
 
 
 def device_route_ok(dct, chunks, haploid):
-    """the device pipeline covers BAM inputs without impute_indel_phase (whose read grouping needs the pileup strings)"""
-    return (isinstance(chunks[0]["sam_path"], str) and not (dct.get("impute_indel_phase") and not haploid)
-            and not os.environ.get("NC_INDEL_HOST_PASS2"))
+    """the device pipeline covers BAM inputs without impute_indel_phase (whose read grouping needs the pileup strings); its plan takes chunks
+    whose starts AND ends ascend (nc_indel_sites_plan): nested or overlapping chunk lists, which sorting by (start, end) does not make
+    monotone, go through the host-assembled route instead of failing the worker"""
+    if not (isinstance(chunks[0]["sam_path"], str) and not (dct.get("impute_indel_phase") and not haploid)
+            and not os.environ.get("NC_INDEL_HOST_PASS2")):
+        return False
+    ends = [c["end"] for c in sorted(chunks, key=lambda c: (c["start"], c["end"]))]
+    return all(b >= a for a, b in zip(ends, ends[1:]))
 
 
 def indel_chunks_vcf_text(dct, chunks, device, haploid, model_kind):
@@ -758,9 +769,11 @@ def sites_to_tuples(r, n_chunks, fasta, haploid, device_x):
             out.append((pos[a:b], x[a:b, 0:5], x[a:b, 5:10], x[a:b, 10:15], alleles[a:b], phase[a:b]))
     return out
 
-def _indel_batch(dct, chunks, device, haploid, device_x):
+def _indel_batch(dct, chunks, device, haploid, device_x, device_route=True):
+    """device_route=False: the caller has already met a capacity limit of the device pipeline for these chunks (indelCaller.indel_run): straight to
+    the host-assembled route instead of computing the expensive groups on the device a second time"""
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
-    if device_route_ok(dct, chunks, haploid):
+    if device_route and device_route_ok(dct, chunks, haploid):
         # everything between the column decisions and the CNN input on the device (nc_pipe.hip); a capacity limit of that route
         # (sets of > 1024 alignment columns, chunks of > 130 kb) sends the group through the host-assembled route below
         try:

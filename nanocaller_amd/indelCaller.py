@@ -224,12 +224,14 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
                 group = [jobs[k][1] for k in ks]
                 hap = ploidy == 'haploid'
                 texts = None
+                device_failed = False
                 if device_route_ok(params, group, hap) and not _os.environ.get("NC_INDEL_PY_RULES"):
                     try:
                         texts = indel_chunks_vcf_text(params, group, device, hap, _lib.MODEL_INDEL_HAP if hap else _lib.MODEL_INDEL)
                     except _lib.NanoCallerHipError as e:
                         if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY:
                             raise
+                        device_failed = True                         # the tuple route below goes straight to the host-assembled featuriser
                 if texts is not None:
                     for txt in texts:
                         f.write(txt.decode("ascii"))
@@ -237,7 +239,7 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
                         os.fsync(f.fileno())
                         counter_Q.put(1)
                     continue
-                tuples = get_indel_testing_candidates_batch(params, group, device=device, haploid=hap, device_x=True)
+                tuples = get_indel_testing_candidates_batch(params, group, device=device, haploid=hap, device_x=True, device_route=not device_failed)
                 probs = forward(ploidy, tuples)
                 tuples = [tuple(None if torch.is_tensor(v) else v for v in t) for t in tuples]        # the tensors are not needed any more
                 for k, t, pr in zip(ks, tuples, probs):

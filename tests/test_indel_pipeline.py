@@ -110,6 +110,33 @@ def test_unsupported_inputs_are_reported_not_accepted(tmp_path):
     assert check(d, np.ascontiguousarray((d["read_flag"] & 0x800) == 0, np.uint8)) == (_lib.NC_OK, 0, 0)
 
 
+def test_the_indel_routes_contig_world_carries_the_unsupported_counts(tmp_path):
+    """the World that decoded_contig registers for the SNP path / pass 1 (one decode per contig) is checked like bam.read_bam's: with
+    --supplementary a read name whose two kept alignments overlap is refused on the indel route too"""
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    ref = "ACGT" * 500
+    recs = [dict(name="r1", flag=0, pos0=10, cigar=[("M", 50)], seq="A" * 50), dict(name="r2", flag=16, pos0=30, cigar=[("M", 40)], seq="C" * 40),
+            dict(name="r1", flag=0x800, pos0=45, cigar=[("M", 30)], seq="T" * 30)]
+    bam, fa = str(tmp_path / "d.bam"), str(tmp_path / "d.fa")
+    bamio.write_bam(bam, "c", len(ref), recs)
+    bamio.write_fasta(fa, "c", ref)
+    gip._CONTIGS.clear()
+    gsp.release_contig()
+    gip.decoded_contig(bam, "c", fa)
+    w = gsp._BAM_WORLDS.get((bam, fa, "c"), lambda: pytest.fail("decoded_contig did not register its World"))
+    assert w.meta["unsupported"] == {False: (0, 0), True: (0, 1)}
+    gsp._check_supported(w, bam, "c", supplementary=False)
+    with pytest.raises(_lib.NanoCallerHipError) as ei:
+        gsp._check_supported(w, bam, "c", supplementary=True)
+    assert ei.value.status == _lib.NC_ERR_UNSUPPORTED
+    # a World nobody counted for is counted on the spot, not waved through
+    del w.meta["unsupported"]
+    with pytest.raises(_lib.NanoCallerHipError):
+        gsp._check_supported(w, bam, "c", supplementary=True)
+    gip._CONTIGS.clear()
+    gsp.release_contig()
+
+
 def _random_sites(rng, n, n_chunks, L, haploid):
     contig = "".join("AGTC"[i] for i in rng.integers(0, 4, size=L))
     chunk = np.sort(rng.integers(0, n_chunks, size=n)).astype(np.int32)
@@ -178,6 +205,32 @@ def test_native_indel_rules_write_the_python_statements_text(haploid):
     if not haploid:
         kinds = {ln.split("\t")[9].split(":")[0] for ln in exp}
         assert kinds == {"1/1", "1|2", "0|1", "1|0"} and any("GT:GQ:PS" in ln for ln in exp) and any(ln.endswith("GT:GQ\t1|2:%s\n" % ln.rstrip("\n").split(":")[-1]) for ln in exp)
+
+
+def test_native_indel_rules_print_nan_for_a_non_finite_probability():
+    """a model that overflowed gives NaN probabilities: the reference's format() writes 'nan' into the quality fields; the native formatter does
+    the same instead of shifting a 128-bit integer by the NaN's exponent"""
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    n, n_chunks, Lc = 300, 3, 20_000
+    contig, pos, chunk, probs, rl, al, alt, off, phase = _random_sites(rng, n, n_chunks, Lc, False)
+    probs[::7, 1] = np.nan
+    probs[3::11, 2] = np.inf
+    letters = np.frombuffer(b"AGTC", np.uint8)[alt].tobytes().decode()
+    exp = []
+    for c in range(n_chunks):
+        sel = np.nonzero(chunk == c)[0]
+        alle = [[(None, None) if rl[j, t] < 0 else (contig[pos[j] - 1:pos[j] - 1 + rl[j, t]], letters[off[j * 3 + t]:off[j * 3 + t + 1]]) for t in range(3)] for j in sel]
+        with np.errstate(all="ignore"):
+            lines, _ = indelCaller.indel_vcf_lines("chrT", pos[sel].tolist(), probs[sel], alle, [int(p) if p else None for p in phase[sel]], 0)
+        exp += lines
+    out = np.empty(n * 400, np.uint8)
+    nb = C.c_int64()
+    rc = L.nc_indel_vcf_format(b"chrT", n, _lib.npp(pos), _lib.npp(chunk), n_chunks, _lib.npp(probs), 3, _lib.npp(rl), _lib.npp(al), _lib.npp(alt),
+                               _lib.npp(phase), contig.encode(), Lc, 0, _lib.npp(out), out.size, C.byref(nb), None)
+    assert rc == _lib.NC_OK
+    got = out[:nb.value].tobytes().decode()
+    assert got == "".join(exp) and "nan" in got
 
 
 # ---------------------------------------------------------------------------------------------------------------- GPU
