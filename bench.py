@@ -62,7 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (HiFi 60x haploid, exact fp32, indel pipeline)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] block (chr1-sized SNP + indel in one timed region)")
-    ap.add_argument("--configs2-steps", type=int, default=3)
+    ap.add_argument("--configs2-steps", type=int, default=5)
+    ap.add_argument("--no-indel-leg", action="store_true", help="N>1: skip the indel passes over the sharded contig list")
+    ap.add_argument("--indel-passes", type=int, default=3)
     ap.add_argument("--configs2-length", type=int, default=CHR1_LEN)
     ap.add_argument("--no-overlap", action="store_true", help="collect every step's results before the next step is enqueued")
     ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each; value = the median, min / max reported")
@@ -875,6 +877,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+    numa = None
+    if use_dist and world > 1 and not one_gpu:
+        from nanocaller_amd.numa import bind_rank                  # before the engine page-locks memory or starts threads
+        numa = bind_rank(local)
     from nanocaller_amd import snpCaller
     from nanocaller_amd.engine import get_engine
     from nanocaller_amd.utils import get_chunks
@@ -953,6 +959,53 @@ def main():
         allt = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(allt, mine_t)
         per_rank_h2d = [[float(t[0]), float(t[1])] for t in allt]
+    # ---- N > 1: the indel half over the same sharded contig list (configs[3] is SNP + indel): every rank runs the indel pass over ITS contigs,
+    # `--indel-passes` times, from pinned host memory, between barriers; no collective on the data path
+    indel_leg = None
+    if world > 1 and not args.no_indel_leg:
+        try:
+            jobs = [IndelJob(eng, L, seed=4813 + k) for k in mine]
+            for j in jobs:
+                j.drop_pack()
+            from concurrent.futures import ThreadPoolExecutor
+
+            def indel_units(n_pass):
+                sites = 0
+                seq = [j for _ in range(n_pass) for j in jobs]
+                with ThreadPoolExecutor(max_workers=1) as pool:
+                    pend = None
+                    nxt = uploader.submit(seq[0].wire) if seq else None
+                    for i, j in enumerate(seq):
+                        tk = nxt
+                        nxt = uploader.submit(seq[i + 1].wire) if i + 1 < len(seq) else None
+                        r_i = j.from_host_pass(uploader, tk)
+                        sites += int(r_i["n"])
+                        if pend is not None:
+                            pend.result()
+                        pend = pool.submit(j.rules, r_i)
+                    if pend is not None:
+                        pend.result()
+                return sites
+            indel_units(1)
+            if len(jobs) < len(uploader.slots):
+                indel_units(2)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            isites = indel_units(args.indel_passes)
+            torch.cuda.synchronize()
+            barrier()
+            idt = _dmax(time.perf_counter() - t0)
+            itot = dist_sum(isites)
+            indel_leg = {"value": itot / idt, "unit": "candidate sites/s (indel half, whole job)", "passes": args.indel_passes, "contigs_per_pass": job_contigs,
+                         "ms_per_pass_over_the_job": idt / args.indel_passes * 1e3, "sites_per_pass": itot // max(1, args.indel_passes),
+                         "wire_bytes_per_contig": jobs[0].wire.nbytes if jobs else None,
+                         "note": "every rank: its contigs' indel passes from pinned host memory (upload ring, rules + text on a host thread), barrier + "
+                                 "synchronize on both sides, MAX over ranks; outside `value`'s timed region"}
+            del jobs
+            torch.cuda.empty_cache()
+        except Exception as e:                                      # never take the headline down
+            indel_leg = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         n_units = args.steps * per_step
         c0 = contigs[0]
@@ -1092,6 +1145,8 @@ def main():
                               "note": "rank 0, per GPU; with_h2d_d2h = the timed region (= value at N=1); hbm_resident = the same passes over a pack "
                                       "already in HBM (round 1's headline); pipelined = + VCF text of pass i formatted on a host thread while the "
                                       "GPU runs pass i+1 (snpCaller.caller), uploads included"},
+            "indel_leg": indel_leg,
+            "numa": ({"rank0_bound": numa["bound"], "node": numa["node"], "cpus": len(numa["cpus"]) if numa["cpus"] else None, "note": numa["note"]} if numa else None),
             "range_guard": {"x_limit": eng.x_limit(_lib_kind(args.ploidy)), "sites_rerun_on_exact_trunk": int(r.get("range_reruns", 0)) if r else None,
                             "note": "fp16x3 trunk: sites whose scaled tensor exceeds the model's proven-safe input bound are re-run on the exact fp32 trunk "
                                     "(nc_cnn_range_watch); 0 = every result of the timed region is proven inside the fp16 range"},

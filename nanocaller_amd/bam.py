@@ -38,6 +38,27 @@ def usable_cpus():
     return n
 
 
+def rank_threads():
+    """host threads one rank of a multi-rank job should start: the CPUs it may use (numa.bind_rank narrows the affinity mask to the rank's
+    share of its GPU's NUMA node), and no more than its share of a cgroup quota the ranks of the node draw from together"""
+    n = usable_cpus()
+    try:
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        lw = 1
+    if lw > 1:
+        quota = None
+        try:
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = max(1, -(-int(q) // int(p)))
+        except (OSError, ValueError):
+            pass
+        if quota is not None:
+            n = min(n, max(1, quota // lw))
+    return max(1, n)
+
+
 class _Owner:
     """keeps a native result alive for as long as a numpy view of its arrays exists (views are zero-copy: a fresh copy of
     a gigabyte array costs more in page faults than the decode itself)"""
@@ -238,7 +259,7 @@ def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=
     bf.close()
     end = tid_len if end is None else min(int(end), tid_len)
     start = max(1, int(start))
-    threads = threads or min(64, usable_cpus())
+    threads = threads or min(64, rank_threads())
     min_region = int(os.environ.get("NANOCALLER_DECODE_MIN_REGION", min_region))
     n_reg = min(threads, max(1, (end - start + 1) // min_region))
     if n_reg <= 1 or not has_index:

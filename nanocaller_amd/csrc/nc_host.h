@@ -32,7 +32,13 @@ static inline int nc_host_cpus()
         if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
     }
     if (quota > 0 && period > 0) {
-        const int c = (int)((quota + period - 1) / period);
+        int c = (int)((quota + period - 1) / period);
+        // one process per GPU: the ranks of a node draw from one quota (torchrun exports LOCAL_WORLD_SIZE); the affinity mask above is
+        // already the rank's own share of its GPU's NUMA node (nanocaller_amd/numa.py)
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {
+            const int k = atoi(lw);
+            if (k > 1) c = c / k > 1 ? c / k : 1;
+        }
         if (c >= 1 && c < n) n = c;
     }
     cached = n;

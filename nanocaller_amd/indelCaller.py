@@ -360,6 +360,9 @@ def call_manager(params, devices=None, aligner=None):
     from .utils import make_and_remove_path
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
     device = local_device(devices, rank)
+    if world > 1:
+        from .numa import bind_rank
+        bind_rank(device)
     mode = params['mode']
     contigs_list = {}
     for x in params['regions_list']:                                           # :299-305
@@ -376,7 +379,8 @@ def call_manager(params, devices=None, aligner=None):
     shard.barrier()
     job_Q, counter_Q = queue.Queue(), queue.Queue()
     indel_dict, phased_snp_files_list, indel_files_list = {}, [], []
-    mine = shard.shard_chunks(params['chunks_list'], rank, world) if mode != 'snps' else []
+    wts = shard.depth_weights(params.get('sam_path'), params['chunks_list']) if world > 1 and mode != 'snps' else None
+    mine = shard.shard_chunks(params['chunks_list'], rank, world, wts) if mode != 'snps' else []
     if mode == 'indels':
         for chunk in mine:
             chunk['sam_path'] = params['sam_path']                             # :322

@@ -413,10 +413,14 @@ def call_manager(params, devices=None):
     from .engine import local_device
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    if world > 1:                                                     # next to its GPU before anything page-locks memory or starts threads
+        from .numa import bind_rank
+        bind_rank(local_device(devices, rank))
     chunks_Q = queue.Queue()
     counter_Q = queue.Queue()
     snp_files = []
-    for chunk in shard.shard_chunks(params['chunks_list'], rank, world):
+    wts = shard.depth_weights(params.get('sam_path'), params['chunks_list']) if world > 1 else None      # balance by the alignments held
+    for chunk in shard.shard_chunks(params['chunks_list'], rank, world, wts):
         chunks_Q.put(chunk)
     params['intermediate_snp_files_dir'] = os.path.join(params['vcf_path'], 'intermediate_snp_files')
     if rank == 0:

@@ -180,3 +180,118 @@ def test_two_rank_gloo_ingest_decodes_no_contig_twice(tmp_path):
         assert sa is not None and sb is not None                      # neither rank decoded the whole contig
         assert sb[0] >= sa[1] - 2 * 50_000 - 1                        # the spans overlap by the two flanks at most
     assert sum(len(w) for w in seen.values()) <= len(lens) + 1        # at most one contig is shared between the two ranks
+
+
+def test_depth_weights_follow_the_alignments_not_the_lengths(tmp_path):
+    """shards are balanced by sum(depth).  A BAM whose second half carries four times the reads of its first half: the weights read off
+    the BAI linear index (no decode) say so, and the two-rank cut moves from the middle of the contig towards the dense half"""
+    from nanocaller_amd.shard import bai_linear_index, depth_weights, shard_plan
+    from tests import bamio
+    rng = np.random.default_rng(8)
+    L = 2_000_000
+    recs = []
+    for p in range(1_000, L - 3_000, 2_000):
+        for k in range(1 if p < L // 2 else 4):
+            recs.append(dict(name="r%d_%d" % (p, k), flag=0, pos0=p + 17 * k, cigar=[("M", 2_000)], seq="".join("ACGT"[b] for b in rng.integers(0, 4, 2_000))))
+    recs.sort(key=lambda r: r["pos0"])
+    bam = str(tmp_path / "w.bam")
+    bamio.write_bam(bam, "c1", L, recs, level=1)
+    lin = bai_linear_index(bam + ".bai")
+    assert list(lin) == [0] and len(lin[0]) >= (L - 3_000) >> 14 and all(b >= a for a, b in zip(lin[0], lin[0][1:]))
+    chunks = get_chunks([("c1", 1, L, "diploid")], cpu=40)
+    w = depth_weights(bam, chunks)
+    assert w is not None and len(w) == len(chunks)
+    first = np.mean([x for x, c in zip(w, chunks) if c["end"] < L // 2 - 100_000])
+    second = np.mean([x for x, c in zip(w, chunks) if c["start"] > L // 2 + 100_000 and c["end"] < L - 200_000])
+    assert 2.5 < second / first < 6.0
+    by_len = shard_plan(chunks, 2)
+    by_depth = shard_plan(chunks, 2, weights=w)
+    assert [c for p in by_depth for c in p] == chunks
+    assert abs(by_len[0][-1]["end"] - L // 2) < 150_000 and by_depth[0][-1]["end"] > L // 2 + 250_000
+    assert depth_weights(str(tmp_path / "none.bam"), chunks) is None and depth_weights(object(), chunks) is None
+
+
+def test_numa_binding_plan():
+    """ranks split the CPUs of the NUMA node their GPUs hang off; unknown topology = no binding"""
+    from nanocaller_amd import numa
+    cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]                                # an 8-GPU node, four GPUs per socket
+    allowed = set(range(128))
+    seen = []
+    for lr in range(8):
+        got, note = numa.plan_binding(nodes, lr, allowed, lambda n: cpus[n])
+        assert len(got) == 16 and set(got) <= set(cpus[nodes[lr]]), note
+        seen += got
+    assert sorted(seen) == list(range(128))                         # disjoint and complete
+    got, _ = numa.plan_binding(nodes, 5, set(range(64, 72)), lambda n: cpus[n])      # a cgroup that allows 8 CPUs of socket 1
+    assert got == [66, 67]
+    assert numa.plan_binding([-1] * 8, 3, allowed, lambda n: cpus[n])[0] is None
+    assert numa.plan_binding(nodes, 2, set(range(64, 128)), lambda n: cpus[n])[0] is None   # no allowed CPU next to the GPU: leave the mask alone
+    assert numa._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert numa.bind_rank(0)["bound"] is False                      # no GPU here: nothing is bound, nothing fails
+
+
+def _wgs_worker(rank, world, port, tmpdir):
+    """one rank of an 8-rank job over a WGS-shaped contig list: indelCaller.call_manager with the per-chunk work stood in"""
+    import torch
+    import torch.distributed as dist
+
+    from nanocaller_amd import indelCaller
+    from tests.test_boundary import _fake_snp_vcf
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 8
+    seen = []
+
+    def fake_indel_run(params, indel_dict, job_Q, counter_Q, files, device=0, worker_id=1, aligner=None):
+        path = os.path.join(params["intermediate_indel_files_dir"], "%s.%d.indel.vcf" % (params["prefix"], worker_id))
+        files.append(path)
+        with open(path, "a") as f:
+            while not job_Q.empty():
+                kind, chunk = job_Q.get()
+                seen.append((device, worker_id, chunk["chrom"], chunk["start"]))
+                f.write("%s\t%d\t.\tAT\tA\t12.00\tPASS\t.\tGT:GQ\t0|1:3.00\n" % (chunk["chrom"], chunk["start"] + 7))
+    indelCaller.indel_run = fake_indel_run
+    indelCaller._whatshap_available = lambda: False
+    regions = [("chr%d" % (k + 1), 1, n * 10_000, "diploid") for k, n in enumerate(WGS_LENS)]
+    snp_vcf = os.path.join(tmpdir, "t.snps.vcf.gz")
+    if rank == 0:
+        _fake_snp_vcf(snp_vcf, [r[0] for r in regions])
+    dist.barrier()
+    params = dict(chunks_list=get_chunks(regions, 16, max_chunk_size=10_000), mode="all", snp_vcf=snp_vcf, regions_list=regions, sam_path="in.bam",
+                  fasta_path="x.fa", vcf_path=tmpdir, prefix="t", sample="S", phase_qual_score=10, suppress_progress=True, verbose=False,
+                  enable_whatshap=False, cpu=2)
+    out = indelCaller.call_manager(params)
+    with open(os.path.join(tmpdir, "wlog.%d" % rank), "w") as f:
+        f.write(repr((out, seen)))
+    dist.destroy_process_group()
+
+
+WGS_LENS = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57]
+
+
+def test_eight_rank_gloo_wgs_plan_through_the_indel_call_manager(tmp_path):
+    """BASELINE.json configs[3]'s shape on CPU: 24 contigs (GRCh38's proportions), 3,078 indel chunks, eight ranks over gloo through
+    indelCaller.call_manager (rank 0 phases every contig, every rank releases ITS block of chunks to its own GPU's worker, rank 0 merges): each chunk
+    is worked on exactly once, in contiguous contig-aware blocks of near-equal size, and the merged outputs are sorted"""
+    from tests.test_boundary import _records
+    world = 8
+    mp.spawn(_wgs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    logs = [eval(open(os.path.join(str(tmp_path), "wlog.%d" % r)).read()) for r in range(world)]
+    regions = [("chr%d" % (k + 1), 1, n * 10_000, "diploid") for k, n in enumerate(WGS_LENS)]
+    chunks = get_chunks(regions, 16, max_chunk_size=10_000)
+    assert len(chunks) > 3000
+    got = [(c, s) for lg in logs for (_, _, c, s) in lg[1]]
+    assert len(got) == len(chunks) and sorted(got) == sorted((c["chrom"], c["start"]) for c in chunks)        # every chunk once
+    order = {(c["chrom"], c["start"]): i for i, c in enumerate(chunks)}
+    for r, lg in enumerate(logs):
+        assert {d for (d, _, _, _) in lg[1]} == {r} and {w for (_, w, _, _) in lg[1]} == {r + 1}              # rank -> its GPU, its worker file
+        idx = sorted(order[(c, s)] for (_, _, c, s) in lg[1])
+        assert idx == list(range(idx[0], idx[-1] + 1))                                                        # one contiguous block
+        assert 0.8 * len(chunks) / world < len(idx) < 1.2 * len(chunks) / world
+    assert all(lg[0] == logs[0][0] for lg in logs)
+    ind = _records(logs[0][0]["indels"])
+    assert len(ind) == len(chunks)
+    keys = [(int(r.split("\t")[0][3:]), int(r.split("\t")[1])) for r in ind]
+    assert keys == sorted(keys)
