@@ -29,7 +29,7 @@ extern "C" {
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
-                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events) */
+                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -179,6 +179,13 @@ int nc_indel_events_pack(int32_t n_reads, const int32_t *rd_start, const int32_t
 int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint16_t *d_d16,
                            const int8_t *d_l8, int32_t n_big, const int32_t *d_big_idx, const int32_t *d_big_pos, const int32_t *d_big_len,
                            const int32_t *d_read_ins_off, int32_t *d_ev_pos, int32_t *d_ev_len, int32_t *d_ins_off);
+
+/* DEFLATE on the device (csrc/nc_inflate.hip): the raw-deflate payloads of n BGZF members (SAMv1 4.1), one lane per member.  All pointers
+ * dev: d_comp = the compressed bytes (readable 8 bytes past the last payload), d_coff / d_clen = byte offset and length of member b's payload
+ * in it, d_out + d_ooff[b] = where its d_isize[b] bytes go, d_status[b] = 0 or why the member is not a valid stream of that length.  Runs on
+ * the context's stream.  CRC-32s are not computed here.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
+int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
+                      const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status);
 
 /* ------------------------------------------------------------------ SNP candidate scan (K1)
  * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch

@@ -1,0 +1,103 @@
+"""DEFLATE on the device (csrc/nc_inflate.hip, one lane per BGZF member) against zlib: every block type and the streams zlib's strategies make,
+members at unaligned offsets, the members of the spec-assembled BAM fixture, and damaged inputs (reported, never a crash)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _run(payloads, sizes):
+    import torch
+    from nanocaller_amd.engine import get_engine
+    eng = get_engine(0)
+    rng = np.random.default_rng(1)
+    off, blob = [], bytearray()
+    for p in payloads:
+        blob += bytes(rng.integers(0, 256, size=int(rng.integers(0, 7))).astype(np.uint8))      # unaligned starts, junk between members
+        off.append(len(blob))
+        blob += p
+    blob += bytes(16)
+    ooff = np.zeros(len(payloads) + 1, np.int64)
+    np.cumsum(np.asarray(sizes, np.int64) + 3, out=ooff[1:])                                      # (3 spare bytes between outputs: overruns would show)
+    dev = eng.device
+    d_comp = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).to(dev)
+    d_coff = torch.tensor(off, dtype=torch.int64, device=dev)
+    d_clen = torch.tensor([len(p) for p in payloads], dtype=torch.int32, device=dev)
+    d_out = torch.full((int(ooff[-1]) + 16,), 0xEE, dtype=torch.uint8, device=dev)
+    d_ooff = torch.from_numpy(ooff[:-1].copy()).to(dev)
+    d_isize = torch.tensor(list(sizes), dtype=torch.int32, device=dev)
+    d_st = torch.full((len(payloads),), -1, dtype=torch.int32, device=dev)
+    eng.use_torch_stream()
+    rc = eng.L.nc_inflate_device(eng.ctx, len(payloads), d_comp.data_ptr(), d_coff.data_ptr(), d_clen.data_ptr(), d_out.data_ptr(), d_ooff.data_ptr(),
+                                 d_isize.data_ptr(), d_st.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), ooff, d_st.cpu().numpy()
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    text = (b"chr20\t1234567\t.\tA\tG\t33.10\tPASS\t.\tGT:DP:FQ\t0/1:31:0.4839\n" * 900)[:60_000]
+    dna4 = bytes(rng.integers(0, 256, size=65_280).astype(np.uint8))                              # packed bases: incompressible
+    qual = bytes((rng.normal(20, 6, size=65_280).clip(0, 60)).astype(np.uint8))                    # quality-like: entropy coded, few matches
+    runs = b"".join(bytes([int(b)]) * int(n) for b, n in zip(rng.integers(0, 4, 400), rng.integers(1, 400, 400)))[:65_280]
+    data = [b"", b"A", b"AB" * 3, bytes(65_280), text, dna4, qual, runs, bytes(range(256)) * 255]
+    out = []
+    for d in data:
+        for kw in (dict(level=6), dict(level=1), dict(level=9), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED), dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY),
+                   dict(level=6, strategy=zlib.Z_RLE), dict(level=6, strategy=zlib.Z_FILTERED), dict(level=9, mem=1)):
+            out.append((d, _deflate(d, **kw)))
+    # several deflate blocks in one member (Z_FULL_FLUSH between pieces: stored + dynamic + fixed in one stream)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    multi = c.compress(text[:20_000]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(dna4[:20_000]) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(runs[:20_000]) + c.flush()
+    out.append((text[:20_000] + dna4[:20_000] + runs[:20_000], multi))
+    return out
+
+
+def test_device_inflate_equals_zlib():
+    cases = _cases()
+    out, ooff, st = _run([p for _, p in cases], [len(d) for d, _ in cases])
+    assert not st.any(), np.nonzero(st)[0][:10]
+    for k, (d, _) in enumerate(cases):
+        got = out[ooff[k]:ooff[k] + len(d)].tobytes()
+        assert got == d, k
+        assert out[ooff[k] + len(d):ooff[k] + len(d) + 3].tolist() == [0xEE] * 3, k               # nothing written past the announced size
+    kinds = {(p[0] >> 1) & 3 for _, p in cases if p}
+    assert kinds == {0, 1, 2}
+
+
+def test_device_inflate_on_the_members_of_the_spec_fixture():
+    raw = open(os.path.join(G, "spec.bam"), "rb").read()
+    pay, want, o = [], [], 0
+    while o < len(raw):
+        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+        p = raw[o + 18:o + bsize - 8]
+        pay.append(p)
+        want.append(zlib.decompress(p, -15))
+        assert len(want[-1]) == int.from_bytes(raw[o + bsize - 4:o + bsize], "little")
+        o += bsize
+    out, ooff, st = _run(pay, [len(w) for w in want])
+    assert not st.any() and len(pay) > 30
+    assert b"".join(out[ooff[k]:ooff[k] + len(w)].tobytes() for k, w in enumerate(want)) == b"".join(want)
+
+
+def test_damaged_members_are_reported():
+    d = (b"ACGTTGCA" * 4000)[:30_000]
+    good = _deflate(d)
+    rng = np.random.default_rng(3)
+    junk = bytes(rng.integers(0, 256, size=400).astype(np.uint8))
+    cases = [(good, len(d)), (good, len(d) - 1), (good, len(d) + 1), (good[:len(good) // 2], len(d)), (junk, 5_000), (b"\x07", 10), (good, len(d))]
+    out, ooff, st = _run([p for p, _ in cases], [n for _, n in cases])
+    assert st[0] == 0 and st[-1] == 0 and all(st[1:-1] != 0), st
+    assert out[ooff[0]:ooff[0] + len(d)].tobytes() == d and out[ooff[6]:ooff[6] + len(d)].tobytes() == d
+    for k, (_, n) in enumerate(cases):
+        assert out[ooff[k] + n:ooff[k] + n + 3].tolist() == [0xEE] * 3, k                         # even a damaged member stays inside its own output

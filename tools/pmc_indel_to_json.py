@@ -14,10 +14,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from build_tag import INDEL_SOURCES, build_tag
 
 STAGE = {"k_hap_depth_b": "k7_scan_anchors_sets", "k_yield_rank_b": "k7_scan_anchors_sets", "k_entry_reads": "k7_scan_anchors_sets",
-         "k_event_tiles": "k7_scan_anchors_sets", "k_pick": "k7_scan_anchors_sets", "k_sets": "k7_scan_anchors_sets", "k_flatten": "k7_scan_anchors_sets",
-         "k_scan_excl": "k7_scan_anchors_sets", "k_windows": "query_windows", "k_fill16q": "fill (star alignment + allele alignment)",
-         "k_fill16p": "fill (star alignment + allele alignment)", "k_end_cells": "star_alignment_traceback", "k_trace16p": "star_alignment_traceback",
-         "k_site_tensor": "k8_tensors_consensus", "k_allele_trace16p": "allele_prediction", "k_scan_rows": "allele_prediction",
+         "k_entry_cursors": "k7_scan_anchors_sets", "k_event_tiles": "k7_scan_anchors_sets", "k_pick": "k7_scan_anchors_sets", "k_sets": "k7_scan_anchors_sets",
+         "k_flatten": "k7_scan_anchors_sets", "k_scan_excl": "k7_scan_anchors_sets", "k_windows": "query_windows",
+         # the banded fills of the star alignment AND of allele_prediction (one kernel name; the allele sets are ~1/9 of the cells)
+         "k_fill_band": "star_alignment_fill",
+         # banded tracebacks + the full-matrix route of the alignments that do not fit a band (star and allele fallbacks share k_fill16q)
+         "k_trace_band12": "star_alignment_traceback", "k_fill16q": "star_alignment_traceback", "k_fill16p": "star_alignment_traceback",
+         "k_end_cells": "star_alignment_traceback", "k_trace16p": "star_alignment_traceback", "k_band_stats": "star_alignment_traceback",
+         "k_site_tensor": "k8_tensors_consensus", "k_allele_trace16p": "allele_prediction", "k_allele_trace_b12": "allele_prediction",
+         "k_allele_classes": "allele_prediction", "k_scan_rows": "allele_prediction",
          "k_alt_offsets": "allele_prediction", "k_alt_copy": "allele_prediction", "k10_indel_trunk_h3": "k9_indel_cnn", "k3_fc1": "k9_indel_cnn",
          "k_indel_heads": "k9_indel_cnn"}
 
