@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (HiFi 60x haploid, exact fp32, indel pipeline)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] block (chr1-sized SNP + indel in one timed region)")
-    ap.add_argument("--configs2-steps", type=int, default=5)
+    ap.add_argument("--configs2-steps", type=int, default=8)
     ap.add_argument("--no-indel-leg", action="store_true", help="N>1: skip the indel passes over the sharded contig list")
     ap.add_argument("--indel-passes", type=int, default=3)
     ap.add_argument("--configs2-length", type=int, default=CHR1_LEN)
@@ -388,11 +388,19 @@ class IndelJob:
         from nanocaller_amd import _lib
         from nanocaller_amd import generate_indel_pileups as gip
         eng = self.eng
+        dbg = os.environ.get("NC_BENCH_DEBUG") == "1"
+        t0 = time.perf_counter()
         r = gip.indel_sites_device(eng, dp, rc, self.L, self.chunks, fetch=False, **self.kw)
+        t1 = time.perf_counter()
         probs = eng.indel_forward(_lib.MODEL_INDEL, r["x"])
+        t2 = time.perf_counter()
         r.update(gip.indel_sites_fetch(eng, r["n"], r["sets"]))
+        t3 = time.perf_counter()
         r["probs"] = probs.cpu().numpy()
         del r["x"]
+        if dbg:
+            print("  indel pass host ms: plan+run %.1f, K9 enqueue %.1f, fetch %.1f, probs %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t3) * 1e3),
+                  file=sys.stderr, flush=True)
         return r
 
     def rules(self, r):
@@ -411,13 +419,17 @@ class IndelJob:
 
     def from_host_pass(self, uploader, tk):
         from nanocaller_amd.wire import indel_reads_struct
+        t0 = time.perf_counter()
         dp = uploader.expand(tk)
+        t1 = time.perf_counter()
         r = self.gpu_pass(dp, indel_reads_struct(dp))
         uploader.release(tk)
+        if os.environ.get("NC_BENCH_DEBUG") == "1":
+            print("  indel pass host ms: expand enqueue %.1f, whole pass %.1f" % ((t1 - t0) * 1e3, (time.perf_counter() - t0) * 1e3), file=sys.stderr, flush=True)
         return r
 
 
-def extra_indel_config(eng, uploader, local, L, reps=10):
+def extra_indel_config(eng, uploader, local, L, reps=20):
     """The indel half of configs[2] at chromosome scale, as candidate sites/s: a chr20-sized synthetic ONT 30x contig (IndelJob).  Timed
     region: decoded alignments + the bases without a reference column in PINNED HOST MEMORY -> one H2D copy (own stream, under the
     previous pass) -> the pass -> genotype rules + VCF text (native, on a host thread under the next pass).  Stage times are HIP events of a

@@ -56,7 +56,9 @@ struct nc_ctx {
     DevBuf chunk_depth;                                   // double per chunk
     DevBuf nbr_idx;                                       // coarse index over nbr_pos
     DevBuf indel_ws;                                      // indel window-scan workspace
-    DevBuf indel_ent_read;                                // read index of every tile entry (k_event_tiles)
+    DevBuf indel_ent_read;                                // read index of every tile entry + its event cursors per 1024-column block (k_entry_cursors)
+    const void *indel_ent_of = nullptr;                   // the tile index (tile_ent) those tables were last made for, NULL: none (pass 1 ran in another form)
+    int indel_ent_spt = 0;                                // 1024-column blocks per tile of that index
     DevBuf msa_reads, msa_read_off, msa_read_set, msa_refs, msa_ref_off;   // device star alignment (nc_msa.hip): inputs,
     DevBuf msa_dup;                                        // duplicate map + list of alignments to compute (nc_star_msa_tensor_dup)
     DevBuf msa_rows_hf, msa_hcol, msa_tb, msa_trace, msa_cols, msa_out;    // DP rows / last column / traceback bytes / alignments / columns / rows

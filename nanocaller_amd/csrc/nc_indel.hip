@@ -782,10 +782,17 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
                                std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev,
                                int32_t *err_bits_dev)
 {
+    ctx->indel_ent_of = nullptr;
     const int tile = pack->tile_size;
     const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
     const int impute = prm->impute && !prm->haploid;
-    const size_t BUDGET = (size_t)6 << 30;                           // workspace per group of chunks
+    // workspace per group of chunks: a twelfth of the device memory that is free at the first call, between 6 and 24 GiB (a chr1-sized contig's
+    // columns need 12 GB: one group, one launch of every K7 kernel -- and ONE pass of k_entry_cursors over the tile index -- instead of two)
+    static const size_t BUDGET = []() {
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) mfree = (size_t)72 << 30;
+        return std::min<size_t>((size_t)24 << 30, std::max<size_t>((size_t)6 << 30, mfree / 12));
+    }();
     ck.clear();
     size_t wsb = 0;
     int64_t ncols = 0;
@@ -843,6 +850,8 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
         int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p, *ent_cur = ent_read + pack->n_entries;
         hipLaunchKernelGGL(k_entry_cursors, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);
+        ctx->indel_ent_of = pack->tile_ent;                              // (the device pipeline's k_sets / k_windows use the tables too)
+        ctx->indel_ent_spt = SPT;
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            ent_read, ent_cur, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size,
                            prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev);

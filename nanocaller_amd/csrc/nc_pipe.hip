@@ -203,6 +203,11 @@ struct SetArgs {
     int32_t *site_pos, *site_chunk, *site_type, *site_phase, *site_al0, *site_nr, *site_n2;
     int32_t *al_read, *al_site;
     uint8_t *al_member;
+    // K7's per-entry tables (k_entry_cursors; NULL when pass 1 ran without them): the read of every tile entry, and its first event at or after every
+    // 1024-column block of the tile (less 64 columns) -> the read without a search, and for k_windows the short stretch of the read's events around the anchor
+    const int32_t *ent_read, *ent_cur, *ev_off;
+    int32_t spt;
+    int2 *al_ev;
 };
 
 template <bool FILL>
@@ -250,19 +255,29 @@ __global__ __launch_bounds__(256) void k_sets(SetArgs p)
                 // the entry's read: its slot offset is unique
                 int r = -1;
                 if (member != 0 || (cov && hp == 1 && first0 < 0)) {
-                    const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
-                    int lo = 0, hi = p.n_reads;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (p.slot_off[mid] < so) lo = mid + 1; else hi = mid;
+                    if (p.ent_read) r = p.ent_read[e];
+                    else {
+                        const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
+                        int lo = 0, hi = p.n_reads;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (p.slot_off[mid] < so) lo = mid + 1; else hi = mid;
+                        }
+                        r = lo;
                     }
-                    r = lo;
                 }
                 if (member != 0) {
                     const int w = al0 + n_u + __popcll(m_u & lt);
                     p.al_read[w] = r;
                     p.al_site[w] = site;
                     p.al_member[w] = (uint8_t)member;
+                    if (p.al_ev) {
+                        // the read's events around the anchor: [first event at or after the anchor's 1024-column block less 64 columns, first one at or
+                        // after the block after next less 64) -- the first event on a column >= v lies in that stretch or is its end
+                        const int h = (v - (p.tile_pos0 + t * p.tile_size)) >> 10;
+                        const int32_t *cur = p.ent_cur + (int64_t)e * (p.spt + 1);
+                        p.al_ev[w] = make_int2(cur[h], h + 2 <= p.spt ? cur[h + 2] : p.ev_off[r + 1]);
+                    }
                 }
                 if (first0 < 0) {
                     const uint64_t mf = p.haploid ? m_all : m_1;
@@ -302,6 +317,7 @@ struct WinArgs {
     const int32_t *ev_off, *ev_pos, *ev_len, *ins_off, *tail_off;
     const uint8_t *ins_bases, *tail_bases, *read_flag;
     const int32_t *al_read, *al_site, *site_pos, *site_n2;    // al_* offset to the group's first alignment
+    const int2 *al_ev;          // (k_sets) the stretch of the read's events that holds the first one at or after the anchor, or NULL: search them all
     int32_t A, W, WS;
     uint8_t *win;           // [A][WS]
     int32_t *n1;            // [A]
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
         if (!(p.read_flag[r] & 1)) {
             const int e0 = p.ev_off[r], e1 = p.ev_off[r + 1];
             int lo = e0, hi = e1;                                  // first event on a column >= v
+            if (p.al_ev) { const int2 b2 = p.al_ev[al]; lo = b2.x; hi = b2.y; }      // (3 probes inside one or two sectors instead of 17 over the whole read)
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (p.ev_pos[mid] < v) lo = mid + 1; else hi = mid;
@@ -1819,7 +1836,8 @@ struct nc_pipe_state {
     int64_t tw_budget = 0;                  // bytes of traceback codes per group (set at the first run from the free device memory)
     size_t al0_cap = 0;
     DevBuf pc, seg_pos, seg_type, cnt, off, anc_pos, anc_type, anc_chunk, kept, nuniq, site_of, al_of;
-    DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member;
+    DevBuf site_pos, site_chunk, site_type, site_phase, site_al0, site_nr, site_n2, al_read, al_site, al_member, al_ev;
+    bool have_al_ev = false;
     struct GroupBufs {
         DevBuf win, n1, tw, hlast, hcol, endc, trace, cns, ncns, arow, alt_off;
         DevBuf band_lo, lists, counts, twb, hrow, hcolb, cband;                // banded star alignment: per-alignment band, class lists, codes, last row / column
@@ -1843,7 +1861,7 @@ void nc_pipe_destroy(nc_ctx *ctx)
     if (!s) return;
     DevBuf *bufs[] = {&s->pc, &s->seg_pos, &s->seg_type, &s->cnt, &s->off, &s->anc_pos, &s->anc_type, &s->anc_chunk, &s->kept, &s->nuniq, &s->site_of,
                       &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
-                      &s->al_site, &s->al_member, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc, &s->ab_lo, &s->ab_lists, &s->ab_counts, &s->ab_twb,
+                      &s->al_site, &s->al_member, &s->al_ev, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc, &s->ab_lo, &s->ab_lists, &s->ab_counts, &s->ab_twb,
                       &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].endc, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
                       &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[0].band_lo, &s->gb[0].lists, &s->gb[0].counts, &s->gb[0].twb, &s->gb[0].hrow, &s->gb[0].hcolb, &s->gb[0].cband, &s->gb[1].cband,
                       &s->gb[1].band_lo, &s->gb[1].lists, &s->gb[1].counts, &s->gb[1].twb, &s->gb[1].hrow, &s->gb[1].hcolb, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].endc, &s->gb[1].trace,
@@ -2002,6 +2020,10 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     sa.ref_code = ref_code_dev; sa.ref_pos0 = ref_pos0; sa.ref_len = ref_len; sa.chrom_len = chrom_len;
     sa.window_after = window_after; sa.maxcov = maxcov; sa.mincov = prm->mincov; sa.haploid = s->haploid;
     sa.slot_off = reads->slot_off; sa.read_ps = reads->read_ps; sa.n_reads = reads->n_reads;
+    const bool have_ent = ctx->indel_ent_of == (const void *)pack->tile_ent && ctx->indel_ent_read.p && !getenv("NC_PIPE_NO_EV_CURSORS");
+    if (have_ent) {
+        sa.ent_read = (const int32_t *)ctx->indel_ent_read.p; sa.ent_cur = sa.ent_read + pack->n_entries; sa.ev_off = reads->ev_off; sa.spt = ctx->indel_ent_spt;
+    }
     sa.n_anchor = na; sa.anc_pos = (const int32_t *)s->anc_pos.p; sa.anc_chunk = (const int32_t *)s->anc_chunk.p; sa.anc_type = (const int8_t *)s->anc_type.p;
     sa.kept = (int32_t *)s->kept.p; sa.nuniq = (int32_t *)s->nuniq.p;
     hipLaunchKernelGGL(k_sets<false>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
@@ -2035,6 +2057,11 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     sa.site_pos = (int32_t *)s->site_pos.p; sa.site_chunk = (int32_t *)s->site_chunk.p; sa.site_type = (int32_t *)s->site_type.p;
     sa.site_phase = (int32_t *)s->site_phase.p; sa.site_al0 = (int32_t *)s->site_al0.p; sa.site_nr = (int32_t *)s->site_nr.p;
     sa.site_n2 = (int32_t *)s->site_n2.p; sa.al_read = (int32_t *)s->al_read.p; sa.al_site = (int32_t *)s->al_site.p; sa.al_member = (uint8_t *)s->al_member.p;
+    s->have_al_ev = have_ent;
+    if (have_ent) {
+        NC_TRY(nc_ensure(ctx, s->al_ev, (size_t)std::max(nal, 1) * 8));
+        sa.al_ev = (int2 *)s->al_ev.p;
+    }
     hipLaunchKernelGGL(k_sets<true>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
     NC_HIP(ctx, hipGetLastError());
     NC_TRY(nc_h2d_small(ctx, (int32_t *)s->site_al0.p + ns, &nal, 4, ctx->stream));
@@ -2179,6 +2206,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         wa.ins_bases = s->rd.ins_bases; wa.tail_bases = s->rd.tail_bases; wa.read_flag = s->rd.read_flag;
         wa.al_read = (const int32_t *)s->al_read.p + A0; wa.al_site = (const int32_t *)s->al_site.p + A0;
         wa.site_pos = (const int32_t *)s->site_pos.p; wa.site_n2 = (const int32_t *)s->site_n2.p;
+        wa.al_ev = s->have_al_ev ? (const int2 *)s->al_ev.p + A0 : nullptr;
         wa.A = Ag; wa.W = s->window_after; wa.WS = WS; wa.win = (uint8_t *)B.win.p; wa.n1 = (int32_t *)B.n1.p; wa.cells = cells;
         wa.band_lo = band ? (int8_t *)B.band_lo.p : nullptr;
         wa.list1 = (int32_t *)B.lists.p; wa.list2 = wa.list1 + Agz; wa.listF = wa.list2 + Agz;
