@@ -862,8 +862,8 @@ __device__ __forceinline__ uint32_t dpp_shl1_z(uint32_t v) { return (uint32_t)__
 __device__ __forceinline__ uint32_t dpp_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t dpp_ror_u(uint32_t v, int n)                   // lane q <- lane (q - n) mod 16
 {
-    return n == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false)
-                  : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12f, 0xf, 0xf, false);
+    return n == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, true)        // (a rotation has a source for every lane: with bound_ctrl
+                  : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12f, 0xf, 0xf, true);       // the `old` operand need not be initialised)
 }
 
 template <int C>
@@ -938,11 +938,12 @@ __global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
         constexpr bool ODD = decltype(odd_tag)::value, TAIL = decltype(tail_tag)::value;
         uint32_t hl[C], el[C], hu[C], fu[C];
         if (ODD) {
+            const uint32_t rot = dpp_ror_u(ch_rf, 1);                   // (rotated first: the entry below then overwrites the chunk register in place, no copy)
             const uint32_t top = dpp_shl1_u(ch_rf, rf[0]);
 #pragma unroll
             for (int c = 0; c + 1 < C; c++) rf[c] = rf[c + 1];
             rf[C - 1] = top;
-            ch_rf = dpp_ror_u(ch_rf, 1);
+            ch_rf = rot;
             const uint32_t hn = dpp_shl1_z(Hp1[0]), fn = dpp_shl1_z(Fp1[0]);
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -951,11 +952,12 @@ __global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
                 fu[c] = c + 1 < C ? Fp1[c + 1 < C ? c + 1 : 0] : fn;
             }
         } else {
+            const uint32_t rot = dpp_ror_u(ch_rd, 15);
             const uint32_t bot = dpp_shr1_u(ch_rd, rd[C - 1]);
 #pragma unroll
             for (int c = C - 1; c > 0; c--) rd[c] = rd[c - 1];
             rd[0] = bot;
-            ch_rd = dpp_ror_u(ch_rd, 15);
+            ch_rd = rot;
             const uint32_t hn = dpp_shr1_z(Hp1[C - 1]), en = dpp_shr1_z(Ep1[C - 1]);
 #pragma unroll
             for (int c = 0; c < C; c++) {
