@@ -64,6 +64,10 @@ for rep in range(4):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     print("k_inflate: %.2f ms = %.1f GB/s compressed, %.1f GB/s inflated" % (ms, len(rb) / ms / 1e6, sum(isize) / ms / 1e6))
+if os.environ.get("NC_INFLATE_DEBUG"):
+    st = d_st.cpu().numpy()
+    print("debug counter %s: mean %.1f per member, min %d, max %d" % (os.environ["NC_INFLATE_DEBUG"], st.mean(), st.min(), st.max()))
+    sys.exit(0)
 assert rc == 0 and not d_st.cpu().numpy().any()
 t0 = time.perf_counter()
 want = b"".join(zlib.decompress(rb[c:c + n], -15) for c, n in zip(coff[:400], clen[:400]))
