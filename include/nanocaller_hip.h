@@ -180,12 +180,14 @@ int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_sta
                            const int8_t *d_l8, int32_t n_big, const int32_t *d_big_idx, const int32_t *d_big_pos, const int32_t *d_big_len,
                            const int32_t *d_read_ins_off, int32_t *d_ev_pos, int32_t *d_ev_len, int32_t *d_ins_off);
 
-/* DEFLATE on the device (csrc/nc_inflate.hip): the raw-deflate payloads of n BGZF members (SAMv1 4.1), one lane per member.  All pointers
- * dev: d_comp = the compressed bytes (readable 8 bytes past the last payload), d_coff / d_clen = byte offset and length of member b's payload
- * in it, d_out + d_ooff[b] = where its d_isize[b] bytes go, d_status[b] = 0 or why the member is not a valid stream of that length.  Runs on
- * the context's stream.  CRC-32s are not computed here.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
+/* DEFLATE on the device (csrc/nc_inflate.hip): the raw-deflate payloads of n BGZF members (SAMv1 4.1) in two launches -- Huffman decoding, one
+ * lane per member, into tokens; match resolution, one wave per member.  All pointers dev: d_comp = the compressed bytes (readable 8 bytes
+ * past the last payload), d_coff / d_clen = byte offset and length of member b's payload in it, d_out + d_ooff[b] = where its d_isize[b]
+ * (<= 65536) bytes go, d_status[b] = 0 or why the member is not a valid stream of that length; workspace: d_tok = one dword per byte of
+ * output (member b's tokens start at dword d_ooff[b]), d_ntok = n_blocks counters.  Runs on the context's stream.  CRC-32s are not computed
+ * here.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
 int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
-                      const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status);
+                      const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok);
 
 /* ------------------------------------------------------------------ SNP candidate scan (K1)
  * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch

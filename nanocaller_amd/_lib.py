@@ -210,7 +210,7 @@ def lib():
         L.nc_indel_sites_band.argtypes = [vp, i32, i32]
         L.nc_indel_events_pack.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, C.POINTER(i64)]
         L.nc_indel_events_expand.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
-        L.nc_inflate_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.nc_inflate_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.nc_indel_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, i32, vp, i32, vp, vp, vp, vp, C.c_char_p, i64, i32, vp, i64, C.POINTER(i64), vp]
         L.nc_synth_indel_truth.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
         L.nc_synth_indel_reads.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -1,14 +1,17 @@
 // DEFLATE (RFC 1951) on the device: the payloads of BGZF members (SAMv1 4.1: independent raw-deflate streams of at most 64 KB of data each)
-// are inflated in HBM, ONE LANE PER MEMBER -- a BAM of a chr20-sized 30x contig is ~30,000 members, so the launch is as wide as the file is
-// long and needs no cooperation between lanes; its duration is the time ONE lane takes for ONE member, whatever the file's size.  This
-// replaces the host's inflate (libdeflate / zlib on worker threads: 73 % of the ingest of generate_SNP_pileups.py:134-164's input,
-// DESIGN.md section 8) on the way from a BAM file to the read pack.
+// are inflated in HBM.  This replaces the host's inflate (libdeflate / zlib on worker threads: 73 % of the ingest of
+// generate_SNP_pileups.py:134-164's input) on the way from a BAM file to the read pack.
 //
-// Per lane: a 64-bit bit buffer refilled from aligned dwords; Huffman decoding through per-lane first-level tables in LDS (literal / length:
-// 9 bits, distance: 8 bits; entry = symbol << 4 | code length), codes longer than the table's index by the canonical count / symbol walk;
-// a lane is either decoding a symbol or copying up to eight bytes of a match per turn of the loop, so a wave never waits for its longest
-// match.  Stored, fixed and dynamic blocks.  Checked: the stream ends exactly at ISIZE bytes, distances stay inside the output, the input
-// is not overrun.  The CRC-32 of a member is the host's to check (nc_bam.cpp, when the bytes come back) -- the device path checks the lengths.
+// Two kernels, because the two halves of inflate want opposite shapes (DESIGN.md section 11.6 has the measurements that led here):
+//   k_huff   ONE LANE PER MEMBER, 64 members per wave.  Huffman decoding is a serial chain per stream but the SAME short loop for every stream:
+//            64-bit bit buffer refilled from aligned dwords, per-lane first-level tables in LDS (literal / length 9 bits, distance 6 bits;
+//            entry = symbol << 4 | code length), codes longer than the index by the canonical count / symbol walk.  It does NOT copy: a literal
+//            leaves as the token 0x80000000 | byte, a match as length << 16 | distance, one dword per symbol into the member's token run.
+//   k_lz     ONE WAVE PER MEMBER.  64 tokens per step: their output positions by a wave scan, all literals stored at once, the matches in
+//            order with all 64 lanes copying (source and destination in a 64 KB LDS image of the member, so overlapping and chained matches
+//            need no memory fences); the finished member leaves LDS as aligned dwords.
+// Stored, fixed and dynamic blocks.  Checked: the stream ends exactly at ISIZE bytes, distances stay inside the output, the input is not
+// overrun.  The CRC-32 of a member is the host's to check (nc_bam.cpp, when the bytes come back) -- the device path checks the lengths.
 #include "nc_common.h"
 
 namespace {
@@ -17,8 +20,9 @@ constexpr int LT_BITS = 9, DT_BITS = 6, LT_SZ = 1 << LT_BITS, DT_SZ = 1 << DT_BI
 // one lane's LDS, in uint16 units: the two first-level tables, the canonical arrays of both codes (count[16] + sym[]), and the code lengths of
 // the block being set up (bytes; reused as scratch).  A wave's 64 lanes walk these at different places all the time: in scratch memory (HBM
 // latency per access, nothing to hide it behind) the set-up loops and the long-code walk were most of the kernel's 260 ms.
-constexpr int L_LT = 0, L_DT = L_LT + LT_SZ, L_HL = L_DT + DT_SZ, L_HD = L_HL + 16 + 288, L_LENS = L_HD + 16 + 32, L_END = L_LENS + 320 / 2;
+constexpr int L_LT = 0, L_DT = L_LT + LT_SZ, L_HL = L_DT + DT_SZ, L_HD = L_HL + 16 + 288, L_LENS = L_HD + 16 + 32, L_WALK = L_LENS + 320 / 2, L_END = L_WALK + 4;
 constexpr int TAB_WORDS = (L_END + 1) / 2 | 1;                      // odd pitch in words: lanes spread over the banks
+constexpr int WIN_PITCH = 68;                                       // a lane's window of the compressed stream: 64 dwords (+4: 16-byte aligned, banks spread)
 
 struct InflateArgs {
     const uint8_t *comp;        // compressed payloads (the buffer is readable 8 bytes past the last payload)
@@ -90,263 +94,40 @@ __device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uin
     }
 }
 
-__global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
+// where the canonical walk stands after `bits` lengths: w[0] = first code of length bits + 1 (before the shift), w[1] = symbols of length <= bits
+__device__ void walk_start(uint16_t *w, int bits, const uint16_t *h)
+{
+    int first = 0, index = 0;
+    for (int l = 1; l <= bits; l++) {
+        first = (first + h[l]) << 1;
+        index += h[l];
+    }
+    w[0] = (uint16_t)first;
+    w[1] = (uint16_t)index;
+}
+
+__global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32_t *ntok)
 {
     extern __shared__ uint32_t tabs[];
-    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
-    if (b >= a.n) return;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * 64 + lane;
+    const bool live = b < a.n;
     uint16_t *lbase = reinterpret_cast<uint16_t *>(tabs + lane * TAB_WORDS);
     uint16_t *lt = lbase + L_LT, *dt = lbase + L_DT, *hl = lbase + L_HL, *hd = lbase + L_HD;
     uint8_t *lens = reinterpret_cast<uint8_t *>(lbase + L_LENS);
-    const int64_t c0 = a.coff[b];
-    const int32_t clen = a.clen[b], isize = a.isize[b];
-    uint8_t *out = a.out + a.ooff[b];
-    // bit reader over aligned dwords, fetched FOUR at a time and one fetch ahead: a lane has nothing else to hide a load's latency behind (a member
-    // is one lane's serial work), so the next 16 bytes are requested while the current ones are decoded
-    const int skew = (int)(c0 & 3);
-    const uint32_t *wp = reinterpret_cast<const uint32_t *>(a.comp + (c0 & ~int64_t(3)));
-    const int64_t w_end = (skew + clen + 3) / 4 + 2;                   // dwords that may be read (two of slack: the buffer is padded)
-    auto fetch4 = [&](int64_t w) -> U4w {                              // dwords w .. w + 3 (zeros beyond the member's end)
-        U4w v = {0u, 0u, 0u, 0u};
-        if (w + 3 < w_end) v = *reinterpret_cast<const U4w *>(wp + w);
-        else {
-            if (w < w_end) v.x = wp[w];
-            if (w + 1 < w_end) v.y = wp[w + 1];
-            if (w + 2 < w_end) v.z = wp[w + 2];
-        }
-        return v;
-    };
-    U4w cur = fetch4(0), nxt = fetch4(4);
-    int64_t wi = 1;                                                    // dwords consumed
-    uint64_t bb = (uint64_t)(cur.x >> (8 * skew));
-    int bc = 32 - 8 * skew;
-    int err = 0;
-    auto refill = [&]() {
-        if (bc <= 32) {
-            const int k = (int)(wi & 3);
-            if (k == 0) {                                              // the queue turns over: the dwords fetched a while ago become current
-                cur = nxt;
-                nxt = fetch4(wi + 4);
-            }
-            const uint32_t w = k == 0 ? cur.x : k == 1 ? cur.y : k == 2 ? cur.z : cur.w;
-            bb |= (uint64_t)w << bc;
-            if (wi > w_end + 1) err = 5;
-            wi++;
-            bc += 32;
-        }
-    };
-    auto take = [&](int n) -> uint32_t {                               // n <= 16 bits (the caller refilled)
-        const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
-        bb >>= n;
-        bc -= n;
-        return v;
-    };
-    auto slow = [&](const uint16_t *h) -> int {                        // RFC 1951 decoding, one bit at a time (codes longer than a table's index)
-        int code = 0, first = 0, index = 0;
-        for (int l = 1; l < 16; l++) {
-            code |= (int)take(1);
-            const int cnt = h[l];
-            if (code - cnt < first) return h[16 + index + (code - first)];
-            index += cnt;
-            first += cnt;
-            first <<= 1;
-            code <<= 1;
-        }
-        return -1;
-    };
-    int op = 0;
-    int copy_left = 0, copy_dist = 0;
-    bool last = false, in_block = false, stored = false;
-    int stored_left = 0;
-    while (!err) {
-        if (!in_block) {
-            if (last) break;
-            refill();
-            last = take(1) != 0;
-            const int type = (int)take(2);
-            if (type == 0) {
-                // stored: skip to the byte boundary, LEN, NLEN
-                take(bc & 7);
-                refill();
-                const uint32_t len = take(16);
-                refill();
-                const uint32_t nlen = take(16);
-                if ((len ^ 0xffffu) != nlen) { err = 1; break; }
-                stored = true;
-                stored_left = (int)len;
-                in_block = true;
-                if (op + stored_left > isize) { err = 4; break; }
-            } else if (type == 1 || type == 2) {
-                int nlen = 288, ndist = 30;
-                if (type == 1) {
-                    for (int i = 0; i < 144; i++) lens[i] = 8;
-                    for (int i = 144; i < 256; i++) lens[i] = 9;
-                    for (int i = 256; i < 280; i++) lens[i] = 7;
-                    for (int i = 280; i < 288; i++) lens[i] = 8;
-                    for (int i = 0; i < 30; i++) lens[288 + i] = 5;
-                } else {
-                    refill();
-                    nlen = (int)take(5) + 257;
-                    ndist = (int)take(5) + 1;
-                    const int ncode = (int)take(4) + 4;
-                    if (nlen > 286 || ndist > 30) { err = 2; break; }
-                    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                    uint8_t cl[19];
-                    for (int i = 0; i < 19; i++) cl[i] = 0;
-                    for (int i = 0; i < ncode; i++) {
-                        refill();
-                        cl[order[i]] = (uint8_t)take(3);
-                    }
-                    if (!huff_build(hl, cl, 19)) { err = 2; break; }
-                    int idx = 0;
-                    while (idx < nlen + ndist && !err) {
-                        refill();
-                        int sym = slow(hl);
-                        if (sym < 0) { err = 2; break; }
-                        if (sym < 16) lens[idx++] = (uint8_t)sym;
-                        else {
-                            int prev = 0, rep;
-                            refill();
-                            if (sym == 16) {
-                                if (idx == 0) { err = 2; break; }
-                                prev = lens[idx - 1];
-                                rep = 3 + (int)take(2);
-                            } else if (sym == 17) rep = 3 + (int)take(3);
-                            else rep = 11 + (int)take(7);
-                            if (idx + rep > nlen + ndist) { err = 2; break; }
-                            while (rep--) lens[idx++] = (uint8_t)prev;
-                        }
-                    }
-                    if (err) break;
-                    if (lens[256] == 0) { err = 2; break; }
-                    // the distance lengths follow the literal / length ones: move them to their own place
-                    for (int i = ndist - 1; i >= 0; i--) lens[288 + i] = lens[nlen + i];
-                    for (int i = nlen; i < 288; i++) lens[i] = 0;
-                    for (int i = ndist; i < 30; i++) lens[288 + i] = 0;
-                }
-                if (!huff_build(hl, lens, 288) || !huff_build(hd, lens + 288, 30)) { err = 2; break; }
-                table_fill(lt, LT_BITS, hl, lens, 288);
-                table_fill(dt, DT_BITS, hd, lens + 288, 30);
-                stored = false;
-                in_block = true;
-            } else { err = 1; break; }
-            continue;
-        }
-        if (stored) {
-            // whole bytes from the bit buffer
-            if (stored_left == 0) { in_block = false; continue; }
-            refill();
-            int n = min(stored_left, bc >> 3);
-            n = min(n, 4);
-            for (int i = 0; i < n; i++) out[op++] = (uint8_t)take(8);
-            stored_left -= n;
-            continue;
-        }
-        if (copy_left > 0) {                                           // a match in progress: up to eight bytes a turn
-            const int n = min(copy_left, 8);
-            if (copy_dist >= n) {                                      // the sources are all written: eight loads on their way at once, then the stores
-                uint8_t v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = i < n ? out[op - copy_dist + i] : (uint8_t)0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) if (i < n) out[op + i] = v[i];
-            } else {                                                   // an overlapping match repeats its last copy_dist bytes
-                uint8_t v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = i < copy_dist ? out[op - copy_dist + i] : (uint8_t)0;
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (i < n) {
-                        const int j = i % copy_dist;                   // (copy_dist <= 7 here)
-                        uint8_t b = v[0];
-#pragma unroll
-                        for (int q = 1; q < 8; q++) b = j == q ? v[q] : b;
-                        out[op + i] = b;
-                    }
-            }
-            op += n;
-            copy_left -= n;
-            continue;
-        }
-        refill();
-        int sym;
-        {
-            const uint32_t e = lt[(uint32_t)bb & (LT_SZ - 1)];
-            if (e) { take(e & 15); sym = (int)(e >> 4); }
-            else sym = slow(hl);
-        }
-        if (sym < 0) { err = 3; break; }
-        if (sym < 256) {
-            if (op >= isize) { err = 4; break; }
-            out[op++] = (uint8_t)sym;
-        } else if (sym == 256) {
-            in_block = false;
-        } else {
-            const int c = sym - 257;
-            if (c > 28) { err = 3; break; }
-            refill();
-            int len;
-            if (c < 8) len = 3 + c;
-            else if (c == 28) len = 258;
-            else {
-                const int e = (c >> 2) - 1;
-                len = 3 + ((4 + (c & 3)) << e) + (int)take(e);
-            }
-            refill();
-            int dsym;
-            {
-                const uint32_t e = dt[(uint32_t)bb & (DT_SZ - 1)];
-                if (e) { take(e & 15); dsym = (int)(e >> 4); }
-                else dsym = slow(hd);
-            }
-            if (dsym < 0 || dsym > 29) { err = 3; break; }
-            refill();
-            int dist;
-            if (dsym < 4) dist = 1 + dsym;
-            else {
-                const int e = (dsym >> 1) - 1;
-                dist = 1 + ((2 + (dsym & 1)) << e) + (int)take(e);
-            }
-            if (dist > op) { err = 3; break; }
-            if (op + len > isize) { err = 4; break; }
-            copy_left = len;
-            copy_dist = dist;
-        }
-    }
-    if (!err && op != isize) err = 6;
-    a.status[b] = err;
-}
-
-// ---- the cooperative form: SIXTEEN lanes per member, four members per wave.  Lane 0 of a group is the member's decoder: bit buffer, Huffman
-// tables (the same per-member LDS tables as above), one symbol at a time -- but only FOUR lanes of a wave decode, so the wave executes the union of
-// four decoders' paths, not of sixty-four (what bounded k_inflate).  The member's output lives in an 8 KB LDS ring: literals are single LDS writes of
-// the decoder lane (up to eight per turn), a match is copied by all sixteen lanes (from the ring, or -- distances beyond the ring -- from the part
-// of the output already flushed to HBM), and every 2 KB the sixteen lanes move a finished stretch of the ring to HBM.
-constexpr int G_TAB = (2 * L_END + 255) & ~255;                     // bytes of a group's tables
-
-template <int RING, int DBG = 0>
-__global__ __launch_bounds__(64) void k_inflate16(InflateArgs a)
-{
-    int dbg = 0;
-    constexpr int RMASK = RING - 1, FLUSH = RING / 4, G_LDS = G_TAB + RING;
-    extern __shared__ uint32_t tabs[];
-    const int lane = threadIdx.x, gi = lane >> 4, l16 = lane & 15, lead = lane & 48;
-    const int b = blockIdx.x * 4 + gi;
-    const bool live = b < a.n;
-    uint8_t *gbase = reinterpret_cast<uint8_t *>(tabs) + gi * G_LDS;
-    uint16_t *lbase = reinterpret_cast<uint16_t *>(gbase);
-    uint16_t *lt = lbase + L_LT, *dt = lbase + L_DT, *hl = lbase + L_HL, *hd = lbase + L_HD;
-    uint8_t *lens = reinterpret_cast<uint8_t *>(lbase + L_LENS);
-    uint8_t *ring = gbase + G_TAB;
+    uint16_t *wk = lbase + L_WALK;
     const int bb_ = live ? b : 0;
     const int64_t c0 = a.coff[bb_];
     const int32_t clen = a.clen[bb_], isize = a.isize[bb_];
-    uint8_t *out = a.out + a.ooff[bb_];
-    const bool dec = live && l16 == 0;
+    uint32_t *tk = tok + a.ooff[bb_];                                  // a token is at least one byte of output: the run is at most isize long
+    // the compressed stream reaches the bit buffer through a per-lane LDS window of 64 dwords.  A global load inside the symbol loop costs
+    // the WAVE a memory round trip (the s_waitcnt before its first use also waits for every token store in flight): with the loads of all
+    // lanes issued together every 16 steps, and written to the window 16 steps later, that wait is paid once per 16 steps and is short.
     const int skew = (int)(c0 & 3);
     const uint32_t *wp = reinterpret_cast<const uint32_t *>(a.comp + (c0 & ~int64_t(3)));
-    const int64_t w_end = (skew + clen + 3) / 4 + 2;
-    auto fetch4 = [&](int64_t w) -> U4w {
+    const int w_end = (skew + clen + 3) / 4 + 2;                       // dwords of the stream (+2: the last code may be looked up past its end)
+    uint32_t *win = tabs + 64 * TAB_WORDS + lane * WIN_PITCH;
+    auto fetch4 = [&](int w) -> U4w {
         U4w v = {0u, 0u, 0u, 0u};
         if (w + 3 < w_end) v = *reinterpret_cast<const U4w *>(wp + w);
         else {
@@ -356,27 +137,36 @@ __global__ __launch_bounds__(64) void k_inflate16(InflateArgs a)
         }
         return v;
     };
-    U4w cur = {0u, 0u, 0u, 0u}, nxt = {0u, 0u, 0u, 0u};
-    int64_t wi = 1;
+    int rd = 0, wr = 0, pend = 0;                                      // dwords consumed / in the window / loaded but still in registers
+    U4w pre[6];
     uint64_t bb = 0;
     int bc = 0, err = 0;
-    if (dec) {
-        cur = fetch4(0);
-        nxt = fetch4(4);
-        bb = (uint64_t)(cur.x >> (8 * skew));
+    if (live) {
+#pragma unroll 1
+        for (; wr < 64; wr += 4) *reinterpret_cast<U4w *>(win + wr) = fetch4(wr);
+        bb = (uint64_t)(win[0] >> (8 * skew));
         bc = 32 - 8 * skew;
+        rd = 1;
     }
-    auto refill = [&]() {
+    // every 16 iterations of a loop that consumes at most 48 bits per iteration: what the previous call loaded goes to the window, the window's
+    // free part is loaded (at most 96 bytes: what 16 iterations can consume, so the window never runs dry: >= 24 dwords after every call)
+    auto tick = [&]() {
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q * 4 < pend) *reinterpret_cast<U4w *>(win + ((wr + q * 4) & 63)) = pre[q];
+        wr += pend;
+        int n4 = (64 - (wr - rd)) >> 2;
+        n4 = n4 > 6 ? 6 : n4;
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q < n4) pre[q] = fetch4(wr + q * 4);
+        pend = n4 * 4;
+    };
+    auto refill = [&]() {                                              // at least 33 valid bits afterwards
         if (bc <= 32) {
-            const int k = (int)(wi & 3);
-            if (k == 0) {
-                cur = nxt;
-                nxt = fetch4(wi + 4);
-            }
-            const uint32_t w = k == 0 ? cur.x : k == 1 ? cur.y : k == 2 ? cur.z : cur.w;
-            bb |= (uint64_t)w << bc;
-            if (wi > w_end + 1) err = 5;
-            wi++;
+            bb |= (uint64_t)win[rd & 63] << bc;
+            if (rd > w_end + 1) err = 5;
+            rd++;
             bc += 32;
         }
     };
@@ -386,8 +176,9 @@ __global__ __launch_bounds__(64) void k_inflate16(InflateArgs a)
         bc -= n;
         return v;
     };
-    auto slow = [&](const uint16_t *h) -> int {
+    auto slow = [&](const uint16_t *h) -> int {                        // RFC 1951 decoding, one bit at a time (the code length code)
         int code = 0, first = 0, index = 0;
+#pragma unroll 1
         for (int l = 1; l < 16; l++) {
             code |= (int)take(1);
             const int cnt = h[l];
@@ -399,222 +190,252 @@ __global__ __launch_bounds__(64) void k_inflate16(InflateArgs a)
         }
         return -1;
     };
-    int op = 0, flushed = 0;                                           // group-uniform: bytes produced / bytes already in HBM
-    bool last = false, in_block = false, stored = false, done = !live;
-    int stored_left = 0;
-    while (!__all(done)) {
-        if (DBG == 1) dbg++;
-        // ---- the decoder lane: literals into the ring (up to eight), until a match, the stream's end or an error
-        int nlit = 0, kind = 0, mlen = 0, mdist = 0;                   // kind 1: a match follows the literals; 2: the member is finished (or broken)
-        if (dec && !done) {
-            for (;;) {
-                if (err) { kind = 2; break; }
-                if (!in_block) {
-                    if (last) { kind = 2; break; }
+    // the same walk for a code the first-level table has no entry for: it is longer than the table's index, so the walk starts behind those bits
+    auto slow_from = [&](const uint16_t *h, const uint16_t *w, int bits) -> int {
+        int code = (int)(__brev(take(bits)) >> (32 - bits)) << 1, first = w[0], index = w[1];
+#pragma unroll 1
+        for (int l = bits + 1; l < 16; l++) {
+            code |= (int)take(1);
+            const int cnt = h[l];
+            if (code - cnt < first) return h[16 + index + (code - first)];
+            index += cnt;
+            first += cnt;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    };
+    int op = 0, nt = 0;
+    bool fin = !live;
+#pragma unroll 1
+    while (!fin) {                                                     // one turn per deflate block: the lanes of a wave set their tables up together
+        refill();
+        const bool last = take(1) != 0;
+        const int type = (int)take(2);
+        if (type == 0) {                                               // stored: skip to the byte boundary, LEN, NLEN, the bytes
+            take(bc & 7);
+            refill();
+            const uint32_t len = take(16);
+            refill();
+            const uint32_t nlen = take(16);
+            if ((len ^ 0xffffu) != nlen) err = 1;
+            else if (op + (int)len > isize) err = 4;
+            else {
+#pragma unroll 1
+                for (uint32_t i = 0; i < len; i++) {
+                    if ((i & 15) == 0) tick();
                     refill();
-                    last = take(1) != 0;
-                    const int type = (int)take(2);
-                    if (type == 0) {
-                        take(bc & 7);
-                        refill();
-                        const uint32_t len = take(16);
-                        refill();
-                        const uint32_t nl = take(16);
-                        if ((len ^ 0xffffu) != nl) { err = 1; continue; }
-                        stored = true;
-                        stored_left = (int)len;
-                        in_block = true;
-                    } else if (type == 1 || type == 2) {
-                        int nlen = 288, ndist = 30;
-                        if (type == 1) {
-                            for (int i = 0; i < 144; i++) lens[i] = 8;
-                            for (int i = 144; i < 256; i++) lens[i] = 9;
-                            for (int i = 256; i < 280; i++) lens[i] = 7;
-                            for (int i = 280; i < 288; i++) lens[i] = 8;
-                            for (int i = 0; i < 30; i++) lens[288 + i] = 5;
-                        } else {
-                            refill();
-                            nlen = (int)take(5) + 257;
-                            ndist = (int)take(5) + 1;
-                            const int ncode = (int)take(4) + 4;
-                            if (nlen > 286 || ndist > 30) { err = 2; continue; }
-                            uint8_t *cl = reinterpret_cast<uint8_t *>(hd);  // 19 code-length-code lengths, in the distance code's area (built later)
-                            for (int i = 0; i < 19; i++) cl[i] = 0;
-                            for (int i = 0; i < ncode; i++) {
-                                refill();
-                                // order of the code length alphabet (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
-                                int sym;
-                                if (i < 3) sym = 16 + i;
-                                else if (i == 3) sym = 0;
-                                else if ((i & 1) == 0) sym = 8 + ((i - 4) >> 1);      // i = 4, 6, 8, ... -> 8, 9, 10, ...
-                                else sym = 7 - ((i - 5) >> 1);                         // i = 5, 7, 9, ... -> 7, 6, 5, ...
-                                cl[sym] = (uint8_t)take(3);
-                            }
-                            if (!huff_build(hl, cl, 19)) { err = 2; continue; }
-                            int idx = 0;
-                            while (idx < nlen + ndist && !err) {
-                                refill();
-                                const int sym = slow(hl);
-                                if (sym < 0) { err = 2; break; }
-                                if (sym < 16) lens[idx++] = (uint8_t)sym;
-                                else {
-                                    int prev = 0, rep;
-                                    refill();
-                                    if (sym == 16) {
-                                        if (idx == 0) { err = 2; break; }
-                                        prev = lens[idx - 1];
-                                        rep = 3 + (int)take(2);
-                                    } else if (sym == 17) rep = 3 + (int)take(3);
-                                    else rep = 11 + (int)take(7);
-                                    if (idx + rep > nlen + ndist) { err = 2; break; }
-                                    while (rep--) lens[idx++] = (uint8_t)prev;
-                                }
-                            }
-                            if (err) continue;
-                            if (lens[256] == 0) { err = 2; continue; }
-                            for (int i = ndist - 1; i >= 0; i--) lens[288 + i] = lens[nlen + i];
-                            for (int i = nlen; i < 288; i++) lens[i] = 0;
-                            for (int i = ndist; i < 30; i++) lens[288 + i] = 0;
-                        }
-                        if (!huff_build(hl, lens, 288) || !huff_build(hd, lens + 288, 30)) { err = 2; continue; }
-                        table_fill(lt, LT_BITS, hl, lens, 288);
-                        table_fill(dt, DT_BITS, hd, lens + 288, 30);
-                        stored = false;
-                        in_block = true;
-                    } else err = 1;
-                    continue;
+                    tk[nt++] = 0x80000000u | take(8);
                 }
-                if (nlit == 8) break;
-                if (stored) {
-                    if (stored_left == 0) { in_block = false; continue; }
-                    if (op + nlit >= isize) { err = 4; continue; }
+                op += (int)len;
+            }
+        } else if (type == 3) err = 1;
+        else {
+            int nlen = 288, ndist = 30;
+            if (type == 1) {
+                for (int i = 0; i < 144; i++) lens[i] = 8;
+                for (int i = 144; i < 256; i++) lens[i] = 9;
+                for (int i = 256; i < 280; i++) lens[i] = 7;
+                for (int i = 280; i < 288; i++) lens[i] = 8;
+                for (int i = 0; i < 30; i++) lens[288 + i] = 5;
+            } else {
+                refill();
+                nlen = (int)take(5) + 257;
+                ndist = (int)take(5) + 1;
+                const int ncode = (int)take(4) + 4;
+                if (nlen > 286 || ndist > 30) err = 2;
+                uint8_t *cl = reinterpret_cast<uint8_t *>(hd);         // 19 code-length-code lengths, in the distance code's area (built later)
+                for (int i = 0; i < 19; i++) cl[i] = 0;
+#pragma unroll 1
+                for (int i = 0; i < ncode; i++) {
                     refill();
-                    ring[(op + nlit) & RMASK] = (uint8_t)take(8);
-                    nlit++;
-                    stored_left--;
-                    continue;
+                    // order of the code length alphabet (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                    const int sym = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) == 0 ? 8 + ((i - 4) >> 1) : 7 - ((i - 5) >> 1);
+                    cl[sym] = (uint8_t)take(3);
                 }
+                if (!err && !huff_build(hl, cl, 19)) err = 2;
+                int idx = 0;
+#pragma unroll 1
+                for (int it = 0; !err && idx < nlen + ndist; it++) {
+                    if ((it & 15) == 0) tick();
+                    refill();
+                    const int sym = slow(hl);
+                    if (sym < 0) { err = 2; break; }
+                    if (sym < 16) lens[idx++] = (uint8_t)sym;
+                    else {
+                        int prev = 0, rep;
+                        refill();
+                        if (sym == 16) {
+                            if (idx == 0) { err = 2; break; }
+                            prev = lens[idx - 1];
+                            rep = 3 + (int)take(2);
+                        } else if (sym == 17) rep = 3 + (int)take(3);
+                        else rep = 11 + (int)take(7);
+                        if (idx + rep > nlen + ndist) { err = 2; break; }
+                        while (rep--) lens[idx++] = (uint8_t)prev;
+                    }
+                }
+                if (!err && lens[256] == 0) err = 2;
+                if (!err) {                                            // the distance lengths follow the literal / length ones: move them to their own place
+                    for (int i = ndist - 1; i >= 0; i--) lens[288 + i] = lens[nlen + i];
+                    for (int i = nlen; i < 288; i++) lens[i] = 0;
+                    for (int i = ndist; i < 30; i++) lens[288 + i] = 0;
+                }
+            }
+            if (!err && (!huff_build(hl, lens, 288) || !huff_build(hd, lens + 288, 30))) err = 2;
+            if (!err) {
+                table_fill(lt, LT_BITS, hl, lens, 288);
+                table_fill(dt, DT_BITS, hd, lens + 288, 30);
+                walk_start(wk, LT_BITS, hl);
+                walk_start(wk + 2, DT_BITS, hd);
+            }
+            // ---- the symbols of the block: the loop the kernel lives in
+            const bool more = !err;
+#pragma unroll 1
+            for (int it = 0; more; it++) {
+                if ((it & 15) == 0) tick();
                 refill();
                 int sym;
                 {
                     const uint32_t e = lt[(uint32_t)bb & (LT_SZ - 1)];
                     if (e) { take(e & 15); sym = (int)(e >> 4); }
-                    else { sym = slow(hl); if (DBG == 4) dbg++; }
+                    else sym = slow_from(hl, wk, LT_BITS);
                 }
-                if (sym < 0) { err = 3; continue; }
-                if (DBG == 2 && sym < 256) dbg++;
-                if (DBG == 3 && sym > 256) dbg++;
-                if (DBG == 5 && sym == 256) dbg++;
                 if (sym < 256) {
-                    if (op + nlit >= isize) { err = 4; continue; }
-                    ring[(op + nlit) & RMASK] = (uint8_t)sym;
-                    nlit++;
+                    if (sym < 0) { err = 3; break; }
+                    if (op >= isize) { err = 4; break; }
+                    tk[nt++] = 0x80000000u | (uint32_t)sym;
+                    op++;
                     continue;
                 }
-                if (sym == 256) { in_block = false; continue; }
+                if (sym == 256) break;
                 const int c = sym - 257;
-                if (c > 28) { err = 3; continue; }
-                refill();
-                if (c < 8) mlen = 3 + c;
-                else if (c == 28) mlen = 258;
+                if (c > 28) { err = 3; break; }
+                int len;
+                if (c < 8) len = 3 + c;
+                else if (c == 28) len = 258;
                 else {
                     const int e = (c >> 2) - 1;
-                    mlen = 3 + ((4 + (c & 3)) << e) + (int)take(e);
+                    len = 3 + ((4 + (c & 3)) << e) + (int)take(e);  // (a length code and its extra bits: at most 20 bits, inside the 33 of the refill)
                 }
                 refill();
                 int dsym;
                 {
                     const uint32_t e = dt[(uint32_t)bb & (DT_SZ - 1)];
                     if (e) { take(e & 15); dsym = (int)(e >> 4); }
-                    else dsym = slow(hd);
+                    else dsym = slow_from(hd, wk + 2, DT_BITS);
                 }
-                if (dsym < 0 || dsym > 29) { err = 3; continue; }
-                refill();
-                if (dsym < 4) mdist = 1 + dsym;
+                if (dsym < 0 || dsym > 29) { err = 3; break; }
+                int dist;
+                if (dsym < 4) dist = 1 + dsym;
                 else {
                     const int e = (dsym >> 1) - 1;
-                    mdist = 1 + ((2 + (dsym & 1)) << e) + (int)take(e);
+                    dist = 1 + ((2 + (dsym & 1)) << e) + (int)take(e);  // (15 + 13 bits)
                 }
-                if (mdist > op + nlit) { err = 3; continue; }
-                if (op + nlit + mlen > isize) { err = 4; continue; }
-                kind = 1;
-                break;
+                if (dist > op) { err = 3; break; }
+                if (op + len > isize) { err = 4; break; }
+                tk[nt++] = (uint32_t)len << 16 | (uint32_t)dist;
+                op += len;
             }
         }
-        // ---- the group: what the decoder found
-        const int word = __shfl(nlit | (kind << 4) | (mlen << 8), lead);
-        mdist = __shfl(mdist, lead);
-        nlit = word & 15; kind = (word >> 4) & 3; mlen = word >> 8;
-        op += nlit;
-        if (kind == 1) {
-            const bool near = mdist <= RING - 512;                     // every source is still in the ring (the copy overwrites at most 258 of its oldest bytes)
-            const float rinv = 1.0f / (float)mdist;
-            for (int k = l16; k < mlen; k += 16) {
-                int j = k;
-                if (mdist < mlen) {                                    // an overlapping match repeats its last mdist bytes: byte k = byte k mod mdist
-                    int q = (int)((float)k * rinv);
-                    j = k - q * mdist;
-                    if (j < 0) j += mdist;
-                    if (j >= mdist) j -= mdist;
-                }
-                const int src = op - mdist + j;
-                const uint8_t v = near ? ring[src & RMASK] : out[src];
-                ring[(op + k) & RMASK] = v;
-            }
-            op += mlen;
-        }
-        // ---- finished stretches of the ring go to HBM
-        const int upto = kind == 2 ? op : op - (op - flushed) % FLUSH;
-        if (upto - flushed >= FLUSH || (kind == 2 && upto > flushed)) {
-            for (int i = flushed + l16; i < upto; i += 16) out[i] = ring[i & RMASK];
-            flushed = upto;
-        }
-        if (kind == 2) {
-            if (dec) a.status[b] = DBG ? dbg : err ? err : (op != isize ? 6 : 0);
-            done = true;
-        }
+        if (err || last) fin = true;
+    }
+    if (live) {
+        if (!err && op != isize) err = 6;
+        ntok[b] = nt;
+        a.status[b] = err;
     }
 }
 
-bool g_lds_set[64] = {false};
+// a wave's inclusive prefix sum
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const int32_t *ntok, uint8_t *out, const int64_t *ooff, const int32_t *isize,
+                                           const int32_t *status)
+{
+    extern __shared__ uint32_t obuf_w[];
+    uint8_t *obuf = reinterpret_cast<uint8_t *>(obuf_w);
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (status[b]) return;
+    const int nt = ntok[b], total = isize[b];
+    const uint32_t *tk = tok + ooff[b];
+    int base = 0;
+#pragma unroll 1
+    for (int c = 0; c < nt; c += 64) {
+        const int i = c + lane;
+        const uint32_t t = i < nt ? tk[i] : 0u;
+        const bool lit = (t >> 31) != 0;
+        const int len = lit ? 1 : (int)(t >> 16), dist = (int)(t & 0xffffu);
+        const int incl = wave_scan_incl(len, lane);
+        const int pos = base + incl - len;
+        if (lit) obuf[pos] = (uint8_t)t;
+        uint64_t m = __ballot(!lit && len > 0);
+#pragma unroll 1
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int P = __builtin_amdgcn_readlane(pos, j), L = __builtin_amdgcn_readlane(len, j), D = __builtin_amdgcn_readlane(dist, j);
+            if (D >= L) {
+                for (int k = lane; k < L; k += 64) obuf[P + k] = obuf[P - D + k];
+            } else {                                                   // an overlapping match repeats its last D bytes: byte k = byte k mod D
+                const float rinv = 1.0f / (float)D;
+                for (int k = lane; k < L; k += 64) {
+                    const int q = (int)((float)k * rinv);
+                    int r = k - q * D;
+                    if (r < 0) r += D;
+                    if (r >= D) r -= D;
+                    obuf[P + k] = obuf[P - D + r];
+                }
+            }
+        }
+        base += __builtin_amdgcn_readlane(incl, 63);
+    }
+    // the member leaves LDS: bytes up to the first aligned dword of the destination, dwords, the tail
+    uint8_t *o = out + ooff[b];
+    const int head = (int)((4 - (reinterpret_cast<uintptr_t>(o) & 3)) & 3);
+    if (lane < head && lane < total) o[lane] = obuf[lane];
+    const int nw = total > head ? (total - head) >> 2 : 0;
+    uint32_t *ow = reinterpret_cast<uint32_t *>(o + head);
+    for (int w = lane; w < nw; w += 64) {
+        const uint32_t lo = obuf_w[w], hi = obuf_w[w + 1];              // (obuf_w has a dword of slack)
+        ow[w] = __builtin_amdgcn_alignbyte(hi, lo, head);
+    }
+    const int done = head + 4 * nw;
+    if (done + lane < total) o[done + lane] = obuf[done + lane];
+}
 
 }   // namespace
 
+// d_tok: workspace of one dword per byte of output (the token run of member b starts at dword d_ooff[b]); d_ntok: n_blocks counters
 extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
-                                 const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status)
+                                 const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok)
 {
     if (!ctx) return NC_ERR_ARG;
-    if (n_blocks < 0 || (n_blocks && (!d_comp || !d_coff || !d_clen || !d_out || !d_ooff || !d_isize || !d_status)))
+    if (n_blocks < 0 || (n_blocks && (!d_comp || !d_coff || !d_clen || !d_out || !d_ooff || !d_isize || !d_status || !d_tok || !d_ntok)))
         return nc_fail(ctx, NC_ERR_ARG, "nc_inflate_device: bad argument");
     if (n_blocks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t lds = (size_t)64 * TAB_WORDS * 4;
-    if (ctx->device >= 0 && ctx->device < 64 && !g_lds_set[ctx->device]) {
-        NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        g_lds_set[ctx->device] = true;
+    const size_t lds_h = (size_t)64 * (TAB_WORDS + WIN_PITCH) * 4, lds_z = 65536 + 16;
+    static bool set[64] = {false};
+    if (ctx->device >= 0 && ctx->device < 64 && !set[ctx->device]) {
+        NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+        NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_z));
+        set[ctx->device] = true;
     }
     InflateArgs a;
     a.comp = d_comp; a.coff = d_coff; a.clen = d_clen; a.out = d_out; a.ooff = d_ooff; a.isize = d_isize; a.n = n_blocks; a.status = d_status;
-    if (!getenv("NC_INFLATE_LANE_PER_MEMBER")) {                    // default: sixteen lanes per member
-        const char *rv = getenv("NC_INFLATE_RING");
-        const int ring = rv ? atoi(rv) : 2048;
-        const size_t lds16 = (size_t)4 * (G_TAB + ring);
-        const dim3 grid((n_blocks + 3) / 4), block(64);
-        const char *dv = getenv("NC_INFLATE_DEBUG");                   // experiment counters in status[]: 1 turns, 2 literals, 3 matches, 4 long codes, 5 blocks
-        const int d = dv ? atoi(dv) : 0;
-        if (d == 1) hipLaunchKernelGGL((k_inflate16<2048, 1>), grid, block, lds16, ctx->stream, a);
-        else if (d == 2) hipLaunchKernelGGL((k_inflate16<2048, 2>), grid, block, lds16, ctx->stream, a);
-        else if (d == 3) hipLaunchKernelGGL((k_inflate16<2048, 3>), grid, block, lds16, ctx->stream, a);
-        else if (d == 4) hipLaunchKernelGGL((k_inflate16<2048, 4>), grid, block, lds16, ctx->stream, a);
-        else if (d == 5) hipLaunchKernelGGL((k_inflate16<2048, 5>), grid, block, lds16, ctx->stream, a);
-        else if (ring == 8192) hipLaunchKernelGGL(k_inflate16<8192>, grid, block, lds16, ctx->stream, a);
-        else if (ring == 4096) hipLaunchKernelGGL(k_inflate16<4096>, grid, block, lds16, ctx->stream, a);
-        else if (ring == 2048) hipLaunchKernelGGL(k_inflate16<2048>, grid, block, lds16, ctx->stream, a);
-        else return nc_fail(ctx, NC_ERR_ARG, "NC_INFLATE_RING: 2048, 4096 or 8192");
-        NC_HIP(ctx, hipGetLastError());
-        return NC_OK;
-    }
-    hipLaunchKernelGGL(k_inflate, dim3((n_blocks + 63) / 64), dim3(64), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_huff, dim3((n_blocks + 63) / 64), dim3(64), lds_h, ctx->stream, a, d_tok, d_ntok);
+    NC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_lz, dim3(n_blocks), dim3(64), lds_z, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out, d_ooff, d_isize,
+                       (const int32_t *)d_status);
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
 }

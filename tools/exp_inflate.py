@@ -54,12 +54,14 @@ d_out = torch.zeros(int(ooff[-1]) + 16, dtype=torch.uint8, device=dev)
 d_ooff = torch.from_numpy(ooff[:-1].copy()).to(dev)
 d_isize = torch.tensor(isize, dtype=torch.int32, device=dev)
 d_st = torch.zeros(len(coff), dtype=torch.int32, device=dev)
+d_tok = torch.empty(int(ooff[-1]) + 16, dtype=torch.int32, device=dev)
+d_ntok = torch.zeros(len(coff), dtype=torch.int32, device=dev)
 eng.use_torch_stream()
 for rep in range(4):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = eng.L.nc_inflate_device(eng.ctx, len(coff), d_comp.data_ptr(), d_coff.data_ptr(), d_clen.data_ptr(), d_out.data_ptr(), d_ooff.data_ptr(),
-                                 d_isize.data_ptr(), d_st.data_ptr())
+                                 d_isize.data_ptr(), d_st.data_ptr(), d_tok.data_ptr(), d_ntok.data_ptr())
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
