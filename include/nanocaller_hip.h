@@ -29,7 +29,7 @@ extern "C" {
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
-                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device */
+                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members + nc_bam_walk / _meta / _codes (BAM ingest on the device) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -183,11 +183,35 @@ int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_sta
 /* DEFLATE on the device (csrc/nc_inflate.hip): the raw-deflate payloads of n BGZF members (SAMv1 4.1) in two launches -- Huffman decoding, one
  * lane per member, into tokens; match resolution, one wave per member.  All pointers dev: d_comp = the compressed bytes (readable 8 bytes
  * past the last payload), d_coff / d_clen = byte offset and length of member b's payload in it, d_out + d_ooff[b] = where its d_isize[b]
- * (<= 65536) bytes go, d_status[b] = 0 or why the member is not a valid stream of that length; workspace: d_tok = one dword per byte of
- * output (member b's tokens start at dword d_ooff[b]), d_ntok = n_blocks counters.  Runs on the context's stream.  CRC-32s are not computed
+ * (<= 65536) bytes go, d_status[b] = 0 or why the member is not a valid stream of that length; workspace: d_tok = ceil(n_blocks / 64)
+ * x 4,194,304 dwords (64 members x 65,536 tokens), d_ntok = n_blocks counters.  Runs on the context's stream.  CRC-32s are not computed
  * here.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
 int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
                       const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok);
+
+/* BAM records on the device (csrc/nc_ingest.hip): from the inflated BGZF stream in HBM to the slots of the read pack, for the SNP route --
+ * what nc_bam_decode + nc_pack_fill do on host threads (generate_SNP_pileups.py:134-164's input).
+ * nc_bgzf_members (host): the members of a BGZF file image: payload offset / length and inflated size of each (the arguments of
+ *   nc_inflate_device).  NC_ERR_CAPACITY when there are more than `cap` (n_members counts them all), NC_ERR_ARG for a malformed member.
+ * nc_bam_walk: record boundaries.  d_seed = n_seeds record starts, ascending offsets into d_raw (the entries of the .bai linear index),
+ *   d_seed_tid = the contig of each.  d_first == NULL: d_out[i] = records from seed i up to seed i + 1 / the end of the contig's records;
+ *   else d_out[d_first[i] + k] = offset of the k-th of them (d_first = exclusive prefix sums of the counts).  d_status (one int32, zeroed
+ *   by the caller): bit 0 a block_size below 32, bit 1 an index entry that is not a record start, bit 2 (nc_bam_meta) a record whose
+ *   fields do not fit its block_size.
+ * nc_bam_meta: d_meta = int32 [NC_BAM_META_COLS][n_rec], field-major: refID, pos (0-based), flag (| NC_FLAG_REFSKIP), reference span of
+ *   the CIGAR (0: not an alignment nc_bam_decode would return), l_seq, 1 if the record carries the bases its CIGAR consumes, HP (0/1/2),
+ *   PS, FNV-1a hash of the read name (low, high), operations of the real CIGAR (the CG tag's for SAMv1 4.2.2 placeholders), its byte
+ *   offset from the record's refID field.
+ * nc_bam_codes: the slots of n_reads kept reads (d_rec = record offsets, d_slot = byte offset of each slot in d_codes, nc_pack_fill's
+ *   layout; d_cigd / d_ncig = the last two meta columns, bit 31 of d_ncig set = no usable bases: code 4 everywhere; d_start = 1-based
+ *   first position).  d_codes holds NC_CODE_ABSENT everywhere beforehand; the result is byte for byte what nc_pack_fill writes. */
+#define NC_BAM_META_COLS 12
+int nc_bgzf_members(const uint8_t *data, int64_t n, int64_t cap, int64_t *coff, int32_t *clen, int32_t *isize, int64_t *n_members);
+int nc_bam_walk(nc_ctx *ctx, const uint8_t *d_raw, int64_t raw_len, int32_t n_seeds, const int64_t *d_seed, const int32_t *d_seed_tid,
+                const int64_t *d_first, int64_t *d_out, int32_t *d_status);
+int nc_bam_meta(nc_ctx *ctx, const uint8_t *d_raw, int64_t n_rec, const int64_t *d_rec_off, int32_t *d_meta, int32_t *d_status);
+int nc_bam_codes(nc_ctx *ctx, const uint8_t *d_raw, int32_t n_reads, const int64_t *d_rec, const int64_t *d_slot, const int32_t *d_cigd,
+                 const int32_t *d_ncig, const int32_t *d_start, uint8_t *d_codes);
 
 /* ------------------------------------------------------------------ SNP candidate scan (K1)
  * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch

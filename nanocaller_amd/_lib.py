@@ -42,7 +42,7 @@ EXPORTS = [
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
     "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
-    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
+    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_bgzf_members", "nc_bam_walk", "nc_bam_meta", "nc_bam_codes", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
 ]
 
 
@@ -126,6 +126,12 @@ def lib():
             raise NanoCallerHipError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # torch first: it brings its own HIP runtime, and the library must bind to THAT one -- loaded the other way round the process holds
+        # two runtimes and nc_ctx_create fails on the first stream (seen when a host-only entry point was the first call of a process)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.nc_abi_version.restype = C.c_int
@@ -211,6 +217,10 @@ def lib():
         L.nc_indel_events_pack.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, C.POINTER(i64)]
         L.nc_indel_events_expand.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.nc_inflate_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.nc_bgzf_members.argtypes = [vp, i64, i64, vp, vp, vp, C.POINTER(i64)]
+        L.nc_bam_walk.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
+        L.nc_bam_meta.argtypes = [vp, vp, i64, vp, vp, vp]
+        L.nc_bam_codes.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.nc_indel_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, i32, vp, i32, vp, vp, vp, vp, C.c_char_p, i64, i32, vp, i64, C.POINTER(i64), vp]
         L.nc_synth_indel_truth.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
         L.nc_synth_indel_reads.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]

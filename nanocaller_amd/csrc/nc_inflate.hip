@@ -119,7 +119,9 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
     const int bb_ = live ? b : 0;
     const int64_t c0 = a.coff[bb_];
     const int32_t clen = a.clen[bb_], isize = a.isize[bb_];
-    uint32_t *tk = tok + a.ooff[bb_];                                  // a token is at least one byte of output: the run is at most isize long
+    // token i of the wave's lane l is dword (i * 64 + l) of the wave's 64 x 65536 dwords: lanes decode in step, so a step's 64 tokens are one
+    // 256-byte store (member-major runs made it 64 partial lines on a handful of channels: the store queue bounded the loop)
+    uint32_t *tk = tok + ((size_t)blockIdx.x << 22) + lane;
     // the compressed stream reaches the bit buffer through a per-lane LDS window of 64 dwords.  A global load inside the symbol loop costs
     // the WAVE a memory round trip (the s_waitcnt before its first use also waits for every token store in flight): with the loads of all
     // lanes issued together every 16 steps, and written to the window 16 steps later, that wait is paid once per 16 steps and is short.
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
                 for (uint32_t i = 0; i < len; i++) {
                     if ((i & 15) == 0) tick();
                     refill();
-                    tk[nt++] = 0x80000000u | take(8);
+                    tk[(size_t)(nt++) << 6] = 0x80000000u | take(8);
                 }
                 op += (int)len;
             }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
                 if (sym < 256) {
                     if (sym < 0) { err = 3; break; }
                     if (op >= isize) { err = 4; break; }
-                    tk[nt++] = 0x80000000u | (uint32_t)sym;
+                    tk[(size_t)(nt++) << 6] = 0x80000000u | (uint32_t)sym;
                     op++;
                     continue;
                 }
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
                 }
                 if (dist > op) { err = 3; break; }
                 if (op + len > isize) { err = 4; break; }
-                tk[nt++] = (uint32_t)len << 16 | (uint32_t)dist;
+                tk[(size_t)(nt++) << 6] = (uint32_t)len << 16 | (uint32_t)dist;
                 op += len;
             }
         }
@@ -366,12 +368,12 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
     const int lane = threadIdx.x, b = blockIdx.x;
     if (status[b]) return;
     const int nt = ntok[b], total = isize[b];
-    const uint32_t *tk = tok + ooff[b];
+    const uint32_t *tk = tok + ((size_t)(b >> 6) << 22) + (b & 63);
     int base = 0;
 #pragma unroll 1
     for (int c = 0; c < nt; c += 64) {
         const int i = c + lane;
-        const uint32_t t = i < nt ? tk[i] : 0u;
+        const uint32_t t = i < nt ? tk[(size_t)i << 6] : 0u;
         const bool lit = (t >> 31) != 0;
         const int len = lit ? 1 : (int)(t >> 16), dist = (int)(t & 0xffffu);
         const int incl = wave_scan_incl(len, lane);
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
 
 }   // namespace
 
-// d_tok: workspace of one dword per byte of output (the token run of member b starts at dword d_ooff[b]); d_ntok: n_blocks counters
+// d_tok: workspace of ceil(n_blocks / 64) x 4,194,304 dwords (64 members x 65,536 tokens, interleaved); d_ntok: n_blocks counters
 extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
                                  const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok)
 {

@@ -1,0 +1,380 @@
+"""BAM -> read pack on the device (csrc/nc_inflate.hip, csrc/nc_ingest.hip).
+
+The reference reads alignments through pysam / htslib (generate_SNP_pileups.py:134-164).  The host route of this package inflates and
+decodes them on worker threads (bam.py, nc_bam.cpp), diffs them against the reference and sends the difference over PCIe (wire.py).  Here
+the FILE crosses PCIe as it is -- a BAM is already a compressed form of the pack -- and everything else happens in HBM:
+
+  file image (page-locked) --H2D--> BGZF payloads --nc_inflate_device--> record stream --nc_bam_walk (.bai entries as chain starts)-->
+  record offsets --nc_bam_meta--> per-record fields --D2H (48 B per record)--> [host: which reads are kept, tile index] --H2D-->
+  nc_bam_codes --> the position-addressed codes of the pack
+
+Which reads the pileup keeps (flag filter, htslib's depth cap, the unsupported-input checks) and the tile index are decided on the host
+from the per-record fields with the same functions the host route uses, so a `DevicePack` made here is byte for byte the one
+`wire.upload_wire(build_wire_from_world(bam.read_bam(...)))` makes (tests/test_device_bam.py), without the indel sections: SNP route only.
+Needs the .bai (its linear index cuts the record chain into independent walks).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import DevicePack, get_engine
+from .pack import pileup_depth_cap
+from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
+
+META_COLS = 12
+(M_REFID, M_POS, M_FLAG, M_RLEN, M_LSEQ, M_HASSEQ, M_HAP, M_PS, M_HASH_LO, M_HASH_HI, M_NCIG, M_CIGD) = range(META_COLS)
+INFLATE_BATCH = 16384            # members per nc_inflate_device call: 256 waves of 64 lanes, one full round of k_huff on 256 CUs
+MAX_RESIDENT = 96 << 30          # inflated bytes kept in HBM at once (a 30x human genome BAM does not fit: it takes the host route)
+
+
+class DeviceIngestUnavailable(RuntimeError):
+    """the input cannot take the device route (no .bai, too large): the caller falls back to the host route"""
+
+
+def _bai_path(path):
+    for p in (path + ".bai", os.path.splitext(path)[0] + ".bai"):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def bai_linear_voffsets(bai_path):
+    """{reference index: uint64 array of the non-zero virtual offsets of its 16 kb windows} (SAM specification 5.2)"""
+    with open(bai_path, "rb") as f:
+        buf = f.read()
+    if buf[:4] != b"BAI\1":
+        raise ValueError("%s is not a BAI file" % bai_path)
+    n_ref, = struct.unpack_from("<i", buf, 4)
+    o, out = 8, {}
+    for r in range(n_ref):
+        n_bin, = struct.unpack_from("<i", buf, o)
+        o += 4
+        for _ in range(n_bin):
+            _, n_chunk = struct.unpack_from("<Ii", buf, o)
+            o += 8 + 16 * n_chunk
+        n_intv, = struct.unpack_from("<i", buf, o)
+        o += 4
+        iv = np.frombuffer(buf, np.uint64, n_intv, o)
+        o += 8 * n_intv
+        out[r] = np.unique(iv[iv != 0])
+    return out
+
+
+def read_file_pinned(path, threads=8, pin=True):
+    """the file's bytes in one page-locked uint8 tensor, read by several threads (a 1 GB file from the page cache: 70 ms instead of 300)"""
+    n = os.path.getsize(path)
+    buf = torch.empty(n + 64, dtype=torch.uint8, pin_memory=bool(pin and torch.cuda.is_available()))
+    view = memoryview(buf.numpy())
+    step = max(1 << 24, -(-n // max(1, threads)))
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        def part(a):
+            b, o = min(n, a + step), a
+            while o < b:
+                got = os.preadv(fd, [view[o:b]], o)
+                if got <= 0:
+                    raise IOError("short read of %s" % path)
+                o += got
+        with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+            list(pool.map(part, range(0, n, step)))
+    finally:
+        os.close(fd)
+    buf[n:] = 0
+    return buf, n
+
+
+class DeviceBam:
+    """One BAM file: inflated and indexed in HBM by `load()`, then `prepare()` (host half, thread-safe) + `pack()` (device half) per contig."""
+
+    def __init__(self, path, device=0, threads=None):
+        self.path, self.device = path, device
+        self.eng = get_engine(device)
+        bai = _bai_path(path)
+        if bai is None:
+            raise DeviceIngestUnavailable("%s: no .bai beside it" % path)
+        self.lin = bai_linear_voffsets(bai)
+        from .bam import rank_threads
+        self.host_buf, self.n_bytes = read_file_pinned(path, threads or rank_threads())
+        L = _lib.lib()
+        data = self.host_buf.numpy()
+        cap = self.n_bytes // 2048 + 4096
+        for _ in range(2):
+            coff, clen, isize = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+            n_mem = C.c_int64()
+            rc = L.nc_bgzf_members(_lib.npp(data), self.n_bytes, cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n_mem))
+            if rc != _lib.NC_ERR_CAPACITY:
+                break
+            cap = int(n_mem.value)
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("%s is not a BGZF file (nc_bgzf_members: %d)" % (path, rc))
+        k = int(n_mem.value)
+        self.coff, self.clen, self.isize = coff[:k].copy(), clen[:k].copy(), isize[:k].copy()
+        self.ooff = np.zeros(k + 1, np.int64)
+        np.cumsum(self.isize, out=self.ooff[1:])
+        self.mstart = np.zeros(k, np.int64)                                                    # file offset of every member
+        self.mstart[1:] = self.coff[:-1] + self.clen[:-1] + 8
+        if int(self.ooff[-1]) > MAX_RESIDENT:
+            raise DeviceIngestUnavailable("%s inflates to %.0f GB: more than is kept in HBM at once" % (path, self.ooff[-1] / 1e9))
+        self._header()
+        self.loaded = False
+
+    def _header(self):
+        """reference names / lengths from the leading members (inflated with zlib: a few kilobytes)"""
+        data, got, k = self.host_buf.numpy(), b"", 0
+
+        def need(n):
+            nonlocal got, k
+            while len(got) < n:
+                if k >= len(self.coff):
+                    raise _lib.NanoCallerHipError("%s: truncated BAM header" % self.path)
+                c = int(self.coff[k])
+                got += zlib.decompress(data[c:c + int(self.clen[k])].tobytes(), -15)
+                k += 1
+        need(12)
+        if got[:4] != b"BAM\1":
+            raise _lib.NanoCallerHipError("%s is not a BAM file" % self.path)
+        l_text, = struct.unpack_from("<i", got, 4)
+        need(12 + l_text)
+        n_ref, = struct.unpack_from("<i", got, 8 + l_text)
+        o = 12 + l_text
+        self.ref_names, self.ref_lengths = [], []
+        for _ in range(n_ref):
+            need(o + 4)
+            l_name, = struct.unpack_from("<i", got, o)
+            need(o + 8 + l_name)
+            self.ref_names.append(got[o + 4:o + 4 + l_name - 1].decode("ascii"))
+            self.ref_lengths.append(struct.unpack_from("<i", got, o + 4 + l_name)[0])
+            o += 8 + l_name
+
+    def voffset_to_stream(self, voff):
+        """virtual offsets (coffset << 16 | uoffset) -> offsets into the inflated stream"""
+        voff = np.asarray(voff, np.uint64)
+        co = (voff >> np.uint64(16)).astype(np.int64)
+        m = np.searchsorted(self.mstart, co)
+        if m.size and (m.max() >= len(self.mstart) or not np.array_equal(self.mstart[m], co)):
+            raise _lib.NanoCallerHipError("%s: an index entry does not point at a BGZF member" % self.path)
+        return self.ooff[m] + (voff & np.uint64(0xffff)).astype(np.int64)
+
+    # ------------------------------------------------------------------ the file, once
+    def load(self):
+        if self.loaded:
+            return self
+        eng, L, dev = self.eng, _lib.lib(), self.eng.device
+        eng.use_torch_stream()
+        vp = lambda t, byte_off=0: C.c_void_p(t.data_ptr() + byte_off)   # noqa: E731
+        n_mem, total = len(self.coff), int(self.ooff[-1])
+        d_file = self.host_buf.to(dev, non_blocking=True)
+        d_coff, d_clen = torch.from_numpy(self.coff).to(dev), torch.from_numpy(self.clen).to(dev)
+        d_ooff, d_isize = torch.from_numpy(self.ooff[:-1].copy()).to(dev), torch.from_numpy(self.isize).to(dev)
+        self.raw = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        d_st = torch.zeros(n_mem, dtype=torch.int32, device=dev)
+        batch = min(INFLATE_BATCH, n_mem)
+        d_tok = torch.empty(((batch + 63) // 64) << 22, dtype=torch.int32, device=dev)
+        d_ntok = torch.zeros(batch, dtype=torch.int32, device=dev)
+        for a in range(0, n_mem, batch):
+            n = min(batch, n_mem - a)
+            eng._check(L.nc_inflate_device(eng.ctx, n, vp(d_file), vp(d_coff, 8 * a), vp(d_clen, 4 * a), vp(self.raw), vp(d_ooff, 8 * a), vp(d_isize, 4 * a),
+                                           vp(d_st, 4 * a), vp(d_tok), vp(d_ntok)), "nc_inflate_device")
+        # chain starts: the linear index entries of every contig
+        seeds, tids = [], []
+        for tid in sorted(self.lin):
+            v = self.lin[tid]
+            if v.size:
+                seeds.append(self.voffset_to_stream(v))
+                tids.append(np.full(v.size, tid, np.int32))
+        self.n_rec = 0
+        self.meta = np.zeros((META_COLS, 0), np.int32)
+        self.rec_off = np.zeros(0, np.int64)
+        bad = int(d_st.count_nonzero().item())                          # (also: the inflate is done)
+        if bad:
+            raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size" % (self.path, bad))
+        del d_tok, d_file
+        if seeds:
+            seed, tid = np.concatenate(seeds), np.concatenate(tids)
+            if np.any(np.diff(seed) <= 0):
+                raise _lib.NanoCallerHipError("%s: the index entries are not in file order" % self.path)
+            d_seed, d_tid = torch.from_numpy(seed).to(dev), torch.from_numpy(tid).to(dev)
+            d_cnt = torch.zeros(seed.size, dtype=torch.int64, device=dev)
+            d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+            eng._check(L.nc_bam_walk(eng.ctx, vp(self.raw), total, seed.size, vp(d_seed), vp(d_tid), None, vp(d_cnt), vp(d_status)), "nc_bam_walk")
+            d_first = torch.cumsum(d_cnt, 0) - d_cnt
+            self.n_rec = int(d_cnt.sum().item())
+            self.d_rec_off = torch.empty(max(1, self.n_rec), dtype=torch.int64, device=dev)
+            eng._check(L.nc_bam_walk(eng.ctx, vp(self.raw), total, seed.size, vp(d_seed), vp(d_tid), vp(d_first), vp(self.d_rec_off), vp(d_status)), "nc_bam_walk")
+            d_meta = torch.empty((META_COLS, max(1, self.n_rec)), dtype=torch.int32, device=dev)
+            eng._check(L.nc_bam_meta(eng.ctx, vp(self.raw), self.n_rec, vp(self.d_rec_off), vp(d_meta), vp(d_status)), "nc_bam_meta")
+            self.meta = d_meta.cpu().numpy()[:, :self.n_rec]
+            self.rec_off = self.d_rec_off.cpu().numpy()[:self.n_rec]
+            st = int(d_status.item())
+            if st:
+                raise _lib.NanoCallerHipError("%s: corrupt BAM records or index (status %d)" % (self.path, st))
+        # the records of a contig are one run of the record list (coordinate-sorted file)
+        refid = self.meta[M_REFID]
+        self.tid_range = {}
+        if self.n_rec:
+            cut = np.flatnonzero(np.diff(refid)) + 1
+            lo = np.concatenate([[0], cut])
+            hi = np.concatenate([cut, [self.n_rec]])
+            for a, b in zip(lo.tolist(), hi.tolist()):
+                t = int(refid[a])
+                if t in self.tid_range:
+                    raise _lib.NanoCallerHipError("%s is not coordinate-sorted (contig %d appears twice)" % (self.path, t))
+                self.tid_range[t] = (a, b)
+        self.loaded = True
+        return self
+
+    def fetch_names(self, recs):
+        """read names of the records `recs` (indices into the record list): a D2H of a few bytes each (the duplicate-name check's slow path)"""
+        out = []
+        for r in np.asarray(recs).tolist():
+            o = int(self.rec_off[r])
+            head = self.raw[o + 4:o + 4 + 32].cpu().numpy()
+            l_name = int(head[8])
+            out.append(self.raw[o + 36:o + 36 + l_name - 1].cpu().numpy().tobytes().decode("ascii", "replace"))
+        return out
+
+    # ------------------------------------------------------------------ one contig: the host's decisions
+    def prepare(self, chrom, ref, supplementary=False, exclude=None, span=None, tile_size=2048):
+        """host half (numpy + native, no GPU call: may run on a worker thread).  ref: the contig's sequence.  -> dict for pack()"""
+        from .wire import ref_wire_from_string
+        if not self.loaded:
+            raise RuntimeError("DeviceBam.load() first")
+        if chrom not in self.ref_names:
+            raise ValueError("%s has no contig %r" % (self.path, chrom))
+        tid = self.ref_names.index(chrom)
+        length = self.ref_lengths[tid]
+        beg1, end1 = (1, length) if span is None else (max(1, int(span[0])), int(span[1]))
+        a, b = self.tid_range.get(tid, (0, 0))
+        m = self.meta[:, a:b]
+        pos, rlen, flag = m[M_POS], m[M_RLEN], m[M_FLAG]
+        # the alignments nc_bam_decode(tid, beg1, end1) returns
+        sel = (pos < end1) & ((flag & 0x4) == 0) & (rlen > 0) & (pos.astype(np.int64) + rlen > beg1 - 1)
+        idx = np.flatnonzero(sel)
+        start = (pos[idx] + 1).astype(np.int32)
+        end = (start + rlen[idx]).astype(np.int32)
+        flag = flag[idx]
+        # inputs the library does not reproduce (generate_SNP_pileups._check_supported)
+        mask = 0x704 if supplementary else 0xF04
+        kept_for_check = (flag & mask) == 0
+        n_skip = int(np.count_nonzero(kept_for_check & ((flag & _lib.FLAG_REFSKIP) != 0)))
+        h = (m[M_HASH_LO][idx].astype(np.uint32).astype(np.uint64) | (m[M_HASH_HI][idx].astype(np.uint32).astype(np.uint64) << np.uint64(32)))
+        n_dup = self._same_name_overlaps(h, start, end, kept_for_check, a + idx)
+        if n_skip or n_dup:
+            what = []
+            if n_skip:
+                what.append("%d alignments with a reference skip (CIGAR N) would enter the pileup; the reference's code table has no entry for "
+                            "their '>' / '<' symbols (generate_SNP_pileups.py:104)" % n_skip)
+            if n_dup:
+                what.append("%d pairs of kept alignments carry the same read name and overlap on the reference; the reference's per-column "
+                            "dicts hold one entry per name (generate_SNP_pileups.py:175,185,208)" % n_dup)
+            err = _lib.NanoCallerHipError("%s, contig %s: %s -- NC_ERR_UNSUPPORTED" % (self.path, chrom, "; ".join(what)))
+            err.status = _lib.NC_ERR_UNSUPPORTED
+            raise err
+        filt = FLAG_FILTER_SUPPL if supplementary else FLAG_FILTER_DEFAULT
+        keep = pileup_depth_cap(start, end, np.ascontiguousarray((flag & filt) == 0, np.uint8))
+        strand = np.ascontiguousarray(((flag & 0x10) != 0).astype(np.uint8) | ((m[M_HAP][idx].astype(np.uint8) & 3) << 1))
+        # tile index + slot layout (nc_pack_plan / nc_pack_fill, index only: what wire.build_wire does)
+        L = _lib.lib()
+        ref_wire = ref_wire_from_string(ref, exclude)
+        Lref = int(ref_wire.shape[0])
+        pos_lo = 1 if span is None else max(1, int(span[0]))
+        pos_hi = max(pos_lo, Lref if span is None else min(Lref, int(span[1])))
+        codes_len, n_ent = C.c_int64(), C.c_int64()
+        tile_pos0, n_tiles = C.c_int32(), C.c_int32()
+        n = int(idx.size)
+        rc = L.nc_pack_plan(n, _lib.npp(start), _lib.npp(end), _lib.npp(keep), tile_size, pos_lo, pos_hi, C.byref(codes_len), C.byref(tile_pos0),
+                            C.byref(n_tiles), C.byref(n_ent))
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_pack_plan failed (%d)" % rc)
+        ref_len = n_tiles.value * tile_size
+        ref_code = np.full(ref_len, 4, np.uint8)
+        ga, gb = max(1, tile_pos0.value), min(Lref, tile_pos0.value + ref_len - 1)
+        if gb >= ga:
+            w = ref_wire[ga - 1:gb]
+            ref_code[ga - tile_pos0.value:gb - tile_pos0.value + 1] = np.where(w & 8, 4, w & 7)
+        tile_off = np.empty(n_tiles.value + 1, np.int32)
+        tile_ent = np.empty(max(1, n_ent.value), _lib.TILE_ENTRY_DTYPE)
+        rc = L.nc_pack_fill(n, _lib.npp(start), _lib.npp(end), None, None, _lib.npp(strand), _lib.npp(keep), tile_size, tile_pos0.value,
+                            n_tiles.value, None, codes_len.value, _lib.npp(tile_off), _lib.npp(tile_ent), n_ent.value)
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_pack_fill (index) failed (%d)" % rc)
+        kk = np.flatnonzero(keep)
+        ks, ke = start[kk], end[kk]
+        size = ((ke.astype(np.int64) + 15) & ~15) - (ks.astype(np.int64) & ~15)
+        slot = np.zeros(kk.size, np.int64)
+        if kk.size:
+            np.cumsum(size[:-1], out=slot[1:])
+        mk = m[:, idx[kk]]
+        ncig = mk[M_NCIG].astype(np.int64) | np.where(mk[M_HASSEQ] != 0, 0, 1 << 31)
+        return dict(chrom=chrom, n_kept=int(kk.size), rec=np.ascontiguousarray(self.rec_off[a + idx[kk]]), slot=slot,
+                    cigd=np.ascontiguousarray(mk[M_CIGD]), ncig=ncig.astype(np.uint32).view(np.int32), start=np.ascontiguousarray(ks),
+                    tile_off=tile_off, tile_ent=tile_ent, ref_code=ref_code, codes_len=int(codes_len.value), tile_size=tile_size,
+                    tile_pos0=int(tile_pos0.value), n_tiles=int(n_tiles.value), n_entries=int(n_ent.value), pos_lo=pos_lo, pos_hi=pos_hi,
+                    n_reads=n, read_start=start, read_end=end, read_flag=flag, keep=keep)
+
+    def _same_name_overlaps(self, h, start, end, keep, recs):
+        """bam.same_name_overlaps on name hashes; hash-equal pairs are confirmed on the names themselves"""
+        k = np.flatnonzero(keep)
+        if k.size < 2:
+            return 0
+        hk = h[k]
+        u, inv, cnt = np.unique(hk, return_inverse=True, return_counts=True)
+        cand = k[cnt[inv] > 1]                                            # kept alignments whose name (hash) occurs more than once
+        if cand.size == 0:
+            return 0
+        names = self.fetch_names(recs[cand])
+        last, n = {}, 0
+        for r, nm in zip(cand.tolist(), names):
+            e = last.get(nm)
+            if e is not None and int(start[r]) < e:
+                n += 1
+            last[nm] = max(int(end[r]), e or 0)
+        return n
+
+    # ------------------------------------------------------------------ one contig: the slots, in HBM
+    def pack(self, prep, codes=None) -> DevicePack:
+        """device half: uploads the (small) arrays of prepare() and decodes the kept reads into `codes` (allocated when None)"""
+        eng, L, dev = self.eng, _lib.lib(), self.eng.device
+        eng.use_torch_stream()
+        vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)   # noqa: E731
+        n = prep["codes_len"]
+        if codes is None:
+            codes = torch.empty(n, dtype=torch.uint8, device=dev)
+        codes = codes[:n]
+        codes.fill_(7)                                                   # NC_CODE_ABSENT
+        if prep["n_kept"]:
+            d = {k: up(prep[k]) for k in ("rec", "slot", "cigd", "ncig", "start")}
+            eng._check(L.nc_bam_codes(eng.ctx, vp(self.raw), prep["n_kept"], vp(d["rec"]), vp(d["slot"]), vp(d["cigd"]), vp(d["ncig"]), vp(d["start"]),
+                                      vp(codes)), "nc_bam_codes")
+        tile_ent = up(prep["tile_ent"].view(np.uint8).reshape(-1))
+        return DevicePack(codes=codes, tile_off=up(prep["tile_off"]), tile_ent=tile_ent, ref_code=up(prep["ref_code"]), tile_size=prep["tile_size"],
+                          tile_pos0=prep["tile_pos0"], n_tiles=prep["n_tiles"], n_entries=prep["n_entries"], pos_lo=prep["pos_lo"], pos_hi=prep["pos_hi"])
+
+
+_OPEN = {}
+
+
+def open_device_bam(path, device=0) -> DeviceBam:
+    """the loaded DeviceBam of (path, device), cached by path + size + mtime"""
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns, device)
+    db = _OPEN.get(key)
+    if db is None:
+        for k in [k for k in _OPEN if k[0] == key[0] and k[3] == device]:
+            del _OPEN[k]
+        db = _OPEN[key] = DeviceBam(path, device)
+    return db.load()
+
+
+def release(path=None):
+    for k in [k for k in _OPEN if path is None or k[0] == os.path.abspath(path)]:
+        del _OPEN[k]

@@ -1,0 +1,155 @@
+"""GPU: the device ingest (nanocaller_amd/device_bam.py: inflate + record walk + decode in HBM) builds the SAME read pack as the host route
+(nc_bam_decode -> wire -> nc_wire_expand), byte for byte, on every kind of test BAM; CPU: the BGZF member scan."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from nanocaller_amd import _lib
+from tests import bamio
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_member_scan_of_the_spec_fixture():
+    raw = open(os.path.join(G, "spec.bam"), "rb").read()
+    L = _lib.lib()
+    import ctypes as C
+    data = np.frombuffer(raw, np.uint8)
+    cap = 4096
+    coff, clen, isize = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+    n = C.c_int64()
+    assert L.nc_bgzf_members(_lib.npp(data), len(raw), cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n)) == _lib.NC_OK
+    k = int(n.value)
+    assert k > 30
+    o = 0
+    for i in range(k):                                                  # against a walk of the same bytes in Python
+        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+        assert coff[i] == o + 18 and clen[i] == bsize - 26
+        assert len(zlib.decompress(raw[coff[i]:coff[i] + clen[i]], -15)) == isize[i]
+        o += bsize
+    assert o == len(raw)
+    assert L.nc_bgzf_members(_lib.npp(data), len(raw), 3, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n)) == _lib.NC_ERR_CAPACITY and n.value == k
+    bad = data.copy()
+    bad[0] = 0
+    assert L.nc_bgzf_members(_lib.npp(bad), len(raw), cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n)) == -1
+    assert L.nc_bgzf_members(_lib.npp(data), len(raw) - 5, cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n)) == -1
+
+
+def _same_pack(bam, fa, chrom, supplementary=False, span=None):
+    import torch
+    from nanocaller_amd.bam import read_bam, read_fasta
+    from nanocaller_amd.device_bam import DeviceBam
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.wire import build_wire_from_world, upload_wire
+    eng = get_engine(0)
+    from nanocaller_amd.generate_SNP_pileups import _check_supported
+    world = read_bam(bam, fa, chrom) if span is None else read_bam(bam, fa, chrom, span[0], span[1])
+    _check_supported(world, bam, chrom, supplementary)
+    kw = dict(pos_lo=span[0], pos_hi=span[1]) if span else {}
+    want = upload_wire(eng, build_wire_from_world(world, supplementary=supplementary, **kw))
+    db = DeviceBam(bam, 0).load()
+    prep = db.prepare(chrom, read_fasta(fa, chrom), supplementary=supplementary, span=span)
+    got = db.pack(prep)
+    torch.cuda.synchronize()
+    for f in ("tile_size", "tile_pos0", "n_tiles", "n_entries", "pos_lo", "pos_hi"):
+        assert getattr(got, f) == getattr(want, f), f
+    assert np.array_equal(got.tile_off.cpu().numpy(), want.tile_off.cpu().numpy())
+    assert np.array_equal(got.tile_ent.cpu().numpy().view(np.uint8).reshape(-1), want.tile_ent.cpu().numpy().view(np.uint8).reshape(-1)[:got.tile_ent.numel()])
+    assert np.array_equal(got.ref_code.cpu().numpy(), want.ref_code.cpu().numpy())
+    a, b = got.codes.cpu().numpy(), want.codes.cpu().numpy()
+    assert a.shape == b.shape
+    assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
+    assert prep["n_reads"] == world.n_reads and np.array_equal(prep["read_start"], world.read_start) and np.array_equal(prep["read_flag"], world.read_flag)
+    return got, prep, world
+
+
+@pytest.mark.gpu
+def test_synthetic_world_bam_gives_the_host_routes_pack(tmp_path):
+    w = bamio.make_bam_world()
+    recs = bamio.world_to_records(w, np.random.Generator(np.random.PCG64(1)))
+    bam, fa = str(tmp_path / "w.bam"), str(tmp_path / "w.fa")
+    bamio.write_bam(bam, w.chrom, w.length, recs, other_refs=[("chrOther", 1000)])
+    bamio.write_fasta(fa, w.chrom, w.ref, extra=[("chrOther", "ACGT" * 250)])
+    got, prep, world = _same_pack(bam, fa, w.chrom)
+    assert prep["n_kept"] > 100
+    lo, hi = w.length // 3, 2 * w.length // 3
+    _same_pack(bam, fa, w.chrom, span=(lo, hi))
+    _same_pack(bam, fa, w.chrom, supplementary=True)
+
+
+@pytest.mark.gpu
+def test_cigar_edge_cases_soft_clips_cg_tags_and_records_without_bases(tmp_path):
+    ops = "MIDNSHP=X"
+    ref = "ACGT" * 500
+    seq = "ACGTACGTAC" + "GG" + "TACGTACG"
+    real = [("M", 10), ("I", 2), ("D", 3), ("M", 8)]
+    cg = [(ln << 4) | ops.index(op) for op, ln in real]
+    long_m = "ACGTTGCA" * 40                                              # a run longer than the wave-cooperative threshold
+    recs = [dict(name="noseq", flag=0x100, pos0=40, cigar=[("M", 300), ("D", 4), ("M", 200)], seq="", tags={}),
+            dict(name="short", flag=0, pos0=60, cigar=[("M", 30)], seq="ACGTA", tags={}),
+            dict(name="clip", flag=16, pos0=99, cigar=[("H", 5), ("S", 2), ("M", 4), ("I", 3), ("M", 2), ("D", 2), ("M", 3), ("=", 2), ("X", 1), ("S", 1)],
+                 seq="TTACGTAAAGGCATACGA", tags={"HP": 2, "PS": 70000, "XX": "str"}),
+            dict(name="longcig", flag=0, pos0=100, cigar=[("S", len(seq)), ("N", 21)], seq=seq, tags={"HP": 2, "CG": cg, "PS": 77}),
+            dict(name="plain", flag=16, pos0=100, cigar=real, seq=seq, tags={"HP": 1}),
+            dict(name="ins1st", flag=0, pos0=120, cigar=[("I", 2), ("M", 5)], seq="GGACGTN", tags={}),
+            dict(name="hifi", flag=0, pos0=300, cigar=[("M", 200), ("D", 70), ("M", 120)], seq=long_m, tags={"HP": 1}),
+            dict(name="unmapped", flag=4, pos0=310, cigar=[], seq="ACGT", tags={}),
+            dict(name="dup", flag=0x400, pos0=400, cigar=[("M", 20)], seq="A" * 20, tags={})]
+    bam, fa = str(tmp_path / "c.bam"), str(tmp_path / "c.fa")
+    bamio.write_bam(bam, "chrT", len(ref), recs)
+    bamio.write_fasta(fa, "chrT", ref)
+    got, prep, world = _same_pack(bam, fa, "chrT")
+    assert prep["n_reads"] == 8 and prep["n_kept"] == 6
+
+
+@pytest.mark.gpu
+def test_reference_skips_and_same_name_overlaps_are_refused_like_the_host_route(tmp_path):
+    from nanocaller_amd.bam import read_fasta
+    from nanocaller_amd.device_bam import DeviceBam
+    ref = "ACGT" * 500
+    recs = [dict(name="a", flag=0, pos0=10, cigar=[("M", 30), ("N", 40), ("M", 30)], seq="ACGT" * 15, tags={}),
+            dict(name="b", flag=0, pos0=50, cigar=[("M", 40)], seq="ACGT" * 10, tags={})]
+    bam, fa = str(tmp_path / "n.bam"), str(tmp_path / "n.fa")
+    bamio.write_bam(bam, "chrT", len(ref), recs)
+    bamio.write_fasta(fa, "chrT", ref)
+    db = DeviceBam(bam, 0).load()
+    with pytest.raises(_lib.NanoCallerHipError) as e:
+        db.prepare("chrT", read_fasta(fa, "chrT"))
+    assert e.value.status == _lib.NC_ERR_UNSUPPORTED and "reference skip" in str(e.value)
+    recs = [dict(name="x", flag=0, pos0=10, cigar=[("M", 60)], seq="ACGT" * 15, tags={}),
+            dict(name="x", flag=0x800, pos0=50, cigar=[("M", 40)], seq="ACGT" * 10, tags={}),
+            dict(name="y", flag=0, pos0=55, cigar=[("M", 40)], seq="ACGT" * 10, tags={})]
+    bam2 = str(tmp_path / "d.bam")
+    bamio.write_bam(bam2, "chrT", len(ref), recs)
+    db = DeviceBam(bam2, 0).load()
+    assert db.prepare("chrT", read_fasta(fa, "chrT"))["n_kept"] == 2          # default filter: the supplementary record is dropped
+    with pytest.raises(_lib.NanoCallerHipError) as e:
+        db.prepare("chrT", read_fasta(fa, "chrT"), supplementary=True)
+    assert e.value.status == _lib.NC_ERR_UNSUPPORTED and "same read name" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_spec_fixture_every_contig(tmp_path):
+    """the BAM assembled from the SAM specification (not written by tests/bamio.py): stored / fixed / dynamic members, records straddling
+    members, every aux type"""
+    from nanocaller_amd.device_bam import DeviceBam
+    bam = os.path.join(G, "spec.bam")
+    db = DeviceBam(bam, 0).load()
+    assert db.n_rec > 0 and len(db.ref_names) > 0
+    rng = np.random.default_rng(5)
+    for chrom, length in zip(db.ref_names, db.ref_lengths):
+        fa = str(tmp_path / ("%s.fa" % chrom))
+        bamio.write_fasta(fa, chrom, "".join("ACGT"[i] for i in rng.integers(0, 4, length)))
+        tid = db.ref_names.index(chrom)
+        if tid not in db.tid_range:
+            continue
+        try:
+            _same_pack(bam, fa, chrom)
+        except _lib.NanoCallerHipError as e:                             # an unsupported input is refused by BOTH routes, with the same words
+            from nanocaller_amd.bam import read_fasta
+            assert getattr(e, "status", None) == _lib.NC_ERR_UNSUPPORTED
+            with pytest.raises(_lib.NanoCallerHipError) as e2:
+                db.prepare(chrom, read_fasta(fa, chrom))
+            assert str(e2.value).split(": ", 1)[1] == str(e).split(": ", 1)[1]

@@ -36,7 +36,7 @@ def _run(payloads, sizes):
     d_ooff = torch.from_numpy(ooff[:-1].copy()).to(dev)
     d_isize = torch.tensor(list(sizes), dtype=torch.int32, device=dev)
     d_st = torch.full((len(payloads),), -1, dtype=torch.int32, device=dev)
-    d_tok = torch.empty(int(ooff[-1]) + 16, dtype=torch.int32, device=dev)
+    d_tok = torch.empty(((len(payloads) + 63) // 64) << 22, dtype=torch.int32, device=dev)
     d_ntok = torch.zeros(len(payloads), dtype=torch.int32, device=dev)
     eng.use_torch_stream()
     rc = eng.L.nc_inflate_device(eng.ctx, len(payloads), d_comp.data_ptr(), d_coff.data_ptr(), d_clen.data_ptr(), d_out.data_ptr(), d_ooff.data_ptr(),

@@ -54,7 +54,7 @@ d_out = torch.zeros(int(ooff[-1]) + 16, dtype=torch.uint8, device=dev)
 d_ooff = torch.from_numpy(ooff[:-1].copy()).to(dev)
 d_isize = torch.tensor(isize, dtype=torch.int32, device=dev)
 d_st = torch.zeros(len(coff), dtype=torch.int32, device=dev)
-d_tok = torch.empty(int(ooff[-1]) + 16, dtype=torch.int32, device=dev)
+d_tok = torch.empty(((len(coff) + 63) // 64) << 22, dtype=torch.int32, device=dev)
 d_ntok = torch.zeros(len(coff), dtype=torch.int32, device=dev)
 eng.use_torch_stream()
 for rep in range(4):
