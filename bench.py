@@ -771,7 +771,7 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
     return out
 
 
-def extra_from_bam(eng, local, n_contigs=12, L=9_000_000):
+def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
     """From a BAM FILE through the product worker loop: snpCaller.caller (BGZF inflate + record decode + wire build on host threads for
     contig i + 1 while the GPU runs contig i, upload through the three-slot ring) -> candidate sites/s including ingest.  The BAM (12 contigs of
     9 Mb, ONT 30x: ~1 GB) is written by test tooling from device-generated reads, streamed contig by contig into the Python writer (~40 s, untimed)."""
@@ -817,39 +817,49 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000):
     base_params = dict(regions_list=regions, sam_path=bam, fasta_path=fa, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1,
                        threshold=[0.4, 0.6], snp_model="ONT-HG002", cpu=16, prefix="t", sample="S", seq="ont", supplementary=False,
                        exclude_bed=None, suppress_progress=True, disable_coverage_normalization=False)
-    out = {}
-    for tag, serial in (("pipelined", None), ("serial_ingest", "1")):
-        if serial:
-            os.environ["NC_SERIAL_INGEST"] = serial
-        else:
-            os.environ.pop("NC_SERIAL_INGEST", None)
-        best = None
-        for rep in range(1):                                           # (one run each: > 1 s of wall time on a ~1 GB file; round 3 timed 95 ms on 88 MB, best of 2)
-            gsp.release_contig()
-            d = os.path.join(tmp, "%s%d" % (tag, rep))
-            os.makedirs(d)
-            params = dict(base_params, chunks_list=get_chunks(regions, 16), vcf_path=d, intermediate_snp_files_dir=d)
-            q = queue.Queue()
-            for c in params["chunks_list"]:
-                q.put(c)
-            files = []
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            snpCaller.caller(params, q, queue.Queue(), files, device=local)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            n_rec = sum(1 for _ in open(files[0], "rb"))
-            if best is None or dt < best[0]:
-                best = (dt, n_rec)
-        out[tag] = {"seconds": best[0], "sites_s": best[1] / best[0], "records": best[1]}
-    os.environ.pop("NC_SERIAL_INGEST", None)
+    out, texts = {}, {}
+    from nanocaller_amd import device_bam
+    # device_ingest: the file crosses PCIe and is inflated / cut into records / decoded into the pack in HBM (device_bam.py); host_ingest: the
+    # same worker loop with inflate + decode + wire build on the host threads (round 3's route); serial_ingest: that without the pipelining
+    for tag, env in (("device_ingest", {"NC_DEVICE_INGEST": "1"}), ("host_ingest", {"NC_DEVICE_INGEST": "0"}),
+                     ("serial_ingest", {"NC_DEVICE_INGEST": "0", "NC_SERIAL_INGEST": "1"})):
+        for k in ("NC_DEVICE_INGEST", "NC_SERIAL_INGEST"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        gsp.release_contig()
+        device_bam.release()
+        d = os.path.join(tmp, tag)
+        os.makedirs(d)
+        params = dict(base_params, chunks_list=get_chunks(regions, 16), vcf_path=d, intermediate_snp_files_dir=d)
+        q = queue.Queue()
+        for c in params["chunks_list"]:
+            q.put(c)
+        files = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        snpCaller.caller(params, q, queue.Queue(), files, device=local)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        texts[tag] = open(files[0], "rb").read()
+        n_rec = texts[tag].count(b"\n")
+        out[tag] = {"seconds": dt, "sites_s": n_rec / dt, "records": n_rec}
+        if tag == "device_ingest":
+            out[tag]["stages_s"] = dict(device_bam.LAST_LOAD)
+    for k in ("NC_DEVICE_INGEST", "NC_SERIAL_INGEST"):
+        os.environ.pop(k, None)
     gsp.release_contig()
+    device_bam.release()
     size = os.path.getsize(bam)
-    shutil.rmtree(tmp, ignore_errors=True)
+    if keep is None:
+        shutil.rmtree(tmp, ignore_errors=True)
+    else:
+        keep.extend([tmp, bam, fa, regions])                        # (tools/exp_from_bam.py goes on with the files)
     return {"workload": "%d contigs of %d bp, ONT 30x, one BAM file (%.0f MB, BGZF level 1) + FASTA -> snpCaller.caller -> worker VCF file; host threads: %d usable CPUs"
                         % (n_contigs, L, size / 1e6, usable_cpus()),
-            "from_bam_sites_s": out["pipelined"]["sites_s"], "unit": "candidate sites/s incl. BGZF inflate, record decode, wire build, upload, GPU, rules + text, file write",
-            "pipelined": out["pipelined"], "serial_ingest": out["serial_ingest"], "bam_writing_s": round(t_files, 1),
+            "from_bam_sites_s": out["device_ingest"]["sites_s"],
+            "unit": "candidate sites/s incl. file read, H2D of the file, BGZF inflate + record walk + decode in HBM, GPU, rules + text, file write",
+            "device_ingest": out["device_ingest"], "host_ingest": out["host_ingest"], "serial_ingest": out["serial_ingest"],
+            "vcf_identical_device_vs_host": texts["device_ingest"] == texts["host_ingest"], "bam_writing_s": round(t_files, 1),
             "bam_bytes": size,
             "note": "ingest is outside SURVEY 8d's timed region (its row n1); this is the product worker loop end to end, one run per variant over a file "
                     "the test tooling wrote moments before (page cache warm)"}

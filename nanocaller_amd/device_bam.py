@@ -35,6 +35,9 @@ INFLATE_BATCH = 16384            # members per nc_inflate_device call: 256 waves
 MAX_RESIDENT = 96 << 30          # inflated bytes kept in HBM at once (a 30x human genome BAM does not fit: it takes the host route)
 
 
+LAST_LOAD = {}                   # seconds per stage of the most recent DeviceBam construction + load() (bench.py reports them)
+
+
 class DeviceIngestUnavailable(RuntimeError):
     """the input cannot take the device route (no .bai, too large): the caller falls back to the host route"""
 
@@ -100,9 +103,14 @@ class DeviceBam:
         bai = _bai_path(path)
         if bai is None:
             raise DeviceIngestUnavailable("%s: no .bai beside it" % path)
+        import time
+        t0 = time.perf_counter()
         self.lin = bai_linear_voffsets(bai)
         from .bam import rank_threads
         self.host_buf, self.n_bytes = read_file_pinned(path, threads or rank_threads())
+        LAST_LOAD.clear()
+        LAST_LOAD["read_file"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         L = _lib.lib()
         data = self.host_buf.numpy()
         cap = self.n_bytes // 2048 + 4096
@@ -124,6 +132,7 @@ class DeviceBam:
         if int(self.ooff[-1]) > MAX_RESIDENT:
             raise DeviceIngestUnavailable("%s inflates to %.0f GB: more than is kept in HBM at once" % (path, self.ooff[-1] / 1e9))
         self._header()
+        LAST_LOAD["members_header"] = time.perf_counter() - t0
         self.loaded = False
 
     def _header(self):
@@ -167,10 +176,12 @@ class DeviceBam:
     def load(self):
         if self.loaded:
             return self
+        import time
         eng, L, dev = self.eng, _lib.lib(), self.eng.device
         eng.use_torch_stream()
         vp = lambda t, byte_off=0: C.c_void_p(t.data_ptr() + byte_off)   # noqa: E731
         n_mem, total = len(self.coff), int(self.ooff[-1])
+        t0 = time.perf_counter()
         d_file = self.host_buf.to(dev, non_blocking=True)
         d_coff, d_clen = torch.from_numpy(self.coff).to(dev), torch.from_numpy(self.clen).to(dev)
         d_ooff, d_isize = torch.from_numpy(self.ooff[:-1].copy()).to(dev), torch.from_numpy(self.isize).to(dev)
@@ -197,6 +208,8 @@ class DeviceBam:
         if bad:
             raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size" % (self.path, bad))
         del d_tok, d_file
+        LAST_LOAD["h2d_inflate"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         if seeds:
             seed, tid = np.concatenate(seeds), np.concatenate(tids)
             if np.any(np.diff(seed) <= 0):
@@ -228,6 +241,8 @@ class DeviceBam:
                 if t in self.tid_range:
                     raise _lib.NanoCallerHipError("%s is not coordinate-sorted (contig %d appears twice)" % (self.path, t))
                 self.tid_range[t] = (a, b)
+        LAST_LOAD["walk_meta"] = time.perf_counter() - t0
+        LAST_LOAD["members"], LAST_LOAD["records"], LAST_LOAD["inflated_bytes"] = n_mem, self.n_rec, total
         self.loaded = True
         return self
 
@@ -244,7 +259,6 @@ class DeviceBam:
     # ------------------------------------------------------------------ one contig: the host's decisions
     def prepare(self, chrom, ref, supplementary=False, exclude=None, span=None, tile_size=2048):
         """host half (numpy + native, no GPU call: may run on a worker thread).  ref: the contig's sequence.  -> dict for pack()"""
-        from .wire import ref_wire_from_string
         if not self.loaded:
             raise RuntimeError("DeviceBam.load() first")
         if chrom not in self.ref_names:
@@ -283,8 +297,8 @@ class DeviceBam:
         strand = np.ascontiguousarray(((flag & 0x10) != 0).astype(np.uint8) | ((m[M_HAP][idx].astype(np.uint8) & 3) << 1))
         # tile index + slot layout (nc_pack_plan / nc_pack_fill, index only: what wire.build_wire does)
         L = _lib.lib()
-        ref_wire = ref_wire_from_string(ref, exclude)
-        Lref = int(ref_wire.shape[0])
+        ref_bytes = np.frombuffer(bytearray(ref.encode("ascii") if isinstance(ref, str) else ref), np.uint8)
+        Lref = int(ref_bytes.shape[0])
         pos_lo = 1 if span is None else max(1, int(span[0]))
         pos_hi = max(pos_lo, Lref if span is None else min(Lref, int(span[1])))
         codes_len, n_ent = C.c_int64(), C.c_int64()
@@ -294,12 +308,6 @@ class DeviceBam:
                             C.byref(n_tiles), C.byref(n_ent))
         if rc != _lib.NC_OK:
             raise _lib.NanoCallerHipError("nc_pack_plan failed (%d)" % rc)
-        ref_len = n_tiles.value * tile_size
-        ref_code = np.full(ref_len, 4, np.uint8)
-        ga, gb = max(1, tile_pos0.value), min(Lref, tile_pos0.value + ref_len - 1)
-        if gb >= ga:
-            w = ref_wire[ga - 1:gb]
-            ref_code[ga - tile_pos0.value:gb - tile_pos0.value + 1] = np.where(w & 8, 4, w & 7)
         tile_off = np.empty(n_tiles.value + 1, np.int32)
         tile_ent = np.empty(max(1, n_ent.value), _lib.TILE_ENTRY_DTYPE)
         rc = L.nc_pack_fill(n, _lib.npp(start), _lib.npp(end), None, None, _lib.npp(strand), _lib.npp(keep), tile_size, tile_pos0.value,
@@ -316,7 +324,7 @@ class DeviceBam:
         ncig = mk[M_NCIG].astype(np.int64) | np.where(mk[M_HASSEQ] != 0, 0, 1 << 31)
         return dict(chrom=chrom, n_kept=int(kk.size), rec=np.ascontiguousarray(self.rec_off[a + idx[kk]]), slot=slot,
                     cigd=np.ascontiguousarray(mk[M_CIGD]), ncig=ncig.astype(np.uint32).view(np.int32), start=np.ascontiguousarray(ks),
-                    tile_off=tile_off, tile_ent=tile_ent, ref_code=ref_code, codes_len=int(codes_len.value), tile_size=tile_size,
+                    tile_off=tile_off, tile_ent=tile_ent, ref_bytes=ref_bytes, exclude=list(exclude or ()), codes_len=int(codes_len.value), tile_size=tile_size,
                     tile_pos0=int(tile_pos0.value), n_tiles=int(n_tiles.value), n_entries=int(n_ent.value), pos_lo=pos_lo, pos_hi=pos_hi,
                     n_reads=n, read_start=start, read_end=end, read_flag=flag, keep=keep)
 
@@ -339,6 +347,14 @@ class DeviceBam:
             last[nm] = max(int(end[r]), e or 0)
         return n
 
+    def _ref_lut(self):
+        if getattr(self, "_lut", None) is None:
+            lut = np.full(256, 4, np.uint8)                              # upper-case AGTC are scanned; soft-masked / other letters are not (quirk E4)
+            for i, ch in enumerate("AGTC"):
+                lut[ord(ch)] = i
+            self._lut = torch.from_numpy(lut).to(self.eng.device)
+        return self._lut
+
     # ------------------------------------------------------------------ one contig: the slots, in HBM
     def pack(self, prep, codes=None) -> DevicePack:
         """device half: uploads the (small) arrays of prepare() and decodes the kept reads into `codes` (allocated when None)"""
@@ -356,7 +372,19 @@ class DeviceBam:
             eng._check(L.nc_bam_codes(eng.ctx, vp(self.raw), prep["n_kept"], vp(d["rec"]), vp(d["slot"]), vp(d["cigd"]), vp(d["ncig"]), vp(d["start"]),
                                       vp(codes)), "nc_bam_codes")
         tile_ent = up(prep["tile_ent"].view(np.uint8).reshape(-1))
-        return DevicePack(codes=codes, tile_off=up(prep["tile_off"]), tile_ent=tile_ent, ref_code=up(prep["ref_code"]), tile_size=prep["tile_size"],
+        # the scan's reference codes on the tile grid, from the contig's letters (wire.ref_wire_from_string + nc_wire_expand's rule, in HBM: the
+        # 9 MB table passes of a contig kept a worker thread -- and the interpreter lock the launching thread needs -- busy for milliseconds)
+        ref_len, t0 = prep["n_tiles"] * prep["tile_size"], prep["tile_pos0"]
+        ref_code = torch.full((ref_len,), 4, dtype=torch.uint8, device=dev)
+        Lref = int(prep["ref_bytes"].shape[0])
+        ga, gb = max(1, t0), min(Lref, t0 + ref_len - 1)
+        if gb >= ga:
+            ref_code[ga - t0:gb - t0 + 1] = self._ref_lut()[up(prep["ref_bytes"][ga - 1:gb]).to(torch.int32)]
+        for (a, b) in prep["exclude"]:                                   # tree.overlaps(pos): a <= pos < b (generate_SNP_pileups.py:116-119,161)
+            lo, hi = max(1, int(a)) - t0, max(1, int(b)) - t0
+            if hi > max(lo, 0):
+                ref_code[max(lo, 0):min(hi, ref_len)] = 4
+        return DevicePack(codes=codes, tile_off=up(prep["tile_off"]), tile_ent=tile_ent, ref_code=ref_code, tile_size=prep["tile_size"],
                           tile_pos0=prep["tile_pos0"], n_tiles=prep["n_tiles"], n_entries=prep["n_entries"], pos_lo=prep["pos_lo"], pos_hi=prep["pos_hi"])
 
 

@@ -288,6 +288,16 @@ def _prepare_wire(params, chrom, grp):
     return build_wire_from_world(world, supplementary=bool(params.get('supplementary')), exclude=_exclude_rows(params, chrom), **kw)
 
 
+def _prepare_device(dbam, params, chrom, grp):
+    """host half of a group's ingest on the device route (device_bam.py), on a worker thread: the contig's reference sequence, which of its
+    alignments the pileup keeps, the tile index -- from the per-record fields the device extracted when the file was loaded"""
+    from .bam import read_fasta
+    from .generate_SNP_pileups import _exclude_rows, contig_span
+    span = contig_span(params['sam_path'], chrom, grp)
+    return dbam.prepare(chrom, read_fasta(params['fasta_path'], chrom), supplementary=bool(params.get('supplementary')),
+                        exclude=_exclude_rows(params, chrom), span=span)
+
+
 def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
     """Worker with the reference's signature (snpCaller.py:57): drains `chunks_Q`, writes
     <intermediate_snp_files_dir>/<prefix>.<worker>.snps.vcf.  Chunks are grouped per (contig, ploidy)
@@ -346,27 +356,44 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
         piped = isinstance(params['sam_path'], str) and os.path.exists(params['sam_path']) and not os.environ.get('NC_SERIAL_INGEST')
         uploader = None
         preps = []                                                   # the next groups' packs, being prepared
+        # Device route (device_bam.py; NC_DEVICE_INGEST=0 or params['device_ingest'] = False keeps the host threads' decode): the FILE crosses
+        # PCIe, is inflated and cut into records in HBM once, and every group's pack is decoded there from the record stream; the worker
+        # threads only decide which alignments are kept and build the tile index.  Needs the .bai; files that do not fit take the host route.
+        dbam, dev_codes = None, [None]
+        if piped and keys and params.get('device_ingest', os.environ.get('NC_DEVICE_INGEST', '1') != '0') and params.get('fasta_path'):
+            from .device_bam import DeviceIngestUnavailable, open_device_bam
+            try:
+                dbam = open_device_bam(params['sam_path'], device)
+            except DeviceIngestUnavailable:
+                dbam = None
+        prepare = (lambda chrom, grp: _prepare_device(dbam, params, chrom, grp)) if dbam is not None else (lambda chrom, grp: _prepare_wire(params, chrom, grp))
         if piped and keys:
             from .wire import WireUploader
-            uploader = WireUploader(get_engine(device))
+            uploader = WireUploader(get_engine(device)) if dbam is None else None
             # two groups ahead: the Python half of one pack's preparation (header parsing, the wire's index arrays, freeing the decoded
             # arrays: ~35 of ~58 ms per 3 Mb contig) runs beside the native decode of the next one, which releases the GIL
             ahead = int(os.environ.get('NC_INGEST_AHEAD', 2))
             prep_pool = ThreadPoolExecutor(max_workers=max(1, ahead))
             nxt = 0
             while nxt < len(keys) and len(preps) < max(1, ahead):
-                preps.append(prep_pool.submit(_prepare_wire, params, keys[nxt][0], groups[keys[nxt]]))
+                preps.append(prep_pool.submit(prepare, keys[nxt][0], groups[keys[nxt]]))
                 nxt += 1
         for i, (chrom, ploidy) in enumerate(keys):
             grp = groups[(chrom, ploidy)]
             if piped:
                 wp = preps.pop(0).result()
                 if nxt < len(keys):
-                    preps.append(prep_pool.submit(_prepare_wire, params, keys[nxt][0], groups[keys[nxt]]))
+                    preps.append(prep_pool.submit(prepare, keys[nxt][0], groups[keys[nxt]]))
                     nxt += 1
-                tk = uploader.submit(wp)
-                call = call_chunks(params, grp, device, dpk=uploader.expand(tk), defer=True)
-                uploader.release(tk)
+                if dbam is not None:
+                    # one codes buffer for every group: all steps run on one stream, so group i + 1's decode is ordered behind group i's last reader
+                    if dev_codes[0] is None or dev_codes[0].numel() < wp['codes_len']:
+                        dev_codes[0] = torch.empty(wp['codes_len'] + wp['codes_len'] // 8, dtype=torch.uint8, device=get_engine(device).device)
+                    call = call_chunks(params, grp, device, dpk=dbam.pack(wp, codes=dev_codes[0]), defer=True)
+                else:
+                    tk = uploader.submit(wp)
+                    call = call_chunks(params, grp, device, dpk=uploader.expand(tk), defer=True)
+                    uploader.release(tk)
             else:
                 call = call_chunks(params, grp, device, defer=True)     # enqueued behind the previous group's CNN
             if in_flight is not None:

@@ -37,7 +37,7 @@ def test_member_scan_of_the_spec_fixture():
     assert L.nc_bgzf_members(_lib.npp(data), len(raw) - 5, cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n)) == -1
 
 
-def _same_pack(bam, fa, chrom, supplementary=False, span=None):
+def _same_pack(bam, fa, chrom, supplementary=False, span=None, exclude=None):
     import torch
     from nanocaller_amd.bam import read_bam, read_fasta
     from nanocaller_amd.device_bam import DeviceBam
@@ -48,9 +48,9 @@ def _same_pack(bam, fa, chrom, supplementary=False, span=None):
     world = read_bam(bam, fa, chrom) if span is None else read_bam(bam, fa, chrom, span[0], span[1])
     _check_supported(world, bam, chrom, supplementary)
     kw = dict(pos_lo=span[0], pos_hi=span[1]) if span else {}
-    want = upload_wire(eng, build_wire_from_world(world, supplementary=supplementary, **kw))
+    want = upload_wire(eng, build_wire_from_world(world, supplementary=supplementary, exclude=exclude, **kw))
     db = DeviceBam(bam, 0).load()
-    prep = db.prepare(chrom, read_fasta(fa, chrom), supplementary=supplementary, span=span)
+    prep = db.prepare(chrom, read_fasta(fa, chrom), supplementary=supplementary, span=span, exclude=exclude)
     got = db.pack(prep)
     torch.cuda.synchronize()
     for f in ("tile_size", "tile_pos0", "n_tiles", "n_entries", "pos_lo", "pos_hi"):
@@ -77,6 +77,7 @@ def test_synthetic_world_bam_gives_the_host_routes_pack(tmp_path):
     lo, hi = w.length // 3, 2 * w.length // 3
     _same_pack(bam, fa, w.chrom, span=(lo, hi))
     _same_pack(bam, fa, w.chrom, supplementary=True)
+    _same_pack(bam, fa, w.chrom, exclude=((0, 40), (w.length // 2, w.length // 2 + 700), (w.length - 5, w.length + 90)))
 
 
 @pytest.mark.gpu
