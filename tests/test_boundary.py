@@ -447,7 +447,8 @@ def test_indel_call_manager_under_gloo_shards_chunks_and_merges(tmp_path):
 @pytest.mark.gpu
 def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files, tmp_path, monkeypatch):
     """snpCaller.caller decodes + wire-builds group i + 1 on a host thread and uploads it through the three-slot ring while the GPU runs
-    group i (VERDICT r2 #2); the worker file is byte-identical to the one the serial caller (NC_SERIAL_INGEST=1) writes"""
+    group i; the worker file is byte-identical to the one the serial caller (NC_SERIAL_INGEST=1) writes -- and to the one of the
+    device ingest route (the default for an indexed BAM: the file is inflated and decoded in HBM, no host decode at all)"""
     import queue
 
     from nanocaller_amd import snpCaller
@@ -457,11 +458,15 @@ def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files
     a = _args(bam, fa, str(tmp_path), haploid_X=True, mincov=2)
     regions = get_regions_list(a)
     outs = []
-    for tag, serial in (("serial", "1"), ("piped", None)):
+    for tag, serial, dev in (("serial", "1", "0"), ("piped", None, "0"), ("device", None, None)):
         if serial:
             monkeypatch.setenv("NC_SERIAL_INGEST", serial)
         else:
             monkeypatch.delenv("NC_SERIAL_INGEST", raising=False)
+        if dev:
+            monkeypatch.setenv("NC_DEVICE_INGEST", dev)
+        else:
+            monkeypatch.delenv("NC_DEVICE_INGEST", raising=False)
         gsp.release_contig()
         del gsp.DECODES[:]
         d = tmp_path / tag
@@ -476,5 +481,5 @@ def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files
         files = []
         snpCaller.caller(params, q, queue.Queue(), files)
         outs.append(open(files[0], "rb").read())
-        assert sorted(x[1] for x in gsp.DECODES) == ["chr1", "chrX"]                # every contig decoded once
-    assert outs[0] == outs[1] and outs[0].count(b"\n") > 100
+        assert sorted(x[1] for x in gsp.DECODES) == ([] if tag == "device" else ["chr1", "chrX"])   # every contig decoded once / not on the host at all
+    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 100
