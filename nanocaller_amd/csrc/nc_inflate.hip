@@ -8,8 +8,8 @@
 //            entry = symbol << 4 | code length), codes longer than the index by the canonical count / symbol walk.  It does NOT copy: a literal
 //            leaves as the token 0x80000000 | byte, a match as length << 16 | distance, one dword per symbol into the member's token run.
 //   k_lz     ONE WAVE PER MEMBER.  64 tokens per step: their output positions by a wave scan, all literals stored at once, the matches in
-//            order with all 64 lanes copying (source and destination in a 64 KB LDS image of the member, so overlapping and chained matches
-//            need no memory fences); the finished member leaves LDS as aligned dwords.
+//            order with all 64 lanes copying (source and destination in a 16 KB LDS ring of the member's recent output, so overlapping and
+//            chained matches are plain LDS traffic; older sources are read back from HBM); finished stretches leave LDS as aligned dwords.
 // Stored, fixed and dynamic blocks.  Checked: the stream ends exactly at ISIZE bytes, distances stay inside the output, the input is not
 // overrun.  The CRC-32 of a member is the host's to check (nc_bam.cpp, when the bytes come back) -- the device path checks the lengths.
 #include "nc_common.h"
@@ -360,58 +360,89 @@ __device__ __forceinline__ int wave_scan_incl(int v, int lane)
     return v;
 }
 
+// One wave per member.  The member's recent output lives in an LDS ring of RING bytes (position p at ring[p & (RING - 1)]): a full 64 KB
+// image per member allowed two waves per CU -- a wave alone on its SIMD, every LDS round trip exposed.  With a 16 KB ring nine members share
+// a CU.  Finished stretches leave for HBM every FLUSH bytes; a match source older than the last flush is read back from there (the
+// stores are fenced at agent scope when they are issued and the loads bypass the CU's cache: same-wave visibility through L2).
+template <int RING>
 __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const int32_t *ntok, uint8_t *out, const int64_t *ooff, const int32_t *isize,
                                            const int32_t *status)
 {
-    extern __shared__ uint32_t obuf_w[];
-    uint8_t *obuf = reinterpret_cast<uint8_t *>(obuf_w);
+    constexpr int M = RING - 1, SPAN = RING / 4, FLUSH = RING / 4;            // RING >= FLUSH + SPAN + 8
+    extern __shared__ uint32_t ring_w[];
+    uint8_t *ring = reinterpret_cast<uint8_t *>(ring_w);
     const int lane = threadIdx.x, b = blockIdx.x;
     if (status[b]) return;
     const int nt = ntok[b], total = isize[b];
     const uint32_t *tk = tok + ((size_t)(b >> 6) << 22) + (b & 63);
-    int base = 0;
+    uint8_t *o = out + ooff[b];
+    const int head = (int)((4 - (reinterpret_cast<uintptr_t>(o) & 3)) & 3);
+    uint32_t *ow = reinterpret_cast<uint32_t *>(o + head);
+    int base = 0, flushed = 0;                                         // bytes produced; bytes that are in HBM (0, or = head mod 4)
+    auto flush = [&](int upto) {                                       // [flushed, upto rounded down to a destination dword) -> HBM
+        int start = flushed;
+        if (flushed == 0) {
+            if (upto < head) return;
+            if (lane < head) o[lane] = ring[lane];
+            start = head;
+        }
+        const int nw = (upto - start) >> 2;
+        for (int w = lane; w < nw; w += 64) {
+            const int p = start + 4 * w, r = (p & M) >> 2;
+            ow[(p - head) >> 2] = __builtin_amdgcn_alignbyte(ring_w[(r + 1) & (RING / 4 - 1)], ring_w[r], p & 3);
+        }
+        flushed = start + 4 * nw;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    };
+    // the tokens of the next step are on their way while this one is resolved (a step normally takes all 64: the guess is seldom wrong)
+    uint32_t t_next = lane < nt ? tk[(size_t)lane << 6] : 0u;
+    int c_next = 0;
 #pragma unroll 1
-    for (int c = 0; c < nt; c += 64) {
+    for (int c = 0; c < nt;) {
         const int i = c + lane;
-        const uint32_t t = i < nt ? tk[(size_t)i << 6] : 0u;
+        const uint32_t t = c == c_next ? t_next : (i < nt ? tk[(size_t)i << 6] : 0u);
+        c_next = c + 64;
+        t_next = c_next + lane < nt ? tk[(size_t)(c_next + lane) << 6] : 0u;
         const bool lit = (t >> 31) != 0;
-        const int len = lit ? 1 : (int)(t >> 16), dist = (int)(t & 0xffffu);
+        int len = lit ? 1 : (int)(t >> 16);
+        const int dist = (int)(t & 0xffffu);
         const int incl = wave_scan_incl(len, lane);
+        // the step takes the tokens whose output ends within SPAN bytes (at least one: a token is at most 258 bytes); the rest wait for the next
+        const uint64_t fit = __ballot(i < nt && incl <= SPAN);
+        const int nv = __builtin_popcountll(fit);                      // (the scan is monotone: `fit` is a prefix of the lanes)
+        if (lane >= nv) len = 0;
         const int pos = base + incl - len;
-        if (lit) obuf[pos] = (uint8_t)t;
+        if (lit && lane < nv) ring[pos & M] = (uint8_t)t;
+        // the ring holds the RING bytes before the end of this step's output (its literals are in already); what is older is in HBM:
+        // flushed >= ring_lo, because a flush is due every FLUSH bytes and a step adds at most SPAN
+        const int ring_lo = base + __builtin_amdgcn_readlane(incl, nv - 1) - RING;
         uint64_t m = __ballot(!lit && len > 0);
 #pragma unroll 1
         while (m) {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const int P = __builtin_amdgcn_readlane(pos, j), L = __builtin_amdgcn_readlane(len, j), D = __builtin_amdgcn_readlane(dist, j);
-            if (D >= L) {
-                for (int k = lane; k < L; k += 64) obuf[P + k] = obuf[P - D + k];
-            } else {                                                   // an overlapping match repeats its last D bytes: byte k = byte k mod D
-                const float rinv = 1.0f / (float)D;
-                for (int k = lane; k < L; k += 64) {
+            const float rinv = 1.0f / (float)D;
+            for (int k = lane; k < L; k += 64) {
+                int r = k;
+                if (D < L) {                                           // an overlapping match repeats its last D bytes: byte k = byte k mod D
                     const int q = (int)((float)k * rinv);
-                    int r = k - q * D;
+                    r = k - q * D;
                     if (r < 0) r += D;
                     if (r >= D) r -= D;
-                    obuf[P + k] = obuf[P - D + r];
                 }
+                const int q = P - D + r;
+                const uint8_t v = q >= ring_lo ? ring[q & M] : __hip_atomic_load(o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ring[(P + k) & M] = v;
             }
         }
-        base += __builtin_amdgcn_readlane(incl, 63);
+        base += __builtin_amdgcn_readlane(incl, nv - 1);
+        c += nv;
+        if (base - flushed >= FLUSH) flush(base);
     }
-    // the member leaves LDS: bytes up to the first aligned dword of the destination, dwords, the tail
-    uint8_t *o = out + ooff[b];
-    const int head = (int)((4 - (reinterpret_cast<uintptr_t>(o) & 3)) & 3);
-    if (lane < head && lane < total) o[lane] = obuf[lane];
-    const int nw = total > head ? (total - head) >> 2 : 0;
-    uint32_t *ow = reinterpret_cast<uint32_t *>(o + head);
-    for (int w = lane; w < nw; w += 64) {
-        const uint32_t lo = obuf_w[w], hi = obuf_w[w + 1];              // (obuf_w has a dword of slack)
-        ow[w] = __builtin_amdgcn_alignbyte(hi, lo, head);
-    }
-    const int done = head + 4 * nw;
-    if (done + lane < total) o[done + lane] = obuf[done + lane];
+    flush(total);
+    if (flushed + lane < total && total >= head) o[flushed + lane] = ring[(flushed + lane) & M];
+    if (total < head && lane < total) o[lane] = ring[lane];
 }
 
 }   // namespace
@@ -425,19 +456,23 @@ extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d
         return nc_fail(ctx, NC_ERR_ARG, "nc_inflate_device: bad argument");
     if (n_blocks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t lds_h = (size_t)64 * (TAB_WORDS + WIN_PITCH) * 4, lds_z = 65536 + 16;
+    const size_t lds_h = (size_t)64 * (TAB_WORDS + WIN_PITCH) * 4;
     static bool set[64] = {false};
     if (ctx->device >= 0 && ctx->device < 64 && !set[ctx->device]) {
         NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
-        NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_z));
         set[ctx->device] = true;
     }
     InflateArgs a;
     a.comp = d_comp; a.coff = d_coff; a.clen = d_clen; a.out = d_out; a.ooff = d_ooff; a.isize = d_isize; a.n = n_blocks; a.status = d_status;
     hipLaunchKernelGGL(k_huff, dim3((n_blocks + 63) / 64), dim3(64), lds_h, ctx->stream, a, d_tok, d_ntok);
     NC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_lz, dim3(n_blocks), dim3(64), lds_z, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out, d_ooff, d_isize,
-                       (const int32_t *)d_status);
+    const char *rv = getenv("NC_INFLATE_RING");                        // (experiment switch: 16384 default, 32768)
+    if (rv && atoi(rv) == 32768)
+        hipLaunchKernelGGL(k_lz<32768>, dim3(n_blocks), dim3(64), 32768, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out, d_ooff,
+                           d_isize, (const int32_t *)d_status);
+    else
+        hipLaunchKernelGGL(k_lz<16384>, dim3(n_blocks), dim3(64), 16384, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out, d_ooff,
+                           d_isize, (const int32_t *)d_status);
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
 }
