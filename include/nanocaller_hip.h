@@ -193,6 +193,8 @@ int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, cons
  * what nc_bam_decode + nc_pack_fill do on host threads (generate_SNP_pileups.py:134-164's input).
  * nc_bgzf_members (host): the members of a BGZF file image: payload offset / length and inflated size of each (the arguments of
  *   nc_inflate_device).  NC_ERR_CAPACITY when there are more than `cap` (n_members counts them all), NC_ERR_ARG for a malformed member.
+ * nc_bgzf_scan (host): the same from byte `start`, as far as whole members lie inside data[0, n) and the outputs have room; *next = where
+ *   it stopped (a file that is still being read is scanned piece by piece).
  * nc_bam_walk: record boundaries.  d_seed = n_seeds record starts, ascending offsets into d_raw (the entries of the .bai linear index),
  *   d_seed_tid = the contig of each.  d_first == NULL: d_out[i] = records from seed i up to seed i + 1 / the end of the contig's records;
  *   else d_out[d_first[i] + k] = offset of the k-th of them (d_first = exclusive prefix sums of the counts).  d_status (one int32, zeroed
@@ -207,6 +209,8 @@ int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, cons
  *   first position).  d_codes holds NC_CODE_ABSENT everywhere beforehand; the result is byte for byte what nc_pack_fill writes. */
 #define NC_BAM_META_COLS 12
 int nc_bgzf_members(const uint8_t *data, int64_t n, int64_t cap, int64_t *coff, int32_t *clen, int32_t *isize, int64_t *n_members);
+int nc_bgzf_scan(const uint8_t *data, int64_t n, int64_t start, int64_t cap, int64_t *coff, int32_t *clen, int32_t *isize, int64_t *n_members,
+                 int64_t *next);
 int nc_bam_walk(nc_ctx *ctx, const uint8_t *d_raw, int64_t raw_len, int32_t n_seeds, const int64_t *d_seed, const int32_t *d_seed_tid,
                 const int64_t *d_first, int64_t *d_out, int32_t *d_status);
 int nc_bam_meta(nc_ctx *ctx, const uint8_t *d_raw, int64_t n_rec, const int64_t *d_rec_off, int32_t *d_meta, int32_t *d_status);

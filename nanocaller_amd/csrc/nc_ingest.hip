@@ -198,35 +198,71 @@ __global__ __launch_bounds__(64 * WPB) void k_codes(const uint8_t *raw, int32_t 
 extern "C" {
 
 // members of a BGZF file image (SAMv1 4.1): the deflate payload of member k lies at data[coff[k] .. coff[k] + clen[k]) and inflates to isize[k]
-// bytes.  Host side, no GPU.  NC_ERR_CAPACITY when there are more than `cap` members (n_members still counts them all).
-int nc_bgzf_members(const uint8_t *data, int64_t n, int64_t cap, int64_t *coff, int32_t *clen, int32_t *isize, int64_t *n_members)
+// bytes.  Host side, no GPU.  nc_bgzf_scan walks from byte `start` as far as whole members lie inside data[0, n) and the outputs have room
+// (`cap`): *n_members of them, *next = where the walk stopped (== n: the image ends with a whole member) -- a file that is still being read
+// is scanned piece by piece.  nc_bgzf_members is the whole image at once: NC_ERR_CAPACITY when there are more than `cap` members
+// (n_members still counts them all), NC_ERR_ARG when the image does not end with a whole member.
+static int bgzf_member(const uint8_t *data, int64_t n, int64_t o, int64_t *bsize_out, int *xlen_out)
 {
-    if (!data || n < 0 || cap < 0 || !n_members || (cap && (!coff || !clen || !isize))) return NC_ERR_ARG;
-    int64_t o = 0, k = 0;
-    while (o < n) {
-        if (o + 18 > n || data[o] != 0x1f || data[o + 1] != 0x8b || data[o + 2] != 8 || !(data[o + 3] & 4)) return NC_ERR_ARG;
-        const int xlen = data[o + 10] | (data[o + 11] << 8);
-        if (o + 12 + xlen > n) return NC_ERR_ARG;
-        int64_t bsize = -1;
-        for (int64_t x = o + 12; x + 4 <= o + 12 + xlen;) {
-            const int slen = data[x + 2] | (data[x + 3] << 8);
-            if (data[x] == 'B' && data[x + 1] == 'C' && slen == 2 && x + 6 <= o + 12 + xlen) bsize = (int64_t)(data[x + 4] | (data[x + 5] << 8)) + 1;
-            x += 4 + slen;
-        }
-        if (bsize < 12 + xlen + 8 || o + bsize > n) return NC_ERR_ARG;
-        if (k < cap) {
-            coff[k] = o + 12 + xlen;
-            clen[k] = (int32_t)(bsize - xlen - 20);
-            uint32_t is;
-            memcpy(&is, data + o + bsize - 4, 4);
-            if (is > 65536u) return NC_ERR_ARG;
-            isize[k] = (int32_t)is;
-        }
+    // -> 0 a whole member at o, 1 not all of it inside [0, n), -1 not a BGZF member
+    if (o + 18 > n) return 1;
+    if (data[o] != 0x1f || data[o + 1] != 0x8b || data[o + 2] != 8 || !(data[o + 3] & 4)) return -1;
+    const int xlen = data[o + 10] | (data[o + 11] << 8);
+    if (o + 12 + xlen > n) return 1;
+    int64_t bsize = -1;
+    for (int64_t x = o + 12; x + 4 <= o + 12 + xlen;) {
+        const int slen = data[x + 2] | (data[x + 3] << 8);
+        if (data[x] == 'B' && data[x + 1] == 'C' && slen == 2 && x + 6 <= o + 12 + xlen) bsize = (int64_t)(data[x + 4] | (data[x + 5] << 8)) + 1;
+        x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8) return -1;
+    if (o + bsize > n) return 1;
+    *bsize_out = bsize;
+    *xlen_out = xlen;
+    return 0;
+}
+
+int nc_bgzf_scan(const uint8_t *data, int64_t n, int64_t start, int64_t cap, int64_t *coff, int32_t *clen, int32_t *isize, int64_t *n_members,
+                 int64_t *next)
+{
+    if (!data || n < 0 || start < 0 || start > n || cap < 0 || !n_members || !next || (cap && (!coff || !clen || !isize))) return NC_ERR_ARG;
+    int64_t o = start, k = 0;
+    while (o < n && k < cap) {
+        int64_t bsize = 0;
+        int xlen = 0;
+        const int st = bgzf_member(data, n, o, &bsize, &xlen);
+        if (st < 0) return NC_ERR_ARG;
+        if (st > 0) break;
+        coff[k] = o + 12 + xlen;
+        clen[k] = (int32_t)(bsize - xlen - 20);
+        uint32_t is;
+        memcpy(&is, data + o + bsize - 4, 4);
+        if (is > 65536u) return NC_ERR_ARG;
+        isize[k] = (int32_t)is;
         k++;
         o += bsize;
     }
     *n_members = k;
-    return k > cap ? NC_ERR_CAPACITY : NC_OK;
+    *next = o;
+    return NC_OK;
+}
+
+int nc_bgzf_members(const uint8_t *data, int64_t n, int64_t cap, int64_t *coff, int32_t *clen, int32_t *isize, int64_t *n_members)
+{
+    if (!data || n < 0 || cap < 0 || !n_members || (cap && (!coff || !clen || !isize))) return NC_ERR_ARG;
+    int64_t k = 0, next = 0;
+    const int rc = nc_bgzf_scan(data, n, 0, cap, coff, clen, isize, &k, &next);
+    if (rc != NC_OK) return rc;
+    int64_t total = k;
+    while (next < n) {                                               // out of room, or a cut member: count on without storing
+        int64_t bsize = 0;
+        int xlen = 0;
+        if (bgzf_member(data, n, next, &bsize, &xlen) != 0) return NC_ERR_ARG;
+        total++;
+        next += bsize;
+    }
+    *n_members = total;
+    return total > cap ? NC_ERR_CAPACITY : NC_OK;
 }
 
 // Record boundaries of the inflated stream d_raw[0, raw_len): n_seeds record starts in ascending order (the .bai linear index entries, as

@@ -103,65 +103,53 @@ class DeviceBam:
         bai = _bai_path(path)
         if bai is None:
             raise DeviceIngestUnavailable("%s: no .bai beside it" % path)
-        import time
-        t0 = time.perf_counter()
         self.lin = bai_linear_voffsets(bai)
         from .bam import rank_threads
-        self.host_buf, self.n_bytes = read_file_pinned(path, threads or rank_threads())
-        LAST_LOAD.clear()
-        LAST_LOAD["read_file"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        L = _lib.lib()
-        data = self.host_buf.numpy()
-        cap = self.n_bytes // 2048 + 4096
-        for _ in range(2):
-            coff, clen, isize = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
-            n_mem = C.c_int64()
-            rc = L.nc_bgzf_members(_lib.npp(data), self.n_bytes, cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n_mem))
-            if rc != _lib.NC_ERR_CAPACITY:
-                break
-            cap = int(n_mem.value)
-        if rc != _lib.NC_OK:
-            raise _lib.NanoCallerHipError("%s is not a BGZF file (nc_bgzf_members: %d)" % (path, rc))
-        k = int(n_mem.value)
-        self.coff, self.clen, self.isize = coff[:k].copy(), clen[:k].copy(), isize[:k].copy()
-        self.ooff = np.zeros(k + 1, np.int64)
-        np.cumsum(self.isize, out=self.ooff[1:])
-        self.mstart = np.zeros(k, np.int64)                                                    # file offset of every member
-        self.mstart[1:] = self.coff[:-1] + self.clen[:-1] + 8
-        if int(self.ooff[-1]) > MAX_RESIDENT:
-            raise DeviceIngestUnavailable("%s inflates to %.0f GB: more than is kept in HBM at once" % (path, self.ooff[-1] / 1e9))
-        self._header()
-        LAST_LOAD["members_header"] = time.perf_counter() - t0
+        self.threads = threads or rank_threads()
+        self.n_bytes = os.path.getsize(path)
+        if self.n_bytes * 3 > MAX_RESIDENT:                              # (a BAM inflates three- to five-fold)
+            raise DeviceIngestUnavailable("%s (%.0f GB): more than is kept in HBM at once" % (path, self.n_bytes / 1e9))
         self.loaded = False
 
-    def _header(self):
-        """reference names / lengths from the leading members (inflated with zlib: a few kilobytes)"""
-        data, got, k = self.host_buf.numpy(), b"", 0
+    def _header(self, data, coff, clen):
+        """reference names / lengths from the leading members (inflated with zlib: a few kilobytes).  -> False when the members seen so far
+        do not hold the whole header yet"""
+        got, k = b"", 0
+
+        class Short(Exception):
+            pass
 
         def need(n):
             nonlocal got, k
             while len(got) < n:
-                if k >= len(self.coff):
-                    raise _lib.NanoCallerHipError("%s: truncated BAM header" % self.path)
-                c = int(self.coff[k])
-                got += zlib.decompress(data[c:c + int(self.clen[k])].tobytes(), -15)
+                if k >= len(coff):
+                    raise Short()
+                c = int(coff[k])
+                got += zlib.decompress(data[c:c + int(clen[k])].tobytes(), -15)
                 k += 1
+        try:
+            return self._header_fields(need, lambda: got)
+        except Short:
+            return False
+
+    def _header_fields(self, need, buf):
         need(12)
-        if got[:4] != b"BAM\1":
+        if buf()[:4] != b"BAM\1":
             raise _lib.NanoCallerHipError("%s is not a BAM file" % self.path)
-        l_text, = struct.unpack_from("<i", got, 4)
+        l_text, = struct.unpack_from("<i", buf(), 4)
         need(12 + l_text)
-        n_ref, = struct.unpack_from("<i", got, 8 + l_text)
+        n_ref, = struct.unpack_from("<i", buf(), 8 + l_text)
         o = 12 + l_text
-        self.ref_names, self.ref_lengths = [], []
+        names, lengths = [], []
         for _ in range(n_ref):
             need(o + 4)
-            l_name, = struct.unpack_from("<i", got, o)
+            l_name, = struct.unpack_from("<i", buf(), o)
             need(o + 8 + l_name)
-            self.ref_names.append(got[o + 4:o + 4 + l_name - 1].decode("ascii"))
-            self.ref_lengths.append(struct.unpack_from("<i", got, o + 4 + l_name)[0])
+            names.append(buf()[o + 4:o + 4 + l_name - 1].decode("ascii"))
+            lengths.append(struct.unpack_from("<i", buf(), o + 4 + l_name)[0])
             o += 8 + l_name
+        self.ref_names, self.ref_lengths = names, lengths
+        return True
 
     def voffset_to_stream(self, voff):
         """virtual offsets (coffset << 16 | uoffset) -> offsets into the inflated stream"""
@@ -174,42 +162,126 @@ class DeviceBam:
 
     # ------------------------------------------------------------------ the file, once
     def load(self):
+        """The file -> HBM, inflated: worker threads read it into page-locked memory piece by piece; as soon as the pieces read so far hold
+        INFLATE_BATCH more whole members their bytes are copied (copy stream) and inflated (compute stream) -- the GPU works while the rest
+        of the file is still being read.  Then the record walk and the per-record fields."""
         if self.loaded:
             return self
         import time
         eng, L, dev = self.eng, _lib.lib(), self.eng.device
         eng.use_torch_stream()
         vp = lambda t, byte_off=0: C.c_void_p(t.data_ptr() + byte_off)   # noqa: E731
-        n_mem, total = len(self.coff), int(self.ooff[-1])
+        t_start = time.perf_counter()
+        n = self.n_bytes
+        self.host_buf = torch.empty(n + 64, dtype=torch.uint8, pin_memory=True)
+        data = self.host_buf.numpy()
+        data[n:] = 0
+        view = memoryview(data)
+        piece = max(32 << 20, -(-n // 64))
+        fd = os.open(self.path, os.O_RDONLY)
+
+        def read_piece(a):
+            b_, o = min(n, a + piece), a
+            while o < b_:
+                got = os.preadv(fd, [view[o:b_]], o)
+                if got <= 0:
+                    raise IOError("short read of %s" % self.path)
+                o += got
+            return b_
+        pool = ThreadPoolExecutor(max_workers=max(1, min(self.threads, 16)))
+        futures = [pool.submit(read_piece, a) for a in range(0, n, piece)]
+        raw_cap = n * 8 + (64 << 20)                                     # the inflated size is known only at the end: room for eight-fold
+        self.raw = torch.empty(raw_cap, dtype=torch.uint8, device=dev)
+        d_file = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+        cap = n // 1024 + 4096
+        stage64 = torch.empty(2 * cap, dtype=torch.int64, pin_memory=True)    # [coff | ooff] of every member, page-locked: the batches' uploads are async
+        stage32 = torch.empty(2 * cap, dtype=torch.int32, pin_memory=True)    # [clen | isize]
+        coff, ooff = stage64.numpy()[:cap], stage64.numpy()[cap:]
+        clen, isize = stage32.numpy()[:cap], stage32.numpy()[cap:]
+        d_tok = torch.empty(((INFLATE_BATCH + 63) // 64) << 22, dtype=torch.int32, device=dev)
+        d_ntok = torch.zeros(INFLATE_BATCH, dtype=torch.int32, device=dev)
+        copy_stream = torch.cuda.Stream(device=dev)
+        compute = torch.cuda.current_stream(dev)
+        n_mem, m0, scan_pos, total, have_header, statuses, keep = 0, 0, 0, 0, False, [], []
+
+        def launch(m1):
+            nonlocal m0
+            a_byte = int(coff[m0 - 1]) + int(clen[m0 - 1]) + 8 if m0 else 0   # (from the batch's first member; the headers ride along)
+            b_byte = int(coff[m1 - 1]) + int(clen[m1 - 1]) + 8
+            k = m1 - m0
+            with torch.cuda.stream(copy_stream):
+                d_file[a_byte:b_byte].copy_(self.host_buf[a_byte:b_byte], non_blocking=True)
+                d64 = stage64[m0:m1].to(dev, non_blocking=True), stage64[cap + m0:cap + m1].to(dev, non_blocking=True)
+                d32 = stage32[m0:m1].to(dev, non_blocking=True), stage32[cap + m0:cap + m1].to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            compute.wait_event(ev)
+            st = torch.zeros(k, dtype=torch.int32, device=dev)
+            eng._check(L.nc_inflate_device(eng.ctx, k, vp(d_file), vp(d64[0]), vp(d32[0]), vp(self.raw), vp(d64[1]), vp(d32[1]), vp(st), vp(d_tok), vp(d_ntok)),
+                       "nc_inflate_device")
+            statuses.append(st)
+            keep.append((d64, d32))                                      # (allocated on the copy stream, read on the compute stream: alive until the sync)
+            m0 = m1
+        try:
+            for fut in futures:
+                avail = fut.result()
+                while True:
+                    k, nxt = C.c_int64(), C.c_int64()
+                    rc = L.nc_bgzf_scan(_lib.npp(data), avail, scan_pos, cap - n_mem, vp(stage64, 8 * n_mem), vp(stage32, 4 * n_mem), vp(stage32, 4 * (cap + n_mem)),
+                                        C.byref(k), C.byref(nxt))
+                    if rc != _lib.NC_OK:
+                        raise _lib.NanoCallerHipError("%s is not a BGZF file (nc_bgzf_scan: %d at byte %d)" % (self.path, rc, scan_pos))
+                    k = int(k.value)
+                    if k:
+                        ooff[n_mem] = total
+                        if k > 1:
+                            np.cumsum(isize[n_mem:n_mem + k - 1], out=ooff[n_mem + 1:n_mem + k])
+                            ooff[n_mem + 1:n_mem + k] += total
+                        total = int(ooff[n_mem + k - 1]) + int(isize[n_mem + k - 1])
+                    n_mem += k
+                    scan_pos = int(nxt.value)
+                    if n_mem < cap or scan_pos >= avail:
+                        break
+                    raise DeviceIngestUnavailable("%s: more BGZF members than planned for" % self.path)
+                if total + 64 > raw_cap:
+                    raise DeviceIngestUnavailable("%s inflates more than eight-fold" % self.path)
+                if not have_header and n_mem:
+                    have_header = self._header(data, coff[:n_mem], clen[:n_mem])
+                while n_mem - m0 >= INFLATE_BATCH:
+                    launch(m0 + INFLATE_BATCH)
+            if scan_pos != n:
+                raise _lib.NanoCallerHipError("%s does not end with a whole BGZF member" % self.path)
+            if not have_header:
+                raise _lib.NanoCallerHipError("%s: truncated BAM header" % self.path)
+            if n_mem > m0:
+                launch(n_mem)
+        finally:
+            pool.shutdown(wait=True)
+            os.close(fd)
+        LAST_LOAD.clear()
+        LAST_LOAD["read_scan_enqueue"] = time.perf_counter() - t_start
         t0 = time.perf_counter()
-        d_file = self.host_buf.to(dev, non_blocking=True)
-        d_coff, d_clen = torch.from_numpy(self.coff).to(dev), torch.from_numpy(self.clen).to(dev)
-        d_ooff, d_isize = torch.from_numpy(self.ooff[:-1].copy()).to(dev), torch.from_numpy(self.isize).to(dev)
-        self.raw = torch.empty(total + 64, dtype=torch.uint8, device=dev)
-        d_st = torch.zeros(n_mem, dtype=torch.int32, device=dev)
-        batch = min(INFLATE_BATCH, n_mem)
-        d_tok = torch.empty(((batch + 63) // 64) << 22, dtype=torch.int32, device=dev)
-        d_ntok = torch.zeros(batch, dtype=torch.int32, device=dev)
-        for a in range(0, n_mem, batch):
-            n = min(batch, n_mem - a)
-            eng._check(L.nc_inflate_device(eng.ctx, n, vp(d_file), vp(d_coff, 8 * a), vp(d_clen, 4 * a), vp(self.raw), vp(d_ooff, 8 * a), vp(d_isize, 4 * a),
-                                           vp(d_st, 4 * a), vp(d_tok), vp(d_ntok)), "nc_inflate_device")
-        # chain starts: the linear index entries of every contig
+        self.coff, self.clen, self.isize = coff[:n_mem].copy(), clen[:n_mem].copy(), isize[:n_mem].copy()
+        self.ooff = np.concatenate([ooff[:n_mem], [total]]).astype(np.int64)
+        self.mstart = np.zeros(n_mem, np.int64)                                               # file offset of every member
+        self.mstart[1:] = self.coff[:-1] + self.clen[:-1] + 8
+        bad = sum(int(st.count_nonzero().item()) for st in statuses)     # (also: the inflate is done)
+        if bad:
+            raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size" % (self.path, bad))
+        del d_tok, d_file, keep, statuses
+        self.host_buf = None
+        LAST_LOAD["inflate_wait"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self.n_rec = 0
+        self.meta = np.zeros((META_COLS, 0), np.int32)
+        self.rec_off = np.zeros(0, np.int64)
         seeds, tids = [], []
+        # chain starts: the linear index entries of every contig
         for tid in sorted(self.lin):
             v = self.lin[tid]
             if v.size:
                 seeds.append(self.voffset_to_stream(v))
                 tids.append(np.full(v.size, tid, np.int32))
-        self.n_rec = 0
-        self.meta = np.zeros((META_COLS, 0), np.int32)
-        self.rec_off = np.zeros(0, np.int64)
-        bad = int(d_st.count_nonzero().item())                          # (also: the inflate is done)
-        if bad:
-            raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size" % (self.path, bad))
-        del d_tok, d_file
-        LAST_LOAD["h2d_inflate"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
         if seeds:
             seed, tid = np.concatenate(seeds), np.concatenate(tids)
             if np.any(np.diff(seed) <= 0):
