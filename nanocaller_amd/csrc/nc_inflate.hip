@@ -164,13 +164,13 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
             if (q < n4) pre[q] = fetch4(wr + q * 4);
         pend = n4 * 4;
     };
-    auto refill = [&]() {                                              // at least 33 valid bits afterwards
-        if (bc <= 32) {
-            bb |= (uint64_t)win[rd & 63] << bc;
-            if (rd > w_end + 1) err = 5;
-            rd++;
-            bc += 32;
-        }
+    auto refill = [&]() {                                              // at least 33 valid bits afterwards (no branch: the window word is read either way)
+        const bool f = bc <= 32;
+        const uint32_t w = win[rd & 63];
+        bb |= f ? (uint64_t)w << (f ? bc : 0) : 0ull;
+        err = (f && rd > w_end + 1 && !err) ? 5 : err;
+        rd += f;
+        bc += f ? 32 : 0;
     };
     auto take = [&](int n) -> uint32_t {
         const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
@@ -291,53 +291,40 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
                 walk_start(wk, LT_BITS, hl);
                 walk_start(wk + 2, DT_BITS, hd);
             }
-            // ---- the symbols of the block: the loop the kernel lives in
-            const bool more = !err;
+            // ---- the symbols of the block: the loop the kernel lives in.  ONE straight line of code for literals and matches alike: a wave
+            // executes the union of its lanes' paths anyway, and as branches that union cost 210 instructions a step (a third of them exec-mask
+            // bookkeeping); a literal lane simply takes zero-width length / distance fields.  Only the long-code walk is a real branch.
+            bool run = !err;
 #pragma unroll 1
-            for (int it = 0; more; it++) {
+            for (int it = 0; run; it++) {
                 if ((it & 15) == 0) tick();
                 refill();
-                int sym;
-                {
-                    const uint32_t e = lt[(uint32_t)bb & (LT_SZ - 1)];
-                    if (e) { take(e & 15); sym = (int)(e >> 4); }
-                    else sym = slow_from(hl, wk, LT_BITS);
-                }
-                if (sym < 256) {
-                    if (sym < 0) { err = 3; break; }
-                    if (op >= isize) { err = 4; break; }
-                    tk[(size_t)(nt++) << 6] = 0x80000000u | (uint32_t)sym;
-                    op++;
-                    continue;
-                }
-                if (sym == 256) break;
-                const int c = sym - 257;
-                if (c > 28) { err = 3; break; }
-                int len;
-                if (c < 8) len = 3 + c;
-                else if (c == 28) len = 258;
-                else {
-                    const int e = (c >> 2) - 1;
-                    len = 3 + ((4 + (c & 3)) << e) + (int)take(e);  // (a length code and its extra bits: at most 20 bits, inside the 33 of the refill)
-                }
+                const uint32_t e = lt[(uint32_t)bb & (LT_SZ - 1)];
+                int sym = (int)(e >> 4);
+                take((int)(e & 15));
+                if (__builtin_expect(e == 0, 0)) sym = slow_from(hl, wk, LT_BITS);
+                const bool lit = sym < 256, mat = sym > 256;
+                const int c = mat ? sym - 257 : 0;
+                const int e1 = (c < 8 || c >= 28) ? 0 : (c >> 2) - 1;
+                const int lbase = c < 8 ? 3 + c : c >= 28 ? 258 : 3 + ((4 + (c & 3)) << e1);
+                const int len = lbase + (int)take(e1);                  // (a length code and its extra bits: at most 20 of the refill's 33 bits)
                 refill();
-                int dsym;
-                {
-                    const uint32_t e = dt[(uint32_t)bb & (DT_SZ - 1)];
-                    if (e) { take(e & 15); dsym = (int)(e >> 4); }
-                    else dsym = slow_from(hd, wk + 2, DT_BITS);
-                }
-                if (dsym < 0 || dsym > 29) { err = 3; break; }
-                int dist;
-                if (dsym < 4) dist = 1 + dsym;
-                else {
-                    const int e = (dsym >> 1) - 1;
-                    dist = 1 + ((2 + (dsym & 1)) << e) + (int)take(e);  // (15 + 13 bits)
-                }
-                if (dist > op) { err = 3; break; }
-                if (op + len > isize) { err = 4; break; }
-                tk[(size_t)(nt++) << 6] = (uint32_t)len << 16 | (uint32_t)dist;
-                op += len;
+                const uint32_t de = dt[(uint32_t)bb & (DT_SZ - 1)];
+                int dsym = (int)(de >> 4);
+                take(mat ? (int)(de & 15) : 0);
+                if (__builtin_expect(mat && de == 0, 0)) dsym = slow_from(hd, wk + 2, DT_BITS);
+                const int ds = mat ? dsym : 0;
+                const int e2 = (ds < 4 || ds > 29) ? 0 : (ds >> 1) - 1;
+                const int dbase = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e2);
+                const int dist = dbase + (int)take(e2);                 // (15 + 13 bits)
+                const int add = lit ? 1 : mat ? len : 0;
+                const int bad = (sym < 0 || (mat && (c > 28 || ds < 0 || ds > 29 || dist > op))) ? 3 : op + add > isize ? 4 : 0;
+                const bool emit = (lit || mat) && !bad;
+                if (emit) tk[(size_t)nt << 6] = lit ? 0x80000000u | (uint32_t)sym : (uint32_t)len << 16 | (uint32_t)dist;
+                nt += emit;
+                op += emit ? add : 0;
+                err = err ? err : bad;
+                run = !err && sym != 256;
             }
         }
         if (err || last) fin = true;
