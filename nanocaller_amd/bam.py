@@ -224,6 +224,11 @@ def _decoded_dict(L, d):
 
 def read_fasta(path, chrom):
     """Whole contig as a string (case preserved: soft-masked bases matter, quirk E4).  Uses <path>.fai if present."""
+    return read_fasta_bytes(path, chrom).decode("ascii")
+
+
+def read_fasta_bytes(path, chrom):
+    """read_fasta without the decode: the contig's letters as bytes"""
     fai = path + ".fai"
     if os.path.exists(fai):
         for line in open(fai):
@@ -233,7 +238,7 @@ def read_fasta(path, chrom):
                 with open(path, "rb") as fh:
                     fh.seek(offset)
                     raw = fh.read(length + (length // lb + 1) * (lw - lb))
-                return raw.replace(b"\n", b"").replace(b"\r", b"")[:length].decode("ascii")
+                return raw.replace(b"\n", b"").replace(b"\r", b"")[:length]
         raise KeyError(chrom)
     seq, on = [], False
     for line in open(path):
@@ -245,7 +250,7 @@ def read_fasta(path, chrom):
             seq.append(line.strip())
     if not seq:
         raise KeyError(chrom)
-    return "".join(seq)
+    return "".join(seq).encode("ascii")
 
 
 def decode_parallel(bam_path, chrom, start=1, end=None, keep_seq=False, threads=None, min_region=125_000):

@@ -22,6 +22,7 @@ constexpr int LT_BITS = 9, DT_BITS = 6, LT_SZ = 1 << LT_BITS, DT_SZ = 1 << DT_BI
 // latency per access, nothing to hide it behind) the set-up loops and the long-code walk were most of the kernel's 260 ms.
 constexpr int L_LT = 0, L_DT = L_LT + LT_SZ, L_HL = L_DT + DT_SZ, L_HD = L_HL + 16 + 288, L_LENS = L_HD + 16 + 32, L_WALK = L_LENS + 320 / 2, L_END = L_WALK + 4;
 constexpr int TAB_WORDS = (L_END + 1) / 2 | 1;                      // odd pitch in words: lanes spread over the banks
+constexpr int LPW = 64, LPW_SH = 6;                                 // members (= lanes) per workgroup of k_huff, and its log2 (16 / 8 / 4 lanes: 1.11 / 1.01 / 1.39 us per member against 0.71 in full rounds of 64)
 constexpr int WIN_PITCH = 68;                                       // a lane's window of the compressed stream: 64 dwords (+4: 16-byte aligned, banks spread)
 
 struct InflateArgs {
@@ -106,11 +107,11 @@ __device__ void walk_start(uint16_t *w, int bits, const uint16_t *h)
     w[1] = (uint16_t)index;
 }
 
-__global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32_t *ntok)
+__global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int32_t *ntok)
 {
     extern __shared__ uint32_t tabs[];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x * 64 + lane;
+    const int b = blockIdx.x * LPW + lane;
     const bool live = b < a.n;
     uint16_t *lbase = reinterpret_cast<uint16_t *>(tabs + lane * TAB_WORDS);
     uint16_t *lt = lbase + L_LT, *dt = lbase + L_DT, *hl = lbase + L_HL, *hd = lbase + L_HD;
@@ -121,14 +122,14 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
     const int32_t clen = a.clen[bb_], isize = a.isize[bb_];
     // token i of the wave's lane l is dword (i * 64 + l) of the wave's 64 x 65536 dwords: lanes decode in step, so a step's 64 tokens are one
     // 256-byte store (member-major runs made it 64 partial lines on a handful of channels: the store queue bounded the loop)
-    uint32_t *tk = tok + ((size_t)blockIdx.x << 22) + lane;
+    uint32_t *tk = tok + ((size_t)blockIdx.x << (16 + LPW_SH)) + lane;
     // the compressed stream reaches the bit buffer through a per-lane LDS window of 64 dwords.  A global load inside the symbol loop costs
     // the WAVE a memory round trip (the s_waitcnt before its first use also waits for every token store in flight): with the loads of all
     // lanes issued together every 16 steps, and written to the window 16 steps later, that wait is paid once per 16 steps and is short.
     const int skew = (int)(c0 & 3);
     const uint32_t *wp = reinterpret_cast<const uint32_t *>(a.comp + (c0 & ~int64_t(3)));
     const int w_end = (skew + clen + 3) / 4 + 2;                       // dwords of the stream (+2: the last code may be looked up past its end)
-    uint32_t *win = tabs + 64 * TAB_WORDS + lane * WIN_PITCH;
+    uint32_t *win = tabs + LPW * TAB_WORDS + lane * WIN_PITCH;
     auto fetch4 = [&](int w) -> U4w {
         U4w v = {0u, 0u, 0u, 0u};
         if (w + 3 < w_end) v = *reinterpret_cast<const U4w *>(wp + w);
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
                 for (uint32_t i = 0; i < len; i++) {
                     if ((i & 15) == 0) tick();
                     refill();
-                    tk[(size_t)(nt++) << 6] = 0x80000000u | take(8);
+                    tk[(size_t)(nt++) << LPW_SH] = 0x80000000u | take(8);
                 }
                 op += (int)len;
             }
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(64) void k_huff(InflateArgs a, uint32_t *tok, int32
                 const int add = lit ? 1 : mat ? len : 0;
                 const int bad = (sym < 0 || (mat && (c > 28 || ds < 0 || ds > 29 || dist > op))) ? 3 : op + add > isize ? 4 : 0;
                 const bool emit = (lit || mat) && !bad;
-                if (emit) tk[(size_t)nt << 6] = lit ? 0x80000000u | (uint32_t)sym : (uint32_t)len << 16 | (uint32_t)dist;
+                if (emit) tk[(size_t)nt << LPW_SH] = lit ? 0x80000000u | (uint32_t)sym : (uint32_t)len << 16 | (uint32_t)dist;
                 nt += emit;
                 op += emit ? add : 0;
                 err = err ? err : bad;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
     const int lane = threadIdx.x, b = blockIdx.x;
     if (status[b]) return;
     const int nt = ntok[b], total = isize[b];
-    const uint32_t *tk = tok + ((size_t)(b >> 6) << 22) + (b & 63);
+    const uint32_t *tk = tok + ((size_t)(b >> LPW_SH) << (16 + LPW_SH)) + (b & (LPW - 1));
     uint8_t *o = out + ooff[b];
     const int head = (int)((4 - (reinterpret_cast<uintptr_t>(o) & 3)) & 3);
     uint32_t *ow = reinterpret_cast<uint32_t *>(o + head);
@@ -382,14 +383,14 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     };
     // the tokens of the next step are on their way while this one is resolved (a step normally takes all 64: the guess is seldom wrong)
-    uint32_t t_next = lane < nt ? tk[(size_t)lane << 6] : 0u;
+    uint32_t t_next = lane < nt ? tk[(size_t)lane << LPW_SH] : 0u;
     int c_next = 0;
 #pragma unroll 1
     for (int c = 0; c < nt;) {
         const int i = c + lane;
-        const uint32_t t = c == c_next ? t_next : (i < nt ? tk[(size_t)i << 6] : 0u);
+        const uint32_t t = c == c_next ? t_next : (i < nt ? tk[(size_t)i << LPW_SH] : 0u);
         c_next = c + 64;
-        t_next = c_next + lane < nt ? tk[(size_t)(c_next + lane) << 6] : 0u;
+        t_next = c_next + lane < nt ? tk[(size_t)(c_next + lane) << LPW_SH] : 0u;
         const bool lit = (t >> 31) != 0;
         int len = lit ? 1 : (int)(t >> 16);
         const int dist = (int)(t & 0xffffu);
@@ -403,7 +404,19 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
         // the ring holds the RING bytes before the end of this step's output (its literals are in already); what is older is in HBM:
         // flushed >= ring_lo, because a flush is due every FLUSH bytes and a step adds at most SPAN
         const int ring_lo = base + __builtin_amdgcn_readlane(incl, nv - 1) - RING;
-        uint64_t m = __ballot(!lit && len > 0);
+        // matches whose whole source lies before this step's first byte depend on nothing the step produces: every lane copies its own (short
+        // ones only -- the wave waits for the longest), sources beyond the ring read back from HBM side by side instead of one after the other
+        const bool mat = !lit && len > 0;
+        const bool indep = mat && len <= 32 && pos - dist + len <= base;
+#pragma unroll 1
+        for (int k = 0; __any(indep && k < len); k++)
+            if (indep && k < len) {
+                const int q = pos - dist + k;
+                const uint8_t v = q >= ring_lo ? ring[q & M] : __hip_atomic_load(o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ring[(pos + k) & M] = v;
+            }
+        // the others in token order, all lanes on one match
+        uint64_t m = __ballot(mat && !indep);
 #pragma unroll 1
         while (m) {
             const int j = __builtin_ctzll(m);
@@ -443,7 +456,7 @@ extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d
         return nc_fail(ctx, NC_ERR_ARG, "nc_inflate_device: bad argument");
     if (n_blocks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t lds_h = (size_t)64 * (TAB_WORDS + WIN_PITCH) * 4;
+    const size_t lds_h = (size_t)LPW * (TAB_WORDS + WIN_PITCH) * 4;
     static bool set[64] = {false};
     if (ctx->device >= 0 && ctx->device < 64 && !set[ctx->device]) {
         NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
@@ -451,7 +464,7 @@ extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d
     }
     InflateArgs a;
     a.comp = d_comp; a.coff = d_coff; a.clen = d_clen; a.out = d_out; a.ooff = d_ooff; a.isize = d_isize; a.n = n_blocks; a.status = d_status;
-    hipLaunchKernelGGL(k_huff, dim3((n_blocks + 63) / 64), dim3(64), lds_h, ctx->stream, a, d_tok, d_ntok);
+    hipLaunchKernelGGL(k_huff, dim3((n_blocks + LPW - 1) / LPW), dim3(LPW), lds_h, ctx->stream, a, d_tok, d_ntok);
     NC_HIP(ctx, hipGetLastError());
     const char *rv = getenv("NC_INFLATE_RING");                        // (experiment switch: 16384 default, 32768)
     if (rv && atoi(rv) == 32768)

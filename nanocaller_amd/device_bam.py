@@ -369,7 +369,7 @@ class DeviceBam:
         strand = np.ascontiguousarray(((flag & 0x10) != 0).astype(np.uint8) | ((m[M_HAP][idx].astype(np.uint8) & 3) << 1))
         # tile index + slot layout (nc_pack_plan / nc_pack_fill, index only: what wire.build_wire does)
         L = _lib.lib()
-        ref_bytes = np.frombuffer(bytearray(ref.encode("ascii") if isinstance(ref, str) else ref), np.uint8)
+        ref_bytes = np.frombuffer(bytearray(ref.encode("ascii") if isinstance(ref, str) else ref), np.uint8)   # (writable: it goes through torch)
         Lref = int(ref_bytes.shape[0])
         pos_lo = 1 if span is None else max(1, int(span[0]))
         pos_hi = max(pos_lo, Lref if span is None else min(Lref, int(span[1])))

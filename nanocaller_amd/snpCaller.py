@@ -288,14 +288,18 @@ def _prepare_wire(params, chrom, grp):
     return build_wire_from_world(world, supplementary=bool(params.get('supplementary')), exclude=_exclude_rows(params, chrom), **kw)
 
 
-def _prepare_device(dbam, params, chrom, grp):
+def _prepare_device(dbam, params, chrom, grp, ref=None):
     """host half of a group's ingest on the device route (device_bam.py), on a worker thread: the contig's reference sequence, which of its
     alignments the pileup keeps, the tile index -- from the per-record fields the device extracted when the file was loaded"""
-    from .bam import read_fasta
-    from .generate_SNP_pileups import _exclude_rows, contig_span
-    span = contig_span(params['sam_path'], chrom, grp)
-    return dbam.prepare(chrom, read_fasta(params['fasta_path'], chrom), supplementary=bool(params.get('supplementary')),
-                        exclude=_exclude_rows(params, chrom), span=span)
+    from .bam import read_fasta_bytes
+    from .generate_SNP_pileups import _exclude_rows
+    # (contig_span's rule, on the lengths the loader already holds: no second open of the BAM)
+    length = dbam.ref_lengths[dbam.ref_names.index(chrom)] if chrom in dbam.ref_names else 0
+    lo = max(1, min(c['start'] for c in grp) - _lib.FLANK)
+    hi = min(length, max(c['end'] for c in grp) + _lib.FLANK)
+    span = None if (hi - lo + 1) >= 0.9 * length else (lo, hi)
+    ref = ref.result() if ref is not None else read_fasta_bytes(params['fasta_path'], chrom)
+    return dbam.prepare(chrom, ref, supplementary=bool(params.get('supplementary')), exclude=_exclude_rows(params, chrom), span=span)
 
 
 def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
@@ -359,14 +363,21 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
         # Device route (device_bam.py; NC_DEVICE_INGEST=0 or params['device_ingest'] = False keeps the host threads' decode): the FILE crosses
         # PCIe, is inflated and cut into records in HBM once, and every group's pack is decoded there from the record stream; the worker
         # threads only decide which alignments are kept and build the tile index.  Needs the .bai; files that do not fit take the host route.
-        dbam, dev_codes = None, [None]
+        dbam, dev_codes, refs = None, [None], {}
         if piped and keys and params.get('device_ingest', os.environ.get('NC_DEVICE_INGEST', '1') != '0') and params.get('fasta_path'):
+            from .bam import read_fasta_bytes
             from .device_bam import DeviceIngestUnavailable, open_device_bam
+            # the first contigs' reference letters are read while the file is loaded (the loader mostly waits: for its reader threads, for the GPU)
+            ref_pool = ThreadPoolExecutor(max_workers=2)
+            for k in keys[:3]:
+                refs.setdefault(k[0], ref_pool.submit(read_fasta_bytes, params['fasta_path'], k[0]))
             try:
                 dbam = open_device_bam(params['sam_path'], device)
             except DeviceIngestUnavailable:
                 dbam = None
-        prepare = (lambda chrom, grp: _prepare_device(dbam, params, chrom, grp)) if dbam is not None else (lambda chrom, grp: _prepare_wire(params, chrom, grp))
+            ref_pool.shutdown(wait=False)
+        prepare = (lambda chrom, grp: _prepare_device(dbam, params, chrom, grp, refs.pop(chrom, None))) if dbam is not None \
+            else (lambda chrom, grp: _prepare_wire(params, chrom, grp))
         if piped and keys:
             from .wire import WireUploader
             uploader = WireUploader(get_engine(device)) if dbam is None else None
