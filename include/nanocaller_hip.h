@@ -188,6 +188,11 @@ int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_sta
  * here.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
 int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
                       const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok);
+/* The two launches apart: phase 1 = tokens only, 2 = resolution only (of the tokens an earlier phase-1 call left in d_tok / d_ntok), 3 = both.
+ * With nc_ctx_set_stream between the calls the halves of consecutive batches overlap (the Huffman kernel takes whole CUs; where a round
+ * leaves CUs free the previous batch's resolution runs on them). */
+int nc_inflate_device_phase(nc_ctx *ctx, int32_t phase, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen,
+                            uint8_t *d_out, const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok);
 
 /* BAM records on the device (csrc/nc_ingest.hip): from the inflated BGZF stream in HBM to the slots of the read pack, for the SNP route --
  * what nc_bam_decode + nc_pack_fill do on host threads (generate_SNP_pileups.py:134-164's input).

@@ -447,9 +447,12 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
 
 }   // namespace
 
-// d_tok: workspace of ceil(n_blocks / 64) x 4,194,304 dwords (64 members x 65,536 tokens, interleaved); d_ntok: n_blocks counters
-extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
-                                 const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok)
+// d_tok: workspace of ceil(n_blocks / 64) x 4,194,304 dwords (64 members x 65,536 tokens, interleaved); d_ntok: n_blocks counters.
+// phase: 1 = tokens only (k_huff), 2 = resolution only (k_lz, of tokens made by an earlier phase-1 call), 3 = both.  The halves may run on
+// different streams (nc_ctx_set_stream between the calls): k_huff takes a CU's whole LDS, so in a round that does not fill the GPU the
+// match resolution of the previous batch runs on the CUs it leaves free.
+static int inflate_phase(nc_ctx *ctx, int phase, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
+                         const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok)
 {
     if (!ctx) return NC_ERR_ARG;
     if (n_blocks < 0 || (n_blocks && (!d_comp || !d_coff || !d_clen || !d_out || !d_ooff || !d_isize || !d_status || !d_tok || !d_ntok)))
@@ -462,17 +465,34 @@ extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d
         NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
         set[ctx->device] = true;
     }
-    InflateArgs a;
-    a.comp = d_comp; a.coff = d_coff; a.clen = d_clen; a.out = d_out; a.ooff = d_ooff; a.isize = d_isize; a.n = n_blocks; a.status = d_status;
-    hipLaunchKernelGGL(k_huff, dim3((n_blocks + LPW - 1) / LPW), dim3(LPW), lds_h, ctx->stream, a, d_tok, d_ntok);
-    NC_HIP(ctx, hipGetLastError());
-    const char *rv = getenv("NC_INFLATE_RING");                        // (experiment switch: 16384 default, 32768)
-    if (rv && atoi(rv) == 32768)
-        hipLaunchKernelGGL(k_lz<32768>, dim3(n_blocks), dim3(64), 32768, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out, d_ooff,
-                           d_isize, (const int32_t *)d_status);
-    else
-        hipLaunchKernelGGL(k_lz<16384>, dim3(n_blocks), dim3(64), 16384, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out, d_ooff,
-                           d_isize, (const int32_t *)d_status);
-    NC_HIP(ctx, hipGetLastError());
+    if (phase & 1) {
+        InflateArgs a;
+        a.comp = d_comp; a.coff = d_coff; a.clen = d_clen; a.out = d_out; a.ooff = d_ooff; a.isize = d_isize; a.n = n_blocks; a.status = d_status;
+        hipLaunchKernelGGL(k_huff, dim3((n_blocks + LPW - 1) / LPW), dim3(LPW), lds_h, ctx->stream, a, d_tok, d_ntok);
+        NC_HIP(ctx, hipGetLastError());
+    }
+    if (phase & 2) {
+        const char *rv = getenv("NC_INFLATE_RING");                    // (experiment switch: 16384 default, 32768)
+        if (rv && atoi(rv) == 32768)
+            hipLaunchKernelGGL(k_lz<32768>, dim3(n_blocks), dim3(64), 32768, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out,
+                               d_ooff, d_isize, (const int32_t *)d_status);
+        else
+            hipLaunchKernelGGL(k_lz<16384>, dim3(n_blocks), dim3(64), 16384, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out,
+                               d_ooff, d_isize, (const int32_t *)d_status);
+        NC_HIP(ctx, hipGetLastError());
+    }
     return NC_OK;
+}
+
+extern "C" int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
+                                 const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok)
+{
+    return inflate_phase(ctx, 3, n_blocks, d_comp, d_coff, d_clen, d_out, d_ooff, d_isize, d_status, d_tok, d_ntok);
+}
+
+extern "C" int nc_inflate_device_phase(nc_ctx *ctx, int32_t phase, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen,
+                                       uint8_t *d_out, const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok)
+{
+    if (phase < 1 || phase > 3) return ctx ? nc_fail(ctx, NC_ERR_ARG, "nc_inflate_device_phase: phase 1, 2 or 3") : NC_ERR_ARG;
+    return inflate_phase(ctx, phase, n_blocks, d_comp, d_coff, d_clen, d_out, d_ooff, d_isize, d_status, d_tok, d_ntok);
 }

@@ -198,10 +198,13 @@ class DeviceBam:
         stage32 = torch.empty(2 * cap, dtype=torch.int32, pin_memory=True)    # [clen | isize]
         coff, ooff = stage64.numpy()[:cap], stage64.numpy()[cap:]
         clen, isize = stage32.numpy()[:cap], stage32.numpy()[cap:]
-        d_tok = torch.empty(((INFLATE_BATCH + 63) // 64) << 22, dtype=torch.int32, device=dev)
-        d_ntok = torch.zeros(INFLATE_BATCH, dtype=torch.int32, device=dev)
-        copy_stream = torch.cuda.Stream(device=dev)
+        # two token workspaces: the Huffman kernel of batch i + 1 (compute stream) runs beside the match resolution of batch i (its own stream)
+        toks = [(torch.empty(((INFLATE_BATCH + 63) // 64) << 22, dtype=torch.int32, device=dev), torch.zeros(INFLATE_BATCH, dtype=torch.int32, device=dev), [None])
+                for _ in range(2)]
+        copy_stream, lz_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         compute = torch.cuda.current_stream(dev)
+        lz_stream.wait_stream(compute)                                   # (the output buffer's allocation)
+        n_batches = [0]
         n_mem, m0, scan_pos, total, have_header, statuses, keep = 0, 0, 0, 0, False, [], []
 
         def launch(m1):
@@ -217,8 +220,21 @@ class DeviceBam:
                 ev.record(copy_stream)
             compute.wait_event(ev)
             st = torch.zeros(k, dtype=torch.int32, device=dev)
-            eng._check(L.nc_inflate_device(eng.ctx, k, vp(d_file), vp(d64[0]), vp(d32[0]), vp(self.raw), vp(d64[1]), vp(d32[1]), vp(st), vp(d_tok), vp(d_ntok)),
-                       "nc_inflate_device")
+            d_tok, d_ntok, lz_done = toks[n_batches[0] & 1]
+            n_batches[0] += 1
+            if lz_done[0] is not None:
+                compute.wait_event(lz_done[0])                           # the workspace's previous tokens have been resolved
+            args = (k, vp(d_file), vp(d64[0]), vp(d32[0]), vp(self.raw), vp(d64[1]), vp(d32[1]), vp(st), vp(d_tok), vp(d_ntok))
+            eng._check(L.nc_inflate_device_phase(eng.ctx, 1, *args), "nc_inflate_device_phase")
+            huffed = torch.cuda.Event()
+            huffed.record(compute)
+            with torch.cuda.stream(lz_stream):
+                lz_stream.wait_event(huffed)
+                eng.use_torch_stream()
+                eng._check(L.nc_inflate_device_phase(eng.ctx, 2, *args), "nc_inflate_device_phase")
+                lz_done[0] = torch.cuda.Event()
+                lz_done[0].record(lz_stream)
+            eng.use_torch_stream()
             statuses.append(st)
             keep.append((d64, d32))                                      # (allocated on the copy stream, read on the compute stream: alive until the sync)
             m0 = m1
@@ -265,10 +281,12 @@ class DeviceBam:
         self.ooff = np.concatenate([ooff[:n_mem], [total]]).astype(np.int64)
         self.mstart = np.zeros(n_mem, np.int64)                                               # file offset of every member
         self.mstart[1:] = self.coff[:-1] + self.clen[:-1] + 8
+        lz_stream.synchronize()
         bad = sum(int(st.count_nonzero().item()) for st in statuses)     # (also: the inflate is done)
         if bad:
             raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size" % (self.path, bad))
-        del d_tok, d_file, keep, statuses
+        compute.wait_stream(lz_stream)
+        del toks, d_file, keep, statuses
         self.host_buf = None
         LAST_LOAD["inflate_wait"] = time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -369,7 +387,7 @@ class DeviceBam:
         strand = np.ascontiguousarray(((flag & 0x10) != 0).astype(np.uint8) | ((m[M_HAP][idx].astype(np.uint8) & 3) << 1))
         # tile index + slot layout (nc_pack_plan / nc_pack_fill, index only: what wire.build_wire does)
         L = _lib.lib()
-        ref_bytes = np.frombuffer(bytearray(ref.encode("ascii") if isinstance(ref, str) else ref), np.uint8)   # (writable: it goes through torch)
+        ref_bytes = np.frombuffer(ref.encode("ascii") if isinstance(ref, str) else ref, np.uint8)
         Lref = int(ref_bytes.shape[0])
         pos_lo = 1 if span is None else max(1, int(span[0]))
         pos_hi = max(pos_lo, Lref if span is None else min(Lref, int(span[1])))
@@ -394,9 +412,24 @@ class DeviceBam:
             np.cumsum(size[:-1], out=slot[1:])
         mk = m[:, idx[kk]]
         ncig = mk[M_NCIG].astype(np.int64) | np.where(mk[M_HASSEQ] != 0, 0, 1 << 31)
-        return dict(chrom=chrom, n_kept=int(kk.size), rec=np.ascontiguousarray(self.rec_off[a + idx[kk]]), slot=slot,
-                    cigd=np.ascontiguousarray(mk[M_CIGD]), ncig=ncig.astype(np.uint32).view(np.int32), start=np.ascontiguousarray(ks),
-                    tile_off=tile_off, tile_ent=tile_ent, ref_bytes=ref_bytes, exclude=list(exclude or ()), codes_len=int(codes_len.value), tile_size=tile_size,
+        # everything the device half uploads, back to back in ONE page-locked buffer (a pageable source makes the copy wait for the GPU to
+        # finish what is queued before it -- the previous contig's CNN -- and the launching thread with it)
+        Lref_b = int(ref_bytes.shape[0])
+        ga, gb = max(1, tile_pos0.value), min(Lref_b, tile_pos0.value + n_tiles.value * tile_size - 1)
+        parts = dict(rec=np.ascontiguousarray(self.rec_off[a + idx[kk]]), slot=slot, cigd=np.ascontiguousarray(mk[M_CIGD]),
+                     ncig=ncig.astype(np.uint32).view(np.int32), start=np.ascontiguousarray(ks), tile_off=tile_off,
+                     tile_ent=tile_ent.view(np.uint8).reshape(-1), ref_letters=ref_bytes[ga - 1:gb] if gb >= ga else ref_bytes[:0])
+        sections, total_b = {}, 0
+        for k, v in parts.items():
+            sections[k] = (total_b, v.dtype, int(v.size))
+            total_b += (v.nbytes + 255) & ~255
+        staged = torch.empty(max(256, total_b), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        host = staged.numpy()
+        for k, v in parts.items():
+            o = sections[k][0]
+            host[o:o + v.nbytes] = v.view(np.uint8).reshape(-1)
+        return dict(chrom=chrom, n_kept=int(kk.size), staged=staged, sections=sections, ref_span=(ga, gb), exclude=list(exclude or ()),
+                    codes_len=int(codes_len.value), tile_size=tile_size,
                     tile_pos0=int(tile_pos0.value), n_tiles=int(n_tiles.value), n_entries=int(n_ent.value), pos_lo=pos_lo, pos_hi=pos_hi,
                     n_reads=n, read_start=start, read_end=end, read_flag=flag, keep=keep)
 
@@ -433,30 +466,32 @@ class DeviceBam:
         eng, L, dev = self.eng, _lib.lib(), self.eng.device
         eng.use_torch_stream()
         vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)   # noqa: E731
+        dbuf = prep["staged"].to(dev, non_blocking=True)
+        tdt = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8}
+
+        def sec(k):
+            o, dt, cnt = prep["sections"][k]
+            return dbuf[o:o + cnt * np.dtype(dt).itemsize].view(tdt[np.dtype(dt)])
         n = prep["codes_len"]
         if codes is None:
             codes = torch.empty(n, dtype=torch.uint8, device=dev)
         codes = codes[:n]
         codes.fill_(7)                                                   # NC_CODE_ABSENT
         if prep["n_kept"]:
-            d = {k: up(prep[k]) for k in ("rec", "slot", "cigd", "ncig", "start")}
-            eng._check(L.nc_bam_codes(eng.ctx, vp(self.raw), prep["n_kept"], vp(d["rec"]), vp(d["slot"]), vp(d["cigd"]), vp(d["ncig"]), vp(d["start"]),
+            eng._check(L.nc_bam_codes(eng.ctx, vp(self.raw), prep["n_kept"], vp(sec("rec")), vp(sec("slot")), vp(sec("cigd")), vp(sec("ncig")), vp(sec("start")),
                                       vp(codes)), "nc_bam_codes")
-        tile_ent = up(prep["tile_ent"].view(np.uint8).reshape(-1))
         # the scan's reference codes on the tile grid, from the contig's letters (wire.ref_wire_from_string + nc_wire_expand's rule, in HBM: the
         # 9 MB table passes of a contig kept a worker thread -- and the interpreter lock the launching thread needs -- busy for milliseconds)
         ref_len, t0 = prep["n_tiles"] * prep["tile_size"], prep["tile_pos0"]
         ref_code = torch.full((ref_len,), 4, dtype=torch.uint8, device=dev)
-        Lref = int(prep["ref_bytes"].shape[0])
-        ga, gb = max(1, t0), min(Lref, t0 + ref_len - 1)
+        ga, gb = prep["ref_span"]
         if gb >= ga:
-            ref_code[ga - t0:gb - t0 + 1] = self._ref_lut()[up(prep["ref_bytes"][ga - 1:gb]).to(torch.int32)]
+            ref_code[ga - t0:gb - t0 + 1] = self._ref_lut()[sec("ref_letters").to(torch.int32)]
         for (a, b) in prep["exclude"]:                                   # tree.overlaps(pos): a <= pos < b (generate_SNP_pileups.py:116-119,161)
             lo, hi = max(1, int(a)) - t0, max(1, int(b)) - t0
             if hi > max(lo, 0):
                 ref_code[max(lo, 0):min(hi, ref_len)] = 4
-        return DevicePack(codes=codes, tile_off=up(prep["tile_off"]), tile_ent=tile_ent, ref_code=ref_code, tile_size=prep["tile_size"],
+        return DevicePack(codes=codes, tile_off=sec("tile_off"), tile_ent=sec("tile_ent"), ref_code=ref_code, tile_size=prep["tile_size"],
                           tile_pos0=prep["tile_pos0"], n_tiles=prep["n_tiles"], n_entries=prep["n_entries"], pos_lo=prep["pos_lo"], pos_hi=prep["pos_hi"])
 
 
