@@ -826,25 +826,29 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
         for k in ("NC_DEVICE_INGEST", "NC_SERIAL_INGEST"):
             os.environ.pop(k, None)
         os.environ.update(env)
-        gsp.release_contig()
-        device_bam.release()
-        d = os.path.join(tmp, tag)
-        os.makedirs(d)
-        params = dict(base_params, chunks_list=get_chunks(regions, 16), vcf_path=d, intermediate_snp_files_dir=d)
-        q = queue.Queue()
-        for c in params["chunks_list"]:
-            q.put(c)
-        files = []
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        snpCaller.caller(params, q, queue.Queue(), files, device=local)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        texts[tag] = open(files[0], "rb").read()
-        n_rec = texts[tag].count(b"\n")
-        out[tag] = {"seconds": dt, "sites_s": n_rec / dt, "records": n_rec}
-        if tag == "device_ingest":
-            out[tag]["stages_s"] = dict(device_bam.LAST_LOAD)
+        best = None
+        for rep in range(2):                                          # best of two: the first run of a route also pays its one-off costs (page-locked
+            gsp.release_contig()                                      # buffers of the file's size, first launches); every run starts from the file
+            device_bam.release()
+            d = os.path.join(tmp, "%s%d" % (tag, rep))
+            os.makedirs(d)
+            params = dict(base_params, chunks_list=get_chunks(regions, 16), vcf_path=d, intermediate_snp_files_dir=d)
+            q = queue.Queue()
+            for c in params["chunks_list"]:
+                q.put(c)
+            files = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            snpCaller.caller(params, q, queue.Queue(), files, device=local)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            texts[tag] = open(files[0], "rb").read()
+            n_rec = texts[tag].count(b"\n")
+            if best is None or dt < best["seconds"]:
+                best = {"seconds": dt, "sites_s": n_rec / dt, "records": n_rec}
+                if tag == "device_ingest":
+                    best["stages_s"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in device_bam.LAST_LOAD.items()}
+        out[tag] = best
     for k in ("NC_DEVICE_INGEST", "NC_SERIAL_INGEST"):
         os.environ.pop(k, None)
     gsp.release_contig()

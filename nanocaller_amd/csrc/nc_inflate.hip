@@ -3,7 +3,7 @@
 // generate_SNP_pileups.py:134-164's input) on the way from a BAM file to the read pack.
 //
 // Two kernels, because the two halves of inflate want opposite shapes (DESIGN.md section 11.6 has the measurements that led here):
-//   k_huff   ONE LANE PER MEMBER, 64 members per wave.  Huffman decoding is a serial chain per stream but the SAME short loop for every stream:
+//   k_huff   ONE LANE PER MEMBER, eight members per workgroup.  Huffman decoding is a serial chain per stream but the SAME short loop for every stream:
 //            64-bit bit buffer refilled from aligned dwords, per-lane first-level tables in LDS (literal / length 9 bits, distance 6 bits;
 //            entry = symbol << 4 | code length), codes longer than the index by the canonical count / symbol walk.  It does NOT copy: a literal
 //            leaves as the token 0x80000000 | byte, a match as length << 16 | distance, one dword per symbol into the member's token run.
@@ -22,7 +22,7 @@ constexpr int LT_BITS = 9, DT_BITS = 6, LT_SZ = 1 << LT_BITS, DT_SZ = 1 << DT_BI
 // latency per access, nothing to hide it behind) the set-up loops and the long-code walk were most of the kernel's 260 ms.
 constexpr int L_LT = 0, L_DT = L_LT + LT_SZ, L_HL = L_DT + DT_SZ, L_HD = L_HL + 16 + 288, L_LENS = L_HD + 16 + 32, L_WALK = L_LENS + 320 / 2, L_END = L_WALK + 4;
 constexpr int TAB_WORDS = (L_END + 1) / 2 | 1;                      // odd pitch in words: lanes spread over the banks
-constexpr int LPW = 64, LPW_SH = 6;                                 // members (= lanes) per workgroup of k_huff, and its log2 (16 / 8 / 4 lanes: 1.11 / 1.01 / 1.39 us per member against 0.71 in full rounds of 64)
+constexpr int LPW = 8, LPW_SH = 3;                                  // members (= lanes) per workgroup of k_huff, and its log2.  One workgroup's duration is its slowest member's; 64 lanes: 15.7 ms per 14.5 k members, 16: 14.3, 8: 13.3 (eight workgroups per CU, two waves per SIMD), 4: issue-bound
 constexpr int WIN_PITCH = 68;                                       // a lane's window of the compressed stream: 64 dwords (+4: 16-byte aligned, banks spread)
 
 struct InflateArgs {
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
     const int bb_ = live ? b : 0;
     const int64_t c0 = a.coff[bb_];
     const int32_t clen = a.clen[bb_], isize = a.isize[bb_];
-    // token i of the wave's lane l is dword (i * 64 + l) of the wave's 64 x 65536 dwords: lanes decode in step, so a step's 64 tokens are one
-    // 256-byte store (member-major runs made it 64 partial lines on a handful of channels: the store queue bounded the loop)
+    // token i of the workgroup's lane l is dword (i * LPW + l) of the workgroup's LPW x 65536 dwords: lanes decode in step, so a step's tokens
+    // are one contiguous store
     uint32_t *tk = tok + ((size_t)blockIdx.x << (16 + LPW_SH)) + lane;
     // the compressed stream reaches the bit buffer through a per-lane LDS window of 64 dwords.  A global load inside the symbol loop costs
     // the WAVE a memory round trip (the s_waitcnt before its first use also waits for every token store in flight): with the loads of all

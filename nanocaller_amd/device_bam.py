@@ -31,7 +31,7 @@ from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
 
 META_COLS = 12
 (M_REFID, M_POS, M_FLAG, M_RLEN, M_LSEQ, M_HASSEQ, M_HAP, M_PS, M_HASH_LO, M_HASH_HI, M_NCIG, M_CIGD) = range(META_COLS)
-INFLATE_BATCH = 16384            # members per nc_inflate_device call: 256 waves of 64 lanes, one full round of k_huff on 256 CUs
+INFLATE_BATCH = 16384            # members per nc_inflate_device call (4 GB of token workspace)
 MAX_RESIDENT = 96 << 30          # inflated bytes kept in HBM at once (a 30x human genome BAM does not fit: it takes the host route)
 
 
