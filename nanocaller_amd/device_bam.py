@@ -97,7 +97,9 @@ def read_file_pinned(path, threads=8, pin=True):
 class DeviceBam:
     """One BAM file: inflated and indexed in HBM by `load()`, then `prepare()` (host half, thread-safe) + `pack()` (device half) per contig."""
 
-    def __init__(self, path, device=0, threads=None):
+    def __init__(self, path, device=0, threads=None, contigs=None):
+        """contigs: only these are wanted (a rank's share of a genome): the part of the file from the first record of the first of them to the
+        first record behind the last is read and inflated, nothing else"""
         self.path, self.device = path, device
         self.eng = get_engine(device)
         bai = _bai_path(path)
@@ -106,10 +108,44 @@ class DeviceBam:
         self.lin = bai_linear_voffsets(bai)
         from .bam import rank_threads
         self.threads = threads or rank_threads()
-        self.n_bytes = os.path.getsize(path)
-        if self.n_bytes * 3 > MAX_RESIDENT:                              # (a BAM inflates three- to five-fold)
-            raise DeviceIngestUnavailable("%s (%.0f GB): more than is kept in HBM at once" % (path, self.n_bytes / 1e9))
+        self.file_bytes = os.path.getsize(path)
+        self._read_header()
+        self.B0, self.B1, self.tids = 0, self.file_bytes, None
+        if contigs is not None:
+            unknown = [c for c in contigs if c not in self.ref_names]
+            if unknown:
+                raise ValueError("%s has no contig %r" % (path, unknown[0]))
+            self.tids = sorted({self.ref_names.index(c) for c in contigs})
+            have = [t for t in self.tids if t in self.lin and self.lin[t].size]
+            if have:
+                self.B0 = int(self.lin[have[0]][0] >> np.uint64(16))
+                later = [t for t in sorted(self.lin) if t > have[-1] and self.lin[t].size]
+                if later:                                                # through the member that holds the next contig's first record
+                    self.B1 = min(self.file_bytes, int(self.lin[later[0]][0] >> np.uint64(16)) + 65536 + 1024)
+            else:
+                self.B1 = 0                                              # none of them has an alignment
+        self.n_bytes = self.B1 - self.B0
+        if self.n_bytes * 8 > MAX_RESIDENT:                              # (the loader reserves eight times the compressed size for the inflated stream)
+            raise DeviceIngestUnavailable("%s (%.1f GB to load): more than is kept in HBM at once" % (path, self.n_bytes / 1e9))
         self.loaded = False
+
+    def _read_header(self):
+        """reference names / lengths: the head of the file, inflated with zlib"""
+        L, want = _lib.lib(), 1 << 20
+        while True:
+            with open(self.path, "rb") as f:
+                head = np.frombuffer(f.read(min(want, self.file_bytes)), np.uint8)
+            cap = head.size // 28 + 16
+            coff, clen, isize = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+            k, nxt = C.c_int64(), C.c_int64()
+            rc = L.nc_bgzf_scan(_lib.npp(head), head.size, 0, cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(k), C.byref(nxt))
+            if rc != _lib.NC_OK:
+                raise _lib.NanoCallerHipError("%s is not a BGZF file (nc_bgzf_scan: %d)" % (self.path, rc))
+            if self._header(head, coff[:int(k.value)], clen[:int(k.value)]):
+                return
+            if head.size >= self.file_bytes:
+                raise _lib.NanoCallerHipError("%s: truncated BAM header" % self.path)
+            want *= 8
 
     def _header(self, data, coff, clen):
         """reference names / lengths from the leading members (inflated with zlib: a few kilobytes).  -> False when the members seen so far
@@ -154,7 +190,7 @@ class DeviceBam:
     def voffset_to_stream(self, voff):
         """virtual offsets (coffset << 16 | uoffset) -> offsets into the inflated stream"""
         voff = np.asarray(voff, np.uint64)
-        co = (voff >> np.uint64(16)).astype(np.int64)
+        co = (voff >> np.uint64(16)).astype(np.int64) - self.B0          # (member offsets are relative to the part of the file that was read)
         m = np.searchsorted(self.mstart, co)
         if m.size and (m.max() >= len(self.mstart) or not np.array_equal(self.mstart[m], co)):
             raise _lib.NanoCallerHipError("%s: an index entry does not point at a BGZF member" % self.path)
@@ -180,10 +216,10 @@ class DeviceBam:
         piece = max(32 << 20, -(-n // 64))
         fd = os.open(self.path, os.O_RDONLY)
 
-        def read_piece(a):
+        def read_piece(a):                                               # (buffer offsets; the file's are B0 higher)
             b_, o = min(n, a + piece), a
             while o < b_:
-                got = os.preadv(fd, [view[o:b_]], o)
+                got = os.preadv(fd, [view[o:b_]], self.B0 + o)
                 if got <= 0:
                     raise IOError("short read of %s" % self.path)
                 o += got
@@ -205,7 +241,7 @@ class DeviceBam:
         compute = torch.cuda.current_stream(dev)
         lz_stream.wait_stream(compute)                                   # (the output buffer's allocation)
         n_batches = [0]
-        n_mem, m0, scan_pos, total, have_header, statuses, keep = 0, 0, 0, 0, False, [], []
+        n_mem, m0, scan_pos, total, statuses, keep = 0, 0, 0, 0, [], []
 
         def launch(m1):
             nonlocal m0
@@ -261,14 +297,10 @@ class DeviceBam:
                     raise DeviceIngestUnavailable("%s: more BGZF members than planned for" % self.path)
                 if total + 64 > raw_cap:
                     raise DeviceIngestUnavailable("%s inflates more than eight-fold" % self.path)
-                if not have_header and n_mem:
-                    have_header = self._header(data, coff[:n_mem], clen[:n_mem])
                 while n_mem - m0 >= INFLATE_BATCH:
                     launch(m0 + INFLATE_BATCH)
-            if scan_pos != n:
+            if scan_pos != n and self.B1 == self.file_bytes:
                 raise _lib.NanoCallerHipError("%s does not end with a whole BGZF member" % self.path)
-            if not have_header:
-                raise _lib.NanoCallerHipError("%s: truncated BAM header" % self.path)
             if n_mem > m0:
                 launch(n_mem)
         finally:
@@ -295,8 +327,8 @@ class DeviceBam:
         self.rec_off = np.zeros(0, np.int64)
         seeds, tids = [], []
         # chain starts: the linear index entries of every contig
-        for tid in sorted(self.lin):
-            v = self.lin[tid]
+        for tid in (sorted(self.lin) if self.tids is None else self.tids):
+            v = self.lin.get(tid, np.zeros(0, np.uint64))
             if v.size:
                 seeds.append(self.voffset_to_stream(v))
                 tids.append(np.full(v.size, tid, np.int32))
@@ -498,15 +530,17 @@ class DeviceBam:
 _OPEN = {}
 
 
-def open_device_bam(path, device=0) -> DeviceBam:
-    """the loaded DeviceBam of (path, device), cached by path + size + mtime"""
+def open_device_bam(path, device=0, contigs=None) -> DeviceBam:
+    """the loaded DeviceBam of (path, device) holding at least `contigs` (None: the whole file), cached by path + size + mtime"""
     st = os.stat(path)
-    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns, device)
-    db = _OPEN.get(key)
-    if db is None:
-        for k in [k for k in _OPEN if k[0] == key[0] and k[3] == device]:
-            del _OPEN[k]
-        db = _OPEN[key] = DeviceBam(path, device)
+    want = None if contigs is None else frozenset(contigs)
+    ident = (os.path.abspath(path), st.st_size, st.st_mtime_ns, device)
+    for k, db in list(_OPEN.items()):
+        if k[:4] == ident and (k[4] is None or (want is not None and want <= k[4])):
+            return db.load()
+        if k[0] == ident[0] and k[3] == device:
+            del _OPEN[k]                                                # another version of the file, or another share of it
+    db = _OPEN[ident + (want,)] = DeviceBam(path, device, contigs=None if want is None else sorted(want))
     return db.load()
 
 

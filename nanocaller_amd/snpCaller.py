@@ -372,7 +372,7 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             for k in keys[:3]:
                 refs.setdefault(k[0], ref_pool.submit(read_fasta_bytes, params['fasta_path'], k[0]))
             try:
-                dbam = open_device_bam(params['sam_path'], device)
+                dbam = open_device_bam(params['sam_path'], device, contigs=[k[0] for k in keys])
             except DeviceIngestUnavailable:
                 dbam = None
             ref_pool.shutdown(wait=False)

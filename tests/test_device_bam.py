@@ -37,7 +37,7 @@ def test_member_scan_of_the_spec_fixture():
     assert L.nc_bgzf_members(_lib.npp(data), len(raw) - 5, cap, _lib.npp(coff), _lib.npp(clen), _lib.npp(isize), C.byref(n)) == -1
 
 
-def _same_pack(bam, fa, chrom, supplementary=False, span=None, exclude=None):
+def _same_pack(bam, fa, chrom, supplementary=False, span=None, exclude=None, contigs=None):
     import torch
     from nanocaller_amd.bam import read_bam, read_fasta
     from nanocaller_amd.device_bam import DeviceBam
@@ -49,7 +49,7 @@ def _same_pack(bam, fa, chrom, supplementary=False, span=None, exclude=None):
     _check_supported(world, bam, chrom, supplementary)
     kw = dict(pos_lo=span[0], pos_hi=span[1]) if span else {}
     want = upload_wire(eng, build_wire_from_world(world, supplementary=supplementary, exclude=exclude, **kw))
-    db = DeviceBam(bam, 0).load()
+    db = DeviceBam(bam, 0, contigs=contigs).load()
     prep = db.prepare(chrom, read_fasta(fa, chrom), supplementary=supplementary, span=span, exclude=exclude)
     got = db.pack(prep)
     torch.cuda.synchronize()
@@ -154,3 +154,36 @@ def test_spec_fixture_every_contig(tmp_path):
             with pytest.raises(_lib.NanoCallerHipError) as e2:
                 db.prepare(chrom, read_fasta(fa, chrom))
             assert str(e2.value).split(": ", 1)[1] == str(e).split(": ", 1)[1]
+
+
+@pytest.mark.gpu
+def test_a_share_of_the_contigs_loads_only_its_part_of_the_file(tmp_path):
+    """a rank that owns some contigs of a genome reads and inflates the members between their first record and the next contig's: same packs"""
+    from nanocaller_amd.device_bam import DeviceBam, open_device_bam, release
+    rng = np.random.default_rng(11)
+    refs = [("c%d" % k, 60_000) for k in range(4)]
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, ln)) for _, ln in refs]
+    recs = []
+    for tid in (0, 1, 3):                                                  # c2 has no alignments
+        for r in range(700):
+            p0 = int(r * 80 + rng.integers(0, 40))
+            ln = int(rng.integers(300, 1500))
+            ln = min(ln, refs[tid][1] - p0)
+            recs.append(dict(tid=tid, name="r%d_%d" % (tid, r), flag=16 * int(rng.integers(0, 2)), pos0=p0, cigar=[("M", ln)], seq=seqs[tid][p0:p0 + ln], tags={}))
+    bam, fa = str(tmp_path / "m.bam"), str(tmp_path / "m.fa")
+    bamio.write_bam(bam, refs[0][0], refs[0][1], recs, other_refs=refs[1:])
+    bamio.write_fasta(fa, refs[0][0], seqs[0], extra=[(n, s_) for (n, _), s_ in zip(refs[1:], seqs[1:])])
+    whole = DeviceBam(bam, 0)
+    part = DeviceBam(bam, 0, contigs=["c1"])
+    last = DeviceBam(bam, 0, contigs=["c3", "c2"])
+    assert 0 < part.n_bytes < whole.n_bytes and part.B0 > 0 and last.B1 == whole.file_bytes and last.n_bytes < whole.n_bytes
+    for contigs, chrom in ((["c1"], "c1"), (["c3", "c2"], "c3"), (["c0", "c1"], "c0"), (["c0", "c1"], "c1"), (None, "c3")):
+        _, prep, _ = _same_pack(bam, fa, chrom, contigs=contigs)
+        assert prep["n_kept"] == 700
+    empty = DeviceBam(bam, 0, contigs=["c2"]).load()
+    assert empty.n_rec == 0 and empty.prepare("c2", seqs[2])["n_kept"] == 0
+    release()
+    a = open_device_bam(bam, 0, contigs=["c1", "c3"])
+    assert open_device_bam(bam, 0, contigs=["c3"]) is a                     # a loaded share that holds the wanted contigs is reused
+    assert open_device_bam(bam, 0) is not a
+    release()
