@@ -865,7 +865,7 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
             "device_ingest": out["device_ingest"], "host_ingest": out["host_ingest"], "serial_ingest": out["serial_ingest"],
             "vcf_identical_device_vs_host": texts["device_ingest"] == texts["host_ingest"], "bam_writing_s": round(t_files, 1),
             "bam_bytes": size,
-            "note": "ingest is outside SURVEY 8d's timed region (its row n1); this is the product worker loop end to end, one run per variant over a file "
+            "note": "ingest is outside SURVEY 8d's timed region (its row n1); this is the product worker loop end to end, best of two runs per route over a file "
                     "the test tooling wrote moments before (page cache warm)"}
 
 
