@@ -359,8 +359,13 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
     constexpr int M = RING - 1, SPAN = RING / 4, FLUSH = RING / 4;            // RING >= FLUSH + SPAN + 8
     extern __shared__ uint32_t ring_w[];
     uint8_t *ring = reinterpret_cast<uint8_t *>(ring_w);
-    const int lane = threadIdx.x, b = blockIdx.x;
-    if (status[b]) return;
+    const int lane = threadIdx.x;
+    // the LPW members of one k_huff workgroup share every 32-byte sector of their interleaved tokens: consecutive workgroups of ONE XCD (every
+    // eighth of the grid) take them, so the sector comes from that XCD's L2 after its first use (member-order blocks spread the eight over the
+    // eight L2s: 11.9 GB fetched per 14.5 k members for 0.8 GB of tokens)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = (((j >> LPW_SH) * 8 + xcd) << LPW_SH) + (j & (LPW - 1));
+    if (b >= n || status[b]) return;
     const int nt = ntok[b], total = isize[b];
     const uint32_t *tk = tok + ((size_t)(b >> LPW_SH) << (16 + LPW_SH)) + (b & (LPW - 1));
     uint8_t *o = out + ooff[b];
@@ -472,12 +477,13 @@ static int inflate_phase(nc_ctx *ctx, int phase, int32_t n_blocks, const uint8_t
         NC_HIP(ctx, hipGetLastError());
     }
     if (phase & 2) {
+        const int lz_grid = (n_blocks + 8 * LPW - 1) / (8 * LPW) * (8 * LPW);   // (k_lz's block -> member map covers whole groups of 8 x LPW)
         const char *rv = getenv("NC_INFLATE_RING");                    // (experiment switch: 16384 default, 32768)
         if (rv && atoi(rv) == 32768)
-            hipLaunchKernelGGL(k_lz<32768>, dim3(n_blocks), dim3(64), 32768, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out,
+            hipLaunchKernelGGL(k_lz<32768>, dim3(lz_grid), dim3(64), 32768, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out,
                                d_ooff, d_isize, (const int32_t *)d_status);
         else
-            hipLaunchKernelGGL(k_lz<16384>, dim3(n_blocks), dim3(64), 16384, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out,
+            hipLaunchKernelGGL(k_lz<16384>, dim3(lz_grid), dim3(64), 16384, ctx->stream, n_blocks, (const uint32_t *)d_tok, (const int32_t *)d_ntok, d_out,
                                d_ooff, d_isize, (const int32_t *)d_status);
         NC_HIP(ctx, hipGetLastError());
     }
