@@ -49,8 +49,20 @@ def _bai_path(path):
     return None
 
 
+_BAI = {}
+
+
 def bai_linear_voffsets(bai_path):
-    """{reference index: uint64 array of the non-zero virtual offsets of its 16 kb windows} (SAM specification 5.2)"""
+    """{reference index: uint64 array of the non-zero virtual offsets of its 16 kb windows} (SAM specification 5.2); parsed once per file"""
+    st = os.stat(bai_path)
+    key = (os.path.abspath(bai_path), st.st_size, st.st_mtime_ns)
+    if key not in _BAI:
+        _BAI.clear()
+        _BAI[key] = _bai_linear_voffsets(bai_path)
+    return _BAI[key]
+
+
+def _bai_linear_voffsets(bai_path):
     with open(bai_path, "rb") as f:
         buf = f.read()
     if buf[:4] != b"BAI\1":
@@ -525,6 +537,56 @@ class DeviceBam:
                 ref_code[max(lo, 0):min(hi, ref_len)] = 4
         return DevicePack(codes=codes, tile_off=sec("tile_off"), tile_ent=sec("tile_ent"), ref_code=ref_code, tile_size=prep["tile_size"],
                           tile_pos0=prep["tile_pos0"], n_tiles=prep["n_tiles"], n_entries=prep["n_entries"], pos_lo=prep["pos_lo"], pos_hi=prep["pos_hi"])
+
+
+def contig_spans(path):
+    """{contig: (lo, hi)} = the bytes of the BAM file that hold its records, from the .bai alone: the member of its first record to the member of
+    the next contig's first record (inclusive: a record straddles members); contigs without alignments are absent.  Raises
+    DeviceIngestUnavailable when there is no .bai."""
+    probe = DeviceBam.__new__(DeviceBam)
+    bai = _bai_path(path)
+    if bai is None:
+        raise DeviceIngestUnavailable("%s: no .bai beside it" % path)
+    probe.path, probe.lin, probe.file_bytes = path, bai_linear_voffsets(bai), os.path.getsize(path)
+    probe._read_header()
+    with_reads = [t for t in sorted(probe.lin) if probe.lin[t].size and t < len(probe.ref_names)]
+    out = {}
+    for k, t in enumerate(with_reads):
+        hi = min(probe.file_bytes, int(probe.lin[with_reads[k + 1]][0] >> np.uint64(16)) + 65536 + 1024) if k + 1 < len(with_reads) else probe.file_bytes
+        out[probe.ref_names[t]] = (int(probe.lin[t][0] >> np.uint64(16)), hi)
+    return out, list(probe.ref_names)
+
+
+def plan_shares(path, contigs, limit_bytes=None):
+    """`contigs` (in the order they will be called) cut into runs whose part of the file -- first record of the run's first contig to the first
+    record behind its last -- stays under `limit_bytes` of compressed BAM (default: what DeviceBam accepts), so that a genome-sized file
+    passes through HBM share by share.  -> list of (contigs of the share, fits): fits False = that contig alone is too large (host route).
+    Raises DeviceIngestUnavailable when there is no .bai."""
+    spans, names = contig_spans(path)
+    limit = (MAX_RESIDENT // 8) if limit_bytes is None else int(limit_bytes)
+    shares, cur, lo, hi = [], [], None, None
+    for c in contigs:
+        if c not in names:
+            raise ValueError("%s has no contig %r" % (path, c))
+        sp = spans.get(c)
+        if sp is None:                                                   # no alignments: rides along
+            cur.append(c)
+            continue
+        if sp[1] - sp[0] > limit:
+            if cur:
+                shares.append((cur, True))
+            shares.append(([c], False))
+            cur, lo, hi = [], None, None
+            continue
+        nlo, nhi = (sp[0], sp[1]) if lo is None else (min(lo, sp[0]), max(hi, sp[1]))
+        if cur and lo is not None and nhi - nlo > limit:
+            shares.append((cur, True))
+            cur, nlo, nhi = [], sp[0], sp[1]
+        cur.append(c)
+        lo, hi = nlo, nhi
+    if cur:
+        shares.append((cur, True))
+    return shares
 
 
 _OPEN = {}

@@ -361,39 +361,71 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
         uploader = None
         preps = []                                                   # the next groups' packs, being prepared
         # Device route (device_bam.py; NC_DEVICE_INGEST=0 or params['device_ingest'] = False keeps the host threads' decode): the FILE crosses
-        # PCIe, is inflated and cut into records in HBM once, and every group's pack is decoded there from the record stream; the worker
-        # threads only decide which alignments are kept and build the tile index.  Needs the .bai; files that do not fit take the host route.
-        dbam, dev_codes, refs = None, [None], {}
+        # PCIe, is inflated and cut into records in HBM, and every group's pack is decoded there from the record stream; the worker threads only
+        # decide which alignments are kept and build the tile index.  Needs the .bai.  A file larger than HBM takes passes share by share: runs of
+        # contigs whose part of the file fits (device_bam.plan_shares; NC_DEVICE_INGEST_SHARE_GB of compressed BAM, default 12); a contig
+        # that alone does not fit is decoded by the host threads.
+        dev_codes, refs = [None], {}
+        run_end, run_dev = [len(keys)] * len(keys), [None] * len(keys)       # per group: where its run of groups ends; the run's contigs (None: host route)
         if piped and keys and params.get('device_ingest', os.environ.get('NC_DEVICE_INGEST', '1') != '0') and params.get('fasta_path'):
             from .bam import read_fasta_bytes
-            from .device_bam import DeviceIngestUnavailable, open_device_bam
-            # the first contigs' reference letters are read while the file is loaded (the loader mostly waits: for its reader threads, for the GPU)
-            ref_pool = ThreadPoolExecutor(max_workers=2)
-            for k in keys[:3]:
-                refs.setdefault(k[0], ref_pool.submit(read_fasta_bytes, params['fasta_path'], k[0]))
+            from .device_bam import DeviceIngestUnavailable, open_device_bam, plan_shares
             try:
-                dbam = open_device_bam(params['sam_path'], device, contigs=[k[0] for k in keys])
+                lim = os.environ.get('NC_DEVICE_INGEST_SHARE_GB')
+                order = list(dict.fromkeys(k[0] for k in keys))
+                share_of = {}
+                for n_sh, (cs, fits) in enumerate(plan_shares(params['sam_path'], order, None if lim is None else int(float(lim) * (1 << 30)))):
+                    for c in cs:
+                        share_of[c] = (n_sh, tuple(cs) if fits else None)
+                a0 = 0
+                for j in range(1, len(keys) + 1):
+                    if j == len(keys) or share_of[keys[j][0]][0] != share_of[keys[a0][0]][0]:
+                        for q in range(a0, j):
+                            run_end[q], run_dev[q] = j, share_of[keys[a0][0]][1]
+                        a0 = j
             except DeviceIngestUnavailable:
-                dbam = None
-            ref_pool.shutdown(wait=False)
-        prepare = (lambda chrom, grp: _prepare_device(dbam, params, chrom, grp, refs.pop(chrom, None))) if dbam is not None \
-            else (lambda chrom, grp: _prepare_wire(params, chrom, grp))
+                pass
+        dbam, prepare, nxt = None, None, 0
         if piped and keys:
-            from .wire import WireUploader
-            uploader = WireUploader(get_engine(device)) if dbam is None else None
+            ahead = int(os.environ.get('NC_INGEST_AHEAD', 2))
             # two groups ahead: the Python half of one pack's preparation (header parsing, the wire's index arrays, freeing the decoded
             # arrays: ~35 of ~58 ms per 3 Mb contig) runs beside the native decode of the next one, which releases the GIL
-            ahead = int(os.environ.get('NC_INGEST_AHEAD', 2))
             prep_pool = ThreadPoolExecutor(max_workers=max(1, ahead))
-            nxt = 0
-            while nxt < len(keys) and len(preps) < max(1, ahead):
+
+        def enter_run(i):
+            """group i opens a run: the device route loads the run's share of the file (the previous share is dropped), the host route needs
+            nothing; then the first preparations of the run are started"""
+            nonlocal dbam, prepare, uploader, nxt
+            dbam = None
+            if run_dev[i] is not None:
+                # the first contigs' reference letters are read while the file is loaded (the loader mostly waits: for its reader threads, for the GPU)
+                ref_pool = ThreadPoolExecutor(max_workers=2)
+                for k in keys[i:min(run_end[i], i + 3)]:
+                    refs.setdefault(k[0], ref_pool.submit(read_fasta_bytes, params['fasta_path'], k[0]))
+                try:
+                    dbam = open_device_bam(params['sam_path'], device, contigs=list(run_dev[i]))
+                except DeviceIngestUnavailable:
+                    dbam = None
+                ref_pool.shutdown(wait=False)
+            if dbam is not None:
+                db = dbam
+                prepare = lambda chrom, grp: _prepare_device(db, params, chrom, grp, refs.pop(chrom, None))   # noqa: E731
+            else:
+                prepare = lambda chrom, grp: _prepare_wire(params, chrom, grp)   # noqa: E731
+                if uploader is None:
+                    from .wire import WireUploader
+                    uploader = WireUploader(get_engine(device))
+            nxt = i
+            while nxt < run_end[i] and len(preps) < max(1, ahead):
                 preps.append(prep_pool.submit(prepare, keys[nxt][0], groups[keys[nxt]]))
                 nxt += 1
         for i, (chrom, ploidy) in enumerate(keys):
             grp = groups[(chrom, ploidy)]
             if piped:
+                if i == 0 or run_end[i - 1] == i:
+                    enter_run(i)
                 wp = preps.pop(0).result()
-                if nxt < len(keys):
+                if nxt < run_end[i]:
                     preps.append(prep_pool.submit(prepare, keys[nxt][0], groups[keys[nxt]]))
                     nxt += 1
                 if dbam is not None:

@@ -458,7 +458,18 @@ def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files
     a = _args(bam, fa, str(tmp_path), haploid_X=True, mincov=2)
     regions = get_regions_list(a)
     outs = []
-    for tag, serial, dev in (("serial", "1", "0"), ("piped", None, "0"), ("device", None, None)):
+    from nanocaller_amd.device_bam import DeviceBam, plan_shares, release
+    each = max(DeviceBam(bam, 0, contigs=[c]).n_bytes for c in ("chr1", "chrX"))
+    assert [fits for _, fits in plan_shares(bam, ["chr1", "chrX"], each + 1)] == [True, True]      # one contig per share
+    assert [fits for _, fits in plan_shares(bam, ["chr1", "chrX"], each - 1)].count(False) >= 1    # a contig that fits no share: host route
+    assert plan_shares(bam, ["chr1", "chrX"]) == [(["chr1", "chrX"], True)]
+    for tag, serial, dev, share in (("serial", "1", "0", None), ("piped", None, "0", None), ("device", None, None, None), ("shares", None, None, each + 1),
+                                    ("mixed", None, None, each - 1)):
+        release()
+        if share:
+            monkeypatch.setenv("NC_DEVICE_INGEST_SHARE_GB", repr(share / (1 << 30)))
+        else:
+            monkeypatch.delenv("NC_DEVICE_INGEST_SHARE_GB", raising=False)
         if serial:
             monkeypatch.setenv("NC_SERIAL_INGEST", serial)
         else:
@@ -481,5 +492,10 @@ def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files
         files = []
         snpCaller.caller(params, q, queue.Queue(), files)
         outs.append(open(files[0], "rb").read())
-        assert sorted(x[1] for x in gsp.DECODES) == ([] if tag == "device" else ["chr1", "chrX"])   # every contig decoded once / not on the host at all
-    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 100
+        if tag in ("device", "shares"):
+            assert gsp.DECODES == []                                                # not decoded on the host at all
+        elif tag != "mixed":
+            assert sorted(x[1] for x in gsp.DECODES) == ["chr1", "chrX"]            # every contig decoded once
+        else:
+            assert 1 <= len(gsp.DECODES) <= 2
+    assert all(o == outs[0] for o in outs) and outs[0].count(b"\n") > 100

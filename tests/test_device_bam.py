@@ -187,3 +187,42 @@ def test_a_share_of_the_contigs_loads_only_its_part_of_the_file(tmp_path):
     assert open_device_bam(bam, 0, contigs=["c3"]) is a                     # a loaded share that holds the wanted contigs is reused
     assert open_device_bam(bam, 0) is not a
     release()
+
+
+def _four_contig_bam(tmp_path):
+    rng = np.random.default_rng(11)
+    refs = [("c%d" % k, 60_000) for k in range(4)]
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, ln)) for _, ln in refs]
+    recs = []
+    for tid in (0, 1, 3):
+        for r in range(700):
+            p0 = int(r * 80 + rng.integers(0, 40))
+            ln = min(int(rng.integers(300, 1500)), refs[tid][1] - p0)
+            recs.append(dict(tid=tid, name="r%d_%d" % (tid, r), flag=0, pos0=p0, cigar=[("M", ln)], seq=seqs[tid][p0:p0 + ln], tags={}))
+    bam = str(tmp_path / "m.bam")
+    bamio.write_bam(bam, refs[0][0], refs[0][1], recs, other_refs=refs[1:])
+    return bam
+
+
+def test_share_plan_of_a_file_that_does_not_fit_at_once(tmp_path):
+    """CPU: device_bam.plan_shares cuts the contigs of a call into runs whose part of the file stays under the limit (from the .bai alone)"""
+    from nanocaller_amd.device_bam import DeviceIngestUnavailable, contig_spans, plan_shares
+    bam = _four_contig_bam(tmp_path)
+    size = os.path.getsize(bam)
+    names = ["c0", "c1", "c2", "c3"]
+    spans, refs = contig_spans(bam)
+    assert refs == names and sorted(spans) == ["c0", "c1", "c3"] and spans["c3"][1] == size and spans["c0"][0] < spans["c1"][0] < spans["c3"][0]
+    assert plan_shares(bam, names) == [(names, True)]
+    assert plan_shares(bam, names, size + 1) == [(names, True)]
+    two = spans["c1"][1] - spans["c0"][0]                                 # c0 + c1 fit, c3 does not fit beside them
+    assert plan_shares(bam, names, two) == [(["c0", "c1", "c2"], True), (["c3"], True)]
+    one = max(hi - lo for lo, hi in spans.values())
+    assert plan_shares(bam, names, one) == [(["c0"], True), (["c1", "c2"], True), (["c3"], True)]
+    tiny = plan_shares(bam, names, 1000)
+    assert tiny == [(["c0"], False), (["c1"], False), (["c2"], True), (["c3"], False)]
+    assert plan_shares(bam, ["c3", "c0"], one) == [(["c3"], True), (["c0"], True)]      # the caller's order is kept
+    with pytest.raises(ValueError):
+        plan_shares(bam, ["nope"])
+    os.remove(bam + ".bai")
+    with pytest.raises(DeviceIngestUnavailable):
+        plan_shares(bam, names)
