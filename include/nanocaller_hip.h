@@ -29,7 +29,7 @@ extern "C" {
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
-                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members + nc_bam_walk / _meta / _codes (BAM ingest on the device) */
+                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members / _scan + nc_bam_walk / _meta / _codes / _indel_reads (BAM ingest on the device) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -221,6 +221,13 @@ int nc_bam_walk(nc_ctx *ctx, const uint8_t *d_raw, int64_t raw_len, int32_t n_se
 int nc_bam_meta(nc_ctx *ctx, const uint8_t *d_raw, int64_t n_rec, const int64_t *d_rec_off, int32_t *d_meta, int32_t *d_status);
 int nc_bam_codes(nc_ctx *ctx, const uint8_t *d_raw, int32_t n_reads, const int64_t *d_rec, const int64_t *d_slot, const int32_t *d_cigd,
                  const int32_t *d_ncig, const int32_t *d_start, uint8_t *d_codes);
+/* The indel path's per-read sections of the same kept reads -- what nc_bam_decode's events and nc_indel_pack_build make on the host
+ * (generate_indel_pileups.py:216-231's '+n' / '-n' markers, the inserted bases, the query bases behind the last aligned one).  Pass 1
+ * (d_ev_off == NULL): d_counts = int32 [3][n_reads]: events, inserted bases, tail bases (at most tail_cap) per read.  Pass 2: d_ev_off /
+ * d_ins_base / d_tail_off = exclusive prefix sums of those; fills d_ev_pos / d_ev_len / d_ins_off (per event) / d_ins_bases / d_tail_bases. */
+int nc_bam_indel_reads(nc_ctx *ctx, const uint8_t *d_raw, int32_t n_reads, const int64_t *d_rec, const int32_t *d_cigd, const int32_t *d_ncig,
+                       int32_t tail_cap, int32_t *d_counts, const int32_t *d_ev_off, const int32_t *d_ins_base, const int32_t *d_tail_off,
+                       int32_t *d_ev_pos, int32_t *d_ev_len, int32_t *d_ins_off, uint8_t *d_ins_bases, uint8_t *d_tail_bases);
 
 /* ------------------------------------------------------------------ SNP candidate scan (K1)
  * Replaces the column loop of get_snp_testing_candidates (generate_SNP_pileups.py:156-186) for a batch

@@ -42,7 +42,7 @@ EXPORTS = [
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
     "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
-    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_inflate_device_phase", "nc_bgzf_members", "nc_bgzf_scan", "nc_bam_walk", "nc_bam_meta", "nc_bam_codes", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
+    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_inflate_device_phase", "nc_bgzf_members", "nc_bgzf_scan", "nc_bam_walk", "nc_bam_meta", "nc_bam_codes", "nc_bam_indel_reads", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
 ]
 
 
@@ -223,6 +223,7 @@ def lib():
         L.nc_bam_walk.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
         L.nc_bam_meta.argtypes = [vp, vp, i64, vp, vp, vp]
         L.nc_bam_codes.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.nc_bam_indel_reads.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.nc_indel_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, i32, vp, i32, vp, vp, vp, vp, C.c_char_p, i64, i32, vp, i64, C.POINTER(i64), vp]
         L.nc_synth_indel_truth.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
         L.nc_synth_indel_reads.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]

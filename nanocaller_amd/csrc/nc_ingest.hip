@@ -193,6 +193,69 @@ __global__ __launch_bounds__(64 * WPB) void k_codes(const uint8_t *raw, int32_t 
     }
 }
 
+// ---- the indel path's per-read sections (nc_bam_decode's events + nc_indel_pack_build, nc_bam.cpp): one lane per kept read walks its CIGAR
+//      FILL == false: counts[0..3)[r] = insertion / deletion events ('+n' / '-n' markers on the previous reference column: an I or D with no
+//      column before it has none), inserted bases of those events, query bases behind the last aligned one (at most tail_cap);
+//      FILL == true: the events, where each one's inserted bases start, the bases themselves (codes), the tail -- at the offsets the counts'
+//      prefix sums give
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_indel_reads(const uint8_t *raw, int32_t n_reads, const int64_t *rec, const int32_t *cigd, const int32_t *ncig,
+                                                    int32_t tail_cap, int32_t *counts, const int32_t *ev_off, const int32_t *ins_base, const int32_t *tail_off,
+                                                    int32_t *ev_pos, int32_t *ev_len, int32_t *ins_off, uint8_t *ins_bases, uint8_t *tail_bases)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint8_t *p = raw + rec[r] + 4;
+    const int32_t pos = ld32(p + 4);
+    const int l_name = p[8], n_cig_field = p[12] | (p[13] << 8);
+    const int64_t L = ld32(p + 16);                                    // bases the record carries (0: SEQ '*')
+    const uint8_t *cig = p + cigd[r];
+    const uint8_t *seq = p + 32 + l_name + 4 * (size_t)n_cig_field;
+    const int nc = ncig[r] & 0x7fffffff;
+    int64_t qp = 0, rp = 0;
+    int32_t ne = 0, ni = 0;
+    int32_t e = FILL ? ev_off[r] : 0, io = FILL ? ins_base[r] : 0;
+    for (int k = 0; k < nc; k++) {
+        const uint32_t c = ldu32(cig + 4 * (size_t)k);
+        const int op = c & 15, len = (int)(c >> 4);
+        switch (op) {
+        case 0: case 7: case 8: rp += len; qp += len; break;
+        case 1:
+            if (rp > 0) {
+                const int64_t a = qp < L ? qp : L, b = qp + len < L ? qp + len : L;
+                if (FILL) {
+                    ev_pos[e] = pos + (int32_t)rp;
+                    ev_len[e] = len;
+                    ins_off[e] = io;
+                    for (int64_t q = a; q < b; q++) ins_bases[io++] = base_code(seq, (int)q);
+                    e++;
+                } else { ne++; ni += (int32_t)(b - a); }
+            }
+            qp += len;
+            break;
+        case 2:
+            if (rp > 0) {
+                if (FILL) { ev_pos[e] = pos + (int32_t)rp; ev_len[e] = -len; ins_off[e] = io; e++; }
+                else ne++;
+            }
+            rp += len;
+            break;
+        case 3: rp += len; break;
+        case 4: if (rp == 0) qp += len; break;                         // (a leading clip; a trailing one is the tail)
+        default: break;
+        }
+    }
+    const int64_t a = qp < L ? qp : L, b = qp + tail_cap < L ? qp + tail_cap : L;
+    if (FILL) {
+        int32_t t = tail_off[r];
+        for (int64_t q = a; q < b; q++) tail_bases[t++] = base_code(seq, (int)q);
+    } else {
+        counts[r] = ne;
+        counts[n_reads + r] = ni;
+        counts[2 * n_reads + r] = (int32_t)(b - a);
+    }
+}
+
 }   // namespace
 
 extern "C" {
@@ -311,6 +374,32 @@ int nc_bam_codes(nc_ctx *ctx, const uint8_t *d_raw, int32_t n_reads, const int64
     NC_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_codes, dim3((n_reads + WPB - 1) / WPB), dim3(64 * WPB), 0, ctx->stream, d_raw, n_reads, d_rec, d_slot, d_cigd, d_ncig, d_start,
                        d_codes);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}
+
+// The indel path's per-read sections of n_reads kept reads (d_rec / d_cigd / d_ncig as nc_bam_codes takes them).  Pass 1 (d_ev_off == NULL):
+// d_counts = int32 [3][n_reads]: events, inserted bases, tail bases (at most tail_cap behind the last aligned base) of every read.  Pass 2:
+// d_ev_off / d_ins_base / d_tail_off = the exclusive prefix sums of those; fills d_ev_pos / d_ev_len / d_ins_off (one entry per event; the
+// caller sets d_ins_off[n_events] = total) / d_ins_bases / d_tail_bases -- the arrays nc_bam_decode + nc_indel_pack_build make on the host.
+int nc_bam_indel_reads(nc_ctx *ctx, const uint8_t *d_raw, int32_t n_reads, const int64_t *d_rec, const int32_t *d_cigd, const int32_t *d_ncig,
+                       int32_t tail_cap, int32_t *d_counts, const int32_t *d_ev_off, const int32_t *d_ins_base, const int32_t *d_tail_off,
+                       int32_t *d_ev_pos, int32_t *d_ev_len, int32_t *d_ins_off, uint8_t *d_ins_bases, uint8_t *d_tail_bases)
+{
+    if (!ctx) return NC_ERR_ARG;
+    const bool fill = d_ev_off != nullptr;
+    if (n_reads < 0 || tail_cap < 0 || (n_reads && (!d_raw || !d_rec || !d_cigd || !d_ncig)) || (n_reads && !fill && !d_counts) ||
+        (n_reads && fill && (!d_ins_base || !d_tail_off || !d_ev_pos || !d_ev_len || !d_ins_off || !d_ins_bases || !d_tail_bases)))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_bam_indel_reads: bad argument");
+    if (n_reads == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((n_reads + 63) / 64), block(64);
+    if (fill)
+        hipLaunchKernelGGL(k_indel_reads<true>, grid, block, 0, ctx->stream, d_raw, n_reads, d_rec, d_cigd, d_ncig, tail_cap, d_counts, d_ev_off, d_ins_base,
+                           d_tail_off, d_ev_pos, d_ev_len, d_ins_off, d_ins_bases, d_tail_bases);
+    else
+        hipLaunchKernelGGL(k_indel_reads<false>, grid, block, 0, ctx->stream, d_raw, n_reads, d_rec, d_cigd, d_ncig, tail_cap, d_counts, d_ev_off, d_ins_base,
+                           d_tail_off, d_ev_pos, d_ev_len, d_ins_off, d_ins_bases, d_tail_bases);
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
 }

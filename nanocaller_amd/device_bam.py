@@ -461,7 +461,9 @@ class DeviceBam:
         Lref_b = int(ref_bytes.shape[0])
         ga, gb = max(1, tile_pos0.value), min(Lref_b, tile_pos0.value + n_tiles.value * tile_size - 1)
         parts = dict(rec=np.ascontiguousarray(self.rec_off[a + idx[kk]]), slot=slot, cigd=np.ascontiguousarray(mk[M_CIGD]),
-                     ncig=ncig.astype(np.uint32).view(np.int32), start=np.ascontiguousarray(ks), tile_off=tile_off,
+                     ncig=ncig.astype(np.uint32).view(np.int32), start=np.ascontiguousarray(ks), rd_end=np.ascontiguousarray(ke),
+                     slot_off=np.concatenate([slot, [int(size.sum())]]).astype(np.int64), read_hap=np.ascontiguousarray(mk[M_HAP].astype(np.uint8)),
+                     read_ps=np.ascontiguousarray(mk[M_PS]), read_flag=np.ascontiguousarray((mk[M_LSEQ] == 0).astype(np.uint8)), tile_off=tile_off,
                      tile_ent=tile_ent.view(np.uint8).reshape(-1), ref_letters=ref_bytes[ga - 1:gb] if gb >= ga else ref_bytes[:0])
         sections, total_b = {}, 0
         for k, v in parts.items():
@@ -505,8 +507,10 @@ class DeviceBam:
         return self._lut
 
     # ------------------------------------------------------------------ one contig: the slots, in HBM
-    def pack(self, prep, codes=None) -> DevicePack:
-        """device half: uploads the (small) arrays of prepare() and decodes the kept reads into `codes` (allocated when None)"""
+    def pack(self, prep, codes=None, indel=False, tail_cap=272) -> DevicePack:
+        """device half: uploads the (small) arrays of prepare() and decodes the kept reads into `codes` (allocated when None).  indel=True: the
+        pack also carries the indel path's sections (events, inserted bases, tails: what wire.build_wire(events=..., indel_extra=...) uploads on
+        the host route), made from the record stream by nc_bam_indel_reads"""
         eng, L, dev = self.eng, _lib.lib(), self.eng.device
         eng.use_torch_stream()
         vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
@@ -535,8 +539,33 @@ class DeviceBam:
             lo, hi = max(1, int(a)) - t0, max(1, int(b)) - t0
             if hi > max(lo, 0):
                 ref_code[max(lo, 0):min(hi, ref_len)] = 4
-        return DevicePack(codes=codes, tile_off=sec("tile_off"), tile_ent=sec("tile_ent"), ref_code=ref_code, tile_size=prep["tile_size"],
-                          tile_pos0=prep["tile_pos0"], n_tiles=prep["n_tiles"], n_entries=prep["n_entries"], pos_lo=prep["pos_lo"], pos_hi=prep["pos_hi"])
+        dp = DevicePack(codes=codes, tile_off=sec("tile_off"), tile_ent=sec("tile_ent"), ref_code=ref_code, tile_size=prep["tile_size"],
+                        tile_pos0=prep["tile_pos0"], n_tiles=prep["n_tiles"], n_entries=prep["n_entries"], pos_lo=prep["pos_lo"], pos_hi=prep["pos_hi"])
+        if indel:
+            K = prep["n_kept"]
+            i32 = lambda n_: torch.zeros(max(int(n_), 4), dtype=torch.int32, device=dev)   # noqa: E731
+            u8 = lambda n_: torch.zeros(max(int(n_), 4), dtype=torch.uint8, device=dev)    # noqa: E731
+            counts = torch.zeros((3, max(K, 1)), dtype=torch.int32, device=dev)
+            args = (vp(self.raw), K, vp(sec("rec")), vp(sec("cigd")), vp(sec("ncig")), int(tail_cap))
+            eng._check(L.nc_bam_indel_reads(eng.ctx, *args, vp(counts), None, None, None, None, None, None, None, None), "nc_bam_indel_reads")
+            offs = torch.zeros((3, K + 1), dtype=torch.int64, device=dev)
+            if K:
+                torch.cumsum(counts[:, :K], 1, out=offs[:, 1:])
+            n_ev, n_ins, n_tail = (int(x) for x in offs[:, K].tolist())
+            if max(n_ev, n_ins, n_tail) > 2**31 - 2:
+                raise _lib.NanoCallerHipError("more than 2^31 indel events / inserted bases in one contig")
+            o32 = offs.to(torch.int32)
+            ev_pos, ev_len, ins_off, ins_bases, tail_bases = i32(n_ev), i32(n_ev), i32(n_ev + 1), u8(n_ins), u8(n_tail)
+            if K:
+                eng._check(L.nc_bam_indel_reads(eng.ctx, *args, None, vp(o32[0]), vp(o32[1]), vp(o32[2]), vp(ev_pos), vp(ev_len), vp(ins_off), vp(ins_bases),
+                                                vp(tail_bases)), "nc_bam_indel_reads")
+            ins_off[n_ev] = n_ins
+            z = lambda t: t if t.numel() else torch.zeros(4, dtype=t.dtype, device=dev)   # noqa: E731
+            dp.events = dict(n_reads=K, ev_off=o32[0].contiguous(), ev_pos=ev_pos[:max(n_ev, 1)], ev_len=ev_len[:max(n_ev, 1)], read_hap=z(sec("read_hap")))
+            dp.reads = dict(n_reads=K, rd_start=z(sec("start")), rd_end=z(sec("rd_end")), slot_off=sec("slot_off"))
+            dp.indel = dict(ins_off=ins_off[:n_ev + 1], ins_bases=ins_bases, tail_off=o32[2].contiguous(), tail_bases=tail_bases, read_ps=z(sec("read_ps")),
+                            read_flag=z(sec("read_flag")))
+        return dp
 
 
 def contig_spans(path):

@@ -80,6 +80,11 @@ def release_contig(chrom=None):
     contig call this when they move on (the LRU bound does the same, later)."""
     _BAM_WORLDS.drop(lambda k: chrom is None or k[2] == chrom)
     _PACKS.drop(lambda k: chrom is None or k[2] == chrom)
+    import sys
+    gip = sys.modules.get(__package__ + ".generate_indel_pileups")       # (the indel route's device-ingested contig: same lifetime)
+    if gip is not None:
+        for k in [k for k in gip._DEV_INGEST if chrom is None or k[1] == chrom]:
+            del gip._DEV_INGEST[k]
 
 
 DECODES = []                  # (bam, contig, span or None) of every BAM decode of this process (tests: no contig is decoded twice)

@@ -652,21 +652,51 @@ def indel_sites_fetch(eng, N, S):
     return dict(pos=pos[:N], chunk=chunk[:N], type=typ[:N], phase=phase[:N], ref_len=rl[:N], alt_len=al[:N], alt=alt[:int(nb.value)])
 
 
+_DEV_INGEST = {}              # one contig at a time: (BAM, contig, FASTA, flag filter, device, file identity) -> (pack, nc_indel_reads, contig dict)
+
+
+def _device_ingest_contig(dct, sam_path, chrom, supp, device):
+    """The contig's read pack WITH the indel sections, made on the device from the BAM file itself (device_bam.py: inflate, record walk, codes,
+    events, inserted bases and tails in HBM) -- what decoded_contig + device_pack + device_indel_reads assemble on host threads.  None when the
+    input cannot take that route (no .bai, too large, NC_DEVICE_INGEST=0 / dct['device_ingest'] = False): the host route follows."""
+    if not dct.get("device_ingest", os.environ.get("NC_DEVICE_INGEST", "1") != "0") or not isinstance(sam_path, str) or not os.path.exists(sam_path):
+        return None
+    st = os.stat(sam_path)
+    key = (sam_path, chrom, dct["fasta_path"], supp, device, st.st_size, st.st_mtime_ns)
+    if key not in _DEV_INGEST:
+        from .bam import read_fasta_bytes
+        from .device_bam import DeviceIngestUnavailable, open_device_bam
+        from .wire import indel_reads_struct
+        _DEV_INGEST.clear()
+        try:
+            dbam = open_device_bam(sam_path, device, contigs=[chrom])
+        except DeviceIngestUnavailable:
+            return None
+        fasta_b = read_fasta_bytes(dct["fasta_path"], chrom)
+        dp = dbam.pack(dbam.prepare(chrom, fasta_b, supplementary=supp), indel=True, tail_cap=TAIL_CAP)
+        _DEV_INGEST[key] = (dp, indel_reads_struct(dp), dict(fasta=fasta_b.decode("ascii"), fasta_b=fasta_b, device_ingest=True))
+    return _DEV_INGEST[key]
+
+
 def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
     """The device pipeline for chunks (ascending) of one BAM and contig -> (result dict of indel_sites_device, contig dict)"""
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
     window_after = 260 if dct["seq"] == "pacbio" else 160
-    ctg = decoded_contig(sam_path, chrom, dct["fasta_path"])
     supp = bool(dct.get("supplementary"))
-    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if supp else 0x800)
-    if flag not in ctg["keep"]:
-        from .pack import pileup_depth_cap
-        dec = ctg["dec"]
-        ctg["keep"][flag] = pileup_depth_cap(dec["read_start"], dec["read_end"], np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8))
     eng = get_engine(device)
     eng.use_torch_stream()
-    dp = device_pack(sam_path, dct.get("fasta_path"), chrom, supp, None, device)[0]
-    reads_c = device_indel_reads(ctg, flag, dp, device)
+    di = _device_ingest_contig(dct, sam_path, chrom, supp, device)
+    if di is not None:
+        dp, reads_c, ctg = di
+    else:
+        ctg = decoded_contig(sam_path, chrom, dct["fasta_path"])
+        flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if supp else 0x800)
+        if flag not in ctg["keep"]:
+            from .pack import pileup_depth_cap
+            dec = ctg["dec"]
+            ctg["keep"][flag] = pileup_depth_cap(dec["read_start"], dec["read_end"], np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8))
+        dp = device_pack(sam_path, dct.get("fasta_path"), chrom, supp, None, device)[0]
+        reads_c = device_indel_reads(ctg, flag, dp, device)
     excl = None
     excl_rows = _exclude_rows(dct, chrom)
     if excl_rows:

@@ -226,3 +226,74 @@ def test_share_plan_of_a_file_that_does_not_fit_at_once(tmp_path):
     os.remove(bam + ".bai")
     with pytest.raises(DeviceIngestUnavailable):
         plan_shares(bam, names)
+
+
+def _same_indel_sections(bam, fa, chrom, supplementary=False):
+    """the indel path's per-read sections made on the device == nc_bam_decode's events + nc_indel_pack_build's arrays (host route)"""
+    import ctypes as C
+    import torch
+    from nanocaller_amd import generate_indel_pileups as gip
+    from nanocaller_amd.bam import read_fasta
+    from nanocaller_amd.device_bam import DeviceBam
+    from nanocaller_amd.pack import pileup_depth_cap
+    gip._CONTIGS.clear()
+    ctg = gip.decoded_contig(bam, chrom, fa)
+    dec = ctg["dec"]
+    flag = 0x4 | 0x100 | 0x200 | 0x400 | (0 if supplementary else 0x800)
+    keep = pileup_depth_cap(dec["read_start"], dec["read_end"], np.ascontiguousarray((dec["read_flag"] & flag) == 0, np.uint8))
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.nc_indel_pack_build(ctg["handle"], _lib.npp(keep), gip.TAIL_CAP, C.byref(h)) == _lib.NC_OK
+    v = _lib.IndelPackArraysC()
+    L.nc_indel_pack_view(h, C.byref(v))
+
+    def arr(ptr, cnt, dt):
+        return np.frombuffer((C.c_char * (int(cnt) * np.dtype(dt).itemsize)).from_address(ptr), dt).copy() if cnt and ptr else np.zeros(0, dt)
+    want = dict(ev_off=arr(v.ev_off, v.n_reads + 1, np.int32), ev_pos=arr(v.ev_pos, v.n_events, np.int32), ev_len=arr(v.ev_len, v.n_events, np.int32),
+                ins_off=arr(v.ins_off, v.n_events + 1, np.int32), ins_bases=arr(v.ins_bases, v.n_ins_bases, np.uint8),
+                tail_off=arr(v.tail_off, v.n_reads + 1, np.int32), tail_bases=arr(v.tail_bases, v.n_tail_bases, np.uint8),
+                read_ps=arr(v.read_ps, v.n_reads, np.int32), read_hap=arr(v.read_hap, v.n_reads, np.uint8), read_flag=arr(v.read_flag, v.n_reads, np.uint8))
+    K = int(v.n_reads)
+    L.nc_indel_pack_free(h)
+    db = DeviceBam(bam, 0).load()
+    dp = db.pack(db.prepare(chrom, read_fasta(fa, chrom), supplementary=supplementary), indel=True, tail_cap=gip.TAIL_CAP)
+    torch.cuda.synchronize()
+    assert dp.events["n_reads"] == dp.reads["n_reads"] == K
+    got = dict(ev_off=dp.events["ev_off"], ev_pos=dp.events["ev_pos"], ev_len=dp.events["ev_len"], read_hap=dp.events["read_hap"], **dp.indel)
+    n_ev = int(want["ev_off"][-1]) if K else 0
+    for k, w in want.items():
+        g = got[k].cpu().numpy()
+        n = {"ev_pos": n_ev, "ev_len": n_ev, "ins_bases": want["ins_bases"].size, "tail_bases": want["tail_bases"].size, "read_ps": K, "read_hap": K, "read_flag": K}.get(k, w.size)
+        assert np.array_equal(g[:n].astype(w.dtype), w[:n]), (k, g[:10], w[:10])
+    kk = np.flatnonzero(keep)
+    assert np.array_equal(dp.reads["rd_start"].cpu().numpy()[:K], dec["read_start"][kk]) and np.array_equal(dp.reads["rd_end"].cpu().numpy()[:K], dec["read_end"][kk])
+    gip._CONTIGS.clear()
+    return n_ev, want
+
+
+@pytest.mark.gpu
+def test_indel_sections_from_the_record_stream_equal_the_host_routes(tmp_path):
+    w = bamio.make_bam_world()
+    recs = bamio.world_to_records(w, np.random.Generator(np.random.PCG64(1)))
+    bam, fa = str(tmp_path / "w.bam"), str(tmp_path / "w.fa")
+    bamio.write_bam(bam, w.chrom, w.length, recs)
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    n_ev, want = _same_indel_sections(bam, fa, w.chrom)
+    assert n_ev > 200 and want["ins_bases"].size > 50
+    ops = "MIDNSHP=X"
+    ref = "ACGT" * 500
+    seq = "ACGTACGTAC" + "GG" + "TACGTACG"
+    real = [("M", 10), ("I", 2), ("D", 3), ("M", 8)]
+    cg = [(ln << 4) | ops.index(op) for op, ln in real]
+    recs = [dict(name="noseq", flag=0, pos0=40, cigar=[("M", 300), ("D", 4), ("M", 200)], seq="", tags={}),
+            dict(name="short", flag=0, pos0=60, cigar=[("M", 10), ("I", 4), ("M", 20)], seq="ACGTACGTACGG", tags={"PS": 5}),
+            dict(name="clip", flag=16, pos0=99, cigar=[("H", 5), ("S", 2), ("M", 4), ("I", 3), ("M", 2), ("D", 2), ("M", 3), ("=", 2), ("X", 1), ("I", 2), ("S", 4)],
+                 seq="TTACGTAAAGGCATACGAGGTTTT", tags={"HP": 2, "PS": 70000}),
+            dict(name="longcig", flag=0, pos0=100, cigar=[("S", len(seq)), ("N", 21)], seq=seq, tags={"HP": 2, "CG": cg, "PS": 77}),
+            dict(name="ins1st", flag=0, pos0=120, cigar=[("S", 3), ("I", 2), ("M", 5), ("D", 1), ("M", 2)], seq="TTTGGACGTNAC" + "A" * 300, tags={}),
+            dict(name="longtail", flag=0, pos0=300, cigar=[("M", 20), ("S", 400)], seq="ACGT" * 105, tags={"HP": 1})]
+    bam2, fa2 = str(tmp_path / "c.bam"), str(tmp_path / "c.fa")
+    bamio.write_bam(bam2, "chrT", len(ref), recs)
+    bamio.write_fasta(fa2, "chrT", ref)
+    n_ev, want = _same_indel_sections(bam2, fa2, "chrT")
+    assert want["read_flag"].tolist() == [1, 0, 0, 0, 0, 0] and want["tail_off"][-1] > 272

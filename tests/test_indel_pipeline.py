@@ -312,6 +312,26 @@ def test_device_pipeline_in_small_groups_is_the_same(world_files, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_device_ingest_feeds_the_indel_pipeline_the_host_ingests_inputs(world_files, monkeypatch):
+    """the contig's pack + events + inserted bases + tails made in HBM from the BAM file (device_bam.py) or on host threads (nc_bam_decode,
+    nc_indel_pack_build, wire): the same tuples; the default takes the device"""
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    w, bam, fa = world_files
+    dct = _params(fa)
+    chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 50_000), sam_path=bam) for s in range(1, w.length, 50_000)]
+    gsp.release_contig()
+    gip._CONTIGS.clear()
+    del gsp.DECODES[:]
+    a = gip.get_indel_testing_candidates_batch(dct, chunks)
+    assert len(gip._DEV_INGEST) == 1 and gsp.DECODES == [] and not gip._CONTIGS        # nothing was decoded on the host
+    monkeypatch.setenv("NC_DEVICE_INGEST", "0")
+    gsp.release_contig()
+    b = gip.get_indel_testing_candidates_batch(dct, chunks)
+    assert not gip._DEV_INGEST and gip._CONTIGS
+    assert _same_tuples(b, a) > 100
+
+
+@pytest.mark.gpu
 def test_indel_run_native_text_equals_the_python_rules(world_files, tmp_path, monkeypatch):
     """indelCaller.indel_run on the device pipeline + nc_indel_vcf_format writes the file the tuple route + Python rules write"""
     import queue
