@@ -6,7 +6,8 @@
 //   k_huff   ONE LANE PER MEMBER, eight members per workgroup.  Huffman decoding is a serial chain per stream but the SAME short loop for every stream:
 //            64-bit bit buffer refilled from aligned dwords, per-lane first-level tables in LDS (literal / length 9 bits, distance 6 bits;
 //            entry = symbol << 4 | code length), codes longer than the index by the canonical count / symbol walk.  It does NOT copy: a literal
-//            leaves as the token 0x80000000 | byte, a match as length << 16 | distance, one dword per symbol into the member's token run.
+//            leaves as the token 0x80000000 | byte (two literals in a row: | 0x10000 | second << 8), a match as length << 16 | distance, into
+//            the member's token run.
 //   k_lz     ONE WAVE PER MEMBER.  64 tokens per step: their output positions by a wave scan, all literals stored at once, the matches in
 //            order with all 64 lanes copying (source and destination in a 16 KB LDS ring of the member's recent output, so overlapping and
 //            chained matches are plain LDS traffic; older sources are read back from HBM); finished stretches leave LDS as aligned dwords.
@@ -305,6 +306,10 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
                 take((int)(e & 15));
                 if (__builtin_expect(e == 0, 0)) sym = slow_from(hl, wk, LT_BITS);
                 const bool lit = sym < 256, mat = sym > 256;
+                // a literal often has a literal behind it: the step takes that one too when the table knows it (two codes: at most 30 of the 33 bits)
+                const uint32_t e_2 = lt[(uint32_t)bb & (LT_SZ - 1)];
+                const bool two = lit && sym >= 0 && e_2 != 0 && (e_2 >> 4) < 256 && op + 2 <= isize;
+                take(two ? (int)(e_2 & 15) : 0);
                 const int c = mat ? sym - 257 : 0;
                 const int e1 = (c < 8 || c >= 28) ? 0 : (c >> 2) - 1;
                 const int lbase = c < 8 ? 3 + c : c >= 28 ? 258 : 3 + ((4 + (c & 3)) << e1);
@@ -318,10 +323,10 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
                 const int e2 = (ds < 4 || ds > 29) ? 0 : (ds >> 1) - 1;
                 const int dbase = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e2);
                 const int dist = dbase + (int)take(e2);                 // (15 + 13 bits)
-                const int add = lit ? 1 : mat ? len : 0;
+                const int add = lit ? (two ? 2 : 1) : mat ? len : 0;
                 const int bad = (sym < 0 || (mat && (c > 28 || ds < 0 || ds > 29 || dist > op))) ? 3 : op + add > isize ? 4 : 0;
                 const bool emit = (lit || mat) && !bad;
-                if (emit) tk[(size_t)nt << LPW_SH] = lit ? 0x80000000u | (uint32_t)sym : (uint32_t)len << 16 | (uint32_t)dist;
+                if (emit) tk[(size_t)nt << LPW_SH] = lit ? 0x80000000u | (two ? 0x10000u | (e_2 >> 4) << 8 : 0u) | (uint32_t)sym : (uint32_t)len << 16 | (uint32_t)dist;
                 nt += emit;
                 op += emit ? add : 0;
                 err = err ? err : bad;
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
         c_next = c + 64;
         t_next = c_next + lane < nt ? tk[(size_t)(c_next + lane) << LPW_SH] : 0u;
         const bool lit = (t >> 31) != 0;
-        int len = lit ? 1 : (int)(t >> 16);
+        int len = lit ? 1 + (int)((t >> 16) & 1u) : (int)(t >> 16);      // (a literal token carries one or two bytes)
         const int dist = (int)(t & 0xffffu);
         const int incl = wave_scan_incl(len, lane);
         // the step takes the tokens whose output ends within SPAN bytes (at least one: a token is at most 258 bytes); the rest wait for the next
@@ -405,7 +410,10 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
         const int nv = __builtin_popcountll(fit);                      // (the scan is monotone: `fit` is a prefix of the lanes)
         if (lane >= nv) len = 0;
         const int pos = base + incl - len;
-        if (lit && lane < nv) ring[pos & M] = (uint8_t)t;
+        if (lit && lane < nv) {
+            ring[pos & M] = (uint8_t)t;
+            if (len == 2) ring[(pos + 1) & M] = (uint8_t)(t >> 8);
+        }
         // the ring holds the RING bytes before the end of this step's output (its literals are in already); what is older is in HBM:
         // flushed >= ring_lo, because a flush is due every FLUSH bytes and a step adds at most SPAN
         const int ring_lo = base + __builtin_amdgcn_readlane(incl, nv - 1) - RING;
