@@ -827,7 +827,7 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
             os.environ.pop(k, None)
         os.environ.update(env)
         best = None
-        for rep in range(2):                                          # best of two: the first run of a route also pays its one-off costs (page-locked
+        for rep in range(3):                                          # best of three: the first run of a route also pays its one-off costs (page-locked
             gsp.release_contig()                                      # buffers of the file's size, first launches); every run starts from the file
             device_bam.release()
             d = os.path.join(tmp, "%s%d" % (tag, rep))
@@ -865,7 +865,7 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
             "device_ingest": out["device_ingest"], "host_ingest": out["host_ingest"], "serial_ingest": out["serial_ingest"],
             "vcf_identical_device_vs_host": texts["device_ingest"] == texts["host_ingest"], "bam_writing_s": round(t_files, 1),
             "bam_bytes": size,
-            "note": "ingest is outside SURVEY 8d's timed region (its row n1); this is the product worker loop end to end, best of two runs per route over a file "
+            "note": "ingest is outside SURVEY 8d's timed region (its row n1); this is the product worker loop end to end, best of three runs per route over a file "
                     "the test tooling wrote moments before (page cache warm)"}
 
 

@@ -99,7 +99,7 @@ if os.environ.get("NC_EXP_PROFILE"):
         snpCaller.caller(params, q, queue.Queue(), [], device=0)
         torch.cuda.synchronize()
         pr.disable()
-        print("route %s: %.1f ms" % (route, (time.perf_counter() - t0) * 1e3))
+        print("route %s: %.1f ms" % (route, (time.perf_counter() - t0) * 1e3), {k: (round(v * 1e3, 1) if isinstance(v, float) else v) for k, v in device_bam.LAST_LOAD.items()} if route == "1" else "")
         for o, n_, f in saved:
             setattr(o, n_, f)
         print("  GPU time between the events around:", ", ".join("%s %.2f ms" % (t, a.elapsed_time(b)) for t, a, b in gpu_ev))
