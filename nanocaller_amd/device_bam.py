@@ -10,8 +10,8 @@ the FILE crosses PCIe as it is -- a BAM is already a compressed form of the pack
 
 Which reads the pileup keeps (flag filter, htslib's depth cap, the unsupported-input checks) and the tile index are decided on the host
 from the per-record fields with the same functions the host route uses, so a `DevicePack` made here is byte for byte the one
-`wire.upload_wire(build_wire_from_world(bam.read_bam(...)))` makes (tests/test_device_bam.py), without the indel sections: SNP route only.
-Needs the .bai (its linear index cuts the record chain into independent walks).
+`wire.upload_wire(build_wire_from_world(bam.read_bam(...)))` makes (tests/test_device_bam.py); `pack(indel=True)` adds the indel path's sections.
+Needs an index beside the file: a .bai's linear index, or a .csi's bin offsets and chunk begins, cut the record chain into independent walks.
 """
 from __future__ import annotations
 
@@ -43,9 +43,11 @@ class DeviceIngestUnavailable(RuntimeError):
 
 
 def _bai_path(path):
-    for p in (path + ".bai", os.path.splitext(path)[0] + ".bai"):
-        if os.path.exists(p):
-            return p
+    """the index beside the BAM: .bai, else .csi (None: the device route is not available)"""
+    for ext in (".bai", ".csi"):
+        for p in (path + ext, os.path.splitext(path)[0] + ext):
+            if os.path.exists(p):
+                return p
     return None
 
 
@@ -58,8 +60,39 @@ def bai_linear_voffsets(bai_path):
     key = (os.path.abspath(bai_path), st.st_size, st.st_mtime_ns)
     if key not in _BAI:
         _BAI.clear()
-        _BAI[key] = _bai_linear_voffsets(bai_path)
+        _BAI[key] = _csi_record_starts(bai_path) if bai_path.endswith(".csi") else _bai_linear_voffsets(bai_path)
     return _BAI[key]
+
+
+def _csi_record_starts(csi_path):
+    """the same from a CSI index (hts-specs CSIv1; the file is BGZF-compressed), which has no linear index: every bin's `loffset` and every
+    chunk's begin are virtual offsets of record starts of that reference -- the leaf bins (16 kb with the default min_shift) make them as
+    dense as a .bai's windows"""
+    import gzip
+    with open(csi_path, "rb") as f:
+        buf = gzip.decompress(f.read())
+    if buf[:4] != b"CSI\1":
+        raise ValueError("%s is not a CSI file" % csi_path)
+    _, depth, l_aux = struct.unpack_from("<3i", buf, 4)
+    o = 16 + l_aux
+    n_ref, = struct.unpack_from("<i", buf, o)
+    o += 4
+    meta_bin = ((1 << (depth * 3 + 3)) - 1) // 7 + 1                   # the pseudo-bin with the mapped / unmapped counts
+    out = {}
+    for r in range(n_ref):
+        n_bin, = struct.unpack_from("<i", buf, o)
+        o += 4
+        starts = []
+        for _ in range(n_bin):
+            b, loff, n_chunk = struct.unpack_from("<IQi", buf, o)
+            o += 16
+            if b != meta_bin:
+                starts.append(np.array([loff], np.uint64))
+                starts.append(np.frombuffer(buf, np.uint64, 2 * n_chunk, o)[0::2])
+            o += 16 * n_chunk
+        v = np.concatenate(starts) if starts else np.zeros(0, np.uint64)
+        out[r] = np.unique(v[v != 0])
+    return out
 
 
 def _bai_linear_voffsets(bai_path):
@@ -116,7 +149,7 @@ class DeviceBam:
         self.eng = get_engine(device)
         bai = _bai_path(path)
         if bai is None:
-            raise DeviceIngestUnavailable("%s: no .bai beside it" % path)
+            raise DeviceIngestUnavailable("%s: no .bai / .csi beside it" % path)
         self.lin = bai_linear_voffsets(bai)
         from .bam import rank_threads
         self.threads = threads or rank_threads()
@@ -579,7 +612,7 @@ def contig_spans(path):
     probe = DeviceBam.__new__(DeviceBam)
     bai = _bai_path(path)
     if bai is None:
-        raise DeviceIngestUnavailable("%s: no .bai beside it" % path)
+        raise DeviceIngestUnavailable("%s: no .bai / .csi beside it" % path)
     probe.path, probe.lin, probe.file_bytes = path, bai_linear_voffsets(bai), os.path.getsize(path)
     probe._read_header()
     with_reads = [t for t in sorted(probe.lin) if probe.lin[t].size and t < len(probe.ref_names)]

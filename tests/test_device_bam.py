@@ -297,3 +297,23 @@ def test_indel_sections_from_the_record_stream_equal_the_host_routes(tmp_path):
     bamio.write_fasta(fa2, "chrT", ref)
     n_ev, want = _same_indel_sections(bam2, fa2, "chrT")
     assert want["read_flag"].tolist() == [1, 0, 0, 0, 0, 0] and want["tail_off"][-1] > 272
+
+
+@pytest.mark.gpu
+def test_csi_indexed_bam_takes_the_device_route_too(tmp_path):
+    """no .bai: the chain starts come from the .csi's bin offsets and chunk begins; same packs, whole file and a share of the contigs"""
+    from nanocaller_amd.device_bam import contig_spans
+    w = bamio.make_bam_world()
+    recs = bamio.world_to_records(w, np.random.Generator(np.random.PCG64(1)))
+    extra = [dict(tid=1, name="o%d" % k, flag=0, pos0=10 * k, cigar=[("M", 50)], seq="ACGTA" * 10, tags={}) for k in range(40)]
+    bam, fa = str(tmp_path / "w.bam"), str(tmp_path / "w.fa")
+    bamio.write_bam(bam, w.chrom, w.length, recs + extra, other_refs=[("chrOther", 1000)], write_bai=False, write_csi=True)
+    bamio.write_fasta(fa, w.chrom, w.ref, extra=[("chrOther", "ACGT" * 250)])
+    assert os.path.exists(bam + ".csi") and not os.path.exists(bam + ".bai")
+    spans, names = contig_spans(bam)
+    assert names == [w.chrom, "chrOther"] and sorted(spans) == sorted(names)
+    _, prep, _ = _same_pack(bam, fa, w.chrom)
+    assert prep["n_kept"] > 100
+    _, prep, _ = _same_pack(bam, fa, "chrOther", contigs=["chrOther"])
+    assert prep["n_kept"] == 40
+    _same_indel_sections(bam, fa, w.chrom)
