@@ -275,7 +275,15 @@ class DeviceBam:
         pool = ThreadPoolExecutor(max_workers=max(2, min(self.threads // 2, 8)))
         futures = [pool.submit(read_piece, a) for a in range(0, n, piece)]
         raw_cap = n * 8 + (64 << 20)                                     # the inflated size is known only at the end: room for eight-fold
-        self.raw = torch.empty(raw_cap, dtype=torch.uint8, device=dev)
+        # the stream's buffer is kept from load to load (share after share of a genome-sized file, run after run of a bench): a fresh multi-gigabyte
+        # request that misses the allocator's cache makes it release and re-acquire device memory, which was seen to take > 100 ms
+        import weakref
+        pooled = _RAW_POOL.get(dev.index)
+        if pooled is not None and pooled[0].numel() >= raw_cap and pooled[1]() in (None, self):
+            self.raw = pooled[0]
+        else:
+            self.raw = torch.empty(raw_cap + raw_cap // 8, dtype=torch.uint8, device=dev)
+        _RAW_POOL[dev.index] = (self.raw, weakref.ref(self))
         d_file = torch.empty(n + 64, dtype=torch.uint8, device=dev)
         cap = n // 1024 + 4096
         stage64 = torch.empty(2 * cap, dtype=torch.int64, pin_memory=True)    # [coff | ooff] of every member, page-locked: the batches' uploads are async
@@ -283,8 +291,11 @@ class DeviceBam:
         coff, ooff = stage64.numpy()[:cap], stage64.numpy()[cap:]
         clen, isize = stage32.numpy()[:cap], stage32.numpy()[cap:]
         # two token workspaces: the Huffman kernel of batch i + 1 (compute stream) runs beside the match resolution of batch i (its own stream)
-        toks = [(torch.empty(((INFLATE_BATCH + 63) // 64) << 22, dtype=torch.int32, device=dev), torch.zeros(INFLATE_BATCH, dtype=torch.int32, device=dev), [None])
+        # (256 KB of tokens per member: a small file gets small workspaces -- and, should its members be unusually short, more batches)
+        batch = min(INFLATE_BATCH, max(64, (n // 4096 + 63) // 64 * 64))
+        toks = [(torch.empty(((batch + 63) // 64) << 22, dtype=torch.int32, device=dev), torch.zeros(batch, dtype=torch.int32, device=dev), [None])
                 for _ in range(2)]
+        t_alloc = time.perf_counter() - t_start
         copy_stream, lz_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         compute = torch.cuda.current_stream(dev)
         lz_stream.wait_stream(compute)                                   # (the output buffer's allocation)
@@ -323,8 +334,11 @@ class DeviceBam:
             keep.append((d64, d32))                                      # (allocated on the copy stream, read on the compute stream: alive until the sync)
             m0 = m1
         try:
+            t_wait = t_launch = 0.0
             for fut in futures:
+                tw = time.perf_counter()
                 avail = fut.result()
+                t_wait += time.perf_counter() - tw
                 while True:
                     k, nxt = C.c_int64(), C.c_int64()
                     rc = L.nc_bgzf_scan(_lib.npp(data), avail, scan_pos, cap - n_mem, vp(stage64, 8 * n_mem), vp(stage32, 4 * n_mem), vp(stage32, 4 * (cap + n_mem)),
@@ -345,18 +359,21 @@ class DeviceBam:
                     raise DeviceIngestUnavailable("%s: more BGZF members than planned for" % self.path)
                 if total + 64 > raw_cap:
                     raise DeviceIngestUnavailable("%s inflates more than eight-fold" % self.path)
-                while n_mem - m0 >= INFLATE_BATCH:
-                    launch(m0 + INFLATE_BATCH)
+                tw = time.perf_counter()
+                while n_mem - m0 >= batch:
+                    launch(m0 + batch)
+                t_launch += time.perf_counter() - tw
             if scan_pos != n and self.B1 == self.file_bytes:
                 raise _lib.NanoCallerHipError("%s does not end with a whole BGZF member" % self.path)
-            if n_mem > m0:
-                launch(n_mem)
+            while n_mem > m0:
+                launch(min(n_mem, m0 + batch))
         finally:
             pool.shutdown(wait=True)
             os.close(fd)
         LAST_LOAD.clear()
         LAST_LOAD["read_scan_enqueue"] = time.perf_counter() - t_start
         LAST_LOAD["of_which_page_locked_alloc"] = t_pin
+        LAST_LOAD["of_which_allocations"], LAST_LOAD["of_which_waiting_for_readers"], LAST_LOAD["of_which_enqueue"] = t_alloc, t_wait, t_launch
         t0 = time.perf_counter()
         self.coff, self.clen, self.isize = coff[:n_mem].copy(), clen[:n_mem].copy(), isize[:n_mem].copy()
         self.ooff = np.concatenate([ooff[:n_mem], [total]]).astype(np.int64)
@@ -656,6 +673,7 @@ def plan_shares(path, contigs, limit_bytes=None):
 
 
 _OPEN = {}
+_RAW_POOL = {}               # device index -> (buffer of the inflated stream, weak reference to the DeviceBam that is using it)
 
 
 def open_device_bam(path, device=0, contigs=None) -> DeviceBam:
@@ -672,6 +690,9 @@ def open_device_bam(path, device=0, contigs=None) -> DeviceBam:
     return db.load()
 
 
-def release(path=None):
+def release(path=None, buffers=False):
+    """forget the loaded files (of `path`, or all); buffers=True also gives the pooled stream buffers back"""
     for k in [k for k in _OPEN if path is None or k[0] == os.path.abspath(path)]:
         del _OPEN[k]
+    if buffers:
+        _RAW_POOL.clear()
