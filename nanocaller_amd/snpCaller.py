@@ -340,15 +340,22 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             counter_Q.put(1)
 
     with open(curr_vcf_path, 'wb') as f, ThreadPoolExecutor(max_workers=1) as pool:
-        pending, in_flight = None, None
+        pending, in_flight = None, []                                # groups whose kernels are queued and whose results have not been collected
 
         def collect():
             nonlocal pending
-            chrom, ploidy, call, grp = in_flight
+            chrom, ploidy, call, grp, gi = in_flight.pop(0)
             r = call.result()
             if pending is not None:
                 pending.result()                                    # keeps the records in group order; re-raises errors
             pending = pool.submit(emit, f, chrom, ploidy, r, grp)
+            if last_use[chrom] == gi:
+                # a genome is walked contig by contig: drop the decoded alignments and the HBM pack of the one just finished (on an
+                # ingest thread when there is one: unmapping ~100 MB takes 8 ms this thread would not be launching kernels)
+                if piped:
+                    prep_pool.submit(release_contig, chrom)
+                else:
+                    release_contig(chrom)
         keys = list(groups)
         last_use = {chrom: i for i, (chrom, _) in enumerate(keys)}         # last group of every contig
         for k in keys:
@@ -386,6 +393,7 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             except DeviceIngestUnavailable:
                 pass
         dbam, prepare, nxt = None, None, 0
+        depth = max(1, int(os.environ.get('NC_CALLER_DEPTH', 2 if piped else 1)))
         if piped and keys:
             ahead = int(os.environ.get('NC_INGEST_AHEAD', 2))
             # two groups ahead: the Python half of one pack's preparation (header parsing, the wire's index arrays, freeing the decoded
@@ -439,18 +447,13 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
                     uploader.release(tk)
             else:
                 call = call_chunks(params, grp, device, defer=True)     # enqueued behind the previous group's CNN
-            if in_flight is not None:
+            in_flight.append((chrom, ploidy, call, grp, i))
+            # results are collected `depth` groups late: the copies that bring a group's results back run as kernels, and those wait for the NEXT
+            # group's CNN (its persistent workgroups hold every CU) -- collecting group i - 1 right after enqueuing group i made the launching
+            # thread wait out that CNN and only then prepare the next launch (6.3 ms a group for 4 ms of GPU work)
+            while len(in_flight) > depth:
                 collect()
-                done = keys[i - 1][0]
-                if last_use[done] == i - 1:
-                    # a genome is walked contig by contig: drop the decoded alignments and the HBM pack of the one just finished (on an
-                    # ingest thread when there is one: unmapping ~100 MB takes 8 ms this thread would not be launching kernels)
-                    if piped:
-                        prep_pool.submit(release_contig, done)
-                    else:
-                        release_contig(done)
-            in_flight = (chrom, ploidy, call, grp)                  # pack of the one just finished
-        if in_flight is not None:
+        while in_flight:
             collect()
         if pending is not None:
             pending.result()
