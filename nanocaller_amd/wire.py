@@ -146,7 +146,8 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
             if kept.size == n:                                        # nothing filtered: the events are already in pack order
                 idx = slice(0, int(ev_off[-1]))
             else:
-                idx = np.concatenate([np.arange(ev_off[r], ev_off[r + 1]) for r in kept]) if kept.size else np.zeros(0, np.int64)
+                # (the kept reads' event ranges, one after the other: start of each range - where it lands, repeated, + a running index)
+                idx = (np.repeat(ev_off[:-1][kept].astype(np.int64) - off[:-1], cnt) + np.arange(int(off[-1]), dtype=np.int64)) if kept.size else np.zeros(0, np.int64)
             hp = (np.asarray(hap, np.uint8) if hap is not None else np.zeros(n, np.uint8))[kept]
             z = lambda x, dt: np.ascontiguousarray(x, dt) if len(x) else np.zeros(1, dt)      # noqa: E731
             # the events cross PCIe as 3 bytes each (distance to the read's previous event, signed length; a side table for the few that do

@@ -41,10 +41,19 @@ for tag, env in (("device_ingest", "1"), ("host_ingest", "0")):
         for s in range(1, w.length, 100_000):
             jobs.put(("indel", dict(chrom=w.chrom, start=s, end=min(w.length, s + 100_000), ploidy="diploid", sam_path=bam)))
         torch.cuda.synchronize()
+        prof = os.environ.get("NC_EXP_PROFILE") and rep == 2
+        if prof:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
         t0 = time.perf_counter()
         out = indelCaller.indel_run(params, {}, jobs, queue.Queue(), [], aligner="device")
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if prof:
+            pr.disable()
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
         texts[tag] = open(out).read()
         best = dt if best is None else min(best, dt)
     print("%s: %.1f ms, %d records" % (tag, best * 1e3, texts[tag].count("\n")), flush=True)
