@@ -2,7 +2,7 @@
 // are inflated in HBM.  This replaces the host's inflate (libdeflate / zlib on worker threads: 73 % of the ingest of
 // generate_SNP_pileups.py:134-164's input) on the way from a BAM file to the read pack.
 //
-// Two kernels, because the two halves of inflate want opposite shapes (DESIGN.md section 11.6 has the measurements that led here):
+// Two kernels, because the two halves of inflate want opposite shapes (DESIGN.md section 12 has the measurements that led here):
 //   k_huff   ONE LANE PER MEMBER, eight members per workgroup.  Huffman decoding is a serial chain per stream but the SAME short loop for every stream:
 //            64-bit bit buffer refilled from aligned dwords, per-lane first-level tables in LDS (literal / length 9 bits, distance 6 bits;
 //            entry = symbol << 4 | code length), codes longer than the index by the canonical count / symbol walk.  It does NOT copy: a literal
