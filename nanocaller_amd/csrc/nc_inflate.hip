@@ -70,7 +70,23 @@ __device__ bool huff_build(uint16_t *h, const uint8_t *lens, int n)
     return true;
 }
 
+// what a literal / length symbol means, in 12 bits: kind x (0-5: a match length with x extra bits; 6: a literal; 7: end of block, or -- value
+// 1 -- one of the two symbols that must not occur) | value << 3 (the byte; the length's base - 3).  The literal / length table holds this
+// instead of the symbol: the symbol loop then has no length arithmetic left (RFC 1951 3.2.5's table, folded into the table build)
+__device__ __forceinline__ uint32_t ll_enc(int s)
+{
+    if (s < 256) return 6u | (uint32_t)s << 3;
+    if (s == 256) return 7u;
+    const int c = s - 257;
+    if (c > 28) return 7u | 1u << 3;
+    const int e1 = (c < 8 || c == 28) ? 0 : (c >> 2) - 1;
+    const int lbase = c < 8 ? 3 + c : c == 28 ? 258 : 3 + ((4 + (c & 3)) << e1);
+    return (uint32_t)e1 | (uint32_t)(lbase - 3) << 3;
+}
+
 // first-level table: index = the next `bits` bits of the stream (first bit lowest) -> symbol << 4 | length, 0 where the code is longer
+// (LL: ll_enc(symbol) << 4 | length)
+template <bool LL = false>
 __device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uint8_t *lens, int n)
 {
     for (int i = 0; i < (1 << bits); i++) tab[i] = 0;
@@ -92,7 +108,8 @@ __device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uin
         for (int q = 1; q < 16; q++) next[q] = l == q ? next[q] + 1 : next[q];
         if (l > bits) continue;
         const uint32_t r = __brev(c) >> (32 - l);
-        for (uint32_t k = r; k < (1u << bits); k += 1u << l) tab[k] = (uint16_t)(s << 4 | l);
+        const uint16_t ent = (uint16_t)((LL ? ll_enc(s) : (uint32_t)s) << 4 | (uint32_t)l);
+        for (uint32_t k = r; k < (1u << bits); k += 1u << l) tab[k] = ent;
     }
 }
 
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
             }
             if (!err && (!huff_build(hl, lens, 288) || !huff_build(hd, lens + 288, 30))) err = 2;
             if (!err) {
-                table_fill(lt, LT_BITS, hl, lens, 288);
+                table_fill<true>(lt, LT_BITS, hl, lens, 288);
                 table_fill(dt, DT_BITS, hd, lens + 288, 30);
                 walk_start(wk, LT_BITS, hl);
                 walk_start(wk + 2, DT_BITS, hd);
@@ -302,18 +319,19 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
                 if ((it & 15) == 0) tick();
                 refill();
                 const uint32_t e = lt[(uint32_t)bb & (LT_SZ - 1)];
-                int sym = (int)(e >> 4);
+                uint32_t code = e >> 4;                                  // ll_enc of the symbol
                 take((int)(e & 15));
-                if (__builtin_expect(e == 0, 0)) sym = slow_from(hl, wk, LT_BITS);
-                const bool lit = sym < 256, mat = sym > 256;
+                if (__builtin_expect(e == 0, 0)) {
+                    const int sym = slow_from(hl, wk, LT_BITS);
+                    code = sym < 0 ? (7u | 1u << 3) : ll_enc(sym);
+                }
+                const uint32_t x = code & 7u, val = code >> 3;
+                const bool lit = x == 6, mat = x < 6, eob = code == 7u;
                 // a literal often has a literal behind it: the step takes that one too when the table knows it (two codes: at most 30 of the 33 bits)
                 const uint32_t e_2 = lt[(uint32_t)bb & (LT_SZ - 1)];
-                const bool two = lit && sym >= 0 && e_2 != 0 && (e_2 >> 4) < 256 && op + 2 <= isize;
+                const bool two = lit && e_2 != 0 && ((e_2 >> 4) & 7u) == 6 && op + 2 <= isize;
                 take(two ? (int)(e_2 & 15) : 0);
-                const int c = mat ? sym - 257 : 0;
-                const int e1 = (c < 8 || c >= 28) ? 0 : (c >> 2) - 1;
-                const int lbase = c < 8 ? 3 + c : c >= 28 ? 258 : 3 + ((4 + (c & 3)) << e1);
-                const int len = lbase + (int)take(e1);                  // (a length code and its extra bits: at most 20 of the refill's 33 bits)
+                const int len = (int)val + 3 + (int)take(mat ? (int)x : 0);   // (a length code and its extra bits: at most 20 of the refill's 33 bits)
                 refill();
                 const uint32_t de = dt[(uint32_t)bb & (DT_SZ - 1)];
                 int dsym = (int)(de >> 4);
@@ -324,13 +342,13 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
                 const int dbase = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e2);
                 const int dist = dbase + (int)take(e2);                 // (15 + 13 bits)
                 const int add = lit ? (two ? 2 : 1) : mat ? len : 0;
-                const int bad = (sym < 0 || (mat && (c > 28 || ds < 0 || ds > 29 || dist > op))) ? 3 : op + add > isize ? 4 : 0;
+                const int bad = ((x == 7 && !eob) || (mat && (ds < 0 || ds > 29 || dist > op))) ? 3 : op + add > isize ? 4 : 0;
                 const bool emit = (lit || mat) && !bad;
-                if (emit) tk[(size_t)nt << LPW_SH] = lit ? 0x80000000u | (two ? 0x10000u | (e_2 >> 4) << 8 : 0u) | (uint32_t)sym : (uint32_t)len << 16 | (uint32_t)dist;
+                if (emit) tk[(size_t)nt << LPW_SH] = lit ? 0x80000000u | (two ? 0x10000u | (e_2 >> 7) << 8 : 0u) | val : (uint32_t)len << 16 | (uint32_t)dist;
                 nt += emit;
                 op += emit ? add : 0;
                 err = err ? err : bad;
-                run = !err && sym != 256;
+                run = !err && !eob;
             }
         }
         if (err || last) fin = true;
