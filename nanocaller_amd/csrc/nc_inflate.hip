@@ -84,9 +84,16 @@ __device__ __forceinline__ uint32_t ll_enc(int s)
     return (uint32_t)e1 | (uint32_t)(lbase - 3) << 3;
 }
 
+// the same for a distance symbol: extra-bit count (15: a symbol that must not occur) | symbol << 4
+__device__ __forceinline__ uint32_t d_enc(int s)
+{
+    if (s > 29) return 15u | (uint32_t)s << 4;
+    return (uint32_t)(s < 4 ? 0 : (s >> 1) - 1) | (uint32_t)s << 4;
+}
+
 // first-level table: index = the next `bits` bits of the stream (first bit lowest) -> symbol << 4 | length, 0 where the code is longer
-// (LL: ll_enc(symbol) << 4 | length)
-template <bool LL = false>
+// (MODE 1: ll_enc(symbol) << 4 | length; 2: d_enc(symbol) << 4 | length)
+template <int MODE = 0>
 __device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uint8_t *lens, int n)
 {
     for (int i = 0; i < (1 << bits); i++) tab[i] = 0;
@@ -108,7 +115,7 @@ __device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uin
         for (int q = 1; q < 16; q++) next[q] = l == q ? next[q] + 1 : next[q];
         if (l > bits) continue;
         const uint32_t r = __brev(c) >> (32 - l);
-        const uint16_t ent = (uint16_t)((LL ? ll_enc(s) : (uint32_t)s) << 4 | (uint32_t)l);
+        const uint16_t ent = (uint16_t)((MODE == 1 ? ll_enc(s) : MODE == 2 ? d_enc(s) : (uint32_t)s) << 4 | (uint32_t)l);
         for (uint32_t k = r; k < (1u << bits); k += 1u << l) tab[k] = ent;
     }
 }
@@ -305,8 +312,8 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
             }
             if (!err && (!huff_build(hl, lens, 288) || !huff_build(hd, lens + 288, 30))) err = 2;
             if (!err) {
-                table_fill<true>(lt, LT_BITS, hl, lens, 288);
-                table_fill(dt, DT_BITS, hd, lens + 288, 30);
+                table_fill<1>(lt, LT_BITS, hl, lens, 288);
+                table_fill<2>(dt, DT_BITS, hd, lens + 288, 30);
                 walk_start(wk, LT_BITS, hl);
                 walk_start(wk + 2, DT_BITS, hd);
             }
@@ -334,15 +341,17 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
                 const int len = (int)val + 3 + (int)take(mat ? (int)x : 0);   // (a length code and its extra bits: at most 20 of the refill's 33 bits)
                 refill();
                 const uint32_t de = dt[(uint32_t)bb & (DT_SZ - 1)];
-                int dsym = (int)(de >> 4);
+                uint32_t dcode = de >> 4;                                // d_enc of the distance symbol
                 take(mat ? (int)(de & 15) : 0);
-                if (__builtin_expect(mat && de == 0, 0)) dsym = slow_from(hd, wk + 2, DT_BITS);
-                const int ds = mat ? dsym : 0;
-                const int e2 = (ds < 4 || ds > 29) ? 0 : (ds >> 1) - 1;
-                const int dbase = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e2);
-                const int dist = dbase + (int)take(e2);                 // (15 + 13 bits)
+                if (__builtin_expect(mat && de == 0, 0)) {
+                    const int dsym = slow_from(hd, wk + 2, DT_BITS);
+                    dcode = dsym < 0 ? 15u : d_enc(dsym);
+                }
+                const int e2 = (int)(dcode & 15u), ds = (int)(dcode >> 4);
+                const bool dbad = mat && e2 == 15;
+                const int dist = (ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e2)) + (int)take(mat && !dbad ? e2 : 0);   // (15 + 13 bits)
                 const int add = lit ? (two ? 2 : 1) : mat ? len : 0;
-                const int bad = ((x == 7 && !eob) || (mat && (ds < 0 || ds > 29 || dist > op))) ? 3 : op + add > isize ? 4 : 0;
+                const int bad = ((x == 7 && !eob) || dbad || (mat && dist > op)) ? 3 : op + add > isize ? 4 : 0;
                 const bool emit = (lit || mat) && !bad;
                 if (emit) tk[(size_t)nt << LPW_SH] = lit ? 0x80000000u | (two ? 0x10000u | (e_2 >> 7) << 8 : 0u) | val : (uint32_t)len << 16 | (uint32_t)dist;
                 nt += emit;
