@@ -383,7 +383,8 @@ __device__ __forceinline__ int wave_scan_incl(int v, int lane)
 // One wave per member.  The member's recent output lives in an LDS ring of RING bytes (position p at ring[p & (RING - 1)]): a full 64 KB
 // image per member allowed two waves per CU -- a wave alone on its SIMD, every LDS round trip exposed.  With a 16 KB ring nine members share
 // a CU.  Finished stretches leave for HBM every FLUSH bytes; a match source older than the last flush is read back from there (the
-// stores are fenced at agent scope when they are issued and the loads bypass the CU's cache: same-wave visibility through L2).
+// stores are waited for when they are issued and the loads pass the CU's cache by -- at WORKGROUP scope: reader and writer are one wave, the
+// XCD's own L2 is where they meet; an agent-scope release made every flush write the whole L2 back, `buffer_wbl2`, 16 times per member).
 template <int RING>
 __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const int32_t *ntok, uint8_t *out, const int64_t *ooff, const int32_t *isize,
                                            const int32_t *status)
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
             ow[(p - head) >> 2] = __builtin_amdgcn_alignbyte(ring_w[(r + 1) & (RING / 4 - 1)], ring_w[r], p & 3);
         }
         flushed = start + 4 * nw;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     };
     // the tokens of the next step are on their way while this one is resolved (a step normally takes all 64: the guess is seldom wrong)
     uint32_t t_next = lane < nt ? tk[(size_t)lane << LPW_SH] : 0u;
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
         for (int k = 0; __any(indep && k < len); k++)
             if (indep && k < len) {
                 const int q = pos - dist + k;
-                const uint8_t v = q >= ring_lo ? ring[q & M] : __hip_atomic_load(o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint8_t v = q >= ring_lo ? ring[q & M] : __hip_atomic_load(o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ring[(pos + k) & M] = v;
             }
         // the others in token order, all lanes on one match
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
                     if (r >= D) r -= D;
                 }
                 const int q = P - D + r;
-                const uint8_t v = q >= ring_lo ? ring[q & M] : __hip_atomic_load(o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint8_t v = q >= ring_lo ? ring[q & M] : __hip_atomic_load(o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ring[(P + k) & M] = v;
             }
         }

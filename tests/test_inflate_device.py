@@ -52,7 +52,9 @@ def _cases():
     dna4 = bytes(rng.integers(0, 256, size=65_280).astype(np.uint8))                              # packed bases: incompressible
     qual = bytes((rng.normal(20, 6, size=65_280).clip(0, 60)).astype(np.uint8))                    # quality-like: entropy coded, few matches
     runs = b"".join(bytes([int(b)]) * int(n) for b, n in zip(rng.integers(0, 4, 400), rng.integers(1, 400, 400)))[:65_280]
-    data = [b"", b"A", b"AB" * 3, bytes(65_280), text, dna4, qual, runs, bytes(range(256)) * 255]
+    far = bytes(rng.integers(0, 256, size=20_000).astype(np.uint8))                                # matches at distance 20,000 / 31,000: older than k_lz's
+    far2 = bytes(rng.integers(0, 256, size=31_000).astype(np.uint8))                               # 16 KB ring, read back from HBM
+    data = [b"", b"A", b"AB" * 3, bytes(65_280), text, dna4, qual, runs, bytes(range(256)) * 255, far * 3, (far2 * 3)[:65_280], (qual[:9_000] + far[:9_000]) * 3]
     out = []
     for d in data:
         for kw in (dict(level=6), dict(level=1), dict(level=9), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED), dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY),
