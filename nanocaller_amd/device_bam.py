@@ -284,7 +284,7 @@ class DeviceBam:
         else:
             self.raw = torch.empty(raw_cap + raw_cap // 8, dtype=torch.uint8, device=dev)
         _RAW_POOL[dev.index] = (self.raw, weakref.ref(self))
-        d_file = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+        d_file = _work_buffer(dev, "file", n + 64, torch.uint8)
         cap = n // 1024 + 4096
         stage64 = torch.empty(2 * cap, dtype=torch.int64, pin_memory=True)    # [coff | ooff] of every member, page-locked: the batches' uploads are async
         stage32 = torch.empty(2 * cap, dtype=torch.int32, pin_memory=True)    # [clen | isize]
@@ -293,8 +293,8 @@ class DeviceBam:
         # two token workspaces: the Huffman kernel of batch i + 1 (compute stream) runs beside the match resolution of batch i (its own stream)
         # (256 KB of tokens per member: a small file gets small workspaces -- and, should its members be unusually short, more batches)
         batch = min(INFLATE_BATCH, max(64, (n // 4096 + 63) // 64 * 64))
-        toks = [(torch.empty(((batch + 63) // 64) << 22, dtype=torch.int32, device=dev), torch.zeros(batch, dtype=torch.int32, device=dev), [None])
-                for _ in range(2)]
+        toks = [(_work_buffer(dev, "tok%d" % k_, ((batch + 63) // 64) << 22, torch.int32), torch.zeros(batch, dtype=torch.int32, device=dev), [None])
+                for k_ in range(2)]
         t_alloc = time.perf_counter() - t_start
         copy_stream, lz_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         compute = torch.cuda.current_stream(dev)
@@ -674,6 +674,18 @@ def plan_shares(path, contigs, limit_bytes=None):
 
 _OPEN = {}
 _RAW_POOL = {}               # device index -> (buffer of the inflated stream, weak reference to the DeviceBam that is using it)
+_WORK_POOL = {}              # (device index, name) -> the loader's work buffers (file image in HBM, token workspaces), kept from load to load
+
+
+def _work_buffer(dev, name, numel, dtype):
+    """a buffer of the loader that lives only during load(): the same allocation every time (grown when a larger file comes).  Handing
+    these back to the framework's allocator let it cut them up for other requests in between; the next load then had to get ~9 GB of fresh
+    device memory, which was measured at 240 ms"""
+    t = _WORK_POOL.get((dev.index, name))
+    if t is None or t.numel() < numel or t.dtype != dtype:
+        _WORK_POOL.pop((dev.index, name), None)
+        t = _WORK_POOL[(dev.index, name)] = torch.empty(numel, dtype=dtype, device=dev)
+    return t[:numel]
 
 
 def open_device_bam(path, device=0, contigs=None) -> DeviceBam:
@@ -696,3 +708,4 @@ def release(path=None, buffers=False):
         del _OPEN[k]
     if buffers:
         _RAW_POOL.clear()
+        _WORK_POOL.clear()
