@@ -32,6 +32,7 @@ from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
 META_COLS = 12
 (M_REFID, M_POS, M_FLAG, M_RLEN, M_LSEQ, M_HASSEQ, M_HAP, M_PS, M_HASH_LO, M_HASH_HI, M_NCIG, M_CIGD) = range(META_COLS)
 INFLATE_BATCH = 16384            # members per nc_inflate_device call (4 GB of token workspace)
+POOL_MAX = 16 << 30              # buffers up to this size stay allocated between loads (larger ones go back to the allocator after use)
 MAX_RESIDENT = 96 << 30          # inflated bytes kept in HBM at once (a 30x human genome BAM does not fit: it takes the host route)
 
 
@@ -283,7 +284,10 @@ class DeviceBam:
             self.raw = pooled[0]
         else:
             self.raw = torch.empty(raw_cap + raw_cap // 8, dtype=torch.uint8, device=dev)
-        _RAW_POOL[dev.index] = (self.raw, weakref.ref(self))
+        if self.raw.numel() <= POOL_MAX:
+            _RAW_POOL[dev.index] = (self.raw, weakref.ref(self))
+        else:
+            _RAW_POOL.pop(dev.index, None)
         d_file = _work_buffer(dev, "file", n + 64, torch.uint8)
         cap = n // 1024 + 4096
         stage64 = torch.empty(2 * cap, dtype=torch.int64, pin_memory=True)    # [coff | ooff] of every member, page-locked: the batches' uploads are async
@@ -684,7 +688,9 @@ def _work_buffer(dev, name, numel, dtype):
     t = _WORK_POOL.get((dev.index, name))
     if t is None or t.numel() < numel or t.dtype != dtype:
         _WORK_POOL.pop((dev.index, name), None)
-        t = _WORK_POOL[(dev.index, name)] = torch.empty(numel, dtype=dtype, device=dev)
+        t = torch.empty(numel, dtype=dtype, device=dev)
+        if numel * t.element_size() <= POOL_MAX:
+            _WORK_POOL[(dev.index, name)] = t
     return t[:numel]
 
 

@@ -459,6 +459,12 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             pending.result()
         if piped and keys:
             prep_pool.shutdown(wait=True)
+        if dbam is not None:
+            # the share of the file this worker had in HBM goes when the worker is done (the stages that follow -- phasing, the indel
+            # callers -- need the memory; the loader's work buffers up to 16 GB stay for the next load)
+            from .device_bam import release as release_device_bam
+            dbam = None
+            release_device_bam(params['sam_path'])
 
 
 # ------------------------------------------------------------------ BGZF (so no bgzip binary is needed)

@@ -493,7 +493,9 @@ def test_pipelined_ingest_writes_the_serial_callers_worker_file(two_contig_files
         snpCaller.caller(params, q, queue.Queue(), files)
         outs.append(open(files[0], "rb").read())
         if tag in ("device", "shares"):
+            from nanocaller_amd import device_bam
             assert gsp.DECODES == []                                                # not decoded on the host at all
+            assert not device_bam._OPEN                                             # the worker's share of the file left HBM with the worker
         elif tag != "mixed":
             assert sorted(x[1] for x in gsp.DECODES) == ["chr1", "chrX"]            # every contig decoded once
         else:
