@@ -869,6 +869,67 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
                     "the test tooling wrote moments before (page cache warm)"}
 
 
+def extra_from_bam_indel(eng, local, L=8_000_000, depth=30, keep=None):
+    """The indel callers from a BAM FILE: indelCaller.indel_run (device pipeline + K9 + native rules + worker file) over one contig with planted
+    indels, the contig's pack and per-read sections made in HBM from the file (device_bam.py) or by the host threads' decode +
+    nc_indel_pack_build + wire form.  The BAM is written by test tooling (untimed)."""
+    import queue
+    import shutil
+    import tempfile
+
+    from nanocaller_amd import device_bam, indelCaller
+    from nanocaller_amd import generate_indel_pileups as gip
+    from nanocaller_amd import generate_SNP_pileups as gsp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamio
+    t0 = time.perf_counter()
+    w = bamio.make_pass2_world(seed=11, length=L, depth=depth)
+    tmp = tempfile.mkdtemp(prefix="nc_bench_ibam_")
+    bam, fa = os.path.join(tmp, "p.bam"), os.path.join(tmp, "p.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, None), level=1)
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    t_files = time.perf_counter() - t0
+    out, texts = {}, {}
+    for tag, env in (("device_ingest", "1"), ("host_ingest", "0")):
+        os.environ["NC_DEVICE_INGEST"] = env
+        best = None
+        for rep in range(3):
+            gsp.release_contig()
+            gip._CONTIGS.clear()
+            gip._DEV_INGEST.clear()
+            device_bam.release()
+            d = os.path.join(tmp, "%s%d" % (tag, rep))
+            os.makedirs(d)
+            params = dict(seq="ont", fasta_path=fa, win_size=40, small_win_size=4, mincov=4, maxcov=160, ins_t=0.4, del_t=0.6, supplementary=False,
+                          exclude_bed=None, impute_indel_phase=False, indel_model="ONT-HG002", intermediate_indel_files_dir=d, prefix="t")
+            jobs = queue.Queue()
+            for s_ in range(1, w.length, 100_000):
+                jobs.put(("indel", dict(chrom=w.chrom, start=s_, end=min(w.length, s_ + 100_000), ploidy="diploid", sam_path=bam)))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            path = indelCaller.indel_run(params, {}, jobs, queue.Queue(), [], aligner="device")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            texts[tag] = open(path).read()
+            if best is None or dt < best:
+                best = dt
+        out[tag] = {"seconds": best, "records": texts[tag].count("\n"), "records_s": texts[tag].count("\n") / best}
+    os.environ.pop("NC_DEVICE_INGEST", None)
+    gsp.release_contig()
+    gip._CONTIGS.clear()
+    gip._DEV_INGEST.clear()
+    device_bam.release()
+    size = os.path.getsize(bam)
+    if keep is None:
+        shutil.rmtree(tmp, ignore_errors=True)
+    else:
+        keep.extend([tmp, bam, fa])
+    return {"workload": "one contig of %d bp with planted indels, ONT-like %dx, %d reads, one BAM file (%.0f MB, BGZF level 1) + FASTA -> indelCaller.indel_run -> worker "
+                        "VCF file" % (L, depth, w.n_reads, size / 1e6),
+            "device_ingest": out["device_ingest"], "host_ingest": out["host_ingest"], "vcf_identical_device_vs_host": texts["device_ingest"] == texts["host_ingest"],
+            "files_writing_s": round(t_files, 1), "note": "best of three runs per route; every run starts from the file"}
+
+
 def trunk_traffic_from_profiles():
     """HBM bytes per site of the dominant kernel from the committed PMC passes (profiles/trunk_traffic.json, written from the
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes by tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md says)"""
@@ -1220,6 +1281,7 @@ def main():
                                                              "headline workload with the exact fp32 MFMA trunk (k4_conv12) on float32 tensors")
                 extra["indel_pipeline"] = extra_indel_config(eng, uploader, local, L)
                 extra["from_bam"] = extra_from_bam(eng, local)
+                extra["from_bam_indel"] = extra_from_bam_indel(eng, local)
             except Exception as e:                                  # an extra must never take the headline line down
                 extra["error"] = "%s: %s" % (type(e).__name__, e)
             out["extra_configs"] = extra
