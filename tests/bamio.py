@@ -67,7 +67,7 @@ class BgzfWriter:
 
 def write_bam(path, chrom, length, records, other_refs=(), write_bai=True, write_csi=False, level=6):
     """records: list of dict(name, flag, pos0, cigar=[(op,len)...] with op in 'MIDNSHP=X', seq (str), tags={'HP':1,...},
-    optional tid = index into [(chrom, length)] + other_refs, default 0) in coordinate order."""
+    optional tid = index into [(chrom, length)] + other_refs, default 0; optional qual = bytes of len(seq), default 0xff: absent) in coordinate order."""
     refs = [(chrom, length)] + list(other_refs)
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     w = BgzfWriter(path, level=level)
@@ -101,7 +101,7 @@ def write_bam(path, chrom, length, records, other_refs=(), write_bai=True, write
                 tags += k.encode() + b"i" + struct.pack("<i", v)
         body = struct.pack("<iiBBHHHiiii", r.get("tid", 0), r["pos0"], len(name), 60, reg2bin(r["pos0"], r["pos0"] + max(1, rlen)), len(cig),
                            r["flag"], len(seq), -1, -1, 0) + name + b"".join(struct.pack("<I", (ln << 4) | ops.index(op)) for op, ln in cig) + \
-            bytes(packed) + b"\xff" * len(seq) + tags
+            bytes(packed) + (r["qual"] if r.get("qual") is not None else b"\xff" * len(seq)) + tags
         voff = w.tell()
         if not (r["flag"] & 4):
             for win in range(r["pos0"] >> 14, ((r["pos0"] + max(1, rlen) - 1) >> 14) + 1):

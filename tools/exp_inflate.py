@@ -20,6 +20,7 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 3_000_000
 eng = get_engine(0)
 lut = np.frombuffer(b"AGTCNNNN", np.uint8)
 recs, refs = [], []
+qrng = np.random.default_rng(3)
 for k in range(n_contigs):
     pack, info = make_device_workload(eng, L, depth=30.0, tech="ont", seed=7000 + k)
     codes = pack.codes.cpu().numpy()
@@ -27,8 +28,12 @@ for k in range(n_contigs):
     s_, e_, base = info["read_start"], info["read_end"], info["read_base"]
     for r in range(info["n_reads"]):
         o = int(base[r]) + int(s_[r])
-        recs.append(dict(tid=k, name="r%d_%d" % (k, r), flag=16 if info["strand"][r] else 0, pos0=int(s_[r]) - 1, cigar=[("M", int(e_[r] - s_[r]))],
-                         seq=lut[codes[o:o + int(e_[r] - s_[r])]].tobytes().decode(), tags={}))
+        n_ = int(e_[r] - s_[r])
+        qual = None
+        if os.environ.get("NC_EXP_QUAL"):                                 # ONT-like base qualities instead of the absent-quality 0xff run: one literal per base
+            qual = qrng.normal(18, 7, n_).clip(1, 50).astype(np.uint8).tobytes()
+        recs.append(dict(tid=k, name="r%d_%d" % (k, r), flag=16 if info["strand"][r] else 0, pos0=int(s_[r]) - 1, cigar=[("M", n_)],
+                         seq=lut[codes[o:o + n_]].tobytes().decode(), tags={}, qual=qual))
     del pack
 tmp = tempfile.mkdtemp()
 bam = os.path.join(tmp, "b.bam")
