@@ -362,7 +362,7 @@ class IndelJob:
     star alignment (banded) -> tensors + consensus (K8) -> allele_prediction -> Indel_model (K9) -> per-site arrays in host memory; genotype
     rules + VCF text natively on the host."""
 
-    def __init__(self, eng, L, seed=4813, name=b"chr20"):
+    def __init__(self, eng, L, seed=4813, name=b"chr20", haploid=False, window_after=160, wire=True):
         from nanocaller_amd import _lib
         from nanocaller_amd.synth_device import make_indel_device_workload
         from nanocaller_amd.weights import Weights, get_indel_model
@@ -370,13 +370,15 @@ class IndelJob:
         t0 = time.perf_counter()
         self.pack, self.reads_c, self.info = make_indel_device_workload(eng, L, depth=30.0, seed=seed)
         self.t_gen = time.perf_counter() - t0
-        self.wgt = Weights(get_indel_model("ONT-HG002"))
-        eng.load_weights(_lib.MODEL_INDEL, self.wgt)
+        self.haploid = bool(haploid)
+        self.kind = _lib.MODEL_INDEL_HAP if haploid else _lib.MODEL_INDEL
+        self.wgt = Weights(get_indel_model("haploid" if haploid else "ONT-HG002"))
+        eng.load_weights(self.kind, self.wgt)
         self.chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
-        self.kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+        self.kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=window_after, haploid=self.haploid)
         self.contig = np.frombuffer(b"AGTCN", np.uint8)[self.info["tensors"]["ref"].cpu().numpy()[1:]].tobytes()
         t0 = time.perf_counter()
-        self.wire = _indel_wire(eng, self.pack, self.reads_c, self.info)
+        self.wire = _indel_wire(eng, self.pack, self.reads_c, self.info) if wire else None
         self.t_wire = time.perf_counter() - t0
 
     def drop_pack(self):
@@ -392,7 +394,7 @@ class IndelJob:
         t0 = time.perf_counter()
         r = gip.indel_sites_device(eng, dp, rc, self.L, self.chunks, fetch=False, **self.kw)
         t1 = time.perf_counter()
-        probs = eng.indel_forward(_lib.MODEL_INDEL, r["x"])
+        probs = eng.indel_forward(self.kind, r["x"])
         t2 = time.perf_counter()
         r.update(gip.indel_sites_fetch(eng, r["n"], r["sets"]))
         t3 = time.perf_counter()
@@ -413,7 +415,7 @@ class IndelJob:
         rc = self.eng.L.nc_indel_vcf_format(self.name, N, _lib.npp(np.ascontiguousarray(r["pos"])), _lib.npp(np.ascontiguousarray(r["chunk"])), len(self.chunks),
                                             _lib.npp(r["probs"]), r["sets"], _lib.npp(np.ascontiguousarray(r["ref_len"])),
                                             _lib.npp(np.ascontiguousarray(r["alt_len"])), _lib.npp(r["alt"]), _lib.npp(np.ascontiguousarray(r["phase"])),
-                                            self.contig, self.L, 0, _lib.npp(buf), buf.size, C.byref(nb), None)
+                                            self.contig, self.L, 1 if self.haploid else 0, _lib.npp(buf), buf.size, C.byref(nb), None)
         assert rc == 0, rc
         return int((buf[:nb.value] == 10).sum())
 
@@ -427,6 +429,29 @@ class IndelJob:
         if os.environ.get("NC_BENCH_DEBUG") == "1":
             print("  indel pass host ms: expand enqueue %.1f, whole pass %.1f" % ((t1 - t0) * 1e3, (time.perf_counter() - t0) * 1e3), file=sys.stderr, flush=True)
         return r
+
+
+def extra_indel_haploid_config(eng, L, reps=6):
+    """The indel half of configs[4]'s shape: --haploid_genome (one read set per site, haploid_Indel_model) with the pacbio preset's 260-base
+    windows, over the same chr20-sized synthetic contig, the pack resident in HBM (no upload in the loop: the transfer form is the diploid
+    workload's)."""
+    job = IndelJob(eng, L, haploid=True, window_after=260, wire=False)
+    job.gpu_pass(job.pack, job.reads_c)
+    ms, n_rec, r = [], 0, None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = job.gpu_pass(job.pack, job.reads_c)
+        n_rec = job.rules(r)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    med = float(np.median(ms))
+    out = {"workload": "indel half, haploid model + 260-base windows (configs[4]'s shape) on the chr20-sized synthetic ONT-like 30x contig: %d candidate sites, "
+                       "%d VCF records per pass" % (r["n"], n_rec),
+           "value": r["n"] / (med * 1e-3), "unit": "candidate sites/s (pack resident in HBM; featuriser -> K9 -> fetch -> native rules, one pass after the other)",
+           "ms_per_pass_median": med, "pass_ms": [round(x, 2) for x in ms], "sites": int(r["n"])}
+    del job
+    torch.cuda.empty_cache()
+    return out
 
 
 def extra_indel_config(eng, uploader, local, L, reps=20):
@@ -1280,6 +1305,7 @@ def main():
                 extra["exact_fp32_trunk"] = extra_snp_config(eng, uploader, local, L, args.depth, args.tech, args.model, args.ploidy, True, 8,
                                                              "headline workload with the exact fp32 MFMA trunk (k4_conv12) on float32 tensors")
                 extra["indel_pipeline"] = extra_indel_config(eng, uploader, local, L)
+                extra["indel_haploid_260"] = extra_indel_haploid_config(eng, L)
                 extra["from_bam"] = extra_from_bam(eng, local)
                 extra["from_bam_indel"] = extra_from_bam_indel(eng, local)
             except Exception as e:                                  # an extra must never take the headline line down
