@@ -445,10 +445,13 @@ def extra_indel_haploid_config(eng, L, reps=6):
         n_rec = job.rules(r)
         ms.append((time.perf_counter() - t0) * 1e3)
     med = float(np.median(ms))
+    st = np.zeros(6, np.int64)
+    eng.L.nc_indel_sites_band_stats(eng.ctx, st.ctypes.data_as(__import__("ctypes").c_void_p))
     out = {"workload": "indel half, haploid model + 260-base windows (configs[4]'s shape) on the chr20-sized synthetic ONT-like 30x contig: %d candidate sites, "
                        "%d VCF records per pass" % (r["n"], n_rec),
            "value": r["n"] / (med * 1e-3), "unit": "candidate sites/s (pack resident in HBM; featuriser -> K9 -> fetch -> native rules, one pass after the other)",
-           "ms_per_pass_median": med, "pass_ms": [round(x, 2) for x in ms], "sites": int(r["n"])}
+           "ms_per_pass_median": med, "pass_ms": [round(x, 2) for x in ms], "sites": int(r["n"]),
+           "star_alignments_last_pass": {"on_32_diagonals": int(st[0]), "on_64_diagonals": int(st[1]), "full_matrix": int(st[2]), "edge_touch_rerun": int(st[3])}}
     del job
     torch.cuda.empty_cache()
     return out

@@ -32,7 +32,7 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 namespace {
 
 constexpr int PICK_CAP = 12288;        // anchors of one chunk held in LDS by k_pick (a 100 kb chunk has at most 9,092)
-constexpr int BAND_NBLK = 41;        // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= 328
+constexpr int BAND_NBLK = 41;        // blocks of 8 anti-diagonals of a banded ALLELE alignment: n1 + n2 <= 328 (the star alignments size theirs by the window: stage_a)
 constexpr int CNS_CAP = 1024;          // alignment columns of one read set (window + the longest insertion of every slot)
 constexpr int32_t NW_NEG = -(1 << 29);
 enum : uint32_t { T_DIAG = 0, T_DEL = 1, T_INS = 2, T_EEXT = 4, T_FEXT = 8 };
@@ -2189,12 +2189,13 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, B.cband, (size_t)ng * S * 4));
         NC_TRY(nc_ensure(ctx, B.arow, ((size_t)ng * S + 1) * 8));
         NC_TRY(nc_ensure(ctx, B.alt_off, (size_t)ng * S * 8));
-        const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && W <= 162 && N1 <= 160;          // the band's 41 blocks of 8 anti-diagonals cover n1 + n2 <= 328
+        const int nblk = (N1 + W + 7) / 8;                             // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= N1 + W (41 for the 160-base windows, 66 for the 260-base ones)
+        const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && nblk <= 80;
         if (band) {
             NC_TRY(nc_ensure(ctx, B.band_lo, Agz + 64));
             NC_TRY(nc_ensure(ctx, B.lists, Agz * 3 * 4 + 64));
             NC_TRY(nc_ensure(ctx, B.counts, 64));
-            NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)BAND_NBLK * 128 + 256));
+            NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)nblk * 128 + 256));
             NC_TRY(nc_ensure(ctx, B.hrow, Agz * 128 + 64));
             NC_TRY(nc_ensure(ctx, B.hcolb, Agz * 128 + 64));
         }
@@ -2233,7 +2234,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
             BandArgs &ba = ba_of[b];
             ba.f = fa;
             ba.band_lo = (const int8_t *)B.band_lo.p; ba.Twb = (uint32_t *)B.twb.p; ba.hrow = (int16_t *)B.hrow.p; ba.hcolb = (int16_t *)B.hcolb.p;
-            ba.NBLK = BAND_NBLK; ba.redo_list = wa.listF; ba.redo_count = wa.counts + 2;
+            ba.NBLK = nblk; ba.redo_list = wa.listF; ba.redo_count = wa.counts + 2;
             ba.edge = getenv("NC_PIPE_BAND_EDGE") ? atoi(getenv("NC_PIPE_BAND_EDGE")) : 0;
             ba.list = wa.list1; ba.count = wa.counts;
             hipLaunchKernelGGL(k_fill_band<1>, dim3((Ag + 7) / 8), dim3(64), 0, sA, ba);

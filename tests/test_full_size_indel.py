@@ -1,7 +1,7 @@
 """BASELINE.json configs[2] / configs[4] at their sizes for the INDEL half of the path (csrc/nc_pipe.hip), through size-independent
 properties -- the oracle cannot run these sizes in seconds: a chr1-sized ONT 30x contig (248,956,422 bp, 2,490 chunks of 100 kb, ~155 k
 candidate sites, ~4.1 M read windows in three balanced alignment groups) and a chr20-sized contig through the haploid model's shape
-(--haploid_genome: one read set per site) with the 260-base windows of the pacbio preset (the 17-column full-matrix aligner).
+(--haploid_genome: one read set per site) with the 260-base windows of the pacbio preset (banded like the 160-base ones).
 What must hold at any size: results are deterministic, do not depend on how the run loop cuts the alignments into groups, every tensor
 column is a frequency distribution, anchors lie inside the window of their chunk, and the first sites equal the oracle's restatement
 (pure Python: CIGAR expansion, banded / full star alignment, msa() by the C oracle)."""
@@ -116,7 +116,8 @@ def test_indel_pipeline_chr1_sized(monkeypatch):
 
 def test_indel_pipeline_haploid_260_base_windows_chr20_sized(monkeypatch):
     """configs[4]'s indel half: --haploid_genome (one read set per site, generate_indel_pileups_haploid.py:128-277) with the pacbio preset's
-    260-base windows (the 17-column full-matrix aligner: wider than the band kernels cover)"""
+    260-base windows -- on the CIGAR-derived bands like the 160-base ones (66 blocks of 8 anti-diagonals instead of 41); the first sites against
+    the pure-Python restatement of the banded aligner AND against its full-matrix form (the band must not change these)"""
     import torch
     from oracle import oracle
     L = 64_444_167
@@ -142,9 +143,11 @@ def test_indel_pipeline_haploid_260_base_windows_chr20_sized(monkeypatch):
         p = int(a["pos"][k])
         if p > hi or checked >= 4:
             break
-        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref, p, 260, 4, 160, haploid=True)      # full matrices, pure Python
-        assert got is not None, p
+        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref, p, 260, 4, 160, haploid=True, band=True)      # pure Python, on the bands
+        full = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref, p, 260, 4, 160, haploid=True)                # ... and on full matrices
+        assert got is not None and full is not None, p
         assert np.array_equal(xh[k].reshape(1, 5, 128, 2), got[0]), p
+        assert np.array_equal(got[0], full[0]), p
         checked += 1
     assert checked >= 3
     del xa, pack
