@@ -1134,9 +1134,6 @@ __global__ __launch_bounds__(256) void k6_fc1_h3(const float *__restrict__ in, c
         for (int tm = 0; tm < FC_TM; tm++) {
             h8 xh, xl;
             split8(a0[tm], a1[tm], xh, xl);
-#ifdef NC_EXP_FC1_X16
-            xl = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 #pragma unroll
             for (int tn = 0; tn < FC_TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[tn], xh, acc[tm][tn], 0, 0, 0);
 #pragma unroll

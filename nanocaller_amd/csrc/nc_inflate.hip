@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
     const int lane = threadIdx.x;
     // the LPW members of one k_huff workgroup share every 32-byte sector of their interleaved tokens: consecutive workgroups of ONE XCD (every
     // eighth of the grid) take them, so the sector comes from that XCD's L2 after its first use (member-order blocks spread the eight over the
-    // eight L2s: 11.9 GB fetched per 14.5 k members for 0.8 GB of tokens)
+    // eight L2s: 6.1 GB read per 14.5 k members for 0.8 GB of tokens, 2.3 GB this way)
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int b = (((j >> LPW_SH) * 8 + xcd) << LPW_SH) + (j & (LPW - 1));
     if (b >= n || status[b]) return;
