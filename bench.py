@@ -1295,6 +1295,20 @@ def main():
                 out["configs2_snp_indel_chr1"] = configs2_block(eng, uploader, local, args.model, args.configs2_steps, args.configs2_length)
             except Exception as e:
                 out["configs2_snp_indel_chr1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # the summary of configs[2] rides INSIDE `config` (the dict a record parser keeps whole): the largest single-GPU configuration
+            c2 = out["configs2_snp_indel_chr1"]
+            if "error" in c2:
+                out["config"]["configs2"] = {"error": c2["error"]}
+            else:
+                out["config"]["configs2"] = {
+                    "workload": "BASELINE.json configs[2]: SNP+indel pipeline, chr1-sized synthetic ONT 30x, one timed region from pinned host memory",
+                    "value": c2["value"], "unit": c2["unit"], "ms_per_step": c2["ms_per_step"], "steps": c2["steps"],
+                    "snp_sites_per_step": c2["snp_half"]["sites_per_step"], "indel_sites_per_step": c2["indel_half"]["sites_per_step"],
+                    "snp_ms_alone": c2["snp_half"]["ms_per_step_alone"], "indel_ms_alone": c2["indel_half"]["ms_per_step_alone"],
+                    "indel_sites_s_alone": c2["indel_half"]["sites_s_alone"],
+                    "frac_snp_trunk_f16x3": c2["snp_half"]["roofline"]["frac"], "frac_k9_f16x3": c2["indel_half"]["roofline"]["frac"],
+                    "frac_fill_valu_issue_model": c2["indel_half"]["roofline_alignment"]["frac"],
+                    "indel_stages_ms": {k: v for k, v in c2["indel_half"]["stages_ms"].items() if k != "note"}}
         if world == 1 and not args.no_extra:
             # other configurations, outside the headline's timed region (BASELINE.json configs[4], the exact-fp32 trunk,
             # and the indel half of configs[2]); each with its own workload and roofline

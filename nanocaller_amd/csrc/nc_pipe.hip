@@ -327,99 +327,103 @@ struct WinArgs {
     int32_t *list1, *list2, *listF;   // alignments whose band fits 32 / 64 diagonals; the rest (full matrix)
     int32_t *counts;        // [0] list1, [1] list2, [2] listF (k_trace_band appends the paths that touch a band edge), [3] class F by width alone
     int32_t band_margin;    // diagonals kept free on either side of the CIGAR's range
+    int8_t *wcls;           // [A] (k_windows16) band class of the window, for k_window_lists
 };
 
-__global__ __launch_bounds__(64) void k_windows(WinArgs p)
+// one window by one lane (the round-3 form): the walk every other form of this kernel must reproduce, and the route of the few windows the 16-lane
+// form leaves out (more events than its LDS arrays hold, three insertions inside one 16-column group)
+__device__ __forceinline__ void window_serial(const WinArgs &p, int al, int r, int32_t v, int &n_out, int &dmin_out, int &dmax_out)
 {
-    const int al = blockIdx.x * 64 + threadIdx.x;
-    long long mycells = 0, bandcells = 0;
-    int cls = -1;
-    if (al < p.A) {
-        const int r = p.al_read[al], site = p.al_site[al];
-        const int32_t v = p.site_pos[site];
-        uint32_t *out = reinterpret_cast<uint32_t *>(p.win + (int64_t)al * p.WS);       // rows are 16-byte aligned
-        int n = 0;
-        int dcur = 0, dmin = 0, dmax = 0;                                                 // diagonal (window column - read index) of the CIGAR's path
-        uint32_t acc = 0;
-        auto emit = [&](uint32_t b) {                                                     // bases leave as whole words
-            acc |= b << ((n & 3) * 8);
-            n++;
-            if ((n & 3) == 0) { out[(n >> 2) - 1] = acc; acc = 0; }
-        };
-        if (!(p.read_flag[r] & 1)) {
-            const int e0 = p.ev_off[r], e1 = p.ev_off[r + 1];
-            int lo = e0, hi = e1;                                  // first event on a column >= v
-            if (p.al_ev) { const int2 b2 = p.al_ev[al]; lo = b2.x; hi = b2.y; }      // (3 probes inside one or two sectors instead of 17 over the whole read)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (p.ev_pos[mid] < v) lo = mid + 1; else hi = mid;
-            }
-            int k = lo;
-            int32_t del_until = 0;                                 // last position of the deletion that covers v, if any
-            if (k > e0) {
-                const int32_t el = p.ev_len[k - 1];
-                if (el < 0) del_until = p.ev_pos[k - 1] - el;
-            }
-            if (del_until >= v) { dcur = del_until + 1 - v; dmax = dcur; }     // the window opens inside a deletion: its first base sits on column del_until + 1
-            const int32_t rs = p.rd_start[r], re = p.rd_end[r];
-            const uint8_t *cd = p.codes + (p.slot_off[r] - (rs & ~15));       // code of position x at cd[x]; 16-position groups are aligned
-            int32_t next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
-            int32_t x = v;
-            while (n < p.W && x < re) {
-                const int32_t x0 = x & ~15;
-                const uint4 g = *reinterpret_cast<const uint4 *>(cd + x0);
-                const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
-                const int32_t xe = min(x0 + 16, re);
-                for (; x < xe && n < p.W; x++) {
-                    const int o = x - x0;
-                    uint32_t code = 0;
+    uint32_t *out = reinterpret_cast<uint32_t *>(p.win + (int64_t)al * p.WS);       // rows are 16-byte aligned
+    int n = 0;
+    int dcur = 0, dmin = 0, dmax = 0;                                                 // diagonal (window column - read index) of the CIGAR's path
+    uint32_t acc = 0;
+    auto emit = [&](uint32_t b) {                                                     // bases leave as whole words
+        acc |= b << ((n & 3) * 8);
+        n++;
+        if ((n & 3) == 0) { out[(n >> 2) - 1] = acc; acc = 0; }
+    };
+    if (!(p.read_flag[r] & 1)) {
+        const int e0 = p.ev_off[r], e1 = p.ev_off[r + 1];
+        int lo = e0, hi = e1;                                  // first event on a column >= v
+        if (p.al_ev) { const int2 b2 = p.al_ev[al]; lo = b2.x; hi = b2.y; }      // (3 probes inside one or two sectors instead of 17 over the whole read)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (p.ev_pos[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        int k = lo;
+        int32_t del_until = 0;                                 // last position of the deletion that covers v, if any
+        if (k > e0) {
+            const int32_t el = p.ev_len[k - 1];
+            if (el < 0) del_until = p.ev_pos[k - 1] - el;
+        }
+        if (del_until >= v) { dcur = del_until + 1 - v; dmax = dcur; }     // the window opens inside a deletion: its first base sits on column del_until + 1
+        const int32_t rs = p.rd_start[r], re = p.rd_end[r];
+        const uint8_t *cd = p.codes + (p.slot_off[r] - (rs & ~15));       // code of position x at cd[x]; 16-position groups are aligned
+        int32_t next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
+        int32_t x = v;
+        while (n < p.W && x < re) {
+            const int32_t x0 = x & ~15;
+            const uint4 g = *reinterpret_cast<const uint4 *>(cd + x0);
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+            const int32_t xe = min(x0 + 16, re);
+            for (; x < xe && n < p.W; x++) {
+                const int o = x - x0;
+                uint32_t code = 0;
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) code = (o >> 2) == q4 ? gw[q4] : code;
-                    code = (code >> ((o & 3) * 8)) & 0xffu;
-                    if (x > del_until) emit(code);
-                    while (next_ev == x) {
-                        const int32_t el = p.ev_len[k];
-                        if (el > 0) {
-                            const int nb = n;
-                            for (int i = p.ins_off[k]; i < p.ins_off[k + 1] && n < p.W; i++) emit(p.ins_bases[i]);
-                            dcur -= n - nb;
-                            dmin = min(dmin, dcur);
-                        } else {
-                            del_until = x - el;
-                            dcur -= el;
-                            dmax = max(dmax, dcur);
-                        }
-                        k++;
-                        next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
+                for (int q4 = 0; q4 < 4; q4++) code = (o >> 2) == q4 ? gw[q4] : code;
+                code = (code >> ((o & 3) * 8)) & 0xffu;
+                if (x > del_until) emit(code);
+                while (next_ev == x) {
+                    const int32_t el = p.ev_len[k];
+                    if (el > 0) {
+                        const int nb = n;
+                        for (int i = p.ins_off[k]; i < p.ins_off[k + 1] && n < p.W; i++) emit(p.ins_bases[i]);
+                        dcur -= n - nb;
+                        dmin = min(dmin, dcur);
+                    } else {
+                        del_until = x - el;
+                        dcur -= el;
+                        dmax = max(dmax, dcur);
                     }
+                    k++;
+                    next_ev = k < e1 ? p.ev_pos[k] : INT32_MAX;
                 }
             }
-            if (x >= re) {                                           // the soft-clipped tail has no column of its own: an insertion behind the last one
-                const int nb = n;
-                for (int i = p.tail_off[r]; i < p.tail_off[r + 1] && n < p.W; i++) emit(p.tail_bases[i]);
-                dcur -= n - nb;
-                dmin = min(dmin, dcur);
-            }
         }
-        if (n & 3) out[n >> 2] = acc;
-        p.n1[al] = n;
-        mycells = (long long)n * p.site_n2[site];
-        if (p.band_lo) {
-            // band of B = 32 or 64 diagonals around [dmin, dmax] (0 is inside: the path starts at the origin), the slack split evenly, lowest
-            // diagonal even (the anti-diagonal sweep alternates between the even and the odd diagonals of the band)
-            // a read that ends inside the window leaves last-row cells to the right of its path: the free tail may jump there (a deletion, then
-            // a few chance matches of the read's last bases), so the band reaches the last row's end: hi >= n2 - n1
-            dmax = max(dmax, p.site_n2[site] - n - p.band_margin + 1);
-            const int w = dmax - dmin;
-            cls = w + 2 * p.band_margin <= 31 ? 0 : w + 2 * p.band_margin <= 63 ? 1 : 2;
-            const int B = cls == 0 ? 32 : 64;
-            int lo = dmin - ((B - 1 - w) >> 1);
-            lo -= lo & 1;
-            p.band_lo[al] = (int8_t)(cls == 2 ? 0 : lo);
-            bandcells = cls == 2 ? 0 : (long long)(n + p.site_n2[site]) * (B / 2);
+        if (x >= re) {                                           // the soft-clipped tail has no column of its own: an insertion behind the last one
+            const int nb = n;
+            for (int i = p.tail_off[r]; i < p.tail_off[r + 1] && n < p.W; i++) emit(p.tail_bases[i]);
+            dcur -= n - nb;
+            dmin = min(dmin, dcur);
         }
     }
-    if (p.band_lo) {                                                                      // class lists: one atomic per wave and class
+    if (n & 3) out[n >> 2] = acc;
+    n_out = n; dmin_out = dmin; dmax_out = dmax;
+}
+
+// band class of a window from the diagonals its CIGAR visits; writes band_lo, returns the class (0: 32 diagonals, 1: 64, 2: full matrix) and the band's cells
+__device__ __forceinline__ int window_band(const WinArgs &p, int al, int n, int n2, int dmin, int dmax, long long &bandcells)
+{
+    // band of B = 32 or 64 diagonals around [dmin, dmax] (0 is inside: the path starts at the origin), the slack split evenly, lowest
+    // diagonal even (the anti-diagonal sweep alternates between the even and the odd diagonals of the band)
+    // a read that ends inside the window leaves last-row cells to the right of its path: the free tail may jump there (a deletion, then
+    // a few chance matches of the read's last bases), so the band reaches the last row's end: hi >= n2 - n1
+    dmax = max(dmax, n2 - n - p.band_margin + 1);
+    const int w = dmax - dmin;
+    const int cls = w + 2 * p.band_margin <= 31 ? 0 : w + 2 * p.band_margin <= 63 ? 1 : 2;
+    const int B = cls == 0 ? 32 : 64;
+    int lo = dmin - ((B - 1 - w) >> 1);
+    lo -= lo & 1;
+    p.band_lo[al] = (int8_t)(cls == 2 ? 0 : lo);
+    bandcells = cls == 2 ? 0 : (long long)(n + n2) * (B / 2);
+    return cls;
+}
+
+// class lists (one atomic per wave and class) and the cell counters; cls = -1 for lanes without a window
+__device__ __forceinline__ void window_lists(const WinArgs &p, int al, int cls, long long mycells, long long bandcells)
+{
+    if (p.band_lo) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const unsigned long long m = __ballot(cls == c);
@@ -438,6 +442,322 @@ __global__ __launch_bounds__(64) void k_windows(WinArgs p)
     for (int o = 32; o > 0; o >>= 1) { mycells += __shfl_xor(mycells, o); bandcells += __shfl_xor(bandcells, o); }
     if (threadIdx.x == 0 && mycells) atomicAdd(p.cells, (unsigned long long)mycells);
     if (threadIdx.x == 0 && bandcells) atomicAdd(p.cells + 1, (unsigned long long)bandcells);
+}
+
+__global__ __launch_bounds__(64) void k_windows(WinArgs p)
+{
+    const int al = blockIdx.x * 64 + threadIdx.x;
+    long long mycells = 0, bandcells = 0;
+    int cls = -1;
+    if (al < p.A) {
+        const int r = p.al_read[al], site = p.al_site[al];
+        int n, dmin, dmax;
+        window_serial(p, al, r, p.site_pos[site], n, dmin, dmax);
+        p.n1[al] = n;
+        mycells = (long long)n * p.site_n2[site];
+        if (p.band_lo) cls = window_band(p, al, n, p.site_n2[site], dmin, dmax, bandcells);
+    }
+    window_lists(p, al, cls, mycells, bandcells);
+}
+
+// ---- the 16-lane form: four windows per wave.  A window is the reference stretch behind the anchor with the read's events applied, so it is
+// written by two passes over those events instead of a walk over its bases:
+//   pass A, lane = event (rounds of 16, carried): prefix sums of the deleted columns and of the inserted bases before every event -> the output
+//           index of every insertion (its bases are copied there), which events the walk would still have processed (those on a column it
+//           reaches before the window is full), and the diagonal of the CIGAR's path behind each of them -> [dmin, dmax];
+//   pass B, lane = one aligned 16-column group of the read's position-addressed codes (one dwordx4): the events before / inside the group from
+//           LDS -> index of the group's first kept column, mask of its deleted columns, at most two insertions inside it; 16 byte stores into
+//           the window's LDS row.
+// The row leaves as 16-byte pieces.  Results are those of window_serial on every window (tests: NC_PIPE_WINDOWS=serial | force16).
+constexpr int WIN_EV_CAP = 64;         // events of one window kept in LDS
+constexpr int WIN_ROW = 288;           // bytes of a window's LDS row (>= WS = 272)
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_scan_add(int x)         // inclusive, over the 16 lanes of a DPP row
+{
+    x += dpp_row<0x111>(0, x); x += dpp_row<0x112>(0, x); x += dpp_row<0x114>(0, x); x += dpp_row<0x118>(0, x);
+    return x;
+}
+__device__ __forceinline__ int row_scan_max(int x)
+{
+    x = max(x, dpp_row<0x111>(INT32_MIN, x)); x = max(x, dpp_row<0x112>(INT32_MIN, x));
+    x = max(x, dpp_row<0x114>(INT32_MIN, x)); x = max(x, dpp_row<0x118>(INT32_MIN, x));
+    return x;
+}
+__device__ __forceinline__ int row_last(int x) { return __shfl(x, (int)(threadIdx.x | 15)); }      // lane 15 of the row
+
+__global__ __launch_bounds__(64) void k_windows16(WinArgs p, int32_t force_serial)
+{
+    __shared__ int32_t s_pos[4][WIN_EV_CAP], s_len[4][WIN_EV_CAP];       // s_len > 0: inserted bases, <= 0: minus the deleted columns
+    __shared__ uint32_t s_row[4][WIN_ROW / 4];
+    const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
+    const int al = blockIdx.x * 4 + g;
+    const bool live = al < p.A;
+    uint8_t *rowb = reinterpret_cast<uint8_t *>(&s_row[g][0]);
+    for (int i = q; i < WIN_ROW / 4; i += 16) s_row[g][i] = 0;
+    int r = 0, site = 0;
+    int32_t v = 0;
+    bool act = false;
+    if (live) {
+        r = p.al_read[al]; site = p.al_site[al];
+        v = p.site_pos[site];
+        act = !(p.read_flag[r] & 1);
+    }
+    const int W = p.W;
+    int n = 0, dmin = 0, dmax = 0;
+    bool serial = act && force_serial;
+    int k = 0, e1 = 0, ne = 0;
+    int32_t del_until = 0, rs = 0, re = 0;
+    const uint8_t *cd = p.codes;
+    int32_t Dsum = 0, Isum = 0, dcur = 0;
+    bool all_events = false;
+    __syncthreads();                                                     // (one wave: orders the LDS accesses for the compiler)
+    {
+        // first event on a column >= v: a 16-ary search by the group's lanes (two dependent loads for the ~70 events of k_sets' stretch
+        // instead of six), the last step also fetching the event before it (a deletion that covers the anchor)
+        const bool srch = act && !serial;
+        int e0 = 0, lo = 0, hi = 0;
+        if (srch) {
+            e0 = p.ev_off[r];
+            e1 = p.ev_off[r + 1];
+            lo = e0; hi = e1;
+            if (p.al_ev) { const int2 b2 = p.al_ev[al]; lo = b2.x; hi = b2.y; }
+            rs = p.rd_start[r]; re = p.rd_end[r];
+            cd = p.codes + (p.slot_off[r] - (rs & ~15));
+        }
+        while (__any(srch && hi - lo > 15)) {
+            const bool on = srch && hi - lo > 15;
+            const int step = (hi - lo + 15) >> 4, idx = lo + q * step;
+            const int32_t pv = on && idx < hi ? p.ev_pos[idx] : INT32_MAX;
+            const int cnt = __popc((uint32_t)(__ballot(pv < v) >> (16 * g)) & 0xffffu);         // the probes ascend: those before v are a prefix
+            if (on) {
+                if (cnt == 0) hi = lo;
+                else { const int nlo = lo + (cnt - 1) * step + 1; hi = min(hi, lo + cnt * step); lo = nlo; }
+            }
+        }
+        {
+            const int idx = lo - 1 + q;                                               // lane 0: the event before the range
+            const bool ld = srch && idx >= e0 && idx < hi;
+            const int32_t pv = ld ? p.ev_pos[idx] : INT32_MAX, lv = ld ? p.ev_len[idx] : 0;
+            const int cnt = __popc((uint32_t)(__ballot(ld && q > 0 && pv < v) >> (16 * g)) & 0xffffu);
+            k = lo + cnt;
+            const int src = (lane & 48) | cnt;                                        // the lane that holds event k - 1
+            const int32_t pp = __shfl(pv, src), pl = __shfl(lv, src);
+            if (srch && k > e0 && pl < 0) del_until = pp - pl;
+        }
+        if (srch) {
+            if (del_until >= v) { dcur = del_until + 1 - v; dmax = dcur; }
+            Dsum = dcur;                                                 // deleted columns of [v, ...] so far
+        }
+    }
+    // ---- pass A
+    {
+        bool more = act && !serial;
+        int32_t c_dend = del_until, c_head = INT32_MIN, c_prev = v - 1;
+        while (__any(more)) {
+            const int i = k + ne + q;
+            const bool valid = more && i < e1;
+            int32_t pos = INT32_MAX, el = 0, io = 0, ilen = 0;
+            if (valid) {                                                             // (four independent loads)
+                pos = p.ev_pos[i]; el = p.ev_len[i];
+                io = p.ins_off[i];
+                const int32_t io1 = p.ins_off[i + 1];
+                ilen = el > 0 ? io1 - io : 0;
+            }
+            const int32_t L = el < 0 ? -el : 0;
+            const bool is_ins = valid && el > 0;
+            const int32_t Iin = row_scan_add(ilen), Din = row_scan_add(L);
+            const int32_t Iex = Isum + Iin - ilen, Dex = Dsum + Din - L;             // inserted bases / deleted columns of the events before this one
+            const int32_t dend_in = row_scan_max(L > 0 ? pos + L : INT32_MIN);
+            const int32_t dend_ex = max(c_dend, dpp_row<0x111>(INT32_MIN, dend_in));
+            const bool deleted = valid && dend_ex >= pos;                            // the event's own column is a deleted one
+            const int32_t prevpos = dpp_row<0x111>(c_prev, pos);
+            const bool head = valid && pos != prevpos;                               // first event on its column
+            const int32_t nh = (pos - v) - Dex + (deleted ? 1 : 0) + Iex;            // (heads) bases written when the walk reaches the event's column
+            const int32_t hs = row_scan_max(head ? nh : INT32_MIN);
+            const int32_t ncol = max(c_head, hs);
+            const bool processed = valid && ncol < W;
+            const int32_t nat = (pos - v + 1) - Dex + Iex;                           // bases written before this insertion's own
+            const int32_t emitted = processed && is_ins ? max(0, min(W - nat, ilen)) : 0;
+            const int32_t delta = processed ? (is_ins ? -emitted : L) : 0;
+            const int32_t dc = dcur + row_scan_add(delta);
+            const int32_t mn = row_scan_max(processed && is_ins ? -dc : INT32_MIN), mx = row_scan_max(processed && !is_ins ? dc : INT32_MIN);
+            const int32_t mnl = row_last(mn), mxl = row_last(mx);
+            if (mnl != INT32_MIN) dmin = min(dmin, -mnl);
+            if (mxl != INT32_MIN) dmax = max(dmax, mxl);
+            if (valid) { s_pos[g][ne + q] = pos; s_len[g][ne + q] = is_ins ? ilen : -L; }
+            // the inserted bases: up to four by the event's own lane (independent loads), a longer run by the 16 lanes of the group together --
+            // a byte loop per lane waits for one load after the other (a planted 50-base insertion: 50 latencies on every wave)
+            {
+                uint32_t b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) b4[t] = t < emitted && emitted <= 4 ? (uint32_t)p.ins_bases[io + t] : 0u;
+#pragma unroll
+                for (int t = 0; t < 4; t++) if (t < emitted && emitted <= 4) rowb[nat + t] = (uint8_t)b4[t];
+                uint32_t em = (uint32_t)(__ballot(emitted > 4) >> (16 * g)) & 0xffffu;
+                while (__any(em != 0)) {
+                    const int src = (lane & 48) | (em ? __builtin_ctz(em) : 0);
+                    const int32_t io_b = __shfl(io, src), nat_b = __shfl(nat, src), cnt_b = __shfl(emitted, src);
+                    if (em) for (int t = q; t < cnt_b; t += 16) rowb[nat_b + t] = p.ins_bases[io_b + t];
+                    em &= em - 1;
+                }
+            }
+            const int nv = __popc((uint32_t)(__ballot(valid) >> (16 * g)) & 0xffffu);
+            Isum += row_last(Iin); Dsum += row_last(Din);
+            c_dend = max(c_dend, row_last(dend_in));
+            c_head = max(c_head, row_last(hs));
+            c_prev = row_last(pos);
+            dcur = row_last(dc);
+            ne += nv;
+            if (more) all_events = k + ne >= e1;
+            more = more && !all_events && c_head < W;
+            if (more && ne + 16 > WIN_EV_CAP) { serial = true; more = false; }
+        }
+    }
+    // ---- the read's end: the soft-clipped tail is an insertion behind the last column
+    int32_t n_end = 0, tail_emit = 0, t0 = 0;
+    if (act && !serial) {
+        n = W;
+        if (all_events) {
+            n_end = (re - v) - Dsum + Isum;
+            if (n_end < W) {
+                t0 = p.tail_off[r];
+                tail_emit = min(W - n_end, p.tail_off[r + 1] - t0);
+                n = n_end + tail_emit;
+                dmin = min(dmin, dcur - tail_emit);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass B
+    {
+        const int32_t xb = v & ~15;
+        int ne_w = act && !serial ? ne : 0;
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) ne_w = max(ne_w, __shfl_xor(ne_w, o));
+        ne_w = __builtin_amdgcn_readfirstlane(ne_w);
+        bool cont = act && !serial;
+        for (int round = 0; __any(cont); round++) {
+            const int32_t x0 = xb + 16 * (q + 16 * round);
+            int32_t Ib = 0, Db = 0;
+            uint32_t delm = 0;
+            int c1 = 16, l1 = 0, c2 = 16, l2 = 0, nin = 0;
+            if (del_until >= v) {                                                    // the deletion the anchor lies in: columns v .. del_until
+                const int32_t b = min(del_until, x0 - 1);
+                if (b >= v) Db += b - v + 1;
+                const int lo2 = max(v, x0) - x0, hi2 = min(del_until, x0 + 15) - x0;
+                if (hi2 >= lo2) delm |= ((2u << hi2) - 1u) & ~((1u << lo2) - 1u);
+            }
+            for (int j = 0; j < ne_w; j++) {
+                if (!(cont && j < ne)) continue;
+                const int32_t pj = s_pos[g][j], lj = s_len[g][j];
+                if (lj > 0) {
+                    if (pj < x0) Ib += lj;
+                    else if (pj < x0 + 16) {
+                        if (nin == 0) { c1 = pj - x0; l1 = lj; } else if (nin == 1) { c2 = pj - x0; l2 = lj; }
+                        nin++;
+                    }
+                } else {
+                    const int32_t a = pj + 1, bb = pj - lj;                         // deleted columns a .. bb
+                    const int32_t b = min(bb, x0 - 1);
+                    if (b >= a) Db += b - a + 1;
+                    const int lo2 = max(a, x0) - x0, hi2 = min(bb, x0 + 15) - x0;
+                    if (hi2 >= lo2) delm |= ((2u << hi2) - 1u) & ~((1u << lo2) - 1u);
+                }
+            }
+            if (nin > 2) serial = true;
+            // kept columns of the group: inside [v, re), not deleted
+            const int klo = max(v, x0) - x0, khi = min(re - 1, x0 + 15) - x0;
+            uint32_t keep = 0;
+            if (cont && khi >= klo) keep = (((2u << khi) - 1u) & ~((1u << klo) - 1u)) & ~delm;
+            const int32_t base = max(x0 - v, 0) - Db + Ib;                           // index of the group's first kept column
+            uint4 cw = make_uint4(0, 0, 0, 0);
+            if (keep) cw = *reinterpret_cast<const uint4 *>(cd + x0);
+            const uint32_t gw[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int32_t idx = base + __popc(keep & ((1u << c) - 1u)) + (c > c1 ? l1 : 0) + (c > c2 ? l2 : 0);
+                if (((keep >> c) & 1u) && idx < W) rowb[idx] = (uint8_t)(gw[c >> 2] >> ((c & 3) * 8));
+            }
+            // another round while the next group's first column is inside the read and before the window's end
+            const int32_t nbase = base + __popc(keep) + l1 + l2;                      // (index behind this group)
+            const int32_t nb15 = row_last(nbase);
+            cont = cont && (xb + 256 * (round + 1) < re) && nb15 < W;
+        }
+    }
+    {
+        const uint32_t sm = (uint32_t)(__ballot(serial) >> (16 * g)) & 0xffffu;
+        serial = sm != 0;
+    }
+    for (int t = q; t < tail_emit; t += 16) if (!serial) rowb[n_end + t] = p.tail_bases[t0 + t];
+    __syncthreads();
+    if (serial) {
+        if (q == 0) window_serial(p, al, r, v, n, dmin, dmax);
+    } else if (live) {
+        uint4 *out = reinterpret_cast<uint4 *>(p.win + (int64_t)al * p.WS);
+        const uint4 *src = reinterpret_cast<const uint4 *>(&s_row[g][0]);
+        for (int w4 = q; w4 * 16 < n; w4 += 16) out[w4] = src[w4];
+    }
+    if (live && q == 0) {
+        p.n1[al] = n;
+        long long bandcells = 0;
+        if (p.band_lo) p.wcls[al] = (int8_t)window_band(p, al, n, p.site_n2[site], dmin, dmax, bandcells);
+    }
+}
+
+// class lists and cell counters of k_windows16's windows.  (One returning atomic per wave on the three list counters and two on the cell
+// counters -- what k_windows does -- made the four-windows-per-wave kernel 1.1 ms slower than the arithmetic it saves: 260 k atomics on
+// five addresses are served one after the other.  Here a workgroup of 1024 threads reserves list space for 4096 windows at once.)
+__global__ __launch_bounds__(1024) void k_window_lists(WinArgs p)
+{
+    __shared__ int32_t l_cnt[3], g_base[3];
+    __shared__ unsigned long long l_cells[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 3) l_cnt[tid] = 0;
+    if (tid < 2) l_cells[tid] = 0;
+    __syncthreads();
+    int cls[4], at[4];
+    long long mycells = 0, bandcells = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int al = blockIdx.x * 4096 + u * 1024 + tid;
+        cls[u] = -1; at[u] = 0;
+        if (al < p.A) {
+            const int n = p.n1[al], n2 = p.site_n2[p.al_site[al]];
+            mycells += (long long)n * n2;
+            if (p.band_lo) {
+                cls[u] = p.wcls[al];
+                if (cls[u] != 2) bandcells += (long long)(n + n2) * (cls[u] == 0 ? 16 : 32);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const unsigned long long m = __ballot(cls[u] == c);
+            if (!m) continue;
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&l_cnt[c], __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (cls[u] == c) at[u] = base + __popcll(m & ((1ull << lane) - 1ull));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mycells += __shfl_xor(mycells, o); bandcells += __shfl_xor(bandcells, o); }
+    if (lane == 0 && mycells) atomicAdd(&l_cells[0], (unsigned long long)mycells);
+    if (lane == 0 && bandcells) atomicAdd(&l_cells[1], (unsigned long long)bandcells);
+    __syncthreads();
+    if (tid < 3 && l_cnt[tid]) {
+        g_base[tid] = atomicAdd(p.counts + tid, l_cnt[tid]);
+        if (tid == 2) atomicAdd(p.counts + 3, l_cnt[2]);
+    }
+    if (tid < 2 && l_cells[tid]) atomicAdd(p.cells + tid, l_cells[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (cls[u] < 0) continue;
+        int32_t *lst = cls[u] == 0 ? p.list1 : cls[u] == 1 ? p.list2 : p.listF;
+        lst[g_base[cls[u]] + at[u]] = blockIdx.x * 4096 + u * 1024 + tid;
+    }
 }
 
 struct FillArgs {
@@ -2192,7 +2512,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int nblk = (N1 + W + 7) / 8;                             // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= N1 + W (41 for the 160-base windows, 66 for the 260-base ones)
         const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && nblk <= 80;
         if (band) {
-            NC_TRY(nc_ensure(ctx, B.band_lo, Agz + 64));
+            NC_TRY(nc_ensure(ctx, B.band_lo, 2 * Agz + 128));            // + the windows' classes (k_windows16 -> k_window_lists)
             NC_TRY(nc_ensure(ctx, B.lists, Agz * 3 * 4 + 64));
             NC_TRY(nc_ensure(ctx, B.counts, 64));
             NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)nblk * 128 + 256));
@@ -2212,9 +2532,19 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         wa.al_ev = s->have_al_ev ? (const int2 *)s->al_ev.p + A0 : nullptr;
         wa.A = Ag; wa.W = s->window_after; wa.WS = WS; wa.win = (uint8_t *)B.win.p; wa.n1 = (int32_t *)B.n1.p; wa.cells = cells;
         wa.band_lo = band ? (int8_t *)B.band_lo.p : nullptr;
+        wa.wcls = band ? (int8_t *)B.band_lo.p + Agz + 64 : nullptr;
         wa.list1 = (int32_t *)B.lists.p; wa.list2 = wa.list1 + Agz; wa.listF = wa.list2 + Agz;
         wa.counts = (int32_t *)B.counts.p; wa.band_margin = s->band_margin_v > 0 ? s->band_margin_v : band_margin();
-        if (Ag > 0) hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, sA, wa);
+        if (Ag > 0) {
+            // NC_PIPE_WINDOWS = serial: one lane per window (the round-3 kernel); force16: the 16-lane kernel with every window on its serial route
+            const char *wm = getenv("NC_PIPE_WINDOWS");
+            if (wm && !strcmp(wm, "serial")) hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, sA, wa);
+            else if (WS <= WIN_ROW - 16) {
+                hipLaunchKernelGGL(k_windows16, dim3((Ag + 3) / 4), dim3(64), 0, sA, wa, (wm && !strcmp(wm, "force16")) ? 1 : 0);
+                hipLaunchKernelGGL(k_window_lists, dim3((Ag + 4095) / 4096), dim3(1024), 0, sA, wa);
+            }
+            else hipLaunchKernelGGL(k_windows, dim3((Ag + 63) / 64), dim3(64), 0, sA, wa);
+        }
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[1], sA));
         // ---- star alignment: every read window against its site's reference window (free tail)
         FillArgs &fa = fa_of[b];

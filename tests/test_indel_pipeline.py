@@ -539,3 +539,50 @@ def test_tiled_event_windows_equal_the_atomic_form(monkeypatch):
         if "excl" in variant:
             pos = np.asarray(new["pos"])
             assert not np.any((pos >= 901_000) & (pos < 907_500))
+
+
+def _window_dump(tmp_path, tag):
+    """the per-alignment arrays NC_PIPE_DUMP left: rows cut to their lengths"""
+    d = {n: np.fromfile(str(tmp_path / (tag + "." + n)), dt) for n, dt in (("n1", np.int32), ("band_lo", np.int8), ("al_read", np.int32), ("al_site", np.int32), ("win", np.uint8))}
+    A = len(d["n1"])
+    ws = len(d["win"]) // A
+    win = d["win"].reshape(A, ws)
+    rows = [win[a, :d["n1"][a]].tobytes() for a in range(A)]
+    return d, rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window_after", [160, 260])
+def test_windows_by_16_lanes_equal_the_serial_walk(tmp_path, monkeypatch, window_after):
+    """k_windows16 (four windows per wave: prefix sums over the read's events, 16-column groups) against the one-lane walk it replaces
+    (NC_PIPE_WINDOWS=serial: the round-3 kernel; force16: the new kernel with every window on its serial route): bases, lengths and bands of
+    every window, on the synthetic workload (planted indels up to 50 bases, 4 % deletions) at both window lengths"""
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    eng = get_engine(0)
+    L = 1_500_000
+    pack, reads_c, info = make_indel_device_workload(eng, L, depth=30.0, seed=31 + window_after)
+    chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=window_after)
+    got = {}
+    for mode in ("default", "serial", "force16"):
+        if mode == "default":
+            monkeypatch.delenv("NC_PIPE_WINDOWS", raising=False)
+        else:
+            monkeypatch.setenv("NC_PIPE_WINDOWS", mode)
+        monkeypatch.setenv("NC_PIPE_DUMP", str(tmp_path / mode))
+        r = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+        monkeypatch.delenv("NC_PIPE_DUMP")
+        got[mode] = (_window_dump(tmp_path, mode), r)
+    monkeypatch.delenv("NC_PIPE_WINDOWS", raising=False)
+    (d0, rows0), r0 = got["serial"]
+    assert len(rows0) > 10_000 and int((d0["n1"] < window_after).sum()) > 0 and int((d0["band_lo"] != d0["band_lo"][0]).sum()) > 0
+    for mode in ("default", "force16"):
+        (d, rows), r = got[mode]
+        for k in ("n1", "band_lo", "al_read", "al_site"):
+            assert np.array_equal(d[k], d0[k]), (mode, k, int((d[k] != d0[k]).sum()))
+        bad = [a for a in range(len(rows0)) if rows[a] != rows0[a]]
+        assert not bad, (mode, len(bad), bad[:5])
+        assert r["n"] == r0["n"] and bool((r["x"] == r0["x"]).all())
+        for k in ("pos", "ref_len", "alt_len"):
+            assert np.array_equal(np.asarray(r[k]), np.asarray(r0[k])), (mode, k)
