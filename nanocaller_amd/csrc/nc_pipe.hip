@@ -169,6 +169,92 @@ __global__ __launch_bounds__(1024) void k_scan_excl(const int32_t *__restrict__ 
     if (threadIdx.x == 0) out[n] = tot;
 }
 
+constexpr int TWB_LOG = 3, TWB = 1 << TWB_LOG;                  // steps per block
+__host__ __device__ __forceinline__ int tw_blocks(int n1) { return ((n1 + 15) >> TWB_LOG) + 1; }      // (traceback storage: below)
+// ---- the same scans in two launches of many workgroups.  (One workgroup walking the whole array, every thread a contiguous chunk, is a chain of
+// uncoalesced loads on one CU: 0.21 ms for the 120 k consensus lengths of a chr20-sized pass, 0.19 for its ALT lengths, 3 x 0.04 in the plan.)
+// k_scan_part: sum of every tile of 4096 inputs; k_scan_apply: a tile's offset = the sum of the tiles before it (a block reduction over <= a few
+// hundred partial sums), then the scan of its own 4096 inputs, four consecutive ones per thread.
+enum { SC_PLAIN = 0, SC_TWB = 1, SC_POS = 2 };
+template <int F>
+__device__ __forceinline__ int sc_val(int x) { return F == SC_TWB ? tw_blocks(x) : F == SC_POS ? max(x, 0) : x; }
+constexpr int SC_TILE = 4096;
+
+template <int F>
+__global__ __launch_bounds__(1024) void k_scan_part(const int32_t *__restrict__ in, int32_t n, int32_t add, long long *__restrict__ part,
+                                                    const long long *__restrict__ base_in)
+{
+    __shared__ long long wsum[16];
+    const int i0 = blockIdx.x * SC_TILE + threadIdx.x * 4;
+    long long local = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (i0 + u < n) local += sc_val<F>(in[i0 + u]) + add;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < 16; w++) t += wsum[w];
+        part[blockIdx.x] = t;
+        if (blockIdx.x == 0) part[gridDim.x] = base_in ? base_in[0] : 0;       // snapshot of the running base (k_scan_apply's last block advances it)
+    }
+}
+
+// out[i] = base + exclusive prefix; OUT = int32_t or int64_t.  total_out (nullable): the grand total as {low 31 bits, 0} (the row mailbox's format) when
+// mbox_fmt, else a plain OUT at out[n].  base_io (nullable): advanced by the total.
+template <int F, class OUT>
+__global__ __launch_bounds__(1024) void k_scan_apply(const int32_t *__restrict__ in, int32_t n, int32_t add, const long long *__restrict__ part,
+                                                     OUT *__restrict__ out, int32_t write_total, int32_t *__restrict__ total_mbox, long long *__restrict__ base_io)
+{
+    __shared__ long long wsum2[16];
+    __shared__ int wsum[16];
+    __shared__ long long s_off;
+    const int nb = gridDim.x;
+    long long before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 1024) before += part[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if ((threadIdx.x & 63) == 0) wsum2[threadIdx.x >> 6] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = part[nb];
+        for (int w = 0; w < 16; w++) t += wsum2[w];
+        s_off = t;
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * SC_TILE + threadIdx.x * 4;
+    int v[4], local = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { v[u] = i0 + u < n ? sc_val<F>(in[i0 + u]) + add : 0; local += v[u]; }
+    int tot;
+    const int inc = block_scan(local, wsum, tot);
+    long long run = s_off + inc - local;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (i0 + u < n) out[i0 + u] = (OUT)run;
+        run += v[u];
+    }
+    if ((int)blockIdx.x == nb - 1 && threadIdx.x == 0) {
+        const long long total = s_off + tot;
+        if (write_total) out[n] = (OUT)total;
+        if (total_mbox) { total_mbox[0] = (int32_t)((total - part[nb]) & 0x7fffffff); total_mbox[1] = (int32_t)((total - part[nb]) >> 31); }
+        if (base_io) base_io[0] = total;
+    }
+}
+
+template <int F, class OUT>
+static int scan_launch(nc_ctx *ctx, hipStream_t st, DevBuf &partbuf, const int32_t *in, int32_t n, int32_t add, OUT *out, bool write_total, int32_t *total_mbox,
+                       long long *base_io)
+{
+    const int nb = std::max(1, (n + SC_TILE - 1) / SC_TILE);
+    NC_TRY(nc_ensure(ctx, partbuf, ((size_t)nb + 2) * 8));
+    long long *part = (long long *)partbuf.p;
+    hipLaunchKernelGGL((k_scan_part<F>), dim3(nb), dim3(1024), 0, st, in, n, add, part, (const long long *)base_io);
+    hipLaunchKernelGGL((k_scan_apply<F, OUT>), dim3(nb), dim3(1024), 0, st, in, n, add, (const long long *)part, out, write_total ? 1 : 0, total_mbox, base_io);
+    return NC_OK;
+}
+
 __global__ __launch_bounds__(256) void k_flatten(const PipeChunk *__restrict__ pc, const int32_t *__restrict__ seg_pos, const int8_t *__restrict__ seg_type,
                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ off, int32_t *__restrict__ anc_pos,
                                                  int8_t *__restrict__ anc_type, int32_t *__restrict__ anc_chunk)
@@ -800,8 +886,6 @@ __device__ __forceinline__ int fill_site(const FillArgs &p, int al) { return p.a
 // after the other fixed the writes (15 ms) but left the traceback one 64-byte sector per step (11 GB per chr20-sized contig); whole words
 // per step (2 for 11 codes, 4 for 17) wrote 28.5 GB per pass for 15.3 GB of codes.]  The fill kernels collect 8 steps per lane in LDS (a
 // lane reads back only what it wrote itself) and write whole runs.
-constexpr int TWB_LOG = 3, TWB = 1 << TWB_LOG;                  // steps per block
-__host__ __device__ __forceinline__ int tw_blocks(int n1) { return ((n1 + 15) >> TWB_LOG) + 1; }
 __device__ __forceinline__ int64_t tw_run(int64_t first_block, int t, int q, int CPL) { return ((first_block + (t >> TWB_LOG)) * 16 + q) * (int64_t)CPL; }
 struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };      // four words at a 4-byte aligned address (one dwordx4 access)
 
@@ -2167,6 +2251,7 @@ struct nc_pipe_state {
     int32_t band_mode = -1, band_margin_v = 0;   // nc_indel_sites_band: -1 = the environment's setting
     int64_t band_stats[6] = {0, 0, 0, 0, 0, 0};   // of the last run: alignments on 32 / 64 diagonals, on the full matrix by width, re-run after an edge touch
     DevBuf tw2, runs, rlen, alen, alt_pool, misc;
+    DevBuf part_a, part_b;                   // partial sums of the two-launch scans (plan / stream A; stream B)
     DevBuf ab_lo, ab_lists, ab_counts, ab_twb;             // banded allele alignments (stage_b2; one group at a time on stream B)
     hipStream_t sB = nullptr;                // second stream: traceback / tensors / alleles of group g beside the alignment fill of g + 1
     hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -2183,7 +2268,7 @@ void nc_pipe_destroy(nc_ctx *ctx)
     if (!s) return;
     DevBuf *bufs[] = {&s->pc, &s->seg_pos, &s->seg_type, &s->cnt, &s->off, &s->anc_pos, &s->anc_type, &s->anc_chunk, &s->kept, &s->nuniq, &s->site_of,
                       &s->al_of, &s->site_pos, &s->site_chunk, &s->site_type, &s->site_phase, &s->site_al0, &s->site_nr, &s->site_n2, &s->al_read,
-                      &s->al_site, &s->al_member, &s->al_ev, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc, &s->ab_lo, &s->ab_lists, &s->ab_counts, &s->ab_twb,
+                      &s->al_site, &s->al_member, &s->al_ev, &s->tw2, &s->runs, &s->rlen, &s->alen, &s->alt_pool, &s->misc, &s->part_a, &s->part_b, &s->ab_lo, &s->ab_lists, &s->ab_counts, &s->ab_twb,
                       &s->gb[0].win, &s->gb[0].n1, &s->gb[0].tw, &s->gb[0].hlast, &s->gb[0].hcol, &s->gb[0].endc, &s->gb[0].trace, &s->gb[0].cns, &s->gb[0].ncns,
                       &s->gb[0].arow, &s->gb[0].alt_off, &s->gb[0].band_lo, &s->gb[0].lists, &s->gb[0].counts, &s->gb[0].twb, &s->gb[0].hrow, &s->gb[0].hcolb, &s->gb[0].cband, &s->gb[1].cband,
                       &s->gb[1].band_lo, &s->gb[1].lists, &s->gb[1].counts, &s->gb[1].twb, &s->gb[1].hrow, &s->gb[1].hcolb, &s->gb[1].win, &s->gb[1].n1, &s->gb[1].tw, &s->gb[1].hlast, &s->gb[1].hcol, &s->gb[1].endc, &s->gb[1].trace,
@@ -2310,7 +2395,9 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
         NC_HIP(ctx, hipGetLastError());
         c0 += used;                                                   // (the next group's K7 reuses the workspace in stream order)
     }
-    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->cnt.p, n_chunks, 0, (int32_t *)s->off.p);
+    NC_TRY(nc_ensure(ctx, s->part_a, 8 * 8192));                      // (sized once: the scans never re-allocate between launches of a pass)
+    NC_TRY(nc_ensure(ctx, s->part_b, 8 * 8192));
+    NC_TRY((scan_launch<SC_PLAIN, int32_t>(ctx, ctx->stream, s->part_a, (const int32_t *)s->cnt.p, n_chunks, 0, (int32_t *)s->off.p, true, nullptr, nullptr)));
     // counts the host waits for travel by copy kernel into the context's page-locked mailbox (a hipMemcpyAsync of either direction
     // queues behind a contig's upload in flight on this platform: DESIGN.md section 2)
     volatile int32_t *mb = ctx->mbox + 32;
@@ -2349,8 +2436,8 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     sa.n_anchor = na; sa.anc_pos = (const int32_t *)s->anc_pos.p; sa.anc_chunk = (const int32_t *)s->anc_chunk.p; sa.anc_type = (const int8_t *)s->anc_type.p;
     sa.kept = (int32_t *)s->kept.p; sa.nuniq = (int32_t *)s->nuniq.p;
     hipLaunchKernelGGL(k_sets<false>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
-    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->kept.p, na, 0, (int32_t *)s->site_of.p);
-    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)s->nuniq.p, na, 0, (int32_t *)s->al_of.p);
+    NC_TRY((scan_launch<SC_PLAIN, int32_t>(ctx, ctx->stream, s->part_a, (const int32_t *)s->kept.p, na, 0, (int32_t *)s->site_of.p, true, nullptr, nullptr)));
+    NC_TRY((scan_launch<SC_PLAIN, int32_t>(ctx, ctx->stream, s->part_a, (const int32_t *)s->nuniq.p, na, 0, (int32_t *)s->al_of.p, true, nullptr, nullptr)));
     NC_HIP(ctx, hipGetLastError());
     NC_TRY(nc_d2h(ctx, ctx->mbox + 34, (int32_t *)s->site_of.p + na, 4, ctx->stream));
     NC_TRY(nc_d2h(ctx, ctx->mbox + 35, (int32_t *)s->al_of.p + na, 4, ctx->stream));
@@ -2615,7 +2702,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         else hipLaunchKernelGGL(k_site_tensor<uint16_t>, dim3(ng), dim3(256), 0, sB, ta);
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[4], sB));
         int32_t *mbox = (int32_t *)s->misc.p + 2;
-        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, sB, (const int32_t *)B.ncns.p, ng * S, (int64_t *)B.arow.p, mbox);
+        NC_TRY((scan_launch<SC_TWB, int64_t>(ctx, sB, s->part_b, (const int32_t *)B.ncns.p, ng * S, 0, (int64_t *)B.arow.p, true, mbox, nullptr)));
         NC_HIP(ctx, hipGetLastError());
         NC_TRY(nc_d2h(ctx, ctx->mbox + 36, mbox, 8, sB));
         return NC_OK;
@@ -2665,7 +2752,7 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         launch_fill(ctx, sB, CPL, fb);
         hipLaunchKernelGGL(k_allele_trace16p<0>, dim3((nset + 63) / 64), dim3(64), 0, sB, bb, CPL, packed_fill() ? 1 : 0, (const int32_t *)s->site_type.p,
                            s->win_size, (int16_t *)s->runs.p, rl, al);
-        hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(1024), 0, sB, (const int32_t *)al, nset, pool_base, (int64_t *)B.alt_off.p);
+        NC_TRY((scan_launch<SC_POS, int64_t>(ctx, sB, s->part_b, (const int32_t *)al, nset, 0, (int64_t *)B.alt_off.p, false, nullptr, pool_base)));
         hipLaunchKernelGGL(k_alt_copy, dim3((nset + 3) / 4), dim3(256), 0, sB, (const uint8_t *)B.cns.p, (const int32_t *)al,
                            (const int64_t *)B.alt_off.p, nset, (uint8_t *)s->alt_pool.p, s->alt_pool_cap, err);
         NC_HIP(ctx, hipGetLastError());
