@@ -32,6 +32,8 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 namespace {
 
 constexpr int PICK_CAP = 12288;        // anchors of one chunk held in LDS by k_pick (a 100 kb chunk has at most 9,092)
+constexpr int TWB_PITCH = 36;        // words of banded traceback codes per block of 8 anti-diagonals and alignment (C = 2: 32 cells + 4 empty slots a superblock)
+constexpr int BAND_NBLK4 = 44;       // ... stored in whole superblocks of four blocks
 constexpr int BAND_NBLK = 41;        // blocks of 8 anti-diagonals of a banded ALLELE alignment: n1 + n2 <= 328 (the star alignments size theirs by the window: stage_a)
 constexpr int CNS_CAP = 1024;          // alignment columns of one read set (window + the longest insertion of every slot)
 constexpr int32_t NW_NEG = -(1 << 29);
@@ -1251,7 +1253,7 @@ struct BandArgs {
     const int32_t *list;         // the alignments of this class (indices into the group), *count of them
     const int32_t *count;
     const int8_t *band_lo;       // [A] lowest diagonal (even, -B < lo <= 0)
-    uint32_t *Twb;               // [A][NBLK * 32] words: block b of an alignment = 16 C words at b * 16 C (lane q's C words at q * C)
+    uint32_t *Twb;               // [A][NBLK * TWB_PITCH] words: see TbBand
     int16_t *hrow, *hcolb;       // [A][64] H of the band's cells in the last row / the last column, by diagonal index d - lo
     int32_t NBLK;                // blocks of 8 anti-diagonals per alignment
     int32_t *redo_list, *redo_count;      // k_trace_band: alignments whose path touched an edge of the band
@@ -1274,6 +1276,7 @@ template <int C>
 __global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
 {
     constexpr int B = 32 * C;
+    __shared__ __attribute__((aligned(16))) uint32_t tws[2][64][4 * C];
     const int cnt = *p.count;
     if ((int)blockIdx.x * 8 >= cnt) return;
     const int lane = threadIdx.x, g = lane >> 4, q = lane & 15;
@@ -1423,49 +1426,105 @@ __global__ __launch_bounds__(64) void k_fill_band(BandArgs p)
 #pragma unroll
             for (int s = 0; s < 8; s += 2) { step(T_{}, T_{}, a0 + s, s); step(F_{}, T_{}, a0 + s + 1, s + 1); }
         }
+        // the block's codes wait in LDS (a lane reads back only what it wrote) until four blocks -- 32 anti-diagonals -- are together: they leave as
+        // 16 C bytes per lane, so that a 64-byte line holds 8 diagonals x 32 steps (the traceback stays on a line for ~32 steps instead of 8)
+        const int bb = b & 3;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            if (!(live[k] && b < nb[k])) continue;
             const uint32_t sel = k == 0 ? 0x05040100u : 0x07060302u;
-            uint32_t *dst = p.Twb + (int64_t)al[k] * p.NBLK * 32 + (b * 16 + q) * C;
-            if (C == 1) dst[0] = __builtin_amdgcn_perm(P[1], P[0], sel);
-            else *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_amdgcn_perm(P[1], P[0], sel), __builtin_amdgcn_perm(P[3], P[2], sel));
+            uint32_t *ls = &tws[k][lane][bb * C];
+            if (C == 1) ls[0] = __builtin_amdgcn_perm(P[1], P[0], sel);
+            else *reinterpret_cast<uint2 *>(ls) = make_uint2(__builtin_amdgcn_perm(P[1], P[0], sel), __builtin_amdgcn_perm(P[3], P[2], sel));
+        }
+        if (bb == 3 || b == nbw - 1) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!(live[k] && (b & ~3) < nb[k])) continue;
+                uint4 *dst = reinterpret_cast<uint4 *>(p.Twb + (int64_t)al[k] * p.NBLK * TWB_PITCH + ((b >> 2) * (16 * C + 4) + q * C + 2) * 4);
+                const uint4 *src = reinterpret_cast<const uint4 *>(&tws[k][lane][0]);
+#pragma unroll
+                for (int u = 0; u < C; u++) dst[u] = src[u];
+            }
         }
     }
 }
 
-// The line cache of a banded traceback (TbLine's role): a block of 8 anti-diagonals is one line of 64 C bytes (16 lanes x C words), kept in LDS per
-// walking lane and re-fetched in epochs.
+// The line cache of a banded traceback (TbLine's role).  k_fill_band stores the codes of four blocks of 8 anti-diagonals -- a superblock of 32 -- as
+// 4 C words per lane: the words of cell x = q C + c of superblock sb at ((sb * (16 C + 4) + x + 2) * 4), block bb = 0 .. 3 of the superblock at + bb
+// (C = 2: a lane's two cells share their words: + bb * 2 + h, steps 0-3 and 4-7 of both).  A 64-byte line is therefore 4 cells = 8 diagonals x 32
+// steps: the walk changes lines every ~32 steps (every 8 when a line was one block of all 32 diagonals: 41 lines per alignment instead of ~13, 4.3 GB
+// read per pass for 0.2 GB of path codes).  The two empty cell slots in front shift the lines by half a line: the middle of the band -- where
+// k_windows put the CIGAR's own diagonals -- is the middle of a line, not the border between two.
+// One line per walking lane in LDS, re-fetched in epochs.
 template <int C>
 struct TbBand {
     static constexpr int B = 32 * C;
-    uint32_t *slot;                                                    // this lane's 16 C words in LDS (odd pitch)
+    uint32_t *slot;                                                    // this lane's 16 words in LDS (odd pitch)
     const uint32_t *tw;                                                // the alignment's codes
-    int lo, cblk, edge;
+    int lo, ckey, edge;
     bool touched;
-    __device__ __forceinline__ bool has(int i, int j) const { return ((i + j - 1) >> 3) == cblk; }
+    U4 pre[4];                                                         // the line one superblock further down the path (same group of diagonals), in flight or arrived
+    int pkey;
+    __device__ __forceinline__ int key(int i, int j) const { return ((i + j - 1) >> 5) * 16 + ((((j - i - lo) >> 1) + 2) >> 2); }      // (superblock, line)
+    __device__ __forceinline__ bool has(int i, int j) const { return key(i, j) == ckey; }
+    // the same from the walk's running coordinates: a = i + j - 1 (anti-diagonal), kd = j - i - lo (diagonal of the band)
+    __device__ __forceinline__ int key_akd(int a, int kd) const { return (a >> 5) * 16 + (((kd >> 1) + 2) >> 2); }
+    __device__ __forceinline__ uint32_t raw(int a, int kd) const          // the cell's four sign bits (any a, kd: the index stays inside the slot)
+    {
+        const int s = a & 7, bb = (a >> 3) & 3, xx = kd >> 1;
+        if (C == 1) return (slot[((xx + 2) & 3) * 4 + bb] >> (4 * s)) & 15u;
+        return (slot[(((xx >> 1) + 1) & 1) * 8 + bb * 2 + (s >> 2)] >> (4 * ((s & 3) * 2 + (xx & 1)))) & 15u;
+    }
+    __device__ __forceinline__ const U4 *line(int k) const { return reinterpret_cast<const U4 *>(tw + (k >> 4) * (64 * C + 16) + (k & 15) * 16); }
+    __device__ __forceinline__ void to_slot(const U4 *v)
+    {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { slot[4 * u] = v[u].x; slot[4 * u + 1] = v[u].y; slot[4 * u + 2] = v[u].z; slot[4 * u + 3] = v[u].w; }
+    }
+    __device__ __forceinline__ void prefetch(int k)
+    {
+        pkey = k >= 0 ? k : -1;
+        if (k >= 0) {
+            const U4 *src = line(k);
+#pragma unroll
+            for (int u = 0; u < 4; u++) pre[u] = src[u];
+        }
+    }
+    // demand load of the line of (i, j) (the wave waits for it), and the request for the one the path most likely enters next
     __device__ __forceinline__ void load(int i, int j)
     {
-        cblk = (i + j - 1) >> 3;
-        const U4 *src = reinterpret_cast<const U4 *>(tw + cblk * 16 * C);
-        U4 v[4 * C];
+        ckey = key(i, j);
+        const U4 *src = line(ckey);
+        U4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4 * C; u++) v[u] = src[u];
-#pragma unroll
-        for (int u = 0; u < 4 * C; u++) { slot[4 * u] = v[u].x; slot[4 * u + 1] = v[u].y; slot[4 * u + 2] = v[u].z; slot[4 * u + 3] = v[u].w; }
+        for (int u = 0; u < 4; u++) v[u] = src[u];
+        prefetch(ckey - 16);
+        to_slot(v);
+    }
+    // the line of (i, j) into the slot at an epoch's start: from the prefetch registers when the guess was right (no memory wait), else from memory.
+    // (Taking a prefetched line inside the walk, lane by lane as each one leaves its line, was tried: the wave then runs the 40-instruction hand-over
+    // ~800 times instead of 13 epochs -- 0.96 -> 1.99 ms.)
+    __device__ __forceinline__ void fetch(int i, int j)
+    {
+        const int k = key(i, j);
+        if (k == pkey) {
+            to_slot(pre);
+            ckey = k;
+            prefetch(k - 16);
+        } else load(i, j);
     }
     // cell (i, j), i, j > 0, of the cached line as a T_* code; notes a cell on (or within `edge` of) an edge diagonal of the band
     __device__ __forceinline__ uint32_t code(int i, int j)
     {
-        const int k = j - i - lo, s = (i + j - 1) & 7, xx = k >> 1;
+        const int k = j - i - lo, a = i + j - 1, s = a & 7, bb = (a >> 3) & 3, xx = k >> 1;
         touched |= k <= edge || k >= B - 1 - edge;
         uint32_t tc;
-        if (C == 1) tc = (slot[xx] >> (4 * s)) & 15u;
-        else tc = (slot[(xx >> 1) * 2 + (s >> 2)] >> (4 * ((s & 3) * 2 + (xx & 1)))) & 15u;
+        if (C == 1) tc = (slot[((xx + 2) & 3) * 4 + bb] >> (4 * s)) & 15u;
+        else tc = (slot[(((xx >> 1) + 1) & 1) * 8 + bb * 2 + (s >> 2)] >> (4 * ((s & 3) * 2 + (xx & 1)))) & 15u;
         return ((tc & 2u) ? (uint32_t)T_INS : (tc & 1u) ? (uint32_t)T_DEL : (uint32_t)T_DIAG) | ((tc & 4u) ? 0u : (uint32_t)T_EEXT) | ((tc & 8u) ? 0u : (uint32_t)T_FEXT);
     }
 };
-constexpr int TBB_PITCH = 33;
+constexpr int TBB_PITCH = 17;
 
 // traceback of a banded alignment: k_trace16p's walk and entries.  The end point (best cell of the last row, ties to the larger column, or a strictly
 // better cell of the last column, ties to the larger row) comes from the band's 2 x B last-row / last-column values.
@@ -1480,7 +1539,8 @@ __device__ __forceinline__ void trace_band_body(const BandArgs &p, uint32_t *__r
     const FillArgs &f = p.f;
     const int al = p.list[idx];
     const int n1 = f.n1[al], n2 = f.site_n2[fill_site(f, al)], lo = p.band_lo[al];
-    TbBand<C> tb = {tbl + lane * TBB_PITCH, p.Twb + (int64_t)al * p.NBLK * 32, lo, -1, p.edge, false};
+    TbBand<C> tb;
+    tb.slot = tbl + lane * TBB_PITCH; tb.tw = p.Twb + (int64_t)al * p.NBLK * TWB_PITCH; tb.lo = lo; tb.ckey = -1; tb.edge = p.edge; tb.touched = false; tb.pkey = -1;
     uint32_t *ent = ent_all + (int64_t)al * EW;
     int i = n1, j = n2;
     if (n1 > 0 && n2 > 0) {
@@ -1516,38 +1576,34 @@ __device__ __forceinline__ void trace_band_body(const BandArgs &p, uint32_t *__r
     };
     while (x > j) put(0u);
     int state = -1;
+    int a = i + j - 1, kd = j - i - lo;                                // running coordinates of the cell (anti-diagonal, diagonal of the band)
+    // one step of the walk without branches but the one around put(): the round-4 form (a chain of if / else per state and border) ran ~200
+    // instructions per step once the lanes of a wave sat in different states -- this kernel's time
     auto step = [&]() {
-        uint32_t t;
-        if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
-        else if (j == 0) t = T_INS | (i > 1 ? T_FEXT : 0);
-        else t = tb.code(i, j);
-        if (state < 0) {
-            const int w = t & 3;
-            if (w == T_DIAG) {
-                put(cur);
-                cur = (uint32_t)i;
-                i--; j--;
-                return;
-            }
-            state = w == T_DEL ? 1 : 2;
-        }
-        if (state == 1) {
-            const bool ext = (t & T_EEXT) != 0;
-            put(cur);
-            cur = 0;
-            j--;
-            if (!ext) state = -1;
-        } else {
-            const bool ext = (t & T_FEXT) != 0;
-            cur = (cur & 0x3ffu) | ((((cur >> 10) & 0x3ffu) + 1u) << 10) | ((uint32_t)(i - 1) << 20);
-            i--;
-            if (!ext) state = -1;
-        }
+        const bool bi = i == 0, bj = j == 0;
+        const uint32_t tc = tb.raw(a, kd);
+        int w = (tc & 2u) ? 2 : (int)(tc & 1u);                        // 0 diagonal, 1 deletion (E), 2 insertion (F)
+        bool eext = !(tc & 4u), fext = !(tc & 8u);
+        w = bi ? 1 : bj ? 2 : w;                                       // row 0 / column 0: a gap to the origin
+        eext = bi ? j > 1 : eext;
+        fext = bj && !bi ? i > 1 : fext;
+        tb.touched |= !bi && !bj && (kd <= tb.edge || kd >= B - 1 - tb.edge);
+        const int wm = state < 0 ? w : state;
+        const bool mv_d = wm == 0, mv_e = wm == 1;
+        if (mv_d || mv_e) put(cur);
+        const uint32_t cur_ins = (cur & 0x3ffu) | ((((cur >> 10) & 0x3ffu) + 1u) << 10) | ((uint32_t)(i - 1) << 20);
+        cur = mv_d ? (uint32_t)i : mv_e ? 0u : cur_ins;
+        const bool ext = mv_e ? eext : fext;
+        state = (mv_d || !ext) ? -1 : wm;
+        i -= mv_e ? 0 : 1;
+        j -= (mv_d || mv_e) ? 1 : 0;
+        a -= mv_d ? 2 : 1;
+        kd += mv_d ? 0 : mv_e ? -1 : 1;
     };
     while (__any(i > 0 || j > 0)) {                                    // epochs: the lanes that left their line load the next one together
-        if (i > 0 && j > 0 && !tb.has(i, j)) tb.load(i, j);
+        if (i > 0 && j > 0 && tb.key_akd(a, kd) != tb.ckey) tb.fetch(i, j);
         for (;;) {
-            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.has(i, j));
+            const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || tb.key_akd(a, kd) == tb.ckey);
             if (!__any(can)) break;
             if (can) step();
         }
@@ -2023,7 +2079,9 @@ __device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CP
     if (idx >= (C ? *bp.count : p.count ? min(*p.count, p.A) : p.A)) return;
     const int al = C ? bp.list[idx] : p.list ? p.list[idx] : idx;
     TbLine tb = {tbl + threadIdx.x * TBL_PITCH, -1, -1, 0, 0};
-    TbBand<(C ? C : 1)> tbb = {tbl + threadIdx.x * TBB_PITCH, C ? bp.Twb + (int64_t)al * bp.NBLK * 32 : nullptr, C ? (int)bp.band_lo[al] : 0, -1, bp.edge, false};
+    TbBand<(C ? C : 1)> tbb;
+    tbb.slot = tbl + threadIdx.x * TBB_PITCH; tbb.tw = C ? bp.Twb + (int64_t)al * bp.NBLK * TWB_PITCH : nullptr; tbb.lo = C ? (int)bp.band_lo[al] : 0;
+    tbb.ckey = -1; tbb.edge = bp.edge; tbb.touched = false; tbb.pkey = -1;
     const int site = fill_site(p, al);
     const uint8_t *s1 = p.s1 + (int64_t)al * p.s1_stride;
     const int n1 = p.n1[al];
@@ -2072,7 +2130,7 @@ __device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CP
     };
     tb.set_j(j, CPL);
     while (__any(i > 0 || j > 0)) {                                    // epochs: see TbLine
-        if (C) { if (i > 0 && j > 0 && !tbb.has(i, j)) tbb.load(i, j); }
+        if (C) { if (i > 0 && j > 0 && !tbb.has(i, j)) tbb.fetch(i, j); }
         else if (i > 0 && j > 0 && !tb.has(i)) tb.load(p.Tw, arow, i, CPL);
         for (;;) {
             const bool can = (i > 0 || j > 0) && (i == 0 || j == 0 || (C ? tbb.has(i, j) : tb.has(i)));
@@ -2596,13 +2654,13 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         NC_TRY(nc_ensure(ctx, B.cband, (size_t)ng * S * 4));
         NC_TRY(nc_ensure(ctx, B.arow, ((size_t)ng * S + 1) * 8));
         NC_TRY(nc_ensure(ctx, B.alt_off, (size_t)ng * S * 8));
-        const int nblk = (N1 + W + 7) / 8;                             // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= N1 + W (41 for the 160-base windows, 66 for the 260-base ones)
+        const int nblk = (((N1 + W + 7) / 8) + 3) & ~3;                             // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= N1 + W (41 for the 160-base windows, 66 for the 260-base ones)
         const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && nblk <= 80;
         if (band) {
             NC_TRY(nc_ensure(ctx, B.band_lo, 2 * Agz + 128));            // + the windows' classes (k_windows16 -> k_window_lists)
             NC_TRY(nc_ensure(ctx, B.lists, Agz * 3 * 4 + 64));
             NC_TRY(nc_ensure(ctx, B.counts, 64));
-            NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)nblk * 128 + 256));
+            NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)nblk * (4 * TWB_PITCH) + 256));
             NC_TRY(nc_ensure(ctx, B.hrow, Agz * 128 + 64));
             NC_TRY(nc_ensure(ctx, B.hcolb, Agz * 128 + 64));
         }
@@ -2732,12 +2790,12 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
             NC_TRY(nc_ensure(ctx, s->ab_lo, nz + 64));
             NC_TRY(nc_ensure(ctx, s->ab_lists, nz * 3 * 4 + 64));
             NC_TRY(nc_ensure(ctx, s->ab_counts, 64));
-            NC_TRY(nc_ensure(ctx, s->ab_twb, nz * (size_t)BAND_NBLK * 128 + 256));
+            NC_TRY(nc_ensure(ctx, s->ab_twb, nz * (size_t)BAND_NBLK4 * (4 * TWB_PITCH) + 256));
             NC_HIP(ctx, hipMemsetAsync(s->ab_counts.p, 0, 64, sB));
             int32_t *l1 = (int32_t *)s->ab_lists.p, *l2 = l1 + nz, *lF = l2 + nz, *cn = (int32_t *)s->ab_counts.p;
             hipLaunchKernelGGL(k_allele_classes, dim3((nset + 255) / 256), dim3(256), 0, sB, fb, (const int16_t *)B.cband.p, s->band_margin_v > 0 ? s->band_margin_v : band_margin(),
                                8 * BAND_NBLK, (int8_t *)s->ab_lo.p, l1, l2, lF, cn);
-            bb.band_lo = (const int8_t *)s->ab_lo.p; bb.Twb = (uint32_t *)s->ab_twb.p; bb.hrow = nullptr; bb.hcolb = nullptr; bb.NBLK = BAND_NBLK;
+            bb.band_lo = (const int8_t *)s->ab_lo.p; bb.Twb = (uint32_t *)s->ab_twb.p; bb.hrow = nullptr; bb.hcolb = nullptr; bb.NBLK = BAND_NBLK4;
             bb.redo_list = lF; bb.redo_count = cn + 2; bb.edge = 0;
             bb.list = l1; bb.count = cn;
             BandArgs bb2 = bb;
