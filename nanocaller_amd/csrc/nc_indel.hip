@@ -96,20 +96,25 @@ __device__ __forceinline__ int32_t *ck_diff(char *ws, const IndelChunk &c) { ret
 // impute_indel_phase only: per column, over ALL kept reads: [0] reads deleted here ('*'), [1] insertions / [2] deletions that follow this column
 __device__ __forceinline__ int32_t *ck_cnt(char *ws, const IndelChunk &c) { return ck_diff(ws, c) + (int64_t)8 * c.nd; }
 
+// chunk of every tile-block (k_hap_depth_b's block index; k_event_tiles' / SPT): a workgroup finds its chunk by one load instead of a bisection of
+// ten dependent scalar loads over the descriptors
+__global__ void k_blk_chunks(const IndelChunk *__restrict__ ck, int32_t n_chunks, int32_t nblk, int32_t *__restrict__ blk_chunk)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int b0 = ck[c].blk0, b1 = c + 1 < n_chunks ? ck[c + 1].blk0 : nblk;
+    for (int b = b0; b < b1; b++) blk_chunk[b] = c;
+}
+
 // per-column depth by haplotype tag; same access scheme as k_scan (one aligned dwordx4 of codes per read and lane).
 // STAR: count the reads whose code is 4 (deleted at this column) of all haplotypes instead, into cnt[0]
 template <int BLOCK, bool STAR>
 __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
                                                        const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
-                                                       const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t haploid)
+                                                       const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t haploid)
 {
     constexpr int TILE = BLOCK * 16;
-    int a = 0, b = n_chunks - 1;                                   // last chunk with blk0 <= blockIdx.x
-    while (a < b) {
-        const int m = (a + b + 1) >> 1;
-        if (ck[m].blk0 <= (int)blockIdx.x) a = m; else b = m - 1;
-    }
-    const IndelChunk c = ck[a];
+    const IndelChunk c = ck[blk_chunk[blockIdx.x]];
     const int t = c.tile0 + ((int)blockIdx.x - c.blk0);
     const int32_t lo = c.lo, hi = c.hi, ncol = c.ncol;
     int32_t *depth = STAR ? ck_cnt(ws, c) : ck_depth(ws, c);
@@ -446,8 +451,10 @@ __global__ __launch_bounds__(64) void k_entry_cursors(const int32_t *__restrict_
                 const int mid = (x + y) >> 1;
                 if (ev_pos[mid] < want) x = mid + 1; else y = mid;
             }
-            ent_cur[(int64_t)e * (SPT + 1) + h] = x;
+            ent_cur[(int64_t)e * (SPT + 3) + h] = x;
         }
+        ent_cur[(int64_t)e * (SPT + 3) + SPT + 1] = ev_off[lo];       // the read's event range rides along: k_event_tiles needs neither the read's index
+        ent_cur[(int64_t)e * (SPT + 3) + SPT + 2] = eb;               // nor ev_off (two levels of dependent loads less per workgroup)
     }
 }
 
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                                                      int32_t tile_size, const int32_t *__restrict__ ent_read, const int32_t *__restrict__ ent_cur,
                                                      const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
                                                      const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
-                                                     const IndelChunk *__restrict__ ck, int32_t n_chunks, char *__restrict__ ws, int32_t win,
+                                                     const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t win,
                                                      int32_t small_win, int32_t haploid, int32_t mincov, double ins_t, double del_t,
                                                      int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits)
 {
@@ -469,15 +476,11 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     __shared__ uint8_t en_h[256];
     __shared__ int32_t evk[EV_CAP];                                  // the batch's events: rank of the column (-1 excluded), classes they qualify for
     __shared__ uint8_t evq[EV_CAP];
+    __shared__ uint8_t own[EV_CAP];                                  // entry (of the batch's 256) every event of the batch belongs to
     __shared__ int32_t sh_k0, sh_k1, sh_mlo, wsum[EV_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int SPT = tile_size / EV_SUB;
-    int a = 0, b = n_chunks - 1;                                   // last chunk whose first block is <= blockIdx.x
-    while (a < b) {
-        const int m = (a + b + 1) >> 1;
-        if (ck[m].blk0 * SPT <= (int)blockIdx.x) a = m; else b = m - 1;
-    }
-    const IndelChunk c = ck[a];
+    const IndelChunk c = ck[blk_chunk[(int)blockIdx.x / SPT]];
     const int rel = (int)blockIdx.x - c.blk0 * SPT, t = c.tile0 + rel / SPT;
     const int32_t s_lo = tile_pos0 + t * tile_size + (rel % SPT) * EV_SUB;
     const int32_t b_lo = max(s_lo, c.lo), b_hi = min(s_lo + EV_SUB - 1, c.hi);
@@ -531,6 +534,9 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     }
     __syncthreads();
     const int32_t m_lo = sh_mlo;
+#ifdef NC_ABL_EVT_A2
+    return;
+#endif
     auto qualifies = [](int32_t sl, int cls) {
         const int32_t ln = sl < 0 ? -sl : sl;
         const bool ins = sl > 0;
@@ -546,37 +552,49 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             int cnt = 0;
             const int e = eb0 + tid;
             if (tid < 256 && e < e1) {
+                // two levels of loads: the entry and its row of the cursor table (cursors of this block and the next, the read's event range); then the
+                // events either side of both cursors, all at once.  The haplotype tag sits in the entry.  (Round 4 walked: entry -> read -> tag, event
+                // range -> cursors -> one event per step: eight dependent loads per workgroup, a third of the kernel.)
                 const nc_tile_entry ent = tile_ent[e];
+                const int32_t *cur = ent_cur + (int64_t)e * (SPT + 3);
+                const int hq = tt == t ? rel % SPT : SPT;
+                int x0 = cur[hq], x1 = tt == t ? cur[hq + 1] : cur[SPT + 2];
+                const int ea = cur[SPT + 1], eb = cur[SPT + 2];
                 // a read is taken at the LAST of these tiles that lists it: tile t's entry knows where the block's events begin and end
                 // (k_entry_cursors), an entry of an earlier tile is of a read that ends before tile t
                 const bool mine = tt == t || ent.end <= tt_lo + tile_size;
-                if (mine && ent.start <= b_hi && ent.end > m_lo) {
-                    const int r = ent_read[e];
-                    const int hp = read_hap[r];
-                    if (haploid || hp == 1 || hp == 2) {
-                        const int ea = ev_off[r], eb = ev_off[r + 1];
-                        const int32_t *cur = ent_cur + (int64_t)e * (SPT + 1);
-                        int x0, x1;                                               // first event at or after m_lo / after b_hi
-                        if (tt == t) { x0 = cur[rel % SPT]; x1 = cur[rel % SPT + 1]; }
-                        else if (tt == t - 1) { x0 = cur[SPT]; x1 = eb; }
-                        else {                                                    // (a margin longer than a tile: excluded stretch)
-                            x0 = ea; x1 = eb;
-                            int y0 = eb;
-                            while (x0 < y0) {
-                                const int m0 = (x0 + y0) >> 1;
-                                if (ev_pos[m0] < m_lo) x0 = m0 + 1; else y0 = m0;
-                            }
+                const int hp = (int)((ent.base_flag >> 1) & 3);
+                if (mine && ent.start <= b_hi && ent.end > m_lo && (haploid || hp == 1 || hp == 2)) {
+                    if (tt < t - 1) {                                         // (a margin longer than a tile: excluded stretch)
+                        x0 = ea;
+                        int y0 = eb;
+                        while (x0 < y0) {
+                            const int m0 = (x0 + y0) >> 1;
+                            if (ev_pos[m0] < m_lo) x0 = m0 + 1; else y0 = m0;
                         }
-                        while (x0 > ea && ev_pos[x0 - 1] >= m_lo) x0--;           // the cursors stand EV_BACK columns before their block: a few steps
+                    }
+                    // the cursors stand EV_BACK columns before their block
+                    const int32_t p0m = x0 > ea ? ev_pos[x0 - 1] : INT32_MIN, p1m = x1 > ea ? ev_pos[x1 - 1] : INT32_MIN;
+                    int32_t q0[4], q1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { q0[u] = x0 + u < eb ? ev_pos[x0 + u] : INT32_MAX; q1[u] = x1 + u < eb ? ev_pos[x1 + u] : INT32_MAX; }
+                    int adv0 = 0, adv1 = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { adv0 += q0[u] < m_lo ? 1 : 0; adv1 += q1[u] <= b_hi ? 1 : 0; }       // (ascending: prefixes)
+                    const int nx0 = x0 + adv0;
+                    const bool slow = p0m >= m_lo || adv0 == 4 || adv1 == 4 || x1 < nx0 || (x1 > nx0 && p1m > b_hi);
+                    if (!slow) { x0 = nx0; x1 += adv1; }
+                    else {                                                   // the general walk
+                        while (x0 > ea && ev_pos[x0 - 1] >= m_lo) x0--;
                         while (x0 < eb && ev_pos[x0] < m_lo) x0++;
                         x1 = max(x1, x0);
                         while (x1 > x0 && ev_pos[x1 - 1] > b_hi) x1--;
                         while (x1 < eb && ev_pos[x1] <= b_hi) x1++;
-                        cnt = x1 - x0;
-                        en_e0[tid] = x0;
-                        en_lim[tid] = x1;
-                        en_h[tid] = (uint8_t)(haploid ? 0 : hp - 1);
                     }
+                    cnt = x1 - x0;
+                    en_e0[tid] = x0;
+                    en_lim[tid] = x1;
+                    en_h[tid] = (uint8_t)(haploid ? 0 : hp - 1);
                 }
             }
             // ---- exclusive prefix of the counts over the 256 entries
@@ -593,6 +611,8 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             if (tid < 256) en_pre[tid] = wp + inc - cnt;
             const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
             if (tid == 0) en_pre[256] = total;
+            // (an event finds its entry by one LDS read: two bisections of eight dependent reads each per event were a third of this kernel)
+            if (tid < 256 && total <= EV_CAP) for (int u = 0; u < cnt; u++) own[wp + inc - cnt + u] = (uint8_t)tid;
             __syncthreads();
             // ---- one event per thread
 #ifdef NC_ABL_EVT_B
@@ -601,45 +621,51 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             if (total <= EV_CAP) {
                 // the batch's events into LDS (independent loads), then every look-up at a neighbour is an LDS read
                 for (int idx = tid; idx < total; idx += EV_NT) {
-                    int lo = 0, hi = 255;
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (en_pre[mid] <= idx) lo = mid; else hi = mid - 1;
-                    }
+                    const int lo = own[idx];
                     const int ev = en_e0[lo] + (idx - en_pre[lo]);
                     const int32_t sl = ev_len[ev];
                     evk[idx] = rk(ev_pos[ev]);
                     evq[idx] = (uint8_t)((qualifies(sl, 0) ? 1 : 0) | (qualifies(sl, 1) ? 2 : 0) | (qualifies(sl, 2) ? 4 : 0) | (qualifies(sl, 3) ? 8 : 0));
                 }
                 __syncthreads();
+#ifdef NC_ABL_EVT_C
+                if (total >= 0) { __syncthreads(); continue; }
+#endif
                 for (int idx = tid; idx < total; idx += EV_NT) {
                     const int k = evk[idx], qm = evq[idx];
                     if (k < 0 || qm == 0) continue;
-                    int lo = 0, hi = 255;
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (en_pre[mid] <= idx) lo = mid; else hi = mid - 1;
-                    }
+                    const int lo = own[idx];
                     const int i0 = en_pre[lo], i1 = en_pre[lo + 1], h = en_h[lo];
+                    // one walk back and one forward for all the classes the event qualifies for (a class leaves the search when the distance passes
+                    // its window: the ranks only grow apart) instead of two loops per class: the per-class form was 0.9 of this kernel's 2.2 ms
+                    uint32_t prevf = 0, nextf = 0, need = (uint32_t)qm;
+                    for (int i2 = idx - 1; i2 >= i0 && need; i2--) {
+                        const int k2 = evk[i2];
+                        if (k2 < 0) continue;
+                        const int d = k - k2;
+                        if (d > win - 1) need &= ~3u;
+                        if (d > small_win - 1) need &= ~12u;
+                        const uint32_t f = (uint32_t)evq[i2] & need;
+                        prevf |= f;
+                        need &= ~f;
+                    }
+                    need = (uint32_t)qm;
+                    for (int i2 = idx + 1; i2 < i1 && need; i2++) {
+                        const int k2 = evk[i2];
+                        if (k2 < 0) continue;
+                        const int d = k2 - k;
+                        if (d > win - 1) need &= ~3u;
+                        if (d > small_win - 1) need &= ~12u;
+                        const uint32_t f = (uint32_t)evq[i2] & need;
+                        nextf |= f;
+                        need &= ~f;
+                    }
 #pragma unroll
                     for (int cls = 0; cls < 4; cls++) {
                         if (!((qm >> cls) & 1)) continue;
                         const int w = cls < 2 ? win : small_win;
-                        bool has_prev = false, has_next = false;
-                        for (int i2 = idx - 1; i2 >= i0; i2--) {
-                            const int k2 = evk[i2];
-                            if (k2 < 0) continue;
-                            if (k - k2 > w - 1) break;
-                            if ((evq[i2] >> cls) & 1) { has_prev = true; break; }
-                        }
-                        for (int i2 = idx + 1; i2 < i1; i2++) {
-                            const int k2 = evk[i2];
-                            if (k2 < 0) continue;
-                            if (k2 - k > w - 1) break;
-                            if ((evq[i2] >> cls) & 1) { has_next = true; break; }
-                        }
-                        if (!has_prev) dif_add(cls * 2 + h, max(k, k0) - k0);
-                        if (!has_next && max(k + w, k0) - k0 < nk) dif_sub(cls * 2 + h, max(k + w, k0) - k0);
+                        if (!((prevf >> cls) & 1)) dif_add(cls * 2 + h, max(k, k0) - k0);
+                        if (!((nextf >> cls) & 1) && max(k + w, k0) - k0 < nk) dif_sub(cls * 2 + h, max(k + w, k0) - k0);
                     }
                 }
             } else
@@ -819,7 +845,8 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     }
     *consumed = c1;
     const int32_t ng = (int32_t)ck.size();
-    const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, total = o_ck + (size_t)ng * sizeof(IndelChunk);
+    const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, o_blk = o_ck + (((size_t)ng * sizeof(IndelChunk) + 15) & ~(size_t)15),
+                 total = o_blk + (size_t)nblk * 4;
     NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
     char *ws = (char *)ctx->indel_ws.p;
     const bool no_tiles = getenv("NC_K7_EVENT_ATOMICS") != nullptr;                         // k_event_intervals_w + k_prefix_rows_b + k_indel_decide_b, for A/B checks (read per call: tests flip it)
@@ -829,9 +856,11 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     IndelChunk *ck_dev = (IndelChunk *)(ws + o_ck);
     NC_TRY(nc_h2d_pieces(ctx, ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), ctx->stream));   // by copy kernel: never behind an upload in flight
     int8_t *ctype = (int8_t *)(ws + o_type);
+    int32_t *blk_chunk = (int32_t *)(ws + o_blk);
+    if (nblk > 0) hipLaunchKernelGGL(k_blk_chunks, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, ck_dev, ng, nblk, blk_chunk);
 #define NC_HAP_DEPTH(B, STAR)                                                                                                        \
     hipLaunchKernelGGL((k_hap_depth_b<B, STAR>), dim3(nblk), dim3(B), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, \
-                       pack->tile_pos0, ck_dev, ng, ws, prm->haploid)
+                       pack->tile_pos0, ck_dev, blk_chunk, ws, prm->haploid)
     if (nblk > 0) {
         if (tile == 1024) NC_HAP_DEPTH(64, false);
         else if (tile == 2048) NC_HAP_DEPTH(128, false);
@@ -846,14 +875,14 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
     if (tiles) {
         const int SPT = tile / EV_SUB;
-        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(SPT + 2)));
+        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(SPT + 4)));
         int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p, *ent_cur = ent_read + pack->n_entries;
         hipLaunchKernelGGL(k_entry_cursors, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);
         ctx->indel_ent_of = pack->tile_ent;                              // (the device pipeline's k_sets / k_windows use the tables too)
         ctx->indel_ent_spt = SPT;
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
-                           ent_read, ent_cur, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, ng, ws, prm->win_size,
+                           ent_read, ent_cur, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, blk_chunk, ws, prm->win_size,
                            prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev);
     } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
