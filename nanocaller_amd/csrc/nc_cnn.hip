@@ -2224,7 +2224,8 @@ int nc_indel_forward(nc_ctx *ctx, int32_t kind, int64_t n, const float *x_dev, f
     NcTimer tm(ctx, 2);
     // batch = what the conv3 activations (fc1's input, 77 KB / 18 KB per site) may take in HBM: ~5 GB.  NC_INDEL_TRUNK_SPLIT's kernels keep conv2's too
     static const bool split_env = getenv("NC_INDEL_TRUNK_SPLIT") != nullptr;
-    const int64_t BATCH = split_env ? (kind == NC_MODEL_INDEL ? 16384 : 32768) : (kind == NC_MODEL_INDEL ? 65536 : 262144);
+    int64_t BATCH = split_env ? (kind == NC_MODEL_INDEL ? 16384 : 32768) : (kind == NC_MODEL_INDEL ? 65536 : 262144);
+    if (const char *be = getenv("NC_INDEL_BATCH")) BATCH = std::max<int64_t>(256, atoll(be));      // (experiments: conv3's activations inside the memory-side cache)
     for (int64_t s0 = 0; s0 < n; s0 += BATCH) {
         const int64_t nb = n - s0 < BATCH ? n - s0 : BATCH;
         const float *tail = nullptr, *f1 = nullptr;

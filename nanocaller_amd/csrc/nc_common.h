@@ -32,6 +32,8 @@ struct nc_ctx {
     bool x_i16 = false;            // SNP tensors between featuriser and CNN as int16 instead of fp32 (nc_set_tensor_format)
     bool cnn_exact_fp32 = false;   // false: fp16x3 split-precision trunk (default); true: exact fp32 MFMA trunk
     bool k10_lds_set[2] = {false, false};   // k10_indel_trunk_h3<15 / 5>: dynamic LDS limit raised on this device
+    bool huff_lds_set = false;              // k_huff: the same
+    size_t k7_budget = 0;                   // bytes of K7 workspace per group of chunks (set from this context's device at its first plan)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches
     hipEvent_t kev[128] = {nullptr};          // per-launch event pairs of the trunk kernel (timing mode)

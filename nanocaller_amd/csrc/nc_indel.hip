@@ -814,11 +814,17 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     const int impute = prm->impute && !prm->haploid;
     // workspace per group of chunks: a twelfth of the device memory that is free at the first call, between 6 and 24 GiB (a chr1-sized contig's
     // columns need 12 GB: one group, one launch of every K7 kernel -- and ONE pass of k_entry_cursors over the tile index -- instead of two)
-    static const size_t BUDGET = []() {
+    // (per context, after hipSetDevice: a process that drives several GPUs sizes each one's workspace from that GPU; what this context's workspace
+    // already holds counts as free, and a budget the device can no longer serve -- other buffers grew since -- shrinks to what is free now)
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) mfree = (size_t)72 << 30;
-        return std::min<size_t>((size_t)24 << 30, std::max<size_t>((size_t)6 << 30, mfree / 12));
-    }();
+        const size_t avail = mfree + ctx->indel_ws.cap;
+        if (ctx->k7_budget == 0) ctx->k7_budget = std::min<size_t>((size_t)24 << 30, std::max<size_t>((size_t)6 << 30, avail / 12));
+        if (ctx->k7_budget > avail / 2) ctx->k7_budget = std::max<size_t>((size_t)256 << 20, avail / 2);
+    }
+    const size_t BUDGET = ctx->k7_budget;
     ck.clear();
     size_t wsb = 0;
     int64_t ncols = 0;

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
     bool fin = !live;
 #pragma unroll 1
     while (!fin) {                                                     // one turn per deflate block: the lanes of a wave set their tables up together
+        tick();                                                        // (a block may consume its header only -- an empty stored block, 5 bytes -- and dozens of them may follow each other: the window is topped up per block, not only inside the symbol loops)
         refill();
         const bool last = take(1) != 0;
         const int type = (int)take(2);
@@ -501,10 +502,9 @@ static int inflate_phase(nc_ctx *ctx, int phase, int32_t n_blocks, const uint8_t
     if (n_blocks == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds_h = (size_t)LPW * (TAB_WORDS + WIN_PITCH) * 4;
-    static bool set[64] = {false};
-    if (ctx->device >= 0 && ctx->device < 64 && !set[ctx->device]) {
+    if (!ctx->huff_lds_set) {                                            // per context (= per device, one thread): no process-wide table
         NC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
-        set[ctx->device] = true;
+        ctx->huff_lds_set = true;
     }
     if (phase & 1) {
         InflateArgs a;

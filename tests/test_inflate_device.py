@@ -79,6 +79,29 @@ def test_device_inflate_equals_zlib():
     assert kinds == {0, 1, 2}
 
 
+def test_runs_of_empty_stored_blocks_do_not_starve_the_stream_window():
+    """legal deflate: dozens of empty stored blocks in a row (repeated sync flushes; 5 bytes each, no symbol loop runs) between real blocks --
+    the per-lane window of the compressed stream is topped up per block header, not only inside the symbol loops"""
+    rng = np.random.default_rng(11)
+    a = bytes((rng.normal(20, 6, size=9_000).clip(0, 60)).astype(np.uint8))
+    b = (b"chr20\t1234567\t.\tA\tG\t33.10\n" * 400)[:9_000]
+    cases = []
+    for n_empty in (1, 30, 64, 200):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        empty = b"\x00\x00\x00\xff\xff"                                                         # BFINAL = 0, BTYPE = 00, padding; LEN = 0, NLEN = 0xffff
+        z = c.compress(a) + c.flush(zlib.Z_SYNC_FLUSH)                                            # (byte-aligned behind a sync flush: zlib itself writes one empty stored block there)
+        z += empty * n_empty
+        z += c.compress(b) + c.flush(zlib.Z_FULL_FLUSH)
+        z += empty * n_empty
+        z += c.compress(a[:100]) + c.flush()
+        assert zlib.decompress(z, -15) == a + b + a[:100]
+        cases.append((a + b + a[:100], z))
+    out, ooff, st = _run([p for _, p in cases], [len(d) for d, _ in cases])
+    assert not st.any(), st
+    for k, (d, _) in enumerate(cases):
+        assert out[ooff[k]:ooff[k] + len(d)].tobytes() == d, k
+
+
 def test_device_inflate_on_the_members_of_the_spec_fixture():
     raw = open(os.path.join(G, "spec.bam"), "rb").read()
     pay, want, o = [], [], 0
