@@ -23,13 +23,14 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 9   /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+#define NC_ABI_VERSION 10  /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
-                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members / _scan + nc_bam_walk / _meta / _codes / _indel_reads (BAM ingest on the device) */
+                              9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members / _scan + nc_bam_walk / _meta / _codes / _indel_reads (BAM ingest on the device);
+                              10: nc_bgzf_crc_device (CRC-32 of the device-inflated members) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -184,8 +185,7 @@ int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_sta
  * lane per member, into tokens; match resolution, one wave per member.  All pointers dev: d_comp = the compressed bytes (readable 8 bytes
  * past the last payload), d_coff / d_clen = byte offset and length of member b's payload in it, d_out + d_ooff[b] = where its d_isize[b]
  * (<= 65536) bytes go, d_status[b] = 0 or why the member is not a valid stream of that length; workspace: d_tok = ceil(n_blocks / 64)
- * x 4,194,304 dwords (64 members x 65,536 tokens), d_ntok = n_blocks counters.  Runs on the context's stream.  CRC-32s are not computed
- * here.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
+ * x 4,194,304 dwords (64 members x 65,536 tokens), d_ntok = n_blocks counters.  Runs on the context's stream.  CRC-32s: nc_bgzf_crc_device.  Replaces the host inflate behind generate_SNP_pileups.py:134-164's input. */
 int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, uint8_t *d_out,
                       const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok);
 /* The two launches apart: phase 1 = tokens only, 2 = resolution only (of the tokens an earlier phase-1 call left in d_tok / d_ntok), 3 = both.
@@ -193,6 +193,11 @@ int nc_inflate_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, cons
  * leaves CUs free the previous batch's resolution runs on them). */
 int nc_inflate_device_phase(nc_ctx *ctx, int32_t phase, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen,
                             uint8_t *d_out, const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status, uint32_t *d_tok, int32_t *d_ntok);
+/* CRC-32 (RFC 1952) of every inflated member against the value in its BGZF trailer (the four bytes behind the payload), on the context's stream
+ * behind the inflate: d_status[b] = 7 where they differ and the inflate left 0.  htslib verifies the CRC of every block it inflates (the reader
+ * behind generate_SNP_pileups.py:134); on the device route the bytes never reach the host, so the check runs where they are. */
+int nc_bgzf_crc_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, const uint8_t *d_out,
+                       const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status);
 
 /* BAM records on the device (csrc/nc_ingest.hip): from the inflated BGZF stream in HBM to the slots of the read pack, for the SNP route --
  * what nc_bam_decode + nc_pack_fill do on host threads (generate_SNP_pileups.py:134-164's input).

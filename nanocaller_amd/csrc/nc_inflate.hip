@@ -12,7 +12,7 @@
 //            order with all 64 lanes copying (source and destination in a 16 KB LDS ring of the member's recent output, so overlapping and
 //            chained matches are plain LDS traffic; older sources are read back from HBM); finished stretches leave LDS as aligned dwords.
 // Stored, fixed and dynamic blocks.  Checked: the stream ends exactly at ISIZE bytes, distances stay inside the output, the input is not
-// overrun.  The CRC-32 of a member is the host's to check (nc_bam.cpp, when the bytes come back) -- the device path checks the lengths.
+// overrun; the CRC-32 of every member against its trailer by k_crc32 (nc_bgzf_crc_device) behind the resolution.
 #include "nc_common.h"
 
 namespace {
@@ -35,7 +35,7 @@ struct InflateArgs {
     const int32_t *isize;       // the length its trailer announces
     int32_t n;
     int32_t *status;            // 0 ok; 1 bad block type / stored length; 2 bad code lengths; 3 bad symbol / distance; 4 output overrun; 5 input
-                                // overrun; 6 length differs from ISIZE
+                                // overrun; 6 length differs from ISIZE; 7 (nc_bgzf_crc_device) CRC-32 differs from the trailer's
 };
 
 struct __attribute__((packed, aligned(4))) U4w { uint32_t x, y, z, w; };   // four dwords at a 4-byte aligned address
@@ -487,6 +487,82 @@ __global__ __launch_bounds__(64) void k_lz(int32_t n, const uint32_t *tok, const
     if (total < head && lane < total) o[lane] = ring[lane];
 }
 
+
+// ---- CRC-32 of the inflated members (RFC 1952 8; BGZF: the member's trailer holds it before ISIZE).  htslib checks it on every block it inflates
+// (the reader behind generate_SNP_pileups.py:134); on the device route the bytes never reach the host, so the check runs here: a member whose
+// bytes form a valid deflate stream of the announced length but are not the ones that were written is reported (status 7), not called from.
+// One wave per member, four members per workgroup.  The member's <= 64 KB are cut from their END into 64 slices of 1024 bytes (the first
+// non-empty slice is the short one and starts from the initial register 0xffffffff); a lane runs slice-by-4 over its slice (tables in LDS,
+// dwords from 4-byte aligned addresses put in place by v_alignbyte); the 64 partial registers combine in a tree whose level l multiplies by
+// x^(8 * 1024 * 2^l) mod P -- six constants, since every slice but the first has the same length (an empty lane's register is 0).
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+struct CrcOps { uint32_t x[6]; };                                      // x^(8 * 1024 * 2^l) mod P, reflected representation, l = 0 .. 5
+
+__host__ __device__ inline uint32_t crc_multmodp(uint32_t a, uint32_t b)      // a * b mod P (zlib's crc32 combine arithmetic)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_crc32(int32_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ coff, const int32_t *__restrict__ clen,
+                                               const uint8_t *__restrict__ out, const int64_t *__restrict__ ooff, const int32_t *__restrict__ isize,
+                                               int32_t *__restrict__ status, CrcOps ops)
+{
+    __shared__ uint32_t T[4][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    {
+        uint32_t c = (uint32_t)tid;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        T[0][tid] = c;
+    }
+    __syncthreads();
+    {
+        uint32_t c = T[0][tid];
+#pragma unroll
+        for (int t = 1; t < 4; t++) { c = (c >> 8) ^ T[0][c & 0xffu]; T[t][tid] = c; }
+    }
+    __syncthreads();
+    const int b = blockIdx.x * 4 + (tid >> 6);
+    if (b >= n_blocks) return;
+    const int n = isize[b];
+    const uint8_t *base = out + ooff[b];
+    // slice `lane` covers bytes [n - (64 - lane) * 1024, n - (63 - lane) * 1024) of the member, clipped at 0
+    const int hi = n - (63 - lane) * 1024, lo = max(hi - 1024, 0);
+    int len = hi > 0 ? hi - lo : 0;
+    uint32_t crc = (len > 0 && lo == 0) ? 0xffffffffu : 0u;            // the first non-empty slice carries the initial register
+    const uint8_t *q = base + lo;
+    for (; len > 0 && ((uintptr_t)q & 3); len--) crc = (crc >> 8) ^ T[0][(crc ^ *q++) & 0xffu];      // up to the next aligned dword (the short first slice only, or an unaligned member)
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(q);
+    for (int i = 0; i + 4 <= len; i += 4) {
+        const uint32_t x = crc ^ *w++;
+        crc = T[3][x & 0xffu] ^ T[2][(x >> 8) & 0xffu] ^ T[1][(x >> 16) & 0xffu] ^ T[0][x >> 24];
+    }
+    q = reinterpret_cast<const uint8_t *>(w);
+    for (int i = len & ~3; i < len; i++) crc = (crc >> 8) ^ T[0][(crc ^ *q++) & 0xffu];
+    // tree: at level l the register of the left half moves 1024 * 2^l bytes forward
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)crc, 1 << l);
+        const bool right = (lane >> l) & 1;
+        const uint32_t left_c = right ? other : crc, right_c = right ? crc : other;
+        crc = crc_multmodp(ops.x[l], left_c) ^ right_c;               // (both lanes of a pair compute the same value)
+    }
+    if (lane == 0) {
+        const uint32_t have = n > 0 ? crc ^ 0xffffffffu : 0u;
+        const uint8_t *t = comp + coff[b] + clen[b];
+        const uint32_t want = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        if (have != want && status[b] == 0) status[b] = 7;
+    }
+}
 }   // namespace
 
 // d_tok: workspace of ceil(n_blocks / 64) x 4,194,304 dwords (64 members x 65,536 tokens, interleaved); d_ntok: n_blocks counters.
@@ -537,4 +613,25 @@ extern "C" int nc_inflate_device_phase(nc_ctx *ctx, int32_t phase, int32_t n_blo
 {
     if (phase < 1 || phase > 3) return ctx ? nc_fail(ctx, NC_ERR_ARG, "nc_inflate_device_phase: phase 1, 2 or 3") : NC_ERR_ARG;
     return inflate_phase(ctx, phase, n_blocks, d_comp, d_coff, d_clen, d_out, d_ooff, d_isize, d_status, d_tok, d_ntok);
+}
+
+// CRC-32 of every inflated member against its trailer; a mismatch sets d_status[b] = 7 (where the inflate itself left 0)
+extern "C" int nc_bgzf_crc_device(nc_ctx *ctx, int32_t n_blocks, const uint8_t *d_comp, const int64_t *d_coff, const int32_t *d_clen, const uint8_t *d_out,
+                                  const int64_t *d_ooff, const int32_t *d_isize, int32_t *d_status)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_blocks < 0 || (n_blocks && (!d_comp || !d_coff || !d_clen || !d_out || !d_ooff || !d_isize || !d_status)))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_bgzf_crc_device: bad argument");
+    if (n_blocks == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    static const CrcOps ops = []() {
+        CrcOps o;
+        uint32_t p = 1u << 30;                                          // x^1
+        for (int k = 0; k < 13; k++) p = crc_multmodp(p, p);           // x^(2^13) = x^(8 * 1024)
+        for (int l = 0; l < 6; l++) { o.x[l] = p; p = crc_multmodp(p, p); }
+        return o;
+    }();
+    hipLaunchKernelGGL(k_crc32, dim3((n_blocks + 3) / 4), dim3(256), 0, ctx->stream, n_blocks, d_comp, d_coff, d_clen, d_out, d_ooff, d_isize, d_status, ops);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
 }

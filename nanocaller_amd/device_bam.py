@@ -31,6 +31,7 @@ from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
 
 META_COLS = 12
 (M_REFID, M_POS, M_FLAG, M_RLEN, M_LSEQ, M_HASSEQ, M_HAP, M_PS, M_HASH_LO, M_HASH_HI, M_NCIG, M_CIGD) = range(META_COLS)
+CHECK_CRC = os.environ.get("NC_BGZF_CRC", "1") != "0"     # CRC-32 of every inflated member on the device (NC_BGZF_CRC=0: lengths only, as in round 4)
 INFLATE_BATCH = 16384            # members per nc_inflate_device call (4 GB of token workspace)
 POOL_MAX = 16 << 30              # buffers up to this size stay allocated between loads (larger ones go back to the allocator after use)
 MAX_RESIDENT = 96 << 30          # inflated bytes kept in HBM at once (a 30x human genome BAM does not fit: it takes the host route)
@@ -308,6 +309,8 @@ class DeviceBam:
                 lz_stream.wait_event(huffed)
                 eng.use_torch_stream()
                 eng._check(L.nc_inflate_device_phase(eng.ctx, 2, *args), "nc_inflate_device_phase")
+                if CHECK_CRC:                                            # what htslib does for every block it inflates: the member's CRC-32 against its trailer
+                    eng._check(L.nc_bgzf_crc_device(eng.ctx, *args[:8]), "nc_bgzf_crc_device")
                 lz_done[0] = torch.cuda.Event()
                 lz_done[0].record(lz_stream)
             eng.use_torch_stream()
@@ -363,7 +366,9 @@ class DeviceBam:
         lz_stream.synchronize()
         bad = sum(int(st.count_nonzero().item()) for st in statuses)     # (also: the inflate is done)
         if bad:
-            raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size" % (self.path, bad))
+            crc = sum(int((st == 7).sum().item()) for st in statuses)
+            raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size%s"
+                                          % (self.path, bad - crc, (", %d fail their CRC-32" % crc) if crc else ""))
         compute.wait_stream(lz_stream)
         del toks, d_file, keep, statuses
         self.host_buf = None

@@ -317,3 +317,32 @@ def test_csi_indexed_bam_takes_the_device_route_too(tmp_path):
     _, prep, _ = _same_pack(bam, fa, "chrOther", contigs=["chrOther"])
     assert prep["n_kept"] == 40
     _same_indel_sections(bam, fa, w.chrom)
+
+
+@pytest.mark.gpu
+def test_a_member_with_a_damaged_crc_is_reported_not_called_from(tmp_path, monkeypatch):
+    """a BGZF member whose bytes still inflate to the announced length but whose CRC-32 does not match (one stored trailer bit flipped: the cheapest
+    way to make one) -- htslib refuses the block; the device route reports it too (nc_bgzf_crc_device), and NC_BGZF_CRC=0 restores round 4's
+    lengths-only check"""
+    from nanocaller_amd import device_bam
+    w = bamio.make_bam_world()
+    recs = bamio.world_to_records(w, np.random.Generator(np.random.PCG64(2)))
+    bam = str(tmp_path / "w.bam")
+    bamio.write_bam(bam, w.chrom, w.length, recs)
+    raw = bytearray(open(bam, "rb").read())
+    bsize = int.from_bytes(raw[16:18], "little") + 1
+    second = bsize                                                                                # damage the SECOND member (the first holds the header the host reads)
+    b2 = int.from_bytes(raw[second + 16:second + 18], "little") + 1
+    raw[second + b2 - 8] ^= 0x04                                                                  # lowest byte of its CRC-32
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    import shutil
+    shutil.copy(bam + ".bai", bad + ".bai")
+    device_bam.release()
+    with pytest.raises(Exception, match="CRC-32"):
+        device_bam.open_device_bam(bad, 0)
+    device_bam.release()
+    monkeypatch.setattr(device_bam, "CHECK_CRC", False)
+    db = device_bam.open_device_bam(bad, 0)                                                       # (the bytes are intact: only the stored CRC is not)
+    assert db.n_rec > 100
+    device_bam.release()

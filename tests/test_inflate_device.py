@@ -128,3 +128,60 @@ def test_damaged_members_are_reported():
     assert out[ooff[0]:ooff[0] + len(d)].tobytes() == d and out[ooff[6]:ooff[6] + len(d)].tobytes() == d
     for k, (_, n) in enumerate(cases):
         assert out[ooff[k] + n:ooff[k] + n + 3].tolist() == [0xEE] * 3, k                         # even a damaged member stays inside its own output
+
+
+def _crc_status(payloads, datas, trailers):
+    """nc_bgzf_crc_device over hand-laid members: payload + trailer (CRC-32, ISIZE) back to back in one buffer, inflated bytes in another"""
+    import torch
+    from nanocaller_amd.engine import get_engine
+    eng = get_engine(0)
+    blob, coff = bytearray(), []
+    for p, t in zip(payloads, trailers):
+        blob += b"\x55" * (len(blob) % 3)                                                        # unaligned members
+        coff.append(len(blob))
+        blob += p + t
+    blob += bytes(16)
+    sizes = [len(d) for d in datas]
+    ooff = np.zeros(len(datas) + 1, np.int64)
+    np.cumsum(np.asarray(sizes, np.int64) + 1, out=ooff[1:])                                      # (odd gaps: every alignment of a member's first byte)
+    raw = np.full(int(ooff[-1]) + 16, 0xEE, np.uint8)
+    for k, d in enumerate(datas):
+        raw[ooff[k]:ooff[k] + len(d)] = np.frombuffer(d, np.uint8)
+    dev = eng.device
+    t = lambda a, dt: torch.from_numpy(np.asarray(a, dt)).to(dev)                                 # noqa: E731
+    d_comp, d_out = t(np.frombuffer(bytes(blob), np.uint8).copy(), np.uint8), t(raw, np.uint8)
+    d_coff, d_clen, d_ooff, d_isize = t(coff, np.int64), t([len(p) for p in payloads], np.int32), t(ooff[:-1].copy(), np.int64), t(sizes, np.int32)
+    d_st = torch.zeros(len(datas), dtype=torch.int32, device=dev)
+    eng.use_torch_stream()
+    rc = eng.L.nc_bgzf_crc_device(eng.ctx, len(datas), d_comp.data_ptr(), d_coff.data_ptr(), d_clen.data_ptr(), d_out.data_ptr(), d_ooff.data_ptr(),
+                                  d_isize.data_ptr(), d_st.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return d_st.cpu().numpy()
+
+
+def test_device_crc32_equals_zlibs_and_reports_a_damaged_member():
+    """k_crc32 (slice-by-4 per lane over 1024-byte slices cut from the member's end, tree combine by x^(8192 * 2^l) mod P) against zlib.crc32 on every
+    length class: empty, shorter than a dword, one slice and a bit, exact multiples of 1024, the BGZF maximum 65,280 and 65,536; then the same
+    members with one bit of data flipped, and with a wrong trailer: status 7"""
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 63, 64, 1023, 1024, 1025, 2048, 4097, 10_000, 30_001, 65_279, 65_280, 65_535, 65_536]
+    datas = [bytes(rng.integers(0, 256, size=n).astype(np.uint8)) for n in lens]
+    pay = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 40))).astype(np.uint8)) for _ in lens]      # (the payload bytes themselves are not read)
+    good = [int(zlib.crc32(d)).to_bytes(4, "little") + len(d).to_bytes(4, "little") for d in datas]
+    st = _crc_status(pay, datas, good)
+    assert not st.any(), [lens[k] for k in np.nonzero(st)[0]]
+    flipped = []
+    for d in datas:
+        if d:
+            b = bytearray(d)
+            k = int(rng.integers(0, len(b)))
+            b[k] ^= 1 << int(rng.integers(0, 8))
+            flipped.append(bytes(b))
+        else:
+            flipped.append(d)
+    st = _crc_status(pay, flipped, good)
+    assert all((s == 7) == (n > 0) for s, n in zip(st.tolist(), lens)), st
+    bad_trailer = [(int(zlib.crc32(d)) ^ 0x00010000).to_bytes(4, "little") + len(d).to_bytes(4, "little") for d in datas]
+    st = _crc_status(pay, datas, bad_trailer)
+    assert (st == 7).all()
