@@ -799,7 +799,7 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
     return out
 
 
-def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
+def extra_from_bam(eng, local, n_contigs=4, L=9_000_000, keep=None):
     """From a BAM FILE through the product worker loop: snpCaller.caller (BGZF inflate + record decode + wire build on host threads for
     contig i + 1 while the GPU runs contig i, upload through the three-slot ring) -> candidate sites/s including ingest.  The BAM (12 contigs of
     9 Mb, ONT 30x: ~1 GB) is written by test tooling from device-generated reads, streamed contig by contig into the Python writer (~40 s, untimed)."""
@@ -815,31 +815,14 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
     import bamio
     tmp = tempfile.mkdtemp(prefix="nc_bench_bam_")
     t0 = time.perf_counter()
-    lut = np.frombuffer(b"AGTCNNNN", np.uint8)
-    refs, fasta = [], []
-    for k in range(n_contigs):                                      # pass 1: the references (the FASTA); the reads are regenerated contig by contig below
-        pack, info = make_device_workload(eng, L, depth=30.0, tech="ont", seed=7000 + k)
-        refc = info["ref_wire"][1:L + 1].cpu().numpy()
-        ref = lut[refc & 7].copy()
-        ref[(refc & 8) != 0] |= 0x20                                 # skipped columns: soft-masked (lower case) in the FASTA
-        name = "ctg%d" % (k + 1)
-        refs.append((name, L))
-        fasta.append((name, ref.tobytes().decode()))
-        del pack, info
-
-    def records():                                                   # streamed into the writer: a ~1 GB BAM's reads never sit in memory as strings together
-        for k in range(n_contigs):
-            pack, info = make_device_workload(eng, L, depth=30.0, tech="ont", seed=7000 + k)
-            codes = pack.codes.cpu().numpy()
-            s_, e_, base = info["read_start"], info["read_end"], info["read_base"]
-            for r in range(info["n_reads"]):
-                o = int(base[r]) + int(s_[r])
-                yield dict(tid=k, name="r%d_%d" % (k, r), flag=16 if info["strand"][r] else 0, pos0=int(s_[r]) - 1,
-                           cigar=[("M", int(e_[r] - s_[r]))], seq=lut[codes[o:o + int(e_[r] - s_[r])]].tobytes().decode(), tags={})
-            del pack, codes
-    bam, fa = os.path.join(tmp, "b.bam"), os.path.join(tmp, "b.fa")
-    bamio.write_bam(bam, refs[0][0], refs[0][1], records(), other_refs=refs[1:], level=1)
+    # the file: ONT-like records (tools/ont_like_bam.py): qualities, the reads' own indels as CIGAR operations (~700 per 10 kb read), soft clips,
+    # NM / MD / HP / PS tags -- what a real alignment file makes the inflate and the record decode work through
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ont_like_bam
+    bam, refs, fasta, fstats = ont_like_bam.make_files(eng, tmp, n_contigs, L, depth=30.0, seed0=7000, level=1)
+    fa = os.path.join(tmp, "b.fa")
     bamio.write_fasta(fa, fasta[0][0], fasta[0][1], extra=fasta[1:])
+    del fasta
     t_files = time.perf_counter() - t0
     regions = [(n, 1, ln, "diploid") for n, ln in refs]
     base_params = dict(regions_list=regions, sam_path=bam, fasta_path=fa, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1,
@@ -854,8 +837,8 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
         for k in ("NC_DEVICE_INGEST", "NC_SERIAL_INGEST"):
             os.environ.pop(k, None)
         os.environ.update(env)
-        best = None
-        for rep in range(3):                                          # best of three: the first run of a route also pays its one-off costs (page-locked
+        best = first = None
+        for rep in range(3):                                          # first run and best of three: the first run of a route also pays its one-off costs (page-locked
             gsp.release_contig()                                      # buffers of the file's size, first launches); every run starts from the file
             device_bam.release()
             d = os.path.join(tmp, "%s%d" % (tag, rep))
@@ -872,8 +855,10 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
             dt = time.perf_counter() - t0
             texts[tag] = open(files[0], "rb").read()
             n_rec = texts[tag].count(b"\n")
+            if first is None:
+                first = {"seconds": dt, "sites_s": n_rec / dt}
             if best is None or dt < best["seconds"]:
-                best = {"seconds": dt, "sites_s": n_rec / dt, "records": n_rec}
+                best = {"seconds": dt, "sites_s": n_rec / dt, "records": n_rec, "first_run": first}
                 if tag == "device_ingest":
                     best["stages_s"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in device_bam.LAST_LOAD.items()}
         out[tag] = best
@@ -886,8 +871,10 @@ def extra_from_bam(eng, local, n_contigs=12, L=9_000_000, keep=None):
         shutil.rmtree(tmp, ignore_errors=True)
     else:
         keep.extend([tmp, bam, fa, regions])                        # (tools/exp_from_bam.py goes on with the files)
-    return {"workload": "%d contigs of %d bp, ONT 30x, one BAM file (%.0f MB, BGZF level 1) + FASTA -> snpCaller.caller -> worker VCF file; host threads: %d usable CPUs"
-                        % (n_contigs, L, size / 1e6, usable_cpus()),
+    return {"workload": "%d contigs of %d bp, ONT 30x, one ONT-like BAM file (%.0f MB, BGZF level 1: base qualities, %d reads with %.0f CIGAR operations each on average -- "
+                        "the reads' own deletions and 3 %% insertions --, soft clips on a third of them, NM / MD / HP / PS tags) + FASTA -> snpCaller.caller -> worker VCF file; "
+                        "host threads: %d usable CPUs" % (n_contigs, L, size / 1e6, fstats["reads"], fstats["cigar_ops"] / max(1, fstats["reads"]), usable_cpus()),
+            "file": fstats,
             "from_bam_sites_s": out["device_ingest"]["sites_s"],
             "unit": "candidate sites/s incl. file read, H2D of the file, BGZF inflate + record walk + decode in HBM, GPU, rules + text, file write",
             "device_ingest": out["device_ingest"], "host_ingest": out["host_ingest"], "serial_ingest": out["serial_ingest"],

@@ -34,7 +34,19 @@ META_COLS = 12
 CHECK_CRC = os.environ.get("NC_BGZF_CRC", "1") != "0"     # CRC-32 of every inflated member on the device (NC_BGZF_CRC=0: lengths only, as in round 4)
 INFLATE_BATCH = 16384            # members per nc_inflate_device call (4 GB of token workspace)
 POOL_MAX = 16 << 30              # buffers up to this size stay allocated between loads (larger ones go back to the allocator after use)
-MAX_RESIDENT = 96 << 30          # inflated bytes kept in HBM at once (a 30x human genome BAM does not fit: it takes the host route)
+MAX_RESIDENT = 96 << 30          # upper bound of the inflated bytes kept in HBM at once; resident_limit() lowers it to what the device has free
+
+
+def resident_limit(device=0):
+    """inflated bytes one share of a file may take on `device`: the loader holds the stream (sized 8 x + 12.5 % of the compressed bytes), the file
+    image (1/8 of the stream) and <= 8 GB of tokens; the read packs, the indel pipeline's workspaces and the CNN's need room beside them -- half of
+    what is free now (plus what this module's own pools already hold), at most MAX_RESIDENT"""
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return MAX_RESIDENT
+    pooled = sum(t[0].numel() for t in _RAW_POOL.values()) + sum(t.numel() * t.element_size() for t in _WORK_POOL.values())
+    return int(max(1 << 30, min(MAX_RESIDENT, (free + pooled) // 2)))
 
 
 LAST_LOAD = {}                   # seconds per stage of the most recent DeviceBam construction + load() (bench.py reports them)
@@ -149,7 +161,7 @@ class DeviceBam:
             else:
                 self.B1 = 0                                              # none of them has an alignment
         self.n_bytes = self.B1 - self.B0
-        if self.n_bytes * 8 > MAX_RESIDENT:                              # (the loader reserves eight times the compressed size for the inflated stream)
+        if self.n_bytes * 8 > resident_limit(device):                    # (the loader reserves eight times the compressed size for the inflated stream)
             raise DeviceIngestUnavailable("%s (%.1f GB to load): more than is kept in HBM at once" % (path, self.n_bytes / 1e9))
         self.loaded = False
 
@@ -632,7 +644,7 @@ def plan_shares(path, contigs, limit_bytes=None):
     passes through HBM share by share.  -> list of (contigs of the share, fits): fits False = that contig alone is too large (host route).
     Raises DeviceIngestUnavailable when there is no .bai."""
     spans, names = contig_spans(path)
-    limit = (MAX_RESIDENT // 8) if limit_bytes is None else int(limit_bytes)
+    limit = (resident_limit(torch.cuda.current_device() if torch.cuda.is_available() else 0) // 8) if limit_bytes is None else int(limit_bytes)
     shares, cur, lo, hi = [], [], None, None
     for c in contigs:
         if c not in names:
@@ -687,7 +699,18 @@ def open_device_bam(path, device=0, contigs=None) -> DeviceBam:
         if k[0] == ident[0] and k[3] == device:
             del _OPEN[k]                                                # another version of the file, or another share of it
     db = _OPEN[ident + (want,)] = DeviceBam(path, device, contigs=None if want is None else sorted(want))
-    return db.load()
+    try:
+        return db.load()
+    except (torch.cuda.OutOfMemoryError, MemoryError) as e:             # device or page-locked memory: the host route needs neither
+        _OPEN.pop(ident + (want,), None)
+        release(path, buffers=True)
+        raise DeviceIngestUnavailable("%s: %s" % (path, str(e).splitlines()[0] if str(e) else type(e).__name__))
+    except RuntimeError as e:
+        if "out of memory" in str(e).lower() or "hipErrorOutOfMemory" in str(e):
+            _OPEN.pop(ident + (want,), None)
+            release(path, buffers=True)
+            raise DeviceIngestUnavailable("%s: %s" % (path, str(e).splitlines()[0]))
+        raise
 
 
 def release(path=None, buffers=False):

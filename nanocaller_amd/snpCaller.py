@@ -404,7 +404,14 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
             """group i opens a run: the device route loads the run's share of the file (the previous share is dropped), the host route needs
             nothing; then the first preparations of the run are started"""
             nonlocal dbam, prepare, uploader, nxt
+            # the previous share goes first: its DeviceBam is still referenced by the old `prepare` closure, and while it lives its stream buffer
+            # cannot be re-used -- a second one next to it is ~2 x 108 GB for a genome-sized file (more than the card holds)
             dbam = None
+            prepare = None
+            if i > 0 and run_dev[i - 1] is not None:
+                from .device_bam import release as _release_device_bam
+                get_engine(device).sync()
+                _release_device_bam(params['sam_path'])
             if run_dev[i] is not None:
                 # the first contigs' reference letters are read while the file is loaded (the loader mostly waits: for its reader threads, for the GPU)
                 ref_pool = ThreadPoolExecutor(max_workers=2)
@@ -413,7 +420,7 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
                 try:
                     dbam = open_device_bam(params['sam_path'], device, contigs=list(run_dev[i]))
                 except DeviceIngestUnavailable:
-                    dbam = None
+                    dbam = None                                           # (includes: not enough free device / page-locked memory -- the host route needs neither)
                 ref_pool.shutdown(wait=False)
             if dbam is not None:
                 db = dbam

@@ -346,3 +346,70 @@ def test_a_member_with_a_damaged_crc_is_reported_not_called_from(tmp_path, monke
     db = device_bam.open_device_bam(bad, 0)                                                       # (the bytes are intact: only the stored CRC is not)
     assert db.n_rec > 100
     device_bam.release()
+
+
+@pytest.mark.gpu
+def test_a_device_without_room_sends_the_file_to_the_host_route(tmp_path, monkeypatch):
+    """the ingest is sized from what the device has free (resident_limit: half of free + pooled memory), and a failed allocation inside the loader is
+    DeviceIngestUnavailable -- the caller's host route -- not a crash of the worker"""
+    import torch
+    from nanocaller_amd import device_bam
+    w = bamio.make_bam_world()
+    recs = bamio.world_to_records(w, np.random.Generator(np.random.PCG64(3)))
+    bam = str(tmp_path / "w.bam")
+    bamio.write_bam(bam, w.chrom, w.length, recs)
+    device_bam.release(buffers=True)
+    lim = device_bam.resident_limit(0)
+    free, total = torch.cuda.mem_get_info(0)
+    assert (1 << 30) <= lim <= min(device_bam.MAX_RESIDENT, free // 2 + (1 << 20))
+    monkeypatch.setattr(device_bam, "resident_limit", lambda device=0: 1024)
+    with pytest.raises(device_bam.DeviceIngestUnavailable):
+        device_bam.open_device_bam(bam, 0)
+    monkeypatch.undo()
+
+    def oom(*a, **k):
+        raise torch.cuda.OutOfMemoryError("HIP out of memory (simulated)")
+    monkeypatch.setattr(device_bam, "_work_buffer", oom)
+    device_bam.release(buffers=True)
+    with pytest.raises(device_bam.DeviceIngestUnavailable):
+        device_bam.open_device_bam(bam, 0)
+    monkeypatch.undo()
+    device_bam.release(buffers=True)
+    assert device_bam.open_device_bam(bam, 0).n_rec > 100
+    device_bam.release(buffers=True)
+
+
+@pytest.mark.gpu
+def test_the_ont_like_bench_bam_decodes_to_the_workload_it_was_written_from(tmp_path):
+    """tools/ont_like_bam.py (the from-BAM leg's file: qualities, ~700 CIGAR operations per read, soft clips, NM / MD / HP / PS tags): the device route's
+    pack of it equals the host route's byte for byte, and both equal the synthetic workload the records were cut from (same aligned bases, deleted
+    positions as code 4; insertions and clips have no column) -- so the bench's file is a valid BAM of the headline workload"""
+    import sys
+    import zlib
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ont_like_bam
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_device_workload
+    eng = get_engine(0)
+    L = 400_000
+    bam, refs, fasta, st = ont_like_bam.make_files(eng, str(tmp_path), 2, L, depth=20.0, seed0=4100, level=1)
+    fa = str(tmp_path / "b.fa")
+    bamio.write_fasta(fa, fasta[0][0], fasta[0][1], extra=fasta[1:])
+    assert st["cigar_ops"] > 300 * st["reads"] and st["bam_bytes"] > 5_000_000
+    raw = open(bam, "rb").read()
+    o, total = 0, 0
+    while o < len(raw):                                                                           # every member: a valid gzip member with the right CRC and size
+        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+        d = zlib.decompress(raw[o + 18:o + bsize - 8], -15)
+        assert zlib.crc32(d) == int.from_bytes(raw[o + bsize - 8:o + bsize - 4], "little") and len(d) == int.from_bytes(raw[o + bsize - 4:o + bsize], "little")
+        total += len(d)
+        o += bsize
+    assert o == len(raw)
+    for k, (name, _) in enumerate(refs):
+        got, prep, world = _same_pack(bam, fa, name)
+        pack, info = make_device_workload(eng, L, depth=20.0, tech="ont", seed=4100 + k)
+        assert prep["n_reads"] == info["n_reads"] and np.array_equal(prep["read_start"], info["read_start"])
+        a, b = got.codes.cpu().numpy(), pack.codes.cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a, b), (k, int((a != b).sum()))
+        assert int((world.read_hp > 0).sum()) > 0.5 * info["n_reads"] if hasattr(world, "read_hp") else True

@@ -1,0 +1,239 @@
+"""A BAM shaped like real ONT data, for the from-BAM leg of bench.py (test tooling: untimed, never on the product path).
+
+What the round-4 bench file lacked (missing #2): base qualities (here: correlated, 1..50), CIGARs with the read's own indels -- the
+synthetic workload's deleted positions as D runs plus 1-3 base insertions after ~3 % of the aligned bases: ~700 operations per 10 kb read instead
+of one M --, soft clips on a third of the reads, and the auxiliary tags aligners and WhatsHap leave (NM, MD, HP, PS).  The aligned bases are the
+device workload's (nanocaller_amd/synth_device.make_device_workload), so the candidate sites are the headline workload's.
+
+Everything per base is done for a whole contig at once on the GPU (torch) -- operations, query stream, MD tokens --; the host loop only cuts the
+per-read slices into records.  BGZF blocks are deflated on a thread pool (zlib releases the GIL)."""
+import os
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+BLOCK = 0xff00
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+_NT16 = np.array([1, 4, 8, 2, 15, 15, 15, 15], np.uint8)            # codes A G T C (N) -> BAM nibbles
+_LET = np.frombuffer(b"AGTCNNNN", np.uint8)
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _digit_lut(dev):
+    """ASCII digits of 0..9999, right-aligned in four columns, and how many are significant"""
+    v = np.arange(10000)
+    d = np.stack([v // 1000 % 10, v // 100 % 10, v // 10 % 10, v % 10], 1).astype(np.uint8) + 48
+    nd = np.where(v >= 1000, 4, np.where(v >= 100, 3, np.where(v >= 10, 2, 1))).astype(np.int64)
+    return torch.from_numpy(d).to(dev), torch.from_numpy(nd).to(dev)
+
+
+def contig_records(eng, pack, info, tid, rng, ins_rate=0.03, clip_frac=0.33):
+    """-> (list of record byte strings in file order, pos0 array, rlen array, stats) of one contig's reads"""
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(rng.integers(1, 2 ** 31)))
+    starts, ends = info["read_start"].astype(np.int64), info["read_end"].astype(np.int64)
+    R = int(starts.shape[0])
+    lens = ends - starts
+    valid = pack.codes != 7
+    c = pack.codes[valid]                                              # read-major, one element per reference position a read spans
+    N = int(c.numel())
+    assert N == int(lens.sum())
+    d_len = torch.from_numpy(lens).to(dev)
+    rid = torch.repeat_interleave(torch.arange(R, device=dev), d_len)
+    rs_idx = torch.cumsum(d_len, 0) - d_len                            # flat index of every read's first element
+    pos = torch.arange(N, device=dev) - rs_idx[rid] + torch.from_numpy(starts).to(dev)[rid]
+    refb = (info["ref_wire"][pos] & 7).to(torch.uint8)
+    isdel = c == 4
+    last = torch.zeros(N, dtype=torch.bool, device=dev)
+    last[rs_idx + d_len - 1] = True
+    u = torch.rand(N, device=dev, generator=g)
+    ins_len = torch.where((u < ins_rate) & ~isdel & ~last, 1 + (u * (1.0 / ins_rate) * 3).to(torch.int64).clamp(0, 2), torch.zeros((), dtype=torch.int64, device=dev))
+    # ---- CIGAR runs: a base run (M / D) starts at a read's first element, behind an insertion, or where the operation changes; I runs behind elements
+    op = torch.where(isdel, 2, 0)
+    first = torch.zeros(N, dtype=torch.bool, device=dev)
+    first[rs_idx] = True
+    prev_op = torch.roll(op, 1)
+    prev_ins = torch.roll(ins_len, 1)
+    start_run = first | (prev_ins > 0) | (op != prev_op)
+    s_idx = torch.nonzero(start_run).squeeze(1)
+    run_len = torch.diff(s_idx, append=torch.tensor([N], device=dev))
+    i_idx = torch.nonzero(ins_len > 0).squeeze(1)
+    keys = torch.cat([s_idx * 2, i_idx * 2 + 1])
+    words = torch.cat([(run_len << 4) | op[s_idx], (ins_len[i_idx] << 4) | 1])
+    order = torch.argsort(keys)
+    words = words[order].to(torch.int32)
+    run_read = rid[torch.cat([s_idx, i_idx])[order]]
+    ncig = torch.bincount(run_read, minlength=R)
+    # ---- query stream: the element's base (unless deleted), then its inserted bases
+    qcnt = (~isdel).to(torch.int64) + ins_len
+    Q = int(qcnt.sum().item())
+    q_elem = torch.repeat_interleave(torch.arange(N, device=dev), qcnt)
+    q_first = torch.cumsum(qcnt, 0) - qcnt
+    own = (torch.arange(Q, device=dev) == q_first[q_elem]) & ~isdel[q_elem]
+    qbase = torch.where(own, c[q_elem], torch.randint(0, 4, (Q,), dtype=torch.uint8, device=dev, generator=g))
+    qlen = torch.bincount(rid, weights=qcnt.to(torch.float64), minlength=R).to(torch.int64)
+    # qualities: a slow component per ~64 bases plus noise (runs of poor bases as in nanopore reads), 1 .. 50
+    slow = torch.randn((Q + 63) // 64 + 1, device=dev, generator=g) * 6.0
+    qual = (20.0 + slow[torch.arange(Q, device=dev) // 64] + torch.randn(Q, device=dev, generator=g) * 5.0).clamp(1, 50).to(torch.uint8)
+    # ---- MD tokens: [matches since the previous event] [^ at the start of a deletion] [reference letter] per mismatch / deleted base, and the matches behind the last one
+    mism = (c != refb) & ~isdel
+    ev = torch.nonzero(mism | isdel).squeeze(1)
+    E = int(ev.numel())
+    prev_ev = torch.roll(ev, 1)
+    same = torch.roll(rid[ev], 1) == rid[ev]
+    if E:
+        same[0] = False
+    before = torch.where(same, prev_ev, rs_idx[rid[ev]] - 1)
+    run = (ev - before - 1).clamp(0, 9999)
+    cont = isdel[ev] & same & (prev_ev == ev - 1) & isdel[prev_ev.clamp(0, N - 1)]      # a deletion going on: no count, no caret
+    dl, dn = _digit_lut(dev)
+    tok = torch.zeros((E + R, 6), dtype=torch.uint8, device=dev)
+    msk = torch.zeros((E + R, 6), dtype=torch.bool, device=dev)
+    tok[:E, :4] = dl[run]
+    msk[:E, :4] = (torch.arange(4, device=dev)[None, :] >= (4 - dn[run])[:, None]) & ~cont[:, None]
+    tok[:E, 4] = 94
+    msk[:E, 4] = isdel[ev] & ~cont
+    tok[:E, 5] = torch.from_numpy(_LET.copy()).to(dev)[refb[ev].to(torch.int64)]
+    msk[:E, 5] = True
+    last_ev = torch.full((R,), -1, dtype=torch.int64, device=dev)
+    last_ev.scatter_reduce_(0, rid[ev], ev, reduce="amax")
+    end_idx = rs_idx + d_len
+    trail = torch.where(last_ev >= 0, end_idx - last_ev - 1, d_len).clamp(0, 9999)
+    tok[E:, :4] = dl[trail]
+    msk[E:, :4] = torch.arange(4, device=dev)[None, :] >= (4 - dn[trail])[:, None]
+    mkeys = torch.cat([ev * 2, (end_idx - 1) * 2 + 1])
+    morder = torch.argsort(mkeys)
+    tok, msk = tok[morder], msk[morder]
+    md_bytes = tok[msk]
+    row_read = torch.cat([rid[ev], torch.arange(R, device=dev)])[morder]
+    mdlen = torch.bincount(row_read, weights=msk.sum(1).to(torch.float64), minlength=R).to(torch.int64)
+    nm = torch.bincount(rid, weights=(mism.to(torch.float64) + isdel.to(torch.float64) + ins_len.to(torch.float64)), minlength=R).to(torch.int64)
+    # ---- to the host, cut per read
+    words_h, ncig_h = words.cpu().numpy().view(np.uint32), ncig.cpu().numpy()
+    qbase_h, qual_h, qlen_h = qbase.cpu().numpy(), qual.cpu().numpy(), qlen.cpu().numpy()
+    md_h, mdlen_h, nm_h = md_bytes.cpu().numpy(), mdlen.cpu().numpy(), nm.cpu().numpy()
+    del c, rid, pos, refb, isdel, u, ins_len, op, q_elem, qbase, qual, tok, msk, words, keys, valid
+    cig_off = np.concatenate([[0], np.cumsum(ncig_h)])
+    q_off = np.concatenate([[0], np.cumsum(qlen_h)])
+    md_off = np.concatenate([[0], np.cumsum(mdlen_h)])
+    clip = rng.random((R, 2)) < clip_frac / 2                         # per end: a third of the reads carry a clip
+    clip_len = np.where(clip, rng.integers(8, 300, size=(R, 2)), 0)
+    hp = rng.integers(0, 3, size=R)                                    # 0: untagged
+    recs = []
+    n_ops = 0
+    for r in range(R):
+        cw = words_h[cig_off[r]:cig_off[r + 1]]
+        qb, ql = qbase_h[q_off[r]:q_off[r + 1]], qual_h[q_off[r]:q_off[r + 1]]
+        a, b = int(clip_len[r, 0]), int(clip_len[r, 1])
+        if a or b:
+            qb = np.concatenate([rng.integers(0, 4, a).astype(np.uint8), qb, rng.integers(0, 4, b).astype(np.uint8)])
+            ql = np.concatenate([rng.integers(2, 15, a).astype(np.uint8), ql, rng.integers(2, 15, b).astype(np.uint8)])
+            cw = np.concatenate([np.array([(a << 4) | 4], np.uint32)[:1 if a else 0], cw, np.array([(b << 4) | 4], np.uint32)[:1 if b else 0]])
+        nib = _NT16[qb]
+        if nib.size & 1:
+            nib = np.append(nib, np.uint8(0))
+        packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8)
+        name = b"r%d_%d\0" % (tid, r)
+        tags = b"NMi" + struct.pack("<i", int(nm_h[r])) + b"MDZ" + md_h[md_off[r]:md_off[r + 1]].tobytes() + b"\0"
+        if hp[r]:
+            tags += b"HPC" + struct.pack("<B", int(hp[r])) + b"PSi" + struct.pack("<i", 1 + (int(starts[r]) // 500_000) * 500_000)
+        pos0, rlen = int(starts[r]) - 1, int(lens[r])
+        body = struct.pack("<iiBBHHHiiii", tid, pos0, len(name), 60, _reg2bin(pos0, pos0 + rlen), cw.size, 16 if info["strand"][r] else 0, qb.size, -1, -1, 0) + \
+            name + cw.tobytes() + packed.tobytes() + ql.tobytes() + tags
+        recs.append(struct.pack("<i", len(body)) + body)
+        n_ops += cw.size
+    return recs, starts - 1, lens, dict(reads=R, cigar_ops=n_ops, query_bases=int(q_off[-1]) + int(clip_len.sum()))
+
+
+def write(path, refs, per_contig_records, level=1, threads=8):
+    """refs: [(name, length)]; per_contig_records: iterator of (tid, recs, pos0, rlen).  Writes path and path.bai (linear index only, as tests/bamio does)."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for n, ln in refs:
+        hdr += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
+
+    def deflate(raw):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(raw) + co.flush()
+        return struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw))
+    lins = [None] * len(refs)
+    coff = 0
+    with open(path, "wb") as f, ThreadPoolExecutor(max_workers=threads) as pool:
+        blk = deflate(hdr)
+        f.write(blk)
+        coff += len(blk)
+        for tid, recs, pos0, rlen in per_contig_records:
+            sizes = np.fromiter((len(x) for x in recs), np.int64, len(recs))
+            uoff = np.concatenate([[0], np.cumsum(sizes)])
+            stream = b"".join(recs)
+            nblk = (len(stream) + BLOCK - 1) // BLOCK
+            blocks = list(pool.map(deflate, (stream[k * BLOCK:(k + 1) * BLOCK] for k in range(nblk))))
+            bsz = np.fromiter((len(x) for x in blocks), np.int64, nblk)
+            bcoff = coff + np.concatenate([[0], np.cumsum(bsz)])
+            for b_ in blocks:
+                f.write(b_)
+            coff = int(bcoff[-1])
+            voff = (bcoff[uoff[:-1] // BLOCK] << 16) | (uoff[:-1] % BLOCK)
+            n_win = int((pos0 + np.maximum(rlen, 1) - 1).max() >> 14) + 1 if len(recs) else 0
+            lin = np.zeros(n_win, np.uint64)
+            seen = np.zeros(n_win, bool)
+            w0, w1 = pos0 >> 14, (pos0 + np.maximum(rlen, 1) - 1) >> 14
+            for k in range(len(recs)):                                    # (file order: the first record of a window wins)
+                a, b = int(w0[k]), int(w1[k])
+                if not seen[a:b + 1].all():
+                    m = ~seen[a:b + 1]
+                    lin[a:b + 1][m] = np.uint64(voff[k])
+                    seen[a:b + 1] = True
+            lastv = np.uint64(0)
+            for k in range(n_win):                                        # samtools fills empty windows with the previous offset
+                if seen[k]:
+                    lastv = lin[k]
+                else:
+                    lin[k] = lastv
+            lins[tid] = lin
+        f.write(_EOF)
+    with open(path + ".bai", "wb") as f:
+        f.write(b"BAI\1" + struct.pack("<i", len(refs)))
+        for lin in lins:
+            n = 0 if lin is None else int(lin.size)
+            f.write(struct.pack("<i", 0) + struct.pack("<i", n) + (lin.astype("<u8").tobytes() if n else b""))
+
+
+def make_files(eng, tmp, n_contigs, L, depth=30.0, seed0=7000, level=1):
+    """-> (bam path, refs, [(name, sequence with the skipped columns soft-masked)], stats): `n_contigs` contigs of the SNP bench workload as one ONT-like BAM"""
+    from nanocaller_amd.synth_device import make_device_workload
+    rng = np.random.default_rng(seed0)
+    refs = [("ctg%d" % (k + 1), L) for k in range(n_contigs)]
+    bam = os.path.join(tmp, "b.bam")
+    stats = dict(reads=0, cigar_ops=0, query_bases=0)
+    fasta = []
+
+    def contigs():
+        for k in range(n_contigs):
+            pack, info = make_device_workload(eng, L, depth=depth, tech="ont", seed=seed0 + k)
+            refc = info["ref_wire"][1:L + 1].cpu().numpy()
+            ref = _LET[refc & 7].copy()
+            ref[(refc & 8) != 0] |= 0x20
+            fasta.append((refs[k][0], ref.tobytes()))
+            recs, pos0, rlen, st = contig_records(eng, pack, info, k, rng)
+            for kk in stats:
+                stats[kk] += st[kk]
+            del pack, info
+            torch.cuda.empty_cache()
+            yield k, recs, pos0, rlen
+    write(bam, refs, contigs(), level=level, threads=max(2, min(16, len(os.sched_getaffinity(0)))))
+    stats["bam_bytes"] = os.path.getsize(bam)
+    return bam, refs, [(n, s_.decode()) for n, s_ in fasta], stats
