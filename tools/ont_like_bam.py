@@ -76,7 +76,9 @@ def contig_records(eng, pack, info, tid, rng, ins_rate=0.03, clip_frac=0.33):
     order = torch.argsort(keys)
     words = words[order].to(torch.int32)
     run_read = rid[torch.cat([s_idx, i_idx])[order]]
-    ncig = torch.bincount(run_read, minlength=R)
+    # (per-read sums are differences of prefix sums: torch.bincount with weights -- float64 atomics on runs of equal bins -- took 56 s per contig here)
+    rbound = torch.searchsorted(run_read, torch.arange(R + 1, device=dev))
+    ncig = rbound[1:] - rbound[:-1]
     # ---- query stream: the element's base (unless deleted), then its inserted bases
     qcnt = (~isdel).to(torch.int64) + ins_len
     Q = int(qcnt.sum().item())
@@ -84,7 +86,12 @@ def contig_records(eng, pack, info, tid, rng, ins_rate=0.03, clip_frac=0.33):
     q_first = torch.cumsum(qcnt, 0) - qcnt
     own = (torch.arange(Q, device=dev) == q_first[q_elem]) & ~isdel[q_elem]
     qbase = torch.where(own, c[q_elem], torch.randint(0, 4, (Q,), dtype=torch.uint8, device=dev, generator=g))
-    qlen = torch.bincount(rid, weights=qcnt.to(torch.float64), minlength=R).to(torch.int64)
+    end_idx = rs_idx + d_len
+
+    def per_read(w):                                                   # sum of an int64 per-element weight over every read's elements
+        cs = torch.cumsum(w, 0)
+        return cs[end_idx - 1] - torch.where(rs_idx > 0, cs[(rs_idx - 1).clamp(min=0)], torch.zeros((), dtype=torch.int64, device=dev))
+    qlen = per_read(qcnt)
     # qualities: a slow component per ~64 bases plus noise (runs of poor bases as in nanopore reads), 1 .. 50
     slow = torch.randn((Q + 63) // 64 + 1, device=dev, generator=g) * 6.0
     qual = (20.0 + slow[torch.arange(Q, device=dev) // 64] + torch.randn(Q, device=dev, generator=g) * 5.0).clamp(1, 50).to(torch.uint8)
@@ -110,7 +117,6 @@ def contig_records(eng, pack, info, tid, rng, ins_rate=0.03, clip_frac=0.33):
     msk[:E, 5] = True
     last_ev = torch.full((R,), -1, dtype=torch.int64, device=dev)
     last_ev.scatter_reduce_(0, rid[ev], ev, reduce="amax")
-    end_idx = rs_idx + d_len
     trail = torch.where(last_ev >= 0, end_idx - last_ev - 1, d_len).clamp(0, 9999)
     tok[E:, :4] = dl[trail]
     msk[E:, :4] = torch.arange(4, device=dev)[None, :] >= (4 - dn[trail])[:, None]
@@ -119,8 +125,11 @@ def contig_records(eng, pack, info, tid, rng, ins_rate=0.03, clip_frac=0.33):
     tok, msk = tok[morder], msk[morder]
     md_bytes = tok[msk]
     row_read = torch.cat([rid[ev], torch.arange(R, device=dev)])[morder]
-    mdlen = torch.bincount(row_read, weights=msk.sum(1).to(torch.float64), minlength=R).to(torch.int64)
-    nm = torch.bincount(rid, weights=(mism.to(torch.float64) + isdel.to(torch.float64) + ins_len.to(torch.float64)), minlength=R).to(torch.int64)
+    mcs = torch.cumsum(msk.sum(1).to(torch.int64), 0)
+    mb = torch.searchsorted(row_read, torch.arange(R + 1, device=dev))                           # (rows are in flat order: a read's rows are one run)
+    mcs0 = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), mcs])
+    mdlen = mcs0[mb[1:]] - mcs0[mb[:-1]]
+    nm = per_read(mism.to(torch.int64) + isdel.to(torch.int64) + ins_len)
     # ---- to the host, cut per read
     words_h, ncig_h = words.cpu().numpy().view(np.uint32), ncig.cpu().numpy()
     qbase_h, qual_h, qlen_h = qbase.cpu().numpy(), qual.cpu().numpy(), qlen.cpu().numpy()
