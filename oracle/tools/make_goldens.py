@@ -492,13 +492,14 @@ def make_chunk_goldens():
 
 
 # ----------------------------------------------------------------------------- pass 2 of the indel featuriser (a11-a13)
-def _install_aligner_stubs(ref_mod, check_every=25):
+def _install_aligner_stubs(ref_mod, check_every=1):
     """MUSCLE and parasail are absent.  The reference's msa() and allele_prediction() are run UNCHANGED with
     * `Popen` replaced by an object that answers the FASTA the reference writes with the star alignment of the same reads
       (nc_star_msa, the aligner the product uses when `muscle` is not on PATH), in the FASTA format the reference parses;
     * `parasail.nw_trace` answered by the Gotoh aligner behind nc_nw_cigar.
-    Every `check_every`-th call is repeated with the pure-Python restatements in oracle/ (star_msa_ref, nw_cigar_ref) and
-    must agree, so the goldens do not depend on which of the two produced them."""
+    EVERY call (check_every = 1; it was every 25th until round 5) is answered by the pure-Python restatements in oracle/ (star_msa_ref,
+    nw_cigar_ref) -- the goldens are "reference code + oracle aligner", no product code in their making -- and the product's host aligners
+    (gip.star_aligner, gip.nw_cigar) are asserted to give the same answer on every one of those calls."""
     import parasail
 
     from nanocaller_amd import generate_indel_pileups as gip
@@ -524,19 +525,23 @@ def _install_aligner_stubs(ref_mod, check_every=25):
                     seqs.append(sq)
             if not seqs:
                 return (b">ref_SEQ\n" + ref.encode() + b"\n", b"")
-            rows, ref_row = gip.star_aligner(names, seqs, ref)
+            from nanocaller_amd import _lib
             cnt["msa"] += 1
-            if cnt["msa"] % check_every == 1:
-                from nanocaller_amd import _lib
-                assert (rows, ref_row) == oracle.star_msa_ref(seqs, ref, *_lib.STAR_SCORING)
+            if check_every == 1 or cnt["msa"] % check_every == 1:
+                rows, ref_row = oracle.star_msa_ref(seqs, ref, *_lib.STAR_SCORING)
+                assert (rows, ref_row) == tuple(gip.star_aligner(names, seqs, ref)), "product star aligner differs from the oracle's"
+            else:
+                rows, ref_row = gip.star_aligner(names, seqs, ref)
             out = "".join(">%s_SEQ\n%s\n" % (n, r) for n, r in zip(names, rows)) + ">ref_SEQ\n%s\n" % ref_row
             return (out.encode(), b"")
 
     def backend(s1, s2, open_, extend, match, mismatch):
-        ops = gip.nw_cigar(s1, s2, open_, extend, match, mismatch)
         cnt["nw"] += 1
-        if cnt["nw"] % check_every == 1:
-            assert ops == oracle.nw_cigar_ref(s1, s2, open_, extend, match, mismatch)
+        if check_every == 1 or cnt["nw"] % check_every == 1:
+            ops = oracle.nw_cigar_ref(s1, s2, open_, extend, match, mismatch)
+            assert ops == gip.nw_cigar(s1, s2, open_, extend, match, mismatch), "product Gotoh aligner differs from the oracle's"
+        else:
+            ops = gip.nw_cigar(s1, s2, open_, extend, match, mismatch)
         return ops
 
     ref_mod.Popen = FakePopen

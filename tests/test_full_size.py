@@ -175,3 +175,68 @@ def test_hifi_60x_haploid_at_full_size():
     finally:
         del pack
         torch.cuda.empty_cache()
+
+
+def test_snp_half_of_configs2_at_chr1_size():
+    """BASELINE.json configs[2]'s SNP half at its full size: a chr1-sized ONT 30x contig (248,956,422 positions, 498 chunks of 500 kb, ~7.5 G pileup
+    entries, ~2.4 M candidate sites) through the uploaded route and the resident one -- bit-identical, deterministic, ordered inside their chunks,
+    the boundary columns emitted by both neighbours (quirk E3), probabilities that are probabilities -- and the first and the LAST two chunks equal
+    to the oracle (the last ones sit behind 2^31 bytes of codes: offsets past 32 bits)"""
+    import torch
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import host_sample_for_oracle, make_device_workload, wire_from_device_workload
+    from nanocaller_amd.utils import get_chunks
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from nanocaller_amd.wire import WireUploader
+    from oracle import oracle
+    eng = get_engine(0)
+    L1 = 248_956_422
+    pack, info = make_device_workload(eng, L1, depth=30.0, tech="ont", seed=914)
+    try:
+        assert pack.codes.numel() > (1 << 32)
+        chunks = get_chunks([("chr1", 1, L1, "diploid")], cpu=16)
+        assert len(chunks) == 498
+        params = dict(mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6], snp_model="ONT-HG002", seq="ont",
+                      supplementary=False, exclude_bed=None, disable_coverage_normalization=False, sam_path=None)
+        wire = wire_from_device_workload(pack, info)
+        up = WireUploader(eng)
+        t = up.submit(wire)
+        dpk = up.expand(t)
+        torch.cuda.synchronize()
+        assert torch.equal(dpk.codes, pack.codes)                                  # 7.5 GB, byte for byte
+        a = snpCaller.call_chunks(params, chunks, dpk=dpk)
+        up.release(t)
+        del dpk, wire
+        b = snpCaller.call_chunks(params, chunks, dpk=pack)
+        assert a["n"] == b["n"] > 2_000_000
+        for k in ("pos", "chunk", "ref", "dp", "alt", "fwd_dp", "rev_dp", "probs", "gt", "freq"):
+            assert np.array_equal(a[k], b[k]), k
+        r = b
+        ch = r["chunk"].astype(np.int64)
+        assert np.all(np.diff(ch) >= 0) and ch[-1] == 497
+        starts = np.array([c_["start"] for c_ in chunks])[ch]
+        ends = np.array([c_["end"] for c_ in chunks])[ch]
+        assert np.all((r["pos"] >= starts) & (r["pos"] <= ends))
+        assert np.all(np.diff(r["pos"].astype(np.int64))[np.diff(ch) == 0] > 0)
+        shared = np.array([c_["end"] for c_ in chunks[:-1]])
+        hit = np.isin(r["pos"], shared)
+        assert np.count_nonzero(hit) % 2 == 0 and np.count_nonzero(hit) > 0         # a shared boundary column is emitted by both chunks
+        assert np.all((r["probs"] >= 0) & (r["probs"] <= 1)) and np.all(np.isfinite(r["probs"])) and np.abs(r["gt"].sum(1) - 1).max() < 1e-5
+        assert np.all(r["dp"] >= 4) and np.all(r["freq"] >= 0.15)
+        path, cov = get_SNP_model("ONT-HG002")
+        w = Weights(path)
+        for lo_c, hi_c in ((0, 2), (496, 498)):
+            sub = chunks[lo_c:hi_c]
+            h = host_sample_for_oracle(pack, info, max(1, sub[0]["start"] - 50_000), min(L1, sub[-1]["end"] + 50_000))
+            rr = oracle.RawReads("chr1", h["L"], h["start"], h["end"], h["off"], h["codes"], h["strand"], h["keep"])
+            for ci, c in zip(range(lo_c, hi_c), sub):
+                pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
+                sel = r["chunk"] == ci
+                assert np.array_equal(r["pos"][sel], pos) and np.array_equal(r["dp"][sel], dp), ci
+                assert np.array_equal(r["fwd_dp"][sel], fwd) and np.array_equal(r["rev_dp"][sel], rev), ci
+                probs, _ = oracle.snp_forward(w.flat, mat, np.argmax(ref, 1).astype(np.int32), np.full(len(pos), cov / depth), precision="f64")
+                assert np.abs(r["probs"][sel] - probs).max() < 1e-4, ci
+    finally:
+        del pack
+        torch.cuda.empty_cache()
