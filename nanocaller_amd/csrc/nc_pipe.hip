@@ -2105,6 +2105,7 @@ __device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CP
         }
     };
     int i = n1, j = n2, state = -1;
+    int32_t path_score = 0;                                            // (banded route) the score of the path walked: the certificate below compares it with what any path outside the band can reach
     auto step = [&]() {
         uint32_t t;
         if (i == 0) t = T_DEL | (j > 1 ? T_EEXT : 0);
@@ -2112,7 +2113,13 @@ __device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CP
         else t = C ? tbb.code(i, j) : tb.code(i, CPL, fmt);
         if (state < 0) {
             const int w = t & 3;
-            if (w == T_DIAG) { push(s1[i - 1] == s2[j - 1] ? 7 : 8); i--; j--; tb.dec_j(CPL); return; }
+            if (w == T_DIAG) {
+                const bool eq = s1[i - 1] == s2[j - 1];
+                push(eq ? 7 : 8);
+                path_score += eq ? p.match : p.mismatch;
+                i--; j--; tb.dec_j(CPL);
+                return;
+            }
             state = w == T_DEL ? 1 : 2;
         }
         if (state == 1) {
@@ -2120,11 +2127,13 @@ __device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CP
             const bool ext = (t & T_EEXT) != 0;
             j--;
             tb.dec_j(CPL);
+            path_score -= ext ? p.extend : p.open;                     // (walked backwards: the step that is not an extension is the gap's first base)
             if (!ext) state = -1;
         } else {
             push(1);
             const bool ext = (t & T_FEXT) != 0;
             i--;
+            path_score -= ext ? p.extend : p.open;
             if (!ext) state = -1;
         }
     };
@@ -2138,9 +2147,30 @@ __device__ __forceinline__ void allele_trace_body(const BandArgs &bp, int32_t CP
             if (can) step();
         }
     }
-    if (C && tbb.touched) {
-        bp.redo_list[atomicAdd(bp.redo_count, 1)] = al;
-        return;
+    if (C) {
+        // Is the banded optimum THE optimum?  A path that leaves the band [lo, lo + B) reaches diagonal d_out = lo - 1 or lo + B.  From diagonal 0 to d_out and
+        // on to the corner's diagonal D = n2 - n1 it spends at least |d_out| gap bases on one string and |d_out - D| on the other -- two gap runs, and that
+        // many bases of either string that pair with nothing -- so it scores at most
+        //     match x min(n1 - gi, n2 - gj) - (open + (gj - 1) ext) - (open + (gi - 1) ext),     gj / gi = the gap bases in the window / the consensus.
+        // A banded path that scores MORE is optimal over the full matrix, ties included (a co-optimal path through cells outside the band would be a
+        // path that leaves the band and reaches the optimum).  A consensus is its window with a few indels applied: the bound holds for all but a few per
+        // ten thousand sets; the rest, and the paths that touch an edge diagonal, go to the full matrix.  (For the star alignment of 8 % error reads
+        // against the window the same bound proves nothing: that band stays part of the aligner's definition, section 11.4.)
+        constexpr int Bw = 32 * (C ? C : 1);
+        const int D = n2 - n1, lo = tbb.lo;
+        // (0 and D are inside the band: k_allele_classes.)  Above the band: the diagonal rises by d_out window-only bases and falls d_out - D
+        // consensus-only ones; below: it falls -d_out and rises D - d_out.
+        auto ub = [&](int d_out) -> int32_t {
+            const int rise = d_out > 0 ? d_out : D - d_out, fall = d_out > 0 ? d_out - D : -d_out;
+            const int pairs = min(n1 - fall, n2 - rise);
+            if (pairs < 0) return INT32_MIN;                               // no path gets there
+            return p.match * pairs - (p.open + (rise - 1) * p.extend) - (p.open + (fall - 1) * p.extend);
+        };
+        const bool certified = path_score > ub(lo - 1) && path_score > ub(lo + Bw);
+        if (tbb.touched || !certified) {
+            bp.redo_list[atomicAdd(bp.redo_count, 1)] = al;
+            return;
+        }
     }
     if (last_op >= 0 && nr < run_cap) { rop[nr] = (int16_t)last_op; rcn[nr] = (int16_t)last_cnt; nr++; }
     bool indel = false, mm_before = false;
@@ -2784,11 +2814,12 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         BandArgs bb;
         memset(&bb, 0, sizeof bb);
         bb.f = fb;
-        // allele_prediction is an exact global alignment in the reference (parasail nw_trace, generate_indel_pileups.py:79): by default every consensus runs
-        // on the full matrix.  The banded form (NC_PIPE_BAND_ALLELES=1: 1.0 ms less per chr20-sized pass) equals it on every set measured, but the edge
-        // rule is not a proof of optimality, and REF / ALT strings are row a13's bit-exact output -- unlike the star alignment, which stands in for
-        // MUSCLE and is judged by concordance
-        static const bool band_alleles = []() { const char *e = getenv("NC_PIPE_BAND_ALLELES"); return e && atoi(e) != 0; }();
+        // allele_prediction is an exact global alignment in the reference (parasail nw_trace, generate_indel_pileups.py:79), and REF / ALT strings are row
+        // a13's bit-exact output.  The banded form is therefore kept only where it PROVES itself: k_allele_trace_b12 compares the score of the path it
+        // walked with the most any path outside the band can reach (allele_trace_body's certificate) and sends every set it cannot certify -- and every
+        // path that touches an edge diagonal -- to the full matrix.  NC_PIPE_BAND_ALLELES=0: every consensus on the full matrix (+1.0 ms per chr20 pass).
+        const char *bae = getenv("NC_PIPE_BAND_ALLELES");                 // (read per run: the tests switch it)
+        const bool band_alleles = !(bae && atoi(bae) == 0);
         if (band_of[b] && band_alleles) {
             // the consensus against its window on a band around the diagonals 0 .. n2 - n1; too long / too wide / edge-touching ones on the full matrix
             const size_t nz = (size_t)std::max(nset, 1);

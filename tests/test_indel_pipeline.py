@@ -586,3 +586,29 @@ def test_windows_by_16_lanes_equal_the_serial_walk(tmp_path, monkeypatch, window
         assert r["n"] == r0["n"] and bool((r["x"] == r0["x"]).all())
         for k in ("pos", "ref_len", "alt_len"):
             assert np.array_equal(np.asarray(r[k]), np.asarray(r0[k])), (mode, k)
+
+
+@pytest.mark.gpu
+def test_banded_allele_alignments_certify_themselves_or_run_on_the_full_matrix(monkeypatch):
+    """allele_prediction's global alignment (exact in the reference: parasail nw_trace, generate_indel_pileups.py:79) runs on a band only where the
+    band proves itself: the score of the banded path must exceed what any path that leaves the band can reach (allele_trace_body's bound), else
+    the set is re-run on the full matrix.  Every REF / ALT of 8 Mb of the bench workload equals the all-full-matrix run (NC_PIPE_BAND_ALLELES=0),
+    with the band of the STAR alignment switched off in both runs so that the consensus strings are the same"""
+    from nanocaller_amd.engine import get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    eng = get_engine(0)
+    L = 8_000_000
+    pack, reads_c, info = make_indel_device_workload(eng, L, depth=30.0, seed=515)
+    chunks = [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)]
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NC_PIPE_BAND_ALLELES", mode)
+        res[mode] = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw)
+    monkeypatch.delenv("NC_PIPE_BAND_ALLELES")
+    a, b = res["1"], res["0"]
+    assert a["n"] == b["n"] > 3000
+    for k in ("pos", "type", "ref_len", "alt_len", "alt"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert bool((a["x"] == b["x"]).all())
+    assert int((np.asarray(a["ref_len"]) > 0).sum()) > 1000                                   # (alleles were called at all)
