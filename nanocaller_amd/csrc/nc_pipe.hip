@@ -1850,61 +1850,19 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
     const int64_t a0 = p.site_al0[site] - p.A0, a1 = p.site_al0[site + 1] - p.A0;
     const uint8_t *mem = p.al_member + p.A0;
     const uint8_t *s2 = p.ref_code + (p.site_pos[site] - p.ref_pos0);
-    // ---- longest insertion of every set in every slot (slot j = before reference position j; slot n2 = after the last).
+    // ---- ONE sweep over the site's packed entries (round 4 made two: the longest insertion per slot, then the histograms -- the entries are the
+    // kernel's traffic, 0.69 GB a sweep per chr20-sized pass): per slot j (thread j; a second turn for the slots past 255 of the 260-base windows) the
+    // longest insertion of every set (slot j = before reference position j; slot n2 = after the last), the four base counters of the position's own
+    // column in registers, and the insertions onto the block's list.  Neither needs the columns, which come from the insertion widths afterwards.
     // Eight alignments a step, loads first: a load behind a test of the one before it costs a full memory latency each
-    for (int j = tid; j <= n2; j += 256) {
-        int m[3] = {0, 0, 0};
-        for (int64_t a = a0; a < a1; a += 8) {
-            uint32_t en[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) en[u] = p.ent[min(a + u, a1 - 1) * p.EW + j];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (a + u >= a1) continue;
-                const int mb = mem[a + u], L = (int)((en[u] >> 10) & 0x3ffu);
-#pragma unroll
-                for (int t = 0; t < 3; t++)
-                    if (mb & (1 << t)) m[t] = max(m[t], L);        // haploid: one set, member bit 0
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 3; t++) mxv[t][j] = (int16_t)m[t];
-    }
     if (tid == 0) s_nq = 0;
     __syncthreads();
-    // ---- column of every slot's position = running sum of the insertion widths + j: scan over the block (2 slots per thread: n2 + 1 <= 288)
-    for (int t = 0; t < S; t++) {
-        const int j0 = 2 * tid, v0 = j0 <= n2 ? mxv[t][j0] : 0, v1 = j0 + 1 <= n2 ? mxv[t][j0 + 1] : 0;
-        int inc = v0 + v1;
+    uint64_t cntr[2][3] = {{0, 0, 0}, {0, 0, 0}};
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(inc, o, 64);
-            if ((tid & 63) >= o) inc += y;
-        }
-        if ((tid & 63) == 63) wcnt[tid >> 6] = inc;
-        __syncthreads();
-        int wp = 0;
-        for (int w = 0; w < (tid >> 6); w++) wp += wcnt[w];
-        const int before = wp + inc - v0 - v1;
-        if (j0 <= n2) colv[t][j0] = before + v0 + j0;
-        if (j0 + 1 <= n2) colv[t][j0 + 1] = before + v0 + v1 + j0 + 1;
-        if (tid == 255) s_ncols[t] = wp + inc + n2;
-        __syncthreads();
-    }
-    bool ok[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) ok[t] = t < S && s_ncols[t] <= CNS_CAP;      // a longer set: never with real windows; reported, the caller falls back
-    for (int t = 0; t < S; t++)
-        if (ok[t])
-            for (int c = tid; c < s_ncols[t] * 4; c += 256) hist[t][c] = 0;
-    __syncthreads();
-    // ---- symbol histogram of every column of every set
-    for (int j = tid; j <= n2; j += 256) {
-        int cj[3], c0[3];
-#pragma unroll
-        for (int t = 0; t < 3; t++) { cj[t] = t < S ? colv[t][j] : 0; c0[t] = cj[t] - (t < S ? mxv[t][j] : 0); }   // thread j owns the columns c0 .. cj of every read
-        // the position column's four counters of every set live in registers (16-bit fields) for the sweep: a read-modify-write of LDS per
-        // (read, set) was a chain of ~50 dependent LDS round trips, 5/6 of this kernel
+    for (int turn = 0; turn < 2; turn++) {
+        const int j = tid + 256 * turn;
+        if (j > n2) continue;
+        int m[3] = {0, 0, 0};
         uint64_t cnt[3] = {0, 0, 0};
         for (int64_t ab = a0; ab < a1; ab += 8) {
             uint32_t en8[8];
@@ -1935,35 +1893,82 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
                 // (some lane always has one) -- 2/3 of the kernel; from the list every thread takes one insertion
                 const int L = (int)((en >> 10) & 0x3ffu);
                 if (L > 0) {
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+                        if (mb & (1 << t)) m[t] = max(m[t], L);        // haploid: one set, member bit 0
                     const int slot = atomicAdd(&s_nq, 1);
                     if (slot < TQ_CAP) qitems[slot] = make_uint2((uint32_t)(a - a0) | ((uint32_t)j << 16) | ((uint32_t)mb << 25), en >> 10);
-                    else {                                            // (a list longer than the LDS holds: the old way)
-                        const uint8_t *s1 = p.win + a * p.WS + (int)(en >> 20);
-                        for (int v = 0; v < L; v++) {
-                            const int sym = s1[v];
-                            if (sym < 4) {
-#pragma unroll
-                                for (int t = 0; t < 3; t++)
-                                    if ((mb & (1 << t)) && ok[t]) hist_add(t, c0[t] + v, sym);
-                            }
-                        }
-                    }
                 }
             }
         }
-        if (j < n2) {
 #pragma unroll
-            for (int t = 0; t < 3; t++)
-                if (t < S && ok[t]) {
+        for (int t = 0; t < 3; t++) { mxv[t][j] = (int16_t)m[t]; cntr[turn][t] = cnt[t]; }
+    }
+    __syncthreads();
+    // ---- column of every slot's position = running sum of the insertion widths + j: scan over the block (2 slots per thread: n2 + 1 <= 288)
+    for (int t = 0; t < S; t++) {
+        const int j0 = 2 * tid, v0 = j0 <= n2 ? mxv[t][j0] : 0, v1 = j0 + 1 <= n2 ? mxv[t][j0 + 1] : 0;
+        int inc = v0 + v1;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) hist[t][cj[t] * 4 + k] = (HT)((cnt[t] >> (16 * k)) & 0xffffu);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if ((tid & 63) >= o) inc += y;
+        }
+        if ((tid & 63) == 63) wcnt[tid >> 6] = inc;
+        __syncthreads();
+        int wp = 0;
+        for (int w = 0; w < (tid >> 6); w++) wp += wcnt[w];
+        const int before = wp + inc - v0 - v1;
+        if (j0 <= n2) colv[t][j0] = before + v0 + j0;
+        if (j0 + 1 <= n2) colv[t][j0 + 1] = before + v0 + v1 + j0 + 1;
+        if (tid == 255) s_ncols[t] = wp + inc + n2;
+        __syncthreads();
+    }
+    bool ok[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) ok[t] = t < S && s_ncols[t] <= CNS_CAP;      // a longer set: never with real windows; reported, the caller falls back
+    for (int t = 0; t < S; t++)
+        if (ok[t])
+            for (int c = tid; c < s_ncols[t] * 4; c += 256) hist[t][c] = 0;
+    __syncthreads();
+    // ---- the position columns' counters go to their places
+#pragma unroll
+    for (int turn = 0; turn < 2; turn++) {
+        const int j = tid + 256 * turn;
+        if (j >= n2) continue;
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (t < S && ok[t]) {
+                const int cj = colv[t][j];
+#pragma unroll
+                for (int k = 0; k < 4; k++) hist[t][cj * 4 + k] = (HT)((cntr[turn][t] >> (16 * k)) & 0xffffu);
+            }
+    }
+    // (more insertions than the block's list holds -- > 1024 at one site --: every insertion of the site the round-3 way, straight from the entries)
+    if (s_nq > TQ_CAP) {
+        for (int j = tid; j <= n2; j += 256) {
+            int c0[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) c0[t] = t < S ? colv[t][j] - mxv[t][j] : 0;
+            for (int64_t a = a0; a < a1; a++) {
+                const uint32_t en = p.ent[a * p.EW + j];
+                const int L = (int)((en >> 10) & 0x3ffu), mb = mem[a];
+                const uint8_t *s1 = p.win + a * p.WS + (int)(en >> 20);
+                for (int v = 0; v < L; v++) {
+                    const int sym = s1[v];
+                    if (sym < 4) {
+#pragma unroll
+                        for (int t = 0; t < 3; t++)
+                            if ((mb & (1 << t)) && ok[t]) hist_add(t, c0[t] + v, sym);
+                    }
                 }
+            }
         }
     }
     __syncthreads();
     // ---- the inserted bases: one insertion per thread (columns c0 .. c0 + L - 1 of its slot, shared by the reads of a set: atomic adds)
     {
-        const int nq = min(s_nq, TQ_CAP);
+        const int nq = s_nq > TQ_CAP ? 0 : s_nq;
         for (int i = tid; i < nq; i += 256) {
             const uint2 it = qitems[i];
             const int a = (int)(it.x & 0xffffu), j = (int)((it.x >> 16) & 0x1ffu), mb = (int)(it.x >> 25), L = (int)(it.y & 0x3ffu), q0 = (int)(it.y >> 10);
