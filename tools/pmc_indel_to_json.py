@@ -16,6 +16,8 @@ from build_tag import INDEL_SOURCES, build_tag
 STAGE = {"k_hap_depth_b": "k7_scan_anchors_sets", "k_yield_rank_b": "k7_scan_anchors_sets", "k_entry_reads": "k7_scan_anchors_sets",
          "k_entry_cursors": "k7_scan_anchors_sets", "k_event_tiles": "k7_scan_anchors_sets", "k_pick": "k7_scan_anchors_sets", "k_sets": "k7_scan_anchors_sets",
          "k_flatten": "k7_scan_anchors_sets", "k_scan_excl": "k7_scan_anchors_sets", "k_windows": "query_windows",
+         "k_windows16": "query_windows", "k_window_lists": "query_windows", "k_blk_chunks": "k7_scan_anchors_sets",
+         "k_scan_part": "k7_scan_anchors_sets", "k_scan_apply": "k7_scan_anchors_sets",        # (round 5's two-launch scans: plan and allele stage alike, a few KB each)
          # the banded fills of the star alignment AND of allele_prediction (one kernel name; the allele sets are ~1/9 of the cells)
          "k_fill_band": "star_alignment_fill",
          # banded tracebacks + the full-matrix route of the alignments that do not fit a band (star and allele fallbacks share k_fill16q)
