@@ -17,14 +17,25 @@
 
 namespace {
 
-constexpr int LT_BITS = 9, DT_BITS = 6, LT_SZ = 1 << LT_BITS, DT_SZ = 1 << DT_BITS;
-// one lane's LDS, in uint16 units: the two first-level tables, the canonical arrays of both codes (count[16] + sym[]), and the code lengths of
-// the block being set up (bytes; reused as scratch).  A wave's 64 lanes walk these at different places all the time: in scratch memory (HBM
-// latency per access, nothing to hide it behind) the set-up loops and the long-code walk were most of the kernel's 260 ms.
-constexpr int L_LT = 0, L_DT = L_LT + LT_SZ, L_HL = L_DT + DT_SZ, L_HD = L_HL + 16 + 288, L_LENS = L_HD + 16 + 32, L_WALK = L_LENS + 320 / 2, L_END = L_WALK + 4;
-constexpr int TAB_WORDS = (L_END + 1) / 2 | 1;                      // odd pitch in words: lanes spread over the banks
-constexpr int LPW = 8, LPW_SH = 3;                                  // members (= lanes) per workgroup of k_huff, and its log2.  One workgroup's duration is its slowest member's; 64 lanes: 15.7 ms per 14.5 k members, 16: 14.3, 8: 13.3 (eight workgroups per CU, two waves per SIMD), 4: issue-bound
-constexpr int WIN_PITCH = 68;                                       // a lane's window of the compressed stream: 64 dwords (+4: 16-byte aligned, banks spread)
+#ifndef NC_HUFF_DT_BITS
+#define NC_HUFF_DT_BITS 5
+#endif
+constexpr int LT_BITS = 8, DT_BITS = NC_HUFF_DT_BITS, LT_SZ = 1 << LT_BITS, DT_SZ = 1 << DT_BITS;
+// one lane's LDS, in BYTES: the two first-level tables (uint16), the canonical arrays of both codes -- count[16] (uint16) and the symbols by code as
+// BYTES (the literal / length code's ninth bit in a bit mask: 30 of its 286 symbols need it) --, the code lengths of the block being set up as
+// NIBBLES, the walk's start.  [r5] 1,164 + 144 bytes of window = 1,308 per member instead of 2,460: 16 members per workgroup, seven workgroups per
+// CU.  The symbol loop is bound by instruction issue -- a wave instruction costs its four cycles whether 8 or 16 of the 64 lanes are live -- and the
+// members in flight by LDS, so what a member's tables do not take, further lanes do.  (An 8-bit first-level table alone, at 8 lanes a wave, was
+// within 4 % either way in round 4: more WAVES per SIMD do not help an issue-bound loop; more LANES per wave do.)
+#ifndef NC_HUFF_WINPAD
+#define NC_HUFF_WINPAD 4
+#endif
+constexpr int B_LT = 0, B_DT = B_LT + 2 * LT_SZ, B_HLC = B_DT + 2 * DT_SZ, B_HLS = B_HLC + 32, B_HLM = B_HLS + 288, B_HDC = B_HLM + 36, B_HDS = B_HDC + 32,
+              B_LENS = B_HDS + 32, B_WALK = B_LENS + 160, B_END = B_WALK + 8;
+static_assert(B_HLC % 2 == 0 && B_HDC % 2 == 0 && B_WALK % 2 == 0, "uint16 sections");
+constexpr int TAB_WORDS = (B_END + 3) / 4 | 1;                      // odd pitch in words: lanes spread over the banks
+constexpr int LPW = 16, LPW_SH = 4;                                 // members (= lanes) per workgroup of k_huff, and its log2.  One workgroup's duration is its slowest member's
+constexpr int WIN_DW = 32, WIN_PITCH = WIN_DW + NC_HUFF_WINPAD;     // a lane's window of the compressed stream: 32 dwords (+ pad: banks spread), topped up every 8 steps
 
 struct InflateArgs {
     const uint8_t *comp;        // compressed payloads (the buffer is readable 8 bytes past the last payload)
@@ -40,12 +51,33 @@ struct InflateArgs {
 
 struct __attribute__((packed, aligned(4))) U4w { uint32_t x, y, z, w; };   // four dwords at a 4-byte aligned address
 
-// canonical code of up to 288 symbols (RFC 1951 3.2.2) for the walk over the lengths: h[0..16) = count per length, h[16..) = symbols by code
+// canonical code of up to 288 symbols (RFC 1951 3.2.2) for the walk over the lengths: cnt[0..16) = count per length, sym[] = symbols by code (low
+// byte; hi = bit mask of the ninth bits, NULL for a code of < 256 symbols)
+struct Huff {
+    uint16_t *cnt;
+    uint8_t *sym, *hi;
+    __device__ __forceinline__ int at(int pos) const { return sym[pos] | (hi ? ((hi[pos >> 3] >> (pos & 7)) & 1) << 8 : 0); }
+};
+// code lengths as nibbles (the literal / length + distance lengths of a block: 320 symbols in 160 bytes) or as plain bytes (the 19 of the code length code)
+struct LensNib {
+    uint8_t *p;
+    int base;
+    __device__ __forceinline__ int get(int i) const { const int k = base + i; return (p[k >> 1] >> ((k & 1) * 4)) & 15; }
+    __device__ __forceinline__ void set(int i, int v) const { const int k = base + i, sh = (k & 1) * 4; p[k >> 1] = (uint8_t)((p[k >> 1] & ~(15 << sh)) | (v << sh)); }
+};
+struct LensByte {
+    const uint8_t *p;
+    __device__ __forceinline__ int get(int i) const { return p[i]; }
+};
 // lens[0..n) -> h; returns false for an over-subscribed set (an incomplete one is accepted: single-symbol distance codes are legal)
-__device__ bool huff_build(uint16_t *h, const uint8_t *lens, int n)
+template <class L>
+__device__ bool huff_build(const Huff &hf, const L &lens, int n)
 {
+    uint16_t *h = hf.cnt;
     for (int i = 0; i < 16; i++) h[i] = 0;
-    for (int i = 0; i < n; i++) h[lens[i]]++;
+    if (hf.hi)
+        for (int i = 0; i < 36; i++) hf.hi[i] = 0;
+    for (int i = 0; i < n; i++) h[lens.get(i)]++;
     uint16_t offs[16];                                                 // first slot of every length (registers: every index below is a compile-time one)
     offs[0] = 0; offs[1] = 0;
 #pragma unroll
@@ -58,14 +90,15 @@ __device__ bool huff_build(uint16_t *h, const uint8_t *lens, int n)
     }
     if (bad) return false;
     for (int i = 0; i < n; i++) {
-        const int l = lens[i];
+        const int l = lens.get(i);
         if (!l) continue;
         uint16_t o = 0;
 #pragma unroll
         for (int q = 1; q < 16; q++) o = l == q ? offs[q] : o;
 #pragma unroll
         for (int q = 1; q < 16; q++) offs[q] = (uint16_t)(l == q ? offs[q] + 1 : offs[q]);
-        h[16 + o] = (uint16_t)i;
+        hf.sym[o] = (uint8_t)i;
+        if (hf.hi && (i & 256)) hf.hi[o >> 3] = (uint8_t)(hf.hi[o >> 3] | (1 << (o & 7)));
     }
     return true;
 }
@@ -93,8 +126,8 @@ __device__ __forceinline__ uint32_t d_enc(int s)
 
 // first-level table: index = the next `bits` bits of the stream (first bit lowest) -> symbol << 4 | length, 0 where the code is longer
 // (MODE 1: ll_enc(symbol) << 4 | length; 2: d_enc(symbol) << 4 | length)
-template <int MODE = 0>
-__device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uint8_t *lens, int n)
+template <int MODE, class L>
+__device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const L &lens, int n)
 {
     for (int i = 0; i < (1 << bits); i++) tab[i] = 0;
     uint32_t next[16];                                                 // first code of every length (h[0], the unused symbols, takes none)
@@ -106,7 +139,7 @@ __device__ void table_fill(uint16_t *tab, int bits, const uint16_t *h, const uin
         code = (code + h[l]) << 1;
     }
     for (int s = 0; s < n; s++) {
-        const int l = lens[s];
+        const int l = lens.get(s);
         if (!l) continue;
         uint32_t c = 0;
 #pragma unroll
@@ -138,10 +171,13 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
     const int lane = threadIdx.x;
     const int b = blockIdx.x * LPW + lane;
     const bool live = b < a.n;
-    uint16_t *lbase = reinterpret_cast<uint16_t *>(tabs + lane * TAB_WORDS);
-    uint16_t *lt = lbase + L_LT, *dt = lbase + L_DT, *hl = lbase + L_HL, *hd = lbase + L_HD;
-    uint8_t *lens = reinterpret_cast<uint8_t *>(lbase + L_LENS);
-    uint16_t *wk = lbase + L_WALK;
+    uint8_t *lbase = reinterpret_cast<uint8_t *>(tabs + lane * TAB_WORDS);
+    uint16_t *lt = reinterpret_cast<uint16_t *>(lbase + B_LT), *dt = reinterpret_cast<uint16_t *>(lbase + B_DT);
+    const Huff hl = {reinterpret_cast<uint16_t *>(lbase + B_HLC), lbase + B_HLS, lbase + B_HLM};
+    const Huff hd = {reinterpret_cast<uint16_t *>(lbase + B_HDC), lbase + B_HDS, nullptr};
+    const Huff hcl = {reinterpret_cast<uint16_t *>(lbase + B_HLC), lbase + B_HLS, nullptr};      // the code length code (19 symbols) borrows the literal code's arrays
+    const LensNib lens = {lbase + B_LENS, 0}, dlens = {lbase + B_LENS, 288};
+    uint16_t *wk = reinterpret_cast<uint16_t *>(lbase + B_WALK);
     const int bb_ = live ? b : 0;
     const int64_t c0 = a.coff[bb_];
     const int32_t clen = a.clen[bb_], isize = a.isize[bb_];
@@ -166,33 +202,34 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
         return v;
     };
     int rd = 0, wr = 0, pend = 0;                                      // dwords consumed / in the window / loaded but still in registers
-    U4w pre[6];
+    U4w pre[3];
     uint64_t bb = 0;
     int bc = 0, err = 0;
     if (live) {
 #pragma unroll 1
-        for (; wr < 64; wr += 4) *reinterpret_cast<U4w *>(win + wr) = fetch4(wr);
+        for (; wr < WIN_DW; wr += 4) *reinterpret_cast<U4w *>(win + wr) = fetch4(wr);
         bb = (uint64_t)(win[0] >> (8 * skew));
         bc = 32 - 8 * skew;
         rd = 1;
     }
-    // every 16 iterations of a loop that consumes at most 48 bits per iteration: what the previous call loaded goes to the window, the window's
-    // free part is loaded (at most 96 bytes: what 16 iterations can consume, so the window never runs dry: >= 24 dwords after every call)
+    // every 8 iterations of a loop that consumes at most 48 bits per iteration (12 dwords): what the previous call loaded goes to the window, the
+    // window's free part is loaded (at most 12 dwords).  After a call the window holds WIN_DW less what the 8 iterations before it consumed, >= 20
+    // dwords: it never runs dry before the next call
     auto tick = [&]() {
 #pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (q * 4 < pend) *reinterpret_cast<U4w *>(win + ((wr + q * 4) & 63)) = pre[q];
+        for (int q = 0; q < 3; q++)
+            if (q * 4 < pend) *reinterpret_cast<U4w *>(win + ((wr + q * 4) & (WIN_DW - 1))) = pre[q];
         wr += pend;
-        int n4 = (64 - (wr - rd)) >> 2;
-        n4 = n4 > 6 ? 6 : n4;
+        int n4 = (WIN_DW - (wr - rd)) >> 2;
+        n4 = n4 > 3 ? 3 : n4;
 #pragma unroll
-        for (int q = 0; q < 6; q++)
+        for (int q = 0; q < 3; q++)
             if (q < n4) pre[q] = fetch4(wr + q * 4);
         pend = n4 * 4;
     };
     auto refill = [&]() {                                              // at least 33 valid bits afterwards (no branch: the window word is read either way)
         const bool f = bc <= 32;
-        const uint32_t w = win[rd & 63];
+        const uint32_t w = win[rd & (WIN_DW - 1)];
         bb |= f ? (uint64_t)w << (f ? bc : 0) : 0ull;
         err = (f && rd > w_end + 1 && !err) ? 5 : err;
         rd += f;
@@ -204,13 +241,13 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
         bc -= n;
         return v;
     };
-    auto slow = [&](const uint16_t *h) -> int {                        // RFC 1951 decoding, one bit at a time (the code length code)
+    auto slow = [&](const Huff &h) -> int {                            // RFC 1951 decoding, one bit at a time (the code length code)
         int code = 0, first = 0, index = 0;
 #pragma unroll 1
         for (int l = 1; l < 16; l++) {
             code |= (int)take(1);
-            const int cnt = h[l];
-            if (code - cnt < first) return h[16 + index + (code - first)];
+            const int cnt = h.cnt[l];
+            if (code - cnt < first) return h.at(index + (code - first));
             index += cnt;
             first += cnt;
             first <<= 1;
@@ -219,13 +256,13 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
         return -1;
     };
     // the same walk for a code the first-level table has no entry for: it is longer than the table's index, so the walk starts behind those bits
-    auto slow_from = [&](const uint16_t *h, const uint16_t *w, int bits) -> int {
+    auto slow_from = [&](const Huff &h, const uint16_t *w, int bits) -> int {
         int code = (int)(__brev(take(bits)) >> (32 - bits)) << 1, first = w[0], index = w[1];
 #pragma unroll 1
         for (int l = bits + 1; l < 16; l++) {
             code |= (int)take(1);
-            const int cnt = h[l];
-            if (code - cnt < first) return h[16 + index + (code - first)];
+            const int cnt = h.cnt[l];
+            if (code - cnt < first) return h.at(index + (code - first));
             index += cnt;
             first += cnt;
             first <<= 1;
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
             else {
 #pragma unroll 1
                 for (uint32_t i = 0; i < len; i++) {
-                    if ((i & 15) == 0) tick();
+                    if ((i & 7) == 0) tick();
                     refill();
                     tk[(size_t)(nt++) << LPW_SH] = 0x80000000u | take(8);
                 }
@@ -262,18 +299,20 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
         else {
             int nlen = 288, ndist = 30;
             if (type == 1) {
-                for (int i = 0; i < 144; i++) lens[i] = 8;
-                for (int i = 144; i < 256; i++) lens[i] = 9;
-                for (int i = 256; i < 280; i++) lens[i] = 7;
-                for (int i = 280; i < 288; i++) lens[i] = 8;
-                for (int i = 0; i < 30; i++) lens[288 + i] = 5;
+                uint8_t *lb = lbase + B_LENS;                           // (two lengths a byte)
+                for (int i = 0; i < 72; i++) lb[i] = 0x88;              // 0 .. 143: 8
+                for (int i = 72; i < 128; i++) lb[i] = 0x99;            // 144 .. 255: 9
+                for (int i = 128; i < 140; i++) lb[i] = 0x77;           // 256 .. 279: 7
+                for (int i = 140; i < 144; i++) lb[i] = 0x88;           // 280 .. 287: 8
+                for (int i = 144; i < 159; i++) lb[i] = 0x55;           // 30 distance symbols: 5
+                lb[159] = 0;
             } else {
                 refill();
                 nlen = (int)take(5) + 257;
                 ndist = (int)take(5) + 1;
                 const int ncode = (int)take(4) + 4;
                 if (nlen > 286 || ndist > 30) err = 2;
-                uint8_t *cl = reinterpret_cast<uint8_t *>(hd);         // 19 code-length-code lengths, in the distance code's area (built later)
+                uint8_t *cl = lbase + B_HDS;                            // 19 code-length-code lengths, in the distance code's symbol area (built later)
                 for (int i = 0; i < 19; i++) cl[i] = 0;
 #pragma unroll 1
                 for (int i = 0; i < ncode; i++) {
@@ -282,41 +321,41 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
                     const int sym = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) == 0 ? 8 + ((i - 4) >> 1) : 7 - ((i - 5) >> 1);
                     cl[sym] = (uint8_t)take(3);
                 }
-                if (!err && !huff_build(hl, cl, 19)) err = 2;
+                if (!err && !huff_build(hcl, LensByte{cl}, 19)) err = 2;
                 int idx = 0;
 #pragma unroll 1
                 for (int it = 0; !err && idx < nlen + ndist; it++) {
-                    if ((it & 15) == 0) tick();
+                    if ((it & 7) == 0) tick();
                     refill();
-                    const int sym = slow(hl);
+                    const int sym = slow(hcl);
                     if (sym < 0) { err = 2; break; }
-                    if (sym < 16) lens[idx++] = (uint8_t)sym;
+                    if (sym < 16) lens.set(idx++, sym);
                     else {
                         int prev = 0, rep;
                         refill();
                         if (sym == 16) {
                             if (idx == 0) { err = 2; break; }
-                            prev = lens[idx - 1];
+                            prev = lens.get(idx - 1);
                             rep = 3 + (int)take(2);
                         } else if (sym == 17) rep = 3 + (int)take(3);
                         else rep = 11 + (int)take(7);
                         if (idx + rep > nlen + ndist) { err = 2; break; }
-                        while (rep--) lens[idx++] = (uint8_t)prev;
+                        while (rep--) lens.set(idx++, prev);
                     }
                 }
-                if (!err && lens[256] == 0) err = 2;
+                if (!err && lens.get(256) == 0) err = 2;
                 if (!err) {                                            // the distance lengths follow the literal / length ones: move them to their own place
-                    for (int i = ndist - 1; i >= 0; i--) lens[288 + i] = lens[nlen + i];
-                    for (int i = nlen; i < 288; i++) lens[i] = 0;
-                    for (int i = ndist; i < 30; i++) lens[288 + i] = 0;
+                    for (int i = ndist - 1; i >= 0; i--) lens.set(288 + i, lens.get(nlen + i));
+                    for (int i = nlen; i < 288; i++) lens.set(i, 0);
+                    for (int i = ndist; i < 30; i++) lens.set(288 + i, 0);
                 }
             }
-            if (!err && (!huff_build(hl, lens, 288) || !huff_build(hd, lens + 288, 30))) err = 2;
+            if (!err && (!huff_build(hl, lens, 288) || !huff_build(hd, dlens, 30))) err = 2;
             if (!err) {
-                table_fill<1>(lt, LT_BITS, hl, lens, 288);
-                table_fill<2>(dt, DT_BITS, hd, lens + 288, 30);
-                walk_start(wk, LT_BITS, hl);
-                walk_start(wk + 2, DT_BITS, hd);
+                table_fill<1>(lt, LT_BITS, hl.cnt, lens, 288);
+                table_fill<2>(dt, DT_BITS, hd.cnt, dlens, 30);
+                walk_start(wk, LT_BITS, hl.cnt);
+                walk_start(wk + 2, DT_BITS, hd.cnt);
             }
             // ---- the symbols of the block: the loop the kernel lives in.  ONE straight line of code for literals and matches alike: a wave
             // executes the union of its lanes' paths anyway, and as branches that union cost 210 instructions a step (a third of them exec-mask
@@ -324,7 +363,7 @@ __global__ __launch_bounds__(LPW) void k_huff(InflateArgs a, uint32_t *tok, int3
             bool run = !err;
 #pragma unroll 1
             for (int it = 0; run; it++) {
-                if ((it & 15) == 0) tick();
+                if ((it & 7) == 0) tick();
                 refill();
                 const uint32_t e = lt[(uint32_t)bb & (LT_SZ - 1)];
                 uint32_t code = e >> 4;                                  // ll_enc of the symbol

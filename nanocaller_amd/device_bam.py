@@ -32,14 +32,16 @@ from .synth import FLAG_FILTER_DEFAULT, FLAG_FILTER_SUPPL
 META_COLS = 12
 (M_REFID, M_POS, M_FLAG, M_RLEN, M_LSEQ, M_HASSEQ, M_HAP, M_PS, M_HASH_LO, M_HASH_HI, M_NCIG, M_CIGD) = range(META_COLS)
 CHECK_CRC = os.environ.get("NC_BGZF_CRC", "1") != "0"     # CRC-32 of every inflated member on the device (NC_BGZF_CRC=0: lengths only, as in round 4)
-INFLATE_BATCH = 16384            # members per nc_inflate_device call (4 GB of token workspace)
+TRACE_LOAD = os.environ.get("NC_LOAD_TRACE") == "1"
+LZ_SERIAL = os.environ.get("NC_LZ_SERIAL", "0") == "1"     # the match resolution behind the Huffman kernel on ONE stream instead of beside the next batch's
+INFLATE_BATCH = int(os.environ.get("NC_INFLATE_BATCH", 28672))   # members per nc_inflate_device call: one full round of k_huff (256 CUs x 7 workgroups x 16 lanes); 7.5 GB of token workspace each, two in flight
 POOL_MAX = 16 << 30              # buffers up to this size stay allocated between loads (larger ones go back to the allocator after use)
 MAX_RESIDENT = 96 << 30          # upper bound of the inflated bytes kept in HBM at once; resident_limit() lowers it to what the device has free
 
 
 def resident_limit(device=0):
     """inflated bytes one share of a file may take on `device`: the loader holds the stream (sized 8 x + 12.5 % of the compressed bytes), the file
-    image (1/8 of the stream) and <= 8 GB of tokens; the read packs, the indel pipeline's workspaces and the CNN's need room beside them -- half of
+    image (1/8 of the stream) and <= 8 GB of tokens; the read packs, the indel pipeline's workspaces and the CNN's need room beside them (two token workspaces of 7.5 GB at the default batch) -- half of
     what is free now (plus what this module's own pools already hold), at most MAX_RESIDENT"""
     try:
         free, _total = torch.cuda.mem_get_info(device)
@@ -295,18 +297,22 @@ class DeviceBam:
         lz_stream.wait_stream(compute)                                   # (the output buffer's allocation)
         n_batches = [0]
         n_mem, m0, scan_pos, total, statuses, keep = 0, 0, 0, 0, [], []
+        traces = []
 
-        def launch(m1):
-            nonlocal m0
-            a_byte = int(coff[m0 - 1]) + int(clen[m0 - 1]) + 8 if m0 else 0   # (from the batch's first member; the headers ride along)
-            b_byte = int(coff[m1 - 1]) + int(clen[m1 - 1]) + 8
-            k = m1 - m0
-            with torch.cuda.stream(copy_stream):
-                d_file[a_byte:b_byte].copy_(self.host_buf[a_byte:b_byte], non_blocking=True)
-                d64 = stage64[m0:m1].to(dev, non_blocking=True), stage64[cap + m0:cap + m1].to(dev, non_blocking=True)
-                d32 = stage32[m0:m1].to(dev, non_blocking=True), stage32[cap + m0:cap + m1].to(dev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
+        pending = []                                                     # the batch whose bytes are on their way and whose kernels are not enqueued yet
+
+        def kernels():
+            """the inflate of the pending batch.  It is enqueued AFTER the next batch's copy: a host-to-device copy submitted while k_huff runs was
+            seen to start only when that kernel ended (batch i + 1's 20 ms of PCIe behind batch i's 27 ms of Huffman decoding instead of under them)"""
+            if not pending:
+                return
+            k, d64, d32, ev, tr, t_host, nbytes = pending.pop()
+
+            def mark(stream, what):
+                if tr is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(stream)
+                    tr.append((what, e))
             compute.wait_event(ev)
             st = torch.zeros(k, dtype=torch.int32, device=dev)
             d_tok, d_ntok, lz_done = toks[n_batches[0] & 1]
@@ -314,20 +320,50 @@ class DeviceBam:
             if lz_done[0] is not None:
                 compute.wait_event(lz_done[0])                           # the workspace's previous tokens have been resolved
             args = (k, vp(d_file), vp(d64[0]), vp(d32[0]), vp(self.raw), vp(d64[1]), vp(d32[1]), vp(st), vp(d_tok), vp(d_ntok))
+            mark(compute, "huff0")
             eng._check(L.nc_inflate_device_phase(eng.ctx, 1, *args), "nc_inflate_device_phase")
+            mark(compute, "huff1")
             huffed = torch.cuda.Event()
             huffed.record(compute)
-            with torch.cuda.stream(lz_stream):
-                lz_stream.wait_event(huffed)
+            with torch.cuda.stream(compute if LZ_SERIAL else lz_stream):
+                (compute if LZ_SERIAL else lz_stream).wait_event(huffed)
                 eng.use_torch_stream()
+                mark(compute if LZ_SERIAL else lz_stream, "lz0")
                 eng._check(L.nc_inflate_device_phase(eng.ctx, 2, *args), "nc_inflate_device_phase")
+                mark(compute if LZ_SERIAL else lz_stream, "lz1")
                 if CHECK_CRC:                                            # what htslib does for every block it inflates: the member's CRC-32 against its trailer
                     eng._check(L.nc_bgzf_crc_device(eng.ctx, *args[:8]), "nc_bgzf_crc_device")
+                mark(compute if LZ_SERIAL else lz_stream, "crc1")
                 lz_done[0] = torch.cuda.Event()
-                lz_done[0].record(lz_stream)
+                lz_done[0].record(compute if LZ_SERIAL else lz_stream)
+            if tr is not None:
+                traces.append((t_host, k, nbytes, tr))
             eng.use_torch_stream()
             statuses.append(st)
             keep.append((d64, d32))                                      # (allocated on the copy stream, read on the compute stream: alive until the sync)
+
+        def launch(m1):
+            nonlocal m0
+            a_byte = int(coff[m0 - 1]) + int(clen[m0 - 1]) + 8 if m0 else 0   # (from the batch's first member; the headers ride along)
+            b_byte = int(coff[m1 - 1]) + int(clen[m1 - 1]) + 8
+            k = m1 - m0
+            tr = [] if TRACE_LOAD else None
+            with torch.cuda.stream(copy_stream):
+                if tr is not None:                                       # (NC_LOAD_TRACE=1: where a load's time goes, by events)
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(copy_stream)
+                    tr.append(("copy0", e))
+                d_file[a_byte:b_byte].copy_(self.host_buf[a_byte:b_byte], non_blocking=True)
+                if tr is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(copy_stream)
+                    tr.append(("copy1", e))
+                d64 = stage64[m0:m1].to(dev, non_blocking=True), stage64[cap + m0:cap + m1].to(dev, non_blocking=True)
+                d32 = stage32[m0:m1].to(dev, non_blocking=True), stage32[cap + m0:cap + m1].to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            kernels()                                                    # the batch before this one
+            pending.append((k, d64, d32, ev, tr, time.perf_counter() - t_start, b_byte - a_byte))
             m0 = m1
         try:
             t_wait = t_launch = 0.0
@@ -363,6 +399,7 @@ class DeviceBam:
                 raise _lib.NanoCallerHipError("%s does not end with a whole BGZF member" % self.path)
             while n_mem > m0:
                 launch(min(n_mem, m0 + batch))
+            kernels()
         finally:
             pool.shutdown(wait=True)
             os.close(fd)
@@ -382,6 +419,10 @@ class DeviceBam:
             raise _lib.NanoCallerHipError("%s: %d BGZF members are not valid deflate streams of their announced size%s"
                                           % (self.path, bad - crc, (", %d fail their CRC-32" % crc) if crc else ""))
         compute.wait_stream(lz_stream)
+        if traces:
+            e0 = traces[0][3][0][1]
+            for t_host, k_, nb_, tr_ in traces:
+                print("  batch of %d members, %.0f MB, enqueued at %.1f ms: " % (k_, nb_ / 1e6, t_host * 1e3) + ", ".join("%s %.1f" % (w, e0.elapsed_time(e)) for w, e in tr_), flush=True)
         del toks, d_file, keep, statuses
         self.host_buf = None
         LAST_LOAD["inflate_wait"] = time.perf_counter() - t0
