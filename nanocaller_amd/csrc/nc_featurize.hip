@@ -35,7 +35,10 @@ __constant__ ModeTab MODES[5] = {
     {4, 20000, {{0, 2000, 4, 1}, {2000, 5000, 5, 0}, {5000, 10000, 5, 0}, {10000, 20000, 6, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}},
 };
 
-constexpr int NBR_IDX_SHIFT = 10;   // coarse index granularity: first neighbour site >= every 1024th position
+#ifndef NC_NBR_IDX_SHIFT
+#define NC_NBR_IDX_SHIFT 10
+#endif
+constexpr int NBR_IDX_SHIFT = NC_NBR_IDX_SHIFT;   // coarse index granularity: first neighbour site >= every 2^shift-th position
 
 __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int64_t key, const int32_t *cidx, int32_t cidx_pos0, int n_cidx)
 {
@@ -340,6 +343,193 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
     }
 }
 
+// ---- [r5] the same tensors with lanes as (read, column) PAIRS.  k_featurize walks the sampled reads one after the other with scalar code (the
+// entry record of a read by v_readlane, 41 of 64 lanes busy, ~45 vector + scalar instructions per read); here the covering reads' records go to an
+// LDS list and the wave sweeps the reads x columns rectangle 64 pairs a step, four steps' gathers in flight: no scalar walk, every lane busy,
+// counters by LDS atomic adds (at most the two reads that share a step meet on one counter).  int16 tensors, maxcov <= 255.
+__global__ __launch_bounds__(256) void k_featurize_pairs(FeatArgs a)
+{
+    __shared__ int32_t nlist[4][64];
+    __shared__ uint4 rec[4][MAXCOV_SMALL];                         // sampled reads with a base at the centre: row address, first position, span | centre base << 28
+    __shared__ int32_t colL[4][64];
+    __shared__ uint32_t cntL[4][41 * 4 + 4];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nblk = (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int s = blk * 4 + wv;
+    if (s >= a.n_sites) return;
+    const int32_t v = __builtin_amdgcn_readfirstlane(a.site_pos[s]);
+    const int32_t ch = __builtin_amdgcn_readfirstlane(a.site_chunk[s]);
+    const int64_t win_lo = max((int64_t)1, (int64_t)a.chunk_start[ch] - NC_FLANK);
+    const int64_t win_hi = (int64_t)a.chunk_end[ch] + NC_FLANK;
+    const ModeTab &M = MODES[a.mode];
+    const int nb = M.nb;
+    // the pileup's first 64 entries and their bases at v are requested NOW: three dependent loads (tile range -> entry -> base) that run under
+    // the neighbour search instead of behind it
+    const int t = (v - a.tile_pos0) >> a.tile_shift;
+    const int e0 = __builtin_amdgcn_readfirstlane(a.tile_off[t]), e1 = __builtin_amdgcn_readfirstlane(a.tile_off[t + 1]);
+    nc_tile_entry pf_ent;
+    pf_ent.start = 0; pf_ent.end = 0; pf_ent.base_flag = 0;
+    int pf_code = 4;
+    if (e0 + lane < e1) {
+        pf_ent = a.tile_ent[e0 + lane];
+        if (pf_ent.start <= v && v < pf_ent.end) pf_code = a.codes[(pf_ent.base_flag & ~int64_t(15)) + v];
+    }
+    const int rc_centre = a.ref_code[(int64_t)v - a.ref_pos0];
+    // ---- K2 (as k_featurize)
+    int take = 0, idx0 = 0;
+    if (lane < 2 * nb) {
+        const bool left = lane < nb;
+        const Bucket B = M.b[left ? nb - 1 - lane : lane - nb];
+        const int64_t dhi = min((int64_t)B.dhi, (int64_t)M.W - 1);
+        int64_t pmin = left ? (int64_t)v - dhi : (int64_t)v + B.dlo + 1;
+        int64_t pmax = left ? (int64_t)v - B.dlo - 1 : (int64_t)v + dhi;
+        pmin = max(pmin, win_lo);
+        pmax = min(pmax, win_hi);
+        if (pmin <= pmax) {
+            const int lo = lower_bound_i32(a.nbr_pos, a.n_nbr, pmin, a.cidx, a.cidx_pos0, a.n_cidx);
+            const int hi = lower_bound_i32(a.nbr_pos, a.n_nbr, pmax + 1, a.cidx, a.cidx_pos0, a.n_cidx);
+            take = min(hi - lo, B.k);
+            const bool first = left ? (B.far != 0) : (B.far == 0);
+            idx0 = first ? lo : hi - take;
+        }
+    }
+    int incl = take;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    const int excl = incl - take;
+    const int nl = __builtin_amdgcn_readlane(incl, nb - 1);
+    const int ntot = __builtin_amdgcn_readlane(incl, 2 * nb - 1);
+    const int ncols = ntot + 1;
+    int32_t col = v;
+    for (int i = 0; i < take; i++) nlist[wv][excl + i] = idx0 + i;
+    for (int i = lane; i < 41 * 4; i += 64) cntL[wv][i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int jj = lane < nl ? lane : lane - 1;
+        if (lane != nl && lane < ncols) col = a.nbr_pos[nlist[wv][jj]];
+    }
+    const bool active = lane < ncols;
+    colL[wv][lane] = col;
+    const int rc_col = active ? a.ref_code[(int64_t)col - a.ref_pos0] : 4;
+    // ---- the pileup at v: depth ballots, and the sampled reads' records into the list
+    const bool ok = ncols >= a.min_nbr_sites;
+    int n_all = 0, nsel = 0;
+    int fw[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int e = eb + lane;
+        bool cov = false;
+        int code = 4, strand = 0;
+        uint4 rr = make_uint4(0, 0, 0, 0);
+        if (e < e1) {
+            nc_tile_entry ent = pf_ent;
+            if (eb != e0) ent = a.tile_ent[e];
+            cov = ent.start <= v && v < ent.end;
+            const uint64_t row = (uint64_t)(uintptr_t)a.codes + (uint64_t)((ent.base_flag & ~int64_t(15)) + ent.start);
+            rr = make_uint4((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)ent.start, (uint32_t)(ent.end - ent.start));
+            if (cov) {
+                code = eb == e0 ? pf_code : (int)a.codes[(ent.base_flag & ~int64_t(15)) + v];
+                strand = (int)(ent.base_flag & 1);
+            }
+        }
+        unsigned long long m = __ballot(cov);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned long long mb = __ballot(cov && code == b), f = __ballot(cov && code == b && strand == 0);
+            fw[b] += __popcll(f);
+            rv[b] += __popcll(mb & ~f);
+        }
+        const int room = a.maxcov - n_all;
+        n_all += __popcll(m);
+        if (!ok || room <= 0) continue;
+        while (__popcll(m) > room) m &= ~(1ull << (63 - __builtin_clzll(m)));   // deeper than maxcov: the first maxcov in coordinate order
+        const bool sel = ((m >> lane) & 1ull) && code < 4;                     // (a read deleted at the centre counts nowhere)
+        const unsigned long long ms = __ballot(sel);
+        if (sel) {
+            rr.w |= (uint32_t)code << 28;
+            rec[wv][nsel + __popcll(ms & ((1ull << lane) - 1ull))] = rr;
+        }
+        nsel += __popcll(ms);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- reads x columns, 64 pairs a step
+    {
+        typedef const uint8_t __attribute__((address_space(1))) *gbyte_ptr;
+        const int P = nsel * ncols;
+        const float inv = 1.0f / (float)ncols;
+#ifndef NC_FEAT_U
+#define NC_FEAT_U 8
+#endif
+        constexpr int U = NC_FEAT_U;                                   // steps whose gathers are in flight together
+        for (int p0 = 0; p0 < P; p0 += 64 * U) {
+            int jk[U];
+            uint32_t bc[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int p = p0 + u * 64 + lane;
+                const bool valid = p < P;
+                const int r = (int)(((float)p + 0.5f) * inv), j = p - r * ncols;           // exact: p < 2^14, the product's error is far below 0.5 / 41
+                const uint4 rr = rec[wv][valid ? r : 0];
+                const uint32_t off = (uint32_t)(colL[wv][valid ? j : 0] - (int32_t)rr.z);
+                bc[u] = 4;
+                jk[u] = j * 4 + (int)(rr.w >> 28);
+                if (valid && off < (rr.w & 0x0fffffffu)) bc[u] = ((gbyte_ptr)(uintptr_t)(((uint64_t)rr.y << 32) | rr.x))[off];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (bc[u] < 4) atomicAdd(&cntL[wv][jk[u]], 1u << (8 * bc[u]));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ns = min(n_all, a.maxcov);
+    // ---- assemble (Appendix A step 5), one tensor column per lane
+    {
+        const int o = NBR - nl;
+        const int src = lane - o;
+        const bool have = ok && lane < 41 && src >= 0 && src < ncols;
+        const int sl = have ? src : 0;
+        const int rc_s = __shfl(rc_col, have ? src : lane, 64);
+        if (lane < 41) {
+            int16_t *dst = reinterpret_cast<int16_t *>(a.x) + (int64_t)s * NC_SNP_TENSOR + lane * 5;
+            typedef uint32_t __attribute__((aligned(2))) u32_a2;
+            auto put_row = [&](int row, int v0, int v1, int v2, int v3, int v4) {
+                int16_t *d = dst + row * (41 * 5);
+                *reinterpret_cast<u32_a2 *>(d) = (uint32_t)(v0 & 0xffff) | ((uint32_t)v1 << 16);
+                *reinterpret_cast<u32_a2 *>(d + 2) = (uint32_t)(v2 & 0xffff) | ((uint32_t)v3 << 16);
+                d[4] = (int16_t)v4;
+            };
+            const int rcs = have ? rc_s : 4;
+            put_row(0, rcs == 0, rcs == 1, rcs == 2, rcs == 3, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t cs = have ? cntL[wv][sl * 4 + i] : 0u;
+                int vv[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int val = (int)((cs >> (8 * b)) & 0xffu);
+                    vv[b] = b == rcs ? -val : val;
+                }
+                put_row(1 + i, vv[0], vv[1], vv[2], vv[3], (have && i == rc_centre) ? 1 : 0);
+            }
+        }
+    }
+    if (lane == 0) {
+        a.ref_out[s] = rc_centre;
+        a.depth[s] = ns;
+        a.valid[s] = ok ? 1 : 0;
+    }
+    if (lane < 4) {
+        a.fwd[s * 4 + lane] = fw[lane];
+        a.rev[s * 4 + lane] = rv[lane];
+    }
+}
+
 // coarse index over the sorted neighbour sites: cidx[b] = lower_bound(nbr_pos, pos0 + b*1024)
 __global__ void k_nbr_index(const int32_t *__restrict__ nbr_pos, int n_nbr, int32_t pos0, int n_cidx, int32_t *__restrict__ cidx)
 {
@@ -435,7 +625,11 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
                        (int32_t *)ctx->nbr_idx.p);
     const dim3 grid((ctx->n_sites + 3) / 4);
     if (maxcov < MAXCOV_SMALL) {                            // 8-bit counter fields: at most 255 sampled reads
-        if (a.x_i16) hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, true>), grid, dim3(256), 0, ctx->stream, a);
+        // int16 tensors (the product path): lanes as (read, column) pairs (k_featurize_pairs); NC_FEAT_PAIRS=0: the scalar-driven read walk
+        // (read per call: A/B checks)
+        const char *fp = getenv("NC_FEAT_PAIRS");
+        if (a.x_i16 && !(fp && atoi(fp) == 0)) hipLaunchKernelGGL(k_featurize_pairs, grid, dim3(256), 0, ctx->stream, a);
+        else if (a.x_i16) hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, true>), grid, dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, false>), grid, dim3(256), 0, ctx->stream, a);
     } else {
         if (a.x_i16) hipLaunchKernelGGL((k_featurize<MAXCOV_CAP, true>), grid, dim3(256), 0, ctx->stream, a);
