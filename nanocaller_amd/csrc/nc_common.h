@@ -23,6 +23,9 @@ struct nc_weights {
     float x_limit = 0.0f;      // largest |input value| for which the L1 norms of conv1-3 prove that no activation reaches the fp16 clamp
 };
 
+// words per tile entry of the K7 cursor table (k_entry_cursors, nc_indel.hip) for spt 1024-column blocks per tile
+#define NC_ENT_CUR_PITCH(spt) (2 * (spt) + 3)
+
 struct nc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;

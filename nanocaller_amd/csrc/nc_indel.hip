@@ -424,7 +424,9 @@ constexpr int EV_SUB = 1024, EV_MARGIN = 256, EV_CAP = 2048, EV_NT = NC_EV_NT;
 
 // read index of every tile entry (its slot offset is unique) and its event cursors: for the tile's 1024-column blocks h = 0 .. SPT-1 (and the
 // one after the tile) the first event of the read at or after (tile start + 1024 h - EV_BACK).  Once per call, one wave per tile, so that
-// the blocks of k_event_tiles find an entry's events by a walk of a few steps instead of two bisections each (a third of that kernel)
+// the blocks of k_event_tiles find an entry's events by a walk of a few steps instead of two bisections each (a third of that kernel).
+// Row of an entry (NC_ENT_CUR_PITCH(SPT) words): [0 .. SPT] those cursors, [SPT + 1] / [SPT + 2] the read's event range, [SPT + 3 + h] the
+// first event at or after the START of block h + 1 (exact: where block h's events end)
 constexpr int EV_BACK = 64;
 __global__ __launch_bounds__(64) void k_entry_cursors(const int32_t *__restrict__ tile_off, const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
                                                       int32_t tile_size, const int64_t *__restrict__ slot_off, int32_t n_reads,
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(64) void k_entry_cursors(const int32_t *__restrict_
         ent_read[e] = lo;
         const int eb = ev_off[lo + 1];
         int x = ev_off[lo];
+        int32_t *row = ent_cur + (int64_t)e * NC_ENT_CUR_PITCH(SPT);
         for (int h = 0; h <= SPT; h++) {
             const int32_t want = t_lo + h * 1024 - EV_BACK;
             int y = eb;                                                // (the cursors ascend: each search starts at the one before)
@@ -451,10 +454,27 @@ __global__ __launch_bounds__(64) void k_entry_cursors(const int32_t *__restrict_
                 const int mid = (x + y) >> 1;
                 if (ev_pos[mid] < want) x = mid + 1; else y = mid;
             }
-            ent_cur[(int64_t)e * (SPT + 3) + h] = x;
+            row[h] = x;
+            if (h > 0) {
+                // the exact cursor of the block's start (= the end of block h - 1's events): a few events past the one EV_BACK columns before it
+                const int32_t edge = t_lo + h * 1024;
+                int z = x, zy = min(eb, x + 16);
+                while (z < zy) {
+                    const int mid = (z + zy) >> 1;
+                    if (ev_pos[mid] < edge) z = mid + 1; else zy = mid;
+                }
+                if (z == x + 16 && z < eb && ev_pos[z] < edge) {
+                    zy = eb;
+                    while (z < zy) {
+                        const int mid = (z + zy) >> 1;
+                        if (ev_pos[mid] < edge) z = mid + 1; else zy = mid;
+                    }
+                }
+                row[SPT + 3 + (h - 1)] = z;
+            }
         }
-        ent_cur[(int64_t)e * (SPT + 3) + SPT + 1] = ev_off[lo];       // the read's event range rides along: k_event_tiles needs neither the read's index
-        ent_cur[(int64_t)e * (SPT + 3) + SPT + 2] = eb;               // nor ev_off (two levels of dependent loads less per workgroup)
+        row[SPT + 1] = ev_off[lo];                                     // the read's event range rides along: k_event_tiles needs neither the read's index
+        row[SPT + 2] = eb;                                             // nor ev_off (two levels of dependent loads less per workgroup)
     }
 }
 
@@ -489,6 +509,27 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
     const int32_t w_lo = max(c.lo, b_lo - EV_MARGIN);             // LDS window of the rank array
     if (tid == 0) { sh_k0 = INT32_MAX; sh_k1 = -1; sh_mlo = c.lo; }
     for (int i = tid; i < 8 * EV_SUB / 2; i += EV_NT) (&difw[0][0])[i] = 0x40004000u;
+    // The entries of the block, FAST form: events from the cursor EV_BACK columns before the block to the exact cursor of the next block's start
+    // -- no load depends on the margin, so the entry + cursor-row loads run beside the rank window's.  Events outside [c.lo, b_hi] are dropped one
+    // by one (rkf below); events before the margin but inside the chunk are harmless: their intervals end before the block's first rank and are
+    // clipped to it (+1 and -1 cancel), and a chain they extend to the left covers the same ranks of the block.  The fast form holds when the margin
+    // starts at or after m_fix (block-uniform; else: excluded / empty stretches) and the tiles' entries fit one batch; otherwise the general walk.
+    const int32_t m_fix = max(c.lo, b_lo - EV_BACK);
+    const int t_fix = max(0, (m_fix - tile_pos0) / tile_size);    // t or t - 1
+    const int fe0 = tile_off[t_fix], fe_t = tile_off[t], fe1 = tile_off[t + 1];
+    const bool fast_ok = fe1 - fe0 <= 256;
+    nc_tile_entry f_ent = {0, 0, 0};
+    int f_x0 = 0, f_x1 = 0;
+    const bool f_on = fast_ok && tid < 256 && fe0 + tid < fe1;
+    const int f_tt = fe0 + tid >= fe_t ? t : t_fix;
+    if (f_on) {
+        const int e = fe0 + tid;
+        f_ent = tile_ent[e];
+        const int32_t *row = ent_cur + (int64_t)e * NC_ENT_CUR_PITCH(SPT);
+        const int hq = rel % SPT;
+        f_x0 = f_tt == t ? row[hq] : row[SPT];
+        f_x1 = f_tt == t ? row[SPT + 3 + hq] : row[SPT + 2];
+    }
     __syncthreads();
     {
         int32_t kmin = INT32_MAX, kmax = -1;                         // first / last yielded rank of the block's own columns
@@ -503,6 +544,18 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             kmax = max(kmax, __shfl_xor(kmax, o, 64));
         }
         if (lane == 0) { atomicMin(&sh_k0, kmin); atomicMax(&sh_k1, kmax); }
+    }
+    int f_cnt = 0;                                                   // (everything but `fast` itself is known here: one register lives on)
+    {
+        const int32_t ft_lo = tile_pos0 + f_tt * tile_size;
+        const bool mine = f_tt == t || f_ent.end <= ft_lo + tile_size;
+        const int hp = (int)((f_ent.base_flag >> 1) & 3);
+        if (f_on && mine && f_ent.start <= b_hi && f_ent.end > m_fix && (haploid || hp == 1 || hp == 2)) {
+            f_cnt = max(f_x1 - f_x0, 0);
+            en_e0[tid] = f_x0;
+            en_lim[tid] = f_x1;
+            en_h[tid] = (uint8_t)(haploid ? 0 : hp - 1);
+        }
     }
     __syncthreads();
 #ifdef NC_ABL_EVT_A
@@ -542,21 +595,26 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
         const bool ins = sl > 0;
         return cls < 2 ? (ln > 2 && ln <= 50 && ins == (cls == 1)) : (ln <= 10 && ins == (cls == 3));
     };
-    const int t_first = max(0, (m_lo - tile_pos0) / tile_size);
+    auto rkf = [&](int32_t p) { return (p < c.lo || p > b_hi) ? -1 : rk(p); };      // (an event off the block's columns counts as on an excluded one)
+    const bool fast = fast_ok && m_lo >= m_fix;
+    if (fe1 - fe0 > 16000 && tid == 0) atomicOr(err_bits, 8);    // more reads than a 16-bit field counts interval ends for: the caller takes the other route
+    const int t_first = fast ? t : max(0, (m_lo - tile_pos0) / tile_size);
     for (int tt = t_first; tt <= t; tt++) {
         const int32_t tt_lo = tile_pos0 + tt * tile_size;
-        const int e0 = tile_off[tt], e1 = tile_off[tt + 1];
-        if (e1 - e0 > 16000 && tid == 0) atomicOr(err_bits, 8);    // more reads than a 16-bit field counts interval ends for: the caller takes the other route
+        const int e0 = fast ? fe0 : tile_off[tt], e1 = fast ? fe0 + 1 : tile_off[tt + 1];          // (fast: one batch)
+        if (e1 - e0 > 16000 && tid == 0) atomicOr(err_bits, 8);
         for (int eb0 = e0; eb0 < e1; eb0 += 256) {
             // ---- one entry per thread: its read, the read's events in [m_lo, b_hi]
             int cnt = 0;
             const int e = eb0 + tid;
+            if (fast) cnt = f_cnt;
+            else
             if (tid < 256 && e < e1) {
                 // two levels of loads: the entry and its row of the cursor table (cursors of this block and the next, the read's event range); then the
                 // events either side of both cursors, all at once.  The haplotype tag sits in the entry.  (Round 4 walked: entry -> read -> tag, event
                 // range -> cursors -> one event per step: eight dependent loads per workgroup, a third of the kernel.)
                 const nc_tile_entry ent = tile_ent[e];
-                const int32_t *cur = ent_cur + (int64_t)e * (SPT + 3);
+                const int32_t *cur = ent_cur + (int64_t)e * NC_ENT_CUR_PITCH(SPT);
                 const int hq = tt == t ? rel % SPT : SPT;
                 int x0 = cur[hq], x1 = tt == t ? cur[hq + 1] : cur[SPT + 2];
                 const int ea = cur[SPT + 1], eb = cur[SPT + 2];
@@ -624,7 +682,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                     const int lo = own[idx];
                     const int ev = en_e0[lo] + (idx - en_pre[lo]);
                     const int32_t sl = ev_len[ev];
-                    evk[idx] = rk(ev_pos[ev]);
+                    evk[idx] = rkf(ev_pos[ev]);
                     evq[idx] = (uint8_t)((qualifies(sl, 0) ? 1 : 0) | (qualifies(sl, 1) ? 2 : 0) | (qualifies(sl, 2) ? 4 : 0) | (qualifies(sl, 3) ? 8 : 0));
                 }
                 __syncthreads();
@@ -678,7 +736,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                 const int j = lo, ef = en_e0[j], el = en_lim[j], h = en_h[j];
                 const int ev = ef + (idx - en_pre[j]);
                 const int32_t p = ev_pos[ev], sl = ev_len[ev];
-                const int k = rk(p);
+                const int k = rkf(p);
                 if (k < 0) continue;                                              // excluded column
 #pragma unroll
                 for (int cls = 0; cls < 4; cls++) {
@@ -686,13 +744,13 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                     const int w = cls < 2 ? win : small_win;
                     bool has_prev = false, has_next = false;
                     for (int e2 = ev - 1; e2 >= ef; e2--) {
-                        const int k2 = rk(ev_pos[e2]);
+                        const int k2 = rkf(ev_pos[e2]);
                         if (k2 < 0) continue;
                         if (k - k2 > w - 1) break;
                         if (qualifies(ev_len[e2], cls)) { has_prev = true; break; }
                     }
                     for (int e2 = ev + 1; e2 < el; e2++) {
-                        const int k2 = rk(ev_pos[e2]);
+                        const int k2 = rkf(ev_pos[e2]);
                         if (k2 < 0) continue;
                         if (k2 - k > w - 1) break;
                         if (qualifies(ev_len[e2], cls)) { has_next = true; break; }
@@ -881,7 +939,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
     if (tiles) {
         const int SPT = tile / EV_SUB;
-        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(SPT + 4)));
+        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(NC_ENT_CUR_PITCH(SPT) + 1)));
         int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p, *ent_cur = ent_read + pack->n_entries;
         hipLaunchKernelGGL(k_entry_cursors, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_sets(SetArgs p)
                         // the read's events around the anchor: [first event at or after the anchor's 1024-column block less 64 columns, first one at or
                         // after the block after next less 64) -- the first event on a column >= v lies in that stretch or is its end
                         const int h = (v - (p.tile_pos0 + t * p.tile_size)) >> 10;
-                        const int32_t *cur = p.ent_cur + (int64_t)e * (p.spt + 3);
+                        const int32_t *cur = p.ent_cur + (int64_t)e * NC_ENT_CUR_PITCH(p.spt);
                         p.al_ev[w] = make_int2(cur[h], h + 2 <= p.spt ? cur[h + 2] : p.ev_off[r + 1]);
                     }
                 }
