@@ -420,6 +420,55 @@ __device__ __forceinline__ int8_t indel_decide(int k, int n0, int n1, UF U, int3
     return -1;
 }
 
+// Decisions without divisions.  fl(U / n) >= t is monotone in the integer U, so for every depth n < DEC_N there is a smallest count that passes:
+// k_decide_tables finds it with the reference's own float64 divide-and-compare (bisection over U; 65535 = none), once per call for del_t and
+// ins_t, and a column's eight ratio tests become table look-ups.  The sum rule (f2 + f3 >= 0.9) is decided in integers when the exact sum is not
+// 0.9 itself (then it is at least 1 / (10 n) > 1e-6 away, against rounding errors below 1e-12), else by the float64 expression.  indel_decide
+// (the division form) stays for depths beyond the table and as the other routes' kernel: test_tiled_event_windows_equal_the_atomic_form compares them.
+constexpr int DEC_N = 1024;
+__global__ void k_decide_tables(double del_t, double ins_t, uint16_t *__restrict__ tab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * DEC_N) return;
+    const int n = i % DEC_N;
+    const double t = i < DEC_N ? del_t : ins_t;
+    int v;
+    if (n == 0) v = 0.0 >= t ? 0 : 65535;                            // (n == 0: the ratio is 0.0 by definition)
+    else {
+        int lo = 0, hi = 65535;                                       // smallest U in [0, 65535) with U / n >= t
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((double)mid / (double)n >= t) hi = mid; else lo = mid + 1;
+        }
+        v = lo;
+    }
+    tab[i] = (uint16_t)v;
+}
+template <class UF>
+__device__ __forceinline__ int8_t indel_decide_tab(int k, int n0, int n1, UF U, int32_t mincov, double ins_t, double del_t, int32_t haploid,
+                                                   const uint16_t *tdel, const uint16_t *tins)
+{
+    if (n0 >= DEC_N || n1 >= DEC_N) return indel_decide(k, n0, n1, U, mincov, ins_t, del_t, haploid);
+    auto sum_rule = [&](int u2, int u3, int n) {
+        if (n <= 0) return false;
+        const int a = 10 * (u2 + u3), b = 9 * n;
+        if (a != b) return a > b;
+        return ((double)u2 / (double)n + (double)u3 / (double)n) >= 0.9;
+    };
+    if (haploid) {
+        if (k >= 0 && n0 >= mincov && n0 > 0) {
+            const int td = tdel[n0], ti = tins[n0];
+            if (U(0, 0) >= td || U(1, 0) >= ti) return 0;
+            if (U(2, 0) >= td || U(3, 0) >= ti || sum_rule(U(2, 0), U(3, 0), n0)) return 1;
+        }
+    } else if (k >= 0 && n0 >= mincov && n1 >= mincov) {
+        const int td0 = tdel[n0], ti0 = tins[n0], td1 = tdel[n1], ti1 = tins[n1];
+        if (U(0, 0) >= td0 || U(0, 1) >= td1 || U(1, 0) >= ti0 || U(1, 1) >= ti1) return 0;
+        if (U(2, 0) >= td0 || U(2, 1) >= td1 || U(3, 0) >= ti0 || U(3, 1) >= ti1 || sum_rule(U(2, 0), U(3, 0), n0) || sum_rule(U(2, 1), U(3, 1), n1)) return 1;
+    }
+    return -1;
+}
+
 constexpr int EV_SUB = 1024, EV_MARGIN = 256, EV_CAP = 2048, EV_NT = NC_EV_NT;
 
 // read index of every tile entry (its slot offset is unique) and its event cursors: for the tile's 1024-column blocks h = 0 .. SPT-1 (and the
@@ -484,7 +533,7 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
                                                      const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
                                                      const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t win,
                                                      int32_t small_win, int32_t haploid, int32_t mincov, double ins_t, double del_t,
-                                                     int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits)
+                                                     int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits, const uint16_t *__restrict__ dec_tab)
 {
     // interval ends per (class, haplotype) row and rank as 16-bit fields, two ranks per word, each biased by 0x4000: +1 is an atomic add and
     // -1 an atomic SUBTRACT of the field's unit, so neither carries into the neighbour field (16 KB instead of 32: a fourth workgroup per CU)
@@ -764,6 +813,22 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
             __syncthreads();
         }
     }
+#ifdef NC_ABL_EVT_D
+    return;
+#endif
+    const int32_t *depth = ck_depth(ws, c);
+    constexpr int DCOL = EV_SUB / EV_NT;
+    int dn0[DCOL], dn1[DCOL];
+#pragma unroll
+    for (int u = 0; u < DCOL; u++) {                                 // (all of a thread's depth loads in one round trip, under the scan)
+        const int i = b_lo + tid + u * EV_NT;
+        dn0[u] = i <= b_hi ? depth[i - c.lo] : 0;
+        dn1[u] = i <= b_hi ? depth[c.ncol + (i - c.lo)] : 0;
+    }
+    // the decision tables over the batch's event ranks (free now); the barrier after the scan publishes them
+    uint16_t *dtab = reinterpret_cast<uint16_t *>(evk);
+    static_assert(sizeof(int32_t) * EV_CAP >= 2 * DEC_N * sizeof(uint16_t), "k_event_tiles: the decision tables fit the event ranks' array");
+    for (int i = tid; i < 2 * DEC_N / 2; i += EV_NT) reinterpret_cast<uint32_t *>(dtab)[i] = reinterpret_cast<const uint32_t *>(dec_tab)[i];
     // ---- inclusive scan of the eight rows: dif becomes U[class, haplotype][rank - k0]
     // a wave per row: each lane sums 16 consecutive ranks, one scan over the 64 lane totals, then the lane's 16 window counts (in place)
     for (int row = wv; row < 8; row += EV_NT / 64) {
@@ -789,12 +854,18 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
         }
     }
     __syncthreads();
+#ifdef NC_ABL_EVT_E
+    return;
+#endif
     // the columns' decisions (k_indel_decide_b's, without the window counts' trip through HBM)
-    const int32_t *depth = ck_depth(ws, c);
-    for (int i = b_lo + tid; i <= b_hi; i += EV_NT) {
+#pragma unroll
+    for (int u = 0; u < DCOL; u++) {
+        const int i = b_lo + tid + u * EV_NT;
+        if (i > b_hi) break;
         const int k = rkw[i - w_lo];
-        const int n0 = depth[i - c.lo], n1 = depth[c.ncol + (i - c.lo)];
-        col_type[i - c.lo] = indel_decide(k, n0, n1, [&](int cls, int h) { return (int)reinterpret_cast<const uint16_t *>(&difw[cls * 2 + h][0])[k - k0]; }, mincov, ins_t, del_t, haploid);
+        const int n0 = dn0[u], n1 = dn1[u];
+        col_type[i - c.lo] = indel_decide_tab(k, n0, n1, [&](int cls, int h) { return (int)reinterpret_cast<const uint16_t *>(&difw[cls * 2 + h][0])[k - k0]; },
+                                              mincov, ins_t, del_t, haploid, dtab, dtab + DEC_N);
     }
 }
 
@@ -939,15 +1010,17 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
     if (tiles) {
         const int SPT = tile / EV_SUB;
-        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(NC_ENT_CUR_PITCH(SPT) + 1)));
+        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(NC_ENT_CUR_PITCH(SPT) + 1) + 2 * DEC_N * sizeof(uint16_t)));
         int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p, *ent_cur = ent_read + pack->n_entries;
         hipLaunchKernelGGL(k_entry_cursors, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);
+        uint16_t *dec_tab = reinterpret_cast<uint16_t *>(ent_cur + (size_t)pack->n_entries * NC_ENT_CUR_PITCH(SPT));
+        hipLaunchKernelGGL(k_decide_tables, dim3(2 * DEC_N / 256), dim3(256), 0, ctx->stream, prm->del_t, prm->ins_t, dec_tab);
         ctx->indel_ent_of = pack->tile_ent;                              // (the device pipeline's k_sets / k_windows use the tables too)
         ctx->indel_ent_spt = SPT;
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            ent_read, ent_cur, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, blk_chunk, ws, prm->win_size,
-                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev);
+                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev, dec_tab);
     } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
         if (per_thread)
