@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void k_entry_cursors(const int32_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict__ tile_off, const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
+__global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restrict__ tile_off, const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
                                                      int32_t tile_size, const int32_t *__restrict__ ent_read, const int32_t *__restrict__ ent_cur,
                                                      const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
                                                      const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
@@ -727,12 +727,28 @@ __global__ __launch_bounds__(EV_NT) void k_event_tiles(const int32_t *__restrict
 #endif
             if (total <= EV_CAP) {
                 // the batch's events into LDS (independent loads), then every look-up at a neighbour is an LDS read
-                for (int idx = tid; idx < total; idx += EV_NT) {
-                    const int lo = own[idx];
-                    const int ev = en_e0[lo] + (idx - en_pre[lo]);
-                    const int32_t sl = ev_len[ev];
-                    evk[idx] = rkf(ev_pos[ev]);
-                    evq[idx] = (uint8_t)((qualifies(sl, 0) ? 1 : 0) | (qualifies(sl, 1) ? 2 : 0) | (qualifies(sl, 2) ? 4 : 0) | (qualifies(sl, 3) ? 8 : 0));
+                constexpr int EVU = 2;                                            // (two of a thread's events per round trip to HBM)
+                for (int base = 0; base < total; base += EVU * EV_NT) {
+                    int32_t e_pos[EVU], e_len[EVU];
+#pragma unroll
+                    for (int u = 0; u < EVU; u++) {
+                        const int idx = base + tid + u * EV_NT;
+                        if (idx < total) {
+                            const int lo = own[idx];
+                            const int ev = en_e0[lo] + (idx - en_pre[lo]);
+                            e_pos[u] = ev_pos[ev];
+                            e_len[u] = ev_len[ev];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < EVU; u++) {
+                        const int idx = base + tid + u * EV_NT;
+                        if (idx < total) {
+                            const int32_t sl = e_len[u];
+                            evk[idx] = rkf(e_pos[u]);
+                            evq[idx] = (uint8_t)((qualifies(sl, 0) ? 1 : 0) | (qualifies(sl, 1) ? 2 : 0) | (qualifies(sl, 2) ? 4 : 0) | (qualifies(sl, 3) ? 8 : 0));
+                        }
+                    }
                 }
                 __syncthreads();
 #ifdef NC_ABL_EVT_C
