@@ -582,8 +582,18 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
     __syncthreads();
     {
         int32_t kmin = INT32_MAX, kmax = -1;                         // first / last yielded rank of the block's own columns
-        for (int i = tid; i <= b_hi - w_lo; i += EV_NT) {
-            const int32_t r = rank[w_lo + i - c.lo];
+        constexpr int RKU = (EV_SUB + EV_MARGIN + EV_NT - 1) / EV_NT;     // (a thread's ranks in one round trip)
+        int32_t rr[RKU];
+#pragma unroll
+        for (int u = 0; u < RKU; u++) {
+            const int i = tid + u * EV_NT;
+            rr[u] = i <= b_hi - w_lo ? rank[w_lo + i - c.lo] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < RKU; u++) {
+            const int i = tid + u * EV_NT;
+            if (i > b_hi - w_lo) break;
+            const int32_t r = rr[u];
             rkw[i] = r;
             if (r >= 0 && w_lo + i >= b_lo) { kmin = min(kmin, r); kmax = max(kmax, r); }
         }
@@ -727,7 +737,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
 #endif
             if (total <= EV_CAP) {
                 // the batch's events into LDS (independent loads), then every look-up at a neighbour is an LDS read
-                constexpr int EVU = 2;                                            // (two of a thread's events per round trip to HBM)
+                constexpr int EVU = 4;                                            // (a thread's events in one round trip to HBM)
                 for (int base = 0; base < total; base += EVU * EV_NT) {
                     int32_t e_pos[EVU], e_len[EVU];
 #pragma unroll
