@@ -111,7 +111,8 @@ __global__ void k_blk_chunks(const IndelChunk *__restrict__ ck, int32_t n_chunks
 template <int BLOCK, bool STAR>
 __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict__ codes, const int32_t *__restrict__ tile_off,
                                                        const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
-                                                       const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t haploid)
+                                                       const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t haploid,
+                                                       const uint8_t *__restrict__ excl, int32_t grid_lo, int32_t *__restrict__ blk_yield)
 {
     constexpr int TILE = BLOCK * 16;
     const IndelChunk c = ck[blk_chunk[blockIdx.x]];
@@ -182,6 +183,78 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
 #pragma unroll
         for (int q = 0; q < (STAR ? 1 : 3); q++) depth[(int64_t)q * ncol + (p - lo)] = tr[q][(j >> 4) * 17 + (j & 15)];
     }
+    if constexpr (!STAR) {
+        if (!blk_yield) return;
+        // The rank of a column among the chunk's yielded ones (depth > 0, not excluded), LOCAL to this tile-block: a lane has its 16 columns' depths
+        // in registers.  The block's count goes to blk_yield, k_blk_base scans the counts of a chunk's blocks, and k_event_tiles adds the base of a
+        // column's block (k_yield_rank_b walked a chunk in 98 dependent rounds of load -> scan: 0.30 ms per chr20-sized contig, all latency).
+        int fl[16], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int d = i >> 2, k = i & 3, wi = 2 * d + (k & 1), sh = (k >> 1) * 16;
+            const int32_t p = P0 + i;
+            const int tot = (int)(((wide[0][wi] >> sh) & 0xFFFF) + ((wide[1][wi] >> sh) & 0xFFFF) + ((wide[2][wi] >> sh) & 0xFFFF));
+            bool y = p >= lo && p <= hi && tot > 0;
+            if (y && excl) y = excl[(lo - grid_lo) + (p - lo)] == 0;
+            fl[i] = y;
+            sum += y;
+        }
+        __shared__ int wtot[BLOCK / 64];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yv = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += yv;
+        }
+        if (lane == 63) wtot[wv] = inc;
+        __syncthreads();                                              // (also: every depth row has left tr)
+        int wp = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < BLOCK / 64; q++) {
+            if (q < wv) wp += wtot[q];
+            all += wtot[q];
+        }
+        int run = wp + inc - sum;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            tr[0][threadIdx.x * 17 + i] = fl[i] ? run : -1;
+            run += fl[i];
+        }
+        if (threadIdx.x == 0) blk_yield[blockIdx.x] = all;
+        __syncthreads();
+        int32_t *rank = ck_rank(ws, c);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = r * BLOCK + threadIdx.x;
+            const int32_t p = T0 + j;
+            if (p < lo || p > hi) continue;
+            rank[p - lo] = tr[0][(j >> 4) * 17 + (j & 15)];
+        }
+    }
+}
+
+// exclusive scan of the yielded-column counts of a chunk's tile-blocks (one wave per chunk) -> the rank of the first yielded column of every block
+__global__ __launch_bounds__(256) void k_blk_base(const IndelChunk *__restrict__ ck, int32_t n_chunks, int32_t nblk, const int32_t *__restrict__ blk_yield,
+                                                  int32_t *__restrict__ blk_base, char *__restrict__ ws)
+{
+    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ci >= n_chunks) return;
+    const IndelChunk c = ck[ci];
+    const int b0 = c.blk0, b1 = ci + 1 < n_chunks ? ck[ci + 1].blk0 : nblk;
+    int carry = 0;
+    for (int b = b0; b < b1; b += 64) {
+        const int v = b + lane < b1 ? blk_yield[b + lane] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int yv = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += yv;
+        }
+        if (b + lane < b1) blk_base[b + lane] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) ck_rank(ws, c)[c.ncol] = carry;                    // ny, as k_yield_rank_b leaves it
 }
 
 // block-wide scan helper shared by the two per-chunk scans below: returns this thread's inclusive prefix inside the block
@@ -533,7 +606,8 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
                                                      const int32_t *__restrict__ ev_len, const uint8_t *__restrict__ read_hap,
                                                      const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t win,
                                                      int32_t small_win, int32_t haploid, int32_t mincov, double ins_t, double del_t,
-                                                     int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits, const uint16_t *__restrict__ dec_tab)
+                                                     int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits, const uint16_t *__restrict__ dec_tab,
+                                                     const int32_t *__restrict__ blk_base)
 {
     // interval ends per (class, haplotype) row and rank as 16-bit fields, two ranks per word, each biased by 0x4000: +1 is an atomic add and
     // -1 an atomic SUBTRACT of the field's unit, so neither carries into the neighbour field (16 KB instead of 32: a fourth workgroup per CU)
@@ -589,6 +663,15 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
             const int i = tid + u * EV_NT;
             rr[u] = i <= b_hi - w_lo ? rank[w_lo + i - c.lo] : -1;
         }
+        // the ranks in HBM are local to their tile-block (k_hap_depth_b): the window lies in at most two blocks of the chunk
+        const int wb0 = c.blk0 + (w_lo - tile_pos0) / tile_size - c.tile0;
+        const int32_t edge = tile_pos0 + ((w_lo - tile_pos0) / tile_size + 1) * tile_size;      // first column of the second block
+        const int32_t base0 = blk_base[wb0], base1 = edge <= b_hi ? blk_base[wb0 + 1] : 0;
+#pragma unroll
+        for (int u = 0; u < RKU; u++) {
+            const int i = tid + u * EV_NT;
+            if (rr[u] >= 0) rr[u] += w_lo + i >= edge ? base1 : base0;
+        }
 #pragma unroll
         for (int u = 0; u < RKU; u++) {
             const int i = tid + u * EV_NT;
@@ -628,7 +711,10 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
     }
     auto rk = [&](int32_t p) {                                       // (written so that the common case is a plain LDS read, not a flat load)
         int32_t k = rkw[max(p - w_lo, 0)];
-        if (p < w_lo) k = rank[p - c.lo];
+        if (p < w_lo) {
+            k = rank[p - c.lo];
+            if (k >= 0) k += blk_base[c.blk0 + (p - tile_pos0) / tile_size - c.tile0];
+        }
         return k;
     };
     const int wmax = max(win, small_win);
@@ -1007,7 +1093,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     *consumed = c1;
     const int32_t ng = (int32_t)ck.size();
     const size_t o_type = wsb, o_ck = (o_type + (size_t)ncols + 15) & ~(size_t)15, o_blk = o_ck + (((size_t)ng * sizeof(IndelChunk) + 15) & ~(size_t)15),
-                 total = o_blk + (size_t)nblk * 4;
+                 total = o_blk + (size_t)nblk * 4 * 3;                // blk_chunk, blk_yield, blk_base
     NC_TRY(nc_ensure(ctx, ctx->indel_ws, total));
     char *ws = (char *)ctx->indel_ws.p;
     const bool no_tiles = getenv("NC_K7_EVENT_ATOMICS") != nullptr;                         // k_event_intervals_w + k_prefix_rows_b + k_indel_decide_b, for A/B checks (read per call: tests flip it)
@@ -1018,10 +1104,11 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     NC_TRY(nc_h2d_pieces(ctx, ck_dev, ck.data(), (size_t)ng * sizeof(IndelChunk), ctx->stream));   // by copy kernel: never behind an upload in flight
     int8_t *ctype = (int8_t *)(ws + o_type);
     int32_t *blk_chunk = (int32_t *)(ws + o_blk);
+    int32_t *blk_yield = tiles ? blk_chunk + nblk : nullptr, *blk_base = blk_chunk + 2 * (size_t)nblk;
     if (nblk > 0) hipLaunchKernelGGL(k_blk_chunks, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, ck_dev, ng, nblk, blk_chunk);
 #define NC_HAP_DEPTH(B, STAR)                                                                                                        \
     hipLaunchKernelGGL((k_hap_depth_b<B, STAR>), dim3(nblk), dim3(B), 0, ctx->stream, pack->codes, pack->tile_off, pack->tile_ent, \
-                       pack->tile_pos0, ck_dev, blk_chunk, ws, prm->haploid)
+                       pack->tile_pos0, ck_dev, blk_chunk, ws, prm->haploid, excl_dev, grid_lo, (STAR) ? nullptr : blk_yield)
     if (nblk > 0) {
         if (tile == 1024) NC_HAP_DEPTH(64, false);
         else if (tile == 2048) NC_HAP_DEPTH(128, false);
@@ -1033,7 +1120,8 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
         }
     }
 #undef NC_HAP_DEPTH
-    hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
+    if (tiles) hipLaunchKernelGGL(k_blk_base, dim3((ng + 3) / 4), dim3(256), 0, ctx->stream, ck_dev, ng, nblk, blk_yield, blk_base, ws);
+    else hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
     if (tiles) {
         const int SPT = tile / EV_SUB;
         NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(NC_ENT_CUR_PITCH(SPT) + 1) + 2 * DEC_N * sizeof(uint16_t)));
@@ -1046,7 +1134,7 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
         ctx->indel_ent_spt = SPT;
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            ent_read, ent_cur, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, blk_chunk, ws, prm->win_size,
-                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev, dec_tab);
+                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev, dec_tab, blk_base);
     } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
         if (per_thread)
