@@ -31,7 +31,7 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 
 namespace {
 
-constexpr int PICK_CAP = 12288;        // anchors of one chunk held in LDS by k_pick (a 100 kb chunk has at most 9,092)
+constexpr int PICK_CAP = 12288;        // anchors of one chunk held in LDS by k_pick (a 100 kb chunk has at most 9,092), one packed word each: 48 KB, three waves per CU
 constexpr int TWB_PITCH = 36;        // words of banded traceback codes per block of 8 anti-diagonals and alignment (C = 2: 32 cells + 4 empty slots a superblock)
 constexpr int BAND_NBLK4 = 44;       // ... stored in whole superblocks of four blocks
 constexpr int BAND_NBLK = 41;        // blocks of 8 anti-diagonals of a banded ALLELE alignment: n1 + n2 <= 328 (the star alignments size theirs by the window: stage_a)
@@ -52,66 +52,87 @@ __global__ __launch_bounds__(64) void k_pick(const PipeChunk *__restrict__ pc, c
                                              int32_t *__restrict__ seg_pos, int8_t *__restrict__ seg_type, int32_t *__restrict__ cnt,
                                              int32_t *__restrict__ err)
 {
-    __shared__ int32_t apos[PICK_CAP];
-    __shared__ int8_t atype[PICK_CAP];
+    __shared__ uint32_t anc[PICK_CAP];                               // (anchor - aoff) << 8 | type: 4 bytes an anchor (5 in two arrays held two waves per CU)
     const PipeChunk c = pc[blockIdx.x];
+    const int32_t aoff = c.lo - win - 16;                            // an anchor is >= max(1, column - win)
+    auto apos = [&](int i) { return (int32_t)(anc[i] >> 8) + aoff; };
+    auto apack = [&](int32_t an, int tb) { return ((uint32_t)(an - aoff) << 8) | (uint32_t)(tb & 0xff); };
     const int lane = threadIdx.x;
     const int8_t *ct = ctype + c.coloff;
     int n = 0;
     int base = 0;
     bool over = false;
-    // 1024 columns a step (16 per lane, one 16-byte load: a step of 64 columns was one dependent load per 64 columns, 0.95 ms per
-    // chr20-sized contig for ~1 % flagged columns); m16 = this lane's flagged columns still to be visited
+    // 4096 columns a round: four steps of 1024 columns (16 per lane, one 16-byte load each), loaded together -- the walk is a chain of dependent
+    // loads (a step of 64 columns was 0.95 ms per chr20-sized contig for ~1 % flagged columns, a step of 1024 columns 0.21 ms);
+    // m16 = this lane's flagged columns of the step still to be visited
     while (base < c.ncol) {
-        const int col0 = base + 16 * lane;
-        uint32_t w[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        if (col0 + 16 <= c.ncol) __builtin_memcpy(w, ct + col0, 16);
-        else
-            for (int k = 0; k < 16 && col0 + k < c.ncol; k++) reinterpret_cast<int8_t *>(w)[k] = ct[col0 + k];
-        uint32_t m16 = 0;
+        uint32_t W[4][4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-            m16 |= (t <= 1u ? 1u : 0u) << k;
+        for (int b = 0; b < 4; b++) {
+            const int col0 = base + 1024 * b + 16 * lane;
+            W[b][0] = W[b][1] = W[b][2] = W[b][3] = 0xffffffffu;
+            if (col0 + 16 <= c.ncol) __builtin_memcpy(W[b], ct + col0, 16);
+            else
+                for (int k = 0; k < 16 && col0 + k < c.ncol; k++) reinterpret_cast<int8_t *>(W[b])[k] = ct[col0 + k];
         }
-        int next_base = base + 1024;
-        for (;;) {
-            const uint64_t lm = __ballot(m16 != 0);
-            if (!lm) break;
-            const int l = __ffsll((long long)lm) - 1;
-            const uint32_t mm = (uint32_t)__shfl((int)m16, l);
-            const int b = __ffs((int)mm) - 1;
-            const int32_t v = c.lo + base + 16 * l + b;
-            const int tb = (int)((__shfl((int)w[0], l) * (b < 4) + __shfl((int)w[1], l) * (b >= 4 && b < 8) + __shfl((int)w[2], l) * (b >= 8 && b < 12) +
-                                  __shfl((int)w[3], l) * (b >= 12)) >> ((b & 3) * 8)) & 0xff;
-            const int32_t prev = tb == 0 ? v + win : v + 10;                     // :267, :273
-            const int32_t an = tb == 0 ? max(1, v - win) : max(1, v - 10);       // :268, :274
-            // variants[an] = tb: the anchors stay sorted; an equal key is overwritten (dict), a smaller one (a small-window
-            // anchor followed by a long-window one less than 30 columns later) goes a few places back
-            int i = n;
-            while (i > 0 && apos[i - 1] > an) i--;
-            if (i > 0 && apos[i - 1] == an) {
-                if (lane == 0) atype[i - 1] = (int8_t)tb;
-            } else if (n >= PICK_CAP) {
-                over = true;
-            } else {
-                if (lane == 0) {
-                    for (int k = n; k > i; k--) { apos[k] = apos[k - 1]; atype[k] = atype[k - 1]; }
-                    apos[i] = an;
-                    atype[i] = (int8_t)tb;
+        int64_t skip_to = 0;                                          // columns before it are skipped (carried from step to step)
+        int next_base = base + 4096;
+        bool jump = false;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int bb = base + 1024 * b, col0 = bb + 16 * lane;
+            if (jump || bb >= c.ncol) continue;
+            const uint32_t (&w)[4] = W[b];
+            uint32_t m16 = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                m16 |= (t <= 1u ? 1u : 0u) << k;
+            }
+            {
+                const int64_t sh = skip_to - col0;                    // (a skip that reaches into this step)
+                if (sh >= 16) m16 = 0;
+                else if (sh > 0) m16 &= ~((1u << (int)sh) - 1u);
+            }
+            for (;;) {
+                const uint64_t lm = __ballot(m16 != 0);
+                if (!lm) break;
+                const int l = __ffsll((long long)lm) - 1;
+                const uint32_t mm = (uint32_t)__shfl((int)m16, l);
+                const int bq = __ffs((int)mm) - 1;
+                const int32_t v = c.lo + bb + 16 * l + bq;
+                const int tb = (int)((__shfl((int)w[0], l) * (bq < 4) + __shfl((int)w[1], l) * (bq >= 4 && bq < 8) + __shfl((int)w[2], l) * (bq >= 8 && bq < 12) +
+                                      __shfl((int)w[3], l) * (bq >= 12)) >> ((bq & 3) * 8)) & 0xff;
+                const int32_t prev = tb == 0 ? v + win : v + 10;                     // :267, :273
+                const int32_t an = tb == 0 ? max(1, v - win) : max(1, v - 10);       // :268, :274
+                // variants[an] = tb: the anchors stay sorted; an equal key is overwritten (dict), a smaller one (a small-window
+                // anchor followed by a long-window one less than 30 columns later) goes a few places back
+                int i = n;
+                while (i > 0 && apos(i - 1) > an) i--;
+                if (i > 0 && apos(i - 1) == an) {
+                    if (lane == 0) anc[i - 1] = apack(an, tb);
+                } else if (n >= PICK_CAP) {
+                    over = true;
+                } else {
+                    if (lane == 0) {
+                        for (int k = n; k > i; k--) anc[k] = anc[k - 1];
+                        anc[i] = apack(an, tb);
+                    }
+                    n++;
                 }
-                n++;
+                __syncthreads();
+                // every column up to `prev` is skipped by `if v_pos <= prev: continue` (:249)
+                skip_to = (int64_t)prev - c.lo + 1;
+                if (skip_to >= base + 4096) {
+                    next_base = (int)min((int64_t)c.ncol, skip_to);
+                    jump = true;
+                    break;
+                }
+                if (skip_to >= bb + 1024) break;                     // the rest of this step is skipped; the next one takes the mask
+                const int sh = (int)(skip_to - col0);                              // this lane's columns before skip_to are done
+                if (sh >= 16) m16 = 0;
+                else if (sh > 0) m16 &= ~((1u << sh) - 1u);
             }
-            __syncthreads();
-            // every column up to `prev` is skipped by `if v_pos <= prev: continue` (:249)
-            const int64_t skip_to = (int64_t)prev - c.lo + 1;
-            if (skip_to >= base + 1024) {
-                next_base = (int)min((int64_t)c.ncol, skip_to);
-                break;
-            }
-            const int sh = (int)(skip_to - col0);                              // this lane's columns before skip_to are done
-            if (sh >= 16) m16 = 0;
-            else if (sh > 0) m16 &= ~((1u << sh) - 1u);
         }
         base = next_base;
     }
@@ -120,12 +141,12 @@ __global__ __launch_bounds__(64) void k_pick(const PipeChunk *__restrict__ pc, c
     int m = 0;
     for (int k0 = 0; k0 < n; k0 += 64) {
         const int k = k0 + lane;
-        const bool ok = k < n && apos[k] > c.a_lo && apos[k] <= c.hi;
+        const bool ok = k < n && apos(k) > c.a_lo && apos(k) <= c.hi;
         const uint64_t bm = __ballot(ok);
         if (ok) {
             const int w = m + __popcll(bm & ((1ull << lane) - 1));
-            seg_pos[c.seg0 + w] = apos[k];
-            seg_type[c.seg0 + w] = atype[k];
+            seg_pos[c.seg0 + w] = apos(k);
+            seg_type[c.seg0 + w] = (int8_t)(anc[k] & 0xffu);
         }
         m += __popcll(bm);
     }
