@@ -596,7 +596,10 @@ __device__ __forceinline__ int row_scan_max(int x)
 }
 __device__ __forceinline__ int row_last(int x) { return __shfl(x, (int)(threadIdx.x | 15)); }      // lane 15 of the row
 
-__global__ __launch_bounds__(64) void k_windows16(WinArgs p, int32_t force_serial)
+#ifndef NC_WIN16_WAVES
+#define NC_WIN16_WAVES 6
+#endif
+__global__ __launch_bounds__(64, NC_WIN16_WAVES) void k_windows16(WinArgs p, int32_t force_serial)
 {
     __shared__ int32_t s_pos[4][WIN_EV_CAP], s_len[4][WIN_EV_CAP];       // s_len > 0: inserted bases, <= 0: minus the deleted columns
     __shared__ uint32_t s_row[4][WIN_ROW / 4];
