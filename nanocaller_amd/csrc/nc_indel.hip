@@ -519,9 +519,9 @@ __global__ void k_decide_tables(double del_t, double ins_t, uint16_t *__restrict
 }
 template <class UF>
 __device__ __forceinline__ int8_t indel_decide_tab(int k, int n0, int n1, UF U, int32_t mincov, double ins_t, double del_t, int32_t haploid,
-                                                   const uint16_t *tdel, const uint16_t *tins)
+                                                   const uint16_t *tdel, const uint16_t *tins, int dec_n)
 {
-    if (n0 >= DEC_N || n1 >= DEC_N) return indel_decide(k, n0, n1, U, mincov, ins_t, del_t, haploid);
+    if (n0 >= dec_n || n1 >= dec_n) return indel_decide(k, n0, n1, U, mincov, ins_t, del_t, haploid);
     auto sum_rule = [&](int u2, int u3, int n) {
         if (n <= 0) return false;
         const int a = 10 * (u2 + u3), b = 9 * n;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
                                                      const IndelChunk *__restrict__ ck, const int32_t *__restrict__ blk_chunk, char *__restrict__ ws, int32_t win,
                                                      int32_t small_win, int32_t haploid, int32_t mincov, double ins_t, double del_t,
                                                      int8_t *__restrict__ col_type_all, int32_t *__restrict__ err_bits, const uint16_t *__restrict__ dec_tab,
-                                                     const int32_t *__restrict__ blk_base)
+                                                     const int32_t *__restrict__ blk_base, int32_t dec_n)
 {
     // interval ends per (class, haplotype) row and rank as 16-bit fields, two ranks per word, each biased by 0x4000: +1 is an atomic add and
     // -1 an atomic SUBTRACT of the field's unit, so neither carries into the neighbour field (16 KB instead of 32: a fourth workgroup per CU)
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
         const int k = rkw[i - w_lo];
         const int n0 = dn0[u], n1 = dn1[u];
         col_type[i - c.lo] = indel_decide_tab(k, n0, n1, [&](int cls, int h) { return (int)reinterpret_cast<const uint16_t *>(&difw[cls * 2 + h][0])[k - k0]; },
-                                              mincov, ins_t, del_t, haploid, dtab, dtab + DEC_N);
+                                              mincov, ins_t, del_t, haploid, dtab, dtab + DEC_N, dec_n);
     }
 }
 
@@ -1130,11 +1130,14 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
                            slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);
         uint16_t *dec_tab = reinterpret_cast<uint16_t *>(ent_cur + (size_t)pack->n_entries * NC_ENT_CUR_PITCH(SPT));
         hipLaunchKernelGGL(k_decide_tables, dim3(2 * DEC_N / 256), dim3(256), 0, ctx->stream, prm->del_t, prm->ins_t, dec_tab);
+        // depths the tables serve (NC_K7_DEC_N < 1024: tests send ordinary depths down the division form; read per call)
+        const char *dn = getenv("NC_K7_DEC_N");
+        const int32_t dec_n = dn ? std::max(0, std::min(DEC_N, atoi(dn))) : DEC_N;
         ctx->indel_ent_of = pack->tile_ent;                              // (the device pipeline's k_sets / k_windows use the tables too)
         ctx->indel_ent_spt = SPT;
         hipLaunchKernelGGL(k_event_tiles, dim3(nblk * (tile / EV_SUB)), dim3(EV_NT), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
                            ent_read, ent_cur, ev->ev_off, ev->ev_pos, ev->ev_len, ev->read_hap, ck_dev, blk_chunk, ws, prm->win_size,
-                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev, dec_tab, blk_base);
+                           prm->small_win_size, prm->haploid, prm->mincov, prm->ins_t, prm->del_t, ctype, err_bits_dev, dec_tab, blk_base, dec_n);
     } else if (ev->n_reads > 0) {
         static const bool per_thread = getenv("NC_K7_THREAD_PER_READ") != nullptr;          // the round-1 form, kept for A/B checks
         if (per_thread)

@@ -539,6 +539,14 @@ def test_tiled_event_windows_equal_the_atomic_form(monkeypatch):
         if "excl" in variant:
             pos = np.asarray(new["pos"])
             assert not np.any((pos >= 901_000) & (pos < 907_500))
+        # the columns' decisions: threshold tables for depths below 1024 (k_decide_tables), the reference's float64 divide-and-compare beyond --
+        # with the tables cut to depths < 12 most columns of this 30x pileup take the division form: same sites
+        monkeypatch.delenv("NC_K7_EVENT_ATOMICS", raising=False)
+        monkeypatch.setenv("NC_K7_DEC_N", "12")
+        cut = gip.indel_sites_device(eng, pack, reads_c, L, chunks, **kw, **variant)
+        monkeypatch.delenv("NC_K7_DEC_N")
+        for key in ("pos", "chunk", "type", "phase", "ref_len", "alt_len"):
+            assert np.array_equal(np.asarray(cut[key]), np.asarray(new[key])), (key, variant.keys())
 
 
 def _window_dump(tmp_path, tag):
