@@ -488,6 +488,9 @@ def extra_indel_config(eng, uploader, local, L, reps=20):
     for _ in range(len(uploader.slots)):                            # sizes EVERY upload slot of the ring (they held the SNP contigs' smaller wires: a slot
         from_host_pass(uploader.submit(wire))                       # that grows inside the timed loop costs an allocation + a device synchronisation, ~30 ms)
     uploader.h2d_events.clear()
+    import gc
+    gc.collect()
+    gc.disable()                                                     # (a full collection of the earlier legs' objects inside the loop: +10 ms on a 15 ms pass, every sixth)
     with ThreadPoolExecutor(max_workers=1) as pool:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -504,6 +507,7 @@ def extra_indel_config(eng, uploader, local, L, reps=20):
         pend.result()
         torch.cuda.synchronize()
         t_host = time.perf_counter() - t0
+    gc.enable()
     h2d_gbs, _, _ = uploader.h2d_rate()
     # ---- instrumented pass: per-stage HIP events
     eng.enable_timing(True)
