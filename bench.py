@@ -457,7 +457,7 @@ def extra_indel_haploid_config(eng, L, reps=6):
     return out
 
 
-def extra_indel_config(eng, uploader, local, L, reps=20):
+def extra_indel_config(eng, uploader, local, L, reps=40):
     """The indel half of configs[2] at chromosome scale, as candidate sites/s: a chr20-sized synthetic ONT 30x contig (IndelJob).  Timed
     region: decoded alignments + the bases without a reference column in PINNED HOST MEMORY -> one H2D copy (own stream, under the
     previous pass) -> the pass -> genotype rules + VCF text (native, on a host thread under the next pass).  Stage times are HIP events of a
