@@ -600,6 +600,88 @@ __global__ __launch_bounds__(64) void k_entry_cursors(const int32_t *__restrict_
     }
 }
 
+// The cursor table WITHOUT random probes (k_entry_cursors bisects every entry's read: ~35 probes into 276 MB of event positions, 2.2 GB fetched per
+// chr20-sized contig, TA busy 0.82).  k_read_cursors streams the events once, one wave per read: event i is the first one at or after every
+// block boundary B (and B - EV_BACK) that lies in (position of event i - 1, position of event i]; boundaries behind the last event get the
+// read's event count.  A read's boundaries are those of the tiles it overlaps; its part of the table starts at rc_off(r) = slot offset / 1024
+// + (2 SPT + 2) r (slots are at least as long as the reads: the parts do not overlap, no scan needed).  k_entry_rows then copies an entry's row.
+__device__ __forceinline__ int64_t rc_off(int64_t slot_off, int r, int SPT) { return (slot_off >> 10) + (int64_t)(2 * SPT + 2) * r; }
+
+__global__ __launch_bounds__(256) void k_read_cursors(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
+                                                      const int64_t *__restrict__ slot_off, const int32_t *__restrict__ ev_off,
+                                                      const int32_t *__restrict__ ev_pos, int32_t tile_pos0, int32_t tile_size,
+                                                      int32_t *__restrict__ rc_lo, int32_t *__restrict__ rc_hi)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const int SPT = tile_size / 1024;
+    const int32_t rs = rd_start[r], re = rd_end[r];
+    const int ea = ev_off[r], eb = ev_off[r + 1];
+    const int ta = (rs - tile_pos0) / tile_size, tb = (max(re - 1, rs) - tile_pos0) / tile_size;
+    const int g0 = ta * SPT, cnt = (tb - ta + 1) * SPT + 1;         // boundaries g0 .. g0 + cnt - 1 at tile_pos0 + 1024 g
+    int32_t *lo = rc_lo + rc_off(slot_off[r], r, SPT), *hi = rc_hi + rc_off(slot_off[r], r, SPT);
+    constexpr int RU = 4;                                            // (a lane's loads of four rounds in flight together)
+    for (int ib = ea + lane; ib <= eb; ib += 64 * RU) {              // (i == eb: the end of the list, behind every event)
+        int32_t pp[RU], pc[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const int i = ib + 64 * u;
+            pp[u] = i > ea && i <= eb ? ev_pos[i - 1] : 0;
+            pc[u] = i < eb ? ev_pos[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const int i = ib + 64 * u;
+            if (i > eb) break;
+            const bool first = i == ea, last = i == eb;
+            // boundaries B with pp < B - back <= pc  <=>  floor((pp + back - p0) / 1024) < k + g0 <= floor((pc + back - p0) / 1024)
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const int back = w == 0 ? EV_BACK : 0;
+                int k0 = first ? 0 : ((pp[u] + back - tile_pos0) >> 10) + 1 - g0;
+                int k1 = last ? cnt - 1 : ((pc[u] + back - tile_pos0) >> 10) - g0;
+                k0 = max(k0, 0);
+                k1 = min(k1, cnt - 1);
+                int32_t *dst = w == 0 ? lo : hi;
+                for (int k = k0; k <= k1; k++) dst[k] = i;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_entry_rows(const int32_t *__restrict__ tile_off, const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
+                                                   int32_t tile_size, const int64_t *__restrict__ slot_off, int32_t n_reads,
+                                                   const int32_t *__restrict__ ev_off, const int32_t *__restrict__ rc_lo, const int32_t *__restrict__ rc_hi,
+                                                   const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
+                                                   int32_t *__restrict__ ent_read, int32_t *__restrict__ ent_cur)
+{
+    const int t = blockIdx.x, SPT = tile_size / 1024;
+    for (int e = tile_off[t] + (int)threadIdx.x; e < tile_off[t + 1]; e += 64) {
+        const nc_tile_entry ent = tile_ent[e];
+        const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
+        int lo = 0, hi = n_reads;
+        while (lo < hi) {                                              // (1.3 MB of slot offsets: the probes stay in L2)
+            const int mid = (lo + hi) >> 1;
+            if (slot_off[mid] < so) lo = mid + 1; else hi = mid;
+        }
+        const int r = lo;
+        ent_read[e] = r;
+        const int32_t rs = rd_start[r], re = rd_end[r];               // (the table's geometry is the read table's, as k_read_cursors took it)
+        const int ta = (rs - tile_pos0) / tile_size, tb = (max(re - 1, rs) - tile_pos0) / tile_size;
+        const int cnt = (tb - ta + 1) * SPT + 1;
+        const int64_t off = rc_off(slot_off[r], r, SPT);
+        int32_t *row = ent_cur + (int64_t)e * NC_ENT_CUR_PITCH(SPT);
+        const int kb = (t - ta) * SPT;                                 // boundary index of the tile's first block (clamped: a tile before / behind the read)
+        for (int h = 0; h <= SPT; h++) {
+            const int k = min(max(kb + h, 0), cnt - 1);
+            row[h] = rc_lo[off + k];
+            if (h > 0) row[SPT + 3 + (h - 1)] = rc_hi[off + k];
+        }
+        row[SPT + 1] = ev_off[r];
+        row[SPT + 2] = ev_off[r + 1];
+    }
+}
+
 __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restrict__ tile_off, const nc_tile_entry *__restrict__ tile_ent, int32_t tile_pos0,
                                                      int32_t tile_size, const int32_t *__restrict__ ent_read, const int32_t *__restrict__ ent_cur,
                                                      const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
@@ -1047,9 +1129,10 @@ int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *
 int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
                                const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t *consumed,
                                std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev,
-                               int32_t *err_bits_dev)
+                               int32_t *err_bits_dev, const int32_t *rd_start_dev, const int32_t *rd_end_dev, bool reuse_tables)
 {
-    ctx->indel_ent_of = nullptr;
+    // reuse_tables: a later group of chunks of the SAME pack and events (the device pipeline's plan): the cursor table of the first group stands
+    if (!reuse_tables) ctx->indel_ent_of = nullptr;
     const int tile = pack->tile_size;
     const int32_t grid_lo = pack->tile_pos0, grid_hi = pack->tile_pos0 + pack->n_tiles * tile - 1;
     const int impute = prm->impute && !prm->haploid;
@@ -1124,12 +1207,25 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
     else hipLaunchKernelGGL(k_yield_rank_b, dim3(ng), dim3(1024), 0, ctx->stream, ck_dev, ws, excl_dev, grid_lo);
     if (tiles) {
         const int SPT = tile / EV_SUB;
-        NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, (size_t)pack->n_entries * 4 * (size_t)(NC_ENT_CUR_PITCH(SPT) + 1) + 2 * DEC_N * sizeof(uint16_t)));
+        const size_t tab_words = (size_t)pack->n_entries * (size_t)(NC_ENT_CUR_PITCH(SPT) + 1) + 2 * DEC_N / 2;
+        const size_t rc_words = (size_t)(pack->codes_len >> 10) + (size_t)(2 * SPT + 2) * (size_t)ev->n_reads + 8;      // per table (rc_off)
+        const bool stream_tab = rd_start_dev && rd_end_dev && !getenv("NC_K7_CURSOR_PROBES");                       // (env: k_entry_cursors, for A/B checks)
+        const bool have = reuse_tables && ctx->indel_ent_of == pack->tile_ent && ctx->indel_ent_read.p;
+        if (!have) NC_TRY(nc_ensure(ctx, ctx->indel_ent_read, 4 * (tab_words + (stream_tab ? 2 * rc_words : 0))));
         int32_t *ent_read = (int32_t *)ctx->indel_ent_read.p, *ent_cur = ent_read + pack->n_entries;
-        hipLaunchKernelGGL(k_entry_cursors, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
-                           slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);
         uint16_t *dec_tab = reinterpret_cast<uint16_t *>(ent_cur + (size_t)pack->n_entries * NC_ENT_CUR_PITCH(SPT));
-        hipLaunchKernelGGL(k_decide_tables, dim3(2 * DEC_N / 256), dim3(256), 0, ctx->stream, prm->del_t, prm->ins_t, dec_tab);
+        if (!have) {
+            if (stream_tab) {
+                int32_t *rc_lo = ent_read + tab_words, *rc_hi = rc_lo + rc_words;
+                hipLaunchKernelGGL(k_read_cursors, dim3((unsigned)((ev->n_reads + 3) / 4)), dim3(256), 0, ctx->stream, ev->n_reads, rd_start_dev, rd_end_dev,
+                                   slot_off_dev, ev->ev_off, ev->ev_pos, pack->tile_pos0, tile, rc_lo, rc_hi);
+                hipLaunchKernelGGL(k_entry_rows, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
+                                   slot_off_dev, ev->n_reads, ev->ev_off, rc_lo, rc_hi, rd_start_dev, rd_end_dev, ent_read, ent_cur);
+            } else
+                hipLaunchKernelGGL(k_entry_cursors, dim3((unsigned)pack->n_tiles), dim3(64), 0, ctx->stream, pack->tile_off, pack->tile_ent, pack->tile_pos0, tile,
+                                   slot_off_dev, ev->n_reads, ev->ev_off, ev->ev_pos, ent_read, ent_cur);
+            hipLaunchKernelGGL(k_decide_tables, dim3(2 * DEC_N / 256), dim3(256), 0, ctx->stream, prm->del_t, prm->ins_t, dec_tab);
+        }
         // depths the tables serve (NC_K7_DEC_N < 1024: tests send ordinary depths down the division form; read per call)
         const char *dn = getenv("NC_K7_DEC_N");
         const int32_t dec_n = dn ? std::max(0, std::min(DEC_N, atoi(dn))) : DEC_N;
@@ -1165,7 +1261,7 @@ static int indel_scan_group(nc_ctx *ctx, const nc_readpack *pack, const nc_indel
     std::vector<IndelChunk> ck;
     const IndelChunk *ck_dev = nullptr;
     const int8_t *ctype = nullptr;
-    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype, nullptr, nullptr));
+    NC_TRY(nc_indel_scan_group_launch(ctx, pack, ev, excl_dev, n_chunks, starts, ends, prm, consumed, ck, &ck_dev, &ctype, nullptr, nullptr, nullptr, nullptr, false));
     const int32_t ng = (int32_t)ck.size();
     for (int32_t k = 0; k < ng;) {                                   // runs of chunks laid out back to back on the host as well
         int32_t j = k + 1;

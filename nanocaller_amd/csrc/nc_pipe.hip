@@ -26,7 +26,8 @@
 
 int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const uint8_t *excl_dev, int32_t n_chunks,
                                const int32_t *starts, const int32_t *ends, const nc_indel_scan_params *prm, int32_t *consumed,
-                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev, int32_t *err_bits_dev);
+                               std::vector<IndelChunk> &ck, const IndelChunk **ck_dev_out, const int8_t **ctype_out, const int64_t *slot_off_dev, int32_t *err_bits_dev,
+                               const int32_t *rd_start_dev, const int32_t *rd_end_dev, bool reuse_tables);
 int nc_indel_check(nc_ctx *ctx, const nc_readpack *pack, const nc_indel_events *ev, const nc_indel_scan_params *prm, const char *who);
 
 namespace {
@@ -2504,7 +2505,7 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
         const IndelChunk *ck_dev = nullptr;
         const int8_t *ctype = nullptr;
         NC_TRY(nc_indel_scan_group_launch(ctx, pack, &ev, excl_dev, n_chunks - c0, starts + c0, ends + c0, prm, &used, ck, &ck_dev, &ctype,
-                                          ev.n_reads == reads->n_reads ? reads->slot_off : nullptr, err));
+                                          ev.n_reads == reads->n_reads ? reads->slot_off : nullptr, err, reads->rd_start, reads->rd_end, c0 > 0));
         for (int32_t k = 0; k < used; k++) pcs[(size_t)(c0 + k)].coloff = ck[(size_t)k].coloff;
         NC_TRY(nc_h2d_pieces(ctx, (PipeChunk *)s->pc.p + c0, pcs.data() + c0, (size_t)used * sizeof(PipeChunk), ctx->stream));
         hipLaunchKernelGGL(k_pick, dim3(used), dim3(64), 0, ctx->stream, (const PipeChunk *)s->pc.p + c0, ctype, prm->win_size, (int32_t *)s->seg_pos.p,
