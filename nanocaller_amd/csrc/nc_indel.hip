@@ -180,8 +180,13 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
         const int j = r * BLOCK + threadIdx.x;                        // position T0 + j = lane j / 16, element j % 16
         const int32_t p = T0 + j;
         if (p < lo || p > hi) continue;
+        if (!STAR && blk_yield) {                                     // the tiled route: 16-bit rows (the counters above are 16-bit fields already)
 #pragma unroll
-        for (int q = 0; q < (STAR ? 1 : 3); q++) depth[(int64_t)q * ncol + (p - lo)] = tr[q][(j >> 4) * 17 + (j & 15)];
+            for (int q = 0; q < 3; q++) reinterpret_cast<uint16_t *>(depth)[(int64_t)q * ncol + (p - lo)] = (uint16_t)tr[q][(j >> 4) * 17 + (j & 15)];
+        } else {
+#pragma unroll
+            for (int q = 0; q < (STAR ? 1 : 3); q++) depth[(int64_t)q * ncol + (p - lo)] = tr[q][(j >> 4) * 17 + (j & 15)];
+        }
     }
     if constexpr (!STAR) {
         if (!blk_yield) return;
@@ -223,13 +228,13 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
         }
         if (threadIdx.x == 0) blk_yield[blockIdx.x] = all;
         __syncthreads();
-        int32_t *rank = ck_rank(ws, c);
+        int16_t *rank = reinterpret_cast<int16_t *>(ck_rank(ws, c));   // (local to the block: < 4096; -1 = not yielded)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int j = r * BLOCK + threadIdx.x;
             const int32_t p = T0 + j;
             if (p < lo || p > hi) continue;
-            rank[p - lo] = tr[0][(j >> 4) * 17 + (j & 15)];
+            rank[p - lo] = (int16_t)tr[0][(j >> 4) * 17 + (j & 15)];
         }
     }
 }
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
     const int32_t s_lo = tile_pos0 + t * tile_size + (rel % SPT) * EV_SUB;
     const int32_t b_lo = max(s_lo, c.lo), b_hi = min(s_lo + EV_SUB - 1, c.hi);
     if (b_lo > b_hi) return;
-    const int32_t *rank = ck_rank(ws, c);
+    const int16_t *rank = reinterpret_cast<const int16_t *>(ck_rank(ws, c));      // 16-bit rows, ranks local to their tile-block (k_hap_depth_b)
     const int32_t w_lo = max(c.lo, b_lo - EV_MARGIN);             // LDS window of the rank array
     if (tid == 0) { sh_k0 = INT32_MAX; sh_k1 = -1; sh_mlo = c.lo; }
     for (int i = tid; i < 8 * EV_SUB / 2; i += EV_NT) (&difw[0][0])[i] = 0x40004000u;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
 #pragma unroll
         for (int u = 0; u < RKU; u++) {
             const int i = tid + u * EV_NT;
-            rr[u] = i <= b_hi - w_lo ? rank[w_lo + i - c.lo] : -1;
+            rr[u] = i <= b_hi - w_lo ? (int32_t)rank[w_lo + i - c.lo] : -1;
         }
         // the ranks in HBM are local to their tile-block (k_hap_depth_b): the window lies in at most two blocks of the chunk
         const int wb0 = c.blk0 + (w_lo - tile_pos0) / tile_size - c.tile0;
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
     auto rk = [&](int32_t p) {                                       // (written so that the common case is a plain LDS read, not a flat load)
         int32_t k = rkw[max(p - w_lo, 0)];
         if (p < w_lo) {
-            k = rank[p - c.lo];
+            k = (int32_t)rank[p - c.lo];
             if (k >= 0) k += blk_base[c.blk0 + (p - tile_pos0) / tile_size - c.tile0];
         }
         return k;
@@ -1010,14 +1015,14 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
 #ifdef NC_ABL_EVT_D
     return;
 #endif
-    const int32_t *depth = ck_depth(ws, c);
+    const uint16_t *depth = reinterpret_cast<const uint16_t *>(ck_depth(ws, c));
     constexpr int DCOL = EV_SUB / EV_NT;
     int dn0[DCOL], dn1[DCOL];
 #pragma unroll
     for (int u = 0; u < DCOL; u++) {                                 // (all of a thread's depth loads in one round trip, under the scan)
         const int i = b_lo + tid + u * EV_NT;
-        dn0[u] = i <= b_hi ? depth[i - c.lo] : 0;
-        dn1[u] = i <= b_hi ? depth[c.ncol + (i - c.lo)] : 0;
+        dn0[u] = i <= b_hi ? (int)depth[i - c.lo] : 0;
+        dn1[u] = i <= b_hi ? (int)depth[c.ncol + (i - c.lo)] : 0;
     }
     // the decision tables over the batch's event ranks (free now); the barrier after the scan publishes them
     uint16_t *dtab = reinterpret_cast<uint16_t *>(evk);
