@@ -691,7 +691,11 @@ __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Flo
 #define NC_MFMA(ACC, W, X) asm volatile("" ::"v"(W), "v"(X));
 #else
 // D[channel 4g + r][position c16] += W[channel][k] * X[k][position]
+#ifdef NC_MFMA_NOP
+#define NC_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(W, X, ACC, 0, 0, 0); asm volatile("s_nop %1" : "+v"(ACC) : "n"(NC_MFMA_NOP));
+#else
 #define NC_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(W, X, ACC, 0, 0, 0);
+#endif
 #endif
 #define NC_MFMA3(ACC, XH, XL, WH, WL) NC_MFMA(ACC, WH, XH) NC_MFMA(ACC, WH, XL) NC_MFMA(ACC, WL, XH)
 
@@ -702,9 +706,9 @@ __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Flo
 // the 5x1 kernel's (6 MFMAs, groups 1..3), bit 2 the 5x5 kernel's (14 MFMAs, all groups).  A tile can so be shared by two
 // waves to even out the SIMDs, and its MFMAs are interleaved with those of the wave's full tiles (a partial tile on its own
 // is one chain of dependent MFMAs: latency-bound).
-template <int NT, int KL = 7>
+template <int NT, int KL = 7, int DP = 1>
 __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const h8 (&w1)[T_NW1],
-                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane, int tile_last = -1)
+                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane, int tile_last = -1, int tile_stride = 4)
 {
     // kernel mask and K-group range of tile tm
 #define C1_KM(tm) ((tm) == NT - 1 ? KL : 7)
@@ -713,7 +717,7 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
     int xbase[NT], obase[NT];
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        const int p = ((tm == NT - 1 && tile_last >= 0) ? tile_last : tile_first + 4 * tm) * 16 + c16;
+        const int p = ((tm == NT - 1 && tile_last >= 0) ? tile_last : tile_first + tile_stride * tm) * 16 + c16;
         const int pr = p < 205 ? p : 204;
         const int h = pr / 41, w = pr - h * 41;
         xbase[tm] = (h * T_RX + w) * 8;                              // halves; tap (dy,dx) of pixel (h,w) is padded pixel (h+dy, w+dx)
@@ -731,13 +735,24 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
         for (int tm = 0; tm < NT; tm++) { acc1[tm] = x1; acc2[tm] = x2; acc3[tm] = x3; }
     }
     // software pipeline: the ds_reads of group G + 1 are issued before the MFMAs of group G (register double buffer)
-    h8 xa[2][NT], xb[2][NT];
+    constexpr int NB = DP + 1;
+    h8 xa[NB][NT], xb[NB][NT];
+#ifdef NC_ABL_LDSDUMMY
+    h8 dm[NB][NT][2];
+#endif
     auto load1 = [&](int G, int slot) {
         const int toff = (int)((c1_tap_pack(G) >> sh) & 0xffffu);       // halves
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) {
             if (G >= C1_GHI(tm)) continue;
-#ifdef NC_ABL_NOLDS
+#ifdef NC_ABL_LDSDUMMY
+            #ifdef NC_ABL_LDSLINEAR
+            { h8 d0 = lds_h8(XA + lane * 8 + (G * NT + tm) * 512), d1 = lds_h8(XA + lane * 8 + (G * NT + tm) * 512 + T_XPLANE); dm[slot][tm][0] = d0; dm[slot][tm][1] = d1; }
+#else
+            { h8 d0 = lds_h8(XA + xbase[tm] + toff), d1 = lds_h8(XA + xbase[tm] + toff + T_XPLANE); dm[slot][tm][0] = d0; dm[slot][tm][1] = d1; }
+#endif
+#endif
+#if defined(NC_ABL_NOLDS) || defined(NC_ABL_LDSDUMMY)
             xa[slot][tm] = w1[(G + tm) % 7]; xb[slot][tm] = w1[7 + (G + 2 * tm) % 7];
 #else
             xa[slot][tm] = lds_h8(XA + xbase[tm] + toff);
@@ -746,11 +761,12 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
         }
     };
     constexpr int NG = NT > 1 ? 7 : C1_GHI(0);
-    load1(0, 0);
+#pragma unroll
+    for (int G = 0; G < DP && G < NG; G++) load1(G, G % NB);
 #pragma unroll
     for (int G = 0; G < NG; G++) {
-        const int cur = G & 1;
-        if (G + 1 < NG) load1(G + 1, cur ^ 1);
+        const int cur = G % NB;
+        if (G + DP < NG) load1(G + DP, (G + DP) % NB);
         __builtin_amdgcn_sched_barrier(0);
         // independent accumulators interleaved: no MFMA depends on the one issued just before it
 #pragma unroll
@@ -774,6 +790,11 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
             for (int tm = 0; tm < NT; tm++) if (C1_KM(tm) & 2) { NC_MFMA(acc2[tm], w1[21 + G - 1], xb[cur][tm]) }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef NC_ABL_LDSDUMMY
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) if (G < C1_GHI(tm)) asm volatile("" ::"v"(dm[cur][tm][0]), "v"(dm[cur][tm][1]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
@@ -784,6 +805,45 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
     }
 #undef C1_KM
 #undef C1_GHI
+}
+
+// One full conv1 tile in two halves: c1_tile_load requests the operands of all 7 K groups (14 fragments; the site's X buffer is
+// complete long before), c1_tile_mma multiplies them.  Role C issues the first before the beta barrier and runs the second behind it:
+// a single tile is one chain of {request, wait, 2-4 MFMAs} steps otherwise, bound by the LDS round trip of every step.
+__device__ __forceinline__ void c1_tile_load(const _Float16 *XA, int tile, int lane, h8 (&xa)[7], h8 (&xb)[7])
+{
+    const int g = lane >> 4, c16 = lane & 15, sh = 16 * g;
+    const int p = tile * 16 + c16, pr = p < 205 ? p : 204, h = pr / 41, w = pr - h * 41;
+    int xbase = (h * T_RX + w) * 8;
+    asm volatile("" : "+v"(xbase));
+#pragma unroll
+    for (int G = 0; G < 7; G++) {
+        const int toff = (int)((c1_tap_pack(G) >> sh) & 0xffffu);
+        xa[G] = lds_h8(XA + xbase + toff);
+        xb[G] = lds_h8(XA + xbase + toff + T_XPLANE);
+    }
+}
+__device__ __forceinline__ void c1_tile_mma(_Float16 *A1H, const h8 (&w1)[T_NW1], const float *__restrict__ b1s, const h_epi &epi, int tile, int lane,
+                                            const h8 (&xa)[7], const h8 (&xb)[7])
+{
+    const int g = lane >> 4, c16 = lane & 15;
+    const int p = tile * 16 + c16, pr = p < 205 ? p : 204, h = pr / 41, w = pr - h * 41;
+    int o = ((g >> 1) * T_PL1 + (p < 205 ? h * T_R1 + w : 4 * T_R1 + 41 + (p - 205))) * 8 + (g & 1) * 4;
+    asm volatile("" : "+v"(o));
+    f32x4v acc1 = *reinterpret_cast<const f32x4v *>(b1s + 4 * g), acc2 = *reinterpret_cast<const f32x4v *>(b1s + 16 + 4 * g),
+           acc3 = *reinterpret_cast<const f32x4v *>(b1s + 32 + 4 * g);
+#pragma unroll
+    for (int G = 0; G < 7; G++) {
+        NC_MFMA(acc3, w1[G], xa[G])
+        if (G < 2) { NC_MFMA(acc1, w1[14 + G], xa[G]) }
+        if (G >= 1 && G <= 3) { NC_MFMA(acc2, w1[18 + G - 1], xa[G]) }
+        NC_MFMA(acc3, w1[7 + G], xb[G])
+        if (G < 2) { NC_MFMA(acc1, w1[16 + G], xb[G]) }
+        if (G >= 1 && G <= 3) { NC_MFMA(acc2, w1[21 + G - 1], xb[G]) }
+    }
+    split4_store(selu4_scaled(acc1, epi), A1H + o, A1H + o + T_A1PLANE);
+    split4_store(selu4_scaled(acc2, epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
+    split4_store(selu4_scaled(acc3, epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
 }
 
 // conv2: wave (tn = wv & 1, t0 = wv >> 1) computes output channels 16 tn .. 16 tn + 15 of tiles t0, t0 + 2, (t0 + 4).
@@ -809,12 +869,29 @@ __device__ __forceinline__ void t_conv2(const _Float16 *A1H, _Float16 *A2H, cons
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) acc[tm] = b;
     }
-    h8 ah[2][NT], al[2][NT];
+#ifndef NC_C2_DEPTH_L
+#define NC_C2_DEPTH_L 1
+#endif
+#ifndef NC_C2_DEPTH_H
+#define NC_C2_DEPTH_H 1
+#endif
+    constexpr int DP = NT == 2 ? NC_C2_DEPTH_L : NC_C2_DEPTH_H, NB = DP + 1;
+    h8 ah[NB][NT], al[NB][NT];
+#ifdef NC_ABL_LDSDUMMY
+    h8 dm[NB][NT][2];
+#endif
     auto load2 = [&](int G, int slot) {
         const int off = (int)((c2_off_pack(G) >> sh) & 0xffffu);
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) {
-#ifdef NC_ABL_NOLDS
+#ifdef NC_ABL_LDSDUMMY
+#ifdef NC_ABL_LDSLINEAR
+            dm[slot][tm][0] = lds_h8(A1H + lane * 8 + (G * NT + tm) * 512); dm[slot][tm][1] = lds_h8(A1H + lane * 8 + (G * NT + tm) * 512 + T_A1PLANE);
+#else
+            dm[slot][tm][0] = lds_h8(A1H + abase[tm] + off); dm[slot][tm][1] = lds_h8(A1H + abase[tm] + off + T_A1PLANE);
+#endif
+#endif
+#if defined(NC_ABL_NOLDS) || defined(NC_ABL_LDSDUMMY)
             ah[slot][tm] = wh[(G + tm) % 9]; al[slot][tm] = wl[(G + 2 * tm) % 9];
 #else
             ah[slot][tm] = lds_h8(A1H + abase[tm] + off);
@@ -822,11 +899,12 @@ __device__ __forceinline__ void t_conv2(const _Float16 *A1H, _Float16 *A2H, cons
 #endif
         }
     };
-    load2(0, 0);
+#pragma unroll
+    for (int G = 0; G < DP; G++) load2(G, G % NB);
 #pragma unroll
     for (int G = 0; G < 9; G++) {
-        const int cur = G & 1;
-        if (G + 1 < 9) load2(G + 1, cur ^ 1);
+        const int cur = G % NB;
+        if (G + DP < 9) load2(G + DP, (G + DP) % NB);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wh[G], ah[cur][tm]) }
@@ -839,6 +917,11 @@ __device__ __forceinline__ void t_conv2(const _Float16 *A1H, _Float16 *A2H, cons
         for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc[tm], wl[G], ah[cur][tm]) }
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#ifdef NC_ABL_LDSDUMMY
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) asm volatile("" ::"v"(dm[cur][tm][0]), "v"(dm[cur][tm][1]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) split4_store(selu4_scaled(acc[tm], epi), A2H + obase[tm], A2H + obase[tm] + T_A2PLANE);
@@ -859,12 +942,26 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
     f32x4v acc[2];
     acc[0] = *reinterpret_cast<const f32x4v *>(b3s + wv * 16 + 4 * g);
     acc[1] = acc[0];
-    h8 ah[2][2], al[2][2];
+#ifndef NC_C3_DEPTH
+#define NC_C3_DEPTH 1
+#endif
+    constexpr int DP = NC_C3_DEPTH, NB = DP + 1;                      // K groups requested ahead of the one being multiplied / register buffers
+    h8 ah[NB][2], al[NB][2];
+#ifdef NC_ABL_LDSDUMMY
+    h8 dm[NB][2][2];
+#endif
     auto load3 = [&](int G, int slot) {                   // K group G = tap G, lane group g = channel chunk g
         const int off = ((G / 3) * T_R2 + (G % 3)) * 8;
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
-#ifdef NC_ABL_NOLDS
+#ifdef NC_ABL_LDSDUMMY
+#ifdef NC_ABL_LDSLINEAR
+            dm[slot][tm][0] = lds_h8(A2H + lane * 8 + (G % 3) * 1024 + tm * 512); dm[slot][tm][1] = lds_h8(A2H + lane * 8 + (G % 3) * 1024 + tm * 512 + T_A2PLANE);
+#else
+            dm[slot][tm][0] = lds_h8(A2H + abase[tm] + off); dm[slot][tm][1] = lds_h8(A2H + abase[tm] + off + T_A2PLANE);
+#endif
+#endif
+#if defined(NC_ABL_NOLDS) || defined(NC_ABL_LDSDUMMY)
             ah[slot][tm] = w3h[(G + tm) % 6]; al[slot][tm] = w3l[(G + 2 * tm) % 6];
 #else
             ah[slot][tm] = lds_h8(A2H + abase[tm] + off);
@@ -872,11 +969,12 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
 #endif
         }
     };
-    load3(0, 0);
+#pragma unroll
+    for (int G = 0; G < DP; G++) load3(G, G % NB);
 #pragma unroll
     for (int G = 0; G < 6; G++) {
-        const int cur = G & 1;
-        if (G + 1 < 6) load3(G + 1, cur ^ 1);
+        const int cur = G % NB;
+        if (G + DP < 6) load3(G + DP, (G + DP) % NB);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3h[G], ah[cur][tm]) }
@@ -889,6 +987,11 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm], w3l[G], ah[cur][tm]) }
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#ifdef NC_ABL_LDSDUMMY
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) asm volatile("" ::"v"(dm[cur][tm][0]), "v"(dm[cur][tm][1]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     const h_epi &e3 = epi;                                            // same fp16 range clamp as the other layers: k6_fc1_h3 splits
                                                                       // these values into fp16 hi/lo without a clamp of its own
@@ -906,11 +1009,18 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
 //   C:  P0 | conv1(0) alpha_0 | conv1(1) first tiles, staging commit of site 2, beta_0, last tile, alpha_1 | ... | beta_last
 //   D:  P0 | alpha_0 conv2(0) beta_0 conv3(0) | alpha_1 conv2(1) beta_1 conv3(1) | ...
 // No weight is re-read per site, and the MFMA phases of one role overlap the epilogues of the other on every SIMD.
-#ifdef NC_TRACE
+#if defined(NC_TRACE) || defined(NC_TRACE_BLOCKS)
 __device__ unsigned long long nc_trace_buf[8][8][8];     // [wave][site k in 8..15][event]
-#define NC_T(ev) if (blockIdx.x == 3 && lane == 0 && k >= 8 && k < 16) nc_trace_buf[wv][k - 8][ev] = __builtin_readcyclecounter();
+#endif
+#if defined(NC_TRACE) && !defined(NC_TRACE_BLOCKS)
+#define NC_T(ev) if (blockIdx.x == 3 && lane == 0 && k >= 8 && k < 16) { nc_trace_buf[wv][k - 8][ev] = __builtin_readcyclecounter(); if (ev == 0) nc_trace_buf[wv][k - 8][7] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define NC_T(ev)
+#endif
+#ifdef NC_ABL_NOBAR
+#define NC_SITE_SYNC()
+#else
+#define NC_SITE_SYNC() __syncthreads()
 #endif
 template <bool X16>                                             // X16: the site tensors are int16 (nc_set_tensor_format(ctx, 1))
 __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
@@ -923,6 +1033,12 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
     __shared__ __attribute__((aligned(16))) _Float16 A1[2][2 * T_A1PLANE];
     __shared__ __attribute__((aligned(16))) _Float16 A2[2 * T_A2PLANE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef NC_TRACE_BLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef NC_TRACE_BLOCKS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 3) (&nc_trace_buf[0][0][0])[504 + (threadIdx.x >> 6)] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | (1ull << 40);
+#endif
     const uint4 *w1f = reinterpret_cast<const uint4 *>(wp), *w2h = w1f + T_NW1 * 64, *w2l = w2h + T_NW2 * 64, *w3h = w2l + T_NW2 * 64,
                 *w3l = w3h + T_NW3 * 64;
     // the scaled biases live in LDS: a global load inside the site loop would make its s_waitcnt vmcnt also wait for the
@@ -1005,6 +1121,9 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         prefetch(site);
         commit(0);
         __syncthreads();                                                           // P0
+#ifdef NC_TRACE_BLOCKS
+        if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int64_t k = 0; k < n_k; k++, site += gridDim.x) {
             const int buf = (int)(k & 1);
             const bool more = k + 1 < n_k;
@@ -1022,21 +1141,35 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
             NC_T(1)
             // the other X buffer's last reader was conv1 of site k-1 (finished before alpha_{k-1}): the next site's tensor is
             // committed here, where role C has slack, and long after its loads were issued
+#if defined(NC_C1_PRELOAD) && !defined(NC_ABL_NOC)
+            h8 lxa[7], lxb[7];
+            c1_tile_load(X[buf], wv == 0 ? 12 : 8 + wv, lane, lxa, lxb);
+#endif
 #ifndef NC_ABL_NOSTAGE
             if (more) commit(buf ^ 1);
 #endif
             NC_T(6)
-            if (k > 0) __syncthreads();                                            // beta_{k-1}
+            if (k > 0) NC_SITE_SYNC();                                            // beta_{k-1}
             NC_T(2)
 #ifndef NC_ABL_NOC
-            t_conv1<1>(X[buf], A1[buf], w1, b1s, epi, wv == 0 ? 12 : 8 + wv, lane);
+#ifdef NC_C1_PRELOAD
+            c1_tile_mma(A1[buf], w1, b1s, epi, wv == 0 ? 12 : 8 + wv, lane, lxa, lxb);
+#else
+#ifndef NC_C1_LAST_DEPTH
+#define NC_C1_LAST_DEPTH 1
+#endif
+            t_conv1<1, 7, NC_C1_LAST_DEPTH>(X[buf], A1[buf], w1, b1s, epi, wv == 0 ? 12 : 8 + wv, lane);
+#endif
 #endif
             NC_T(3)
             NC_T(4)
-            __syncthreads();                                                       // alpha_k
+            NC_SITE_SYNC();                                                       // alpha_k
             NC_T(5)
         }
         __syncthreads();                                                           // beta_{n_k - 1}
+#ifdef NC_TRACE_BLOCKS
+        if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     } else {
         // ------------------------------------------------------------------ role D: conv2 + conv3
         const int d = wv - 4, tn = d & 1, heavy = d >> 1;                          // heavy: conv2 tiles 0,2,4; light: tiles 1,3
@@ -1051,19 +1184,312 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
         for (int64_t k = 0; k < n_k; k++, site += gridDim.x) {
             const int buf = (int)(k & 1);
             NC_T(0)
-            __syncthreads();                                                       // alpha_k
+            NC_SITE_SYNC();                                                       // alpha_k
             NC_T(1)
 #ifndef NC_ABL_NOD
             if (heavy) t_conv2<3>(A1[buf], A2, c2h, c2l, b2s, epi, tn, 0, lane);
             else t_conv2<2>(A1[buf], A2, c2h, c2l, b2s, epi, tn, 1, lane);
 #endif
             NC_T(2)
-            __syncthreads();                                                       // beta_k
+            NC_SITE_SYNC();                                                       // beta_k
             NC_T(3)
 #ifndef NC_ABL_NOD
             t_conv3(A2, c3h, c3l, b3s, epi, a3 + site * (27 * 64), c3slot, c3out, d, lane);
 #endif
             NC_T(4)
+        }
+    }
+}
+
+// ---- the three-stage form of the trunk (k5_trunk_p3): conv1, conv2 and conv3 work on three consecutive sites, ONE workgroup barrier per
+// site.  A conv2 wave computes all 32 output channels of its tiles and a conv3 wave 32 of the 64, so that every operand fragment read from
+// LDS feeds 6 MFMAs instead of 3 (338 instead of 458 ds_read_b128 per site: the LDS pipe at 128 B/clk is as loaded as the matrix pipe).
+// conv2, wave CW of two: tiles CW and CW + 2 in full, and channel half CW of tile 4 (columns 16..19 of the four rows)
+template <int CW>
+__device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H, const h8 (&wh)[9][2], const h8 (&wl)[9][2],
+                                             const float *__restrict__ b2s, const h_epi &epi, int lane)
+{
+    const int g = lane >> 4, c16 = lane & 15, sh = 16 * g;
+    int abase[3], obase[3];
+#pragma unroll
+    for (int tm = 0; tm < 3; tm++) {
+        const int t = tm < 2 ? CW + 2 * tm : 4;
+        const int y = t < 4 ? t : (c16 & 3), x = t < 4 ? c16 : 16 + (c16 >> 2);
+        abase[tm] = (y * T_R1 + 2 * x) * 8;
+        obase[tm] = ((g >> 1) * T_PL2 + y * T_R2 + x) * 8 + (g & 1) * 4;              // channel half 0; half 1: + 2 * T_PL2 * 8
+        asm volatile("" : "+v"(abase[tm]), "+v"(obase[tm]));
+    }
+    f32x4v acc[2][2], acc4;
+    {
+        const f32x4v b0 = *reinterpret_cast<const f32x4v *>(b2s + 4 * g), b1 = *reinterpret_cast<const f32x4v *>(b2s + 16 + 4 * g);
+        acc[0][0] = b0; acc[1][0] = b0; acc[0][1] = b1; acc[1][1] = b1;
+        acc4 = CW ? b1 : b0;
+    }
+#ifndef NC_P3_C2_DEPTH
+#define NC_P3_C2_DEPTH 1
+#endif
+    constexpr int DP = NC_P3_C2_DEPTH, NB = DP + 1;
+    h8 ah[NB][3], al[NB][3];
+    auto load2 = [&](int G, int slot) {
+        const int off = (int)((c2_off_pack(G) >> sh) & 0xffffu);
+#pragma unroll
+        for (int tm = 0; tm < 3; tm++) {
+            ah[slot][tm] = lds_h8(A1H + abase[tm] + off);
+            al[slot][tm] = lds_h8(A1H + abase[tm] + off + T_A1PLANE);
+        }
+    };
+#pragma unroll
+    for (int G = 0; G < DP; G++) load2(G, G % NB);
+#pragma unroll
+    for (int G = 0; G < 9; G++) {
+        const int cur = G % NB;
+        if (G + DP < 9) load2(G + DP, (G + DP) % NB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], wh[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], wh[G][1], ah[cur][tm]) }
+        NC_MFMA(acc4, wh[G][CW], ah[cur][2])
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], wh[G][0], al[cur][tm]) NC_MFMA(acc[tm][1], wh[G][1], al[cur][tm]) }
+        NC_MFMA(acc4, wh[G][CW], al[cur][2])
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], wl[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], wl[G][1], ah[cur][tm]) }
+        NC_MFMA(acc4, wl[G][CW], ah[cur][2])
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int o = obase[tm] + tn * 2 * T_PL2 * 8;
+            split4_store(selu4_scaled(acc[tm][tn], epi), A2H + o, A2H + o + T_A2PLANE);
+        }
+    {
+        const int o = obase[2] + CW * 2 * T_PL2 * 8;
+        split4_store(selu4_scaled(acc4, epi), A2H + o, A2H + o + T_A2PLANE);
+    }
+}
+
+// conv3, wave CW of two: output channels 32 CW .. 32 CW + 31 of both position tiles
+template <int CW>
+__device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h)[6][2], const h8 (&w3l)[6][2], const float *__restrict__ b3s,
+                                             const h_epi &epi, float *__restrict__ out_site, const int (&c3slot)[2], const int (&c3out)[2], int lane)
+{
+    const int g = lane >> 4;
+    int abase[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        abase[tm] = (g * T_PL2 + c3slot[tm]) * 8;
+        asm volatile("" : "+v"(abase[tm]));
+    }
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        acc[0][tn] = *reinterpret_cast<const f32x4v *>(b3s + (2 * CW + tn) * 16 + 4 * g);
+        acc[1][tn] = acc[0][tn];
+    }
+#ifndef NC_P3_C3_DEPTH
+#define NC_P3_C3_DEPTH 1
+#endif
+    constexpr int DP = NC_P3_C3_DEPTH, NB = DP + 1;
+    h8 ah[NB][2], al[NB][2];
+    auto load3 = [&](int G, int slot) {
+        const int off = ((G / 3) * T_R2 + (G % 3)) * 8;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            ah[slot][tm] = lds_h8(A2H + abase[tm] + off);
+            al[slot][tm] = lds_h8(A2H + abase[tm] + off + T_A2PLANE);
+        }
+    };
+#pragma unroll
+    for (int G = 0; G < DP; G++) load3(G, G % NB);
+#pragma unroll
+    for (int G = 0; G < 6; G++) {
+        const int cur = G % NB;
+        if (G + DP < 6) load3(G + DP, (G + DP) % NB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], w3h[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], w3h[G][1], ah[cur][tm]) }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], w3h[G][0], al[cur][tm]) NC_MFMA(acc[tm][1], w3h[G][1], al[cur][tm]) }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], w3l[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], w3l[G][1], ah[cur][tm]) }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+        if (c3out[tm] >= 0) {
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++)
+                *reinterpret_cast<f32x4v *>(out_site + c3out[tm] * 64 + (2 * CW + tn) * 16 + 4 * g) = selu4_scaled(acc[tm][tn], epi);
+        }
+}
+
+// Three roles, one barrier per site.  Step s: waves 0-3 ("C") run conv1 of site s (X[s & 1] -> A1[s & 1]) and stage site s + 1; waves 4, 5
+// run conv2 of site s - 1 (A1[(s - 1) & 1] -> A2[(s - 1) & 1]); waves 6, 7 run conv3 of site s - 2 (A2[s & 1] -> HBM).  Every wave's weight
+// fragments stay in its registers (conv1 96, conv2 144, conv3 96 VGPRs).  Matrix instructions per SIMD and site: waves 0 / 1 two conv1 tiles
+// (48) beside a conv2 wave (135), waves 2 / 3 four tiles and a part of tile 12 (110 / 106) beside a conv3 wave (72).
+template <bool X16>
+__global__ __launch_bounds__(512) void k5_trunk_p3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
+                                                   int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0, float x_limit,
+                                                   uint8_t *__restrict__ range_sites)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 X[2][2 * T_XPLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 A1[2][2 * T_A1PLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 A2[2][2 * T_A2PLANE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef NC_TRACE_BLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef NC_TRACE_BLOCKS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 3) (&nc_trace_buf[0][0][0])[504 + (threadIdx.x >> 6)] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | (1ull << 40);
+#endif
+    const uint4 *w1f = reinterpret_cast<const uint4 *>(wp), *w2h = w1f + T_NW1 * 64, *w2l = w2h + T_NW2 * 64, *w3h = w2l + T_NW2 * 64,
+                *w3l = w3h + T_NW3 * 64;
+    __shared__ __attribute__((aligned(16))) float BIAS[48 + 32 + 64];
+    const float *bg = reinterpret_cast<const float *>(w3l + T_NW3 * 64);
+    const float *b1s = BIAS, *b2s = BIAS + 48, *b3s = BIAS + 80;
+    const int *c3tab = reinterpret_cast<const int *>(bg + 48 + 32 + 68);
+    const float inv_s = bg[48 + 32 + 64];
+    if (threadIdx.x < 48 + 32 + 64) BIAS[threadIdx.x] = bg[threadIdx.x];
+    const h_epi epi = {inv_s * 1.44269504088896341f, inv_s * SELU_L, 60000.0f / (inv_s * SELU_L)};
+    const int64_t n_k = (n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x;        // sites of this workgroup (>= 1)
+    for (int i = threadIdx.x; i < 4 * T_XS; i += 512) *reinterpret_cast<uint4 *>(&X[0][0] + i * 8) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (wv < 4) {
+        // ------------------------------------------------------------------ role C: staging + conv1 (as in k5_trunk_h3)
+        h8 w1[T_NW1];
+#pragma unroll
+        for (int q = 0; q < T_NW1; q++) w1[q] = as_h8(w1f[q * 64 + lane]);
+        const int px = threadIdx.x < 205 ? threadIdx.x : 204, ph = px / 41, pw = px - ph * 41;
+        const int xslot = ((ph + 2) * T_RX + pw + 2) * 8;
+        float pre[5];
+        uint32_t raw[3];
+        double pre_sd = 1.0;
+        int64_t pre_site = 0;
+        auto prefetch = [&](int64_t site) {
+            pre_site = site;
+            if constexpr (X16) {
+                const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;       // 2-byte aligned
+                typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                raw[0] = *reinterpret_cast<const u32_a2 *>(xs);
+                raw[1] = *reinterpret_cast<const u32_a2 *>(xs + 2);
+                raw[2] = (uint32_t)(uint16_t)xs[4];
+            } else {
+                const float *xs = x + site * NC_SNP_TENSOR + px * 5;
+#pragma unroll
+                for (int u = 0; u < 5; u++) pre[u] = xs[u];
+            }
+            if (scale) pre_sd = scale[site0 + site];
+        };
+        auto commit = [&](int buf) {
+            if (threadIdx.x < 205) {
+                if constexpr (X16) {
+                    pre[0] = (float)(int16_t)(raw[0] & 0xffffu); pre[1] = (float)(int16_t)(raw[0] >> 16);
+                    pre[2] = (float)(int16_t)(raw[1] & 0xffffu); pre[3] = (float)(int16_t)(raw[1] >> 16);
+                    pre[4] = (float)(int16_t)raw[2];
+                }
+                const double md = (scale && ph > 0) ? pre_sd : 1.0;               // snpCaller.py:93-96
+                const float mf = (float)md;
+                if (scale_mode == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pre[u] *= mf;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pre[u] = (float)((double)pre[u] * md);
+                }
+                const float amax = fmaxf(fmaxf(fmaxf(fabsf(pre[0]), fabsf(pre[1])), fmaxf(fabsf(pre[2]), fabsf(pre[3]))), fabsf(pre[4]));
+                if (range_sites && !(amax <= x_limit)) range_sites[site0 + pre_site] = 1;
+                _Float16 hi[5], lo[5];
+#pragma unroll
+                for (int u = 0; u < 5; u++) {
+                    float v = pre[u];
+                    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                    hi[u] = (_Float16)v;
+                    lo[u] = (_Float16)(v - (float)hi[u]);
+                }
+                const h8 sa = {hi[0], hi[1], hi[2], hi[3], hi[4], lo[0], lo[1], lo[2]};
+                const h8 sb = {lo[3], lo[4], hi[0], hi[1], hi[2], hi[3], hi[4], (_Float16)0.0f};
+                *reinterpret_cast<h8 *>(&X[buf][xslot]) = sa;
+                *reinterpret_cast<h8 *>(&X[buf][xslot + T_XPLANE]) = sb;
+            }
+        };
+        int64_t site = blockIdx.x;
+        prefetch(site);
+        commit(0);
+        __syncthreads();                                                           // P0
+#ifdef NC_TRACE_BLOCKS
+        if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef NC_P3_COMMIT_FIRST
+        if (n_k > 1) prefetch(site + gridDim.x);
+#endif
+        for (int64_t s = 0; s < n_k + 2; s++, site += gridDim.x) {
+            if (s < n_k) {
+                const int buf = (int)(s & 1);
+                const bool more = s + 1 < n_k;
+#ifdef NC_P3_COMMIT_FIRST
+                // the staging of site s + 1 (vector work) opens the step, beside the matrix work the SIMD's other wave opens its step with
+                if (more) commit(buf ^ 1);
+                if (s + 2 < n_k) prefetch(site + 2 * gridDim.x);
+#else
+                if (more) prefetch(site + gridDim.x);
+#endif
+                if (wv < 2) t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, wv, lane);                       // tiles wv, wv + 4
+                else if (wv == 2) {
+                    t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, 2, lane);                                 // tiles 2, 6
+                    t_conv1<3, 4>(X[buf], A1[buf], w1, b1s, epi, 3, lane, 12);                          // tiles 3, 7, the 5x5 channels of tile 12
+                } else {
+                    t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, 8, lane, -1, 1);                          // tiles 8, 9
+                    t_conv1<3, 3>(X[buf], A1[buf], w1, b1s, epi, 10, lane, 12, 1);                      // tiles 10, 11, the 1x5 + 5x1 channels of tile 12
+                }
+#ifndef NC_P3_COMMIT_FIRST
+                if (more) commit(buf ^ 1);
+#endif
+            }
+            NC_SITE_SYNC();
+        }
+#ifdef NC_TRACE_BLOCKS
+        if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    } else if (wv < 6) {
+        // ------------------------------------------------------------------ conv2 of site s - 1
+        h8 c2h[9][2], c2l[9][2];
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) { c2h[q][tn] = as_h8(w2h[(q * 2 + tn) * 64 + lane]); c2l[q][tn] = as_h8(w2l[(q * 2 + tn) * 64 + lane]); }
+        __syncthreads();                                                           // P0
+        for (int64_t s = 0; s < n_k + 2; s++) {
+            if (s >= 1 && s - 1 < n_k) {
+                const int buf = (int)((s - 1) & 1);
+                if (wv == 4) t_conv2_pair<0>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane);
+                else t_conv2_pair<1>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane);
+            }
+            NC_SITE_SYNC();
+        }
+    } else {
+        // ------------------------------------------------------------------ conv3 of site s - 2
+        const int cw = wv - 6;
+        h8 c3h[6][2], c3l[6][2];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                c3h[q][tn] = as_h8(w3h[(q * 4 + 2 * cw + tn) * 64 + lane]);
+                c3l[q][tn] = as_h8(w3l[(q * 4 + 2 * cw + tn) * 64 + lane]);
+            }
+        const int c3slot[2] = {c3tab[lane & 15], c3tab[16 + (lane & 15)]}, c3out[2] = {c3tab[32 + (lane & 15)], c3tab[48 + (lane & 15)]};
+        __syncthreads();                                                           // P0
+        int64_t site = blockIdx.x;
+        for (int64_t s = 0; s < n_k + 2; s++) {
+            if (s >= 2) {
+                const int buf = (int)(s & 1);
+                float *out_site = a3 + site * (27 * 64);
+                if (cw == 0) t_conv3_pair<0>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane);
+                else t_conv3_pair<1>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane);
+                site += gridDim.x;
+            }
+            NC_SITE_SYNC();
         }
     }
 }
@@ -1884,7 +2310,10 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         constexpr int TMF = 1;
         (void)np2;
         const unsigned nblk = (unsigned)(nb < 512 ? nb : 512);          // k4: 2 resident workgroups per CU, persistent over sites
-        const unsigned nblk5 = (unsigned)(nb < 256 ? nb : 256);        // k5: one 512-thread workgroup per CU
+#ifndef NC_EXP_NBLK
+#define NC_EXP_NBLK 256
+#endif
+        const unsigned nblk5 = (unsigned)(nb < NC_EXP_NBLK ? nb : NC_EXP_NBLK);        // k5: one 512-thread workgroup per CU
         (void)np3; (void)a2; (void)k3; (void)b3;
         const bool tk = ctx->timing && ctx->n_kev + 2 <= 128;
         // timing mode: the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL), so they
@@ -1900,10 +2329,14 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
         if (ctx->cnn_exact_fp32)
             hipExtLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, ev0, ev1, 0, x_batch, packed, a3, nb, scale, scale_mode, site0);
         else
-            if (ctx->x_i16)
-                hipExtLaunchKernelGGL(k5_trunk_h3<true>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
-            else
-                hipExtLaunchKernelGGL(k5_trunk_h3<false>, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
+        {
+#ifdef NC_TRUNK_P3
+            auto *kt = ctx->x_i16 ? k5_trunk_p3<true> : k5_trunk_p3<false>;
+#else
+            auto *kt = ctx->x_i16 ? k5_trunk_h3<true> : k5_trunk_h3<false>;
+#endif
+            hipExtLaunchKernelGGL(kt, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
+        }
         if (ctx->cnn_exact_fp32)
             hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
         else
@@ -1937,7 +2370,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
 
 extern "C" {
 
-#ifdef NC_TRACE
+#if defined(NC_TRACE) || defined(NC_TRACE_BLOCKS)
 int nc_debug_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nc_trace_buf), sizeof(nc_trace_buf)); }
 #endif
 

@@ -19,7 +19,7 @@ def one(libpath):
     eng = get_engine(0)
     w = Weights(get_SNP_model("ONT-HG002")[0])
     eng.load_weights(_lib.MODEL_SNP, w)
-    n = 32768 * 8
+    n = int(os.environ.get("NC_EXP_SITES", 32768 * 8))
     g = torch.Generator(device="cuda").manual_seed(1)
     i16 = os.environ.get("NC_EXP_FP32X") is None                  # product format: int16 site tensors
     x = torch.rand((n, 5, 41, 5), device="cuda", generator=g) * 30
@@ -33,15 +33,45 @@ def one(libpath):
         eng.snp_forward(_lib.MODEL_SNP, x, rc, sc)
         eng.enable_timing(True)
         ms, nl = 0.0, 0.0
-        for _ in range(3):
+        for _ in range(12):                                        # the first launches after an idle device run 15-25 % slower (clock ramp): not timed
+            eng.snp_forward(_lib.MODEL_SNP, x, rc, sc)
+        for _ in range(20):
             eng.snp_forward(_lib.MODEL_SNP, x, rc, sc)
             ms += eng.last_ms(4); nl += eng.last_ms(5)
+        if os.environ.get("NC_EXP_WALL"):
+            for reps in (1, 3, 10):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                tk = 0.0
+                for _ in range(reps):
+                    eng.snp_forward(_lib.MODEL_SNP, x, rc, sc)
+                    tk += eng.last_ms(4)
+                e1.record()
+                torch.cuda.synchronize()
+                print("   %d forwards back to back: %.4f ms each by stream events around them; trunk launches by their dispatch events %.4f ms each" % (reps, e0.elapsed_time(e1) / reps, tk / reps), flush=True)
+        if os.environ.get("NC_EXP_ISOLATED"):
+            iso = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                eng.snp_forward(_lib.MODEL_SNP, x, rc, sc)
+                torch.cuda.synchronize()
+                iso.append(eng.last_ms(4) / max(eng.last_ms(5), 1))
+            print("   isolated launches (device idle before each): %s ms" % " ".join("%.4f" % v for v in iso), flush=True)
         eng.enable_timing(False)
         print("%-32s %s trunk %.4f ms/launch" % (os.path.basename(libpath or "in-tree"), "fp32  " if exact else "fp16x3", ms / nl), flush=True)
     if hasattr(_lib.lib(), "nc_debug_trace"):
         import ctypes
         buf = np.zeros((8, 8, 8), np.uint64)
         _lib.lib().nc_debug_trace(ctypes.c_void_p(buf.ctypes.data))
+        if os.environ.get("NC_TRACE_CLOCK"):
+            b = buf.reshape(128, 4).astype(np.int64)
+            t0 = b[:, 0].min()
+            en0, p0, en = (b[:, 0] - t0) / 100.0, (b[:, 1] - t0) / 100.0, (b[:, 2] - t0) / 100.0
+            hw = buf.reshape(-1)[504:512].astype(np.int64) & 0xffffffff
+            print("   HW_ID of block 3's waves 0..7: " + " ".join("w%d:simd%d,wave%d,cu%d,se%d" % (i, (h >> 4) & 3, h & 15, (h >> 8) & 15, (h >> 13) & 7) for i, h in enumerate(hw)))
+            print("   blocks: entry %.1f .. %.1f us, P0 %.1f .. %.1f us, loop end %.1f .. %.1f us" % (en0.min(), en0.max(), p0.min(), p0.max(), en.min(), en.max()))
+            return
         t0 = buf[:, :, :6][buf[:, :, :6] > 0].min()
         rel = np.where(buf > 0, buf.astype(np.int64) - int(t0), -1)
         for w in range(8):
