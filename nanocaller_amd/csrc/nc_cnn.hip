@@ -1957,7 +1957,11 @@ constexpr bool K10_C1 = true, K10_C2 = true, K10_C3 = true;
 #ifdef NC_K10_NOMFMA
 #define K10_MFMA(ACC, A_, B_) asm volatile("" ::"v"(A_), "v"(B_));
 #else
+#ifdef NC_K10_NOP
+#define K10_MFMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0); asm volatile("s_nop %1" : "+v"(ACC) : "n"(NC_K10_NOP));
+#else
 #define K10_MFMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0);
+#endif
 #endif
 template <int H>
 __global__ __launch_bounds__(768) void k10_indel_trunk_h3(const float *__restrict__ x, const uint8_t *__restrict__ wp1, const uint8_t *__restrict__ wp2,
