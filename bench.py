@@ -39,7 +39,7 @@ TRUNK_FLOP_PER_SITE = 2 * (574_000 + 737_280 + 331_776)   # conv1 (3 kernels) + 
 INDEL_FLOP_PER_SITE = 18_946_752       # SURVEY.md 8d (haploid 5,040,688)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md, dense
-# k5_trunk_h3 issues 3 f16 MFMA products per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so the peak its ALGORITHMIC
+# k5_trunk_p3 issues 3 f16 MFMA products per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so the peak its ALGORITHMIC
 # FLOP can reach is the dense f16 MFMA peak / 3; the executed v_mfma_f32_16x16x32_f16 per site come from the library
 HBM_PEAK_GBS = 8000.0
 PCIE_PEAK_GBS = 63.0                   # MI355X_MICROARCH.md: PCIe Gen5 x16
@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--cpu-sample-chunks", type=int, default=0,
                     help="chunks of contig 0 the CPU baseline runs; 0 = the whole contig (SURVEY 8d: one OS process per usable core pulling chunks from a queue)")
     ap.add_argument("--cnn-precision", default="default", choices=["default", "fp32", "fp16x3"],
-                    help="trunk kernel: exact fp32 MFMA (k4_conv12) or fp16x3 split precision (k5_trunk_h3)")
+                    help="trunk kernel: exact fp32 MFMA (k4_conv12) or fp16x3 split precision (k5_trunk_p3)")
     return ap.parse_args()
 
 
@@ -312,7 +312,7 @@ def extra_snp_config(eng, uploader, local, L, depth, tech, model, ploidy, exact_
         out = {"workload": label, "value": sites / dt, "unit": "sites/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                "sites_per_step": sites // steps, "hbm_resident_sites_s": sites_r / dt_r, "wire_bytes_per_contig": c.wire.nbytes,
                "pileup_entries": c.entries,
-               "roofline": {"bound": "mfma", "kernel": "k4_conv12 (exact fp32 MFMA 16x16x4)" if exact_fp32 else "k5_trunk_h3 (f16x3 split MFMA)",
+               "roofline": {"bound": "mfma", "kernel": "k4_conv12 (exact fp32 MFMA 16x16x4)" if exact_fp32 else "k5_trunk_p3 (f16x3 split MFMA)",
                             "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
                             "avg_launch_ms": sums[4] / max(1.0, sums[5])}}
         del c
@@ -784,7 +784,7 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
                            % (snp.wire.nbytes / 1e6, job.wire.nbytes / 1e6),
            "vcf_records_per_step_indel": nrec // steps,
            "snp_half": {"sites_per_step": ns // steps, "ms_per_step_alone": dt_s / steps * 1e3, "sites_s_alone": ns_a / dt_s,
-                        "roofline": {"bound": "mfma", "kernel": "k5_trunk_h3", "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
+                        "roofline": {"bound": "mfma", "kernel": "k5_trunk_p3", "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
                                      "avg_launch_ms": float(trunk_ms / trunk_n), "launches": trunk_n,
                                      "note": "HIP events on the trunk's launches inside the combined timed region"}},
            "indel_half": {"sites_per_step": ni // steps, "ms_per_step_alone": dt_i / steps * 1e3, "sites_s_alone": ni_a / dt_i,
@@ -1197,7 +1197,7 @@ def main():
         feat_bytes = (5403 - 2050) * n_sites                  # SURVEY.md 8d's 5,403 B/site with the tensor written as int16 (2,050 B) instead of fp32
         tt = trunk_traffic_from_profiles()
         traffic, stale_note = None, None
-        if tt and tt.get("kernel") == ("k4_conv12" if exact_fp32 else "k5_trunk_h3"):
+        if tt and tt.get("kernel") == ("k4_conv12" if exact_fp32 else "k5_trunk_p3"):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from build_tag import TRUNK_SOURCES
             tag_ok, stale_note = traffic_build_check(tt, TRUNK_SOURCES)
@@ -1216,7 +1216,7 @@ def main():
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
             mfma_per_site = eng.trunk_mfma_per_site()
             exec_tflops = mfma_per_site * 16384.0 * sites_timed / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": "k5_trunk_h3: fused conv1+conv2+conv3 of the SNP CNN, fp32-equivalent via 3 "
+            roofline = {"bound": "mfma", "kernel": "k5_trunk_p3: fused conv1+conv2+conv3 of the SNP CNN (three roles on three consecutive sites), fp32-equivalent via 3 "
                         "f16 MFMA 16x16x32 products (hi*hi + hi*lo + lo*hi), fp32 accumulate",
                         "peak": peak, "peak_note": "dense f16 MFMA peak 2500 TF / 3 products per fp32-equivalent product",
                         "frac": trunk_tflops / peak, "executed_mfma_per_site": mfma_per_site, "executed_f16_mfma_tflops": exec_tflops,

@@ -12,6 +12,7 @@
 // fp32 matrix and vector peaks are equal on gfx950 (157.3 TFLOP/s), so this VALU form has the same roof as
 // v_mfma_f32_* while keeping the weights out of the vector register file.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -658,6 +659,10 @@ __device__ __forceinline__ float exp2_clamp01(float x) { float r; asm("v_exp_f32
 // v - float(lo / hi half of a packed f16 pair): v_fma_mix_f32 reads the f16 operand directly (no separate v_cvt_f32_f16)
 __device__ __forceinline__ float sub_h_lo(float v, uint32_t hpk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v)); return r; }
 __device__ __forceinline__ float sub_h_hi(float v, uint32_t hpk) { float r; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v)); return r; }
+#ifndef NC_EPI_VAR
+#define NC_EPI_VAR 0
+#endif
+__device__ __forceinline__ float fma_plain(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ f32x4v selu4_scaled(const f32x4v &acc, const h_epi &k)
 {
     f32x4v s;
@@ -668,9 +673,15 @@ __device__ __forceinline__ f32x4v selu4_scaled(const f32x4v &acc, const h_epi &k
     for (int r = 0; r < 4; r++) {
         const float a = acc[r];
         const float e = exp2_clamp01(a * k.c1);                       // exp(min(a, 0) / S)
-        const float neg = fmaf(e, SELU_LA, -SELU_LA);                 // exactly 0 for a >= 0
         const float pos = __builtin_amdgcn_fmed3f(a, 0.0f, k.c3);
+#if NC_EPI_VAR >= 1
+        // plain v_fma_f32 (the compiler would pair these into v_pk_fma_f32, which does not run beside MFMAs: tools/ubench/coexec3.hip, epi.hip)
+        const float neg = fma_plain(e, SELU_LA, -SELU_LA);
+        s[r] = fma_plain(pos, k.c2, neg);
+#else
+        const float neg = fmaf(e, SELU_LA, -SELU_LA);                 // exactly 0 for a >= 0
         s[r] = fmaf(pos, k.c2, neg);
+#endif
     }
     return s;
 }
@@ -682,10 +693,22 @@ __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Flo
 {
     const h2 h01 = __builtin_convertvector((f32x2v){v[0], v[1]}, h2), h23 = __builtin_convertvector((f32x2v){v[2], v[3]}, h2);   // v_cvt_pk_f16_f32, RNE
     const uint32_t u01 = __builtin_bit_cast(uint32_t, h01), u23 = __builtin_bit_cast(uint32_t, h23);
+#if NC_EPI_VAR >= 2
+    // lo = f16(v - f32(hi)) in ONE instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16: the fp32 difference is exact, the result is rounded to
+    // fp16 like v_cvt_pk_f16_f32 rounds it) instead of v_fma_mix_f32 + half a v_cvt_pk_f16_f32
+    uint32_t w01, w23;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(w01) : "v"(u01), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(w01) : "v"(u01), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(w23) : "v"(u23), "v"(v[2]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(w23) : "v"(u23), "v"(v[3]));
+    *reinterpret_cast<uint2 *>(hp) = make_uint2(u01, u23);
+    *reinterpret_cast<uint2 *>(lp) = make_uint2(w01, w23);
+#else
     const f32x2v d01 = {sub_h_lo(v[0], u01), sub_h_hi(v[1], u01)}, d23 = {sub_h_lo(v[2], u23), sub_h_hi(v[3], u23)};              // exact in fp32
     const h2 l01 = __builtin_convertvector(d01, h2), l23 = __builtin_convertvector(d23, h2);
     *reinterpret_cast<uint2 *>(hp) = make_uint2(u01, u23);
     *reinterpret_cast<uint2 *>(lp) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+#endif
 }
 #ifdef NC_ABL_NOMFMA
 #define NC_MFMA(ACC, W, X) asm volatile("" ::"v"(W), "v"(X));
@@ -706,9 +729,14 @@ __device__ __forceinline__ void split4_store(const f32x4v &v, _Float16 *hp, _Flo
 // the 5x1 kernel's (6 MFMAs, groups 1..3), bit 2 the 5x5 kernel's (14 MFMAs, all groups).  A tile can so be shared by two
 // waves to even out the SIMDs, and its MFMAs are interleaved with those of the wave's full tiles (a partial tile on its own
 // is one chain of dependent MFMAs: latency-bound).
+#ifdef NC_TRACE_P3
+#define P3_T(ev) if (trk) trk[ev] = __builtin_readcyclecounter();
+#else
+#define P3_T(ev)
+#endif
 template <int NT, int KL = 7, int DP = 1>
 __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const h8 (&w1)[T_NW1],
-                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane, int tile_last = -1, int tile_stride = 4)
+                                        const float *__restrict__ b1s, const h_epi &epi, int tile_first, int lane, int tile_last = -1, int tile_stride = 4, unsigned long long *trk = nullptr, int tev = 0)
 {
     // kernel mask and K-group range of tile tm
 #define C1_KM(tm) ((tm) == NT - 1 ? KL : 7)
@@ -796,6 +824,7 @@ __device__ __forceinline__ void t_conv1(const _Float16 *XA, _Float16 *A1H, const
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+    if (trk) trk[tev] = __builtin_readcyclecounter();
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
         const int o = obase[tm];
@@ -1009,7 +1038,7 @@ __device__ __forceinline__ void t_conv3(const _Float16 *A2H, const h8 (&w3h)[6],
 //   C:  P0 | conv1(0) alpha_0 | conv1(1) first tiles, staging commit of site 2, beta_0, last tile, alpha_1 | ... | beta_last
 //   D:  P0 | alpha_0 conv2(0) beta_0 conv3(0) | alpha_1 conv2(1) beta_1 conv3(1) | ...
 // No weight is re-read per site, and the MFMA phases of one role overlap the epilogues of the other on every SIMD.
-#if defined(NC_TRACE) || defined(NC_TRACE_BLOCKS)
+#if defined(NC_TRACE) || defined(NC_TRACE_BLOCKS) || defined(NC_TRACE_P3)
 __device__ unsigned long long nc_trace_buf[8][8][8];     // [wave][site k in 8..15][event]
 #endif
 #if defined(NC_TRACE) && !defined(NC_TRACE_BLOCKS)
@@ -1205,9 +1234,14 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
 // site.  A conv2 wave computes all 32 output channels of its tiles and a conv3 wave 32 of the 64, so that every operand fragment read from
 // LDS feeds 6 MFMAs instead of 3 (338 instead of 458 ds_read_b128 per site: the LDS pipe at 128 B/clk is as loaded as the matrix pipe).
 // conv2, wave CW of two: tiles CW and CW + 2 in full, and channel half CW of tile 4 (columns 16..19 of the four rows)
+#ifdef NC_P3_NOP
+#define NC_MFMA_P(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(W, X, ACC, 0, 0, 0); asm volatile("s_nop %1" : "+v"(ACC) : "n"(NC_P3_NOP));
+#else
+#define NC_MFMA_P(ACC, W, X) NC_MFMA(ACC, W, X)
+#endif
 template <int CW>
 __device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H, const h8 (&wh)[9][2], const h8 (&wl)[9][2],
-                                             const float *__restrict__ b2s, const h_epi &epi, int lane)
+                                             const float *__restrict__ b2s, const h_epi &epi, int lane, unsigned long long *trk = nullptr)
 {
     const int g = lane >> 4, c16 = lane & 15, sh = 16 * g;
     int abase[3], obase[3];
@@ -1246,16 +1280,17 @@ __device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H,
         if (G + DP < 9) load2(G + DP, (G + DP) % NB);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], wh[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], wh[G][1], ah[cur][tm]) }
-        NC_MFMA(acc4, wh[G][CW], ah[cur][2])
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA_P(acc[tm][0], wh[G][0], ah[cur][tm]) NC_MFMA_P(acc[tm][1], wh[G][1], ah[cur][tm]) }
+        NC_MFMA_P(acc4, wh[G][CW], ah[cur][2])
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], wh[G][0], al[cur][tm]) NC_MFMA(acc[tm][1], wh[G][1], al[cur][tm]) }
-        NC_MFMA(acc4, wh[G][CW], al[cur][2])
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA_P(acc[tm][0], wh[G][0], al[cur][tm]) NC_MFMA_P(acc[tm][1], wh[G][1], al[cur][tm]) }
+        NC_MFMA_P(acc4, wh[G][CW], al[cur][2])
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], wl[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], wl[G][1], ah[cur][tm]) }
-        NC_MFMA(acc4, wl[G][CW], ah[cur][2])
+        for (int tm = 0; tm < 2; tm++) { NC_MFMA_P(acc[tm][0], wl[G][0], ah[cur][tm]) NC_MFMA_P(acc[tm][1], wl[G][1], ah[cur][tm]) }
+        NC_MFMA_P(acc4, wl[G][CW], ah[cur][2])
         __builtin_amdgcn_sched_barrier(0);
     }
+    P3_T(1)
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
@@ -1272,7 +1307,8 @@ __device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H,
 // conv3, wave CW of two: output channels 32 CW .. 32 CW + 31 of both position tiles
 template <int CW>
 __device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h)[6][2], const h8 (&w3l)[6][2], const float *__restrict__ b3s,
-                                             const h_epi &epi, float *__restrict__ out_site, const int (&c3slot)[2], const int (&c3out)[2], int lane)
+                                             const h_epi &epi, float *__restrict__ out_site, const int (&c3slot)[2], const int (&c3out)[2], int lane,
+                                             unsigned long long *trk = nullptr)
 {
     const int g = lane >> 4;
     int abase[2];
@@ -1315,6 +1351,7 @@ __device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], w3l[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], w3l[G][1], ah[cur][tm]) }
         __builtin_amdgcn_sched_barrier(0);
     }
+    P3_T(1)
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
         if (c3out[tm] >= 0) {
@@ -1324,10 +1361,15 @@ __device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h
         }
 }
 
-// Three roles, one barrier per site.  Step s: waves 0-3 ("C") run conv1 of site s (X[s & 1] -> A1[s & 1]) and stage site s + 1; waves 4, 5
-// run conv2 of site s - 1 (A1[(s - 1) & 1] -> A2[(s - 1) & 1]); waves 6, 7 run conv3 of site s - 2 (A2[s & 1] -> HBM).  Every wave's weight
-// fragments stay in its registers (conv1 96, conv2 144, conv3 96 VGPRs).  Matrix instructions per SIMD and site: waves 0 / 1 two conv1 tiles
-// (48) beside a conv2 wave (135), waves 2 / 3 four tiles and a part of tile 12 (110 / 106) beside a conv3 wave (72).
+// Three roles, one barrier per site (the default trunk since round 5).  Step s:
+//   waves 4-7: conv1 of site s (X[s & 1] -> A1[s & 1]); waves 4, 5 three tiles (72 MFMAs), waves 6, 7 three tiles + their part of tile 12 (86 / 82);
+//   waves 0, 1: conv2 of site s - 1 (A1[(s - 1) & 1] -> A2[(s - 1) & 1]), all 32 channels of two tiles + one channel half of tile 4 (135 MFMAs);
+//   waves 2, 3: staging of site s + 1 into X[(s + 1) & 1] (two pixels per thread, loads issued a step earlier), then conv3 of site s - 2
+//               (A2[s & 1] -> HBM; 32 of the 64 channels each, 72 MFMAs).
+// Every wave's weight fragments stay in its registers (conv1 96, conv2 144, conv3 96 VGPRs).  Waves w and w + 4 share a SIMD (tools/ubench/simdmap.hip):
+// 207 / 207 / 158 / 154 MFMAs per SIMD and site.  What sets the step is the longest single-wave chain {requests, MFMAs, epilogue}, not a pipe: the roles
+// are cut so that the chains are even (per-wave phase times: NC_TRACE_P3 + tools/exp_trunk.py), and the MFMA-heaviest role sits on the OLDEST waves,
+// whose instructions the issue arbiter prefers (a younger wave's MFMAs starve behind an older wave's vector burst, not the other way round).
 template <bool X16>
 __global__ __launch_bounds__(512) void k5_trunk_p3(const float *__restrict__ x, const uint8_t *__restrict__ wp, float *__restrict__ a3,
                                                    int64_t n_sites, const double *__restrict__ scale, int scale_mode, int64_t site0, float x_limit,
@@ -1355,54 +1397,124 @@ __global__ __launch_bounds__(512) void k5_trunk_p3(const float *__restrict__ x, 
     const int64_t n_k = (n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x;        // sites of this workgroup (>= 1)
     for (int i = threadIdx.x; i < 4 * T_XS; i += 512) *reinterpret_cast<uint4 *>(&X[0][0] + i * 8) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (wv < 4) {
-        // ------------------------------------------------------------------ role C: staging + conv1 (as in k5_trunk_h3)
+    // staging, by the two conv3 waves (the lightest role): thread t of the 128 owns pixels t and t + 128 (< 205).  prefetch() only issues the loads
+    // of a site's tensor; commit() converts them a step later (scale, range guard, fp16 hi / lo) and writes the two operand planes of X
+    auto stage_px = [&](int j) { const int t = (int)threadIdx.x - 128 + 128 * j; return t < 205 ? t : 204; };
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ conv1 of site s: 13 tiles as 3 / 3 / 3 / 3 + tile 12 shared by waves 0, 1
         h8 w1[T_NW1];
 #pragma unroll
         for (int q = 0; q < T_NW1; q++) w1[q] = as_h8(w1f[q * 64 + lane]);
-        const int px = threadIdx.x < 205 ? threadIdx.x : 204, ph = px / 41, pw = px - ph * 41;
-        const int xslot = ((ph + 2) * T_RX + pw + 2) * 8;
-        float pre[5];
-        uint32_t raw[3];
+        __syncthreads();                                                           // P0
+        for (int64_t s = 0; s < n_k + 2; s++) {
+#ifdef NC_TRACE_P3
+            unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
+#else
+            unsigned long long *trk = nullptr;
+#endif
+            P3_T(0)
+            P3_T(1)
+            if (s < n_k) {
+                const int buf = (int)(s & 1);
+                // waves 4, 5 (beside the conv2 waves: 135 MFMAs) three tiles, waves 6, 7 (beside the conv3 waves: 72) three tiles + their part of tile 12
+                if (wv == 6) t_conv1<4, 4>(X[buf], A1[buf], w1, b1s, epi, 0, lane, 12, 4, trk, 2);     // tiles 0, 4, 8, the 5x5 channels of tile 12
+                else if (wv == 7) t_conv1<4, 3>(X[buf], A1[buf], w1, b1s, epi, 1, lane, 12, 4, trk, 2);  // tiles 1, 5, 9, the 1x5 + 5x1 channels of tile 12
+                else t_conv1<3>(X[buf], A1[buf], w1, b1s, epi, wv - 2, lane, -1, 4, trk, 2);           // tiles 2, 6, 10 / 3, 7, 11
+            }
+            P3_T(5)
+            NC_SITE_SYNC();
+            P3_T(6)
+        }
+    } else if (wv < 2) {
+        // ------------------------------------------------------------------ conv2 of site s - 1
+        h8 c2h[9][2], c2l[9][2];
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) { c2h[q][tn] = as_h8(w2h[(q * 2 + tn) * 64 + lane]); c2l[q][tn] = as_h8(w2l[(q * 2 + tn) * 64 + lane]); }
+        __syncthreads();                                                           // P0
+        for (int64_t s = 0; s < n_k + 2; s++) {
+#ifdef NC_TRACE_P3
+            unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
+#else
+            unsigned long long *trk = nullptr;
+#endif
+            P3_T(0)
+            if (s >= 1 && s - 1 < n_k) {
+                const int buf = (int)((s - 1) & 1);
+                if (wv == 0) t_conv2_pair<0>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+                else t_conv2_pair<1>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+            }
+            P3_T(5)
+            NC_SITE_SYNC();
+            P3_T(6)
+        }
+    } else {
+        // ------------------------------------------------------------------ staging of site s + 1, conv3 of site s - 2
+        const int cw = wv - 2;
+        h8 c3h[6][2], c3l[6][2];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                c3h[q][tn] = as_h8(w3h[(q * 4 + 2 * cw + tn) * 64 + lane]);
+                c3l[q][tn] = as_h8(w3l[(q * 4 + 2 * cw + tn) * 64 + lane]);
+            }
+        const int c3slot[2] = {c3tab[lane & 15], c3tab[16 + (lane & 15)]}, c3out[2] = {c3tab[32 + (lane & 15)], c3tab[48 + (lane & 15)]};
+        const int st = (int)threadIdx.x - 128;                                    // 0..127
+        float pre[2][5];
+        uint32_t raw[2][3];
         double pre_sd = 1.0;
         int64_t pre_site = 0;
         auto prefetch = [&](int64_t site) {
             pre_site = site;
-            if constexpr (X16) {
-                const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;       // 2-byte aligned
-                typedef uint32_t __attribute__((aligned(2))) u32_a2;
-                raw[0] = *reinterpret_cast<const u32_a2 *>(xs);
-                raw[1] = *reinterpret_cast<const u32_a2 *>(xs + 2);
-                raw[2] = (uint32_t)(uint16_t)xs[4];
-            } else {
-                const float *xs = x + site * NC_SNP_TENSOR + px * 5;
 #pragma unroll
-                for (int u = 0; u < 5; u++) pre[u] = xs[u];
+            for (int j = 0; j < 2; j++) {
+                const int px = stage_px(j);
+                if constexpr (X16) {
+                    const int16_t *xs = reinterpret_cast<const int16_t *>(x) + site * NC_SNP_TENSOR + px * 5;       // 2-byte aligned
+                    typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                    raw[j][0] = *reinterpret_cast<const u32_a2 *>(xs);
+                    raw[j][1] = *reinterpret_cast<const u32_a2 *>(xs + 2);
+                    raw[j][2] = (uint32_t)(uint16_t)xs[4];
+                } else {
+                    const float *xs = x + site * NC_SNP_TENSOR + px * 5;
+#pragma unroll
+                    for (int u = 0; u < 5; u++) pre[j][u] = xs[u];
+                }
             }
             if (scale) pre_sd = scale[site0 + site];
         };
         auto commit = [&](int buf) {
-            if (threadIdx.x < 205) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (st + 128 * j >= 205) continue;
+                const int px = st + 128 * j, ph = px / 41, pw = px - ph * 41;
+                const int xslot = ((ph + 2) * T_RX + pw + 2) * 8;
+                float v5[5];
                 if constexpr (X16) {
-                    pre[0] = (float)(int16_t)(raw[0] & 0xffffu); pre[1] = (float)(int16_t)(raw[0] >> 16);
-                    pre[2] = (float)(int16_t)(raw[1] & 0xffffu); pre[3] = (float)(int16_t)(raw[1] >> 16);
-                    pre[4] = (float)(int16_t)raw[2];
+                    v5[0] = (float)(int16_t)(raw[j][0] & 0xffffu); v5[1] = (float)(int16_t)(raw[j][0] >> 16);
+                    v5[2] = (float)(int16_t)(raw[j][1] & 0xffffu); v5[3] = (float)(int16_t)(raw[j][1] >> 16);
+                    v5[4] = (float)(int16_t)raw[j][2];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 5; u++) v5[u] = pre[j][u];
                 }
                 const double md = (scale && ph > 0) ? pre_sd : 1.0;               // snpCaller.py:93-96
                 const float mf = (float)md;
                 if (scale_mode == 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) pre[u] *= mf;
+                    for (int u = 0; u < 4; u++) v5[u] *= mf;
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) pre[u] = (float)((double)pre[u] * md);
+                    for (int u = 0; u < 4; u++) v5[u] = (float)((double)v5[u] * md);
                 }
-                const float amax = fmaxf(fmaxf(fmaxf(fabsf(pre[0]), fabsf(pre[1])), fmaxf(fabsf(pre[2]), fabsf(pre[3]))), fabsf(pre[4]));
+                const float amax = fmaxf(fmaxf(fmaxf(fabsf(v5[0]), fabsf(v5[1])), fmaxf(fabsf(v5[2]), fabsf(v5[3]))), fabsf(v5[4]));
                 if (range_sites && !(amax <= x_limit)) range_sites[site0 + pre_site] = 1;
                 _Float16 hi[5], lo[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) {
-                    float v = pre[u];
+                    float v = v5[u];
                     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
                     hi[u] = (_Float16)v;
                     lo[u] = (_Float16)(v - (float)hi[u]);
@@ -1413,83 +1525,32 @@ __global__ __launch_bounds__(512) void k5_trunk_p3(const float *__restrict__ x, 
                 *reinterpret_cast<h8 *>(&X[buf][xslot + T_XPLANE]) = sb;
             }
         };
-        int64_t site = blockIdx.x;
-        prefetch(site);
+        int64_t site = blockIdx.x;                                                 // the site conv3 works on next
+        prefetch(blockIdx.x);
         commit(0);
+        if (n_k > 1) prefetch((int64_t)blockIdx.x + gridDim.x);
         __syncthreads();                                                           // P0
-#ifdef NC_TRACE_BLOCKS
-        if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef NC_P3_COMMIT_FIRST
-        if (n_k > 1) prefetch(site + gridDim.x);
-#endif
-        for (int64_t s = 0; s < n_k + 2; s++, site += gridDim.x) {
-            if (s < n_k) {
-                const int buf = (int)(s & 1);
-                const bool more = s + 1 < n_k;
-#ifdef NC_P3_COMMIT_FIRST
-                // the staging of site s + 1 (vector work) opens the step, beside the matrix work the SIMD's other wave opens its step with
-                if (more) commit(buf ^ 1);
-                if (s + 2 < n_k) prefetch(site + 2 * gridDim.x);
+        for (int64_t s = 0; s < n_k + 2; s++) {
+#ifdef NC_TRACE_P3
+            unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
 #else
-                if (more) prefetch(site + gridDim.x);
+            unsigned long long *trk = nullptr;
 #endif
-                if (wv < 2) t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, wv, lane);                       // tiles wv, wv + 4
-                else if (wv == 2) {
-                    t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, 2, lane);                                 // tiles 2, 6
-                    t_conv1<3, 4>(X[buf], A1[buf], w1, b1s, epi, 3, lane, 12);                          // tiles 3, 7, the 5x5 channels of tile 12
-                } else {
-                    t_conv1<2>(X[buf], A1[buf], w1, b1s, epi, 8, lane, -1, 1);                          // tiles 8, 9
-                    t_conv1<3, 3>(X[buf], A1[buf], w1, b1s, epi, 10, lane, 12, 1);                      // tiles 10, 11, the 1x5 + 5x1 channels of tile 12
-                }
-#ifndef NC_P3_COMMIT_FIRST
-                if (more) commit(buf ^ 1);
-#endif
-            }
-            NC_SITE_SYNC();
-        }
-#ifdef NC_TRACE_BLOCKS
-        if (threadIdx.x == 0 && blockIdx.x < 128) (&nc_trace_buf[0][0][0])[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-#endif
-    } else if (wv < 6) {
-        // ------------------------------------------------------------------ conv2 of site s - 1
-        h8 c2h[9][2], c2l[9][2];
-#pragma unroll
-        for (int q = 0; q < 9; q++)
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) { c2h[q][tn] = as_h8(w2h[(q * 2 + tn) * 64 + lane]); c2l[q][tn] = as_h8(w2l[(q * 2 + tn) * 64 + lane]); }
-        __syncthreads();                                                           // P0
-        for (int64_t s = 0; s < n_k + 2; s++) {
-            if (s >= 1 && s - 1 < n_k) {
-                const int buf = (int)((s - 1) & 1);
-                if (wv == 4) t_conv2_pair<0>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane);
-                else t_conv2_pair<1>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane);
-            }
-            NC_SITE_SYNC();
-        }
-    } else {
-        // ------------------------------------------------------------------ conv3 of site s - 2
-        const int cw = wv - 6;
-        h8 c3h[6][2], c3l[6][2];
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                c3h[q][tn] = as_h8(w3h[(q * 4 + 2 * cw + tn) * 64 + lane]);
-                c3l[q][tn] = as_h8(w3l[(q * 4 + 2 * cw + tn) * 64 + lane]);
-            }
-        const int c3slot[2] = {c3tab[lane & 15], c3tab[16 + (lane & 15)]}, c3out[2] = {c3tab[32 + (lane & 15)], c3tab[48 + (lane & 15)]};
-        __syncthreads();                                                           // P0
-        int64_t site = blockIdx.x;
-        for (int64_t s = 0; s < n_k + 2; s++) {
+            P3_T(0)
+            // the other X buffer's last reader was conv1 of site s - 1 (a barrier ago); site s + 1's loads were issued a step ago
+            if (s + 1 < n_k) commit((int)((s + 1) & 1));
+            if (s + 2 < n_k) prefetch((int64_t)blockIdx.x + (s + 2) * gridDim.x);
+            P3_T(2)
             if (s >= 2) {
                 const int buf = (int)(s & 1);
                 float *out_site = a3 + site * (27 * 64);
-                if (cw == 0) t_conv3_pair<0>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane);
-                else t_conv3_pair<1>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane);
+                if (cw == 0) t_conv3_pair<0>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane, trk);
+                else t_conv3_pair<1>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane, trk);
                 site += gridDim.x;
             }
+            P3_T(5)
             NC_SITE_SYNC();
+            P3_T(6)
         }
     }
 }
@@ -2334,11 +2395,11 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
             hipExtLaunchKernelGGL(k4_conv12, dim3(nblk), dim3(256), 0, ctx->stream, ev0, ev1, 0, x_batch, packed, a3, nb, scale, scale_mode, site0);
         else
         {
-#ifdef NC_TRUNK_P3
-            auto *kt = ctx->x_i16 ? k5_trunk_p3<true> : k5_trunk_p3<false>;
-#else
-            auto *kt = ctx->x_i16 ? k5_trunk_h3<true> : k5_trunk_h3<false>;
-#endif
+            // the three-stage trunk k5_trunk_p3 is the default since round 5 (-4 % per launch on the bench's tensors); NC_TRUNK_P3=0 selects the
+            // two-stage k5_trunk_h3: the same results bit for bit (the same MFMA sequence per accumulator; tests/test_gpu_parity.py)
+            const char *e3 = getenv("NC_TRUNK_P3");
+            const bool p3 = !(e3 && e3[0] == '0');
+            auto *kt = p3 ? (ctx->x_i16 ? k5_trunk_p3<true> : k5_trunk_p3<false>) : (ctx->x_i16 ? k5_trunk_h3<true> : k5_trunk_h3<false>);
             hipExtLaunchKernelGGL(kt, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
         }
         if (ctx->cnn_exact_fp32)
@@ -2374,7 +2435,7 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
 
 extern "C" {
 
-#if defined(NC_TRACE) || defined(NC_TRACE_BLOCKS)
+#if defined(NC_TRACE) || defined(NC_TRACE_BLOCKS) || defined(NC_TRACE_P3)
 int nc_debug_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nc_trace_buf), sizeof(nc_trace_buf)); }
 #endif
 

@@ -141,7 +141,7 @@ class Engine:
         self.x_int16 = bool(int16)
 
     def trunk_mfma_per_site(self) -> int:
-        """v_mfma_f32_16x16x32_f16 instructions k5_trunk_h3 executes per site (zero-weight tap slots included): conv1 24 per
+        """v_mfma_f32_16x16x32_f16 instructions k5_trunk_p3 / k5_trunk_h3 execute per site (zero-weight tap slots included): conv1 24 per
         16-position tile x 13 tiles, conv2 27 per (tile, half of the channels) x 10, conv3 18 x 8"""
         return 13 * 24 + 10 * 27 + 8 * 18
 

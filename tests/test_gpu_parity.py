@@ -229,6 +229,43 @@ def test_snp_cnn_odd_site_counts(eng, n, precision):
     assert np.array_equal(hp, probs.cpu().numpy()) and np.array_equal(hg, gt.cpu().numpy())
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 257, 513, 1300])
+def test_three_stage_trunk_equals_two_stage_trunk(eng, n, monkeypatch):
+    """k5_trunk_p3 (the default: conv1 | conv2 | conv3 on three consecutive sites, one barrier per site) runs the same MFMA sequence per
+    accumulator as k5_trunk_h3 (NC_TRUNK_P3=0): the probabilities are equal bit for bit, for site counts around the pipeline's fill / drain (1, 2, 3 sites
+    per workgroup) and the grid's edges, float32 and int16 tensors"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    path, cov = get_SNP_model("ONT-HG002")
+    w = Weights(path)
+    eng.load_weights(_lib.MODEL_SNP, w)
+    eng.set_cnn_precision(exact_fp32=False)
+    x, ref_code, depth = _golden_inputs("ont_dip")
+    reps = -(-n // len(x))
+    x = np.concatenate([x] * reps)[:n]
+    ref_code = np.concatenate([ref_code] * reps)[:n]
+    scale = np.linspace(0.5, 2.0, n)
+    rd, sd = torch.from_numpy(ref_code).cuda(), torch.from_numpy(scale).cuda()
+    ep, _ = oracle.snp_forward(w.flat, x, ref_code, scale, precision="f64")
+    try:
+        for i16 in (False, True):
+            xd = torch.from_numpy(x).cuda()
+            if i16:
+                assert np.array_equal(x, np.rint(x)) and np.abs(x).max() < 32768
+                xd = xd.to(torch.int16)
+            eng.set_tensor_format(int16=i16)
+            got = {}
+            for p3 in ("0", "1"):
+                monkeypatch.setenv("NC_TRUNK_P3", p3)
+                got[p3] = eng.snp_forward(_lib.MODEL_SNP, xd, rd, sd)[0].cpu().numpy()
+            assert np.array_equal(got["0"], got["1"]), (n, i16)
+            assert np.abs(got["1"] - ep).max() < 2e-5
+    finally:
+        eng.set_tensor_format(int16=False)
+
+
 def test_snp_hap_cnn_matches_oracle(eng, precision):
     import torch
     from nanocaller_amd import _lib

@@ -72,6 +72,22 @@ def one(libpath):
             print("   HW_ID of block 3's waves 0..7: " + " ".join("w%d:simd%d,wave%d,cu%d,se%d" % (i, (h >> 4) & 3, h & 15, (h >> 8) & 15, (h >> 13) & 7) for i, h in enumerate(hw)))
             print("   blocks: entry %.1f .. %.1f us, P0 %.1f .. %.1f us, loop end %.1f .. %.1f us" % (en0.min(), en0.max(), p0.min(), p0.max(), en.min(), en.max()))
             return
+        if os.environ.get("NC_TRACE_P3"):
+            b = buf.astype(np.int64)
+            names = {4: "C-light", 5: "C-light", 6: "C-heavy", 7: "C-heavy", 0: "conv2a", 1: "conv2b", 2: "conv3a", 3: "conv3b"}
+            for w in range(8):
+                rows = []
+                for k in range(1, 7):
+                    e = b[w, k]
+                    if w >= 4:     # 0 start, 2 MFMAs done, 5 before barrier, 6 after
+                        rows.append((0, e[2] - e[0], e[5] - e[2], 0, 0, e[6] - e[5], e[6] - b[w, k - 1][6]))
+                    elif w < 2:    # 0 start, 1 MFMAs done, 5 before barrier, 6 after
+                        rows.append((0, e[1] - e[0], e[5] - e[1], 0, 0, e[6] - e[5], e[6] - b[w, k - 1][6]))
+                    else:          # 0 start, 2 staging done, 1 MFMAs done, 5 before barrier, 6 after
+                        rows.append((e[2] - e[0], e[1] - e[2], e[5] - e[1], 0, 0, e[6] - e[5], e[6] - b[w, k - 1][6]))
+                m = np.array(rows).mean(0)
+                print("   %-7s commit %5d | MFMA loop %5d | epilogue %5d | MFMA loop 2 %5d | epilogue 2 %5d | barrier wait %5d | step %5d" % ((names[w],) + tuple(int(v) for v in m)))
+            return
         t0 = buf[:, :, :6][buf[:, :, :6] > 0].min()
         rel = np.where(buf > 0, buf.astype(np.int64) - int(t0), -1)
         for w in range(8):
