@@ -2038,7 +2038,17 @@ __global__ __launch_bounds__(768) void k10_indel_trunk_h3(const float *__restric
     constexpr int R1S = W * T_P1, R2S = 64 * T_P2;                                                // halves per ring slot
     _Float16 *R1H = reinterpret_cast<_Float16 *>(smem + 8 * C1H_ROWPX * 12 + 64), *R1L = R1H + NS * R1S;
     _Float16 *R2H = R1L + NS * R1S, *R2L = R2H + NS * R2S;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    // role of a wave: wv 0-3 conv1, 4-7 conv2, 8-10 conv3, 11 stager.  NC_K10_ORDER (experiment) permutes which HARDWARE waves (age = issue priority;
+    // waves w, w + 4, w + 8 share a SIMD) take which role, keeping every role's SIMDs
+#ifndef NC_K10_ORDER
+#define NC_K10_ORDER 0
+#endif
+    const int lane = threadIdx.x & 63, hwv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int wv = NC_K10_ORDER == 1 ? (hwv < 4 ? hwv + 4 : hwv < 8 ? hwv - 4 : hwv)                  // conv2 | conv1 | conv3 + stager
+                 : NC_K10_ORDER == 2 ? (hwv < 4 ? hwv + 8 : hwv < 8 ? hwv - 4 : hwv - 4)              // conv3 + stager | conv1 | conv2
+                 : NC_K10_ORDER == 3 ? (hwv < 4 ? hwv + 8 : hwv < 8 ? hwv : hwv - 8)                  // conv3 + stager | conv2 | conv1
+                 : NC_K10_ORDER == 4 ? (hwv < 4 ? hwv + 4 : hwv < 8 ? hwv + 4 : hwv - 8)              // conv2 | conv3 + stager | conv1
+                 : hwv;
     const int nloc = (int)((n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x);                   // this workgroup's sites: blockIdx.x + k gridDim.x
     constexpr int RD = 8;                                             // the input stager's look-ahead (rows); T is a multiple of RD / 2
     const int T = ((nloc * P + 8) / 2 + RD / 2 - 1) / (RD / 2) * (RD / 2);
