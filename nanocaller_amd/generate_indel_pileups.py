@@ -678,10 +678,10 @@ def _device_ingest_contig(dct, sam_path, chrom, supp, device):
     return _DEV_INGEST[key]
 
 
-def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
-    """The device pipeline for chunks (ascending) of one BAM and contig -> (result dict of indel_sites_device, contig dict)"""
+def _indel_pack_for(dct, chunks, device):
+    """(engine, read pack with the indel sections, nc_indel_reads struct, contig dict, exclusion mask or None) of the chunks' BAM and contig: made on the
+    device from the BAM file itself where that route is open (_device_ingest_contig), else from the host decode"""
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
-    window_after = 260 if dct["seq"] == "pacbio" else 160
     supp = bool(dct.get("supplementary"))
     eng = get_engine(device)
     eng.use_torch_stream()
@@ -704,6 +704,23 @@ def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
         for (a, b) in excl_rows:
             m[max(0, a - dp.tile_pos0):max(0, b - dp.tile_pos0)] = 1
         excl = torch.from_numpy(m).to(eng.device)
+    return eng, dp, reads_c, ctg, excl
+
+
+def imputed_chunk_mask(dct, chunks, device):
+    """impute_indel_phase (generate_indel_pileups.py:278-304) on the device pipeline: which chunks hold a column that meets the rule's COLUMN-level
+    predicate (:278-284; K7's col_type 2 on the resident pack).  A chunk without one takes no imputed anchor, and its `variants` are those of the flag
+    off -- it runs on the device pipeline; the others (their read grouping needs the pileup strings, :285-304) take the host-assembled route."""
+    eng, dp, _, _, excl = _indel_pack_for(dct, chunks, device)
+    cols = eng.indel_scan_batch(dp, [(c["start"], c["end"]) for c in chunks], mincov=dct["mincov"], win_size=dct["win_size"],
+                                small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"], excl=excl, haploid=False, impute=True)
+    return [bool((ct == 2).any()) for ct in cols]
+
+
+def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
+    """The device pipeline for chunks (ascending) of one BAM and contig -> (result dict of indel_sites_device, contig dict)"""
+    window_after = 260 if dct["seq"] == "pacbio" else 160
+    eng, dp, reads_c, ctg, excl = _indel_pack_for(dct, chunks, device)
     r = indel_sites_device(eng, dp, reads_c, len(ctg["fasta"]), [(c["start"], c["end"]) for c in chunks], mincov=dct["mincov"], maxcov=dct["maxcov"],
                            win_size=dct["win_size"], small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"],
                            window_after=window_after, haploid=haploid, excl=excl, fetch=fetch)
@@ -711,7 +728,7 @@ def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
 
 
 def _indel_batch_device(dct, chunks, device, haploid, device_x):
-    """_indel_batch on the device-resident pipeline (no impute_indel_phase): the per-chunk tuples of the reference's calls"""
+    """_indel_batch on the device-resident pipeline (impute_indel_phase: only chunks impute_split_chunks sends here): the per-chunk tuples of the reference's calls"""
     order = sorted(range(len(chunks)), key=lambda k: (chunks[k]["start"], chunks[k]["end"]))
     r, ctg = indel_sites_for_chunks(dct, [chunks[k] for k in order], device, haploid)
     tuples = sites_to_tuples(r, len(chunks), ctg["fasta"], haploid, device_x)
@@ -721,11 +738,12 @@ def _indel_batch_device(dct, chunks, device, haploid, device_x):
     return out
 
 
-def device_route_ok(dct, chunks, haploid):
-    """the device pipeline covers BAM inputs without impute_indel_phase (whose read grouping needs the pileup strings); its plan takes chunks
-    whose starts AND ends ascend (nc_indel_sites_plan): nested or overlapping chunk lists, which sorting by (start, end) does not make
-    monotone, go through the host-assembled route instead of failing the worker"""
-    if not (isinstance(chunks[0]["sam_path"], str) and not (dct.get("impute_indel_phase") and not haploid)
+def device_route_ok(dct, chunks, haploid, impute_split=False):
+    """the device pipeline covers BAM inputs; its plan takes chunks whose starts AND ends ascend (nc_indel_sites_plan): nested or overlapping chunk
+    lists, which sorting by (start, end) does not make monotone, go through the host-assembled route instead of failing the worker.  With
+    dct['impute_indel_phase'] (diploid) the route is open only to callers that split the chunk list first (impute_split_chunks: chunks with a
+    column that meets the rule's predicate take the host-assembled route, whose read grouping needs the pileup strings)"""
+    if not (isinstance(chunks[0]["sam_path"], str) and (impute_split or not (dct.get("impute_indel_phase") and not haploid))
             and not os.environ.get("NC_INDEL_HOST_PASS2")):
         return False
     ends = [c["end"] for c in sorted(chunks, key=lambda c: (c["start"], c["end"]))]
@@ -799,10 +817,34 @@ def sites_to_tuples(r, n_chunks, fasta, haploid, device_x):
             out.append((pos[a:b], x[a:b, 0:5], x[a:b, 5:10], x[a:b, 10:15], alleles[a:b], phase[a:b]))
     return out
 
+def impute_split_chunks(dct, chunks, device, haploid):
+    """dct['impute_indel_phase'] on a chunk list the device pipeline could take: -> (indices for the device pipeline, indices for the host-assembled
+    route), or None when there is nothing to split (flag off, haploid, route closed).  NC_IMPUTE_SPLIT=0: everything on the host-assembled route"""
+    if not dct.get("impute_indel_phase") or haploid or os.environ.get("NC_IMPUTE_SPLIT") == "0" or not device_route_ok(dct, chunks, haploid, impute_split=True):
+        return None
+    order = sorted(range(len(chunks)), key=lambda k: (chunks[k]["start"], chunks[k]["end"]))
+    mask = imputed_chunk_mask(dct, [chunks[k] for k in order], device)
+    dev = sorted(k for k, m in zip(order, mask) if not m)
+    host = sorted(k for k, m in zip(order, mask) if m)
+    return dev, host
+
+
 def _indel_batch(dct, chunks, device, haploid, device_x, device_route=True):
     """device_route=False: the caller has already met a capacity limit of the device pipeline for these chunks (indelCaller.indel_run): straight to
     the host-assembled route instead of computing the expensive groups on the device a second time"""
     chrom, sam_path = chunks[0]["chrom"], chunks[0]["sam_path"]
+    split = impute_split_chunks(dct, chunks, device, haploid) if device_route else None
+    if split is not None and split[0]:
+        # impute_indel_phase: the chunks without a column that meets the rule's predicate are the flag-off problem -> device pipeline
+        dev, host = split
+        off = dict(dct, impute_indel_phase=False)
+        out = [None] * len(chunks)
+        for k, t in zip(dev, _indel_batch(off, [chunks[k] for k in dev], device, haploid, device_x, True)):
+            out[k] = t
+        if host:
+            for k, t in zip(host, _indel_batch(dct, [chunks[k] for k in host], device, haploid, device_x, False)):
+                out[k] = t
+        return out
     if device_route and device_route_ok(dct, chunks, haploid):
         # everything between the column decisions and the CNN input on the device (nc_pipe.hip); a capacity limit of that route
         # (sets of > 1024 alignment columns, chunks of > 130 kb) sends the group through the host-assembled route below

@@ -132,7 +132,7 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
     from . import _lib
     from .engine import get_engine
     from .generate_indel_pileups import (default_aligner, device_route_ok, get_indel_testing_candidates, get_indel_testing_candidates_batch,
-                                         indel_chunks_vcf_text, star_aligner)
+                                         impute_split_chunks, indel_chunks_vcf_text, star_aligner)
     from .generate_indel_pileups_haploid import get_indel_testing_candidates_haploid
     from .weights import Weights
     curr_vcf_path = os.path.join(params['intermediate_indel_files_dir'], '%s.%d.indel.vcf' % (params['prefix'], worker_id))
@@ -225,6 +225,36 @@ def indel_run(params, indel_dict, job_Q, counter_Q, indel_files_list, device=0, 
                 hap = ploidy == 'haploid'
                 texts = None
                 device_failed = False
+                split = impute_split_chunks(params, group, device, hap) if not _os.environ.get("NC_INDEL_PY_RULES") else None
+                if split is not None and split[0]:
+                    # impute_indel_phase (generate_indel_pileups.py:278-304): chunks without a column that meets the rule's predicate are the flag-off
+                    # problem and run on the device pipeline; the others need the pileup strings -> host-assembled route.  Written in job order.
+                    dev, host = split
+                    off = dict(params, impute_indel_phase=False)
+                    try:
+                        dtx = indel_chunks_vcf_text(off, [group[i] for i in dev], device, hap, _lib.MODEL_INDEL)
+                    except _lib.NanoCallerHipError as e:
+                        if getattr(e, "status", None) != _lib.NC_ERR_CAPACITY:
+                            raise
+                        dtx = None
+                    if dtx is not None:
+                        by = dict(zip(dev, dtx))
+                        htup, hpr = [], []
+                        if host:
+                            htup = get_indel_testing_candidates_batch(params, [group[i] for i in host], device=device, haploid=hap, device_x=True, device_route=False)
+                            hpr = forward(ploidy, htup)
+                            htup = [tuple(None if torch.is_tensor(v) else v for v in t) for t in htup]
+                        hby = {i: (t, pr) for i, t, pr in zip(host, htup, hpr)}
+                        for i, k in enumerate(ks):
+                            if i in by:
+                                f.write(by[i].decode("ascii"))
+                                f.flush()
+                                os.fsync(f.fileno())
+                                counter_Q.put(1)
+                            else:
+                                emit(f, jobs[k][1], hby[i][0], hby[i][1])
+                        continue
+                    device_failed = True
                 if device_route_ok(params, group, hap) and not _os.environ.get("NC_INDEL_PY_RULES"):
                     try:
                         texts = indel_chunks_vcf_text(params, group, device, hap, _lib.MODEL_INDEL_HAP if hap else _lib.MODEL_INDEL)

@@ -300,6 +300,54 @@ def test_device_pipeline_returns_the_host_routes_tuples(world_files, variant, mo
 
 
 @pytest.mark.gpu
+def test_impute_indel_phase_splits_the_chunks_between_the_device_pipeline_and_the_host_route(tmp_path, monkeypatch):
+    """dct['impute_indel_phase'] (generate_indel_pileups.py:278-304): chunks without a column that meets the rule's predicate run on the device
+    pipeline, the others on the host-assembled route (their read grouping needs the pileup strings): the same tuples, and the same indel_run text,
+    as everything on the host-assembled route"""
+    import queue
+    w = bamio.make_pass2_world(seed=23, length=120_000, depth=24, blocks=[(30_000, 60_000)])
+    bam, fa = str(tmp_path / "i.bam"), str(tmp_path / "i.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, None))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    dct = _params(fa, impute_indel_phase=True, mincov=3, ins_t=0.3, del_t=0.3)
+    chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 10_000), sam_path=bam) for s in range(1, w.length, 10_000)]
+    gip._CONTIGS.clear()
+    monkeypatch.setenv("NC_PIPE_BAND", "0")                                          # the host-assembled route aligns on the full matrix
+    monkeypatch.setenv("NC_IMPUTE_SPLIT", "0")
+    exp = gip.get_indel_testing_candidates_batch(dct, chunks)
+    monkeypatch.delenv("NC_IMPUTE_SPLIT")
+    dev, host = gip.impute_split_chunks(dct, chunks, 0, False)
+    assert len(dev) >= 4 and len(host) >= 2 and sorted(dev + host) == list(range(len(chunks)))
+    assert all(30_000 - 10_000 < chunks[k]["start"] < 60_000 + 200 for k in host), [chunks[k]["start"] for k in host]
+    calls = []
+    real = gip._indel_batch_device
+    monkeypatch.setattr(gip, "_indel_batch_device", lambda d, c, *a: (calls.append(len(c)), real(d, c, *a))[1])
+    got = gip.get_indel_testing_candidates_batch(dct, chunks)
+    assert calls == [len(dev)]
+    n = _same_tuples(got, exp)
+    assert n > 60
+    # imputed anchors exist and sit in the host route's chunks only
+    from oracle import oracle
+    ev, ex = oracle.indel_scan_impute(w, 28_000, 62_000, mincov=3, win_size=40, small_win_size=4, ins_t=0.3, del_t=0.3)
+    assert len(ex) > 3 and all(any(chunks[k]["start"] - 60 <= a <= chunks[k]["end"] for k in host) for a in ex)
+    # indelCaller.indel_run: the same file either way
+    outs = []
+    for tag, split in (("host", "0"), ("split", None)):
+        if split:
+            monkeypatch.setenv("NC_IMPUTE_SPLIT", split)
+        else:
+            monkeypatch.delenv("NC_IMPUTE_SPLIT", raising=False)
+        d = tmp_path / tag
+        d.mkdir()
+        params = _params(fa, impute_indel_phase=True, mincov=3, ins_t=0.3, del_t=0.3, indel_model="ONT-HG002", intermediate_indel_files_dir=str(d), prefix="t")
+        jobs = queue.Queue()
+        for c in chunks:
+            jobs.put(("indel", dict(c, ploidy="diploid")))
+        outs.append(open(indelCaller.indel_run(params, {}, jobs, queue.Queue(), [], aligner="device")).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 40
+
+
+@pytest.mark.gpu
 def test_device_pipeline_in_small_groups_is_the_same(world_files, monkeypatch):
     """the run loop cut into many groups of sites (traceback workspace bound) gives the same arrays"""
     w, bam, fa = world_files
