@@ -34,7 +34,10 @@ constexpr int B_LT = 0, B_DT = B_LT + 2 * LT_SZ, B_HLC = B_DT + 2 * DT_SZ, B_HLS
               B_LENS = B_HDS + 32, B_WALK = B_LENS + 160, B_END = B_WALK + 8;
 static_assert(B_HLC % 2 == 0 && B_HDC % 2 == 0 && B_WALK % 2 == 0, "uint16 sections");
 constexpr int TAB_WORDS = (B_END + 3) / 4 | 1;                      // odd pitch in words: lanes spread over the banks
-constexpr int LPW = 16, LPW_SH = 4;                                 // members (= lanes) per workgroup of k_huff, and its log2.  One workgroup's duration is its slowest member's
+#ifndef NC_HUFF_LPW_SH
+#define NC_HUFF_LPW_SH 4
+#endif
+constexpr int LPW_SH = NC_HUFF_LPW_SH, LPW = 1 << LPW_SH;                                 // members (= lanes) per workgroup of k_huff, and its log2.  One workgroup's duration is its slowest member's
 constexpr int WIN_DW = 32, WIN_PITCH = WIN_DW + NC_HUFF_WINPAD;     // a lane's window of the compressed stream: 32 dwords (+ pad: banks spread), topped up every 8 steps
 
 struct InflateArgs {
