@@ -126,7 +126,19 @@ class Engine:
             raise _lib.NanoCallerHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
     def use_torch_stream(self):
+        """The library's kernels go to torch's current stream of this thread.  Where that is the legacy default stream, the thread is first moved to
+        this engine's own torch stream: torch's kernels (fills, reductions, copies) and the library's then share ONE hardware queue.  On the default
+        stream the library used a stream of its own beside it, and every torch kernel in a pass cost two cross-queue hand-overs (~0.4 ms of idle GPU
+        per 11 ms contig pass: bench.py 56.0 -> 58.2 M sites/s; `rocprofv3 --kernel-trace` timelines by tools/one_pass.py).  Work the caller has
+        already enqueued on the default stream is waited for.  NC_ONE_QUEUE=0: the old arrangement."""
+        import os
         s = torch.cuda.current_stream(self.device)
+        if s.cuda_stream == 0 and os.environ.get("NC_ONE_QUEUE", "1") != "0":
+            if getattr(self, "_tstream", None) is None:
+                self._tstream = torch.cuda.Stream(device=self.device)
+            self._tstream.wait_stream(s)
+            torch.cuda.set_stream(self._tstream)
+            s = self._tstream
         self._check(self.L.nc_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)), "nc_ctx_set_stream")
 
     def set_cnn_precision(self, exact_fp32: bool):
@@ -536,6 +548,8 @@ _engines = {}
 def get_engine(device: int = 0) -> Engine:
     if device not in _engines:
         _engines[device] = Engine(device)
+    else:
+        _engines[device].use_torch_stream()              # (a thread that meets the engine for the first time is moved to its stream)
     return _engines[device]
 
 
