@@ -68,7 +68,9 @@ int nc_d2h(nc_ctx *ctx, void *host, const void *dev, size_t bytes, hipStream_t s
     // Bulk results stay on the copy engine (no CU time, full PCIe rate): the caller enqueues a contig's upload BEFORE the
     // result copies of the step running under it, so they queue behind it and still land before the step ends.  Only the
     // small transfers the HOST WAITS FOR mid-step (scan totals) must not queue behind 7 ms of upload: those go by kernel.
-    if (!alias || bytes > NC_D2H_KERNEL_MAX) {
+    // NC_D2H_KERNEL_BYTES (experiment / tuning): largest transfer that goes by copy kernel
+    static const size_t kernel_max = [] { const char *e = getenv("NC_D2H_KERNEL_BYTES"); return e ? (size_t)atoll(e) : (size_t)NC_D2H_KERNEL_MAX; }();
+    if (!alias || bytes > kernel_max) {
         NC_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
         return NC_OK;
     }
