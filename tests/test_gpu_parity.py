@@ -436,6 +436,41 @@ def test_deferred_calls_equal_drained_calls(eng):
     assert pend[0].result() is got[0]                                        # result() is idempotent
 
 
+def test_one_queue_and_the_library_on_its_own_stream_give_the_same_results(eng, monkeypatch):
+    """Engine.use_torch_stream: a thread on torch's default stream is moved to the engine's own torch stream (torch's kernels and the library's on
+    one hardware queue); NC_ONE_QUEUE=0 + the default stream is the arrangement of rounds 1-4 (the library on a stream of its own, ordered by the
+    default stream's implicit synchronisation).  Pipelined calls give bit-identical arrays either way."""
+    import torch
+    from nanocaller_amd import snpCaller
+    from nanocaller_amd.utils import get_chunks
+    world = load_world("ont")
+    params = dict(sam_path=world, fasta_path=None, mincov=4, maxcov=160, min_allele_freq=0.15, min_nbr_sites=1, threshold=[0.4, 0.6],
+                  snp_model="ONT-HG002", seq="ont", supplementary=False, exclude_bed=None, disable_coverage_normalization=False)
+    groups = [get_chunks([(world.chrom, a, b, "diploid")], cpu=2) for (a, b) in ((20_000, 70_000), (60_000, 118_000), (1, 9_000))]
+
+    def run():
+        pend = [snpCaller.call_chunks(params, g, defer=True) for g in groups]
+        return [p.result() for p in pend]
+    eng.use_torch_stream()
+    assert torch.cuda.current_stream(eng.device).cuda_stream != 0, "the thread should be on the engine's stream"
+    one = run()
+    try:
+        monkeypatch.setenv("NC_ONE_QUEUE", "0")
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream(eng.device))
+        two = run()
+        torch.cuda.synchronize()
+    finally:
+        monkeypatch.delenv("NC_ONE_QUEUE")
+        eng.use_torch_stream()
+    assert torch.cuda.current_stream(eng.device).cuda_stream != 0
+    assert sum(r["n"] for r in one) > 400
+    for a, b in zip(one, two):
+        assert a["n"] == b["n"]
+        for key in ("pos", "chunk", "ref", "probs", "gt", "dp", "alt", "fwd_dp", "rev_dp", "freq", "chunk_depth"):
+            assert np.array_equal(a[key], b[key]), key
+
+
 def test_indel_window_scan_matches_reference_pass1(eng):
     """K7: the `variants` dict of the reference's pass 1 (captured from its own frame) and the CPU oracle"""
     from nanocaller_amd.generate_indel_pileups import scan_indel_candidates
