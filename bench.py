@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (HiFi 60x haploid, exact fp32, indel pipeline)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] block (chr1-sized SNP + indel in one timed region)")
     ap.add_argument("--configs2-steps", type=int, default=8)
+    ap.add_argument("--no-wgs", action="store_true", help="skip the whole-genome N=1 pass (24 contigs at GRCh38 lengths, SNP + indel halves)")
+    ap.add_argument("--wgs", action="store_true", help="(default at N=1; kept for explicit invocations)")
+    ap.add_argument("--wgs-passes", type=int, default=1)
+    ap.add_argument("--wgs-scale", type=float, default=1.0, help="contig lengths = GRCh38 x this (1.0 = the genome)")
     ap.add_argument("--no-indel-leg", action="store_true", help="N>1: skip the indel passes over the sharded contig list")
     ap.add_argument("--indel-passes", type=int, default=3)
     ap.add_argument("--configs2-length", type=int, default=CHR1_LEN)
@@ -431,6 +435,57 @@ class IndelJob:
         return r
 
 
+def indel_parity_sample(pack, info, contig, rt, probs, wgt, hi=40_000, max_sites=40):
+    """The checker of the indel half (test infrastructure: bench.py's post-timing parity block and tests/test_wgs_slice.py): the sites of `rt` (the
+    product's per-site arrays, tensors still on the device) below position `hi` against the oracle's restatement of pass 2 from SAM-like records
+    (oracle.read_windows_ref: CIGAR expansion; every star alignment in pure Python on the band the read's CIGAR allows; msa() by the C oracle) and
+    against generate_indel_pileups.allele_prediction; K9 against the float64 oracle.  -> (sites checked, tensors + phase exact, alleles exact,
+    max |dp| of K9, K9 sites checked)"""
+    from nanocaller_amd import generate_indel_pileups as gip
+    from oracle import oracle
+    S = rt["sets"]
+    r1 = int(np.searchsorted(info["read_start"], hi + 400))
+    s_, e_ = info["read_start"][:r1], info["read_end"][:r1]
+    slot = pack.reads["slot_off"][:r1 + 1].cpu().numpy()
+    codes = pack.codes[:int(slot[-1])].cpu().numpy()
+    ev_off = pack.events["ev_off"][:r1 + 1].cpu().numpy()
+    ev_pos = pack.events["ev_pos"][:int(ev_off[-1])].cpu().numpy()
+    ev_len = pack.events["ev_len"][:int(ev_off[-1])].cpu().numpy()
+    ins_off = info["tensors"]["ins_off"][:int(ev_off[-1]) + 1].cpu().numpy()
+    ins = info["tensors"]["ins_bases"][:max(int(ins_off[-1]), 1)].cpu().numpy()
+    recs = oracle.records_from_indel_pack(
+        s_, e_, lambda q: codes[int(slot[q]) + (int(s_[q]) & 15):int(slot[q]) + (int(s_[q]) & 15) + int(e_[q] - s_[q])],
+        lambda q: list(zip(ev_pos[ev_off[q]:ev_off[q + 1]].tolist(), ev_len[ev_off[q]:ev_off[q + 1]].tolist())),
+        lambda q, k: ins[ins_off[int(ev_off[q]) + k]:ins_off[int(ev_off[q]) + k + 1]])
+    masked = pack.ref_code[1:hi + 401].cpu().numpy() == 4
+    ref_s = "".join(c.lower() if m_ else c for c, m_ in zip(contig[:hi + 400].decode(), masked))
+    xh = rt["x"][:max_sites + 24].cpu().numpy()
+    alt_all = np.frombuffer(b"AGTCN", np.uint8)[rt["alt"]].tobytes().decode()
+    aoff = np.zeros(rt["n"] * S + 1, np.int64)
+    np.cumsum(np.maximum(rt["alt_len"].reshape(-1), 0), out=aoff[1:])
+    checked, x_exact, alleles_exact = 0, True, True
+    for k in range(min(rt["n"], max_sites)):
+        p_ = int(rt["pos"][k])
+        if p_ > hi:
+            break
+        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref_s, p_, 160, 4, 160, band=True)     # pure Python: no product aligner in the check
+        if got is None:
+            x_exact = False
+            break
+        xs, cns, win, phase = got
+        x_exact &= bool(np.array_equal(xh[k].reshape(S, 5, 128, 2), xs)) and phase == int(rt["phase"][k])
+        mr = 40 if rt["type"][k] == 0 else 10
+        for t_ in range(S):
+            exp = gip.allele_prediction(cns[t_], win, mr)
+            rl, al = int(rt["ref_len"][k, t_]), int(rt["alt_len"][k, t_])
+            alleles_exact &= ((None, None) if rl < 0 else (win[:rl], alt_all[aoff[k * S + t_]:aoff[k * S + t_] + al])) == exp
+        checked += 1
+    m = min(rt["n"], 256)
+    ep = oracle.indel_forward(wgt.flat, rt["x"][:m].cpu().numpy(), precision="f64")
+    k9_err = float(np.abs(probs[:m].cpu().numpy() - ep).max())
+    return checked, bool(x_exact), bool(alleles_exact), k9_err, int(m)
+
+
 def extra_indel_haploid_config(eng, L, reps=6):
     """The indel half of configs[4]'s shape: --haploid_genome (one read set per site, haploid_Indel_model) with the pacbio preset's 260-base
     windows, over the same chr20-sized synthetic contig, the pack resident in HBM (no upload in the loop: the transfer form is the diploid
@@ -491,23 +546,25 @@ def extra_indel_config(eng, uploader, local, L, reps=40):
     import gc
     gc.collect()
     gc.disable()                                                     # (a full collection of the earlier legs' objects inside the loop: +10 ms on a 15 ms pass, every sixth)
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nxt, pend, pass_ms = uploader.submit(wire), None, []
-        for i in range(reps):
-            tk = nxt
-            nxt = uploader.submit(wire) if i + 1 < reps else None    # the next pass's copy runs under this pass's kernels
-            tp = time.perf_counter()
-            rr = from_host_pass(tk)
-            if pend is not None:
-                pend.result()
-            pass_ms.append((time.perf_counter() - tp) * 1e3)          # (the first one waits for its own upload: nothing to hide it under)
-            pend = pool.submit(rules, rr)                            # rules + text of pass i under pass i + 1
-        pend.result()
-        torch.cuda.synchronize()
-        t_host = time.perf_counter() - t0
-    gc.enable()
+    try:
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nxt, pend, pass_ms = uploader.submit(wire), None, []
+            for i in range(reps):
+                tk = nxt
+                nxt = uploader.submit(wire) if i + 1 < reps else None    # the next pass's copy runs under this pass's kernels
+                tp = time.perf_counter()
+                rr = from_host_pass(tk)
+                if pend is not None:
+                    pend.result()
+                pass_ms.append((time.perf_counter() - tp) * 1e3)          # (the first one waits for its own upload: nothing to hide it under)
+                pend = pool.submit(rules, rr)                            # rules + text of pass i under pass i + 1
+            pend.result()
+            torch.cuda.synchronize()
+            t_host = time.perf_counter() - t0
+    finally:
+        gc.enable()
     h2d_gbs, _, _ = uploader.h2d_rate()
     # ---- instrumented pass: per-stage HIP events
     eng.enable_timing(True)
@@ -576,46 +633,7 @@ def extra_indel_config(eng, uploader, local, L, reps=40):
     except (OSError, ValueError, KeyError):
         pass
     # ---- in-run parity on a sample: pass 2 restated from SAM-like records by the oracle (CIGAR expansion, host star alignment, msa() in C)
-    hi = 40_000
-    r1 = int(np.searchsorted(info["read_start"], hi + 400))
-    s_, e_ = info["read_start"][:r1], info["read_end"][:r1]
-    slot = pack.reads["slot_off"][:r1 + 1].cpu().numpy()
-    codes = pack.codes[:int(slot[-1])].cpu().numpy()
-    ev_off = pack.events["ev_off"][:r1 + 1].cpu().numpy()
-    ev_pos = pack.events["ev_pos"][:int(ev_off[-1])].cpu().numpy()
-    ev_len = pack.events["ev_len"][:int(ev_off[-1])].cpu().numpy()
-    ins_off = info["tensors"]["ins_off"][:int(ev_off[-1]) + 1].cpu().numpy()
-    ins = info["tensors"]["ins_bases"][:max(int(ins_off[-1]), 1)].cpu().numpy()
-    recs = oracle.records_from_indel_pack(
-        s_, e_, lambda q: codes[int(slot[q]) + (int(s_[q]) & 15):int(slot[q]) + (int(s_[q]) & 15) + int(e_[q] - s_[q])],
-        lambda q: list(zip(ev_pos[ev_off[q]:ev_off[q + 1]].tolist(), ev_len[ev_off[q]:ev_off[q + 1]].tolist())),
-        lambda q, k: ins[ins_off[int(ev_off[q]) + k]:ins_off[int(ev_off[q]) + k + 1]])
-    masked = pack.ref_code[1:hi + 401].cpu().numpy() == 4
-    ref_s = "".join(c.lower() if m else c for c, m in zip(contig[:hi + 400].decode(), masked))
-    xh = rt["x"][:64].cpu().numpy()
-    alt_all = np.frombuffer(b"AGTCN", np.uint8)[rt["alt"]].tobytes().decode()
-    aoff = np.zeros(rt["n"] * S + 1, np.int64)
-    np.cumsum(np.maximum(rt["alt_len"].reshape(-1), 0), out=aoff[1:])
-    checked, x_exact, alleles_exact = 0, True, True
-    for k in range(min(rt["n"], 40)):
-        p_ = int(rt["pos"][k])
-        if p_ > hi:
-            break
-        got = oracle.indel_site_ref(recs, info["hap"], info["ps"], ref_s, p_, 160, 4, 160, band=True)     # pure Python: no product aligner in the check
-        if got is None:
-            x_exact = False
-            break
-        xs, cns, win, phase = got
-        x_exact &= bool(np.array_equal(xh[k].reshape(S, 5, 128, 2), xs)) and phase == int(rt["phase"][k])
-        mr = 40 if rt["type"][k] == 0 else 10
-        for t_ in range(S):
-            exp = gip.allele_prediction(cns[t_], win, mr)
-            rl, al = int(rt["ref_len"][k, t_]), int(rt["alt_len"][k, t_])
-            alleles_exact &= ((None, None) if rl < 0 else (win[:rl], alt_all[aoff[k * S + t_]:aoff[k * S + t_] + al])) == exp
-        checked += 1
-    m = min(rt["n"], 256)
-    ep = oracle.indel_forward(wgt.flat, rt["x"][:m].cpu().numpy(), precision="f64")
-    k9_err = float(np.abs(probs[:m].cpu().numpy() - ep).max())
+    checked, x_exact, alleles_exact, k9_err, m = indel_parity_sample(pack, info, contig, rt, probs, wgt)
     # ---- call concordance (how SURVEY 8f judges the aligner that replaces MUSCLE): planted indels whose exact length comes back in an
     # allele called at a site up to 60 bp before them
     truth = info["truth"].cpu().numpy()
@@ -651,6 +669,145 @@ def extra_indel_config(eng, uploader, local, L, reps=40):
     return out
 
 
+class PairUnit:
+    """one contig of a SNP + indel job: the SNP half's transfer form, the indel half's job (phased reads: its own transfer form), the SNP chunks"""
+
+    def __init__(self, snp, job, chunks, name):
+        self.snp, self.job, self.chunks, self.name = snp, job, chunks, name
+        self.scratch = {}
+
+    def snp_text(self, res):
+        from nanocaller_amd import snpCaller
+        n = max(int(res["n"]), 1)
+        if self.scratch.get("n", 0) < n:
+            self.scratch["buf"], self.scratch["n"] = np.empty((400 + 5) * n * 5 // 4 + 65536, np.uint8), n
+        return len(snpCaller.snp_vcf_text(self.name, res["pos"], res["ref"], res["probs"], res["dp"], res["freq"], res["fwd_dp"], res["rev_dp"],
+                                          haploid=False, as_array=True, out=self.scratch["buf"]))
+
+
+def run_pairs(uploader, local, params, units, n_steps, snp_half=True, indel_half=True):
+    """n_steps steps, step i over units[i % len(units)]: the SNP pass (upload -> expansion -> scan -> tensors -> SNP CNN) then the indel pass
+    (upload -> expansion -> K7 ... K9) of that contig, the reference's order (NanoCaller:25-55).  The copies of step i + 1 (SNP wire, then indel
+    wire) are both enqueued before the indel pass of step i starts, so they run under its kernels and the SNP kernels of step i + 1; genotype
+    rules + VCF text of both halves run natively on a host thread under the next step.  -> (SNP sites, indel sites, indel VCF records)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from nanocaller_amd import snpCaller
+    ns = ni = nrec = 0
+    nu = len(units)
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        pend = prev = prev_u = None
+        tk_s = uploader.submit(units[0].snp.wire) if snp_half else None
+        tk_i = uploader.submit(units[0].job.wire) if indel_half else None
+        dbg = os.environ.get("NC_BENCH_DEBUG") == "1"
+        tdbg = time.perf_counter()
+        for i in range(n_steps):
+            u = units[i % nu]
+            un = units[(i + 1) % nu]
+            if dbg:
+                print("pair step %d %s (snp %s indel %s): +%.1f ms" % (i, u.name, snp_half, indel_half, (time.perf_counter() - tdbg) * 1e3), file=sys.stderr, flush=True)
+            more = i + 1 < n_steps
+            cur = ri = rs = None
+            rs_u = u
+            nxt_s = nxt_i = None
+            if snp_half:
+                dpk = uploader.expand(tk_s)
+                cur = snpCaller.call_chunks(params, u.chunks, device=local, dpk=dpk, defer=True)
+                uploader.release(tk_s)
+                nxt_s = uploader.submit(un.snp.wire) if more else None
+            if indel_half:
+                nxt_i = uploader.submit(un.job.wire) if more else None
+                ri = u.job.from_host_pass(uploader, tk_i)
+                ni += int(ri["n"])
+                rs = cur.result() if cur is not None else None       # (the indel pass ends on host waits: the SNP half before it is complete)
+            elif prev is not None:
+                rs, rs_u = prev.result(), prev_u                     # SNP alone: step i - 1 is collected while step i runs
+            prev, prev_u = cur, u
+            tk_s, tk_i = nxt_s, nxt_i
+            if rs is not None:
+                ns += int(rs["n"])
+            if pend is not None:
+                nrec += pend.result()
+                pend = None
+            if rs is not None or ri is not None:
+                pend = pool.submit(_pair_host_half, rs_u, rs, u, ri)
+        if not indel_half and prev is not None:
+            rs = prev.result()
+            ns += int(rs["n"])
+            if pend is not None:
+                nrec += pend.result()
+            pend = pool.submit(_pair_host_half, prev_u, rs, None, None)
+        if pend is not None:
+            nrec += pend.result()
+    return ns, ni, nrec
+
+
+def _pair_host_half(us, rs, ui, ri):
+    if rs is not None:
+        us.snp_text(rs)
+    return ui.job.rules(ri) if ri is not None else 0
+
+
+# GRCh38 primary assembly, chr1..chr22, chrX, chrY (bp): the contig list the reference's `-chrom`-less invocation walks (NanoCaller:25-55, utils.py:6-63)
+GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
+          ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+          ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
+          ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+
+
+def wgs_block(eng, uploader, local, model, passes=1, scale=1.0, contigs=None):
+    """The metric's own configuration at N = 1: ONE pass over a whole genome -- 24 contigs at the GRCh38 lengths (3.09 Gb), per contig the SNP half
+    then the indel half, every wire from PINNED HOST MEMORY, one timed region (the reference walks all regions with snpCaller, then indelCaller:
+    NanoCaller:25-55, utils.py:6-83).  Contigs of unequal length: the upload ring and every workspace are sized by chr1 (priming steps, untimed),
+    the tails of short contigs and the SNP -> indel hand-over are inside the region.  value = (SNP + indel candidate sites) / wall time."""
+    from nanocaller_amd.utils import get_chunks
+    t0 = time.perf_counter()
+    params = snp_params(model, "ont")
+    units, snp_bytes, indel_bytes, bp = [], 0, 0, 0
+    for k, (name, L0) in enumerate(contigs or GRCH38):
+        L = max(200_000, int(L0 * scale))
+        snp = Contig(eng, L, 30.0, "ont", seed=2000 + k, keep_pack=False)
+        job = IndelJob(eng, L, seed=6000 + k, name=name.encode())
+        job.drop_pack()
+        units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
+        snp_bytes += snp.wire.nbytes
+        indel_bytes += job.wire.nbytes
+        bp += L
+    t_setup = time.perf_counter() - t0
+    big = max(units, key=lambda u: u.job.wire.nbytes)
+    run_pairs(uploader, local, params, [big], len(uploader.slots))      # sizes every upload slot, workspace and result pool by the largest contig (untimed)
+    uploader.h2d_events.clear()
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        eng.enable_timing(True, trunk_only=True)
+        s0, _ = eng.timing_sums()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ns, ni, nrec = run_pairs(uploader, local, params, units, passes * len(units))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        s1, _ = eng.timing_sums()
+    finally:
+        eng.enable_timing(False)
+        gc.enable()
+    h2d_gbs, _, h2d_bytes = uploader.h2d_rate()
+    trunk_ms = s1[4] - s0[4]
+    trunk_tf = TRUNK_FLOP_PER_SITE * ns / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
+    out = {"workload": "whole genome at N=1: %d contigs at GRCh38 lengths x %g (%d bp), synthetic ONT 30x, SNP half + indel half per contig" % (len(units), scale, bp),
+           "value": (ns + ni) / dt, "unit": "candidate sites/s (SNP + indel, one timed region over the genome)", "passes": passes,
+           "s_per_pass": dt / passes, "snp_sites_per_pass": ns // passes, "indel_sites_per_pass": ni // passes, "sites_per_pass": (ns + ni) // passes,
+           "indel_vcf_records_per_pass": nrec // passes, "contigs": len(units), "bp": bp,
+           "wire_bytes_snp": snp_bytes, "wire_bytes_indel": indel_bytes, "h2d_achieved_GBs": h2d_gbs,
+           "frac_snp_trunk_f16x3": trunk_tf / (F16_MFMA_PEAK_TFLOPS / 3.0), "setup_s": round(t_setup, 1),
+           "timed_region": "per contig: SNP wire and indel wire from pinned host memory (copies under the other half's kernels) -> per-site results in host "
+                           "memory -> native rules + VCF text on a host thread under the next contig; ring and workspaces sized by chr1 beforehand"}
+    del units
+    torch.cuda.empty_cache()
+    return out
+
+
 def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
     """BASELINE.json configs[2]: "SNP+indel full pipeline on 1 MI355X, HG002 ONT 30x chr1" as ONE timed region.  A step = the SNP pass over a
     chr1-sized contig (248,956,422 bp, 498 chunks of 500 kb; upload -> expansion -> scan -> tensors -> SNP CNN -> per-site results) followed by the
@@ -670,66 +827,10 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
     params = snp_params(model, "ont")
     job = IndelJob(eng, L, seed=4913, name=b"chr1")
     t_setup = time.perf_counter() - t0
-    scratch = {}
-
-    def snp_text(res):
-        n = max(int(res["n"]), 1)
-        if scratch.get("n", 0) < n:
-            scratch["buf"], scratch["n"] = np.empty((400 + 5) * n * 5 // 4 + 65536, np.uint8), n
-        return len(snpCaller.snp_vcf_text("chr1", res["pos"], res["ref"], res["probs"], res["dp"], res["freq"], res["fwd_dp"], res["rev_dp"],
-                                          haploid=False, as_array=True, out=scratch["buf"]))
-
-    def host_half(rs, ri):
-        if rs is not None:
-            snp_text(rs)
-        return job.rules(ri) if ri is not None else 0
+    units = [PairUnit(snp, job, chunks, "chr1")]
 
     def run(n_steps, snp_half=True, indel_half=True):
-        """n_steps steps; the copies of step i + 1 (SNP wire, then indel wire: 110 ms of PCIe at chr1 size) are both enqueued before the indel
-        pass of step i starts, so they run under ~100 ms of its kernels and the SNP kernels of step i + 1"""
-        ns = ni = nrec = 0
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            pend = prev = None
-            tk_s = uploader.submit(snp.wire) if snp_half else None
-            tk_i = uploader.submit(job.wire) if indel_half else None
-            dbg = os.environ.get("NC_BENCH_DEBUG") == "1"
-            tdbg = time.perf_counter()
-            for i in range(n_steps):
-                if dbg:
-                    print("configs2 step %d (snp %s indel %s): +%.1f ms" % (i, snp_half, indel_half, (time.perf_counter() - tdbg) * 1e3), file=sys.stderr, flush=True)
-                more = i + 1 < n_steps
-                cur = ri = rs = None
-                nxt_s = nxt_i = None
-                if snp_half:
-                    dpk = uploader.expand(tk_s)
-                    cur = snpCaller.call_chunks(params, chunks, device=local, dpk=dpk, defer=True)
-                    uploader.release(tk_s)
-                    nxt_s = uploader.submit(snp.wire) if more else None
-                if indel_half:
-                    nxt_i = uploader.submit(job.wire) if more else None
-                    ri = job.from_host_pass(uploader, tk_i)
-                    ni += int(ri["n"])
-                    rs = cur.result() if cur is not None else None       # (the indel pass ends on host waits: the SNP half before it is complete)
-                elif prev is not None:
-                    rs = prev.result()                                   # SNP alone: step i - 1 is collected while step i runs
-                prev = cur
-                tk_s, tk_i = nxt_s, nxt_i
-                if rs is not None:
-                    ns += int(rs["n"])
-                if pend is not None:
-                    nrec += pend.result()
-                    pend = None
-                if rs is not None or ri is not None:
-                    pend = pool.submit(host_half, rs, ri)
-            if not indel_half and prev is not None:
-                rs = prev.result()
-                ns += int(rs["n"])
-                if pend is not None:
-                    nrec += pend.result()
-                pend = pool.submit(host_half, rs, None)
-            if pend is not None:
-                nrec += pend.result()
-        return ns, ni, nrec
+        return run_pairs(uploader, local, params, units, n_steps, snp_half, indel_half)
 
     def timed(n_steps, **kw):
         import gc
@@ -805,8 +906,8 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
 
 def extra_from_bam(eng, local, n_contigs=4, L=9_000_000, keep=None):
     """From a BAM FILE through the product worker loop: snpCaller.caller (BGZF inflate + record decode + wire build on host threads for
-    contig i + 1 while the GPU runs contig i, upload through the three-slot ring) -> candidate sites/s including ingest.  The BAM (12 contigs of
-    9 Mb, ONT 30x: ~1 GB) is written by test tooling from device-generated reads, streamed contig by contig into the Python writer (~40 s, untimed)."""
+    contig i + 1 while the GPU runs contig i, upload through the three-slot ring) -> candidate sites/s including ingest.  The BAM (4 contigs of
+    9 Mb, ONT-like 30x with qualities, CIGARs and tags: ~1.5 GB) is written by test tooling from device-generated reads, streamed contig by contig into the Python writer (~40 s, untimed)."""
     import queue
     import shutil
     import tempfile
@@ -1229,13 +1330,12 @@ def main():
             "repeat": {"regions": len(dts), "value_is": "median region", "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3,
                        "sites_s_min": total_sites / max(dts), "sites_s_max": total_sites / min(dts)},
             "scaling": scaling, "vs_baseline": None, "dtype": "f32" if exact_fp32 else "f32 (f16x3 split MFMA, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "SNP-only pileup+CNN, synthetic HG002-like %s %gx %s, chr20-sized contigs (%d bp, %d chunks of 500 kb); %s"
-                       % (args.tech.upper(), args.depth, args.ploidy, L, len(chunks),
-                          ("1 contig per step, %d distinct contigs cycled" % len(contigs)) if world == 1 else
-                          ("%d contigs per step sharded over %d GPUs in contiguous blocks (%d on rank 0)" % (job_contigs, world, len(mine))) if scaling == "strong"
-                          else "1 contig per GPU per step"),
+            "config": {"workload": "configs[1]: SNP-only pileup+CNN, synthetic HG002-like %s %gx %s, chr20-sized contigs (%d bp)" % (args.tech.upper(), args.depth, args.ploidy, L),
+                       "chunks_per_contig": len(chunks), "chunk_bp": 500000, "distinct_contigs_cycled": len(contigs) if world == 1 else None,
+                       "sharding": (None if world == 1 else ("%d contigs per step in contiguous blocks over %d GPUs (%d on rank 0)" % (job_contigs, world, len(mine)))
+                                    if scaling == "strong" else "1 contig per GPU per step"),
                        "timed_region": "HBM-resident packs (--resident)" if args.resident else
-                       "pinned host memory -> H2D (reference-difference wire form, own stream, ring of three slots) -> expand -> scan -> tensors -> CNN -> results in pinned host memory",
+                       "pinned host wire -> H2D (own stream, 3-slot ring) -> expand -> scan -> tensors -> CNN -> results in pinned host memory",
                        "contigs_per_step": job_contigs if world > 1 else 1, "sites_per_contig": n_sites,
                        "pileup_entries_per_contig": c0.entries, "snp_weights": args.model,
                        "tensor_format": "int16 between featuriser and CNN (exact; fp32 with --cnn-precision fp32)", "generator": "synth_v1 seed 812+contig",
@@ -1286,20 +1386,36 @@ def main():
                 out["configs2_snp_indel_chr1"] = configs2_block(eng, uploader, local, args.model, args.configs2_steps, args.configs2_length)
             except Exception as e:
                 out["configs2_snp_indel_chr1"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            # the summary of configs[2] rides INSIDE `config` (the dict a record parser keeps whole): the largest single-GPU configuration
+            # the summary of configs[2] rides INSIDE `config` as SCALARS (a record parser keeps scalar / short-string leaves of `config` only)
             c2 = out["configs2_snp_indel_chr1"]
+            cfg = out["config"]
             if "error" in c2:
-                out["config"]["configs2"] = {"error": c2["error"]}
+                cfg["configs2_error"] = str(c2["error"])[:120]
             else:
-                out["config"]["configs2"] = {
-                    "workload": "BASELINE.json configs[2]: SNP+indel pipeline, chr1-sized synthetic ONT 30x, one timed region from pinned host memory",
-                    "value": c2["value"], "unit": c2["unit"], "ms_per_step": c2["ms_per_step"], "steps": c2["steps"],
-                    "snp_sites_per_step": c2["snp_half"]["sites_per_step"], "indel_sites_per_step": c2["indel_half"]["sites_per_step"],
-                    "snp_ms_alone": c2["snp_half"]["ms_per_step_alone"], "indel_ms_alone": c2["indel_half"]["ms_per_step_alone"],
-                    "indel_sites_s_alone": c2["indel_half"]["sites_s_alone"],
-                    "frac_snp_trunk_f16x3": c2["snp_half"]["roofline"]["frac"], "frac_k9_f16x3": c2["indel_half"]["roofline"]["frac"],
-                    "frac_fill_valu_issue_model": c2["indel_half"]["roofline_alignment"]["frac"],
-                    "indel_stages_ms": {k: v for k, v in c2["indel_half"]["stages_ms"].items() if k != "note"}}
+                cfg.update({"configs2_workload": "configs[2]: SNP+indel, chr1-sized synthetic ONT 30x, one timed region from pinned host memory",
+                            "configs2_value": c2["value"], "configs2_ms_per_step": c2["ms_per_step"], "configs2_steps": c2["steps"],
+                            "configs2_snp_sites": c2["snp_half"]["sites_per_step"], "configs2_indel_sites": c2["indel_half"]["sites_per_step"],
+                            "configs2_snp_ms": c2["snp_half"]["ms_per_step_alone"], "configs2_indel_ms": c2["indel_half"]["ms_per_step_alone"],
+                            "configs2_indel_sites_s": c2["indel_half"]["sites_s_alone"],
+                            "configs2_frac_trunk": c2["snp_half"]["roofline"]["frac"], "configs2_frac_k9": c2["indel_half"]["roofline"]["frac"],
+                            "configs2_frac_fill_issue_model": c2["indel_half"]["roofline_alignment"]["frac"],
+                            "configs2_h2d_GBs": c2["h2d"]["achieved_GBs"], "configs2_wire_bytes": c2["h2d"]["bytes_per_step"]})
+        if world == 1 and not args.no_wgs:
+            # the metric's own configuration at N = 1: one pass over 24 contigs at GRCh38 lengths, both halves (scalars in `config` as well)
+            contigs.clear()
+            c0 = pack = None
+            torch.cuda.empty_cache()
+            cfg = out["config"]
+            try:
+                wg = wgs_block(eng, uploader, local, args.model, args.wgs_passes, args.wgs_scale)
+                out["wgs_n1"] = wg
+                cfg.update({"wgs_workload": wg["workload"][:120], "wgs_value": wg["value"], "wgs_s_per_pass": wg["s_per_pass"], "wgs_sites": wg["sites_per_pass"],
+                            "wgs_snp_sites": wg["snp_sites_per_pass"], "wgs_indel_sites": wg["indel_sites_per_pass"], "wgs_contigs": wg["contigs"], "wgs_bp": wg["bp"],
+                            "wgs_wire_bytes": wg["wire_bytes_snp"] + wg["wire_bytes_indel"], "wgs_h2d_GBs": wg["h2d_achieved_GBs"],
+                            "wgs_frac_trunk": wg["frac_snp_trunk_f16x3"], "wgs_setup_s": wg["setup_s"]})
+            except Exception as e:
+                out["wgs_n1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                cfg["wgs_error"] = ("%s: %s" % (type(e).__name__, e))[:120]
         if world == 1 and not args.no_extra:
             # other configurations, outside the headline's timed region (BASELINE.json configs[4], the exact-fp32 trunk,
             # and the indel half of configs[2]); each with its own workload and roofline
@@ -1319,6 +1435,11 @@ def main():
             except Exception as e:                                  # an extra must never take the headline line down
                 extra["error"] = "%s: %s" % (type(e).__name__, e)
             out["extra_configs"] = extra
+        # what a record parser keeps of `config`: scalar leaves and strings of at most 120 characters -- enforce it here
+        for k, v in list(out["config"].items()):
+            assert not isinstance(v, (dict, list, tuple)), "config[%s] must be a scalar" % k
+            if isinstance(v, str) and len(v) > 120:
+                out["config"][k] = v[:117] + "..."
         print(json.dumps(out, default=float), flush=True)
     if use_dist:
         import torch.distributed as dist

@@ -23,14 +23,15 @@
 extern "C" {
 #endif
 
-#define NC_ABI_VERSION 10  /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
+#define NC_ABI_VERSION 11  /* 2: nc_decoded_arrays.qstart, nc_indel_scan_params.haploid, drain / async / pass-2 entry points;
                               3: nc_indel_scan_params.impute; 4: nc_timing_sums, nc_enable_timing(2), nc_snp_chunk_depth_async;
                               5: nc_wire_* (reference-difference transfer form of the read pack), nc_d2h_async, nc_indel_pass2_sets;
                               6: nc_allele_prediction_device; 7: nc_star_msa_tensor_dup + nc_pass2_arrays.al_dup, nc_bgzf_read_file, nc_consensus_strings;
                               8: device-resident indel pipeline (nc_indel_pack_*, nc_indel_sites_*, nc_indel_vcf_format), NC_ERR_UNSUPPORTED +
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
                               9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members / _scan + nc_bam_walk / _meta / _codes / _indel_reads (BAM ingest on the device);
-                              10: nc_bgzf_crc_device (CRC-32 of the device-inflated members) */
+                              10: nc_bgzf_crc_device (CRC-32 of the device-inflated members);
+                              11: nc_snp_trunk_info (which SNP trunk kernel the next nc_snp_forward runs, its MFMA count per site) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -339,6 +340,11 @@ int nc_snp_forward_drain(nc_ctx *ctx, int32_t model_kind, int64_t n, const float
  * runs on the exact fp32 kernels. */
 int nc_cnn_x_limit(nc_ctx *ctx, int32_t model_kind, float *x_limit);
 int nc_cnn_range_watch(nc_ctx *ctx, uint8_t *site_flags_dev);
+/* The split-precision SNP trunk the next nc_snp_forward[_drain] of this context launches (it depends on the tensor format and the precision
+ * mode): kernel_id 0 = k4_conv12 (exact fp32), 1 = k5_trunk_h3, 2 = k5_trunk_p3, 3 = k5_trunk_lin (int16 tensors: conv1 by linearity, two f16
+ * products on the integer entries instead of three); mfma_per_site = v_mfma_f32_16x16x32_f16 instructions it executes per site (bench.py's
+ * executed-vs-algorithmic figure).  No reference counterpart (measurement support for model_architect.py:36-64's conv1-3). */
+int nc_snp_trunk_info(nc_ctx *ctx, int32_t *mfma_per_site, int32_t *kernel_id);
 /* Indel CNN (model_architect_indel.py:28-48 rows=15 -> [n][4]; haploid rows=5 -> [n][1] sigmoid). */
 int nc_indel_forward(nc_ctx *ctx, int32_t model_kind, int64_t n, const float *x_dev, float *probs_dev);
 

@@ -18,7 +18,7 @@ NC_ERR_CAPACITY = -2
 NC_ERR_NOMEM = -3
 NC_ERR_UNSUPPORTED = -7
 FLAG_REFSKIP = 0x10000   # nc_decoded_arrays.flag bit: the CIGAR holds a reference skip
-ABI_VERSION = 10         # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
+ABI_VERSION = 11         # include/nanocaller_hip.h NC_ABI_VERSION this binding was written for
 MODEL_SNP, MODEL_SNP_HAP, MODEL_INDEL, MODEL_INDEL_HAP = 0, 1, 2, 3
 SEQ_MODES = {"ont": 0, "short_ont": 1, "ul_ont": 2, "ul_ont_extreme": 3, "pacbio": 4}
 CODE_ABSENT = 7
@@ -42,7 +42,7 @@ EXPORTS = [
     "nc_wire_build", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
     "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
-    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_inflate_device_phase", "nc_bgzf_crc_device", "nc_bgzf_members", "nc_bgzf_scan", "nc_bam_walk", "nc_bam_meta", "nc_bam_codes", "nc_bam_indel_reads", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch",
+    "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_inflate_device_phase", "nc_bgzf_crc_device", "nc_bgzf_members", "nc_bgzf_scan", "nc_bam_walk", "nc_bam_meta", "nc_bam_codes", "nc_bam_indel_reads", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch", "nc_snp_trunk_info",
 ]
 
 
@@ -229,6 +229,7 @@ def lib():
         L.nc_synth_indel_truth.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
         L.nc_synth_indel_reads.argtypes = [vp, i64, C.c_uint64, dbl, dbl, dbl, dbl, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.nc_cnn_x_limit.argtypes = [vp, i32, C.POINTER(C.c_float)]
+        L.nc_snp_trunk_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.nc_cnn_range_watch.argtypes = [vp, vp]
         L.nc_argsort4.argtypes = [vp, i64, vp, C.POINTER(i64), vp, i64]
         L.nc_snp_vcf_format.argtypes = [C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, C.POINTER(i64)]

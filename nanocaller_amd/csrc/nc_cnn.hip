@@ -1554,6 +1554,367 @@ __global__ __launch_bounds__(512) void k5_trunk_p3(const float *__restrict__ x, 
         }
     }
 }
+// =====================================================================================================================
+// k5_trunk_lin: the three-stage trunk with conv1 BY LINEARITY (round 6; VERDICT r5 #1b / #1c).
+//
+// The int16 site tensor is exact in fp16 (|x| <= 2048) and conv1 is linear, so the coverage scale s (snpCaller.py:93-96) does not have
+// to be multiplied into the operand (which makes it a 22-bit number: hi + lo planes, three products): with
+//     pre-activation = b + s * SUM(W x_scaled) + SUM(W u_unscaled) = s * [ b / s + SUM(W x) + SUM(W (u / s)) ]
+// the scaled entries (rows 1-4, channels 0-3) enter the MFMA as the INTEGERS they are -- two products (x Wh + x Wl), no lo plane -- the few
+// unscaled ones (channel 4 = the reference-base marker, and row 0 = the one-hot reference row) enter as u * rho, rho = 1 / s split into fp16
+// hi / lo, and s itself folds into the epilogue's constants (the accumulators already carry a scale S).  Operand layout: a "record" per
+// (image row r, column w) = the 5 pixels (r, w-2 .. w+2) x 6 values [x0 x1 x2 x3 hi(u4 rho) lo(u4 rho)] = 30 of 32 K slots = ONE K group per
+// 5-tap kernel row (the pixel form of k5_trunk_p3 spends 7 K groups x 2 planes on the 25 taps); row 0 has its own records (hi and lo plane of
+// u rho, same K layout, same weight fragments).  Kernel rows that fall on the `same` padding of the 5-row image for every position of a tile are
+// not executed at all.  Per site: conv1 199 MFMAs (312 before) and 83 operand reads (182): 613 MFMAs (726), 239 ds_read_b128 (338).
+// LDS: X buffer = P1 [4 slots][176 records] + P0 hi / lo [4][48] each (slot-planar: the 16 positions of a tile read 16 consecutive 16-byte slots).
+constexpr int L_NR1 = 176, L_NR0 = 48;                                       // records per slot plane (multiples of 16): 4 x 41 = 164 + zero / dump records; 41 + ...
+constexpr int L_P0H = 4 * L_NR1 * 8, L_P0L = L_P0H + 4 * L_NR0 * 8, L_XBUF = L_P0L + 4 * L_NR0 * 8;   // halves
+constexpr int L_Z1 = 164, L_Z0 = 41, L_DUMP1 = 170, L_DUMP0 = 44;           // all-zero records (read by lanes whose kernel row is off the image); write-only dump records
+constexpr int T_NW1L = 17;                                                   // conv1 fragments: 5x5 hi / lo per kernel row, 1x5 hi / lo, 5x1 groups A, B (hi / lo), C (hi)
+enum { LW_5H = 0, LW_5L = 5, LW_1H = 10, LW_1L = 11, LW_2HA = 12, LW_2LA = 13, LW_2HB = 14, LW_2LB = 15, LW_2HC = 16 };
+constexpr int L_PACKED_BYTES = 2 * T_FRAG * T_NW1L;
+constexpr int L_DXO[5] = {0, -2, -1, 1, 2};                                  // pixel i of a record is column w + L_DXO[i] (the centre first: slot 0 serves the 5x1 kernel)
+// which tiles of 16 positions a conv1 wave computes (position p = 16 t + lane % 16 = 41 h + w)
+struct c1l_role { int nt; int tile[5]; };
+#ifndef NC_LIN_ROLES
+#define NC_LIN_ROLES {{4, {0, 4, 8, 12, 0}}, {3, {1, 5, 9, 0, 0}}, {3, {2, 6, 10, 0, 0}}, {3, {3, 7, 11, 0, 0}}}
+#endif
+constexpr c1l_role C1L_ROLES[4] = NC_LIN_ROLES;
+constexpr int c1l_hlo(int t) { return (16 * t) / 41; }
+constexpr int c1l_hhi(int t) { return (16 * t + 15 > 204 ? 204 : 16 * t + 15) / 41; }
+constexpr bool c1l_v1(int h, int dy) { return h + dy - 2 >= 1 && h + dy - 2 <= 4; }
+constexpr bool c1l_v0(int h, int dy) { return h + dy - 2 == 0; }
+constexpr bool c1l_need1(int t, int dy) { return c1l_v1(c1l_hlo(t), dy) || c1l_v1(c1l_hhi(t), dy); }
+constexpr bool c1l_all1(int t, int dy) { return c1l_v1(c1l_hlo(t), dy) && c1l_v1(c1l_hhi(t), dy); }
+constexpr bool c1l_need0(int t, int dy) { return c1l_v0(c1l_hlo(t), dy) || c1l_v0(c1l_hhi(t), dy); }
+constexpr bool c1l_all0(int t, int dy) { return c1l_v0(c1l_hlo(t), dy) && c1l_v0(c1l_hhi(t), dy); }
+constexpr bool c1l_low(int t) { return c1l_hlo(t) <= 2; }                    // some position of the tile has image row 0 under a 5x1 tap (groups B, C)
+constexpr int c1l_n0(int role, int dy) { int n = 0; for (int tm = 0; tm < C1L_ROLES[role].nt; tm++) n += c1l_need0(C1L_ROLES[role].tile[tm], dy) ? 1 : 0; return n; }
+constexpr int c1l_mfma_tile(int t)
+{
+    int n = 0;
+    for (int dy = 0; dy < 5; dy++) n += (c1l_need1(t, dy) ? 2 : 0) + (c1l_need0(t, dy) ? 3 : 0) + (dy == 2 ? (c1l_need1(t, dy) ? 2 : 0) + (c1l_need0(t, dy) ? 3 : 0) : 0);
+    return n + 2 + (c1l_low(t) ? 3 : 0);
+}
+constexpr int c1l_mfma_site() { int n = 0; for (int t = 0; t < 13; t++) n += c1l_mfma_tile(t); return n; }
+constexpr int L_MFMA_PER_SITE = c1l_mfma_site() + 10 * 27 + 8 * 18;
+
+template <int ROLE>
+__device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, const h8 (&wl)[T_NW1L], const float *__restrict__ b1s, const h_epi &epi, float rho, int lane,
+                                            unsigned long long *trk = nullptr)
+{
+    constexpr c1l_role R = C1L_ROLES[ROLE];
+    constexpr int NT = R.nt;
+    static_assert(c1l_n0(ROLE, 0) <= 2 && c1l_n0(ROLE, 1) <= 2 && c1l_n0(ROLE, 2) <= 2, "t_conv1_lin: at most two row-0 operand pairs per kernel row and wave");
+    const int g = lane >> 4, c16 = lane & 15;
+    int pr8[NT], w8[NT], hrow[NT], obase[NT];
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        const int t = R.tile[tm];
+        const int p = 16 * t + c16, pr = p < 205 ? p : 204;
+        const int h = c1l_hlo(t) == c1l_hhi(t) ? c1l_hlo(t) : (pr >= 41 * c1l_hhi(t) ? c1l_hhi(t) : c1l_hlo(t));
+        const int w = pr - 41 * h;
+        hrow[tm] = h;
+        pr8[tm] = (pr - 123) * 8;                                      // halves; record of kernel row dy = pr - 123 + 41 dy  (= (h + dy - 3) * 41 + w)
+        w8[tm] = w * 8;
+        // positions 205..207 (tile 12) go to the three unused slots at the end of row 4
+        obase[tm] = ((g >> 1) * T_PL1 + (p < 205 ? h * T_R1 + w : 4 * T_R1 + 41 + (p - 205))) * 8 + (g & 1) * 4;
+        asm volatile("" : "+v"(pr8[tm]), "+v"(w8[tm]), "+v"(obase[tm]), "+v"(hrow[tm]));     // (keeps the address arithmetic inside the site loop: no spills)
+    }
+    const int g1 = g * L_NR1 * 8, g0 = L_P0H + g * L_NR0 * 8;          // this lane group's slot plane
+    auto a1 = [&](int tm, int dy) -> int {                             // operand of the 5-tap kernel row dy, rows 1..4
+        const int t = R.tile[tm];
+        int a = g1 + pr8[tm] + 41 * 8 * dy;
+        if (!c1l_all1(t, dy)) { const int r = hrow[tm] + dy - 2; a = (r >= 1 && r <= 4) ? a : g1 + L_Z1 * 8; }
+        return a;
+    };
+    auto a0 = [&](int tm, int dy) -> int {                             // the same of image row 0 (hi plane; the lo plane is L_P0L - L_P0H further)
+        const int t = R.tile[tm];
+        int a = g0 + w8[tm];
+        if (!c1l_all0(t, dy)) a = (hrow[tm] + dy - 2 == 0) ? a : g0 + L_Z0 * 8;
+        return a;
+    };
+    // 5x1 kernel: lane group g reads slot 0 (the centre pixel) of the record of ITS kernel row.  A: rows dy = g of P1.  B: g = 0: dy = 4 of P1;
+    // g = 1..3: dy = g - 1 of the row-0 hi plane.  C: g = 0..2: dy = g of the row-0 lo plane.
+    auto aA = [&](int tm) -> int { const int r = hrow[tm] + g - 2; return (r >= 1 && r <= 4) ? pr8[tm] + 41 * 8 * g : L_Z1 * 8; };
+    auto aB = [&](int tm) -> int {
+        const int h = hrow[tm];
+        const int p1 = h <= 2 ? pr8[tm] + 41 * 8 * 4 : L_Z1 * 8, p0 = L_P0H + (h == 3 - g ? w8[tm] : L_Z0 * 8);
+        return g == 0 ? p1 : p0;
+    };
+    auto aC = [&](int tm) -> int { return L_P0L + ((g < 3 && hrow[tm] == 2 - g) ? w8[tm] : L_Z0 * 8); };
+    f32x4v acc1[NT], acc2[NT], acc3[NT];
+    {
+        const f32x4v x1 = *reinterpret_cast<const f32x4v *>(b1s + 4 * g) * rho, x2 = *reinterpret_cast<const f32x4v *>(b1s + 16 + 4 * g) * rho,
+                     x3 = *reinterpret_cast<const f32x4v *>(b1s + 32 + 4 * g) * rho;
+#pragma unroll
+        for (int tm = 0; tm < NT; tm++) { acc1[tm] = x1; acc2[tm] = x2; acc3[tm] = x3; }
+    }
+    // steps 0..4: the 5-tap kernel rows dy (5x5 kernel; dy == 2 also feeds the 1x5 kernel); step 5: 5x1 group A; step 6: 5x1 groups B and C.
+    // The operands of step s + 1 are requested before the MFMAs of step s (register double buffer).
+    h8 x1[2][NT], xh[2][2], xl[2][2], xc[NT];
+    auto load = [&](int s, int slot) {
+        if (s < 5) {
+            int n0 = 0;
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) {
+                const int t = R.tile[tm];
+                if (c1l_need1(t, s)) x1[slot][tm] = lds_h8(XB + a1(tm, s));
+                if (c1l_need0(t, s)) { const int a = a0(tm, s); xh[slot][n0] = lds_h8(XB + a); xl[slot][n0] = lds_h8(XB + a + (L_P0L - L_P0H)); n0++; }
+            }
+        } else if (s == 5) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) x1[slot][tm] = lds_h8(XB + aA(tm));
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++)
+                if (c1l_low(R.tile[tm])) { x1[slot][tm] = lds_h8(XB + aB(tm)); xc[tm] = lds_h8(XB + aC(tm)); }
+        }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        const int cur = s & 1;
+        if (s + 1 < 7) load(s + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < 5) {
+            // independent accumulators interleaved; the three products of a row-0 operand pair are spread over the step
+            int n0 = 0;
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], x1[cur][tm]) }
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_need0(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xh[cur][n0]) } n0++; }
+            if (s == 2) {
+#pragma unroll
+                for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc1[tm], wl[LW_1H], x1[cur][tm]) }
+            }
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], x1[cur][tm]) }
+            n0 = 0;
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_need0(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xl[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xl[cur][n0]) } n0++; }
+            if (s == 2) {
+#pragma unroll
+                for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc1[tm], wl[LW_1L], x1[cur][tm]) }
+            }
+            n0 = 0;
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_need0(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1L], xh[cur][n0]) } n0++; }
+        } else if (s == 5) {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], wl[LW_2HA], x1[cur][tm]) }
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], wl[LW_2LA], x1[cur][tm]) }
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_low(R.tile[tm])) { NC_MFMA(acc2[tm], wl[LW_2HB], x1[cur][tm]) }
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_low(R.tile[tm])) { NC_MFMA(acc2[tm], wl[LW_2HC], xc[tm]) }
+#pragma unroll
+            for (int tm = 0; tm < NT; tm++) if (c1l_low(R.tile[tm])) { NC_MFMA(acc2[tm], wl[LW_2LB], x1[cur][tm]) }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (trk) trk[2] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int tm = 0; tm < NT; tm++) {
+        const int o = obase[tm];
+        split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
+        split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
+        split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
+    }
+}
+
+// fp16 hi / lo of a float as one packed dword (lo in the upper half)
+__device__ __forceinline__ uint32_t split_pack(float v)
+{
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+    return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+}
+
+__global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ x, const uint8_t *__restrict__ wp, const uint8_t *__restrict__ wlin, float *__restrict__ a3,
+                                                    int64_t n_sites, const double *__restrict__ scale, int64_t site0, float x_limit, uint8_t *__restrict__ range_sites)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 X[2][L_XBUF];
+    __shared__ __attribute__((aligned(16))) _Float16 A1[2][2 * T_A1PLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 A2[2][2 * T_A2PLANE];
+    __shared__ __attribute__((aligned(16))) float BIAS[48 + 32 + 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint4 *w1f = reinterpret_cast<const uint4 *>(wp), *w2h = w1f + T_NW1 * 64, *w2l = w2h + T_NW2 * 64, *w3h = w2l + T_NW2 * 64, *w3l = w3h + T_NW3 * 64;
+    const uint4 *wlf = reinterpret_cast<const uint4 *>(wlin);
+    const float *bg = reinterpret_cast<const float *>(w3l + T_NW3 * 64);
+    const float *b1s = BIAS, *b2s = BIAS + 48, *b3s = BIAS + 80;
+    const int *c3tab = reinterpret_cast<const int *>(bg + 48 + 32 + 68);
+    const float inv_s = bg[48 + 32 + 64];
+    if (threadIdx.x < 48 + 32 + 64) BIAS[threadIdx.x] = bg[threadIdx.x];
+    const h_epi epi = {inv_s * 1.44269504088896341f, inv_s * SELU_L, 60000.0f / (inv_s * SELU_L)};
+    const int64_t n_k = (n_sites - blockIdx.x + gridDim.x - 1) / gridDim.x;        // sites of this workgroup (>= 1)
+    for (int i = threadIdx.x; i < 2 * L_XBUF / 8; i += 512) *reinterpret_cast<uint4 *>(&X[0][0] + i * 8) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // coverage scale of a site (snpCaller.py:93-96): s as float (numpy's float32 product in both modes up to one rounding of the operand, which this
+    // kernel does not perform at all), 1 without a scale array
+    auto site_scale = [&](int64_t k) -> float { return scale ? (float)scale[site0 + blockIdx.x + k * gridDim.x] : 1.0f; };
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ conv1 of site s
+        h8 wl[T_NW1L];
+#pragma unroll
+        for (int q = 0; q < T_NW1L; q++) wl[q] = as_h8(wlf[q * 64 + lane]);
+        float s_next = site_scale(0);
+        __syncthreads();                                                           // P0
+        for (int64_t s = 0; s < n_k + 2; s++) {
+#ifdef NC_TRACE_P3
+            unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
+#else
+            unsigned long long *trk = nullptr;
+#endif
+            P3_T(0)
+            P3_T(1)
+            if (s < n_k) {
+                const int buf = (int)(s & 1);
+                const float sf = s_next, rho = 1.0f / sf;
+                if (s + 1 < n_k) s_next = site_scale(s + 1);                       // (a scalar load: a step ahead of its use)
+                const h_epi e1 = {epi.c1 * sf, epi.c2 * sf, epi.c3 * rho};         // the accumulators hold S / s x (pre-activation)
+                if (wv == 4) t_conv1_lin<0>(X[buf], A1[buf], wl, b1s, e1, rho, lane, trk);
+                else if (wv == 5) t_conv1_lin<1>(X[buf], A1[buf], wl, b1s, e1, rho, lane, trk);
+                else if (wv == 6) t_conv1_lin<2>(X[buf], A1[buf], wl, b1s, e1, rho, lane, trk);
+                else t_conv1_lin<3>(X[buf], A1[buf], wl, b1s, e1, rho, lane, trk);
+            }
+            P3_T(5)
+            NC_SITE_SYNC();
+            P3_T(6)
+        }
+    } else if (wv < 2) {
+        // ------------------------------------------------------------------ conv2 of site s - 1
+        h8 c2h[9][2], c2l[9][2];
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) { c2h[q][tn] = as_h8(w2h[(q * 2 + tn) * 64 + lane]); c2l[q][tn] = as_h8(w2l[(q * 2 + tn) * 64 + lane]); }
+        __syncthreads();                                                           // P0
+        for (int64_t s = 0; s < n_k + 2; s++) {
+#ifdef NC_TRACE_P3
+            unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
+#else
+            unsigned long long *trk = nullptr;
+#endif
+            P3_T(0)
+            if (s >= 1 && s - 1 < n_k) {
+                const int buf = (int)((s - 1) & 1);
+                if (wv == 0) t_conv2_pair<0>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+                else t_conv2_pair<1>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+            }
+            P3_T(5)
+            NC_SITE_SYNC();
+            P3_T(6)
+        }
+    } else {
+        // ------------------------------------------------------------------ staging of site s + 1, conv3 of site s - 2
+        const int cw = wv - 2;
+        h8 c3h[6][2], c3l[6][2];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                c3h[q][tn] = as_h8(w3h[(q * 4 + 2 * cw + tn) * 64 + lane]);
+                c3l[q][tn] = as_h8(w3l[(q * 4 + 2 * cw + tn) * 64 + lane]);
+            }
+        const int c3slot[2] = {c3tab[lane & 15], c3tab[16 + (lane & 15)]}, c3out[2] = {c3tab[32 + (lane & 15)], c3tab[48 + (lane & 15)]};
+        const int st = (int)threadIdx.x - 128;                                    // 0..127: pixels st and st + 128 (< 205) of the 5 x 41 image
+        uint32_t raw[2][3];
+        float pre_s = 1.0f;
+        int64_t pre_site = 0;
+        auto prefetch = [&](int64_t k) {                                           // issues the loads of the workgroup's k-th site; commit() converts them a step later
+            const int64_t site = (int64_t)blockIdx.x + k * gridDim.x;
+            pre_site = site;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int t = st + 128 * j, px = t < 205 ? t : 204;
+                const int16_t *xs = x + site * NC_SNP_TENSOR + px * 5;             // 2-byte aligned
+                typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                raw[j][0] = *reinterpret_cast<const u32_a2 *>(xs);
+                raw[j][1] = *reinterpret_cast<const u32_a2 *>(xs + 2);
+                raw[j][2] = (uint32_t)(uint16_t)xs[4];
+            }
+            pre_s = site_scale(k);
+        };
+        auto commit = [&](int buf) {
+            const float sf = pre_s, rho = 1.0f / sf;
+            _Float16 *XB = &X[buf][0];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (st + 128 * j >= 205) continue;
+                const int px = st + 128 * j, ph = px / 41, pw = px - ph * 41;
+                const int v0 = (int16_t)(raw[j][0] & 0xffffu), v1 = (int16_t)(raw[j][0] >> 16), v2 = (int16_t)(raw[j][1] & 0xffffu), v3 = (int16_t)(raw[j][1] >> 16),
+                          v4 = (int16_t)raw[j][2];
+                const int m4 = max(max(abs(v0), abs(v1)), max(abs(v2), abs(v3)));
+                // range guard: the scaled entries as the epilogue sees them (|x| s), the unscaled ones as they are; integers beyond fp16's exact range
+                // (2048) cannot take this kernel at all.  Flagged sites are computed again by the exact fp32 trunk (nc_cnn_range_watch).
+                const float amax = ph > 0 ? fmaxf((float)m4 * sf, fabsf((float)v4)) : fmaxf((float)m4, fabsf((float)v4));
+                if (range_sites && (!(amax <= x_limit) || (ph > 0 && m4 > 2048))) range_sites[site0 + pre_site] = 1;
+                // the pixel's 6 K values as three dwords per plane
+                uint32_t d[2][3];
+                const uint32_t u4 = split_pack((float)v4 * rho);
+                if (ph > 0) {
+                    const h2 q01 = {(_Float16)(float)v0, (_Float16)(float)v1}, q23 = {(_Float16)(float)v2, (_Float16)(float)v3};      // exact: |v| <= 2048
+                    d[0][0] = __builtin_bit_cast(uint32_t, q01); d[0][1] = __builtin_bit_cast(uint32_t, q23); d[0][2] = u4;              // [x0 x1 x2 x3 hi(u4 rho) lo(u4 rho)]
+                } else {
+                    const uint32_t u0 = split_pack((float)v0 * rho), u1 = split_pack((float)v1 * rho), u2 = split_pack((float)v2 * rho), u3 = split_pack((float)v3 * rho);
+                    d[0][0] = (u0 & 0xffffu) | (u1 << 16); d[0][1] = (u2 & 0xffffu) | (u3 << 16); d[0][2] = u4 & 0xffffu;                // hi plane [h0 h1 h2 h3 h4 0]
+                    d[1][0] = (u0 >> 16) | (u1 & 0xffff0000u); d[1][1] = (u2 >> 16) | (u3 & 0xffff0000u); d[1][2] = u4 >> 16;            // lo plane [l0 l1 l2 l3 l4 0]
+                }
+                // the pixel is element i of the records of columns w' = pw - L_DXO[i] of its row: K slots 6 i .. 6 i + 5 of that record
+                const int nr = ph > 0 ? L_NR1 : L_NR0, rec0 = ph > 0 ? (ph - 1) * 41 : 0, dump = ph > 0 ? L_DUMP1 : L_DUMP0, pbase = ph > 0 ? 0 : L_P0H;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int wq = pw - L_DXO[i];
+                    const int rec = (wq >= 0 && wq <= 40) ? rec0 + wq : dump;
+                    constexpr int NPL = 2;
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) {
+                        if (pl == 1 && ph > 0) continue;
+                        _Float16 *rb = XB + pbase + pl * (L_P0L - L_P0H) + rec * 8;
+                        const int k0 = 6 * i, sl = k0 >> 3, of = k0 & 7;            // first K slot: 16-byte slot sl, half `of` (0, 6, 4, 2, 0)
+                        _Float16 *q0 = rb + sl * nr * 8 + of;
+                        if (of == 0) { *reinterpret_cast<uint2 *>(q0) = make_uint2(d[pl][0], d[pl][1]); *reinterpret_cast<uint32_t *>(q0 + 4) = d[pl][2]; }
+                        else if (of == 6) { *reinterpret_cast<uint32_t *>(q0) = d[pl][0]; *reinterpret_cast<uint2 *>(rb + (sl + 1) * nr * 8) = make_uint2(d[pl][1], d[pl][2]); }
+                        else if (of == 4) { *reinterpret_cast<uint2 *>(q0) = make_uint2(d[pl][0], d[pl][1]); *reinterpret_cast<uint32_t *>(rb + (sl + 1) * nr * 8) = d[pl][2]; }
+                        else { *reinterpret_cast<uint32_t *>(q0) = d[pl][0]; *reinterpret_cast<uint2 *>(q0 + 2) = make_uint2(d[pl][1], d[pl][2]); }
+                    }
+                }
+            }
+        };
+        int64_t site = blockIdx.x;                                                 // the site conv3 works on next
+        prefetch(0);
+        commit(0);
+        if (n_k > 1) prefetch(1);
+        __syncthreads();                                                           // P0
+        for (int64_t s = 0; s < n_k + 2; s++) {
+#ifdef NC_TRACE_P3
+            unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
+#else
+            unsigned long long *trk = nullptr;
+#endif
+            P3_T(0)
+            // the other X buffer's last reader was conv1 of site s - 1 (a barrier ago); site s + 1's loads were issued a step ago
+            if (s + 1 < n_k) commit((int)((s + 1) & 1));
+            if (s + 2 < n_k) prefetch(s + 2);
+            P3_T(2)
+            if (s >= 2) {
+                const int buf = (int)(s & 1);
+                float *out_site = a3 + site * (27 * 64);
+                if (cw == 0) t_conv3_pair<0>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane, trk);
+                else t_conv3_pair<1>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane, trk);
+                site += gridDim.x;
+            }
+            P3_T(5)
+            NC_SITE_SYNC();
+            P3_T(6)
+        }
+    }
+}
+
 #undef NC_MFMA3
 #undef NC_MFMA
 
@@ -2337,6 +2698,14 @@ const size_t NPARAM[4] = {109370, 108308, 634420, 158185};
 inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
 // conv trunk for `nb` sites -> fc1 activations [nb][F]; *f1_out / *tail receive the fc1 buffer and the tail weights
+// which split-precision SNP trunk a forward call runs: k5_trunk_lin (conv1 by linearity; int16 tensors only) unless NC_TRUNK_LIN=0 or the
+// two-stage kernel was asked for (NC_TRUNK_P3=0); float32 tensors take k5_trunk_p3 (their entries need not be integers)
+static bool trunk_lin_selected(const nc_ctx *ctx)
+{
+    const char *el = getenv("NC_TRUNK_LIN"), *e3 = getenv("NC_TRUNK_P3");
+    return ctx->x_i16 && !ctx->cnn_exact_fp32 && !(el && el[0] == '0') && !(e3 && e3[0] == '0');
+}
+
 template <int H, int W, int CI, int C1, int C2, int C3, int F, int P2, int P3, bool MFMA>
 int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *packed_h, int64_t site0, int64_t nb, const float *x_batch, const double *scale, int scale_mode,
               const float **f1_out, const float **tail, float x_limit = 0.0f)
@@ -2409,8 +2778,15 @@ int run_trunk(nc_ctx *ctx, const float *w, const float *packed, const uint8_t *p
             // two-stage k5_trunk_h3: the same results bit for bit (the same MFMA sequence per accumulator; tests/test_gpu_parity.py)
             const char *e3 = getenv("NC_TRUNK_P3");
             const bool p3 = !(e3 && e3[0] == '0');
-            auto *kt = p3 ? (ctx->x_i16 ? k5_trunk_p3<true> : k5_trunk_p3<false>) : (ctx->x_i16 ? k5_trunk_h3<true> : k5_trunk_h3<false>);
-            hipExtLaunchKernelGGL(kt, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
+            if (trunk_lin_selected(ctx)) {
+                // int16 tensors (the product path): conv1 by linearity, k5_trunk_lin (round 6).  Both scale modes are the same arithmetic here: the
+                // scale multiplies the accumulators, not the operand
+                hipExtLaunchKernelGGL(k5_trunk_lin, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, reinterpret_cast<const int16_t *>(x_batch), packed_h,
+                                      packed_h + H_PACKED_BYTES + FC_PACKED_BYTES, a3, nb, scale, site0, x_limit, ctx->range_sites);
+            } else {
+                auto *kt = p3 ? (ctx->x_i16 ? k5_trunk_p3<true> : k5_trunk_p3<false>) : (ctx->x_i16 ? k5_trunk_h3<true> : k5_trunk_h3<false>);
+                hipExtLaunchKernelGGL(kt, dim3(nblk5), dim3(512), 0, ctx->stream, ev0, ev1, 0, x_batch, packed_h, a3, nb, scale, scale_mode, site0, x_limit, ctx->range_sites);
+            }
         }
         if (ctx->cnn_exact_fp32)
             hipLaunchKernelGGL((k3_fc1<F, TMF>), dim3(blocks_for(nb, 16 * TMF)), dim3(256), 0, ctx->stream, a3, (int)n3, kf, bf, f1, nb);
@@ -2550,7 +2926,7 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
         for (const float *q = blob_host; q < b3 + 64; q++) wmax = std::fmax(wmax, std::fabs(*q));
         float S = 1024.0f;
         while (S > 1.0f && wmax * S > 16384.0f) S *= 0.5f;
-        std::vector<uint8_t> hp((size_t)H_PACKED_BYTES + FC_PACKED_BYTES, 0);
+        std::vector<uint8_t> hp((size_t)H_PACKED_BYTES + FC_PACKED_BYTES + L_PACKED_BYTES, 0);
         _Float16 *w1f = reinterpret_cast<_Float16 *>(hp.data()), *w2h = w1f + T_NW1 * T_FRAG, *w2l = w2h + T_NW2 * T_FRAG,
                  *w3h = w2l + T_NW2 * T_FRAG, *w3l = w3h + T_NW3 * T_FRAG;
         float *b1s = reinterpret_cast<float *>(w3l + T_NW3 * T_FRAG), *b2s = b1s + 48, *b3s = b2s + 32;
@@ -2631,6 +3007,46 @@ int nc_load_weights(nc_ctx *ctx, int32_t kind, const float *blob_host, size_t n_
             for (int c = 0; c < 48; c++) fbs[c] = bf[c] * SF;
             fbs[48] = 1.0f / SF;
         }
+        {
+            // conv1 fragments of k5_trunk_lin (record form): K slot k = 6 i + v of a 5-tap kernel row = pixel i (column offset L_DXO[i]), value v of
+            // [x0 x1 x2 x3 hi(u4 rho) lo(u4 rho)]; the lo-weight fragment has no entry for v = 5 (lo x lo is dropped, as everywhere)
+            _Float16 *lf = reinterpret_cast<_Float16 *>(hp.data() + H_PACKED_BYTES + FC_PACKED_BYTES);
+            auto lput = [&](int frag, int lane, int j, _Float16 v) { lf[((size_t)frag * 64 + lane) * 8 + j] = v; };
+            const _Float16 Z = (_Float16)0.0f;
+            for (int lane = 0; lane < 64; lane++) {
+                const int g = lane >> 4, c = lane & 15;
+                for (int j = 0; j < 8; j++) {
+                    _Float16 H, L;
+                    const int k = 8 * g + j;
+                    if (k < 30) {
+                        const int i = k / 6, v = k % 6, dx = 2 + L_DXO[i], ci = v < 4 ? v : 4;
+                        for (int dy = 0; dy < 5; dy++) {
+                            split(k13[((dy * 5 + dx) * 5 + ci) * 16 + c], H, L);
+                            lput(LW_5H + dy, lane, j, H);
+                            lput(LW_5L + dy, lane, j, v == 5 ? Z : L);
+                        }
+                        split(k11[(dx * 5 + ci) * 16 + c], H, L);
+                        lput(LW_1H, lane, j, H);
+                        lput(LW_1L, lane, j, v == 5 ? Z : L);
+                    }
+                    // 5x1 kernel: slot 0 of a record = the centre pixel's six values (+ two of another pixel: zero weights)
+                    if (j < 6) {
+                        const int ci = j < 4 ? j : 4;
+                        split(k12[(g * 5 + ci) * 16 + c], H, L);                       // group A: kernel row dy = g, rows 1..4
+                        lput(LW_2HA, lane, j, H);
+                        lput(LW_2LA, lane, j, j == 5 ? Z : L);
+                        const int dyb = g == 0 ? 4 : g - 1;                             // group B: g = 0: dy = 4 of rows 1..4; g >= 1: dy = g - 1 of the row-0 hi plane
+                        split(k12[(dyb * 5 + ci) * 16 + c], H, L);
+                        lput(LW_2HB, lane, j, (g > 0 && j == 5) ? Z : H);
+                        lput(LW_2LB, lane, j, j == 5 ? Z : L);
+                        if (g < 3) {                                                     // group C: dy = g of the row-0 lo plane
+                            split(k12[(g * 5 + ci) * 16 + c], H, L);
+                            lput(LW_2HC, lane, j, j == 5 ? Z : H);
+                        }
+                    }
+                }
+            }
+        }
         if (!w.packed_h) {
             hipError_t e = hipMalloc(&w.packed_h, hp.size());
             if (e != hipSuccess) return nc_fail(ctx, NC_ERR_NOMEM, "hipMalloc packed fp16 weights: %s", hipGetErrorString(e));
@@ -2710,6 +3126,16 @@ int nc_cnn_x_limit(nc_ctx *ctx, int32_t kind, float *x_limit)
     if (!ctx || kind < 0 || kind > 3 || !x_limit) return NC_ERR_ARG;
     if (!ctx->w[kind].dev) return nc_fail(ctx, NC_ERR_STATE, "nc_cnn_x_limit: weights of kind %d not loaded", kind);
     *x_limit = ctx->w[kind].x_limit;
+    return NC_OK;
+}
+
+int nc_snp_trunk_info(nc_ctx *ctx, int32_t *mfma_per_site, int32_t *kernel_id)
+{
+    if (!ctx) return NC_ERR_ARG;
+    const char *e3 = getenv("NC_TRUNK_P3");
+    const bool lin = trunk_lin_selected(ctx);
+    if (mfma_per_site) *mfma_per_site = lin ? L_MFMA_PER_SITE : 13 * 24 + 10 * 27 + 8 * 18;
+    if (kernel_id) *kernel_id = ctx->cnn_exact_fp32 ? 0 : lin ? 3 : (e3 && e3[0] == '0') ? 1 : 2;
     return NC_OK;
 }
 

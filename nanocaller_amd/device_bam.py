@@ -45,9 +45,13 @@ def resident_limit(device=0):
     what is free now (plus what this module's own pools already hold), at most MAX_RESIDENT"""
     try:
         free, _total = torch.cuda.mem_get_info(device)
+        # blocks torch's caching allocator holds but has handed back (a released share larger than POOL_MAX lands there) are invisible to
+        # mem_get_info and are served to the next torch.empty all the same: they count as free (ADVICE r5)
+        free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
     except Exception:
         return MAX_RESIDENT
-    pooled = sum(t[0].numel() for t in _RAW_POOL.values()) + sum(t.numel() * t.element_size() for t in _WORK_POOL.values())
+    pooled = sum(t[0].numel() for k, t in _RAW_POOL.items() if k == device) + sum(t.numel() * t.element_size() for k, t in _WORK_POOL.items() if k[0] == device)
+    # (the pools' tensors are torch allocations: part of memory_allocated, so they are added back here as the loader re-uses them)
     return int(max(1 << 30, min(MAX_RESIDENT, (free + pooled) // 2)))
 
 
@@ -679,13 +683,15 @@ def contig_spans(path):
     return out, list(probe.ref_names)
 
 
-def plan_shares(path, contigs, limit_bytes=None):
+def plan_shares(path, contigs, limit_bytes=None, device=None):
     """`contigs` (in the order they will be called) cut into runs whose part of the file -- first record of the run's first contig to the first
     record behind its last -- stays under `limit_bytes` of compressed BAM (default: what DeviceBam accepts), so that a genome-sized file
     passes through HBM share by share.  -> list of (contigs of the share, fits): fits False = that contig alone is too large (host route).
     Raises DeviceIngestUnavailable when there is no .bai."""
     spans, names = contig_spans(path)
-    limit = (resident_limit(torch.cuda.current_device() if torch.cuda.is_available() else 0) // 8) if limit_bytes is None else int(limit_bytes)
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    limit = (resident_limit(device) // 8) if limit_bytes is None else int(limit_bytes)
     shares, cur, lo, hi = [], [], None, None
     for c in contigs:
         if c not in names:

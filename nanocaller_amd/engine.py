@@ -152,10 +152,17 @@ class Engine:
         self._check(self.L.nc_set_tensor_format(self.ctx, 1 if int16 else 0), "nc_set_tensor_format")
         self.x_int16 = bool(int16)
 
+    TRUNK_KERNELS = {0: "k4_conv12", 1: "k5_trunk_h3", 2: "k5_trunk_p3", 3: "k5_trunk_lin"}
+
+    def trunk_info(self):
+        """-> (v_mfma_f32_16x16x32_f16 instructions per site, kernel name) of the SNP trunk the next snp_forward of this context launches (it depends
+        on the tensor format and the precision mode): k5_trunk_p3 / _h3 13 x 24 + 10 x 27 + 8 x 18 = 726, k5_trunk_lin (int16 tensors) 613"""
+        n, k = C.c_int32(), C.c_int32()
+        self._check(self.L.nc_snp_trunk_info(self.ctx, C.byref(n), C.byref(k)), "nc_snp_trunk_info")
+        return int(n.value), self.TRUNK_KERNELS[int(k.value)]
+
     def trunk_mfma_per_site(self) -> int:
-        """v_mfma_f32_16x16x32_f16 instructions k5_trunk_p3 / k5_trunk_h3 execute per site (zero-weight tap slots included): conv1 24 per
-        16-position tile x 13 tiles, conv2 27 per (tile, half of the channels) x 10, conv3 18 x 8"""
-        return 13 * 24 + 10 * 27 + 8 * 18
+        return self.trunk_info()[0]
 
     def enable_timing(self, on=True, trunk_only=False):
         """HIP-event timers: all stages, or (trunk_only) just the trunk kernel's launches, whose events ride on the

@@ -381,7 +381,7 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
                 lim = os.environ.get('NC_DEVICE_INGEST_SHARE_GB')
                 order = list(dict.fromkeys(k[0] for k in keys))
                 share_of = {}
-                for n_sh, (cs, fits) in enumerate(plan_shares(params['sam_path'], order, None if lim is None else int(float(lim) * (1 << 30)))):
+                for n_sh, (cs, fits) in enumerate(plan_shares(params['sam_path'], order, None if lim is None else int(float(lim) * (1 << 30)), device=device)):
                     for c in cs:
                         share_of[c] = (n_sh, tuple(cs) if fits else None)
                 a0 = 0

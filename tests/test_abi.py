@@ -23,7 +23,7 @@ def test_header_symbols_all_exported():
     for n in names:
         assert hasattr(L, n), "missing export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert L.nc_abi_version() == _lib.ABI_VERSION == 10
+    assert L.nc_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_header_compiles_as_plain_c(tmp_path):

@@ -361,6 +361,7 @@ def test_a_device_without_room_sends_the_file_to_the_host_route(tmp_path, monkey
     device_bam.release(buffers=True)
     lim = device_bam.resident_limit(0)
     free, total = torch.cuda.mem_get_info(0)
+    free += torch.cuda.memory_reserved(0) - torch.cuda.memory_allocated(0)                          # torch's cached blocks are served to the loader too
     assert (1 << 30) <= lim <= min(device_bam.MAX_RESIDENT, free // 2 + (1 << 20))
     monkeypatch.setattr(device_bam, "resident_limit", lambda device=0: 1024)
     with pytest.raises(device_bam.DeviceIngestUnavailable):
@@ -377,6 +378,32 @@ def test_a_device_without_room_sends_the_file_to_the_host_route(tmp_path, monkey
     device_bam.release(buffers=True)
     assert device_bam.open_device_bam(bam, 0).n_rec > 100
     device_bam.release(buffers=True)
+
+
+@pytest.mark.gpu
+def test_a_released_share_in_torchs_cache_does_not_shrink_the_next_share(monkeypatch):
+    """a share whose stream buffer exceeds POOL_MAX goes back to torch's caching allocator on release; mem_get_info no longer shows it
+    as free, torch.empty still gets it.  resident_limit() counts it, so share 2..N of a genome-sized file keep the device route; plan_shares takes
+    the worker's device."""
+    import torch
+    from nanocaller_amd import device_bam
+    device_bam.release(buffers=True)
+    torch.cuda.empty_cache()
+    monkeypatch.setattr(device_bam, "MAX_RESIDENT", 1 << 42)
+    lim0 = device_bam.resident_limit(0)
+    free0, _ = torch.cuda.mem_get_info(0)
+    t = torch.empty(device_bam.POOL_MAX + (4 << 30), dtype=torch.uint8, device="cuda:0")         # a stream buffer too large for the module's pool
+    del t                                                                                         # -> torch's cache, not the driver
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 < free0 - device_bam.POOL_MAX                                                    # invisible as 'free' ...
+    lim1 = device_bam.resident_limit(0)
+    assert lim1 >= lim0 - (256 << 20), (lim0, lim1)                                               # ... and still counted
+    again = torch.empty(device_bam.POOL_MAX + (4 << 30), dtype=torch.uint8, device="cuda:0")      # served from the cache
+    assert torch.cuda.mem_get_info(0)[0] >= free1 - (64 << 20)
+    del again
+    torch.cuda.empty_cache()
+    import inspect
+    assert "device" in inspect.signature(device_bam.plan_shares).parameters
 
 
 @pytest.mark.gpu

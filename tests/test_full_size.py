@@ -73,6 +73,28 @@ def test_wire_form_reproduces_the_full_pack_and_both_routes_agree(setup):
     assert 0.5 * L / 1000 < np.count_nonzero((r["probs"] >= 0.5).sum(1) >= 2) < 2.5 * L / 1000
 
 
+def device_tensors(eng, pack, chunks, params, haploid=False):
+    """the product's int16 site tensors of ALL `chunks` (scan + featuriser through the C ABI, as snpCaller.call_chunks runs them) -> (SnpSites, x int16
+    [N, 5, 41, 5] on the device): the full-size tests compare the tensors of the checked chunks with the oracle's, not only what the CNN makes of them"""
+    eng.use_torch_stream()
+    sites = eng.snp_scan(pack, [(c["start"], c["end"]) for c in chunks], mincov=params["mincov"], min_allele_freq=params["min_allele_freq"],
+                         threshold=params["threshold"], haploid=haploid)
+    eng.set_tensor_format(int16=True)
+    try:
+        eng.snp_featurize(pack, sites, seq=params["seq"], maxcov=params["maxcov"], min_nbr_sites=params["min_nbr_sites"])
+    finally:
+        eng.set_tensor_format(int16=False)
+    return sites, sites.x
+
+
+def assert_chunk_tensors_equal(sites, x, ci, pos, mat):
+    import torch
+    sel = np.nonzero(sites.chunk == ci)[0]
+    assert np.array_equal(sites.pos[sel], pos), ci
+    got = x[torch.from_numpy(sel).to(x.device)].cpu().numpy()
+    assert got.shape == mat.shape and np.array_equal(got, mat.astype(np.int16)), "site tensors of chunk %d differ from the oracle's" % ci
+
+
 def test_tensor_invariants_at_full_size(setup):
     """SURVEY Appendix A on every site of the first 40 chunks (~190 k tensors)"""
     from nanocaller_amd import _lib
@@ -121,11 +143,13 @@ def test_first_chunks_equal_the_oracle(setup):
     rr = oracle.RawReads("chr20", h["L"], h["start"], h["end"], h["off"], h["codes"], h["strand"], h["keep"])
     path, cov = get_SNP_model("ONT-HG002")
     w = Weights(path)
+    sites, x = device_tensors(eng, pack, chunks, params)
     for ci, c in enumerate(sub):
         pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
         sel = r["chunk"] == ci
         assert np.array_equal(r["pos"][sel], pos) and np.array_equal(r["dp"][sel], dp)
         assert np.array_equal(r["fwd_dp"][sel], fwd) and np.array_equal(r["rev_dp"][sel], rev)
+        assert_chunk_tensors_equal(sites, x, ci, pos, mat)
         probs, _ = oracle.snp_forward(w.flat, mat, np.argmax(ref, 1).astype(np.int32), np.full(len(pos), cov / depth), precision="f64")
         assert np.abs(r["probs"][sel] - probs).max() < 1e-4
 
@@ -166,10 +190,12 @@ def test_hifi_60x_haploid_at_full_size():
         h = host_sample_for_oracle(pack, info, 1, sub[-1]["end"] + 50_000)
         rr = oracle.RawReads("chr20", h["L"], h["start"], h["end"], h["off"], h["codes"], h["strand"], h["keep"])
         w = Weights(get_SNP_model("haploid")[0])
+        sites, x = device_tensors(eng, pack, chunks[:4], params, haploid=True)
         for ci, c in enumerate(sub):
             pos, ref, mat, dp, freq, depth, fwd, rev = oracle.get_snp_testing_candidates(rr, params, c, rc=h["ref_codes"])
             sel = b["chunk"] == ci
             assert np.array_equal(b["pos"][sel], pos) and np.array_equal(b["dp"][sel], dp)
+            assert_chunk_tensors_equal(sites, x, ci, pos, mat)
             probs = oracle.snp_hap_forward(w.flat, mat, np.argmax(ref, 1).astype(np.int32), np.full(len(pos), 30.0 / depth), precision="f64")
             assert np.abs(b["probs"][sel] - probs).max() < 1e-4
     finally:
@@ -226,6 +252,7 @@ def test_snp_half_of_configs2_at_chr1_size():
         assert np.all(r["dp"] >= 4) and np.all(r["freq"] >= 0.15)
         path, cov = get_SNP_model("ONT-HG002")
         w = Weights(path)
+        sites, x = device_tensors(eng, pack, chunks, params)                          # 2.4 M tensors, 5 GB as int16
         for lo_c, hi_c in ((0, 2), (496, 498)):
             sub = chunks[lo_c:hi_c]
             h = host_sample_for_oracle(pack, info, max(1, sub[0]["start"] - 50_000), min(L1, sub[-1]["end"] + 50_000))
@@ -235,6 +262,7 @@ def test_snp_half_of_configs2_at_chr1_size():
                 sel = r["chunk"] == ci
                 assert np.array_equal(r["pos"][sel], pos) and np.array_equal(r["dp"][sel], dp), ci
                 assert np.array_equal(r["fwd_dp"][sel], fwd) and np.array_equal(r["rev_dp"][sel], rev), ci
+                assert_chunk_tensors_equal(sites, x, ci, pos, mat)
                 probs, _ = oracle.snp_forward(w.flat, mat, np.argmax(ref, 1).astype(np.int32), np.full(len(pos), cov / depth), precision="f64")
                 assert np.abs(r["probs"][sel] - probs).max() < 1e-4, ci
     finally:
