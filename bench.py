@@ -316,7 +316,7 @@ def extra_snp_config(eng, uploader, local, L, depth, tech, model, ploidy, exact_
         out = {"workload": label, "value": sites / dt, "unit": "sites/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                "sites_per_step": sites // steps, "hbm_resident_sites_s": sites_r / dt_r, "wire_bytes_per_contig": c.wire.nbytes,
                "pileup_entries": c.entries,
-               "roofline": {"bound": "mfma", "kernel": "k4_conv12 (exact fp32 MFMA 16x16x4)" if exact_fp32 else "k5_trunk_p3 (f16x3 split MFMA)",
+               "roofline": {"bound": "mfma", "kernel": "k4_conv12 (exact fp32 MFMA 16x16x4)" if exact_fp32 else "k5_trunk_lin (f16 split MFMA, int16 tensors)",
                             "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
                             "avg_launch_ms": sums[4] / max(1.0, sums[5])}}
         del c
@@ -885,7 +885,7 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
                            % (snp.wire.nbytes / 1e6, job.wire.nbytes / 1e6),
            "vcf_records_per_step_indel": nrec // steps,
            "snp_half": {"sites_per_step": ns // steps, "ms_per_step_alone": dt_s / steps * 1e3, "sites_s_alone": ns_a / dt_s,
-                        "roofline": {"bound": "mfma", "kernel": "k5_trunk_p3", "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
+                        "roofline": {"bound": "mfma", "kernel": "k5_trunk_lin", "achieved": trunk_tf, "peak": peak, "unit": "TFLOP/s", "frac": trunk_tf / peak,
                                      "avg_launch_ms": float(trunk_ms / trunk_n), "launches": trunk_n,
                                      "note": "HIP events on the trunk's launches inside the combined timed region"}},
            "indel_half": {"sites_per_step": ni // steps, "ms_per_step_alone": dt_i / steps * 1e3, "sites_s_alone": ni_a / dt_i,
@@ -1298,7 +1298,10 @@ def main():
         feat_bytes = (5403 - 2050) * n_sites                  # SURVEY.md 8d's 5,403 B/site with the tensor written as int16 (2,050 B) instead of fp32
         tt = trunk_traffic_from_profiles()
         traffic, stale_note = None, None
-        if tt and tt.get("kernel") == ("k4_conv12" if exact_fp32 else "k5_trunk_p3"):
+        eng.set_tensor_format(int16=not exact_fp32)                # (as the timed region ran: which trunk kernel does this context launch?)
+        mfma_per_site, trunk_kernel = eng.trunk_info()
+        eng.set_tensor_format(int16=False)
+        if tt and tt.get("kernel") == trunk_kernel:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from build_tag import TRUNK_SOURCES
             tag_ok, stale_note = traffic_build_check(tt, TRUNK_SOURCES)
@@ -1315,10 +1318,10 @@ def main():
                         "peak": FP32_MFMA_PEAK_TFLOPS, "frac": trunk_tflops / FP32_MFMA_PEAK_TFLOPS, **common}
         else:
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
-            mfma_per_site = eng.trunk_mfma_per_site()
             exec_tflops = mfma_per_site * 16384.0 * sites_timed / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": "k5_trunk_p3: fused conv1+conv2+conv3 of the SNP CNN (three roles on three consecutive sites), fp32-equivalent via 3 "
-                        "f16 MFMA 16x16x32 products (hi*hi + hi*lo + lo*hi), fp32 accumulate",
+            roofline = {"bound": "mfma", "kernel": "%s: fused conv1+conv2+conv3 of the SNP CNN, three roles on three sites; f16 MFMA 16x16x32, f32 accumulate" % trunk_kernel,
+                        "kernel_note": "fp32-equivalent products as hi*hi + hi*lo + lo*hi (3 f16 products); k5_trunk_lin runs conv1 on the integer tensor entries "
+                                       "(exact in f16) with the coverage scale on the accumulators: 2 products there",
                         "peak": peak, "peak_note": "dense f16 MFMA peak 2500 TF / 3 products per fp32-equivalent product",
                         "frac": trunk_tflops / peak, "executed_mfma_per_site": mfma_per_site, "executed_f16_mfma_tflops": exec_tflops,
                         "executed_frac_of_f16_peak": exec_tflops / F16_MFMA_PEAK_TFLOPS,

@@ -1239,19 +1239,20 @@ __global__ __launch_bounds__(512) void k5_trunk_h3(const float *__restrict__ x, 
 #else
 #define NC_MFMA_P(ACC, W, X) NC_MFMA(ACC, W, X)
 #endif
+// the accumulators of a conv2 wave between its MFMA loop and its epilogue (k5_trunk_lin runs the epilogue a step later: the other wave of the SIMD is
+// in its MFMA loop then)
+struct c2_acc { f32x4v a[2][2], a4; };
 template <int CW>
-__device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H, const h8 (&wh)[9][2], const h8 (&wl)[9][2],
-                                             const float *__restrict__ b2s, const h_epi &epi, int lane, unsigned long long *trk = nullptr)
+__device__ __forceinline__ void t_conv2_pair_mma(const _Float16 *A1H, const h8 (&wh)[9][2], const h8 (&wl)[9][2], const float *__restrict__ b2s, int lane, c2_acc &o)
 {
     const int g = lane >> 4, c16 = lane & 15, sh = 16 * g;
-    int abase[3], obase[3];
+    int abase[3];
 #pragma unroll
     for (int tm = 0; tm < 3; tm++) {
         const int t = tm < 2 ? CW + 2 * tm : 4;
         const int y = t < 4 ? t : (c16 & 3), x = t < 4 ? c16 : 16 + (c16 >> 2);
         abase[tm] = (y * T_R1 + 2 * x) * 8;
-        obase[tm] = ((g >> 1) * T_PL2 + y * T_R2 + x) * 8 + (g & 1) * 4;              // channel half 0; half 1: + 2 * T_PL2 * 8
-        asm volatile("" : "+v"(abase[tm]), "+v"(obase[tm]));
+        asm volatile("" : "+v"(abase[tm]));
     }
     f32x4v acc[2][2], acc4;
     {
@@ -1290,25 +1291,138 @@ __device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H,
         NC_MFMA_P(acc4, wl[G][CW], ah[cur][2])
         __builtin_amdgcn_sched_barrier(0);
     }
-    P3_T(1)
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) o.a[tm][tn] = acc[tm][tn];
+    o.a4 = acc4;
+}
+template <int CW>
+__device__ __forceinline__ void t_conv2_pair_epi(_Float16 *A2H, const h_epi &epi, int lane, const c2_acc &o)
+{
+    const int g = lane >> 4, c16 = lane & 15;
+    int obase[3];
+#pragma unroll
+    for (int tm = 0; tm < 3; tm++) {
+        const int t = tm < 2 ? CW + 2 * tm : 4;
+        const int y = t < 4 ? t : (c16 & 3), x = t < 4 ? c16 : 16 + (c16 >> 2);
+        obase[tm] = ((g >> 1) * T_PL2 + y * T_R2 + x) * 8 + (g & 1) * 4;              // channel half 0; half 1: + 2 * T_PL2 * 8
+        asm volatile("" : "+v"(obase[tm]));
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
         for (int tn = 0; tn < 2; tn++) {
-            const int o = obase[tm] + tn * 2 * T_PL2 * 8;
-            split4_store(selu4_scaled(acc[tm][tn], epi), A2H + o, A2H + o + T_A2PLANE);
+            const int oo = obase[tm] + tn * 2 * T_PL2 * 8;
+            split4_store(selu4_scaled(o.a[tm][tn], epi), A2H + oo, A2H + oo + T_A2PLANE);
         }
     {
-        const int o = obase[2] + CW * 2 * T_PL2 * 8;
-        split4_store(selu4_scaled(acc4, epi), A2H + o, A2H + o + T_A2PLANE);
+        const int oo = obase[2] + CW * 2 * T_PL2 * 8;
+        split4_store(selu4_scaled(o.a4, epi), A2H + oo, A2H + oo + T_A2PLANE);
     }
+}
+// conv2 in two phases inside one step (k5_trunk_lin, NC_LIN_PIPE): phase A = the MFMAs of tile CW and of the wave's half of tile 4; phase B = the
+// MFMAs of tile CW + 2 with the EPILOGUE of phase A's three accumulators (SELU, hi / lo split, stores) issued between them -- a wave's own vector
+// instructions ride in the shadow of its own MFMAs (about three issue slots per 16-cycle MFMA), which the two waves of a SIMD do not do for
+// each other (the issue port goes to the older wave: per-wave phase times, profiles/r06_trunk_phases.md); then the epilogue of tile CW + 2.
+// Every operand fragment is still read once and feeds 6 (tile 4: 3) MFMAs.  The interleave is requested from the scheduler per K group:
+// 6 x {1 MFMA, NC_PIPE_NV vector instructions}.
+#ifndef NC_PIPE_NV
+#define NC_PIPE_NV 3
+#endif
+template <int CW>
+__device__ __forceinline__ void t_conv2_two_phase(const _Float16 *A1H, _Float16 *A2H, const h8 (&wh)[9][2], const h8 (&wl)[9][2], const float *__restrict__ b2s,
+                                                  const h_epi &epi, int lane, unsigned long long *trk = nullptr)
+{
+    const int g = lane >> 4, c16 = lane & 15, sh = 16 * g;
+    int abase[3], obase[3];
+#pragma unroll
+    for (int tm = 0; tm < 3; tm++) {
+        const int t = tm < 2 ? CW + 2 * tm : 4;
+        const int y = t < 4 ? t : (c16 & 3), x = t < 4 ? c16 : 16 + (c16 >> 2);
+        abase[tm] = (y * T_R1 + 2 * x) * 8;
+        obase[tm] = ((g >> 1) * T_PL2 + y * T_R2 + x) * 8 + (g & 1) * 4;
+        asm volatile("" : "+v"(abase[tm]), "+v"(obase[tm]));
+    }
+    f32x4v acc[2][2], acc4;
+    {
+        const f32x4v b0 = *reinterpret_cast<const f32x4v *>(b2s + 4 * g), b1 = *reinterpret_cast<const f32x4v *>(b2s + 16 + 4 * g);
+        acc[0][0] = b0; acc[1][0] = b0; acc[0][1] = b1; acc[1][1] = b1;
+        acc4 = CW ? b1 : b0;
+    }
+    constexpr int DP = 1, NB = DP + 1;
+    h8 ah[NB][2], al[NB][2];
+    // ---- phase A: tiles CW (index 0) and 4 (index 2)
+    auto loadA = [&](int G, int slot) {
+        const int off = (int)((c2_off_pack(G) >> sh) & 0xffffu);
+        ah[slot][0] = lds_h8(A1H + abase[0] + off); al[slot][0] = lds_h8(A1H + abase[0] + off + T_A1PLANE);
+        ah[slot][1] = lds_h8(A1H + abase[2] + off); al[slot][1] = lds_h8(A1H + abase[2] + off + T_A1PLANE);
+    };
+    loadA(0, 0);
+#pragma unroll
+    for (int G = 0; G < 9; G++) {
+        const int cur = G % NB;
+        if (G + DP < 9) loadA(G + DP, (G + DP) % NB);
+        __builtin_amdgcn_sched_barrier(0);
+        NC_MFMA_P(acc[0][0], wh[G][0], ah[cur][0]) NC_MFMA_P(acc[0][1], wh[G][1], ah[cur][0]) NC_MFMA_P(acc4, wh[G][CW], ah[cur][1])
+        NC_MFMA_P(acc[0][0], wh[G][0], al[cur][0]) NC_MFMA_P(acc[0][1], wh[G][1], al[cur][0]) NC_MFMA_P(acc4, wh[G][CW], al[cur][1])
+        NC_MFMA_P(acc[0][0], wl[G][0], ah[cur][0]) NC_MFMA_P(acc[0][1], wl[G][1], ah[cur][0]) NC_MFMA_P(acc4, wl[G][CW], ah[cur][1])
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    P3_T(3)
+    // ---- phase B: tile CW + 2 (index 1), with the epilogue of phase A's accumulators in slices: K groups 0..5 take (SELU of an accumulator, then
+    // its split + stores) in turn
+    auto loadB = [&](int G, int slot) {
+        const int off = (int)((c2_off_pack(G) >> sh) & 0xffffu);
+        ah[slot][0] = lds_h8(A1H + abase[1] + off); al[slot][0] = lds_h8(A1H + abase[1] + off + T_A1PLANE);
+    };
+    loadB(0, 0);
+    f32x4v sv[3];
+#pragma unroll
+    for (int G = 0; G < 9; G++) {
+        const int cur = G % NB;
+        if (G + DP < 9) loadB(G + DP, (G + DP) % NB);
+        __builtin_amdgcn_sched_barrier(0);
+        NC_MFMA_P(acc[1][0], wh[G][0], ah[cur][0]) NC_MFMA_P(acc[1][1], wh[G][1], ah[cur][0])
+        NC_MFMA_P(acc[1][0], wh[G][0], al[cur][0]) NC_MFMA_P(acc[1][1], wh[G][1], al[cur][0])
+        NC_MFMA_P(acc[1][0], wl[G][0], ah[cur][0]) NC_MFMA_P(acc[1][1], wl[G][1], ah[cur][0])
+        if (G < 6) {
+            const int a = G >> 1;                                     // accumulator 0, 1: tile CW's channel halves; 2: tile 4
+            if ((G & 1) == 0) sv[a] = selu4_scaled(a == 0 ? acc[0][0] : a == 1 ? acc[0][1] : acc4, epi);
+            else {
+                const int oo = a < 2 ? obase[0] + a * 2 * T_PL2 * 8 : obase[2] + CW * 2 * T_PL2 * 8;
+                split4_store(sv[a], A2H + oo, A2H + oo + T_A2PLANE);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, NC_PIPE_NV, 0);   // NC_PIPE_NV vector instructions
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    P3_T(1)
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int oo = obase[1] + tn * 2 * T_PL2 * 8;
+        split4_store(selu4_scaled(acc[1][tn], epi), A2H + oo, A2H + oo + T_A2PLANE);
+    }
+}
+template <int CW>
+__device__ __forceinline__ void t_conv2_pair(const _Float16 *A1H, _Float16 *A2H, const h8 (&wh)[9][2], const h8 (&wl)[9][2],
+                                             const float *__restrict__ b2s, const h_epi &epi, int lane, unsigned long long *trk = nullptr)
+{
+    c2_acc o;
+    t_conv2_pair_mma<CW>(A1H, wh, wl, b2s, lane, o);
+    P3_T(1)
+    t_conv2_pair_epi<CW>(A2H, epi, lane, o);
 }
 
 // conv3, wave CW of two: output channels 32 CW .. 32 CW + 31 of both position tiles
+struct c3_acc { f32x4v a[2][2]; };
 template <int CW>
-__device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h)[6][2], const h8 (&w3l)[6][2], const float *__restrict__ b3s,
-                                             const h_epi &epi, float *__restrict__ out_site, const int (&c3slot)[2], const int (&c3out)[2], int lane,
-                                             unsigned long long *trk = nullptr)
+__device__ __forceinline__ void t_conv3_pair_mma(const _Float16 *A2H, const h8 (&w3h)[6][2], const h8 (&w3l)[6][2], const float *__restrict__ b3s, const int (&c3slot)[2], int lane,
+                                                 c3_acc &o)
 {
     const int g = lane >> 4;
     int abase[2];
@@ -1351,14 +1465,32 @@ __device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h
         for (int tm = 0; tm < 2; tm++) { NC_MFMA(acc[tm][0], w3l[G][0], ah[cur][tm]) NC_MFMA(acc[tm][1], w3l[G][1], ah[cur][tm]) }
         __builtin_amdgcn_sched_barrier(0);
     }
-    P3_T(1)
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) o.a[tm][tn] = acc[tm][tn];
+}
+template <int CW>
+__device__ __forceinline__ void t_conv3_pair_epi(const h_epi &epi, float *__restrict__ out_site, const int (&c3out)[2], int lane, const c3_acc &o)
+{
+    const int g = lane >> 4;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
         if (c3out[tm] >= 0) {
 #pragma unroll
             for (int tn = 0; tn < 2; tn++)
-                *reinterpret_cast<f32x4v *>(out_site + c3out[tm] * 64 + (2 * CW + tn) * 16 + 4 * g) = selu4_scaled(acc[tm][tn], epi);
+                *reinterpret_cast<f32x4v *>(out_site + c3out[tm] * 64 + (2 * CW + tn) * 16 + 4 * g) = selu4_scaled(o.a[tm][tn], epi);
         }
+}
+template <int CW>
+__device__ __forceinline__ void t_conv3_pair(const _Float16 *A2H, const h8 (&w3h)[6][2], const h8 (&w3l)[6][2], const float *__restrict__ b3s,
+                                             const h_epi &epi, float *__restrict__ out_site, const int (&c3slot)[2], const int (&c3out)[2], int lane,
+                                             unsigned long long *trk = nullptr)
+{
+    c3_acc o;
+    t_conv3_pair_mma<CW>(A2H, w3h, w3l, b3s, c3slot, lane, o);
+    P3_T(1)
+    t_conv3_pair_epi<CW>(epi, out_site, c3out, lane, o);
 }
 
 // Three roles, one barrier per site (the default trunk since round 5).  Step s:
@@ -1568,6 +1700,9 @@ __global__ __launch_bounds__(512) void k5_trunk_p3(const float *__restrict__ x, 
 // u rho, same K layout, same weight fragments).  Kernel rows that fall on the `same` padding of the 5-row image for every position of a tile are
 // not executed at all.  Per site: conv1 199 MFMAs (312 before) and 83 operand reads (182): 613 MFMAs (726), 239 ds_read_b128 (338).
 // LDS: X buffer = P1 [4 slots][176 records] + P0 hi / lo [4][48] each (slot-planar: the 16 positions of a tile read 16 consecutive 16-byte slots).
+#ifndef NC_LIN_PIPE
+#define NC_LIN_PIPE 0                 // bit 0: conv2 in two phases with its first epilogue inside the second MFMA loop; bit 1: conv3; bit 2: conv1
+#endif
 constexpr int L_NR1 = 176, L_NR0 = 48;                                       // records per slot plane (multiples of 16): 4 x 41 = 164 + zero / dump records; 41 + ...
 constexpr int L_P0H = 4 * L_NR1 * 8, L_P0L = L_P0H + 4 * L_NR0 * 8, L_XBUF = L_P0L + 4 * L_NR0 * 8;   // halves
 constexpr int L_Z1 = 164, L_Z0 = 41, L_DUMP1 = 170, L_DUMP0 = 44;           // all-zero records (read by lanes whose kernel row is off the image); write-only dump records
@@ -1600,18 +1735,20 @@ constexpr int c1l_mfma_tile(int t)
 constexpr int c1l_mfma_site() { int n = 0; for (int t = 0; t < 13; t++) n += c1l_mfma_tile(t); return n; }
 constexpr int L_MFMA_PER_SITE = c1l_mfma_site() + 10 * 27 + 8 * 18;
 
-template <int ROLE>
-__device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, const h8 (&wl)[T_NW1L], const float *__restrict__ b1s, const h_epi &epi, float rho, int lane,
-                                            unsigned long long *trk = nullptr)
+// the MFMAs of tiles [T0, T0 + NTT) of a conv1 role; payload(step) is called once per step (7 steps) inside the step's scheduling region: the two-phase
+// form passes the epilogue of the role's EARLIER tiles in slices, issued between this loop's MFMAs (NC_LIN_PIPE bit 2)
+template <int ROLE, int T0, int NTT, typename P>
+__device__ __forceinline__ void c1l_mma(const _Float16 *XB, const h8 (&wl)[T_NW1L], const float *__restrict__ b1s, float rho, int lane, f32x4v (&acc1)[NTT], f32x4v (&acc2)[NTT],
+                                        f32x4v (&acc3)[NTT], int (&obase)[NTT], P payload)
 {
     constexpr c1l_role R = C1L_ROLES[ROLE];
-    constexpr int NT = R.nt;
-    static_assert(c1l_n0(ROLE, 0) <= 2 && c1l_n0(ROLE, 1) <= 2 && c1l_n0(ROLE, 2) <= 2, "t_conv1_lin: at most two row-0 operand pairs per kernel row and wave");
+    constexpr int NT = NTT;
+    auto tile_of = [](int tm) constexpr { return C1L_ROLES[ROLE].tile[T0 + tm]; };
     const int g = lane >> 4, c16 = lane & 15;
-    int pr8[NT], w8[NT], hrow[NT], obase[NT];
+    int pr8[NT], w8[NT], hrow[NT];
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        const int t = R.tile[tm];
+        const int t = tile_of(tm);
         const int p = 16 * t + c16, pr = p < 205 ? p : 204;
         const int h = c1l_hlo(t) == c1l_hhi(t) ? c1l_hlo(t) : (pr >= 41 * c1l_hhi(t) ? c1l_hhi(t) : c1l_hlo(t));
         const int w = pr - 41 * h;
@@ -1622,15 +1759,16 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
         obase[tm] = ((g >> 1) * T_PL1 + (p < 205 ? h * T_R1 + w : 4 * T_R1 + 41 + (p - 205))) * 8 + (g & 1) * 4;
         asm volatile("" : "+v"(pr8[tm]), "+v"(w8[tm]), "+v"(obase[tm]), "+v"(hrow[tm]));     // (keeps the address arithmetic inside the site loop: no spills)
     }
+    (void)R;
     const int g1 = g * L_NR1 * 8, g0 = L_P0H + g * L_NR0 * 8;          // this lane group's slot plane
     auto a1 = [&](int tm, int dy) -> int {                             // operand of the 5-tap kernel row dy, rows 1..4
-        const int t = R.tile[tm];
+        const int t = tile_of(tm);
         int a = g1 + pr8[tm] + 41 * 8 * dy;
         if (!c1l_all1(t, dy)) { const int r = hrow[tm] + dy - 2; a = (r >= 1 && r <= 4) ? a : g1 + L_Z1 * 8; }
         return a;
     };
     auto a0 = [&](int tm, int dy) -> int {                             // the same of image row 0 (hi plane; the lo plane is L_P0L - L_P0H further)
-        const int t = R.tile[tm];
+        const int t = tile_of(tm);
         int a = g0 + w8[tm];
         if (!c1l_all0(t, dy)) a = (hrow[tm] + dy - 2 == 0) ? a : g0 + L_Z0 * 8;
         return a;
@@ -1644,7 +1782,6 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
         return g == 0 ? p1 : p0;
     };
     auto aC = [&](int tm) -> int { return L_P0L + ((g < 3 && hrow[tm] == 2 - g) ? w8[tm] : L_Z0 * 8); };
-    f32x4v acc1[NT], acc2[NT], acc3[NT];
     {
         const f32x4v x1 = *reinterpret_cast<const f32x4v *>(b1s + 4 * g) * rho, x2 = *reinterpret_cast<const f32x4v *>(b1s + 16 + 4 * g) * rho,
                      x3 = *reinterpret_cast<const f32x4v *>(b1s + 32 + 4 * g) * rho;
@@ -1652,14 +1789,18 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
         for (int tm = 0; tm < NT; tm++) { acc1[tm] = x1; acc2[tm] = x2; acc3[tm] = x3; }
     }
     // steps 0..4: the 5-tap kernel rows dy (5x5 kernel; dy == 2 also feeds the 1x5 kernel); step 5: 5x1 group A; step 6: 5x1 groups B and C.
-    // The operands of step s + 1 are requested before the MFMAs of step s (register double buffer).
-    h8 x1[2][NT], xh[2][2], xl[2][2], xc[NT];
+    // The operands of step s + DP are requested before the MFMAs of step s (register buffers).
+#ifndef NC_LIN_DEPTH
+#define NC_LIN_DEPTH 1
+#endif
+    constexpr int DP = NC_LIN_DEPTH, NB = DP + 1;                      // steps requested ahead of the one being multiplied / register buffers
+    h8 x1[NB][NT], xh[NB][2], xl[NB][2], xc[NT];
     auto load = [&](int s, int slot) {
         if (s < 5) {
             int n0 = 0;
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) {
-                const int t = R.tile[tm];
+                const int t = tile_of(tm);
                 if (c1l_need1(t, s)) x1[slot][tm] = lds_h8(XB + a1(tm, s));
                 if (c1l_need0(t, s)) { const int a = a0(tm, s); xh[slot][n0] = lds_h8(XB + a); xl[slot][n0] = lds_h8(XB + a + (L_P0L - L_P0H)); n0++; }
             }
@@ -1669,38 +1810,39 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
         } else {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++)
-                if (c1l_low(R.tile[tm])) { x1[slot][tm] = lds_h8(XB + aB(tm)); xc[tm] = lds_h8(XB + aC(tm)); }
+                if (c1l_low(tile_of(tm))) { x1[slot][tm] = lds_h8(XB + aB(tm)); xc[tm] = lds_h8(XB + aC(tm)); }
         }
     };
-    load(0, 0);
+#pragma unroll
+    for (int s = 0; s < DP; s++) load(s, s % NB);
 #pragma unroll
     for (int s = 0; s < 7; s++) {
-        const int cur = s & 1;
-        if (s + 1 < 7) load(s + 1, cur ^ 1);
+        const int cur = s % NB;
+        if (s + DP < 7) load(s + DP, (s + DP) % NB);
         __builtin_amdgcn_sched_barrier(0);
         if (s < 5) {
             // independent accumulators interleaved; the three products of a row-0 operand pair are spread over the step
             int n0 = 0;
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], x1[cur][tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need0(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xh[cur][n0]) } n0++; }
+            for (int tm = 0; tm < NT; tm++) if (c1l_need0(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xh[cur][n0]) } n0++; }
             if (s == 2) {
 #pragma unroll
-                for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc1[tm], wl[LW_1H], x1[cur][tm]) }
+                for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc1[tm], wl[LW_1H], x1[cur][tm]) }
             }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], x1[cur][tm]) }
             n0 = 0;
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need0(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xl[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xl[cur][n0]) } n0++; }
+            for (int tm = 0; tm < NT; tm++) if (c1l_need0(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xl[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xl[cur][n0]) } n0++; }
             if (s == 2) {
 #pragma unroll
-                for (int tm = 0; tm < NT; tm++) if (c1l_need1(R.tile[tm], s)) { NC_MFMA(acc1[tm], wl[LW_1L], x1[cur][tm]) }
+                for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc1[tm], wl[LW_1L], x1[cur][tm]) }
             }
             n0 = 0;
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need0(R.tile[tm], s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1L], xh[cur][n0]) } n0++; }
+            for (int tm = 0; tm < NT; tm++) if (c1l_need0(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1L], xh[cur][n0]) } n0++; }
         } else if (s == 5) {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], wl[LW_2HA], x1[cur][tm]) }
@@ -1708,22 +1850,66 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
             for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], wl[LW_2LA], x1[cur][tm]) }
         } else {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_low(R.tile[tm])) { NC_MFMA(acc2[tm], wl[LW_2HB], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2HB], x1[cur][tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_low(R.tile[tm])) { NC_MFMA(acc2[tm], wl[LW_2HC], xc[tm]) }
+            for (int tm = 0; tm < NT; tm++) if (c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2HC], xc[tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_low(R.tile[tm])) { NC_MFMA(acc2[tm], wl[LW_2LB], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2LB], x1[cur][tm]) }
         }
+        payload(s);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+// the epilogue of one accumulator of a conv1 tile: which = 0 the 1x5 kernel's 16 channels, 1 the 5x1 kernel's, 2 the 5x5 kernel's
+__device__ __forceinline__ void c1l_epi_one(const f32x4v &acc, int which, int o, const h_epi &epi, _Float16 *A1H)
+{
+    split4_store(selu4_scaled(acc, epi), A1H + o + which * 2 * T_PL1 * 8, A1H + o + which * 2 * T_PL1 * 8 + T_A1PLANE);
+}
+
+template <int ROLE>
+__device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, const h8 (&wl)[T_NW1L], const float *__restrict__ b1s, const h_epi &epi, float rho, int lane,
+                                            unsigned long long *trk = nullptr)
+{
+    constexpr int NT = C1L_ROLES[ROLE].nt;
+    static_assert(c1l_n0(ROLE, 0) <= 2 && c1l_n0(ROLE, 1) <= 2 && c1l_n0(ROLE, 2) <= 2, "t_conv1_lin: at most two row-0 operand pairs per kernel row and wave");
+#if NC_LIN_PIPE & 4
+    // two phases: the MFMAs of the first two tiles; then the MFMAs of the others with the first two tiles' epilogue between them (one accumulator per step:
+    // a wave's own vector instructions ride in the shadow of its own MFMAs); then the epilogue of the others
+    constexpr int NA = 2, NB2 = NT - 2;
+    f32x4v p1[NA], p2[NA], p3[NA], q1[NB2], q2[NB2], q3[NB2];
+    int oa[NA], ob[NB2];
+    c1l_mma<ROLE, 0, NA>(XB, wl, b1s, rho, lane, p1, p2, p3, oa, [](int) {});
+    P3_T(3)
+    c1l_mma<ROLE, 2, NB2>(XB, wl, b1s, rho, lane, q1, q2, q3, ob, [&](int s) {
+        if (s < 6) {
+            const int tm = s / 3, which = s % 3;
+            c1l_epi_one(which == 0 ? p1[tm] : which == 1 ? p2[tm] : p3[tm], which, oa[tm], epi, A1H);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, NC_PIPE_NV, 0);   // NC_PIPE_NV vector instructions
+            }
+        }
+    });
+    if (trk) trk[2] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int tm = 0; tm < NB2; tm++) {
+        c1l_epi_one(q1[tm], 0, ob[tm], epi, A1H);
+        c1l_epi_one(q2[tm], 1, ob[tm], epi, A1H);
+        c1l_epi_one(q3[tm], 2, ob[tm], epi, A1H);
+    }
+#else
+    f32x4v acc1[NT], acc2[NT], acc3[NT];
+    int obase[NT];
+    c1l_mma<ROLE, 0, NT>(XB, wl, b1s, rho, lane, acc1, acc2, acc3, obase, [](int) {});
     if (trk) trk[2] = __builtin_readcyclecounter();
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        const int o = obase[tm];
-        split4_store(selu4_scaled(acc1[tm], epi), A1H + o, A1H + o + T_A1PLANE);
-        split4_store(selu4_scaled(acc2[tm], epi), A1H + o + 2 * T_PL1 * 8, A1H + o + 2 * T_PL1 * 8 + T_A1PLANE);
-        split4_store(selu4_scaled(acc3[tm], epi), A1H + o + 4 * T_PL1 * 8, A1H + o + 4 * T_PL1 * 8 + T_A1PLANE);
+        c1l_epi_one(acc1[tm], 0, obase[tm], epi, A1H);
+        c1l_epi_one(acc2[tm], 1, obase[tm], epi, A1H);
+        c1l_epi_one(acc3[tm], 2, obase[tm], epi, A1H);
     }
+#endif
 }
 
 // fp16 hi / lo of a float as one packed dword (lo in the upper half)
@@ -1756,6 +1942,15 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
     // coverage scale of a site (snpCaller.py:93-96): s as float (numpy's float32 product in both modes up to one rounding of the operand, which this
     // kernel does not perform at all), 1 without a scale array
     auto site_scale = [&](int64_t k) -> float { return scale ? (float)scale[site0 + blockIdx.x + k * gridDim.x] : 1.0f; };
+    // NC_LIN_SKEW=1 (measured slower, profiles/r06_trunk_phases.md; off): the conv2 and conv3 waves run the EPILOGUE of their previous step's accumulators first and their MFMA loop second, the
+    // conv1 waves their MFMA loop first and their epilogue second: on every SIMD one wave is in its vector phase while the other is in its matrix
+    // phase (the two add up otherwise: per-wave phase times, profiles/r06_trunk_phases.md).  conv2's / conv3's results land a step later: one more step.
+#ifndef NC_LIN_SKEW
+#define NC_LIN_SKEW 0
+#endif
+
+    constexpr int SKEW = NC_LIN_SKEW;
+    const int64_t n_steps = n_k + 2 + SKEW;
     if (wv >= 4) {
         // ------------------------------------------------------------------ conv1 of site s
         h8 wl[T_NW1L];
@@ -1763,7 +1958,7 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
         for (int q = 0; q < T_NW1L; q++) wl[q] = as_h8(wlf[q * 64 + lane]);
         float s_next = site_scale(0);
         __syncthreads();                                                           // P0
-        for (int64_t s = 0; s < n_k + 2; s++) {
+        for (int64_t s = 0; s < n_steps; s++) {
 #ifdef NC_TRACE_P3
             unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
 #else
@@ -1792,18 +1987,40 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
         for (int q = 0; q < 9; q++)
 #pragma unroll
             for (int tn = 0; tn < 2; tn++) { c2h[q][tn] = as_h8(w2h[(q * 2 + tn) * 64 + lane]); c2l[q][tn] = as_h8(w2l[(q * 2 + tn) * 64 + lane]); }
+        c2_acc pend2;
         __syncthreads();                                                           // P0
-        for (int64_t s = 0; s < n_k + 2; s++) {
+        for (int64_t s = 0; s < n_steps; s++) {
 #ifdef NC_TRACE_P3
             unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
 #else
             unsigned long long *trk = nullptr;
 #endif
             P3_T(0)
-            if (s >= 1 && s - 1 < n_k) {
+            if constexpr (SKEW) {
+                const bool do_epi = s >= 2 && s - 2 < n_k, do_mma = s >= 1 && s - 1 < n_k;
+                {
+                if (do_epi) {                                                      // epilogue of site s - 2 (MFMA loop: a step ago)
+                    const int buf = (int)(s & 1);
+                    if (wv == 0) t_conv2_pair_epi<0>(A2[buf], epi, lane, pend2);
+                    else t_conv2_pair_epi<1>(A2[buf], epi, lane, pend2);
+                }
+                P3_T(3)
+                if (do_mma) {
+                    const int buf = (int)((s - 1) & 1);
+                    if (wv == 0) t_conv2_pair_mma<0>(A1[buf], c2h, c2l, b2s, lane, pend2);
+                    else t_conv2_pair_mma<1>(A1[buf], c2h, c2l, b2s, lane, pend2);
+                }
+                P3_T(1)
+                }
+            } else if (s >= 1 && s - 1 < n_k) {
                 const int buf = (int)((s - 1) & 1);
+#if NC_LIN_PIPE & 1
+                if (wv == 0) t_conv2_two_phase<0>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+                else t_conv2_two_phase<1>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+#else
                 if (wv == 0) t_conv2_pair<0>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
                 else t_conv2_pair<1>(A1[buf], A2[buf], c2h, c2l, b2s, epi, lane, trk);
+#endif
             }
             P3_T(5)
             NC_SITE_SYNC();
@@ -1851,8 +2068,12 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
                 const int m4 = max(max(abs(v0), abs(v1)), max(abs(v2), abs(v3)));
                 // range guard: the scaled entries as the epilogue sees them (|x| s), the unscaled ones as they are; integers beyond fp16's exact range
                 // (2048) cannot take this kernel at all.  Flagged sites are computed again by the exact fp32 trunk (nc_cnn_range_watch).
-                const float amax = ph > 0 ? fmaxf((float)m4 * sf, fabsf((float)v4)) : fmaxf((float)m4, fabsf((float)v4));
-                if (range_sites && (!(amax <= x_limit) || (ph > 0 && m4 > 2048))) range_sites[site0 + pre_site] = 1;
+                // An unscaled entry travels as u * rho in fp16 hi + lo: it must stay inside fp16's range, and rho's lo half must not sink into the
+                // subnormals (s <= 64; a scale that is not a positive finite number takes the exact trunk as well).
+                const float un = ph > 0 ? fabsf((float)v4) : fmaxf((float)m4, fabsf((float)v4));
+                const float amax = ph > 0 ? fmaxf((float)m4 * sf, un) : un;
+                if (range_sites && (!(amax <= x_limit) || (ph > 0 && m4 > 2048) || !(un * rho <= 60000.0f) || !(sf > 0.0f && sf <= 64.0f)))
+                    range_sites[site0 + pre_site] = 1;
                 // the pixel's 6 K values as three dwords per plane
                 uint32_t d[2][3];
                 const uint32_t u4 = split_pack((float)v4 * rho);
@@ -1885,12 +2106,13 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
                 }
             }
         };
-        int64_t site = blockIdx.x;                                                 // the site conv3 works on next
+        int64_t site = blockIdx.x;                                                 // the site conv3's epilogue stores next
+        c3_acc pend3;
         prefetch(0);
         commit(0);
         if (n_k > 1) prefetch(1);
         __syncthreads();                                                           // P0
-        for (int64_t s = 0; s < n_k + 2; s++) {
+        for (int64_t s = 0; s < n_steps; s++) {
 #ifdef NC_TRACE_P3
             unsigned long long *trk = (blockIdx.x == 3 && lane == 0 && s >= 8 && s < 16) ? &nc_trace_buf[wv][s - 8][0] : nullptr;
 #else
@@ -1901,7 +2123,21 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
             if (s + 1 < n_k) commit((int)((s + 1) & 1));
             if (s + 2 < n_k) prefetch(s + 2);
             P3_T(2)
-            if (s >= 2) {
+            if constexpr (SKEW) {
+                if (s >= 4) {                                                      // epilogue of site s - 4 (MFMA loop: a step ago)
+                    float *out_site = a3 + site * (27 * 64);
+                    if (cw == 0) t_conv3_pair_epi<0>(epi, out_site, c3out, lane, pend3);
+                    else t_conv3_pair_epi<1>(epi, out_site, c3out, lane, pend3);
+                    site += gridDim.x;
+                }
+                P3_T(3)
+                if (s >= 3) {                                                      // conv3 of site s - 3: conv2's epilogue wrote A2[(s - 3) & 1] during step s - 1
+                    const int buf = (int)((s - 3) & 1);
+                    if (cw == 0) t_conv3_pair_mma<0>(A2[buf], c3h, c3l, b3s, c3slot, lane, pend3);
+                    else t_conv3_pair_mma<1>(A2[buf], c3h, c3l, b3s, c3slot, lane, pend3);
+                }
+                P3_T(1)
+            } else if (s >= 2) {
                 const int buf = (int)(s & 1);
                 float *out_site = a3 + site * (27 * 64);
                 if (cw == 0) t_conv3_pair<0>(A2[buf], c3h, c3l, b3s, epi, out_site, c3slot, c3out, lane, trk);
@@ -1911,6 +2147,11 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
             P3_T(5)
             NC_SITE_SYNC();
             P3_T(6)
+        }
+        if constexpr (SKEW) {                                                      // the last site's epilogue
+            float *out_site = a3 + site * (27 * 64);
+            if (cw == 0) t_conv3_pair_epi<0>(epi, out_site, c3out, lane, pend3);
+            else t_conv3_pair_epi<1>(epi, out_site, c3out, lane, pend3);
         }
     }
 }

@@ -166,20 +166,31 @@ def eng():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exact", [False, True], ids=["fp16x3", "fp32"])
-def test_hip_snp_cnn_equals_reference_call(eng, exact):
+@pytest.mark.parametrize("exact,i16", [(False, False), (False, True), (True, False)], ids=["fp16x3", "fp16x3_int16_linear_conv1", "fp32"])
+def test_hip_snp_cnn_equals_reference_call(eng, exact, i16):
+    """every shipped SNP model against the reference class's own call(): the split-precision trunk on float32 tensors (k5_trunk_p3), on the product's
+    int16 tensors (k5_trunk_lin: conv1 by linearity), and the exact fp32 trunk"""
     import torch
     worst = 0.0
+
+    def dev_x(x):
+        x = np.ascontiguousarray(x)
+        if i16:
+            assert np.array_equal(x, np.rint(x)) and np.abs(x).max() <= 2048
+            return torch.from_numpy(x.astype(np.int16)).cuda()
+        return torch.from_numpy(x).cuda()
     try:
         eng.set_cnn_precision(exact_fp32=exact)
+        eng.set_tensor_format(int16=i16)
+        if i16:
+            assert eng.trunk_info() == (613, "k5_trunk_lin")
         for k in range(int(ZS["n"])):
             model = str(ZS["c%d_model" % k])
             case, n, mode, x, ref_code, depth, dp, out = _snp_case("c", k)
             path, cov = get_SNP_model(model)
             eng.load_weights(_lib.MODEL_SNP, Weights(path))
             sc = torch.from_numpy(_scale(cov, depth, dp, mode, n)).cuda()
-            probs, gt = eng.snp_forward(_lib.MODEL_SNP, torch.from_numpy(np.ascontiguousarray(x)).cuda(), torch.from_numpy(ref_code).cuda(),
-                                        sc, scale_mode=mode)
+            probs, gt = eng.snp_forward(_lib.MODEL_SNP, dev_x(x), torch.from_numpy(ref_code).cuda(), sc, scale_mode=mode)
             p, g = probs.cpu().numpy(), gt.cpu().numpy()
             err = max(np.abs(p - out[:, :4, 1]).max(), np.abs(g - out[:, 4, :]).max())
             worst = max(worst, err)
@@ -190,13 +201,13 @@ def test_hip_snp_cnn_equals_reference_call(eng, exact):
             case, n, mode, x, ref_code, depth, dp, out = _snp_case("h", k)
             eng.load_weights(_lib.MODEL_SNP_HAP, Weights(get_SNP_model("haploid")[0]))
             sc = torch.from_numpy(_scale(30.0, depth, dp, mode, n)).cuda()
-            probs, _ = eng.snp_forward(_lib.MODEL_SNP_HAP, torch.from_numpy(np.ascontiguousarray(x)).cuda(), torch.from_numpy(ref_code).cuda(),
-                                       sc, scale_mode=mode)
+            probs, _ = eng.snp_forward(_lib.MODEL_SNP_HAP, dev_x(x), torch.from_numpy(ref_code).cuda(), sc, scale_mode=mode)
             err = np.abs(probs.cpu().numpy() - out).max()
             worst = max(worst, err)
             assert err < TOL_GPU, (case, err)
     finally:
         eng.set_cnn_precision(exact_fp32=False)
+        eng.set_tensor_format(int16=False)
     assert worst < 2e-5, "measured ~3e-6: far inside the 1e-4 contract"
 
 

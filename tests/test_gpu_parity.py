@@ -257,11 +257,98 @@ def test_three_stage_trunk_equals_two_stage_trunk(eng, n, monkeypatch):
                 xd = xd.to(torch.int16)
             eng.set_tensor_format(int16=i16)
             got = {}
+            monkeypatch.setenv("NC_TRUNK_LIN", "0")                      # (int16 tensors would otherwise take k5_trunk_lin: its own test below)
             for p3 in ("0", "1"):
                 monkeypatch.setenv("NC_TRUNK_P3", p3)
                 got[p3] = eng.snp_forward(_lib.MODEL_SNP, xd, rd, sd)[0].cpu().numpy()
             assert np.array_equal(got["0"], got["1"]), (n, i16)
             assert np.abs(got["1"] - ep).max() < 2e-5
+    finally:
+        eng.set_tensor_format(int16=False)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 257, 513, 1300])
+def test_linear_conv1_trunk_equals_the_oracle_and_the_pixel_form(eng, n, monkeypatch):
+    """k5_trunk_lin (int16 tensors, the product path: conv1 on the integer entries with the coverage scale applied to the accumulators, row 0 and
+    channel 4 as u / s in fp16 hi + lo) against the float64 oracle and against k5_trunk_p3 (which multiplies the scale into the operand as the
+    reference does, snpCaller.py:93-96): real site tensors and arbitrary int16 ones (negative entries, row 0 / channel 4 not 0 / 1, zero columns),
+    scales from 0.05 to 20, both scale modes, no scale array at all; site counts around the pipeline's fill / drain and the grid's edges"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    from oracle import oracle
+    path, cov = get_SNP_model("ONT-HG002")
+    w = Weights(path)
+    eng.load_weights(_lib.MODEL_SNP, w)
+    eng.set_cnn_precision(exact_fp32=False)
+    x, ref_code, depth = _golden_inputs("ont_dip")
+    reps = -(-n // len(x))
+    x = np.concatenate([x] * reps)[:n].copy()
+    ref_code = np.concatenate([ref_code] * reps)[:n]
+    rng = np.random.Generator(np.random.PCG64(n))
+    for k in range(1, n, 2):                                               # every second site: arbitrary small integers everywhere
+        x[k] = rng.integers(-25, 26, size=x[k].shape)
+        x[k][:, rng.integers(0, 41, size=6), :] = 0
+    scale = np.exp(rng.uniform(np.log(0.05), np.log(20.0), n))
+    scale[0] = 1.0
+    x_lim = eng.x_limit(_lib.MODEL_SNP)
+    for k in range(n):                                                     # keep every site inside the model's proven fp16 range (the guard has its own test)
+        m = np.abs(x[k][1:, :, :4]).max() * scale[k]
+        if m > 0.9 * x_lim:
+            scale[k] *= 0.9 * x_lim / m
+    rd = torch.from_numpy(ref_code).cuda()
+    xd16 = torch.from_numpy(x.astype(np.int16)).cuda()
+    xd32 = torch.from_numpy(x.astype(np.float32)).cuda()
+    try:
+        for mode in (0, 1):
+            for with_scale in (True, False):
+                sc = scale if with_scale else np.ones(n)
+                sd = torch.from_numpy(sc).cuda()
+                ep, eg = oracle.snp_forward(w.flat, x.astype(np.float32), ref_code, sc, scale_mode=mode, precision="f64")
+                eng.set_tensor_format(int16=True)
+                assert eng.trunk_info()[1] == "k5_trunk_lin"
+                flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+                lin_p, lin_g = eng.snp_forward(_lib.MODEL_SNP, xd16, rd, sd if with_scale else None, scale_mode=mode, range_flags=flags)[:2]
+                lin_p, lin_g = lin_p.cpu().numpy(), lin_g.cpu().numpy()
+                assert int(flags.sum().item()) == 0
+                eng.set_tensor_format(int16=False)
+                assert eng.trunk_info()[1] == "k5_trunk_p3"
+                pix_p = eng.snp_forward(_lib.MODEL_SNP, xd32, rd, sd if with_scale else None, scale_mode=mode)[0].cpu().numpy()
+                assert np.abs(lin_p - ep).max() < 2e-5 and np.abs(lin_g - eg).max() < 2e-5, (n, mode, with_scale, np.abs(lin_p - ep).max())
+                assert np.abs(lin_p - pix_p).max() < 2e-5, (n, mode, with_scale)
+    finally:
+        eng.set_tensor_format(int16=False)
+
+
+def test_linear_conv1_trunk_flags_what_it_cannot_take(eng):
+    """the range guard of k5_trunk_lin: a scaled entry beyond the model's proven fp16 range, an unscaled one beyond it, and an integer beyond fp16's
+    exact range (2048) mark their site (nc_cnn_range_watch) -- snpCaller.call_chunks re-runs exactly those on the exact fp32 trunk -- and nothing else"""
+    import torch
+    from nanocaller_amd import _lib
+    from nanocaller_amd.weights import Weights, get_SNP_model
+    w = Weights(get_SNP_model("ONT-HG002")[0])
+    eng.load_weights(_lib.MODEL_SNP, w)
+    eng.set_cnn_precision(exact_fp32=False)
+    x_lim = eng.x_limit(_lib.MODEL_SNP)
+    n = 600
+    x = np.zeros((n, 5, 41, 5), np.int16)
+    x[:, 0, :, 0] = 1
+    x[:, 1, :, 4] = 1
+    x[:, 1:, :, :4] = 3
+    scale = np.full(n, 1.5)
+    x[7, 2, 5, 1] = int(x_lim / 1.5) + 2                   # scaled entry over the limit
+    x[300, 0, 40, 3] = int(x_lim) + 2                      # unscaled (row 0) entry over the limit
+    x[301, 4, 0, 4] = -(int(x_lim) + 2)                    # unscaled (channel 4) entry over the limit
+    x[599, 4, 40, 2] = 2049                                # not exact in fp16
+    scale[599] = 1e-3
+    x[100, 3, 3, 3] = int(x_lim / 1.5) - 1                 # just inside
+    x[101, 4, 40, 0] = 2048
+    scale[101] = 1e-3
+    try:
+        eng.set_tensor_format(int16=True)
+        flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        eng.snp_forward(_lib.MODEL_SNP, torch.from_numpy(x).cuda(), torch.zeros(n, dtype=torch.int32, device="cuda"), torch.from_numpy(scale).cuda(), range_flags=flags)
+        assert sorted(torch.nonzero(flags).flatten().tolist()) == [7, 300, 301, 599]
     finally:
         eng.set_tensor_format(int16=False)
 
@@ -379,9 +466,10 @@ def test_end_to_end_vcf_matches_oracle_pipeline(eng, tmp_path):
     assert ngt > 10
 
 
-def test_int16_tensors_equal_float32_tensors(eng):
-    """nc_set_tensor_format(ctx, 1): the featuriser's int16 tensors are the float32 tensors value for value, and the
-    split-precision trunk returns bit-identical probabilities from either; the exact-fp32 trunk refuses int16"""
+def test_int16_tensors_equal_float32_tensors(eng, monkeypatch):
+    """nc_set_tensor_format(ctx, 1): the featuriser's int16 tensors are the float32 tensors value for value; the pixel-form split-precision trunk
+    (k5_trunk_p3, NC_TRUNK_LIN=0) returns bit-identical probabilities from either, k5_trunk_lin (the int16 default: conv1 by linearity, other
+    roundings) the same within 2e-5; the exact-fp32 trunk refuses int16"""
     import torch
     from nanocaller_amd import _lib
     from nanocaller_amd.pack import pack_world
@@ -391,6 +479,7 @@ def test_int16_tensors_equal_float32_tensors(eng):
     path, cov = get_SNP_model("ONT-HG002")
     eng.load_weights(_lib.MODEL_SNP, Weights(path))
     out = {}
+    monkeypatch.setenv("NC_TRUNK_LIN", "0")
     for i16 in (False, True):
         eng.set_tensor_format(int16=i16)
         sites = eng.snp_scan(dp, [(20_000, 60_000), (60_001, 100_003)], mincov=4, min_allele_freq=0.15, threshold=[0.4, 0.6])
@@ -401,6 +490,11 @@ def test_int16_tensors_equal_float32_tensors(eng):
     assert out[True][0].dtype == torch.int16 and out[False][0].dtype == torch.float32 and out[True][3] == out[False][3] > 300
     assert torch.equal(out[True][0].to(torch.float32), out[False][0])
     assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+    monkeypatch.delenv("NC_TRUNK_LIN")
+    eng.set_tensor_format(int16=True)
+    assert eng.trunk_info()[1] == "k5_trunk_lin"
+    lp, lg = eng.snp_forward(_lib.MODEL_SNP, out[True][0], sites.ref_code, scale)
+    assert float((lp - out[False][1]).abs().max()) < 2e-5 and float((lg - out[False][2]).abs().max()) < 2e-5
     eng.set_cnn_precision(exact_fp32=True)
     with pytest.raises(Exception):
         eng.snp_forward(_lib.MODEL_SNP, out[True][0], sites.ref_code, scale)

@@ -75,6 +75,21 @@ def one(libpath):
         if os.environ.get("NC_TRACE_P3"):
             b = buf.astype(np.int64)
             names = {4: "C-light", 5: "C-light", 6: "C-heavy", 7: "C-heavy", 0: "conv2a", 1: "conv2b", 2: "conv3a", 3: "conv3b"}
+            skew = bool((b[0, 1:7, 3] > 0).all())      # k5_trunk_lin with NC_LIN_SKEW: event 3 = the deferred epilogue of the conv2 / conv3 waves is done
+            for w in range(8 if skew else 0):
+                rows = []
+                for k in range(1, 7):
+                    e = b[w, k]
+                    if w >= 4:     # 0 start, 2 MFMAs done, 5 before barrier, 6 after
+                        rows.append((0, 0, e[2] - e[0], e[5] - e[2], e[6] - e[5], e[6] - b[w, k - 1][6]))
+                    elif w < 2:    # 0 start, 3 deferred epilogue done, 1 MFMAs done, 5 before barrier, 6 after
+                        rows.append((0, e[3] - e[0], e[1] - e[3], 0, e[6] - e[5], e[6] - b[w, k - 1][6]))
+                    else:          # 0 start, 2 staging done, 3 deferred epilogue done, 1 MFMAs done
+                        rows.append((e[2] - e[0], e[3] - e[2], e[1] - e[3], 0, e[6] - e[5], e[6] - b[w, k - 1][6]))
+                m = np.array(rows).mean(0)
+                print("   %-7s commit %5d | epilogue of the previous step %5d | MFMA loop %5d | epilogue %5d | barrier wait %5d | step %5d" % ((names[w],) + tuple(int(v) for v in m)))
+            if skew:
+                return
             for w in range(8):
                 rows = []
                 for k in range(1, 7):
