@@ -808,6 +808,79 @@ def wgs_block(eng, uploader, local, model, passes=1, scale=1.0, contigs=None):
     return out
 
 
+def wgs_sharded_block(eng, uploader, local, model, rank, world, barrier, scale=1.0, contigs=None):
+    """BASELINE.json configs[3]: the whole genome (24 contigs at GRCh38 lengths x `scale`), SNP half + indel half, sharded over the ranks by
+    shard.shard_plan -- contiguous, contig-aware blocks of the 500 kb chunk list, balanced by scanned columns (a uniform-depth synthetic genome; a BAM's
+    depth weights come from its index) -- every rank building and passing over ITS block only, from pinned host memory, no collective on the data path
+    (the reference: one worker pool over all chunks, files as the gather medium, snpCaller.py:213-245, 278-285).  A rank's part of a contig it shares with
+    a neighbour is a synthetic contig of that part's length.  -> dict on every rank (rank 0 prints it): whole-job sites / MAX rank time, the ranks' times
+    and their imbalance (max / mean), per-rank upload rates."""
+    import torch.distributed as dist
+
+    from nanocaller_amd.shard import dist_max, dist_sum, shard_plan
+    from nanocaller_amd.utils import get_chunks
+    spec = [(n, max(500_000, int(L0 * scale))) for n, L0 in (contigs or GRCH38)]
+    all_chunks = get_chunks([(n, 1, L, "diploid") for n, L in spec], cpu=16)
+    plan = shard_plan(all_chunks, world)
+    mine = plan[rank]
+    parts = {}
+    for c in mine:                                                   # this rank's part of every contig it touches
+        a, b = parts.get(c["chrom"], (c["start"], c["end"]))
+        parts[c["chrom"]] = (min(a, c["start"]), max(b, c["end"]))
+    t0 = time.perf_counter()
+    params = snp_params(model, "ont")
+    units, bp, wire_bytes = [], 0, 0
+    order = [n for n, _ in spec if n in parts]
+    for k, name in enumerate(order):
+        a, b = parts[name]
+        L = b - a + 1
+        snp = Contig(eng, L, 30.0, "ont", seed=2000 + 100 * rank + k, keep_pack=False)
+        job = IndelJob(eng, L, seed=6000 + 100 * rank + k, name=name.encode())
+        job.drop_pack()
+        units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
+        bp += L
+        wire_bytes += snp.wire.nbytes + job.wire.nbytes
+    t_setup = time.perf_counter() - t0
+    ns = ni = nrec = 0
+    dt = 0.0
+    uploader.h2d_events.clear()
+    if units:
+        big = max(units, key=lambda u: u.job.wire.nbytes)
+        run_pairs(uploader, local, params, [big], len(uploader.slots))  # sizes ring, workspaces and pools by this rank's largest part (untimed)
+        uploader.h2d_events.clear()
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if units:
+            ns, ni, nrec = run_pairs(uploader, local, params, units, len(units))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t                                 # this rank's own time; the job's time is the MAX (barrier on both sides)
+        barrier()
+    finally:
+        gc.enable()
+    h2d_gbs, _, _ = uploader.h2d_rate()
+    dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", local)
+    mine_t = torch.tensor([dt, float(ns + ni), float(bp), h2d_gbs, float(len(mine)), float(wire_bytes)], dtype=torch.float64, device=dev)
+    allt = [torch.zeros_like(mine_t) for _ in range(world)]
+    dist.all_gather(allt, mine_t)
+    rows = [[float(v) for v in t_] for t_ in allt]
+    times = [r_[0] for r_ in rows]
+    job_dt = dist_max(dt)
+    total = dist_sum(ns + ni)
+    return {"workload": "configs[3]: %d contigs at GRCh38 lengths x %g (%d bp) sharded over %d ranks by shard_plan, SNP + indel halves" % (len(spec), scale, sum(L for _, L in spec), world),
+            "value": total / job_dt if job_dt > 0 else 0.0, "unit": "candidate sites/s (SNP + indel, whole job, MAX over ranks)", "s_per_pass": job_dt, "sites": total,
+            "rank_s": [round(v, 4) for v in times], "rank_imbalance_max_over_mean": max(times) / (sum(times) / len(times)) if sum(times) > 0 else None,
+            "rank_sites": [int(r_[1]) for r_ in rows], "rank_bp": [int(r_[2]) for r_ in rows], "rank_chunks": [int(r_[4]) for r_ in rows],
+            "rank_h2d_GBs": [round(r_[3], 2) for r_ in rows], "rank_wire_bytes": [int(r_[5]) for r_ in rows],
+            "host_pinned_read_GBs_all_ranks": sum(r_[5] for r_ in rows) / job_dt / 1e9 if job_dt > 0 else None, "setup_s_rank0": round(t_setup, 1),
+            "note": "every rank: its block's contigs (parts) from pinned host memory through its own upload ring; barrier + synchronize on both sides; value = all "
+                    "ranks' sites / the slowest rank's time"}
+
+
 def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
     """BASELINE.json configs[2]: "SNP+indel full pipeline on 1 MI355X, HG002 ONT 30x chr1" as ONE timed region.  A step = the SNP pass over a
     chr1-sized contig (248,956,422 bp, 498 chunks of 500 kb; upload -> expansion -> scan -> tensors -> SNP CNN -> per-site results) followed by the
@@ -1220,6 +1293,17 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                                      # never take the headline down
             indel_leg = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- N > 1: BASELINE.json configs[3], the whole-genome mix sharded by shard_plan (every rank takes part; rank 0 reports it)
+    wgs_sharded = None
+    if world > 1 and not args.no_wgs:
+        try:
+            wgs_sharded = wgs_sharded_block(eng, uploader, local, args.model, rank, world, barrier, args.wgs_scale)
+        except Exception as e:                                      # never take the headline down
+            wgs_sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                barrier()
+            except Exception:
+                pass
     if rank == 0:
         n_units = args.steps * per_step
         c0 = contigs[0]
@@ -1361,7 +1445,7 @@ def main():
                               "note": "rank 0, per GPU; with_h2d_d2h = the timed region (= value at N=1); hbm_resident = the same passes over a pack "
                                       "already in HBM (round 1's headline); pipelined = + VCF text of pass i formatted on a host thread while the "
                                       "GPU runs pass i+1 (snpCaller.caller), uploads included"},
-            "indel_leg": indel_leg,
+            "indel_leg": indel_leg, "wgs_sharded": wgs_sharded,
             "numa": ({"rank0_bound": numa["bound"], "node": numa["node"], "cpus": len(numa["cpus"]) if numa["cpus"] else None, "note": numa["note"]} if numa else None),
             "range_guard": {"x_limit": eng.x_limit(_lib_kind(args.ploidy)), "sites_rerun_on_exact_trunk": int(r.get("range_reruns", 0)) if r else None,
                             "note": "fp16x3 trunk: sites whose scaled tensor exceeds the model's proven-safe input bound are re-run on the exact fp32 trunk "
@@ -1373,6 +1457,15 @@ def main():
                        "featurize_frac_hbm": feat_bytes / (stage_ms[1] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms[1] else 0,
                        "cnn_ms": float(stage_ms[2]), "trunk_ms_per_contig": float(trunk_ms / max(1, n_units * len(dts)))},
         }
+        if wgs_sharded is not None:
+            cfg = out["config"]
+            if "error" in wgs_sharded:
+                cfg["wgs_sharded_error"] = str(wgs_sharded["error"])[:120]
+            else:
+                cfg.update({"wgs_sharded_value": wgs_sharded["value"], "wgs_sharded_s_per_pass": wgs_sharded["s_per_pass"], "wgs_sharded_sites": wgs_sharded["sites"],
+                            "wgs_sharded_rank_imbalance": wgs_sharded["rank_imbalance_max_over_mean"], "wgs_sharded_scale": args.wgs_scale,
+                            "wgs_sharded_h2d_GBs_min": min(wgs_sharded["rank_h2d_GBs"]), "wgs_sharded_h2d_GBs_max": max(wgs_sharded["rank_h2d_GBs"]),
+                            "wgs_sharded_host_read_GBs": wgs_sharded["host_pinned_read_GBs_all_ranks"]})
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_sample_chunks or len(chunks)
             cb, parity = cpu_baseline_processes(pack, c0.info, chunks, params, args.model, r0, n_cpu)

@@ -295,3 +295,57 @@ def test_eight_rank_gloo_wgs_plan_through_the_indel_call_manager(tmp_path):
     assert len(ind) == len(chunks)
     keys = [(int(r.split("\t")[0][3:]), int(r.split("\t")[1])) for r in ind]
     assert keys == sorted(keys)
+
+
+def _merge_worker(rank, world, port, tmpdir):
+    """one rank of the indel half over a small 5-contig list: every chunk yields two records (the second BEFORE the first in position, as two overlapping
+    chunks' records can be) so that the merge has to order what the workers wrote"""
+    import torch
+    import torch.distributed as dist
+
+    from nanocaller_amd import indelCaller
+    from tests.test_boundary import _fake_snp_vcf
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 8
+
+    def fake_indel_run(params, indel_dict, job_Q, counter_Q, files, device=0, worker_id=1, aligner=None):
+        path = os.path.join(params["intermediate_indel_files_dir"], "%s.%d.indel.vcf" % (params["prefix"], worker_id))
+        files.append(path)
+        with open(path, "a") as f:
+            while not job_Q.empty():
+                kind, chunk = job_Q.get()
+                for off, alt in ((900, "ATT"), (40, "A")):
+                    f.write("%s\t%d\t.\tAT\t%s\t%d.00\tPASS\t.\tGT:GQ\t0|1:3.00\n" % (chunk["chrom"], chunk["start"] + off, alt, 10 + chunk["start"] % 7))
+    indelCaller.indel_run = fake_indel_run
+    indelCaller._whatshap_available = lambda: False
+    regions = [("chr%d" % (k + 1), 1, n * 1_000, "diploid") for k, n in enumerate([61, 17, 33, 9, 48])]
+    snp_vcf = os.path.join(tmpdir, "t.snps.vcf.gz")
+    if rank == 0:
+        _fake_snp_vcf(snp_vcf, [r[0] for r in regions])
+    dist.barrier()
+    params = dict(chunks_list=get_chunks(regions, 16, max_chunk_size=3_000), mode="all", snp_vcf=snp_vcf, regions_list=regions, sam_path="in.bam",
+                  fasta_path="x.fa", vcf_path=tmpdir, prefix="t", sample="S", phase_qual_score=10, suppress_progress=True, verbose=False,
+                  enable_whatshap=False, cpu=2)
+    out = indelCaller.call_manager(params)
+    with open(os.path.join(tmpdir, "out.%d" % rank), "w") as f:
+        f.write(repr(out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_indel_merge_equals_the_single_process_file(tmp_path):
+    """the indel half's gather (indelCaller.py:290-353: per-worker files, merged and sorted by rank 0): two ranks' per-rank files merge into the SAME records
+    in the SAME order as one process writes -- headers aside, the .indels.vcf.gz and the final .vcf.gz are identical"""
+    from tests.test_boundary import _records
+    outs = {}
+    for world in (1, 2):
+        d = tmp_path / ("w%d" % world)
+        d.mkdir()
+        mp.spawn(_merge_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        outs[world] = eval(open(os.path.join(str(d), "out.0")).read())
+    one, two = _records(outs[1]["indels"]), _records(outs[2]["indels"])
+    assert len(one) > 100 and one == two
+    keys = [(int(r.split("\t")[0][3:]), int(r.split("\t")[1])) for r in two]
+    assert keys == sorted(keys)
+    assert _records(outs[1]["final"]) == _records(outs[2]["final"])
