@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (HiFi 60x haploid, exact fp32, indel pipeline)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] block (chr1-sized SNP + indel in one timed region)")
-    ap.add_argument("--configs2-steps", type=int, default=8)
+    ap.add_argument("--configs2-steps", type=int, default=12)
     ap.add_argument("--no-wgs", action="store_true", help="skip the whole-genome N=1 pass (24 contigs at GRCh38 lengths, SNP + indel halves)")
     ap.add_argument("--wgs", action="store_true", help="(default at N=1; kept for explicit invocations)")
     ap.add_argument("--wgs-passes", type=int, default=1)
@@ -685,58 +685,68 @@ class PairUnit:
                                           haploid=False, as_array=True, out=self.scratch["buf"]))
 
 
+STEP_STARTS = []                 # host time at which run_pairs began each step of its last call (steady-state step time = the median difference)
+
+
+def steady_step_ms():
+    d = np.diff(np.asarray(STEP_STARTS))
+    return float(np.median(d[1:]) * 1e3) if d.size > 2 else None
+
+
 def run_pairs(uploader, local, params, units, n_steps, snp_half=True, indel_half=True):
     """n_steps steps, step i over units[i % len(units)]: the SNP pass (upload -> expansion -> scan -> tensors -> SNP CNN) then the indel pass
     (upload -> expansion -> K7 ... K9) of that contig, the reference's order (NanoCaller:25-55).  The copies of step i + 1 (SNP wire, then indel
-    wire) are both enqueued before the indel pass of step i starts, so they run under its kernels and the SNP kernels of step i + 1; genotype
-    rules + VCF text of both halves run natively on a host thread under the next step.  -> (SNP sites, indel sites, indel VCF records)"""
+    wire) are both enqueued before the indel pass of step i starts, so they run under its kernels; the moment the indel pass of step i returns (its
+    last results are on the host: the GPU has nothing queued) the SNP half of step i + 1 is enqueued, and only then are step i's results collected and
+    handed to the host thread (genotype rules + VCF text of both halves, natively, under the next step): the host's turn-around work runs under the
+    next SNP half's kernels instead of beside an idle GPU.  -> (SNP sites, indel sites, indel VCF records)"""
     from concurrent.futures import ThreadPoolExecutor
 
     from nanocaller_amd import snpCaller
     ns = ni = nrec = 0
     nu = len(units)
+    dbg = os.environ.get("NC_BENCH_DEBUG") == "1"
+    tdbg = time.perf_counter()
+    STEP_STARTS.clear()
+
+    def enqueue_snp(u, tk):
+        dpk = uploader.expand(tk)
+        c = snpCaller.call_chunks(params, u.chunks, device=local, dpk=dpk, defer=True)
+        uploader.release(tk)
+        return c
     with ThreadPoolExecutor(max_workers=1) as pool:
-        pend = prev = prev_u = None
-        tk_s = uploader.submit(units[0].snp.wire) if snp_half else None
-        tk_i = uploader.submit(units[0].job.wire) if indel_half else None
-        dbg = os.environ.get("NC_BENCH_DEBUG") == "1"
-        tdbg = time.perf_counter()
+        pend = None
+        cur = enqueue_snp(units[0], uploader.submit(units[0].snp.wire)) if (snp_half and n_steps > 0) else None
+        tk_i = uploader.submit(units[0].job.wire) if (indel_half and n_steps > 0) else None
+        # SNP alone: nothing runs between two SNP halves, so the copy of step i + 2 goes out before step i + 1 is enqueued (a copy submitted right
+        # before its own expansion is waited for in full: tools/exp_pairs_trace.py)
+        early = uploader.submit(units[1 % nu].snp.wire) if (snp_half and not indel_half and n_steps > 1) else None
         for i in range(n_steps):
             u = units[i % nu]
             un = units[(i + 1) % nu]
+            STEP_STARTS.append(time.perf_counter())
             if dbg:
                 print("pair step %d %s (snp %s indel %s): +%.1f ms" % (i, u.name, snp_half, indel_half, (time.perf_counter() - tdbg) * 1e3), file=sys.stderr, flush=True)
             more = i + 1 < n_steps
-            cur = ri = rs = None
-            rs_u = u
-            nxt_s = nxt_i = None
-            if snp_half:
-                dpk = uploader.expand(tk_s)
-                cur = snpCaller.call_chunks(params, u.chunks, device=local, dpk=dpk, defer=True)
-                uploader.release(tk_s)
-                nxt_s = uploader.submit(un.snp.wire) if more else None
             if indel_half:
-                nxt_i = uploader.submit(un.job.wire) if more else None
-                ri = u.job.from_host_pass(uploader, tk_i)
+                nxt_s = uploader.submit(un.snp.wire) if (snp_half and more) else None
+            else:
+                nxt_s, early = early, (uploader.submit(units[(i + 2) % nu].snp.wire) if (snp_half and i + 2 < n_steps) else None)
+            nxt_i = uploader.submit(un.job.wire) if (indel_half and more) else None
+            ri = None
+            if indel_half:
+                ri = u.job.from_host_pass(uploader, tk_i)           # (ends on host waits: the GPU is idle when it returns)
                 ni += int(ri["n"])
-                rs = cur.result() if cur is not None else None       # (the indel pass ends on host waits: the SNP half before it is complete)
-            elif prev is not None:
-                rs, rs_u = prev.result(), prev_u                     # SNP alone: step i - 1 is collected while step i runs
-            prev, prev_u = cur, u
-            tk_s, tk_i = nxt_s, nxt_i
+            cur_next = enqueue_snp(un, nxt_s) if nxt_s is not None else None
+            rs = cur.result() if cur is not None else None
             if rs is not None:
                 ns += int(rs["n"])
             if pend is not None:
                 nrec += pend.result()
                 pend = None
             if rs is not None or ri is not None:
-                pend = pool.submit(_pair_host_half, rs_u, rs, u, ri)
-        if not indel_half and prev is not None:
-            rs = prev.result()
-            ns += int(rs["n"])
-            if pend is not None:
-                nrec += pend.result()
-            pend = pool.submit(_pair_host_half, prev_u, rs, None, None)
+                pend = pool.submit(_pair_host_half, u, rs, u, ri)
+            cur, tk_i = cur_next, nxt_i
         if pend is not None:
             nrec += pend.result()
     return ns, ni, nrec
@@ -922,6 +932,7 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
     eng.enable_timing(True, trunk_only=True)
     s0, _ = eng.timing_sums()
     (ns, ni, nrec), dt = timed(steps)
+    steady = steady_step_ms()
     s1, _ = eng.timing_sums()
     eng.enable_timing(False)
     h2d_gbs, _, h2d_bytes = uploader.h2d_rate()
@@ -953,6 +964,7 @@ def configs2_block(eng, uploader, local, model, steps=3, L=CHR1_LEN):
                        "sites per step; indel half (planted indels 1-50 bp, HP/PS tags) %d chunks of 100 kb, %d candidate sites (%d read windows aligned) per step"
                        % (L, len(chunks), ns // steps, len(job.chunks), ni // steps, int(rt["n_alignments"])),
            "value": (ns + ni) / dt, "unit": "candidate sites/s (SNP + indel, one timed region)", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "ms_per_step_steady": steady, "steady_note": "median step-to-step time from the third step on: the first step of the region has nothing to hide its own two uploads under",
            "timed_region": "per step: SNP wire (%.0f MB) and indel wire (%.0f MB) from pinned host memory, each copy under the other half's kernels -> both halves' "
                            "per-site results in host memory -> native rules + VCF text of both on a host thread under the next step"
                            % (snp.wire.nbytes / 1e6, job.wire.nbytes / 1e6),
@@ -1489,7 +1501,7 @@ def main():
                 cfg["configs2_error"] = str(c2["error"])[:120]
             else:
                 cfg.update({"configs2_workload": "configs[2]: SNP+indel, chr1-sized synthetic ONT 30x, one timed region from pinned host memory",
-                            "configs2_value": c2["value"], "configs2_ms_per_step": c2["ms_per_step"], "configs2_steps": c2["steps"],
+                            "configs2_value": c2["value"], "configs2_ms_per_step": c2["ms_per_step"], "configs2_ms_per_step_steady": c2["ms_per_step_steady"], "configs2_steps": c2["steps"],
                             "configs2_snp_sites": c2["snp_half"]["sites_per_step"], "configs2_indel_sites": c2["indel_half"]["sites_per_step"],
                             "configs2_snp_ms": c2["snp_half"]["ms_per_step_alone"], "configs2_indel_ms": c2["indel_half"]["ms_per_step_alone"],
                             "configs2_indel_sites_s": c2["indel_half"]["sites_s_alone"],

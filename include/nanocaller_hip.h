@@ -31,7 +31,9 @@ extern "C" {
                                  nc_decoded_check, nc_cnn_x_limit + nc_cnn_range_watch (range guard of the fp16x3 trunk), nc_synth_indel_*;
                               9: nc_indel_sites_band + nc_indel_sites_band_stats (banded star alignment), nc_indel_events_pack / _expand (3-byte transfer form of the indel events), nc_inflate_device, nc_bgzf_members / _scan + nc_bam_walk / _meta / _codes / _indel_reads (BAM ingest on the device);
                               10: nc_bgzf_crc_device (CRC-32 of the device-inflated members);
-                              11: nc_snp_trunk_info (which SNP trunk kernel the next nc_snp_forward runs, its MFMA count per site) */
+                              11: nc_snp_trunk_info (which SNP trunk kernel the next nc_snp_forward runs, its MFMA count per site), nc_wire_build_del +
+                                  nc_wire_apply_deletions (deleted columns implied by the indel events), nc_wire_ref_unpack (reference bytes two per byte), two-byte
+                                  indel events (nc_indel_events_pack / _expand with l8 = NULL) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -161,6 +163,19 @@ int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, con
                   const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, nc_wire **out);
 int nc_wire_view(const nc_wire *w, nc_wire_arrays *view);
 int nc_wire_free(nc_wire *w);
+/* The same with a read pack that travels beside its indel events (nc_indel_events': ev_off [n_reads + 1] per read of the INPUT order, a negative
+ * length -L at column c deletes columns c + 1 .. c + L): the deleted columns' code (4) is implied by the events and left out of the difference
+ * events; nc_wire_apply_deletions (all pointers dev, the KEPT reads' tables and events in pack order, after nc_wire_expand and
+ * nc_indel_events_expand, same stream) writes them back.  Both are this library's own transfer form: no reference counterpart (the reference
+ * decodes per chunk with pysam, generate_indel_pileups.py:213-264). */
+/* ref_wire as it crosses PCIe since ABI 11: two positions per byte (position 2 i in the low nibble of byte i); nc_wire_ref_unpack (pointers dev, 16-byte
+ * aligned) rebuilds the byte array nc_wire_expand reads, on the context's stream. */
+int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire);
+int nc_wire_build_del(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                      const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
+                      const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out);
+int nc_wire_apply_deletions(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                            const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len, uint8_t *d_codes);
 /* All pointers dev, 16-byte aligned; d_codes [codes_len] and d_ref_code [ref_len] (may be NULL) are written on the
  * context's stream.  HBM-write-bound: 1 B per pileup entry. */
 int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,

@@ -38,16 +38,22 @@ struct nc_wire {
 static inline int64_t floor16w(int64_t p) { return p & ~(int64_t)15; }
 static inline int64_t ceil16w(int64_t p) { return (p + 15) & ~(int64_t)15; }
 
-extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
-                             const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, nc_wire **out)
+// ev_off / ev_pos / ev_len (optional; per read of the INPUT order, nc_indel_events' convention: a negative length -L at column c deletes
+// columns c + 1 .. c + L): a deleted column's code (4) is implied by the read's own deletion event, which crosses PCIe anyway with the indel
+// events -- it is left out of the difference events and written back in HBM by nc_wire_apply_deletions (round 6: 62.8 M of the 120.7 M
+// events of a chr20-sized ONT contig).  A code 4 outside every deletion run (a read base N) stays an event.
+static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in, const uint8_t *keep,
+                      const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out)
 {
     if (!out || n_reads < 0 || (n_reads && (!start || !end || !off || !codes_in)) || !ref_wire || ref_len < 0 || (ref_pos0 & 15))
         return NC_ERR_ARG;
+    if (ev_off && n_reads && ev_off[n_reads] > 0 && (!ev_pos || !ev_len)) return NC_ERR_ARG;
     *out = nullptr;
     nc_wire *w = new (std::nothrow) nc_wire;
     if (!w) return NC_ERR_NOMEM;
     try {
         std::vector<int64_t> rd_off;
+        std::vector<int32_t> orig;                                    // input index of every kept read (its events)
         w->slot_off.push_back(0);
         int32_t prev = INT32_MIN;
         for (int32_t r = 0; r < n_reads; r++) {
@@ -57,6 +63,7 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
             w->rd_start.push_back(start[r]);
             w->rd_end.push_back(end[r]);
             rd_off.push_back(off[r]);
+            orig.push_back(r);
             w->slot_off.push_back(w->slot_off.back() + (ceil16w(end[r]) - floor16w(start[r])));
         }
         const int64_t n = (int64_t)w->rd_start.size();
@@ -86,6 +93,23 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
                     const int64_t p_lo = std::max<int64_t>(s, byte0 - base), p_hi = std::min<int64_t>(e, byte1 - base);
                     const uint8_t *src = codes_in + rd_off[(size_t)q] - s;                     // src[p]
                     const int64_t off0 = base - byte0;                                         // event offset of position p: off0 + p
+                    // this read's deletion runs from p_lo on (events ascend): `covered(p)` for ascending p
+                    int32_t de = 0, de1 = 0;
+                    if (ev_off) {
+                        de = ev_off[orig[(size_t)q]];
+                        de1 = ev_off[orig[(size_t)q] + 1];
+                        // first event whose run can reach p_lo: runs are short, so the first event with column >= p_lo - 65536 would do; bisect on the column
+                        int32_t lo = de, hi = de1;
+                        while (lo < hi) {
+                            const int32_t mid = (lo + hi) >> 1;
+                            if ((int64_t)ev_pos[mid] + (ev_len[mid] < 0 ? -(int64_t)ev_len[mid] : 0) < p_lo) lo = mid + 1; else hi = mid;
+                        }
+                        de = lo;
+                    }
+                    auto covered = [&](int64_t p) -> bool {
+                        while (de < de1 && (ev_len[de] >= 0 || (int64_t)ev_pos[de] - (int64_t)ev_len[de] < p)) de++;
+                        return de < de1 && (int64_t)ev_pos[de] < p;              // (de: first deletion whose last column c - len >= p)
+                    };
                     // positions off the reference grid (none in a pack built by build_wire: the grid covers every kept read) compare with 'N'
                     const int64_t g_lo = std::min(std::max<int64_t>(p_lo, ref_pos0), p_hi), g_hi = std::max(std::min<int64_t>(p_hi, ref_pos0 + ref_len), g_lo);
                     unsigned worst = 0;
@@ -107,6 +131,7 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
                         while (m) {
                             const int k = __builtin_ctz(m);
                             m &= m - 1;
+                            if (src[p + k] == 4u && ev_off && covered(p + k)) continue;
                             ev.push_back((uint16_t)((off0 + p + k) | ((unsigned)src[p + k] << 12)));
                         }
                     }
@@ -119,7 +144,7 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
                     for (; p < g_hi; p++) {
                         const unsigned c = src[p];
                         wmax = std::max(wmax, c);
-                        if (c != (rf[p] & 7u)) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                        if (c != (rf[p] & 7u) && !(c == 4u && ev_off && covered(p))) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
                     }
                     for (p = g_hi; p < p_hi; p++) {
                         const unsigned c = src[p];
@@ -164,6 +189,33 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
     }
     *out = w;
     return NC_OK;
+}
+
+extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                             const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, nc_wire **out)
+{
+    return wire_build(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, nullptr, nullptr, nullptr, out);
+}
+
+extern "C" int nc_wire_build_del(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                                 const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
+                                 const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out)
+{
+    if (!ev_off || n_reads < 0 || (n_reads && (!start || !end || !off || !codes_in)) || (n_reads && ev_off[n_reads] > 0 && (!ev_pos || !ev_len))) return NC_ERR_ARG;
+    // the events must describe the codes: every deleted column inside its read carries code 4 (what a pileup's '*' decodes to,
+    // generate_SNP_pileups.py:104).  Codes that say otherwise (a pack assembled from unrelated arrays) cannot leave them out: NC_ERR_UNSUPPORTED,
+    // and the caller builds the plain form
+    for (int32_t r = 0; r < n_reads; r++) {
+        if (keep && !keep[r]) continue;
+        const uint8_t *src = codes_in + off[r] - start[r];
+        for (int32_t e = ev_off[r]; e < ev_off[r + 1]; e++) {
+            if (ev_len[e] >= 0) continue;
+            const int64_t a = std::max<int64_t>((int64_t)ev_pos[e] + 1, start[r]), b = std::min<int64_t>((int64_t)ev_pos[e] + 1 - ev_len[e], end[r]);
+            for (int64_t p = a; p < b; p++)
+                if (src[p] != 4u) return NC_ERR_UNSUPPORTED;
+        }
+    }
+    return wire_build(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, ev_off, ev_pos, ev_len, out);
 }
 
 extern "C" int nc_wire_view(const nc_wire *w, nc_wire_arrays *v)
@@ -333,6 +385,29 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
     }
 }
 
+// the reference bytes cross PCIe two per byte (round 6: 4 bits say all there is -- base code + skip bit); unpacked into the byte array
+// nc_wire_expand reads, 32 positions per thread
+__global__ void k_ref_unpack(const uint8_t *__restrict__ nib, uint8_t *__restrict__ ref_wire, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 32;
+    if (i + 32 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(nib + i / 2);
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // bytes b0 b1 b2 b3, each lo | hi << 4 -> positions b0.lo b0.hi b1.lo b1.hi | b2.lo b2.hi b3.lo b3.hi
+            const uint32_t x = in[q], lo = x & 0x0f0f0f0fu, hi = (x >> 4) & 0x0f0f0f0fu;
+            o[2 * q] = (lo & 0xffu) | ((hi & 0xffu) << 8) | ((lo & 0xff00u) << 8) | ((hi & 0xff00u) << 16);
+            o[2 * q + 1] = ((lo >> 16) & 0xffu) | (((hi >> 16) & 0xffu) << 8) | (((lo >> 24) & 0xffu) << 16) | (((hi >> 24) & 0xffu) << 24);
+        }
+        *reinterpret_cast<uint4 *>(ref_wire + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(ref_wire + i + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        for (int64_t j = i; j < n; j++) ref_wire[j] = (nib[j >> 1] >> ((j & 1) * 4)) & 0xfu;
+    }
+}
+
 // reference codes of the column scan from the wire form: skipped columns (bit 3: soft-masked, non-AGTC, excluded) become 4
 __global__ void k_ref_from_wire(const uint8_t *__restrict__ ref_wire, uint8_t *__restrict__ ref_code, int64_t n)
 {
@@ -380,7 +455,8 @@ extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_
 // The indel path's per-read events ('+n' / '-n' of the pileup: column, signed length, offset of the inserted bases) are 12 bytes each as the
 // kernels read them -- 830 MB of a chr20-sized ONT contig's 1.2 GB transfer, more than its 21 ms pass can hide.  They cross PCIe as 3 bytes:
 //     d16  uint16  column - column of the read's previous event (the first one: - the read's start); 0xFFFF = see the side table
-//     l8   int8    signed length; the side table's entry when d16 is 0xFFFF
+//     l8   int8    signed length; the side table's entry when d16 is 0xFFFF.  l8 == NULL (round 6): the TWO-byte form, d16 = distance (bits 0-10,
+//                  0x7ff -> side table) | signed length << 11 (-16 .. 15)
 //     side table (big_idx ascending, big_pos, big_len): events with a distance >= 0xFFFF or |length| >= 128
 //     read_ins_off [n_reads + 1]: offset of the read's first inserted base (the per-event offsets are its running sum of the positive lengths)
 // nc_indel_events_pack makes them on the host; nc_indel_events_expand rebuilds ev_pos / ev_len / ins_off in HBM, one wave per read.
@@ -396,7 +472,15 @@ extern "C" int nc_indel_events_pack(int32_t n_reads, const int32_t *rd_start, co
         for (int32_t e = ev_off[r]; e < ev_off[r + 1]; e++) {
             const int32_t d = ev_pos[e] - prev, l = ev_len[e];
             if (d < 0) return NC_ERR_ARG;                            // events of a read ascend
-            if (d >= 0xFFFF || l >= 128 || l <= -128) {
+            if (!l8) {
+                // two-byte form (round 6): distance in bits 0-10 (0x7ff = side table), signed length in bits 11-15 (-16 .. 15)
+                if (d >= 0x7ff || l > 15 || l < -16) {
+                    if (nb < big_cap) { big_idx[nb] = e; big_pos[nb] = ev_pos[e]; big_len[nb] = l; }
+                    nb++;
+                    d16[e] = 0xFFFF;
+                } else
+                    d16[e] = (uint16_t)((unsigned)d | (((unsigned)l & 0x1fu) << 11));
+            } else if (d >= 0xFFFF || l >= 128 || l <= -128) {
                 if (nb < big_cap) { big_idx[nb] = e; big_pos[nb] = ev_pos[e]; big_len[nb] = l; }
                 nb++;
                 d16[e] = 0xFFFF;
@@ -438,8 +522,12 @@ __global__ __launch_bounds__(256) void k_events_expand(int32_t n_reads, const in
     for (int c = e0; c < e1; c += 64) {
         const int e = c + lane;
         const bool valid = e < e1;
-        int32_t d = valid ? (int32_t)d16[e] : 0, l = valid ? (int32_t)l8[e] : 0, ab = 0;
+        int32_t d = valid ? (int32_t)d16[e] : 0, l = (valid && l8) ? (int32_t)l8[e] : 0, ab = 0;
         const bool big = valid && d == 0xFFFF;
+        if (!l8 && valid && !big) {                                   // two-byte form: distance | signed 5-bit length << 11
+            l = (int32_t)((uint32_t)d << 16) >> 27;
+            d &= 0x7ff;
+        }
         if (big) {
             int lo = 0, hi = n_big;
             while (lo < hi) {
@@ -469,13 +557,59 @@ __global__ __launch_bounds__(256) void k_events_expand(int32_t n_reads, const in
 }
 }   // namespace
 
+extern "C" int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (ref_len < 0 || (ref_len && (!d_ref_nib || !d_ref_wire))) return nc_fail(ctx, NC_ERR_ARG, "nc_wire_ref_unpack: bad argument");
+    if (ref_len == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nt = (ref_len + 31) / 32;
+    hipLaunchKernelGGL(k_ref_unpack, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_nib, d_ref_wire, ref_len);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}
+
+namespace {
+// the deleted columns of every read written back into the expanded codes (nc_wire_build_del left them out of the difference events): one wave per
+// read, a lane per event, a byte store per deleted column (runs are 1-2 columns long)
+__global__ __launch_bounds__(256) void k_apply_deletions(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
+                                                         const int64_t *__restrict__ slot_off, const int32_t *__restrict__ ev_off, const int32_t *__restrict__ ev_pos,
+                                                         const int32_t *__restrict__ ev_len, uint8_t *__restrict__ codes)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const int32_t s = rd_start[r], e_ = rd_end[r];
+    uint8_t *c = codes + (slot_off[r] - (int64_t)(s & ~15));             // c[p] = the read's code at column p
+    for (int e = ev_off[r] + lane; e < ev_off[r + 1]; e += 64) {
+        const int32_t l = ev_len[e];
+        if (l >= 0) continue;
+        const int32_t p0 = ev_pos[e] + 1, p1 = min(p0 - l, e_);
+        for (int32_t p = max(p0, s); p < p1; p++) c[p] = 4;
+    }
+}
+}   // namespace
+
+extern "C" int nc_wire_apply_deletions(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                                       const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len, uint8_t *d_codes)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_reads < 0 || (n_reads && (!d_rd_start || !d_rd_end || !d_slot_off || !d_ev_off || !d_ev_pos || !d_ev_len || !d_codes)))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_wire_apply_deletions: bad argument");
+    if (n_reads == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_apply_deletions, dim3((n_reads + 3) / 4), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_rd_end, d_slot_off, d_ev_off, d_ev_pos, d_ev_len,
+                       d_codes);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}
+
 extern "C" int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint16_t *d_d16,
                                       const int8_t *d_l8, int32_t n_big, const int32_t *d_big_idx, const int32_t *d_big_pos,
                                       const int32_t *d_big_len, const int32_t *d_read_ins_off, int32_t *d_ev_pos, int32_t *d_ev_len,
                                       int32_t *d_ins_off)
 {
     if (!ctx) return NC_ERR_ARG;
-    if (n_reads < 0 || n_big < 0 || (n_reads && (!d_rd_start || !d_ev_off || !d_d16 || !d_l8 || !d_ev_pos || !d_ev_len)) ||
+    if (n_reads < 0 || n_big < 0 || (n_reads && (!d_rd_start || !d_ev_off || !d_d16 || !d_ev_pos || !d_ev_len)) ||
         (n_big && (!d_big_idx || !d_big_pos || !d_big_len)) || (d_ins_off && !d_read_ins_off))
         return nc_fail(ctx, NC_ERR_ARG, "nc_indel_events_expand: bad argument");
     if (n_reads == 0) return NC_OK;

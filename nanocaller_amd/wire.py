@@ -10,6 +10,7 @@ compute stream and rebuilds the position-addressed codes in HBM (nc_wire_expand)
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -117,8 +118,18 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
     if rc != _lib.NC_OK:
         raise _lib.NanoCallerHipError("nc_pack_fill (index) failed (%d)" % rc)
     h = C.c_void_p()
-    rc = L.nc_wire_build(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value,
-                         ref_len, C.byref(h))
+    del_implied = events is not None and os.environ.get("NC_WIRE_DEL_IMPLIED", "1") != "0"
+    if del_implied:
+        # the reads travel with their indel events: a deleted column's code is implied by the deletion event and left out of the difference events
+        # (nc_wire_apply_deletions writes it back in HBM)
+        e_off, e_pos, e_len = (np.ascontiguousarray(x, np.int32) for x in events)
+        rc = L.nc_wire_build_del(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value,
+                                 ref_len, _lib.npp(e_off), _lib.npp(e_pos) if e_pos.size else None, _lib.npp(e_len) if e_len.size else None, C.byref(h))
+        if rc == _lib.NC_ERR_UNSUPPORTED:                               # codes and events disagree about a deleted column: the plain form
+            del_implied = False
+    if not del_implied:
+        rc = L.nc_wire_build(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value,
+                             ref_len, C.byref(h))
     if rc != _lib.NC_OK:
         raise _lib.NanoCallerHipError("nc_wire_build failed (%d)" % rc)
     try:
@@ -134,7 +145,7 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
         parts = [("rd_start", arr(v.rd_start, v.n_reads, np.int32)), ("rd_end", arr(v.rd_end, v.n_reads, np.int32)),
                  ("slot_off", arr(v.slot_off, v.n_reads + 1, np.int64)), ("blk_off", arr(v.blk_off, v.n_blocks + 1, np.uint32)),
                  ("blk_read", arr(v.blk_read, v.n_blocks, np.int32)),
-                 ("events", arr(v.events, v.n_events, np.uint16)), ("ref_wire", ref_grid), ("tile_off", tile_off),
+                 ("events", arr(v.events, v.n_events, np.uint16)), ("ref_nib", ref_grid[0::2] | (ref_grid[1::2] << 4)), ("tile_off", tile_off),
                  ("tile_ent", np.frombuffer(tile_ent[:n_ent.value].tobytes(), np.uint8) if n_ent.value else np.zeros(16, np.uint8))]
         n_indel = -1
         if events is not None:
@@ -155,13 +166,13 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
             evp, evl = np.ascontiguousarray(ev_pos[idx], np.int32), np.ascontiguousarray(ev_len[idx], np.int32)
             n_ev = int(evp.size)
             kept_start = np.ascontiguousarray(rs[kept], np.int32)
-            d16, l8 = np.empty(max(n_ev, 1), np.uint16), np.empty(max(n_ev, 1), np.int8)
+            d16 = np.empty(max(n_ev, 1), np.uint16)                   # two bytes per event: distance | signed 5-bit length << 11 (nc_indel_events_pack with l8 = NULL)
             rio = np.zeros(kept.size + 1, np.int32)
             cap = max(1024, n_ev // 64)
             while True:
                 bi, bp, bl = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int32)
                 nbig = C.c_int64()
-                rc = L.nc_indel_events_pack(int(kept.size), _lib.npp(kept_start), _lib.npp(off), _lib.npp(evp), _lib.npp(evl), _lib.npp(d16), _lib.npp(l8),
+                rc = L.nc_indel_events_pack(int(kept.size), _lib.npp(kept_start), _lib.npp(off), _lib.npp(evp), _lib.npp(evl), _lib.npp(d16), None,
                                             _lib.npp(rio), cap, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nbig))
                 if rc == _lib.NC_ERR_CAPACITY:
                     cap = int(nbig.value)
@@ -170,9 +181,9 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
                     raise _lib.NanoCallerHipError("nc_indel_events_pack failed (%d)" % rc)
                 break
             nb_ = int(nbig.value)
-            parts += [("ev_off", z(off, np.int32)), ("ev_d16", d16), ("ev_l8", l8), ("ev_big_idx", z(bi[:nb_], np.int32)),
+            parts += [("ev_off", z(off, np.int32)), ("ev_d16", d16), ("ev_big_idx", z(bi[:nb_], np.int32)),
                       ("ev_big_pos", z(bp[:nb_], np.int32)), ("ev_big_len", z(bl[:nb_], np.int32)), ("read_ins_off", rio), ("read_hap", z(hp, np.uint8))]
-            meta_ev = dict(n_ev=n_ev, n_big=nb_)
+            meta_ev = dict(n_ev=n_ev, n_big=nb_, del_implied=bool(del_implied))
             n_indel = int(kept.size)
             if indel_extra is not None:
                 if n_ev and int(np.asarray(indel_extra["ins_off"])[n_ev]) != int(rio[-1]):
@@ -215,7 +226,12 @@ def _views(dev_buf, wp: WirePack):
     return out
 
 
-def _expand(eng, wp: WirePack, v, codes, ref_code):
+def _expand(eng, wp: WirePack, v, codes, ref_code, scratch=None):
+    if "ref_wire" not in v:                                             # the reference bytes travel two per byte: the byte array nc_wire_expand reads
+        if scratch is None or scratch.numel() < wp.ref_len:
+            scratch = torch.empty(wp.ref_len, dtype=torch.uint8, device=codes.device)
+        eng._check(eng.L.nc_wire_ref_unpack(eng.ctx, C.c_void_p(v["ref_nib"].data_ptr()), wp.ref_len, C.c_void_p(scratch.data_ptr())), "nc_wire_ref_unpack")
+        v["ref_wire"] = scratch
     rc = eng.L.nc_wire_expand(eng.ctx, wp.n_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
                               C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ref_wire"].data_ptr()), wp.tile_pos0, wp.ref_len,
                               C.c_void_p(v["blk_off"].data_ptr()), C.c_void_p(v["blk_read"].data_ptr()),
@@ -224,7 +240,7 @@ def _expand(eng, wp: WirePack, v, codes, ref_code):
     eng._check(rc, "nc_wire_expand")
 
 
-def _expand_events(eng, wp: WirePack, v, out):
+def _expand_events(eng, wp: WirePack, v, out, codes=None):
     """the 3-byte transfer form of the indel events -> ev_pos / ev_len / ins_off int32 in `out` (dict of device tensors, grown on demand),
     put into the views dict `v` under the names the kernels' structs take"""
     me = wp.meta.get("indel_events") if wp.meta else None
@@ -236,7 +252,7 @@ def _expand_events(eng, wp: WirePack, v, out):
             out[name] = torch.zeros(max(n, 4) + max(n, 4) // 16, dtype=torch.int32, device=dev)
     if n_ev:
         rc = eng.L.nc_indel_events_expand(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
-                                          C.c_void_p(v["ev_d16"].data_ptr()), C.c_void_p(v["ev_l8"].data_ptr()), me["n_big"],
+                                          C.c_void_p(v["ev_d16"].data_ptr()), None, me["n_big"],
                                           C.c_void_p(v["ev_big_idx"].data_ptr()), C.c_void_p(v["ev_big_pos"].data_ptr()), C.c_void_p(v["ev_big_len"].data_ptr()),
                                           C.c_void_p(v["read_ins_off"].data_ptr()), C.c_void_p(out["ev_pos"].data_ptr()), C.c_void_p(out["ev_len"].data_ptr()),
                                           C.c_void_p(out["ins_off"].data_ptr()))
@@ -244,6 +260,11 @@ def _expand_events(eng, wp: WirePack, v, out):
     v["ev_pos"], v["ev_len"] = out["ev_pos"][:max(n_ev, 1)], out["ev_len"][:max(n_ev, 1)]
     if me.get("extra"):
         v["ins_off"] = out["ins_off"][:n_ev + 1]
+    if me.get("del_implied") and n_ev and codes is not None:
+        rc = eng.L.nc_wire_apply_deletions(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
+                                           C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()), C.c_void_p(out["ev_pos"].data_ptr()),
+                                           C.c_void_p(out["ev_len"].data_ptr()), C.c_void_p(codes.data_ptr()))
+        eng._check(rc, "nc_wire_apply_deletions")
 
 
 def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
@@ -278,7 +299,7 @@ def upload_wire(eng, wp: WirePack) -> DevicePack:
     codes = torch.empty(wp.codes_len, dtype=torch.uint8, device=dev)
     ref_code = torch.empty(wp.ref_len, dtype=torch.uint8, device=dev)
     _expand(eng, wp, v, codes, ref_code)
-    _expand_events(eng, wp, v, {})
+    _expand_events(eng, wp, v, {}, codes)
     return _device_pack(wp, v, codes, ref_code, own_index=True)
 
 
@@ -297,6 +318,7 @@ class WireUploader:
         self.turn = 0
         self.codes = None
         self.ref_code = None
+        self.ref_bytes = None                      # the reference bytes unpacked from the wire's nibbles (scratch of nc_wire_expand, like codes: one, reused)
         self.ev = {}                               # expanded indel events (ev_pos / ev_len / ins_off), like codes: one set, reused by every step
         self.h2d_events = []                       # (start, stop) event pairs of the copies, for the achieved PCIe rate
         self.timing = False
@@ -332,8 +354,10 @@ class WireUploader:
             self.ref_code = torch.empty(wp.ref_len + wp.ref_len // 16, dtype=torch.uint8, device=eng.device)
         v = _views(ticket["slot"]["buf"], wp)
         codes, ref_code = self.codes[:wp.codes_len], self.ref_code[:wp.ref_len]
-        _expand(eng, wp, v, codes, ref_code)
-        _expand_events(eng, wp, v, self.ev)
+        if self.ref_bytes is None or self.ref_bytes.numel() < wp.ref_len:
+            self.ref_bytes = torch.empty(wp.ref_len + wp.ref_len // 16, dtype=torch.uint8, device=eng.device)
+        _expand(eng, wp, v, codes, ref_code, self.ref_bytes)
+        _expand_events(eng, wp, v, self.ev, codes)
         return _device_pack(wp, v, codes, ref_code, own_index=False)
 
     def release(self, ticket):

@@ -12,7 +12,9 @@ from util import load_world
 def _expand_numpy(wp):
     """what nc_wire_expand writes, restated with numpy on the host arrays of a WirePack"""
     rs, re_, so = wp.host("rd_start").astype(np.int64), wp.host("rd_end").astype(np.int64), wp.host("slot_off")
-    refw, bo, ev = wp.host("ref_wire"), wp.host("blk_off"), wp.host("events")
+    nib, bo, ev = wp.host("ref_nib"), wp.host("blk_off"), wp.host("events")
+    refw = np.empty(2 * nib.size, np.uint8)                             # two positions per byte on the wire (nc_wire_ref_unpack)
+    refw[0::2], refw[1::2] = nib & 15, nib >> 4
     codes = np.full(wp.codes_len, 7, np.uint8)
     for r in range(wp.n_reads):
         base = so[r] - (rs[r] & ~15)
@@ -29,7 +31,9 @@ def _expand_events_numpy(wp):
     """the 3-byte transfer form of the indel events (nc_indel_events_pack) restated: ev_pos / ev_len / ins_off as nc_indel_events_expand writes them"""
     me = wp.meta["indel_events"]
     n_ev, off, start = me["n_ev"], wp.host("ev_off"), wp.host("rd_start")
-    d16, l8 = wp.host("ev_d16")[:n_ev].astype(np.int64), wp.host("ev_l8")[:n_ev].astype(np.int64)
+    raw = wp.host("ev_d16")[:n_ev].astype(np.int64)                  # two bytes per event: distance (bits 0-10; 0xFFFF: side table) | signed 5-bit length << 11
+    d16 = np.where(raw == 0xFFFF, 0xFFFF, raw & 0x7ff)
+    l8 = ((raw >> 11) ^ 16) - 16
     big = {int(i): (int(p), int(ln)) for i, p, ln in zip(wp.host("ev_big_idx")[:me["n_big"]], wp.host("ev_big_pos")[:me["n_big"]], wp.host("ev_big_len")[:me["n_big"]])}
     pos, ln = np.zeros(n_ev, np.int32), np.zeros(n_ev, np.int32)
     for r in range(wp.n_indel_reads):
@@ -76,12 +80,56 @@ CASES = [("ont", False, None, 2048), ("ont", True, [(55_000, 58_000), (30_000, 4
          ("deep", False, None, 2048), ("indel", False, None, 2048)]
 
 
+def _consistent_deletions(w):
+    """the synthetic indel world with its codes made consistent with its events: every deleted column carries code 4, as a pileup's '*' decodes
+    (the stock world plants events without touching the codes: the builder then keeps the plain form)"""
+    import copy
+    w = copy.copy(w)
+    w.codes = w.codes.copy()
+    ev_off, ev_pos, ev_len = w.meta["events"]
+    for r in range(len(w.read_start)):
+        s_, e_ = int(w.read_start[r]), int(w.read_end[r])
+        for e in range(int(ev_off[r]), int(ev_off[r + 1])):
+            if ev_len[e] < 0:
+                a, b = max(int(ev_pos[e]) + 1, s_), min(int(ev_pos[e]) + 1 - int(ev_len[e]), e_)
+                w.codes[int(w.read_off[r]) + a - s_:int(w.read_off[r]) + b - s_] = 4
+    return w
+
+
+CASES = CASES + [("indel_consistent", False, None, 2048)]
+
+
 @pytest.mark.parametrize("name,supp,excl,tile", CASES)
 def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
-    w = load_world(name)
+    w = _consistent_deletions(load_world("indel")) if name == "indel_consistent" else load_world(name)
+    assert ((w.meta or {}).get("events") is None) or name.startswith("indel")
     hp = pack_world(w, supplementary=supp, exclude=excl, tile_size=tile)
     wp = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile, pin=False)
     codes, ref_code = _expand_numpy(wp)
+    me = (wp.meta or {}).get("indel_events")
+    assert bool(me and me.get("del_implied")) == (name == "indel_consistent")
+    if me and me.get("del_implied"):
+        # the deleted columns are implied by the reads' own deletion events (nc_wire_build_del) and written back after the expansion
+        # (nc_wire_apply_deletions, restated): without that step the codes differ exactly there, and the wire is that much smaller
+        assert not np.array_equal(codes, hp.codes)
+        ev_pos, ev_len, _ = _expand_events_numpy(wp)
+        off, rs, re_, so = wp.host("ev_off"), wp.host("rd_start").astype(np.int64), wp.host("rd_end").astype(np.int64), wp.host("slot_off")
+        n_written = 0
+        for r in range(wp.n_indel_reads):
+            base = so[r] - (rs[r] & ~15)
+            for e in range(int(off[r]), int(off[r + 1])):
+                if ev_len[e] < 0:
+                    a, b = max(int(ev_pos[e]) + 1, int(rs[r])), min(int(ev_pos[e]) + 1 - int(ev_len[e]), int(re_[r]))
+                    codes[base + a:base + b] = 4
+                    n_written += max(0, b - a)
+        import os
+        os.environ["NC_WIRE_DEL_IMPLIED"] = "0"
+        try:
+            full = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile, pin=False)
+        finally:
+            del os.environ["NC_WIRE_DEL_IMPLIED"]
+        assert np.array_equal(_expand_numpy(full)[0], hp.codes)
+        assert 0 < full.n_events - wp.n_events <= n_written            # every dropped event is a deleted column (a deleted column may also carry the reference's code 4: never an event)
     assert wp.codes_len == hp.codes.size and np.array_equal(codes, hp.codes)
     assert np.array_equal(ref_code, hp.ref_code)
     assert np.array_equal(wp.host("tile_off"), hp.tile_off)
@@ -93,7 +141,7 @@ def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
         ev_pos, ev_len, ins_off = _expand_events_numpy(wp)
         assert np.array_equal(ev_pos, hp.ev_pos) and np.array_equal(ev_len, hp.ev_len)
         assert np.array_equal(ins_off[1:], np.cumsum(np.maximum(hp.ev_len, 0)))
-        assert 3 * ev_pos.size + 12 * wp.meta["indel_events"]["n_big"] < 0.3 * 12 * max(ev_pos.size, 1) or ev_pos.size < 100
+        assert 2 * ev_pos.size + 12 * wp.meta["indel_events"]["n_big"] < 0.3 * 12 * max(ev_pos.size, 1) or ev_pos.size < 100
     # the point of it: far fewer bytes than 1 B per pileup entry (ONT worlds: 4 % substitutions + 4 % deletions)
     entries = int((w.read_end - w.read_start).sum())
     assert 2 * wp.n_events < 0.25 * entries
@@ -107,6 +155,29 @@ def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
 def test_ref_wire_bytes():
     rw = ref_wire_from_string("AGTCagtcNnR", exclude=[(2, 4)])
     assert rw.tolist() == [0, 1 | 8, 2 | 8, 3, 0 | 8, 1 | 8, 2 | 8, 3 | 8, 4 | 8, 4 | 8, 4 | 8]
+
+
+def test_indel_events_two_byte_form():
+    """l8 = NULL: distance (< 0x7ff) | signed 5-bit length (-16 .. 15) << 11 in ONE uint16 per event; the rest through the side table"""
+    import ctypes as C
+
+    from nanocaller_amd import _lib
+    L = _lib.lib()
+    start = np.array([1000], np.int32)
+    off = np.array([0, 8], np.int32)
+    pos = np.array([1000, 1000 + 0x7fe, 1000 + 0x7fe + 0x7ff, 5100, 5101, 5102, 5103, 5104], np.int32)
+    ln = np.array([15, -16, 3, 16, -17, -1, 1, -16], np.int32)
+    d16, rio = np.zeros(8, np.uint16), np.zeros(2, np.int32)
+    bi, bp, bl = (np.zeros(8, np.int32) for _ in range(3))
+    nb = C.c_int64()
+    assert L.nc_indel_events_pack(1, _lib.npp(start), _lib.npp(off), _lib.npp(pos), _lib.npp(ln), _lib.npp(d16), None, _lib.npp(rio), 8,
+                                  _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nb)) == _lib.NC_OK
+    assert nb.value == 3 and bi[:3].tolist() == [2, 3, 4] and bl[:3].tolist() == [3, 16, -17]            # distance 0x7ff; lengths beyond 5 bits
+    raw = d16.astype(np.int64)
+    assert raw[[2, 3, 4]].tolist() == [0xFFFF] * 3
+    keep = [0, 1, 5, 6, 7]
+    assert (raw[keep] & 0x7ff).tolist() == [0, 0x7fe, 1, 1, 1] and (((raw[keep] >> 11) ^ 16) - 16).tolist() == [15, -16, -1, 1, -16]
+    assert rio.tolist() == [0, 15 + 3 + 16 + 1]
 
 
 def test_degenerate_worlds():
@@ -143,9 +214,10 @@ def eng():
 def test_wire_expand_on_device_equals_direct_pack(eng, name, supp, excl, tile):
     import torch
     from nanocaller_amd.wire import WireUploader, upload_wire
-    w = load_world(name)
+    w = _consistent_deletions(load_world("indel")) if name == "indel_consistent" else load_world(name)
     a = eng.upload(pack_world(w, supplementary=supp, exclude=excl, tile_size=tile))
     wp = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile)
+    assert bool(((wp.meta or {}).get("indel_events") or {}).get("del_implied")) == (name == "indel_consistent")     # (then nc_wire_apply_deletions completes the codes)
     b = upload_wire(eng, wp)
     up = WireUploader(eng)
     t = up.submit(wp)

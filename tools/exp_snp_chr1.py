@@ -57,3 +57,20 @@ pr.disable()
 torch.cuda.synchronize()
 print("pipelined: %.1f ms per step" % ((time.perf_counter() - t0) / 5 * 1e3))
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+# bench.run_pairs, SNP half alone (configs[2]'s `snp_ms`), with and without the host thread's VCF text
+u = [bench.PairUnit(c, None, chunks, "chr1")]
+for label, patch in (("with VCF text on the host thread", None), ("without host text", lambda *a: 0)):
+    orig = bench._pair_host_half
+    if patch:
+        bench._pair_host_half = patch
+    bench.run_pairs(up, 0, params, u, 3, True, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bench.run_pairs(up, 0, params, u, 8, True, False)
+    torch.cuda.synchronize()
+    print("run_pairs SNP alone, %s: %.1f ms per step" % (label, (time.perf_counter() - t0) / 8 * 1e3), flush=True)
+    bench._pair_host_half = orig
+t0 = time.perf_counter()
+n = u[0].snp_text(r)
+print("snp_text of one chr1-sized result: %.1f ms, %d bytes" % ((time.perf_counter() - t0) * 1e3, n))
