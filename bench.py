@@ -243,7 +243,8 @@ def run_units(eng, uploader, contigs, n_units, params, chunks, local, overlap=Tr
     """n_units passes of the hot path over contigs[i % len(contigs)], each enqueued behind the previous one's CNN, every
     upload enqueued one unit ahead on the upload stream.  -> (total sites, last result)"""
     from nanocaller_amd import snpCaller
-    total, prev, r = 0, None, None
+    total, r = 0, None
+    pend, depth = [], (2 if os.environ.get("NC_PIPE_CNN", "0") == "1" else 1)
     nc = len(contigs)
     nxt = None if resident else uploader.submit(contigs[0].wire)
     for i in range(n_units):
@@ -260,15 +261,17 @@ def run_units(eng, uploader, contigs, n_units, params, chunks, local, overlap=Tr
         if t is not None:
             uploader.release(t)
         if overlap:
-            if prev is not None:
-                r = prev.result()
+            # results are collected `depth` units behind: a pipelined call_chunks enqueues unit i's CNN inside unit i + 1's scan, so waiting for
+            # unit i - 1's results right here would hold back the call that enqueues the device's next work
+            pend.append(cur)
+            if len(pend) > depth:
+                r = pend.pop(0).result()
                 total += int(r["n"])
-            prev = cur
         else:
             r = cur
             total += int(r["n"])
-    if overlap and prev is not None:
-        r = prev.result()
+    while pend:
+        r = pend.pop(0).result()
         total += int(r["n"])
     return total, r
 
@@ -711,7 +714,8 @@ def run_pairs(uploader, local, params, units, n_steps, snp_half=True, indel_half
 
     def enqueue_snp(u, tk):
         dpk = uploader.expand(tk)
-        c = snpCaller.call_chunks(params, u.chunks, device=local, dpk=dpk, defer=True)
+        # (the indel pass follows this SNP half on the device: its CNN goes out now, not inside the next SNP half's scan)
+        c = snpCaller.call_chunks(params, u.chunks, device=local, dpk=dpk, defer=True, pipeline=False if indel_half else None)
         uploader.release(tk)
         return c
     with ThreadPoolExecutor(max_workers=1) as pool:

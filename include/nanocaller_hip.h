@@ -33,7 +33,7 @@ extern "C" {
                               10: nc_bgzf_crc_device (CRC-32 of the device-inflated members);
                               11: nc_snp_trunk_info (which SNP trunk kernel the next nc_snp_forward runs, its MFMA count per site), nc_wire_build_del +
                                   nc_wire_apply_deletions (deleted columns implied by the indel events), nc_wire_ref_unpack (reference bytes two per byte), two-byte
-                                  indel events (nc_indel_events_pack / _expand with l8 = NULL) */
+                                  indel events (nc_indel_events_pack / _expand with l8 = NULL), nc_snp_scan_begin / _end */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -274,6 +274,17 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack,
                 int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params,
                 int32_t n_chunks, const int32_t *chunk_start_host, const int32_t *chunk_end_host,
                 int32_t *n_nbr, int32_t *n_cand, int32_t *n_sites);
+
+/* The same scan in two halves (ABI 11): nc_snp_scan_begin enqueues every kernel up to the candidate compaction plus the copy of the three totals into the
+ * context's pinned mailbox and returns without waiting; nc_snp_scan_end waits for that copy alone (an event, not the stream), then sizes and
+ * launches what depends on the totals and returns the counts.  Work enqueued between the two runs on: snpCaller.call_chunks puts the PREVIOUS
+ * contig's CNN there, so the host's round trip for the totals is hidden under it (the reference's per-chunk loop has no such step:
+ * snpCaller.py:83-87).  One scan per context may be open; nc_snp_scan = begin + end. */
+int nc_snp_scan_begin(nc_ctx *ctx, const nc_readpack *pack,
+                      const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                      int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params,
+                      int32_t n_chunks, const int32_t *chunk_start_host, const int32_t *chunk_end_host);
+int nc_snp_scan_end(nc_ctx *ctx, int32_t *n_nbr, int32_t *n_cand, int32_t *n_sites);
 
 /* Copies the scan results of the context to host arrays (any may be NULL):
  * nbr_pos[n_nbr]; per site (n_sites, chunk-major then ascending position): pos, chunk id,

@@ -34,7 +34,7 @@ STAR_SCORING = (25, 1, 20, -10)
 EXPORTS = [
     "nc_abi_version", "nc_device_count", "nc_ctx_create", "nc_ctx_destroy", "nc_ctx_set_stream", "nc_ctx_sync",
     "nc_last_error", "nc_malloc", "nc_free", "nc_memcpy_h2d", "nc_memcpy_d2h", "nc_last_kernel_ms",
-    "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_fetch", "nc_snp_featurize",
+    "nc_enable_timing", "nc_pack_plan", "nc_pack_fill", "nc_snp_scan", "nc_snp_scan_begin", "nc_snp_scan_end", "nc_snp_scan_fetch", "nc_snp_featurize",
     "nc_snp_scale", "nc_load_weights", "nc_snp_forward", "nc_indel_forward", "nc_indel_tensor", "nc_indel_scan",
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
@@ -157,6 +157,8 @@ def lib():
         L.nc_pack_fill.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, vp, vp, i64]
         L.nc_snp_scan.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, C.POINTER(ScanParamsC), i32, vp, vp,
                                   C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.nc_snp_scan_begin.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, C.POINTER(ScanParamsC), i32, vp, vp]
+        L.nc_snp_scan_end.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.nc_snp_scan_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
         L.nc_snp_scan_fetch_async.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.nc_snp_featurize.argtypes = [vp, C.POINTER(ReadPackC), vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]

@@ -79,6 +79,10 @@ struct nc_ctx {
     // memory directly, NOT through hipMemcpyAsync: on this platform every hipMemcpyAsync of either direction queues in order
     // behind a large H2D copy in flight (7 ms for a contig's wire pack), measured with tools/exp_sdma.py.
     int32_t *mbox = nullptr;       // pinned host, 64 int32: scan totals
+    // nc_snp_scan_begin .. nc_snp_scan_end
+    bool scan_begun = false;
+    int scan_tile = 0, scan_n_tiles = 0, scan_n_chunks = 0, scan_cap_nbr = 0, scan_cap_cand = 0;
+    hipEvent_t scan_tot_ev = nullptr;          // recorded behind the copy of the totals into the mailbox
     uint8_t *stage_h = nullptr;    // pinned host ring for small host -> device arrays (chunk bounds)
     int stage_turn = 0;
 };

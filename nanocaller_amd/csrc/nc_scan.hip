@@ -321,10 +321,31 @@ int nc_selftest_device(nc_ctx *ctx)
 
 extern "C" {
 
-int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
-                int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params, int32_t n_chunks,
-                const int32_t *chunk_start_host, const int32_t *chunk_end_host, int32_t *n_nbr, int32_t *n_cand,
-                int32_t *n_sites)
+// The scan in two halves (round 6): nc_snp_scan_begin enqueues every kernel up to the candidate compaction and the copy of the totals into the pinned
+// mailbox and returns WITHOUT waiting; nc_snp_scan_end waits for that copy alone (an event, not the stream), sizes and launches what depends on the
+// totals.  A caller may enqueue other work between the two (the previous contig's CNN: the host's round trip for the totals then runs under it
+// instead of beside an idle GPU).  nc_snp_scan = begin + end.
+static int scan_compact(nc_ctx *ctx, int cap_nbr, int cap_cand)
+{
+    const int tile = ctx->scan_tile, n_tiles = ctx->scan_n_tiles, n_chunks = ctx->scan_n_chunks;
+    hipLaunchKernelGGL(k_compact, dim3(n_tiles), dim3(256), 0, ctx->stream, tile, (int2 *)ctx->tile_cnt.p, (const int2 *)ctx->tile_pre.p,
+                       (int32_t *)ctx->stage_nbr.p, (int32_t *)ctx->stage_cpos.p, (int32_t *)ctx->stage_cn.p, (int32_t *)ctx->stage_calt.p,
+                       (int32_t *)ctx->nbr_pos.p, (int32_t *)ctx->cand_pos.p, (int32_t *)ctx->cand_n.p, (int32_t *)ctx->cand_alt.p, cap_nbr, cap_cand);
+    NC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->cand_pos.p, cap_cand,
+                       (const int32_t *)ctx->chunk_start.p, (const int32_t *)ctx->chunk_end.p, (int32_t *)ctx->chunk_lo.p,
+                       (int32_t *)ctx->chunk_cnt.p, (int32_t *)ctx->chunk_off.p, n_chunks, (int32_t *)ctx->totals.p);
+    NC_HIP(ctx, hipGetLastError());
+    NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
+    if (!ctx->scan_tot_ev) NC_HIP(ctx, hipEventCreateWithFlags(&ctx->scan_tot_ev, hipEventDisableTiming));
+    NC_HIP(ctx, hipEventRecord(ctx->scan_tot_ev, ctx->stream));
+    return NC_OK;
+}
+static int cap_of(const DevBuf &b) { return (int)std::min<size_t>(b.cap / 4, (size_t)INT32_MAX); }
+
+int nc_snp_scan_begin(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                      int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params, int32_t n_chunks,
+                      const int32_t *chunk_start_host, const int32_t *chunk_end_host)
 {
     if (!ctx) return NC_ERR_ARG;
     if (!pack || !ref_code_dev || !params || n_chunks <= 0 || !chunk_start_host || !chunk_end_host)
@@ -340,6 +361,7 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     if (scan_hi < scan_lo) return nc_fail(ctx, NC_ERR_ARG, "nc_snp_scan: empty scan range");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     ctx->have_scan = false;
+    ctx->scan_begun = false;
     const int64_t npos = (int64_t)pack->n_tiles * tile;
     NC_TRY(nc_ensure(ctx, ctx->stage_nbr, npos * 4));
     NC_TRY(nc_ensure(ctx, ctx->stage_cpos, npos * 4));
@@ -385,45 +407,51 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, ctx->stream, tc, (int2 *)ctx->tile_pre.p, pack->n_tiles,
                        (int32_t *)ctx->totals.p);
     NC_HIP(ctx, hipGetLastError());
+    ctx->scan_tile = tile;
+    ctx->scan_n_tiles = pack->n_tiles;
+    ctx->scan_n_chunks = n_chunks;
     volatile int32_t *tot = ctx->mbox;                           // pinned mailbox: the totals arrive through a copy kernel
-    auto compact_and_ranges = [&](int cap_nbr, int cap_cand) -> int {
-        hipLaunchKernelGGL(k_compact, dim3(pack->n_tiles), dim3(256), 0, ctx->stream, tile, tc, (const int2 *)ctx->tile_pre.p, sn,
-                           sc, scn, sca, (int32_t *)ctx->nbr_pos.p, (int32_t *)ctx->cand_pos.p, (int32_t *)ctx->cand_n.p,
-                           (int32_t *)ctx->cand_alt.p, cap_nbr, cap_cand);
-        NC_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->cand_pos.p, cap_cand,
-                           (const int32_t *)ctx->chunk_start.p, (const int32_t *)ctx->chunk_end.p, (int32_t *)ctx->chunk_lo.p,
-                           (int32_t *)ctx->chunk_cnt.p, (int32_t *)ctx->chunk_off.p, n_chunks, (int32_t *)ctx->totals.p);
-        NC_HIP(ctx, hipGetLastError());
-        NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
-        NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return NC_OK;
-    };
-    auto cap_of = [](const DevBuf &b) { return (int)std::min<size_t>(b.cap / 4, (size_t)INT32_MAX); };
-    int cap_nbr = cap_of(ctx->nbr_pos), cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
-    bool known = false;
-    if (cap_nbr == 0 || cap_cand == 0) {
+    ctx->scan_cap_nbr = cap_of(ctx->nbr_pos);
+    ctx->scan_cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
+    if (ctx->scan_cap_nbr == 0 || ctx->scan_cap_cand == 0) {
         // first scan of this context: one round trip for the totals that size the outputs
         NC_TRY(nc_d2h(ctx, ctx->mbox, ctx->totals.p, 16, ctx->stream));
         NC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        known = true;
+        NC_TRY(nc_ensure(ctx, ctx->nbr_pos, (size_t)(tot[0] + 1) * 4));
+        NC_TRY(nc_ensure(ctx, ctx->cand_pos, (size_t)(tot[1] + 1) * 4));
+        NC_TRY(nc_ensure(ctx, ctx->cand_n, (size_t)(tot[1] + 1) * 4));
+        NC_TRY(nc_ensure(ctx, ctx->cand_alt, (size_t)(tot[1] + 1) * 4));
+        ctx->scan_cap_nbr = cap_of(ctx->nbr_pos);
+        ctx->scan_cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if (known) {
-            NC_TRY(nc_ensure(ctx, ctx->nbr_pos, (size_t)(tot[0] + 1) * 4));
-            NC_TRY(nc_ensure(ctx, ctx->cand_pos, (size_t)(tot[1] + 1) * 4));
-            NC_TRY(nc_ensure(ctx, ctx->cand_n, (size_t)(tot[1] + 1) * 4));
-            NC_TRY(nc_ensure(ctx, ctx->cand_alt, (size_t)(tot[1] + 1) * 4));
-            cap_nbr = cap_of(ctx->nbr_pos);
-            cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
-        }
-        // otherwise: the outputs of the previous scan (a quarter larger than its totals) are reused without asking first --
-        // ONE host round trip per scan; the kernels never write past the capacities
-        NC_TRY(compact_and_ranges(cap_nbr, cap_cand));
-        if (tot[0] <= cap_nbr && tot[1] <= cap_cand) break;
-        if (attempt == 1) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan: outputs still too small after regrowth");
-        known = true;                                                // they did not fit: grow and repeat (rare)
+    // otherwise: the outputs of the previous scan (a quarter larger than its totals) are reused without asking first -- ONE host round trip per scan,
+    // taken in nc_snp_scan_end; the kernels never write past the capacities
+    NC_TRY(scan_compact(ctx, ctx->scan_cap_nbr, ctx->scan_cap_cand));
+    ctx->scan_begun = true;
+    return NC_OK;
+}
+
+int nc_snp_scan_end(nc_ctx *ctx, int32_t *n_nbr, int32_t *n_cand, int32_t *n_sites)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!ctx->scan_begun) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan_end: no nc_snp_scan_begin on this context");
+    ctx->scan_begun = false;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    volatile int32_t *tot = ctx->mbox;
+    NC_HIP(ctx, hipEventSynchronize(ctx->scan_tot_ev));          // the totals' copy alone: work enqueued behind it keeps running
+    if (!(tot[0] <= ctx->scan_cap_nbr && tot[1] <= ctx->scan_cap_cand)) {
+        // they did not fit: grow and repeat the compaction (rare)
+        NC_TRY(nc_ensure(ctx, ctx->nbr_pos, (size_t)(tot[0] + 1) * 4));
+        NC_TRY(nc_ensure(ctx, ctx->cand_pos, (size_t)(tot[1] + 1) * 4));
+        NC_TRY(nc_ensure(ctx, ctx->cand_n, (size_t)(tot[1] + 1) * 4));
+        NC_TRY(nc_ensure(ctx, ctx->cand_alt, (size_t)(tot[1] + 1) * 4));
+        ctx->scan_cap_nbr = cap_of(ctx->nbr_pos);
+        ctx->scan_cap_cand = std::min(cap_of(ctx->cand_pos), std::min(cap_of(ctx->cand_n), cap_of(ctx->cand_alt)));
+        NC_TRY(scan_compact(ctx, ctx->scan_cap_nbr, ctx->scan_cap_cand));
+        NC_HIP(ctx, hipEventSynchronize(ctx->scan_tot_ev));
+        if (!(tot[0] <= ctx->scan_cap_nbr && tot[1] <= ctx->scan_cap_cand)) return nc_fail(ctx, NC_ERR_STATE, "nc_snp_scan: outputs still too small after regrowth");
     }
+    const int32_t n_chunks = ctx->scan_n_chunks;
     ctx->n_nbr = tot[0];
     ctx->n_cand = tot[1];
     ctx->n_sites = tot[2];
@@ -449,6 +477,15 @@ int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_de
     if (n_cand) *n_cand = tot[1];
     if (n_sites) *n_sites = tot[2];
     return NC_OK;
+}
+
+int nc_snp_scan(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_code_dev, int32_t ref_pos0, int32_t ref_len,
+                int32_t scan_lo, int32_t scan_hi, const nc_scan_params *params, int32_t n_chunks,
+                const int32_t *chunk_start_host, const int32_t *chunk_end_host, int32_t *n_nbr, int32_t *n_cand,
+                int32_t *n_sites)
+{
+    const int rc = nc_snp_scan_begin(ctx, pack, ref_code_dev, ref_pos0, ref_len, scan_lo, scan_hi, params, n_chunks, chunk_start_host, chunk_end_host);
+    return rc != NC_OK ? rc : nc_snp_scan_end(ctx, n_nbr, n_cand, n_sites);
 }
 
 static int scan_fetch(nc_ctx *ctx, hipStream_t st, bool wait, int32_t *nbr_pos, int32_t *site_pos, int32_t *site_chunk, int32_t *site_n,

@@ -205,8 +205,9 @@ class Engine:
         self._loaded[kind] = w.path
 
     # ------------------------------------------------------------------ K1
-    def snp_scan(self, dp: DevicePack, chunks, *, mincov, min_allele_freq, threshold, haploid=False, async_fetch=False) -> SnpSites:
-        """chunks: list of (start, end) inclusive, same contig, ascending."""
+    def snp_scan(self, dp: DevicePack, chunks, *, mincov, min_allele_freq, threshold, haploid=False, async_fetch=False, between=None) -> SnpSites:
+        """chunks: list of (start, end) inclusive, same contig, ascending.  `between` (callable): run after the scan's kernels are enqueued and before
+        the host waits for the scan's totals (nc_snp_scan_begin / _end): what it enqueues keeps the GPU busy during that round trip."""
         cs = np.ascontiguousarray([c[0] for c in chunks], np.int32)
         ce = np.ascontiguousarray([c[1] for c in chunks], np.int32)
         scan_lo = max(1, int(cs.min()) - _lib.FLANK)
@@ -216,10 +217,12 @@ class Engine:
         params = _lib.ScanParamsC(mincov=int(mincov), min_allele_freq=float(min_allele_freq), nbr_t0=float(threshold[0]),
                                   nbr_t1=float(threshold[1]), haploid=1 if haploid else 0)
         pc = dp.c_struct()
+        self._check(self.L.nc_snp_scan_begin(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(), scan_lo,
+                                             scan_hi, C.byref(params), len(chunks), _lib.npp(cs), _lib.npp(ce)), "nc_snp_scan_begin")
+        if between is not None:
+            between()                                                # enqueued behind the scan's kernels, ahead of the host's wait for its totals
         n_nbr, n_cand, n_sites = C.c_int32(), C.c_int32(), C.c_int32()
-        self._check(self.L.nc_snp_scan(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(), scan_lo,
-                                       scan_hi, C.byref(params), len(chunks), _lib.npp(cs), _lib.npp(ce), C.byref(n_nbr),
-                                       C.byref(n_cand), C.byref(n_sites)), "nc_snp_scan")
+        self._check(self.L.nc_snp_scan_end(self.ctx, C.byref(n_nbr), C.byref(n_cand), C.byref(n_sites)), "nc_snp_scan_end")
         N = n_sites.value
         # pinned host buffers (cached by torch's host allocator): the four copies run at PCIe speed, one sync
         hb, h = self._pinned.get((4, max(N, 1)), torch.int32)

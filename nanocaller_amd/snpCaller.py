@@ -191,13 +191,30 @@ class PendingCall:
         return self._res
 
 
-def call_chunks(params, chunks, device=0, dpk=None, defer=False):
+_PENDING_CNN = {}                  # device -> the CNN launch of the previous deferred call_chunks (enqueued inside the next call's scan, or on demand)
+
+
+def flush_pending_cnn(device=0):
+    """enqueue the CNN a pipelined call_chunks left pending on `device` (no-op when there is none)"""
+    f = _PENDING_CNN.pop(device, None)
+    if f is not None:
+        f()
+
+
+def call_chunks(params, chunks, device=0, dpk=None, defer=False, pipeline=None):
     """Run pileup featurisation + CNN for a list of chunks of ONE contig and ploidy on the GPU.
     `dpk`: alignments already resident in HBM (engine.DevicePack); default: packed from params['sam_path'].
     -> dict of host arrays (pos, chunk, ref, probs, gt, dp, freq, fwd_dp, rev_dp, chunk_depth).
-    defer=True -> PendingCall: returns once the CNN is enqueued; the caller starts the next group (its scan queues right
-    behind this group's CNN, so the GPU does not idle while results drain and the host turns around) and collects
-    result() afterwards."""
+    defer=True -> PendingCall: returns once the group's work is handed over; the caller starts the next group and collects result() afterwards.
+    pipeline (NC_PIPE_CNN=1; OFF by default): this group's CNN is not enqueued by this call but INSIDE the next call's scan (nc_snp_scan_begin ->
+    the pending CNN -> nc_snp_scan_end), or by result() / flush_pending_cnn() if no call follows: the host's round trip for the next scan's totals
+    (~0.2 ms) then runs under 8 ms of CNN instead of beside an idle GPU.  Device order scan(k+1), CNN(k), tensors(k+1),
+    scan(k+2), CNN(k+1) ...; same results.  Measured: 10.55 -> 11.2 ms per contig (the scan's and the featuriser's result copies -- blit kernels on this
+    platform -- then collide with the trunk instead of running in the gap they filled): not the default (profiles/README.md, round 6)."""
+    if pipeline is None:
+        pipeline = bool(defer) and os.environ.get('NC_PIPE_CNN', '0') == '1'
+    if not pipeline:
+        flush_pending_cnn(device)                                    # keep the device order of calls that do not take part
     chrom = chunks[0]['chrom']
     ploidy = chunks[0]['ploidy']
     assert all(c['chrom'] == chrom and c['ploidy'] == ploidy for c in chunks)
@@ -222,7 +239,7 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     # featuriser's per-site arrays during the CNN, and every CNN batch's probabilities while the next batch runs.
     sites = eng.snp_scan(dpk, [(c['start'], c['end']) for c in chunks], mincov=params['mincov'],
                          min_allele_freq=params['min_allele_freq'], threshold=params['threshold'],
-                         haploid=(ploidy == 'haploid'), async_fetch=True)
+                         haploid=(ploidy == 'haploid'), async_fetch=True, between=(lambda: flush_pending_cnn(device)) if pipeline else None)
     res = dict(chrom=chrom, ploidy=ploidy, n=0)
     if sites.n_sites == 0:
         eng.wait_copies()
@@ -240,19 +257,39 @@ def call_chunks(params, chunks, device=0, dpk=None, defer=False):
     # range guard of the split-precision trunk (nc_cnn_range_watch): sites whose scaled tensor exceeds what the model's weights prove
     # safe for the fp16 range are marked and, in finish(), computed once more by the exact fp32 trunk
     guard = not getattr(eng, "exact_fp32", False)
-    flags = torch.zeros(sites.n_sites, dtype=torch.uint8, device=eng.device) if guard else None
-    d_probs, d_gt, h_probs, h_gt = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0, drain=True,
-                                                   range_flags=flags)
-    h_nflag = eng.to_host_async([flags.sum(dtype=torch.int32).reshape(1)])[0] if guard else None
+    i16 = not getattr(eng, "exact_fp32", False)
     eng.set_tensor_format(int16=False)                             # the direct API keeps the reference's float32 default
-    drained = eng.copy_event()                                     # completes with this call's last result copy
+    cnn = {}                                                       # filled when the CNN is enqueued: now, or inside the next call's scan
+
+    def enqueue_cnn():
+        eng.use_torch_stream()
+        eng.set_tensor_format(int16=i16)
+        try:
+            flags_ = torch.zeros(sites.n_sites, dtype=torch.uint8, device=eng.device) if guard else None
+            cnn['d_probs'], cnn['d_gt'], cnn['h_probs'], cnn['h_gt'] = eng.snp_forward(kind, sites.x, sites.ref_code, scale, scale_mode=1 if per_site else 0,
+                                                                                   drain=True, range_flags=flags_)
+            cnn['flags'] = flags_
+            cnn['h_nflag'] = eng.to_host_async([flags_.sum(dtype=torch.int32).reshape(1)])[0] if guard else None
+        finally:
+            eng.set_tensor_format(int16=False)
+        cnn['drained'] = eng.copy_event()                          # completes with this call's last result copy
+    if pipeline:
+        _PENDING_CNN[device] = enqueue_cnn
+    else:
+        enqueue_cnn()
     # host work that only needs the scan results runs under the CNN: freq = alt / n in float64 (:166)
     scan_copied.synchronize()
     freq = sites.alt.astype(np.float64) / sites.dp.astype(np.float64)
-    keep_alive = (sites, scale, d_probs, d_gt)                     # device buffers the pending copies read from
+    keep_alive = (sites, scale, cnn)                               # device buffers the pending copies read from
 
     def finish():
         nonlocal keep_alive
+        if 'drained' not in cnn:                                   # nobody enqueued this group's CNN yet (no call followed): now
+            if _PENDING_CNN.get(device) is enqueue_cnn:
+                flush_pending_cnn(device)
+            else:
+                enqueue_cnn()
+        drained, h_nflag, flags, d_probs, d_gt, h_probs, h_gt = (cnn[k] for k in ('drained', 'h_nflag', 'flags', 'd_probs', 'd_gt', 'h_probs', 'h_gt'))
         drained.synchronize()
         n_rerun = int(h_nflag[0]) if h_nflag is not None else 0
         if n_rerun:
