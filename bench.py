@@ -883,6 +883,8 @@ def wgs_sharded_block(eng, uploader, local, model, rank, world, barrier, scale=1
     dist.all_gather(allt, mine_t)
     rows = [[float(v) for v in t_] for t_ in allt]
     times = [r_[0] for r_ in rows]
+    del units
+    torch.cuda.empty_cache()
     job_dt = dist_max(dt)
     total = dist_sum(ns + ni)
     return {"workload": "configs[3]: %d contigs at GRCh38 lengths x %g (%d bp) sharded over %d ranks by shard_plan, SNP + indel halves" % (len(spec), scale, sum(L for _, L in spec), world),
