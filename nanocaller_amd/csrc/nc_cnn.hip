@@ -2163,7 +2163,10 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
 // A workgroup owns 64 sites (4 position... site tiles of 16) so that every weight fragment read from L2 feeds 4 MFMAs per
 // product; the four waves split K and combine through LDS.  The fp32 activations are split into fp16 hi/lo on load (each
 // lane reads the 8 K values of its site as two dwordx4: the four lane groups of a site cover one 128-byte line).
-constexpr int FC_K = 1728, FC_G = FC_K / 32, FC_TM = 4, FC_TN = 3;
+#ifndef NC_FC_TM
+#define NC_FC_TM 4
+#endif
+constexpr int FC_K = 1728, FC_G = FC_K / 32, FC_TM = NC_FC_TM, FC_TN = 3;
 constexpr int FC_PACKED_BYTES = 2 * FC_G * FC_TN * T_FRAG * 2 + 4 * 64;        // hi + lo fragments, then b*S[48], 1/S
 __device__ __forceinline__ void split8(const float4 &a, const float4 &b, h8 &hi, h8 &lo)
 {

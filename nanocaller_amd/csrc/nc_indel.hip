@@ -1150,8 +1150,15 @@ int nc_indel_scan_group_launch(nc_ctx *ctx, const nc_readpack *pack, const nc_in
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) mfree = (size_t)72 << 30;
         const size_t avail = mfree + ctx->indel_ws.cap;
-        if (ctx->k7_budget == 0) ctx->k7_budget = std::min<size_t>((size_t)24 << 30, std::max<size_t>((size_t)6 << 30, avail / 12));
-        if (ctx->k7_budget > avail / 2) ctx->k7_budget = std::max<size_t>((size_t)256 << 20, avail / 2);
+        const size_t want = std::min<size_t>((size_t)24 << 30, std::max<size_t>((size_t)6 << 30, avail / 12));
+        if (ctx->k7_budget == 0 || (ctx->k7_budget_shrunk && want <= avail / 2)) {      // first plan, or memory has been freed since a low moment
+            ctx->k7_budget = want;
+            ctx->k7_budget_shrunk = false;
+        }
+        if (ctx->k7_budget > avail / 2) {
+            ctx->k7_budget = std::max<size_t>((size_t)256 << 20, avail / 2);
+            ctx->k7_budget_shrunk = true;
+        }
     }
     const size_t BUDGET = ctx->k7_budget;
     ck.clear();

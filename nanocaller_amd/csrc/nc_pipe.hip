@@ -267,12 +267,16 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const int32_t *__restrict__
     }
 }
 
+constexpr int SC_PARTS = 65536;
 template <int F, class OUT>
 static int scan_launch(nc_ctx *ctx, hipStream_t st, DevBuf &partbuf, const int32_t *in, int32_t n, int32_t add, OUT *out, bool write_total, int32_t *total_mbox,
                        long long *base_io)
 {
     const int nb = std::max(1, (n + SC_TILE - 1) / SC_TILE);
-    NC_TRY(nc_ensure(ctx, partbuf, ((size_t)nb + 2) * 8));
+    // the partial-sum buffers are sized ONCE per pass (nc_indel_sites_plan: SC_PARTS entries): launches queued on another stream may still read
+    // them, so a scan never re-allocates -- an array too long for them is refused
+    if (((size_t)nb + 2) * 8 > partbuf.cap)
+        return nc_fail(ctx, NC_ERR_CAPACITY, "scan of %d elements needs %d partial sums, the pass holds %zu", n, nb + 2, partbuf.cap / 8);
     long long *part = (long long *)partbuf.p;
     hipLaunchKernelGGL((k_scan_part<F>), dim3(nb), dim3(1024), 0, st, in, n, add, part, (const long long *)base_io);
     hipLaunchKernelGGL((k_scan_apply<F, OUT>), dim3(nb), dim3(1024), 0, st, in, n, add, (const long long *)part, out, write_total ? 1 : 0, total_mbox, base_io);
@@ -2513,8 +2517,8 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
         NC_HIP(ctx, hipGetLastError());
         c0 += used;                                                   // (the next group's K7 reuses the workspace in stream order)
     }
-    NC_TRY(nc_ensure(ctx, s->part_a, 8 * 8192));                      // (sized once: the scans never re-allocate between launches of a pass)
-    NC_TRY(nc_ensure(ctx, s->part_b, 8 * 8192));
+    NC_TRY(nc_ensure(ctx, s->part_a, 8 * SC_PARTS));                  // (sized once: the scans never re-allocate between launches of a pass; SC_PARTS x SC_TILE
+    NC_TRY(nc_ensure(ctx, s->part_b, 8 * SC_PARTS));                  // = 268 M elements per scan, beyond any array of a pass)
     NC_TRY((scan_launch<SC_PLAIN, int32_t>(ctx, ctx->stream, s->part_a, (const int32_t *)s->cnt.p, n_chunks, 0, (int32_t *)s->off.p, true, nullptr, nullptr)));
     // counts the host waits for travel by copy kernel into the context's page-locked mailbox (a hipMemcpyAsync of either direction
     // queues behind a contig's upload in flight on this platform: DESIGN.md section 2)

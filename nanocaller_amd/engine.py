@@ -141,6 +141,17 @@ class Engine:
             s = self._tstream
         self._check(self.L.nc_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)), "nc_ctx_set_stream")
 
+    def _adopt_thread(self):
+        """get_engine() from a thread that meets this engine for the first time: a thread on the legacy default stream is moved to the engine's own torch
+        stream (one hardware queue); the CONTEXT's launch stream is left alone (get_engine used to call use_torch_stream(), which rewrites
+        the shared ctx->stream -- a worker thread could retarget another thread's launches between its `with torch.cuda.stream(...)` and its kernel).
+        Only an explicit use_torch_stream() retargets the context."""
+        import os
+        s = torch.cuda.current_stream(self.device)
+        if s.cuda_stream == 0 and os.environ.get("NC_ONE_QUEUE", "1") != "0" and getattr(self, "_tstream", None) is not None:
+            self._tstream.wait_stream(s)
+            torch.cuda.set_stream(self._tstream)
+
     def set_cnn_precision(self, exact_fp32: bool):
         """False (default): fp16x3 split-precision trunk; True: exact fp32 MFMA trunk."""
         self._check(self.L.nc_set_cnn_precision(self.ctx, 1 if exact_fp32 else 0), "nc_set_cnn_precision")
@@ -559,7 +570,7 @@ def get_engine(device: int = 0) -> Engine:
     if device not in _engines:
         _engines[device] = Engine(device)
     else:
-        _engines[device].use_torch_stream()              # (a thread that meets the engine for the first time is moved to its stream)
+        _engines[device]._adopt_thread()                 # (a thread that meets the engine for the first time is moved to its stream; ctx->stream untouched)
     return _engines[device]
 
 

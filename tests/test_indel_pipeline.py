@@ -649,7 +649,8 @@ def test_banded_allele_alignments_certify_themselves_or_run_on_the_full_matrix(m
     """allele_prediction's global alignment (exact in the reference: parasail nw_trace, generate_indel_pileups.py:79) runs on a band only where the
     band proves itself: the score of the banded path must exceed what any path that leaves the band can reach (allele_trace_body's bound), else
     the set is re-run on the full matrix.  Every REF / ALT of 8 Mb of the bench workload equals the all-full-matrix run (NC_PIPE_BAND_ALLELES=0),
-    with the band of the STAR alignment switched off in both runs so that the consensus strings are the same"""
+    with the STAR alignment on its default band in both runs (only NC_PIPE_BAND_ALLELES differs), so that the consensus strings the alleles are read
+    from are the same"""
     from nanocaller_amd.engine import get_engine
     from nanocaller_amd.synth_device import make_indel_device_workload
     eng = get_engine(0)
