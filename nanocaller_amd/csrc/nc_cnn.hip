@@ -1927,7 +1927,16 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
     __shared__ __attribute__((aligned(16))) _Float16 A1[2][2 * T_A1PLANE];
     __shared__ __attribute__((aligned(16))) _Float16 A2[2][2 * T_A2PLANE];
     __shared__ __attribute__((aligned(16))) float BIAS[48 + 32 + 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // role of a hardware wave (roles 0, 1: conv2; 2, 3: staging + conv3; 4..7: conv1 roles 0..3).  Waves w and w + 4 share a SIMD and the lower-numbered one
+    // is the older, which the issue arbiter prefers (MI355X_MICROARCH.md, two waves per SIMD): NC_LIN_PERM lists the role of hardware waves 0..7.
+#ifndef NC_LIN_PERM
+#define NC_LIN_PERM {2, 3, 4, 5, 6, 7, 0, 1}
+#endif
+    constexpr int LIN_PERM[8] = NC_LIN_PERM;
+    const int lane = threadIdx.x & 63, wv = LIN_PERM[threadIdx.x >> 6];
+#ifdef NC_LIN_PRIO                                                   // (experiment) static issue priority 1 for the roles whose bit is set
+    if ((NC_LIN_PRIO >> wv) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
     const uint4 *w1f = reinterpret_cast<const uint4 *>(wp), *w2h = w1f + T_NW1 * 64, *w2l = w2h + T_NW2 * 64, *w3h = w2l + T_NW2 * 64, *w3l = w3h + T_NW3 * 64;
     const uint4 *wlf = reinterpret_cast<const uint4 *>(wlin);
     const float *bg = reinterpret_cast<const float *>(w3l + T_NW3 * 64);
@@ -2038,7 +2047,7 @@ __global__ __launch_bounds__(512) void k5_trunk_lin(const int16_t *__restrict__ 
                 c3l[q][tn] = as_h8(w3l[(q * 4 + 2 * cw + tn) * 64 + lane]);
             }
         const int c3slot[2] = {c3tab[lane & 15], c3tab[16 + (lane & 15)]}, c3out[2] = {c3tab[32 + (lane & 15)], c3tab[48 + (lane & 15)]};
-        const int st = (int)threadIdx.x - 128;                                    // 0..127: pixels st and st + 128 (< 205) of the 5 x 41 image
+        const int st = (wv - 2) * 64 + lane;                                      // 0..127: pixels st and st + 128 (< 205) of the 5 x 41 image
         uint32_t raw[2][3];
         float pre_s = 1.0f;
         int64_t pre_site = 0;
