@@ -156,6 +156,7 @@ typedef struct {
     const int32_t *blk_read;    /* host [n_blocks] */
     const uint16_t *events;     /* host [n_events] */
     int64_t n_events;
+    const uint32_t *blk_ev;     /* host [n_blocks], nc_wire_build_del only (else NULL): see nc_wire_expand_del */
 } nc_wire_arrays;
 /* ref_wire[i] describes position ref_pos0 + i (ref_pos0 a multiple of 16: the tile grid's tile_pos0), i < ref_len;
  * positions outside predict code 4.  Other arguments as nc_pack_fill.  The result is owned by the library. */
@@ -164,10 +165,14 @@ int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, con
 int nc_wire_view(const nc_wire *w, nc_wire_arrays *view);
 int nc_wire_free(nc_wire *w);
 /* The same with a read pack that travels beside its indel events (nc_indel_events': ev_off [n_reads + 1] per read of the INPUT order, a negative
- * length -L at column c deletes columns c + 1 .. c + L): the deleted columns' code (4) is implied by the events and left out of the difference
- * events; nc_wire_apply_deletions (all pointers dev, the KEPT reads' tables and events in pack order, after nc_wire_expand and
- * nc_indel_events_expand, same stream) writes them back.  Both are this library's own transfer form: no reference counterpart (the reference
- * decodes per chunk with pysam, generate_indel_pileups.py:213-264). */
+ * length -L at column c deletes columns c + 1 .. c + L): in every block that lies inside ONE read and inside the reference grid the deleted columns'
+ * code (4) is implied by the read's events and left out of the difference events; blk_ev[b] = index, among the KEPT reads' events in pack order, of
+ * the read's first event whose run reaches the block (0xffffffff: not such a block).  nc_wire_expand_del = nc_wire_expand that writes those columns
+ * from d_ev_off / d_ev_pos / d_ev_len (dev, the kept reads' events, absolute: after nc_indel_events_expand on the same stream) in the block's LDS
+ * image, so the codes array is written once.  nc_wire_apply_deletions (all pointers dev) writes code 4 over EVERY deleted column of an expanded
+ * array: a separate pass with the same result (idempotent), kept for callers that expand without the events at hand.  NC_ERR_UNSUPPORTED from
+ * nc_wire_build_del: a deleted column of the input does not carry code 4 (build the plain form).  This library's own transfer form: no reference
+ * counterpart (the reference decodes per chunk with pysam, generate_indel_pileups.py:213-264). */
 /* ref_wire as it crosses PCIe since ABI 11: two positions per byte (position 2 i in the low nibble of byte i); nc_wire_ref_unpack (pointers dev, 16-byte
  * aligned) rebuilds the byte array nc_wire_expand reads, on the context's stream. */
 int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire);
@@ -182,6 +187,11 @@ int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, cons
                    const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
                    const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
                    uint8_t *d_ref_code);
+int nc_wire_expand_del(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                       const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                       const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                       uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos,
+                       const int32_t *d_ev_len);
 
 /* Transfer form of the indel path's per-read events (csrc/nc_wire.hip): 3 bytes per event instead of the 12 the kernels read.
  *   d16 [n_events]  column - column of the read's previous event (the first one: - rd_start[r]); 0xFFFF: the event is in the side table

@@ -32,6 +32,7 @@ struct nc_wire {
     std::vector<uint32_t> blk_off;
     std::vector<int32_t> blk_read;
     std::vector<uint16_t> events;
+    std::vector<uint32_t> blk_ev;    // nc_wire_build_del: per block the cursor into the kept reads' indel events (0xffffffff: nothing implied in this block)
     int64_t codes_len = 0;
 };
 
@@ -72,6 +73,13 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
         const int64_t n_blocks = (w->codes_len + WIRE_BLOCK - 1) / WIRE_BLOCK;
         w->blk_off.assign((size_t)n_blocks + 1, 0);
         w->blk_read.assign((size_t)n_blocks, 0);
+        std::vector<int64_t> kept_ev_off;                             // running event count of the kept reads (the order the events are uploaded in)
+        if (ev_off) {
+            w->blk_ev.assign((size_t)n_blocks, 0xffffffffu);
+            kept_ev_off.assign((size_t)n + 1, 0);
+            for (int64_t q = 0; q < n; q++) kept_ev_off[(size_t)q + 1] = kept_ev_off[(size_t)q] + (ev_off[orig[(size_t)q] + 1] - ev_off[orig[(size_t)q]]);
+            if (kept_ev_off[(size_t)n] >= 0xffffffffll) { delete w; return NC_ERR_CAPACITY; }
+        }
         int T = std::min(nc_host_cpus(), 32);
         if (n_blocks < 64) T = 1;
         std::vector<std::vector<uint16_t>> part((size_t)T);
@@ -95,7 +103,11 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                     const int64_t off0 = base - byte0;                                         // event offset of position p: off0 + p
                     // this read's deletion runs from p_lo on (events ascend): `covered(p)` for ascending p
                     int32_t de = 0, de1 = 0;
-                    if (ev_off) {
+                    // deleted columns are left out only in blocks that lie wholly inside ONE read and inside the reference grid (k_wire_expand's short
+                    // path: it applies that read's deletion events from the block's cursor); blocks with a read boundary keep them as events
+                    const int64_t pb = floor16w(s) + (byte0 - w->slot_off[(size_t)q]);        // position of the block's first byte in this read's frame
+                    const bool single = ev_off && q == r && pb >= s && pb + WIRE_BLOCK <= e && pb - ref_pos0 >= 0 && pb - ref_pos0 + WIRE_BLOCK <= ref_len;
+                    if (single) {
                         de = ev_off[orig[(size_t)q]];
                         de1 = ev_off[orig[(size_t)q] + 1];
                         // first event whose run can reach p_lo: runs are short, so the first event with column >= p_lo - 65536 would do; bisect on the column
@@ -105,8 +117,10 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                             if ((int64_t)ev_pos[mid] + (ev_len[mid] < 0 ? -(int64_t)ev_len[mid] : 0) < p_lo) lo = mid + 1; else hi = mid;
                         }
                         de = lo;
+                        w->blk_ev[(size_t)b] = (uint32_t)(kept_ev_off[(size_t)q] + (de - ev_off[orig[(size_t)q]]));
                     }
                     auto covered = [&](int64_t p) -> bool {
+                        if (!single) return false;
                         while (de < de1 && (ev_len[de] >= 0 || (int64_t)ev_pos[de] - (int64_t)ev_len[de] < p)) de++;
                         return de < de1 && (int64_t)ev_pos[de] < p;              // (de: first deletion whose last column c - len >= p)
                     };
@@ -131,7 +145,7 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                         while (m) {
                             const int k = __builtin_ctz(m);
                             m &= m - 1;
-                            if (src[p + k] == 4u && ev_off && covered(p + k)) continue;
+                            if (src[p + k] == 4u && single && covered(p + k)) continue;
                             ev.push_back((uint16_t)((off0 + p + k) | ((unsigned)src[p + k] << 12)));
                         }
                     }
@@ -144,7 +158,7 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                     for (; p < g_hi; p++) {
                         const unsigned c = src[p];
                         wmax = std::max(wmax, c);
-                        if (c != (rf[p] & 7u) && !(c == 4u && ev_off && covered(p))) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                        if (c != (rf[p] & 7u) && !(c == 4u && single && covered(p))) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
                     }
                     for (p = g_hi; p < p_hi; p++) {
                         const unsigned c = src[p];
@@ -231,6 +245,7 @@ extern "C" int nc_wire_view(const nc_wire *w, nc_wire_arrays *v)
     v->blk_read = w->blk_read.data();
     v->events = w->events.data();
     v->n_events = (int64_t)w->events.size();
+    v->blk_ev = w->blk_ev.empty() ? nullptr : w->blk_ev.data();
     return NC_OK;
 }
 
@@ -296,12 +311,18 @@ __device__ __noinline__ uint4 wire_group_general(int64_t B, int64_t r, int32_t n
 // inside the reference (8 of 10 blocks: reads are kilobases long) takes the short path -- one dwordx4 of ref_wire per lane from a
 // scalar base, masked, into LDS.  Only blocks with a read boundary or a reference edge run the per-lane general form.  U blocks
 // per wave: the scalar loads of all of them are issued before the first is used.
-template <int U>
+// DEL (round 6): the pack travels with its indel events and the builder left the deleted columns of single-read blocks out of the difference events
+// (nc_wire_build_del): such a block writes them into its LDS image from the read's own deletion events (absolute ev_pos / ev_len, expanded before this
+// kernel), starting at the block's cursor blk_ev -- one coalesced load of 64 events per ~1 KiB block, no second pass over the codes (a separate
+// kernel writing 63 M scattered bytes re-reads and re-writes the whole 1.9 GB array: +0.6 ms per chr20-sized pass).
+template <int U, bool DEL>
 __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
                                                      const int64_t *__restrict__ slot_off, const uint8_t *__restrict__ ref_wire,
                                                      int32_t ref_pos0, int64_t ref_len, const uint32_t *__restrict__ blk_off,
                                                      const int32_t *__restrict__ blk_read, const uint16_t *__restrict__ events,
-                                                     int64_t n_blocks, uint8_t *__restrict__ codes, int64_t codes_len)
+                                                     int64_t n_blocks, uint8_t *__restrict__ codes, int64_t codes_len,
+                                                     const uint32_t *__restrict__ blk_ev, const int32_t *__restrict__ ev_off,
+                                                     const int32_t *__restrict__ ev_pos, const int32_t *__restrict__ ev_len)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img_all[4 * U * WIRE_BLOCK];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -320,14 +341,23 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         e1[u] = blk_off[blk + 1];
     }
     int64_t ri0[U];                                                  // short path: reference index of the block's first byte, else -1
+    uint32_t dcur[U], dend[U];                                       // DEL: the block's cursor into the events, the read's last event + 1
 #pragma unroll
     for (int u = 0; u < U; u++) {
         ri0[u] = -1;
+        dcur[u] = 0xffffffffu;
+        dend[u] = 0;
         if (u < nu && r[u] < n_reads) {
             const int64_t s = rd_start[r[u]], e = rd_end[r[u]], so = slot_off[r[u]];
             const int64_t p0 = (s & ~(int64_t)15) + ((blk0 + u) * WIRE_BLOCK - so);
             const int64_t ri = p0 - ref_pos0;
-            if (p0 >= s && p0 + WIRE_BLOCK <= e && ri >= 0 && ri + WIRE_BLOCK <= ref_len) ri0[u] = ri;
+            if (p0 >= s && p0 + WIRE_BLOCK <= e && ri >= 0 && ri + WIRE_BLOCK <= ref_len) {
+                ri0[u] = ri;
+                if constexpr (DEL) {
+                    dcur[u] = blk_ev[blk0 + u];
+                    dend[u] = (uint32_t)ev_off[r[u] + 1];
+                }
+            }
         }
     }
     // ---- vector: the first 128 events of every block (a PAIR of events per lane: one dword load -- sub-dword global loads run
@@ -371,6 +401,29 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         scatter(im, pr0[u]);
         if (u < nu)
             for (uint32_t k = (e0[u] & ~1u) + 128 + 2 * lane; k < e1[u]; k += 128) scatter(im, load_pair(k, e0[u], e1[u], blk0 + u == n_blocks - 1));
+    }
+    if constexpr (DEL) {
+        // the deleted columns of single-read blocks, from the read's deletion events (LDS stores of a wave land in program order: on top of the image,
+        // never on a byte a difference event wrote -- a deleted column carries no base)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (dcur[u] == 0xffffffffu) continue;                    // (wave-uniform)
+            uint8_t *im = img + u * WIRE_BLOCK;
+            const int32_t pbase = (int32_t)(ri0[u] + ref_pos0);      // position of the block's first byte
+            for (uint32_t k0 = dcur[u]; k0 < dend[u]; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const bool act = k < dend[u];
+                const int32_t pos = act ? ev_pos[k] : INT32_MAX, len = act ? ev_len[k] : 0;
+                if (act && len < 0) {
+                    const int32_t c0 = pos + 1 - pbase;
+                    for (int32_t j = 0; j < -len; j++) {
+                        const int32_t c = c0 + j;
+                        if (c >= 0 && c < WIRE_BLOCK) im[c] = 4;
+                    }
+                }
+                if (__shfl(pos, 63) >= pbase + WIRE_BLOCK) break;  // events ascend: nothing further reaches into this block
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -426,10 +479,10 @@ __global__ void k_ref_from_wire(const uint8_t *__restrict__ ref_wire, uint8_t *_
 
 }   // namespace
 
-extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
-                              const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
-                              const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
-                              uint8_t *d_ref_code)
+static int wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                       const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                       const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                       uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len)
 {
     if (!ctx) return NC_ERR_ARG;
     if (n_reads < 0 || !d_slot_off || (n_reads && (!d_rd_start || !d_rd_end)) || !d_ref_wire || (ref_pos0 & 15) || ref_len < 0 ||
@@ -438,10 +491,12 @@ extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_
         return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand: bad argument");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     static const int U = [] { const char *e = getenv("NC_WIRE_U"); const int v = e ? atoi(e) : NC_WIRE_U; return (v == 1 || v == 2 || v == 8) ? v : 4; }();
-#define NC_LAUNCH_EXPAND(UU)                                                                                                                  \
-    hipLaunchKernelGGL(k_wire_expand<UU>, dim3((unsigned)((n_blocks + 4 * UU - 1) / (4 * UU))), dim3(256), 0, ctx->stream, n_reads, d_rd_start, \
-                       d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len)
-    if (U == 1) NC_LAUNCH_EXPAND(1); else if (U == 2) NC_LAUNCH_EXPAND(2); else if (U == 8) NC_LAUNCH_EXPAND(8); else NC_LAUNCH_EXPAND(4);
+#define NC_LAUNCH_EXPAND(UU, DD)                                                                                                                  \
+    hipLaunchKernelGGL((k_wire_expand<UU, DD>), dim3((unsigned)((n_blocks + 4 * UU - 1) / (4 * UU))), dim3(256), 0, ctx->stream, n_reads, d_rd_start, \
+                       d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len, d_blk_ev,  \
+                       d_ev_off, d_ev_pos, d_ev_len)
+    if (d_blk_ev) { if (U == 1) NC_LAUNCH_EXPAND(1, true); else if (U == 2) NC_LAUNCH_EXPAND(2, true); else if (U == 8) NC_LAUNCH_EXPAND(8, true); else NC_LAUNCH_EXPAND(4, true); }
+    else { if (U == 1) NC_LAUNCH_EXPAND(1, false); else if (U == 2) NC_LAUNCH_EXPAND(2, false); else if (U == 8) NC_LAUNCH_EXPAND(8, false); else NC_LAUNCH_EXPAND(4, false); }
 #undef NC_LAUNCH_EXPAND
     if (d_ref_code && ref_len) {
         const int64_t groups = (ref_len + 15) / 16;
@@ -556,6 +611,26 @@ __global__ __launch_bounds__(256) void k_events_expand(int32_t n_reads, const in
     if (ins_off && r == n_reads - 1 && lane == 0) ins_off[e1] = run_ins;
 }
 }   // namespace
+
+extern "C" int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                              const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                              const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                              uint8_t *d_ref_code)
+{
+    return wire_expand(ctx, n_reads, d_rd_start, d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len,
+                       d_ref_code, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int nc_wire_expand_del(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                                  const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                                  const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                                  uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!d_blk_ev || !d_ev_off || (n_reads && (!d_ev_pos || !d_ev_len))) return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand_del: bad argument");
+    return wire_expand(ctx, n_reads, d_rd_start, d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len,
+                       d_ref_code, d_blk_ev, d_ev_off, d_ev_pos, d_ev_len);
+}
 
 extern "C" int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire)
 {

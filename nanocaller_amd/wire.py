@@ -120,8 +120,8 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
     h = C.c_void_p()
     del_implied = events is not None and os.environ.get("NC_WIRE_DEL_IMPLIED", "1") != "0"
     if del_implied:
-        # the reads travel with their indel events: a deleted column's code is implied by the deletion event and left out of the difference events
-        # (nc_wire_apply_deletions writes it back in HBM)
+        # the reads travel with their indel events: in a block that lies inside one read a deleted column's code is implied by the deletion event
+        # and left out of the difference events (nc_wire_expand_del writes it from the events, expanded first)
         e_off, e_pos, e_len = (np.ascontiguousarray(x, np.int32) for x in events)
         rc = L.nc_wire_build_del(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value,
                                  ref_len, _lib.npp(e_off), _lib.npp(e_pos) if e_pos.size else None, _lib.npp(e_len) if e_len.size else None, C.byref(h))
@@ -147,6 +147,8 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
                  ("blk_read", arr(v.blk_read, v.n_blocks, np.int32)),
                  ("events", arr(v.events, v.n_events, np.uint16)), ("ref_nib", ref_grid[0::2] | (ref_grid[1::2] << 4)), ("tile_off", tile_off),
                  ("tile_ent", np.frombuffer(tile_ent[:n_ent.value].tobytes(), np.uint8) if n_ent.value else np.zeros(16, np.uint8))]
+        if del_implied:
+            parts.append(("blk_ev", arr(v.blk_ev, v.n_blocks, np.uint32)))     # per block: where the read's deletion events start (nc_wire_expand_del)
         n_indel = -1
         if events is not None:
             ev_off, ev_pos, ev_len = (np.asarray(x) for x in events)
@@ -232,15 +234,21 @@ def _expand(eng, wp: WirePack, v, codes, ref_code, scratch=None):
             scratch = torch.empty(wp.ref_len, dtype=torch.uint8, device=codes.device)
         eng._check(eng.L.nc_wire_ref_unpack(eng.ctx, C.c_void_p(v["ref_nib"].data_ptr()), wp.ref_len, C.c_void_p(scratch.data_ptr())), "nc_wire_ref_unpack")
         v["ref_wire"] = scratch
-    rc = eng.L.nc_wire_expand(eng.ctx, wp.n_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
-                              C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ref_wire"].data_ptr()), wp.tile_pos0, wp.ref_len,
-                              C.c_void_p(v["blk_off"].data_ptr()), C.c_void_p(v["blk_read"].data_ptr()),
-                              C.c_void_p(v["events"].data_ptr() if wp.n_events else v["blk_off"].data_ptr()),
-                              wp.n_blocks, C.c_void_p(codes.data_ptr()), wp.codes_len, C.c_void_p(ref_code.data_ptr()))
+    args = (eng.ctx, wp.n_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
+            C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ref_wire"].data_ptr()), wp.tile_pos0, wp.ref_len,
+            C.c_void_p(v["blk_off"].data_ptr()), C.c_void_p(v["blk_read"].data_ptr()),
+            C.c_void_p(v["events"].data_ptr() if wp.n_events else v["blk_off"].data_ptr()),
+            wp.n_blocks, C.c_void_p(codes.data_ptr()), wp.codes_len, C.c_void_p(ref_code.data_ptr()))
+    if "blk_ev" in v:                                                   # deleted columns implied: from the reads' events (_expand_events ran first)
+        assert wp.n_indel_reads == wp.n_reads and "ev_pos" in v
+        rc = eng.L.nc_wire_expand_del(*args, C.c_void_p(v["blk_ev"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
+                                      C.c_void_p(v["ev_pos"].data_ptr()), C.c_void_p(v["ev_len"].data_ptr()))
+    else:
+        rc = eng.L.nc_wire_expand(*args)
     eng._check(rc, "nc_wire_expand")
 
 
-def _expand_events(eng, wp: WirePack, v, out, codes=None):
+def _expand_events(eng, wp: WirePack, v, out):
     """the 3-byte transfer form of the indel events -> ev_pos / ev_len / ins_off int32 in `out` (dict of device tensors, grown on demand),
     put into the views dict `v` under the names the kernels' structs take"""
     me = wp.meta.get("indel_events") if wp.meta else None
@@ -260,11 +268,6 @@ def _expand_events(eng, wp: WirePack, v, out, codes=None):
     v["ev_pos"], v["ev_len"] = out["ev_pos"][:max(n_ev, 1)], out["ev_len"][:max(n_ev, 1)]
     if me.get("extra"):
         v["ins_off"] = out["ins_off"][:n_ev + 1]
-    if me.get("del_implied") and n_ev and codes is not None:
-        rc = eng.L.nc_wire_apply_deletions(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
-                                           C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()), C.c_void_p(out["ev_pos"].data_ptr()),
-                                           C.c_void_p(out["ev_len"].data_ptr()), C.c_void_p(codes.data_ptr()))
-        eng._check(rc, "nc_wire_apply_deletions")
 
 
 def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
@@ -298,8 +301,8 @@ def upload_wire(eng, wp: WirePack) -> DevicePack:
     v = _views(d, wp)
     codes = torch.empty(wp.codes_len, dtype=torch.uint8, device=dev)
     ref_code = torch.empty(wp.ref_len, dtype=torch.uint8, device=dev)
+    _expand_events(eng, wp, v, {})
     _expand(eng, wp, v, codes, ref_code)
-    _expand_events(eng, wp, v, {}, codes)
     return _device_pack(wp, v, codes, ref_code, own_index=True)
 
 
@@ -356,8 +359,8 @@ class WireUploader:
         codes, ref_code = self.codes[:wp.codes_len], self.ref_code[:wp.ref_len]
         if self.ref_bytes is None or self.ref_bytes.numel() < wp.ref_len:
             self.ref_bytes = torch.empty(wp.ref_len + wp.ref_len // 16, dtype=torch.uint8, device=eng.device)
+        _expand_events(eng, wp, v, self.ev)
         _expand(eng, wp, v, codes, ref_code, self.ref_bytes)
-        _expand_events(eng, wp, v, self.ev, codes)
         return _device_pack(wp, v, codes, ref_code, own_index=False)
 
     def release(self, ticket):

@@ -154,6 +154,28 @@ def test_first_chunks_equal_the_oracle(setup):
         assert np.abs(r["probs"][sel] - probs).max() < 1e-4
 
 
+def test_the_cnn_enqueued_inside_the_next_scan_gives_the_same_results(setup):
+    """snpCaller.call_chunks(pipeline=True) (NC_PIPE_CNN=1; off by default: measured slower): a group's CNN is enqueued between nc_snp_scan_begin and
+    nc_snp_scan_end of the NEXT group, or by result() when no call follows -- device order scan(k + 1), CNN(k), tensors(k + 1) -- and every result equals
+    the unpipelined call's bit for bit"""
+    from nanocaller_amd import snpCaller
+    eng, pack, info, wire, chunks, params = setup
+    groups = [chunks[:12], chunks[12:30], chunks[5:9], chunks[:12]]
+    plain = [snpCaller.call_chunks(params, g, dpk=pack, defer=True, pipeline=False).result() for g in groups]
+    pend = []
+    for k, g in enumerate(groups):
+        pend.append(snpCaller.call_chunks(params, g, dpk=pack, defer=True, pipeline=True))
+        assert 0 in snpCaller._PENDING_CNN                              # this group's CNN waits for the next scan
+        if k == 1:
+            assert pend[0].result()["n"] == plain[0]["n"]              # (collected while a later group's CNN is still pending)
+    piped = [p.result() for p in pend]
+    assert 0 not in snpCaller._PENDING_CNN
+    for a, b in zip(plain, piped):
+        assert a["n"] == b["n"] > 1000
+        for key in ("pos", "chunk", "ref", "dp", "alt", "fwd_dp", "rev_dp", "probs", "gt", "freq"):
+            assert np.array_equal(a[key], b[key]), key
+
+
 def test_hifi_60x_haploid_at_full_size():
     """BASELINE.json configs[4]'s shape: a chr20-sized HiFi 60x contig (3.9 G pileup entries), `pacbio` neighbour buckets,
     haploid model.  The wire form (0.04 B per entry: a HiFi read is 99.8 % reference) reproduces the pack byte for byte, the

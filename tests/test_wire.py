@@ -109,19 +109,26 @@ def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
     me = (wp.meta or {}).get("indel_events")
     assert bool(me and me.get("del_implied")) == (name == "indel_consistent")
     if me and me.get("del_implied"):
-        # the deleted columns are implied by the reads' own deletion events (nc_wire_build_del) and written back after the expansion
-        # (nc_wire_apply_deletions, restated): without that step the codes differ exactly there, and the wire is that much smaller
+        # in blocks inside one read the deleted columns are implied by the read's own deletion events (nc_wire_build_del) and written by the
+        # expansion from the block's cursor into the events (nc_wire_expand_del, restated): without that step the codes differ exactly there
         assert not np.array_equal(codes, hp.codes)
         ev_pos, ev_len, _ = _expand_events_numpy(wp)
-        off, rs, re_, so = wp.host("ev_off"), wp.host("rd_start").astype(np.int64), wp.host("rd_end").astype(np.int64), wp.host("slot_off")
+        off, rs, so = wp.host("ev_off"), wp.host("rd_start").astype(np.int64), wp.host("slot_off")
+        be, br_ = wp.host("blk_ev"), wp.host("blk_read")
         n_written = 0
-        for r in range(wp.n_indel_reads):
-            base = so[r] - (rs[r] & ~15)
-            for e in range(int(off[r]), int(off[r + 1])):
+        assert np.any(be != 0xffffffff)
+        for b in np.nonzero(be != 0xffffffff)[0]:
+            r = int(br_[b])
+            p0 = (int(rs[r]) & ~15) + (int(b) * 1024 - int(so[r]))    # position of the block's first byte
+            assert int(off[r]) <= int(be[b]) <= int(off[r + 1])
+            assert int(be[b]) == int(off[r]) or ev_pos[be[b] - 1] + max(0, -ev_len[be[b] - 1]) < p0       # nothing before the cursor reaches the block
+            for e in range(int(be[b]), int(off[r + 1])):
+                if ev_pos[e] >= p0 + 1024:
+                    break
                 if ev_len[e] < 0:
-                    a, b = max(int(ev_pos[e]) + 1, int(rs[r])), min(int(ev_pos[e]) + 1 - int(ev_len[e]), int(re_[r]))
-                    codes[base + a:base + b] = 4
-                    n_written += max(0, b - a)
+                    a, z = max(int(ev_pos[e]) + 1 - p0, 0), min(int(ev_pos[e]) + 1 - int(ev_len[e]) - p0, 1024)
+                    codes[b * 1024 + a:b * 1024 + z] = 4
+                    n_written += max(0, z - a)
         import os
         os.environ["NC_WIRE_DEL_IMPLIED"] = "0"
         try:
@@ -217,7 +224,7 @@ def test_wire_expand_on_device_equals_direct_pack(eng, name, supp, excl, tile):
     w = _consistent_deletions(load_world("indel")) if name == "indel_consistent" else load_world(name)
     a = eng.upload(pack_world(w, supplementary=supp, exclude=excl, tile_size=tile))
     wp = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile)
-    assert bool(((wp.meta or {}).get("indel_events") or {}).get("del_implied")) == (name == "indel_consistent")     # (then nc_wire_apply_deletions completes the codes)
+    assert bool(((wp.meta or {}).get("indel_events") or {}).get("del_implied")) == (name == "indel_consistent")     # (then nc_wire_expand_del completes the codes)
     b = upload_wire(eng, wp)
     up = WireUploader(eng)
     t = up.submit(wp)
@@ -232,6 +239,23 @@ def test_wire_expand_on_device_equals_direct_pack(eng, name, supp, excl, tile):
             for k in ("ev_off", "ev_pos", "ev_len", "read_hap"):
                 assert torch.equal(d.events[k][:a.events[k].numel()], a.events[k])
             assert d.events["n_reads"] == a.events["n_reads"]
+    if name == "indel_consistent":
+        # the separate pass (nc_wire_apply_deletions) completes an array that was expanded WITHOUT the events at hand, and changes nothing in a complete one
+        import ctypes as C
+        from nanocaller_amd.wire import _views
+        v = _views(wp.buf.to(eng.device), wp)
+        v.pop("blk_ev")
+        from nanocaller_amd import wire as wire_mod
+        plain = torch.empty_like(a.codes)
+        wire_mod._expand(eng, wp, v, plain, torch.empty_like(a.ref_code))
+        torch.cuda.synchronize()
+        assert not torch.equal(plain, a.codes)
+        for _ in range(2):
+            rc = eng.L.nc_wire_apply_deletions(eng.ctx, wp.n_indel_reads, *(C.c_void_p(t_.data_ptr()) for t_ in (
+                b.reads["rd_start"], b.reads["rd_end"], b.reads["slot_off"], b.events["ev_off"], b.events["ev_pos"], b.events["ev_len"], plain)))
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.equal(plain, a.codes)
     # slot reuse: a second and third contig through the same two slots, each expanded result checked before the next
     for nm in ("hifi", "ont", "deep"):
         w2 = load_world(nm)
