@@ -1711,9 +1711,12 @@ enum { LW_5H = 0, LW_5L = 5, LW_1H = 10, LW_1L = 11, LW_2HA = 12, LW_2LA = 13, L
 constexpr int L_PACKED_BYTES = 2 * T_FRAG * T_NW1L;
 constexpr int L_DXO[5] = {0, -2, -1, 1, 2};                                  // pixel i of a record is column w + L_DXO[i] (the centre first: slot 0 serves the 5x1 kernel)
 // which tiles of 16 positions a conv1 wave computes (position p = 16 t + lane % 16 = 41 h + w)
-struct c1l_role { int nt; int tile[5]; };
+// `part` = which of a tile's three accumulators the wave computes (1: the 1x5 kernel's 16 channels, 2: the 5x1 kernel's, 4: the 5x5 kernel's): the 13th
+// tile (positions 192..204: 10 MFMAs but a full 12 activations per lane) is split by kernel over three waves, 36 / 40 / 40 / 40 activations per lane
+// instead of 48 / 36 / 36 / 36 -- the conv1 waves' epilogues are the pole of the step (profiles/r06_trunk_phases.md)
+struct c1l_role { int nt; int tile[5]; int part[5]; };
 #ifndef NC_LIN_ROLES
-#define NC_LIN_ROLES {{4, {0, 4, 8, 12, 0}}, {3, {1, 5, 9, 0, 0}}, {3, {2, 6, 10, 0, 0}}, {3, {3, 7, 11, 0, 0}}}
+#define NC_LIN_ROLES {{3, {0, 4, 8, 0, 0}, {7, 7, 7, 0, 0}}, {4, {1, 5, 9, 12, 0}, {7, 7, 7, 1, 0}}, {4, {2, 6, 10, 12, 0}, {7, 7, 7, 2, 0}}, {4, {3, 7, 11, 12, 0}, {7, 7, 7, 4, 0}}}
 #endif
 constexpr c1l_role C1L_ROLES[4] = NC_LIN_ROLES;
 constexpr int c1l_hlo(int t) { return (16 * t) / 41; }
@@ -1732,6 +1735,18 @@ constexpr int c1l_mfma_tile(int t)
     for (int dy = 0; dy < 5; dy++) n += (c1l_need1(t, dy) ? 2 : 0) + (c1l_need0(t, dy) ? 3 : 0) + (dy == 2 ? (c1l_need1(t, dy) ? 2 : 0) + (c1l_need0(t, dy) ? 3 : 0) : 0);
     return n + 2 + (c1l_low(t) ? 3 : 0);
 }
+constexpr bool c1l_roles_cover()                                             // every accumulator of every tile is exactly one wave's
+{
+    for (int t = 0; t < 13; t++) {
+        int seen = 0;
+        for (int r = 0; r < 4; r++)
+            for (int tm = 0; tm < C1L_ROLES[r].nt; tm++)
+                if (C1L_ROLES[r].tile[tm] == t) { if (seen & C1L_ROLES[r].part[tm]) return false; seen |= C1L_ROLES[r].part[tm]; }
+        if (seen != 7) return false;
+    }
+    return true;
+}
+static_assert(c1l_roles_cover(), "NC_LIN_ROLES: the roles do not cover the 13 tiles x 3 kernels exactly once");
 constexpr int c1l_mfma_site() { int n = 0; for (int t = 0; t < 13; t++) n += c1l_mfma_tile(t); return n; }
 constexpr int L_MFMA_PER_SITE = c1l_mfma_site() + 10 * 27 + 8 * 18;
 
@@ -1744,6 +1759,11 @@ __device__ __forceinline__ void c1l_mma(const _Float16 *XB, const h8 (&wl)[T_NW1
     constexpr c1l_role R = C1L_ROLES[ROLE];
     constexpr int NT = NTT;
     auto tile_of = [](int tm) constexpr { return C1L_ROLES[ROLE].tile[T0 + tm]; };
+    auto part_of = [](int tm) constexpr { return C1L_ROLES[ROLE].part[T0 + tm]; };
+    auto k55 = [&](int tm) constexpr { return (part_of(tm) & 4) != 0; };            // the 5x5 kernel's accumulator of this tile is this wave's
+    auto k15 = [&](int tm) constexpr { return (part_of(tm) & 1) != 0; };
+    auto k51 = [&](int tm) constexpr { return (part_of(tm) & 2) != 0; };
+    auto use = [&](int tm, int s) constexpr { return k55(tm) || (s == 2 && k15(tm)); };   // the kernel row's operand is needed
     const int g = lane >> 4, c16 = lane & 15;
     int pr8[NT], w8[NT], hrow[NT];
 #pragma unroll
@@ -1801,16 +1821,17 @@ __device__ __forceinline__ void c1l_mma(const _Float16 *XB, const h8 (&wl)[T_NW1
 #pragma unroll
             for (int tm = 0; tm < NT; tm++) {
                 const int t = tile_of(tm);
+                if (!use(tm, s)) continue;
                 if (c1l_need1(t, s)) x1[slot][tm] = lds_h8(XB + a1(tm, s));
                 if (c1l_need0(t, s)) { const int a = a0(tm, s); xh[slot][n0] = lds_h8(XB + a); xl[slot][n0] = lds_h8(XB + a + (L_P0L - L_P0H)); n0++; }
             }
         } else if (s == 5) {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) x1[slot][tm] = lds_h8(XB + aA(tm));
+            for (int tm = 0; tm < NT; tm++) if (k51(tm)) x1[slot][tm] = lds_h8(XB + aA(tm));
         } else {
 #pragma unroll
             for (int tm = 0; tm < NT; tm++)
-                if (c1l_low(tile_of(tm))) { x1[slot][tm] = lds_h8(XB + aB(tm)); xc[tm] = lds_h8(XB + aC(tm)); }
+                if (k51(tm) && c1l_low(tile_of(tm))) { x1[slot][tm] = lds_h8(XB + aB(tm)); xc[tm] = lds_h8(XB + aC(tm)); }
         }
     };
 #pragma unroll
@@ -1822,39 +1843,40 @@ __device__ __forceinline__ void c1l_mma(const _Float16 *XB, const h8 (&wl)[T_NW1
         __builtin_amdgcn_sched_barrier(0);
         if (s < 5) {
             // independent accumulators interleaved; the three products of a row-0 operand pair are spread over the step
+            // (n0: index of the tile's row-0 operand pair among those this wave loaded for the step)
             int n0 = 0;
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k55(tm) && c1l_need1(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], x1[cur][tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need0(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xh[cur][n0]) } n0++; }
+            for (int tm = 0; tm < NT; tm++) if (use(tm, s) && c1l_need0(tile_of(tm), s)) { if (k55(tm)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xh[cur][n0]) } if (s == 2 && k15(tm)) { NC_MFMA(acc1[tm], wl[LW_1H], xh[cur][n0]) } n0++; }
             if (s == 2) {
 #pragma unroll
-                for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc1[tm], wl[LW_1H], x1[cur][tm]) }
+                for (int tm = 0; tm < NT; tm++) if (k15(tm) && c1l_need1(tile_of(tm), s)) { NC_MFMA(acc1[tm], wl[LW_1H], x1[cur][tm]) }
             }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k55(tm) && c1l_need1(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], x1[cur][tm]) }
             n0 = 0;
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need0(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xl[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1H], xl[cur][n0]) } n0++; }
+            for (int tm = 0; tm < NT; tm++) if (use(tm, s) && c1l_need0(tile_of(tm), s)) { if (k55(tm)) { NC_MFMA(acc3[tm], wl[LW_5H + s], xl[cur][n0]) } if (s == 2 && k15(tm)) { NC_MFMA(acc1[tm], wl[LW_1H], xl[cur][n0]) } n0++; }
             if (s == 2) {
 #pragma unroll
-                for (int tm = 0; tm < NT; tm++) if (c1l_need1(tile_of(tm), s)) { NC_MFMA(acc1[tm], wl[LW_1L], x1[cur][tm]) }
+                for (int tm = 0; tm < NT; tm++) if (k15(tm) && c1l_need1(tile_of(tm), s)) { NC_MFMA(acc1[tm], wl[LW_1L], x1[cur][tm]) }
             }
             n0 = 0;
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_need0(tile_of(tm), s)) { NC_MFMA(acc3[tm], wl[LW_5L + s], xh[cur][n0]) if (s == 2) { NC_MFMA(acc1[tm], wl[LW_1L], xh[cur][n0]) } n0++; }
+            for (int tm = 0; tm < NT; tm++) if (use(tm, s) && c1l_need0(tile_of(tm), s)) { if (k55(tm)) { NC_MFMA(acc3[tm], wl[LW_5L + s], xh[cur][n0]) } if (s == 2 && k15(tm)) { NC_MFMA(acc1[tm], wl[LW_1L], xh[cur][n0]) } n0++; }
         } else if (s == 5) {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], wl[LW_2HA], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k51(tm)) { NC_MFMA(acc2[tm], wl[LW_2HA], x1[cur][tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) { NC_MFMA(acc2[tm], wl[LW_2LA], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k51(tm)) { NC_MFMA(acc2[tm], wl[LW_2LA], x1[cur][tm]) }
         } else {
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2HB], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k51(tm) && c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2HB], x1[cur][tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2HC], xc[tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k51(tm) && c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2HC], xc[tm]) }
 #pragma unroll
-            for (int tm = 0; tm < NT; tm++) if (c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2LB], x1[cur][tm]) }
+            for (int tm = 0; tm < NT; tm++) if (k51(tm) && c1l_low(tile_of(tm))) { NC_MFMA(acc2[tm], wl[LW_2LB], x1[cur][tm]) }
         }
         payload(s);
         __builtin_amdgcn_sched_barrier(0);
@@ -1876,6 +1898,7 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
     // two phases: the MFMAs of the first two tiles; then the MFMAs of the others with the first two tiles' epilogue between them (one accumulator per step:
     // a wave's own vector instructions ride in the shadow of its own MFMAs); then the epilogue of the others
     constexpr int NA = 2, NB2 = NT - 2;
+    static_assert(C1L_ROLES[ROLE].part[0] == 7 && C1L_ROLES[ROLE].part[1] == 7 && C1L_ROLES[ROLE].part[2] == 7 && (NT < 4 || C1L_ROLES[ROLE].part[3] == 7), "two-phase conv1: whole tiles only");
     f32x4v p1[NA], p2[NA], p3[NA], q1[NB2], q2[NB2], q3[NB2];
     int oa[NA], ob[NB2];
     c1l_mma<ROLE, 0, NA>(XB, wl, b1s, rho, lane, p1, p2, p3, oa, [](int) {});
@@ -1905,9 +1928,9 @@ __device__ __forceinline__ void t_conv1_lin(const _Float16 *XB, _Float16 *A1H, c
     if (trk) trk[2] = __builtin_readcyclecounter();
 #pragma unroll
     for (int tm = 0; tm < NT; tm++) {
-        c1l_epi_one(acc1[tm], 0, obase[tm], epi, A1H);
-        c1l_epi_one(acc2[tm], 1, obase[tm], epi, A1H);
-        c1l_epi_one(acc3[tm], 2, obase[tm], epi, A1H);
+        if (C1L_ROLES[ROLE].part[tm] & 1) c1l_epi_one(acc1[tm], 0, obase[tm], epi, A1H);
+        if (C1L_ROLES[ROLE].part[tm] & 2) c1l_epi_one(acc2[tm], 1, obase[tm], epi, A1H);
+        if (C1L_ROLES[ROLE].part[tm] & 4) c1l_epi_one(acc3[tm], 2, obase[tm], epi, A1H);
     }
 #endif
 }
