@@ -33,7 +33,8 @@ extern "C" {
                               10: nc_bgzf_crc_device (CRC-32 of the device-inflated members);
                               11: nc_snp_trunk_info (which SNP trunk kernel the next nc_snp_forward runs, its MFMA count per site), nc_wire_build_del +
                                   nc_wire_apply_deletions (deleted columns implied by the indel events), nc_wire_ref_unpack (reference bytes two per byte), two-byte
-                                  indel events (nc_indel_events_pack / _expand with l8 = NULL), nc_snp_scan_begin / _end */
+                                  indel events (nc_indel_events_pack / _expand with l8 = NULL), nc_snp_scan_begin / _end, nc_wire_expand_del + nc_wire_arrays.blk_ev,
+                                  nc_decoded_name_groups + nc_snp_set_mates (alignments that share a read name, keyed by name in the SNP featuriser) */
 
 typedef struct nc_ctx nc_ctx;
 
@@ -101,7 +102,8 @@ typedef struct {
     int32_t start;      /* first covered position (1-based) */
     int32_t end;        /* one past the last covered position */
     int64_t base_flag;  /* (base & ~15) | flags; bit0 = reverse strand ((flag & 0x910)/16, :143);
-                           bits 1-2 = haplotype tag HP (0 untagged, 1, 2; generate_indel_pileups.py:180-185) */
+                           bits 1-2 = haplotype tag HP (0 untagged, 1, 2; generate_indel_pileups.py:180-185);
+                           bit 3 = the read name is shared with another kept alignment (nc_snp_set_mates) */
 } nc_tile_entry;
 
 typedef struct {
@@ -117,7 +119,7 @@ typedef struct {
 
 /* Host-side packer.  Inputs (host): n reads in coordinate order, read r covers [start[r], end[r]) and
  * codes_in[off[r] + p - start[r]] is its code (0..4) at p; keep[r]==0 drops the read (pileup flag filter
- * 0x4|0x100|0x200|0x400|0x800, generate_SNP_pileups.py:151-157); strand[r] bit0 = reverse strand, bits 1-2 = HP tag.
+ * 0x4|0x100|0x200|0x400|0x800, generate_SNP_pileups.py:151-157); strand[r] bit0 = reverse strand, bits 1-2 = HP tag, bit 3 = shared read name.
  * Step 1 sizes the outputs; step 2 fills caller-allocated host buffers.  With codes_in == codes_out == NULL
  * nc_pack_fill builds the tile index only (slot r starts at byte sum_{q<r} slot_size(q), kept reads only). */
 int nc_pack_plan(int32_t n_reads, const int32_t *start, const int32_t *end, const uint8_t *keep,
@@ -325,6 +327,17 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack,
                      float *x_dev, int32_t *ref_code_out_dev, int32_t *fwd_dp_dev, int32_t *rev_dp_dev,
                      int32_t *site_depth_dev, uint8_t *valid_dev);
 
+/* Alignments that share a read name (a split read's primary + supplementary records under dct['supplementary']; ABI 11).  The reference's
+ * pileup is a dict keyed by NAME per column (generate_SNP_pileups.py:175,185): where several alignments of one name cover a column the LAST in
+ * file order is the column's entry (all of them count in `n` and the allele frequency, :164-166: the scan is per alignment), a site's row for a
+ * name takes each neighbour column from whichever of the name's alignments covers it (:223,232), the sampled depth counts names (:208,263), and
+ * the strand is the name's (:141-143: the caller writes it into every member's tile entries).  The pack's tile entries of such alignments carry
+ * bit 3 of base_flag; this call hands the featuriser their table for the following nc_snp_featurize calls (n_mates = 0 clears it; the pointers
+ * are borrowed): d_mate_key [n_mates] = byte offset of the alignment's slot in `codes`, ascending (= file order); d_mate_rec [n_mates][4] int32,
+ * 16-byte aligned = {start, end, table index of the next alignment of the same name (circular), 0}.  Needs the int16 tensor format and
+ * maxcov < 256 (NC_ERR_UNSUPPORTED from nc_snp_featurize otherwise). */
+int nc_snp_set_mates(nc_ctx *ctx, int32_t n_mates, const int64_t *d_mate_key, const int32_t *d_mate_rec);
+
 /* Per-site coverage scale (snpCaller.py:93-96, 170-173) for the sites of the last scan:
  * mode 0: scale[s] = train_coverage / mean(site_depth over the site's chunk) (chunk constant, quirk E2)
  * mode 1: scale[s] = train_coverage / dp[s] (--disable_coverage_normalization).
@@ -492,6 +505,10 @@ int nc_decoded_free(nc_decoded *d);
  * reference's per-column dicts are keyed by name (:175,185,208), the read-major pack keeps them apart.  Returns NC_ERR_UNSUPPORTED
  * when either count is non-zero, NC_OK otherwise. */
 int nc_decoded_check(const nc_decoded *d, const uint8_t *keep, int64_t *n_refskip, int64_t *n_dup_overlap);
+/* Kept alignments that share a read name (ABI 11): gid[r] (host [n_reads]) = index of the first kept alignment with r's name when more than one
+ * kept alignment carries it, else -1; *n_shared = how many alignments that is.  What nc_snp_set_mates' table is built from (the reference keys
+ * its per-column pileups, strand table and neighbour lookups by name: generate_SNP_pileups.py:141-143,175,185,223,232). */
+int nc_decoded_name_groups(const nc_decoded *d, const uint8_t *keep, int32_t *gid, int64_t *n_shared);
 
 /* ------------------------------------------------------------------ indel pass 2, host side
  * nc_indel_slices replaces the per-read loop of generate_indel_pileups.py:329-338 at the anchor columns chosen by pass 1:

@@ -336,6 +336,7 @@ def read_bam(bam_path, fasta_path, chrom, start=1, end=None, keep_seq=False, thr
         w.meta.update(seq_off=d["seq_off"], seq=d["seq"])
     # inputs the library does not reproduce (nc_decoded_check): counted here, under either flag filter; the pack builders refuse them
     w.meta["unsupported"] = unsupported_counts(d)
+    w.meta["name_gid"] = name_gids(d)
     return w
 
 
@@ -355,6 +356,26 @@ def unsupported_counts(d):
             n_skip = int(np.count_nonzero(keep.astype(bool) & ((d["read_flag"] & _lib.FLAG_REFSKIP) != 0)))
             counts[supp] = (n_skip, same_name_overlaps(d["names"], d["read_start"], d["read_end"], keep))
     return counts
+
+
+def name_gids(d):
+    """{supplementary flag: gid int32 [n] or None}: per alignment the first kept alignment of its read name when the name is shared among the
+    kept ones, else -1 (nc_decoded_name_groups; None = no shared name, or a decode without a native handle: pack.name_groups then walks the
+    names).  What keys a split read's records by NAME as the reference's pileup dicts do (generate_SNP_pileups.py:175,185)."""
+    owner = d.get("_owner")
+    out = {}
+    for supp in (False, True):
+        if owner is None:
+            out[supp] = None
+            continue
+        keep = np.ascontiguousarray(((d["read_flag"] & (0x704 if supp else 0xF04)) == 0).astype(np.uint8))
+        gid = np.empty(max(1, keep.size), np.int32)
+        ns = C.c_int64()
+        rc = _lib.lib().nc_decoded_name_groups(owner.handle, _lib.npp(keep), _lib.npp(gid), C.byref(ns))
+        if rc != _lib.NC_OK:
+            raise _lib.NanoCallerHipError("nc_decoded_name_groups failed (%d)" % rc)
+        out[supp] = gid[:keep.size] if ns.value else np.full(keep.size, -1, np.int32)
+    return out
 
 
 def same_name_overlaps(names, start, end, keep):

@@ -1131,6 +1131,44 @@ int nc_decoded_check(const nc_decoded *d, const uint8_t *keep, int64_t *n_refski
     return (nskip || ndup) ? NC_ERR_UNSUPPORTED : NC_OK;
 }
 
+// Alignments that share a read name among the kept ones (a split read's primary + supplementary records; paired-end mates): gid[r] = index of
+// the FIRST kept alignment with r's name when the name occurs on more than one kept alignment, else -1.  The reference keys a column's pileup,
+// the strand table and the neighbour lookups by name (generate_SNP_pileups.py:141-143,175,185,223,232): pack.name_groups builds the
+// featuriser's table from this (nc_snp_set_mates).
+int nc_decoded_name_groups(const nc_decoded *d, const uint8_t *keep, int32_t *gid, int64_t *n_shared)
+{
+    if (!d || !gid) return NC_ERR_ARG;
+    const int32_t n = (int32_t)d->start.size();
+    std::vector<std::pair<uint64_t, int32_t>> h;
+    try { h.reserve((size_t)n); } catch (const std::bad_alloc &) { return NC_ERR_NOMEM; }
+    for (int32_t r = 0; r < n; r++) {
+        gid[r] = -1;
+        if (keep && !keep[r]) continue;
+        uint64_t x = 1469598103934665603ull;                                   // FNV-1a of the name
+        for (const char *c = d->names.data() + d->name_off[r]; *c; c++) x = (x ^ (uint8_t)*c) * 1099511628211ull;
+        h.emplace_back(x, r);
+    }
+    std::sort(h.begin(), h.end());                                             // (hash, then index: members of a name ascend)
+    int64_t shared = 0;
+    for (size_t i = 0; i < h.size();) {
+        size_t j = i + 1;
+        while (j < h.size() && h[j].first == h[i].first) j++;
+        for (size_t a = i; a < j; a++) {                                       // hash-equal runs are confirmed on the names themselves
+            const int32_t ra = h[a].second;
+            if (gid[ra] >= 0) continue;
+            bool any = false;
+            for (size_t b = a + 1; b < j; b++) {
+                const int32_t rb = h[b].second;
+                if (gid[rb] < 0 && strcmp(d->names.data() + d->name_off[ra], d->names.data() + d->name_off[rb]) == 0) { gid[rb] = ra; any = true; shared++; }
+            }
+            if (any) { gid[ra] = ra; shared++; }
+        }
+        i = j;
+    }
+    if (n_shared) *n_shared = shared;
+    return NC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The per-read inputs of the DEVICE pass 2 (nc_indel_sites_*), for the kept reads in pack order.  The position-addressed
 // codes in HBM hold every aligned base of a read; what a query window (query_sequence[q : q + window], generate_indel_pileups.py:

@@ -37,6 +37,10 @@ struct nc_ctx {
     bool k10_lds_set[2] = {false, false};   // k10_indel_trunk_h3<15 / 5>: dynamic LDS limit raised on this device
     bool huff_lds_set = false;              // k_huff: the same
     size_t k7_budget = 0;                   // bytes of K7 workspace per group of chunks (set from this context's device at its first plan)
+    // alignments that share a read name (nc_snp_set_mates): borrowed device pointers, read by the next nc_snp_featurize calls
+    int32_t n_mates = 0;
+    const int64_t *mate_key = nullptr;
+    const int32_t *mate_rec = nullptr;
     bool k7_budget_shrunk = false;          // the budget was cut to half of what was free at some plan: restored when memory allows again
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 scan, 1 featurize, 2 cnn stage, 3 indel, 4 trunk kernel total, 5 trunk launches

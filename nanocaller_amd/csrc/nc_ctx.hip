@@ -360,7 +360,7 @@ int nc_pack_fill(int32_t n_reads, const int32_t *start, const int32_t *end, cons
         nc_tile_entry e;
         e.start = start[r];
         e.end = end[r];
-        e.base_flag = base[(size_t)r] | (strand ? (strand[r] & 7) : 0);  // bit0 reverse strand, bits 1-2 HP tag
+        e.base_flag = base[(size_t)r] | (strand ? (strand[r] & 15) : 0); // bit0 reverse strand, bits 1-2 HP tag, bit 3: the read name is shared (nc_snp_set_mates)
         int64_t a = std::max<int64_t>(start[r], t0), b = std::min<int64_t>((int64_t)end[r] - 1, t0 + (int64_t)n_tiles * tile_size - 1);
         if (a > b) continue;
         for (int64_t t = (a - t0) / tile_size; t <= (b - t0) / tile_size; t++) tile_ent[cur[(size_t)t]++] = e;

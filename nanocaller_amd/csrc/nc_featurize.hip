@@ -76,7 +76,35 @@ struct FeatArgs {
     int32_t *ref_out, *fwd, *rev, *depth;
     uint8_t *valid;
     int32_t x_i16;                 // 1: the tensors leave as int16 (every entry is a small integer: exact), half the bytes
+    // alignments that share a read name (nc_snp_set_mates; k_featurize_pairs<true>): slot offsets ascending, {start, end, next member of the name, 0}
+    const int64_t *mate_key;
+    const int4 *mate_rec;
+    int32_t n_mates;
 };
+
+// The reference's pileup dicts are keyed by read NAME (generate_SNP_pileups.py:175,185): where several alignments of one name cover a column the
+// last in file order is the column's entry, and a site's row for a name takes every column from whichever of the name's alignments covers it
+// (:223,232).  named_member: among the alignments of the name of the read whose slot starts at byte `key`, the last one (= the largest table
+// index: slots ascend in file order) that covers p; -1: none.  *self = the read's own index in the table.
+__device__ __forceinline__ int named_member(const FeatArgs &a, int64_t key, int32_t p, int *self)
+{
+    int lo = 0, hi = a.n_mates;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.mate_key[mid] < key) lo = mid + 1; else hi = mid; }
+    if (self) *self = lo;
+    int best = -1, i = lo;
+    do {
+        const int4 r = a.mate_rec[i];
+        if (r.x <= p && p < r.y && i > best) best = i;
+        i = r.z;
+    } while (i != lo);
+    return best;
+}
+__device__ __forceinline__ int named_code(const FeatArgs &a, int64_t key, int32_t p)
+{
+    const int m = named_member(a, key, p, nullptr);
+    if (m < 0) return 4;
+    return a.codes[a.mate_key[m] - (a.mate_rec[m].x & ~15) + p];
+}
 
 // I16: the tensors leave as int16 (product path).  Then nothing is assembled in LDS: lane L < 41 takes tensor column L, fetches
 // the counters of the lane that walked that column (ds_bpermute) and writes its five rows' 10 bytes straight to global memory
@@ -347,6 +375,9 @@ __global__ __launch_bounds__(256) void k_featurize(FeatArgs a)
 // entry record of a read by v_readlane, 41 of 64 lanes busy, ~45 vector + scalar instructions per read); here the covering reads' records go to an
 // LDS list and the wave sweeps the reads x columns rectangle 64 pairs a step, four steps' gathers in flight: no scalar walk, every lane busy,
 // counters by LDS atomic adds (at most the two reads that share a step meet on one counter).  int16 tensors, maxcov <= 255.
+// MATES: the pack holds alignments that share read names (entries with bit 3 of base_flag; nc_snp_set_mates): such an entry is left out of a
+// column's pileup when a later alignment of its name covers the column, and its row reads every column through named_code.
+template <bool MATES>
 __global__ __launch_bounds__(256) void k_featurize_pairs(FeatArgs a)
 {
     __shared__ int32_t nlist[4][64];
@@ -431,6 +462,13 @@ __global__ __launch_bounds__(256) void k_featurize_pairs(FeatArgs a)
             cov = ent.start <= v && v < ent.end;
             const uint64_t row = (uint64_t)(uintptr_t)a.codes + (uint64_t)((ent.base_flag & ~int64_t(15)) + ent.start);
             rr = make_uint4((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)ent.start, (uint32_t)(ent.end - ent.start));
+            if constexpr (MATES) {
+                if (cov && (ent.base_flag & 8)) {
+                    int self;
+                    cov = named_member(a, (ent.base_flag & ~int64_t(15)) + (ent.start & ~15), v, &self) == self;   // else: replaced in this column
+                    rr.w |= 0x80000000u;
+                }
+            }
             if (cov) {
                 code = eb == e0 ? pf_code : (int)a.codes[(ent.base_flag & ~int64_t(15)) + v];
                 strand = (int)(ent.base_flag & 1);
@@ -477,8 +515,12 @@ __global__ __launch_bounds__(256) void k_featurize_pairs(FeatArgs a)
                 const uint4 rr = rec[wv][valid ? r : 0];
                 const uint32_t off = (uint32_t)(colL[wv][valid ? j : 0] - (int32_t)rr.z);
                 bc[u] = 4;
-                jk[u] = j * 4 + (int)(rr.w >> 28);
-                if (valid && off < (rr.w & 0x0fffffffu)) bc[u] = ((gbyte_ptr)(uintptr_t)(((uint64_t)rr.y << 32) | rr.x))[off];
+                jk[u] = j * 4 + (int)((rr.w >> 28) & 7u);
+                if (MATES && valid && (rr.w >> 31)) {
+                    // (row address = codes + base + start; the slot starts at base + floor16(start))
+                    const int64_t key = (int64_t)((((uint64_t)rr.y << 32) | rr.x) - (uint64_t)(uintptr_t)a.codes) - (int64_t)(int32_t)rr.z + ((int32_t)rr.z & ~15);
+                    bc[u] = (uint32_t)named_code(a, key, colL[wv][j]);
+                } else if (valid && off < (rr.w & 0x0fffffffu)) bc[u] = ((gbyte_ptr)(uintptr_t)(((uint64_t)rr.y << 32) | rr.x))[off];
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -620,6 +662,13 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     a.depth = site_depth_dev;
     a.valid = valid_dev;
     a.x_i16 = ctx->x_i16 ? 1 : 0;
+    a.mate_key = (const int64_t *)ctx->mate_key;
+    a.mate_rec = (const int4 *)ctx->mate_rec;
+    a.n_mates = ctx->n_mates;
+    const char *fp = getenv("NC_FEAT_PAIRS");
+    const bool pairs = maxcov < MAXCOV_SMALL && a.x_i16 && !(fp && atoi(fp) == 0);
+    if (a.n_mates > 0 && !pairs)
+        return nc_fail(ctx, NC_ERR_UNSUPPORTED, "nc_snp_featurize: alignments that share read names (nc_snp_set_mates) need the int16 tensor format and maxcov < %d", MAXCOV_SMALL);
     NcTimer tm(ctx, 1);
     hipLaunchKernelGGL(k_nbr_index, dim3((n_cidx + 255) / 256), dim3(256), 0, ctx->stream, a.nbr_pos, a.n_nbr, a.cidx_pos0, n_cidx,
                        (int32_t *)ctx->nbr_idx.p);
@@ -627,8 +676,8 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     if (maxcov < MAXCOV_SMALL) {                            // 8-bit counter fields: at most 255 sampled reads
         // int16 tensors (the product path): lanes as (read, column) pairs (k_featurize_pairs); NC_FEAT_PAIRS=0: the scalar-driven read walk
         // (read per call: A/B checks)
-        const char *fp = getenv("NC_FEAT_PAIRS");
-        if (a.x_i16 && !(fp && atoi(fp) == 0)) hipLaunchKernelGGL(k_featurize_pairs, grid, dim3(256), 0, ctx->stream, a);
+        if (pairs && a.n_mates > 0) hipLaunchKernelGGL(k_featurize_pairs<true>, grid, dim3(256), 0, ctx->stream, a);
+        else if (pairs) hipLaunchKernelGGL(k_featurize_pairs<false>, grid, dim3(256), 0, ctx->stream, a);
         else if (a.x_i16) hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, true>), grid, dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_featurize<MAXCOV_SMALL, false>), grid, dim3(256), 0, ctx->stream, a);
     } else {
@@ -637,6 +686,17 @@ int nc_snp_featurize(nc_ctx *ctx, const nc_readpack *pack, const uint8_t *ref_co
     }
     NC_HIP(ctx, hipGetLastError());
     tm.stop();
+    return NC_OK;
+}
+
+int nc_snp_set_mates(nc_ctx *ctx, int32_t n_mates, const int64_t *d_mate_key, const int32_t *d_mate_rec)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_mates < 0 || (n_mates > 0 && (!d_mate_key || !d_mate_rec || ((uintptr_t)d_mate_rec & 15))))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_snp_set_mates: bad argument");
+    ctx->n_mates = n_mates;
+    ctx->mate_key = n_mates ? d_mate_key : nullptr;
+    ctx->mate_rec = n_mates ? d_mate_rec : nullptr;
     return NC_OK;
 }
 

@@ -511,15 +511,15 @@ class DeviceBam:
         kept_for_check = (flag & mask) == 0
         n_skip = int(np.count_nonzero(kept_for_check & ((flag & _lib.FLAG_REFSKIP) != 0)))
         h = (m[M_HASH_LO][idx].astype(np.uint32).astype(np.uint64) | (m[M_HASH_HI][idx].astype(np.uint32).astype(np.uint64) << np.uint64(32)))
-        n_dup = self._same_name_overlaps(h, start, end, kept_for_check, a + idx)
+        n_dup = self._same_name_overlaps(h, start, end, kept_for_check, a + idx, any_pair=bool(supplementary))
         if n_skip or n_dup:
             what = []
             if n_skip:
                 what.append("%d alignments with a reference skip (CIGAR N) would enter the pileup; the reference's code table has no entry for "
                             "their '>' / '<' symbols (generate_SNP_pileups.py:104)" % n_skip)
             if n_dup:
-                what.append("%d pairs of kept alignments carry the same read name and overlap on the reference; the reference's per-column "
-                            "dicts hold one entry per name (generate_SNP_pileups.py:175,185,208)" % n_dup)
+                what.append("%d pairs of kept alignments carry the same read name%s; the reference's per-column dicts hold one entry per name "
+                            "(generate_SNP_pileups.py:175,185,208): the host route (NC_DEVICE_INGEST=0) keys them by name" % (n_dup, "" if supplementary else " and overlap on the reference"))
             err = _lib.NanoCallerHipError("%s, contig %s: %s -- NC_ERR_UNSUPPORTED" % (self.path, chrom, "; ".join(what)))
             err.status = _lib.NC_ERR_UNSUPPORTED
             raise err
@@ -576,8 +576,10 @@ class DeviceBam:
                     tile_pos0=int(tile_pos0.value), n_tiles=int(n_tiles.value), n_entries=int(n_ent.value), pos_lo=pos_lo, pos_hi=pos_hi,
                     n_reads=n, read_start=start, read_end=end, read_flag=flag, keep=keep)
 
-    def _same_name_overlaps(self, h, start, end, keep, recs):
-        """bam.same_name_overlaps on name hashes; hash-equal pairs are confirmed on the names themselves"""
+    def _same_name_overlaps(self, h, start, end, keep, recs, any_pair=False):
+        """bam.same_name_overlaps on name hashes; hash-equal pairs are confirmed on the names themselves.  any_pair: count every pair of kept
+        alignments that share a name, overlapping or not (under dct['supplementary'] the reference looks neighbour columns up by NAME: the host
+        route keys such records by name, pack.name_groups; this route does not)"""
         k = np.flatnonzero(keep)
         if k.size < 2:
             return 0
@@ -590,7 +592,7 @@ class DeviceBam:
         last, n = {}, 0
         for r, nm in zip(cand.tolist(), names):
             e = last.get(nm)
-            if e is not None and int(start[r]) < e:
+            if e is not None and (any_pair or int(start[r]) < e):
                 n += 1
             last[nm] = max(int(end[r]), e or 0)
         return n

@@ -37,6 +37,7 @@ class DevicePack:
     events: dict | None = None    # device tensors ev_off / ev_pos / ev_len / read_hap (indel scan inputs)
     reads: dict | None = None     # device tensors rd_start / rd_end / slot_off of the kept reads (device pass 2: tile entry -> read)
     indel: dict | None = None     # device tensors ins_off / ins_bases / tail_off / tail_bases / read_ps / read_flag (device pass 2)
+    mates: tuple | None = None    # (key int64 [M], rec int32 [M, 4]) device tensors: alignments that share read names (nc_snp_set_mates)
 
     def c_struct(self) -> _lib.ReadPackC:
         return _lib.ReadPackC(codes_len=self.codes.numel(), codes=self.codes.data_ptr(), tile_size=self.tile_size,
@@ -200,6 +201,8 @@ class Engine:
                         tile_ent=torch.from_numpy(ent_bytes.copy()).to(dev), ref_code=torch.from_numpy(hp.ref_code).to(dev),
                         tile_size=hp.tile_size, tile_pos0=hp.tile_pos0, n_tiles=hp.n_tiles,
                         n_entries=int(hp.tile_ent.shape[0]), pos_lo=hp.pos_lo, pos_hi=hp.pos_hi)
+        if hp.mates is not None:
+            dp.mates = (torch.from_numpy(hp.mates[0]).to(dev), torch.from_numpy(hp.mates[1]).to(dev))
         if hp.ev_off is not None:
             z = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt) if a.size else np.zeros(1, dt)).to(dev)   # noqa: E731
             dp.events = dict(n_reads=int(hp.read_hap.shape[0]), ev_off=z(hp.ev_off, np.int32), ev_pos=z(hp.ev_pos, np.int32),
@@ -256,6 +259,15 @@ class Engine:
     def snp_featurize(self, dp: DevicePack, sites: SnpSites, *, seq, maxcov, min_nbr_sites=1) -> SnpSites:
         N = sites.n_sites
         dev = self.device
+        if dp.mates is not None and not getattr(self, "x_int16", False):
+            # alignments that share read names are keyed by name in the int16-tensor kernel only: run it, hand the tensors on as float32 (exact)
+            self.set_tensor_format(int16=True)
+            try:
+                self.snp_featurize(dp, sites, seq=seq, maxcov=maxcov, min_nbr_sites=min_nbr_sites)
+            finally:
+                self.set_tensor_format(int16=False)
+            sites.x = sites.x.to(torch.float32)
+            return sites
         # one allocation carved into the six outputs (this sits between the scan's totals and the featuriser's launch: the GPU idles)
         i16 = getattr(self, "x_int16", False)
         xb = N * 1025 * (2 if i16 else 4)
@@ -269,10 +281,16 @@ class Engine:
         sites.depth = buf[o_dep:o_dep + 4 * N].view(torch.int32)
         sites.valid = buf[o_val:o_val + N]
         pc = dp.c_struct()
-        self._check(self.L.nc_snp_featurize(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(),
-                                            _lib.SEQ_MODES[seq], int(maxcov), int(min_nbr_sites), _ptr(sites.x),
-                                            _ptr(sites.ref_code), _ptr(sites.fwd_dp), _ptr(sites.rev_dp), _ptr(sites.depth),
-                                            _ptr(sites.valid)), "nc_snp_featurize")
+        if dp.mates is not None:                                     # alignments that share read names: the featuriser keys them by name
+            self._check(self.L.nc_snp_set_mates(self.ctx, int(dp.mates[0].numel()), _ptr(dp.mates[0]), _ptr(dp.mates[1])), "nc_snp_set_mates")
+        try:
+            self._check(self.L.nc_snp_featurize(self.ctx, C.byref(pc), _ptr(dp.ref_code), dp.tile_pos0, dp.ref_code.numel(),
+                                                _lib.SEQ_MODES[seq], int(maxcov), int(min_nbr_sites), _ptr(sites.x),
+                                                _ptr(sites.ref_code), _ptr(sites.fwd_dp), _ptr(sites.rev_dp), _ptr(sites.depth),
+                                                _ptr(sites.valid)), "nc_snp_featurize")
+        finally:
+            if dp.mates is not None:
+                self.L.nc_snp_set_mates(self.ctx, 0, None, None)
         return sites
 
     def snp_scale(self, sites: SnpSites, n_chunks, train_coverage, per_site=False, async_fetch=False):

@@ -132,16 +132,21 @@ def _exclude_rows(dct, chrom):
     return tuple(rows)
 
 
-def _check_supported(world, sam_path, chrom, supplementary=False):
+def _check_supported(world, sam_path, chrom, supplementary=False, by_name=False):
     """inputs the library does not reproduce are refused, not silently accepted (nc_decoded_check): among the alignments
     the pileup keeps, reference skips in the CIGAR (the reference raises KeyError on their pileup symbols, quirk E10) and same-name
-    alignments that overlap on the reference (the reference's per-column dicts are keyed by name: one entry where the pack has two)"""
+    alignments that overlap on the reference (the reference's per-column dicts are keyed by name: one entry where the pack has two).
+    by_name (the SNP featuriser's callers, round 6): alignments that share a read name are keyed by name as the reference does
+    (pack.name_groups -> nc_snp_set_mates) when the World carries the names; the indel route still refuses them."""
     mask = 0x704 if supplementary else 0xF04                      # unmapped / secondary / qcfail / duplicate (/ supplementary) are never kept
     keep = (world.read_flag & mask) == 0
     n_skip = int(np.count_nonzero(keep & ((world.read_flag & _lib.FLAG_REFSKIP) != 0)))
-    if "unsupported" in world.meta:
+    from .pack import world_names
+    if by_name and world_names(world) is not None:
+        n_dup = 0                                                 # keyed by name downstream
+    elif "unsupported" in world.meta:
         n_dup = world.meta["unsupported"].get(bool(supplementary), (0, 0))[1]
-    elif getattr(world, "names", None) is not None and len(world.names) == len(world.read_start):
+    elif world_names(world) is not None:
         from .bam import same_name_overlaps                       # a World nobody counted for: count now rather than assume none
         n_dup = same_name_overlaps(world.names, world.read_start, world.read_end, keep)
     else:
@@ -176,12 +181,12 @@ def contig_span(sam_path, chrom, chunks):
     return None if (hi - lo + 1) >= 0.9 * length else (lo, hi)
 
 
-def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, device=0, span=None):
+def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, device=0, span=None, by_name=False):
     """Packed + uploaded alignments of ONE contig -> (DevicePack, World).  The key carries the contig (one BAM holds many),
     the FASTA, the flag filter, the exclusion list and the device; the SNP and the indel path share the entry.
     span (lo, hi): only the alignments overlapping it are decoded and packed (a rank that owns part of a contig)."""
     world = _resolve(sam_path, chrom, fasta_path, span)
-    _check_supported(world, sam_path, chrom, supplementary)
+    _check_supported(world, sam_path, chrom, supplementary, by_name=by_name)
     if world.chrom != chrom:
         raise ValueError("alignments of contig %r requested, the source holds %r" % (chrom, world.chrom))
     src = id(world) if isinstance(sam_path, World) else sam_path
@@ -198,7 +203,7 @@ def device_pack(sam_path, fasta_path, chrom, supplementary=False, excl=None, dev
 
 def device_pack_for(dct, chrom, device=0, span=None):
     """Packed + uploaded alignments of contig `chrom` of dct['sam_path'] (cached per source / contig / filter / exclusions / span)."""
-    return device_pack(dct["sam_path"], dct.get("fasta_path"), chrom, dct.get("supplementary"), _exclude_rows(dct, chrom), device, span)[0]
+    return device_pack(dct["sam_path"], dct.get("fasta_path"), chrom, dct.get("supplementary"), _exclude_rows(dct, chrom), device, span, by_name=True)[0]
 
 
 def get_snp_testing_candidates(dct, region, device=0):

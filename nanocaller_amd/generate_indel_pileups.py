@@ -414,7 +414,7 @@ def decoded_contig(sam_path, chrom, fasta_path):
     contig, + the contig's reference bases.  One contig at a time stays cached."""
     key = (sam_path, chrom, fasta_path)
     if key not in _CONTIGS:
-        from .bam import decode_parallel, read_fasta, unsupported_counts
+        from .bam import decode_parallel, name_gids, read_fasta, unsupported_counts
         _CONTIGS.clear()
         dec = decode_parallel(sam_path, chrom, keep_seq=True)
         fasta = read_fasta(fasta_path, chrom)
@@ -428,6 +428,7 @@ def decoded_contig(sam_path, chrom, fasta_path):
                       read_off=dec["read_off"], codes=dec["codes"], names=dec["names"])
             w.meta.update(events=(dec["ev_off"], dec["ev_pos"], dec["ev_len"]), hap=dec["hap"], ps=dec["ps"], seq_off=dec["seq_off"], seq=dec["seq"])
             w.meta["unsupported"] = unsupported_counts(dec)          # (bam.read_bam's check: this World serves the SNP path and pass 1 too)
+            w.meta["name_gid"] = name_gids(dec)
             return w
         gsp._BAM_WORLDS.get((sam_path, fasta_path, chrom), as_world)
     return _CONTIGS[key]

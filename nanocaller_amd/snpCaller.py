@@ -320,7 +320,7 @@ def _prepare_wire(params, chrom, grp):
     from .wire import build_wire_from_world
     span = contig_span(params['sam_path'], chrom, grp)
     world = _resolve(params['sam_path'], chrom, params.get('fasta_path'), span)
-    _check_supported(world, params['sam_path'], chrom, bool(params.get('supplementary')))
+    _check_supported(world, params['sam_path'], chrom, bool(params.get('supplementary')), by_name=True)
     kw = dict(pos_lo=span[0], pos_hi=span[1]) if span else {}
     return build_wire_from_world(world, supplementary=bool(params.get('supplementary')), exclude=_exclude_rows(params, chrom), **kw)
 
@@ -411,7 +411,8 @@ def caller(params, chunks_Q, counter_Q, snp_files, device=0, worker_id=1):
         # that alone does not fit is decoded by the host threads.
         dev_codes, refs = [None], {}
         run_end, run_dev = [len(keys)] * len(keys), [None] * len(keys)       # per group: where its run of groups ends; the run's contigs (None: host route)
-        if piped and keys and params.get('device_ingest', os.environ.get('NC_DEVICE_INGEST', '1') != '0') and params.get('fasta_path'):
+        # (dct['supplementary']: a split read's records are keyed by NAME, pack.name_groups -- the host route's builders do that; the CLI never sets it)
+        if piped and keys and params.get('device_ingest', os.environ.get('NC_DEVICE_INGEST', '1') != '0') and params.get('fasta_path') and not params.get('supplementary'):
             from .bam import read_fasta_bytes
             from .device_bam import DeviceIngestUnavailable, open_device_bam, plan_shares
             try:

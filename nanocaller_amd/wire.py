@@ -75,7 +75,7 @@ def ref_wire_from_string(ref: str, exclude=None, pos0=1):
 
 
 def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, *, supplementary=False, tile_size=2048,
-               pos_lo=None, pos_hi=None, hap=None, events=None, strand=None, keep=None, pin=True, indel_extra=None) -> WirePack:
+               pos_lo=None, pos_hi=None, hap=None, events=None, strand=None, keep=None, pin=True, indel_extra=None, names=None, name_gid=None) -> WirePack:
     """read_* / codes as synth.World (coordinate order, codes[read_off[r] + p - read_start[r]]); `ref_wire_pos1`: uint8 per
     position, index p - 1 (ref_wire_from_string).  Flag filter and strand as pack.pack_reads, or given directly (`keep`,
     `strand`).  `indel_extra` (with `events`): dict of the per-read arrays of the device pass 2 for the KEPT reads (ins_off,
@@ -94,6 +94,13 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
     else:
         keep = np.ascontiguousarray(keep, np.uint8)
         strand = np.ascontiguousarray(strand, np.uint8)
+    mates = None
+    if (names is not None or name_gid is not None) and read_flag is not None:   # alignments that share read names (pack.name_groups): the name's strand, bit 3
+        from .pack import mate_table, name_groups
+        nxt, gstrand = name_groups(names, read_flag, keep, name_gid)
+        if nxt is not None:
+            strand = np.ascontiguousarray(gstrand | ((nxt >= 0).astype(np.uint8) << 3))
+            mates = mate_table(nxt, keep, rs, re_)
     if hap is not None:
         strand = np.ascontiguousarray(strand | (np.asarray(hap, np.uint8) & 3) << 1)          # bits 1-2: HP tag
     Lref = int(ref_wire_pos1.shape[0])
@@ -147,6 +154,9 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
                  ("blk_read", arr(v.blk_read, v.n_blocks, np.int32)),
                  ("events", arr(v.events, v.n_events, np.uint16)), ("ref_nib", ref_grid[0::2] | (ref_grid[1::2] << 4)), ("tile_off", tile_off),
                  ("tile_ent", np.frombuffer(tile_ent[:n_ent.value].tobytes(), np.uint8) if n_ent.value else np.zeros(16, np.uint8))]
+        if mates is not None:
+            mates = mate_table(nxt, keep, rs, re_, slot_off=arr(v.slot_off, v.n_reads + 1, np.int64))     # (checked against the builder's own slots)
+            parts += [("mate_key", mates[0]), ("mate_rec", mates[1].reshape(-1))]
         if del_implied:
             parts.append(("blk_ev", arr(v.blk_ev, v.n_blocks, np.uint32)))     # per block: where the read's deletion events start (nc_wire_expand_del)
         n_indel = -1
@@ -214,6 +224,9 @@ def build_wire_from_world(world: World, supplementary=False, exclude=None, **kw)
     if "events" in world.meta:
         kw.setdefault("hap", world.meta["hap"])
         kw.setdefault("events", world.meta["events"])
+    from .pack import world_name_gid, world_names
+    kw.setdefault("names", world_names(world))
+    kw.setdefault("name_gid", world_name_gid(world, supplementary))
     return build_wire(world.read_start, world.read_end, world.read_off, world.codes, world.read_flag,
                       ref_wire_from_string(world.ref, exclude), supplementary=supplementary, **kw)
 
@@ -274,6 +287,8 @@ def _device_pack(wp: WirePack, v, codes, ref_code, own_index):
     g = (lambda t: t.clone()) if own_index else (lambda t: t)
     dp = DevicePack(codes=codes, tile_off=g(v["tile_off"]), tile_ent=g(v["tile_ent"]), ref_code=ref_code, tile_size=wp.tile_size,
                     tile_pos0=wp.tile_pos0, n_tiles=wp.n_tiles, n_entries=wp.n_entries, pos_lo=wp.pos_lo, pos_hi=wp.pos_hi)
+    if "mate_key" in v:
+        dp.mates = (g(v["mate_key"]), g(v["mate_rec"]))
     if wp.n_indel_reads >= 0:
         dp.events = dict(n_reads=wp.n_indel_reads, ev_off=g(v["ev_off"]), ev_pos=g(v["ev_pos"]), ev_len=g(v["ev_len"]), read_hap=g(v["read_hap"]))
         dp.reads = dict(n_reads=wp.n_reads, rd_start=g(v["rd_start"]), rd_end=g(v["rd_end"]), slot_off=g(v["slot_off"]))

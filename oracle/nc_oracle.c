@@ -191,6 +191,20 @@ int oracle_snp_scan(int32_t n_reads, const int32_t *rstart, const int32_t *rend,
  * Above maxcov the reference draws an UNSEEDED random.sample (:215-216); this build's documented
  * policy is "first maxcov reads in input order" (parity is only defined for depth <= maxcov).
  */
+/* Alignments that share a read name: the reference's per-column pileup dict is keyed by NAME (:175,185), so where several alignments of one name
+ * cover a column the LAST in file order is the column's entry for that name, and a site's row for a name reads every column from whichever of
+ * the name's alignments covers it (:223,232).  mate_next[r] = the next alignment of r's name among the kept ones, circular (-1: the name is
+ * r's alone).  named_code: the code of r's NAME at p (-1: no alignment of the name in that column's pileup); *who = the alignment that gives it. */
+static inline int named_code(const reads_t *R, const int32_t *mate_next, int r, int32_t p, int *who)
+{
+    int best = (p >= R->start[r] && p < R->end[r]) ? r : -1;
+    if (mate_next && mate_next[r] >= 0)
+        for (int m = mate_next[r]; m != r; m = mate_next[m])
+            if (p >= R->start[m] && p < R->end[m] && m > best) best = m;
+    if (who) *who = best;
+    return best < 0 ? -1 : R->codes[R->off[best] + (p - R->start[best])];
+}
+
 int oracle_snp_featurize(int32_t n_reads, const int32_t *rstart, const int32_t *rend, const int64_t *roff,
                          const uint8_t *codes, const uint8_t *strand, const uint8_t *keep,
                          const uint8_t *ref_code,
@@ -198,7 +212,7 @@ int oracle_snp_featurize(int32_t n_reads, const int32_t *rstart, const int32_t *
                          const int32_t *cand_pos, int32_t n_cand,
                          int mode, int32_t maxcov, int32_t min_nbr_sites,
                          int32_t *out_pos, int32_t *out_ref, float *mat, int32_t *fwd, int32_t *rev,
-                         int32_t *depth_each)
+                         int32_t *depth_each, const int32_t *mate_next)
 {
     reads_t R = {n_reads, rstart, rend, roff, codes, strand, keep};
     int32_t *S = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads > 0 ? n_reads : 1));
@@ -224,6 +238,11 @@ int oracle_snp_featurize(int32_t n_reads, const int32_t *rstart, const int32_t *
             if (keep && !keep[r]) continue;
             int c = read_code(&R, r, v);
             if (c < 0) continue;
+            if (mate_next && mate_next[r] >= 0) {                        /* a later alignment of the same name in this column replaces r (:175,185) */
+                int who;
+                named_code(&R, mate_next, r, v, &who);
+                if (who != r) continue;
+            }
             S[ns++] = r;
             if (c < 4) { if (strand[r]) rv[c]++; else f[c]++; }          /* :210-213, all reads */
         }
@@ -241,7 +260,7 @@ int oracle_snp_featurize(int32_t n_reads, const int32_t *rstart, const int32_t *
             int c = read_code(&R, r, v);
             if (c > 3) continue;                                         /* centre code 4 contributes nowhere (:247) */
             for (int j = 0; j < ncols; j++) {
-                int b = read_code(&R, r, cols[j]);
+                int b = named_code(&R, mate_next, r, cols[j], NULL);      /* pileup_dict[nb_pos][name] (:223,232) */
                 if (b >= 0 && b < 4) cnt[c][j][b]++;
             }
         }

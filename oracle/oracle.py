@@ -57,6 +57,32 @@ def _reads(world, supplementary=False):
             strand, keep)
 
 
+def _mates(world, keep, strand):
+    """Alignments that share a read name (the reference's pileup dicts are keyed by name, generate_SNP_pileups.py:141-143,175,185): -> (mate_next
+    int32 [n] or None, strand): mate_next[r] = the next kept alignment of r's name, circular, -1 when the name is r's alone; the strand of every
+    alignment of a name is the 0x10 bit of its LAST primary record in file order (strand_dict[qname] is assigned per primary record, :141-143;
+    the reference raises KeyError when none is in the chunk's fetch window -- here the alignments of such a name keep their own bits)."""
+    names = getattr(world, "names", None)
+    if names is None or len(names) != len(world.read_start):
+        return None, strand
+    groups = {}
+    for r in np.nonzero(keep)[0].tolist():
+        groups.setdefault(names[r], []).append(r)
+    nxt = np.full(len(keep), -1, np.int32)
+    strand = strand.copy()
+    any_ = False
+    for g in groups.values():
+        if len(g) < 2:
+            continue
+        any_ = True
+        for a, b in zip(g, g[1:] + g[:1]):
+            nxt[a] = b
+        prim = [r for r in g if (int(world.read_flag[r]) & 0x900) == 0]
+        if prim:
+            strand[g] = strand[prim[-1]]
+    return (nxt if any_ else None), strand
+
+
 def ref_codes_with_exclusions(world, exclude=None):
     from nanocaller_amd.synth import world_ref_codes
     rc = world_ref_codes(world).copy()
@@ -100,6 +126,7 @@ def snp_scan(world, rc, start, end, ploidy, mincov, min_allele_freq, threshold, 
 
 def snp_featurize(world, rc, nbr, cpos, seq, maxcov, min_nbr_sites, supplementary=False):
     rs, re_, ro, codes, strand, keep = _reads(world, supplementary)
+    mate_next, strand = _mates(world, keep, strand)
     n = int(cpos.size)
     out_pos = np.zeros(max(n, 1), np.int32)
     out_ref = np.zeros(max(n, 1), np.int32)
@@ -114,7 +141,8 @@ def snp_featurize(world, rc, nbr, cpos, seq, maxcov, min_nbr_sites, supplementar
                                    _p(rc, C.c_uint8), _p(nbr, C.c_int32), C.c_int32(nbr.size),
                                    _p(cpos, C.c_int32), C.c_int32(n), C.c_int(MODES[seq]), C.c_int32(maxcov),
                                    C.c_int32(min_nbr_sites), _p(out_pos, C.c_int32), _p(out_ref, C.c_int32),
-                                   _p(mat, C.c_float), _p(fwd, C.c_int32), _p(rev, C.c_int32), _p(dep, C.c_int32))
+                                   _p(mat, C.c_float), _p(fwd, C.c_int32), _p(rev, C.c_int32), _p(dep, C.c_int32),
+                                   _p(mate_next, C.c_int32) if mate_next is not None else None)
     assert k >= 0, k
     return out_pos[:k], out_ref[:k], mat[:k], fwd[:k], rev[:k], dep[:k]
 

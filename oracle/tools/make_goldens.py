@@ -48,7 +48,7 @@ def save_world(name, w):
 
 
 def run_snp(case, world_name, w, seq, ploidy, start, end, threshold=(0.4, 0.6), mincov=4, maxcov=160,
-            min_allele_freq=0.15, min_nbr_sites=1, supplementary=False, exclude=None):
+            min_allele_freq=0.15, min_nbr_sites=1, supplementary=False, exclude=None, extra=None):
     pysam.register("bam", w)
     pysam.register("fa", w)
     if exclude:
@@ -70,7 +70,48 @@ def run_snp(case, world_name, w, seq, ploidy, start, end, threshold=(0.4, 0.6), 
         exclude=np.array([(a, b) for (_, a, b) in (exclude or [])], np.int64).reshape(-1, 2),
         pos=np.asarray(pos, np.int64), ref=np.asarray(ref, np.int32).reshape(n, 4), mat=mat.astype(np.int16),
         dp=np.asarray(dp, np.int64), freq=np.asarray(freq, np.float64), depth=np.float64(depth),
-        fwd_dp=np.asarray(fwd, np.float64).reshape(n, 4), rev_dp=np.asarray(rev, np.float64).reshape(n, 4))
+        fwd_dp=np.asarray(fwd, np.float64).reshape(n, 4), rev_dp=np.asarray(rev, np.float64).reshape(n, 4), **(extra or {}))
+    return np.asarray(pos, np.int64)
+
+
+def mates_world(w, start, end, seed):
+    """`w` with some alignments RENAMED to share another alignment's read name and flagged supplementary (0x800, strand bit redrawn): what a split
+    read looks like to the pileup (generate_SNP_pileups.py:141-143,175,185 key strand, bases and neighbour lookups by NAME).  Every group's
+    primary overlaps [start, end] (the reference raises KeyError for a name without a primary in its fetch window).  Kinds, in turn: a later
+    overlapping alignment, an earlier overlapping one, one nearby without overlap, two partners.  -> (world, name id per alignment)"""
+    import copy
+    rng = np.random.Generator(np.random.PCG64(seed))
+    R = w.n_reads
+    name_id = np.arange(R, dtype=np.int32)
+    flag = w.read_flag.copy()
+    plain = [r for r in range(R) if int(flag[r]) in (0, 16)]
+    prim = [r for r in plain if w.read_start[r] <= end and w.read_end[r] > start]
+    rng.shuffle(prim)
+    used, kinds, made = set(), 0, []
+    for r1 in prim:
+        if r1 in used:
+            continue
+        ov = [r for r in plain if r != r1 and r not in used and w.read_start[r] < w.read_end[r1] and w.read_start[r1] < w.read_end[r]]
+        near = [r for r in plain if r != r1 and r not in used and r not in ov
+                and min(abs(int(w.read_start[r]) - int(w.read_end[r1])), abs(int(w.read_start[r1]) - int(w.read_end[r]))) < 15_000]
+        kind = kinds % 4
+        pick = {0: [r for r in ov if r > r1][:1], 1: [r for r in ov if r < r1][-1:], 2: near[:1], 3: ([r for r in ov if r > r1][:1] + near[:1])}[kind]
+        if not pick or (kind == 3 and len(pick) < 2):
+            continue
+        kinds += 1
+        used.add(r1)
+        for r2 in pick:
+            used.add(r2)
+            name_id[r2] = name_id[r1]
+            flag[r2] = 0x800 | (16 if rng.random() < 0.5 else 0)
+        made.append((r1, pick))
+        if len(made) >= 14:
+            break
+    w2 = copy.copy(w)
+    w2.read_flag = flag
+    w2.names = ["r%07d" % i for i in name_id]
+    print("mates_world: %d names shared by %d alignments" % (len(made), len(made) + sum(len(p) for _, p in made)))
+    return w2, name_id
 
 
 def make_snp_goldens():
@@ -102,6 +143,14 @@ def make_snp_goldens():
     run_snp("ont_suppl_params", "ont", w_ont, "ont", "diploid", 60_000, 72_000, threshold=(0.3, 0.7), mincov=8,
             min_allele_freq=0.2, supplementary=True, min_nbr_sites=3)
     run_snp("ont_empty", "ont", w_ont, "ont", "diploid", 60_000, 60_400, min_allele_freq=0.999, mincov=500)
+    # alignments that share read names (split reads under dct['supplementary']): the world "ont" with the names / flags stored in the case file
+    w_m, name_id = mates_world(w_ont, 60_000, 72_000, seed=77)
+    plain = run_snp("ont_mates_off", "ont", w_ont, "ont", "diploid", 60_000, 72_000, supplementary=True, mincov=4)
+    got = run_snp("ont_mates", "ont", w_m, "ont", "diploid", 60_000, 72_000, supplementary=True, mincov=4,
+                  extra=dict(name_id=name_id, read_flag=w_m.read_flag))
+    os.remove(os.path.join(OUT, "snp_ont_mates_off.npz"))                # (only its sites: the renamed world must not be the plain one in disguise)
+    z0, z1 = plain, got
+    print("   sites: %d with shared names, %d with unique names" % (len(z1), len(z0)))
     run_snp("hifi_pacbio_dip", "hifi", w_hifi, "pacbio", "diploid", 30_000, 60_000, threshold=(0.3, 0.7))
     run_snp("hifi_pacbio_hap", "hifi", w_hifi, "pacbio", "haploid", 30_000, 60_000)
     run_snp("deep_ont", "deep", w_deep, "ont", "diploid", 6_000, 18_000)

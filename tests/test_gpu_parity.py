@@ -852,10 +852,11 @@ def test_reference_skips_are_refused_not_silently_accepted(eng, tmp_path):
     gsp.release_contig()
 
 
-def test_same_name_overlaps_are_refused_not_silently_accepted(eng, tmp_path):
+def test_same_name_overlaps_are_keyed_by_name_on_the_snp_route_and_refused_on_the_indel_route(eng, tmp_path):
     """two kept alignments of one read name that overlap on the reference: the reference's per-column dicts hold ONE entry per name
-    (generate_SNP_pileups.py:175,185,208), the read-major pack would count two -- NC_ERR_UNSUPPORTED (nc_decoded_check).  A supplementary
-    alignment of the same name is only in the way when the flag filter keeps supplementary alignments"""
+    (generate_SNP_pileups.py:175,185,208).  The SNP route keys such records by name (round 6: pack.name_groups -> nc_snp_set_mates; results
+    against the reference's golden and the oracle: tests/test_mates.py); the indel route, whose pass 2 is per alignment, still answers
+    NC_ERR_UNSUPPORTED (nc_decoded_check).  A supplementary alignment of the same name only matters when the flag filter keeps it"""
     from nanocaller_amd import _lib, generate_SNP_pileups as gsp, snpCaller
     from tests import bamio
     ref = "ACGT" * 2000
@@ -869,18 +870,23 @@ def test_same_name_overlaps_are_refused_not_silently_accepted(eng, tmp_path):
     bam1 = str(tmp_path / "d1.bam")
     bamio.write_bam(bam1, "c", len(ref), sorted(recs + [dict(name="r3", flag=0, pos0=150, cigar=[("M", 200)], seq=ref[150:350])], key=lambda r: r["pos0"]))
     gsp.release_contig()
+    assert snpCaller.call_chunks(dict(base, sam_path=bam1, fasta_path=fa), chunks)["n"] >= 0
+    w1 = gsp._resolve(bam1, "c", fa)
     with pytest.raises(_lib.NanoCallerHipError) as e:
-        snpCaller.call_chunks(dict(base, sam_path=bam1, fasta_path=fa), chunks)
+        gsp._check_supported(w1, bam1, "c")                              # (what the indel route's device_pack() asks)
     assert e.value.status == _lib.NC_ERR_UNSUPPORTED and "same read name" in str(e.value)
-    # (2) the second one flagged supplementary: dropped by the default filter, refused with dct['supplementary']
+    # (2) the second one flagged supplementary: dropped by the default filter, kept and keyed by name with dct['supplementary']
     bam2 = str(tmp_path / "d2.bam")
     bamio.write_bam(bam2, "c", len(ref), sorted(recs + [dict(name="r3", flag=0x800, pos0=150, cigar=[("M", 200)], seq=ref[150:350])], key=lambda r: r["pos0"]))
     gsp.release_contig()
     res = snpCaller.call_chunks(dict(base, sam_path=bam2, fasta_path=fa), chunks)
     assert res["n"] >= 0
     gsp.release_contig()
+    assert snpCaller.call_chunks(dict(base, sam_path=bam2, fasta_path=fa, supplementary=True), chunks)["n"] >= 0
+    w2 = gsp._resolve(bam2, "c", fa)
+    gsp._check_supported(w2, bam2, "c", supplementary=False)
     with pytest.raises(_lib.NanoCallerHipError) as e:
-        snpCaller.call_chunks(dict(base, sam_path=bam2, fasta_path=fa, supplementary=True), chunks)
+        gsp._check_supported(w2, bam2, "c", supplementary=True)
     assert e.value.status == _lib.NC_ERR_UNSUPPORTED
     gsp.release_contig()
 

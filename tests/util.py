@@ -28,6 +28,11 @@ SNP_CASES = sorted(f[4:-4] for f in os.listdir(GOLD) if f.startswith("snp_") and
 def load_snp_case(case):
     z = np.load(os.path.join(GOLD, "snp_%s.npz" % case))
     world = load_world(str(z["world"]))
+    if "name_id" in z:                                                   # the same alignments with shared read names / other flags (make_goldens.mates_world)
+        import copy
+        world = copy.copy(world)
+        world.names = ["r%07d" % i for i in z["name_id"]]
+        world.read_flag = z["read_flag"]
     dct = dict(threshold=[float(z["threshold"][0]), float(z["threshold"][1])], supplementary=bool(z["supplementary"]),
                mincov=int(z["mincov"]), maxcov=int(z["maxcov"]), min_allele_freq=float(z["min_allele_freq"]),
                min_nbr_sites=int(z["min_nbr_sites"]), seq=str(z["seq"]), exclude_bed=None)
