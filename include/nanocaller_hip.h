@@ -570,8 +570,10 @@ int nc_pass2_free(nc_pass2 *p);
  * (:331) rebuilt from the position-addressed codes + the indel events + the bases that have no reference column, the star
  * alignment (nc_star_msa_tensor_dup's algorithm: same recurrences and tie rules), msa()'s histogram / consensus / tensor
  * (:57-71) and allele_prediction (:77-127).  Results equal nc_indel_pass2_sets -> nc_star_msa_tensor_dup ->
- * nc_allele_prediction_device on the same inputs.  dct['impute_indel_phase'] is not covered (its read grouping needs the
- * pileup strings): callers use the host route for it.
+ * nc_allele_prediction_device on the same inputs.  dct['impute_indel_phase'] (params.impute, diploid; :278-304) since round 6: the reads of
+ * every col_type-2 column are grouped by pileup string in HBM (letter + event length + inserted bases, keyed by a 64-bit hash), the
+ * column becomes a small-window anchor 10 bp upstream when both sides of the rule hold mincov reads, and the anchor's pass-2 sets are
+ * those two groups instead of the HP tags; needs reads->ins_off / ins_bases; NC_ERR_CAPACITY on a col_type-2 column deeper than 512 reads.
  *
  * nc_indel_pack_build (host): the per-read arrays of the KEPT reads in pack order, from a decoded contig (keep_seq != 0):
  * events / HP / PS, the inserted bases of every insertion event (ins_off [n_events + 1] into ins_bases; deletions own empty

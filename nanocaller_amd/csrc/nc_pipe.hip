@@ -49,6 +49,158 @@ struct PipeChunk {
 };
 
 // ---------------------------------------------------------------------------------------------------------------- plan
+// dct['impute_indel_phase'] on the device pipeline (generate_indel_pileups.py:278-304; round 6).  K7 marks the columns that meet the rule's column-level
+// predicate (:278-284) with col_type 2; the rule then groups the column's reads by their pileup STRING (base letter + '+n<inserted bases>' /
+// '-nN..', upper-cased: :279,287-289), takes the largest group against the runner-up (or against everybody else; or, when one string holds more
+// than 80 % of the reads, its first half against its second: :291-297) and makes the column an anchor 10 bp upstream when both sides hold mincov
+// reads (:298-303); pass 2 uses those two read-name sets instead of the haplotype tags (:310-312).  Here: k_impute_flags runs the grouping for
+// every col_type-2 column and rewrites it to 3 (anchor) or -1; k_pick treats 3 as the small-window rule and notes the source column in the
+// anchor's type byte (bit 1 = imputed, bits 2-5 = column - anchor: 10 unless the anchor was clipped to 1); k_sets<.., true> repeats the grouping
+// at the source column of an imputed anchor and reads the members' sides where it read the HP tags.  A read's string is keyed by a 64-bit hash
+// of (letter, event length, inserted bases); columns deeper than IMP_CAP reads raise the capacity bit (host-assembled route).
+constexpr int IMP_CAP = 512;
+struct ImpArgs {
+    const int32_t *tile_off;
+    const nc_tile_entry *tile_ent;
+    int32_t tile_pos0, tile_size, n_tiles;
+    const uint8_t *codes;
+    const int64_t *slot_off;
+    int32_t n_reads;
+    const int32_t *ev_off, *ev_pos, *ev_len, *ins_off;
+    const uint8_t *ins_bases;
+    const int32_t *ent_read;           // the read of every tile entry (K7's table), or NULL: by search on the slot offsets
+    int32_t mincov;
+};
+struct ImpLds {                        // one wave's scratch
+    uint64_t key[IMP_CAP];
+    int64_t slot[IMP_CAP];             // the read's slot offset: what identifies it in any tile's entries
+    uint16_t first[IMP_CAP], cnt[IMP_CAP];
+    uint8_t side[IMP_CAP];             // 0: in neither set, 1: read_names_0, 2: read_names_1
+};
+// One wave.  -> n = reads in the column's pileup (file order; -1: more than IMP_CAP), L.slot / L.side filled; pass = both sets hold mincov reads
+__device__ __forceinline__ int impute_group(const ImpArgs &p, int32_t v, ImpLds &L, bool &pass)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    pass = false;
+    const int t = (v - p.tile_pos0) / p.tile_size;
+    if (v < p.tile_pos0 || t >= p.n_tiles) return 0;
+    const int e0 = p.tile_off[t], e1 = p.tile_off[t + 1];
+    int n = 0;
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int e = eb + lane;
+        nc_tile_entry ent;
+        ent.start = 0; ent.end = 0; ent.base_flag = 0;
+        if (e < e1) ent = p.tile_ent[e];
+        const bool cov = e < e1 && ent.start <= v && v < ent.end;
+        const uint64_t m = __ballot(cov);
+        const int idx = n + __popcll(m & lt);
+        if (cov && idx < IMP_CAP) {
+            const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
+            int r;
+            if (p.ent_read) r = p.ent_read[e];
+            else {
+                int lo = 0, hi = p.n_reads;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (p.slot_off[mid] < so) lo = mid + 1; else hi = mid; }
+                r = lo;
+            }
+            const int f0 = p.ev_off[r], f1 = p.ev_off[r + 1];
+            int lo = f0, hi = f1;                                            // first event on a column >= v
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (p.ev_pos[mid] < v) lo = mid + 1; else hi = mid; }
+            const int k = lo;
+            bool deleted = false;
+            if (k > f0) { const int32_t el = p.ev_len[k - 1]; deleted = el < 0 && p.ev_pos[k - 1] - el >= v; }
+            const int code = p.codes[(ent.base_flag & ~int64_t(15)) + v];
+            const uint32_t letter = deleted ? 5u : (code < 4 ? (uint32_t)code : 4u);       // A G T C, N (any other base), '*'
+            int32_t len = 0;
+            if (k < f1 && p.ev_pos[k] == v) len = p.ev_len[k];
+            uint64_t h = 1469598103934665603ull;                                             // FNV-1a over letter, length, inserted bases
+            h = (h ^ letter) * 1099511628211ull;
+            h = (h ^ (uint64_t)(uint32_t)len) * 1099511628211ull;
+            if (len > 0)
+                for (int i = p.ins_off[k]; i < p.ins_off[k + 1]; i++) h = (h ^ p.ins_bases[i]) * 1099511628211ull;
+            L.key[idx] = h;
+            L.slot[idx] = so;
+        }
+        n += __popcll(m);
+    }
+    if (n > IMP_CAP) return -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // groups: first member and size of every read's string
+    for (int i = lane; i < n; i += 64) {
+        const uint64_t ki = L.key[i];
+        int first = -1, c = 0;
+        for (int j = 0; j < n; j++)
+            if (L.key[j] == ki) { if (first < 0) first = j; c++; }
+        L.first[i] = (uint16_t)first;
+        L.cnt[i] = (uint16_t)c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // sorted(groups, key = size, reverse = True) is stable: the largest, ties to the string seen first; then the runner-up
+    auto top = [&](int skip) -> uint32_t {
+        uint32_t best = 0;
+        for (int i = lane; i < n; i += 64)
+            if (L.first[i] == i && i != skip) best = max(best, ((uint32_t)L.cnt[i] << 16) | (uint32_t)(0xffff - i));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
+        return best;
+    };
+    if (n == 0) return 0;
+    const uint32_t b0 = top(-1);
+    const int g0 = 0xffff - (int)(b0 & 0xffffu), c0 = (int)(b0 >> 16);
+    int n0 = 0, n1 = 0;
+    if ((double)c0 <= 0.8 * (double)n) {                                                     // :291
+        const uint32_t b1 = top(g0);
+        const int g1 = 0xffff - (int)(b1 & 0xffffu), c1 = (int)(b1 >> 16);
+        const bool second = c1 >= p.mincov;                                                  // :293: the runner-up, else everybody else
+        for (int i = lane; i < n; i += 64) L.side[i] = L.first[i] == g0 ? 1 : ((second ? L.first[i] == g1 : true) ? 2 : 0);
+        n0 = c0;
+        n1 = second ? c1 : n - c0;
+    } else {                                                                                 // :295-296: the string's first half against its second
+        const int half = c0 / 2;
+        int base = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = i < n && L.first[i] == g0;
+            const uint64_t m = __ballot(in);
+            const int rank = base + __popcll(m & lt);
+            if (i < n) L.side[i] = in ? (rank < half ? 1 : 2) : 0;
+            base += __popcll(m);
+        }
+        n0 = half;
+        n1 = c0 - half;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    pass = n0 >= p.mincov && n1 >= p.mincov;                                                 // :298
+    return n;
+}
+
+// every col_type-2 column of the chunks -> 3 (the grouping yields two sets of mincov reads: an anchor, :298-303) or -1.  One block per chunk and
+// slab of 4096 columns, a wave per 1024 of them.
+__global__ __launch_bounds__(256) void k_impute_flags(const PipeChunk *__restrict__ pc, int8_t *__restrict__ ctype, ImpArgs p, int32_t *__restrict__ err)
+{
+    __shared__ ImpLds lds[4];
+    const PipeChunk c = pc[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int8_t *ct = ctype + c.coloff;
+    const int col_lo = (int)blockIdx.y * 4096 + wv * 1024;
+    for (int b = col_lo; b < min(col_lo + 1024, c.ncol); b += 64) {
+        const int col = b + lane;
+        uint64_t m = __ballot(col < c.ncol && ct[col] == 2);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            bool pass;
+            const int n = impute_group(p, c.lo + b + l, lds[wv], pass);
+            if (n < 0 && lane == 0) atomicOr(err, 16);
+            if (lane == 0) ct[b + l] = pass ? 3 : -1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_pick(const PipeChunk *__restrict__ pc, const int8_t *__restrict__ ctype, int32_t win,
                                              int32_t *__restrict__ seg_pos, int8_t *__restrict__ seg_type, int32_t *__restrict__ cnt,
                                              int32_t *__restrict__ err)
@@ -88,7 +240,7 @@ __global__ __launch_bounds__(64) void k_pick(const PipeChunk *__restrict__ pc, c
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-                m16 |= (t <= 1u ? 1u : 0u) << k;
+                m16 |= ((t <= 1u || t == 3u) ? 1u : 0u) << k;                 // (3: an imputed column, k_impute_flags)
             }
             {
                 const int64_t sh = skip_to - col0;                    // (a skip that reaches into this step)
@@ -102,16 +254,21 @@ __global__ __launch_bounds__(64) void k_pick(const PipeChunk *__restrict__ pc, c
                 const uint32_t mm = (uint32_t)__shfl((int)m16, l);
                 const int bq = __ffs((int)mm) - 1;
                 const int32_t v = c.lo + bb + 16 * l + bq;
-                const int tb = (int)((__shfl((int)w[0], l) * (bq < 4) + __shfl((int)w[1], l) * (bq >= 4 && bq < 8) + __shfl((int)w[2], l) * (bq >= 8 && bq < 12) +
+                const int tc = (int)((__shfl((int)w[0], l) * (bq < 4) + __shfl((int)w[1], l) * (bq >= 4 && bq < 8) + __shfl((int)w[2], l) * (bq >= 8 && bq < 12) +
                                       __shfl((int)w[3], l) * (bq >= 12)) >> ((bq & 3) * 8)) & 0xff;
-                const int32_t prev = tb == 0 ? v + win : v + 10;                     // :267, :273
-                const int32_t an = tb == 0 ? max(1, v - win) : max(1, v - 10);       // :268, :274
+                const int32_t prev = tc == 0 ? v + win : v + 10;                     // :267, :273, :301
+                const int32_t an = tc == 0 ? max(1, v - win) : max(1, v - 10);       // :268, :274, :302
+                const int tb = tc == 3 ? (1 | 2 | ((v - an) << 2)) : tc;             // imputed: the small-window type + where its read sets come from
                 // variants[an] = tb: the anchors stay sorted; an equal key is overwritten (dict), a smaller one (a small-window
                 // anchor followed by a long-window one less than 30 columns later) goes a few places back
                 int i = n;
                 while (i > 0 && apos(i - 1) > an) i--;
                 if (i > 0 && apos(i - 1) == an) {
-                    if (lane == 0) anc[i - 1] = apack(an, tb);
+                    // variants[an] is overwritten; extra_variants[an] (an imputed column's read sets) stays unless an imputed column writes it again
+                    if (lane == 0) {
+                        const int old = (int)(anc[i - 1] & 0xffu);
+                        anc[i - 1] = apack(an, ((tb & 2) || !(old & 2)) ? tb : ((old & ~1) | tb));
+                    }
                 } else if (n >= PICK_CAP) {
                     over = true;
                 } else {
@@ -322,11 +479,14 @@ struct SetArgs {
     const int32_t *ent_read, *ent_cur, *ev_off;
     int32_t spt;
     int2 *al_ev;
+    ImpArgs imp;                       // (k_sets<.., true>) the grouping of an imputed anchor's source column
+    int32_t *err;
 };
 
-template <bool FILL>
+template <bool FILL, bool IMP>
 __global__ __launch_bounds__(256) void k_sets(SetArgs p)
 {
+    __shared__ ImpLds imp_lds[IMP ? 4 : 1];
     const int lane = threadIdx.x & 63;
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= p.n_anchor) return;
@@ -344,6 +504,16 @@ __global__ __launch_bounds__(256) void k_sets(SetArgs p)
         ok = ok && __all(mine);
     }
     int n_all = 0, n_1 = 0, n_2 = 0, n_u = 0, first0 = -1;
+    // an imputed anchor (impute_indel_phase): the two read sets of its source column stand where the HP tags stand otherwise (:310-312)
+    int n_imp = -1;
+    if constexpr (IMP) {
+        const int tb = (int)(uint8_t)p.anc_type[a];
+        if (tb & 2) {
+            bool pass_unused;
+            n_imp = impute_group(p.imp, v + (tb >> 2), imp_lds[threadIdx.x >> 6], pass_unused);
+            if (n_imp < 0) { if (lane == 0) atomicOr(p.err, 16); n_imp = 0; }
+        }
+    }
     const int t = (v - p.tile_pos0) / p.tile_size;
     const int site = FILL ? p.site_of[a] : 0;
     const int al0 = FILL ? p.al_of[a] : 0;
@@ -356,7 +526,18 @@ __global__ __launch_bounds__(256) void k_sets(SetArgs p)
             ent.start = 0; ent.end = 0; ent.base_flag = 0;
             if (e < e1) ent = p.tile_ent[e];
             const bool cov = e < e1 && ent.start <= v && v < ent.end;            // the pileup at the anchor, in pack (= file) order
-            const int hp = (int)((ent.base_flag >> 1) & 3);
+            int hp = (int)((ent.base_flag >> 1) & 3);
+            if constexpr (IMP) {
+                if (n_imp >= 0) {
+                    hp = 0;
+                    if (cov) {
+                        const ImpLds &L = imp_lds[threadIdx.x >> 6];
+                        const int64_t so = (ent.base_flag & ~int64_t(15)) + (ent.start & ~15);
+                        for (int j = 0; j < n_imp; j++)
+                            if (L.slot[j] == so) { hp = L.side[j]; break; }
+                    }
+                }
+            }
             const uint64_t m_all = __ballot(cov), m_1 = __ballot(cov && hp == 1), m_2 = __ballot(cov && hp == 2);
             const int my_all = n_all + __popcll(m_all & lt), my_1 = n_1 + __popcll(m_1 & lt), my_2 = n_2 + __popcll(m_2 & lt);
             int member = 0;
@@ -414,7 +595,7 @@ __global__ __launch_bounds__(256) void k_sets(SetArgs p)
     } else if (lane == 0) {
         p.site_pos[site] = v;
         p.site_chunk[site] = p.anc_chunk[a];
-        p.site_type[site] = p.anc_type[a];
+        p.site_type[site] = p.anc_type[a] & 1;                                          // (the window rule; bits 1-5: an imputed anchor's source)
         p.site_phase[site] = (!p.haploid && first0 >= 0) ? p.read_ps[first0] : 0;       // :349 (set 0 holds HP-tagged reads only)
         p.site_al0[site] = al0;
         p.site_n2[site] = (int32_t)(b - v);
@@ -2450,7 +2631,8 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     if (!pack || !ref_code_dev || !reads || !prm || !n_sites || !n_alignments || n_chunks < 0 || (n_chunks && (!starts || !ends)) || window_after < 1 ||
         maxcov < 1 || chrom_len < 1)
         return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: bad argument");
-    if (prm->impute && !prm->haploid) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: impute_indel_phase is not covered by the device pipeline");
+    const bool impute = prm->impute && !prm->haploid;                 // (generate_indel_pileups.py:278: the diploid function only)
+    if (impute && (!reads->ins_off || !reads->ins_bases)) return nc_fail(ctx, NC_ERR_ARG, "nc_indel_sites_plan: impute_indel_phase needs the inserted bases");
     if (cpl_for(window_after + 1) == 0) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: windows longer than 271 bases");
     nc_indel_events ev;
     ev.n_reads = reads->n_reads; ev.ev_off = reads->ev_off; ev.ev_pos = reads->ev_pos; ev.ev_len = reads->ev_len; ev.read_hap = reads->read_hap;
@@ -2502,6 +2684,12 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     NC_TRY(nc_ensure(ctx, s->misc, 256));
     int32_t *err = (int32_t *)s->misc.p;                              // [0] error bits, [2..3] row total mailbox, [4..5] cells, [6..7] banded cells, [8..9] alt pool bytes, [16..23] band classes
     NC_HIP(ctx, hipMemsetAsync(s->misc.p, 0, 256, ctx->stream));
+    ImpArgs imp;
+    memset(&imp, 0, sizeof imp);
+    imp.tile_off = pack->tile_off; imp.tile_ent = pack->tile_ent; imp.tile_pos0 = pack->tile_pos0; imp.tile_size = pack->tile_size; imp.n_tiles = pack->n_tiles;
+    imp.codes = pack->codes; imp.slot_off = reads->slot_off; imp.n_reads = reads->n_reads;
+    imp.ev_off = reads->ev_off; imp.ev_pos = reads->ev_pos; imp.ev_len = reads->ev_len; imp.ins_off = reads->ins_off; imp.ins_bases = reads->ins_bases;
+    imp.mincov = prm->mincov;
     int32_t c0 = 0;
     std::vector<IndelChunk> ck;
     while (c0 < n_chunks) {
@@ -2512,6 +2700,12 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
                                           ev.n_reads == reads->n_reads ? reads->slot_off : nullptr, err, reads->rd_start, reads->rd_end, c0 > 0));
         for (int32_t k = 0; k < used; k++) pcs[(size_t)(c0 + k)].coloff = ck[(size_t)k].coloff;
         NC_TRY(nc_h2d_pieces(ctx, (PipeChunk *)s->pc.p + c0, pcs.data() + c0, (size_t)used * sizeof(PipeChunk), ctx->stream));
+        if (impute) {                                                 // the read grouping of every col_type-2 column: 3 (an anchor) or -1
+            int32_t maxcol = 1;
+            for (int32_t k = 0; k < used; k++) maxcol = std::max(maxcol, pcs[(size_t)(c0 + k)].ncol);
+            hipLaunchKernelGGL(k_impute_flags, dim3((unsigned)used, (unsigned)((maxcol + 4095) / 4096)), dim3(256), 0, ctx->stream, (const PipeChunk *)s->pc.p + c0,
+                               const_cast<int8_t *>(ctype), imp, err);
+        }
         hipLaunchKernelGGL(k_pick, dim3(used), dim3(64), 0, ctx->stream, (const PipeChunk *)s->pc.p + c0, ctype, prm->win_size, (int32_t *)s->seg_pos.p,
                            (int8_t *)s->seg_type.p, (int32_t *)s->cnt.p, err);
         NC_HIP(ctx, hipGetLastError());
@@ -2529,6 +2723,7 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     const int32_t na = mb[0], errh = mb[1];
     if (errh & 1) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: anchor buffer of a chunk overflowed");
     if (errh & 8) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: more than 16,000 alignments over one tile of the index");
+    if (errh & 16) return nc_fail(ctx, NC_ERR_CAPACITY, "nc_indel_sites_plan: impute_indel_phase on a column deeper than %d reads", IMP_CAP);
     s->n_anchor = na;
     s->planned = true;
     if (na == 0) {
@@ -2557,7 +2752,9 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
     }
     sa.n_anchor = na; sa.anc_pos = (const int32_t *)s->anc_pos.p; sa.anc_chunk = (const int32_t *)s->anc_chunk.p; sa.anc_type = (const int8_t *)s->anc_type.p;
     sa.kept = (int32_t *)s->kept.p; sa.nuniq = (int32_t *)s->nuniq.p;
-    hipLaunchKernelGGL(k_sets<false>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
+    sa.imp = imp; sa.imp.ent_read = sa.ent_read; sa.err = err;
+    if (impute) hipLaunchKernelGGL((k_sets<false, true>), dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL((k_sets<false, false>), dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
     NC_TRY((scan_launch<SC_PLAIN, int32_t>(ctx, ctx->stream, s->part_a, (const int32_t *)s->kept.p, na, 0, (int32_t *)s->site_of.p, true, nullptr, nullptr)));
     NC_TRY((scan_launch<SC_PLAIN, int32_t>(ctx, ctx->stream, s->part_a, (const int32_t *)s->nuniq.p, na, 0, (int32_t *)s->al_of.p, true, nullptr, nullptr)));
     NC_HIP(ctx, hipGetLastError());
@@ -2593,7 +2790,8 @@ extern "C" int nc_indel_sites_plan(nc_ctx *ctx, const nc_readpack *pack, const u
         NC_TRY(nc_ensure(ctx, s->al_ev, (size_t)std::max(nal, 1) * 8));
         sa.al_ev = (int2 *)s->al_ev.p;
     }
-    hipLaunchKernelGGL(k_sets<true>, dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
+    if (impute) hipLaunchKernelGGL((k_sets<true, true>), dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL((k_sets<true, false>), dim3((na + 3) / 4), dim3(256), 0, ctx->stream, sa);
     NC_HIP(ctx, hipGetLastError());
     NC_TRY(nc_h2d_small(ctx, (int32_t *)s->site_al0.p + ns, &nal, 4, ctx->stream));
     if (s->al0_cap < NS + 1) {

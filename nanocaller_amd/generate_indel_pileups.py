@@ -602,13 +602,13 @@ def device_indel_reads(ctg, flag, dp, device):
 
 
 def indel_sites_device(eng, dp, reads_c, chrom_len, chunks, *, mincov, maxcov, win_size, small_win_size, ins_t, del_t, window_after,
-                       haploid=False, excl=None, fetch=True):
+                       haploid=False, excl=None, fetch=True, impute=False):
     """nc_indel_sites_plan + _run (+ _fetch) for a list of (start, end) chunks of one contig -> dict: n, x (device float32
     [n, sets * 5, 128, 2]: the CNN input), and with fetch: pos / chunk / type / phase int32 [n], ref_len / alt_len int32 [n, sets],
     alt (uint8 codes, the ALT prefixes back to back in (site, set) order).  Raises NanoCallerHipError with .status."""
     L = eng.L
     prm = _lib.IndelScanParamsC(mincov=int(mincov), win_size=int(win_size), small_win_size=int(small_win_size), ins_t=float(ins_t),
-                                del_t=float(del_t), haploid=1 if haploid else 0, impute=0)
+                                del_t=float(del_t), haploid=1 if haploid else 0, impute=1 if (impute and not haploid) else 0)
     starts = np.ascontiguousarray([c[0] for c in chunks], np.int32)
     ends = np.ascontiguousarray([c[1] for c in chunks], np.int32)
     pc = dp.c_struct()
@@ -724,7 +724,7 @@ def indel_sites_for_chunks(dct, chunks, device, haploid, fetch=True):
     eng, dp, reads_c, ctg, excl = _indel_pack_for(dct, chunks, device)
     r = indel_sites_device(eng, dp, reads_c, len(ctg["fasta"]), [(c["start"], c["end"]) for c in chunks], mincov=dct["mincov"], maxcov=dct["maxcov"],
                            win_size=dct["win_size"], small_win_size=dct["small_win_size"], ins_t=dct["ins_t"], del_t=dct["del_t"],
-                           window_after=window_after, haploid=haploid, excl=excl, fetch=fetch)
+                           window_after=window_after, haploid=haploid, excl=excl, fetch=fetch, impute=bool(dct.get("impute_indel_phase")))
     return r, ctg
 
 
@@ -744,7 +744,10 @@ def device_route_ok(dct, chunks, haploid, impute_split=False):
     lists, which sorting by (start, end) does not make monotone, go through the host-assembled route instead of failing the worker.  With
     dct['impute_indel_phase'] (diploid) the route is open only to callers that split the chunk list first (impute_split_chunks: chunks with a
     column that meets the rule's predicate take the host-assembled route, whose read grouping needs the pileup strings)"""
-    if not (isinstance(chunks[0]["sam_path"], str) and (impute_split or not (dct.get("impute_indel_phase") and not haploid))
+    imputes = bool(dct.get("impute_indel_phase")) and not haploid
+    if imputes and os.environ.get("NC_IMPUTE_SPLIT") == "0":
+        return False
+    if not (isinstance(chunks[0]["sam_path"], str) and (impute_split or not imputes or impute_on_device())
             and not os.environ.get("NC_INDEL_HOST_PASS2")):
         return False
     ends = [c["end"] for c in sorted(chunks, key=lambda c: (c["start"], c["end"]))]
@@ -805,7 +808,7 @@ def sites_to_tuples(r, n_chunks, fasta, haploid, device_x):
                 row.append((fasta[p - 1:p - 1 + a], alt_all[o:o + b]))
             o += max(b, 0)
         alleles.append(row)
-    phase = r["phase"].tolist()
+    phase = [v if v else None for v in r["phase"].tolist()]          # PS of set 0's first read; a read without the tag (imputed sets): None (:181-183,349)
     bounds = np.searchsorted(chunk, np.arange(n_chunks + 1))                       # sites are chunk-major
     out = []
     for ci in range(n_chunks):
@@ -818,10 +821,19 @@ def sites_to_tuples(r, n_chunks, fasta, haploid, device_x):
             out.append((pos[a:b], x[a:b, 0:5], x[a:b, 5:10], x[a:b, 10:15], alleles[a:b], phase[a:b]))
     return out
 
+def impute_on_device():
+    """[r6] the device pipeline groups the reads of the imputed columns itself (k_impute_flags, k_sets<.., true>); NC_IMPUTE_DEVICE=0: round 5's
+    split (chunks with a column that meets the rule's predicate take the host-assembled route)"""
+    return os.environ.get("NC_IMPUTE_DEVICE", "1") != "0"
+
+
 def impute_split_chunks(dct, chunks, device, haploid):
-    """dct['impute_indel_phase'] on a chunk list the device pipeline could take: -> (indices for the device pipeline, indices for the host-assembled
-    route), or None when there is nothing to split (flag off, haploid, route closed).  NC_IMPUTE_SPLIT=0: everything on the host-assembled route"""
+    """dct['impute_indel_phase'] on a chunk list the device pipeline could take, when the device does not group the reads itself
+    (NC_IMPUTE_DEVICE=0): -> (indices for the device pipeline, indices for the host-assembled route), or None when there is nothing to split
+    (flag off, haploid, route closed, or the device takes the rule).  NC_IMPUTE_SPLIT=0: everything on the host-assembled route"""
     if not dct.get("impute_indel_phase") or haploid or os.environ.get("NC_IMPUTE_SPLIT") == "0" or not device_route_ok(dct, chunks, haploid, impute_split=True):
+        return None
+    if impute_on_device():
         return None
     order = sorted(range(len(chunks)), key=lambda k: (chunks[k]["start"], chunks[k]["end"]))
     mask = imputed_chunk_mask(dct, [chunks[k] for k in order], device)

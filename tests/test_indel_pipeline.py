@@ -316,6 +316,7 @@ def test_impute_indel_phase_splits_the_chunks_between_the_device_pipeline_and_th
     monkeypatch.setenv("NC_IMPUTE_SPLIT", "0")
     exp = gip.get_indel_testing_candidates_batch(dct, chunks)
     monkeypatch.delenv("NC_IMPUTE_SPLIT")
+    monkeypatch.setenv("NC_IMPUTE_DEVICE", "0")                                      # (round 5's route; the default groups on the device: next test)
     dev, host = gip.impute_split_chunks(dct, chunks, 0, False)
     assert len(dev) >= 4 and len(host) >= 2 and sorted(dev + host) == list(range(len(chunks)))
     assert all(30_000 - 10_000 < chunks[k]["start"] < 60_000 + 200 for k in host), [chunks[k]["start"] for k in host]
@@ -333,6 +334,60 @@ def test_impute_indel_phase_splits_the_chunks_between_the_device_pipeline_and_th
     # indelCaller.indel_run: the same file either way
     outs = []
     for tag, split in (("host", "0"), ("split", None)):
+        if split:
+            monkeypatch.setenv("NC_IMPUTE_SPLIT", split)
+        else:
+            monkeypatch.delenv("NC_IMPUTE_SPLIT", raising=False)
+        d = tmp_path / tag
+        d.mkdir()
+        params = _params(fa, impute_indel_phase=True, mincov=3, ins_t=0.3, del_t=0.3, indel_model="ONT-HG002", intermediate_indel_files_dir=str(d), prefix="t")
+        jobs = queue.Queue()
+        for c in chunks:
+            jobs.put(("indel", dict(c, ploidy="diploid")))
+        outs.append(open(indelCaller.indel_run(params, {}, jobs, queue.Queue(), [], aligner="device")).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 40
+
+
+@pytest.mark.gpu
+def test_impute_indel_phase_on_the_device_pipeline_equals_the_host_assembled_route(tmp_path, monkeypatch):
+    """[r6] dct['impute_indel_phase'] (generate_indel_pileups.py:278-304) entirely on the device pipeline: K7's col_type-2 columns grouped by pileup
+    string in HBM (k_impute_flags), the imputed anchors' read sets taken by k_sets<.., true> where it takes the HP tags otherwise -- the tuples and
+    the indel_run text of the host-assembled route (whose grouping, gip.impute_groups on the column strings, the reference-captured golden pins:
+    tests/test_indel_pass2.py, test_gpu_parity.py::test_impute_indel_phase_scan_matches_reference_pass1)"""
+    import queue
+    w = bamio.make_pass2_world(seed=23, length=120_000, depth=24, blocks=[(30_000, 60_000)])
+    bam, fa = str(tmp_path / "i.bam"), str(tmp_path / "i.fa")
+    bamio.write_bam(bam, w.chrom, w.length, bamio.world_to_records(w, None))
+    bamio.write_fasta(fa, w.chrom, w.ref)
+    from oracle import oracle
+    for kw in (dict(mincov=3, ins_t=0.3, del_t=0.3), dict(mincov=6, ins_t=0.25, del_t=0.25), dict(mincov=2, ins_t=0.4, del_t=0.5, maxcov=12)):
+        dct = _params(fa, impute_indel_phase=True, **kw)
+        chunks = [dict(chrom=w.chrom, start=s, end=min(w.length, s + 10_000), sam_path=bam) for s in range(1, w.length, 10_000)]
+        gip._CONTIGS.clear()
+        monkeypatch.setenv("NC_PIPE_BAND", "0")                                      # the host-assembled route aligns on the full matrix
+        monkeypatch.setenv("NC_IMPUTE_SPLIT", "0")
+        exp = gip.get_indel_testing_candidates_batch(dct, chunks)
+        monkeypatch.delenv("NC_IMPUTE_SPLIT")
+        real = gip._pass2_native
+
+        def boom(*a, **k):
+            raise AssertionError("the host-assembled route ran where the device pipeline was expected")
+        monkeypatch.setattr(gip, "_pass2_native", boom)
+        got = gip.get_indel_testing_candidates_batch(dct, chunks)
+        monkeypatch.setattr(gip, "_pass2_native", real)
+        n = _same_tuples(got, exp)
+        assert n > 40, (kw, n)
+        # imputed anchors exist among them (the unphased block), and so do sites outside it
+        ev, ex = oracle.indel_scan_impute(w, 28_000, 62_000, mincov=kw["mincov"], win_size=40, small_win_size=4, ins_t=kw["ins_t"], del_t=kw["del_t"])
+        got_pos = {int(p) for t in got for p in t[0]}
+        assert len(ex) > 3 and len(got_pos & set(ex)) >= 1 and any(p < 25_000 or p > 65_000 for p in got_pos), (kw, len(ex))
+    # round 5's split (NC_IMPUTE_DEVICE=0) still gives the same
+    monkeypatch.setenv("NC_IMPUTE_DEVICE", "0")
+    assert _same_tuples(gip.get_indel_testing_candidates_batch(dct, chunks), exp) == n
+    monkeypatch.delenv("NC_IMPUTE_DEVICE")
+    # indelCaller.indel_run: the same file either way
+    outs = []
+    for tag, split in (("host", "0"), ("device", None)):
         if split:
             monkeypatch.setenv("NC_IMPUTE_SPLIT", split)
         else:
