@@ -91,12 +91,14 @@ __device__ __forceinline__ int named_member(const FeatArgs &a, int64_t key, int3
     int lo = 0, hi = a.n_mates;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.mate_key[mid] < key) lo = mid + 1; else hi = mid; }
     if (self) *self = lo;
+    if (lo >= a.n_mates || a.mate_key[lo] != key) { if (self) *self = -2; return -1; }     // (an entry flagged without a row: a table of another pack)
     int best = -1, i = lo;
-    do {
+    for (int guard = 0; guard < 64; guard++) {                       // (a name's ring closes on itself; a damaged table must not hang the wave)
         const int4 r = a.mate_rec[i];
         if (r.x <= p && p < r.y && i > best) best = i;
         i = r.z;
-    } while (i != lo);
+        if (i == lo || i < 0 || i >= a.n_mates) break;
+    }
     return best;
 }
 __device__ __forceinline__ int named_code(const FeatArgs &a, int64_t key, int32_t p)
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(256) void k_featurize_pairs(FeatArgs a)
             if constexpr (MATES) {
                 if (cov && (ent.base_flag & 8)) {
                     int self;
-                    cov = named_member(a, (ent.base_flag & ~int64_t(15)) + (ent.start & ~15), v, &self) == self;   // else: replaced in this column
-                    rr.w |= 0x80000000u;
+                    const int m = named_member(a, (ent.base_flag & ~int64_t(15)) + (ent.start & ~15), v, &self);
+                    if (self >= 0) { cov = m == self; rr.w |= 0x80000000u; }                                      // m != self: replaced in this column
                 }
             }
             if (cov) {

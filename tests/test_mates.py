@@ -158,6 +158,11 @@ def test_shared_names_from_a_bam_file_equal_the_oracle_and_the_caller_takes_them
     assert len(out[0]) == len(exp[0]) > 50
     assert np.array_equal(out[0], exp[0]) and np.array_equal(np.asarray(out[2]), np.asarray(exp[2]))
     assert np.array_equal(out[6], exp[6]) and np.array_equal(out[7], exp[7]) and float(out[5]) == float(exp[5])
+    # the caller's chunk loop (int16 tensors, the wire through the upload ring) keys them by name as well: the strand depths it reports are the oracle's
+    from nanocaller_amd import snpCaller
+    res = snpCaller.call_chunks(dict(dct, snp_model="ONT-HG002", disable_coverage_normalization=False), [region])
+    assert res["n"] == len(exp[0]) and np.array_equal(res["pos"], exp[0])
+    assert np.array_equal(res["fwd_dp"], np.asarray(exp[6], res["fwd_dp"].dtype)) and np.array_equal(res["rev_dp"], np.asarray(exp[7], res["rev_dp"].dtype))
     plain = copy.copy(w)
     plain.names = None
     per_alignment = oracle.get_snp_testing_candidates(plain, dct, region)
