@@ -178,6 +178,11 @@ int nc_wire_free(nc_wire *w);
 /* ref_wire as it crosses PCIe since ABI 11: two positions per byte (position 2 i in the low nibble of byte i); nc_wire_ref_unpack (pointers dev, 16-byte
  * aligned) rebuilds the byte array nc_wire_expand reads, on the context's stream. */
 int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire);
+/* The inserted bases of the indel caller's pack (nc_indel_reads.ins_bases: codes 0..4) as they cross PCIe since round 6: two bits a base (base i in
+ * bits 2 (i & 3) of byte i >> 2), the few code-4 bases as a list of their indices.  nc_wire_ins_unpack (pointers dev; d_packed 4-byte,
+ * d_ins_bases 16-byte aligned, both padded to a multiple of 16 bases) rebuilds the byte array on the context's stream.  No reference
+ * counterpart (pysam hands the reference query_sequence strings, generate_indel_pileups.py:331). */
+int nc_wire_ins_unpack(nc_ctx *ctx, const uint8_t *d_packed, int64_t n_bases, const int32_t *d_other_idx, int32_t n_other, uint8_t *d_ins_bases);
 int nc_wire_build_del(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
                       const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
                       const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out);
@@ -208,6 +213,17 @@ int nc_indel_events_pack(int32_t n_reads, const int32_t *rd_start, const int32_t
 int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint16_t *d_d16,
                            const int8_t *d_l8, int32_t n_big, const int32_t *d_big_idx, const int32_t *d_big_pos, const int32_t *d_big_len,
                            const int32_t *d_read_ins_off, int32_t *d_ev_pos, int32_t *d_ev_len, int32_t *d_ins_off);
+/* One byte per event (round 6): b8 [n_events] = distance to the read's previous event in bits 2-7 (0 .. 62) | length code in bits 0-1 (+1, -1, +2, -2);
+ * 0xFF = the event is the next entry of d16x (the two-byte form above: distance | signed 5-bit length << 11, 0xFFFF -> side table), whose entries
+ * start at read_esc_off[r] [n_reads + 1] for read r.  NC_ERR_CAPACITY from the packer when esc_cap / big_cap are too small (*n_esc / *n_big say
+ * what is needed). */
+int nc_indel_events_pack8(int32_t n_reads, const int32_t *rd_start, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len,
+                          uint8_t *b8, uint16_t *d16x, int64_t esc_cap, int32_t *read_esc_off, int32_t *read_ins_off, int64_t big_cap,
+                          int32_t *big_idx, int32_t *big_pos, int32_t *big_len, int64_t *n_esc, int64_t *n_big);
+int nc_indel_events_expand8(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint8_t *d_b8,
+                            const uint16_t *d_d16x, const int32_t *d_read_esc_off, int32_t n_big, const int32_t *d_big_idx,
+                            const int32_t *d_big_pos, const int32_t *d_big_len, const int32_t *d_read_ins_off, int32_t *d_ev_pos,
+                            int32_t *d_ev_len, int32_t *d_ins_off);
 
 /* DEFLATE on the device (csrc/nc_inflate.hip): the raw-deflate payloads of n BGZF members (SAMv1 4.1) in two launches -- Huffman decoding, one
  * lane per member, into tokens; match resolution, one wave per member.  All pointers dev: d_comp = the compressed bytes (readable 8 bytes

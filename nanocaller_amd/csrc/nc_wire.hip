@@ -553,6 +553,47 @@ extern "C" int nc_indel_events_pack(int32_t n_reads, const int32_t *rd_start, co
     return nb > big_cap ? NC_ERR_CAPACITY : NC_OK;
 }
 
+// One byte per event (round 6): distance to the read's previous event in bits 2-7 (0 .. 62), length code in bits 0-1 (+1, -1, +2, -2) -- 86 % of an ONT
+// read's events; 0xFF = the event is the next entry of the two-byte array d16x (the form above, its 0xFFFF pointing on into the side table), whose first
+// entry per read is read_esc_off[r].  69 M events of a chr20-sized contig: 138 -> 88 MB.
+extern "C" int nc_indel_events_pack8(int32_t n_reads, const int32_t *rd_start, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len,
+                                     uint8_t *b8, uint16_t *d16x, int64_t esc_cap, int32_t *read_esc_off, int32_t *read_ins_off, int64_t big_cap,
+                                     int32_t *big_idx, int32_t *big_pos, int32_t *big_len, int64_t *n_esc, int64_t *n_big)
+{
+    if (n_reads < 0 || (n_reads && (!rd_start || !ev_off || !read_esc_off)) || !n_big || !n_esc) return NC_ERR_ARG;
+    int64_t nb = 0, ne = 0, ins = 0;
+    for (int32_t r = 0; r < n_reads; r++) {
+        int32_t prev = rd_start[r];
+        if (read_ins_off) read_ins_off[r] = (int32_t)ins;
+        read_esc_off[r] = (int32_t)ne;
+        for (int32_t e = ev_off[r]; e < ev_off[r + 1]; e++) {
+            const int32_t d = ev_pos[e] - prev, l = ev_len[e];
+            if (d < 0) return NC_ERR_ARG;                            // events of a read ascend
+            const int code = l == 1 ? 0 : l == -1 ? 1 : l == 2 ? 2 : l == -2 ? 3 : -1;
+            if (d <= 62 && code >= 0) b8[e] = (uint8_t)((d << 2) | code);
+            else {
+                b8[e] = 0xFF;
+                uint16_t w;
+                if (d >= 0x7ff || l > 15 || l < -16) {
+                    if (nb < big_cap) { big_idx[nb] = e; big_pos[nb] = ev_pos[e]; big_len[nb] = l; }
+                    nb++;
+                    w = 0xFFFF;
+                } else
+                    w = (uint16_t)((unsigned)d | (((unsigned)l & 0x1fu) << 11));
+                if (ne < esc_cap) d16x[ne] = w;
+                ne++;
+            }
+            prev = ev_pos[e];
+            if (l > 0) ins += l;
+        }
+    }
+    read_esc_off[n_reads] = (int32_t)ne;
+    if (read_ins_off) read_ins_off[n_reads] = (int32_t)ins;
+    *n_big = nb;
+    *n_esc = ne;
+    return (nb > big_cap || ne > esc_cap || ne > INT32_MAX) ? NC_ERR_CAPACITY : NC_OK;
+}
+
 namespace {
 __device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane)
 {
@@ -564,22 +605,39 @@ __device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane)
     return v;
 }
 
+// B8: the one-byte form (nc_indel_events_pack8): b8 per event, d16 = the two-byte array of the escapes, read_esc_off their start per read
+template <bool B8>
 __global__ __launch_bounds__(256) void k_events_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ ev_off,
                                                        const uint16_t *__restrict__ d16, const int8_t *__restrict__ l8, int32_t n_big,
                                                        const int32_t *__restrict__ big_idx, const int32_t *__restrict__ big_pos,
                                                        const int32_t *__restrict__ big_len, const int32_t *__restrict__ read_ins_off,
-                                                       int32_t *__restrict__ ev_pos, int32_t *__restrict__ ev_len, int32_t *__restrict__ ins_off)
+                                                       int32_t *__restrict__ ev_pos, int32_t *__restrict__ ev_len, int32_t *__restrict__ ins_off,
+                                                       const uint8_t *__restrict__ b8, const int32_t *__restrict__ read_esc_off)
 {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n_reads) return;
     const int e0 = ev_off[r], e1 = ev_off[r + 1];
     int32_t run_pos = rd_start[r], run_ins = read_ins_off ? read_ins_off[r] : 0;
+    int32_t run_esc = 0;
+    if constexpr (B8) run_esc = read_esc_off[r];
     for (int c = e0; c < e1; c += 64) {
         const int e = c + lane;
         const bool valid = e < e1;
-        int32_t d = valid ? (int32_t)d16[e] : 0, l = (valid && l8) ? (int32_t)l8[e] : 0, ab = 0;
-        const bool big = valid && d == 0xFFFF;
-        if (!l8 && valid && !big) {                                   // two-byte form: distance | signed 5-bit length << 11
+        int32_t d = 0, l = 0, ab = 0;
+        bool two = !B8;                                                  // this event is in the two-byte form
+        if constexpr (B8) {
+            const uint32_t b = valid ? (uint32_t)b8[e] : 0u;
+            const bool esc = valid && b == 0xFFu;
+            const unsigned long long em = __ballot(esc);
+            if (esc) { d = (int32_t)d16[run_esc + __popcll(em & ((1ull << lane) - 1ull))]; two = true; }
+            else { d = (int32_t)(b >> 2); l = ((b & 2u) ? 2 : 1) * ((b & 1u) ? -1 : 1); if (!valid) l = 0; }
+            run_esc += __popcll(em);
+        } else {
+            d = valid ? (int32_t)d16[e] : 0;
+            l = (valid && l8) ? (int32_t)l8[e] : 0;
+        }
+        const bool big = valid && two && d == 0xFFFF;
+        if (!l8 && valid && two && !big) {                            // two-byte form: distance | signed 5-bit length << 11
             l = (int32_t)((uint32_t)d << 16) >> 27;
             d &= 0x7ff;
         }
@@ -630,6 +688,43 @@ extern "C" int nc_wire_expand_del(nc_ctx *ctx, int32_t n_reads, const int32_t *d
     if (!d_blk_ev || !d_ev_off || (n_reads && (!d_ev_pos || !d_ev_len))) return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand_del: bad argument");
     return wire_expand(ctx, n_reads, d_rd_start, d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len,
                        d_ref_code, d_blk_ev, d_ev_off, d_ev_pos, d_ev_len);
+}
+
+// Inserted bases as they cross PCIe since round 6 (the indel caller's pack): two bits a base (A0 G1 T2 C3, base i in bits 2 (i & 3) of byte i >> 2);
+// the few other letters (code 4) travel as a list of indices.  nc_wire_ins_unpack rebuilds the byte array the kernels read.
+namespace {
+__global__ __launch_bounds__(256) void k_ins_unpack(const uint8_t *__restrict__ packed, int64_t n, uint8_t *__restrict__ out)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;                       // 16 bases = one dword in, one dwordx4 out
+    if (i >= n) return;
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(packed + (i >> 2));
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t b = (w >> (8 * q)) & 0xffu;
+        o[q] = (b & 3u) | ((b >> 2) & 3u) << 8 | ((b >> 4) & 3u) << 16 | ((b >> 6) & 3u) << 24;
+    }
+    *reinterpret_cast<uint4 *>(out + i) = make_uint4(o[0], o[1], o[2], o[3]);                 // (the buffers are padded to 16 bases)
+}
+__global__ __launch_bounds__(256) void k_ins_others(const int32_t *__restrict__ idx, int32_t n, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[idx[i]] = 4;
+}
+}   // namespace
+
+extern "C" int nc_wire_ins_unpack(nc_ctx *ctx, const uint8_t *d_packed, int64_t n_bases, const int32_t *d_other_idx, int32_t n_other, uint8_t *d_ins_bases)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_bases < 0 || n_other < 0 || (n_bases && (!d_packed || !d_ins_bases)) || (n_other && !d_other_idx) || ((uintptr_t)d_packed & 3) || ((uintptr_t)d_ins_bases & 15))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_wire_ins_unpack: bad argument");
+    if (n_bases == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t groups = (n_bases + 15) / 16;
+    hipLaunchKernelGGL(k_ins_unpack, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, n_bases, d_ins_bases);
+    if (n_other) hipLaunchKernelGGL(k_ins_others, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, ctx->stream, d_other_idx, n_other, d_ins_bases);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
 }
 
 extern "C" int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire)
@@ -689,8 +784,25 @@ extern "C" int nc_indel_events_expand(nc_ctx *ctx, int32_t n_reads, const int32_
         return nc_fail(ctx, NC_ERR_ARG, "nc_indel_events_expand: bad argument");
     if (n_reads == 0) return NC_OK;
     NC_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_events_expand, dim3((n_reads + 3) / 4), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_ev_off, d_d16, d_l8, n_big, d_big_idx,
-                       d_big_pos, d_big_len, d_read_ins_off, d_ev_pos, d_ev_len, d_ins_off);
+    hipLaunchKernelGGL(k_events_expand<false>, dim3((n_reads + 3) / 4), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_ev_off, d_d16, d_l8, n_big, d_big_idx,
+                       d_big_pos, d_big_len, d_read_ins_off, d_ev_pos, d_ev_len, d_ins_off, nullptr, nullptr);
+    NC_HIP(ctx, hipGetLastError());
+    return NC_OK;
+}
+
+extern "C" int nc_indel_events_expand8(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_ev_off, const uint8_t *d_b8,
+                                       const uint16_t *d_d16x, const int32_t *d_read_esc_off, int32_t n_big, const int32_t *d_big_idx,
+                                       const int32_t *d_big_pos, const int32_t *d_big_len, const int32_t *d_read_ins_off, int32_t *d_ev_pos,
+                                       int32_t *d_ev_len, int32_t *d_ins_off)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (n_reads < 0 || n_big < 0 || (n_reads && (!d_rd_start || !d_ev_off || !d_b8 || !d_d16x || !d_read_esc_off || !d_ev_pos || !d_ev_len)) ||
+        (n_big && (!d_big_idx || !d_big_pos || !d_big_len)) || (d_ins_off && !d_read_ins_off))
+        return nc_fail(ctx, NC_ERR_ARG, "nc_indel_events_expand8: bad argument");
+    if (n_reads == 0) return NC_OK;
+    NC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_events_expand<true>, dim3((n_reads + 3) / 4), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_ev_off, d_d16x, nullptr, n_big, d_big_idx,
+                       d_big_pos, d_big_len, d_read_ins_off, d_ev_pos, d_ev_len, d_ins_off, d_b8, d_read_esc_off);
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
 }

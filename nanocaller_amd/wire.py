@@ -178,29 +178,51 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
             evp, evl = np.ascontiguousarray(ev_pos[idx], np.int32), np.ascontiguousarray(ev_len[idx], np.int32)
             n_ev = int(evp.size)
             kept_start = np.ascontiguousarray(rs[kept], np.int32)
-            d16 = np.empty(max(n_ev, 1), np.uint16)                   # two bytes per event: distance | signed 5-bit length << 11 (nc_indel_events_pack with l8 = NULL)
             rio = np.zeros(kept.size + 1, np.int32)
+            ev8 = os.environ.get("NC_WIRE_EV8", "1") != "0"
             cap = max(1024, n_ev // 64)
+            ecap = max(1024, n_ev // 4)
+            b8 = np.empty(max(n_ev, 1), np.uint8) if ev8 else None     # one byte per event, the others through the two-byte array (nc_indel_events_pack8)
+            reo = np.zeros(kept.size + 1, np.int32)
             while True:
                 bi, bp, bl = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int32)
-                nbig = C.c_int64()
-                rc = L.nc_indel_events_pack(int(kept.size), _lib.npp(kept_start), _lib.npp(off), _lib.npp(evp), _lib.npp(evl), _lib.npp(d16), None,
-                                            _lib.npp(rio), cap, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nbig))
+                nbig, nesc = C.c_int64(), C.c_int64()
+                if ev8:
+                    d16 = np.empty(ecap, np.uint16)
+                    rc = L.nc_indel_events_pack8(int(kept.size), _lib.npp(kept_start), _lib.npp(off), _lib.npp(evp), _lib.npp(evl), _lib.npp(b8), _lib.npp(d16), ecap,
+                                                 _lib.npp(reo), _lib.npp(rio), cap, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nesc), C.byref(nbig))
+                else:
+                    d16 = np.empty(max(n_ev, 1), np.uint16)           # two bytes per event: distance | signed 5-bit length << 11 (nc_indel_events_pack with l8 = NULL)
+                    rc = L.nc_indel_events_pack(int(kept.size), _lib.npp(kept_start), _lib.npp(off), _lib.npp(evp), _lib.npp(evl), _lib.npp(d16), None,
+                                                _lib.npp(rio), cap, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(nbig))
                 if rc == _lib.NC_ERR_CAPACITY:
-                    cap = int(nbig.value)
+                    cap, ecap = max(cap, int(nbig.value)), max(ecap, int(nesc.value))
                     continue
                 if rc != _lib.NC_OK:
                     raise _lib.NanoCallerHipError("nc_indel_events_pack failed (%d)" % rc)
                 break
             nb_ = int(nbig.value)
-            parts += [("ev_off", z(off, np.int32)), ("ev_d16", d16), ("ev_big_idx", z(bi[:nb_], np.int32)),
+            parts += [("ev_off", z(off, np.int32)), ("ev_d16", z(d16[:int(nesc.value)], np.uint16) if ev8 else d16), ("ev_big_idx", z(bi[:nb_], np.int32)),
                       ("ev_big_pos", z(bp[:nb_], np.int32)), ("ev_big_len", z(bl[:nb_], np.int32)), ("read_ins_off", rio), ("read_hap", z(hp, np.uint8))]
-            meta_ev = dict(n_ev=n_ev, n_big=nb_, del_implied=bool(del_implied))
+            if ev8:
+                parts += [("ev_b8", b8), ("read_esc_off", reo)]
+            meta_ev = dict(n_ev=n_ev, n_big=nb_, del_implied=bool(del_implied), ev8=bool(ev8))
             n_indel = int(kept.size)
             if indel_extra is not None:
                 if n_ev and int(np.asarray(indel_extra["ins_off"])[n_ev]) != int(rio[-1]):
                     raise _lib.NanoCallerHipError("indel_extra['ins_off'] is not the running sum of the insertion lengths")
-                for name, dt in (("ins_bases", np.uint8), ("tail_off", np.int32), ("tail_bases", np.uint8), ("read_ps", np.int32), ("read_flag", np.uint8)):
+                ib = np.ascontiguousarray(indel_extra["ins_bases"], np.uint8)
+                if os.environ.get("NC_WIRE_INS_2BIT", "1") != "0" and ib.size:
+                    # the inserted bases two bits each (nc_wire_ins_unpack rebuilds the bytes in HBM); the few other letters (code 4) as indices
+                    other = np.flatnonzero(ib > 3).astype(np.int32)
+                    q = np.zeros((ib.size + 15) // 16 * 16, np.uint8)
+                    q[:ib.size] = ib & 3
+                    q = q.reshape(-1, 4)
+                    parts += [("ins_2b", np.ascontiguousarray(q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6))), ("ins_other", z(other, np.int32))]
+                    meta_ev["ins_2b"] = dict(n=int(ib.size), n_other=int(other.size))
+                else:
+                    parts.append(("ins_bases", z(ib, np.uint8)))
+                for name, dt in (("tail_off", np.int32), ("tail_bases", np.uint8), ("read_ps", np.int32), ("read_flag", np.uint8)):
                     parts.append((name, z(indel_extra[name], dt)))
                 meta_ev["extra"] = True
         sections, total = {}, 0
@@ -272,15 +294,27 @@ def _expand_events(eng, wp: WirePack, v, out):
         if out.get(name) is None or out[name].numel() < max(n, 4):
             out[name] = torch.zeros(max(n, 4) + max(n, 4) // 16, dtype=torch.int32, device=dev)
     if n_ev:
-        rc = eng.L.nc_indel_events_expand(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
-                                          C.c_void_p(v["ev_d16"].data_ptr()), None, me["n_big"],
-                                          C.c_void_p(v["ev_big_idx"].data_ptr()), C.c_void_p(v["ev_big_pos"].data_ptr()), C.c_void_p(v["ev_big_len"].data_ptr()),
-                                          C.c_void_p(v["read_ins_off"].data_ptr()), C.c_void_p(out["ev_pos"].data_ptr()), C.c_void_p(out["ev_len"].data_ptr()),
-                                          C.c_void_p(out["ins_off"].data_ptr()))
+        tail = (me["n_big"], C.c_void_p(v["ev_big_idx"].data_ptr()), C.c_void_p(v["ev_big_pos"].data_ptr()), C.c_void_p(v["ev_big_len"].data_ptr()),
+                C.c_void_p(v["read_ins_off"].data_ptr()), C.c_void_p(out["ev_pos"].data_ptr()), C.c_void_p(out["ev_len"].data_ptr()),
+                C.c_void_p(out["ins_off"].data_ptr()))
+        if me.get("ev8"):
+            rc = eng.L.nc_indel_events_expand8(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
+                                               C.c_void_p(v["ev_b8"].data_ptr()), C.c_void_p(v["ev_d16"].data_ptr()), C.c_void_p(v["read_esc_off"].data_ptr()), *tail)
+        else:
+            rc = eng.L.nc_indel_events_expand(eng.ctx, wp.n_indel_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
+                                              C.c_void_p(v["ev_d16"].data_ptr()), None, *tail)
         eng._check(rc, "nc_indel_events_expand")
     v["ev_pos"], v["ev_len"] = out["ev_pos"][:max(n_ev, 1)], out["ev_len"][:max(n_ev, 1)]
     if me.get("extra"):
         v["ins_off"] = out["ins_off"][:n_ev + 1]
+    if me.get("ins_2b"):
+        n, no = me["ins_2b"]["n"], me["ins_2b"]["n_other"]
+        need = (n + 15) // 16 * 16 + 16
+        if out.get("ins_bases") is None or out["ins_bases"].numel() < need:
+            out["ins_bases"] = torch.zeros(need + need // 16, dtype=torch.uint8, device=dev)
+        eng._check(eng.L.nc_wire_ins_unpack(eng.ctx, C.c_void_p(v["ins_2b"].data_ptr()), n, C.c_void_p(v["ins_other"].data_ptr()), no,
+                                            C.c_void_p(out["ins_bases"].data_ptr())), "nc_wire_ins_unpack")
+        v["ins_bases"] = out["ins_bases"][:max(n, 1)]
 
 
 def _device_pack(wp: WirePack, v, codes, ref_code, own_index):

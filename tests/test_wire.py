@@ -28,22 +28,36 @@ def _expand_numpy(wp):
 
 
 def _expand_events_numpy(wp):
-    """the 3-byte transfer form of the indel events (nc_indel_events_pack) restated: ev_pos / ev_len / ins_off as nc_indel_events_expand writes them"""
+    """the transfer form of the indel events (nc_indel_events_pack / _pack8) restated: ev_pos / ev_len / ins_off as nc_indel_events_expand[8] writes them"""
     me = wp.meta["indel_events"]
     n_ev, off, start = me["n_ev"], wp.host("ev_off"), wp.host("rd_start")
-    raw = wp.host("ev_d16")[:n_ev].astype(np.int64)                  # two bytes per event: distance (bits 0-10; 0xFFFF: side table) | signed 5-bit length << 11
-    d16 = np.where(raw == 0xFFFF, 0xFFFF, raw & 0x7ff)
-    l8 = ((raw >> 11) ^ 16) - 16
     big = {int(i): (int(p), int(ln)) for i, p, ln in zip(wp.host("ev_big_idx")[:me["n_big"]], wp.host("ev_big_pos")[:me["n_big"]], wp.host("ev_big_len")[:me["n_big"]])}
     pos, ln = np.zeros(n_ev, np.int32), np.zeros(n_ev, np.int32)
-    for r in range(wp.n_indel_reads):
-        prev = int(start[r])
-        for e in range(int(off[r]), int(off[r + 1])):
-            if d16[e] == 0xFFFF:
-                prev, ln[e] = big[e]
-            else:
-                prev, ln[e] = prev + int(d16[e]), l8[e]
-            pos[e] = prev
+
+    def two_byte(raw, e, prev):                                         # distance (bits 0-10; 0xFFFF: side table) | signed 5-bit length << 11
+        if raw == 0xFFFF:
+            return big[e]
+        return prev + (raw & 0x7ff), ((raw >> 11) ^ 16) - 16
+    if me.get("ev8"):
+        # one byte per event: distance << 2 | length code (+1 -1 +2 -2); 0xFF: the next entry of the two-byte array, which starts at read_esc_off[r] for read r
+        b8, d16x, reo = wp.host("ev_b8")[:n_ev].astype(np.int64), wp.host("ev_d16").astype(np.int64), wp.host("read_esc_off")
+        for r in range(wp.n_indel_reads):
+            prev, x = int(start[r]), int(reo[r])
+            for e in range(int(off[r]), int(off[r + 1])):
+                if b8[e] == 0xFF:
+                    prev, ln[e] = two_byte(int(d16x[x]), e, prev)
+                    x += 1
+                else:
+                    prev, ln[e] = prev + int(b8[e] >> 2), (1, -1, 2, -2)[int(b8[e] & 3)]
+                pos[e] = prev
+            assert x == int(reo[r + 1])
+    else:
+        raw = wp.host("ev_d16")[:n_ev].astype(np.int64)
+        for r in range(wp.n_indel_reads):
+            prev = int(start[r])
+            for e in range(int(off[r]), int(off[r + 1])):
+                prev, ln[e] = two_byte(int(raw[e]), e, prev)
+                pos[e] = prev
     ins = np.zeros(n_ev + 1, np.int64)
     np.cumsum(np.maximum(ln, 0), out=ins[1:])
     assert np.array_equal(wp.host("read_ins_off"), ins[off[:wp.n_indel_reads + 1]])
@@ -185,6 +199,32 @@ def test_indel_events_two_byte_form():
     keep = [0, 1, 5, 6, 7]
     assert (raw[keep] & 0x7ff).tolist() == [0, 0x7fe, 1, 1, 1] and (((raw[keep] >> 11) ^ 16) - 16).tolist() == [15, -16, -1, 1, -16]
     assert rio.tolist() == [0, 15 + 3 + 16 + 1]
+
+
+def test_indel_events_one_byte_form():
+    """nc_indel_events_pack8: distance (<= 62) << 2 | length code (+1 -1 +2 -2) in one byte; 0xFF = the next entry of the two-byte array (whose own
+    0xFFFF goes on to the side table); read_esc_off = where a read's escapes start"""
+    import ctypes as C
+
+    from nanocaller_amd import _lib
+    L = _lib.lib()
+    start = np.array([1000, 9000], np.int32)
+    off = np.array([0, 7, 10], np.int32)
+    pos = np.array([1000, 1062, 1125, 1126, 1127, 4000, 4001, 9000, 9010, 9010 + 0x7ff], np.int32)
+    ln = np.array([1, -2, 2, 3, -1, 1, -40, 2, -1, 1], np.int32)
+    b8, d16x, reo, rio = np.zeros(10, np.uint8), np.zeros(10, np.uint16), np.zeros(3, np.int32), np.zeros(3, np.int32)
+    bi, bp, bl = (np.zeros(8, np.int32) for _ in range(3))
+    nb, ne = C.c_int64(), C.c_int64()
+    args = (2, _lib.npp(start), _lib.npp(off), _lib.npp(pos), _lib.npp(ln), _lib.npp(b8), _lib.npp(d16x))
+    assert L.nc_indel_events_pack8(*args, 1, _lib.npp(reo), _lib.npp(rio), 8, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(ne), C.byref(nb)) == _lib.NC_ERR_CAPACITY and ne.value == 5
+    assert L.nc_indel_events_pack8(*args, 10, _lib.npp(reo), _lib.npp(rio), 8, _lib.npp(bi), _lib.npp(bp), _lib.npp(bl), C.byref(ne), C.byref(nb)) == _lib.NC_OK
+    # events 2 (distance 63), 3 (length 3), 5 (distance 2873), 6 (length -40) and 9 (distance 0x7ff) escape; 5, 6, 9 go on to the side table
+    assert b8.tolist() == [0 << 2 | 0, 62 << 2 | 3, 0xFF, 0xFF, 1 << 2 | 1, 0xFF, 0xFF, 0 << 2 | 2, 10 << 2 | 1, 0xFF]
+    assert ne.value == 5 and reo.tolist() == [0, 4, 5]
+    raw = d16x[:5].astype(np.int64)
+    assert raw.tolist()[2:] == [0xFFFF] * 3 and (raw[:2] & 0x7ff).tolist() == [63, 1] and (((raw[:2] >> 11) ^ 16) - 16).tolist() == [2, 3]
+    assert nb.value == 3 and bi[:3].tolist() == [5, 6, 9] and bp[:3].tolist() == [4000, 4001, 9010 + 0x7ff] and bl[:3].tolist() == [1, -40, 1]
+    assert rio.tolist() == [0, 1 + 2 + 3 + 1, 1 + 2 + 3 + 1 + 2 + 1]
 
 
 def test_degenerate_worlds():
