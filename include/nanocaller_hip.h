@@ -159,6 +159,8 @@ typedef struct {
     const uint16_t *events;     /* host [n_events] */
     int64_t n_events;
     const uint32_t *blk_ev;     /* host [n_blocks], nc_wire_build_del only (else NULL): see nc_wire_expand_del */
+    const uint8_t *ev_bytes;    /* host [n_ev_bytes (+ 8 readable)], nc_wire_build2 with flag 1 (else NULL): the events one byte each; blk_off then counts bytes */
+    int64_t n_ev_bytes;
 } nc_wire_arrays;
 /* ref_wire[i] describes position ref_pos0 + i (ref_pos0 a multiple of 16: the tile grid's tile_pos0), i < ref_len;
  * positions outside predict code 4.  Other arguments as nc_pack_fill.  The result is owned by the library. */
@@ -194,6 +196,19 @@ int nc_wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, cons
                    const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
                    const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
                    uint8_t *d_ref_code);
+/* The difference events one byte each (round 6; 126 -> 72 MB per chr20-sized ONT contig): bits 2-7 = columns skipped since the block's previous event
+ * (0 .. 62; 63 = a filler that skips 63 columns and is no event), bits 0-1 = which of the four codes other than the predicted one (against a predicted
+ * base b: 0 / 1 / 2 = base (b + 1 + k) & 3, 3 = code 4; against a predicted 4: the base).  nc_wire_build2: flags bit 0 asks for them (a pack with a
+ * code beyond 4 keeps the two-byte events: view.ev_bytes == NULL); ev_off != NULL = nc_wire_build_del's implied deletions.  nc_wire_expand2 = the
+ * expansion of that form (d_blk_ev .. d_ev_len NULL without implied deletions). */
+int nc_wire_build2(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                   const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
+                   const int32_t *ev_pos, const int32_t *ev_len, int32_t flags, nc_wire **out);
+int nc_wire_expand2(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                    const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                    const int32_t *d_blk_read, const uint8_t *d_ev_bytes, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                    uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos,
+                    const int32_t *d_ev_len);
 int nc_wire_expand_del(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
                        const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
                        const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,

@@ -39,7 +39,7 @@ EXPORTS = [
     "nc_bam_open", "nc_bam_close", "nc_bam_n_refs", "nc_bam_ref", "nc_bam_error", "nc_bam_decode", "nc_decoded_view",
     "nc_decoded_free", "nc_snp_vcf_format", "nc_set_cnn_precision", "nc_snp_scan_fetch_async", "nc_snp_forward_drain", "nc_argsort4", "nc_indel_slices", "nc_slices_view", "nc_slices_free",
     "nc_nw_cigar", "nc_allele_prediction", "nc_bgzf_compress", "nc_bam_set_threads", "nc_indel_scan_batch", "nc_timing_sums", "nc_snp_chunk_depth_async", "nc_bam_decode_regions", "nc_star_msa", "nc_star_msa_tensor", "nc_star_msa_tensor_dup", "nc_set_tensor_format", "nc_allele_prediction_batch", "nc_allele_prediction_device", "nc_bgzf_read_file", "nc_consensus_strings",
-    "nc_wire_build", "nc_wire_build_del", "nc_wire_apply_deletions", "nc_wire_ref_unpack", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_wire_expand_del", "nc_snp_set_mates", "nc_decoded_name_groups", "nc_wire_ins_unpack", "nc_indel_events_pack8", "nc_indel_events_expand8", "nc_d2h_async",
+    "nc_wire_build", "nc_wire_build_del", "nc_wire_apply_deletions", "nc_wire_ref_unpack", "nc_wire_view", "nc_wire_free", "nc_wire_expand", "nc_wire_expand_del", "nc_snp_set_mates", "nc_decoded_name_groups", "nc_wire_ins_unpack", "nc_indel_events_pack8", "nc_indel_events_expand8", "nc_wire_build2", "nc_wire_expand2", "nc_d2h_async",
     "nc_indel_pass2_sets", "nc_pass2_view", "nc_pass2_free",
     "nc_decoded_check", "nc_indel_pack_build", "nc_indel_pack_view", "nc_indel_pack_free", "nc_indel_sites_plan", "nc_indel_sites_run",
     "nc_indel_sites_fetch", "nc_indel_sites_fetch_alt", "nc_indel_sites_stage_ms", "nc_indel_sites_band_stats", "nc_indel_sites_band", "nc_indel_events_pack", "nc_indel_events_expand", "nc_inflate_device", "nc_inflate_device_phase", "nc_bgzf_crc_device", "nc_bgzf_members", "nc_bgzf_scan", "nc_bam_walk", "nc_bam_meta", "nc_bam_codes", "nc_bam_indel_reads", "nc_indel_sites_scoring", "nc_indel_vcf_format", "nc_synth_indel_truth", "nc_synth_indel_reads", "nc_cnn_x_limit", "nc_cnn_range_watch", "nc_snp_trunk_info",
@@ -109,7 +109,7 @@ class IndelReadsC(C.Structure):
 class WireArraysC(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("rd_start", C.c_void_p), ("rd_end", C.c_void_p), ("slot_off", C.c_void_p),
                 ("codes_len", C.c_int64), ("n_blocks", C.c_int64), ("blk_off", C.c_void_p), ("blk_read", C.c_void_p), ("events", C.c_void_p),
-                ("n_events", C.c_int64), ("blk_ev", C.c_void_p)]
+                ("n_events", C.c_int64), ("blk_ev", C.c_void_p), ("ev_bytes", C.c_void_p), ("n_ev_bytes", C.c_int64)]
 
 
 _lib = None
@@ -201,12 +201,14 @@ def lib():
         L.nc_d2h_async.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.nc_wire_build.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i64, C.POINTER(vp)]
         L.nc_wire_build_del.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, C.POINTER(vp)]
+        L.nc_wire_build2.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, i32, C.POINTER(vp)]
         L.nc_wire_apply_deletions.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.nc_wire_ref_unpack.argtypes = [vp, vp, i64, vp]
         L.nc_wire_view.argtypes = [vp, C.POINTER(WireArraysC)]
         L.nc_wire_free.argtypes = [vp]
         L.nc_wire_expand.argtypes = [vp, i32, vp, vp, vp, vp, i32, i64, vp, vp, vp, i64, vp, i64, vp]
         L.nc_wire_expand_del.argtypes = L.nc_wire_expand.argtypes + [vp, vp, vp, vp]
+        L.nc_wire_expand2.argtypes = L.nc_wire_expand.argtypes + [vp, vp, vp, vp]
         L.nc_snp_set_mates.argtypes = [vp, i32, vp, vp]
         L.nc_decoded_name_groups.argtypes = [vp, vp, vp, C.POINTER(i64)]
         L.nc_wire_ins_unpack.argtypes = [vp, vp, i64, vp, i32, vp]

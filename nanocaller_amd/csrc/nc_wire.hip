@@ -33,8 +33,17 @@ struct nc_wire {
     std::vector<int32_t> blk_read;
     std::vector<uint16_t> events;
     std::vector<uint32_t> blk_ev;    // nc_wire_build_del: per block the cursor into the kept reads' indel events (0xffffffff: nothing implied in this block)
+    std::vector<uint8_t> ev_bytes;   // nc_wire_build_bytes: the events one byte each (then `events` is empty and blk_off counts bytes)
     int64_t codes_len = 0;
 };
+
+// The difference events one byte each (round 6): bits 2-7 = columns skipped since the block's previous event (0 .. 62; 63: a filler that skips 63 columns and
+// is no event), bits 0-1 = WHICH other code -- an event's code differs from the predicted one, so two bits tell it: against a predicted base b (0 .. 3)
+// 0 / 1 / 2 = base (b + 1 + k) & 3, 3 = code 4; against a predicted 4 the base itself.  63 M events of a chr20-sized ONT contig: 126 -> 72 MB.
+static inline unsigned wire_which(unsigned c, unsigned pred) { return pred < 4u ? (c == 4u ? 3u : ((c - pred - 1u) & 3u)) : c; }
+// (the builder's intermediate events carry the predicted code in the three spare bits 10, 11, 15)
+static inline uint16_t wire_stash(unsigned pred) { return (uint16_t)(((pred & 3u) << 10) | ((pred >> 2) << 15)); }
+static inline unsigned wire_stashed(uint16_t e) { return ((e >> 10) & 3u) | (((unsigned)e >> 15) << 2); }
 
 static inline int64_t floor16w(int64_t p) { return p & ~(int64_t)15; }
 static inline int64_t ceil16w(int64_t p) { return (p + 15) & ~(int64_t)15; }
@@ -44,7 +53,8 @@ static inline int64_t ceil16w(int64_t p) { return (p + 15) & ~(int64_t)15; }
 // events -- it is left out of the difference events and written back in HBM by nc_wire_apply_deletions (round 6: 62.8 M of the 120.7 M
 // events of a chr20-sized ONT contig).  A code 4 outside every deletion run (a read base N) stays an event.
 static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in, const uint8_t *keep,
-                      const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out)
+                      const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off, const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out,
+                      bool want_bytes = false)
 {
     if (!out || n_reads < 0 || (n_reads && (!start || !end || !off || !codes_in)) || !ref_wire || ref_len < 0 || (ref_pos0 & 15))
         return NC_ERR_ARG;
@@ -83,7 +93,10 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
         int T = std::min(nc_host_cpus(), 32);
         if (n_blocks < 64) T = 1;
         std::vector<std::vector<uint16_t>> part((size_t)T);
-        std::vector<int> status((size_t)T, NC_OK);
+        std::vector<std::vector<uint8_t>> bpart((size_t)T);           // want_bytes: the same events one byte each
+        std::vector<uint32_t> blk_bytes;
+        if (want_bytes) blk_bytes.assign((size_t)n_blocks + 1, 0);
+        std::vector<int> status((size_t)T, NC_OK), no_bytes((size_t)T, 0);
         auto work = [&](int t) {
             const int64_t b0 = n_blocks * t / T, b1 = n_blocks * (t + 1) / T;
             std::vector<uint16_t> &ev = part[(size_t)t];
@@ -130,7 +143,7 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                     for (int64_t p = p_lo; p < g_lo; p++) {
                         const unsigned c = src[p];
                         worst = std::max(worst, c);
-                        if (c != 4u) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                        if (c != 4u) ev.push_back((uint16_t)((off0 + p) | (c << 12) | wire_stash(4)));
                     }
                     // on the grid: 16 positions a step (SSE2 is part of x86-64), the ~8 % that differ leave through the mask's set bits
                     const uint8_t *rf = ref_wire - ref_pos0;                                    // rf[p]
@@ -146,7 +159,7 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                             const int k = __builtin_ctz(m);
                             m &= m - 1;
                             if (src[p + k] == 4u && single && covered(p + k)) continue;
-                            ev.push_back((uint16_t)((off0 + p + k) | ((unsigned)src[p + k] << 12)));
+                            ev.push_back((uint16_t)((off0 + p + k) | ((unsigned)src[p + k] << 12) | wire_stash(rf[p + k] & 7u)));
                         }
                     }
                     vmax = _mm_max_epu8(vmax, _mm_srli_si128(vmax, 8));
@@ -158,16 +171,33 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                     for (; p < g_hi; p++) {
                         const unsigned c = src[p];
                         wmax = std::max(wmax, c);
-                        if (c != (rf[p] & 7u) && !(c == 4u && single && covered(p))) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                        if (c != (rf[p] & 7u) && !(c == 4u && single && covered(p))) ev.push_back((uint16_t)((off0 + p) | (c << 12) | wire_stash(rf[p] & 7u)));
                     }
                     for (p = g_hi; p < p_hi; p++) {
                         const unsigned c = src[p];
                         wmax = std::max(wmax, c);
-                        if (c != 4u) ev.push_back((uint16_t)((off0 + p) | (c << 12)));
+                        if (c != 4u) ev.push_back((uint16_t)((off0 + p) | (c << 12) | wire_stash(4)));
                     }
                     if (wmax >= NC_CODE_ABSENT) { status[(size_t)t] = NC_ERR_ARG; return; }   // codes are 0..6
                 }
                 w->blk_off[(size_t)b + 1] = (uint32_t)(ev.size() - before);
+                // the block's events, in ascending offset, one byte each; the stash bits leave the two-byte form
+                std::vector<uint8_t> &bv = bpart[(size_t)t];
+                const size_t bbefore = bv.size();
+                int prevo = -1;
+                for (size_t i = before; i < ev.size(); i++) {
+                    const uint16_t x = ev[i];
+                    const unsigned pred = wire_stashed(x), c = (x >> 12) & 7u;
+                    const int o = x & 0x3ff;
+                    ev[i] = (uint16_t)(x & 0x73ffu);
+                    if (!want_bytes) continue;
+                    if (c > 4u || pred > 4u || o <= prevo) { no_bytes[(size_t)t] = 1; continue; }
+                    int gap = o - prevo - 1;
+                    while (gap >= 63) { bv.push_back((uint8_t)(63u << 2)); gap -= 63; }
+                    bv.push_back((uint8_t)(((unsigned)gap << 2) | wire_which(c, pred)));
+                    prevo = o;
+                }
+                if (want_bytes) blk_bytes[(size_t)b + 1] = (uint32_t)(bv.size() - bbefore);
             }
         };
         if (T == 1) work(0);
@@ -178,6 +208,17 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
         }
         for (int t = 0; t < T; t++)
             if (status[(size_t)t] != NC_OK) { delete w; return status[(size_t)t]; }
+        bool bytes = want_bytes;
+        for (int t = 0; t < T; t++) bytes = bytes && !no_bytes[(size_t)t];     // (a code beyond 4: the two-byte form)
+        if (bytes) {                                                            // sparse events (HiFi) are mostly fillers: the two-byte form when it is the shorter one
+            uint64_t nb = 0, ne = 0;
+            for (int t = 0; t < T; t++) { nb += bpart[(size_t)t].size(); ne += part[(size_t)t].size(); }
+            bytes = nb < 2 * ne;
+        }
+        if (bytes) {
+            for (int t = 0; t < T; t++) std::vector<uint16_t>().swap(part[(size_t)t]);
+            w->blk_off.swap(blk_bytes);
+        }
         {
             uint64_t acc = 0;
             for (int64_t b = 0; b < n_blocks; b++) {
@@ -186,13 +227,16 @@ static int wire_build(int32_t n_reads, const int32_t *start, const int32_t *end,
                 w->blk_off[(size_t)b + 1] = (uint32_t)acc;
             }
         }
-        w->events.resize((size_t)w->blk_off[(size_t)n_blocks]);
+        if (bytes) w->ev_bytes.resize((size_t)w->blk_off[(size_t)n_blocks] + 8);             // (+ 8: the expansion loads whole dwords)
+        else w->events.resize((size_t)w->blk_off[(size_t)n_blocks]);
         {
             std::vector<std::thread> th;
             for (int t = 0; t < T; t++)
                 th.emplace_back([&, t]() {
                     const int64_t b0 = n_blocks * t / T;
-                    if (!part[(size_t)t].empty())
+                    if (bytes) {
+                        if (!bpart[(size_t)t].empty()) memcpy(w->ev_bytes.data() + w->blk_off[(size_t)b0], bpart[(size_t)t].data(), bpart[(size_t)t].size());
+                    } else if (!part[(size_t)t].empty())
                         memcpy(w->events.data() + w->blk_off[(size_t)b0], part[(size_t)t].data(), part[(size_t)t].size() * sizeof(uint16_t));
                 });
             for (auto &x : th) x.join();
@@ -211,9 +255,9 @@ extern "C" int nc_wire_build(int32_t n_reads, const int32_t *start, const int32_
     return wire_build(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, nullptr, nullptr, nullptr, out);
 }
 
-extern "C" int nc_wire_build_del(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
-                                 const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
-                                 const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out)
+static int wire_build_del(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                          const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
+                          const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out, bool want_bytes)
 {
     if (!ev_off || n_reads < 0 || (n_reads && (!start || !end || !off || !codes_in)) || (n_reads && ev_off[n_reads] > 0 && (!ev_pos || !ev_len))) return NC_ERR_ARG;
     // the events must describe the codes: every deleted column inside its read carries code 4 (what a pileup's '*' decodes to,
@@ -229,7 +273,23 @@ extern "C" int nc_wire_build_del(int32_t n_reads, const int32_t *start, const in
                 if (src[p] != 4u) return NC_ERR_UNSUPPORTED;
         }
     }
-    return wire_build(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, ev_off, ev_pos, ev_len, out);
+    return wire_build(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, ev_off, ev_pos, ev_len, out, want_bytes);
+}
+
+extern "C" int nc_wire_build_del(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                                 const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
+                                 const int32_t *ev_pos, const int32_t *ev_len, nc_wire **out)
+{
+    return wire_build_del(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, ev_off, ev_pos, ev_len, out, false);
+}
+
+// flags: bit 0 = the events one byte each (nc_wire_arrays.ev_bytes; blk_off then counts bytes); ev_off == NULL: no implied deletions
+extern "C" int nc_wire_build2(int32_t n_reads, const int32_t *start, const int32_t *end, const int64_t *off, const uint8_t *codes_in,
+                              const uint8_t *keep, const uint8_t *ref_wire, int32_t ref_pos0, int64_t ref_len, const int32_t *ev_off,
+                              const int32_t *ev_pos, const int32_t *ev_len, int32_t flags, nc_wire **out)
+{
+    if (ev_off) return wire_build_del(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, ev_off, ev_pos, ev_len, out, (flags & 1) != 0);
+    return wire_build(n_reads, start, end, off, codes_in, keep, ref_wire, ref_pos0, ref_len, nullptr, nullptr, nullptr, out, (flags & 1) != 0);
 }
 
 extern "C" int nc_wire_view(const nc_wire *w, nc_wire_arrays *v)
@@ -246,6 +306,8 @@ extern "C" int nc_wire_view(const nc_wire *w, nc_wire_arrays *v)
     v->events = w->events.data();
     v->n_events = (int64_t)w->events.size();
     v->blk_ev = w->blk_ev.empty() ? nullptr : w->blk_ev.data();
+    v->ev_bytes = w->ev_bytes.empty() ? nullptr : w->ev_bytes.data();
+    v->n_ev_bytes = w->ev_bytes.empty() ? 0 : (int64_t)w->ev_bytes.size() - 8;
     return NC_OK;
 }
 
@@ -315,7 +377,9 @@ __device__ __noinline__ uint4 wire_group_general(int64_t B, int64_t r, int32_t n
 // (nc_wire_build_del): such a block writes them into its LDS image from the read's own deletion events (absolute ev_pos / ev_len, expanded before this
 // kernel), starting at the block's cursor blk_ev -- one coalesced load of 64 events per ~1 KiB block, no second pass over the codes (a separate
 // kernel writing 63 M scattered bytes re-reads and re-writes the whole 1.9 GB array: +0.6 ms per chr20-sized pass).
-template <int U, bool DEL>
+// BYTES (round 6): the events one byte each (nc_wire_build2 flag 1): `events` is that byte stream, blk_off counts bytes.  A lane takes four bytes (one
+// dword), the columns they skip are summed across the wave, and an event's code follows from the predicted code already in the image (wire_which).
+template <int U, bool DEL, bool BYTES>
 __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
                                                      const int64_t *__restrict__ slot_off, const uint8_t *__restrict__ ref_wire,
                                                      int32_t ref_pos0, int64_t ref_len, const uint32_t *__restrict__ blk_off,
@@ -372,11 +436,16 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         if (k + 1 >= eb) pr |= 0xffff0000u;
         return pr;
     };
+    const uint8_t *evb = reinterpret_cast<const uint8_t *>(events);
+    auto load_quad = [&](uint32_t k, uint32_t eb) -> uint32_t {       // bytes k .. k + 3 (k a multiple of 4; the stream is readable 8 bytes past its end)
+        return k < eb ? *reinterpret_cast<const uint32_t *>(evb + k) : 0u;
+    };
     uint32_t pr0[U];
     uint4 rv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        pr0[u] = u < nu ? load_pair((e0[u] & ~1u) + 2 * lane, e0[u], e1[u], blk0 + u == n_blocks - 1) : 0xffffffffu;
+        if constexpr (BYTES) pr0[u] = u < nu ? load_quad((e0[u] & ~3u) + 4 * lane, e1[u]) : 0u;
+        else pr0[u] = u < nu ? load_pair((e0[u] & ~1u) + 2 * lane, e0[u], e1[u], blk0 + u == n_blocks - 1) : 0xffffffffu;
         if (ri0[u] >= 0) rv[u] = *reinterpret_cast<const uint4 *>(ref_wire + ri0[u] + lane * 16);
     }
 #pragma unroll
@@ -395,12 +464,51 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         if (a != 0xffffu) im[a & 0x3ffu] = (uint8_t)(a >> 12);
         if (b != 0xffffu) im[b & 0x3ffu] = (uint8_t)(b >> 12);
     };
+    // BYTES: four events of a lane; `carry` = columns covered by the block's earlier bytes
+    auto scatter4 = [&](uint8_t *im, uint32_t q, uint32_t k, uint32_t ea, uint32_t eb, int32_t &carry) {
+        int32_t v[4], cum = 0;
+        uint32_t which[4];
+        bool isev[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t b = (q >> (8 * i)) & 0xffu, g = b >> 2;
+            const bool in = k + i >= ea && k + i < eb;
+            isev[i] = in && g != 63u;
+            which[i] = b & 3u;
+            cum += in ? (g == 63u ? 63 : (int32_t)g + 1) : 0;
+            v[i] = cum;
+        }
+        int32_t incl = cum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        const int32_t base = carry + incl - cum;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (isev[i]) {
+                const int32_t o = base + v[i] - 1;
+                const uint32_t pred = im[o & 0x3ff];
+                im[o & 0x3ff] = (uint8_t)(pred < 4u ? (which[i] == 3u ? 4u : ((pred + 1u + which[i]) & 3u)) : which[i]);
+            }
+        carry += __shfl(incl, 63);
+    };
 #pragma unroll
     for (int u = 0; u < U; u++) {
         uint8_t *im = img + u * WIRE_BLOCK;
-        scatter(im, pr0[u]);
-        if (u < nu)
-            for (uint32_t k = (e0[u] & ~1u) + 128 + 2 * lane; k < e1[u]; k += 128) scatter(im, load_pair(k, e0[u], e1[u], blk0 + u == n_blocks - 1));
+        if constexpr (BYTES) {
+            if (u < nu) {
+                int32_t carry = 0;
+                const uint32_t k = (e0[u] & ~3u) + 4 * lane;
+                scatter4(im, pr0[u], k, e0[u], e1[u], carry);
+                for (uint32_t kb = (e0[u] & ~3u) + 256; kb < e1[u]; kb += 256) scatter4(im, load_quad(kb + 4 * lane, e1[u]), kb + 4 * lane, e0[u], e1[u], carry);
+            }
+        } else {
+            scatter(im, pr0[u]);
+            if (u < nu)
+                for (uint32_t k = (e0[u] & ~1u) + 128 + 2 * lane; k < e1[u]; k += 128) scatter(im, load_pair(k, e0[u], e1[u], blk0 + u == n_blocks - 1));
+        }
     }
     if constexpr (DEL) {
         // the deleted columns of single-read blocks, from the read's deletion events (LDS stores of a wave land in program order: on top of the image,
@@ -482,7 +590,7 @@ __global__ void k_ref_from_wire(const uint8_t *__restrict__ ref_wire, uint8_t *_
 static int wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
                        const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
                        const int32_t *d_blk_read, const uint16_t *d_events, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
-                       uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len)
+                       uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len, bool bytes = false)
 {
     if (!ctx) return NC_ERR_ARG;
     if (n_reads < 0 || !d_slot_off || (n_reads && (!d_rd_start || !d_rd_end)) || !d_ref_wire || (ref_pos0 & 15) || ref_len < 0 ||
@@ -491,13 +599,19 @@ static int wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, 
         return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand: bad argument");
     NC_HIP(ctx, hipSetDevice(ctx->device));
     static const int U = [] { const char *e = getenv("NC_WIRE_U"); const int v = e ? atoi(e) : NC_WIRE_U; return (v == 1 || v == 2 || v == 8) ? v : 4; }();
-#define NC_LAUNCH_EXPAND(UU, DD)                                                                                                                  \
-    hipLaunchKernelGGL((k_wire_expand<UU, DD>), dim3((unsigned)((n_blocks + 4 * UU - 1) / (4 * UU))), dim3(256), 0, ctx->stream, n_reads, d_rd_start, \
-                       d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len, d_blk_ev,  \
+#define NC_LAUNCH_EXPAND(UU, DD)                                                                                                                         \
+    hipLaunchKernelGGL((k_wire_expand<UU, DD, false>), dim3((unsigned)((n_blocks + 4 * UU - 1) / (4 * UU))), dim3(256), 0, ctx->stream, n_reads, d_rd_start, \
+                       d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len, d_blk_ev,         \
                        d_ev_off, d_ev_pos, d_ev_len)
-    if (d_blk_ev) { if (U == 1) NC_LAUNCH_EXPAND(1, true); else if (U == 2) NC_LAUNCH_EXPAND(2, true); else if (U == 8) NC_LAUNCH_EXPAND(8, true); else NC_LAUNCH_EXPAND(4, true); }
+#define NC_LAUNCH_EXPAND_B(DD)                                                                                                                          \
+    hipLaunchKernelGGL((k_wire_expand<4, DD, true>), dim3((unsigned)((n_blocks + 15) / 16)), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_rd_end,  \
+                       d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len, d_blk_ev, d_ev_off,    \
+                       d_ev_pos, d_ev_len)
+    if (bytes) { if (d_blk_ev) NC_LAUNCH_EXPAND_B(true); else NC_LAUNCH_EXPAND_B(false); }
+    else if (d_blk_ev) { if (U == 1) NC_LAUNCH_EXPAND(1, true); else if (U == 2) NC_LAUNCH_EXPAND(2, true); else if (U == 8) NC_LAUNCH_EXPAND(8, true); else NC_LAUNCH_EXPAND(4, true); }
     else { if (U == 1) NC_LAUNCH_EXPAND(1, false); else if (U == 2) NC_LAUNCH_EXPAND(2, false); else if (U == 8) NC_LAUNCH_EXPAND(8, false); else NC_LAUNCH_EXPAND(4, false); }
 #undef NC_LAUNCH_EXPAND
+#undef NC_LAUNCH_EXPAND_B
     if (d_ref_code && ref_len) {
         const int64_t groups = (ref_len + 15) / 16;
         hipLaunchKernelGGL(k_ref_from_wire, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_wire, d_ref_code, ref_len);
@@ -725,6 +839,19 @@ extern "C" int nc_wire_ins_unpack(nc_ctx *ctx, const uint8_t *d_packed, int64_t 
     if (n_other) hipLaunchKernelGGL(k_ins_others, dim3((unsigned)((n_other + 255) / 256)), dim3(256), 0, ctx->stream, d_other_idx, n_other, d_ins_bases);
     NC_HIP(ctx, hipGetLastError());
     return NC_OK;
+}
+
+// the same with the events one byte each (nc_wire_build2, flag 1): d_ev_bytes (readable 8 bytes past its end), d_blk_off counting bytes; d_blk_ev etc. NULL
+// when the pack does not leave deleted columns out
+extern "C" int nc_wire_expand2(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, const int32_t *d_rd_end, const int64_t *d_slot_off,
+                               const uint8_t *d_ref_wire, int32_t ref_pos0, int64_t ref_len, const uint32_t *d_blk_off,
+                               const int32_t *d_blk_read, const uint8_t *d_ev_bytes, int64_t n_blocks, uint8_t *d_codes, int64_t codes_len,
+                               uint8_t *d_ref_code, const uint32_t *d_blk_ev, const int32_t *d_ev_off, const int32_t *d_ev_pos, const int32_t *d_ev_len)
+{
+    if (!ctx) return NC_ERR_ARG;
+    if (!d_ev_bytes || (d_blk_ev && (!d_ev_off || (n_reads && (!d_ev_pos || !d_ev_len))))) return nc_fail(ctx, NC_ERR_ARG, "nc_wire_expand2: bad argument");
+    return wire_expand(ctx, n_reads, d_rd_start, d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, reinterpret_cast<const uint16_t *>(d_ev_bytes),
+                       n_blocks, d_codes, codes_len, d_ref_code, d_blk_ev, d_ev_off, d_ev_pos, d_ev_len, true);
 }
 
 extern "C" int nc_wire_ref_unpack(nc_ctx *ctx, const uint8_t *d_ref_nib, int64_t ref_len, uint8_t *d_ref_wire)

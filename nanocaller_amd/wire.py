@@ -126,7 +126,20 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
         raise _lib.NanoCallerHipError("nc_pack_fill (index) failed (%d)" % rc)
     h = C.c_void_p()
     del_implied = events is not None and os.environ.get("NC_WIRE_DEL_IMPLIED", "1") != "0"
-    if del_implied:
+    # the difference events one byte each (nc_wire_build2; the builder keeps the two-byte form where that is shorter: sparse events, HiFi):
+    # NC_WIRE_EVB = 2 (default) every pack, 1 only packs that travel with their indel events, 0 never
+    evb = os.environ.get("NC_WIRE_EVB", "2")
+    byte_events = evb == "2" or (evb == "1" and events is not None)
+    if byte_events:
+        e3 = [None, None, None]
+        if del_implied:
+            e_off, e_pos, e_len = (np.ascontiguousarray(x, np.int32) for x in events)
+            e3 = [_lib.npp(e_off), _lib.npp(e_pos) if e_pos.size else None, _lib.npp(e_len) if e_len.size else None]
+        rc = L.nc_wire_build2(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value, ref_len, *e3, 1, C.byref(h))
+        if rc == _lib.NC_ERR_UNSUPPORTED and del_implied:              # codes and events disagree about a deleted column: without the implied deletions
+            del_implied = False
+            rc = L.nc_wire_build2(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value, ref_len, None, None, None, 1, C.byref(h))
+    elif del_implied:
         # the reads travel with their indel events: in a block that lies inside one read a deleted column's code is implied by the deletion event
         # and left out of the difference events (nc_wire_expand_del writes it from the events, expanded first)
         e_off, e_pos, e_len = (np.ascontiguousarray(x, np.int32) for x in events)
@@ -134,7 +147,7 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
                                  ref_len, _lib.npp(e_off), _lib.npp(e_pos) if e_pos.size else None, _lib.npp(e_len) if e_len.size else None, C.byref(h))
         if rc == _lib.NC_ERR_UNSUPPORTED:                               # codes and events disagree about a deleted column: the plain form
             del_implied = False
-    if not del_implied:
+    if not del_implied and not byte_events:
         rc = L.nc_wire_build(n, _lib.npp(rs), _lib.npp(re_), _lib.npp(ro), _lib.npp(cd), _lib.npp(keep), _lib.npp(ref_grid), tile_pos0.value,
                              ref_len, C.byref(h))
     if rc != _lib.NC_OK:
@@ -152,7 +165,8 @@ def build_wire(read_start, read_end, read_off, codes, read_flag, ref_wire_pos1, 
         parts = [("rd_start", arr(v.rd_start, v.n_reads, np.int32)), ("rd_end", arr(v.rd_end, v.n_reads, np.int32)),
                  ("slot_off", arr(v.slot_off, v.n_reads + 1, np.int64)), ("blk_off", arr(v.blk_off, v.n_blocks + 1, np.uint32)),
                  ("blk_read", arr(v.blk_read, v.n_blocks, np.int32)),
-                 ("events", arr(v.events, v.n_events, np.uint16)), ("ref_nib", ref_grid[0::2] | (ref_grid[1::2] << 4)), ("tile_off", tile_off),
+                 (("ev_bytes", np.frombuffer((C.c_char * int(v.n_ev_bytes + 8)).from_address(v.ev_bytes), np.uint8)) if v.ev_bytes
+                  else ("events", arr(v.events, v.n_events, np.uint16))), ("ref_nib", ref_grid[0::2] | (ref_grid[1::2] << 4)), ("tile_off", tile_off),
                  ("tile_ent", np.frombuffer(tile_ent[:n_ent.value].tobytes(), np.uint8) if n_ent.value else np.zeros(16, np.uint8))]
         if mates is not None:
             mates = mate_table(nxt, keep, rs, re_, slot_off=arr(v.slot_off, v.n_reads + 1, np.int64))     # (checked against the builder's own slots)
@@ -269,12 +283,19 @@ def _expand(eng, wp: WirePack, v, codes, ref_code, scratch=None):
             scratch = torch.empty(wp.ref_len, dtype=torch.uint8, device=codes.device)
         eng._check(eng.L.nc_wire_ref_unpack(eng.ctx, C.c_void_p(v["ref_nib"].data_ptr()), wp.ref_len, C.c_void_p(scratch.data_ptr())), "nc_wire_ref_unpack")
         v["ref_wire"] = scratch
+    evs = v["ev_bytes"] if "ev_bytes" in v else (v["events"] if wp.n_events else v["blk_off"])
     args = (eng.ctx, wp.n_reads, C.c_void_p(v["rd_start"].data_ptr()), C.c_void_p(v["rd_end"].data_ptr()),
             C.c_void_p(v["slot_off"].data_ptr()), C.c_void_p(v["ref_wire"].data_ptr()), wp.tile_pos0, wp.ref_len,
-            C.c_void_p(v["blk_off"].data_ptr()), C.c_void_p(v["blk_read"].data_ptr()),
-            C.c_void_p(v["events"].data_ptr() if wp.n_events else v["blk_off"].data_ptr()),
+            C.c_void_p(v["blk_off"].data_ptr()), C.c_void_p(v["blk_read"].data_ptr()), C.c_void_p(evs.data_ptr()),
             wp.n_blocks, C.c_void_p(codes.data_ptr()), wp.codes_len, C.c_void_p(ref_code.data_ptr()))
-    if "blk_ev" in v:                                                   # deleted columns implied: from the reads' events (_expand_events ran first)
+    if "ev_bytes" in v:                                                 # the events one byte each (nc_wire_build2)
+        if "blk_ev" in v:
+            assert wp.n_indel_reads == wp.n_reads and "ev_pos" in v
+            rc = eng.L.nc_wire_expand2(*args, C.c_void_p(v["blk_ev"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
+                                       C.c_void_p(v["ev_pos"].data_ptr()), C.c_void_p(v["ev_len"].data_ptr()))
+        else:
+            rc = eng.L.nc_wire_expand2(*args, None, None, None, None)
+    elif "blk_ev" in v:                                                   # deleted columns implied: from the reads' events (_expand_events ran first)
         assert wp.n_indel_reads == wp.n_reads and "ev_pos" in v
         rc = eng.L.nc_wire_expand_del(*args, C.c_void_p(v["blk_ev"].data_ptr()), C.c_void_p(v["ev_off"].data_ptr()),
                                       C.c_void_p(v["ev_pos"].data_ptr()), C.c_void_p(v["ev_len"].data_ptr()))

@@ -1,5 +1,7 @@
 """The reference-difference transfer form of the read pack (nc_wire_*, nanocaller_amd/wire.py): the host builder against a
 numpy restatement of the expansion (CPU), and nc_wire_expand on the GPU byte for byte against nc_pack_fill's codes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,7 @@ from util import load_world
 def _expand_numpy(wp):
     """what nc_wire_expand writes, restated with numpy on the host arrays of a WirePack"""
     rs, re_, so = wp.host("rd_start").astype(np.int64), wp.host("rd_end").astype(np.int64), wp.host("slot_off")
-    nib, bo, ev = wp.host("ref_nib"), wp.host("blk_off"), wp.host("events")
+    nib, bo, ev = wp.host("ref_nib"), wp.host("blk_off"), (wp.host("events") if "events" in wp.sections else None)
     refw = np.empty(2 * nib.size, np.uint8)                             # two positions per byte on the wire (nc_wire_ref_unpack)
     refw[0::2], refw[1::2] = nib & 15, nib >> 4
     codes = np.full(wp.codes_len, 7, np.uint8)
@@ -21,10 +23,33 @@ def _expand_numpy(wp):
         ri = np.arange(rs[r], re_[r]) - wp.tile_pos0
         ok = (ri >= 0) & (ri < wp.ref_len)
         codes[base + rs[r]:base + re_[r]] = np.where(ok, refw[np.clip(ri, 0, wp.ref_len - 1)] & 7, 4)
-    blk = np.repeat(np.arange(wp.n_blocks), np.diff(bo.astype(np.int64)))
-    codes[blk * 1024 + (ev & 0x3ff)] = ev >> 12
+    if "ev_bytes" in wp.sections:
+        # the events one byte each (nc_wire_build2): columns skipped since the block's previous event << 2 (63: a filler, no event) | which of the
+        # four codes other than the predicted one
+        evb = wp.host("ev_bytes").astype(np.int64)
+        bo64 = bo.astype(np.int64)
+        for b in np.flatnonzero(np.diff(bo64)):
+            g = evb[bo64[b]:bo64[b + 1]] >> 2
+            k = evb[bo64[b]:bo64[b + 1]] & 3
+            offs = np.cumsum(np.where(g == 63, 63, g + 1)) - 1
+            is_ev = g != 63
+            o, k = b * 1024 + offs[is_ev], k[is_ev]
+            pred = codes[o].astype(np.int64)
+            assert np.all(pred <= 4) and np.all(offs[is_ev] < 1024)
+            codes[o] = np.where(pred < 4, np.where(k == 3, 4, (pred + 1 + k) & 3), k)
+    else:
+        blk = np.repeat(np.arange(wp.n_blocks), np.diff(bo.astype(np.int64)))
+        codes[blk * 1024 + (ev & 0x3ff)] = ev >> 12
     ref_code = np.where(refw & 8, 4, refw & 7).astype(np.uint8)
     return codes, ref_code
+
+
+def _n_diff_events(wp):
+    """difference events of a pack in either form (the one-byte form's fillers are no events)"""
+    if "ev_bytes" in wp.sections:
+        evb = wp.host("ev_bytes")[:int(wp.host("blk_off")[-1])]
+        return int(np.count_nonzero((evb >> 2) != 63))
+    return wp.n_events
 
 
 def _expand_events_numpy(wp):
@@ -113,8 +138,10 @@ def _consistent_deletions(w):
 CASES = CASES + [("indel_consistent", False, None, 2048)]
 
 
+@pytest.mark.parametrize("evb", ["2", "1", "0"])
 @pytest.mark.parametrize("name,supp,excl,tile", CASES)
-def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
+def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile, evb, monkeypatch):
+    monkeypatch.setenv("NC_WIRE_EVB", evb)                               # the events one byte each: every pack (default) / packs with indel events / never
     w = _consistent_deletions(load_world("indel")) if name == "indel_consistent" else load_world(name)
     assert ((w.meta or {}).get("events") is None) or name.startswith("indel")
     hp = pack_world(w, supplementary=supp, exclude=excl, tile_size=tile)
@@ -143,14 +170,13 @@ def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
                     a, z = max(int(ev_pos[e]) + 1 - p0, 0), min(int(ev_pos[e]) + 1 - int(ev_len[e]) - p0, 1024)
                     codes[b * 1024 + a:b * 1024 + z] = 4
                     n_written += max(0, z - a)
-        import os
         os.environ["NC_WIRE_DEL_IMPLIED"] = "0"
         try:
             full = build_wire_from_world(w, supplementary=supp, exclude=excl, tile_size=tile, pin=False)
         finally:
             del os.environ["NC_WIRE_DEL_IMPLIED"]
         assert np.array_equal(_expand_numpy(full)[0], hp.codes)
-        assert 0 < full.n_events - wp.n_events <= n_written            # every dropped event is a deleted column (a deleted column may also carry the reference's code 4: never an event)
+        assert 0 < _n_diff_events(full) - _n_diff_events(wp) <= n_written            # every dropped event is a deleted column (a deleted column may also carry the reference's code 4: never an event)
     assert wp.codes_len == hp.codes.size and np.array_equal(codes, hp.codes)
     assert np.array_equal(ref_code, hp.ref_code)
     assert np.array_equal(wp.host("tile_off"), hp.tile_off)
@@ -165,9 +191,15 @@ def test_wire_build_reconstructs_the_packed_codes(name, supp, excl, tile):
         assert 2 * ev_pos.size + 12 * wp.meta["indel_events"]["n_big"] < 0.3 * 12 * max(ev_pos.size, 1) or ev_pos.size < 100
     # the point of it: far fewer bytes than 1 B per pileup entry (ONT worlds: 4 % substitutions + 4 % deletions)
     entries = int((w.read_end - w.read_start).sum())
-    assert 2 * wp.n_events < 0.25 * entries
-    ev, bo = wp.host("events"), wp.host("blk_off")
-    assert bo[0] == 0 and bo[-1] == wp.n_events and np.all(np.diff(bo.astype(np.int64)) >= 0) and np.all((ev >> 12) <= 4)
+    bo = wp.host("blk_off")
+    if "ev_bytes" in wp.sections:                                        # one byte an event (+ a filler per 63 columns without one)
+        assert (name.startswith("indel") or os.environ.get("NC_WIRE_EVB", "2") == "2") and wp.n_events == 0 and "events" not in wp.sections
+        assert int(bo[-1]) < 0.125 * entries and int(bo[-1]) < 2 * _n_diff_events(wp)          # (the builder keeps the two-byte form when that is shorter: HiFi)
+    else:
+        assert 2 * wp.n_events < 0.25 * entries and (name != "ont" or os.environ.get("NC_WIRE_EVB", "2") != "2")
+        ev = wp.host("events")
+        assert bo[-1] == wp.n_events and np.all((ev >> 12) <= 4)
+    assert bo[0] == 0 and np.all(np.diff(bo.astype(np.int64)) >= 0)
     br, so = wp.host("blk_read"), wp.host("slot_off")
     b0 = np.arange(wp.n_blocks, dtype=np.int64) * 1024
     assert np.array_equal(br, np.minimum(np.searchsorted(so[1:], b0, side="right"), wp.n_reads))   # first read with slot end > block start
@@ -257,9 +289,11 @@ def eng():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("evb", ["2", "0"])
 @pytest.mark.parametrize("name,supp,excl,tile", CASES)
-def test_wire_expand_on_device_equals_direct_pack(eng, name, supp, excl, tile):
+def test_wire_expand_on_device_equals_direct_pack(eng, name, supp, excl, tile, evb, monkeypatch):
     import torch
+    monkeypatch.setenv("NC_WIRE_EVB", evb)                               # the events one byte each (default) / two bytes each
     from nanocaller_amd.wire import WireUploader, upload_wire
     w = _consistent_deletions(load_world("indel")) if name == "indel_consistent" else load_world(name)
     a = eng.upload(pack_world(w, supplementary=supp, exclude=excl, tile_size=tile))
