@@ -223,13 +223,14 @@ def cpu_baseline(pack, info, chunks, params, model, gpu_result, n_sample):
 class Contig:
     """one chr20-sized unit of work: its transfer form in pinned host memory (+ optionally the expanded pack kept in HBM)"""
 
-    def __init__(self, eng, L, depth, tech, seed, keep_pack):
+    def __init__(self, eng, L, depth, tech, seed, keep_pack, pool=None):
+        """pool: the host builder of the transfer form runs there; finish() waits for it (many-contig set-up)"""
         from nanocaller_amd.synth_device import make_device_workload, wire_from_device_workload
         t0 = time.perf_counter()
         pack, info = make_device_workload(eng, L, depth=depth, tech=tech, seed=seed)
         self.gen_s = time.perf_counter() - t0
         t0 = time.perf_counter()
-        self.wire = wire_from_device_workload(pack, info)
+        self.wire = wire_from_device_workload(pack, info, pool=pool)
         self.wire_s = time.perf_counter() - t0
         self.entries = info["pileup_entries"]
         info.pop("ref_wire", None)
@@ -237,6 +238,11 @@ class Contig:
         self.pack = pack if keep_pack else None
         del pack
         torch.cuda.empty_cache()
+
+    def finish(self):
+        if hasattr(self.wire, "result"):
+            self.wire = self.wire.result()
+        return self
 
 
 def run_units(eng, uploader, contigs, n_units, params, chunks, local, overlap=True, resident=False):
@@ -340,9 +346,10 @@ CLOCK_HZ = 2.4e9
 FILL_PEAK_CELLS_S = 256 * 4 * CLOCK_HZ * 128 / (FILL_INSTR_PK * VALU_PK_CYC + FILL_INSTR_PLAIN * VALU_PLAIN_CYC)
 
 
-def _indel_wire(eng, pack, reads_c, info):
+def _indel_wire(eng, pack, reads_c, info, pool=None):
     """the synthetic indel contig as the host would hold it after decoding a BAM: ONE page-locked buffer with the
-    reference-difference wire form of the codes, the tile index, the indel events and the bases without a reference column"""
+    reference-difference wire form of the codes, the tile index, the indel events and the bases without a reference column.
+    pool: the arrays are fetched here, the host builder runs on the pool -> a Future"""
     from nanocaller_amd.wire import build_wire
     L = info["L"]
     codes_h = pack.codes.cpu().numpy()
@@ -357,9 +364,13 @@ def _indel_wire(eng, pack, reads_c, info):
     n_ev = info["n_events"]
     extra = dict(ins_off=h(t["ins_off"])[:n_ev + 1], ins_bases=h(t["ins_bases"])[:max(info["n_ins_bases"], 1)], tail_off=h(t["tail_off"]),
                  tail_bases=h(t["tail_bases"]), read_ps=h(t["read_ps"]), read_flag=h(t["read_flag"]))
-    return build_wire(info["read_start"], info["read_end"], off, codes_h, None, ref_wire, tile_size=pack.tile_size, pos_lo=1, pos_hi=L,
-                      keep=np.ones(n, np.uint8), strand=info["strand"], hap=info["hap"],
-                      events=(h(ev["ev_off"]), h(ev["ev_pos"])[:n_ev], h(ev["ev_len"])[:n_ev]), indel_extra=extra)
+    events = (h(ev["ev_off"]), h(ev["ev_pos"])[:n_ev], h(ev["ev_len"])[:n_ev])
+    rs, re_, ts, strand, hap = info["read_start"], info["read_end"], pack.tile_size, info["strand"], info["hap"]
+
+    def build():
+        return build_wire(rs, re_, off, codes_h, None, ref_wire, tile_size=ts, pos_lo=1, pos_hi=L, keep=np.ones(n, np.uint8), strand=strand, hap=hap,
+                          events=events, indel_extra=extra)
+    return pool.submit(build) if pool is not None else build()
 
 
 class IndelJob:
@@ -369,7 +380,7 @@ class IndelJob:
     star alignment (banded) -> tensors + consensus (K8) -> allele_prediction -> Indel_model (K9) -> per-site arrays in host memory; genotype
     rules + VCF text natively on the host."""
 
-    def __init__(self, eng, L, seed=4813, name=b"chr20", haploid=False, window_after=160, wire=True):
+    def __init__(self, eng, L, seed=4813, name=b"chr20", haploid=False, window_after=160, wire=True, pool=None):
         from nanocaller_amd import _lib
         from nanocaller_amd.synth_device import make_indel_device_workload
         from nanocaller_amd.weights import Weights, get_indel_model
@@ -385,8 +396,13 @@ class IndelJob:
         self.kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=window_after, haploid=self.haploid)
         self.contig = np.frombuffer(b"AGTCN", np.uint8)[self.info["tensors"]["ref"].cpu().numpy()[1:]].tobytes()
         t0 = time.perf_counter()
-        self.wire = _indel_wire(eng, self.pack, self.reads_c, self.info) if wire else None
+        self.wire = _indel_wire(eng, self.pack, self.reads_c, self.info, pool=pool) if wire else None
         self.t_wire = time.perf_counter() - t0
+
+    def finish(self):
+        if hasattr(self.wire, "result"):
+            self.wire = self.wire.result()
+        return self
 
     def drop_pack(self):
         """keep only the host-side transfer form (the HBM-resident pack is for the resident / instrumented passes)"""
@@ -778,15 +794,25 @@ def wgs_block(eng, uploader, local, model, passes=1, scale=1.0, contigs=None):
     t0 = time.perf_counter()
     params = snp_params(model, "ont")
     units, snp_bytes, indel_bytes, bp = [], 0, 0, 0
-    for k, (name, L0) in enumerate(contigs or GRCH38):
-        L = max(200_000, int(L0 * scale))
-        snp = Contig(eng, L, 30.0, "ont", seed=2000 + k, keep_pack=False)
-        job = IndelJob(eng, L, seed=6000 + k, name=name.encode())
-        job.drop_pack()
-        units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
-        snp_bytes += snp.wire.nbytes
-        indel_bytes += job.wire.nbytes
-        bp += L
+    # set-up (untimed): the generator runs on the GPU contig by contig; the host builders of the transfer forms (1.2 + 1.8 s per 64 Mb, single
+    # threads of numpy + the native builder) run on a pool beside it -- at most `ahead` contigs' decoded arrays wait in host memory
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(8, len(os.sched_getaffinity(0)) // 2))
+    ahead = workers + 2
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for k, (name, L0) in enumerate(contigs or GRCH38):
+            L = max(200_000, int(L0 * scale))
+            if k >= ahead:
+                units[k - ahead].snp.finish()
+                units[k - ahead].job.finish()
+            snp = Contig(eng, L, 30.0, "ont", seed=2000 + k, keep_pack=False, pool=pool)
+            job = IndelJob(eng, L, seed=6000 + k, name=name.encode(), pool=pool)
+            job.drop_pack()
+            units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
+            bp += L
+        for u in units:
+            snp_bytes += u.snp.finish().wire.nbytes
+            indel_bytes += u.job.finish().wire.nbytes
     t_setup = time.perf_counter() - t0
     big = max(units, key=lambda u: u.job.wire.nbytes)
     run_pairs(uploader, local, params, [big], len(uploader.slots))      # sizes every upload slot, workspace and result pool by the largest contig (untimed)

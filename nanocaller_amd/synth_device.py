@@ -155,18 +155,23 @@ def host_sample_for_oracle(pack: DevicePack, info, pos_lo, pos_hi):
                 codes=raw, strand=np.ascontiguousarray(info["strand"][r0:r1]), keep=keep, ref_codes=ref, L=L)
 
 
-def wire_from_device_workload(pack: DevicePack, info, pin=True):
+def wire_from_device_workload(pack: DevicePack, info, pin=True, pool=None):
     """The workload as the host would hold it after decoding a BAM: codes copied back to host memory and put into the
     reference-difference transfer form by the library's host builder (nc_wire_build) -- bench.py uploads THIS inside its
-    timed region (the timed region starts at decoded alignments in pinned host memory)."""
+    timed region (the timed region starts at decoded alignments in pinned host memory).
+    pool (a ThreadPoolExecutor): the arrays are fetched here, the host builder runs on the pool -> a Future of the WirePack
+    (set-up of many contigs: the builder is host-only work, the generator of the next contig need not wait for it)."""
     from .wire import build_wire
     L = info["L"]
     codes_h = pack.codes.cpu().numpy()
     ref_h = info["ref_wire"][1:L + 1].cpu().numpy()
     off = info["read_base"] + info["read_start"].astype(np.int64)               # codes[off + p - start]: the slot layout is read-major
     n = info["n_reads"]
-    return build_wire(info["read_start"], info["read_end"], off, codes_h, None, ref_h, tile_size=info["tile_size"], pos_lo=1, pos_hi=L,
-                      keep=np.ones(n, np.uint8), strand=info["strand"], pin=pin)
+    rs, re_, ts, strand = info["read_start"], info["read_end"], info["tile_size"], info["strand"]
+
+    def build():
+        return build_wire(rs, re_, off, codes_h, None, ref_h, tile_size=ts, pos_lo=1, pos_hi=L, keep=np.ones(n, np.uint8), strand=strand, pin=pin)
+    return pool.submit(build) if pool is not None else build()
 
 
 # ---------------------------------------------------------------------------------------------------------------- indel workload
