@@ -746,7 +746,10 @@ def run_pairs(uploader, local, params, units, n_steps, snp_half=True, indel_half
             un = units[(i + 1) % nu]
             STEP_STARTS.append(time.perf_counter())
             if dbg:
-                print("pair step %d %s (snp %s indel %s): +%.1f ms" % (i, u.name, snp_half, indel_half, (time.perf_counter() - tdbg) * 1e3), file=sys.stderr, flush=True)
+                mf, _mt = torch.cuda.mem_get_info()
+                print("pair step %d %s (snp %s indel %s): +%.1f ms; device memory free %.1f GB, torch reserved %.1f GB (allocated %.1f)"
+                      % (i, u.name, snp_half, indel_half, (time.perf_counter() - tdbg) * 1e3, mf / 1e9, torch.cuda.memory_reserved() / 1e9,
+                         torch.cuda.memory_allocated() / 1e9), file=sys.stderr, flush=True)
             more = i + 1 < n_steps
             if indel_half:
                 nxt_s = uploader.submit(un.snp.wire) if (snp_half and more) else None

@@ -2876,6 +2876,11 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         }
     }
     const int G = (int)groups.size();
+    // A contig with more alignments than one group holds is cut into groups of about the same size, each smaller than GROUP_AL; a later, slightly
+    // shorter contig may then arrive as ONE group of nearly GROUP_AL alignments -- larger than any group before it.  Sized by their own group, the
+    // per-alignment buffers then grew in the middle of a whole-genome pass (hipFree + hipMalloc of ~9 GB: a second of idle GPU at chr18 after
+    // chr1 .. chr17).  A run of several groups therefore sizes them for GROUP_AL at once; a run of one group takes what it needs.
+    const size_t Acap = G > 1 ? (size_t)std::min<int64_t>(GROUP_AL, al0h[ns]) + 64 : 0;
     // Stream A (the context's): query windows + alignment fill (bound by vector issue).  Stream B: traceback, tensors, allele_prediction
     // (bound by memory latency) of the previous group, beside it on the same CUs.  Stage timers (timing mode) need the stages one
     // after the other: one stream then.
@@ -2904,13 +2909,14 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int64_t A0 = al0h[k0];
         const int32_t Ag = al0h[k1] - al0h[k0];
         const size_t Agz = (size_t)std::max(Ag, 1);
-        NC_TRY(nc_ensure(ctx, B.win, Agz * WS + 64));
-        NC_TRY(nc_ensure(ctx, B.n1, Agz * 4));
-        NC_TRY(nc_ensure(ctx, B.tw, Agz * (size_t)tw_per_al + 64));
-        NC_TRY(nc_ensure(ctx, B.hlast, Agz * hlast_pitch(W) * 4 + 64));
-        NC_TRY(nc_ensure(ctx, B.hcol, Agz * hcol_pitch(N1) * 4 + 64));
-        NC_TRY(nc_ensure(ctx, B.endc, Agz * sizeof(int2)));
-        NC_TRY(nc_ensure(ctx, B.trace, Agz * EW * 4 + 64));
+        const size_t Asz = std::max(Agz, Acap);                          // what the buffers are sized for (the layout inside them goes by Agz)
+        NC_TRY(nc_ensure(ctx, B.win, Asz * WS + 64));
+        NC_TRY(nc_ensure(ctx, B.n1, Asz * 4));
+        NC_TRY(nc_ensure(ctx, B.tw, Asz * (size_t)tw_per_al + 64));
+        NC_TRY(nc_ensure(ctx, B.hlast, Asz * hlast_pitch(W) * 4 + 64));
+        NC_TRY(nc_ensure(ctx, B.hcol, Asz * hcol_pitch(N1) * 4 + 64));
+        NC_TRY(nc_ensure(ctx, B.endc, Asz * sizeof(int2)));
+        NC_TRY(nc_ensure(ctx, B.trace, Asz * EW * 4 + 64));
         NC_TRY(nc_ensure(ctx, B.cns, (size_t)ng * S * CNS_CAP));
         NC_TRY(nc_ensure(ctx, B.ncns, (size_t)ng * S * 4));
         NC_TRY(nc_ensure(ctx, B.cband, (size_t)ng * S * 4));
@@ -2919,12 +2925,12 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int nblk = (((N1 + W + 7) / 8) + 3) & ~3;                             // blocks of 8 anti-diagonals of a banded alignment: n1 + n2 <= N1 + W (41 for the 160-base windows, 66 for the 260-base ones)
         const bool band = packed_fill() && (s->band_mode < 0 ? band_on() : s->band_mode != 0) && nblk <= 80;
         if (band) {
-            NC_TRY(nc_ensure(ctx, B.band_lo, 2 * Agz + 128));            // + the windows' classes (k_windows16 -> k_window_lists)
-            NC_TRY(nc_ensure(ctx, B.lists, Agz * 3 * 4 + 64));
+            NC_TRY(nc_ensure(ctx, B.band_lo, 2 * Asz + 128));            // + the windows' classes (k_windows16 -> k_window_lists)
+            NC_TRY(nc_ensure(ctx, B.lists, Asz * 3 * 4 + 64));
             NC_TRY(nc_ensure(ctx, B.counts, 64));
-            NC_TRY(nc_ensure(ctx, B.twb, Agz * (size_t)nblk * (4 * TWB_PITCH) + 256));
-            NC_TRY(nc_ensure(ctx, B.hrow, Agz * 128 + 64));
-            NC_TRY(nc_ensure(ctx, B.hcolb, Agz * 128 + 64));
+            NC_TRY(nc_ensure(ctx, B.twb, Asz * (size_t)nblk * (4 * TWB_PITCH) + 256));
+            NC_TRY(nc_ensure(ctx, B.hrow, Asz * 128 + 64));
+            NC_TRY(nc_ensure(ctx, B.hcolb, Asz * 128 + 64));
         }
         if (two && g >= 2) NC_HIP(ctx, hipStreamWaitEvent(sA, s->evB[b], 0));     // stream B is done with this buffer set (group g - 2)
         if (timing) NC_HIP(ctx, hipEventRecord(s->ev[0], sA));
@@ -3032,8 +3038,11 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const int b = g & 1, k0 = groups[(size_t)g].first, k1 = groups[(size_t)g].second;
         nc_pipe_state::GroupBufs &B = s->gb[b];
         const int nset = (k1 - k0) * S;
-        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows + 1) * 64 * CPL + 64));                     // `rows` counts blocks of TWB steps
-        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(TWB * rows + (int64_t)nset * (W + 1) + 2) * 4 + 64));
+        // (a run of several groups sizes these for the largest group its bounds allow, like stage_a's buffers: no growth in the middle of a genome)
+        const int64_t nset_cap = G > 1 ? std::max<int64_t>(nset, std::min<int64_t>(GROUP_SITES, ns) * S) : nset;
+        const int64_t rows_cap = nset > 0 ? (rows * nset_cap + nset - 1) / nset : rows;
+        NC_TRY(nc_ensure(ctx, s->tw2, (size_t)(rows_cap + 1) * 64 * CPL + 64));                 // `rows` counts blocks of TWB steps
+        NC_TRY(nc_ensure(ctx, s->runs, (size_t)(TWB * rows_cap + nset_cap * (W + 1) + 2) * 4 + 64));
         FillArgs fb = fa_of[b];
         fb.s1 = (const uint8_t *)B.cns.p; fb.s1_stride = CNS_CAP; fb.n1 = (const int32_t *)B.ncns.p;
         fb.al_site = nullptr; fb.site0 = k0; fb.site_div = S;
@@ -3054,11 +3063,11 @@ extern "C" int nc_indel_sites_run(nc_ctx *ctx, float *x_dev)
         const bool band_alleles = !(bae && atoi(bae) == 0);
         if (band_of[b] && band_alleles) {
             // the consensus against its window on a band around the diagonals 0 .. n2 - n1; too long / too wide / edge-touching ones on the full matrix
-            const size_t nz = (size_t)std::max(nset, 1);
-            NC_TRY(nc_ensure(ctx, s->ab_lo, nz + 64));
-            NC_TRY(nc_ensure(ctx, s->ab_lists, nz * 3 * 4 + 64));
+            const size_t nz = (size_t)std::max(nset, 1), nzc = (size_t)std::max<int64_t>(nset_cap, 1);
+            NC_TRY(nc_ensure(ctx, s->ab_lo, nzc + 64));
+            NC_TRY(nc_ensure(ctx, s->ab_lists, nzc * 3 * 4 + 64));
             NC_TRY(nc_ensure(ctx, s->ab_counts, 64));
-            NC_TRY(nc_ensure(ctx, s->ab_twb, nz * (size_t)BAND_NBLK4 * (4 * TWB_PITCH) + 256));
+            NC_TRY(nc_ensure(ctx, s->ab_twb, nzc * (size_t)BAND_NBLK4 * (4 * TWB_PITCH) + 256));
             NC_HIP(ctx, hipMemsetAsync(s->ab_counts.p, 0, 64, sB));
             int32_t *l1 = (int32_t *)s->ab_lists.p, *l2 = l1 + nz, *lF = l2 + nz, *cn = (int32_t *)s->ab_counts.p;
             hipLaunchKernelGGL(k_allele_classes, dim3((nset + 255) / 256), dim3(256), 0, sB, fb, (const int16_t *)B.cband.p, s->band_margin_v > 0 ? s->band_margin_v : band_margin(),
