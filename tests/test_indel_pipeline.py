@@ -579,6 +579,53 @@ def test_device_pipeline_at_scale_is_deterministic_and_group_invariant(monkeypat
 
 
 @pytest.mark.gpu
+def test_a_contig_of_one_group_after_a_contig_of_several_allocates_nothing(monkeypatch):
+    """nc_indel_sites_run cuts a contig with more alignments than the group bound into groups of EQUAL size, all smaller than the bound; a later,
+    shorter contig may fit ONE group that is larger than any of those.  A run of several groups therefore sizes the per-group buffers for the bound:
+    the second contig must not make the library allocate (sized by the group at hand they grew there -- a hipFree + hipMalloc of 9 GB at chr18 of a
+    whole-genome pass, a second of idle GPU: profiles/README.md, round 6).  A context of its own: the shared one's buffers are as large as the
+    largest test before this one left them."""
+    import torch
+    from nanocaller_amd.engine import Engine, get_engine
+    from nanocaller_amd.synth_device import make_indel_device_workload
+    shared = get_engine(0)
+    kw = dict(mincov=4, maxcov=160, win_size=40, small_win_size=4, ins_t=0.4, del_t=0.6, window_after=160)
+
+    def contig(L, seed):
+        pack, reads_c, info = make_indel_device_workload(shared, L, depth=30.0, seed=seed)
+        return pack, reads_c, L, [(s, min(L, s + 100_000)) for s in range(1, L, 100_000)], info      # (info keeps the device arrays alive)
+
+    def library_bytes():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return (total - free) - torch.cuda.memory_reserved()
+
+    a, b = contig(8_000_000, 4242), contig(6_900_000, 4243)
+    # the alignments of both contigs, counted on the shared context (whatever its buffers hold)
+    na = gip.indel_sites_device(shared, a[0], a[1], a[2], a[3], fetch=False, **kw)["n_alignments"]
+    nb = gip.indel_sites_device(shared, b[0], b[1], b[2], b[3], fetch=False, **kw)["n_alignments"]
+    bound = int(0.92 * na)
+    # A: two groups of na / 2 (+ the allocator's 25 % = 0.625 na); B: one group, more than that, within the bound
+    assert 0.7 * na < nb <= bound, (na, nb)
+    monkeypatch.setenv("NC_PIPE_GROUP_AL", str(bound))
+    eng = Engine(0)
+    try:
+        ra = gip.indel_sites_device(eng, a[0], a[1], a[2], a[3], fetch=False, **kw)
+        assert ra["n_alignments"] == na
+        del ra
+        before = library_bytes()
+        rb = gip.indel_sites_device(eng, b[0], b[1], b[2], b[3], fetch=False, **kw)
+        assert rb["n_alignments"] == nb
+        del rb
+        grown = library_bytes() - before
+        assert grown < (64 << 20), "the second contig made the library allocate %.1f MB" % (grown / 1e6)
+    finally:
+        torch.cuda.synchronize()
+        eng.close()
+        shared.use_torch_stream()
+
+
+@pytest.mark.gpu
 def test_banded_star_alignment_against_the_full_matrix(monkeypatch):
     """the default (every read window aligned on the 32 / 64 diagonals its own CIGAR allows, full matrix after an edge touch) against the
     full matrix for every window: same sites, and all but a few per ten thousand tensors / alleles identical; most windows fit 32 diagonals"""
