@@ -788,6 +788,32 @@ GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4"
           ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
 
 
+def build_pair_units(eng, parts, seed0, seed1):
+    """PairUnits of the contigs `parts` = [(name, length), ...] (set-up, untimed): the generator runs on the GPU contig by contig; the host builders of
+    the transfer forms (1.2 + 1.8 s per 64 Mb: single threads of numpy + the native builder) run on a pool beside it -- at most `ahead` contigs'
+    decoded arrays wait in host memory.  -> (units, SNP wire bytes, indel wire bytes, bp)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from nanocaller_amd.utils import get_chunks
+    units, snp_bytes, indel_bytes, bp = [], 0, 0, 0
+    workers = max(1, min(8, len(os.sched_getaffinity(0)) // 2))
+    ahead = workers + 2
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for k, (name, L) in enumerate(parts):
+            if k >= ahead:
+                units[k - ahead].snp.finish()
+                units[k - ahead].job.finish()
+            snp = Contig(eng, L, 30.0, "ont", seed=seed0 + k, keep_pack=False, pool=pool)
+            job = IndelJob(eng, L, seed=seed1 + k, name=name.encode(), pool=pool)
+            job.drop_pack()
+            units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
+            bp += L
+        for u in units:
+            snp_bytes += u.snp.finish().wire.nbytes
+            indel_bytes += u.job.finish().wire.nbytes
+    return units, snp_bytes, indel_bytes, bp
+
+
 def wgs_block(eng, uploader, local, model, passes=1, scale=1.0, contigs=None):
     """The metric's own configuration at N = 1: ONE pass over a whole genome -- 24 contigs at the GRCh38 lengths (3.09 Gb), per contig the SNP half
     then the indel half, every wire from PINNED HOST MEMORY, one timed region (the reference walks all regions with snpCaller, then indelCaller:
@@ -796,26 +822,7 @@ def wgs_block(eng, uploader, local, model, passes=1, scale=1.0, contigs=None):
     from nanocaller_amd.utils import get_chunks
     t0 = time.perf_counter()
     params = snp_params(model, "ont")
-    units, snp_bytes, indel_bytes, bp = [], 0, 0, 0
-    # set-up (untimed): the generator runs on the GPU contig by contig; the host builders of the transfer forms (1.2 + 1.8 s per 64 Mb, single
-    # threads of numpy + the native builder) run on a pool beside it -- at most `ahead` contigs' decoded arrays wait in host memory
-    from concurrent.futures import ThreadPoolExecutor
-    workers = max(1, min(8, len(os.sched_getaffinity(0)) // 2))
-    ahead = workers + 2
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        for k, (name, L0) in enumerate(contigs or GRCH38):
-            L = max(200_000, int(L0 * scale))
-            if k >= ahead:
-                units[k - ahead].snp.finish()
-                units[k - ahead].job.finish()
-            snp = Contig(eng, L, 30.0, "ont", seed=2000 + k, keep_pack=False, pool=pool)
-            job = IndelJob(eng, L, seed=6000 + k, name=name.encode(), pool=pool)
-            job.drop_pack()
-            units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
-            bp += L
-        for u in units:
-            snp_bytes += u.snp.finish().wire.nbytes
-            indel_bytes += u.job.finish().wire.nbytes
+    units, snp_bytes, indel_bytes, bp = build_pair_units(eng, [(name, max(200_000, int(L0 * scale))) for name, L0 in (contigs or GRCH38)], 2000, 6000)
     t_setup = time.perf_counter() - t0
     big = max(units, key=lambda u: u.job.wire.nbytes)
     run_pairs(uploader, local, params, [big], len(uploader.slots))      # sizes every upload slot, workspace and result pool by the largest contig (untimed)
@@ -872,17 +879,9 @@ def wgs_sharded_block(eng, uploader, local, model, rank, world, barrier, scale=1
         parts[c["chrom"]] = (min(a, c["start"]), max(b, c["end"]))
     t0 = time.perf_counter()
     params = snp_params(model, "ont")
-    units, bp, wire_bytes = [], 0, 0
     order = [n for n, _ in spec if n in parts]
-    for k, name in enumerate(order):
-        a, b = parts[name]
-        L = b - a + 1
-        snp = Contig(eng, L, 30.0, "ont", seed=2000 + 100 * rank + k, keep_pack=False)
-        job = IndelJob(eng, L, seed=6000 + 100 * rank + k, name=name.encode())
-        job.drop_pack()
-        units.append(PairUnit(snp, job, get_chunks([(name, 1, L, "diploid")], cpu=16), name))
-        bp += L
-        wire_bytes += snp.wire.nbytes + job.wire.nbytes
+    units, snp_bytes, indel_bytes, bp = build_pair_units(eng, [(name, parts[name][1] - parts[name][0] + 1) for name in order], 2000 + 100 * rank, 6000 + 100 * rank)
+    wire_bytes = snp_bytes + indel_bytes
     t_setup = time.perf_counter() - t0
     ns = ni = nrec = 0
     dt = 0.0
