@@ -313,7 +313,9 @@ def extra_snp_config(eng, uploader, local, L, depth, tech, model, ploidy, exact_
         chunks = get_chunks([("chr20", 1, L, ploidy)], cpu=16)
         params = snp_params(model, tech)
         nobar = lambda: None                                                 # noqa: E731
-        sites, dt, r = measure(eng, uploader, [c], steps, 2, params, chunks, local, nobar)
+        # (8 untimed steps: the leg starts behind its own data generation, an idle device -- the first ~10 forwards after one run 15-25 % slower,
+        # profiles/README.md "clock ramp"; with 2 the leg read 39-40 M sites/s on some boxes and 46-47 M on others)
+        sites, dt, r = measure(eng, uploader, [c], steps, 8, params, chunks, local, nobar)
         sites_r, dt_r, _ = measure(eng, uploader, [c], steps, 1, params, chunks, local, nobar, resident=True)
         eng.enable_timing(True, trunk_only=True)
         run_units(eng, uploader, [c], steps, params, chunks, local, True, True)
