@@ -9,6 +9,20 @@
 
 #include "../../include/nanocaller_hip.h"
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP additions (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2
+// into rows 1 and 3, then lane 31 into rows 2 and 3): no LDS traffic, no per-step compare -- the __shfl_up form is six ds_bpermute_b32 round trips
+// with a compare and a select each.
+__device__ __forceinline__ int32_t nc_wave_incl_scan(int32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;

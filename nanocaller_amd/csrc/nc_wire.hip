@@ -478,12 +478,7 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
             cum += in ? (g == 63u ? 63 : (int32_t)g + 1) : 0;
             v[i] = cum;
         }
-        int32_t incl = cum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-        }
+        const int32_t incl = nc_wave_incl_scan(cum);
         const int32_t base = carry + incl - cum;
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -492,7 +487,7 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
                 const uint32_t pred = im[o & 0x3ff];
                 im[o & 0x3ff] = (uint8_t)(pred < 4u ? (which[i] == 3u ? 4u : ((pred + 1u + which[i]) & 3u)) : which[i]);
             }
-        carry += __shfl(incl, 63);
+        carry += __builtin_amdgcn_readlane(incl, 63);
     };
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -711,12 +706,8 @@ extern "C" int nc_indel_events_pack8(int32_t n_reads, const int32_t *rd_start, c
 namespace {
 __device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
-    return v;
+    (void)lane;
+    return nc_wave_incl_scan(v);
 }
 
 // B8: the one-byte form (nc_indel_events_pack8): b8 per event, d16 = the two-byte array of the escapes, read_esc_off their start per read
