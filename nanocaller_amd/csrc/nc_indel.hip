@@ -207,11 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_hap_depth_b(const uint8_t *__restrict
         __shared__ int wtot[BLOCK / 64];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         int inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int yv = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += yv;
-        }
+        inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
         if (lane == 63) wtot[wv] = inc;
         __syncthreads();                                              // (also: every depth row has left tr)
         int wp = 0, all = 0;
@@ -251,11 +247,7 @@ __global__ __launch_bounds__(256) void k_blk_base(const IndelChunk *__restrict__
     for (int b = b0; b < b1; b += 64) {
         const int v = b + lane < b1 ? blk_yield[b + lane] : 0;
         int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int yv = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += yv;
-        }
+        inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
         if (b + lane < b1) blk_base[b + lane] = carry + inc - v;
         carry += __shfl(inc, 63, 64);
     }
@@ -268,11 +260,7 @@ __device__ __forceinline__ int block_scan_1024(int v, int *wsum, int &tot)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += y;
-    }
+    inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     int wp = 0;
@@ -889,11 +877,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
             }
             // ---- exclusive prefix of the counts over the 256 entries
             int inc = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int yv = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += yv;
-            }
+            inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
             if (lane == 63 && wv < 4) wsum[wv] = inc;
             __syncthreads();
             int wp = 0;
@@ -1039,11 +1023,7 @@ __global__ __launch_bounds__(EV_NT, 8) void k_event_tiles(const int32_t *__restr
             tot += v[q];
         }
         int inc = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int yv = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += yv;
-        }
+        inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
         int run = inc - tot;
         uint16_t *U16 = reinterpret_cast<uint16_t *>(&difw[row][0]);        // the window counts (0 .. reads of the block) over the fields they came from:
 #pragma unroll                                                        // a lane rewrites the 16 ranks (8 words) it has just read

@@ -315,11 +315,7 @@ __device__ __forceinline__ int block_scan(int v, int *wsum, int &tot)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += y;
-    }
+    inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     int wp = 0;
@@ -2119,11 +2115,7 @@ __global__ __launch_bounds__(256) void k_site_tensor(TensorArgs p)
     for (int t = 0; t < S; t++) {
         const int j0 = 2 * tid, v0 = j0 <= n2 ? mxv[t][j0] : 0, v1 = j0 + 1 <= n2 ? mxv[t][j0 + 1] : 0;
         int inc = v0 + v1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(inc, o, 64);
-            if ((tid & 63) >= o) inc += y;
-        }
+        inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
         if ((tid & 63) == 63) wcnt[tid >> 6] = inc;
         __syncthreads();
         int wp = 0;

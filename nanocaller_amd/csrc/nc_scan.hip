@@ -104,11 +104,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const uint8_t *__restrict__ code
     const uint32_t mine = __popc(nbr_mask) | (__popc(cand_mask) << 16);
     uint32_t incl = mine;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += y;
-    }
+    incl = (decltype(incl))nc_wave_incl_scan((int32_t)incl);
     __shared__ uint32_t wsum[BLOCK / 64 + 1];
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
@@ -242,11 +238,7 @@ __global__ __launch_bounds__(1024) void k_chunk_prefix(const int32_t *__restrict
             chunk_cnt[i] = v;
         }
         int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += y;
-        }
+        inc = (decltype(inc))nc_wave_incl_scan((int32_t)inc);
         if (lane == 63) wsum[wv] = inc;
         __syncthreads();
         int wp = 0, tot = 0;
