@@ -379,6 +379,9 @@ __device__ __noinline__ uint4 wire_group_general(int64_t B, int64_t r, int32_t n
 // kernel writing 63 M scattered bytes re-reads and re-writes the whole 1.9 GB array: +0.6 ms per chr20-sized pass).
 // BYTES (round 6): the events one byte each (nc_wire_build2 flag 1): `events` is that byte stream, blk_off counts bytes.  A lane takes four bytes (one
 // dword), the columns they skip are summed across the wave, and an event's code follows from the predicted code already in the image (wire_which).
+#ifndef NC_WIRE_EVL
+#define NC_WIRE_EVL 2                 // byte events per lane and round of k_wire_expand<.., true>: 4 (round 6's first form), 2 or 1
+#endif
 template <int U, bool DEL, bool BYTES>
 __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int32_t *__restrict__ rd_start, const int32_t *__restrict__ rd_end,
                                                      const int64_t *__restrict__ slot_off, const uint8_t *__restrict__ ref_wire,
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
     uint4 rv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        if constexpr (BYTES) pr0[u] = u < nu ? load_quad((e0[u] & ~3u) + 4 * lane, e1[u]) : 0u;
+        if constexpr (BYTES) pr0[u] = (u < nu && lane < 16 * NC_WIRE_EVL) ? load_quad((e0[u] & ~3u) + 4 * lane, e1[u]) : 0u;
         else pr0[u] = u < nu ? load_pair((e0[u] & ~1u) + 2 * lane, e0[u], e1[u], blk0 + u == n_blocks - 1) : 0xffffffffu;
         if (ri0[u] >= 0) rv[u] = *reinterpret_cast<const uint4 *>(ref_wire + ri0[u] + lane * 16);
     }
@@ -464,13 +467,20 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         if (a != 0xffffu) im[a & 0x3ffu] = (uint8_t)(a >> 12);
         if (b != 0xffffu) im[b & 0x3ffu] = (uint8_t)(b >> 12);
     };
-    // BYTES: four events of a lane; `carry` = columns covered by the block's earlier bytes
-    auto scatter4 = [&](uint8_t *im, uint32_t q, uint32_t k, uint32_t ea, uint32_t eb, int32_t &carry) {
-        int32_t v[4], cum = 0;
-        uint32_t which[4];
-        bool isev[4];
+    // BYTES: NC_WIRE_EVL events of a lane (a round of the wave = 64 NC_WIRE_EVL bytes, loaded as dwords by its first 16 NC_WIRE_EVL lanes; a block of an
+    // ONT contig has ~61 events: with four per lane three lanes in four carried none and the wave still ran four scatter steps; with two a round of
+    // 128 bytes covers nearly every block at half the steps); `carry` = columns covered by the block's earlier bytes
+    auto scatter4 = [&](uint8_t *im, uint32_t qd, uint32_t kb, uint32_t ea, uint32_t eb, int32_t &carry) {
+        constexpr int EVL = NC_WIRE_EVL;
+        uint32_t q = qd;
+        if constexpr (EVL == 2) q = ((uint32_t)__shfl((int)qd, lane >> 1) >> (16 * (lane & 1))) & 0xffffu;
+        else if constexpr (EVL == 1) q = ((uint32_t)__shfl((int)qd, lane >> 2) >> (8 * (lane & 3))) & 0xffu;
+        const uint32_t k = kb + EVL * lane;
+        int32_t v[EVL], cum = 0;
+        uint32_t which[EVL];
+        bool isev[EVL];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < EVL; i++) {
             const uint32_t b = (q >> (8 * i)) & 0xffu, g = b >> 2;
             const bool in = k + i >= ea && k + i < eb;
             isev[i] = in && g != 63u;
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
         const int32_t incl = nc_wave_incl_scan(cum);
         const int32_t base = carry + incl - cum;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < EVL; i++)
             if (isev[i]) {
                 const int32_t o = base + v[i] - 1;
                 const uint32_t pred = im[o & 0x3ff];
@@ -493,11 +503,16 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
     for (int u = 0; u < U; u++) {
         uint8_t *im = img + u * WIRE_BLOCK;
         if constexpr (BYTES) {
+#ifdef NC_ABL_NOSCATTER
+            if (u < 0) {
+#else
             if (u < nu) {
+#endif
                 int32_t carry = 0;
-                const uint32_t k = (e0[u] & ~3u) + 4 * lane;
-                scatter4(im, pr0[u], k, e0[u], e1[u], carry);
-                for (uint32_t kb = (e0[u] & ~3u) + 256; kb < e1[u]; kb += 256) scatter4(im, load_quad(kb + 4 * lane, e1[u]), kb + 4 * lane, e0[u], e1[u], carry);
+                constexpr uint32_t RB = 64 * NC_WIRE_EVL;                 // bytes a round of the wave takes
+                scatter4(im, pr0[u], e0[u] & ~3u, e0[u], e1[u], carry);
+                for (uint32_t kb = (e0[u] & ~3u) + RB; kb < e1[u]; kb += RB)
+                    scatter4(im, lane < 16 * NC_WIRE_EVL ? load_quad(kb + 4 * lane, e1[u]) : 0u, kb, e0[u], e1[u], carry);
             }
         } else {
             scatter(im, pr0[u]);
@@ -533,7 +548,11 @@ __global__ __launch_bounds__(256) void k_wire_expand(int32_t n_reads, const int3
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int64_t B = (blk0 + u) * WIRE_BLOCK + (int64_t)lane * 16;
+#ifdef NC_ABL_NOSTORE
+        if (u < nu && B + 16 <= codes_len && B == 12345) {
+#else
         if (u < nu && B + 16 <= codes_len) {
+#endif
             // streaming store: the expanded codes are read once by the scan, later, from HBM
             const u32x4 v = *reinterpret_cast<const u32x4 *>(img + u * WIRE_BLOCK + lane * 16);
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(codes + B));
