@@ -140,39 +140,43 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const uint8_t *__restrict__ code
     if (threadIdx.x == 0) tile_cnt[t] = make_int2((int)(total & 0xFFFF), (int)(total >> 16));
 }
 
-// single-workgroup exclusive scan of int2 counts (n_tiles is at most a few million)
+// single-workgroup exclusive scan of int2 counts (n_tiles is at most a few million).  A WAVE owns a contiguous sixteenth of the counts and walks it 64
+// at a time (coalesced): first pass = the wave's total, one barrier for the 16 totals, second pass (the counts come from L2) = a DPP prefix sum per
+// step with the running carry in SGPRs, prefixes written coalesced.  The round-1 form scanned 1024 counts per turn across the workgroup -- a load
+// latency, twelve ds_bpermute and three barriers per turn, 31 turns for a chr20-sized contig: 52-56 us in front of the scan's totals, on the critical
+// path of every contig (a thread-owns-a-run form is no faster: its strided loads are 64 lines per instruction on ONE CU's memory pipeline).
 __global__ __launch_bounds__(1024) void k_tile_prefix(const int2 *__restrict__ cnt, int2 *__restrict__ pre, int n,
                                                       int32_t *__restrict__ totals)
 {
     __shared__ int2 wsum[16];
-    __shared__ int2 carry;
-    if (threadIdx.x == 0) carry = make_int2(0, 0);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        int2 v = i < n ? cnt[i] : make_int2(0, 0);
-        int2 inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int yx = __shfl_up(inc.x, o, 64), yy = __shfl_up(inc.y, o, 64);
-            if (lane >= o) { inc.x += yx; inc.y += yy; }
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int2 wp = make_int2(0, 0), tot = make_int2(0, 0);
-        for (int w = 0; w < 16; w++) {
-            const int2 s = wsum[w];
-            if (w < wv) { wp.x += s.x; wp.y += s.y; }
-            tot.x += s.x; tot.y += s.y;
-        }
-        const int2 c = carry;
-        if (i < n) pre[i] = make_int2(c.x + wp.x + inc.x - v.x, c.y + wp.y + inc.y - v.y);
-        __syncthreads();
-        if (threadIdx.x == 0) carry = make_int2(c.x + tot.x, c.y + tot.y);
-        __syncthreads();
+    const int per = ((n + 15) / 16 + 63) & ~63;                          // counts per wave, a multiple of 64
+    const int b0 = min(n, wv * per), b1 = min(n, b0 + per);
+    int2 sum = make_int2(0, 0);
+#pragma unroll 4
+    for (int i = b0 + lane; i < b1; i += 64) {
+        const int2 v = cnt[i];
+        sum.x += v.x; sum.y += v.y;
     }
-    if (threadIdx.x == 0) { totals[0] = carry.x; totals[1] = carry.y; }
+    const int2 winc = make_int2(nc_wave_incl_scan(sum.x), nc_wave_incl_scan(sum.y));
+    if (lane == 63) wsum[wv] = winc;
+    __syncthreads();
+    int cx = 0, cy = 0, tx = 0, ty = 0;
+    for (int w = 0; w < 16; w++) {
+        const int2 t = wsum[w];
+        if (w < wv) { cx += t.x; cy += t.y; }
+        tx += t.x; ty += t.y;
+    }
+#pragma unroll 4
+    for (int base = b0; base < b1; base += 64) {                           // (wave-uniform bounds; the loads do not depend on the carry: four in flight)
+        const int i = base + lane;
+        const int2 v = i < b1 ? cnt[i] : make_int2(0, 0);
+        const int ix = nc_wave_incl_scan(v.x), iy = nc_wave_incl_scan(v.y);
+        if (i < b1) pre[i] = make_int2(cx + ix - v.x, cy + iy - v.y);
+        cx += __builtin_amdgcn_readlane(ix, 63);
+        cy += __builtin_amdgcn_readlane(iy, 63);
+    }
+    if (threadIdx.x == 0) { totals[0] = tx; totals[1] = ty; }
 }
 
 __global__ __launch_bounds__(256) void k_compact(int tile, const int2 *__restrict__ cnt, const int2 *__restrict__ pre,

@@ -379,6 +379,9 @@ __device__ __noinline__ uint4 wire_group_general(int64_t B, int64_t r, int32_t n
 // kernel writing 63 M scattered bytes re-reads and re-writes the whole 1.9 GB array: +0.6 ms per chr20-sized pass).
 // BYTES (round 6): the events one byte each (nc_wire_build2 flag 1): `events` is that byte stream, blk_off counts bytes.  A lane takes four bytes (one
 // dword), the columns they skip are summed across the wave, and an event's code follows from the predicted code already in the image (wire_which).
+#ifndef NC_WIRE_UB
+#define NC_WIRE_UB 4                  // blocks per wave of the byte-event form
+#endif
 #ifndef NC_WIRE_EVL
 #define NC_WIRE_EVL 2                 // byte events per lane and round of k_wire_expand<.., true>: 4 (round 6's first form), 2 or 1
 #endif
@@ -618,7 +621,7 @@ static int wire_expand(nc_ctx *ctx, int32_t n_reads, const int32_t *d_rd_start, 
                        d_rd_end, d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len, d_blk_ev,         \
                        d_ev_off, d_ev_pos, d_ev_len)
 #define NC_LAUNCH_EXPAND_B(DD)                                                                                                                          \
-    hipLaunchKernelGGL((k_wire_expand<4, DD, true>), dim3((unsigned)((n_blocks + 15) / 16)), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_rd_end,  \
+    hipLaunchKernelGGL((k_wire_expand<NC_WIRE_UB, DD, true>), dim3((unsigned)((n_blocks + 4 * NC_WIRE_UB - 1) / (4 * NC_WIRE_UB))), dim3(256), 0, ctx->stream, n_reads, d_rd_start, d_rd_end,  \
                        d_slot_off, d_ref_wire, ref_pos0, ref_len, d_blk_off, d_blk_read, d_events, n_blocks, d_codes, codes_len, d_blk_ev, d_ev_off,    \
                        d_ev_pos, d_ev_len)
     if (bytes) { if (d_blk_ev) NC_LAUNCH_EXPAND_B(true); else NC_LAUNCH_EXPAND_B(false); }
